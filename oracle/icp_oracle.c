@@ -1,0 +1,554 @@
+/*
+ * icp_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see icp_oracle.h header comment).
+ *
+ * Plain-C restatement of cilantro's rigid ICP hot path.  Citations are relative to
+ * /root/reference/include/cilantro/.  Build: see oracle/Makefile (-O2 -ffp-contract=off -fopenmp).
+ * Never linked into, loaded by, or called from the product library.
+ */
+#include "icp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* =================================================================================================
+ * kd-tree: restates nanoflann 1.7.1 (3rd_party/nanoflann/nanoflann.hpp) KDTreeSingleIndexAdaptor
+ * with L2_Adaptor, DIM=3, as driven by core/kd_tree.hpp:162-170 (leaf 10, 1 build thread, eps=0).
+ * ================================================================================================= */
+typedef struct {
+  /* leaf: left/right offsets into vacc; inner: divfeat/divlow/divhigh (nanoflann.hpp:1085-1105) */
+  int32_t child1, child2; /* -1 for leaves */
+  uint32_t left, right;
+  int32_t divfeat;
+  float divlow, divhigh;
+} orc_node;
+
+struct orc_kdtree {
+  const float* pts;
+  size_t n;
+  size_t leaf_max;
+  uint32_t* vacc; /* vAcc_ permutation, nanoflann.hpp:1837-1844 */
+  orc_node* nodes;
+  size_t n_nodes, cap_nodes;
+  int32_t root;
+  float bb_lo[3], bb_hi[3]; /* root_bbox_ */
+};
+
+static inline float pt(const orc_kdtree* t, uint32_t idx, int dim) {
+  return t->pts[3 * (size_t)idx + dim]; /* core/kd_tree.hpp:26 kdtree_get_pt = obj(dim, idx) */
+}
+
+static int32_t new_node(orc_kdtree* t) {
+  if (t->n_nodes == t->cap_nodes) {
+    t->cap_nodes = t->cap_nodes ? 2 * t->cap_nodes : 1024;
+    t->nodes = (orc_node*)realloc(t->nodes, t->cap_nodes * sizeof(orc_node));
+  }
+  return (int32_t)t->n_nodes++;
+}
+
+/* nanoflann.hpp:1383-1428 planeSplit (Dutch-flag partition of vacc[ind .. ind+count)) */
+static void plane_split(orc_kdtree* t, size_t ind, size_t count, int cutfeat, float cutval,
+                        size_t* lim1, size_t* lim2) {
+  size_t left = 0, right = count - 1;
+  for (;;) {
+    while (left <= right && pt(t, t->vacc[ind + left], cutfeat) < cutval) ++left;
+    while (right && left <= right && pt(t, t->vacc[ind + right], cutfeat) >= cutval) --right;
+    if (left > right || !right) break;
+    uint32_t tmp = t->vacc[ind + left]; t->vacc[ind + left] = t->vacc[ind + right]; t->vacc[ind + right] = tmp;
+    ++left; --right;
+  }
+  *lim1 = left;
+  right = count - 1;
+  for (;;) {
+    while (left <= right && pt(t, t->vacc[ind + left], cutfeat) <= cutval) ++left;
+    while (right && left <= right && pt(t, t->vacc[ind + right], cutfeat) > cutval) --right;
+    if (left > right || !right) break;
+    uint32_t tmp = t->vacc[ind + left]; t->vacc[ind + left] = t->vacc[ind + right]; t->vacc[ind + right] = tmp;
+    ++left; --right;
+  }
+  *lim2 = left;
+}
+
+/* nanoflann.hpp:1321-1372 middleSplit_ */
+static void middle_split(orc_kdtree* t, size_t ind, size_t count, size_t* index, int* cutfeat,
+                         float* cutval, const float lo[3], const float hi[3]) {
+  const float EPS = 0.00001f;
+  float max_span = hi[0] - lo[0];
+  for (int i = 1; i < 3; ++i) { float span = hi[i] - lo[i]; if (span > max_span) max_span = span; }
+  float max_spread = -1.0f;
+  *cutfeat = 0;
+  float min_elem = 0, max_elem = 0;
+  for (int i = 0; i < 3; ++i) {
+    float span = hi[i] - lo[i];
+    if (span >= (1 - EPS) * max_span) {
+      /* computeMinMax, nanoflann.hpp:1117-1130 */
+      float mn = pt(t, t->vacc[ind], i), mx = mn;
+      for (size_t k = 1; k < count; ++k) {
+        float v = pt(t, t->vacc[ind + k], i);
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+      }
+      float spread = mx - mn;
+      if (spread > max_spread) { *cutfeat = i; max_spread = spread; min_elem = mn; max_elem = mx; }
+    }
+  }
+  float split_val = (lo[*cutfeat] + hi[*cutfeat]) / 2;
+  if (split_val < min_elem) *cutval = min_elem;
+  else if (split_val > max_elem) *cutval = max_elem;
+  else *cutval = split_val;
+  size_t lim1, lim2;
+  plane_split(t, ind, count, *cutfeat, *cutval, &lim1, &lim2);
+  if (lim1 > count / 2) *index = lim1;
+  else if (lim2 < count / 2) *index = lim2;
+  else *index = count / 2;
+}
+
+/* nanoflann.hpp:1150-1212 divideTree; bbox in/out */
+static int32_t divide_tree(orc_kdtree* t, size_t left, size_t right, float lo[3], float hi[3]) {
+  int32_t ni = new_node(t);
+  if ((right - left) <= t->leaf_max) {
+    orc_node nd;
+    nd.child1 = nd.child2 = -1;
+    nd.left = (uint32_t)left; nd.right = (uint32_t)right;
+    nd.divfeat = 0; nd.divlow = nd.divhigh = 0;
+    for (int i = 0; i < 3; ++i) lo[i] = hi[i] = pt(t, t->vacc[left], i);
+    for (size_t k = left + 1; k < right; ++k)
+      for (int i = 0; i < 3; ++i) {
+        float v = pt(t, t->vacc[k], i);
+        if (lo[i] > v) lo[i] = v;
+        if (hi[i] < v) hi[i] = v;
+      }
+    t->nodes[ni] = nd;
+  } else {
+    size_t idx; int cutfeat; float cutval;
+    middle_split(t, left, right - left, &idx, &cutfeat, &cutval, lo, hi);
+    float llo[3], lhi[3], rlo[3], rhi[3];
+    memcpy(llo, lo, sizeof(llo)); memcpy(lhi, hi, sizeof(lhi));
+    memcpy(rlo, lo, sizeof(rlo)); memcpy(rhi, hi, sizeof(rhi));
+    lhi[cutfeat] = cutval;
+    int32_t c1 = divide_tree(t, left, left + idx, llo, lhi);
+    rlo[cutfeat] = cutval;
+    int32_t c2 = divide_tree(t, left + idx, right, rlo, rhi);
+    orc_node nd;
+    nd.child1 = c1; nd.child2 = c2; nd.left = nd.right = 0;
+    nd.divfeat = cutfeat;
+    nd.divlow = lhi[cutfeat];
+    nd.divhigh = rlo[cutfeat];
+    t->nodes[ni] = nd; /* (re-index: nodes may have been realloc'd during recursion) */
+    for (int i = 0; i < 3; ++i) {
+      lo[i] = llo[i] < rlo[i] ? llo[i] : rlo[i];
+      hi[i] = lhi[i] > rhi[i] ? lhi[i] : rhi[i];
+    }
+  }
+  return ni;
+}
+
+orc_kdtree* orc_kdtree_build(const float* pts_xyz, size_t n, size_t leaf_max) {
+  orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof(orc_kdtree));
+  t->pts = pts_xyz; t->n = n; t->leaf_max = leaf_max ? leaf_max : 10;
+  t->root = -1;
+  if (n == 0) return t;                                   /* nanoflann.hpp:1669 */
+  t->vacc = (uint32_t*)malloc(n * sizeof(uint32_t));
+  for (size_t i = 0; i < n; ++i) t->vacc[i] = (uint32_t)i; /* init_vind */
+  /* computeBoundingBox nanoflann.hpp:1846-1877 */
+  for (int i = 0; i < 3; ++i) t->bb_lo[i] = t->bb_hi[i] = pt(t, 0, i);
+  for (size_t k = 1; k < n; ++k)
+    for (int i = 0; i < 3; ++i) {
+      float v = pt(t, (uint32_t)k, i);
+      if (v < t->bb_lo[i]) t->bb_lo[i] = v;
+      if (v > t->bb_hi[i]) t->bb_hi[i] = v;
+    }
+  t->root = divide_tree(t, 0, n, t->bb_lo, t->bb_hi);
+  return t;
+}
+
+void orc_kdtree_free(orc_kdtree* t) {
+  if (!t) return;
+  free(t->vacc); free(t->nodes); free(t);
+}
+
+/* core/kd_tree.hpp:63-109 KNNSearchResultAdaptor */
+typedef struct { size_t* idx; float* val; size_t k, count; } orc_rs;
+
+static inline void rs_add(orc_rs* r, float dist, size_t index) {
+  size_t i;
+  for (i = r->count; i > 0; --i) {
+    if (r->val[i - 1] > dist) {
+      if (i < r->k) { r->idx[i] = r->idx[i - 1]; r->val[i] = r->val[i - 1]; }
+    } else break;
+  }
+  if (i < r->k) { r->idx[i] = index; r->val[i] = dist; }
+  if (r->count < r->k) r->count++;
+}
+
+/* nanoflann.hpp:570-604 evalMetric, DIM=3: only the tail loop runs -> ((0+dx2)+dy2)+dz2 */
+static inline float eval_metric(const float* a, const float* b) {
+  float result = 0.0f;
+  float d0 = a[0] - b[0]; result += d0 * d0;
+  float d1 = a[1] - b[1]; result += d1 * d1;
+  float d2 = a[2] - b[2]; result += d2 * d2;
+  return result;
+}
+
+/* nanoflann.hpp:1885-1961 searchLevel */
+static void search_level(const orc_kdtree* t, orc_rs* rs, const float* vec, int32_t ni,
+                         float mindist, float dists[3]) {
+  const orc_node* node = &t->nodes[ni];
+  if (node->child1 < 0 && node->child2 < 0) {
+    float worst = rs->val[rs->k - 1];                     /* read once per leaf (:1891) */
+    for (uint32_t i = node->left; i < node->right; ++i) {
+      uint32_t acc = t->vacc[i];
+      float dist = eval_metric(vec, t->pts + 3 * (size_t)acc);
+      if (dist < worst) rs_add(rs, dist, acc);
+    }
+    return;
+  }
+  int idx = node->divfeat;
+  float val = vec[idx];
+  float diff1 = val - node->divlow;
+  float diff2 = val - node->divhigh;
+  int32_t best, other;
+  float cut_dist;
+  if ((diff1 + diff2) < 0) {
+    best = node->child1; other = node->child2;
+    cut_dist = (val - node->divhigh) * (val - node->divhigh);
+  } else {
+    best = node->child2; other = node->child1;
+    cut_dist = (val - node->divlow) * (val - node->divlow);
+  }
+  search_level(t, rs, vec, best, mindist, dists);
+  float dst = dists[idx];
+  mindist = mindist + cut_dist - dst;
+  dists[idx] = cut_dist;
+  if (mindist * 1.0f <= rs->val[rs->k - 1]) search_level(t, rs, vec, other, mindist, dists);
+  dists[idx] = dst;
+}
+
+size_t orc_kdtree_knn_in_radius(const orc_kdtree* t, const float q[3], size_t k, float radius_sq,
+                                size_t* out_idx, float* out_d2) {
+  if (t->n == 0 || k == 0) return 0;                       /* nanoflann.hpp:1714 */
+  orc_rs rs = {out_idx, out_d2, k, 0};
+  rs.val[k - 1] = radius_sq;                               /* kd_tree.hpp:73 */
+  float dists[3] = {0, 0, 0};
+  float dist = 0.0f;                                       /* computeInitialDistances :1430-1453 */
+  for (int i = 0; i < 3; ++i) {
+    if (q[i] < t->bb_lo[i]) { dists[i] = (q[i] - t->bb_lo[i]) * (q[i] - t->bb_lo[i]); dist += dists[i]; }
+    if (q[i] > t->bb_hi[i]) { dists[i] = (q[i] - t->bb_hi[i]) * (q[i] - t->bb_hi[i]); dist += dists[i]; }
+  }
+  search_level(t, &rs, q, t->root, dist, dists);
+  return rs.count;
+}
+
+/* ================================================================================================= */
+
+/* correspondence_search/common_transformable_feature_adaptors.hpp:28-33  q = L*s + t (f32).
+ * Pinned pairing (see header): q_r = (L_r0*x + (L_r1*y + L_r2*z)) + t_r, no FMA contraction. */
+void orc_transform_points(const float T[16], const float* s, size_t n, float* out) {
+  const float l00 = T[0], l10 = T[1], l20 = T[2];
+  const float l01 = T[4], l11 = T[5], l21 = T[6];
+  const float l02 = T[8], l12 = T[9], l22 = T[10];
+  const float t0 = T[12], t1 = T[13], t2 = T[14];
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    const float x = s[3 * i], y = s[3 * i + 1], z = s[3 * i + 2];
+    out[3 * i + 0] = (l00 * x + (l01 * y + l02 * z)) + t0;
+    out[3 * i + 1] = (l10 * x + (l11 * y + l12 * z)) + t1;
+    out[3 * i + 2] = (l20 * x + (l21 * y + l22 * z)) + t2;
+  }
+}
+
+/* correspondence_search/correspondence_search_kd_tree_utilities.hpp:7-51 (ref_is_first = true,
+ * DistanceEvaluator = identity on d2, core/common_pair_evaluators.hpp:13-27). */
+size_t orc_find_correspondences(const orc_kdtree* t, const float* q, size_t nq, float max_d,
+                                int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads) {
+  if (t->n == 0) return 0;                                 /* :16-19 */
+  int64_t* tmp_idx = (int64_t*)malloc(nq * sizeof(int64_t));
+  float* tmp_d2 = (float*)malloc(nq * sizeof(float));
+#ifdef _OPENMP
+  if (num_threads <= 0) num_threads = omp_get_max_threads();
+#endif
+  (void)num_threads;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(num_threads)
+  for (size_t i = 0; i < nq; ++i) {                        /* :26-33 */
+    size_t idx; float val;
+    size_t found = orc_kdtree_knn_in_radius(t, q + 3 * i, 1, max_d, &idx, &val);
+    int keep = (found > 0) && (val < max_d);
+    tmp_idx[i] = keep ? (int64_t)idx : -1;
+    tmp_d2[i] = val;
+  }
+  size_t count = 0;                                        /* :45-50 serial order-preserving compaction */
+  for (size_t i = 0; i < nq; ++i)
+    if (tmp_idx[i] >= 0) { dst_idx[count] = tmp_idx[i]; src_idx[count] = (int64_t)i; d2[count] = tmp_d2[i]; ++count; }
+  free(tmp_idx); free(tmp_d2);
+  return count;
+}
+
+void orc_nn_brute(const float* dst, size_t nd, const float* q, size_t nq, float max_d,
+                  int64_t* nn_idx, float* nn_d2, int num_threads) {
+#ifdef _OPENMP
+  if (num_threads <= 0) num_threads = omp_get_max_threads();
+#endif
+  (void)num_threads;
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+  for (size_t i = 0; i < nq; ++i) {
+    float best = max_d; int64_t bi = -1;
+    for (size_t j = 0; j < nd; ++j) {
+      float d = eval_metric(q + 3 * i, dst + 3 * j);
+      if (d < best) { best = d; bi = (int64_t)j; }
+    }
+    nn_idx[i] = bi; nn_d2[i] = (bi >= 0) ? best : max_d;
+  }
+}
+
+/* ---- solver / estimator instantiations ---------------------------------------------------------- */
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+#define REAL float
+#define SFX(n) CAT(n, _f32)
+#define R_SQRT sqrtf
+#define R_FABS fabsf
+#define R_ATAN atanf
+#define R_SIN sinf
+#define R_COS cosf
+#define R_EPS FLT_EPSILON
+#define R_MIN FLT_MIN
+#include "solver_impl.inc"
+#undef REAL
+#undef SFX
+#undef R_SQRT
+#undef R_FABS
+#undef R_ATAN
+#undef R_SIN
+#undef R_COS
+#undef R_EPS
+#undef R_MIN
+
+#define REAL double
+#define SFX(n) CAT(n, _f64)
+#define R_SQRT sqrt
+#define R_FABS fabs
+#define R_ATAN atan
+#define R_SIN sin
+#define R_COS cos
+#define R_EPS DBL_EPSILON
+#define R_MIN DBL_MIN
+#include "solver_impl.inc"
+#undef REAL
+#undef SFX
+#undef R_SQRT
+#undef R_FABS
+#undef R_ATAN
+#undef R_SIN
+#undef R_COS
+#undef R_EPS
+#undef R_MIN
+
+#define TERM float
+#define ACC float
+#define EFX(n) CAT(n, _m0)
+#define AFX(n) CAT(n, _f32)
+#define A_SQRT sqrtf
+#include "estimator_impl.inc"
+#undef TERM
+#undef ACC
+#undef EFX
+#undef AFX
+#undef A_SQRT
+
+#define TERM float
+#define ACC double
+#define EFX(n) CAT(n, _m1)
+#define AFX(n) CAT(n, _f64)
+#define A_SQRT sqrt
+#include "estimator_impl.inc"
+#undef TERM
+#undef ACC
+#undef EFX
+#undef AFX
+#undef A_SQRT
+
+#define TERM double
+#define ACC double
+#define EFX(n) CAT(n, _m2)
+#define AFX(n) CAT(n, _f64)
+#define A_SQRT sqrt
+#include "estimator_impl.inc"
+#undef TERM
+#undef ACC
+#undef EFX
+#undef AFX
+#undef A_SQRT
+
+void orc_svd3_f64(const double A[9], double U[9], double S[3], double V[9]) { svd3_f64(A, U, S, V); }
+void orc_svd3_f32(const float A[9], float U[9], float S[3], float V[9]) { svd3_f32(A, U, S, V); }
+void orc_ldlt6_solve_f64(const double A[36], const double b[6], double x[6]) { ldlt6_solve_f64(A, b, x); }
+void orc_ldlt6_solve_f32(const float A[36], const float b[6], float x[6]) { ldlt6_solve_f32(A, b, x); }
+void orc_nearest_rotation_f64(const double L[9], double R[9]) { nearest_rotation_f64(L, R); }
+void orc_nearest_rotation_f32(const float L[9], float R[9]) { nearest_rotation_f32(L, R); }
+
+static void pack_T_f32(const float L[9], const float t[3], float T[16]) {
+  memset(T, 0, 16 * sizeof(float)); T[15] = 1.0f;
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[c * 4 + r] = L[r * 3 + c]; T[12 + r] = t[r]; }
+}
+static void pack_T_f64(const double L[9], const double t[3], float T[16]) {
+  memset(T, 0, 16 * sizeof(float)); T[15] = 1.0f;
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T[c * 4 + r] = (float)L[r * 3 + c]; T[12 + r] = (float)t[r]; }
+}
+
+int orc_estimate_p2p(const float* dst, const float* src, const int64_t* di, const int64_t* si,
+                     size_t n, int mode, float T_out[16], double* sums) {
+  int ok;
+  if (mode == ORC_MODE_F32) {
+    float L[9], t[3]; ok = estimate_p2p_m0(dst, src, di, si, n, L, t, sums); pack_T_f32(L, t, T_out);
+  } else if (mode == ORC_MODE_MIXED) {
+    double L[9], t[3]; ok = estimate_p2p_m1(dst, src, di, si, n, L, t, sums); pack_T_f64(L, t, T_out);
+  } else {
+    double L[9], t[3]; ok = estimate_p2p_m2(dst, src, di, si, n, L, t, sums); pack_T_f64(L, t, T_out);
+  }
+  return ok;
+}
+
+int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* src_p,
+                          const int64_t* di, const int64_t* si, size_t n, float w_p2p, float w_p2pl,
+                          size_t max_iter, float conv_tol, const float dst_mean[3],
+                          const float src_mean[3], int mode, float T_out[16], double* AtA_out,
+                          double* Atb_out) {
+  int ok;
+  if (mode == ORC_MODE_F32) {
+    float L[9], t[3];
+    ok = estimate_combined_m0(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    pack_T_f32(L, t, T_out);
+  } else if (mode == ORC_MODE_MIXED) {
+    double L[9], t[3];
+    ok = estimate_combined_m1(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    pack_T_f64(L, t, T_out);
+  } else {
+    double L[9], t[3];
+    ok = estimate_combined_m2(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    pack_T_f64(L, t, T_out);
+  }
+  return ok;
+}
+
+void orc_mean3(const float* xyz, size_t n, int mode, float mean[3]) {
+  mean[0] = mean[1] = mean[2] = 0.0f;
+  if (n == 0) return;
+  if (mode == ORC_MODE_F32) {
+    float s[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) s[c] += xyz[3 * i + c];
+    for (int c = 0; c < 3; ++c) mean[c] = s[c] / (float)n;
+  } else {
+    double s[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) s[c] += (double)xyz[3 * i + c];
+    for (int c = 0; c < 3; ++c) mean[c] = (float)(s[c] / (double)n);
+  }
+}
+
+/* One outer iteration's updateEstimate() given the correspondences.
+ * icp_single_transform_point_to_point_metric.hpp:46-65 / icp_single_transform_combined_metric.hpp:173-217 */
+static float icp_update_impl(const float* dst_p, const float* dst_n, const float* src_trans,
+                             const float T_cur[16], const int64_t* di, const int64_t* si, size_t nc,
+                             const orc_icp_params* prm, const float dst_mean[3],
+                             const float src_mean[3], float T_new[16]) {
+  const int mode = prm->mode;
+  if (prm->metric == 0) {
+    if (mode == ORC_MODE_F32) {
+      float L[9], t[3]; estimate_p2p_m0(dst_p, src_trans, di, si, nc, L, t, NULL);
+      return compose_m0(L, t, T_cur, T_new);
+    } else if (mode == ORC_MODE_MIXED) {
+      double L[9], t[3]; estimate_p2p_m1(dst_p, src_trans, di, si, nc, L, t, NULL);
+      return compose_m1(L, t, T_cur, T_new);
+    } else {
+      double L[9], t[3]; estimate_p2p_m2(dst_p, src_trans, di, si, nc, L, t, NULL);
+      return compose_m2(L, t, T_cur, T_new);
+    }
+  }
+  /* this->transform_ * src_mean_  (:196) -- Eigen Isometry * vector, f32 */
+  float smt[3];
+  orc_transform_points(T_cur, src_mean, 1, smt);
+  if (mode == ORC_MODE_F32) {
+    float L[9], t[3];
+    estimate_combined_m0(dst_p, dst_n, src_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    return compose_m0(L, t, T_cur, T_new);
+  } else if (mode == ORC_MODE_MIXED) {
+    double L[9], t[3];
+    estimate_combined_m1(dst_p, dst_n, src_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    return compose_m1(L, t, T_cur, T_new);
+  } else {
+    double L[9], t[3];
+    estimate_combined_m2(dst_p, dst_n, src_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    return compose_m2(L, t, T_cur, T_new);
+  }
+}
+
+float orc_icp_update(const float* dst_p, const float* dst_n, size_t nd, const float* src_p,
+                     size_t ns, const float T_cur[16], const int64_t* di, const int64_t* si,
+                     size_t nc, const orc_icp_params* prm, float T_new[16]) {
+  float dst_mean[3], src_mean[3];
+  orc_mean3(dst_p, nd, prm->mode, dst_mean);               /* combined ctor :51-58 */
+  orc_mean3(src_p, ns, prm->mode, src_mean);
+  float* src_trans = (float*)malloc(3 * (ns ? ns : 1) * sizeof(float));
+  orc_transform_points(T_cur, src_p, ns, src_trans);       /* transformPoints, space_transformations.hpp:203-216 */
+  float d = icp_update_impl(dst_p, dst_n, src_trans, T_cur, di, si, nc, prm, dst_mean, src_mean, T_new);
+  free(src_trans);
+  return d;
+}
+
+/* registration/icp_base.hpp:68-87 */
+int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* src_p, size_t ns,
+                const float* T0, const orc_icp_params* prm, const orc_kdtree* tree_in,
+                orc_icp_result* out) {
+  memset(out, 0, sizeof(*out));
+  float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (T0) memcpy(T, T0, sizeof(T));
+  float dst_mean[3], src_mean[3];
+  orc_mean3(dst_p, nd, prm->mode, dst_mean);
+  orc_mean3(src_p, ns, prm->mode, src_mean);
+  const size_t cap = ns ? ns : 1;
+  float* q = (float*)malloc(3 * cap * sizeof(float));
+  int64_t* di = (int64_t*)malloc(cap * sizeof(int64_t));
+  int64_t* si = (int64_t*)malloc(cap * sizeof(int64_t));
+  float* d2 = (float*)malloc(cap * sizeof(float));
+  orc_kdtree* own = NULL;
+  const orc_kdtree* tree = tree_in;
+  float last = INFINITY;
+  size_t it = 0;
+  while (it < prm->max_iter) {
+    if (!tree) {                                           /* correspondence_search_kd_tree.hpp:202-203 lazy build */
+      double t0 = now_s();
+      own = orc_kdtree_build(dst_p, nd, 10);
+      tree = own;
+      out->t_build_s += now_s() - t0;
+    }
+    double t0 = now_s();
+    orc_transform_points(T, src_p, ns, q);                 /* transformFeatures(tform) */
+    size_t nc = orc_find_correspondences(tree, q, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
+    double t1 = now_s();
+    out->t_knn_s += t1 - t0;
+    float Tn[16];
+    last = icp_update_impl(dst_p, dst_n, q, T, di, si, nc, prm, dst_mean, src_mean, Tn);
+    memcpy(T, Tn, sizeof(T));
+    out->t_est_s += now_s() - t1;
+    out->last_ncorr = nc;
+    ++it;
+    if (last < prm->conv_tol) break;                       /* icp_base.hpp:83 */
+  }
+  memcpy(out->T, T, sizeof(T));
+  out->iterations = it;
+  out->last_delta_norm = last;
+  free(q); free(di); free(si); free(d2);
+  if (own) orc_kdtree_free(own);
+  return 0;
+}

@@ -1,0 +1,143 @@
+/*
+ * icp_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY) for the rigid-ICP hot path of
+ * kzampog/cilantro.  Plain C restatement of the reference algorithm; every function cites the
+ * reference file:line it follows (paths relative to /root/reference/include/cilantro/).
+ *
+ * THIS IS NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it -- and only as the checker.  The shipped path is the HIP library
+ * (cilantro_amd/csrc -> libcilantro_hip.so); it never links or calls anything in oracle/.
+ *
+ * Parity pinning status (see DESIGN.md "Oracle"):
+ *   - kNN half: PINNED against the reference's own vendored nanoflann 1.7.1 compiled from
+ *     /root/reference into oracle/_ref/ (tests/test_oracle_cpu.py) and against the
+ *     examples/kd_tree.cpp known answer.
+ *   - estimator / solver half: the arithmetic lives in Eigen3 (>=3.3, unpinned, NOT vendored,
+ *     absent from this container) => "parity unpinned" for JacobiSVD/LDLT/AngleAxis round-off;
+ *     anchored analytically (numpy SVD/solve, convergence to ground truth on synthetic data).
+ *
+ * Numeric contract pinned here (and reproduced by the HIP kernels):
+ *   d2(q,p)   = ((dx*dx) + (dy*dy)) + (dz*dz), dx = q.x - p.x, each op rounded to f32
+ *               (3rd_party/nanoflann/nanoflann.hpp:570-604, DIM=3 takes the tail loop only)
+ *   q = T*s   : q.x = (L00*x + (L01*y + L02*z)) + t0, each op rounded to f32
+ *               (correspondence_search/common_transformable_feature_adaptors.hpp:28-33; pairing is
+ *               Eigen's unrolled 3-term redux; build with -ffp-contract=off)
+ */
+#ifndef ICP_ORACLE_H
+#define ICP_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- kd-tree (restates nanoflann 1.7.1 KDTreeSingleIndexAdaptor, L2, DIM=3) ------------------ */
+typedef struct orc_kdtree orc_kdtree;
+
+/* core/kd_tree.hpp:162-170 (leaf_max=10, 1 build thread); nanoflann.hpp:1661-1687,1150-1212 */
+orc_kdtree* orc_kdtree_build(const float* pts_xyz, size_t n, size_t leaf_max);
+void orc_kdtree_free(orc_kdtree* t);
+
+/* core/kd_tree.hpp:283-291 kNNInRadiusSearch (KNNSearchResultAdaptor :63-109).
+ * radius is SQUARED.  Returns the number of neighbours found (<=k), sorted ascending,
+ * first-encountered wins ties (strict '<' insert). */
+size_t orc_kdtree_knn_in_radius(const orc_kdtree* t, const float q[3], size_t k, float radius_sq,
+                                size_t* out_idx, float* out_d2);
+
+/* ---- transform (common_transformable_feature_adaptors.hpp:28-33) ----------------------------- */
+/* T: 4x4 column-major (Eigen::Transform<float,3,Isometry>::matrix().data()). */
+void orc_transform_points(const float T[16], const float* src_xyz, size_t n, float* out_xyz);
+
+/* ---- correspondence search (correspondence_search_kd_tree_utilities.hpp:7-51, ref_is_first) -- */
+/* q: already transformed query points.  Outputs (capacity nq): ascending src index order.
+ * Returns the number of correspondences kept (strict d2 < max_sq_dist). */
+size_t orc_find_correspondences(const orc_kdtree* t, const float* q_xyz, size_t nq,
+                                float max_sq_dist, int64_t* dst_idx, int64_t* src_idx, float* d2,
+                                int num_threads);
+
+/* Exhaustive exact 1-NN-in-radius (validation of both the kd-tree restatement and the GPU grid):
+ * argmin over all dst of the pinned d2 expression, strict '<' vs radius, LOWEST index on ties.
+ * nn_idx[i] = -1 if none. */
+void orc_nn_brute(const float* dst_xyz, size_t nd, const float* q_xyz, size_t nq, float max_sq_dist,
+                  int64_t* nn_idx, float* nn_d2, int num_threads);
+
+/* ---- small dense solvers (Eigen-free restatements; double and float variants) ---------------- */
+/* Two-sided Jacobi SVD of a 3x3 (row-major in/out), A = U diag(S) V^T, S >= 0 sorted descending.
+ * Stands in for Eigen::JacobiSVD<Matrix3> (registration/transform_estimation.hpp:36-37). */
+void orc_svd3_f64(const double A[9], double U[9], double S[3], double V[9]);
+void orc_svd3_f32(const float A[9], float U[9], float S[3], float V[9]);
+/* LDLT with diagonal pivoting + Eigen's pseudo-inverse-of-D solve (transform_estimation.hpp:346). */
+void orc_ldlt6_solve_f64(const double A[36], const double b[6], double x[6]);
+void orc_ldlt6_solve_f32(const float A[36], const float b[6], float x[6]);
+/* core/space_transformations.hpp:43-51: nearest rotation, flips U.col(0) on det<0. Row-major. */
+void orc_nearest_rotation_f64(const double L[9], double R[9]);
+void orc_nearest_rotation_f32(const float L[9], float R[9]);
+
+/* ---- estimators ------------------------------------------------------------------------------ */
+/* mode: 0 = all-f32 serial ("reference-like": ENABLE_NON_DETERMINISTIC_PARALLELISM off),
+ *       1 = per-term f32, accumulate/solve f64 (what the HIP path mirrors, deterministic),
+ *       2 = all f64. */
+enum { ORC_MODE_F32 = 0, ORC_MODE_MIXED = 1, ORC_MODE_F64 = 2 };
+
+/* registration/transform_estimation.hpp:11-48 + :104-113 (gather by correspondences).
+ * src_trans = already transformed source points.  T_out: 4x4 col-major float.
+ * sums_out (optional, 16 doubles): n, sum_d(3), sum_s(3), sum_{d s^T}(9, row-major) --
+ * raw (uncentred) moments, for checking the GPU accumulation kernel.
+ * Returns 1 if n >= 3, 0 otherwise (identity on n == 0). */
+int orc_estimate_p2p(const float* dst_xyz, const float* src_trans_xyz, const int64_t* dst_idx,
+                     const int64_t* src_idx, size_t ncorr, int mode, float T_out[16],
+                     double* sums_out);
+
+/* registration/transform_estimation.hpp:237-367 (rigid, combined metric, 3D).
+ * Unity weight evaluators.  AtA_out(36,row-major)/Atb_out(6): first Gauss-Newton step's normal
+ * equations (optional).  Returns 1 if converged inside max_iter (d_theta.norm() < tol). */
+int orc_estimate_combined(const float* dst_xyz, const float* dst_nrm, const float* src_trans_xyz,
+                          const int64_t* dst_idx, const int64_t* src_idx, size_t ncorr,
+                          float w_p2p, float w_p2pl, size_t max_iter, float conv_tol,
+                          const float dst_mean[3], const float src_mean[3], int mode,
+                          float T_out[16], double* AtA_out, double* Atb_out);
+
+/* ---- whole ICP loop (registration/icp_base.hpp:68-87 + the two instance classes) ------------- */
+typedef struct {
+  int metric;            /* 0 = point-to-point (icp_single_transform_point_to_point_metric.hpp),
+                            1 = combined (icp_single_transform_combined_metric.hpp) */
+  float w_p2p, w_p2pl;   /* combined metric weights (defaults 0 / 1, :46-47) */
+  size_t max_iter;       /* icp_base.hpp:24 default 15 */
+  float conv_tol;        /* icp_base.hpp:25 default 1e-5 */
+  size_t max_opt_iter;   /* combined: max_optimization_iterations_ (default 1) */
+  float opt_conv_tol;    /* combined: optimization_convergence_tol_ (default 1e-5) */
+  float max_sq_dist;     /* engine max_distance_ (squared; default 0.01*0.01) */
+  int mode;              /* ORC_MODE_* */
+  int num_threads;       /* OpenMP threads for the kNN loop */
+} orc_icp_params;
+
+typedef struct {
+  float T[16];           /* final transform_, col-major */
+  size_t iterations;     /* iterations_ */
+  float last_delta_norm; /* last_delta_norm_ */
+  size_t last_ncorr;     /* correspondences in the last iteration */
+  double t_build_s, t_knn_s, t_est_s; /* wall-clock split (tree build once / kNN / estimate) */
+} orc_icp_result;
+
+/* dst_nrm may be NULL for metric 0.  T0: initial transform (col-major) or NULL = identity.
+ * tree: optional prebuilt kd-tree on dst (NULL = build here, as the engine does lazily). */
+int orc_icp_run(const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz,
+                size_t ns, const float* T0, const orc_icp_params* prm, const orc_kdtree* tree,
+                orc_icp_result* out);
+
+/* One ICP outer iteration given correspondences (used by tests to step GPU vs oracle in lockstep).
+ * T_cur -> T_new, returns delta norm. */
+float orc_icp_update(const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz,
+                     size_t ns, const float T_cur[16], const int64_t* dst_idx,
+                     const int64_t* src_idx, size_t ncorr, const orc_icp_params* prm,
+                     float T_new[16]);
+
+/* rowwise().mean() as the reference ctor does (icp_single_transform_combined_metric.hpp:51-58):
+ * f32 serial sum / n. */
+void orc_mean3(const float* xyz, size_t n, int mode, float mean[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,271 @@
+"""ctypes binding of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the checker.  Nothing under ``cilantro_amd/`` imports it.
+
+Two libraries:
+  * ``oracle/liboracle.so``            -- plain-C restatement (``icp_oracle.c``)
+  * ``oracle/_ref/libref_nanoflann.so`` -- the reference's own nanoflann 1.7.1, compiled from
+    /root/reference by ``oracle/Makefile`` (prebuilt file travels to the GPU box)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_nanoflann.so")
+
+MODE_F32, MODE_MIXED, MODE_F64 = 0, 1, 2
+METRIC_P2P, METRIC_COMBINED = 0, 1
+
+
+def build(force=False):
+    """Compile the oracle (and, when /root/reference is present, oracle/_ref)."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
+    # make is incremental: liboracle.so rebuilds only when its sources changed; the `ref` target
+    # rebuilds oracle/_ref only when /root/reference is present and keeps the prebuilt file otherwise.
+    subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("metric", C.c_int), ("w_p2p", C.c_float), ("w_p2pl", C.c_float),
+        ("max_iter", C.c_size_t), ("conv_tol", C.c_float), ("max_opt_iter", C.c_size_t),
+        ("opt_conv_tol", C.c_float), ("max_sq_dist", C.c_float), ("mode", C.c_int),
+        ("num_threads", C.c_int),
+    ]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_float * 16), ("iterations", C.c_size_t), ("last_delta_norm", C.c_float),
+        ("last_ncorr", C.c_size_t), ("t_build_s", C.c_double), ("t_knn_s", C.c_double),
+        ("t_est_s", C.c_double),
+    ]
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.orc_kdtree_build.restype = C.c_void_p
+        L.orc_kdtree_build.argtypes = [_f32p, C.c_size_t, C.c_size_t]
+        L.orc_kdtree_free.argtypes = [C.c_void_p]
+        L.orc_kdtree_knn_in_radius.restype = C.c_size_t
+        L.orc_kdtree_knn_in_radius.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _u64p, _f32p]
+        L.orc_transform_points.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
+        L.orc_find_correspondences.restype = C.c_size_t
+        L.orc_find_correspondences.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
+        L.orc_nn_brute.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _f32p, C.c_int]
+        L.orc_svd3_f64.argtypes = [_f64p] * 4
+        L.orc_svd3_f32.argtypes = [_f32p] * 4
+        L.orc_ldlt6_solve_f64.argtypes = [_f64p] * 3
+        L.orc_ldlt6_solve_f32.argtypes = [_f32p] * 3
+        L.orc_nearest_rotation_f64.argtypes = [_f64p] * 2
+        L.orc_nearest_rotation_f32.argtypes = [_f32p] * 2
+        L.orc_estimate_p2p.restype = C.c_int
+        L.orc_estimate_p2p.argtypes = [_f32p, _f32p, _i64p, _i64p, C.c_size_t, C.c_int, _f32p, C.c_void_p]
+        L.orc_estimate_combined.restype = C.c_int
+        L.orc_estimate_combined.argtypes = [_f32p, _f32p, _f32p, _i64p, _i64p, C.c_size_t, C.c_float,
+                                            C.c_float, C.c_size_t, C.c_float, _f32p, _f32p, C.c_int,
+                                            _f32p, C.c_void_p, C.c_void_p]
+        L.orc_icp_run.restype = C.c_int
+        L.orc_icp_run.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.c_void_p,
+                                  C.POINTER(IcpParams), C.c_void_p, C.POINTER(IcpResult)]
+        L.orc_icp_update.restype = C.c_float
+        L.orc_icp_update.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_size_t, _f32p, _i64p,
+                                     _i64p, C.c_size_t, C.POINTER(IcpParams), _f32p]
+        L.orc_mean3.argtypes = [_f32p, C.c_size_t, C.c_int, _f32p]
+        _lib = L
+    return _lib
+
+
+def ref_available():
+    return os.path.exists(_REF)
+
+
+def ref():
+    """The reference's own nanoflann (oracle/_ref). Raises if it was never built."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(_REF):
+            raise RuntimeError("oracle/_ref/libref_nanoflann.so missing (needs /root/reference at build time)")
+        R = C.CDLL(_REF)
+        R.ref_kdtree_build.restype = C.c_void_p
+        R.ref_kdtree_build.argtypes = [_f32p, C.c_size_t]
+        R.ref_kdtree_free.argtypes = [C.c_void_p]
+        R.ref_kdtree_knn_in_radius.restype = C.c_size_t
+        R.ref_kdtree_knn_in_radius.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _u64p, _f32p]
+        R.ref_find_correspondences.restype = C.c_size_t
+        R.ref_find_correspondences.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
+        _ref = R
+    return _ref
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class KDTree:
+    """Oracle kd-tree (restatement) or the reference's nanoflann (``use_ref=True``)."""
+
+    def __init__(self, pts, use_ref=False, leaf_max=10):
+        self.pts = _c(pts).reshape(-1, 3)
+        self.use_ref = use_ref
+        if use_ref:
+            self.h = ref().ref_kdtree_build(self.pts, len(self.pts))
+        else:
+            self.h = lib().orc_kdtree_build(self.pts, len(self.pts), leaf_max)
+
+    def __del__(self):
+        try:
+            if self.h:
+                (ref().ref_kdtree_free if self.use_ref else lib().orc_kdtree_free)(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def knn_in_radius(self, q, k, radius_sq):
+        q = _c(q).reshape(3)
+        idx = np.zeros(k, np.uint64)
+        d2 = np.zeros(k, np.float32)
+        fn = ref().ref_kdtree_knn_in_radius if self.use_ref else lib().orc_kdtree_knn_in_radius
+        n = fn(self.h, q, k, np.float32(radius_sq), idx, d2)
+        return idx[:n].astype(np.int64), d2[:n]
+
+    def find_correspondences(self, q, max_sq_dist, num_threads=0):
+        """-> (dst_idx, src_idx, d2) in ascending src order (kd_tree_utilities.hpp:45-50)."""
+        q = _c(q).reshape(-1, 3)
+        n = len(q)
+        di = np.zeros(max(n, 1), np.int64)
+        si = np.zeros(max(n, 1), np.int64)
+        d2 = np.zeros(max(n, 1), np.float32)
+        fn = ref().ref_find_correspondences if self.use_ref else lib().orc_find_correspondences
+        if self.use_ref and num_threads <= 0:
+            num_threads = os.cpu_count() or 1
+        c = fn(self.h, q, n, np.float32(max_sq_dist), di, si, d2, num_threads)
+        return di[:c].copy(), si[:c].copy(), d2[:c].copy()
+
+
+def transform_points(T, pts):
+    """T: 4x4 (numpy, math layout). Pinned f32 expression."""
+    pts = _c(pts).reshape(-1, 3)
+    out = np.empty_like(pts)
+    lib().orc_transform_points(T_to_colmajor(T), pts, len(pts), out)
+    return out
+
+
+def T_to_colmajor(T):
+    return _c(np.asarray(T, np.float32).reshape(4, 4).T).reshape(16)
+
+
+def T_from_colmajor(t16):
+    return np.asarray(t16, np.float32).reshape(4, 4).T.copy()
+
+
+def nn_brute(dst, q, max_sq_dist, num_threads=0):
+    dst = _c(dst).reshape(-1, 3)
+    q = _c(q).reshape(-1, 3)
+    idx = np.zeros(len(q), np.int64)
+    d2 = np.zeros(len(q), np.float32)
+    lib().orc_nn_brute(dst, len(dst), q, len(q), np.float32(max_sq_dist), idx, d2, num_threads)
+    return idx, d2
+
+
+def svd3(A, dtype=np.float64):
+    A = _c(A, dtype).reshape(9)
+    U = np.zeros(9, dtype); S = np.zeros(3, dtype); V = np.zeros(9, dtype)
+    (lib().orc_svd3_f64 if dtype == np.float64 else lib().orc_svd3_f32)(A, U, S, V)
+    return U.reshape(3, 3), S, V.reshape(3, 3)
+
+
+def ldlt6_solve(A, b, dtype=np.float64):
+    A = _c(A, dtype).reshape(36); b = _c(b, dtype).reshape(6)
+    x = np.zeros(6, dtype)
+    (lib().orc_ldlt6_solve_f64 if dtype == np.float64 else lib().orc_ldlt6_solve_f32)(A, b, x)
+    return x
+
+
+def nearest_rotation(L, dtype=np.float64):
+    L = _c(L, dtype).reshape(9)
+    R = np.zeros(9, dtype)
+    (lib().orc_nearest_rotation_f64 if dtype == np.float64 else lib().orc_nearest_rotation_f32)(L, R)
+    return R.reshape(3, 3)
+
+
+def estimate_p2p(dst, src_trans, dst_idx, src_idx, mode=MODE_MIXED):
+    dst = _c(dst).reshape(-1, 3); src_trans = _c(src_trans).reshape(-1, 3)
+    di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
+    T = np.zeros(16, np.float32); sums = np.zeros(16, np.float64)
+    ok = lib().orc_estimate_p2p(dst, src_trans, di, si, len(di), mode, T, sums.ctypes.data)
+    return T_from_colmajor(T), sums, bool(ok)
+
+
+def estimate_combined(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, dst_mean, src_mean,
+                      max_iter=1, conv_tol=1e-5, mode=MODE_MIXED):
+    dst = _c(dst).reshape(-1, 3); dst_n = _c(dst_n).reshape(-1, 3)
+    src_trans = _c(src_trans).reshape(-1, 3)
+    di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
+    T = np.zeros(16, np.float32); AtA = np.zeros(36, np.float64); Atb = np.zeros(6, np.float64)
+    ok = lib().orc_estimate_combined(dst, dst_n, src_trans, di, si, len(di), w_p2p, w_p2pl, max_iter,
+                                     conv_tol, _c(dst_mean).reshape(3), _c(src_mean).reshape(3), mode,
+                                     T, AtA.ctypes.data, Atb.ctypes.data)
+    return T_from_colmajor(T), AtA.reshape(6, 6), Atb, bool(ok)
+
+
+def mean3(pts, mode=MODE_MIXED):
+    pts = _c(pts).reshape(-1, 3)
+    m = np.zeros(3, np.float32)
+    lib().orc_mean3(pts, len(pts), mode, m)
+    return m
+
+
+def make_params(metric=METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=15, conv_tol=1e-5,
+                max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=1e-4, mode=MODE_MIXED, num_threads=0):
+    return IcpParams(metric, w_p2p, w_p2pl, max_iter, conv_tol, max_opt_iter, opt_conv_tol,
+                     max_sq_dist, mode, num_threads)
+
+
+def icp_run(dst, dst_n, src, params, T0=None, tree=None):
+    dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3)
+    dn = None
+    if dst_n is not None:
+        dn = _c(dst_n).reshape(-1, 3)
+    res = IcpResult()
+    t0 = T_to_colmajor(T0) if T0 is not None else None
+    lib().orc_icp_run(dst, dn.ctypes.data if dn is not None else None, len(dst), src, len(src),
+                      t0.ctypes.data if t0 is not None else None, C.byref(params),
+                      tree.h if tree is not None else None, C.byref(res))
+    return {
+        "T": T_from_colmajor(np.array(res.T[:], np.float32)),
+        "iterations": int(res.iterations),
+        "last_delta_norm": float(res.last_delta_norm),
+        "last_ncorr": int(res.last_ncorr),
+        "t_build_s": res.t_build_s, "t_knn_s": res.t_knn_s, "t_est_s": res.t_est_s,
+    }
+
+
+def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params):
+    dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3)
+    dn = _c(dst_n).reshape(-1, 3) if dst_n is not None else None
+    di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
+    Tn = np.zeros(16, np.float32)
+    d = lib().orc_icp_update(dst, dn.ctypes.data if dn is not None else None, len(dst), src, len(src),
+                             T_to_colmajor(T_cur), di, si, len(di), C.byref(params), Tn)
+    return T_from_colmajor(Tn), float(d)
