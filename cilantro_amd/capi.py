@@ -1,0 +1,106 @@
+"""ctypes binding of libcilantro_hip.so (include/cilantro_hip/c_api.h) -- 1:1, no logic.
+
+The library is the product; this module only loads it.  There is NO CPU fallback anywhere in
+``cilantro_amd``: if the shared library is missing, ``load()`` raises; if no HIP device is usable,
+``cilhip_create`` returns CILHIP_ERR_NO_DEVICE and :class:`Context` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcilantro_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4
+MEM_HOST, MEM_DEVICE = 0, 1
+METRIC_POINT_TO_POINT, METRIC_COMBINED = 0, 1
+SUMS_LEN = 48
+NONE_IDX = 0xFFFFFFFF
+
+# every symbol include/cilantro_hip/c_api.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = [
+    "cilhip_create", "cilhip_destroy", "cilhip_last_error", "cilhip_set_stream", "cilhip_synchronize",
+    "cilhip_set_target", "cilhip_set_source", "cilhip_get_means", "cilhip_find_correspondences",
+    "cilhip_get_nn", "cilhip_get_correspondences", "cilhip_estimate_point_to_point",
+    "cilhip_estimate_combined", "cilhip_icp_default_params", "cilhip_icp_run", "cilhip_icp_begin",
+    "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
+    "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing",
+]
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("metric", C.c_int), ("w_p2p", C.c_float), ("w_p2pl", C.c_float), ("max_iter", C.c_size_t),
+        ("conv_tol", C.c_float), ("max_opt_iter", C.c_size_t), ("opt_conv_tol", C.c_float),
+        ("max_sq_dist", C.c_float),
+    ]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [
+        ("T", C.c_float * 16), ("iterations", C.c_size_t), ("last_delta_norm", C.c_float),
+        ("last_ncorr", C.c_size_t),
+    ]
+
+
+class GridInfo(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("cell", C.c_float),
+        ("origin", C.c_float * 3), ("n_cells", C.c_size_t), ("avg_occupancy", C.c_double),
+        ("build_ms", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libcilantro_hip.so.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -m cilantro_amd.build` / `__graft_entry__.build()`). There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p
+    L.cilhip_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.cilhip_destroy.argtypes = [vp]
+    L.cilhip_destroy.restype = None
+    L.cilhip_last_error.argtypes = [vp]
+    L.cilhip_last_error.restype = C.c_char_p
+    L.cilhip_set_stream.argtypes = [vp, vp]
+    L.cilhip_synchronize.argtypes = [vp]
+    L.cilhip_set_target.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_int]
+    L.cilhip_set_source.argtypes = [vp, f32p, C.c_size_t, C.c_int]
+    L.cilhip_get_means.argtypes = [vp, f32p, f32p]
+    L.cilhip_find_correspondences.argtypes = [vp, f32p, C.c_float, C.POINTER(C.c_size_t)]
+    L.cilhip_get_nn.argtypes = [vp, vp, f32p, C.c_int]
+    L.cilhip_get_correspondences.argtypes = [vp, vp, vp, f32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.cilhip_estimate_point_to_point.argtypes = [vp, f32p, f64p, C.POINTER(C.c_int)]
+    L.cilhip_estimate_combined.argtypes = [vp, C.c_float, C.c_float, C.c_size_t, C.c_float, f32p, f64p,
+                                           f64p, C.POINTER(C.c_int)]
+    L.cilhip_icp_default_params.argtypes = [C.POINTER(IcpParams)]
+    L.cilhip_icp_default_params.restype = None
+    L.cilhip_icp_run.argtypes = [vp, C.POINTER(IcpParams), f32p, C.POINTER(IcpResult)]
+    L.cilhip_icp_begin.argtypes = [vp, C.POINTER(IcpParams), f32p, f32p]
+    L.cilhip_icp_partial_sums.argtypes = [vp, f64p]
+    L.cilhip_icp_apply_sums.argtypes = [vp, f64p]
+    L.cilhip_icp_state.argtypes = [vp, C.POINTER(IcpResult)]
+    L.cilhip_compute_residuals.argtypes = [vp, C.c_int, C.c_float, C.c_float, f32p, f32p, C.c_int]
+    L.cilhip_get_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
+    L.cilhip_get_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.cilhip_enable_kernel_timing.argtypes = [vp, C.c_int]
+    for name in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        if name not in ("cilhip_destroy", "cilhip_last_error", "cilhip_icp_default_params"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+class CilhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"cilhip error {code}: {msg}")
+        self.code = code

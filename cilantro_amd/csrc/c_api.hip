@@ -1,0 +1,616 @@
+// c_api.hip -- the C ABI of libcilantro_hip.so (declared in include/cilantro_hip/c_api.h).
+// Host-side orchestration only: owns device buffers + stream, enqueues the kernels of kernels.hip /
+// grid_build.hip.  No CPU compute fallback exists: without a usable HIP device every call fails.
+#include "../../include/cilantro_hip/c_api.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+
+using namespace cilhip;
+
+struct cilhip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // target
+  bool has_target = false;
+  GridDev grid{};
+  bool has_normals = false;
+  double grid_occ = 0.0;
+  size_t grid_cells = 0;
+  double build_ms = 0.0;
+  float dst_mean[3] = {0, 0, 0};
+
+  // source
+  bool has_source = false;
+  uint32_t ns = 0;
+  float* d_src_xyz = nullptr;     // original order (kept for re-sorting)
+  float4* d_src_sorted = nullptr; // sorted by target-grid cell under sort_T
+  bool src_sorted = false;
+  float sort_T[16];
+  float src_mean[3] = {0, 0, 0};
+  uint32_t* d_nn_pos = nullptr;
+  float* d_nn_d2 = nullptr;
+  bool have_nn = false;           // nn_pos/nn_d2 hold the result of a search
+  float nn_T[16];                 // transform used by that search
+
+  // loop state / scratch
+  IcpState* d_state = nullptr;
+  double* d_partials = nullptr;
+  int partial_blocks = 0;
+  unsigned long long* d_count = nullptr;
+  uint32_t* d_out_idx = nullptr;  // [ns] original-order results
+  float* d_out_d2 = nullptr;
+
+  // sharded-run state
+  cilhip_icp_params run_prm{};
+  bool run_active = false;
+  float run_src_mean[3] = {0, 0, 0};
+
+  // timing
+  bool kernel_timing = false;
+  double last_loop_ms = 0.0, last_search_ms = 0.0;
+  int last_search_launches = 0;
+  std::vector<hipEvent_t> ev;
+};
+
+#define CK(ctx, call)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                   \
+      return CILHIP_ERR_HIP;                                                                            \
+    }                                                                                                   \
+  } while (0)
+
+static int fail(cilhip_ctx* c, int code, const char* msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+
+extern "C" {
+
+int cilhip_create(cilhip_ctx** out, int device) {
+  if (!out) return CILHIP_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CILHIP_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return CILHIP_ERR_INVALID;
+  cilhip_ctx* c = new (std::nothrow) cilhip_ctx();
+  if (!c) return CILHIP_ERR_HIP;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return CILHIP_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess) {
+    delete c;
+    return CILHIP_ERR_HIP;
+  }
+  memcpy(c->sort_T, kIdentity, sizeof(kIdentity));
+  memcpy(c->nn_T, kIdentity, sizeof(kIdentity));
+  *out = c;
+  return CILHIP_OK;
+}
+
+static void free_source(cilhip_ctx* c) {
+  if (c->d_src_xyz) (void)hipFree(c->d_src_xyz);
+  if (c->d_src_sorted) (void)hipFree(c->d_src_sorted);
+  if (c->d_nn_pos) (void)hipFree(c->d_nn_pos);
+  if (c->d_nn_d2) (void)hipFree(c->d_nn_d2);
+  if (c->d_out_idx) (void)hipFree(c->d_out_idx);
+  if (c->d_out_d2) (void)hipFree(c->d_out_d2);
+  c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
+  c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
+  c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
+}
+
+void cilhip_destroy(cilhip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_source(c);
+  if (c->has_target) free_grid(c->grid);
+  if (c->d_state) (void)hipFree(c->d_state);
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_count) (void)hipFree(c->d_count);
+  for (auto e : c->ev) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* cilhip_last_error(const cilhip_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int cilhip_set_stream(cilhip_ctx* c, void* s) {
+  if (!c) return CILHIP_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return CILHIP_OK;
+}
+
+int cilhip_synchronize(cilhip_ctx* c) {
+  if (!c) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  CK(c, hipStreamSynchronize(c->stream));
+  return CILHIP_OK;
+}
+
+int cilhip_enable_kernel_timing(cilhip_ctx* c, int on) {
+  if (!c) return CILHIP_ERR_INVALID;
+  c->kernel_timing = on != 0;
+  return CILHIP_OK;
+}
+
+static int upload(cilhip_ctx* c, const float* src, size_t count, int mem, float** d_out) {
+  *d_out = nullptr;
+  CK(c, hipMalloc(d_out, (count ? count : 1) * sizeof(float)));
+  if (count)
+    CK(c, hipMemcpyAsync(*d_out, src, count * sizeof(float), mem == CILHIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  return CILHIP_OK;
+}
+
+int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t n, int mem) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if ((n && !xyz) || n >= 0xFFFFFFF0ull) return fail(c, CILHIP_ERR_INVALID, "set_target: bad cloud (null or >= 2^32-16 points)");
+  CK(c, hipSetDevice(c->device));
+  auto t0 = std::chrono::steady_clock::now();
+  if (c->has_target) { free_grid(c->grid); c->has_target = false; }
+  float *d_xyz = nullptr, *d_nrm = nullptr;
+  int rc = upload(c, xyz, 3 * n, mem, &d_xyz);
+  if (rc) return rc;
+  if (nrm) { rc = upload(c, nrm, 3 * n, mem, &d_nrm); if (rc) { (void)hipFree(d_xyz); return rc; } }
+  GridBuildResult r{};
+  double mean[3];
+  hipError_t e = build_grid(d_xyz, d_nrm, (uint32_t)n, c->stream, &r, mean);
+  (void)hipFree(d_xyz);
+  if (d_nrm) (void)hipFree(d_nrm);
+  if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
+  c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
+  c->has_normals = (nrm != nullptr);
+  for (int i = 0; i < 3; ++i) c->dst_mean[i] = (float)mean[i];
+  c->has_target = true;
+  c->src_sorted = false;  // source order is tied to the target grid
+  c->have_nn = false;
+  c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return CILHIP_OK;
+}
+
+int cilhip_set_source(cilhip_ctx* c, const float* xyz, size_t n, int mem) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if ((n && !xyz) || n >= 0xFFFFFFF0ull) return fail(c, CILHIP_ERR_INVALID, "set_source: bad cloud");
+  CK(c, hipSetDevice(c->device));
+  free_source(c);
+  int rc = upload(c, xyz, 3 * n, mem, &c->d_src_xyz);
+  if (rc) return rc;
+  const size_t cap = n ? n : 1;
+  CK(c, hipMalloc(&c->d_src_sorted, cap * sizeof(float4)));
+  CK(c, hipMalloc(&c->d_nn_pos, cap * sizeof(uint32_t)));
+  CK(c, hipMalloc(&c->d_nn_d2, cap * sizeof(float)));
+  c->ns = (uint32_t)n;
+  double mean[3];
+  hipError_t e = mean3_device(c->d_src_xyz, c->ns, c->stream, mean);
+  if (e != hipSuccess) { c->err = std::string("mean3: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
+  for (int i = 0; i < 3; ++i) c->src_mean[i] = (float)mean[i];
+  const int nb = iter_num_blocks(c->ns);
+  if (nb > c->partial_blocks) {
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    CK(c, hipMalloc(&c->d_partials, (size_t)nb * SUMS_MAX * sizeof(double)));
+    c->partial_blocks = nb;
+  }
+  c->has_source = true;
+  return CILHIP_OK;
+}
+
+int cilhip_get_means(cilhip_ctx* c, float dm[3], float sm[3]) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (dm) memcpy(dm, c->dst_mean, sizeof(c->dst_mean));
+  if (sm) memcpy(sm, c->src_mean, sizeof(c->src_mean));
+  return CILHIP_OK;
+}
+
+// Spatially sort the source under T (once; re-sorted only if the transform moved it by more than a few cells).
+static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
+  if (!c->has_target || !c->has_source) return fail(c, CILHIP_ERR_INVALID, "set_target and set_source first");
+  bool need = !c->src_sorted;
+  if (!need) {
+    // displacement of the source bbox centre proxy: compare transforms on the source mean
+    float a[3], b[3];
+    transform_point(T, c->src_mean[0], c->src_mean[1], c->src_mean[2], a[0], a[1], a[2]);
+    transform_point(c->sort_T, c->src_mean[0], c->src_mean[1], c->src_mean[2], b[0], b[1], b[2]);
+    float dl = 0.f;
+    for (int i = 0; i < 3; ++i) dl = fmaxf(dl, fabsf(a[i] - b[i]));
+    float dr = 0.f;
+    for (int i = 0; i < 11; ++i) if (i % 4 != 3) dr = fmaxf(dr, fabsf(T[i] - c->sort_T[i]));
+    const float ext = fmaxf(c->grid.nx, fmaxf(c->grid.ny, c->grid.nz)) * c->grid.cell;
+    if (dl > 4.0f * c->grid.cell || dr * ext > 4.0f * c->grid.cell) need = true;
+  }
+  if (need) {
+    hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream);
+    if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
+    memcpy(c->sort_T, T, sizeof(c->sort_T));
+    c->src_sorted = true;
+    c->have_nn = false;
+  }
+  return CILHIP_OK;
+}
+
+static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
+  IterArgs a{};
+  a.grid = c->grid;
+  a.src = c->d_src_sorted;
+  a.ns = c->ns;
+  a.max_sq = max_sq;
+  for (int i = 0; i < 3; ++i) a.dst_mean[i] = c->dst_mean[i];
+  a.state = c->d_state;
+  a.nn_pos = c->d_nn_pos;
+  a.nn_d2 = c->d_nn_d2;
+  a.partials = c->d_partials;
+  a.skip_if_inner_done = 0;
+  return a;
+}
+
+int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, size_t* n_found) {
+  if (!c || !T) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  int rc = ensure_sorted(c, T);
+  if (rc) return rc;
+  launch_init_state(c->d_state, T, c->src_mean, c->stream);
+  IterArgs a = make_iter_args(c, max_sq);
+  if (c->ns) launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
+  CK(c, hipGetLastError());
+  memcpy(c->nn_T, T, sizeof(c->nn_T));
+  c->have_nn = true;
+  if (n_found) {
+    unsigned long long cnt = 0;
+    launch_count_found(c->d_nn_pos, c->ns, c->d_count, c->stream);
+    CK(c, hipMemcpyAsync(&cnt, c->d_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    *n_found = (size_t)cnt;
+  }
+  return CILHIP_OK;
+}
+
+static int scatter_to_original(cilhip_ctx* c) {
+  const size_t cap = c->ns ? c->ns : 1;
+  if (!c->d_out_idx) CK(c, hipMalloc(&c->d_out_idx, cap * sizeof(uint32_t)));
+  if (!c->d_out_d2) CK(c, hipMalloc(&c->d_out_d2, cap * sizeof(float)));
+  launch_scatter_nn(c->d_src_sorted, c->grid.pts, c->d_nn_pos, c->d_nn_d2, c->ns, c->d_out_idx, c->d_out_d2, c->stream);
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
+int cilhip_get_nn(cilhip_ctx* c, uint32_t* nn_idx, float* nn_d2, int mem) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "get_nn: no search has been run");
+  CK(c, hipSetDevice(c->device));
+  int rc = scatter_to_original(c);
+  if (rc) return rc;
+  const hipMemcpyKind k = mem == CILHIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (nn_idx && c->ns) CK(c, hipMemcpyAsync(nn_idx, c->d_out_idx, (size_t)c->ns * 4, k, c->stream));
+  if (nn_d2 && c->ns) CK(c, hipMemcpyAsync(nn_d2, c->d_out_d2, (size_t)c->ns * 4, k, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  return CILHIP_OK;
+}
+
+int cilhip_get_correspondences(cilhip_ctx* c, uint64_t* i1, uint64_t* i2, float* val, size_t cap, size_t* n_out) {
+  if (!c || !n_out) return CILHIP_ERR_INVALID;
+  if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "get_correspondences: no search has been run");
+  std::vector<uint32_t> idx(c->ns ? c->ns : 1);
+  std::vector<float> d2(c->ns ? c->ns : 1);
+  int rc = cilhip_get_nn(c, idx.data(), d2.data(), CILHIP_MEM_HOST);
+  if (rc) return rc;
+  // order-preserving compaction in ascending source index (kd_tree_utilities.hpp:45-50)
+  size_t cnt = 0;
+  for (uint32_t i = 0; i < c->ns; ++i) {
+    if (idx[i] == NONE_U32) continue;
+    if (cnt < cap) {
+      if (i1) i1[cnt] = idx[i];
+      if (i2) i2[cnt] = i;
+      if (val) val[cnt] = d2[i];
+    }
+    ++cnt;
+  }
+  *n_out = cnt;
+  if (cnt > cap) return fail(c, CILHIP_ERR_INVALID, "get_correspondences: capacity too small");
+  return CILHIP_OK;
+}
+
+static void pack_T(const double L[9], const double t[3], float T[16]) {
+  for (int i = 0; i < 16; ++i) T[i] = 0.f;
+  T[15] = 1.f;
+  for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) T[cc * 4 + r] = (float)L[r * 3 + cc]; T[12 + r] = (float)t[r]; }
+}
+
+// Accumulate over the stored matches (transform = nn_T) and bring the reduced sums to the host.
+static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], const double innert[3], double sums[SUMS_MAX]) {
+  IcpState hs;
+  launch_init_state(c->d_state, c->nn_T, c->src_mean, c->stream);
+  if (innerL) {
+    CK(c, hipMemcpyAsync(&hs, c->d_state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 9; ++i) { hs.innerL[i] = (float)innerL[i]; hs.dLd[i] = innerL[i]; }
+    for (int i = 0; i < 3; ++i) { hs.innert[i] = (float)innert[i]; hs.dtd[i] = innert[i]; }
+    CK(c, hipMemcpyAsync(c->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, c->stream));
+  }
+  IterArgs a = make_iter_args(c, 0.0f);
+  const int nb = iter_num_blocks(c->ns);
+  for (int i = 0; i < SUMS_MAX; ++i) sums[i] = 0.0;
+  if (c->ns == 0) return CILHIP_OK;
+  launch_iter(a, metric, false, false, nb, c->stream);
+  launch_reduce_partials(c->d_partials, nb, c->d_partials, c->stream);  // in place: block 0's slots become the total
+  CK(c, hipGetLastError());
+  CK(c, hipMemcpyAsync(sums, c->d_partials, SUMS_MAX * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  return CILHIP_OK;
+}
+
+int cilhip_estimate_point_to_point(cilhip_ctx* c, float dT[16], double* sums_out, int* ok) {
+  if (!c || !dT) return CILHIP_ERR_INVALID;
+  if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
+  CK(c, hipSetDevice(c->device));
+  double sums[SUMS_MAX];
+  int rc = accumulate_stored(c, IM_KABSCH, nullptr, nullptr, sums);
+  if (rc) return rc;
+  double L[9], t[3];
+  kabsch_from_sums(sums, L, t);
+  pack_T(L, t, dT);
+  if (sums_out) memcpy(sums_out, sums, 16 * sizeof(double));
+  if (ok) *ok = sums[0] >= 3.0;
+  return CILHIP_OK;
+}
+
+int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t max_iter, float conv_tol, float dT[16],
+                             double* AtA_out, double* Atb_out, int* converged) {
+  if (!c || !dT) return CILHIP_ERR_INVALID;
+  if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
+  CK(c, hipSetDevice(c->device));
+  double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+  memcpy(dT, kIdentity, sizeof(kIdentity));
+  if (converged) *converged = 0;
+  if (AtA_out) for (int i = 0; i < 36; ++i) AtA_out[i] = 0.0;
+  if (Atb_out) for (int i = 0; i < 6; ++i) Atb_out[i] = 0.0;
+  const bool wp = w_p2p > 0.0f, wl = w_p2pl > 0.0f;
+  if (!wp && !wl) return CILHIP_OK;                      // transform_estimation.hpp:264-272
+  if (wl && !c->has_normals) return CILHIP_OK;           // dst_p.cols() != dst_n.cols() -> identity, false
+  const int metric = (wp && wl) ? IM_BOTH : (wl ? IM_PLANE : IM_POINT);
+  float smt[3];
+  transform_point(c->nn_T, c->src_mean[0], c->src_mean[1], c->src_mean[2], smt[0], smt[1], smt[2]);
+  int conv = 0;
+  for (size_t it = 0; it < max_iter; ++it) {
+    double sums[SUMS_MAX];
+    int rc = accumulate_stored(c, metric, L, t, sums);
+    if (rc) return rc;
+    if (!(sums[0] > 0.0)) return CILHIP_OK;              // no correspondences: identity
+    double AtA[36], Atb[6], dth[6];
+    gn_normal_equations(sums, wp ? (double)w_p2p : 0.0, wl ? (double)w_p2pl : 0.0, AtA, Atb);
+    if (it == 0) {
+      if (AtA_out) memcpy(AtA_out, AtA, sizeof(AtA));
+      if (Atb_out) memcpy(Atb_out, Atb, sizeof(Atb));
+    }
+    ldlt6_solve(AtA, Atb, dth);
+    rigid_gn_update(dth, L, t);
+    double nrm = 0.0;
+    for (int i = 0; i < 6; ++i) nrm += dth[i] * dth[i];
+    if (std::sqrt(nrm) < (double)conv_tol) { conv = 1; break; }
+  }
+  double tt[3];
+  for (int r = 0; r < 3; ++r)
+    tt[r] = t[r] - (L[r * 3] * (double)smt[0] + L[r * 3 + 1] * (double)smt[1] + L[r * 3 + 2] * (double)smt[2]) + (double)c->dst_mean[r];
+  pack_T(L, tt, dT);
+  if (converged) *converged = conv;
+  return CILHIP_OK;
+}
+
+void cilhip_icp_default_params(cilhip_icp_params* p) {
+  if (!p) return;
+  p->metric = CILHIP_METRIC_COMBINED;
+  p->w_p2p = 0.0f; p->w_p2pl = 1.0f;
+  p->max_iter = 15; p->conv_tol = 1e-5f;
+  p->max_opt_iter = 1; p->opt_conv_tol = 1e-5f;
+  p->max_sq_dist = 0.01f * 0.01f;
+}
+
+static int iter_metric_of(const cilhip_icp_params* p) {
+  if (p->metric == CILHIP_METRIC_POINT_TO_POINT) return IM_KABSCH;
+  const bool wp = p->w_p2p > 0.0f, wl = p->w_p2pl > 0.0f;
+  if (wp && wl) return IM_BOTH;
+  if (wl) return IM_PLANE;
+  if (wp) return IM_POINT;
+  return IM_PLANE;  // no terms: sums unused, the epilogue takes the identity branch
+}
+
+static SolveArgs make_solve_args(cilhip_ctx* c, const cilhip_icp_params* p, int im, const float src_mean[3]) {
+  SolveArgs sa{};
+  sa.state = c->d_state;
+  sa.partials = c->d_partials;
+  sa.nblocks = iter_num_blocks(c->ns);
+  sa.reduced = nullptr;
+  sa.metric = im;
+  sa.w_p2p = p->w_p2p; sa.w_p2pl = p->w_p2pl;
+  sa.conv_tol = p->conv_tol; sa.opt_conv_tol = p->opt_conv_tol;
+  for (int i = 0; i < 3; ++i) { sa.dst_mean[i] = c->dst_mean[i]; sa.src_mean[i] = src_mean[i]; }
+  sa.gn_last_step = 1;
+  sa.has_normals = c->has_normals ? 1 : 0;
+  return sa;
+}
+
+static hipEvent_t get_event(cilhip_ctx* c, size_t i) {
+  while (c->ev.size() <= i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev.push_back(e); }
+  return c->ev[i];
+}
+
+static int read_state(cilhip_ctx* c, cilhip_icp_result* out) {
+  IcpState hs;
+  CK(c, hipMemcpyAsync(&hs, c->d_state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  memcpy(out->T, hs.T, sizeof(hs.T));
+  out->iterations = (size_t)hs.iterations;
+  out->last_delta_norm = hs.delta;
+  out->last_ncorr = (size_t)hs.ncorr;
+  return CILHIP_OK;
+}
+
+int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, cilhip_icp_result* out) {
+  if (!c || !p || !out) return CILHIP_ERR_INVALID;
+  if (p->metric != CILHIP_METRIC_POINT_TO_POINT && p->metric != CILHIP_METRIC_COMBINED) return fail(c, CILHIP_ERR_INVALID, "icp_run: bad metric");
+  CK(c, hipSetDevice(c->device));
+  const float* Ti = T0 ? T0 : kIdentity;
+  int rc = ensure_sorted(c, Ti);
+  if (rc) return rc;
+  const int im = iter_metric_of(p);
+  const bool gn = (im != IM_KABSCH);
+  const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 0) : 1;
+  launch_init_state(c->d_state, Ti, c->src_mean, c->stream);
+  IterArgs a = make_iter_args(c, p->max_sq_dist);
+  SolveArgs sa = make_solve_args(c, p, im, c->src_mean);
+  const int nb = sa.nblocks;
+  const bool timing = c->kernel_timing && p->max_iter <= 4096;
+  hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
+  CK(c, hipEventRecord(e_beg, c->stream));
+  size_t nev = 2;
+  int launches = 0;
+  for (size_t it = 0; it < p->max_iter; ++it) {
+    if (gn && opt_steps == 0) {
+      // max_optimization_iterations_ == 0: estimateTransformCombinedMetric leaves tform = identity
+      // and still un-centres it (:365): handled by an epilogue with zero weights is NOT identical, so
+      // mirror literally: tform = t_dst * I * t_src.
+      return fail(c, CILHIP_ERR_UNSUPPORTED, "max_opt_iter == 0 is not supported");
+    }
+    for (size_t st = 0; st < opt_steps; ++st) {
+      a.skip_if_inner_done = (st > 0);
+      if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+      if (c->ns) launch_iter(a, im, st == 0, gn && opt_steps > 1 && st == 0, nb, c->stream);
+      if (timing && st == 0) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); ++launches; }
+      sa.gn_last_step = (st + 1 == opt_steps);
+      launch_solve(sa, c->stream);
+    }
+  }
+  CK(c, hipEventRecord(e_end, c->stream));
+  CK(c, hipGetLastError());
+  rc = read_state(c, out);
+  if (rc) return rc;
+  c->have_nn = false;
+  float ms = 0.f;
+  CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
+  c->last_loop_ms = ms;
+  c->last_search_ms = 0.0; c->last_search_launches = 0;
+  if (timing) {
+    // only iterations that actually executed (not the early-exit launches after convergence)
+    const size_t executed = out->iterations < (size_t)launches ? out->iterations : (size_t)launches;
+    for (size_t k = 0; k < executed; ++k) {
+      float m = 0.f;
+      CK(c, hipEventElapsedTime(&m, c->ev[2 + 2 * k], c->ev[3 + 2 * k]));
+      c->last_search_ms += m;
+    }
+    c->last_search_launches = (int)executed;
+  }
+  return CILHIP_OK;
+}
+
+int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, const float* gmean) {
+  if (!c || !p) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
+  const float* Ti = T0 ? T0 : kIdentity;
+  int rc = ensure_sorted(c, Ti);
+  if (rc) return rc;
+  c->run_prm = *p;
+  for (int i = 0; i < 3; ++i) c->run_src_mean[i] = gmean ? gmean[i] : c->src_mean[i];
+  launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream);
+  CK(c, hipGetLastError());
+  c->run_active = true;
+  return CILHIP_OK;
+}
+
+int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
+  if (!c || !sums_dev) return CILHIP_ERR_INVALID;
+  if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
+  CK(c, hipSetDevice(c->device));
+  const int im = iter_metric_of(&c->run_prm);
+  IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
+  const int nb = iter_num_blocks(c->ns);
+  if (c->ns) {
+    launch_iter(a, im, true, false, nb, c->stream);
+    launch_reduce_partials(c->d_partials, nb, sums_dev, c->stream);
+  } else {
+    CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));
+  }
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
+int cilhip_icp_apply_sums(cilhip_ctx* c, const double* sums_dev) {
+  if (!c || !sums_dev) return CILHIP_ERR_INVALID;
+  if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
+  CK(c, hipSetDevice(c->device));
+  const int im = iter_metric_of(&c->run_prm);
+  SolveArgs sa = make_solve_args(c, &c->run_prm, im, c->run_src_mean);
+  sa.nblocks = 0;
+  sa.reduced = sums_dev;
+  launch_solve(sa, c->stream);
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
+int cilhip_icp_state(cilhip_ctx* c, cilhip_icp_result* out) {
+  if (!c || !out) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  return read_state(c, out);
+}
+
+int cilhip_compute_residuals(cilhip_ctx* c, int metric, float w_p2p, float w_p2pl, const float T[16], float* out, int mem) {
+  if (!c || !T || !out) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  if (metric != 0 && !c->has_normals) return fail(c, CILHIP_ERR_INVALID, "compute_residuals: combined metric needs target normals");
+  int rc = ensure_sorted(c, T);
+  if (rc) return rc;
+  launch_init_state(c->d_state, T, c->src_mean, c->stream);
+  IterArgs a = make_iter_args(c, 3.402823466e+38f);
+  float* d_out = out;
+  if (mem != CILHIP_MEM_DEVICE) CK(c, hipMalloc(&d_out, (c->ns ? c->ns : 1) * sizeof(float)));
+  launch_residuals(a, metric, w_p2p, w_p2pl, d_out, c->stream);
+  CK(c, hipGetLastError());
+  if (mem != CILHIP_MEM_DEVICE) {
+    if (c->ns) CK(c, hipMemcpyAsync(out, d_out, (size_t)c->ns * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_out);
+  }
+  return CILHIP_OK;
+}
+
+int cilhip_get_grid_info(cilhip_ctx* c, cilhip_grid_info* o) {
+  if (!c || !o) return CILHIP_ERR_INVALID;
+  if (!c->has_target) return fail(c, CILHIP_ERR_INVALID, "no target");
+  o->nx = c->grid.nx; o->ny = c->grid.ny; o->nz = c->grid.nz;
+  o->cell = c->grid.cell;
+  o->origin[0] = c->grid.ox; o->origin[1] = c->grid.oy; o->origin[2] = c->grid.oz;
+  o->n_cells = c->grid_cells;
+  o->avg_occupancy = c->grid_occ;
+  o->build_ms = c->build_ms;
+  return CILHIP_OK;
+}
+
+int cilhip_get_last_timing(cilhip_ctx* c, double* loop_ms, double* search_ms, int* launches) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (loop_ms) *loop_ms = c->last_loop_ms;
+  if (search_ms) *search_ms = c->last_search_ms;
+  if (launches) *launches = c->last_search_launches;
+  return CILHIP_OK;
+}
+
+}  // extern "C"

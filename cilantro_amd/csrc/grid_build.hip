@@ -1,0 +1,279 @@
+// grid_build.hip -- one-off construction of the target index (replaces the single-threaded nanoflann
+// kd-tree build: core/kd_tree.hpp:162-170 -> 3rd_party/nanoflann/nanoflann.hpp:1661-1687,1150-1212,
+// 5.7 s for 10M points on the reference's CPU path) and the spatial pre-sort of the source cloud.
+//
+//   bbox + f64 mean (one pass)  ->  cell size from density (adaptive: shrink until the expected
+//   own-cell population is small)  ->  cell key per point  ->  stable LSD radix sort of (key, index)
+//   (rocPRIM; stable => within a cell points stay in ascending original index)  ->  cell_start table
+//   ->  gather into 16-byte {x,y,z,idx} records (+ normals in the same order).
+//
+// The search radius is NOT baked into the grid (the kd-tree it replaces is radius-agnostic too):
+// the query kernel expands shells until its pruning bound proves exactness.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace cilhip {
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+constexpr int RB = 1024;  // reduction blocks
+
+// per-block min/max (f32) and sum (f64) of xyz
+__global__ __launch_bounds__(256) void k_bbox_sum(const float* __restrict__ xyz, uint32_t n, float* bmin, float* bmax, double* bsum) {
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  double sm[3] = {0, 0, 0};
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t beg = blockIdx.x * per, end = min(beg + per, n);
+  for (uint32_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = xyz[3 * (size_t)i + c];
+      mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); sm[c] += (double)v;
+    }
+  }
+  __shared__ float smn[4][3], smx[4][3];
+  __shared__ double ssm[4][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a = mn[c], b = mx[c]; double s = sm[c];
+    for (int off = 32; off > 0; off >>= 1) {
+      a = fminf(a, __shfl_down(a, off, 64)); b = fmaxf(b, __shfl_down(b, off, 64)); s += __shfl_down(s, off, 64);
+    }
+    if (lane == 0) { smn[wave][c] = a; smx[wave][c] = b; ssm[wave][c] = s; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    bmin[blockIdx.x * 3 + c] = fminf(fminf(smn[0][c], smn[1][c]), fminf(smn[2][c], smn[3][c]));
+    bmax[blockIdx.x * 3 + c] = fmaxf(fmaxf(smx[0][c], smx[1][c]), fmaxf(smx[2][c], smx[3][c]));
+    bsum[blockIdx.x * 3 + c] = (ssm[0][c] + ssm[1][c]) + (ssm[2][c] + ssm[3][c]);
+  }
+}
+
+static hipError_t bbox_mean(const float* d_xyz, uint32_t n, hipStream_t s, float lo[3], float hi[3], double mean[3]) {
+  float *d_min = nullptr, *d_max = nullptr; double* d_sum = nullptr;
+  HIP_TRY(hipMalloc(&d_min, RB * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_max, RB * 3 * sizeof(float)));
+  HIP_TRY(hipMalloc(&d_sum, RB * 3 * sizeof(double)));
+  hipLaunchKernelGGL(k_bbox_sum, dim3(RB), dim3(256), 0, s, d_xyz, n, d_min, d_max, d_sum);
+  std::vector<float> hmin(RB * 3), hmax(RB * 3); std::vector<double> hsum(RB * 3);
+  HIP_TRY(hipMemcpyAsync(hmin.data(), d_min, RB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hmax.data(), d_max, RB * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(hsum.data(), d_sum, RB * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(d_min); (void)hipFree(d_max); (void)hipFree(d_sum);
+  for (int c = 0; c < 3; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; mean[c] = 0.0; }
+  for (int b = 0; b < RB; ++b)
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = std::min(lo[c], hmin[b * 3 + c]); hi[c] = std::max(hi[c], hmax[b * 3 + c]); mean[c] += hsum[b * 3 + c];
+    }
+  for (int c = 0; c < 3; ++c) mean[c] = n ? mean[c] / (double)n : 0.0;
+  return hipSuccess;
+}
+
+hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3]) {
+  float lo[3], hi[3];
+  if (n == 0) { mean_out[0] = mean_out[1] = mean_out[2] = 0.0; return hipSuccess; }
+  return bbox_mean(d_xyz, n, s, lo, hi, mean_out);
+}
+
+__device__ __forceinline__ uint32_t cell_of(const GridDev& g, float x, float y, float z) {
+  int cx = (int)floorf(fminf(fmaxf((x - g.ox) * g.inv_cell, -1.0f), 1.0e9f));
+  int cy = (int)floorf(fminf(fmaxf((y - g.oy) * g.inv_cell, -1.0f), 1.0e9f));
+  int cz = (int)floorf(fminf(fmaxf((z - g.oz) * g.inv_cell, -1.0f), 1.0e9f));
+  cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+  return ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+}
+
+__global__ void k_cell_keys(const float* __restrict__ xyz, uint32_t n, GridDev g, uint32_t* keys, uint32_t* vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    keys[i] = cell_of(g, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+    vals[i] = i;
+  }
+}
+
+struct Tf { float m[16]; };
+
+__global__ void k_cell_keys_tf(const float* __restrict__ xyz, uint32_t n, GridDev g, Tf T, uint32_t* keys, uint32_t* vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float qx, qy, qz;
+    transform_point(T.m, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], qx, qy, qz);
+    keys[i] = cell_of(g, qx, qy, qz);
+    vals[i] = i;
+  }
+}
+
+// cell_start[k] = first sorted position whose key >= k, for k in [0, ncells]
+__global__ void k_cell_start(const uint32_t* __restrict__ keys_sorted, uint32_t n, uint32_t ncells, uint32_t* cell_start) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+    const uint32_t prev = (i == 0) ? 0u : keys_sorted[i - 1] + 1u;           // first key not yet closed
+    const uint32_t cur = (i == n) ? ncells + 1u : keys_sorted[i] + 1u;      // exclusive end to fill
+    for (uint32_t k = prev; k < cur; ++k) cell_start[k] = i;
+  }
+}
+
+__global__ void k_gather(const float* __restrict__ xyz, const float* __restrict__ nrm, const uint32_t* __restrict__ perm,
+                         uint32_t n, float4* pts_out, float4* nrm_out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t j = perm[i];
+    pts_out[i] = make_float4(xyz[3 * (size_t)j], xyz[3 * (size_t)j + 1], xyz[3 * (size_t)j + 2], __uint_as_float(j));
+    if (nrm_out) nrm_out[i] = make_float4(nrm[3 * (size_t)j], nrm[3 * (size_t)j + 1], nrm[3 * (size_t)j + 2], 0.0f);
+  }
+}
+
+// sum over cells of count^2 (f64): expected own-cell population seen by a random target point is this / n
+__global__ void k_occupancy(const uint32_t* __restrict__ cell_start, uint32_t ncells, double* out) {
+  double s = 0.0;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < ncells; k += gridDim.x * blockDim.x) {
+    const double c = (double)(cell_start[k + 1] - cell_start[k]);
+    s += c * c;
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
+}
+
+static inline int grid_blocks(uint32_t n) { return (int)std::min<uint32_t>((n + 255) / 256, 8192u) + (n == 0); }
+
+static hipError_t sort_pairs(uint32_t* k_in, uint32_t* k_out, uint32_t* v_in, uint32_t* v_out, uint32_t n, unsigned bits, hipStream_t s) {
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, bits, s));
+  void* tmp = nullptr;
+  HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0u, bits, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  return e != hipSuccess ? e : e2;
+}
+
+static unsigned bits_for(uint32_t ncells) {
+  unsigned b = 1;
+  while (b < 32 && (1ull << b) < (unsigned long long)ncells) ++b;
+  return b;
+}
+
+static void set_dims(GridDev& g, const float lo[3], const float hi[3], double cell) {
+  const int MAXD = 2048;
+  const double MAXCELLS = 67108864.0;  // 2^26
+  double ext[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
+  double maxext = std::max(ext[0], std::max(ext[1], ext[2]));
+  if (!(maxext > 0.0) || !std::isfinite(maxext)) maxext = 1.0;
+  if (!(cell > 0.0) || !std::isfinite(cell)) cell = maxext;
+  cell = std::max(cell, maxext / (MAXD - 1));
+  for (;;) {
+    double nxd = std::floor(ext[0] / cell) + 1, nyd = std::floor(ext[1] / cell) + 1, nzd = std::floor(ext[2] / cell) + 1;
+    if (nxd * nyd * nzd <= MAXCELLS && nxd <= MAXD && nyd <= MAXD && nzd <= MAXD) {
+      g.nx = (int)nxd; g.ny = (int)nyd; g.nz = (int)nzd;
+      break;
+    }
+    cell *= 1.1;
+  }
+  g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+  g.cell = (float)cell;
+  g.inv_cell = 1.0f / g.cell;
+  g.margin = g.cell * (1.0f / 512.0f);
+}
+
+hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStream_t s, GridBuildResult* out, double mean_out[3]) {
+  GridDev g{};
+  g.n = n; g.pts = nullptr; g.nrm = nullptr; g.cell_start = nullptr;
+  out->avg_occupancy = 0.0;
+  if (n == 0) {
+    // empty target: 1 empty cell; every search returns "none" (kd_tree_utilities.hpp:16-19)
+    const float z3[3] = {0, 0, 0};
+    set_dims(g, z3, z3, 1.0);
+    uint32_t* cs = nullptr;
+    HIP_TRY(hipMalloc(&cs, 2 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(cs, 0, 2 * sizeof(uint32_t), s));
+    float4* dummy = nullptr;
+    HIP_TRY(hipMalloc(&dummy, sizeof(float4)));
+    g.cell_start = cs; g.pts = dummy;
+    out->grid = g; out->n_cells = 1;
+    mean_out[0] = mean_out[1] = mean_out[2] = 0.0;
+    return hipSuccess;
+  }
+  float lo[3], hi[3];
+  HIP_TRY(bbox_mean(d_xyz, n, s, lo, hi, mean_out));
+  double ext[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
+  const double maxext = std::max(ext[0], std::max(ext[1], ext[2]));
+  // volume with degenerate extents floored so planar / linear clouds still get a sane first guess
+  double vol = 1.0;
+  for (int c = 0; c < 3; ++c) vol *= std::max(ext[c], maxext * 1e-3);
+  const double TARGET = 4.0;  // points per cell for a volumetric cloud
+  double cell = std::cbrt(vol * TARGET / (double)n);
+
+  uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr, *cs = nullptr;
+  double* d_occ = nullptr;
+  HIP_TRY(hipMalloc(&k_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&k_out, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&v_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&v_out, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&d_occ, sizeof(double)));
+  double occ = 0.0;
+  size_t ncells = 0;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    set_dims(g, lo, hi, cell);
+    ncells = (size_t)g.nx * g.ny * g.nz;
+    if (cs) { (void)hipFree(cs); cs = nullptr; }
+    HIP_TRY(hipMalloc(&cs, (ncells + 1) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_cell_keys, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, k_in, v_in);
+    HIP_TRY(sort_pairs(k_in, k_out, v_in, v_out, n, bits_for((uint32_t)ncells), s));
+    hipLaunchKernelGGL(k_cell_start, dim3(grid_blocks(n + 1)), dim3(256), 0, s, k_out, n, (uint32_t)ncells, cs);
+    HIP_TRY(hipMemsetAsync(d_occ, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_occupancy, dim3(grid_blocks((uint32_t)ncells)), dim3(256), 0, s, cs, (uint32_t)ncells, d_occ);
+    HIP_TRY(hipMemcpyAsync(&occ, d_occ, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    occ /= (double)n;
+    // adaptive refinement for surface-like / clustered clouds: too many candidates per cell -> shrink
+    if (occ <= 12.0) break;
+    const double shrink = std::min(0.85, std::max(0.3, std::pow(8.0 / occ, 1.0 / 2.5)));
+    const double new_cell = (double)g.cell * shrink;
+    GridDev probe = g;
+    set_dims(probe, lo, hi, new_cell);
+    if (probe.cell >= g.cell * 0.97f) break;  // dims / cell-count caps reached: keep the current grid
+    cell = new_cell;
+  }
+  float4 *pts = nullptr, *nrm = nullptr;
+  HIP_TRY(hipMalloc(&pts, (size_t)n * sizeof(float4)));
+  if (d_nrm) HIP_TRY(hipMalloc(&nrm, (size_t)n * sizeof(float4)));
+  hipLaunchKernelGGL(k_gather, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, d_nrm, v_out, n, pts, nrm);
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in); (void)hipFree(v_out); (void)hipFree(d_occ);
+  g.pts = pts; g.nrm = nrm; g.cell_start = cs;
+  out->grid = g; out->avg_occupancy = occ; out->n_cells = ncells;
+  return hipSuccess;
+}
+
+void free_grid(GridDev& g) {
+  if (g.pts) (void)hipFree((void*)g.pts);
+  if (g.nrm) (void)hipFree((void*)g.nrm);
+  if (g.cell_start) (void)hipFree((void*)g.cell_start);
+  g.pts = nullptr; g.nrm = nullptr; g.cell_start = nullptr;
+}
+
+hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr;
+  HIP_TRY(hipMalloc(&k_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&k_out, (size_t)n * 4));
+  HIP_TRY(hipMalloc(&v_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&v_out, (size_t)n * 4));
+  Tf tf;
+  for (int i = 0; i < 16; ++i) tf.m[i] = T[i];
+  hipLaunchKernelGGL(k_cell_keys_tf, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, tf, k_in, v_in);
+  const size_t ncells = (size_t)g.nx * g.ny * g.nz;
+  hipError_t e = sort_pairs(k_in, k_out, v_in, v_out, n, bits_for((uint32_t)ncells), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_gather, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, (const float*)nullptr, v_out, n, d_out, (float4*)nullptr);
+    e = hipStreamSynchronize(s);
+  }
+  (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in); (void)hipFree(v_out);
+  return e;
+}
+
+}  // namespace cilhip

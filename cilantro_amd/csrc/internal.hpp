@@ -1,0 +1,103 @@
+// internal.hpp -- shared declarations of libcilantro_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "solve.hpp"
+
+namespace cilhip {
+
+constexpr uint32_t NONE_U32 = 0xFFFFFFFFu;
+
+// Uniform grid over the target cloud (the structure that replaces the nanoflann kd-tree).
+// Target points are stored sorted by linear cell id (x fastest) as 16-byte records
+// {x, y, z, bitcast(original index)} so one global_load_dwordx4 fetches a candidate and a run of
+// cells along x is one contiguous range.
+struct GridDev {
+  float ox, oy, oz;            // origin = bbox min
+  float cell, inv_cell;        // cell edge and its reciprocal
+  float margin;                // geometric safety margin for the pruning bounds (cell * 2^-9)
+  int nx, ny, nz;
+  uint32_t n;                  // number of target points
+  const float4* pts;           // [n]  sorted {x,y,z,orig_idx}
+  const float4* nrm;           // [n]  sorted {nx,ny,nz,0} or nullptr
+  const uint32_t* cell_start;  // [nx*ny*nz + 1]
+};
+
+// Device-resident ICP loop state: lets every iteration be enqueued without a host round trip.
+struct IcpState {
+  float T[16];        // transform_ (col-major)
+  float smt[3];       // transform_ * src_mean_   (icp_single_transform_combined_metric.hpp:196)
+  float delta;        // last_delta_norm_
+  float innerL[9];    // Gauss-Newton inner tform (row-major), identity at step 0
+  float innert[3];
+  int iterations;     // iterations_
+  int done;           // last_delta_norm_ < convergence_tol_ reached
+  int inner_done;     // inner GN loop converged (transform_estimation.hpp:360)
+  int pad0;
+  unsigned long long ncorr;
+  double dLd[9];      // f64 copies of the inner tform (the f32 ones feed the kernels)
+  double dtd[3];
+  double sums[SUMS_MAX];  // reduced sums of the last accumulation
+};
+
+enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4 };
+
+struct IterArgs {
+  GridDev grid;
+  const float4* src;       // [ns] source sorted by target-grid cell {x,y,z,orig_idx}
+  uint32_t ns;
+  float max_sq;            // engine max_distance_ (squared)
+  float dst_mean[3];
+  const IcpState* state;   // T, smt, inner tform, done flags
+  uint32_t* nn_pos;        // [ns] (sorted-source order) sorted-target position or NONE
+  float* nn_d2;            // [ns]
+  double* partials;        // [nblocks * SUMS_MAX]
+  int skip_if_inner_done;
+};
+
+struct SolveArgs {
+  IcpState* state;
+  const double* partials;
+  int nblocks;             // 0: sums already reduced in `reduced`
+  const double* reduced;   // [SUMS_MAX] (multi-GPU: all-reduced buffer)
+  int metric;              // IterMetric
+  float w_p2p, w_p2pl;
+  float conv_tol, opt_conv_tol;
+  float dst_mean[3], src_mean[3];
+  int gn_last_step;        // finalize the outer iteration after this GN step
+  int has_normals;
+};
+
+// kernels.hip
+void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
+void launch_solve(const SolveArgs& a, hipStream_t s);
+void launch_reduce_partials(const double* partials, int nblocks, double* out, hipStream_t s);
+void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s);
+void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
+                       const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,
+                       hipStream_t s);
+void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
+void launch_residuals(const IterArgs& a, int metric, float w_p2p, float w_p2pl, float* out, hipStream_t s);
+int iter_num_blocks(uint32_t ns);
+
+// grid_build.hip
+struct GridBuildResult {
+  GridDev grid;
+  double avg_occupancy;
+  size_t n_cells;
+};
+// Builds the grid for n points (device xyz, optional device normals).  Allocates the sorted
+// arrays and the cell table (freed by free_grid).  Returns hipSuccess or an error.
+hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStream_t s,
+                      GridBuildResult* out, double mean_out[3]);
+void free_grid(GridDev& g);
+// Sorts the source by the target-grid cell of T*s; writes {x,y,z,orig} records.  d_out preallocated [n].
+hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out,
+                       hipStream_t s);
+hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3]);
+
+}  // namespace cilhip

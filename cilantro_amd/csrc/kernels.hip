@@ -1,0 +1,508 @@
+// kernels.hip -- the per-iteration hot path of rigid ICP as hand-written HIP for gfx950 (CDNA4).
+//
+// One fused kernel per ICP iteration replaces four OpenMP loops of the reference:
+//   q_i = T*s_i                         correspondence_search/common_transformable_feature_adaptors.hpp:28-33
+//   1-NN of q_i in dst within r^2       correspondence_search/correspondence_search_kd_tree_utilities.hpp:26-33
+//                                       (nanoflann searchLevel, 3rd_party/nanoflann/nanoflann.hpp:1885-1961)
+//   second transform of src             core/space_transformations.hpp:203-216   (eliminated: q stays in registers)
+//   normal-equation / moment sums       registration/transform_estimation.hpp:25-34, :298-320, :328-343
+// followed by a one-block epilogue kernel that reduces the per-block partial sums in a fixed order
+// and performs the 3x3 SVD / 6x6 LDL^T solve + compose on the device (solve.hpp), so all
+// iterations of IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) can be
+// enqueued back-to-back with no host round trip.
+//
+// Design notes (MI355X):
+//   * HBM/L2-bound gather workload, no MFMA: K=3 contraction, and the -2q.p+|p|^2 form would change the
+//     rounding of d2 and break index parity with the reference.
+//   * wave64: one query per lane; queries are pre-sorted by target-grid cell so the 64 lanes of a
+//     wave walk the same few cell runs (loads coalesce / broadcast in the TA, hit L1/L2).
+//   * blockIdx -> work mapping is XCD-aware: hardware places block b on XCD b%8, so virtual block
+//     (b%8)*(nb/8)+b/8 gives every XCD one contiguous eighth of the (spatially sorted) queries and
+//     each private 4 MiB L2 caches one slab of the target instead of all of it.
+//   * f64 accumulators live in registers across a contiguous chunk of queries per lane; one wave64
+//     shuffle tree + LDS + fixed-order cross-block reduction => bitwise run-to-run reproducible
+//     (the reference's OpenMP reduction is not).
+#include "internal.hpp"
+
+namespace cilhip {
+
+#define KSHRINK 0.99999905f /* 1 - 2^-20: covers the <= 2^-22 relative rounding of the f32 d2 */
+
+// d2 exactly as nanoflann's L2_Adaptor::evalMetric computes it for DIM=3
+// (nanoflann.hpp:570-604: only the tail loop runs): ((dx*dx)+(dy*dy))+(dz*dz), dx = q.x - p.x,
+// every operation individually rounded (no FMA contraction).
+__device__ __forceinline__ float d2_pinned(float qx, float qy, float qz, float px, float py, float pz) {
+  const float dx = __fsub_rn(qx, px), dy = __fsub_rn(qy, py), dz = __fsub_rn(qz, pz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+struct NN {
+  unsigned long long key;  // (bits(d2) << 32) | original target index : strict '<' + lowest-index tie-break
+  uint32_t pos;            // position in the sorted target array, NONE_U32 if nothing within the radius
+};
+
+__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, uint32_t beg, uint32_t end,
+                                           float qx, float qy, float qz, NN& best) {
+  for (uint32_t j = beg; j < end; ++j) {
+    const float4 p = pts[j];
+    const float d2 = d2_pinned(qx, qy, qz, p.x, p.y, p.z);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p.w);
+    if (key < best.key) { best.key = key; best.pos = j; }
+  }
+}
+
+// distance from q to the interval [lo,hi], shrunk by the grid margin (never over-estimates)
+__device__ __forceinline__ float axis_gap(float q, float lo, float hi, float margin) {
+  return fmaxf(fmaxf(lo - q, q - hi) - margin, 0.0f);
+}
+
+// Exact 1-NN in radius over the uniform grid: expanding Chebyshev shells around the query's cell,
+// each shell scanned as runs of cells along x (contiguous in memory), with conservative box-distance
+// pruning.  Result == brute-force argmin of the pinned f32 d2 with lowest-index tie-break, restricted
+// to d2 < max_sq (strict, as nanoflann.hpp:1901 and kd_tree_utilities.hpp:29).
+__device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best) {
+  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  best.pos = NONE_U32;
+  const float BIG = 1.0e9f;
+  const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
+  const float fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG);
+  const float fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  {  // query farther than the radius from the whole grid: nothing to find
+    const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
+    const float gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
+    const float gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+    if ((gx * gx + gy * gy + gz * gz) * KSHRINK >= max_sq) return;
+  }
+  int s = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+  for (;; ++s) {
+    const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1);
+    const int y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+    const int xlo = cx - s, xhi = cx + s;
+    for (int z = z0; z <= z1; ++z) {
+      const bool zface = (z == cz - s) || (z == cz + s);
+      const float zl = g.oz + (float)z * g.cell;
+      const float gz = axis_gap(qz, zl, zl + g.cell, g.margin);
+      const float gz2 = gz * gz;
+      if (gz2 * KSHRINK > __uint_as_float((uint32_t)(best.key >> 32))) continue;
+      for (int y = y0; y <= y1; ++y) {
+        const bool face = zface || (y == cy - s) || (y == cy + s);
+        const float yl = g.oy + (float)y * g.cell;
+        const float gy = axis_gap(qy, yl, yl + g.cell, g.margin);
+        const float gyz2 = gz2 + gy * gy;
+        const float bd = __uint_as_float((uint32_t)(best.key >> 32));
+        if (gyz2 * KSHRINK > bd) continue;
+        const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+        if (face) {
+          const int xa = max(xlo, 0), xb = min(xhi, g.nx - 1);
+          if (xa <= xb) {
+            const float gx = axis_gap(qx, g.ox + (float)xa * g.cell, g.ox + (float)(xb + 1) * g.cell, g.margin);
+            if ((gyz2 + gx * gx) * KSHRINK <= bd)
+              scan_range(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
+          }
+        } else {
+          if (xlo >= 0 && xlo < g.nx) {
+            const float xl = g.ox + (float)xlo * g.cell;
+            const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
+            if ((gyz2 + gx * gx) * KSHRINK <= bd)
+              scan_range(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, best);
+          }
+          if (xhi >= 0 && xhi < g.nx) {
+            const float xl = g.ox + (float)xhi * g.cell;
+            const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
+            if ((gyz2 + gx * gx) * KSHRINK <= __uint_as_float((uint32_t)(best.key >> 32)))
+              scan_range(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, best);
+          }
+        }
+      }
+    }
+    // lower bound on the distance to anything not yet scanned (outside the (2s+1)^3 block, inside the grid)
+    float b = INFINITY;
+    if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+    if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+    if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+    if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+    if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+    if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+    if (b == INFINITY) break;  // block covers the grid: everything scanned
+    b -= g.margin;
+    if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) break;
+  }
+}
+
+// ---- accumulation helpers ------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+constexpr int ITER_THREADS = 256;
+constexpr int ITER_WAVES = ITER_THREADS / 64;
+
+template <int METRIC>
+struct AccTraits {
+  static constexpr bool plane = (METRIC == IM_PLANE || METRIC == IM_BOTH);
+  static constexpr bool point = (METRIC == IM_POINT || METRIC == IM_BOTH);
+  static constexpr bool kabsch = (METRIC == IM_KABSCH);
+  static constexpr int NA = kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
+  static constexpr int NB = point ? 15 : 0;                  // slots [28, 28+NB)
+};
+
+// The fused iteration kernel.  METRIC: what to accumulate; SEARCH: run the grid search (else reuse the
+// stored matches: Gauss-Newton steps >= 1); STORE: keep (pos,d2) per query for later steps / the host.
+template <int METRIC, bool SEARCH, bool STORE>
+__global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
+  using TR = AccTraits<METRIC>;
+  const IcpState* __restrict__ st = a.state;
+  if (st->done) return;
+  if (a.skip_if_inner_done && st->inner_done) return;
+
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = st->T[i];
+  float iL[9], it[3], smt[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) iL[i] = st->innerL[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { it[i] = st->innert[i]; smt[i] = st->smt[i]; }
+
+  double accA[TR::NA];
+  double accB[TR::NB > 0 ? TR::NB : 1];
+#pragma unroll
+  for (int i = 0; i < TR::NA; ++i) accA[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < (TR::NB > 0 ? TR::NB : 1); ++i) accB[i] = 0.0;
+
+  // XCD-aware virtual block id (gridDim.x is a multiple of 8)
+  const uint32_t nb = gridDim.x;
+  const uint32_t vb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+  const uint32_t chunk = (((a.ns + nb - 1) / nb) + 63u) & ~63u;
+  const uint64_t beg64 = (uint64_t)vb * chunk;
+  const uint32_t beg = beg64 < a.ns ? (uint32_t)beg64 : a.ns;
+  const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
+
+  for (uint32_t i = beg + threadIdx.x; i < end; i += ITER_THREADS) {
+    const float4 s4 = a.src[i];
+    float qx, qy, qz;
+    transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+    uint32_t pos;
+    if (SEARCH) {
+      NN best;
+      nn_search(a.grid, qx, qy, qz, a.max_sq, best);
+      pos = best.pos;
+      if (STORE) { a.nn_pos[i] = pos; a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
+    } else {
+      pos = a.nn_pos[i];
+    }
+    if (METRIC != IM_NONE && pos != NONE_U32) {
+      const float4 p = a.grid.pts[pos];
+      if (TR::kabsch) {
+        // raw moments for the closed-form estimator (transform_estimation.hpp:25-34)
+        const double pd[3] = {(double)p.x, (double)p.y, (double)p.z};
+        const double qd[3] = {(double)qx, (double)qy, (double)qz};
+        accA[0] += 1.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { accA[1 + c] += pd[c]; accA[4 + c] += qd[c]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) accA[7 + r * 3 + c] = fma(pd[r], qd[c], accA[7 + r * 3 + c]);
+      } else {
+        // per-term quantities in f32 exactly as the reference forms them (transform_estimation.hpp:302-304,:333-335)
+        const float d0 = __fsub_rn(p.x, a.dst_mean[0]), d1 = __fsub_rn(p.y, a.dst_mean[1]), d2 = __fsub_rn(p.z, a.dst_mean[2]);
+        const float u0 = __fsub_rn(qx, smt[0]), u1 = __fsub_rn(qy, smt[1]), u2 = __fsub_rn(qz, smt[2]);
+        // s = inner_tform * (q - T*src_mean); identity on the first Gauss-Newton step
+        const float s0 = __fadd_rn(__fadd_rn(__fmul_rn(iL[0], u0), __fadd_rn(__fmul_rn(iL[1], u1), __fmul_rn(iL[2], u2))), it[0]);
+        const float s1 = __fadd_rn(__fadd_rn(__fmul_rn(iL[3], u0), __fadd_rn(__fmul_rn(iL[4], u1), __fmul_rn(iL[5], u2))), it[1]);
+        const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(iL[6], u0), __fadd_rn(__fmul_rn(iL[7], u1), __fmul_rn(iL[8], u2))), it[2]);
+        const float a0 = __fadd_rn(d0, s0), a1 = __fadd_rn(d1, s1), a2 = __fadd_rn(d2, s2);
+        const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
+        accA[0] += 1.0;
+        if (TR::plane) {
+          const float4 nv = a.grid.nrm[pos];
+          float e[6];
+          e[0] = __fsub_rn(__fmul_rn(a1, nv.z), __fmul_rn(a2, nv.y));   // (d+s).cross(n)  :337
+          e[1] = __fsub_rn(__fmul_rn(a2, nv.x), __fmul_rn(a0, nv.z));
+          e[2] = __fsub_rn(__fmul_rn(a0, nv.y), __fmul_rn(a1, nv.x));
+          e[3] = nv.x; e[4] = nv.y; e[5] = nv.z;
+          const float res = __fadd_rn(__fmul_rn(nv.x, r0), __fadd_rn(__fmul_rn(nv.y, r1), __fmul_rn(nv.z, r2)));  // n.dot(d-s)
+          double ed[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ed[k] = (double)e[k];
+          int k = 1;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) { accA[k] = fma(ed[r], ed[c], accA[k]); ++k; }
+          const double rd = (double)res;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) accA[22 + r] = fma(rd, ed[r], accA[22 + r]);
+        }
+        if (TR::point) {
+          const double ad[3] = {(double)a0, (double)a1, (double)a2};
+          const double rd[3] = {(double)r0, (double)r1, (double)r2};
+          accB[0] += ad[0]; accB[1] += ad[1]; accB[2] += ad[2];
+          accB[3] = fma(ad[0], ad[0], accB[3]); accB[4] = fma(ad[0], ad[1], accB[4]); accB[5] = fma(ad[0], ad[2], accB[5]);
+          accB[6] = fma(ad[1], ad[1], accB[6]); accB[7] = fma(ad[1], ad[2], accB[7]); accB[8] = fma(ad[2], ad[2], accB[8]);
+          accB[9] += ad[1] * rd[2] - ad[2] * rd[1];
+          accB[10] += ad[2] * rd[0] - ad[0] * rd[2];
+          accB[11] += ad[0] * rd[1] - ad[1] * rd[0];
+          accB[12] += rd[0]; accB[13] += rd[1]; accB[14] += rd[2];
+        }
+      }
+    }
+  }
+
+  if (METRIC != IM_NONE) {
+    __shared__ double sh[ITER_WAVES][SUMS_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < SUMS_MAX) {
+#pragma unroll
+      for (int w = 0; w < ITER_WAVES; ++w) sh[w][threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TR::NA; ++k) {
+      const double v = wave_sum(accA[k]);
+      if (lane == 0) sh[wave][k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < TR::NB; ++k) {
+      const double v = wave_sum(accB[k]);
+      if (lane == 0) sh[wave][28 + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < SUMS_MAX)
+      a.partials[(size_t)vb * SUMS_MAX + threadIdx.x] =
+          (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  }
+}
+
+int iter_num_blocks(uint32_t ns) {
+  // >= 8 blocks per CU on 256 CUs when there is enough work; multiple of 8 for the XCD mapping;
+  // at least one wave of work per block.
+  long want = ((long)ns + 255) / 256;
+  long nb = want < 2048 ? want : 2048;
+  nb = (nb + 7) & ~7L;
+  if (nb < 8) nb = 8;
+  return (int)nb;
+}
+
+template <int METRIC>
+static void launch_iter_m(const IterArgs& a, bool search, bool store, int nblocks, hipStream_t s) {
+  dim3 g(nblocks), b(ITER_THREADS);
+  if (search && store) hipLaunchKernelGGL((k_iter<METRIC, true, true>), g, b, 0, s, a);
+  else if (search) hipLaunchKernelGGL((k_iter<METRIC, true, false>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_iter<METRIC, false, false>), g, b, 0, s, a);
+}
+
+void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s) {
+  switch (metric) {
+    case IM_NONE: launch_iter_m<IM_NONE>(a, search, store, nblocks, s); break;
+    case IM_KABSCH: launch_iter_m<IM_KABSCH>(a, search, store, nblocks, s); break;
+    case IM_PLANE: launch_iter_m<IM_PLANE>(a, search, store, nblocks, s); break;
+    case IM_POINT: launch_iter_m<IM_POINT>(a, search, store, nblocks, s); break;
+    default: launch_iter_m<IM_BOTH>(a, search, store, nblocks, s); break;
+  }
+}
+
+// ---- epilogue: fixed-order reduction of block partials + solve + state update --------------------
+__device__ void reduce_partials_block(const double* __restrict__ partials, int nblocks, double* sums /*shared*/) {
+  __shared__ double sh[4][64];
+  const int slot = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  double v = 0.0;
+  if (slot < SUMS_MAX)
+    for (int b = grp; b < nblocks; b += 4) v += partials[(size_t)b * SUMS_MAX + slot];
+  sh[grp][slot] = v;
+  __syncthreads();
+  if (threadIdx.x < SUMS_MAX)
+    sums[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* partials, int nblocks, double* out) {
+  __shared__ double sums[SUMS_MAX];
+  reduce_partials_block(partials, nblocks, sums);
+  if (threadIdx.x < SUMS_MAX) out[threadIdx.x] = sums[threadIdx.x];
+}
+
+void launch_reduce_partials(const double* partials, int nblocks, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, partials, nblocks, out);
+}
+
+__device__ void reset_inner(IcpState* st) {
+  for (int i = 0; i < 9; ++i) { st->dLd[i] = (i % 4 == 0) ? 1.0 : 0.0; st->innerL[i] = (i % 4 == 0) ? 1.0f : 0.0f; }
+  for (int i = 0; i < 3; ++i) { st->dtd[i] = 0.0; st->innert[i] = 0.0f; }
+  st->inner_done = 0;
+  st->pad0 = 0;
+}
+
+__global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
+  __shared__ double sums[SUMS_MAX];
+  IcpState* st = a.state;
+  if (st->done) return;
+  if (a.nblocks > 0) {
+    reduce_partials_block(a.partials, a.nblocks, sums);
+  } else {
+    if (threadIdx.x < SUMS_MAX) sums[threadIdx.x] = a.reduced[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+
+  const double n = sums[0];
+  double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+  bool finalize = false;
+  if (a.metric == IM_KABSCH) {
+    for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = sums[i];
+    kabsch_from_sums(sums, L, t);
+    finalize = true;
+  } else {
+    // transform_estimation.hpp:264-272: no usable terms => tform stays identity, return false
+    const bool has_p2p = (n > 0.0) && (a.w_p2p > 0.0f);
+    const bool has_p2pl = (n > 0.0) && (a.w_p2pl > 0.0f);
+    if (!st->inner_done) {
+      if ((!has_p2p && !has_p2pl) || (has_p2pl && !a.has_normals)) {
+        st->pad0 = 1;  // identity step
+        st->inner_done = 1;
+        for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = sums[i];
+      } else {
+        if (st->pad0 == 0 && st->dLd[0] == 1.0 && st->dtd[0] == 0.0 && st->dLd[4] == 1.0) {
+          // keep the first Gauss-Newton step's sums for inspection (AtA/Atb of the host API)
+        }
+        double AtA[36], Atb[6], dth[6];
+        gn_normal_equations(sums, has_p2p ? (double)a.w_p2p : 0.0, has_p2pl ? (double)a.w_p2pl : 0.0, AtA, Atb);
+        ldlt6_solve(AtA, Atb, dth);
+        rigid_gn_update(dth, st->dLd, st->dtd);
+        for (int i = 0; i < 9; ++i) st->innerL[i] = (float)st->dLd[i];
+        for (int i = 0; i < 3; ++i) st->innert[i] = (float)st->dtd[i];
+        double nrm = 0.0;
+        for (int i = 0; i < 6; ++i) nrm += dth[i] * dth[i];
+        if (sqrt(nrm) < (double)a.opt_conv_tol) st->inner_done = 1;     // :360
+        for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = sums[i];
+      }
+    }
+    if (a.gn_last_step) {
+      if (st->pad0 == 0) {
+        for (int i = 0; i < 9; ++i) L[i] = st->dLd[i];
+        // tform = t_dst * tform * t_src, t_src = Translation(-(transform_*src_mean_))   :361/:365
+        for (int r = 0; r < 3; ++r)
+          t[r] = st->dtd[r] - (L[r * 3] * (double)st->smt[0] + L[r * 3 + 1] * (double)st->smt[1] + L[r * 3 + 2] * (double)st->smt[2]) +
+                 (double)a.dst_mean[r];
+      }
+      finalize = true;
+    }
+  }
+  if (finalize) {
+    float Tn[16];
+    const float delta = compose_update(L, t, st->T, Tn);
+    for (int i = 0; i < 16; ++i) st->T[i] = Tn[i];
+    float mx, my, mz;
+    transform_point(Tn, a.src_mean[0], a.src_mean[1], a.src_mean[2], mx, my, mz);
+    st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
+    st->delta = delta;
+    st->iterations += 1;
+    st->ncorr = (unsigned long long)(n + 0.5);
+    st->done = (delta < a.conv_tol) ? 1 : 0;                            // icp_base.hpp:83
+    reset_inner(st);
+  }
+}
+
+void launch_solve(const SolveArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, a);
+}
+
+struct InitArgs { float T[16]; float src_mean[3]; };
+
+__global__ void k_init_state(IcpState* st, InitArgs ia) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; ++i) st->T[i] = ia.T[i];
+  float mx, my, mz;
+  transform_point(ia.T, ia.src_mean[0], ia.src_mean[1], ia.src_mean[2], mx, my, mz);
+  st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
+  st->delta = INFINITY;
+  st->iterations = 0;
+  st->done = 0;
+  st->ncorr = 0;
+  for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = 0.0;
+  reset_inner(st);
+}
+
+void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s) {
+  InitArgs ia;
+  for (int i = 0; i < 16; ++i) ia.T[i] = T0[i];
+  for (int i = 0; i < 3; ++i) ia.src_mean[i] = src_mean[i];
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, st, ia);
+}
+
+// ---- result extraction ----------------------------------------------------------------------------
+__global__ void k_scatter_nn(const float4* __restrict__ src_sorted, const float4* __restrict__ dst_sorted,
+                             const uint32_t* __restrict__ nn_pos, const float* __restrict__ nn_d2, uint32_t ns,
+                             uint32_t* out_idx, float* out_d2) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t orig = __float_as_uint(src_sorted[i].w);
+    const uint32_t pos = nn_pos[i];
+    if (out_idx) out_idx[orig] = (pos == NONE_U32) ? NONE_U32 : __float_as_uint(dst_sorted[pos].w);
+    if (out_d2) out_d2[orig] = nn_d2[i];
+  }
+}
+
+void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
+                       const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2, hipStream_t s) {
+  if (ns == 0) return;
+  const int nb = (int)((ns + 255) / 256 < 4096 ? (ns + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_scatter_nn, dim3(nb), dim3(256), 0, s, src_sorted, dst_sorted, nn_pos, nn_d2, ns, out_idx, out_d2);
+}
+
+__global__ void k_count_found(const uint32_t* __restrict__ nn_pos, uint32_t ns, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x)
+    c += (nn_pos[i] != NONE_U32) ? 1ull : 0ull;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s) {
+  (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+  if (ns == 0) return;
+  const int nb = (int)((ns + 255) / 256 < 2048 ? (ns + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_count_found, dim3(nb), dim3(256), 0, s, nn_pos, ns, out);
+}
+
+// computeResiduals() of both ICP classes (icp_single_transform_combined_metric.hpp:220-243,
+// icp_single_transform_point_to_point_metric.hpp:68-85): unbounded exact 1-NN, then the metric value.
+__global__ __launch_bounds__(256) void k_residuals(IterArgs a, int metric, float w_p2p, float w_p2pl, float* out) {
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = a.state->T[i];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.ns; i += gridDim.x * blockDim.x) {
+    const float4 s4 = a.src[i];
+    float qx, qy, qz;
+    transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+    NN best;
+    nn_search(a.grid, qx, qy, qz, a.max_sq, best);
+    float v = __uint_as_float(0x7fc00000u);  // NaN when the target is empty (:221-224)
+    if (best.pos != NONE_U32) {
+      const float4 p = a.grid.pts[best.pos];
+      const float dx = __fsub_rn(p.x, qx), dy = __fsub_rn(p.y, qy), dz = __fsub_rn(p.z, qz);
+      const float sq = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));  // squaredNorm()
+      if (metric == 0) {
+        v = sq;
+      } else {
+        const float4 nv = a.grid.nrm[best.pos];
+        const float pd = __fadd_rn(__fmul_rn(nv.x, dx), __fadd_rn(__fmul_rn(nv.y, dy), __fmul_rn(nv.z, dz)));
+        v = __fadd_rn(__fmul_rn(w_p2p, sq), __fmul_rn(__fmul_rn(w_p2pl, pd), pd));
+      }
+    }
+    out[__float_as_uint(s4.w)] = v;
+  }
+}
+
+void launch_residuals(const IterArgs& a, int metric, float w_p2p, float w_p2pl, float* out, hipStream_t s) {
+  if (a.ns == 0) return;
+  const int nb = iter_num_blocks(a.ns);
+  hipLaunchKernelGGL(k_residuals, dim3(nb), dim3(256), 0, s, a, metric, w_p2p, w_p2pl, out);
+}
+
+}  // namespace cilhip

@@ -1,0 +1,297 @@
+// solve.hpp -- the tiny dense solves of one ICP iteration, shared by the host API and the
+// single-lane device epilogue (so the fused loop never round-trips to the host).
+//
+// Replaces (all f64 here; the reference does them in f32 through Eigen3):
+//   * Eigen::JacobiSVD<Matrix3f>         registration/transform_estimation.hpp:36-44
+//                                        core/space_transformations.hpp:43-51 (rotation())
+//   * Eigen::LDLT<Matrix6f>::solve       registration/transform_estimation.hpp:346
+//   * AngleAxis / Translation update     registration/transform_estimation.hpp:349-357,361/365
+//   * compose + delta norm               registration/icp_single_transform_combined_metric.hpp:207-216
+//                                        registration/icp_single_transform_point_to_point_metric.hpp:56-64
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace cilhip {
+
+#define CILHIP_HD __host__ __device__ __forceinline__
+
+// Layout of the raw f64 sums produced by the accumulation kernels (one slot per value).
+//   Kabsch (point-to-point ICP class):  [0]=n, [1..3]=sum p, [4..6]=sum q, [7..15]=sum p q^T (row-major)
+//   Gauss-Newton (combined metric class), plane part: [0]=n, [1..21]=upper triangle of sum e e^T
+//     (row-major: 00 01 02 03 04 05 11 12 ... 55), [22..27]=sum (n.(d-s)) e
+//   Gauss-Newton, point part (only when w_p2p>0): [28..30]=sum a, [31..36]=sum a a^T upper
+//     (00 01 02 11 12 22), [37..39]=sum a x r, [40..42]=sum r          with a=d+s, r=d-s
+constexpr int SUMS_KABSCH = 16;
+constexpr int SUMS_PLANE = 28;
+constexpr int SUMS_GN_FULL = 43;
+constexpr int SUMS_MAX = 48;  // padded slot count per block partial
+
+// ---- 3x3 two-sided Jacobi SVD (row-major), S >= 0 sorted descending --------------------------
+CILHIP_HD void svd3(const double Ain[9], double U[9], double S[3], double V[9]) {
+  double W[9];
+  for (int i = 0; i < 9; ++i) { W[i] = Ain[i]; U[i] = V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  double scale = 0.0;
+  for (int i = 0; i < 9; ++i) scale = fmax(scale, fabs(W[i]));
+  if (scale == 0.0) { S[0] = S[1] = S[2] = 0.0; return; }
+  for (int i = 0; i < 9; ++i) W[i] /= scale;
+  const double precision = 2.0 * 2.220446049250313e-16;
+  const double tiny = 2.2250738585072014e-308;
+  double max_diag = fmax(fabs(W[0]), fmax(fabs(W[4]), fabs(W[8])));
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    bool finished = true;
+    for (int p = 1; p < 3; ++p) {
+      for (int q = 0; q < p; ++q) {
+        const double thr = fmax(tiny, precision * max_diag);
+        if (fabs(W[p * 3 + q]) > thr || fabs(W[q * 3 + p]) > thr) {
+          finished = false;
+          const double a = W[q * 3 + q], b = W[q * 3 + p], c = W[p * 3 + q], d = W[p * 3 + p];
+          double c1 = 1.0, s1 = 0.0;               // left rotation making the 2x2 block symmetric
+          {
+            const double t = a + d, dd = c - b;
+            if (fabs(dd) > tiny) { const double h = sqrt(t * t + dd * dd); c1 = t / h; s1 = dd / h; }
+          }
+          const double x = c1 * a + s1 * c, y = c1 * b + s1 * d, z = -s1 * b + c1 * d;
+          double cj = 1.0, sj = 0.0;               // symmetric Jacobi rotation
+          if (fabs(y) > tiny) {
+            const double tau = (z - x) / (2.0 * y);
+            const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            cj = 1.0 / sqrt(1.0 + tt * tt);
+            sj = tt * cj;
+          }
+          const double cl = cj * c1 + sj * s1, sl = cj * s1 - sj * c1;
+          for (int k = 0; k < 3; ++k) {
+            const double wq = W[q * 3 + k], wp = W[p * 3 + k];
+            W[q * 3 + k] = cl * wq + sl * wp;
+            W[p * 3 + k] = -sl * wq + cl * wp;
+          }
+          for (int k = 0; k < 3; ++k) {
+            const double uq = U[k * 3 + q], up = U[k * 3 + p];
+            U[k * 3 + q] = cl * uq + sl * up;
+            U[k * 3 + p] = -sl * uq + cl * up;
+          }
+          for (int k = 0; k < 3; ++k) {
+            const double wq = W[k * 3 + q], wp = W[k * 3 + p];
+            W[k * 3 + q] = cj * wq - sj * wp;
+            W[k * 3 + p] = sj * wq + cj * wp;
+            const double vq = V[k * 3 + q], vp = V[k * 3 + p];
+            V[k * 3 + q] = cj * vq - sj * vp;
+            V[k * 3 + p] = sj * vq + cj * vp;
+          }
+          max_diag = fmax(max_diag, fmax(fabs(W[p * 3 + p]), fabs(W[q * 3 + q])));
+        }
+      }
+    }
+    if (finished) break;
+  }
+  for (int i = 0; i < 3; ++i) {
+    double s = W[i * 3 + i];
+    if (s < 0.0) { s = -s; for (int k = 0; k < 3; ++k) U[k * 3 + i] = -U[k * 3 + i]; }
+    S[i] = s * scale;
+  }
+  for (int i = 0; i < 3; ++i) {
+    int m = i;
+    for (int j = i + 1; j < 3; ++j) if (S[j] > S[m]) m = j;
+    if (m != i) {
+      double ts = S[i]; S[i] = S[m]; S[m] = ts;
+      for (int k = 0; k < 3; ++k) {
+        double tu = U[k * 3 + i]; U[k * 3 + i] = U[k * 3 + m]; U[k * 3 + m] = tu;
+        double tv = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + m]; V[k * 3 + m] = tv;
+      }
+    }
+  }
+}
+
+CILHIP_HD double det3(const double M[9]) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+         M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// R = U V^T, negating column `flip_col` of U when det(U V) < 0
+// (flip_col 2: transform_estimation.hpp:38-41; flip_col 0: space_transformations.hpp:45-48).
+CILHIP_HD void uvt_fix(const double Uin[9], const double V[9], int flip_col, double R[9]) {
+  double U[9], UV[9];
+  for (int i = 0; i < 9; ++i) U[i] = Uin[i];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      UV[i * 3 + j] = U[i * 3] * V[j] + U[i * 3 + 1] * V[3 + j] + U[i * 3 + 2] * V[6 + j];
+  if (det3(UV) < 0.0)
+    for (int k = 0; k < 3; ++k) U[k * 3 + flip_col] = -U[k * 3 + flip_col];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      R[i * 3 + j] = U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1] + U[i * 3 + 2] * V[j * 3 + 2];
+}
+
+CILHIP_HD void nearest_rotation(const double L[9], double R[9]) {
+  double U[9], S[3], V[9];
+  svd3(L, U, S, V);
+  uvt_fix(U, V, 0, R);
+}
+
+// ---- 6x6 LDL^T, diagonal pivoting, pseudo-inverse of D (Eigen LDLT::solve semantics) ----------
+CILHIP_HD void ldlt6_solve(const double Ain[36], const double bin[6], double x[6]) {
+  double A[36];
+  int perm[6];
+  for (int i = 0; i < 36; ++i) A[i] = Ain[i];
+  for (int i = 0; i < 6; ++i) perm[i] = i;
+  const double tiny = 2.2250738585072014e-308;
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    double best = fabs(A[k * 6 + k]);
+    for (int i = k + 1; i < 6; ++i)
+      if (fabs(A[i * 6 + i]) > best) { best = fabs(A[i * 6 + i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < 6; ++j) { double t = A[k * 6 + j]; A[k * 6 + j] = A[piv * 6 + j]; A[piv * 6 + j] = t; }
+      for (int i = 0; i < 6; ++i) { double t = A[i * 6 + k]; A[i * 6 + k] = A[i * 6 + piv]; A[i * 6 + piv] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    const double dk = A[k * 6 + k];
+    if (fabs(dk) <= tiny) {
+      for (int i = k + 1; i < 6; ++i) A[i * 6 + k] = 0.0;
+      continue;
+    }
+    for (int i = k + 1; i < 6; ++i) A[i * 6 + k] /= dk;
+    for (int i = k + 1; i < 6; ++i)
+      for (int j = k + 1; j <= i; ++j) {
+        A[i * 6 + j] -= A[i * 6 + k] * dk * A[j * 6 + k];
+        A[j * 6 + i] = A[i * 6 + j];
+      }
+  }
+  double y[6];
+  for (int i = 0; i < 6; ++i) y[i] = bin[perm[i]];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < i; ++j) y[i] -= A[i * 6 + j] * y[j];
+  for (int i = 0; i < 6; ++i) {
+    const double d = A[i * 6 + i];
+    y[i] = (fabs(d) > tiny) ? y[i] / d : 0.0;
+  }
+  for (int i = 5; i >= 0; --i)
+    for (int j = i + 1; j < 6; ++j) y[i] -= A[j * 6 + i] * y[j];
+  for (int i = 0; i < 6; ++i) x[perm[i]] = y[i];
+}
+
+// tform = Ra * ta * Ra * tform  (transform_estimation.hpp:349-357); L row-major, in place.
+CILHIP_HD void rigid_gn_update(const double dth[6], double L[9], double t[3]) {
+  const double ax = dth[0], ay = dth[1], az = dth[2];
+  const double na = sqrt(ax * ax + ay * ay + az * az);
+  const double theta = atan(na);
+  double ux = 0.0, uy = 0.0, uz = 0.0;
+  if (na > 0.0) { ux = ax / na; uy = ay / na; uz = az / na; }
+  const double s = sin(theta), c = cos(theta);
+  const double sx = s * ux, sy = s * uy, sz = s * uz;
+  const double c1x = (1.0 - c) * ux, c1y = (1.0 - c) * uy, c1z = (1.0 - c) * uz;
+  double Ra[9], tmp;
+  tmp = c1x * uy; Ra[1] = tmp - sz; Ra[3] = tmp + sz;
+  tmp = c1x * uz; Ra[2] = tmp + sy; Ra[6] = tmp - sy;
+  tmp = c1y * uz; Ra[5] = tmp - sx; Ra[7] = tmp + sx;
+  Ra[0] = c1x * ux + c; Ra[4] = c1y * uy + c; Ra[8] = c1z * uz + c;
+  const double ta[3] = {c * dth[3], c * dth[4], c * dth[5]};
+  double L1[9], t1[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      L1[i * 3 + j] = Ra[i * 3] * L[j] + Ra[i * 3 + 1] * L[3 + j] + Ra[i * 3 + 2] * L[6 + j];
+    t1[i] = Ra[i * 3] * t[0] + Ra[i * 3 + 1] * t[1] + Ra[i * 3 + 2] * t[2] + ta[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      L[i * 3 + j] = Ra[i * 3] * L1[j] + Ra[i * 3 + 1] * L1[3 + j] + Ra[i * 3 + 2] * L1[6 + j];
+    t[i] = Ra[i * 3] * t1[0] + Ra[i * 3 + 1] * t1[1] + Ra[i * 3 + 2] * t1[2];
+  }
+}
+
+// Closed-form rigid point-to-point estimate from raw moments (transform_estimation.hpp:11-48).
+// sums: SUMS_KABSCH layout. Identity when n == 0 (:20-23).
+CILHIP_HD void kabsch_from_sums(const double* sums, double L[9], double t[3]) {
+  for (int i = 0; i < 9; ++i) L[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  t[0] = t[1] = t[2] = 0.0;
+  const double n = sums[0];
+  if (!(n > 0.0)) return;
+  double mud[3], mus[3], sig[9];
+  for (int c = 0; c < 3; ++c) { mud[c] = sums[1 + c] / n; mus[c] = sums[4 + c] / n; }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) sig[r * 3 + c] = sums[7 + r * 3 + c] / n - mud[r] * mus[c];
+  double U[9], S[3], V[9];
+  svd3(sig, U, S, V);
+  uvt_fix(U, V, 2, L);
+  for (int r = 0; r < 3; ++r) t[r] = mud[r] - (L[r * 3] * mus[0] + L[r * 3 + 1] * mus[1] + L[r * 3 + 2] * mus[2]);
+}
+
+// Normal equations of one Gauss-Newton step from the raw sums (transform_estimation.hpp:292-344).
+CILHIP_HD void gn_normal_equations(const double* sums, double w_p2p, double w_p2pl, double AtA[36],
+                                   double Atb[6]) {
+  for (int i = 0; i < 36; ++i) AtA[i] = 0.0;
+  for (int i = 0; i < 6; ++i) Atb[i] = 0.0;
+  if (w_p2pl > 0.0) {
+    int k = 1;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) {
+        const double v = w_p2pl * sums[k++];
+        AtA[a * 6 + b] += v;
+        if (b != a) AtA[b * 6 + a] += v;
+      }
+    for (int a = 0; a < 6; ++a) Atb[a] += w_p2pl * sums[22 + a];
+  }
+  if (w_p2p > 0.0) {
+    // E = [[a]x ; I3]  =>  E E^T = [[ (a.a) I - a a^T , [a]x ], [ [a]x^T , I ]],  E r = [a x r ; r]
+    const double n = sums[0];
+    const double sa[3] = {sums[28], sums[29], sums[30]};
+    const double aa00 = sums[31], aa01 = sums[32], aa02 = sums[33], aa11 = sums[34], aa12 = sums[35], aa22 = sums[36];
+    const double tr = aa00 + aa11 + aa22;
+    const double TL[9] = {tr - aa00, -aa01, -aa02, -aa01, tr - aa11, -aa12, -aa02, -aa12, tr - aa22};
+    const double X[9] = {0.0, -sa[2], sa[1], sa[2], 0.0, -sa[0], -sa[1], sa[0], 0.0};  // sum [a]x
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        AtA[r * 6 + c] += w_p2p * TL[r * 3 + c];
+        AtA[r * 6 + 3 + c] += w_p2p * X[r * 3 + c];
+        AtA[(3 + r) * 6 + c] += w_p2p * X[c * 3 + r];
+      }
+    for (int r = 0; r < 3; ++r) AtA[(3 + r) * 6 + 3 + r] += w_p2p * n;
+    for (int r = 0; r < 3; ++r) { Atb[r] += w_p2p * sums[37 + r]; Atb[3 + r] += w_p2p * sums[40 + r]; }
+  }
+}
+
+// Instance-class tail: rotation() polish, transform_ = tform_iter * transform_, delta norm.
+// T_cur/T_new col-major float 4x4 (Eigen Isometry storage).
+CILHIP_HD float compose_update(const double Lin[9], const double t[3], const float T_cur[16], float T_new[16]) {
+  double R[9];
+  nearest_rotation(Lin, R);
+  double Lc[9], tc[3];
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Lc[r * 3 + c] = (double)T_cur[c * 4 + r]; tc[r] = (double)T_cur[12 + r]; }
+  float out[16];
+  for (int i = 0; i < 16; ++i) out[i] = 0.0f;
+  out[15] = 1.0f;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c)
+      out[c * 4 + r] = (float)(R[r * 3] * Lc[c] + R[r * 3 + 1] * Lc[3 + c] + R[r * 3 + 2] * Lc[6 + c]);
+    out[12 + r] = (float)((R[r * 3] * tc[0] + R[r * 3 + 1] * tc[1] + R[r * 3 + 2] * tc[2]) + t[r]);
+  }
+  for (int i = 0; i < 16; ++i) T_new[i] = out[i];
+  double dn = 0.0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) { const double v = R[r * 3 + c] - ((r == c) ? 1.0 : 0.0); dn += v * v; }
+  for (int r = 0; r < 3; ++r) dn += t[r] * t[r];
+  return (float)sqrt(dn);
+}
+
+// The pinned f32 transform expression (see oracle/icp_oracle.h): q_r = (L_r0*x + (L_r1*y + L_r2*z)) + t_r,
+// every operation individually rounded -- no FMA contraction.
+// common_transformable_feature_adaptors.hpp:28-33.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CILHIP_MUL(a, b) __fmul_rn((a), (b))
+#define CILHIP_ADD(a, b) __fadd_rn((a), (b))
+#define CILHIP_SUB(a, b) __fsub_rn((a), (b))
+#else
+// host side is compiled with -ffp-contract=off (see build.py)
+#define CILHIP_MUL(a, b) ((a) * (b))
+#define CILHIP_ADD(a, b) ((a) + (b))
+#define CILHIP_SUB(a, b) ((a) - (b))
+#endif
+
+CILHIP_HD void transform_point(const float T[16], float x, float y, float z, float& qx, float& qy, float& qz) {
+  qx = CILHIP_ADD(CILHIP_ADD(CILHIP_MUL(T[0], x), CILHIP_ADD(CILHIP_MUL(T[4], y), CILHIP_MUL(T[8], z))), T[12]);
+  qy = CILHIP_ADD(CILHIP_ADD(CILHIP_MUL(T[1], x), CILHIP_ADD(CILHIP_MUL(T[5], y), CILHIP_MUL(T[9], z))), T[13]);
+  qz = CILHIP_ADD(CILHIP_ADD(CILHIP_MUL(T[2], x), CILHIP_ADD(CILHIP_MUL(T[6], y), CILHIP_MUL(T[10], z))), T[14]);
+}
+
+}  // namespace cilhip

@@ -1,0 +1,410 @@
+"""Python host-side mirror of cilantro's rigid ICP interface for this path, on top of the C ABI.
+
+Same names, argument meaning and defaults as the reference classes so the parity tests read like
+the reference's own usage (examples/rigid_icp.cpp:116-125):
+
+    icp = SimpleCombinedMetricRigidICP3f(dst_points, dst_normals, src_points)
+    icp.setMaxNumberOfOptimizationStepIterations(1).setPointToPointMetricWeight(0.0) \
+       .setPointToPlaneMetricWeight(1.0)
+    icp.correspondenceSearchEngine().setMaxDistance(0.1 * 0.1)
+    icp.setConvergenceTolerance(1e-4).setMaxNumberOfIterations(30)
+    T = icp.estimate().getTransform()
+
+Mirrors: registration/icp_base.hpp (IterativeClosestPointBase), icp_common_instances.hpp:250,261
+(SimplePointToPointMetricRigidICP3f / SimpleCombinedMetricRigidICP3f),
+correspondence_search/correspondence_search_kd_tree.hpp (engine knobs :239-271).
+Clouds: (N,3) float32 C-contiguous numpy arrays (== Eigen 3xN column-major) or CUDA torch tensors.
+Transforms: 4x4 numpy float32 in math layout (row, col); converted to Eigen column-major at the ABI.
+
+All compute happens in libcilantro_hip.so; nothing here falls back to the CPU.
+"""
+import ctypes as C
+from enum import Enum
+
+import numpy as np
+
+from . import capi
+
+
+class CorrespondenceSearchDirection(Enum):  # core/correspondence.hpp:7
+    FIRST_TO_SECOND = 0
+    SECOND_TO_FIRST = 1
+    BOTH = 2
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _as_cloud(x):
+    """-> (pointer, n, mem, keepalive)"""
+    if x is None:
+        return None, 0, capi.MEM_HOST, None
+    if _is_torch(x):
+        import torch
+
+        t = x
+        if t.dtype != torch.float32:
+            raise TypeError("clouds must be float32")
+        t = t.contiguous()
+        if t.dim() != 2 or t.shape[1] != 3:
+            raise ValueError("clouds must have shape (N, 3)")
+        if t.is_cuda:
+            return t.data_ptr(), t.shape[0], capi.MEM_DEVICE, t
+        a = t.numpy()
+        return a.ctypes.data, a.shape[0], capi.MEM_HOST, a
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("clouds must have shape (N, 3)")
+    return a.ctypes.data, a.shape[0], capi.MEM_HOST, a
+
+
+def _T_to_abi(T):
+    a = np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T).reshape(16)
+    return a
+
+
+def _T_from_abi(buf):
+    return np.array(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class Context:
+    """Thin RAII wrapper of cilhip_ctx."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = capi.load()
+        h = C.c_void_p()
+        rc = self._L.cilhip_create(C.byref(h), int(device))
+        if rc != capi.OK:
+            raise capi.CilhipError(rc, "cilhip_create failed (no usable HIP device? there is no CPU fallback)")
+        self._h = h
+        self._keep = []
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cilhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != capi.OK:
+            raise capi.CilhipError(rc, self._L.cilhip_last_error(self._h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._ck(self._L.cilhip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._ck(self._L.cilhip_synchronize(self._h))
+
+    def set_target(self, points, normals=None):
+        p, n, mem, k1 = _as_cloud(points)
+        q, nn, mem2, k2 = _as_cloud(normals)
+        if normals is not None and (nn != n or mem2 != mem):
+            raise ValueError("normals must match points (count and memory space)")
+        self._ck(self._L.cilhip_set_target(self._h, p, q, n, mem))
+        self.n_target = n
+
+    def set_source(self, points):
+        p, n, mem, k = _as_cloud(points)
+        self._ck(self._L.cilhip_set_source(self._h, p, n, mem))
+        self.n_source = n
+
+    def means(self):
+        dm = np.zeros(3, np.float32); sm = np.zeros(3, np.float32)
+        self._ck(self._L.cilhip_get_means(self._h, dm.ctypes.data, sm.ctypes.data))
+        return dm, sm
+
+    def find_correspondences(self, T, max_sq_dist, count=True):
+        t = _T_to_abi(T)
+        n = C.c_size_t(0)
+        self._ck(self._L.cilhip_find_correspondences(self._h, t.ctypes.data, C.c_float(max_sq_dist),
+                                                     C.byref(n) if count else None))
+        return n.value if count else None
+
+    def get_nn(self):
+        idx = np.zeros(max(self.n_source, 1), np.uint32); d2 = np.zeros(max(self.n_source, 1), np.float32)
+        self._ck(self._L.cilhip_get_nn(self._h, idx.ctypes.data, d2.ctypes.data, capi.MEM_HOST))
+        return idx[: self.n_source], d2[: self.n_source]
+
+    def get_correspondences(self):
+        cap = max(self.n_source, 1)
+        i1 = np.zeros(cap, np.uint64); i2 = np.zeros(cap, np.uint64); v = np.zeros(cap, np.float32)
+        n = C.c_size_t(0)
+        self._ck(self._L.cilhip_get_correspondences(self._h, i1.ctypes.data, i2.ctypes.data, v.ctypes.data, cap, C.byref(n)))
+        return i1[: n.value].astype(np.int64), i2[: n.value].astype(np.int64), v[: n.value].copy()
+
+    def estimate_point_to_point(self):
+        T = np.zeros(16, np.float32); sums = np.zeros(16, np.float64); ok = C.c_int(0)
+        self._ck(self._L.cilhip_estimate_point_to_point(self._h, T.ctypes.data, sums.ctypes.data, C.byref(ok)))
+        return _T_from_abi(T), sums, bool(ok.value)
+
+    def estimate_combined(self, w_p2p, w_p2pl, max_iter=1, conv_tol=1e-5):
+        T = np.zeros(16, np.float32); AtA = np.zeros(36, np.float64); Atb = np.zeros(6, np.float64)
+        cv = C.c_int(0)
+        self._ck(self._L.cilhip_estimate_combined(self._h, w_p2p, w_p2pl, max_iter, conv_tol, T.ctypes.data,
+                                                  AtA.ctypes.data, Atb.ctypes.data, C.byref(cv)))
+        return _T_from_abi(T), AtA.reshape(6, 6), Atb, bool(cv.value)
+
+    def icp_run(self, params, T0=None):
+        res = capi.IcpResult()
+        t0 = _T_to_abi(T0) if T0 is not None else None
+        self._ck(self._L.cilhip_icp_run(self._h, C.byref(params), t0.ctypes.data if t0 is not None else None, C.byref(res)))
+        return res
+
+    def icp_begin(self, params, T0=None, global_src_mean=None):
+        t0 = _T_to_abi(T0) if T0 is not None else None
+        gm = np.ascontiguousarray(global_src_mean, np.float32) if global_src_mean is not None else None
+        self._ck(self._L.cilhip_icp_begin(self._h, C.byref(params), t0.ctypes.data if t0 is not None else None,
+                                          gm.ctypes.data if gm is not None else None))
+
+    def icp_partial_sums(self, sums_dev_ptr):
+        self._ck(self._L.cilhip_icp_partial_sums(self._h, C.c_void_p(sums_dev_ptr)))
+
+    def icp_apply_sums(self, sums_dev_ptr):
+        self._ck(self._L.cilhip_icp_apply_sums(self._h, C.c_void_p(sums_dev_ptr)))
+
+    def icp_state(self):
+        res = capi.IcpResult()
+        self._ck(self._L.cilhip_icp_state(self._h, C.byref(res)))
+        return res
+
+    def compute_residuals(self, metric, w_p2p, w_p2pl, T):
+        out = np.zeros(max(self.n_source, 1), np.float32)
+        t = _T_to_abi(T)
+        self._ck(self._L.cilhip_compute_residuals(self._h, metric, w_p2p, w_p2pl, t.ctypes.data, out.ctypes.data, capi.MEM_HOST))
+        return out[: self.n_source]
+
+    def grid_info(self):
+        gi = capi.GridInfo()
+        self._ck(self._L.cilhip_get_grid_info(self._h, C.byref(gi)))
+        return gi
+
+    def enable_kernel_timing(self, on=True):
+        self._ck(self._L.cilhip_enable_kernel_timing(self._h, 1 if on else 0))
+
+    def last_timing(self):
+        a = C.c_double(0); b = C.c_double(0); n = C.c_int(0)
+        self._ck(self._L.cilhip_get_last_timing(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+
+class CorrespondenceSearchHIP:
+    """Models the reference's correspondence-search engine concept
+    (CorrespondenceSearchKDTree, correspondence_search/correspondence_search_kd_tree.hpp) on the GPU.
+    Option combinations the GPU path does not implement raise -- they never silently differ."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self.search_dir_ = CorrespondenceSearchDirection.SECOND_TO_FIRST   # :47
+        self.max_distance_ = np.float32(0.01 * 0.01)                        # :48 (squared)
+        self.inlier_fraction_ = 1.0
+        self.require_reciprocality_ = False
+        self.one_to_one_ = False
+        self._corr = None
+
+    def findCorrespondences(self, tform=None):
+        T = np.eye(4, dtype=np.float32) if tform is None else tform
+        self._ctx.find_correspondences(T, float(self.max_distance_), count=False)
+        self._corr = None
+        return self
+
+    def getCorrespondences(self):
+        """-> structured view of the reference's CorrespondenceSet: (indexInFirst, indexInSecond, value)."""
+        if self._corr is None:
+            self._corr = self._ctx.get_correspondences()
+        return self._corr
+
+    def getSearchDirection(self):
+        return self.search_dir_
+
+    def setSearchDirection(self, d):
+        if d != CorrespondenceSearchDirection.SECOND_TO_FIRST:
+            raise NotImplementedError("GPU engine implements SECOND_TO_FIRST only")
+        self.search_dir_ = d
+        return self
+
+    def getMaxDistance(self):
+        return self.max_distance_
+
+    def setMaxDistance(self, dist_thresh):
+        self.max_distance_ = np.float32(dist_thresh)
+        return self
+
+    def getInlierFraction(self):
+        return self.inlier_fraction_
+
+    def setInlierFraction(self, f):
+        if not (f >= 1.0 or f <= 0.0):
+            raise NotImplementedError("GPU engine implements inlier_fraction == 1 only")
+        self.inlier_fraction_ = f
+        return self
+
+    def getRequireReciprocality(self):
+        return self.require_reciprocality_
+
+    def setRequireReciprocality(self, b):
+        if b:
+            raise NotImplementedError("reciprocal search is not implemented on the GPU engine")
+        return self
+
+    def getOneToOne(self):
+        return self.one_to_one_
+
+    def setOneToOne(self, b):
+        if b:
+            raise NotImplementedError("one-to-one filtering is not implemented on the GPU engine")
+        return self
+
+
+class _IterativeClosestPointBase:
+    """registration/icp_base.hpp"""
+
+    def __init__(self, device=0, stream=None):
+        self._ctx = Context(device, stream)
+        self._engine = CorrespondenceSearchHIP(self._ctx)
+        self.max_iterations_ = 15            # :24
+        self.convergence_tol_ = np.float32(1e-5)  # :25
+        self.iterations_ = 0
+        self.last_delta_norm_ = np.float32(np.inf)
+        self.transform_init_ = np.eye(4, dtype=np.float32)
+        self.transform_ = np.eye(4, dtype=np.float32)
+        self.last_ncorr_ = 0
+
+    def correspondenceSearchEngine(self):
+        return self._engine
+
+    def getMaxNumberOfIterations(self):
+        return self.max_iterations_
+
+    def setMaxNumberOfIterations(self, n):
+        self.max_iterations_ = int(n)
+        return self
+
+    def getNumberOfPerformedIterations(self):
+        return self.iterations_
+
+    def getConvergenceTolerance(self):
+        return self.convergence_tol_
+
+    def setConvergenceTolerance(self, tol):
+        self.convergence_tol_ = np.float32(tol)
+        return self
+
+    def getInitialTransform(self):
+        return self.transform_init_
+
+    def setInitialTransform(self, T):
+        self.transform_init_ = np.asarray(T, np.float32).reshape(4, 4).copy()
+        return self
+
+    def getLastUpdateNorm(self):
+        return self.last_delta_norm_
+
+    def hasConverged(self):
+        return bool(self.last_delta_norm_ < self.convergence_tol_)
+
+    def getTransform(self):
+        return self.transform_
+
+    def _params(self):
+        raise NotImplementedError
+
+    def estimate(self, max_iter=None, conv_tol=None):
+        if max_iter is not None:
+            self.max_iterations_ = int(max_iter)
+        if conv_tol is not None:
+            self.convergence_tol_ = np.float32(conv_tol)
+        res = self._ctx.icp_run(self._params(), self.transform_init_)
+        self.transform_ = _T_from_abi(res.T[:])
+        self.iterations_ = int(res.iterations)
+        self.last_delta_norm_ = np.float32(res.last_delta_norm)
+        self.last_ncorr_ = int(res.last_ncorr)
+        return self
+
+
+class SimplePointToPointMetricRigidICP3f(_IterativeClosestPointBase):
+    """registration/icp_common_instances.hpp:250 (wrapper :34-45) over
+    PointToPointMetricSingleTransformICP (icp_single_transform_point_to_point_metric.hpp)."""
+
+    def __init__(self, dst_points, src_points, device=0, stream=None):
+        super().__init__(device, stream)
+        self._ctx.set_target(dst_points, None)
+        self._ctx.set_source(src_points)
+
+    def _params(self):
+        p = capi.IcpParams()
+        self._ctx._L.cilhip_icp_default_params(C.byref(p))
+        p.metric = capi.METRIC_POINT_TO_POINT
+        p.max_iter = self.max_iterations_
+        p.conv_tol = float(self.convergence_tol_)
+        p.max_sq_dist = float(self._engine.max_distance_)
+        return p
+
+    def getResiduals(self):
+        return self._ctx.compute_residuals(0, 0.0, 0.0, self.transform_)
+
+
+class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
+    """registration/icp_common_instances.hpp:261 (wrapper :74-97) over
+    CombinedMetricSingleTransformICP (icp_single_transform_combined_metric.hpp); defaults :44-47."""
+
+    def __init__(self, dst_points, dst_normals, src_points, device=0, stream=None):
+        super().__init__(device, stream)
+        self._ctx.set_target(dst_points, dst_normals)
+        self._ctx.set_source(src_points)
+        self.max_optimization_iterations_ = 1
+        self.optimization_convergence_tol_ = np.float32(1e-5)
+        self.point_to_point_weight_ = np.float32(0.0)
+        self.point_to_plane_weight_ = np.float32(1.0)
+
+    def getPointToPointMetricWeight(self):
+        return self.point_to_point_weight_
+
+    def setPointToPointMetricWeight(self, w):
+        self.point_to_point_weight_ = np.float32(w)
+        return self
+
+    def getPointToPlaneMetricWeight(self):
+        return self.point_to_plane_weight_
+
+    def setPointToPlaneMetricWeight(self, w):
+        self.point_to_plane_weight_ = np.float32(w)
+        return self
+
+    def getMaxNumberOfOptimizationStepIterations(self):
+        return self.max_optimization_iterations_
+
+    def setMaxNumberOfOptimizationStepIterations(self, n):
+        self.max_optimization_iterations_ = int(n)
+        return self
+
+    def getOptimizationStepConvergenceTolerance(self):
+        return self.optimization_convergence_tol_
+
+    def setOptimizationStepConvergenceTolerance(self, tol):
+        self.optimization_convergence_tol_ = np.float32(tol)
+        return self
+
+    def _params(self):
+        p = capi.IcpParams()
+        self._ctx._L.cilhip_icp_default_params(C.byref(p))
+        p.metric = capi.METRIC_COMBINED
+        p.w_p2p = float(self.point_to_point_weight_)
+        p.w_p2pl = float(self.point_to_plane_weight_)
+        p.max_iter = self.max_iterations_
+        p.conv_tol = float(self.convergence_tol_)
+        p.max_opt_iter = self.max_optimization_iterations_
+        p.opt_conv_tol = float(self.optimization_convergence_tol_)
+        p.max_sq_dist = float(self._engine.max_distance_)
+        return p
+
+    def getResiduals(self):
+        return self._ctx.compute_residuals(1, float(self.point_to_point_weight_), float(self.point_to_plane_weight_),
+                                           self.transform_)

@@ -1,0 +1,177 @@
+/*
+ * cilantro_hip/c_api.h -- C ABI of the MI355X-native rigid ICP engine (libcilantro_hip.so).
+ *
+ * cilantro (the reference) has NO ABI for this path: it is C++ template duck typing
+ * (registration/icp_base.hpp:8-10,114).  This header is the drop-in
+ * boundary a maintainer binds instead: plain pointers and sizes, no Eigen / torch types.
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/include/cilantro/).  The C++ mirror of the reference classes that sits on
+ * top of it is include/cilantro_hip/icp.hpp; INTEGRATION.md shows the binding.
+ *
+ * Conventions (identical to the reference):
+ *   - clouds: const float* xyz, point i at xyz[3i..3i+2]  (Eigen::Matrix<float,3,Dynamic>
+ *     column-major, core/data_containers.hpp:155-156); "first" = dst/target, "second" = src.
+ *   - transforms: float[16], 4x4 COLUMN-major (Eigen::Transform<float,3,Isometry>::data()).
+ *   - all distances are SQUARED L2 (core/kd_tree.hpp:46-47).
+ *   - every call returns 0 on success or a negative cilhip_status; cilhip_last_error() has text.
+ *     Nothing throws across the boundary.  A context is single-caller (like one ICP object).
+ *   - `mem` arguments: CILHIP_MEM_HOST = pointer is host memory (copied), CILHIP_MEM_DEVICE =
+ *     pointer is device memory on the context's GPU (copied device-to-device; caller keeps
+ *     ownership either way).
+ */
+#ifndef CILANTRO_HIP_C_API_H
+#define CILANTRO_HIP_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cilhip_ctx cilhip_ctx;
+
+typedef enum {
+  CILHIP_OK = 0,
+  CILHIP_ERR_INVALID = -1,      /* bad argument / call order */
+  CILHIP_ERR_HIP = -2,          /* HIP runtime failure (no device, OOM, launch failure) */
+  CILHIP_ERR_UNSUPPORTED = -3,  /* option combination the GPU path does not implement */
+  CILHIP_ERR_NO_DEVICE = -4
+} cilhip_status;
+
+enum { CILHIP_MEM_HOST = 0, CILHIP_MEM_DEVICE = 1 };
+
+/* metric selector: which reference ICP class is being replaced */
+enum {
+  CILHIP_METRIC_POINT_TO_POINT = 0, /* PointToPointMetricSingleTransformICP (closed-form SVD),
+                                       registration/icp_single_transform_point_to_point_metric.hpp */
+  CILHIP_METRIC_COMBINED = 1        /* CombinedMetricSingleTransformICP (Gauss-Newton; defaults
+                                       w_p2p=0, w_p2pl=1 = point-to-plane),
+                                       registration/icp_single_transform_combined_metric.hpp */
+};
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* device: HIP device ordinal.  Owns one stream, all device buffers, the target grid index. */
+int cilhip_create(cilhip_ctx** out, int device);
+void cilhip_destroy(cilhip_ctx* ctx);
+const char* cilhip_last_error(const cilhip_ctx* ctx);
+/* Run all work on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * context's own; pass NULL to go back.  The caller keeps the stream alive. */
+int cilhip_set_stream(cilhip_ctx* ctx, void* hip_stream);
+int cilhip_synchronize(cilhip_ctx* ctx);
+
+/* ---- clouds ---------------------------------------------------------------------------------- */
+/* Target ("first"/dst) cloud + optional normals.  Builds the uniform-grid index on the GPU.
+ * Replaces: KDTree ctor core/kd_tree.hpp:162-170 -> nanoflann buildIndex
+ * (3rd_party/nanoflann/nanoflann.hpp:1661-1687), lazily triggered at
+ * correspondence_search/correspondence_search_kd_tree.hpp:202-203; and the dst_mean_ of
+ * registration/icp_single_transform_combined_metric.hpp:51-54. */
+int cilhip_set_target(cilhip_ctx* ctx, const float* xyz, const float* normals_or_null, size_t n,
+                      int mem);
+/* Source ("second"/src) cloud.  Replaces the PointFeaturesAdaptor src_feat_
+ * (correspondence_search/common_transformable_feature_adaptors.hpp:14-17) and src_mean_
+ * (icp_single_transform_combined_metric.hpp:55-58). */
+int cilhip_set_source(cilhip_ctx* ctx, const float* xyz, size_t n, int mem);
+/* dst_mean_ / src_mean_ as the ICP classes hold them (f64 sum, rounded to f32). */
+int cilhip_get_means(cilhip_ctx* ctx, float dst_mean[3], float src_mean[3]);
+
+/* ---- correspondence search (engine concept) -------------------------------------------------- */
+/* CorrespondenceSearchKDTree::findCorrespondences(tform), SECOND_TO_FIRST, L2, identity
+ * evaluator, inlier_fraction 1, no one-to-one/reciprocity
+ * (correspondence_search/correspondence_search_kd_tree.hpp:107-229 live code :185-228):
+ *   q_i = T*s_i (common_transformable_feature_adaptors.hpp:28-33), exact 1-NN of q_i among dst with
+ *   d2 < max_sq_dist, strict (correspondence_search_kd_tree_utilities.hpp:26-33; nanoflann.hpp:1901).
+ * Ties on d2 resolve to the LOWEST dst index (the reference keeps the first met in kd-tree order).
+ * Results stay on the device; n_found (optional) forces a sync and returns the count. */
+int cilhip_find_correspondences(cilhip_ctx* ctx, const float T[16], float max_sq_dist,
+                                size_t* n_found_or_null);
+/* Per-source raw result of the last search, in ORIGINAL source order: nn_idx[i] = dst index or
+ * 0xFFFFFFFF (none), nn_d2[i] = squared distance (undefined when none).  Either may be NULL. */
+int cilhip_get_nn(cilhip_ctx* ctx, uint32_t* nn_idx, float* nn_d2, int mem);
+/* The reference's SearchResult: CorrespondenceSet<float,size_t> compacted in ascending source
+ * index order (correspondence_search_kd_tree_utilities.hpp:45-50; core/correspondence.hpp:9-55),
+ * as three host arrays of capacity `cap` (>= n_found): indexInFirst, indexInSecond, value. */
+int cilhip_get_correspondences(cilhip_ctx* ctx, uint64_t* index_in_first, uint64_t* index_in_second,
+                               float* value, size_t cap, size_t* n_out);
+
+/* ---- estimators on the correspondences of the last search ------------------------------------ */
+/* estimateTransformPointToPointMetric (rigid, closed form), registration/transform_estimation.hpp
+ * :11-48 via :104-113.  dT_out: the step transform (tform_iter before the rotation() polish).
+ * sums_or_null (16 doubles): n, sum p(3), sum q(3), sum p q^T(9, row-major) -- raw moments.
+ * Returns CILHIP_OK; *ok_or_null = (n >= 3) as the reference's bool. */
+int cilhip_estimate_point_to_point(cilhip_ctx* ctx, float dT_out[16], double* sums_or_null,
+                                   int* ok_or_null);
+/* estimateTransformCombinedMetric (rigid 3D, unity weights), transform_estimation.hpp:237-367,
+ * called as icp_single_transform_combined_metric.hpp:191-196 does (dst_mean, T*src_mean).
+ * AtA_or_null (36, row-major) / Atb_or_null (6): first Gauss-Newton step's normal equations.
+ * *converged_or_null: the reference's bool return (d_theta.norm() < conv_tol inside max_iter). */
+int cilhip_estimate_combined(cilhip_ctx* ctx, float w_p2p, float w_p2pl, size_t max_iter,
+                             float conv_tol, float dT_out[16], double* AtA_or_null,
+                             double* Atb_or_null, int* converged_or_null);
+
+/* ---- the whole ICP loop, fused on the device ------------------------------------------------- */
+typedef struct {
+  int metric;            /* CILHIP_METRIC_* */
+  float w_p2p, w_p2pl;   /* combined metric weights (reference defaults 0 / 1) */
+  size_t max_iter;       /* icp_base.hpp:24  (default 15) */
+  float conv_tol;        /* icp_base.hpp:25  (default 1e-5) */
+  size_t max_opt_iter;   /* max_optimization_iterations_ (default 1) */
+  float opt_conv_tol;    /* optimization_convergence_tol_ (default 1e-5) */
+  float max_sq_dist;     /* engine max_distance_, SQUARED (default 0.01*0.01) */
+} cilhip_icp_params;
+
+typedef struct {
+  float T[16];           /* transform_ */
+  size_t iterations;     /* iterations_ */
+  float last_delta_norm; /* last_delta_norm_ */
+  size_t last_ncorr;     /* correspondences used by the last executed iteration */
+} cilhip_icp_result;
+
+void cilhip_icp_default_params(cilhip_icp_params* p);
+/* IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) with
+ * updateCorrespondences()+updateEstimate() of the selected class, all iterations enqueued
+ * back-to-back on the stream (convergence is decided on the device); one sync at the end. */
+int cilhip_icp_run(cilhip_ctx* ctx, const cilhip_icp_params* prm, const float T0_or_null[16],
+                   cilhip_icp_result* out);
+
+/* ---- building blocks for source-sharded multi-GPU runs (one process per GPU) ----------------- */
+/* Each rank holds the full target and a shard of the source.  Per iteration:
+ *   cilhip_icp_begin (once)  ->  { cilhip_icp_partial_sums -> all-reduce(sum) of
+ *   CILHIP_SUMS_LEN doubles over RCCL (caller, e.g. torch.distributed) -> cilhip_icp_apply_sums }
+ * sums_dev: DEVICE pointer to CILHIP_SUMS_LEN doubles owned by the caller.  No host sync. */
+#define CILHIP_SUMS_LEN 48
+int cilhip_icp_begin(cilhip_ctx* ctx, const cilhip_icp_params* prm, const float T0_or_null[16],
+                     const float global_src_mean_or_null[3]);
+int cilhip_icp_partial_sums(cilhip_ctx* ctx, double* sums_dev);
+int cilhip_icp_apply_sums(cilhip_ctx* ctx, const double* sums_dev);
+int cilhip_icp_state(cilhip_ctx* ctx, cilhip_icp_result* out); /* syncs */
+
+/* ---- residuals ------------------------------------------------------------------------------- */
+/* computeResiduals() of both classes (icp_single_transform_combined_metric.hpp:220-243,
+ * icp_single_transform_point_to_point_metric.hpp:68-85): unbounded 1-NN of T*s_i, then
+ * w_p2p*|p-q|^2 + w_p2pl*(n.(p-q))^2  (metric 0: |p-q|^2).  out: ns floats, original order. */
+int cilhip_compute_residuals(cilhip_ctx* ctx, int metric, float w_p2p, float w_p2pl,
+                             const float T[16], float* out, int mem);
+
+/* ---- introspection (bench / tests) ----------------------------------------------------------- */
+typedef struct {
+  int nx, ny, nz;        /* grid dims */
+  float cell;            /* cell edge */
+  float origin[3];
+  size_t n_cells;
+  double avg_occupancy;  /* sum(count^2)/n: expected own-cell candidates of a target point */
+  double build_ms;       /* last set_target wall time (upload + grid build) */
+} cilhip_grid_info;
+int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
+/* ms of the kernels of the last cilhip_icp_run, measured with hipEvents on the ctx stream:
+ * total loop, and the fused search+accumulate kernel alone (sum over executed iterations). */
+int cilhip_get_last_timing(cilhip_ctx* ctx, double* loop_ms, double* search_kernel_ms,
+                           int* search_kernel_launches);
+/* Record a hipEvent pair around every fused search+accumulate launch of cilhip_icp_run (off by
+ * default: the extra event records perturb a back-to-back loop slightly). */
+int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

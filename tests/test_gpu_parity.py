@@ -1,0 +1,233 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Integer / index work must be bit-exact; transforms within 1e-5 Frobenius
+(BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from cilantro_amd import capi
+from cilantro_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL_T = 1e-5  # north_star: final rotation/translation within 1e-5 Frobenius
+
+
+@pytest.fixture(scope="module")
+def Context(hip_lib):
+    from cilantro_amd.icp import Context as C
+
+    return C
+
+
+def classify_mismatches(orc, dst, q, gi, gd, oi, od):
+    """exact / equal-distance tie / gpu strictly nearer / gpu worse (must be 0)"""
+    bad = np.nonzero(gi != oi)[0]
+    ties = nearer = worse = 0
+    for i in bad:
+        if gi[i] >= 0 and oi[i] >= 0 and gd[i] == od[i]:
+            ties += 1
+        elif gi[i] >= 0 and (oi[i] < 0 or gd[i] < od[i]):
+            nearer += 1
+        else:
+            worse += 1
+    return len(bad), ties, nearer, worse
+
+
+def gpu_nn(ctx, T, max_sq):
+    ctx.find_correspondences(T, max_sq, count=False)
+    idx, d2 = ctx.get_nn()
+    gi = idx.astype(np.int64)
+    gi[idx == capi.NONE_IDX] = -1
+    return gi, d2
+
+
+def test_kd_tree_example_known_answer(Context, orc):
+    # examples/kd_tree.cpp:6-19 (k=2 there; the engine is k=1: nearest of the two is index 0, d2=0.18)
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 1, 1], [1, 0, 1], [1, 1, 0], [1, 1, 1]], np.float32)
+    ctx = Context()
+    ctx.set_target(pts)
+    ctx.set_source(np.array([[0.1, 0.1, 0.4]], np.float32))
+    n = ctx.find_correspondences(np.eye(4), 1.001)
+    i1, i2, v = ctx.get_correspondences()
+    assert n == 1 and list(i1) == [0] and list(i2) == [0]
+    oi, od = orc.KDTree(pts).knn_in_radius([0.1, 0.1, 0.4], 2, 1.001)
+    assert v[0] == od[0] and oi[0] == 0 and oi[1] == 3
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 20000])
+def test_nn_vs_bruteforce_exact(Context, orc, n):
+    rng = np.random.default_rng(n)
+    dst = rng.random((n, 3), dtype=np.float32)
+    if n >= 1000:
+        dst[n // 2: n // 2 + 50] = dst[:50]          # exact duplicates -> ties resolved to lowest index
+    q = rng.random((max(n, 500), 3), dtype=np.float32) * 1.2 - 0.1   # some queries outside the bbox
+    q[:20] = dst[:20] if n >= 20 else q[:20]          # zero-distance matches
+    h = n ** (-1.0 / 3.0)
+    for max_sq in (np.float32((0.7 * h) ** 2), np.float32(0.05), np.float32(3.4e38)):
+        ctx = Context()
+        ctx.set_target(dst)
+        ctx.set_source(q)
+        gi, gd = gpu_nn(ctx, np.eye(4), max_sq)
+        bi, bd = orc.nn_brute(dst, q, max_sq)
+        assert np.array_equal(gi, bi), (n, max_sq, np.nonzero(gi != bi)[0][:10])
+        m = bi >= 0
+        assert np.array_equal(gd[m], bd[m])
+
+
+def test_radius_edge_is_strict(Context, orc):
+    # d2 == r2 must be rejected (strict '<' at nanoflann.hpp:1901 and kd_tree_utilities.hpp:29)
+    dst = np.array([[0, 0, 0], [4, 0, 0]], np.float32)
+    q = np.array([[0.5, 0, 0], [2.0, 0, 0]], np.float32)
+    ctx = Context()
+    ctx.set_target(dst); ctx.set_source(q)
+    gi, gd = gpu_nn(ctx, np.eye(4), np.float32(0.25))
+    assert list(gi) == [-1, -1]
+    gi, gd = gpu_nn(ctx, np.eye(4), np.nextafter(np.float32(0.25), np.float32(1)))
+    assert list(gi) == [0, -1]
+    gi, gd = gpu_nn(ctx, np.eye(4), np.float32(4.0))
+    assert list(gi) == [0, -1]                         # q1 is at d2 == 4.0 from both -> rejected
+    gi, gd = gpu_nn(ctx, np.eye(4), np.float32(4.5))
+    assert list(gi) == [0, 0]                          # tie -> lowest index
+
+
+def test_empty_inputs(Context):
+    ctx = Context()
+    ctx.set_target(np.zeros((0, 3), np.float32))
+    ctx.set_source(np.random.default_rng(0).random((100, 3), dtype=np.float32))
+    assert ctx.find_correspondences(np.eye(4), 1.0) == 0        # kd_tree_utilities.hpp:16-19
+    ctx2 = Context()
+    ctx2.set_target(np.random.default_rng(0).random((100, 3), dtype=np.float32))
+    ctx2.set_source(np.zeros((0, 3), np.float32))
+    assert ctx2.find_correspondences(np.eye(4), 1.0) == 0
+    i1, i2, v = ctx2.get_correspondences()
+    assert len(i1) == 0
+
+
+@pytest.mark.parametrize("n", [200000, 1000000])
+def test_nn_vs_kdtree_oracle_and_reference(Context, orc, n):
+    d = syn.make_pair(n)
+    T = np.eye(4, dtype=np.float32)
+    q = orc.transform_points(T, d["src"])
+    ctx = Context()
+    ctx.set_target(d["dst"]); ctx.set_source(d["src"])
+    ng = ctx.find_correspondences(T, d["max_sq_dist"])
+    g1, g2, gv = ctx.get_correspondences()
+    for use_ref in ([False, True] if orc.ref_available() else [False]):
+        o1, o2, ov = orc.KDTree(d["dst"], use_ref=use_ref).find_correspondences(q, d["max_sq_dist"])
+        assert ng == len(o1)
+        assert np.array_equal(g2, o2)                  # same kept set, ascending source order
+        nbad, ties, nearer, worse = classify_mismatches(orc, d["dst"], q, g1, gv, o1, ov)
+        # uniform random data: no duplicates, so indices must match exactly; any deviation is classified
+        assert worse == 0, (nbad, ties, nearer, worse)
+        assert nbad == 0, (nbad, ties, nearer, worse)
+        assert np.array_equal(gv, ov)
+
+
+def test_accumulation_sums_vs_oracle(Context, orc):
+    d = syn.make_pair(300000)
+    T = syn.true_transform(d["h"], 0.1).astype(np.float32)
+    ctx = Context()
+    ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+    ctx.find_correspondences(T, d["max_sq_dist"])
+    g1, g2, gv = ctx.get_correspondences()
+    q = orc.transform_points(T, d["src"])
+    dm, sm = ctx.means()
+    smt = orc.transform_points(T, sm.reshape(1, 3))[0]
+    # point-to-point raw moments
+    Tg, sums_g, ok = ctx.estimate_point_to_point()
+    To, sums_o, ok2 = orc.estimate_p2p(d["dst"], q, g1, g2, orc.MODE_MIXED)
+    assert ok == ok2
+    np.testing.assert_allclose(sums_g, sums_o, rtol=1e-11, atol=1e-9)
+    assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6
+    # Gauss-Newton normal equations, all three weightings
+    for w_p2p, w_p2pl in ((0.0, 1.0), (1.0, 0.0), (0.1, 1.0)):
+        Tg, AtA, Atb, cv = ctx.estimate_combined(w_p2p, w_p2pl, 1, 1e-5)
+        To, AtAo, Atbo, cvo = orc.estimate_combined(d["dst"], d["dst_n"], q, g1, g2, w_p2p, w_p2pl, dm, smt,
+                                                    1, 1e-5, orc.MODE_MIXED)
+        scale = np.abs(AtAo).max()
+        assert np.abs(AtA - AtAo).max() <= 1e-9 * scale, (w_p2p, w_p2pl, np.abs(AtA - AtAo).max() / scale)
+        assert np.abs(Atb - Atbo).max() <= 1e-9 * max(np.abs(Atbo).max(), 1e-30) + 1e-12 * scale
+        assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6, (w_p2p, w_p2pl)
+        assert cv == cvo
+        # reference-like all-f32 arithmetic agrees loosely (f32 accumulation of 3e5 terms)
+        Tf, _, _, _ = orc.estimate_combined(d["dst"], d["dst_n"], q, g1, g2, w_p2p, w_p2pl, dm, smt, 1, 1e-5, orc.MODE_F32)
+        assert np.linalg.norm(Tg - Tf) < 1e-4
+    # multi-step Gauss-Newton (max_optimization_iterations_ = 3)
+    Tg, _, _, cv = ctx.estimate_combined(0.0, 1.0, 3, 1e-7)
+    To, _, _, cvo = orc.estimate_combined(d["dst"], d["dst_n"], q, g1, g2, 0.0, 1.0, dm, smt, 3, 1e-7, orc.MODE_MIXED)
+    assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6 and cv == cvo
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("n", [20000, 500000])
+def test_icp_end_to_end_vs_oracle(orc, hip_lib, metric, n):
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f
+
+    d = syn.make_pair(n, perturb=0.6)
+    for max_iter, tol in ((6, 0.0), (50, 1e-5)):       # fixed iteration count AND convergence-gated
+        if metric == 1:
+            icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+        else:
+            icp = SimplePointToPointMetricRigidICP3f(d["dst"], d["src"])
+        icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+        icp.setMaxNumberOfIterations(max_iter).setConvergenceTolerance(tol)
+        Tg = icp.estimate().getTransform()
+        for mode in (orc.MODE_MIXED, orc.MODE_F32):
+            p = orc.make_params(metric=metric, max_iter=max_iter, conv_tol=tol, max_sq_dist=d["max_sq_dist"], mode=mode)
+            r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+            err = np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64))
+            assert err <= TOL_T, (metric, n, max_iter, mode, err)
+            if mode == orc.MODE_MIXED:
+                assert abs(icp.getNumberOfPerformedIterations() - r["iterations"]) <= (0 if tol == 0.0 else 1)
+                if tol == 0.0:
+                    assert icp.last_ncorr_ == r["last_ncorr"]
+        assert np.linalg.norm(Tg - d["T_true"]) < 2e-3 * (20000 / n) ** 0.5 + 2e-4
+        if tol > 0:
+            assert icp.hasConverged()
+
+
+def test_icp_combined_weights_and_gn_steps(orc, hip_lib):
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(100000, perturb=0.5)
+    for w_p2p, w_p2pl, steps in ((0.1, 1.0, 1), (1.0, 0.0, 1), (0.0, 1.0, 3), (0.5, 0.5, 2)):
+        icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+        icp.setPointToPointMetricWeight(w_p2p).setPointToPlaneMetricWeight(w_p2pl)
+        icp.setMaxNumberOfOptimizationStepIterations(steps).setOptimizationStepConvergenceTolerance(1e-6)
+        icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+        icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, w_p2p=w_p2p, w_p2pl=w_p2pl, max_iter=8, conv_tol=0.0, max_opt_iter=steps,
+                            opt_conv_tol=1e-6, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+        r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+        err = np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64))
+        assert err <= TOL_T, (w_p2p, w_p2pl, steps, err)
+
+
+def test_icp_degenerate_inputs(hip_lib):
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f
+
+    rng = np.random.default_rng(1)
+    dst = rng.random((1000, 3), dtype=np.float32)
+    far = dst + np.float32(100.0)                       # no correspondences at all
+    icp = SimplePointToPointMetricRigidICP3f(dst, far)
+    T = icp.estimate().getTransform()
+    # transform_estimation.hpp:20-23: identity step, delta 0 -> "converged" after one iteration
+    assert np.array_equal(T, np.eye(4, dtype=np.float32)) and icp.getNumberOfPerformedIterations() == 1
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (1000, 1))
+    icp = SimpleCombinedMetricRigidICP3f(dst, nrm, far)
+    T = icp.estimate().getTransform()
+    assert np.array_equal(T, np.eye(4, dtype=np.float32)) and icp.getNumberOfPerformedIterations() == 1
+
+
+def test_run_to_run_bitwise_reproducible(hip_lib):
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(300000)
+    outs = []
+    for _ in range(3):
+        icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+        icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+        icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0)
+        outs.append(icp.estimate().getTransform().tobytes())
+    assert outs[0] == outs[1] == outs[2]
