@@ -24,6 +24,7 @@ SYMBOLS = [
     "cilhip_estimate_combined", "cilhip_icp_default_params", "cilhip_icp_run", "cilhip_icp_begin",
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
     "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing",
+    "cilhip_set_option", "cilhip_get_last_timing2",
 ]
 
 
@@ -92,6 +93,8 @@ def load():
     L.cilhip_get_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
     L.cilhip_get_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.cilhip_enable_kernel_timing.argtypes = [vp, C.c_int]
+    L.cilhip_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.cilhip_get_last_timing2.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if the library does not export it
         if name not in ("cilhip_destroy", "cilhip_last_error", "cilhip_icp_default_params"):

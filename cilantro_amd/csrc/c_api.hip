@@ -49,6 +49,9 @@ struct cilhip_ctx {
   IcpState* d_state = nullptr;
   double* d_partials = nullptr;
   int partial_blocks = 0;
+  double* d_stage = nullptr;      // [REDUCE_STAGE_DOUBLES] stage-1 rows of the cross-block reduction
+  double* d_sums = nullptr;       // [SUMS_MAX]
+  bool fused = true;              // search+accumulate in one kernel (false: two kernels)
   unsigned long long* d_count = nullptr;
   uint32_t* d_out_idx = nullptr;  // [ns] original-order results
   float* d_out_d2 = nullptr;
@@ -60,7 +63,7 @@ struct cilhip_ctx {
 
   // timing
   bool kernel_timing = false;
-  double last_loop_ms = 0.0, last_search_ms = 0.0;
+  double last_loop_ms = 0.0, last_search_ms = 0.0, last_acc_ms = 0.0;
   int last_search_launches = 0;
   std::vector<hipEvent_t> ev;
 };
@@ -97,7 +100,8 @@ int cilhip_create(cilhip_ctx** out, int device) {
     return CILHIP_ERR_HIP;
   }
   c->stream = c->own_stream;
-  if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess) {
+  if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&c->d_stage, REDUCE_STAGE_DOUBLES * sizeof(double)) != hipSuccess || hipMalloc(&c->d_sums, SUMS_MAX * sizeof(double)) != hipSuccess) {
     delete c;
     return CILHIP_ERR_HIP;
   }
@@ -128,6 +132,8 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_count) (void)hipFree(c->d_count);
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->d_sums) (void)hipFree(c->d_sums);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -147,6 +153,20 @@ int cilhip_synchronize(cilhip_ctx* c) {
   if (!c) return CILHIP_ERR_INVALID;
   CK(c, hipSetDevice(c->device));
   CK(c, hipStreamSynchronize(c->stream));
+  return CILHIP_OK;
+}
+
+int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
+  if (!c || !key) return CILHIP_ERR_INVALID;
+  if (!strcmp(key, "fused")) { c->fused = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
+  return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
+}
+
+int cilhip_get_last_timing2(cilhip_ctx* c, double* search_ms, double* accumulate_ms) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (search_ms) *search_ms = c->last_search_ms;
+  if (accumulate_ms) *accumulate_ms = c->last_acc_ms;
   return CILHIP_OK;
 }
 
@@ -352,9 +372,9 @@ static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], 
   for (int i = 0; i < SUMS_MAX; ++i) sums[i] = 0.0;
   if (c->ns == 0) return CILHIP_OK;
   launch_iter(a, metric, false, false, nb, c->stream);
-  launch_reduce_partials(c->d_partials, nb, c->d_partials, c->stream);  // in place: block 0's slots become the total
+  launch_reduce_partials(c->d_partials, nb, c->d_stage, c->d_sums, c->stream);
   CK(c, hipGetLastError());
-  CK(c, hipMemcpyAsync(sums, c->d_partials, SUMS_MAX * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipMemcpyAsync(sums, c->d_sums, SUMS_MAX * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   CK(c, hipStreamSynchronize(c->stream));
   return CILHIP_OK;
 }
@@ -479,6 +499,11 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   IterArgs a = make_iter_args(c, p->max_sq_dist);
   SolveArgs sa = make_solve_args(c, p, im, c->src_mean);
   const int nb = sa.nblocks;
+  if (c->ns == 0) {  // no source points: the epilogue runs on all-zero sums (identity step)
+    CK(c, hipMemsetAsync(c->d_sums, 0, SUMS_MAX * sizeof(double), c->stream));
+    sa.nblocks = 0;
+    sa.reduced = c->d_sums;
+  }
   const bool timing = c->kernel_timing && p->max_iter <= 4096;
   hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
   CK(c, hipEventRecord(e_beg, c->stream));
@@ -494,9 +519,24 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     for (size_t st = 0; st < opt_steps; ++st) {
       a.skip_if_inner_done = (st > 0);
       if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
-      if (c->ns) launch_iter(a, im, st == 0, gn && opt_steps > 1 && st == 0, nb, c->stream);
+      if (c->ns) {
+        if (st == 0 && c->fused) {
+          launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
+        } else if (st == 0) {
+          launch_iter(a, IM_NONE, true, true, nb, c->stream);                 // search kernel
+          if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_event(c, nev++), c->stream)); }
+          launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
+        } else {
+          launch_iter(a, im, false, false, nb, c->stream);
+        }
+      }
       if (timing && st == 0) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); ++launches; }
       sa.gn_last_step = (st + 1 == opt_steps);
+      if (c->ns) {
+        const int rows = launch_reduce_stage1(c->d_partials, nb, c->d_stage, c->stream);
+        sa.partials = rows ? c->d_stage : c->d_partials;
+        sa.nblocks = rows ? rows : nb;
+      }
       launch_solve(sa, c->stream);
     }
   }
@@ -512,10 +552,16 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (timing) {
     // only iterations that actually executed (not the early-exit launches after convergence)
     const size_t executed = out->iterations < (size_t)launches ? out->iterations : (size_t)launches;
+    const size_t per = (c->fused || c->ns == 0) ? 2 : 4;
+    c->last_acc_ms = 0.0;
     for (size_t k = 0; k < executed; ++k) {
       float m = 0.f;
-      CK(c, hipEventElapsedTime(&m, c->ev[2 + 2 * k], c->ev[3 + 2 * k]));
+      CK(c, hipEventElapsedTime(&m, c->ev[2 + per * k], c->ev[3 + per * k]));
       c->last_search_ms += m;
+      if (per == 4) {
+        CK(c, hipEventElapsedTime(&m, c->ev[4 + per * k], c->ev[5 + per * k]));
+        c->last_acc_ms += m;
+      }
     }
     c->last_search_launches = (int)executed;
   }
@@ -546,7 +592,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
   const int nb = iter_num_blocks(c->ns);
   if (c->ns) {
     launch_iter(a, im, true, false, nb, c->stream);
-    launch_reduce_partials(c->d_partials, nb, sums_dev, c->stream);
+    launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);
   } else {
     CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));
   }

@@ -75,7 +75,9 @@ struct SolveArgs {
 // kernels.hip
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
 void launch_solve(const SolveArgs& a, hipStream_t s);
-void launch_reduce_partials(const double* partials, int nblocks, double* out, hipStream_t s);
+void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
+int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
+constexpr int REDUCE_STAGE_DOUBLES = 32 * SUMS_MAX;
 void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s);
 void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
                        const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,

@@ -41,41 +41,41 @@ struct NN {
   uint32_t pos;            // position in the sorted target array, NONE_U32 if nothing within the radius
 };
 
-__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, uint32_t beg, uint32_t end,
-                                           float qx, float qy, float qz, NN& best) {
-  for (uint32_t j = beg; j < end; ++j) {
-    const float4 p = pts[j];
-    const float d2 = d2_pinned(qx, qy, qz, p.x, p.y, p.z);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p.w);
-    if (key < best.key) { best.key = key; best.pos = j; }
-  }
-}
-
 // distance from q to the interval [lo,hi], shrunk by the grid margin (never over-estimates)
 __device__ __forceinline__ float axis_gap(float q, float lo, float hi, float margin) {
   return fmaxf(fmaxf(lo - q, q - hi) - margin, 0.0f);
 }
 
-// Exact 1-NN in radius over the uniform grid: expanding Chebyshev shells around the query's cell,
-// each shell scanned as runs of cells along x (contiguous in memory), with conservative box-distance
-// pruning.  Result == brute-force argmin of the pinned f32 d2 with lowest-index tie-break, restricted
-// to d2 < max_sq (strict, as nanoflann.hpp:1901 and kd_tree_utilities.hpp:29).
-__device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best) {
-  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
-  best.pos = NONE_U32;
-  const float BIG = 1.0e9f;
-  const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
-  const float fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG);
-  const float fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
-  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-  {  // query farther than the radius from the whole grid: nothing to find
-    const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
-    const float gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
-    const float gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
-    if ((gx * gx + gy * gy + gz * gz) * KSHRINK >= max_sq) return;
+// Batched candidate scan: 4 independent 16-byte loads in flight per trip (indices clamped to the
+// last element of the range: re-evaluating a candidate never changes the result), so a wave pays
+// one memory round trip per 4 candidates instead of one per candidate.
+__device__ __forceinline__ void scan_range4(const float4* __restrict__ pts, uint32_t beg, uint32_t end,
+                                            float qx, float qy, float qz, NN& best) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 4) {
+    const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+    const float4 p0 = pts[j], p1 = pts[j1], p2 = pts[j2], p3 = pts[j3];
+    const float e0 = d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z), e1 = d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z);
+    const float e2 = d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z), e3 = d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z);
+    const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
+    const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
+    const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
+    const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
+    if (k0 < best.key) { best.key = k0; best.pos = j; }
+    if (k1 < best.key) { best.key = k1; best.pos = j1; }
+    if (k2 < best.key) { best.key = k2; best.pos = j2; }
+    if (k3 < best.key) { best.key = k3; best.pos = j3; }
   }
-  int s = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
-  for (;; ++s) {
+}
+
+// Generic exact search: expanding Chebyshev shells s = s_start, s_start+1, ... around cell (cx,cy,cz)
+// (which may lie outside the grid), each shell scanned as runs of cells along x (contiguous in
+// memory), with conservative box-distance pruning.  `best` carries what inner shells already found.
+// Terminates when the pruning bound proves that no unscanned point can beat or tie the best.
+__device__ __forceinline__ void nn_search_shells(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                              int s_start, NN& best) {
+  for (int s = s_start;; ++s) {
     const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1);
     const int y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
     const int xlo = cx - s, xhi = cx + s;
@@ -98,20 +98,20 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
           if (xa <= xb) {
             const float gx = axis_gap(qx, g.ox + (float)xa * g.cell, g.ox + (float)(xb + 1) * g.cell, g.margin);
             if ((gyz2 + gx * gx) * KSHRINK <= bd)
-              scan_range(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
+              scan_range4(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
           }
         } else {
           if (xlo >= 0 && xlo < g.nx) {
             const float xl = g.ox + (float)xlo * g.cell;
             const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
             if ((gyz2 + gx * gx) * KSHRINK <= bd)
-              scan_range(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, best);
+              scan_range4(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, best);
           }
           if (xhi >= 0 && xhi < g.nx) {
             const float xl = g.ox + (float)xhi * g.cell;
             const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
             if ((gyz2 + gx * gx) * KSHRINK <= __uint_as_float((uint32_t)(best.key >> 32)))
-              scan_range(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, best);
+              scan_range4(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, best);
           }
         }
       }
@@ -130,15 +130,119 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
   }
 }
 
+constexpr int ITER_THREADS = 256;
+constexpr int ITER_WAVES = ITER_THREADS / 64;
+constexpr int LIST_CAP = 10;  // 8 neighbour rows + the two x-neighbours of the own cell
+
+// Exact 1-NN in radius (== brute-force argmin of the pinned f32 d2, lowest-index tie-break, d2 < max_sq
+// strict as nanoflann.hpp:1901 / kd_tree_utilities.hpp:29).
+//
+// Fast path (query inside the grid): scan the own cell; from the best so far decide, per neighbour
+// row of the 3x3x3 block, which run of cells along x can still hold a nearer point; fetch all run
+// boundaries with independent loads (one round trip); push the non-empty runs on a per-lane LDS
+// work list and scan them in ONE loop (dense trips: lanes do not wait on each other's culled rows).
+// If the 3x3x3 block does not prove exactness (sparse data / large radius) or the query lies outside
+// the grid, continue with the generic shell search.
+// lst: this lane's column of the LDS work list, entries at lst[k * ITER_THREADS].
+__device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best,
+                                          uint2* lst) {
+  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  best.pos = NONE_U32;
+  const float BIG = 1.0e9f;
+  const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
+  const float fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG);
+  const float fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
+  if (!inside) {
+    // query farther than the radius from the whole grid: nothing to find
+    const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
+    const float gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
+    const float gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+    if ((gx * gx + gy * gy + gz * gz) * KSHRINK >= max_sq) return;
+    const int s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+    nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
+    return;
+  }
+  const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+  const uint32_t b0 = g.cell_start[cid], e0 = g.cell_start[cid + 1];
+  scan_range4(g.pts, b0, e0, qx, qy, qz, best);
+  const float bd = __uint_as_float((uint32_t)(best.key >> 32));
+
+  // shrunk distances from q to the six faces of its own cell
+  const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
+  const float gmx = fmaxf(qx - xl - g.margin, 0.0f), gpx = fmaxf(xl + g.cell - qx - g.margin, 0.0f);
+  const float gmy = fmaxf(qy - yl - g.margin, 0.0f), gpy = fmaxf(yl + g.cell - qy - g.margin, 0.0f);
+  const float gmz = fmaxf(qz - zl - g.margin, 0.0f), gpz = fmaxf(zl + g.cell - qz - g.margin, 0.0f);
+  const bool hmx = cx > 0, hpx = cx + 1 < g.nx, hmy = cy > 0, hpy = cy + 1 < g.ny, hmz = cz > 0, hpz = cz + 1 < g.nz;
+  {  // nothing outside the own cell can beat or tie the best: done (no neighbour = no constraint)
+    float b = INFINITY;
+    if (hmx) b = fminf(b, gmx);
+    if (hpx) b = fminf(b, gpx);
+    if (hmy) b = fminf(b, gmy);
+    if (hpy) b = fminf(b, gpy);
+    if (hmz) b = fminf(b, gmz);
+    if (hpz) b = fminf(b, gpz);
+    if (b == INFINITY || bd < b * b * KSHRINK) return;
+  }
+  const float ax2[3] = {gmx * gmx, 0.0f, gpx * gpx};
+  const float ay2[3] = {gmy * gmy, 0.0f, gpy * gpy};
+  const float az2[3] = {gmz * gmz, 0.0f, gpz * gpz};
+  const bool okx[3] = {hmx, true, hpx}, oky[3] = {hmy, true, hpy}, okz[3] = {hmz, true, hpz};
+
+  // run boundaries of the 9 rows: unconditional independent loads (index 0 when the row is culled)
+  uint32_t ia[9], ib[9];
+  bool pass[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int dz = r / 3, dy = r % 3;  // 0,1,2 <-> -1,0,+1
+    const float gyz2 = az2[dz] + ay2[dy];
+    const bool p = okz[dz] && oky[dy] && (gyz2 * KSHRINK <= bd);
+    const bool left = p && okx[0] && ((gyz2 + ax2[0]) * KSHRINK <= bd);
+    const bool right = p && okx[2] && ((gyz2 + ax2[2]) * KSHRINK <= bd);
+    const uint32_t row = cid + (uint32_t)((dz - 1) * g.ny * g.nx + (dy - 1) * g.nx);  // wraps harmlessly when !p
+    pass[r] = (r == 4) ? (left || right) : p;
+    ia[r] = pass[r] ? (row - (left ? 1u : 0u)) : 0u;
+    ib[r] = pass[r] ? (row + 1u + (right ? 1u : 0u)) : 0u;
+  }
+  uint32_t va[9], vb[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { va[r] = g.cell_start[ia[r]]; vb[r] = g.cell_start[ib[r]]; }
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    if (r == 4) {  // own row: the own cell [b0,e0) is already scanned -> up to two side runs
+      if (pass[r] && b0 > va[r]) { lst[cnt * ITER_THREADS] = make_uint2(va[r], b0); ++cnt; }
+      if (pass[r] && vb[r] > e0) { lst[cnt * ITER_THREADS] = make_uint2(e0, vb[r]); ++cnt; }
+    } else {
+      if (pass[r] && vb[r] > va[r]) { lst[cnt * ITER_THREADS] = make_uint2(va[r], vb[r]); ++cnt; }
+    }
+  }
+  for (int k = 0; k < cnt; ++k) {
+    const uint2 r = lst[k * ITER_THREADS];
+    scan_range4(g.pts, r.x, r.y, qx, qy, qz, best);
+  }
+  {  // does the 3x3x3 block prove exactness?  faces of the block that still have cells beyond them
+    float b = INFINITY;
+    if (cx - 1 > 0) b = fminf(b, gmx + g.cell);
+    if (cx + 2 < g.nx) b = fminf(b, gpx + g.cell);
+    if (cy - 1 > 0) b = fminf(b, gmy + g.cell);
+    if (cy + 2 < g.ny) b = fminf(b, gpy + g.cell);
+    if (cz - 1 > 0) b = fminf(b, gmz + g.cell);
+    if (cz + 2 < g.nz) b = fminf(b, gpz + g.cell);
+    if (b == INFINITY) return;
+    b -= g.margin;
+    if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) return;
+  }
+  nn_search_shells(g, qx, qy, qz, cx, cy, cz, 2, best);
+}
+
 // ---- accumulation helpers ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
-
-constexpr int ITER_THREADS = 256;
-constexpr int ITER_WAVES = ITER_THREADS / 64;
 
 template <int METRIC>
 struct AccTraits {
@@ -167,6 +271,9 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) { it[i] = st->innert[i]; smt[i] = st->smt[i]; }
 
+  __shared__ uint2 worklist[SEARCH ? LIST_CAP * ITER_THREADS : 1];
+  uint2* lst = worklist + (SEARCH ? threadIdx.x : 0);
+
   double accA[TR::NA];
   double accB[TR::NB > 0 ? TR::NB : 1];
 #pragma unroll
@@ -189,7 +296,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
     uint32_t pos;
     if (SEARCH) {
       NN best;
-      nn_search(a.grid, qx, qy, qz, a.max_sq, best);
+      nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
       pos = best.pos;
       if (STORE) { a.nn_pos[i] = pos; a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
     } else {
@@ -321,14 +428,42 @@ __device__ void reduce_partials_block(const double* __restrict__ partials, int n
   __syncthreads();
 }
 
+// Stage 1 of the cross-block reduction: REDUCE_GROUPS blocks, each folding a contiguous slice of the
+// per-block partials (fixed order => deterministic).  A single block reading all 2048 x 48 doubles
+// is latency-bound (~170 us measured); 32 blocks do it in a few us.
+constexpr int REDUCE_GROUPS = 32;
+
+__global__ __launch_bounds__(256) void k_reduce_stage1(const double* __restrict__ partials, int nblocks, double* __restrict__ stage) {
+  __shared__ double sums[SUMS_MAX];
+  const int per = (nblocks + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
+  const int b0 = blockIdx.x * per;
+  const int b1 = min(b0 + per, nblocks);
+  reduce_partials_block(partials + (size_t)b0 * SUMS_MAX, max(b1 - b0, 0), sums);
+  if (threadIdx.x < SUMS_MAX) stage[blockIdx.x * SUMS_MAX + threadIdx.x] = sums[threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* partials, int nblocks, double* out) {
   __shared__ double sums[SUMS_MAX];
   reduce_partials_block(partials, nblocks, sums);
   if (threadIdx.x < SUMS_MAX) out[threadIdx.x] = sums[threadIdx.x];
 }
 
-void launch_reduce_partials(const double* partials, int nblocks, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, partials, nblocks, out);
+// partials[nblocks][SUMS_MAX] -> out[SUMS_MAX]; `stage` is scratch of REDUCE_GROUPS*SUMS_MAX doubles.
+void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s) {
+  if (nblocks > 2 * REDUCE_GROUPS) {
+    hipLaunchKernelGGL(k_reduce_stage1, dim3(REDUCE_GROUPS), dim3(256), 0, s, partials, nblocks, stage);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, (const double*)stage, REDUCE_GROUPS, out);
+  } else {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, partials, nblocks, out);
+  }
+}
+
+// Stage 1 only (the epilogue kernel k_solve folds the REDUCE_GROUPS rows itself).  Returns the number
+// of rows k_solve has to read from `stage`, or 0 if it should read `partials` directly.
+int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s) {
+  if (nblocks <= 2 * REDUCE_GROUPS) return 0;
+  hipLaunchKernelGGL(k_reduce_stage1, dim3(REDUCE_GROUPS), dim3(256), 0, s, partials, nblocks, stage);
+  return REDUCE_GROUPS;
 }
 
 __device__ void reset_inner(IcpState* st) {
@@ -367,9 +502,6 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
         st->inner_done = 1;
         for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = sums[i];
       } else {
-        if (st->pad0 == 0 && st->dLd[0] == 1.0 && st->dtd[0] == 0.0 && st->dLd[4] == 1.0) {
-          // keep the first Gauss-Newton step's sums for inspection (AtA/Atb of the host API)
-        }
         double AtA[36], Atb[6], dth[6];
         gn_normal_equations(sums, has_p2p ? (double)a.w_p2p : 0.0, has_p2pl ? (double)a.w_p2pl : 0.0, AtA, Atb);
         ldlt6_solve(AtA, Atb, dth);
@@ -473,6 +605,8 @@ void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long*
 // computeResiduals() of both ICP classes (icp_single_transform_combined_metric.hpp:220-243,
 // icp_single_transform_point_to_point_metric.hpp:68-85): unbounded exact 1-NN, then the metric value.
 __global__ __launch_bounds__(256) void k_residuals(IterArgs a, int metric, float w_p2p, float w_p2pl, float* out) {
+  __shared__ uint2 worklist[LIST_CAP * ITER_THREADS];
+  uint2* lst = worklist + threadIdx.x;
   float T[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) T[i] = a.state->T[i];
@@ -481,7 +615,7 @@ __global__ __launch_bounds__(256) void k_residuals(IterArgs a, int metric, float
     float qx, qy, qz;
     transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
     NN best;
-    nn_search(a.grid, qx, qy, qz, a.max_sq, best);
+    nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
     float v = __uint_as_float(0x7fc00000u);  // NaN when the target is empty (:221-224)
     if (best.pos != NONE_U32) {
       const float4 p = a.grid.pts[best.pos];

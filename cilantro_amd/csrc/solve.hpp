@@ -175,10 +175,11 @@ CILHIP_HD void ldlt6_solve(const double Ain[36], const double bin[6], double x[6
 CILHIP_HD void rigid_gn_update(const double dth[6], double L[9], double t[3]) {
   const double ax = dth[0], ay = dth[1], az = dth[2];
   const double na = sqrt(ax * ax + ay * ay + az * az);
-  const double theta = atan(na);
+  // theta = atan(|a|):  sin(theta) = |a| / sqrt(1+|a|^2), cos(theta) = 1 / sqrt(1+|a|^2)  (exact identities;
+  // avoids three f64 libm calls in the single-lane device epilogue)
   double ux = 0.0, uy = 0.0, uz = 0.0;
   if (na > 0.0) { ux = ax / na; uy = ay / na; uz = az / na; }
-  const double s = sin(theta), c = cos(theta);
+  const double c = 1.0 / sqrt(1.0 + na * na), s = na * c;
   const double sx = s * ux, sy = s * uy, sz = s * uz;
   const double c1x = (1.0 - c) * ux, c1y = (1.0 - c) * uy, c1z = (1.0 - c) * uz;
   double Ra[9], tmp;

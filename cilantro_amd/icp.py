@@ -189,6 +189,14 @@ class Context:
     def enable_kernel_timing(self, on=True):
         self._ck(self._L.cilhip_enable_kernel_timing(self._h, 1 if on else 0))
 
+    def set_option(self, key, value):
+        self._ck(self._L.cilhip_set_option(self._h, key.encode(), float(value)))
+
+    def last_timing2(self):
+        a = C.c_double(0); b = C.c_double(0)
+        self._ck(self._L.cilhip_get_last_timing2(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def last_timing(self):
         a = C.c_double(0); b = C.c_double(0); n = C.c_int(0)
         self._ck(self._L.cilhip_get_last_timing(self._h, C.byref(a), C.byref(b), C.byref(n)))

@@ -170,6 +170,14 @@ int cilhip_get_last_timing(cilhip_ctx* ctx, double* loop_ms, double* search_kern
 /* Record a hipEvent pair around every fused search+accumulate launch of cilhip_icp_run (off by
  * default: the extra event records perturb a back-to-back loop slightly). */
 int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
+/* Tuning knobs (never change results beyond f64 summation order):
+ *   "fused" (default 1): 1 = one fused search+accumulate kernel per iteration,
+ *                        0 = search kernel (stores the matches) + streaming accumulation kernel.
+ *   "kernel_timing": same as cilhip_enable_kernel_timing. */
+int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
+/* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
+ * kernels of the last cilhip_icp_run (sum over executed iterations). */
+int cilhip_get_last_timing2(cilhip_ctx* ctx, double* search_ms, double* accumulate_ms);
 
 #ifdef __cplusplus
 }
