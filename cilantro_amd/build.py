@@ -30,7 +30,13 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), tag=""):
+    """tag/defines: build a variant library libcilantro_hip<tag>.so with extra -D flags (dev A/B runs;
+    select it with CILHIP_LIB_PATH)."""
+    global OBJDIR, LIB
+    if tag:
+        OBJDIR = os.path.join(HERE, "lib", "obj" + tag)
+        LIB = os.path.join(LIBDIR, f"libcilantro_hip{tag}.so")
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
@@ -40,7 +46,7 @@ def build(force=False, verbose=False):
         op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", sp, "-o", op])
+            jobs.append([HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -60,4 +66,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    tags = [a[6:] for a in sys.argv[1:] if a.startswith("--tag=")]
+    print(build(force="--force" in sys.argv, verbose=True, defines=defs, tag=tags[0] if tags else ""))

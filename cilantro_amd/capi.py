@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcilantro_hip.so")
+LIB_PATH = os.environ.get("CILHIP_LIB_PATH") or os.path.join(_HERE, "lib", "libcilantro_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -51,7 +51,8 @@ struct cilhip_ctx {
   int partial_blocks = 0;
   double* d_stage = nullptr;      // [REDUCE_STAGE_DOUBLES] stage-1 rows of the cross-block reduction
   double* d_sums = nullptr;       // [SUMS_MAX]
-  bool fused = true;              // search+accumulate in one kernel (false: two kernels)
+  bool fused = false;             // true: search+accumulate in one kernel; false: search kernel + streaming accumulate kernel (faster: the search runs at 2x the occupancy)
+  double cell_occupancy = 4.0;    // target points per grid cell (takes effect at the next set_target)
   unsigned long long* d_count = nullptr;
   uint32_t* d_out_idx = nullptr;  // [ns] original-order results
   float* d_out_d2 = nullptr;
@@ -159,6 +160,7 @@ int cilhip_synchronize(cilhip_ctx* c) {
 int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!c || !key) return CILHIP_ERR_INVALID;
   if (!strcmp(key, "fused")) { c->fused = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "cell_occupancy")) { c->cell_occupancy = value; return CILHIP_OK; }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
 }
@@ -196,7 +198,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (nrm) { rc = upload(c, nrm, 3 * n, mem, &d_nrm); if (rc) { (void)hipFree(d_xyz); return rc; } }
   GridBuildResult r{};
   double mean[3];
-  hipError_t e = build_grid(d_xyz, d_nrm, (uint32_t)n, c->stream, &r, mean);
+  hipError_t e = build_grid(d_xyz, d_nrm, (uint32_t)n, c->stream, &r, mean, c->cell_occupancy);
   (void)hipFree(d_xyz);
   if (d_nrm) (void)hipFree(d_nrm);
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
@@ -591,7 +593,12 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   const int nb = iter_num_blocks(c->ns);
   if (c->ns) {
-    launch_iter(a, im, true, false, nb, c->stream);
+    if (c->fused) {
+      launch_iter(a, im, true, false, nb, c->stream);
+    } else {
+      launch_iter(a, IM_NONE, true, true, nb, c->stream);
+      launch_iter(a, im, false, false, nb, c->stream);
+    }
     launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);
   } else {
     CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));

@@ -183,7 +183,8 @@ static void set_dims(GridDev& g, const float lo[3], const float hi[3], double ce
   g.margin = g.cell * (1.0f / 512.0f);
 }
 
-hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStream_t s, GridBuildResult* out, double mean_out[3]) {
+hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStream_t s, GridBuildResult* out, double mean_out[3],
+                      double target_occupancy) {
   GridDev g{};
   g.n = n; g.pts = nullptr; g.nrm = nullptr; g.cell_start = nullptr;
   out->avg_occupancy = 0.0;
@@ -208,7 +209,7 @@ hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStr
   // volume with degenerate extents floored so planar / linear clouds still get a sane first guess
   double vol = 1.0;
   for (int c = 0; c < 3; ++c) vol *= std::max(ext[c], maxext * 1e-3);
-  const double TARGET = 4.0;  // points per cell for a volumetric cloud
+  const double TARGET = target_occupancy > 0.0 ? target_occupancy : 4.0;  // points per cell for a volumetric cloud
   double cell = std::cbrt(vol * TARGET / (double)n);
 
   uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr, *cs = nullptr;
@@ -232,8 +233,8 @@ hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStr
     HIP_TRY(hipStreamSynchronize(s));
     occ /= (double)n;
     // adaptive refinement for surface-like / clustered clouds: too many candidates per cell -> shrink
-    if (occ <= 12.0) break;
-    const double shrink = std::min(0.85, std::max(0.3, std::pow(8.0 / occ, 1.0 / 2.5)));
+    if (occ <= 3.0 * TARGET) break;
+    const double shrink = std::min(0.85, std::max(0.3, std::pow(2.0 * TARGET / occ, 1.0 / 2.5)));
     const double new_cell = (double)g.cell * shrink;
     GridDev probe = g;
     set_dims(probe, lo, hi, new_cell);

@@ -95,7 +95,7 @@ struct GridBuildResult {
 // Builds the grid for n points (device xyz, optional device normals).  Allocates the sorted
 // arrays and the cell table (freed by free_grid).  Returns hipSuccess or an error.
 hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStream_t s,
-                      GridBuildResult* out, double mean_out[3]);
+                      GridBuildResult* out, double mean_out[3], double target_occupancy);
 void free_grid(GridDev& g);
 // Sorts the source by the target-grid cell of T*s; writes {x,y,z,orig} records.  d_out preallocated [n].
 hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out,

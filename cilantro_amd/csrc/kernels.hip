@@ -26,6 +26,10 @@
 
 namespace cilhip {
 
+#ifndef CILHIP_CAND
+#define CILHIP_CAND 4 /* candidates per lane per trip of the flattened work-list loop */
+#endif
+
 #define KSHRINK 0.99999905f /* 1 - 2^-20: covers the <= 2^-22 relative rounding of the f32 d2 */
 
 // d2 exactly as nanoflann's L2_Adaptor::evalMetric computes it for DIM=3
@@ -218,9 +222,41 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
       if (pass[r] && vb[r] > va[r]) { lst[cnt * ITER_THREADS] = make_uint2(va[r], vb[r]); ++cnt; }
     }
   }
-  for (int k = 0; k < cnt; ++k) {
-    const uint2 r = lst[k * ITER_THREADS];
-    scan_range4(g.pts, r.x, r.y, qx, qy, qz, best);
+  {
+    // ONE flattened loop over this lane's work list: every trip each lane evaluates its next
+    // CILHIP_CAND candidates, popping the next range when the current one is exhausted, so the
+    // wave runs max_lane(total trips) instead of sum_k max_lane(trips of range k).
+    int k = 0;
+    uint32_t j = 0, e = 0;
+    for (;;) {
+      if (j >= e) {
+        if (k >= cnt) break;
+        const uint2 r = lst[k * ITER_THREADS];
+        ++k;
+        j = r.x; e = r.y;
+      }
+      const uint32_t last = e - 1;
+      const float4 p0 = g.pts[j];
+      const uint32_t j1 = min(j + 1, last);
+      const float4 p1 = g.pts[j1];
+#if CILHIP_CAND == 4
+      const uint32_t j2 = min(j + 2, last), j3 = min(j + 3, last);
+      const float4 p2 = g.pts[j2], p3 = g.pts[j3];
+#endif
+      const float e0 = d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z), e1 = d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z);
+      const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
+      const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
+      if (k0 < best.key) { best.key = k0; best.pos = j; }
+      if (k1 < best.key) { best.key = k1; best.pos = j1; }
+#if CILHIP_CAND == 4
+      const float e2 = d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z), e3 = d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z);
+      const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
+      const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
+      if (k2 < best.key) { best.key = k2; best.pos = j2; }
+      if (k3 < best.key) { best.key = k3; best.pos = j3; }
+#endif
+      j += CILHIP_CAND;
+    }
   }
   {  // does the 3x3x3 block prove exactness?  faces of the block that still have cells beyond them
     float b = INFINITY;

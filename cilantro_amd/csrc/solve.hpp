@@ -275,7 +275,7 @@ CILHIP_HD float compose_update(const double Lin[9], const double t[3], const flo
   return (float)sqrt(dn);
 }
 
-// The pinned f32 transform expression (see oracle/icp_oracle.h): q_r = (L_r0*x + (L_r1*y + L_r2*z)) + t_r,
+// The pinned f32 transform expression (DESIGN.md "Numeric contract"): q_r = (L_r0*x + (L_r1*y + L_r2*z)) + t_r,
 // every operation individually rounded -- no FMA contraction.
 // common_transformable_feature_adaptors.hpp:28-33.
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -171,8 +171,9 @@ int cilhip_get_last_timing(cilhip_ctx* ctx, double* loop_ms, double* search_kern
  * default: the extra event records perturb a back-to-back loop slightly). */
 int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
 /* Tuning knobs (never change results beyond f64 summation order):
- *   "fused" (default 1): 1 = one fused search+accumulate kernel per iteration,
+ *   "fused" (default 0): 1 = one fused search+accumulate kernel per iteration,
  *                        0 = search kernel (stores the matches) + streaming accumulation kernel.
+ *   "cell_occupancy" (default 4): target points per grid cell, used by the next cilhip_set_target.
  *   "kernel_timing": same as cilhip_enable_kernel_timing. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation

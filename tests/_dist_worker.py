@@ -1,0 +1,108 @@
+"""Worker of tests/test_distributed_cpu.py: runs ShardedRigidICP over gloo with a TEST-ONLY per-rank
+engine (oracle kNN + numpy estimator) and prints the final transform as JSON on rank 0."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cilantro_amd import capi, distributed, synthetic as syn  # noqa: E402
+from oracle import oracle as orc  # noqa: E402  (tests may use the oracle)
+
+
+class OracleShardEngine:
+    """Same interface as cilantro_amd.distributed.HipShardEngine, computed on the CPU by the checker."""
+
+    def __init__(self, dst, dst_n, src_shard):
+        self.dst, self.dst_n, self.src = dst, dst_n, np.ascontiguousarray(src_shard)
+        self.tree = orc.KDTree(dst)
+        self.sums = torch.zeros(distributed.SUMS_LEN, dtype=torch.float64)
+        self.dst_mean = orc.mean3(dst)
+
+    def local_source_sum(self):
+        return self.src.astype(np.float64).sum(0), len(self.src)
+
+    def begin(self, params, T0, gmean):
+        self.p, self.T, self.gmean = params, np.asarray(T0, np.float32).copy(), np.asarray(gmean, np.float32)
+        self.iters, self.delta, self.nc, self.done = 0, np.inf, 0, False
+
+    def partial_sums(self):
+        self.sums.zero_()
+        if self.done:
+            return self.sums
+        q = orc.transform_points(self.T, self.src)
+        di, si, _ = self.tree.find_correspondences(q, self.p.max_sq_dist, num_threads=1)
+        s = np.zeros(distributed.SUMS_LEN)
+        if self.p.metric == capi.METRIC_POINT_TO_POINT:
+            _, s16, _ = orc.estimate_p2p(self.dst, q, di, si, orc.MODE_MIXED)
+            s[:16] = s16
+        else:
+            smt = orc.transform_points(self.T, self.gmean.reshape(1, 3))[0]
+            _, AtA, Atb, _ = orc.estimate_combined(self.dst, self.dst_n, q, di, si, 0.0, 1.0, self.dst_mean, smt, 1, 1e-5, orc.MODE_MIXED)
+            s[0] = len(di)
+            s[1:22] = AtA[np.triu_indices(6)]
+            s[22:28] = Atb
+        self.sums.copy_(torch.from_numpy(s))
+        return self.sums
+
+    def apply_sums(self, sums):
+        if self.done:
+            return
+        s = sums.numpy()
+        n = s[0]
+        L, t = np.eye(3), np.zeros(3)
+        if self.p.metric == capi.METRIC_POINT_TO_POINT:
+            if n > 0:
+                mp, mq = s[1:4] / n, s[4:7] / n
+                S = s[7:16].reshape(3, 3) / n - np.outer(mp, mq)
+                U, _, Vt = np.linalg.svd(S)
+                if np.linalg.det(U @ Vt) < 0:
+                    U[:, 2] *= -1
+                L = U @ Vt
+                t = mp - L @ mq
+        elif n > 0:
+            AtA = np.zeros((6, 6)); AtA[np.triu_indices(6)] = s[1:22]; AtA = AtA + np.triu(AtA, 1).T
+            x = np.linalg.solve(AtA, s[22:28])
+            na = np.linalg.norm(x[:3]); th = np.arctan(na); u = x[:3] / na if na > 0 else np.zeros(3)
+            K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
+            Ra = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+            L = Ra @ Ra
+            smt = orc.transform_points(self.T, self.gmean.reshape(1, 3))[0].astype(np.float64)
+            t = Ra @ (np.cos(th) * x[3:]) - L @ smt + self.dst_mean.astype(np.float64)
+        R = orc.nearest_rotation(L)
+        Tn = np.eye(4)
+        Tn[:3, :3] = R @ self.T[:3, :3].astype(np.float64)
+        Tn[:3, 3] = R @ self.T[:3, 3].astype(np.float64) + t
+        self.T = Tn.astype(np.float32)
+        self.delta = float(np.sqrt(((R - np.eye(3)) ** 2).sum() + (t ** 2).sum()))
+        self.iters += 1
+        self.nc = int(round(n))
+        self.done = self.delta < self.p.conv_tol
+
+    def state(self):
+        return self.T, self.iters, self.delta, self.nc
+
+
+def main():
+    metric = int(sys.argv[1]); n = int(sys.argv[2])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    d = syn.make_pair(n, perturb=0.5)
+    lo, hi = distributed.shard_bounds(n, rank, world)
+    eng = OracleShardEngine(d["dst"], d["dst_n"], d["src"][lo:hi])
+    p = distributed.default_params(metric=metric, max_iter=12, conv_tol=1e-6, max_sq_dist=float(d["max_sq_dist"]))
+    T, iters, delta, nc = distributed.ShardedRigidICP(eng, dist).estimate(p, check_every=1)
+    allT = [None] * world
+    dist.all_gather_object(allT, T.tolist())
+    if rank == 0:
+        print("RESULT " + json.dumps({"T": T.tolist(), "iters": iters, "delta": delta, "ncorr": nc, "world": world,
+                                       "identical": all(a == allT[0] for a in allT)}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cilantro_hip/c_api.h declares.
+No compute calls are made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from cilantro_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cilantro_hip", "c_api.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cilhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_what_the_binding_lists():
+    assert sorted(capi.SYMBOLS) == declared_symbols()
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    raw = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), f"{name} is declared in c_api.h but not exported by libcilantro_hip.so"
+
+
+def test_header_cites_reference_interfaces():
+    txt = open(HEADER).read()
+    for needle in ("icp_base.hpp:68-87", "kd_tree.hpp:162-170", "transform_estimation.hpp:237-367",
+                   "transform_estimation.hpp\n * :11-48", "correspondence_search_kd_tree.hpp:107-229"):
+        assert needle in txt, needle
+
+
+def test_no_device_fails_loudly(hip_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert hip_lib.cilhip_create(ctypes.byref(h), 0) == capi.ERR_NO_DEVICE and not h.value
+    from cilantro_amd.icp import Context
+
+    with pytest.raises(capi.CilhipError):
+        Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under cilantro_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "cilantro_amd")
+    bad = re.compile(r"(^\s*(import|from)\s+oracle\b)|liboracle|libref_nanoflann|#include\s*[<\"][^>\"]*oracle|oracle/_ref", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not bad.search(src), os.path.join(dirpath, f)
+    for f in ("c_api.h", "icp.hpp"):
+        p = os.path.join(ROOT, "include", "cilantro_hip", f)
+        if os.path.exists(p):
+            assert not bad.search(open(p).read())
+    # and the shared library has no dynamic dependency on it
+    import subprocess
+
+    deps = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in deps and "nanoflann" not in deps

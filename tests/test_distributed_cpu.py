@@ -1,0 +1,45 @@
+"""CPU: the N>1 path (source-sharded ICP, one all-reduce(sum) per iteration) with world_size 2 over
+gloo.  The per-rank compute is a test-only engine (the oracle); what is under test is the product's
+sharding / reduction protocol in cilantro_amd/distributed.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cilantro_amd import synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(world, metric, n):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(metric), str(n)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_sharded_icp_world2_matches_single_process(orc, metric):
+    n = 6000
+    r2 = _run(2, metric, n)
+    assert r2["world"] == 2 and r2["identical"]          # every rank ends with the bit-identical transform
+    d = syn.make_pair(n, perturb=0.5)
+    p = orc.make_params(metric=metric, max_iter=12, conv_tol=1e-6, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+    ref = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+    T2 = np.array(r2["T"], np.float64)
+    assert np.linalg.norm(T2 - ref["T"]) <= 1e-5
+    assert abs(r2["iters"] - ref["iterations"]) <= 1 and r2["ncorr"] == ref["last_ncorr"]
+    assert np.linalg.norm(T2 - d["T_true"]) < 5e-4

@@ -231,3 +231,53 @@ def test_run_to_run_bitwise_reproducible(hip_lib):
         icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0)
         outs.append(icp.estimate().getTransform().tobytes())
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_residuals_vs_oracle(orc, hip_lib):
+    # computeResiduals(): icp_single_transform_combined_metric.hpp:220-243 / point_to_point_metric.hpp:68-85
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f
+
+    d = syn.make_pair(50000, perturb=0.4)
+    f = np.float32
+    for metric in (0, 1):
+        icp = (SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"]) if metric else
+               SimplePointToPointMetricRigidICP3f(d["dst"], d["src"]))
+        icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+        if metric:
+            icp.setPointToPointMetricWeight(0.25)
+        T = icp.estimate().getTransform()
+        res = icp.getResiduals()
+        q = orc.transform_points(T, d["src"])
+        bi, _ = orc.nn_brute(d["dst"], q, np.float32(3.4e38))
+        p = d["dst"][bi]
+        dx, dy, dz = p[:, 0] - q[:, 0], p[:, 1] - q[:, 1], p[:, 2] - q[:, 2]
+        sq = dx * dx + (dy * dy + dz * dz)
+        if metric == 0:
+            exp = sq
+        else:
+            n = d["dst_n"][bi]
+            pd = n[:, 0] * dx + (n[:, 1] * dy + n[:, 2] * dz)
+            exp = f(0.25) * sq + (f(1.0) * pd) * pd
+        assert np.array_equal(res, exp.astype(np.float32))
+
+
+def test_torch_device_inputs_and_shard_engine(orc, hip_lib):
+    import torch
+
+    from cilantro_amd import distributed
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(200000, perturb=0.5)
+    dst, nrm, src = (torch.from_numpy(d[k]).cuda() for k in ("dst", "dst_n", "src"))
+    icp = SimpleCombinedMetricRigidICP3f(dst, nrm, src, stream=torch.cuda.current_stream().cuda_stream)
+    icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+    T1 = icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0).estimate().getTransform()
+    # the sharded protocol with one rank must reproduce icp_run bit for bit (same kernels, same order)
+    eng = distributed.HipShardEngine(dst, nrm, src, 0)
+    p = distributed.default_params(max_iter=6, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+    T2, iters, delta, nc = distributed.ShardedRigidICP(eng, None).estimate(p)
+    assert iters == 6 and np.array_equal(T1, T2) and nc == icp.last_ncorr_
+    # fused and unfused kernels agree to f64 summation-order accuracy
+    icp._ctx.set_option("fused", 1)
+    T3 = icp.estimate().getTransform()
+    assert np.abs(T3 - T1).max() <= 1e-7

@@ -1,0 +1,45 @@
+"""CPU: host-side logic that needs no GPU (engine option validation, transform layout, sharding)."""
+import numpy as np
+import pytest
+
+from cilantro_amd import capi, distributed
+from cilantro_amd.icp import CorrespondenceSearchDirection, CorrespondenceSearchHIP, _T_from_abi, _T_to_abi
+
+
+def test_transform_abi_is_eigen_column_major():
+    T = np.arange(16, dtype=np.float32).reshape(4, 4)
+    a = _T_to_abi(T)
+    # Eigen::Transform<float,3,Isometry>::data(): column-major -> element (r,c) at [c*4+r]
+    assert a[1] == T[1, 0] and a[4] == T[0, 1] and a[12] == T[0, 3] and a[14] == T[2, 3]
+    assert np.array_equal(_T_from_abi(a), T)
+
+
+def test_engine_defaults_and_unsupported_options():
+    e = CorrespondenceSearchHIP(ctx=None)
+    # correspondence_search_kd_tree.hpp:47-51 defaults
+    assert e.getSearchDirection() == CorrespondenceSearchDirection.SECOND_TO_FIRST
+    assert e.getMaxDistance() == np.float32(0.01 * 0.01) and e.getInlierFraction() == 1.0
+    assert not e.getRequireReciprocality() and not e.getOneToOne()
+    assert e.setMaxDistance(0.1 * 0.1) is e and e.getMaxDistance() == np.float32(0.1 * 0.1)
+    for bad in (lambda: e.setSearchDirection(CorrespondenceSearchDirection.BOTH),
+                lambda: e.setInlierFraction(0.5), lambda: e.setRequireReciprocality(True), lambda: e.setOneToOne(True)):
+        with pytest.raises(NotImplementedError):
+            bad()
+    assert e.setOneToOne(False) is e and e.setInlierFraction(1.0) is e
+
+
+@pytest.mark.parametrize("n,world", [(10, 1), (10, 3), (7, 8), (1000001, 8), (0, 4)])
+def test_shard_bounds_partition(n, world):
+    parts = [distributed.shard_bounds(n, r, world) for r in range(world)]
+    assert parts[0][0] == 0 and parts[-1][1] == n
+    for (a, b), (c, d) in zip(parts, parts[1:]):
+        assert b == c and b >= a
+    sizes = [b - a for a, b in parts]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_default_params_match_reference_defaults():
+    p = distributed.default_params()
+    assert p.metric == capi.METRIC_COMBINED and p.w_p2p == 0.0 and p.w_p2pl == 1.0      # combined_metric.hpp:44-47
+    assert p.max_iter == 15 and abs(p.conv_tol - 1e-5) < 1e-12                           # icp_base.hpp:24-25
+    assert p.max_opt_iter == 1 and abs(p.max_sq_dist - 1e-4) < 1e-10

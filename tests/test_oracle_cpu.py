@@ -1,0 +1,206 @@
+"""CPU tests (-m "not gpu"): the oracle against the reference's golden vectors, known answers and
+independent numpy restatements.  No GPU, no /root/reference needed (golden fixtures are committed)."""
+import os
+
+import numpy as np
+import pytest
+
+from cilantro_amd import synthetic as syn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def knn_gold():
+    return np.load(os.path.join(GOLD, "knn_golden.npz"))
+
+
+def test_kd_tree_example_known_answer(orc, knn_gold):
+    # examples/kd_tree.cpp:6-19 -> by hand: idx {0,3}, d2 {0.18, 0.38}
+    ii, dd = orc.KDTree(knn_gold["cube"]).knn_in_radius(knn_gold["cube_q"], 2, 1.001)
+    assert list(ii) == [0, 3]
+    np.testing.assert_allclose(dd, [0.18, 0.38], rtol=1e-6)
+    assert list(knn_gold["cube_idx"]) == [0, 3] and np.array_equal(dd, knn_gold["cube_d2"])
+
+
+@pytest.mark.parametrize("name", ["r_small", "r_mid", "r_inf"])
+def test_oracle_kdtree_matches_reference_nanoflann_golden(orc, knn_gold, name):
+    dst, q, r2 = knn_gold["dst"], knn_gold["q"], knn_gold[f"{name}_r2"]
+    tree = orc.KDTree(dst)
+    gi, gd = knn_gold[f"{name}_knn3_idx"], knn_gold[f"{name}_knn3_d2"]
+    for i in range(len(q)):
+        ii, dd = tree.knn_in_radius(q[i], 3, r2)
+        n = int((gi[i] >= 0).sum())
+        assert len(ii) == n and np.array_equal(ii, gi[i, :n]) and np.array_equal(dd, gd[i, :n]), i
+    di, si, dv = tree.find_correspondences(q, r2)
+    assert np.array_equal(di, knn_gold[f"{name}_corr_first"])
+    assert np.array_equal(si, knn_gold[f"{name}_corr_second"])
+    assert np.array_equal(dv, knn_gold[f"{name}_corr_value"])
+    # brute force agrees on distances everywhere and on indices wherever the distance is unique
+    bi, bd = orc.nn_brute(dst, q, r2)
+    kept = bi >= 0
+    assert np.array_equal(np.nonzero(kept)[0], si)
+    assert np.array_equal(bd[kept], dv)
+    diff = bi[kept] != di
+    for j in np.nonzero(diff)[0]:                      # only exact ties (duplicated points) may differ
+        assert np.array_equal(dst[bi[kept][j]], dst[di[j]])
+        assert bi[kept][j] < di[j]                     # brute force = lowest index
+
+
+def test_oracle_kdtree_vs_live_reference(orc):
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    d = syn.make_pair(60000)
+    q = orc.transform_points(np.eye(4), d["src"])
+    a = orc.KDTree(d["dst"]).find_correspondences(q, d["max_sq_dist"])
+    b = orc.KDTree(d["dst"], use_ref=True).find_correspondences(q, d["max_sq_dist"], num_threads=2)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_radius_is_strict_and_empty_inputs(orc):
+    dst = np.array([[0, 0, 0], [4, 0, 0]], np.float32)
+    t = orc.KDTree(dst)
+    assert len(t.knn_in_radius([0.5, 0, 0], 1, np.float32(0.25))[0]) == 0     # d2 == r2 rejected
+    assert list(t.knn_in_radius([0.5, 0, 0], 1, np.nextafter(np.float32(0.25), np.float32(1)))[0]) == [0]
+    e = orc.KDTree(np.zeros((0, 3), np.float32))
+    assert len(e.find_correspondences(np.zeros((5, 3), np.float32), 1.0)[0]) == 0   # kd_tree_utilities.hpp:16-19
+    assert len(t.find_correspondences(np.zeros((0, 3), np.float32), 1.0)[0]) == 0
+
+
+def test_transform_expression_is_pinned(orc):
+    rng = np.random.default_rng(3)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = syn.rot_xyz(0.3, -0.2, 0.5).astype(np.float32)
+    T[:3, 3] = [0.1, -0.4, 0.25]
+    p = rng.random((1000, 3), dtype=np.float32)
+    q = orc.transform_points(T, p)
+    L = T[:3, :3]
+    f = np.float32
+    exp = np.stack([(f(L[r, 0]) * p[:, 0] + (f(L[r, 1]) * p[:, 1] + f(L[r, 2]) * p[:, 2])) + f(T[r, 3]) for r in range(3)], 1)
+    assert np.array_equal(q, exp.astype(np.float32))
+
+
+def test_svd_ldlt_rotation_vs_numpy(orc):
+    rng = np.random.default_rng(0)
+    for i in range(300):
+        A = rng.standard_normal((3, 3))
+        if i % 7 == 0:
+            A[:, 2] = A[:, 0] * 2.0                       # rank deficient
+        if i % 11 == 0:
+            A = np.diag([1.0, 1.0, 1.0]) + 1e-9 * A       # near identity (the rotation() polish case)
+        U, S, V = orc.svd3(A)
+        assert np.abs(U @ np.diag(S) @ V.T - A).max() < 1e-13 * max(1.0, np.abs(A).max())
+        assert np.abs(U.T @ U - np.eye(3)).max() < 1e-13 and np.abs(V.T @ V - np.eye(3)).max() < 1e-13
+        assert S[0] >= S[1] >= S[2] >= 0
+        np.testing.assert_allclose(S, np.linalg.svd(A, compute_uv=False), atol=1e-13)
+        R = orc.nearest_rotation(A)
+        Un, _, Vnt = np.linalg.svd(A)
+        if np.linalg.det(Un @ Vnt) < 0:
+            Un[:, 0] *= -1                                # space_transformations.hpp:45-48 flips column 0
+        if i % 7 != 0:
+            np.testing.assert_allclose(R, Un @ Vnt, atol=1e-9)
+        assert abs(np.linalg.det(R) - 1.0) < 1e-12
+    for i in range(50):
+        M = rng.standard_normal((30, 6))
+        A = M.T @ M
+        b = rng.standard_normal(6)
+        np.testing.assert_allclose(orc.ldlt6_solve(A, b), np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    # singular system: Eigen's LDLT::solve pseudo-inverse-of-D semantics -> finite, residual orthogonal
+    A = np.zeros((6, 6)); A[:3, :3] = np.eye(3)
+    x = orc.ldlt6_solve(A, np.array([1, 2, 3, 4, 5, 6.0]))
+    np.testing.assert_allclose(x, [1, 2, 3, 0, 0, 0])
+
+
+def _numpy_kabsch(P, Q):
+    mp, mq = P.mean(0), Q.mean(0)
+    S = (P - mp).T @ (Q - mq) / len(P)
+    U, _, Vt = np.linalg.svd(S)
+    if np.linalg.det(U @ Vt) < 0:
+        U[:, 2] *= -1
+    R = U @ Vt
+    return R, mp - R @ mq
+
+
+def _numpy_gn_step(P, N, Q, w_p2p, w_p2pl, dm, sm):
+    AtA = np.zeros((6, 6)); Atb = np.zeros(6)
+    d = P - dm; s = Q - sm
+    a = d + s; r = d - s
+    if w_p2pl > 0:
+        e = np.concatenate([np.cross(a, N), N], 1)
+        res = (N * r).sum(1)
+        AtA += w_p2pl * e.T @ e
+        Atb += w_p2pl * e.T @ res
+    if w_p2p > 0:
+        for i in range(len(P)):
+            ax = np.array([[0, -a[i, 2], a[i, 1]], [a[i, 2], 0, -a[i, 0]], [-a[i, 1], a[i, 0], 0]])
+            E = np.concatenate([ax, np.eye(3)], 0)
+            AtA += w_p2p * E @ E.T
+            Atb += w_p2p * E @ r[i]
+    return AtA, Atb
+
+
+def test_estimators_vs_numpy(orc):
+    d = syn.make_pair(3000, perturb=0.4)
+    q = orc.transform_points(np.eye(4), d["src"])
+    di, si, dv = orc.KDTree(d["dst"]).find_correspondences(q, d["max_sq_dist"])
+    P = d["dst"][di].astype(np.float64); Q = q[si].astype(np.float64); N = d["dst_n"][di].astype(np.float64)
+    R, t = _numpy_kabsch(P, Q)
+    for mode, tol in ((orc.MODE_F64, 1e-9), (orc.MODE_MIXED, 1e-6), (orc.MODE_F32, 2e-5)):
+        T, sums, ok = orc.estimate_p2p(d["dst"], q, di, si, mode)
+        assert ok and np.abs(T[:3, :3] - R).max() < tol + 1e-7 and np.abs(T[:3, 3] - t).max() < tol + 1e-7
+    assert sums[0] == len(di)
+    np.testing.assert_allclose(sums[1:4], P.sum(0), rtol=1e-12)
+    np.testing.assert_allclose(sums[7:16].reshape(3, 3), P.T @ Q, rtol=1e-12)
+    dm = orc.mean3(d["dst"]); sm = orc.mean3(q)
+    for w_p2p, w_p2pl in ((0.0, 1.0), (1.0, 0.0), (0.3, 1.0)):
+        # the reference's weights are f32 (TransformT::Scalar): compare against the same rounded values
+        AtA_np, Atb_np = _numpy_gn_step(P, N, Q, float(np.float32(w_p2p)), float(np.float32(w_p2pl)), dm.astype(np.float64), sm.astype(np.float64))
+        T, AtA, Atb, cv = orc.estimate_combined(d["dst"], d["dst_n"], q, di, si, w_p2p, w_p2pl, dm, sm, 1, 1e-5, orc.MODE_F64)
+        np.testing.assert_allclose(AtA, AtA_np, rtol=1e-9, atol=1e-9 * np.abs(AtA_np).max())
+        np.testing.assert_allclose(Atb, Atb_np, rtol=1e-8, atol=1e-9 * np.abs(AtA_np).max())
+        x = np.linalg.solve(AtA_np, Atb_np)
+        na = np.linalg.norm(x[:3]); th = np.arctan(na); u = x[:3] / na
+        K = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0]])
+        Ra = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        L = Ra @ Ra; tt = Ra @ (np.cos(th) * x[3:])
+        tt = tt - L @ sm.astype(np.float64) + dm.astype(np.float64)
+        assert np.abs(T[:3, :3] - L).max() < 1e-6 and np.abs(T[:3, 3] - tt).max() < 1e-6
+        # the three arithmetic modes agree to f32 accumulation accuracy
+        T32, *_ = orc.estimate_combined(d["dst"], d["dst_n"], q, di, si, w_p2p, w_p2pl, dm, sm, 1, 1e-5, orc.MODE_F32)
+        Tmx, *_ = orc.estimate_combined(d["dst"], d["dst_n"], q, di, si, w_p2p, w_p2pl, dm, sm, 1, 1e-5, orc.MODE_MIXED)
+        assert np.abs(T32 - T).max() < 2e-5 and np.abs(Tmx - T).max() < 1e-6
+
+
+def test_degenerate_estimates_are_identity(orc):
+    d = syn.make_pair(100)
+    e = np.zeros(0, np.int64)
+    T, _, ok = orc.estimate_p2p(d["dst"], d["src"], e, e)
+    assert not ok and np.array_equal(T, np.eye(4, dtype=np.float32))            # transform_estimation.hpp:20-23
+    T, _, _, cv = orc.estimate_combined(d["dst"], d["dst_n"], d["src"], e, e, 0.0, 1.0, np.zeros(3), np.zeros(3))
+    assert not cv and np.array_equal(T, np.eye(4, dtype=np.float32))            # :269-272
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_icp_converges_to_ground_truth_and_golden(orc, metric):
+    g = np.load(os.path.join(GOLD, "icp_golden.npz"))
+    d = syn.make_pair(int(g["n"]), perturb=float(g["perturb"]))
+    np.testing.assert_array_equal(d["T_true"], g["T_true"])
+    for mode in (orc.MODE_F32, orc.MODE_MIXED, orc.MODE_F64):
+        p = orc.make_params(metric=metric, max_iter=6, conv_tol=0.0, max_sq_dist=d["max_sq_dist"], mode=mode, num_threads=1)
+        r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+        assert np.abs(r["T"] - g[f"T_m{metric}_mode{mode}"]).max() <= 2e-7        # regression vector
+        assert r["last_ncorr"] == int(g[f"ncorr_m{metric}_mode{mode}"])
+        assert np.linalg.norm(r["T"] - d["T_true"]) < 5e-4                        # analytic anchor (noise-limited)
+    p = orc.make_params(metric=metric, max_iter=50, conv_tol=1e-5, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+    r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+    assert r["last_delta_norm"] < 1e-5 and r["iterations"] < 15
+
+
+def test_synthetic_generator_is_deterministic():
+    z = syn.splitmix64(42, 3)
+    assert [int(v) for v in z] == [13679457532755275413, 2949826092126892291, 5139283748462763858]
+    a = syn.make_pair(1000); b = syn.make_pair(1000)
+    assert np.array_equal(a["dst"], b["dst"]) and np.array_equal(a["src"], b["src"]) and np.array_equal(a["dst_n"], b["dst_n"])
+    assert a["dst"].min() >= 0 and a["dst"].max() < 1
+    np.testing.assert_allclose(np.linalg.norm(a["dst_n"], axis=1), 1.0, atol=1e-6)

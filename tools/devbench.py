@@ -17,12 +17,14 @@ ap.add_argument("--n", type=int, nargs="+", default=[1_000_000, 10_000_000])
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--metric", default="p2plane")
 ap.add_argument("--modes", type=int, nargs="+", default=[1, 0])
+ap.add_argument("--occ", type=float, nargs="+", default=[4.0])
 a = ap.parse_args()
 
 for n in a.n:
     d = syn.make_pair(n, n, with_normals=True)
-    for fused in a.modes:
+    for fused, occ in [(f, o) for f in a.modes for o in a.occ]:
         ctx = Context(0)
+        ctx.set_option("cell_occupancy", occ)
         ctx.set_target(d["dst"], d["dst_n"] if a.metric == "p2plane" else None)
         ctx.set_source(d["src"])
         ctx.set_option("fused", fused)
@@ -42,7 +44,7 @@ for n in a.n:
         loop2, sk, nl = ctx.last_timing()
         s_ms, a_ms = ctx.last_timing2()
         T = np.array(r.T[:], np.float32).reshape(4, 4).T
-        print(f"n={n} fused={fused} wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
+        print(f"n={n} fused={fused} occ={occ} wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
               f"[timed: loop/iter={loop2/a.steps:.3f} search(or fused)/iter={s_ms/max(nl,1):.3f} acc/iter={a_ms/max(nl,1):.3f}] "
               f"it/s={a.steps/dt:.1f} err_true={np.linalg.norm(T-d['T_true']):.2e} ncorr={r.last_ncorr}", flush=True)
         ctx.close()
