@@ -1,0 +1,379 @@
+// cilantro_hip/icp.hpp -- C++ host-side mirror of cilantro's rigid-ICP template surface for this
+// path, header-only, on top of the C ABI (c_api.h).  Same class / method names, argument meaning,
+// defaults and result conventions as the reference, so code written against
+//
+//     cilantro::SimpleCombinedMetricRigidICP3f icp(dst.points, dst.normals, src.points);
+//     icp.setMaxNumberOfOptimizationStepIterations(1).setPointToPointMetricWeight(0.0f)
+//        .setPointToPlaneMetricWeight(1.0f);
+//     icp.correspondenceSearchEngine().setMaxDistance(0.1f * 0.1f);
+//     icp.setConvergenceTolerance(1e-4f).setMaxNumberOfIterations(30);
+//     auto tf = icp.estimate().getTransform();                    (examples/rigid_icp.cpp:116-125)
+//
+// switches engines by changing the namespace.  Mirrors (paths relative to
+// /root/reference/include/cilantro/):
+//   registration/icp_base.hpp:8-123                        IterativeClosestPointBase (CRTP, setters return *this)
+//   registration/icp_single_transform_point_to_point_metric.hpp
+//   registration/icp_single_transform_combined_metric.hpp  (weights / GN step knobs :100-143)
+//   registration/icp_common_instances.hpp:34-45,74-97,250,261   Simple* wrappers
+//   correspondence_search/correspondence_search_kd_tree.hpp:23-307  engine concept + knobs :239-271
+//   core/correspondence.hpp:9-55                            Correspondence / CorrespondenceSet
+//
+// Eigen is NOT required: clouds are passed as non-owning (pointer, count) views with the reference's
+// memory layout (3xN column-major float == packed xyz).  When <Eigen/Dense> is available the
+// overloads at the bottom accept cilantro's own ConstVectorSetMatrixMap / RigidTransform3f types.
+//
+// Every option combination the GPU path does not implement throws std::invalid_argument; results
+// never silently differ from the reference.  There is no CPU fallback: without a usable HIP device
+// construction throws std::runtime_error.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "c_api.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define CILANTRO_HIP_HAVE_EIGEN 1
+#endif
+#endif
+
+namespace cilantro_hip {
+
+// core/data_containers.hpp:73-122: non-owning view of a 3xN column-major float matrix
+struct ConstPointsView {
+  const float* data_ = nullptr;
+  size_t cols_ = 0;
+  ConstPointsView() = default;
+  ConstPointsView(const float* d, size_t n) : data_(d), cols_(n) {}
+  ConstPointsView(const std::vector<float>& xyz) : data_(xyz.data()), cols_(xyz.size() / 3) {}
+  const float* data() const { return data_; }
+  size_t cols() const { return cols_; }
+  static constexpr size_t rows() { return 3; }
+};
+
+// core/space_transformations.hpp:54-55: Eigen::Transform<float,3,Isometry> storage (4x4 column-major)
+struct RigidTransform3f {
+  float m[16];
+  RigidTransform3f() { setIdentity(); }
+  void setIdentity() {
+    std::memset(m, 0, sizeof(m));
+    m[0] = m[5] = m[10] = m[15] = 1.0f;
+  }
+  static RigidTransform3f Identity() { return RigidTransform3f(); }
+  const float* data() const { return m; }
+  float* data() { return m; }
+  float linear(int r, int c) const { return m[c * 4 + r]; }
+  float& linear(int r, int c) { return m[c * 4 + r]; }
+  float translation(int r) const { return m[12 + r]; }
+  float& translation(int r) { return m[12 + r]; }
+  float operator()(int r, int c) const { return m[c * 4 + r]; }
+};
+
+enum struct CorrespondenceSearchDirection { FIRST_TO_SECOND, SECOND_TO_FIRST, BOTH };  // core/correspondence.hpp:7
+
+template <typename ScalarT, typename IndexT = size_t>
+struct Correspondence {  // core/correspondence.hpp:9-52
+  using Scalar = ScalarT;
+  using Index = IndexT;
+  IndexT indexInFirst;
+  IndexT indexInSecond;
+  ScalarT value;
+};
+template <typename ScalarT, typename IndexT = size_t>
+using CorrespondenceSet = std::vector<Correspondence<ScalarT, IndexT>>;
+
+namespace internal {
+struct CtxDeleter {
+  void operator()(cilhip_ctx* c) const { cilhip_destroy(c); }
+};
+using CtxPtr = std::unique_ptr<cilhip_ctx, CtxDeleter>;
+
+inline void check(cilhip_ctx* c, int rc, const char* what) {
+  if (rc == CILHIP_OK) return;
+  std::string msg = std::string(what) + ": " + (c ? cilhip_last_error(c) : "no context");
+  if (rc == CILHIP_ERR_UNSUPPORTED || rc == CILHIP_ERR_INVALID) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+
+inline CtxPtr make_ctx(int device) {
+  cilhip_ctx* c = nullptr;
+  const int rc = cilhip_create(&c, device);
+  if (rc != CILHIP_OK)
+    throw std::runtime_error("cilhip_create failed (no usable HIP device; libcilantro_hip has no CPU fallback)");
+  return CtxPtr(c);
+}
+
+template <class TransformT>
+inline void to_abi(const TransformT& t, float out[16]) {
+  std::memcpy(out, t.data(), 16 * sizeof(float));  // Eigen::Transform::data() and RigidTransform3f::data(): col-major 4x4
+}
+}  // namespace internal
+
+// Models cilantro's correspondence-search engine concept (the CorrespondenceSearchEngineT template
+// parameter of the ICP classes, registration/icp_base.hpp:8-10) with the search on the GPU.
+class CorrespondenceSearchHIP {
+public:
+  using CorrespondenceScalar = float;
+  using CorrespondenceIndex = size_t;
+  using SearchResult = CorrespondenceSet<CorrespondenceScalar, CorrespondenceIndex>;
+
+  explicit CorrespondenceSearchHIP(cilhip_ctx* ctx)
+      : ctx_(ctx),
+        search_dir_(CorrespondenceSearchDirection::SECOND_TO_FIRST),  // correspondence_search_kd_tree.hpp:47
+        max_distance_(0.01f * 0.01f),                                  // :48 (squared)
+        inlier_fraction_(1.0),
+        require_reciprocality_(false),
+        one_to_one_(false),
+        fetched_(false) {}
+
+  CorrespondenceSearchHIP& findCorrespondences() { return findCorrespondences(RigidTransform3f::Identity()); }
+
+  template <class TransformT>
+  CorrespondenceSearchHIP& findCorrespondences(const TransformT& tform) {  // :107
+    float T[16];
+    internal::to_abi(tform, T);
+    internal::check(ctx_, cilhip_find_correspondences(ctx_, T, max_distance_, nullptr), "findCorrespondences");
+    fetched_ = false;
+    return *this;
+  }
+
+  // ascending source index, as correspondence_search_kd_tree_utilities.hpp:45-50 leaves them
+  const SearchResult& getCorrespondences() const {
+    if (!fetched_) {
+      size_t n = 0;
+      const size_t cap = capacity_;  // = number of source points (every one may have a match)
+      std::vector<uint64_t> i1, i2;
+      std::vector<float> v;
+      i1.resize(cap ? cap : 1); i2.resize(cap ? cap : 1); v.resize(cap ? cap : 1);
+      internal::check(ctx_, cilhip_get_correspondences(ctx_, i1.data(), i2.data(), v.data(), cap, &n), "getCorrespondences");
+      correspondences_.resize(n);
+      for (size_t k = 0; k < n; ++k) correspondences_[k] = {static_cast<size_t>(i1[k]), static_cast<size_t>(i2[k]), v[k]};
+      fetched_ = true;
+    }
+    return correspondences_;
+  }
+
+  const CorrespondenceSearchDirection& getSearchDirection() const { return search_dir_; }
+  CorrespondenceSearchHIP& setSearchDirection(const CorrespondenceSearchDirection& d) {
+    if (d != CorrespondenceSearchDirection::SECOND_TO_FIRST)
+      throw std::invalid_argument("CorrespondenceSearchHIP implements SECOND_TO_FIRST only");
+    search_dir_ = d;
+    return *this;
+  }
+  CorrespondenceScalar getMaxDistance() const { return max_distance_; }
+  CorrespondenceSearchHIP& setMaxDistance(CorrespondenceScalar dist_thresh) {  // SQUARED, as the reference
+    max_distance_ = dist_thresh;
+    return *this;
+  }
+  double getInlierFraction() const { return inlier_fraction_; }
+  CorrespondenceSearchHIP& setInlierFraction(double fraction) {
+    // core/correspondence.hpp:57-66: the filter only acts for 0 < fraction < 1
+    if (fraction > 0.0 && fraction < 1.0) throw std::invalid_argument("CorrespondenceSearchHIP implements inlier_fraction == 1 only");
+    inlier_fraction_ = fraction;
+    return *this;
+  }
+  bool getRequireReciprocality() const { return require_reciprocality_; }
+  CorrespondenceSearchHIP& setRequireReciprocality(bool b) {
+    if (b) throw std::invalid_argument("reciprocal search is not implemented on the GPU engine");
+    return *this;
+  }
+  bool getOneToOne() const { return one_to_one_; }
+  CorrespondenceSearchHIP& setOneToOne(bool b) {
+    if (b) throw std::invalid_argument("one-to-one filtering is not implemented on the GPU engine");
+    return *this;
+  }
+
+  void setSourceCount_(size_t n) { capacity_ = n; }  // internal: result capacity
+
+private:
+  cilhip_ctx* ctx_;
+  CorrespondenceSearchDirection search_dir_;
+  CorrespondenceScalar max_distance_;
+  double inlier_fraction_;
+  bool require_reciprocality_;
+  bool one_to_one_;
+  size_t capacity_ = 0;
+  mutable bool fetched_;
+  mutable SearchResult correspondences_;
+};
+
+// registration/icp_base.hpp: CRTP base with the reference's public interface.
+template <class ICPInstanceT>
+class IterativeClosestPointBase {
+public:
+  using Transform = RigidTransform3f;
+  using Scalar = float;
+  using CorrespondenceSearchEngine = CorrespondenceSearchHIP;
+  using ResidualVector = std::vector<float>;
+
+  inline const CorrespondenceSearchEngine& correspondenceSearchEngine() const { return engine_; }
+  inline CorrespondenceSearchEngine& correspondenceSearchEngine() { return engine_; }
+
+  inline size_t getMaxNumberOfIterations() const { return max_iterations_; }
+  inline ICPInstanceT& setMaxNumberOfIterations(size_t max_iter) { max_iterations_ = max_iter; return self(); }
+  inline size_t getNumberOfPerformedIterations() const { return iterations_; }
+  inline float getConvergenceTolerance() const { return convergence_tol_; }
+  inline ICPInstanceT& setConvergenceTolerance(float conv_tol) { convergence_tol_ = conv_tol; return self(); }
+  inline const Transform& getInitialTransform() const { return transform_init_; }
+  template <class TransformT>
+  inline ICPInstanceT& setInitialTransform(const TransformT& tform_init) {
+    internal::to_abi(tform_init, transform_init_.m);
+    return self();
+  }
+  inline Transform& initialTransform() { return transform_init_; }
+  inline float getLastUpdateNorm() const { return last_delta_norm_; }
+
+  // Main ICP loop (icp_base.hpp:68-87): all iterations run on the device, one sync at the end.
+  ICPInstanceT& estimate() {
+    cilhip_icp_params p;
+    cilhip_icp_default_params(&p);
+    self().fillParams(p);
+    p.max_iter = max_iterations_;
+    p.conv_tol = convergence_tol_;
+    p.max_sq_dist = engine_.getMaxDistance();
+    cilhip_icp_result r;
+    internal::check(ctx_.get(), cilhip_icp_run(ctx_.get(), &p, transform_init_.m, &r), "estimate");
+    std::memcpy(transform_.m, r.T, sizeof(r.T));
+    iterations_ = r.iterations;
+    last_delta_norm_ = r.last_delta_norm;
+    last_ncorr_ = r.last_ncorr;
+    return self();
+  }
+  inline ICPInstanceT& estimate(size_t max_iter, float conv_tol) {
+    max_iterations_ = max_iter;
+    convergence_tol_ = conv_tol;
+    return estimate();
+  }
+  inline const Transform& getTransform() const { return transform_; }
+  template <class TransformT>
+  inline const ICPInstanceT& getTransform(TransformT& tform) const {
+    std::memcpy(tform.data(), transform_.m, sizeof(transform_.m));
+    return static_cast<const ICPInstanceT&>(*this);
+  }
+  inline ResidualVector getResiduals() { return self().computeResiduals(); }
+  inline bool hasConverged() const { return last_delta_norm_ < convergence_tol_; }
+  inline size_t getNumberOfLastCorrespondences() const { return last_ncorr_; }  // (extension)
+  inline cilhip_ctx* context() { return ctx_.get(); }                            // (extension)
+
+protected:
+  IterativeClosestPointBase(int device, size_t max_iter = 15, float conv_tol = 1e-5f)  // icp_base.hpp:24-25
+      : ctx_(internal::make_ctx(device)),
+        engine_(ctx_.get()),
+        max_iterations_(max_iter),
+        iterations_(0),
+        convergence_tol_(conv_tol),
+        last_delta_norm_(std::numeric_limits<float>::infinity()),
+        last_ncorr_(0) {}
+
+  ICPInstanceT& self() { return *static_cast<ICPInstanceT*>(this); }
+
+  internal::CtxPtr ctx_;
+  CorrespondenceSearchEngine engine_;
+  size_t max_iterations_;
+  size_t iterations_;
+  float convergence_tol_;
+  float last_delta_norm_;
+  size_t last_ncorr_;
+  Transform transform_init_;
+  Transform transform_;
+  size_t n_src_ = 0;
+};
+
+// icp_single_transform_point_to_point_metric.hpp + icp_common_instances.hpp:34-45,250
+class SimplePointToPointMetricRigidICP3f : public IterativeClosestPointBase<SimplePointToPointMetricRigidICP3f> {
+  using Base = IterativeClosestPointBase<SimplePointToPointMetricRigidICP3f>;
+  friend Base;
+
+public:
+  SimplePointToPointMetricRigidICP3f(const ConstPointsView& dst, const ConstPointsView& src, int device = 0)
+      : Base(device) {
+    internal::check(ctx_.get(), cilhip_set_target(ctx_.get(), dst.data(), nullptr, dst.cols(), CILHIP_MEM_HOST), "set_target");
+    internal::check(ctx_.get(), cilhip_set_source(ctx_.get(), src.data(), src.cols(), CILHIP_MEM_HOST), "set_source");
+    n_src_ = src.cols();
+    engine_.setSourceCount_(n_src_);
+  }
+
+private:
+  void fillParams(cilhip_icp_params& p) const { p.metric = CILHIP_METRIC_POINT_TO_POINT; }
+  std::vector<float> computeResiduals() {
+    std::vector<float> res(n_src_ ? n_src_ : 1);
+    internal::check(ctx_.get(), cilhip_compute_residuals(ctx_.get(), CILHIP_METRIC_POINT_TO_POINT, 0.f, 0.f, transform_.m, res.data(), CILHIP_MEM_HOST), "getResiduals");
+    res.resize(n_src_);
+    return res;
+  }
+};
+
+// icp_single_transform_combined_metric.hpp + icp_common_instances.hpp:74-97,261
+class SimpleCombinedMetricRigidICP3f : public IterativeClosestPointBase<SimpleCombinedMetricRigidICP3f> {
+  using Base = IterativeClosestPointBase<SimpleCombinedMetricRigidICP3f>;
+  friend Base;
+
+public:
+  SimpleCombinedMetricRigidICP3f(const ConstPointsView& dst_p, const ConstPointsView& dst_n, const ConstPointsView& src_p, int device = 0)
+      : Base(device),
+        max_optimization_iterations_(1),             // icp_single_transform_combined_metric.hpp:44-47
+        optimization_convergence_tol_(1e-5f),
+        point_to_point_weight_(0.0f),
+        point_to_plane_weight_(1.0f) {
+    if (dst_n.cols() != dst_p.cols()) throw std::invalid_argument("dst normals must match dst points");
+    internal::check(ctx_.get(), cilhip_set_target(ctx_.get(), dst_p.data(), dst_n.data(), dst_p.cols(), CILHIP_MEM_HOST), "set_target");
+    internal::check(ctx_.get(), cilhip_set_source(ctx_.get(), src_p.data(), src_p.cols(), CILHIP_MEM_HOST), "set_source");
+    n_src_ = src_p.cols();
+    engine_.setSourceCount_(n_src_);
+  }
+
+  inline float getPointToPointMetricWeight() const { return point_to_point_weight_; }
+  inline SimpleCombinedMetricRigidICP3f& setPointToPointMetricWeight(float w) { point_to_point_weight_ = w; return *this; }
+  inline float getPointToPlaneMetricWeight() const { return point_to_plane_weight_; }
+  inline SimpleCombinedMetricRigidICP3f& setPointToPlaneMetricWeight(float w) { point_to_plane_weight_ = w; return *this; }
+  inline size_t getMaxNumberOfOptimizationStepIterations() const { return max_optimization_iterations_; }
+  inline SimpleCombinedMetricRigidICP3f& setMaxNumberOfOptimizationStepIterations(size_t n) { max_optimization_iterations_ = n; return *this; }
+  inline float getOptimizationStepConvergenceTolerance() const { return optimization_convergence_tol_; }
+  inline SimpleCombinedMetricRigidICP3f& setOptimizationStepConvergenceTolerance(float t) { optimization_convergence_tol_ = t; return *this; }
+
+private:
+  void fillParams(cilhip_icp_params& p) const {
+    p.metric = CILHIP_METRIC_COMBINED;
+    p.w_p2p = point_to_point_weight_;
+    p.w_p2pl = point_to_plane_weight_;
+    p.max_opt_iter = max_optimization_iterations_;
+    p.opt_conv_tol = optimization_convergence_tol_;
+  }
+  std::vector<float> computeResiduals() {
+    std::vector<float> res(n_src_ ? n_src_ : 1);
+    internal::check(ctx_.get(), cilhip_compute_residuals(ctx_.get(), CILHIP_METRIC_COMBINED, point_to_point_weight_, point_to_plane_weight_, transform_.m, res.data(), CILHIP_MEM_HOST), "getResiduals");
+    res.resize(n_src_);
+    return res;
+  }
+
+  size_t max_optimization_iterations_;
+  float optimization_convergence_tol_;
+  float point_to_point_weight_;
+  float point_to_plane_weight_;
+};
+
+#ifdef CILANTRO_HIP_HAVE_EIGEN
+// Adaptors for cilantro's own types (compiled only where Eigen3 exists; it is absent from the build
+// container, so these are exercised by downstream builds, not by this repository's tests).
+template <class Derived>
+inline ConstPointsView view(const Eigen::DenseBase<Derived>& m) {
+  static_assert(Derived::RowsAtCompileTime == 3, "3xN matrix expected");
+  return ConstPointsView(m.derived().data(), static_cast<size_t>(m.cols()));
+}
+inline Eigen::Transform<float, 3, Eigen::Isometry> toEigen(const RigidTransform3f& t) {
+  Eigen::Transform<float, 3, Eigen::Isometry> e;
+  std::memcpy(e.data(), t.m, sizeof(t.m));
+  return e;
+}
+#endif
+
+}  // namespace cilantro_hip

@@ -1,0 +1,104 @@
+// tests/cpp/test_icp.cpp -- exercises the C++ host mirror (include/cilantro_hip/icp.hpp) the way
+// examples/rigid_icp.cpp:116-133 uses cilantro, and checks the result against the CPU oracle
+// (linked here as the CHECKER only).
+//   test_icp                      : needs a GPU; exit 0 iff every parity check passes
+//   test_icp --expect-no-device   : CPU box; exit 0 iff construction fails loudly (no CPU fallback)
+#include <cilantro_hip/icp.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../oracle/icp_oracle.h"
+
+static uint64_t splitmix(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static float u01(uint64_t seed, uint64_t i) { return (float)(splitmix(seed, i) >> 40) * (1.0f / 16777216.0f); }
+
+static double frob(const float* a, const float* b) {
+  double s = 0;
+  for (int i = 0; i < 16; ++i) s += ((double)a[i] - b[i]) * ((double)a[i] - b[i]);
+  return std::sqrt(s);
+}
+
+int main(int argc, char** argv) {
+  const bool expect_no_device = argc > 1 && !std::strcmp(argv[1], "--expect-no-device");
+  const size_t n = 60000;
+  const double h = std::pow((double)n, -1.0 / 3.0);
+  std::vector<float> dst(3 * n), nrm(3 * n), src(3 * n);
+  for (size_t i = 0; i < 3 * n; ++i) dst[i] = u01(42, i);
+  for (size_t i = 0; i < n; ++i) {
+    const double z = 2.0 * u01(43, 2 * i) - 1.0, phi = 6.283185307179586 * u01(43, 2 * i + 1), r = std::sqrt(1 - z * z);
+    nrm[3 * i] = (float)(r * std::cos(phi)); nrm[3 * i + 1] = (float)(r * std::sin(phi)); nrm[3 * i + 2] = (float)z;
+  }
+  // src = dst + noise, moved by a small rigid motion (recipe shape of examples/rigid_icp.cpp:57-62)
+  const double a = 0.4 * h, ca = std::cos(a), sa = std::sin(a);
+  for (size_t i = 0; i < n; ++i) {
+    const double x = dst[3 * i] + (2 * u01(44, 3 * i) - 1) * 0.05 * h, y = dst[3 * i + 1] + (2 * u01(44, 3 * i + 1) - 1) * 0.05 * h,
+                 z = dst[3 * i + 2] + (2 * u01(44, 3 * i + 2) - 1) * 0.05 * h;
+    src[3 * i] = (float)(ca * x - sa * y + 0.3 * h); src[3 * i + 1] = (float)(sa * x + ca * y - 0.2 * h); src[3 * i + 2] = (float)(z + 0.1 * h);
+  }
+  const float max_sq = (float)((2 * h) * (2 * h));
+  using namespace cilantro_hip;
+  int failures = 0;
+  try {
+    const ConstPointsView dst_v(dst), nrm_v(nrm), src_v(src);
+    SimpleCombinedMetricRigidICP3f icp(dst_v, nrm_v, src_v);
+    if (expect_no_device) { std::printf("FAIL: construction succeeded without a device\n"); return 1; }
+    icp.setMaxNumberOfOptimizationStepIterations(1).setPointToPointMetricWeight(0.0f).setPointToPlaneMetricWeight(1.0f);
+    icp.correspondenceSearchEngine().setMaxDistance(max_sq);
+    icp.setConvergenceTolerance(1e-5f).setMaxNumberOfIterations(30);
+    RigidTransform3f tf = icp.estimate().getTransform();
+
+    orc_icp_params p; std::memset(&p, 0, sizeof(p));
+    p.metric = 1; p.w_p2p = 0; p.w_p2pl = 1; p.max_iter = 30; p.conv_tol = 1e-5f; p.max_opt_iter = 1; p.opt_conv_tol = 1e-5f;
+    p.max_sq_dist = max_sq; p.mode = ORC_MODE_MIXED; p.num_threads = 0;
+    orc_icp_result r;
+    orc_icp_run(dst.data(), nrm.data(), n, src.data(), n, nullptr, &p, nullptr, &r);
+    const double e1 = frob(tf.m, r.T);
+    std::printf("combined: iters gpu=%zu oracle=%zu converged=%d |T_gpu-T_oracle|_F=%.3e\n", icp.getNumberOfPerformedIterations(), r.iterations, (int)icp.hasConverged(), e1);
+    if (!(e1 <= 1e-5) || !icp.hasConverged()) ++failures;
+
+    // engine concept: findCorrespondences(tform) / getCorrespondences() vs the oracle's kd-tree
+    icp.correspondenceSearchEngine().findCorrespondences(tf);
+    const auto& corr = icp.correspondenceSearchEngine().getCorrespondences();
+    std::vector<float> q(3 * n);
+    orc_transform_points(tf.m, src.data(), n, q.data());
+    orc_kdtree* tree = orc_kdtree_build(dst.data(), n, 10);
+    std::vector<int64_t> di(n), si(n); std::vector<float> dv(n);
+    const size_t nc = orc_find_correspondences(tree, q.data(), n, max_sq, di.data(), si.data(), dv.data(), 0);
+    size_t bad = (nc != corr.size());
+    for (size_t k = 0; k < nc && k < corr.size(); ++k)
+      bad += (corr[k].indexInFirst != (size_t)di[k]) || (corr[k].indexInSecond != (size_t)si[k]) || (corr[k].value != dv[k]);
+    std::printf("engine: %zu correspondences, %zu mismatches vs oracle\n", corr.size(), bad);
+    if (bad) ++failures;
+    orc_kdtree_free(tree);
+
+    std::vector<float> res = icp.getResiduals();
+    if (res.size() != n) ++failures;
+
+    SimplePointToPointMetricRigidICP3f icp2(dst_v, src_v);
+    icp2.correspondenceSearchEngine().setMaxDistance(max_sq);
+    icp2.setMaxNumberOfIterations(30).setConvergenceTolerance(1e-5f).estimate();
+    p.metric = 0;
+    orc_icp_run(dst.data(), nullptr, n, src.data(), n, nullptr, &p, nullptr, &r);
+    const double e2 = frob(icp2.getTransform().m, r.T);
+    std::printf("point-to-point: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp2.getNumberOfPerformedIterations(), r.iterations, e2);
+    if (!(e2 <= 1e-5)) ++failures;
+
+    bool threw = false;
+    try { icp.correspondenceSearchEngine().setOneToOne(true); } catch (const std::invalid_argument&) { threw = true; }
+    if (!threw) ++failures;
+  } catch (const std::runtime_error& e) {
+    if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }
+    std::printf("FAIL: %s\n", e.what());
+    return 1;
+  }
+  std::printf(failures ? "FAILED (%d)\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,30 @@
+"""The C++ host mirror (include/cilantro_hip/icp.hpp) compiled with g++ against the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin", "test_icp")
+
+
+def _ensure_built(hip_lib, orc):
+    if not os.path.exists(BIN):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cpp", "build.sh")])
+
+
+def test_cpp_header_compiles_and_fails_loudly_without_device(hip_lib, orc):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cpp", "build.sh")])   # compile check of the header
+    out = subprocess.run([BIN, "--expect-no-device"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_api_parity_on_gpu(hip_lib, orc):
+    _ensure_built(hip_lib, orc)
+    out = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
