@@ -64,6 +64,14 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension has not been built "
             "(run `python -m cilantro_amd.build` / `__graft_entry__.build()`). There is no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64/libhsa-runtime64 (same
+    # SONAME as /opt/rocm's).  If torch is imported AFTER this library, two runtimes end up loaded and
+    # the second one finds no device; importing torch first makes the dynamic loader bind this
+    # library to the runtime torch already loaded (measured: tools/diag_runtime.py).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, f32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p
     L.cilhip_create.argtypes = [C.POINTER(vp), C.c_int]
