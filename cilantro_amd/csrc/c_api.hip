@@ -36,7 +36,11 @@ struct cilhip_ctx {
   bool has_source = false;
   uint32_t ns = 0;
   float* d_src_xyz = nullptr;     // original order (kept for re-sorting)
-  float4* d_src_sorted = nullptr; // sorted by target-grid cell under sort_T
+  float4* d_src_sorted = nullptr; // sorted cube-major by target-grid cell under sort_T
+  uint2* d_tiles = nullptr;       // [ntiles] query ranges of the LDS-tiled search kernel
+  uint32_t* d_todo = nullptr;     // [ns] + counter at d_todo[ns]: clean-up list of the tiled search
+  uint32_t ntiles = 0;
+  bool tiled = false;             // true: LDS-tiled search kernel (exact, measured slower so far: DESIGN.md section 5); false: per-lane global-memory search
   bool src_sorted = false;
   float sort_T[16];
   float src_mean[3] = {0, 0, 0};
@@ -119,6 +123,9 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_nn_d2) (void)hipFree(c->d_nn_d2);
   if (c->d_out_idx) (void)hipFree(c->d_out_idx);
   if (c->d_out_d2) (void)hipFree(c->d_out_d2);
+  if (c->d_tiles) (void)hipFree(c->d_tiles);
+  if (c->d_todo) (void)hipFree(c->d_todo);
+  c->d_tiles = nullptr; c->ntiles = 0; c->d_todo = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
@@ -160,6 +167,7 @@ int cilhip_synchronize(cilhip_ctx* c) {
 int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!c || !key) return CILHIP_ERR_INVALID;
   if (!strcmp(key, "fused")) { c->fused = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "tiled")) { c->tiled = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "cell_occupancy")) { c->cell_occupancy = value; return CILHIP_OK; }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
@@ -223,6 +231,7 @@ int cilhip_set_source(cilhip_ctx* c, const float* xyz, size_t n, int mem) {
   CK(c, hipMalloc(&c->d_src_sorted, cap * sizeof(float4)));
   CK(c, hipMalloc(&c->d_nn_pos, cap * sizeof(uint32_t)));
   CK(c, hipMalloc(&c->d_nn_d2, cap * sizeof(float)));
+  CK(c, hipMalloc(&c->d_todo, (cap + 1) * sizeof(uint32_t)));
   c->ns = (uint32_t)n;
   double mean[3];
   hipError_t e = mean3_device(c->d_src_xyz, c->ns, c->stream, mean);
@@ -262,7 +271,8 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     if (dl > 4.0f * c->grid.cell || dr * ext > 4.0f * c->grid.cell) need = true;
   }
   if (need) {
-    hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream);
+    if (c->d_tiles) { (void)hipFree(c->d_tiles); c->d_tiles = nullptr; c->ntiles = 0; }
+    hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->ntiles);
     if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
@@ -282,6 +292,8 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.nn_pos = c->d_nn_pos;
   a.nn_d2 = c->d_nn_d2;
   a.partials = c->d_partials;
+  a.todo = c->d_todo;
+  a.todo_count = c->d_todo ? c->d_todo + (c->ns ? c->ns : 1) : nullptr;
   a.skip_if_inner_done = 0;
   return a;
 }
@@ -293,7 +305,10 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   if (rc) return rc;
   launch_init_state(c->d_state, T, c->src_mean, c->stream);
   IterArgs a = make_iter_args(c, max_sq);
-  if (c->ns) launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
+  if (c->ns) {
+    if (c->tiled) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);
+    else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
+  }
   CK(c, hipGetLastError());
   memcpy(c->nn_T, T, sizeof(c->nn_T));
   c->have_nn = true;
@@ -525,7 +540,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         if (st == 0 && c->fused) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
         } else if (st == 0) {
-          launch_iter(a, IM_NONE, true, true, nb, c->stream);                 // search kernel
+          if (c->tiled) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);   // LDS-tiled search kernel
+          else launch_iter(a, IM_NONE, true, true, nb, c->stream);                  // per-lane global-memory search
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_event(c, nev++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
         } else {
@@ -596,7 +612,8 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
     if (c->fused) {
       launch_iter(a, im, true, false, nb, c->stream);
     } else {
-      launch_iter(a, IM_NONE, true, true, nb, c->stream);
+      if (c->tiled) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);
+      else launch_iter(a, IM_NONE, true, true, nb, c->stream);
       launch_iter(a, im, false, false, nb, c->stream);
     }
     launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);

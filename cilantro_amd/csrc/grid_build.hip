@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -259,21 +260,93 @@ void free_grid(GridDev& g) {
   g.pts = nullptr; g.nrm = nullptr; g.cell_start = nullptr;
 }
 
-hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out, hipStream_t s) {
+// ---- source ordering + tiles ------------------------------------------------------------------------
+// The source is sorted CUBE-major: cube = 4x4x4 block of target-grid cells, key = cube_id*64 + cell
+// within the cube.  Queries of one cube become one (or, above 256 queries, several) TILE(s) of the
+// LDS-tiled search kernel: the 3x3x3-cell neighbourhoods of a cube's queries fit a 6x6x6-cell region
+// that one workgroup stages in LDS once.
+__device__ __forceinline__ uint32_t cube_key_of(const GridDev& g, float x, float y, float z) {
+  int cx = (int)floorf(fminf(fmaxf((x - g.ox) * g.inv_cell, -1.0f), 1.0e9f));
+  int cy = (int)floorf(fminf(fmaxf((y - g.oy) * g.inv_cell, -1.0f), 1.0e9f));
+  int cz = (int)floorf(fminf(fmaxf((z - g.oz) * g.inv_cell, -1.0f), 1.0e9f));
+  cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+  const uint32_t cnx = (uint32_t)(g.nx + 3) >> 2, cny = (uint32_t)(g.ny + 3) >> 2;
+  const uint32_t cube = (((uint32_t)cz >> 2) * cny + ((uint32_t)cy >> 2)) * cnx + ((uint32_t)cx >> 2);
+  return (cube << 6) | (((uint32_t)cz & 3u) << 4) | (((uint32_t)cy & 3u) << 2) | ((uint32_t)cx & 3u);
+}
+
+__global__ void k_cube_keys_tf(const float* __restrict__ xyz, uint32_t n, GridDev g, Tf T, uint32_t* keys, uint32_t* vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float qx, qy, qz;
+    transform_point(T.m, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], qx, qy, qz);
+    keys[i] = cube_key_of(g, qx, qy, qz);
+    vals[i] = i;
+  }
+}
+
+__global__ void k_shift_keys(const uint32_t* __restrict__ in, uint32_t n, uint32_t* out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] >> 6;
+}
+
+// tiles of one cube: ceil(count / TILE_QUERIES)
+__global__ void k_tile_counts(const uint32_t* __restrict__ cube_start, uint32_t ncubes, uint32_t* counts) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncubes; c += gridDim.x * blockDim.x)
+    counts[c] = (cube_start[c + 1] - cube_start[c] + (TILE_QUERIES - 1)) / TILE_QUERIES;
+}
+
+__global__ void k_emit_tiles(const uint32_t* __restrict__ cube_start, const uint32_t* __restrict__ tile_off, uint32_t ncubes, uint2* tiles) {
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncubes; c += gridDim.x * blockDim.x) {
+    const uint32_t b = cube_start[c], e = cube_start[c + 1];
+    uint32_t t = tile_off[c];
+    for (uint32_t q = b; q < e; q += TILE_QUERIES) tiles[t++] = make_uint2(q, min(q + TILE_QUERIES, e));
+  }
+}
+
+hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out, hipStream_t s,
+                       uint2** d_tiles_out, uint32_t* ntiles_out) {
+  *d_tiles_out = nullptr; *ntiles_out = 0;
   if (n == 0) return hipSuccess;
   uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr;
   HIP_TRY(hipMalloc(&k_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&k_out, (size_t)n * 4));
   HIP_TRY(hipMalloc(&v_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&v_out, (size_t)n * 4));
   Tf tf;
   for (int i = 0; i < 16; ++i) tf.m[i] = T[i];
-  hipLaunchKernelGGL(k_cell_keys_tf, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, tf, k_in, v_in);
-  const size_t ncells = (size_t)g.nx * g.ny * g.nz;
-  hipError_t e = sort_pairs(k_in, k_out, v_in, v_out, n, bits_for((uint32_t)ncells), s);
-  if (e == hipSuccess) {
+  hipLaunchKernelGGL(k_cube_keys_tf, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, tf, k_in, v_in);
+  const uint32_t cnx = (uint32_t)(g.nx + 3) >> 2, cny = (uint32_t)(g.ny + 3) >> 2, cnz = (uint32_t)(g.nz + 3) >> 2;
+  const uint32_t ncubes = cnx * cny * cnz;
+  hipError_t e = sort_pairs(k_in, k_out, v_in, v_out, n, bits_for(ncubes) + 6, s);
+  uint32_t *cube_start = nullptr, *tcount = nullptr, *toff = nullptr;
+  void* tmp = nullptr;
+  uint2* tiles = nullptr;
+  do {
+    if (e != hipSuccess) break;
     hipLaunchKernelGGL(k_gather, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, (const float*)nullptr, v_out, n, d_out, (float4*)nullptr);
+    // cube_start[] over the sorted cube ids, then the tile table
+    hipLaunchKernelGGL(k_shift_keys, dim3(grid_blocks(n)), dim3(256), 0, s, k_out, n, k_in);
+    if ((e = hipMalloc(&cube_start, ((size_t)ncubes + 1) * 4)) != hipSuccess) break;
+    if ((e = hipMalloc(&tcount, ((size_t)ncubes + 1) * 4)) != hipSuccess) break;
+    if ((e = hipMalloc(&toff, ((size_t)ncubes + 1) * 4)) != hipSuccess) break;
+    hipLaunchKernelGGL(k_cell_start, dim3(grid_blocks(n + 1)), dim3(256), 0, s, k_in, n, ncubes, cube_start);
+    if ((e = hipMemsetAsync(tcount, 0, ((size_t)ncubes + 1) * 4, s)) != hipSuccess) break;
+    hipLaunchKernelGGL(k_tile_counts, dim3(grid_blocks(ncubes)), dim3(256), 0, s, cube_start, ncubes, tcount);
+    size_t tmp_bytes = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, tmp_bytes, tcount, toff, 0u, (size_t)ncubes + 1, rocprim::plus<uint32_t>(), s)) != hipSuccess) break;
+    if ((e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16)) != hipSuccess) break;
+    if ((e = rocprim::exclusive_scan(tmp, tmp_bytes, tcount, toff, 0u, (size_t)ncubes + 1, rocprim::plus<uint32_t>(), s)) != hipSuccess) break;
+    uint32_t ntiles = 0;
+    if ((e = hipMemcpyAsync(&ntiles, toff + ncubes, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+    if ((e = hipMalloc(&tiles, ((size_t)ntiles + 1) * sizeof(uint2))) != hipSuccess) break;
+    hipLaunchKernelGGL(k_emit_tiles, dim3(grid_blocks(ncubes)), dim3(256), 0, s, cube_start, toff, ncubes, tiles);
     e = hipStreamSynchronize(s);
-  }
+    *d_tiles_out = tiles; *ntiles_out = ntiles;
+  } while (0);
   (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in); (void)hipFree(v_out);
+  if (cube_start) (void)hipFree(cube_start);
+  if (tcount) (void)hipFree(tcount);
+  if (toff) (void)hipFree(toff);
+  if (tmp) (void)hipFree(tmp);
+  if (e != hipSuccess && tiles) { (void)hipFree(tiles); *d_tiles_out = nullptr; *ntiles_out = 0; }
   return e;
 }
 

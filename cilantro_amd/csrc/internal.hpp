@@ -11,6 +11,7 @@
 namespace cilhip {
 
 constexpr uint32_t NONE_U32 = 0xFFFFFFFFu;
+constexpr int TILE_QUERIES = 256;  // queries per tile == threads per workgroup of the search kernels
 
 // Uniform grid over the target cloud (the structure that replaces the nanoflann kd-tree).
 // Target points are stored sorted by linear cell id (x fastest) as 16-byte records
@@ -56,6 +57,8 @@ struct IterArgs {
   uint32_t* nn_pos;        // [ns] (sorted-source order) sorted-target position or NONE
   float* nn_d2;            // [ns]
   double* partials;        // [nblocks * SUMS_MAX]
+  uint32_t* todo;          // [ns] queries deferred by the tiled search to its clean-up pass
+  uint32_t* todo_count;    // [1]
   int skip_if_inner_done;
 };
 
@@ -75,6 +78,7 @@ struct SolveArgs {
 // kernels.hip
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
 void launch_solve(const SolveArgs& a, hipStream_t s);
+void launch_search_tiled(const IterArgs& a, const uint2* tiles, uint32_t ntiles, hipStream_t s);
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 32 * SUMS_MAX;
@@ -98,8 +102,10 @@ hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStr
                       GridBuildResult* out, double mean_out[3], double target_occupancy);
 void free_grid(GridDev& g);
 // Sorts the source by the target-grid cell of T*s; writes {x,y,z,orig} records.  d_out preallocated [n].
+// Also emits the tile table of the LDS-tiled search kernel: tiles[t] = [begin,end) of <= TILE_QUERIES sorted
+// queries that share one 4x4x4-cell cube (caller frees *d_tiles_out with hipFree).
 hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out,
-                       hipStream_t s);
+                       hipStream_t s, uint2** d_tiles_out, uint32_t* ntiles_out);
 hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3]);
 
 }  // namespace cilhip

@@ -281,3 +281,27 @@ def test_torch_device_inputs_and_shard_engine(orc, hip_lib):
     icp._ctx.set_option("fused", 1)
     T3 = icp.estimate().getTransform()
     assert np.abs(T3 - T1).max() <= 1e-7
+
+
+@pytest.mark.parametrize("n", [20000, 1000000])
+def test_tiled_search_kernel_is_exact_too(Context, orc, n):
+    """The optional LDS-tiled search kernel ("tiled"=1) must give bit-identical matches."""
+    d = syn.make_pair(n, perturb=0.8)
+    T = syn.true_transform(d["h"], 0.5).astype(np.float32)
+    outs = []
+    for tiled in (0, 1):
+        ctx = Context()
+        ctx.set_option("tiled", tiled)
+        ctx.set_target(d["dst"]); ctx.set_source(d["src"])
+        # sort under identity, search under T: queries have drifted from their sort-time cells
+        ctx.find_correspondences(np.eye(4), d["max_sq_dist"], count=False)
+        for max_sq in (d["max_sq_dist"], np.float32(3.0e38), np.float32((0.3 * d["h"]) ** 2)):
+            outs.append((tiled, gpu_nn(ctx, T, max_sq)))
+    half = len(outs) // 2
+    for (t0, (i0, d0)), (t1, (i1, d1)) in zip(outs[:half], outs[half:]):
+        assert np.array_equal(i0, i1)
+        m = i0 >= 0
+        assert np.array_equal(d0[m], d1[m])
+    if n <= 20000:
+        bi, bd = orc.nn_brute(d["dst"], orc.transform_points(T, d["src"]), d["max_sq_dist"])
+        assert np.array_equal(outs[0][1][0], bi)

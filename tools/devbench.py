@@ -18,16 +18,18 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--metric", default="p2plane")
 ap.add_argument("--modes", type=int, nargs="+", default=[1, 0])
 ap.add_argument("--occ", type=float, nargs="+", default=[4.0])
+ap.add_argument("--tiled", type=int, nargs="+", default=[1])
 a = ap.parse_args()
 
 for n in a.n:
     d = syn.make_pair(n, n, with_normals=True)
-    for fused, occ in [(f, o) for f in a.modes for o in a.occ]:
+    for fused, occ, tiled in [(f, o, t) for f in a.modes for o in a.occ for t in a.tiled]:
         ctx = Context(0)
         ctx.set_option("cell_occupancy", occ)
         ctx.set_target(d["dst"], d["dst_n"] if a.metric == "p2plane" else None)
         ctx.set_source(d["src"])
         ctx.set_option("fused", fused)
+        ctx.set_option("tiled", tiled)
         p = capi.IcpParams()
         ctx._L.cilhip_icp_default_params(C.byref(p))
         p.metric = capi.METRIC_COMBINED if a.metric == "p2plane" else capi.METRIC_POINT_TO_POINT
@@ -44,7 +46,7 @@ for n in a.n:
         loop2, sk, nl = ctx.last_timing()
         s_ms, a_ms = ctx.last_timing2()
         T = np.array(r.T[:], np.float32).reshape(4, 4).T
-        print(f"n={n} fused={fused} occ={occ} wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
+        print(f"n={n} fused={fused} occ={occ} tiled={tiled} wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
               f"[timed: loop/iter={loop2/a.steps:.3f} search(or fused)/iter={s_ms/max(nl,1):.3f} acc/iter={a_ms/max(nl,1):.3f}] "
               f"it/s={a.steps/dt:.1f} err_true={np.linalg.norm(T-d['T_true']):.2e} ncorr={r.last_ncorr}", flush=True)
         ctx.close()
