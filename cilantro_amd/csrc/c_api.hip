@@ -38,9 +38,10 @@ struct cilhip_ctx {
   float* d_src_xyz = nullptr;     // original order (kept for re-sorting)
   float4* d_src_sorted = nullptr; // sorted cube-major by target-grid cell under sort_T
   uint2* d_tiles = nullptr;       // [ntiles] query ranges of the LDS-tiled search kernel
-  uint32_t* d_todo = nullptr;     // [ns] + counter at d_todo[ns]: clean-up list of the tiled search
+  uint32_t* d_todo = nullptr;     // [ns] deferred queries + 2 counters at d_todo[ns..ns+1]: clean-up lists of the tiled search
+  uint32_t* d_todo_tiles = nullptr; // [ntiles]
   uint32_t ntiles = 0;
-  bool tiled = false;             // true: LDS-tiled search kernel (exact, measured slower so far: DESIGN.md section 5); false: per-lane global-memory search
+  bool tiled = true;              // true: LDS-tiled search kernel; false: per-lane global-memory search
   bool src_sorted = false;
   float sort_T[16];
   float src_mean[3] = {0, 0, 0};
@@ -56,7 +57,7 @@ struct cilhip_ctx {
   double* d_stage = nullptr;      // [REDUCE_STAGE_DOUBLES] stage-1 rows of the cross-block reduction
   double* d_sums = nullptr;       // [SUMS_MAX]
   bool fused = false;             // true: search+accumulate in one kernel; false: search kernel + streaming accumulate kernel (faster: the search runs at 2x the occupancy)
-  double cell_occupancy = 4.0;    // target points per grid cell (takes effect at the next set_target)
+  double cell_occupancy = 3.0;    // target points per grid cell (takes effect at the next set_target)
   unsigned long long* d_count = nullptr;
   uint32_t* d_out_idx = nullptr;  // [ns] original-order results
   float* d_out_d2 = nullptr;
@@ -125,7 +126,8 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_out_d2) (void)hipFree(c->d_out_d2);
   if (c->d_tiles) (void)hipFree(c->d_tiles);
   if (c->d_todo) (void)hipFree(c->d_todo);
-  c->d_tiles = nullptr; c->ntiles = 0; c->d_todo = nullptr;
+  if (c->d_todo_tiles) (void)hipFree(c->d_todo_tiles);
+  c->d_tiles = nullptr; c->ntiles = 0; c->d_todo = nullptr; c->d_todo_tiles = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
@@ -231,7 +233,7 @@ int cilhip_set_source(cilhip_ctx* c, const float* xyz, size_t n, int mem) {
   CK(c, hipMalloc(&c->d_src_sorted, cap * sizeof(float4)));
   CK(c, hipMalloc(&c->d_nn_pos, cap * sizeof(uint32_t)));
   CK(c, hipMalloc(&c->d_nn_d2, cap * sizeof(float)));
-  CK(c, hipMalloc(&c->d_todo, (cap + 1) * sizeof(uint32_t)));
+  CK(c, hipMalloc(&c->d_todo, (cap + 2) * sizeof(uint32_t)));
   c->ns = (uint32_t)n;
   double mean[3];
   hipError_t e = mean3_device(c->d_src_xyz, c->ns, c->stream, mean);
@@ -272,14 +274,20 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
   }
   if (need) {
     if (c->d_tiles) { (void)hipFree(c->d_tiles); c->d_tiles = nullptr; c->ntiles = 0; }
+    if (c->d_todo_tiles) { (void)hipFree(c->d_todo_tiles); c->d_todo_tiles = nullptr; }
     hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->ntiles);
     if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
+    CK(c, hipMalloc(&c->d_todo_tiles, ((size_t)c->ntiles + 1) * sizeof(uint32_t)));
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
     c->have_nn = false;
   }
   return CILHIP_OK;
 }
+
+// The LDS-tiled kernel runs 1024-thread workgroups, two per CU: below ~4 full rounds of tiles on the
+// 256 CUs the per-lane kernel (8x more, smaller workgroups) balances better (measured at 1M points).
+static bool use_tiled(const cilhip_ctx* c) { return c->tiled && c->ntiles >= 2048; }
 
 static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   IterArgs a{};
@@ -294,6 +302,7 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.partials = c->d_partials;
   a.todo = c->d_todo;
   a.todo_count = c->d_todo ? c->d_todo + (c->ns ? c->ns : 1) : nullptr;
+  a.todo_tiles = c->d_todo_tiles;
   a.skip_if_inner_done = 0;
   return a;
 }
@@ -306,7 +315,7 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   launch_init_state(c->d_state, T, c->src_mean, c->stream);
   IterArgs a = make_iter_args(c, max_sq);
   if (c->ns) {
-    if (c->tiled) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);
+    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
   }
   CK(c, hipGetLastError());
@@ -540,7 +549,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         if (st == 0 && c->fused) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
         } else if (st == 0) {
-          if (c->tiled) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);   // LDS-tiled search kernel
+          if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);   // LDS-tiled search kernel
           else launch_iter(a, IM_NONE, true, true, nb, c->stream);                  // per-lane global-memory search
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_event(c, nev++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
@@ -612,7 +621,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
     if (c->fused) {
       launch_iter(a, im, true, false, nb, c->stream);
     } else {
-      if (c->tiled) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);
+      if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);
       else launch_iter(a, IM_NONE, true, true, nb, c->stream);
       launch_iter(a, im, false, false, nb, c->stream);
     }

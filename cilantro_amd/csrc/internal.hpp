@@ -11,7 +11,13 @@
 namespace cilhip {
 
 constexpr uint32_t NONE_U32 = 0xFFFFFFFFu;
-constexpr int TILE_QUERIES = 256;  // queries per tile == threads per workgroup of the search kernels
+#ifndef CILHIP_CUBE_LOG2
+#define CILHIP_CUBE_LOG2 3
+#endif
+// LDS-tiled search: queries are grouped by cubes of (2^CUBE_LOG2)^3 target-grid cells
+constexpr int CUBE_LOG2 = CILHIP_CUBE_LOG2;
+constexpr int TILE_QUERIES = CUBE_LOG2 == 3 ? 2048 : 256;  // max queries per tile
+constexpr int TILE_THREADS = CUBE_LOG2 == 3 ? 1024 : 256;  // workgroup size of the tiled search kernel
 
 // Uniform grid over the target cloud (the structure that replaces the nanoflann kd-tree).
 // Target points are stored sorted by linear cell id (x fastest) as 16-byte records
@@ -58,7 +64,8 @@ struct IterArgs {
   float* nn_d2;            // [ns]
   double* partials;        // [nblocks * SUMS_MAX]
   uint32_t* todo;          // [ns] queries deferred by the tiled search to its clean-up pass
-  uint32_t* todo_count;    // [1]
+  uint32_t* todo_count;    // [2]: number of deferred queries, number of deferred tiles
+  uint32_t* todo_tiles;    // [ntiles] tiles deferred as a whole
   int skip_if_inner_done;
 };
 

@@ -26,6 +26,16 @@
 
 namespace cilhip {
 
+// LDS-tiled search geometry: cube of 2^L cells per axis, <= TILE_QUERIES queries per tile,
+// TILE_THREADS threads per workgroup.  (4^3 cells / 256 queries / 256 threads, or 8^3 / 2048 / 1024.)
+#ifndef CILHIP_TILE_CAP
+#if CILHIP_CUBE_LOG2 == 3
+#define CILHIP_TILE_CAP 4400
+#else
+#define CILHIP_TILE_CAP 1536
+#endif
+#endif
+
 #ifndef CILHIP_CAND
 #define CILHIP_CAND 4 /* candidates per lane per trip of the flattened work-list loop */
 #endif
@@ -291,13 +301,12 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
 // Exactness is unchanged: lanes whose 3x3x3 block does not prove the result (sparse data, large
 // radius), queries outside the grid, and whole tiles whose region exceeds the LDS budget (queries that
 // drifted far from their sort-time cells) fall back to the global-memory search.
-#ifndef CILHIP_TILE_CAP
-#define CILHIP_TILE_CAP 1536
-#endif
-constexpr int TILE_CAP = CILHIP_TILE_CAP;                // staged target points per tile (16 B each)
-constexpr int TILE_MAXROWS = 49;                         // RY*RZ (6x6 normally, 7x7 with drift)
-constexpr int TILE_MAXW = 10;                            // RX
+constexpr int TILE_CAP = CILHIP_TILE_CAP;                    // staged target points per tile (16 B each)
+constexpr int TILE_RMAX = (1 << CILHIP_CUBE_LOG2) + 3;       // region edge: cube + halo + one cell of drift
+constexpr int TILE_MAXROWS = TILE_RMAX * TILE_RMAX;          // RY*RZ
+constexpr int TILE_MAXW = TILE_RMAX + 2;                     // RX
 constexpr int TILE_MAXE = TILE_MAXROWS * (TILE_MAXW + 1);
+constexpr int TILE_QPT = TILE_QUERIES / TILE_THREADS;        // queries per thread
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -316,10 +325,6 @@ __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, 
   bp = lt ? pos : bp;
 }
 
-// LDS candidate scan, 4 per trip, NOT clamped to the range: reading up to 3 records past `end` only
-// evaluates further real target points (or the far-away pad records after the tile), which can never
-// make the result wrong -- and it removes the per-candidate index clamps.  `bl` tracks the LDS index of
-// the best; it is converted to a position in the global sorted array once, after the search.
 // LDS tile index -> position in the global sorted target array (row found by binary search over rowbase)
 __device__ __forceinline__ uint32_t lds_to_global(uint32_t l, const uint32_t* rowbase, const uint32_t* rowdelta, int rows) {
   if (l == NONE_U32) return NONE_U32;
@@ -331,6 +336,10 @@ __device__ __forceinline__ uint32_t lds_to_global(uint32_t l, const uint32_t* ro
   return l + rowdelta[lo];
 }
 
+// LDS candidate scan, 4 per trip, NOT clamped to the range: reading up to 3 records past `end` only
+// evaluates further real target points (or the far-away pad records after the tile), which can never
+// make the result wrong -- and it removes the per-candidate index clamps.  `bl` tracks the LDS index of
+// the best; it is converted to a position in the global sorted array once, after the search.
 __device__ __forceinline__ void scan_lds4(const float4* lpts, uint32_t beg, uint32_t end,
                                           const f32x2 qxy, float qz, unsigned long long& bk, uint32_t& bl) {
   for (uint32_t j = beg; j < end; j += 4) {
@@ -342,7 +351,102 @@ __device__ __forceinline__ void scan_lds4(const float4* lpts, uint32_t beg, uint
   }
 }
 
-__global__ __launch_bounds__(TILE_QUERIES, 8) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles, uint32_t ntiles) {
+struct TileLds {
+  const float4* lpts;
+  const uint32_t* lcs;
+  const uint32_t* rowbase;
+  const uint32_t* rowdelta;
+  int lox, loy, loz, RY, W1, rows;
+};
+
+// Exact search of one in-grid query out of the LDS tile.  Returns false if the 3x3x3 block does not
+// prove the result (the query then goes to the clean-up pass).
+__device__ __forceinline__ bool search_in_tile(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
+                                               int cx, int cy, int cz, float max_sq, NN& best) {
+  const f32x2 qxy = {qx, qy};
+  unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  uint32_t bl = NONE_U32;                                    // LDS index of the best
+  const int lx = cx - t.lox, ly = cy - t.loy, lz = cz - t.loz;
+  const int row0 = lz * t.RY + ly;
+  const int e0i = row0 * t.W1 + lx;
+  const uint32_t b0 = t.lcs[e0i], e0 = t.lcs[e0i + 1];
+  scan_lds4(t.lpts, b0, e0, qxy, qz, bk, bl);
+  const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
+  const float gmx = fmaxf(qx - xl - g.margin, 0.0f), gpx = fmaxf(xl + g.cell - qx - g.margin, 0.0f);
+  const float gmy = fmaxf(qy - yl - g.margin, 0.0f), gpy = fmaxf(yl + g.cell - qy - g.margin, 0.0f);
+  const float gmz = fmaxf(qz - zl - g.margin, 0.0f), gpz = fmaxf(zl + g.cell - qz - g.margin, 0.0f);
+  const bool hmx = cx > 0, hpx = cx + 1 < g.nx, hmy = cy > 0, hpy = cy + 1 < g.ny, hmz = cz > 0, hpz = cz + 1 < g.nz;
+  float bface = INFINITY;
+  if (hmx) bface = fminf(bface, gmx);
+  if (hpx) bface = fminf(bface, gpx);
+  if (hmy) bface = fminf(bface, gmy);
+  if (hpy) bface = fminf(bface, gpy);
+  if (hmz) bface = fminf(bface, gmz);
+  if (hpz) bface = fminf(bface, gpz);
+  const float bd0 = __uint_as_float((uint32_t)(bk >> 32));
+  bool proven = true;
+  if (!((bface == INFINITY) || (bd0 < bface * bface * KSHRINK))) {
+    const float ax2m = gmx * gmx, ax2p = gpx * gpx, ay2m = gmy * gmy, ay2p = gpy * gpy, az2m = gmz * gmz, az2p = gpz * gpz;
+    // work mask from the best after the own cell: bit r (r = 3*dz+dy, 0..8) = row r still holds candidates,
+    // bit 9+r / 18+r = its x-1 / x+1 cell does too.  Own row (r = 4): only the side cells (bits 4 and 27).
+    uint32_t mask = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int dz = r / 3, dy = r % 3;
+      const float gyz2 = (dz == 0 ? az2m : dz == 2 ? az2p : 0.0f) + (dy == 0 ? ay2m : dy == 2 ? ay2p : 0.0f);
+      const bool okr = (dz == 0 ? hmz : dz == 2 ? hpz : true) && (dy == 0 ? hmy : dy == 2 ? hpy : true) && (gyz2 * KSHRINK <= bd0);
+      const bool left = okr && hmx && ((gyz2 + ax2m) * KSHRINK <= bd0);
+      const bool right = okr && hpx && ((gyz2 + ax2p) * KSHRINK <= bd0);
+      if (r == 4) { if (left) mask |= 1u << 4; if (right) mask |= 1u << 27; }
+      else if (okr) mask |= 1u << r;
+      if (left) mask |= 1u << (9 + r);
+      if (right) mask |= 1u << (18 + r);
+    }
+    // ONE flattened loop over all remaining ranges of this lane (dense trips across the wave)
+    uint32_t items = mask & 0x080001FFu;
+    uint32_t j = 0, e = 0;
+    for (;;) {
+      if (j >= e) {
+        if (items == 0) break;
+        const int it = __ffs(items) - 1;
+        items &= items - 1;
+        const int r = (it == 27) ? 4 : it;
+        const int dz = (r * 11) >> 5, dy = r - 3 * dz;      // r/3, r%3 for r in 0..8
+        const float gyz2 = (dz == 0 ? az2m : dz == 2 ? az2p : 0.0f) + (dy == 0 ? ay2m : dy == 2 ? ay2p : 0.0f);
+        if (gyz2 * KSHRINK > __uint_as_float((uint32_t)(bk >> 32))) continue;   // culled by a newer best
+        const int row = row0 + (dz - 1) * t.RY + (dy - 1);
+        const int eb = row * t.W1 + lx;
+        if (it == 4) { j = t.lcs[eb - 1]; e = b0; }                 // own row, x-1 side
+        else if (it == 27) { j = e0; e = t.lcs[eb + 2]; }            // own row, x+1 side
+        else { j = t.lcs[eb - ((mask >> (9 + r)) & 1u)]; e = t.lcs[eb + 1 + ((mask >> (18 + r)) & 1u)]; }
+        continue;
+      }
+      const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
+      eval_candidate(p0, qxy, qz, j, bk, bl);
+      eval_candidate(p1, qxy, qz, j + 1, bk, bl);
+      eval_candidate(p2, qxy, qz, j + 2, bk, bl);
+      eval_candidate(p3, qxy, qz, j + 3, bk, bl);
+      j += 4;
+    }
+    // does the 3x3x3 block prove exactness?
+    float b = INFINITY;
+    if (cx - 1 > 0) b = fminf(b, gmx + g.cell);
+    if (cx + 2 < g.nx) b = fminf(b, gpx + g.cell);
+    if (cy - 1 > 0) b = fminf(b, gmy + g.cell);
+    if (cy + 2 < g.ny) b = fminf(b, gpy + g.cell);
+    if (cz - 1 > 0) b = fminf(b, gmz + g.cell);
+    if (cz + 2 < g.nz) b = fminf(b, gpz + g.cell);
+    if (b != INFINITY) {
+      b -= g.margin;
+      if (!(b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK)) proven = false;   // rare
+    }
+  }
+  best.key = bk;
+  best.pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
+  return proven;
+}
+
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles, uint32_t ntiles) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
   // XCD-aware tile order: block b runs on XCD b%8 -> each XCD gets one contiguous eighth of the tiles
@@ -359,37 +463,44 @@ __global__ __launch_bounds__(TILE_QUERIES, 8) void k_search_tiled(IterArgs a, co
 
   const GridDev& g = a.grid;
   const uint2 tile = tiles[vb];
-  const uint32_t i = tile.x + threadIdx.x;
-  const bool active = i < tile.y;
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  int cx = 0, cy = 0, cz = 0;
-  bool inside = false;
-  if (active) {
-    float T[16];
+  float T[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) T[k] = st->T[k];
-    const float4 s4 = a.src[i];
-    transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-    const float BIG = 1.0e9f;
-    cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG));
-    cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG));
-    cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
-    inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
+  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+
+  float qx[TILE_QPT], qy[TILE_QPT], qz[TILE_QPT];
+  int cx[TILE_QPT], cy[TILE_QPT], cz[TILE_QPT];
+  bool active[TILE_QPT], inside[TILE_QPT];
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+#pragma unroll
+  for (int u = 0; u < TILE_QPT; ++u) {
+    const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+    active[u] = i < tile.y;
+    inside[u] = false;
+    qx[u] = qy[u] = qz[u] = 0.f; cx[u] = cy[u] = cz[u] = 0;
+    if (active[u]) {
+      const float4 s4 = a.src[i];
+      transform_point(T, s4.x, s4.y, s4.z, qx[u], qy[u], qz[u]);
+      const float BIG = 1.0e9f;
+      cx[u] = (int)floorf(fminf(fmaxf((qx[u] - g.ox) * g.inv_cell, -BIG), BIG));
+      cy[u] = (int)floorf(fminf(fmaxf((qy[u] - g.oy) * g.inv_cell, -BIG), BIG));
+      cz[u] = (int)floorf(fminf(fmaxf((qz[u] - g.oz) * g.inv_cell, -BIG), BIG));
+      inside[u] = (cx[u] >= 0) & (cx[u] < g.nx) & (cy[u] >= 0) & (cy[u] < g.ny) & (cz[u] >= 0) & (cz[u] < g.nz);
+      if (inside[u]) {
+        mn[0] = min(mn[0], cx[u]); mn[1] = min(mn[1], cy[u]); mn[2] = min(mn[2], cz[u]);
+        mx[0] = max(mx[0], cx[u]); mx[1] = max(mx[1], cy[u]); mx[2] = max(mx[2], cz[u]);
+      }
+    }
   }
   // ---- 1. bounding box of the current cells of the tile's in-grid queries ----
   if (threadIdx.x < 3) { box[threadIdx.x] = 0x7fffffff; box[3 + threadIdx.x] = -1; }
   __syncthreads();
-  {
-    int mn[3] = {inside ? cx : 0x7fffffff, inside ? cy : 0x7fffffff, inside ? cz : 0x7fffffff};
-    int mx[3] = {inside ? cx : -1, inside ? cy : -1, inside ? cz : -1};
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+  for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], off, 64)); }
-    if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], off, 64)); }
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { atomicMin(&box[k], mn[k]); atomicMax(&box[3 + k], mx[k]); }
-    }
+    for (int k = 0; k < 3; ++k) { atomicMin(&box[k], mn[k]); atomicMax(&box[3 + k], mx[k]); }
   }
   __syncthreads();
   const bool any_inside = box[3] >= 0;
@@ -398,44 +509,46 @@ __global__ __launch_bounds__(TILE_QUERIES, 8) void k_search_tiled(IterArgs a, co
   const int RX = hix - lox + 1, RY = hiy - loy + 1, RZ = hiz - loz + 1;
   const int rows = RY * RZ;
   const int W1 = RX + 1;
-  bool ok = any_inside && RX <= TILE_MAXW && RY <= TILE_MAXROWS && RZ <= TILE_MAXROWS && rows <= TILE_MAXROWS;   // block-uniform
+  bool ok = any_inside && RX <= TILE_MAXW && RY <= TILE_RMAX + 2 && RZ <= TILE_RMAX + 2 && rows <= TILE_MAXROWS;   // block-uniform
   uint32_t P = 0;
   if (ok) {
     // ---- 2a. cell table of the region (global cell_start values) ----
     const int E = rows * W1;
-    for (int e = threadIdx.x; e < E; e += TILE_QUERIES) {
+    for (int e = threadIdx.x; e < E; e += TILE_THREADS) {
       const int r = e / W1, x = e - r * W1;
       const int z = loz + r / RY, y = loy + r % RY;
       lcs[e] = g.cell_start[((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)(lox + x)];
     }
     __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive prefix over the row lengths (one wave)
-      const int r = threadIdx.x;
-      const uint32_t first = r < rows ? lcs[r * W1] : 0u;
-      const uint32_t len = r < rows ? lcs[r * W1 + RX] - first : 0u;
-      uint32_t incl = len;
+    if (threadIdx.x < 64) {  // exclusive prefix over the row lengths (one wave, 64 rows per pass)
+      uint32_t carry = 0;
+      for (int base = 0; base < rows; base += 64) {
+        const int r = base + threadIdx.x;
+        const uint32_t first = r < rows ? lcs[r * W1] : 0u;
+        const uint32_t len = r < rows ? lcs[r * W1 + RX] - first : 0u;
+        uint32_t incl = len;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(incl, off, 64);
-        if (r >= off) incl += t;
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t tt = __shfl_up(incl, off, 64);
+          if ((int)threadIdx.x >= off) incl += tt;
+        }
+        if (r < rows) {
+          rowbase[r + 1] = carry + incl;
+          rowdelta[r] = first - (carry + incl - len);  // global position - LDS index (mod 2^32)
+        }
+        carry += __shfl(incl, 63, 64);
       }
-      rowbase[r + 1] = incl;
-      if (r == 0) rowbase[0] = 0;
-      rowdelta[r] = first - (incl - len);  // global position - LDS index (mod 2^32)
+      if (threadIdx.x == 0) rowbase[0] = 0;
     }
     __syncthreads();
     P = rowbase[rows];
     ok = P <= (uint32_t)TILE_CAP;
   }
-  NN best;
-  best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
-  best.pos = NONE_U32;
-  bool defer = false;   // this query goes to the clean-up pass
   if (ok) {
     // ---- 2b. table -> LDS indices; stage the points (flat index, row found by binary search) ----
     const int E = rows * W1;
-    for (int e = threadIdx.x; e < E; e += TILE_QUERIES) lcs[e] -= rowdelta[e / W1];
-    for (uint32_t f = threadIdx.x; f < P; f += TILE_QUERIES) {
+    for (int e = threadIdx.x; e < E; e += TILE_THREADS) lcs[e] -= rowdelta[e / W1];
+    for (uint32_t f = threadIdx.x; f < P; f += TILE_THREADS) {
       int lo = 0, hi = rows;               // largest r with rowbase[r] <= f
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -445,102 +558,32 @@ __global__ __launch_bounds__(TILE_QUERIES, 8) void k_search_tiled(IterArgs a, co
     }
     if (threadIdx.x < 4) lpts[P + threadIdx.x] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __uint_as_float(NONE_U32));  // pad: d2 = inf
     __syncthreads();
-    // ---- 3. per-lane exact search out of LDS ----
-#ifdef CILHIP_EXP_NOSEARCH
-    if (active && inside) { best.pos = (uint32_t)lpts[threadIdx.x % (P ? P : 1)].w; } else
-#endif
-    if (active && inside) {
-      const f32x2 qxy = {qx, qy};
-      unsigned long long bk = best.key;
-      uint32_t bl = NONE_U32;                                    // LDS index of the best
-      const int lx = cx - lox, ly = cy - loy, lz = cz - loz;
-      const int row0 = lz * RY + ly;
-      const int e0i = row0 * W1 + lx;
-      const uint32_t b0 = lcs[e0i], e0 = lcs[e0i + 1];
-      scan_lds4(lpts, b0, e0, qxy, qz, bk, bl);
-      const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
-      const float gmx = fmaxf(qx - xl - g.margin, 0.0f), gpx = fmaxf(xl + g.cell - qx - g.margin, 0.0f);
-      const float gmy = fmaxf(qy - yl - g.margin, 0.0f), gpy = fmaxf(yl + g.cell - qy - g.margin, 0.0f);
-      const float gmz = fmaxf(qz - zl - g.margin, 0.0f), gpz = fmaxf(zl + g.cell - qz - g.margin, 0.0f);
-      const bool hmx = cx > 0, hpx = cx + 1 < g.nx, hmy = cy > 0, hpy = cy + 1 < g.ny, hmz = cz > 0, hpz = cz + 1 < g.nz;
-      float bface = INFINITY;
-      if (hmx) bface = fminf(bface, gmx);
-      if (hpx) bface = fminf(bface, gpx);
-      if (hmy) bface = fminf(bface, gmy);
-      if (hpy) bface = fminf(bface, gpy);
-      if (hmz) bface = fminf(bface, gmz);
-      if (hpz) bface = fminf(bface, gpz);
-      const float bd0 = __uint_as_float((uint32_t)(bk >> 32));
-      if (!((bface == INFINITY) || (bd0 < bface * bface * KSHRINK))) {
-        const float ax2m = gmx * gmx, ax2p = gpx * gpx, ay2m = gmy * gmy, ay2p = gpy * gpy, az2m = gmz * gmz, az2p = gpz * gpz;
-        // work mask from the best after the own cell: bit r (r = 3*dz+dy, 0..8) = row r still holds candidates,
-        // bit 9+r / 18+r = its x-1 / x+1 cell does too.  Own row (r = 4): only the side cells (bits 13, 22).
-        uint32_t mask = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-          const int dz = r / 3, dy = r % 3;
-          const float gyz2 = (dz == 0 ? az2m : dz == 2 ? az2p : 0.0f) + (dy == 0 ? ay2m : dy == 2 ? ay2p : 0.0f);
-          const bool okr = (dz == 0 ? hmz : dz == 2 ? hpz : true) && (dy == 0 ? hmy : dy == 2 ? hpy : true) && (gyz2 * KSHRINK <= bd0);
-          const bool left = okr && hmx && ((gyz2 + ax2m) * KSHRINK <= bd0);
-          const bool right = okr && hpx && ((gyz2 + ax2p) * KSHRINK <= bd0);
-          if (r == 4) { if (left) mask |= 1u << 4; if (right) mask |= 1u << 27; }
-          else if (okr) mask |= 1u << r;
-          if (left) mask |= 1u << (9 + r);
-          if (right) mask |= 1u << (18 + r);
-        }
-        // ONE flattened loop over all remaining ranges of this lane (dense trips across the wave)
-        uint32_t items = mask & 0x080001FFu;
-        uint32_t j = 0, e = 0;
-        for (;;) {
-          if (j >= e) {
-            if (items == 0) break;
-            const int it = __ffs(items) - 1;
-            items &= items - 1;
-            const int r = (it == 27) ? 4 : it;
-            const int dz = (r * 11) >> 5, dy = r - 3 * dz;      // r/3, r%3 for r in 0..8
-            const float gyz2 = (dz == 0 ? az2m : dz == 2 ? az2p : 0.0f) + (dy == 0 ? ay2m : dy == 2 ? ay2p : 0.0f);
-            if (gyz2 * KSHRINK > __uint_as_float((uint32_t)(bk >> 32))) continue;   // culled by a newer best
-            const int row = row0 + (dz - 1) * RY + (dy - 1);
-            const int eb = row * W1 + lx;
-            if (it == 4) { j = lcs[eb - 1]; e = b0; }                 // own row, x-1 side
-            else if (it == 27) { j = e0; e = lcs[eb + 2]; }            // own row, x+1 side
-            else { j = lcs[eb - ((mask >> (9 + r)) & 1u)]; e = lcs[eb + 1 + ((mask >> (18 + r)) & 1u)]; }
-            continue;
-          }
-          const float4 p0 = lpts[j], p1 = lpts[j + 1], p2 = lpts[j + 2], p3 = lpts[j + 3];
-          eval_candidate(p0, qxy, qz, j, bk, bl);
-          eval_candidate(p1, qxy, qz, j + 1, bk, bl);
-          eval_candidate(p2, qxy, qz, j + 2, bk, bl);
-          eval_candidate(p3, qxy, qz, j + 3, bk, bl);
-          j += 4;
-        }
-        best.key = bk; best.pos = lds_to_global(bl, rowbase, rowdelta, rows);
-        // does the 3x3x3 block prove exactness?
-        float b = INFINITY;
-        if (cx - 1 > 0) b = fminf(b, gmx + g.cell);
-        if (cx + 2 < g.nx) b = fminf(b, gpx + g.cell);
-        if (cy - 1 > 0) b = fminf(b, gmy + g.cell);
-        if (cy + 2 < g.ny) b = fminf(b, gpy + g.cell);
-        if (cz - 1 > 0) b = fminf(b, gmz + g.cell);
-        if (cz + 2 < g.nz) b = fminf(b, gpz + g.cell);
-        if (b != INFINITY) {
-          b -= g.margin;
-          if (!(b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK)) defer = true;   // rare
-        }
-      } else {
-        best.key = bk; best.pos = lds_to_global(bl, rowbase, rowdelta, rows);
-      }
-    } else if (active) {
-      // query outside the grid: nothing to find if it is farther than the radius, else generic search
-      const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
-      const float gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
-      const float gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
-      if ((gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq) defer = true;
-    }
-  } else {
-    defer = active;  // whole-tile fallback (region too large for LDS, or no query inside the grid)
   }
-  if (active) {
+  if (!ok) {
+    // whole-tile fallback (region does not fit LDS: the queries drifted far from their sort-time cells, or
+    // the data is much denser here): the clean-up pass searches this tile's queries in their sorted order
+    if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
+    return;
+  }
+  // ---- 3. per-lane exact search out of LDS (or hand-off to the clean-up pass) ----
+  TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
+#pragma unroll
+  for (int u = 0; u < TILE_QPT; ++u) {
+    if (!active[u]) continue;
+    const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+    NN best;
+    best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
+    best.pos = NONE_U32;
+    bool defer = false;
+    if (inside[u]) {
+      defer = !search_in_tile(g, tl, qx[u], qy[u], qz[u], cx[u], cy[u], cz[u], a.max_sq, best);
+    } else {
+      // query outside the grid: nothing to find if it is farther than the radius, else generic search
+      const float gx = axis_gap(qx[u], g.ox, g.ox + (float)g.nx * g.cell, g.margin);
+      const float gy = axis_gap(qy[u], g.oy, g.oy + (float)g.ny * g.cell, g.margin);
+      const float gz = axis_gap(qz[u], g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+      defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
+    }
     if (defer) {
       // hand the query to the clean-up pass (k_search_todo: generic global-memory search); order-independent
       a.todo[atomicAdd(a.todo_count, 1u)] = i;
@@ -554,15 +597,31 @@ __global__ __launch_bounds__(TILE_QUERIES, 8) void k_search_tiled(IterArgs a, co
 // Clean-up pass of the tiled search: the (few) queries the LDS tile could not settle -- sparse data or a
 // radius beyond the 3x3x3 block, queries outside the grid, tiles whose region exceeded the LDS budget --
 // run the generic exact search out of global memory.
-__global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a) {
+__global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const uint2* __restrict__ tiles) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
-  const uint32_t n = *a.todo_count;
-  if (n == 0) return;
+  const uint32_t n = a.todo_count[0], nt = a.todo_count[1];
+  if (n == 0 && nt == 0) return;
   __shared__ uint2 worklist[LIST_CAP * ITER_THREADS];
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  // (a) whole deferred tiles: consecutive lanes take consecutive (spatially sorted) queries
+  constexpr uint32_t CHUNKS = TILE_QUERIES / ITER_THREADS;
+  for (uint32_t w = blockIdx.x; w < nt * CHUNKS; w += gridDim.x) {
+    const uint2 tile = tiles[a.todo_tiles[w / CHUNKS]];
+    const uint32_t i = tile.x + (w % CHUNKS) * ITER_THREADS + threadIdx.x;
+    if (i < tile.y) {
+      const float4 s4 = a.src[i];
+      float qx, qy, qz;
+      transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+      NN best;
+      nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
+      a.nn_pos[i] = best.pos;
+      a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    }
+  }
+  // (b) individual stragglers
   for (uint32_t t = blockIdx.x * ITER_THREADS + threadIdx.x; t < n; t += gridDim.x * ITER_THREADS) {
     const uint32_t i = a.todo[t];
     const float4 s4 = a.src[i];
@@ -577,11 +636,11 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a) {
 
 void launch_search_tiled(const IterArgs& a, const uint2* tiles, uint32_t ntiles, hipStream_t s) {
   if (ntiles == 0) return;
-  (void)hipMemsetAsync(a.todo_count, 0, sizeof(uint32_t), s);
+  (void)hipMemsetAsync(a.todo_count, 0, 2 * sizeof(uint32_t), s);
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
-  hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_QUERIES), 0, s, a, tiles, ntiles);
-  const uint32_t nb2 = (uint32_t)(((a.ns + ITER_THREADS - 1) / ITER_THREADS) < 512 ? ((a.ns + ITER_THREADS - 1) / ITER_THREADS) : 512);
-  hipLaunchKernelGGL(k_search_todo, dim3(nb2 ? nb2 : 1), dim3(ITER_THREADS), 0, s, a);
+  hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, ntiles);
+  const uint32_t nb2 = (uint32_t)(((a.ns + ITER_THREADS - 1) / ITER_THREADS) < 2048 ? ((a.ns + ITER_THREADS - 1) / ITER_THREADS) : 2048);
+  hipLaunchKernelGGL(k_search_todo, dim3(nb2 ? nb2 : 1), dim3(ITER_THREADS), 0, s, a, tiles);
 }
 
 // ---- accumulation helpers ------------------------------------------------------------------------

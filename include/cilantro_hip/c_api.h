@@ -173,10 +173,10 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
 /* Tuning knobs (never change results beyond f64 summation order):
  *   "fused" (default 0): 1 = one fused search+accumulate kernel per iteration,
  *                        0 = search kernel (stores the matches) + streaming accumulation kernel.
- *   "tiled" (default 0): 1 = LDS-tiled search kernel (one workgroup stages the 6x6x6-cell region of a
- *                        4x4x4-cell cube of queries in LDS; exact, currently slower -- DESIGN.md section 5),
+ *   "tiled" (default 1): 1 = LDS-tiled search kernel (one workgroup stages the cell region around an
+ *                        8x8x8-cell cube of queries in LDS; tiles that do not fit fall back per tile),
  *                        0 = per-lane global-memory search.
- *   "cell_occupancy" (default 4): target points per grid cell, used by the next cilhip_set_target.
+ *   "cell_occupancy" (default 3): target points per grid cell, used by the next cilhip_set_target.
  *   "kernel_timing": same as cilhip_enable_kernel_timing. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation

@@ -305,3 +305,57 @@ def test_tiled_search_kernel_is_exact_too(Context, orc, n):
     if n <= 20000:
         bi, bd = orc.nn_brute(d["dst"], orc.transform_points(T, d["src"]), d["max_sq_dist"])
         assert np.array_equal(outs[0][1][0], bi)
+
+
+def _bumpy_surface(n, seed=7):
+    """Non-uniform (2-D manifold) cloud: a bumpy height field + its analytic normals; well conditioned for ICP."""
+    rng = np.random.default_rng(seed)
+    x = rng.random(n) * 2 - 1
+    y = rng.random(n) * 2 - 1
+    z = 0.15 * np.sin(3 * x) * np.cos(4 * y) + 0.05 * np.sin(11 * x + 1.0) * np.sin(9 * y)
+    dzdx = 0.45 * np.cos(3 * x) * np.cos(4 * y) + 0.55 * np.cos(11 * x + 1.0) * np.sin(9 * y)
+    dzdy = -0.6 * np.sin(3 * x) * np.sin(4 * y) + 0.45 * np.sin(11 * x + 1.0) * np.cos(9 * y)
+    nrm = np.stack([-dzdx, -dzdy, np.ones(n)], 1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return np.stack([x, y, z], 1).astype(np.float32), nrm.astype(np.float32)
+
+
+def test_surface_cloud_adaptive_grid_parity(Context, orc, hip_lib):
+    """Surface-like data: most grid cells are empty, the adaptive cell sizing and the generic shell search
+    (radius >> point spacing, as examples/rigid_icp.cpp:122 uses) are exercised."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f
+
+    n = 150000
+    dst, nrm = _bumpy_surface(n)
+    T_true = np.eye(4)
+    T_true[:3, :3] = syn.rot_xyz(0.02, -0.015, 0.01)
+    T_true[:3, 3] = [0.01, -0.008, 0.012]
+    Ti = np.linalg.inv(T_true)
+    rng = np.random.default_rng(11)
+    src = ((dst.astype(np.float64) + rng.normal(0, 3e-4, dst.shape)) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    src = src[rng.random(n) < 0.7]                              # partial overlap in count
+    max_sq = np.float32(0.1 * 0.1)                               # radius ~ 25x the point spacing
+    # kNN parity with mismatch classification (ties are legal, "worse" is not)
+    ctx = Context()
+    ctx.set_target(dst, nrm); ctx.set_source(src)
+    gi = ctx.grid_info()
+    assert gi.avg_occupancy < 40, gi.avg_occupancy               # adaptive sizing kept cells small
+    g_idx, g_d2 = gpu_nn(ctx, np.eye(4), max_sq)
+    q = orc.transform_points(np.eye(4), src)
+    di, si, dv = orc.KDTree(dst).find_correspondences(q, max_sq)
+    o_idx = np.full(len(src), -1, np.int64); o_idx[si] = di
+    o_d2 = np.zeros(len(src), np.float32); o_d2[si] = dv
+    nbad, ties, nearer, worse = classify_mismatches(orc, dst, q, g_idx, g_d2, o_idx, o_d2)
+    assert worse == 0 and nearer == 0 and nbad == ties and ties <= 5, (nbad, ties, nearer, worse)
+    bi, bd = orc.nn_brute(dst, q[:20000], max_sq)
+    assert np.array_equal(g_idx[:20000], bi)                     # == brute force incl. lowest-index ties
+    # end-to-end
+    for metric in (1, 0):
+        icp = (SimpleCombinedMetricRigidICP3f(dst, nrm, src) if metric else SimplePointToPointMetricRigidICP3f(dst, src))
+        icp.correspondenceSearchEngine().setMaxDistance(max_sq)
+        icp.setMaxNumberOfIterations(40).setConvergenceTolerance(1e-6)
+        T = icp.estimate().getTransform()
+        p = orc.make_params(metric=metric, max_iter=40, conv_tol=1e-6, max_sq_dist=max_sq, mode=orc.MODE_MIXED)
+        r = orc.icp_run(dst, nrm, src, p)
+        assert np.linalg.norm(T.astype(np.float64) - r["T"]) <= TOL_T, (metric, np.linalg.norm(T - r["T"]))
+        assert np.linalg.norm(T - T_true) < 2e-3
