@@ -41,7 +41,7 @@ struct cilhip_ctx {
   uint32_t* d_todo = nullptr;     // [ns] deferred queries + 2 counters at d_todo[ns..ns+1]: clean-up lists of the tiled search
   uint32_t* d_todo_tiles = nullptr; // [ntiles]
   uint32_t ntiles = 0;
-  bool tiled = true;              // true: LDS-tiled search kernel; false: per-lane global-memory search
+  int tiled = 1;                  // 0: per-lane global-memory search; 1: LDS-tiled search when the cloud is large enough; 2: always tiled
   bool src_sorted = false;
   float sort_T[16];
   float src_mean[3] = {0, 0, 0};
@@ -169,7 +169,7 @@ int cilhip_synchronize(cilhip_ctx* c) {
 int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!c || !key) return CILHIP_ERR_INVALID;
   if (!strcmp(key, "fused")) { c->fused = value != 0.0; return CILHIP_OK; }
-  if (!strcmp(key, "tiled")) { c->tiled = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "cell_occupancy")) { c->cell_occupancy = value; return CILHIP_OK; }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
@@ -287,7 +287,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
 
 // The LDS-tiled kernel runs 1024-thread workgroups, two per CU: below ~4 full rounds of tiles on the
 // 256 CUs the per-lane kernel (8x more, smaller workgroups) balances better (measured at 1M points).
-static bool use_tiled(const cilhip_ctx* c) { return c->tiled && c->ntiles >= 2048; }
+static bool use_tiled(const cilhip_ctx* c) { return c->tiled >= 2 || (c->tiled == 1 && c->ntiles >= 2048); }
 
 static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   IterArgs a{};

@@ -29,7 +29,7 @@ for n in a.n:
         ctx.set_target(d["dst"], d["dst_n"] if a.metric == "p2plane" else None)
         ctx.set_source(d["src"])
         ctx.set_option("fused", fused)
-        ctx.set_option("tiled", tiled)
+        ctx.set_option("tiled", 2 if tiled else 0)
         p = capi.IcpParams()
         ctx._L.cilhip_icp_default_params(C.byref(p))
         p.metric = capi.METRIC_COMBINED if a.metric == "p2plane" else capi.METRIC_POINT_TO_POINT
