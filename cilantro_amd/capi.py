@@ -19,7 +19,7 @@ NONE_IDX = 0xFFFFFFFF
 # every symbol include/cilantro_hip/c_api.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "cilhip_create", "cilhip_destroy", "cilhip_last_error", "cilhip_set_stream", "cilhip_synchronize",
-    "cilhip_set_target", "cilhip_set_source", "cilhip_get_means", "cilhip_find_correspondences",
+    "cilhip_set_target", "cilhip_set_source", "cilhip_set_source_normals", "cilhip_get_means", "cilhip_find_correspondences",
     "cilhip_get_nn", "cilhip_get_correspondences", "cilhip_estimate_point_to_point",
     "cilhip_estimate_combined", "cilhip_icp_default_params", "cilhip_icp_run", "cilhip_icp_begin",
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
@@ -83,6 +83,7 @@ def load():
     L.cilhip_synchronize.argtypes = [vp]
     L.cilhip_set_target.argtypes = [vp, f32p, f32p, C.c_size_t, C.c_int]
     L.cilhip_set_source.argtypes = [vp, f32p, C.c_size_t, C.c_int]
+    L.cilhip_set_source_normals.argtypes = [vp, f32p, C.c_int]
     L.cilhip_get_means.argtypes = [vp, f32p, f32p]
     L.cilhip_find_correspondences.argtypes = [vp, f32p, C.c_float, C.POINTER(C.c_size_t)]
     L.cilhip_get_nn.argtypes = [vp, vp, f32p, C.c_int]

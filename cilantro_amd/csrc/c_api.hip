@@ -45,6 +45,8 @@ struct cilhip_ctx {
   bool src_sorted = false;
   float sort_T[16];
   float src_mean[3] = {0, 0, 0};
+  float* d_src_nrm = nullptr;         // optional source normals, original order (4-cloud ctor => symmetric metric)
+  float4* d_src_nrm_sorted = nullptr;
   uint32_t* d_nn_pos = nullptr;
   float* d_nn_d2 = nullptr;
   bool have_nn = false;           // nn_pos/nn_d2 hold the result of a search
@@ -125,6 +127,9 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_out_idx) (void)hipFree(c->d_out_idx);
   if (c->d_out_d2) (void)hipFree(c->d_out_d2);
   if (c->d_tiles) (void)hipFree(c->d_tiles);
+  if (c->d_src_nrm) (void)hipFree(c->d_src_nrm);
+  if (c->d_src_nrm_sorted) (void)hipFree(c->d_src_nrm_sorted);
+  c->d_src_nrm = nullptr; c->d_src_nrm_sorted = nullptr;
   if (c->d_todo) (void)hipFree(c->d_todo);
   if (c->d_todo_tiles) (void)hipFree(c->d_todo_tiles);
   c->d_tiles = nullptr; c->ntiles = 0; c->d_todo = nullptr; c->d_todo_tiles = nullptr;
@@ -249,6 +254,21 @@ int cilhip_set_source(cilhip_ctx* c, const float* xyz, size_t n, int mem) {
   return CILHIP_OK;
 }
 
+int cilhip_set_source_normals(cilhip_ctx* c, const float* nrm, int mem) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (!c->has_source) return fail(c, CILHIP_ERR_INVALID, "set_source_normals: set_source first");
+  CK(c, hipSetDevice(c->device));
+  if (c->d_src_nrm) { (void)hipFree(c->d_src_nrm); c->d_src_nrm = nullptr; }
+  if (c->d_src_nrm_sorted) { (void)hipFree(c->d_src_nrm_sorted); c->d_src_nrm_sorted = nullptr; }
+  if (!nrm) return CILHIP_OK;                              // back to the 3-cloud (non-symmetric) form
+  int rc = upload(c, nrm, 3 * (size_t)c->ns, mem, &c->d_src_nrm);
+  if (rc) return rc;
+  CK(c, hipMalloc(&c->d_src_nrm_sorted, (c->ns ? c->ns : 1) * sizeof(float4)));
+  c->src_sorted = false;                                   // the sorted copy is (re)built with the next sort
+  c->have_nn = false;
+  return CILHIP_OK;
+}
+
 int cilhip_get_means(cilhip_ctx* c, float dm[3], float sm[3]) {
   if (!c) return CILHIP_ERR_INVALID;
   if (dm) memcpy(dm, c->dst_mean, sizeof(c->dst_mean));
@@ -278,6 +298,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->ntiles);
     if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
     CK(c, hipMalloc(&c->d_todo_tiles, ((size_t)c->ntiles + 1) * sizeof(uint32_t)));
+    if (c->d_src_nrm) launch_gather_by_w(c->d_src_sorted, c->d_src_nrm, c->ns, c->d_src_nrm_sorted, c->stream);
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
     c->have_nn = false;
@@ -293,6 +314,7 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   IterArgs a{};
   a.grid = c->grid;
   a.src = c->d_src_sorted;
+  a.src_nrm = c->d_src_nrm ? c->d_src_nrm_sorted : nullptr;
   a.ns = c->ns;
   a.max_sq = max_sq;
   for (int i = 0; i < 3; ++i) a.dst_mean[i] = c->dst_mean[i];

@@ -56,6 +56,7 @@ enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOT
 struct IterArgs {
   GridDev grid;
   const float4* src;       // [ns] source sorted by target-grid cell {x,y,z,orig_idx}
+  const float4* src_nrm;   // [ns] source normals in the same order, or nullptr (non-null => symmetric metric)
   uint32_t ns;
   float max_sq;            // engine max_distance_ (squared)
   float dst_mean[3];
@@ -93,6 +94,7 @@ void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3]
 void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
                        const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,
                        hipStream_t s);
+void launch_gather_by_w(const float4* src_sorted, const float* in_xyz, uint32_t ns, float4* out, hipStream_t s);
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
 void launch_residuals(const IterArgs& a, int metric, float w_p2p, float w_p2pl, float* out, hipStream_t s);
 int iter_num_blocks(uint32_t ns);

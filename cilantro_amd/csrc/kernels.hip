@@ -733,7 +733,18 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
         const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
         accA[0] += 1.0;
         if (TR::plane) {
-          const float4 nv = a.grid.nrm[pos];
+          float4 nv = a.grid.nrm[pos];
+          if (a.src_nrm) {
+            // symmetric metric (transform_estimation.hpp:705-706): n = n_dst + tform.linear() * n_src', with
+            // n_src' = transform_.linear() * n_src (transformNormals, core/space_transformations.hpp:374-390)
+            const float4 sn = a.src_nrm[i];
+            const float t0 = __fadd_rn(__fmul_rn(T[0], sn.x), __fadd_rn(__fmul_rn(T[4], sn.y), __fmul_rn(T[8], sn.z)));
+            const float t1 = __fadd_rn(__fmul_rn(T[1], sn.x), __fadd_rn(__fmul_rn(T[5], sn.y), __fmul_rn(T[9], sn.z)));
+            const float t2 = __fadd_rn(__fmul_rn(T[2], sn.x), __fadd_rn(__fmul_rn(T[6], sn.y), __fmul_rn(T[10], sn.z)));
+            nv.x = __fadd_rn(nv.x, __fadd_rn(__fmul_rn(iL[0], t0), __fadd_rn(__fmul_rn(iL[1], t1), __fmul_rn(iL[2], t2))));
+            nv.y = __fadd_rn(nv.y, __fadd_rn(__fmul_rn(iL[3], t0), __fadd_rn(__fmul_rn(iL[4], t1), __fmul_rn(iL[5], t2))));
+            nv.z = __fadd_rn(nv.z, __fadd_rn(__fmul_rn(iL[6], t0), __fadd_rn(__fmul_rn(iL[7], t1), __fmul_rn(iL[8], t2))));
+          }
           float e[6];
           e[0] = __fsub_rn(__fmul_rn(a1, nv.z), __fmul_rn(a2, nv.y));   // (d+s).cross(n)  :337
           e[1] = __fsub_rn(__fmul_rn(a2, nv.x), __fmul_rn(a0, nv.z));
@@ -1001,6 +1012,20 @@ __global__ void k_count_found(const uint32_t* __restrict__ nn_pos, uint32_t ns, 
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// reorder per-source attributes (normals) into the sorted-source order: out[i] = {in[orig(i)], 0}
+__global__ void k_gather_by_w(const float4* __restrict__ src_sorted, const float* __restrict__ in_xyz, uint32_t ns, float4* out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t o = __float_as_uint(src_sorted[i].w);
+    out[i] = make_float4(in_xyz[3 * (size_t)o], in_xyz[3 * (size_t)o + 1], in_xyz[3 * (size_t)o + 2], 0.0f);
+  }
+}
+
+void launch_gather_by_w(const float4* src_sorted, const float* in_xyz, uint32_t ns, float4* out, hipStream_t s) {
+  if (ns == 0) return;
+  const int nb = (int)((ns + 255) / 256 < 4096 ? (ns + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_gather_by_w, dim3(nb), dim3(256), 0, s, src_sorted, in_xyz, ns, out);
+}
+
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s) {
   (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
   if (ns == 0) return;
@@ -1030,8 +1055,12 @@ __global__ __launch_bounds__(256) void k_residuals(IterArgs a, int metric, float
       if (metric == 0) {
         v = sq;
       } else {
-        const float4 nv = a.grid.nrm[best.pos];
-        const float pd = __fadd_rn(__fmul_rn(nv.x, dx), __fadd_rn(__fmul_rn(nv.y, dy), __fmul_rn(nv.z, dz)));
+        float4 nv = a.grid.nrm[best.pos];
+        if (a.src_nrm) {  // `normal += src_normals_.col(i)` -- the UNtransformed source normal, as the reference (:237)
+          const float4 sn = a.src_nrm[i];
+          nv.x = __fadd_rn(nv.x, sn.x); nv.y = __fadd_rn(nv.y, sn.y); nv.z = __fadd_rn(nv.z, sn.z);
+        }
+        const float pd =__fadd_rn(__fmul_rn(nv.x, dx), __fadd_rn(__fmul_rn(nv.y, dy), __fmul_rn(nv.z, dz)));
         v = __fadd_rn(__fmul_rn(w_p2p, sq), __fmul_rn(__fmul_rn(w_p2pl, pd), pd));
       }
     }

@@ -111,10 +111,15 @@ class Context:
         self._ck(self._L.cilhip_set_target(self._h, p, q, n, mem))
         self.n_target = n
 
-    def set_source(self, points):
+    def set_source(self, points, normals=None):
         p, n, mem, k = _as_cloud(points)
         self._ck(self._L.cilhip_set_source(self._h, p, n, mem))
         self.n_source = n
+        if normals is not None:
+            q, nn, mem2, k2 = _as_cloud(normals)
+            if nn != n:
+                raise ValueError("source normals must match source points")
+            self._ck(self._L.cilhip_set_source_normals(self._h, q, mem2))
 
     def means(self):
         dm = np.zeros(3, np.float32); sm = np.zeros(3, np.float32)
@@ -363,10 +368,12 @@ class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
     """registration/icp_common_instances.hpp:261 (wrapper :74-97) over
     CombinedMetricSingleTransformICP (icp_single_transform_combined_metric.hpp); defaults :44-47."""
 
-    def __init__(self, dst_points, dst_normals, src_points, device=0, stream=None):
+    def __init__(self, dst_points, dst_normals, src_points, src_normals=None, device=0, stream=None):
+        """Three clouds: combined (point-to-point + point-to-plane) metric.  Four clouds (src_normals):
+        the symmetric objective (icp_common_instances.hpp:88-97 -> transform_estimation.hpp:604-739)."""
         super().__init__(device, stream)
         self._ctx.set_target(dst_points, dst_normals)
-        self._ctx.set_source(src_points)
+        self._ctx.set_source(src_points, src_normals)
         self.max_optimization_iterations_ = 1
         self.optimization_convergence_tol_ = np.float32(1e-5)
         self.point_to_point_weight_ = np.float32(0.0)

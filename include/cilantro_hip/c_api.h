@@ -72,6 +72,11 @@ int cilhip_set_target(cilhip_ctx* ctx, const float* xyz, const float* normals_or
  * (correspondence_search/common_transformable_feature_adaptors.hpp:14-17) and src_mean_
  * (icp_single_transform_combined_metric.hpp:55-58). */
 int cilhip_set_source(cilhip_ctx* ctx, const float* xyz, size_t n, int mem);
+/* Optional source normals (call after cilhip_set_source; NULL removes them).  With them the combined
+ * metric becomes the SYMMETRIC objective, exactly as constructing CombinedMetricSingleTransformICP with four
+ * clouds does (icp_single_transform_combined_metric.hpp:63-93,182-189 -> estimateTransformSymmetricMetric,
+ * transform_estimation.hpp:604-739: n = n_dst + R*n_src), and computeResiduals adds them (:237). */
+int cilhip_set_source_normals(cilhip_ctx* ctx, const float* normals_or_null, int mem);
 /* dst_mean_ / src_mean_ as the ICP classes hold them (f64 sum, rounded to f32). */
 int cilhip_get_means(cilhip_ctx* ctx, float dst_mean[3], float src_mean[3]);
 

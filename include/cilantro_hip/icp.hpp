@@ -331,6 +331,14 @@ public:
     engine_.setSourceCount_(n_src_);
   }
 
+  // four-cloud form (icp_common_instances.hpp:88-97): source normals => symmetric metric
+  SimpleCombinedMetricRigidICP3f(const ConstPointsView& dst_p, const ConstPointsView& dst_n, const ConstPointsView& src_p,
+                                 const ConstPointsView& src_n, int device = 0)
+      : SimpleCombinedMetricRigidICP3f(dst_p, dst_n, src_p, device) {
+    if (src_n.cols() != src_p.cols()) throw std::invalid_argument("src normals must match src points");
+    internal::check(ctx_.get(), cilhip_set_source_normals(ctx_.get(), src_n.data(), CILHIP_MEM_HOST), "set_source_normals");
+  }
+
   inline float getPointToPointMetricWeight() const { return point_to_point_weight_; }
   inline SimpleCombinedMetricRigidICP3f& setPointToPointMetricWeight(float w) { point_to_point_weight_ = w; return *this; }
   inline float getPointToPlaneMetricWeight() const { return point_to_plane_weight_; }

@@ -268,6 +268,20 @@ void orc_transform_points(const float T[16], const float* s, size_t n, float* ou
   }
 }
 
+/* core/space_transformations.hpp:374-390 transformNormals for a RigidTransform: n' = L*n (same pinned pairing) */
+void orc_transform_normals(const float T[16], const float* n, size_t cnt, float* out) {
+  const float l00 = T[0], l10 = T[1], l20 = T[2];
+  const float l01 = T[4], l11 = T[5], l21 = T[6];
+  const float l02 = T[8], l12 = T[9], l22 = T[10];
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < cnt; ++i) {
+    const float x = n[3 * i], y = n[3 * i + 1], z = n[3 * i + 2];
+    out[3 * i + 0] = l00 * x + (l01 * y + l02 * z);
+    out[3 * i + 1] = l10 * x + (l11 * y + l12 * z);
+    out[3 * i + 2] = l20 * x + (l21 * y + l22 * z);
+  }
+}
+
 /* correspondence_search/correspondence_search_kd_tree_utilities.hpp:7-51 (ref_is_first = true,
  * DistanceEvaluator = identity on d2, core/common_pair_evaluators.hpp:13-27). */
 size_t orc_find_correspondences(const orc_kdtree* t, const float* q, size_t nq, float max_d,
@@ -420,7 +434,7 @@ int orc_estimate_p2p(const float* dst, const float* src, const int64_t* di, cons
   return ok;
 }
 
-int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* src_p,
+int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* src_p, const float* src_n,
                           const int64_t* di, const int64_t* si, size_t n, float w_p2p, float w_p2pl,
                           size_t max_iter, float conv_tol, const float dst_mean[3],
                           const float src_mean[3], int mode, float T_out[16], double* AtA_out,
@@ -428,15 +442,15 @@ int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* s
   int ok;
   if (mode == ORC_MODE_F32) {
     float L[9], t[3];
-    ok = estimate_combined_m0(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    ok = estimate_combined_m0(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
     pack_T_f32(L, t, T_out);
   } else if (mode == ORC_MODE_MIXED) {
     double L[9], t[3];
-    ok = estimate_combined_m1(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    ok = estimate_combined_m1(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
     pack_T_f64(L, t, T_out);
   } else {
     double L[9], t[3];
-    ok = estimate_combined_m2(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    ok = estimate_combined_m2(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
     pack_T_f64(L, t, T_out);
   }
   return ok;
@@ -459,7 +473,7 @@ void orc_mean3(const float* xyz, size_t n, int mode, float mean[3]) {
 /* One outer iteration's updateEstimate() given the correspondences.
  * icp_single_transform_point_to_point_metric.hpp:46-65 / icp_single_transform_combined_metric.hpp:173-217 */
 static float icp_update_impl(const float* dst_p, const float* dst_n, const float* src_trans,
-                             const float T_cur[16], const int64_t* di, const int64_t* si, size_t nc,
+                             const float* src_nrm_trans, const float T_cur[16], const int64_t* di, const int64_t* si, size_t nc,
                              const orc_icp_params* prm, const float dst_mean[3],
                              const float src_mean[3], float T_new[16]) {
   const int mode = prm->mode;
@@ -480,34 +494,39 @@ static float icp_update_impl(const float* dst_p, const float* dst_n, const float
   orc_transform_points(T_cur, src_mean, 1, smt);
   if (mode == ORC_MODE_F32) {
     float L[9], t[3];
-    estimate_combined_m0(dst_p, dst_n, src_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    estimate_combined_m0(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
     return compose_m0(L, t, T_cur, T_new);
   } else if (mode == ORC_MODE_MIXED) {
     double L[9], t[3];
-    estimate_combined_m1(dst_p, dst_n, src_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    estimate_combined_m1(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
     return compose_m1(L, t, T_cur, T_new);
   } else {
     double L[9], t[3];
-    estimate_combined_m2(dst_p, dst_n, src_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    estimate_combined_m2(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
     return compose_m2(L, t, T_cur, T_new);
   }
 }
 
 float orc_icp_update(const float* dst_p, const float* dst_n, size_t nd, const float* src_p,
-                     size_t ns, const float T_cur[16], const int64_t* di, const int64_t* si,
+                     const float* src_n, size_t ns, const float T_cur[16], const int64_t* di, const int64_t* si,
                      size_t nc, const orc_icp_params* prm, float T_new[16]) {
   float dst_mean[3], src_mean[3];
   orc_mean3(dst_p, nd, prm->mode, dst_mean);               /* combined ctor :51-58 */
   orc_mean3(src_p, ns, prm->mode, src_mean);
   float* src_trans = (float*)malloc(3 * (ns ? ns : 1) * sizeof(float));
   orc_transform_points(T_cur, src_p, ns, src_trans);       /* transformPoints, space_transformations.hpp:203-216 */
-  float d = icp_update_impl(dst_p, dst_n, src_trans, T_cur, di, si, nc, prm, dst_mean, src_mean, T_new);
-  free(src_trans);
+  float* nrm_trans = NULL;
+  if (src_n && prm->metric == 1) {                         /* icp_single_transform_combined_metric.hpp:182-189 */
+    nrm_trans = (float*)malloc(3 * (ns ? ns : 1) * sizeof(float));
+    orc_transform_normals(T_cur, src_n, ns, nrm_trans);
+  }
+  float d = icp_update_impl(dst_p, dst_n, src_trans, nrm_trans, T_cur, di, si, nc, prm, dst_mean, src_mean, T_new);
+  free(src_trans); free(nrm_trans);
   return d;
 }
 
 /* registration/icp_base.hpp:68-87 */
-int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* src_p, size_t ns,
+int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* src_p, const float* src_n, size_t ns,
                 const float* T0, const orc_icp_params* prm, const orc_kdtree* tree_in,
                 orc_icp_result* out) {
   memset(out, 0, sizeof(*out));
@@ -521,6 +540,7 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
   int64_t* di = (int64_t*)malloc(cap * sizeof(int64_t));
   int64_t* si = (int64_t*)malloc(cap * sizeof(int64_t));
   float* d2 = (float*)malloc(cap * sizeof(float));
+  float* nq_trans = (src_n && prm->metric == 1) ? (float*)malloc(3 * cap * sizeof(float)) : NULL;
   orc_kdtree* own = NULL;
   const orc_kdtree* tree = tree_in;
   float last = INFINITY;
@@ -538,7 +558,8 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
     double t1 = now_s();
     out->t_knn_s += t1 - t0;
     float Tn[16];
-    last = icp_update_impl(dst_p, dst_n, q, T, di, si, nc, prm, dst_mean, src_mean, Tn);
+    if (nq_trans) orc_transform_normals(T, src_n, ns, nq_trans);
+    last = icp_update_impl(dst_p, dst_n, q, nq_trans, T, di, si, nc, prm, dst_mean, src_mean, Tn);
     memcpy(T, Tn, sizeof(T));
     out->t_est_s += now_s() - t1;
     out->last_ncorr = nc;
@@ -548,7 +569,7 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
   memcpy(out->T, T, sizeof(T));
   out->iterations = it;
   out->last_delta_norm = last;
-  free(q); free(di); free(si); free(d2);
+  free(q); free(di); free(si); free(d2); free(nq_trans);
   if (own) orc_kdtree_free(own);
   return 0;
 }

@@ -48,6 +48,8 @@ size_t orc_kdtree_knn_in_radius(const orc_kdtree* t, const float q[3], size_t k,
 /* ---- transform (common_transformable_feature_adaptors.hpp:28-33) ----------------------------- */
 /* T: 4x4 column-major (Eigen::Transform<float,3,Isometry>::matrix().data()). */
 void orc_transform_points(const float T[16], const float* src_xyz, size_t n, float* out_xyz);
+/* core/space_transformations.hpp:374-390 (rigid): n' = L*n */
+void orc_transform_normals(const float T[16], const float* nrm, size_t n, float* out);
 
 /* ---- correspondence search (correspondence_search_kd_tree_utilities.hpp:7-51, ref_is_first) -- */
 /* q: already transformed query points.  Outputs (capacity nq): ascending src index order.
@@ -92,8 +94,9 @@ int orc_estimate_p2p(const float* dst_xyz, const float* src_trans_xyz, const int
 /* registration/transform_estimation.hpp:237-367 (rigid, combined metric, 3D).
  * Unity weight evaluators.  AtA_out(36,row-major)/Atb_out(6): first Gauss-Newton step's normal
  * equations (optional).  Returns 1 if converged inside max_iter (d_theta.norm() < tol). */
+/* src_nrm_trans (optional): transformed source normals => estimateTransformSymmetricMetric (:604-739). */
 int orc_estimate_combined(const float* dst_xyz, const float* dst_nrm, const float* src_trans_xyz,
-                          const int64_t* dst_idx, const int64_t* src_idx, size_t ncorr,
+                          const float* src_nrm_trans, const int64_t* dst_idx, const int64_t* src_idx, size_t ncorr,
                           float w_p2p, float w_p2pl, size_t max_iter, float conv_tol,
                           const float dst_mean[3], const float src_mean[3], int mode,
                           float T_out[16], double* AtA_out, double* Atb_out);
@@ -123,13 +126,13 @@ typedef struct {
 /* dst_nrm may be NULL for metric 0.  T0: initial transform (col-major) or NULL = identity.
  * tree: optional prebuilt kd-tree on dst (NULL = build here, as the engine does lazily). */
 int orc_icp_run(const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz,
-                size_t ns, const float* T0, const orc_icp_params* prm, const orc_kdtree* tree,
+                const float* src_nrm_or_null /* 4-cloud ctor: symmetric metric */, size_t ns, const float* T0, const orc_icp_params* prm, const orc_kdtree* tree,
                 orc_icp_result* out);
 
 /* One ICP outer iteration given correspondences (used by tests to step GPU vs oracle in lockstep).
  * T_cur -> T_new, returns delta norm. */
 float orc_icp_update(const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz,
-                     size_t ns, const float T_cur[16], const int64_t* dst_idx,
+                     const float* src_nrm_or_null, size_t ns, const float T_cur[16], const int64_t* dst_idx,
                      const int64_t* src_idx, size_t ncorr, const orc_icp_params* prm,
                      float T_new[16]);
 

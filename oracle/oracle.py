@@ -82,14 +82,15 @@ def lib():
         L.orc_estimate_p2p.restype = C.c_int
         L.orc_estimate_p2p.argtypes = [_f32p, _f32p, _i64p, _i64p, C.c_size_t, C.c_int, _f32p, C.c_void_p]
         L.orc_estimate_combined.restype = C.c_int
-        L.orc_estimate_combined.argtypes = [_f32p, _f32p, _f32p, _i64p, _i64p, C.c_size_t, C.c_float,
+        L.orc_transform_normals.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
+        L.orc_estimate_combined.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, _i64p, _i64p, C.c_size_t, C.c_float,
                                             C.c_float, C.c_size_t, C.c_float, _f32p, _f32p, C.c_int,
                                             _f32p, C.c_void_p, C.c_void_p]
         L.orc_icp_run.restype = C.c_int
-        L.orc_icp_run.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.c_void_p,
+        L.orc_icp_run.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_void_p, C.c_size_t, C.c_void_p,
                                   C.POINTER(IcpParams), C.c_void_p, C.POINTER(IcpResult)]
         L.orc_icp_update.restype = C.c_float
-        L.orc_icp_update.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_size_t, _f32p, _i64p,
+        L.orc_icp_update.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_void_p, C.c_size_t, _f32p, _i64p,
                                      _i64p, C.c_size_t, C.POINTER(IcpParams), _f32p]
         L.orc_mean3.argtypes = [_f32p, C.c_size_t, C.c_int, _f32p]
         _lib = L
@@ -217,13 +218,21 @@ def estimate_p2p(dst, src_trans, dst_idx, src_idx, mode=MODE_MIXED):
     return T_from_colmajor(T), sums, bool(ok)
 
 
+def transform_normals(T, nrm):
+    nrm = _c(nrm).reshape(-1, 3)
+    out = np.empty_like(nrm)
+    lib().orc_transform_normals(T_to_colmajor(T), nrm, len(nrm), out)
+    return out
+
+
 def estimate_combined(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, dst_mean, src_mean,
-                      max_iter=1, conv_tol=1e-5, mode=MODE_MIXED):
+                      max_iter=1, conv_tol=1e-5, mode=MODE_MIXED, src_n_trans=None):
     dst = _c(dst).reshape(-1, 3); dst_n = _c(dst_n).reshape(-1, 3)
     src_trans = _c(src_trans).reshape(-1, 3)
     di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
     T = np.zeros(16, np.float32); AtA = np.zeros(36, np.float64); Atb = np.zeros(6, np.float64)
-    ok = lib().orc_estimate_combined(dst, dst_n, src_trans, di, si, len(di), w_p2p, w_p2pl, max_iter,
+    sn = _c(src_n_trans).reshape(-1, 3) if src_n_trans is not None else None
+    ok = lib().orc_estimate_combined(dst, dst_n, src_trans, sn.ctypes.data if sn is not None else None, di, si, len(di), w_p2p, w_p2pl, max_iter,
                                      conv_tol, _c(dst_mean).reshape(3), _c(src_mean).reshape(3), mode,
                                      T, AtA.ctypes.data, Atb.ctypes.data)
     return T_from_colmajor(T), AtA.reshape(6, 6), Atb, bool(ok)
@@ -242,14 +251,16 @@ def make_params(metric=METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=15, conv
                      max_sq_dist, mode, num_threads)
 
 
-def icp_run(dst, dst_n, src, params, T0=None, tree=None):
+def icp_run(dst, dst_n, src, params, T0=None, tree=None, src_n=None):
     dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3)
     dn = None
     if dst_n is not None:
         dn = _c(dst_n).reshape(-1, 3)
     res = IcpResult()
     t0 = T_to_colmajor(T0) if T0 is not None else None
-    lib().orc_icp_run(dst, dn.ctypes.data if dn is not None else None, len(dst), src, len(src),
+    sn = _c(src_n).reshape(-1, 3) if src_n is not None else None
+    lib().orc_icp_run(dst, dn.ctypes.data if dn is not None else None, len(dst), src,
+                      sn.ctypes.data if sn is not None else None, len(src),
                       t0.ctypes.data if t0 is not None else None, C.byref(params),
                       tree.h if tree is not None else None, C.byref(res))
     return {
@@ -261,11 +272,13 @@ def icp_run(dst, dst_n, src, params, T0=None, tree=None):
     }
 
 
-def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params):
+def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params, src_n=None):
     dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3)
     dn = _c(dst_n).reshape(-1, 3) if dst_n is not None else None
     di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
     Tn = np.zeros(16, np.float32)
-    d = lib().orc_icp_update(dst, dn.ctypes.data if dn is not None else None, len(dst), src, len(src),
+    sn = _c(src_n).reshape(-1, 3) if src_n is not None else None
+    d = lib().orc_icp_update(dst, dn.ctypes.data if dn is not None else None, len(dst), src,
+                             sn.ctypes.data if sn is not None else None, len(src),
                              T_to_colmajor(T_cur), di, si, len(di), C.byref(params), Tn)
     return T_from_colmajor(Tn), float(d)

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     p.metric = 1; p.w_p2p = 0; p.w_p2pl = 1; p.max_iter = 30; p.conv_tol = 1e-5f; p.max_opt_iter = 1; p.opt_conv_tol = 1e-5f;
     p.max_sq_dist = max_sq; p.mode = ORC_MODE_MIXED; p.num_threads = 0;
     orc_icp_result r;
-    orc_icp_run(dst.data(), nrm.data(), n, src.data(), n, nullptr, &p, nullptr, &r);
+    orc_icp_run(dst.data(), nrm.data(), n, src.data(), nullptr, n, nullptr, &p, nullptr, &r);
     const double e1 = frob(tf.m, r.T);
     std::printf("combined: iters gpu=%zu oracle=%zu converged=%d |T_gpu-T_oracle|_F=%.3e\n", icp.getNumberOfPerformedIterations(), r.iterations, (int)icp.hasConverged(), e1);
     if (!(e1 <= 1e-5) || !icp.hasConverged()) ++failures;
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
     icp2.correspondenceSearchEngine().setMaxDistance(max_sq);
     icp2.setMaxNumberOfIterations(30).setConvergenceTolerance(1e-5f).estimate();
     p.metric = 0;
-    orc_icp_run(dst.data(), nullptr, n, src.data(), n, nullptr, &p, nullptr, &r);
+    orc_icp_run(dst.data(), nullptr, n, src.data(), nullptr, n, nullptr, &p, nullptr, &r);
     const double e2 = frob(icp2.getTransform().m, r.T);
     std::printf("point-to-point: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp2.getNumberOfPerformedIterations(), r.iterations, e2);
     if (!(e2 <= 1e-5)) ++failures;

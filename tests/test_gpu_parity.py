@@ -359,3 +359,37 @@ def test_surface_cloud_adaptive_grid_parity(Context, orc, hip_lib):
         r = orc.icp_run(dst, nrm, src, p)
         assert np.linalg.norm(T.astype(np.float64) - r["T"]) <= TOL_T, (metric, np.linalg.norm(T - r["T"]))
         assert np.linalg.norm(T - T_true) < 2e-3
+
+
+def test_symmetric_metric_vs_oracle(orc, hip_lib):
+    """Four-cloud constructor => estimateTransformSymmetricMetric (transform_estimation.hpp:604-739) and the
+    residual with the added source normal (icp_single_transform_combined_metric.hpp:237)."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(120000, perturb=0.5)
+    Ri = np.linalg.inv(d["T_true"])[:3, :3]
+    src_n = (d["dst_n"].astype(np.float64) @ Ri.T).astype(np.float32)     # normals of the source points
+    for w_p2p, steps in ((0.0, 1), (0.2, 2)):
+        icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"], src_n)
+        icp.setPointToPointMetricWeight(w_p2p).setMaxNumberOfOptimizationStepIterations(steps)
+        icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+        icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, w_p2p=w_p2p, w_p2pl=1.0, max_iter=8, conv_tol=0.0, max_opt_iter=steps,
+                            max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+        r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p, src_n=src_n)
+        assert np.linalg.norm(Tg.astype(np.float64) - r["T"]) <= TOL_T, (w_p2p, steps)
+        # differs from the non-symmetric result (so the source normals are really used) yet converges to the truth
+        r3 = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+        assert np.abs(r3["T"] - r["T"]).max() > 0
+        assert np.linalg.norm(Tg - d["T_true"]) < 1e-3
+    res = icp.getResiduals()
+    q = orc.transform_points(Tg, d["src"])
+    bi, _ = orc.nn_brute(d["dst"], q[:5000], np.float32(3.4e38))
+    p_ = d["dst"][bi]
+    dx, dy, dz = p_[:, 0] - q[:5000, 0], p_[:, 1] - q[:5000, 1], p_[:, 2] - q[:5000, 2]
+    sq = dx * dx + (dy * dy + dz * dz)
+    n = d["dst_n"][bi] + src_n[:5000]
+    pd = n[:, 0] * dx + (n[:, 1] * dy + n[:, 2] * dz)
+    exp = np.float32(0.2) * sq + (np.float32(1.0) * pd) * pd
+    assert np.array_equal(res[:5000], exp.astype(np.float32))
