@@ -31,6 +31,8 @@ struct cilhip_ctx {
   size_t grid_cells = 0;
   double build_ms = 0.0;
   float dst_mean[3] = {0, 0, 0};
+  uint32_t index_offset = 0;      // global index of this shard's first target point (target-sharded runs)
+  uint32_t* d_inv_perm = nullptr; // [n_target] original local index -> sorted position (built on first use)
 
   // source
   bool has_source = false;
@@ -146,6 +148,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->has_target) free_grid(c->grid);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_inv_perm) (void)hipFree(c->d_inv_perm);
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_sums) (void)hipFree(c->d_sums);
@@ -207,6 +210,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   CK(c, hipSetDevice(c->device));
   auto t0 = std::chrono::steady_clock::now();
   if (c->has_target) { free_grid(c->grid); c->has_target = false; }
+  if (c->d_inv_perm) { (void)hipFree(c->d_inv_perm); c->d_inv_perm = nullptr; }
   float *d_xyz = nullptr, *d_nrm = nullptr;
   int rc = upload(c, xyz, 3 * n, mem, &d_xyz);
   if (rc) return rc;
@@ -664,6 +668,53 @@ int cilhip_icp_apply_sums(cilhip_ctx* c, const double* sums_dev) {
   sa.nblocks = 0;
   sa.reduced = sums_dev;
   launch_solve(sa, c->stream);
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
+int cilhip_set_shard_info(cilhip_ctx* c, uint64_t target_index_offset, const float* dst_mean, const float* src_mean) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (target_index_offset + (c->has_target ? c->grid.n : 0) > 0xFFFFFFFFull) return fail(c, CILHIP_ERR_INVALID, "global target indices must fit 32 bits");
+  c->index_offset = (uint32_t)target_index_offset;
+  if (dst_mean) memcpy(c->dst_mean, dst_mean, sizeof(c->dst_mean));
+  if (src_mean) memcpy(c->src_mean, src_mean, sizeof(c->src_mean));
+  return CILHIP_OK;
+}
+
+int cilhip_icp_partial_keys(cilhip_ctx* c, uint64_t* keys_dev) {
+  if (!c || !keys_dev) return CILHIP_ERR_INVALID;
+  if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
+  CK(c, hipSetDevice(c->device));
+  IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
+  if (c->ns) {
+    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);
+    else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
+    launch_pack_keys(c->d_src_sorted, c->grid.pts, c->d_nn_pos, c->d_nn_d2, c->ns, c->index_offset,
+                     reinterpret_cast<unsigned long long*>(keys_dev), c->stream);
+  }
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
+int cilhip_icp_sums_from_keys(cilhip_ctx* c, const uint64_t* keys_dev, double* sums_dev) {
+  if (!c || !keys_dev || !sums_dev) return CILHIP_ERR_INVALID;
+  if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
+  CK(c, hipSetDevice(c->device));
+  if (!c->d_inv_perm) {
+    CK(c, hipMalloc(&c->d_inv_perm, (c->grid.n ? c->grid.n : 1) * sizeof(uint32_t)));
+    launch_inv_perm(c->grid.pts, c->grid.n, c->d_inv_perm, c->stream);
+  }
+  const int im = iter_metric_of(&c->run_prm);
+  IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
+  const int nb = iter_num_blocks(c->ns);
+  if (c->ns) {
+    launch_keys_to_pos(c->d_src_sorted, reinterpret_cast<const unsigned long long*>(keys_dev), c->d_inv_perm, c->ns,
+                       c->index_offset, c->grid.n, c->d_nn_pos, c->d_nn_d2, c->stream);
+    launch_iter(a, im, false, false, nb, c->stream);
+    launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);
+  } else {
+    CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));
+  }
   CK(c, hipGetLastError());
   return CILHIP_OK;
 }

@@ -1026,6 +1026,60 @@ void launch_gather_by_w(const float4* src_sorted, const float* in_xyz, uint32_t 
   hipLaunchKernelGGL(k_gather_by_w, dim3(nb), dim3(256), 0, s, src_sorted, in_xyz, ns, out);
 }
 
+// ---- target-sharded runs (SURVEY.md 8(e) partitioning A) -------------------------------------------
+// Every rank searches ALL source points against its own target shard and publishes, per source point
+// (ORIGINAL source order, so the ranks' arrays line up), the packed key (bits(d2) << 32) | GLOBAL target
+// index; "none" = 0x7fff...f so that a signed-int64 MIN all-reduce picks the globally nearest target
+// (ties -> lowest global index, exactly the single-GPU rule).
+constexpr unsigned long long KEY_NONE = 0x7fffffffffffffffull;
+
+__global__ void k_pack_keys(const float4* __restrict__ src_sorted, const float4* __restrict__ dst_sorted,
+                            const uint32_t* __restrict__ nn_pos, const float* __restrict__ nn_d2, uint32_t ns,
+                            uint32_t index_offset, unsigned long long* keys) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t orig = __float_as_uint(src_sorted[i].w);
+    const uint32_t pos = nn_pos[i];
+    keys[orig] = (pos == NONE_U32) ? KEY_NONE
+                                   : (((unsigned long long)__float_as_uint(nn_d2[i]) << 32) |
+                                      (unsigned long long)(__float_as_uint(dst_sorted[pos].w) + index_offset));
+  }
+}
+
+// after the MIN all-reduce: keep the pairs whose winning target lives in THIS rank's shard
+__global__ void k_keys_to_pos(const float4* __restrict__ src_sorted, const unsigned long long* __restrict__ keys,
+                              const uint32_t* __restrict__ inv_perm, uint32_t ns, uint32_t index_offset, uint32_t n_local,
+                              uint32_t* nn_pos, float* nn_d2) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const unsigned long long k = keys[__float_as_uint(src_sorted[i].w)];
+    uint32_t pos = NONE_U32;
+    if (k != KEY_NONE) {
+      const uint32_t gidx = (uint32_t)k;
+      if (gidx >= index_offset && gidx - index_offset < n_local) pos = inv_perm[gidx - index_offset];
+    }
+    nn_pos[i] = pos;
+    nn_d2[i] = __uint_as_float((uint32_t)(k >> 32));
+  }
+}
+
+__global__ void k_inv_perm(const float4* __restrict__ dst_sorted, uint32_t n, uint32_t* inv) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    inv[__float_as_uint(dst_sorted[i].w)] = i;
+}
+
+static inline int blocks_for(uint32_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096) + (n == 0); }
+
+void launch_pack_keys(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos, const float* nn_d2,
+                      uint32_t ns, uint32_t index_offset, unsigned long long* keys, hipStream_t s) {
+  if (ns) hipLaunchKernelGGL(k_pack_keys, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, dst_sorted, nn_pos, nn_d2, ns, index_offset, keys);
+}
+void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys, const uint32_t* inv_perm, uint32_t ns,
+                        uint32_t index_offset, uint32_t n_local, uint32_t* nn_pos, float* nn_d2, hipStream_t s) {
+  if (ns) hipLaunchKernelGGL(k_keys_to_pos, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, keys, inv_perm, ns, index_offset, n_local, nn_pos, nn_d2);
+}
+void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_inv_perm, dim3(blocks_for(n)), dim3(256), 0, s, dst_sorted, n, inv);
+}
+
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s) {
   (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
   if (ns == 0) return;

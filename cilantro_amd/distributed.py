@@ -125,3 +125,70 @@ def default_params(metric=capi.METRIC_COMBINED, **kw):
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+# ---- target-sharded runs (BASELINE configs[3]; SURVEY.md 8(e) partitioning A) ---------------------------
+KEY_NONE = 0x7FFFFFFFFFFFFFFF  # packed (d2, global index) key meaning "no neighbour in this shard"
+
+
+class HipTargetShardEngine:
+    """Per-rank engine for a target cloud sharded by index over the ranks: this rank indexes
+    dst[lo:hi) only, holds ALL source points, and tags its matches with GLOBAL target indices."""
+
+    def __init__(self, dst_shard, dst_normals_shard, src_points, index_offset, global_dst_mean, device):
+        import torch
+
+        from .icp import Context
+
+        self.torch = torch
+        self.ctx = Context(device, torch.cuda.current_stream().cuda_stream)
+        self.ctx.set_target(dst_shard, dst_normals_shard)
+        self.ctx.set_source(src_points)
+        self.ctx.set_shard_info(index_offset, dst_mean=global_dst_mean)
+        dev = f"cuda:{device}"
+        self.keys = torch.full((max(self.ctx.n_source, 1),), KEY_NONE, dtype=torch.int64, device=dev)
+        self.sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=dev)
+
+    def begin(self, params, T0):
+        self.ctx.icp_begin(params, T0, None)
+
+    def partial_keys(self):
+        self.ctx.icp_partial_keys(self.keys.data_ptr())
+        return self.keys
+
+    def sums_from_keys(self, keys):
+        self.ctx.icp_sums_from_keys(keys.data_ptr(), self.sums.data_ptr())
+        return self.sums
+
+    def apply_sums(self, sums):
+        self.ctx.icp_apply_sums(sums.data_ptr())
+
+    def state(self):
+        r = self.ctx.icp_state()
+        T = np.array(r.T[:], np.float32).reshape(4, 4).T.copy()
+        return T, int(r.iterations), float(r.last_delta_norm), int(r.last_ncorr)
+
+
+class TargetShardedRigidICP:
+    """ICP with the TARGET sharded over the ranks: two collectives per iteration --
+    all-reduce(MIN) of one packed int64 key per source point (the global nearest neighbour; ring cost
+    2(G-1)/G x 8 B x Ns per GPU over xGMI), then all-reduce(SUM) of the 48 accumulated f64."""
+
+    def __init__(self, engine, dist=None, group=None):
+        self.engine, self.dist, self.group = engine, dist, group
+
+    def _multi(self):
+        return self.dist is not None and self.dist.get_world_size(self.group) > 1
+
+    def estimate(self, params, T0=None):
+        T0 = np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32)
+        self.engine.begin(params, T0)
+        for _ in range(int(params.max_iter)):
+            keys = self.engine.partial_keys()
+            if self._multi():
+                self.dist.all_reduce(keys, op=self.dist.ReduceOp.MIN, group=self.group)
+            sums = self.engine.sums_from_keys(keys)
+            if self._multi():
+                self.dist.all_reduce(sums, group=self.group)
+            self.engine.apply_sums(sums)
+        return self.engine.state()

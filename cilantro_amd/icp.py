@@ -175,6 +175,18 @@ class Context:
     def icp_apply_sums(self, sums_dev_ptr):
         self._ck(self._L.cilhip_icp_apply_sums(self._h, C.c_void_p(sums_dev_ptr)))
 
+    def set_shard_info(self, target_index_offset, dst_mean=None, src_mean=None):
+        dm = np.ascontiguousarray(dst_mean, np.float32) if dst_mean is not None else None
+        sm = np.ascontiguousarray(src_mean, np.float32) if src_mean is not None else None
+        self._ck(self._L.cilhip_set_shard_info(self._h, int(target_index_offset), dm.ctypes.data if dm is not None else None,
+                                               sm.ctypes.data if sm is not None else None))
+
+    def icp_partial_keys(self, keys_dev_ptr):
+        self._ck(self._L.cilhip_icp_partial_keys(self._h, C.c_void_p(keys_dev_ptr)))
+
+    def icp_sums_from_keys(self, keys_dev_ptr, sums_dev_ptr):
+        self._ck(self._L.cilhip_icp_sums_from_keys(self._h, C.c_void_p(keys_dev_ptr), C.c_void_p(sums_dev_ptr)))
+
     def icp_state(self):
         res = capi.IcpResult()
         self._ck(self._L.cilhip_icp_state(self._h, C.byref(res)))

@@ -151,6 +151,21 @@ int cilhip_icp_partial_sums(cilhip_ctx* ctx, double* sums_dev);
 int cilhip_icp_apply_sums(cilhip_ctx* ctx, const double* sums_dev);
 int cilhip_icp_state(cilhip_ctx* ctx, cilhip_icp_result* out); /* syncs */
 
+/* ---- target-sharded runs (BASELINE configs[3]: one target too large / sharded over the GPUs of a node) ----
+ * Every rank holds ALL source points and ONE shard of the target (set with cilhip_set_target) plus
+ *   cilhip_set_shard_info(ctx, global index of the shard's first point, GLOBAL dst mean, GLOBAL src mean).
+ * Per iteration (after cilhip_icp_begin):
+ *   cilhip_icp_partial_keys(ctx, keys_dev)      keys_dev[i] = (bits(d2) << 32) | global target index of source
+ *                                               point i's nearest neighbour in THIS shard (0x7fff...f = none)
+ *   all-reduce(MIN, int64) of keys_dev over RCCL  -> the globally nearest target per source point
+ *   cilhip_icp_sums_from_keys(ctx, keys_dev, sums_dev)  accumulates only the pairs won by this shard
+ *   all-reduce(SUM, f64) of sums_dev;  cilhip_icp_apply_sums(ctx, sums_dev)
+ * keys_dev: DEVICE pointer to n_source uint64 (original source order). */
+int cilhip_set_shard_info(cilhip_ctx* ctx, uint64_t target_index_offset, const float* dst_mean_or_null,
+                          const float* src_mean_or_null);
+int cilhip_icp_partial_keys(cilhip_ctx* ctx, uint64_t* keys_dev);
+int cilhip_icp_sums_from_keys(cilhip_ctx* ctx, const uint64_t* keys_dev, double* sums_dev);
+
 /* ---- residuals ------------------------------------------------------------------------------- */
 /* computeResiduals() of both classes (icp_single_transform_combined_metric.hpp:220-243,
  * icp_single_transform_point_to_point_metric.hpp:68-85): unbounded 1-NN of T*s_i, then

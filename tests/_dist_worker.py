@@ -87,8 +87,68 @@ class OracleShardEngine:
         return self.T, self.iters, self.delta, self.nc
 
 
+class OracleTargetShardEngine(OracleShardEngine):
+    """Test-only counterpart of HipTargetShardEngine: kd-tree over dst[lo:hi), keys with global indices."""
+
+    def __init__(self, dst_full, dst_n_full, src, lo, hi):
+        super().__init__(np.ascontiguousarray(dst_full[lo:hi]), np.ascontiguousarray(dst_n_full[lo:hi]), src)
+        self.lo, self.hi = lo, hi
+        self.dst_mean = orc.mean3(dst_full)                       # GLOBAL target mean
+        self.keys = torch.full((len(src),), distributed.KEY_NONE, dtype=torch.int64)
+
+    def begin(self, params, T0):
+        super().begin(params, T0, orc.mean3(self.src))
+
+    def partial_keys(self):
+        self.keys.fill_(distributed.KEY_NONE)
+        if not self.done:
+            self.q = orc.transform_points(self.T, self.src)
+            di, si, d2 = self.tree.find_correspondences(self.q, self.p.max_sq_dist, num_threads=1)
+            k = (d2.view(np.uint32).astype(np.int64) << 32) | (di + self.lo)
+            self.keys[torch.from_numpy(si)] = torch.from_numpy(k)
+        return self.keys
+
+    def sums_from_keys(self, keys):
+        self.sums.zero_()
+        if self.done:
+            return self.sums
+        k = keys.numpy()
+        gidx = k & 0xFFFFFFFF
+        mine = (k != distributed.KEY_NONE) & (gidx >= self.lo) & (gidx < self.hi)
+        si = np.nonzero(mine)[0].astype(np.int64)
+        di = (gidx[mine] - self.lo).astype(np.int64)
+        s = np.zeros(distributed.SUMS_LEN)
+        if self.p.metric == capi.METRIC_POINT_TO_POINT:
+            _, s16, _ = orc.estimate_p2p(self.dst, self.q, di, si, orc.MODE_MIXED)
+            s[:16] = s16
+        else:
+            smt = orc.transform_points(self.T, self.gmean.reshape(1, 3))[0]
+            _, AtA, Atb, _ = orc.estimate_combined(self.dst, self.dst_n, self.q, di, si, 0.0, 1.0, self.dst_mean, smt, 1, 1e-5, orc.MODE_MIXED)
+            s[0] = len(di); s[1:22] = AtA[np.triu_indices(6)]; s[22:28] = Atb
+        self.sums.copy_(torch.from_numpy(s))
+        return self.sums
+
+
+def main_target_sharded(metric, n):
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    d = syn.make_pair(n, perturb=0.5)
+    lo, hi = distributed.shard_bounds(n, rank, world)
+    eng = OracleTargetShardEngine(d["dst"], d["dst_n"], d["src"], lo, hi)
+    p = distributed.default_params(metric=metric, max_iter=8, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+    T, iters, delta, nc = distributed.TargetShardedRigidICP(eng, dist).estimate(p)
+    allT = [None] * world
+    dist.all_gather_object(allT, T.tolist())
+    if rank == 0:
+        print("RESULT " + json.dumps({"T": T.tolist(), "iters": iters, "delta": delta, "ncorr": nc, "world": world,
+                                       "identical": all(a == allT[0] for a in allT)}))
+    dist.destroy_process_group()
+
+
 def main():
     metric = int(sys.argv[1]); n = int(sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "tshard":
+        return main_target_sharded(metric, n)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     d = syn.make_pair(n, perturb=0.5)

@@ -20,10 +20,10 @@ def _free_port():
     return p
 
 
-def _run(world, metric, n):
+def _run(world, metric, n, mode=""):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "_dist_worker.py"), str(metric), str(n)]
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(metric), str(n)] + ([mode] if mode else [])
     env = dict(os.environ, OMP_NUM_THREADS="1")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -43,3 +43,17 @@ def test_sharded_icp_world2_matches_single_process(orc, metric):
     assert np.linalg.norm(T2 - ref["T"]) <= 1e-5
     assert abs(r2["iters"] - ref["iterations"]) <= 1 and r2["ncorr"] == ref["last_ncorr"]
     assert np.linalg.norm(T2 - d["T_true"]) < 5e-4
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_target_sharded_icp_world2_matches_single_process(orc, metric):
+    """BASELINE configs[3] protocol: target split by index over 2 ranks, MIN all-reduce of packed
+    (d2, global index) keys, each rank accumulates the pairs its shard won, SUM all-reduce."""
+    n = 6000
+    r2 = _run(2, metric, n, "tshard")
+    assert r2["world"] == 2 and r2["identical"] and r2["iters"] == 8
+    d = syn.make_pair(n, perturb=0.5)
+    p = orc.make_params(metric=metric, max_iter=8, conv_tol=0.0, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+    ref = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+    assert np.linalg.norm(np.array(r2["T"], np.float64) - ref["T"]) <= 1e-5
+    assert r2["ncorr"] == ref["last_ncorr"]

@@ -393,3 +393,31 @@ def test_symmetric_metric_vs_oracle(orc, hip_lib):
     pd = n[:, 0] * dx + (n[:, 1] * dy + n[:, 2] * dz)
     exp = np.float32(0.2) * sq + (np.float32(1.0) * pd) * pd
     assert np.array_equal(res[:5000], exp.astype(np.float32))
+
+
+def test_target_shard_protocol_single_rank(orc, hip_lib):
+    """Target-sharded building blocks with one rank == the plain loop; and with the shard given a global
+    index offset the published keys carry global indices."""
+    import torch
+
+    from cilantro_amd import distributed
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(150000, perturb=0.5)
+    icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+    icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+    T1 = icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0).estimate().getTransform()
+    dm, _ = icp._ctx.means()
+    off = 1000000
+    eng = distributed.HipTargetShardEngine(d["dst"], d["dst_n"], d["src"], off, dm, 0)
+    p = distributed.default_params(max_iter=6, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+    T2, iters, delta, nc = distributed.TargetShardedRigidICP(eng, None).estimate(p)
+    assert iters == 6 and nc == icp.last_ncorr_
+    assert np.array_equal(T1, T2)
+    # keys of a fresh search under T2: (d2 bits << 32) | (local index + offset), original source order
+    eng.begin(p, T2)
+    keys = eng.partial_keys().cpu().numpy()
+    q = orc.transform_points(T2, d["src"])
+    bi, bd = orc.nn_brute(d["dst"], q[:20000], d["max_sq_dist"])
+    exp = np.where(bi >= 0, (bd.view(np.uint32).astype(np.int64) << 32) | (bi + off), distributed.KEY_NONE)
+    assert np.array_equal(keys[:20000], exp)
