@@ -359,6 +359,75 @@ struct TileLds {
   int lox, loy, loz, RY, W1, rows;
 };
 
+// Octant-first search (the common case, uniform control flow across the wave): the 2x2x2 block of cells
+// on the side of q's own cell that q leans towards contains every target point closer than the distance
+// from q to that block's faces, which is at least half a cell.  All lanes scan exactly 4 runs (2 cells
+// each) -- no per-lane culling decisions, so the wave stays in lock-step.  Returns true (result proven
+// exact) iff the best found is strictly nearer than any point outside the block can be.
+__device__ __forceinline__ bool search_octant_in_tile(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
+                                                      int cx, int cy, int cz, float max_sq, NN& best) {
+  const f32x2 qxy = {qx, qy};
+  unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  uint32_t bl = NONE_U32;
+  const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
+  const float half = 0.5f * g.cell;
+  const int ox = (qx - xl >= half) ? 0 : -1, oy = (qy - yl >= half) ? 0 : -1, oz = (qz - zl >= half) ? 0 : -1;
+  // cells of the block along x, clipped to the grid (the own cell is always inside)
+  const int xa = max(cx + ox, 0), xb = min(cx + ox + 1, g.nx - 1);
+  const int lx = cx - t.lox, ly = cy - t.loy, lz = cz - t.loz;
+  uint32_t rj[4], re[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int dz = oz + (k >> 1), dy = oy + (k & 1);
+    const int z = cz + dz, y = cy + dy;
+    const bool okr = (z >= 0) & (z < g.nz) & (y >= 0) & (y < g.ny);
+    const int row = (lz + dz) * t.RY + (ly + dy);
+    const int eb = row * t.W1 + lx;
+    rj[k] = okr ? t.lcs[eb + (xa - cx)] : 0u;
+    re[k] = okr ? t.lcs[eb + (xb - cx) + 1] : 0u;
+  }
+  // one flattened loop over the 4 runs
+  int k = 0;
+  uint32_t j = rj[0], e = re[0];
+  for (;;) {
+    if (j >= e) {
+      ++k;
+      if (k >= 4) break;
+      j = (k == 1) ? rj[1] : (k == 2) ? rj[2] : rj[3];
+      e = (k == 1) ? re[1] : (k == 2) ? re[2] : re[3];
+      continue;
+    }
+    const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
+    eval_candidate(p0, qxy, qz, j, bk, bl);
+    eval_candidate(p1, qxy, qz, j + 1, bk, bl);
+    eval_candidate(p2, qxy, qz, j + 2, bk, bl);
+    eval_candidate(p3, qxy, qz, j + 3, bk, bl);
+    j += 4;
+  }
+  // distance from q to the faces of the block that still have grid cells beyond them
+  float b = INFINITY;
+  {
+    const float lo = xl + (float)ox * g.cell, hi = lo + 2.0f * g.cell;
+    if (cx + ox > 0) b = fminf(b, qx - lo);
+    if (cx + ox + 2 < g.nx) b = fminf(b, hi - qx);
+  }
+  {
+    const float lo = yl + (float)oy * g.cell, hi = lo + 2.0f * g.cell;
+    if (cy + oy > 0) b = fminf(b, qy - lo);
+    if (cy + oy + 2 < g.ny) b = fminf(b, hi - qy);
+  }
+  {
+    const float lo = zl + (float)oz * g.cell, hi = lo + 2.0f * g.cell;
+    if (cz + oz > 0) b = fminf(b, qz - lo);
+    if (cz + oz + 2 < g.nz) b = fminf(b, hi - qz);
+  }
+  best.key = bk;
+  best.pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
+  if (b == INFINITY) return true;                    // the block covers the whole grid
+  b -= g.margin;
+  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
+}
+
 // Exact search of one in-grid query out of the LDS tile.  Returns false if the 3x3x3 block does not
 // prove the result (the query then goes to the clean-up pass).
 __device__ __forceinline__ bool search_in_tile(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
@@ -576,7 +645,8 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
     best.pos = NONE_U32;
     bool defer = false;
     if (inside[u]) {
-      defer = !search_in_tile(g, tl, qx[u], qy[u], qz[u], cx[u], cy[u], cz[u], a.max_sq, best);
+      if (!search_octant_in_tile(g, tl, qx[u], qy[u], qz[u], cx[u], cy[u], cz[u], a.max_sq, best))
+        defer = !search_in_tile(g, tl, qx[u], qy[u], qz[u], cx[u], cy[u], cz[u], a.max_sq, best);   // full 3x3x3 search
     } else {
       // query outside the grid: nothing to find if it is farther than the radius, else generic search
       const float gx = axis_gap(qx[u], g.ox, g.ox + (float)g.nx * g.cell, g.margin);
