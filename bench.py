@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native rigid ICP engine.
 
-A "step" is ONE ICP iteration (fused kNN correspondence search + residual accumulation kernel,
-then the on-device 6x6 / 3x3 solve) over one synthetic cloud pair resident in HBM.
+A "step" is ONE ICP iteration (LDS-tiled kNN correspondence search kernel, streaming residual
+accumulation kernel, then the on-device 6x6 / 3x3 solve) over one synthetic cloud pair resident in HBM.
 
   N=1  : BASELINE.json configs[2]: 10M <-> 10M synthetic cloud with normals, point-to-plane
          (SimpleCombinedMetricRigidICP3f defaults w_p2p=0, w_p2pl=1), SURVEY.md 8(d) recipe.
@@ -181,7 +181,7 @@ def main():
             avg_ms = search_ms / launches
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": "k_iter<IM_NONE,search,store> (kNN correspondence search)",
+                    "traffic": None, "kernel": "k_search_tiled + k_search_todo (kNN correspondence search, LDS-tiled)",
                     "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
                     "accumulate_kernel": {"avg_kernel_ms": acc_ms / launches,
                                           "algorithmic_bytes_per_launch": acc_bytes,

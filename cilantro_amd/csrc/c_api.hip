@@ -183,6 +183,16 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
 }
 
+int cilhip_debug_counters(cilhip_ctx* c, uint32_t out[2]) {
+  if (!c || !out) return CILHIP_ERR_INVALID;
+  out[0] = out[1] = 0;
+  if (!c->d_todo) return CILHIP_OK;
+  CK(c, hipSetDevice(c->device));
+  CK(c, hipMemcpyAsync(out, c->d_todo + (c->ns ? c->ns : 1), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  return CILHIP_OK;
+}
+
 int cilhip_get_last_timing2(cilhip_ctx* c, double* search_ms, double* accumulate_ms) {
   if (!c) return CILHIP_ERR_INVALID;
   if (search_ms) *search_ms = c->last_search_ms;

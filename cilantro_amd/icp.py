@@ -206,6 +206,11 @@ class Context:
     def enable_kernel_timing(self, on=True):
         self._ck(self._L.cilhip_enable_kernel_timing(self._h, 1 if on else 0))
 
+    def debug_counters(self):
+        out = (C.c_uint32 * 2)()
+        self._ck(self._L.cilhip_debug_counters(self._h, out))
+        return int(out[0]), int(out[1])
+
     def set_option(self, key, value):
         self._ck(self._L.cilhip_set_option(self._h, key.encode(), float(value)))
 

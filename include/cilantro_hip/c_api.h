@@ -203,6 +203,9 @@ int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
  * kernels of the last cilhip_icp_run (sum over executed iterations). */
 int cilhip_get_last_timing2(cilhip_ctx* ctx, double* search_ms, double* accumulate_ms);
+/* Tiled search bookkeeping of the most recent search launch: out[0] = queries, out[1] = whole tiles that were
+ * handed to the global-memory clean-up pass (syncs). */
+int cilhip_debug_counters(cilhip_ctx* ctx, uint32_t out[2]);
 
 #ifdef __cplusplus
 }

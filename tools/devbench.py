@@ -45,8 +45,10 @@ for n in a.n:
         r = ctx.icp_run(p)
         loop2, sk, nl = ctx.last_timing()
         s_ms, a_ms = ctx.last_timing2()
+        dq, dt = ctx.debug_counters()
+        gi = ctx.grid_info()
         T = np.array(r.T[:], np.float32).reshape(4, 4).T
         print(f"n={n} fused={fused} occ={occ} tiled={tiled} wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
               f"[timed: loop/iter={loop2/a.steps:.3f} search(or fused)/iter={s_ms/max(nl,1):.3f} acc/iter={a_ms/max(nl,1):.3f}] "
-              f"it/s={a.steps/dt:.1f} err_true={np.linalg.norm(T-d['T_true']):.2e} ncorr={r.last_ncorr}", flush=True)
+              f"it/s={a.steps/dt:.1f} err_true={np.linalg.norm(T-d['T_true']):.2e} ncorr={r.last_ncorr} deferred_queries={dq} deferred_tiles={dt} grid={gi.nx}x{gi.ny}x{gi.nz}", flush=True)
         ctx.close()
