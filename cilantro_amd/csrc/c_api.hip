@@ -61,7 +61,7 @@ struct cilhip_ctx {
   double* d_stage = nullptr;      // [REDUCE_STAGE_DOUBLES] stage-1 rows of the cross-block reduction
   double* d_sums = nullptr;       // [SUMS_MAX]
   bool fused = false;             // true: search+accumulate in one kernel; false: search kernel + streaming accumulate kernel (faster: the search runs at 2x the occupancy)
-  double cell_occupancy = 3.0;    // target points per grid cell (takes effect at the next set_target)
+  double cell_occupancy = 1.0;    // target points per grid cell (takes effect at the next set_target)
   unsigned long long* d_count = nullptr;
   uint32_t* d_out_idx = nullptr;  // [ns] original-order results
   float* d_out_d2 = nullptr;

@@ -210,7 +210,7 @@ hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStr
   // volume with degenerate extents floored so planar / linear clouds still get a sane first guess
   double vol = 1.0;
   for (int c = 0; c < 3; ++c) vol *= std::max(ext[c], maxext * 1e-3);
-  const double TARGET = target_occupancy > 0.0 ? target_occupancy : 3.0;  // points per cell for a volumetric cloud
+  const double TARGET = target_occupancy > 0.0 ? target_occupancy : 1.0;  // points per cell for a volumetric cloud
   double cell = std::cbrt(vol * TARGET / (double)n);
 
   uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr, *cs = nullptr;
@@ -270,10 +270,12 @@ __device__ __forceinline__ uint32_t cube_key_of(const GridDev& g, float x, float
   int cy = (int)floorf(fminf(fmaxf((y - g.oy) * g.inv_cell, -1.0f), 1.0e9f));
   int cz = (int)floorf(fminf(fmaxf((z - g.oz) * g.inv_cell, -1.0f), 1.0e9f));
   cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
-  constexpr uint32_t L = CUBE_LOG2, M = (1u << L) - 1u;
-  const uint32_t cnx = ((uint32_t)g.nx + M) >> L, cny = ((uint32_t)g.ny + M) >> L;
-  const uint32_t cube = (((uint32_t)cz >> L) * cny + ((uint32_t)cy >> L)) * cnx + ((uint32_t)cx >> L);
-  return (cube << (3 * L)) | (((uint32_t)cz & M) << (2 * L)) | (((uint32_t)cy & M) << L) | ((uint32_t)cx & M);
+  constexpr uint32_t C = CUBE_EDGE;
+  const uint32_t cnx = ((uint32_t)g.nx + C - 1) / C, cny = ((uint32_t)g.ny + C - 1) / C;
+  const uint32_t bx = (uint32_t)cx / C, by = (uint32_t)cy / C, bz = (uint32_t)cz / C;
+  const uint32_t cube = (bz * cny + by) * cnx + bx;
+  const uint32_t local = (((uint32_t)cz - bz * C) * C + ((uint32_t)cy - by * C)) * C + ((uint32_t)cx - bx * C);
+  return cube * (C * C * C) + local;
 }
 
 __global__ void k_cube_keys_tf(const float* __restrict__ xyz, uint32_t n, GridDev g, Tf T, uint32_t* keys, uint32_t* vals) {
@@ -286,7 +288,7 @@ __global__ void k_cube_keys_tf(const float* __restrict__ xyz, uint32_t n, GridDe
 }
 
 __global__ void k_shift_keys(const uint32_t* __restrict__ in, uint32_t n, uint32_t* out) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] >> (3 * CUBE_LOG2);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] / (uint32_t)(CUBE_EDGE * CUBE_EDGE * CUBE_EDGE);
 }
 
 // tiles of one cube: ceil(count / TILE_QUERIES)
@@ -313,10 +315,10 @@ hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const f
   Tf tf;
   for (int i = 0; i < 16; ++i) tf.m[i] = T[i];
   hipLaunchKernelGGL(k_cube_keys_tf, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, tf, k_in, v_in);
-  constexpr uint32_t CM = (1u << CUBE_LOG2) - 1u;
-  const uint32_t cnx = ((uint32_t)g.nx + CM) >> CUBE_LOG2, cny = ((uint32_t)g.ny + CM) >> CUBE_LOG2, cnz = ((uint32_t)g.nz + CM) >> CUBE_LOG2;
+  constexpr uint32_t CE = CUBE_EDGE;
+  const uint32_t cnx = ((uint32_t)g.nx + CE - 1) / CE, cny = ((uint32_t)g.ny + CE - 1) / CE, cnz = ((uint32_t)g.nz + CE - 1) / CE;
   const uint32_t ncubes = cnx * cny * cnz;
-  hipError_t e = sort_pairs(k_in, k_out, v_in, v_out, n, std::min(32u, bits_for(ncubes) + 3 * CUBE_LOG2), s);
+  hipError_t e = sort_pairs(k_in, k_out, v_in, v_out, n, std::min(32u, bits_for(ncubes * CE * CE * CE)), s);
   uint32_t *cube_start = nullptr, *tcount = nullptr, *toff = nullptr;
   void* tmp = nullptr;
   uint2* tiles = nullptr;

@@ -11,13 +11,13 @@
 namespace cilhip {
 
 constexpr uint32_t NONE_U32 = 0xFFFFFFFFu;
-#ifndef CILHIP_CUBE_LOG2
-#define CILHIP_CUBE_LOG2 3
+#ifndef CILHIP_CUBE_EDGE
+#define CILHIP_CUBE_EDGE 12
 #endif
-// LDS-tiled search: queries are grouped by cubes of (2^CUBE_LOG2)^3 target-grid cells
-constexpr int CUBE_LOG2 = CILHIP_CUBE_LOG2;
-constexpr int TILE_QUERIES = CUBE_LOG2 == 3 ? 2048 : 256;  // max queries per tile
-constexpr int TILE_THREADS = CUBE_LOG2 == 3 ? 1024 : 256;  // workgroup size of the tiled search kernel
+// LDS-tiled search: queries are grouped by cubes of CUBE_EDGE^3 target-grid cells
+constexpr int CUBE_EDGE = CILHIP_CUBE_EDGE;
+constexpr int TILE_QUERIES = 2048;  // max queries per tile
+constexpr int TILE_THREADS = 1024;  // workgroup size of the tiled search kernel
 
 // Uniform grid over the target cloud (the structure that replaces the nanoflann kd-tree).
 // Target points are stored sorted by linear cell id (x fastest) as 16-byte records

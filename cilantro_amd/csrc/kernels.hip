@@ -29,11 +29,7 @@ namespace cilhip {
 // LDS-tiled search geometry: cube of 2^L cells per axis, <= TILE_QUERIES queries per tile,
 // TILE_THREADS threads per workgroup.  (4^3 cells / 256 queries / 256 threads, or 8^3 / 2048 / 1024.)
 #ifndef CILHIP_TILE_CAP
-#if CILHIP_CUBE_LOG2 == 3
-#define CILHIP_TILE_CAP 4400
-#else
-#define CILHIP_TILE_CAP 1536
-#endif
+#define CILHIP_TILE_CAP 3712
 #endif
 
 #ifndef CILHIP_CAND
@@ -302,7 +298,7 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
 // radius), queries outside the grid, and whole tiles whose region exceeds the LDS budget (queries that
 // drifted far from their sort-time cells) fall back to the global-memory search.
 constexpr int TILE_CAP = CILHIP_TILE_CAP;                    // staged target points per tile (16 B each)
-constexpr int TILE_RMAX = (1 << CILHIP_CUBE_LOG2) + 3;       // region edge: cube + halo + one cell of drift
+constexpr int TILE_RMAX = CUBE_EDGE + 3;                     // region edge: cube + halo + one cell of drift
 constexpr int TILE_MAXROWS = TILE_RMAX * TILE_RMAX;          // RY*RZ
 constexpr int TILE_MAXW = TILE_RMAX + 2;                     // RX
 constexpr int TILE_MAXE = TILE_MAXROWS * (TILE_MAXW + 1);
@@ -636,6 +632,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
   }
   // ---- 3. per-lane exact search out of LDS (or hand-off to the clean-up pass) ----
   TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
+#ifdef CILHIP_EXP_DOUBLE_SEARCH
+  for (int rep = 0; rep < 2; ++rep)   // experiment: run phase 3 twice to measure its share of the kernel time
+#endif
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
     if (!active[u]) continue;

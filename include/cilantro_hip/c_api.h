@@ -194,10 +194,10 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   "fused" (default 0): 1 = one fused search+accumulate kernel per iteration,
  *                        0 = search kernel (stores the matches) + streaming accumulation kernel.
  *   "tiled" (default 1): LDS-tiled search kernel (one workgroup stages the cell region around an
- *                        8x8x8-cell cube of queries in LDS; tiles that do not fit fall back per tile):
+ *                        12x12x12-cell cube of queries in LDS; tiles that do not fit fall back per tile):
  *                        0 = never (per-lane global-memory search), 1 = when the cloud is large enough
  *                        to fill the chip with tiles (>= 2048 tiles, ~3M points), 2 = always.
- *   "cell_occupancy" (default 3): target points per grid cell, used by the next cilhip_set_target.
+ *   "cell_occupancy" (default 1): target points per grid cell, used by the next cilhip_set_target.
  *   "kernel_timing": same as cilhip_enable_kernel_timing. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation

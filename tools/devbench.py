@@ -17,7 +17,7 @@ ap.add_argument("--n", type=int, nargs="+", default=[1_000_000, 10_000_000])
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--metric", default="p2plane")
 ap.add_argument("--modes", type=int, nargs="+", default=[1, 0])
-ap.add_argument("--occ", type=float, nargs="+", default=[4.0])
+ap.add_argument("--occ", type=float, nargs="+", default=[1.0])
 ap.add_argument("--tiled", type=int, nargs="+", default=[1])
 a = ap.parse_args()
 
@@ -45,10 +45,10 @@ for n in a.n:
         r = ctx.icp_run(p)
         loop2, sk, nl = ctx.last_timing()
         s_ms, a_ms = ctx.last_timing2()
-        dq, dt = ctx.debug_counters()
+        dq, dtl = ctx.debug_counters()
         gi = ctx.grid_info()
         T = np.array(r.T[:], np.float32).reshape(4, 4).T
         print(f"n={n} fused={fused} occ={occ} tiled={tiled} wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
               f"[timed: loop/iter={loop2/a.steps:.3f} search(or fused)/iter={s_ms/max(nl,1):.3f} acc/iter={a_ms/max(nl,1):.3f}] "
-              f"it/s={a.steps/dt:.1f} err_true={np.linalg.norm(T-d['T_true']):.2e} ncorr={r.last_ncorr} deferred_queries={dq} deferred_tiles={dt} grid={gi.nx}x{gi.ny}x{gi.nz}", flush=True)
+              f"it/s={a.steps/dt:.1f} err_true={np.linalg.norm(T-d['T_true']):.2e} ncorr={r.last_ncorr} deferred_queries={dq} deferred_tiles={dtl} grid={gi.nx}x{gi.ny}x{gi.nz}", flush=True)
         ctx.close()
