@@ -764,21 +764,36 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
   const uint32_t beg = beg64 < a.ns ? (uint32_t)beg64 : a.ns;
   const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
 
-  for (uint32_t i = beg + threadIdx.x; i < end; i += ITER_THREADS) {
-    const float4 s4 = a.src[i];
+  // Software-pipelined by one element: the next element's source point / stored match are requested before
+  // the current element's gathers (matched point, normal) are consumed, so every lane keeps two levels of
+  // independent loads in flight (the streaming accumulation pass is otherwise a chain of dependent gathers).
+  uint32_t inext = beg + threadIdx.x;
+  float4 s4n = inext < end ? a.src[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t posn = (!SEARCH && inext < end) ? a.nn_pos[inext] : NONE_U32;
+  while (inext < end) {
+    const uint32_t i = inext;
+    const float4 s4 = s4n;
+    uint32_t pos = posn;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nvp = p, snp = p;
+    if (!SEARCH && METRIC != IM_NONE && pos != NONE_U32) {
+      p = a.grid.pts[pos];
+      if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; }
+    }
+    inext += ITER_THREADS;
+    if (inext < end) { s4n = a.src[inext]; if (!SEARCH) posn = a.nn_pos[inext]; }
     float qx, qy, qz;
     transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-    uint32_t pos;
     if (SEARCH) {
       NN best;
       nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
       pos = best.pos;
       if (STORE) { a.nn_pos[i] = pos; a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
-    } else {
-      pos = a.nn_pos[i];
+      if (METRIC != IM_NONE && pos != NONE_U32) {
+        p = a.grid.pts[pos];
+        if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; }
+      }
     }
     if (METRIC != IM_NONE && pos != NONE_U32) {
-      const float4 p = a.grid.pts[pos];
       if (TR::kabsch) {
         // raw moments for the closed-form estimator (transform_estimation.hpp:25-34)
         const double pd[3] = {(double)p.x, (double)p.y, (double)p.z};
@@ -802,11 +817,11 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
         const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
         accA[0] += 1.0;
         if (TR::plane) {
-          float4 nv = a.grid.nrm[pos];
+          float4 nv = nvp;
           if (a.src_nrm) {
             // symmetric metric (transform_estimation.hpp:705-706): n = n_dst + tform.linear() * n_src', with
             // n_src' = transform_.linear() * n_src (transformNormals, core/space_transformations.hpp:374-390)
-            const float4 sn = a.src_nrm[i];
+            const float4 sn = snp;
             const float t0 = __fadd_rn(__fmul_rn(T[0], sn.x), __fadd_rn(__fmul_rn(T[4], sn.y), __fmul_rn(T[8], sn.z)));
             const float t1 = __fadd_rn(__fmul_rn(T[1], sn.x), __fadd_rn(__fmul_rn(T[5], sn.y), __fmul_rn(T[9], sn.z)));
             const float t2 = __fadd_rn(__fmul_rn(T[2], sn.x), __fadd_rn(__fmul_rn(T[6], sn.y), __fmul_rn(T[10], sn.z)));
