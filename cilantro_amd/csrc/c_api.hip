@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -65,6 +66,13 @@ struct cilhip_ctx {
   unsigned long long* d_count = nullptr;
   uint32_t* d_out_idx = nullptr;  // [ns] original-order results
   float* d_out_d2 = nullptr;
+
+  // engine post-filters (correspondence_search_kd_tree.hpp:224-225)
+  double inlier_fraction = 1.0;
+  bool one_to_one = false;
+  unsigned long long* d_keys = nullptr;    // [ns]
+  void* d_sel_state = nullptr;
+  unsigned long long* d_winner = nullptr;  // [n_target]
 
   // sharded-run state
   cilhip_icp_params run_prm{};
@@ -133,6 +141,8 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_src_nrm_sorted) (void)hipFree(c->d_src_nrm_sorted);
   c->d_src_nrm = nullptr; c->d_src_nrm_sorted = nullptr;
   if (c->d_todo) (void)hipFree(c->d_todo);
+  if (c->d_keys) (void)hipFree(c->d_keys);
+  c->d_keys = nullptr;
   if (c->d_todo_tiles) (void)hipFree(c->d_todo_tiles);
   c->d_tiles = nullptr; c->ntiles = 0; c->d_todo = nullptr; c->d_todo_tiles = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
@@ -149,6 +159,8 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_inv_perm) (void)hipFree(c->d_inv_perm);
+  if (c->d_sel_state) (void)hipFree(c->d_sel_state);
+  if (c->d_winner) (void)hipFree(c->d_winner);
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_sums) (void)hipFree(c->d_sums);
@@ -177,6 +189,8 @@ int cilhip_synchronize(cilhip_ctx* c) {
 int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!c || !key) return CILHIP_ERR_INVALID;
   if (!strcmp(key, "fused")) { c->fused = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
+  if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "cell_occupancy")) { c->cell_occupancy = value; return CILHIP_OK; }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
@@ -221,6 +235,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   auto t0 = std::chrono::steady_clock::now();
   if (c->has_target) { free_grid(c->grid); c->has_target = false; }
   if (c->d_inv_perm) { (void)hipFree(c->d_inv_perm); c->d_inv_perm = nullptr; }
+  if (c->d_winner) { (void)hipFree(c->d_winner); c->d_winner = nullptr; }
   float *d_xyz = nullptr, *d_nrm = nullptr;
   int rc = upload(c, xyz, 3 * n, mem, &d_xyz);
   if (rc) return rc;
@@ -324,6 +339,26 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
 // 256 CUs the per-lane kernel (8x more, smaller workgroups) balances better (measured at 1M points).
 static bool use_tiled(const cilhip_ctx* c) { return c->tiled >= 2 || (c->tiled == 1 && c->ntiles >= 2048); }
 
+static bool filters_active(const cilhip_ctx* c) {
+  return (c->inlier_fraction > 0.0 && c->inlier_fraction < 1.0) || c->one_to_one;
+}
+
+// filterCorrespondencesFraction then filterCorrespondencesOneToOne on the stored matches
+static int apply_filters(cilhip_ctx* c) {
+  if (!filters_active(c) || c->ns == 0) return CILHIP_OK;
+  if (c->inlier_fraction > 0.0 && c->inlier_fraction < 1.0) {
+    if (!c->d_keys) CK(c, hipMalloc(&c->d_keys, (size_t)c->ns * sizeof(unsigned long long)));
+    if (!c->d_sel_state) CK(c, hipMalloc(&c->d_sel_state, filter_state_bytes()));
+    launch_filter_fraction(c->d_src_sorted, c->d_nn_pos, c->d_nn_d2, c->ns, c->inlier_fraction, c->d_keys, c->d_sel_state, c->stream);
+  }
+  if (c->one_to_one && c->grid.n) {
+    if (!c->d_winner) CK(c, hipMalloc(&c->d_winner, (size_t)c->grid.n * sizeof(unsigned long long)));
+    launch_filter_one_to_one(c->d_src_sorted, c->d_nn_pos, c->d_nn_d2, c->ns, c->d_winner, c->grid.n, c->stream);
+  }
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
 static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   IterArgs a{};
   a.grid = c->grid;
@@ -355,6 +390,8 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
   }
   CK(c, hipGetLastError());
+  rc = apply_filters(c);
+  if (rc) return rc;
   memcpy(c->nn_T, T, sizeof(c->nn_T));
   c->have_nn = true;
   if (n_found) {
@@ -409,6 +446,17 @@ int cilhip_get_correspondences(cilhip_ctx* c, uint64_t* i1, uint64_t* i2, float*
   }
   *n_out = cnt;
   if (cnt > cap) return fail(c, CILHIP_ERR_INVALID, "get_correspondences: capacity too small");
+  // the reference's filters leave the set sorted: by value after the fraction filter (correspondence.hpp:61),
+  // by indexInFirst after the one-to-one filter (:86-94); reproduce that order (ties: ascending source index)
+  if (filters_active(c) && cnt > 1 && i1 && i2 && val) {
+    std::vector<size_t> ord(cnt);
+    for (size_t k = 0; k < cnt; ++k) ord[k] = k;
+    if (c->one_to_one) std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return i1[a] < i1[b]; });
+    else std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return val[a] < val[b]; });
+    std::vector<uint64_t> t1(cnt), t2(cnt); std::vector<float> tv(cnt);
+    for (size_t k = 0; k < cnt; ++k) { t1[k] = i1[ord[k]]; t2[k] = i2[ord[k]]; tv[k] = val[ord[k]]; }
+    memcpy(i1, t1.data(), cnt * sizeof(uint64_t)); memcpy(i2, t2.data(), cnt * sizeof(uint64_t)); memcpy(val, tv.data(), cnt * sizeof(float));
+  }
   return CILHIP_OK;
 }
 
@@ -582,11 +630,12 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       a.skip_if_inner_done = (st > 0);
       if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
       if (c->ns) {
-        if (st == 0 && c->fused) {
+        if (st == 0 && c->fused && !filters_active(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
         } else if (st == 0) {
           if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->ntiles, c->stream);   // LDS-tiled search kernel
           else launch_iter(a, IM_NONE, true, true, nb, c->stream);                  // per-lane global-memory search
+          { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_event(c, nev++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
         } else {
@@ -615,7 +664,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (timing) {
     // only iterations that actually executed (not the early-exit launches after convergence)
     const size_t executed = out->iterations < (size_t)launches ? out->iterations : (size_t)launches;
-    const size_t per = (c->fused || c->ns == 0) ? 2 : 4;
+    const size_t per = ((c->fused && !filters_active(c)) || c->ns == 0) ? 2 : 4;
     c->last_acc_ms = 0.0;
     for (size_t k = 0; k < executed; ++k) {
       float m = 0.f;
@@ -635,6 +684,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   if (!c || !p) return CILHIP_ERR_INVALID;
   CK(c, hipSetDevice(c->device));
   if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
+  if (filters_active(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "inlier_fraction / one_to_one are global filters: not available in sharded runs");
   const float* Ti = T0 ? T0 : kIdentity;
   int rc = ensure_sorted(c, Ti);
   if (rc) return rc;

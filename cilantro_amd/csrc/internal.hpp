@@ -104,6 +104,13 @@ void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long*
 void launch_residuals(const IterArgs& a, int metric, float w_p2p, float w_p2pl, float* out, hipStream_t s);
 int iter_num_blocks(uint32_t ns);
 
+// filters.hip
+void launch_filter_fraction(const float4* src_sorted, uint32_t* nn_pos, const float* nn_d2, uint32_t ns, double fraction,
+                            unsigned long long* keys, void* state, hipStream_t s);
+void launch_filter_one_to_one(const float4* src_sorted, uint32_t* nn_pos, const float* nn_d2, uint32_t ns,
+                              unsigned long long* winner, uint32_t n_target, hipStream_t s);
+size_t filter_state_bytes();
+
 // grid_build.hip
 struct GridBuildResult {
   GridDev grid;

@@ -271,9 +271,9 @@ class CorrespondenceSearchHIP:
         return self.inlier_fraction_
 
     def setInlierFraction(self, f):
-        if not (f >= 1.0 or f <= 0.0):
-            raise NotImplementedError("GPU engine implements inlier_fraction == 1 only")
-        self.inlier_fraction_ = f
+        self.inlier_fraction_ = float(f)
+        if self._ctx is not None:
+            self._ctx.set_option("inlier_fraction", self.inlier_fraction_)
         return self
 
     def getRequireReciprocality(self):
@@ -288,8 +288,9 @@ class CorrespondenceSearchHIP:
         return self.one_to_one_
 
     def setOneToOne(self, b):
-        if b:
-            raise NotImplementedError("one-to-one filtering is not implemented on the GPU engine")
+        self.one_to_one_ = bool(b)
+        if self._ctx is not None:
+            self._ctx.set_option("one_to_one", 1.0 if b else 0.0)
         return self
 
 

@@ -198,7 +198,12 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        0 = never (per-lane global-memory search), 1 = when the cloud is large enough
  *                        to fill the chip with tiles (>= 2048 tiles, ~3M points), 2 = always.
  *   "cell_occupancy" (default 1): target points per grid cell, used by the next cilhip_set_target.
- *   "kernel_timing": same as cilhip_enable_kernel_timing. */
+ *   "kernel_timing": same as cilhip_enable_kernel_timing.
+ * Engine post-filters (correspondence_search_kd_tree.hpp:224-225, setInlierFraction / setOneToOne :253-271):
+ *   "inlier_fraction" (default 1): in (0,1) keeps the llround(f*n) correspondences of smallest value
+ *                        (core/correspondence.hpp:57-66; equal values: lowest source index first),
+ *   "one_to_one" (default 0): 1 keeps, per target point, the correspondence of smallest value (:84-95).
+ *   Applied to cilhip_find_correspondences and inside cilhip_icp_run; not available in sharded runs. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
  * kernels of the last cilhip_icp_run (sum over executed iterations). */

@@ -177,8 +177,9 @@ public:
   double getInlierFraction() const { return inlier_fraction_; }
   CorrespondenceSearchHIP& setInlierFraction(double fraction) {
     // core/correspondence.hpp:57-66: the filter only acts for 0 < fraction < 1
-    if (fraction > 0.0 && fraction < 1.0) throw std::invalid_argument("CorrespondenceSearchHIP implements inlier_fraction == 1 only");
+    internal::check(ctx_, cilhip_set_option(ctx_, "inlier_fraction", fraction), "setInlierFraction");
     inlier_fraction_ = fraction;
+    fetched_ = false;
     return *this;
   }
   bool getRequireReciprocality() const { return require_reciprocality_; }
@@ -187,8 +188,10 @@ public:
     return *this;
   }
   bool getOneToOne() const { return one_to_one_; }
-  CorrespondenceSearchHIP& setOneToOne(bool b) {
-    if (b) throw std::invalid_argument("one-to-one filtering is not implemented on the GPU engine");
+  CorrespondenceSearchHIP& setOneToOne(bool b) {  // core/correspondence.hpp:68-100 (SECOND_TO_FIRST branch)
+    internal::check(ctx_, cilhip_set_option(ctx_, "one_to_one", b ? 1.0 : 0.0), "setOneToOne");
+    one_to_one_ = b;
+    fetched_ = false;
     return *this;
   }
 

@@ -308,6 +308,45 @@ size_t orc_find_correspondences(const orc_kdtree* t, const float* q, size_t nq, 
   return count;
 }
 
+typedef struct { int64_t a, b; float v; } orc_corr;
+static int cmp_value_src(const void* x, const void* y) {
+  const orc_corr* p = (const orc_corr*)x; const orc_corr* q = (const orc_corr*)y;
+  if (p->v < q->v) return -1;
+  if (p->v > q->v) return 1;
+  return (p->b > q->b) - (p->b < q->b);
+}
+static int cmp_first_value_src(const void* x, const void* y) {
+  const orc_corr* p = (const orc_corr*)x; const orc_corr* q = (const orc_corr*)y;
+  if (p->a != q->a) return (p->a > q->a) - (p->a < q->a);
+  return cmp_value_src(x, y);
+}
+
+/* core/correspondence.hpp:57-66 */
+size_t orc_filter_fraction(int64_t* di, int64_t* si, float* d2, size_t n, double f) {
+  if (!(f > 0.0 && f < 1.0)) return n;
+  orc_corr* c = (orc_corr*)malloc((n ? n : 1) * sizeof(orc_corr));
+  for (size_t i = 0; i < n; ++i) { c[i].a = di[i]; c[i].b = si[i]; c[i].v = d2[i]; }
+  qsort(c, n, sizeof(orc_corr), cmp_value_src);
+  size_t keep = (size_t)llround(f * (double)n);
+  if (keep > n) keep = n;
+  for (size_t i = 0; i < keep; ++i) { di[i] = c[i].a; si[i] = c[i].b; d2[i] = c[i].v; }
+  free(c);
+  return keep;
+}
+
+/* core/correspondence.hpp:68-100, case SECOND_TO_FIRST */
+size_t orc_filter_one_to_one(int64_t* di, int64_t* si, float* d2, size_t n) {
+  if (n == 0) return 0;
+  orc_corr* c = (orc_corr*)malloc(n * sizeof(orc_corr));
+  for (size_t i = 0; i < n; ++i) { c[i].a = di[i]; c[i].b = si[i]; c[i].v = d2[i]; }
+  qsort(c, n, sizeof(orc_corr), cmp_first_value_src);
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (i == 0 || c[i].a != di[m - 1]) { di[m] = c[i].a; si[m] = c[i].b; d2[m] = c[i].v; ++m; }
+  free(c);
+  return m;
+}
+
 void orc_nn_brute(const float* dst, size_t nd, const float* q, size_t nq, float max_d,
                   int64_t* nn_idx, float* nn_d2, int num_threads) {
 #ifdef _OPENMP
@@ -555,6 +594,8 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
     double t0 = now_s();
     orc_transform_points(T, src_p, ns, q);                 /* transformFeatures(tform) */
     size_t nc = orc_find_correspondences(tree, q, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
+    nc = orc_filter_fraction(di, si, d2, nc, prm->inlier_fraction);      /* correspondence_search_kd_tree.hpp:224 */
+    if (prm->one_to_one) nc = orc_filter_one_to_one(di, si, d2, nc);     /* :225 */
     double t1 = now_s();
     out->t_knn_s += t1 - t0;
     float Tn[16];

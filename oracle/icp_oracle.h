@@ -58,6 +58,15 @@ size_t orc_find_correspondences(const orc_kdtree* t, const float* q_xyz, size_t 
                                 float max_sq_dist, int64_t* dst_idx, int64_t* src_idx, float* d2,
                                 int num_threads);
 
+/* Engine post-filters, applied in place in this order (correspondence_search_kd_tree.hpp:224-225).
+ * filterCorrespondencesFraction (core/correspondence.hpp:57-66): keep the llround(f*n) smallest values; the
+ * reference uses an unstable std::sort, so WHICH of several equal values survives is unspecified there --
+ * pinned here (and in the HIP path) to: lowest source index first.  Result is ordered by (value, src).
+ * filterCorrespondencesOneToOne, SECOND_TO_FIRST (:84-95): per target index keep the smallest value (ties:
+ * lowest source index); result ordered by target index.  Both return the new count. */
+size_t orc_filter_fraction(int64_t* dst_idx, int64_t* src_idx, float* d2, size_t n, double fraction);
+size_t orc_filter_one_to_one(int64_t* dst_idx, int64_t* src_idx, float* d2, size_t n);
+
 /* Exhaustive exact 1-NN-in-radius (validation of both the kd-tree restatement and the GPU grid):
  * argmin over all dst of the pinned d2 expression, strict '<' vs radius, LOWEST index on ties.
  * nn_idx[i] = -1 if none. */
@@ -113,6 +122,8 @@ typedef struct {
   float max_sq_dist;     /* engine max_distance_ (squared; default 0.01*0.01) */
   int mode;              /* ORC_MODE_* */
   int num_threads;       /* OpenMP threads for the kNN loop */
+  double inlier_fraction; /* engine inlier_fraction_ (filter active iff 0 < f < 1; correspondence.hpp:57-66) */
+  int one_to_one;        /* engine one_to_one_ (correspondence.hpp:68-100, SECOND_TO_FIRST branch) */
 } orc_icp_params;
 
 typedef struct {

@@ -42,7 +42,7 @@ class IcpParams(C.Structure):
         ("metric", C.c_int), ("w_p2p", C.c_float), ("w_p2pl", C.c_float),
         ("max_iter", C.c_size_t), ("conv_tol", C.c_float), ("max_opt_iter", C.c_size_t),
         ("opt_conv_tol", C.c_float), ("max_sq_dist", C.c_float), ("mode", C.c_int),
-        ("num_threads", C.c_int),
+        ("num_threads", C.c_int), ("inlier_fraction", C.c_double), ("one_to_one", C.c_int),
     ]
 
 
@@ -72,6 +72,10 @@ def lib():
         L.orc_transform_points.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
         L.orc_find_correspondences.restype = C.c_size_t
         L.orc_find_correspondences.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
+        L.orc_filter_fraction.restype = C.c_size_t
+        L.orc_filter_fraction.argtypes = [_i64p, _i64p, _f32p, C.c_size_t, C.c_double]
+        L.orc_filter_one_to_one.restype = C.c_size_t
+        L.orc_filter_one_to_one.argtypes = [_i64p, _i64p, _f32p, C.c_size_t]
         L.orc_nn_brute.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _f32p, C.c_int]
         L.orc_svd3_f64.argtypes = [_f64p] * 4
         L.orc_svd3_f32.argtypes = [_f32p] * 4
@@ -246,9 +250,22 @@ def mean3(pts, mode=MODE_MIXED):
 
 
 def make_params(metric=METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=15, conv_tol=1e-5,
-                max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=1e-4, mode=MODE_MIXED, num_threads=0):
+                max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=1e-4, mode=MODE_MIXED, num_threads=0,
+                inlier_fraction=1.0, one_to_one=False):
     return IcpParams(metric, w_p2p, w_p2pl, max_iter, conv_tol, max_opt_iter, opt_conv_tol,
-                     max_sq_dist, mode, num_threads)
+                     max_sq_dist, mode, num_threads, inlier_fraction, 1 if one_to_one else 0)
+
+
+def filter_fraction(dst_idx, src_idx, d2, fraction):
+    di = _c(dst_idx, np.int64).copy(); si = _c(src_idx, np.int64).copy(); dv = _c(d2).copy()
+    n = lib().orc_filter_fraction(di, si, dv, len(di), float(fraction))
+    return di[:n], si[:n], dv[:n]
+
+
+def filter_one_to_one(dst_idx, src_idx, d2):
+    di = _c(dst_idx, np.int64).copy(); si = _c(src_idx, np.int64).copy(); dv = _c(d2).copy()
+    n = lib().orc_filter_one_to_one(di, si, dv, len(di))
+    return di[:n], si[:n], dv[:n]
 
 
 def icp_run(dst, dst_n, src, params, T0=None, tree=None, src_n=None):

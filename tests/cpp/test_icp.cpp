@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     if (!(e2 <= 1e-5)) ++failures;
 
     bool threw = false;
-    try { icp.correspondenceSearchEngine().setOneToOne(true); } catch (const std::invalid_argument&) { threw = true; }
+    try { icp.correspondenceSearchEngine().setRequireReciprocality(true); } catch (const std::invalid_argument&) { threw = true; }
     if (!threw) ++failures;
   } catch (const std::runtime_error& e) {
     if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }

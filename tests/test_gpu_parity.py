@@ -421,3 +421,38 @@ def test_target_shard_protocol_single_rank(orc, hip_lib):
     bi, bd = orc.nn_brute(d["dst"], q[:20000], d["max_sq_dist"])
     exp = np.where(bi >= 0, (bd.view(np.uint32).astype(np.int64) << 32) | (bi + off), distributed.KEY_NONE)
     assert np.array_equal(keys[:20000], exp)
+
+
+def test_engine_post_filters_vs_oracle(Context, orc, hip_lib):
+    """setInlierFraction / setOneToOne (correspondence_search_kd_tree.hpp:224-225, core/correspondence.hpp:57-100):
+    identical surviving set AND identical order as the reference leaves it (ties pinned to lowest source index)."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(60000, perturb=0.6)
+    dst = d["dst"][::2].copy(); nrm = d["dst_n"][::2].copy()       # 2 sources per target -> one-to-one really drops
+    src = d["src"].copy()
+    src[1000:1100] = src[:100]                                       # duplicated sources -> exact value ties
+    T = np.eye(4, dtype=np.float32)
+    q = orc.transform_points(T, src)
+    base = orc.KDTree(dst).find_correspondences(q, d["max_sq_dist"])
+    for frac, o2o in ((0.6, False), (1.0, True), (0.35, True), (0.999999, False), (1e-9, False)):
+        ctx = Context()
+        ctx.set_target(dst, nrm); ctx.set_source(src)
+        ctx.set_option("inlier_fraction", frac); ctx.set_option("one_to_one", 1 if o2o else 0)
+        n = ctx.find_correspondences(T, d["max_sq_dist"])
+        g1, g2, gv = ctx.get_correspondences()
+        o1, o2, ov = orc.filter_fraction(*base, frac)
+        if o2o:
+            o1, o2, ov = orc.filter_one_to_one(o1, o2, ov)
+        assert n == len(o1), (frac, o2o, n, len(o1))
+        assert np.array_equal(g1, o1) and np.array_equal(g2, o2) and np.array_equal(gv, ov), (frac, o2o)
+    # inside the ICP loop
+    for frac, o2o in ((0.8, False), (0.9, True)):
+        icp = SimpleCombinedMetricRigidICP3f(dst, nrm, src)
+        icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"]).setInlierFraction(frac).setOneToOne(o2o)
+        Tg = icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0).estimate().getTransform()
+        p = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED,
+                            inlier_fraction=frac, one_to_one=o2o)
+        r = orc.icp_run(dst, nrm, src, p)
+        assert icp.last_ncorr_ == r["last_ncorr"]
+        assert np.linalg.norm(Tg.astype(np.float64) - r["T"]) <= TOL_T, (frac, o2o)

@@ -22,10 +22,12 @@ def test_engine_defaults_and_unsupported_options():
     assert not e.getRequireReciprocality() and not e.getOneToOne()
     assert e.setMaxDistance(0.1 * 0.1) is e and e.getMaxDistance() == np.float32(0.1 * 0.1)
     for bad in (lambda: e.setSearchDirection(CorrespondenceSearchDirection.BOTH),
-                lambda: e.setInlierFraction(0.5), lambda: e.setRequireReciprocality(True), lambda: e.setOneToOne(True)):
+                lambda: e.setSearchDirection(CorrespondenceSearchDirection.FIRST_TO_SECOND),
+                lambda: e.setRequireReciprocality(True)):
         with pytest.raises(NotImplementedError):
             bad()
     assert e.setOneToOne(False) is e and e.setInlierFraction(1.0) is e
+    assert e.setOneToOne(True).getOneToOne() and e.setInlierFraction(0.7).getInlierFraction() == 0.7   # filters are implemented
 
 
 @pytest.mark.parametrize("n,world", [(10, 1), (10, 3), (7, 8), (1000001, 8), (0, 4)])
