@@ -25,7 +25,7 @@ SYMBOLS = [
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
     "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing",
     "cilhip_set_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
-    "cilhip_icp_sums_from_keys", "cilhip_debug_counters",
+    "cilhip_icp_sums_from_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign",
 ]
 
 
@@ -107,6 +107,8 @@ def load():
     L.cilhip_set_shard_info.argtypes = [vp, C.c_uint64, f32p, f32p]
     L.cilhip_icp_partial_keys.argtypes = [vp, vp]
     L.cilhip_debug_counters.argtypes = [vp, vp]
+    L.cilhip_kmeans3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_float, vp, C.POINTER(C.c_size_t)]
+    L.cilhip_kmeans3f_assign.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, vp]
     L.cilhip_icp_sums_from_keys.argtypes = [vp, vp, f64p]
     L.cilhip_get_last_timing2.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     for name in SYMBOLS:

@@ -1,0 +1,232 @@
+// kmeans.hip -- KMeans<float,3> with the brute-force assignment, on the device (SURVEY.md section 8(f) rank 1;
+// BASELINE configs[4]).  Replaces cilantro's clustering/kmeans.hpp:67-194 (cluster_, use_kd_tree = false):
+//   assignment   :95-119   argmin_j ||c_j - x_i||^2, strict '<' over ascending j   -> k_assign_accumulate
+//   centroid sums :126-131 serial f32 in the reference                              -> exact fixed-point int64
+//                                                                                     sums in LDS, flushed with
+//                                                                                     integer atomics (order-
+//                                                                                     independent => deterministic)
+//   empty clusters :134-176, new centroids :179-181, convergence :186-188           -> host, from k*(3+1) values
+// The assignment is VALU-bound (n*k distance evaluations, no reuse to tile): two points per lane so the
+// distance math runs on packed f32 (v_pk_*), centroids come through the scalar cache (wave-uniform index).
+// d2 is (c-x).squaredNorm() with Eigen's 3-term redux pairing d0*d0 + (d1*d1 + d2*d2), no FMA contraction,
+// so labels are bit-identical to the reference given identical centroids.
+#include "../../include/cilantro_hip/c_api.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int KM_THREADS = 256;
+constexpr int KM_MAX_K = 2048;   // LDS accumulators: k * 4 * 8 B <= 64 KiB of dynamic LDS
+
+struct KmArgs {
+  const float* xyz;        // [3n]
+  const float* centroids;  // [3k]
+  uint32_t n, k;
+  uint32_t* labels;        // [n] in: previous, out: new
+  long long* sums;         // [k*4] fixed-point sums x,y,z and count
+  unsigned int* changed;   // [1]
+  double scale;            // 2^S
+  int accumulate;
+};
+
+__global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
+  extern __shared__ long long lsum[];  // [k*4]
+  if (a.accumulate) {
+    for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS) lsum[t] = 0;
+    __syncthreads();
+  }
+  const uint32_t pairs = (a.n + 1) / 2;
+  unsigned int changed = 0;
+  for (uint32_t pidx = blockIdx.x * KM_THREADS + threadIdx.x; pidx < pairs; pidx += gridDim.x * KM_THREADS) {
+    const uint32_t i0 = 2 * pidx, i1 = min(2 * pidx + 1, a.n - 1);
+    const f32x2 px = {a.xyz[3 * (size_t)i0], a.xyz[3 * (size_t)i1]};
+    const f32x2 py = {a.xyz[3 * (size_t)i0 + 1], a.xyz[3 * (size_t)i1 + 1]};
+    const f32x2 pz = {a.xyz[3 * (size_t)i0 + 2], a.xyz[3 * (size_t)i1 + 2]};
+    f32x2 best = {INFINITY, INFINITY};
+    uint32_t b0 = 0, b1 = 0;
+    for (uint32_t j = 0; j < a.k; ++j) {
+      const float cx = a.centroids[3 * j], cy = a.centroids[3 * j + 1], cz = a.centroids[3 * j + 2];  // scalar loads
+      const f32x2 dx = (f32x2){cx, cx} - px, dy = (f32x2){cy, cy} - py, dz = (f32x2){cz, cz} - pz;
+      const f32x2 d = dx * dx + (dy * dy + dz * dz);     // d0*d0 + (d1*d1 + d2*d2), -ffp-contract=off
+      if (d.x < best.x) { best.x = d.x; b0 = j; }
+      if (d.y < best.y) { best.y = d.y; b1 = j; }
+    }
+    const bool two = (2 * pidx + 1) < a.n;
+    changed += (a.labels[i0] != b0) ? 1u : 0u;
+    a.labels[i0] = b0;
+    if (two) { changed += (a.labels[i1] != b1) ? 1u : 0u; a.labels[i1] = b1; }
+    if (a.accumulate) {
+      atomicAdd((unsigned long long*)&lsum[b0 * 4 + 0], (unsigned long long)llrint((double)px.x * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b0 * 4 + 1], (unsigned long long)llrint((double)py.x * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b0 * 4 + 2], (unsigned long long)llrint((double)pz.x * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b0 * 4 + 3], 1ull);
+      if (two) {
+        atomicAdd((unsigned long long*)&lsum[b1 * 4 + 0], (unsigned long long)llrint((double)px.y * a.scale));
+        atomicAdd((unsigned long long*)&lsum[b1 * 4 + 1], (unsigned long long)llrint((double)py.y * a.scale));
+        atomicAdd((unsigned long long*)&lsum[b1 * 4 + 2], (unsigned long long)llrint((double)pz.y * a.scale));
+        atomicAdd((unsigned long long*)&lsum[b1 * 4 + 3], 1ull);
+      }
+    }
+  }
+  if (changed) atomicAdd(a.changed, changed);
+  if (a.accumulate) {
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS)
+      if (lsum[t] != 0) atomicAdd((unsigned long long*)&a.sums[t], (unsigned long long)lsum[t]);
+  }
+}
+
+// farthest member of one cluster from a given point (empty-cluster repair, kmeans.hpp:145-168);
+// ties -> lowest point index (the reference's omp-critical order is unspecified)
+__global__ void k_farthest_member(const float* __restrict__ xyz, const uint32_t* __restrict__ labels, uint32_t n, uint32_t cluster,
+                                  float ox, float oy, float oz, unsigned long long* best) {
+  unsigned long long loc = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (labels[i] != cluster) continue;
+    const float d0 = ox - xyz[3 * (size_t)i], d1 = oy - xyz[3 * (size_t)i + 1], d2 = oz - xyz[3 * (size_t)i + 2];
+    const float d = d0 * d0 + (d1 * d1 + d2 * d2);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+    loc = key > loc ? key : loc;   // +1 offset below keeps "no member" (0) distinguishable
+  }
+  for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(loc, off, 64); loc = o > loc ? o : loc; }
+  if ((threadIdx.x & 63) == 0 && loc) atomicMax(best, loc);
+}
+
+__global__ void k_set_label(uint32_t* labels, uint32_t i, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) labels[i] = v; }
+
+#define KM_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = CILHIP_ERR_HIP; goto done; } } while (0)
+
+int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
+                uint32_t* labels_out, size_t* iterations_out, bool assign_only) {
+  if (!xyz || !centroids || k == 0 || n == 0 || n >= 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
+  if (k > KM_MAX_K) return CILHIP_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CILHIP_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return CILHIP_ERR_INVALID;
+  int rc = CILHIP_OK;
+  float *d_xyz = nullptr, *d_c = nullptr;
+  uint32_t* d_lab = nullptr;
+  long long* d_sums = nullptr;
+  unsigned int* d_changed = nullptr;
+  unsigned long long* d_best = nullptr;
+  hipStream_t s = nullptr;
+  std::vector<long long> hs(k * 4);
+  std::vector<float> c_old(3 * k);
+  size_t iter = 0;
+  {
+    KM_CK(hipSetDevice(device));
+    KM_CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (mem == CILHIP_MEM_DEVICE) {
+      d_xyz = const_cast<float*>(xyz);
+    } else {
+      KM_CK(hipMalloc(&d_xyz, 3 * n * sizeof(float)));
+      KM_CK(hipMemcpyAsync(d_xyz, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    KM_CK(hipMalloc(&d_c, 3 * k * sizeof(float)));
+    KM_CK(hipMalloc(&d_lab, n * sizeof(uint32_t)));
+    KM_CK(hipMalloc(&d_sums, k * 4 * sizeof(long long)));
+    KM_CK(hipMalloc(&d_changed, sizeof(unsigned int)));
+    KM_CK(hipMalloc(&d_best, sizeof(unsigned long long)));
+    KM_CK(hipMemsetAsync(d_lab, 0, n * sizeof(uint32_t), s));   // point_to_cluster_index_map_.resize(n): zeros (:80)
+    // fixed-point scale: |x| * 2^S < 2^(62 - ceil(log2 n)) so that a whole cluster's sum cannot overflow int64
+    double maxabs = 0.0;
+    {
+      // bounding magnitude from a host-side pass when the data is on the host, else a conservative device copy of it
+      std::vector<float> tmp;
+      const float* hp = xyz;
+      if (mem == CILHIP_MEM_DEVICE) { tmp.resize(3 * n); KM_CK(hipMemcpy(tmp.data(), xyz, 3 * n * sizeof(float), hipMemcpyDeviceToHost)); hp = tmp.data(); }
+      for (size_t i = 0; i < 3 * n; ++i) { const double v = std::fabs((double)hp[i]); if (v > maxabs) maxabs = v; }
+    }
+    int e = 0;
+    (void)std::frexp(maxabs > 0.0 ? maxabs : 1.0, &e);           // maxabs < 2^e
+    int nbits = 0;
+    while (((size_t)1 << nbits) < n) ++nbits;
+    const int S = 62 - nbits - e;
+    const double scale = std::ldexp(1.0, S);
+    const int nblocks = (int)std::min<size_t>((n / 2 + KM_THREADS - 1) / KM_THREADS + 1, 1024);
+    const float tol_sq = tol * tol;
+    const size_t rounds = assign_only ? 1 : max_iter;
+    while (iter < rounds) {
+      KM_CK(hipMemcpyAsync(d_c, centroids, 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
+      KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
+      KM_CK(hipMemsetAsync(d_sums, 0, k * 4 * sizeof(long long), s));
+      KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)k, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1};
+      hipLaunchKernelGGL(k_assign_accumulate, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : k * 4 * sizeof(long long), s, a);
+      KM_CK(hipGetLastError());
+      if (assign_only) break;
+      unsigned int changed = 0;
+      KM_CK(hipMemcpyAsync(&changed, d_changed, sizeof(changed), hipMemcpyDeviceToHost, s));
+      KM_CK(hipMemcpyAsync(hs.data(), d_sums, k * 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
+      KM_CK(hipStreamSynchronize(s));
+      if (changed == 0 && iter > 0) break;                                            // kmeans.hpp:122
+      if (tol > 0.0f) std::memcpy(c_old.data(), centroids, 3 * k * sizeof(float));   // :123
+      // empty clusters (:134-176), processed in ascending cluster index like the reference
+      for (size_t i = 0; i < k; ++i) {
+        if (hs[i * 4 + 3] != 0) continue;
+        size_t mx = 0;
+        for (size_t j = 1; j < k; ++j) if (hs[j * 4 + 3] > hs[mx * 4 + 3]) mx = j;
+        const double cm = (double)hs[mx * 4 + 3];
+        const float oc[3] = {(float)((double)hs[mx * 4] / scale / cm), (float)((double)hs[mx * 4 + 1] / scale / cm), (float)((double)hs[mx * 4 + 2] / scale / cm)};
+        KM_CK(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_farthest_member, dim3(1024), dim3(256), 0, s, d_xyz, d_lab, (uint32_t)n, (uint32_t)mx, oc[0], oc[1], oc[2], d_best);
+        unsigned long long best = 0;
+        KM_CK(hipMemcpyAsync(&best, d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+        KM_CK(hipStreamSynchronize(s));
+        const uint32_t mi = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu);
+        hipLaunchKernelGGL(k_set_label, dim3(1), dim3(64), 0, s, d_lab, mi, (uint32_t)i);
+        float p[3];
+        KM_CK(hipMemcpyAsync(p, d_xyz + 3 * (size_t)mi, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+        KM_CK(hipStreamSynchronize(s));
+        for (int d = 0; d < 3; ++d) hs[mx * 4 + d] -= (long long)std::llrint((double)p[d] * scale);
+        hs[mx * 4 + 3]--; hs[i * 4 + 3]++;   // the reference does not add the point to cluster i's sum (:171-175)
+      }
+      for (size_t i = 0; i < k; ++i)                                                    // :179-181
+        for (int d = 0; d < 3; ++d) centroids[3 * i + d] = (float)((double)hs[i * 4 + d] / scale / (double)hs[i * 4 + 3]);
+      ++iter;
+      if (tol > 0.0f) {                                                                  // :186-188
+        float mxs = 0.0f;
+        for (size_t i = 0; i < k; ++i) {
+          const float d0 = centroids[3 * i] - c_old[3 * i], d1 = centroids[3 * i + 1] - c_old[3 * i + 1], d2 = centroids[3 * i + 2] - c_old[3 * i + 2];
+          const float sq = d0 * d0 + (d1 * d1 + d2 * d2);
+          if (sq > mxs) mxs = sq;
+        }
+        if (mxs < tol_sq) break;
+      }
+    }
+    if (labels_out) {
+      KM_CK(hipMemcpyAsync(labels_out, d_lab, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    KM_CK(hipStreamSynchronize(s));
+  }
+done:
+  if (iterations_out) *iterations_out = iter;
+  if (mem != CILHIP_MEM_DEVICE && d_xyz) (void)hipFree(d_xyz);
+  if (d_c) (void)hipFree(d_c);
+  if (d_lab) (void)hipFree(d_lab);
+  if (d_sums) (void)hipFree(d_sums);
+  if (d_changed) (void)hipFree(d_changed);
+  if (d_best) (void)hipFree(d_best);
+  if (s) (void)hipStreamDestroy(s);
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cilhip_kmeans3f(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
+                    uint32_t* labels_out, size_t* iterations_out) {
+  return kmeans_impl(device, xyz, n, mem, centroids, k, max_iter, tol, labels_out, iterations_out, false);
+}
+
+int cilhip_kmeans3f_assign(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k, uint32_t* labels_out) {
+  return kmeans_impl(device, xyz, n, mem, const_cast<float*>(centroids), k, 1, 0.0f, labels_out, nullptr, true);
+}
+
+}  // extern "C"

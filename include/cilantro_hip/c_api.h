@@ -173,6 +173,20 @@ int cilhip_icp_sums_from_keys(cilhip_ctx* ctx, const uint64_t* keys_dev, double*
 int cilhip_compute_residuals(cilhip_ctx* ctx, int metric, float w_p2p, float w_p2pl,
                              const float T[16], float* out, int mem);
 
+/* ---- next tier: KMeans3f --------------------------------------------------------- */
+/* KMeans<float,3>::cluster(centroids, max_iter, tol, use_kd_tree = false)  (clustering/kmeans.hpp:24-30 ->
+ * cluster_ :67-194): brute-force assignment (strict '<' over ascending cluster index, :95-119), centroid
+ * update, empty-cluster repair (:134-176, including the reference's quirk that the moved point is not added
+ * to the re-seeded cluster's sum), convergence on assignments (:122) or on the centroid shift (:186-188).
+ * centroids: HOST array of 3*k floats, in = initial centroids, out = final.  labels_out: HOST array of n
+ * (point_to_cluster_index_map_) or NULL.  k <= 2048.  Cluster sums are exact (fixed point) instead of the
+ * reference's serial f32 sums; labels are bit-identical to the reference given identical centroids. */
+int cilhip_kmeans3f(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter,
+                    float tol, uint32_t* labels_out, size_t* iterations_out);
+/* one assignment pass only (kmeans.hpp:95-119) */
+int cilhip_kmeans3f_assign(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k,
+                           uint32_t* labels_out);
+
 /* ---- introspection (bench / tests) ----------------------------------------------------------- */
 typedef struct {
   int nx, ny, nz;        /* grid dims */

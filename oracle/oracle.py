@@ -97,6 +97,10 @@ def lib():
         L.orc_icp_update.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_void_p, C.c_size_t, _f32p, _i64p,
                                      _i64p, C.c_size_t, C.POINTER(IcpParams), _f32p]
         L.orc_mean3.argtypes = [_f32p, C.c_size_t, C.c_int, _f32p]
+        L.orc_kmeans_assign.restype = C.c_size_t
+        L.orc_kmeans_assign.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _i64p]
+        L.orc_kmeans.restype = C.c_size_t
+        L.orc_kmeans.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_int, _i64p]
         _lib = L
     return _lib
 
@@ -299,3 +303,19 @@ def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params, src_n=None):
                              sn.ctypes.data if sn is not None else None, len(src),
                              T_to_colmajor(T_cur), di, si, len(di), C.byref(params), Tn)
     return T_from_colmajor(Tn), float(d)
+
+
+def kmeans_assign(x, centroids, labels=None):
+    """clustering/kmeans.hpp:95-119 -> (labels int64, number changed)"""
+    x = _c(x).reshape(-1, 3); c = _c(centroids).reshape(-1, 3)
+    lab = np.zeros(len(x), np.int64) if labels is None else _c(labels, np.int64).copy()
+    ch = lib().orc_kmeans_assign(x, len(x), c, len(c), lab)
+    return lab, int(ch)
+
+
+def kmeans(x, centroids, max_iter=100, tol=np.finfo(np.float32).eps, mode=1):
+    """KMeans<float,3>::cluster(centroids, max_iter, tol, false) -> (centroids, labels, iterations)"""
+    x = _c(x).reshape(-1, 3); c = _c(centroids).reshape(-1, 3).copy()
+    lab = np.zeros(len(x), np.int64)
+    it = lib().orc_kmeans(x, len(x), c, len(c), max_iter, np.float32(tol), mode, lab)
+    return c, lab, int(it)

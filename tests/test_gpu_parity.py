@@ -456,3 +456,34 @@ def test_engine_post_filters_vs_oracle(Context, orc, hip_lib):
         r = orc.icp_run(dst, nrm, src, p)
         assert icp.last_ncorr_ == r["last_ncorr"]
         assert np.linalg.norm(Tg.astype(np.float64) - r["T"]) <= TOL_T, (frac, o2o)
+
+
+def test_kmeans3f_vs_oracle(orc, hip_lib):
+    """KMeans<float,3> brute-force path (clustering/kmeans.hpp:67-194)."""
+    from cilantro_amd.clustering import KMeans3f, kmeans_assign
+
+    rng = np.random.default_rng(5)
+    # clustered data (mixture) so that k-means has structure; explicit initial centroids (no random_device)
+    centres = rng.random((40, 3)).astype(np.float32)
+    x = (centres[rng.integers(0, 40, 300000)] + rng.normal(0, 0.03, (300000, 3))).astype(np.float32)
+    for k in (1, 7, 64, 1024):
+        c0 = x[:k].copy()
+        # one assignment pass: labels bit-exact given identical centroids
+        lab_g = kmeans_assign(x, c0)
+        lab_o, _ = orc.kmeans_assign(x, c0)
+        assert np.array_equal(lab_g, lab_o), k
+    for k, iters, tol in ((64, 12, 0.0), (257, 6, 0.0), (64, 100, 1e-4)):
+        c0 = x[:k].copy()
+        km = KMeans3f(x).cluster(c0, max_iter=iters, tol=tol)
+        co, lo, ito = orc.kmeans(x, c0, max_iter=iters, tol=tol, mode=1)
+        assert km.getNumberOfPerformedIterations() == ito, (k, km.getNumberOfPerformedIterations(), ito)
+        assert np.abs(km.getClusterCentroids() - co).max() <= 1e-6, k
+        assert (km.getPointToClusterIndexMap() != lo).mean() <= 1e-5, k
+        groups = km.getClusterToPointIndicesMap()
+        assert len(groups) == k and sum(len(g) for g in groups) == len(x)
+    # empty-cluster repair (kmeans.hpp:134-176): a far-away initial centroid attracts nothing
+    c0 = x[:8].copy(); c0[5] = [50.0, 50.0, 50.0]
+    km = KMeans3f(x).cluster(c0, max_iter=3, tol=0.0)
+    co, lo, ito = orc.kmeans(x, c0, max_iter=3, tol=0.0, mode=1)
+    assert np.abs(km.getClusterCentroids() - co).max() <= 1e-6
+    assert (km.getPointToClusterIndexMap() != lo).mean() <= 1e-5
