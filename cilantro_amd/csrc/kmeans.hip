@@ -38,7 +38,7 @@ struct KmArgs {
 __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
   extern __shared__ long long lsum[];  // [k*4]
   if (a.accumulate) {
-    for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS) lsum[t] = 0;
+    for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS) lsum[t] = 0;   // a.k = padded count
     __syncthreads();
   }
   const uint32_t pairs = (a.n + 1) / 2;
@@ -50,12 +50,20 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
     const f32x2 pz = {a.xyz[3 * (size_t)i0 + 2], a.xyz[3 * (size_t)i1 + 2]};
     f32x2 best = {INFINITY, INFINITY};
     uint32_t b0 = 0, b1 = 0;
-    for (uint32_t j = 0; j < a.k; ++j) {
-      const float cx = a.centroids[3 * j], cy = a.centroids[3 * j + 1], cz = a.centroids[3 * j + 2];  // scalar loads
-      const f32x2 dx = (f32x2){cx, cx} - px, dy = (f32x2){cy, cy} - py, dz = (f32x2){cz, cz} - pz;
-      const f32x2 d = dx * dx + (dy * dy + dz * dz);     // d0*d0 + (d1*d1 + d2*d2), -ffp-contract=off
-      if (d.x < best.x) { best.x = d.x; b0 = j; }
-      if (d.y < best.y) { best.y = d.y; b1 = j; }
+    // centroids are padded to a multiple of 8 (pad = +inf: never the minimum); 24 consecutive floats per
+    // block of 8 come through the scalar cache with wide s_load's, one wait per 8 candidates
+    for (uint32_t j = 0; j < a.k; j += 8) {
+      float c[24];
+#pragma unroll
+      for (int t = 0; t < 24; ++t) c[t] = a.centroids[3 * j + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float cx = c[3 * u], cy = c[3 * u + 1], cz = c[3 * u + 2];
+        const f32x2 dx = (f32x2){cx, cx} - px, dy = (f32x2){cy, cy} - py, dz = (f32x2){cz, cz} - pz;
+        const f32x2 d = dx * dx + (dy * dy + dz * dz);     // d0*d0 + (d1*d1 + d2*d2), -ffp-contract=off
+        if (d.x < best.x) { best.x = d.x; b0 = j + u; }
+        if (d.y < best.y) { best.y = d.y; b1 = j + u; }
+      }
     }
     const bool two = (2 * pidx + 1) < a.n;
     changed += (a.labels[i0] != b0) ? 1u : 0u;
@@ -98,6 +106,14 @@ __global__ void k_farthest_member(const float* __restrict__ xyz, const uint32_t*
   if ((threadIdx.x & 63) == 0 && loc) atomicMax(best, loc);
 }
 
+__global__ void k_maxabs_bits(const float* __restrict__ v, size_t count, unsigned int* out) {
+  unsigned int m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(fabsf(v[i])));
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_down((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 __global__ void k_set_label(uint32_t* labels, uint32_t i, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) labels[i] = v; }
 
 #define KM_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = CILHIP_ERR_HIP; goto done; } } while (0)
@@ -128,20 +144,25 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
       KM_CK(hipMalloc(&d_xyz, 3 * n * sizeof(float)));
       KM_CK(hipMemcpyAsync(d_xyz, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
     }
-    KM_CK(hipMalloc(&d_c, 3 * k * sizeof(float)));
+    const size_t kpad = (k + 7) & ~(size_t)7;                     // device copy padded with +inf centroids
+    std::vector<float> cpad(3 * kpad, INFINITY);
+    KM_CK(hipMalloc(&d_c, 3 * kpad * sizeof(float)));
     KM_CK(hipMalloc(&d_lab, n * sizeof(uint32_t)));
-    KM_CK(hipMalloc(&d_sums, k * 4 * sizeof(long long)));
+    KM_CK(hipMalloc(&d_sums, ((k + 7) & ~(size_t)7) * 4 * sizeof(long long)));
     KM_CK(hipMalloc(&d_changed, sizeof(unsigned int)));
     KM_CK(hipMalloc(&d_best, sizeof(unsigned long long)));
     KM_CK(hipMemsetAsync(d_lab, 0, n * sizeof(uint32_t), s));   // point_to_cluster_index_map_.resize(n): zeros (:80)
     // fixed-point scale: |x| * 2^S < 2^(62 - ceil(log2 n)) so that a whole cluster's sum cannot overflow int64
     double maxabs = 0.0;
     {
-      // bounding magnitude from a host-side pass when the data is on the host, else a conservative device copy of it
-      std::vector<float> tmp;
-      const float* hp = xyz;
-      if (mem == CILHIP_MEM_DEVICE) { tmp.resize(3 * n); KM_CK(hipMemcpy(tmp.data(), xyz, 3 * n * sizeof(float), hipMemcpyDeviceToHost)); hp = tmp.data(); }
-      for (size_t i = 0; i < 3 * n; ++i) { const double v = std::fabs((double)hp[i]); if (v > maxabs) maxabs = v; }
+      unsigned int hmax = 0;   // max |x| as f32 bits (non-negative floats order like unsigned ints)
+      KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
+      hipLaunchKernelGGL(k_maxabs_bits, dim3(1024), dim3(256), 0, s, d_xyz, 3 * n, d_changed);
+      KM_CK(hipMemcpyAsync(&hmax, d_changed, sizeof(hmax), hipMemcpyDeviceToHost, s));
+      KM_CK(hipStreamSynchronize(s));
+      float f;
+      std::memcpy(&f, &hmax, sizeof(f));
+      maxabs = (double)f;
     }
     int e = 0;
     (void)std::frexp(maxabs > 0.0 ? maxabs : 1.0, &e);           // maxabs < 2^e
@@ -153,11 +174,12 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
     const float tol_sq = tol * tol;
     const size_t rounds = assign_only ? 1 : max_iter;
     while (iter < rounds) {
-      KM_CK(hipMemcpyAsync(d_c, centroids, 3 * k * sizeof(float), hipMemcpyHostToDevice, s));
+      std::memcpy(cpad.data(), centroids, 3 * k * sizeof(float));
+      KM_CK(hipMemcpyAsync(d_c, cpad.data(), 3 * kpad * sizeof(float), hipMemcpyHostToDevice, s));
       KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
-      KM_CK(hipMemsetAsync(d_sums, 0, k * 4 * sizeof(long long), s));
-      KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)k, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1};
-      hipLaunchKernelGGL(k_assign_accumulate, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : k * 4 * sizeof(long long), s, a);
+      KM_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
+      KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1};
+      hipLaunchKernelGGL(k_assign_accumulate, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
       KM_CK(hipGetLastError());
       if (assign_only) break;
       unsigned int changed = 0;
