@@ -26,6 +26,7 @@ SYMBOLS = [
     "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing",
     "cilhip_set_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
     "cilhip_icp_sums_from_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign",
+    "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f",
 ]
 
 
@@ -49,6 +50,13 @@ class GridInfo(C.Structure):
         ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("cell", C.c_float),
         ("origin", C.c_float * 3), ("n_cells", C.c_size_t), ("avg_occupancy", C.c_double),
         ("build_ms", C.c_double),
+    ]
+
+
+class PlaneModel(C.Structure):
+    _fields_ = [
+        ("normal", C.c_float * 3), ("offset", C.c_float), ("iterations", C.c_size_t), ("n_inliers", C.c_size_t),
+        ("target_reached", C.c_int), ("device_ms", C.c_double),
     ]
 
 
@@ -109,6 +117,10 @@ def load():
     L.cilhip_debug_counters.argtypes = [vp, vp]
     L.cilhip_kmeans3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_float, vp, C.POINTER(C.c_size_t)]
     L.cilhip_kmeans3f_assign.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, vp]
+    L.cilhip_plane_ransac3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, vp, C.c_uint64, C.c_float, C.c_size_t, C.c_size_t,
+                                        C.c_int, C.POINTER(PlaneModel), vp, vp]
+    L.cilhip_plane_score3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_float, vp]
+    L.cilhip_plane_fit3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p]
     L.cilhip_icp_sums_from_keys.argtypes = [vp, vp, f64p]
     L.cilhip_get_last_timing2.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     for name in SYMBOLS:

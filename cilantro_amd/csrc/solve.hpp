@@ -295,4 +295,51 @@ CILHIP_HD void transform_point(const float T[16], float x, float y, float z, flo
   qz = CILHIP_ADD(CILHIP_ADD(CILHIP_MUL(T[2], x), CILHIP_ADD(CILHIP_MUL(T[6], y), CILHIP_MUL(T[10], z))), T[14]);
 }
 
+// ---- symmetric 3x3 eigen-decomposition (cyclic Jacobi, f64), PCA convention ---------------------
+// Replaces Eigen::SelfAdjointEigenSolver<Matrix3f> + the reordering of
+// core/principal_component_analysis.hpp:76-84: V columns = eigenvectors by DESCENDING eigenvalue,
+// last column negated when det(V) < 0.  A row-major, only read.
+CILHIP_HD void sym_eig3(const double Ain[9], double w[3], double V[9]) {
+  double A[9];
+  for (int i = 0; i < 9; ++i) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    const double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
+    const double dia = fabs(A[0]) + fabs(A[4]) + fabs(A[8]);
+    if (off <= 2.220446049250313e-16 * 0.125 * dia || off == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+        A[p * 3 + q] = A[q * 3 + p] = 0.0;
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+          V[k * 3 + p] = c * vkp - s * vkq;
+          V[k * 3 + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (w[j] > w[i]) {
+        const double tw = w[i]; w[i] = w[j]; w[j] = tw;
+        for (int k = 0; k < 3; ++k) { const double tv = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + j]; V[k * 3 + j] = tv; }
+      }
+  const double det = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) + V[2] * (V[3] * V[7] - V[4] * V[6]);
+  if (det < 0.0) { V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8]; }
+}
+
 }  // namespace cilhip

@@ -187,6 +187,36 @@ int cilhip_kmeans3f(int device, const float* xyz, size_t n, int mem, float* cent
 int cilhip_kmeans3f_assign(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k,
                            uint32_t* labels_out);
 
+/* ---- next tier: PlaneRANSACEstimator3f ----------------------------------- */
+typedef struct {
+  float normal[3];     /* Eigen::Hyperplane<float,3>::normal()  (unit; sign as PCA leaves it)               */
+  float offset;        /* ::offset(): the plane is normal . x + offset = 0                                  */
+  size_t iterations;   /* getNumberOfPerformedIterations()   (ransac_base.hpp:103)                          */
+  size_t n_inliers;    /* getModelInliers().size()                                                          */
+  int target_reached;  /* targetInlierCountAchieved()        (ransac_base.hpp:172)                          */
+  double device_ms;    /* kernels only (hypothesis fit + scoring + re-estimation + outputs), HIP events     */
+} cilhip_plane_model;
+/* HyperplaneRANSACEstimator<float,3>::estimate() (model_estimation/ransac_base.hpp:64-131 with
+ * ransac_hyperplane_estimator.hpp:47-55 computeResiduals and :78-85 estimate_params_).
+ * samples: HOST array of 3*max_iter point indices, the random sample of every iteration in order
+ *   (ransac_base.hpp:83-91), or NULL to draw them here (uniform distinct triples from `seed`; the
+ *   reference seeds std::mt19937 from std::random_device, so its sequence is not reproducible either).
+ * All max_iter hypotheses may be scored, but the result is the one the reference's sequential loop reaches
+ * with the same samples: first strictly-better model wins, stop at the first iteration whose best inlier
+ * count reaches target_inliers (clamped to n, :68).  re_estimate: PCA over the best model's inliers, then
+ * residuals / inliers of the re-estimated plane (:118-128).
+ * residuals_out: HOST, n floats or NULL.  inliers_out: HOST, capacity n, ascending indices, or NULL.
+ * No accepted model => NaN plane, no inliers. */
+int cilhip_plane_ransac3f(int device, const float* xyz, size_t n, int mem, const uint32_t* samples, uint64_t seed,
+                          float max_residual, size_t target_inliers, size_t max_iter, int re_estimate,
+                          cilhip_plane_model* out, float* residuals_out, uint32_t* inliers_out);
+/* inlier counts (#points with absDistance <= max_residual, ransac_base.hpp:98-100) of m given planes
+ * (HOST, 4*m floats: normal, offset) in one pass over the points per 128 planes.  counts_out: HOST, m. */
+int cilhip_plane_score3f(int device, const float* xyz, size_t n, int mem, const float* planes, size_t m,
+                         float max_residual, uint32_t* counts_out);
+/* estimateModel() over ALL points (ransac_hyperplane_estimator.hpp:22-25, :70-76): PCA plane fit. */
+int cilhip_plane_fit3f(int device, const float* xyz, size_t n, int mem, float plane_out[4]);
+
 /* ---- introspection (bench / tests) ----------------------------------------------------------- */
 typedef struct {
   int nx, ny, nz;        /* grid dims */

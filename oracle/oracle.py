@@ -35,6 +35,7 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 
 
 class IcpParams(C.Structure):
@@ -101,6 +102,14 @@ def lib():
         L.orc_kmeans_assign.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _i64p]
         L.orc_kmeans.restype = C.c_size_t
         L.orc_kmeans.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_int, _i64p]
+        L.orc_sym_eig3.argtypes = [_f64p, _f64p, _f64p]
+        L.orc_plane_residuals.argtypes = [_f32p, C.c_size_t, _f32p, _f32p]
+        L.orc_plane_count_inliers.restype = C.c_size_t
+        L.orc_plane_count_inliers.argtypes = [_f32p, C.c_size_t, _f32p, C.c_float]
+        L.orc_plane_fit.argtypes = [_f32p, C.c_void_p, C.c_size_t, C.c_int, _f32p]
+        L.orc_plane_ransac.restype = C.c_size_t
+        L.orc_plane_ransac.argtypes = [_f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
+                                       _f32p, _f32p, _u32p, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -319,3 +328,46 @@ def kmeans(x, centroids, max_iter=100, tol=np.finfo(np.float32).eps, mode=1):
     lab = np.zeros(len(x), np.int64)
     it = lib().orc_kmeans(x, len(x), c, len(c), max_iter, np.float32(tol), mode, lab)
     return c, lab, int(it)
+
+
+# ---- plane RANSAC (model_estimation/ransac_hyperplane_estimator.hpp, ransac_base.hpp) ----------------
+def sym_eig3(A):
+    """symmetric 3x3 eigen-decomposition, PCA convention (descending, det fix) -> (w, V)"""
+    A = np.ascontiguousarray(A, np.float64).reshape(9)
+    w = np.zeros(3); V = np.zeros(9)
+    lib().orc_sym_eig3(A, w, V)
+    return w, V.reshape(3, 3)
+
+
+def plane_residuals(pts, plane):
+    pts = _c(pts).reshape(-1, 3); r = np.zeros(len(pts), np.float32)
+    lib().orc_plane_residuals(pts, len(pts), _c(plane).reshape(4), r)
+    return r
+
+
+def plane_count_inliers(pts, plane, thresh):
+    pts = _c(pts).reshape(-1, 3)
+    return int(lib().orc_plane_count_inliers(pts, len(pts), _c(plane).reshape(4), np.float32(thresh)))
+
+
+def plane_fit(pts, idx=None, mode=1):
+    """estimate_params_ (ransac_hyperplane_estimator.hpp:70-85) -> plane (nx, ny, nz, offset) f32"""
+    pts = _c(pts).reshape(-1, 3); pl = np.zeros(4, np.float32)
+    if idx is None:
+        lib().orc_plane_fit(pts, None, len(pts), mode, pl)
+    else:
+        idx = np.ascontiguousarray(idx, np.uint32)
+        lib().orc_plane_fit(pts, idx.ctypes.data, len(idx), mode, pl)
+    return pl
+
+
+def plane_ransac(pts, samples, thresh, target_inliers, max_iter=None, re_estimate=True, mode=1):
+    """RandomSampleConsensusBase::estimate() -> (plane, residuals, inliers, iterations)"""
+    pts = _c(pts).reshape(-1, 3); n = len(pts)
+    samples = np.ascontiguousarray(samples, np.uint32).reshape(-1, 3)
+    max_iter = len(samples) if max_iter is None else max_iter
+    pl = np.zeros(4, np.float32); res = np.zeros(n, np.float32); inl = np.zeros(max(n, 1), np.uint32)
+    k = C.c_size_t(0)
+    it = lib().orc_plane_ransac(pts, n, samples, max_iter, np.float32(thresh), target_inliers, int(re_estimate), mode,
+                                pl, res, inl, C.byref(k))
+    return pl, res, inl[:k.value].copy(), int(it)

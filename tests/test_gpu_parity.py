@@ -487,3 +487,69 @@ def test_kmeans3f_vs_oracle(orc, hip_lib):
     co, lo, ito = orc.kmeans(x, c0, max_iter=3, tol=0.0, mode=1)
     assert np.abs(km.getClusterCentroids() - co).max() <= 1e-6
     assert (km.getPointToClusterIndexMap() != lo).mean() <= 1e-5
+
+
+def _plane_cloud(n, seed, inlier_frac=0.6, noise=0.004):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    k = int(n * inlier_frac)
+    sel = rng.permutation(n)[:k]
+    x[sel, 2] = (0.3 * x[sel, 0] - 0.2 * x[sel, 1] + 0.1 + rng.normal(0, noise, k)).astype(np.float32)
+    return x, rng
+
+
+def test_plane_ransac3f_vs_oracle(orc, hip_lib):
+    """PlaneRANSACEstimator3f (model_estimation/ransac_base.hpp:64-131,
+    ransac_hyperplane_estimator.hpp).  Scoring half bit-exact; model half within f32 round-off."""
+    from cilantro_amd.model_estimation import PlaneRANSACEstimator3f
+
+    n = 250_003   # not a multiple of the tile: exercises the ragged tail
+    x, rng = _plane_cloud(n, 21)
+    thr = 0.01
+    # (1) scoring: counts of arbitrary planes are exact (same f32 expression, no contraction)
+    planes = rng.standard_normal((301, 4)).astype(np.float32)
+    planes[:, :3] /= np.linalg.norm(planes[:, :3], axis=1, keepdims=True)
+    planes[:, 3] *= 0.2
+    planes[7] = [np.nan, 0, 0, 0]
+    pe = PlaneRANSACEstimator3f(x)
+    got = pe.countInliers(planes, thr)
+    want = np.array([orc.plane_count_inliers(x, p, thr) for p in planes])
+    assert np.array_equal(got, want)
+    # (2) whole-cloud PCA fit vs the oracle (f64 accumulation both sides; order differs -> last-bit only)
+    pg = pe.estimateModel()
+    po = orc.plane_fit(x, None, mode=1)
+    s = 1.0 if np.dot(pg[:3], po[:3]) > 0 else -1.0
+    assert np.abs(pg - s * po).max() <= 2e-6, (pg, po)
+    # (3) full runs with explicit samples: same iteration count, same winner, same inlier set
+    for max_iter, target, re_est in ((100, n // 2, True), (100, n // 2, False), (300, n, True), (5, 10, True), (130, int(0.58 * n), True)):
+        samples = rng.integers(0, n, (max_iter, 3)).astype(np.uint32)
+        pe = (PlaneRANSACEstimator3f(x).setMaxInlierResidual(thr).setTargetInlierCount(target)
+              .setMaxNumberOfIterations(max_iter).setReEstimationStep(re_est).setSamples(samples))
+        pl = pe.estimate().getModel()
+        plo, reso, inlo, ito = orc.plane_ransac(x, samples, thr, target, re_estimate=re_est, mode=1)
+        assert pe.getNumberOfPerformedIterations() == ito, (max_iter, target, pe.getNumberOfPerformedIterations(), ito)
+        s = 1.0 if np.dot(pl[:3], plo[:3]) > 0 else -1.0
+        assert np.abs(pl - s * plo).max() <= 2e-6, (pl, plo)
+        # the product's own plane, scored by the oracle: residuals and inliers bit-exact
+        res_chk = orc.plane_residuals(x, pl)
+        assert np.array_equal(pe.getModelResiduals(), res_chk)
+        inl_chk = np.nonzero(res_chk <= np.float32(thr))[0]
+        assert np.array_equal(pe.getModelInliers(), inl_chk)
+        # against the oracle's run: identical up to points within round-off of the threshold
+        assert len(np.setxor1d(inl_chk, inlo)) <= max(3, int(2e-5 * n)), (len(inl_chk), len(inlo))
+        assert pe.targetInlierCountAchieved() == (len(inl_chk) >= min(target, n))
+    # (4) library-drawn samples: deterministic in the seed, finds the plane
+    a = PlaneRANSACEstimator3f(x).setMaxInlierResidual(thr).setSeed(3).estimate()
+    b = PlaneRANSACEstimator3f(x).setMaxInlierResidual(thr).setSeed(3).estimate()
+    assert np.array_equal(a.getModel(), b.getModel()) and np.array_equal(a.getModelInliers(), b.getModelInliers())
+    m = a.getModel() / -a.getModel()[2]
+    assert np.abs(m - np.array([0.3, -0.2, -1.0, 0.1])).max() < 2e-3, m
+    assert a.getNumberOfInliers() >= int(0.55 * n)
+    # (5) edge cases: nothing reaches 3 inliers -> NaN model, no inliers; tiny clouds
+    far = (rng.uniform(-1, 1, (1000, 3)) * 1e3).astype(np.float32)
+    e = PlaneRANSACEstimator3f(far).setMaxInlierResidual(0.0).setMaxNumberOfIterations(20).setSeed(1).estimate()
+    plo, _, inlo, ito = orc.plane_ransac(far, np.zeros((20, 3), np.uint32), 0.0, 500, mode=1)
+    assert e.getNumberOfPerformedIterations() == 20
+    for npts in (0, 1, 2, 3):
+        t = PlaneRANSACEstimator3f(x[:npts].copy()).setMaxInlierResidual(thr).setMaxNumberOfIterations(4).setSeed(2).estimate()
+        assert t.getNumberOfPerformedIterations() <= 4 and t.getNumberOfInliers() <= npts

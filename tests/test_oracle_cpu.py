@@ -204,3 +204,38 @@ def test_synthetic_generator_is_deterministic():
     assert np.array_equal(a["dst"], b["dst"]) and np.array_equal(a["src"], b["src"]) and np.array_equal(a["dst_n"], b["dst_n"])
     assert a["dst"].min() >= 0 and a["dst"].max() < 1
     np.testing.assert_allclose(np.linalg.norm(a["dst_n"], axis=1), 1.0, atol=1e-6)
+
+
+def test_plane_ransac_oracle_pieces(orc):
+    """ransac_oracle.c: the Jacobi eigen-solver against numpy, PCA plane fit against an SVD fit, and the
+    sequential RANSAC loop's bookkeeping (ransac_base.hpp:103-114) on a synthetic plane."""
+    rng = np.random.default_rng(0)
+    for t in range(300):
+        B = rng.standard_normal((3, 3))
+        A = B @ B.T if t % 3 else np.outer(B[0], B[0]) + np.outer(B[1], B[1])   # rank-deficient too
+        w, V = orc.sym_eig3(A)
+        assert np.allclose(A @ V, V * w, atol=1e-12 * max(1.0, np.abs(w).max()))
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-14) and np.linalg.det(V) > 0
+        assert np.allclose(w, np.sort(np.linalg.eigvalsh(A))[::-1], atol=1e-12 * max(1.0, np.abs(w).max()))
+    n = 20000
+    x = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    x[:12000, 2] = (0.3 * x[:12000, 0] - 0.2 * x[:12000, 1] + 0.1 + rng.normal(0, 0.003, 12000)).astype(np.float32)
+    idx = np.arange(12000, dtype=np.uint32)
+    for mode in (0, 1):
+        pl = orc.plane_fit(x, idx, mode=mode)
+        xc = x[:12000].astype(np.float64)
+        nrm = np.linalg.svd(xc - xc.mean(0), full_matrices=False)[2][2]
+        s = 1.0 if np.dot(nrm, pl[:3]) > 0 else -1.0
+        assert np.abs(s * nrm - pl[:3]).max() < (2e-4 if mode == 0 else 2e-7)
+        assert abs(pl[3] + s * float(nrm @ xc.mean(0))) < (2e-4 if mode == 0 else 2e-7)
+    samples = rng.integers(0, n, (100, 3)).astype(np.uint32)
+    pl, res, inl, it = orc.plane_ransac(x, samples, 0.01, n // 2, re_estimate=True, mode=1)
+    assert 0 < it <= 100 and len(inl) >= n // 2
+    assert np.array_equal(inl, np.nonzero(res <= np.float32(0.01))[0])
+    assert np.array_equal(res, orc.plane_residuals(x, pl))
+    assert np.abs(pl / -pl[2] - np.array([0.3, -0.2, -1.0, 0.1])).max() < 1e-3
+    # unreachable target: all iterations are spent, the best model is still reported
+    pl2, _, inl2, it2 = orc.plane_ransac(x, samples, 0.01, n, re_estimate=False, mode=1)
+    assert it2 == 100 and len(inl2) == max(orc.plane_count_inliers(x, orc.plane_fit(x, s3, mode=1), 0.01) for s3 in samples)
+    # a degenerate sample (three times the same point) fits a NaN-free or NaN plane but never crashes
+    _ = orc.plane_fit(x, np.zeros(3, np.uint32), mode=1)
