@@ -151,6 +151,19 @@ float orc_icp_update(const float* dst_xyz, const float* dst_nrm, size_t nd, cons
  * f32 serial sum / n. */
 void orc_mean3(const float* xyz, size_t n, int mode, float mean[3]);
 
+/* ---- kmeans_oracle.c: KMeans<float,3> brute-force path (clustering/kmeans.hpp:67-194) ---- */
+size_t orc_kmeans_assign(const float* x, size_t n, const float* c, size_t k, int64_t* labels);
+size_t orc_kmeans(const float* x, size_t n, float* c, size_t k, size_t max_iter, float tol, int mode, int64_t* labels);
+
+/* ---- ransac_oracle.c: PlaneRANSACEstimator3f (model_estimation/ransac_base.hpp:64-131) ---- */
+void orc_sym_eig3(const double A[9], double w[3], double V[9]);
+void orc_plane_residuals(const float* pts, size_t n, const float plane[4], float* res);
+size_t orc_plane_count_inliers(const float* pts, size_t n, const float plane[4], float thresh);
+void orc_plane_fit(const float* pts, const uint32_t* idx, size_t m, int mode, float plane[4]);
+size_t orc_plane_ransac(const float* pts, size_t n, const uint32_t* samples, size_t max_iter, float thresh,
+                        size_t target_inliers, int re_estimate, int mode, float plane[4], float* residuals,
+                        uint32_t* inliers, size_t* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+// tests/cpp/test_model_estimation.cpp -- the C++ mirrors of PlaneRANSACEstimator3f and KMeans3f
+// (include/cilantro_hip/model_estimation.hpp) used the way examples/ransac_plane_estimator.cpp:32-41 and
+// examples/kmeans.cpp use cilantro, checked against the CPU oracle (linked as the CHECKER only).
+//   test_model_estimation                      : needs a GPU; exit 0 iff every check passes
+//   test_model_estimation --expect-no-device   : CPU box; exit 0 iff the calls fail loudly
+#include <cilantro_hip/model_estimation.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../oracle/icp_oracle.h"
+
+static uint64_t splitmix(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static float u01(uint64_t seed, uint64_t i) { return (float)(splitmix(seed, i) >> 40) * (1.0f / 16777216.0f); }
+
+int main(int argc, char** argv) {
+  const bool expect_no_device = argc > 1 && !std::strcmp(argv[1], "--expect-no-device");
+  using namespace cilantro_hip;
+  const size_t n = 100003;
+  std::vector<float> x(3 * n);
+  for (size_t i = 0; i < n; ++i) {
+    x[3 * i] = 2 * u01(1, 3 * i) - 1; x[3 * i + 1] = 2 * u01(1, 3 * i + 1) - 1; x[3 * i + 2] = 2 * u01(1, 3 * i + 2) - 1;
+    if (i % 5 < 3) x[3 * i + 2] = 0.3f * x[3 * i] - 0.2f * x[3 * i + 1] + 0.1f + 0.008f * (u01(2, i) - 0.5f);   // 60% on a plane
+  }
+  int failures = 0;
+  try {
+    const size_t max_iter = 60;
+    std::vector<uint32_t> samples(3 * max_iter);
+    for (size_t i = 0; i < samples.size(); ++i) samples[i] = (uint32_t)(splitmix(3, i) % n);
+    const ConstPointsView xv(x);
+    PlaneRANSACEstimator3f pe(xv);
+    pe.setMaxInlierResidual(0.01f).setTargetInlierCount((size_t)(0.59 * n)).setMaxNumberOfIterations(max_iter).setReEstimationStep(true);
+    pe.setSamples(samples);
+    const Hyperplane3f plane = pe.estimate().getModel();
+    if (expect_no_device) { std::printf("FAIL: estimate() succeeded without a device\n"); return 1; }
+    float po[4]; size_t ko = 0;
+    std::vector<float> ro(n); std::vector<uint32_t> io(n);
+    const size_t ito = orc_plane_ransac(x.data(), n, samples.data(), max_iter, 0.01f, (size_t)(0.59 * n), 1, ORC_MODE_MIXED, po, ro.data(), io.data(), &ko);
+    const float sgn = (plane.coeffs()[0] * po[0] + plane.coeffs()[1] * po[1] + plane.coeffs()[2] * po[2]) > 0 ? 1.0f : -1.0f;
+    float dmax = 0;
+    for (int d = 0; d < 4; ++d) dmax = std::fmax(dmax, std::fabs(plane.coeffs()[d] - sgn * po[d]));
+    std::vector<float> chk(n);
+    orc_plane_residuals(x.data(), n, plane.coeffs(), chk.data());
+    size_t bad = 0, k = 0;
+    const auto& inl = pe.getModelInliers();
+    for (size_t i = 0; i < n; ++i) {
+      bad += chk[i] != pe.getModelResiduals()[i];
+      if (chk[i] <= 0.01f) { bad += (k >= inl.size() || inl[k] != i); ++k; }
+    }
+    bad += k != inl.size();
+    std::printf("plane RANSAC: iters gpu=%zu oracle=%zu, inliers gpu=%zu oracle=%zu, |plane diff|=%.2e, residual/inlier mismatches=%zu, absDistance(p0)=%.4f\n",
+                pe.getNumberOfPerformedIterations(), ito, inl.size(), ko, dmax, bad, plane.absDistance(x.data()));
+    if (pe.getNumberOfPerformedIterations() != ito || bad || !(dmax <= 2e-6f) || !pe.targetInlierCountAchieved()) ++failures;
+    const Hyperplane3f all = pe.estimateModel();
+    float pa[4];
+    orc_plane_fit(x.data(), nullptr, n, ORC_MODE_MIXED, pa);
+    const float sg2 = (all.coeffs()[0] * pa[0] + all.coeffs()[1] * pa[1] + all.coeffs()[2] * pa[2]) > 0 ? 1.0f : -1.0f;
+    for (int d = 0; d < 4; ++d) if (!(std::fabs(all.coeffs()[d] - sg2 * pa[d]) <= 2e-6f)) ++failures;
+
+    // KMeans3f with explicit initial centroids (examples/kmeans.cpp uses a cluster count; that draws at random)
+    const size_t kc = 37;
+    std::vector<float> c0(x.begin(), x.begin() + 3 * kc), co(c0);
+    KMeans3f km(xv);
+    km.cluster(ConstPointsView(c0.data(), kc), 8, 0.0f);
+    std::vector<int64_t> lo(n, 0);
+    const size_t itk = orc_kmeans(x.data(), n, co.data(), kc, 8, 0.0f, ORC_MODE_MIXED, lo.data());
+    float cmax = 0; size_t ldiff = 0;
+    for (size_t i = 0; i < 3 * kc; ++i) cmax = std::fmax(cmax, std::fabs(km.getClusterCentroids()[i] - co[i]));
+    for (size_t i = 0; i < n; ++i) ldiff += km.getPointToClusterIndexMap()[i] != (size_t)lo[i];
+    std::printf("KMeans3f: iters gpu=%zu oracle=%zu, max centroid diff=%.2e, label mismatches=%zu, clusters=%zu\n",
+                km.getNumberOfPerformedIterations(), itk, cmax, ldiff, km.getClusterToPointIndicesMap().size());
+    if (km.getNumberOfPerformedIterations() != itk || !(cmax <= 1e-6f) || ldiff > 2) ++failures;
+    km.cluster(5, 3);
+    if (km.getNumberOfClusters() != 5) ++failures;
+  } catch (const std::runtime_error& e) {
+    if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }
+    std::printf("FAIL: %s\n", e.what());
+    return 1;
+  }
+  std::printf(failures ? "FAILED (%d)\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}
