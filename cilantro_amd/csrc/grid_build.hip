@@ -297,17 +297,47 @@ __global__ void k_tile_counts(const uint32_t* __restrict__ cube_start, uint32_t 
     counts[c] = (cube_start[c + 1] - cube_start[c] + (TILE_QUERIES - 1)) / TILE_QUERIES;
 }
 
-__global__ void k_emit_tiles(const uint32_t* __restrict__ cube_start, const uint32_t* __restrict__ tile_off, uint32_t ncubes, uint2* tiles) {
+// tile_center[t] = centre of the tile's cube mapped back to SOURCE space (Tinv = inverse of the sort transform):
+// with the common half-axes (tile_axes) that is the oriented box k_search_tiled pushes through the current transform
+__global__ void k_emit_tiles(const uint32_t* __restrict__ cube_start, const uint32_t* __restrict__ tile_off, uint32_t ncubes, GridDev g, Tf Tinv,
+                             uint2* tiles, float4* tile_center) {
+  constexpr uint32_t C = CUBE_EDGE;
+  const uint32_t cnx = ((uint32_t)g.nx + C - 1) / C, cny = ((uint32_t)g.ny + C - 1) / C;
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncubes; c += gridDim.x * blockDim.x) {
     const uint32_t b = cube_start[c], e = cube_start[c + 1];
+    if (b == e) continue;
+    const uint32_t bx = c % cnx, by = (c / cnx) % cny, bz = c / (cnx * cny);
+    const float hx = g.ox + ((float)(bx * C) + 0.5f * (float)C) * g.cell, hy = g.oy + ((float)(by * C) + 0.5f * (float)C) * g.cell,
+                hz = g.oz + ((float)(bz * C) + 0.5f * (float)C) * g.cell;
+    const float* m = Tinv.m;
+    const float4 ctr = make_float4(m[0] * hx + m[4] * hy + m[8] * hz + m[12], m[1] * hx + m[5] * hy + m[9] * hz + m[13],
+                                   m[2] * hx + m[6] * hy + m[10] * hz + m[14], 0.0f);
     uint32_t t = tile_off[c];
-    for (uint32_t q = b; q < e; q += TILE_QUERIES) tiles[t++] = make_uint2(q, min(q + TILE_QUERIES, e));
+    for (uint32_t q = b; q < e; q += TILE_QUERIES) { tiles[t] = make_uint2(q, min(q + TILE_QUERIES, e)); tile_center[t] = ctr; ++t; }
   }
 }
 
 hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out, hipStream_t s,
-                       uint2** d_tiles_out, uint32_t* ntiles_out) {
-  *d_tiles_out = nullptr; *ntiles_out = 0;
+                       uint2** d_tiles_out, float4** d_tile_center_out, float tile_axes_out[9], uint32_t* ntiles_out) {
+  *d_tiles_out = nullptr; *d_tile_center_out = nullptr; *ntiles_out = 0;
+  // inverse of the (affine) sort transform, in double; a singular linear part leaves a zero box (every query
+  // then takes the clean-up pass: slow, still exact)
+  Tf tinv;
+  {
+    const double a00 = T[0], a01 = T[4], a02 = T[8], a10 = T[1], a11 = T[5], a12 = T[9], a20 = T[2], a21 = T[6], a22 = T[10];
+    const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+    const double id = (det != 0.0 && std::isfinite(det)) ? 1.0 / det : 0.0;
+    const double i00 = (a11 * a22 - a12 * a21) * id, i01 = (a02 * a21 - a01 * a22) * id, i02 = (a01 * a12 - a02 * a11) * id;
+    const double i10 = (a12 * a20 - a10 * a22) * id, i11 = (a00 * a22 - a02 * a20) * id, i12 = (a02 * a10 - a00 * a12) * id;
+    const double i20 = (a10 * a21 - a11 * a20) * id, i21 = (a01 * a20 - a00 * a21) * id, i22 = (a00 * a11 - a01 * a10) * id;
+    const double t0 = T[12], t1 = T[13], t2 = T[14];
+    const double inv[16] = {i00, i10, i20, 0, i01, i11, i21, 0, i02, i12, i22, 0,
+                            -(i00 * t0 + i01 * t1 + i02 * t2), -(i10 * t0 + i11 * t1 + i12 * t2), -(i20 * t0 + i21 * t1 + i22 * t2), 1};
+    for (int i = 0; i < 16; ++i) tinv.m[i] = (float)inv[i];
+    const double h = 0.5 * (double)CUBE_EDGE * (double)g.cell;
+    const double li[9] = {i00, i01, i02, i10, i11, i12, i20, i21, i22};
+    for (int i = 0; i < 9; ++i) tile_axes_out[i] = (float)(h * li[i]);
+  }
   if (n == 0) return hipSuccess;
   uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr;
   HIP_TRY(hipMalloc(&k_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&k_out, (size_t)n * 4));
@@ -322,6 +352,7 @@ hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const f
   uint32_t *cube_start = nullptr, *tcount = nullptr, *toff = nullptr;
   void* tmp = nullptr;
   uint2* tiles = nullptr;
+  float4* centers = nullptr;
   do {
     if (e != hipSuccess) break;
     hipLaunchKernelGGL(k_gather, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, (const float*)nullptr, v_out, n, d_out, (float4*)nullptr);
@@ -341,16 +372,21 @@ hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const f
     if ((e = hipMemcpyAsync(&ntiles, toff + ncubes, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
     if ((e = hipMalloc(&tiles, ((size_t)ntiles + 1) * sizeof(uint2))) != hipSuccess) break;
-    hipLaunchKernelGGL(k_emit_tiles, dim3(grid_blocks(ncubes)), dim3(256), 0, s, cube_start, toff, ncubes, tiles);
+    if ((e = hipMalloc(&centers, ((size_t)ntiles + 1) * sizeof(float4))) != hipSuccess) break;
+    hipLaunchKernelGGL(k_emit_tiles, dim3(grid_blocks(ncubes)), dim3(256), 0, s, cube_start, toff, ncubes, g, tinv, tiles, centers);
     e = hipStreamSynchronize(s);
-    *d_tiles_out = tiles; *ntiles_out = ntiles;
+    *d_tiles_out = tiles; *d_tile_center_out = centers; *ntiles_out = ntiles;
   } while (0);
   (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in); (void)hipFree(v_out);
   if (cube_start) (void)hipFree(cube_start);
   if (tcount) (void)hipFree(tcount);
   if (toff) (void)hipFree(toff);
   if (tmp) (void)hipFree(tmp);
-  if (e != hipSuccess && tiles) { (void)hipFree(tiles); *d_tiles_out = nullptr; *ntiles_out = 0; }
+  if (e != hipSuccess) {
+    if (tiles) (void)hipFree(tiles);
+    if (centers) (void)hipFree(centers);
+    *d_tiles_out = nullptr; *d_tile_center_out = nullptr; *ntiles_out = 0;
+  }
   return e;
 }
 

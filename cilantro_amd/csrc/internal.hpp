@@ -60,6 +60,7 @@ struct IterArgs {
   uint32_t ns;
   float max_sq;            // engine max_distance_ (squared)
   float dst_mean[3];
+  float tile_axes[9];      // half-axes of a tile cube in SOURCE space (row-major 3x3: component j of axis k), see k_search_tiled
   const IcpState* state;   // T, smt, inner tform, done flags
   uint32_t* nn_pos;        // [ns] (sorted-source order) sorted-target position or NONE
   float* nn_d2;            // [ns]
@@ -86,7 +87,10 @@ struct SolveArgs {
 // kernels.hip
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
 void launch_solve(const SolveArgs& a, hipStream_t s);
-void launch_search_tiled(const IterArgs& a, const uint2* tiles, uint32_t ntiles, hipStream_t s);
+void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, uint32_t ntiles, hipStream_t s);
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_search_tiled -> stderr
+#endif
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 32 * SUMS_MAX;
@@ -126,7 +130,7 @@ void free_grid(GridDev& g);
 // Also emits the tile table of the LDS-tiled search kernel: tiles[t] = [begin,end) of <= TILE_QUERIES sorted
 // queries that share one 4x4x4-cell cube (caller frees *d_tiles_out with hipFree).
 hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out,
-                       hipStream_t s, uint2** d_tiles_out, uint32_t* ntiles_out);
+                       hipStream_t s, uint2** d_tiles_out, float4** d_tile_center_out, float tile_axes_out[9], uint32_t* ntiles_out);
 hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3]);
 
 }  // namespace cilhip

@@ -23,13 +23,18 @@
 //     shuffle tree + LDS + fixed-order cross-block reduction => bitwise run-to-run reproducible
 //     (the reference's OpenMP reduction is not).
 #include "internal.hpp"
+#include <cstdio>
+#include <cstring>
 
 namespace cilhip {
 
 // LDS-tiled search geometry: cube of 2^L cells per axis, <= TILE_QUERIES queries per tile,
 // TILE_THREADS threads per workgroup.  (4^3 cells / 256 queries / 256 threads, or 8^3 / 2048 / 1024.)
 #ifndef CILHIP_TILE_CAP
-#define CILHIP_TILE_CAP 3712
+#define CILHIP_TILE_CAP 3840
+#endif
+#ifndef CILHIP_TILE_MAXE
+#define CILHIP_TILE_MAXE 4352
 #endif
 
 #ifndef CILHIP_CAND
@@ -284,25 +289,34 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
 //
 // Profiling the per-lane global-memory search showed it bound by the texture-address / L1 path
 // (TA busy ~70 %: every candidate is a per-lane 16-byte gather at 64 B/clk/CU, and neighbouring lanes
-// fetch the same points again and again).  Here one workgroup owns one TILE = up to 256 queries whose
-// home cells share a 4x4x4-cell cube (the source is sorted cube-major).  Per tile:
-//   1. every lane transforms its query and finds its CURRENT cell; a block reduction gives the tile's
-//      cell bounding box, grown by one cell and clipped to the grid = the REGION (normally 6x6x6 cells);
-//   2. the region's cell table (rows x (RX+1) cell_start values) and then its points (each row of the
-//      region is one contiguous run of the sorted target array) are staged into LDS with full-width
-//      coalesced loads -- every target point is fetched once per tile instead of once per lane;
-//   3. every lane runs the same exact search as nn_search, but cell ranges and candidates come from LDS
-//      (ds_read_b128, ~100-cycle latency, 128 B/clk/CU) and the culling bound is re-checked per row
-//      against the current best.
+// fetch the same points again and again).  Here one workgroup owns one TILE = up to TILE_QUERIES queries
+// whose sort-time cells share one cube of CUBE_EDGE^3 target-grid cells (the source is sorted cube-major).
+// Per tile:
+//   1. the REGION of target cells the tile can touch comes from the tile alone, with no pass over its
+//      queries: the cube is an oriented box in source space (centre per tile, half-axes common to all
+//      tiles); its image under the current transform is bounded by centre' +- |R A| 1, converted to
+//      cells, grown by one cell and clipped to the grid (14^3 cells when the transform has not moved
+//      since the sort).  Queries whose current cell lies outside that box (f32 rounding, clamped
+//      out-of-grid queries that moved in) are handed to the clean-up pass, so the box only has to be
+//      right for performance, never for correctness;
+//   2. the region's cell table (rows x (RX+1) cell_start values) is fetched into LDS -- its loads and the
+//      query loads are issued together at kernel start, nothing waits on the queries; one wave turns the
+//      row lengths into LDS offsets while the others transform their queries and pick their octant
+//      blocks; then all waves copy the rows into LDS with 16 lanes per row (each row of the region is
+//      ONE contiguous run of the sorted target array) -- every target point is fetched once per tile
+//      instead of once per lane;
+//   3. every lane searches out of LDS (ds_read_b128): octant-first in straight-line code, the full
+//      3x3x3 block with per-row culling for the lanes the octant does not prove.
 // Exactness is unchanged: lanes whose 3x3x3 block does not prove the result (sparse data, large
-// radius), queries outside the grid, and whole tiles whose region exceeds the LDS budget (queries that
-// drifted far from their sort-time cells) fall back to the global-memory search.
+// radius), queries outside the grid or outside the tile's box, and whole tiles whose region exceeds the
+// LDS budget (queries that drifted far from their sort-time cells) fall back to the global-memory search.
 constexpr int TILE_CAP = CILHIP_TILE_CAP;                    // staged target points per tile (16 B each)
-constexpr int TILE_RMAX = CUBE_EDGE + 3;                     // region edge: cube + halo + one cell of drift
-constexpr int TILE_MAXROWS = TILE_RMAX * TILE_RMAX;          // RY*RZ
-constexpr int TILE_MAXW = TILE_RMAX + 2;                     // RX
-constexpr int TILE_MAXE = TILE_MAXROWS * (TILE_MAXW + 1);
+constexpr int TILE_MAXSPAN = CUBE_EDGE + 6;                  // region rows per axis (y, z) the row tables hold
+constexpr int TILE_MAXROWS = TILE_MAXSPAN * TILE_MAXSPAN;    // RY*RZ
+constexpr int TILE_MAXE = CILHIP_TILE_MAXE;                  // entries of the staged cell table: rows * (RX + 1)
 constexpr int TILE_QPT = TILE_QUERIES / TILE_THREADS;        // queries per thread
+static_assert(TILE_MAXROWS <= TILE_THREADS, "one thread per region row fetches the row extent");
+static_assert(TILE_MAXROWS <= 64 * 8, "the row scan holds at most 8 rows per lane of one wave");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -349,57 +363,63 @@ __device__ __forceinline__ void scan_lds4(const float4* lpts, uint32_t beg, uint
 
 struct TileLds {
   const float4* lpts;
-  const uint32_t* lcs;
-  const uint32_t* rowbase;
-  const uint32_t* rowdelta;
+  const uint32_t* lcs;        // [rows][W1] cell_start values (GLOBAL sorted positions) of the region's cells, +1 end column
+  const uint32_t* rowbase;    // [rows+1] LDS index of the first staged point of each region row
+  const uint32_t* rowdelta;   // [rows]   global sorted position - LDS index, per row (mod 2^32)
   int lox, loy, loz, RY, W1, rows;
 };
 
-// Octant-first search (the common case, uniform control flow across the wave): the 2x2x2 block of cells
-// on the side of q's own cell that q leans towards contains every target point closer than the distance
-// from q to that block's faces, which is at least half a cell.  All lanes scan exactly 4 runs (2 cells
-// each) -- no per-lane culling decisions, so the wave stays in lock-step.  Returns true (result proven
-// exact) iff the best found is strictly nearer than any point outside the block can be.
-__device__ __forceinline__ bool search_octant_in_tile(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
-                                                      int cx, int cy, int cz, float max_sq, NN& best) {
-  const f32x2 qxy = {qx, qy};
-  unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
-  uint32_t bl = NONE_U32;
+#ifndef CILHIP_OCT_CAND
+#define CILHIP_OCT_CAND 4   /* candidates per run evaluated unconditionally (a run = 2 cells, ~2 points at the default occupancy) */
+#endif
+#ifndef CILHIP_OCT_EXTRA
+#define CILHIP_OCT_EXTRA 1  /* further quads taken in straight-line code before the overflow loop */
+#endif
+constexpr int OCT_CAND = CILHIP_OCT_CAND;
+constexpr int OCT_EXTRA = CILHIP_OCT_EXTRA;
+
+__device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 qxy, float qz, uint32_t code,
+                                                   unsigned long long& bk, uint32_t& sel) {
+  const f32x2 pxy = {p.x, p.y};
+  const f32x2 d = qxy - pxy;
+  const f32x2 m = d * d;
+  const float dz = __fsub_rn(qz, p.z);
+  const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
+  const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.w);
+  const bool lt = k < bk;
+  bk = lt ? k : bk;
+  sel = lt ? code : sel;      // code is a compile-time constant: no address arithmetic per candidate
+}
+
+// What a lane keeps of one query between its preparation (while the target points are still in flight) and the search.
+struct OctQuery {
+  float qx, qy, qz;
+  float bound;   // distance from q to the nearest face of the octant block that has grid cells behind it (INF: none)
+  int eb00;      // cell-table index of the first cell of run 0 (runs 1..3: + W1, + RY*W1, + (RY+1)*W1)
+  int info;      // bits 0-3: run k lies inside the grid; bit 4: the run is two cells wide; bits 8..: region row of run 0
+};
+
+// Octant-first search (the common case): the 2x2x2 block of cells on the side of q's own cell that q
+// leans towards contains every target point closer than the distance from q to that block's faces, which
+// is at least half a cell.  The block is 4 runs of the sorted target array (2 x-adjacent cells each).
+// octant_prepare() only needs the query; octant_search() runs out of LDS in STRAIGHT-LINE code: every lane
+// evaluates exactly OCT_CAND unclamped candidates per run (reading past a short run only evaluates further
+// real target points or the far-away pad records -- never wrong), no per-lane loop or branch, so the wave
+// executes each instruction once with all lanes busy; the rare longer runs go through one short flattened
+// overflow loop.  The winner is tracked as a small constant (run, slot) code and turned into an LDS index once.
+__device__ __forceinline__ void octant_prepare(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                               int lox, int loy, int loz, int RY, int W1, OctQuery& o) {
+  o.qx = qx; o.qy = qy; o.qz = qz;
   const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
   const float half = 0.5f * g.cell;
   const int ox = (qx - xl >= half) ? 0 : -1, oy = (qy - yl >= half) ? 0 : -1, oz = (qz - zl >= half) ? 0 : -1;
   // cells of the block along x, clipped to the grid (the own cell is always inside)
   const int xa = max(cx + ox, 0), xb = min(cx + ox + 1, g.nx - 1);
-  const int lx = cx - t.lox, ly = cy - t.loy, lz = cz - t.loz;
-  uint32_t rj[4], re[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int dz = oz + (k >> 1), dy = oy + (k & 1);
-    const int z = cz + dz, y = cy + dy;
-    const bool okr = (z >= 0) & (z < g.nz) & (y >= 0) & (y < g.ny);
-    const int row = (lz + dz) * t.RY + (ly + dy);
-    const int eb = row * t.W1 + lx;
-    rj[k] = okr ? t.lcs[eb + (xa - cx)] : 0u;
-    re[k] = okr ? t.lcs[eb + (xb - cx) + 1] : 0u;
-  }
-  // one flattened loop over the 4 runs
-  int k = 0;
-  uint32_t j = rj[0], e = re[0];
-  for (;;) {
-    if (j >= e) {
-      ++k;
-      if (k >= 4) break;
-      j = (k == 1) ? rj[1] : (k == 2) ? rj[2] : rj[3];
-      e = (k == 1) ? re[1] : (k == 2) ? re[2] : re[3];
-      continue;
-    }
-    const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
-    eval_candidate(p0, qxy, qz, j, bk, bl);
-    eval_candidate(p1, qxy, qz, j + 1, bk, bl);
-    eval_candidate(p2, qxy, qz, j + 2, bk, bl);
-    eval_candidate(p3, qxy, qz, j + 3, bk, bl);
-    j += 4;
-  }
+  const int y0 = cy + oy, z0 = cz + oz;
+  const int row00 = (z0 - loz) * RY + (y0 - loy);
+  o.eb00 = row00 * W1 + (xa - lox);
+  const uint32_t vz0 = z0 >= 0, vz1 = z0 + 1 < g.nz, vy0 = y0 >= 0, vy1 = y0 + 1 < g.ny;
+  o.info = (int)((vz0 & vy0) | ((vz0 & vy1) << 1) | ((vz1 & vy0) << 2) | ((vz1 & vy1) << 3) | ((uint32_t)(xb > xa) << 4)) | (row00 << 8);
   // distance from q to the faces of the block that still have grid cells beyond them
   float b = INFINITY;
   {
@@ -417,24 +437,110 @@ __device__ __forceinline__ bool search_octant_in_tile(const GridDev& g, const Ti
     if (cz + oz > 0) b = fminf(b, qz - lo);
     if (cz + oz + 2 < g.nz) b = fminf(b, hi - qz);
   }
+  o.bound = b;
+}
+
+// Returns true (result proven exact) iff the best found is strictly nearer than any point outside the block can be.
+__device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best) {
+  const f32x2 qxy = {o.qx, o.qy};
+  const float qz = o.qz;
+  unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  uint32_t rj[4], re[4];
+  const int row00 = o.info >> 8;
+  const uint32_t vmask = (uint32_t)o.info & 15u;
+  const int wid = 1 + ((o.info >> 4) & 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = row00 + (k >> 1) * t.RY + (k & 1);
+    const int eb = o.eb00 + ((k >> 1) * t.RY + (k & 1)) * t.W1;
+    const bool okr = (vmask >> k) & 1u;
+    const uint32_t dl = okr ? t.rowdelta[row] : 0u;
+    rj[k] = (okr ? t.lcs[eb] : 0u) - dl;
+    re[k] = (okr ? t.lcs[eb + wid] : 0u) - dl;
+  }
+  uint32_t sel = 0xFFu;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 p[OCT_CAND];
+#pragma unroll
+    for (int c = 0; c < OCT_CAND; ++c) p[c] = t.lpts[rj[k] + c];
+#pragma unroll
+    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel);
+  }
+  uint32_t bl = NONE_U32;
+  if (sel != 0xFFu) {
+    const uint32_t k = sel / OCT_CAND;
+    bl = (k == 0 ? rj[0] : k == 1 ? rj[1] : k == 2 ? rj[2] : rj[3]) + (sel - k * OCT_CAND);
+  }
+  // Runs longer than OCT_CAND.  A flattened per-lane loop costs the whole wave its longest lane (and every
+  // transition between runs is a wave-wide iteration), and some lane of almost every wave has one long run.
+  // So: OCT_EXTRA more quads in straight-line code -- every lane takes the first run it has not finished
+  // (or harmlessly re-reads its first candidates) -- and only then the loop, which few waves enter.
+  uint32_t nj[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nj[k] = rj[k] + OCT_CAND;
+#ifndef CILHIP_EXP_NO_OVERFLOW
+#pragma unroll
+  for (int x = 0; x < OCT_EXTRA; ++x) {
+    const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
+    const uint32_t jx = c0 ? nj[0] : c1 ? nj[1] : c2 ? nj[2] : c3 ? nj[3] : rj[0];
+    nj[0] += c0 ? 4u : 0u;
+    nj[1] += (!c0 & c1) ? 4u : 0u;
+    nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
+    nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
+    const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
+    eval_candidate(p0, qxy, qz, jx, bk, bl);
+    eval_candidate(p1, qxy, qz, jx + 1, bk, bl);
+    eval_candidate(p2, qxy, qz, jx + 2, bk, bl);
+    eval_candidate(p3, qxy, qz, jx + 3, bk, bl);
+  }
+  for (;;) {
+    const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
+    if (!(c0 | c1 | c2 | c3)) break;
+    const uint32_t jx = c0 ? nj[0] : c1 ? nj[1] : c2 ? nj[2] : nj[3];
+    nj[0] += c0 ? 4u : 0u;
+    nj[1] += (!c0 & c1) ? 4u : 0u;
+    nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
+    nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
+    const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
+    eval_candidate(p0, qxy, qz, jx, bk, bl);
+    eval_candidate(p1, qxy, qz, jx + 1, bk, bl);
+    eval_candidate(p2, qxy, qz, jx + 2, bk, bl);
+    eval_candidate(p3, qxy, qz, jx + 3, bk, bl);
+  }
+#endif
   best.key = bk;
-  best.pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
-  if (b == INFINITY) return true;                    // the block covers the whole grid
-  b -= g.margin;
+  // LDS index -> global position: the winner normally lies in the row of its run (one table read); an
+  // over-read winner past the end of that row (or one picked up through a clipped run) takes the binary search
+  uint32_t pos = NONE_U32;
+  if (bl != NONE_U32) {
+    const uint32_t vm = vmask;
+    const int k = (int)(((vm >> 1) & 1u) & (uint32_t)(bl >= rj[1])) + (int)(((vm >> 2) & 1u) & (uint32_t)(bl >= rj[2])) +
+                  (int)(((vm >> 3) & 1u) & (uint32_t)(bl >= rj[3]));
+    const int row = row00 + (k >> 1) * t.RY + (k & 1);
+    const bool rok = (row >= 0) & (row < t.rows);
+    const uint32_t lo = rok ? t.rowbase[row] : 1u, hi = rok ? t.rowbase[row + 1] : 0u;
+    if (bl >= lo && bl < hi) pos = bl + t.rowdelta[row];
+    else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
+  }
+  best.pos = pos;
+  if (o.bound == INFINITY) return true;                    // the block covers the whole grid
+  const float b = o.bound - g.margin;
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
 
-// Exact search of one in-grid query out of the LDS tile.  Returns false if the 3x3x3 block does not
-// prove the result (the query then goes to the clean-up pass).
+// Exact search of one in-grid query out of the LDS tile: own cell, then the 3x3x3 block with per-row
+// culling (the lanes the octant block did not prove).  Returns false if the 3x3x3 block does not prove
+// the result (the query then goes to the clean-up pass).
 __device__ __forceinline__ bool search_in_tile(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
                                                int cx, int cy, int cz, float max_sq, NN& best) {
   const f32x2 qxy = {qx, qy};
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
   uint32_t bl = NONE_U32;                                    // LDS index of the best
-  const int lx = cx - t.lox, ly = cy - t.loy, lz = cz - t.loz;
-  const int row0 = lz * t.RY + ly;
-  const int e0i = row0 * t.W1 + lx;
-  const uint32_t b0 = t.lcs[e0i], e0 = t.lcs[e0i + 1];
+  const int row0 = (cz - t.loz) * t.RY + (cy - t.loy);       // region row of the own cell
+  const int e0i = row0 * t.W1 + (cx - t.lox);                // its entry in the cell table
+  const uint32_t d0 = t.rowdelta[row0];
+  const uint32_t b0 = t.lcs[e0i] - d0, e0 = t.lcs[e0i + 1] - d0;
   scan_lds4(t.lpts, b0, e0, qxy, qz, bk, bl);
   const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
   const float gmx = fmaxf(qx - xl - g.margin, 0.0f), gpx = fmaxf(xl + g.cell - qx - g.margin, 0.0f);
@@ -480,10 +586,11 @@ __device__ __forceinline__ bool search_in_tile(const GridDev& g, const TileLds& 
         const float gyz2 = (dz == 0 ? az2m : dz == 2 ? az2p : 0.0f) + (dy == 0 ? ay2m : dy == 2 ? ay2p : 0.0f);
         if (gyz2 * KSHRINK > __uint_as_float((uint32_t)(bk >> 32))) continue;   // culled by a newer best
         const int row = row0 + (dz - 1) * t.RY + (dy - 1);
-        const int eb = row * t.W1 + lx;
-        if (it == 4) { j = t.lcs[eb - 1]; e = b0; }                 // own row, x-1 side
-        else if (it == 27) { j = e0; e = t.lcs[eb + 2]; }            // own row, x+1 side
-        else { j = t.lcs[eb - ((mask >> (9 + r)) & 1u)]; e = t.lcs[eb + 1 + ((mask >> (18 + r)) & 1u)]; }
+        const int eb = e0i + ((dz - 1) * t.RY + (dy - 1)) * t.W1;   // own-cell column of that row
+        const uint32_t dl = t.rowdelta[row];
+        if (it == 4) { j = t.lcs[eb - 1] - dl; e = b0; }                 // own row, x-1 side
+        else if (it == 27) { j = e0; e = t.lcs[eb + 2] - dl; }            // own row, x+1 side
+        else { j = t.lcs[eb - ((mask >> (9 + r)) & 1u)] - dl; e = t.lcs[eb + 1 + ((mask >> (18 + r)) & 1u)] - dl; }
         continue;
       }
       const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
@@ -511,7 +618,30 @@ __device__ __forceinline__ bool search_in_tile(const GridDev& g, const TileLds& 
   return proven;
 }
 
-__global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles, uint32_t ntiles) {
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+__device__ unsigned long long g_phase_clk[8];
+#define PHASE_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_clk[k], now_ - tprev_); tprev_ = now_; } } while (0)
+void debug_dump_phase_clocks() {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof h) != hipSuccess) return;
+  unsigned long long tot = 0;
+  for (int k = 0; k < 8; ++k) tot += h[k];
+  fprintf(stderr, "[phase clocks, 100 MHz ticks summed over blocks] queries+extents=%llu scan=%llu stage=%llu search=%llu total=%llu\n", h[0], h[1], h[2], h[3], tot);
+  memset(h, 0, sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), h, sizeof h);
+}
+#else
+#define PHASE_CLK(k)
+#endif
+#ifdef CILHIP_EXP_STOP_AFTER   /* dev experiment: leave the kernel after phase k (counter deltas per phase) */
+#define STOP_SINK 0.0f
+#define STOP_AFTER(k) do { if ((k) == CILHIP_EXP_STOP_AFTER) { if ((k) > 0 && tile.x + threadIdx.x < tile.y) a.nn_d2[tile.x + threadIdx.x] = STOP_SINK; return; } } while (0)
+#else
+#define STOP_AFTER(k)
+#endif
+
+__global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
+                                                                  const float4* __restrict__ tile_center, uint32_t ntiles) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
   // XCD-aware tile order: block b runs on XCD b%8 -> each XCD gets one contiguous eighth of the tiles
@@ -519,12 +649,14 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
   const uint32_t vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per || vb >= ntiles) return;
 
-  __shared__ __attribute__((aligned(16))) unsigned char raw[(TILE_CAP + 4) * sizeof(float4)];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[(TILE_CAP + 8) * sizeof(float4)];
   __shared__ uint32_t lcs[TILE_MAXE];
   __shared__ uint32_t rowbase[TILE_MAXROWS + 1];
   __shared__ uint32_t rowdelta[TILE_MAXROWS];
-  __shared__ int box[6];
   float4* lpts = reinterpret_cast<float4*>(raw);
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+  unsigned long long tprev_ = wall_clock64();
+#endif
 
   const GridDev& g = a.grid;
   const uint2 tile = tiles[vb];
@@ -532,125 +664,211 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
 
-  float qx[TILE_QPT], qy[TILE_QPT], qz[TILE_QPT];
-  int cx[TILE_QPT], cy[TILE_QPT], cz[TILE_QPT];
-  bool active[TILE_QPT], inside[TILE_QPT];
-  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+  // the lane's queries: issue the loads first, they fly while the region's cell table is fetched
+  float4 s4[TILE_QPT];
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
     const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
-    active[u] = i < tile.y;
-    inside[u] = false;
-    qx[u] = qy[u] = qz[u] = 0.f; cx[u] = cy[u] = cz[u] = 0;
-    if (active[u]) {
-      const float4 s4 = a.src[i];
-      transform_point(T, s4.x, s4.y, s4.z, qx[u], qy[u], qz[u]);
-      const float BIG = 1.0e9f;
-      cx[u] = (int)floorf(fminf(fmaxf((qx[u] - g.ox) * g.inv_cell, -BIG), BIG));
-      cy[u] = (int)floorf(fminf(fmaxf((qy[u] - g.oy) * g.inv_cell, -BIG), BIG));
-      cz[u] = (int)floorf(fminf(fmaxf((qz[u] - g.oz) * g.inv_cell, -BIG), BIG));
-      inside[u] = (cx[u] >= 0) & (cx[u] < g.nx) & (cy[u] >= 0) & (cy[u] < g.ny) & (cz[u] >= 0) & (cz[u] < g.nz);
-      if (inside[u]) {
-        mn[0] = min(mn[0], cx[u]); mn[1] = min(mn[1], cy[u]); mn[2] = min(mn[2], cz[u]);
-        mx[0] = max(mx[0], cx[u]); mx[1] = max(mx[1], cy[u]); mx[2] = max(mx[2], cz[u]);
-      }
+    s4[u] = i < tile.y ? a.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- 1. region of the tile: image of its cube (oriented box in source space) under T, in cells ----
+  int bx0, bx1, by0, by1, bz0, bz1;
+  {
+    const float4 c4 = tile_center[vb];
+    float ccx, ccy, ccz;
+    transform_point(T, c4.x, c4.y, c4.z, ccx, ccy, ccz);
+    float ext[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float e = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        e += fabsf(T[i] * a.tile_axes[k] + T[i + 4] * a.tile_axes[3 + k] + T[i + 8] * a.tile_axes[6 + k]);   // |(R A)_ik|
+      ext[i] = e;
     }
+    const float SHR = 1.0e-3f, BIG = 1.0e9f;   // the cube is half-open: shrink by 1e-3 cell so that an unmoved cube maps to itself
+    bx0 = (int)floorf(fminf(fmaxf((ccx - ext[0] - g.ox) * g.inv_cell + SHR, -BIG), BIG));
+    bx1 = (int)floorf(fminf(fmaxf((ccx + ext[0] - g.ox) * g.inv_cell - SHR, -BIG), BIG));
+    by0 = (int)floorf(fminf(fmaxf((ccy - ext[1] - g.oy) * g.inv_cell + SHR, -BIG), BIG));
+    by1 = (int)floorf(fminf(fmaxf((ccy + ext[1] - g.oy) * g.inv_cell - SHR, -BIG), BIG));
+    bz0 = (int)floorf(fminf(fmaxf((ccz - ext[2] - g.oz) * g.inv_cell + SHR, -BIG), BIG));
+    bz1 = (int)floorf(fminf(fmaxf((ccz + ext[2] - g.oz) * g.inv_cell - SHR, -BIG), BIG));
   }
-  // ---- 1. bounding box of the current cells of the tile's in-grid queries ----
-  if (threadIdx.x < 3) { box[threadIdx.x] = 0x7fffffff; box[3 + threadIdx.x] = -1; }
-  __syncthreads();
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], off, 64)); }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { atomicMin(&box[k], mn[k]); atomicMax(&box[3 + k], mx[k]); }
-  }
-  __syncthreads();
-  const bool any_inside = box[3] >= 0;
-  const int lox = max(box[0] - 1, 0), loy = max(box[1] - 1, 0), loz = max(box[2] - 1, 0);
-  const int hix = min(box[3] + 1, g.nx - 1), hiy = min(box[4] + 1, g.ny - 1), hiz = min(box[5] + 1, g.nz - 1);
+  const int lox = max(bx0 - 1, 0), loy = max(by0 - 1, 0), loz = max(bz0 - 1, 0);
+  const int hix = min(bx1 + 1, g.nx - 1), hiy = min(by1 + 1, g.ny - 1), hiz = min(bz1 + 1, g.nz - 1);
   const int RX = hix - lox + 1, RY = hiy - loy + 1, RZ = hiz - loz + 1;
-  const int rows = RY * RZ;
-  const int W1 = RX + 1;
-  bool ok = any_inside && RX <= TILE_MAXW && RY <= TILE_RMAX + 2 && RZ <= TILE_RMAX + 2 && rows <= TILE_MAXROWS;   // block-uniform
-  uint32_t P = 0;
-  if (ok) {
-    // ---- 2a. cell table of the region (global cell_start values) ----
-    const int E = rows * W1;
-    for (int e = threadIdx.x; e < E; e += TILE_THREADS) {
-      const int r = e / W1, x = e - r * W1;
-      const int z = loz + r / RY, y = loy + r % RY;
-      lcs[e] = g.cell_start[((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx + (uint32_t)(lox + x)];
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive prefix over the row lengths (one wave, 64 rows per pass)
-      uint32_t carry = 0;
-      for (int base = 0; base < rows; base += 64) {
-        const int r = base + threadIdx.x;
-        const uint32_t first = r < rows ? lcs[r * W1] : 0u;
-        const uint32_t len = r < rows ? lcs[r * W1 + RX] - first : 0u;
-        uint32_t incl = len;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t tt = __shfl_up(incl, off, 64);
-          if ((int)threadIdx.x >= off) incl += tt;
-        }
-        if (r < rows) {
-          rowbase[r + 1] = carry + incl;
-          rowdelta[r] = first - (carry + incl - len);  // global position - LDS index (mod 2^32)
-        }
-        carry += __shfl(incl, 63, 64);
-      }
-      if (threadIdx.x == 0) rowbase[0] = 0;
-    }
-    __syncthreads();
-    P = rowbase[rows];
-    ok = P <= (uint32_t)TILE_CAP;
-  }
-  if (ok) {
-    // ---- 2b. table -> LDS indices; stage the points (flat index, row found by binary search) ----
-    const int E = rows * W1;
-    for (int e = threadIdx.x; e < E; e += TILE_THREADS) lcs[e] -= rowdelta[e / W1];
-    for (uint32_t f = threadIdx.x; f < P; f += TILE_THREADS) {
-      int lo = 0, hi = rows;               // largest r with rowbase[r] <= f
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (rowbase[mid] <= f) lo = mid; else hi = mid;
-      }
-      lpts[f] = g.pts[f + rowdelta[lo]];
-    }
-    if (threadIdx.x < 4) lpts[P + threadIdx.x] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __uint_as_float(NONE_U32));  // pad: d2 = inf
-    __syncthreads();
-  }
+  const int rows = RY * RZ, W1 = RX + 1, E = rows * W1;
+  bool ok = (RX >= 1) & (RY >= 1) & (RZ >= 1) & (RY <= TILE_MAXSPAN) & (RZ <= TILE_MAXSPAN) & (E <= TILE_MAXE);   // block-uniform
   if (!ok) {
-    // whole-tile fallback (region does not fit LDS: the queries drifted far from their sort-time cells, or
-    // the data is much denser here): the clean-up pass searches this tile's queries in their sorted order
+    // whole-tile fallback (the cube's image is outside the grid or too large for the LDS budget: the transform
+    // moved far from the sort-time one): the clean-up pass searches this tile's queries in their sorted order
     if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
     return;
   }
-  // ---- 3. per-lane exact search out of LDS (or hand-off to the clean-up pass) ----
-  TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
-#ifdef CILHIP_EXP_DOUBLE_SEARCH
-  for (int rep = 0; rep < 2; ++rep)   // experiment: run phase 3 twice to measure its share of the kernel time
-#endif
+
+  // ---- 2a. cell table of the region: rows x (RX+1) cell_start values, flat over the block.  Buffer loads:
+  //          32-bit offsets (one shift per address) and out-of-range lanes simply read 0 ----
+  const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)g.cell_start, 0, ((uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz + 1u) * 4u, 0x00020000);
+  {
+    const uint32_t inv_w1 = ((1u << 20) + (uint32_t)W1 - 1u) / (uint32_t)W1;   // e / W1 == (e * inv_w1) >> 20 for e < 2^20 / W1
+    const uint32_t inv_ry = (65536u + (uint32_t)RY - 1u) / (uint32_t)RY;       // r / RY == (r * inv_ry) >> 16 for r < 3855
+    constexpr int TRIPS = (TILE_MAXE + TILE_THREADS - 1) / TILE_THREADS;
+    const uint32_t rowstride = (uint32_t)g.nx, slab = (uint32_t)g.ny * (uint32_t)g.nx;
+    const uint32_t gbase = ((uint32_t)loz * (uint32_t)g.ny + (uint32_t)loy) * (uint32_t)g.nx + (uint32_t)lox;
+    uint32_t v[TRIPS];
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      if (k * TILE_THREADS < E) {   // block-uniform
+        const uint32_t e = (uint32_t)k * TILE_THREADS + threadIdx.x;
+        const uint32_t r = (e * inv_w1) >> 20;
+        const uint32_t x = e - r * (uint32_t)W1;
+        const uint32_t zr = (r * inv_ry) >> 16;
+        const uint32_t gi = gbase + zr * slab + (r - zr * (uint32_t)RY) * rowstride + x;
+        v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_cs, e < (uint32_t)E ? gi * 4u : 0xFFFFFFFFu, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      if (k * TILE_THREADS < E) {
+        const uint32_t e = (uint32_t)k * TILE_THREADS + threadIdx.x;
+        if (e < (uint32_t)E) lcs[e] = v[k];
+      }
+    }
+  }
+  __syncthreads();
+  PHASE_CLK(0);
+  STOP_AFTER(0);
+
+  // ---- 2b. row lengths -> LDS offsets (one wave, each lane a block of consecutive rows) ----
+  if (threadIdx.x < 64) {
+    const int K = (rows + 63) >> 6;              // rows per lane, <= 8
+    const int r0 = (int)threadIdx.x * K;
+    uint32_t len[8], fst[8], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = r0 + k;
+      const bool v = (k < K) & (r < rows);
+      fst[k] = v ? lcs[r * W1] : 0u;
+      len[k] = v ? lcs[r * W1 + RX] - fst[k] : 0u;
+      tot += len[k];
+    }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t tt = __shfl_up(incl, off, 64);
+      if ((int)threadIdx.x >= off) incl += tt;
+    }
+    uint32_t run = incl - tot;                    // exclusive prefix of this lane's block
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = r0 + k;
+      if ((k < K) & (r < rows)) {
+        rowbase[r] = run;
+        rowdelta[r] = fst[k] - run;               // global position - LDS index (mod 2^32)
+        run += len[k];
+      }
+    }
+    if (threadIdx.x == 63) rowbase[rows] = incl;
+  }
+
+  // ---- 2c. (all waves, overlapping the scan) the lane's queries: transform, current cell, octant block ----
+  OctQuery oq[TILE_QPT];
+  uint32_t flags = 0;   // per query u: bit u = active, bit 8+u = inside the grid, bit 16+u = inside the tile's box (fast path)
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
-    if (!active[u]) continue;
+    const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+    float qx, qy, qz;
+    transform_point(T, s4[u].x, s4[u].y, s4[u].z, qx, qy, qz);
+    const float BIG = 1.0e9f;
+    const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG));
+    const int cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG));
+    const int cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
+    const bool active = i < tile.y;
+    const bool inside = active & (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
+    const bool inbox = inside & (cx >= bx0) & (cx <= bx1) & (cy >= by0) & (cy <= by1) & (cz >= bz0) & (cz <= bz1);
+    flags |= (active ? (1u << u) : 0u) | (inside ? (1u << (8 + u)) : 0u) | (inbox ? (1u << (16 + u)) : 0u);
+    // (lanes outside the box get a harmless in-region stand-in so that the code below stays branch-free)
+    octant_prepare(g, qx, qy, qz, inbox ? cx : bx0 < 0 ? 0 : min(bx0, g.nx - 1), inbox ? cy : by0 < 0 ? 0 : min(by0, g.ny - 1),
+                   inbox ? cz : bz0 < 0 ? 0 : min(bz0, g.nz - 1), lox, loy, loz, RY, W1, oq[u]);
+  }
+  __syncthreads();
+#ifdef CILHIP_EXP_STOP_AFTER
+#undef STOP_SINK
+#define STOP_SINK (oq[0].qx + oq[0].bound + (float)oq[0].eb00 + (float)oq[0].info + oq[1].qy + oq[1].bound + (float)oq[1].eb00 + (float)oq[1].info + (float)flags + oq[0].qz + oq[1].qz + oq[0].qy + oq[1].qx)
+#endif
+  PHASE_CLK(1);
+  STOP_AFTER(1);
+  const uint32_t P = rowbase[rows];
+  if (P > (uint32_t)TILE_CAP) {   // block-uniform: the data is much denser here than the LDS budget assumes
+    if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
+    return;
+  }
+  // ---- 2d. stage the points: 16 lanes per row (every row is one contiguous run of the sorted target array),
+  //          four rows in flight per lane; buffer loads (32-bit offsets, idle lanes read out of range = nothing) ----
+  {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_pts = __builtin_amdgcn_make_buffer_rsrc((void*)g.pts, 0, g.n * 16u, 0x00020000);
+    const uint32_t o0 = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;
+    constexpr int GR = TILE_THREADS / 16;   // rows per batch step
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {   // points [0,16) of every row, then points [16,32)
+      u32x4 v[4];
+      uint32_t dst[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int r = grp + GR * m;
+        const bool rv = r < rows;
+        const uint32_t f = rv ? rowbase[r] : 0u, l = rv ? rowbase[r + 1] - f : 0u, d = rv ? rowdelta[r] : 0u;
+        const uint32_t o = o0 + 16u * (uint32_t)half;
+        const bool has = o < l;
+        dst[m] = has ? f + o : NONE_U32;
+        v[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_pts, has ? (f + o + d) * 16u : 0xFFFFFFFFu, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (dst[m] != NONE_U32) lpts[dst[m]] = make_float4(__uint_as_float(v[m].x), __uint_as_float(v[m].y), __uint_as_float(v[m].z), __uint_as_float(v[m].w));
+    }
+    // rare leftovers: rows longer than 32 points, rows beyond the four batches
+    for (int r = grp; r < rows; r += GR) {
+      const uint32_t f = rowbase[r], l = rowbase[r + 1] - f, d = rowdelta[r];
+      for (uint32_t o = o0 + (r < 4 * GR ? 32u : 0u); o < l; o += 16) lpts[f + o] = g.pts[f + o + d];
+    }
+    if (threadIdx.x < 8) lpts[P + threadIdx.x] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __uint_as_float(NONE_U32));  // pad: d2 = inf
+  }
+  __syncthreads();
+  PHASE_CLK(2);
+  STOP_AFTER(2);
+  // ---- 3. per-lane exact search out of LDS (or hand-off to the clean-up pass) ----
+  TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
+#pragma unroll
+  for (int u = 0; u < TILE_QPT; ++u) {
+    if (!((flags >> u) & 1u)) continue;
     const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
     NN best;
     best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
     best.pos = NONE_U32;
     bool defer = false;
-    if (inside[u]) {
-      if (!search_octant_in_tile(g, tl, qx[u], qy[u], qz[u], cx[u], cy[u], cz[u], a.max_sq, best))
-        defer = !search_in_tile(g, tl, qx[u], qy[u], qz[u], cx[u], cy[u], cz[u], a.max_sq, best);   // full 3x3x3 search
+    if ((flags >> (16 + u)) & 1u) {
+#ifdef CILHIP_EXP_NO_FULL
+      if (!octant_search(g, tl, oq[u], a.max_sq, best)) defer = true;
+      if (false) {
+#else
+      if (!octant_search(g, tl, oq[u], a.max_sq, best)) {   // full 3x3x3 search (the cell is recomputed: rare path)
+#endif
+        const int cx = (int)floorf((oq[u].qx - g.ox) * g.inv_cell), cy = (int)floorf((oq[u].qy - g.oy) * g.inv_cell),
+                  cz = (int)floorf((oq[u].qz - g.oz) * g.inv_cell);
+        defer = !search_in_tile(g, tl, oq[u].qx, oq[u].qy, oq[u].qz, cx, cy, cz, a.max_sq, best);
+      }
+    } else if ((flags >> (8 + u)) & 1u) {
+      defer = true;   // in the grid but outside the tile's box: the clean-up pass takes it
     } else {
       // query outside the grid: nothing to find if it is farther than the radius, else generic search
-      const float gx = axis_gap(qx[u], g.ox, g.ox + (float)g.nx * g.cell, g.margin);
-      const float gy = axis_gap(qy[u], g.oy, g.oy + (float)g.ny * g.cell, g.margin);
-      const float gz = axis_gap(qz[u], g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+      const float gx = axis_gap(oq[u].qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
+      const float gy = axis_gap(oq[u].qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
+      const float gz = axis_gap(oq[u].qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
       defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
     }
     if (defer) {
@@ -661,6 +879,10 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
       a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
   }
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+  __syncthreads();
+  PHASE_CLK(3);
+#endif
 }
 
 // Clean-up pass of the tiled search: the (few) queries the LDS tile could not settle -- sparse data or a
@@ -703,11 +925,11 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const 
   }
 }
 
-void launch_search_tiled(const IterArgs& a, const uint2* tiles, uint32_t ntiles, hipStream_t s) {
+void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, uint32_t ntiles, hipStream_t s) {
   if (ntiles == 0) return;
   (void)hipMemsetAsync(a.todo_count, 0, 2 * sizeof(uint32_t), s);
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
-  hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, ntiles);
+  hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_center, ntiles);
   const uint32_t nb2 = (uint32_t)(((a.ns + ITER_THREADS - 1) / ITER_THREADS) < 2048 ? ((a.ns + ITER_THREADS - 1) / ITER_THREADS) : 2048);
   hipLaunchKernelGGL(k_search_todo, dim3(nb2 ? nb2 : 1), dim3(ITER_THREADS), 0, s, a, tiles);
 }
