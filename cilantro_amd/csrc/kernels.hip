@@ -394,50 +394,33 @@ __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 q
 // What a lane keeps of one query between its preparation (while the target points are still in flight) and the search.
 struct OctQuery {
   float qx, qy, qz;
-  float bound;   // distance from q to the nearest face of the octant block that has grid cells behind it (INF: none)
+  float bound;   // distance from q to the nearest face of its octant block
   int eb00;      // cell-table index of the first cell of run 0 (runs 1..3: + W1, + RY*W1, + (RY+1)*W1)
-  int info;      // bits 0-3: run k lies inside the grid; bit 4: the run is two cells wide; bits 8..: region row of run 0
+  int row00;     // region row of run 0 (runs 1..3: +1, +RY, +RY+1)
 };
 
 // Octant-first search (the common case): the 2x2x2 block of cells on the side of q's own cell that q
 // leans towards contains every target point closer than the distance from q to that block's faces, which
 // is at least half a cell.  The block is 4 runs of the sorted target array (2 x-adjacent cells each).
+// The grid carries one layer of empty cells around the data and the fast path only takes queries whose
+// cell is not in that layer, so the block never leaves the grid: no clipping, no validity flags.
 // octant_prepare() only needs the query; octant_search() runs out of LDS in STRAIGHT-LINE code: every lane
 // evaluates exactly OCT_CAND unclamped candidates per run (reading past a short run only evaluates further
 // real target points or the far-away pad records -- never wrong), no per-lane loop or branch, so the wave
-// executes each instruction once with all lanes busy; the rare longer runs go through one short flattened
-// overflow loop.  The winner is tracked as a small constant (run, slot) code and turned into an LDS index once.
+// executes each instruction once with all lanes busy.  The winner is tracked as a small constant (run, slot)
+// code and turned into an LDS index once.
 __device__ __forceinline__ void octant_prepare(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
                                                int lox, int loy, int loz, int RY, int W1, OctQuery& o) {
   o.qx = qx; o.qy = qy; o.qz = qz;
-  const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
+  // offsets of q inside its cell; q leans to the low side of an axis when the offset is below half a cell
+  const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
   const float half = 0.5f * g.cell;
-  const int ox = (qx - xl >= half) ? 0 : -1, oy = (qy - yl >= half) ? 0 : -1, oz = (qz - zl >= half) ? 0 : -1;
-  // cells of the block along x, clipped to the grid (the own cell is always inside)
-  const int xa = max(cx + ox, 0), xb = min(cx + ox + 1, g.nx - 1);
-  const int y0 = cy + oy, z0 = cz + oz;
-  const int row00 = (z0 - loz) * RY + (y0 - loy);
-  o.eb00 = row00 * W1 + (xa - lox);
-  const uint32_t vz0 = z0 >= 0, vz1 = z0 + 1 < g.nz, vy0 = y0 >= 0, vy1 = y0 + 1 < g.ny;
-  o.info = (int)((vz0 & vy0) | ((vz0 & vy1) << 1) | ((vz1 & vy0) << 2) | ((vz1 & vy1) << 3) | ((uint32_t)(xb > xa) << 4)) | (row00 << 8);
-  // distance from q to the faces of the block that still have grid cells beyond them
-  float b = INFINITY;
-  {
-    const float lo = xl + (float)ox * g.cell, hi = lo + 2.0f * g.cell;
-    if (cx + ox > 0) b = fminf(b, qx - lo);
-    if (cx + ox + 2 < g.nx) b = fminf(b, hi - qx);
-  }
-  {
-    const float lo = yl + (float)oy * g.cell, hi = lo + 2.0f * g.cell;
-    if (cy + oy > 0) b = fminf(b, qy - lo);
-    if (cy + oy + 2 < g.ny) b = fminf(b, hi - qy);
-  }
-  {
-    const float lo = zl + (float)oz * g.cell, hi = lo + 2.0f * g.cell;
-    if (cz + oz > 0) b = fminf(b, qz - lo);
-    if (cz + oz + 2 < g.nz) b = fminf(b, hi - qz);
-  }
-  o.bound = b;
+  const int ox = (ux >= half) ? 0 : -1, oy = (uy >= half) ? 0 : -1, oz = (uz >= half) ? 0 : -1;
+  o.row00 = (cz + oz - loz) * RY + (cy + oy - loy);
+  o.eb00 = o.row00 * W1 + (cx + ox - lox);
+  // nearest face of the two-cell span along an axis: at distance max(u, cell - u) (the far face of the own
+  // cell on the side q leans away from; the other face of the span is a full cell further)
+  o.bound = fminf(fminf(fmaxf(ux, g.cell - ux), fmaxf(uy, g.cell - uy)), fmaxf(uz, g.cell - uz));
 }
 
 // Returns true (result proven exact) iff the best found is strictly nearer than any point outside the block can be.
@@ -446,17 +429,14 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   const float qz = o.qz;
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
   uint32_t rj[4], re[4];
-  const int row00 = o.info >> 8;
-  const uint32_t vmask = (uint32_t)o.info & 15u;
-  const int wid = 1 + ((o.info >> 4) & 1);
+  const int row00 = o.row00;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int row = row00 + (k >> 1) * t.RY + (k & 1);
     const int eb = o.eb00 + ((k >> 1) * t.RY + (k & 1)) * t.W1;
-    const bool okr = (vmask >> k) & 1u;
-    const uint32_t dl = okr ? t.rowdelta[row] : 0u;
-    rj[k] = (okr ? t.lcs[eb] : 0u) - dl;
-    re[k] = (okr ? t.lcs[eb + wid] : 0u) - dl;
+    const uint32_t dl = t.rowdelta[row];
+    rj[k] = t.lcs[eb] - dl;
+    re[k] = t.lcs[eb + 2] - dl;
   }
   uint32_t sel = 0xFFu;
 #pragma unroll
@@ -514,17 +494,12 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   // over-read winner past the end of that row (or one picked up through a clipped run) takes the binary search
   uint32_t pos = NONE_U32;
   if (bl != NONE_U32) {
-    const uint32_t vm = vmask;
-    const int k = (int)(((vm >> 1) & 1u) & (uint32_t)(bl >= rj[1])) + (int)(((vm >> 2) & 1u) & (uint32_t)(bl >= rj[2])) +
-                  (int)(((vm >> 3) & 1u) & (uint32_t)(bl >= rj[3]));
+    const int k = (int)(bl >= rj[1]) + (int)(bl >= rj[2]) + (int)(bl >= rj[3]);   // the runs ascend in LDS
     const int row = row00 + (k >> 1) * t.RY + (k & 1);
-    const bool rok = (row >= 0) & (row < t.rows);
-    const uint32_t lo = rok ? t.rowbase[row] : 1u, hi = rok ? t.rowbase[row + 1] : 0u;
-    if (bl >= lo && bl < hi) pos = bl + t.rowdelta[row];
+    if (bl < t.rowbase[row + 1]) pos = bl + t.rowdelta[row];
     else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
   }
   best.pos = pos;
-  if (o.bound == INFINITY) return true;                    // the block covers the whole grid
   const float b = o.bound - g.margin;
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
@@ -699,7 +674,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
   const int hix = min(bx1 + 1, g.nx - 1), hiy = min(by1 + 1, g.ny - 1), hiz = min(bz1 + 1, g.nz - 1);
   const int RX = hix - lox + 1, RY = hiy - loy + 1, RZ = hiz - loz + 1;
   const int rows = RY * RZ, W1 = RX + 1, E = rows * W1;
-  bool ok = (RX >= 1) & (RY >= 1) & (RZ >= 1) & (RY <= TILE_MAXSPAN) & (RZ <= TILE_MAXSPAN) & (E <= TILE_MAXE);   // block-uniform
+  // cells of the box whose whole 3x3x3 neighbourhood is inside the grid: the only ones the fast path takes
+  const int fx0 = max(bx0, 1), fx1 = min(bx1, g.nx - 2), fy0 = max(by0, 1), fy1 = min(by1, g.ny - 2), fz0 = max(bz0, 1), fz1 = min(bz1, g.nz - 2);
+  bool ok = (fx0 <= fx1) & (fy0 <= fy1) & (fz0 <= fz1) & (RY <= TILE_MAXSPAN) & (RZ <= TILE_MAXSPAN) & (E <= TILE_MAXE);   // block-uniform
   if (!ok) {
     // whole-tile fallback (the cube's image is outside the grid or too large for the LDS budget: the transform
     // moved far from the sort-time one): the clean-up pass searches this tile's queries in their sorted order
@@ -775,7 +752,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
 
   // ---- 2c. (all waves, overlapping the scan) the lane's queries: transform, current cell, octant block ----
   OctQuery oq[TILE_QPT];
-  uint32_t flags = 0;   // per query u: bit u = active, bit 8+u = inside the grid, bit 16+u = inside the tile's box (fast path)
+  uint32_t flags = 0;   // per query u: bit u = active, bit 8+u = fast path (cell inside the tile's box, not in the grid's outer layer)
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
     const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
@@ -786,17 +763,15 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
     const int cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG));
     const int cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
     const bool active = i < tile.y;
-    const bool inside = active & (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
-    const bool inbox = inside & (cx >= bx0) & (cx <= bx1) & (cy >= by0) & (cy <= by1) & (cz >= bz0) & (cz <= bz1);
-    flags |= (active ? (1u << u) : 0u) | (inside ? (1u << (8 + u)) : 0u) | (inbox ? (1u << (16 + u)) : 0u);
-    // (lanes outside the box get a harmless in-region stand-in so that the code below stays branch-free)
-    octant_prepare(g, qx, qy, qz, inbox ? cx : bx0 < 0 ? 0 : min(bx0, g.nx - 1), inbox ? cy : by0 < 0 ? 0 : min(by0, g.ny - 1),
-                   inbox ? cz : bz0 < 0 ? 0 : min(bz0, g.nz - 1), lox, loy, loz, RY, W1, oq[u]);
+    const bool fast = active & (cx >= fx0) & (cx <= fx1) & (cy >= fy0) & (cy <= fy1) & (cz >= fz0) & (cz <= fz1);
+    flags |= (active ? (1u << u) : 0u) | (fast ? (1u << (8 + u)) : 0u);
+    // (the other lanes run on the nearest fast cell so that the code below stays branch-free; their result is dropped)
+    octant_prepare(g, qx, qy, qz, min(max(cx, fx0), fx1), min(max(cy, fy0), fy1), min(max(cz, fz0), fz1), lox, loy, loz, RY, W1, oq[u]);
   }
   __syncthreads();
 #ifdef CILHIP_EXP_STOP_AFTER
 #undef STOP_SINK
-#define STOP_SINK (oq[0].qx + oq[0].bound + (float)oq[0].eb00 + (float)oq[0].info + oq[1].qy + oq[1].bound + (float)oq[1].eb00 + (float)oq[1].info + (float)flags + oq[0].qz + oq[1].qz + oq[0].qy + oq[1].qx)
+#define STOP_SINK (oq[0].qx + oq[0].bound + (float)oq[0].eb00 + (float)oq[0].row00 + oq[1].qy + oq[1].bound + (float)oq[1].eb00 + (float)oq[1].row00 + (float)flags + oq[0].qz + oq[1].qz + oq[0].qy + oq[1].qx)
 #endif
   PHASE_CLK(1);
   STOP_AFTER(1);
@@ -851,7 +826,7 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
     best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
     best.pos = NONE_U32;
     bool defer = false;
-    if ((flags >> (16 + u)) & 1u) {
+    if ((flags >> (8 + u)) & 1u) {
 #ifdef CILHIP_EXP_NO_FULL
       if (!octant_search(g, tl, oq[u], a.max_sq, best)) defer = true;
       if (false) {
@@ -862,10 +837,9 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
                   cz = (int)floorf((oq[u].qz - g.oz) * g.inv_cell);
         defer = !search_in_tile(g, tl, oq[u].qx, oq[u].qy, oq[u].qz, cx, cy, cz, a.max_sq, best);
       }
-    } else if ((flags >> (8 + u)) & 1u) {
-      defer = true;   // in the grid but outside the tile's box: the clean-up pass takes it
     } else {
-      // query outside the grid: nothing to find if it is farther than the radius, else generic search
+      // outside the tile's box or in the grid's outer layer (or beyond): nothing to find if the query is farther
+      // from the grid than the radius, else the clean-up pass (generic search) takes it
       const float gx = axis_gap(oq[u].qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
       const float gy = axis_gap(oq[u].qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
       const float gz = axis_gap(oq[u].qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
