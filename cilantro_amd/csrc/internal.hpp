@@ -16,8 +16,14 @@ constexpr uint32_t NONE_U32 = 0xFFFFFFFFu;
 #endif
 // LDS-tiled search: queries are grouped by cubes of CUBE_EDGE^3 target-grid cells
 constexpr int CUBE_EDGE = CILHIP_CUBE_EDGE;
-constexpr int TILE_QUERIES = 2048;  // max queries per tile
-constexpr int TILE_THREADS = 1024;  // workgroup size of the tiled search kernel
+#ifndef CILHIP_TILE_THREADS
+#define CILHIP_TILE_THREADS 1024
+#endif
+#ifndef CILHIP_TILE_WAVES_PER_SIMD
+#define CILHIP_TILE_WAVES_PER_SIMD 8   /* resident waves per SIMD the tiled kernel is compiled for (register budget) */
+#endif
+constexpr int TILE_THREADS = CILHIP_TILE_THREADS;  // workgroup size of the tiled search kernel
+constexpr int TILE_QUERIES = 2 * TILE_THREADS;     // max queries per tile (two per lane)
 
 // Uniform grid over the target cloud (the structure that replaces the nanoflann kd-tree).
 // Target points are stored sorted by linear cell id (x fastest) as 16-byte records

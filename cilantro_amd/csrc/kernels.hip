@@ -615,7 +615,7 @@ void debug_dump_phase_clocks() {
 #define STOP_AFTER(k)
 #endif
 
-__global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
+__global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
                                                                   const float4* __restrict__ tile_center, uint32_t ntiles) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
@@ -788,28 +788,30 @@ __global__ __launch_bounds__(TILE_THREADS, 8) void k_search_tiled(IterArgs a, co
     const uint32_t o0 = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
     constexpr int GR = TILE_THREADS / 16;   // rows per batch step
+    for (int rb = 0; rb < rows; rb += 4 * GR) {   // block-uniform rounds of 4 * GR rows
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {   // points [0,16) of every row, then points [16,32)
-      u32x4 v[4];
-      uint32_t dst[4];
+      for (int half = 0; half < 2; ++half) {   // points [0,16) of every row, then points [16,32)
+        u32x4 v[4];
+        uint32_t dst[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int r = grp + GR * m;
-        const bool rv = r < rows;
-        const uint32_t f = rv ? rowbase[r] : 0u, l = rv ? rowbase[r + 1] - f : 0u, d = rv ? rowdelta[r] : 0u;
-        const uint32_t o = o0 + 16u * (uint32_t)half;
-        const bool has = o < l;
-        dst[m] = has ? f + o : NONE_U32;
-        v[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_pts, has ? (f + o + d) * 16u : 0xFFFFFFFFu, 0, 0);
+        for (int m = 0; m < 4; ++m) {
+          const int r = rb + grp + GR * m;
+          const bool rv = r < rows;
+          const uint32_t f = rv ? rowbase[r] : 0u, l = rv ? rowbase[r + 1] - f : 0u, d = rv ? rowdelta[r] : 0u;
+          const uint32_t o = o0 + 16u * (uint32_t)half;
+          const bool has = o < l;
+          dst[m] = has ? f + o : NONE_U32;
+          v[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_pts, has ? (f + o + d) * 16u : 0xFFFFFFFFu, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (dst[m] != NONE_U32) lpts[dst[m]] = make_float4(__uint_as_float(v[m].x), __uint_as_float(v[m].y), __uint_as_float(v[m].z), __uint_as_float(v[m].w));
       }
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (dst[m] != NONE_U32) lpts[dst[m]] = make_float4(__uint_as_float(v[m].x), __uint_as_float(v[m].y), __uint_as_float(v[m].z), __uint_as_float(v[m].w));
     }
-    // rare leftovers: rows longer than 32 points, rows beyond the four batches
+    // rare leftovers: rows longer than 32 points
     for (int r = grp; r < rows; r += GR) {
       const uint32_t f = rowbase[r], l = rowbase[r + 1] - f, d = rowdelta[r];
-      for (uint32_t o = o0 + (r < 4 * GR ? 32u : 0u); o < l; o += 16) lpts[f + o] = g.pts[f + o + d];
+      for (uint32_t o = o0 + 32u; o < l; o += 16) lpts[f + o] = g.pts[f + o + d];
     }
     if (threadIdx.x < 8) lpts[P + threadIdx.x] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __uint_as_float(NONE_U32));  // pad: d2 = inf
   }
