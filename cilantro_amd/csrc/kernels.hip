@@ -962,26 +962,116 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
   const uint32_t beg = beg64 < a.ns ? (uint32_t)beg64 : a.ns;
   const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
 
-  // Software-pipelined by one element: the next element's source point / stored match are requested before
-  // the current element's gathers (matched point, normal) are consumed, so every lane keeps two levels of
-  // independent loads in flight (the streaming accumulation pass is otherwise a chain of dependent gathers).
+  // the accumulation of one matched pair (q = T*s already formed); shared by the loops below
+  auto accumulate = [&](float qx, float qy, float qz, uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
+  if (METRIC != IM_NONE && pos != NONE_U32) {
+    if (TR::kabsch) {
+      // raw moments for the closed-form estimator (transform_estimation.hpp:25-34)
+      const double pd[3] = {(double)p.x, (double)p.y, (double)p.z};
+      const double qd[3] = {(double)qx, (double)qy, (double)qz};
+      accA[0] += 1.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { accA[1 + c] += pd[c]; accA[4 + c] += qd[c]; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) accA[7 + r * 3 + c] = fma(pd[r], qd[c], accA[7 + r * 3 + c]);
+    } else {
+      // per-term quantities in f32 exactly as the reference forms them (transform_estimation.hpp:302-304,:333-335)
+      const float d0 = __fsub_rn(p.x, a.dst_mean[0]), d1 = __fsub_rn(p.y, a.dst_mean[1]), d2 = __fsub_rn(p.z, a.dst_mean[2]);
+      const float u0 = __fsub_rn(qx, smt[0]), u1 = __fsub_rn(qy, smt[1]), u2 = __fsub_rn(qz, smt[2]);
+      // s = inner_tform * (q - T*src_mean); identity on the first Gauss-Newton step
+      const float s0 = __fadd_rn(__fadd_rn(__fmul_rn(iL[0], u0), __fadd_rn(__fmul_rn(iL[1], u1), __fmul_rn(iL[2], u2))), it[0]);
+      const float s1 = __fadd_rn(__fadd_rn(__fmul_rn(iL[3], u0), __fadd_rn(__fmul_rn(iL[4], u1), __fmul_rn(iL[5], u2))), it[1]);
+      const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(iL[6], u0), __fadd_rn(__fmul_rn(iL[7], u1), __fmul_rn(iL[8], u2))), it[2]);
+      const float a0 = __fadd_rn(d0, s0), a1 = __fadd_rn(d1, s1), a2 = __fadd_rn(d2, s2);
+      const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
+      accA[0] += 1.0;
+      if (TR::plane) {
+        float4 nv = nvp;
+        if (a.src_nrm) {
+          // symmetric metric (transform_estimation.hpp:705-706): n = n_dst + tform.linear() * n_src', with
+          // n_src' = transform_.linear() * n_src (transformNormals, core/space_transformations.hpp:374-390)
+          const float4 sn = snp;
+          const float t0 = __fadd_rn(__fmul_rn(T[0], sn.x), __fadd_rn(__fmul_rn(T[4], sn.y), __fmul_rn(T[8], sn.z)));
+          const float t1 = __fadd_rn(__fmul_rn(T[1], sn.x), __fadd_rn(__fmul_rn(T[5], sn.y), __fmul_rn(T[9], sn.z)));
+          const float t2 = __fadd_rn(__fmul_rn(T[2], sn.x), __fadd_rn(__fmul_rn(T[6], sn.y), __fmul_rn(T[10], sn.z)));
+          nv.x = __fadd_rn(nv.x, __fadd_rn(__fmul_rn(iL[0], t0), __fadd_rn(__fmul_rn(iL[1], t1), __fmul_rn(iL[2], t2))));
+          nv.y = __fadd_rn(nv.y, __fadd_rn(__fmul_rn(iL[3], t0), __fadd_rn(__fmul_rn(iL[4], t1), __fmul_rn(iL[5], t2))));
+          nv.z = __fadd_rn(nv.z, __fadd_rn(__fmul_rn(iL[6], t0), __fadd_rn(__fmul_rn(iL[7], t1), __fmul_rn(iL[8], t2))));
+        }
+        float e[6];
+        e[0] = __fsub_rn(__fmul_rn(a1, nv.z), __fmul_rn(a2, nv.y));   // (d+s).cross(n)  :337
+        e[1] = __fsub_rn(__fmul_rn(a2, nv.x), __fmul_rn(a0, nv.z));
+        e[2] = __fsub_rn(__fmul_rn(a0, nv.y), __fmul_rn(a1, nv.x));
+        e[3] = nv.x; e[4] = nv.y; e[5] = nv.z;
+        const float res = __fadd_rn(__fmul_rn(nv.x, r0), __fadd_rn(__fmul_rn(nv.y, r1), __fmul_rn(nv.z, r2)));  // n.dot(d-s)
+        double ed[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ed[k] = (double)e[k];
+        int k = 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) { accA[k] = fma(ed[r], ed[c], accA[k]); ++k; }
+        const double rd = (double)res;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) accA[22 + r] = fma(rd, ed[r], accA[22 + r]);
+      }
+      if (TR::point) {
+        const double ad[3] = {(double)a0, (double)a1, (double)a2};
+        const double rd[3] = {(double)r0, (double)r1, (double)r2};
+        accB[0] += ad[0]; accB[1] += ad[1]; accB[2] += ad[2];
+        accB[3] = fma(ad[0], ad[0], accB[3]); accB[4] = fma(ad[0], ad[1], accB[4]); accB[5] = fma(ad[0], ad[2], accB[5]);
+        accB[6] = fma(ad[1], ad[1], accB[6]); accB[7] = fma(ad[1], ad[2], accB[7]); accB[8] = fma(ad[2], ad[2], accB[8]);
+        accB[9] += ad[1] * rd[2] - ad[2] * rd[1];
+        accB[10] += ad[2] * rd[0] - ad[0] * rd[2];
+        accB[11] += ad[0] * rd[1] - ad[1] * rd[0];
+        accB[12] += rd[0]; accB[13] += rd[1]; accB[14] += rd[2];
+      }
+    }
+  }
+  };
+
+  if (!SEARCH) {
+    // Streaming pass over the stored matches, TWO elements per lane per trip and the next trip's source points /
+    // match indices requested before the current gathers (matched point, normal) are consumed: every lane keeps
+    // 4 coalesced loads + 4 gathers in flight.  Per-lane accumulation order is unchanged (i, i+T, i+2T, ...).
+    uint32_t i0 = beg + threadIdx.x;
+    float4 sa = i0 < end ? a.src[i0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sb = i0 + ITER_THREADS < end ? a.src[i0 + ITER_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t pa = i0 < end ? a.nn_pos[i0] : NONE_U32, pb = i0 + ITER_THREADS < end ? a.nn_pos[i0 + ITER_THREADS] : NONE_U32;
+    while (i0 < end) {
+      const float4 s4a = sa, s4b = sb;
+      const uint32_t posa = pa, posb = pb;
+      const uint32_t ia = i0, ib = i0 + ITER_THREADS;
+      float4 p_a = make_float4(0.f, 0.f, 0.f, 0.f), nv_a = p_a, sn_a = p_a, p_b = p_a, nv_b = p_a, sn_b = p_a;
+      if (METRIC != IM_NONE) {
+        if (posa != NONE_U32) { p_a = a.grid.pts[posa]; if (TR::plane) { nv_a = a.grid.nrm[posa]; if (a.src_nrm) sn_a = a.src_nrm[ia]; } }
+        if (posb != NONE_U32) { p_b = a.grid.pts[posb]; if (TR::plane) { nv_b = a.grid.nrm[posb]; if (a.src_nrm) sn_b = a.src_nrm[ib]; } }
+      }
+      i0 += 2 * ITER_THREADS;
+      if (i0 < end) { sa = a.src[i0]; pa = a.nn_pos[i0]; } else pa = NONE_U32;
+      if (i0 + ITER_THREADS < end) { sb = a.src[i0 + ITER_THREADS]; pb = a.nn_pos[i0 + ITER_THREADS]; } else pb = NONE_U32;
+      float qx, qy, qz;
+      transform_point(T, s4a.x, s4a.y, s4a.z, qx, qy, qz);
+      accumulate(qx, qy, qz, posa, p_a, nv_a, sn_a);
+      transform_point(T, s4b.x, s4b.y, s4b.z, qx, qy, qz);
+      accumulate(qx, qy, qz, posb, p_b, nv_b, sn_b);
+    }
+  } else {
   uint32_t inext = beg + threadIdx.x;
   float4 s4n = inext < end ? a.src[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t posn = (!SEARCH && inext < end) ? a.nn_pos[inext] : NONE_U32;
   while (inext < end) {
     const uint32_t i = inext;
     const float4 s4 = s4n;
-    uint32_t pos = posn;
+    uint32_t pos = NONE_U32;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nvp = p, snp = p;
-    if (!SEARCH && METRIC != IM_NONE && pos != NONE_U32) {
-      p = a.grid.pts[pos];
-      if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; }
-    }
     inext += ITER_THREADS;
-    if (inext < end) { s4n = a.src[inext]; if (!SEARCH) posn = a.nn_pos[inext]; }
+    if (inext < end) s4n = a.src[inext];
     float qx, qy, qz;
     transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-    if (SEARCH) {
+    {
       NN best;
       nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
       pos = best.pos;
@@ -991,73 +1081,8 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
         if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; }
       }
     }
-    if (METRIC != IM_NONE && pos != NONE_U32) {
-      if (TR::kabsch) {
-        // raw moments for the closed-form estimator (transform_estimation.hpp:25-34)
-        const double pd[3] = {(double)p.x, (double)p.y, (double)p.z};
-        const double qd[3] = {(double)qx, (double)qy, (double)qz};
-        accA[0] += 1.0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { accA[1 + c] += pd[c]; accA[4 + c] += qd[c]; }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) accA[7 + r * 3 + c] = fma(pd[r], qd[c], accA[7 + r * 3 + c]);
-      } else {
-        // per-term quantities in f32 exactly as the reference forms them (transform_estimation.hpp:302-304,:333-335)
-        const float d0 = __fsub_rn(p.x, a.dst_mean[0]), d1 = __fsub_rn(p.y, a.dst_mean[1]), d2 = __fsub_rn(p.z, a.dst_mean[2]);
-        const float u0 = __fsub_rn(qx, smt[0]), u1 = __fsub_rn(qy, smt[1]), u2 = __fsub_rn(qz, smt[2]);
-        // s = inner_tform * (q - T*src_mean); identity on the first Gauss-Newton step
-        const float s0 = __fadd_rn(__fadd_rn(__fmul_rn(iL[0], u0), __fadd_rn(__fmul_rn(iL[1], u1), __fmul_rn(iL[2], u2))), it[0]);
-        const float s1 = __fadd_rn(__fadd_rn(__fmul_rn(iL[3], u0), __fadd_rn(__fmul_rn(iL[4], u1), __fmul_rn(iL[5], u2))), it[1]);
-        const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(iL[6], u0), __fadd_rn(__fmul_rn(iL[7], u1), __fmul_rn(iL[8], u2))), it[2]);
-        const float a0 = __fadd_rn(d0, s0), a1 = __fadd_rn(d1, s1), a2 = __fadd_rn(d2, s2);
-        const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
-        accA[0] += 1.0;
-        if (TR::plane) {
-          float4 nv = nvp;
-          if (a.src_nrm) {
-            // symmetric metric (transform_estimation.hpp:705-706): n = n_dst + tform.linear() * n_src', with
-            // n_src' = transform_.linear() * n_src (transformNormals, core/space_transformations.hpp:374-390)
-            const float4 sn = snp;
-            const float t0 = __fadd_rn(__fmul_rn(T[0], sn.x), __fadd_rn(__fmul_rn(T[4], sn.y), __fmul_rn(T[8], sn.z)));
-            const float t1 = __fadd_rn(__fmul_rn(T[1], sn.x), __fadd_rn(__fmul_rn(T[5], sn.y), __fmul_rn(T[9], sn.z)));
-            const float t2 = __fadd_rn(__fmul_rn(T[2], sn.x), __fadd_rn(__fmul_rn(T[6], sn.y), __fmul_rn(T[10], sn.z)));
-            nv.x = __fadd_rn(nv.x, __fadd_rn(__fmul_rn(iL[0], t0), __fadd_rn(__fmul_rn(iL[1], t1), __fmul_rn(iL[2], t2))));
-            nv.y = __fadd_rn(nv.y, __fadd_rn(__fmul_rn(iL[3], t0), __fadd_rn(__fmul_rn(iL[4], t1), __fmul_rn(iL[5], t2))));
-            nv.z = __fadd_rn(nv.z, __fadd_rn(__fmul_rn(iL[6], t0), __fadd_rn(__fmul_rn(iL[7], t1), __fmul_rn(iL[8], t2))));
-          }
-          float e[6];
-          e[0] = __fsub_rn(__fmul_rn(a1, nv.z), __fmul_rn(a2, nv.y));   // (d+s).cross(n)  :337
-          e[1] = __fsub_rn(__fmul_rn(a2, nv.x), __fmul_rn(a0, nv.z));
-          e[2] = __fsub_rn(__fmul_rn(a0, nv.y), __fmul_rn(a1, nv.x));
-          e[3] = nv.x; e[4] = nv.y; e[5] = nv.z;
-          const float res = __fadd_rn(__fmul_rn(nv.x, r0), __fadd_rn(__fmul_rn(nv.y, r1), __fmul_rn(nv.z, r2)));  // n.dot(d-s)
-          double ed[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) ed[k] = (double)e[k];
-          int k = 1;
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) { accA[k] = fma(ed[r], ed[c], accA[k]); ++k; }
-          const double rd = (double)res;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) accA[22 + r] = fma(rd, ed[r], accA[22 + r]);
-        }
-        if (TR::point) {
-          const double ad[3] = {(double)a0, (double)a1, (double)a2};
-          const double rd[3] = {(double)r0, (double)r1, (double)r2};
-          accB[0] += ad[0]; accB[1] += ad[1]; accB[2] += ad[2];
-          accB[3] = fma(ad[0], ad[0], accB[3]); accB[4] = fma(ad[0], ad[1], accB[4]); accB[5] = fma(ad[0], ad[2], accB[5]);
-          accB[6] = fma(ad[1], ad[1], accB[6]); accB[7] = fma(ad[1], ad[2], accB[7]); accB[8] = fma(ad[2], ad[2], accB[8]);
-          accB[9] += ad[1] * rd[2] - ad[2] * rd[1];
-          accB[10] += ad[2] * rd[0] - ad[0] * rd[2];
-          accB[11] += ad[0] * rd[1] - ad[1] * rd[0];
-          accB[12] += rd[0]; accB[13] += rd[1]; accB[14] += rd[2];
-        }
-      }
-    }
+    accumulate(qx, qy, qz, pos, p, nvp, snp);
+  }
   }
 
   if (METRIC != IM_NONE) {
@@ -1088,8 +1113,11 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
 int iter_num_blocks(uint32_t ns) {
   // >= 8 blocks per CU on 256 CUs when there is enough work; multiple of 8 for the XCD mapping;
   // at least one wave of work per block.
+#ifndef CILHIP_ITER_BLOCKS
+#define CILHIP_ITER_BLOCKS 2048
+#endif
   long want = ((long)ns + 255) / 256;
-  long nb = want < 2048 ? want : 2048;
+  long nb = want < CILHIP_ITER_BLOCKS ? want : CILHIP_ITER_BLOCKS;
   nb = (nb + 7) & ~7L;
   if (nb < 8) nb = 8;
   return (int)nb;
@@ -1174,15 +1202,20 @@ __device__ void reset_inner(IcpState* st) {
 
 __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   __shared__ double sums[SUMS_MAX];
-  IcpState* st = a.state;
-  if (st->done) return;
+  __shared__ IcpState lst;   // the state is pulled into LDS in one coalesced pass, updated by one lane, written back in one pass:
+                             // the serial epilogue then pays one global round trip instead of one per field it touches
+  static_assert(sizeof(IcpState) % 4 == 0, "IcpState is copied as dwords");
+  constexpr int ST_DWORDS = (int)(sizeof(IcpState) / 4);
+  if (a.state->done) return;
+  for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(&lst)[k] = reinterpret_cast<const uint32_t*>(a.state)[k];
   if (a.nblocks > 0) {
     reduce_partials_block(a.partials, a.nblocks, sums);
   } else {
     if (threadIdx.x < SUMS_MAX) sums[threadIdx.x] = a.reduced[threadIdx.x];
-    __syncthreads();
   }
-  if (threadIdx.x != 0) return;
+  __syncthreads();
+  IcpState* st = &lst;
+  if (threadIdx.x == 0) {
 
   const double n = sums[0];
   double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
@@ -1237,6 +1270,9 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
     st->done = (delta < a.conv_tol) ? 1 : 0;                            // icp_base.hpp:83
     reset_inner(st);
   }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(a.state)[k] = reinterpret_cast<const uint32_t*>(&lst)[k];
 }
 
 void launch_solve(const SolveArgs& a, hipStream_t s) {
