@@ -176,12 +176,22 @@ def main():
         alg_bytes = 20.0 * ns + 12.0 * nd
         # streaming accumulation kernel (point-to-plane): B_acc = 16*Ns + 24*Nc  
         acc_bytes = 16.0 * ns + (24.0 if with_normals else 12.0) * nc
+        # HBM bytes per launch of the search kernel(s) from the committed PMC passes (separate rocprofv3 --pmc runs,
+        # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); only quoted for the workload it was measured on
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
+            w = tj["workload"]
+            if (w["n_target"], w["n_source_per_gpu"], bool(w["with_normals"])) == (nd, ns, bool(with_normals)):
+                traffic = float(tj["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
         roof = None
         if not sharded and launches > 0:
             avg_ms = search_ms / launches
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": "k_search_tiled + k_search_todo (kNN correspondence search, LDS-tiled)",
+                    "traffic": traffic, "kernel": "k_search_tiled + k_search_todo (kNN correspondence search, LDS-tiled)",
                     "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
                     "accumulate_kernel": {"avg_kernel_ms": acc_ms / launches,
                                           "algorithmic_bytes_per_launch": acc_bytes,

@@ -788,13 +788,17 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     const uint32_t o0 = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
     constexpr int GR = TILE_THREADS / 16;   // rows per batch step
-    for (int rb = 0; rb < rows; rb += 4 * GR) {   // block-uniform rounds of 4 * GR rows
+#ifndef CILHIP_STAGE_ROWS
+#define CILHIP_STAGE_ROWS 4
+#endif
+    constexpr int STAGE_ROWS = CILHIP_STAGE_ROWS;   // rows in flight per lane
+    for (int rb = 0; rb < rows; rb += STAGE_ROWS * GR) {   // block-uniform rounds of STAGE_ROWS * GR rows
 #pragma unroll
       for (int half = 0; half < 2; ++half) {   // points [0,16) of every row, then points [16,32)
-        u32x4 v[4];
-        uint32_t dst[4];
+        u32x4 v[STAGE_ROWS];
+        uint32_t dst[STAGE_ROWS];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < STAGE_ROWS; ++m) {
           const int r = rb + grp + GR * m;
           const bool rv = r < rows;
           const uint32_t f = rv ? rowbase[r] : 0u, l = rv ? rowbase[r + 1] - f : 0u, d = rv ? rowdelta[r] : 0u;
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
           v[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_pts, has ? (f + o + d) * 16u : 0xFFFFFFFFu, 0, 0);
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < STAGE_ROWS; ++m)
           if (dst[m] != NONE_U32) lpts[dst[m]] = make_float4(__uint_as_float(v[m].x), __uint_as_float(v[m].y), __uint_as_float(v[m].z), __uint_as_float(v[m].w));
       }
     }
