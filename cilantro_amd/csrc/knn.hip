@@ -1,0 +1,323 @@
+// knn.hip -- exact k-nearest-neighbour search (k > 1) on the uniform grid, and the consumer that sits right
+// before the ICP path: NormalEstimation.  Replaces
+//   core/kd_tree.hpp:216-256, :286-318     KDTree::kNNSearch / kNNInRadiusSearch (nanoflann findNeighbors with
+//                                           cilantro's KNNSearchResultAdaptor :63-109: k smallest, d2 < r2 strict)
+//   core/normal_estimation.hpp:294-420      per point: k-NN -> mean / covariance of the neighbourhood
+//                                           (core/covariance.hpp:140-170) -> eigenvector of the smallest eigenvalue,
+//                                           optional flip towards the view point, curvature = l0 / (l0+l1+l2)
+//
+// One lane per query.  The k best candidates live in LDS as a per-lane sorted column of 64-bit keys
+// (bits(d2) << 32 | original index: strict '<' plus lowest-index tie-break, the rule of the 1-NN path).  The
+// grid is searched in expanding Chebyshev shells; a row / cell is skipped when its box distance already
+// exceeds the current k-th best, and the search stops when every unscanned point is provably farther than
+// the k-th best.  d2 is the pinned ((dx*dx)+(dy*dy))+(dz*dz), so neighbour sets and distances are
+// bit-identical to the reference except on exactly tied distances at the k-th place.
+// Queries are processed in target-grid cell order (neighbouring lanes scan the same cells).
+#include "../../include/cilantro_hip/c_api.h"
+#include "internal.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace cilhip {
+
+namespace {
+
+constexpr int KNN_THREADS = 256;
+constexpr int KNN_MAX_K = 32;
+constexpr float KNN_SHRINK = 0.99999905f;   // 1 - 2^-20, as in the 1-NN path
+
+struct KnnArgs {
+  GridDev g;
+  const float4* queries;   // [nq] {x,y,z,bitcast(original query index)}, in target-grid cell order
+  uint32_t nq, k;
+  float radius_sq;         // accept d2 < radius_sq (INFINITY: no radius)
+  uint32_t* out_idx;       // [nq*k] rows by ORIGINAL query index, ascending (d2, index), NONE-padded; may be null
+  float* out_d2;           // [nq*k] or null
+  uint32_t* out_cnt;       // [nq] or null
+  // normal estimation (do_pca): neighbourhood PCA
+  int do_pca;
+  const float* ref_xyz;    // [3*n_ref] reference points in ORIGINAL order (gathered by neighbour index)
+  float* normals;          // [3*nq] by original query index
+  float* curvature;        // [nq] or null
+  float vp[3];
+  int use_vp;
+};
+
+__device__ __forceinline__ float d2_pinned(float qx, float qy, float qz, float px, float py, float pz) {
+  const float dx = __fsub_rn(qx, px), dy = __fsub_rn(qy, py), dz = __fsub_rn(qz, pz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+__device__ __forceinline__ float gap(float q, float lo, float hi, float margin) { return fmaxf(fmaxf(lo - q, q - hi) - margin, 0.0f); }
+
+// per-lane sorted list of the k best keys, column `tid` of lists[k][KNN_THREADS]
+struct KList {
+  unsigned long long* col;   // &lists[threadIdx.x]
+  uint32_t k, cnt;
+  unsigned long long worst;  // a candidate enters iff key < worst
+  unsigned long long none_key;
+  __device__ __forceinline__ float worst_d2() const { return __uint_as_float((uint32_t)(worst >> 32)); }
+  __device__ __forceinline__ void insert(unsigned long long key) {
+    if (key >= worst) return;
+    uint32_t j = cnt < k ? cnt : k - 1;
+    while (j > 0 && col[(size_t)(j - 1) * KNN_THREADS] > key) { col[(size_t)j * KNN_THREADS] = col[(size_t)(j - 1) * KNN_THREADS]; --j; }
+    col[(size_t)j * KNN_THREADS] = key;
+    if (cnt < k) ++cnt;
+    worst = cnt < k ? none_key : col[(size_t)(k - 1) * KNN_THREADS];
+  }
+};
+
+__device__ __forceinline__ void scan_run(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, KList& L) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 4) {
+    const float4 p0 = pts[j], p1 = pts[min(j + 1, last)], p2 = pts[min(j + 2, last)], p3 = pts[min(j + 3, last)];
+    const unsigned long long k0 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z)) << 32) | __float_as_uint(p0.w);
+    const unsigned long long k1 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z)) << 32) | __float_as_uint(p1.w);
+    const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z)) << 32) | __float_as_uint(p2.w);
+    const unsigned long long k3 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z)) << 32) | __float_as_uint(p3.w);
+    L.insert(k0);
+    if (j + 1 <= last) L.insert(k1);   // (a clamped duplicate must not enter twice)
+    if (j + 2 <= last) L.insert(k2);
+    if (j + 3 <= last) L.insert(k3);
+  }
+}
+
+__global__ __launch_bounds__(KNN_THREADS) void k_knn(KnnArgs a) {
+  extern __shared__ unsigned long long lists[];   // [k][KNN_THREADS]
+  const GridDev& g = a.g;
+  const uint32_t qi = blockIdx.x * KNN_THREADS + threadIdx.x;
+  if (qi >= a.nq) return;
+  const float4 q4 = a.queries[qi];
+  const float qx = q4.x, qy = q4.y, qz = q4.z;
+  const uint32_t orig = __float_as_uint(q4.w);
+  KList L;
+  L.col = lists + threadIdx.x;
+  L.k = a.k; L.cnt = 0;
+  L.none_key = ((unsigned long long)__float_as_uint(a.radius_sq) << 32);
+  L.worst = L.none_key;
+  const float BIG = 1.0e9f;
+  const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG));
+  const int cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG));
+  const int cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
+  const bool finite = fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY;   // false for NaN too
+  // start at the first shell that can touch the grid (queries far outside would otherwise walk empty shells)
+  int s0 = 0;
+  s0 = max(s0, max(-cx, cx - (g.nx - 1)));
+  s0 = max(s0, max(-cy, cy - (g.ny - 1)));
+  s0 = max(s0, max(-cz, cz - (g.nz - 1)));
+  if (finite && g.n > 0) {
+    for (int s = s0;; ++s) {
+      const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1);
+      const int y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+      const int xlo = cx - s, xhi = cx + s;
+      for (int z = z0; z <= z1; ++z) {
+        const bool zface = (z == cz - s) || (z == cz + s);
+        const float zl = g.oz + (float)z * g.cell;
+        const float gz = gap(qz, zl, zl + g.cell, g.margin);
+        const float gz2 = gz * gz;
+        if (gz2 * KNN_SHRINK > L.worst_d2()) continue;
+        for (int y = y0; y <= y1; ++y) {
+          const bool face = zface || (y == cy - s) || (y == cy + s);
+          const float yl = g.oy + (float)y * g.cell;
+          const float gy = gap(qy, yl, yl + g.cell, g.margin);
+          const float gyz2 = gz2 + gy * gy;
+          if (gyz2 * KNN_SHRINK > L.worst_d2()) continue;
+          const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          if (face) {
+            const int xa = max(xlo, 0), xb = min(xhi, g.nx - 1);
+            if (xa <= xb) {
+              const float gx = gap(qx, g.ox + (float)xa * g.cell, g.ox + (float)(xb + 1) * g.cell, g.margin);
+              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, L);
+            }
+          } else {
+            if (xlo >= 0 && xlo < g.nx) {
+              const float xl = g.ox + (float)xlo * g.cell;
+              const float gx = gap(qx, xl, xl + g.cell, g.margin);
+              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, L);
+            }
+            if (xhi >= 0 && xhi < g.nx && xhi != xlo) {
+              const float xl = g.ox + (float)xhi * g.cell;
+              const float gx = gap(qx, xl, xl + g.cell, g.margin);
+              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, L);
+            }
+          }
+        }
+      }
+      // lower bound on the distance to anything not yet scanned (outside the (2s+1)^3 block, inside the grid)
+      float b = INFINITY;
+      if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+      if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+      if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+      if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+      if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+      if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+      if (b == INFINITY) break;  // block covers the grid: everything scanned
+      b -= g.margin;
+      if (b > 0.0f && L.worst_d2() < b * b * KNN_SHRINK) break;   // (also ends radius searches once the shell passed the radius)
+    }
+  }
+  const uint32_t m = L.cnt;
+  if (a.out_cnt) a.out_cnt[orig] = m;
+  if (a.out_idx) {
+    for (uint32_t j = 0; j < a.k; ++j) {
+      const unsigned long long key = j < m ? L.col[(size_t)j * KNN_THREADS] : 0ull;
+      a.out_idx[(size_t)orig * a.k + j] = j < m ? (uint32_t)(key & 0xFFFFFFFFull) : NONE_U32;
+      if (a.out_d2) a.out_d2[(size_t)orig * a.k + j] = j < m ? __uint_as_float((uint32_t)(key >> 32)) : INFINITY;
+    }
+  }
+  if (a.do_pca) {
+    float n0 = NAN, n1 = NAN, n2 = NAN, curv = NAN;
+    if (m >= 3) {   // setMinValidSampleSize(3), core/normal_estimation.hpp:28
+      // mean: neighbours in ascending-distance order (the order of the reference's result set); f64 accumulation
+      double s0d = 0.0, s1d = 0.0, s2d = 0.0;
+      for (uint32_t j = 0; j < m; ++j) {
+        const size_t id = (size_t)(L.col[(size_t)j * KNN_THREADS] & 0xFFFFFFFFull);
+        s0d += (double)a.ref_xyz[3 * id]; s1d += (double)a.ref_xyz[3 * id + 1]; s2d += (double)a.ref_xyz[3 * id + 2];
+      }
+      const float m0 = (float)(s0d / (double)m), m1 = (float)(s1d / (double)m), m2 = (float)(s2d / (double)m);
+      double cs[6] = {0, 0, 0, 0, 0, 0};
+      for (uint32_t j = 0; j < m; ++j) {
+        const size_t id = (size_t)(L.col[(size_t)j * KNN_THREADS] & 0xFFFFFFFFull);
+        const float t0 = __fsub_rn(a.ref_xyz[3 * id], m0), t1 = __fsub_rn(a.ref_xyz[3 * id + 1], m1), t2 = __fsub_rn(a.ref_xyz[3 * id + 2], m2);
+        cs[0] += (double)__fmul_rn(t0, t0); cs[1] += (double)__fmul_rn(t0, t1); cs[2] += (double)__fmul_rn(t0, t2);
+        cs[3] += (double)__fmul_rn(t1, t1); cs[4] += (double)__fmul_rn(t1, t2); cs[5] += (double)__fmul_rn(t2, t2);
+      }
+      const double inv = (double)m - 1.0;
+      const double C[9] = {cs[0] / inv, cs[1] / inv, cs[2] / inv, cs[1] / inv, cs[3] / inv, cs[4] / inv, cs[2] / inv, cs[4] / inv, cs[5] / inv};
+      double w[3], V[9];
+      sym_eig3(C, w, V);   // descending; the normal is the eigenvector of the SMALLEST eigenvalue (eigenvectors().col(0) of Eigen's ascending order)
+      n0 = (float)V[2]; n1 = (float)V[5]; n2 = (float)V[8];
+      if (a.use_vp) {      // normal_estimation.hpp:326-330: flip when it points away from the view point
+        const float d = __fadd_rn(__fmul_rn(n0, __fsub_rn(a.vp[0], qx)), __fadd_rn(__fmul_rn(n1, __fsub_rn(a.vp[1], qy)), __fmul_rn(n2, __fsub_rn(a.vp[2], qz))));
+        if (d < 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
+      }
+      curv = (float)(w[2] / ((w[0] + w[1]) + w[2]));   // :388
+    }
+    a.normals[3 * (size_t)orig] = n0; a.normals[3 * (size_t)orig + 1] = n1; a.normals[3 * (size_t)orig + 2] = n2;
+    if (a.curvature) a.curvature[orig] = curv;
+  }
+}
+
+#define KN_CK(x)               \
+  do {                         \
+    if ((x) != hipSuccess) {   \
+      rc = CILHIP_ERR_HIP;     \
+      goto done;               \
+    }                          \
+  } while (0)
+
+int knn_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k, float max_sq_dist,
+             uint32_t* idx_out, float* d2_out, uint32_t* cnt_out, bool do_pca, const float* view_point, float* normals_out,
+             float* curvature_out) {
+  if ((!ref_xyz && n_ref) || k == 0 || k > (size_t)KNN_MAX_K || n_ref > 0xFFFFFFF0ull || n_query > 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
+  if (!(max_sq_dist > 0.0f)) max_sq_dist = 0.0f;   // NaN / negative radius: nothing is inside
+  const bool self = query_xyz == nullptr;
+  if (self) n_query = n_ref;
+  int rc = CILHIP_OK;
+  hipStream_t s = nullptr;
+  float *d_ref = nullptr, *d_q = nullptr, *d_d2 = nullptr, *d_nrm = nullptr, *d_curv = nullptr;
+  bool own_ref = false, own_q = false;
+  float4* d_qs = nullptr;
+  uint2* d_tiles = nullptr;
+  float4* d_tc = nullptr;
+  uint32_t *d_idx = nullptr, *d_cnt = nullptr;
+  GridBuildResult gr{};
+  bool have_grid = false;
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CILHIP_ERR_NO_DEVICE;
+    KN_CK(hipSetDevice(device));
+    if (n_query == 0) return CILHIP_OK;
+    KN_CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (mem == CILHIP_MEM_DEVICE) {
+      d_ref = const_cast<float*>(ref_xyz);
+      d_q = self ? d_ref : const_cast<float*>(query_xyz);
+    } else {
+      if (n_ref) {
+        own_ref = true;
+        KN_CK(hipMalloc(&d_ref, 3 * n_ref * sizeof(float)));
+        KN_CK(hipMemcpyAsync(d_ref, ref_xyz, 3 * n_ref * sizeof(float), hipMemcpyHostToDevice, s));
+      }
+      if (self) d_q = d_ref;
+      else {
+        own_q = true;
+        KN_CK(hipMalloc(&d_q, 3 * n_query * sizeof(float)));
+        KN_CK(hipMemcpyAsync(d_q, query_xyz, 3 * n_query * sizeof(float), hipMemcpyHostToDevice, s));
+      }
+    }
+    double mean[3];
+    // ~k/4 points per cell: the k-th neighbour then normally lies inside the 3x3x3 block of cells
+    KN_CK(build_grid(d_ref, nullptr, (uint32_t)n_ref, s, &gr, mean, std::max(1.0, (double)k / 4.0)));
+    have_grid = true;
+    // queries in target-grid cell order (identity transform)
+    KN_CK(hipMalloc(&d_qs, n_query * sizeof(float4)));
+    {
+      const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      float axes[9];
+      uint32_t nt = 0;
+      KN_CK(sort_source(d_q, (uint32_t)n_query, gr.grid, I, d_qs, s, &d_tiles, &d_tc, axes, &nt));
+    }
+    KnnArgs a{};
+    a.g = gr.grid; a.queries = d_qs; a.nq = (uint32_t)n_query; a.k = (uint32_t)k; a.radius_sq = max_sq_dist;
+    if (idx_out) { KN_CK(hipMalloc(&d_idx, n_query * k * sizeof(uint32_t))); a.out_idx = d_idx; }
+    if (idx_out && d2_out) { KN_CK(hipMalloc(&d_d2, n_query * k * sizeof(float))); a.out_d2 = d_d2; }
+    if (cnt_out) { KN_CK(hipMalloc(&d_cnt, n_query * sizeof(uint32_t))); a.out_cnt = d_cnt; }
+    a.do_pca = do_pca ? 1 : 0;
+    if (do_pca) {
+      KN_CK(hipMalloc(&d_nrm, 3 * n_query * sizeof(float)));
+      a.ref_xyz = d_ref; a.normals = d_nrm;
+      if (curvature_out) { KN_CK(hipMalloc(&d_curv, n_query * sizeof(float))); a.curvature = d_curv; }
+      a.use_vp = 0;
+      if (view_point && std::isfinite(view_point[0]) && std::isfinite(view_point[1]) && std::isfinite(view_point[2])) {   // normal_estimation.hpp:366
+        a.use_vp = 1;
+        for (int i = 0; i < 3; ++i) a.vp[i] = view_point[i];
+      }
+    }
+    hipLaunchKernelGGL(k_knn, dim3((unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), k * KNN_THREADS * sizeof(unsigned long long), s, a);
+    KN_CK(hipGetLastError());
+    if (idx_out) KN_CK(hipMemcpyAsync(idx_out, d_idx, n_query * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (idx_out && d2_out) KN_CK(hipMemcpyAsync(d2_out, d_d2, n_query * k * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (cnt_out) KN_CK(hipMemcpyAsync(cnt_out, d_cnt, n_query * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (do_pca) KN_CK(hipMemcpyAsync(normals_out, d_nrm, 3 * n_query * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (do_pca && curvature_out) KN_CK(hipMemcpyAsync(curvature_out, d_curv, n_query * sizeof(float), hipMemcpyDeviceToHost, s));
+    KN_CK(hipStreamSynchronize(s));
+  }
+done:
+  if (have_grid) free_grid(gr.grid);
+  if (own_ref && d_ref) (void)hipFree(d_ref);
+  if (own_q && d_q) (void)hipFree(d_q);
+  if (d_qs) (void)hipFree(d_qs);
+  if (d_tiles) (void)hipFree(d_tiles);
+  if (d_tc) (void)hipFree(d_tc);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_d2) (void)hipFree(d_d2);
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (d_nrm) (void)hipFree(d_nrm);
+  if (d_curv) (void)hipFree(d_curv);
+  if (s) (void)hipStreamDestroy(s);
+  return rc;
+}
+
+}  // namespace
+}  // namespace cilhip
+
+extern "C" {
+
+int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k,
+                 float max_sq_dist, uint32_t* idx_out, float* d2_out, uint32_t* counts_out) {
+  if (!idx_out && !counts_out) return CILHIP_ERR_INVALID;
+  return cilhip::knn_impl(device, ref_xyz, n_ref, query_xyz, n_query, mem, k, max_sq_dist, idx_out, d2_out, counts_out, false, nullptr, nullptr,
+                          nullptr);
+}
+
+int cilhip_normals_knn3f(int device, const float* xyz, size_t n, int mem, size_t k, float max_sq_dist, const float* view_point,
+                         float* normals_out, float* curvature_out) {
+  if (!normals_out && n) return CILHIP_ERR_INVALID;
+  return cilhip::knn_impl(device, xyz, n, nullptr, n, mem, k, max_sq_dist, nullptr, nullptr, nullptr, true, view_point, normals_out, curvature_out);
+}
+
+}  // extern "C"

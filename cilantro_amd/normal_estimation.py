@@ -1,0 +1,103 @@
+"""Python mirrors of the k-NN side of cilantro's KDTree3f and of NormalEstimation3f on top of the C ABI
+(cilhip_knn3f, cilhip_normals_knn3f).
+
+    tree = KDTree3f(points)                                   # core/kd_tree.hpp:144-388
+    idx, d2, cnt = tree.kNNSearch(queries, k)                  # :233-240   (rows padded with -1 / +inf)
+    idx, d2, cnt = tree.kNNInRadiusSearch(queries, k, radius)  # :303-318   (radius is a SQUARED distance, as everywhere)
+
+    ne = NormalEstimation3f(points).setViewPoint([0, 0, 0])   # core/normal_estimation.hpp
+    normals, curvature = ne.getNormalsAndCurvatureKNN(k)       # :72-80
+    normals = ne.getNormalsKNNInRadius(k, radius)              # :189-196
+
+Radius-only neighbourhoods (variable, unbounded size) are not implemented and raise.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .icp import _as_cloud
+
+
+class KDTree3f:
+    def __init__(self, points, device=0):
+        self._L = capi.load()
+        self._points = points
+        self._device = device
+
+    def _search(self, queries, k, radius_sq):
+        p, n, mem, keep = _as_cloud(self._points)
+        if queries is None:
+            qp, nq = None, n
+        else:
+            qp, nq, qmem, qkeep = _as_cloud(queries)
+            if qmem != mem:
+                raise ValueError("reference points and queries must live in the same memory space")
+        k = int(k)
+        idx = np.zeros((nq, k), np.uint32); d2 = np.zeros((nq, k), np.float32); cnt = np.zeros(nq, np.uint32)
+        rc = self._L.cilhip_knn3f(self._device, p, n, qp, nq, mem, k, C.c_float(radius_sq), idx.ctypes.data, d2.ctypes.data, cnt.ctypes.data)
+        if rc != capi.OK:
+            raise capi.CilhipError(rc, "cilhip_knn3f failed (no HIP device, k > 32, or bad arguments)")
+        out = idx.astype(np.int64)
+        out[idx == capi.NONE_IDX] = -1
+        return out, d2, cnt.astype(np.int64)
+
+    def kNNSearch(self, queries, k):
+        """queries None: the tree's own points"""
+        return self._search(queries, k, np.inf)
+
+    def kNNInRadiusSearch(self, queries, k, radius):
+        return self._search(queries, k, float(radius))
+
+    def nearestNeighborSearch(self, queries):
+        idx, d2, _ = self._search(queries, 1, np.inf)
+        return idx[:, 0], d2[:, 0]
+
+
+class NormalEstimation3f:
+    def __init__(self, points, device=0):
+        self._L = capi.load()
+        self._points = points
+        self._device = device
+        self._vp = None          # normal_estimation.hpp:24: NaN view point = no orientation step
+
+    def setViewPoint(self, vp):
+        self._vp = None if vp is None else np.ascontiguousarray(vp, np.float32).reshape(3)
+        return self
+
+    def getViewPoint(self):
+        return np.full(3, np.nan, np.float32) if self._vp is None else self._vp
+
+    def _run(self, k, radius_sq, want_curvature):
+        p, n, mem, keep = _as_cloud(self._points)
+        nrm = np.zeros((n, 3), np.float32)
+        cur = np.zeros(n, np.float32) if want_curvature else None
+        rc = self._L.cilhip_normals_knn3f(self._device, p, n, mem, int(k), C.c_float(radius_sq),
+                                          None if self._vp is None else self._vp.ctypes.data, nrm.ctypes.data,
+                                          None if cur is None else cur.ctypes.data)
+        if rc != capi.OK:
+            raise capi.CilhipError(rc, "cilhip_normals_knn3f failed (no HIP device, k > 32, or bad arguments)")
+        return nrm, cur
+
+    def getNormalsAndCurvatureKNN(self, k):
+        return self._run(k, np.inf, True)
+
+    def getNormalsKNN(self, k):
+        return self._run(k, np.inf, False)[0]
+
+    def getCurvatureKNN(self, k):
+        return self._run(k, np.inf, True)[1]
+
+    def getNormalsAndCurvatureKNNInRadius(self, k, radius):
+        return self._run(k, float(radius), True)
+
+    def getNormalsKNNInRadius(self, k, radius):
+        return self._run(k, float(radius), False)[0]
+
+    def getCurvatureKNNInRadius(self, k, radius):
+        return self._run(k, float(radius), True)[1]
+
+    def getNormalsAndCurvatureRadius(self, radius):
+        raise NotImplementedError("radius-only neighbourhoods (unbounded size) are not implemented on the GPU path")
+
+    getNormalsRadius = getCurvatureRadius = getNormalsAndCurvatureRadius

@@ -217,6 +217,26 @@ int cilhip_plane_score3f(int device, const float* xyz, size_t n, int mem, const 
 /* estimateModel() over ALL points (ransac_hyperplane_estimator.hpp:22-25, :70-76): PCA plane fit. */
 int cilhip_plane_fit3f(int device, const float* xyz, size_t n, int mem, float plane_out[4]);
 
+/* ---- next tier: k-NN (k > 1) and NormalEstimation ------------------------- */
+/* KDTree<float,3,L2>::kNNSearch / kNNInRadiusSearch for a set of queries (core/kd_tree.hpp:216-256, :286-318;
+ * result adaptor :63-109): the k nearest reference points of every query with d2 < max_sq_dist (strict; pass
+ * INFINITY for a plain k-NN), ascending by (d2, index).  query_xyz == NULL: the reference points are the queries
+ * (every point then finds itself first).  1 <= k <= 32.  All outputs are HOST arrays:
+ * idx_out [n_query*k] (row per query, padded with 0xFFFFFFFF), d2_out [n_query*k] or NULL (padded with +inf),
+ * counts_out [n_query] or NULL (neighbours found).  Neighbour sets and distances are bit-identical to the
+ * reference except on exactly tied distances at the k-th place (there: lowest index here, first met there). */
+int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k,
+                 float max_sq_dist, uint32_t* idx_out, float* d2_out, uint32_t* counts_out);
+/* NormalEstimation<float,3>::estimateNormalsAndCurvatureKNN / ...KNNInRadius (core/normal_estimation.hpp:72-90,
+ * :166-187 -> :362-420): per point the k-NN neighbourhood (including the point itself), mean and covariance of it
+ * (core/covariance.hpp:140-170), normal = eigenvector of the smallest eigenvalue, curvature = l_min / (l0+l1+l2);
+ * fewer than 3 neighbours => NaN.  view_point: 3 floats; if all finite the normal is flipped to point towards it
+ * (:326-330), NULL / non-finite: sign left as the eigen-solver gives it (as in the reference).
+ * normals_out: HOST 3*n, curvature_out: HOST n or NULL.  f32 per-term arithmetic, f64 accumulation and f64 Jacobi
+ * eigen-solve in place of Eigen's f32 SelfAdjointEigenSolver. */
+int cilhip_normals_knn3f(int device, const float* xyz, size_t n, int mem, size_t k, float max_sq_dist, const float* view_point,
+                         float* normals_out, float* curvature_out);
+
 /* ---- introspection (bench / tests) ----------------------------------------------------------- */
 typedef struct {
   int nx, ny, nz;        /* grid dims */

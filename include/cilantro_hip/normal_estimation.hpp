@@ -1,0 +1,99 @@
+// cilantro_hip/normal_estimation.hpp -- C++ host-side mirrors of the k-NN side of cilantro's KDTree3f and of
+// NormalEstimation3f, header-only on top of the C ABI (c_api.h):
+//
+//   KDTree3f              core/kd_tree.hpp:144-388     kNNSearch :216-256, kNNInRadiusSearch :286-318
+//   NormalEstimation3f    core/normal_estimation.hpp   get/estimate Normals[AndCurvature]KNN[InRadius] :72-221
+//
+// Same method names, argument meaning (radii are SQUARED distances) and defaults as the reference; clouds are
+// non-owning (pointer, count) views.  Radius-only neighbourhoods are not implemented on the GPU path and throw.
+// No CPU fallback: a failing C-ABI call throws.
+#pragma once
+
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "c_api.h"
+#include "icp.hpp"
+
+namespace cilantro_hip {
+
+// core/nearest_neighbors.hpp:7-47
+struct Neighbor {
+  size_t index;
+  float value;
+};
+typedef std::vector<Neighbor> Neighborhood;
+typedef std::vector<Neighborhood> NeighborhoodSet;
+
+class KDTree3f {
+public:
+  explicit KDTree3f(const ConstPointsView& points, int device = 0) : points_(points), device_(device) {}
+
+  // kd_tree.hpp:233-240 / :303-311: one Neighborhood per query, ascending distance
+  NeighborhoodSet kNNSearch(const ConstPointsView& queries, size_t k) const { return search(queries, k, std::numeric_limits<float>::infinity()); }
+  NeighborhoodSet kNNInRadiusSearch(const ConstPointsView& queries, size_t k, float radius) const { return search(queries, k, radius); }
+  const ConstPointsView& getPointsMatrixMap() const { return points_; }
+
+private:
+  NeighborhoodSet search(const ConstPointsView& queries, size_t k, float radius) const {
+    const size_t nq = queries.cols();
+    std::vector<uint32_t> idx(nq * k ? nq * k : 1), cnt(nq ? nq : 1);
+    std::vector<float> d2(nq * k ? nq * k : 1);
+    const int rc = cilhip_knn3f(device_, points_.data(), points_.cols(), queries.data(), nq, CILHIP_MEM_HOST, k, radius, idx.data(), d2.data(),
+                                cnt.data());
+    if (rc != CILHIP_OK) throw std::runtime_error("cilhip_knn3f failed (rc " + std::to_string(rc) + ")");
+    NeighborhoodSet out(nq);
+    for (size_t i = 0; i < nq; ++i) {
+      out[i].resize(cnt[i]);
+      for (size_t j = 0; j < cnt[i]; ++j) out[i][j] = Neighbor{(size_t)idx[i * k + j], d2[i * k + j]};
+    }
+    return out;
+  }
+  ConstPointsView points_;
+  int device_;
+};
+
+class NormalEstimation3f {
+public:
+  explicit NormalEstimation3f(const ConstPointsView& points, int device = 0) : points_(points), device_(device) {
+    const float nan = std::numeric_limits<float>::quiet_NaN();   // normal_estimation.hpp:24: no view point by default
+    view_point_[0] = view_point_[1] = view_point_[2] = nan;
+  }
+
+  const float* getViewPoint() const { return view_point_; }
+  NormalEstimation3f& setViewPoint(const float vp[3]) { for (int i = 0; i < 3; ++i) view_point_[i] = vp[i]; return *this; }
+  NormalEstimation3f& setViewPoint(float x, float y, float z) { view_point_[0] = x; view_point_[1] = y; view_point_[2] = z; return *this; }
+
+  // normals: packed xyz per point (VectorSet<float,3>), curvature: one float per point
+  const NormalEstimation3f& getNormalsAndCurvatureKNN(std::vector<float>& normals, std::vector<float>& curvature, size_t k) const {
+    run(normals, &curvature, k, std::numeric_limits<float>::infinity());
+    return *this;
+  }
+  std::vector<float> getNormalsKNN(size_t k) const { std::vector<float> n; run(n, nullptr, k, std::numeric_limits<float>::infinity()); return n; }
+  std::vector<float> getCurvatureKNN(size_t k) const { std::vector<float> n, c; run(n, &c, k, std::numeric_limits<float>::infinity()); return c; }
+  const NormalEstimation3f& getNormalsAndCurvatureKNNInRadius(std::vector<float>& normals, std::vector<float>& curvature, size_t k, float radius) const {
+    run(normals, &curvature, k, radius);
+    return *this;
+  }
+  std::vector<float> getNormalsKNNInRadius(size_t k, float radius) const { std::vector<float> n; run(n, nullptr, k, radius); return n; }
+  std::vector<float> getCurvatureKNNInRadius(size_t k, float radius) const { std::vector<float> n, c; run(n, &c, k, radius); return c; }
+  std::vector<float> getNormalsRadius(float) const { throw std::invalid_argument("radius-only neighbourhoods are not implemented on the GPU path"); }
+
+private:
+  void run(std::vector<float>& normals, std::vector<float>* curvature, size_t k, float radius) const {
+    const size_t n = points_.cols();
+    normals.assign(3 * n, 0.0f);
+    if (curvature) curvature->assign(n, 0.0f);
+    const int rc = cilhip_normals_knn3f(device_, points_.data(), n, CILHIP_MEM_HOST, k, radius, view_point_, normals.data(),
+                                        curvature ? curvature->data() : nullptr);
+    if (rc != CILHIP_OK) throw std::runtime_error("cilhip_normals_knn3f failed (rc " + std::to_string(rc) + ")");
+  }
+  ConstPointsView points_;
+  int device_;
+  float view_point_[3];
+};
+
+}  // namespace cilantro_hip

@@ -110,6 +110,8 @@ def lib():
         L.orc_plane_ransac.restype = C.c_size_t
         L.orc_plane_ransac.argtypes = [_f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
                                        _f32p, _f32p, _u32p, C.POINTER(C.c_size_t)]
+        L.orc_knn_batch.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, C.c_float, _i64p, _f32p, _u32p]
+        L.orc_normals_knn.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_int, _f32p, _f32p]
         _lib = L
     return _lib
 
@@ -371,3 +373,20 @@ def plane_ransac(pts, samples, thresh, target_inliers, max_iter=None, re_estimat
     it = lib().orc_plane_ransac(pts, n, samples, max_iter, np.float32(thresh), target_inliers, int(re_estimate), mode,
                                 pl, res, inl, C.byref(k))
     return pl, res, inl[:k.value].copy(), int(it)
+
+
+# ---- k-NN batch + NormalEstimation (core/kd_tree.hpp kNNSearch, core/normal_estimation.hpp) -------------
+def knn_batch(tree, queries, k, radius_sq=np.inf):
+    """tree: oracle.KDTree (restatement, not the _ref one) -> (idx int64 [nq,k] -1 padded, d2 [nq,k], counts)"""
+    q = _c(queries).reshape(-1, 3)
+    idx = np.zeros((len(q), k), np.int64); d2 = np.zeros((len(q), k), np.float32); cnt = np.zeros(len(q), np.uint32)
+    lib().orc_knn_batch(tree.h, q, len(q), k, np.float32(radius_sq), idx.reshape(-1), d2.reshape(-1), cnt)
+    return idx, d2, cnt
+
+
+def normals_knn(pts, k, radius_sq=np.inf, view_point=None, mode=1):
+    pts = _c(pts).reshape(-1, 3)
+    nrm = np.zeros((len(pts), 3), np.float32); cur = np.zeros(len(pts), np.float32)
+    vp = None if view_point is None else np.ascontiguousarray(view_point, np.float32)
+    lib().orc_normals_knn(pts, len(pts), k, np.float32(radius_sq), None if vp is None else vp.ctypes.data, mode, nrm.reshape(-1), cur)
+    return nrm, cur

@@ -4,6 +4,7 @@
 //   test_model_estimation                      : needs a GPU; exit 0 iff every check passes
 //   test_model_estimation --expect-no-device   : CPU box; exit 0 iff the calls fail loudly
 #include <cilantro_hip/model_estimation.hpp>
+#include <cilantro_hip/normal_estimation.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -79,6 +80,35 @@ int main(int argc, char** argv) {
     if (km.getNumberOfPerformedIterations() != itk || !(cmax <= 1e-6f) || ldiff > 2) ++failures;
     km.cluster(5, 3);
     if (km.getNumberOfClusters() != 5) ++failures;
+
+    // KDTree3f::kNNSearch and NormalEstimation3f (examples/normal_estimation.cpp uses k-NN normals with a view point)
+    const size_t nq = 2000, kk = 9;
+    KDTree3f tree(xv);
+    const NeighborhoodSet nns = tree.kNNSearch(ConstPointsView(x.data(), nq), kk);
+    orc_kdtree* ot = orc_kdtree_build(x.data(), n, 10);
+    std::vector<int64_t> oi(nq * kk); std::vector<float> od(nq * kk); std::vector<uint32_t> oc(nq);
+    orc_knn_batch(ot, x.data(), nq, kk, INFINITY, oi.data(), od.data(), oc.data());
+    size_t kbad = 0;
+    for (size_t i = 0; i < nq; ++i) {
+      kbad += nns[i].size() != oc[i];
+      for (size_t j = 0; j < nns[i].size() && j < oc[i]; ++j) kbad += (nns[i][j].value != od[i * kk + j]) || ((int64_t)nns[i][j].index != oi[i * kk + j]);
+    }
+    orc_kdtree_free(ot);
+    NormalEstimation3f ne(xv);
+    ne.setViewPoint(0.0f, 0.0f, 10.0f);
+    std::vector<float> nrm, cur, onrm(3 * n), ocur(n);
+    ne.getNormalsAndCurvatureKNN(nrm, cur, 10);
+    const float vp[3] = {0.0f, 0.0f, 10.0f};
+    orc_normals_knn(x.data(), n, 10, INFINITY, vp, ORC_MODE_MIXED, onrm.data(), ocur.data());
+    size_t nbad = 0, nwell = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (!(cur[i] < 0.2f)) continue;   // nearly isotropic neighbourhoods: the normal itself is ill-conditioned
+      ++nwell;
+      const float dot = nrm[3 * i] * onrm[3 * i] + nrm[3 * i + 1] * onrm[3 * i + 1] + nrm[3 * i + 2] * onrm[3 * i + 2];
+      nbad += !(dot > 1.0f - 1e-4f) || !(std::fabs(cur[i] - ocur[i]) < 1e-4f);
+    }
+    std::printf("k-NN: %zu mismatches vs oracle over %zu queries; normals: %zu of %zu well-defined ones differ\n", kbad, nq, nbad, nwell);
+    if (kbad > 2 || nbad * 1000 > nwell) ++failures;
   } catch (const std::runtime_error& e) {
     if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }
     std::printf("FAIL: %s\n", e.what());

