@@ -76,6 +76,13 @@ struct cilhip_ctx {
   void* d_sel_state = nullptr;
   unsigned long long* d_winner = nullptr;  // [n_target]
 
+  // other search directions (correspondence_search_kd_tree.hpp:185-222): the correspondence set is a pair list
+  int search_dir = 0;             // 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH
+  bool reciprocal = false;        // require_reciprocality_ (BOTH only)
+  PairSet pairs;
+  bool have_pairs = false;        // `pairs` holds the result of the last find_correspondences
+  IcpState* d_state_id = nullptr; // a state holding the identity transform (the reverse search transforms nothing)
+
   // sharded-run state
   cilhip_icp_params run_prm{};
   bool run_active = false;
@@ -160,6 +167,8 @@ void cilhip_destroy(cilhip_ctx* c) {
   free_source(c);
   if (c->has_target) free_grid(c->grid);
   if (c->d_state) (void)hipFree(c->d_state);
+  if (c->d_state_id) (void)hipFree(c->d_state_id);
+  free_pairs(c->pairs);
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_inv_perm) (void)hipFree(c->d_inv_perm);
   if (c->d_sel_state) (void)hipFree(c->d_sel_state);
@@ -195,6 +204,12 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
+  if (!strcmp(key, "search_direction")) {
+    if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "search_direction: 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH");
+    c->search_dir = (int)value; c->have_nn = false; c->have_pairs = false;
+    return CILHIP_OK;
+  }
+  if (!strcmp(key, "require_reciprocality")) { c->reciprocal = value != 0.0; c->have_nn = false; c->have_pairs = false; return CILHIP_OK; }
   if (!strcmp(key, "cell_occupancy")) { c->cell_occupancy = value; return CILHIP_OK; }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
@@ -383,6 +398,23 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   return a;
 }
 
+// Search directions FIRST_TO_SECOND / BOTH with the transform held by c->d_state: fills c->pairs (post-filters included).
+static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq) {
+  if (!c->d_state_id) {
+    CK(c, hipMalloc(&c->d_state_id, sizeof(IcpState)));
+    const float zero[3] = {0, 0, 0};
+    launch_init_state(c->d_state_id, kIdentity, zero, c->stream);
+  }
+  if (c->search_dir == 2 && c->ns && c->grid.n) {   // forward half of BOTH: the usual search, no filters yet
+    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->ntiles, c->stream);
+    else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
+  }
+  const hipError_t e = find_pairs(c->grid, c->d_src_sorted, c->d_src_nrm ? c->d_src_nrm_sorted : nullptr, c->ns, c->d_state, c->d_state_id, max_sq,
+                                  c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2, c->pairs, c->stream);
+  if (e != hipSuccess) { c->err = std::string("find_pairs: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
+  return CILHIP_OK;
+}
+
 int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, size_t* n_found) {
   if (!c || !T) return CILHIP_ERR_INVALID;
   CK(c, hipSetDevice(c->device));
@@ -390,6 +422,17 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   if (rc) return rc;
   launch_init_state(c->d_state, T, c->src_mean, c->stream);
   IterArgs a = make_iter_args(c, max_sq);
+  if (c->search_dir != 0) {
+    if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
+    rc = run_pair_search(c, a, max_sq);
+    if (rc) return rc;
+    memcpy(c->nn_T, T, sizeof(c->nn_T));
+    c->have_nn = false;
+    c->have_pairs = true;
+    if (n_found) *n_found = c->pairs.count;
+    return CILHIP_OK;
+  }
+  c->have_pairs = false;
   if (c->ns) {
     if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
@@ -420,6 +463,7 @@ static int scatter_to_original(cilhip_ctx* c) {
 
 int cilhip_get_nn(cilhip_ctx* c, uint32_t* nn_idx, float* nn_d2, int mem) {
   if (!c) return CILHIP_ERR_INVALID;
+  if (c->have_pairs) return fail(c, CILHIP_ERR_UNSUPPORTED, "get_nn: the last search ran in a direction whose result is a pair list; use get_correspondences");
   if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "get_nn: no search has been run");
   CK(c, hipSetDevice(c->device));
   int rc = scatter_to_original(c);
@@ -433,6 +477,35 @@ int cilhip_get_nn(cilhip_ctx* c, uint32_t* nn_idx, float* nn_d2, int mem) {
 
 int cilhip_get_correspondences(cilhip_ctx* c, uint64_t* i1, uint64_t* i2, float* val, size_t cap, size_t* n_out) {
   if (!c || !n_out) return CILHIP_ERR_INVALID;
+  if (c->have_pairs) {
+    // pair list of FIRST_TO_SECOND / BOTH: stored ascending (first, second); the reference leaves the set sorted by
+    // value after the fraction filter (correspondence.hpp:61) and by (indexInSecond, value) after the FIRST_TO_SECOND
+    // one-to-one filter (:74-82) -- reproduce that (ties keep the stored order)
+    const size_t cnt = c->pairs.count;
+    *n_out = cnt;
+    if (cnt > cap) return fail(c, CILHIP_ERR_INVALID, "get_correspondences: capacity too small");
+    if (cnt == 0) return CILHIP_OK;
+    CK(c, hipSetDevice(c->device));
+    std::vector<uint32_t> f(cnt), sc(cnt);
+    std::vector<float> v(cnt);
+    CK(c, hipMemcpyAsync(f.data(), c->pairs.first, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipMemcpyAsync(sc.data(), c->pairs.second, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipMemcpyAsync(v.data(), c->pairs.d2, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    std::vector<size_t> ord(cnt);
+    for (size_t k = 0; k < cnt; ++k) ord[k] = k;
+    const bool frac = c->inlier_fraction > 0.0 && c->inlier_fraction < 1.0;
+    if (c->one_to_one && c->search_dir == 1)
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return sc[x] != sc[y] ? sc[x] < sc[y] : v[x] < v[y]; });
+    else if (frac)
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return v[x] < v[y]; });
+    for (size_t k = 0; k < cnt; ++k) {
+      if (i1) i1[k] = f[ord[k]];
+      if (i2) i2[k] = sc[ord[k]];
+      if (val) val[k] = v[ord[k]];
+    }
+    return CILHIP_OK;
+  }
   if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "get_correspondences: no search has been run");
   std::vector<uint32_t> idx(c->ns ? c->ns : 1);
   std::vector<float> d2(c->ns ? c->ns : 1);
@@ -619,6 +692,56 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     sa.nblocks = 0;
     sa.reduced = c->d_sums;
   }
+  if (c->search_dir != 0) {
+    // FIRST_TO_SECOND / BOTH: the correspondence set is a pair list rebuilt every iteration (a grid over the transformed
+    // source, like the reference's per-iteration kd-tree); host-driven loop, the accumulation kernels stream over the pairs
+    if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
+    if (gn && opt_steps == 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "max_opt_iter == 0 is not supported");
+    hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
+    CK(c, hipEventRecord(e_beg, c->stream));
+    for (size_t it = 0; it < p->max_iter; ++it) {
+      rc = run_pair_search(c, a, p->max_sq_dist);
+      if (rc) return rc;
+      IterArgs pa = a;
+      pa.src = c->pairs.src_view; pa.src_nrm = c->d_src_nrm ? c->pairs.nrm_view : nullptr; pa.ns = c->pairs.count; pa.nn_pos = c->pairs.posd;
+      const int pnb = iter_num_blocks(pa.ns);
+      if (pnb > c->partial_blocks) {
+        if (c->d_partials) (void)hipFree(c->d_partials);
+        c->d_partials = nullptr; c->partial_blocks = 0;
+        CK(c, hipMalloc(&c->d_partials, (size_t)pnb * SUMS_MAX * sizeof(double)));
+        c->partial_blocks = pnb;
+      }
+      pa.partials = c->d_partials;
+      for (size_t st = 0; st < opt_steps; ++st) {
+        pa.skip_if_inner_done = (st > 0);
+        sa.gn_last_step = (st + 1 == opt_steps);
+        if (pa.ns) {
+          launch_iter(pa, im, false, false, pnb, c->stream);
+          const int rows = launch_reduce_stage1(c->d_partials, pnb, c->d_stage, c->stream);
+          sa.partials = rows ? c->d_stage : c->d_partials;
+          sa.nblocks = rows ? rows : pnb;
+          sa.reduced = nullptr;
+        } else {
+          CK(c, hipMemsetAsync(c->d_sums, 0, SUMS_MAX * sizeof(double), c->stream));
+          sa.nblocks = 0;
+          sa.reduced = c->d_sums;
+        }
+        launch_solve(sa, c->stream);
+      }
+      rc = read_state(c, out);
+      if (rc) return rc;
+      if (out->last_delta_norm < p->conv_tol) break;   // the device sets `done` by the same test (icp_base.hpp:83)
+    }
+    CK(c, hipEventRecord(e_end, c->stream));
+    CK(c, hipGetLastError());
+    rc = read_state(c, out);
+    if (rc) return rc;
+    c->have_nn = false; c->have_pairs = false;
+    float ms = 0.f;
+    CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
+    c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
+    return CILHIP_OK;
+  }
   const bool timing = c->kernel_timing && p->max_iter <= 4096;
   hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
   CK(c, hipEventRecord(e_beg, c->stream));
@@ -693,6 +816,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   CK(c, hipSetDevice(c->device));
   if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
   if (filters_active(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "inlier_fraction / one_to_one are global filters: not available in sharded runs");
+  if (c->search_dir != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available in sharded runs");
   const float* Ti = T0 ? T0 : kIdentity;
   int rc = ensure_sorted(c, Ti);
   if (rc) return rc;

@@ -133,6 +133,31 @@ void launch_filter_fraction(const float4* src_sorted, uint32_t* nn_pos, const fl
 
 size_t filter_state_bytes() { return sizeof(SelectState); }
 
+// Generic form for a plain list of values (the pair lists of the other search directions): keep the
+// k = llround(fraction * n) smallest, ties in list order.  flags[i] = 1 for kept entries.
+__global__ void k_build_keys_pos(const float* __restrict__ d2, uint32_t n, unsigned long long* keys, SelectState* st) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    keys[i] = ((unsigned long long)__float_as_uint(d2[i]) << 32) | (unsigned long long)i;
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->n_found = n;
+}
+__global__ void k_flags_fraction(const unsigned long long* __restrict__ keys, uint32_t n, const SelectState* st, uint32_t* flags) {
+  const bool none = st->keep_none != 0;
+  const unsigned long long thr = st->threshold;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) flags[i] = (!none && keys[i] <= thr) ? 1u : 0u;
+}
+void launch_select_fraction(const float* d2, uint32_t n, double fraction, unsigned long long* keys, void* state, uint32_t* flags, hipStream_t s) {
+  if (n == 0) return;
+  SelectState* st = static_cast<SelectState*>(state);
+  (void)hipMemsetAsync(st, 0, sizeof(SelectState), s);
+  hipLaunchKernelGGL(k_build_keys_pos, dim3(nblk(n)), dim3(256), 0, s, d2, n, keys, st);
+  hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, s, st, fraction);
+  for (int byte = 7; byte >= 0; --byte) {
+    hipLaunchKernelGGL(k_select_hist, dim3(nblk(n)), dim3(256), 0, s, keys, n, st, byte);
+    hipLaunchKernelGGL(k_select_pick, dim3(1), dim3(256), 0, s, st, byte);
+  }
+  hipLaunchKernelGGL(k_flags_fraction, dim3(nblk(n)), dim3(256), 0, s, keys, n, st, flags);
+}
+
 // winner: [n_target] u64 scratch
 void launch_filter_one_to_one(const float4* src_sorted, uint32_t* nn_pos, const float* nn_d2, uint32_t ns,
                               unsigned long long* winner, uint32_t n_target, hipStream_t s) {

@@ -120,6 +120,23 @@ void launch_filter_fraction(const float4* src_sorted, uint32_t* nn_pos, const fl
 void launch_filter_one_to_one(const float4* src_sorted, uint32_t* nn_pos, const float* nn_d2, uint32_t ns,
                               unsigned long long* winner, uint32_t n_target, hipStream_t s);
 size_t filter_state_bytes();
+void launch_select_fraction(const float* d2, uint32_t n, double fraction, unsigned long long* keys, void* state, uint32_t* flags, hipStream_t s);
+
+// bidir.hip -- search directions FIRST_TO_SECOND / BOTH: the correspondence set as a device pair list
+struct PairSet {
+  uint32_t *first = nullptr, *second = nullptr;   // ORIGINAL target / source indices, ascending (first, second)
+  uint32_t *posd = nullptr, *poss = nullptr;      // sorted-target / sorted-source positions of the same pairs
+  float* d2 = nullptr;
+  uint32_t *first2 = nullptr, *second2 = nullptr, *posd2 = nullptr, *poss2 = nullptr;   // ping-pong buffers of the post-filters
+  float* d2b = nullptr;
+  float4 *src_view = nullptr, *nrm_view = nullptr;   // sorted-source records (and normals) gathered per pair: what the accumulation streams over
+  size_t cap = 0;
+  uint32_t count = 0;
+};
+void free_pairs(PairSet& p);
+hipError_t find_pairs(const GridDev& g, const float4* src_sorted, const float4* src_nrm_sorted, uint32_t ns, const IcpState* state,
+                      const IcpState* id_state, float max_sq, int direction, bool reciprocal, double inlier_fraction, bool one_to_one,
+                      const uint32_t* fwd_pos, const float* fwd_d2, PairSet& out, hipStream_t s);
 
 // grid_build.hip
 struct GridBuildResult {

@@ -459,7 +459,6 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   uint32_t nj[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) nj[k] = rj[k] + OCT_CAND;
-#ifndef CILHIP_EXP_NO_OVERFLOW
 #pragma unroll
   for (int x = 0; x < OCT_EXTRA; ++x) {
     const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
@@ -488,7 +487,6 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     eval_candidate(p2, qxy, qz, jx + 2, bk, bl);
     eval_candidate(p3, qxy, qz, jx + 3, bk, bl);
   }
-#endif
   best.key = bk;
   // LDS index -> global position: the winner normally lies in the row of its run (one table read); an
   // over-read winner past the end of that row (or one picked up through a clipped run) takes the binary search
@@ -608,12 +606,6 @@ void debug_dump_phase_clocks() {
 #else
 #define PHASE_CLK(k)
 #endif
-#ifdef CILHIP_EXP_STOP_AFTER   /* dev experiment: leave the kernel after phase k (counter deltas per phase) */
-#define STOP_SINK 0.0f
-#define STOP_AFTER(k) do { if ((k) == CILHIP_EXP_STOP_AFTER) { if ((k) > 0 && tile.x + threadIdx.x < tile.y) a.nn_d2[tile.x + threadIdx.x] = STOP_SINK; return; } } while (0)
-#else
-#define STOP_AFTER(k)
-#endif
 
 __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
                                                                   const float4* __restrict__ tile_center, uint32_t ntiles) {
@@ -716,7 +708,6 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   }
   __syncthreads();
   PHASE_CLK(0);
-  STOP_AFTER(0);
 
   // ---- 2b. row lengths -> LDS offsets (one wave, each lane a block of consecutive rows) ----
   if (threadIdx.x < 64) {
@@ -769,12 +760,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     octant_prepare(g, qx, qy, qz, min(max(cx, fx0), fx1), min(max(cy, fy0), fy1), min(max(cz, fz0), fz1), lox, loy, loz, RY, W1, oq[u]);
   }
   __syncthreads();
-#ifdef CILHIP_EXP_STOP_AFTER
-#undef STOP_SINK
-#define STOP_SINK (oq[0].qx + oq[0].bound + (float)oq[0].eb00 + (float)oq[0].row00 + oq[1].qy + oq[1].bound + (float)oq[1].eb00 + (float)oq[1].row00 + (float)flags + oq[0].qz + oq[1].qz + oq[0].qy + oq[1].qx)
-#endif
   PHASE_CLK(1);
-  STOP_AFTER(1);
   const uint32_t P = rowbase[rows];
   if (P > (uint32_t)TILE_CAP) {   // block-uniform: the data is much denser here than the LDS budget assumes
     if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
@@ -821,7 +807,6 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   }
   __syncthreads();
   PHASE_CLK(2);
-  STOP_AFTER(2);
   // ---- 3. per-lane exact search out of LDS (or hand-off to the clean-up pass) ----
   TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
 #pragma unroll
@@ -833,12 +818,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     best.pos = NONE_U32;
     bool defer = false;
     if ((flags >> (8 + u)) & 1u) {
-#ifdef CILHIP_EXP_NO_FULL
-      if (!octant_search(g, tl, oq[u], a.max_sq, best)) defer = true;
-      if (false) {
-#else
       if (!octant_search(g, tl, oq[u], a.max_sq, best)) {   // full 3x3x3 search (the cell is recomputed: rare path)
-#endif
         const int cx = (int)floorf((oq[u].qx - g.ox) * g.inv_cell), cy = (int)floorf((oq[u].qy - g.oy) * g.inv_cell),
                   cz = (int)floorf((oq[u].qz - g.oz) * g.inv_cell);
         defer = !search_in_tile(g, tl, oq[u].qx, oq[u].qy, oq[u].qz, cx, cy, cz, a.max_sq, best);

@@ -139,7 +139,7 @@ class Context:
         return idx[: self.n_source], d2[: self.n_source]
 
     def get_correspondences(self):
-        cap = max(self.n_source, 1)
+        cap = max(self.n_source + self.n_target, 1)   # search direction BOTH: up to one match per point of either cloud
         i1 = np.zeros(cap, np.uint64); i2 = np.zeros(cap, np.uint64); v = np.zeros(cap, np.float32)
         n = C.c_size_t(0)
         self._ck(self._L.cilhip_get_correspondences(self._h, i1.ctypes.data, i2.ctypes.data, v.ctypes.data, cap, C.byref(n)))
@@ -255,9 +255,15 @@ class CorrespondenceSearchHIP:
         return self.search_dir_
 
     def setSearchDirection(self, d):
-        if d != CorrespondenceSearchDirection.SECOND_TO_FIRST:
-            raise NotImplementedError("GPU engine implements SECOND_TO_FIRST only")
+        """correspondence_search_kd_tree.hpp:239-247.  FIRST_TO_SECOND / BOTH rebuild an index over the transformed
+        source every search (as the reference rebuilds its kd-tree) and hand the estimators a pair list."""
+        d = CorrespondenceSearchDirection(d)
         self.search_dir_ = d
+        if self._ctx is not None:
+            self._ctx.set_option("search_direction", {CorrespondenceSearchDirection.SECOND_TO_FIRST: 0,
+                                                      CorrespondenceSearchDirection.FIRST_TO_SECOND: 1,
+                                                      CorrespondenceSearchDirection.BOTH: 2}[d])
+        self._corr = None
         return self
 
     def getMaxDistance(self):
@@ -280,8 +286,11 @@ class CorrespondenceSearchHIP:
         return self.require_reciprocality_
 
     def setRequireReciprocality(self, b):
-        if b:
-            raise NotImplementedError("reciprocal search is not implemented on the GPU engine")
+        """:257-263: only read when the search direction is BOTH (set_intersection instead of set_union)"""
+        self.require_reciprocality_ = bool(b)
+        if self._ctx is not None:
+            self._ctx.set_option("require_reciprocality", 1.0 if b else 0.0)
+        self._corr = None
         return self
 
     def getOneToOne(self):

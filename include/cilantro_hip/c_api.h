@@ -267,7 +267,17 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   "inlier_fraction" (default 1): in (0,1) keeps the llround(f*n) correspondences of smallest value
  *                        (core/correspondence.hpp:57-66; equal values: lowest source index first),
  *   "one_to_one" (default 0): 1 keeps, per target point, the correspondence of smallest value (:84-95).
- *   Applied to cilhip_find_correspondences and inside cilhip_icp_run; not available in sharded runs. */
+ *   Applied to cilhip_find_correspondences and inside cilhip_icp_run; not available in sharded runs.
+ * Search direction (correspondence_search_kd_tree.hpp:185-222, setSearchDirection / setRequireReciprocality :239-263):
+ *   "search_direction" (default 0): 0 = SECOND_TO_FIRST (source points look for their nearest target point),
+ *                        1 = FIRST_TO_SECOND (every target point looks for its nearest TRANSFORMED source point; like the
+ *                        reference, an index over the transformed source is rebuilt for every search), 2 = BOTH (the
+ *                        union of the two sets in (indexInFirst, indexInSecond) order, kd_tree_utilities.hpp:65-101),
+ *   "require_reciprocality" (default 0): with BOTH, the intersection instead of the union.
+ *   With 1 / 2 the correspondence set is a pair list (up to n_target + n_source entries): read it with
+ *   cilhip_get_correspondences (cilhip_get_nn does not apply); the post-filters follow the reference's branches for
+ *   those directions (one-to-one: per source point for FIRST_TO_SECOND, a no-op for BOTH, correspondence.hpp:72-98);
+ *   cilhip_icp_run accumulates over the pair list.  Not available in sharded runs. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
  * kernels of the last cilhip_icp_run (sum over executed iterations). */

@@ -150,7 +150,7 @@ public:
   const SearchResult& getCorrespondences() const {
     if (!fetched_) {
       size_t n = 0;
-      const size_t cap = capacity_;  // = number of source points (every one may have a match)
+      const size_t cap = capacity_;  // = points of both clouds (direction BOTH: up to one match per point of either)
       std::vector<uint64_t> i1, i2;
       std::vector<float> v;
       i1.resize(cap ? cap : 1); i2.resize(cap ? cap : 1); v.resize(cap ? cap : 1);
@@ -163,10 +163,13 @@ public:
   }
 
   const CorrespondenceSearchDirection& getSearchDirection() const { return search_dir_; }
+  // correspondence_search_kd_tree.hpp:239-247.  FIRST_TO_SECOND / BOTH rebuild an index over the transformed source every
+  // search (as the reference rebuilds its kd-tree) and hand the estimators a pair list.
   CorrespondenceSearchHIP& setSearchDirection(const CorrespondenceSearchDirection& d) {
-    if (d != CorrespondenceSearchDirection::SECOND_TO_FIRST)
-      throw std::invalid_argument("CorrespondenceSearchHIP implements SECOND_TO_FIRST only");
+    const double v = d == CorrespondenceSearchDirection::SECOND_TO_FIRST ? 0.0 : d == CorrespondenceSearchDirection::FIRST_TO_SECOND ? 1.0 : 2.0;
+    internal::check(ctx_, cilhip_set_option(ctx_, "search_direction", v), "setSearchDirection");
     search_dir_ = d;
+    fetched_ = false;
     return *this;
   }
   CorrespondenceScalar getMaxDistance() const { return max_distance_; }
@@ -183,8 +186,10 @@ public:
     return *this;
   }
   bool getRequireReciprocality() const { return require_reciprocality_; }
-  CorrespondenceSearchHIP& setRequireReciprocality(bool b) {
-    if (b) throw std::invalid_argument("reciprocal search is not implemented on the GPU engine");
+  CorrespondenceSearchHIP& setRequireReciprocality(bool b) {  // :257-263: only read when the direction is BOTH
+    internal::check(ctx_, cilhip_set_option(ctx_, "require_reciprocality", b ? 1.0 : 0.0), "setRequireReciprocality");
+    require_reciprocality_ = b;
+    fetched_ = false;
     return *this;
   }
   bool getOneToOne() const { return one_to_one_; }
@@ -195,7 +200,7 @@ public:
     return *this;
   }
 
-  void setSourceCount_(size_t n) { capacity_ = n; }  // internal: result capacity
+  void setSourceCount_(size_t n) { capacity_ += n; }  // internal: result capacity (called with both cloud sizes)
 
 private:
   cilhip_ctx* ctx_;
@@ -303,6 +308,7 @@ public:
     internal::check(ctx_.get(), cilhip_set_source(ctx_.get(), src.data(), src.cols(), CILHIP_MEM_HOST), "set_source");
     n_src_ = src.cols();
     engine_.setSourceCount_(n_src_);
+    engine_.setSourceCount_(dst.cols());
   }
 
 private:
@@ -332,6 +338,7 @@ public:
     internal::check(ctx_.get(), cilhip_set_source(ctx_.get(), src_p.data(), src_p.cols(), CILHIP_MEM_HOST), "set_source");
     n_src_ = src_p.cols();
     engine_.setSourceCount_(n_src_);
+    engine_.setSourceCount_(dst_p.cols());
   }
 
   // four-cloud form (icp_common_instances.hpp:88-97): source normals => symmetric metric

@@ -347,6 +347,99 @@ size_t orc_filter_one_to_one(int64_t* di, int64_t* si, float* d2, size_t n) {
   return m;
 }
 
+/* ---- other search directions (correspondence_search_kd_tree.hpp:185-222, kd_tree_utilities.hpp:65-101) ----
+ * direction: 0 = SECOND_TO_FIRST (default: queries = transformed source, tree on dst),
+ *            1 = FIRST_TO_SECOND (queries = dst, tree REBUILT on the transformed source each call, :188-195),
+ *            2 = BOTH (:206-218): both unidirectional sets, sorted by (indexInFirst, indexInSecond), then
+ *                set_union, or set_intersection when `reciprocal` (kd_tree_utilities.hpp:76-100).
+ * Output capacity: nd + ns.  dst_tree may be NULL for direction 1. */
+static int cmp_lex(const void* x, const void* y) {
+  const orc_corr* p = (const orc_corr*)x; const orc_corr* q = (const orc_corr*)y;
+  if (p->a != q->a) return (p->a > q->a) - (p->a < q->a);
+  return (p->b > q->b) - (p->b < q->b);
+}
+static int cmp_value_lex(const void* x, const void* y) {
+  const orc_corr* p = (const orc_corr*)x; const orc_corr* q = (const orc_corr*)y;
+  if (p->v < q->v) return -1;
+  if (p->v > q->v) return 1;
+  return cmp_lex(x, y);
+}
+static int cmp_second_value_first(const void* x, const void* y) {
+  const orc_corr* p = (const orc_corr*)x; const orc_corr* q = (const orc_corr*)y;
+  if (p->b != q->b) return (p->b > q->b) - (p->b < q->b);
+  if (p->v < q->v) return -1;
+  if (p->v > q->v) return 1;
+  return (p->a > q->a) - (p->a < q->a);
+}
+
+size_t orc_find_correspondences_dir(const float* dst, size_t nd, const orc_kdtree* dst_tree, const float* q, size_t ns, float max_d,
+                                    int direction, int reciprocal, int64_t* di, int64_t* si, float* d2, int num_threads) {
+  if (direction == 0) return orc_find_correspondences(dst_tree, q, ns, max_d, di, si, d2, num_threads);
+  /* FIRST_TO_SECOND part: queries = dst points against a tree on the transformed source; ref_is_first = false */
+  orc_kdtree* qt = orc_kdtree_build(q, ns, 10);
+  const size_t capf = nd ? nd : 1;
+  int64_t* fa = (int64_t*)malloc(capf * sizeof(int64_t));
+  int64_t* fb = (int64_t*)malloc(capf * sizeof(int64_t));
+  float* fv = (float*)malloc(capf * sizeof(float));
+  /* orc_find_correspondences returns (index in the tree, query index): here (source index, dst index) */
+  const size_t nf = orc_find_correspondences(qt, dst, nd, max_d, fb, fa, fv, num_threads);
+  orc_kdtree_free(qt);
+  size_t n = 0;
+  if (direction == 1) {
+    for (size_t k = 0; k < nf; ++k) { di[k] = fa[k]; si[k] = fb[k]; d2[k] = fv[k]; }   /* ascending dst index */
+    n = nf;
+  } else {
+    const size_t caps = ns ? ns : 1;
+    int64_t* sa = (int64_t*)malloc(caps * sizeof(int64_t));
+    int64_t* sb = (int64_t*)malloc(caps * sizeof(int64_t));
+    float* sv = (float*)malloc(caps * sizeof(float));
+    const size_t nsf = orc_find_correspondences(dst_tree, q, ns, max_d, sa, sb, sv, num_threads);
+    orc_corr* A = (orc_corr*)malloc((nf ? nf : 1) * sizeof(orc_corr));
+    orc_corr* B = (orc_corr*)malloc((nsf ? nsf : 1) * sizeof(orc_corr));
+    for (size_t k = 0; k < nf; ++k) { A[k].a = fa[k]; A[k].b = fb[k]; A[k].v = fv[k]; }
+    for (size_t k = 0; k < nsf; ++k) { B[k].a = sa[k]; B[k].b = sb[k]; B[k].v = sv[k]; }
+    qsort(A, nf, sizeof(orc_corr), cmp_lex);
+    qsort(B, nsf, sizeof(orc_corr), cmp_lex);
+    size_t i = 0, j = 0;
+    while (i < nf || j < nsf) {            /* std::set_union / std::set_intersection (elements of A win on equality) */
+      int c;
+      if (i >= nf) c = 1; else if (j >= nsf) c = -1; else c = cmp_lex(&A[i], &B[j]);
+      if (c == 0) { di[n] = A[i].a; si[n] = A[i].b; d2[n] = A[i].v; ++n; ++i; ++j; }
+      else if (c < 0) { if (!reciprocal) { di[n] = A[i].a; si[n] = A[i].b; d2[n] = A[i].v; ++n; } ++i; }
+      else { if (!reciprocal) { di[n] = B[j].a; si[n] = B[j].b; d2[n] = B[j].v; ++n; } ++j; }
+    }
+    free(A); free(B); free(sa); free(sb); free(sv);
+  }
+  free(fa); free(fb); free(fv);
+  return n;
+}
+
+/* fraction filter on a set in (first, second) order: ties on the value keep that order */
+size_t orc_filter_fraction_lex(int64_t* di, int64_t* si, float* d2, size_t n, double f) {
+  if (!(f > 0.0 && f < 1.0)) return n;
+  orc_corr* c = (orc_corr*)malloc((n ? n : 1) * sizeof(orc_corr));
+  for (size_t i = 0; i < n; ++i) { c[i].a = di[i]; c[i].b = si[i]; c[i].v = d2[i]; }
+  qsort(c, n, sizeof(orc_corr), cmp_value_lex);
+  size_t keep = (size_t)llround(f * (double)n);
+  if (keep > n) keep = n;
+  for (size_t i = 0; i < keep; ++i) { di[i] = c[i].a; si[i] = c[i].b; d2[i] = c[i].v; }
+  free(c);
+  return keep;
+}
+
+/* core/correspondence.hpp:68-100, case FIRST_TO_SECOND: per indexInSecond keep the smallest value (ties: lowest indexInFirst) */
+size_t orc_filter_one_to_one_f2s(int64_t* di, int64_t* si, float* d2, size_t n) {
+  if (n == 0) return 0;
+  orc_corr* c = (orc_corr*)malloc(n * sizeof(orc_corr));
+  for (size_t i = 0; i < n; ++i) { c[i].a = di[i]; c[i].b = si[i]; c[i].v = d2[i]; }
+  qsort(c, n, sizeof(orc_corr), cmp_second_value_first);
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (i == 0 || c[i].b != si[m - 1]) { di[m] = c[i].a; si[m] = c[i].b; d2[m] = c[i].v; ++m; }
+  free(c);
+  return m;
+}
+
 void orc_nn_brute(const float* dst, size_t nd, const float* q, size_t nq, float max_d,
                   int64_t* nn_idx, float* nn_d2, int num_threads) {
 #ifdef _OPENMP
@@ -575,17 +668,18 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
   orc_mean3(dst_p, nd, prm->mode, dst_mean);
   orc_mean3(src_p, ns, prm->mode, src_mean);
   const size_t cap = ns ? ns : 1;
+  const size_t ccap = (prm->direction != 0 ? nd + ns : ns) + 1;      /* BOTH: up to nd + ns correspondences */
   float* q = (float*)malloc(3 * cap * sizeof(float));
-  int64_t* di = (int64_t*)malloc(cap * sizeof(int64_t));
-  int64_t* si = (int64_t*)malloc(cap * sizeof(int64_t));
-  float* d2 = (float*)malloc(cap * sizeof(float));
+  int64_t* di = (int64_t*)malloc(ccap * sizeof(int64_t));
+  int64_t* si = (int64_t*)malloc(ccap * sizeof(int64_t));
+  float* d2 = (float*)malloc(ccap * sizeof(float));
   float* nq_trans = (src_n && prm->metric == 1) ? (float*)malloc(3 * cap * sizeof(float)) : NULL;
   orc_kdtree* own = NULL;
   const orc_kdtree* tree = tree_in;
   float last = INFINITY;
   size_t it = 0;
   while (it < prm->max_iter) {
-    if (!tree) {                                           /* correspondence_search_kd_tree.hpp:202-203 lazy build */
+    if (!tree && prm->direction != 1) {                    /* correspondence_search_kd_tree.hpp:202-203 lazy build */
       double t0 = now_s();
       own = orc_kdtree_build(dst_p, nd, 10);
       tree = own;
@@ -593,9 +687,17 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
     }
     double t0 = now_s();
     orc_transform_points(T, src_p, ns, q);                 /* transformFeatures(tform) */
-    size_t nc = orc_find_correspondences(tree, q, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
-    nc = orc_filter_fraction(di, si, d2, nc, prm->inlier_fraction);      /* correspondence_search_kd_tree.hpp:224 */
-    if (prm->one_to_one) nc = orc_filter_one_to_one(di, si, d2, nc);     /* :225 */
+    size_t nc;
+    if (prm->direction == 0) {
+      nc = orc_find_correspondences(tree, q, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
+      nc = orc_filter_fraction(di, si, d2, nc, prm->inlier_fraction);      /* correspondence_search_kd_tree.hpp:224 */
+      if (prm->one_to_one) nc = orc_filter_one_to_one(di, si, d2, nc);     /* :225 */
+    } else {
+      nc = orc_find_correspondences_dir(dst_p, nd, tree, q, ns, prm->max_sq_dist, prm->direction, prm->reciprocal, di, si, d2,
+                                        prm->num_threads);
+      nc = orc_filter_fraction_lex(di, si, d2, nc, prm->inlier_fraction);
+      if (prm->one_to_one && prm->direction == 1) nc = orc_filter_one_to_one_f2s(di, si, d2, nc);   /* BOTH: no-op (:96-98) */
+    }
     double t1 = now_s();
     out->t_knn_s += t1 - t0;
     float Tn[16];

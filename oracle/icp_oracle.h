@@ -123,7 +123,9 @@ typedef struct {
   int mode;              /* ORC_MODE_* */
   int num_threads;       /* OpenMP threads for the kNN loop */
   double inlier_fraction; /* engine inlier_fraction_ (filter active iff 0 < f < 1; correspondence.hpp:57-66) */
-  int one_to_one;        /* engine one_to_one_ (correspondence.hpp:68-100, SECOND_TO_FIRST branch) */
+  int one_to_one;        /* engine one_to_one_ (correspondence.hpp:68-100) */
+  int direction;         /* search_dir_: 0 = SECOND_TO_FIRST (the default), 1 = FIRST_TO_SECOND, 2 = BOTH */
+  int reciprocal;        /* require_reciprocality_ (only read for BOTH) */
 } orc_icp_params;
 
 typedef struct {
@@ -150,6 +152,12 @@ float orc_icp_update(const float* dst_xyz, const float* dst_nrm, size_t nd, cons
 /* rowwise().mean() as the reference ctor does (icp_single_transform_combined_metric.hpp:51-58):
  * f32 serial sum / n. */
 void orc_mean3(const float* xyz, size_t n, int mode, float mean[3]);
+
+/* other search directions (correspondence_search_kd_tree.hpp:185-222); output capacity nd + ns */
+size_t orc_find_correspondences_dir(const float* dst, size_t nd, const orc_kdtree* dst_tree, const float* q, size_t ns, float max_d,
+                                    int direction, int reciprocal, int64_t* di, int64_t* si, float* d2, int num_threads);
+size_t orc_filter_fraction_lex(int64_t* di, int64_t* si, float* d2, size_t n, double f);
+size_t orc_filter_one_to_one_f2s(int64_t* di, int64_t* si, float* d2, size_t n);
 
 /* ---- kmeans_oracle.c: KMeans<float,3> brute-force path (clustering/kmeans.hpp:67-194) ---- */
 size_t orc_kmeans_assign(const float* x, size_t n, const float* c, size_t k, int64_t* labels);

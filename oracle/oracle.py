@@ -44,6 +44,7 @@ class IcpParams(C.Structure):
         ("max_iter", C.c_size_t), ("conv_tol", C.c_float), ("max_opt_iter", C.c_size_t),
         ("opt_conv_tol", C.c_float), ("max_sq_dist", C.c_float), ("mode", C.c_int),
         ("num_threads", C.c_int), ("inlier_fraction", C.c_double), ("one_to_one", C.c_int),
+        ("direction", C.c_int), ("reciprocal", C.c_int),
     ]
 
 
@@ -110,6 +111,13 @@ def lib():
         L.orc_plane_ransac.restype = C.c_size_t
         L.orc_plane_ransac.argtypes = [_f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
                                        _f32p, _f32p, _u32p, C.POINTER(C.c_size_t)]
+        L.orc_find_correspondences_dir.restype = C.c_size_t
+        L.orc_find_correspondences_dir.argtypes = [_f32p, C.c_size_t, C.c_void_p, _f32p, C.c_size_t, C.c_float, C.c_int, C.c_int,
+                                                   _i64p, _i64p, _f32p, C.c_int]
+        L.orc_filter_fraction_lex.restype = C.c_size_t
+        L.orc_filter_fraction_lex.argtypes = [_i64p, _i64p, _f32p, C.c_size_t, C.c_double]
+        L.orc_filter_one_to_one_f2s.restype = C.c_size_t
+        L.orc_filter_one_to_one_f2s.argtypes = [_i64p, _i64p, _f32p, C.c_size_t]
         L.orc_knn_batch.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, C.c_float, _i64p, _f32p, _u32p]
         L.orc_normals_knn.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_int, _f32p, _f32p]
         _lib = L
@@ -266,9 +274,10 @@ def mean3(pts, mode=MODE_MIXED):
 
 def make_params(metric=METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=15, conv_tol=1e-5,
                 max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=1e-4, mode=MODE_MIXED, num_threads=0,
-                inlier_fraction=1.0, one_to_one=False):
+                inlier_fraction=1.0, one_to_one=False, direction=0, reciprocal=False):
+    """direction: 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH"""
     return IcpParams(metric, w_p2p, w_p2pl, max_iter, conv_tol, max_opt_iter, opt_conv_tol,
-                     max_sq_dist, mode, num_threads, inlier_fraction, 1 if one_to_one else 0)
+                     max_sq_dist, mode, num_threads, inlier_fraction, 1 if one_to_one else 0, int(direction), 1 if reciprocal else 0)
 
 
 def filter_fraction(dst_idx, src_idx, d2, fraction):
@@ -390,3 +399,24 @@ def normals_knn(pts, k, radius_sq=np.inf, view_point=None, mode=1):
     vp = None if view_point is None else np.ascontiguousarray(view_point, np.float32)
     lib().orc_normals_knn(pts, len(pts), k, np.float32(radius_sq), None if vp is None else vp.ctypes.data, mode, nrm.reshape(-1), cur)
     return nrm, cur
+
+
+# ---- other search directions (correspondence_search_kd_tree.hpp:185-222) ---------------------------------
+def find_correspondences_dir(dst, q, max_sq_dist, direction, reciprocal=False, inlier_fraction=1.0, one_to_one=False):
+    """direction 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH; q = already transformed source.
+    -> (dst_idx, src_idx, d2) after the engine's post-filters, in the reference's order"""
+    dst = _c(dst).reshape(-1, 3); q = _c(q).reshape(-1, 3)
+    cap = len(dst) + len(q) + 1
+    di = np.zeros(cap, np.int64); si = np.zeros(cap, np.int64); dv = np.zeros(cap, np.float32)
+    tree = KDTree(dst) if direction != 1 else None
+    n = lib().orc_find_correspondences_dir(dst, len(dst), tree.h if tree is not None else None, q, len(q), np.float32(max_sq_dist),
+                                           int(direction), 1 if reciprocal else 0, di, si, dv, 0)
+    if direction == 0:
+        n = lib().orc_filter_fraction(di, si, dv, n, float(inlier_fraction))
+        if one_to_one:
+            n = lib().orc_filter_one_to_one(di, si, dv, n)
+    else:
+        n = lib().orc_filter_fraction_lex(di, si, dv, n, float(inlier_fraction))
+        if one_to_one and direction == 1:
+            n = lib().orc_filter_one_to_one_f2s(di, si, dv, n)
+    return di[:n].copy(), si[:n].copy(), dv[:n].copy()

@@ -91,9 +91,16 @@ int main(int argc, char** argv) {
     std::printf("point-to-point: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp2.getNumberOfPerformedIterations(), r.iterations, e2);
     if (!(e2 <= 1e-5)) ++failures;
 
-    bool threw = false;
-    try { icp.correspondenceSearchEngine().setRequireReciprocality(true); } catch (const std::invalid_argument&) { threw = true; }
-    if (!threw) ++failures;
+    // search direction BOTH with reciprocity (correspondence_search_kd_tree_utilities.hpp:65-101) through the same classes
+    SimpleCombinedMetricRigidICP3f icp3(dst_v, nrm_v, src_v);
+    icp3.setMaxNumberOfOptimizationStepIterations(1).setPointToPointMetricWeight(0.0f).setPointToPlaneMetricWeight(1.0f);
+    icp3.correspondenceSearchEngine().setMaxDistance(max_sq).setSearchDirection(CorrespondenceSearchDirection::BOTH).setRequireReciprocality(true);
+    icp3.setConvergenceTolerance(1e-5f).setMaxNumberOfIterations(8).estimate();
+    p.metric = 1; p.max_iter = 8; p.direction = 2; p.reciprocal = 1;
+    orc_icp_run(dst.data(), nrm.data(), n, src.data(), nullptr, n, nullptr, &p, nullptr, &r);
+    const double e3 = frob(icp3.getTransform().m, r.T);
+    std::printf("BOTH+reciprocal: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp3.getNumberOfPerformedIterations(), r.iterations, e3);
+    if (!(e3 <= 1e-5) || icp3.getNumberOfPerformedIterations() != r.iterations) ++failures;
   } catch (const std::runtime_error& e) {
     if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }
     std::printf("FAIL: %s\n", e.what());

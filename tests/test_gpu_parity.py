@@ -610,3 +610,43 @@ def test_knn_and_normal_estimation_vs_oracle(orc, hip_lib):
     assert (gc == 2).all() and (gi[:, 2:] == -1).all()
     nn, cc = NormalEstimation3f(x[:2].copy()).getNormalsAndCurvatureKNN(5)
     assert np.isnan(nn).all() and np.isnan(cc).all()
+
+
+def test_search_directions_vs_oracle(Context, orc, hip_lib):
+    """Engine search directions FIRST_TO_SECOND / BOTH (+ reciprocity) and their post-filters
+    (correspondence_search_kd_tree.hpp:185-225, kd_tree_utilities.hpp:65-101, correspondence.hpp:57-100)."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D, CorrespondenceSearchHIP, SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(60000, 45000, with_normals=True)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = [0.004, -0.003, 0.002]
+    q = orc.transform_points(T, d["src"])
+    r2 = float(d["max_sq_dist"])
+    ctx = Context()
+    ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+    eng = CorrespondenceSearchHIP(ctx=ctx).setMaxDistance(r2)
+    code = {D.SECOND_TO_FIRST: 0, D.FIRST_TO_SECOND: 1, D.BOTH: 2}
+    for direction, recip, frac, o2o in ((D.FIRST_TO_SECOND, False, 1.0, False), (D.BOTH, False, 1.0, False), (D.BOTH, True, 1.0, False),
+                                        (D.FIRST_TO_SECOND, False, 0.6, False), (D.FIRST_TO_SECOND, False, 1.0, True),
+                                        (D.BOTH, True, 0.8, True), (D.FIRST_TO_SECOND, False, 0.5, True), (D.SECOND_TO_FIRST, False, 1.0, False)):
+        eng.setSearchDirection(direction).setRequireReciprocality(recip).setInlierFraction(frac).setOneToOne(o2o)
+        eng.findCorrespondences(T)
+        g1, g2, gv = eng.getCorrespondences()
+        o1, o2, ov = orc.find_correspondences_dir(d["dst"], q, r2, code[direction], recip, frac, o2o)
+        assert len(g1) == len(o1), (direction, recip, frac, o2o, len(g1), len(o1))
+        assert np.array_equal(g1, o1) and np.array_equal(g2, o2) and np.array_equal(gv, ov), (direction, recip, frac, o2o)
+    # whole ICP loops: transforms within tolerance of the oracle, same iteration counts
+    for direction, recip, metric in ((D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 1), (D.BOTH, True, 0)):
+        if metric == 1:
+            icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+        else:
+            from cilantro_amd.icp import SimplePointToPointMetricRigidICP3f
+            icp = SimplePointToPointMetricRigidICP3f(d["dst"], d["src"])
+        icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
+        icp.setMaxNumberOfIterations(12).setConvergenceTolerance(1e-5)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=metric, max_sq_dist=r2, max_iter=12, conv_tol=1e-5, direction=code[direction], reciprocal=recip)
+        ro = orc.icp_run(d["dst"], d["dst_n"] if metric == 1 else None, d["src"], p)
+        assert icp.getNumberOfPerformedIterations() == ro["iterations"], (direction, recip)
+        assert icp.last_ncorr_ == ro["last_ncorr"]
+        assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (direction, recip, np.linalg.norm(Tg - ro["T"]))

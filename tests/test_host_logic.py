@@ -14,18 +14,19 @@ def test_transform_abi_is_eigen_column_major():
     assert np.array_equal(_T_from_abi(a), T)
 
 
-def test_engine_defaults_and_unsupported_options():
+def test_engine_defaults_and_options():
     e = CorrespondenceSearchHIP(ctx=None)
     # correspondence_search_kd_tree.hpp:47-51 defaults
     assert e.getSearchDirection() == CorrespondenceSearchDirection.SECOND_TO_FIRST
     assert e.getMaxDistance() == np.float32(0.01 * 0.01) and e.getInlierFraction() == 1.0
     assert not e.getRequireReciprocality() and not e.getOneToOne()
     assert e.setMaxDistance(0.1 * 0.1) is e and e.getMaxDistance() == np.float32(0.1 * 0.1)
-    for bad in (lambda: e.setSearchDirection(CorrespondenceSearchDirection.BOTH),
-                lambda: e.setSearchDirection(CorrespondenceSearchDirection.FIRST_TO_SECOND),
-                lambda: e.setRequireReciprocality(True)):
-        with pytest.raises(NotImplementedError):
-            bad()
+    # every knob of correspondence_search_kd_tree.hpp:239-271 is implemented
+    assert e.setSearchDirection(CorrespondenceSearchDirection.BOTH).getSearchDirection() == CorrespondenceSearchDirection.BOTH
+    assert e.setSearchDirection(CorrespondenceSearchDirection.FIRST_TO_SECOND) is e
+    assert e.setRequireReciprocality(True).getRequireReciprocality()
+    with pytest.raises(ValueError):
+        e.setSearchDirection(7)
     assert e.setOneToOne(False) is e and e.setInlierFraction(1.0) is e
     assert e.setOneToOne(True).getOneToOne() and e.setInlierFraction(0.7).getInlierFraction() == 0.7   # filters are implemented
 
