@@ -190,7 +190,22 @@ def main():
         if not sharded and launches > 0:
             avg_ms = search_ms / launches
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            # the measured device copy bandwidth beside the spec peak (1 GiB torch copy = read + write)
+            copy_gbs = None
+            try:
+                xb = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); yb = torch.empty_like(xb)
+                yb.copy_(xb); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    yb.copy_(xb)
+                e1.record(); torch.cuda.synchronize()
+                copy_gbs = 5 * 2 * xb.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                del xb, yb
+            except Exception:
+                copy_gbs = None
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "measured_copy_bandwidth_GBps": copy_gbs,
                     "traffic": traffic, "kernel": "k_search_tiled + k_search_todo (kNN correspondence search, LDS-tiled)",
                     "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
                     "accumulate_kernel": {"avg_kernel_ms": acc_ms / launches,

@@ -24,6 +24,57 @@ from oracle import oracle as orc  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def read_ply_xyz_normals(path):
+    """minimal reader for the reference's test clouds: binary_little_endian, vertex properties float x y z nx ny nz +
+    uchar red green blue (what utilities/ply_io.hpp:43-106 reads through tinyply)"""
+    with open(path, "rb") as f:
+        header = b""
+        while not header.endswith(b"end_header\n"):
+            header += f.readline()
+        lines = header.decode("ascii").split("\n")
+        assert "format binary_little_endian 1.0" in lines
+        n = int([l for l in lines if l.startswith("element vertex")][0].split()[2])
+        props = [l.split()[1:] for l in lines if l.startswith("property")]
+        dt = np.dtype([(name, {"float": "<f4", "uchar": "u1"}[t]) for t, name in props])
+        v = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
+    pts = np.stack([v["x"], v["y"], v["z"]], 1).astype(np.float32)
+    nrm = np.stack([v["nx"], v["ny"], v["nz"]], 1).astype(np.float32)
+    return pts, nrm
+
+
+def make_frame1_fixture(out_path, ply="/root/reference/examples/test_clouds/frame_1.ply", keep=20000):
+    """BASELINE configs[0] / SURVEY 8(d) C1: frame_1.ply through the recipe of examples/rigid_icp.cpp:25-65 (voxel
+    downsample 0.005, src = dst + 0.01*uniform jitter, dst keeps x > -0.4, src moved by tf_ref), with OUR seeded jitter and a
+    seeded subsample so the fixture stays small.  Real sensor data: a surface, strongly non-uniform density."""
+    pts, nrm = read_ply_xyz_normals(ply)
+    ok = np.isfinite(pts).all(1) & np.isfinite(nrm).all(1)
+    pts, nrm = pts[ok], nrm[ok]
+    # gridDownsample(0.005f): one averaged point / re-normalised normal per occupied voxel
+    key = np.floor(pts / np.float32(0.005)).astype(np.int64)
+    _, inv = np.unique(key, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    m = inv.max() + 1
+    cnt = np.bincount(inv, minlength=m).astype(np.float64)
+    dpts = np.stack([np.bincount(inv, pts[:, c].astype(np.float64), m) / cnt for c in range(3)], 1).astype(np.float32)
+    dn = np.stack([np.bincount(inv, nrm[:, c].astype(np.float64), m) for c in range(3)], 1)
+    dn = (dn / np.maximum(np.linalg.norm(dn, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    rng = np.random.default_rng(20250629)
+    sel = np.sort(rng.permutation(m)[:keep])
+    dpts, dn = dpts[sel], dn[sel]
+    src = (dpts + np.float32(0.01) * rng.uniform(-1, 1, dpts.shape).astype(np.float32)).astype(np.float32)
+    keep_dst = dpts[:, 0] > -0.4
+    dst, dst_n = dpts[keep_dst], dn[keep_dst]
+    cz, sz, cy, sy, cx, sx = np.cos(-0.1), np.sin(-0.1), np.cos(0.1), np.sin(0.1), np.cos(-0.1), np.sin(-0.1)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    R = (Rz @ Ry @ Rx).astype(np.float32)
+    t = np.array([-0.20, -0.05, 0.10], np.float32)
+    src = (src @ R.T + t).astype(np.float32)                       # src.transform(tf_ref)
+    T_ref = np.eye(4, dtype=np.float32); T_ref[:3, :3] = R; T_ref[:3, 3] = t
+    np.savez_compressed(out_path, dst=dst, dst_n=dst_n, src=src, T_ref=T_ref)
+    return len(dst), len(src)
+
+
 def main():
     assert orc.ref_available(), "oracle/_ref missing: run `make -C oracle` where /root/reference exists"
     rng = np.random.default_rng(20250629)
@@ -61,5 +112,11 @@ def main():
     print("wrote", os.listdir(HERE))
 
 
+def main_frame1():
+    nd, ns = make_frame1_fixture(os.path.join(HERE, "frame1_c1.npz"))
+    print(f"frame1_c1.npz: dst {nd} points, src {ns} points")
+
+
 if __name__ == "__main__":
     main()
+    main_frame1()

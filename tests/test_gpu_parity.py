@@ -650,3 +650,38 @@ def test_search_directions_vs_oracle(Context, orc, hip_lib):
         assert icp.getNumberOfPerformedIterations() == ro["iterations"], (direction, recip)
         assert icp.last_ncorr_ == ro["last_ncorr"]
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (direction, recip, np.linalg.norm(Tg - ro["T"]))
+
+
+def test_frame1_recipe_real_cloud(orc, hip_lib, Context):
+    """BASELINE configs[0]: real sensor data -- the reference's examples/test_clouds/frame_1.ply
+    through the recipe and parameters of examples/rigid_icp.cpp (fixture tests/golden/frame1_c1.npz)."""
+    import os
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f
+
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame1_c1.npz"))
+    dst, dst_n, src = f["dst"], f["dst_n"], f["src"]
+    # nearest neighbours on a real surface cloud, large radius (0.1^2 as in the example), far-from-converged pose
+    ctx = Context()
+    ctx.set_target(dst, dst_n); ctx.set_source(src)
+    T0 = np.eye(4, dtype=np.float32)
+    ng = ctx.find_correspondences(T0, 0.1 * 0.1)
+    g1, g2, gv = ctx.get_correspondences()
+    o1, o2, ov = orc.KDTree(dst).find_correspondences(orc.transform_points(T0, src), 0.1 * 0.1)
+    assert ng == len(o1) and np.array_equal(g2, o2) and np.array_equal(gv, ov)
+    nbad, ties, nearer, worse = classify_mismatches(orc, dst, orc.transform_points(T0, src), g1, gv, o1, ov)
+    assert worse == 0 and nbad == ties, (nbad, ties, nearer, worse)
+    for metric in (1, 0):
+        if metric == 1:
+            icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+            icp.setMaxNumberOfOptimizationStepIterations(1).setPointToPointMetricWeight(0.0).setPointToPlaneMetricWeight(1.0)
+        else:
+            icp = SimplePointToPointMetricRigidICP3f(dst, src)
+        icp.correspondenceSearchEngine().setMaxDistance(0.1 * 0.1)
+        icp.setConvergenceTolerance(1e-4).setMaxNumberOfIterations(30)          # examples/rigid_icp.cpp:116-125
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=metric, w_p2p=0.0, w_p2pl=1.0, max_iter=30, conv_tol=1e-4, max_opt_iter=1, max_sq_dist=0.1 * 0.1)
+        r = orc.icp_run(dst, dst_n if metric == 1 else None, src, p)
+        assert icp.getNumberOfPerformedIterations() == r["iterations"]
+        assert np.linalg.norm(Tg.astype(np.float64) - r["T"]) <= TOL_T, np.linalg.norm(Tg - r["T"])
+        if metric == 1:   # point-to-plane converges inside the example's 30 iterations; point-to-point is still creeping
+            assert icp.hasConverged() and np.linalg.norm(Tg - np.linalg.inv(f["T_ref"].astype(np.float64))) < 5e-3

@@ -239,3 +239,21 @@ def test_plane_ransac_oracle_pieces(orc):
     assert it2 == 100 and len(inl2) == max(orc.plane_count_inliers(x, orc.plane_fit(x, s3, mode=1), 0.01) for s3 in samples)
     # a degenerate sample (three times the same point) fits a NaN-free or NaN plane but never crashes
     _ = orc.plane_fit(x, np.zeros(3, np.uint32), mode=1)
+
+
+def test_frame1_recipe_fixture_converges(orc):
+    """BASELINE configs[0]: the reference's own test cloud examples/test_clouds/frame_1.ply through the
+    recipe of examples/rigid_icp.cpp:25-65 (fixture tests/golden/frame1_c1.npz, made by make_golden.py), with the
+    parameters of examples/rigid_icp.cpp:116-125.  The estimate must be the inverse of the applied motion (:132-133)."""
+    f = np.load(os.path.join(GOLD, "frame1_c1.npz"))
+    p = orc.make_params(metric=orc.METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=30, conv_tol=1e-4, max_opt_iter=1,
+                        max_sq_dist=0.1 * 0.1, mode=orc.MODE_MIXED)
+    r = orc.icp_run(f["dst"], f["dst_n"], f["src"], p)
+    T_true = np.linalg.inv(f["T_ref"].astype(np.float64))
+    assert r["iterations"] < 30 and r["last_delta_norm"] < 1e-4
+    assert np.linalg.norm(r["T"] - T_true) < 5e-3, np.linalg.norm(r["T"] - T_true)     # jitter-limited (0.01 uniform noise)
+    # the reference-like all-f32 mode lands on the same transform to f32 accumulation accuracy
+    p32 = orc.make_params(metric=orc.METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=30, conv_tol=1e-4, max_opt_iter=1,
+                          max_sq_dist=0.1 * 0.1, mode=orc.MODE_F32)
+    r32 = orc.icp_run(f["dst"], f["dst_n"], f["src"], p32)
+    assert np.linalg.norm(r32["T"] - r["T"]) < 1e-3
