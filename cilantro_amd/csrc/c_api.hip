@@ -356,7 +356,18 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
 
 // The LDS-tiled kernel runs 1024-thread workgroups, two per CU: below ~4 full rounds of tiles on the
 // 256 CUs the per-lane kernel (8x more, smaller workgroups) balances better (measured at 1M points).
-static bool use_tiled(const cilhip_ctx* c) { return c->tiled >= 2 || (c->tiled == 1 && c->ntiles >= 2048); }
+// It also needs tiles that are reasonably full (a source much sparser than the target leaves most lanes of
+// a tile idle: 10M source points against an 80M-point target fill 14 % of the slots) and a target whose
+// local density fits the LDS budget of a tile's region (cube + halo + one cell of drift per axis);
+// otherwise every tile would be handed to the clean-up pass, which is the per-lane search done worse.
+static bool use_tiled(const cilhip_ctx* c) {
+  if (c->tiled >= 2) return true;
+  if (c->tiled != 1 || c->ntiles < 2048) return false;
+  const double fill = (double)c->ns / ((double)c->ntiles * (double)TILE_QUERIES);
+  const double region_cells = (double)(CUBE_EDGE + 3) * (CUBE_EDGE + 3) * (CUBE_EDGE + 3);
+  const double density = c->grid_occ > 1.0 ? c->grid_occ - 1.0 : c->grid_occ;   // sum(count^2)/n = lambda + 1 for a Poisson cloud
+  return fill >= 0.45 && density * region_cells <= 0.92 * (double)CILHIP_TILE_CAP;
+}
 
 static bool filters_active(const cilhip_ctx* c) {
   return (c->inlier_fraction > 0.0 && c->inlier_fraction < 1.0) || c->one_to_one;

@@ -22,6 +22,12 @@ constexpr int CUBE_EDGE = CILHIP_CUBE_EDGE;
 #ifndef CILHIP_TILE_WAVES_PER_SIMD
 #define CILHIP_TILE_WAVES_PER_SIMD 8   /* resident waves per SIMD the tiled kernel is compiled for (register budget) */
 #endif
+#ifndef CILHIP_TILE_CAP
+#define CILHIP_TILE_CAP 3840   /* target points one tile can stage in LDS (16 B each) */
+#endif
+#ifndef CILHIP_TILE_MAXE
+#define CILHIP_TILE_MAXE 4352  /* entries of the staged cell table: region rows x (region width + 1) */
+#endif
 constexpr int TILE_THREADS = CILHIP_TILE_THREADS;  // workgroup size of the tiled search kernel
 constexpr int TILE_QUERIES = 2 * TILE_THREADS;     // max queries per tile (two per lane)
 

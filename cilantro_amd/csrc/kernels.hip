@@ -30,12 +30,6 @@ namespace cilhip {
 
 // LDS-tiled search geometry: cube of 2^L cells per axis, <= TILE_QUERIES queries per tile,
 // TILE_THREADS threads per workgroup.  (4^3 cells / 256 queries / 256 threads, or 8^3 / 2048 / 1024.)
-#ifndef CILHIP_TILE_CAP
-#define CILHIP_TILE_CAP 3840
-#endif
-#ifndef CILHIP_TILE_MAXE
-#define CILHIP_TILE_MAXE 4352
-#endif
 
 #ifndef CILHIP_CAND
 #define CILHIP_CAND 4 /* candidates per lane per trip of the flattened work-list loop */
