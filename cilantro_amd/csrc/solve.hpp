@@ -130,9 +130,9 @@ CILHIP_HD void nearest_rotation(const double L[9], double R[9]) {
 }
 
 // ---- 6x6 LDL^T, diagonal pivoting, pseudo-inverse of D (Eigen LDLT::solve semantics) ----------
-CILHIP_HD void ldlt6_solve(const double Ain[36], const double bin[6], double x[6]) {
-  double A[36];
-  int perm[6];
+// (work arrays passed in: the pivoting indexes them dynamically, which would put function-local arrays into
+// scratch = global memory on the device; the single-lane epilogue hands in LDS)
+CILHIP_HD void ldlt6_solve_ws(const double Ain[36], const double bin[6], double x[6], double* A /*[36]*/, double* y /*[6]*/, int* perm /*[6]*/) {
   for (int i = 0; i < 36; ++i) A[i] = Ain[i];
   for (int i = 0; i < 6; ++i) perm[i] = i;
   const double tiny = 2.2250738585072014e-308;
@@ -158,7 +158,6 @@ CILHIP_HD void ldlt6_solve(const double Ain[36], const double bin[6], double x[6
         A[j * 6 + i] = A[i * 6 + j];
       }
   }
-  double y[6];
   for (int i = 0; i < 6; ++i) y[i] = bin[perm[i]];
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < i; ++j) y[i] -= A[i * 6 + j] * y[j];
@@ -169,6 +168,12 @@ CILHIP_HD void ldlt6_solve(const double Ain[36], const double bin[6], double x[6
   for (int i = 5; i >= 0; --i)
     for (int j = i + 1; j < 6; ++j) y[i] -= A[j * 6 + i] * y[j];
   for (int i = 0; i < 6; ++i) x[perm[i]] = y[i];
+}
+
+CILHIP_HD void ldlt6_solve(const double Ain[36], const double bin[6], double x[6]) {
+  double A[36], y[6];
+  int perm[6];
+  ldlt6_solve_ws(Ain, bin, x, A, y, perm);
 }
 
 // tform = Ra * ta * Ra * tform  (transform_estimation.hpp:349-357); L row-major, in place.
