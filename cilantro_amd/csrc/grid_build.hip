@@ -170,11 +170,11 @@ static void set_dims(GridDev& g, const float lo[3], const float hi[3], double ce
   if (!(maxext > 0.0) || !std::isfinite(maxext)) maxext = 1.0;
   if (!(cell > 0.0) || !std::isfinite(cell)) cell = maxext;
   cell = std::max(cell, maxext / (MAXD - 1));
-  // One layer of (empty) cells around the data: every cell that can hold a target point then has all 26
-  // neighbours inside the grid, so the fast search path needs no boundary cases (queries in the outer layer,
-  // i.e. outside the data's bounding box, take the generic path).
+  // GRID_PAD layers of (empty) cells around the data: every cell that can hold a target point (and the first layer
+  // around them) has all 26 neighbours inside the grid, so the fast search path needs no boundary cases (queries in
+  // the outermost layer or beyond take the generic path).
   for (;;) {
-    double nxd = std::floor(ext[0] / cell) + 3, nyd = std::floor(ext[1] / cell) + 3, nzd = std::floor(ext[2] / cell) + 3;
+    double nxd = std::floor(ext[0] / cell) + 1 + 2 * GRID_PAD, nyd = std::floor(ext[1] / cell) + 1 + 2 * GRID_PAD, nzd = std::floor(ext[2] / cell) + 1 + 2 * GRID_PAD;
     if (nxd * nyd * nzd <= MAXCELLS && nxd <= MAXD && nyd <= MAXD && nzd <= MAXD) {
       g.nx = (int)nxd; g.ny = (int)nyd; g.nz = (int)nzd;
       break;
@@ -182,7 +182,7 @@ static void set_dims(GridDev& g, const float lo[3], const float hi[3], double ce
     cell *= 1.1;
   }
   g.cell = (float)cell;
-  g.ox = lo[0] - g.cell; g.oy = lo[1] - g.cell; g.oz = lo[2] - g.cell;
+  g.ox = lo[0] - (float)GRID_PAD * g.cell; g.oy = lo[1] - (float)GRID_PAD * g.cell; g.oz = lo[2] - (float)GRID_PAD * g.cell;
   g.inv_cell = 1.0f / g.cell;
   g.margin = g.cell * (1.0f / 512.0f);
 }
@@ -273,11 +273,11 @@ __device__ __forceinline__ uint32_t cube_key_of(const GridDev& g, float x, float
   int cx = (int)floorf(fminf(fmaxf((x - g.ox) * g.inv_cell, -1.0f), 1.0e9f));
   int cy = (int)floorf(fminf(fmaxf((y - g.oy) * g.inv_cell, -1.0f), 1.0e9f));
   int cz = (int)floorf(fminf(fmaxf((z - g.oz) * g.inv_cell, -1.0f), 1.0e9f));
-  // cubes tile the DATA cells 1..n-2 (the grid's outer layer holds no target points): shift by one cell, so a
-  // cloud registered onto itself fills whole cubes; queries in the low outer layer join cube 0
-  cx = min(max(cx - 1, 0), g.nx - 2); cy = min(max(cy - 1, 0), g.ny - 2); cz = min(max(cz - 1, 0), g.nz - 2);
+  // cubes tile the DATA cells GRID_PAD..n-1-GRID_PAD (the outer layers hold no target points): shift by the padding,
+  // so a cloud registered onto itself fills whole cubes; queries in the low outer layers join cube 0
+  cx = min(max(cx - GRID_PAD, 0), g.nx - 1 - GRID_PAD); cy = min(max(cy - GRID_PAD, 0), g.ny - 1 - GRID_PAD); cz = min(max(cz - GRID_PAD, 0), g.nz - 1 - GRID_PAD);
   constexpr uint32_t C = CUBE_EDGE;
-  const uint32_t cnx = (uint32_t)(g.nx - 2) / C + 1, cny = (uint32_t)(g.ny - 2) / C + 1;
+  const uint32_t cnx = (uint32_t)(g.nx - 1 - GRID_PAD) / C + 1, cny = (uint32_t)(g.ny - 1 - GRID_PAD) / C + 1;
   const uint32_t bx = (uint32_t)cx / C, by = (uint32_t)cy / C, bz = (uint32_t)cz / C;
   const uint32_t cube = (bz * cny + by) * cnx + bx;
   const uint32_t local = (((uint32_t)cz - bz * C) * C + ((uint32_t)cy - by * C)) * C + ((uint32_t)cx - bx * C);
@@ -308,14 +308,14 @@ __global__ void k_tile_counts(const uint32_t* __restrict__ cube_start, uint32_t 
 __global__ void k_emit_tiles(const uint32_t* __restrict__ cube_start, const uint32_t* __restrict__ tile_off, uint32_t ncubes, GridDev g, Tf Tinv,
                              uint2* tiles, float4* tile_center) {
   constexpr uint32_t C = CUBE_EDGE;
-  const uint32_t cnx = (uint32_t)(g.nx - 2) / C + 1, cny = (uint32_t)(g.ny - 2) / C + 1;
+  const uint32_t cnx = (uint32_t)(g.nx - 1 - GRID_PAD) / C + 1, cny = (uint32_t)(g.ny - 1 - GRID_PAD) / C + 1;
   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncubes; c += gridDim.x * blockDim.x) {
     const uint32_t b = cube_start[c], e = cube_start[c + 1];
     if (b == e) continue;
     const uint32_t bx = c % cnx, by = (c / cnx) % cny, bz = c / (cnx * cny);
-    // cube b spans the cells [1 + b C, 1 + (b + 1) C)
-    const float hx = g.ox + ((float)(bx * C) + 1.0f + 0.5f * (float)C) * g.cell, hy = g.oy + ((float)(by * C) + 1.0f + 0.5f * (float)C) * g.cell,
-                hz = g.oz + ((float)(bz * C) + 1.0f + 0.5f * (float)C) * g.cell;
+    // cube b spans the cells [GRID_PAD + b C, GRID_PAD + (b + 1) C)
+    const float hx = g.ox + ((float)(bx * C) + (float)GRID_PAD + 0.5f * (float)C) * g.cell, hy = g.oy + ((float)(by * C) + (float)GRID_PAD + 0.5f * (float)C) * g.cell,
+                hz = g.oz + ((float)(bz * C) + (float)GRID_PAD + 0.5f * (float)C) * g.cell;
     const float* m = Tinv.m;
     const float4 ctr = make_float4(m[0] * hx + m[4] * hy + m[8] * hz + m[12], m[1] * hx + m[5] * hy + m[9] * hz + m[13],
                                    m[2] * hx + m[6] * hy + m[10] * hz + m[14], 0.0f);
@@ -353,7 +353,7 @@ hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const f
   for (int i = 0; i < 16; ++i) tf.m[i] = T[i];
   hipLaunchKernelGGL(k_cube_keys_tf, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, tf, k_in, v_in);
   constexpr uint32_t CE = CUBE_EDGE;
-  const uint32_t cnx = (uint32_t)(g.nx - 2) / CE + 1, cny = (uint32_t)(g.ny - 2) / CE + 1, cnz = (uint32_t)(g.nz - 2) / CE + 1;
+  const uint32_t cnx = (uint32_t)(g.nx - 1 - GRID_PAD) / CE + 1, cny = (uint32_t)(g.ny - 1 - GRID_PAD) / CE + 1, cnz = (uint32_t)(g.nz - 1 - GRID_PAD) / CE + 1;
   const uint32_t ncubes = cnx * cny * cnz;
   hipError_t e = sort_pairs(k_in, k_out, v_in, v_out, n, std::min(32u, bits_for(ncubes * CE * CE * CE)), s);
   uint32_t *cube_start = nullptr, *tcount = nullptr, *toff = nullptr;

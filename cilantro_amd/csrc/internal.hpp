@@ -16,6 +16,10 @@ constexpr uint32_t NONE_U32 = 0xFFFFFFFFu;
 #endif
 // LDS-tiled search: queries are grouped by cubes of CUBE_EDGE^3 target-grid cells
 constexpr int CUBE_EDGE = CILHIP_CUBE_EDGE;
+// Layers of empty cells around the data's bounding box.  Two: queries up to one cell outside the data (source points
+// that noise / the current transform pushed just past the target's bounding box) still have all 26 neighbour cells
+// inside the grid and stay on the fast search path.
+constexpr int GRID_PAD = 2;
 #ifndef CILHIP_TILE_THREADS
 #define CILHIP_TILE_THREADS 1024
 #endif

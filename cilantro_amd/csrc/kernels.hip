@@ -656,6 +656,14 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     bz0 = (int)floorf(fminf(fmaxf((ccz - ext[2] - g.oz) * g.inv_cell + SHR, -BIG), BIG));
     bz1 = (int)floorf(fminf(fmaxf((ccz + ext[2] - g.oz) * g.inv_cell - SHR, -BIG), BIG));
   }
+  // a box that reaches the first / last layer of data cells also takes the empty layer next to it: the queries the
+  // current transform (or noise) pushed just outside the data's bounding box stay on the fast path
+  if (bx0 <= GRID_PAD) bx0 = min(bx0, GRID_PAD - 1);
+  if (by0 <= GRID_PAD) by0 = min(by0, GRID_PAD - 1);
+  if (bz0 <= GRID_PAD) bz0 = min(bz0, GRID_PAD - 1);
+  if (bx1 >= g.nx - 1 - GRID_PAD) bx1 = max(bx1, g.nx - GRID_PAD);
+  if (by1 >= g.ny - 1 - GRID_PAD) by1 = max(by1, g.ny - GRID_PAD);
+  if (bz1 >= g.nz - 1 - GRID_PAD) bz1 = max(bz1, g.nz - GRID_PAD);
   const int lox = max(bx0 - 1, 0), loy = max(by0 - 1, 0), loz = max(bz0 - 1, 0);
   const int hix = min(bx1 + 1, g.nx - 1), hiy = min(by1 + 1, g.ny - 1), hiz = min(bz1 + 1, g.nz - 1);
   const int RX = hix - lox + 1, RY = hiy - loy + 1, RZ = hiz - loz + 1;
