@@ -309,7 +309,7 @@ constexpr int TILE_MAXSPAN = CUBE_EDGE + 6;                  // region rows per 
 constexpr int TILE_MAXROWS = TILE_MAXSPAN * TILE_MAXSPAN;    // RY*RZ
 constexpr int TILE_MAXE = CILHIP_TILE_MAXE;                  // entries of the staged cell table: rows * (RX + 1)
 constexpr int TILE_QPT = TILE_QUERIES / TILE_THREADS;        // queries per thread
-static_assert(TILE_MAXROWS <= TILE_THREADS, "one thread per region row fetches the row extent");
+static_assert(TILE_MAXE <= 65536 && TILE_MAXROWS <= 32767, "OctQuery packs a table index and a row into 16 bits each");
 static_assert(TILE_MAXROWS <= 64 * 8, "the row scan holds at most 8 rows per lane of one wave");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -388,9 +388,8 @@ __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 q
 // What a lane keeps of one query between its preparation (while the target points are still in flight) and the search.
 struct OctQuery {
   float qx, qy, qz;
-  float bound;   // distance from q to the nearest face of its octant block
-  int eb00;      // cell-table index of the first cell of run 0 (runs 1..3: + W1, + RY*W1, + (RY+1)*W1)
-  int row00;     // region row of run 0 (runs 1..3: +1, +RY, +RY+1)
+  int ebrow;     // low 16 bits: cell-table index of the first cell of run 0 (runs 1..3: + W1, + RY*W1, + (RY+1)*W1);
+                 // high 16 bits: region row of run 0 (runs 1..3: +1, +RY, +RY+1)
 };
 
 // Octant-first search (the common case): the 2x2x2 block of cells on the side of q's own cell that q
@@ -410,11 +409,17 @@ __device__ __forceinline__ void octant_prepare(const GridDev& g, float qx, float
   const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
   const float half = 0.5f * g.cell;
   const int ox = (ux >= half) ? 0 : -1, oy = (uy >= half) ? 0 : -1, oz = (uz >= half) ? 0 : -1;
-  o.row00 = (cz + oz - loz) * RY + (cy + oy - loy);
-  o.eb00 = o.row00 * W1 + (cx + ox - lox);
-  // nearest face of the two-cell span along an axis: at distance max(u, cell - u) (the far face of the own
-  // cell on the side q leans away from; the other face of the span is a full cell further)
-  o.bound = fminf(fminf(fmaxf(ux, g.cell - ux), fmaxf(uy, g.cell - uy)), fmaxf(uz, g.cell - uz));
+  const int row00 = (cz + oz - loz) * RY + (cy + oy - loy);
+  o.ebrow = (row00 * W1 + (cx + ox - lox)) | (row00 << 16);
+}
+
+// distance from q to the nearest face of its octant block: along an axis the two-cell span's nearest face is at
+// max(u, cell - u), u = offset of q inside its cell (the far face of the own cell on the side q leans away from; the
+// other face of the span is a full cell further).  Recomputed at search time rather than carried in registers.
+__device__ __forceinline__ float octant_bound(const GridDev& g, float qx, float qy, float qz) {
+  const float ux = qx - (g.ox + floorf((qx - g.ox) * g.inv_cell) * g.cell), uy = qy - (g.oy + floorf((qy - g.oy) * g.inv_cell) * g.cell),
+              uz = qz - (g.oz + floorf((qz - g.oz) * g.inv_cell) * g.cell);
+  return fminf(fminf(fmaxf(ux, g.cell - ux), fmaxf(uy, g.cell - uy)), fmaxf(uz, g.cell - uz));
 }
 
 // Returns true (result proven exact) iff the best found is strictly nearer than any point outside the block can be.
@@ -423,11 +428,11 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   const float qz = o.qz;
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
   uint32_t rj[4], re[4];
-  const int row00 = o.row00;
+  const int row00 = o.ebrow >> 16, eb00 = o.ebrow & 0xFFFF;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int row = row00 + (k >> 1) * t.RY + (k & 1);
-    const int eb = o.eb00 + ((k >> 1) * t.RY + (k & 1)) * t.W1;
+    const int eb = eb00 + ((k >> 1) * t.RY + (k & 1)) * t.W1;
     const uint32_t dl = t.rowdelta[row];
     rj[k] = t.lcs[eb] - dl;
     re[k] = t.lcs[eb + 2] - dl;
@@ -492,7 +497,7 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
   }
   best.pos = pos;
-  const float b = o.bound - g.margin;
+  const float b = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
 
