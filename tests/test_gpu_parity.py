@@ -685,3 +685,45 @@ def test_frame1_recipe_real_cloud(orc, hip_lib, Context):
         assert np.linalg.norm(Tg.astype(np.float64) - r["T"]) <= TOL_T, np.linalg.norm(Tg - r["T"])
         if metric == 1:   # point-to-plane converges inside the example's 30 iterations; point-to-point is still creeping
             assert icp.hasConverged() and np.linalg.norm(Tg - np.linalg.inv(f["T_ref"].astype(np.float64))) < 5e-3
+
+
+def test_tiled_search_under_large_and_non_rigid_motion(Context, orc):
+    """The tiled kernel derives each tile's region from the image of its cube under the CURRENT transform.  Rotations,
+    shears / scales and translations of a few cells since the sort must only ever cost speed (tiles or queries handed to
+    the clean-up pass), never exactness."""
+    n = 300_000
+    d = syn.make_pair(n, perturb=0.3)
+    h = d["h"]
+    rng = np.random.default_rng(3)
+
+    def rot(axis, ang):
+        axis = np.asarray(axis, np.float64); axis /= np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+    cases = []
+    for ang, shift in ((0.002, 0.5), (0.02, 1.7), (0.09, 3.0)):          # radians; translation in cells
+        T = np.eye(4); T[:3, :3] = rot(rng.normal(size=3), ang); T[:3, 3] = rng.uniform(-1, 1, 3) * shift * h
+        # rotate about the cloud centre so that the points stay near the grid
+        c = np.array([0.5, 0.5, 0.5]); T[:3, 3] += c - T[:3, :3] @ c
+        cases.append(T.astype(np.float32))
+    A = np.eye(4); A[:3, :3] = np.diag([1.004, 0.997, 1.002]) + 0.002 * rng.normal(size=(3, 3)); A[:3, 3] = [0.3 * h, -0.2 * h, 0.1 * h]
+    cases.append(A.astype(np.float32))
+    ctxs = []
+    for tiled in (0, 2):
+        ctx = Context()
+        ctx.set_option("tiled", tiled)
+        ctx.set_target(d["dst"]); ctx.set_source(d["src"])
+        ctx.find_correspondences(np.eye(4), d["max_sq_dist"], count=False)    # sort under the identity
+        ctxs.append(ctx)
+    for T in cases:
+        (i0, d0), (i1, d1) = (gpu_nn(c, T, d["max_sq_dist"]) for c in ctxs)
+        assert np.array_equal(i0, i1), float(np.mean(i0 != i1))
+        m = i0 >= 0
+        assert np.array_equal(d0[m], d1[m])
+    # and against the kd-tree oracle for the largest motion
+    T = cases[2]
+    q = orc.transform_points(T, d["src"])
+    o1, o2, ov = orc.KDTree(d["dst"]).find_correspondences(q, d["max_sq_dist"])
+    i1, d1 = gpu_nn(ctxs[1], T, d["max_sq_dist"])
+    assert np.array_equal(np.nonzero(i1 >= 0)[0], o2) and np.array_equal(i1[o2], o1) and np.array_equal(d1[o2], ov)
