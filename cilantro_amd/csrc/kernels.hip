@@ -395,8 +395,8 @@ struct OctQuery {
 // Octant-first search (the common case): the 2x2x2 block of cells on the side of q's own cell that q
 // leans towards contains every target point closer than the distance from q to that block's faces, which
 // is at least half a cell.  The block is 4 runs of the sorted target array (2 x-adjacent cells each).
-// The grid carries one layer of empty cells around the data and the fast path only takes queries whose
-// cell is not in that layer, so the block never leaves the grid: no clipping, no validity flags.
+// The grid carries GRID_PAD layers of empty cells around the data and the fast path only takes queries whose
+// cell is not in the outermost layer, so the block never leaves the grid: no clipping, no validity flags.
 // octant_prepare() only needs the query; octant_search() runs out of LDS in STRAIGHT-LINE code: every lane
 // evaluates exactly OCT_CAND unclamped candidates per run (reading past a short run only evaluates further
 // real target points or the far-away pad records -- never wrong), no per-lane loop or branch, so the wave
