@@ -354,15 +354,16 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
   return CILHIP_OK;
 }
 
-// The LDS-tiled kernel runs 1024-thread workgroups, two per CU: below ~4 full rounds of tiles on the
-// 256 CUs the per-lane kernel (8x more, smaller workgroups) balances better (measured at 1M points).
+// The LDS-tiled kernel runs 1024-thread workgroups, two per CU: below ~2 full rounds of tiles on the
+// 256 CUs the per-lane kernel (8x more, smaller workgroups) balances better (measured: per-lane wins at 1M
+// points = 580 tiles, tiled wins from 2M = 1160 tiles on).
 // It also needs tiles that are reasonably full (a source much sparser than the target leaves most lanes of
 // a tile idle: 10M source points against an 80M-point target fill 14 % of the slots) and a target whose
 // local density fits the LDS budget of a tile's region (cube + halo + one cell of drift per axis);
 // otherwise every tile would be handed to the clean-up pass, which is the per-lane search done worse.
 static bool use_tiled(const cilhip_ctx* c) {
   if (c->tiled >= 2) return true;
-  if (c->tiled != 1 || c->ntiles < 2048) return false;
+  if (c->tiled != 1 || c->ntiles < 900) return false;
   const double fill = (double)c->ns / ((double)c->ntiles * (double)TILE_QUERIES);
   const double region_cells = (double)(CUBE_EDGE + 3) * (CUBE_EDGE + 3) * (CUBE_EDGE + 3);
   const double density = c->grid_occ > 1.0 ? c->grid_occ - 1.0 : c->grid_occ;   // sum(count^2)/n = lambda + 1 for a Poisson cloud
