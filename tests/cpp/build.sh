@@ -8,3 +8,5 @@ g++ -O2 -std=c++17 -ffp-contract=off -I"$ROOT/include" "$HERE/$t.cpp" -o "$HERE/
     -L"$ROOT/cilantro_amd/lib" -lcilantro_hip -L"$ROOT/oracle" -loracle \
     -Wl,-rpath,"$ROOT/cilantro_amd/lib" -Wl,-rpath,"$ROOT/oracle" -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib -lamdhip64
 done
+# host-only PLY round-trip helper (no GPU library needed)
+g++ -O2 -std=c++17 -I"$ROOT/include" "$HERE/test_ply.cpp" -o "$HERE/bin/test_ply"

@@ -25,21 +25,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def read_ply_xyz_normals(path):
-    """minimal reader for the reference's test clouds: binary_little_endian, vertex properties float x y z nx ny nz +
-    uchar red green blue (what utilities/ply_io.hpp:43-106 reads through tinyply)"""
-    with open(path, "rb") as f:
-        header = b""
-        while not header.endswith(b"end_header\n"):
-            header += f.readline()
-        lines = header.decode("ascii").split("\n")
-        assert "format binary_little_endian 1.0" in lines
-        n = int([l for l in lines if l.startswith("element vertex")][0].split()[2])
-        props = [l.split()[1:] for l in lines if l.startswith("property")]
-        dt = np.dtype([(name, {"float": "<f4", "uchar": "u1"}[t]) for t, name in props])
-        v = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
-    pts = np.stack([v["x"], v["y"], v["z"]], 1).astype(np.float32)
-    nrm = np.stack([v["nx"], v["ny"], v["nz"]], 1).astype(np.float32)
-    return pts, nrm
+    """the reference's test clouds: binary_little_endian, vertex float x y z nx ny nz + uchar red green blue
+    (what utilities/ply_io.hpp:43-106 reads through tinyply); read with the product's own PLY reader"""
+    from cilantro_amd.ply_io import read_ply
+    c = read_ply(path)
+    return c["points"], c["normals"]
 
 
 def make_frame1_fixture(out_path, ply="/root/reference/examples/test_clouds/frame_1.ply", keep=20000):

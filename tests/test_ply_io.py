@@ -1,0 +1,66 @@
+"""PLY ingest / output either side of the path: the Python reader / writer, the C++ header
+(include/cilantro_hip/point_cloud.hpp) and their interoperability.  CPU only."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cilantro_amd.ply_io import read_ply, write_ply
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin", "test_ply")
+
+
+def _cloud(n=500, seed=0):
+    rng = np.random.default_rng(seed)
+    p = rng.normal(size=(n, 3)).astype(np.float32)
+    nr = rng.normal(size=(n, 3)).astype(np.float32); nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+    c = (rng.integers(0, 256, (n, 3)) / 255.0).astype(np.float32)
+    return p, nr, c
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_python_round_trip(tmp_path, binary):
+    p, nr, c = _cloud()
+    f = str(tmp_path / "a.ply")
+    write_ply(f, p, nr, c, binary=binary)
+    r = read_ply(f)
+    assert np.array_equal(r["points"], p) and np.array_equal(r["normals"], nr)          # %.9g round-trips f32 exactly
+    assert np.array_equal(np.round(r["colors"] * 255), np.round(c * 255))
+    write_ply(f, p, binary=binary)
+    r = read_ply(f)
+    assert np.array_equal(r["points"], p) and r["normals"] is None and r["colors"] is None
+    write_ply(f, np.zeros((0, 3), np.float32), binary=binary)
+    assert len(read_ply(f)["points"]) == 0
+
+
+def test_cpp_header_interoperates(tmp_path, hip_lib, orc):
+    subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cpp", "build.sh")])
+    p, nr, c = _cloud(777, 3)
+    for binary_in in (True, False):
+        for binary_out in (1, 0):
+            a, b = str(tmp_path / "in.ply"), str(tmp_path / "out.ply")
+            write_ply(a, p, nr, c, binary=binary_in)
+            out = subprocess.run([BIN, "copy", a, b, str(binary_out)], capture_output=True, text=True, timeout=60)
+            assert out.returncode == 0 and "777 points normals=1 colors=1" in out.stdout, out.stdout + out.stderr
+            r = read_ply(b)
+            assert np.array_equal(r["points"], p) and np.array_equal(r["normals"], nr)
+            assert np.abs(r["colors"] - c).max() <= 1.0 / 255.0 + 1e-6
+    # a file written by the C++ header alone, read back by Python
+    w = str(tmp_path / "w.ply")
+    assert subprocess.run([BIN, "write", w, "1"], timeout=60).returncode == 0
+    r = read_ply(w)
+    assert r["points"].shape == (1000, 3) and r["normals"] is not None and r["colors"] is not None
+    assert np.all(r["normals"][:, 2] == 1.0)
+
+
+def test_reads_the_references_test_cloud():
+    """examples/test_clouds/frame_1.ply (binary little endian, xyz + normals + uchar rgb): only where the reference is present"""
+    f = "/root/reference/examples/test_clouds/frame_1.ply"
+    if not os.path.exists(f):
+        pytest.skip("reference not present on this box")
+    r = read_ply(f)
+    assert r["points"].shape == (120111, 3) and r["normals"].shape == (120111, 3) and r["colors"].shape == (120111, 3)
+    ok = np.isfinite(r["normals"]).all(axis=1)
+    assert np.abs(np.linalg.norm(r["normals"][ok], axis=1) - 1).max() < 1e-3
