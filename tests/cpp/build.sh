@@ -10,3 +10,6 @@ g++ -O2 -std=c++17 -ffp-contract=off -I"$ROOT/include" "$HERE/$t.cpp" -o "$HERE/
 done
 # host-only PLY round-trip helper (no GPU library needed)
 g++ -O2 -std=c++17 -I"$ROOT/include" "$HERE/test_ply.cpp" -o "$HERE/bin/test_ply"
+# the example program (compile check; run it on a GPU box with a PLY file)
+g++ -O2 -std=c++17 -I"$ROOT/include" "$ROOT/examples/rigid_icp.cpp" -o "$HERE/bin/example_rigid_icp" \
+    -L"$ROOT/cilantro_amd/lib" -lcilantro_hip -Wl,-rpath,"$ROOT/cilantro_amd/lib" -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib -lamdhip64
