@@ -202,6 +202,69 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(KnnArgs a) {
   }
 }
 
+// Radius neighbourhoods (normal_estimation.hpp:120-162 with RadiusNeighborhoodSpecification -> KDTree::radiusSearch,
+// nanoflann RadiusResultSet: d2 < r2, strict): the neighbourhood is unbounded, so nothing is listed -- the moments are
+// accumulated in two passes over the cells the ball overlaps (f64; the reference sums in ascending-distance order in f32).
+__global__ __launch_bounds__(KNN_THREADS) void k_radius_pca(KnnArgs a) {
+  const GridDev& g = a.g;
+  const uint32_t qi = blockIdx.x * KNN_THREADS + threadIdx.x;
+  if (qi >= a.nq) return;
+  const float4 q4 = a.queries[qi];
+  const float qx = q4.x, qy = q4.y, qz = q4.z;
+  const uint32_t orig = __float_as_uint(q4.w);
+  float n0 = NAN, n1 = NAN, n2 = NAN, curv = NAN;
+  const bool finite = fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY;
+  if (finite && g.n > 0 && a.radius_sq > 0.0f) {
+    const float r = sqrtf(a.radius_sq) * 1.000001f + g.margin;   // cells the ball can touch (never fewer)
+    const float BIG = 1.0e9f;
+    const int x0 = max((int)floorf(fminf(fmaxf((qx - r - g.ox) * g.inv_cell, -BIG), BIG)), 0), x1 = min((int)floorf(fminf(fmaxf((qx + r - g.ox) * g.inv_cell, -BIG), BIG)), g.nx - 1);
+    const int y0 = max((int)floorf(fminf(fmaxf((qy - r - g.oy) * g.inv_cell, -BIG), BIG)), 0), y1 = min((int)floorf(fminf(fmaxf((qy + r - g.oy) * g.inv_cell, -BIG), BIG)), g.ny - 1);
+    const int z0 = max((int)floorf(fminf(fmaxf((qz - r - g.oz) * g.inv_cell, -BIG), BIG)), 0), z1 = min((int)floorf(fminf(fmaxf((qz + r - g.oz) * g.inv_cell, -BIG), BIG)), g.nz - 1);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    double cs[6] = {0, 0, 0, 0, 0, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+      if (x0 <= x1)
+        for (int z = z0; z <= z1; ++z)
+          for (int y = y0; y <= y1; ++y) {
+            const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+            const uint32_t beg = g.cell_start[row + x0], end = g.cell_start[row + x1 + 1];
+            for (uint32_t j = beg; j < end; ++j) {
+              const float4 p = g.pts[j];
+              if (!(d2_pinned(qx, qy, qz, p.x, p.y, p.z) < a.radius_sq)) continue;
+              if (pass == 0) { s0 += (double)p.x; s1 += (double)p.y; s2 += (double)p.z; cnt += 1.0; }
+              else {
+                const float t0 = __fsub_rn(p.x, m0), t1 = __fsub_rn(p.y, m1), t2 = __fsub_rn(p.z, m2);
+                cs[0] += (double)__fmul_rn(t0, t0); cs[1] += (double)__fmul_rn(t0, t1); cs[2] += (double)__fmul_rn(t0, t2);
+                cs[3] += (double)__fmul_rn(t1, t1); cs[4] += (double)__fmul_rn(t1, t2); cs[5] += (double)__fmul_rn(t2, t2);
+              }
+            }
+          }
+      if (pass == 0) {
+        if (cnt < 3.0) break;
+        m0 = (float)(s0 / cnt); m1 = (float)(s1 / cnt); m2 = (float)(s2 / cnt);
+      }
+    }
+    if (cnt >= 3.0) {
+      const double inv = cnt - 1.0;
+      const double C[9] = {cs[0] / inv, cs[1] / inv, cs[2] / inv, cs[1] / inv, cs[3] / inv, cs[4] / inv, cs[2] / inv, cs[4] / inv, cs[5] / inv};
+      double w[3], V[9];
+      sym_eig3(C, w, V);
+      n0 = (float)V[2]; n1 = (float)V[5]; n2 = (float)V[8];
+      if (a.use_vp) {
+        const float d = __fadd_rn(__fmul_rn(n0, __fsub_rn(a.vp[0], qx)), __fadd_rn(__fmul_rn(n1, __fsub_rn(a.vp[1], qy)), __fmul_rn(n2, __fsub_rn(a.vp[2], qz))));
+        if (d < 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
+      }
+      curv = (float)(w[2] / ((w[0] + w[1]) + w[2]));
+    }
+    if (a.out_cnt) a.out_cnt[orig] = (uint32_t)cnt;
+  } else if (a.out_cnt) {
+    a.out_cnt[orig] = 0;
+  }
+  a.normals[3 * (size_t)orig] = n0; a.normals[3 * (size_t)orig + 1] = n1; a.normals[3 * (size_t)orig + 2] = n2;
+  if (a.curvature) a.curvature[orig] = curv;
+}
+
 #define KN_CK(x)               \
   do {                         \
     if ((x) != hipSuccess) {   \
@@ -213,7 +276,9 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(KnnArgs a) {
 int knn_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k, float max_sq_dist,
              uint32_t* idx_out, float* d2_out, uint32_t* cnt_out, bool do_pca, const float* view_point, float* normals_out,
              float* curvature_out) {
-  if ((!ref_xyz && n_ref) || k == 0 || k > (size_t)KNN_MAX_K || n_ref > 0xFFFFFFF0ull || n_query > 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
+  const bool radius_only = do_pca && k == 0;   // unbounded neighbourhood: moments only, no list
+  if ((!ref_xyz && n_ref) || (k == 0 && !radius_only) || k > (size_t)KNN_MAX_K || n_ref > 0xFFFFFFF0ull || n_query > 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
+  if (radius_only && !std::isfinite(max_sq_dist)) return CILHIP_ERR_INVALID;
   if (!(max_sq_dist > 0.0f)) max_sq_dist = 0.0f;   // NaN / negative radius: nothing is inside
   const bool self = query_xyz == nullptr;
   if (self) n_query = n_ref;
@@ -251,7 +316,7 @@ int knn_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_
     }
     double mean[3];
     // ~k/4 points per cell: the k-th neighbour then normally lies inside the 3x3x3 block of cells
-    KN_CK(build_grid(d_ref, nullptr, (uint32_t)n_ref, s, &gr, mean, std::max(1.0, (double)k / 4.0)));
+    KN_CK(build_grid(d_ref, nullptr, (uint32_t)n_ref, s, &gr, mean, std::max(1.0, (double)k / 4.0)));   // (radius-only: 1 point per cell)
     have_grid = true;
     // queries in target-grid cell order (identity transform)
     KN_CK(hipMalloc(&d_qs, n_query * sizeof(float4)));
@@ -277,7 +342,10 @@ int knn_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_
         for (int i = 0; i < 3; ++i) a.vp[i] = view_point[i];
       }
     }
-    hipLaunchKernelGGL(k_knn, dim3((unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), k * KNN_THREADS * sizeof(unsigned long long), s, a);
+    if (radius_only)
+      hipLaunchKernelGGL(k_radius_pca, dim3((unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), 0, s, a);
+    else
+      hipLaunchKernelGGL(k_knn, dim3((unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), k * KNN_THREADS * sizeof(unsigned long long), s, a);
     KN_CK(hipGetLastError());
     if (idx_out) KN_CK(hipMemcpyAsync(idx_out, d_idx, n_query * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (idx_out && d2_out) KN_CK(hipMemcpyAsync(d2_out, d_d2, n_query * k * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -312,6 +380,12 @@ int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* qu
   if (!idx_out && !counts_out) return CILHIP_ERR_INVALID;
   return cilhip::knn_impl(device, ref_xyz, n_ref, query_xyz, n_query, mem, k, max_sq_dist, idx_out, d2_out, counts_out, false, nullptr, nullptr,
                           nullptr);
+}
+
+int cilhip_normals_radius3f(int device, const float* xyz, size_t n, int mem, float radius_sq, const float* view_point, float* normals_out,
+                            float* curvature_out) {
+  if (!normals_out && n) return CILHIP_ERR_INVALID;
+  return cilhip::knn_impl(device, xyz, n, nullptr, n, mem, 0, radius_sq, nullptr, nullptr, nullptr, true, view_point, normals_out, curvature_out);
 }
 
 int cilhip_normals_knn3f(int device, const float* xyz, size_t n, int mem, size_t k, float max_sq_dist, const float* view_point,

@@ -7,9 +7,9 @@
 
     ne = NormalEstimation3f(points).setViewPoint([0, 0, 0])   # core/normal_estimation.hpp
     normals, curvature = ne.getNormalsAndCurvatureKNN(k)       # :72-80
-    normals = ne.getNormalsKNNInRadius(k, radius)              # :189-196
+    normals = ne.getNormalsKNNInRadius(k, radius)              # :189-196   (NormalEstimation squares its radius itself, :174)
 
-Radius-only neighbourhoods (variable, unbounded size) are not implemented and raise.
+Radius-only neighbourhoods are supported for the normals (moments accumulated without listing the neighbours).
 """
 import ctypes as C
 
@@ -88,16 +88,36 @@ class NormalEstimation3f:
     def getCurvatureKNN(self, k):
         return self._run(k, np.inf, True)[1]
 
+    @staticmethod
+    def _sq(radius):
+        """NormalEstimation takes a plain radius and squares it in f32 (normal_estimation.hpp:126, :174)"""
+        r = np.float32(radius)
+        return float(r * r)
+
     def getNormalsAndCurvatureKNNInRadius(self, k, radius):
-        return self._run(k, float(radius), True)
+        return self._run(k, self._sq(radius), True)
 
     def getNormalsKNNInRadius(self, k, radius):
-        return self._run(k, float(radius), False)[0]
+        return self._run(k, self._sq(radius), False)[0]
 
     def getCurvatureKNNInRadius(self, k, radius):
-        return self._run(k, float(radius), True)[1]
+        return self._run(k, self._sq(radius), True)[1]
+
+    def _run_radius(self, radius_sq, want_curvature):
+        p, n, mem, keep = _as_cloud(self._points)
+        nrm = np.zeros((n, 3), np.float32)
+        cur = np.zeros(n, np.float32) if want_curvature else None
+        rc = self._L.cilhip_normals_radius3f(self._device, p, n, mem, C.c_float(radius_sq), None if self._vp is None else self._vp.ctypes.data,
+                                             nrm.ctypes.data, None if cur is None else cur.ctypes.data)
+        if rc != capi.OK:
+            raise capi.CilhipError(rc, "cilhip_normals_radius3f failed (no HIP device or bad arguments)")
+        return nrm, cur
 
     def getNormalsAndCurvatureRadius(self, radius):
-        raise NotImplementedError("radius-only neighbourhoods (unbounded size) are not implemented on the GPU path")
+        return self._run_radius(self._sq(radius), True)
 
-    getNormalsRadius = getCurvatureRadius = getNormalsAndCurvatureRadius
+    def getNormalsRadius(self, radius):
+        return self._run_radius(self._sq(radius), False)[0]
+
+    def getCurvatureRadius(self, radius):
+        return self._run_radius(self._sq(radius), True)[1]

@@ -236,6 +236,10 @@ int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* qu
  * eigen-solve in place of Eigen's f32 SelfAdjointEigenSolver. */
 int cilhip_normals_knn3f(int device, const float* xyz, size_t n, int mem, size_t k, float max_sq_dist, const float* view_point,
                          float* normals_out, float* curvature_out);
+/* ...Radius (core/normal_estimation.hpp:120-162, RadiusNeighborhoodSpecification): every point with d2 < radius_sq
+ * (strict) takes part; the neighbourhood is unbounded, its moments are accumulated without listing it. */
+int cilhip_normals_radius3f(int device, const float* xyz, size_t n, int mem, float radius_sq, const float* view_point,
+                            float* normals_out, float* curvature_out);
 
 /* ---- introspection (bench / tests) ----------------------------------------------------------- */
 typedef struct {

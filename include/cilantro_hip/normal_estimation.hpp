@@ -4,8 +4,9 @@
 //   KDTree3f              core/kd_tree.hpp:144-388     kNNSearch :216-256, kNNInRadiusSearch :286-318
 //   NormalEstimation3f    core/normal_estimation.hpp   get/estimate Normals[AndCurvature]KNN[InRadius] :72-221
 //
-// Same method names, argument meaning (radii are SQUARED distances) and defaults as the reference; clouds are
-// non-owning (pointer, count) views.  Radius-only neighbourhoods are not implemented on the GPU path and throw.
+// Same method names, argument meaning and defaults as the reference -- including its asymmetry: KDTree's radii are
+// SQUARED distances (kd_tree.hpp:286-318), NormalEstimation takes a plain radius and squares it itself
+// (normal_estimation.hpp:126, :174).  Clouds are non-owning (pointer, count) views.
 // No CPU fallback: a failing C-ABI call throws.
 #pragma once
 
@@ -75,12 +76,18 @@ public:
   std::vector<float> getNormalsKNN(size_t k) const { std::vector<float> n; run(n, nullptr, k, std::numeric_limits<float>::infinity()); return n; }
   std::vector<float> getCurvatureKNN(size_t k) const { std::vector<float> n, c; run(n, &c, k, std::numeric_limits<float>::infinity()); return c; }
   const NormalEstimation3f& getNormalsAndCurvatureKNNInRadius(std::vector<float>& normals, std::vector<float>& curvature, size_t k, float radius) const {
-    run(normals, &curvature, k, radius);
+    run(normals, &curvature, k, radius * radius);
     return *this;
   }
-  std::vector<float> getNormalsKNNInRadius(size_t k, float radius) const { std::vector<float> n; run(n, nullptr, k, radius); return n; }
-  std::vector<float> getCurvatureKNNInRadius(size_t k, float radius) const { std::vector<float> n, c; run(n, &c, k, radius); return c; }
-  std::vector<float> getNormalsRadius(float) const { throw std::invalid_argument("radius-only neighbourhoods are not implemented on the GPU path"); }
+  std::vector<float> getNormalsKNNInRadius(size_t k, float radius) const { std::vector<float> n; run(n, nullptr, k, radius * radius); return n; }
+  std::vector<float> getCurvatureKNNInRadius(size_t k, float radius) const { std::vector<float> n, c; run(n, &c, k, radius * radius); return c; }
+  // :120-162: every point inside the radius takes part (unbounded neighbourhood; moments accumulated without listing it)
+  const NormalEstimation3f& getNormalsAndCurvatureRadius(std::vector<float>& normals, std::vector<float>& curvature, float radius) const {
+    run_radius(normals, &curvature, radius * radius);
+    return *this;
+  }
+  std::vector<float> getNormalsRadius(float radius) const { std::vector<float> n; run_radius(n, nullptr, radius * radius); return n; }
+  std::vector<float> getCurvatureRadius(float radius) const { std::vector<float> n, c; run_radius(n, &c, radius * radius); return c; }
 
 private:
   void run(std::vector<float>& normals, std::vector<float>* curvature, size_t k, float radius) const {
@@ -90,6 +97,14 @@ private:
     const int rc = cilhip_normals_knn3f(device_, points_.data(), n, CILHIP_MEM_HOST, k, radius, view_point_, normals.data(),
                                         curvature ? curvature->data() : nullptr);
     if (rc != CILHIP_OK) throw std::runtime_error("cilhip_normals_knn3f failed (rc " + std::to_string(rc) + ")");
+  }
+  void run_radius(std::vector<float>& normals, std::vector<float>* curvature, float radius_sq) const {
+    const size_t n = points_.cols();
+    normals.assign(3 * n, 0.0f);
+    if (curvature) curvature->assign(n, 0.0f);
+    const int rc = cilhip_normals_radius3f(device_, points_.data(), n, CILHIP_MEM_HOST, radius_sq, view_point_, normals.data(),
+                                           curvature ? curvature->data() : nullptr);
+    if (rc != CILHIP_OK) throw std::runtime_error("cilhip_normals_radius3f failed (rc " + std::to_string(rc) + ")");
   }
   ConstPointsView points_;
   int device_;

@@ -174,6 +174,7 @@ size_t orc_plane_ransac(const float* pts, size_t n, const uint32_t* samples, siz
 
 /* ---- normals_oracle.c: k-NN batch + NormalEstimation (core/normal_estimation.hpp:294-420) ---- */
 void orc_knn_batch(const orc_kdtree* t, const float* q, size_t nq, size_t k, float radius_sq, int64_t* idx, float* d2, uint32_t* cnt);
+void orc_normals_radius(const float* pts, size_t n, float radius_sq, const float* view_point, int mode, float* normals, float* curvature);
 void orc_normals_knn(const float* pts, size_t n, size_t k, float radius_sq, const float* view_point, int mode, float* normals,
                      float* curvature);
 

@@ -87,3 +87,61 @@ void orc_normals_knn(const float* pts, size_t n, size_t k, float radius_sq, cons
   }
   orc_kdtree_free(t);
 }
+
+/* Radius neighbourhoods (normal_estimation.hpp:120-162 -> KDTree::radiusSearch, nanoflann RadiusResultSet: d2 < r2 strict,
+ * sorted ascending).  The restated kd-tree serves them through its k-NN-in-radius search with k = n. */
+void orc_normals_radius(const float* pts, size_t n, float radius_sq, const float* view_point, int mode, float* normals, float* curvature) {
+  orc_kdtree* t = orc_kdtree_build(pts, n, 10);
+  const int use_vp = view_point && isfinite(view_point[0]) && isfinite(view_point[1]) && isfinite(view_point[2]);
+#pragma omp parallel
+  {
+    uint64_t* ii = (uint64_t*)malloc((n ? n : 1) * sizeof(uint64_t));
+    float* dd = (float*)malloc((n ? n : 1) * sizeof(float));
+#pragma omp for schedule(dynamic, 64)
+    for (size_t i = 0; i < n; ++i) {
+      const size_t m = orc_kdtree_knn_in_radius(t, pts + 3 * i, n, radius_sq, ii, dd);
+      float nrm[3] = {NAN, NAN, NAN}, curv = NAN;
+      if (m >= 3) {
+        float mean[3];
+        double C[9];
+        if (mode == 0) {
+          float s[3] = {0, 0, 0};
+          for (size_t j = 0; j < m; ++j) for (int d = 0; d < 3; ++d) s[d] += pts[3 * ii[j] + d];
+          const float inv = 1.0f / (float)m;
+          for (int d = 0; d < 3; ++d) mean[d] = inv * s[d];
+          float c[9] = {0};
+          for (size_t j = 0; j < m; ++j) {
+            const float tt[3] = {pts[3 * ii[j]] - mean[0], pts[3 * ii[j] + 1] - mean[1], pts[3 * ii[j] + 2] - mean[2]};
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) c[a * 3 + b] += tt[a] * tt[b];
+          }
+          const float invc = 1.0f / (float)(m - 1);
+          for (int a = 0; a < 9; ++a) C[a] = (double)(c[a] * invc);
+        } else {
+          double s[3] = {0, 0, 0};
+          for (size_t j = 0; j < m; ++j) for (int d = 0; d < 3; ++d) s[d] += (double)pts[3 * ii[j] + d];
+          for (int d = 0; d < 3; ++d) mean[d] = (float)(s[d] / (double)m);
+          double c[9] = {0};
+          for (size_t j = 0; j < m; ++j) {
+            const float tt[3] = {pts[3 * ii[j]] - mean[0], pts[3 * ii[j] + 1] - mean[1], pts[3 * ii[j] + 2] - mean[2]};
+            for (int a = 0; a < 3; ++a) for (int b = a; b < 3; ++b) c[a * 3 + b] += (double)(tt[a] * tt[b]);
+          }
+          c[3] = c[1]; c[6] = c[2]; c[7] = c[5];
+          for (int a = 0; a < 9; ++a) C[a] = c[a] / (double)(m - 1);
+        }
+        double w[3], V[9];
+        orc_sym_eig3(C, w, V);
+        nrm[0] = (float)V[2]; nrm[1] = (float)V[5]; nrm[2] = (float)V[8];
+        if (use_vp) {
+          const float* p = pts + 3 * i;
+          const float t0 = nrm[0] * (view_point[0] - p[0]), t1 = nrm[1] * (view_point[1] - p[1]), t2 = nrm[2] * (view_point[2] - p[2]);
+          if (t0 + (t1 + t2) < 0.0f) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+        }
+        curv = (float)(w[2] / ((w[0] + w[1]) + w[2]));
+      }
+      for (int d = 0; d < 3; ++d) normals[3 * i + d] = nrm[d];
+      if (curvature) curvature[i] = curv;
+    }
+    free(ii); free(dd);
+  }
+  orc_kdtree_free(t);
+}

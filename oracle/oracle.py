@@ -119,6 +119,7 @@ def lib():
         L.orc_filter_one_to_one_f2s.restype = C.c_size_t
         L.orc_filter_one_to_one_f2s.argtypes = [_i64p, _i64p, _f32p, C.c_size_t]
         L.orc_knn_batch.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, C.c_float, _i64p, _f32p, _u32p]
+        L.orc_normals_radius.argtypes = [_f32p, C.c_size_t, C.c_float, C.c_void_p, C.c_int, _f32p, _f32p]
         L.orc_normals_knn.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_int, _f32p, _f32p]
         _lib = L
     return _lib
@@ -420,3 +421,11 @@ def find_correspondences_dir(dst, q, max_sq_dist, direction, reciprocal=False, i
         if one_to_one and direction == 1:
             n = lib().orc_filter_one_to_one_f2s(di, si, dv, n)
     return di[:n].copy(), si[:n].copy(), dv[:n].copy()
+
+
+def normals_radius(pts, radius_sq, view_point=None, mode=1):
+    pts = _c(pts).reshape(-1, 3)
+    nrm = np.zeros((len(pts), 3), np.float32); cur = np.zeros(len(pts), np.float32)
+    vp = None if view_point is None else np.ascontiguousarray(view_point, np.float32)
+    lib().orc_normals_radius(pts, len(pts), np.float32(radius_sq), None if vp is None else vp.ctypes.data, mode, nrm.reshape(-1), cur)
+    return nrm, cur

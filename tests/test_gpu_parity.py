@@ -587,9 +587,9 @@ def test_knn_and_normal_estimation_vs_oracle(orc, hip_lib):
     oi, od, oc = orc.knn_batch(tree_o, x[:5000], 6)
     assert np.array_equal(gd[:5000], od) and (gi[:5000] != oi).sum() == 0
     # normals + curvature
-    for k, r2, vp in ((10, np.inf, [0.5, 0.5, 10.0]), (7, np.inf, None), (12, 0.015 ** 2, [0.0, 0.0, -5.0])):
+    for k, r2, vp in ((10, np.inf, [0.5, 0.5, 10.0]), (7, np.inf, None), (12, np.float32(0.015) ** 2, [0.0, 0.0, -5.0])):
         ne = NormalEstimation3f(x).setViewPoint(vp)
-        ng, cg = (ne.getNormalsAndCurvatureKNN(k) if np.isinf(r2) else ne.getNormalsAndCurvatureKNNInRadius(k, r2))
+        ng, cg = (ne.getNormalsAndCurvatureKNN(k) if np.isinf(r2) else ne.getNormalsAndCurvatureKNNInRadius(k, np.sqrt(np.float32(r2))))   # plain radius
         no, co = orc.normals_knn(x, k, r2, vp, mode=1)
         nan_g, nan_o = np.isnan(ng).any(axis=1), np.isnan(no).any(axis=1)
         assert np.array_equal(nan_g, nan_o)
@@ -604,6 +604,16 @@ def test_knn_and_normal_estimation_vs_oracle(orc, hip_lib):
         assert np.abs(np.linalg.norm(ng[ok], axis=1) - 1).max() < 1e-5
         if vp is not None:
             assert (((np.asarray(vp, np.float32) - x[ok]) * ng[ok]).sum(axis=1) >= -1e-6).all()
+    # radius-only neighbourhoods (unbounded size): moments accumulated without a list
+    rad = np.float32(0.012)
+    ng, cg = NormalEstimation3f(x).setViewPoint([0.5, 0.5, 10.0]).getNormalsAndCurvatureRadius(rad)
+    no, co = orc.normals_radius(x, rad * rad, [0.5, 0.5, 10.0], mode=1)
+    nan_g, nan_o = np.isnan(ng).any(axis=1), np.isnan(no).any(axis=1)
+    assert np.array_equal(nan_g, nan_o) and 0 < nan_g.sum() < len(x)            # sparse regions: fewer than 3 points in the ball
+    ok = ~nan_g
+    well = cg[ok] < 0.2
+    assert (((ng[ok] * no[ok]).sum(axis=1))[well] > 1 - 1e-4).mean() > 0.999
+    assert np.nanmax(np.abs(cg[ok] - co[ok])) < 1e-4
     # degenerate inputs
     t2 = KDTree3f(x[:2].copy())
     gi, gd, gc = t2.kNNSearch(q[:10], 5)
