@@ -172,8 +172,10 @@ def main():
         ns, nd, nc = n, n, int(res.last_ncorr)
         # Dominant kernel = the kNN correspondence-search kernel.  Algorithmic bytes of one kNN pass
         # (B_knn): read every source point once (12 B), every target point once (12 B),
-        # write (index, d2) per source point (8 B)  =>  20*Ns + 12*Nd.
-        alg_bytes = 20.0 * ns + 12.0 * nd
+        # write (index, d2) per source point (8 B)  =>  20*Ns + 12*Nd for a stand-alone search.
+        # Inside the ICP loop (no post-filters) nothing reads the squared distances, so the kernel does not write them:
+        # 4 B per source point less than SURVEY's B_knn -- counted as such, not inflated.
+        alg_bytes = 16.0 * ns + 12.0 * nd
         # streaming accumulation kernel (point-to-plane): B_acc = 16*Ns + 24*Nc  
         acc_bytes = 16.0 * ns + (24.0 if with_normals else 12.0) * nc
         # HBM bytes per launch of the search kernel(s) from the committed PMC passes (separate rocprofv3 --pmc runs,

@@ -754,6 +754,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
     return CILHIP_OK;
   }
+  if (!filters_active(c)) a.nn_d2 = nullptr;   // nobody reads the distances inside the loop: 4 B per query less to write
   const bool timing = c->kernel_timing && p->max_iter <= 4096;
   hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
   CK(c, hipEventRecord(e_beg, c->stream));

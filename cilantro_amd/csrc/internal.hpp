@@ -79,7 +79,7 @@ struct IterArgs {
   float tile_axes[9];      // half-axes of a tile cube in SOURCE space (row-major 3x3: component j of axis k), see k_search_tiled
   const IcpState* state;   // T, smt, inner tform, done flags
   uint32_t* nn_pos;        // [ns] (sorted-source order) sorted-target position or NONE
-  float* nn_d2;            // [ns]
+  float* nn_d2;            // [ns], or null: the squared distances are not stored (the ICP loop without post-filters never reads them)
   double* partials;        // [nblocks * SUMS_MAX]
   uint32_t* todo;          // [ns] queries deferred by the tiled search to its clean-up pass
   uint32_t* todo_count;    // [2]: number of deferred queries, number of deferred tiles

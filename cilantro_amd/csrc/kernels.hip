@@ -843,7 +843,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       a.todo[atomicAdd(a.todo_count, 1u)] = i;
     } else {
       a.nn_pos[i] = best.pos;
-      a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
   }
 #ifdef CILHIP_EXP_PHASE_CLOCKS
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const 
       NN best;
       nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
       a.nn_pos[i] = best.pos;
-      a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
   }
   // (b) individual stragglers
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const 
     NN best;
     nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
     a.nn_pos[i] = best.pos;
-    a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
   }
 }
 
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       NN best;
       nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
       pos = best.pos;
-      if (STORE) { a.nn_pos[i] = pos; a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
+      if (STORE) { a.nn_pos[i] = pos; if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
       if (METRIC != IM_NONE && pos != NONE_U32) {
         p = a.grid.pts[pos];
         if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; }
