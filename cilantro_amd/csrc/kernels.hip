@@ -321,9 +321,9 @@ __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, 
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
-  const float dz = __fsub_rn(qz, p.z);
+  const float dz = __fsub_rn(qz, p.w);      // LDS record layout {x, y, bits(index), z}: see k_search_tiled, staging
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
-  const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.w);
+  const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
   bk = lt ? k : bk;
   bp = lt ? pos : bp;
@@ -377,9 +377,9 @@ __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 q
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
-  const float dz = __fsub_rn(qz, p.z);
+  const float dz = __fsub_rn(qz, p.w);      // LDS record layout {x, y, bits(index), z}: see k_search_tiled, staging
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
-  const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.w);
+  const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
   bk = lt ? k : bk;
   sel = lt ? code : sel;      // code is a compile-time constant: no address arithmetic per candidate
@@ -802,15 +802,16 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         }
 #pragma unroll
         for (int m = 0; m < STAGE_ROWS; ++m)
-          if (dst[m] != NONE_U32) lpts[dst[m]] = make_float4(__uint_as_float(v[m].x), __uint_as_float(v[m].y), __uint_as_float(v[m].z), __uint_as_float(v[m].w));
+          if (dst[m] != NONE_U32)   // LDS record = {x, y, bits(index), z}: index and (later) d2 then sit in one aligned register pair, the 64-bit key
+            lpts[dst[m]] = make_float4(__uint_as_float(v[m].x), __uint_as_float(v[m].y), __uint_as_float(v[m].w), __uint_as_float(v[m].z));
       }
     }
     // rare leftovers: rows longer than 32 points
     for (int r = grp; r < rows; r += GR) {
       const uint32_t f = rowbase[r], l = rowbase[r + 1] - f, d = rowdelta[r];
-      for (uint32_t o = o0 + 32u; o < l; o += 16) lpts[f + o] = g.pts[f + o + d];
+      for (uint32_t o = o0 + 32u; o < l; o += 16) { const float4 q = g.pts[f + o + d]; lpts[f + o] = make_float4(q.x, q.y, q.w, q.z); }
     }
-    if (threadIdx.x < 8) lpts[P + threadIdx.x] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __uint_as_float(NONE_U32));  // pad: d2 = inf
+    if (threadIdx.x < 8) lpts[P + threadIdx.x] = make_float4(1.0e30f, 1.0e30f, __uint_as_float(NONE_U32), 1.0e30f);  // pad: d2 = inf
   }
   __syncthreads();
   PHASE_CLK(2);
