@@ -21,6 +21,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # written on host and device; f64 accumulations use explicit fma().
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-result", "-DNDEBUG"]
+# kernels.hip: the SLP vectoriser pairs scalar f32 operations of DIFFERENT candidates into v_pk_* instructions and pays
+# for it in v_mov's that gather the operands (measured: +7 % VALU in the search kernel's hot block); the packed math that
+# pays is written explicitly (f32x2).
+EXTRA_FLAGS = {"kernels.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(out, deps):
@@ -46,7 +50,7 @@ def build(force=False, verbose=False, defines=(), tag=""):
         op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            jobs.append([HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-c", sp, "-o", op])
+            jobs.append([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + [f"-D{d}" for d in defines] + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
