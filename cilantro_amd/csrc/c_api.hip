@@ -42,6 +42,7 @@ struct cilhip_ctx {
   float4* d_src_sorted = nullptr; // sorted cube-major by target-grid cell under sort_T
   uint2* d_tiles = nullptr;       // [ntiles] query ranges of the LDS-tiled search kernel
   float4* d_tile_center = nullptr;  // [ntiles] cube centre of each tile in source space
+  int* d_tile_box = nullptr;        // [8*ntiles] cell range of each tile's cube under the current transform (recomputed per search)
   float tile_axes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t* d_todo = nullptr;     // [ns] deferred queries + 2 counters at d_todo[ns..ns+1]: clean-up lists of the tiled search
   uint32_t* d_todo_tiles = nullptr; // [ntiles]
@@ -147,6 +148,7 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_out_d2) (void)hipFree(c->d_out_d2);
   if (c->d_tiles) (void)hipFree(c->d_tiles);
   if (c->d_tile_center) (void)hipFree(c->d_tile_center);
+  if (c->d_tile_box) (void)hipFree(c->d_tile_box);
   if (c->d_src_nrm) (void)hipFree(c->d_src_nrm);
   if (c->d_src_nrm_sorted) (void)hipFree(c->d_src_nrm_sorted);
   c->d_src_nrm = nullptr; c->d_src_nrm_sorted = nullptr;
@@ -154,7 +156,7 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_keys) (void)hipFree(c->d_keys);
   c->d_keys = nullptr;
   if (c->d_todo_tiles) (void)hipFree(c->d_todo_tiles);
-  c->d_tiles = nullptr; c->d_tile_center = nullptr; c->ntiles = 0; c->d_todo = nullptr; c->d_todo_tiles = nullptr;
+  c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_todo = nullptr; c->d_todo_tiles = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
@@ -342,10 +344,12 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
   if (need) {
     if (c->d_tiles) { (void)hipFree(c->d_tiles); c->d_tiles = nullptr; c->ntiles = 0; }
     if (c->d_tile_center) { (void)hipFree(c->d_tile_center); c->d_tile_center = nullptr; }
+    if (c->d_tile_box) { (void)hipFree(c->d_tile_box); c->d_tile_box = nullptr; }
     if (c->d_todo_tiles) { (void)hipFree(c->d_todo_tiles); c->d_todo_tiles = nullptr; }
     hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->d_tile_center, c->tile_axes, &c->ntiles);
     if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
     CK(c, hipMalloc(&c->d_todo_tiles, ((size_t)c->ntiles + 1) * sizeof(uint32_t)));
+    CK(c, hipMalloc(&c->d_tile_box, ((size_t)c->ntiles + 1) * 8 * sizeof(int)));
     if (c->d_src_nrm) launch_gather_by_w(c->d_src_sorted, c->d_src_nrm, c->ns, c->d_src_nrm_sorted, c->stream);
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
@@ -418,7 +422,7 @@ static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq) {
     launch_init_state(c->d_state_id, kIdentity, zero, c->stream);
   }
   if (c->search_dir == 2 && c->ns && c->grid.n) {   // forward half of BOTH: the usual search, no filters yet
-    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->ntiles, c->stream);
+    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
   }
   const hipError_t e = find_pairs(c->grid, c->d_src_sorted, c->d_src_nrm ? c->d_src_nrm_sorted : nullptr, c->ns, c->d_state, c->d_state_id, max_sq,
@@ -446,7 +450,7 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   }
   c->have_pairs = false;
   if (c->ns) {
-    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->ntiles, c->stream);
+    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
   }
   CK(c, hipGetLastError());
@@ -774,7 +778,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         if (st == 0 && c->fused && !filters_active(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
         } else if (st == 0) {
-          if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->ntiles, c->stream);   // LDS-tiled search kernel
+          if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel
           else launch_iter(a, IM_NONE, true, true, nb, c->stream);                  // per-lane global-memory search
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_event(c, nev++), c->stream)); }
@@ -852,7 +856,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
     if (c->fused) {
       launch_iter(a, im, true, false, nb, c->stream);
     } else {
-      if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->ntiles, c->stream);
+      if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
       else launch_iter(a, IM_NONE, true, true, nb, c->stream);
       launch_iter(a, im, false, false, nb, c->stream);
     }
@@ -892,7 +896,7 @@ int cilhip_icp_partial_keys(cilhip_ctx* c, uint64_t* keys_dev) {
   CK(c, hipSetDevice(c->device));
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   if (c->ns) {
-    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->ntiles, c->stream);
+    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
     launch_pack_keys(c->d_src_sorted, c->grid.pts, c->d_nn_pos, c->d_nn_d2, c->ns, c->index_offset,
                      reinterpret_cast<unsigned long long*>(keys_dev), c->stream);

@@ -103,7 +103,8 @@ struct SolveArgs {
 // kernels.hip
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
 void launch_solve(const SolveArgs& a, hipStream_t s);
-void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, uint32_t ntiles, hipStream_t s);
+void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box /*[8*ntiles] scratch*/, uint32_t ntiles,
+                         hipStream_t s);
 #ifdef CILHIP_EXP_PHASE_CLOCKS
 void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_search_tiled -> stderr
 #endif

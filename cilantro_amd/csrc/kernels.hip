@@ -606,8 +606,53 @@ void debug_dump_phase_clocks() {
 #define PHASE_CLK(k)
 #endif
 
+// Region of every tile under the CURRENT transform, once per search instead of once per wave of the search kernel (the
+// arithmetic is wave-uniform there, but still costs every wave ~100 vector instructions): the image of the tile's cube
+// (oriented box in source space: centre per tile, half-axes common to all tiles) is T c +- |R A| 1, converted to cells.
+// box[8t..8t+7] = bx0, bx1, by0, by1, bz0, bz1 (cell range of the box, already extended into the empty layer next to the
+// data where it touches the first / last data cells), 0, 0.
+__global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center, uint32_t ntiles, int* __restrict__ box) {
+  const IcpState* __restrict__ st = a.state;
+  if (st->done) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const GridDev& g = a.grid;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  const float4 c4 = tile_center[t];
+  float ccx, ccy, ccz;
+  transform_point(T, c4.x, c4.y, c4.z, ccx, ccy, ccz);
+  float ext[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float e = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      e += fabsf(T[i] * a.tile_axes[k] + T[i + 4] * a.tile_axes[3 + k] + T[i + 8] * a.tile_axes[6 + k]);   // |(R A)_ik|
+    ext[i] = e;
+  }
+  const float SHR = 1.0e-3f, BIG = 1.0e9f;   // the cube is half-open: shrink by 1e-3 cell so that an unmoved cube maps to itself
+  int bx0 = (int)floorf(fminf(fmaxf((ccx - ext[0] - g.ox) * g.inv_cell + SHR, -BIG), BIG));
+  int bx1 = (int)floorf(fminf(fmaxf((ccx + ext[0] - g.ox) * g.inv_cell - SHR, -BIG), BIG));
+  int by0 = (int)floorf(fminf(fmaxf((ccy - ext[1] - g.oy) * g.inv_cell + SHR, -BIG), BIG));
+  int by1 = (int)floorf(fminf(fmaxf((ccy + ext[1] - g.oy) * g.inv_cell - SHR, -BIG), BIG));
+  int bz0 = (int)floorf(fminf(fmaxf((ccz - ext[2] - g.oz) * g.inv_cell + SHR, -BIG), BIG));
+  int bz1 = (int)floorf(fminf(fmaxf((ccz + ext[2] - g.oz) * g.inv_cell - SHR, -BIG), BIG));
+  // a box that reaches the first / last layer of data cells also takes the empty layer next to it: the queries the
+  // current transform (or noise) pushed just outside the data's bounding box stay on the fast path
+  if (bx0 <= GRID_PAD) bx0 = min(bx0, GRID_PAD - 1);
+  if (by0 <= GRID_PAD) by0 = min(by0, GRID_PAD - 1);
+  if (bz0 <= GRID_PAD) bz0 = min(bz0, GRID_PAD - 1);
+  if (bx1 >= g.nx - 1 - GRID_PAD) bx1 = max(bx1, g.nx - GRID_PAD);
+  if (by1 >= g.ny - 1 - GRID_PAD) by1 = max(by1, g.ny - GRID_PAD);
+  if (bz1 >= g.nz - 1 - GRID_PAD) bz1 = max(bz1, g.nz - GRID_PAD);
+  int* b = box + 8 * (size_t)t;
+  b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = bz0; b[5] = bz1; b[6] = 0; b[7] = 0;
+}
+
 __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
-                                                                  const float4* __restrict__ tile_center, uint32_t ntiles) {
+                                                                  const int* __restrict__ tile_box, uint32_t ntiles) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
   // XCD-aware tile order: block b runs on XCD b%8 -> each XCD gets one contiguous eighth of the tiles
@@ -638,37 +683,9 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     s4[u] = i < tile.y ? a.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // ---- 1. region of the tile: image of its cube (oriented box in source space) under T, in cells ----
-  int bx0, bx1, by0, by1, bz0, bz1;
-  {
-    const float4 c4 = tile_center[vb];
-    float ccx, ccy, ccz;
-    transform_point(T, c4.x, c4.y, c4.z, ccx, ccy, ccz);
-    float ext[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float e = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        e += fabsf(T[i] * a.tile_axes[k] + T[i + 4] * a.tile_axes[3 + k] + T[i + 8] * a.tile_axes[6 + k]);   // |(R A)_ik|
-      ext[i] = e;
-    }
-    const float SHR = 1.0e-3f, BIG = 1.0e9f;   // the cube is half-open: shrink by 1e-3 cell so that an unmoved cube maps to itself
-    bx0 = (int)floorf(fminf(fmaxf((ccx - ext[0] - g.ox) * g.inv_cell + SHR, -BIG), BIG));
-    bx1 = (int)floorf(fminf(fmaxf((ccx + ext[0] - g.ox) * g.inv_cell - SHR, -BIG), BIG));
-    by0 = (int)floorf(fminf(fmaxf((ccy - ext[1] - g.oy) * g.inv_cell + SHR, -BIG), BIG));
-    by1 = (int)floorf(fminf(fmaxf((ccy + ext[1] - g.oy) * g.inv_cell - SHR, -BIG), BIG));
-    bz0 = (int)floorf(fminf(fmaxf((ccz - ext[2] - g.oz) * g.inv_cell + SHR, -BIG), BIG));
-    bz1 = (int)floorf(fminf(fmaxf((ccz + ext[2] - g.oz) * g.inv_cell - SHR, -BIG), BIG));
-  }
-  // a box that reaches the first / last layer of data cells also takes the empty layer next to it: the queries the
-  // current transform (or noise) pushed just outside the data's bounding box stay on the fast path
-  if (bx0 <= GRID_PAD) bx0 = min(bx0, GRID_PAD - 1);
-  if (by0 <= GRID_PAD) by0 = min(by0, GRID_PAD - 1);
-  if (bz0 <= GRID_PAD) bz0 = min(bz0, GRID_PAD - 1);
-  if (bx1 >= g.nx - 1 - GRID_PAD) bx1 = max(bx1, g.nx - GRID_PAD);
-  if (by1 >= g.ny - 1 - GRID_PAD) by1 = max(by1, g.ny - GRID_PAD);
-  if (bz1 >= g.nz - 1 - GRID_PAD) bz1 = max(bz1, g.nz - GRID_PAD);
+  // ---- 1. region of the tile: the cell range of its cube's image under the current transform (k_tile_boxes) ----
+  const int* tb = tile_box + 8 * (size_t)vb;
+  const int bx0 = tb[0], bx1 = tb[1], by0 = tb[2], by1 = tb[3], bz0 = tb[4], bz1 = tb[5];
   const int lox = max(bx0 - 1, 0), loy = max(by0 - 1, 0), loz = max(bz0 - 1, 0);
   const int hix = min(bx1 + 1, g.nx - 1), hiy = min(by1 + 1, g.ny - 1), hiz = min(bz1 + 1, g.nz - 1);
   const int RX = hix - lox + 1, RY = hiy - loy + 1, RZ = hiz - loz + 1;
@@ -893,11 +910,12 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const 
   }
 }
 
-void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, uint32_t ntiles, hipStream_t s) {
+void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s) {
   if (ntiles == 0) return;
   (void)hipMemsetAsync(a.todo_count, 0, 2 * sizeof(uint32_t), s);
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
-  hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_center, ntiles);
+  hipLaunchKernelGGL(k_tile_boxes, dim3((ntiles + 255) / 256), dim3(256), 0, s, a, tile_center, ntiles, tile_box);
+  hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, (const int*)tile_box, ntiles);
   const uint32_t nb2 = (uint32_t)(((a.ns + ITER_THREADS - 1) / ITER_THREADS) < 2048 ? ((a.ns + ITER_THREADS - 1) / ITER_THREADS) : 2048);
   hipLaunchKernelGGL(k_search_todo, dim3(nb2 ? nb2 : 1), dim3(ITER_THREADS), 0, s, a, tiles);
 }
