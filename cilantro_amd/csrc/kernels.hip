@@ -610,7 +610,7 @@ void debug_dump_phase_clocks() {
 // arithmetic is wave-uniform there, but still costs every wave ~100 vector instructions): the image of the tile's cube
 // (oriented box in source space: centre per tile, half-axes common to all tiles) is T c +- |R A| 1, converted to cells.
 // box[8t..8t+7] = bx0, bx1, by0, by1, bz0, bz1 (cell range of the box, already extended into the empty layer next to the
-// data where it touches the first / last data cells), 0, 0.
+// data where it touches the first / last data cells), then the two reciprocals the search kernel's table fill uses.
 __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center, uint32_t ntiles, int* __restrict__ box) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
@@ -647,8 +647,13 @@ __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center,
   if (bx1 >= g.nx - 1 - GRID_PAD) bx1 = max(bx1, g.nx - GRID_PAD);
   if (by1 >= g.ny - 1 - GRID_PAD) by1 = max(by1, g.ny - GRID_PAD);
   if (bz1 >= g.nz - 1 - GRID_PAD) bz1 = max(bz1, g.nz - GRID_PAD);
+  // reciprocals for the flat cell-table fill of the search kernel (division by a run-time width there would be ~20
+  // emulated instructions per wave): e / W1 == (e * inv_w1) >> 20 for e < 2^20 / W1, r / RY == (r * inv_ry) >> 16 for r < 3855
+  const int W1 = (min(bx1 + 1, g.nx - 1) - max(bx0 - 1, 0) + 1) + 1, RY = min(by1 + 1, g.ny - 1) - max(by0 - 1, 0) + 1;
+  const uint32_t inv_w1 = W1 > 0 ? ((1u << 20) + (uint32_t)W1 - 1u) / (uint32_t)W1 : 0u;
+  const uint32_t inv_ry = RY > 0 ? (65536u + (uint32_t)RY - 1u) / (uint32_t)RY : 0u;
   int* b = box + 8 * (size_t)t;
-  b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = bz0; b[5] = bz1; b[6] = 0; b[7] = 0;
+  b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = bz0; b[5] = bz1; b[6] = (int)inv_w1; b[7] = (int)inv_ry;
 }
 
 __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
@@ -705,8 +710,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   const __amdgpu_buffer_rsrc_t rs_cs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)g.cell_start, 0, ((uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz + 1u) * 4u, 0x00020000);
   {
-    const uint32_t inv_w1 = ((1u << 20) + (uint32_t)W1 - 1u) / (uint32_t)W1;   // e / W1 == (e * inv_w1) >> 20 for e < 2^20 / W1
-    const uint32_t inv_ry = (65536u + (uint32_t)RY - 1u) / (uint32_t)RY;       // r / RY == (r * inv_ry) >> 16 for r < 3855
+    const uint32_t inv_w1 = (uint32_t)tb[6], inv_ry = (uint32_t)tb[7];   // e / W1 == (e * inv_w1) >> 20, r / RY == (r * inv_ry) >> 16 (k_tile_boxes)
     constexpr int TRIPS = (TILE_MAXE + TILE_THREADS - 1) / TILE_THREADS;
     const uint32_t rowstride = (uint32_t)g.nx, slab = (uint32_t)g.ny * (uint32_t)g.nx;
     const uint32_t gbase = ((uint32_t)loz * (uint32_t)g.ny + (uint32_t)loy) * (uint32_t)g.nx + (uint32_t)lox;
@@ -715,10 +719,12 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     for (int k = 0; k < TRIPS; ++k) {
       if (k * TILE_THREADS < E) {   // block-uniform
         const uint32_t e = (uint32_t)k * TILE_THREADS + threadIdx.x;
-        const uint32_t r = (e * inv_w1) >> 20;
-        const uint32_t x = e - r * (uint32_t)W1;
-        const uint32_t zr = (r * inv_ry) >> 16;
-        const uint32_t gi = gbase + zr * slab + (r - zr * (uint32_t)RY) * rowstride + x;
+        // (24-bit multiplies: full rate, and every factor here is far below 2^24 -- e < 2^13, inv_w1 <= 2^17,
+        //  rows < 2^9, inv_ry <= 2^16, grid dims <= 2^11 per axis)
+        const uint32_t r = __umul24(e, inv_w1) >> 20;
+        const uint32_t x = e - __umul24(r, (uint32_t)W1);
+        const uint32_t zr = __umul24(r, inv_ry) >> 16;
+        const uint32_t gi = gbase + __umul24(zr, slab) + __umul24(r - __umul24(zr, (uint32_t)RY), rowstride) + x;
         v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_cs, e < (uint32_t)E ? gi * 4u : 0xFFFFFFFFu, 0, 0);
       }
     }
