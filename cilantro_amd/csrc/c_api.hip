@@ -224,6 +224,9 @@ int cilhip_debug_counters(cilhip_ctx* c, uint32_t out[2]) {
   CK(c, hipSetDevice(c->device));
   CK(c, hipMemcpyAsync(out, c->d_todo + (c->ns ? c->ns : 1), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   CK(c, hipStreamSynchronize(c->stream));
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+  cilhip::debug_dump_phase_clocks();
+#endif
   return CILHIP_OK;
 }
 
@@ -366,6 +369,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
 // local density fits the LDS budget of a tile's region (cube + halo + one cell of drift per axis);
 // otherwise every tile would be handed to the clean-up pass, which is the per-lane search done worse.
 static bool use_tiled(const cilhip_ctx* c) {
+  if (c->ns >= 0x80000000ull) return false;   // the clean-up list keeps a flag in bit 31 of a query index
   if (c->tiled >= 2) return true;
   if (c->tiled != 1 || c->ntiles < 900) return false;
   const double fill = (double)c->ns / ((double)c->ntiles * (double)TILE_QUERIES);

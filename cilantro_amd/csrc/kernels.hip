@@ -278,6 +278,75 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
   nn_search_shells(g, qx, qy, qz, cx, cy, cz, 2, best);
 }
 
+// The same exact search by a GROUP of G adjacent lanes for ONE query (the clean-up pass of the tiled search: few queries,
+// each with a large block of cells to look at -- one lane per query leaves the chip idle behind long dependent chains).
+// The rows of the (2s+1)^2 x (2s+1) block around the query's cell are dealt round-robin to the lanes, each row one run of
+// the sorted target array; the group then takes the minimum key (keys are unique: they carry the target index).  If the
+// block does not prove the result, s grows straight to the size the best found so far needs.  All control flow is
+// uniform within a group.  `sub` = lane index inside the group; every lane of the group returns the same result.
+template <int G>
+__device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, float qy, float qz, float max_sq, int sub, int s_start, NN& best) {
+  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  best.pos = NONE_U32;
+  const float BIG = 1.0e9f;
+  const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
+  const float fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG);
+  const float fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  {  // query farther than the radius from the whole grid: nothing to find
+    const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
+    const float gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
+    const float gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+    if ((gx * gx + gy * gy + gz * gz) * KSHRINK >= max_sq) return;
+  }
+  // first block size that reaches the grid at all
+  int s = max(s_start, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+  for (;;) {
+    const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1);
+    const int y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+    const int xa = max(cx - s, 0), xb = min(cx + s, g.nx - 1);
+    if (xa <= xb && y0 <= y1 && z0 <= z1) {
+      const float gx = axis_gap(qx, g.ox + (float)xa * g.cell, g.ox + (float)(xb + 1) * g.cell, g.margin);
+      const float gx2 = gx * gx;
+      const int wy = y1 - y0 + 1, nrows = wy * (z1 - z0 + 1);
+      int z = z0, y = y0 + sub;                    // row `sub` of the block, then every G-th
+      while (y > y1) { y -= wy; ++z; }
+      for (int k = sub; k < nrows; k += G) {
+        const float zl = g.oz + (float)z * g.cell, yl = g.oy + (float)y * g.cell;
+        const float gz = axis_gap(qz, zl, zl + g.cell, g.margin), gy = axis_gap(qy, yl, yl + g.cell, g.margin);
+        if ((gz * gz + gy * gy + gx2) * KSHRINK <= __uint_as_float((uint32_t)(best.key >> 32))) {
+          const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          scan_range4(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
+        }
+        y += G;
+        while (y > y1) { y -= wy; ++z; }
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+      const unsigned long long ok = __shfl_xor(best.key, off, 64);
+      const uint32_t op = __shfl_xor(best.pos, off, 64);
+      if (ok < best.key) { best.key = ok; best.pos = op; }
+    }
+    // lower bound on the distance to anything outside the block (and inside the grid)
+    float b = INFINITY;
+    if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+    if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+    if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+    if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+    if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+    if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+    if (b == INFINITY) break;  // block covers the grid: everything scanned
+    b -= g.margin;
+    const float bd = __uint_as_float((uint32_t)(best.key >> 32));   // the radius while nothing is found
+    if (b > 0.0f && bd < b * b * KSHRINK) break;
+    // the block size that proves a result at distance sqrt(bd) whatever the offset of q in its cell (at least one more)
+    // (nothing found yet: grow geometrically -- the radius may be infinite)
+    const float need = sqrtf(bd) * g.inv_cell + 1.0f;
+    s = (best.pos == NONE_U32) ? s + max(1, s >> 1) : max(s + 1, (int)fminf(need, (float)(g.nx + g.ny + g.nz)));
+  }
+}
+
 // =====================================================================================================
 // LDS-tiled search kernel.
 //
@@ -299,11 +368,15 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
 //      blocks; then all waves copy the rows into LDS with 16 lanes per row (each row of the region is
 //      ONE contiguous run of the sorted target array) -- every target point is fetched once per tile
 //      instead of once per lane;
-//   3. every lane searches out of LDS (ds_read_b128): octant-first in straight-line code, the full
-//      3x3x3 block with per-row culling for the lanes the octant does not prove.
-// Exactness is unchanged: lanes whose 3x3x3 block does not prove the result (sparse data, large
-// radius), queries outside the grid or outside the tile's box, and whole tiles whose region exceeds the
-// LDS budget (queries that drifted far from their sort-time cells) fall back to the global-memory search.
+//   3. every lane searches out of LDS (ds_read_b128): (a) octant-first in straight-line code; the queries
+//      the octant does not prove are queued in LDS and (b) searched in the full 3x3x3 block, again in
+//      straight-line code, packed densely over the lanes (so a wave never runs the long block for a few
+//      of its lanes, and a source still far from its final pose -- most octant proofs failing -- costs
+//      one dense second pass instead of a divergent one).
+// Exactness is unchanged: queries whose 3x3x3 block does not prove the result (sparse data, large
+// radius), queries outside the grid or outside the tile's box, the slabs of a region that exceed the LDS
+// budget (and whole tiles whose region cannot be staged at all: queries that drifted far from their
+// sort-time cells) fall back to the global-memory search of the clean-up pass, k_search_todo.
 constexpr int TILE_CAP = CILHIP_TILE_CAP;                    // staged target points per tile (16 B each)
 constexpr int TILE_MAXSPAN = CUBE_EDGE + 6;                  // region rows per axis (y, z) the row tables hold
 constexpr int TILE_MAXROWS = TILE_MAXSPAN * TILE_MAXSPAN;    // RY*RZ
@@ -338,21 +411,6 @@ __device__ __forceinline__ uint32_t lds_to_global(uint32_t l, const uint32_t* ro
     if (rowbase[mid] <= l) lo = mid; else hi = mid;
   }
   return l + rowdelta[lo];
-}
-
-// LDS candidate scan, 4 per trip, NOT clamped to the range: reading up to 3 records past `end` only
-// evaluates further real target points (or the far-away pad records after the tile), which can never
-// make the result wrong -- and it removes the per-candidate index clamps.  `bl` tracks the LDS index of
-// the best; it is converted to a position in the global sorted array once, after the search.
-__device__ __forceinline__ void scan_lds4(const float4* lpts, uint32_t beg, uint32_t end,
-                                          const f32x2 qxy, float qz, unsigned long long& bk, uint32_t& bl) {
-  for (uint32_t j = beg; j < end; j += 4) {
-    const float4 p0 = lpts[j], p1 = lpts[j + 1], p2 = lpts[j + 2], p3 = lpts[j + 3];
-    eval_candidate(p0, qxy, qz, j, bk, bl);
-    eval_candidate(p1, qxy, qz, j + 1, bk, bl);
-    eval_candidate(p2, qxy, qz, j + 2, bk, bl);
-    eval_candidate(p3, qxy, qz, j + 3, bk, bl);
-  }
 }
 
 struct TileLds {
@@ -501,93 +559,86 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
 
-// Exact search of one in-grid query out of the LDS tile: own cell, then the 3x3x3 block with per-row
-// culling (the lanes the octant block did not prove).  Returns false if the 3x3x3 block does not prove
-// the result (the query then goes to the clean-up pass).
-__device__ __forceinline__ bool search_in_tile(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
+// The full 3x3x3 block of cells around the query's cell, for the queries the octant block did not prove, in
+// STRAIGHT-LINE code: 9 runs of 3 x-adjacent cells, B27_CAND unclamped candidates each, no culling, no per-lane loop --
+// the wave executes each instruction once with all its lanes busy (the queued queries are packed densely over the
+// lanes, see phase 3b of the kernel).  Longer runs go through a per-lane list afterwards (most lanes: none or one).
+// Needs cx, cy, cz one cell inside the region on every side (the fast range).  Returns false if the block does not
+// prove the result (the query then goes to the clean-up pass).
+#ifndef CILHIP_B27_CAND
+#define CILHIP_B27_CAND 6
+#endif
+constexpr int B27_CAND = CILHIP_B27_CAND;
+__device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
                                                int cx, int cy, int cz, float max_sq, NN& best) {
   const f32x2 qxy = {qx, qy};
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
-  uint32_t bl = NONE_U32;                                    // LDS index of the best
   const int row0 = (cz - t.loz) * t.RY + (cy - t.loy);       // region row of the own cell
-  const int e0i = row0 * t.W1 + (cx - t.lox);                // its entry in the cell table
-  const uint32_t d0 = t.rowdelta[row0];
-  const uint32_t b0 = t.lcs[e0i] - d0, e0 = t.lcs[e0i + 1] - d0;
-  scan_lds4(t.lpts, b0, e0, qxy, qz, bk, bl);
-  const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
-  const float gmx = fmaxf(qx - xl - g.margin, 0.0f), gpx = fmaxf(xl + g.cell - qx - g.margin, 0.0f);
-  const float gmy = fmaxf(qy - yl - g.margin, 0.0f), gpy = fmaxf(yl + g.cell - qy - g.margin, 0.0f);
-  const float gmz = fmaxf(qz - zl - g.margin, 0.0f), gpz = fmaxf(zl + g.cell - qz - g.margin, 0.0f);
-  const bool hmx = cx > 0, hpx = cx + 1 < g.nx, hmy = cy > 0, hpy = cy + 1 < g.ny, hmz = cz > 0, hpz = cz + 1 < g.nz;
-  float bface = INFINITY;
-  if (hmx) bface = fminf(bface, gmx);
-  if (hpx) bface = fminf(bface, gpx);
-  if (hmy) bface = fminf(bface, gmy);
-  if (hpy) bface = fminf(bface, gpy);
-  if (hmz) bface = fminf(bface, gmz);
-  if (hpz) bface = fminf(bface, gpz);
-  const float bd0 = __uint_as_float((uint32_t)(bk >> 32));
-  bool proven = true;
-  if (!((bface == INFINITY) || (bd0 < bface * bface * KSHRINK))) {
-    const float ax2m = gmx * gmx, ax2p = gpx * gpx, ay2m = gmy * gmy, ay2p = gpy * gpy, az2m = gmz * gmz, az2p = gpz * gpz;
-    // work mask from the best after the own cell: bit r (r = 3*dz+dy, 0..8) = row r still holds candidates,
-    // bit 9+r / 18+r = its x-1 / x+1 cell does too.  Own row (r = 4): only the side cells (bits 4 and 27).
-    uint32_t mask = 0;
+  const int e0 = row0 * t.W1 + (cx - t.lox) - 1;             // table entry of the x-1 cell of that row
+  uint32_t sel = 0xFFFFu;
+  uint32_t over = 0;            // bit r: run r is longer than B27_CAND
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int dz = r / 3, dy = r % 3;
-      const float gyz2 = (dz == 0 ? az2m : dz == 2 ? az2p : 0.0f) + (dy == 0 ? ay2m : dy == 2 ? ay2p : 0.0f);
-      const bool okr = (dz == 0 ? hmz : dz == 2 ? hpz : true) && (dy == 0 ? hmy : dy == 2 ? hpy : true) && (gyz2 * KSHRINK <= bd0);
-      const bool left = okr && hmx && ((gyz2 + ax2m) * KSHRINK <= bd0);
-      const bool right = okr && hpx && ((gyz2 + ax2p) * KSHRINK <= bd0);
-      if (r == 4) { if (left) mask |= 1u << 4; if (right) mask |= 1u << 27; }
-      else if (okr) mask |= 1u << r;
-      if (left) mask |= 1u << (9 + r);
-      if (right) mask |= 1u << (18 + r);
+  for (int r = 0; r < 9; ++r) {
+    const int off = (r / 3 - 1) * t.RY + (r % 3 - 1);
+    const uint32_t dl = t.rowdelta[row0 + off];
+    const uint32_t rj = t.lcs[e0 + off * t.W1] - dl, re = t.lcs[e0 + off * t.W1 + 3] - dl;
+    over |= (re > rj + (uint32_t)B27_CAND) ? (1u << r) : 0u;
+#pragma unroll
+    for (int h = 0; h < B27_CAND; h += 3) {     // three loads in flight at a time: the block shares the kernel's 64 registers
+      float4 p[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p[c] = t.lpts[rj + h + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) eval_candidate_sel(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel);
     }
-    // ONE flattened loop over all remaining ranges of this lane (dense trips across the wave)
-    uint32_t items = mask & 0x080001FFu;
-    uint32_t j = 0, e = 0;
-    for (;;) {
-      if (j >= e) {
-        if (items == 0) break;
-        const int it = __ffs(items) - 1;
-        items &= items - 1;
-        const int r = (it == 27) ? 4 : it;
-        const int dz = (r * 11) >> 5, dy = r - 3 * dz;      // r/3, r%3 for r in 0..8
-        const float gyz2 = (dz == 0 ? az2m : dz == 2 ? az2p : 0.0f) + (dy == 0 ? ay2m : dy == 2 ? ay2p : 0.0f);
-        if (gyz2 * KSHRINK > __uint_as_float((uint32_t)(bk >> 32))) continue;   // culled by a newer best
-        const int row = row0 + (dz - 1) * t.RY + (dy - 1);
-        const int eb = e0i + ((dz - 1) * t.RY + (dy - 1)) * t.W1;   // own-cell column of that row
-        const uint32_t dl = t.rowdelta[row];
-        if (it == 4) { j = t.lcs[eb - 1] - dl; e = b0; }                 // own row, x-1 side
-        else if (it == 27) { j = e0; e = t.lcs[eb + 2] - dl; }            // own row, x+1 side
-        else { j = t.lcs[eb - ((mask >> (9 + r)) & 1u)] - dl; e = t.lcs[eb + 1 + ((mask >> (18 + r)) & 1u)] - dl; }
-        continue;
-      }
+  }
+  uint32_t bl = NONE_U32;
+  int brow = row0;
+  if (sel != 0xFFFFu) {
+    const int r = (int)(sel >> 3);
+    const int dz = (r * 11) >> 5, dy = r - 3 * dz;            // r/3, r%3 for r in 0..8
+    const int off = (dz - 1) * t.RY + (dy - 1);
+    brow = row0 + off;
+    bl = t.lcs[e0 + off * t.W1] - t.rowdelta[brow] + (sel & 7u);
+  }
+  // the rest of the long runs: each lane walks its own list of them (most lanes: none or one), so the wave pays
+  // the longest list, not one pass per run of the block
+  while (over) {
+    const int r = __ffs(over) - 1;
+    over &= over - 1;
+    const int dz = (r * 11) >> 5, dy = r - 3 * dz;
+    const int off = (dz - 1) * t.RY + (dy - 1);
+    const uint32_t dl = t.rowdelta[row0 + off];
+    const uint32_t re = t.lcs[e0 + off * t.W1 + 3] - dl;
+    const uint32_t before = bl;
+    for (uint32_t j = t.lcs[e0 + off * t.W1] - dl + (uint32_t)B27_CAND; j < re; j += 4) {
       const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
       eval_candidate(p0, qxy, qz, j, bk, bl);
       eval_candidate(p1, qxy, qz, j + 1, bk, bl);
       eval_candidate(p2, qxy, qz, j + 2, bk, bl);
       eval_candidate(p3, qxy, qz, j + 3, bk, bl);
-      j += 4;
     }
-    // does the 3x3x3 block prove exactness?
-    float b = INFINITY;
-    if (cx - 1 > 0) b = fminf(b, gmx + g.cell);
-    if (cx + 2 < g.nx) b = fminf(b, gpx + g.cell);
-    if (cy - 1 > 0) b = fminf(b, gmy + g.cell);
-    if (cy + 2 < g.ny) b = fminf(b, gpy + g.cell);
-    if (cz - 1 > 0) b = fminf(b, gmz + g.cell);
-    if (cz + 2 < g.nz) b = fminf(b, gpz + g.cell);
-    if (b != INFINITY) {
-      b -= g.margin;
-      if (!(b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK)) proven = false;   // rare
-    }
+    if (bl != before) brow = row0 + off;
   }
   best.key = bk;
-  best.pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
-  return proven;
+  uint32_t pos = NONE_U32;
+  if (bl != NONE_U32) {
+    if (bl < t.rowbase[brow + 1]) pos = bl + t.rowdelta[brow];   // an over-read winner may lie past the end of its run's row
+    else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
+  }
+  best.pos = pos;
+  // does the 3x3x3 block prove exactness?  (no bound from a side where the block reaches the edge of the grid)
+  const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
+  float b = INFINITY;
+  if (cx - 1 > 0) b = fminf(b, ux);
+  if (cx + 2 < g.nx) b = fminf(b, g.cell - ux);
+  if (cy - 1 > 0) b = fminf(b, uy);
+  if (cy + 2 < g.ny) b = fminf(b, g.cell - uy);
+  if (cz - 1 > 0) b = fminf(b, uz);
+  if (cz + 2 < g.nz) b = fminf(b, g.cell - uz);
+  if (b == INFINITY) return true;
+  b = fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin;
+  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
 
 #ifdef CILHIP_EXP_PHASE_CLOCKS
@@ -669,7 +720,12 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   __shared__ uint32_t lcs[TILE_MAXE];
   __shared__ uint32_t rowbase[TILE_MAXROWS + 1];
   __shared__ uint32_t rowdelta[TILE_MAXROWS];
+  __shared__ uint32_t queue_count;            // queries queued for the 3x3x3 pass (phase 3)
+  __shared__ float tform_lds[16];             // the transform, for phase 3b
+  __shared__ int geom_lds[8];                 // the region's geometry, for phase 3b (so that nothing it derives is kept live from here)
   float4* lpts = reinterpret_cast<float4*>(raw);
+  if (threadIdx.x == 0) queue_count = 0;      // (several barriers before its first use)
+  if (threadIdx.x < 16) tform_lds[threadIdx.x] = st->T[threadIdx.x];
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   unsigned long long tprev_ = wall_clock64();
 #endif
@@ -694,7 +750,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   const int lox = max(bx0 - 1, 0), loy = max(by0 - 1, 0), loz = max(bz0 - 1, 0);
   const int hix = min(bx1 + 1, g.nx - 1), hiy = min(by1 + 1, g.ny - 1), hiz = min(bz1 + 1, g.nz - 1);
   const int RX = hix - lox + 1, RY = hiy - loy + 1, RZ = hiz - loz + 1;
-  const int rows = RY * RZ, W1 = RX + 1, E = rows * W1;
+  int rows = RY * RZ;               // (shrinks if the region's points exceed the LDS budget)
+  const int W1 = RX + 1, E = rows * W1;
   // cells of the box whose whole 3x3x3 neighbourhood is inside the grid: the only ones the fast path takes
   const int fx0 = max(bx0, 1), fx1 = min(bx1, g.nx - 2), fy0 = max(by0, 1), fy1 = min(by1, g.ny - 2), fz0 = max(bz0, 1), fz1 = min(bz1, g.nz - 2);
   bool ok = (fx0 <= fx1) & (fy0 <= fy1) & (fz0 <= fz1) & (RY <= TILE_MAXSPAN) & (RZ <= TILE_MAXSPAN) & (E <= TILE_MAXE);   // block-uniform
@@ -704,6 +761,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
     return;
   }
+
+  if (threadIdx.x == 0) { geom_lds[0] = lox; geom_lds[1] = loy; geom_lds[2] = loz; geom_lds[3] = RY; geom_lds[4] = W1; geom_lds[5] = rows; }
 
   // ---- 2a. cell table of the region: rows x (RX+1) cell_start values, flat over the block.  Buffer loads:
   //          32-bit offsets (one shift per address) and out-of-range lanes simply read 0 ----
@@ -791,10 +850,24 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   }
   __syncthreads();
   PHASE_CLK(1);
-  const uint32_t P = rowbase[rows];
-  if (P > (uint32_t)TILE_CAP) {   // block-uniform: the data is much denser here than the LDS budget assumes
-    if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
-    return;
+  uint32_t P = rowbase[rows];
+  if (P > (uint32_t)TILE_CAP) {   // block-uniform: the region holds more points than the LDS budget
+    // Drop z-slabs off the top of the region until it fits (rows are z-major, so rowbase[k * RY] = points of the first k
+    // slabs); the queries whose 3x3x3 block needs a dropped slab leave the fast path and go to the clean-up pass one by
+    // one.  Only a region that does not even fit three slabs sends the whole tile there.
+    int rz = RZ;
+    while (rz > 3 && rowbase[rz * RY] > (uint32_t)TILE_CAP) --rz;
+    if (rowbase[rz * RY] > (uint32_t)TILE_CAP) {
+      if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
+      return;
+    }
+    rows = rz * RY;
+    P = rowbase[rows];
+    const int fz1n = loz + rz - 2;   // last cell whose z+1 slab is still staged
+#pragma unroll
+    for (int u = 0; u < TILE_QPT; ++u)
+      if ((int)floorf((oq[u].qz - g.oz) * g.inv_cell) > fz1n) flags &= ~(1u << (8 + u));
+    if (threadIdx.x == 0) geom_lds[5] = rows;
   }
   // ---- 2d. stage the points: 16 lanes per row (every row is one contiguous run of the sorted target array),
   //          four rows in flight per lane; buffer loads (32-bit offsets, idle lanes read out of range = nothing) ----
@@ -839,35 +912,90 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   __syncthreads();
   PHASE_CLK(2);
   // ---- 3. per-lane exact search out of LDS (or hand-off to the clean-up pass) ----
+  // 3a: the octant block, every lane, straight-line.  Queries it does not prove are QUEUED in LDS (16-bit slot ids in
+  // the unused tail of the point buffer) instead of being finished in place: finishing them in place costs a wave the
+  // whole 3x3x3 search even when one of its lanes needs it.
   TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
+  // (queue base and capacity are re-derived from the LDS row table where needed rather than kept in registers across
+  //  the search: P = rowbase[rows], block-uniform)
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
-    if (!((flags >> u) & 1u)) continue;
+    const bool active = (flags >> u) & 1u, fast = (flags >> (8 + u)) & 1u;
     const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
     NN best;
     best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
     best.pos = NONE_U32;
-    bool defer = false;
-    if ((flags >> (8 + u)) & 1u) {
-      if (!octant_search(g, tl, oq[u], a.max_sq, best)) {   // full 3x3x3 search (the cell is recomputed: rare path)
-        const int cx = (int)floorf((oq[u].qx - g.ox) * g.inv_cell), cy = (int)floorf((oq[u].qy - g.oy) * g.inv_cell),
-                  cz = (int)floorf((oq[u].qz - g.oz) * g.inv_cell);
-        defer = !search_in_tile(g, tl, oq[u].qx, oq[u].qy, oq[u].qz, cx, cy, cz, a.max_sq, best);
+    bool defer = false, unproven = false;
+    if (active) {
+      if (fast) {
+        unproven = !octant_search(g, tl, oq[u], a.max_sq, best);
+      } else {
+        // outside the tile's box or in the grid's outer layer (or beyond): nothing to find if the query is farther
+        // from the grid than the radius, else the clean-up pass (generic search) takes it
+        const float gx = axis_gap(oq[u].qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
+        const float gy = axis_gap(oq[u].qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
+        const float gz = axis_gap(oq[u].qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+        defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
       }
-    } else {
-      // outside the tile's box or in the grid's outer layer (or beyond): nothing to find if the query is farther
-      // from the grid than the radius, else the clean-up pass (generic search) takes it
-      const float gx = axis_gap(oq[u].qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
-      const float gy = axis_gap(oq[u].qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
-      const float gz = axis_gap(oq[u].qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
-      defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
     }
-    if (defer) {
-      // hand the query to the clean-up pass (k_search_todo: generic global-memory search); order-independent
-      a.todo[atomicAdd(a.todo_count, 1u)] = i;
-    } else {
-      a.nn_pos[i] = best.pos;
-      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    const unsigned long long m = __ballot(unproven);
+    if (m) {   // one LDS atomic per wave
+      const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)m) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&queue_count, (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[rows]);
+      uint16_t* const queue = reinterpret_cast<uint16_t*>(lpts + Pq + 8);
+      const uint32_t queue_cap = min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 8u);
+      if (unproven) {
+        if (slot < queue_cap) {
+          queue[slot] = (uint16_t)(u * TILE_THREADS + threadIdx.x);
+        } else {   // no room (a tile near the LDS budget with many unproven queries): the clean-up pass takes it
+          defer = true;
+          unproven = false;
+        }
+      }
+    }
+    if (active && !unproven) {
+      if (defer) {
+        // hand the query to the clean-up pass (k_search_todo: generic global-memory search); order-independent
+        a.todo[atomicAdd(a.todo_count, 1u)] = i;
+      } else {
+        a.nn_pos[i] = best.pos;
+        if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+      }
+    }
+  }
+  __syncthreads();
+  // 3b: the queued queries, densely packed over the lanes: the full 3x3x3 block (straight-line when the wave is
+  // reasonably full, the culled per-lane loop for a sparse last wave).  The query is fetched and transformed again.
+  if (__builtin_amdgcn_readfirstlane((int)queue_count) == 0) return;   // block-uniform
+  TileLds tq{lpts, lcs, rowbase, rowdelta, __builtin_amdgcn_readfirstlane(geom_lds[0]), __builtin_amdgcn_readfirstlane(geom_lds[1]),
+             __builtin_amdgcn_readfirstlane(geom_lds[2]), __builtin_amdgcn_readfirstlane(geom_lds[3]),
+             __builtin_amdgcn_readfirstlane(geom_lds[4]), __builtin_amdgcn_readfirstlane(geom_lds[5])};
+  const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[tq.rows]);
+  const uint16_t* const queue = reinterpret_cast<const uint16_t*>(lpts + Pq + 8);
+  const uint32_t nq = min((uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count), min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 8u));
+  if (threadIdx.x < nq) {   // wave-uniform except in the last wave
+    float Tq[16];        // from LDS rather than kept live across the kernel
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Tq[k] = tform_lds[k];
+    for (uint32_t k = threadIdx.x; k < nq; k += TILE_THREADS) {
+      const uint32_t i = tile.x + queue[k];
+      const float4 sq = a.src[i];
+      float qx, qy, qz;
+      transform_point(Tq, sq.x, sq.y, sq.z, qx, qy, qz);
+      const int cx = (int)floorf((qx - g.ox) * g.inv_cell), cy = (int)floorf((qy - g.oy) * g.inv_cell), cz = (int)floorf((qz - g.oz) * g.inv_cell);
+      NN best;
+      bool proven;
+      proven = block27_search(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best);
+      if (proven) {
+        a.nn_pos[i] = best.pos;
+        if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+      } else {
+        a.todo[atomicAdd(a.todo_count, 1u)] = i | 0x80000000u;
+      }
     }
   }
 #ifdef CILHIP_EXP_PHASE_CLOCKS
@@ -879,6 +1007,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
 // Clean-up pass of the tiled search: the (few) queries the LDS tile could not settle -- sparse data or a
 // radius beyond the 3x3x3 block, queries outside the grid, tiles whose region exceeded the LDS budget --
 // run the generic exact search out of global memory.
+constexpr int TODO_GROUP = 8;   // lanes per deferred query
 __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const uint2* __restrict__ tiles) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
@@ -903,16 +1032,20 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const 
       if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
   }
-  // (b) individual stragglers
-  for (uint32_t t = blockIdx.x * ITER_THREADS + threadIdx.x; t < n; t += gridDim.x * ITER_THREADS) {
-    const uint32_t i = a.todo[t];
+  // (b) individual stragglers: TODO_GROUP lanes per query (bit 31 of an entry: the 3x3x3 block was already searched)
+  const int sub = threadIdx.x & (TODO_GROUP - 1);
+  for (uint32_t t = (blockIdx.x * ITER_THREADS + threadIdx.x) / TODO_GROUP; t < n; t += gridDim.x * (ITER_THREADS / TODO_GROUP)) {
+    const uint32_t e = a.todo[t];
+    const uint32_t i = e & 0x7FFFFFFFu;
     const float4 s4 = a.src[i];
     float qx, qy, qz;
     transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
     NN best;
-    nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
-    a.nn_pos[i] = best.pos;
-    if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, (e >> 31) ? 2 : 1, best);
+    if (sub == 0) {
+      a.nn_pos[i] = best.pos;
+      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    }
   }
 }
 

@@ -737,3 +737,40 @@ def test_tiled_search_under_large_and_non_rigid_motion(Context, orc):
     o1, o2, ov = orc.KDTree(d["dst"]).find_correspondences(q, d["max_sq_dist"])
     i1, d1 = gpu_nn(ctxs[1], T, d["max_sq_dist"])
     assert np.array_equal(np.nonzero(i1 >= 0)[0], o2) and np.array_equal(i1[o2], o1) and np.array_equal(d1[o2], ov)
+
+
+@pytest.mark.gpu
+def test_tiled_clean_up_pass_sparse_far_and_unbounded(Context, orc):
+    """The queries the LDS tiles cannot settle -- far outside the target's grid, inside holes of the target, results
+    beyond the 3x3x3 block, with a finite, a large and an infinite radius -- are searched by groups of lanes out of
+    global memory.  Same indices and distances as the per-lane search and as the kd-tree oracle."""
+    n = 200_000
+    d = syn.make_pair(n, perturb=0.4)
+    h = d["h"]
+    rng = np.random.default_rng(11)
+    dst = d["dst"].copy()
+    keep = np.linalg.norm(dst - np.array([0.5, 0.5, 0.5], np.float32), axis=1) > 0.12     # a hole ~7 cells across
+    keep &= ~((dst[:, 0] > 0.8) & (rng.random(n) < 0.9))                                   # and a thinned-out slab
+    dst = np.ascontiguousarray(dst[keep])
+    src = d["src"].copy()
+    far = rng.choice(n, n // 50, replace=False)
+    src[far] += rng.normal(size=(far.size, 3)).astype(np.float32) * np.float32(20 * h)    # outliers, many outside the grid
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = np.array([0.9, 0.8, 0.7], np.float32) * h
+    q = orc.transform_points(T, src)
+    tree = orc.KDTree(dst)
+    ctxs = []
+    for tiled in (0, 2):
+        ctx = Context()
+        ctx.set_option("tiled", tiled)
+        ctx.set_target(dst); ctx.set_source(src)
+        ctx.find_correspondences(np.eye(4), d["max_sq_dist"], count=False)    # sort under the identity
+        ctxs.append(ctx)
+    for max_sq in (float(d["max_sq_dist"]), float((6 * h) ** 2), float("inf")):
+        (i0, d0), (i1, d1) = (gpu_nn(c, T, max_sq) for c in ctxs)
+        assert np.array_equal(i0, i1), float(np.mean(i0 != i1))
+        m = i1 >= 0
+        assert np.array_equal(d0[m], d1[m])
+        o1, o2, ov = tree.find_correspondences(q, max_sq)
+        assert np.array_equal(np.nonzero(m)[0], o2) and np.array_equal(i1[o2], o1) and np.array_equal(d1[o2], ov)
+    dq, _ = ctxs[1].debug_counters()
+    assert dq > 1000      # the group search really ran

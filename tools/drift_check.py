@@ -12,7 +12,10 @@ ctx = Context(0)
 ctx.set_target(d["dst"], None); ctx.set_source(d["src"])
 ctx.set_option("tiled", 2)
 ctx.find_correspondences(np.eye(4, dtype=np.float32), float(d["max_sq_dist"]), count=False)   # sorts under the identity
-for shift in ((0, 0, 0), (0.3, 0.1, 0.2), (0.5, 0.5, 0.5), (0.9, 0.8, 0.7), (1.5, 2.5, 3.5)):
+SHIFTS = ((0, 0, 0), (0.3, 0.1, 0.2), (0.5, 0.5, 0.5), (0.9, 0.8, 0.7), (1.5, 2.5, 3.5))
+if len(sys.argv) > 2:
+    SHIFTS = (SHIFTS[int(sys.argv[2])],)      # one case only (for a kernel trace)
+for shift in SHIFTS:
     T = np.eye(4, dtype=np.float32); T[:3, 3] = np.array(shift, np.float32) * d["h"]
     ctx.find_correspondences(T, float(d["max_sq_dist"]), count=False); ctx.synchronize()
     t0 = time.perf_counter()
