@@ -21,7 +21,7 @@ SYMBOLS = [
     "cilhip_create", "cilhip_destroy", "cilhip_last_error", "cilhip_set_stream", "cilhip_synchronize",
     "cilhip_set_target", "cilhip_set_source", "cilhip_set_source_normals", "cilhip_get_means", "cilhip_find_correspondences",
     "cilhip_get_nn", "cilhip_get_correspondences", "cilhip_estimate_point_to_point",
-    "cilhip_estimate_combined", "cilhip_icp_default_params", "cilhip_icp_run", "cilhip_icp_begin",
+    "cilhip_estimate_combined", "cilhip_estimate_affine", "cilhip_icp_default_params", "cilhip_icp_run", "cilhip_icp_begin",
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
     "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing",
     "cilhip_set_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
@@ -100,6 +100,7 @@ def load():
     L.cilhip_estimate_point_to_point.argtypes = [vp, f32p, f64p, C.POINTER(C.c_int)]
     L.cilhip_estimate_combined.argtypes = [vp, C.c_float, C.c_float, C.c_size_t, C.c_float, f32p, f64p,
                                            f64p, C.POINTER(C.c_int)]
+    L.cilhip_estimate_affine.argtypes = [vp, C.c_float, C.c_float, C.c_int, f32p, f64p, f64p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.cilhip_icp_default_params.argtypes = [C.POINTER(IcpParams)]
     L.cilhip_icp_default_params.restype = None
     L.cilhip_icp_run.argtypes = [vp, C.POINTER(IcpParams), f32p, C.POINTER(IcpResult)]

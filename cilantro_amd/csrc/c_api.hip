@@ -63,7 +63,7 @@ struct cilhip_ctx {
   double* d_partials = nullptr;
   int partial_blocks = 0;
   double* d_stage = nullptr;      // [REDUCE_STAGE_DOUBLES] stage-1 rows of the cross-block reduction
-  double* d_sums = nullptr;       // [SUMS_MAX]
+  double* d_sums = nullptr;       // [3 * SUMS_MAX] (the affine estimator reduces three passes before one copy to the host)
   bool fused = false;             // true: search+accumulate in one kernel; false: search kernel + streaming accumulate kernel (faster: the search runs at 2x the occupancy)
   double cell_occupancy = 1.0;    // target points per grid cell (takes effect at the next set_target)
   unsigned long long* d_count = nullptr;
@@ -80,6 +80,7 @@ struct cilhip_ctx {
   // other search directions (correspondence_search_kd_tree.hpp:185-222): the correspondence set is a pair list
   int search_dir = 0;             // 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH
   bool reciprocal = false;        // require_reciprocality_ (BOTH only)
+  int transform_mode = 0;         // 0 = rigid (Isometry), 1 = affine: which ICP instance family cilhip_icp_run mirrors
   PairSet pairs;
   bool have_pairs = false;        // `pairs` holds the result of the last find_correspondences
   IcpState* d_state_id = nullptr; // a state holding the identity transform (the reverse search transforms nothing)
@@ -129,7 +130,7 @@ int cilhip_create(cilhip_ctx** out, int device) {
   }
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc(&c->d_stage, REDUCE_STAGE_DOUBLES * sizeof(double)) != hipSuccess || hipMalloc(&c->d_sums, SUMS_MAX * sizeof(double)) != hipSuccess) {
+      hipMalloc(&c->d_stage, REDUCE_STAGE_DOUBLES * sizeof(double)) != hipSuccess || hipMalloc(&c->d_sums, 3 * SUMS_MAX * sizeof(double)) != hipSuccess) {
     delete c;
     return CILHIP_ERR_HIP;
   }
@@ -209,6 +210,11 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "search_direction")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "search_direction: 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH");
     c->search_dir = (int)value; c->have_nn = false; c->have_pairs = false;
+    return CILHIP_OK;
+  }
+  if (!strcmp(key, "transform_mode")) {
+    if (value != 0.0 && value != 1.0) return fail(c, CILHIP_ERR_INVALID, "transform_mode: 0 = rigid, 1 = affine");
+    c->transform_mode = (int)value;
     return CILHIP_OK;
   }
   if (!strcmp(key, "require_reciprocality")) { c->reciprocal = value != 0.0; c->have_nn = false; c->have_pairs = false; return CILHIP_OK; }
@@ -644,6 +650,121 @@ int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t ma
   return CILHIP_OK;
 }
 
+static hipEvent_t get_event(cilhip_ctx* c, size_t i);
+
+// ---- affine variants: SimpleCombinedMetricAffineICP3f / SimplePointToPointMetricAffineICP3f ---------------------------
+// Moments of the 12-unknown normal equations over the stored correspondences (matches or pair list), three streaming
+// passes on the device, one copy to the host.
+static int affine_accumulate(cilhip_ctx* c, bool centered, bool plane, double sums[3 * SUMS_MAX]) {
+  for (int i = 0; i < 3 * SUMS_MAX; ++i) sums[i] = 0.0;
+  launch_init_state(c->d_state, c->nn_T, c->src_mean, c->stream);
+  IterArgs a = make_iter_args(c, 0.0f);
+  if (c->have_pairs) { a.src = c->pairs.src_view; a.ns = c->pairs.count; a.nn_pos = c->pairs.posd; }
+  a.src_nrm = nullptr;   // (the symmetric metric exists for the rigid classes only)
+  a.no_centering = centered ? 0 : 1;
+  if (a.ns == 0) return CILHIP_OK;
+  const int nb = iter_num_blocks(a.ns);
+  if (nb > c->partial_blocks) {
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    c->d_partials = nullptr; c->partial_blocks = 0;
+    CK(c, hipMalloc(&c->d_partials, (size_t)nb * SUMS_MAX * sizeof(double)));
+    c->partial_blocks = nb;
+  }
+  a.partials = c->d_partials;
+  const int passes[3] = {IM_AFF0, IM_AFF1, IM_AFF2};
+  const int np = plane ? 3 : 1;
+  for (int k = 0; k < np; ++k) {
+    launch_iter(a, passes[k], false, false, nb, c->stream);
+    launch_reduce_partials(c->d_partials, nb, c->d_stage, c->d_sums + k * SUMS_MAX, c->stream);
+  }
+  CK(c, hipGetLastError());
+  CK(c, hipMemcpyAsync(sums, c->d_sums, (size_t)np * SUMS_MAX * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  return CILHIP_OK;
+}
+
+int cilhip_estimate_affine(cilhip_ctx* c, float w_p2p, float w_p2pl, int centered, float dT[16], double* AtA_out,
+                           double* Atb_out, size_t* n_corr, int* ok) {
+  if (!c || !dT) return CILHIP_ERR_INVALID;
+  if (!c->have_nn && !c->have_pairs) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
+  CK(c, hipSetDevice(c->device));
+  memcpy(dT, kIdentity, sizeof(kIdentity));
+  if (ok) *ok = 0;
+  if (n_corr) *n_corr = 0;
+  if (AtA_out) for (int i = 0; i < 144; ++i) AtA_out[i] = 0.0;
+  if (Atb_out) for (int i = 0; i < 12; ++i) Atb_out[i] = 0.0;
+  const bool wp = w_p2p > 0.0f, wl = w_p2pl > 0.0f;
+  if (!wp && !wl) return CILHIP_OK;                      // transform_estimation.hpp:400-409
+  if (wl && !c->has_normals) return CILHIP_OK;           // dst_p.cols() != dst_n.cols() -> identity, false
+  double sums[3 * SUMS_MAX];
+  const int rc = affine_accumulate(c, centered != 0, wl, sums);
+  if (rc) return rc;
+  const double n = sums[0];
+  if (n_corr) *n_corr = (size_t)n;
+  if (!(n > 0.0)) return CILHIP_OK;                      // no correspondences: identity, false
+  double AtA[144], Atb[12], th[12];
+  affine_normal_equations(sums, sums + SUMS_MAX, sums + 2 * SUMS_MAX, wp ? (double)w_p2p : 0.0, wl ? (double)w_p2pl : 0.0, AtA, Atb);
+  if (AtA_out) memcpy(AtA_out, AtA, sizeof(AtA));
+  if (Atb_out) memcpy(Atb_out, Atb, sizeof(Atb));
+  ldlt_solve_n(12, AtA, Atb, th);                        // :468 AtA.ldlt().solve(Atb)
+  double L[9], t[3];
+  for (int i = 0; i < 9; ++i) L[i] = th[i];              // :470-472 row-major linear part, then the translation
+  for (int i = 0; i < 3; ++i) t[i] = th[9 + i];
+  if (centered) {                                        // :473 tform = t_dst * tform * t_src
+    float smt[3];
+    transform_point(c->nn_T, c->src_mean[0], c->src_mean[1], c->src_mean[2], smt[0], smt[1], smt[2]);
+    for (int r = 0; r < 3; ++r)
+      t[r] = t[r] - (L[r * 3] * (double)smt[0] + L[r * 3 + 1] * (double)smt[1] + L[r * 3 + 2] * (double)smt[2]) + (double)c->dst_mean[r];
+  }
+  pack_T(L, t, dT);
+  if (ok) *ok = ((wp ? 1.0 : 0.0) + (wl ? 1.0 : 0.0)) * n >= 4.0;
+  return CILHIP_OK;
+}
+
+// icp_base.hpp:68-87 with the affine updateEstimate() (icp_single_transform_point_to_point_metric.hpp:46-65,
+// icp_single_transform_combined_metric.hpp:173-217 without the rotation() polish): host-driven, one 12x12 solve per iteration.
+static int icp_run_affine(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, cilhip_icp_result* out) {
+  float T[16];
+  memcpy(T, T0 ? T0 : kIdentity, sizeof(T));
+  float delta = INFINITY;
+  size_t it = 0, ncorr = 0;
+  hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
+  CK(c, hipEventRecord(e_beg, c->stream));
+  while (it < p->max_iter) {
+    int rc = cilhip_find_correspondences(c, T, p->max_sq_dist, nullptr);
+    if (rc) return rc;
+    float dT[16];
+    if (p->metric == CILHIP_METRIC_POINT_TO_POINT) rc = cilhip_estimate_affine(c, 1.0f, 0.0f, 0, dT, nullptr, nullptr, &ncorr, nullptr);
+    else rc = cilhip_estimate_affine(c, p->w_p2p, p->w_p2pl, 1, dT, nullptr, nullptr, &ncorr, nullptr);
+    if (rc) return rc;
+    float Tn[16] = {0};
+    Tn[15] = 1.0f;                                       // transform_ = tform_iter * transform_ (f32, Eigen affine product)
+    for (int r = 0; r < 3; ++r) {
+      for (int cc = 0; cc < 3; ++cc) Tn[cc * 4 + r] = dT[0 * 4 + r] * T[cc * 4 + 0] + dT[1 * 4 + r] * T[cc * 4 + 1] + dT[2 * 4 + r] * T[cc * 4 + 2];
+      Tn[12 + r] = (dT[0 * 4 + r] * T[12] + dT[1 * 4 + r] * T[13] + dT[2 * 4 + r] * T[14]) + dT[12 + r];
+    }
+    memcpy(T, Tn, sizeof(T));
+    float dn = 0.0f;
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) { const float v = dT[cc * 4 + r] - (r == cc ? 1.0f : 0.0f); dn += v * v; }
+    for (int r = 0; r < 3; ++r) dn += dT[12 + r] * dT[12 + r];
+    delta = std::sqrt(dn);
+    ++it;
+    if (delta < p->conv_tol) break;
+  }
+  CK(c, hipEventRecord(e_end, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  memcpy(out->T, T, sizeof(T));
+  out->iterations = it;
+  out->last_delta_norm = delta;
+  out->last_ncorr = ncorr;
+  c->have_nn = false; c->have_pairs = false;
+  float ms = 0.f;
+  CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
+  c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
+  return CILHIP_OK;
+}
+
 void cilhip_icp_default_params(cilhip_icp_params* p) {
   if (!p) return;
   p->metric = CILHIP_METRIC_COMBINED;
@@ -697,6 +818,10 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (!c || !p || !out) return CILHIP_ERR_INVALID;
   if (p->metric != CILHIP_METRIC_POINT_TO_POINT && p->metric != CILHIP_METRIC_COMBINED) return fail(c, CILHIP_ERR_INVALID, "icp_run: bad metric");
   CK(c, hipSetDevice(c->device));
+  if (c->transform_mode == 1) {
+    if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "the affine variants are not available on target shards");
+    return icp_run_affine(c, p, T0, out);
+  }
   const float* Ti = T0 ? T0 : kIdentity;
   int rc = ensure_sorted(c, Ti);
   if (rc) return rc;

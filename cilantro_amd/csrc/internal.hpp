@@ -67,7 +67,11 @@ struct IcpState {
   double sums[SUMS_MAX];  // reduced sums of the last accumulation
 };
 
-enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4 };
+enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
+                  // moments of the 12-unknown affine normal equations (transform_estimation.hpp:369-476), three streaming passes:
+                  IM_AFF0 = 5,    // [0] n, [1..6] sum s s^T (upper), [7..9] sum s, [10..18] sum s_a d_r, [19..21] sum d, [22..33] sum (n.d) n_j (s,1)_a
+                  IM_AFF1 = 6,    // sum n_j n_k (s,1)_a (s,1)_b, (j,k) = (0,0),(0,1),(0,2) x the 10 pairs a <= b
+                  IM_AFF2 = 7 };  // the same for (j,k) = (1,1),(1,2),(2,2)
 
 struct IterArgs {
   GridDev grid;
@@ -85,6 +89,7 @@ struct IterArgs {
   uint32_t* todo_count;    // [2]: number of deferred queries, number of deferred tiles
   uint32_t* todo_tiles;    // [ntiles] tiles deferred as a whole
   int skip_if_inner_done;
+  int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
 };
 
 struct SolveArgs {

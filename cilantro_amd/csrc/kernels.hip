@@ -1071,7 +1071,8 @@ struct AccTraits {
   static constexpr bool plane = (METRIC == IM_PLANE || METRIC == IM_BOTH);
   static constexpr bool point = (METRIC == IM_POINT || METRIC == IM_BOTH);
   static constexpr bool kabsch = (METRIC == IM_KABSCH);
-  static constexpr int NA = kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
+  static constexpr bool affine = (METRIC == IM_AFF0 || METRIC == IM_AFF1 || METRIC == IM_AFF2);
+  static constexpr int NA = affine ? (METRIC == IM_AFF0 ? 34 : 30) : kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
   static constexpr int NB = point ? 15 : 0;                  // slots [28, 28+NB)
 };
 
@@ -1092,6 +1093,8 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
   for (int i = 0; i < 9; ++i) iL[i] = st->innerL[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { it[i] = st->innert[i]; smt[i] = st->smt[i]; }
+  float dmean[3] = {a.dst_mean[0], a.dst_mean[1], a.dst_mean[2]};
+  if (a.no_centering) { smt[0] = smt[1] = smt[2] = 0.0f; dmean[0] = dmean[1] = dmean[2] = 0.0f; }
 
   __shared__ uint2 worklist[SEARCH ? LIST_CAP * ITER_THREADS : 1];
   uint2* lst = worklist + (SEARCH ? threadIdx.x : 0);
@@ -1125,9 +1128,58 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) accA[7 + r * 3 + c] = fma(pd[r], qd[c], accA[7 + r * 3 + c]);
+    } else if (TR::affine) {
+      // Affine closed form (transform_estimation.hpp:369-476; :50-102 for the point-to-point class): per-term
+      // quantities in f32 as the reference forms them -- s = q - src_mean', d = p - dst_mean -- their products and
+      // sums in f64.  eq_vec = (n_0 s, n_1 s, n_2 s, n): every entry of eq_vec eq_vec^T is n_j n_k (s,1)_a (s,1)_b.
+      const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
+      const float s0 = __fsub_rn(qx, smt[0]), s1 = __fsub_rn(qy, smt[1]), s2 = __fsub_rn(qz, smt[2]);
+      const double sd[4] = {(double)s0, (double)s1, (double)s2, 1.0};
+      if (METRIC == IM_AFF0) {
+        const double dd[3] = {(double)d0, (double)d1, (double)d2};
+        accA[0] += 1.0;
+        int k = 1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = r; c < 3; ++c) { accA[k] = fma(sd[r], sd[c], accA[k]); ++k; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) accA[7 + c] += sd[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) accA[10 + r * 3 + c] = fma(sd[r], dd[c], accA[10 + r * 3 + c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) accA[19 + c] += dd[c];
+        if (a.grid.nrm) {
+          // n.dot(dst - dst_mean)  (:464), f32 like the reference's dot product
+          const float res = __fadd_rn(__fadd_rn(__fmul_rn(nvp.x, d0), __fmul_rn(nvp.y, d1)), __fmul_rn(nvp.z, d2));
+          const double nd[3] = {(double)nvp.x, (double)nvp.y, (double)nvp.z};
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const double rn = (double)res * nd[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accA[22 + j * 4 + c] = fma(rn, sd[c], accA[22 + j * 4 + c]);
+          }
+        }
+      } else {
+        const double nd[3] = {(double)nvp.x, (double)nvp.y, (double)nvp.z};
+        int k = 0;
+#pragma unroll
+        for (int jk = 0; jk < 3; ++jk) {
+          // (j,k): AFF1 -> (0,0),(0,1),(0,2); AFF2 -> (1,1),(1,2),(2,2)
+          const int j = (METRIC == IM_AFF1) ? 0 : (jk == 2 ? 2 : 1);
+          const int kk = (METRIC == IM_AFF1) ? jk : (jk == 0 ? 1 : 2);
+          const double nn = nd[j] * nd[kk];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = r; c < 4; ++c) { accA[k] = fma(nn * sd[r], sd[c], accA[k]); ++k; }
+        }
+      }
     } else {
       // per-term quantities in f32 exactly as the reference forms them (transform_estimation.hpp:302-304,:333-335)
-      const float d0 = __fsub_rn(p.x, a.dst_mean[0]), d1 = __fsub_rn(p.y, a.dst_mean[1]), d2 = __fsub_rn(p.z, a.dst_mean[2]);
+      const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
       const float u0 = __fsub_rn(qx, smt[0]), u1 = __fsub_rn(qy, smt[1]), u2 = __fsub_rn(qz, smt[2]);
       // s = inner_tform * (q - T*src_mean); identity on the first Gauss-Newton step
       const float s0 = __fadd_rn(__fadd_rn(__fmul_rn(iL[0], u0), __fadd_rn(__fmul_rn(iL[1], u1), __fmul_rn(iL[2], u2))), it[0]);
@@ -1196,8 +1248,8 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       const uint32_t ia = i0, ib = i0 + ITER_THREADS;
       float4 p_a = make_float4(0.f, 0.f, 0.f, 0.f), nv_a = p_a, sn_a = p_a, p_b = p_a, nv_b = p_a, sn_b = p_a;
       if (METRIC != IM_NONE) {
-        if (posa != NONE_U32) { p_a = a.grid.pts[posa]; if (TR::plane) { nv_a = a.grid.nrm[posa]; if (a.src_nrm) sn_a = a.src_nrm[ia]; } }
-        if (posb != NONE_U32) { p_b = a.grid.pts[posb]; if (TR::plane) { nv_b = a.grid.nrm[posb]; if (a.src_nrm) sn_b = a.src_nrm[ib]; } }
+        if (posa != NONE_U32) { p_a = a.grid.pts[posa]; if (TR::plane) { nv_a = a.grid.nrm[posa]; if (a.src_nrm) sn_a = a.src_nrm[ia]; } else if (TR::affine && a.grid.nrm) nv_a = a.grid.nrm[posa]; }
+        if (posb != NONE_U32) { p_b = a.grid.pts[posb]; if (TR::plane) { nv_b = a.grid.nrm[posb]; if (a.src_nrm) sn_b = a.src_nrm[ib]; } else if (TR::affine && a.grid.nrm) nv_b = a.grid.nrm[posb]; }
       }
       i0 += 2 * ITER_THREADS;
       if (i0 < end) { sa = a.src[i0]; pa = a.nn_pos[i0]; } else pa = NONE_U32;
@@ -1227,7 +1279,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       if (STORE) { a.nn_pos[i] = pos; if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
       if (METRIC != IM_NONE && pos != NONE_U32) {
         p = a.grid.pts[pos];
-        if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; }
+        if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; } else if (TR::affine && a.grid.nrm) nvp = a.grid.nrm[pos];
       }
     }
     accumulate(qx, qy, qz, pos, p, nvp, snp);
@@ -1286,6 +1338,9 @@ void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nbl
     case IM_KABSCH: launch_iter_m<IM_KABSCH>(a, search, store, nblocks, s); break;
     case IM_PLANE: launch_iter_m<IM_PLANE>(a, search, store, nblocks, s); break;
     case IM_POINT: launch_iter_m<IM_POINT>(a, search, store, nblocks, s); break;
+    case IM_AFF0: hipLaunchKernelGGL((k_iter<IM_AFF0, false, false>), dim3(nblocks), dim3(ITER_THREADS), 0, s, a); break;   // stored matches only
+    case IM_AFF1: hipLaunchKernelGGL((k_iter<IM_AFF1, false, false>), dim3(nblocks), dim3(ITER_THREADS), 0, s, a); break;
+    case IM_AFF2: hipLaunchKernelGGL((k_iter<IM_AFF2, false, false>), dim3(nblocks), dim3(ITER_THREADS), 0, s, a); break;
     default: launch_iter_m<IM_BOTH>(a, search, store, nblocks, s); break;
   }
 }

@@ -347,4 +347,90 @@ CILHIP_HD void sym_eig3(const double Ain[9], double w[3], double V[9]) {
   if (det < 0.0) { V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8]; }
 }
 
+// ---- affine variants (transform_estimation.hpp:369-476 combined, :50-102 point-to-point class) --------------------
+// 12 unknowns theta = (row-major 3x3 linear part, translation); eq_vec of a plane term = (n_0 s, n_1 s, n_2 s, n),
+// the three eq_vecs of a point term = s in block j and e_j in the tail.  With st = (s, 1):
+//   AtA[(j,a),(k,b)] = w_pl * sum n_j n_k st_a st_b  +  w_pt * delta_jk * sum st_a st_b,
+//   Atb[(j,a)]       = w_pl * sum (n.d) n_j st_a     +  w_pt * sum st_a d_j,         index (j,a) = a < 3 ? 3j+a : 9+j.
+// s0/s1/s2: the reduced sums of the IM_AFF0/1/2 passes (layout: internal.hpp, IterMetric).
+inline int affine_pair_slot(int a, int b) {   // position of (a <= b) among the 10 pairs of 0..3, row by row
+  if (a > b) { const int t = a; a = b; b = t; }
+  const int base[4] = {0, 4, 7, 9};
+  return base[a] + (b - a);
+}
+inline void affine_normal_equations(const double* s0, const double* s1, const double* s2, double w_pt, double w_pl,
+                                    double AtA[144], double Atb[12]) {
+  for (int i = 0; i < 144; ++i) AtA[i] = 0.0;
+  for (int i = 0; i < 12; ++i) Atb[i] = 0.0;
+  auto idx = [](int j, int a) { return a < 3 ? 3 * j + a : 9 + j; };
+  auto S = [&](int a, int b) -> double {     // sum st_a st_b
+    if (a > b) { const int t = a; a = b; b = t; }
+    if (b < 3) { const int up[3] = {1, 4, 6}; return s0[up[a] + (b - a)]; }
+    if (a < 3) return s0[7 + a];
+    return s0[0];
+  };
+  auto M = [&](int j, int k, int a, int b) -> double {   // sum n_j n_k st_a st_b
+    if (j > k) { const int t = j; j = k; k = t; }
+    const int p = affine_pair_slot(a, b);
+    if (j == 0) return s1[k * 10 + p];
+    return s2[(j == 1 ? (k - 1) : 2) * 10 + p];
+  };
+  for (int j = 0; j < 3; ++j)
+    for (int a = 0; a < 4; ++a) {
+      const int r = idx(j, a);
+      for (int k = 0; k < 3; ++k)
+        for (int b = 0; b < 4; ++b) {
+          double v = 0.0;
+          if (w_pl > 0.0) v += w_pl * M(j, k, a, b);
+          if (w_pt > 0.0 && j == k) v += w_pt * S(a, b);
+          AtA[r * 12 + idx(k, b)] = v;
+        }
+      double bv = 0.0;
+      if (w_pl > 0.0) bv += w_pl * s0[22 + 4 * j + a];
+      if (w_pt > 0.0) bv += w_pt * (a < 3 ? s0[10 + 3 * a + j] : s0[19 + j]);
+      Atb[r] = bv;
+    }
+}
+
+// n x n LDL^T with diagonal pivoting and the pseudo-inverse of D (Eigen LDLT::solve semantics), n <= 12; host side.
+inline void ldlt_solve_n(int n, const double* Ain, const double* bin, double* x) {
+  double A[144], y[12];
+  int perm[12];
+  for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  const double tiny = 2.2250738585072014e-308;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    double best = fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i)
+      if (fabs(A[i * n + i]) > best) { best = fabs(A[i * n + i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < n; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+      for (int i = 0; i < n; ++i) { const double t = A[i * n + k]; A[i * n + k] = A[i * n + piv]; A[i * n + piv] = t; }
+      const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    const double dk = A[k * n + k];
+    if (fabs(dk) <= tiny) {
+      for (int i = k + 1; i < n; ++i) A[i * n + k] = 0.0;
+      continue;
+    }
+    for (int i = k + 1; i < n; ++i) A[i * n + k] /= dk;
+    for (int i = k + 1; i < n; ++i)
+      for (int j = k + 1; j <= i; ++j) {
+        A[i * n + j] -= A[i * n + k] * dk * A[j * n + k];
+        A[j * n + i] = A[i * n + j];
+      }
+  }
+  for (int i = 0; i < n; ++i) y[i] = bin[perm[i]];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j) y[i] -= A[i * n + j] * y[j];
+  for (int i = 0; i < n; ++i) {
+    const double d = A[i * n + i];
+    y[i] = (fabs(d) > tiny) ? y[i] / d : 0.0;
+  }
+  for (int i = n - 1; i >= 0; --i)
+    for (int j = i + 1; j < n; ++j) y[i] -= A[j * n + i] * y[j];
+  for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+}
+
 }  // namespace cilhip

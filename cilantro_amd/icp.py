@@ -157,6 +157,15 @@ class Context:
                                                   AtA.ctypes.data, Atb.ctypes.data, C.byref(cv)))
         return _T_from_abi(T), AtA.reshape(6, 6), Atb, bool(cv.value)
 
+    def estimate_affine(self, w_p2p, w_p2pl, centered=True):
+        """Affine closed form over the last correspondences (transform_estimation.hpp:369-476; the point-to-point
+        overload :50-102 is w_p2p=1, w_p2pl=0, centered=False)."""
+        T = np.zeros(16, np.float32); AtA = np.zeros(144, np.float64); Atb = np.zeros(12, np.float64)
+        ok = C.c_int(0); n = C.c_size_t(0)
+        self._ck(self._L.cilhip_estimate_affine(self._h, w_p2p, w_p2pl, 1 if centered else 0, T.ctypes.data, AtA.ctypes.data,
+                                                Atb.ctypes.data, C.byref(n), C.byref(ok)))
+        return _T_from_abi(T), AtA.reshape(12, 12), Atb, bool(ok.value)
+
     def icp_run(self, params, T0=None):
         res = capi.IcpResult()
         t0 = _T_to_abi(T0) if T0 is not None else None
@@ -450,3 +459,22 @@ class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
     def getResiduals(self):
         return self._ctx.compute_residuals(1, float(self.point_to_point_weight_), float(self.point_to_plane_weight_),
                                            self.transform_)
+
+
+class SimplePointToPointMetricAffineICP3f(SimplePointToPointMetricRigidICP3f):
+    """registration/icp_common_instances.hpp:255: the same loop and correspondence engine with an AffineTransform --
+    the step is the affine closed form on the raw coordinates (transform_estimation.hpp:50-102), no rotation() polish."""
+
+    def __init__(self, dst_points, src_points, device=0, stream=None):
+        super().__init__(dst_points, src_points, device, stream)
+        self._ctx.set_option("transform_mode", 1)
+
+
+class SimpleCombinedMetricAffineICP3f(SimpleCombinedMetricRigidICP3f):
+    """registration/icp_common_instances.hpp:266: combined metric with an AffineTransform -- 12-unknown closed form
+    (transform_estimation.hpp:369-476).  Source normals, if given, are not used: the symmetric objective exists for the
+    rigid instances only (icp_single_transform_combined_metric.hpp:180-204)."""
+
+    def __init__(self, dst_points, dst_normals, src_points, src_normals=None, device=0, stream=None):
+        super().__init__(dst_points, dst_normals, src_points, None, device, stream)
+        self._ctx.set_option("transform_mode", 1)

@@ -114,6 +114,16 @@ int cilhip_estimate_combined(cilhip_ctx* ctx, float w_p2p, float w_p2pl, size_t 
                              float conv_tol, float dT_out[16], double* AtA_or_null,
                              double* Atb_or_null, int* converged_or_null);
 
+/* Affine closed form: estimateTransformCombinedMetric for Affine / AffineCompact transforms
+ * (transform_estimation.hpp:369-476) called as icp_single_transform_combined_metric.hpp:199-204 does (centered != 0:
+ * dst_mean, T*src_mean), or estimateTransformPointToPointMetric (affine, :50-102 via :104-113) with
+ * w_p2p = 1, w_p2pl = 0, centered = 0 (that overload works on the raw coordinates).  Works on the correspondences of
+ * the last cilhip_find_correspondences in every search direction.  AtA_or_null (144, row-major) / Atb_or_null (12):
+ * the normal equations in the reference's unknown order (row-major linear part, translation).
+ * *ok_or_null: the reference's bool return (terms >= Dim + 1). */
+int cilhip_estimate_affine(cilhip_ctx* ctx, float w_p2p, float w_p2pl, int centered, float dT_out[16],
+                           double* AtA_or_null, double* Atb_or_null, size_t* n_corr_or_null, int* ok_or_null);
+
 /* ---- the whole ICP loop, fused on the device ------------------------------------------------- */
 typedef struct {
   int metric;            /* CILHIP_METRIC_* */
@@ -282,7 +292,14 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   With 1 / 2 the correspondence set is a pair list (up to n_target + n_source entries): read it with
  *   cilhip_get_correspondences (cilhip_get_nn does not apply); the post-filters follow the reference's branches for
  *   those directions (one-to-one: per source point for FIRST_TO_SECOND, a no-op for BOTH, correspondence.hpp:72-98);
- *   cilhip_icp_run accumulates over the pair list.  Not available in sharded runs. */
+ *   cilhip_icp_run accumulates over the pair list.  Not available in sharded runs.
+ * Transform family (registration/icp_common_instances.hpp:253-267):
+ *   "transform_mode" (default 0): 0 = rigid -- cilhip_icp_run is Simple{PointToPoint,Combined}MetricRigidICP3f;
+ *                        1 = affine -- Simple{PointToPoint,Combined}MetricAffineICP3f: same loop and correspondence engine,
+ *                        the step is cilhip_estimate_affine's closed form and there is no rotation() polish
+ *                        (icp_single_transform_combined_metric.hpp:207-216); max_opt_iter / opt_conv_tol are unused,
+ *                        as in the reference's affine overload.  Host-driven loop (one 12x12 solve per iteration).
+ *                        Not available in sharded runs. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
  * kernels of the last cilhip_icp_run (sum over executed iterations). */

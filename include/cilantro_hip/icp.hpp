@@ -379,6 +379,33 @@ private:
   float point_to_plane_weight_;
 };
 
+// Affine instances (registration/icp_common_instances.hpp:255, :266): the same loop and correspondence engine with an
+// AffineTransform -- the step is the 12-unknown closed form (transform_estimation.hpp:50-102 on the raw coordinates for
+// the point-to-point class, :369-476 with the means for the combined class) and there is no rotation() polish.  The 4x4
+// holder type is shared with the rigid instances (AffineTransform3f below): its linear part is then a general 3x3 matrix.
+typedef RigidTransform3f AffineTransform3f;
+
+class SimplePointToPointMetricAffineICP3f : public SimplePointToPointMetricRigidICP3f {
+public:
+  SimplePointToPointMetricAffineICP3f(const ConstPointsView& dst, const ConstPointsView& src, int device = 0)
+      : SimplePointToPointMetricRigidICP3f(dst, src, device) {
+    internal::check(context(), cilhip_set_option(context(), "transform_mode", 1.0), "transform_mode");
+  }
+};
+
+class SimpleCombinedMetricAffineICP3f : public SimpleCombinedMetricRigidICP3f {
+public:
+  SimpleCombinedMetricAffineICP3f(const ConstPointsView& dst_p, const ConstPointsView& dst_n, const ConstPointsView& src_p, int device = 0)
+      : SimpleCombinedMetricRigidICP3f(dst_p, dst_n, src_p, device) {
+    internal::check(context(), cilhip_set_option(context(), "transform_mode", 1.0), "transform_mode");
+  }
+  // four-cloud form: accepted like the reference's wrapper, but the symmetric objective exists for the rigid instances
+  // only (icp_single_transform_combined_metric.hpp:180-204): the source normals are not used
+  SimpleCombinedMetricAffineICP3f(const ConstPointsView& dst_p, const ConstPointsView& dst_n, const ConstPointsView& src_p,
+                                  const ConstPointsView& /*src_n*/, int device = 0)
+      : SimpleCombinedMetricAffineICP3f(dst_p, dst_n, src_p, device) {}
+};
+
 #ifdef CILANTRO_HIP_HAVE_EIGEN
 // Adaptors for cilantro's own types (compiled only where Eigen3 exists; it is absent from the build
 // container, so these are exercised by downstream builds, not by this repository's tests).

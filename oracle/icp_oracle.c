@@ -588,6 +588,26 @@ int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* s
   return ok;
 }
 
+int orc_estimate_affine(const float* dst_p, const float* dst_n, const float* src_p, const int64_t* di, const int64_t* si,
+                        size_t n, float w_p2p, float w_p2pl, const float dst_mean[3], const float src_mean[3], int mode,
+                        float T_out[16], double* AtA_out, double* Atb_out) {
+  int ok;
+  if (mode == ORC_MODE_F32) {
+    float L[9], t[3];
+    ok = estimate_affine_m0(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    pack_T_f32(L, t, T_out);
+  } else if (mode == ORC_MODE_MIXED) {
+    double L[9], t[3];
+    ok = estimate_affine_m1(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    pack_T_f64(L, t, T_out);
+  } else {
+    double L[9], t[3];
+    ok = estimate_affine_m2(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    pack_T_f64(L, t, T_out);
+  }
+  return ok;
+}
+
 void orc_mean3(const float* xyz, size_t n, int mode, float mean[3]) {
   mean[0] = mean[1] = mean[2] = 0.0f;
   if (n == 0) return;
@@ -609,6 +629,25 @@ static float icp_update_impl(const float* dst_p, const float* dst_n, const float
                              const orc_icp_params* prm, const float dst_mean[3],
                              const float src_mean[3], float T_new[16]) {
   const int mode = prm->mode;
+  if (prm->transform_mode == 1) {
+    /* affine instances: the point-to-point class estimates on the raw coordinates (transform_estimation.hpp:50-102),
+     * the combined class with (dst_mean_, transform_ * src_mean_) (icp_single_transform_combined_metric.hpp:199-204) */
+    const float zero[3] = {0, 0, 0};
+    float smt[3] = {0, 0, 0};
+    if (prm->metric != 0) orc_transform_points(T_cur, src_mean, 1, smt);
+    const float* dm = prm->metric == 0 ? zero : dst_mean;
+    const float wp = prm->metric == 0 ? 1.0f : prm->w_p2p, wl = prm->metric == 0 ? 0.0f : prm->w_p2pl;
+    if (mode == ORC_MODE_F32) {
+      float L[9], t[3]; estimate_affine_m0(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL);
+      return compose_affine_m0(L, t, T_cur, T_new);
+    } else if (mode == ORC_MODE_MIXED) {
+      double L[9], t[3]; estimate_affine_m1(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL);
+      return compose_affine_m1(L, t, T_cur, T_new);
+    } else {
+      double L[9], t[3]; estimate_affine_m2(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL);
+      return compose_affine_m2(L, t, T_cur, T_new);
+    }
+  }
   if (prm->metric == 0) {
     if (mode == ORC_MODE_F32) {
       float L[9], t[3]; estimate_p2p_m0(dst_p, src_trans, di, si, nc, L, t, NULL);

@@ -126,6 +126,7 @@ typedef struct {
   int one_to_one;        /* engine one_to_one_ (correspondence.hpp:68-100) */
   int direction;         /* search_dir_: 0 = SECOND_TO_FIRST (the default), 1 = FIRST_TO_SECOND, 2 = BOTH */
   int reciprocal;        /* require_reciprocality_ (only read for BOTH) */
+  int transform_mode;    /* 0 = rigid instances, 1 = affine (icp_common_instances.hpp:253-267) */
 } orc_icp_params;
 
 typedef struct {
@@ -135,6 +136,12 @@ typedef struct {
   size_t last_ncorr;     /* correspondences in the last iteration */
   double t_build_s, t_knn_s, t_est_s; /* wall-clock split (tree build once / kNN / estimate) */
 } orc_icp_result;
+
+/* Affine closed form, transform_estimation.hpp:369-476 (and :50-102 with w_p2p = 1, w_p2pl = 0, zero means).
+ * AtA_out (144) / Atb_out (12) optional.  Returns the reference's bool. */
+int orc_estimate_affine(const float* dst_xyz, const float* dst_nrm_or_null, const float* src_xyz, const int64_t* dst_idx,
+                        const int64_t* src_idx, size_t n, float w_p2p, float w_p2pl, const float dst_mean[3],
+                        const float src_mean[3], int mode, float T_out[16], double* AtA_out, double* Atb_out);
 
 /* dst_nrm may be NULL for metric 0.  T0: initial transform (col-major) or NULL = identity.
  * tree: optional prebuilt kd-tree on dst (NULL = build here, as the engine does lazily). */

@@ -44,7 +44,7 @@ class IcpParams(C.Structure):
         ("max_iter", C.c_size_t), ("conv_tol", C.c_float), ("max_opt_iter", C.c_size_t),
         ("opt_conv_tol", C.c_float), ("max_sq_dist", C.c_float), ("mode", C.c_int),
         ("num_threads", C.c_int), ("inlier_fraction", C.c_double), ("one_to_one", C.c_int),
-        ("direction", C.c_int), ("reciprocal", C.c_int),
+        ("direction", C.c_int), ("reciprocal", C.c_int), ("transform_mode", C.c_int),
     ]
 
 
@@ -87,6 +87,9 @@ def lib():
         L.orc_nearest_rotation_f32.argtypes = [_f32p] * 2
         L.orc_estimate_p2p.restype = C.c_int
         L.orc_estimate_p2p.argtypes = [_f32p, _f32p, _i64p, _i64p, C.c_size_t, C.c_int, _f32p, C.c_void_p]
+        L.orc_estimate_affine.restype = C.c_int
+        L.orc_estimate_affine.argtypes = [_f32p, C.c_void_p, _f32p, _i64p, _i64p, C.c_size_t, C.c_float, C.c_float,
+                                          _f32p, _f32p, C.c_int, _f32p, C.c_void_p, C.c_void_p]
         L.orc_estimate_combined.restype = C.c_int
         L.orc_transform_normals.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
         L.orc_estimate_combined.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, _i64p, _i64p, C.c_size_t, C.c_float,
@@ -266,6 +269,17 @@ def estimate_combined(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, ds
     return T_from_colmajor(T), AtA.reshape(6, 6), Atb, bool(ok)
 
 
+def estimate_affine(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, dst_mean, src_mean, mode=MODE_MIXED):
+    """transform_estimation.hpp:369-476; the point-to-point overload :50-102 with w_p2p=1, w_p2pl=0 and zero means."""
+    dst = _c(dst).reshape(-1, 3); src_trans = _c(src_trans).reshape(-1, 3)
+    dn = _c(dst_n).reshape(-1, 3) if dst_n is not None else None
+    di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
+    T = np.zeros(16, np.float32); AtA = np.zeros(144, np.float64); Atb = np.zeros(12, np.float64)
+    ok = lib().orc_estimate_affine(dst, dn.ctypes.data if dn is not None else None, src_trans, di, si, len(di), w_p2p, w_p2pl,
+                                   _c(dst_mean).reshape(3), _c(src_mean).reshape(3), mode, T, AtA.ctypes.data, Atb.ctypes.data)
+    return T_from_colmajor(T), AtA.reshape(12, 12), Atb, bool(ok)
+
+
 def mean3(pts, mode=MODE_MIXED):
     pts = _c(pts).reshape(-1, 3)
     m = np.zeros(3, np.float32)
@@ -275,10 +289,11 @@ def mean3(pts, mode=MODE_MIXED):
 
 def make_params(metric=METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=15, conv_tol=1e-5,
                 max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=1e-4, mode=MODE_MIXED, num_threads=0,
-                inlier_fraction=1.0, one_to_one=False, direction=0, reciprocal=False):
-    """direction: 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH"""
+                inlier_fraction=1.0, one_to_one=False, direction=0, reciprocal=False, affine=False):
+    """direction: 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH; affine: the Affine ICP instances"""
     return IcpParams(metric, w_p2p, w_p2pl, max_iter, conv_tol, max_opt_iter, opt_conv_tol,
-                     max_sq_dist, mode, num_threads, inlier_fraction, 1 if one_to_one else 0, int(direction), 1 if reciprocal else 0)
+                     max_sq_dist, mode, num_threads, inlier_fraction, 1 if one_to_one else 0, int(direction), 1 if reciprocal else 0,
+                     1 if affine else 0)
 
 
 def filter_fraction(dst_idx, src_idx, d2, fraction):

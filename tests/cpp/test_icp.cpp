@@ -101,6 +101,27 @@ int main(int argc, char** argv) {
     const double e3 = frob(icp3.getTransform().m, r.T);
     std::printf("BOTH+reciprocal: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp3.getNumberOfPerformedIterations(), r.iterations, e3);
     if (!(e3 <= 1e-5) || icp3.getNumberOfPerformedIterations() != r.iterations) ++failures;
+
+    // affine instances (icp_common_instances.hpp:255, :266) through the mirrors
+    SimpleCombinedMetricAffineICP3f icp4(dst_v, nrm_v, src_v);
+    icp4.setPointToPointMetricWeight(0.1f).setPointToPlaneMetricWeight(1.0f);
+    icp4.correspondenceSearchEngine().setMaxDistance(max_sq);
+    icp4.setConvergenceTolerance(1e-5f).setMaxNumberOfIterations(10).estimate();
+    std::memset(&p, 0, sizeof(p));
+    p.metric = 1; p.w_p2p = 0.1f; p.w_p2pl = 1; p.max_iter = 10; p.conv_tol = 1e-5f; p.max_opt_iter = 1; p.opt_conv_tol = 1e-5f;
+    p.max_sq_dist = max_sq; p.mode = ORC_MODE_MIXED; p.transform_mode = 1;
+    orc_icp_run(dst.data(), nrm.data(), n, src.data(), nullptr, n, nullptr, &p, nullptr, &r);
+    const double e4 = frob(icp4.getTransform().m, r.T);
+    std::printf("affine combined: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp4.getNumberOfPerformedIterations(), r.iterations, e4);
+    if (!(e4 <= 1e-4) || icp4.getNumberOfPerformedIterations() != r.iterations) ++failures;
+    SimplePointToPointMetricAffineICP3f icp5(dst_v, src_v);
+    icp5.correspondenceSearchEngine().setMaxDistance(max_sq);
+    icp5.setMaxNumberOfIterations(10).setConvergenceTolerance(1e-5f).estimate();
+    p.metric = 0;
+    orc_icp_run(dst.data(), nullptr, n, src.data(), nullptr, n, nullptr, &p, nullptr, &r);
+    const double e5 = frob(icp5.getTransform().m, r.T);
+    std::printf("affine point-to-point: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp5.getNumberOfPerformedIterations(), r.iterations, e5);
+    if (!(e5 <= 1e-4) || icp5.getNumberOfPerformedIterations() != r.iterations) ++failures;
   } catch (const std::runtime_error& e) {
     if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }
     std::printf("FAIL: %s\n", e.what());

@@ -774,3 +774,83 @@ def test_tiled_clean_up_pass_sparse_far_and_unbounded(Context, orc):
         assert np.array_equal(np.nonzero(m)[0], o2) and np.array_equal(i1[o2], o1) and np.array_equal(d1[o2], ov)
     dq, _ = ctxs[1].debug_counters()
     assert dq > 1000      # the group search really ran
+
+
+@pytest.mark.gpu
+def test_affine_variants_vs_oracle(Context, orc, hip_lib):
+    """SURVEY 8(f) rank 3, affine variants: the 12-unknown closed forms (transform_estimation.hpp:50-102, :369-476) and the
+    Affine ICP instances (icp_common_instances.hpp:255, :266).  The device accumulates the moments of the normal equations
+    with per-term f32 quantities and f64 products / sums; the oracle's MIXED mode rounds every product to f32 first, its
+    F32 mode is the reference's all-f32 arithmetic: tolerances below are set by those roundings, not by the algorithm."""
+    from cilantro_amd.icp import SimpleCombinedMetricAffineICP3f, SimplePointToPointMetricAffineICP3f, CorrespondenceSearchDirection
+
+    n = 60_000
+    d = syn.make_pair(n, perturb=0.5)
+    rng = np.random.default_rng(5)
+    S = np.eye(3) + 0.004 * rng.normal(size=(3, 3))          # a genuinely affine distortion of the source
+    c0 = np.array([0.5, 0.5, 0.5])
+    src = ((d["src"].astype(np.float64) - c0) @ S.T + c0).astype(np.float32)
+    dst, dst_n = d["dst"], d["dst_n"]
+    max_sq = float((3 * d["h"]) ** 2)
+
+    # --- the estimators on one correspondence set
+    ctx = Context()
+    ctx.set_target(dst, dst_n); ctx.set_source(src)
+    T0 = np.eye(4, dtype=np.float32)
+    ctx.find_correspondences(T0, max_sq, count=False)
+    g1, g2, _ = ctx.get_correspondences()
+    q = orc.transform_points(T0, src)
+    dm, sm = ctx.means()
+    for w_p2p, w_p2pl, centered in ((0.0, 1.0, True), (0.2, 1.0, True), (1.0, 0.0, True), (1.0, 0.0, False)):
+        Tg, AtA, Atb, ok = ctx.estimate_affine(w_p2p, w_p2pl, centered)
+        zero = np.zeros(3, np.float32)
+        To, AtAo, Atbo, oko = orc.estimate_affine(dst, dst_n, q, g1, g2, w_p2p, w_p2pl, dm if centered else zero,
+                                                  orc.transform_points(T0, sm.reshape(1, 3))[0] if centered else zero, orc.MODE_MIXED)
+        assert ok and oko
+        assert np.allclose(AtA, AtAo, rtol=2e-6, atol=1e-9 * np.abs(AtAo).max()), np.abs(AtA - AtAo).max()
+        assert np.allclose(Atb, Atbo, rtol=2e-6, atol=1e-9 * np.abs(Atbo).max() + 1e-12)
+        assert np.linalg.norm(Tg.astype(np.float64) - To) < 2e-5, (w_p2p, w_p2pl, centered)
+    # degenerate inputs follow the reference's early returns: no terms / plane terms without normals -> identity, false
+    Tg, _, _, ok = ctx.estimate_affine(0.0, 0.0, True)
+    assert not ok and np.array_equal(Tg, np.eye(4, dtype=np.float32))
+    ctx2 = Context(); ctx2.set_target(dst); ctx2.set_source(src); ctx2.find_correspondences(T0, max_sq, count=False)
+    Tg, _, _, ok = ctx2.estimate_affine(0.0, 1.0, True)
+    assert not ok and np.array_equal(Tg, np.eye(4, dtype=np.float32))
+
+    # --- the ICP instances
+    for metric in (1, 0):
+        for max_iter, tol in ((5, 0.0), (40, 1e-5)):
+            if metric == 1:
+                icp = SimpleCombinedMetricAffineICP3f(dst, dst_n, src)
+                icp.setPointToPointMetricWeight(0.1).setPointToPlaneMetricWeight(1.0)
+            else:
+                icp = SimplePointToPointMetricAffineICP3f(dst, src)
+            icp.correspondenceSearchEngine().setMaxDistance(max_sq)
+            icp.setMaxNumberOfIterations(max_iter).setConvergenceTolerance(tol)
+            Tg = icp.estimate().getTransform()
+            for mode, lim in ((orc.MODE_MIXED, 3e-5), (orc.MODE_F32, 1e-3)):
+                p = orc.make_params(metric=metric, w_p2p=0.1, w_p2pl=1.0, max_iter=max_iter, conv_tol=tol, max_sq_dist=max_sq,
+                                    mode=mode, affine=True)
+                r = orc.icp_run(dst, dst_n, src, p)
+                err = np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64))
+                assert err <= lim, (metric, max_iter, mode, err)
+                if mode == orc.MODE_MIXED:
+                    assert abs(icp.getNumberOfPerformedIterations() - r["iterations"]) <= (0 if tol == 0.0 else 1)
+                    if tol == 0.0:
+                        assert icp.last_ncorr_ == r["last_ncorr"]
+            if tol > 0:
+                assert icp.hasConverged()
+                # the recovered map undoes the distortion: T * src lands on dst's surface
+                qf = orc.transform_points(Tg, src)
+                _, _, dv = orc.KDTree(dst).find_correspondences(qf, max_sq)
+                assert np.sqrt(np.median(dv)) < 0.6 * d["h"]
+    # a pair-list search direction through the same loop
+    icp = SimpleCombinedMetricAffineICP3f(dst, dst_n, src)
+    icp.correspondenceSearchEngine().setMaxDistance(max_sq).setSearchDirection(CorrespondenceSearchDirection.BOTH)
+    icp.setMaxNumberOfIterations(4).setConvergenceTolerance(0.0)
+    Tg = icp.estimate().getTransform()
+    p = orc.make_params(metric=1, w_p2p=0.0, w_p2pl=1.0, max_iter=4, conv_tol=0.0, max_sq_dist=max_sq, mode=orc.MODE_MIXED,
+                        affine=True, direction=2)
+    r = orc.icp_run(dst, dst_n, src, p)
+    assert np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64)) <= 3e-5
+    assert icp.last_ncorr_ == r["last_ncorr"]

@@ -257,3 +257,36 @@ def test_frame1_recipe_fixture_converges(orc):
                           max_sq_dist=0.1 * 0.1, mode=orc.MODE_F32)
     r32 = orc.icp_run(f["dst"], f["dst_n"], f["src"], p32)
     assert np.linalg.norm(r32["T"] - r["T"]) < 1e-3
+
+
+def test_affine_estimator_known_answer(orc):
+    """The affine closed forms (transform_estimation.hpp:50-102, :369-476) recover a known affine map exactly from exact
+    correspondences, in every arithmetic mode, for any mix of point / plane weights; and follow the reference's early
+    returns (no terms, plane terms without normals: identity, false)."""
+    rng = np.random.default_rng(0)
+    n = 3000
+    src = rng.random((n, 3)).astype(np.float32)
+    A = np.eye(3) + 0.05 * rng.normal(size=(3, 3)); t = np.array([0.01, -0.02, 0.03])
+    dst = (src.astype(np.float64) @ A.T + t).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True); nrm = nrm.astype(np.float32)
+    idx = np.arange(n)
+    dm, sm = orc.mean3(dst), orc.mean3(src)
+    zero = np.zeros(3, np.float32)
+    for mode, tol in ((orc.MODE_F32, 2e-5), (orc.MODE_MIXED, 5e-7), (2, 5e-7)):
+        for w_p2p, w_p2pl, means in ((0.3, 1.0, (dm, sm)), (0.0, 1.0, (dm, sm)), (1.0, 0.0, (dm, sm)), (1.0, 0.0, (zero, zero))):
+            T, AtA, Atb, ok = orc.estimate_affine(dst, nrm, src, idx, idx, w_p2p, w_p2pl, means[0], means[1], mode)
+            assert ok and np.abs(AtA - AtA.T).max() <= 1e-6 * np.abs(AtA).max()
+            assert np.abs(T[:3, :3] - A).max() < tol and np.abs(T[:3, 3] - t).max() < tol, (mode, w_p2p, w_p2pl)
+    T, _, _, ok = orc.estimate_affine(dst, nrm, src, idx, idx, 0.0, 0.0, dm, sm, orc.MODE_MIXED)
+    assert not ok and np.array_equal(T, np.eye(4))
+    T, _, _, ok = orc.estimate_affine(dst, None, src, idx, idx, 0.0, 1.0, dm, sm, orc.MODE_MIXED)
+    assert not ok and np.array_equal(T, np.eye(4))
+    T, _, _, ok = orc.estimate_affine(dst, nrm, src, idx[:3], idx[:3], 1.0, 0.0, dm, sm, orc.MODE_MIXED)
+    assert not ok            # fewer than Dim + 1 terms (:475-477)
+    # the ICP instance on top: a distorted copy converges back onto the target
+    p = orc.make_params(metric=1, w_p2p=0.1, w_p2pl=1.0, max_iter=30, conv_tol=1e-6, max_sq_dist=0.05 ** 2, affine=True)
+    S = np.eye(3) + 0.01 * rng.normal(size=(3, 3))
+    moved = ((dst.astype(np.float64) - 0.5) @ S.T + 0.5 + 0.004).astype(np.float32)
+    r = orc.icp_run(dst, nrm, moved, p)
+    back = orc.transform_points(r["T"], moved)
+    assert np.abs(back - dst).max() < 5e-4 and r["iterations"] < 30
