@@ -81,6 +81,8 @@ struct cilhip_ctx {
   int search_dir = 0;             // 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH
   bool reciprocal = false;        // require_reciprocality_ (BOTH only)
   int transform_mode = 0;         // 0 = rigid (Isometry), 1 = affine: which ICP instance family cilhip_icp_run mirrors
+  float normal_weight = 0.0f;     // > 0: the correspondence search runs on 6-D point+normal features (PointNormalFeaturesAdaptor)
+  bool symmetric = true;          // source normals, when set, also switch the combined metric to the symmetric objective
   PairSet pairs;
   bool have_pairs = false;        // `pairs` holds the result of the last find_correspondences
   IcpState* d_state_id = nullptr; // a state holding the identity transform (the reverse search transforms nothing)
@@ -212,6 +214,12 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
     c->search_dir = (int)value; c->have_nn = false; c->have_pairs = false;
     return CILHIP_OK;
   }
+  if (!strcmp(key, "feature_normal_weight")) {
+    if (!(value >= 0.0)) return fail(c, CILHIP_ERR_INVALID, "feature_normal_weight: >= 0 (0 = plain point features)");
+    c->normal_weight = (float)value; c->have_nn = false; c->have_pairs = false;
+    return CILHIP_OK;
+  }
+  if (!strcmp(key, "symmetric_metric")) { c->symmetric = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "transform_mode")) {
     if (value != 0.0 && value != 1.0) return fail(c, CILHIP_ERR_INVALID, "transform_mode: 0 = rigid, 1 = affine");
     c->transform_mode = (int)value;
@@ -408,7 +416,9 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   IterArgs a{};
   a.grid = c->grid;
   a.src = c->d_src_sorted;
-  a.src_nrm = c->d_src_nrm ? c->d_src_nrm_sorted : nullptr;
+  a.src_nrm = (c->d_src_nrm && c->symmetric) ? c->d_src_nrm_sorted : nullptr;
+  a.feat_src_nrm = c->d_src_nrm ? c->d_src_nrm_sorted : nullptr;
+  a.normal_weight = c->normal_weight;
   a.ns = c->ns;
   a.max_sq = max_sq;
   for (int i = 0; i < 3; ++i) a.dst_mean[i] = c->dst_mean[i];
@@ -424,8 +434,25 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   return a;
 }
 
+// The SECOND_TO_FIRST search under the transform held by c->d_state: LDS-tiled or per-lane kernel for point features, the
+// 6-D feature search when a normal weight is set.
+static int launch_search(cilhip_ctx* c, const IterArgs& a) {
+  if (c->normal_weight > 0.0f) {
+    if (!c->has_normals || !c->d_src_nrm) return fail(c, CILHIP_ERR_INVALID, "point+normal features need target and source normals");
+    if (c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for rigid transforms only");
+    if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are not available on target shards");
+    launch_search_feat6(a, c->stream);
+    return CILHIP_OK;
+  }
+  if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel
+  else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);                                 // per-lane global-memory search
+  return CILHIP_OK;
+}
+static bool feat6(const cilhip_ctx* c) { return c->normal_weight > 0.0f; }
+
 // Search directions FIRST_TO_SECOND / BOTH with the transform held by c->d_state: fills c->pairs (post-filters included).
 static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq) {
+  if (feat6(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for SECOND_TO_FIRST only");
   if (!c->d_state_id) {
     CK(c, hipMalloc(&c->d_state_id, sizeof(IcpState)));
     const float zero[3] = {0, 0, 0};
@@ -435,7 +462,7 @@ static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq) {
     if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
   }
-  const hipError_t e = find_pairs(c->grid, c->d_src_sorted, c->d_src_nrm ? c->d_src_nrm_sorted : nullptr, c->ns, c->d_state, c->d_state_id, max_sq,
+  const hipError_t e = find_pairs(c->grid, c->d_src_sorted, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm_sorted : nullptr, c->ns, c->d_state, c->d_state_id, max_sq,
                                   c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2, c->pairs, c->stream);
   if (e != hipSuccess) { c->err = std::string("find_pairs: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   return CILHIP_OK;
@@ -460,8 +487,8 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   }
   c->have_pairs = false;
   if (c->ns) {
-    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
-    else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
+    rc = launch_search(c, a);
+    if (rc) return rc;
   }
   CK(c, hipGetLastError());
   rc = apply_filters(c);
@@ -848,7 +875,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       rc = run_pair_search(c, a, p->max_sq_dist);
       if (rc) return rc;
       IterArgs pa = a;
-      pa.src = c->pairs.src_view; pa.src_nrm = c->d_src_nrm ? c->pairs.nrm_view : nullptr; pa.ns = c->pairs.count; pa.nn_pos = c->pairs.posd;
+      pa.src = c->pairs.src_view; pa.src_nrm = (c->d_src_nrm && c->symmetric) ? c->pairs.nrm_view : nullptr; pa.ns = c->pairs.count; pa.nn_pos = c->pairs.posd;
       const int pnb = iter_num_blocks(pa.ns);
       if (pnb > c->partial_blocks) {
         if (c->d_partials) (void)hipFree(c->d_partials);
@@ -904,11 +931,10 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       a.skip_if_inner_done = (st > 0);
       if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
       if (c->ns) {
-        if (st == 0 && c->fused && !filters_active(c)) {
+        if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
         } else if (st == 0) {
-          if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel
-          else launch_iter(a, IM_NONE, true, true, nb, c->stream);                  // per-lane global-memory search
+          { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_event(c, nev++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
@@ -941,7 +967,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (timing) {
     // only iterations that actually executed (not the early-exit launches after convergence)
     const size_t executed = out->iterations < (size_t)launches ? out->iterations : (size_t)launches;
-    const size_t per = ((c->fused && !filters_active(c)) || c->ns == 0) ? 2 : 4;
+    const size_t per = ((c->fused && !filters_active(c) && !feat6(c)) || c->ns == 0) ? 2 : 4;
     c->last_acc_ms = 0.0;
     for (size_t k = 0; k < executed; ++k) {
       float m = 0.f;
@@ -963,6 +989,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
   if (filters_active(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "inlier_fraction / one_to_one are global filters: not available in sharded runs");
   if (c->search_dir != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available in sharded runs");
+  if (c->normal_weight > 0.0f || c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features and the affine variants are not available in sharded runs");
   const float* Ti = T0 ? T0 : kIdentity;
   int rc = ensure_sorted(c, Ti);
   if (rc) return rc;

@@ -90,6 +90,8 @@ struct IterArgs {
   uint32_t* todo_tiles;    // [ntiles] tiles deferred as a whole
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
+  const float4* feat_src_nrm;  // 6-D point+normal feature search: sorted source normals, and
+  float normal_weight;         // the adaptor's normal weight (0 = plain point features)
 };
 
 struct SolveArgs {
@@ -110,6 +112,7 @@ void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nbl
 void launch_solve(const SolveArgs& a, hipStream_t s);
 void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box /*[8*ntiles] scratch*/, uint32_t ntiles,
                          hipStream_t s);
+void launch_search_feat6(const IterArgs& a, hipStream_t s);   // correspondence search over 6-D point+normal features
 #ifdef CILHIP_EXP_PHASE_CLOCKS
 void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_search_tiled -> stderr
 #endif

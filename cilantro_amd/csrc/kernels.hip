@@ -78,6 +78,37 @@ __device__ __forceinline__ void scan_range4(const float4* __restrict__ pts, uint
   }
 }
 
+// The same scan over 6-D point+normal features (PointNormalFeaturesAdaptor, common_transformable_feature_adaptors.hpp:60-161):
+// feature = (p, w n); squared distance exactly as nanoflann's L2_Adaptor::evalMetric forms it for DIM = 6
+// (nanoflann.hpp:570-604): one group of four, result = ((d0*d0 + d1*d1) + d2*d2) + d3*d3, then the tail loop adds
+// d4*d4 and d5*d5 one by one.  The target's feature normals are formed as w * n in f32, as the adaptor stores them (:90).
+struct Feat6 {
+  float fx, fy, fz;   // the query's (transformed) feature normal
+  float w;            // normal weight
+  const float4* nrm;  // sorted target normals
+};
+__device__ __forceinline__ float d6_pinned(float qx, float qy, float qz, const Feat6& f, const float4 p, const float4 n) {
+  const float d0 = __fsub_rn(qx, p.x), d1 = __fsub_rn(qy, p.y), d2 = __fsub_rn(qz, p.z);
+  const float d3 = __fsub_rn(f.fx, __fmul_rn(f.w, n.x)), d4 = __fsub_rn(f.fy, __fmul_rn(f.w, n.y)), d5 = __fsub_rn(f.fz, __fmul_rn(f.w, n.z));
+  float r = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
+  r = __fadd_rn(r, __fmul_rn(d4, d4));
+  return __fadd_rn(r, __fmul_rn(d5, d5));
+}
+__device__ __forceinline__ void scan_range_f6(const float4* __restrict__ pts, uint32_t beg, uint32_t end,
+                                              float qx, float qy, float qz, const Feat6& f, NN& best) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 2) {
+    const uint32_t j1 = min(j + 1, last);
+    const float4 p0 = pts[j], p1 = pts[j1], n0 = f.nrm[j], n1 = f.nrm[j1];
+    const float e0 = d6_pinned(qx, qy, qz, f, p0, n0), e1 = d6_pinned(qx, qy, qz, f, p1, n1);
+    const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
+    const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
+    if (k0 < best.key) { best.key = k0; best.pos = j; }
+    if (k1 < best.key) { best.key = k1; best.pos = j1; }
+  }
+}
+
 // Generic exact search: expanding Chebyshev shells s = s_start, s_start+1, ... around cell (cx,cy,cz)
 // (which may lie outside the grid), each shell scanned as runs of cells along x (contiguous in
 // memory), with conservative box-distance pruning.  `best` carries what inner shells already found.
@@ -284,8 +315,10 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
 // the sorted target array; the group then takes the minimum key (keys are unique: they carry the target index).  If the
 // block does not prove the result, s grows straight to the size the best found so far needs.  All control flow is
 // uniform within a group.  `sub` = lane index inside the group; every lane of the group returns the same result.
-template <int G>
-__device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, float qy, float qz, float max_sq, int sub, int s_start, NN& best) {
+// FEAT6: candidates are compared by the 6-D feature distance (the proof still uses the 3-D geometry: d6 >= d3).
+template <int G, bool FEAT6 = false>
+__device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, float qy, float qz, float max_sq, int sub, int s_start, NN& best,
+                                                const Feat6* f6 = nullptr) {
   best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
   best.pos = NONE_U32;
   const float BIG = 1.0e9f;
@@ -316,7 +349,8 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
         const float gz = axis_gap(qz, zl, zl + g.cell, g.margin), gy = axis_gap(qy, yl, yl + g.cell, g.margin);
         if ((gz * gz + gy * gy + gx2) * KSHRINK <= __uint_as_float((uint32_t)(best.key >> 32))) {
           const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-          scan_range4(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
+          if (FEAT6) scan_range_f6(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, *f6, best);
+          else scan_range4(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
         }
         y += G;
         while (y > y1) { y -= wy; ++z; }
@@ -1057,6 +1091,42 @@ void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* ti
   hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, (const int*)tile_box, ntiles);
   const uint32_t nb2 = (uint32_t)(((a.ns + ITER_THREADS - 1) / ITER_THREADS) < 2048 ? ((a.ns + ITER_THREADS - 1) / ITER_THREADS) : 2048);
   hipLaunchKernelGGL(k_search_todo, dim3(nb2 ? nb2 : 1), dim3(ITER_THREADS), 0, s, a, tiles);
+}
+
+// Correspondence search over 6-D point+normal features (SECOND_TO_FIRST): groups of 8 lanes per query, the generic exact
+// search out of global memory with the feature distance.  Rigid transforms only (:104-111: the normal part is L * (w n)).
+__global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
+  const IcpState* __restrict__ st = a.state;
+  if (st->done) return;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  const int sub = threadIdx.x & (TODO_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * ITER_THREADS + threadIdx.x) / TODO_GROUP;
+  if (gid >= a.ns) return;      // (whole groups leave together)
+  const uint32_t i = (uint32_t)gid;
+  const float4 s4 = a.src[i], sn = a.feat_src_nrm[i];
+  float qx, qy, qz;
+  transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+  const float wx = __fmul_rn(a.normal_weight, sn.x), wy = __fmul_rn(a.normal_weight, sn.y), wz = __fmul_rn(a.normal_weight, sn.z);
+  Feat6 f;
+  f.fx = __fadd_rn(__fmul_rn(T[0], wx), __fadd_rn(__fmul_rn(T[4], wy), __fmul_rn(T[8], wz)));
+  f.fy = __fadd_rn(__fmul_rn(T[1], wx), __fadd_rn(__fmul_rn(T[5], wy), __fmul_rn(T[9], wz)));
+  f.fz = __fadd_rn(__fmul_rn(T[2], wx), __fadd_rn(__fmul_rn(T[6], wy), __fmul_rn(T[10], wz)));
+  f.w = a.normal_weight;
+  f.nrm = a.grid.nrm;
+  NN best;
+  nn_search_group<TODO_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
+  if (sub == 0) {
+    a.nn_pos[i] = best.pos;
+    if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+  }
+}
+
+void launch_search_feat6(const IterArgs& a, hipStream_t s) {
+  if (a.ns == 0) return;
+  const uint64_t lanes = (uint64_t)a.ns * TODO_GROUP;
+  hipLaunchKernelGGL(k_search_feat6, dim3((unsigned)((lanes + ITER_THREADS - 1) / ITER_THREADS)), dim3(ITER_THREADS), 0, s, a);
 }
 
 // ---- accumulation helpers ------------------------------------------------------------------------

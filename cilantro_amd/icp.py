@@ -254,6 +254,22 @@ class CorrespondenceSearchHIP:
         self._corr = None
         return self
 
+    def setPointNormalFeatureAdaptors(self, src_normals, normal_weight, keep_metric=True):
+        """Feature adaptors of the engine (common_transformable_feature_adaptors.hpp): the default is PointFeaturesAdaptor3f
+        on both clouds; this switches both to PointNormalFeaturesAdaptor3f(points, normals, normal_weight) (:60-161): the
+        search runs on the 6-D features (p, w n).  The target's normals are the ones the ICP object was built with;
+        src_normals: the source's (None: reuse the normals given to a four-cloud ICP constructor).  keep_metric: the
+        combined metric stays the three-cloud one.  normal_weight = 0 switches back to point features."""
+        if src_normals is not None:
+            q, nn, mem, _ = _as_cloud(src_normals)
+            if nn != self._ctx.n_source:
+                raise ValueError("source normals must match source points")
+            self._ctx._ck(self._ctx._L.cilhip_set_source_normals(self._ctx._h, q, mem))
+            self._ctx.set_option("symmetric_metric", 0 if keep_metric else 1)
+        self._ctx.set_option("feature_normal_weight", float(normal_weight))
+        self._corr = None
+        return self
+
     def getCorrespondences(self):
         """-> structured view of the reference's CorrespondenceSet: (indexInFirst, indexInSecond, value)."""
         if self._corr is None:

@@ -293,6 +293,15 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   cilhip_get_correspondences (cilhip_get_nn does not apply); the post-filters follow the reference's branches for
  *   those directions (one-to-one: per source point for FIRST_TO_SECOND, a no-op for BOTH, correspondence.hpp:72-98);
  *   cilhip_icp_run accumulates over the pair list.  Not available in sharded runs.
+ * Feature adaptor of the engine (correspondence_search/common_transformable_feature_adaptors.hpp):
+ *   "feature_normal_weight" (default 0 = PointFeaturesAdaptor3f, :8-57): w > 0 = PointNormalFeaturesAdaptor3f (:60-161)
+ *                        on both clouds -- features (p, w n), transformed as (T p, L (w n)), matched by the 6-D squared
+ *                        distance (which is then also what max_sq_dist, the filters and the returned values refer to).
+ *                        Needs target normals and source normals (cilhip_set_source_normals); SECOND_TO_FIRST, rigid
+ *                        transforms, unsharded runs.
+ *   "symmetric_metric" (default 1): 0 = source normals feed the feature adaptor only and the combined metric stays the
+ *                        three-cloud one (the reference decides this by the ICP constructor used,
+ *                        icp_common_instances.hpp:74-97).
  * Transform family (registration/icp_common_instances.hpp:253-267):
  *   "transform_mode" (default 0): 0 = rigid -- cilhip_icp_run is Simple{PointToPoint,Combined}MetricRigidICP3f;
  *                        1 = affine -- Simple{PointToPoint,Combined}MetricAffineICP3f: same loop and correspondence engine,

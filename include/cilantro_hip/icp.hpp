@@ -200,6 +200,21 @@ public:
     return *this;
   }
 
+  // Feature adaptors of the engine (common_transformable_feature_adaptors.hpp): the default is PointFeaturesAdaptor3f on
+  // both clouds; this switches both to PointNormalFeaturesAdaptor3f(points, normals, normal_weight) (:60-161) -- the
+  // search then runs on the 6-D features (p, w n).  The target's normals are the ones the ICP object was built with;
+  // src_normals: the source's (pass an empty view to reuse normals given to a four-cloud ICP constructor).  With
+  // keep_metric = true (default) the combined metric stays the three-cloud one.  normal_weight = 0 switches back.
+  CorrespondenceSearchHIP& setPointNormalFeatureAdaptors(const ConstPointsView& src_normals, float normal_weight, bool keep_metric = true) {
+    if (src_normals.cols()) {
+      internal::check(ctx_, cilhip_set_source_normals(ctx_, src_normals.data(), CILHIP_MEM_HOST), "set_source_normals");
+      internal::check(ctx_, cilhip_set_option(ctx_, "symmetric_metric", keep_metric ? 0.0 : 1.0), "symmetric_metric");
+    }
+    internal::check(ctx_, cilhip_set_option(ctx_, "feature_normal_weight", (double)normal_weight), "feature_normal_weight");
+    fetched_ = false;
+    return *this;
+  }
+
   void setSourceCount_(size_t n) { capacity_ += n; }  // internal: result capacity (called with both cloud sizes)
 
 private:

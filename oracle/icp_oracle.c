@@ -282,6 +282,56 @@ void orc_transform_normals(const float T[16], const float* n, size_t cnt, float*
   }
 }
 
+/* ---- 6-D point+normal features (correspondence_search/common_transformable_feature_adaptors.hpp:60-161) ---- */
+/* :81-91  data = [points; normal_weight * normals]; row-major n x 6 here. */
+void orc_point_normal_features(const float* pts, const float* nrm, size_t n, float w, float* out6) {
+  for (size_t i = 0; i < n; ++i) {
+    for (int c = 0; c < 3; ++c) { out6[6 * i + c] = pts[3 * i + c]; out6[6 * i + 3 + c] = w * nrm[3 * i + c]; }
+  }
+}
+/* :101-111 rigid: head = L * p + t, tail = L * (w n) */
+void orc_transform_features6(const float T[16], const float* in6, size_t n, float* out6) {
+  float* p = (float*)calloc(3 * (n ? n : 1), sizeof(float));
+  float* q = (float*)malloc(3 * (n ? n : 1) * sizeof(float));
+  for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) p[3 * i + c] = in6[6 * i + c];
+  orc_transform_points(T, p, n, q);
+  for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) { out6[6 * i + c] = q[3 * i + c]; p[3 * i + c] = in6[6 * i + 3 + c]; }
+  orc_transform_normals(T, p, n, q);
+  for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) out6[6 * i + 3 + c] = q[3 * i + c];
+  free(p); free(q);
+}
+/* nanoflann.hpp:570-604 for DIM = 6: one group of four, then the tail loop */
+static inline float d6_pinned(const float* a, const float* b) {
+  const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2], d3 = a[3] - b[3], d4 = a[4] - b[4], d5 = a[5] - b[5];
+  float r = 0.0f;
+  r += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  r += d4 * d4;
+  r += d5 * d5;
+  return r;
+}
+/* The correspondence loop (correspondence_search_kd_tree_utilities.hpp:7-51) over 6-D features by exhaustive search:
+ * nearest feature (strict '<' over ascending index), kept iff d2 < max_sq_dist. */
+size_t orc_find_correspondences_feat6(const float* dst6, size_t nd, const float* q6, size_t nq, float max_sq_dist,
+                                      int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads) {
+  int64_t* bi = (int64_t*)malloc((nq ? nq : 1) * sizeof(int64_t));
+  float* bd = (float*)malloc((nq ? nq : 1) * sizeof(float));
+  if (num_threads <= 0) num_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+  for (size_t i = 0; i < nq; ++i) {
+    float best = INFINITY; int64_t bj = -1;
+    for (size_t j = 0; j < nd; ++j) {
+      const float v = d6_pinned(q6 + 6 * i, dst6 + 6 * j);
+      if (v < best) { best = v; bj = (int64_t)j; }
+    }
+    bi[i] = bj; bd[i] = best;
+  }
+  size_t cnt = 0;
+  for (size_t i = 0; i < nq; ++i)
+    if (bi[i] >= 0 && bd[i] < max_sq_dist) { dst_idx[cnt] = bi[i]; src_idx[cnt] = (int64_t)i; d2[cnt] = bd[i]; ++cnt; }
+  free(bi); free(bd);
+  return cnt;
+}
+
 /* correspondence_search/correspondence_search_kd_tree_utilities.hpp:7-51 (ref_is_first = true,
  * DistanceEvaluator = identity on d2, core/common_pair_evaluators.hpp:13-27). */
 size_t orc_find_correspondences(const orc_kdtree* t, const float* q, size_t nq, float max_d,
@@ -712,13 +762,22 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
   int64_t* di = (int64_t*)malloc(ccap * sizeof(int64_t));
   int64_t* si = (int64_t*)malloc(ccap * sizeof(int64_t));
   float* d2 = (float*)malloc(ccap * sizeof(float));
-  float* nq_trans = (src_n && prm->metric == 1) ? (float*)malloc(3 * cap * sizeof(float)) : NULL;
+  const int use_src_n_in_metric = src_n && prm->metric == 1 && !prm->three_cloud_metric;
+  float* nq_trans = use_src_n_in_metric ? (float*)malloc(3 * cap * sizeof(float)) : NULL;
+  float *dst6 = NULL, *src6 = NULL, *q6 = NULL;     /* PointNormalFeaturesAdaptor on both clouds */
+  if (prm->normal_weight > 0.0f && dst_n && src_n) {
+    dst6 = (float*)malloc(6 * (nd ? nd : 1) * sizeof(float));
+    src6 = (float*)malloc(6 * cap * sizeof(float));
+    q6 = (float*)malloc(6 * cap * sizeof(float));
+    orc_point_normal_features(dst_p, dst_n, nd, prm->normal_weight, dst6);
+    orc_point_normal_features(src_p, src_n, ns, prm->normal_weight, src6);
+  }
   orc_kdtree* own = NULL;
   const orc_kdtree* tree = tree_in;
   float last = INFINITY;
   size_t it = 0;
   while (it < prm->max_iter) {
-    if (!tree && prm->direction != 1) {                    /* correspondence_search_kd_tree.hpp:202-203 lazy build */
+    if (!tree && prm->direction != 1 && !dst6) {           /* correspondence_search_kd_tree.hpp:202-203 lazy build */
       double t0 = now_s();
       own = orc_kdtree_build(dst_p, nd, 10);
       tree = own;
@@ -728,6 +787,10 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
     orc_transform_points(T, src_p, ns, q);                 /* transformFeatures(tform) */
     size_t nc;
     if (prm->direction == 0) {
+      if (dst6) {
+        orc_transform_features6(T, src6, ns, q6);
+        nc = orc_find_correspondences_feat6(dst6, nd, q6, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
+      } else
       nc = orc_find_correspondences(tree, q, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
       nc = orc_filter_fraction(di, si, d2, nc, prm->inlier_fraction);      /* correspondence_search_kd_tree.hpp:224 */
       if (prm->one_to_one) nc = orc_filter_one_to_one(di, si, d2, nc);     /* :225 */
@@ -751,7 +814,7 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
   memcpy(out->T, T, sizeof(T));
   out->iterations = it;
   out->last_delta_norm = last;
-  free(q); free(di); free(si); free(d2); free(nq_trans);
+  free(q); free(di); free(si); free(d2); free(nq_trans); free(dst6); free(src6); free(q6);
   if (own) orc_kdtree_free(own);
   return 0;
 }

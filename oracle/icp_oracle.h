@@ -127,6 +127,8 @@ typedef struct {
   int direction;         /* search_dir_: 0 = SECOND_TO_FIRST (the default), 1 = FIRST_TO_SECOND, 2 = BOTH */
   int reciprocal;        /* require_reciprocality_ (only read for BOTH) */
   int transform_mode;    /* 0 = rigid instances, 1 = affine (icp_common_instances.hpp:253-267) */
+  float normal_weight;   /* > 0: the engine runs on PointNormalFeaturesAdaptor features (needs both clouds' normals); direction 0 */
+  int three_cloud_metric; /* source normals feed the feature adaptor only (three-cloud ICP constructor): no symmetric metric */
 } orc_icp_params;
 
 typedef struct {
@@ -136,6 +138,12 @@ typedef struct {
   size_t last_ncorr;     /* correspondences in the last iteration */
   double t_build_s, t_knn_s, t_est_s; /* wall-clock split (tree build once / kNN / estimate) */
 } orc_icp_result;
+
+/* 6-D point+normal features (common_transformable_feature_adaptors.hpp:60-161), row-major n x 6 */
+void orc_point_normal_features(const float* pts, const float* nrm, size_t n, float normal_weight, float* out6);
+void orc_transform_features6(const float T[16], const float* in6, size_t n, float* out6);
+size_t orc_find_correspondences_feat6(const float* dst6, size_t nd, const float* q6, size_t nq, float max_sq_dist,
+                                      int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads);
 
 /* Affine closed form, transform_estimation.hpp:369-476 (and :50-102 with w_p2p = 1, w_p2pl = 0, zero means).
  * AtA_out (144) / Atb_out (12) optional.  Returns the reference's bool. */

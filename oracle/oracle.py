@@ -45,6 +45,7 @@ class IcpParams(C.Structure):
         ("opt_conv_tol", C.c_float), ("max_sq_dist", C.c_float), ("mode", C.c_int),
         ("num_threads", C.c_int), ("inlier_fraction", C.c_double), ("one_to_one", C.c_int),
         ("direction", C.c_int), ("reciprocal", C.c_int), ("transform_mode", C.c_int),
+        ("normal_weight", C.c_float), ("three_cloud_metric", C.c_int),
     ]
 
 
@@ -87,6 +88,12 @@ def lib():
         L.orc_nearest_rotation_f32.argtypes = [_f32p] * 2
         L.orc_estimate_p2p.restype = C.c_int
         L.orc_estimate_p2p.argtypes = [_f32p, _f32p, _i64p, _i64p, C.c_size_t, C.c_int, _f32p, C.c_void_p]
+        L.orc_point_normal_features.restype = None
+        L.orc_point_normal_features.argtypes = [_f32p, _f32p, C.c_size_t, C.c_float, _f32p]
+        L.orc_transform_features6.restype = None
+        L.orc_transform_features6.argtypes = [_f32p, _f32p, C.c_size_t, _f32p]
+        L.orc_find_correspondences_feat6.restype = C.c_size_t
+        L.orc_find_correspondences_feat6.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
         L.orc_estimate_affine.restype = C.c_int
         L.orc_estimate_affine.argtypes = [_f32p, C.c_void_p, _f32p, _i64p, _i64p, C.c_size_t, C.c_float, C.c_float,
                                           _f32p, _f32p, C.c_int, _f32p, C.c_void_p, C.c_void_p]
@@ -144,6 +151,8 @@ def ref():
         R.ref_kdtree_free.argtypes = [C.c_void_p]
         R.ref_kdtree_knn_in_radius.restype = C.c_size_t
         R.ref_kdtree_knn_in_radius.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _u64p, _f32p]
+        R.ref_find_correspondences6.restype = C.c_size_t
+        R.ref_find_correspondences6.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
         R.ref_find_correspondences.restype = C.c_size_t
         R.ref_find_correspondences.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
         _ref = R
@@ -269,6 +278,34 @@ def estimate_combined(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, ds
     return T_from_colmajor(T), AtA.reshape(6, 6), Atb, bool(ok)
 
 
+def point_normal_features(pts, nrm, w):
+    """PointNormalFeaturesAdaptor ctor: [points; w * normals] -> (n, 6)"""
+    pts = _c(pts).reshape(-1, 3); nrm = _c(nrm).reshape(-1, 3)
+    out = np.empty((len(pts), 6), np.float32)
+    lib().orc_point_normal_features(pts, nrm, len(pts), float(w), out.reshape(-1))
+    return out
+
+
+def transform_features6(T, feat6):
+    feat6 = _c(feat6).reshape(-1, 6)
+    out = np.empty_like(feat6)
+    lib().orc_transform_features6(T_to_colmajor(T), feat6.reshape(-1), len(feat6), out.reshape(-1))
+    return out
+
+
+def find_correspondences_feat6(dst6, q6, max_sq_dist, use_ref=False, num_threads=0):
+    """Nearest 6-D feature per query (exhaustive restatement, or the reference's nanoflann for DIM = 6 with use_ref)."""
+    dst6 = _c(dst6).reshape(-1, 6); q6 = _c(q6).reshape(-1, 6)
+    nq = len(q6)
+    di = np.empty(max(nq, 1), np.int64); si = np.empty(max(nq, 1), np.int64); dv = np.empty(max(nq, 1), np.float32)
+    if use_ref:
+        n = ref().ref_find_correspondences6(dst6.reshape(-1), len(dst6), q6.reshape(-1), nq, float(max_sq_dist), di, si, dv,
+                                            num_threads if num_threads > 0 else (os.cpu_count() or 1))
+    else:
+        n = lib().orc_find_correspondences_feat6(dst6.reshape(-1), len(dst6), q6.reshape(-1), nq, float(max_sq_dist), di, si, dv, num_threads)
+    return di[:n].copy(), si[:n].copy(), dv[:n].copy()
+
+
 def estimate_affine(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, dst_mean, src_mean, mode=MODE_MIXED):
     """transform_estimation.hpp:369-476; the point-to-point overload :50-102 with w_p2p=1, w_p2pl=0 and zero means."""
     dst = _c(dst).reshape(-1, 3); src_trans = _c(src_trans).reshape(-1, 3)
@@ -289,11 +326,12 @@ def mean3(pts, mode=MODE_MIXED):
 
 def make_params(metric=METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=15, conv_tol=1e-5,
                 max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=1e-4, mode=MODE_MIXED, num_threads=0,
-                inlier_fraction=1.0, one_to_one=False, direction=0, reciprocal=False, affine=False):
+                inlier_fraction=1.0, one_to_one=False, direction=0, reciprocal=False, affine=False,
+                normal_weight=0.0, three_cloud_metric=False):
     """direction: 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH; affine: the Affine ICP instances"""
     return IcpParams(metric, w_p2p, w_p2pl, max_iter, conv_tol, max_opt_iter, opt_conv_tol,
                      max_sq_dist, mode, num_threads, inlier_fraction, 1 if one_to_one else 0, int(direction), 1 if reciprocal else 0,
-                     1 if affine else 0)
+                     1 if affine else 0, float(normal_weight), 1 if three_cloud_metric else 0)
 
 
 def filter_fraction(dst_idx, src_idx, d2, fraction):

@@ -854,3 +854,62 @@ def test_affine_variants_vs_oracle(Context, orc, hip_lib):
     r = orc.icp_run(dst, dst_n, src, p)
     assert np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64)) <= 3e-5
     assert icp.last_ncorr_ == r["last_ncorr"]
+
+
+@pytest.mark.gpu
+def test_point_normal_feature_search_vs_oracle(Context, orc, hip_lib):
+    """SURVEY 8(f) rank 3, 6-D point+normal features (PointNormalFeaturesAdaptor, common_transformable_feature_adaptors.hpp
+    :60-161): the engine matches (T p, L (w n)) against (p, w n) by the 6-D squared distance.  Indices, distances and the
+    strict radius test bit-identical to the oracle (exhaustive search with nanoflann's DIM = 6 arithmetic, itself pinned
+    against the reference's nanoflann on the CPU); then the ICP loop on top."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    n = 20_000
+    d = syn.make_pair(n, perturb=0.5)
+    h = d["h"]
+    rng = np.random.default_rng(9)
+    dst, dst_n, src = d["dst"], d["dst_n"], d["src"]
+    # source normals: the matched target normals, rotated back roughly and jittered (so that the feature term matters)
+    sn = dst_n[rng.permutation(n)] * 0.3 + rng.normal(size=(n, 3)).astype(np.float32)
+    sn = (sn / np.linalg.norm(sn, axis=1, keepdims=True)).astype(np.float32)
+    T = d["T_true"].astype(np.float32).copy(); T[:3, 3] += np.array([0.4, -0.3, 0.2], np.float32) * h
+    for w in (0.5 * h, 3.0 * h):
+        ctx = Context()
+        ctx.set_target(dst, dst_n); ctx.set_source(src, sn)
+        ctx.set_option("feature_normal_weight", w)
+        dst6 = orc.point_normal_features(dst, dst_n, w)
+        q6 = orc.transform_features6(T, orc.point_normal_features(src, sn, w))
+        for max_sq in (float((2.5 * h) ** 2), float("inf")):
+            ctx.find_correspondences(T, max_sq, count=False)
+            g1, g2, gv = ctx.get_correspondences()
+            o1, o2, ov = orc.find_correspondences_feat6(dst6, q6, max_sq)
+            assert np.array_equal(g2, o2) and np.array_equal(g1, o1) and np.array_equal(gv, ov), (w, max_sq)
+        # engine post-filters act on the feature distances
+        ctx.set_option("inlier_fraction", 0.7)
+        ctx.find_correspondences(T, float((2.5 * h) ** 2), count=False)
+        g1, g2, gv = ctx.get_correspondences()
+        o1, o2, ov = orc.find_correspondences_feat6(dst6, q6, float((2.5 * h) ** 2))
+        f1, f2, fv = orc.filter_fraction(o1, o2, ov, 0.7)
+        assert np.array_equal(g2, f2) and np.array_equal(g1, f1) and np.array_equal(gv, fv)
+    # options the feature search does not cover fail loudly
+    ctx.set_option("inlier_fraction", 1.0)
+    ctx.set_option("search_direction", 2)
+    with pytest.raises(RuntimeError):
+        ctx.find_correspondences(T, 1.0, count=False)
+    ctx.set_option("search_direction", 0)
+    ctx3 = Context(); ctx3.set_target(dst, dst_n); ctx3.set_source(src); ctx3.set_option("feature_normal_weight", 0.1)
+    with pytest.raises(RuntimeError):
+        ctx3.find_correspondences(T, 1.0, count=False)      # no source normals
+
+    # the ICP loop with feature correspondences (three-cloud combined metric) against the oracle's loop
+    w = 0.5 * h
+    sn_true = orc.transform_normals(np.linalg.inv(d["T_true"].astype(np.float64)).astype(np.float32), dst_n)   # plausible source normals
+    icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+    icp.correspondenceSearchEngine().setMaxDistance(float((2.5 * h) ** 2)).setPointNormalFeatureAdaptors(sn_true, w)
+    icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0)
+    Tg = icp.estimate().getTransform()
+    p = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=float((2.5 * h) ** 2), mode=orc.MODE_MIXED,
+                        normal_weight=w, three_cloud_metric=True)
+    r = orc.icp_run(dst, dst_n, src, p, src_n=sn_true)
+    assert np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64)) <= TOL_T
+    assert icp.last_ncorr_ == r["last_ncorr"]

@@ -290,3 +290,33 @@ def test_affine_estimator_known_answer(orc):
     r = orc.icp_run(dst, nrm, moved, p)
     back = orc.transform_points(r["T"], moved)
     assert np.abs(back - dst).max() < 5e-4 and r["iterations"] < 30
+
+
+def test_point_normal_feature_search_vs_reference_nanoflann(orc):
+    """6-D point+normal features (common_transformable_feature_adaptors.hpp:60-161): the oracle's exhaustive search with
+    the pinned DIM = 6 distance arithmetic against the reference's own nanoflann instantiated for DIM = 6 -- same indices,
+    bit-identical distances, same strict radius test."""
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(21)
+    n = 6000
+    dst = rng.random((n, 3)).astype(np.float32)
+    dn = rng.normal(size=(n, 3)); dn /= np.linalg.norm(dn, axis=1, keepdims=True); dn = dn.astype(np.float32)
+    src = (dst + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(0.01))[rng.permutation(n)[:4000]]
+    sn = rng.normal(size=(len(src), 3)); sn /= np.linalg.norm(sn, axis=1, keepdims=True); sn = sn.astype(np.float32)
+    ang = 0.05
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    T[:3, 3] = [0.01, -0.005, 0.002]
+    for w in (0.02, 0.3):
+        dst6 = orc.point_normal_features(dst, dn, w)
+        assert np.array_equal(dst6[:, :3], dst) and np.array_equal(dst6[:, 3:], np.float32(w) * dn)
+        q6 = orc.transform_features6(T, orc.point_normal_features(src, sn, w))
+        assert np.array_equal(q6[:, :3], orc.transform_points(T, src))
+        for max_sq in (0.05 ** 2, float("inf")):
+            a1, a2, av = orc.find_correspondences_feat6(dst6, q6, max_sq)
+            b1, b2, bv = orc.find_correspondences_feat6(dst6, q6, max_sq, use_ref=True)
+            assert np.array_equal(a2, b2) and np.array_equal(a1, b1) and np.array_equal(av, bv)
+        # with a heavy normal weight the feature match differs from the plain nearest point for many queries
+    p1, _, _ = orc.KDTree(dst).find_correspondences(q6[:, :3].copy(), float("inf"))
+    assert np.mean(p1 != a1) > 0.2
