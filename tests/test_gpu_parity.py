@@ -913,3 +913,60 @@ def test_point_normal_feature_search_vs_oracle(Context, orc, hip_lib):
     r = orc.icp_run(dst, dst_n, src, p, src_n=sn_true)
     assert np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64)) <= TOL_T
     assert icp.last_ncorr_ == r["last_ncorr"]
+
+
+@pytest.mark.gpu
+def test_full_size_properties_10m(Context, orc, hip_lib):
+    """BASELINE configs[2] at its full size (10M <-> 10M, point-to-plane), through properties that do not need an
+    exhaustive oracle:
+      * round trip: a source that is an exact rigid image of the target finds its own twin for every point (identity
+        permutation of indices), through the LDS-tiled kernel;
+      * two independent search kernels (LDS-tiled / per-lane) agree bit for bit on a noisy source under a drifted
+        transform -- every index and every squared distance;
+      * a random sample of the queries against the reference's own nanoflann kd-tree over the full target (oracle/_ref)
+        or the oracle's kd-tree restatement: same indices, bit-identical distances;
+      * the ICP run recovers the known transform, and is bitwise reproducible run to run."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    n = 10_000_000
+    d = syn.make_pair(n, noise=0.0, perturb=0.3)         # src = T_true^-1 * dst up to f32 rounding
+    h = d["h"]
+    ctx = Context()
+    ctx.set_option("tiled", 2)
+    ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+    i1, d1 = gpu_nn(ctx, d["T_true"].astype(np.float32), float(d["max_sq_dist"]))
+    # (the exact twin unless two target points are closer to each other than the f32 rounding of the mapped source)
+    assert np.count_nonzero(i1 != np.arange(n)) <= 5 and float(d1.max()) < (1e-5) ** 2
+    del ctx
+
+    d = syn.make_pair(n, perturb=0.3)                      # the benchmark's noisy source
+    T = d["T_true"].astype(np.float32).copy(); T[:3, 3] += np.array([0.45, -0.3, 0.2], np.float32) * np.float32(h)
+    res = []
+    for tiled in (2, 0):
+        ctx = Context()
+        ctx.set_option("tiled", tiled)
+        ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+        res.append(gpu_nn(ctx, T, float(d["max_sq_dist"])))
+        del ctx
+    (it, dt), (ip, dp) = res
+    assert np.array_equal(it, ip) and np.array_equal(dt, dp)
+    assert int(np.count_nonzero(it >= 0)) > 0.99 * n
+    rng = np.random.default_rng(123)
+    sample = np.sort(rng.choice(n, 40_000, replace=False))
+    q = orc.transform_points(T, d["src"][sample])
+    tree = orc.KDTree(d["dst"], use_ref=orc.ref_available())
+    o1, o2, ov = tree.find_correspondences(q, float(d["max_sq_dist"]))
+    found = it[sample] >= 0
+    assert np.array_equal(np.nonzero(found)[0], o2) and np.array_equal(it[sample][o2], o1) and np.array_equal(dt[sample][o2], ov)
+    del tree
+
+    Ts = []
+    for _ in range(2):
+        icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+        icp.correspondenceSearchEngine().setMaxDistance(float(d["max_sq_dist"]))
+        icp.setMaxNumberOfIterations(20).setConvergenceTolerance(0.0)
+        Ts.append(icp.estimate().getTransform().copy())
+        assert icp.last_ncorr_ == n
+        del icp
+    assert np.array_equal(Ts[0], Ts[1])
+    assert np.linalg.norm(Ts[0] - d["T_true"]) < 1e-5
