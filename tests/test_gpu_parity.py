@@ -970,3 +970,65 @@ def test_full_size_properties_10m(Context, orc, hip_lib):
         del icp
     assert np.array_equal(Ts[0], Ts[1])
     assert np.linalg.norm(Ts[0] - d["T_true"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_full_size_properties_other_configs(orc, hip_lib):
+    """The other BASELINE configs at their full single-GPU sizes, through size-independent properties.
+    configs[1] (1M <-> 1M, point-to-point): the whole ICP run against the oracle's run (kd-tree restatement, all 1M points).
+    configs[4] (KMeans3f k = 1024 and the plane RANSAC on 50M points): one Lloyd step -- sampled labels against the oracle's
+    brute-force assignment, cluster sizes summing to n, centroids = means of their members (recomputed on the host);
+    RANSAC -- the returned inlier set is exactly the set the returned plane selects (recount on the host), the run is
+    deterministic in the seed, and the planted plane is found."""
+    from cilantro_amd.clustering import KMeans3f, kmeans_assign
+    from cilantro_amd.icp import SimplePointToPointMetricRigidICP3f
+    from cilantro_amd.model_estimation import PlaneRANSACEstimator3f
+
+    n = 1_000_000
+    d = syn.make_pair(n, perturb=0.6)
+    icp = SimplePointToPointMetricRigidICP3f(d["dst"], d["src"])
+    icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+    icp.setMaxNumberOfIterations(15).setConvergenceTolerance(0.0)
+    Tg = icp.estimate().getTransform()
+    p = orc.make_params(metric=0, max_iter=15, conv_tol=0.0, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+    r = orc.icp_run(d["dst"], None, d["src"], p)
+    assert np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64)) <= TOL_T
+    assert icp.last_ncorr_ == r["last_ncorr"] and icp.getNumberOfPerformedIterations() == r["iterations"]
+    del icp, d
+
+    n = 50_000_000
+    rng = np.random.default_rng(77)
+    x = rng.random((n, 3), dtype=np.float32)
+    k = 1024
+    c0 = x[:k].copy()
+    km = KMeans3f(x).cluster(c0, max_iter=1, tol=0.0)
+    lab = km.getPointToClusterIndexMap()
+    sample = rng.choice(n, 20_000, replace=False)
+    lab_o, _ = orc.kmeans_assign(np.ascontiguousarray(x[sample]), c0)
+    assert np.array_equal(lab[sample], lab_o)
+    sizes = np.bincount(lab, minlength=k)
+    assert int(sizes.sum()) == n and int(sizes.min()) > 0
+    cen = km.getClusterCentroids()
+    for j in (0, 17, 511, 1023):
+        mean_j = x[lab == j].astype(np.float64).mean(axis=0)
+        assert np.abs(cen[j] - mean_j).max() <= 2e-6
+    del km, lab
+
+    # a planted plane holding 40 % of the points
+    sel = rng.random(n) < 0.4
+    x[sel, 2] = (0.3 * x[sel, 0] - 0.2 * x[sel, 1] + 0.4 + rng.normal(0, 0.002, int(sel.sum()))).astype(np.float32)
+    thr = 0.006
+    runs = []
+    for _ in range(2):
+        pe = (PlaneRANSACEstimator3f(x).setMaxInlierResidual(thr).setTargetInlierCount(int(0.39 * n)).setMaxNumberOfIterations(60)
+              .setSeed(5).estimate())
+        runs.append((pe.getModel().copy(), pe.getNumberOfInliers(), pe.getNumberOfPerformedIterations()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1:] == runs[1][1:]
+    pl = runs[0][0]
+    inl = pe.getModelInliers()
+    res = np.abs(x @ pl[:3] + pl[3])                       # host recount (f32 expression order differs: allow the boundary)
+    want = np.nonzero(res <= np.float32(thr))[0]
+    assert len(np.setxor1d(inl, want)) <= int(2e-5 * n)
+    assert len(inl) == runs[0][1] and len(inl) >= int(0.39 * n)
+    m = pl / -pl[2]
+    assert np.abs(m - np.array([0.3, -0.2, -1.0, 0.4])).max() < 1e-3
