@@ -98,7 +98,16 @@ class Context:
             raise capi.CilhipError(rc, self._L.cilhip_last_error(self._h).decode())
 
     def set_stream(self, stream_ptr):
-        self._ck(self._L.cilhip_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        """Run all work of this context on a caller-owned stream (e.g. ``torch.cuda.current_stream().cuda_stream``), so
+        that it is ordered with the caller's own work (torch ops, RCCL collectives).  ``None``: back to the context's own
+        stream.  Handle 0 -- what torch reports for its default stream -- means the LEGACY DEFAULT stream and is passed on
+        as hipStreamLegacy (the C ABI reserves NULL for "the context's own stream")."""
+        HIP_STREAM_LEGACY = 1   # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
+        if stream_ptr is None:
+            h = 0
+        else:
+            h = int(stream_ptr) or HIP_STREAM_LEGACY
+        self._ck(self._L.cilhip_set_stream(self._h, C.c_void_p(h)))
 
     def synchronize(self):
         self._ck(self._L.cilhip_synchronize(self._h))

@@ -56,7 +56,9 @@ int cilhip_create(cilhip_ctx** out, int device);
 void cilhip_destroy(cilhip_ctx* ctx);
 const char* cilhip_last_error(const cilhip_ctx* ctx);
 /* Run all work on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * context's own; pass NULL to go back.  The caller keeps the stream alive. */
+ * context's own; pass NULL to go back.  The caller keeps the stream alive.  NULL never means the legacy default
+ * stream here: a caller whose work runs there (torch's default stream reports handle 0) passes hipStreamLegacy --
+ * otherwise the context's own NON-BLOCKING stream is not ordered with that work at all. */
 int cilhip_set_stream(cilhip_ctx* ctx, void* hip_stream);
 int cilhip_synchronize(cilhip_ctx* ctx);
 

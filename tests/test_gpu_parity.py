@@ -1032,3 +1032,72 @@ def test_full_size_properties_other_configs(orc, hip_lib):
     assert len(inl) == runs[0][1] and len(inl) >= int(0.39 * n)
     m = pl / -pl[2]
     assert np.abs(m - np.array([0.3, -0.2, -1.0, 0.4])).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_full_size_target_sharded_config(orc, hip_lib):
+    """BASELINE configs[3] at its full size (10M source points against an 80M-point target, combined metric 0.1 / 1.0),
+    with the 8-GPU form's protocol played by two target shards on this one GPU: per iteration the element-wise MIN of the
+    shards' packed keys (what all-reduce(MIN) computes) and the sum of their partial sums (all-reduce(SUM)) -- a checksum
+    of checksums: the run must land on the transform of the unsharded run over the whole target, with the same number of
+    correspondences, and recover the known transform."""
+    import torch
+
+    from cilantro_amd import distributed
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    nd = 80_000_000
+    d = syn.make_pair(nd, nd // 8, with_normals=True, src_stride=8)
+    icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+    icp.setPointToPointMetricWeight(0.1).setPointToPlaneMetricWeight(1.0)
+    icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+    T1 = icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0).estimate().getTransform()
+    nc1 = icp.last_ncorr_
+    dm, _ = icp._ctx.means()
+    del icp
+    half = nd // 2
+    engs = [distributed.HipTargetShardEngine(d["dst"][lo:hi], d["dst_n"][lo:hi], d["src"], lo, dm, 0) for lo, hi in ((0, half), (half, nd))]
+    p = distributed.default_params(max_iter=6, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+    p.w_p2p = 0.1; p.w_p2pl = 1.0
+    for e in engs:
+        e.begin(p, np.eye(4, dtype=np.float32))
+    for _ in range(6):
+        keys = torch.minimum(engs[0].partial_keys(), engs[1].partial_keys())
+        sums = engs[0].sums_from_keys(keys).clone() + engs[1].sums_from_keys(keys)
+        for e in engs:
+            e.apply_sums(sums)
+    (Ta, ita, _, nca), (Tb, itb, _, ncb) = engs[0].state(), engs[1].state()
+    assert np.array_equal(Ta, Tb) and ita == itb == 6 and nca == ncb == nc1
+    assert np.abs(Ta.astype(np.float64) - T1.astype(np.float64)).max() <= 1e-6, float(np.abs(Ta.astype(np.float64) - T1.astype(np.float64)).max())
+    assert np.linalg.norm(T1 - d["T_true"]) < 1e-5, float(np.linalg.norm(T1 - d["T_true"]))
+
+
+@pytest.mark.gpu
+def test_two_source_shards_on_one_gpu_are_ordered_with_torch(orc, hip_lib):
+    """The source-sharded protocol with the collective played by torch ops on torch's stream (sum of the two shards'
+    partial sums): the engines must run on the stream torch works on -- torch's default stream reports handle 0, which
+    the Python layer passes on as hipStreamLegacy; the C ABI's NULL would select the context's own non-blocking stream
+    and leave the exchange unordered.  The run must land on the unsharded run's transform (f64 summation order only)."""
+    import torch
+
+    from cilantro_amd import distributed
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    n = 400_000
+    d = syn.make_pair(n, perturb=0.5)
+    icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+    icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+    T1 = icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0).estimate().getTransform()
+    _, gmean = icp._ctx.means()
+    half = n // 2
+    engs = [distributed.HipShardEngine(d["dst"], d["dst_n"], d["src"][lo:hi], 0) for lo, hi in ((0, half), (half, n))]
+    p = distributed.default_params(max_iter=8, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+    for e in engs:
+        e.begin(p, np.eye(4, dtype=np.float32), gmean)
+    for _ in range(8):
+        total = engs[0].partial_sums() + engs[1].partial_sums()      # what all-reduce(SUM) leaves on every rank
+        for e in engs:
+            e.apply_sums(total)
+    (Ta, ita, _, nca), (Tb, _, _, _) = engs[0].state(), engs[1].state()
+    assert np.array_equal(Ta, Tb) and ita == 8 and nca == icp.last_ncorr_
+    assert np.abs(Ta.astype(np.float64) - T1.astype(np.float64)).max() <= 2e-7
