@@ -26,7 +26,7 @@ SYMBOLS = [
     "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing",
     "cilhip_set_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
     "cilhip_icp_sums_from_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign",
-    "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f", "cilhip_knn3f", "cilhip_normals_knn3f", "cilhip_normals_radius3f",
+    "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f", "cilhip_knn3f", "cilhip_normals_knn3f", "cilhip_normals_radius3f", "cilhip_radius_search3f",
 ]
 
 
@@ -124,6 +124,8 @@ def load():
     L.cilhip_plane_fit3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p]
     L.cilhip_knn3f.argtypes = [C.c_int, f32p, C.c_size_t, f32p, C.c_size_t, C.c_int, C.c_size_t, C.c_float, vp, vp, vp]
     L.cilhip_normals_radius3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, C.c_float, f32p, f32p, f32p]
+    L.cilhip_radius_search3f.argtypes = [C.c_int, f32p, C.c_size_t, f32p, C.c_size_t, C.c_int, C.c_float, vp, vp, vp, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]
     L.cilhip_normals_knn3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, C.c_size_t, C.c_float, f32p, f32p, f32p]
     L.cilhip_icp_sums_from_keys.argtypes = [vp, vp, f64p]
     L.cilhip_get_last_timing2.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -17,6 +17,8 @@
 #include "internal.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include <cmath>
 #include <cstring>
@@ -370,10 +372,181 @@ done:
   return rc;
 }
 
+
+// ---- KDTree::radiusSearch as a list-returning call (core/kd_tree.hpp:251-282) ---------------------------------
+// Every target point with squared distance < radius (strict, RadiusSearchResultAdaptor :111-142 / nanoflann.hpp:1901),
+// per query, ascending by distance.  The reference orders equal distances as std::sort leaves them (unspecified); here
+// ties are ordered by index.  Three passes over the cells a query's ball can touch: count, then -- after a prefix sum of
+// the counts in the callers' query order -- fill packed (d2, index) keys, then one segmented radix sort of all lists.
+__device__ __forceinline__ void ball_cells(const GridDev& g, float qx, float qy, float qz, float radius_sq, int& x0, int& x1, int& y0, int& y1,
+                                           int& z0, int& z1) {
+  const float r = sqrtf(radius_sq) * 1.000001f + g.margin;   // cells the ball can touch (never fewer)
+  const float BIG = 1.0e9f;
+  x0 = max((int)floorf(fminf(fmaxf((qx - r - g.ox) * g.inv_cell, -BIG), BIG)), 0); x1 = min((int)floorf(fminf(fmaxf((qx + r - g.ox) * g.inv_cell, -BIG), BIG)), g.nx - 1);
+  y0 = max((int)floorf(fminf(fmaxf((qy - r - g.oy) * g.inv_cell, -BIG), BIG)), 0); y1 = min((int)floorf(fminf(fmaxf((qy + r - g.oy) * g.inv_cell, -BIG), BIG)), g.ny - 1);
+  z0 = max((int)floorf(fminf(fmaxf((qz - r - g.oz) * g.inv_cell, -BIG), BIG)), 0); z1 = min((int)floorf(fminf(fmaxf((qz + r - g.oz) * g.inv_cell, -BIG), BIG)), g.nz - 1);
+}
+
+// FILL = false: counts[orig] = neighbours of the query; FILL = true: keys[offsets[orig] + j] = (bits(d2) << 32) | index
+template <bool FILL>
+__global__ __launch_bounds__(KNN_THREADS) void k_radius_lists(GridDev g, const float4* __restrict__ queries, uint32_t nq, float radius_sq,
+                                                              unsigned long long* __restrict__ counts_or_offsets, unsigned long long* __restrict__ keys) {
+  const uint32_t qi = blockIdx.x * KNN_THREADS + threadIdx.x;
+  if (qi >= nq) return;
+  const float4 q4 = queries[qi];
+  const float qx = q4.x, qy = q4.y, qz = q4.z;
+  const uint32_t orig = __float_as_uint(q4.w);
+  unsigned long long cnt = 0;
+  const unsigned long long base = FILL ? counts_or_offsets[orig] : 0ull;
+  const bool finite = fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY;
+  if (finite && g.n > 0 && radius_sq > 0.0f) {
+    int x0, x1, y0, y1, z0, z1;
+    ball_cells(g, qx, qy, qz, radius_sq, x0, x1, y0, y1, z0, z1);
+    if (x0 <= x1)
+      for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+          const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          const uint32_t beg = g.cell_start[row + x0], end = g.cell_start[row + x1 + 1];
+          for (uint32_t j = beg; j < end; ++j) {
+            const float4 p = g.pts[j];
+            const float d2 = d2_pinned(qx, qy, qz, p.x, p.y, p.z);
+            if (!(d2 < radius_sq)) continue;
+            if (FILL) keys[base + cnt] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(p.w);
+            ++cnt;
+          }
+        }
+  }
+  if (!FILL) counts_or_offsets[orig] = cnt;
+}
+
+__global__ void k_unpack_radius(const unsigned long long* __restrict__ keys, size_t total, uint32_t* __restrict__ idx, float* __restrict__ d2) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = keys[i];
+    idx[i] = (uint32_t)k;
+    if (d2) d2[i] = __uint_as_float((uint32_t)(k >> 32));
+  }
+}
+__global__ void k_offsets32(const unsigned long long* __restrict__ off64, uint32_t n, uint32_t* __restrict__ off32) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) off32[i] = (uint32_t)off64[i];
+}
+
+int radius_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, float radius_sq,
+                uint64_t* offsets_out, uint32_t* idx_out, float* d2_out, size_t capacity, size_t* total_out) {
+  if ((!ref_xyz && n_ref) || !offsets_out || n_ref > 0xFFFFFFF0ull || n_query > 0xFFFFFFF0ull || !std::isfinite(radius_sq)) return CILHIP_ERR_INVALID;
+  if (!(radius_sq > 0.0f)) radius_sq = 0.0f;
+  const bool self = query_xyz == nullptr;
+  if (self) n_query = n_ref;
+  if (total_out) *total_out = 0;
+  int rc = CILHIP_OK;
+  hipStream_t s = nullptr;
+  float *d_ref = nullptr, *d_q = nullptr, *d_d2 = nullptr;
+  bool own_ref = false, own_q = false;
+  float4* d_qs = nullptr;
+  uint2* d_tiles = nullptr;
+  float4* d_tc = nullptr;
+  unsigned long long *d_cnt = nullptr, *d_keys = nullptr, *d_keys2 = nullptr;
+  uint32_t *d_off32 = nullptr, *d_idx = nullptr;
+  void* d_tmp = nullptr;
+  GridBuildResult gr{};
+  bool have_grid = false;
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CILHIP_ERR_NO_DEVICE;
+    KN_CK(hipSetDevice(device));
+    offsets_out[0] = 0;
+    if (n_query == 0) return CILHIP_OK;
+    KN_CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (mem == CILHIP_MEM_DEVICE) {
+      d_ref = const_cast<float*>(ref_xyz);
+      d_q = self ? d_ref : const_cast<float*>(query_xyz);
+    } else {
+      if (n_ref) {
+        own_ref = true;
+        KN_CK(hipMalloc(&d_ref, 3 * n_ref * sizeof(float)));
+        KN_CK(hipMemcpyAsync(d_ref, ref_xyz, 3 * n_ref * sizeof(float), hipMemcpyHostToDevice, s));
+      }
+      if (self) d_q = d_ref;
+      else {
+        own_q = true;
+        KN_CK(hipMalloc(&d_q, 3 * n_query * sizeof(float)));
+        KN_CK(hipMemcpyAsync(d_q, query_xyz, 3 * n_query * sizeof(float), hipMemcpyHostToDevice, s));
+      }
+    }
+    double mean[3];
+    KN_CK(build_grid(d_ref, nullptr, (uint32_t)n_ref, s, &gr, mean, 2.0));
+    have_grid = true;
+    KN_CK(hipMalloc(&d_qs, n_query * sizeof(float4)));
+    {
+      const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      float axes[9];
+      uint32_t nt = 0;
+      KN_CK(sort_source(d_q, (uint32_t)n_query, gr.grid, I, d_qs, s, &d_tiles, &d_tc, axes, &nt));
+    }
+    const unsigned nblk = (unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS);
+    KN_CK(hipMalloc(&d_cnt, (n_query + 1) * sizeof(unsigned long long)));
+    KN_CK(hipMemsetAsync(d_cnt, 0, (n_query + 1) * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((k_radius_lists<false>), dim3(nblk), dim3(KNN_THREADS), 0, s, gr.grid, (const float4*)d_qs, (uint32_t)n_query, radius_sq, d_cnt,
+                       (unsigned long long*)nullptr);
+    {  // counts -> offsets (exclusive scan over n_query + 1 entries: the last one is the total), in place
+      size_t tmp_bytes = 0;
+      KN_CK(rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt, d_cnt, 0ull, n_query + 1, rocprim::plus<unsigned long long>(), s));
+      KN_CK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8));
+      KN_CK(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_cnt, d_cnt, 0ull, n_query + 1, rocprim::plus<unsigned long long>(), s));
+      (void)hipFree(d_tmp); d_tmp = nullptr;
+    }
+    KN_CK(hipMemcpyAsync(offsets_out, d_cnt, (n_query + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    KN_CK(hipStreamSynchronize(s));
+    const size_t total = (size_t)offsets_out[n_query];
+    if (total_out) *total_out = total;
+    if (idx_out && capacity >= total && total > 0) {
+      if (total > 0xFFFFFFF0ull) { rc = CILHIP_ERR_UNSUPPORTED; goto done; }   // one segmented sort call takes 32-bit sizes
+      KN_CK(hipMalloc(&d_keys, total * sizeof(unsigned long long)));
+      KN_CK(hipMalloc(&d_keys2, total * sizeof(unsigned long long)));
+      hipLaunchKernelGGL((k_radius_lists<true>), dim3(nblk), dim3(KNN_THREADS), 0, s, gr.grid, (const float4*)d_qs, (uint32_t)n_query, radius_sq, d_cnt, d_keys);
+      KN_CK(hipMalloc(&d_off32, (n_query + 1) * sizeof(uint32_t)));
+      hipLaunchKernelGGL(k_offsets32, dim3(256), dim3(256), 0, s, (const unsigned long long*)d_cnt, (uint32_t)(n_query + 1), d_off32);
+      {
+        size_t tmp_bytes = 0;
+        KN_CK(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, d_keys, d_keys2, (unsigned int)total, (unsigned int)n_query, d_off32, d_off32 + 1, 0, 64, s));
+        KN_CK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8));
+        KN_CK(rocprim::segmented_radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_keys2, (unsigned int)total, (unsigned int)n_query, d_off32, d_off32 + 1, 0, 64, s));
+      }
+      KN_CK(hipMalloc(&d_idx, total * sizeof(uint32_t)));
+      if (d2_out) KN_CK(hipMalloc(&d_d2, total * sizeof(float)));
+      hipLaunchKernelGGL(k_unpack_radius, dim3(2048), dim3(256), 0, s, (const unsigned long long*)d_keys2, total, d_idx, d_d2);
+      KN_CK(hipGetLastError());
+      KN_CK(hipMemcpyAsync(idx_out, d_idx, total * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      if (d2_out) KN_CK(hipMemcpyAsync(d2_out, d_d2, total * sizeof(float), hipMemcpyDeviceToHost, s));
+      KN_CK(hipStreamSynchronize(s));
+    }
+  }
+done:
+  if (have_grid) free_grid(gr.grid);
+  if (own_ref && d_ref) (void)hipFree(d_ref);
+  if (own_q && d_q) (void)hipFree(d_q);
+  if (d_qs) (void)hipFree(d_qs);
+  if (d_tiles) (void)hipFree(d_tiles);
+  if (d_tc) (void)hipFree(d_tc);
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (d_keys) (void)hipFree(d_keys);
+  if (d_keys2) (void)hipFree(d_keys2);
+  if (d_off32) (void)hipFree(d_off32);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_d2) (void)hipFree(d_d2);
+  if (d_tmp) (void)hipFree(d_tmp);
+  if (s) (void)hipStreamDestroy(s);
+  return rc;
+}
+
 }  // namespace
 }  // namespace cilhip
 
 extern "C" {
+
+int cilhip_radius_search3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, float radius_sq,
+                           uint64_t* offsets_out, uint32_t* idx_out, float* d2_out, size_t capacity, size_t* total_out) {
+  return cilhip::radius_impl(device, ref_xyz, n_ref, query_xyz, n_query, mem, radius_sq, offsets_out, idx_out, d2_out, capacity, total_out);
+}
 
 int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k,
                  float max_sq_dist, uint32_t* idx_out, float* d2_out, uint32_t* counts_out) {

@@ -49,6 +49,30 @@ class KDTree3f:
     def kNNInRadiusSearch(self, queries, k, radius):
         return self._search(queries, k, float(radius))
 
+    def radiusSearch(self, queries, radius):
+        """core/kd_tree.hpp:251-282: every neighbour with squared distance < radius, ascending by distance (ties by index).
+        -> (offsets int64 [nq+1], indices int64 [total], squared distances f32 [total]); query i owns
+        indices[offsets[i]:offsets[i+1]].  queries None: the tree's own points."""
+        p, n, mem, keep = _as_cloud(self._points)
+        if queries is None:
+            qp, nq = None, n
+        else:
+            qp, nq, qmem, qkeep = _as_cloud(queries)
+            if qmem != mem:
+                raise ValueError("reference points and queries must live in the same memory space")
+        off = np.zeros(nq + 1, np.uint64)
+        total = C.c_size_t(0)
+        rc = self._L.cilhip_radius_search3f(self._device, p, n, qp, nq, mem, C.c_float(radius), off.ctypes.data, None, None, 0, C.byref(total))
+        if rc != capi.OK:
+            raise capi.CilhipError(rc, "cilhip_radius_search3f failed (no HIP device or bad arguments)")
+        idx = np.zeros(max(total.value, 1), np.uint32); d2 = np.zeros(max(total.value, 1), np.float32)
+        if total.value:
+            rc = self._L.cilhip_radius_search3f(self._device, p, n, qp, nq, mem, C.c_float(radius), off.ctypes.data, idx.ctypes.data,
+                                                d2.ctypes.data, total.value, C.byref(total))
+            if rc != capi.OK:
+                raise capi.CilhipError(rc, "cilhip_radius_search3f failed")
+        return off.astype(np.int64), idx[: total.value].astype(np.int64), d2[: total.value]
+
     def nearestNeighborSearch(self, queries):
         idx, d2, _ = self._search(queries, 1, np.inf)
         return idx[:, 0], d2[:, 0]

@@ -239,6 +239,15 @@ int cilhip_plane_fit3f(int device, const float* xyz, size_t n, int mem, float pl
  * reference except on exactly tied distances at the k-th place (there: lowest index here, first met there). */
 int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k,
                  float max_sq_dist, uint32_t* idx_out, float* d2_out, uint32_t* counts_out);
+/* KDTree<float,3>::radiusSearch (core/kd_tree.hpp:251-282; RadiusSearchResultAdaptor :111-142): per query, EVERY target
+ * point with squared distance < radius_sq (strict), ascending by distance; equal distances are ordered by index (the
+ * reference leaves them as std::sort does).  query_xyz == NULL: the target points are the queries.
+ * offsets_out: HOST n_query + 1 -- list of query i = [offsets[i], offsets[i+1]); *total_out_or_null = offsets[n_query].
+ * idx_out / d2_out: HOST `capacity` entries (d2_out may be NULL); when capacity < total (or idx_out == NULL) only the
+ * offsets and the total are produced -- call again with enough room.  radius_sq must be finite. */
+int cilhip_radius_search3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem,
+                           float radius_sq, uint64_t* offsets_out, uint32_t* idx_out, float* d2_out, size_t capacity,
+                           size_t* total_out_or_null);
 /* NormalEstimation<float,3>::estimateNormalsAndCurvatureKNN / ...KNNInRadius (core/normal_estimation.hpp:72-90,
  * :166-187 -> :362-420): per point the k-NN neighbourhood (including the point itself), mean and covariance of it
  * (core/covariance.hpp:140-170), normal = eigenvector of the smallest eigenvalue, curvature = l_min / (l0+l1+l2);

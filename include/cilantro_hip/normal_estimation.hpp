@@ -1,7 +1,7 @@
 // cilantro_hip/normal_estimation.hpp -- C++ host-side mirrors of the k-NN side of cilantro's KDTree3f and of
 // NormalEstimation3f, header-only on top of the C ABI (c_api.h):
 //
-//   KDTree3f              core/kd_tree.hpp:144-388     kNNSearch :216-256, kNNInRadiusSearch :286-318
+//   KDTree3f              core/kd_tree.hpp:144-388     kNNSearch :216-256, radiusSearch :251-282, kNNInRadiusSearch :286-318
 //   NormalEstimation3f    core/normal_estimation.hpp   get/estimate Normals[AndCurvature]KNN[InRadius] :72-221
 //
 // Same method names, argument meaning and defaults as the reference -- including its asymmetry: KDTree's radii are
@@ -36,6 +36,26 @@ public:
   // kd_tree.hpp:233-240 / :303-311: one Neighborhood per query, ascending distance
   NeighborhoodSet kNNSearch(const ConstPointsView& queries, size_t k) const { return search(queries, k, std::numeric_limits<float>::infinity()); }
   NeighborhoodSet kNNInRadiusSearch(const ConstPointsView& queries, size_t k, float radius) const { return search(queries, k, radius); }
+  // kd_tree.hpp:266-282: every neighbour with squared distance < radius, ascending distance (equal distances by index)
+  NeighborhoodSet radiusSearch(const ConstPointsView& queries, float radius) const {
+    const size_t nq = queries.cols();
+    std::vector<uint64_t> off(nq + 1, 0);
+    size_t total = 0;
+    int rc = cilhip_radius_search3f(device_, points_.data(), points_.cols(), queries.data(), nq, CILHIP_MEM_HOST, radius, off.data(), nullptr, nullptr, 0, &total);
+    if (rc != CILHIP_OK) throw std::runtime_error("cilhip_radius_search3f failed (rc " + std::to_string(rc) + ")");
+    std::vector<uint32_t> idx(total ? total : 1);
+    std::vector<float> d2(total ? total : 1);
+    if (total) {
+      rc = cilhip_radius_search3f(device_, points_.data(), points_.cols(), queries.data(), nq, CILHIP_MEM_HOST, radius, off.data(), idx.data(), d2.data(), total, &total);
+      if (rc != CILHIP_OK) throw std::runtime_error("cilhip_radius_search3f failed (rc " + std::to_string(rc) + ")");
+    }
+    NeighborhoodSet out(nq);
+    for (size_t i = 0; i < nq; ++i) {
+      out[i].resize((size_t)(off[i + 1] - off[i]));
+      for (size_t j = 0; j < out[i].size(); ++j) out[i][j] = Neighbor{(size_t)idx[off[i] + j], d2[off[i] + j]};
+    }
+    return out;
+  }
   const ConstPointsView& getPointsMatrixMap() const { return points_; }
 
 private:

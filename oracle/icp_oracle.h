@@ -139,6 +139,10 @@ typedef struct {
   double t_build_s, t_knn_s, t_est_s; /* wall-clock split (tree build once / kNN / estimate) */
 } orc_icp_result;
 
+/* KDTree::radiusSearch (core/kd_tree.hpp:251-282), exhaustive; see normals_oracle.c */
+size_t orc_radius_search(const float* pts, size_t n, const float* q, size_t nq, float radius_sq, uint64_t* offsets, int64_t* idx,
+                         float* d2, size_t cap);
+
 /* 6-D point+normal features (common_transformable_feature_adaptors.hpp:60-161), row-major n x 6 */
 void orc_point_normal_features(const float* pts, const float* nrm, size_t n, float normal_weight, float* out6);
 void orc_transform_features6(const float T[16], const float* in6, size_t n, float* out6);

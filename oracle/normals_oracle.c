@@ -145,3 +145,44 @@ void orc_normals_radius(const float* pts, size_t n, float radius_sq, const float
   }
   orc_kdtree_free(t);
 }
+
+/* KDTree::radiusSearch (core/kd_tree.hpp:251-282) by exhaustive search: every point with d2 < radius_sq (strict),
+ * ascending by (d2, index).  offsets[nq+1] always; idx / d2 written when cap >= total.  Returns the total. */
+typedef struct { float d2; int64_t idx; } orc_rs_item;
+static int orc_rs_cmp(const void* a, const void* b) {
+  const orc_rs_item* x = (const orc_rs_item*)a; const orc_rs_item* y = (const orc_rs_item*)b;
+  if (x->d2 < y->d2) return -1;
+  if (x->d2 > y->d2) return 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+size_t orc_radius_search(const float* pts, size_t n, const float* q, size_t nq, float radius_sq, uint64_t* offsets, int64_t* idx,
+                         float* d2, size_t cap) {
+  offsets[0] = 0;
+  for (size_t i = 0; i < nq; ++i) {
+    size_t c = 0;
+    for (size_t j = 0; j < n; ++j) {
+      const float dx = q[3 * i] - pts[3 * j], dy = q[3 * i + 1] - pts[3 * j + 1], dz = q[3 * i + 2] - pts[3 * j + 2];
+      const float v = ((dx * dx) + (dy * dy)) + (dz * dz);
+      if (v < radius_sq) ++c;
+    }
+    offsets[i + 1] = offsets[i] + c;
+  }
+  const size_t total = (size_t)offsets[nq];
+  if (!idx || cap < total) return total;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (size_t i = 0; i < nq; ++i) {
+    const size_t c = (size_t)(offsets[i + 1] - offsets[i]);
+    if (!c) continue;
+    orc_rs_item* it = (orc_rs_item*)malloc(c * sizeof(orc_rs_item));
+    size_t k = 0;
+    for (size_t j = 0; j < n; ++j) {
+      const float dx = q[3 * i] - pts[3 * j], dy = q[3 * i + 1] - pts[3 * j + 1], dz = q[3 * i + 2] - pts[3 * j + 2];
+      const float v = ((dx * dx) + (dy * dy)) + (dz * dz);
+      if (v < radius_sq) { it[k].d2 = v; it[k].idx = (int64_t)j; ++k; }
+    }
+    qsort(it, c, sizeof(orc_rs_item), orc_rs_cmp);
+    for (k = 0; k < c; ++k) { idx[offsets[i] + k] = it[k].idx; d2[offsets[i] + k] = it[k].d2; }
+    free(it);
+  }
+  return total;
+}

@@ -88,6 +88,8 @@ def lib():
         L.orc_nearest_rotation_f32.argtypes = [_f32p] * 2
         L.orc_estimate_p2p.restype = C.c_int
         L.orc_estimate_p2p.argtypes = [_f32p, _f32p, _i64p, _i64p, C.c_size_t, C.c_int, _f32p, C.c_void_p]
+        L.orc_radius_search.restype = C.c_size_t
+        L.orc_radius_search.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _u64p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_point_normal_features.restype = None
         L.orc_point_normal_features.argtypes = [_f32p, _f32p, C.c_size_t, C.c_float, _f32p]
         L.orc_transform_features6.restype = None
@@ -151,6 +153,8 @@ def ref():
         R.ref_kdtree_free.argtypes = [C.c_void_p]
         R.ref_kdtree_knn_in_radius.restype = C.c_size_t
         R.ref_kdtree_knn_in_radius.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _u64p, _f32p]
+        R.ref_kdtree_radius_search.restype = C.c_size_t
+        R.ref_kdtree_radius_search.argtypes = [C.c_void_p, _f32p, C.c_float, _u64p, _f32p, C.c_size_t]
         R.ref_find_correspondences6.restype = C.c_size_t
         R.ref_find_correspondences6.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
         R.ref_find_correspondences.restype = C.c_size_t
@@ -276,6 +280,23 @@ def estimate_combined(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, ds
                                      conv_tol, _c(dst_mean).reshape(3), _c(src_mean).reshape(3), mode,
                                      T, AtA.ctypes.data, Atb.ctypes.data)
     return T_from_colmajor(T), AtA.reshape(6, 6), Atb, bool(ok)
+
+
+def radius_search(pts, queries, radius_sq):
+    """KDTree::radiusSearch, exhaustive -> (offsets int64 [nq+1], idx int64 [total], d2 f32 [total]); (d2, index) order."""
+    pts = _c(pts).reshape(-1, 3); q = _c(queries).reshape(-1, 3)
+    off = np.zeros(len(q) + 1, np.uint64)
+    total = lib().orc_radius_search(pts, len(pts), q, len(q), float(radius_sq), off, None, None, 0)
+    idx = np.zeros(max(total, 1), np.int64); d2 = np.zeros(max(total, 1), np.float32)
+    lib().orc_radius_search(pts, len(pts), q, len(q), float(radius_sq), off, idx.ctypes.data, d2.ctypes.data, total)
+    return off.astype(np.int64), idx[:total], d2[:total]
+
+
+def ref_radius_search(tree, query, radius_sq, cap=100000):
+    """One query through the reference's nanoflann (tree: KDTree(..., use_ref=True)) -> (idx, d2) sorted by distance."""
+    idx = np.zeros(cap, np.uint64); d2 = np.zeros(cap, np.float32)
+    n = ref().ref_kdtree_radius_search(tree.h, _c(query).reshape(3), float(radius_sq), idx, d2, cap)
+    return idx[:n].astype(np.int64), d2[:n]
 
 
 def point_normal_features(pts, nrm, w):

@@ -16,6 +16,7 @@
 // for the kNN pass in bench.py.
 #include <nanoflann.hpp>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <limits>
@@ -124,6 +125,29 @@ size_t ref_find_correspondences(const void* tp, const float* q, size_t nq, float
   for (size_t i = 0; i < nq; i++)
     if (keep[i]) { dst_idx[count] = tmp_idx[i]; src_idx[count] = (int64_t)i; d2[count] = tmp_d2[i]; ++count; }
   return count;
+}
+
+// KDTree::radiusSearch for one query (core/kd_tree.hpp:251-257 with RadiusSearchResultAdaptor :111-142), then the
+// std::sort by value of :254; returns the number of neighbours (written up to `cap`).
+size_t ref_kdtree_radius_search(const void* tp, const float q[3], float radius_sq, size_t* out_idx, float* out_d2, size_t cap) {
+  const RefTree* t = static_cast<const RefTree*>(tp);
+  if (t->adaptor.n == 0) return 0;
+  struct RadiusResult {
+    using DistanceType = float;
+    using IndexType = size_t;
+    std::vector<Neighbor>& r; float radius;
+    size_t size() const { return r.size(); }
+    bool full() const { return true; }
+    bool addPoint(float dist, size_t index) { r.push_back(Neighbor{index, dist}); return true; }
+    float worstDist() const { return radius; }
+    void sort() const {}
+  };
+  std::vector<Neighbor> nn;
+  RadiusResult rr{nn, radius_sq};
+  t->tree.findNeighbors(rr, q, t->params);
+  std::sort(nn.begin(), nn.end(), [](const Neighbor& a, const Neighbor& b) { return a.value < b.value; });
+  for (size_t i = 0; i < nn.size() && i < cap; ++i) { out_idx[i] = nn[i].index; out_d2[i] = nn[i].value; }
+  return nn.size();
 }
 
 // The same loop over 6-D point+normal features (PointNormalFeaturesAdaptor, common_transformable_feature_adaptors.hpp:60-161):

@@ -94,6 +94,24 @@ int main(int argc, char** argv) {
       for (size_t j = 0; j < nns[i].size() && j < oc[i]; ++j) kbad += (nns[i][j].value != od[i * kk + j]) || ((int64_t)nns[i][j].index != oi[i * kk + j]);
     }
     orc_kdtree_free(ot);
+    // KDTree3f::radiusSearch (list-returning, kd_tree.hpp:266-282) against the oracle's exhaustive search
+    {
+      const size_t nr = 300;
+      const float r2 = 0.004f;
+      const NeighborhoodSet rs = tree.radiusSearch(ConstPointsView(x.data(), nr), r2);
+      std::vector<uint64_t> off(nr + 1);
+      const size_t total = orc_radius_search(x.data(), n, x.data(), nr, r2, off.data(), nullptr, nullptr, 0);
+      std::vector<int64_t> ri(total ? total : 1); std::vector<float> rd(total ? total : 1);
+      orc_radius_search(x.data(), n, x.data(), nr, r2, off.data(), ri.data(), rd.data(), total);
+      size_t rbad = 0;
+      for (size_t i = 0; i < nr; ++i) {
+        rbad += rs[i].size() != (size_t)(off[i + 1] - off[i]);
+        for (size_t j = 0; j < rs[i].size() && j < (size_t)(off[i + 1] - off[i]); ++j)
+          rbad += ((int64_t)rs[i][j].index != ri[off[i] + j]) || (rs[i][j].value != rd[off[i] + j]);
+      }
+      std::printf("radiusSearch: %zu neighbours over %zu queries, %zu mismatches vs oracle\n", total, nr, rbad);
+      if (rbad || total == 0) ++failures;
+    }
     NormalEstimation3f ne(xv);
     ne.setViewPoint(0.0f, 0.0f, 10.0f);
     std::vector<float> nrm, cur, onrm(3 * n), ocur(n);

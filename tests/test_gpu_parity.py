@@ -1101,3 +1101,36 @@ def test_two_source_shards_on_one_gpu_are_ordered_with_torch(orc, hip_lib):
     (Ta, ita, _, nca), (Tb, _, _, _) = engs[0].state(), engs[1].state()
     assert np.array_equal(Ta, Tb) and ita == 8 and nca == icp.last_ncorr_
     assert np.abs(Ta.astype(np.float64) - T1.astype(np.float64)).max() <= 2e-7
+
+
+@pytest.mark.gpu
+def test_radius_search_lists_vs_oracle(orc, hip_lib):
+    """KDTree3f::radiusSearch (core/kd_tree.hpp:251-282) as a list-returning call: per query every neighbour with squared
+    distance < radius (strict), ascending by (distance, index) -- offsets, indices and distances identical to the oracle
+    (exhaustive search, itself pinned against the reference's nanoflann on the CPU)."""
+    from cilantro_amd.normal_estimation import KDTree3f
+
+    rng = np.random.default_rng(17)
+    pts = rng.random((30_000, 3)).astype(np.float32)
+    pts[100:110] = pts[100]                                           # exact duplicates: ties broken by index
+    q = np.concatenate([pts[:300], rng.random((500, 3)).astype(np.float32) * 1.3 - 0.15, np.array([[5, 5, 5], [np.nan, 0, 0]], np.float32)])
+    tree = KDTree3f(pts)
+    for r2 in (0.0, 0.02 ** 2, 0.09 ** 2):
+        off, idx, d2 = tree.radiusSearch(q, r2)
+        fin = np.all(np.isfinite(q), axis=1)
+        ooff, oidx, od2 = orc.radius_search(pts, q[fin], r2)
+        cnt = np.diff(off)
+        assert np.array_equal(cnt[fin], np.diff(ooff)) and np.all(cnt[~fin] == 0)
+        keep = np.repeat(fin, cnt)
+        assert np.array_equal(idx[keep], oidx) and np.array_equal(d2[keep], od2), r2
+    # the tree's own points as queries; every list starts with the point itself (or its lowest-index duplicate)
+    off, idx, d2 = tree.radiusSearch(None, 0.03 ** 2)
+    ooff, oidx, od2 = orc.radius_search(pts[:2000], pts[:2000], 0.03 ** 2)   # (oracle on a subset is a different problem: only shape checks here)
+    assert len(off) == len(pts) + 1 and off[-1] == len(idx) and np.all(d2[off[:-1]] == 0.0)
+    first = idx[off[:-1]]
+    assert np.array_equal(first[:100], np.arange(100)) and np.all(first[100:110] == 100)
+    # empty tree / no queries
+    o, i, d = KDTree3f(np.zeros((0, 3), np.float32)).radiusSearch(q[:10], 1.0)
+    assert np.all(o == 0) and len(i) == 0
+    o, i, d = tree.radiusSearch(np.zeros((0, 3), np.float32), 1.0)
+    assert len(o) == 1 and len(i) == 0

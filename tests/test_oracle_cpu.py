@@ -320,3 +320,26 @@ def test_point_normal_feature_search_vs_reference_nanoflann(orc):
         # with a heavy normal weight the feature match differs from the plain nearest point for many queries
     p1, _, _ = orc.KDTree(dst).find_correspondences(q6[:, :3].copy(), float("inf"))
     assert np.mean(p1 != a1) > 0.2
+
+
+def test_radius_search_oracle_vs_reference_nanoflann(orc):
+    """KDTree::radiusSearch (core/kd_tree.hpp:251-282): the exhaustive oracle against the reference's own nanoflann with
+    cilantro's RadiusSearchResultAdaptor -- same neighbour sets, bit-identical sorted distances, strict radius."""
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(31)
+    pts = rng.random((4000, 3)).astype(np.float32)
+    q = np.concatenate([pts[:50], rng.random((50, 3)).astype(np.float32) * 1.2 - 0.1])
+    tree = orc.KDTree(pts, use_ref=True)
+    for r2 in (0.0, 0.03 ** 2, 0.11 ** 2):
+        off, idx, d2 = orc.radius_search(pts, q, r2)
+        assert off[0] == 0 and off[-1] == len(idx)
+        for i in range(len(q)):
+            ri, rd = orc.ref_radius_search(tree, q[i], r2)
+            mine_i, mine_d = idx[off[i]:off[i + 1]], d2[off[i]:off[i + 1]]
+            assert np.array_equal(rd, mine_d)                      # sorted distances, bit for bit
+            assert np.array_equal(np.sort(ri), np.sort(mine_i))    # the same set (tie order is unspecified in the reference)
+            assert np.all(mine_d < np.float32(r2)) if len(mine_d) else True
+    # a query point that is a tree point sits in its own list at distance 0 (first)
+    off, idx, d2 = orc.radius_search(pts, pts[:5], 0.05 ** 2)
+    assert all(idx[off[i]] == i and d2[off[i]] == 0.0 for i in range(5))
