@@ -79,6 +79,7 @@ class Context:
             raise capi.CilhipError(rc, "cilhip_create failed (no usable HIP device? there is no CPU fallback)")
         self._h = h
         self._keep = []
+        self._on_caller_stream = False
         if stream is not None:
             self.set_stream(stream)
 
@@ -107,14 +108,24 @@ class Context:
             h = 0
         else:
             h = int(stream_ptr) or HIP_STREAM_LEGACY
+        self._on_caller_stream = stream_ptr is not None
         self._ck(self._L.cilhip_set_stream(self._h, C.c_void_p(h)))
 
     def synchronize(self):
         self._ck(self._L.cilhip_synchronize(self._h))
 
+    def _settle_device_inputs(self, mem):
+        """Device-resident inputs produced on the caller's (torch) stream: when this context runs on its own stream it is
+        not ordered with that work, so wait for it once before the library reads the arrays."""
+        if mem == capi.MEM_DEVICE and not self._on_caller_stream:
+            import torch
+
+            torch.cuda.current_stream().synchronize()
+
     def set_target(self, points, normals=None):
         p, n, mem, k1 = _as_cloud(points)
         q, nn, mem2, k2 = _as_cloud(normals)
+        self._settle_device_inputs(mem)
         if normals is not None and (nn != n or mem2 != mem):
             raise ValueError("normals must match points (count and memory space)")
         self._ck(self._L.cilhip_set_target(self._h, p, q, n, mem))
@@ -122,6 +133,7 @@ class Context:
 
     def set_source(self, points, normals=None):
         p, n, mem, k = _as_cloud(points)
+        self._settle_device_inputs(mem)
         self._ck(self._L.cilhip_set_source(self._h, p, n, mem))
         self.n_source = n
         if normals is not None:
