@@ -1178,7 +1178,14 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
 
   // XCD-aware virtual block id (gridDim.x is a multiple of 8)
   const uint32_t nb = gridDim.x;
-  const uint32_t vb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+  // The streaming accumulation pass (!SEARCH) walks each XCD's eighth BACKWARDS: the search pass that ran just before
+  // walked it forwards, so the queries / matched points it touched last are the ones still in the XCD's L2 and in the
+  // 256 MB Infinity Cache -- read those first, before this pass's own traffic evicts them.
+#ifndef CILHIP_ACC_REVERSE
+#define CILHIP_ACC_REVERSE 1
+#endif
+  const uint32_t slot = (!SEARCH && CILHIP_ACC_REVERSE) ? ((nb >> 3) - 1u - (blockIdx.x >> 3)) : (blockIdx.x >> 3);
+  const uint32_t vb = (blockIdx.x & 7u) * (nb >> 3) + slot;
   const uint32_t chunk = (((a.ns + nb - 1) / nb) + 63u) & ~63u;
   const uint64_t beg64 = (uint64_t)vb * chunk;
   const uint32_t beg = beg64 < a.ns ? (uint32_t)beg64 : a.ns;
