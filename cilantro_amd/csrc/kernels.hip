@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
         __shared__ double AtA[36], Atb[6], dth[6], wsA[36], wsy[6];
         __shared__ int wsperm[6];
         gn_normal_equations(sums, has_p2p ? (double)a.w_p2p : 0.0, has_p2pl ? (double)a.w_p2pl : 0.0, AtA, Atb);
-        ldlt6_solve_ws(AtA, Atb, dth, wsA, wsy, wsperm);
+        if (!ldlt6_solve_fast(AtA, Atb, dth)) ldlt6_solve_ws(AtA, Atb, dth, wsA, wsy, wsperm);   // (pivoted: rank-deficient systems only)
         rigid_gn_update(dth, st->dLd, st->dtd);
         for (int i = 0; i < 9; ++i) st->innerL[i] = (float)st->dLd[i];
         for (int i = 0; i < 3; ++i) st->innert[i] = (float)st->dtd[i];

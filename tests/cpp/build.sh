@@ -8,6 +8,8 @@ g++ -O2 -std=c++17 -ffp-contract=off -I"$ROOT/include" "$HERE/$t.cpp" -o "$HERE/
     -L"$ROOT/cilantro_amd/lib" -lcilantro_hip -L"$ROOT/oracle" -loracle \
     -Wl,-rpath,"$ROOT/cilantro_amd/lib" -Wl,-rpath,"$ROOT/oracle" -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib -lamdhip64
 done
+# host-side check of the fast paths in csrc/solve.hpp (hipcc: the header pulls in the HIP runtime API; runs without a GPU)
+/opt/rocm/bin/hipcc -O2 -std=c++17 -ffp-contract=off --offload-arch=gfx950 "$HERE/test_solve.cpp" -o "$HERE/bin/test_solve"
 # host-only PLY round-trip helper (no GPU library needed)
 g++ -O2 -std=c++17 -I"$ROOT/include" "$HERE/test_ply.cpp" -o "$HERE/bin/test_ply"
 # the example program (compile check; run it on a GPU box with a PLY file)

@@ -1,0 +1,83 @@
+// Host-side check of the fast paths in cilantro_amd/csrc/solve.hpp (compiled with hipcc, runs without a GPU):
+//   nearest_rotation_polar  vs the SVD-based nearest_rotation (U V^T, the reference's rotation() polish)
+//   ldlt6_solve_fast        vs the pivoted LDL^T with pseudo-inverse semantics
+#include "../../cilantro_amd/csrc/solve.hpp"
+
+#include <cstdint>
+#include <cstdio>
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static double urand() {   // xorshift64*, [0,1)
+  rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
+  return (double)((rng_state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0;
+}
+
+int main() {
+  using namespace cilhip;
+  int failures = 0;
+  // near-rotations: Rodrigues rotation times (I + small perturbation), as the Gauss-Newton step produces them
+  double worst = 0.0;
+  int fast_taken = 0;
+  for (int trial = 0; trial < 20000; ++trial) {
+    double ax[3] = {urand() - 0.5, urand() - 0.5, urand() - 0.5};
+    const double nrm = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]) + 1e-30;
+    for (double& v : ax) v /= nrm;
+    const double ang = (trial % 5 == 0 ? 3.0 : 0.05) * urand(), c = std::cos(ang), s = std::sin(ang);
+    double Rm[9] = {c + ax[0] * ax[0] * (1 - c), ax[0] * ax[1] * (1 - c) - ax[2] * s, ax[0] * ax[2] * (1 - c) + ax[1] * s,
+                    ax[1] * ax[0] * (1 - c) + ax[2] * s, c + ax[1] * ax[1] * (1 - c), ax[1] * ax[2] * (1 - c) - ax[0] * s,
+                    ax[2] * ax[0] * (1 - c) - ax[1] * s, ax[2] * ax[1] * (1 - c) + ax[0] * s, c + ax[2] * ax[2] * (1 - c)};
+    const double eps = (trial % 3 == 0) ? 1e-2 : 1e-6;
+    double L[9];
+    for (int i = 0; i < 9; ++i) L[i] = Rm[i] + eps * (urand() - 0.5);
+    double A[9], B[9];
+    nearest_rotation(L, A);
+    if (nearest_rotation_polar(L, B)) {
+      ++fast_taken;
+      for (int i = 0; i < 9; ++i) worst = std::fmax(worst, std::fabs(A[i] - B[i]));
+    }
+  }
+  std::printf("polar vs SVD: fast path taken %d / 20000, max |dR| = %.3e\n", fast_taken, worst);
+  if (!(worst <= 5e-15) || fast_taken < 19990) ++failures;
+  // matrices the fast path must refuse: reflections, far from orthogonal, singular, NaN
+  {
+    const double refl[9] = {1, 0, 0, 0, 1, 0, 0, 0, -1}, far[9] = {2, 0, 0, 0, 1, 0, 0, 0, 1}, sing[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+    double nanm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; nanm[4] = NAN;
+    double R[9];
+    if (nearest_rotation_polar(refl, R) || nearest_rotation_polar(far, R) || nearest_rotation_polar(sing, R) || nearest_rotation_polar(nanm, R)) {
+      std::printf("polar fast path accepted a matrix it must refuse\n"); ++failures;
+    }
+  }
+  // LDL^T: random SPD normal equations (J^T J of 40 random rows + ridge), against the pivoted solve
+  double worst_rel = 0.0;
+  for (int trial = 0; trial < 5000; ++trial) {
+    double A[36] = {0}, b[6], x1[6], x2[6];
+    for (int r = 0; r < 40; ++r) {
+      double row[6];
+      for (double& v : row) v = urand() - 0.5;
+      if (trial % 2) { row[3] *= 1e3; row[0] *= 1e-2; }   // badly scaled unknowns, as rotation vs translation terms are
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i * 6 + j] += row[i] * row[j];
+    }
+    for (double& v : b) v = urand() - 0.5;
+    double W[36], y[6]; int perm[6];
+    ldlt6_solve_ws(A, b, x1, W, y, perm);
+    if (!ldlt6_solve_fast(A, b, x2)) { std::printf("fast LDLT refused an SPD system\n"); ++failures; break; }
+    double num = 0, den = 0;
+    for (int i = 0; i < 6; ++i) { num += (x1[i] - x2[i]) * (x1[i] - x2[i]); den += x1[i] * x1[i]; }
+    worst_rel = std::fmax(worst_rel, std::sqrt(num / (den + 1e-300)));
+  }
+  std::printf("LDLT fast vs pivoted: max relative difference %.3e\n", worst_rel);
+  if (!(worst_rel <= 1e-9)) ++failures;
+  // rank-deficient / indefinite / zero systems go to the pivoted solve
+  {
+    double A[36] = {0}, b[6] = {1, 2, 3, 4, 5, 6}, x[6];
+    if (ldlt6_solve_fast(A, b, x)) { std::printf("fast LDLT accepted the zero matrix\n"); ++failures; }
+    for (int i = 0; i < 5; ++i) A[i * 6 + i] = 1.0;       // rank 5
+    if (ldlt6_solve_fast(A, b, x)) { std::printf("fast LDLT accepted a rank-deficient matrix\n"); ++failures; }
+    A[35] = -1.0;                                          // indefinite
+    if (ldlt6_solve_fast(A, b, x)) { std::printf("fast LDLT accepted an indefinite matrix\n"); ++failures; }
+    ldlt6_solve(A, b, x);                                  // the wrapper still answers (pivoted)
+    if (!(std::fabs(x[0] - 1.0) < 1e-12 && std::fabs(x[5] + 6.0) < 1e-12)) { std::printf("wrapper fallback wrong\n"); ++failures; }
+  }
+  std::printf(failures ? "FAILED (%d)\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}

@@ -38,3 +38,14 @@ def test_cpp_model_estimation_mirrors_on_gpu(hip_lib, orc):
     _ensure_built(hip_lib, orc)
     out = subprocess.run([BIN2], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_solve_fast_paths_on_host(hip_lib, orc):
+    """cilantro_amd/csrc/solve.hpp is shared by the host API and the single-lane device epilogue: its fast paths (polar
+    iteration for the rotation() polish, unpivoted register-resident LDL^T) against the general ones (SVD, pivoted LDL^T
+    with pseudo-inverse), compiled for the host -- no GPU needed."""
+    binp = os.path.join(ROOT, "tests", "cpp", "bin", "test_solve")
+    if not os.path.exists(binp):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cpp", "build.sh")])
+    out = subprocess.run([binp], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
