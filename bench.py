@@ -140,6 +140,7 @@ def main():
         if not sharded:
             ctx.enable_kernel_timing(timing)
             return ctx.icp_run(p, T0)
+        ctx.enable_kernel_timing(timing)
         ctx.icp_begin(p, T0, gmean)
         for _ in range(iters):
             ctx.icp_partial_sums(sums.data_ptr())
@@ -189,7 +190,7 @@ def main():
         except Exception:
             traffic = None
         roof = None
-        if not sharded and launches > 0:
+        if launches > 0:      # (sharded runs: rank 0's own kernels)
             avg_ms = search_ms / launches
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             # the measured device copy bandwidth beside the spec peak (1 GiB torch copy = read + write)

@@ -96,6 +96,7 @@ struct cilhip_ctx {
   bool kernel_timing = false;
   double last_loop_ms = 0.0, last_search_ms = 0.0, last_acc_ms = 0.0;
   int last_search_launches = 0;
+  size_t run_nev = 0;             // sharded runs: hipEvents recorded by cilhip_icp_partial_sums since cilhip_icp_begin (3 per call)
   std::vector<hipEvent_t> ev;
 };
 
@@ -998,6 +999,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream);
   CK(c, hipGetLastError());
   c->run_active = true;
+  c->run_nev = 0;
   return CILHIP_OK;
 }
 
@@ -1012,9 +1014,15 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
     if (c->fused) {
       launch_iter(a, im, true, false, nb, c->stream);
     } else {
+      a.nn_d2 = nullptr;   // no post-filters in sharded runs: nobody reads the squared distances (as in cilhip_icp_run)
+      const bool timing = c->kernel_timing && c->run_nev + 3 <= 3 * 4096;
+      const size_t e = 2 + c->run_nev;
+      if (timing) CK(c, hipEventRecord(get_event(c, e), c->stream));
       if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
       else launch_iter(a, IM_NONE, true, true, nb, c->stream);
+      if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
       launch_iter(a, im, false, false, nb, c->stream);
+      if (timing) { CK(c, hipEventRecord(get_event(c, e + 2), c->stream)); c->run_nev += 3; }
     }
     launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);
   } else {
@@ -1087,7 +1095,22 @@ int cilhip_icp_sums_from_keys(cilhip_ctx* c, const uint64_t* keys_dev, double* s
 int cilhip_icp_state(cilhip_ctx* c, cilhip_icp_result* out) {
   if (!c || !out) return CILHIP_ERR_INVALID;
   CK(c, hipSetDevice(c->device));
-  return read_state(c, out);
+  const int rc = read_state(c, out);   // (synchronises the stream)
+  if (rc == CILHIP_OK && c->run_nev) {
+    // kernel timing of a sharded run: search / accumulation time summed over the cilhip_icp_partial_sums calls since
+    // cilhip_icp_begin (read with cilhip_get_last_timing / cilhip_get_last_timing2)
+    double sm = 0.0, am = 0.0;
+    for (size_t k = 0; k + 3 <= c->run_nev; k += 3) {
+      float a = 0.f, b = 0.f;
+      CK(c, hipEventElapsedTime(&a, get_event(c, 2 + k), get_event(c, 2 + k + 1)));
+      CK(c, hipEventElapsedTime(&b, get_event(c, 2 + k + 1), get_event(c, 2 + k + 2)));
+      sm += a; am += b;
+    }
+    c->last_search_ms = sm; c->last_acc_ms = am; c->last_search_launches = (int)(c->run_nev / 3);
+    c->last_loop_ms = 0.0;
+    c->run_nev = 0;
+  }
+  return rc;
 }
 
 int cilhip_compute_residuals(cilhip_ctx* c, int metric, float w_p2p, float w_p2pl, const float T[16], float* out, int mem) {
