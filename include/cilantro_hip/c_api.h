@@ -322,7 +322,9 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        Not available in sharded runs. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
- * kernels of the last cilhip_icp_run (sum over executed iterations). */
+ * kernels of the last cilhip_icp_run (sum over executed iterations).  Sharded runs: the same two sums over the
+ * cilhip_icp_partial_sums calls since cilhip_icp_begin, available after cilhip_icp_state (which synchronises);
+ * cilhip_get_last_timing then reports the number of those calls as the launch count. */
 int cilhip_get_last_timing2(cilhip_ctx* ctx, double* search_ms, double* accumulate_ms);
 /* Tiled search bookkeeping of the most recent search launch: out[0] = queries, out[1] = whole tiles that were
  * handed to the global-memory clean-up pass (syncs). */
