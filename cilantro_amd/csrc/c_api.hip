@@ -386,7 +386,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
 static bool use_tiled(const cilhip_ctx* c) {
   if (c->ns >= 0x80000000ull) return false;   // the clean-up list keeps a flag in bit 31 of a query index
   if (c->tiled >= 2) return true;
-  if (c->tiled != 1 || c->ntiles < 900) return false;
+  if (c->tiled != 1 || c->ntiles < 600) return false;   // (measured: 729 tiles / 1M points already favour the tiles by 4 %, 2M by 27 %)
   const double fill = (double)c->ns / ((double)c->ntiles * (double)TILE_QUERIES);
   const double region_cells = (double)(CUBE_EDGE + 3) * (CUBE_EDGE + 3) * (CUBE_EDGE + 3);
   const double density = c->grid_occ > 1.0 ? c->grid_occ - 1.0 : c->grid_occ;   // sum(count^2)/n = lambda + 1 for a Poisson cloud

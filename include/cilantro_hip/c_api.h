@@ -285,7 +285,7 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   "tiled" (default 1): LDS-tiled search kernel (one workgroup stages the cell region around an
  *                        12x12x12-cell cube of queries in LDS; tiles that do not fit fall back per tile):
  *                        0 = never (per-lane global-memory search), 1 = when the cloud is large enough
- *                        to fill the chip with tiles (>= 900 tiles, ~1.5M points), full enough tiles and a
+ *                        to fill the chip with tiles (>= 600 tiles, ~1M points), full enough tiles and a
  *                        target density that fits a tile's LDS budget, 2 = always.
  *   "cell_occupancy" (default 1): target points per grid cell, used by the next cilhip_set_target.
  *   "kernel_timing": same as cilhip_enable_kernel_timing.
