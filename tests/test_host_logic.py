@@ -46,3 +46,28 @@ def test_default_params_match_reference_defaults():
     assert p.metric == capi.METRIC_COMBINED and p.w_p2p == 0.0 and p.w_p2pl == 1.0      # combined_metric.hpp:44-47
     assert p.max_iter == 15 and abs(p.conv_tol - 1e-5) < 1e-12                           # icp_base.hpp:24-25
     assert p.max_opt_iter == 1 and abs(p.max_sq_dist - 1e-4) < 1e-10
+
+
+def test_torch_default_stream_handle_maps_to_hip_stream_legacy():
+    """The C ABI reserves NULL for "the context's own non-blocking stream".  torch reports handle 0 for its default
+    stream: the Python layer must pass hipStreamLegacy ((hipStream_t)1) for it -- with NULL the sharded protocols'
+    kernels were not ordered with torch / RCCL work at all.  None goes back to the own stream; other handles pass through."""
+    from cilantro_amd.icp import Context
+
+    seen = []
+
+    class _Lib:
+        @staticmethod
+        def cilhip_set_stream(h, s):
+            seen.append(s.value)
+            return capi.OK
+
+    c = object.__new__(Context)
+    c._L, c._h, c._on_caller_stream = _Lib(), None, False
+    c.set_stream(0)
+    assert seen[-1] == 1 and c._on_caller_stream
+    c.set_stream(0x7F00DEADBEE0)
+    assert seen[-1] == 0x7F00DEADBEE0 and c._on_caller_stream
+    c.set_stream(None)
+    assert (seen[-1] or 0) == 0 and not c._on_caller_stream
+    c._h = None   # nothing to destroy
