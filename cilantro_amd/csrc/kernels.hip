@@ -1042,6 +1042,11 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
 // radius beyond the 3x3x3 block, queries outside the grid, tiles whose region exceeded the LDS budget --
 // run the generic exact search out of global memory.
 constexpr int TODO_GROUP = 8;   // lanes per deferred query
+#ifndef CILHIP_FEAT6_GROUP
+#define CILHIP_FEAT6_GROUP 1
+#endif
+constexpr int FEAT6_GROUP = CILHIP_FEAT6_GROUP;   // lanes per query of the feature search: every query takes this path, so one lane each fills the chip best
+                                                  // (10M<->10M iteration: 8 lanes 1.69 ms, 4: 1.22, 2: 1.07, 1: 0.93)
 __global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const uint2* __restrict__ tiles) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
@@ -1093,7 +1098,7 @@ void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* ti
   hipLaunchKernelGGL(k_search_todo, dim3(nb2 ? nb2 : 1), dim3(ITER_THREADS), 0, s, a, tiles);
 }
 
-// Correspondence search over 6-D point+normal features (SECOND_TO_FIRST): groups of 8 lanes per query, the generic exact
+// Correspondence search over 6-D point+normal features (SECOND_TO_FIRST): FEAT6_GROUP lane(s) per query, the generic exact
 // search out of global memory with the feature distance.  Rigid transforms only (:104-111: the normal part is L * (w n)).
 __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
   const IcpState* __restrict__ st = a.state;
@@ -1101,8 +1106,8 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
-  const int sub = threadIdx.x & (TODO_GROUP - 1);
-  const uint64_t gid = ((uint64_t)blockIdx.x * ITER_THREADS + threadIdx.x) / TODO_GROUP;
+  const int sub = threadIdx.x & (FEAT6_GROUP - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * ITER_THREADS + threadIdx.x) / FEAT6_GROUP;
   if (gid >= a.ns) return;      // (whole groups leave together)
   const uint32_t i = (uint32_t)gid;
   const float4 s4 = a.src[i], sn = a.feat_src_nrm[i];
@@ -1116,7 +1121,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
   f.w = a.normal_weight;
   f.nrm = a.grid.nrm;
   NN best;
-  nn_search_group<TODO_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
+  nn_search_group<FEAT6_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
   if (sub == 0) {
     a.nn_pos[i] = best.pos;
     if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
@@ -1125,7 +1130,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
 
 void launch_search_feat6(const IterArgs& a, hipStream_t s) {
   if (a.ns == 0) return;
-  const uint64_t lanes = (uint64_t)a.ns * TODO_GROUP;
+  const uint64_t lanes = (uint64_t)a.ns * FEAT6_GROUP;
   hipLaunchKernelGGL(k_search_feat6, dim3((unsigned)((lanes + ITER_THREADS - 1) / ITER_THREADS)), dim3(ITER_THREADS), 0, s, a);
 }
 
