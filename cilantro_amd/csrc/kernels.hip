@@ -1,21 +1,23 @@
 // kernels.hip -- the per-iteration hot path of rigid ICP as hand-written HIP for gfx950 (CDNA4).
 //
-// One fused kernel per ICP iteration replaces four OpenMP loops of the reference:
+// Per ICP iteration these kernels replace four OpenMP loops of the reference:
 //   q_i = T*s_i                         correspondence_search/common_transformable_feature_adaptors.hpp:28-33
 //   1-NN of q_i in dst within r^2       correspondence_search/correspondence_search_kd_tree_utilities.hpp:26-33
 //                                       (nanoflann searchLevel, 3rd_party/nanoflann/nanoflann.hpp:1885-1961)
-//   second transform of src             core/space_transformations.hpp:203-216   (eliminated: q stays in registers)
+//   second transform of src             core/space_transformations.hpp:203-216   (eliminated: q is re-formed in registers)
 //   normal-equation / moment sums       registration/transform_estimation.hpp:25-34, :298-320, :328-343
-// followed by a one-block epilogue kernel that reduces the per-block partial sums in a fixed order
-// and performs the 3x3 SVD / 6x6 LDL^T solve + compose on the device (solve.hpp), so all
-// iterations of IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) can be
-// enqueued back-to-back with no host round trip.
+// as: the LDS-tiled search (k_tile_boxes, k_search_tiled, k_search_todo) or, for small clouds, the per-lane search
+// (k_iter<NONE, search, store>); the streaming accumulation (k_iter<metric, no search>; k_iter<metric, search> is the
+// fused small-cloud form); then k_reduce_stage1 and the one-block epilogue k_solve, which reduces the partial sums in a
+// fixed order and performs the 3x3 SVD / 6x6 LDL^T solve + compose on the device (solve.hpp), so all iterations of
+// IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) are enqueued back-to-back with no host
+// round trip.  DESIGN.md section 5 has the kernel table, the measurements and what was tried.
 //
 // Design notes (MI355X):
-//   * HBM/L2-bound gather workload, no MFMA: K=3 contraction, and the -2q.p+|p|^2 form would change the
-//     rounding of d2 and break index parity with the reference.
-//   * wave64: one query per lane; queries are pre-sorted by target-grid cell so the 64 lanes of a
-//     wave walk the same few cell runs (loads coalesce / broadcast in the TA, hit L1/L2).
+//   * no MFMA in the search: K=3 contraction, and the -2q.p+|p|^2 form would change the rounding of d2 and break
+//     index parity with the reference.
+//   * wave64: one query per lane; queries are pre-sorted by target-grid cube / cell so the 64 lanes of a
+//     wave walk the same few cell runs (LDS tile, or loads that coalesce / broadcast in the TA and hit L1/L2).
 //   * blockIdx -> work mapping is XCD-aware: hardware places block b on XCD b%8, so virtual block
 //     (b%8)*(nb/8)+b/8 gives every XCD one contiguous eighth of the (spatially sorted) queries and
 //     each private 4 MiB L2 caches one slab of the target instead of all of it.
