@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -164,6 +165,7 @@ static void free_source(cilhip_ctx* c) {
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
+  c->have_pairs = false; c->pairs.count = 0;   // a pair list refers to the source / target it was found on
 }
 
 void cilhip_destroy(cilhip_ctx* c) {
@@ -290,6 +292,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   c->has_target = true;
   c->src_sorted = false;  // source order is tied to the target grid
   c->have_nn = false;
+  c->have_pairs = false; c->pairs.count = 0;
   c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return CILHIP_OK;
 }
@@ -327,12 +330,14 @@ int cilhip_set_source_normals(cilhip_ctx* c, const float* nrm, int mem) {
   CK(c, hipSetDevice(c->device));
   if (c->d_src_nrm) { (void)hipFree(c->d_src_nrm); c->d_src_nrm = nullptr; }
   if (c->d_src_nrm_sorted) { (void)hipFree(c->d_src_nrm_sorted); c->d_src_nrm_sorted = nullptr; }
+  c->have_pairs = false; c->pairs.count = 0;
   if (!nrm) return CILHIP_OK;                              // back to the 3-cloud (non-symmetric) form
   int rc = upload(c, nrm, 3 * (size_t)c->ns, mem, &c->d_src_nrm);
   if (rc) return rc;
   CK(c, hipMalloc(&c->d_src_nrm_sorted, (c->ns ? c->ns : 1) * sizeof(float4)));
   c->src_sorted = false;                                   // the sorted copy is (re)built with the next sort
   c->have_nn = false;
+  c->have_pairs = false; c->pairs.count = 0;
   return CILHIP_OK;
 }
 
@@ -373,6 +378,19 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     c->src_sorted = true;
     c->have_nn = false;
   }
+  return CILHIP_OK;
+}
+
+int cilhip_prepare_source(cilhip_ctx* c, const float* T, int force, double* ms) {
+  if (!c) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  CK(c, hipStreamSynchronize(c->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  if (force) c->src_sorted = false;
+  const int rc = ensure_sorted(c, T ? T : kIdentity);
+  if (rc) return rc;
+  CK(c, hipStreamSynchronize(c->stream));
+  if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return CILHIP_OK;
 }
 
@@ -802,9 +820,14 @@ void cilhip_icp_default_params(cilhip_icp_params* p) {
   p->max_sq_dist = 0.01f * 0.01f;
 }
 
-static int iter_metric_of(const cilhip_icp_params* p) {
+// What the accumulation kernels sum for one ICP instance.  A plane term without target normals is the reference's
+// "dst_p.cols() != dst_n.cols()" case (transform_estimation.hpp:264-272: identity, false): the kernels must then never
+// touch grid.nrm (it is null) -- they count the correspondences only (IM_POINT's slot 0) and the epilogue's identity
+// branch (k_solve: has_p2pl && !has_normals) does the rest.
+static int iter_metric_of(const cilhip_ctx* c, const cilhip_icp_params* p) {
   if (p->metric == CILHIP_METRIC_POINT_TO_POINT) return IM_KABSCH;
   const bool wp = p->w_p2p > 0.0f, wl = p->w_p2pl > 0.0f;
+  if (wl && !c->has_normals) return IM_POINT;
   if (wp && wl) return IM_BOTH;
   if (wl) return IM_PLANE;
   if (wp) return IM_POINT;
@@ -853,7 +876,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   const float* Ti = T0 ? T0 : kIdentity;
   int rc = ensure_sorted(c, Ti);
   if (rc) return rc;
-  const int im = iter_metric_of(p);
+  const int im = iter_metric_of(c, p);
   const bool gn = (im != IM_KABSCH);
   const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 0) : 1;
   launch_init_state(c->d_state, Ti, c->src_mean, c->stream);
@@ -952,6 +975,15 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       }
       launch_solve(sa, c->stream);
     }
+    // Long runs ("iterate until converged" with a large max_iter): the kernels of a converged run return at once, but
+    // the post-filter / reduction launches do not look at the flag, so look at it from the host now and then and stop
+    // enqueueing.  Short runs (the reference's default is 15) stay free of host round trips.
+    if (p->max_iter > 64 && (it + 1) % 32 == 0 && it + 1 < p->max_iter) {
+      int done = 0;
+      CK(c, hipMemcpyAsync(&done, reinterpret_cast<const char*>(c->d_state) + offsetof(IcpState, done), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      CK(c, hipStreamSynchronize(c->stream));
+      if (done) break;
+    }
   }
   CK(c, hipEventRecord(e_end, c->stream));
   CK(c, hipGetLastError());
@@ -1007,7 +1039,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
   if (!c || !sums_dev) return CILHIP_ERR_INVALID;
   if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
   CK(c, hipSetDevice(c->device));
-  const int im = iter_metric_of(&c->run_prm);
+  const int im = iter_metric_of(c, &c->run_prm);
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   const int nb = iter_num_blocks(c->ns);
   if (c->ns) {
@@ -1036,7 +1068,7 @@ int cilhip_icp_apply_sums(cilhip_ctx* c, const double* sums_dev) {
   if (!c || !sums_dev) return CILHIP_ERR_INVALID;
   if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
   CK(c, hipSetDevice(c->device));
-  const int im = iter_metric_of(&c->run_prm);
+  const int im = iter_metric_of(c, &c->run_prm);
   SolveArgs sa = make_solve_args(c, &c->run_prm, im, c->run_src_mean);
   sa.nblocks = 0;
   sa.reduced = sums_dev;
@@ -1077,7 +1109,7 @@ int cilhip_icp_sums_from_keys(cilhip_ctx* c, const uint64_t* keys_dev, double* s
     CK(c, hipMalloc(&c->d_inv_perm, (c->grid.n ? c->grid.n : 1) * sizeof(uint32_t)));
     launch_inv_perm(c->grid.pts, c->grid.n, c->d_inv_perm, c->stream);
   }
-  const int im = iter_metric_of(&c->run_prm);
+  const int im = iter_metric_of(c, &c->run_prm);
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   const int nb = iter_num_blocks(c->ns);
   if (c->ns) {

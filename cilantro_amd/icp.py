@@ -228,6 +228,13 @@ class Context:
         self._ck(self._L.cilhip_compute_residuals(self._h, metric, w_p2p, w_p2pl, t.ctypes.data, out.ctypes.data, capi.MEM_HOST))
         return out[: self.n_source]
 
+    def prepare_source(self, T=None, force=False):
+        """Run the spatial pre-sort of the source explicitly (otherwise lazy); returns its wall time in ms."""
+        ms = C.c_double(0)
+        t = None if T is None else _T_to_abi(T)
+        self._ck(self._L.cilhip_prepare_source(self._h, None if t is None else t.ctypes.data, 1 if force else 0, C.byref(ms)))
+        return ms.value
+
     def grid_info(self):
         gi = capi.GridInfo()
         self._ck(self._L.cilhip_get_grid_info(self._h, C.byref(gi)))

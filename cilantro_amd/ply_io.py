@@ -37,7 +37,13 @@ def read_ply(path):
         if fmt not in ("ascii", "binary_little_endian"):
             raise ValueError(f"{path}: unsupported PLY format {fmt}")
         out = {"points": np.zeros((0, 3), np.float32), "normals": None, "colors": None}
+        import os
+
+        data_bytes = os.fstat(f.fileno()).st_size - f.tell()
         for name, count, props in elems:
+            # the counts are untrusted: a row takes at least one byte per property
+            if count < 0 or count * max(1, len(props)) > data_bytes:
+                raise ValueError(f"{path}: element count exceeds the file size")
             if any(t is None for _, t in props):
                 if name == "vertex":
                     raise ValueError(f"{path}: list property in the vertex element")

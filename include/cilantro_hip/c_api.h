@@ -79,6 +79,14 @@ int cilhip_set_source(cilhip_ctx* ctx, const float* xyz, size_t n, int mem);
  * clouds does (icp_single_transform_combined_metric.hpp:63-93,182-189 -> estimateTransformSymmetricMetric,
  * transform_estimation.hpp:604-739: n = n_dst + R*n_src), and computeResiduals adds them (:237). */
 int cilhip_set_source_normals(cilhip_ctx* ctx, const float* normals_or_null, int mem);
+/* The per-registration set-up of THIS design (the reference has no counterpart: its queries are searched in their
+ * given order, correspondence_search_kd_tree_utilities.hpp:26): spatial pre-sort of the source by the target-grid cube
+ * of T*s and the tile table of the LDS-tiled search.  It runs lazily inside the first search / cilhip_icp_run of a
+ * (target, source) pair and is re-run when the transform has moved the source by more than a few cells; this entry
+ * runs it explicitly so that its cost can be put on the bench line.  T NULL = identity; force != 0 re-sorts even if a
+ * valid order exists; ms_or_null = host wall time of the step (allocations and the two host round trips of the
+ * radix sort included), stream-synchronised. */
+int cilhip_prepare_source(cilhip_ctx* ctx, const float* T_or_null, int force, double* ms_or_null);
 /* dst_mean_ / src_mean_ as the ICP classes hold them (f64 sum, rounded to f32). */
 int cilhip_get_means(cilhip_ctx* ctx, float dst_mean[3], float src_mean[3]);
 

@@ -69,6 +69,19 @@ public:
       }
     }
     points.clear(); normals.clear(); colors.clear();
+    // The element counts are untrusted input: a count larger than the rest of the file can hold (every row takes at
+    // least one byte per property) is a malformed file, not an allocation request.
+    const std::streamoff data_begin = (std::streamoff)f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streamoff data_bytes = (std::streamoff)f.tellg() - data_begin;
+    f.seekg(data_begin, std::ios::beg);
+    if (!f || data_bytes < 0) throw std::runtime_error(file_name + ": cannot size the PLY data section");
+    for (const Elem& e : elems) {
+      size_t min_row = 0;
+      for (const Prop& pr : e.props) min_row += fmt == ASCII ? 1 : scalar_size(pr.is_list ? pr.count_type : pr.type, file_name);
+      if (min_row == 0) min_row = 1;
+      if (e.count > (size_t)data_bytes / min_row) throw std::runtime_error(file_name + ": element count exceeds the file size");
+    }
     for (const Elem& e : elems) {
       const bool vertex = e.name == "vertex";
       int ix[9];
@@ -150,6 +163,13 @@ private:
     f.read(reinterpret_cast<char*>(&v), sizeof(T));   // the host is little endian (x86-64 / the GPU boxes)
     if (!f) throw std::runtime_error(file + ": truncated PLY data");
     return (double)v;
+  }
+  static size_t scalar_size(const std::string& type, const std::string& file) {
+    if (type == "double" || type == "float64") return 8;
+    if (type == "float" || type == "float32" || type == "uint" || type == "uint32" || type == "int" || type == "int32") return 4;
+    if (type == "ushort" || type == "uint16" || type == "short" || type == "int16") return 2;
+    if (type == "uchar" || type == "uint8" || type == "char" || type == "int8") return 1;
+    throw std::runtime_error(file + ": unknown PLY property type " + type);
   }
   static double read_scalar(std::istream& f, const std::string& type, bool ascii, const std::string& file) {
     if (ascii) {

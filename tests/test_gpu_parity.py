@@ -33,6 +33,33 @@ def classify_mismatches(orc, dst, q, gi, gd, oi, od):
     return len(bad), ties, nearer, worse
 
 
+def _report(name, obj):
+    """Measured figures of the full-size tests, kept next to the run (gpurun_out/ travels back from the GPU box)."""
+    import json
+    import os
+
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+    print(name, obj)
+
+
+def _oracle_icp_loop(orc, tree, d, p, iters):
+    """icp_base.hpp:68-87 driven from here so that the kNN half can be the reference's own nanoflann (oracle/_ref) over a
+    tree built once: transformFeatures -> findCorrespondences -> updateEstimate (the oracle's estimator), `iters` times."""
+    T = np.eye(4, dtype=np.float32)
+    nc = 0
+    for _ in range(iters):
+        di, si, _ = tree.find_correspondences(orc.transform_points(T, d["src"]), float(d["max_sq_dist"]))
+        T, _ = orc.icp_update(d["dst"], d["dst_n"], d["src"], T, di, si, p)
+        nc = len(di)
+    return T, nc
+
+
 def gpu_nn(ctx, T, max_sq):
     ctx.find_correspondences(T, max_sq, count=False)
     idx, d2 = ctx.get_nn()
@@ -218,6 +245,26 @@ def test_icp_degenerate_inputs(hip_lib):
     icp = SimpleCombinedMetricRigidICP3f(dst, nrm, far)
     T = icp.estimate().getTransform()
     assert np.array_equal(T, np.eye(4, dtype=np.float32)) and icp.getNumberOfPerformedIterations() == 1
+    # a plane term without target normals: dst_p.cols() != dst_n.cols() in the reference (transform_estimation.hpp:264-272)
+    # -> identity step, "converged" after one iteration -- with correspondences present, in the loop, through the raw
+    # sharded entry points, with the per-lane and the LDS-tiled search, and with the combined weights
+    d = syn.make_pair(30000)
+    for tiled in (0, 2):
+        for w_p2p in (0.0, 0.3):
+            icp = SimpleCombinedMetricRigidICP3f(d["dst"], None, d["src"])
+            icp._ctx.set_option("tiled", tiled)
+            icp.setPointToPointMetricWeight(w_p2p).setPointToPlaneMetricWeight(1.0)
+            icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+            T = icp.setMaxNumberOfIterations(5).estimate().getTransform()
+            assert np.array_equal(T, np.eye(4, dtype=np.float32)) and icp.getNumberOfPerformedIterations() == 1
+            assert icp.last_ncorr_ > 0
+    import torch
+
+    from cilantro_amd import distributed
+    eng = distributed.HipShardEngine(d["dst"], None, d["src"], 0)
+    r = distributed.ShardedRigidICP(eng).estimate(distributed.default_params(max_iter=3, max_sq_dist=float(d["max_sq_dist"])))
+    assert np.array_equal(r[0], np.eye(4, dtype=np.float32)) and r[1] == 1
+    torch.cuda.synchronize()
 
 
 def test_run_to_run_bitwise_reproducible(hip_lib):
@@ -458,6 +505,18 @@ def test_engine_post_filters_vs_oracle(Context, orc, hip_lib):
         assert np.linalg.norm(Tg.astype(np.float64) - r["T"]) <= TOL_T, (frac, o2o)
 
 
+def _kmeans_label_mismatches_are_near_ties(x, lab_g, lab_o, centroids, k):
+    """After several Lloyd steps the two sides' centroids differ in their last bits (the GPU sums exactly in fixed point,
+    the reference serially in f32), so a point that sits on a cell boundary of the Voronoi diagram can flip.  Every
+    mismatch must be such a point -- its two candidate centroids equidistant to 1e-5 relative -- and there are few."""
+    bad = np.nonzero(lab_g != lab_o)[0]
+    assert len(bad) <= max(1, int(1e-5 * len(x))), (k, len(bad))
+    for i in bad:
+        dg = float(((x[i].astype(np.float64) - centroids[lab_g[i]]) ** 2).sum())
+        do = float(((x[i].astype(np.float64) - centroids[lab_o[i]]) ** 2).sum())
+        assert abs(dg - do) <= 1e-5 * max(dg, do), (k, int(i), dg, do)
+
+
 def test_kmeans3f_vs_oracle(orc, hip_lib):
     """KMeans<float,3> brute-force path (clustering/kmeans.hpp:67-194)."""
     from cilantro_amd.clustering import KMeans3f, kmeans_assign
@@ -478,7 +537,7 @@ def test_kmeans3f_vs_oracle(orc, hip_lib):
         co, lo, ito = orc.kmeans(x, c0, max_iter=iters, tol=tol, mode=1)
         assert km.getNumberOfPerformedIterations() == ito, (k, km.getNumberOfPerformedIterations(), ito)
         assert np.abs(km.getClusterCentroids() - co).max() <= 1e-6, k
-        assert (km.getPointToClusterIndexMap() != lo).mean() <= 1e-5, k
+        _kmeans_label_mismatches_are_near_ties(x, km.getPointToClusterIndexMap(), lo, co, k)
         groups = km.getClusterToPointIndicesMap()
         assert len(groups) == k and sum(len(g) for g in groups) == len(x)
     # empty-cluster repair (kmeans.hpp:134-176): a far-away initial centroid attracts nothing
@@ -486,7 +545,7 @@ def test_kmeans3f_vs_oracle(orc, hip_lib):
     km = KMeans3f(x).cluster(c0, max_iter=3, tol=0.0)
     co, lo, ito = orc.kmeans(x, c0, max_iter=3, tol=0.0, mode=1)
     assert np.abs(km.getClusterCentroids() - co).max() <= 1e-6
-    assert (km.getPointToClusterIndexMap() != lo).mean() <= 1e-5
+    _kmeans_label_mismatches_are_near_ties(x, km.getPointToClusterIndexMap(), lo, co, 8)
 
 
 def _plane_cloud(n, seed, inlier_frac=0.6, noise=0.004):
@@ -578,8 +637,12 @@ def test_knn_and_normal_estimation_vs_oracle(orc, hip_lib):
         bad = np.nonzero((gi != oi).any(axis=1))[0]
         for i in bad:                                                # index differences only inside groups of tied distances
             for j in np.nonzero(gi[i] != oi[i])[0]:
-                assert (od[i] == od[i, j]).sum() >= 2 or True
+                # slot j holds a different index: then the other index sits at the same (bit-identical) distance -- either
+                # in another slot of this list (a tie inside the k best) or just outside it (a tie on the k-th distance)
                 assert gd[i, j] == od[i, j]
+                dj = q[i] - x[[gi[i, j], oi[i, j]]]                       # f32, the pinned expression ((dx*dx)+(dy*dy))+(dz*dz)
+                dd = (dj[:, 0] * dj[:, 0] + dj[:, 1] * dj[:, 1]) + dj[:, 2] * dj[:, 2]
+                assert dd[0] == dd[1] == od[i, j], (i, j, dd, od[i, j])
         assert len(bad) <= 2, (k, r2, len(bad))
     # self k-NN: every point finds itself first at distance 0
     gi, gd, gc = tree_g.kNNSearch(None, 6)
@@ -958,7 +1021,7 @@ def test_full_size_properties_10m(Context, orc, hip_lib):
     o1, o2, ov = tree.find_correspondences(q, float(d["max_sq_dist"]))
     found = it[sample] >= 0
     assert np.array_equal(np.nonzero(found)[0], o2) and np.array_equal(it[sample][o2], o1) and np.array_equal(dt[sample][o2], ov)
-    del tree
+    tree10 = tree
 
     Ts = []
     for _ in range(2):
@@ -970,6 +1033,28 @@ def test_full_size_properties_10m(Context, orc, hip_lib):
         del icp
     assert np.array_equal(Ts[0], Ts[1])
     assert np.linalg.norm(Ts[0] - d["T_true"]) < 1e-5
+
+    # The whole run against the ORACLE's run at the full size (all 10M correspondences per iteration, the reference's
+    # nanoflann where available): 6 iterations from the identity.  MODE_MIXED is the arithmetic the HIP path mirrors
+    # (per-term f32, f64 sums): must agree to 1e-5.  MODE_F32 is the reference-like all-f32 serial accumulation
+    # (transform_estimation.hpp:339-341 sums 1e7 f32 terms): its distance from the f64-summed result is REPORTED
+    # (gpurun_out/parity_10m.json; DESIGN.md numeric contract) and bounded loosely.
+    icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+    icp.correspondenceSearchEngine().setMaxDistance(float(d["max_sq_dist"]))
+    Tg = icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0).estimate().getTransform().astype(np.float64)
+    nc = icp.last_ncorr_
+    del icp
+    rep = {"n": n, "iterations": 6, "T_err_gpu_vs_truth": float(np.linalg.norm(Tg - d["T_true"]))}
+    for name, mode in (("mixed", orc.MODE_MIXED), ("f32", orc.MODE_F32)):
+        p = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]), mode=mode)
+        To, nco = _oracle_icp_loop(orc, tree10, d, p, 6)
+        rep[name] = {"T_gpu_minus_T_oracle_frobenius": float(np.linalg.norm(Tg - To.astype(np.float64))),
+                     "T_oracle_minus_truth_frobenius": float(np.linalg.norm(To.astype(np.float64) - d["T_true"])),
+                     "ncorr_gpu": int(nc), "ncorr_oracle": int(nco), "knn": "reference nanoflann" if tree10.use_ref else "oracle kd-tree"}
+        assert nco == nc
+    _report("parity_10m.json", rep)
+    assert rep["mixed"]["T_gpu_minus_T_oracle_frobenius"] <= TOL_T, rep
+    assert rep["f32"]["T_gpu_minus_T_oracle_frobenius"] <= 1e-3, rep
 
 
 @pytest.mark.gpu
@@ -1070,6 +1155,36 @@ def test_full_size_target_sharded_config(orc, hip_lib):
     assert np.array_equal(Ta, Tb) and ita == itb == 6 and nca == ncb == nc1
     assert np.abs(Ta.astype(np.float64) - T1.astype(np.float64)).max() <= 1e-6, float(np.abs(Ta.astype(np.float64) - T1.astype(np.float64)).max())
     assert np.linalg.norm(T1 - d["T_true"]) < 1e-5, float(np.linalg.norm(T1 - d["T_true"]))
+    del engs
+    torch.cuda.empty_cache()
+
+    # Against the oracle over the FULL 80M-point target (the reference's nanoflann where available): a 40k-query sample of
+    # the source under a drifted transform -- indices and squared distances bit for bit -- and one combined-metric
+    # (0.1 / 1.0) ICP update from those sampled correspondences, GPU engine vs the oracle's estimator.
+    from cilantro_amd.icp import Context
+
+    rng = np.random.default_rng(321)
+    sample = np.sort(rng.choice(len(d["src"]), 40_000, replace=False))
+    src_s = np.ascontiguousarray(d["src"][sample])
+    T = d["T_true"].astype(np.float32).copy(); T[:3, 3] += np.array([0.3, -0.2, 0.25], np.float32) * np.float32(d["h"])
+    ctx = Context(); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(src_s)
+    gi, gd = gpu_nn(ctx, T, float(d["max_sq_dist"]))
+    del ctx
+    tree = orc.KDTree(d["dst"], use_ref=orc.ref_available())
+    o1, o2, ov = tree.find_correspondences(orc.transform_points(T, src_s), float(d["max_sq_dist"]))
+    found = gi >= 0
+    assert len(o2) > 0.99 * len(sample)
+    assert np.array_equal(np.nonzero(found)[0], o2) and np.array_equal(gi[o2], o1) and np.array_equal(gd[o2], ov)
+    del tree
+    icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], src_s)
+    icp.setPointToPointMetricWeight(0.1).setPointToPlaneMetricWeight(1.0).setInitialTransform(T)
+    icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+    Tg = icp.setMaxNumberOfIterations(1).setConvergenceTolerance(0.0).estimate().getTransform()
+    p = orc.make_params(metric=1, w_p2p=0.1, w_p2pl=1.0, max_iter=1, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]), mode=orc.MODE_MIXED)
+    To, _ = orc.icp_update(d["dst"], d["dst_n"], src_s, T, o1, o2, p)
+    err = float(np.linalg.norm(Tg.astype(np.float64) - To.astype(np.float64)))
+    _report("parity_c4.json", {"n_target": nd, "sample": len(sample), "found": int(len(o2)), "T_gpu_minus_T_oracle_frobenius": err})
+    assert err <= TOL_T, err
 
 
 @pytest.mark.gpu

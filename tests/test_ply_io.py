@@ -64,3 +64,20 @@ def test_reads_the_references_test_cloud():
     assert r["points"].shape == (120111, 3) and r["normals"].shape == (120111, 3) and r["colors"].shape == (120111, 3)
     ok = np.isfinite(r["normals"]).all(axis=1)
     assert np.abs(np.linalg.norm(r["normals"][ok], axis=1) - 1).max() < 1e-3
+
+
+def test_malformed_element_count_is_rejected(tmp_path, hip_lib, orc):
+    """An element count the file cannot hold (crafted so that 3 * count wraps, or merely huge) is a malformed file:
+    both readers refuse it before allocating or writing anything."""
+    subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cpp", "build.sh")])
+    p, _, _ = _cloud(10)
+    for count in (6148914691236517206, 1 << 40):       # ~2^64 / 3 (the product wraps in size_t), and a huge valid one
+        for binary in (True, False):
+            f = str(tmp_path / "bad.ply")
+            write_ply(f, p, binary=binary)
+            raw = open(f, "rb").read().replace(b"element vertex 10\n", b"element vertex %d\n" % count)
+            open(f, "wb").write(raw)
+            with pytest.raises(ValueError):
+                read_ply(f)
+            out = subprocess.run([BIN, "copy", f, str(tmp_path / "o.ply"), "1"], capture_output=True, text=True, timeout=60)
+            assert out.returncode == 1 and "exceeds the file size" in out.stdout, out.stdout + out.stderr
