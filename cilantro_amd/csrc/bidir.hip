@@ -209,7 +209,7 @@ hipError_t find_pairs(const GridDev& g, const float4* src_sorted, const float4* 
     if ((e = hipMalloc(&rev_d2, (size_t)nd * 4)) != hipSuccess) break;
     IterArgs r{};
     r.grid = qg.grid; r.src = g.pts; r.src_nrm = nullptr; r.ns = nd; r.max_sq = max_sq; r.state = id_state;
-    r.nn_pos = rev_pos; r.nn_d2 = rev_d2; r.partials = nullptr; r.todo = nullptr; r.todo_count = nullptr; r.todo_tiles = nullptr;
+    r.nn_pos = rev_pos; r.nn_d2 = rev_d2; r.partials = nullptr; r.defer_mask = nullptr; r.tile_partials = nullptr; r.store_matches = 1;
     r.skip_if_inner_done = 0;
     launch_iter(r, IM_NONE, true, true, iter_num_blocks(nd), s);
     // 3. candidates -> keys (original indices) -> sort

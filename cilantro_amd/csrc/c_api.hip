@@ -45,8 +45,9 @@ struct cilhip_ctx {
   float4* d_tile_center = nullptr;  // [ntiles] cube centre of each tile in source space
   int* d_tile_box = nullptr;        // [8*ntiles] cell range of each tile's cube under the current transform (recomputed per search)
   float tile_axes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t* d_todo = nullptr;     // [ns] deferred queries + 2 counters at d_todo[ns..ns+1]: clean-up lists of the tiled search
-  uint32_t* d_todo_tiles = nullptr; // [ntiles]
+  unsigned long long* d_defer_mask = nullptr;  // [ntiles * 32] queries the tiles hand to the clean-up pass (bit masks, rewritten by every search)
+  double* d_tile_partials = nullptr;           // [ntiles * SUMS_MAX] per-tile partial sums of the in-tile accumulation
+  uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint32_t ntiles = 0;
   int tiled = 1;                  // 0: per-lane global-memory search; 1: LDS-tiled search when the cloud is large enough; 2: always tiled
   bool src_sorted = false;
@@ -65,6 +66,7 @@ struct cilhip_ctx {
   int partial_blocks = 0;
   double* d_stage = nullptr;      // [REDUCE_STAGE_DOUBLES] stage-1 rows of the cross-block reduction
   double* d_sums = nullptr;       // [3 * SUMS_MAX] (the affine estimator reduces three passes before one copy to the host)
+  bool tile_acc = true;           // accumulate inside the LDS tiles of the search when the engine allows it (option "tile_accumulation", A/B)
   bool fused = false;             // true: search+accumulate in one kernel; false: search kernel + streaming accumulate kernel (faster: the search runs at 2x the occupancy)
   double cell_occupancy = 1.0;    // target points per grid cell (takes effect at the next set_target)
   unsigned long long* d_count = nullptr;
@@ -157,11 +159,11 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_src_nrm) (void)hipFree(c->d_src_nrm);
   if (c->d_src_nrm_sorted) (void)hipFree(c->d_src_nrm_sorted);
   c->d_src_nrm = nullptr; c->d_src_nrm_sorted = nullptr;
-  if (c->d_todo) (void)hipFree(c->d_todo);
+  if (c->d_defer_mask) (void)hipFree(c->d_defer_mask);
   if (c->d_keys) (void)hipFree(c->d_keys);
   c->d_keys = nullptr;
-  if (c->d_todo_tiles) (void)hipFree(c->d_todo_tiles);
-  c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_todo = nullptr; c->d_todo_tiles = nullptr;
+  if (c->d_tile_partials) (void)hipFree(c->d_tile_partials);
+  c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_defer_mask = nullptr; c->d_tile_partials = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
@@ -182,6 +184,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_sel_state) (void)hipFree(c->d_sel_state);
   if (c->d_winner) (void)hipFree(c->d_winner);
   if (c->d_count) (void)hipFree(c->d_count);
+  if (c->d_dbg) (void)hipFree(c->d_dbg);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_sums) (void)hipFree(c->d_sums);
   for (auto e : c->ev) (void)hipEventDestroy(e);
@@ -212,6 +215,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
+  if (!strcmp(key, "tile_accumulation")) { c->tile_acc = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "search_direction")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "search_direction: 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH");
     c->search_dir = (int)value; c->have_nn = false; c->have_pairs = false;
@@ -237,9 +241,11 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
 int cilhip_debug_counters(cilhip_ctx* c, uint32_t out[2]) {
   if (!c || !out) return CILHIP_ERR_INVALID;
   out[0] = out[1] = 0;
-  if (!c->d_todo) return CILHIP_OK;
+  if (!c->d_defer_mask || !c->ntiles) return CILHIP_OK;
   CK(c, hipSetDevice(c->device));
-  CK(c, hipMemcpyAsync(out, c->d_todo + (c->ns ? c->ns : 1), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (!c->d_dbg) CK(c, hipMalloc(&c->d_dbg, 2 * sizeof(uint32_t)));
+  launch_count_deferred(c->d_defer_mask, c->ntiles, c->d_dbg, c->stream);
+  CK(c, hipMemcpyAsync(out, c->d_dbg, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   CK(c, hipStreamSynchronize(c->stream));
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   cilhip::debug_dump_phase_clocks();
@@ -308,7 +314,6 @@ int cilhip_set_source(cilhip_ctx* c, const float* xyz, size_t n, int mem) {
   CK(c, hipMalloc(&c->d_src_sorted, cap * sizeof(float4)));
   CK(c, hipMalloc(&c->d_nn_pos, cap * sizeof(uint32_t)));
   CK(c, hipMalloc(&c->d_nn_d2, cap * sizeof(float)));
-  CK(c, hipMalloc(&c->d_todo, (cap + 2) * sizeof(uint32_t)));
   c->ns = (uint32_t)n;
   double mean[3];
   hipError_t e = mean3_device(c->d_src_xyz, c->ns, c->stream, mean);
@@ -368,10 +373,22 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     if (c->d_tiles) { (void)hipFree(c->d_tiles); c->d_tiles = nullptr; c->ntiles = 0; }
     if (c->d_tile_center) { (void)hipFree(c->d_tile_center); c->d_tile_center = nullptr; }
     if (c->d_tile_box) { (void)hipFree(c->d_tile_box); c->d_tile_box = nullptr; }
-    if (c->d_todo_tiles) { (void)hipFree(c->d_todo_tiles); c->d_todo_tiles = nullptr; }
+    if (c->d_defer_mask) { (void)hipFree(c->d_defer_mask); c->d_defer_mask = nullptr; }
+    if (c->d_tile_partials) { (void)hipFree(c->d_tile_partials); c->d_tile_partials = nullptr; }
     hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->d_tile_center, c->tile_axes, &c->ntiles);
     if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
-    CK(c, hipMalloc(&c->d_todo_tiles, ((size_t)c->ntiles + 1) * sizeof(uint32_t)));
+    CK(c, hipMalloc(&c->d_defer_mask, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long)));
+    CK(c, hipMemsetAsync(c->d_defer_mask, 0, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long), c->stream));
+    CK(c, hipMalloc(&c->d_tile_partials, ((size_t)c->ntiles + 1) * SUMS_MAX * sizeof(double)));
+    {   // the clean-up pass of the tiled search leaves one row of partial sums per block
+      const int rows = std::max(iter_num_blocks(c->ns), tiled_partial_rows(c->ntiles));
+      if (rows > c->partial_blocks) {
+        if (c->d_partials) (void)hipFree(c->d_partials);
+        c->d_partials = nullptr; c->partial_blocks = 0;
+        CK(c, hipMalloc(&c->d_partials, (size_t)rows * SUMS_MAX * sizeof(double)));
+        c->partial_blocks = rows;
+      }
+    }
     CK(c, hipMalloc(&c->d_tile_box, ((size_t)c->ntiles + 1) * 8 * sizeof(int)));
     if (c->d_src_nrm) launch_gather_by_w(c->d_src_sorted, c->d_src_nrm, c->ns, c->d_src_nrm_sorted, c->stream);
     memcpy(c->sort_T, T, sizeof(c->sort_T));
@@ -415,6 +432,14 @@ static bool filters_active(const cilhip_ctx* c) {
   return (c->inlier_fraction > 0.0 && c->inlier_fraction < 1.0) || c->one_to_one;
 }
 
+// The ICP loop's first Gauss-Newton step is accumulated inside the LDS tiles of the search (one pass instead of a search
+// pass + a streaming accumulation pass) whenever the plain engine runs tiled: no post-filters (they act on the complete
+// match set), point features, the three-cloud metric (the symmetric objective reads source normals per pair), and not
+// the A/B option "fused" (per-lane kernel) or "tile_accumulation" = 0.
+static bool tile_accumulation(const cilhip_ctx* c) {
+  return c->tile_acc && use_tiled(c) && !filters_active(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+}
+
 // filterCorrespondencesFraction then filterCorrespondencesOneToOne on the stored matches
 static int apply_filters(cilhip_ctx* c) {
   if (!filters_active(c) || c->ns == 0) return CILHIP_OK;
@@ -446,9 +471,9 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.nn_pos = c->d_nn_pos;
   a.nn_d2 = c->d_nn_d2;
   a.partials = c->d_partials;
-  a.todo = c->d_todo;
-  a.todo_count = c->d_todo ? c->d_todo + (c->ns ? c->ns : 1) : nullptr;
-  a.todo_tiles = c->d_todo_tiles;
+  a.defer_mask = c->d_defer_mask;
+  a.tile_partials = c->d_tile_partials;
+  a.store_matches = 1;
   a.skip_if_inner_done = 0;
   return a;
 }
@@ -463,7 +488,7 @@ static int launch_search(cilhip_ctx* c, const IterArgs& a) {
     launch_search_feat6(a, c->stream);
     return CILHIP_OK;
   }
-  if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel
+  if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel
   else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);                                 // per-lane global-memory search
   return CILHIP_OK;
 }
@@ -478,7 +503,7 @@ static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq) {
     launch_init_state(c->d_state_id, kIdentity, zero, c->stream);
   }
   if (c->search_dir == 2 && c->ns && c->grid.n) {   // forward half of BOTH: the usual search, no filters yet
-    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+    if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
   }
   const hipError_t e = find_pairs(c->grid, c->d_src_sorted, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm_sorted : nullptr, c->ns, c->d_state, c->d_state_id, max_sq,
@@ -939,6 +964,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     return CILHIP_OK;
   }
   if (!filters_active(c)) a.nn_d2 = nullptr;   // nobody reads the distances inside the loop: 4 B per query less to write
+  const bool tile_acc = tile_accumulation(c);
   const bool timing = c->kernel_timing && p->max_iter <= 4096;
   hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
   CK(c, hipEventRecord(e_beg, c->stream));
@@ -957,6 +983,12 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (c->ns) {
         if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
+        } else if (st == 0 && tile_acc) {
+          // search + accumulation of the first Gauss-Newton step inside the LDS tiles (one pass; the matches are only
+          // stored when further Gauss-Newton steps will stream over them)
+          IterArgs fa = a;
+          fa.store_matches = opt_steps > 1 ? 1 : 0;
+          launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         } else if (st == 0) {
           { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
@@ -969,9 +1001,10 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (timing && st == 0) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); ++launches; }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
-        const int rows = launch_reduce_stage1(c->d_partials, nb, c->d_stage, c->stream);
+        const int prows = (st == 0 && tile_acc) ? tiled_partial_rows(c->ntiles) : nb;
+        const int rows = launch_reduce_stage1(c->d_partials, prows, c->d_stage, c->stream);
         sa.partials = rows ? c->d_stage : c->d_partials;
-        sa.nblocks = rows ? rows : nb;
+        sa.nblocks = rows ? rows : prows;
       }
       launch_solve(sa, c->stream);
     }
@@ -1000,7 +1033,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (timing) {
     // only iterations that actually executed (not the early-exit launches after convergence)
     const size_t executed = out->iterations < (size_t)launches ? out->iterations : (size_t)launches;
-    const size_t per = ((c->fused && !filters_active(c) && !feat6(c)) || c->ns == 0) ? 2 : 4;
+    const size_t per = ((c->fused && !filters_active(c) && !feat6(c)) || tile_acc || c->ns == 0) ? 2 : 4;
     c->last_acc_ms = 0.0;
     for (size_t k = 0; k < executed; ++k) {
       float m = 0.f;
@@ -1042,6 +1075,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
   const int im = iter_metric_of(c, &c->run_prm);
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   const int nb = iter_num_blocks(c->ns);
+  int prows = nb;
   if (c->ns) {
     if (c->fused) {
       launch_iter(a, im, true, false, nb, c->stream);
@@ -1050,13 +1084,20 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
       const bool timing = c->kernel_timing && c->run_nev + 3 <= 3 * 4096;
       const size_t e = 2 + c->run_nev;
       if (timing) CK(c, hipEventRecord(get_event(c, e), c->stream));
-      if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
-      else launch_iter(a, IM_NONE, true, true, nb, c->stream);
-      if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
-      launch_iter(a, im, false, false, nb, c->stream);
+      if (tile_accumulation(c)) {
+        a.store_matches = 0;
+        launch_search_tiled(a, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+        if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
+        prows = tiled_partial_rows(c->ntiles);
+      } else {
+        if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+        else launch_iter(a, IM_NONE, true, true, nb, c->stream);
+        if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
+        launch_iter(a, im, false, false, nb, c->stream);
+      }
       if (timing) { CK(c, hipEventRecord(get_event(c, e + 2), c->stream)); c->run_nev += 3; }
     }
-    launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);
+    launch_reduce_partials(c->d_partials, prows, c->d_stage, sums_dev, c->stream);
   } else {
     CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));
   }
@@ -1092,7 +1133,7 @@ int cilhip_icp_partial_keys(cilhip_ctx* c, uint64_t* keys_dev) {
   CK(c, hipSetDevice(c->device));
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   if (c->ns) {
-    if (use_tiled(c)) launch_search_tiled(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+    if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
     launch_pack_keys(c->d_src_sorted, c->grid.pts, c->d_nn_pos, c->d_nn_d2, c->ns, c->index_offset,
                      reinterpret_cast<unsigned long long*>(keys_dev), c->stream);

@@ -85,9 +85,9 @@ struct IterArgs {
   uint32_t* nn_pos;        // [ns] (sorted-source order) sorted-target position or NONE
   float* nn_d2;            // [ns], or null: the squared distances are not stored (the ICP loop without post-filters never reads them)
   double* partials;        // [nblocks * SUMS_MAX]
-  uint32_t* todo;          // [ns] queries deferred by the tiled search to its clean-up pass
-  uint32_t* todo_count;    // [2]: number of deferred queries, number of deferred tiles
-  uint32_t* todo_tiles;    // [ntiles] tiles deferred as a whole
+  unsigned long long* defer_mask;  // [ntiles * 2 * (TILE_THREADS / 64)] tiled search: queries handed to its clean-up pass, one word per wave and query slot
+  double* tile_partials;   // [ntiles * SUMS_MAX] tiled search with in-tile accumulation: one row of partial sums per tile
+  int store_matches;       // tiled search: also write nn_pos / nn_d2 for the queries settled inside the tile (the pure ICP loop needs neither)
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
   const float4* feat_src_nrm;  // 6-D point+normal feature search: sorted source normals, and
@@ -110,8 +110,12 @@ struct SolveArgs {
 // kernels.hip
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
 void launch_solve(const SolveArgs& a, hipStream_t s);
-void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box /*[8*ntiles] scratch*/, uint32_t ntiles,
-                         hipStream_t s);
+// acc_metric IM_NONE: search only; IM_KABSCH / IM_PLANE / IM_POINT / IM_BOTH: search + accumulation inside the tile
+// (first Gauss-Newton step), leaving tiled_partial_rows(ntiles) rows in a.partials
+void launch_search_tiled(const IterArgs& a, int acc_metric, const uint2* tiles, const float4* tile_center, int* tile_box /*[8*ntiles] scratch*/,
+                         uint32_t ntiles, hipStream_t s);
+int tiled_partial_rows(uint32_t ntiles);
+void launch_count_deferred(const unsigned long long* mask, uint32_t ntiles, uint32_t* out2, hipStream_t s);
 void launch_search_feat6(const IterArgs& a, hipStream_t s);   // correspondence search over 6-D point+normal features
 #ifdef CILHIP_EXP_PHASE_CLOCKS
 void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_search_tiled -> stderr

@@ -383,6 +383,223 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
   }
 }
 
+// ---- accumulation helpers ------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <int METRIC>
+struct AccTraits {
+  static constexpr bool plane = (METRIC == IM_PLANE || METRIC == IM_BOTH);
+  static constexpr bool point = (METRIC == IM_POINT || METRIC == IM_BOTH);
+  static constexpr bool kabsch = (METRIC == IM_KABSCH);
+  static constexpr bool affine = (METRIC == IM_AFF0 || METRIC == IM_AFF1 || METRIC == IM_AFF2);
+  static constexpr int NA = affine ? (METRIC == IM_AFF0 ? 34 : 30) : kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
+  static constexpr int NB = point ? 15 : 0;                  // slots [28, 28+NB)
+};
+
+// The accumulation of one matched pair (q = T*s already formed): what every accumulating kernel adds per correspondence.
+// accA / accB are the caller's per-lane f64 accumulators (slots [0, NA) and [28, 28 + NB) of a partial-sum row).
+template <int METRIC>
+__device__ __forceinline__ void accumulate_pair(double* __restrict__ accA, double* __restrict__ accB, const float* T, const float* iL, const float* it,
+                                                const float* smt, const float* dmean, const bool sym, const bool has_nrm, float qx, float qy, float qz,
+                                                uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
+  using TR = AccTraits<METRIC>;
+  if (METRIC != IM_NONE && pos != NONE_U32) {
+    if (TR::kabsch) {
+      // raw moments for the closed-form estimator (transform_estimation.hpp:25-34)
+      const double pd[3] = {(double)p.x, (double)p.y, (double)p.z};
+      const double qd[3] = {(double)qx, (double)qy, (double)qz};
+      accA[0] += 1.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { accA[1 + c] += pd[c]; accA[4 + c] += qd[c]; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) accA[7 + r * 3 + c] = fma(pd[r], qd[c], accA[7 + r * 3 + c]);
+    } else if (TR::affine) {
+      // Affine closed form (transform_estimation.hpp:369-476; :50-102 for the point-to-point class): per-term
+      // quantities in f32 as the reference forms them -- s = q - src_mean', d = p - dst_mean -- their products and
+      // sums in f64.  eq_vec = (n_0 s, n_1 s, n_2 s, n): every entry of eq_vec eq_vec^T is n_j n_k (s,1)_a (s,1)_b.
+      const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
+      const float s0 = __fsub_rn(qx, smt[0]), s1 = __fsub_rn(qy, smt[1]), s2 = __fsub_rn(qz, smt[2]);
+      const double sd[4] = {(double)s0, (double)s1, (double)s2, 1.0};
+      if (METRIC == IM_AFF0) {
+        const double dd[3] = {(double)d0, (double)d1, (double)d2};
+        accA[0] += 1.0;
+        int k = 1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = r; c < 3; ++c) { accA[k] = fma(sd[r], sd[c], accA[k]); ++k; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) accA[7 + c] += sd[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) accA[10 + r * 3 + c] = fma(sd[r], dd[c], accA[10 + r * 3 + c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) accA[19 + c] += dd[c];
+        if (has_nrm) {
+          // n.dot(dst - dst_mean)  (:464), f32 like the reference's dot product
+          const float res = __fadd_rn(__fadd_rn(__fmul_rn(nvp.x, d0), __fmul_rn(nvp.y, d1)), __fmul_rn(nvp.z, d2));
+          const double nd[3] = {(double)nvp.x, (double)nvp.y, (double)nvp.z};
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const double rn = (double)res * nd[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accA[22 + j * 4 + c] = fma(rn, sd[c], accA[22 + j * 4 + c]);
+          }
+        }
+      } else {
+        const double nd[3] = {(double)nvp.x, (double)nvp.y, (double)nvp.z};
+        int k = 0;
+#pragma unroll
+        for (int jk = 0; jk < 3; ++jk) {
+          // (j,k): AFF1 -> (0,0),(0,1),(0,2); AFF2 -> (1,1),(1,2),(2,2)
+          const int j = (METRIC == IM_AFF1) ? 0 : (jk == 2 ? 2 : 1);
+          const int kk = (METRIC == IM_AFF1) ? jk : (jk == 0 ? 1 : 2);
+          const double nn = nd[j] * nd[kk];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = r; c < 4; ++c) { accA[k] = fma(nn * sd[r], sd[c], accA[k]); ++k; }
+        }
+      }
+    } else {
+      // per-term quantities in f32 exactly as the reference forms them (transform_estimation.hpp:302-304,:333-335)
+      const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
+      const float u0 = __fsub_rn(qx, smt[0]), u1 = __fsub_rn(qy, smt[1]), u2 = __fsub_rn(qz, smt[2]);
+      // s = inner_tform * (q - T*src_mean); identity on the first Gauss-Newton step
+      const float s0 = __fadd_rn(__fadd_rn(__fmul_rn(iL[0], u0), __fadd_rn(__fmul_rn(iL[1], u1), __fmul_rn(iL[2], u2))), it[0]);
+      const float s1 = __fadd_rn(__fadd_rn(__fmul_rn(iL[3], u0), __fadd_rn(__fmul_rn(iL[4], u1), __fmul_rn(iL[5], u2))), it[1]);
+      const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(iL[6], u0), __fadd_rn(__fmul_rn(iL[7], u1), __fmul_rn(iL[8], u2))), it[2]);
+      const float a0 = __fadd_rn(d0, s0), a1 = __fadd_rn(d1, s1), a2 = __fadd_rn(d2, s2);
+      const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
+      accA[0] += 1.0;
+      if (TR::plane) {
+        float4 nv = nvp;
+        if (sym) {
+          // symmetric metric (transform_estimation.hpp:705-706): n = n_dst + tform.linear() * n_src', with
+          // n_src' = transform_.linear() * n_src (transformNormals, core/space_transformations.hpp:374-390)
+          const float4 sn = snp;
+          const float t0 = __fadd_rn(__fmul_rn(T[0], sn.x), __fadd_rn(__fmul_rn(T[4], sn.y), __fmul_rn(T[8], sn.z)));
+          const float t1 = __fadd_rn(__fmul_rn(T[1], sn.x), __fadd_rn(__fmul_rn(T[5], sn.y), __fmul_rn(T[9], sn.z)));
+          const float t2 = __fadd_rn(__fmul_rn(T[2], sn.x), __fadd_rn(__fmul_rn(T[6], sn.y), __fmul_rn(T[10], sn.z)));
+          nv.x = __fadd_rn(nv.x, __fadd_rn(__fmul_rn(iL[0], t0), __fadd_rn(__fmul_rn(iL[1], t1), __fmul_rn(iL[2], t2))));
+          nv.y = __fadd_rn(nv.y, __fadd_rn(__fmul_rn(iL[3], t0), __fadd_rn(__fmul_rn(iL[4], t1), __fmul_rn(iL[5], t2))));
+          nv.z = __fadd_rn(nv.z, __fadd_rn(__fmul_rn(iL[6], t0), __fadd_rn(__fmul_rn(iL[7], t1), __fmul_rn(iL[8], t2))));
+        }
+        float e[6];
+        e[0] = __fsub_rn(__fmul_rn(a1, nv.z), __fmul_rn(a2, nv.y));   // (d+s).cross(n)  :337
+        e[1] = __fsub_rn(__fmul_rn(a2, nv.x), __fmul_rn(a0, nv.z));
+        e[2] = __fsub_rn(__fmul_rn(a0, nv.y), __fmul_rn(a1, nv.x));
+        e[3] = nv.x; e[4] = nv.y; e[5] = nv.z;
+        const float res = __fadd_rn(__fmul_rn(nv.x, r0), __fadd_rn(__fmul_rn(nv.y, r1), __fmul_rn(nv.z, r2)));  // n.dot(d-s)
+        double ed[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ed[k] = (double)e[k];
+        int k = 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) { accA[k] = fma(ed[r], ed[c], accA[k]); ++k; }
+        const double rd = (double)res;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) accA[22 + r] = fma(rd, ed[r], accA[22 + r]);
+      }
+      if (TR::point) {
+        const double ad[3] = {(double)a0, (double)a1, (double)a2};
+        const double rd[3] = {(double)r0, (double)r1, (double)r2};
+        accB[0] += ad[0]; accB[1] += ad[1]; accB[2] += ad[2];
+        accB[3] = fma(ad[0], ad[0], accB[3]); accB[4] = fma(ad[0], ad[1], accB[4]); accB[5] = fma(ad[0], ad[2], accB[5]);
+        accB[6] = fma(ad[1], ad[1], accB[6]); accB[7] = fma(ad[1], ad[2], accB[7]); accB[8] = fma(ad[2], ad[2], accB[8]);
+        accB[9] += ad[1] * rd[2] - ad[2] * rd[1];
+        accB[10] += ad[2] * rd[0] - ad[0] * rd[2];
+        accB[11] += ad[0] * rd[1] - ad[1] * rd[0];
+        accB[12] += rd[0]; accB[13] += rd[1]; accB[14] += rd[2];
+      }
+    }
+  }
+}
+
+
+// ---- in-tile accumulation (k_search_tiled<ACC>): the per-correspondence vector z and where the sums sit in z z^T ----
+// PLANE : z = (e0..e5, res, 1)              e = [(d+s) x n ; n], res = n.(d-s)          transform_estimation.hpp:333-341
+// POINT : z = (a0,a1,a2, r0,r1,r2, 1, 0)    a = d+s, r = d-s                             :302-319
+// BOTH  : z = (PLANE's 8, a0,a1,a2, r0,r1,r2)
+// KABSCH: z = (p0,p1,p2, q0,q1,q2, 1, 0)    raw coordinates                              :25-34
+// with d = p - dst_mean, s = q - T*src_mean (the inner Gauss-Newton transform is the identity on the first step), every
+// term formed in f32 exactly as accumulate_pair forms it.  slot_terms(): partial-sum slot = Z[i1][j1] - Z[i2][j2]
+// (i2 < 0: one term) in accumulate_pair's slot layout; the point-to-point cross product a x r becomes a difference of two
+// accumulated products (f64: the cancellation costs ~1e-16 of sum |a_i r_j|, far below the estimator's own round-off).
+template <int ACC>
+struct FusedZ {
+  static constexpr bool plane = (ACC == IM_PLANE || ACC == IM_BOTH);
+  static constexpr int NC = (ACC == IM_BOTH) ? 14 : 8;
+  static constexpr bool needs_normal = plane;
+  __device__ static bool slot_terms(int s, int& i1, int& j1, int& i2, int& j2) {
+    i1 = j1 = 0; i2 = j2 = -1;
+    if (ACC == IM_KABSCH) {
+      if (s == 0) { i1 = 6; j1 = 6; return true; }
+      if (s < 4) { i1 = s - 1; j1 = 6; return true; }
+      if (s < 7) { i1 = 3 + (s - 4); j1 = 6; return true; }
+      if (s < 16) { i1 = (s - 7) / 3; j1 = 3 + (s - 7) % 3; return true; }
+      return false;
+    }
+    if (plane && s < 28) {
+      if (s == 0) { i1 = 7; j1 = 7; return true; }
+      if (s >= 22) { i1 = s - 22; j1 = 6; return true; }
+      int k = s - 1, r = 0;
+      while (k >= 6 - r) { k -= 6 - r; ++r; }
+      i1 = r; j1 = r + k;
+      return true;
+    }
+    if (ACC == IM_POINT && s == 0) { i1 = 6; j1 = 6; return true; }
+    if ((ACC == IM_POINT || ACC == IM_BOTH) && s >= 28 && s < 43) {
+      const int A0 = (ACC == IM_BOTH) ? 8 : 0, R0 = A0 + 3, ONE = (ACC == IM_BOTH) ? 7 : 6;
+      const int b = s - 28;
+      if (b < 3) { i1 = A0 + b; j1 = ONE; return true; }
+      if (b < 9) { int k = b - 3, r = 0; while (k >= 3 - r) { k -= 3 - r; ++r; } i1 = A0 + r; j1 = A0 + r + k; return true; }
+      if (b == 9) { i1 = A0 + 1; j1 = R0 + 2; i2 = A0 + 2; j2 = R0 + 1; return true; }     // a1 r2 - a2 r1
+      if (b == 10) { i1 = A0 + 2; j1 = R0 + 0; i2 = A0 + 0; j2 = R0 + 2; return true; }    // a2 r0 - a0 r2
+      if (b == 11) { i1 = A0 + 0; j1 = R0 + 1; i2 = A0 + 1; j2 = R0 + 0; return true; }    // a0 r1 - a1 r0
+      i1 = R0 + (b - 12); j1 = ONE;
+      return true;
+    }
+    return false;
+  }
+};
+
+template <int ACC>
+__device__ __forceinline__ void fused_z(bool has, float qx, float qy, float qz, const float4 p, const float4 nv, const float* dmean, const float* smt,
+                                        float* z) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) z[k] = 0.0f;
+  if (!has) return;
+  if (ACC == IM_KABSCH) {
+    z[0] = p.x; z[1] = p.y; z[2] = p.z; z[3] = qx; z[4] = qy; z[5] = qz; z[6] = 1.0f;
+    return;
+  }
+  const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
+  const float s0 = __fsub_rn(qx, smt[0]), s1 = __fsub_rn(qy, smt[1]), s2 = __fsub_rn(qz, smt[2]);
+  const float a0 = __fadd_rn(d0, s0), a1 = __fadd_rn(d1, s1), a2 = __fadd_rn(d2, s2);
+  const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
+  if (FusedZ<ACC>::plane) {
+    z[0] = __fsub_rn(__fmul_rn(a1, nv.z), __fmul_rn(a2, nv.y));   // (d+s).cross(n)
+    z[1] = __fsub_rn(__fmul_rn(a2, nv.x), __fmul_rn(a0, nv.z));
+    z[2] = __fsub_rn(__fmul_rn(a0, nv.y), __fmul_rn(a1, nv.x));
+    z[3] = nv.x; z[4] = nv.y; z[5] = nv.z;
+    z[6] = __fadd_rn(__fmul_rn(nv.x, r0), __fadd_rn(__fmul_rn(nv.y, r1), __fmul_rn(nv.z, r2)));   // n.dot(d-s)
+    z[7] = 1.0f;
+    if (ACC == IM_BOTH) { z[8] = a0; z[9] = a1; z[10] = a2; z[11] = r0; z[12] = r1; z[13] = r2; }
+  } else {
+    z[0] = a0; z[1] = a1; z[2] = a2; z[3] = r0; z[4] = r1; z[5] = r2; z[6] = 1.0f;
+  }
+}
+
 // =====================================================================================================
 // LDS-tiled search kernel.
 //
@@ -418,6 +635,11 @@ constexpr int TILE_MAXSPAN = CUBE_EDGE + 6;                  // region rows per 
 constexpr int TILE_MAXROWS = TILE_MAXSPAN * TILE_MAXSPAN;    // RY*RZ
 constexpr int TILE_MAXE = CILHIP_TILE_MAXE;                  // entries of the staged cell table: rows * (RX + 1)
 constexpr int TILE_QPT = TILE_QUERIES / TILE_THREADS;        // queries per thread
+constexpr int TILE_WAVES = TILE_THREADS / 64;
+constexpr uint32_t DEFER_MARK = 0xFFFFFFFEu;                 // nn_pos value: "the LDS tile could not settle this query" (between a tile's 3x3x3 pass and its home lanes)
+constexpr int FUSED_WAVE_BYTES = 3584;                       // per-wave scratch of the in-tile accumulation (64 correspondences x 14 floats) carved from the point buffer
+static_assert(FUSED_WAVE_BYTES * TILE_WAVES <= (TILE_CAP + 8) * 16, "the accumulation scratch reuses the tile's point buffer");
+static_assert(FUSED_WAVE_BYTES >= 64 * 8 * 4 + 64 && FUSED_WAVE_BYTES >= 4 * 64 * 8, "scratch holds the padded 8-float layout and the wave's 16x16 f64 tile");
 static_assert(TILE_MAXE <= 65536 && TILE_MAXROWS <= 32767, "OctQuery packs a table index and a row into 16 bits each");
 static_assert(TILE_MAXROWS <= 64 * 8, "the row scan holds at most 8 rows per lane of one wave");
 
@@ -517,7 +739,7 @@ __device__ __forceinline__ float octant_bound(const GridDev& g, float qx, float 
 }
 
 // Returns true (result proven exact) iff the best found is strictly nearer than any point outside the block can be.
-__device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best) {
+__device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best, uint32_t& bl_out) {
   const f32x2 qxy = {o.qx, o.qy};
   const float qz = o.qz;
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
@@ -591,6 +813,7 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
   }
   best.pos = pos;
+  bl_out = bl;      // LDS index of the winner (NONE_U32: nothing within the radius): the in-tile accumulation reads the point from there
   const float b = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
@@ -743,6 +966,18 @@ __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center,
   b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = bz0; b[5] = bz1; b[6] = (int)inv_w1; b[7] = (int)inv_ry;
 }
 
+// A tile that cannot be staged at all hands every query to the clean-up pass (all-ones masks; the pass clips to the
+// tile's range) and contributes a zero partial row.
+template <int ACC>
+__device__ __forceinline__ void defer_whole_tile(const IterArgs& a, uint32_t vb) {
+  if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+    for (int u = 0; u < TILE_QPT; ++u) a.defer_mask[(size_t)vb * (2 * TILE_WAVES) + u * TILE_WAVES + (threadIdx.x >> 6)] = ~0ull;
+  }
+  if (ACC != IM_NONE && threadIdx.x < SUMS_MAX) a.tile_partials[(size_t)vb * SUMS_MAX + threadIdx.x] = 0.0;
+}
+
+template <int ACC>
 __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
                                                                   const int* __restrict__ tile_box, uint32_t ntiles) {
   const IcpState* __restrict__ st = a.state;
@@ -794,7 +1029,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   if (!ok) {
     // whole-tile fallback (the cube's image is outside the grid or too large for the LDS budget: the transform
     // moved far from the sort-time one): the clean-up pass searches this tile's queries in their sorted order
-    if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
+    defer_whole_tile<ACC>(a, vb);
     return;
   }
 
@@ -894,7 +1129,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     int rz = RZ;
     while (rz > 3 && rowbase[rz * RY] > (uint32_t)TILE_CAP) --rz;
     if (rowbase[rz * RY] > (uint32_t)TILE_CAP) {
-      if (threadIdx.x == 0) a.todo_tiles[atomicAdd(a.todo_count + 1, 1u)] = vb;
+      defer_whole_tile<ACC>(a, vb);
       return;
     }
     rows = rz * RY;
@@ -947,13 +1182,14 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   }
   __syncthreads();
   PHASE_CLK(2);
-  // ---- 3. per-lane exact search out of LDS (or hand-off to the clean-up pass) ----
+  // ---- 3. per-lane exact search out of LDS ----
   // 3a: the octant block, every lane, straight-line.  Queries it does not prove are QUEUED in LDS (16-bit slot ids in
   // the unused tail of the point buffer) instead of being finished in place: finishing them in place costs a wave the
   // whole 3x3x3 search even when one of its lanes needs it.
   TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
   // (queue base and capacity are re-derived from the LDS row table where needed rather than kept in registers across
   //  the search: P = rowbase[rows], block-uniform)
+  uint32_t mpos[TILE_QPT];   // per query: sorted-target position of the match (NONE: none / not settled here)
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
     const bool active = (flags >> u) & 1u, fast = (flags >> (8 + u)) & 1u;
@@ -961,10 +1197,11 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     NN best;
     best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
     best.pos = NONE_U32;
+    uint32_t bl = NONE_U32;
     bool defer = false, unproven = false;
     if (active) {
       if (fast) {
-        unproven = !octant_search(g, tl, oq[u], a.max_sq, best);
+        unproven = !octant_search(g, tl, oq[u], a.max_sq, best, bl);
       } else {
         // outside the tile's box or in the grid's outer layer (or beyond): nothing to find if the query is farther
         // from the grid than the radius, else the clean-up pass (generic search) takes it
@@ -993,111 +1230,314 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         }
       }
     }
-    if (active && !unproven) {
-      if (defer) {
-        // hand the query to the clean-up pass (k_search_todo: generic global-memory search); order-independent
-        a.todo[atomicAdd(a.todo_count, 1u)] = i;
-      } else {
-        a.nn_pos[i] = best.pos;
-        if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
-      }
+    if (active && !unproven && !defer && a.store_matches) {
+      a.nn_pos[i] = best.pos;
+      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
+    mpos[u] = (unproven | defer) ? NONE_U32 : best.pos;
+    flags |= (unproven ? (1u << (16 + u)) : 0u) | (defer ? (1u << (24 + u)) : 0u);
   }
   __syncthreads();
-  // 3b: the queued queries, densely packed over the lanes: the full 3x3x3 block (straight-line when the wave is
-  // reasonably full, the culled per-lane loop for a sparse last wave).  The query is fetched and transformed again.
-  if (__builtin_amdgcn_readfirstlane((int)queue_count) == 0) return;   // block-uniform
-  TileLds tq{lpts, lcs, rowbase, rowdelta, __builtin_amdgcn_readfirstlane(geom_lds[0]), __builtin_amdgcn_readfirstlane(geom_lds[1]),
-             __builtin_amdgcn_readfirstlane(geom_lds[2]), __builtin_amdgcn_readfirstlane(geom_lds[3]),
-             __builtin_amdgcn_readfirstlane(geom_lds[4]), __builtin_amdgcn_readfirstlane(geom_lds[5])};
-  const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[tq.rows]);
-  const uint16_t* const queue = reinterpret_cast<const uint16_t*>(lpts + Pq + 8);
-  const uint32_t nq = min((uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count), min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 8u));
-  if (threadIdx.x < nq) {   // wave-uniform except in the last wave
-    float Tq[16];        // from LDS rather than kept live across the kernel
+  // 3b: the queued queries, densely packed over the lanes: the full 3x3x3 block in straight-line code.  The query is
+  // fetched and transformed again.  Results go through nn_pos (DEFER_MARK: not proven either): the query's home lane
+  // picks them up below, so that whatever is accumulated per query is accumulated by the same lane in every run.
+  const uint32_t nqueued = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count);   // block-uniform
+  if (nqueued != 0) {
+    TileLds tq{lpts, lcs, rowbase, rowdelta, __builtin_amdgcn_readfirstlane(geom_lds[0]), __builtin_amdgcn_readfirstlane(geom_lds[1]),
+               __builtin_amdgcn_readfirstlane(geom_lds[2]), __builtin_amdgcn_readfirstlane(geom_lds[3]),
+               __builtin_amdgcn_readfirstlane(geom_lds[4]), __builtin_amdgcn_readfirstlane(geom_lds[5])};
+    const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[tq.rows]);
+    const uint16_t* const queue = reinterpret_cast<const uint16_t*>(lpts + Pq + 8);
+    const uint32_t nq = min(nqueued, min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 8u));
+    if (threadIdx.x < nq) {   // wave-uniform except in the last wave
+      float Tq[16];        // from LDS rather than kept live across the kernel
 #pragma unroll
-    for (int k = 0; k < 16; ++k) Tq[k] = tform_lds[k];
-    for (uint32_t k = threadIdx.x; k < nq; k += TILE_THREADS) {
-      const uint32_t i = tile.x + queue[k];
-      const float4 sq = a.src[i];
-      float qx, qy, qz;
-      transform_point(Tq, sq.x, sq.y, sq.z, qx, qy, qz);
-      const int cx = (int)floorf((qx - g.ox) * g.inv_cell), cy = (int)floorf((qy - g.oy) * g.inv_cell), cz = (int)floorf((qz - g.oz) * g.inv_cell);
-      NN best;
-      bool proven;
-      proven = block27_search(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best);
-      if (proven) {
-        a.nn_pos[i] = best.pos;
-        if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
-      } else {
-        a.todo[atomicAdd(a.todo_count, 1u)] = i | 0x80000000u;
+      for (int k = 0; k < 16; ++k) Tq[k] = tform_lds[k];
+      for (uint32_t k = threadIdx.x; k < nq; k += TILE_THREADS) {
+        const uint32_t i = tile.x + queue[k];
+        const float4 sq = a.src[i];
+        float qx, qy, qz;
+        transform_point(Tq, sq.x, sq.y, sq.z, qx, qy, qz);
+        const int cx = (int)floorf((qx - g.ox) * g.inv_cell), cy = (int)floorf((qy - g.oy) * g.inv_cell), cz = (int)floorf((qz - g.oz) * g.inv_cell);
+        NN best;
+        const bool proven = block27_search(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best);
+        a.nn_pos[i] = proven ? best.pos : DEFER_MARK;
+        if (proven && a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
       }
     }
+    __syncthreads();
+  }
+  // ---- 4. home lanes: results of their queued queries; the deferred ones are published as one mask word per wave and
+  //         query slot (bit = lane): the clean-up pass walks the masks in a fixed order ----
+#pragma unroll
+  for (int u = 0; u < TILE_QPT; ++u) {
+    bool defer = (flags >> (24 + u)) & 1u;
+    if (nqueued != 0 && ((flags >> (16 + u)) & 1u)) {
+      const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+      // (agent-scope load: served by L2, never by a line this CU cached before the 3b lane's store)
+      const uint32_t v = __hip_atomic_load(a.nn_pos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v == DEFER_MARK) defer = true; else mpos[u] = v;
+    }
+    const unsigned long long dm = __ballot(defer);
+    if ((threadIdx.x & 63u) == 0) a.defer_mask[(size_t)vb * (2 * TILE_WAVES) + u * TILE_WAVES + (threadIdx.x >> 6)] = dm;
   }
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   __syncthreads();
   PHASE_CLK(3);
 #endif
+  if (ACC == IM_NONE) return;
+
+  // ---- 5. accumulation inside the tile (ACC != IM_NONE; first Gauss-Newton step: the inner transform is the identity).
+  // Every sum the estimators need is an entry of  Z = sum_i z_i z_i^T  for a per-correspondence vector z of f32 terms
+  // (fused_z): a rank update with K = number of correspondences -- v_mfma_f64_16x16x4_f64 work, the one place on the
+  // path where the matrix cores fit the arithmetic contract (products of f32 terms are exact in f64, sums in f64).
+  // Nothing but the match position is carried through the search in registers: the query is fetched and transformed
+  // again, the matched point and its normal are gathered -- all of it was touched by this tile a moment ago (L2).
+  // From here on nobody reads the staged points or the cell table: the point buffer becomes per-wave scratch.
+  {
+    constexpr int NC = FusedZ<ACC>::NC;
+    constexpr bool DUAL = NC <= 8;        // two groups of 4 correspondences per instruction: rows/cols 0-7 and 8-15
+    float z[TILE_QPT][16];
+    {
+      float4 s4[TILE_QPT], p4[TILE_QPT], n4[TILE_QPT];
+#pragma unroll
+      for (int u = 0; u < TILE_QPT; ++u) {
+        uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+        asm volatile("" : "+v"(i));       // (a fresh load: do not keep the kernel-start copy of the query alive through the search)
+        const bool has = mpos[u] != NONE_U32;
+        s4[u] = p4[u] = n4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has) {
+          s4[u] = a.src[i];
+          p4[u] = g.pts[mpos[u]];
+          if (FusedZ<ACC>::needs_normal) n4[u] = g.nrm[mpos[u]];
+        }
+      }
+      float Tq[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) Tq[k] = tform_lds[k];
+#pragma unroll
+      for (int u = 0; u < TILE_QPT; ++u) {
+        float qx, qy, qz;
+        transform_point(Tq, s4[u].x, s4[u].y, s4[u].z, qx, qy, qz);
+        fused_z<ACC>(mpos[u] != NONE_U32, qx, qy, qz, p4[u], n4[u], a.dst_mean, st->smt, z[u]);
+      }
+    }
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < TILE_QPT; ++u) {
+      if (DUAL) {
+        // [64 correspondences][8 floats]; the second half of the wave 16 floats further (so that the two groups an
+        // instruction reads sit on different banks)
+        float4* w4 = reinterpret_cast<float4*>(zb + lane * 8 + (lane >= 32 ? 16 : 0));
+        w4[0] = make_float4(z[u][0], z[u][1], z[u][2], z[u][3]);
+        w4[1] = make_float4(z[u][4], z[u][5], z[u][6], z[u][7]);
+      } else {
+        float2* w2 = reinterpret_cast<float2*>(zb + lane * NC);
+#pragma unroll
+        for (int c = 0; c < NC / 2; ++c) w2[c] = make_float2(z[u][2 * c], z[u][2 * c + 1]);
+      }
+      __builtin_amdgcn_wave_barrier();    // (DS operations of one wave execute in order: the reads below see the writes)
+      if (DUAL) {
+        const int comp = lane & 7, half = (lane >> 3) & 1, k4 = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int qi = half * 32 + 4 * j + k4;
+          const double x = (double)zb[qi * 8 + half * 16 + comp];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+        }
+      } else {
+        const int comp = lane & 15, k4 = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float f = zb[(4 * j + k4) * NC + (comp < NC ? comp : 0)];
+          const double x = comp < NC ? (double)f : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // D[(lane >> 4) + 4 r][lane & 15] = acc[r]  ->  this wave's 16x16 tile in its scratch, then one fixed-order sum
+    double* const db = reinterpret_cast<double*>(raw + wave * FUSED_WAVE_BYTES);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) db[r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (threadIdx.x < SUMS_MAX) {
+      int i1, j1, i2, j2;
+      const bool used = FusedZ<ACC>::slot_terms((int)threadIdx.x, i1, j1, i2, j2);
+      double v1 = 0.0, v2 = 0.0;
+      if (used) {
+        const int e1 = (i1 >> 2) * 64 + 16 * (i1 & 3) + j1, e1b = ((i1 + 8) >> 2) * 64 + 16 * ((i1 + 8) & 3) + j1 + 8;
+        const int e2 = i2 >= 0 ? (i2 >> 2) * 64 + 16 * (i2 & 3) + j2 : 0, e2b = i2 >= 0 ? ((i2 + 8) >> 2) * 64 + 16 * ((i2 + 8) & 3) + j2 + 8 : 0;
+        for (int w = 0; w < TILE_WAVES; ++w) {
+          const double* dw = reinterpret_cast<const double*>(raw + w * FUSED_WAVE_BYTES);
+          v1 += dw[e1];
+          if (DUAL) v1 += dw[e1b];
+          if (i2 >= 0) { v2 += dw[e2]; if (DUAL) v2 += dw[e2b]; }
+        }
+      }
+      a.tile_partials[(size_t)vb * SUMS_MAX + threadIdx.x] = v1 - v2;
+    }
+  }
 }
 
-// Clean-up pass of the tiled search: the (few) queries the LDS tile could not settle -- sparse data or a
-// radius beyond the 3x3x3 block, queries outside the grid, tiles whose region exceeded the LDS budget --
-// run the generic exact search out of global memory.
+// Clean-up pass of the tiled search: the (few) queries the LDS tile could not settle -- sparse data or a radius beyond
+// the 3x3x3 block, queries outside the grid, tiles whose region exceeded the LDS budget -- run the generic exact search
+// out of global memory.  The tiles publish them as bit masks (one 64-bit word per wave and query slot); the words are
+// dealt to the waves of this kernel in a fixed interleaved order, so that with ACC != IM_NONE what a lane accumulates --
+// and with it every partial sum -- is the same in every run.  Sparse words: TODO_GROUP lanes per query; dense words
+// (whole deferred tiles): one lane per query.  With ACC the block also folds its share of the tiles' partial rows.
 constexpr int TODO_GROUP = 8;   // lanes per deferred query
 #ifndef CILHIP_FEAT6_GROUP
 #define CILHIP_FEAT6_GROUP 1
 #endif
 constexpr int FEAT6_GROUP = CILHIP_FEAT6_GROUP;   // lanes per query of the feature search: every query takes this path, so one lane each fills the chip best
                                                   // (10M<->10M iteration: 8 lanes 1.69 ms, 4: 1.22, 2: 1.07, 1: 0.93)
-__global__ __launch_bounds__(ITER_THREADS) void k_search_todo(IterArgs a, const uint2* __restrict__ tiles) {
+template <int ACC>
+__global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, const uint2* __restrict__ tiles, uint32_t ntiles) {
+  using TR = AccTraits<ACC>;
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
-  const uint32_t n = a.todo_count[0], nt = a.todo_count[1];
-  if (n == 0 && nt == 0) return;
   __shared__ uint2 worklist[LIST_CAP * ITER_THREADS];
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
-  // (a) whole deferred tiles: consecutive lanes take consecutive (spatially sorted) queries
-  constexpr uint32_t CHUNKS = TILE_QUERIES / ITER_THREADS;
-  for (uint32_t w = blockIdx.x; w < nt * CHUNKS; w += gridDim.x) {
-    const uint2 tile = tiles[a.todo_tiles[w / CHUNKS]];
-    const uint32_t i = tile.x + (w % CHUNKS) * ITER_THREADS + threadIdx.x;
-    if (i < tile.y) {
-      const float4 s4 = a.src[i];
-      float qx, qy, qz;
-      transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-      NN best;
-      nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
-      a.nn_pos[i] = best.pos;
-      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+  const float iL[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, it[3] = {0.f, 0.f, 0.f};   // first Gauss-Newton step
+  const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]}, dmean[3] = {a.dst_mean[0], a.dst_mean[1], a.dst_mean[2]};
+  double accA[TR::NA];
+  double accB[TR::NB > 0 ? TR::NB : 1];
+#pragma unroll
+  for (int i = 0; i < TR::NA; ++i) accA[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < (TR::NB > 0 ? TR::NB : 1); ++i) accB[i] = 0.0;
+
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  const uint32_t W = ntiles * (2 * TILE_WAVES), nchunks = (W + 63u) >> 6;
+  auto finish = [&](uint32_t i, float qx, float qy, float qz, const NN& best) {
+    a.nn_pos[i] = best.pos;
+    if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    if (ACC != IM_NONE && best.pos != NONE_U32) {
+      const float4 p = a.grid.pts[best.pos];
+      float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (TR::plane) nv = a.grid.nrm[best.pos];
+      accumulate_pair<ACC>(accA, accB, T, iL, it, smt, dmean, false, true, qx, qy, qz, best.pos, p, nv, nv);
+    }
+  };
+  for (uint32_t chunk = blockIdx.x * ITER_WAVES + wave; chunk < nchunks; chunk += gridDim.x * ITER_WAVES) {
+    const uint32_t widx = chunk * 64u + (uint32_t)lane;
+    const unsigned long long mw = widx < W ? a.defer_mask[widx] : 0ull;
+    unsigned long long nz = __ballot(mw != 0ull);
+    while (nz) {
+      const int sl = __ffsll((long long)nz) - 1;
+      nz &= nz - 1;
+      unsigned long long word = __shfl(mw, sl, 64);                 // wave-uniform
+      const uint32_t wi = chunk * 64u + (uint32_t)sl;
+      const uint2 tile = tiles[wi / (2 * TILE_WAVES)];
+      const uint32_t i0 = tile.x + ((wi / TILE_WAVES) & 1u) * TILE_THREADS + (wi % TILE_WAVES) * 64u;
+      if (__popcll(word) >= 24) {
+        // dense (a whole deferred tile, or a tile far from its sort-time cells): one lane per query
+        const uint32_t i = i0 + (uint32_t)lane;
+        if (((word >> lane) & 1ull) && i < tile.y) {
+          const float4 s4 = a.src[i];
+          float qx, qy, qz;
+          transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+          NN best;
+          nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
+          finish(i, qx, qy, qz, best);
+        }
+      } else {
+        // sparse: 8 queries per trip, TODO_GROUP lanes each
+        const int grp = lane / TODO_GROUP, sub = lane % TODO_GROUP;
+        while (word) {
+          unsigned long long t = word;
+          for (int k = 0; k < grp; ++k) t &= t - 1;                   // the grp-th set bit
+          const uint32_t i = i0 + (uint32_t)(t ? __ffsll((long long)t) - 1 : 0);
+          if (t != 0ull && i < tile.y) {                              // (uniform within a group)
+            const float4 s4 = a.src[i];
+            float qx, qy, qz;
+            transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+            NN best;
+            nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
+            if (sub == 0) finish(i, qx, qy, qz, best);
+          }
+          for (int k = 0; k < 64 / TODO_GROUP; ++k) word &= word - 1;  // drop the 8 lowest set bits
+        }
+      }
     }
   }
-  // (b) individual stragglers: TODO_GROUP lanes per query (bit 31 of an entry: the 3x3x3 block was already searched)
-  const int sub = threadIdx.x & (TODO_GROUP - 1);
-  for (uint32_t t = (blockIdx.x * ITER_THREADS + threadIdx.x) / TODO_GROUP; t < n; t += gridDim.x * (ITER_THREADS / TODO_GROUP)) {
-    const uint32_t e = a.todo[t];
-    const uint32_t i = e & 0x7FFFFFFFu;
-    const float4 s4 = a.src[i];
-    float qx, qy, qz;
-    transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-    NN best;
-    nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, (e >> 31) ? 2 : 1, best);
-    if (sub == 0) {
-      a.nn_pos[i] = best.pos;
-      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+  if (ACC != IM_NONE) {
+    __shared__ double sh[ITER_WAVES][SUMS_MAX];
+    if (threadIdx.x < SUMS_MAX) {
+#pragma unroll
+      for (int w = 0; w < ITER_WAVES; ++w) sh[w][threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TR::NA; ++k) {
+      const double v = wave_sum(accA[k]);
+      if (lane == 0) sh[wave][k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < TR::NB; ++k) {
+      const double v = wave_sum(accB[k]);
+      if (lane == 0) sh[wave][28 + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < SUMS_MAX) {
+      double v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+      // this block's share of the tiles' partial rows, in ascending tile order
+      const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+      const uint32_t t0 = min(blockIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
+      for (uint32_t t = t0; t < t1; ++t) v += a.tile_partials[(size_t)t * SUMS_MAX + threadIdx.x];
+      a.partials[(size_t)blockIdx.x * SUMS_MAX + threadIdx.x] = v;
     }
   }
 }
 
-void launch_search_tiled(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s) {
-  if (ntiles == 0) return;
-  (void)hipMemsetAsync(a.todo_count, 0, 2 * sizeof(uint32_t), s);
+// rows of partial sums the tiled path with in-tile accumulation leaves in a.partials (= blocks of its clean-up pass)
+int tiled_partial_rows(uint32_t ntiles) {
+  const uint32_t nchunks = (ntiles * (2u * TILE_WAVES) + 63u) >> 6;
+  uint32_t nb = (nchunks + ITER_WAVES - 1) / ITER_WAVES;
+  if (nb > 1024u) nb = 1024u;
+  if (nb < 1u) nb = 1u;
+  return (int)nb;
+}
+
+template <int ACC>
+static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const int* tile_box, uint32_t ntiles, hipStream_t s) {
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
+  hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
+  hipLaunchKernelGGL((k_search_deferred<ACC>), dim3(tiled_partial_rows(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
+}
+
+// acc_metric: IM_NONE = search only (matches stored); IM_KABSCH / IM_PLANE / IM_POINT / IM_BOTH = search + accumulation of
+// the first Gauss-Newton step's sums in one pass (a.partials[0 .. tiled_partial_rows) rows afterwards).
+void launch_search_tiled(const IterArgs& a, int acc_metric, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s) {
+  if (ntiles == 0) return;
   hipLaunchKernelGGL(k_tile_boxes, dim3((ntiles + 255) / 256), dim3(256), 0, s, a, tile_center, ntiles, tile_box);
-  hipLaunchKernelGGL(k_search_tiled, dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, (const int*)tile_box, ntiles);
-  const uint32_t nb2 = (uint32_t)(((a.ns + ITER_THREADS - 1) / ITER_THREADS) < 2048 ? ((a.ns + ITER_THREADS - 1) / ITER_THREADS) : 2048);
-  hipLaunchKernelGGL(k_search_todo, dim3(nb2 ? nb2 : 1), dim3(ITER_THREADS), 0, s, a, tiles);
+  switch (acc_metric) {
+    case IM_KABSCH: launch_search_tiled_m<IM_KABSCH>(a, tiles, tile_box, ntiles, s); break;
+    case IM_PLANE: launch_search_tiled_m<IM_PLANE>(a, tiles, tile_box, ntiles, s); break;
+    case IM_POINT: launch_search_tiled_m<IM_POINT>(a, tiles, tile_box, ntiles, s); break;
+    case IM_BOTH: launch_search_tiled_m<IM_BOTH>(a, tiles, tile_box, ntiles, s); break;
+    default: launch_search_tiled_m<IM_NONE>(a, tiles, tile_box, ntiles, s); break;
+  }
+}
+
+// deferred queries / wholly deferred tiles of the last tiled search (introspection: tests, dev tools)
+__global__ void k_count_deferred(const unsigned long long* __restrict__ mask, uint32_t ntiles, uint32_t* out) {
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+    uint32_t bits = 0;
+    bool all = true;
+    for (int k = 0; k < 2 * TILE_WAVES; ++k) { const unsigned long long w = mask[(size_t)t * (2 * TILE_WAVES) + k]; bits += (uint32_t)__popcll(w); all &= (w == ~0ull); }
+    if (all) atomicAdd(out + 1, 1u); else if (bits) atomicAdd(out, bits);
+  }
+}
+void launch_count_deferred(const unsigned long long* mask, uint32_t ntiles, uint32_t* out2, hipStream_t s) {
+  (void)hipMemsetAsync(out2, 0, 2 * sizeof(uint32_t), s);
+  if (ntiles) hipLaunchKernelGGL(k_count_deferred, dim3((ntiles + 255) / 256), dim3(256), 0, s, mask, ntiles, out2);
 }
 
 // Correspondence search over 6-D point+normal features (SECOND_TO_FIRST): FEAT6_GROUP lane(s) per query, the generic exact
@@ -1135,23 +1575,6 @@ void launch_search_feat6(const IterArgs& a, hipStream_t s) {
   const uint64_t lanes = (uint64_t)a.ns * FEAT6_GROUP;
   hipLaunchKernelGGL(k_search_feat6, dim3((unsigned)((lanes + ITER_THREADS - 1) / ITER_THREADS)), dim3(ITER_THREADS), 0, s, a);
 }
-
-// ---- accumulation helpers ------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-template <int METRIC>
-struct AccTraits {
-  static constexpr bool plane = (METRIC == IM_PLANE || METRIC == IM_BOTH);
-  static constexpr bool point = (METRIC == IM_POINT || METRIC == IM_BOTH);
-  static constexpr bool kabsch = (METRIC == IM_KABSCH);
-  static constexpr bool affine = (METRIC == IM_AFF0 || METRIC == IM_AFF1 || METRIC == IM_AFF2);
-  static constexpr int NA = affine ? (METRIC == IM_AFF0 ? 34 : 30) : kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
-  static constexpr int NB = point ? 15 : 0;                  // slots [28, 28+NB)
-};
 
 // The fused iteration kernel.  METRIC: what to accumulate; SEARCH: run the grid search (else reuse the
 // stored matches: Gauss-Newton steps >= 1); STORE: keep (pos,d2) per query for later steps / the host.
@@ -1200,122 +1623,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
 
   // the accumulation of one matched pair (q = T*s already formed); shared by the loops below
   auto accumulate = [&](float qx, float qy, float qz, uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
-  if (METRIC != IM_NONE && pos != NONE_U32) {
-    if (TR::kabsch) {
-      // raw moments for the closed-form estimator (transform_estimation.hpp:25-34)
-      const double pd[3] = {(double)p.x, (double)p.y, (double)p.z};
-      const double qd[3] = {(double)qx, (double)qy, (double)qz};
-      accA[0] += 1.0;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { accA[1 + c] += pd[c]; accA[4 + c] += qd[c]; }
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) accA[7 + r * 3 + c] = fma(pd[r], qd[c], accA[7 + r * 3 + c]);
-    } else if (TR::affine) {
-      // Affine closed form (transform_estimation.hpp:369-476; :50-102 for the point-to-point class): per-term
-      // quantities in f32 as the reference forms them -- s = q - src_mean', d = p - dst_mean -- their products and
-      // sums in f64.  eq_vec = (n_0 s, n_1 s, n_2 s, n): every entry of eq_vec eq_vec^T is n_j n_k (s,1)_a (s,1)_b.
-      const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
-      const float s0 = __fsub_rn(qx, smt[0]), s1 = __fsub_rn(qy, smt[1]), s2 = __fsub_rn(qz, smt[2]);
-      const double sd[4] = {(double)s0, (double)s1, (double)s2, 1.0};
-      if (METRIC == IM_AFF0) {
-        const double dd[3] = {(double)d0, (double)d1, (double)d2};
-        accA[0] += 1.0;
-        int k = 1;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = r; c < 3; ++c) { accA[k] = fma(sd[r], sd[c], accA[k]); ++k; }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) accA[7 + c] += sd[c];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) accA[10 + r * 3 + c] = fma(sd[r], dd[c], accA[10 + r * 3 + c]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) accA[19 + c] += dd[c];
-        if (a.grid.nrm) {
-          // n.dot(dst - dst_mean)  (:464), f32 like the reference's dot product
-          const float res = __fadd_rn(__fadd_rn(__fmul_rn(nvp.x, d0), __fmul_rn(nvp.y, d1)), __fmul_rn(nvp.z, d2));
-          const double nd[3] = {(double)nvp.x, (double)nvp.y, (double)nvp.z};
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const double rn = (double)res * nd[j];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) accA[22 + j * 4 + c] = fma(rn, sd[c], accA[22 + j * 4 + c]);
-          }
-        }
-      } else {
-        const double nd[3] = {(double)nvp.x, (double)nvp.y, (double)nvp.z};
-        int k = 0;
-#pragma unroll
-        for (int jk = 0; jk < 3; ++jk) {
-          // (j,k): AFF1 -> (0,0),(0,1),(0,2); AFF2 -> (1,1),(1,2),(2,2)
-          const int j = (METRIC == IM_AFF1) ? 0 : (jk == 2 ? 2 : 1);
-          const int kk = (METRIC == IM_AFF1) ? jk : (jk == 0 ? 1 : 2);
-          const double nn = nd[j] * nd[kk];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = r; c < 4; ++c) { accA[k] = fma(nn * sd[r], sd[c], accA[k]); ++k; }
-        }
-      }
-    } else {
-      // per-term quantities in f32 exactly as the reference forms them (transform_estimation.hpp:302-304,:333-335)
-      const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
-      const float u0 = __fsub_rn(qx, smt[0]), u1 = __fsub_rn(qy, smt[1]), u2 = __fsub_rn(qz, smt[2]);
-      // s = inner_tform * (q - T*src_mean); identity on the first Gauss-Newton step
-      const float s0 = __fadd_rn(__fadd_rn(__fmul_rn(iL[0], u0), __fadd_rn(__fmul_rn(iL[1], u1), __fmul_rn(iL[2], u2))), it[0]);
-      const float s1 = __fadd_rn(__fadd_rn(__fmul_rn(iL[3], u0), __fadd_rn(__fmul_rn(iL[4], u1), __fmul_rn(iL[5], u2))), it[1]);
-      const float s2 = __fadd_rn(__fadd_rn(__fmul_rn(iL[6], u0), __fadd_rn(__fmul_rn(iL[7], u1), __fmul_rn(iL[8], u2))), it[2]);
-      const float a0 = __fadd_rn(d0, s0), a1 = __fadd_rn(d1, s1), a2 = __fadd_rn(d2, s2);
-      const float r0 = __fsub_rn(d0, s0), r1 = __fsub_rn(d1, s1), r2 = __fsub_rn(d2, s2);
-      accA[0] += 1.0;
-      if (TR::plane) {
-        float4 nv = nvp;
-        if (a.src_nrm) {
-          // symmetric metric (transform_estimation.hpp:705-706): n = n_dst + tform.linear() * n_src', with
-          // n_src' = transform_.linear() * n_src (transformNormals, core/space_transformations.hpp:374-390)
-          const float4 sn = snp;
-          const float t0 = __fadd_rn(__fmul_rn(T[0], sn.x), __fadd_rn(__fmul_rn(T[4], sn.y), __fmul_rn(T[8], sn.z)));
-          const float t1 = __fadd_rn(__fmul_rn(T[1], sn.x), __fadd_rn(__fmul_rn(T[5], sn.y), __fmul_rn(T[9], sn.z)));
-          const float t2 = __fadd_rn(__fmul_rn(T[2], sn.x), __fadd_rn(__fmul_rn(T[6], sn.y), __fmul_rn(T[10], sn.z)));
-          nv.x = __fadd_rn(nv.x, __fadd_rn(__fmul_rn(iL[0], t0), __fadd_rn(__fmul_rn(iL[1], t1), __fmul_rn(iL[2], t2))));
-          nv.y = __fadd_rn(nv.y, __fadd_rn(__fmul_rn(iL[3], t0), __fadd_rn(__fmul_rn(iL[4], t1), __fmul_rn(iL[5], t2))));
-          nv.z = __fadd_rn(nv.z, __fadd_rn(__fmul_rn(iL[6], t0), __fadd_rn(__fmul_rn(iL[7], t1), __fmul_rn(iL[8], t2))));
-        }
-        float e[6];
-        e[0] = __fsub_rn(__fmul_rn(a1, nv.z), __fmul_rn(a2, nv.y));   // (d+s).cross(n)  :337
-        e[1] = __fsub_rn(__fmul_rn(a2, nv.x), __fmul_rn(a0, nv.z));
-        e[2] = __fsub_rn(__fmul_rn(a0, nv.y), __fmul_rn(a1, nv.x));
-        e[3] = nv.x; e[4] = nv.y; e[5] = nv.z;
-        const float res = __fadd_rn(__fmul_rn(nv.x, r0), __fadd_rn(__fmul_rn(nv.y, r1), __fmul_rn(nv.z, r2)));  // n.dot(d-s)
-        double ed[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ed[k] = (double)e[k];
-        int k = 1;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = r; c < 6; ++c) { accA[k] = fma(ed[r], ed[c], accA[k]); ++k; }
-        const double rd = (double)res;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) accA[22 + r] = fma(rd, ed[r], accA[22 + r]);
-      }
-      if (TR::point) {
-        const double ad[3] = {(double)a0, (double)a1, (double)a2};
-        const double rd[3] = {(double)r0, (double)r1, (double)r2};
-        accB[0] += ad[0]; accB[1] += ad[1]; accB[2] += ad[2];
-        accB[3] = fma(ad[0], ad[0], accB[3]); accB[4] = fma(ad[0], ad[1], accB[4]); accB[5] = fma(ad[0], ad[2], accB[5]);
-        accB[6] = fma(ad[1], ad[1], accB[6]); accB[7] = fma(ad[1], ad[2], accB[7]); accB[8] = fma(ad[2], ad[2], accB[8]);
-        accB[9] += ad[1] * rd[2] - ad[2] * rd[1];
-        accB[10] += ad[2] * rd[0] - ad[0] * rd[2];
-        accB[11] += ad[0] * rd[1] - ad[1] * rd[0];
-        accB[12] += rd[0]; accB[13] += rd[1]; accB[14] += rd[2];
-      }
-    }
-  }
+    accumulate_pair<METRIC>(accA, accB, T, iL, it, smt, dmean, a.src_nrm != nullptr, a.grid.nrm != nullptr, qx, qy, qz, pos, p, nvp, snp);
   };
 
   if (!SEARCH) {
