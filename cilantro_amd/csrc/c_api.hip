@@ -46,7 +46,7 @@ struct cilhip_ctx {
   int* d_tile_box = nullptr;        // [8*ntiles] cell range of each tile's cube under the current transform (recomputed per search)
   float tile_axes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long* d_defer_mask = nullptr;  // [ntiles * 32] queries the tiles hand to the clean-up pass (bit masks, rewritten by every search)
-  double* d_tile_partials = nullptr;           // [ntiles * SUMS_MAX] per-tile partial sums of the in-tile accumulation
+  uint32_t* d_defer_flag = nullptr;            // [1] "some tile deferred a query" (reset before, set by, every tiled search)
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint32_t ntiles = 0;
   int tiled = 1;                  // 0: per-lane global-memory search; 1: LDS-tiled search when the cloud is large enough; 2: always tiled
@@ -136,6 +136,7 @@ int cilhip_create(cilhip_ctx** out, int device) {
   }
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&c->d_defer_flag, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_defer_flag, 0, sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&c->d_stage, REDUCE_STAGE_DOUBLES * sizeof(double)) != hipSuccess || hipMalloc(&c->d_sums, 3 * SUMS_MAX * sizeof(double)) != hipSuccess) {
     delete c;
     return CILHIP_ERR_HIP;
@@ -162,8 +163,7 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_defer_mask) (void)hipFree(c->d_defer_mask);
   if (c->d_keys) (void)hipFree(c->d_keys);
   c->d_keys = nullptr;
-  if (c->d_tile_partials) (void)hipFree(c->d_tile_partials);
-  c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_defer_mask = nullptr; c->d_tile_partials = nullptr;
+  c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_defer_mask = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
@@ -185,6 +185,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_winner) (void)hipFree(c->d_winner);
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
+  if (c->d_defer_flag) (void)hipFree(c->d_defer_flag);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_sums) (void)hipFree(c->d_sums);
   for (auto e : c->ev) (void)hipEventDestroy(e);
@@ -374,13 +375,11 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     if (c->d_tile_center) { (void)hipFree(c->d_tile_center); c->d_tile_center = nullptr; }
     if (c->d_tile_box) { (void)hipFree(c->d_tile_box); c->d_tile_box = nullptr; }
     if (c->d_defer_mask) { (void)hipFree(c->d_defer_mask); c->d_defer_mask = nullptr; }
-    if (c->d_tile_partials) { (void)hipFree(c->d_tile_partials); c->d_tile_partials = nullptr; }
     hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->d_tile_center, c->tile_axes, &c->ntiles);
     if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
     CK(c, hipMalloc(&c->d_defer_mask, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long)));
     CK(c, hipMemsetAsync(c->d_defer_mask, 0, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long), c->stream));
-    CK(c, hipMalloc(&c->d_tile_partials, ((size_t)c->ntiles + 1) * SUMS_MAX * sizeof(double)));
-    {   // the clean-up pass of the tiled search leaves one row of partial sums per block
+    {   // the tiled search with in-tile accumulation leaves one row of partial sums per tile and per block of its clean-up pass
       const int rows = std::max(iter_num_blocks(c->ns), tiled_partial_rows(c->ntiles));
       if (rows > c->partial_blocks) {
         if (c->d_partials) (void)hipFree(c->d_partials);
@@ -472,7 +471,8 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.nn_d2 = c->d_nn_d2;
   a.partials = c->d_partials;
   a.defer_mask = c->d_defer_mask;
-  a.tile_partials = c->d_tile_partials;
+  a.tile_partials = c->d_partials;            // (in-tile accumulation: tile rows first, then the clean-up pass's rows)
+  a.defer_flag = c->d_defer_flag;
   a.store_matches = 1;
   a.skip_if_inner_done = 0;
   return a;
@@ -988,6 +988,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           // stored when further Gauss-Newton steps will stream over them)
           IterArgs fa = a;
           fa.store_matches = opt_steps > 1 ? 1 : 0;
+          fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
           launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         } else if (st == 0) {
           { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
@@ -1085,8 +1086,10 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
       const size_t e = 2 + c->run_nev;
       if (timing) CK(c, hipEventRecord(get_event(c, e), c->stream));
       if (tile_accumulation(c)) {
-        a.store_matches = 0;
-        launch_search_tiled(a, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+        IterArgs fa = a;
+        fa.store_matches = 0;
+        fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
+        launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
         prows = tiled_partial_rows(c->ntiles);
       } else {

@@ -86,7 +86,8 @@ struct IterArgs {
   float* nn_d2;            // [ns], or null: the squared distances are not stored (the ICP loop without post-filters never reads them)
   double* partials;        // [nblocks * SUMS_MAX]
   unsigned long long* defer_mask;  // [ntiles * 2 * (TILE_THREADS / 64)] tiled search: queries handed to its clean-up pass, one word per wave and query slot
-  double* tile_partials;   // [ntiles * SUMS_MAX] tiled search with in-tile accumulation: one row of partial sums per tile
+  double* tile_partials;   // [ntiles * SUMS_MAX] tiled search with in-tile accumulation: one row of partial sums per tile (followed by the clean-up pass's rows)
+  uint32_t* defer_flag;    // [1] set by a tile that defers a query: the clean-up pass has work
   int store_matches;       // tiled search: also write nn_pos / nn_d2 for the queries settled inside the tile (the pure ICP loop needs neither)
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
@@ -122,7 +123,7 @@ void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_s
 #endif
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
-constexpr int REDUCE_STAGE_DOUBLES = 32 * SUMS_MAX;
+constexpr int REDUCE_STAGE_DOUBLES = 128 * SUMS_MAX;
 void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s);
 void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
                        const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,

@@ -718,15 +718,20 @@ struct OctQuery {
 // real target points or the far-away pad records -- never wrong), no per-lane loop or branch, so the wave
 // executes each instruction once with all lanes busy.  The winner is tracked as a small constant (run, slot)
 // code and turned into an LDS index once.
-__device__ __forceinline__ void octant_prepare(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                               int lox, int loy, int loz, int RY, int W1, OctQuery& o) {
+// Returns whether the block lies inside the staged region [lo, hi] (cells, inclusive) -- all the fast path needs.  The
+// block of the other queries is clamped into the region so that the code below stays branch-free; their result is dropped.
+__device__ __forceinline__ bool octant_prepare(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                               int lox, int loy, int loz, int hix, int hiy, int hiz, int RY, int W1, OctQuery& o) {
   o.qx = qx; o.qy = qy; o.qz = qz;
   // offsets of q inside its cell; q leans to the low side of an axis when the offset is below half a cell
   const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
   const float half = 0.5f * g.cell;
-  const int ox = (ux >= half) ? 0 : -1, oy = (uy >= half) ? 0 : -1, oz = (uz >= half) ? 0 : -1;
-  const int row00 = (cz + oz - loz) * RY + (cy + oy - loy);
-  o.ebrow = (row00 * W1 + (cx + ox - lox)) | (row00 << 16);
+  const int bx = cx + ((ux >= half) ? 0 : -1), by = cy + ((uy >= half) ? 0 : -1), bz = cz + ((uz >= half) ? 0 : -1);   // low corner of the block
+  const bool inside = (bx >= lox) & (bx < hix) & (by >= loy) & (by < hiy) & (bz >= loz) & (bz < hiz);
+  const int kx = min(max(bx, lox), hix - 1), ky = min(max(by, loy), hiy - 1), kz = min(max(bz, loz), hiz - 1);
+  const int row00 = (kz - loz) * RY + (ky - loy);
+  o.ebrow = (row00 * W1 + (kx - lox)) | (row00 << 16);
+  return inside;
 }
 
 // distance from q to the nearest face of its octant block: along an axis the two-cell span's nearest face is at
@@ -908,7 +913,8 @@ void debug_dump_phase_clocks() {
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof h) != hipSuccess) return;
   unsigned long long tot = 0;
   for (int k = 0; k < 8; ++k) tot += h[k];
-  fprintf(stderr, "[phase clocks, 100 MHz ticks summed over blocks] queries+extents=%llu scan=%llu stage=%llu search=%llu total=%llu\n", h[0], h[1], h[2], h[3], tot);
+  fprintf(stderr, "[phase clocks, 100 MHz ticks summed over blocks, thread 0] table=%llu scan+prep=%llu stage=%llu search(+3b, masks)=%llu tail loads+z=%llu mfma+D=%llu row=%llu total=%llu\n",
+          h[0], h[1], h[2], h[3], h[4], h[5], h[6], tot);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), h, sizeof h);
 }
@@ -925,6 +931,7 @@ __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center,
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *a.defer_flag = 0u;       // (the tiles of the search that follows set it when they defer a query)
   if (t >= ntiles) return;
   const GridDev& g = a.grid;
   float T[16];
@@ -943,20 +950,32 @@ __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center,
     ext[i] = e;
   }
   const float SHR = 1.0e-3f, BIG = 1.0e9f;   // the cube is half-open: shrink by 1e-3 cell so that an unmoved cube maps to itself
-  int bx0 = (int)floorf(fminf(fmaxf((ccx - ext[0] - g.ox) * g.inv_cell + SHR, -BIG), BIG));
-  int bx1 = (int)floorf(fminf(fmaxf((ccx + ext[0] - g.ox) * g.inv_cell - SHR, -BIG), BIG));
-  int by0 = (int)floorf(fminf(fmaxf((ccy - ext[1] - g.oy) * g.inv_cell + SHR, -BIG), BIG));
-  int by1 = (int)floorf(fminf(fmaxf((ccy + ext[1] - g.oy) * g.inv_cell - SHR, -BIG), BIG));
-  int bz0 = (int)floorf(fminf(fmaxf((ccz - ext[2] - g.oz) * g.inv_cell + SHR, -BIG), BIG));
-  int bz1 = (int)floorf(fminf(fmaxf((ccz + ext[2] - g.oz) * g.inv_cell - SHR, -BIG), BIG));
-  // a box that reaches the first / last layer of data cells also takes the empty layer next to it: the queries the
-  // current transform (or noise) pushed just outside the data's bounding box stay on the fast path
-  if (bx0 <= GRID_PAD) bx0 = min(bx0, GRID_PAD - 1);
-  if (by0 <= GRID_PAD) by0 = min(by0, GRID_PAD - 1);
-  if (bz0 <= GRID_PAD) bz0 = min(bz0, GRID_PAD - 1);
-  if (bx1 >= g.nx - 1 - GRID_PAD) bx1 = max(bx1, g.nx - GRID_PAD);
-  if (by1 >= g.ny - 1 - GRID_PAD) by1 = max(by1, g.ny - GRID_PAD);
-  if (bz1 >= g.nz - 1 - GRID_PAD) bz1 = max(bz1, g.nz - GRID_PAD);
+  // Per axis: the cells [b0, b1] the image covers, and the REGION the tile stages = those cells plus a halo cell on a
+  // side only where a query can lean that way: the octant block of a query is the 2 cells on the side of its own cell it
+  // leans to, so the low halo is needed only if the first cell can hold a query in its lower half (the image starts
+  // below the cell's middle), the high halo only if the last cell can hold one in its upper half.  A cube of 12 cells
+  // shifted by a fraction of a cell covers 13 cells and needs ONE of the two halos: 14 cells per axis instead of 15 --
+  // a fifth fewer points to stage, and regions that stay inside the LDS budget.  (Only a matter of speed: the search
+  // kernel tests every query's block against the region and hands what does not fit to the clean-up pass.)
+  const float HALF_SLACK = 0.01f;
+  int lo[3], hi[3];
+  const float cc3[3] = {ccx, ccy, ccz}, o3[3] = {g.ox, g.oy, g.oz};
+  const int n3[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a0 = fminf(fmaxf((cc3[i] - ext[i] - o3[i]) * g.inv_cell + SHR, -BIG), BIG);
+    const float a1 = fminf(fmaxf((cc3[i] + ext[i] - o3[i]) * g.inv_cell - SHR, -BIG), BIG);
+    int b0 = (int)floorf(a0), b1 = (int)floorf(a1);
+    bool halo0 = (a0 - (float)b0) < 0.5f + HALF_SLACK, halo1 = (a1 - (float)b1) > 0.5f - HALF_SLACK;
+    // a box that reaches the first / last layer of data cells also takes the empty layer next to it: the queries the
+    // current transform (or noise) pushed just outside the data's bounding box stay on the fast path
+    if (b0 <= GRID_PAD) { b0 = min(b0, GRID_PAD - 1); halo0 = true; }
+    if (b1 >= n3[i] - 1 - GRID_PAD) { b1 = max(b1, n3[i] - GRID_PAD); halo1 = true; }
+    // (stored as the region shrunk by one cell on both sides, the form the search kernel grows back and clips)
+    lo[i] = b0 - (halo0 ? 1 : 0) + 1;
+    hi[i] = b1 + (halo1 ? 1 : 0) - 1;
+  }
+  const int bx0 = lo[0], bx1 = hi[0], by0 = lo[1], by1 = hi[1], bz0 = lo[2], bz1 = hi[2];
   // reciprocals for the flat cell-table fill of the search kernel (division by a run-time width there would be ~20
   // emulated instructions per wave): e / W1 == (e * inv_w1) >> 20 for e < 2^20 / W1, r / RY == (r * inv_ry) >> 16 for r < 3855
   const int W1 = (min(bx1 + 1, g.nx - 1) - max(bx0 - 1, 0) + 1) + 1, RY = min(by1 + 1, g.ny - 1) - max(by0 - 1, 0) + 1;
@@ -973,6 +992,7 @@ __device__ __forceinline__ void defer_whole_tile(const IterArgs& a, uint32_t vb)
   if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
     for (int u = 0; u < TILE_QPT; ++u) a.defer_mask[(size_t)vb * (2 * TILE_WAVES) + u * TILE_WAVES + (threadIdx.x >> 6)] = ~0ull;
+    if (threadIdx.x == 0) atomicOr(a.defer_flag, 1u);
   }
   if (ACC != IM_NONE && threadIdx.x < SUMS_MAX) a.tile_partials[(size_t)vb * SUMS_MAX + threadIdx.x] = 0.0;
 }
@@ -1114,10 +1134,10 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     const int cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG));
     const int cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
     const bool active = i < tile.y;
-    const bool fast = active & (cx >= fx0) & (cx <= fx1) & (cy >= fy0) & (cy <= fy1) & (cz >= fz0) & (cz <= fz1);
+    // fast path: the query's octant block is staged (the region holds a halo cell only on the sides some query of the
+    // tile can lean to, k_tile_boxes: every query is checked against what was actually staged)
+    const bool fast = active & octant_prepare(g, qx, qy, qz, cx, cy, cz, lox, loy, loz, hix, hiy, hiz, RY, W1, oq[u]);
     flags |= (active ? (1u << u) : 0u) | (fast ? (1u << (8 + u)) : 0u);
-    // (the other lanes run on the nearest fast cell so that the code below stays branch-free; their result is dropped)
-    octant_prepare(g, qx, qy, qz, min(max(cx, fx0), fx1), min(max(cy, fy0), fy1), min(max(cz, fz0), fz1), lox, loy, loz, RY, W1, oq[u]);
   }
   __syncthreads();
   PHASE_CLK(1);
@@ -1211,7 +1231,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
       }
     }
-    const unsigned long long m = __ballot(unproven);
+    if (ACC != IM_NONE && unproven) { defer = true; unproven = false; }   // (accumulating form: no second pass in the tile, see 3b)
+    const unsigned long long m = (ACC == IM_NONE) ? __ballot(unproven) : 0ull;
     if (m) {   // one LDS atomic per wave
       const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)m) - 1;
       uint32_t base = 0;
@@ -1224,10 +1245,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       if (unproven) {
         if (slot < queue_cap) {
           queue[slot] = (uint16_t)(u * TILE_THREADS + threadIdx.x);
-        } else {   // no room (a tile near the LDS budget with many unproven queries): the clean-up pass takes it
-          defer = true;
-          unproven = false;
-        }
+        }          // (no room: not written; the tile then defers all its unproven queries, see below)
       }
     }
     if (active && !unproven && !defer && a.store_matches) {
@@ -1237,18 +1255,51 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     mpos[u] = (unproven | defer) ? NONE_U32 : best.pos;
     flags |= (unproven ? (1u << (16 + u)) : 0u) | (defer ? (1u << (24 + u)) : 0u);
   }
+  // (ACC) What the accumulation needs for the queries settled above is requested NOW, before the barrier: the query again
+  // (not kept in registers through the search), the matched point and its normal -- the loads fly while the slower waves
+  // of the tile finish their searches (a barrier does not wait for outstanding loads).
+  float4 s4t[TILE_QPT], p4t[TILE_QPT], n4t[TILE_QPT];
+  auto request_pairs = [&]() {
+#pragma unroll
+    for (int u = 0; u < TILE_QPT; ++u) {
+      uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+      asm volatile("" : "+v"(i));       // (a fresh load: do not keep the kernel-start copy of the query alive through the search)
+      s4t[u] = p4t[u] = n4t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mpos[u] != NONE_U32) {
+        s4t[u] = a.src[i];
+        p4t[u] = g.pts[mpos[u]];
+        if (FusedZ<ACC>::needs_normal) n4t[u] = g.nrm[mpos[u]];
+      }
+    }
+  };
+  if (ACC != IM_NONE) request_pairs();
   __syncthreads();
-  // 3b: the queued queries, densely packed over the lanes: the full 3x3x3 block in straight-line code.  The query is
-  // fetched and transformed again.  Results go through nn_pos (DEFER_MARK: not proven either): the query's home lane
-  // picks them up below, so that whatever is accumulated per query is accumulated by the same lane in every run.
-  const uint32_t nqueued = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count);   // block-uniform
-  if (nqueued != 0) {
+  // 3b (search-only form): the queued queries, densely packed over the lanes: the full 3x3x3 block in straight-line code.
+  // The query is fetched and transformed again.  Results go through nn_pos (DEFER_MARK: not proven either) and the
+  // query's home lane picks them up below.  The ACCUMULATING form has no 3b: what the octant block does not prove goes to
+  // the clean-up pass, which accumulates what it settles -- in a converged registration that is nothing, and the
+  // register-hungry 3x3x3 pass between the search and the accumulation would cost every tile its in-flight pair loads
+  // (the allocator spills them around it); a source far from its sort-time cells is what the re-sort is for.
+  uint32_t nqueued = (ACC == IM_NONE) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count) : 0u;   // block-uniform
+  if (ACC == IM_NONE) {
+    // A queue that cannot hold every unproven query of the tile (a region near the LDS budget AND a source far from its
+    // sort-time cells): WHICH queries found room depends on the order the waves arrived in, so none of them is taken --
+    // all unproven queries of the tile go to the clean-up pass (the set is then the same in every run).
+    const uint32_t Pq0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[rows]);
+    if (nqueued > min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq0) * 8u)) {
+#pragma unroll
+      for (int u = 0; u < TILE_QPT; ++u) if ((flags >> (16 + u)) & 1u) flags = (flags & ~(1u << (16 + u))) | (1u << (24 + u));
+      nqueued = 0;
+    }
+  }
+  if (ACC == IM_NONE && nqueued != 0) {
     TileLds tq{lpts, lcs, rowbase, rowdelta, __builtin_amdgcn_readfirstlane(geom_lds[0]), __builtin_amdgcn_readfirstlane(geom_lds[1]),
                __builtin_amdgcn_readfirstlane(geom_lds[2]), __builtin_amdgcn_readfirstlane(geom_lds[3]),
                __builtin_amdgcn_readfirstlane(geom_lds[4]), __builtin_amdgcn_readfirstlane(geom_lds[5])};
     const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[tq.rows]);
     const uint16_t* const queue = reinterpret_cast<const uint16_t*>(lpts + Pq + 8);
     const uint32_t nq = min(nqueued, min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 8u));
+    const int hx27 = tq.lox + tq.W1 - 2, hy27 = tq.loy + tq.RY - 1, hz27 = tq.loz + tq.rows / tq.RY - 1;   // last staged cell per axis
     if (threadIdx.x < nq) {   // wave-uniform except in the last wave
       float Tq[16];        // from LDS rather than kept live across the kernel
 #pragma unroll
@@ -1260,7 +1311,9 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         transform_point(Tq, sq.x, sq.y, sq.z, qx, qy, qz);
         const int cx = (int)floorf((qx - g.ox) * g.inv_cell), cy = (int)floorf((qy - g.oy) * g.inv_cell), cz = (int)floorf((qz - g.oz) * g.inv_cell);
         NN best;
-        const bool proven = block27_search(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best);
+        // (the region holds the octant blocks of the tile's queries, not necessarily all of this query's 3x3x3 block)
+        const bool in27 = (cx - 1 >= tq.lox) & (cx + 1 <= hx27) & (cy - 1 >= tq.loy) & (cy + 1 <= hy27) & (cz - 1 >= tq.loz) & (cz + 1 <= hz27);
+        const bool proven = in27 && block27_search(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best);
         a.nn_pos[i] = proven ? best.pos : DEFER_MARK;
         if (proven && a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
       }
@@ -1274,54 +1327,42 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     bool defer = (flags >> (24 + u)) & 1u;
     if (nqueued != 0 && ((flags >> (16 + u)) & 1u)) {
       const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
-      // (agent-scope load: served by L2, never by a line this CU cached before the 3b lane's store)
-      const uint32_t v = __hip_atomic_load(a.nn_pos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (a store by another wave of this workgroup, ordered by the barrier above: workgroup scope is all it takes)
+      const uint32_t v = __hip_atomic_load(a.nn_pos + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (v == DEFER_MARK) defer = true; else mpos[u] = v;
     }
     const unsigned long long dm = __ballot(defer);
-    if ((threadIdx.x & 63u) == 0) a.defer_mask[(size_t)vb * (2 * TILE_WAVES) + u * TILE_WAVES + (threadIdx.x >> 6)] = dm;
+    if ((threadIdx.x & 63u) == 0) {
+      a.defer_mask[(size_t)vb * (2 * TILE_WAVES) + u * TILE_WAVES + (threadIdx.x >> 6)] = dm;
+      if (dm != 0ull) atomicOr(a.defer_flag, 1u);      // (rare: tells the clean-up pass that it has anything to do at all)
+    }
   }
-#ifdef CILHIP_EXP_PHASE_CLOCKS
-  __syncthreads();
   PHASE_CLK(3);
-#endif
   if (ACC == IM_NONE) return;
 
   // ---- 5. accumulation inside the tile (ACC != IM_NONE; first Gauss-Newton step: the inner transform is the identity).
   // Every sum the estimators need is an entry of  Z = sum_i z_i z_i^T  for a per-correspondence vector z of f32 terms
   // (fused_z): a rank update with K = number of correspondences -- v_mfma_f64_16x16x4_f64 work, the one place on the
   // path where the matrix cores fit the arithmetic contract (products of f32 terms are exact in f64, sums in f64).
-  // Nothing but the match position is carried through the search in registers: the query is fetched and transformed
-  // again, the matched point and its normal are gathered -- all of it was touched by this tile a moment ago (L2).
+  // Nothing but the match position is carried through the search in registers: the query was fetched again and the
+  // matched point and its normal gathered right after the search (above) -- all of it touched by this tile a moment ago.
   // From here on nobody reads the staged points or the cell table: the point buffer becomes per-wave scratch.
   {
     constexpr int NC = FusedZ<ACC>::NC;
     constexpr bool DUAL = NC <= 8;        // two groups of 4 correspondences per instruction: rows/cols 0-7 and 8-15
     float z[TILE_QPT][16];
     {
-      float4 s4[TILE_QPT], p4[TILE_QPT], n4[TILE_QPT];
-#pragma unroll
-      for (int u = 0; u < TILE_QPT; ++u) {
-        uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
-        asm volatile("" : "+v"(i));       // (a fresh load: do not keep the kernel-start copy of the query alive through the search)
-        const bool has = mpos[u] != NONE_U32;
-        s4[u] = p4[u] = n4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has) {
-          s4[u] = a.src[i];
-          p4[u] = g.pts[mpos[u]];
-          if (FusedZ<ACC>::needs_normal) n4[u] = g.nrm[mpos[u]];
-        }
-      }
       float Tq[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) Tq[k] = tform_lds[k];
 #pragma unroll
       for (int u = 0; u < TILE_QPT; ++u) {
         float qx, qy, qz;
-        transform_point(Tq, s4[u].x, s4[u].y, s4[u].z, qx, qy, qz);
-        fused_z<ACC>(mpos[u] != NONE_U32, qx, qy, qz, p4[u], n4[u], a.dst_mean, st->smt, z[u]);
+        transform_point(Tq, s4t[u].x, s4t[u].y, s4t[u].z, qx, qy, qz);
+        fused_z<ACC>(mpos[u] != NONE_U32, qx, qy, qz, p4t[u], n4t[u], a.dst_mean, st->smt, z[u]);
       }
     }
+    PHASE_CLK(4);
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
     typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -1364,6 +1405,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
 #pragma unroll
     for (int r = 0; r < 4; ++r) db[r * 64 + lane] = acc[r];
     __syncthreads();
+    PHASE_CLK(5);
     if (threadIdx.x < SUMS_MAX) {
       int i1, j1, i2, j2;
       const bool used = FusedZ<ACC>::slot_terms((int)threadIdx.x, i1, j1, i2, j2);
@@ -1380,15 +1422,16 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       }
       a.tile_partials[(size_t)vb * SUMS_MAX + threadIdx.x] = v1 - v2;
     }
+    PHASE_CLK(6);
   }
 }
 
 // Clean-up pass of the tiled search: the (few) queries the LDS tile could not settle -- sparse data or a radius beyond
 // the 3x3x3 block, queries outside the grid, tiles whose region exceeded the LDS budget -- run the generic exact search
-// out of global memory.  The tiles publish them as bit masks (one 64-bit word per wave and query slot); the words are
-// dealt to the waves of this kernel in a fixed interleaved order, so that with ACC != IM_NONE what a lane accumulates --
-// and with it every partial sum -- is the same in every run.  Sparse words: TODO_GROUP lanes per query; dense words
-// (whole deferred tiles): one lane per query.  With ACC the block also folds its share of the tiles' partial rows.
+// out of global memory.  The tiles publish them as bit masks (one 64-bit word per wave and query slot); a block lists
+// the queries of 64 words at a time and deals the list to its lanes in a fixed order, so that with ACC != IM_NONE what a
+// lane accumulates -- and with it every partial sum -- is the same in every run.  Short lists: TODO_GROUP lanes per query;
+// long lists (whole deferred tiles): one lane per query.  With ACC the block also folds its share of the tiles' partial rows.
 constexpr int TODO_GROUP = 8;   // lanes per deferred query
 #ifndef CILHIP_FEAT6_GROUP
 #define CILHIP_FEAT6_GROUP 1
@@ -1400,6 +1443,10 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
   using TR = AccTraits<ACC>;
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
+  if (*a.defer_flag == 0u) {     // no tile deferred anything (the usual case near convergence): a zero row, nothing else
+    if (ACC != IM_NONE && threadIdx.x < SUMS_MAX) a.partials[(size_t)blockIdx.x * SUMS_MAX + threadIdx.x] = 0.0;
+    return;
+  }
   __shared__ uint2 worklist[LIST_CAP * ITER_THREADS];
   float T[16];
 #pragma unroll
@@ -1425,36 +1472,92 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
       accumulate_pair<ACC>(accA, accB, T, iL, it, smt, dmean, false, true, qx, qy, qz, best.pos, p, nv, nv);
     }
   };
-  for (uint32_t chunk = blockIdx.x * ITER_WAVES + wave; chunk < nchunks; chunk += gridDim.x * ITER_WAVES) {
-    const uint32_t widx = chunk * 64u + (uint32_t)lane;
-    const unsigned long long mw = widx < W ? a.defer_mask[widx] : 0ull;
-    unsigned long long nz = __ballot(mw != 0ull);
-    while (nz) {
-      const int sl = __ffsll((long long)nz) - 1;
-      nz &= nz - 1;
-      unsigned long long word = __shfl(mw, sl, 64);                 // wave-uniform
-      const uint32_t wi = chunk * 64u + (uint32_t)sl;
-      const uint2 tile = tiles[wi / (2 * TILE_WAVES)];
-      const uint32_t i0 = tile.x + ((wi / TILE_WAVES) & 1u) * TILE_THREADS + (wi % TILE_WAVES) * 64u;
-      if (__popcll(word) >= 24) {
-        // dense (a whole deferred tile, or a tile far from its sort-time cells): one lane per query
-        const uint32_t i = i0 + (uint32_t)lane;
-        if (((word >> lane) & 1ull) && i < tile.y) {
-          const float4 s4 = a.src[i];
-          float qx, qy, qz;
-          transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-          NN best;
-          nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
-          finish(i, qx, qy, qz, best);
+  // One chunk = 64 mask words, STRIDED through the mask array (slot j of chunk c = word j * nchunks + c): the 32 words of a
+  // tile land in 32 different chunks, so a few tiles that defer a slab of queries each (an over-budget region) are spread
+  // over as many blocks.  The block lists the chunk's deferred queries in LDS (ascending slot, bit) and deals the LIST to
+  // its lanes -- a static assignment: every lane accumulates the same queries in the same order in every run.
+  __shared__ unsigned long long words[64];
+  __shared__ uint32_t wpre[65];
+  __shared__ uint16_t entries[64 * 64];           // (word << 6) | bit
+  __shared__ uint32_t block_has_work;
+  // most blocks have nothing to search (a converged registration defers a few hundred queries in all): find out with
+  // all mask loads of the block in flight at once
+  __shared__ unsigned char chunk_flag[64];      // the block's k-th chunk holds a deferred query (k < 64; later ones are looked at anyway)
+  if (threadIdx.x < 64) {
+    unsigned long long any = 0ull;
+    uint32_t kk = 0;
+    for (uint32_t c0 = blockIdx.x; c0 < nchunks; c0 += 8u * gridDim.x, kk += 8) {
+      unsigned long long mw[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint64_t cc = (uint64_t)c0 + (uint64_t)k * gridDim.x;
+        const uint64_t widx = (uint64_t)threadIdx.x * nchunks + cc;
+        mw[k] = (cc < nchunks && widx < W) ? a.defer_mask[widx] : 0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned long long bk = __ballot(mw[k] != 0ull);
+        any |= bk;
+        if (threadIdx.x == 0 && kk + k < 64) chunk_flag[kk + k] = bk != 0ull ? 1 : 0;
+      }
+    }
+    if (threadIdx.x == 0) block_has_work = any != 0ull ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool has_work = block_has_work != 0u;     // block-uniform
+  uint32_t kc = 0;
+  for (uint32_t chunk = blockIdx.x; has_work && chunk < nchunks; chunk += gridDim.x, ++kc) {      // block-uniform
+    if (kc < 64 && !chunk_flag[kc]) continue;
+    if (threadIdx.x < 64) {
+      const uint32_t widx = threadIdx.x * nchunks + chunk;
+      const unsigned long long mw = widx < W ? a.defer_mask[widx] : 0ull;
+      words[threadIdx.x] = mw;
+      uint32_t incl = (uint32_t)__popcll(mw);
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if ((int)threadIdx.x >= off) incl += t;
+      }
+      wpre[threadIdx.x + 1] = incl;
+      if (threadIdx.x == 0) wpre[0] = 0;
+    }
+    __syncthreads();
+    const uint32_t total = wpre[64];
+    if (total != 0) {
+      if (threadIdx.x < 64) {
+        unsigned long long mw = words[threadIdx.x];
+        uint32_t o = wpre[threadIdx.x];
+        while (mw) { entries[o++] = (uint16_t)((threadIdx.x << 6) | (uint32_t)(__ffsll((long long)mw) - 1)); mw &= mw - 1; }
+      }
+      __syncthreads();
+      auto query_of = [&](uint32_t e, uint2& tile) -> uint32_t {
+        const uint32_t ent = entries[e], wi = (ent >> 6) * nchunks + chunk;
+        tile = tiles[wi / (2 * TILE_WAVES)];
+        return tile.x + ((wi / TILE_WAVES) & 1u) * TILE_THREADS + (wi % TILE_WAVES) * 64u + (ent & 63u);
+      };
+      if (total > ITER_THREADS / TODO_GROUP) {
+        // more queries than lane groups (an over-budget tile's dropped slab, whole deferred tiles, a source far from its
+        // sort-time cells): one lane per query -- one trip per 256 queries instead of one per 32
+        for (uint32_t e = threadIdx.x; e < total; e += ITER_THREADS) {
+          uint2 tile;
+          const uint32_t i = query_of(e, tile);
+          if (i < tile.y) {
+            const float4 s4 = a.src[i];
+            float qx, qy, qz;
+            transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+            NN best;
+            nn_search(a.grid, qx, qy, qz, a.max_sq, best, worklist + threadIdx.x);
+            finish(i, qx, qy, qz, best);
+          }
         }
       } else {
-        // sparse: 8 queries per trip, TODO_GROUP lanes each
-        const int grp = lane / TODO_GROUP, sub = lane % TODO_GROUP;
-        while (word) {
-          unsigned long long t = word;
-          for (int k = 0; k < grp; ++k) t &= t - 1;                   // the grp-th set bit
-          const uint32_t i = i0 + (uint32_t)(t ? __ffsll((long long)t) - 1 : 0);
-          if (t != 0ull && i < tile.y) {                              // (uniform within a group)
+        // a handful of queries: TODO_GROUP lanes each (shorter dependent chains per query)
+        const uint32_t grp = threadIdx.x / TODO_GROUP;
+        const int sub = (int)(threadIdx.x % TODO_GROUP);
+        for (uint32_t e = grp; e < total; e += ITER_THREADS / TODO_GROUP) {      // (uniform within a group)
+          uint2 tile;
+          const uint32_t i = query_of(e, tile);
+          if (i < tile.y) {
             const float4 s4 = a.src[i];
             float qx, qy, qz;
             transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
@@ -1462,54 +1565,51 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
             nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
             if (sub == 0) finish(i, qx, qy, qz, best);
           }
-          for (int k = 0; k < 64 / TODO_GROUP; ++k) word &= word - 1;  // drop the 8 lowest set bits
         }
       }
     }
+    __syncthreads();    // (the lists are rewritten by the next chunk)
   }
   if (ACC != IM_NONE) {
     __shared__ double sh[ITER_WAVES][SUMS_MAX];
-    if (threadIdx.x < SUMS_MAX) {
+    if (has_work) {         // (block-uniform; a block that searched nothing contributes exact zeros, as the sums below would)
+      if (threadIdx.x < SUMS_MAX) {
 #pragma unroll
-      for (int w = 0; w < ITER_WAVES; ++w) sh[w][threadIdx.x] = 0.0;
-    }
-    __syncthreads();
+        for (int w = 0; w < ITER_WAVES; ++w) sh[w][threadIdx.x] = 0.0;
+      }
+      __syncthreads();
 #pragma unroll
-    for (int k = 0; k < TR::NA; ++k) {
-      const double v = wave_sum(accA[k]);
-      if (lane == 0) sh[wave][k] = v;
-    }
+      for (int k = 0; k < TR::NA; ++k) {
+        const double v = wave_sum(accA[k]);
+        if (lane == 0) sh[wave][k] = v;
+      }
 #pragma unroll
-    for (int k = 0; k < TR::NB; ++k) {
-      const double v = wave_sum(accB[k]);
-      if (lane == 0) sh[wave][28 + k] = v;
+      for (int k = 0; k < TR::NB; ++k) {
+        const double v = wave_sum(accB[k]);
+        if (lane == 0) sh[wave][28 + k] = v;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < SUMS_MAX) {
-      double v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-      // this block's share of the tiles' partial rows, in ascending tile order
-      const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
-      const uint32_t t0 = min(blockIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
-      for (uint32_t t = t0; t < t1; ++t) v += a.tile_partials[(size_t)t * SUMS_MAX + threadIdx.x];
-      a.partials[(size_t)blockIdx.x * SUMS_MAX + threadIdx.x] = v;
-    }
+    if (threadIdx.x < SUMS_MAX)
+      a.partials[(size_t)blockIdx.x * SUMS_MAX + threadIdx.x] =
+          has_work ? (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]) : 0.0;
   }
 }
 
-// rows of partial sums the tiled path with in-tile accumulation leaves in a.partials (= blocks of its clean-up pass)
-int tiled_partial_rows(uint32_t ntiles) {
+// blocks of the clean-up pass (64 mask words = two tiles per chunk; at most 1024 blocks, then several chunks each)
+static uint32_t deferred_blocks(uint32_t ntiles) {
   const uint32_t nchunks = (ntiles * (2u * TILE_WAVES) + 63u) >> 6;
-  uint32_t nb = (nchunks + ITER_WAVES - 1) / ITER_WAVES;
-  if (nb > 1024u) nb = 1024u;
-  if (nb < 1u) nb = 1u;
-  return (int)nb;
+  return nchunks < 1u ? 1u : (nchunks > 1024u ? 1024u : nchunks);
 }
+// rows of partial sums the tiled path with in-tile accumulation leaves in a.tile_partials: one per tile, then one per
+// block of the clean-up pass (a.partials = a.tile_partials + ntiles rows)
+int tiled_partial_rows(uint32_t ntiles) { return (int)(ntiles + deferred_blocks(ntiles)); }
 
 template <int ACC>
 static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const int* tile_box, uint32_t ntiles, hipStream_t s) {
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
   hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
-  hipLaunchKernelGGL((k_search_deferred<ACC>), dim3(tiled_partial_rows(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
+  hipLaunchKernelGGL((k_search_deferred<ACC>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
 }
 
 // acc_metric: IM_NONE = search only (matches stored); IM_KABSCH / IM_PLANE / IM_POINT / IM_BOTH = search + accumulation of
@@ -1742,8 +1842,17 @@ __device__ void reduce_partials_block(const double* __restrict__ partials, int n
   __shared__ double sh[4][64];
   const int slot = threadIdx.x & 63, grp = threadIdx.x >> 6;
   double v = 0.0;
-  if (slot < SUMS_MAX)
-    for (int b = grp; b < nblocks; b += 4) v += partials[(size_t)b * SUMS_MAX + slot];
+  if (slot < SUMS_MAX) {
+    int b = grp;
+    for (; b + 28 < nblocks; b += 32) {          // 8 independent loads in flight, added in ascending order
+      double r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = partials[(size_t)(b + 4 * k) * SUMS_MAX + slot];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += r[k];
+    }
+    for (; b < nblocks; b += 4) v += partials[(size_t)b * SUMS_MAX + slot];
+  }
   sh[grp][slot] = v;
   __syncthreads();
   if (threadIdx.x < SUMS_MAX)
@@ -1754,11 +1863,12 @@ __device__ void reduce_partials_block(const double* __restrict__ partials, int n
 // Stage 1 of the cross-block reduction: REDUCE_GROUPS blocks, each folding a contiguous slice of the
 // per-block partials (fixed order => deterministic).  A single block reading all 2048 x 48 doubles
 // is latency-bound (~170 us measured); 32 blocks do it in a few us.
-constexpr int REDUCE_GROUPS = 32;
+constexpr int REDUCE_GROUPS_MAX = 128;
+static inline int reduce_groups(int nblocks) { return nblocks > 4096 ? REDUCE_GROUPS_MAX : 32; }   // ~50 rows per group at most
 
 __global__ __launch_bounds__(256) void k_reduce_stage1(const double* __restrict__ partials, int nblocks, double* __restrict__ stage) {
   __shared__ double sums[SUMS_MAX];
-  const int per = (nblocks + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
+  const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
   const int b0 = blockIdx.x * per;
   const int b1 = min(b0 + per, nblocks);
   reduce_partials_block(partials + (size_t)b0 * SUMS_MAX, max(b1 - b0, 0), sums);
@@ -1773,9 +1883,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* partials,
 
 // partials[nblocks][SUMS_MAX] -> out[SUMS_MAX]; `stage` is scratch of REDUCE_GROUPS*SUMS_MAX doubles.
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s) {
-  if (nblocks > 2 * REDUCE_GROUPS) {
-    hipLaunchKernelGGL(k_reduce_stage1, dim3(REDUCE_GROUPS), dim3(256), 0, s, partials, nblocks, stage);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, (const double*)stage, REDUCE_GROUPS, out);
+  if (nblocks > 64) {
+    const int G = reduce_groups(nblocks);
+    hipLaunchKernelGGL(k_reduce_stage1, dim3(G), dim3(256), 0, s, partials, nblocks, stage);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, (const double*)stage, G, out);
   } else {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, partials, nblocks, out);
   }
@@ -1784,9 +1895,10 @@ void launch_reduce_partials(const double* partials, int nblocks, double* stage, 
 // Stage 1 only (the epilogue kernel k_solve folds the REDUCE_GROUPS rows itself).  Returns the number
 // of rows k_solve has to read from `stage`, or 0 if it should read `partials` directly.
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s) {
-  if (nblocks <= 2 * REDUCE_GROUPS) return 0;
-  hipLaunchKernelGGL(k_reduce_stage1, dim3(REDUCE_GROUPS), dim3(256), 0, s, partials, nblocks, stage);
-  return REDUCE_GROUPS;
+  if (nblocks <= 64) return 0;
+  const int G = reduce_groups(nblocks);
+  hipLaunchKernelGGL(k_reduce_stage1, dim3(G), dim3(256), 0, s, partials, nblocks, stage);
+  return G;
 }
 
 __device__ void reset_inner(IcpState* st) {
@@ -1864,7 +1976,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
     st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
     st->delta = delta;
     st->iterations += 1;
-    st->ncorr = (unsigned long long)(n + 0.5);
+    st->ncorr = (unsigned long long)(st->sums[0] + 0.5);   // (the sums of the last accumulation that ran: a converged inner loop skips the later ones)
     st->done = (delta < a.conv_tol) ? 1 : 0;                            // icp_base.hpp:83
     reset_inner(st);
   }
