@@ -1,23 +1,34 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native rigid ICP engine.
 
-A "step" is ONE ICP iteration (LDS-tiled kNN correspondence search kernel, streaming residual
-accumulation kernel, then the on-device 6x6 / 3x3 solve) over one synthetic cloud pair resident in HBM.
+A "step" is ONE ICP iteration over one synthetic cloud pair resident in HBM: the LDS-tiled kNN correspondence
+search with the residual accumulation inside the tile (k_search_tiled<metric> + its clean-up pass), the cross-block
+reduction and the on-device 6x6 / 3x3 solve.
 
-  N=1  : BASELINE.json configs[2]: 10M <-> 10M synthetic cloud with normals, point-to-plane
-         (SimpleCombinedMetricRigidICP3f defaults w_p2p=0, w_p2pl=1), SURVEY.md 8(d) recipe.
-  N>1  : weak scaling, one process per GPU: every rank holds the full 10M target and its own 10M
-         source shard (source points are independent work units); the only exchange
-         is the all-reduce(sum) of 48 doubles per iteration over RCCL (torch.distributed "nccl").
+  --config c3 (default)  BASELINE.json configs[2]: 10M <-> 10M synthetic cloud with normals, point-to-plane
+                         (SimpleCombinedMetricRigidICP3f defaults w_p2p = 0, w_p2pl = 1), SURVEY.md 8(d) recipe --
+                         the configuration BASELINE's metric is quoted on.
+           c2            configs[1]: 1M <-> 1M, point-to-point (SimplePointToPointMetricRigidICP3f)
+           c4 / c4_1gpu  configs[3]: 10M source points against an 80M-point target, combined metric 0.1 / 1.0
+           kmeans        configs[4]: KMeans3f k = 1024 on 50M points (step = one Lloyd iteration)
+           ransac        configs[4]: plane RANSAC scoring on 50M points (step = one pass of 128 hypotheses)
+  --gpus N (one process per GPU under torch.distributed.run; backend "nccl" = RCCL):
+      c3, --scaling weak (default): every rank holds the full 10M target and its own 10M source shard; one
+          all-reduce(sum) of 48 f64 per iteration (source points are independent work units).
+      c3 --scaling strong, c4: spatial slabs (SURVEY.md 8(e) partitioning B, cilantro_amd.distributed.SlabPartition):
+          rank r owns the target points of its slab plus a halo and the source points that fall into the slab; the same
+          single all-reduce per iteration.  Total work is fixed as N grows.
 
-Timed region = exactly K iterations from T0 = identity with conv_tol = 0 (never early-exits),
-bracketed by barrier + torch.cuda.synchronize(); MAX over ranks; rank 0 prints one JSON line.
-`value` = correspondence pairs/s of the whole job (all ranks' source points x K / time);
-`icp_iterations_per_sec` = K / time is reported beside it.
+Timed region = exactly K steps from T0 = identity with conv_tol = 0 (never early-exits), bracketed by barrier +
+torch.cuda.synchronize(); MAX over ranks; rank 0 prints one JSON line.  `value` = correspondence pairs/s of the whole
+job (source points of all ranks x K / time); `icp_iterations_per_sec` = K / time is reported beside it.
 """
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,7 +38,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_NOFMA_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: 157.3 TFLOP/s f32 vector peak counts FMA as 2; pinned, uncontracted f32 ops run at half of it
+
+ICP_CONFIGS = {
+    # name: (n_target, n_source, source stride, metric, w_p2p, w_p2pl, label)
+    "c2": (1_000_000, 1_000_000, 1, "p2p", 0.0, 0.0, "point-to-point (SimplePointToPointMetricRigidICP3f)"),
+    "c3": (10_000_000, 10_000_000, 1, "p2plane", 0.0, 1.0, "with normals, point-to-plane (SimpleCombinedMetricRigidICP3f)"),
+    "c4": (80_000_000, 10_000_000, 8, "combined", 0.1, 1.0, "with normals, combined metric w_p2p = 0.1, w_p2pl = 1 (SimpleCombinedMetricRigidICP3f)"),
+}
+ICP_CONFIGS["c4_1gpu"] = ICP_CONFIGS["c4"]
 
 
 def parse():
@@ -35,17 +55,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000, help="points per cloud (target and per-rank source)")
-    ap.add_argument("--metric", choices=["p2plane", "p2p"], default="p2plane")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c4_1gpu", "kmeans", "ransac"], default="c3")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="c3 with --gpus > 1 (c4 is always strong)")
+    ap.add_argument("--n", type=int, default=None, help="override the number of target points (source scaled alike): quick runs only")
+    ap.add_argument("--metric", choices=["p2plane", "p2p"], default=None, help="(compatibility) c3 sizes with another metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold-start / converging-trajectory measurements")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="source points of the CPU baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(d, metric, n_sample, T):
-    """Reference CPU path timed on this host: the reference's own nanoflann (oracle/_ref, OpenMP
-    schedule(dynamic,256) loop as correspondence_search_kd_tree_utilities.hpp:26) for the kNN pass +
-    the oracle's accumulation/solve, on a bounded sample of the source."""
+def source_hash():
+    """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp"):
+        with open(os.path.join(ROOT, "cilantro_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_icp(d, metric, w_p2p, w_p2pl, n_sample, T):
+    """Reference CPU path timed on this host: the reference's own nanoflann (oracle/_ref, OpenMP schedule(dynamic,256) loop as
+    correspondence_search_kd_tree_utilities.hpp:26) for the kNN pass + the oracle's accumulation / solve in the reference's f32
+    arithmetic, on a bounded sample of the source against the full target.  Warm-up, then the median of 5."""
     from oracle import oracle as orc
 
     cores = os.cpu_count() or 1
@@ -55,42 +87,59 @@ def cpu_baseline(d, metric, n_sample, T):
     t_build = time.perf_counter() - t0
     src = d["src"][:n_sample]
     q = orc.transform_points(T, src)
-    best = None
-    for _ in range(2):                                # warm + measured
+    knn = []
+    for k in range(6):                                # 1 warm-up + 5 measured
         t0 = time.perf_counter()
         di, si, d2 = tree.find_correspondences(q, d["max_sq_dist"], num_threads=cores)
-        t_knn = time.perf_counter() - t0
-        best = t_knn if best is None else min(best, t_knn)
-    p = orc.make_params(metric=1 if metric == "p2plane" else 0, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_F32)
-    t0 = time.perf_counter()
-    orc.icp_update(d["dst"], d["dst_n"], src, T, di, si, p)
-    t_est = time.perf_counter() - t0
-    pairs_s = len(src) / (best + t_est)
+        if k:
+            knn.append(time.perf_counter() - t0)
+    p = orc.make_params(metric=0 if metric == "p2p" else 1, w_p2p=w_p2p, w_p2pl=w_p2pl, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_F32)
+    est = []
+    for k in range(6):
+        t0 = time.perf_counter()
+        orc.icp_update(d["dst"], d["dst_n"], src, T, di, si, p)
+        if k:
+            est.append(time.perf_counter() - t0)
+    t_knn, t_est = statistics.median(knn), statistics.median(est)
+    pairs_s = len(src) / (t_knn + t_est)
     return {
         "value": pairs_s, "unit": "pairs/s", "cores": cores,
         "kind": "reference" if use_ref else "port",
-        "sample": f"{len(src)} of {len(d['src'])} source points vs full {len(d['dst'])}-point target, 1 iteration "
-                  f"(kNN {best:.3f}s on {cores} OpenMP threads + accumulate/solve {t_est:.3f}s single thread); "
+        "sample": f"{len(src)} of {len(d['src'])} source points vs full {len(d['dst'])}-point target, 1 iteration, median of 5 after a warm-up "
+                  f"(kNN {t_knn:.3f}s on {cores} OpenMP threads + accumulate/solve {t_est:.3f}s single thread, f32 as the reference); "
                   f"one-off kd-tree build {t_build:.2f}s (1 thread, excluded)",
-        "knn_s": best, "estimate_s": t_est, "tree_build_s": t_build,
+        "knn_s": t_knn, "knn_s_min_max": [min(knn), max(knn)], "estimate_s": t_est, "tree_build_s": t_build,
         "icp_iterations_per_sec_equiv": pairs_s / len(d["src"]),
     }
 
 
-def main():
-    a = parse()
-    import torch
+def copy_bandwidth(torch):
+    """the measured device copy bandwidth beside the spec peak (1 GiB torch copy = read + write)."""
+    try:
+        xb = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); yb = torch.empty_like(xb)
+        yb.copy_(xb); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            yb.copy_(xb)
+        e1.record(); torch.cuda.synchronize()
+        return 5 * 2 * xb.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    except Exception:
+        return None
 
-    from cilantro_amd import capi
+
+def bench_icp(a, torch, rank, world, local_rank):
+    from cilantro_amd import capi, distributed
     from cilantro_amd import synthetic as syn
     from cilantro_amd.icp import Context
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
+    nd, ns, stride, metric, w_p2p, w_p2pl, label = ICP_CONFIGS[a.config]
+    if a.metric is not None and a.config == "c3":
+        metric = a.metric
+        label = ICP_CONFIGS["c2"][6] if metric == "p2p" else label
+    if a.n is not None:
+        ns = max(1, a.n * ns // nd); nd = a.n
+    with_normals = metric != "p2p"
     dist = None
     # CILHIP_BENCH_FORCE_SHARDED=1 (under torchrun): run the sharded protocol + RCCL even with one rank,
     # to exercise exactly the code path the multi-GPU runs take
@@ -100,16 +149,34 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == a.gpus or world == 1, (world, a.gpus)
+    strong = sharded and (a.config in ("c4", "c4_1gpu") or a.scaling == "strong")
 
-    n = a.n
-    with_normals = a.metric == "p2plane"
-    # rank r: same target, its own window of source points / noise stream
-    d = syn.make_pair(n, n, with_normals=with_normals, src_offset=rank * 7919)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = Context(local_rank, stream)
-    dst_t = torch.from_numpy(d["dst"]).cuda()
-    nrm_t = torch.from_numpy(d["dst_n"]).cuda() if with_normals else None
-    src_t = torch.from_numpy(d["src"]).cuda()
+    p = capi.IcpParams()
+    ctx._L.cilhip_icp_default_params(C.byref(p))
+    p.metric = capi.METRIC_POINT_TO_POINT if metric == "p2p" else capi.METRIC_COMBINED
+    p.w_p2p, p.w_p2pl = (w_p2p, w_p2pl) if metric != "p2p" else (0.0, 1.0)
+    p.conv_tol = 0.0
+    T0 = np.eye(4, dtype=np.float32)
+    slab_info = None
+    if strong:
+        # every rank generates the whole pair (synthetic, deterministic) and keeps its slab: target points of the slab + halo,
+        # source points whose T0-image falls into the slab
+        d = syn.make_pair(nd, ns, with_normals=with_normals, src_stride=stride)
+        part = distributed.SlabPartition.plan(d["dst"], d["src"], T0, float(d["max_sq_dist"]), world)
+        dst_l, nrm_l, src_l = part.select(rank, d["dst"], d["dst_n"], d["src"])
+        n_src_rank = len(src_l)
+        slab_info = part.describe(rank, len(dst_l), len(src_l))
+    else:
+        # weak scaling / single GPU: rank r: same target, its own window of source points / noise stream
+        d = syn.make_pair(nd, ns, with_normals=with_normals, src_stride=stride, src_offset=rank * 7919)
+        dst_l, nrm_l, src_l = d["dst"], d["dst_n"], d["src"]
+        n_src_rank = ns
+    p.max_sq_dist = float(d["max_sq_dist"])
+    dst_t = torch.from_numpy(dst_l).cuda()
+    nrm_t = torch.from_numpy(nrm_l).cuda() if with_normals else None
+    src_t = torch.from_numpy(src_l).cuda()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ctx.set_target(dst_t, nrm_t)
@@ -118,29 +185,24 @@ def main():
     t_setup = time.perf_counter() - t0
     gi = ctx.grid_info()
 
-    import ctypes as C
-
-    p = capi.IcpParams()
-    ctx._L.cilhip_icp_default_params(C.byref(p))
-    p.metric = capi.METRIC_COMBINED if with_normals else capi.METRIC_POINT_TO_POINT
-    p.conv_tol = 0.0
-    p.max_sq_dist = float(d["max_sq_dist"])
-    T0 = np.eye(4, dtype=np.float32)
-
     sums = torch.zeros(capi.SUMS_LEN, dtype=torch.float64, device="cuda")
     gmean = None
     if sharded:
-        _, sm = ctx.means()
-        m = torch.tensor(sm.astype(np.float64) * n, dtype=torch.float64, device="cuda")
-        dist.all_reduce(m)
-        gmean = (m.cpu().numpy() / (n * world)).astype(np.float32)
+        if strong:
+            gdm, gmean = part.global_means(d["dst"], d["src"])
+            ctx.set_shard_info(0, dst_mean=gdm)
+            part.arm_guard(ctx, T0)
+        else:
+            _, sm = ctx.means()
+            m = torch.tensor(sm.astype(np.float64) * n_src_rank, dtype=torch.float64, device="cuda")
+            dist.all_reduce(m)
+            gmean = (m.cpu().numpy() / (n_src_rank * world)).astype(np.float32)
 
     def run(iters, timing):
         p.max_iter = iters
-        if not sharded:
-            ctx.enable_kernel_timing(timing)
-            return ctx.icp_run(p, T0)
         ctx.enable_kernel_timing(timing)
+        if not sharded:
+            return ctx.icp_run(p, T0)
         ctx.icp_begin(p, T0, gmean)
         for _ in range(iters):
             ctx.icp_partial_sums(sums.data_ptr())
@@ -153,92 +215,246 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sort_ms = ctx.prepare_source(T0, force=True) if not a.no_extras else None   # (the first run below would do it lazily)
     run(a.warmup, False)
     barrier()
     t0 = time.perf_counter()
     res = run(a.steps, True)
     barrier()
     dt = time.perf_counter() - t0
+    n_src_total = n_src_rank
     if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        c = torch.tensor([float(n_src_rank)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c)
+        n_src_total = int(c.item())
+        if strong:
+            assert not ctx.slab_violation(), "a source point left its slab's halo: the partition had to be redone (not expected in the bench)"
     assert int(res.iterations) == a.steps, (res.iterations, a.steps)
 
+    out = None
     if rank == 0:
         T = np.array(res.T[:], np.float32).reshape(4, 4).T
         err_true = float(np.linalg.norm(T - d["T_true"]))
         loop_ms, _, launches = ctx.last_timing()
         search_ms, acc_ms = ctx.last_timing2()
-        ns, nd, nc = n, n, int(res.last_ncorr)
-        # Dominant kernel = the kNN correspondence-search kernel.  Algorithmic bytes of one kNN pass
-        # (B_knn): read every source point once (12 B), every target point once (12 B),
-        # write (index, d2) per source point (8 B)  =>  20*Ns + 12*Nd for a stand-alone search.
-        # Inside the ICP loop (no post-filters) nothing reads the squared distances, so the kernel does not write them:
-        # 4 B per source point less than SURVEY's B_knn -- counted as such, not inflated.
-        alg_bytes = 16.0 * ns + 12.0 * nd
-        # streaming accumulation kernel (point-to-plane): B_acc = 16*Ns + 24*Nc  
-        acc_bytes = 16.0 * ns + (24.0 if with_normals else 12.0) * nc
-        # HBM bytes per launch of the search kernel(s) from the committed PMC passes (separate rocprofv3 --pmc runs,
-        # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); only quoted for the workload it was measured on
-        traffic = None
+        ns_l, nd_l, nc = len(src_l), len(dst_l), int(res.last_ncorr)
+        fused = acc_ms == 0.0 and launches > 0
+        # Algorithmic (compulsory) bytes, SURVEY.md 8(d): every datum touched once.
+        #   search + accumulation in ONE pass (the default: no index round trip):  12 Ns + 12 Nd + 12 Nc (the matched normals;
+        #   point-to-point: the matched points are part of the 12 Nd)
+        #   search alone inside the loop: 16 Ns + 12 Nd (the match index is written, the squared distance is not: nothing reads
+        #   it); the streaming accumulation pass that then follows: 16 Ns + 24 Nc (point-to-point: 12 Nc)
+        nc_l = nc if not sharded else ns_l       # (rank 0's own pairs; ncorr is the job's total)
+        if fused:
+            alg_bytes = 12.0 * ns_l + 12.0 * nd_l + (12.0 * nc_l if with_normals else 0.0)
+            kern = "k_search_tiled<metric> + k_search_deferred<metric> (LDS-tiled kNN search with the accumulation inside the tile)"
+        else:
+            alg_bytes = 16.0 * ns_l + 12.0 * nd_l
+            kern = "kNN correspondence search (k_search_tiled<none> + clean-up pass, or the per-lane search for small clouds)"
+        traffic, traffic_note = None, "no PMC measurement of this build / workload committed"
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             w = tj["workload"]
-            if (w["n_target"], w["n_source_per_gpu"], bool(w["with_normals"])) == (nd, ns, bool(with_normals)):
-                traffic = float(tj["traffic_bytes_per_launch"])
+            if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and fused == bool(tj.get("fused")):
+                traffic, traffic_note = float(tj["traffic_bytes_per_launch"]), tj.get("method", "")
+            else:
+                traffic_note = "profiles/r02_traffic.json was measured on another build or workload (source hash / sizes differ): not quoted"
         except Exception:
-            traffic = None
+            pass
         roof = None
         if launches > 0:      # (sharded runs: rank 0's own kernels)
             avg_ms = search_ms / launches
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-            # the measured device copy bandwidth beside the spec peak (1 GiB torch copy = read + write)
-            copy_gbs = None
-            try:
-                xb = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); yb = torch.empty_like(xb)
-                yb.copy_(xb); torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    yb.copy_(xb)
-                e1.record(); torch.cuda.synchronize()
-                copy_gbs = 5 * 2 * xb.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-                del xb, yb
-            except Exception:
-                copy_gbs = None
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "measured_copy_bandwidth_GBps": copy_gbs,
-                    "traffic": traffic, "kernel": "k_search_tiled + k_search_todo (kNN correspondence search, LDS-tiled)",
-                    "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
-                    "accumulate_kernel": {"avg_kernel_ms": acc_ms / launches,
-                                          "algorithmic_bytes_per_launch": acc_bytes,
-                                          "achieved_GBps": acc_bytes / max(acc_ms / launches * 1e-3, 1e-12) / 1e9}}
+                    "measured_copy_bandwidth_GBps": copy_bandwidth(torch), "traffic": traffic, "traffic_note": traffic_note,
+                    "kernel": kern, "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
+                    "timing": "hipEvents around the kernel(s) on the context's stream, every launch of the timed region"}
+            if not fused:
+                acc_bytes = 16.0 * ns_l + (24.0 if with_normals else 12.0) * nc_l
+                roof["accumulate_kernel"] = {"avg_kernel_ms": acc_ms / launches, "algorithmic_bytes_per_launch": acc_bytes,
+                                             "achieved_GBps": acc_bytes / max(acc_ms / launches * 1e-3, 1e-12) / 1e9}
+        sharding = "none"
+        if sharded:
+            sharding = ("spatial slabs: per rank the target points of its slab + halo and the source points inside the slab; all-reduce(sum) of 48 f64 per iteration"
+                        if strong else "source-sharded, target replicated, all-reduce(sum) of 48 f64 per iteration")
         out = {
             "metric": "ICP corr. pairs/sec (+ iterations/sec), synthetic uniform clouds",
-            "value": n * world * a.steps / dt, "unit": "pairs/s",
+            "value": n_src_total * a.steps / dt, "unit": "pairs/s",
             "icp_iterations_per_sec": a.steps / dt,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 search / f64 accumulate+solve",
-            "data": "synthetic",
-            "config": {"workload": f"{n/1e6:g}M<->{n/1e6:g}M synthetic float3 clouds"
-                                   + (" with normals, point-to-plane (SimpleCombinedMetricRigidICP3f)" if with_normals
-                                      else ", point-to-point (SimplePointToPointMetricRigidICP3f)"),
-                       "n_target": nd, "n_source_per_gpu": ns, "max_sq_dist": float(d["max_sq_dist"]),
-                       "iterations": a.steps, "conv_tol": 0.0, "sharding": "source-sharded, target replicated, all-reduce(sum) of 48 f64 per iteration" if sharded else "none",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32 search / f64 accumulate+solve", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {ns/1e6:g}M<->{nd/1e6:g}M synthetic float3 clouds " + label,
+                       "n_target": nd, "n_source_per_gpu": ns_l, "n_source_total": n_src_total, "max_sq_dist": float(d["max_sq_dist"]),
+                       "iterations": a.steps, "conv_tol": 0.0, "sharding": sharding, "slab": slab_info,
                        "grid": [gi.nx, gi.ny, gi.nz], "grid_cell": gi.cell, "grid_avg_occupancy": gi.avg_occupancy},
-            "setup_ms": t_setup * 1e3, "loop_ms_hip_events": loop_ms,
+            "setup_ms": t_setup * 1e3, "source_sort_ms": sort_ms, "loop_ms_hip_events": loop_ms,
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,
             "roofline": roof,
         }
-        if not sharded and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(d, a.metric, min(a.cpu_sample, n), T0)
-            except Exception as e:  # the baseline is a report, never the product path
-                out["cpu_baseline"] = {"error": repr(e)}
+    if not sharded and not a.no_extras:
+        extras = {}
+        # cost of a whole estimate() the way the reference's example calls it (15 iterations), sort included: what a caller sees
+        cold = []
+        for _ in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.prepare_source(T0, force=True)
+            p.max_iter = 15
+            ctx.enable_kernel_timing(False)
+            ctx.icp_run(p, T0)
+            ctx.synchronize()
+            cold.append((time.perf_counter() - t0) * 1e3)
+        extras["icp_estimate_ms_15iter_cold"] = statistics.median(cold)
+        extras["source_sort_ms_runs"] = [ctx.prepare_source(T0, force=True) for _ in range(3)]
+        # a converging trajectory (SURVEY.md 8(d) "recipe sanity": perturbation 0.8 h, tolerance 1e-5) beside the fixed-point run
+        try:
+            dc = syn.make_pair(nd, ns, with_normals=False, src_stride=stride, perturb=0.8)
+            ctx.set_source(torch.from_numpy(dc["src"]).cuda())
+            p.max_iter, p.conv_tol = 50, 1e-5
+            ctx.icp_run(p, T0)                       # (first call: sort + run, warm)
+            ctx.synchronize(); t0 = time.perf_counter()
+            ctx.prepare_source(T0, force=True)
+            rc = ctx.icp_run(p, T0)
+            ctx.synchronize(); tc = (time.perf_counter() - t0) * 1e3
+            Tc = np.array(rc.T[:], np.float32).reshape(4, 4).T
+            extras["converging_run"] = {"perturbation_h": 0.8, "conv_tol": 1e-5, "iterations": int(rc.iterations), "ms_total_incl_sort": tc,
+                                        "ms_per_iteration": tc / max(int(rc.iterations), 1), "T_err_vs_truth_frobenius": float(np.linalg.norm(Tc - dc["T_true"]))}
+            p.conv_tol = 0.0
+        except Exception as e:
+            extras["converging_run"] = {"error": repr(e)}
+        out.update(extras)
+    if rank == 0 and not sharded and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline_icp(d, metric, w_p2p, w_p2pl, min(a.cpu_sample, ns), T0)
+        except Exception as e:  # the baseline is a report, never the product path
+            out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
         print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
+
+
+def bench_kmeans(a, torch):
+    """BASELINE configs[4], first half: KMeans3f k = 1024 on 50M points, explicit initial centroids (the first k points).
+    Step = one Lloyd iteration (brute-force assignment + centroid update, one pass over the points)."""
+    from cilantro_amd import synthetic as syn
+    from cilantro_amd.clustering import KMeans3f
+
+    n, k = (a.n or 50_000_000), 1024
+    x = syn.make_dst(n)
+    xd = torch.from_numpy(x).cuda()
+    c0 = x[:k].copy()
+    KMeans3f(xd).cluster(c0, max_iter=max(a.warmup, 1), tol=0.0)
+
+    def timed(iters):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        km = KMeans3f(xd).cluster(c0, max_iter=iters, tol=0.0)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, km
+
+    t1, _ = timed(1)                      # fixed costs (centroid upload, label download) cancel in the difference
+    tk, km = timed(a.steps + 1)
+    assert km.getNumberOfPerformedIterations() == a.steps + 1
+    dt = (tk - t1)
+    evals = float(n) * k * a.steps
+    flops = 8.0 * evals                   # 3 sub, 3 mul, 2 add per point-centroid distance, each individually rounded
+    out = {"metric": "KMeans3f point-centroid distance evaluations/sec (k = 1024)", "value": evals / dt, "unit": "distances/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32 distances / exact fixed-point sums", "data": "synthetic",
+           "config": {"workload": f"kmeans: KMeans3f k = {k} on {n/1e6:g}M uniform points, initial centroids = the first k points, tol = 0", "n_points": n, "k": k},
+           "roofline": {"bound": "valu", "achieved": flops / dt / 1e12, "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / VALU_NOFMA_PEAK_TFLOPS,
+                        "traffic": None, "kernel": "k_assign_accumulate", "note": "8 individually rounded f32 ops per distance (no FMA contraction: labels must match the reference bit for bit); peak = half of the 157.3 TFLOP/s FMA figure"}}
+    if not a.no_cpu_baseline:
+        try:
+            from oracle import oracle as orc
+
+            m = min(n, 400_000)
+            ts = []
+            for r in range(4):
+                t0 = time.perf_counter(); orc.kmeans_assign(x[:m], c0); t = time.perf_counter() - t0
+                if r:
+                    ts.append(t)
+            out["cpu_baseline"] = {"value": m * k / statistics.median(ts), "unit": "distances/s", "cores": 1, "kind": "port",
+                                   "sample": f"assignment of {m} of {n} points to the {k} centroids, oracle (scalar C, 1 thread), median of 3"}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+
+
+def bench_ransac(a, torch):
+    """BASELINE configs[4], second half: plane RANSAC inlier counting on 50M points.  Step = one scoring pass of 128
+    hypotheses over all points (the estimator scores its hypotheses 128 at a time)."""
+    from cilantro_amd.model_estimation import PlaneRANSACEstimator3f
+
+    n = a.n or 50_000_000
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand((n, 3), device="cuda", generator=g) * 2 - 1
+    k = int(0.6 * n)
+    x[:k, 2] = 0.3 * x[:k, 0] - 0.2 * x[:k, 1] + 0.1 + 0.004 * torch.randn(k, device="cuda", generator=g)
+    rng = np.random.default_rng(3)
+    nrm = rng.normal(size=(128 * a.steps, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    planes = np.concatenate([nrm, rng.uniform(-0.5, 0.5, (len(nrm), 1))], axis=1).astype(np.float32)
+    pe = PlaneRANSACEstimator3f(x).setMaxInlierResidual(0.01)
+    pe.countInliers(planes[:128 * max(a.warmup, 1)])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    cnt1 = pe.countInliers(planes[:128])
+    torch.cuda.synchronize(); t1 = time.perf_counter() - t0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    cnt = pe.countInliers(np.concatenate([planes, planes[:128]]))
+    torch.cuda.synchronize(); tk = time.perf_counter() - t0
+    dt = tk - t1                                  # a.steps passes of 128 hypotheses
+    tests = float(n) * 128 * a.steps
+    alg = 12.0 * n                                # one read of the points per 128-hypothesis pass
+    out = {"metric": "plane RANSAC point-plane tests/sec", "value": tests / dt, "unit": "tests/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"ransac: PlaneRANSACEstimator3f inlier counting, {n/1e6:g}M points, 128 hypotheses per pass", "n_points": n},
+           "roofline": {"bound": "hbm", "achieved": alg / (dt / a.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "k_score", "algorithmic_bytes_per_launch": alg,
+                        "note": "128 hypotheses share one read of the points: the pass is VALU-bound (5 ops per test), the HBM fraction says how far the read is amortised"}}
+    if not a.no_cpu_baseline:
+        try:
+            from oracle import oracle as orc
+
+            m = min(n, 2_000_000)
+            xs = np.ascontiguousarray(x[:m].cpu().numpy())
+            ts = []
+            for r in range(4):
+                t0 = time.perf_counter()
+                for j in range(4):
+                    orc.plane_count_inliers(xs, planes[j], 0.01)
+                t = time.perf_counter() - t0
+                if r:
+                    ts.append(t)
+            out["cpu_baseline"] = {"value": 4 * m / statistics.median(ts), "unit": "tests/s", "cores": 1, "kind": "port",
+                                   "sample": f"4 hypotheses x {m} of {n} points, oracle (scalar C, 1 thread), median of 3"}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    assert int(cnt[0]) == int(cnt1[0])
+    print(json.dumps(out))
+
+
+def main():
+    a = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    if a.config == "kmeans":
+        if rank == 0:
+            bench_kmeans(a, torch)
+    elif a.config == "ransac":
+        if rank == 0:
+            bench_ransac(a, torch)
+    else:
+        bench_icp(a, torch, rank, world, local_rank)
 
 
 if __name__ == "__main__":

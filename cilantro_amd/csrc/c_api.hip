@@ -93,6 +93,8 @@ struct cilhip_ctx {
   // sharded-run state
   cilhip_icp_params run_prm{};
   bool run_active = false;
+  int guard_axis = -1;            // slab-sharded runs: see SolveArgs::guard_*
+  float guard_slack = 0.0f, guard_center[3] = {0, 0, 0}, guard_half[3] = {0, 0, 0}, guard_T[16] = {0};
   float run_src_mean[3] = {0, 0, 0};
 
   // timing
@@ -871,6 +873,9 @@ static SolveArgs make_solve_args(cilhip_ctx* c, const cilhip_icp_params* p, int 
   for (int i = 0; i < 3; ++i) { sa.dst_mean[i] = c->dst_mean[i]; sa.src_mean[i] = src_mean[i]; }
   sa.gn_last_step = 1;
   sa.has_normals = c->has_normals ? 1 : 0;
+  sa.guard_axis = c->guard_axis; sa.guard_slack = c->guard_slack;
+  for (int i = 0; i < 3; ++i) { sa.guard_center[i] = c->guard_center[i]; sa.guard_half[i] = c->guard_half[i]; }
+  for (int i = 0; i < 16; ++i) sa.guard_T[i] = c->guard_T[i];
   return sa;
 }
 
@@ -1127,6 +1132,26 @@ int cilhip_set_shard_info(cilhip_ctx* c, uint64_t target_index_offset, const flo
   c->index_offset = (uint32_t)target_index_offset;
   if (dst_mean) memcpy(c->dst_mean, dst_mean, sizeof(c->dst_mean));
   if (src_mean) memcpy(c->src_mean, src_mean, sizeof(c->src_mean));
+  return CILHIP_OK;
+}
+
+int cilhip_set_slab_guard(cilhip_ctx* c, int axis, float slack, const float center[3], const float half_extent[3], const float T_part[16]) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (axis < 0) { c->guard_axis = -1; return CILHIP_OK; }
+  if (axis > 2 || !center || !half_extent || !T_part || !(slack >= 0.0f)) return fail(c, CILHIP_ERR_INVALID, "set_slab_guard: axis 0..2, slack >= 0, box and transform required");
+  c->guard_axis = axis; c->guard_slack = slack;
+  memcpy(c->guard_center, center, sizeof(c->guard_center)); memcpy(c->guard_half, half_extent, sizeof(c->guard_half));
+  memcpy(c->guard_T, T_part, sizeof(c->guard_T));
+  return CILHIP_OK;
+}
+
+int cilhip_get_slab_violation(cilhip_ctx* c, int* out) {
+  if (!c || !out) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  int v = 0;
+  CK(c, hipMemcpyAsync(&v, reinterpret_cast<const char*>(c->d_state) + offsetof(IcpState, slab_violation), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  *out = v;
   return CILHIP_OK;
 }
 

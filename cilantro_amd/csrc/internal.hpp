@@ -65,6 +65,8 @@ struct IcpState {
   double dLd[9];      // f64 copies of the inner tform (the f32 ones feed the kernels)
   double dtd[3];
   double sums[SUMS_MAX];  // reduced sums of the last accumulation
+  int slab_violation;     // spatially sharded runs: some source point may have left its slab's halo since the partition (sticky)
+  int pad1;
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -95,6 +97,18 @@ struct IterArgs {
   float normal_weight;         // the adaptor's normal weight (0 = plain point features)
 };
 
+// What k_tile_boxes needs to compute the tiles' regions for the state's transform.
+struct BoxArgs {
+  const float4* tile_center;   // null: nothing to do
+  int* tile_box;
+  uint32_t ntiles;
+  uint32_t* defer_flag;
+  float ox, oy, oz, inv_cell;
+  int nx, ny, nz;
+  float tile_axes[9];
+  int trim;
+};
+
 struct SolveArgs {
   IcpState* state;
   const double* partials;
@@ -106,6 +120,14 @@ struct SolveArgs {
   float dst_mean[3], src_mean[3];
   int gn_last_step;        // finalize the outer iteration after this GN step
   int has_normals;
+  // spatially sharded runs (slab partition of target and source along one axis): after every update of the transform the
+  // epilogue bounds how far ANY source point (global bounding box of the source, in source coordinates) can have moved
+  // along the slab axis since the partition was made, and raises IcpState::slab_violation when that exceeds the slack the
+  // halos were sized with -- every rank evaluates the same bound on the same values, so all take the same decision
+  int guard_axis;          // -1: off
+  float guard_slack;
+  float guard_center[3], guard_half[3];
+  float guard_T[16];       // transform the partition was made under
 };
 
 // kernels.hip

@@ -927,17 +927,9 @@ void debug_dump_phase_clocks() {
 // (oriented box in source space: centre per tile, half-axes common to all tiles) is T c +- |R A| 1, converted to cells.
 // box[8t..8t+7] = bx0, bx1, by0, by1, bz0, bz1 (cell range of the box, already extended into the empty layer next to the
 // data where it touches the first / last data cells), then the two reciprocals the search kernel's table fill uses.
-__global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center, uint32_t ntiles, int* __restrict__ box) {
-  const IcpState* __restrict__ st = a.state;
-  if (st->done) return;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) *a.defer_flag = 0u;       // (the tiles of the search that follows set it when they defer a query)
-  if (t >= ntiles) return;
-  const GridDev& g = a.grid;
-  float T[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
-  const float4 c4 = tile_center[t];
+__device__ __forceinline__ void compute_tile_box(const float* T, const BoxArgs& g, uint32_t t) {
+  const bool trim = g.trim != 0;
+  const float4 c4 = g.tile_center[t];
   float ccx, ccy, ccz;
   transform_point(T, c4.x, c4.y, c4.z, ccx, ccy, ccz);
   float ext[3];
@@ -946,13 +938,14 @@ __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center,
     float e = 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      e += fabsf(T[i] * a.tile_axes[k] + T[i + 4] * a.tile_axes[3 + k] + T[i + 8] * a.tile_axes[6 + k]);   // |(R A)_ik|
+      e += fabsf(T[i] * g.tile_axes[k] + T[i + 4] * g.tile_axes[3 + k] + T[i + 8] * g.tile_axes[6 + k]);   // |(R A)_ik|
     ext[i] = e;
   }
   const float SHR = 1.0e-3f, BIG = 1.0e9f;   // the cube is half-open: shrink by 1e-3 cell so that an unmoved cube maps to itself
   // Per axis: the cells [b0, b1] the image covers, and the REGION the tile stages = those cells plus a halo cell on a
-  // side only where a query can lean that way: the octant block of a query is the 2 cells on the side of its own cell it
-  // leans to, so the low halo is needed only if the first cell can hold a query in its lower half (the image starts
+  // side only where a query can lean that way (trim: the accumulating form of the search; the search-only form keeps both
+  // halos -- its second, 3x3x3 pass needs the whole neighbourhood of a cell): the octant block of a query is the 2 cells
+  // on the side of its own cell it leans to, so the low halo is needed only if the first cell can hold a query in its lower half (the image starts
   // below the cell's middle), the high halo only if the last cell can hold one in its upper half.  A cube of 12 cells
   // shifted by a fraction of a cell covers 13 cells and needs ONE of the two halos: 14 cells per axis instead of 15 --
   // a fifth fewer points to stage, and regions that stay inside the LDS budget.  (Only a matter of speed: the search
@@ -966,7 +959,7 @@ __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center,
     const float a0 = fminf(fmaxf((cc3[i] - ext[i] - o3[i]) * g.inv_cell + SHR, -BIG), BIG);
     const float a1 = fminf(fmaxf((cc3[i] + ext[i] - o3[i]) * g.inv_cell - SHR, -BIG), BIG);
     int b0 = (int)floorf(a0), b1 = (int)floorf(a1);
-    bool halo0 = (a0 - (float)b0) < 0.5f + HALF_SLACK, halo1 = (a1 - (float)b1) > 0.5f - HALF_SLACK;
+    bool halo0 = !trim || (a0 - (float)b0) < 0.5f + HALF_SLACK, halo1 = !trim || (a1 - (float)b1) > 0.5f - HALF_SLACK;
     // a box that reaches the first / last layer of data cells also takes the empty layer next to it: the queries the
     // current transform (or noise) pushed just outside the data's bounding box stay on the fast path
     if (b0 <= GRID_PAD) { b0 = min(b0, GRID_PAD - 1); halo0 = true; }
@@ -981,8 +974,30 @@ __global__ void k_tile_boxes(IterArgs a, const float4* __restrict__ tile_center,
   const int W1 = (min(bx1 + 1, g.nx - 1) - max(bx0 - 1, 0) + 1) + 1, RY = min(by1 + 1, g.ny - 1) - max(by0 - 1, 0) + 1;
   const uint32_t inv_w1 = W1 > 0 ? ((1u << 20) + (uint32_t)W1 - 1u) / (uint32_t)W1 : 0u;
   const uint32_t inv_ry = RY > 0 ? (65536u + (uint32_t)RY - 1u) / (uint32_t)RY : 0u;
-  int* b = box + 8 * (size_t)t;
+  int* b = g.tile_box + 8 * (size_t)t;
   b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = bz0; b[5] = bz1; b[6] = (int)inv_w1; b[7] = (int)inv_ry;
+}
+
+
+__global__ void k_tile_boxes(BoxArgs g, const IcpState* __restrict__ st) {
+  if (st->done) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *g.defer_flag = 0u;       // (the tiles of the search that follows set it when they defer a query)
+  if (t >= g.ntiles) return;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  compute_tile_box(T, g, t);
+}
+
+BoxArgs make_box_args(const IterArgs& a, const float4* tile_center, int* tile_box, uint32_t ntiles, bool trim) {
+  BoxArgs b{};
+  b.tile_center = tile_center; b.tile_box = tile_box; b.ntiles = ntiles; b.defer_flag = a.defer_flag;
+  b.ox = a.grid.ox; b.oy = a.grid.oy; b.oz = a.grid.oz; b.inv_cell = a.grid.inv_cell;
+  b.nx = a.grid.nx; b.ny = a.grid.ny; b.nz = a.grid.nz;
+  for (int i = 0; i < 9; ++i) b.tile_axes[i] = a.tile_axes[i];
+  b.trim = trim ? 1 : 0;
+  return b;
 }
 
 // A tile that cannot be staged at all hands every query to the clean-up pass (all-ones masks; the pass clips to the
@@ -1616,7 +1631,7 @@ static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const i
 // the first Gauss-Newton step's sums in one pass (a.partials[0 .. tiled_partial_rows) rows afterwards).
 void launch_search_tiled(const IterArgs& a, int acc_metric, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s) {
   if (ntiles == 0) return;
-  hipLaunchKernelGGL(k_tile_boxes, dim3((ntiles + 255) / 256), dim3(256), 0, s, a, tile_center, ntiles, tile_box);
+  hipLaunchKernelGGL(k_tile_boxes, dim3((ntiles + 255) / 256), dim3(256), 0, s, make_box_args(a, tile_center, tile_box, ntiles, acc_metric != IM_NONE), a.state);
   switch (acc_metric) {
     case IM_KABSCH: launch_search_tiled_m<IM_KABSCH>(a, tiles, tile_box, ntiles, s); break;
     case IM_PLANE: launch_search_tiled_m<IM_PLANE>(a, tiles, tile_box, ntiles, s); break;
@@ -1979,6 +1994,17 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
     st->ncorr = (unsigned long long)(st->sums[0] + 0.5);   // (the sums of the last accumulation that ran: a converged inner loop skips the later ones)
     st->done = (delta < a.conv_tol) ? 1 : 0;                            // icp_base.hpp:83
     reset_inner(st);
+    if (a.guard_axis >= 0) {
+      // |((T - T_part) p)_axis| over the source's bounding box: an affine function of p, extreme at a corner
+      const int ax = a.guard_axis;
+      float d = Tn[12 + ax] - a.guard_T[12 + ax], spread = 0.0f;
+      for (int j = 0; j < 3; ++j) {
+        const float dl = Tn[j * 4 + ax] - a.guard_T[j * 4 + ax];
+        d += dl * a.guard_center[j];
+        spread += fabsf(dl) * a.guard_half[j];
+      }
+      if (!(fabsf(d) + spread <= a.guard_slack)) st->slab_violation = 1;
+    }
   }
   }
   __syncthreads();
@@ -2002,6 +2028,7 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
   st->done = 0;
   st->ncorr = 0;
   for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = 0.0;
+  st->slab_violation = 0; st->pad1 = 0;
   reset_inner(st);
 }
 

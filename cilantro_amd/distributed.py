@@ -192,3 +192,129 @@ class TargetShardedRigidICP:
                 self.dist.all_reduce(sums, group=self.group)
             self.engine.apply_sums(sums)
         return self.engine.state()
+
+
+# ---- spatially sharded runs (SURVEY.md 8(e) partitioning B) --------------------------------------------------------
+class SlabPartition:
+    """Slabs along the longest axis of the target's bounding box.
+
+    Rank r owns the source points whose image under ``T_part`` has its axis coordinate in [b_r, b_{r+1}) and holds the
+    target points with coordinate in [b_r - halo, b_{r+1} + halo), halo = sqrt(max_sq_dist) + slack: the nearest neighbour
+    within the search radius of every owned query is then among the rank's own target points, for as long as no source
+    point has moved by more than ``slack`` along the axis since the partition (the device-side guard,
+    ``cilhip_set_slab_guard``).  Boundaries are quantiles of the source coordinates: the queries are the work.
+    No data-path collective besides the 48-double all-reduce of the partial sums.
+    """
+
+    def __init__(self, axis, bounds, halo, slack, T_part, src_center, src_half):
+        self.axis, self.bounds, self.halo, self.slack = int(axis), np.asarray(bounds, np.float64), float(halo), float(slack)
+        self.T_part = np.asarray(T_part, np.float32).reshape(4, 4).copy()
+        self.src_center, self.src_half = np.asarray(src_center, np.float32), np.asarray(src_half, np.float32)
+
+    @staticmethod
+    def _image_coord(T, pts, axis):
+        T = np.asarray(T, np.float64)
+        return pts.astype(np.float64) @ T[axis, :3] + T[axis, 3]
+
+    @classmethod
+    def plan(cls, dst, src, T_part, max_sq_dist, world, slack=None):
+        dst = np.asarray(dst, np.float32).reshape(-1, 3); src = np.asarray(src, np.float32).reshape(-1, 3)
+        lo, hi = dst.min(axis=0).astype(np.float64), dst.max(axis=0).astype(np.float64)
+        axis = int(np.argmax(hi - lo))
+        r = float(np.sqrt(max_sq_dist)) if np.isfinite(max_sq_dist) else float((hi - lo)[axis])
+        slack = 2.0 * r if slack is None else float(slack)
+        q = cls._image_coord(T_part, src, axis) if len(src) else np.zeros(0)
+        qs = np.quantile(q, np.linspace(0.0, 1.0, world + 1)[1:-1]) if len(q) and world > 1 else np.zeros(0)
+        bounds = np.concatenate([[-np.inf], qs, [np.inf]])
+        slo, shi = (src.min(axis=0), src.max(axis=0)) if len(src) else (np.zeros(3), np.zeros(3))
+        return cls(axis, bounds, r + slack, slack, T_part, 0.5 * (slo + shi), 0.5 * (shi - slo))
+
+    def select(self, rank, dst, dst_n, src):
+        """-> (target points of the slab + halo, their normals or None, owned source points) for ``rank``; also keeps the
+        index arrays (``self.dst_index``, ``self.src_index``) of the last call for callers that map results back."""
+        dst = np.asarray(dst, np.float32).reshape(-1, 3); src = np.asarray(src, np.float32).reshape(-1, 3)
+        b0, b1 = self.bounds[rank], self.bounds[rank + 1]
+        x = dst[:, self.axis].astype(np.float64)
+        dm = (x >= b0 - self.halo) & (x < b1 + self.halo)
+        q = self._image_coord(self.T_part, src, self.axis)
+        sm = (q >= b0) & (q < b1)
+        self.dst_index, self.src_index = np.nonzero(dm)[0], np.nonzero(sm)[0]
+        return (np.ascontiguousarray(dst[dm]), None if dst_n is None else np.ascontiguousarray(np.asarray(dst_n, np.float32).reshape(-1, 3)[dm]),
+                np.ascontiguousarray(src[sm]))
+
+    @staticmethod
+    def global_means(dst, src):
+        """dst_mean_ / src_mean_ of the WHOLE clouds as the ICP classes hold them (f64 sums rounded to f32); ranks that
+        only hold their part obtain the same values from an all-reduce of (sum, count)."""
+        return (np.asarray(dst, np.float64).reshape(-1, 3).mean(axis=0).astype(np.float32),
+                np.asarray(src, np.float64).reshape(-1, 3).mean(axis=0).astype(np.float32))
+
+    def arm_guard(self, ctx, T_part=None):
+        ctx.set_slab_guard(self.axis, self.slack, self.src_center, self.src_half, self.T_part if T_part is None else T_part)
+
+    def describe(self, rank, n_dst_local, n_src_local):
+        return {"axis": self.axis, "halo": self.halo, "slack": self.slack, "rank0_slab": [float(self.bounds[rank]), float(self.bounds[rank + 1])],
+                "n_target_local": int(n_dst_local), "n_source_local": int(n_src_local)}
+
+
+class HipSlabEngine(HipShardEngine):
+    """Per-rank engine of a slab-partitioned run: HipShardEngine over this rank's part, with the GLOBAL means and the guard."""
+
+    def __init__(self, part, rank, dst, dst_n, src, device):
+        d, n, s = part.select(rank, dst, dst_n, src)
+        super().__init__(d, n, s, device)
+        self.part = part
+        self.gdm, self.gsm = part.global_means(dst, src)
+        self.ctx.set_shard_info(0, dst_mean=self.gdm)
+        part.arm_guard(self.ctx)
+
+    def begin(self, params, T0, global_src_mean):
+        self.ctx.icp_begin(params, T0, self.gsm)
+
+    def violated(self):
+        return self.ctx.slab_violation()
+
+
+class SlabShardedRigidICP:
+    """ICP over a slab partition: ShardedRigidICP's loop (one all-reduce of the 48 partial sums per iteration) plus the
+    guard: every ``check_every`` iterations the (identical on all ranks) violation flag is read; if a source point may
+    have left its halo, ``repartition(T)`` -- a caller-supplied function that returns a new engine partitioned under T --
+    is called with the last checked transform and the run continues from there."""
+
+    def __init__(self, engine, dist=None, group=None, repartition=None):
+        self.engine, self.dist, self.group, self.repartition = engine, dist, group, repartition
+        self.repartitions = 0
+
+    def estimate(self, params, T0=None, check_every=5):
+        T_ck = np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32).copy()
+        total, base, since, begin_base = int(params.max_iter), 0, 0, 0   # base: iterations up to the last checked state; begin_base: up to the last begin()
+        inner = ShardedRigidICP(self.engine, self.dist, self.group)
+        self.engine.begin(params, T_ck, None)
+        fresh = True                      # the engine's partition was made under exactly T_ck
+        every = max(check_every, 1)
+        while base + since < total:
+            sums = self.engine.partial_sums()
+            inner._allreduce(sums)
+            self.engine.apply_sums(sums)
+            since += 1
+            if since % every == 0 or base + since == total:
+                T, iters, delta, nc = self.engine.state()
+                bad = self.engine.violated()          # (the same answer on every rank: same transform, same global box)
+                # The flag is about the NEXT search (it is raised by the update that moved the source too far).  One
+                # iteration whose search ran under the partition's own transform is exact whatever the flag says: keep it --
+                # that is what guarantees progress when every update trips the guard.
+                if not bad or (fresh and since == 1):
+                    T_ck, base, since, fresh = T, base + since, 0, False
+                    if delta < params.conv_tol or base >= total:
+                        return T, begin_base + iters, delta, nc
+                    every = max(check_every, 1) if not bad else 1
+                if bad:
+                    if self.repartition is None:
+                        raise RuntimeError("a source point may have left its slab's halo and no repartition function was given")
+                    self.engine = self.repartition(T_ck)
+                    inner = ShardedRigidICP(self.engine, self.dist, self.group)
+                    self.repartitions += 1
+                    self.engine.begin(params, T_ck, None)
+                    since, begin_base, fresh, every = 0, base, True, 1
+        T, iters, delta, nc = self.engine.state()
+        return T, begin_base + iters, delta, nc

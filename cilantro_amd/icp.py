@@ -217,6 +217,18 @@ class Context:
     def icp_sums_from_keys(self, keys_dev_ptr, sums_dev_ptr):
         self._ck(self._L.cilhip_icp_sums_from_keys(self._h, C.c_void_p(keys_dev_ptr), C.c_void_p(sums_dev_ptr)))
 
+    def set_slab_guard(self, axis, slack=0.0, center=None, half_extent=None, T_part=None):
+        if axis is None or axis < 0:
+            self._ck(self._L.cilhip_set_slab_guard(self._h, -1, C.c_float(0.0), None, None, None))
+            return
+        c = np.ascontiguousarray(center, np.float32); h = np.ascontiguousarray(half_extent, np.float32); t = _T_to_abi(T_part)
+        self._ck(self._L.cilhip_set_slab_guard(self._h, int(axis), C.c_float(slack), c.ctypes.data, h.ctypes.data, t.ctypes.data))
+
+    def slab_violation(self):
+        v = C.c_int(0)
+        self._ck(self._L.cilhip_get_slab_violation(self._h, C.byref(v)))
+        return bool(v.value)
+
     def icp_state(self):
         res = capi.IcpResult()
         self._ck(self._L.cilhip_icp_state(self._h, C.byref(res)))

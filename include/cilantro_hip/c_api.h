@@ -171,6 +171,18 @@ int cilhip_icp_partial_sums(cilhip_ctx* ctx, double* sums_dev);
 int cilhip_icp_apply_sums(cilhip_ctx* ctx, const double* sums_dev);
 int cilhip_icp_state(cilhip_ctx* ctx, cilhip_icp_result* out); /* syncs */
 
+/* Spatially sharded runs (SURVEY.md 8(e) partitioning B; no counterpart in the reference, which has one address space):
+ * target and source are cut into slabs along one axis -- a context holds the target points of its slab plus a halo of
+ * sqrt(max distance) + slack and the source points whose image under T_part falls into the slab -- so every nearest
+ * neighbour is local and the only exchange per iteration is cilhip_icp_partial_sums' 48 doubles.  The guard keeps that
+ * exact: after every transform update the device bounds how far any point of the source's bounding box (centre,
+ * half-extents, SOURCE coordinates, the same box on every rank) can have moved along the axis since the partition; once
+ * that exceeds the slack the sticky flag cilhip_get_slab_violation reads is raised (identically on all ranks): the
+ * caller re-partitions under the current transform and repeats from its last checked state.  axis < 0 disarms. */
+int cilhip_set_slab_guard(cilhip_ctx* ctx, int axis, float slack, const float center[3], const float half_extent[3],
+                          const float T_part[16]);
+int cilhip_get_slab_violation(cilhip_ctx* ctx, int* violated_out);
+
 /* ---- target-sharded runs (BASELINE configs[3]: one target too large / sharded over the GPUs of a node) ----
  * Every rank holds ALL source points and ONE shard of the target (set with cilhip_set_target) plus
  *   cilhip_set_shard_info(ctx, global index of the shard's first point, GLOBAL dst mean, GLOBAL src mean).

@@ -145,10 +145,64 @@ def main_target_sharded(metric, n):
     dist.destroy_process_group()
 
 
+class OracleSlabEngine(OracleShardEngine):
+    """Test-only counterpart of HipSlabEngine: kd-tree over the rank's slab + halo, its owned source points, the GLOBAL
+    means, and the guard's bound restated on the host (cilhip_set_slab_guard / k_solve)."""
+
+    def __init__(self, part, rank, d):
+        dst, dst_n, src = part.select(rank, d["dst"], d["dst_n"], d["src"])
+        super().__init__(dst, dst_n, src)
+        self.part = part
+        gdm, self.gsm = part.global_means(d["dst"], d["src"])
+        self.dst_mean = gdm
+        self.viol = False
+
+    def begin(self, params, T0, gmean):
+        super().begin(params, T0, self.gsm)
+        self.viol = False
+
+    def apply_sums(self, sums):
+        super().apply_sums(sums)
+        pt, ax = self.part, self.part.axis
+        dl = self.T[ax, :3].astype(np.float32) - pt.T_part[ax, :3]
+        bound = abs(float(self.T[ax, 3] - pt.T_part[ax, 3] + dl @ pt.src_center)) + float(np.abs(dl) @ pt.src_half)
+        self.viol |= not (bound <= pt.slack)
+
+    def violated(self):
+        return self.viol
+
+
+def main_slab(metric, n, slack_cells):
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    d = syn.make_pair(n, perturb=0.5)
+    slack = None if slack_cells < 0 else slack_cells * d["h"]
+    plans = []
+
+    def engine_for(T):
+        plans.append(distributed.SlabPartition.plan(d["dst"], d["src"], T, float(d["max_sq_dist"]), world, slack=slack))
+        return OracleSlabEngine(plans[-1], rank, d)
+
+    icp = distributed.SlabShardedRigidICP(engine_for(np.eye(4, dtype=np.float32)), dist, repartition=engine_for)
+    p = distributed.default_params(metric=metric, max_iter=12, conv_tol=1e-6, max_sq_dist=float(d["max_sq_dist"]))
+    T, iters, delta, nc = icp.estimate(p, check_every=2)
+    counts = [None] * world
+    dist.all_gather_object(counts, (len(icp.engine.src), len(icp.engine.dst)))
+    allT = [None] * world
+    dist.all_gather_object(allT, T.tolist())
+    if rank == 0:
+        print("RESULT " + json.dumps({"T": T.tolist(), "iters": iters, "delta": delta, "ncorr": nc, "world": world, "repartitions": icp.repartitions,
+                                       "n_src": [c[0] for c in counts], "n_dst": [c[1] for c in counts],
+                                       "identical": all(a == allT[0] for a in allT)}))
+    dist.destroy_process_group()
+
+
 def main():
     metric = int(sys.argv[1]); n = int(sys.argv[2])
     if len(sys.argv) > 3 and sys.argv[3] == "tshard":
         return main_target_sharded(metric, n)
+    if len(sys.argv) > 3 and sys.argv[3].startswith("slab"):
+        return main_slab(metric, n, float(sys.argv[3][4:] or -1))
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     d = syn.make_pair(n, perturb=0.5)

@@ -57,3 +57,52 @@ def test_target_sharded_icp_world2_matches_single_process(orc, metric):
     ref = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
     assert np.linalg.norm(np.array(r2["T"], np.float64) - ref["T"]) <= 1e-5
     assert r2["ncorr"] == ref["last_ncorr"]
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_slab_sharded_icp_world2_matches_single_process(orc, metric):
+    """SURVEY 8(e) partitioning B: target and source cut into spatial slabs (halo = radius + slack), one all-reduce(sum) of
+    the partial sums per iteration and nothing else.  With the default slack the partition survives the run; with a slack
+    of a hundredth of a cell the guard fires, the ranks re-partition under the last checked transform and continue --
+    either way the result is the single-process run's."""
+    n = 6000
+    d = syn.make_pair(n, perturb=0.5)
+    p = orc.make_params(metric=metric, max_iter=12, conv_tol=1e-6, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+    ref = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+    for mode, want_repart in (("slab", False), ("slab0.01", True)):
+        r2 = _run(2, metric, n, mode)
+        assert r2["world"] == 2 and r2["identical"]
+        assert (r2["repartitions"] > 0) == want_repart, r2["repartitions"]
+        assert sum(r2["n_src"]) == n and max(r2["n_src"]) - min(r2["n_src"]) <= 1          # every query owned exactly once, balanced
+        assert all(nd < 0.9 * n for nd in r2["n_dst"])                                   # a slab + halo (wide at this tiny size: radius + slack = 6 h), not the whole target
+        T2 = np.array(r2["T"], np.float64)
+        assert np.linalg.norm(T2 - ref["T"]) <= 1e-5, np.linalg.norm(T2 - ref["T"])
+        assert abs(r2["iters"] - ref["iterations"]) <= 1 and r2["ncorr"] == ref["last_ncorr"]
+
+
+def test_slab_partition_is_exact(orc):
+    """Every owned query finds, inside its own slab + halo, exactly the neighbour the whole target gives it -- under the
+    partition transform and under any transform that moves no point by more than the slack along the axis."""
+    from cilantro_amd import distributed
+
+    n = 20000
+    d = syn.make_pair(n, perturb=0.5)
+    h = d["h"]
+    T0 = np.eye(4, dtype=np.float32)
+    full = orc.KDTree(d["dst"])
+    for world in (2, 3, 5):
+        part = distributed.SlabPartition.plan(d["dst"], d["src"], T0, float(d["max_sq_dist"]), world)
+        owned = np.zeros(n, np.int32)
+        for T in (T0, d["T_true"].astype(np.float32)):
+            ax = part.axis
+            disp = np.abs(part._image_coord(T, d["src"], ax) - part._image_coord(T0, d["src"], ax)).max()
+            assert disp <= part.slack                                      # (what the guard bounds from the box corners)
+            for r in range(world):
+                dst_l, _, src_l = part.select(r, d["dst"], d["dst_n"], d["src"])
+                if T is T0:
+                    owned[part.src_index] += 1
+                q = orc.transform_points(T, src_l)
+                li, ls, lv = orc.KDTree(dst_l).find_correspondences(q, d["max_sq_dist"])
+                gi, gs, gv = full.find_correspondences(q, d["max_sq_dist"])
+                assert np.array_equal(ls, gs) and np.array_equal(part.dst_index[li], gi) and np.array_equal(lv, gv)
+        assert (owned == 1).all()

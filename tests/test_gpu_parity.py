@@ -1328,3 +1328,49 @@ def test_in_tile_accumulation_vs_streaming_pass_and_oracle(Context, orc, hip_lib
         r = orc.icp_run(d["dst"], d["dst_n"] if metric else None, d["src"], p)
         assert np.linalg.norm(Ts[1] - Ts[0]) <= 1e-6, (metric, w_p2p, w_p2pl, steps, np.linalg.norm(Ts[1] - Ts[0]))
         assert np.linalg.norm(Ts[1] - r["T"].astype(np.float64)) <= TOL_T and nc == r["last_ncorr"], (metric, w_p2p, w_p2pl, steps)
+
+
+@pytest.mark.gpu
+def test_slab_partition_two_slabs_on_one_gpu(orc, hip_lib):
+    """SURVEY 8(e) partitioning B with the product engine: two spatial slabs (target slab + halo, owned source points) played
+    on this one GPU, the all-reduce replaced by the sum it computes.  Same correspondences as the unsharded run (count),
+    transform equal to summation round-off, identical on both "ranks"; the device-side guard stays quiet with the default
+    slack and fires when the slack is a thousandth of a cell."""
+    import torch
+
+    from cilantro_amd import distributed
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    n = 400_000
+    d = syn.make_pair(n, perturb=0.5)
+    for w_p2p in (0.0, 0.1):
+        icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+        icp.setPointToPointMetricWeight(w_p2p).setPointToPlaneMetricWeight(1.0)
+        icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+        T1 = icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0).estimate().getTransform()
+        nc1 = icp.last_ncorr_
+        del icp
+        part = distributed.SlabPartition.plan(d["dst"], d["src"], np.eye(4, dtype=np.float32), float(d["max_sq_dist"]), 2)
+        engs = [distributed.HipSlabEngine(part, r, d["dst"], d["dst_n"], d["src"], 0) for r in range(2)]
+        assert sum(e.n_local for e in engs) == n and all(e.ctx.n_target < 0.7 * n for e in engs)
+        p = distributed.default_params(max_iter=8, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+        p.w_p2p, p.w_p2pl = w_p2p, 1.0
+        for e in engs:
+            e.begin(p, np.eye(4, dtype=np.float32), None)
+        for _ in range(8):
+            sums = engs[0].partial_sums().clone() + engs[1].partial_sums()
+            for e in engs:
+                e.apply_sums(sums)
+        (Ta, ita, _, nca), (Tb, itb, _, ncb) = engs[0].state(), engs[1].state()
+        assert np.array_equal(Ta, Tb) and ita == itb == 8 and nca == ncb == nc1
+        assert np.abs(Ta.astype(np.float64) - T1.astype(np.float64)).max() <= 1e-6
+        assert not engs[0].violated() and not engs[1].violated()
+        del engs
+    # the guard: a slack of a thousandth of a cell cannot survive the first update
+    part = distributed.SlabPartition.plan(d["dst"], d["src"], np.eye(4, dtype=np.float32), float(d["max_sq_dist"]), 2, slack=1e-3 * d["h"])
+    eng = distributed.HipSlabEngine(part, 0, d["dst"], d["dst_n"], d["src"], 0)
+    eng.begin(p, np.eye(4, dtype=np.float32), None)
+    s = eng.partial_sums()
+    eng.apply_sums(s * 2.0)                # (any plausible sums: the update moves the source by a fraction of a cell)
+    assert eng.violated()
+    torch.cuda.synchronize()

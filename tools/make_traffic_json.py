@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""HBM traffic per launch of the dominant kernel(s) from a tools/pmc.sh output directory, corrected as calibrated in
+profiles/r02_calibration.txt: on this gfx950 / rocprofv3, FETCH_SIZE counts 128-B fabric requests at 64 B each (every read
+pattern: x2), WRITE_SIZE is exact.  usage: tools/make_traffic_json.py <pmc dir> <kernel substring> [...]  ->  JSON on stdout
+(commit it as profiles/r02_traffic.json: bench.py quotes it only while the kernel sources still hash to `source_hash`)."""
+import collections, csv, glob, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_hash)
+
+d, subs = sys.argv[1], sys.argv[2:]
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{d}/*/**/*_counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if any(s in r["Kernel_Name"] for s in subs) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+per = {}
+tot = 0.0
+for k, c in vals.items():
+    f = sum(c["FETCH_SIZE"][3:]) / max(len(c["FETCH_SIZE"][3:]), 1) * 1024.0      # KB -> B, warm-up launches dropped
+    w = sum(c["WRITE_SIZE"][3:]) / max(len(c["WRITE_SIZE"][3:]), 1) * 1024.0
+    per[k] = {"FETCH_SIZE_bytes_reported": f, "WRITE_SIZE_bytes": w, "hbm_bytes": 2.0 * f + w, "launches": len(c["FETCH_SIZE"])}
+    tot += 2.0 * f + w
+line = json.loads(open(f"{d}/bench_line.json").read()) if os.path.exists(f"{d}/bench_line.json") else {}
+cfg = line.get("config", {})
+print(json.dumps({"traffic_bytes_per_launch": tot, "kernels": per, "source_hash": bench.source_hash(),
+                  "fused": "accumulation inside the tile" in (line.get("roofline") or {}).get("kernel", ""),
+                  "workload": {"n_target": cfg.get("n_target"), "n_source_per_gpu": cfg.get("n_source_per_gpu"),
+                               "metric": "p2plane" if "point-to-plane" in cfg.get("workload", "") else ("p2p" if "point-to-point" in cfg.get("workload", "") else "combined")},
+                  "method": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline`; "
+                            "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (profiles/r02_calibration.txt: FETCH_SIZE reports half of the 128-B-line bytes for every read pattern, WRITE_SIZE is exact)"},
+                 indent=1))
