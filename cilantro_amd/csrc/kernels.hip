@@ -1225,6 +1225,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   // (queue base and capacity are re-derived from the LDS row table where needed rather than kept in registers across
   //  the search: P = rowbase[rows], block-uniform)
   uint32_t mpos[TILE_QPT];   // per query: sorted-target position of the match (NONE: none / not settled here)
+  uint32_t mbl = 0;          // (accumulating form) the matches' LDS indices, 16 bits each: the matched points are read from the staged tile
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
     const bool active = (flags >> u) & 1u, fast = (flags >> (8 + u)) & 1u;
@@ -1268,26 +1269,36 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
     mpos[u] = (unproven | defer) ? NONE_U32 : best.pos;
+    if (ACC != IM_NONE) mbl |= (bl & 0xFFFFu) << (16 * u);      // (bl < TILE_CAP + 8 < 2^16; NONE's low bits are never used: mpos says so)
     flags |= (unproven ? (1u << (16 + u)) : 0u) | (defer ? (1u << (24 + u)) : 0u);
   }
-  // (ACC) What the accumulation needs for the queries settled above is requested NOW, before the barrier: the query again
-  // (not kept in registers through the search), the matched point and its normal -- the loads fly while the slower waves
-  // of the tile finish their searches (a barrier does not wait for outstanding loads).
-  float4 s4t[TILE_QPT], p4t[TILE_QPT], n4t[TILE_QPT];
-  auto request_pairs = [&]() {
+  // (ACC) What the accumulation needs for the queries settled above is fetched NOW, before the barrier: the matched normal
+  // (the one gather from HBM), the matched point out of the staged tile, and the lane's FIRST query again (the last one is
+  // still in registers; the first is not kept alive through the second search) -- the loads fly while the slower waves of
+  // the tile finish their searches (a barrier does not wait for outstanding loads).
+  float4 p4t[TILE_QPT], n4t[TILE_QPT];
+  float qt[TILE_QPT][3];
+  if (ACC != IM_NONE) {
+    static_assert(TILE_QPT == 2, "the tail keeps the LAST query of a lane in registers and fetches the first one again");
 #pragma unroll
     for (int u = 0; u < TILE_QPT; ++u) {
-      uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
-      asm volatile("" : "+v"(i));       // (a fresh load: do not keep the kernel-start copy of the query alive through the search)
-      s4t[u] = p4t[u] = n4t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      p4t[u] = n4t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      qt[u][0] = qt[u][1] = qt[u][2] = 0.0f;
       if (mpos[u] != NONE_U32) {
-        s4t[u] = a.src[i];
-        p4t[u] = g.pts[mpos[u]];
-        if (FusedZ<ACC>::needs_normal) n4t[u] = g.nrm[mpos[u]];
+        if (FusedZ<ACC>::needs_normal) n4t[u] = g.nrm[mpos[u]];                 // the one gather from HBM
+        const float4 r = lpts[(mbl >> (16 * u)) & 0xFFFFu];                     // LDS record {x, y, index, z}
+        p4t[u] = make_float4(r.x, r.y, r.w, 0.f);
+        if (u == TILE_QPT - 1) {
+          qt[u][0] = oq[u].qx; qt[u][1] = oq[u].qy; qt[u][2] = oq[u].qz;        // searched last: still in registers
+        } else {
+          uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+          asm volatile("" : "+v"(i));   // (a fresh load: do not keep the kernel-start copy of the query alive through the search)
+          const float4 s4r = a.src[i];
+          transform_point(T, s4r.x, s4r.y, s4r.z, qt[u][0], qt[u][1], qt[u][2]);
+        }
       }
     }
-  };
-  if (ACC != IM_NONE) request_pairs();
+  }
   __syncthreads();
   // 3b (search-only form): the queued queries, densely packed over the lanes: the full 3x3x3 block in straight-line code.
   // The query is fetched and transformed again.  Results go through nn_pos (DEFER_MARK: not proven either) and the
@@ -1366,17 +1377,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     constexpr int NC = FusedZ<ACC>::NC;
     constexpr bool DUAL = NC <= 8;        // two groups of 4 correspondences per instruction: rows/cols 0-7 and 8-15
     float z[TILE_QPT][16];
-    {
-      float Tq[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) Tq[k] = tform_lds[k];
-#pragma unroll
-      for (int u = 0; u < TILE_QPT; ++u) {
-        float qx, qy, qz;
-        transform_point(Tq, s4t[u].x, s4t[u].y, s4t[u].z, qx, qy, qz);
-        fused_z<ACC>(mpos[u] != NONE_U32, qx, qy, qz, p4t[u], n4t[u], a.dst_mean, st->smt, z[u]);
-      }
-    }
+    for (int u = 0; u < TILE_QPT; ++u) fused_z<ACC>(mpos[u] != NONE_U32, qt[u][0], qt[u][1], qt[u][2], p4t[u], n4t[u], a.dst_mean, st->smt, z[u]);
     PHASE_CLK(4);
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
