@@ -241,7 +241,8 @@ def bench_icp(a, torch, rank, world, local_rank):
         loop_ms, _, launches = ctx.last_timing()
         search_ms, acc_ms = ctx.last_timing2()
         ns_l, nd_l, nc = len(src_l), len(dst_l), int(res.last_ncorr)
-        fused = acc_ms == 0.0 and launches > 0
+        one_pass_iters, two_pass_iters = ctx.last_run_forms()
+        fused = (launches > 0 and acc_ms == 0.0) if sharded else (launches > 0 and two_pass_iters == 0 and one_pass_iters > 0)
         # Algorithmic (compulsory) bytes, SURVEY.md 8(d): every datum touched once.
         #   search + accumulation in ONE pass (the default: no index round trip):  12 Ns + 12 Nd + 12 Nc (the matched normals;
         #   point-to-point: the matched points are part of the 12 Nd)
@@ -293,6 +294,7 @@ def bench_icp(a, torch, rank, world, local_rank):
                        "grid": [gi.nx, gi.ny, gi.nz], "grid_cell": gi.cell, "grid_avg_occupancy": gi.avg_occupancy},
             "setup_ms": t_setup * 1e3, "source_sort_ms": sort_ms, "loop_ms_hip_events": loop_ms,
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,
+            "iterations_one_pass": one_pass_iters if not sharded else None, "iterations_two_pass": two_pass_iters if not sharded else None,
             "roofline": roof,
         }
     if not sharded and not a.no_extras:
@@ -322,6 +324,7 @@ def bench_icp(a, torch, rank, world, local_rank):
             ctx.synchronize(); tc = (time.perf_counter() - t0) * 1e3
             Tc = np.array(rc.T[:], np.float32).reshape(4, 4).T
             extras["converging_run"] = {"perturbation_h": 0.8, "conv_tol": 1e-5, "iterations": int(rc.iterations), "ms_total_incl_sort": tc,
+                                        "iterations_one_pass_two_pass": list(ctx.last_run_forms()),
                                         "ms_per_iteration": tc / max(int(rc.iterations), 1), "T_err_vs_truth_frobenius": float(np.linalg.norm(Tc - dc["T_true"]))}
             p.conv_tol = 0.0
         except Exception as e:

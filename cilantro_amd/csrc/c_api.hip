@@ -47,6 +47,13 @@ struct cilhip_ctx {
   float tile_axes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long* d_defer_mask = nullptr;  // [ntiles * 32] queries the tiles hand to the clean-up pass (bit masks, rewritten by every search)
   uint32_t* d_defer_flag = nullptr;            // [1] "some tile deferred a query" (reset before, set by, every tiled search)
+  uint32_t* d_unproven = nullptr;              // [64] queries the tiles' first stage did not prove (summed / zeroed by the epilogue)
+  Feedback* h_feedback = nullptr;              // pinned, host-coherent: what the epilogue kernel publishes after every iteration (pacing, kernel form)
+  Feedback* d_feedback = nullptr;              // the device's address of it
+  unsigned int run_tag = 0;
+  bool far_mode = true;                        // tiled ICP loop: the source is far from alignment (many unproven octant searches): search and
+                                               // accumulate in two passes (the search's 3x3x3 pass settles them in LDS) instead of one
+  int last_fused_iters = 0, last_two_pass_iters = 0;
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint32_t ntiles = 0;
   int tiled = 1;                  // 0: per-lane global-memory search; 1: LDS-tiled search when the cloud is large enough; 2: always tiled
@@ -66,6 +73,7 @@ struct cilhip_ctx {
   int partial_blocks = 0;
   double* d_stage = nullptr;      // [REDUCE_STAGE_DOUBLES] stage-1 rows of the cross-block reduction
   double* d_sums = nullptr;       // [3 * SUMS_MAX] (the affine estimator reduces three passes before one copy to the host)
+  bool tile_acc_adaptive = true;  // choose one pass / two passes per iteration from the device's feedback (option "tile_accumulation" = 2: always one pass)
   bool tile_acc = true;           // accumulate inside the LDS tiles of the search when the engine allows it (option "tile_accumulation", A/B)
   bool fused = false;             // true: search+accumulate in one kernel; false: search kernel + streaming accumulate kernel (faster: the search runs at 2x the occupancy)
   double cell_occupancy = 1.0;    // target points per grid cell (takes effect at the next set_target)
@@ -102,7 +110,8 @@ struct cilhip_ctx {
   double last_loop_ms = 0.0, last_search_ms = 0.0, last_acc_ms = 0.0;
   int last_search_launches = 0;
   size_t run_nev = 0;             // sharded runs: hipEvents recorded by cilhip_icp_partial_sums since cilhip_icp_begin (3 per call)
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> ev, ev_acc;
+
 };
 
 #define CK(ctx, call)                                                                                   \
@@ -139,6 +148,9 @@ int cilhip_create(cilhip_ctx** out, int device) {
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&c->d_defer_flag, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_defer_flag, 0, sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&c->d_unproven, 64 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_unproven, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
+      hipHostMalloc(&c->h_feedback, sizeof(Feedback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_feedback), c->h_feedback, 0) != hipSuccess ||
       hipMalloc(&c->d_stage, REDUCE_STAGE_DOUBLES * sizeof(double)) != hipSuccess || hipMalloc(&c->d_sums, 3 * SUMS_MAX * sizeof(double)) != hipSuccess) {
     delete c;
     return CILHIP_ERR_HIP;
@@ -170,6 +182,7 @@ static void free_source(cilhip_ctx* c) {
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
   c->have_pairs = false; c->pairs.count = 0;   // a pair list refers to the source / target it was found on
+  c->far_mode = true;
 }
 
 void cilhip_destroy(cilhip_ctx* c) {
@@ -188,9 +201,13 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   if (c->d_defer_flag) (void)hipFree(c->d_defer_flag);
+  if (c->d_unproven) (void)hipFree(c->d_unproven);
+  if (c->h_feedback) (void)hipHostFree(c->h_feedback);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_sums) (void)hipFree(c->d_sums);
   for (auto e : c->ev) (void)hipEventDestroy(e);
+  for (auto e : c->ev_acc) (void)hipEventDestroy(e);
+
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -218,7 +235,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
-  if (!strcmp(key, "tile_accumulation")) { c->tile_acc = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "tile_accumulation")) { c->tile_acc = value != 0.0; c->tile_acc_adaptive = value != 2.0; return CILHIP_OK; }
   if (!strcmp(key, "search_direction")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "search_direction: 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH");
     c->search_dir = (int)value; c->have_nn = false; c->have_pairs = false;
@@ -263,6 +280,13 @@ int cilhip_get_last_timing2(cilhip_ctx* c, double* search_ms, double* accumulate
   return CILHIP_OK;
 }
 
+int cilhip_get_last_run_forms(cilhip_ctx* c, int* one_pass_iterations, int* two_pass_iterations) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (one_pass_iterations) *one_pass_iterations = c->last_fused_iters;
+  if (two_pass_iterations) *two_pass_iterations = c->last_two_pass_iters;
+  return CILHIP_OK;
+}
+
 int cilhip_enable_kernel_timing(cilhip_ctx* c, int on) {
   if (!c) return CILHIP_ERR_INVALID;
   c->kernel_timing = on != 0;
@@ -302,6 +326,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   c->src_sorted = false;  // source order is tied to the target grid
   c->have_nn = false;
   c->have_pairs = false; c->pairs.count = 0;
+  c->far_mode = true;
   c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return CILHIP_OK;
 }
@@ -475,6 +500,7 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.defer_mask = c->d_defer_mask;
   a.tile_partials = c->d_partials;            // (in-tile accumulation: tile rows first, then the clean-up pass's rows)
   a.defer_flag = c->d_defer_flag;
+  a.unproven_cnt = c->d_unproven;
   a.store_matches = 1;
   a.skip_if_inner_done = 0;
   return a;
@@ -724,6 +750,7 @@ int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t ma
 }
 
 static hipEvent_t get_event(cilhip_ctx* c, size_t i);
+static hipEvent_t get_acc_event(cilhip_ctx* c, size_t i);
 
 // ---- affine variants: SimpleCombinedMetricAffineICP3f / SimplePointToPointMetricAffineICP3f ---------------------------
 // Moments of the 12-unknown normal equations over the stored correspondences (matches or pair list), three streaming
@@ -873,10 +900,16 @@ static SolveArgs make_solve_args(cilhip_ctx* c, const cilhip_icp_params* p, int 
   for (int i = 0; i < 3; ++i) { sa.dst_mean[i] = c->dst_mean[i]; sa.src_mean[i] = src_mean[i]; }
   sa.gn_last_step = 1;
   sa.has_normals = c->has_normals ? 1 : 0;
+  sa.unproven_cnt = c->d_unproven;
   sa.guard_axis = c->guard_axis; sa.guard_slack = c->guard_slack;
   for (int i = 0; i < 3; ++i) { sa.guard_center[i] = c->guard_center[i]; sa.guard_half[i] = c->guard_half[i]; }
   for (int i = 0; i < 16; ++i) sa.guard_T[i] = c->guard_T[i];
   return sa;
+}
+
+static hipEvent_t get_acc_event(cilhip_ctx* c, size_t i) {
+  while (c->ev_acc.size() <= i) { hipEvent_t e; (void)hipEventCreate(&e); c->ev_acc.push_back(e); }
+  return c->ev_acc[i];
 }
 
 static hipEvent_t get_event(cilhip_ctx* c, size_t i) {
@@ -909,9 +942,11 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   const int im = iter_metric_of(c, p);
   const bool gn = (im != IM_KABSCH);
   const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 0) : 1;
-  launch_init_state(c->d_state, Ti, c->src_mean, c->stream);
+  ++c->run_tag;
+  launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag);
   IterArgs a = make_iter_args(c, p->max_sq_dist);
   SolveArgs sa = make_solve_args(c, p, im, c->src_mean);
+  sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;
   const int nb = sa.nblocks;
   if (c->ns == 0) {  // no source points: the epilogue runs on all-zero sums (identity step)
     CK(c, hipMemsetAsync(c->d_sums, 0, SUMS_MAX * sizeof(double), c->stream));
@@ -973,9 +1008,38 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   const bool timing = c->kernel_timing && p->max_iter <= 4096;
   hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
   CK(c, hipEventRecord(e_beg, c->stream));
-  size_t nev = 2;
+  size_t nev = 2, nacc = 0;
   int launches = 0;
+  // Tiled runs are PACED: the host stays at most two iterations ahead of the device and looks at the loop state of
+  // iteration it - 2 before it enqueues iteration it (a pinned copy + an event per iteration; the device never waits: an
+  // iteration takes hundreds of microseconds, the look a few).  That buys (1) no launches after convergence and (2) the
+  // choice of the kernel FORM per iteration: while the octant stage leaves many queries unproven (source far from
+  // alignment: first iterations of a registration) the search runs with its in-LDS 3x3x3 second pass and a separate
+  // streaming accumulation; once nearly all are proven, search + accumulation run as one pass inside the tiles.
+  const bool paced = tile_acc && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
+  if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
+  c->last_fused_iters = c->last_two_pass_iters = 0;
   for (size_t it = 0; it < p->max_iter; ++it) {
+    if (paced && it >= 2) {
+      // wait (briefly, if at all) until iteration it - 2 has been published
+      volatile Feedback* fb = c->h_feedback;
+      const auto t_wait = std::chrono::steady_clock::now();
+      bool stop = false;
+      for (unsigned spins = 0;; ++spins) {
+        const unsigned long long cm = fb->commit;
+        if ((unsigned int)(cm >> 32) == c->run_tag) {
+          if (fb->done) { stop = true; break; }
+          if ((unsigned int)cm >= (unsigned int)(it - 1)) break;
+        }
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(30)) {
+          CK(c, hipStreamSynchronize(c->stream));       // (surfaces a device fault, if that is why nothing arrives)
+          return fail(c, CILHIP_ERR_HIP, "icp_run: the device stopped publishing its loop state");
+        }
+      }
+      if (stop) break;
+      c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
+    }
+    const bool one_pass = tile_acc && !c->far_mode;
     if (gn && opt_steps == 0) {
       // max_optimization_iterations_ == 0: estimateTransformCombinedMetric leaves tform = identity
       // and still un-centres it (:365): handled by an epilogue with zero weights is NOT identical, so
@@ -988,7 +1052,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (c->ns) {
         if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
-        } else if (st == 0 && tile_acc) {
+        } else if (st == 0 && one_pass) {
           // search + accumulation of the first Gauss-Newton step inside the LDS tiles (one pass; the matches are only
           // stored when further Gauss-Newton steps will stream over them)
           IterArgs fa = a;
@@ -998,16 +1062,23 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         } else if (st == 0) {
           { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
-          if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_event(c, nev++), c->stream)); }
+          if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
         } else {
           launch_iter(a, im, false, false, nb, c->stream);
         }
       }
-      if (timing && st == 0) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); ++launches; }
+      if (timing && st == 0) {
+        // (two events per iteration around the search / one-pass kernels; a two-pass iteration adds a pair around its
+        //  streaming accumulation, kept in a list of its own)
+        if (one_pass || (c->fused && !filters_active(c) && !feat6(c)) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+        else CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream));
+        ++launches;
+      }
+      if (st == 0) { if (one_pass) ++c->last_fused_iters; else ++c->last_two_pass_iters; }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
-        const int prows = (st == 0 && tile_acc) ? tiled_partial_rows(c->ntiles) : nb;
+        const int prows = (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : nb;
         const int rows = launch_reduce_stage1(c->d_partials, prows, c->d_stage, c->stream);
         sa.partials = rows ? c->d_stage : c->d_partials;
         sa.nblocks = rows ? rows : prows;
@@ -1017,7 +1088,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // Long runs ("iterate until converged" with a large max_iter): the kernels of a converged run return at once, but
     // the post-filter / reduction launches do not look at the flag, so look at it from the host now and then and stop
     // enqueueing.  Short runs (the reference's default is 15) stay free of host round trips.
-    if (p->max_iter > 64 && (it + 1) % 32 == 0 && it + 1 < p->max_iter) {
+    if (!paced && p->max_iter > 64 && (it + 1) % 32 == 0 && it + 1 < p->max_iter) {
       int done = 0;
       CK(c, hipMemcpyAsync(&done, reinterpret_cast<const char*>(c->d_state) + offsetof(IcpState, done), sizeof(int), hipMemcpyDeviceToHost, c->stream));
       CK(c, hipStreamSynchronize(c->stream));
@@ -1039,16 +1110,16 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (timing) {
     // only iterations that actually executed (not the early-exit launches after convergence)
     const size_t executed = out->iterations < (size_t)launches ? out->iterations : (size_t)launches;
-    const size_t per = ((c->fused && !filters_active(c) && !feat6(c)) || tile_acc || c->ns == 0) ? 2 : 4;
     c->last_acc_ms = 0.0;
     for (size_t k = 0; k < executed; ++k) {
       float m = 0.f;
-      CK(c, hipEventElapsedTime(&m, c->ev[2 + per * k], c->ev[3 + per * k]));
+      CK(c, hipEventElapsedTime(&m, c->ev[2 + 2 * k], c->ev[3 + 2 * k]));
       c->last_search_ms += m;
-      if (per == 4) {
-        CK(c, hipEventElapsedTime(&m, c->ev[4 + per * k], c->ev[5 + per * k]));
-        c->last_acc_ms += m;
-      }
+    }
+    for (size_t k = 0; k + 1 < nacc; k += 2) {      // (two-pass iterations; those enqueued past convergence measure ~0)
+      float m = 0.f;
+      CK(c, hipEventElapsedTime(&m, c->ev_acc[k], c->ev_acc[k + 1]));
+      c->last_acc_ms += m;
     }
     c->last_search_launches = (int)executed;
   }

@@ -66,7 +66,7 @@ struct IcpState {
   double dtd[3];
   double sums[SUMS_MAX];  // reduced sums of the last accumulation
   int slab_violation;     // spatially sharded runs: some source point may have left its slab's halo since the partition (sticky)
-  int pad1;
+  unsigned int unproven;  // tiled search of the last iteration: queries its first stage (the octant block) did not prove
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -90,6 +90,7 @@ struct IterArgs {
   unsigned long long* defer_mask;  // [ntiles * 2 * (TILE_THREADS / 64)] tiled search: queries handed to its clean-up pass, one word per wave and query slot
   double* tile_partials;   // [ntiles * SUMS_MAX] tiled search with in-tile accumulation: one row of partial sums per tile (followed by the clean-up pass's rows)
   uint32_t* defer_flag;    // [1] set by a tile that defers a query: the clean-up pass has work
+  uint32_t* unproven_cnt;  // [64] (spread by tile index) queries the octant block did not prove: how far the source is from alignment
   int store_matches;       // tiled search: also write nn_pos / nn_d2 for the queries settled inside the tile (the pure ICP loop needs neither)
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
@@ -109,7 +110,17 @@ struct BoxArgs {
   int trim;
 };
 
+// Loop state the device publishes to the host after every iteration (pinned, host-coherent memory the epilogue kernel
+// writes directly: no copy engine, no event): payload first, then -- after a system-scope fence -- the commit word.
+struct Feedback {
+  unsigned int done;            // converged
+  unsigned int unproven;        // IcpState::unproven of that iteration
+  unsigned long long commit;    // (run tag << 32) | iterations performed
+};
+
 struct SolveArgs {
+  Feedback* feedback;      // device-visible address of the host's Feedback (or null)
+  unsigned int run_tag;
   IcpState* state;
   const double* partials;
   int nblocks;             // 0: sums already reduced in `reduced`
@@ -124,6 +135,7 @@ struct SolveArgs {
   // epilogue bounds how far ANY source point (global bounding box of the source, in source coordinates) can have moved
   // along the slab axis since the partition was made, and raises IcpState::slab_violation when that exceeds the slack the
   // halos were sized with -- every rank evaluates the same bound on the same values, so all take the same decision
+  uint32_t* unproven_cnt;  // [64] counters of the tiled search, summed into IcpState::unproven and zeroed by the epilogue (or null)
   int guard_axis;          // -1: off
   float guard_slack;
   float guard_center[3], guard_half[3];
@@ -146,7 +158,7 @@ void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_s
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 128 * SUMS_MAX;
-void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s);
+void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb = nullptr, unsigned int run_tag = 0);
 void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
                        const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,
                        hipStream_t s);

@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void defer_whole_tile(const IterArgs& a, uint32_t vb)
   if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
     for (int u = 0; u < TILE_QPT; ++u) a.defer_mask[(size_t)vb * (2 * TILE_WAVES) + u * TILE_WAVES + (threadIdx.x >> 6)] = ~0ull;
-    if (threadIdx.x == 0) atomicOr(a.defer_flag, 1u);
+    if (threadIdx.x == 0) { atomicOr(a.defer_flag, 1u); atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)TILE_QUERIES); }
   }
   if (ACC != IM_NONE && threadIdx.x < SUMS_MAX) a.tile_partials[(size_t)vb * SUMS_MAX + threadIdx.x] = 0.0;
 }
@@ -1247,7 +1247,11 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
       }
     }
-    if (ACC != IM_NONE && unproven) { defer = true; unproven = false; }   // (accumulating form: no second pass in the tile, see 3b)
+    if (ACC != IM_NONE) {   // (accumulating form: no second pass in the tile, see 3b; the unproven ones are only counted)
+      const unsigned long long mu = __ballot(unproven);
+      if (mu != 0ull && (threadIdx.x & 63u) == 0) atomicAdd(&queue_count, (uint32_t)__popcll(mu));
+      if (unproven) { defer = true; unproven = false; }
+    }
     const unsigned long long m = (ACC == IM_NONE) ? __ballot(unproven) : 0ull;
     if (m) {   // one LDS atomic per wave
       const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)m) - 1;
@@ -1306,6 +1310,10 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   // the clean-up pass, which accumulates what it settles -- in a converged registration that is nothing, and the
   // register-hungry 3x3x3 pass between the search and the accumulation would cost every tile its in-flight pair loads
   // (the allocator spills them around it); a source far from its sort-time cells is what the re-sort is for.
+  if (threadIdx.x == 0) {   // what the octant block did not prove, for the host's choice of the next iteration's form
+    const uint32_t cu = queue_count;
+    if (cu != 0u) atomicAdd(a.unproven_cnt + (vb & 63u), cu);
+  }
   uint32_t nqueued = (ACC == IM_NONE) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count) : 0u;   // block-uniform
   if (ACC == IM_NONE) {
     // A queue that cannot hold every unproven query of the tile (a region near the LDS budget AND a source far from its
@@ -1933,6 +1941,14 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   constexpr int ST_DWORDS = (int)(sizeof(IcpState) / 4);
   if (a.state->done) return;
   for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(&lst)[k] = reinterpret_cast<const uint32_t*>(a.state)[k];
+  __shared__ unsigned int unproven_total;
+  if (a.unproven_cnt != nullptr && a.gn_last_step && threadIdx.x < 64) {   // (once per iteration)
+    unsigned int v = a.unproven_cnt[threadIdx.x];
+    a.unproven_cnt[threadIdx.x] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0) unproven_total = v;
+  }
   if (a.nblocks > 0) {
     reduce_partials_block(a.partials, a.nblocks, sums);
   } else {
@@ -1941,6 +1957,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   __syncthreads();
   IcpState* st = &lst;
   if (threadIdx.x == 0) {
+  if (a.unproven_cnt != nullptr && a.gn_last_step) st->unproven = unproven_total;
 
   const double n = sums[0];
   double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
@@ -2011,16 +2028,27 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   }
   __syncthreads();
   for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(a.state)[k] = reinterpret_cast<const uint32_t*>(&lst)[k];
+  if (a.feedback != nullptr && a.gn_last_step && threadIdx.x == 0) {
+    a.feedback->done = (unsigned int)lst.done;
+    a.feedback->unproven = lst.unproven;
+    __threadfence_system();
+    a.feedback->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
+  }
 }
 
 void launch_solve(const SolveArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, a);
 }
 
-struct InitArgs { float T[16]; float src_mean[3]; };
+struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; };
 
 __global__ void k_init_state(IcpState* st, InitArgs ia) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (ia.fb != nullptr) {
+    ia.fb->done = 0u; ia.fb->unproven = 0u;
+    __threadfence_system();
+    ia.fb->commit = (unsigned long long)ia.run_tag << 32;
+  }
   for (int i = 0; i < 16; ++i) st->T[i] = ia.T[i];
   float mx, my, mz;
   transform_point(ia.T, ia.src_mean[0], ia.src_mean[1], ia.src_mean[2], mx, my, mz);
@@ -2030,12 +2058,13 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
   st->done = 0;
   st->ncorr = 0;
   for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = 0.0;
-  st->slab_violation = 0; st->pad1 = 0;
+  st->slab_violation = 0; st->unproven = 0;
   reset_inner(st);
 }
 
-void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s) {
+void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb, unsigned int run_tag) {
   InitArgs ia;
+  ia.fb = fb; ia.run_tag = run_tag;
   for (int i = 0; i < 16; ++i) ia.T[i] = T0[i];
   for (int i = 0; i < 3; ++i) ia.src_mean[i] = src_mean[i];
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, st, ia);

@@ -263,6 +263,12 @@ class Context:
     def set_option(self, key, value):
         self._ck(self._L.cilhip_set_option(self._h, key.encode(), float(value)))
 
+    def last_run_forms(self):
+        """(iterations run as one pass, iterations run as search + streaming accumulation) of the last icp_run"""
+        a = C.c_int(0); b = C.c_int(0)
+        self._ck(self._L.cilhip_get_last_run_forms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def last_timing2(self):
         a = C.c_double(0); b = C.c_double(0)
         self._ck(self._L.cilhip_get_last_timing2(self._h, C.byref(a), C.byref(b)))

@@ -292,6 +292,11 @@ typedef struct {
   double build_ms;       /* last set_target wall time (upload + grid build) */
 } cilhip_grid_info;
 int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
+/* How the iterations of the last cilhip_icp_run were executed: as ONE pass (search with the accumulation inside the LDS
+ * tiles) or as TWO (search with its in-tile 3x3x3 second pass, then the streaming accumulation).  Large clouds choose per
+ * iteration from the device's count of queries the first search stage left unproven (source far from alignment: two passes). */
+int cilhip_get_last_run_forms(cilhip_ctx* ctx, int* one_pass_iterations, int* two_pass_iterations);
+
 /* ms of the kernels of the last cilhip_icp_run, measured with hipEvents on the ctx stream:
  * total loop, and the fused search+accumulate kernel alone (sum over executed iterations). */
 int cilhip_get_last_timing(cilhip_ctx* ctx, double* loop_ms, double* search_kernel_ms,

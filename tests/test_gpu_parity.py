@@ -1283,7 +1283,7 @@ def test_in_tile_accumulation_vs_streaming_pass_and_oracle(Context, orc, hip_lib
         ctxs = {}
         for acc in (0, 1):
             c = Context(0, torch.cuda.current_stream().cuda_stream)
-            c.set_option("tiled", 2); c.set_option("tile_accumulation", acc)
+            c.set_option("tiled", 2); c.set_option("tile_accumulation", 2 * acc)
             c.set_target(dst, nrm); c.set_source(src)
             c.find_correspondences(np.eye(4), max_sq, count=False)       # sort under the identity: T0 is a drift since the sort
             ctxs[acc] = c
@@ -1319,7 +1319,7 @@ def test_in_tile_accumulation_vs_streaming_pass_and_oracle(Context, orc, hip_lib
             else:
                 icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
                 icp.setPointToPointMetricWeight(w_p2p).setPointToPlaneMetricWeight(w_p2pl).setMaxNumberOfOptimizationStepIterations(steps)
-            icp._ctx.set_option("tiled", 2); icp._ctx.set_option("tile_accumulation", acc)
+            icp._ctx.set_option("tiled", 2); icp._ctx.set_option("tile_accumulation", 2 * acc)     # 2: one pass from the first iteration on
             icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
             Ts.append(icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0).estimate().getTransform().astype(np.float64))
             nc = icp.last_ncorr_
@@ -1374,3 +1374,27 @@ def test_slab_partition_two_slabs_on_one_gpu(orc, hip_lib):
     eng.apply_sums(s * 2.0)                # (any plausible sums: the update moves the source by a fraction of a cell)
     assert eng.violated()
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_adaptive_kernel_form_and_pacing(orc, hip_lib):
+    """Large clouds pace the loop on the device's feedback: far from alignment (most octant searches unproven) an iteration
+    runs as search + streaming accumulation, near alignment as one pass inside the tiles, and nothing is enqueued after
+    convergence.  Whatever the mix, the run lands on the oracle's transform with the oracle's iteration count."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    n = 1_200_000
+    d = syn.make_pair(n, perturb=0.9)                         # ~0.9 cell from alignment: the first iterations are "far"
+    icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+    icp.correspondenceSearchEngine().setMaxDistance(d["max_sq_dist"])
+    Tg = icp.setMaxNumberOfIterations(40).setConvergenceTolerance(1e-5).estimate().getTransform()
+    one, two = icp._ctx.last_run_forms()
+    p = orc.make_params(metric=1, max_iter=40, conv_tol=1e-5, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+    r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+    assert icp.getNumberOfPerformedIterations() == r["iterations"] and icp.hasConverged()
+    assert np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64)) <= TOL_T
+    assert two >= 2 and one >= 1, (one, two)                  # both forms ran
+    assert one + two <= r["iterations"] + 2, (one, two, r["iterations"])     # at most two iterations enqueued past convergence
+    # a second run on the same pair starts in the form the first one ended in
+    icp.setMaxNumberOfIterations(3).setConvergenceTolerance(0.0).setInitialTransform(Tg).estimate()
+    assert icp._ctx.last_run_forms() == (3, 0)
