@@ -12,6 +12,8 @@
 // unchanged over a gathered view of that list (one "query" per pair).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <utility>
 
@@ -31,34 +33,152 @@ inline int nblk(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 25
 
 struct TfDev { float m[16]; };
 
-// q (packed xyz, index = sorted-source position) = T * s with the pinned arithmetic of the search kernels
-__global__ void k_transform_sorted(const float4* __restrict__ src_sorted, uint32_t ns, const IcpState* __restrict__ st, float* __restrict__ out) {
+// q (packed xyz, ORIGINAL source order: the grid built over it then carries original indices) = T * s with the pinned
+// arithmetic of the search kernels -- only for transforms that cannot be searched through their inverse
+__global__ void k_transform_original(const float* __restrict__ src_xyz, uint32_t ns, const IcpState* __restrict__ st, float* __restrict__ out) {
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
-    const float4 s = src_sorted[i];
     float qx, qy, qz;
-    transform_point(T, s.x, s.y, s.z, qx, qy, qz);
+    transform_point(T, src_xyz[3 * (size_t)i], src_xyz[3 * (size_t)i + 1], src_xyz[3 * (size_t)i + 2], qx, qy, qz);
     out[3 * (size_t)i] = qx; out[3 * (size_t)i + 1] = qy; out[3 * (size_t)i + 2] = qz;
   }
 }
 
+// ---- reverse search without a per-search index -------------------------------------------------------------------
+// The reference rebuilds a kd-tree over the transformed source q = T s for every FIRST_TO_SECOND / BOTH search
+// (correspondence_search_kd_tree.hpp:188-190, :209-211).  Here the source is indexed ONCE, in its own coordinates
+// (a grid over s, records carrying the ORIGINAL source index), and a target point p is searched through the inverse
+// transform: p' = T^-1 p picks the cells, every candidate is still compared by the pinned d2(p, T s) -- so the result is
+// the exact argmin over the transformed source (ties: lowest original source index) -- and the geometric bounds are
+// mapped back: a point at distance >= D from p' in source space lies at >= smin * D - eps from p in target space
+// (smin = smallest singular value of T's linear part; eps covers the f32 rounding of p' and of T s).
+struct InvArgs {
+  int rigid_on_device;  // the state's transform is a rotation + translation: T^-1 = [L^T | -L^T t] is formed in the kernel (device-resident loops)
+  float Ti[16];       // T^-1 (col-major), computed in f64 on the host
+  float smin;         // lower bound on the smallest singular value of the linear part (slightly shrunk)
+  float eps;          // absolute slack of the mapped bound
+};
+
+__device__ __forceinline__ float mapped_bound(float gap, const InvArgs& iv) { return fmaxf(iv.smin * gap - iv.eps, 0.0f); }
+
+__device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, uint32_t beg, uint32_t end, const float* T, float px, float py, float pz,
+                                               unsigned long long& bkey, uint32_t& bpos) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 4) {
+    uint32_t jj[4];
+    float4 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { jj[k] = min(j + (uint32_t)k, last); c[k] = pts[jj[k]]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float qx, qy, qz;
+      transform_point(T, c[k].x, c[k].y, c[k].z, qx, qy, qz);
+      // nanoflann's L2_Adaptor with the TARGET point as the query and q as the data point: dx = p.x - q.x
+      const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
+      const float e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(c[k].w);
+      if (key < bkey) { bkey = key; bpos = jj[k]; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over the source, source space*/, const float4* __restrict__ dst_sorted, uint32_t nd,
+                                                        const IcpState* __restrict__ st, InvArgs iv, float max_sq, uint32_t* __restrict__ rev_pos,
+                                                        float* __restrict__ rev_d2) {
+  if (st->done) return;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  if (iv.rigid_on_device) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) iv.Ti[c * 4 + r] = T[r * 4 + c];                                   // L^T
+      iv.Ti[12 + r] = -(T[r * 4 + 0] * T[12] + T[r * 4 + 1] * T[13] + T[r * 4 + 2] * T[14]);       // -L^T t
+    }
+    iv.Ti[3] = iv.Ti[7] = iv.Ti[11] = 0.0f; iv.Ti[15] = 1.0f;
+  }
+  const float KS = 0.99999905f;
+  for (uint32_t jd = blockIdx.x * blockDim.x + threadIdx.x; jd < nd; jd += gridDim.x * blockDim.x) {
+    const float4 p = dst_sorted[jd];
+    float sx, sy, sz;
+    transform_point(iv.Ti, p.x, p.y, p.z, sx, sy, sz);
+    unsigned long long bkey = (unsigned long long)__float_as_uint(max_sq) << 32;
+    uint32_t bpos = NONE_U32;
+    const float BIG = 1.0e9f;
+    const int cx = (int)floorf(fminf(fmaxf((sx - sg.ox) * sg.inv_cell, -BIG), BIG));
+    const int cy = (int)floorf(fminf(fmaxf((sy - sg.oy) * sg.inv_cell, -BIG), BIG));
+    const int cz = (int)floorf(fminf(fmaxf((sz - sg.oz) * sg.inv_cell, -BIG), BIG));
+    {  // farther than the radius from the whole source grid: nothing to find
+      const float gx = fmaxf(fmaxf(sg.ox - sx, sx - (sg.ox + (float)sg.nx * sg.cell)) - sg.margin, 0.0f);
+      const float gy = fmaxf(fmaxf(sg.oy - sy, sy - (sg.oy + (float)sg.ny * sg.cell)) - sg.margin, 0.0f);
+      const float gz = fmaxf(fmaxf(sg.oz - sz, sz - (sg.oz + (float)sg.nz * sg.cell)) - sg.margin, 0.0f);
+      const float lb = mapped_bound(sqrtf(gx * gx + gy * gy + gz * gz), iv);
+      if (lb * lb * KS >= max_sq) { rev_pos[jd] = NONE_U32; rev_d2[jd] = max_sq; continue; }
+    }
+    int s = max(0, max(max(-cx, cx - (sg.nx - 1)), max(max(-cy, cy - (sg.ny - 1)), max(-cz, cz - (sg.nz - 1)))));   // first shell that reaches the grid
+    for (;; ++s) {
+      const int z0 = max(cz - s, 0), z1 = min(cz + s, sg.nz - 1);
+      const int y0 = max(cy - s, 0), y1 = min(cy + s, sg.ny - 1);
+      const int xlo = cx - s, xhi = cx + s;
+      for (int z = z0; z <= z1; ++z) {
+        const bool zface = (z == cz - s) || (z == cz + s);
+        const float zl = sg.oz + (float)z * sg.cell;
+        const float gz = fmaxf(fmaxf(zl - sz, sz - (zl + sg.cell)) - sg.margin, 0.0f);
+        for (int y = y0; y <= y1; ++y) {
+          const bool face = zface || (y == cy - s) || (y == cy + s);
+          const float yl = sg.oy + (float)y * sg.cell;
+          const float gy = fmaxf(fmaxf(yl - sy, sy - (yl + sg.cell)) - sg.margin, 0.0f);
+          const float bd = __uint_as_float((uint32_t)(bkey >> 32));
+          {
+            const float lb = mapped_bound(sqrtf(gz * gz + gy * gy), iv);
+            if (lb * lb * KS > bd) continue;
+          }
+          const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
+          if (face) {
+            const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
+            if (xa <= xb) scan_range_inv(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos);
+          } else {
+            if (xlo >= 0 && xlo < sg.nx) scan_range_inv(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos);
+            if (xhi >= 0 && xhi < sg.nx) scan_range_inv(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos);
+          }
+        }
+      }
+      // lower bound (source space) on the distance to anything outside the (2s+1)^3 block and inside the grid
+      float b = INFINITY;
+      if (cx - s > 0) b = fminf(b, sx - (sg.ox + (float)(cx - s) * sg.cell));
+      if (cx + s + 1 < sg.nx) b = fminf(b, (sg.ox + (float)(cx + s + 1) * sg.cell) - sx);
+      if (cy - s > 0) b = fminf(b, sy - (sg.oy + (float)(cy - s) * sg.cell));
+      if (cy + s + 1 < sg.ny) b = fminf(b, (sg.oy + (float)(cy + s + 1) * sg.cell) - sy);
+      if (cz - s > 0) b = fminf(b, sz - (sg.oz + (float)(cz - s) * sg.cell));
+      if (cz + s + 1 < sg.nz) b = fminf(b, (sg.oz + (float)(cz + s + 1) * sg.cell) - sz);
+      if (b == INFINITY) break;  // the block covers the grid: everything scanned
+      const float lb = mapped_bound(b - sg.margin, iv);
+      if (lb > 0.0f && __uint_as_float((uint32_t)(bkey >> 32)) < lb * lb * KS) break;
+    }
+    rev_pos[jd] = bpos;
+    rev_d2[jd] = __uint_as_float((uint32_t)(bkey >> 32));
+  }
+}
+
 // candidate slots [0, nd): reverse matches (target point jd -> nearest transformed source point)
+// (poss = ORIGINAL source index of the pair throughout this file: the pair view is gathered from the original arrays)
 __global__ void k_cand_reverse(const float4* __restrict__ dst_sorted, uint32_t nd, const uint32_t* __restrict__ rev_pos,
-                               const float* __restrict__ rev_d2, const float4* __restrict__ q_sorted /*w = sorted-source position*/,
-                               const float4* __restrict__ src_sorted, unsigned long long* keys, uint32_t* slots, uint32_t* posd, uint32_t* poss,
-                               float* d2) {
+                               const float* __restrict__ rev_d2, const float4* __restrict__ sgrid_pts /*w = original source index*/,
+                               unsigned long long* keys, uint32_t* slots, uint32_t* posd, uint32_t* poss, float* d2) {
   for (uint32_t jd = blockIdx.x * blockDim.x + threadIdx.x; jd < nd; jd += gridDim.x * blockDim.x) {
     const uint32_t rp = rev_pos[jd];
     unsigned long long key = KEY_INVALID;
-    uint32_t sp = NONE_U32;
+    uint32_t so = NONE_U32;
     if (rp != NONE_U32) {
-      sp = __float_as_uint(q_sorted[rp].w);
-      key = ((unsigned long long)__float_as_uint(dst_sorted[jd].w) << 32) | (unsigned long long)__float_as_uint(src_sorted[sp].w);
+      so = __float_as_uint(sgrid_pts[rp].w);
+      key = ((unsigned long long)__float_as_uint(dst_sorted[jd].w) << 32) | (unsigned long long)so;
     }
     keys[jd] = key; slots[jd] = jd;
-    posd[jd] = jd; poss[jd] = sp; d2[jd] = rev_d2[jd];
+    posd[jd] = jd; poss[jd] = so; d2[jd] = rev_d2[jd];
   }
 }
 
@@ -72,7 +192,7 @@ __global__ void k_cand_forward(const float4* __restrict__ dst_sorted, uint32_t n
     keys[t] = pos != NONE_U32 ? (((unsigned long long)__float_as_uint(dst_sorted[pos].w) << 32) | (unsigned long long)__float_as_uint(src_sorted[i].w))
                               : KEY_INVALID;
     slots[t] = t;
-    posd[t] = pos; poss[t] = i; d2[t] = nn_d2[i];
+    posd[t] = pos; poss[t] = __float_as_uint(src_sorted[i].w); d2[t] = nn_d2[i];
   }
 }
 
@@ -123,32 +243,13 @@ __global__ void k_o2o_flags_pairs(const uint32_t* __restrict__ first, const uint
     flags[t] = winner[poss[t]] == (((unsigned long long)__float_as_uint(d2[t]) << 32) | (unsigned long long)first[t]) ? 1u : 0u;
 }
 
-__global__ void k_gather_pair_view(const float4* __restrict__ src_sorted, const float4* __restrict__ src_nrm_sorted, const uint32_t* __restrict__ poss,
+__global__ void k_gather_pair_view(const float* __restrict__ src_xyz, const float* __restrict__ src_nrm, const uint32_t* __restrict__ poss,
                                    uint32_t n, float4* src_view, float4* nrm_view) {
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    const uint32_t sp = poss[t];
-    src_view[t] = src_sorted[sp];
-    if (nrm_view) nrm_view[t] = src_nrm_sorted[sp];
+    const size_t o = poss[t];
+    src_view[t] = make_float4(src_xyz[3 * o], src_xyz[3 * o + 1], src_xyz[3 * o + 2], __uint_as_float((uint32_t)o));
+    if (nrm_view) nrm_view[t] = make_float4(src_nrm[3 * o], src_nrm[3 * o + 1], src_nrm[3 * o + 2], 0.0f);
   }
-}
-
-hipError_t scan_flags(const uint32_t* flags, uint32_t* offs, uint32_t n, uint32_t* total_out, hipStream_t s) {
-  *total_out = 0;
-  if (n == 0) return hipSuccess;
-  size_t tmp_bytes = 0;
-  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
-  void* tmp = nullptr;
-  HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-  hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, flags, offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
-  uint32_t last_off = 0, last_flag = 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(&last_off, offs + (n - 1), 4, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, s);
-  hipError_t e2 = hipStreamSynchronize(s);
-  (void)hipFree(tmp);
-  if (e != hipSuccess) return e;
-  if (e2 != hipSuccess) return e2;
-  *total_out = last_off + last_flag;
-  return hipSuccess;
 }
 
 }  // namespace
@@ -162,11 +263,18 @@ void free_pairs(PairSet& p) {
   if (p.nrm_view) (void)hipFree(p.nrm_view);
   p.d2 = p.d2b = nullptr; p.src_view = p.nrm_view = nullptr;
   p.cap = 0; p.count = 0;
+  for (void*& w : p.ws) { if (w) (void)hipFree(w); w = nullptr; }
+  p.ws_cand = 0; p.ws_tmp_bytes = 0;
 }
 
 static hipError_t ensure_pairs(PairSet& p, size_t cap, bool with_normals) {
   if (cap <= p.cap && (!with_normals || p.nrm_view)) return hipSuccess;
+  void* keep_ws[PairSet::WS_COUNT];
+  for (int k = 0; k < PairSet::WS_COUNT; ++k) { keep_ws[k] = p.ws[k]; p.ws[k] = nullptr; }   // (free_pairs would drop the workspace too)
+  const size_t wc = p.ws_cand, wt = p.ws_tmp_bytes;
   free_pairs(p);
+  for (int k = 0; k < PairSet::WS_COUNT; ++k) p.ws[k] = keep_ws[k];
+  p.ws_cand = wc; p.ws_tmp_bytes = wt;
   const size_t c = cap ? cap : 1;
   uint32_t** u[] = {&p.first, &p.second, &p.posd, &p.poss, &p.first2, &p.second2, &p.posd2, &p.poss2};
   for (auto q : u) HIP_TRY(hipMalloc(q, c * sizeof(uint32_t)));
@@ -178,72 +286,145 @@ static hipError_t ensure_pairs(PairSet& p, size_t cap, bool with_normals) {
   return hipSuccess;
 }
 
+// The workspace of a pair search lives with the pair set: a search allocates nothing once it has run at its size
+// (a dozen hipMalloc / hipFree pairs per search -- each free a device synchronisation -- were a third of its time).
+static hipError_t ensure_ws(PairSet& p, size_t ncand, size_t nd, size_t ns, size_t tmp_bytes) {
+  enum { REV_POS, REV_D2, KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, WINNER, SEL_KEYS, SEL_STATE, TMP };
+  if (ncand > p.ws_cand) {
+    const int cand_slots[] = {KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, SEL_KEYS, REV_POS, REV_D2, WINNER};
+    for (int k : cand_slots) { if (p.ws[k]) (void)hipFree(p.ws[k]); p.ws[k] = nullptr; }
+    const size_t c = ncand;
+    HIP_TRY(hipMalloc(&p.ws[KEYS_IN], c * 8)); HIP_TRY(hipMalloc(&p.ws[KEYS_OUT], c * 8)); HIP_TRY(hipMalloc(&p.ws[SEL_KEYS], c * 8));
+    HIP_TRY(hipMalloc(&p.ws[SLOTS_IN], c * 4)); HIP_TRY(hipMalloc(&p.ws[SLOTS_OUT], c * 4));
+    HIP_TRY(hipMalloc(&p.ws[C_POSD], c * 4)); HIP_TRY(hipMalloc(&p.ws[C_POSS], c * 4)); HIP_TRY(hipMalloc(&p.ws[C_D2], c * 4));
+    HIP_TRY(hipMalloc(&p.ws[FLAGS], c * 4)); HIP_TRY(hipMalloc(&p.ws[OFFS], c * 4));
+    HIP_TRY(hipMalloc(&p.ws[REV_POS], (nd ? nd : 1) * 4)); HIP_TRY(hipMalloc(&p.ws[REV_D2], (nd ? nd : 1) * 4));
+    HIP_TRY(hipMalloc(&p.ws[WINNER], (ns ? ns : 1) * 8));
+    if (!p.ws[SEL_STATE]) HIP_TRY(hipMalloc(&p.ws[SEL_STATE], filter_state_bytes()));
+    p.ws_cand = ncand;
+  }
+  if (tmp_bytes > p.ws_tmp_bytes) {
+    if (p.ws[TMP]) (void)hipFree(p.ws[TMP]);
+    p.ws[TMP] = nullptr;
+    HIP_TRY(hipMalloc(&p.ws[TMP], tmp_bytes));
+    p.ws_tmp_bytes = tmp_bytes;
+  }
+  return hipSuccess;
+}
+
+// exclusive scan of flags into offs; the total comes back to the host (one synchronisation: the next launches are sized by it)
+static hipError_t scan_flags_ws(PairSet& p, const uint32_t* flags, uint32_t* offs, uint32_t n, uint32_t* total_out, hipStream_t s) {
+  *total_out = 0;
+  if (n == 0) return hipSuccess;
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+  HIP_TRY(ensure_ws(p, p.ws_cand, 0, 0, tmp_bytes ? tmp_bytes : 16));
+  HIP_TRY(rocprim::exclusive_scan(p.ws[14], tmp_bytes, flags, offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+  uint32_t last_off = 0, last_flag = 0;
+  HIP_TRY(hipMemcpyAsync(&last_off, offs + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *total_out = last_off + last_flag;
+  return hipSuccess;
+}
+
+static unsigned bits_for_u32(uint32_t n) {
+  unsigned b = 1;
+  while (b < 32 && (1ull << b) < (unsigned long long)n) ++b;
+  return b;
+}
+
 // direction: 1 = FIRST_TO_SECOND, 2 = BOTH.  For BOTH the caller has already run the forward search with the state's
-// transform (fwd_pos / fwd_d2 by sorted-source position).  id_state: a device IcpState holding the identity.
-hipError_t find_pairs(const GridDev& g, const float4* src_sorted, const float4* src_nrm_sorted, uint32_t ns, const IcpState* state,
-                      const IcpState* id_state, float max_sq, int direction, bool reciprocal, double inlier_fraction, bool one_to_one,
-                      const uint32_t* fwd_pos, const float* fwd_d2, PairSet& out, hipStream_t s) {
+// transform (fwd_pos / fwd_d2 by sorted-source position).  sgrid: the grid over the source in SOURCE coordinates (records
+// carry original source indices); T_host: the state's transform.  A transform whose linear part is (nearly) singular
+// cannot be searched through its inverse: then -- and only then -- a grid over the transformed source is built for this
+// one search, as the reference builds its kd-tree.
+hipError_t find_pairs(const GridDev& g, const GridDev& sgrid, const float* d_src_xyz, const float* d_src_nrm, const float4* src_sorted, uint32_t ns,
+                      const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq, int direction, bool reciprocal,
+                      double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2, PairSet& out, hipStream_t s) {
+  enum { REV_POS, REV_D2, KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, WINNER, SEL_KEYS, SEL_STATE, TMP };
   const uint32_t nd = g.n;
   out.count = 0;
   const size_t ncand = (size_t)nd + (direction == 2 ? ns : 0);
-  HIP_TRY(ensure_pairs(out, ncand, src_nrm_sorted != nullptr));
+  HIP_TRY(ensure_pairs(out, ncand, d_src_nrm != nullptr));
   if (nd == 0 || ns == 0) return hipSuccess;   // kd_tree_utilities.hpp:16-19: an empty side gives no correspondences
+  const unsigned end_bit = 32u + bits_for_u32(nd);            // keys = first << 32 | second, first < nd; the invalid key (all ones) still sorts last
+  size_t sort_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ncand, 0u, end_bit, s));
+  HIP_TRY(ensure_ws(out, ncand, nd, ns, sort_bytes ? sort_bytes : 16));
+  uint32_t* rev_pos = (uint32_t*)out.ws[REV_POS]; float* rev_d2 = (float*)out.ws[REV_D2];
+  unsigned long long *keys_in = (unsigned long long*)out.ws[KEYS_IN], *keys_out = (unsigned long long*)out.ws[KEYS_OUT];
+  uint32_t *slots_in = (uint32_t*)out.ws[SLOTS_IN], *slots_out = (uint32_t*)out.ws[SLOTS_OUT], *c_posd = (uint32_t*)out.ws[C_POSD], *c_poss = (uint32_t*)out.ws[C_POSS];
+  float* c_d2 = (float*)out.ws[C_D2];
+  uint32_t *flags = (uint32_t*)out.ws[FLAGS], *offs = (uint32_t*)out.ws[OFFS];
 
-  // 1. q = T*s (sorted-source order) and a grid over it
+  // 1. reverse search: the target points (in their grid order) against the source
+  InvArgs iv{};
+  bool through_inverse = false;
+  {
+    const double a00 = T_host[0], a01 = T_host[4], a02 = T_host[8], a10 = T_host[1], a11 = T_host[5], a12 = T_host[9], a20 = T_host[2], a21 = T_host[6], a22 = T_host[10];
+    const double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+    const double M[9] = {a00 * a00 + a10 * a10 + a20 * a20, a00 * a01 + a10 * a11 + a20 * a21, a00 * a02 + a10 * a12 + a20 * a22,
+                         a00 * a01 + a10 * a11 + a20 * a21, a01 * a01 + a11 * a11 + a21 * a21, a01 * a02 + a11 * a12 + a21 * a22,
+                         a00 * a02 + a10 * a12 + a20 * a22, a01 * a02 + a11 * a12 + a21 * a22, a02 * a02 + a12 * a12 + a22 * a22};   // L^T L
+    double w[3], V[9];
+    sym_eig3(M, w, V);
+    const double wmin = std::min(w[0], std::min(w[1], w[2])), wmax = std::max(w[0], std::max(w[1], w[2]));
+    if (std::isfinite(det) && wmin > 0.0 && wmin > 1e-6 * wmax) {
+      const double id = 1.0 / det, smin = std::sqrt(wmin), smax = std::sqrt(wmax);
+      const double i00 = (a11 * a22 - a12 * a21) * id, i01 = (a02 * a21 - a01 * a22) * id, i02 = (a01 * a12 - a02 * a11) * id;
+      const double i10 = (a12 * a20 - a10 * a22) * id, i11 = (a00 * a22 - a02 * a20) * id, i12 = (a02 * a10 - a00 * a12) * id;
+      const double i20 = (a10 * a21 - a11 * a20) * id, i21 = (a01 * a20 - a00 * a21) * id, i22 = (a00 * a11 - a01 * a10) * id;
+      const double t0 = T_host[12], t1 = T_host[13], t2 = T_host[14];
+      const double inv[16] = {i00, i10, i20, 0, i01, i11, i21, 0, i02, i12, i22, 0,
+                              -(i00 * t0 + i01 * t1 + i02 * t2), -(i10 * t0 + i11 * t1 + i12 * t2), -(i20 * t0 + i21 * t1 + i22 * t2), 1};
+      for (int i = 0; i < 16; ++i) iv.Ti[i] = (float)inv[i];
+      iv.smin = (float)(smin * (1.0 - 1e-5));
+      // |T p' - p| and the rounding of T s: a few f32 ulps of the coordinates involved, through the larger of T and T^-1
+      const double ext_t = std::max({std::fabs((double)g.ox), std::fabs((double)g.oy), std::fabs((double)g.oz)}) + (double)std::max(g.nx, std::max(g.ny, g.nz)) * g.cell;
+      const double ext_s = std::max({std::fabs((double)sgrid.ox), std::fabs((double)sgrid.oy), std::fabs((double)sgrid.oz)}) + (double)std::max(sgrid.nx, std::max(sgrid.ny, sgrid.nz)) * sgrid.cell;
+      const double scale = std::max(ext_t, smax * ext_s) + std::fabs(t0) + std::fabs(t1) + std::fabs(t2);
+      iv.eps = (float)(4e-6 * scale * std::max(1.0, smax / smin));
+      through_inverse = sgrid.pts != nullptr;
+    }
+  }
   float* d_q = nullptr;
   GridBuildResult qg{};
-  uint32_t *rev_pos = nullptr, *slots_in = nullptr, *slots_out = nullptr, *flags = nullptr, *offs = nullptr, *c_posd = nullptr, *c_poss = nullptr;
-  float *rev_d2 = nullptr, *c_d2 = nullptr;
-  unsigned long long *keys_in = nullptr, *keys_out = nullptr, *winner = nullptr, *sel_keys = nullptr;
-  void *tmp = nullptr, *sel_state = nullptr;
   bool have_grid = false;
   hipError_t e = hipSuccess;
   do {
-    if ((e = hipMalloc(&d_q, 3 * (size_t)ns * sizeof(float))) != hipSuccess) break;
-    hipLaunchKernelGGL(k_transform_sorted, dim3(nblk(ns)), dim3(256), 0, s, src_sorted, ns, state, d_q);
-    double mean[3];
-    if ((e = build_grid(d_q, nullptr, ns, s, &qg, mean, 1.0)) != hipSuccess) break;
-    have_grid = true;
-    // 2. reverse search: the target points (in their grid order) against the grid over q
-    if ((e = hipMalloc(&rev_pos, (size_t)nd * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&rev_d2, (size_t)nd * 4)) != hipSuccess) break;
-    IterArgs r{};
-    r.grid = qg.grid; r.src = g.pts; r.src_nrm = nullptr; r.ns = nd; r.max_sq = max_sq; r.state = id_state;
-    r.nn_pos = rev_pos; r.nn_d2 = rev_d2; r.partials = nullptr; r.defer_mask = nullptr; r.tile_partials = nullptr; r.store_matches = 1;
-    r.skip_if_inner_done = 0;
-    launch_iter(r, IM_NONE, true, true, iter_num_blocks(nd), s);
-    // 3. candidates -> keys (original indices) -> sort
-    if ((e = hipMalloc(&keys_in, ncand * 8)) != hipSuccess) break;
-    if ((e = hipMalloc(&keys_out, ncand * 8)) != hipSuccess) break;
-    if ((e = hipMalloc(&slots_in, ncand * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&slots_out, ncand * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&c_posd, ncand * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&c_poss, ncand * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&c_d2, ncand * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&flags, ncand * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&offs, ncand * 4)) != hipSuccess) break;
-    hipLaunchKernelGGL(k_cand_reverse, dim3(nblk(nd)), dim3(256), 0, s, g.pts, nd, rev_pos, rev_d2, qg.grid.pts, src_sorted, keys_in, slots_in, c_posd,
-                       c_poss, c_d2);
+    const float4* cand_pts = sgrid.pts;
+    if (through_inverse) {
+      hipLaunchKernelGGL(k_reverse_search, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2);
+    } else {
+      if ((e = hipMalloc(&d_q, 3 * (size_t)ns * sizeof(float))) != hipSuccess) break;
+      hipLaunchKernelGGL(k_transform_original, dim3(nblk(ns)), dim3(256), 0, s, d_src_xyz, ns, state, d_q);
+      double mean[3];
+      if ((e = build_grid(d_q, nullptr, ns, s, &qg, mean, 1.0)) != hipSuccess) break;
+      have_grid = true;
+      IterArgs r{};
+      r.grid = qg.grid; r.src = g.pts; r.src_nrm = nullptr; r.ns = nd; r.max_sq = max_sq; r.state = id_state;
+      r.nn_pos = rev_pos; r.nn_d2 = rev_d2; r.store_matches = 1;
+      launch_iter(r, IM_NONE, true, true, iter_num_blocks(nd), s);
+      cand_pts = qg.grid.pts;       // (records carry original source indices here too: q was formed in the original order)
+    }
+    // 2. candidates -> keys (original indices) -> sort
+    hipLaunchKernelGGL(k_cand_reverse, dim3(nblk(nd)), dim3(256), 0, s, g.pts, nd, rev_pos, rev_d2, cand_pts, keys_in, slots_in, c_posd, c_poss, c_d2);
     if (direction == 2)
       hipLaunchKernelGGL(k_cand_forward, dim3(nblk(ns)), dim3(256), 0, s, g.pts, nd, src_sorted, ns, fwd_pos, fwd_d2, keys_in, slots_in, c_posd, c_poss,
                          c_d2);
-    size_t tmp_bytes = 0;
-    if ((e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, slots_in, slots_out, ncand, 0u, 64u, s)) != hipSuccess) break;
-    if ((e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16)) != hipSuccess) break;
-    if ((e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, slots_in, slots_out, ncand, 0u, 64u, s)) != hipSuccess) break;
-    // 4. union / intersection / plain, then ordered compaction
+    if ((e = rocprim::radix_sort_pairs(out.ws[TMP], sort_bytes, keys_in, keys_out, slots_in, slots_out, ncand, 0u, end_bit, s)) != hipSuccess) break;
+    // 3. union / intersection / plain, then ordered compaction
     hipLaunchKernelGGL(k_mark, dim3(nblk(ncand)), dim3(256), 0, s, keys_out, (uint32_t)ncand, direction == 2 ? (reciprocal ? 2 : 1) : 0, flags);
     uint32_t m = 0;
-    if ((e = scan_flags(flags, offs, (uint32_t)ncand, &m, s)) != hipSuccess) break;
+    if ((e = scan_flags_ws(out, flags, offs, (uint32_t)ncand, &m, s)) != hipSuccess) break;
     hipLaunchKernelGGL(k_compact_sorted, dim3(nblk(ncand)), dim3(256), 0, s, keys_out, slots_out, flags, offs, (uint32_t)ncand, c_posd, c_poss, c_d2,
                        out.first, out.second, out.posd, out.poss, out.d2);
-    // 5. post-filters on the pair list (correspondence_search_kd_tree.hpp:224-225)
+    // 4. post-filters on the pair list (correspondence_search_kd_tree.hpp:224-225)
     if (m > 0 && inlier_fraction > 0.0 && inlier_fraction < 1.0) {
-      if ((e = hipMalloc(&sel_keys, (size_t)m * 8)) != hipSuccess) break;
-      if ((e = hipMalloc(&sel_state, filter_state_bytes())) != hipSuccess) break;
-      launch_select_fraction(out.d2, m, inlier_fraction, sel_keys, sel_state, flags, s);
+      launch_select_fraction(out.d2, m, inlier_fraction, (unsigned long long*)out.ws[SEL_KEYS], out.ws[SEL_STATE], flags, s);
       uint32_t m2 = 0;
-      if ((e = scan_flags(flags, offs, m, &m2, s)) != hipSuccess) break;
+      if ((e = scan_flags_ws(out, flags, offs, m, &m2, s)) != hipSuccess) break;
       hipLaunchKernelGGL(k_compact_pairs, dim3(nblk(m)), dim3(256), 0, s, flags, offs, m, out.first, out.second, out.posd, out.poss, out.d2, out.first2,
                          out.second2, out.posd2, out.poss2, out.d2b);
       std::swap(out.first, out.first2); std::swap(out.second, out.second2); std::swap(out.posd, out.posd2); std::swap(out.poss, out.poss2);
@@ -251,29 +432,39 @@ hipError_t find_pairs(const GridDev& g, const float4* src_sorted, const float4* 
       m = m2;
     }
     if (m > 0 && one_to_one && direction == 1) {
-      if ((e = hipMalloc(&winner, (size_t)ns * 8)) != hipSuccess) break;
+      unsigned long long* winner = (unsigned long long*)out.ws[WINNER];
       if ((e = hipMemsetAsync(winner, 0xFF, (size_t)ns * 8, s)) != hipSuccess) break;
       hipLaunchKernelGGL(k_o2o_min_pairs, dim3(nblk(m)), dim3(256), 0, s, out.first, out.poss, out.d2, m, winner);
       hipLaunchKernelGGL(k_o2o_flags_pairs, dim3(nblk(m)), dim3(256), 0, s, out.first, out.poss, out.d2, m, winner, flags);
       uint32_t m2 = 0;
-      if ((e = scan_flags(flags, offs, m, &m2, s)) != hipSuccess) break;
+      if ((e = scan_flags_ws(out, flags, offs, m, &m2, s)) != hipSuccess) break;
       hipLaunchKernelGGL(k_compact_pairs, dim3(nblk(m)), dim3(256), 0, s, flags, offs, m, out.first, out.second, out.posd, out.poss, out.d2, out.first2,
                          out.second2, out.posd2, out.poss2, out.d2b);
       std::swap(out.first, out.first2); std::swap(out.second, out.second2); std::swap(out.posd, out.posd2); std::swap(out.poss, out.poss2);
       std::swap(out.d2, out.d2b);
       m = m2;
     }
-    // 6. the view the accumulation kernels stream over: one "query" per pair
+    // 5. the view the accumulation kernels stream over: one "query" per pair
     if (m > 0)
-      hipLaunchKernelGGL(k_gather_pair_view, dim3(nblk(m)), dim3(256), 0, s, src_sorted, src_nrm_sorted, out.poss, m, out.src_view,
-                         src_nrm_sorted ? out.nrm_view : (float4*)nullptr);
-    e = hipStreamSynchronize(s);
+      hipLaunchKernelGGL(k_gather_pair_view, dim3(nblk(m)), dim3(256), 0, s, d_src_xyz, d_src_nrm, out.poss, m, out.src_view,
+                         d_src_nrm ? out.nrm_view : (float4*)nullptr);
+    if (have_grid) e = hipStreamSynchronize(s);      // (the one-off grid is freed below)
     out.count = m;
   } while (0);
   if (have_grid) free_grid(qg.grid);
-  void* frees[] = {d_q, rev_pos, rev_d2, keys_in, keys_out, slots_in, slots_out, c_posd, c_poss, c_d2, flags, offs, tmp, winner, sel_keys, sel_state};
-  for (void* f : frees) if (f) (void)hipFree(f);
+  if (d_q) (void)hipFree(d_q);
   return e;
+}
+
+void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s) {
+  if (g.n == 0) return;
+  InvArgs iv{};
+  iv.rigid_on_device = 1;
+  iv.smin = 1.0f - 1e-4f;        // (the loop's transforms are polar-projected rotations: singular values within ~1e-6 of 1)
+  const double ext_t = std::max({std::fabs((double)g.ox), std::fabs((double)g.oy), std::fabs((double)g.oz)}) + (double)std::max(g.nx, std::max(g.ny, g.nz)) * g.cell;
+  const double ext_s = std::max({std::fabs((double)sgrid.ox), std::fabs((double)sgrid.oy), std::fabs((double)sgrid.oz)}) + (double)std::max(sgrid.nx, std::max(sgrid.ny, sgrid.nz)) * sgrid.cell;
+  iv.eps = (float)(8e-6 * (ext_t + ext_s) + 1e-4 * ext_s);   // rounding of p' and of T s, and |T p' - p| for a linear part up to 1e-4 off orthonormal
+  hipLaunchKernelGGL(k_reverse_search, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2);
 }
 
 }  // namespace cilhip

@@ -95,6 +95,10 @@ struct cilhip_ctx {
   float normal_weight = 0.0f;     // > 0: the correspondence search runs on 6-D point+normal features (PointNormalFeaturesAdaptor)
   bool symmetric = true;          // source normals, when set, also switch the combined metric to the symmetric objective
   PairSet pairs;
+  GridDev src_grid{};             // grid over the source in SOURCE coordinates (built on the first FIRST_TO_SECOND / BOTH search of a source)
+  bool has_src_grid = false;
+  uint32_t *d_rev_pos = nullptr, *d_src_inv = nullptr;   // list-free loops of those directions: reverse matches by target position; original -> sorted source position
+  float* d_rev_d2 = nullptr;
   bool have_pairs = false;        // `pairs` holds the result of the last find_correspondences
   IcpState* d_state_id = nullptr; // a state holding the identity transform (the reverse search transforms nothing)
 
@@ -180,6 +184,8 @@ static void free_source(cilhip_ctx* c) {
   c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_defer_mask = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
+  if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }
+  if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
   c->have_pairs = false; c->pairs.count = 0;   // a pair list refers to the source / target it was found on
   c->far_mode = true;
@@ -202,6 +208,8 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_dbg) (void)hipFree(c->d_dbg);
   if (c->d_defer_flag) (void)hipFree(c->d_defer_flag);
   if (c->d_unproven) (void)hipFree(c->d_unproven);
+  if (c->d_rev_pos) (void)hipFree(c->d_rev_pos);
+  if (c->d_rev_d2) (void)hipFree(c->d_rev_d2);
   if (c->h_feedback) (void)hipHostFree(c->h_feedback);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_sums) (void)hipFree(c->d_sums);
@@ -309,6 +317,8 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (c->has_target) { free_grid(c->grid); c->has_target = false; }
   if (c->d_inv_perm) { (void)hipFree(c->d_inv_perm); c->d_inv_perm = nullptr; }
   if (c->d_winner) { (void)hipFree(c->d_winner); c->d_winner = nullptr; }
+  if (c->d_rev_pos) { (void)hipFree(c->d_rev_pos); c->d_rev_pos = nullptr; }
+  if (c->d_rev_d2) { (void)hipFree(c->d_rev_d2); c->d_rev_d2 = nullptr; }
   float *d_xyz = nullptr, *d_nrm = nullptr;
   int rc = upload(c, xyz, 3 * n, mem, &d_xyz);
   if (rc) return rc;
@@ -417,6 +427,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     }
     CK(c, hipMalloc(&c->d_tile_box, ((size_t)c->ntiles + 1) * 8 * sizeof(int)));
     if (c->d_src_nrm) launch_gather_by_w(c->d_src_sorted, c->d_src_nrm, c->ns, c->d_src_nrm_sorted, c->stream);
+    if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
     c->have_nn = false;
@@ -523,7 +534,35 @@ static int launch_search(cilhip_ctx* c, const IterArgs& a) {
 static bool feat6(const cilhip_ctx* c) { return c->normal_weight > 0.0f; }
 
 // Search directions FIRST_TO_SECOND / BOTH with the transform held by c->d_state: fills c->pairs (post-filters included).
-static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq) {
+// the source's own grid (source coordinates) and what else the list-free FIRST_TO_SECOND / BOTH loop needs
+static int ensure_src_grid(cilhip_ctx* c) {
+  if (!c->has_src_grid && c->ns) {
+    // the source indexed once, in its own coordinates (the reference builds a kd-tree over T*src per search): the reverse
+    // searches go through the inverse transform
+    GridBuildResult r{};
+    double mean[3];
+    const hipError_t eg = build_grid(c->d_src_xyz, nullptr, c->ns, c->stream, &r, mean, 1.0);
+    if (eg != hipSuccess) { c->err = std::string("build_grid (source): ") + hipGetErrorString(eg); return CILHIP_ERR_HIP; }
+    c->src_grid = r.grid; c->has_src_grid = true;
+  }
+  return CILHIP_OK;
+}
+
+static int ensure_reverse_buffers(cilhip_ctx* c) {
+  const int rc = ensure_src_grid(c);
+  if (rc) return rc;
+  if (!c->d_rev_pos) {
+    CK(c, hipMalloc(&c->d_rev_pos, (c->grid.n ? c->grid.n : 1) * sizeof(uint32_t)));
+    CK(c, hipMalloc(&c->d_rev_d2, (c->grid.n ? c->grid.n : 1) * sizeof(float)));
+  }
+  if (!c->d_src_inv) {      // original source index -> position in the cube-sorted source (the forward matches are stored by that)
+    CK(c, hipMalloc(&c->d_src_inv, (c->ns ? c->ns : 1) * sizeof(uint32_t)));
+    launch_inv_perm(c->d_src_sorted, c->ns, c->d_src_inv, c->stream);
+  }
+  return CILHIP_OK;
+}
+
+static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq, const float T_host[16]) {
   if (feat6(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for SECOND_TO_FIRST only");
   if (!c->d_state_id) {
     CK(c, hipMalloc(&c->d_state_id, sizeof(IcpState)));
@@ -534,8 +573,10 @@ static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq) {
     if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
   }
-  const hipError_t e = find_pairs(c->grid, c->d_src_sorted, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm_sorted : nullptr, c->ns, c->d_state, c->d_state_id, max_sq,
-                                  c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2, c->pairs, c->stream);
+  { const int grc = ensure_src_grid(c); if (grc) return grc; }
+  const hipError_t e = find_pairs(c->grid, c->src_grid, c->d_src_xyz, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm : nullptr, c->d_src_sorted, c->ns, c->d_state,
+                                  c->d_state_id, T_host, max_sq, c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2,
+                                  c->pairs, c->stream);
   if (e != hipSuccess) { c->err = std::string("find_pairs: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   return CILHIP_OK;
 }
@@ -549,7 +590,7 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   IterArgs a = make_iter_args(c, max_sq);
   if (c->search_dir != 0) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
-    rc = run_pair_search(c, a, max_sq);
+    rc = run_pair_search(c, a, max_sq, T);
     if (rc) return rc;
     memcpy(c->nn_T, T, sizeof(c->nn_T));
     c->have_nn = false;
@@ -960,8 +1001,68 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     if (gn && opt_steps == 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "max_opt_iter == 0 is not supported");
     hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
     CK(c, hipEventRecord(e_beg, c->stream));
+    // Without post-filters the loop needs the SUMS over the correspondence set, not the sorted list: the reverse matches are
+    // found through the inverse of the (rigid) transform against a grid over the source built once, and accumulated where
+    // they are found (BOTH: forward pass + the reverse matches that are not reciprocal duplicates; reciprocal: the
+    // duplicates alone) -- no per-iteration index, no sort, no host round trip: every iteration is enqueued back to back.
+    bool t0_rigid = true;
+    for (int i = 0; i < 3 && t0_rigid; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const double dot = (double)Ti[i * 4] * Ti[j * 4] + (double)Ti[i * 4 + 1] * Ti[j * 4 + 1] + (double)Ti[i * 4 + 2] * Ti[j * 4 + 2];
+        if (std::fabs(dot - (i == j ? 1.0 : 0.0)) > 1e-5) t0_rigid = false;
+      }
+    if (!filters_active(c) && !(c->d_src_nrm && c->symmetric) && t0_rigid && c->ns && c->grid.n) {
+      rc = ensure_reverse_buffers(c);
+      if (rc) return rc;
+      const int nb_f = iter_num_blocks(c->ns), nb_r = iter_num_blocks(c->grid.n);
+      if (nb_f + nb_r > c->partial_blocks) {
+        if (c->d_partials) (void)hipFree(c->d_partials);
+        c->d_partials = nullptr; c->partial_blocks = 0;
+        CK(c, hipMalloc(&c->d_partials, (size_t)(nb_f + nb_r) * SUMS_MAX * sizeof(double)));
+        c->partial_blocks = nb_f + nb_r;
+        a.partials = c->d_partials; a.tile_partials = c->d_partials;
+      }
+      const bool both_union = c->search_dir == 2 && !c->reciprocal;
+      const int rmode = c->search_dir == 1 ? 1 : (c->reciprocal ? 3 : 2);
+      IterArgs ar = a;
+      ar.partials = c->d_partials + (both_union ? (size_t)nb_f * SUMS_MAX : 0);
+      const int rows_total = both_union ? nb_f + nb_r : nb_r;
+      a.nn_d2 = nullptr;
+      for (size_t it = 0; it < p->max_iter; ++it) {
+        for (size_t st = 0; st < opt_steps; ++st) {
+          a.skip_if_inner_done = ar.skip_if_inner_done = (st > 0);
+          if (st == 0) {
+            if (c->search_dir == 2) { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
+            launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream);
+          }
+          if (both_union) launch_iter(a, im, false, false, nb_f, c->stream);
+          launch_acc_reverse(ar, im, c->src_grid.pts, c->d_rev_pos, c->grid.n, rmode, c->d_nn_pos, c->d_src_inv, nb_r, c->stream);
+          sa.gn_last_step = (st + 1 == opt_steps);
+          const int rows = launch_reduce_stage1(c->d_partials, rows_total, c->d_stage, c->stream);
+          sa.partials = rows ? c->d_stage : c->d_partials;
+          sa.nblocks = rows ? rows : rows_total;
+          sa.reduced = nullptr;
+          launch_solve(sa, c->stream);
+        }
+        if (p->max_iter > 64 && (it + 1) % 32 == 0 && it + 1 < p->max_iter) {     // (long runs: stop enqueueing once converged)
+          int done = 0;
+          CK(c, hipMemcpyAsync(&done, reinterpret_cast<const char*>(c->d_state) + offsetof(IcpState, done), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+          CK(c, hipStreamSynchronize(c->stream));
+          if (done) break;
+        }
+      }
+      CK(c, hipEventRecord(e_end, c->stream));
+      CK(c, hipGetLastError());
+      rc = read_state(c, out);
+      if (rc) return rc;
+      c->have_nn = false; c->have_pairs = false;
+      float ms = 0.f;
+      CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
+      c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
+      return CILHIP_OK;
+    }
     for (size_t it = 0; it < p->max_iter; ++it) {
-      rc = run_pair_search(c, a, p->max_sq_dist);
+      rc = run_pair_search(c, a, p->max_sq_dist, it == 0 ? Ti : out->T);
       if (rc) return rc;
       IterArgs pa = a;
       pa.src = c->pairs.src_view; pa.src_nrm = (c->d_src_nrm && c->symmetric) ? c->pairs.nrm_view : nullptr; pa.ns = c->pairs.count; pa.nn_pos = c->pairs.posd;

@@ -171,6 +171,10 @@ void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStr
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
 void launch_residuals(const IterArgs& a, int metric, float w_p2p, float w_p2pl, float* out, hipStream_t s);
 int iter_num_blocks(uint32_t ns);
+// accumulation over reverse matches (FIRST_TO_SECOND / BOTH loops without post-filters): element i = target sorted position i,
+// rev_pos[i] = position of its match in the source's own grid; mode 1: all, 2: not the reciprocal duplicates, 3: only those
+void launch_acc_reverse(const IterArgs& a, int metric, const float4* sgrid_pts, const uint32_t* rev_pos, uint32_t nd, int mode, const uint32_t* fwd_pos,
+                        const uint32_t* src_inv, int nblocks, hipStream_t s);
 
 // filters.hip
 void launch_filter_fraction(const float4* src_sorted, uint32_t* nn_pos, const float* nn_d2, uint32_t ns, double fraction,
@@ -190,11 +194,19 @@ struct PairSet {
   float4 *src_view = nullptr, *nrm_view = nullptr;   // sorted-source records (and normals) gathered per pair: what the accumulation streams over
   size_t cap = 0;
   uint32_t count = 0;
+  // workspace of find_pairs (reverse matches, sort keys / slots, flags, scan temporaries ...): allocated once per size
+  static constexpr int WS_COUNT = 15;
+  void* ws[WS_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t ws_cand = 0, ws_tmp_bytes = 0;
 };
 void free_pairs(PairSet& p);
-hipError_t find_pairs(const GridDev& g, const float4* src_sorted, const float4* src_nrm_sorted, uint32_t ns, const IcpState* state,
-                      const IcpState* id_state, float max_sq, int direction, bool reciprocal, double inlier_fraction, bool one_to_one,
-                      const uint32_t* fwd_pos, const float* fwd_d2, PairSet& out, hipStream_t s);
+// the reverse search of those directions alone (every target point against the source, through the inverse of the state's
+// rigid transform computed on the device): rev_pos / rev_d2 [nd] by target sorted position
+void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s);
+hipError_t find_pairs(const GridDev& g, const GridDev& src_grid /*over the source, SOURCE coordinates*/, const float* d_src_xyz, const float* d_src_nrm,
+                      const float4* src_sorted, uint32_t ns, const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq,
+                      int direction, bool reciprocal, double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2,
+                      PairSet& out, hipStream_t s);
 
 // grid_build.hip
 struct GridBuildResult {

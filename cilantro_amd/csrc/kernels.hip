@@ -1828,6 +1828,89 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
   }
 }
 
+// ---- accumulation over REVERSE matches (search directions FIRST_TO_SECOND / BOTH without post-filters) ----------------
+// The pair list of those directions (bidir.hip: sort, union / intersection, ordered compaction) is what a caller of
+// getCorrespondences() sees; the ICP loop only needs its SUMS, and a sum does not care about the list's order: the
+// reverse matches are accumulated where they are found -- element i = target point at sorted position i (read in order),
+// its match = a record of the source's own grid (gathered; neighbours match neighbours) -- and BOTH is the forward pass
+// plus the reverse matches that are not reciprocal duplicates (mode 2), its reciprocal form the duplicates alone (mode 3).
+// A reverse match (target i -> source s) duplicates a forward one iff the forward match of s is i.
+template <int METRIC>
+__global__ __launch_bounds__(ITER_THREADS) void k_acc_reverse(IterArgs a, const float4* __restrict__ sgrid_pts, const uint32_t* __restrict__ rev_pos, uint32_t nd,
+                                                              int mode, const uint32_t* __restrict__ fwd_pos, const uint32_t* __restrict__ src_inv) {
+  using TR = AccTraits<METRIC>;
+  const IcpState* __restrict__ st = a.state;
+  if (st->done) return;
+  if (a.skip_if_inner_done && st->inner_done) return;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = st->T[i];
+  float iL[9], it[3], smt[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) iL[i] = st->innerL[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { it[i] = st->innert[i]; smt[i] = st->smt[i]; }
+  const float dmean[3] = {a.dst_mean[0], a.dst_mean[1], a.dst_mean[2]};
+  double accA[TR::NA];
+  double accB[TR::NB > 0 ? TR::NB : 1];
+#pragma unroll
+  for (int i = 0; i < TR::NA; ++i) accA[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < (TR::NB > 0 ? TR::NB : 1); ++i) accB[i] = 0.0;
+  const uint32_t nb = gridDim.x;
+  const uint32_t vb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);      // XCD-aware (gridDim.x is a multiple of 8)
+  const uint32_t chunk = (((nd + nb - 1) / nb) + 63u) & ~63u;
+  const uint64_t beg64 = (uint64_t)vb * chunk;
+  const uint32_t beg = beg64 < nd ? (uint32_t)beg64 : nd;
+  const uint32_t end = (beg64 + chunk < nd) ? (uint32_t)(beg64 + chunk) : nd;
+  for (uint32_t i = beg + threadIdx.x; i < end; i += ITER_THREADS) {
+    const uint32_t pos = rev_pos[i];
+    if (pos == NONE_U32) continue;
+    const float4 s4 = sgrid_pts[pos];
+    if (mode >= 2) {
+      const bool dup = fwd_pos[src_inv[__float_as_uint(s4.w)]] == i;
+      if (dup == (mode == 2)) continue;
+    }
+    const float4 p = a.grid.pts[i];
+    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TR::plane) nv = a.grid.nrm[i];
+    float qx, qy, qz;
+    transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+    accumulate_pair<METRIC>(accA, accB, T, iL, it, smt, dmean, false, true, qx, qy, qz, i, p, nv, nv);
+  }
+  __shared__ double sh[ITER_WAVES][SUMS_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < SUMS_MAX) {
+#pragma unroll
+    for (int w = 0; w < ITER_WAVES; ++w) sh[w][threadIdx.x] = 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TR::NA; ++k) {
+    const double v = wave_sum(accA[k]);
+    if (lane == 0) sh[wave][k] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < TR::NB; ++k) {
+    const double v = wave_sum(accB[k]);
+    if (lane == 0) sh[wave][28 + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < SUMS_MAX)
+    a.partials[(size_t)vb * SUMS_MAX + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+void launch_acc_reverse(const IterArgs& a, int metric, const float4* sgrid_pts, const uint32_t* rev_pos, uint32_t nd, int mode, const uint32_t* fwd_pos,
+                        const uint32_t* src_inv, int nblocks, hipStream_t s) {
+  const dim3 g(nblocks), b(ITER_THREADS);
+  switch (metric) {
+    case IM_KABSCH: hipLaunchKernelGGL((k_acc_reverse<IM_KABSCH>), g, b, 0, s, a, sgrid_pts, rev_pos, nd, mode, fwd_pos, src_inv); break;
+    case IM_PLANE: hipLaunchKernelGGL((k_acc_reverse<IM_PLANE>), g, b, 0, s, a, sgrid_pts, rev_pos, nd, mode, fwd_pos, src_inv); break;
+    case IM_POINT: hipLaunchKernelGGL((k_acc_reverse<IM_POINT>), g, b, 0, s, a, sgrid_pts, rev_pos, nd, mode, fwd_pos, src_inv); break;
+    default: hipLaunchKernelGGL((k_acc_reverse<IM_BOTH>), g, b, 0, s, a, sgrid_pts, rev_pos, nd, mode, fwd_pos, src_inv); break;
+  }
+}
+
 int iter_num_blocks(uint32_t ns) {
   // >= 8 blocks per CU on 256 CUs when there is enough work; multiple of 8 for the XCD mapping;
   // at least one wave of work per block.
