@@ -524,7 +524,8 @@ static int launch_search(cilhip_ctx* c, const IterArgs& a) {
     if (!c->has_normals || !c->d_src_nrm) return fail(c, CILHIP_ERR_INVALID, "point+normal features need target and source normals");
     if (c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for rigid transforms only");
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are not available on target shards");
-    launch_search_feat6(a, c->stream);
+    if (use_tiled(c)) launch_search_tiled_feat6(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+    else launch_search_feat6(a, c->stream);
     return CILHIP_OK;
   }
   if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel

@@ -151,7 +151,8 @@ void launch_search_tiled(const IterArgs& a, int acc_metric, const uint2* tiles, 
                          uint32_t ntiles, hipStream_t s);
 int tiled_partial_rows(uint32_t ntiles);
 void launch_count_deferred(const unsigned long long* mask, uint32_t ntiles, uint32_t* out2, hipStream_t s);
-void launch_search_feat6(const IterArgs& a, hipStream_t s);   // correspondence search over 6-D point+normal features
+void launch_search_feat6(const IterArgs& a, hipStream_t s);   // correspondence search over 6-D point+normal features (one lane per query, global memory: small clouds)
+void launch_search_tiled_feat6(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s);   // its LDS-tiled form
 #ifdef CILHIP_EXP_PHASE_CLOCKS
 void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_search_tiled -> stderr
 #endif

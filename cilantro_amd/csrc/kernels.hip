@@ -647,8 +647,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One candidate against the running best.  (x,y) go through packed f32 math (v_pk_add/v_pk_mul: the same
 // IEEE operations per component, so d2 still rounds exactly as ((dx*dx)+(dy*dy))+(dz*dz)).
+// TRACK2 (feature search): also keep the two smallest squared distances met (m12[0] <= m12[1]) -- plain f32 min / median
+// beside the key compare; `counted` = false keeps a re-read candidate out of them.
+template <bool TRACK2 = false>
 __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, float qz, uint32_t pos,
-                                               unsigned long long& bk, uint32_t& bp) {
+                                               unsigned long long& bk, uint32_t& bp, float* m12 = nullptr, bool counted = true) {
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
@@ -656,6 +659,7 @@ __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, 
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
   const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
+  if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], counted ? e : INFINITY);   // hi(bk) is the smallest so far
   bk = lt ? k : bk;
   bp = lt ? pos : bp;
 }
@@ -688,8 +692,9 @@ struct TileLds {
 constexpr int OCT_CAND = CILHIP_OCT_CAND;
 constexpr int OCT_EXTRA = CILHIP_OCT_EXTRA;
 
+template <bool TRACK2 = false>
 __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 qxy, float qz, uint32_t code,
-                                                   unsigned long long& bk, uint32_t& sel) {
+                                                   unsigned long long& bk, uint32_t& sel, float* m12 = nullptr) {
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
@@ -697,6 +702,7 @@ __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 q
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
   const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
+  if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], e);
   bk = lt ? k : bk;
   sel = lt ? code : sel;      // code is a compile-time constant: no address arithmetic per candidate
 }
@@ -744,7 +750,12 @@ __device__ __forceinline__ float octant_bound(const GridDev& g, float qx, float 
 }
 
 // Returns true (result proven exact) iff the best found is strictly nearer than any point outside the block can be.
-__device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best, uint32_t& bl_out) {
+// TRACK2 (feature search): *second_out = the second smallest 3-D squared distance among the candidates evaluated (the
+// radius while there is none): the 6-D feature distance of any candidate but the winner is at least that.
+template <bool TRACK2 = false>
+__device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best, uint32_t& bl_out,
+                                              float* second_out = nullptr) {
+  float m12[2] = {INFINITY, INFINITY};
   const f32x2 qxy = {o.qx, o.qy};
   const float qz = o.qz;
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
@@ -765,7 +776,12 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
 #pragma unroll
     for (int c = 0; c < OCT_CAND; ++c) p[c] = t.lpts[rj[k] + c];
 #pragma unroll
-    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel);
+    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel, m12);
+    if (TRACK2 && k < 3) {   // ties the next run's address to this run's result: keeps the scheduler from issuing all 16 reads first (64 live registers)
+      uint32_t hi = (uint32_t)(bk >> 32);
+      asm volatile("" : "+v"(rj[k + 1]), "+v"(hi), "+v"(m12[1]));
+      bk = ((unsigned long long)hi << 32) | (uint32_t)bk;
+    }
   }
   uint32_t bl = NONE_U32;
   if (sel != 0xFFu) {
@@ -788,10 +804,10 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
     const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate(p0, qxy, qz, jx, bk, bl);
-    eval_candidate(p1, qxy, qz, jx + 1, bk, bl);
-    eval_candidate(p2, qxy, qz, jx + 2, bk, bl);
-    eval_candidate(p3, qxy, qz, jx + 3, bk, bl);
+    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, c0 | c1 | c2 | c3);
+    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, c0 | c1 | c2 | c3);
+    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, c0 | c1 | c2 | c3);
+    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, c0 | c1 | c2 | c3);
   }
   for (;;) {
     const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
@@ -802,10 +818,10 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
     const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate(p0, qxy, qz, jx, bk, bl);
-    eval_candidate(p1, qxy, qz, jx + 1, bk, bl);
-    eval_candidate(p2, qxy, qz, jx + 2, bk, bl);
-    eval_candidate(p3, qxy, qz, jx + 3, bk, bl);
+    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12);
+    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12);
+    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12);
+    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12);
   }
   best.key = bk;
   // LDS index -> global position: the winner normally lies in the row of its run (one table read); an
@@ -818,6 +834,7 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
   }
   best.pos = pos;
+  if (TRACK2) *second_out = m12[1];
   bl_out = bl;      // LDS index of the winner (NONE_U32: nothing within the radius): the in-tile accumulation reads the point from there
   const float b = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
@@ -1012,7 +1029,14 @@ __device__ __forceinline__ void defer_whole_tile(const IterArgs& a, uint32_t vb)
   if (ACC != IM_NONE && threadIdx.x < SUMS_MAX) a.tile_partials[(size_t)vb * SUMS_MAX + threadIdx.x] = 0.0;
 }
 
-template <int ACC>
+// FEAT6 (search-only form): the correspondence search over 6-D point+normal features (PointNormalFeaturesAdaptor,
+// common_transformable_feature_adaptors.hpp:60-161).  Candidates are compared by the feature distance d6 = d3 + |w dn|^2,
+// which is never below the 3-D distance d3 -- so the tile searches by d3 out of LDS exactly as for points, remembers the
+// second smallest d3 it met, fetches the WINNER's normal (one gather) and forms its d6: if that is still below the
+// second smallest d3, no other candidate can win (their d6 >= their d3), and the usual geometric proof -- now with d6 --
+// settles the query.  Otherwise (normals that disagree by more than the spacing of the candidates) the query goes to the
+// clean-up pass, which searches by d6 outright.  Normals are not staged: the LDS budget holds the points.
+template <int ACC, bool FEAT6 = false>
 __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
                                                                   const int* __restrict__ tile_box, uint32_t ntiles) {
   const IcpState* __restrict__ st = a.state;
@@ -1225,7 +1249,9 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   // (queue base and capacity are re-derived from the LDS row table where needed rather than kept in registers across
   //  the search: P = rowbase[rows], block-uniform)
   uint32_t mpos[TILE_QPT];   // per query: sorted-target position of the match (NONE: none / not settled here)
-  uint32_t mbl = 0;          // (accumulating form) the matches' LDS indices, 16 bits each: the matched points are read from the staged tile
+  uint32_t mbl = 0;          // (accumulating form, feature search) the matches' LDS indices, 16 bits each: the matched points are read from the staged tile
+  uint32_t f6_pos[TILE_QPT];  // (feature search) the 3-D winners and the second smallest 3-D distances, until the lane's searches are done
+  float f6_second[TILE_QPT];
 #pragma unroll
   for (int u = 0; u < TILE_QPT; ++u) {
     const bool active = (flags >> u) & 1u, fast = (flags >> (8 + u)) & 1u;
@@ -1234,9 +1260,16 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
     best.pos = NONE_U32;
     uint32_t bl = NONE_U32;
-    bool defer = false, unproven = false;
+    bool defer = false, unproven = false, pending = false;
     if (active) {
-      if (fast) {
+      if (fast && FEAT6) {
+        // searched by the 3-D distance now; settled after BOTH of the lane's searches, with the winners' normals gathered
+        // in one round trip (below)
+        (void)octant_search<true>(g, tl, oq[u], a.max_sq, best, bl, &f6_second[u]);
+        f6_pos[u] = best.pos;
+        mbl |= (bl & 0xFFFFu) << (16 * u);
+        pending = true;
+      } else if (fast) {
         unproven = !octant_search(g, tl, oq[u], a.max_sq, best, bl);
       } else {
         // outside the tile's box or in the grid's outer layer (or beyond): nothing to find if the query is farther
@@ -1247,12 +1280,12 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
       }
     }
-    if (ACC != IM_NONE) {   // (accumulating form: no second pass in the tile, see 3b; the unproven ones are only counted)
+    if (ACC != IM_NONE || FEAT6) {   // (accumulating form / feature search: no second pass in the tile, see 3b; the unproven ones are only counted)
       const unsigned long long mu = __ballot(unproven);
       if (mu != 0ull && (threadIdx.x & 63u) == 0) atomicAdd(&queue_count, (uint32_t)__popcll(mu));
       if (unproven) { defer = true; unproven = false; }
     }
-    const unsigned long long m = (ACC == IM_NONE) ? __ballot(unproven) : 0ull;
+    const unsigned long long m = (ACC == IM_NONE && !FEAT6) ? __ballot(unproven) : 0ull;
     if (m) {   // one LDS atomic per wave
       const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)m) - 1;
       uint32_t base = 0;
@@ -1268,13 +1301,55 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         }          // (no room: not written; the tile then defers all its unproven queries, see below)
       }
     }
-    if (active && !unproven && !defer && a.store_matches) {
+    if (active && !unproven && !defer && !pending && a.store_matches) {
       a.nn_pos[i] = best.pos;
       if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
     mpos[u] = (unproven | defer) ? NONE_U32 : best.pos;
     if (ACC != IM_NONE) mbl |= (bl & 0xFFFFu) << (16 * u);      // (bl < TILE_CAP + 8 < 2^16; NONE's low bits are never used: mpos says so)
-    flags |= (unproven ? (1u << (16 + u)) : 0u) | (defer ? (1u << (24 + u)) : 0u);
+    flags |= (unproven ? (1u << (16 + u)) : 0u) | (defer ? (1u << (24 + u)) : 0u) | (pending ? (1u << (20 + u)) : 0u);
+  }
+  if (FEAT6) {
+    // settle the pending queries: feature distance of the 3-D winner against the second smallest 3-D distance met
+    float4 sn[TILE_QPT], np[TILE_QPT], rr[TILE_QPT];
+#pragma unroll
+    for (int u = 0; u < TILE_QPT; ++u) {
+      const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+      sn[u] = np[u] = rr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (((flags >> (20 + u)) & 1u) && f6_pos[u] != NONE_U32) {
+        sn[u] = a.feat_src_nrm[i];
+        np[u] = g.nrm[f6_pos[u]];
+        rr[u] = lpts[(mbl >> (16 * u)) & 0xFFFFu];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TILE_QPT; ++u) {
+      const bool pend = (flags >> (20 + u)) & 1u;
+      const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+      float dbest = a.max_sq;                       // min(d6 of the winner, radius): what the proof compares
+      uint32_t pos = NONE_U32;
+      bool ambiguous = false;
+      if (pend && f6_pos[u] != NONE_U32) {
+        const float wx = __fmul_rn(a.normal_weight, sn[u].x), wy = __fmul_rn(a.normal_weight, sn[u].y), wz = __fmul_rn(a.normal_weight, sn[u].z);
+        Feat6 f;
+        f.fx = __fadd_rn(__fmul_rn(T[0], wx), __fadd_rn(__fmul_rn(T[4], wy), __fmul_rn(T[8], wz)));
+        f.fy = __fadd_rn(__fmul_rn(T[1], wx), __fadd_rn(__fmul_rn(T[5], wy), __fmul_rn(T[9], wz)));
+        f.fz = __fadd_rn(__fmul_rn(T[2], wx), __fadd_rn(__fmul_rn(T[6], wy), __fmul_rn(T[10], wz)));
+        f.w = a.normal_weight; f.nrm = nullptr;
+        const float d6 = d6_pinned(oq[u].qx, oq[u].qy, oq[u].qz, f, make_float4(rr[u].x, rr[u].y, rr[u].w, 0.f), np[u]);
+        ambiguous = !(f6_second[u] > d6);           // another candidate's d6 (>= its d3 >= second) could be <= d6: not settled here
+        if (d6 < a.max_sq) { dbest = d6; pos = f6_pos[u]; }
+      }
+      const float b = octant_bound(g, oq[u].qx, oq[u].qy, oq[u].qz) - g.margin;
+      const bool unproven = pend && (ambiguous || !(b > 0.0f && dbest < b * b * KSHRINK));
+      const unsigned long long mu = __ballot(unproven);
+      if (mu != 0ull && (threadIdx.x & 63u) == 0) atomicAdd(&queue_count, (uint32_t)__popcll(mu));
+      if (unproven) flags |= 1u << (24 + u);
+      if (pend && !unproven && a.store_matches) {
+        a.nn_pos[i] = pos;
+        if (a.nn_d2) a.nn_d2[i] = dbest;
+      }
+    }
   }
   // (ACC) What the accumulation needs for the queries settled above is fetched NOW, before the barrier: the matched normal
   // (the one gather from HBM), the matched point out of the staged tile, and the lane's FIRST query again (the last one is
@@ -1283,6 +1358,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   float4 p4t[TILE_QPT], n4t[TILE_QPT];
   float qt[TILE_QPT][3];
   if (ACC != IM_NONE) {
+    static_assert(!FEAT6 || ACC == IM_NONE, "the feature search has no accumulating form");
     static_assert(TILE_QPT == 2, "the tail keeps the LAST query of a lane in registers and fetches the first one again");
 #pragma unroll
     for (int u = 0; u < TILE_QPT; ++u) {
@@ -1314,8 +1390,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     const uint32_t cu = queue_count;
     if (cu != 0u) atomicAdd(a.unproven_cnt + (vb & 63u), cu);
   }
-  uint32_t nqueued = (ACC == IM_NONE) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count) : 0u;   // block-uniform
-  if (ACC == IM_NONE) {
+  uint32_t nqueued = (ACC == IM_NONE && !FEAT6) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count) : 0u;   // block-uniform
+  if (ACC == IM_NONE && !FEAT6) {
     // A queue that cannot hold every unproven query of the tile (a region near the LDS budget AND a source far from its
     // sort-time cells): WHICH queries found room depends on the order the waves arrived in, so none of them is taken --
     // all unproven queries of the tile go to the clean-up pass (the set is then the same in every run).
@@ -1326,7 +1402,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       nqueued = 0;
     }
   }
-  if (ACC == IM_NONE && nqueued != 0) {
+  if (ACC == IM_NONE && !FEAT6 && nqueued != 0) {
     TileLds tq{lpts, lcs, rowbase, rowdelta, __builtin_amdgcn_readfirstlane(geom_lds[0]), __builtin_amdgcn_readfirstlane(geom_lds[1]),
                __builtin_amdgcn_readfirstlane(geom_lds[2]), __builtin_amdgcn_readfirstlane(geom_lds[3]),
                __builtin_amdgcn_readfirstlane(geom_lds[4]), __builtin_amdgcn_readfirstlane(geom_lds[5])};
@@ -1463,7 +1539,7 @@ constexpr int TODO_GROUP = 8;   // lanes per deferred query
 #endif
 constexpr int FEAT6_GROUP = CILHIP_FEAT6_GROUP;   // lanes per query of the feature search: every query takes this path, so one lane each fills the chip best
                                                   // (10M<->10M iteration: 8 lanes 1.69 ms, 4: 1.22, 2: 1.07, 1: 0.93)
-template <int ACC>
+template <int ACC, bool FEAT6 = false>
 __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, const uint2* __restrict__ tiles, uint32_t ntiles) {
   using TR = AccTraits<ACC>;
   const IcpState* __restrict__ st = a.state;
@@ -1560,7 +1636,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
         tile = tiles[wi / (2 * TILE_WAVES)];
         return tile.x + ((wi / TILE_WAVES) & 1u) * TILE_THREADS + (wi % TILE_WAVES) * 64u + (ent & 63u);
       };
-      if (total > ITER_THREADS / TODO_GROUP) {
+      if (!FEAT6 && total > ITER_THREADS / TODO_GROUP) {
         // more queries than lane groups (an over-budget tile's dropped slab, whole deferred tiles, a source far from its
         // sort-time cells): one lane per query -- one trip per 256 queries instead of one per 32
         for (uint32_t e = threadIdx.x; e < total; e += ITER_THREADS) {
@@ -1587,7 +1663,18 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
             float qx, qy, qz;
             transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
             NN best;
-            nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
+            if (FEAT6) {
+              const float4 sn = a.feat_src_nrm[i];
+              const float wx = __fmul_rn(a.normal_weight, sn.x), wy = __fmul_rn(a.normal_weight, sn.y), wz = __fmul_rn(a.normal_weight, sn.z);
+              Feat6 f;
+              f.fx = __fadd_rn(__fmul_rn(T[0], wx), __fadd_rn(__fmul_rn(T[4], wy), __fmul_rn(T[8], wz)));
+              f.fy = __fadd_rn(__fmul_rn(T[1], wx), __fadd_rn(__fmul_rn(T[5], wy), __fmul_rn(T[9], wz)));
+              f.fz = __fadd_rn(__fmul_rn(T[2], wx), __fadd_rn(__fmul_rn(T[6], wy), __fmul_rn(T[10], wz)));
+              f.w = a.normal_weight; f.nrm = a.grid.nrm;
+              nn_search_group<TODO_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
+            } else {
+              nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
+            }
             if (sub == 0) finish(i, qx, qy, qz, best);
           }
         }
@@ -1649,6 +1736,15 @@ void launch_search_tiled(const IterArgs& a, int acc_metric, const uint2* tiles, 
     case IM_BOTH: launch_search_tiled_m<IM_BOTH>(a, tiles, tile_box, ntiles, s); break;
     default: launch_search_tiled_m<IM_NONE>(a, tiles, tile_box, ntiles, s); break;
   }
+}
+
+// the tiled form of the 6-D point+normal feature search (matches stored; SECOND_TO_FIRST, rigid transforms)
+void launch_search_tiled_feat6(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s) {
+  if (ntiles == 0) return;
+  hipLaunchKernelGGL(k_tile_boxes, dim3((ntiles + 255) / 256), dim3(256), 0, s, make_box_args(a, tile_center, tile_box, ntiles, true), a.state);
+  const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
+  hipLaunchKernelGGL((k_search_tiled<IM_NONE, true>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, (const int*)tile_box, ntiles);
+  hipLaunchKernelGGL((k_search_deferred<IM_NONE, true>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
 }
 
 // deferred queries / wholly deferred tiles of the last tiled search (introspection: tests, dev tools)

@@ -936,8 +936,9 @@ def test_point_normal_feature_search_vs_oracle(Context, orc, hip_lib):
     sn = dst_n[rng.permutation(n)] * 0.3 + rng.normal(size=(n, 3)).astype(np.float32)
     sn = (sn / np.linalg.norm(sn, axis=1, keepdims=True)).astype(np.float32)
     T = d["T_true"].astype(np.float32).copy(); T[:3, 3] += np.array([0.4, -0.3, 0.2], np.float32) * h
-    for w in (0.5 * h, 3.0 * h):
+    for w, tiled in ((0.5 * h, 0), (3.0 * h, 0), (0.5 * h, 2), (3.0 * h, 2)):      # per-lane search and the LDS-tiled form
         ctx = Context()
+        ctx.set_option("tiled", tiled)
         ctx.set_target(dst, dst_n); ctx.set_source(src, sn)
         ctx.set_option("feature_normal_weight", w)
         dst6 = orc.point_normal_features(dst, dst_n, w)
@@ -954,6 +955,29 @@ def test_point_normal_feature_search_vs_oracle(Context, orc, hip_lib):
         o1, o2, ov = orc.find_correspondences_feat6(dst6, q6, float((2.5 * h) ** 2))
         f1, f2, fv = orc.filter_fraction(o1, o2, ov, 0.7)
         assert np.array_equal(g2, f2) and np.array_equal(g1, f1) and np.array_equal(gv, fv)
+    # the tiled form where it settles nearly everything inside the tile: a larger, nearly aligned pair whose source normals are
+    # (nearly) the matched target normals -- and the same with normals that disagree (most queries take the clean-up pass)
+    d2 = syn.make_pair(300_000, perturb=0.3)
+    h2 = d2["h"]
+    Ti = np.linalg.inv(d2["T_true"])
+    sn_good = (d2["dst_n"].astype(np.float64) @ Ti[:3, :3].T).astype(np.float32)
+    sn_bad = np.ascontiguousarray(sn_good[rng.permutation(len(sn_good))])
+    T2 = d2["T_true"].astype(np.float32).copy(); T2[:3, 3] += np.array([0.1, -0.05, 0.08], np.float32) * np.float32(h2)
+    for sn2, w in ((sn_good, 0.5 * h2), (sn_bad, 0.5 * h2), (sn_good, 4.0 * h2)):
+        res = []
+        for tiled in (0, 2):
+            ctx2 = Context()
+            ctx2.set_option("tiled", tiled)
+            ctx2.set_target(d2["dst"], d2["dst_n"]); ctx2.set_source(d2["src"], sn2)
+            ctx2.set_option("feature_normal_weight", w)
+            ctx2.find_correspondences(T2, float(d2["max_sq_dist"]), count=False)
+            res.append(ctx2.get_nn())
+            dq, _ = ctx2.debug_counters()
+        assert np.array_equal(res[0][0], res[1][0])
+        m = res[0][0] != capi.NONE_IDX
+        assert np.array_equal(res[0][1][m], res[1][1][m]) and m.sum() > 0.9 * len(m)
+        if sn2 is sn_good and w < h2:
+            assert dq < 0.05 * len(m), dq            # settled inside the tiles
     # options the feature search does not cover fail loudly
     ctx.set_option("inlier_fraction", 1.0)
     ctx.set_option("search_direction", 2)
