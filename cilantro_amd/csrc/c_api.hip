@@ -64,6 +64,8 @@ struct cilhip_ctx {
   float4* d_src_nrm_sorted = nullptr;
   uint32_t* d_nn_pos = nullptr;
   float* d_nn_d2 = nullptr;
+  int cw_point_kind = 0, cw_plane_kind = 0;     // correspondence weight evaluators (CW_*), combined metric
+  float cw_point_sigma = 1.0f, cw_plane_sigma = 1.0f;
   bool have_nn = false;           // nn_pos/nn_d2 hold the result of a search
   float nn_T[16];                 // transform used by that search
 
@@ -243,6 +245,16 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
+  if (!strcmp(key, "point_weight_evaluator") || !strcmp(key, "plane_weight_evaluator")) {
+    if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "weight evaluator: 0 = Unity, 1 = Identity, 2 = RBF kernel");
+    (key[1] == 'o' ? c->cw_point_kind : c->cw_plane_kind) = (int)value;
+    return CILHIP_OK;
+  }
+  if (!strcmp(key, "point_weight_sigma") || !strcmp(key, "plane_weight_sigma")) {
+    if (!(value > 0.0)) return fail(c, CILHIP_ERR_INVALID, "weight evaluator sigma must be positive");
+    (key[1] == 'o' ? c->cw_point_sigma : c->cw_plane_sigma) = (float)value;
+    return CILHIP_OK;
+  }
   if (!strcmp(key, "tile_accumulation")) { c->tile_acc = value != 0.0; c->tile_acc_adaptive = value != 2.0; return CILHIP_OK; }
   if (!strcmp(key, "search_direction")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "search_direction: 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH");
@@ -473,8 +485,24 @@ static bool filters_active(const cilhip_ctx* c) {
 // pass + a streaming accumulation pass) whenever the plain engine runs tiled: no post-filters (they act on the complete
 // match set), point features, the three-cloud metric (the symmetric objective reads source normals per pair), and not
 // the A/B option "fused" (per-lane kernel) or "tile_accumulation" = 0.
+static bool weighted(const cilhip_ctx* c) { return c->cw_point_kind != CW_UNITY || c->cw_plane_kind != CW_UNITY; }
+// The per-pair weights of the combined-metric classes (PointToPoint/PointToPlaneCorrWeightEvaluatorT of
+// icp_single_transform_combined_metric.hpp:11-14; the point-to-point class has none): evaluator(corr.value) times the
+// metric weight, in f32.  RBF coefficient as common_pair_evaluators.hpp:53.
+static CorrWeights corr_weights_of(const cilhip_ctx* c, bool combined_metric, float w_p2p, float w_p2pl) {
+  CorrWeights w{};
+  w.enabled = (combined_metric && weighted(c)) ? 1 : 0;
+  w.point_kind = c->cw_point_kind; w.plane_kind = c->cw_plane_kind;
+  w.point_coeff = -0.5f / (c->cw_point_sigma * c->cw_point_sigma);
+  w.plane_coeff = -0.5f / (c->cw_plane_sigma * c->cw_plane_sigma);
+  w.w_p2p = w_p2p; w.w_p2pl = w_p2pl;
+  return w;
+}
+static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params* p) {
+  return corr_weights_of(c, p->metric == CILHIP_METRIC_COMBINED, p->w_p2p, p->w_p2pl);
+}
 static bool tile_accumulation(const cilhip_ctx* c) {
-  return c->tile_acc && use_tiled(c) && !filters_active(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+  return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
 }
 
 // filterCorrespondencesFraction then filterCorrespondencesOneToOne on the stored matches
@@ -712,7 +740,8 @@ static void pack_T(const double L[9], const double t[3], float T[16]) {
 }
 
 // Accumulate over the stored matches (transform = nn_T) and bring the reduced sums to the host.
-static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], const double innert[3], double sums[SUMS_MAX]) {
+static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], const double innert[3], double sums[SUMS_MAX],
+                             const CorrWeights* cw = nullptr) {
   IcpState hs;
   launch_init_state(c->d_state, c->nn_T, c->src_mean, c->stream);
   if (innerL) {
@@ -723,6 +752,7 @@ static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], 
     CK(c, hipMemcpyAsync(c->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, c->stream));
   }
   IterArgs a = make_iter_args(c, 0.0f);
+  if (cw) a.cw = *cw;
   const int nb = iter_num_blocks(c->ns);
   for (int i = 0; i < SUMS_MAX; ++i) sums[i] = 0.0;
   if (c->ns == 0) return CILHIP_OK;
@@ -766,13 +796,15 @@ int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t ma
   float smt[3];
   transform_point(c->nn_T, c->src_mean[0], c->src_mean[1], c->src_mean[2], smt[0], smt[1], smt[2]);
   int conv = 0;
+  const CorrWeights cw = corr_weights_of(c, true, w_p2p, w_p2pl);
   for (size_t it = 0; it < max_iter; ++it) {
     double sums[SUMS_MAX];
-    int rc = accumulate_stored(c, metric, L, t, sums);
+    int rc = accumulate_stored(c, metric, L, t, sums, &cw);
     if (rc) return rc;
     if (!(sums[0] > 0.0)) return CILHIP_OK;              // no correspondences: identity
     double AtA[36], Atb[6], dth[6];
-    gn_normal_equations(sums, wp ? (double)w_p2p : 0.0, wl ? (double)w_p2pl : 0.0, AtA, Atb);
+    if (cw.enabled) gn_normal_equations(sums, wp ? 1.0 : 0.0, wl ? 1.0 : 0.0, AtA, Atb, true);   // (metric weights inside the per-pair weights)
+    else gn_normal_equations(sums, wp ? (double)w_p2p : 0.0, wl ? (double)w_p2pl : 0.0, AtA, Atb);
     if (it == 0) {
       if (AtA_out) memcpy(AtA_out, AtA, sizeof(AtA));
       if (Atb_out) memcpy(Atb_out, Atb, sizeof(Atb));
@@ -938,6 +970,10 @@ static SolveArgs make_solve_args(cilhip_ctx* c, const cilhip_icp_params* p, int 
   sa.reduced = nullptr;
   sa.metric = im;
   sa.w_p2p = p->w_p2p; sa.w_p2pl = p->w_p2pl;
+  if (p->metric == CILHIP_METRIC_COMBINED && weighted(c)) {   // the metric weights are inside the per-pair weights already
+    sa.w_p2p = p->w_p2p > 0.0f ? 1.0f : 0.0f; sa.w_p2pl = p->w_p2pl > 0.0f ? 1.0f : 0.0f;
+    sa.point_weighted = 1;
+  }
   sa.conv_tol = p->conv_tol; sa.opt_conv_tol = p->opt_conv_tol;
   for (int i = 0; i < 3; ++i) { sa.dst_mean[i] = c->dst_mean[i]; sa.src_mean[i] = src_mean[i]; }
   sa.gn_last_step = 1;
@@ -976,6 +1012,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   CK(c, hipSetDevice(c->device));
   if (c->transform_mode == 1) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "the affine variants are not available on target shards");
+    if (p->metric == CILHIP_METRIC_COMBINED && weighted(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "weight evaluators other than Unity are available for the rigid classes only");
     return icp_run_affine(c, p, T0, out);
   }
   const float* Ti = T0 ? T0 : kIdentity;
@@ -987,6 +1024,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   ++c->run_tag;
   launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag);
   IterArgs a = make_iter_args(c, p->max_sq_dist);
+  a.cw = corr_weights_of(c, p);
   SolveArgs sa = make_solve_args(c, p, im, c->src_mean);
   sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;
   const int nb = sa.nblocks;
@@ -1066,6 +1104,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       rc = run_pair_search(c, a, p->max_sq_dist, it == 0 ? Ti : out->T);
       if (rc) return rc;
       IterArgs pa = a;
+      pa.nn_d2 = nullptr;      // (d_nn_d2 is indexed by sorted source position, not by pair: a weight evaluator forms the distance again)
       pa.src = c->pairs.src_view; pa.src_nrm = (c->d_src_nrm && c->symmetric) ? c->pairs.nrm_view : nullptr; pa.ns = c->pairs.count; pa.nn_pos = c->pairs.posd;
       const int pnb = iter_num_blocks(pa.ns);
       if (pnb > c->partial_blocks) {
@@ -1105,7 +1144,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
     return CILHIP_OK;
   }
-  if (!filters_active(c)) a.nn_d2 = nullptr;   // nobody reads the distances inside the loop: 4 B per query less to write
+  if (!filters_active(c) && !(a.cw.enabled && feat6(c))) a.nn_d2 = nullptr;   // nobody reads the distances inside the loop: 4 B per query less to write
+                                                                              // (a weight evaluator over the 6-D feature distance does)
   const bool tile_acc = tile_accumulation(c);
   const bool timing = c->kernel_timing && p->max_iter <= 4096;
   hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
@@ -1253,6 +1293,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
   CK(c, hipSetDevice(c->device));
   const int im = iter_metric_of(c, &c->run_prm);
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
+  a.cw = corr_weights_of(c, &c->run_prm);
   const int nb = iter_num_blocks(c->ns);
   int prows = nb;
   if (c->ns) {
@@ -1353,6 +1394,7 @@ int cilhip_icp_sums_from_keys(cilhip_ctx* c, const uint64_t* keys_dev, double* s
   }
   const int im = iter_metric_of(c, &c->run_prm);
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
+  a.cw = corr_weights_of(c, &c->run_prm);
   const int nb = iter_num_blocks(c->ns);
   if (c->ns) {
     launch_keys_to_pos(c->d_src_sorted, reinterpret_cast<const unsigned long long*>(keys_dev), c->d_inv_perm, c->ns,

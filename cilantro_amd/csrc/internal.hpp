@@ -75,6 +75,18 @@ enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOT
                   IM_AFF1 = 6,    // sum n_j n_k (s,1)_a (s,1)_b, (j,k) = (0,0),(0,1),(0,2) x the 10 pairs a <= b
                   IM_AFF2 = 7 };  // the same for (j,k) = (1,1),(1,2),(2,2)
 
+// Correspondence weight evaluators of the combined-metric classes (core/common_pair_evaluators.hpp:14-27 Identity, :30-43
+// Unity, :46-80 RBF kernel over squared distances), selected per term type.  enabled: some evaluator is not Unity -- the
+// accumulation then forms the reference's per-pair f32 weight metric_weight * evaluator(corr.value)
+// (registration/transform_estimation.hpp:301-303, :330-332) and the solver is handed unit metric weights.
+enum { CW_UNITY = 0, CW_IDENTITY = 1, CW_RBF = 2 };
+struct CorrWeights {
+  int enabled;
+  int point_kind, plane_kind;
+  float point_coeff, plane_coeff;   // RBF: -0.5 / sigma^2 (common_pair_evaluators.hpp:53)
+  float w_p2p, w_p2pl;              // the metric weights, folded into the per-pair weight
+};
+
 struct IterArgs {
   GridDev grid;
   const float4* src;       // [ns] source sorted by target-grid cell {x,y,z,orig_idx}
@@ -96,6 +108,7 @@ struct IterArgs {
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
   const float4* feat_src_nrm;  // 6-D point+normal feature search: sorted source normals, and
   float normal_weight;         // the adaptor's normal weight (0 = plain point features)
+  CorrWeights cw;              // per-correspondence weights (enabled = 0: unity)
 };
 
 // What k_tile_boxes needs to compute the tiles' regions for the state's transform.
@@ -127,6 +140,7 @@ struct SolveArgs {
   const double* reduced;   // [SUMS_MAX] (multi-GPU: all-reduced buffer)
   int metric;              // IterMetric
   float w_p2p, w_p2pl;
+  int point_weighted;      // per-pair weights in the sums (CorrWeights::enabled): the point block's count is slot 43, sum of weights
   float conv_tol, opt_conv_tol;
   float dst_mean[3], src_mean[3];
   int gn_last_step;        // finalize the outer iteration after this GN step

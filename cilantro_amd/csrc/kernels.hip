@@ -390,6 +390,38 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// exp() for the RBF weight evaluator in PINNED f32 arithmetic (one fixed sequence of correctly rounded operations, the same
+// in oracle/icp_oracle.c): round-to-nearest argument reduction by ln 2 (two-part constant), degree-6 polynomial, exact
+// scaling.  Within 1 ulp of the correctly rounded value on [-80, 0]; the reference calls std::exp(float), whose last
+// bit depends on its libm.  Arguments below -80 give 0 (the true value is < 2e-35).
+__device__ __forceinline__ float pinned_expf(float x) {
+  if (!(x >= -80.0f)) return x != x ? x : 0.0f;
+  if (x > 80.0f) x = 80.0f;
+  const float n = rintf(__fmul_rn(x, 1.44269504f));
+  float r = __fmaf_rn(n, -0.693359375f, x);
+  r = __fmaf_rn(n, 2.12194440e-4f, r);
+  float q = 1.9875691500e-4f;
+  q = __fmaf_rn(q, r, 1.3981999507e-3f);
+  q = __fmaf_rn(q, r, 8.3334519073e-3f);
+  q = __fmaf_rn(q, r, 4.1665795894e-2f);
+  q = __fmaf_rn(q, r, 1.6666665459e-1f);
+  q = __fmaf_rn(q, r, 5.0000001201e-1f);
+  q = __fmaf_rn(q, __fmul_rn(r, r), r);
+  q = __fadd_rn(q, 1.0f);
+  return ldexpf(q, (int)n);
+}
+__device__ __forceinline__ float corr_weight(int kind, float coeff, float value) {
+  return kind == CW_UNITY ? 1.0f : kind == CW_IDENTITY ? value : pinned_expf(__fmul_rn(coeff, value));
+}
+// per-pair weights (point term, plane term) of a correspondence with search distance `value`
+__device__ __forceinline__ void pair_weights(const CorrWeights& cw, float value, float& wq, float& wp) {
+  wq = wp = 1.0f;
+  if (cw.enabled) {
+    wq = __fmul_rn(cw.w_p2p, corr_weight(cw.point_kind, cw.point_coeff, value));
+    wp = __fmul_rn(cw.w_p2pl, corr_weight(cw.plane_kind, cw.plane_coeff, value));
+  }
+}
+
 template <int METRIC>
 struct AccTraits {
   static constexpr bool plane = (METRIC == IM_PLANE || METRIC == IM_BOTH);
@@ -397,7 +429,7 @@ struct AccTraits {
   static constexpr bool kabsch = (METRIC == IM_KABSCH);
   static constexpr bool affine = (METRIC == IM_AFF0 || METRIC == IM_AFF1 || METRIC == IM_AFF2);
   static constexpr int NA = affine ? (METRIC == IM_AFF0 ? 34 : 30) : kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
-  static constexpr int NB = point ? 15 : 0;                  // slots [28, 28+NB)
+  static constexpr int NB = point ? 16 : 0;                  // slots [28, 28+NB)
 };
 
 // The accumulation of one matched pair (q = T*s already formed): what every accumulating kernel adds per correspondence.
@@ -405,7 +437,10 @@ struct AccTraits {
 template <int METRIC>
 __device__ __forceinline__ void accumulate_pair(double* __restrict__ accA, double* __restrict__ accB, const float* T, const float* iL, const float* it,
                                                 const float* smt, const float* dmean, const bool sym, const bool has_nrm, float qx, float qy, float qz,
-                                                uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
+                                                uint32_t pos, const float4 p, const float4 nvp, const float4 snp, const float wq = 1.0f,
+                                                const float wp = 1.0f) {
+  // wq / wp: the per-pair weights of the point and plane terms (pair_weights(); 1 = unity evaluators, where the metric
+  // weights are applied to the sums by the solver instead).  Only the rigid combined-metric forms take them.
   using TR = AccTraits<METRIC>;
   if (METRIC != IM_NONE && pos != NONE_U32) {
     if (TR::kabsch) {
@@ -498,28 +533,34 @@ __device__ __forceinline__ void accumulate_pair(double* __restrict__ accA, doubl
         e[2] = __fsub_rn(__fmul_rn(a0, nv.y), __fmul_rn(a1, nv.x));
         e[3] = nv.x; e[4] = nv.y; e[5] = nv.z;
         const float res = __fadd_rn(__fmul_rn(nv.x, r0), __fadd_rn(__fmul_rn(nv.y, r1), __fmul_rn(nv.z, r2)));  // n.dot(d-s)
-        double ed[6];
+        // weight * eq_vec and weight * residual rounded to f32 as the reference forms them (:340-341); entry (r, c), r <= c,
+        // is the LOWER-triangle product (w e_c) e_r -- the triangle LDLT reads.  wp = 1 changes nothing.
+        double ed[6], wed[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ed[k] = (double)e[k];
+        for (int k = 0; k < 6; ++k) { ed[k] = (double)e[k]; wed[k] = (double)__fmul_rn(wp, e[k]); }
         int k = 1;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-          for (int c = r; c < 6; ++c) { accA[k] = fma(ed[r], ed[c], accA[k]); ++k; }
-        const double rd = (double)res;
+          for (int c = r; c < 6; ++c) { accA[k] = fma(wed[c], ed[r], accA[k]); ++k; }
+        const double rd = (double)__fmul_rn(wp, res);
 #pragma unroll
         for (int r = 0; r < 6; ++r) accA[22 + r] = fma(rd, ed[r], accA[22 + r]);
       }
       if (TR::point) {
+        // every point-term sum is linear in the weight: w a as the first factor, w r on the right-hand side (:318-319)
+        const double wd = (double)wq;
         const double ad[3] = {(double)a0, (double)a1, (double)a2};
-        const double rd[3] = {(double)r0, (double)r1, (double)r2};
-        accB[0] += ad[0]; accB[1] += ad[1]; accB[2] += ad[2];
-        accB[3] = fma(ad[0], ad[0], accB[3]); accB[4] = fma(ad[0], ad[1], accB[4]); accB[5] = fma(ad[0], ad[2], accB[5]);
-        accB[6] = fma(ad[1], ad[1], accB[6]); accB[7] = fma(ad[1], ad[2], accB[7]); accB[8] = fma(ad[2], ad[2], accB[8]);
+        const double wa[3] = {wd * ad[0], wd * ad[1], wd * ad[2]};
+        const double rd[3] = {wd * (double)r0, wd * (double)r1, wd * (double)r2};
+        accB[0] += wa[0]; accB[1] += wa[1]; accB[2] += wa[2];
+        accB[3] = fma(wa[0], ad[0], accB[3]); accB[4] = fma(wa[0], ad[1], accB[4]); accB[5] = fma(wa[0], ad[2], accB[5]);
+        accB[6] = fma(wa[1], ad[1], accB[6]); accB[7] = fma(wa[1], ad[2], accB[7]); accB[8] = fma(wa[2], ad[2], accB[8]);
         accB[9] += ad[1] * rd[2] - ad[2] * rd[1];
         accB[10] += ad[2] * rd[0] - ad[0] * rd[2];
         accB[11] += ad[0] * rd[1] - ad[1] * rd[0];
         accB[12] += rd[0]; accB[13] += rd[1]; accB[14] += rd[2];
+        accB[15] += wd;      // sum of the weights: the translation block of E E^T
       }
     }
   }
@@ -569,6 +610,7 @@ struct FusedZ {
       i1 = R0 + (b - 12); j1 = ONE;
       return true;
     }
+    if ((ACC == IM_POINT || ACC == IM_BOTH) && s == 43) { i1 = j1 = (ACC == IM_BOTH) ? 7 : 6; return true; }   // sum of the (unit) weights = n
     return false;
   }
 };
@@ -1846,8 +1888,11 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
   const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
 
   // the accumulation of one matched pair (q = T*s already formed); shared by the loops below
-  auto accumulate = [&](float qx, float qy, float qz, uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
-    accumulate_pair<METRIC>(accA, accB, T, iL, it, smt, dmean, a.src_nrm != nullptr, a.grid.nrm != nullptr, qx, qy, qz, pos, p, nvp, snp);
+  // (value: the correspondence's search distance, read by the weight evaluators only)
+  auto accumulate = [&](float value, float qx, float qy, float qz, uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
+    float wq = 1.0f, wp = 1.0f;
+    if (a.cw.enabled) pair_weights(a.cw, value, wq, wp);
+    accumulate_pair<METRIC>(accA, accB, T, iL, it, smt, dmean, a.src_nrm != nullptr, a.grid.nrm != nullptr, qx, qy, qz, pos, p, nvp, snp, wq, wp);
   };
 
   if (!SEARCH) {
@@ -1872,9 +1917,13 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       if (i0 + ITER_THREADS < end) { sb = a.src[i0 + ITER_THREADS]; pb = a.nn_pos[i0 + ITER_THREADS]; } else pb = NONE_U32;
       float qx, qy, qz;
       transform_point(T, s4a.x, s4a.y, s4a.z, qx, qy, qz);
-      accumulate(qx, qy, qz, posa, p_a, nv_a, sn_a);
+      // stored matches: the stored distance (the feature search's is the 6-D one) or, where none is kept, formed again
+      float va = 0.0f, vb2 = 0.0f;
+      if (a.cw.enabled && posa != NONE_U32) va = a.nn_d2 ? a.nn_d2[ia] : d2_pinned(qx, qy, qz, p_a.x, p_a.y, p_a.z);
+      accumulate(va, qx, qy, qz, posa, p_a, nv_a, sn_a);
       transform_point(T, s4b.x, s4b.y, s4b.z, qx, qy, qz);
-      accumulate(qx, qy, qz, posb, p_b, nv_b, sn_b);
+      if (a.cw.enabled && posb != NONE_U32) vb2 = a.nn_d2 ? a.nn_d2[ib] : d2_pinned(qx, qy, qz, p_b.x, p_b.y, p_b.z);
+      accumulate(vb2, qx, qy, qz, posb, p_b, nv_b, sn_b);
     }
   } else {
   uint32_t inext = beg + threadIdx.x;
@@ -1883,6 +1932,7 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
     const uint32_t i = inext;
     const float4 s4 = s4n;
     uint32_t pos = NONE_U32;
+    float value = 0.0f;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nvp = p, snp = p;
     inext += ITER_THREADS;
     if (inext < end) s4n = a.src[inext];
@@ -1892,13 +1942,14 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       NN best;
       nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
       pos = best.pos;
+      value = __uint_as_float((uint32_t)(best.key >> 32));
       if (STORE) { a.nn_pos[i] = pos; if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
       if (METRIC != IM_NONE && pos != NONE_U32) {
         p = a.grid.pts[pos];
         if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; } else if (TR::affine && a.grid.nrm) nvp = a.grid.nrm[pos];
       }
     }
-    accumulate(qx, qy, qz, pos, p, nvp, snp);
+    accumulate(value, qx, qy, qz, pos, p, nvp, snp);
   }
   }
 
@@ -1975,7 +2026,9 @@ __global__ __launch_bounds__(ITER_THREADS) void k_acc_reverse(IterArgs a, const 
     if (TR::plane) nv = a.grid.nrm[i];
     float qx, qy, qz;
     transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-    accumulate_pair<METRIC>(accA, accB, T, iL, it, smt, dmean, false, true, qx, qy, qz, i, p, nv, nv);
+    float wq = 1.0f, wp = 1.0f;
+    if (a.cw.enabled) pair_weights(a.cw, d2_pinned(qx, qy, qz, p.x, p.y, p.z), wq, wp);     // the reverse search's distance, formed again
+    accumulate_pair<METRIC>(accA, accB, T, iL, it, smt, dmean, false, true, qx, qy, qz, i, p, nv, nv, wq, wp);
   }
   __shared__ double sh[ITER_WAVES][SUMS_MAX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2161,7 +2214,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
         // (LDS, not function-local arrays: the pivoted solve indexes them dynamically, and scratch is global memory)
         __shared__ double AtA[36], Atb[6], dth[6], wsA[36], wsy[6];
         __shared__ int wsperm[6];
-        gn_normal_equations(sums, has_p2p ? (double)a.w_p2p : 0.0, has_p2pl ? (double)a.w_p2pl : 0.0, AtA, Atb);
+        gn_normal_equations(sums, has_p2p ? (double)a.w_p2p : 0.0, has_p2pl ? (double)a.w_p2pl : 0.0, AtA, Atb, a.point_weighted != 0);
         if (!ldlt6_solve_fast(AtA, Atb, dth)) ldlt6_solve_ws(AtA, Atb, dth, wsA, wsy, wsperm);   // (pivoted: rank-deficient systems only)
         rigid_gn_update(dth, st->dLd, st->dtd);
         for (int i = 0; i < 9; ++i) st->innerL[i] = (float)st->dLd[i];

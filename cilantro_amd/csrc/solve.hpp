@@ -22,10 +22,11 @@ namespace cilhip {
 //   Gauss-Newton (combined metric class), plane part: [0]=n, [1..21]=upper triangle of sum e e^T
 //     (row-major: 00 01 02 03 04 05 11 12 ... 55), [22..27]=sum (n.(d-s)) e
 //   Gauss-Newton, point part (only when w_p2p>0): [28..30]=sum a, [31..36]=sum a a^T upper
-//     (00 01 02 11 12 22), [37..39]=sum a x r, [40..42]=sum r          with a=d+s, r=d-s
+//     (00 01 02 11 12 22), [37..39]=sum a x r, [40..42]=sum r          with a=d+s, r=d-s;  [43]=sum of the point-term
+//     weights (streaming kernels only; equals n with unity evaluators)
 constexpr int SUMS_KABSCH = 16;
 constexpr int SUMS_PLANE = 28;
-constexpr int SUMS_GN_FULL = 43;
+constexpr int SUMS_GN_FULL = 44;
 constexpr int SUMS_MAX = 48;  // padded slot count per block partial
 
 // ---- 3x3 two-sided Jacobi SVD (row-major), S >= 0 sorted descending --------------------------
@@ -313,8 +314,9 @@ CILHIP_HD void kabsch_from_sums(const double* sums, double L[9], double t[3]) {
 }
 
 // Normal equations of one Gauss-Newton step from the raw sums (transform_estimation.hpp:292-344).
+// point_weighted: the sums carry per-pair weights; the point block's "n" is then the sum of the weights, slot 43.
 CILHIP_HD void gn_normal_equations(const double* sums, double w_p2p, double w_p2pl, double AtA[36],
-                                   double Atb[6]) {
+                                   double Atb[6], bool point_weighted = false) {
   for (int i = 0; i < 36; ++i) AtA[i] = 0.0;
   for (int i = 0; i < 6; ++i) Atb[i] = 0.0;
   if (w_p2pl > 0.0) {
@@ -329,7 +331,7 @@ CILHIP_HD void gn_normal_equations(const double* sums, double w_p2p, double w_p2
   }
   if (w_p2p > 0.0) {
     // E = [[a]x ; I3]  =>  E E^T = [[ (a.a) I - a a^T , [a]x ], [ [a]x^T , I ]],  E r = [a x r ; r]
-    const double n = sums[0];
+    const double n = point_weighted ? sums[43] : sums[0];
     const double sa[3] = {sums[28], sums[29], sums[30]};
     const double aa00 = sums[31], aa01 = sums[32], aa02 = sums[33], aa11 = sums[34], aa12 = sums[35], aa22 = sums[36];
     const double tr = aa00 + aa11 + aa22;

@@ -462,6 +462,30 @@ class SimplePointToPointMetricRigidICP3f(_IterativeClosestPointBase):
         return self._ctx.compute_residuals(0, 0.0, 0.0, self.transform_)
 
 
+class UnityWeightEvaluator:
+    """core/common_pair_evaluators.hpp:30-43: every correspondence weighs 1 (the instances' default)."""
+    kind = 0
+    sigma = 1.0
+
+
+class IdentityWeightEvaluator:
+    """core/common_pair_evaluators.hpp:14-27: the weight is the correspondence's value (its squared search distance)."""
+    kind = 1
+    sigma = 1.0
+
+
+class RBFKernelWeightEvaluator:
+    """core/common_pair_evaluators.hpp:46-80 over squared distances: exp(-0.5 / sigma^2 * value)."""
+    kind = 2
+
+    def __init__(self, sigma=1.0):
+        self.sigma = float(sigma)
+
+    def setSigma(self, sigma):
+        self.sigma = float(sigma)
+        return self
+
+
 class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
     """registration/icp_common_instances.hpp:261 (wrapper :74-97) over
     CombinedMetricSingleTransformICP (icp_single_transform_combined_metric.hpp); defaults :44-47."""
@@ -476,6 +500,30 @@ class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
         self.optimization_convergence_tol_ = np.float32(1e-5)
         self.point_to_point_weight_ = np.float32(0.0)
         self.point_to_plane_weight_ = np.float32(1.0)
+        # the class template's PointToPoint/PointToPlaneCorrWeightEvaluatorT (icp_single_transform_combined_metric.hpp:11-14)
+        self.point_corr_eval_ = UnityWeightEvaluator()
+        self.plane_corr_eval_ = UnityWeightEvaluator()
+
+    def pointToPointCorrespondenceWeightEvaluator(self):
+        """:95-97"""
+        return self.point_corr_eval_
+
+    def pointToPlaneCorrespondenceWeightEvaluator(self):
+        """:99-101"""
+        return self.plane_corr_eval_
+
+    def setCorrespondenceWeightEvaluators(self, point_eval=None, plane_eval=None):
+        """The reference fixes the evaluator TYPES at compile time (template arguments); here they are objects."""
+        if point_eval is not None:
+            self.point_corr_eval_ = point_eval
+        if plane_eval is not None:
+            self.plane_corr_eval_ = plane_eval
+        return self
+
+    def _push_weight_evaluators(self):
+        for name, ev in (("point", self.point_corr_eval_), ("plane", self.plane_corr_eval_)):
+            self._ctx.set_option(name + "_weight_evaluator", ev.kind)
+            self._ctx.set_option(name + "_weight_sigma", ev.sigma)
 
     def getPointToPointMetricWeight(self):
         return self.point_to_point_weight_
@@ -516,6 +564,7 @@ class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
         p.max_opt_iter = self.max_optimization_iterations_
         p.opt_conv_tol = float(self.optimization_convergence_tol_)
         p.max_sq_dist = float(self._engine.max_distance_)
+        self._push_weight_evaluators()
         return p
 
     def getResiduals(self):

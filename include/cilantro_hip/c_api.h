@@ -344,7 +344,19 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        the step is cilhip_estimate_affine's closed form and there is no rotation() polish
  *                        (icp_single_transform_combined_metric.hpp:207-216); max_opt_iter / opt_conv_tol are unused,
  *                        as in the reference's affine overload.  Host-driven loop (one 12x12 solve per iteration).
- *                        Not available in sharded runs. */
+ *                        Not available in sharded runs.
+ * Correspondence weight evaluators of the combined-metric classes (the PointToPoint/PointToPlaneCorrWeightEvaluatorT
+ * template arguments of registration/icp_single_transform_combined_metric.hpp:11-14, core/common_pair_evaluators.hpp):
+ *   "point_weight_evaluator", "plane_weight_evaluator" (default 0): 0 = UnityWeightEvaluator (:30-43),
+ *                        1 = IdentityWeightEvaluator (:14-27: the weight is the correspondence's value, i.e. the squared
+ *                        search distance -- 6-D with the point+normal features), 2 = RBFKernelWeightEvaluator over squared
+ *                        distances (:46-80): exp(-0.5 / sigma^2 * value).
+ *   "point_weight_sigma", "plane_weight_sigma" (default 1): the RBF evaluators' sigma (setSigma, :55-58).
+ *                        The per-pair f32 weight is metric weight * evaluator(value) as transform_estimation.hpp:301-303,
+ *                        :330-332 form it; exp() is a pinned f32 sequence (within 1 ulp of the correctly rounded value; the
+ *                        reference's std::exp depends on its libm).  Rigid classes only (cilhip_icp_run, the sharded
+ *                        building blocks, cilhip_estimate_combined); the accumulation then always runs as its own
+ *                        streaming pass. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
  * kernels of the last cilhip_icp_run (sum over executed iterations).  Sharded runs: the same two sums over the

@@ -551,6 +551,25 @@ void orc_nn_brute(const float* dst, size_t nd, const float* q, size_t nq, float 
 #undef R_EPS
 #undef R_MIN
 
+/* exp() in pinned f32 arithmetic (see icp_oracle.h); fmaf / rintf / ldexpf are exact-by-definition operations, so the
+ * sequence gives the same bits everywhere (-ffp-contract=off: nothing else is fused). */
+float orc_pinned_expf(float x) {
+  if (!(x >= -80.0f)) return x != x ? x : 0.0f;
+  if (x > 80.0f) x = 80.0f;
+  const float n = rintf(x * 1.44269504f);
+  float r = fmaf(n, -0.693359375f, x);
+  r = fmaf(n, 2.12194440e-4f, r);
+  float q = 1.9875691500e-4f;
+  q = fmaf(q, r, 1.3981999507e-3f);
+  q = fmaf(q, r, 8.3334519073e-3f);
+  q = fmaf(q, r, 4.1665795894e-2f);
+  q = fmaf(q, r, 1.6666665459e-1f);
+  q = fmaf(q, r, 5.0000001201e-1f);
+  q = fmaf(q, r * r, r);
+  q = q + 1.0f;
+  return ldexpf(q, (int)n);
+}
+
 #define TERM float
 #define ACC float
 #define EFX(n) CAT(n, _m0)
@@ -616,26 +635,35 @@ int orc_estimate_p2p(const float* dst, const float* src, const int64_t* di, cons
   return ok;
 }
 
+int orc_estimate_combined_w(const float* dst_p, const float* dst_n, const float* src_p, const float* src_n,
+                            const int64_t* di, const int64_t* si, size_t n, float w_p2p, float w_p2pl,
+                            size_t max_iter, float conv_tol, const float dst_mean[3],
+                            const float src_mean[3], int mode, float T_out[16], double* AtA_out,
+                            double* Atb_out, const float* val, const orc_weights* wt) {
+  int ok;
+  if (mode == ORC_MODE_F32) {
+    float L[9], t[3];
+    ok = estimate_combined_m0(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out, val, wt);
+    pack_T_f32(L, t, T_out);
+  } else if (mode == ORC_MODE_MIXED) {
+    double L[9], t[3];
+    ok = estimate_combined_m1(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out, val, wt);
+    pack_T_f64(L, t, T_out);
+  } else {
+    double L[9], t[3];
+    ok = estimate_combined_m2(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out, val, wt);
+    pack_T_f64(L, t, T_out);
+  }
+  return ok;
+}
+
 int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* src_p, const float* src_n,
                           const int64_t* di, const int64_t* si, size_t n, float w_p2p, float w_p2pl,
                           size_t max_iter, float conv_tol, const float dst_mean[3],
                           const float src_mean[3], int mode, float T_out[16], double* AtA_out,
                           double* Atb_out) {
-  int ok;
-  if (mode == ORC_MODE_F32) {
-    float L[9], t[3];
-    ok = estimate_combined_m0(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
-    pack_T_f32(L, t, T_out);
-  } else if (mode == ORC_MODE_MIXED) {
-    double L[9], t[3];
-    ok = estimate_combined_m1(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
-    pack_T_f64(L, t, T_out);
-  } else {
-    double L[9], t[3];
-    ok = estimate_combined_m2(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, AtA_out, Atb_out);
-    pack_T_f64(L, t, T_out);
-  }
-  return ok;
+  return orc_estimate_combined_w(dst_p, dst_n, src_p, src_n, di, si, n, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, mode, T_out,
+                                 AtA_out, Atb_out, NULL, NULL);
 }
 
 int orc_estimate_affine(const float* dst_p, const float* dst_n, const float* src_p, const int64_t* di, const int64_t* si,
@@ -675,10 +703,12 @@ void orc_mean3(const float* xyz, size_t n, int mode, float mean[3]) {
 /* One outer iteration's updateEstimate() given the correspondences.
  * icp_single_transform_point_to_point_metric.hpp:46-65 / icp_single_transform_combined_metric.hpp:173-217 */
 static float icp_update_impl(const float* dst_p, const float* dst_n, const float* src_trans,
-                             const float* src_nrm_trans, const float T_cur[16], const int64_t* di, const int64_t* si, size_t nc,
-                             const orc_icp_params* prm, const float dst_mean[3],
+                             const float* src_nrm_trans, const float T_cur[16], const int64_t* di, const int64_t* si, const float* val,
+                             size_t nc, const orc_icp_params* prm, const float dst_mean[3],
                              const float src_mean[3], float T_new[16]) {
   const int mode = prm->mode;
+  const orc_weights wts = {prm->point_weight_kind, prm->plane_weight_kind, prm->point_weight_sigma, prm->plane_weight_sigma};
+  const orc_weights* wt = (val && (wts.point_kind || wts.plane_kind)) ? &wts : NULL;
   if (prm->transform_mode == 1) {
     /* affine instances: the point-to-point class estimates on the raw coordinates (transform_estimation.hpp:50-102),
      * the combined class with (dst_mean_, transform_ * src_mean_) (icp_single_transform_combined_metric.hpp:199-204) */
@@ -715,15 +745,15 @@ static float icp_update_impl(const float* dst_p, const float* dst_n, const float
   orc_transform_points(T_cur, src_mean, 1, smt);
   if (mode == ORC_MODE_F32) {
     float L[9], t[3];
-    estimate_combined_m0(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    estimate_combined_m0(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL, val, wt);
     return compose_m0(L, t, T_cur, T_new);
   } else if (mode == ORC_MODE_MIXED) {
     double L[9], t[3];
-    estimate_combined_m1(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    estimate_combined_m1(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL, val, wt);
     return compose_m1(L, t, T_cur, T_new);
   } else {
     double L[9], t[3];
-    estimate_combined_m2(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL);
+    estimate_combined_m2(dst_p, dst_n, src_trans, src_nrm_trans, di, si, nc, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL, val, wt);
     return compose_m2(L, t, T_cur, T_new);
   }
 }
@@ -731,6 +761,12 @@ static float icp_update_impl(const float* dst_p, const float* dst_n, const float
 float orc_icp_update(const float* dst_p, const float* dst_n, size_t nd, const float* src_p,
                      const float* src_n, size_t ns, const float T_cur[16], const int64_t* di, const int64_t* si,
                      size_t nc, const orc_icp_params* prm, float T_new[16]) {
+  return orc_icp_update_w(dst_p, dst_n, nd, src_p, src_n, ns, T_cur, di, si, NULL, nc, prm, T_new);
+}
+
+float orc_icp_update_w(const float* dst_p, const float* dst_n, size_t nd, const float* src_p,
+                       const float* src_n, size_t ns, const float T_cur[16], const int64_t* di, const int64_t* si, const float* val,
+                       size_t nc, const orc_icp_params* prm, float T_new[16]) {
   float dst_mean[3], src_mean[3];
   orc_mean3(dst_p, nd, prm->mode, dst_mean);               /* combined ctor :51-58 */
   orc_mean3(src_p, ns, prm->mode, src_mean);
@@ -741,7 +777,7 @@ float orc_icp_update(const float* dst_p, const float* dst_n, size_t nd, const fl
     nrm_trans = (float*)malloc(3 * (ns ? ns : 1) * sizeof(float));
     orc_transform_normals(T_cur, src_n, ns, nrm_trans);
   }
-  float d = icp_update_impl(dst_p, dst_n, src_trans, nrm_trans, T_cur, di, si, nc, prm, dst_mean, src_mean, T_new);
+  float d = icp_update_impl(dst_p, dst_n, src_trans, nrm_trans, T_cur, di, si, val, nc, prm, dst_mean, src_mean, T_new);
   free(src_trans); free(nrm_trans);
   return d;
 }
@@ -804,7 +840,7 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
     out->t_knn_s += t1 - t0;
     float Tn[16];
     if (nq_trans) orc_transform_normals(T, src_n, ns, nq_trans);
-    last = icp_update_impl(dst_p, dst_n, q, nq_trans, T, di, si, nc, prm, dst_mean, src_mean, Tn);
+    last = icp_update_impl(dst_p, dst_n, q, nq_trans, T, di, si, d2, nc, prm, dst_mean, src_mean, Tn);
     memcpy(T, Tn, sizeof(T));
     out->t_est_s += now_s() - t1;
     out->last_ncorr = nc;

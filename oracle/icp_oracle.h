@@ -85,6 +85,13 @@ void orc_ldlt6_solve_f32(const float A[36], const float b[6], float x[6]);
 void orc_nearest_rotation_f64(const double L[9], double R[9]);
 void orc_nearest_rotation_f32(const float L[9], float R[9]);
 
+/* ---- correspondence weight evaluators (core/common_pair_evaluators.hpp:14-27, :30-43, :46-80) ---- */
+enum { ORC_W_UNITY = 0, ORC_W_IDENTITY = 1, ORC_W_RBF = 2 };
+typedef struct { int point_kind, plane_kind; float point_sigma, plane_sigma; } orc_weights;
+/* exp() as ONE pinned sequence of f32 operations (the HIP path runs the same one): nearest-integer reduction by ln 2 in two
+ * parts, degree-6 polynomial, exact scaling; 0 below -80.  tests/ hold it within 1 ulp of the correctly rounded value. */
+float orc_pinned_expf(float x);
+
 /* ---- estimators ------------------------------------------------------------------------------ */
 /* mode: 0 = all-f32 serial ("reference-like": ENABLE_NON_DETERMINISTIC_PARALLELISM off),
  *       1 = per-term f32, accumulate/solve f64 (what the HIP path mirrors, deterministic),
@@ -110,6 +117,13 @@ int orc_estimate_combined(const float* dst_xyz, const float* dst_nrm, const floa
                           const float dst_mean[3], const float src_mean[3], int mode,
                           float T_out[16], double* AtA_out, double* Atb_out);
 
+/* The same with weight evaluators: val[k] = value of correspondence k (its search distance), wt = the evaluators. */
+int orc_estimate_combined_w(const float* dst_xyz, const float* dst_nrm, const float* src_trans_xyz,
+                            const float* src_nrm_trans, const int64_t* dst_idx, const int64_t* src_idx, size_t ncorr,
+                            float w_p2p, float w_p2pl, size_t max_iter, float conv_tol,
+                            const float dst_mean[3], const float src_mean[3], int mode,
+                            float T_out[16], double* AtA_out, double* Atb_out, const float* val, const orc_weights* wt);
+
 /* ---- whole ICP loop (registration/icp_base.hpp:68-87 + the two instance classes) ------------- */
 typedef struct {
   int metric;            /* 0 = point-to-point (icp_single_transform_point_to_point_metric.hpp),
@@ -129,6 +143,8 @@ typedef struct {
   int transform_mode;    /* 0 = rigid instances, 1 = affine (icp_common_instances.hpp:253-267) */
   float normal_weight;   /* > 0: the engine runs on PointNormalFeaturesAdaptor features (needs both clouds' normals); direction 0 */
   int three_cloud_metric; /* source normals feed the feature adaptor only (three-cloud ICP constructor): no symmetric metric */
+  int point_weight_kind, plane_weight_kind;      /* ORC_W_*: the combined-metric classes' correspondence weight evaluators */
+  float point_weight_sigma, plane_weight_sigma;  /* RBF evaluators' sigma */
 } orc_icp_params;
 
 typedef struct {
@@ -167,6 +183,12 @@ float orc_icp_update(const float* dst_xyz, const float* dst_nrm, size_t nd, cons
                      const float* src_nrm_or_null, size_t ns, const float T_cur[16], const int64_t* dst_idx,
                      const int64_t* src_idx, size_t ncorr, const orc_icp_params* prm,
                      float T_new[16]);
+
+/* orc_icp_update with the correspondences' values (read by prm's weight evaluators; NULL = unity). */
+float orc_icp_update_w(const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz,
+                       const float* src_nrm_or_null, size_t ns, const float T_cur[16], const int64_t* dst_idx,
+                       const int64_t* src_idx, const float* val, size_t ncorr, const orc_icp_params* prm,
+                       float T_new[16]);
 
 /* rowwise().mean() as the reference ctor does (icp_single_transform_combined_metric.hpp:51-58):
  * f32 serial sum / n. */

@@ -46,7 +46,16 @@ class IcpParams(C.Structure):
         ("num_threads", C.c_int), ("inlier_fraction", C.c_double), ("one_to_one", C.c_int),
         ("direction", C.c_int), ("reciprocal", C.c_int), ("transform_mode", C.c_int),
         ("normal_weight", C.c_float), ("three_cloud_metric", C.c_int),
+        ("point_weight_kind", C.c_int), ("plane_weight_kind", C.c_int),
+        ("point_weight_sigma", C.c_float), ("plane_weight_sigma", C.c_float),
     ]
+
+
+class Weights(C.Structure):
+    _fields_ = [("point_kind", C.c_int), ("plane_kind", C.c_int), ("point_sigma", C.c_float), ("plane_sigma", C.c_float)]
+
+
+W_UNITY, W_IDENTITY, W_RBF = 0, 1, 2
 
 
 class IcpResult(C.Structure):
@@ -104,6 +113,15 @@ def lib():
         L.orc_estimate_combined.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, _i64p, _i64p, C.c_size_t, C.c_float,
                                             C.c_float, C.c_size_t, C.c_float, _f32p, _f32p, C.c_int,
                                             _f32p, C.c_void_p, C.c_void_p]
+        L.orc_estimate_combined_w.restype = C.c_int
+        L.orc_estimate_combined_w.argtypes = [_f32p, _f32p, _f32p, C.c_void_p, _i64p, _i64p, C.c_size_t, C.c_float,
+                                              C.c_float, C.c_size_t, C.c_float, _f32p, _f32p, C.c_int,
+                                              _f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_icp_update_w.restype = C.c_float
+        L.orc_icp_update_w.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_void_p, C.c_size_t, _f32p, _i64p,
+                                       _i64p, C.c_void_p, C.c_size_t, C.POINTER(IcpParams), _f32p]
+        L.orc_pinned_expf.restype = C.c_float
+        L.orc_pinned_expf.argtypes = [C.c_float]
         L.orc_icp_run.restype = C.c_int
         L.orc_icp_run.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_void_p, C.c_size_t, C.c_void_p,
                                   C.POINTER(IcpParams), C.c_void_p, C.POINTER(IcpResult)]
@@ -270,15 +288,20 @@ def transform_normals(T, nrm):
 
 
 def estimate_combined(dst, dst_n, src_trans, dst_idx, src_idx, w_p2p, w_p2pl, dst_mean, src_mean,
-                      max_iter=1, conv_tol=1e-5, mode=MODE_MIXED, src_n_trans=None):
+                      max_iter=1, conv_tol=1e-5, mode=MODE_MIXED, src_n_trans=None, values=None, weights=None):
+    """values / weights=(point kind, plane kind, point sigma, plane sigma): the correspondences' values and the weight
+    evaluators applied to them"""
     dst = _c(dst).reshape(-1, 3); dst_n = _c(dst_n).reshape(-1, 3)
     src_trans = _c(src_trans).reshape(-1, 3)
     di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
     T = np.zeros(16, np.float32); AtA = np.zeros(36, np.float64); Atb = np.zeros(6, np.float64)
     sn = _c(src_n_trans).reshape(-1, 3) if src_n_trans is not None else None
-    ok = lib().orc_estimate_combined(dst, dst_n, src_trans, sn.ctypes.data if sn is not None else None, di, si, len(di), w_p2p, w_p2pl, max_iter,
-                                     conv_tol, _c(dst_mean).reshape(3), _c(src_mean).reshape(3), mode,
-                                     T, AtA.ctypes.data, Atb.ctypes.data)
+    val = _c(values) if values is not None else None
+    wt = Weights(int(weights[0]), int(weights[1]), float(weights[2]), float(weights[3])) if weights is not None else None
+    ok = lib().orc_estimate_combined_w(dst, dst_n, src_trans, sn.ctypes.data if sn is not None else None, di, si, len(di), w_p2p, w_p2pl, max_iter,
+                                       conv_tol, _c(dst_mean).reshape(3), _c(src_mean).reshape(3), mode,
+                                       T, AtA.ctypes.data, Atb.ctypes.data, val.ctypes.data if val is not None else None,
+                                       C.byref(wt) if wt is not None else None)
     return T_from_colmajor(T), AtA.reshape(6, 6), Atb, bool(ok)
 
 
@@ -348,11 +371,14 @@ def mean3(pts, mode=MODE_MIXED):
 def make_params(metric=METRIC_COMBINED, w_p2p=0.0, w_p2pl=1.0, max_iter=15, conv_tol=1e-5,
                 max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=1e-4, mode=MODE_MIXED, num_threads=0,
                 inlier_fraction=1.0, one_to_one=False, direction=0, reciprocal=False, affine=False,
-                normal_weight=0.0, three_cloud_metric=False):
-    """direction: 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH; affine: the Affine ICP instances"""
+                normal_weight=0.0, three_cloud_metric=False, point_weight=W_UNITY, plane_weight=W_UNITY,
+                point_sigma=1.0, plane_sigma=1.0):
+    """direction: 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH; affine: the Affine ICP instances;
+    point_weight / plane_weight: W_* correspondence weight evaluators of the combined-metric classes"""
     return IcpParams(metric, w_p2p, w_p2pl, max_iter, conv_tol, max_opt_iter, opt_conv_tol,
                      max_sq_dist, mode, num_threads, inlier_fraction, 1 if one_to_one else 0, int(direction), 1 if reciprocal else 0,
-                     1 if affine else 0, float(normal_weight), 1 if three_cloud_metric else 0)
+                     1 if affine else 0, float(normal_weight), 1 if three_cloud_metric else 0,
+                     int(point_weight), int(plane_weight), float(point_sigma), float(plane_sigma))
 
 
 def filter_fraction(dst_idx, src_idx, d2, fraction):
@@ -388,15 +414,22 @@ def icp_run(dst, dst_n, src, params, T0=None, tree=None, src_n=None):
     }
 
 
-def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params, src_n=None):
+def pinned_expf(x):
+    x = _c(x).reshape(-1)
+    f = lib().orc_pinned_expf
+    return np.array([f(float(v)) for v in x], np.float32)
+
+
+def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params, src_n=None, values=None):
     dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3)
     dn = _c(dst_n).reshape(-1, 3) if dst_n is not None else None
     di = _c(dst_idx, np.int64); si = _c(src_idx, np.int64)
     Tn = np.zeros(16, np.float32)
     sn = _c(src_n).reshape(-1, 3) if src_n is not None else None
-    d = lib().orc_icp_update(dst, dn.ctypes.data if dn is not None else None, len(dst), src,
-                             sn.ctypes.data if sn is not None else None, len(src),
-                             T_to_colmajor(T_cur), di, si, len(di), C.byref(params), Tn)
+    val = _c(values) if values is not None else None
+    d = lib().orc_icp_update_w(dst, dn.ctypes.data if dn is not None else None, len(dst), src,
+                               sn.ctypes.data if sn is not None else None, len(src),
+                               T_to_colmajor(T_cur), di, si, val.ctypes.data if val is not None else None, len(di), C.byref(params), Tn)
     return T_from_colmajor(Tn), float(d)
 
 

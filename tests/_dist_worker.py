@@ -198,6 +198,8 @@ def main_slab(metric, n, slack_cells):
 
 
 def main():
+    import signal
+    signal.alarm(300)      # a worker never outlives its test (SIGALRM's default action terminates the process)
     metric = int(sys.argv[1]); n = int(sys.argv[2])
     if len(sys.argv) > 3 and sys.argv[3] == "tshard":
         return main_target_sharded(metric, n)

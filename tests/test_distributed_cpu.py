@@ -3,6 +3,7 @@ gloo.  The per-rank compute is a test-only engine (the oracle); what is under te
 sharding / reduction protocol in cilantro_amd/distributed.py."""
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -25,9 +26,16 @@ def _run(world, metric, n, mode=""):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_dist_worker.py"), str(metric), str(n)] + ([mode] if mode else [])
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    # own process group, killed as a whole on a timeout: a worker that outlives the launcher would keep the host busy
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        stdout, stderr = proc.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, stderr = proc.communicate()
+        raise AssertionError("distributed worker timed out\n" + stdout[-2000:] + stderr[-2000:])
+    assert proc.returncode == 0, stdout[-2000:] + stderr[-2000:]
+    line = [l for l in stdout.splitlines() if l.startswith("RESULT ")][-1]
     return json.loads(line[7:])
 
 

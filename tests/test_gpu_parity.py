@@ -1422,3 +1422,109 @@ def test_adaptive_kernel_form_and_pacing(orc, hip_lib):
     # a second run on the same pair starts in the form the first one ended in
     icp.setMaxNumberOfIterations(3).setConvergenceTolerance(0.0).setInitialTransform(Tg).estimate()
     assert icp._ctx.last_run_forms() == (3, 0)
+
+
+@pytest.mark.gpu
+def test_correspondence_weight_evaluators_vs_oracle(Context, orc, hip_lib):
+    """The combined-metric classes' correspondence weight evaluators (icp_single_transform_combined_metric.hpp:11-14;
+    core/common_pair_evaluators.hpp:14-27 Identity, :30-43 Unity, :46-80 RBF): per-pair f32 weight = metric weight *
+    evaluator(corr.value) (transform_estimation.hpp:301-303, :330-332).  Normal equations of one step against the oracle's,
+    then whole loops -- plain, with engine post-filters, with 6-D feature distances as the values, in the other search
+    directions, with several Gauss-Newton steps -- against the oracle's loop."""
+    from cilantro_amd.icp import (CorrespondenceSearchDirection as D, IdentityWeightEvaluator, RBFKernelWeightEvaluator,
+                                  SimpleCombinedMetricAffineICP3f, SimpleCombinedMetricRigidICP3f, UnityWeightEvaluator)
+
+    U, I, R = orc.W_UNITY, orc.W_IDENTITY, orc.W_RBF
+    d = syn.make_pair(200000, perturb=0.5)
+    r2 = float(d["max_sq_dist"])
+    sigma = 0.4 * np.sqrt(r2)                                    # weights between exp(-3.1) and 1 over the radius
+    T = syn.true_transform(d["h"], 0.1).astype(np.float32)
+    ctx = Context()
+    ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+    ctx.find_correspondences(T, r2)
+    g1, g2, gv = ctx.get_correspondences()
+    q = orc.transform_points(T, d["src"])
+    dm, sm = ctx.means()
+    smt = orc.transform_points(T, sm.reshape(1, 3))[0]
+    for pk, lk, w_p2p, w_p2pl in ((U, R, 0.0, 1.0), (R, R, 0.3, 1.0), (I, U, 1.0, 0.0), (R, I, 0.5, 0.7), (U, U, 0.2, 1.0)):
+        ctx.set_option("point_weight_evaluator", pk); ctx.set_option("plane_weight_evaluator", lk)
+        ctx.set_option("point_weight_sigma", sigma); ctx.set_option("plane_weight_sigma", 2.0 * sigma)
+        Tg, AtA, Atb, cv = ctx.estimate_combined(w_p2p, w_p2pl, 1, 1e-5)
+        To, AtAo, Atbo, cvo = orc.estimate_combined(d["dst"], d["dst_n"], q, g1, g2, w_p2p, w_p2pl, dm, smt, 1, 1e-5, orc.MODE_MIXED,
+                                                    values=gv, weights=(pk, lk, sigma, 2.0 * sigma))
+        scale = np.abs(AtAo).max()
+        # plane terms: the same f32 per-term quantities and weights, f64 sums (order differs); point terms: the oracle forms
+        # E E^T per pair in f32, the kernel in f64
+        tol = 1e-9 if w_p2p == 0.0 else 2e-6
+        assert np.abs(AtA - AtAo).max() <= tol * scale, (pk, lk, np.abs(AtA - AtAo).max() / scale)
+        assert np.abs(Atb - Atbo).max() <= tol * np.abs(Atbo).max() + 1e-3 * tol * scale, (pk, lk)
+        assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6 and cv == cvo, (pk, lk)
+        # several Gauss-Newton steps over the same weighted correspondences
+        Tg, _, _, cv = ctx.estimate_combined(w_p2p, w_p2pl, 3, 1e-7)
+        To, _, _, cvo = orc.estimate_combined(d["dst"], d["dst_n"], q, g1, g2, w_p2p, w_p2pl, dm, smt, 3, 1e-7, orc.MODE_MIXED,
+                                              values=gv, weights=(pk, lk, sigma, 2.0 * sigma))
+        assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6 and cv == cvo, (pk, lk)
+    # the weights change the estimate (the test would pass vacuously otherwise)
+    ctx.set_option("point_weight_evaluator", U); ctx.set_option("plane_weight_evaluator", U)
+    Tu = ctx.estimate_combined(0.0, 1.0, 1, 1e-5)[0]
+    ctx.set_option("plane_weight_evaluator", R); ctx.set_option("plane_weight_sigma", sigma)
+    Tr = ctx.estimate_combined(0.0, 1.0, 1, 1e-5)[0]
+    assert np.linalg.norm(Tu - Tr) > 1e-6
+
+    def evaluator(kind, s):
+        return UnityWeightEvaluator() if kind == U else IdentityWeightEvaluator() if kind == I else RBFKernelWeightEvaluator(s)
+
+    # whole loops
+    dl = syn.make_pair(100000, perturb=0.5)
+    r2 = float(dl["max_sq_dist"]); sigma = 0.4 * np.sqrt(r2)
+    for pk, lk, w_p2p, w_p2pl, steps, frac, o2o, tiled in ((U, R, 0.0, 1.0, 1, 1.0, False, 2), (R, R, 0.2, 1.0, 2, 1.0, False, 2),
+                                                           (I, I, 0.5, 0.5, 1, 1.0, False, 0), (R, U, 0.1, 1.0, 1, 0.8, True, 2)):
+        icp = SimpleCombinedMetricRigidICP3f(dl["dst"], dl["dst_n"], dl["src"])
+        icp._ctx.set_option("tiled", tiled)
+        icp.setPointToPointMetricWeight(w_p2p).setPointToPlaneMetricWeight(w_p2pl)
+        icp.setCorrespondenceWeightEvaluators(evaluator(pk, sigma), evaluator(lk, sigma))
+        assert icp.pointToPlaneCorrespondenceWeightEvaluator().kind == lk
+        icp.setMaxNumberOfOptimizationStepIterations(steps).setOptimizationStepConvergenceTolerance(1e-6)
+        icp.correspondenceSearchEngine().setMaxDistance(r2).setInlierFraction(frac).setOneToOne(o2o)
+        icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, w_p2p=w_p2p, w_p2pl=w_p2pl, max_iter=8, conv_tol=0.0, max_opt_iter=steps, opt_conv_tol=1e-6,
+                            max_sq_dist=r2, mode=orc.MODE_MIXED, inlier_fraction=frac, one_to_one=o2o, point_weight=pk, plane_weight=lk,
+                            point_sigma=sigma, plane_sigma=sigma)
+        ro = orc.icp_run(dl["dst"], dl["dst_n"], dl["src"], p)
+        err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
+        assert err <= TOL_T and icp.last_ncorr_ == ro["last_ncorr"], (pk, lk, w_p2p, w_p2pl, steps, frac, o2o, err)
+        assert icp._ctx.last_run_forms()[0] == 0                 # never the in-tile (unweighted) accumulation
+    # the other search directions (list-free reverse accumulation): the value of a reverse match is its search distance too
+    for direction, recip, code in ((D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 2), (D.BOTH, True, 2)):
+        icp = SimpleCombinedMetricRigidICP3f(dl["dst"], dl["dst_n"], dl["src"])
+        icp.setPointToPointMetricWeight(0.1).setCorrespondenceWeightEvaluators(evaluator(R, sigma), evaluator(R, 1.5 * sigma))
+        icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
+        icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, w_p2p=0.1, w_p2pl=1.0, max_sq_dist=r2, max_iter=6, conv_tol=0.0, direction=code, reciprocal=recip,
+                            point_weight=R, plane_weight=R, point_sigma=sigma, plane_sigma=1.5 * sigma)
+        ro = orc.icp_run(dl["dst"], dl["dst_n"], dl["src"], p)
+        err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
+        assert err <= TOL_T and icp.last_ncorr_ == ro["last_ncorr"], (direction, recip, err)
+    # 6-D feature correspondences: the evaluator reads the FEATURE distance
+    dn = syn.make_pair(20000, perturb=0.5)
+    h = dn["h"]; w = 0.5 * h; r6 = float((2.5 * h) ** 2)
+    sn_true = orc.transform_normals(np.linalg.inv(dn["T_true"].astype(np.float64)).astype(np.float32), dn["dst_n"])
+    for tiled in (0, 2):
+        icp = SimpleCombinedMetricRigidICP3f(dn["dst"], dn["dst_n"], dn["src"])
+        icp._ctx.set_option("tiled", tiled)
+        icp.correspondenceSearchEngine().setMaxDistance(r6).setPointNormalFeatureAdaptors(sn_true, w)
+        icp.setCorrespondenceWeightEvaluators(None, evaluator(R, 0.5 * np.sqrt(r6)))
+        icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=r6, mode=orc.MODE_MIXED, normal_weight=w, three_cloud_metric=True,
+                            plane_weight=R, plane_sigma=0.5 * np.sqrt(r6))
+        ro = orc.icp_run(dn["dst"], dn["dst_n"], dn["src"], p, src_n=sn_true)
+        assert np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64)) <= TOL_T and icp.last_ncorr_ == ro["last_ncorr"], tiled
+    # the affine classes take unity evaluators only: anything else fails loudly
+    icp = SimpleCombinedMetricAffineICP3f(dl["dst"], dl["dst_n"], dl["src"])
+    icp.setCorrespondenceWeightEvaluators(None, evaluator(R, sigma))
+    icp.correspondenceSearchEngine().setMaxDistance(r2)
+    with pytest.raises(RuntimeError):
+        icp.estimate()

@@ -343,3 +343,68 @@ def test_radius_search_oracle_vs_reference_nanoflann(orc):
     # a query point that is a tree point sits in its own list at distance 0 (first)
     off, idx, d2 = orc.radius_search(pts, pts[:5], 0.05 ** 2)
     assert all(idx[off[i]] == i and d2[off[i]] == 0.0 for i in range(5))
+
+
+def test_weight_evaluators_vs_numpy(orc):
+    """core/common_pair_evaluators.hpp:14-27 / :30-43 / :46-80 inside the combined-metric estimator
+    (transform_estimation.hpp:301-303, :330-332): weighted normal equations against a direct numpy evaluation, the pinned
+    exp against the correctly rounded one, and a weighted loop that still converges to the ground truth."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([-np.abs(rng.standard_normal(20000).astype(np.float32)) * 12, np.float32([0, -1e-8, -79.9, -80.0, -80.1, -1e4])])
+    y = orc.pinned_expf(x)
+    ref = np.exp(x.astype(np.float64))
+    m = x >= -80.0
+    assert np.all(np.abs(y[m].astype(np.float64) - ref[m]) <= 1.0 * np.spacing(ref[m].astype(np.float32)))   # within 1 ulp
+    assert np.all(y[~m] == 0.0) and y[-6] == 1.0
+
+    d = syn.make_pair(3000, perturb=0.4)
+    q = orc.transform_points(np.eye(4), d["src"])
+    di, si, dv = orc.KDTree(d["dst"]).find_correspondences(q, d["max_sq_dist"])
+    P = d["dst"][di].astype(np.float64); Q = q[si].astype(np.float64); N = d["dst_n"][di].astype(np.float64)
+    dm = orc.mean3(d["dst"]); sm = orc.mean3(q)
+    sig_p, sig_l = 0.4 * float(np.sqrt(d["max_sq_dist"])), 0.8 * float(np.sqrt(d["max_sq_dist"]))
+
+    def weights(kind, sigma, w_metric):
+        v = dv.astype(np.float64)
+        if kind == orc.W_UNITY:
+            e = np.ones_like(v)
+        elif kind == orc.W_IDENTITY:
+            e = v
+        else:
+            e = np.exp(float(np.float32(-0.5) / (np.float32(sigma) * np.float32(sigma))) * v)
+        return float(np.float32(w_metric)) * e
+
+    for pk, lk, w_p2p, w_p2pl in ((orc.W_UNITY, orc.W_RBF, 0.0, 1.0), (orc.W_RBF, orc.W_RBF, 0.3, 1.0), (orc.W_IDENTITY, orc.W_UNITY, 1.0, 0.0),
+                                  (orc.W_RBF, orc.W_IDENTITY, 0.5, 0.7)):
+        wp, wl = weights(pk, sig_p, w_p2p), weights(lk, sig_l, w_p2pl)
+        dd = P - dm.astype(np.float64); ss = Q - sm.astype(np.float64)
+        a = dd + ss; r = dd - ss
+        AtA_np = np.zeros((6, 6)); Atb_np = np.zeros(6)
+        if w_p2pl > 0:
+            e = np.concatenate([np.cross(a, N), N], 1)
+            AtA_np += (e * wl[:, None]).T @ e
+            Atb_np += (e * wl[:, None]).T @ (N * r).sum(1)
+        if w_p2p > 0:
+            for i in range(len(P)):
+                ax = np.array([[0, -a[i, 2], a[i, 1]], [a[i, 2], 0, -a[i, 0]], [-a[i, 1], a[i, 0], 0]])
+                E = np.concatenate([ax, np.eye(3)], 0)
+                AtA_np += wp[i] * E @ E.T
+                Atb_np += wp[i] * E @ r[i]
+        Ts = {}
+        for mode, tol in ((orc.MODE_F64, 1e-9), (orc.MODE_MIXED, 2e-6), (orc.MODE_F32, 1e-4)):
+            T, AtA, Atb, _ = orc.estimate_combined(d["dst"], d["dst_n"], q, di, si, w_p2p, w_p2pl, dm, sm, 1, 1e-5, mode,
+                                                   values=dv, weights=(pk, lk, sig_p, sig_l))
+            np.testing.assert_allclose(AtA, AtA_np, rtol=0, atol=tol * np.abs(AtA_np).max())
+            np.testing.assert_allclose(Atb, Atb_np, rtol=0, atol=tol * np.abs(Atb_np).max() + 1e-3 * tol * np.abs(AtA_np).max())
+            Ts[mode] = T
+        assert np.abs(Ts[orc.MODE_MIXED] - Ts[orc.MODE_F64]).max() < 1e-6 and np.abs(Ts[orc.MODE_F32] - Ts[orc.MODE_F64]).max() < 5e-5
+    # unity evaluators through the weighted entry point = the plain one, bit for bit
+    T0, A0, b0, _ = orc.estimate_combined(d["dst"], d["dst_n"], q, di, si, 0.3, 1.0, dm, sm, 2, 1e-7, orc.MODE_MIXED)
+    T1, A1, b1, _ = orc.estimate_combined(d["dst"], d["dst_n"], q, di, si, 0.3, 1.0, dm, sm, 2, 1e-7, orc.MODE_MIXED, values=dv,
+                                          weights=(orc.W_UNITY, orc.W_UNITY, 1.0, 1.0))
+    assert np.array_equal(T0, T1) and np.array_equal(A0, A1) and np.array_equal(b0, b1)
+    # a weighted loop still lands on the ground truth
+    p = orc.make_params(metric=1, w_p2p=0.1, max_iter=30, conv_tol=1e-5, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED,
+                        point_weight=orc.W_RBF, plane_weight=orc.W_RBF, point_sigma=sig_p, plane_sigma=sig_l)
+    r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+    assert r["last_delta_norm"] < 1e-5 and np.linalg.norm(r["T"] - d["T_true"]) < 2e-3
