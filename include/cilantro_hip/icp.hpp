@@ -336,6 +336,23 @@ private:
   }
 };
 
+// The correspondence weight evaluators of the combined-metric classes (core/common_pair_evaluators.hpp:14-27 Identity,
+// :30-43 Unity, :46-80 RBF kernel over squared distances).  The reference fixes their TYPES as template arguments
+// (icp_single_transform_combined_metric.hpp:11-14); here one runtime object covers the three.
+class CorrespondenceWeightEvaluator {
+public:
+  enum Kind { Unity = 0, Identity = 1, RBFKernel = 2 };
+  CorrespondenceWeightEvaluator(Kind kind = Unity, float sigma = 1.0f) : kind_(kind), sigma_(sigma) {}
+  inline CorrespondenceWeightEvaluator& setKind(Kind k) { kind_ = k; return *this; }
+  inline CorrespondenceWeightEvaluator& setSigma(float sigma) { sigma_ = sigma; return *this; }   // :55-58
+  inline Kind kind() const { return kind_; }
+  inline float sigma() const { return sigma_; }
+
+private:
+  Kind kind_;
+  float sigma_;
+};
+
 // icp_single_transform_combined_metric.hpp + icp_common_instances.hpp:74-97,261
 class SimpleCombinedMetricRigidICP3f : public IterativeClosestPointBase<SimpleCombinedMetricRigidICP3f> {
   using Base = IterativeClosestPointBase<SimpleCombinedMetricRigidICP3f>;
@@ -372,9 +389,16 @@ public:
   inline SimpleCombinedMetricRigidICP3f& setMaxNumberOfOptimizationStepIterations(size_t n) { max_optimization_iterations_ = n; return *this; }
   inline float getOptimizationStepConvergenceTolerance() const { return optimization_convergence_tol_; }
   inline SimpleCombinedMetricRigidICP3f& setOptimizationStepConvergenceTolerance(float t) { optimization_convergence_tol_ = t; return *this; }
+  // icp_single_transform_combined_metric.hpp:95-101
+  inline CorrespondenceWeightEvaluator& pointToPointCorrespondenceWeightEvaluator() { return point_corr_eval_; }
+  inline CorrespondenceWeightEvaluator& pointToPlaneCorrespondenceWeightEvaluator() { return plane_corr_eval_; }
 
 private:
   void fillParams(cilhip_icp_params& p) const {
+    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "point_weight_evaluator", (double)point_corr_eval_.kind()), "point_weight_evaluator");
+    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "point_weight_sigma", (double)point_corr_eval_.sigma()), "point_weight_sigma");
+    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "plane_weight_evaluator", (double)plane_corr_eval_.kind()), "plane_weight_evaluator");
+    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "plane_weight_sigma", (double)plane_corr_eval_.sigma()), "plane_weight_sigma");
     p.metric = CILHIP_METRIC_COMBINED;
     p.w_p2p = point_to_point_weight_;
     p.w_p2pl = point_to_plane_weight_;
@@ -392,6 +416,7 @@ private:
   float optimization_convergence_tol_;
   float point_to_point_weight_;
   float point_to_plane_weight_;
+  CorrespondenceWeightEvaluator point_corr_eval_, plane_corr_eval_;
 };
 
 // Affine instances (registration/icp_common_instances.hpp:255, :266): the same loop and correspondence engine with an

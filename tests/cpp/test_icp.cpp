@@ -102,6 +102,22 @@ int main(int argc, char** argv) {
     std::printf("BOTH+reciprocal: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp3.getNumberOfPerformedIterations(), r.iterations, e3);
     if (!(e3 <= 1e-5) || icp3.getNumberOfPerformedIterations() != r.iterations) ++failures;
 
+    // correspondence weight evaluators (icp_single_transform_combined_metric.hpp:95-101): RBF on the plane terms, Identity on the point terms
+    SimpleCombinedMetricRigidICP3f icp6(dst_v, nrm_v, src_v);
+    icp6.setPointToPointMetricWeight(0.2f).setPointToPlaneMetricWeight(1.0f);
+    icp6.pointToPlaneCorrespondenceWeightEvaluator().setKind(CorrespondenceWeightEvaluator::RBFKernel).setSigma((float)h);
+    icp6.pointToPointCorrespondenceWeightEvaluator().setKind(CorrespondenceWeightEvaluator::Identity);
+    icp6.correspondenceSearchEngine().setMaxDistance(max_sq);
+    icp6.setConvergenceTolerance(0.0f).setMaxNumberOfIterations(8).estimate();
+    std::memset(&p, 0, sizeof(p));
+    p.metric = 1; p.w_p2p = 0.2f; p.w_p2pl = 1; p.max_iter = 8; p.conv_tol = 0.0f; p.max_opt_iter = 1; p.opt_conv_tol = 1e-5f;
+    p.max_sq_dist = max_sq; p.mode = ORC_MODE_MIXED;
+    p.point_weight_kind = ORC_W_IDENTITY; p.plane_weight_kind = ORC_W_RBF; p.point_weight_sigma = 1.0f; p.plane_weight_sigma = (float)h;
+    orc_icp_run(dst.data(), nrm.data(), n, src.data(), nullptr, n, nullptr, &p, nullptr, &r);
+    const double e6 = frob(icp6.getTransform().m, r.T);
+    std::printf("weight evaluators: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp6.getNumberOfPerformedIterations(), r.iterations, e6);
+    if (!(e6 <= 1e-5)) ++failures;
+
     // affine instances (icp_common_instances.hpp:255, :266) through the mirrors
     SimpleCombinedMetricAffineICP3f icp4(dst_v, nrm_v, src_v);
     icp4.setPointToPointMetricWeight(0.1f).setPointToPlaneMetricWeight(1.0f);
