@@ -242,7 +242,7 @@ def bench_icp(a, torch, rank, world, local_rank):
         search_ms, acc_ms = ctx.last_timing2()
         ns_l, nd_l, nc = len(src_l), len(dst_l), int(res.last_ncorr)
         one_pass_iters, two_pass_iters = ctx.last_run_forms()
-        fused = (launches > 0 and acc_ms == 0.0) if sharded else (launches > 0 and two_pass_iters == 0 and one_pass_iters > 0)
+        fused = launches > 0 and two_pass_iters == 0 and one_pass_iters > 0     # (sharded runs: counted per partial-sums call)
         # Algorithmic (compulsory) bytes, SURVEY.md 8(d): every datum touched once.
         #   search + accumulation in ONE pass (the default: no index round trip):  12 Ns + 12 Nd + 12 Nc (the matched normals;
         #   point-to-point: the matched points are part of the 12 Nd)
@@ -294,7 +294,7 @@ def bench_icp(a, torch, rank, world, local_rank):
                        "grid": [gi.nx, gi.ny, gi.nz], "grid_cell": gi.cell, "grid_avg_occupancy": gi.avg_occupancy},
             "setup_ms": t_setup * 1e3, "source_sort_ms": sort_ms, "loop_ms_hip_events": loop_ms,
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,
-            "iterations_one_pass": one_pass_iters if not sharded else None, "iterations_two_pass": two_pass_iters if not sharded else None,
+            "iterations_one_pass": one_pass_iters, "iterations_two_pass": two_pass_iters,
             "roofline": roof,
         }
     if not sharded and not a.no_extras:

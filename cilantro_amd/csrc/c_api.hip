@@ -1284,6 +1284,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   CK(c, hipGetLastError());
   c->run_active = true;
   c->run_nev = 0;
+  c->last_fused_iters = c->last_two_pass_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
   return CILHIP_OK;
 }
 
@@ -1311,7 +1312,9 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
         prows = tiled_partial_rows(c->ntiles);
+        ++c->last_fused_iters;
       } else {
+        ++c->last_two_pass_iters;
         if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         else launch_iter(a, IM_NONE, true, true, nb, c->stream);
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));

@@ -294,7 +294,8 @@ typedef struct {
 int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
 /* How the iterations of the last cilhip_icp_run were executed: as ONE pass (search with the accumulation inside the LDS
  * tiles) or as TWO (search with its in-tile 3x3x3 second pass, then the streaming accumulation).  Large clouds choose per
- * iteration from the device's count of queries the first search stage left unproven (source far from alignment: two passes). */
+ * iteration from the device's count of queries the first search stage left unproven (source far from alignment: two passes).
+ * Sharded runs: the same two counts over the cilhip_icp_partial_sums calls since cilhip_icp_begin. */
 int cilhip_get_last_run_forms(cilhip_ctx* ctx, int* one_pass_iterations, int* two_pass_iterations);
 
 /* ms of the kernels of the last cilhip_icp_run, measured with hipEvents on the ctx stream:
