@@ -53,7 +53,8 @@ struct cilhip_ctx {
   unsigned int run_tag = 0;
   bool far_mode = true;                        // tiled ICP loop: the source is far from alignment (many unproven octant searches): search and
                                                // accumulate in two passes (the search's 3x3x3 pass settles them in LDS) instead of one
-  int last_fused_iters = 0, last_two_pass_iters = 0;
+  int last_fused_iters = 0, last_two_pass_iters = 0, last_warm_iters = 0;
+  int warm_start = 1;             // option "warm_start": 0 = never, 1 = when the device reports the source near alignment, 2 = from the second iteration on
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint32_t ntiles = 0;
   int tiled = 1;                  // 0: per-lane global-memory search; 1: LDS-tiled search when the cloud is large enough; 2: always tiled
@@ -64,6 +65,7 @@ struct cilhip_ctx {
   float4* d_src_nrm_sorted = nullptr;
   uint32_t* d_nn_pos = nullptr;
   float* d_nn_d2 = nullptr;
+  float* d_safe2 = nullptr;       // [grid.n] k_self_nn's table for the warm-started iteration; built with the target
   int cw_point_kind = 0, cw_plane_kind = 0;     // correspondence weight evaluators (CW_*), combined metric
   float cw_point_sigma = 1.0f, cw_plane_sigma = 1.0f;
   bool have_nn = false;           // nn_pos/nn_d2 hold the result of a search
@@ -199,6 +201,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   free_source(c);
   if (c->has_target) free_grid(c->grid);
+  if (c->d_safe2) (void)hipFree(c->d_safe2);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_state_id) (void)hipFree(c->d_state_id);
   free_pairs(c->pairs);
@@ -245,6 +248,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
+  if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "point_weight_evaluator") || !strcmp(key, "plane_weight_evaluator")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "weight evaluator: 0 = Unity, 1 = Identity, 2 = RBF kernel");
     (key[1] == 'o' ? c->cw_point_kind : c->cw_plane_kind) = (int)value;
@@ -300,6 +304,12 @@ int cilhip_get_last_timing2(cilhip_ctx* c, double* search_ms, double* accumulate
   return CILHIP_OK;
 }
 
+int cilhip_get_last_warm_iterations(cilhip_ctx* c, int* warm_iterations) {
+  if (!c || !warm_iterations) return CILHIP_ERR_INVALID;
+  *warm_iterations = c->last_warm_iters;
+  return CILHIP_OK;
+}
+
 int cilhip_get_last_run_forms(cilhip_ctx* c, int* one_pass_iterations, int* two_pass_iterations) {
   if (!c) return CILHIP_ERR_INVALID;
   if (one_pass_iterations) *one_pass_iterations = c->last_fused_iters;
@@ -342,6 +352,9 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (d_nrm) (void)hipFree(d_nrm);
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
+  if (c->d_safe2) { (void)hipFree(c->d_safe2); c->d_safe2 = nullptr; }
+  CK(c, hipMalloc(&c->d_safe2, (c->grid.n ? c->grid.n : 1) * sizeof(float)));
+  launch_self_nn(c->grid, c->d_safe2, c->stream);
   c->has_normals = (nrm != nullptr);
   for (int i = 0; i < 3; ++i) c->dst_mean[i] = (float)mean[i];
   c->has_target = true;
@@ -1160,7 +1173,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   // streaming accumulation; once nearly all are proven, search + accumulation run as one pass inside the tiles.
   const bool paced = tile_acc && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
   if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
-  c->last_fused_iters = c->last_two_pass_iters = 0;
+  c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
   for (size_t it = 0; it < p->max_iter; ++it) {
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
@@ -1182,6 +1195,11 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
     }
     const bool one_pass = tile_acc && !c->far_mode;
+    // Third form, near alignment and from the second iteration on: the per-lane search + accumulation kernel WARM-STARTED
+    // from the previous iteration's matches (kept by the forms above) -- no tile to stage at all.  Same matches, same sums
+    // up to the order of the f64 additions.
+    const bool warm = tile_acc && c->warm_start && it >= 1 && (c->warm_start == 2 || (one_pass && paced && it >= 2));
+    const bool single = one_pass || warm;        // search + accumulation in one kernel
     if (gn && opt_steps == 0) {
       // max_optimization_iterations_ == 0: estimateTransformCombinedMetric leaves tform = identity
       // and still un-centres it (:365): handled by an epilogue with zero weights is NOT identical, so
@@ -1194,11 +1212,17 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (c->ns) {
         if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
+        } else if (st == 0 && warm) {
+          IterArgs wa = a;
+          wa.warm_pos = c->d_nn_pos;
+          wa.safe2 = c->d_safe2;
+          wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;      // bound beyond half a cell: what the tiles' octant stage calls unproven
+          launch_warm(wa, im, nb, c->stream);
         } else if (st == 0 && one_pass) {
           // search + accumulation of the first Gauss-Newton step inside the LDS tiles (one pass; the matches are only
-          // stored when further Gauss-Newton steps will stream over them)
+          // stored when further Gauss-Newton steps will stream over them or the next iteration may start from them)
           IterArgs fa = a;
-          fa.store_matches = opt_steps > 1 ? 1 : 0;
+          fa.store_matches = (opt_steps > 1 || c->warm_start) ? 1 : 0;
           fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
           launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         } else if (st == 0) {
@@ -1213,14 +1237,14 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (timing && st == 0) {
         // (two events per iteration around the search / one-pass kernels; a two-pass iteration adds a pair around its
         //  streaming accumulation, kept in a list of its own)
-        if (one_pass || (c->fused && !filters_active(c) && !feat6(c)) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+        if (single || (c->fused && !filters_active(c) && !feat6(c)) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
         else CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream));
         ++launches;
       }
-      if (st == 0) { if (one_pass) ++c->last_fused_iters; else ++c->last_two_pass_iters; }
+      if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
-        const int prows = (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : nb;
+        const int prows = (st == 0 && one_pass && !warm) ? tiled_partial_rows(c->ntiles) : nb;
         const int rows = launch_reduce_stage1(c->d_partials, prows, c->d_stage, c->stream);
         sa.partials = rows ? c->d_stage : c->d_partials;
         sa.nblocks = rows ? rows : prows;

@@ -109,6 +109,9 @@ struct IterArgs {
   const float4* feat_src_nrm;  // 6-D point+normal feature search: sorted source normals, and
   float normal_weight;         // the adaptor's normal weight (0 = plain point features)
   CorrWeights cw;              // per-correspondence weights (enabled = 0: unity)
+  const uint32_t* warm_pos;    // [ns] or null: matches of the previous iteration, the per-lane search's warm start (may alias nn_pos)
+  float warm_far_sq;           // warm bounds at or above this (squared) are counted in unproven_cnt
+  const float* safe2;          // [grid.n] per sorted target point: lower bound on the squared distance to its nearest other target point (k_self_nn)
 };
 
 // What k_tile_boxes needs to compute the tiles' regions for the state's transform.
@@ -158,6 +161,9 @@ struct SolveArgs {
 
 // kernels.hip
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
+// warm-started search + accumulation (a.warm_pos / a.nn_pos: previous / new matches, may alias); nblocks: a multiple of 8
+void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s);
+void launch_warm(const IterArgs& a, int metric, int nblocks, hipStream_t s);
 void launch_solve(const SolveArgs& a, hipStream_t s);
 // acc_metric IM_NONE: search only; IM_KABSCH / IM_PLANE / IM_POINT / IM_BOTH: search + accumulation inside the tile
 // (first Gauss-Newton step), leaving tiled_partial_rows(ntiles) rows in a.partials

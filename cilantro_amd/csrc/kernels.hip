@@ -186,10 +186,10 @@ constexpr int LIST_CAP = 10;  // 8 neighbour rows + the two x-neighbours of the 
 // If the 3x3x3 block does not prove exactness (sparse data / large radius) or the query lies outside
 // the grid, continue with the generic shell search.
 // lst: this lane's column of the LDS work list, entries at lst[k * ITER_THREADS].
-__device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best,
-                                          uint2* lst) {
-  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
-  best.pos = NONE_U32;
+// nn_search_from(): `best` comes in initialised -- (radius, none), or a point KNOWN to lie within the radius (a warm start:
+// the search then only looks where something nearer, or as near with a lower index, can be; the result is the same).
+__device__ __forceinline__ void nn_search_from(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best,
+                                               uint2* lst) {
   const float BIG = 1.0e9f;
   const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
   const float fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG);
@@ -309,6 +309,12 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
     if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) return;
   }
   nn_search_shells(g, qx, qy, qz, cx, cy, cz, 2, best);
+}
+__device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best,
+                                          uint2* lst) {
+  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  best.pos = NONE_U32;
+  nn_search_from(g, qx, qy, qz, max_sq, best, lst);
 }
 
 // The same exact search by a GROUP of G adjacent lanes for ONE query (the clean-up pass of the tiled search: few queries,
@@ -1926,21 +1932,39 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       accumulate(vb2, qx, qy, qz, posb, p_b, nv_b, sn_b);
     }
   } else {
+  // Warm start (a.warm_pos: the matches of the PREVIOUS iteration, may alias nn_pos): the old match is a real target point,
+  // so its distance from the new q bounds the search -- near convergence that ball lies inside q's own cell for most
+  // queries and the search is one cell scan.  Lanes whose bound exceeds a.warm_far_sq (or that have none) are counted:
+  // the host falls back to the tiled kernels when they are many.
   uint32_t inext = beg + threadIdx.x;
   float4 s4n = inext < end ? a.src[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t wn = (a.warm_pos && inext < end) ? a.warm_pos[inext] : NONE_U32;
+  uint32_t nfar = 0;
   while (inext < end) {
     const uint32_t i = inext;
     const float4 s4 = s4n;
+    const uint32_t w = wn;
     uint32_t pos = NONE_U32;
     float value = 0.0f;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nvp = p, snp = p;
     inext += ITER_THREADS;
-    if (inext < end) s4n = a.src[inext];
+    if (inext < end) { s4n = a.src[inext]; if (a.warm_pos) wn = a.warm_pos[inext]; }
     float qx, qy, qz;
     transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
     {
       NN best;
-      nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
+      best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
+      best.pos = NONE_U32;
+      if (a.warm_pos) {
+        bool far = true;
+        if (w != NONE_U32) {
+          const float4 pw = a.grid.pts[w];
+          const float e = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
+          if (e < a.max_sq) { best.key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(pw.w); best.pos = w; far = !(e < a.warm_far_sq); }
+        }
+        nfar += far ? 1u : 0u;
+      }
+      nn_search_from(a.grid, qx, qy, qz, a.max_sq, best, lst);
       pos = best.pos;
       value = __uint_as_float((uint32_t)(best.key >> 32));
       if (STORE) { a.nn_pos[i] = pos; if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
@@ -1950,6 +1974,10 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       }
     }
     accumulate(value, qx, qy, qz, pos, p, nvp, snp);
+  }
+  if (a.warm_pos && a.unproven_cnt) {
+    const double tot = wave_sum((double)nfar);
+    if ((threadIdx.x & 63) == 0 && tot > 0.0) atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)tot);
   }
   }
 
@@ -1975,6 +2003,253 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
     if (threadIdx.x < SUMS_MAX)
       a.partials[(size_t)vb * SUMS_MAX + threadIdx.x] =
           (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  }
+}
+
+// ---- per target point: a lower bound on the squared distance to its nearest OTHER target point -------------------------
+// What the warm-started iteration settles most queries with: if |q - p| < nnd(p) / 2 then p is the one nearest target
+// point of q (any other p' has |q - p'| >= nnd(p) - |q - p| > |q - p|) -- no neighbour has to be looked at.  Computed once
+// per target: minimum over the 3x3x3 block of cells around the point (itself excluded by position: a duplicate gives 0),
+// capped by the distance to the faces of that block (whatever lies beyond is at least that far) -- a LOWER bound is all
+// the test needs.
+__global__ __launch_bounds__(256) void k_self_nn(GridDev g, float* __restrict__ safe2) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= g.n) return;
+  const float4 p = g.pts[j];
+  const int cx = min(max((int)floorf((p.x - g.ox) * g.inv_cell), 0), g.nx - 1), cy = min(max((int)floorf((p.y - g.oy) * g.inv_cell), 0), g.ny - 1),
+            cz = min(max((int)floorf((p.z - g.oz) * g.inv_cell), 0), g.nz - 1);
+  float best = INFINITY;
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+  for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); ++z)
+    for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); ++y) {
+      const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+      const uint32_t beg = g.cell_start[row + x0], end = g.cell_start[row + x1 + 1];
+      for (uint32_t k = beg; k < end; ++k) {
+        const float4 o = g.pts[k];
+        const float e = d2_pinned(p.x, p.y, p.z, o.x, o.y, o.z);
+        if (k != j) best = fminf(best, e);
+      }
+    }
+  float b = INFINITY;      // faces of the block that still have cells beyond them
+  if (cx - 1 > 0) b = fminf(b, p.x - (g.ox + (float)(cx - 1) * g.cell));
+  if (cx + 2 < g.nx) b = fminf(b, (g.ox + (float)(cx + 2) * g.cell) - p.x);
+  if (cy - 1 > 0) b = fminf(b, p.y - (g.oy + (float)(cy - 1) * g.cell));
+  if (cy + 2 < g.ny) b = fminf(b, (g.oy + (float)(cy + 2) * g.cell) - p.y);
+  if (cz - 1 > 0) b = fminf(b, p.z - (g.oz + (float)(cz - 1) * g.cell));
+  if (cz + 2 < g.nz) b = fminf(b, (g.oz + (float)(cz + 2) * g.cell) - p.z);
+  if (b != INFINITY) { b = fmaxf(b - g.margin, 0.0f); best = fminf(best, b * b * KSHRINK); }
+  safe2[j] = best;
+}
+void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s) {
+  if (g.n == 0) return;
+  hipLaunchKernelGGL(k_self_nn, dim3((g.n + 255u) / 256u), dim3(256), 0, s, g, safe2);
+}
+
+// ---- the WARM-STARTED iteration: search + accumulation from the previous iteration's matches -------------------------
+// From the second iteration on every query has a match from the iteration before.  That match is a real target point, so
+// its distance from the NEW q = T s bounds the search: anything nearer (or as near, with a lower index) lies in the ball
+// of that radius around q.  Near alignment the radius is a small fraction of a cell and the ball stays inside q's octant
+// block (the 2x2x2 cells q leans towards) -- usually inside q's own cell: per axis the neighbour is looked at only when
+// the ball reaches its face.  No tile is staged: a lane reads its old match and the one to three cells its ball touches
+// straight from memory (neighbouring lanes read neighbouring lines).  Two to three memory round trips per query:
+// {old match, its normal, the run boundaries} -> {candidates, 4 per trip} -> done.  Queries without a usable bound (no old
+// match, bound beyond the octant block, cell in the grid's outer layer) take the generic shell search -- exact as well --
+// and are counted: the host goes back to the tiled kernels when they are many.  The matches and therefore the sums are
+// the ones every other form finds; the accumulation is the tiles' rank update Z += z z^T on the matrix cores (per-wave
+// 16x16 f64 tile kept in registers across the whole chunk, fixed order => bitwise reproducible run to run).
+constexpr int WARM_THREADS = 256;
+constexpr int WARM_WAVES = WARM_THREADS / 64;
+template <int ACC>
+__global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
+  const IcpState* __restrict__ st = a.state;
+  if (st->done) return;
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = st->T[(i / 3) * 4 + (i % 3)];     // columns 0..3, rows 0..2
+  const GridDev& g = a.grid;
+  __shared__ __attribute__((aligned(16))) unsigned char raw[WARM_WAVES * FUSED_WAVE_BYTES];
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  constexpr int NC = FusedZ<ACC>::NC;
+  constexpr bool DUAL = NC <= 8;
+
+  const uint32_t nb = gridDim.x;
+  const uint32_t vb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);      // XCD-aware (gridDim.x is a multiple of 8)
+  const uint32_t chunk = (((a.ns + nb - 1) / nb) + (WARM_THREADS - 1)) & ~(uint32_t)(WARM_THREADS - 1);
+  const uint64_t beg64 = (uint64_t)vb * chunk;
+  const uint32_t beg = beg64 < a.ns ? (uint32_t)beg64 : a.ns;
+  const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
+  const float half = 0.5f * g.cell;
+  const int sy = g.nx, sz = g.nx * g.ny;
+  uint32_t nfar = 0;
+
+  uint32_t inext = beg + threadIdx.x;
+  float4 s4n = inext < end ? a.src[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t wn = inext < end ? a.warm_pos[inext] : NONE_U32;
+  for (uint32_t base = beg; base < end; base += WARM_THREADS) {     // (block-uniform trip count: every wave runs every MFMA round)
+    const uint32_t i = inext;
+    const bool valid = i < end;
+    const float4 s4 = s4n;
+    const uint32_t w = wn;
+    inext += WARM_THREADS;
+    if (inext < end) { s4n = a.src[inext]; wn = a.warm_pos[inext]; }
+    const float qx = __fadd_rn(__fadd_rn(__fmul_rn(T[0], s4.x), __fadd_rn(__fmul_rn(T[3], s4.y), __fmul_rn(T[6], s4.z))), T[9]);
+    const float qy = __fadd_rn(__fadd_rn(__fmul_rn(T[1], s4.x), __fadd_rn(__fmul_rn(T[4], s4.y), __fmul_rn(T[7], s4.z))), T[10]);
+    const float qz = __fadd_rn(__fadd_rn(__fmul_rn(T[2], s4.x), __fadd_rn(__fmul_rn(T[5], s4.y), __fmul_rn(T[8], s4.z))), T[11]);
+    NN best;
+    best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
+    best.pos = NONE_U32;
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), nm = pm;      // the matched point and its normal
+    if (valid) {
+      // the old match and (speculatively: it nearly always stays the match) its normal
+      float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), nw = pw;
+      float s2 = 0.0f;
+      if (w != NONE_U32) { pw = g.pts[w]; s2 = a.safe2[w]; if (FusedZ<ACC>::needs_normal) nw = g.nrm[w]; }
+      const float BIG = 1.0e9f;
+      const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG), fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG),
+                  fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
+      const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+      const bool inner = (cx >= 1) & (cx <= g.nx - 2) & (cy >= 1) & (cy <= g.ny - 2) & (cz >= 1) & (cz <= g.nz - 2);
+      // offsets inside the cell; per axis: which neighbour q leans to, the gap to the face shared with it, the gap to the
+      // far face of the own cell (beyond which the octant block ends)
+      const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
+      const bool lx = ux < half, ly = uy < half, lz = uz < half;
+      const float nx_ = fmaxf((lx ? ux : g.cell - ux) - g.margin, 0.0f), ny_ = fmaxf((ly ? uy : g.cell - uy) - g.margin, 0.0f),
+                  nz_ = fmaxf((lz ? uz : g.cell - uz) - g.margin, 0.0f);
+      const float ob = fminf(fminf(lx ? g.cell - ux : ux, ly ? g.cell - uy : uy), lz ? g.cell - uz : uz) - g.margin;   // nearest face of the octant block
+      bool bounded = false, settled = false;
+      if (w != NONE_U32) {
+        const float e = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
+        if (e < a.max_sq) {
+          best.key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(pw.w);
+          best.pos = w;
+          // nearer to the old match than half the distance from it to any other target point: it is THE nearest, nothing to
+          // look at (the factor covers the 2^-22 relative rounding of the three f32 squared distances involved)
+          settled = 4.0f * e < s2 * 0.99998f;
+          bounded = inner && ob > 0.0f && e < ob * ob * KSHRINK;
+        }
+      }
+      if (settled) {
+      } else if (bounded) {
+        const float bd = __uint_as_float((uint32_t)(best.key >> 32));
+        const bool kx = nx_ * nx_ * KSHRINK <= bd, ky = ny_ * ny_ * KSHRINK <= bd, kz = nz_ * nz_ * KSHRINK <= bd;   // the ball reaches that neighbour
+        const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+        const int xlo = (kx && lx) ? -1 : 0, xhi = (kx && !lx) ? 2 : 1;
+        const int dy = ly ? -sy : sy, dz = lz ? -sz : sz;
+        // up to four runs (rows y / y', z / z'), each one or two x-adjacent cells: boundaries fetched together
+        uint32_t rb[4] = {0u, 0u, 0u, 0u}, re[4] = {0u, 0u, 0u, 0u};
+        { const uint32_t r = cid; rb[0] = g.cell_start[(int)r + xlo]; re[0] = g.cell_start[(int)r + xhi]; }
+        if (ky) { const uint32_t r = cid + (uint32_t)dy; rb[1] = g.cell_start[(int)r + xlo]; re[1] = g.cell_start[(int)r + xhi]; }
+        if (kz) { const uint32_t r = cid + (uint32_t)dz; rb[2] = g.cell_start[(int)r + xlo]; re[2] = g.cell_start[(int)r + xhi]; }
+        if (ky && kz) { const uint32_t r = cid + (uint32_t)(dy + dz); rb[3] = g.cell_start[(int)r + xlo]; re[3] = g.cell_start[(int)r + xhi]; }
+        const uint32_t c0 = re[0] - rb[0], c1 = c0 + (re[1] - rb[1]), c2 = c1 + (re[2] - rb[2]), total = c2 + (re[3] - rb[3]);
+        for (uint32_t t = 0; t < total; t += 4) {
+          uint32_t j[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t tt = min(t + (uint32_t)k, total - 1u);      // (re-evaluating a candidate never changes the result)
+            j[k] = tt < c0 ? rb[0] + tt : tt < c1 ? rb[1] + (tt - c0) : tt < c2 ? rb[2] + (tt - c1) : rb[3] + (tt - c2);
+          }
+          const float4 p0 = g.pts[j[0]], p1 = g.pts[j[1]], p2 = g.pts[j[2]], p3 = g.pts[j[3]];
+          const float e0 = d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z), e1 = d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z);
+          const float e2 = d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z), e3 = d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z);
+          const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
+          const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
+          const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
+          const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
+          if (k0 < best.key) { best.key = k0; best.pos = j[0]; }
+          if (k1 < best.key) { best.key = k1; best.pos = j[1]; }
+          if (k2 < best.key) { best.key = k2; best.pos = j[2]; }
+          if (k3 < best.key) { best.key = k3; best.pos = j[3]; }
+        }
+      } else {
+        // no usable bound: the generic exact search (shells around the query's cell, pruned by whatever `best` holds)
+        ++nfar;
+        const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
+        bool skip = false;
+        int s0 = 0;
+        if (!inside) {
+          const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin), gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin),
+                      gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+          skip = (gx * gx + gy * gy + gz * gz) * KSHRINK >= a.max_sq;      // farther than the radius from the whole grid
+          s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+        }
+        if (!skip) nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
+      }
+      if (best.pos != NONE_U32) {
+        if (best.pos == w) { pm = pw; nm = nw; }
+        else { pm = g.pts[best.pos]; if (FusedZ<ACC>::needs_normal) nm = g.nrm[best.pos]; }
+      }
+      if (best.pos != w || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
+      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    }
+    // ---- rank update of the wave's 16x16 tile with this round's 64 correspondences (k_search_tiled, step 5) ----
+    float z[16];
+    fused_z<ACC>(valid && best.pos != NONE_U32, qx, qy, qz, pm, nm, a.dst_mean, st->smt, z);
+    if (DUAL) {
+      float4* w4 = reinterpret_cast<float4*>(zb + lane * 8 + (lane >= 32 ? 16 : 0));
+      w4[0] = make_float4(z[0], z[1], z[2], z[3]);
+      w4[1] = make_float4(z[4], z[5], z[6], z[7]);
+    } else {
+      float2* w2 = reinterpret_cast<float2*>(zb + lane * NC);
+#pragma unroll
+      for (int c = 0; c < NC / 2; ++c) w2[c] = make_float2(z[2 * c], z[2 * c + 1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (DUAL) {
+      const int comp = lane & 7, hf = (lane >> 3) & 1, k4 = lane >> 4;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int qi = hf * 32 + 4 * jj + k4;
+        const double x = (double)zb[qi * 8 + hf * 16 + comp];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+      }
+    } else {
+      const int comp = lane & 15, k4 = lane >> 4;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const float f = zb[(4 * jj + k4) * NC + (comp < NC ? comp : 0)];
+        const double x = comp < NC ? (double)f : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.unproven_cnt) {
+    const double tot = wave_sum((double)nfar);
+    if (lane == 0 && tot > 0.0) atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)tot);
+  }
+  double* const db = reinterpret_cast<double*>(raw + wave * FUSED_WAVE_BYTES);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) db[r * 64 + lane] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < SUMS_MAX) {
+    int i1, j1, i2, j2;
+    const bool used = FusedZ<ACC>::slot_terms((int)threadIdx.x, i1, j1, i2, j2);
+    double v1 = 0.0, v2 = 0.0;
+    if (used) {
+      const int e1 = (i1 >> 2) * 64 + 16 * (i1 & 3) + j1, e1b = ((i1 + 8) >> 2) * 64 + 16 * ((i1 + 8) & 3) + j1 + 8;
+      const int e2 = i2 >= 0 ? (i2 >> 2) * 64 + 16 * (i2 & 3) + j2 : 0, e2b = i2 >= 0 ? ((i2 + 8) >> 2) * 64 + 16 * ((i2 + 8) & 3) + j2 + 8 : 0;
+      for (int w = 0; w < WARM_WAVES; ++w) {
+        const double* dw = reinterpret_cast<const double*>(raw + w * FUSED_WAVE_BYTES);
+        v1 += dw[e1];
+        if (DUAL) v1 += dw[e1b];
+        if (i2 >= 0) { v2 += dw[e2]; if (DUAL) v2 += dw[e2b]; }
+      }
+    }
+    a.partials[(size_t)vb * SUMS_MAX + threadIdx.x] = v1 - v2;
+  }
+}
+
+void launch_warm(const IterArgs& a, int metric, int nblocks, hipStream_t s) {
+  const dim3 g(nblocks), b(WARM_THREADS);
+  switch (metric) {
+    case IM_KABSCH: hipLaunchKernelGGL((k_warm<IM_KABSCH>), g, b, 0, s, a); break;
+    case IM_PLANE: hipLaunchKernelGGL((k_warm<IM_PLANE>), g, b, 0, s, a); break;
+    case IM_POINT: hipLaunchKernelGGL((k_warm<IM_POINT>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_warm<IM_BOTH>), g, b, 0, s, a); break;
   }
 }
 

@@ -269,6 +269,12 @@ class Context:
         self._ck(self._L.cilhip_get_last_run_forms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_warm_iterations(self):
+        """how many of the one-pass iterations of the last icp_run ran as the warm-started per-lane kernel"""
+        a = C.c_int(0)
+        self._ck(self._L.cilhip_get_last_warm_iterations(self._h, C.byref(a)))
+        return a.value
+
     def last_timing2(self):
         a = C.c_double(0); b = C.c_double(0)
         self._ck(self._L.cilhip_get_last_timing2(self._h, C.byref(a), C.byref(b)))

@@ -297,6 +297,10 @@ int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
  * iteration from the device's count of queries the first search stage left unproven (source far from alignment: two passes).
  * Sharded runs: the same two counts over the cilhip_icp_partial_sums calls since cilhip_icp_begin. */
 int cilhip_get_last_run_forms(cilhip_ctx* ctx, int* one_pass_iterations, int* two_pass_iterations);
+/* ... and how many of the one-pass iterations ran as the WARM-STARTED per-lane kernel (option "warm_start"): from the second
+ * iteration on, near alignment, the search starts from the previous iteration's match -- a real target point, so its
+ * distance from the new query bounds the search -- and usually ends inside the query's own cell; same matches. */
+int cilhip_get_last_warm_iterations(cilhip_ctx* ctx, int* warm_iterations);
 
 /* ms of the kernels of the last cilhip_icp_run, measured with hipEvents on the ctx stream:
  * total loop, and the fused search+accumulate kernel alone (sum over executed iterations). */

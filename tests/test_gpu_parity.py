@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
 seeded inputs.  Integer / index work must be bit-exact; transforms within 1e-5 Frobenius
 (BASELINE.json north_star)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -1528,3 +1530,55 @@ def test_correspondence_weight_evaluators_vs_oracle(Context, orc, hip_lib):
     icp.correspondenceSearchEngine().setMaxDistance(r2)
     with pytest.raises(RuntimeError):
         icp.estimate()
+
+
+@pytest.mark.gpu
+def test_warm_started_iterations_find_the_same_matches(Context, orc, hip_lib):
+    """From the second iteration on (near alignment) the loop runs a per-lane kernel that starts every search from the
+    previous iteration's match: a real target point bounds the search, and a query nearer to it than half its distance to
+    any other target point is settled without looking at a neighbour.  Same matches, hence the same loop: against the
+    tiled forms (option warm_start = 0) and the oracle, on a uniform cloud, a cloud with holes and exact duplicate target
+    points (nearest-other distance 0: never settled by the shortcut), from near and from farther away, both metrics."""
+    rng = np.random.default_rng(5)
+    base = syn.make_pair(1_200_000, perturb=0.5)
+    h = base["h"]
+    dst, dst_n, src = base["dst"], base["dst_n"], base["src"]
+    # holes + duplicates: drop two slabs of the target, then repeat a few thousand target points exactly
+    keep = ~(((dst[:, 0] > 0.3) & (dst[:, 0] < 0.36)) | ((dst[:, 2] > 0.7) & (dst[:, 2] < 0.73)))
+    dup = rng.choice(np.nonzero(keep)[0], 5000, replace=False)
+    dst_h = np.ascontiguousarray(np.concatenate([dst[keep], dst[dup]])); dst_hn = np.ascontiguousarray(np.concatenate([dst_n[keep], dst_n[dup]]))
+    far = syn.make_pair(1_200_000, perturb=0.9)
+    cases = (("uniform", dst, dst_n, src, base["max_sq_dist"], base["T_true"]), ("holes+duplicates", dst_h, dst_hn, src, base["max_sq_dist"], base["T_true"]),
+             ("far start", far["dst"], far["dst_n"], far["src"], far["max_sq_dist"], far["T_true"]))
+    for name, D, N, S, r2, Tt in cases:
+        for metric, w_p2p in ((capi.METRIC_COMBINED, 0.0), (capi.METRIC_COMBINED, 0.1), (capi.METRIC_POINT_TO_POINT, 0.0)):
+            res = {}
+            for warm in (0, 2, 1):
+                ctx = Context()
+                ctx.set_option("warm_start", warm)
+                ctx.set_option("tiled", 2)                    # (the cloud with holes would otherwise be left to the per-lane kernels)
+                ctx.set_target(D, N); ctx.set_source(S)
+                p = capi.IcpParams()
+                ctx._L.cilhip_icp_default_params(C.byref(p))
+                p.metric, p.w_p2p, p.max_sq_dist, p.max_iter, p.conv_tol = metric, w_p2p, float(r2), 10, 0.0
+                runs = [ctx.icp_run(p) for _ in range(2)]
+                T = [np.array(r.T[:], np.float32) for r in runs]
+                assert np.array_equal(T[0], T[1]) or warm == 1, (name, metric, warm)        # bitwise reproducible (fixed forms)
+                res[warm] = (T[0].astype(np.float64), int(runs[0].last_ncorr), ctx.last_warm_iterations())
+                ctx.close()
+            assert res[0][2] == 0 and res[2][2] == 9, (name, res[0][2], res[2][2])
+            if name == "uniform":
+                assert res[1][2] >= 6, (name, res[1][2])                                   # the adaptive loop takes it when near
+            for warm in (2, 1):
+                assert res[warm][1] == res[0][1], (name, metric, w_p2p, warm, res[warm][1], res[0][1])      # same correspondences
+                assert np.abs(res[warm][0] - res[0][0]).max() <= 2e-7, (name, metric, w_p2p, warm, np.abs(res[warm][0] - res[0][0]).max())
+        # ... and the oracle's loop
+        po = orc.make_params(metric=1, max_iter=10, conv_tol=0.0, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
+        ro = orc.icp_run(D, N, S, po)
+        ctx = Context(); ctx.set_option("warm_start", 2); ctx.set_option("tiled", 2); ctx.set_target(D, N); ctx.set_source(S)
+        p = capi.IcpParams(); ctx._L.cilhip_icp_default_params(C.byref(p))
+        p.max_sq_dist, p.max_iter, p.conv_tol = float(r2), 10, 0.0
+        rg = ctx.icp_run(p)
+        Tg = np.array(rg.T[:], np.float32).reshape(4, 4).T
+        assert np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64)) <= TOL_T and int(rg.last_ncorr) == ro["last_ncorr"], name
+        ctx.close()

@@ -20,11 +20,12 @@ ap.add_argument("--modes", type=int, nargs="+", default=[1, 0])
 ap.add_argument("--occ", type=float, nargs="+", default=[1.0])
 ap.add_argument("--tiled", type=int, nargs="+", default=[1])
 ap.add_argument("--tacc", type=int, nargs="+", default=[1], help="tile_accumulation option values to compare")
+ap.add_argument("--warm", type=int, nargs="+", default=[1], help="warm_start option values to compare")
 a = ap.parse_args()
 
 for n in a.n:
     d = syn.make_pair(n, n, with_normals=True)
-    for fused, occ, tiled, tacc in [(f, o, t, ta) for f in a.modes for o in a.occ for t in a.tiled for ta in a.tacc]:
+    for fused, occ, tiled, tacc, warm in [(f, o, t, ta, w) for f in a.modes for o in a.occ for t in a.tiled for ta in a.tacc for w in a.warm]:
         ctx = Context(0)
         ctx.set_option("cell_occupancy", occ)
         ctx.set_target(d["dst"], d["dst_n"] if a.metric == "p2plane" else None)
@@ -32,6 +33,7 @@ for n in a.n:
         ctx.set_option("fused", fused)
         ctx.set_option("tiled", 2 if tiled else 0)
         ctx.set_option("tile_accumulation", tacc)
+        ctx.set_option("warm_start", warm)
         p = capi.IcpParams()
         ctx._L.cilhip_icp_default_params(C.byref(p))
         p.metric = capi.METRIC_COMBINED if a.metric == "p2plane" else capi.METRIC_POINT_TO_POINT
@@ -50,7 +52,7 @@ for n in a.n:
         dq, dtl = ctx.debug_counters()
         gi = ctx.grid_info()
         T = np.array(r.T[:], np.float32).reshape(4, 4).T
-        print(f"n={n} fused={fused} occ={occ} tiled={tiled} tile_acc={tacc} wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
+        print(f"n={n} fused={fused} occ={occ} tiled={tiled} tile_acc={tacc} warm={warm} (warm iterations {ctx.last_warm_iterations()}) wall/iter={dt*1e3/a.steps:.3f}ms loop(ev)/iter={loop_ms/a.steps:.3f}ms "
               f"[timed: loop/iter={loop2/a.steps:.3f} search(or fused)/iter={s_ms/max(nl,1):.3f} acc/iter={a_ms/max(nl,1):.3f}] "
               f"it/s={a.steps/dt:.1f} err_true={np.linalg.norm(T-d['T_true']):.2e} ncorr={r.last_ncorr} deferred_queries={dq} deferred_tiles={dtl} grid={gi.nx}x{gi.ny}x{gi.nz}", flush=True)
         ctx.close()
