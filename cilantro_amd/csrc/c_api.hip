@@ -54,6 +54,7 @@ struct cilhip_ctx {
   bool far_mode = true;                        // tiled ICP loop: the source is far from alignment (many unproven octant searches): search and
                                                // accumulate in two passes (the search's 3x3x3 pass settles them in LDS) instead of one
   int last_fused_iters = 0, last_two_pass_iters = 0, last_warm_iters = 0;
+  int run_calls = 0;              // cilhip_icp_partial_sums calls since cilhip_icp_begin
   int warm_start = 1;             // option "warm_start": 0 = never, 1 = when the device reports the source near alignment, 2 = from the second iteration on
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint32_t ntiles = 0;
@@ -65,6 +66,8 @@ struct cilhip_ctx {
   float4* d_src_nrm_sorted = nullptr;
   uint32_t* d_nn_pos = nullptr;
   float* d_nn_d2 = nullptr;
+  float4* d_warm_rec = nullptr;   // [2 * ns] match records of the warm-started iterations (valid inside a run, after the first of them)
+  bool rec_valid = false;
   float* d_safe2 = nullptr;       // [grid.n] k_self_nn's table for the warm-started iteration; built with the target
   int cw_point_kind = 0, cw_plane_kind = 0;     // correspondence weight evaluators (CW_*), combined metric
   float cw_point_sigma = 1.0f, cw_plane_sigma = 1.0f;
@@ -174,6 +177,8 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_src_sorted) (void)hipFree(c->d_src_sorted);
   if (c->d_nn_pos) (void)hipFree(c->d_nn_pos);
   if (c->d_nn_d2) (void)hipFree(c->d_nn_d2);
+  if (c->d_warm_rec) { (void)hipFree(c->d_warm_rec); c->d_warm_rec = nullptr; }
+  c->rec_valid = false;
   if (c->d_out_idx) (void)hipFree(c->d_out_idx);
   if (c->d_out_d2) (void)hipFree(c->d_out_d2);
   if (c->d_tiles) (void)hipFree(c->d_tiles);
@@ -442,7 +447,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     CK(c, hipMalloc(&c->d_defer_mask, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long)));
     CK(c, hipMemsetAsync(c->d_defer_mask, 0, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long), c->stream));
     {   // the tiled search with in-tile accumulation leaves one row of partial sums per tile and per block of its clean-up pass
-      const int rows = std::max(iter_num_blocks(c->ns), tiled_partial_rows(c->ntiles));
+      const int rows = std::max(std::max(iter_num_blocks(c->ns), warm_num_blocks(c->ns)), tiled_partial_rows(c->ntiles));
       if (rows > c->partial_blocks) {
         if (c->d_partials) (void)hipFree(c->d_partials);
         c->d_partials = nullptr; c->partial_blocks = 0;
@@ -1174,6 +1179,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   const bool paced = tile_acc && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
   if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
+  c->rec_valid = false;
   for (size_t it = 0; it < p->max_iter; ++it) {
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
@@ -1217,8 +1223,14 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           wa.warm_pos = c->d_nn_pos;
           wa.safe2 = c->d_safe2;
           wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;      // bound beyond half a cell: what the tiles' octant stage calls unproven
-          launch_warm(wa, im, nb, c->stream);
+          // the first warm iteration of a stretch gathers through the stored positions and leaves a 32-byte match record per
+          // query; the following ones read the records (two coalesced loads) instead of gathering
+          if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * 2 * sizeof(float4)));
+          wa.warm_rec = c->d_warm_rec;
+          launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
+          c->rec_valid = true;
         } else if (st == 0 && one_pass) {
+          c->rec_valid = false;
           // search + accumulation of the first Gauss-Newton step inside the LDS tiles (one pass; the matches are only
           // stored when further Gauss-Newton steps will stream over them or the next iteration may start from them)
           IterArgs fa = a;
@@ -1226,6 +1238,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
           launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         } else if (st == 0) {
+          c->rec_valid = false;
           { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
@@ -1244,7 +1257,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
-        const int prows = (st == 0 && one_pass && !warm) ? tiled_partial_rows(c->ntiles) : nb;
+        const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : nb;
         const int rows = launch_reduce_stage1(c->d_partials, prows, c->d_stage, c->stream);
         sa.partials = rows ? c->d_stage : c->d_partials;
         sa.nblocks = rows ? rows : prows;
@@ -1304,11 +1317,14 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   if (rc) return rc;
   c->run_prm = *p;
   for (int i = 0; i < 3; ++i) c->run_src_mean[i] = gmean ? gmean[i] : c->src_mean[i];
-  launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream);
+  ++c->run_tag;
+  launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream, c->d_feedback, c->run_tag);     // (the epilogue publishes the loop state: see cilhip_icp_partial_sums)
   CK(c, hipGetLastError());
   c->run_active = true;
   c->run_nev = 0;
-  c->last_fused_iters = c->last_two_pass_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
+  c->run_calls = 0;
+  c->rec_valid = false;
+  c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
   return CILHIP_OK;
 }
 
@@ -1329,9 +1345,44 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
       const bool timing = c->kernel_timing && c->run_nev + 3 <= 3 * 4096;
       const size_t e = 2 + c->run_nev;
       if (timing) CK(c, hipEventRecord(get_event(c, e), c->stream));
-      if (tile_accumulation(c)) {
+      // Warm-started form (see cilhip_icp_run): from the second call on, when the latest loop state this run's epilogues have
+      // published (a look, never a wait) says the source is near alignment.  Ranks may differ in their choice: the sums are
+      // the same up to the order of the f64 additions.
+      bool warm = false;
+      if (tile_accumulation(c) && c->warm_start && c->run_calls >= 1) {
+        warm = c->warm_start == 2;
+        if (!warm && c->run_calls >= 2) {
+          // paced like cilhip_icp_run: at most two iterations ahead of the device (which never waits: an iteration takes
+          // hundreds of microseconds), so that the loop state looked at is that of iteration run_calls - 2
+          const volatile Feedback* fb = c->h_feedback;
+          const auto t_wait = std::chrono::steady_clock::now();
+          for (unsigned spins = 0;; ++spins) {
+            const unsigned long long cm = fb->commit;
+            if ((unsigned int)(cm >> 32) == c->run_tag && (unsigned int)cm >= (unsigned int)(c->run_calls - 1)) {
+              warm = (unsigned long long)fb->unproven * 16ull <= (unsigned long long)c->ns;
+              break;
+            }
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;   // (no news: the tiled form)
+          }
+        }
+      }
+      if (warm) {
+        IterArgs wa = a;
+        wa.nn_pos = c->d_nn_pos;
+        wa.warm_pos = c->d_nn_pos;
+        wa.safe2 = c->d_safe2;
+        wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;
+        if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * 2 * sizeof(float4)));
+        wa.warm_rec = c->d_warm_rec;
+        launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
+        prows = warm_num_blocks(c->ns);
+        c->rec_valid = true;
+        if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
+        ++c->last_fused_iters; ++c->last_warm_iters;
+      } else if (tile_accumulation(c)) {
+        c->rec_valid = false;
         IterArgs fa = a;
-        fa.store_matches = 0;
+        fa.store_matches = c->warm_start ? 1 : 0;
         fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
         launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
@@ -1350,6 +1401,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
   } else {
     CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));
   }
+  ++c->run_calls;
   CK(c, hipGetLastError());
   return CILHIP_OK;
 }
@@ -1360,6 +1412,7 @@ int cilhip_icp_apply_sums(cilhip_ctx* c, const double* sums_dev) {
   CK(c, hipSetDevice(c->device));
   const int im = iter_metric_of(c, &c->run_prm);
   SolveArgs sa = make_solve_args(c, &c->run_prm, im, c->run_src_mean);
+  sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;
   sa.nblocks = 0;
   sa.reduced = sums_dev;
   launch_solve(sa, c->stream);

@@ -111,6 +111,7 @@ struct IterArgs {
   CorrWeights cw;              // per-correspondence weights (enabled = 0: unity)
   const uint32_t* warm_pos;    // [ns] or null: matches of the previous iteration, the per-lane search's warm start (may alias nn_pos)
   float warm_far_sq;           // warm bounds at or above this (squared) are counted in unproven_cnt
+  float4* warm_rec;            // [2 * ns] or null: per query {matched point, index} {its normal, its safe2 entry (< 0: no match)}
   const float* safe2;          // [grid.n] per sorted target point: lower bound on the squared distance to its nearest other target point (k_self_nn)
 };
 
@@ -163,7 +164,9 @@ struct SolveArgs {
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
 // warm-started search + accumulation (a.warm_pos / a.nn_pos: previous / new matches, may alias); nblocks: a multiple of 8
 void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s);
-void launch_warm(const IterArgs& a, int metric, int nblocks, hipStream_t s);
+// rec: 0 = gather through warm_pos, 1 = the same and write the match records, 2 = read the match records (a.warm_rec)
+void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_t s);
+int warm_num_blocks(uint32_t ns);      // blocks (= partial-sum rows) of launch_warm
 void launch_solve(const SolveArgs& a, hipStream_t s);
 // acc_metric IM_NONE: search only; IM_KABSCH / IM_PLANE / IM_POINT / IM_BOTH: search + accumulation inside the tile
 // (first Gauss-Newton step), leaving tiled_partial_rows(ntiles) rows in a.partials

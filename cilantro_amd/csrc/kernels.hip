@@ -2059,7 +2059,17 @@ void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s) {
 // 16x16 f64 tile kept in registers across the whole chunk, fixed order => bitwise reproducible run to run).
 constexpr int WARM_THREADS = 256;
 constexpr int WARM_WAVES = WARM_THREADS / 64;
-template <int ACC>
+// REC: 0 = the old match, its normal and its table entry are gathered through warm_pos; 1 = the same, and every query's
+// match record {point, index, normal, table entry} (32 B, in query order) is written; 2 = the records are READ instead --
+// two coalesced 16-byte loads per query, no gather at all for the queries the table settles (nearly all of them); a query
+// whose match changes rewrites its record.
+// The queries the table does NOT settle (a percent or so) are not searched where they turn up -- nearly every wave holds
+// one, and the whole wave would walk the search code for it: each wave lists them in LDS (ballot order: no atomics, the
+// same list in every run) and searches the list afterwards, densely packed (the list holds all of the wave's queries if
+// need be: a source far from alignment).
+constexpr int WARM_CHUNK_MAX = 5120;                        // queries per block at most (warm_num_blocks): what the lists are sized for
+constexpr int WARM_QCAP = WARM_CHUNK_MAX / WARM_WAVES;      // listed queries per wave: every query of the wave fits
+template <int ACC, int REC>
 __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
@@ -2068,12 +2078,15 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   for (int i = 0; i < 12; ++i) T[i] = st->T[(i / 3) * 4 + (i % 3)];     // columns 0..3, rows 0..2
   const GridDev& g = a.grid;
   __shared__ __attribute__((aligned(16))) unsigned char raw[WARM_WAVES * FUSED_WAVE_BYTES];
+  __shared__ uint32_t dq[WARM_WAVES][WARM_QCAP];
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
+  uint32_t* const wq = dq[wave];
   typedef double double4_t __attribute__((ext_vector_type(4)));
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   constexpr int NC = FusedZ<ACC>::NC;
   constexpr bool DUAL = NC <= 8;
+  constexpr bool NRM = FusedZ<ACC>::needs_normal;
 
   const uint32_t nb = gridDim.x;
   const uint32_t vb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);      // XCD-aware (gridDim.x is a multiple of 8)
@@ -2083,111 +2096,19 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
   const float half = 0.5f * g.cell;
   const int sy = g.nx, sz = g.nx * g.ny;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t nfar = 0;
 
-  uint32_t inext = beg + threadIdx.x;
-  float4 s4n = inext < end ? a.src[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
-  uint32_t wn = inext < end ? a.warm_pos[inext] : NONE_U32;
-  for (uint32_t base = beg; base < end; base += WARM_THREADS) {     // (block-uniform trip count: every wave runs every MFMA round)
-    const uint32_t i = inext;
-    const bool valid = i < end;
-    const float4 s4 = s4n;
-    const uint32_t w = wn;
-    inext += WARM_THREADS;
-    if (inext < end) { s4n = a.src[inext]; wn = a.warm_pos[inext]; }
-    const float qx = __fadd_rn(__fadd_rn(__fmul_rn(T[0], s4.x), __fadd_rn(__fmul_rn(T[3], s4.y), __fmul_rn(T[6], s4.z))), T[9]);
-    const float qy = __fadd_rn(__fadd_rn(__fmul_rn(T[1], s4.x), __fadd_rn(__fmul_rn(T[4], s4.y), __fmul_rn(T[7], s4.z))), T[10]);
-    const float qz = __fadd_rn(__fadd_rn(__fmul_rn(T[2], s4.x), __fadd_rn(__fmul_rn(T[5], s4.y), __fmul_rn(T[8], s4.z))), T[11]);
-    NN best;
-    best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
-    best.pos = NONE_U32;
-    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f), nm = pm;      // the matched point and its normal
-    if (valid) {
-      // the old match and (speculatively: it nearly always stays the match) its normal
-      float4 pw = make_float4(0.f, 0.f, 0.f, 0.f), nw = pw;
-      float s2 = 0.0f;
-      if (w != NONE_U32) { pw = g.pts[w]; s2 = a.safe2[w]; if (FusedZ<ACC>::needs_normal) nw = g.nrm[w]; }
-      const float BIG = 1.0e9f;
-      const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG), fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG),
-                  fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
-      const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-      const bool inner = (cx >= 1) & (cx <= g.nx - 2) & (cy >= 1) & (cy <= g.ny - 2) & (cz >= 1) & (cz <= g.nz - 2);
-      // offsets inside the cell; per axis: which neighbour q leans to, the gap to the face shared with it, the gap to the
-      // far face of the own cell (beyond which the octant block ends)
-      const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
-      const bool lx = ux < half, ly = uy < half, lz = uz < half;
-      const float nx_ = fmaxf((lx ? ux : g.cell - ux) - g.margin, 0.0f), ny_ = fmaxf((ly ? uy : g.cell - uy) - g.margin, 0.0f),
-                  nz_ = fmaxf((lz ? uz : g.cell - uz) - g.margin, 0.0f);
-      const float ob = fminf(fminf(lx ? g.cell - ux : ux, ly ? g.cell - uy : uy), lz ? g.cell - uz : uz) - g.margin;   // nearest face of the octant block
-      bool bounded = false, settled = false;
-      if (w != NONE_U32) {
-        const float e = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
-        if (e < a.max_sq) {
-          best.key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(pw.w);
-          best.pos = w;
-          // nearer to the old match than half the distance from it to any other target point: it is THE nearest, nothing to
-          // look at (the factor covers the 2^-22 relative rounding of the three f32 squared distances involved)
-          settled = 4.0f * e < s2 * 0.99998f;
-          bounded = inner && ob > 0.0f && e < ob * ob * KSHRINK;
-        }
-      }
-      if (settled) {
-      } else if (bounded) {
-        const float bd = __uint_as_float((uint32_t)(best.key >> 32));
-        const bool kx = nx_ * nx_ * KSHRINK <= bd, ky = ny_ * ny_ * KSHRINK <= bd, kz = nz_ * nz_ * KSHRINK <= bd;   // the ball reaches that neighbour
-        const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
-        const int xlo = (kx && lx) ? -1 : 0, xhi = (kx && !lx) ? 2 : 1;
-        const int dy = ly ? -sy : sy, dz = lz ? -sz : sz;
-        // up to four runs (rows y / y', z / z'), each one or two x-adjacent cells: boundaries fetched together
-        uint32_t rb[4] = {0u, 0u, 0u, 0u}, re[4] = {0u, 0u, 0u, 0u};
-        { const uint32_t r = cid; rb[0] = g.cell_start[(int)r + xlo]; re[0] = g.cell_start[(int)r + xhi]; }
-        if (ky) { const uint32_t r = cid + (uint32_t)dy; rb[1] = g.cell_start[(int)r + xlo]; re[1] = g.cell_start[(int)r + xhi]; }
-        if (kz) { const uint32_t r = cid + (uint32_t)dz; rb[2] = g.cell_start[(int)r + xlo]; re[2] = g.cell_start[(int)r + xhi]; }
-        if (ky && kz) { const uint32_t r = cid + (uint32_t)(dy + dz); rb[3] = g.cell_start[(int)r + xlo]; re[3] = g.cell_start[(int)r + xhi]; }
-        const uint32_t c0 = re[0] - rb[0], c1 = c0 + (re[1] - rb[1]), c2 = c1 + (re[2] - rb[2]), total = c2 + (re[3] - rb[3]);
-        for (uint32_t t = 0; t < total; t += 4) {
-          uint32_t j[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t tt = min(t + (uint32_t)k, total - 1u);      // (re-evaluating a candidate never changes the result)
-            j[k] = tt < c0 ? rb[0] + tt : tt < c1 ? rb[1] + (tt - c0) : tt < c2 ? rb[2] + (tt - c1) : rb[3] + (tt - c2);
-          }
-          const float4 p0 = g.pts[j[0]], p1 = g.pts[j[1]], p2 = g.pts[j[2]], p3 = g.pts[j[3]];
-          const float e0 = d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z), e1 = d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z);
-          const float e2 = d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z), e3 = d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z);
-          const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
-          const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
-          const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
-          const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
-          if (k0 < best.key) { best.key = k0; best.pos = j[0]; }
-          if (k1 < best.key) { best.key = k1; best.pos = j[1]; }
-          if (k2 < best.key) { best.key = k2; best.pos = j[2]; }
-          if (k3 < best.key) { best.key = k3; best.pos = j[3]; }
-        }
-      } else {
-        // no usable bound: the generic exact search (shells around the query's cell, pruned by whatever `best` holds)
-        ++nfar;
-        const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
-        bool skip = false;
-        int s0 = 0;
-        if (!inside) {
-          const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin), gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin),
-                      gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
-          skip = (gx * gx + gy * gy + gz * gz) * KSHRINK >= a.max_sq;      // farther than the radius from the whole grid
-          s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
-        }
-        if (!skip) nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
-      }
-      if (best.pos != NONE_U32) {
-        if (best.pos == w) { pm = pw; nm = nw; }
-        else { pm = g.pts[best.pos]; if (FusedZ<ACC>::needs_normal) nm = g.nrm[best.pos]; }
-      }
-      if (best.pos != w || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
-      if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
-    }
-    // ---- rank update of the wave's 16x16 tile with this round's 64 correspondences (k_search_tiled, step 5) ----
+  auto transform = [&](const float4 s4, float& qx, float& qy, float& qz) {
+    qx = __fadd_rn(__fadd_rn(__fmul_rn(T[0], s4.x), __fadd_rn(__fmul_rn(T[3], s4.y), __fmul_rn(T[6], s4.z))), T[9]);
+    qy = __fadd_rn(__fadd_rn(__fmul_rn(T[1], s4.x), __fadd_rn(__fmul_rn(T[4], s4.y), __fmul_rn(T[7], s4.z))), T[10]);
+    qz = __fadd_rn(__fadd_rn(__fmul_rn(T[2], s4.x), __fadd_rn(__fmul_rn(T[5], s4.y), __fmul_rn(T[8], s4.z))), T[11]);
+  };
+
+  // rank update of the wave's 16x16 tile with one round of (up to) 64 correspondences (k_search_tiled, step 5)
+  auto rank_update = [&](bool has, float qx, float qy, float qz, const float4 pm, const float4 nm) {
     float z[16];
-    fused_z<ACC>(valid && best.pos != NONE_U32, qx, qy, qz, pm, nm, a.dst_mean, st->smt, z);
+    fused_z<ACC>(has, qx, qy, qz, pm, nm, a.dst_mean, st->smt, z);
     if (DUAL) {
       float4* w4 = reinterpret_cast<float4*>(zb + lane * 8 + (lane >= 32 ? 16 : 0));
       w4[0] = make_float4(z[0], z[1], z[2], z[3]);
@@ -2216,6 +2137,150 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+  };
+
+  // The search of one query the table did not settle: from its old match (a real target point: its distance bounds the
+  // search) inside the octant block when the bound allows, else the generic shell search.  Stores what changed.
+  auto slow = [&](uint32_t i, float qx, float qy, float qz, float4& pm, float4& nm) -> bool {
+    const uint32_t w = a.warm_pos[i];
+    float4 pw = zero4, nw = zero4;
+    float s2 = -1.0f;
+    if (w != NONE_U32) { pw = g.pts[w]; s2 = a.safe2[w]; if (NRM) nw = g.nrm[w]; }
+    NN best;
+    best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
+    best.pos = NONE_U32;
+    float e_old = INFINITY;
+    if (w != NONE_U32) {
+      e_old = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
+      if (e_old < a.max_sq) { best.key = ((unsigned long long)__float_as_uint(e_old) << 32) | __float_as_uint(pw.w); best.pos = w; }
+    }
+    const float BIG = 1.0e9f;
+    const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG), fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG),
+                fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
+    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    const bool inner = (cx >= 1) & (cx <= g.nx - 2) & (cy >= 1) & (cy <= g.ny - 2) & (cz >= 1) & (cz <= g.nz - 2);
+    // offsets inside the cell; per axis: which neighbour q leans to, the gap to the face shared with it, the gap to the far
+    // face of the own cell (beyond which the octant block ends)
+    const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
+    const bool lx = ux < half, ly = uy < half, lz = uz < half;
+    const float nx_ = fmaxf((lx ? ux : g.cell - ux) - g.margin, 0.0f), ny_ = fmaxf((ly ? uy : g.cell - uy) - g.margin, 0.0f),
+                nz_ = fmaxf((lz ? uz : g.cell - uz) - g.margin, 0.0f);
+    const float ob = fminf(fminf(lx ? g.cell - ux : ux, ly ? g.cell - uy : uy), lz ? g.cell - uz : uz) - g.margin;   // nearest face of the octant block
+    const bool bounded = best.pos != NONE_U32 && inner && ob > 0.0f && e_old < ob * ob * KSHRINK;
+    if (bounded) {
+      const float bd = e_old;
+      const bool kx = nx_ * nx_ * KSHRINK <= bd, ky = ny_ * ny_ * KSHRINK <= bd, kz = nz_ * nz_ * KSHRINK <= bd;   // the ball reaches that neighbour
+      const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+      const int xlo = (kx && lx) ? -1 : 0, xhi = (kx && !lx) ? 2 : 1;
+      const int dy = ly ? -sy : sy, dz = lz ? -sz : sz;
+      // up to four runs (rows y / y', z / z'), each one or two x-adjacent cells: boundaries fetched together
+      uint32_t rb[4] = {0u, 0u, 0u, 0u}, re[4] = {0u, 0u, 0u, 0u};
+      { const uint32_t r = cid; rb[0] = g.cell_start[(int)r + xlo]; re[0] = g.cell_start[(int)r + xhi]; }
+      if (ky) { const uint32_t r = cid + (uint32_t)dy; rb[1] = g.cell_start[(int)r + xlo]; re[1] = g.cell_start[(int)r + xhi]; }
+      if (kz) { const uint32_t r = cid + (uint32_t)dz; rb[2] = g.cell_start[(int)r + xlo]; re[2] = g.cell_start[(int)r + xhi]; }
+      if (ky && kz) { const uint32_t r = cid + (uint32_t)(dy + dz); rb[3] = g.cell_start[(int)r + xlo]; re[3] = g.cell_start[(int)r + xhi]; }
+      const uint32_t c0 = re[0] - rb[0], c1 = c0 + (re[1] - rb[1]), c2 = c1 + (re[2] - rb[2]), total = c2 + (re[3] - rb[3]);
+      for (uint32_t t = 0; t < total; t += 4) {
+        uint32_t j[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t tt = min(t + (uint32_t)k, total - 1u);      // (re-evaluating a candidate never changes the result)
+          j[k] = tt < c0 ? rb[0] + tt : tt < c1 ? rb[1] + (tt - c0) : tt < c2 ? rb[2] + (tt - c1) : rb[3] + (tt - c2);
+        }
+        const float4 p0 = g.pts[j[0]], p1 = g.pts[j[1]], p2 = g.pts[j[2]], p3 = g.pts[j[3]];
+        const float e0 = d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z), e1 = d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z);
+        const float e2 = d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z), e3 = d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z);
+        const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
+        const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
+        const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
+        const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
+        if (k0 < best.key) { best.key = k0; best.pos = j[0]; }
+        if (k1 < best.key) { best.key = k1; best.pos = j[1]; }
+        if (k2 < best.key) { best.key = k2; best.pos = j[2]; }
+        if (k3 < best.key) { best.key = k3; best.pos = j[3]; }
+      }
+    } else {
+      // no usable bound: the generic exact search (shells around the query's cell, pruned by whatever `best` holds)
+      ++nfar;
+      const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
+      bool skip = false;
+      int s0 = 0;
+      if (!inside) {
+        const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin), gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin),
+                    gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+        skip = (gx * gx + gy * gy + gz * gz) * KSHRINK >= a.max_sq;      // farther than the radius from the whole grid
+        s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+      }
+      if (!skip) nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
+    }
+    const bool same = best.pos == w, has = best.pos != NONE_U32;
+    pm = nm = zero4;
+    if (has) {
+      if (same) { pm = pw; nm = nw; }
+      else { pm = g.pts[best.pos]; s2 = a.safe2[best.pos]; if (NRM) nm = g.nrm[best.pos]; }
+    }
+    if (!same || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
+    if (REC == 1 || (REC == 2 && !same)) {
+      a.warm_rec[2 * (size_t)i] = pm;
+      a.warm_rec[2 * (size_t)i + 1] = make_float4(nm.x, nm.y, nm.z, has ? s2 : -1.0f);
+    }
+    if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    return has;
+  };
+
+  uint32_t qcount = 0;      // (wave-uniform)
+  uint32_t inext = beg + threadIdx.x;
+  float4 s4n = inext < end ? a.src[inext] : zero4;
+  uint32_t wn = (REC != 2 && inext < end) ? a.warm_pos[inext] : NONE_U32;
+  float4 r0n = zero4, r1n = zero4;
+  if (REC == 2 && inext < end) { r0n = a.warm_rec[2 * (size_t)inext]; r1n = a.warm_rec[2 * (size_t)inext + 1]; }
+  for (uint32_t base = beg; base < end; base += WARM_THREADS) {
+    const uint32_t i = inext;
+    const bool valid = i < end;
+    const float4 s4 = s4n;
+    const uint32_t w = wn;
+    const float4 r0 = r0n, r1 = r1n;
+    inext += WARM_THREADS;
+    if (inext < end) {
+      s4n = a.src[inext];
+      if (REC != 2) wn = a.warm_pos[inext];
+      else { r0n = a.warm_rec[2 * (size_t)inext]; r1n = a.warm_rec[2 * (size_t)inext + 1]; }
+    }
+    float qx, qy, qz;
+    transform(s4, qx, qy, qz);
+    // the old match, its normal and its table entry: from the record, or gathered through the stored position
+    float4 pm = zero4, nm = zero4;
+    float s2 = -1.0f;                     // (< 0: no old match)
+    if (REC == 2) { pm = r0; nm = make_float4(r1.x, r1.y, r1.z, 0.f); s2 = r1.w; }
+    else if (valid && w != NONE_U32) { pm = g.pts[w]; s2 = a.safe2[w]; if (NRM) nm = g.nrm[w]; }
+    // Nearer to the old match than half the distance from it to any other target point: it is THE nearest, nothing to look
+    // at -- not even the query's cell (the factor covers the 2^-22 relative rounding of the three f32 squared distances).
+    const float e_old = d2_pinned(qx, qy, qz, pm.x, pm.y, pm.z);
+    const bool settled = valid && s2 >= 0.0f && e_old < a.max_sq && 4.0f * e_old < s2 * 0.99998f;
+    if (settled) {
+      if (REC != 2 && a.nn_pos != a.warm_pos) a.nn_pos[i] = w;
+      if (REC == 1) { a.warm_rec[2 * (size_t)i] = pm; a.warm_rec[2 * (size_t)i + 1] = make_float4(nm.x, nm.y, nm.z, s2); }
+      if (a.nn_d2) a.nn_d2[i] = e_old;
+    }
+    const bool todo = valid && !settled;
+    const unsigned long long um = __ballot(todo);
+    if (todo) wq[qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = i;
+    qcount += (uint32_t)__popcll(um);
+    rank_update(settled, qx, qy, qz, pm, nm);
+  }
+  // the listed queries, 64 per round
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t b0 = 0; b0 < qcount; b0 += 64u) {
+    const bool v = b0 + (uint32_t)lane < qcount;
+    const uint32_t li = v ? wq[b0 + (uint32_t)lane] : 0u;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    float4 pm = zero4, nm = zero4;
+    bool has = false;
+    if (v) {
+      transform(a.src[li], qx, qy, qz);
+      has = slow(li, qx, qy, qz, pm, nm);
+    }
+    rank_update(has, qx, qy, qz, pm, nm);
   }
   if (a.unproven_cnt) {
     const double tot = wave_sum((double)nfar);
@@ -2243,13 +2308,25 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   }
 }
 
-void launch_warm(const IterArgs& a, int metric, int nblocks, hipStream_t s) {
+template <int ACC>
+static void launch_warm_m(const IterArgs& a, int rec, int nblocks, hipStream_t s) {
   const dim3 g(nblocks), b(WARM_THREADS);
+  if (rec == 2) hipLaunchKernelGGL((k_warm<ACC, 2>), g, b, 0, s, a);
+  else if (rec == 1) hipLaunchKernelGGL((k_warm<ACC, 1>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_warm<ACC, 0>), g, b, 0, s, a);
+}
+int warm_num_blocks(uint32_t ns) {
+  long nb = iter_num_blocks(ns);
+  const long need = ((long)ns + WARM_CHUNK_MAX - 1) / WARM_CHUNK_MAX;      // a block's chunk must fit its lists
+  if (need > nb) nb = need;
+  return (int)((nb + 7) & ~7L);
+}
+void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_t s) {
   switch (metric) {
-    case IM_KABSCH: hipLaunchKernelGGL((k_warm<IM_KABSCH>), g, b, 0, s, a); break;
-    case IM_PLANE: hipLaunchKernelGGL((k_warm<IM_PLANE>), g, b, 0, s, a); break;
-    case IM_POINT: hipLaunchKernelGGL((k_warm<IM_POINT>), g, b, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_warm<IM_BOTH>), g, b, 0, s, a); break;
+    case IM_KABSCH: launch_warm_m<IM_KABSCH>(a, rec, nblocks, s); break;
+    case IM_PLANE: launch_warm_m<IM_PLANE>(a, rec, nblocks, s); break;
+    case IM_POINT: launch_warm_m<IM_POINT>(a, rec, nblocks, s); break;
+    default: launch_warm_m<IM_BOTH>(a, rec, nblocks, s); break;
   }
 }
 

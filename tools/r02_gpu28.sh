@@ -1,0 +1,11 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02ac; mkdir -p $O; cd $R
+( time timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "shard or slab or in_tile or warm" ) > $O/pytest.log 2>&1
+tail -8 $O/pytest.log
+export CILHIP_BENCH_FORCE_SHARDED=1
+TR="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517"
+( timeout 600 $TR bench.py --gpus 1 --steps 20 --warmup 3 --no-extras ) > $O/sharded_weak.log 2>&1; tail -1 $O/sharded_weak.log | cut -c1-400
+( timeout 600 $TR bench.py --gpus 1 --steps 20 --warmup 3 --no-extras --scaling strong ) > $O/sharded_strong.log 2>&1; tail -1 $O/sharded_strong.log | cut -c1-400
+unset CILHIP_BENCH_FORCE_SHARDED
+( timeout 600 python bench.py --no-extras ) > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-600
