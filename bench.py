@@ -242,38 +242,49 @@ def bench_icp(a, torch, rank, world, local_rank):
         search_ms, acc_ms = ctx.last_timing2()
         ns_l, nd_l, nc = len(src_l), len(dst_l), int(res.last_ncorr)
         one_pass_iters, two_pass_iters = ctx.last_run_forms()
-        fused = launches > 0 and two_pass_iters == 0 and one_pass_iters > 0     # (sharded runs: counted per partial-sums call)
         # Algorithmic (compulsory) bytes, SURVEY.md 8(d): every datum touched once.
         #   search + accumulation in ONE pass (the default: no index round trip):  12 Ns + 12 Nd + 12 Nc (the matched normals;
         #   point-to-point: the matched points are part of the 12 Nd)
         #   search alone inside the loop: 16 Ns + 12 Nd (the match index is written, the squared distance is not: nothing reads
         #   it); the streaming accumulation pass that then follows: 16 Ns + 24 Nc (point-to-point: 12 Nc)
         nc_l = nc if not sharded else ns_l       # (rank 0's own pairs; ncorr is the job's total)
-        if fused:
-            alg_bytes = 12.0 * ns_l + 12.0 * nd_l + (12.0 * nc_l if with_normals else 0.0)
-            kern = "k_search_tiled<metric> + k_search_deferred<metric> (LDS-tiled kNN search with the accumulation inside the tile)"
-        else:
-            alg_bytes = 16.0 * ns_l + 12.0 * nd_l
-            kern = "kNN correspondence search (k_search_tiled<none> + clean-up pass, or the per-lane search for small clouds)"
+        one_pass_bytes = 12.0 * ns_l + 12.0 * nd_l + (12.0 * nc_l if with_normals else 0.0)
+        FORMS = {
+            0: ("kNN correspondence search alone (k_search_tiled<none> + clean-up pass, or the per-lane search: small / sparse-source clouds); "
+                "a streaming accumulation pass follows", 16.0 * ns_l + 12.0 * nd_l),
+            1: ("k_search_tiled<metric> + k_search_deferred<metric> (LDS-tiled kNN search with the accumulation inside the tile)", one_pass_bytes),
+            2: ("k_warm<metric, 1> (first warm-started iteration: search from the previous matches, gathers, writes the match records)", one_pass_bytes),
+            3: ("k_warm<metric, 2> (warm-started iteration: search from the previous matches read as records, accumulation on the matrix cores)",
+                one_pass_bytes),
+            4: ("k_iter<metric, search> (per-lane fused search + accumulation)", one_pass_bytes),
+        }
+        ft = ctx.last_form_timing()
+        forms = {str(f): {"launches": n, "avg_kernel_ms": ms / n} for f, (ms, n) in ft.items() if n > 0}
+        dom = max(ft, key=lambda f: ft[f][0]) if launches > 0 else None      # the form the timed region spent most kernel time in
+        fused = dom is not None and dom != 0
         traffic, traffic_note = None, "no PMC measurement of this build / workload committed"
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             w = tj["workload"]
-            if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and fused == bool(tj.get("fused")):
+            if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and tj.get("form") == dom:
                 traffic, traffic_note = float(tj["traffic_bytes_per_launch"]), tj.get("method", "")
             else:
-                traffic_note = "profiles/r02_traffic.json was measured on another build or workload (source hash / sizes differ): not quoted"
+                traffic_note = "profiles/r02_traffic.json was measured on another build, workload or kernel form: not quoted"
         except Exception:
             pass
         roof = None
-        if launches > 0:      # (sharded runs: rank 0's own kernels)
-            avg_ms = search_ms / launches
+        if dom is not None:      # (sharded runs: rank 0's own kernels)
+            kern, alg_bytes = FORMS[dom]
+            avg_ms = ft[dom][0] / ft[dom][1]
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "measured_copy_bandwidth_GBps": copy_bandwidth(torch), "traffic": traffic, "traffic_note": traffic_note,
-                    "kernel": kern, "avg_kernel_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
-                    "timing": "hipEvents around the kernel(s) on the context's stream, every launch of the timed region"}
-            if not fused:
+                    "kernel": kern, "form": dom, "avg_kernel_ms": avg_ms, "launches": ft[dom][1], "algorithmic_bytes_per_launch": alg_bytes,
+                    "timing": "hipEvents around the kernel(s) on the context's stream, every launch of the timed region; the dominant "
+                              "kernel is the form with the largest share of the timed region's kernel time",
+                    "forms_in_timed_region": forms,
+                    "all_forms_avg_kernel_ms": search_ms / launches}
+            if dom == 0:
                 acc_bytes = 16.0 * ns_l + (24.0 if with_normals else 12.0) * nc_l
                 roof["accumulate_kernel"] = {"avg_kernel_ms": acc_ms / launches, "algorithmic_bytes_per_launch": acc_bytes,
                                              "achieved_GBps": acc_bytes / max(acc_ms / launches * 1e-3, 1e-12) / 1e9}
@@ -294,7 +305,7 @@ def bench_icp(a, torch, rank, world, local_rank):
                        "grid": [gi.nx, gi.ny, gi.nz], "grid_cell": gi.cell, "grid_avg_occupancy": gi.avg_occupancy},
             "setup_ms": t_setup * 1e3, "source_sort_ms": sort_ms, "loop_ms_hip_events": loop_ms,
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,
-            "iterations_one_pass": one_pass_iters, "iterations_two_pass": two_pass_iters,
+            "iterations_one_pass": one_pass_iters, "iterations_two_pass": two_pass_iters, "iterations_warm_started": ctx.last_warm_iterations(),
             "roofline": roof,
         }
     if not sharded and not a.no_extras:

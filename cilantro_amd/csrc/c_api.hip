@@ -55,6 +55,9 @@ struct cilhip_ctx {
                                                // accumulate in two passes (the search's 3x3x3 pass settles them in LDS) instead of one
   int last_fused_iters = 0, last_two_pass_iters = 0, last_warm_iters = 0;
   int run_calls = 0;              // cilhip_icp_partial_sums calls since cilhip_icp_begin
+  std::vector<unsigned char> iter_form;   // form of every timed search / one-pass launch of the last run (FORM_*), in launch order
+  double form_ms[5] = {0, 0, 0, 0, 0};    // ... and the kernel time summed per form
+  int form_n[5] = {0, 0, 0, 0, 0};
   int warm_start = 1;             // option "warm_start": 0 = never, 1 = when the device reports the source near alignment, 2 = from the second iteration on
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint32_t ntiles = 0;
@@ -309,6 +312,13 @@ int cilhip_get_last_timing2(cilhip_ctx* c, double* search_ms, double* accumulate
   return CILHIP_OK;
 }
 
+int cilhip_get_last_form_timing(cilhip_ctx* c, int form, double* kernel_ms, int* launches) {
+  if (!c || form < 0 || form > 4) return CILHIP_ERR_INVALID;
+  if (kernel_ms) *kernel_ms = c->form_ms[form];
+  if (launches) *launches = c->form_n[form];
+  return CILHIP_OK;
+}
+
 int cilhip_get_last_warm_iterations(cilhip_ctx* c, int* warm_iterations) {
   if (!c || !warm_iterations) return CILHIP_ERR_INVALID;
   *warm_iterations = c->last_warm_iters;
@@ -503,6 +513,8 @@ static bool filters_active(const cilhip_ctx* c) {
 // pass + a streaming accumulation pass) whenever the plain engine runs tiled: no post-filters (they act on the complete
 // match set), point features, the three-cloud metric (the symmetric objective reads source normals per pair), and not
 // the A/B option "fused" (per-lane kernel) or "tile_accumulation" = 0.
+// kernel forms of an iteration's search (+ accumulation): cilhip_get_last_form_timing
+enum { FORM_SEARCH = 0, FORM_TILE_ONE_PASS = 1, FORM_WARM_FIRST = 2, FORM_WARM = 3, FORM_LANE_FUSED = 4 };
 static bool weighted(const cilhip_ctx* c) { return c->cw_point_kind != CW_UNITY || c->cw_plane_kind != CW_UNITY; }
 // The per-pair weights of the combined-metric classes (PointToPoint/PointToPlaneCorrWeightEvaluatorT of
 // icp_single_transform_combined_metric.hpp:11-14; the point-to-point class has none): evaluator(corr.value) times the
@@ -1180,6 +1192,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
   c->rec_valid = false;
+  c->iter_form.clear();
+  for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   for (size_t it = 0; it < p->max_iter; ++it) {
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
@@ -1204,6 +1218,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // Third form, near alignment and from the second iteration on: the per-lane search + accumulation kernel WARM-STARTED
     // from the previous iteration's matches (kept by the forms above) -- no tile to stage at all.  Same matches, same sums
     // up to the order of the f64 additions.
+    // (not at it = 1 unless forced: the first step of a registration is its largest, the bounds from the matches of it = 0 are
+    //  loose -- measured at 10M: 0.43 ms against 0.30 ms for the tiles)
     const bool warm = tile_acc && c->warm_start && it >= 1 && (c->warm_start == 2 || (one_pass && paced && it >= 2));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     if (gn && opt_steps == 0) {
@@ -1212,6 +1228,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       // mirror literally: tform = t_dst * I * t_src.
       return fail(c, CILHIP_ERR_UNSUPPORTED, "max_opt_iter == 0 is not supported");
     }
+    bool warm_first = false;
     for (size_t st = 0; st < opt_steps; ++st) {
       a.skip_if_inner_done = (st > 0);
       if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
@@ -1227,6 +1244,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           // query; the following ones read the records (two coalesced loads) instead of gathering
           if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * 2 * sizeof(float4)));
           wa.warm_rec = c->d_warm_rec;
+          warm_first = !c->rec_valid;
           launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
           c->rec_valid = true;
         } else if (st == 0 && one_pass) {
@@ -1255,6 +1273,9 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         ++launches;
       }
       if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
+      if (timing && st == 0)
+        c->iter_form.push_back((unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
+                                               : (c->fused && !filters_active(c) && !feat6(c)) ? FORM_LANE_FUSED : FORM_SEARCH));
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
         const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : nb;
@@ -1294,6 +1315,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       float m = 0.f;
       CK(c, hipEventElapsedTime(&m, c->ev[2 + 2 * k], c->ev[3 + 2 * k]));
       c->last_search_ms += m;
+      if (k < c->iter_form.size()) { c->form_ms[c->iter_form[k]] += m; ++c->form_n[c->iter_form[k]]; }
     }
     for (size_t k = 0; k + 1 < nacc; k += 2) {      // (two-pass iterations; those enqueued past convergence measure ~0)
       float m = 0.f;
@@ -1324,6 +1346,8 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   c->run_nev = 0;
   c->run_calls = 0;
   c->rec_valid = false;
+  c->iter_form.clear();
+  for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
   return CILHIP_OK;
 }
@@ -1360,6 +1384,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
             const unsigned long long cm = fb->commit;
             if ((unsigned int)(cm >> 32) == c->run_tag && (unsigned int)cm >= (unsigned int)(c->run_calls - 1)) {
               warm = (unsigned long long)fb->unproven * 16ull <= (unsigned long long)c->ns;
+              c->far_mode = !warm;
               break;
             }
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;   // (no news: the tiled form)
@@ -1374,6 +1399,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;
         if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * 2 * sizeof(float4)));
         wa.warm_rec = c->d_warm_rec;
+        if (timing) c->iter_form.push_back((unsigned char)(c->rec_valid ? FORM_WARM : FORM_WARM_FIRST));
         launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
         prows = warm_num_blocks(c->ns);
         c->rec_valid = true;
@@ -1381,6 +1407,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         ++c->last_fused_iters; ++c->last_warm_iters;
       } else if (tile_accumulation(c)) {
         c->rec_valid = false;
+        if (timing) c->iter_form.push_back((unsigned char)FORM_TILE_ONE_PASS);
         IterArgs fa = a;
         fa.store_matches = c->warm_start ? 1 : 0;
         fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
@@ -1389,6 +1416,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         prows = tiled_partial_rows(c->ntiles);
         ++c->last_fused_iters;
       } else {
+        if (timing) c->iter_form.push_back((unsigned char)FORM_SEARCH);
         ++c->last_two_pass_iters;
         if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         else launch_iter(a, IM_NONE, true, true, nb, c->stream);
@@ -1501,6 +1529,7 @@ int cilhip_icp_state(cilhip_ctx* c, cilhip_icp_result* out) {
       CK(c, hipEventElapsedTime(&a, get_event(c, 2 + k), get_event(c, 2 + k + 1)));
       CK(c, hipEventElapsedTime(&b, get_event(c, 2 + k + 1), get_event(c, 2 + k + 2)));
       sm += a; am += b;
+      if (k / 3 < c->iter_form.size()) { c->form_ms[c->iter_form[k / 3]] += a; ++c->form_n[c->iter_form[k / 3]]; }
     }
     c->last_search_ms = sm; c->last_acc_ms = am; c->last_search_launches = (int)(c->run_nev / 3);
     c->last_loop_ms = 0.0;

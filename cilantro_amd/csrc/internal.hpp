@@ -111,7 +111,7 @@ struct IterArgs {
   CorrWeights cw;              // per-correspondence weights (enabled = 0: unity)
   const uint32_t* warm_pos;    // [ns] or null: matches of the previous iteration, the per-lane search's warm start (may alias nn_pos)
   float warm_far_sq;           // warm bounds at or above this (squared) are counted in unproven_cnt
-  float4* warm_rec;            // [2 * ns] or null: per query {matched point, index} {its normal, its safe2 entry (< 0: no match)}
+  float4* warm_rec;            // [2 * ns] or null: per query {matched point, index} in [0, ns), {its normal, its safe2 entry (< 0: no match)} in [ns, 2 ns)
   const float* safe2;          // [grid.n] per sorted target point: lower bound on the squared distance to its nearest other target point (k_self_nn)
 };
 

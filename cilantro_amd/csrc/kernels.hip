@@ -2060,7 +2060,7 @@ void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s) {
 constexpr int WARM_THREADS = 256;
 constexpr int WARM_WAVES = WARM_THREADS / 64;
 // REC: 0 = the old match, its normal and its table entry are gathered through warm_pos; 1 = the same, and every query's
-// match record {point, index, normal, table entry} (32 B, in query order) is written; 2 = the records are READ instead --
+// match record {point, index} {normal, table entry} (two arrays of 16 B per query, in query order) is written; 2 = the records are READ instead --
 // two coalesced 16-byte loads per query, no gather at all for the queries the table settles (nearly all of them); a query
 // whose match changes rewrites its record.
 // The queries the table does NOT settle (a percent or so) are not searched where they turn up -- nearly every wave holds
@@ -2221,8 +2221,8 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     }
     if (!same || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
     if (REC == 1 || (REC == 2 && !same)) {
-      a.warm_rec[2 * (size_t)i] = pm;
-      a.warm_rec[2 * (size_t)i + 1] = make_float4(nm.x, nm.y, nm.z, has ? s2 : -1.0f);
+      a.warm_rec[i] = pm;
+      a.warm_rec[(size_t)a.ns + i] = make_float4(nm.x, nm.y, nm.z, has ? s2 : -1.0f);
     }
     if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     return has;
@@ -2233,7 +2233,7 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   float4 s4n = inext < end ? a.src[inext] : zero4;
   uint32_t wn = (REC != 2 && inext < end) ? a.warm_pos[inext] : NONE_U32;
   float4 r0n = zero4, r1n = zero4;
-  if (REC == 2 && inext < end) { r0n = a.warm_rec[2 * (size_t)inext]; r1n = a.warm_rec[2 * (size_t)inext + 1]; }
+  if (REC == 2 && inext < end) { r0n = a.warm_rec[inext]; r1n = a.warm_rec[(size_t)a.ns + inext]; }
   for (uint32_t base = beg; base < end; base += WARM_THREADS) {
     const uint32_t i = inext;
     const bool valid = i < end;
@@ -2244,7 +2244,7 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     if (inext < end) {
       s4n = a.src[inext];
       if (REC != 2) wn = a.warm_pos[inext];
-      else { r0n = a.warm_rec[2 * (size_t)inext]; r1n = a.warm_rec[2 * (size_t)inext + 1]; }
+      else { r0n = a.warm_rec[inext]; r1n = a.warm_rec[(size_t)a.ns + inext]; }
     }
     float qx, qy, qz;
     transform(s4, qx, qy, qz);
@@ -2259,7 +2259,7 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     const bool settled = valid && s2 >= 0.0f && e_old < a.max_sq && 4.0f * e_old < s2 * 0.99998f;
     if (settled) {
       if (REC != 2 && a.nn_pos != a.warm_pos) a.nn_pos[i] = w;
-      if (REC == 1) { a.warm_rec[2 * (size_t)i] = pm; a.warm_rec[2 * (size_t)i + 1] = make_float4(nm.x, nm.y, nm.z, s2); }
+      if (REC == 1) { a.warm_rec[i] = pm; a.warm_rec[(size_t)a.ns + i] = make_float4(nm.x, nm.y, nm.z, s2); }
       if (a.nn_d2) a.nn_d2[i] = e_old;
     }
     const bool todo = valid && !settled;

@@ -269,6 +269,16 @@ class Context:
         self._ck(self._L.cilhip_get_last_run_forms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_form_timing(self):
+        """{form: (kernel ms, launches)} of the last timed run; forms: 0 search alone, 1 tiled one pass, 2 first warm-started
+        iteration, 3 warm-started iterations, 4 per-lane fused kernel"""
+        out = {}
+        for f in range(5):
+            ms = C.c_double(0); n = C.c_int(0)
+            self._ck(self._L.cilhip_get_last_form_timing(self._h, f, C.byref(ms), C.byref(n)))
+            out[f] = (ms.value, n.value)
+        return out
+
     def last_warm_iterations(self):
         """how many of the one-pass iterations of the last icp_run ran as the warm-started per-lane kernel"""
         a = C.c_int(0)

@@ -301,6 +301,11 @@ int cilhip_get_last_run_forms(cilhip_ctx* ctx, int* one_pass_iterations, int* tw
  * iteration on, near alignment, the search starts from the previous iteration's match -- a real target point, so its
  * distance from the new query bounds the search -- and usually ends inside the query's own cell; same matches. */
 int cilhip_get_last_warm_iterations(cilhip_ctx* ctx, int* warm_iterations);
+/* With kernel timing on: kernel time (hipEvents on the ctx stream) and launch count of the last run's iterations per FORM of
+ * their search kernel -- 0: search alone (a streaming accumulation follows: cilhip_get_last_timing2), 1: LDS-tiled search with
+ * the accumulation inside the tile, 2: the first warm-started iteration of a stretch (gathers through the stored matches and
+ * writes the match records), 3: warm-started iterations reading the records, 4: the per-lane fused kernel (option "fused"). */
+int cilhip_get_last_form_timing(cilhip_ctx* ctx, int form, double* kernel_ms, int* launches);
 
 /* ms of the kernels of the last cilhip_icp_run, measured with hipEvents on the ctx stream:
  * total loop, and the fused search+accumulate kernel alone (sum over executed iterations). */

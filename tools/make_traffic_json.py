@@ -1,18 +1,24 @@
 #!/usr/bin/env python
 """HBM traffic per launch of the dominant kernel(s) from a tools/pmc.sh output directory, corrected as calibrated in
 profiles/r02_calibration.txt: on this gfx950 / rocprofv3, FETCH_SIZE counts 128-B fabric requests at 64 B each (every read
-pattern: x2), WRITE_SIZE is exact.  usage: tools/make_traffic_json.py <pmc dir> <kernel substring> [...]  ->  JSON on stdout
+pattern: x2), WRITE_SIZE is exact.  usage: tools/make_traffic_json.py <pmc dir> [kernel regex ...]  ->  JSON on stdout; without
+a regex the kernels of the bench line's dominant form (<pmc dir>/bench_line.json, roofline.form) are taken
 (commit it as profiles/r02_traffic.json: bench.py quotes it only while the kernel sources still hash to `source_hash`)."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (source_hash)
 
 d, subs = sys.argv[1], sys.argv[2:]
+line = json.loads(open(f"{d}/bench_line.json").read()) if os.path.exists(f"{d}/bench_line.json") else {}
+form = (line.get("roofline") or {}).get("form")
+if not subs:
+    subs = {0: [r"k_search_tiled<0", r"k_search_deferred<0", r"k_iter<\d+, true"], 1: [r"k_search_tiled<[1-4]", r"k_search_deferred<[1-4]"],
+            2: [r"k_warm<\d+, 1>"], 3: [r"k_warm<\d+, 2>"], 4: [r"k_iter<\d+, true"]}[form]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{d}/*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(s in r["Kernel_Name"] for s in subs) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if any(re.search(s, r["Kernel_Name"]) for s in subs) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             vals[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 per = {}
 tot = 0.0
@@ -21,10 +27,9 @@ for k, c in vals.items():
     w = sum(c["WRITE_SIZE"][3:]) / max(len(c["WRITE_SIZE"][3:]), 1) * 1024.0
     per[k] = {"FETCH_SIZE_bytes_reported": f, "WRITE_SIZE_bytes": w, "hbm_bytes": 2.0 * f + w, "launches": len(c["FETCH_SIZE"])}
     tot += 2.0 * f + w
-line = json.loads(open(f"{d}/bench_line.json").read()) if os.path.exists(f"{d}/bench_line.json") else {}
 cfg = line.get("config", {})
 print(json.dumps({"traffic_bytes_per_launch": tot, "kernels": per, "source_hash": bench.source_hash(),
-                  "fused": "accumulation inside the tile" in (line.get("roofline") or {}).get("kernel", ""),
+                  "form": form, "kernel_patterns": list(subs),
                   "workload": {"n_target": cfg.get("n_target"), "n_source_per_gpu": cfg.get("n_source_per_gpu"),
                                "metric": "p2plane" if "point-to-plane" in cfg.get("workload", "") else ("p2p" if "point-to-point" in cfg.get("workload", "") else "combined")},
                   "method": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline`; "
