@@ -55,6 +55,7 @@ struct cilhip_ctx {
                                                // accumulate in two passes (the search's 3x3x3 pass settles them in LDS) instead of one
   int last_fused_iters = 0, last_two_pass_iters = 0, last_warm_iters = 0;
   int run_calls = 0;              // cilhip_icp_partial_sums calls since cilhip_icp_begin
+  bool run_warm_on = false;       // sharded runs: the loop has been seen to (nearly) stand still
   std::vector<unsigned char> iter_form;   // form of every timed search / one-pass launch of the last run (FORM_*), in launch order
   double form_ms[5] = {0, 0, 0, 0, 0};    // ... and the kernel time summed per form
   int form_n[5] = {0, 0, 0, 0, 0};
@@ -515,6 +516,22 @@ static bool filters_active(const cilhip_ctx* c) {
 // the A/B option "fused" (per-lane kernel) or "tile_accumulation" = 0.
 // kernel forms of an iteration's search (+ accumulation): cilhip_get_last_form_timing
 enum { FORM_SEARCH = 0, FORM_TILE_ONE_PASS = 1, FORM_WARM_FIRST = 2, FORM_WARM = 3, FORM_LANE_FUSED = 4 };
+// 1 + the largest distance of a corner of the target's grid from the origin: a point of a (roughly aligned) source moves by
+// at most delta * this per iteration, delta = the iteration's update norm
+static float warm_scale(const cilhip_ctx* c) {
+  const GridDev& g = c->grid;
+  const float hx = std::max(std::fabs(g.ox), std::fabs(g.ox + (float)g.nx * g.cell)), hy = std::max(std::fabs(g.oy), std::fabs(g.oy + (float)g.ny * g.cell)),
+              hz = std::max(std::fabs(g.oz), std::fabs(g.oz + (float)g.nz * g.cell));
+  return 1.0f + std::sqrt(hx * hx + hy * hy + hz * hz);
+}
+// Will the NEXT step be small against a cell?  Extrapolated from the last two update norms (the loop contracts at least as fast
+// as it just did: quadratically for the point-to-plane metric, linearly for point-to-point): next <= delta * min(1, delta / prev).
+// Measured on the benchmark recipe (update norm x scale / cell per iteration): 1.97, 0.29, 7.5e-4, 3e-6 ...; from 0.8 cell away:
+// 1.3, 1.9, 2.2, 0.65, 4.7e-3, 5e-6.
+static bool warm_worthwhile(const cilhip_ctx* c, float delta, float prev_delta) {
+  const float ratio = (prev_delta > 0.0f && std::isfinite(prev_delta)) ? std::min(1.0f, delta / prev_delta) : 1.0f;
+  return delta * ratio * warm_scale(c) < 0.1f * c->grid.cell;
+}
 static bool weighted(const cilhip_ctx* c) { return c->cw_point_kind != CW_UNITY || c->cw_plane_kind != CW_UNITY; }
 // The per-pair weights of the combined-metric classes (PointToPoint/PointToPlaneCorrWeightEvaluatorT of
 // icp_single_transform_combined_metric.hpp:11-14; the point-to-point class has none): evaluator(corr.value) times the
@@ -1194,6 +1211,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   c->rec_valid = false;
   c->iter_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
+  bool warm_on = false;       // the loop has been seen to (nearly) stand still: iterations run warm-started until it is seen far again
   for (size_t it = 0; it < p->max_iter; ++it) {
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
@@ -1213,6 +1231,23 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       }
       if (stop) break;
       c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
+      if (c->far_mode) warm_on = false;
+      if (!c->far_mode && c->warm_start == 1 && !warm_on) {
+        // Candidate for the warm-started form (below): it pays once the source has (nearly) stopped moving -- the bounds it
+        // searches with are the distances to the PREVIOUS matches.  Decided on the step the loop made last, so wait for
+        // iteration it - 1 itself (a bubble of some tens of microseconds, only while this decision is pending): a point moves
+        // by at most delta * (1 + |x|) per iteration.
+        for (unsigned spins = 0;; ++spins) {
+          const unsigned long long cm = fb->commit;
+          if ((unsigned int)(cm >> 32) == c->run_tag && ((unsigned int)cm >= (unsigned int)it || fb->done)) break;
+          if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(30)) {
+            CK(c, hipStreamSynchronize(c->stream));
+            return fail(c, CILHIP_ERR_HIP, "icp_run: the device stopped publishing its loop state");
+          }
+        }
+        if (fb->done) break;
+        warm_on = warm_worthwhile(c, fb->delta, fb->prev_delta);
+      }
     }
     const bool one_pass = tile_acc && !c->far_mode;
     // Third form, near alignment and from the second iteration on: the per-lane search + accumulation kernel WARM-STARTED
@@ -1220,7 +1255,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // up to the order of the f64 additions.
     // (not at it = 1 unless forced: the first step of a registration is its largest, the bounds from the matches of it = 0 are
     //  loose -- measured at 10M: 0.43 ms against 0.30 ms for the tiles)
-    const bool warm = tile_acc && c->warm_start && it >= 1 && (c->warm_start == 2 || (one_pass && paced && it >= 2));
+    const bool warm = tile_acc && c->warm_start && it >= 1 && (c->warm_start == 2 || (one_pass && paced && it >= 2 && warm_on));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     if (gn && opt_steps == 0) {
       // max_optimization_iterations_ == 0: estimateTransformCombinedMetric leaves tform = identity
@@ -1345,6 +1380,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   c->run_active = true;
   c->run_nev = 0;
   c->run_calls = 0;
+  c->run_warm_on = false;
   c->rec_valid = false;
   c->iter_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
@@ -1383,8 +1419,11 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
           for (unsigned spins = 0;; ++spins) {
             const unsigned long long cm = fb->commit;
             if ((unsigned int)(cm >> 32) == c->run_tag && (unsigned int)cm >= (unsigned int)(c->run_calls - 1)) {
-              warm = (unsigned long long)fb->unproven * 16ull <= (unsigned long long)c->ns;
-              c->far_mode = !warm;
+              c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
+              if (c->far_mode) c->run_warm_on = false;
+              // (the step is the one of iteration run_calls - 2 here -- no second wait in the caller-driven protocol)
+              if (!c->far_mode && !c->run_warm_on) c->run_warm_on = warm_worthwhile(c, fb->delta, fb->prev_delta);
+              warm = !c->far_mode && c->run_warm_on;
               break;
             }
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;   // (no news: the tiled form)

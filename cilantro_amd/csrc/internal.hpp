@@ -67,6 +67,8 @@ struct IcpState {
   double sums[SUMS_MAX];  // reduced sums of the last accumulation
   int slab_violation;     // spatially sharded runs: some source point may have left its slab's halo since the partition (sticky)
   unsigned int unproven;  // tiled search of the last iteration: queries its first stage (the octant block) did not prove
+  float prev_delta;       // delta of the iteration before the last one (INFINITY before there is one)
+  int pad1;
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -132,6 +134,8 @@ struct BoxArgs {
 struct Feedback {
   unsigned int done;            // converged
   unsigned int unproven;        // IcpState::unproven of that iteration
+  float delta;                  // IcpState::delta (last_delta_norm_) of that iteration
+  float prev_delta;             // ... and of the one before it
   unsigned long long commit;    // (run tag << 32) | iterations performed
 };
 

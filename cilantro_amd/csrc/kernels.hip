@@ -2595,6 +2595,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
     float mx, my, mz;
     transform_point(Tn, a.src_mean[0], a.src_mean[1], a.src_mean[2], mx, my, mz);
     st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
+    st->prev_delta = st->delta;
     st->delta = delta;
     st->iterations += 1;
     st->ncorr = (unsigned long long)(st->sums[0] + 0.5);   // (the sums of the last accumulation that ran: a converged inner loop skips the later ones)
@@ -2618,6 +2619,8 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   if (a.feedback != nullptr && a.gn_last_step && threadIdx.x == 0) {
     a.feedback->done = (unsigned int)lst.done;
     a.feedback->unproven = lst.unproven;
+    a.feedback->delta = lst.delta;
+    a.feedback->prev_delta = lst.prev_delta;
     __threadfence_system();
     a.feedback->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
   }
@@ -2632,7 +2635,7 @@ struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run
 __global__ void k_init_state(IcpState* st, InitArgs ia) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (ia.fb != nullptr) {
-    ia.fb->done = 0u; ia.fb->unproven = 0u;
+    ia.fb->done = 0u; ia.fb->unproven = 0u; ia.fb->delta = 0.0f; ia.fb->prev_delta = 0.0f;
     __threadfence_system();
     ia.fb->commit = (unsigned long long)ia.run_tag << 32;
   }
@@ -2641,6 +2644,7 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
   transform_point(ia.T, ia.src_mean[0], ia.src_mean[1], ia.src_mean[2], mx, my, mz);
   st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
   st->delta = INFINITY;
+  st->prev_delta = INFINITY;
   st->iterations = 0;
   st->done = 0;
   st->ncorr = 0;
