@@ -70,7 +70,7 @@ struct cilhip_ctx {
   float4* d_src_nrm_sorted = nullptr;
   uint32_t* d_nn_pos = nullptr;
   float* d_nn_d2 = nullptr;
-  float4* d_warm_rec = nullptr;   // [2 * ns] match records of the warm-started iterations (valid inside a run, after the first of them)
+  float4* d_warm_rec = nullptr;   // [ns] float4 + 2 x [ns] F3: match records and the 12-byte source copy of the warm-started iterations (valid inside a run, after the first of them)
   bool rec_valid = false;
   float* d_safe2 = nullptr;       // [grid.n] k_self_nn's table for the warm-started iteration; built with the target
   int cw_point_kind = 0, cw_plane_kind = 0;     // correspondence weight evaluators (CW_*), combined metric
@@ -1277,8 +1277,10 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;      // bound beyond half a cell: what the tiles' octant stage calls unproven
           // the first warm iteration of a stretch gathers through the stored positions and leaves a 32-byte match record per
           // query; the following ones read the records (two coalesced loads) instead of gathering
-          if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * 2 * sizeof(float4)));
+          if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * (sizeof(float4) + 2 * sizeof(F3))));
           wa.warm_rec = c->d_warm_rec;
+          wa.warm_rec_n = reinterpret_cast<F3*>(c->d_warm_rec + c->ns);
+          wa.warm_src3 = wa.warm_rec_n + c->ns;
           warm_first = !c->rec_valid;
           launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
           c->rec_valid = true;
@@ -1436,8 +1438,10 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         wa.warm_pos = c->d_nn_pos;
         wa.safe2 = c->d_safe2;
         wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;
-        if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * 2 * sizeof(float4)));
+        if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * (sizeof(float4) + 2 * sizeof(F3))));
         wa.warm_rec = c->d_warm_rec;
+          wa.warm_rec_n = reinterpret_cast<F3*>(c->d_warm_rec + c->ns);
+          wa.warm_src3 = wa.warm_rec_n + c->ns;
         if (timing) c->iter_form.push_back((unsigned char)(c->rec_valid ? FORM_WARM : FORM_WARM_FIRST));
         launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
         prows = warm_num_blocks(c->ns);

@@ -89,6 +89,8 @@ struct CorrWeights {
   float w_p2p, w_p2pl;              // the metric weights, folded into the per-pair weight
 };
 
+struct F3 { float x, y, z; };      // 12-byte record (one global_load_dwordx3 per lane)
+
 struct IterArgs {
   GridDev grid;
   const float4* src;       // [ns] source sorted by target-grid cell {x,y,z,orig_idx}
@@ -113,7 +115,9 @@ struct IterArgs {
   CorrWeights cw;              // per-correspondence weights (enabled = 0: unity)
   const uint32_t* warm_pos;    // [ns] or null: matches of the previous iteration, the per-lane search's warm start (may alias nn_pos)
   float warm_far_sq;           // warm bounds at or above this (squared) are counted in unproven_cnt
-  float4* warm_rec;            // [2 * ns] or null: per query {matched point, index} in [0, ns), {its normal, its safe2 entry (< 0: no match)} in [ns, 2 ns)
+  float4* warm_rec;            // [ns] or null: per query {matched point, its safe2 entry (< 0: no match)}
+  F3* warm_rec_n;              // [ns]: the matched point's normal
+  F3* warm_src3;               // [ns]: the sorted source points without their index (12 B instead of 16)
   const float* safe2;          // [grid.n] per sorted target point: lower bound on the squared distance to its nearest other target point (k_self_nn)
 };
 

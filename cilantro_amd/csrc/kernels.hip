@@ -2060,9 +2060,9 @@ void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s) {
 constexpr int WARM_THREADS = 256;
 constexpr int WARM_WAVES = WARM_THREADS / 64;
 // REC: 0 = the old match, its normal and its table entry are gathered through warm_pos; 1 = the same, and every query's
-// match record {point, index} {normal, table entry} (two arrays of 16 B per query, in query order) is written; 2 = the records are READ instead --
-// two coalesced 16-byte loads per query, no gather at all for the queries the table settles (nearly all of them); a query
-// whose match changes rewrites its record.
+// match record {point, table entry} {normal} (16 + 12 B, two arrays in query order) and a 12-byte copy of its source point
+// are written; 2 = those are READ instead -- 40 B per query in three coalesced loads, no gather at all for the queries the
+// table settles (nearly all of them); a query whose match changes rewrites its record.
 // The queries the table does NOT settle (a percent or so) are not searched where they turn up -- nearly every wave holds
 // one, and the whole wave would walk the search code for it: each wave lists them in LDS (ballot order: no atomics, the
 // same list in every run) and searches the list afterwards, densely packed (the list holds all of the wave's queries if
@@ -2220,9 +2220,10 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
       else { pm = g.pts[best.pos]; s2 = a.safe2[best.pos]; if (NRM) nm = g.nrm[best.pos]; }
     }
     if (!same || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
+    if (REC == 1) { const float4 t4 = a.src[i]; a.warm_src3[i] = F3{t4.x, t4.y, t4.z}; }
     if (REC == 1 || (REC == 2 && !same)) {
-      a.warm_rec[i] = pm;
-      a.warm_rec[(size_t)a.ns + i] = make_float4(nm.x, nm.y, nm.z, has ? s2 : -1.0f);
+      a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, has ? s2 : -1.0f);
+      if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z};
     }
     if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     return has;
@@ -2230,28 +2231,33 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
 
   uint32_t qcount = 0;      // (wave-uniform)
   uint32_t inext = beg + threadIdx.x;
-  float4 s4n = inext < end ? a.src[inext] : zero4;
-  uint32_t wn = (REC != 2 && inext < end) ? a.warm_pos[inext] : NONE_U32;
-  float4 r0n = zero4, r1n = zero4;
-  if (REC == 2 && inext < end) { r0n = a.warm_rec[inext]; r1n = a.warm_rec[(size_t)a.ns + inext]; }
+  // what a round streams in: REC 0 / 1 the sorted source record and the stored position; REC 2 the 12-byte copy of the source
+  // point and the match record {point, table entry} {normal} -- 40 B per query (28 without normals), all of it coalesced
+  const F3 zero3 = {0.f, 0.f, 0.f};
+  F3 s3n = zero3, r1n = zero3;
+  float4 r0n = zero4;
+  uint32_t wn = NONE_U32;
+  auto fetch = [&](uint32_t k) {
+    if (REC == 2) { s3n = a.warm_src3[k]; r0n = a.warm_rec[k]; if (NRM) r1n = a.warm_rec_n[k]; }
+    else { const float4 t4 = a.src[k]; s3n = F3{t4.x, t4.y, t4.z}; wn = a.warm_pos[k]; }
+  };
+  if (inext < end) fetch(inext);
   for (uint32_t base = beg; base < end; base += WARM_THREADS) {
     const uint32_t i = inext;
     const bool valid = i < end;
-    const float4 s4 = s4n;
+    const F3 s3c = s3n;
+    const float4 s4 = make_float4(s3c.x, s3c.y, s3c.z, 0.f);
     const uint32_t w = wn;
-    const float4 r0 = r0n, r1 = r1n;
+    const float4 r0 = r0n;
+    const F3 r1 = r1n;
     inext += WARM_THREADS;
-    if (inext < end) {
-      s4n = a.src[inext];
-      if (REC != 2) wn = a.warm_pos[inext];
-      else { r0n = a.warm_rec[inext]; r1n = a.warm_rec[(size_t)a.ns + inext]; }
-    }
+    if (inext < end) fetch(inext);
     float qx, qy, qz;
     transform(s4, qx, qy, qz);
     // the old match, its normal and its table entry: from the record, or gathered through the stored position
     float4 pm = zero4, nm = zero4;
     float s2 = -1.0f;                     // (< 0: no old match)
-    if (REC == 2) { pm = r0; nm = make_float4(r1.x, r1.y, r1.z, 0.f); s2 = r1.w; }
+    if (REC == 2) { pm = make_float4(r0.x, r0.y, r0.z, 0.f); nm = make_float4(r1.x, r1.y, r1.z, 0.f); s2 = r0.w; }
     else if (valid && w != NONE_U32) { pm = g.pts[w]; s2 = a.safe2[w]; if (NRM) nm = g.nrm[w]; }
     // Nearer to the old match than half the distance from it to any other target point: it is THE nearest, nothing to look
     // at -- not even the query's cell (the factor covers the 2^-22 relative rounding of the three f32 squared distances).
@@ -2259,7 +2265,7 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     const bool settled = valid && s2 >= 0.0f && e_old < a.max_sq && 4.0f * e_old < s2 * 0.99998f;
     if (settled) {
       if (REC != 2 && a.nn_pos != a.warm_pos) a.nn_pos[i] = w;
-      if (REC == 1) { a.warm_rec[i] = pm; a.warm_rec[(size_t)a.ns + i] = make_float4(nm.x, nm.y, nm.z, s2); }
+      if (REC == 1) { a.warm_src3[i] = s3c; a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, s2); if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z}; }
       if (a.nn_d2) a.nn_d2[i] = e_old;
     }
     const bool todo = valid && !settled;
