@@ -398,7 +398,7 @@ int cilhip_set_source(cilhip_ctx* c, const float* xyz, size_t n, int mem) {
   hipError_t e = mean3_device(c->d_src_xyz, c->ns, c->stream, mean);
   if (e != hipSuccess) { c->err = std::string("mean3: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   for (int i = 0; i < 3; ++i) c->src_mean[i] = (float)mean[i];
-  const int nb = iter_num_blocks(c->ns);
+  const int nb = std::max(iter_num_blocks(c->ns), warm_num_blocks(c->ns));      // rows of partial sums: the streaming and the warm-started kernels
   if (nb > c->partial_blocks) {
     if (c->d_partials) (void)hipFree(c->d_partials);
     CK(c, hipMalloc(&c->d_partials, (size_t)nb * SUMS_MAX * sizeof(double)));
@@ -547,6 +547,12 @@ static CorrWeights corr_weights_of(const cilhip_ctx* c, bool combined_metric, fl
 }
 static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params* p) {
   return corr_weights_of(c, p->metric == CILHIP_METRIC_COMBINED, p->w_p2p, p->w_p2pl);
+}
+// The warm-started iteration (k_warm) needs stored matches, unit weights and the first Gauss-Newton step's plain terms -- the
+// same engine conditions as the in-tile accumulation, but no tiles: it also serves clouds the tiles do not (a source much
+// sparser than the target: BASELINE configs[3]).
+static bool warm_capable(const cilhip_ctx* c) {
+  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
 }
 static bool tile_accumulation(const cilhip_ctx* c) {
   return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
@@ -1205,7 +1211,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   // choice of the kernel FORM per iteration: while the octant stage leaves many queries unproven (source far from
   // alignment: first iterations of a registration) the search runs with its in-LDS 3x3x3 second pass and a separate
   // streaming accumulation; once nearly all are proven, search + accumulation run as one pass inside the tiles.
-  const bool paced = tile_acc && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
+  const bool wcap = warm_capable(c);
+  const bool paced = (tile_acc || wcap) && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
   if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
   c->rec_valid = false;
@@ -1255,7 +1262,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // up to the order of the f64 additions.
     // (not at it = 1 unless forced: the first step of a registration is its largest, the bounds from the matches of it = 0 are
     //  loose -- measured at 10M: 0.43 ms against 0.30 ms for the tiles)
-    const bool warm = tile_acc && c->warm_start && it >= 1 && (c->warm_start == 2 || (one_pass && paced && it >= 2 && warm_on));
+    const bool warm = wcap && it >= 1 && (c->warm_start == 2 || ((one_pass || !tile_acc) && paced && it >= 2 && warm_on));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     if (gn && opt_steps == 0) {
       // max_optimization_iterations_ == 0: estimateTransformCombinedMetric leaves tform = identity
@@ -1411,7 +1418,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
       // published (a look, never a wait) says the source is near alignment.  Ranks may differ in their choice: the sums are
       // the same up to the order of the f64 additions.
       bool warm = false;
-      if (tile_accumulation(c) && c->warm_start && c->run_calls >= 1) {
+      if (warm_capable(c) && c->run_calls >= 1) {
         warm = c->warm_start == 2;
         if (!warm && c->run_calls >= 2) {
           // paced like cilhip_icp_run: at most two iterations ahead of the device (which never waits: an iteration takes
