@@ -322,6 +322,18 @@ def bench_icp(a, torch, rank, world, local_rank):
             ctx.synchronize()
             cold.append((time.perf_counter() - t0) * 1e3)
         extras["icp_estimate_ms_15iter_cold"] = statistics.median(cold)
+        # the same timed region with the warm-started form switched off (every iteration through the LDS-tiled kernels): the
+        # matches -- and so the loop -- are the same, only the way they are found differs
+        ctx.set_option("warm_start", 0)
+        ctx.prepare_source(T0, force=True)
+        p.max_iter = a.warmup; ctx.icp_run(p, T0)
+        ctx.synchronize(); t0 = time.perf_counter()
+        p.max_iter = a.steps; r0 = ctx.icp_run(p, T0)
+        ctx.synchronize(); dt0 = time.perf_counter() - t0
+        T_nw = np.array(r0.T[:], np.float32).reshape(4, 4).T
+        extras["without_warm_start"] = {"ms_per_step": dt0 * 1e3 / a.steps, "icp_iterations_per_sec": a.steps / dt0, "last_ncorr": int(r0.last_ncorr),
+                                        "max_abs_T_difference_to_the_timed_run": float(np.abs(T_nw - np.array(res.T[:], np.float32).reshape(4, 4).T).max())}
+        ctx.set_option("warm_start", 1)
         extras["source_sort_ms_runs"] = [ctx.prepare_source(T0, force=True) for _ in range(3)]
         # a converging trajectory (SURVEY.md 8(d) "recipe sanity": perturbation 0.8 h, tolerance 1e-5) beside the fixed-point run
         try:
