@@ -41,6 +41,8 @@ struct cilhip_ctx {
   uint32_t ns = 0;
   float* d_src_xyz = nullptr;     // original order (kept for re-sorting)
   float4* d_src_sorted = nullptr; // sorted cube-major by target-grid cell under sort_T
+  SortWorkspace sort_ws;          // scratch + tile table of sort_source, kept between the sorts of a source (d_tiles / d_tile_center point into it)
+  uint32_t tile_aux_cap = 0;      // tiles d_tile_box / d_defer_mask are sized for
   uint2* d_tiles = nullptr;       // [ntiles] query ranges of the LDS-tiled search kernel
   float4* d_tile_center = nullptr;  // [ntiles] cube centre of each tile in source space
   int* d_tile_box = nullptr;        // [8*ntiles] cell range of each tile's cube under the current transform (recomputed per search)
@@ -185,8 +187,8 @@ static void free_source(cilhip_ctx* c) {
   c->rec_valid = false;
   if (c->d_out_idx) (void)hipFree(c->d_out_idx);
   if (c->d_out_d2) (void)hipFree(c->d_out_d2);
-  if (c->d_tiles) (void)hipFree(c->d_tiles);
-  if (c->d_tile_center) (void)hipFree(c->d_tile_center);
+  free_sort_workspace(c->sort_ws);      // (owns d_tiles / d_tile_center)
+  c->tile_aux_cap = 0;
   if (c->d_tile_box) (void)hipFree(c->d_tile_box);
   if (c->d_src_nrm) (void)hipFree(c->d_src_nrm);
   if (c->d_src_nrm_sorted) (void)hipFree(c->d_src_nrm_sorted);
@@ -449,13 +451,19 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     if (dl > 4.0f * c->grid.cell || dr * ext > 4.0f * c->grid.cell) need = true;
   }
   if (need) {
-    if (c->d_tiles) { (void)hipFree(c->d_tiles); c->d_tiles = nullptr; c->ntiles = 0; }
-    if (c->d_tile_center) { (void)hipFree(c->d_tile_center); c->d_tile_center = nullptr; }
-    if (c->d_tile_box) { (void)hipFree(c->d_tile_box); c->d_tile_box = nullptr; }
-    if (c->d_defer_mask) { (void)hipFree(c->d_defer_mask); c->d_defer_mask = nullptr; }
-    hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->d_tile_center, c->tile_axes, &c->ntiles);
+    // (scratch, tile table and the per-tile arrays are kept between the sorts of a source: a re-sort costs its kernels only)
+    c->d_tiles = nullptr; c->d_tile_center = nullptr; c->ntiles = 0;
+    hipError_t e = sort_source(c->d_src_xyz, c->ns, c->grid, T, c->d_src_sorted, c->stream, &c->d_tiles, &c->d_tile_center, c->tile_axes, &c->ntiles, &c->sort_ws);
     if (e != hipSuccess) { c->err = std::string("sort_source: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
-    CK(c, hipMalloc(&c->d_defer_mask, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long)));
+    if (c->ntiles + 1 > c->tile_aux_cap) {
+      if (c->d_tile_box) { (void)hipFree(c->d_tile_box); c->d_tile_box = nullptr; }
+      if (c->d_defer_mask) { (void)hipFree(c->d_defer_mask); c->d_defer_mask = nullptr; }
+      c->tile_aux_cap = 0;
+      const uint32_t cap = c->ntiles + 1 + c->ntiles / 8;
+      CK(c, hipMalloc(&c->d_defer_mask, (size_t)cap * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long)));
+      CK(c, hipMalloc(&c->d_tile_box, (size_t)cap * 8 * sizeof(int)));
+      c->tile_aux_cap = cap;
+    }
     CK(c, hipMemsetAsync(c->d_defer_mask, 0, ((size_t)c->ntiles + 1) * 2 * (TILE_THREADS / 64) * sizeof(unsigned long long), c->stream));
     {   // the tiled search with in-tile accumulation leaves one row of partial sums per tile and per block of its clean-up pass
       const int rows = std::max(std::max(iter_num_blocks(c->ns), warm_num_blocks(c->ns)), tiled_partial_rows(c->ntiles));
@@ -466,7 +474,6 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
         c->partial_blocks = rows;
       }
     }
-    CK(c, hipMalloc(&c->d_tile_box, ((size_t)c->ntiles + 1) * 8 * sizeof(int)));
     if (c->d_src_nrm) launch_gather_by_w(c->d_src_sorted, c->d_src_nrm, c->ns, c->d_src_nrm_sorted, c->stream);
     if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
     memcpy(c->sort_T, T, sizeof(c->sort_T));

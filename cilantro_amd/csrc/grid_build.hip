@@ -324,8 +324,11 @@ __global__ void k_emit_tiles(const uint32_t* __restrict__ cube_start, const uint
   }
 }
 
+// ws (optional): scratch and tile-table storage kept between calls -- a registration loop re-sorts the same source for every new
+// initial transform, and the dozen hipMalloc / hipFree of a stand-alone call cost more than its kernels (1.7 -> 0.8 ms at 10M).
+// With ws the tile table lives in ws (valid until the next call with it); without, the caller frees *d_tiles_out / *d_tile_center_out.
 hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out, hipStream_t s,
-                       uint2** d_tiles_out, float4** d_tile_center_out, float tile_axes_out[9], uint32_t* ntiles_out) {
+                       uint2** d_tiles_out, float4** d_tile_center_out, float tile_axes_out[9], uint32_t* ntiles_out, SortWorkspace* ws) {
   *d_tiles_out = nullptr; *d_tile_center_out = nullptr; *ntiles_out = 0;
   // inverse of the (affine) sort transform, in double; a singular linear part leaves a zero box (every query
   // then takes the clean-up pass: slow, still exact)
@@ -346,55 +349,87 @@ hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const f
     for (int i = 0; i < 9; ++i) tile_axes_out[i] = (float)(h * li[i]);
   }
   if (n == 0) return hipSuccess;
-  uint32_t *k_in = nullptr, *k_out = nullptr, *v_in = nullptr, *v_out = nullptr;
-  HIP_TRY(hipMalloc(&k_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&k_out, (size_t)n * 4));
-  HIP_TRY(hipMalloc(&v_in, (size_t)n * 4)); HIP_TRY(hipMalloc(&v_out, (size_t)n * 4));
-  Tf tf;
-  for (int i = 0; i < 16; ++i) tf.m[i] = T[i];
-  hipLaunchKernelGGL(k_cube_keys_tf, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, tf, k_in, v_in);
   constexpr uint32_t CE = CUBE_EDGE;
   const uint32_t cnx = (uint32_t)(g.nx - 1 - GRID_PAD) / CE + 1, cny = (uint32_t)(g.ny - 1 - GRID_PAD) / CE + 1, cnz = (uint32_t)(g.nz - 1 - GRID_PAD) / CE + 1;
   const uint32_t ncubes = cnx * cny * cnz;
-  hipError_t e = sort_pairs(k_in, k_out, v_in, v_out, n, std::min(32u, bits_for(ncubes * CE * CE * CE)), s);
-  uint32_t *cube_start = nullptr, *tcount = nullptr, *toff = nullptr;
-  void* tmp = nullptr;
+  const unsigned bits = std::min(32u, bits_for(ncubes * CE * CE * CE));
+  // one slab of scratch: 4 key / value arrays, 3 per-cube arrays, the temporaries of the sort and of the scan
+  uint32_t* nul = nullptr;
+  size_t sort_tmp = 0, scan_tmp = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_tmp, nul, nul, nul, nul, (size_t)n, 0u, bits, s));
+  HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tmp, nul, nul, 0u, (size_t)ncubes + 1, rocprim::plus<uint32_t>(), s));
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t arr = up((size_t)n * 4), carr = up(((size_t)ncubes + 1) * 4);
+  const size_t need = 4 * arr + 3 * carr + up(sort_tmp ? sort_tmp : 16) + up(scan_tmp ? scan_tmp : 16);
+  SortWorkspace local;
+  SortWorkspace* w = ws ? ws : &local;
+  hipError_t e = hipSuccess;
+  if (w->scratch_bytes < need) {
+    if (w->scratch) (void)hipFree(w->scratch);
+    w->scratch = nullptr; w->scratch_bytes = 0;
+    if ((e = hipMalloc(&w->scratch, need)) != hipSuccess) return e;
+    w->scratch_bytes = need;
+  }
+  char* base = static_cast<char*>(w->scratch);
+  uint32_t *k_in = reinterpret_cast<uint32_t*>(base), *k_out = reinterpret_cast<uint32_t*>(base + arr), *v_in = reinterpret_cast<uint32_t*>(base + 2 * arr),
+           *v_out = reinterpret_cast<uint32_t*>(base + 3 * arr);
+  uint32_t *cube_start = reinterpret_cast<uint32_t*>(base + 4 * arr), *tcount = reinterpret_cast<uint32_t*>(base + 4 * arr + carr),
+           *toff = reinterpret_cast<uint32_t*>(base + 4 * arr + 2 * carr);
+  void* tmp_sort = base + 4 * arr + 3 * carr;
+  void* tmp_scan = base + 4 * arr + 3 * carr + up(sort_tmp ? sort_tmp : 16);
+  Tf tf;
+  for (int i = 0; i < 16; ++i) tf.m[i] = T[i];
   uint2* tiles = nullptr;
   float4* centers = nullptr;
   do {
-    if (e != hipSuccess) break;
+    hipLaunchKernelGGL(k_cube_keys_tf, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, n, g, tf, k_in, v_in);
+    if ((e = rocprim::radix_sort_pairs(tmp_sort, sort_tmp, k_in, k_out, v_in, v_out, (size_t)n, 0u, bits, s)) != hipSuccess) break;
     hipLaunchKernelGGL(k_gather, dim3(grid_blocks(n)), dim3(256), 0, s, d_xyz, (const float*)nullptr, v_out, n, d_out, (float4*)nullptr);
     // cube_start[] over the sorted cube ids, then the tile table
     hipLaunchKernelGGL(k_shift_keys, dim3(grid_blocks(n)), dim3(256), 0, s, k_out, n, k_in);
-    if ((e = hipMalloc(&cube_start, ((size_t)ncubes + 1) * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&tcount, ((size_t)ncubes + 1) * 4)) != hipSuccess) break;
-    if ((e = hipMalloc(&toff, ((size_t)ncubes + 1) * 4)) != hipSuccess) break;
     hipLaunchKernelGGL(k_cell_start, dim3(grid_blocks(n + 1)), dim3(256), 0, s, k_in, n, ncubes, cube_start);
     if ((e = hipMemsetAsync(tcount, 0, ((size_t)ncubes + 1) * 4, s)) != hipSuccess) break;
     hipLaunchKernelGGL(k_tile_counts, dim3(grid_blocks(ncubes)), dim3(256), 0, s, cube_start, ncubes, tcount);
-    size_t tmp_bytes = 0;
-    if ((e = rocprim::exclusive_scan(nullptr, tmp_bytes, tcount, toff, 0u, (size_t)ncubes + 1, rocprim::plus<uint32_t>(), s)) != hipSuccess) break;
-    if ((e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16)) != hipSuccess) break;
-    if ((e = rocprim::exclusive_scan(tmp, tmp_bytes, tcount, toff, 0u, (size_t)ncubes + 1, rocprim::plus<uint32_t>(), s)) != hipSuccess) break;
+    if ((e = rocprim::exclusive_scan(tmp_scan, scan_tmp, tcount, toff, 0u, (size_t)ncubes + 1, rocprim::plus<uint32_t>(), s)) != hipSuccess) break;
     uint32_t ntiles = 0;
     if ((e = hipMemcpyAsync(&ntiles, toff + ncubes, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
-    if ((e = hipMalloc(&tiles, ((size_t)ntiles + 1) * sizeof(uint2))) != hipSuccess) break;
-    if ((e = hipMalloc(&centers, ((size_t)ntiles + 1) * sizeof(float4))) != hipSuccess) break;
+    if (ws) {
+      if (ws->tile_cap < ntiles + 1) {
+        if (ws->tiles) (void)hipFree(ws->tiles);
+        if (ws->centers) (void)hipFree(ws->centers);
+        ws->tiles = nullptr; ws->centers = nullptr; ws->tile_cap = 0;
+        const uint32_t cap = ntiles + 1 + ntiles / 8;
+        if ((e = hipMalloc(&ws->tiles, (size_t)cap * sizeof(uint2))) != hipSuccess) break;
+        if ((e = hipMalloc(&ws->centers, (size_t)cap * sizeof(float4))) != hipSuccess) break;
+        ws->tile_cap = cap;
+      }
+      tiles = ws->tiles; centers = ws->centers;
+    } else {
+      if ((e = hipMalloc(&tiles, ((size_t)ntiles + 1) * sizeof(uint2))) != hipSuccess) break;
+      if ((e = hipMalloc(&centers, ((size_t)ntiles + 1) * sizeof(float4))) != hipSuccess) break;
+    }
     hipLaunchKernelGGL(k_emit_tiles, dim3(grid_blocks(ncubes)), dim3(256), 0, s, cube_start, toff, ncubes, g, tinv, tiles, centers);
-    e = hipStreamSynchronize(s);
+    e = ws ? hipGetLastError() : hipStreamSynchronize(s);      // (with ws everything stays on the stream)
     *d_tiles_out = tiles; *d_tile_center_out = centers; *ntiles_out = ntiles;
   } while (0);
-  (void)hipFree(k_in); (void)hipFree(k_out); (void)hipFree(v_in); (void)hipFree(v_out);
-  if (cube_start) (void)hipFree(cube_start);
-  if (tcount) (void)hipFree(tcount);
-  if (toff) (void)hipFree(toff);
-  if (tmp) (void)hipFree(tmp);
-  if (e != hipSuccess) {
-    if (tiles) (void)hipFree(tiles);
-    if (centers) (void)hipFree(centers);
-    *d_tiles_out = nullptr; *d_tile_center_out = nullptr; *ntiles_out = 0;
+  if (!ws) {
+    (void)hipStreamSynchronize(s);
+    if (local.scratch) (void)hipFree(local.scratch);
+    if (e != hipSuccess) {
+      if (tiles) (void)hipFree(tiles);
+      if (centers) (void)hipFree(centers);
+    }
   }
+  if (e != hipSuccess) { *d_tiles_out = nullptr; *d_tile_center_out = nullptr; *ntiles_out = 0; }
   return e;
+}
+
+void free_sort_workspace(SortWorkspace& ws) {
+  if (ws.scratch) (void)hipFree(ws.scratch);
+  if (ws.tiles) (void)hipFree(ws.tiles);
+  if (ws.centers) (void)hipFree(ws.centers);
+  ws = SortWorkspace();
 }
 
 }  // namespace cilhip

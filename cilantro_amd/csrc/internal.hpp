@@ -254,8 +254,14 @@ void free_grid(GridDev& g);
 // Sorts the source by the target-grid cell of T*s; writes {x,y,z,orig} records.  d_out preallocated [n].
 // Also emits the tile table of the LDS-tiled search kernel: tiles[t] = [begin,end) of <= TILE_QUERIES sorted
 // queries that share one 4x4x4-cell cube (caller frees *d_tiles_out with hipFree).
+struct SortWorkspace {      // scratch + tile-table storage a caller keeps between sort_source calls (free_sort_workspace)
+  void* scratch = nullptr; size_t scratch_bytes = 0;
+  uint2* tiles = nullptr; float4* centers = nullptr; uint32_t tile_cap = 0;
+};
 hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const float T[16], float4* d_out,
-                       hipStream_t s, uint2** d_tiles_out, float4** d_tile_center_out, float tile_axes_out[9], uint32_t* ntiles_out);
+                       hipStream_t s, uint2** d_tiles_out, float4** d_tile_center_out, float tile_axes_out[9], uint32_t* ntiles_out,
+                       SortWorkspace* ws = nullptr);
+void free_sort_workspace(SortWorkspace& ws);
 hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3]);
 
 }  // namespace cilhip
