@@ -17,7 +17,7 @@ python bench.py > $O/bench_c3_full.json 2> $O/bench_c3_full.err; cut -c1-400 $O/
 python bench.py --config c2 > $O/bench_c2.json 2> $O/bench_c2.err; cut -c1-300 $O/bench_c2.json
 python bench.py --config kmeans > $O/bench_kmeans.json 2> $O/bench_kmeans.err; cut -c1-300 $O/bench_kmeans.json
 python bench.py --config ransac > $O/bench_ransac.json 2> $O/bench_ransac.err; cut -c1-300 $O/bench_ransac.json
-python bench.py --config c4_1gpu --steps 10 --warmup 2 --no-extras > $O/bench_c4_1gpu.json 2> $O/bench_c4.err; cut -c1-300 $O/bench_c4_1gpu.json
+python bench.py --config c4_1gpu --steps 20 --warmup 3 --no-extras > $O/bench_c4_1gpu.json 2> $O/bench_c4.err; cut -c1-300 $O/bench_c4_1gpu.json
 timeout 600 python tools/variants_bench.py 10000000 > $O/variants.txt 2>&1; grep "n=" $O/variants.txt
 timeout 600 python tools/directions_bench.py 10000000 > $O/directions.txt 2>&1; tail -8 $O/directions.txt
 timeout 300 python tools/drift_check.py > $O/drift.txt 2>&1; tail -6 $O/drift.txt
