@@ -249,13 +249,16 @@ def bench_icp(a, torch, rank, world, local_rank):
         #   it); the streaming accumulation pass that then follows: 16 Ns + 24 Nc (point-to-point: 12 Nc)
         nc_l = nc if not sharded else ns_l       # (rank 0's own pairs; ncorr is the job's total)
         one_pass_bytes = 12.0 * ns_l + 12.0 * nd_l + (12.0 * nc_l if with_normals else 0.0)
+        # warm-started iteration: of the target only the MATCHED points (and normals) are data of the computation -- the search
+        # starts from the previous matches instead of reading the target (equal to the line above when Nd = Nc, as in C3)
+        warm_bytes = 12.0 * ns_l + 12.0 * nc_l + (12.0 * nc_l if with_normals else 0.0)
         FORMS = {
             0: ("kNN correspondence search alone (k_search_tiled<none> + clean-up pass, or the per-lane search: small / sparse-source clouds); "
                 "a streaming accumulation pass follows", 16.0 * ns_l + 12.0 * nd_l),
             1: ("k_search_tiled<metric> + k_search_deferred<metric> (LDS-tiled kNN search with the accumulation inside the tile)", one_pass_bytes),
-            2: ("k_warm<metric, 1> (first warm-started iteration: search from the previous matches, gathers, writes the match records)", one_pass_bytes),
+            2: ("k_warm<metric, 1> (first warm-started iteration: search from the previous matches, gathers, writes the match records)", warm_bytes),
             3: ("k_warm<metric, 2> (warm-started iteration: search from the previous matches read as records, accumulation on the matrix cores)",
-                one_pass_bytes),
+                warm_bytes),
             4: ("k_iter<metric, search> (per-lane fused search + accumulation)", one_pass_bytes),
         }
         ft = ctx.last_form_timing()
