@@ -6,12 +6,21 @@
 //                                       (nanoflann searchLevel, 3rd_party/nanoflann/nanoflann.hpp:1885-1961)
 //   second transform of src             core/space_transformations.hpp:203-216   (eliminated: q is re-formed in registers)
 //   normal-equation / moment sums       registration/transform_estimation.hpp:25-34, :298-320, :328-343
-// as: the LDS-tiled search (k_tile_boxes, k_search_tiled, k_search_todo) or, for small clouds, the per-lane search
-// (k_iter<NONE, search, store>); the streaming accumulation (k_iter<metric, no search>; k_iter<metric, search> is the
-// fused small-cloud form); then k_reduce_stage1 and the one-block epilogue k_solve, which reduces the partial sums in a
-// fixed order and performs the 3x3 SVD / 6x6 LDL^T solve + compose on the device (solve.hpp), so all iterations of
-// IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) are enqueued back-to-back with no host
-// round trip.  DESIGN.md section 5 has the kernel table, the measurements and what was tried.
+// as, per iteration, ONE of three forms of the search (+ accumulation):
+//   * k_tile_boxes + k_search_tiled<metric> + k_search_deferred<metric>: the LDS-tiled search with the accumulation inside
+//     the tile (f64 MFMA rank update) -- the first iterations of a run on a large cloud;
+//   * k_warm<metric, rec>: the search warm-started from the previous iteration's matches (settled by k_self_nn's
+//     nearest-other-point table for nearly all queries, listed and searched densely for the rest) + the same MFMA
+//     accumulation, streaming 40 B per query -- every later iteration near alignment;
+//   * k_search_tiled<none> / k_iter<none, search, store> (per-lane search) followed by the streaming accumulation
+//     k_iter<metric, no search>: sources far from alignment, engine post-filters, weight evaluators, later Gauss-Newton
+//     steps, small clouds (k_iter<metric, search> is the per-lane fused form, option "fused");
+// variants: k_search_tiled<none, feat6> (6-D point+normal features), k_acc_reverse (reverse matches of the other search
+// directions, accumulated where they are found).  Then k_reduce_stage1 and the one-block epilogue k_solve, which reduces
+// the partial sums in a fixed order, performs the 3x3 SVD / 6x6 LDL^T solve + compose on the device (solve.hpp) and
+// publishes the loop state to the host, so all iterations of IterativeClosestPointBase::estimate()
+// (registration/icp_base.hpp:68-87) are enqueued without a host round trip on the critical path.  DESIGN.md section 5
+// has the kernel table, the measurements and what was tried.
 //
 // Design notes (MI355X):
 //   * no MFMA in the search: K=3 contraction, and the -2q.p+|p|^2 form would change the rounding of d2 and break
@@ -21,9 +30,10 @@
 //   * blockIdx -> work mapping is XCD-aware: hardware places block b on XCD b%8, so virtual block
 //     (b%8)*(nb/8)+b/8 gives every XCD one contiguous eighth of the (spatially sorted) queries and
 //     each private 4 MiB L2 caches one slab of the target instead of all of it.
-//   * f64 accumulators live in registers across a contiguous chunk of queries per lane; one wave64
-//     shuffle tree + LDS + fixed-order cross-block reduction => bitwise run-to-run reproducible
-//     (the reference's OpenMP reduction is not).
+//   * the normal-equation sums are a rank update Z += z z^T of per-correspondence f32 term vectors: v_mfma_f64_16x16x4_f64
+//     work (products of f32 terms exact in f64, sums in f64) with the wave's 16x16 tile in registers; the streaming
+//     kernel keeps per-lane f64 accumulators instead.  Fixed orders everywhere (per wave, per block, across blocks)
+//     => bitwise run-to-run reproducible (the reference's OpenMP reduction is not).
 #include "internal.hpp"
 #include <cstdio>
 #include <cstring>
