@@ -78,6 +78,47 @@ int main() {
     ldlt6_solve(A, b, x);                                  // the wrapper still answers (pivoted)
     if (!(std::fabs(x[0] - 1.0) < 1e-12 && std::fabs(x[5] + 6.0) < 1e-12)) { std::printf("wrapper fallback wrong\n"); ++failures; }
   }
+  // gn_normal_equations: weighted correspondences against a direct per-pair assembly (point terms E = [[a]x ; I], plane terms
+  // e = [a x n ; n]); with per-pair weights the point block's translation part is the SUM OF THE WEIGHTS (slot 43), not the count
+  {
+    double sums[SUMS_MAX] = {0}, AtA_ref[36] = {0}, Atb_ref[6] = {0};
+    const int N = 200;
+    for (int k = 0; k < N; ++k) {
+      double a[3], r[3], nrm[3];
+      for (int c = 0; c < 3; ++c) { a[c] = urand() - 0.5; r[c] = 0.1 * (urand() - 0.5); nrm[c] = urand() - 0.5; }
+      const double wq = 0.2 + urand(), wp = 0.2 + urand();
+      double e[6] = {a[1] * nrm[2] - a[2] * nrm[1], a[2] * nrm[0] - a[0] * nrm[2], a[0] * nrm[1] - a[1] * nrm[0], nrm[0], nrm[1], nrm[2]};
+      const double res = nrm[0] * r[0] + nrm[1] * r[1] + nrm[2] * r[2];
+      double E[6][3] = {{0, -a[2], a[1]}, {a[2], 0, -a[0]}, {-a[1], a[0], 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+      for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) {
+          AtA_ref[i * 6 + j] += wp * e[i] * e[j];
+          for (int c = 0; c < 3; ++c) AtA_ref[i * 6 + j] += wq * E[i][c] * E[j][c];
+        }
+        Atb_ref[i] += wp * res * e[i];
+        for (int c = 0; c < 3; ++c) Atb_ref[i] += wq * E[i][c] * r[c];
+      }
+      // the accumulation kernels' slot layout (solve.hpp), weights folded in
+      sums[0] += 1.0;
+      int s = 1;
+      for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) sums[s++] += wp * e[i] * e[j];
+      for (int i = 0; i < 6; ++i) sums[22 + i] += wp * res * e[i];
+      for (int c = 0; c < 3; ++c) sums[28 + c] += wq * a[c];
+      sums[31] += wq * a[0] * a[0]; sums[32] += wq * a[0] * a[1]; sums[33] += wq * a[0] * a[2];
+      sums[34] += wq * a[1] * a[1]; sums[35] += wq * a[1] * a[2]; sums[36] += wq * a[2] * a[2];
+      sums[37] += wq * (a[1] * r[2] - a[2] * r[1]); sums[38] += wq * (a[2] * r[0] - a[0] * r[2]); sums[39] += wq * (a[0] * r[1] - a[1] * r[0]);
+      for (int c = 0; c < 3; ++c) sums[40 + c] += wq * r[c];
+      sums[43] += wq;
+    }
+    double AtA[36], Atb[6], worst_w = 0.0;
+    gn_normal_equations(sums, 1.0, 1.0, AtA, Atb, true);
+    for (int i = 0; i < 36; ++i) worst_w = std::fmax(worst_w, std::fabs(AtA[i] - AtA_ref[i]));
+    for (int i = 0; i < 6; ++i) worst_w = std::fmax(worst_w, std::fabs(Atb[i] - Atb_ref[i]));
+    std::printf("weighted normal equations vs per-pair assembly: max |difference| = %.3e\n", worst_w);
+    if (!(worst_w <= 1e-11)) ++failures;
+    gn_normal_equations(sums, 1.0, 1.0, AtA, Atb, false);      // unweighted reading: the count instead of the weight sum
+    if (std::fabs(AtA[3 * 6 + 3] - AtA_ref[3 * 6 + 3]) < 1e-6) { std::printf("the point block ignored the weight sum\n"); ++failures; }
+  }
   std::printf(failures ? "FAILED (%d)\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }
