@@ -1582,3 +1582,17 @@ def test_warm_started_iterations_find_the_same_matches(Context, orc, hip_lib):
         Tg = np.array(rg.T[:], np.float32).reshape(4, 4).T
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64)) <= TOL_T and int(rg.last_ncorr) == ro["last_ncorr"], name
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_warm_start_stress_sweep(hip_lib):
+    """tools/warm_stress.py: 168 loop comparisons (uniform and surface-like clouds, 70k-1.5M points, three metrics, one and two
+    Gauss-Newton steps, fixed and tolerance-gated iteration counts, tiled and per-lane first iterations) of the adaptive and the
+    forced warm-started forms against the loop without them: same iteration counts, same correspondence counts, same transform."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "warm_stress.py")], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
