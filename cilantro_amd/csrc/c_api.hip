@@ -1239,7 +1239,11 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           if ((unsigned int)cm >= (unsigned int)(it - 1)) break;
         }
         if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(30)) {
-          CK(c, hipStreamSynchronize(c->stream));       // (surfaces a device fault, if that is why nothing arrives)
+          // nothing for 30 s: a caller-owned stream may have long work of its own queued ahead of this run -- wait for the
+          // stream (that also surfaces a device fault); everything enqueued has then run and must have been published
+          CK(c, hipStreamSynchronize(c->stream));
+          const unsigned long long cm2 = fb->commit;
+          if ((unsigned int)(cm2 >> 32) == c->run_tag && (fb->done || (unsigned int)cm2 >= (unsigned int)(it - 1))) continue;
           return fail(c, CILHIP_ERR_HIP, "icp_run: the device stopped publishing its loop state");
         }
       }
@@ -1256,6 +1260,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           if ((unsigned int)(cm >> 32) == c->run_tag && ((unsigned int)cm >= (unsigned int)it || fb->done)) break;
           if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(30)) {
             CK(c, hipStreamSynchronize(c->stream));
+            const unsigned long long cm2 = fb->commit;
+            if ((unsigned int)(cm2 >> 32) == c->run_tag && (fb->done || (unsigned int)cm2 >= (unsigned int)it)) continue;
             return fail(c, CILHIP_ERR_HIP, "icp_run: the device stopped publishing its loop state");
           }
         }
