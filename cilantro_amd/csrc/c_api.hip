@@ -49,7 +49,8 @@ struct cilhip_ctx {
   float tile_axes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long* d_defer_mask = nullptr;  // [ntiles * 32] queries the tiles hand to the clean-up pass (bit masks, rewritten by every search)
   uint32_t* d_defer_flag = nullptr;            // [1] "some tile deferred a query" (reset before, set by, every tiled search)
-  uint32_t* d_unproven = nullptr;              // [64] queries the tiles' first stage did not prove (summed / zeroed by the epilogue)
+  uint32_t* d_unproven = nullptr;              // [128] queries the tiles' first stage did not prove / the warm-started kernel listed (summed / zeroed by the epilogue)
+  bool warm_banned = false;                    // the warm-started form was seen not to pay on this cloud pair (too few queries settled by the table)
   Feedback* h_feedback = nullptr;              // pinned, host-coherent: what the epilogue kernel publishes after every iteration (pacing, kernel form)
   Feedback* d_feedback = nullptr;              // the device's address of it
   unsigned int run_tag = 0;
@@ -165,7 +166,7 @@ int cilhip_create(cilhip_ctx** out, int device) {
   c->stream = c->own_stream;
   if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&c->d_defer_flag, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_defer_flag, 0, sizeof(uint32_t)) != hipSuccess ||
-      hipMalloc(&c->d_unproven, 64 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_unproven, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&c->d_unproven, 128 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_unproven, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(&c->h_feedback, sizeof(Feedback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_feedback), c->h_feedback, 0) != hipSuccess ||
       hipMalloc(&c->d_stage, REDUCE_STAGE_DOUBLES * sizeof(double)) != hipSuccess || hipMalloc(&c->d_sums, 3 * SUMS_MAX * sizeof(double)) != hipSuccess) {
@@ -204,6 +205,7 @@ static void free_source(cilhip_ctx* c) {
   c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
   c->have_pairs = false; c->pairs.count = 0;   // a pair list refers to the source / target it was found on
   c->far_mode = true;
+  c->warm_banned = false;
 }
 
 void cilhip_destroy(cilhip_ctx* c) {
@@ -370,6 +372,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (d_nrm) (void)hipFree(d_nrm);
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
+  c->warm_banned = false;
   if (c->d_safe2) { (void)hipFree(c->d_safe2); c->d_safe2 = nullptr; }
   CK(c, hipMalloc(&c->d_safe2, (c->grid.n ? c->grid.n : 1) * sizeof(float)));
   launch_self_nn(c->grid, c->d_safe2, c->stream);
@@ -1250,7 +1253,11 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (stop) break;
       c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
       if (c->far_mode) warm_on = false;
-      if (!c->far_mode && c->warm_start == 1 && !warm_on) {
+      // the warm-started form pays while the nearest-other-point table settles nearly every query; when an eighth of them had
+      // to be searched from the lists (a source that is not the target's points plus small noise: matches at a good fraction
+      // of the point spacing) the tiles are faster: no more warm-started iterations on this cloud pair
+      if (c->warm_start == 1 && (unsigned long long)fb->listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; warm_on = false; }
+      if (!c->far_mode && c->warm_start == 1 && !warm_on && !c->warm_banned) {
         // Candidate for the warm-started form (below): it pays once the source has (nearly) stopped moving -- the bounds it
         // searches with are the distances to the PREVIOUS matches.  Decided on the step the loop made last, so wait for
         // iteration it - 1 itself (a bubble of some tens of microseconds, only while this decision is pending): a point moves
@@ -1443,8 +1450,9 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
             if ((unsigned int)(cm >> 32) == c->run_tag && (unsigned int)cm >= (unsigned int)(c->run_calls - 1)) {
               c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
               if (c->far_mode) c->run_warm_on = false;
+              if ((unsigned long long)fb->listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; c->run_warm_on = false; }
               // (the step is the one of iteration run_calls - 2 here -- no second wait in the caller-driven protocol)
-              if (!c->far_mode && !c->run_warm_on) c->run_warm_on = warm_worthwhile(c, fb->delta, fb->prev_delta);
+              if (!c->far_mode && !c->run_warm_on && !c->warm_banned) c->run_warm_on = warm_worthwhile(c, fb->delta, fb->prev_delta);
               warm = !c->far_mode && c->run_warm_on;
               break;
             }

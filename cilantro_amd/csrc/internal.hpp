@@ -68,7 +68,7 @@ struct IcpState {
   int slab_violation;     // spatially sharded runs: some source point may have left its slab's halo since the partition (sticky)
   unsigned int unproven;  // tiled search of the last iteration: queries its first stage (the octant block) did not prove
   float prev_delta;       // delta of the iteration before the last one (INFINITY before there is one)
-  int pad1;
+  unsigned int listed;    // warm-started iteration: queries the nearest-other-point table did not settle (searched from their lists)
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -106,7 +106,8 @@ struct IterArgs {
   unsigned long long* defer_mask;  // [ntiles * 2 * (TILE_THREADS / 64)] tiled search: queries handed to its clean-up pass, one word per wave and query slot
   double* tile_partials;   // [ntiles * SUMS_MAX] tiled search with in-tile accumulation: one row of partial sums per tile (followed by the clean-up pass's rows)
   uint32_t* defer_flag;    // [1] set by a tile that defers a query: the clean-up pass has work
-  uint32_t* unproven_cnt;  // [64] (spread by tile index) queries the octant block did not prove: how far the source is from alignment
+  uint32_t* unproven_cnt;  // [128] (spread by tile / block index) [0, 64): queries the octant block did not prove (how far the source is from
+                           // alignment; the warm-started kernel: queries without a usable bound), [64, 128): queries the warm-started kernel listed
   int store_matches;       // tiled search: also write nn_pos / nn_d2 for the queries settled inside the tile (the pure ICP loop needs neither)
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
@@ -140,6 +141,8 @@ struct Feedback {
   unsigned int unproven;        // IcpState::unproven of that iteration
   float delta;                  // IcpState::delta (last_delta_norm_) of that iteration
   float prev_delta;             // ... and of the one before it
+  unsigned int listed;          // IcpState::listed of that iteration
+  unsigned int pad;
   unsigned long long commit;    // (run tag << 32) | iterations performed
 };
 
@@ -161,7 +164,7 @@ struct SolveArgs {
   // epilogue bounds how far ANY source point (global bounding box of the source, in source coordinates) can have moved
   // along the slab axis since the partition was made, and raises IcpState::slab_violation when that exceeds the slack the
   // halos were sized with -- every rank evaluates the same bound on the same values, so all take the same decision
-  uint32_t* unproven_cnt;  // [64] counters of the tiled search, summed into IcpState::unproven and zeroed by the epilogue (or null)
+  uint32_t* unproven_cnt;  // [128] counters of the search kernels, summed into IcpState::unproven / ::listed and zeroed by the epilogue (or null)
   int guard_axis;          // -1: off
   float guard_slack;
   float guard_center[3], guard_half[3];

@@ -2301,6 +2301,7 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   if (a.unproven_cnt) {
     const double tot = wave_sum((double)nfar);
     if (lane == 0 && tot > 0.0) atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)tot);
+    if (lane == 0 && qcount != 0u) atomicAdd(a.unproven_cnt + 64u + ((vb * WARM_WAVES + (uint32_t)wave) & 63u), qcount);   // listed queries: is the form paying?
   }
   double* const db = reinterpret_cast<double*>(raw + wave * FUSED_WAVE_BYTES);
 #pragma unroll
@@ -2545,12 +2546,14 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   if (a.state->done) return;
   for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(&lst)[k] = reinterpret_cast<const uint32_t*>(a.state)[k];
   __shared__ unsigned int unproven_total;
-  if (a.unproven_cnt != nullptr && a.gn_last_step && threadIdx.x < 64) {   // (once per iteration)
+  __shared__ unsigned int listed_total;
+  if (a.unproven_cnt != nullptr && a.gn_last_step && threadIdx.x < 128) {   // (once per iteration; wave 0: unproven, wave 1: listed)
     unsigned int v = a.unproven_cnt[threadIdx.x];
     a.unproven_cnt[threadIdx.x] = 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (threadIdx.x == 0) unproven_total = v;
+    if (threadIdx.x == 64) listed_total = v;
   }
   if (a.nblocks > 0) {
     reduce_partials_block(a.partials, a.nblocks, sums);
@@ -2560,7 +2563,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   __syncthreads();
   IcpState* st = &lst;
   if (threadIdx.x == 0) {
-  if (a.unproven_cnt != nullptr && a.gn_last_step) st->unproven = unproven_total;
+  if (a.unproven_cnt != nullptr && a.gn_last_step) { st->unproven = unproven_total; st->listed = listed_total; }
 
   const double n = sums[0];
   double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
@@ -2637,6 +2640,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
     a.feedback->unproven = lst.unproven;
     a.feedback->delta = lst.delta;
     a.feedback->prev_delta = lst.prev_delta;
+    a.feedback->listed = lst.listed;
     __threadfence_system();
     a.feedback->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
   }
@@ -2651,7 +2655,7 @@ struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run
 __global__ void k_init_state(IcpState* st, InitArgs ia) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (ia.fb != nullptr) {
-    ia.fb->done = 0u; ia.fb->unproven = 0u; ia.fb->delta = 0.0f; ia.fb->prev_delta = 0.0f;
+    ia.fb->done = 0u; ia.fb->unproven = 0u; ia.fb->delta = 0.0f; ia.fb->prev_delta = 0.0f; ia.fb->listed = 0u;
     __threadfence_system();
     ia.fb->commit = (unsigned long long)ia.run_tag << 32;
   }
@@ -2665,7 +2669,7 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
   st->done = 0;
   st->ncorr = 0;
   for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = 0.0;
-  st->slab_violation = 0; st->unproven = 0;
+  st->slab_violation = 0; st->unproven = 0; st->listed = 0;
   reset_inner(st);
 }
 
