@@ -17,6 +17,11 @@ rng = np.random.default_rng(3)
 src = rng.random((n, 3), dtype=np.float32)
 Ti = np.linalg.inv(d["T_true"].astype(np.float64))
 src = (src.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+# second case (argv[2] = noise in units of the point spacing): the target's points plus LARGE noise -- matches near enough for the
+# tiles' octant stage to prove them, too far for the table to settle most of them: the case the listed-query count is for
+if len(sys.argv) > 2:
+    d = syn.make_pair(n, n, with_normals=True, noise=float(sys.argv[2]))
+    src = d["src"]
 ref = None
 for warm in (0, 1, 2):
     ctx = Context(); ctx.set_option("warm_start", warm)
