@@ -322,6 +322,12 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        0 = never (per-lane global-memory search), 1 = when the cloud is large enough
  *                        to fill the chip with tiles (>= 600 tiles, ~1M points), full enough tiles and a
  *                        target density that fits a tile's LDS budget, 2 = always.
+ *   "tile_accumulation" (default 1): where the first Gauss-Newton step of an iteration is accumulated when the tiled search runs
+ *                        without post-filters: 0 = always in a separate streaming pass, 1 = inside the LDS tiles (one pass per
+ *                        iteration) unless the device reports the source far from alignment, 2 = always inside the tiles.
+ *   "warm_start" (default 1): the warm-started iteration kernel (cilhip_get_last_warm_iterations): 0 = never, 1 = when the loop
+ *                        has nearly stopped moving and the form pays on this cloud pair, 2 = from the second iteration on.
+ *                        Neither option changes a result beyond the order of f64 additions.
  *   "cell_occupancy" (default 1): target points per grid cell, used by the next cilhip_set_target.
  *   "kernel_timing": same as cilhip_enable_kernel_timing.
  * Engine post-filters (correspondence_search_kd_tree.hpp:224-225, setInlierFraction / setOneToOne :253-271):

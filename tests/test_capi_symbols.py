@@ -66,3 +66,15 @@ def test_product_never_imports_the_oracle():
 
     deps = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in deps and "nanoflann" not in deps
+
+
+def test_every_option_key_is_documented_in_the_header():
+    """cilhip_set_option's keys (cilantro_amd/csrc/c_api.hip) all appear, quoted, in include/cilantro_hip/c_api.h"""
+    import re
+
+    src = open(os.path.join(ROOT, "cilantro_amd", "csrc", "c_api.hip")).read()
+    hdr = open(os.path.join(ROOT, "include", "cilantro_hip", "c_api.h")).read()
+    keys = sorted(set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', src)))
+    assert len(keys) >= 15
+    missing = [k for k in keys if '"%s"' % k not in hdr]
+    assert not missing, missing
