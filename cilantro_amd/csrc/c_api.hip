@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.hpp"
@@ -80,6 +81,12 @@ struct cilhip_ctx {
   float cw_point_sigma = 1.0f, cw_plane_sigma = 1.0f;
   bool have_nn = false;           // nn_pos/nn_d2 hold the result of a search
   float nn_T[16];                 // transform used by that search
+  // after cilhip_icp_run the engine's correspondence set is the last executed iteration's (correspondence_search_kd_tree.hpp:231 through
+  // icp_base.hpp:32-38): either the loop's kernels left it in nn_pos (have_nn, origin 1) or it is searched again on demand under
+  // nn_T = the transform that iteration searched under (pending_matches, origin 2) -- the search is exact, so it is the same set
+  bool pending_matches = false;
+  float pending_max_sq = 0.0f;
+  int matches_origin = 0;         // cilhip_get_last_matches_origin
 
   // loop state / scratch
   IcpState* d_state = nullptr;
@@ -148,6 +155,9 @@ static int fail(cilhip_ctx* c, int code, const char* msg) {
 
 static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
+// the stored correspondence set (matches or pair list) no longer describes anything a caller may read
+static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->pending_matches = false; c->matches_origin = 0; }
+
 extern "C" {
 
 int cilhip_create(cilhip_ctx** out, int device) {
@@ -202,7 +212,7 @@ static void free_source(cilhip_ctx* c) {
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }
   if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
-  c->has_source = false; c->src_sorted = false; c->have_nn = false; c->ns = 0;
+  c->has_source = false; c->src_sorted = false; drop_matches(c); c->ns = 0;
   c->have_pairs = false; c->pairs.count = 0;   // a pair list refers to the source / target it was found on
   c->far_mode = true;
   c->warm_banned = false;
@@ -275,12 +285,12 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "tile_accumulation")) { c->tile_acc = value != 0.0; c->tile_acc_adaptive = value != 2.0; return CILHIP_OK; }
   if (!strcmp(key, "search_direction")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "search_direction: 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH");
-    c->search_dir = (int)value; c->have_nn = false; c->have_pairs = false;
+    c->search_dir = (int)value; drop_matches(c); c->have_pairs = false;
     return CILHIP_OK;
   }
   if (!strcmp(key, "feature_normal_weight")) {
     if (!(value >= 0.0)) return fail(c, CILHIP_ERR_INVALID, "feature_normal_weight: >= 0 (0 = plain point features)");
-    c->normal_weight = (float)value; c->have_nn = false; c->have_pairs = false;
+    c->normal_weight = (float)value; drop_matches(c); c->have_pairs = false;
     return CILHIP_OK;
   }
   if (!strcmp(key, "symmetric_metric")) { c->symmetric = value != 0.0; return CILHIP_OK; }
@@ -289,7 +299,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
     c->transform_mode = (int)value;
     return CILHIP_OK;
   }
-  if (!strcmp(key, "require_reciprocality")) { c->reciprocal = value != 0.0; c->have_nn = false; c->have_pairs = false; return CILHIP_OK; }
+  if (!strcmp(key, "require_reciprocality")) { c->reciprocal = value != 0.0; drop_matches(c); c->have_pairs = false; return CILHIP_OK; }
   if (!strcmp(key, "cell_occupancy")) { c->cell_occupancy = value; return CILHIP_OK; }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
@@ -373,14 +383,12 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
   c->warm_banned = false;
-  if (c->d_safe2) { (void)hipFree(c->d_safe2); c->d_safe2 = nullptr; }
-  CK(c, hipMalloc(&c->d_safe2, (c->grid.n ? c->grid.n : 1) * sizeof(float)));
-  launch_self_nn(c->grid, c->d_safe2, c->stream);
+  if (c->d_safe2) { (void)hipFree(c->d_safe2); c->d_safe2 = nullptr; }      // (rebuilt by the first run that can use it: ensure_safe2)
   c->has_normals = (nrm != nullptr);
   for (int i = 0; i < 3; ++i) c->dst_mean[i] = (float)mean[i];
   c->has_target = true;
   c->src_sorted = false;  // source order is tied to the target grid
-  c->have_nn = false;
+  drop_matches(c);
   c->have_pairs = false; c->pairs.count = 0;
   c->far_mode = true;
   c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -425,7 +433,7 @@ int cilhip_set_source_normals(cilhip_ctx* c, const float* nrm, int mem) {
   if (rc) return rc;
   CK(c, hipMalloc(&c->d_src_nrm_sorted, (c->ns ? c->ns : 1) * sizeof(float4)));
   c->src_sorted = false;                                   // the sorted copy is (re)built with the next sort
-  c->have_nn = false;
+  drop_matches(c);
   c->have_pairs = false; c->pairs.count = 0;
   return CILHIP_OK;
 }
@@ -481,7 +489,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
-    c->have_nn = false;
+    drop_matches(c);
   }
   return CILHIP_OK;
 }
@@ -563,6 +571,13 @@ static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params*
 // sparser than the target: BASELINE configs[3]).
 static bool warm_capable(const cilhip_ctx* c) {
   return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+}
+// k_self_nn's nearest-other-point table (4 B per target point, 0.5 ms at 10M): built by the first warm-capable run on a target
+static int ensure_safe2(cilhip_ctx* c) {
+  if (c->d_safe2) return CILHIP_OK;
+  CK(c, hipMalloc(&c->d_safe2, (c->grid.n ? c->grid.n : 1) * sizeof(float)));
+  launch_self_nn(c->grid, c->d_safe2, c->stream);
+  return CILHIP_OK;
 }
 static bool tile_accumulation(const cilhip_ctx* c) {
   return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
@@ -685,8 +700,9 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
     rc = run_pair_search(c, a, max_sq, T);
     if (rc) return rc;
     memcpy(c->nn_T, T, sizeof(c->nn_T));
-    c->have_nn = false;
+    drop_matches(c);
     c->have_pairs = true;
+    c->matches_origin = 3;
     if (n_found) *n_found = c->pairs.count;
     return CILHIP_OK;
   }
@@ -699,7 +715,9 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   rc = apply_filters(c);
   if (rc) return rc;
   memcpy(c->nn_T, T, sizeof(c->nn_T));
+  c->pending_matches = false;
   c->have_nn = true;
+  c->matches_origin = 3;
   if (n_found) {
     unsigned long long cnt = 0;
     launch_count_found(c->d_nn_pos, c->ns, c->d_count, c->stream);
@@ -719,8 +737,36 @@ static int scatter_to_original(cilhip_ctx* c) {
   return CILHIP_OK;
 }
 
+// The correspondence set of the last executed iteration of cilhip_icp_run, when the loop's kernels did not leave it in memory
+// (post-filters, pair-list directions, feature search, forms that store no matches): searched again under the transform that
+// iteration searched under.  The search is exact and deterministic: the same set.
+static int materialize_pending(cilhip_ctx* c) {
+  if (!c->pending_matches) return CILHIP_OK;
+  float T[16];
+  memcpy(T, c->nn_T, sizeof(T));
+  const float r = c->pending_max_sq;
+  c->pending_matches = false;
+  const int rc = cilhip_find_correspondences(c, T, r, nullptr);
+  if (rc == CILHIP_OK) c->matches_origin = 2;
+  return rc;
+}
+
+int cilhip_get_last_matches_origin(cilhip_ctx* c, int* origin) {
+  if (!c || !origin) return CILHIP_ERR_INVALID;
+  *origin = c->matches_origin;
+  return CILHIP_OK;
+}
+
+int cilhip_get_matches_transform(cilhip_ctx* c, float T[16]) {
+  if (!c || !T) return CILHIP_ERR_INVALID;
+  if (!c->have_nn && !c->have_pairs && !c->pending_matches) return fail(c, CILHIP_ERR_INVALID, "get_matches_transform: no search has been run");
+  memcpy(T, c->nn_T, sizeof(c->nn_T));
+  return CILHIP_OK;
+}
+
 int cilhip_get_nn(cilhip_ctx* c, uint32_t* nn_idx, float* nn_d2, int mem) {
   if (!c) return CILHIP_ERR_INVALID;
+  { const int prc = materialize_pending(c); if (prc) return prc; }
   if (c->have_pairs) return fail(c, CILHIP_ERR_UNSUPPORTED, "get_nn: the last search ran in a direction whose result is a pair list; use get_correspondences");
   if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "get_nn: no search has been run");
   CK(c, hipSetDevice(c->device));
@@ -735,6 +781,7 @@ int cilhip_get_nn(cilhip_ctx* c, uint32_t* nn_idx, float* nn_d2, int mem) {
 
 int cilhip_get_correspondences(cilhip_ctx* c, uint64_t* i1, uint64_t* i2, float* val, size_t cap, size_t* n_out) {
   if (!c || !n_out) return CILHIP_ERR_INVALID;
+  { const int prc = materialize_pending(c); if (prc) return prc; }
   if (c->have_pairs) {
     // pair list of FIRST_TO_SECOND / BOTH: stored ascending (first, second); the reference leaves the set sorted by
     // value after the fraction filter (correspondence.hpp:61) and by (indexInSecond, value) after the FIRST_TO_SECOND
@@ -829,6 +876,7 @@ static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], 
 
 int cilhip_estimate_point_to_point(cilhip_ctx* c, float dT[16], double* sums_out, int* ok) {
   if (!c || !dT) return CILHIP_ERR_INVALID;
+  { const int prc = materialize_pending(c); if (prc) return prc; }
   if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
   CK(c, hipSetDevice(c->device));
   double sums[SUMS_MAX];
@@ -845,6 +893,7 @@ int cilhip_estimate_point_to_point(cilhip_ctx* c, float dT[16], double* sums_out
 int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t max_iter, float conv_tol, float dT[16],
                              double* AtA_out, double* Atb_out, int* converged) {
   if (!c || !dT) return CILHIP_ERR_INVALID;
+  { const int prc = materialize_pending(c); if (prc) return prc; }
   if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
   CK(c, hipSetDevice(c->device));
   double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
@@ -923,6 +972,7 @@ static int affine_accumulate(cilhip_ctx* c, bool centered, bool plane, double su
 int cilhip_estimate_affine(cilhip_ctx* c, float w_p2p, float w_p2pl, int centered, float dT[16], double* AtA_out,
                            double* Atb_out, size_t* n_corr, int* ok) {
   if (!c || !dT) return CILHIP_ERR_INVALID;
+  { const int prc = materialize_pending(c); if (prc) return prc; }
   if (!c->have_nn && !c->have_pairs) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
   CK(c, hipSetDevice(c->device));
   memcpy(dT, kIdentity, sizeof(kIdentity));
@@ -995,7 +1045,8 @@ static int icp_run_affine(cilhip_ctx* c, const cilhip_icp_params* p, const float
   out->iterations = it;
   out->last_delta_norm = delta;
   out->last_ncorr = ncorr;
-  c->have_nn = false; c->have_pairs = false;
+  // (the last iteration's cilhip_find_correspondences left the set it estimated from: what getCorrespondences() returns)
+  if (it == 0) { drop_matches(c); c->have_pairs = false; } else c->matches_origin = 1;
   float ms = 0.f;
   CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
   c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
@@ -1058,15 +1109,74 @@ static hipEvent_t get_event(cilhip_ctx* c, size_t i) {
   return c->ev[i];
 }
 
-static int read_state(cilhip_ctx* c, cilhip_icp_result* out) {
+// What the run's epilogues have published (Feedback): a consistent snapshot of the LATEST published iteration.
+struct FbView { bool done; unsigned int iterations, unproven, listed; float delta, prev_delta; };
+static inline void cpu_relax(unsigned spins) {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+  if ((spins & 255u) == 255u) std::this_thread::yield();      // (the device publishes within tens of microseconds: rarely reached)
+}
+// Waits until iteration `need` of the current run (or its convergence) has been published.  patience_s: how long to spin;
+// returns 0 and fills *v, or 1 when nothing came in that time.
+static int wait_published(cilhip_ctx* c, unsigned int need, double patience_s, FbView* v) {
+  const volatile Feedback* fb = c->h_feedback;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const unsigned long long lt = fb->latest;
+    if ((unsigned int)(lt >> 32) == c->run_tag) {
+      const bool done = (lt & 0x80000000ull) != 0ull;
+      const unsigned int iters = (unsigned int)lt & 0x7fffffffu;
+      if (done || iters >= need) {
+        // the slot of the latest published iteration: the device's next write goes to another slot (the host is at most two
+        // iterations ahead), so this read cannot be torn; its commit word is checked all the same
+        const volatile FeedbackSlot* sl = &fb->slot[iters & 3u];
+        v->done = done; v->iterations = iters;
+        v->unproven = sl->unproven; v->listed = sl->listed; v->delta = sl->delta; v->prev_delta = sl->prev_delta;
+        if (iters == 0u || sl->commit == (((unsigned long long)c->run_tag << 32) | iters)) return 0;
+      }
+    }
+    cpu_relax(spins);
+    if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > patience_s) return 1;
+  }
+}
+// ... with the long-stall handling of cilhip_icp_run: nothing for 30 s -- a caller-owned stream may have long work of its own
+// queued ahead of this run -- wait for the stream (that also surfaces a device fault); everything enqueued has then run and
+// must have been published
+static int wait_published_or_sync(cilhip_ctx* c, unsigned int need, FbView* v) {
+  if (wait_published(c, need, 30.0, v) == 0) return CILHIP_OK;
+  CK(c, hipStreamSynchronize(c->stream));
+  if (wait_published(c, need, 0.01, v) == 0) return CILHIP_OK;
+  return fail(c, CILHIP_ERR_HIP, "icp_run: the device stopped publishing its loop state");
+}
+
+static int read_state(cilhip_ctx* c, cilhip_icp_result* out, float* Tprev = nullptr) {
   IcpState hs;
   CK(c, hipMemcpyAsync(&hs, c->d_state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
   CK(c, hipStreamSynchronize(c->stream));
   memcpy(out->T, hs.T, sizeof(hs.T));
+  if (Tprev) memcpy(Tprev, hs.Tprev, sizeof(hs.Tprev));
   out->iterations = (size_t)hs.iterations;
   out->last_delta_norm = hs.delta;
   out->last_ncorr = (size_t)hs.ncorr;
   return CILHIP_OK;
+}
+
+// What the engine's getCorrespondences() refers to after a run: the set of the last executed iteration, found under Tprev
+// (correspondence_search_kd_tree.hpp:231 keeps it; icp_base.hpp:32-38 hands the engine out).  stored: the loop's kernels left
+// it in nn_pos (the squared distances are formed again with the search's pinned arithmetic); pairs: c->pairs holds it;
+// otherwise it is searched again when somebody asks (materialize_pending).
+static void finish_run_matches(cilhip_ctx* c, const cilhip_icp_params* p, size_t iterations, const float Tprev[16], bool stored, bool pairs) {
+  drop_matches(c); c->have_pairs = false;
+  if (iterations == 0) return;
+  memcpy(c->nn_T, Tprev, sizeof(c->nn_T));
+  if (pairs) { c->have_pairs = true; c->matches_origin = 1; return; }
+  if (stored && c->ns) {
+    launch_fill_d2(c->d_src_sorted, c->grid.pts, c->d_nn_pos, Tprev, c->ns, c->d_nn_d2, c->stream);
+    c->have_nn = true; c->matches_origin = 1;
+  } else {
+    c->pending_matches = true; c->pending_max_sq = p->max_sq_dist; c->matches_origin = 2;
+  }
 }
 
 int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, cilhip_icp_result* out) {
@@ -1101,6 +1211,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // source, like the reference's per-iteration kd-tree); host-driven loop, the accumulation kernels stream over the pairs
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
     if (gn && opt_steps == 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "max_opt_iter == 0 is not supported");
+    if (feat6(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for SECOND_TO_FIRST only");
     hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
     CK(c, hipEventRecord(e_beg, c->stream));
     // Without post-filters the loop needs the SUMS over the correspondence set, not the sorted list: the reverse matches are
@@ -1155,9 +1266,10 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       }
       CK(c, hipEventRecord(e_end, c->stream));
       CK(c, hipGetLastError());
-      rc = read_state(c, out);
+      float Tprev[16];
+      rc = read_state(c, out, Tprev);
       if (rc) return rc;
-      c->have_nn = false; c->have_pairs = false;
+      finish_run_matches(c, p, out->iterations, Tprev, false, false);      // (nothing was listed: searched again on demand)
       float ms = 0.f;
       CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
       c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
@@ -1199,9 +1311,10 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     }
     CK(c, hipEventRecord(e_end, c->stream));
     CK(c, hipGetLastError());
-    rc = read_state(c, out);
+    float Tprev[16];
+    rc = read_state(c, out, Tprev);
     if (rc) return rc;
-    c->have_nn = false; c->have_pairs = false;
+    finish_run_matches(c, p, out->iterations, Tprev, false, out->iterations > 0);      // c->pairs: the last iteration's list
     float ms = 0.f;
     CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
     c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
@@ -1222,6 +1335,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   // alignment: first iterations of a registration) the search runs with its in-LDS 3x3x3 second pass and a separate
   // streaming accumulation; once nearly all are proven, search + accumulation run as one pass inside the tiles.
   const bool wcap = warm_capable(c);
+  if (wcap) { rc = ensure_safe2(c); if (rc) return rc; }
   const bool paced = (tile_acc || wcap) && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
   if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
@@ -1229,51 +1343,29 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   c->iter_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   bool warm_on = false;       // the loop has been seen to (nearly) stand still: iterations run warm-started until it is seen far again
+  bool all_stored = true;     // every iteration enqueued left its matches in nn_pos (finish_run_matches)
   for (size_t it = 0; it < p->max_iter; ++it) {
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
-      volatile Feedback* fb = c->h_feedback;
-      const auto t_wait = std::chrono::steady_clock::now();
-      bool stop = false;
-      for (unsigned spins = 0;; ++spins) {
-        const unsigned long long cm = fb->commit;
-        if ((unsigned int)(cm >> 32) == c->run_tag) {
-          if (fb->done) { stop = true; break; }
-          if ((unsigned int)cm >= (unsigned int)(it - 1)) break;
-        }
-        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(30)) {
-          // nothing for 30 s: a caller-owned stream may have long work of its own queued ahead of this run -- wait for the
-          // stream (that also surfaces a device fault); everything enqueued has then run and must have been published
-          CK(c, hipStreamSynchronize(c->stream));
-          const unsigned long long cm2 = fb->commit;
-          if ((unsigned int)(cm2 >> 32) == c->run_tag && (fb->done || (unsigned int)cm2 >= (unsigned int)(it - 1))) continue;
-          return fail(c, CILHIP_ERR_HIP, "icp_run: the device stopped publishing its loop state");
-        }
-      }
-      if (stop) break;
-      c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
+      FbView fv;
+      rc = wait_published_or_sync(c, (unsigned int)(it - 1), &fv);
+      if (rc) return rc;
+      if (fv.done) break;
+      c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
       if (c->far_mode) warm_on = false;
       // the warm-started form pays while the nearest-other-point table settles nearly every query; when an eighth of them had
       // to be searched from the lists (a source that is not the target's points plus small noise: matches at a good fraction
       // of the point spacing) the tiles are faster: no more warm-started iterations on this cloud pair
-      if (c->warm_start == 1 && (unsigned long long)fb->listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; warm_on = false; }
+      if (c->warm_start == 1 && (unsigned long long)fv.listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; warm_on = false; }
       if (!c->far_mode && c->warm_start == 1 && !warm_on && !c->warm_banned) {
         // Candidate for the warm-started form (below): it pays once the source has (nearly) stopped moving -- the bounds it
         // searches with are the distances to the PREVIOUS matches.  Decided on the step the loop made last, so wait for
         // iteration it - 1 itself (a bubble of some tens of microseconds, only while this decision is pending): a point moves
         // by at most delta * (1 + |x|) per iteration.
-        for (unsigned spins = 0;; ++spins) {
-          const unsigned long long cm = fb->commit;
-          if ((unsigned int)(cm >> 32) == c->run_tag && ((unsigned int)cm >= (unsigned int)it || fb->done)) break;
-          if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(30)) {
-            CK(c, hipStreamSynchronize(c->stream));
-            const unsigned long long cm2 = fb->commit;
-            if ((unsigned int)(cm2 >> 32) == c->run_tag && (fb->done || (unsigned int)cm2 >= (unsigned int)it)) continue;
-            return fail(c, CILHIP_ERR_HIP, "icp_run: the device stopped publishing its loop state");
-          }
-        }
-        if (fb->done) break;
-        warm_on = warm_worthwhile(c, fb->delta, fb->prev_delta);
+        rc = wait_published_or_sync(c, (unsigned int)it, &fv);
+        if (rc) return rc;
+        if (fv.done) break;
+        warm_on = warm_worthwhile(c, fv.delta, fv.prev_delta);
       }
     }
     const bool one_pass = tile_acc && !c->far_mode;
@@ -1297,6 +1389,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (c->ns) {
         if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
+          all_stored = all_stored && gn && opt_steps > 1;
         } else if (st == 0 && warm) {
           IterArgs wa = a;
           wa.warm_pos = c->d_nn_pos;
@@ -1319,6 +1412,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           fa.store_matches = (opt_steps > 1 || c->warm_start) ? 1 : 0;
           fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
           launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+          all_stored = all_stored && fa.store_matches != 0;
         } else if (st == 0) {
           c->rec_valid = false;
           { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
@@ -1361,9 +1455,10 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   }
   CK(c, hipEventRecord(e_end, c->stream));
   CK(c, hipGetLastError());
-  rc = read_state(c, out);
+  float Tprev[16];
+  rc = read_state(c, out, Tprev);
   if (rc) return rc;
-  c->have_nn = false;
+  finish_run_matches(c, p, out->iterations, Tprev, all_stored && !filters_active(c) && !feat6(c), false);
   float ms = 0.f;
   CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
 #ifdef CILHIP_EXP_PHASE_CLOCKS
@@ -1411,6 +1506,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   c->run_calls = 0;
   c->run_warm_on = false;
   c->rec_valid = false;
+  if (warm_capable(c)) { rc = ensure_safe2(c); if (rc) return rc; }
   c->iter_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
@@ -1435,28 +1531,23 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
       const size_t e = 2 + c->run_nev;
       if (timing) CK(c, hipEventRecord(get_event(c, e), c->stream));
       // Warm-started form (see cilhip_icp_run): from the second call on, when the latest loop state this run's epilogues have
-      // published (a look, never a wait) says the source is near alignment.  Ranks may differ in their choice: the sums are
+      // published (a bounded wait for iteration run_calls - 2) says the source is near alignment.  Ranks may differ in their choice: the sums are
       // the same up to the order of the f64 additions.
       bool warm = false;
       if (warm_capable(c) && c->run_calls >= 1) {
         warm = c->warm_start == 2;
         if (!warm && c->run_calls >= 2) {
           // paced like cilhip_icp_run: at most two iterations ahead of the device (which never waits: an iteration takes
-          // hundreds of microseconds), so that the loop state looked at is that of iteration run_calls - 2
-          const volatile Feedback* fb = c->h_feedback;
-          const auto t_wait = std::chrono::steady_clock::now();
-          for (unsigned spins = 0;; ++spins) {
-            const unsigned long long cm = fb->commit;
-            if ((unsigned int)(cm >> 32) == c->run_tag && (unsigned int)cm >= (unsigned int)(c->run_calls - 1)) {
-              c->far_mode = (unsigned long long)fb->unproven * 16ull > (unsigned long long)c->ns;
-              if (c->far_mode) c->run_warm_on = false;
-              if ((unsigned long long)fb->listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; c->run_warm_on = false; }
-              // (the step is the one of iteration run_calls - 2 here -- no second wait in the caller-driven protocol)
-              if (!c->far_mode && !c->run_warm_on && !c->warm_banned) c->run_warm_on = warm_worthwhile(c, fb->delta, fb->prev_delta);
-              warm = !c->far_mode && c->run_warm_on;
-              break;
-            }
-            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) break;   // (no news: the tiled form)
+          // hundreds of microseconds), so that the loop state looked at is at least that of iteration run_calls - 2; a brief
+          // wait at most (5 s without news: the tiled form)
+          FbView fv;
+          if (wait_published(c, (unsigned int)(c->run_calls - 1), 5.0, &fv) == 0) {
+            c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
+            if (c->far_mode) c->run_warm_on = false;
+            if ((unsigned long long)fv.listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; c->run_warm_on = false; }
+            // (the step is the one of iteration run_calls - 2 here -- no second wait in the caller-driven protocol)
+            if (!c->far_mode && !c->run_warm_on && !c->warm_banned) c->run_warm_on = warm_worthwhile(c, fv.delta, fv.prev_delta);
+            warm = !c->far_mode && c->run_warm_on;
           }
         }
       }
@@ -1487,6 +1578,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         prows = tiled_partial_rows(c->ntiles);
         ++c->last_fused_iters;
       } else {
+        c->rec_valid = false;
         if (timing) c->iter_form.push_back((unsigned char)FORM_SEARCH);
         ++c->last_two_pass_iters;
         if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);

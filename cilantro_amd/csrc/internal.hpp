@@ -69,6 +69,8 @@ struct IcpState {
   unsigned int unproven;  // tiled search of the last iteration: queries its first stage (the octant block) did not prove
   float prev_delta;       // delta of the iteration before the last one (INFINITY before there is one)
   unsigned int listed;    // warm-started iteration: queries the nearest-other-point table did not settle (searched from their lists)
+  float Tprev[16];        // transform_ BEFORE the last update = the transform the last executed iteration searched under: what the
+                          // engine's correspondence set refers to after estimate() (correspondence_search_kd_tree.hpp:231)
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -135,15 +137,19 @@ struct BoxArgs {
 };
 
 // Loop state the device publishes to the host after every iteration (pinned, host-coherent memory the epilogue kernel
-// writes directly: no copy engine, no event): payload first, then -- after a system-scope fence -- the commit word.
-struct Feedback {
-  unsigned int done;            // converged
+// writes directly: no copy engine, no event).  Iteration k goes to slot k % 4, then -- after a system-scope fence -- the
+// `latest` word: the host is never more than two iterations ahead of the device, so the slot it reads (the latest published
+// one) cannot be the one the device is writing -- a snapshot is never torn.
+struct FeedbackSlot {
   unsigned int unproven;        // IcpState::unproven of that iteration
+  unsigned int listed;          // IcpState::listed of that iteration
   float delta;                  // IcpState::delta (last_delta_norm_) of that iteration
   float prev_delta;             // ... and of the one before it
-  unsigned int listed;          // IcpState::listed of that iteration
-  unsigned int pad;
-  unsigned long long commit;    // (run tag << 32) | iterations performed
+  unsigned long long commit;    // (run tag << 32) | iterations performed: sanity check of the slot
+};
+struct Feedback {
+  FeedbackSlot slot[4];
+  unsigned long long latest;    // (run tag << 32) | (converged ? 1u << 31 : 0) | iterations performed
 };
 
 struct SolveArgs {
@@ -204,6 +210,9 @@ void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys
                         uint32_t index_offset, uint32_t n_local, uint32_t* nn_pos, float* nn_d2, hipStream_t s);
 void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s);
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
+// squared distances of the stored matches under T, formed again with the search's pinned arithmetic (bit-identical to what the
+// search compared): the ICP loop does not store them, a caller of getCorrespondences() after estimate() reads them
+void launch_fill_d2(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos, const float T[16], uint32_t ns, float* nn_d2, hipStream_t s);
 void launch_residuals(const IterArgs& a, int metric, float w_p2p, float w_p2pl, float* out, hipStream_t s);
 int iter_num_blocks(uint32_t ns);
 // accumulation over reverse matches (FIRST_TO_SECOND / BOTH loops without post-filters): element i = target sorted position i,

@@ -2610,7 +2610,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   if (finalize) {
     float Tn[16];
     const float delta = compose_update(L, t, st->T, Tn);
-    for (int i = 0; i < 16; ++i) st->T[i] = Tn[i];
+    for (int i = 0; i < 16; ++i) { st->Tprev[i] = st->T[i]; st->T[i] = Tn[i]; }
     float mx, my, mz;
     transform_point(Tn, a.src_mean[0], a.src_mean[1], a.src_mean[2], mx, my, mz);
     st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
@@ -2636,13 +2636,14 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   __syncthreads();
   for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(a.state)[k] = reinterpret_cast<const uint32_t*>(&lst)[k];
   if (a.feedback != nullptr && a.gn_last_step && threadIdx.x == 0) {
-    a.feedback->done = (unsigned int)lst.done;
-    a.feedback->unproven = lst.unproven;
-    a.feedback->delta = lst.delta;
-    a.feedback->prev_delta = lst.prev_delta;
-    a.feedback->listed = lst.listed;
+    FeedbackSlot* sl = &a.feedback->slot[(unsigned int)lst.iterations & 3u];
+    sl->unproven = lst.unproven;
+    sl->listed = lst.listed;
+    sl->delta = lst.delta;
+    sl->prev_delta = lst.prev_delta;
+    sl->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
     __threadfence_system();
-    a.feedback->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
+    a.feedback->latest = ((unsigned long long)a.run_tag << 32) | (lst.done ? 0x80000000ull : 0ull) | (unsigned long long)((unsigned int)lst.iterations & 0x7fffffffu);
   }
 }
 
@@ -2655,11 +2656,11 @@ struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run
 __global__ void k_init_state(IcpState* st, InitArgs ia) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (ia.fb != nullptr) {
-    ia.fb->done = 0u; ia.fb->unproven = 0u; ia.fb->delta = 0.0f; ia.fb->prev_delta = 0.0f; ia.fb->listed = 0u;
+    for (int k = 0; k < 4; ++k) { ia.fb->slot[k].unproven = 0u; ia.fb->slot[k].listed = 0u; ia.fb->slot[k].delta = 0.0f; ia.fb->slot[k].prev_delta = 0.0f; ia.fb->slot[k].commit = 0ull; }
     __threadfence_system();
-    ia.fb->commit = (unsigned long long)ia.run_tag << 32;
+    ia.fb->latest = (unsigned long long)ia.run_tag << 32;
   }
-  for (int i = 0; i < 16; ++i) st->T[i] = ia.T[i];
+  for (int i = 0; i < 16; ++i) st->T[i] = st->Tprev[i] = ia.T[i];
   float mx, my, mz;
   transform_point(ia.T, ia.src_mean[0], ia.src_mean[1], ia.src_mean[2], mx, my, mz);
   st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
@@ -2775,6 +2776,28 @@ void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys
 }
 void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_inv_perm, dim3(blocks_for(n)), dim3(256), 0, s, dst_sorted, n, inv);
+}
+
+struct T16 { float v[16]; };
+__global__ void k_fill_d2(const float4* __restrict__ src_sorted, const float4* __restrict__ dst_sorted, const uint32_t* __restrict__ nn_pos, T16 T, uint32_t ns,
+                          float* __restrict__ nn_d2) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t pos = nn_pos[i];
+    float e = 0.0f;
+    if (pos != NONE_U32) {
+      const float4 s4 = src_sorted[i], p = dst_sorted[pos];
+      float qx, qy, qz;
+      transform_point(T.v, s4.x, s4.y, s4.z, qx, qy, qz);
+      e = d2_pinned(qx, qy, qz, p.x, p.y, p.z);
+    }
+    nn_d2[i] = e;
+  }
+}
+void launch_fill_d2(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos, const float T[16], uint32_t ns, float* nn_d2, hipStream_t s) {
+  if (ns == 0) return;
+  T16 t;
+  for (int i = 0; i < 16; ++i) t.v[i] = T[i];
+  hipLaunchKernelGGL(k_fill_d2, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, dst_sorted, nn_pos, t, ns, nn_d2);
 }
 
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s) {

@@ -285,6 +285,19 @@ class Context:
         self._ck(self._L.cilhip_get_last_warm_iterations(self._h, C.byref(a)))
         return a.value
 
+    def last_matches_origin(self):
+        """where get_nn / get_correspondences read from: 0 none, 3 find_correspondences, 1 kept by the last icp_run's kernels,
+        2 searched again on demand under the last iteration's transform"""
+        a = C.c_int(0)
+        self._ck(self._L.cilhip_get_last_matches_origin(self._h, C.byref(a)))
+        return a.value
+
+    def matches_transform(self):
+        """the 4x4 transform the current correspondence set was found under (after icp_run: transform_ before the last update)"""
+        T = np.zeros(16, np.float32)
+        self._ck(self._L.cilhip_get_matches_transform(self._h, T.ctypes.data))
+        return _T_from_abi(T)
+
     def last_timing2(self):
         a = C.c_double(0); b = C.c_double(0)
         self._ck(self._L.cilhip_get_last_timing2(self._h, C.byref(a), C.byref(b)))
@@ -449,6 +462,7 @@ class _IterativeClosestPointBase:
         if conv_tol is not None:
             self.convergence_tol_ = np.float32(conv_tol)
         res = self._ctx.icp_run(self._params(), self.transform_init_)
+        self._engine._corr = None      # the engine now holds the last iteration's set (correspondence_search_kd_tree.hpp:231)
         self.transform_ = _T_from_abi(res.T[:])
         self.iterations_ = int(res.iterations)
         self.last_delta_norm_ = np.float32(res.last_delta_norm)

@@ -101,8 +101,23 @@ int cilhip_get_means(cilhip_ctx* ctx, float dst_mean[3], float src_mean[3]);
 int cilhip_find_correspondences(cilhip_ctx* ctx, const float T[16], float max_sq_dist,
                                 size_t* n_found_or_null);
 /* Per-source raw result of the last search, in ORIGINAL source order: nn_idx[i] = dst index or
- * 0xFFFFFFFF (none), nn_d2[i] = squared distance (undefined when none).  Either may be NULL. */
+ * 0xFFFFFFFF (none), nn_d2[i] = squared distance (undefined when none).  Either may be NULL.
+ * "The last search" includes the one of the last executed iteration of cilhip_icp_run: like the reference's engine, which
+ * keeps `correspondences_` of its last findCorrespondences call (correspondence_search_kd_tree.hpp:231; the ICP object hands
+ * the engine out, registration/icp_base.hpp:32-38), the context answers cilhip_get_nn / cilhip_get_correspondences /
+ * cilhip_estimate_* after a run with that iteration's set (found under the transform BEFORE the last update). */
 int cilhip_get_nn(cilhip_ctx* ctx, uint32_t* nn_idx, float* nn_d2, int mem);
+/* Where the set those calls return comes from: 0 = there is none, 3 = a cilhip_find_correspondences call, 1 = left in device
+ * memory by the kernels of the last cilhip_icp_run iteration (the squared distances formed again with the search's pinned
+ * arithmetic), 2 = searched again on demand under that iteration's transform (loops whose kernels keep no per-query matches:
+ * post-filters, pair-list directions, the feature search, options "fused" / "warm_start" = 0).  The search is exact, so 1 and
+ * 2 are the same set; tests use the value to know WHICH kernel's matches they are comparing. */
+int cilhip_get_last_matches_origin(cilhip_ctx* ctx, int* origin);
+/* The transform (col-major 4x4) the current correspondence set was found under: the argument of the last
+ * cilhip_find_correspondences, or -- after cilhip_icp_run -- transform_ as it was BEFORE the last iteration's update, the
+ * tform the reference's loop handed its last engine.findCorrespondences(transform_) call
+ * (registration/icp_single_transform_combined_metric.hpp:170). */
+int cilhip_get_matches_transform(cilhip_ctx* ctx, float T[16]);
 /* The reference's SearchResult: CorrespondenceSet<float,size_t> compacted in ascending source
  * index order (correspondence_search_kd_tree_utilities.hpp:45-50; core/correspondence.hpp:9-55),
  * as three host arrays of capacity `cap` (>= n_found): indexInFirst, indexInSecond, value. */

@@ -162,6 +162,7 @@ public:
     return correspondences_;
   }
 
+  void invalidateFetched() { fetched_ = false; }      // (extension: the ICP loop replaced the context's correspondence set)
   const CorrespondenceSearchDirection& getSearchDirection() const { return search_dir_; }
   // correspondence_search_kd_tree.hpp:239-247.  FIRST_TO_SECOND / BOTH rebuild an index over the transformed source every
   // search (as the reference rebuilds its kd-tree) and hand the estimators a pair list.
@@ -265,6 +266,7 @@ public:
     p.max_sq_dist = engine_.getMaxDistance();
     cilhip_icp_result r;
     internal::check(ctx_.get(), cilhip_icp_run(ctx_.get(), &p, transform_init_.m, &r), "estimate");
+    engine_.invalidateFetched();      // the engine now holds the last iteration's set (correspondence_search_kd_tree.hpp:231)
     std::memcpy(transform_.m, r.T, sizeof(r.T));
     iterations_ = r.iterations;
     last_delta_norm_ = r.last_delta_norm;

@@ -54,6 +54,26 @@ int main(int argc, char** argv) {
     icp.correspondenceSearchEngine().setMaxDistance(max_sq);
     icp.setConvergenceTolerance(1e-5f).setMaxNumberOfIterations(30);
     RigidTransform3f tf = icp.estimate().getTransform();
+    {
+      // after estimate() the engine holds the LAST iteration's correspondences (correspondence_search_kd_tree.hpp:231 keeps
+      // them, icp_base.hpp:32-38 hands the engine out): as many as the last update was computed from, ascending source index,
+      // and exactly what a search under the transform that iteration started from finds
+      const auto last = icp.correspondenceSearchEngine().getCorrespondences();     // (a copy: the engine's set is replaced below)
+      float Tl[16];
+      int origin = -1;
+      cilhip_get_last_matches_origin(icp.context(), &origin);
+      size_t bad = (last.size() != icp.getNumberOfLastCorrespondences()) || last.empty() || cilhip_get_matches_transform(icp.context(), Tl) != CILHIP_OK;
+      for (size_t k = 1; k < last.size(); ++k) bad += !(last[k - 1].indexInSecond < last[k].indexInSecond);
+      RigidTransform3f tl;
+      std::memcpy(tl.m, Tl, sizeof(Tl));
+      const auto& again = icp.correspondenceSearchEngine().findCorrespondences(tl).getCorrespondences();
+      bad += again.size() != last.size();
+      for (size_t k = 0; k < last.size() && k < again.size(); ++k)
+        bad += (last[k].indexInFirst != again[k].indexInFirst) || (last[k].indexInSecond != again[k].indexInSecond) || (last[k].value != again[k].value);
+      std::printf("getCorrespondences() after estimate(): %zu correspondences (origin %d), %zu mismatches vs a search under that iteration's transform\n",
+                  last.size(), origin, bad);
+      if (bad) ++failures;
+    }
 
     orc_icp_params p; std::memset(&p, 0, sizeof(p));
     p.metric = 1; p.w_p2p = 0; p.w_p2pl = 1; p.max_iter = 30; p.conv_tol = 1e-5f; p.max_opt_iter = 1; p.opt_conv_tol = 1e-5f;

@@ -102,9 +102,24 @@ def main():
     print("wrote", os.listdir(HERE))
 
 
+def make_frames_full_fixture(out_path, d="/root/reference/examples/test_clouds"):
+    """The reference's two sensor frames at FULL resolution (120k points each, no voxel grid): frame_1 with its normals (the
+    target of examples/rigid_icp.cpp), frame_2's points (a second, independent sampling of the same scene from a slightly
+    different pose).  Large enough for every adaptive kernel form (tiles forced, per-lane, warm-started: >= 65 536 points)."""
+    p1, n1 = read_ply_xyz_normals(os.path.join(d, "frame_1.ply"))
+    ok = np.isfinite(p1).all(1) & np.isfinite(n1).all(1)
+    p1, n1 = p1[ok], n1[ok]
+    p2, _ = read_ply_xyz_normals(os.path.join(d, "frame_2.ply"))
+    p2 = p2[np.isfinite(p2).all(1)]
+    np.savez_compressed(out_path, p1=p1.astype(np.float32), n1=n1.astype(np.float32), p2=p2.astype(np.float32))
+    return len(p1), len(p2)
+
+
 def main_frame1():
     nd, ns = make_frame1_fixture(os.path.join(HERE, "frame1_c1.npz"))
     print(f"frame1_c1.npz: dst {nd} points, src {ns} points")
+    n1, n2 = make_frames_full_fixture(os.path.join(HERE, "frames_full.npz"))
+    print(f"frames_full.npz: frame_1 {n1} points (+ normals), frame_2 {n2} points")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,304 @@
+"""The correspondence set the ICP loop's OWN kernels leave behind, index for index.
+
+north_star bar #1 is "correspondence indices bit-exact".  cilhip_find_correspondences is compared with the oracle / the
+reference's nanoflann all over tests/test_gpu_parity.py; the kernels that run INSIDE cilhip_icp_run -- the LDS tiles with the
+accumulation inside, the warm-started kernel k_warm<ACC, REC> the headline number is measured on -- used to be compared
+through counts and transforms only.  Here their matches are pulled out after the run (the engine keeps the last iteration's
+set like the reference's, correspondence_search_kd_tree.hpp:231) and every index and every d2 BIT is compared with
+  * a fresh search under the same transform by the search-only kernels (another code path altogether), and
+  * the reference's own nanoflann (oracle/_ref) over a >= 100k-query sample at that transform, mismatches classified
+    exact / tie / nearer / worse -- worse must be 0 and, on clouds without exact duplicates, everything exact.
+Clouds: the synthetic recipe, a target with holes and exact duplicate points, the reference's real sensor frames at full
+resolution (tests/golden/frames_full.npz: frame_1.ply / frame_2.ply of examples/test_clouds, 120k points each), and
+BASELINE configs[2] at its full 10M <-> 10M size.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from cilantro_amd import capi
+from cilantro_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def Context(hip_lib):
+    from cilantro_amd.icp import Context as Ctx
+
+    return Ctx
+
+
+def _report(name, obj):
+    """measured figures, kept next to the run (gpurun_out/ travels back from the GPU box)"""
+    import json
+
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+    print(name, obj)
+
+
+def _params(ctx, metric, w_p2p, r2, iters):
+    p = capi.IcpParams()
+    ctx._L.cilhip_icp_default_params(C.byref(p))
+    p.metric, p.w_p2p, p.max_sq_dist, p.max_iter, p.conv_tol = metric, w_p2p, float(r2), iters, 0.0
+    return p
+
+
+def _signed(idx):
+    gi = idx.astype(np.int64)
+    gi[idx == capi.NONE_IDX] = -1
+    return gi
+
+
+def _classify(gi, gd, oi, od):
+    """mismatching queries: equal-distance tie / GPU strictly nearer / GPU worse"""
+    bad = np.nonzero(gi != oi)[0]
+    ties = nearer = worse = 0
+    for i in bad:
+        if gi[i] >= 0 and oi[i] >= 0 and gd[i] == od[i]:
+            ties += 1
+        elif gi[i] >= 0 and (oi[i] < 0 or gd[i] < od[i]):
+            nearer += 1
+        else:
+            worse += 1
+    return len(bad), ties, nearer, worse
+
+
+def _loop_matches(Context, D, N, S, r2, iters, metric=capi.METRIC_COMBINED, w_p2p=0.0, options=(), expect_origin=1):
+    """run `iters` iterations (tolerance 0) and return what the loop's last iteration left: (idx, d2, T it searched under, ctx)"""
+    ctx = Context()
+    for k, v in options:
+        ctx.set_option(k, v)
+    ctx.set_target(D, N)
+    ctx.set_source(S)
+    res = ctx.icp_run(_params(ctx, metric, w_p2p, r2, iters))
+    assert int(res.iterations) == iters
+    origin = ctx.last_matches_origin()
+    assert origin == expect_origin, (origin, options)
+    T = ctx.matches_transform()
+    idx, d2 = ctx.get_nn()
+    return _signed(idx), d2, T, ctx, int(res.last_ncorr)
+
+
+def _check_against_fresh_search_and_reference(Context, orc, name, D, N, S, r2, gi, gd, T, ncorr, sample_n, rng, allow_ties):
+    n = len(S)
+    assert int(np.count_nonzero(gi >= 0)) == ncorr, name                  # last_ncorr counts exactly this set
+    # (1) a fresh search by the search-only kernels under the same transform: every index, every d2 bit
+    for tiled in (2, 0):
+        ctx = Context()
+        ctx.set_option("tiled", tiled)
+        ctx.set_target(D, N)
+        ctx.set_source(S)
+        ctx.find_correspondences(T, float(r2), count=False)
+        assert ctx.last_matches_origin() == 3
+        fi, fd = ctx.get_nn()
+        fi = _signed(fi)
+        ctx.close()
+        assert np.array_equal(gi, fi), (name, tiled, np.nonzero(gi != fi)[0][:10])
+        m = gi >= 0
+        assert np.array_equal(gd[m].view(np.uint32), fd[m].view(np.uint32)), (name, tiled)
+    # (2) the reference's nanoflann over a sample of the queries at that transform
+    sample = np.sort(rng.choice(n, min(sample_n, n), replace=False))
+    q = orc.transform_points(T, S[sample])
+    tree = orc.KDTree(D, use_ref=orc.ref_available())
+    o1, o2, ov = tree.find_correspondences(q, float(r2))
+    oi = np.full(len(sample), -1, np.int64)
+    od = np.zeros(len(sample), np.float32)
+    oi[o2] = o1
+    od[o2] = ov
+    nbad, ties, nearer, worse = _classify(gi[sample], gd[sample], oi, od)
+    assert worse == 0 and nearer == 0, (name, nbad, ties, nearer, worse)
+    if not allow_ties:
+        assert nbad == 0, (name, nbad, ties)
+    m = (gi[sample] >= 0) & (gi[sample] == oi)
+    assert np.array_equal(gd[sample][m].view(np.uint32), od[m].view(np.uint32)), name
+    return {"queries": int(n), "matched": int(ncorr), "sample": int(len(sample)), "mismatches": int(nbad), "ties": int(ties), "nearer": int(nearer),
+            "worse": int(worse), "knn": "reference nanoflann" if tree.use_ref else "oracle kd-tree"}
+
+
+def _holes_and_duplicates(rng):
+    base = syn.make_pair(1_200_000, perturb=0.5)
+    dst, dst_n = base["dst"], base["dst_n"]
+    keep = ~(((dst[:, 0] > 0.3) & (dst[:, 0] < 0.36)) | ((dst[:, 2] > 0.7) & (dst[:, 2] < 0.73)))
+    dup = rng.choice(np.nonzero(keep)[0], 5000, replace=False)
+    D = np.ascontiguousarray(np.concatenate([dst[keep], dst[dup]]))
+    N = np.ascontiguousarray(np.concatenate([dst_n[keep], dst_n[dup]]))
+    return base, D, N
+
+
+def test_warm_kernel_matches_index_for_index(Context, orc):
+    """k_warm<ACC, REC>: the first warm iteration of a stretch (REC = 1: gathers through the stored positions, writes the
+    match records) and the record-reading ones (REC = 2), all four accumulation variants, on the uniform recipe and on a
+    target with holes and exact duplicates (nearest-other distance 0: never settled by the shortcut)."""
+    rng = np.random.default_rng(11)
+    base, Dh, Nh = _holes_and_duplicates(rng)
+    report = {}
+    for name, D, N, allow_ties in (("uniform", base["dst"], base["dst_n"], False), ("holes+duplicates", Dh, Nh, True)):
+        S, r2 = base["src"], base["max_sq_dist"]
+        for metric, w_p2p, mname in ((capi.METRIC_COMBINED, 0.0, "plane"), (capi.METRIC_COMBINED, 0.1, "both"), (capi.METRIC_POINT_TO_POINT, 0.0, "kabsch")):
+            for iters in (2, 5):         # the last iteration is REC = 1 / REC = 2
+                if mname != "plane" and iters == 2 and name == "uniform":
+                    continue
+                gi, gd, T, ctx, nc = _loop_matches(Context, D, N, S, r2, iters, metric, w_p2p, (("warm_start", 2), ("tiled", 2)))
+                assert ctx.last_warm_iterations() == iters - 1
+                ctx.close()
+                report[f"{name}/{mname}/{iters}"] = _check_against_fresh_search_and_reference(
+                    Context, orc, (name, mname, iters), D, N, S, r2, gi, gd, T, nc, 100_000, rng, allow_ties)
+    # point metric alone (w_p2pl = 0): the fourth ACC variant
+    ctx = Context()
+    ctx.set_option("warm_start", 2); ctx.set_option("tiled", 2)
+    ctx.set_target(base["dst"], base["dst_n"]); ctx.set_source(base["src"])
+    p = _params(ctx, capi.METRIC_COMBINED, 1.0, base["max_sq_dist"], 4)
+    p.w_p2pl = 0.0
+    res = ctx.icp_run(p)
+    assert ctx.last_matches_origin() == 1 and ctx.last_warm_iterations() == 3
+    T = ctx.matches_transform()
+    idx, gd = ctx.get_nn()
+    ctx.close()
+    report["uniform/point/4"] = _check_against_fresh_search_and_reference(Context, orc, "point", base["dst"], base["dst_n"], base["src"], base["max_sq_dist"],
+                                                                         _signed(idx), gd, T, int(res.last_ncorr), 100_000, rng, False)
+    _report("warm_matches_1m.json", report)
+
+
+def test_tile_and_lane_loop_kernels_matches_index_for_index(Context, orc):
+    """The other forms an iteration can take, same check: the LDS tiles with the accumulation inside (one pass), the two-pass
+    form (tiled search with its 3x3x3 pass + streaming accumulation), the per-lane search; and loops whose kernels keep no
+    per-query matches answer through a search repeated on demand (origin 2) -- the same set."""
+    rng = np.random.default_rng(12)
+    d = syn.make_pair(1_200_000, perturb=0.9)          # starts far: the first iterations leave many octant proofs open
+    D, N, S, r2 = d["dst"], d["dst_n"], d["src"], d["max_sq_dist"]
+    forms = (("tile one pass", (("warm_start", 0), ("tiled", 2), ("tile_accumulation", 2)), 2),         # stores nothing with warm_start = 0: searched again
+             ("tile one pass, stored", (("warm_start", 1), ("tiled", 2), ("tile_accumulation", 2)), 1),
+             ("two pass tiled", (("warm_start", 0), ("tiled", 2), ("tile_accumulation", 0)), 1),
+             ("two pass per lane", (("warm_start", 0), ("tiled", 0)), 1),
+             ("per lane fused", (("warm_start", 0), ("tiled", 0), ("fused", 1)), 2))
+    for name, opts, origin in forms:
+        for iters in (1, 3):
+            gi, gd, T, ctx, nc = _loop_matches(Context, D, N, S, r2, iters, options=opts, expect_origin=origin)
+            ctx.close()
+            _check_against_fresh_search_and_reference(Context, orc, (name, iters), D, N, S, r2, gi, gd, T, nc, 100_000, rng, False)
+    # post-filters: the set of the last iteration is the FILTERED one (searched again, filtered again)
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+    icp = SimpleCombinedMetricRigidICP3f(D, N, S)
+    icp.correspondenceSearchEngine().setMaxDistance(float(r2)).setInlierFraction(0.7)
+    icp.setMaxNumberOfIterations(3).setConvergenceTolerance(0.0).estimate()
+    i1, i2, v = icp.correspondenceSearchEngine().getCorrespondences()
+    assert icp._ctx.last_matches_origin() == 2 and len(i1) == icp.last_ncorr_ and np.all(np.diff(v) >= 0)
+    Tl = icp._ctx.matches_transform()
+    eng = icp.correspondenceSearchEngine()
+    eng.findCorrespondences(Tl)
+    j1, j2, w = eng.getCorrespondences()
+    assert np.array_equal(i1, j1) and np.array_equal(i2, j2) and np.array_equal(v, w)
+
+
+def test_real_sensor_frames_every_form(Context, orc):
+    """examples/test_clouds at full resolution (120k points; no voxel grid), two registrations: frame_1 against a jittered,
+    moved copy of itself (the recipe of examples/rigid_icp.cpp:25-65 at the sensor's resolution) and frame_1 against frame_2
+    (an independent sampling of the scene).  Every kernel form forced in turn -- tiles (one pass / two passes), per-lane, warm
+    -- and the adaptive default: the last iteration's matches against a fresh search and the reference's nanoflann; the loops
+    against the oracle's.  Which form the adaptive loop picks is recorded (profiles/r03_real_cloud.txt)."""
+    f = np.load(os.path.join(HERE, "golden", "frames_full.npz"))
+    p1, n1, p2 = f["p1"], f["n1"], f["p2"]
+    rng = np.random.default_rng(13)
+    # rigid_icp.cpp:33-62 -- src = dst + jitter, dst keeps x > -0.4, src moved by tf_ref (a smaller motion: the raw cloud's
+    # spacing is ~1.5 mm, the example's 0.1 rad / 0.2 m start is far outside any nearest-neighbour basin at that resolution)
+    jit = (np.float32(0.0005) * rng.uniform(-1, 1, p1.shape)).astype(np.float32)
+    Tm = np.eye(4)
+    Tm[:3, :3] = syn.rot_xyz(-0.004, 0.004, -0.004)
+    Tm[:3, 3] = [-0.003, -0.001, 0.002]
+    src_self = ((p1 + jit).astype(np.float64) @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.float32)
+    keep = p1[:, 0] > -0.4
+    D, N = np.ascontiguousarray(p1[keep]), np.ascontiguousarray(n1[keep])
+    report = {}
+    tree_ref = orc.KDTree(D, use_ref=orc.ref_available())
+    cases = (("frame_1 vs moved+jittered frame_1", src_self, np.float32(0.01 * 0.01)), ("frame_1 vs frame_2", np.ascontiguousarray(p2), np.float32(0.02 * 0.02)))
+    forms = (("adaptive", (), None), ("warm forced, per-lane start", (("warm_start", 2), ("tiled", 0)), 1), ("warm forced, tiled start", (("warm_start", 2), ("tiled", 2)), 1),
+             ("tiles one pass", (("warm_start", 1), ("tiled", 2), ("tile_accumulation", 2)), 1), ("tiles two passes", (("warm_start", 0), ("tiled", 2), ("tile_accumulation", 0)), 1),
+             ("per lane", (("warm_start", 0), ("tiled", 0)), 1))
+    for cname, S, r2 in cases:
+        po = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
+        # Two oracle loops.  (1) the reference's order of ties: nanoflann keeps the first candidate met in ITS tree traversal
+        # (core/kd_tree.hpp:82-90); (2) the same loop with the engine's documented rule, lowest target index (exhaustive
+        # argmin).  They only differ on exactly equal f32 distances -- which the depth sensor's lattice (232 distinct z values,
+        # a regular pixel grid) does produce between two raw frames under the identity: 321 ties in the first search of
+        # frame_1 vs frame_2, a 4.5e-6 difference in that iteration's update (tools/real_cloud_diag2.py).  The HIP loop must
+        # equal (2) to the tolerance; its distance from (1) is recorded and bounded by the ties' effect.
+        ro = orc.icp_run(D, N, S, po)
+        T_low = np.eye(4, dtype=np.float32)
+        ties_seen = 0
+        for _ in range(6):
+            q = orc.transform_points(T_low, S)
+            bi, _bd = orc.nn_brute(D, q, float(r2))
+            o1, o2, ov = tree_ref.find_correspondences(q, float(r2))
+            oi = np.full(len(S), -1, np.int64); oi[o2] = o1
+            ties_seen += int(np.count_nonzero(bi != oi))
+            si = np.nonzero(bi >= 0)[0]
+            T_low, _ = orc.icp_update(D, N, S, T_low, bi[si], si, po)
+            nc_low = len(si)
+        for fname, opts, origin in forms:
+            ctx = Context()
+            for k, v in opts:
+                ctx.set_option(k, v)
+            ctx.set_target(D, N)
+            ctx.set_source(S)
+            res = ctx.icp_run(_params(ctx, capi.METRIC_COMBINED, 0.0, r2, 6))
+            Tg = np.array(res.T[:], np.float32).reshape(4, 4).T
+            err = float(np.linalg.norm(Tg.astype(np.float64) - T_low.astype(np.float64)))
+            err_ref = float(np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64)))
+            assert err <= 1e-5 and int(res.last_ncorr) == nc_low, (cname, fname, err, int(res.last_ncorr), nc_low)
+            assert err_ref <= (1e-5 if ties_seen == 0 else 1e-4), (cname, fname, err_ref, ties_seen)
+            one, two = ctx.last_run_forms()
+            warm = ctx.last_warm_iterations()
+            if origin is not None:
+                assert ctx.last_matches_origin() == origin, (cname, fname)
+            T = ctx.matches_transform()
+            idx, gd = ctx.get_nn()
+            ctx.close()
+            chk = _check_against_fresh_search_and_reference(Context, orc, (cname, fname), D, N, S, r2, _signed(idx), gd, T, int(res.last_ncorr), 120_000, rng, True)
+            report[f"{cname} / {fname}"] = {"one_pass_iterations": one, "two_pass_iterations": two, "warm_iterations": warm, "T_minus_oracle_lowest_index_ties": err,
+                                            "T_minus_oracle_nanoflann_tie_order": err_ref, "tie_queries_over_6_searches": ties_seen, **chk}
+        assert report[f"{cname} / warm forced, per-lane start"]["warm_iterations"] == 5
+    _report("real_cloud_forms.json", report)
+
+
+def test_warm_kernel_matches_index_for_index_10m(Context, orc):
+    """BASELINE configs[2] at full size: the adaptive loop of the bench (tiles, then warm-started iterations) and the forced
+    warm form; the last iteration's 10M matches against a fresh tiled search (every index, every d2 bit) and a 200k-query
+    sample of the reference's nanoflann over the 10M-point target."""
+    rng = np.random.default_rng(14)
+    n = 10_000_000
+    d = syn.make_pair(n, perturb=0.3)
+    D, N, S, r2 = d["dst"], d["dst_n"], d["src"], d["max_sq_dist"]
+    tree = orc.KDTree(D, use_ref=orc.ref_available())
+    report = {}
+    for name, opts, iters in (("adaptive, 6 iterations", (), 6), ("warm forced, 3 iterations", (("warm_start", 2),), 3)):
+        gi, gd, T, ctx, nc = _loop_matches(Context, D, N, S, r2, iters, options=opts)
+        warm = ctx.last_warm_iterations()
+        assert warm >= 2, (name, warm)
+        # fresh search under the same transform, same context (the tiled search-only kernel)
+        ctx.find_correspondences(T, float(r2), count=False)
+        fi, fd = ctx.get_nn()
+        ctx.close()
+        fi = _signed(fi)
+        assert np.array_equal(gi, fi), (name, np.nonzero(gi != fi)[0][:10])
+        assert np.array_equal(gd.view(np.uint32)[gi >= 0], fd.view(np.uint32)[gi >= 0]), name
+        sample = np.sort(rng.choice(n, 200_000, replace=False))
+        o1, o2, ov = tree.find_correspondences(orc.transform_points(T, S[sample]), float(r2))
+        oi = np.full(len(sample), -1, np.int64); od = np.zeros(len(sample), np.float32)
+        oi[o2] = o1; od[o2] = ov
+        nbad, ties, nearer, worse = _classify(gi[sample], gd[sample], oi, od)
+        assert nbad == 0, (name, nbad, ties, nearer, worse)
+        assert np.array_equal(gd[sample].view(np.uint32)[oi >= 0], od.view(np.uint32)[oi >= 0]), name
+        report[name] = {"queries": n, "matched": nc, "warm_iterations": warm, "sample": len(sample), "mismatches": nbad, "ties": ties, "nearer": nearer, "worse": worse,
+                        "knn": "reference nanoflann" if tree.use_ref else "oracle kd-tree"}
+    _report("warm_matches_10m.json", report)
