@@ -12,12 +12,16 @@ reduction and the on-device 6x6 / 3x3 solve.
            c4 / c4_1gpu  configs[3]: 10M source points against an 80M-point target, combined metric 0.1 / 1.0
            kmeans        configs[4]: KMeans3f k = 1024 on 50M points (step = one Lloyd iteration)
            ransac        configs[4]: plane RANSAC scoring on 50M points (step = one pass of 128 hypotheses)
-  --gpus N (one process per GPU under torch.distributed.run; backend "nccl" = RCCL):
-      c3, --scaling weak (default): every rank holds the full 10M target and its own 10M source shard; one
-          all-reduce(sum) of 48 f64 per iteration (source points are independent work units).
-      c3 --scaling strong, c4: spatial slabs (SURVEY.md 8(e) partitioning B, cilantro_amd.distributed.SlabPartition):
-          rank r owns the target points of its slab plus a halo and the source points that fall into the slab; the same
-          single all-reduce per iteration.  Total work is fixed as N grows.
+  --gpus N (one process per GPU; backend "nccl" = RCCL).  Started without a launcher (`python bench.py --gpus N`) the script
+      re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; started
+      under one (RANK / WORLD_SIZE set) it checks that WORLD_SIZE == N.  Fewer than N visible devices: exits non-zero.
+      c2 / c3 (default --scaling strong) and c4: spatial slabs (SURVEY.md 8(e) partitioning B, cilantro_amd.distributed.SlabPartition):
+          BASELINE's metric is "10M<->10M at 1/2/4/8 GPUs" -- the SAME registration on N GPUs.  Rank r owns the target points of
+          its slab plus a halo and the source points that fall into the slab; one all-reduce(sum) of 48 f64 per iteration
+          ("per-rank partial covariances reduced via RCCL all-reduce").  Total work is fixed as N grows.
+      --scaling weak: every rank holds the full target and its own source shard of the config's size (source points are
+          independent work units); the same single all-reduce.
+      The SCALE commands: `python bench.py --gpus N` for N = 1, 2, 4, 8 (c3) and `python bench.py --config c4 --gpus 8`.
 
 Timed region = exactly K steps from T0 = identity with conv_tol = 0 (never early-exits), bracketed by barrier +
 torch.cuda.synchronize(); MAX over ranks; rank 0 prints one JSON line.  `value` = correspondence pairs/s of the whole
@@ -56,7 +60,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c4_1gpu", "kmeans", "ransac"], default="c3")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="c3 with --gpus > 1 (c4 is always strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None, help="--gpus > 1: strong (default; slabs, total work fixed) or weak (c4 is always strong)")
+    ap.add_argument("--selftest-spawn", action="store_true", help="(tests) exercise the self-launch path on CPU: gloo, one all-reduce, no GPU work")
     ap.add_argument("--n", type=int, default=None, help="override the number of target points (source scaled alike): quick runs only")
     ap.add_argument("--metric", choices=["p2plane", "p2p"], default=None, help="(compatibility) c3 sizes with another metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,12 +149,17 @@ def bench_icp(a, torch, rank, world, local_rank):
     # CILHIP_BENCH_FORCE_SHARDED=1 (under torchrun): run the sharded protocol + RCCL even with one rank,
     # to exercise exactly the code path the multi-GPU runs take
     sharded = world > 1 or (os.environ.get("CILHIP_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ)
+    rccl_ranks = 1
     if sharded:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == a.gpus or world == 1, (world, a.gpus)
-    strong = sharded and (a.config in ("c4", "c4_1gpu") or a.scaling == "strong")
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ones)                      # how many ranks the RCCL all-reduce really spans
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: the RCCL all-reduce spans {rccl_ranks} rank(s)")
+    strong = sharded and (a.config in ("c4", "c4_1gpu") or a.scaling != "weak")
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = Context(local_rank, stream)
@@ -287,6 +297,16 @@ def bench_icp(a, torch, rank, world, local_rank):
                               "kernel is the form with the largest share of the timed region's kernel time",
                     "forms_in_timed_region": forms,
                     "all_forms_avg_kernel_ms": search_ms / launches}
+            if 1 in ft and ft[1][1] > 0 and dom != 1:
+                # the COLD form beside the headline: the LDS-tiled search with the accumulation inside the tile -- what the first
+                # iterations of every registration, and every iteration of a source that is not the target's points plus small
+                # noise (`independent_source` below), run in
+                cold_ms = ft[1][0] / ft[1][1]
+                out_cold = {"bound": "hbm", "kernel": FORMS[1][0], "form": 1, "avg_kernel_ms": cold_ms, "launches": ft[1][1],
+                            "algorithmic_bytes_per_launch": one_pass_bytes, "achieved": one_pass_bytes / (cold_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": one_pass_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            else:
+                out_cold = None
             if dom == 0:
                 acc_bytes = 16.0 * ns_l + (24.0 if with_normals else 12.0) * nc_l
                 roof["accumulate_kernel"] = {"avg_kernel_ms": acc_ms / launches, "algorithmic_bytes_per_launch": acc_bytes,
@@ -299,7 +319,7 @@ def bench_icp(a, torch, rank, world, local_rank):
             "metric": "ICP corr. pairs/sec (+ iterations/sec), synthetic uniform clouds",
             "value": n_src_total * a.steps / dt, "unit": "pairs/s",
             "icp_iterations_per_sec": a.steps / dt,
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32 search / f64 accumulate+solve", "data": "synthetic",
             "config": {"workload": f"{a.config}: {ns/1e6:g}M<->{nd/1e6:g}M synthetic float3 clouds " + label,
@@ -309,7 +329,7 @@ def bench_icp(a, torch, rank, world, local_rank):
             "setup_ms": t_setup * 1e3, "source_sort_ms": sort_ms, "loop_ms_hip_events": loop_ms,
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,
             "iterations_one_pass": one_pass_iters, "iterations_two_pass": two_pass_iters, "iterations_warm_started": ctx.last_warm_iterations(),
-            "roofline": roof,
+            "roofline": roof, "roofline_cold": out_cold if dom is not None else None,
         }
     if not sharded and not a.no_extras:
         extras = {}
@@ -355,6 +375,35 @@ def bench_icp(a, torch, rank, world, local_rank):
             p.conv_tol = 0.0
         except Exception as e:
             extras["converging_run"] = {"error": repr(e)}
+        # A source that is NOT the target's points plus small noise: an independent uniform sample of the same volume (matches at
+        # about half the point spacing).  The nearest-other-point table settles few of its queries, so the adaptive loop stays
+        # with the LDS-tiled kernels: the regime every registration of two separately sampled clouds lives in.
+        try:
+            rng = np.random.default_rng(3)
+            si = rng.random((ns, 3), dtype=np.float32)
+            Ti = np.linalg.inv(d["T_true"].astype(np.float64))
+            si = (si.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+            ctx.set_source(torch.from_numpy(si).cuda())
+            p.conv_tol = 0.0
+            p.max_iter = a.steps; ctx.enable_kernel_timing(False); ctx.icp_run(p, T0)       # (sort + warm-up run)
+            ctx.enable_kernel_timing(True)
+            ctx.synchronize(); t0 = time.perf_counter()
+            ri = ctx.icp_run(p, T0)
+            ctx.synchronize(); dti = time.perf_counter() - t0
+            fti = ctx.last_form_timing()
+            nci = int(ri.last_ncorr)
+            domi = max(fti, key=lambda f: fti[f][0])
+            bytes_i = {0: 16.0 * ns + 12.0 * nd, 1: 12.0 * ns + 12.0 * nd + (12.0 * nci if with_normals else 0.0)}.get(domi, 12.0 * ns + (24.0 if with_normals else 12.0) * nci)
+            ms_i = fti[domi][0] / max(fti[domi][1], 1)
+            extras["independent_source"] = {
+                "workload": f"{ns/1e6:g}M independent uniform source points against the same {nd/1e6:g}M-point target, {a.steps} iterations, tolerance 0",
+                "ms_per_step": dti * 1e3 / a.steps, "icp_iterations_per_sec": a.steps / dti, "last_ncorr": nci,
+                "iterations_one_pass_two_pass": list(ctx.last_run_forms()), "iterations_warm_started": ctx.last_warm_iterations(),
+                "forms": {str(f): {"launches": n, "avg_kernel_ms": ms / n} for f, (ms, n) in fti.items() if n > 0},
+                "roofline": {"bound": "hbm", "form": domi, "avg_kernel_ms": ms_i, "algorithmic_bytes_per_launch": bytes_i,
+                             "achieved": bytes_i / (ms_i * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        except Exception as e:
+            extras["independent_source"] = {"error": repr(e)}
         out.update(extras)
     if rank == 0 and not sharded and not a.no_cpu_baseline:
         try:
@@ -401,14 +450,16 @@ def bench_kmeans(a, torch):
         try:
             from oracle import oracle as orc
 
-            m = min(n, 400_000)
+            m = min(n, 4_000_000)
             ts = []
             for r in range(4):
                 t0 = time.perf_counter(); orc.kmeans_assign(x[:m], c0); t = time.perf_counter() - t0
                 if r:
                     ts.append(t)
-            out["cpu_baseline"] = {"value": m * k / statistics.median(ts), "unit": "distances/s", "cores": 1, "kind": "port",
-                                   "sample": f"assignment of {m} of {n} points to the {k} centroids, oracle (scalar C, 1 thread), median of 3"}
+            cores = os.cpu_count() or 1
+            out["cpu_baseline"] = {"value": m * k / statistics.median(ts), "unit": "distances/s", "cores": cores, "kind": "port",
+                                   "sample": f"assignment of {m} of {n} points to the {k} centroids, oracle (C restatement of clustering/kmeans.hpp:95-119, "
+                                             f"OpenMP parallel for over the points as the reference's :100, {cores} threads), median of 3 after a warm-up"}
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(out))
@@ -441,40 +492,95 @@ def bench_ransac(a, torch):
     out = {"metric": "plane RANSAC point-plane tests/sec", "value": tests / dt, "unit": "tests/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"ransac: PlaneRANSACEstimator3f inlier counting, {n/1e6:g}M points, 128 hypotheses per pass", "n_points": n},
-           "roofline": {"bound": "hbm", "achieved": alg / (dt / a.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "k_score", "algorithmic_bytes_per_launch": alg,
-                        "note": "128 hypotheses share one read of the points: the pass is VALU-bound (5 ops per test), the HBM fraction says how far the read is amortised"}}
+           "roofline": {"bound": "valu", "achieved": 6.0 * tests / dt / 1e12, "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": 6.0 * tests / dt / 1e12 / VALU_NOFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_score",
+                        "note": "6 individually rounded f32 operations per point-plane test (3 multiplies + 3 additions of n.p + offset, hyperplane.hpp absDistance; the "
+                                "|.| <= threshold compare and the ballot/popcount are not counted), no FMA contraction: counts must match the reference bit for bit; "
+                                "peak = half of the 157.3 TFLOP/s FMA figure.  128 hypotheses share one read of the points, so HBM is not the bound:",
+                        "hbm_GBps": alg / (dt / a.steps) / 1e9, "hbm_frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg}}
     if not a.no_cpu_baseline:
         try:
             from oracle import oracle as orc
 
-            m = min(n, 2_000_000)
+            m = min(n, 20_000_000)
             xs = np.ascontiguousarray(x[:m].cpu().numpy())
-            ts = []
+            ts, ts1 = [], []
             for r in range(4):
                 t0 = time.perf_counter()
                 for j in range(4):
-                    orc.plane_count_inliers(xs, planes[j], 0.01)
+                    orc.plane_count_inliers_mt(xs, planes[j], 0.01)
                 t = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                orc.plane_count_inliers(xs[: m // 10], planes[0], 0.01)
+                t1 = time.perf_counter() - t0
                 if r:
-                    ts.append(t)
-            out["cpu_baseline"] = {"value": 4 * m / statistics.median(ts), "unit": "tests/s", "cores": 1, "kind": "port",
-                                   "sample": f"4 hypotheses x {m} of {n} points, oracle (scalar C, 1 thread), median of 3"}
+                    ts.append(t); ts1.append(t1)
+            cores = os.cpu_count() or 1
+            out["cpu_baseline"] = {"value": 4 * m / statistics.median(ts), "unit": "tests/s", "cores": cores, "kind": "port",
+                                   "sample": f"4 hypotheses x {m} of {n} points, oracle (C restatement of ransac_hyperplane_estimator.hpp:47-55) with an OpenMP "
+                                             f"parallel for over the points on {cores} threads, median of 3 after a warm-up; the reference itself evaluates the "
+                                             f"residuals as a SERIAL Eigen expression: `serial_value` is the same loop on 1 thread",
+                                   "serial_value": (m // 10) / statistics.median(ts1)}
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     assert int(cnt[0]) == int(cnt1[0])
     print(json.dumps(out))
 
 
+def relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1).  Never prints a 1-GPU line for an N-GPU request: fewer visible devices than ranks is an error."""
+    import socket
+    import subprocess
+
+    if not a.selftest_spawn:
+        import torch
+
+        nvis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if nvis < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {nvis} HIP device(s) visible on this node -- refusing to report a {a.gpus}-GPU number")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def selftest_spawn(a, rank, world):
+    """CPU-only check of the launch path (tests/test_bench_launch.py): the ranks rendezvous over gloo and all-reduce once."""
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo")
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"selftest_spawn": True, "n_gpus": world, "ranks_in_all_reduce": int(ones.item()), "requested": a.gpus}))
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
-    import torch
-
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if a.gpus > 1 and not launched and a.config not in ("kmeans", "ransac"):
+        relaunch_under_torchrun(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and not (world == 1 and a.config in ("kmeans", "ransac")):
+        raise SystemExit(f"bench.py --gpus {a.gpus} started with WORLD_SIZE = {world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus}) or let bench.py launch itself")
+    if a.selftest_spawn:
+        return selftest_spawn(a, rank, world)
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     if a.config == "kmeans":
         if rank == 0:

@@ -208,6 +208,7 @@ size_t orc_kmeans(const float* x, size_t n, float* c, size_t k, size_t max_iter,
 void orc_sym_eig3(const double A[9], double w[3], double V[9]);
 void orc_plane_residuals(const float* pts, size_t n, const float plane[4], float* res);
 size_t orc_plane_count_inliers(const float* pts, size_t n, const float plane[4], float thresh);
+size_t orc_plane_count_inliers_mt(const float* pts, size_t n, const float plane[4], float thresh);   /* all host cores (OpenMP) */
 void orc_plane_fit(const float* pts, const uint32_t* idx, size_t m, int mode, float plane[4]);
 size_t orc_plane_ransac(const float* pts, size_t n, const uint32_t* samples, size_t max_iter, float thresh,
                         size_t target_inliers, int re_estimate, int mode, float plane[4], float* residuals,

@@ -137,6 +137,8 @@ def lib():
         L.orc_plane_residuals.argtypes = [_f32p, C.c_size_t, _f32p, _f32p]
         L.orc_plane_count_inliers.restype = C.c_size_t
         L.orc_plane_count_inliers.argtypes = [_f32p, C.c_size_t, _f32p, C.c_float]
+        L.orc_plane_count_inliers_mt.restype = C.c_size_t
+        L.orc_plane_count_inliers_mt.argtypes = [_f32p, C.c_size_t, _f32p, C.c_float]
         L.orc_plane_fit.argtypes = [_f32p, C.c_void_p, C.c_size_t, C.c_int, _f32p]
         L.orc_plane_ransac.restype = C.c_size_t
         L.orc_plane_ransac.argtypes = [_f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
@@ -467,6 +469,12 @@ def plane_residuals(pts, plane):
 def plane_count_inliers(pts, plane, thresh):
     pts = _c(pts).reshape(-1, 3)
     return int(lib().orc_plane_count_inliers(pts, len(pts), _c(plane).reshape(4), np.float32(thresh)))
+
+
+def plane_count_inliers_mt(pts, plane, thresh):
+    """the same count on all host cores (OpenMP)"""
+    pts = _c(pts).reshape(-1, 3)
+    return int(lib().orc_plane_count_inliers_mt(pts, len(pts), _c(plane).reshape(4), np.float32(thresh)))
 
 
 def plane_fit(pts, idx=None, mode=1):

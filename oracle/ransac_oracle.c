@@ -95,6 +95,15 @@ size_t orc_plane_count_inliers(const float* pts, size_t n, const float plane[4],
   return k;
 }
 
+/* the same count on all host cores (bench.py's cpu_baseline: the reference's computeResiduals is a serial Eigen expression,
+ * ransac_hyperplane_estimator.hpp:47-55 -- this is what an OpenMP build of it could reach; an integer count: order-independent) */
+size_t orc_plane_count_inliers_mt(const float* pts, size_t n, const float plane[4], float thresh) {
+  size_t k = 0;
+#pragma omp parallel for reduction(+ : k) schedule(static)
+  for (size_t i = 0; i < n; ++i) k += abs_distance(plane, pts + 3 * i) <= thresh;
+  return k;
+}
+
 /* estimate_params_(sample_ind, model) (ransac_hyperplane_estimator.hpp:78-85): PCA of the subset
  * (covariance.hpp:125-141 serial branch), normal = eigenvector of the smallest eigenvalue,
  * offset = -normal.dot(mean).  idx == NULL => all points 0..m-1 (:70-76). */
