@@ -66,6 +66,8 @@ struct cilhip_ctx {
   int warm_start = 1;             // option "warm_start": 0 = never, 1 = when the device reports the source near alignment, 2 = from the second iteration on
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint32_t ntiles = 0;
+  int tile_pipeline = 0;          // option "tile_pipeline": 1 = the in-tile accumulation runs as the persistent, software-pipelined kernel k_tile_pipe
+                                  // (round 3 experiment, exact, measured 17 % slower than two workgroups per CU: off)
   int tiled = 1;                  // 0: per-lane global-memory search; 1: LDS-tiled search when the cloud is large enough; 2: always tiled
   bool src_sorted = false;
   float sort_T[16];
@@ -271,6 +273,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
+  if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "point_weight_evaluator") || !strcmp(key, "plane_weight_evaluator")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "weight evaluator: 0 = Unity, 1 = Identity, 2 = RBF kernel");
@@ -619,6 +622,7 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.defer_flag = c->d_defer_flag;
   a.unproven_cnt = c->d_unproven;
   a.store_matches = 1;
+  a.tile_pipeline = c->tile_pipeline;
   a.skip_if_inner_done = 0;
   return a;
 }

@@ -110,6 +110,7 @@ struct IterArgs {
   uint32_t* defer_flag;    // [1] set by a tile that defers a query: the clean-up pass has work
   uint32_t* unproven_cnt;  // [128] (spread by tile / block index) [0, 64): queries the octant block did not prove (how far the source is from
                            // alignment; the warm-started kernel: queries without a usable bound), [64, 128): queries the warm-started kernel listed
+  int tile_pipeline;       // tiled search with in-tile accumulation: the persistent, software-pipelined kernel (k_tile_pipe) instead of one workgroup per tile
   int store_matches;       // tiled search: also write nn_pos / nn_d2 for the queries settled inside the tile (the pure ICP loop needs neither)
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)

@@ -983,7 +983,9 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
 #ifdef CILHIP_EXP_PHASE_CLOCKS
 __device__ unsigned long long g_phase_clk[8];
 #define PHASE_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_clk[k], now_ - tprev_); tprev_ = now_; } } while (0)
+void debug_dump_pipe_clocks();
 void debug_dump_phase_clocks() {
+  debug_dump_pipe_clocks();
   unsigned long long h[8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof h) != hipSuccess) return;
   unsigned long long tot = 0;
@@ -1778,10 +1780,13 @@ static uint32_t deferred_blocks(uint32_t ntiles) {
 // block of the clean-up pass (a.partials = a.tile_partials + ntiles rows)
 int tiled_partial_rows(uint32_t ntiles) { return (int)(ntiles + deferred_blocks(ntiles)); }
 
+#include "tile_pipe.inc"
+
 template <int ACC>
 static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const int* tile_box, uint32_t ntiles, hipStream_t s) {
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
-  hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
+  if (ACC != IM_NONE && a.tile_pipeline) hipLaunchKernelGGL((k_tile_pipe<ACC>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
+  else hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   hipLaunchKernelGGL((k_search_deferred<ACC>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
 }
 
