@@ -913,6 +913,12 @@ int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t ma
   transform_point(c->nn_T, c->src_mean[0], c->src_mean[1], c->src_mean[2], smt[0], smt[1], smt[2]);
   int conv = 0;
   const CorrWeights cw = corr_weights_of(c, true, w_p2p, w_p2pl);
+  if (max_iter == 0) {      // the loop body never runs; "no usable terms" (no correspondences) still means identity (:264-272)
+    double sums[SUMS_MAX];
+    const int rc = accumulate_stored(c, metric, L, t, sums, &cw);
+    if (rc) return rc;
+    if (!(sums[0] > 0.0)) return CILHIP_OK;
+  }
   for (size_t it = 0; it < max_iter; ++it) {
     double sums[SUMS_MAX];
     int rc = accumulate_stored(c, metric, L, t, sums, &cw);
@@ -1197,13 +1203,17 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (rc) return rc;
   const int im = iter_metric_of(c, p);
   const bool gn = (im != IM_KABSCH);
-  const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 0) : 1;
+  // max_optimization_iterations == 0 (combined metric): the estimator's loop body never runs -- one accumulation pass still counts
+  // the correspondences (the "no usable terms" test, transform_estimation.hpp:264-272), the epilogue skips the solve
+  const bool zero_steps = gn && p->max_opt_iter == 0;
+  const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 1) : 1;
   ++c->run_tag;
   launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag);
   IterArgs a = make_iter_args(c, p->max_sq_dist);
   a.cw = corr_weights_of(c, p);
   SolveArgs sa = make_solve_args(c, p, im, c->src_mean);
   sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;
+  sa.gn_zero_steps = zero_steps ? 1 : 0;
   const int nb = sa.nblocks;
   if (c->ns == 0) {  // no source points: the epilogue runs on all-zero sums (identity step)
     CK(c, hipMemsetAsync(c->d_sums, 0, SUMS_MAX * sizeof(double), c->stream));
@@ -1214,7 +1224,6 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // FIRST_TO_SECOND / BOTH: the correspondence set is a pair list rebuilt every iteration (a grid over the transformed
     // source, like the reference's per-iteration kd-tree); host-driven loop, the accumulation kernels stream over the pairs
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
-    if (gn && opt_steps == 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "max_opt_iter == 0 is not supported");
     if (feat6(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for SECOND_TO_FIRST only");
     hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
     CK(c, hipEventRecord(e_beg, c->stream));
@@ -1380,12 +1389,6 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     //  loose -- measured at 10M: 0.43 ms against 0.30 ms for the tiles)
     const bool warm = wcap && it >= 1 && (c->warm_start == 2 || ((one_pass || !tile_acc) && paced && it >= 2 && warm_on));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
-    if (gn && opt_steps == 0) {
-      // max_optimization_iterations_ == 0: estimateTransformCombinedMetric leaves tform = identity
-      // and still un-centres it (:365): handled by an epilogue with zero weights is NOT identical, so
-      // mirror literally: tform = t_dst * I * t_src.
-      return fail(c, CILHIP_ERR_UNSUPPORTED, "max_opt_iter == 0 is not supported");
-    }
     bool warm_first = false;
     for (size_t st = 0; st < opt_steps; ++st) {
       a.skip_if_inner_done = (st > 0);
@@ -1641,6 +1644,22 @@ int cilhip_get_slab_violation(cilhip_ctx* c, int* out) {
   CK(c, hipMemcpyAsync(&v, reinterpret_cast<const char*>(c->d_state) + offsetof(IcpState, slab_violation), sizeof(int), hipMemcpyDeviceToHost, c->stream));
   CK(c, hipStreamSynchronize(c->stream));
   *out = v;
+  return CILHIP_OK;
+}
+
+int cilhip_get_slab_violation_state(cilhip_ctx* c, int* violated, cilhip_icp_result* at) {
+  if (!c || !violated) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  IcpState hs;
+  CK(c, hipMemcpyAsync(&hs, c->d_state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  *violated = hs.slab_violation;
+  if (at) {
+    memcpy(at->T, hs.slab_violation ? hs.violation_T : hs.T, sizeof(hs.T));
+    at->iterations = (size_t)(hs.slab_violation ? hs.violation_iter : hs.iterations);
+    at->last_delta_norm = hs.slab_violation ? hs.violation_delta : hs.delta;
+    at->last_ncorr = (size_t)(hs.slab_violation ? hs.violation_ncorr : hs.ncorr);
+  }
   return CILHIP_OK;
 }
 

@@ -69,6 +69,12 @@ struct IcpState {
   unsigned int unproven;  // tiled search of the last iteration: queries its first stage (the octant block) did not prove
   float prev_delta;       // delta of the iteration before the last one (INFINITY before there is one)
   unsigned int listed;    // warm-started iteration: queries the nearest-other-point table did not settle (searched from their lists)
+  // slab-sharded runs: the loop state right after the update that raised slab_violation (that update is still exact -- its
+  // search ran inside the halos; the flag is about the NEXT search), so the caller can keep every iteration up to and including it
+  int violation_iter;     // iterations performed when the flag went up (0: never)
+  float violation_delta;
+  unsigned long long violation_ncorr;
+  float violation_T[16];
   float Tprev[16];        // transform_ BEFORE the last update = the transform the last executed iteration searched under: what the
                           // engine's correspondence set refers to after estimate() (correspondence_search_kd_tree.hpp:231)
 };
@@ -166,6 +172,7 @@ struct SolveArgs {
   float conv_tol, opt_conv_tol;
   float dst_mean[3], src_mean[3];
   int gn_last_step;        // finalize the outer iteration after this GN step
+  int gn_zero_steps;       // max_optimization_iterations == 0: the estimator's loop does not run, tform = t_dst * I * t_src (transform_estimation.hpp:281, :365)
   int has_normals;
   // spatially sharded runs (slab partition of target and source along one axis): after every update of the transform the
   // epilogue bounds how far ANY source point (global bounding box of the source, in source coordinates) can have moved

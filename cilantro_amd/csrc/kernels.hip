@@ -2586,6 +2586,10 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
         st->pad0 = 1;  // identity step
         st->inner_done = 1;
         for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = sums[i];
+      } else if (a.gn_zero_steps) {
+        // no Gauss-Newton step at all: the inner transform stays the identity and is un-centred below
+        st->inner_done = 1;
+        for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = sums[i];
       } else {
         // (LDS, not function-local arrays: the pivoted solve indexes them dynamically, and scratch is global memory)
         __shared__ double AtA[36], Atb[6], dth[6], wsA[36], wsy[6];
@@ -2634,7 +2638,11 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
         d += dl * a.guard_center[j];
         spread += fabsf(dl) * a.guard_half[j];
       }
-      if (!(fabsf(d) + spread <= a.guard_slack)) st->slab_violation = 1;
+      if (!(fabsf(d) + spread <= a.guard_slack) && st->slab_violation == 0) {
+        st->slab_violation = 1;
+        st->violation_iter = st->iterations; st->violation_delta = delta; st->violation_ncorr = st->ncorr;
+        for (int i = 0; i < 16; ++i) st->violation_T[i] = Tn[i];
+      }
     }
   }
   }
@@ -2676,6 +2684,8 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
   st->ncorr = 0;
   for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = 0.0;
   st->slab_violation = 0; st->unproven = 0; st->listed = 0;
+  st->violation_iter = 0; st->violation_delta = 0.0f; st->violation_ncorr = 0ull;
+  for (int i = 0; i < 16; ++i) st->violation_T[i] = ia.T[i];
   reset_inner(st);
 }
 

@@ -219,7 +219,10 @@ class SlabPartition:
     @classmethod
     def plan(cls, dst, src, T_part, max_sq_dist, world, slack=None):
         dst = np.asarray(dst, np.float32).reshape(-1, 3); src = np.asarray(src, np.float32).reshape(-1, 3)
-        lo, hi = dst.min(axis=0).astype(np.float64), dst.max(axis=0).astype(np.float64)
+        if len(dst) == 0:      # an empty target: nothing to cut -- one unbounded slab per rank boundary, no correspondences anywhere
+            lo = hi = np.zeros(3)
+        else:
+            lo, hi = dst.min(axis=0).astype(np.float64), dst.max(axis=0).astype(np.float64)
         axis = int(np.argmax(hi - lo))
         r = float(np.sqrt(max_sq_dist)) if np.isfinite(max_sq_dist) else float((hi - lo)[axis])
         slack = 2.0 * r if slack is None else float(slack)
@@ -274,6 +277,11 @@ class HipSlabEngine(HipShardEngine):
     def violated(self):
         return self.ctx.slab_violation()
 
+    def violation_state(self):
+        """-> (violated, (T, iterations, delta, ncorr) right after the update that raised the guard)"""
+        bad, r = self.ctx.slab_violation_state()
+        return bad, (np.array(r.T[:], np.float32).reshape(4, 4).T.copy(), int(r.iterations), float(r.last_delta_norm), int(r.last_ncorr))
+
 
 class SlabShardedRigidICP:
     """ICP over a slab partition: ShardedRigidICP's loop (one all-reduce of the 48 partial sums per iteration) plus the
@@ -299,11 +307,21 @@ class SlabShardedRigidICP:
             since += 1
             if since % every == 0 or base + since == total:
                 T, iters, delta, nc = self.engine.state()
-                bad = self.engine.violated()          # (the same answer on every rank: same transform, same global box)
-                # The flag is about the NEXT search (it is raised by the update that moved the source too far).  One
-                # iteration whose search ran under the partition's own transform is exact whatever the flag says: keep it --
-                # that is what guarantees progress when every update trips the guard.
-                if not bad or (fresh and since == 1):
+                # (the same answers on every rank: same transform, same global box)
+                vs = getattr(self.engine, "violation_state", None)
+                if vs is not None:
+                    bad, (Tv, iv, dv, ncv) = vs()
+                else:
+                    bad, Tv, iv, dv, ncv = self.engine.violated(), None, 0, 0.0, 0
+                # The flag is about the NEXT search: the update that raised it is still exact (its search ran inside the
+                # halos).  An engine that reports the loop state at that update lets every iteration up to and including it
+                # be kept; otherwise only a window whose single iteration ran under the partition's own transform is (that
+                # alone already guarantees progress when every update trips the guard).
+                if bad and Tv is not None and iv > 0:
+                    T_ck, base, since, fresh = Tv, begin_base + iv, 0, False
+                    if dv < params.conv_tol or base >= total:
+                        return Tv, base, dv, ncv
+                elif not bad or (fresh and since == 1):
                     T_ck, base, since, fresh = T, base + since, 0, False
                     if delta < params.conv_tol or base >= total:
                         return T, begin_base + iters, delta, nc

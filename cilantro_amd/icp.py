@@ -229,6 +229,13 @@ class Context:
         self._ck(self._L.cilhip_get_slab_violation(self._h, C.byref(v)))
         return bool(v.value)
 
+    def slab_violation_state(self):
+        """-> (violated, IcpResult): the loop state right after the update that raised the guard (still exact: the flag is about
+        the NEXT search); the current state when the guard has not fired"""
+        v = C.c_int(0); res = capi.IcpResult()
+        self._ck(self._L.cilhip_get_slab_violation_state(self._h, C.byref(v), C.byref(res)))
+        return bool(v.value), res
+
     def icp_state(self):
         res = capi.IcpResult()
         self._ck(self._L.cilhip_icp_state(self._h, C.byref(res)))

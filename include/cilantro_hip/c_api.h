@@ -197,6 +197,11 @@ int cilhip_icp_state(cilhip_ctx* ctx, cilhip_icp_result* out); /* syncs */
 int cilhip_set_slab_guard(cilhip_ctx* ctx, int axis, float slack, const float center[3], const float half_extent[3],
                           const float T_part[16]);
 int cilhip_get_slab_violation(cilhip_ctx* ctx, int* violated_out);
+/* ... and the loop state right AFTER the update that raised the flag (iterations performed, transform, update norm,
+ * correspondence count): that update is still exact -- its search ran inside the halos, the flag is about the next search --
+ * so a caller re-partitions under THAT transform and keeps every iteration up to and including it.  Not violated: the
+ * current state. */
+int cilhip_get_slab_violation_state(cilhip_ctx* ctx, int* violated, cilhip_icp_result* at_violation);
 
 /* ---- target-sharded runs (BASELINE configs[3]: one target too large / sharded over the GPUs of a node) ----
  * Every rank holds ALL source points and ONE shard of the target (set with cilhip_set_target) plus

@@ -160,16 +160,22 @@ class OracleSlabEngine(OracleShardEngine):
     def begin(self, params, T0, gmean):
         super().begin(params, T0, self.gsm)
         self.viol = False
+        self.viol_state = None
 
     def apply_sums(self, sums):
         super().apply_sums(sums)
         pt, ax = self.part, self.part.axis
         dl = self.T[ax, :3].astype(np.float32) - pt.T_part[ax, :3]
         bound = abs(float(self.T[ax, 3] - pt.T_part[ax, 3] + dl @ pt.src_center)) + float(np.abs(dl) @ pt.src_half)
-        self.viol |= not (bound <= pt.slack)
+        if not (bound <= pt.slack) and not self.viol:
+            self.viol = True
+            self.viol_state = self.state()          # (cilhip_get_slab_violation_state: the loop state at the update that raised the flag)
 
     def violated(self):
         return self.viol
+
+    def violation_state(self):
+        return self.viol, (self.viol_state if self.viol else self.state())
 
 
 def main_slab(metric, n, slack_cells):

@@ -231,6 +231,24 @@ def test_icp_combined_weights_and_gn_steps(orc, hip_lib):
         r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
         err = np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64))
         assert err <= TOL_T, (w_p2p, w_p2pl, steps, err)
+    # max_optimization_iterations = 0: the estimator's loop body never runs, tform = t_dst * I * t_src (transform_estimation.hpp:281,
+    # :365) -- every outer iteration translates the source's mean onto the target's; tiled and per-lane forms, the pair-list directions
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D
+    dz = syn.make_pair(1_200_000, perturb=0.5)
+    for dd, opts, direction in ((d, (), D.SECOND_TO_FIRST), (dz, (("tiled", 2),), D.SECOND_TO_FIRST), (d, (), D.BOTH), (d, (), D.FIRST_TO_SECOND)):
+        icp = SimpleCombinedMetricRigidICP3f(dd["dst"], dd["dst_n"], dd["src"])
+        for k, v in opts:
+            icp._ctx.set_option(k, v)
+        icp.setMaxNumberOfOptimizationStepIterations(0)
+        icp.correspondenceSearchEngine().setMaxDistance(dd["max_sq_dist"]).setSearchDirection(direction)
+        icp.setMaxNumberOfIterations(3).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, max_iter=3, conv_tol=0.0, max_opt_iter=0, max_sq_dist=dd["max_sq_dist"], mode=orc.MODE_MIXED,
+                            direction={D.SECOND_TO_FIRST: 0, D.FIRST_TO_SECOND: 1, D.BOTH: 2}[direction])
+        r = orc.icp_run(dd["dst"], dd["dst_n"], dd["src"], p)
+        err = np.linalg.norm(Tg.astype(np.float64) - r["T"].astype(np.float64))
+        assert err <= TOL_T and icp.getNumberOfPerformedIterations() == 3 and icp.last_ncorr_ == r["last_ncorr"], (direction, err)
+        assert np.array_equal(Tg[:3, :3], np.eye(3, dtype=np.float32))            # a pure translation
 
 
 def test_icp_degenerate_inputs(hip_lib):
