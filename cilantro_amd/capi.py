@@ -25,8 +25,8 @@ SYMBOLS = [
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
     "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing", "cilhip_prepare_source", "cilhip_get_last_run_forms", "cilhip_get_last_warm_iterations", "cilhip_get_last_matches_origin", "cilhip_get_matches_transform", "cilhip_get_last_form_timing", "cilhip_set_slab_guard", "cilhip_get_slab_violation", "cilhip_get_slab_violation_state",
     "cilhip_set_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
-    "cilhip_icp_sums_from_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign",
-    "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f", "cilhip_knn3f", "cilhip_normals_knn3f", "cilhip_normals_radius3f", "cilhip_radius_search3f",
+    "cilhip_icp_sums_from_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign", "cilhip_kmeans3f_ex", "cilhip_kmeans3f_assign_ex",
+    "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f", "cilhip_transform_ransac3f", "cilhip_transform_score3f", "cilhip_transform_fit3f", "cilhip_knn3f", "cilhip_normals_knn3f", "cilhip_normals_radius3f", "cilhip_radius_search3f",
 ]
 
 
@@ -56,6 +56,13 @@ class GridInfo(C.Structure):
 class PlaneModel(C.Structure):
     _fields_ = [
         ("normal", C.c_float * 3), ("offset", C.c_float), ("iterations", C.c_size_t), ("n_inliers", C.c_size_t),
+        ("target_reached", C.c_int), ("device_ms", C.c_double),
+    ]
+
+
+class TransformModel(C.Structure):
+    _fields_ = [
+        ("T", C.c_float * 16), ("iterations", C.c_size_t), ("n_inliers", C.c_size_t), ("have_model", C.c_int),
         ("target_reached", C.c_int), ("device_ms", C.c_double),
     ]
 
@@ -118,10 +125,16 @@ def load():
     L.cilhip_debug_counters.argtypes = [vp, vp]
     L.cilhip_kmeans3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_float, vp, C.POINTER(C.c_size_t)]
     L.cilhip_kmeans3f_assign.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, vp]
+    L.cilhip_kmeans3f_ex.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_int, vp, C.POINTER(C.c_size_t)]
+    L.cilhip_kmeans3f_assign_ex.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_int, vp]
     L.cilhip_plane_ransac3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, vp, C.c_uint64, C.c_float, C.c_size_t, C.c_size_t,
                                         C.c_int, C.POINTER(PlaneModel), vp, vp]
     L.cilhip_plane_score3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_float, vp]
     L.cilhip_plane_fit3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p]
+    L.cilhip_transform_ransac3f.argtypes = [C.c_int, f32p, f32p, C.c_size_t, C.c_int, vp, C.c_uint64, C.c_float, C.c_size_t, C.c_size_t,
+                                            C.c_int, C.POINTER(TransformModel), vp, vp]
+    L.cilhip_transform_score3f.argtypes = [C.c_int, f32p, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_float, vp]
+    L.cilhip_transform_fit3f.argtypes = [C.c_int, f32p, f32p, C.c_size_t, C.c_int, f32p]
     L.cilhip_knn3f.argtypes = [C.c_int, f32p, C.c_size_t, f32p, C.c_size_t, C.c_int, C.c_size_t, C.c_float, vp, vp, vp]
     L.cilhip_normals_radius3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, C.c_float, f32p, f32p, f32p]
     L.cilhip_radius_search3f.argtypes = [C.c_int, f32p, C.c_size_t, f32p, C.c_size_t, C.c_int, C.c_float, vp, vp, vp, C.c_size_t,

@@ -5,8 +5,9 @@
     km.cluster(num_clusters, ...)                               # :32-53 (random initial centroids)
     km.getClusterCentroids(); km.getPointToClusterIndexMap(); km.getClusterToPointIndicesMap()
 
-`use_kd_tree=True` (kd-tree assignment) is not implemented: it is a CPU acceleration of the same argmin
-and returns the same labels up to ties; the GPU path always does the exact brute-force argmin.
+`use_kd_tree=True` (kmeans.hpp:86-94, the mode examples/kmeans.cpp uses): a kd-tree over the centroids only accelerates the same
+nearest-centroid search, so the device runs the same exhaustive pass -- with the distance rounded as nanoflann's L2 metric rounds
+it (((dx*dx)+(dy*dy))+(dz*dz)), so labels equal that branch's wherever the nearest centroid is unique.
 """
 import ctypes as C
 
@@ -26,8 +27,6 @@ class KMeans3f:
         self.iteration_count_ = 0
 
     def cluster(self, centroids_or_k, max_iter=100, tol=float(np.finfo(np.float32).eps), use_kd_tree=False, seed=None):
-        if use_kd_tree:
-            raise NotImplementedError("the GPU path always runs the exact brute-force assignment")
         p, n, mem, keep = _as_cloud(self._data)
         if np.isscalar(centroids_or_k):
             # kmeans.hpp:32-53 draws distinct random points (std::random_device): same law, numpy generator
@@ -39,8 +38,8 @@ class KMeans3f:
             cent = np.ascontiguousarray(centroids_or_k, np.float32).reshape(-1, 3).copy()
         labels = np.zeros(n, np.uint32)
         iters = C.c_size_t(0)
-        rc = self._L.cilhip_kmeans3f(self._device, p, n, mem, cent.ctypes.data, len(cent), int(max_iter), C.c_float(tol),
-                                     labels.ctypes.data, C.byref(iters))
+        rc = self._L.cilhip_kmeans3f_ex(self._device, p, n, mem, cent.ctypes.data, len(cent), int(max_iter), C.c_float(tol), int(bool(use_kd_tree)),
+                                        labels.ctypes.data, C.byref(iters))
         if rc != capi.OK:
             raise capi.CilhipError(rc, "cilhip_kmeans3f failed (no HIP device, k > 2048, or bad arguments)")
         self.cluster_centroids_ = cent
@@ -67,12 +66,12 @@ class KMeans3f:
         return np.split(order, np.cumsum(counts)[:-1])
 
 
-def kmeans_assign(data, centroids, device=0):
+def kmeans_assign(data, centroids, device=0, use_kd_tree=False):
     L = capi.load()
     p, n, mem, keep = _as_cloud(data)
     cent = np.ascontiguousarray(centroids, np.float32).reshape(-1, 3)
     labels = np.zeros(n, np.uint32)
-    rc = L.cilhip_kmeans3f_assign(device, p, n, mem, cent.ctypes.data, len(cent), labels.ctypes.data)
+    rc = L.cilhip_kmeans3f_assign_ex(device, p, n, mem, cent.ctypes.data, len(cent), int(bool(use_kd_tree)), labels.ctypes.data)
     if rc != capi.OK:
         raise capi.CilhipError(rc, "cilhip_kmeans3f_assign failed")
     return labels.astype(np.int64)

@@ -35,6 +35,10 @@ struct KmArgs {
   int accumulate;
 };
 
+// KD: the distance the reference's kd-tree branch compares (use_kd_tree = true, kmeans.hpp:86-94: a KDTree over the centroids,
+// nanoflann's L2 metric) -- ((dx*dx) + (dy*dy)) + (dz*dz) -- instead of the brute-force branch's Eigen squaredNorm pairing
+// dx*dx + (dy*dy + dz*dz) (:107).  Same argmin except where two centroids are equidistant to within that rounding.
+template <bool KD>
 __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
   extern __shared__ long long lsum[];  // [k*4]
   if (a.accumulate) {
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
       for (int u = 0; u < 8; ++u) {
         const float cx = c[3 * u], cy = c[3 * u + 1], cz = c[3 * u + 2];
         const f32x2 dx = (f32x2){cx, cx} - px, dy = (f32x2){cy, cy} - py, dz = (f32x2){cz, cz} - pz;
-        const f32x2 d = dx * dx + (dy * dy + dz * dz);     // d0*d0 + (d1*d1 + d2*d2), -ffp-contract=off
+        const f32x2 d = KD ? (dx * dx + dy * dy) + dz * dz : dx * dx + (dy * dy + dz * dz);     // (-ffp-contract=off)
         if (d.x < best.x) { best.x = d.x; b0 = j + u; }
         if (d.y < best.y) { best.y = d.y; b1 = j + u; }
       }
@@ -119,7 +123,7 @@ __global__ void k_set_label(uint32_t* labels, uint32_t i, uint32_t v) { if (thre
 #define KM_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = CILHIP_ERR_HIP; goto done; } } while (0)
 
 int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
-                uint32_t* labels_out, size_t* iterations_out, bool assign_only) {
+                uint32_t* labels_out, size_t* iterations_out, bool assign_only, bool kd_order = false) {
   if (!xyz || !centroids || k == 0 || n == 0 || n >= 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
   if (k > KM_MAX_K) return CILHIP_ERR_UNSUPPORTED;
   int ndev = 0;
@@ -179,7 +183,8 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
       KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
       KM_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
       KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1};
-      hipLaunchKernelGGL(k_assign_accumulate, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
+      if (kd_order) hipLaunchKernelGGL(k_assign_accumulate<true>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
+      else hipLaunchKernelGGL(k_assign_accumulate<false>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
       KM_CK(hipGetLastError());
       if (assign_only) break;
       unsigned int changed = 0;
@@ -249,6 +254,15 @@ int cilhip_kmeans3f(int device, const float* xyz, size_t n, int mem, float* cent
 
 int cilhip_kmeans3f_assign(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k, uint32_t* labels_out) {
   return kmeans_impl(device, xyz, n, mem, const_cast<float*>(centroids), k, 1, 0.0f, labels_out, nullptr, true);
+}
+
+int cilhip_kmeans3f_ex(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol, int use_kd_tree,
+                       uint32_t* labels_out, size_t* iterations_out) {
+  return kmeans_impl(device, xyz, n, mem, centroids, k, max_iter, tol, labels_out, iterations_out, false, use_kd_tree != 0);
+}
+
+int cilhip_kmeans3f_assign_ex(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k, int use_kd_tree, uint32_t* labels_out) {
+  return kmeans_impl(device, xyz, n, mem, const_cast<float*>(centroids), k, 1, 0.0f, labels_out, nullptr, true, use_kd_tree != 0);
 }
 
 }  // extern "C"

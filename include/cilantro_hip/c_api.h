@@ -238,6 +238,15 @@ int cilhip_kmeans3f(int device, const float* xyz, size_t n, int mem, float* cent
 /* one assignment pass only (kmeans.hpp:95-119) */
 int cilhip_kmeans3f_assign(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k,
                            uint32_t* labels_out);
+/* ... with the reference's `use_kd_tree` argument (clustering/kmeans.hpp:24-30, branch :86-94 -- the mode examples/kmeans.cpp
+ * uses): a kd-tree over the centroids is only a way of finding the same nearest centroid, so the device runs the same exhaustive
+ * pass; what the flag changes is the ROUNDING of the compared distance -- nanoflann's L2 metric ((dx*dx)+(dy*dy))+(dz*dz)
+ * instead of Eigen's squaredNorm pairing of the brute-force branch -- so that labels equal the reference's kd-tree branch
+ * wherever its nearest centroid is unique (exactly equidistant centroids: lowest index here, first met in the tree there). */
+int cilhip_kmeans3f_ex(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol, int use_kd_tree,
+                       uint32_t* labels_out, size_t* iterations_out);
+int cilhip_kmeans3f_assign_ex(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k, int use_kd_tree,
+                              uint32_t* labels_out);
 
 /* ---- next tier: PlaneRANSACEstimator3f ----------------------------------- */
 typedef struct {
@@ -268,6 +277,32 @@ int cilhip_plane_score3f(int device, const float* xyz, size_t n, int mem, const 
                          float max_residual, uint32_t* counts_out);
 /* estimateModel() over ALL points (ransac_hyperplane_estimator.hpp:22-25, :70-76): PCA plane fit. */
 int cilhip_plane_fit3f(int device, const float* xyz, size_t n, int mem, float plane_out[4]);
+
+/* ---- RigidTransformRANSACEstimator3f (model_estimation/ransac_transform_estimator.hpp, SURVEY.md section 2 "next tier") ---- */
+typedef struct cilhip_transform_model {
+  float T[16];         /* getModel(): col-major 4x4 rigid transform mapping src onto dst (identity when nothing was estimated) */
+  size_t iterations;   /* getNumberOfPerformedIterations()                                                   */
+  size_t n_inliers;    /* getModelInliers().size()                                                           */
+  int have_model;      /* bit 0: some hypothesis was accepted (>= sample_size inliers), bit 1: re-estimated  */
+  int target_reached;  /* targetInlierCountAchieved()        (ransac_base.hpp:172)                           */
+  double device_ms;    /* kernels only, HIP events                                                           */
+} cilhip_transform_model;
+/* TransformRANSACEstimator<RigidTransform<float,3>>::estimate() over n point PAIRS (dst_xyz[i], src_xyz[i]) -- the
+ * reference's constructors gather them from a correspondence set or two index lists (ransac_transform_estimator.hpp:34-59);
+ * estimateModel = estimateTransformPointToPointMetric of the sampled pairs (:75-83; registration/transform_estimation.hpp:11-48),
+ * residual_i = |T * src_i - dst_i| (:90-98), loop / replay / re-estimation as ransac_base.hpp:64-131.
+ * samples: HOST, 3 * max_iter pair indices (the sample of every iteration, in order) or NULL to draw them here from `seed`.
+ * Defaults of the reference (:27-30): sample size 3, target ceil(n / 2), 100 iterations, max residual 0.01, re-estimate.
+ * residuals_out: HOST, n floats or NULL.  inliers_out: HOST, capacity n, ascending pair indices, or NULL.
+ * No accepted model and no re-estimation => identity, no inliers (the reference's model is then uninitialised). */
+int cilhip_transform_ransac3f(int device, const float* dst_xyz, const float* src_xyz, size_t n, int mem, const uint32_t* samples, uint64_t seed,
+                              float max_residual, size_t target_inliers, size_t max_iter, int re_estimate, cilhip_transform_model* out,
+                              float* residuals_out, uint32_t* inliers_out);
+/* inlier counts of m given transforms (HOST, 16 * m floats, col-major 4x4 each), one pass over the pairs per 64 transforms */
+int cilhip_transform_score3f(int device, const float* dst_xyz, const float* src_xyz, size_t n, int mem, const float* transforms, size_t m,
+                             float max_residual, uint32_t* counts_out);
+/* estimateModel() over ALL pairs (ransac_transform_estimator.hpp:61-64): the closed-form rigid fit */
+int cilhip_transform_fit3f(int device, const float* dst_xyz, const float* src_xyz, size_t n, int mem, float T_out[16]);
 
 /* ---- next tier: k-NN (k > 1) and NormalEstimation ------------------------- */
 /* KDTree<float,3,L2>::kNNSearch / kNNInRadiusSearch for a set of queries (core/kd_tree.hpp:216-256, :286-318;

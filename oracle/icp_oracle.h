@@ -203,6 +203,9 @@ size_t orc_filter_one_to_one_f2s(int64_t* di, int64_t* si, float* d2, size_t n);
 /* ---- kmeans_oracle.c: KMeans<float,3> brute-force path (clustering/kmeans.hpp:67-194) ---- */
 size_t orc_kmeans_assign(const float* x, size_t n, const float* c, size_t k, int64_t* labels);
 size_t orc_kmeans(const float* x, size_t n, float* c, size_t k, size_t max_iter, float tol, int mode, int64_t* labels);
+/* the use_kd_tree = true branch (kmeans.hpp:86-94) */
+size_t orc_kmeans_assign_kd(const float* x, size_t n, const float* c, size_t k, int64_t* labels);
+size_t orc_kmeans_kd(const float* x, size_t n, float* c, size_t k, size_t max_iter, float tol, int mode, int64_t* labels);
 
 /* ---- ransac_oracle.c: PlaneRANSACEstimator3f (model_estimation/ransac_base.hpp:64-131) ---- */
 void orc_sym_eig3(const double A[9], double w[3], double V[9]);
@@ -213,6 +216,14 @@ void orc_plane_fit(const float* pts, const uint32_t* idx, size_t m, int mode, fl
 size_t orc_plane_ransac(const float* pts, size_t n, const uint32_t* samples, size_t max_iter, float thresh,
                         size_t target_inliers, int re_estimate, int mode, float plane[4], float* residuals,
                         uint32_t* inliers, size_t* n_inliers);
+
+/* RigidTransformRANSACEstimator3f (model_estimation/ransac_transform_estimator.hpp) over point pairs; T col-major 4x4 */
+void orc_transform_residuals(const float* dst, const float* src, size_t n, const float T[16], float* res);
+size_t orc_transform_count_inliers(const float* dst, const float* src, size_t n, const float T[16], float thresh);
+void orc_transform_fit(const float* dst, const float* src, const uint32_t* idx, size_t m, int mode, float T[16]);
+size_t orc_transform_ransac(const float* dst, const float* src, size_t n, const uint32_t* samples, size_t max_iter, float thresh,
+                            size_t target_inliers, int re_estimate, int mode, float T[16], float* residuals, uint32_t* inliers,
+                            size_t* n_inliers, int* have_model);
 
 /* ---- normals_oracle.c: k-NN batch + NormalEstimation (core/normal_estimation.hpp:294-420) ---- */
 void orc_knn_batch(const orc_kdtree* t, const float* q, size_t nq, size_t k, float radius_sq, int64_t* idx, float* d2, uint32_t* cnt);

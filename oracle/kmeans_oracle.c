@@ -12,6 +12,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "icp_oracle.h"
+
 /* (c - x).squaredNorm(): Eigen's unrolled 3-term redux pairing d0*d0 + (d1*d1 + d2*d2), f32, no contraction */
 static inline float sqn(const float* c, const float* x) {
   const float d0 = c[0] - x[0], d1 = c[1] - x[1], d2 = c[2] - x[2];
@@ -35,8 +37,33 @@ size_t orc_kmeans_assign(const float* x, size_t n, const float* c, size_t k, int
   return changed;
 }
 
+/* kmeans.hpp:86-94, the use_kd_tree branch: a KDTree over the centroids (core/kd_tree.hpp, leaf 10), nearestNeighborSearch per
+ * point (:181-185 -> nanoflann knnSearch, k = 1: first met wins ties); the pinned kd-tree restatement of icp_oracle.c. */
+size_t orc_kmeans_assign_kd(const float* x, size_t n, const float* c, size_t k, int64_t* labels) {
+  orc_kdtree* t = orc_kdtree_build(c, k, 10);
+  int64_t* idx = (int64_t*)malloc((n ? n : 1) * sizeof(int64_t));
+  float* d2 = (float*)malloc((n ? n : 1) * sizeof(float));
+  uint32_t* cnt = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+  orc_knn_batch(t, x, n, 1, INFINITY, idx, d2, cnt);
+  size_t changed = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (labels[i] != idx[i]) ++changed;
+    labels[i] = idx[i];
+  }
+  free(idx); free(d2); free(cnt);
+  orc_kdtree_free(t);
+  return changed;
+}
+
+static size_t kmeans_impl(const float* x, size_t n, float* c, size_t k, size_t max_iter, float tol, int mode, int use_kd, int64_t* labels);
 /* kmeans.hpp:67-194.  centroids: in = initial, out = final (3*k floats). labels: n, caller-zeroed (:80 resize). */
 size_t orc_kmeans(const float* x, size_t n, float* c, size_t k, size_t max_iter, float tol, int mode, int64_t* labels) {
+  return kmeans_impl(x, n, c, k, max_iter, tol, mode, 0, labels);
+}
+size_t orc_kmeans_kd(const float* x, size_t n, float* c, size_t k, size_t max_iter, float tol, int mode, int64_t* labels) {
+  return kmeans_impl(x, n, c, k, max_iter, tol, mode, 1, labels);
+}
+static size_t kmeans_impl(const float* x, size_t n, float* c, size_t k, size_t max_iter, float tol, int mode, int use_kd, int64_t* labels) {
   const float tol_sq = tol * tol;
   float* c_old = (float*)malloc(3 * k * sizeof(float));
   float* sf = (float*)malloc(3 * k * sizeof(float));
@@ -44,7 +71,7 @@ size_t orc_kmeans(const float* x, size_t n, float* c, size_t k, size_t max_iter,
   size_t* cnt = (size_t*)malloc(k * sizeof(size_t));
   size_t iter = 0;
   while (iter < max_iter) {
-    const size_t changed = orc_kmeans_assign(x, n, c, k, labels);
+    const size_t changed = use_kd ? orc_kmeans_assign_kd(x, n, c, k, labels) : orc_kmeans_assign(x, n, c, k, labels);
     if (changed == 0 && iter > 0) break;                                   /* :122 */
     if (tol > 0.0f) memcpy(c_old, c, 3 * k * sizeof(float));               /* :123 */
     memset(sf, 0, 3 * k * sizeof(float)); memset(sd, 0, 3 * k * sizeof(double)); memset(cnt, 0, k * sizeof(size_t));

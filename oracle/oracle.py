@@ -133,6 +133,10 @@ def lib():
         L.orc_kmeans_assign.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _i64p]
         L.orc_kmeans.restype = C.c_size_t
         L.orc_kmeans.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_int, _i64p]
+        L.orc_kmeans_assign_kd.restype = C.c_size_t
+        L.orc_kmeans_assign_kd.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, _i64p]
+        L.orc_kmeans_kd.restype = C.c_size_t
+        L.orc_kmeans_kd.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_int, _i64p]
         L.orc_sym_eig3.argtypes = [_f64p, _f64p, _f64p]
         L.orc_plane_residuals.argtypes = [_f32p, C.c_size_t, _f32p, _f32p]
         L.orc_plane_count_inliers.restype = C.c_size_t
@@ -143,6 +147,13 @@ def lib():
         L.orc_plane_ransac.restype = C.c_size_t
         L.orc_plane_ransac.argtypes = [_f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
                                        _f32p, _f32p, _u32p, C.POINTER(C.c_size_t)]
+        L.orc_transform_residuals.argtypes = [_f32p, _f32p, C.c_size_t, _f32p, _f32p]
+        L.orc_transform_count_inliers.restype = C.c_size_t
+        L.orc_transform_count_inliers.argtypes = [_f32p, _f32p, C.c_size_t, _f32p, C.c_float]
+        L.orc_transform_fit.argtypes = [_f32p, _f32p, C.c_void_p, C.c_size_t, C.c_int, _f32p]
+        L.orc_transform_ransac.restype = C.c_size_t
+        L.orc_transform_ransac.argtypes = [_f32p, _f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
+                                           _f32p, _f32p, _u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         L.orc_find_correspondences_dir.restype = C.c_size_t
         L.orc_find_correspondences_dir.argtypes = [_f32p, C.c_size_t, C.c_void_p, _f32p, C.c_size_t, C.c_float, C.c_int, C.c_int,
                                                    _i64p, _i64p, _f32p, C.c_int]
@@ -435,19 +446,19 @@ def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params, src_n=None, val
     return T_from_colmajor(Tn), float(d)
 
 
-def kmeans_assign(x, centroids, labels=None):
-    """clustering/kmeans.hpp:95-119 -> (labels int64, number changed)"""
+def kmeans_assign(x, centroids, labels=None, use_kd_tree=False):
+    """clustering/kmeans.hpp:95-119 (use_kd_tree: :86-94, a kd-tree over the centroids) -> (labels int64, number changed)"""
     x = _c(x).reshape(-1, 3); c = _c(centroids).reshape(-1, 3)
     lab = np.zeros(len(x), np.int64) if labels is None else _c(labels, np.int64).copy()
-    ch = lib().orc_kmeans_assign(x, len(x), c, len(c), lab)
+    ch = (lib().orc_kmeans_assign_kd if use_kd_tree else lib().orc_kmeans_assign)(x, len(x), c, len(c), lab)
     return lab, int(ch)
 
 
-def kmeans(x, centroids, max_iter=100, tol=np.finfo(np.float32).eps, mode=1):
-    """KMeans<float,3>::cluster(centroids, max_iter, tol, false) -> (centroids, labels, iterations)"""
+def kmeans(x, centroids, max_iter=100, tol=np.finfo(np.float32).eps, mode=1, use_kd_tree=False):
+    """KMeans<float,3>::cluster(centroids, max_iter, tol, use_kd_tree) -> (centroids, labels, iterations)"""
     x = _c(x).reshape(-1, 3); c = _c(centroids).reshape(-1, 3).copy()
     lab = np.zeros(len(x), np.int64)
-    it = lib().orc_kmeans(x, len(x), c, len(c), max_iter, np.float32(tol), mode, lab)
+    it = (lib().orc_kmeans_kd if use_kd_tree else lib().orc_kmeans)(x, len(x), c, len(c), max_iter, np.float32(tol), mode, lab)
     return c, lab, int(it)
 
 
@@ -498,6 +509,41 @@ def plane_ransac(pts, samples, thresh, target_inliers, max_iter=None, re_estimat
     it = lib().orc_plane_ransac(pts, n, samples, max_iter, np.float32(thresh), target_inliers, int(re_estimate), mode,
                                 pl, res, inl, C.byref(k))
     return pl, res, inl[:k.value].copy(), int(it)
+
+
+# ---- RigidTransformRANSACEstimator3f over point pairs (model_estimation/ransac_transform_estimator.hpp) ----------------------
+def transform_residuals(dst, src, T):
+    dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3); res = np.zeros(len(dst), np.float32)
+    lib().orc_transform_residuals(dst, src, len(dst), T_to_colmajor(T), res)
+    return res
+
+
+def transform_count_inliers(dst, src, T, thresh):
+    dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3)
+    return int(lib().orc_transform_count_inliers(dst, src, len(dst), T_to_colmajor(T), np.float32(thresh)))
+
+
+def transform_fit(dst, src, idx=None, mode=1):
+    """estimateModel (ransac_transform_estimator.hpp:61-83) -> 4x4 rigid transform mapping src onto dst"""
+    dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3); T = np.zeros(16, np.float32)
+    if idx is None:
+        lib().orc_transform_fit(dst, src, None, len(dst), mode, T)
+    else:
+        idx = np.ascontiguousarray(idx, np.uint32)
+        lib().orc_transform_fit(dst, src, idx.ctypes.data, len(idx), mode, T)
+    return T_from_colmajor(T)
+
+
+def transform_ransac(dst, src, samples, thresh, target_inliers, max_iter=None, re_estimate=True, mode=1):
+    """RandomSampleConsensusBase::estimate() -> (T 4x4, residuals, inliers, iterations, have_model bits)"""
+    dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3); n = len(dst)
+    samples = np.ascontiguousarray(samples, np.uint32).reshape(-1, 3)
+    max_iter = len(samples) if max_iter is None else max_iter
+    T = np.zeros(16, np.float32); res = np.zeros(max(n, 1), np.float32); inl = np.zeros(max(n, 1), np.uint32)
+    k = C.c_size_t(0); have = C.c_int(0)
+    it = lib().orc_transform_ransac(dst, src, n, samples if len(samples) else np.zeros((1, 3), np.uint32), max_iter, np.float32(thresh), target_inliers,
+                                    int(re_estimate), mode, T, res, inl, C.byref(k), C.byref(have))
+    return T_from_colmajor(T), res[:n], inl[:k.value].copy(), int(it), have.value
 
 
 # ---- k-NN batch + NormalEstimation (core/kd_tree.hpp kNNSearch, core/normal_estimation.hpp) -------------

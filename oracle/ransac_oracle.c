@@ -25,6 +25,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "icp_oracle.h"
+
 /* cyclic Jacobi for a symmetric 3x3 (row-major).  V columns = eigenvectors, sorted by DESCENDING eigenvalue
  * (principal_component_analysis.hpp:78,83 reverse Eigen's ascending order); if det(V) < 0 the LAST column
  * is negated (:79-82). */
@@ -194,6 +196,79 @@ size_t orc_plane_ransac(const float* pts, size_t n, const uint32_t* samples, siz
   if (residuals) orc_plane_residuals(pts, n, best, residuals);
   if (inliers) memcpy(inliers, inl, k * sizeof(uint32_t));
   *n_inliers = k;
+  free(inl);
+  return it;
+}
+
+/* ---- RigidTransformRANSACEstimator3f (model_estimation/ransac_transform_estimator.hpp) over n point PAIRS ------------------
+ * computeResiduals (:90-98): residual_i = (model_params * src_i - dst_i).norm() in f32 -- T * s with Eigen's unrolled 3-term
+ * pairing (x L0 + (y L1 + z L2)) + t (the pinned transform expression of the whole engine), the difference, squaredNorm as
+ * e0*e0 + (e1*e1 + e2*e2), sqrtf; no FMA contraction (-ffp-contract=off).  T: col-major 4x4. */
+static inline float tf_residual(const float T[16], const float* s, const float* d) {
+  const float qx = (T[0] * s[0] + (T[4] * s[1] + T[8] * s[2])) + T[12];
+  const float qy = (T[1] * s[0] + (T[5] * s[1] + T[9] * s[2])) + T[13];
+  const float qz = (T[2] * s[0] + (T[6] * s[1] + T[10] * s[2])) + T[14];
+  const float e0 = qx - d[0], e1 = qy - d[1], e2 = qz - d[2];
+  return sqrtf(e0 * e0 + (e1 * e1 + e2 * e2));
+}
+
+void orc_transform_residuals(const float* dst, const float* src, size_t n, const float T[16], float* res) {
+  for (size_t i = 0; i < n; ++i) res[i] = tf_residual(T, src + 3 * i, dst + 3 * i);
+}
+
+size_t orc_transform_count_inliers(const float* dst, const float* src, size_t n, const float T[16], float thresh) {
+  size_t k = 0;
+  for (size_t i = 0; i < n; ++i) k += tf_residual(T, src + 3 * i, dst + 3 * i) <= thresh;
+  return k;
+}
+
+/* estimateModel(sample_ind, .) (:75-83) / estimateModel() (:61-64): estimateTransformPointToPointMetric of the selected pairs
+ * (registration/transform_estimation.hpp:11-48, restated in estimator_impl.inc).  idx == NULL: all pairs 0..m-1. */
+void orc_transform_fit(const float* dst, const float* src, const uint32_t* idx, size_t m, int mode, float T[16]) {
+  int64_t* ii = (int64_t*)malloc((m ? m : 1) * sizeof(int64_t));
+  for (size_t k = 0; k < m; ++k) ii[k] = idx ? (int64_t)idx[k] : (int64_t)k;
+  orc_estimate_p2p(dst, src, ii, ii, m, mode, T, NULL);
+  free(ii);
+}
+
+/* RandomSampleConsensusBase::estimate() (ransac_base.hpp:64-131) for the rigid transform estimator: sample size 3
+ * (MinSampleSize = Dim, ransac_transform_estimator.hpp:20-23).  Returns the iterations performed; *have_model bit 0: some
+ * hypothesis was accepted, bit 1: re-estimated.  No accepted model and no re-estimation: identity, no inliers (the
+ * reference's model_params_ is then an uninitialised Eigen transform). */
+size_t orc_transform_ransac(const float* dst, const float* src, size_t n, const uint32_t* samples, size_t max_iter, float thresh,
+                            size_t target_inliers, int re_estimate, int mode, float T[16], float* residuals, uint32_t* inliers,
+                            size_t* n_inliers, int* have_model) {
+  size_t sample_size = 3;
+  if (n < sample_size) sample_size = n;             /* :67 */
+  if (target_inliers > n) target_inliers = n;       /* :68 */
+  float best[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  size_t best_cnt = 0, it = 0;
+  int have = 0;
+  while (it < max_iter) {
+    float cur[16];
+    orc_transform_fit(dst, src, samples + 3 * it, sample_size, mode, cur);       /* :94 */
+    const size_t cnt = orc_transform_count_inliers(dst, src, n, cur, thresh);     /* :95-101 */
+    ++it;                                                                         /* :103 */
+    if (cnt < sample_size) continue;                                              /* :104 */
+    if (cnt > best_cnt) { memcpy(best, cur, sizeof best); best_cnt = cnt; have = 1; } /* :107-111 */
+    if (best_cnt >= target_inliers) break;                                        /* :114 */
+  }
+  uint32_t* inl = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+  size_t k = 0;
+  for (size_t i = 0; i < n && have; ++i)
+    if (tf_residual(best, src + 3 * i, dst + 3 * i) <= thresh) inl[k++] = (uint32_t)i;
+  if (re_estimate) {                                                              /* :118-128 */
+    orc_transform_fit(dst, src, inl, k, mode, best);
+    have |= 2;
+    k = 0;
+    for (size_t i = 0; i < n; ++i)
+      if (tf_residual(best, src + 3 * i, dst + 3 * i) <= thresh) inl[k++] = (uint32_t)i;
+  }
+  memcpy(T, best, sizeof best);
+  if (residuals) orc_transform_residuals(dst, src, n, best, residuals);
+  if (inliers) memcpy(inliers, inl, k * sizeof(uint32_t));
+  if (n_inliers) *n_inliers = k;
+  if (have_model) *have_model = have;
   free(inl);
   return it;
 }

@@ -127,6 +127,43 @@ int main(int argc, char** argv) {
     }
     std::printf("k-NN: %zu mismatches vs oracle over %zu queries; normals: %zu of %zu well-defined ones differ\n", kbad, nq, nbad, nwell);
     if (kbad > 2 || nbad * 1000 > nwell) ++failures;
+    {
+      // RigidTransformRANSACEstimator3f (ransac_transform_estimator.hpp) through its index-list constructor: a known motion with
+      // 30 % gross outliers; iteration count and model against the oracle's restatement with the same samples, the model's own
+      // residuals / inliers bit for bit
+      const size_t m = 40000;
+      std::vector<float> d3(3 * m), s3(3 * m);
+      const float ca = std::cos(0.3f), sa = std::sin(0.3f);
+      for (size_t i = 0; i < m; ++i) {
+        const float px = u01(77, 3 * i), py = u01(77, 3 * i + 1), pz = u01(77, 3 * i + 2);
+        s3[3 * i] = px; s3[3 * i + 1] = py; s3[3 * i + 2] = pz;
+        d3[3 * i] = ca * px - sa * py + 0.2f; d3[3 * i + 1] = sa * px + ca * py - 0.1f; d3[3 * i + 2] = pz + 0.05f;
+        if (u01(78, i) < 0.3f) { d3[3 * i] += 1.0f + u01(79, i); d3[3 * i + 2] -= 0.7f; }
+      }
+      std::vector<size_t> ia(m), ib(m);
+      for (size_t i = 0; i < m; ++i) ia[i] = ib[i] = i;
+      std::vector<uint32_t> samples(3 * 60);
+      for (size_t i = 0; i < samples.size(); ++i) samples[i] = (uint32_t)(u01(80, i) * m) % (uint32_t)m;
+      RigidTransformRANSACEstimator3f te(ConstPointsView(d3.data(), m), ConstPointsView(s3.data(), m), ia, ib);
+      te.setMaxInlierResidual(1e-3f).setTargetInlierCount(m / 2).setMaxNumberOfIterations(60).setSamples(samples);
+      const RigidTransform3f Tm = te.estimate().getModel();
+      float To[16]; std::vector<float> ores(m); std::vector<uint32_t> oinl(m); size_t ok = 0; int ohave = 0;
+      const size_t oit = orc_transform_ransac(d3.data(), s3.data(), m, samples.data(), 60, 1e-3f, m / 2, 1, ORC_MODE_MIXED, To, ores.data(), oinl.data(), &ok, &ohave);
+      double dmax = 0.0;
+      for (int i = 0; i < 16; ++i) dmax = std::fmax(dmax, std::fabs((double)Tm.m[i] - (double)To[i]));
+      std::vector<float> chk(m);
+      orc_transform_residuals(d3.data(), s3.data(), m, Tm.m, chk.data());
+      size_t tbad = (te.getNumberOfPerformedIterations() != oit) + !(dmax <= 5e-6) + (te.getModelResiduals().size() != m);
+      size_t k = 0;
+      for (size_t i = 0; i < m && te.getModelResiduals().size() == m; ++i) {
+        tbad += te.getModelResiduals()[i] != chk[i];
+        if (chk[i] <= 1e-3f) { tbad += (k >= te.getModelInliers().size()) || te.getModelInliers()[k] != i; ++k; }
+      }
+      tbad += k != te.getModelInliers().size();
+      std::printf("transform RANSAC: %zu iterations (oracle %zu), %zu inliers (oracle %zu), |T - T_oracle|max %.2e, %zu mismatches\n",
+                  te.getNumberOfPerformedIterations(), oit, te.getNumberOfInliers(), ok, dmax, tbad);
+      if (tbad || te.getNumberOfInliers() < m / 2) ++failures;
+    }
   } catch (const std::runtime_error& e) {
     if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }
     std::printf("FAIL: %s\n", e.what());

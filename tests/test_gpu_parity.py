@@ -566,6 +566,25 @@ def test_kmeans3f_vs_oracle(orc, hip_lib):
     co, lo, ito = orc.kmeans(x, c0, max_iter=3, tol=0.0, mode=1)
     assert np.abs(km.getClusterCentroids() - co).max() <= 1e-6
     _kmeans_label_mismatches_are_near_ties(x, km.getPointToClusterIndexMap(), lo, co, 8)
+    # use_kd_tree = true (kmeans.hpp:86-94, the mode examples/kmeans.cpp runs): a kd-tree over the centroids finds the same nearest
+    # centroid, compared by nanoflann's rounding of the distance -- labels of one pass bit-exact against the oracle's kd-tree
+    # restatement (pinned on the reference's nanoflann), whole runs iteration for iteration
+    for k in (1, 7, 64, 1024):
+        c0 = x[:k].copy()
+        lab_g = kmeans_assign(x, c0, use_kd_tree=True)
+        lab_o, _ = orc.kmeans_assign(x, c0, use_kd_tree=True)
+        bad = np.nonzero(lab_g != lab_o)[0]
+        for i in bad:      # only exactly equidistant centroids may differ (lowest index here, first met in the tree there)
+            dg = orc.nn_brute(c0[[lab_g[i]]], x[[i]], 3.0e38)[1][0]; do = orc.nn_brute(c0[[lab_o[i]]], x[[i]], 3.0e38)[1][0]
+            assert dg == do, (k, int(i), dg, do)
+        assert len(bad) <= 2, (k, len(bad))
+    for k, iters, tol in ((64, 12, 0.0), (64, 100, 1e-4)):
+        c0 = x[:k].copy()
+        km = KMeans3f(x).cluster(c0, max_iter=iters, tol=tol, use_kd_tree=True)
+        co, lo, ito = orc.kmeans(x, c0, max_iter=iters, tol=tol, mode=1, use_kd_tree=True)
+        assert km.getNumberOfPerformedIterations() == ito, (k, km.getNumberOfPerformedIterations(), ito)
+        assert np.abs(km.getClusterCentroids() - co).max() <= 1e-6, k
+        _kmeans_label_mismatches_are_near_ties(x, km.getPointToClusterIndexMap(), lo, co, k)
 
 
 def _plane_cloud(n, seed, inlier_frac=0.6, noise=0.004):
@@ -1614,3 +1633,63 @@ def test_warm_start_stress_sweep(hip_lib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "warm_stress.py")], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_transform_ransac3f_vs_oracle(orc, hip_lib):
+    """RigidTransformRANSACEstimator3f (model_estimation/ransac_transform_estimator.hpp; SURVEY section 2 "next tier") through the
+    Python mirror: inlier counts of arbitrary transforms bit-exact, the closed-form fit to f32 round-off, whole runs with explicit
+    samples -- same iteration count, same winner, inlier sets bit-exact for the product's own model and equal to the oracle's run up
+    to pairs within round-off of the threshold -- correspondences as index lists, library-drawn samples, edge cases."""
+    from cilantro_amd.model_estimation import RigidTransformRANSACEstimator3f
+
+    rng = np.random.default_rng(31)
+    n = 300_007
+    src = rng.random((n, 3)).astype(np.float32)
+    T = np.eye(4); T[:3, :3] = syn.rot_xyz(0.25, -0.4, 0.1); T[:3, 3] = [0.2, 0.1, -0.3]
+    dst = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 5e-4, (n, 3))).astype(np.float32)
+    bad = rng.random(n) < 0.45
+    dst[bad] = (rng.random((int(bad.sum()), 3)) * 2.0 - 0.5).astype(np.float32)
+    thr = 2e-3
+    te = RigidTransformRANSACEstimator3f(dst, src)
+    # (1) scoring
+    Ts = np.tile(np.eye(4, dtype=np.float32), (131, 1, 1))
+    for k in range(131):
+        Ts[k, :3, :3] = syn.rot_xyz(*(rng.normal(0, 0.3, 3))).astype(np.float32)
+        Ts[k, :3, 3] = rng.normal(0, 0.2, 3).astype(np.float32)
+    Ts[0] = T.astype(np.float32)
+    Ts[5, 0, 0] = np.nan
+    got = te.countInliers(Ts, thr)
+    want = np.array([orc.transform_count_inliers(dst, src, t, thr) for t in Ts])
+    assert np.array_equal(got, want) and got[0] > 0.5 * n
+    # (2) the closed-form fit over all pairs of the inlier set
+    good = np.nonzero(~bad)[0]
+    tg = RigidTransformRANSACEstimator3f(dst, src, correspondences=(good, good)).estimateModel()
+    to = orc.transform_fit(dst, src, good.astype(np.uint32), mode=orc.MODE_MIXED)
+    assert np.abs(tg - to).max() <= 2e-6 and np.abs(tg.astype(np.float64) - T).max() < 1e-4
+    # (3) full runs
+    for max_iter, target, re_est in ((100, n // 2, True), (100, n // 2, False), (200, n, True), (3, 10, True), (70, int(0.52 * n), True)):
+        samples = rng.integers(0, n, (max_iter, 3)).astype(np.uint32)
+        te = (RigidTransformRANSACEstimator3f(dst, src).setMaxInlierResidual(thr).setTargetInlierCount(target)
+              .setMaxNumberOfIterations(max_iter).setReEstimationStep(re_est).setSamples(samples))
+        Tg = te.estimate().getModel()
+        To, reso, inlo, ito, haveo = orc.transform_ransac(dst, src, samples, thr, target, re_estimate=re_est, mode=orc.MODE_MIXED)
+        assert te.getNumberOfPerformedIterations() == ito, (max_iter, target, te.getNumberOfPerformedIterations(), ito)
+        assert np.abs(Tg - To).max() <= 5e-6, (max_iter, target, np.abs(Tg - To).max())
+        res_chk = orc.transform_residuals(dst, src, Tg)
+        assert np.array_equal(te.getModelResiduals().view(np.uint32), res_chk.view(np.uint32))
+        inl_chk = np.nonzero(res_chk <= np.float32(thr))[0]
+        assert np.array_equal(te.getModelInliers(), inl_chk)
+        assert len(np.setxor1d(inl_chk, inlo)) <= max(3, int(2e-4 * n)), (len(inl_chk), len(inlo))
+        assert te.targetInlierCountAchieved() == (len(inl_chk) >= min(target, n))
+    # (4) library-drawn samples: deterministic in the seed, finds the motion
+    a = RigidTransformRANSACEstimator3f(dst, src).setMaxInlierResidual(thr).setSeed(3).estimate()
+    b = RigidTransformRANSACEstimator3f(dst, src).setMaxInlierResidual(thr).setSeed(3).estimate()
+    assert np.array_equal(a.getModel(), b.getModel()) and np.array_equal(a.getModelInliers(), b.getModelInliers())
+    assert np.abs(a.getModel().astype(np.float64) - T).max() < 1e-4 and a.getNumberOfInliers() >= int(0.5 * n)
+    # (5) edge cases: no accepted model (threshold 0 on noisy pairs); tiny inputs
+    e = RigidTransformRANSACEstimator3f(dst[bad][:1000], src[bad][:1000]).setMaxInlierResidual(0.0).setMaxNumberOfIterations(20).setSeed(1).setReEstimationStep(False).estimate()
+    assert e.getNumberOfPerformedIterations() == 20 and e.getNumberOfInliers() == 0 and np.array_equal(e.getModel(), np.eye(4, dtype=np.float32))
+    for npts in (0, 1, 2, 3):
+        t = RigidTransformRANSACEstimator3f(dst[:npts].copy(), src[:npts].copy()).setMaxInlierResidual(thr).setMaxNumberOfIterations(4).setSeed(2).estimate()
+        assert t.getNumberOfPerformedIterations() <= 4 and t.getNumberOfInliers() <= npts

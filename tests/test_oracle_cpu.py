@@ -408,3 +408,34 @@ def test_weight_evaluators_vs_numpy(orc):
                         point_weight=orc.W_RBF, plane_weight=orc.W_RBF, point_sigma=sig_p, plane_sigma=sig_l)
     r = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
     assert r["last_delta_norm"] < 1e-5 and np.linalg.norm(r["T"] - d["T_true"]) < 2e-3
+
+
+def test_transform_ransac_oracle_known_answers(orc):
+    """RigidTransformRANSACEstimator3f restatement (oracle/ransac_oracle.c): the residual expression against numpy, the closed-form
+    fit recovers a known rigid motion from exact pairs, the loop recovers it from pairs with 40 % gross outliers and stops at the
+    reference's iteration (ransac_base.hpp:103-114), and the degenerate cases follow the reference (no accepted model)."""
+    from cilantro_amd import synthetic as syn
+
+    rng = np.random.default_rng(5)
+    n = 5000
+    src = rng.random((n, 3)).astype(np.float32)
+    T = np.eye(4); T[:3, :3] = syn.rot_xyz(0.3, -0.2, 0.5); T[:3, 3] = [0.1, -0.3, 0.2]
+    dst = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    Tf = orc.transform_fit(dst, src, None, mode=orc.MODE_MIXED)
+    assert np.abs(Tf.astype(np.float64) - T).max() < 2e-6
+    res = orc.transform_residuals(dst, src, T.astype(np.float32))
+    ref = np.linalg.norm((src.astype(np.float64) @ T.astype(np.float32).astype(np.float64)[:3, :3].T + T.astype(np.float32).astype(np.float64)[:3, 3]) - dst, axis=1)
+    assert np.abs(res - ref).max() < 1e-6 and orc.transform_count_inliers(dst, src, T.astype(np.float32), 1e-4) == n
+    # outliers
+    bad = rng.random(n) < 0.4
+    dst_o = dst.copy(); dst_o[bad] = rng.random((int(bad.sum()), 3)).astype(np.float32) * 3.0
+    samples = rng.integers(0, n, (200, 3)).astype(np.uint32)
+    Tr, resr, inl, it, have = orc.transform_ransac(dst_o, src, samples, 1e-3, n // 2, mode=orc.MODE_MIXED)
+    assert have == 3 and it <= 200 and np.abs(Tr.astype(np.float64) - T).max() < 1e-5
+    assert set(inl.tolist()) >= set(np.nonzero(~bad)[0].tolist()) and len(inl) <= int((~bad).sum()) + 5
+    # the stopping iteration is the first one whose sample lies entirely among the good pairs
+    good_iter = next(k for k in range(200) if not bad[samples[k]].any()) + 1
+    assert it == good_iter
+    # nothing reaches 3 inliers: no model; without re-estimation no inliers, with it the identity's
+    Tn, _, inln, itn, haven = orc.transform_ransac(dst_o[bad][:500], src[bad][:500], samples[:20] % 500, 0.0, 250, re_estimate=False, mode=orc.MODE_MIXED)
+    assert haven == 0 and itn == 20 and len(inln) == 0 and np.array_equal(Tn, np.eye(4, dtype=np.float32))
