@@ -951,11 +951,13 @@ static hipEvent_t get_acc_event(cilhip_ctx* c, size_t i);
 // ---- affine variants: SimpleCombinedMetricAffineICP3f / SimplePointToPointMetricAffineICP3f ---------------------------
 // Moments of the 12-unknown normal equations over the stored correspondences (matches or pair list), three streaming
 // passes on the device, one copy to the host.
-static int affine_accumulate(cilhip_ctx* c, bool centered, bool plane, double sums[3 * SUMS_MAX]) {
+static int affine_accumulate(cilhip_ctx* c, bool centered, bool plane, double sums[3 * SUMS_MAX], const CorrWeights* cw = nullptr) {
   for (int i = 0; i < 3 * SUMS_MAX; ++i) sums[i] = 0.0;
   launch_init_state(c->d_state, c->nn_T, c->src_mean, c->stream);
   IterArgs a = make_iter_args(c, 0.0f);
-  if (c->have_pairs) { a.src = c->pairs.src_view; a.ns = c->pairs.count; a.nn_pos = c->pairs.posd; }
+  if (cw) a.cw = *cw;
+  // (a pair list's values are per pair, d_nn_d2 is per sorted source position: a weight evaluator forms the distance again)
+  if (c->have_pairs) { a.src = c->pairs.src_view; a.ns = c->pairs.count; a.nn_pos = c->pairs.posd; a.nn_d2 = nullptr; }
   a.src_nrm = nullptr;   // (the symmetric metric exists for the rigid classes only)
   a.no_centering = centered ? 0 : 1;
   if (a.ns == 0) return CILHIP_OK;
@@ -994,13 +996,16 @@ int cilhip_estimate_affine(cilhip_ctx* c, float w_p2p, float w_p2pl, int centere
   if (!wp && !wl) return CILHIP_OK;                      // transform_estimation.hpp:400-409
   if (wl && !c->has_normals) return CILHIP_OK;           // dst_p.cols() != dst_n.cols() -> identity, false
   double sums[3 * SUMS_MAX];
-  const int rc = affine_accumulate(c, centered != 0, wl, sums);
+  // weight evaluators (the combined-metric class only: `centered` distinguishes it from the point-to-point class here)
+  const CorrWeights cw = corr_weights_of(c, centered != 0, w_p2p, w_p2pl);
+  const int rc = affine_accumulate(c, centered != 0, wl, sums, &cw);
   if (rc) return rc;
   const double n = sums[0];
   if (n_corr) *n_corr = (size_t)n;
   if (!(n > 0.0)) return CILHIP_OK;                      // no correspondences: identity, false
   double AtA[144], Atb[12], th[12];
-  affine_normal_equations(sums, sums + SUMS_MAX, sums + 2 * SUMS_MAX, wp ? (double)w_p2p : 0.0, wl ? (double)w_p2pl : 0.0, AtA, Atb);
+  if (cw.enabled) affine_normal_equations(sums, sums + SUMS_MAX, sums + 2 * SUMS_MAX, wp ? 1.0 : 0.0, wl ? 1.0 : 0.0, AtA, Atb, true);      // (metric weights inside the per-pair weights)
+  else affine_normal_equations(sums, sums + SUMS_MAX, sums + 2 * SUMS_MAX, wp ? (double)w_p2p : 0.0, wl ? (double)w_p2pl : 0.0, AtA, Atb);
   if (AtA_out) memcpy(AtA_out, AtA, sizeof(AtA));
   if (Atb_out) memcpy(Atb_out, Atb, sizeof(Atb));
   ldlt_solve_n(12, AtA, Atb, th);                        // :468 AtA.ldlt().solve(Atb)
@@ -1195,7 +1200,6 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   CK(c, hipSetDevice(c->device));
   if (c->transform_mode == 1) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "the affine variants are not available on target shards");
-    if (p->metric == CILHIP_METRIC_COMBINED && weighted(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "weight evaluators other than Unity are available for the rigid classes only");
     return icp_run_affine(c, p, T0, out);
   }
   const float* Ti = T0 ? T0 : kIdentity;

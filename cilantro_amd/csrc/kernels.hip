@@ -444,7 +444,7 @@ struct AccTraits {
   static constexpr bool point = (METRIC == IM_POINT || METRIC == IM_BOTH);
   static constexpr bool kabsch = (METRIC == IM_KABSCH);
   static constexpr bool affine = (METRIC == IM_AFF0 || METRIC == IM_AFF1 || METRIC == IM_AFF2);
-  static constexpr int NA = affine ? (METRIC == IM_AFF0 ? 34 : 30) : kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
+  static constexpr int NA = affine ? (METRIC == IM_AFF0 ? 35 : 30) : kabsch ? 16 : (plane ? 28 : 1);  // slots [0, NA)
   static constexpr int NB = point ? 16 : 0;                  // slots [28, 28+NB)
 };
 
@@ -477,29 +477,33 @@ __device__ __forceinline__ void accumulate_pair(double* __restrict__ accA, doubl
       const float d0 = __fsub_rn(p.x, dmean[0]), d1 = __fsub_rn(p.y, dmean[1]), d2 = __fsub_rn(p.z, dmean[2]);
       const float s0 = __fsub_rn(qx, smt[0]), s1 = __fsub_rn(qy, smt[1]), s2 = __fsub_rn(qz, smt[2]);
       const double sd[4] = {(double)s0, (double)s1, (double)s2, 1.0};
+      // wq / wp: per-pair weights of the point and plane terms (weight evaluators of the affine combined-metric class, :432-434,
+      // :453-455; 1 = unity, where the metric weights are applied to the sums by the solver).  Every sum is linear in its weight.
+      const double wqd = (double)wq, wpd = (double)wp;
       if (METRIC == IM_AFF0) {
         const double dd[3] = {(double)d0, (double)d1, (double)d2};
         accA[0] += 1.0;
+        accA[34] += wqd;                 // sum of the point weights: the translation block of the point terms
         int k = 1;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int c = r; c < 3; ++c) { accA[k] = fma(sd[r], sd[c], accA[k]); ++k; }
+          for (int c = r; c < 3; ++c) { accA[k] = fma(wqd * sd[r], sd[c], accA[k]); ++k; }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) accA[7 + c] += sd[c];
+        for (int c = 0; c < 3; ++c) accA[7 + c] = fma(wqd, sd[c], accA[7 + c]);
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) accA[10 + r * 3 + c] = fma(sd[r], dd[c], accA[10 + r * 3 + c]);
+          for (int c = 0; c < 3; ++c) accA[10 + r * 3 + c] = fma(wqd * sd[r], dd[c], accA[10 + r * 3 + c]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) accA[19 + c] += dd[c];
+        for (int c = 0; c < 3; ++c) accA[19 + c] = fma(wqd, dd[c], accA[19 + c]);
         if (has_nrm) {
           // n.dot(dst - dst_mean)  (:464), f32 like the reference's dot product
           const float res = __fadd_rn(__fadd_rn(__fmul_rn(nvp.x, d0), __fmul_rn(nvp.y, d1)), __fmul_rn(nvp.z, d2));
           const double nd[3] = {(double)nvp.x, (double)nvp.y, (double)nvp.z};
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            const double rn = (double)res * nd[j];
+            const double rn = wpd * (double)res * nd[j];
 #pragma unroll
             for (int c = 0; c < 4; ++c) accA[22 + j * 4 + c] = fma(rn, sd[c], accA[22 + j * 4 + c]);
           }
@@ -512,7 +516,7 @@ __device__ __forceinline__ void accumulate_pair(double* __restrict__ accA, doubl
           // (j,k): AFF1 -> (0,0),(0,1),(0,2); AFF2 -> (1,1),(1,2),(2,2)
           const int j = (METRIC == IM_AFF1) ? 0 : (jk == 2 ? 2 : 1);
           const int kk = (METRIC == IM_AFF1) ? jk : (jk == 0 ? 1 : 2);
-          const double nn = nd[j] * nd[kk];
+          const double nn = wpd * nd[j] * nd[kk];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll

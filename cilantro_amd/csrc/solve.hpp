@@ -449,8 +449,10 @@ inline int affine_pair_slot(int a, int b) {   // position of (a <= b) among the 
   const int base[4] = {0, 4, 7, 9};
   return base[a] + (b - a);
 }
+// pair_weighted: the sums carry per-pair weights (weight evaluators); the point block's "count" is then the sum of the point
+// weights, slot 34 of s0
 inline void affine_normal_equations(const double* s0, const double* s1, const double* s2, double w_pt, double w_pl,
-                                    double AtA[144], double Atb[12]) {
+                                    double AtA[144], double Atb[12], bool pair_weighted = false) {
   for (int i = 0; i < 144; ++i) AtA[i] = 0.0;
   for (int i = 0; i < 12; ++i) Atb[i] = 0.0;
   auto idx = [](int j, int a) { return a < 3 ? 3 * j + a : 9 + j; };
@@ -458,7 +460,7 @@ inline void affine_normal_equations(const double* s0, const double* s1, const do
     if (a > b) { const int t = a; a = b; b = t; }
     if (b < 3) { const int up[3] = {1, 4, 6}; return s0[up[a] + (b - a)]; }
     if (a < 3) return s0[7 + a];
-    return s0[0];
+    return pair_weighted ? s0[34] : s0[0];
   };
   auto M = [&](int j, int k, int a, int b) -> double {   // sum n_j n_k st_a st_b
     if (j > k) { const int t = j; j = k; k = t; }

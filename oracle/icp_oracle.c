@@ -669,18 +669,24 @@ int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* s
 int orc_estimate_affine(const float* dst_p, const float* dst_n, const float* src_p, const int64_t* di, const int64_t* si,
                         size_t n, float w_p2p, float w_p2pl, const float dst_mean[3], const float src_mean[3], int mode,
                         float T_out[16], double* AtA_out, double* Atb_out) {
+  return orc_estimate_affine_w(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, mode, T_out, AtA_out, Atb_out, NULL, NULL);
+}
+
+int orc_estimate_affine_w(const float* dst_p, const float* dst_n, const float* src_p, const int64_t* di, const int64_t* si,
+                          size_t n, float w_p2p, float w_p2pl, const float dst_mean[3], const float src_mean[3], int mode,
+                          float T_out[16], double* AtA_out, double* Atb_out, const float* val, const orc_weights* wt) {
   int ok;
   if (mode == ORC_MODE_F32) {
     float L[9], t[3];
-    ok = estimate_affine_m0(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    ok = estimate_affine_m0(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out, val, wt);
     pack_T_f32(L, t, T_out);
   } else if (mode == ORC_MODE_MIXED) {
     double L[9], t[3];
-    ok = estimate_affine_m1(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    ok = estimate_affine_m1(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out, val, wt);
     pack_T_f64(L, t, T_out);
   } else {
     double L[9], t[3];
-    ok = estimate_affine_m2(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out);
+    ok = estimate_affine_m2(dst_p, dst_n, src_p, di, si, n, w_p2p, w_p2pl, dst_mean, src_mean, L, t, AtA_out, Atb_out, val, wt);
     pack_T_f64(L, t, T_out);
   }
   return ok;
@@ -718,13 +724,13 @@ static float icp_update_impl(const float* dst_p, const float* dst_n, const float
     const float* dm = prm->metric == 0 ? zero : dst_mean;
     const float wp = prm->metric == 0 ? 1.0f : prm->w_p2p, wl = prm->metric == 0 ? 0.0f : prm->w_p2pl;
     if (mode == ORC_MODE_F32) {
-      float L[9], t[3]; estimate_affine_m0(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL);
+      float L[9], t[3]; estimate_affine_m0(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL, prm->metric == 0 ? NULL : val, wt);
       return compose_affine_m0(L, t, T_cur, T_new);
     } else if (mode == ORC_MODE_MIXED) {
-      double L[9], t[3]; estimate_affine_m1(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL);
+      double L[9], t[3]; estimate_affine_m1(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL, prm->metric == 0 ? NULL : val, wt);
       return compose_affine_m1(L, t, T_cur, T_new);
     } else {
-      double L[9], t[3]; estimate_affine_m2(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL);
+      double L[9], t[3]; estimate_affine_m2(dst_p, dst_n, src_trans, di, si, nc, wp, wl, dm, smt, L, t, NULL, NULL, prm->metric == 0 ? NULL : val, wt);
       return compose_affine_m2(L, t, T_cur, T_new);
     }
   }

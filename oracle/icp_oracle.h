@@ -170,6 +170,11 @@ size_t orc_find_correspondences_feat6(const float* dst6, size_t nd, const float*
 int orc_estimate_affine(const float* dst_xyz, const float* dst_nrm_or_null, const float* src_xyz, const int64_t* dst_idx,
                         const int64_t* src_idx, size_t n, float w_p2p, float w_p2pl, const float dst_mean[3],
                         const float src_mean[3], int mode, float T_out[16], double* AtA_out, double* Atb_out);
+/* ... with the correspondence weight evaluators of the combined-metric class (val = corr.value per pair; :432-434, :453-455) */
+int orc_estimate_affine_w(const float* dst_xyz, const float* dst_nrm_or_null, const float* src_xyz, const int64_t* dst_idx,
+                          const int64_t* src_idx, size_t n, float w_p2p, float w_p2pl, const float dst_mean[3],
+                          const float src_mean[3], int mode, float T_out[16], double* AtA_out, double* Atb_out, const float* val,
+                          const orc_weights* wt);
 
 /* dst_nrm may be NULL for metric 0.  T0: initial transform (col-major) or NULL = identity.
  * tree: optional prebuilt kd-tree on dst (NULL = build here, as the engine does lazily). */

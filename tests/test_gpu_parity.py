@@ -1561,12 +1561,19 @@ def test_correspondence_weight_evaluators_vs_oracle(Context, orc, hip_lib):
                             plane_weight=R, plane_sigma=0.5 * np.sqrt(r6))
         ro = orc.icp_run(dn["dst"], dn["dst_n"], dn["src"], p, src_n=sn_true)
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64)) <= TOL_T and icp.last_ncorr_ == ro["last_ncorr"], tiled
-    # the affine classes take unity evaluators only: anything else fails loudly
-    icp = SimpleCombinedMetricAffineICP3f(dl["dst"], dl["dst_n"], dl["src"])
-    icp.setCorrespondenceWeightEvaluators(None, evaluator(R, sigma))
-    icp.correspondenceSearchEngine().setMaxDistance(r2)
-    with pytest.raises(RuntimeError):
-        icp.estimate()
+    # the affine combined-metric class with weight evaluators (transform_estimation.hpp:432-434, :453-455): every search direction
+    for direction, recip, code in ((D.SECOND_TO_FIRST, False, 0), (D.BOTH, False, 2), (D.FIRST_TO_SECOND, False, 1)):
+        for pe, le, pk, lk in ((None, evaluator(R, sigma), 0, R), (evaluator(I, 1.0), evaluator(R, 1.5 * sigma), I, R)):
+            icp = SimpleCombinedMetricAffineICP3f(dl["dst"], dl["dst_n"], dl["src"])
+            icp.setPointToPointMetricWeight(0.1).setCorrespondenceWeightEvaluators(pe, le)
+            icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
+            icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0)
+            Tg = icp.estimate().getTransform()
+            p = orc.make_params(metric=1, w_p2p=0.1, w_p2pl=1.0, max_sq_dist=r2, max_iter=5, conv_tol=0.0, direction=code, reciprocal=recip, affine=True,
+                                point_weight=pk, plane_weight=lk, point_sigma=1.0, plane_sigma=sigma if pe is None else 1.5 * sigma)
+            ro = orc.icp_run(dl["dst"], dl["dst_n"], dl["src"], p)
+            err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
+            assert err <= 1e-4 and icp.last_ncorr_ == ro["last_ncorr"], (direction, pk, lk, err)
 
 
 @pytest.mark.gpu
