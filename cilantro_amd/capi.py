@@ -19,7 +19,7 @@ NONE_IDX = 0xFFFFFFFF
 # every symbol include/cilantro_hip/c_api.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "cilhip_create", "cilhip_destroy", "cilhip_last_error", "cilhip_set_stream", "cilhip_synchronize",
-    "cilhip_set_target", "cilhip_set_source", "cilhip_set_source_normals", "cilhip_get_means", "cilhip_find_correspondences",
+    "cilhip_set_target", "cilhip_set_source", "cilhip_set_source_normals", "cilhip_get_means", "cilhip_set_color_features", "cilhip_find_correspondences",
     "cilhip_get_nn", "cilhip_get_correspondences", "cilhip_estimate_point_to_point",
     "cilhip_estimate_combined", "cilhip_estimate_affine", "cilhip_icp_default_params", "cilhip_icp_run", "cilhip_icp_begin",
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
@@ -145,6 +145,7 @@ def load():
     L.cilhip_prepare_source.argtypes = [vp, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.cilhip_get_last_run_forms.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cilhip_get_last_warm_iterations.argtypes = [vp, C.POINTER(C.c_int)]
+    L.cilhip_set_color_features.argtypes = [vp, vp, vp, C.c_int]
     L.cilhip_get_last_matches_origin.argtypes = [vp, C.POINTER(C.c_int)]
     L.cilhip_get_matches_transform.argtypes = [vp, vp]
     L.cilhip_get_last_form_timing.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]

@@ -63,8 +63,13 @@ struct InvArgs {
 
 __device__ __forceinline__ float mapped_bound(float gap, const InvArgs& iv) { return fmaxf(iv.smin * gap - iv.eps, 0.0f); }
 
+// FEAT6: candidates are compared by the 6-D feature distance (point, w v) -- the same value, bit for bit, as the forward search's
+// (d6_features is symmetric in its two sides); pf = the target point's feature part w * v_p.  The geometric pruning around this
+// scan stays 3-D: d6 >= d3.
+template <bool FEAT6>
 __device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, uint32_t beg, uint32_t end, const float* T, float px, float py, float pz,
-                                               unsigned long long& bkey, uint32_t& bpos) {
+                                               unsigned long long& bkey, uint32_t& bpos, const FeatSpec* fs = nullptr, float pfx = 0.f, float pfy = 0.f,
+                                               float pfz = 0.f) {
   if (beg >= end) return;
   const uint32_t last = end - 1;
   for (uint32_t j = beg; j < end; j += 4) {
@@ -77,17 +82,25 @@ __device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, u
       float qx, qy, qz;
       transform_point(T, c[k].x, c[k].y, c[k].z, qx, qy, qz);
       // nanoflann's L2_Adaptor with the TARGET point as the query and q as the data point: dx = p.x - q.x
-      const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
-      const float e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      float e;
+      if (FEAT6) {
+        float fx, fy, fz;
+        source_feature(*fs, T, fs->src[jj[k]], fx, fy, fz);
+        e = d6_features(px, py, pz, pfx, pfy, pfz, qx, qy, qz, fx, fy, fz);
+      } else {
+        const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
+        e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      }
       const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(c[k].w);
       if (key < bkey) { bkey = key; bpos = jj[k]; }
     }
   }
 }
 
+template <bool FEAT6>
 __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over the source, source space*/, const float4* __restrict__ dst_sorted, uint32_t nd,
                                                         const IcpState* __restrict__ st, InvArgs iv, float max_sq, uint32_t* __restrict__ rev_pos,
-                                                        float* __restrict__ rev_d2) {
+                                                        float* __restrict__ rev_d2, FeatSpec fs) {
   if (st->done) return;
   float T[16];
 #pragma unroll
@@ -104,6 +117,8 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
   const float KS = 0.99999905f;
   for (uint32_t jd = blockIdx.x * blockDim.x + threadIdx.x; jd < nd; jd += gridDim.x * blockDim.x) {
     const float4 p = dst_sorted[jd];
+    float pfx = 0.f, pfy = 0.f, pfz = 0.f;
+    if (FEAT6) { const float4 v = fs.dst[jd]; pfx = __fmul_rn(fs.w, v.x); pfy = __fmul_rn(fs.w, v.y); pfz = __fmul_rn(fs.w, v.z); }      // the adaptor stores w * v (:90)
     float sx, sy, sz;
     transform_point(iv.Ti, p.x, p.y, p.z, sx, sy, sz);
     unsigned long long bkey = (unsigned long long)__float_as_uint(max_sq) << 32;
@@ -140,10 +155,12 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
           const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
           if (face) {
             const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
-            if (xa <= xb) scan_range_inv(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos);
+            if (xa <= xb) scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz);
           } else {
-            if (xlo >= 0 && xlo < sg.nx) scan_range_inv(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos);
-            if (xhi >= 0 && xhi < sg.nx) scan_range_inv(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos);
+            if (xlo >= 0 && xlo < sg.nx)
+              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz);
+            if (xhi >= 0 && xhi < sg.nx)
+              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz);
           }
         }
       }
@@ -339,7 +356,7 @@ static unsigned bits_for_u32(uint32_t n) {
 // carry original source indices); T_host: the state's transform.  A transform whose linear part is (nearly) singular
 // cannot be searched through its inverse: then -- and only then -- a grid over the transformed source is built for this
 // one search, as the reference builds its kd-tree.
-hipError_t find_pairs(const GridDev& g, const GridDev& sgrid, const float* d_src_xyz, const float* d_src_nrm, const float4* src_sorted, uint32_t ns,
+hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgrid, const float* d_src_xyz, const float* d_src_nrm, const float4* src_sorted, uint32_t ns,
                       const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq, int direction, bool reciprocal,
                       double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2, PairSet& out, hipStream_t s) {
   enum { REV_POS, REV_D2, KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, WINNER, SEL_KEYS, SEL_STATE, TMP };
@@ -395,8 +412,10 @@ hipError_t find_pairs(const GridDev& g, const GridDev& sgrid, const float* d_src
   do {
     const float4* cand_pts = sgrid.pts;
     if (through_inverse) {
-      hipLaunchKernelGGL(k_reverse_search, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2);
+      if (feat.w > 0.0f) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat);
+      else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat);
     } else {
+      if (feat.w > 0.0f) { e = hipErrorNotSupported; break; }      // (a feature search under a (nearly) singular transform: not implemented)
       if ((e = hipMalloc(&d_q, 3 * (size_t)ns * sizeof(float))) != hipSuccess) break;
       hipLaunchKernelGGL(k_transform_original, dim3(nblk(ns)), dim3(256), 0, s, d_src_xyz, ns, state, d_q);
       double mean[3];
@@ -456,7 +475,8 @@ hipError_t find_pairs(const GridDev& g, const GridDev& sgrid, const float* d_src
   return e;
 }
 
-void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s) {
+void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
+                                 const FeatSpec* feat) {
   if (g.n == 0) return;
   InvArgs iv{};
   iv.rigid_on_device = 1;
@@ -464,7 +484,9 @@ void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const I
   const double ext_t = std::max({std::fabs((double)g.ox), std::fabs((double)g.oy), std::fabs((double)g.oz)}) + (double)std::max(g.nx, std::max(g.ny, g.nz)) * g.cell;
   const double ext_s = std::max({std::fabs((double)sgrid.ox), std::fabs((double)sgrid.oy), std::fabs((double)sgrid.oz)}) + (double)std::max(sgrid.nx, std::max(sgrid.ny, sgrid.nz)) * sgrid.cell;
   iv.eps = (float)(8e-6 * (ext_t + ext_s) + 1e-4 * ext_s);   // rounding of p' and of T s, and |T p' - p| for a linear part up to 1e-4 off orthonormal
-  hipLaunchKernelGGL(k_reverse_search, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2);
+  FeatSpec none{};
+  if (feat && feat->w > 0.0f) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, *feat);
+  else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, none);
 }
 
 }  // namespace cilhip

@@ -115,7 +115,14 @@ struct cilhip_ctx {
   int search_dir = 0;             // 0 = SECOND_TO_FIRST (default), 1 = FIRST_TO_SECOND, 2 = BOTH
   bool reciprocal = false;        // require_reciprocality_ (BOTH only)
   int transform_mode = 0;         // 0 = rigid (Isometry), 1 = affine: which ICP instance family cilhip_icp_run mirrors
-  float normal_weight = 0.0f;     // > 0: the correspondence search runs on 6-D point+normal features (PointNormalFeaturesAdaptor)
+  float normal_weight = 0.0f;     // > 0: the correspondence search runs on 6-D features (point, weight * v)
+  int feature_kind = 0;           // option "feature_kind": 0 = v = normals, following the transform (PointNormalFeaturesAdaptor);
+                                  // 1 = v = colours, untouched by it (PointColorFeaturesAdaptor; cilhip_set_color_features)
+  float *d_dst_rgb = nullptr, *d_src_rgb = nullptr;             // colour features, original order
+  float4 *d_dst_rgb_sorted = nullptr, *d_src_rgb_sorted = nullptr;
+  bool dst_rgb_sorted_ok = false;
+  float src_nrm0[3] = {0, 0, 0};  // the first source normal (the affine feature adaptor's normal weight is |w n_0|, adaptors.hpp:113-114)
+  float feat_M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};              // L^-T of the transform being searched under (affine adaptor)
   bool symmetric = true;          // source normals, when set, also switch the combined metric to the symmetric objective
   PairSet pairs;
   GridDev src_grid{};             // grid over the source in SOURCE coordinates (built on the first FIRST_TO_SECOND / BOTH search of a source)
@@ -206,6 +213,9 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_src_nrm) (void)hipFree(c->d_src_nrm);
   if (c->d_src_nrm_sorted) (void)hipFree(c->d_src_nrm_sorted);
   c->d_src_nrm = nullptr; c->d_src_nrm_sorted = nullptr;
+  if (c->d_src_rgb) (void)hipFree(c->d_src_rgb);
+  if (c->d_src_rgb_sorted) (void)hipFree(c->d_src_rgb_sorted);
+  c->d_src_rgb = nullptr; c->d_src_rgb_sorted = nullptr;
   if (c->d_defer_mask) (void)hipFree(c->d_defer_mask);
   if (c->d_keys) (void)hipFree(c->d_keys);
   c->d_keys = nullptr;
@@ -227,6 +237,8 @@ void cilhip_destroy(cilhip_ctx* c) {
   free_source(c);
   if (c->has_target) free_grid(c->grid);
   if (c->d_safe2) (void)hipFree(c->d_safe2);
+  if (c->d_dst_rgb) (void)hipFree(c->d_dst_rgb);
+  if (c->d_dst_rgb_sorted) (void)hipFree(c->d_dst_rgb_sorted);
   if (c->d_state) (void)hipFree(c->d_state);
   if (c->d_state_id) (void)hipFree(c->d_state_id);
   free_pairs(c->pairs);
@@ -294,6 +306,11 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "feature_normal_weight")) {
     if (!(value >= 0.0)) return fail(c, CILHIP_ERR_INVALID, "feature_normal_weight: >= 0 (0 = plain point features)");
     c->normal_weight = (float)value; drop_matches(c); c->have_pairs = false;
+    return CILHIP_OK;
+  }
+  if (!strcmp(key, "feature_kind")) {
+    if (value != 0.0 && value != 1.0) return fail(c, CILHIP_ERR_INVALID, "feature_kind: 0 = normals (follow the transform), 1 = colours (do not)");
+    c->feature_kind = (int)value; drop_matches(c); c->have_pairs = false;
     return CILHIP_OK;
   }
   if (!strcmp(key, "symmetric_metric")) { c->symmetric = value != 0.0; return CILHIP_OK; }
@@ -386,6 +403,9 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
   c->warm_banned = false;
+  c->dst_rgb_sorted_ok = false;
+  if (c->d_dst_rgb) { (void)hipFree(c->d_dst_rgb); c->d_dst_rgb = nullptr; }      // (colours belong to the target they were set for)
+  if (c->d_dst_rgb_sorted) { (void)hipFree(c->d_dst_rgb_sorted); c->d_dst_rgb_sorted = nullptr; }
   if (c->d_safe2) { (void)hipFree(c->d_safe2); c->d_safe2 = nullptr; }      // (rebuilt by the first run that can use it: ensure_safe2)
   c->has_normals = (nrm != nullptr);
   for (int i = 0; i < 3; ++i) c->dst_mean[i] = (float)mean[i];
@@ -431,11 +451,38 @@ int cilhip_set_source_normals(cilhip_ctx* c, const float* nrm, int mem) {
   if (c->d_src_nrm) { (void)hipFree(c->d_src_nrm); c->d_src_nrm = nullptr; }
   if (c->d_src_nrm_sorted) { (void)hipFree(c->d_src_nrm_sorted); c->d_src_nrm_sorted = nullptr; }
   c->have_pairs = false; c->pairs.count = 0;
+  if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }      // (it carries the feature vectors of the reverse searches)
   if (!nrm) return CILHIP_OK;                              // back to the 3-cloud (non-symmetric) form
   int rc = upload(c, nrm, 3 * (size_t)c->ns, mem, &c->d_src_nrm);
   if (rc) return rc;
+  c->src_nrm0[0] = c->src_nrm0[1] = c->src_nrm0[2] = 0.0f;
+  if (c->ns) {
+    CK(c, hipMemcpyAsync(c->src_nrm0, c->d_src_nrm, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+  }
   CK(c, hipMalloc(&c->d_src_nrm_sorted, (c->ns ? c->ns : 1) * sizeof(float4)));
   c->src_sorted = false;                                   // the sorted copy is (re)built with the next sort
+  drop_matches(c);
+  c->have_pairs = false; c->pairs.count = 0;
+  return CILHIP_OK;
+}
+
+int cilhip_set_color_features(cilhip_ctx* c, const float* dst_rgb, const float* src_rgb, int mem) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (!c->has_target || !c->has_source) return fail(c, CILHIP_ERR_INVALID, "set_color_features: set_target and set_source first");
+  if (!dst_rgb || !src_rgb) return fail(c, CILHIP_ERR_INVALID, "set_color_features: both clouds' colours are needed");
+  CK(c, hipSetDevice(c->device));
+  if (c->d_dst_rgb) { (void)hipFree(c->d_dst_rgb); c->d_dst_rgb = nullptr; }
+  if (c->d_src_rgb) { (void)hipFree(c->d_src_rgb); c->d_src_rgb = nullptr; }
+  if (c->d_src_rgb_sorted) { (void)hipFree(c->d_src_rgb_sorted); c->d_src_rgb_sorted = nullptr; }
+  int rc = upload(c, dst_rgb, 3 * (size_t)c->grid.n, mem, &c->d_dst_rgb);
+  if (rc) return rc;
+  rc = upload(c, src_rgb, 3 * (size_t)c->ns, mem, &c->d_src_rgb);
+  if (rc) return rc;
+  CK(c, hipMalloc(&c->d_src_rgb_sorted, (c->ns ? c->ns : 1) * sizeof(float4)));
+  c->dst_rgb_sorted_ok = false;
+  c->src_sorted = false;                                   // the source's sorted copy is (re)built with the next sort
+  if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }      // (it carries the features of the reverse searches)
   drop_matches(c);
   c->have_pairs = false; c->pairs.count = 0;
   return CILHIP_OK;
@@ -489,6 +536,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
       }
     }
     if (c->d_src_nrm) launch_gather_by_w(c->d_src_sorted, c->d_src_nrm, c->ns, c->d_src_nrm_sorted, c->stream);
+    if (c->d_src_rgb) launch_gather_by_w(c->d_src_sorted, c->d_src_rgb, c->ns, c->d_src_rgb_sorted, c->stream);
     if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
@@ -602,13 +650,38 @@ static int apply_filters(cilhip_ctx* c) {
   return CILHIP_OK;
 }
 
+// The 6-D feature search's inputs: vectors (normals or colours), weight, and how the source's part follows the transform being
+// searched under (FeatSpec::mode; M = L^-T of that transform is refreshed by cilhip_find_correspondences -- the affine loops are
+// host-driven, the device-resident loops are rigid).
+static FeatSpec feat_spec_of(const cilhip_ctx* c) {
+  FeatSpec f{};
+  f.w = c->normal_weight;
+  if (c->feature_kind == 1) { f.src = c->d_src_rgb_sorted; f.dst = c->d_dst_rgb_sorted; f.mode = 2; }
+  else { f.src = c->d_src_nrm ? c->d_src_nrm_sorted : nullptr; f.dst = c->grid.nrm; f.mode = c->transform_mode == 1 ? 1 : 0; }
+  for (int i = 0; i < 9; ++i) f.M[i] = c->feat_M[i];
+  // normal_weight = the norm of the FIRST source feature's normal part (adaptors.hpp:113-114), f32
+  const float x = c->normal_weight * c->src_nrm0[0], y = c->normal_weight * c->src_nrm0[1], z = c->normal_weight * c->src_nrm0[2];
+  f.nw = std::sqrt(x * x + (y * y + z * z));
+  return f;
+}
+// sorted copy of the target's colour features (gathered by the sorted records' original indices), built on first use
+static int ensure_feature_arrays(cilhip_ctx* c) {
+  if (c->feature_kind != 1) return CILHIP_OK;
+  if (!c->d_dst_rgb || !c->d_src_rgb) return fail(c, CILHIP_ERR_INVALID, "colour features: cilhip_set_color_features first");
+  if (!c->dst_rgb_sorted_ok) {
+    if (!c->d_dst_rgb_sorted) CK(c, hipMalloc(&c->d_dst_rgb_sorted, (c->grid.n ? c->grid.n : 1) * sizeof(float4)));
+    launch_gather_by_w(c->grid.pts, c->d_dst_rgb, c->grid.n, c->d_dst_rgb_sorted, c->stream);
+    c->dst_rgb_sorted_ok = true;
+  }
+  return CILHIP_OK;
+}
+
 static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   IterArgs a{};
   a.grid = c->grid;
   a.src = c->d_src_sorted;
   a.src_nrm = (c->d_src_nrm && c->symmetric) ? c->d_src_nrm_sorted : nullptr;
-  a.feat_src_nrm = c->d_src_nrm ? c->d_src_nrm_sorted : nullptr;
-  a.normal_weight = c->normal_weight;
+  a.feat = feat_spec_of(c);
   a.ns = c->ns;
   a.max_sq = max_sq;
   for (int i = 0; i < 3; ++i) a.dst_mean[i] = c->dst_mean[i];
@@ -631,9 +704,9 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
 // 6-D feature search when a normal weight is set.
 static int launch_search(cilhip_ctx* c, const IterArgs& a) {
   if (c->normal_weight > 0.0f) {
-    if (!c->has_normals || !c->d_src_nrm) return fail(c, CILHIP_ERR_INVALID, "point+normal features need target and source normals");
-    if (c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for rigid transforms only");
-    if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are not available on target shards");
+    if (c->feature_kind == 0 && (!c->has_normals || !c->d_src_nrm)) return fail(c, CILHIP_ERR_INVALID, "point+normal features need target and source normals");
+    if (c->feature_kind == 1 && (!a.feat.src || !a.feat.dst)) return fail(c, CILHIP_ERR_INVALID, "colour features: cilhip_set_color_features first");
+    if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "feature adaptors are not available on target shards");
     if (use_tiled(c)) launch_search_tiled_feat6(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_search_feat6(a, c->stream);
     return CILHIP_OK;
@@ -652,7 +725,9 @@ static int ensure_src_grid(cilhip_ctx* c) {
     // searches go through the inverse transform
     GridBuildResult r{};
     double mean[3];
-    const hipError_t eg = build_grid(c->d_src_xyz, nullptr, c->ns, c->stream, &r, mean, 1.0);
+    // (its per-point attribute = the feature vectors a 6-D reverse search compares by: normals or colours)
+    const float* attr = c->feature_kind == 1 ? c->d_src_rgb : c->d_src_nrm;
+    const hipError_t eg = build_grid(c->d_src_xyz, attr, c->ns, c->stream, &r, mean, 1.0);
     if (eg != hipSuccess) { c->err = std::string("build_grid (source): ") + hipGetErrorString(eg); return CILHIP_ERR_HIP; }
     c->src_grid = r.grid; c->has_src_grid = true;
   }
@@ -674,18 +749,21 @@ static int ensure_reverse_buffers(cilhip_ctx* c) {
 }
 
 static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq, const float T_host[16]) {
-  if (feat6(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for SECOND_TO_FIRST only");
   if (!c->d_state_id) {
     CK(c, hipMalloc(&c->d_state_id, sizeof(IcpState)));
     const float zero[3] = {0, 0, 0};
     launch_init_state(c->d_state_id, kIdentity, zero, c->stream);
   }
   if (c->search_dir == 2 && c->ns && c->grid.n) {   // forward half of BOTH: the usual search, no filters yet
-    if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
-    else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
+    const int src_rc = launch_search(c, a);
+    if (src_rc) return src_rc;
   }
   { const int grc = ensure_src_grid(c); if (grc) return grc; }
-  const hipError_t e = find_pairs(c->grid, c->src_grid, c->d_src_xyz, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm : nullptr, c->d_src_sorted, c->ns, c->d_state,
+  FeatSpec rf = a.feat;                              // the reverse search reads the source's features in the source grid's order
+  rf.src = c->has_src_grid ? c->src_grid.nrm : nullptr;
+  if (feat6(c) && (!rf.src || !rf.dst)) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
+  if (!feat6(c)) rf.w = 0.0f;
+  const hipError_t e = find_pairs(rf, c->grid, c->src_grid, c->d_src_xyz, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm : nullptr, c->d_src_sorted, c->ns, c->d_state,
                                   c->d_state_id, T_host, max_sq, c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2,
                                   c->pairs, c->stream);
   if (e != hipSuccess) { c->err = std::string("find_pairs: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
@@ -698,6 +776,11 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   int rc = ensure_sorted(c, T);
   if (rc) return rc;
   launch_init_state(c->d_state, T, c->src_mean, c->stream);
+  if (feat6(c)) {
+    rc = ensure_feature_arrays(c);
+    if (rc) return rc;
+    linear_inverse_transpose_f32(T, c->feat_M);
+  }
   IterArgs a = make_iter_args(c, max_sq);
   if (c->search_dir != 0) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
@@ -956,8 +1039,8 @@ static int affine_accumulate(cilhip_ctx* c, bool centered, bool plane, double su
   launch_init_state(c->d_state, c->nn_T, c->src_mean, c->stream);
   IterArgs a = make_iter_args(c, 0.0f);
   if (cw) a.cw = *cw;
-  // (a pair list's values are per pair, d_nn_d2 is per sorted source position: a weight evaluator forms the distance again)
-  if (c->have_pairs) { a.src = c->pairs.src_view; a.ns = c->pairs.count; a.nn_pos = c->pairs.posd; a.nn_d2 = nullptr; }
+  // (a pair list carries its own values, per pair)
+  if (c->have_pairs) { a.src = c->pairs.src_view; a.ns = c->pairs.count; a.nn_pos = c->pairs.posd; a.nn_d2 = c->pairs.d2; }
   a.src_nrm = nullptr;   // (the symmetric metric exists for the rigid classes only)
   a.no_centering = centered ? 0 : 1;
   if (a.ns == 0) return CILHIP_OK;
@@ -1228,7 +1311,9 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // FIRST_TO_SECOND / BOTH: the correspondence set is a pair list rebuilt every iteration (a grid over the transformed
     // source, like the reference's per-iteration kd-tree); host-driven loop, the accumulation kernels stream over the pairs
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
-    if (feat6(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features are available for SECOND_TO_FIRST only");
+    if (feat6(c)) { rc = ensure_feature_arrays(c); if (rc) return rc; a.feat = feat_spec_of(c); }
+    // (a weight evaluator over FEATURE distances reads them per pair: those loops go through the pair list below)
+    const bool feat_weights = feat6(c) && a.cw.enabled;
     hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
     CK(c, hipEventRecord(e_beg, c->stream));
     // Without post-filters the loop needs the SUMS over the correspondence set, not the sorted list: the reverse matches are
@@ -1241,9 +1326,12 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         const double dot = (double)Ti[i * 4] * Ti[j * 4] + (double)Ti[i * 4 + 1] * Ti[j * 4 + 1] + (double)Ti[i * 4 + 2] * Ti[j * 4 + 2];
         if (std::fabs(dot - (i == j ? 1.0 : 0.0)) > 1e-5) t0_rigid = false;
       }
-    if (!filters_active(c) && !(c->d_src_nrm && c->symmetric) && t0_rigid && c->ns && c->grid.n) {
+    if (!filters_active(c) && !(c->d_src_nrm && c->symmetric) && t0_rigid && c->ns && c->grid.n && !feat_weights) {
       rc = ensure_reverse_buffers(c);
       if (rc) return rc;
+      FeatSpec rf = a.feat;
+      rf.src = c->src_grid.nrm;
+      if (feat6(c) && (!rf.src || !rf.dst)) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
       const int nb_f = iter_num_blocks(c->ns), nb_r = iter_num_blocks(c->grid.n);
       if (nb_f + nb_r > c->partial_blocks) {
         if (c->d_partials) (void)hipFree(c->d_partials);
@@ -1263,7 +1351,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           a.skip_if_inner_done = ar.skip_if_inner_done = (st > 0);
           if (st == 0) {
             if (c->search_dir == 2) { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
-            launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream);
+            launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr);
           }
           if (both_union) launch_iter(a, im, false, false, nb_f, c->stream);
           launch_acc_reverse(ar, im, c->src_grid.pts, c->d_rev_pos, c->grid.n, rmode, c->d_nn_pos, c->d_src_inv, nb_r, c->stream);
@@ -1296,7 +1384,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       rc = run_pair_search(c, a, p->max_sq_dist, it == 0 ? Ti : out->T);
       if (rc) return rc;
       IterArgs pa = a;
-      pa.nn_d2 = nullptr;      // (d_nn_d2 is indexed by sorted source position, not by pair: a weight evaluator forms the distance again)
+      pa.nn_d2 = c->pairs.d2;  // (per pair: corr.value -- the 6-D distance under a feature adaptor -- for the weight evaluators)
       pa.src = c->pairs.src_view; pa.src_nrm = (c->d_src_nrm && c->symmetric) ? c->pairs.nrm_view : nullptr; pa.ns = c->pairs.count; pa.nn_pos = c->pairs.posd;
       const int pnb = iter_num_blocks(pa.ns);
       if (pnb > c->partial_blocks) {
@@ -1337,6 +1425,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
     return CILHIP_OK;
   }
+  if (feat6(c)) { rc = ensure_feature_arrays(c); if (rc) return rc; a.feat = feat_spec_of(c); }
   if (!filters_active(c) && !(a.cw.enabled && feat6(c))) a.nn_d2 = nullptr;   // nobody reads the distances inside the loop: 4 B per query less to write
                                                                               // (a weight evaluator over the 6-D feature distance does)
   const bool tile_acc = tile_accumulation(c);

@@ -99,6 +99,20 @@ struct CorrWeights {
 
 struct F3 { float x, y, z; };      // 12-byte record (one global_load_dwordx3 per lane)
 
+// Six-dimensional feature search (correspondence_search/common_transformable_feature_adaptors.hpp): features = (point, w * v), v a
+// per-point 3-vector (normal or colour).  mode: how the SOURCE's feature part follows the transform --
+//   0: rigid -- L * (w v)                                                         PointNormalFeaturesAdaptor, Isometry   :104-111
+//   1: affine -- nw * normalized(L^-T (w v)), M = L^-T, nw = |w v_0|              PointNormalFeaturesAdaptor, otherwise  :112-124
+//   2: not at all -- w v                                                          PointColorFeaturesAdaptor              :236-243
+struct FeatSpec {
+  const float4* src;     // the source's feature vectors in the order of the searched source array
+  const float4* dst;     // the target's, in sorted-target order
+  float w;               // feature weight (0 = plain point features)
+  int mode;
+  float M[9];            // row-major L^-T (mode 1)
+  float nw;
+};
+
 struct IterArgs {
   GridDev grid;
   const float4* src;       // [ns] source sorted by target-grid cell {x,y,z,orig_idx}
@@ -120,8 +134,7 @@ struct IterArgs {
   int store_matches;       // tiled search: also write nn_pos / nn_d2 for the queries settled inside the tile (the pure ICP loop needs neither)
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)
-  const float4* feat_src_nrm;  // 6-D point+normal feature search: sorted source normals, and
-  float normal_weight;         // the adaptor's normal weight (0 = plain point features)
+  FeatSpec feat;               // 6-D feature search (feat.w > 0): feature vectors, weight, how the source's part follows the transform
   CorrWeights cw;              // per-correspondence weights (enabled = 0: unity)
   const uint32_t* warm_pos;    // [ns] or null: matches of the previous iteration, the per-lane search's warm start (may alias nn_pos)
   float warm_far_sq;           // warm bounds at or above this (squared) are counted in unproven_cnt
@@ -184,6 +197,41 @@ struct SolveArgs {
   float guard_center[3], guard_half[3];
   float guard_T[16];       // transform the partition was made under
 };
+
+#if defined(__HIPCC__)
+// The transformed feature part of a source point (the three adaptor behaviours of FeatSpec::mode).  f32, the engine's pinned
+// 3-term pairing r0*x + (r1*y + r2*z) for every matrix-vector product (Eigen's unrolled redux); the affine case's norm and
+// divisions are the correctly rounded f32 ones (formed in f64: the device's f32 sqrt / divide instructions are not).
+__device__ __forceinline__ void source_feature(const FeatSpec& a, const float* T /*col-major 4x4*/, const float4 sn, float& fx, float& fy, float& fz) {
+  const float wx = __fmul_rn(a.w, sn.x), wy = __fmul_rn(a.w, sn.y), wz = __fmul_rn(a.w, sn.z);
+  if (a.mode == 2) { fx = wx; fy = wy; fz = wz; return; }
+  if (a.mode == 1) {
+    const float* M = a.M;
+    const float v0 = __fadd_rn(__fmul_rn(M[0], wx), __fadd_rn(__fmul_rn(M[1], wy), __fmul_rn(M[2], wz)));
+    const float v1 = __fadd_rn(__fmul_rn(M[3], wx), __fadd_rn(__fmul_rn(M[4], wy), __fmul_rn(M[5], wz)));
+    const float v2 = __fadd_rn(__fmul_rn(M[6], wx), __fadd_rn(__fmul_rn(M[7], wy), __fmul_rn(M[8], wz)));
+    const float nrm = (float)sqrt((double)__fadd_rn(__fmul_rn(v0, v0), __fadd_rn(__fmul_rn(v1, v1), __fmul_rn(v2, v2))));
+    fx = __fmul_rn(a.nw, (float)((double)v0 / (double)nrm));
+    fy = __fmul_rn(a.nw, (float)((double)v1 / (double)nrm));
+    fz = __fmul_rn(a.nw, (float)((double)v2 / (double)nrm));
+    return;
+  }
+  fx = __fadd_rn(__fmul_rn(T[0], wx), __fadd_rn(__fmul_rn(T[4], wy), __fmul_rn(T[8], wz)));
+  fy = __fadd_rn(__fmul_rn(T[1], wx), __fadd_rn(__fmul_rn(T[5], wy), __fmul_rn(T[9], wz)));
+  fz = __fadd_rn(__fmul_rn(T[2], wx), __fadd_rn(__fmul_rn(T[6], wy), __fmul_rn(T[10], wz)));
+}
+// squared distance of two 6-D features exactly as nanoflann's L2_Adaptor::evalMetric forms it for DIM = 6 (nanoflann.hpp:570-604): one
+// group of four -- ((d0*d0 + d1*d1) + d2*d2) + d3*d3 -- then the tail loop adds d4*d4 and d5*d5 one by one; every operation
+// individually rounded.  (a - b) and (b - a) square to the same bits: the value does not depend on which side is the query.
+__device__ __forceinline__ float d6_features(float ax, float ay, float az, float afx, float afy, float afz, float bx, float by, float bz, float bfx, float bfy,
+                                             float bfz) {
+  const float d0 = __fsub_rn(ax, bx), d1 = __fsub_rn(ay, by), d2 = __fsub_rn(az, bz);
+  const float d3 = __fsub_rn(afx, bfx), d4 = __fsub_rn(afy, bfy), d5 = __fsub_rn(afz, bfz);
+  float r = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
+  r = __fadd_rn(r, __fmul_rn(d4, d4));
+  return __fadd_rn(r, __fmul_rn(d5, d5));
+}
+#endif
 
 // kernels.hip
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
@@ -254,8 +302,10 @@ struct PairSet {
 void free_pairs(PairSet& p);
 // the reverse search of those directions alone (every target point against the source, through the inverse of the state's
 // rigid transform computed on the device): rev_pos / rev_d2 [nd] by target sorted position
-void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s);
-hipError_t find_pairs(const GridDev& g, const GridDev& src_grid /*over the source, SOURCE coordinates*/, const float* d_src_xyz, const float* d_src_nrm,
+// feat (optional, w > 0): the reverse matches are the nearest 6-D FEATURES (feat->src in the source grid's order, feat->dst by target position)
+void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
+                                 const FeatSpec* feat = nullptr);
+hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& src_grid /*over the source, SOURCE coordinates*/, const float* d_src_xyz, const float* d_src_nrm,
                       const float4* src_sorted, uint32_t ns, const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq,
                       int direction, bool reciprocal, double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2,
                       PairSet& out, hipStream_t s);

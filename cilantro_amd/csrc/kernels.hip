@@ -106,6 +106,8 @@ __device__ __forceinline__ float d6_pinned(float qx, float qy, float qz, const F
   r = __fadd_rn(r, __fmul_rn(d4, d4));
   return __fadd_rn(r, __fmul_rn(d5, d5));
 }
+__device__ __forceinline__ const float4* target_features(const IterArgs& a) { return a.feat.dst; }
+
 __device__ __forceinline__ void scan_range_f6(const float4* __restrict__ pts, uint32_t beg, uint32_t end,
                                               float qx, float qy, float qz, const Feat6& f, NN& best) {
   if (beg >= end) return;
@@ -1381,8 +1383,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
       sn[u] = np[u] = rr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (((flags >> (20 + u)) & 1u) && f6_pos[u] != NONE_U32) {
-        sn[u] = a.feat_src_nrm[i];
-        np[u] = g.nrm[f6_pos[u]];
+        sn[u] = a.feat.src[i];
+        np[u] = target_features(a)[f6_pos[u]];
         rr[u] = lpts[(mbl >> (16 * u)) & 0xFFFFu];
       }
     }
@@ -1394,12 +1396,9 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       uint32_t pos = NONE_U32;
       bool ambiguous = false;
       if (pend && f6_pos[u] != NONE_U32) {
-        const float wx = __fmul_rn(a.normal_weight, sn[u].x), wy = __fmul_rn(a.normal_weight, sn[u].y), wz = __fmul_rn(a.normal_weight, sn[u].z);
         Feat6 f;
-        f.fx = __fadd_rn(__fmul_rn(T[0], wx), __fadd_rn(__fmul_rn(T[4], wy), __fmul_rn(T[8], wz)));
-        f.fy = __fadd_rn(__fmul_rn(T[1], wx), __fadd_rn(__fmul_rn(T[5], wy), __fmul_rn(T[9], wz)));
-        f.fz = __fadd_rn(__fmul_rn(T[2], wx), __fadd_rn(__fmul_rn(T[6], wy), __fmul_rn(T[10], wz)));
-        f.w = a.normal_weight; f.nrm = nullptr;
+        source_feature(a.feat, T, sn[u], f.fx, f.fy, f.fz);
+        f.w = a.feat.w; f.nrm = nullptr;
         const float d6 = d6_pinned(oq[u].qx, oq[u].qy, oq[u].qz, f, make_float4(rr[u].x, rr[u].y, rr[u].w, 0.f), np[u]);
         ambiguous = !(f6_second[u] > d6);           // another candidate's d6 (>= its d3 >= second) could be <= d6: not settled here
         if (d6 < a.max_sq) { dbest = d6; pos = f6_pos[u]; }
@@ -1731,13 +1730,10 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
             transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
             NN best;
             if (FEAT6) {
-              const float4 sn = a.feat_src_nrm[i];
-              const float wx = __fmul_rn(a.normal_weight, sn.x), wy = __fmul_rn(a.normal_weight, sn.y), wz = __fmul_rn(a.normal_weight, sn.z);
+              const float4 sn = a.feat.src[i];
               Feat6 f;
-              f.fx = __fadd_rn(__fmul_rn(T[0], wx), __fadd_rn(__fmul_rn(T[4], wy), __fmul_rn(T[8], wz)));
-              f.fy = __fadd_rn(__fmul_rn(T[1], wx), __fadd_rn(__fmul_rn(T[5], wy), __fmul_rn(T[9], wz)));
-              f.fz = __fadd_rn(__fmul_rn(T[2], wx), __fadd_rn(__fmul_rn(T[6], wy), __fmul_rn(T[10], wz)));
-              f.w = a.normal_weight; f.nrm = a.grid.nrm;
+              source_feature(a.feat, T, sn, f.fx, f.fy, f.fz);
+              f.w = a.feat.w; f.nrm = target_features(a);
               nn_search_group<TODO_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
             } else {
               nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
@@ -1843,16 +1839,13 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
   const uint64_t gid = ((uint64_t)blockIdx.x * ITER_THREADS + threadIdx.x) / FEAT6_GROUP;
   if (gid >= a.ns) return;      // (whole groups leave together)
   const uint32_t i = (uint32_t)gid;
-  const float4 s4 = a.src[i], sn = a.feat_src_nrm[i];
+  const float4 s4 = a.src[i], sn = a.feat.src[i];
   float qx, qy, qz;
   transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-  const float wx = __fmul_rn(a.normal_weight, sn.x), wy = __fmul_rn(a.normal_weight, sn.y), wz = __fmul_rn(a.normal_weight, sn.z);
   Feat6 f;
-  f.fx = __fadd_rn(__fmul_rn(T[0], wx), __fadd_rn(__fmul_rn(T[4], wy), __fmul_rn(T[8], wz)));
-  f.fy = __fadd_rn(__fmul_rn(T[1], wx), __fadd_rn(__fmul_rn(T[5], wy), __fmul_rn(T[9], wz)));
-  f.fz = __fadd_rn(__fmul_rn(T[2], wx), __fadd_rn(__fmul_rn(T[6], wy), __fmul_rn(T[10], wz)));
-  f.w = a.normal_weight;
-  f.nrm = a.grid.nrm;
+  source_feature(a.feat, T, sn, f.fx, f.fy, f.fz);
+  f.w = a.feat.w;
+  f.nrm = target_features(a);
   NN best;
   nn_search_group<FEAT6_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
   if (sub == 0) {

@@ -385,6 +385,25 @@ CILHIP_HD float compose_update(const double Lin[9], const double t[3], const flo
 #define CILHIP_SUB(a, b) ((a) - (b))
 #endif
 
+// tform.linear().inverse().transpose() in f32, restating Eigen's fixed-size 3x3 inverse (cofactors, det along column 0 with the
+// 3-term pairing x0 + (x1 + x2), multiplication by the reciprocal of det): what PointNormalFeaturesAdaptor applies to normals
+// under a non-rigid transform (common_transformable_feature_adaptors.hpp:118-122).  M row-major.  (Eigen's own evaluation order
+// is unpinnable here -- Eigen is absent; oracle and engine share this restatement.)
+CILHIP_HD void linear_inverse_transpose_f32(const float T[16], float M[9]) {
+  float m[3][3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[r][c] = T[c * 4 + r];
+  float cof[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      cof[i][j] = CILHIP_SUB(CILHIP_MUL(m[i1][j1], m[i2][j2]), CILHIP_MUL(m[i1][j2], m[i2][j1]));
+    }
+  const float det = CILHIP_ADD(CILHIP_MUL(cof[0][0], m[0][0]), CILHIP_ADD(CILHIP_MUL(cof[1][0], m[1][0]), CILHIP_MUL(cof[2][0], m[2][0])));
+  const float invdet = 1.0f / det;
+  // inverse(i, j) = cofactor(j, i) * invdet  =>  (inverse^T)(i, j) = cofactor(i, j) * invdet
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i * 3 + j] = CILHIP_MUL(cof[i][j], invdet);
+}
+
 CILHIP_HD void transform_point(const float T[16], float x, float y, float z, float& qx, float& qy, float& qz) {
   qx = CILHIP_ADD(CILHIP_ADD(CILHIP_MUL(T[0], x), CILHIP_ADD(CILHIP_MUL(T[4], y), CILHIP_MUL(T[8], z))), T[12]);
   qy = CILHIP_ADD(CILHIP_ADD(CILHIP_MUL(T[1], x), CILHIP_ADD(CILHIP_MUL(T[5], y), CILHIP_MUL(T[9], z))), T[13]);

@@ -348,7 +348,22 @@ class CorrespondenceSearchHIP:
                 raise ValueError("source normals must match source points")
             self._ctx._ck(self._ctx._L.cilhip_set_source_normals(self._ctx._h, q, mem))
             self._ctx.set_option("symmetric_metric", 0 if keep_metric else 1)
+        self._ctx.set_option("feature_kind", 0)
         self._ctx.set_option("feature_normal_weight", float(normal_weight))
+        self._corr = None
+        return self
+
+    def setPointColorFeatureAdaptors(self, dst_colors, src_colors, color_weight):
+        """both clouds' adaptors become PointColorFeaturesAdaptor3f(points, colors, color_weight)
+        (common_transformable_feature_adaptors.hpp:164-252): the search runs on the 6-D features (p, w c); the colour part does
+        not move with the transform.  color_weight = 0 switches back to point features."""
+        d, nd, mem, _k1 = _as_cloud(dst_colors)
+        s, ns, mem2, _k2 = _as_cloud(src_colors)
+        if nd != self._ctx.n_target or ns != self._ctx.n_source or mem != mem2:
+            raise ValueError("colours must match the clouds (and live in the same memory space)")
+        self._ctx._ck(self._ctx._L.cilhip_set_color_features(self._ctx._h, d, s, mem))
+        self._ctx.set_option("feature_kind", 1)
+        self._ctx.set_option("feature_normal_weight", float(color_weight))
         self._corr = None
         return self
 

@@ -89,6 +89,10 @@ int cilhip_set_source_normals(cilhip_ctx* ctx, const float* normals_or_null, int
 int cilhip_prepare_source(cilhip_ctx* ctx, const float* T_or_null, int force, double* ms_or_null);
 /* dst_mean_ / src_mean_ as the ICP classes hold them (f64 sum, rounded to f32). */
 int cilhip_get_means(cilhip_ctx* ctx, float dst_mean[3], float src_mean[3]);
+/* Per-point colours of both clouds (packed rgb, n_target / n_source triples) for the point + colour feature adaptor
+ * (PointColorFeaturesAdaptor3f(points, colors, color_weight), common_transformable_feature_adaptors.hpp:164-252; options
+ * "feature_kind" = 1, "feature_normal_weight" = the colour weight).  After cilhip_set_target and cilhip_set_source. */
+int cilhip_set_color_features(cilhip_ctx* ctx, const float* dst_rgb, const float* src_rgb, int mem);
 
 /* ---- correspondence search (engine concept) -------------------------------------------------- */
 /* CorrespondenceSearchKDTree::findCorrespondences(tform), SECOND_TO_FIRST, L2, identity
@@ -407,8 +411,13 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   "feature_normal_weight" (default 0 = PointFeaturesAdaptor3f, :8-57): w > 0 = PointNormalFeaturesAdaptor3f (:60-161)
  *                        on both clouds -- features (p, w n), transformed as (T p, L (w n)), matched by the 6-D squared
  *                        distance (which is then also what max_sq_dist, the filters and the returned values refer to).
- *                        Needs target normals and source normals (cilhip_set_source_normals); SECOND_TO_FIRST, rigid
- *                        transforms, unsharded runs.
+ *                        Needs target normals and source normals (cilhip_set_source_normals).  Every search direction; under
+ *                        "transform_mode" = 1 the normal part follows the adaptor's non-rigid branch (:112-124):
+ *                        normal_weight * (L^-T (w n)).normalized(), normal_weight = |w n_0| of the first source point.
+ *                        Unsharded runs.
+ *   "feature_kind" (default 0): 1 = the 6-D features are point + COLOUR, PointColorFeaturesAdaptor (:164-252): (p, w c) with
+ *                        the colour part untouched by the transform; colours through cilhip_set_color_features, weight through
+ *                        "feature_normal_weight".  (The 9-D point + normal + colour adaptor, :255-343, is not built.)
  *   "symmetric_metric" (default 1): 0 = source normals feed the feature adaptor only and the combined metric stays the
  *                        three-cloud one (the reference decides this by the ICP constructor used,
  *                        icp_common_instances.hpp:74-97).

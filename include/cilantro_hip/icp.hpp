@@ -211,7 +211,17 @@ public:
       internal::check(ctx_, cilhip_set_source_normals(ctx_, src_normals.data(), CILHIP_MEM_HOST), "set_source_normals");
       internal::check(ctx_, cilhip_set_option(ctx_, "symmetric_metric", keep_metric ? 0.0 : 1.0), "symmetric_metric");
     }
+    internal::check(ctx_, cilhip_set_option(ctx_, "feature_kind", 0.0), "feature_kind");
     internal::check(ctx_, cilhip_set_option(ctx_, "feature_normal_weight", (double)normal_weight), "feature_normal_weight");
+    fetched_ = false;
+    return *this;
+  }
+  // ... or PointColorFeaturesAdaptor3f(points, colors, color_weight) on both clouds (:164-252): features (p, w c), the colour part
+  // does not move with the transform.  color_weight = 0 switches back to point features.
+  CorrespondenceSearchHIP& setPointColorFeatureAdaptors(const ConstPointsView& dst_colors, const ConstPointsView& src_colors, float color_weight) {
+    internal::check(ctx_, cilhip_set_color_features(ctx_, dst_colors.data(), src_colors.data(), CILHIP_MEM_HOST), "set_color_features");
+    internal::check(ctx_, cilhip_set_option(ctx_, "feature_kind", 1.0), "feature_kind");
+    internal::check(ctx_, cilhip_set_option(ctx_, "feature_normal_weight", (double)color_weight), "feature_normal_weight");
     fetched_ = false;
     return *this;
   }

@@ -300,6 +300,45 @@ void orc_transform_features6(const float T[16], const float* in6, size_t n, floa
   for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) out6[6 * i + 3 + c] = q[3 * i + c];
   free(p); free(q);
 }
+/* tform.linear().inverse().transpose() in f32: Eigen's fixed-size 3x3 inverse restated (cofactors, det along column 0 with the
+ * 3-term pairing x0 + (x1 + x2), multiplication by 1 / det) -- the same restatement as cilantro_amd/csrc/solve.hpp; Eigen's own
+ * evaluation order is unpinnable here (Eigen is absent).  M row-major. */
+static void linear_inverse_transpose_f32(const float T[16], float M[9]) {
+  float m[3][3], cof[3][3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[r][c] = T[c * 4 + r];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      cof[i][j] = m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+    }
+  const float det = cof[0][0] * m[0][0] + (cof[1][0] * m[1][0] + cof[2][0] * m[2][0]);
+  const float invdet = 1.0f / det;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i * 3 + j] = cof[i][j] * invdet;
+}
+/* transformFeatures(tform) of the 6-D adaptors (common_transformable_feature_adaptors.hpp), the point part always T * p:
+ *   mode 0: PointNormalFeaturesAdaptor, Isometry (:104-111)  -- feature part L * f
+ *   mode 1: PointNormalFeaturesAdaptor, otherwise (:112-124) -- normal_weight * (L^-T f).normalized(), normal_weight = |f_0|
+ *   mode 2: PointColorFeaturesAdaptor (:236-243)              -- feature part unchanged */
+void orc_transform_features6_mode(const float T[16], const float* in6, size_t n, int mode, float* out6) {
+  if (mode == 0) { orc_transform_features6(T, in6, n, out6); return; }
+  float M[9];
+  linear_inverse_transpose_f32(T, M);
+  const float nw = n ? sqrtf(in6[3] * in6[3] + (in6[4] * in6[4] + in6[5] * in6[5])) : 0.0f;
+  float* p = (float*)malloc(3 * (n ? n : 1) * sizeof(float));
+  float* q = (float*)malloc(3 * (n ? n : 1) * sizeof(float));
+  for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) p[3 * i + c] = in6[6 * i + c];
+  orc_transform_points(T, p, n, q);
+  for (size_t i = 0; i < n; ++i) {
+    const float* a = in6 + 6 * i;
+    float* o = out6 + 6 * i;
+    o[0] = q[3 * i]; o[1] = q[3 * i + 1]; o[2] = q[3 * i + 2];
+    if (mode == 2) { o[3] = a[3]; o[4] = a[4]; o[5] = a[5]; continue; }
+    const float v0 = M[0] * a[3] + (M[1] * a[4] + M[2] * a[5]), v1 = M[3] * a[3] + (M[4] * a[4] + M[5] * a[5]), v2 = M[6] * a[3] + (M[7] * a[4] + M[8] * a[5]);
+    const float nrm = sqrtf(v0 * v0 + (v1 * v1 + v2 * v2));
+    o[3] = nw * (v0 / nrm); o[4] = nw * (v1 / nrm); o[5] = nw * (v2 / nrm);
+  }
+  free(p); free(q);
+}
 /* nanoflann.hpp:570-604 for DIM = 6: one group of four, then the tail loop */
 static inline float d6_pinned(const float* a, const float* b) {
   const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2], d3 = a[3] - b[3], d4 = a[4] - b[4], d5 = a[5] - b[5];
@@ -452,6 +491,46 @@ size_t orc_find_correspondences_dir(const float* dst, size_t nd, const orc_kdtre
     qsort(B, nsf, sizeof(orc_corr), cmp_lex);
     size_t i = 0, j = 0;
     while (i < nf || j < nsf) {            /* std::set_union / std::set_intersection (elements of A win on equality) */
+      int c;
+      if (i >= nf) c = 1; else if (j >= nsf) c = -1; else c = cmp_lex(&A[i], &B[j]);
+      if (c == 0) { di[n] = A[i].a; si[n] = A[i].b; d2[n] = A[i].v; ++n; ++i; ++j; }
+      else if (c < 0) { if (!reciprocal) { di[n] = A[i].a; si[n] = A[i].b; d2[n] = A[i].v; ++n; } ++i; }
+      else { if (!reciprocal) { di[n] = B[j].a; si[n] = B[j].b; d2[n] = B[j].v; ++n; } ++j; }
+    }
+    free(A); free(B); free(sa); free(sb); free(sv);
+  }
+  free(fa); free(fb); free(fv);
+  return n;
+}
+
+/* The same for 6-D features by exhaustive search (both directions; ties: lowest index of the searched side) */
+size_t orc_find_correspondences_feat6_dir(const float* dst6, size_t nd, const float* q6, size_t ns, float max_d, int direction, int reciprocal,
+                                          int64_t* di, int64_t* si, float* d2, int num_threads) {
+  if (direction == 0) return orc_find_correspondences_feat6(dst6, nd, q6, ns, max_d, di, si, d2, num_threads);
+  const size_t capf = nd ? nd : 1;
+  int64_t* fa = (int64_t*)malloc(capf * sizeof(int64_t));
+  int64_t* fb = (int64_t*)malloc(capf * sizeof(int64_t));
+  float* fv = (float*)malloc(capf * sizeof(float));
+  /* queries = the target features against the transformed source features: returns (index in the searched set, query index) */
+  const size_t nf = orc_find_correspondences_feat6(q6, ns, dst6, nd, max_d, fb, fa, fv, num_threads);
+  size_t n = 0;
+  if (direction == 1) {
+    for (size_t k = 0; k < nf; ++k) { di[k] = fa[k]; si[k] = fb[k]; d2[k] = fv[k]; }
+    n = nf;
+  } else {
+    const size_t caps = ns ? ns : 1;
+    int64_t* sa = (int64_t*)malloc(caps * sizeof(int64_t));
+    int64_t* sb = (int64_t*)malloc(caps * sizeof(int64_t));
+    float* sv = (float*)malloc(caps * sizeof(float));
+    const size_t nsf = orc_find_correspondences_feat6(dst6, nd, q6, ns, max_d, sa, sb, sv, num_threads);
+    orc_corr* A = (orc_corr*)malloc((nf ? nf : 1) * sizeof(orc_corr));
+    orc_corr* B = (orc_corr*)malloc((nsf ? nsf : 1) * sizeof(orc_corr));
+    for (size_t k = 0; k < nf; ++k) { A[k].a = fa[k]; A[k].b = fb[k]; A[k].v = fv[k]; }
+    for (size_t k = 0; k < nsf; ++k) { B[k].a = sa[k]; B[k].b = sb[k]; B[k].v = sv[k]; }
+    qsort(A, nf, sizeof(orc_corr), cmp_lex);
+    qsort(B, nsf, sizeof(orc_corr), cmp_lex);
+    size_t i = 0, j = 0;
+    while (i < nf || j < nsf) {
       int c;
       if (i >= nf) c = 1; else if (j >= nsf) c = -1; else c = cmp_lex(&A[i], &B[j]);
       if (c == 0) { di[n] = A[i].a; si[n] = A[i].b; d2[n] = A[i].v; ++n; ++i; ++j; }
@@ -830,13 +909,17 @@ int orc_icp_run(const float* dst_p, const float* dst_n, size_t nd, const float* 
     size_t nc;
     if (prm->direction == 0) {
       if (dst6) {
-        orc_transform_features6(T, src6, ns, q6);
+        orc_transform_features6_mode(T, src6, ns, prm->transform_mode == 1 ? 1 : 0, q6);
         nc = orc_find_correspondences_feat6(dst6, nd, q6, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
       } else
       nc = orc_find_correspondences(tree, q, ns, prm->max_sq_dist, di, si, d2, prm->num_threads);
       nc = orc_filter_fraction(di, si, d2, nc, prm->inlier_fraction);      /* correspondence_search_kd_tree.hpp:224 */
       if (prm->one_to_one) nc = orc_filter_one_to_one(di, si, d2, nc);     /* :225 */
     } else {
+      if (dst6) {
+        orc_transform_features6_mode(T, src6, ns, prm->transform_mode == 1 ? 1 : 0, q6);
+        nc = orc_find_correspondences_feat6_dir(dst6, nd, q6, ns, prm->max_sq_dist, prm->direction, prm->reciprocal, di, si, d2, prm->num_threads);
+      } else
       nc = orc_find_correspondences_dir(dst_p, nd, tree, q, ns, prm->max_sq_dist, prm->direction, prm->reciprocal, di, si, d2,
                                         prm->num_threads);
       nc = orc_filter_fraction_lex(di, si, d2, nc, prm->inlier_fraction);

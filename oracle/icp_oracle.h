@@ -162,6 +162,10 @@ size_t orc_radius_search(const float* pts, size_t n, const float* q, size_t nq, 
 /* 6-D point+normal features (common_transformable_feature_adaptors.hpp:60-161), row-major n x 6 */
 void orc_point_normal_features(const float* pts, const float* nrm, size_t n, float normal_weight, float* out6);
 void orc_transform_features6(const float T[16], const float* in6, size_t n, float* out6);
+/* transformFeatures(tform) of the 6-D adaptors: mode 0 rigid point+normal, 1 affine point+normal, 2 point+colour */
+void orc_transform_features6_mode(const float T[16], const float* in6, size_t n, int mode, float* out6);
+size_t orc_find_correspondences_feat6_dir(const float* dst6, size_t nd, const float* q6, size_t ns, float max_d, int direction, int reciprocal,
+                                          int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads);
 size_t orc_find_correspondences_feat6(const float* dst6, size_t nd, const float* q6, size_t nq, float max_sq_dist,
                                       int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads);
 

@@ -154,6 +154,9 @@ def lib():
         L.orc_transform_ransac.restype = C.c_size_t
         L.orc_transform_ransac.argtypes = [_f32p, _f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
                                            _f32p, _f32p, _u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.orc_transform_features6_mode.argtypes = [_f32p, _f32p, C.c_size_t, C.c_int, _f32p]
+        L.orc_find_correspondences_feat6_dir.restype = C.c_size_t
+        L.orc_find_correspondences_feat6_dir.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_int, C.c_int, _i64p, _i64p, _f32p, C.c_int]
         L.orc_find_correspondences_dir.restype = C.c_size_t
         L.orc_find_correspondences_dir.argtypes = [_f32p, C.c_size_t, C.c_void_p, _f32p, C.c_size_t, C.c_float, C.c_int, C.c_int,
                                                    _i64p, _i64p, _f32p, C.c_int]
@@ -343,11 +346,22 @@ def point_normal_features(pts, nrm, w):
     return out
 
 
-def transform_features6(T, feat6):
+def transform_features6(T, feat6, mode=0):
+    """transformFeatures(tform) of the 6-D adaptors: mode 0 rigid point+normal, 1 affine point+normal, 2 point+colour"""
     feat6 = _c(feat6).reshape(-1, 6)
     out = np.empty_like(feat6)
-    lib().orc_transform_features6(T_to_colmajor(T), feat6.reshape(-1), len(feat6), out.reshape(-1))
+    lib().orc_transform_features6_mode(T_to_colmajor(T), feat6.reshape(-1), len(feat6), int(mode), out.reshape(-1))
     return out
+
+
+def find_correspondences_feat6_dir(dst6, q6, max_sq_dist, direction, reciprocal=False, num_threads=0):
+    """6-D feature correspondences in any search direction (exhaustive) -> (dst_idx, src_idx, d2)"""
+    dst6 = _c(dst6).reshape(-1, 6); q6 = _c(q6).reshape(-1, 6)
+    cap = len(dst6) + len(q6) + 1
+    di = np.zeros(cap, np.int64); si = np.zeros(cap, np.int64); d2 = np.zeros(cap, np.float32)
+    n = lib().orc_find_correspondences_feat6_dir(dst6.reshape(-1), len(dst6), q6.reshape(-1), len(q6), np.float32(max_sq_dist), int(direction),
+                                                 1 if reciprocal else 0, di, si, d2, num_threads)
+    return di[:n].copy(), si[:n].copy(), d2[:n].copy()
 
 
 def find_correspondences_feat6(dst6, q6, max_sq_dist, use_ref=False, num_threads=0):

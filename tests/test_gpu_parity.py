@@ -1017,12 +1017,8 @@ def test_point_normal_feature_search_vs_oracle(Context, orc, hip_lib):
         assert np.array_equal(res[0][1][m], res[1][1][m]) and m.sum() > 0.9 * len(m)
         if sn2 is sn_good and w < h2:
             assert dq < 0.05 * len(m), dq            # settled inside the tiles
-    # options the feature search does not cover fail loudly
+    # what the feature search cannot do fails loudly
     ctx.set_option("inlier_fraction", 1.0)
-    ctx.set_option("search_direction", 2)
-    with pytest.raises(RuntimeError):
-        ctx.find_correspondences(T, 1.0, count=False)
-    ctx.set_option("search_direction", 0)
     ctx3 = Context(); ctx3.set_target(dst, dst_n); ctx3.set_source(src); ctx3.set_option("feature_normal_weight", 0.1)
     with pytest.raises(RuntimeError):
         ctx3.find_correspondences(T, 1.0, count=False)      # no source normals
@@ -1700,3 +1696,94 @@ def test_transform_ransac3f_vs_oracle(orc, hip_lib):
     for npts in (0, 1, 2, 3):
         t = RigidTransformRANSACEstimator3f(dst[:npts].copy(), src[:npts].copy()).setMaxInlierResidual(thr).setMaxNumberOfIterations(4).setSeed(2).estimate()
         assert t.getNumberOfPerformedIterations() <= 4 and t.getNumberOfInliers() <= npts
+
+
+@pytest.mark.gpu
+def test_feature_adaptors_directions_affine_colour_vs_oracle(Context, orc, hip_lib):
+    """The 6-D feature adaptors beyond the default direction (common_transformable_feature_adaptors.hpp):
+    PointNormalFeaturesAdaptor3f in FIRST_TO_SECOND / BOTH (+ reciprocity), under AFFINE transforms (the adaptor's non-rigid branch:
+    normals through L^-T, renormalised, :112-124), and PointColorFeaturesAdaptor3f (colours untouched by the transform, :164-252).
+    Correspondence lists element for element against the oracle's exhaustive 6-D search (itself pinned on the reference's
+    nanoflann for DIM = 6), loops against the oracle's loops."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D
+    from cilantro_amd.icp import SimpleCombinedMetricAffineICP3f, SimpleCombinedMetricRigidICP3f
+
+    n = 12000
+    d = syn.make_pair(n, perturb=0.5)
+    h = d["h"]
+    dst, dst_n, src = d["dst"], d["dst_n"], d["src"]
+    Ti = np.linalg.inv(d["T_true"].astype(np.float64)).astype(np.float32)
+    src_n = orc.transform_normals(Ti, dst_n)
+    w = 0.6 * h
+    r2 = float((2.5 * h) ** 2)
+    dst6 = orc.point_normal_features(dst, dst_n, w)
+    src6 = orc.point_normal_features(src, src_n, w)
+    T_rigid = d["T_true"].astype(np.float32).copy(); T_rigid[:3, 3] += np.float32(0.2 * h)
+    T_aff = T_rigid.copy(); T_aff[:3, :3] = (T_aff[:3, :3].astype(np.float64) @ (np.eye(3) + np.array([[0.02, 0.01, 0], [0, -0.03, 0.015], [0.01, 0, 0.025]]))).astype(np.float32)
+
+    def lists_equal(g, o):
+        return len(g[0]) == len(o[0]) and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]) and np.array_equal(g[2].view(np.uint32), o[2].view(np.uint32))
+
+    # (1) + (2): correspondence lists, every direction, rigid and affine transforms, both search kernels
+    for tiled in (0, 2):
+        for T, mode, tmode in ((T_rigid, 0, 0), (T_aff, 1, 1)):
+            q6 = orc.transform_features6(T, src6, mode)
+            for direction, recip, code in ((D.SECOND_TO_FIRST, False, 0), (D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 2), (D.BOTH, True, 2)):
+                ctx = Context()
+                ctx.set_option("tiled", tiled); ctx.set_option("transform_mode", tmode)
+                ctx.set_target(dst, dst_n); ctx.set_source(src, src_n)
+                ctx.set_option("symmetric_metric", 0); ctx.set_option("feature_normal_weight", w)
+                ctx.set_option("search_direction", code); ctx.set_option("require_reciprocality", 1 if recip else 0)
+                ng = ctx.find_correspondences(T, r2)
+                got = ctx.get_correspondences()
+                ctx.close()
+                want = orc.find_correspondences_feat6_dir(dst6, q6, r2, code, recip)
+                assert ng == len(want[0]) and len(want[0]) > 0.5 * n, (tiled, mode, direction, ng, len(want[0]))
+                assert lists_equal(got, want), (tiled, mode, direction, recip)
+    # (3) colours: source colours = the matched target's colour + noise; the colour part does not move with T
+    rng = np.random.default_rng(9)
+    dst_c = rng.random((n, 3)).astype(np.float32)
+    src_c = np.clip(dst_c + rng.normal(0, 0.05, (n, 3)), 0, 1).astype(np.float32)
+    wc = 0.8 * h
+    dstc6 = orc.point_normal_features(dst, dst_c, wc)          # (p, w c): the same 6-D layout
+    srcc6 = orc.point_normal_features(src, src_c, wc)
+    for tiled in (0, 2):
+        for direction, recip, code in ((D.SECOND_TO_FIRST, False, 0), (D.BOTH, False, 2), (D.FIRST_TO_SECOND, False, 1)):
+            icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+            icp._ctx.set_option("tiled", tiled)
+            eng = icp.correspondenceSearchEngine()
+            eng.setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip).setPointColorFeatureAdaptors(dst_c, src_c, wc)
+            eng.findCorrespondences(T_rigid)
+            got = eng.getCorrespondences()
+            want = orc.find_correspondences_feat6_dir(dstc6, orc.transform_features6(T_rigid, srcc6, 2), r2, code, recip)
+            assert lists_equal(got, want) and len(want[0]) > 0.5 * n, (tiled, direction)
+    # the colour loop against the oracle's pieces driven from here (transformFeatures -> findCorrespondences -> updateEstimate)
+    icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+    icp.correspondenceSearchEngine().setMaxDistance(r2).setPointColorFeatureAdaptors(dst_c, src_c, wc)
+    Tg = icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0).estimate().getTransform()
+    p = orc.make_params(metric=1, max_iter=1, conv_tol=0.0, max_sq_dist=r2, mode=orc.MODE_MIXED)
+    To = np.eye(4, dtype=np.float32)
+    for _ in range(5):
+        di, si, dv = orc.find_correspondences_feat6_dir(dstc6, orc.transform_features6(To, srcc6, 2), r2, 0)
+        To, _ = orc.icp_update(dst, dst_n, src, To, di, si, p)
+    assert np.linalg.norm(Tg.astype(np.float64) - To.astype(np.float64)) <= TOL_T and icp.last_ncorr_ == len(di)
+    # (4) loops: point+normal features in the pair-list directions (rigid) and under the affine class
+    for direction, recip, code in ((D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 2), (D.BOTH, True, 2)):
+        icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+        icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip).setPointNormalFeatureAdaptors(src_n, w)
+        Tg = icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0).estimate().getTransform()
+        p = orc.make_params(metric=1, max_iter=5, conv_tol=0.0, max_sq_dist=r2, mode=orc.MODE_MIXED, normal_weight=w, three_cloud_metric=True,
+                            direction=code, reciprocal=recip)
+        ro = orc.icp_run(dst, dst_n, src, p, src_n=src_n)
+        err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
+        assert err <= TOL_T and icp.last_ncorr_ == ro["last_ncorr"], (direction, recip, err, icp.last_ncorr_, ro["last_ncorr"])
+    for direction, code in ((D.SECOND_TO_FIRST, 0), (D.BOTH, 2)):
+        icp = SimpleCombinedMetricAffineICP3f(dst, dst_n, src)
+        icp.setPointToPointMetricWeight(0.1)
+        icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setPointNormalFeatureAdaptors(src_n, w)
+        Tg = icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0).estimate().getTransform()
+        p = orc.make_params(metric=1, w_p2p=0.1, max_iter=5, conv_tol=0.0, max_sq_dist=r2, mode=orc.MODE_MIXED, normal_weight=w, three_cloud_metric=True,
+                            direction=code, affine=True)
+        ro = orc.icp_run(dst, dst_n, src, p, src_n=src_n)
+        err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
+        assert err <= 1e-4 and icp.last_ncorr_ == ro["last_ncorr"], (direction, err, icp.last_ncorr_, ro["last_ncorr"])
