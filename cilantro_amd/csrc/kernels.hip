@@ -1774,7 +1774,8 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
 // blocks of the clean-up pass (64 mask words = two tiles per chunk; at most 1024 blocks, then several chunks each)
 static uint32_t deferred_blocks(uint32_t ntiles) {
   const uint32_t nchunks = (ntiles * (2u * TILE_WAVES) + 63u) >> 6;
-  return nchunks < 1u ? 1u : (nchunks > 1024u ? 1024u : nchunks);
+  static const uint32_t cap = [] { const char* e = getenv("CILHIP_EXP_DEFER_BLOCKS"); return e ? (uint32_t)atoi(e) : 1024u; }();
+  return nchunks < 1u ? 1u : (nchunks > cap ? cap : nchunks);
 }
 // rows of partial sums the tiled path with in-tile accumulation leaves in a.tile_partials: one per tile, then one per
 // block of the clean-up pass (a.partials = a.tile_partials + ntiles rows)
@@ -2079,8 +2080,7 @@ constexpr int WARM_WAVES = WARM_THREADS / 64;
 // one, and the whole wave would walk the search code for it: each wave lists them in LDS (ballot order: no atomics, the
 // same list in every run) and searches the list afterwards, densely packed (the list holds all of the wave's queries if
 // need be: a source far from alignment).
-constexpr int WARM_CHUNK_MAX = 5120;                        // queries per block at most (warm_num_blocks): what the lists are sized for
-constexpr int WARM_QCAP = WARM_CHUNK_MAX / WARM_WAVES;      // listed queries per wave: every query of the wave fits
+constexpr int WARM_QCAP = 1024;                             // listed queries per wave; a list that could not take another round is searched at once
 template <int ACC, int REC>
 __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   const IcpState* __restrict__ st = a.state;
@@ -2088,6 +2088,9 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   float T[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) T[i] = st->T[(i / 3) * 4 + (i % 3)];     // columns 0..3, rows 0..2
+  // (loop state read HERE, into scalar registers: a load of it inside the streaming loop is a vector-memory load whose wait
+  //  -- vmcnt counts in order -- also waits for the next round's prefetch, i.e. serialises memory latency and arithmetic)
+  const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};
   const GridDev& g = a.grid;
   __shared__ __attribute__((aligned(16))) unsigned char raw[WARM_WAVES * FUSED_WAVE_BYTES];
   __shared__ uint32_t dq[WARM_WAVES][WARM_QCAP];
@@ -2120,7 +2123,11 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   // rank update of the wave's 16x16 tile with one round of (up to) 64 correspondences (k_search_tiled, step 5)
   auto rank_update = [&](bool has, float qx, float qy, float qz, const float4 pm, const float4 nm) {
     float z[16];
-    fused_z<ACC>(has, qx, qy, qz, pm, nm, a.dst_mean, st->smt, z);
+    fused_z<ACC>(has, qx, qy, qz, pm, nm, a.dst_mean, smt, z);
+#if defined(CILHIP_EXP_WARM_NOACC)
+    if (z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7] == 1.2345e30f) acc[0] += 1.0;
+    return;
+#endif
     if (DUAL) {
       float4* w4 = reinterpret_cast<float4*>(zb + lane * 8 + (lane >= 32 ? 16 : 0));
       w4[0] = make_float4(z[0], z[1], z[2], z[3]);
@@ -2137,7 +2144,11 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
       for (int jj = 0; jj < 8; ++jj) {
         const int qi = hf * 32 + 4 * jj + k4;
         const double x = (double)zb[qi * 8 + hf * 16 + comp];
+#if defined(CILHIP_EXP_WARM_NOMFMA)
+        acc[0] += x;
+#else
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+#endif
       }
     } else {
       const int comp = lane & 15, k4 = lane >> 4;
@@ -2254,7 +2265,11 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     else { const float4 t4 = a.src[k]; s3n = F3{t4.x, t4.y, t4.z}; wn = a.warm_pos[k]; }
   };
   if (inext < end) fetch(inext);
-  for (uint32_t base = beg; base < end; base += WARM_THREADS) {
+  uint32_t base = beg, qlisted = 0;
+  for (;;) {
+  // stream rounds until the chunk is done -- or the wave's list could not take another round's queries (a source far from
+  // alignment lists most of them): then the list is searched first
+  for (; base < end && qcount <= (uint32_t)(WARM_QCAP - 64); base += WARM_THREADS) {
     const uint32_t i = inext;
     const bool valid = i < end;
     const F3 s3c = s3n;
@@ -2288,6 +2303,9 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   }
   // the listed queries, 64 per round
   __builtin_amdgcn_wave_barrier();
+#if defined(CILHIP_EXP_WARM_NOSLOW)
+  qcount = 0;
+#endif
   for (uint32_t b0 = 0; b0 < qcount; b0 += 64u) {
     const bool v = b0 + (uint32_t)lane < qcount;
     const uint32_t li = v ? wq[b0 + (uint32_t)lane] : 0u;
@@ -2300,10 +2318,15 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     }
     rank_update(has, qx, qy, qz, pm, nm);
   }
+  qlisted += qcount;
+  qcount = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (base >= end) break;
+  }
   if (a.unproven_cnt) {
     const double tot = wave_sum((double)nfar);
     if (lane == 0 && tot > 0.0) atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)tot);
-    if (lane == 0 && qcount != 0u) atomicAdd(a.unproven_cnt + 64u + ((vb * WARM_WAVES + (uint32_t)wave) & 63u), qcount);   // listed queries: is the form paying?
+    if (lane == 0 && qlisted != 0u) atomicAdd(a.unproven_cnt + 64u + ((vb * WARM_WAVES + (uint32_t)wave) & 63u), qlisted);   // listed queries: is the form paying?
   }
   double* const db = reinterpret_cast<double*>(raw + wave * FUSED_WAVE_BYTES);
 #pragma unroll
@@ -2335,9 +2358,14 @@ static void launch_warm_m(const IterArgs& a, int rec, int nblocks, hipStream_t s
   else hipLaunchKernelGGL((k_warm<ACC, 0>), g, b, 0, s, a);
 }
 int warm_num_blocks(uint32_t ns) {
-  long nb = iter_num_blocks(ns);
-  const long need = ((long)ns + WARM_CHUNK_MAX - 1) / WARM_CHUNK_MAX;      // a block's chunk must fit its lists
-  if (need > nb) nb = need;
+  // ONE generation of blocks (4 resident per CU: registers, LDS): every wave searches its list once, at the end of its chunk --
+  // with more, shorter blocks those latency-bound tails take wave slots from the streaming ones (measured: 2048 / 4096 / 8192
+  // blocks 0.106 / 0.124 / 0.142 ms at 10M)
+  static const long exp_nb = [] { const char* e = getenv("CILHIP_EXP_WARM_BLOCKS"); return e ? atol(e) : 0L; }();
+  const long cap = exp_nb > 0 ? exp_nb : 1024;
+  long nb = ((long)ns + WARM_THREADS - 1) / WARM_THREADS;
+  if (nb > cap) nb = cap;
+  if (nb < 8) nb = 8;
   return (int)((nb + 7) & ~7L);
 }
 void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_t s) {
