@@ -990,8 +990,20 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
 __device__ unsigned long long g_phase_clk[8];
 #define PHASE_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_clk[k], now_ - tprev_); tprev_ = now_; } } while (0)
 void debug_dump_pipe_clocks();
+__device__ unsigned long long g_warm_clk[8];
+#define WARM_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_warm_clk[k], now_ - tprev_); atomicAdd(&g_warm_clk[4 + (k)], 1ull); tprev_ = now_; } } while (0)
+static void debug_dump_warm_clocks() {
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_warm_clk), sizeof h) != hipSuccess) return;
+  if (h[4] == 0) return;
+  fprintf(stderr, "[warm clocks, 100 MHz ticks per block (thread 0), %llu blocks] prologue=%.1f stream=%.1f list=%.1f end=%.1f\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4],
+          (double)h[2] / h[4], (double)h[3] / h[4]);
+  memset(h, 0, sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warm_clk), h, sizeof h);
+}
 void debug_dump_phase_clocks() {
   debug_dump_pipe_clocks();
+  debug_dump_warm_clocks();
   unsigned long long h[8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof h) != hipSuccess) return;
   unsigned long long tot = 0;
@@ -1003,6 +1015,7 @@ void debug_dump_phase_clocks() {
 }
 #else
 #define PHASE_CLK(k)
+#define WARM_CLK(k)
 #endif
 
 // Region of every tile under the CURRENT transform, once per search instead of once per wave of the search kernel (the
@@ -2080,9 +2093,10 @@ constexpr int WARM_WAVES = WARM_THREADS / 64;
 // one, and the whole wave would walk the search code for it: each wave lists them in LDS (ballot order: no atomics, the
 // same list in every run) and searches the list afterwards, densely packed (the list holds all of the wave's queries if
 // need be: a source far from alignment).
-constexpr int WARM_QCAP = 1024;                             // listed queries per wave; a list that could not take another round is searched at once
+constexpr int WARM_QCAP = 256;                              // listed queries per wave (16 B each); a list that could not take another round is searched at once
+#define Z4 make_float4(0.f, 0.f, 0.f, 0.f)
 template <int ACC, int REC>
-__global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
+__global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
   float T[12];
@@ -2093,10 +2107,13 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};
   const GridDev& g = a.grid;
   __shared__ __attribute__((aligned(16))) unsigned char raw[WARM_WAVES * FUSED_WAVE_BYTES];
-  __shared__ uint32_t dq[WARM_WAVES][WARM_QCAP];
+  __shared__ float4 dq[WARM_WAVES][WARM_QCAP];             // listed queries: {q = T s, index}
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
-  uint32_t* const wq = dq[wave];
+  float4* const wq = dq[wave];
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+  unsigned long long tprev_ = wall_clock64();
+#endif
   typedef double double4_t __attribute__((ext_vector_type(4)));
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   constexpr int NC = FusedZ<ACC>::NC;
@@ -2111,7 +2128,6 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
   const float half = 0.5f * g.cell;
   const int sy = g.nx, sz = g.nx * g.ny;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t nfar = 0;
 
   auto transform = [&](const float4 s4, float& qx, float& qy, float& qz) {
@@ -2121,13 +2137,11 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
   };
 
   // rank update of the wave's 16x16 tile with one round of (up to) 64 correspondences (k_search_tiled, step 5)
-  auto rank_update = [&](bool has, float qx, float qy, float qz, const float4 pm, const float4 nm) {
+  // (two halves: the terms z of the wave's correspondences -> LDS; then LDS -> f64 operands -> the matrix cores.  Between them
+  //  a round's streamed registers are dead, which is where the streaming loop requests the data of the round after next.)
+  auto z_to_lds = [&](bool has, float qx, float qy, float qz, const float4 pm, const float4 nm) {
     float z[16];
     fused_z<ACC>(has, qx, qy, qz, pm, nm, a.dst_mean, smt, z);
-#if defined(CILHIP_EXP_WARM_NOACC)
-    if (z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7] == 1.2345e30f) acc[0] += 1.0;
-    return;
-#endif
     if (DUAL) {
       float4* w4 = reinterpret_cast<float4*>(zb + lane * 8 + (lane >= 32 ? 16 : 0));
       w4[0] = make_float4(z[0], z[1], z[2], z[3]);
@@ -2137,6 +2151,8 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
 #pragma unroll
       for (int c = 0; c < NC / 2; ++c) w2[c] = make_float2(z[2 * c], z[2 * c + 1]);
     }
+  };
+  auto lds_to_mfma = [&]() {
     __builtin_amdgcn_wave_barrier();
     if (DUAL) {
       const int comp = lane & 7, hf = (lane >> 3) & 1, k4 = lane >> 4;
@@ -2144,11 +2160,7 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
       for (int jj = 0; jj < 8; ++jj) {
         const int qi = hf * 32 + 4 * jj + k4;
         const double x = (double)zb[qi * 8 + hf * 16 + comp];
-#if defined(CILHIP_EXP_WARM_NOMFMA)
-        acc[0] += x;
-#else
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
-#endif
       }
     } else {
       const int comp = lane & 15, k4 = lane >> 4;
@@ -2161,27 +2173,24 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   };
+  auto rank_update = [&](bool has, float qx, float qy, float qz, const float4 pm, const float4 nm) {
+    z_to_lds(has, qx, qy, qz, pm, nm);
+    lds_to_mfma();
+  };
 
-  // The search of one query the table did not settle: from its old match (a real target point: its distance bounds the
-  // search) inside the octant block when the bound allows, else the generic shell search.  Stores what changed.
-  auto slow = [&](uint32_t i, float qx, float qy, float qz, float4& pm, float4& nm) -> bool {
-    const uint32_t w = a.warm_pos[i];
-    float4 pw = zero4, nw = zero4;
-    float s2 = -1.0f;
-    if (w != NONE_U32) { pw = g.pts[w]; s2 = a.safe2[w]; if (NRM) nw = g.nrm[w]; }
-    NN best;
-    best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
-    best.pos = NONE_U32;
-    float e_old = INFINITY;
-    if (w != NONE_U32) {
-      e_old = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
-      if (e_old < a.max_sq) { best.key = ((unsigned long long)__float_as_uint(e_old) << 32) | __float_as_uint(pw.w); best.pos = w; }
-    }
+  // The search of the queries the table did not settle, one list round (64 entries) at a time.  An entry carries the query
+  // (index and transformed point), so everything that depends on them alone is requested TOGETHER: the stored position and
+  // the match record, and the run boundaries of the four rows of the octant block (three cell-table entries per row cover
+  // both "own cell" and "own cell + the neighbour q leans to").  Then one trip for up to eight candidates, one more for the
+  // new match's data if the match changed: three to four memory round trips instead of eight -- the tail every wave runs
+  // through at the end of its chunk is latency, not bandwidth.  From the old match (a real target point: its distance
+  // bounds the search) inside the octant block when the bound allows, else the generic shell search.  Stores what changed.
+  auto slow_round = [&](bool v, uint32_t i, float qx, float qy, float qz, float4& pm, float4& nm) -> bool {
     const float BIG = 1.0e9f;
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG), fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG),
                 fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
     const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-    const bool inner = (cx >= 1) & (cx <= g.nx - 2) & (cy >= 1) & (cy <= g.ny - 2) & (cz >= 1) & (cz <= g.nz - 2);
+    const bool inner = v & (cx >= 1) & (cx <= g.nx - 2) & (cy >= 1) & (cy <= g.ny - 2) & (cz >= 1) & (cz <= g.nz - 2);
     // offsets inside the cell; per axis: which neighbour q leans to, the gap to the face shared with it, the gap to the far
     // face of the own cell (beyond which the octant block ends)
     const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
@@ -2189,42 +2198,78 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     const float nx_ = fmaxf((lx ? ux : g.cell - ux) - g.margin, 0.0f), ny_ = fmaxf((ly ? uy : g.cell - uy) - g.margin, 0.0f),
                 nz_ = fmaxf((lz ? uz : g.cell - uz) - g.margin, 0.0f);
     const float ob = fminf(fminf(lx ? g.cell - ux : ux, ly ? g.cell - uy : uy), lz ? g.cell - uz : uz) - g.margin;   // nearest face of the octant block
+    const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+    const int dy = ly ? -sy : sy, dz = lz ? -sz : sz;
+    // trip 1: all that depends on (i, q) alone -- straight-line, from addresses that are valid for every lane (a lane without
+    // an entry reads entry 0's data, a query outside the inner cells the rows of cell (1,1,1); both are masked afterwards),
+    // so that the loads leave together instead of one exec-masked group after the other
+    const uint32_t ii = v ? i : 0u;
+    uint32_t w = a.warm_pos[ii];
+    float4 r0 = Z4, s4 = Z4;
+    F3 r1 = {0.f, 0.f, 0.f};
+    if (REC == 2) { r0 = a.warm_rec[ii]; if (NRM) r1 = a.warm_rec_n[ii]; }
+    if (REC == 1) s4 = a.src[ii];
+    uint32_t cs[12];
+    {
+      const int xo = lx ? -1 : 0;
+      const int r00 = inner ? (int)cid : sz + sy + 1;
+      const int rows[4] = {r00, r00 + dy, r00 + dz, r00 + dy + dz};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cs[3 * r] = g.cell_start[rows[r] + xo]; cs[3 * r + 1] = g.cell_start[rows[r] + xo + 1]; cs[3 * r + 2] = g.cell_start[rows[r] + xo + 2];
+      }
+    }
+    if (!v) w = NONE_U32;
+    // the old match: from its record, else (trip 1b) through the stored position
+    float4 pw = Z4, nw = Z4;
+    float s2 = -1.0f;
+    if (REC == 2) { pw = make_float4(r0.x, r0.y, r0.z, __uint_as_float(0xFFFFFFFFu)); nw = make_float4(r1.x, r1.y, r1.z, 0.f); s2 = r0.w; if (s2 < 0.0f) w = NONE_U32; }
+    else if (w != NONE_U32) { pw = g.pts[w]; s2 = a.safe2[w]; if (NRM) nw = g.nrm[w]; }
+    NN best;
+    best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
+    best.pos = NONE_U32;
+    float e_old = INFINITY;
+    if (w != NONE_U32) {
+      e_old = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
+      // (REC 2: the record does not hold the old match's original index; the placeholder loses every tie, and the old
+      //  match itself -- inside the ball it defines, hence inside the cells searched below -- is met again with its own)
+      if (e_old < a.max_sq) { best.key = ((unsigned long long)__float_as_uint(e_old) << 32) | __float_as_uint(pw.w); best.pos = w; }
+    }
     const bool bounded = best.pos != NONE_U32 && inner && ob > 0.0f && e_old < ob * ob * KSHRINK;
     if (bounded) {
       const float bd = e_old;
       const bool kx = nx_ * nx_ * KSHRINK <= bd, ky = ny_ * ny_ * KSHRINK <= bd, kz = nz_ * nz_ * KSHRINK <= bd;   // the ball reaches that neighbour
-      const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
-      const int xlo = (kx && lx) ? -1 : 0, xhi = (kx && !lx) ? 2 : 1;
-      const int dy = ly ? -sy : sy, dz = lz ? -sz : sz;
-      // up to four runs (rows y / y', z / z'), each one or two x-adjacent cells: boundaries fetched together
-      uint32_t rb[4] = {0u, 0u, 0u, 0u}, re[4] = {0u, 0u, 0u, 0u};
-      { const uint32_t r = cid; rb[0] = g.cell_start[(int)r + xlo]; re[0] = g.cell_start[(int)r + xhi]; }
-      if (ky) { const uint32_t r = cid + (uint32_t)dy; rb[1] = g.cell_start[(int)r + xlo]; re[1] = g.cell_start[(int)r + xhi]; }
-      if (kz) { const uint32_t r = cid + (uint32_t)dz; rb[2] = g.cell_start[(int)r + xlo]; re[2] = g.cell_start[(int)r + xhi]; }
-      if (ky && kz) { const uint32_t r = cid + (uint32_t)(dy + dz); rb[3] = g.cell_start[(int)r + xlo]; re[3] = g.cell_start[(int)r + xhi]; }
-      const uint32_t c0 = re[0] - rb[0], c1 = c0 + (re[1] - rb[1]), c2 = c1 + (re[2] - rb[2]), total = c2 + (re[3] - rb[3]);
-      for (uint32_t t = 0; t < total; t += 4) {
-        uint32_t j[4];
+      // up to four runs (rows y / y', z / z'), each one or two x-adjacent cells
+      uint32_t rb[4], re[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+      for (int r = 0; r < 4; ++r) {
+        const bool on = r == 0 || (r == 1 && ky) || (r == 2 && kz) || (r == 3 && ky && kz);
+        const uint32_t A = cs[3 * r], B = cs[3 * r + 1], C = cs[3 * r + 2];
+        rb[r] = on ? ((lx && !kx) ? B : A) : 0u;
+        re[r] = on ? ((!lx && !kx) ? B : C) : 0u;
+      }
+      const uint32_t c0 = re[0] - rb[0], c1 = c0 + (re[1] - rb[1]), c2 = c1 + (re[2] - rb[2]), total = c2 + (re[3] - rb[3]);
+      for (uint32_t t = 0; t < total; t += 8) {
+        uint32_t j[8];
+        float4 pc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
           const uint32_t tt = min(t + (uint32_t)k, total - 1u);      // (re-evaluating a candidate never changes the result)
           j[k] = tt < c0 ? rb[0] + tt : tt < c1 ? rb[1] + (tt - c0) : tt < c2 ? rb[2] + (tt - c1) : rb[3] + (tt - c2);
         }
-        const float4 p0 = g.pts[j[0]], p1 = g.pts[j[1]], p2 = g.pts[j[2]], p3 = g.pts[j[3]];
-        const float e0 = d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z), e1 = d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z);
-        const float e2 = d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z), e3 = d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z);
-        const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
-        const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
-        const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
-        const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
-        if (k0 < best.key) { best.key = k0; best.pos = j[0]; }
-        if (k1 < best.key) { best.key = k1; best.pos = j[1]; }
-        if (k2 < best.key) { best.key = k2; best.pos = j[2]; }
-        if (k3 < best.key) { best.key = k3; best.pos = j[3]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pc[k] = g.pts[j[k]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float e = d2_pinned(qx, qy, qz, pc[k].x, pc[k].y, pc[k].z);
+          const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(pc[k].w);
+          if (key < best.key) { best.key = key; best.pos = j[k]; }
+        }
       }
-    } else {
+    } else if (v) {
       // no usable bound: the generic exact search (shells around the query's cell, pruned by whatever `best` holds)
       ++nfar;
+      if (REC == 2 && best.pos != NONE_U32) best.key = ((unsigned long long)__float_as_uint(e_old) << 32) | __float_as_uint(g.pts[w].w);
       const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
       bool skip = false;
       int s0 = 0;
@@ -2237,55 +2282,28 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
       if (!skip) nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
     }
     const bool same = best.pos == w, has = best.pos != NONE_U32;
-    pm = nm = zero4;
+    pm = nm = Z4;
     if (has) {
       if (same) { pm = pw; nm = nw; }
       else { pm = g.pts[best.pos]; s2 = a.safe2[best.pos]; if (NRM) nm = g.nrm[best.pos]; }
     }
-    if (!same || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
-    if (REC == 1) { const float4 t4 = a.src[i]; a.warm_src3[i] = F3{t4.x, t4.y, t4.z}; }
-    if (REC == 1 || (REC == 2 && !same)) {
-      a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, has ? s2 : -1.0f);
-      if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z};
+    if (v) {
+      if (!same || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
+      if (REC == 1) a.warm_src3[i] = F3{s4.x, s4.y, s4.z};
+      if (REC == 1 || (REC == 2 && !same)) {
+        a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, has ? s2 : -1.0f);
+        if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z};
+      }
     }
-    if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     return has;
   };
 
   uint32_t qcount = 0;      // (wave-uniform)
-  uint32_t inext = beg + threadIdx.x;
-  // what a round streams in: REC 0 / 1 the sorted source record and the stored position; REC 2 the 12-byte copy of the source
-  // point and the match record {point, table entry} {normal} -- 40 B per query (28 without normals), all of it coalesced
-  const F3 zero3 = {0.f, 0.f, 0.f};
-  F3 s3n = zero3, r1n = zero3;
-  float4 r0n = zero4;
-  uint32_t wn = NONE_U32;
-  auto fetch = [&](uint32_t k) {
-    if (REC == 2) { s3n = a.warm_src3[k]; r0n = a.warm_rec[k]; if (NRM) r1n = a.warm_rec_n[k]; }
-    else { const float4 t4 = a.src[k]; s3n = F3{t4.x, t4.y, t4.z}; wn = a.warm_pos[k]; }
-  };
-  if (inext < end) fetch(inext);
-  uint32_t base = beg, qlisted = 0;
-  for (;;) {
-  // stream rounds until the chunk is done -- or the wave's list could not take another round's queries (a source far from
-  // alignment lists most of them): then the list is searched first
-  for (; base < end && qcount <= (uint32_t)(WARM_QCAP - 64); base += WARM_THREADS) {
-    const uint32_t i = inext;
-    const bool valid = i < end;
-    const F3 s3c = s3n;
-    const float4 s4 = make_float4(s3c.x, s3c.y, s3c.z, 0.f);
-    const uint32_t w = wn;
-    const float4 r0 = r0n;
-    const F3 r1 = r1n;
-    inext += WARM_THREADS;
-    if (inext < end) fetch(inext);
+  // One round of the streaming loop for the query whose data has arrived: transform, the table's test, what a settled
+  // query stores, the list entry of an unsettled one, the rank update.
+  auto round = [&](uint32_t i, bool valid, const F3 s3c, uint32_t w, float4 pm, float4 nm, float s2) {
     float qx, qy, qz;
-    transform(s4, qx, qy, qz);
-    // the old match, its normal and its table entry: from the record, or gathered through the stored position
-    float4 pm = zero4, nm = zero4;
-    float s2 = -1.0f;                     // (< 0: no old match)
-    if (REC == 2) { pm = make_float4(r0.x, r0.y, r0.z, 0.f); nm = make_float4(r1.x, r1.y, r1.z, 0.f); s2 = r0.w; }
-    else if (valid && w != NONE_U32) { pm = g.pts[w]; s2 = a.safe2[w]; if (NRM) nm = g.nrm[w]; }
+    transform(make_float4(s3c.x, s3c.y, s3c.z, 0.f), qx, qy, qz);
     // Nearer to the old match than half the distance from it to any other target point: it is THE nearest, nothing to look
     // at -- not even the query's cell (the factor covers the 2^-22 relative rounding of the three f32 squared distances).
     const float e_old = d2_pinned(qx, qy, qz, pm.x, pm.y, pm.z);
@@ -2293,34 +2311,110 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     if (settled) {
       if (REC != 2 && a.nn_pos != a.warm_pos) a.nn_pos[i] = w;
       if (REC == 1) { a.warm_src3[i] = s3c; a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, s2); if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z}; }
-      if (a.nn_d2) a.nn_d2[i] = e_old;
     }
     const bool todo = valid && !settled;
     const unsigned long long um = __ballot(todo);
-    if (todo) wq[qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = i;
+    if (todo) wq[qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = make_float4(qx, qy, qz, __uint_as_float(i));
     qcount += (uint32_t)__popcll(um);
-    rank_update(settled, qx, qy, qz, pm, nm);
+    z_to_lds(settled, qx, qy, qz, pm, nm);
+  };
+  // What a round streams in.  REC 2: the 12-byte copy of the source point and the match record {point, table entry} {normal}
+  // -- 40 B per query (28 without normals), all of it coalesced, TWO rounds in flight per wave (sets A and B; vmcnt retires in
+  // order, so the wait for A leaves B's loads flying).  REC 0 / 1: the sorted source record and the stored position one
+  // round, the gathers through that position (old match, its normal, its table entry) the next: a three-stage pipeline
+  // with one wait per round for loads that were issued a whole round earlier.
+  uint32_t base = beg, qlisted = 0;
+  F3 sA = F3{0.f, 0.f, 0.f}, nA = F3{0.f, 0.f, 0.f}, sB = F3{0.f, 0.f, 0.f}, nB = F3{0.f, 0.f, 0.f};
+  float4 rA = Z4, rB = Z4;
+  uint32_t iA = beg + threadIdx.x, iB = iA + WARM_THREADS;
+  // (REC 0 / 1) stage 1 -> 2: source record + position of the round after next; stage 2 -> 3: what was gathered for the next round
+  uint32_t w1 = NONE_U32, w2 = NONE_U32;
+  F3 s1 = F3{0.f, 0.f, 0.f}, s2_ = F3{0.f, 0.f, 0.f};
+  float4 gp = Z4, gn = Z4;
+  float gs = -1.0f;
+  // (the three loads leave in THIS order everywhere -- scheduling barriers -- : the wait for a set is computed from the
+  //  position of its loads in the in-order vmcnt queue, merged over all paths into the loop)
+  auto load2 = [&](uint32_t k, F3& sv, float4& rv, F3& nv) {
+    __builtin_amdgcn_sched_barrier(0);
+    sv = a.warm_src3[k];
+    __builtin_amdgcn_sched_barrier(0);
+    rv = a.warm_rec[k];
+    __builtin_amdgcn_sched_barrier(0);
+    if (NRM) nv = a.warm_rec_n[k];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto load1 = [&](uint32_t k, F3& sv, uint32_t& wv) { const float4 t4 = a.src[k]; sv = F3{t4.x, t4.y, t4.z}; wv = a.warm_pos[k]; };
+  // (every load of the streaming loop is UNCONDITIONAL, from an index clamped into the chunk / a position clamped into the
+  //  target: a load under a divergent branch may or may not have been issued as far as the compiler's vmcnt bookkeeping
+  //  is concerned, and the waits it then inserts drain the younger prefetches as well)
+  const uint32_t last = end > beg ? end - 1u : 0u;
+  auto gather = [&](uint32_t wv) {
+    const uint32_t wc = wv != NONE_U32 ? wv : 0u;
+    gp = g.pts[wc]; gs = a.safe2[wc]; if (NRM) gn = g.nrm[wc];
+    if (wv == NONE_U32) { gp = gn = Z4; gs = -1.0f; }
+  };
+  WARM_CLK(0);
+  for (;;) {
+  // (the pipeline is filled HERE, at every entry of the streaming loop -- also after a list that had to be searched early:
+  //  registers with loads in flight must not live across that search, where they would be spilled and reloaded)
+  // (unconditionally: an empty chunk reads element 0, which exists)
+  if (REC == 2) {
+    load2(min(iA, last), sA, rA, nA);
+    load2(min(iB, last), sB, rB, nB);
+  } else {
+    load1(min(iA, last), s2_, w2);         // next round: record, then (dependent) its gathers
+    gather(w2);
+    load1(min(iA + WARM_THREADS, last), s1, w1);      // the round after: record
+  }
+  // stream rounds until the chunk is done -- or the wave's list could not take two more rounds' queries (a source far from
+  // alignment lists most of them): then the list is searched first
+  if (REC == 2) {
+    for (; base < end && qcount <= (uint32_t)(WARM_QCAP - 128); base += 2 * WARM_THREADS) {
+      // (a set's registers are consumed -- down to the terms in LDS -- BEFORE the set is requested again, so that the new
+      //  loads can land in the same registers: no copy at the loop's end that would have to wait for them)
+      round(iA, iA < end, sA, NONE_U32, make_float4(rA.x, rA.y, rA.z, 0.f), make_float4(nA.x, nA.y, nA.z, 0.f), rA.w);
+      __builtin_amdgcn_sched_barrier(0);
+      iA += 2 * WARM_THREADS;
+      load2(min(iA, last), sA, rA, nA);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_to_mfma();
+      round(iB, iB < end, sB, NONE_U32, make_float4(rB.x, rB.y, rB.z, 0.f), make_float4(nB.x, nB.y, nB.z, 0.f), rB.w);
+      __builtin_amdgcn_sched_barrier(0);
+      iB += 2 * WARM_THREADS;
+      load2(min(iB, last), sB, rB, nB);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_to_mfma();
+    }
+  } else {
+    for (; base < end && qcount <= (uint32_t)(WARM_QCAP - 64); base += WARM_THREADS) {
+      const uint32_t i = iA;
+      const F3 sc = s2_;
+      const uint32_t wc = w2;
+      const float4 pc = gp, nc = gn;
+      const float gc = gs;
+      // next round: its record has arrived, its gathers leave now; the round after: its record leaves now
+      iA += WARM_THREADS;
+      s2_ = s1; w2 = w1;
+      gather(w2);
+      load1(min(iA + WARM_THREADS, last), s1, w1);
+      round(i, i < end, sc, wc, pc, nc, gc);
+      lds_to_mfma();
+    }
   }
   // the listed queries, 64 per round
   __builtin_amdgcn_wave_barrier();
-#if defined(CILHIP_EXP_WARM_NOSLOW)
-  qcount = 0;
-#endif
+  WARM_CLK(1);
   for (uint32_t b0 = 0; b0 < qcount; b0 += 64u) {
     const bool v = b0 + (uint32_t)lane < qcount;
-    const uint32_t li = v ? wq[b0 + (uint32_t)lane] : 0u;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    float4 pm = zero4, nm = zero4;
-    bool has = false;
-    if (v) {
-      transform(a.src[li], qx, qy, qz);
-      has = slow(li, qx, qy, qz, pm, nm);
-    }
-    rank_update(has, qx, qy, qz, pm, nm);
+    const float4 ent = wq[min(b0 + (uint32_t)lane, (uint32_t)(WARM_QCAP - 1))];      // (lanes beyond the list: masked by v)
+    float4 pm = Z4, nm = Z4;
+    const bool has = slow_round(v, __float_as_uint(ent.w), ent.x, ent.y, ent.z, pm, nm);
+    rank_update(has, ent.x, ent.y, ent.z, pm, nm);
   }
   qlisted += qcount;
   qcount = 0;
   __builtin_amdgcn_wave_barrier();
+  WARM_CLK(2);
   if (base >= end) break;
   }
   if (a.unproven_cnt) {
@@ -2348,8 +2442,10 @@ __global__ __launch_bounds__(WARM_THREADS) void k_warm(IterArgs a) {
     }
     a.partials[(size_t)vb * SUMS_MAX + threadIdx.x] = v1 - v2;
   }
+  WARM_CLK(3);
 }
 
+#undef Z4
 template <int ACC>
 static void launch_warm_m(const IterArgs& a, int rec, int nblocks, hipStream_t s) {
   const dim3 g(nblocks), b(WARM_THREADS);
@@ -2368,6 +2464,9 @@ int warm_num_blocks(uint32_t ns) {
   if (nb < 8) nb = 8;
   return (int)((nb + 7) & ~7L);
 }
+// (squared distances are NOT written by this form -- a store inside the streaming loop shares the in-order vmcnt counter with
+//  the prefetched loads; nobody reads them in the configurations that run warm-started (no post-filters, no weight
+//  evaluators), and launch_fill_d2 recomputes them from the stored matches on demand)
 void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_t s) {
   switch (metric) {
     case IM_KABSCH: launch_warm_m<IM_KABSCH>(a, rec, nblocks, s); break;
