@@ -73,7 +73,7 @@ def parse():
 def source_hash():
     """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp"):
+    for f in ("kernels.hip", "tile_pipe.inc", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp"):
         with open(os.path.join(ROOT, "cilantro_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -276,15 +276,18 @@ def bench_icp(a, torch, rank, world, local_rank):
         dom = max(ft, key=lambda f: ft[f][0]) if launches > 0 else None      # the form the timed region spent most kernel time in
         fused = dom is not None and dom != 0
         traffic, traffic_note = None, "no PMC measurement of this build / workload committed"
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            w = tj["workload"]
-            if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and tj.get("form") == dom:
-                traffic, traffic_note = float(tj["traffic_bytes_per_launch"]), tj.get("method", "")
-            else:
-                traffic_note = "profiles/r02_traffic.json was measured on another build, workload or kernel form: not quoted"
-        except Exception:
-            pass
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):      # newest round first
+            try:
+                tj = json.load(open(tf))
+                w = tj["workload"]
+                if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and tj.get("form") == dom:
+                    traffic, traffic_note = float(tj["traffic_bytes_per_launch"]), os.path.basename(tf) + ": " + tj.get("method", "")
+                    break
+                if traffic_note.startswith("no PMC"):      # (name the newest file only)
+                    traffic_note = "profiles/" + os.path.basename(tf) + " was measured on another build, workload or kernel form: not quoted"
+            except Exception:
+                pass
         roof = None
         if dom is not None:      # (sharded runs: rank 0's own kernels)
             kern, alg_bytes = FORMS[dom]

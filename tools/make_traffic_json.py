@@ -3,7 +3,7 @@
 profiles/r02_calibration.txt: on this gfx950 / rocprofv3, FETCH_SIZE counts 128-B fabric requests at 64 B each (every read
 pattern: x2), WRITE_SIZE is exact.  usage: tools/make_traffic_json.py <pmc dir> [kernel regex ...]  ->  JSON on stdout; without
 a regex the kernels of the bench line's dominant form (<pmc dir>/bench_line.json, roofline.form) are taken
-(commit it as profiles/r02_traffic.json: bench.py quotes it only while the kernel sources still hash to `source_hash`)."""
+(commit it as profiles/rNN_traffic.json: bench.py quotes it only while the kernel sources still hash to `source_hash`)."""
 import collections, csv, glob, json, os, re, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
