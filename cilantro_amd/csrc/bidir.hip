@@ -69,7 +69,7 @@ __device__ __forceinline__ float mapped_bound(float gap, const InvArgs& iv) { re
 template <bool FEAT6>
 __device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, uint32_t beg, uint32_t end, const float* T, float px, float py, float pz,
                                                unsigned long long& bkey, uint32_t& bpos, const FeatSpec* fs = nullptr, float pfx = 0.f, float pfy = 0.f,
-                                               float pfz = 0.f) {
+                                               float pfz = 0.f, float pgx = 0.f, float pgy = 0.f, float pgz = 0.f) {
   if (beg >= end) return;
   const uint32_t last = end - 1;
   for (uint32_t j = beg; j < end; j += 4) {
@@ -86,7 +86,12 @@ __device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, u
       if (FEAT6) {
         float fx, fy, fz;
         source_feature(*fs, T, fs->src[jj[k]], fx, fy, fz);
-        e = d6_features(px, py, pz, pfx, pfy, pfz, qx, qy, qz, fx, fy, fz);
+        if (fs->dst2 != nullptr) {      // 9-D: the colour part does not follow the transform
+          const float4 sc = fs->src2[jj[k]];
+          e = d9_features(px, py, pz, pfx, pfy, pfz, pgx, pgy, pgz, qx, qy, qz, fx, fy, fz, __fmul_rn(fs->w2, sc.x), __fmul_rn(fs->w2, sc.y), __fmul_rn(fs->w2, sc.z));
+        } else {
+          e = d6_features(px, py, pz, pfx, pfy, pfz, qx, qy, qz, fx, fy, fz);
+        }
       } else {
         const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
         e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -118,7 +123,9 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
   for (uint32_t jd = blockIdx.x * blockDim.x + threadIdx.x; jd < nd; jd += gridDim.x * blockDim.x) {
     const float4 p = dst_sorted[jd];
     float pfx = 0.f, pfy = 0.f, pfz = 0.f;
+    float pgx = 0.f, pgy = 0.f, pgz = 0.f;
     if (FEAT6) { const float4 v = fs.dst[jd]; pfx = __fmul_rn(fs.w, v.x); pfy = __fmul_rn(fs.w, v.y); pfz = __fmul_rn(fs.w, v.z); }      // the adaptor stores w * v (:90)
+    if (FEAT6 && fs.dst2 != nullptr) { const float4 v = fs.dst2[jd]; pgx = __fmul_rn(fs.w2, v.x); pgy = __fmul_rn(fs.w2, v.y); pgz = __fmul_rn(fs.w2, v.z); }
     float sx, sy, sz;
     transform_point(iv.Ti, p.x, p.y, p.z, sx, sy, sz);
     unsigned long long bkey = (unsigned long long)__float_as_uint(max_sq) << 32;
@@ -155,12 +162,12 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
           const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
           if (face) {
             const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
-            if (xa <= xb) scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz);
+            if (xa <= xb) scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
           } else {
             if (xlo >= 0 && xlo < sg.nx)
-              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz);
+              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
             if (xhi >= 0 && xhi < sg.nx)
-              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz);
+              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
           }
         }
       }

@@ -120,6 +120,8 @@ struct cilhip_ctx {
                                   // 1 = v = colours, untouched by it (PointColorFeaturesAdaptor; cilhip_set_color_features)
   float *d_dst_rgb = nullptr, *d_src_rgb = nullptr;             // colour features, original order
   float4 *d_dst_rgb_sorted = nullptr, *d_src_rgb_sorted = nullptr;
+  float4* d_src_rgb_grid = nullptr;      // the source's colours in the order of the source's own grid (9-D reverse search)
+  float color_weight = 0.0f;             // option "feature_color_weight" (feature_kind 2: the 9-D adaptor's colour weight)
   bool dst_rgb_sorted_ok = false;
   float src_nrm0[3] = {0, 0, 0};  // the first source normal (the affine feature adaptor's normal weight is |w n_0|, adaptors.hpp:113-114)
   float feat_M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};              // L^-T of the transform being searched under (affine adaptor)
@@ -165,6 +167,10 @@ static int fail(cilhip_ctx* c, int code, const char* msg) {
 static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
 // the stored correspondence set (matches or pair list) no longer describes anything a caller may read
+static void drop_src_grid(cilhip_ctx* c) {
+  if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }
+  if (c->d_src_rgb_grid) { (void)hipFree(c->d_src_rgb_grid); c->d_src_rgb_grid = nullptr; }
+}
 static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->pending_matches = false; c->matches_origin = 0; }
 
 extern "C" {
@@ -222,7 +228,7 @@ static void free_source(cilhip_ctx* c) {
   c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_defer_mask = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
-  if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }
+  drop_src_grid(c);
   if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
   c->has_source = false; c->src_sorted = false; drop_matches(c); c->ns = 0;
   c->have_pairs = false; c->pairs.count = 0;   // a pair list refers to the source / target it was found on
@@ -309,8 +315,15 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
     return CILHIP_OK;
   }
   if (!strcmp(key, "feature_kind")) {
-    if (value != 0.0 && value != 1.0) return fail(c, CILHIP_ERR_INVALID, "feature_kind: 0 = normals (follow the transform), 1 = colours (do not)");
+    if (value != 0.0 && value != 1.0 && value != 2.0)
+      return fail(c, CILHIP_ERR_INVALID, "feature_kind: 0 = normals (follow the transform), 1 = colours (do not), 2 = normals + colours (9-D)");
+    if ((int)value != c->feature_kind) drop_src_grid(c);      // (the source's grid carries the feature vectors of the reverse searches)
     c->feature_kind = (int)value; drop_matches(c); c->have_pairs = false;
+    return CILHIP_OK;
+  }
+  if (!strcmp(key, "feature_color_weight")) {
+    if (!(value >= 0.0)) return fail(c, CILHIP_ERR_INVALID, "feature_color_weight: >= 0");
+    c->color_weight = (float)value; drop_matches(c); c->have_pairs = false;
     return CILHIP_OK;
   }
   if (!strcmp(key, "symmetric_metric")) { c->symmetric = value != 0.0; return CILHIP_OK; }
@@ -451,7 +464,7 @@ int cilhip_set_source_normals(cilhip_ctx* c, const float* nrm, int mem) {
   if (c->d_src_nrm) { (void)hipFree(c->d_src_nrm); c->d_src_nrm = nullptr; }
   if (c->d_src_nrm_sorted) { (void)hipFree(c->d_src_nrm_sorted); c->d_src_nrm_sorted = nullptr; }
   c->have_pairs = false; c->pairs.count = 0;
-  if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }      // (it carries the feature vectors of the reverse searches)
+  drop_src_grid(c);      // (it carries the feature vectors of the reverse searches)
   if (!nrm) return CILHIP_OK;                              // back to the 3-cloud (non-symmetric) form
   int rc = upload(c, nrm, 3 * (size_t)c->ns, mem, &c->d_src_nrm);
   if (rc) return rc;
@@ -482,7 +495,7 @@ int cilhip_set_color_features(cilhip_ctx* c, const float* dst_rgb, const float* 
   CK(c, hipMalloc(&c->d_src_rgb_sorted, (c->ns ? c->ns : 1) * sizeof(float4)));
   c->dst_rgb_sorted_ok = false;
   c->src_sorted = false;                                   // the source's sorted copy is (re)built with the next sort
-  if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }      // (it carries the features of the reverse searches)
+  drop_src_grid(c);      // (it carries the features of the reverse searches)
   drop_matches(c);
   c->have_pairs = false; c->pairs.count = 0;
   return CILHIP_OK;
@@ -620,8 +633,10 @@ static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params*
 // The warm-started iteration (k_warm) needs stored matches, unit weights and the first Gauss-Newton step's plain terms -- the
 // same engine conditions as the in-tile accumulation, but no tiles: it also serves clouds the tiles do not (a source much
 // sparser than the target: BASELINE configs[3]).
+// a feature adaptor is in force (6-D point+normal or point+colour, 9-D point+normal+colour): correspondences are compared by feature distance
+static bool feat6(const cilhip_ctx* c) { return c->normal_weight > 0.0f || (c->feature_kind == 2 && c->color_weight > 0.0f); }
 static bool warm_capable(const cilhip_ctx* c) {
-  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused;
 }
 // k_self_nn's nearest-other-point table (4 B per target point, 0.5 ms at 10M): built by the first warm-capable run on a target
 static int ensure_safe2(cilhip_ctx* c) {
@@ -631,7 +646,7 @@ static int ensure_safe2(cilhip_ctx* c) {
   return CILHIP_OK;
 }
 static bool tile_accumulation(const cilhip_ctx* c) {
-  return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !(c->normal_weight > 0.0f) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+  return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused;
 }
 
 // filterCorrespondencesFraction then filterCorrespondencesOneToOne on the stored matches
@@ -658,6 +673,7 @@ static FeatSpec feat_spec_of(const cilhip_ctx* c) {
   f.w = c->normal_weight;
   if (c->feature_kind == 1) { f.src = c->d_src_rgb_sorted; f.dst = c->d_dst_rgb_sorted; f.mode = 2; }
   else { f.src = c->d_src_nrm ? c->d_src_nrm_sorted : nullptr; f.dst = c->grid.nrm; f.mode = c->transform_mode == 1 ? 1 : 0; }
+  if (c->feature_kind == 2) { f.src2 = c->d_src_rgb_sorted; f.dst2 = c->d_dst_rgb_sorted; f.w2 = c->color_weight; }
   for (int i = 0; i < 9; ++i) f.M[i] = c->feat_M[i];
   // normal_weight = the norm of the FIRST source feature's normal part (adaptors.hpp:113-114), f32
   const float x = c->normal_weight * c->src_nrm0[0], y = c->normal_weight * c->src_nrm0[1], z = c->normal_weight * c->src_nrm0[2];
@@ -666,7 +682,7 @@ static FeatSpec feat_spec_of(const cilhip_ctx* c) {
 }
 // sorted copy of the target's colour features (gathered by the sorted records' original indices), built on first use
 static int ensure_feature_arrays(cilhip_ctx* c) {
-  if (c->feature_kind != 1) return CILHIP_OK;
+  if (c->feature_kind == 0) return CILHIP_OK;
   if (!c->d_dst_rgb || !c->d_src_rgb) return fail(c, CILHIP_ERR_INVALID, "colour features: cilhip_set_color_features first");
   if (!c->dst_rgb_sorted_ok) {
     if (!c->d_dst_rgb_sorted) CK(c, hipMalloc(&c->d_dst_rgb_sorted, (c->grid.n ? c->grid.n : 1) * sizeof(float4)));
@@ -703,9 +719,10 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
 // The SECOND_TO_FIRST search under the transform held by c->d_state: LDS-tiled or per-lane kernel for point features, the
 // 6-D feature search when a normal weight is set.
 static int launch_search(cilhip_ctx* c, const IterArgs& a) {
-  if (c->normal_weight > 0.0f) {
-    if (c->feature_kind == 0 && (!c->has_normals || !c->d_src_nrm)) return fail(c, CILHIP_ERR_INVALID, "point+normal features need target and source normals");
+  if (feat6(c)) {
+    if (c->feature_kind != 1 && (!c->has_normals || !c->d_src_nrm)) return fail(c, CILHIP_ERR_INVALID, "point+normal features need target and source normals");
     if (c->feature_kind == 1 && (!a.feat.src || !a.feat.dst)) return fail(c, CILHIP_ERR_INVALID, "colour features: cilhip_set_color_features first");
+    if (c->feature_kind == 2 && (!a.feat.src2 || !a.feat.dst2)) return fail(c, CILHIP_ERR_INVALID, "point+normal+colour features: cilhip_set_color_features first");
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "feature adaptors are not available on target shards");
     if (use_tiled(c)) launch_search_tiled_feat6(a, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_search_feat6(a, c->stream);
@@ -715,7 +732,6 @@ static int launch_search(cilhip_ctx* c, const IterArgs& a) {
   else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);                                 // per-lane global-memory search
   return CILHIP_OK;
 }
-static bool feat6(const cilhip_ctx* c) { return c->normal_weight > 0.0f; }
 
 // Search directions FIRST_TO_SECOND / BOTH with the transform held by c->d_state: fills c->pairs (post-filters included).
 // the source's own grid (source coordinates) and what else the list-free FIRST_TO_SECOND / BOTH loop needs
@@ -730,6 +746,10 @@ static int ensure_src_grid(cilhip_ctx* c) {
     const hipError_t eg = build_grid(c->d_src_xyz, attr, c->ns, c->stream, &r, mean, 1.0);
     if (eg != hipSuccess) { c->err = std::string("build_grid (source): ") + hipGetErrorString(eg); return CILHIP_ERR_HIP; }
     c->src_grid = r.grid; c->has_src_grid = true;
+  }
+  if (c->has_src_grid && c->feature_kind == 2 && c->d_src_rgb && !c->d_src_rgb_grid) {      // 9-D: the colours in the same order
+    CK(c, hipMalloc(&c->d_src_rgb_grid, (c->ns ? c->ns : 1) * sizeof(float4)));
+    launch_gather_by_w(c->src_grid.pts, c->d_src_rgb, c->ns, c->d_src_rgb_grid, c->stream);
   }
   return CILHIP_OK;
 }
@@ -761,7 +781,8 @@ static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq, const
   { const int grc = ensure_src_grid(c); if (grc) return grc; }
   FeatSpec rf = a.feat;                              // the reverse search reads the source's features in the source grid's order
   rf.src = c->has_src_grid ? c->src_grid.nrm : nullptr;
-  if (feat6(c) && (!rf.src || !rf.dst)) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
+  if (rf.dst2) rf.src2 = c->d_src_rgb_grid;
+  if (feat6(c) && (!rf.src || !rf.dst || (rf.dst2 && !rf.src2))) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
   if (!feat6(c)) rf.w = 0.0f;
   const hipError_t e = find_pairs(rf, c->grid, c->src_grid, c->d_src_xyz, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm : nullptr, c->d_src_sorted, c->ns, c->d_state,
                                   c->d_state_id, T_host, max_sq, c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2,
@@ -1331,7 +1352,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (rc) return rc;
       FeatSpec rf = a.feat;
       rf.src = c->src_grid.nrm;
-      if (feat6(c) && (!rf.src || !rf.dst)) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
+      if (rf.dst2) rf.src2 = c->d_src_rgb_grid;
+      if (feat6(c) && (!rf.src || !rf.dst || (rf.dst2 && !rf.src2))) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
       const int nb_f = iter_num_blocks(c->ns), nb_r = iter_num_blocks(c->grid.n);
       if (nb_f + nb_r > c->partial_blocks) {
         if (c->d_partials) (void)hipFree(c->d_partials);
@@ -1592,7 +1614,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
   if (filters_active(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "inlier_fraction / one_to_one are global filters: not available in sharded runs");
   if (c->search_dir != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available in sharded runs");
-  if (c->normal_weight > 0.0f || c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features and the affine variants are not available in sharded runs");
+  if (feat6(c) || c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features and the affine variants are not available in sharded runs");
   const float* Ti = T0 ? T0 : kIdentity;
   int rc = ensure_sorted(c, Ti);
   if (rc) return rc;

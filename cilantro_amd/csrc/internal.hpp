@@ -111,6 +111,11 @@ struct FeatSpec {
   int mode;
   float M[9];            // row-major L^-T (mode 1)
   float nw;
+  // 9-D point + normal + colour features (PointNormalColorFeaturesAdaptor, common_transformable_feature_adaptors.hpp:255-343): a
+  // SECOND attribute that does not follow the transform, weight w2; nullptr = 6-D
+  const float4* src2;
+  const float4* dst2;
+  float w2;
 };
 
 struct IterArgs {
@@ -230,6 +235,16 @@ __device__ __forceinline__ float d6_features(float ax, float ay, float az, float
   float r = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
   r = __fadd_rn(r, __fmul_rn(d4, d4));
   return __fadd_rn(r, __fmul_rn(d5, d5));
+}
+// ... and for DIM = 9 (point, w v, w2 c): two groups of four, result = 0 + g1, result += g2, then the tail adds d8*d8.
+__device__ __forceinline__ float d9_features(float ax, float ay, float az, float afx, float afy, float afz, float agx, float agy, float agz, float bx, float by, float bz,
+                                             float bfx, float bfy, float bfz, float bgx, float bgy, float bgz) {
+  const float d0 = __fsub_rn(ax, bx), d1 = __fsub_rn(ay, by), d2 = __fsub_rn(az, bz);
+  const float d3 = __fsub_rn(afx, bfx), d4 = __fsub_rn(afy, bfy), d5 = __fsub_rn(afz, bfz);
+  const float d6 = __fsub_rn(agx, bgx), d7 = __fsub_rn(agy, bgy), d8 = __fsub_rn(agz, bgz);
+  const float g1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
+  const float g2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d4, d4), __fmul_rn(d5, d5)), __fmul_rn(d6, d6)), __fmul_rn(d7, d7));
+  return __fadd_rn(__fadd_rn(g1, g2), __fmul_rn(d8, d8));
 }
 #endif
 

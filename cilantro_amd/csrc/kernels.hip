@@ -98,13 +98,36 @@ struct Feat6 {
   float fx, fy, fz;   // the query's (transformed) feature normal
   float w;            // normal weight
   const float4* nrm;  // sorted target normals
+  // 9-D point + normal + colour features (DIM = 9: two groups of four, then one tail term): the query's w2 * colour, the
+  // colour weight and the sorted target colours; att2 == nullptr: 6-D
+  float gx, gy, gz;
+  float w2;
+  const float4* att2;
 };
-__device__ __forceinline__ float d6_pinned(float qx, float qy, float qz, const Feat6& f, const float4 p, const float4 n) {
+__device__ __forceinline__ float d6_pinned(float qx, float qy, float qz, const Feat6& f, const float4 p, const float4 n, const float4 c = make_float4(0.f, 0.f, 0.f, 0.f)) {
   const float d0 = __fsub_rn(qx, p.x), d1 = __fsub_rn(qy, p.y), d2 = __fsub_rn(qz, p.z);
   const float d3 = __fsub_rn(f.fx, __fmul_rn(f.w, n.x)), d4 = __fsub_rn(f.fy, __fmul_rn(f.w, n.y)), d5 = __fsub_rn(f.fz, __fmul_rn(f.w, n.z));
+  if (f.att2 != nullptr) {
+    const float d6 = __fsub_rn(f.gx, __fmul_rn(f.w2, c.x)), d7 = __fsub_rn(f.gy, __fmul_rn(f.w2, c.y)), d8 = __fsub_rn(f.gz, __fmul_rn(f.w2, c.z));
+    const float g1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
+    const float g2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d4, d4), __fmul_rn(d5, d5)), __fmul_rn(d6, d6)), __fmul_rn(d7, d7));
+    return __fadd_rn(__fadd_rn(g1, g2), __fmul_rn(d8, d8));
+  }
   float r = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
   r = __fadd_rn(r, __fmul_rn(d4, d4));
   return __fadd_rn(r, __fmul_rn(d5, d5));
+}
+// the query side of a feature search: the source point's feature parts under the current transform (i = index in a.src's order)
+__device__ __forceinline__ void query_features(const IterArgs& a, const float* T, uint32_t i, bool with_targets, Feat6& f) {
+  source_feature(a.feat, T, a.feat.src[i], f.fx, f.fy, f.fz);
+  f.w = a.feat.w;
+  f.nrm = with_targets ? a.feat.dst : nullptr;
+  f.gx = f.gy = f.gz = 0.0f; f.w2 = a.feat.w2;
+  f.att2 = a.feat.dst2;
+  if (a.feat.dst2 != nullptr) {
+    const float4 sc = a.feat.src2[i];
+    f.gx = __fmul_rn(a.feat.w2, sc.x); f.gy = __fmul_rn(a.feat.w2, sc.y); f.gz = __fmul_rn(a.feat.w2, sc.z);
+  }
 }
 __device__ __forceinline__ const float4* target_features(const IterArgs& a) { return a.feat.dst; }
 
@@ -115,7 +138,9 @@ __device__ __forceinline__ void scan_range_f6(const float4* __restrict__ pts, ui
   for (uint32_t j = beg; j < end; j += 2) {
     const uint32_t j1 = min(j + 1, last);
     const float4 p0 = pts[j], p1 = pts[j1], n0 = f.nrm[j], n1 = f.nrm[j1];
-    const float e0 = d6_pinned(qx, qy, qz, f, p0, n0), e1 = d6_pinned(qx, qy, qz, f, p1, n1);
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+    if (f.att2 != nullptr) { c0 = f.att2[j]; c1 = f.att2[j1]; }
+    const float e0 = d6_pinned(qx, qy, qz, f, p0, n0, c0), e1 = d6_pinned(qx, qy, qz, f, p1, n1, c1);
     const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
     const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
     if (k0 < best.key) { best.key = k0; best.pos = j; }
@@ -1391,14 +1416,13 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   }
   if (FEAT6) {
     // settle the pending queries: feature distance of the 3-D winner against the second smallest 3-D distance met
-    float4 sn[TILE_QPT], np[TILE_QPT], rr[TILE_QPT];
+    float4 np[TILE_QPT], cp[TILE_QPT], rr[TILE_QPT];
 #pragma unroll
     for (int u = 0; u < TILE_QPT; ++u) {
-      const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
-      sn[u] = np[u] = rr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      np[u] = cp[u] = rr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (((flags >> (20 + u)) & 1u) && f6_pos[u] != NONE_U32) {
-        sn[u] = a.feat.src[i];
         np[u] = target_features(a)[f6_pos[u]];
+        if (a.feat.dst2 != nullptr) cp[u] = a.feat.dst2[f6_pos[u]];
         rr[u] = lpts[(mbl >> (16 * u)) & 0xFFFFu];
       }
     }
@@ -1411,9 +1435,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       bool ambiguous = false;
       if (pend && f6_pos[u] != NONE_U32) {
         Feat6 f;
-        source_feature(a.feat, T, sn[u], f.fx, f.fy, f.fz);
-        f.w = a.feat.w; f.nrm = nullptr;
-        const float d6 = d6_pinned(oq[u].qx, oq[u].qy, oq[u].qz, f, make_float4(rr[u].x, rr[u].y, rr[u].w, 0.f), np[u]);
+        query_features(a, T, i, false, f);
+        const float d6 = d6_pinned(oq[u].qx, oq[u].qy, oq[u].qz, f, make_float4(rr[u].x, rr[u].y, rr[u].w, 0.f), np[u], cp[u]);
         ambiguous = !(f6_second[u] > d6);           // another candidate's d6 (>= its d3 >= second) could be <= d6: not settled here
         if (d6 < a.max_sq) { dbest = d6; pos = f6_pos[u]; }
       }
@@ -1749,10 +1772,8 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
             transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
             NN best;
             if (FEAT6) {
-              const float4 sn = a.feat.src[i];
               Feat6 f;
-              source_feature(a.feat, T, sn, f.fx, f.fy, f.fz);
-              f.w = a.feat.w; f.nrm = target_features(a);
+              query_features(a, T, i, true, f);
               nn_search_group<TODO_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
             } else {
               nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
@@ -1861,13 +1882,11 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
   const uint64_t gid = ((uint64_t)blockIdx.x * ITER_THREADS + threadIdx.x) / FEAT6_GROUP;
   if (gid >= a.ns) return;      // (whole groups leave together)
   const uint32_t i = (uint32_t)gid;
-  const float4 s4 = a.src[i], sn = a.feat.src[i];
+  const float4 s4 = a.src[i];
   float qx, qy, qz;
   transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
   Feat6 f;
-  source_feature(a.feat, T, sn, f.fx, f.fy, f.fz);
-  f.w = a.feat.w;
-  f.nrm = target_features(a);
+  query_features(a, T, i, true, f);
   NN best;
   nn_search_group<FEAT6_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
   if (sub == 0) {

@@ -367,6 +367,28 @@ class CorrespondenceSearchHIP:
         self._corr = None
         return self
 
+    def setPointNormalColorFeatureAdaptors(self, src_normals, dst_colors, src_colors, normal_weight, color_weight, keep_metric=True):
+        """both clouds' adaptors become PointNormalColorFeaturesAdaptor3f(points, normals, colors, normal_weight, color_weight)
+        (common_transformable_feature_adaptors.hpp:255-343): the search runs on the 9-D features (p, wn n, wc c); the normal part
+        follows the transform as the point+normal adaptor's does, the colour part does not move.  Target normals: the ones the
+        ICP object was built with; src_normals None: reuse the normals given to a four-cloud constructor."""
+        if src_normals is not None:
+            q, nn, mem, _ = _as_cloud(src_normals)
+            if nn != self._ctx.n_source:
+                raise ValueError("source normals must match source points")
+            self._ctx._ck(self._ctx._L.cilhip_set_source_normals(self._ctx._h, q, mem))
+            self._ctx.set_option("symmetric_metric", 0 if keep_metric else 1)
+        d, nd, mem, _k1 = _as_cloud(dst_colors)
+        s, ns, mem2, _k2 = _as_cloud(src_colors)
+        if nd != self._ctx.n_target or ns != self._ctx.n_source or mem != mem2:
+            raise ValueError("colours must match the clouds (and live in the same memory space)")
+        self._ctx._ck(self._ctx._L.cilhip_set_color_features(self._ctx._h, d, s, mem))
+        self._ctx.set_option("feature_kind", 2)
+        self._ctx.set_option("feature_normal_weight", float(normal_weight))
+        self._ctx.set_option("feature_color_weight", float(color_weight))
+        self._corr = None
+        return self
+
     def getCorrespondences(self):
         """-> structured view of the reference's CorrespondenceSet: (indexInFirst, indexInSecond, value)."""
         if self._corr is None:

@@ -91,7 +91,8 @@ int cilhip_prepare_source(cilhip_ctx* ctx, const float* T_or_null, int force, do
 int cilhip_get_means(cilhip_ctx* ctx, float dst_mean[3], float src_mean[3]);
 /* Per-point colours of both clouds (packed rgb, n_target / n_source triples) for the point + colour feature adaptor
  * (PointColorFeaturesAdaptor3f(points, colors, color_weight), common_transformable_feature_adaptors.hpp:164-252; options
- * "feature_kind" = 1, "feature_normal_weight" = the colour weight).  After cilhip_set_target and cilhip_set_source. */
+ * "feature_kind" = 1, "feature_normal_weight" = the colour weight) and for the 9-D point + normal + colour adaptor (:255-343;
+ * "feature_kind" = 2, "feature_color_weight").  After cilhip_set_target and cilhip_set_source. */
 int cilhip_set_color_features(cilhip_ctx* ctx, const float* dst_rgb, const float* src_rgb, int mem);
 
 /* ---- correspondence search (engine concept) -------------------------------------------------- */
@@ -417,7 +418,11 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        Unsharded runs.
  *   "feature_kind" (default 0): 1 = the 6-D features are point + COLOUR, PointColorFeaturesAdaptor (:164-252): (p, w c) with
  *                        the colour part untouched by the transform; colours through cilhip_set_color_features, weight through
- *                        "feature_normal_weight".  (The 9-D point + normal + colour adaptor, :255-343, is not built.)
+ *                        "feature_normal_weight".  2 = the 9-D point + NORMAL + COLOUR features, PointNormalColorFeaturesAdaptor
+ *                        (:255-343): (p, wn n, wc c), matched by the 9-D squared distance (nanoflann's DIM = 9 summation order);
+ *                        the normal part follows the transform as for kind 0, the colour part does not move; wn through
+ *                        "feature_normal_weight", wc through "feature_color_weight"; needs both clouds' normals and colours.
+ *   "feature_color_weight" (default 0): the colour weight of feature_kind 2.
  *   "symmetric_metric" (default 1): 0 = source normals feed the feature adaptor only and the combined metric stays the
  *                        three-cloud one (the reference decides this by the ICP constructor used,
  *                        icp_common_instances.hpp:74-97).

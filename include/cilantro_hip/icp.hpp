@@ -226,6 +226,23 @@ public:
     return *this;
   }
 
+  // ... or PointNormalColorFeaturesAdaptor3f(points, normals, colors, normal_weight, color_weight) on both clouds (:255-343): 9-D
+  // features (p, wn n, wc c); the normal part follows the transform like the point+normal adaptor's, the colour part does not move.
+  CorrespondenceSearchHIP& setPointNormalColorFeatureAdaptors(const ConstPointsView& src_normals, const ConstPointsView& dst_colors,
+                                                              const ConstPointsView& src_colors, float normal_weight, float color_weight,
+                                                              bool keep_metric = true) {
+    if (src_normals.cols()) {
+      internal::check(ctx_, cilhip_set_source_normals(ctx_, src_normals.data(), CILHIP_MEM_HOST), "set_source_normals");
+      internal::check(ctx_, cilhip_set_option(ctx_, "symmetric_metric", keep_metric ? 0.0 : 1.0), "symmetric_metric");
+    }
+    internal::check(ctx_, cilhip_set_color_features(ctx_, dst_colors.data(), src_colors.data(), CILHIP_MEM_HOST), "set_color_features");
+    internal::check(ctx_, cilhip_set_option(ctx_, "feature_kind", 2.0), "feature_kind");
+    internal::check(ctx_, cilhip_set_option(ctx_, "feature_normal_weight", (double)normal_weight), "feature_normal_weight");
+    internal::check(ctx_, cilhip_set_option(ctx_, "feature_color_weight", (double)color_weight), "feature_color_weight");
+    fetched_ = false;
+    return *this;
+  }
+
   void setSourceCount_(size_t n) { capacity_ += n; }  // internal: result capacity (called with both cloud sizes)
 
 private:

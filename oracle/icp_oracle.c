@@ -348,6 +348,56 @@ static inline float d6_pinned(const float* a, const float* b) {
   r += d5 * d5;
   return r;
 }
+/* nanoflann.hpp:570-604 for DIM = 9 (PointNormalColorFeaturesAdaptor): two groups of four, then the tail loop's one term */
+static inline float d9_pinned(const float* a, const float* b) {
+  float d[9];
+  for (int k = 0; k < 9; ++k) d[k] = a[k] - b[k];
+  float r = 0.0f;
+  r += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  r += d[4] * d[4] + d[5] * d[5] + d[6] * d[6] + d[7] * d[7];
+  r += d[8] * d[8];
+  return r;
+}
+/* 9-D point + normal + colour features (common_transformable_feature_adaptors.hpp:255-343), row-major n x 9:
+ * data = [points; normal_weight * normals; color_weight * colors] (:251-258) */
+void orc_point_normal_color_features(const float* pts, const float* nrm, const float* rgb, size_t n, float wn, float wc, float* out9) {
+  for (size_t i = 0; i < n; ++i)
+    for (int c = 0; c < 3; ++c) { out9[9 * i + c] = pts[3 * i + c]; out9[9 * i + 3 + c] = wn * nrm[3 * i + c]; out9[9 * i + 6 + c] = wc * rgb[3 * i + c]; }
+}
+/* transformFeatures(tform) (:270-296): point and normal parts as the 6-D point+normal adaptor's (mode 0 Isometry / 1 otherwise,
+ * normal_weight = |normal part of feature 0|), the colour part copied */
+void orc_transform_features9_mode(const float T[16], const float* in9, size_t n, int mode, float* out9) {
+  float* a6 = (float*)malloc(6 * (n ? n : 1) * sizeof(float));
+  float* b6 = (float*)malloc(6 * (n ? n : 1) * sizeof(float));
+  for (size_t i = 0; i < n; ++i) for (int c = 0; c < 6; ++c) a6[6 * i + c] = in9[9 * i + c];
+  orc_transform_features6_mode(T, a6, n, mode, b6);
+  for (size_t i = 0; i < n; ++i) {
+    for (int c = 0; c < 6; ++c) out9[9 * i + c] = b6[6 * i + c];
+    for (int c = 6; c < 9; ++c) out9[9 * i + c] = in9[9 * i + c];
+  }
+  free(a6); free(b6);
+}
+/* exhaustive nearest feature for DIM = 9 (strict '<' over ascending index), kept iff d2 < max_sq_dist */
+size_t orc_find_correspondences_feat9(const float* dst9, size_t nd, const float* q9, size_t nq, float max_sq_dist,
+                                      int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads) {
+  int64_t* bi = (int64_t*)malloc((nq ? nq : 1) * sizeof(int64_t));
+  float* bd = (float*)malloc((nq ? nq : 1) * sizeof(float));
+  if (num_threads <= 0) num_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+  for (size_t i = 0; i < nq; ++i) {
+    float best = INFINITY; int64_t bj = -1;
+    for (size_t j = 0; j < nd; ++j) {
+      const float v = d9_pinned(q9 + 9 * i, dst9 + 9 * j);
+      if (v < best) { best = v; bj = (int64_t)j; }
+    }
+    bi[i] = bj; bd[i] = best;
+  }
+  size_t cnt = 0;
+  for (size_t i = 0; i < nq; ++i)
+    if (bi[i] >= 0 && bd[i] < max_sq_dist) { dst_idx[cnt] = bi[i]; src_idx[cnt] = (int64_t)i; d2[cnt] = bd[i]; ++cnt; }
+  free(bi); free(bd);
+  return cnt;
+}
 /* The correspondence loop (correspondence_search_kd_tree_utilities.hpp:7-51) over 6-D features by exhaustive search:
  * nearest feature (strict '<' over ascending index), kept iff d2 < max_sq_dist. */
 size_t orc_find_correspondences_feat6(const float* dst6, size_t nd, const float* q6, size_t nq, float max_sq_dist,
@@ -503,9 +553,10 @@ size_t orc_find_correspondences_dir(const float* dst, size_t nd, const orc_kdtre
   return n;
 }
 
-/* The same for 6-D features by exhaustive search (both directions; ties: lowest index of the searched side) */
-size_t orc_find_correspondences_feat6_dir(const float* dst6, size_t nd, const float* q6, size_t ns, float max_d, int direction, int reciprocal,
-                                          int64_t* di, int64_t* si, float* d2, int num_threads) {
+/* The same for 6-D / 9-D features by exhaustive search (both directions; ties: lowest index of the searched side) */
+typedef size_t (*orc_feat_search)(const float*, size_t, const float*, size_t, float, int64_t*, int64_t*, float*, int);
+static size_t find_correspondences_featn_dir(orc_feat_search orc_find_correspondences_feat6, const float* dst6, size_t nd, const float* q6, size_t ns, float max_d,
+                                             int direction, int reciprocal, int64_t* di, int64_t* si, float* d2, int num_threads) {
   if (direction == 0) return orc_find_correspondences_feat6(dst6, nd, q6, ns, max_d, di, si, d2, num_threads);
   const size_t capf = nd ? nd : 1;
   int64_t* fa = (int64_t*)malloc(capf * sizeof(int64_t));
@@ -541,6 +592,14 @@ size_t orc_find_correspondences_feat6_dir(const float* dst6, size_t nd, const fl
   }
   free(fa); free(fb); free(fv);
   return n;
+}
+size_t orc_find_correspondences_feat6_dir(const float* dst6, size_t nd, const float* q6, size_t ns, float max_d, int direction, int reciprocal,
+                                          int64_t* di, int64_t* si, float* d2, int num_threads) {
+  return find_correspondences_featn_dir(orc_find_correspondences_feat6, dst6, nd, q6, ns, max_d, direction, reciprocal, di, si, d2, num_threads);
+}
+size_t orc_find_correspondences_feat9_dir(const float* dst9, size_t nd, const float* q9, size_t ns, float max_d, int direction, int reciprocal,
+                                          int64_t* di, int64_t* si, float* d2, int num_threads) {
+  return find_correspondences_featn_dir(orc_find_correspondences_feat9, dst9, nd, q9, ns, max_d, direction, reciprocal, di, si, d2, num_threads);
 }
 
 /* fraction filter on a set in (first, second) order: ties on the value keep that order */

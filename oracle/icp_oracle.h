@@ -166,6 +166,13 @@ void orc_transform_features6(const float T[16], const float* in6, size_t n, floa
 void orc_transform_features6_mode(const float T[16], const float* in6, size_t n, int mode, float* out6);
 size_t orc_find_correspondences_feat6_dir(const float* dst6, size_t nd, const float* q6, size_t ns, float max_d, int direction, int reciprocal,
                                           int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads);
+/* 9-D point + normal + colour features (PointNormalColorFeaturesAdaptor, :255-343), row-major n x 9 */
+void orc_point_normal_color_features(const float* pts, const float* nrm, const float* rgb, size_t n, float wn, float wc, float* out9);
+void orc_transform_features9_mode(const float T[16], const float* in9, size_t n, int mode, float* out9);
+size_t orc_find_correspondences_feat9(const float* dst9, size_t nd, const float* q9, size_t nq, float max_sq_dist,
+                                      int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads);
+size_t orc_find_correspondences_feat9_dir(const float* dst9, size_t nd, const float* q9, size_t ns, float max_d, int direction, int reciprocal,
+                                          int64_t* di, int64_t* si, float* d2, int num_threads);
 size_t orc_find_correspondences_feat6(const float* dst6, size_t nd, const float* q6, size_t nq, float max_sq_dist,
                                       int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads);
 

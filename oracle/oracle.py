@@ -155,6 +155,14 @@ def lib():
         L.orc_transform_ransac.argtypes = [_f32p, _f32p, C.c_size_t, _u32p, C.c_size_t, C.c_float, C.c_size_t, C.c_int, C.c_int,
                                            _f32p, _f32p, _u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         L.orc_transform_features6_mode.argtypes = [_f32p, _f32p, C.c_size_t, C.c_int, _f32p]
+        L.orc_point_normal_color_features.restype = None
+        L.orc_point_normal_color_features.argtypes = [_f32p, _f32p, _f32p, C.c_size_t, C.c_float, C.c_float, _f32p]
+        L.orc_transform_features9_mode.restype = None
+        L.orc_transform_features9_mode.argtypes = [_f32p, _f32p, C.c_size_t, C.c_int, _f32p]
+        L.orc_find_correspondences_feat9.restype = C.c_size_t
+        L.orc_find_correspondences_feat9.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
+        L.orc_find_correspondences_feat9_dir.restype = C.c_size_t
+        L.orc_find_correspondences_feat9_dir.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_int, C.c_int, _i64p, _i64p, _f32p, C.c_int]
         L.orc_find_correspondences_feat6_dir.restype = C.c_size_t
         L.orc_find_correspondences_feat6_dir.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_int, C.c_int, _i64p, _i64p, _f32p, C.c_int]
         L.orc_find_correspondences_dir.restype = C.c_size_t
@@ -191,6 +199,8 @@ def ref():
         R.ref_kdtree_radius_search.argtypes = [C.c_void_p, _f32p, C.c_float, _u64p, _f32p, C.c_size_t]
         R.ref_find_correspondences6.restype = C.c_size_t
         R.ref_find_correspondences6.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
+        R.ref_find_correspondences9.restype = C.c_size_t
+        R.ref_find_correspondences9.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
         R.ref_find_correspondences.restype = C.c_size_t
         R.ref_find_correspondences.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _i64p, _i64p, _f32p, C.c_int]
         _ref = R
@@ -362,6 +372,45 @@ def find_correspondences_feat6_dir(dst6, q6, max_sq_dist, direction, reciprocal=
     n = lib().orc_find_correspondences_feat6_dir(dst6.reshape(-1), len(dst6), q6.reshape(-1), len(q6), np.float32(max_sq_dist), int(direction),
                                                  1 if reciprocal else 0, di, si, d2, num_threads)
     return di[:n].copy(), si[:n].copy(), d2[:n].copy()
+
+
+def point_normal_color_features(pts, nrm, rgb, normal_weight, color_weight):
+    """PointNormalColorFeaturesAdaptor's data (common_transformable_feature_adaptors.hpp:251-258): n x 9 rows (p, wn n, wc c)"""
+    pts = _c(pts).reshape(-1, 3); nrm = _c(nrm).reshape(-1, 3); rgb = _c(rgb).reshape(-1, 3)
+    out = np.empty((len(pts), 9), np.float32)
+    lib().orc_point_normal_color_features(pts.reshape(-1), nrm.reshape(-1), rgb.reshape(-1), len(pts), np.float32(normal_weight), np.float32(color_weight), out.reshape(-1))
+    return out
+
+
+def transform_features9(T, feat9, mode=0):
+    """transformFeatures(tform) of the 9-D adaptor: mode 0 rigid, 1 otherwise (normals through L^-T, renormalised); colours copied"""
+    feat9 = _c(feat9).reshape(-1, 9)
+    out = np.empty_like(feat9)
+    lib().orc_transform_features9_mode(T_to_colmajor(T), feat9.reshape(-1), len(feat9), int(mode), out.reshape(-1))
+    return out
+
+
+def find_correspondences_feat9_dir(dst9, q9, max_sq_dist, direction, reciprocal=False, num_threads=0):
+    """9-D feature correspondences in any search direction (exhaustive) -> (dst_idx, src_idx, d2)"""
+    dst9 = _c(dst9).reshape(-1, 9); q9 = _c(q9).reshape(-1, 9)
+    cap = len(dst9) + len(q9) + 1
+    di = np.zeros(cap, np.int64); si = np.zeros(cap, np.int64); d2 = np.zeros(cap, np.float32)
+    n = lib().orc_find_correspondences_feat9_dir(dst9.reshape(-1), len(dst9), q9.reshape(-1), len(q9), np.float32(max_sq_dist), int(direction),
+                                                 1 if reciprocal else 0, di, si, d2, num_threads)
+    return di[:n].copy(), si[:n].copy(), d2[:n].copy()
+
+
+def find_correspondences_feat9(dst9, q9, max_sq_dist, use_ref=False, num_threads=0):
+    """Nearest 9-D feature per query (exhaustive restatement, or the reference's nanoflann for DIM = 9 with use_ref)."""
+    dst9 = _c(dst9).reshape(-1, 9); q9 = _c(q9).reshape(-1, 9)
+    nq = len(q9)
+    di = np.empty(max(nq, 1), np.int64); si = np.empty(max(nq, 1), np.int64); dv = np.empty(max(nq, 1), np.float32)
+    if use_ref:
+        n = ref().ref_find_correspondences9(dst9.reshape(-1), len(dst9), q9.reshape(-1), nq, float(max_sq_dist), di, si, dv,
+                                            num_threads if num_threads > 0 else (os.cpu_count() or 1))
+    else:
+        n = lib().orc_find_correspondences_feat9(dst9.reshape(-1), len(dst9), q9.reshape(-1), nq, float(max_sq_dist), di, si, dv, num_threads)
+    return di[:n].copy(), si[:n].copy(), dv[:n].copy()
 
 
 def find_correspondences_feat6(dst6, q6, max_sq_dist, use_ref=False, num_threads=0):

@@ -65,14 +65,15 @@ class KNNResult {                            // core/kd_tree.hpp:63-109
   size_t count_;
 };
 
-struct Adaptor6 {                            // the same data adaptor over row-major n x 6 features
-  const float* data; size_t n;
+template <int D>
+struct AdaptorN {                            // the same data adaptor over row-major n x D features (D = 6: point + normal or
+  const float* data; size_t n;               // point + colour, D = 9: point + normal + colour)
   inline size_t kdtree_get_point_count() const { return n; }
-  inline float kdtree_get_pt(size_t idx, size_t dim) const { return data[6 * idx + dim]; }
+  inline float kdtree_get_pt(size_t idx, size_t dim) const { return data[D * idx + dim]; }
   template <class BBOX> bool kdtree_get_bbox(BBOX&) const { return false; }
 };
-using Metric6 = nanoflann::L2_Adaptor<float, Adaptor6, float, size_t>;
-using Tree6 = nanoflann::KDTreeSingleIndexAdaptor<Metric6, Adaptor6, 6, size_t>;
+template <int D> using MetricN = nanoflann::L2_Adaptor<float, AdaptorN<D>, float, size_t>;
+template <int D> using TreeN = nanoflann::KDTreeSingleIndexAdaptor<MetricN<D>, AdaptorN<D>, D, size_t>;
 
 struct RefTree {
   PointsAdaptor adaptor;
@@ -84,6 +85,35 @@ struct RefTree {
                              10, nanoflann::KDTreeSingleIndexAdaptorFlags::None, 1)),
         params(0.0f, true) {}
 };
+
+// The same loop over D-dimensional features (PointNormalFeaturesAdaptor / PointColorFeaturesAdaptor: D = 6,
+// PointNormalColorFeaturesAdaptor: D = 9; common_transformable_feature_adaptors.hpp:60-343): the reference's kd-tree instantiated
+// for that DIM on row-major n x D feature arrays (tree built here, one call).
+template <int D>
+static size_t ref_find_correspondences_n(const float* dstf, size_t nd, const float* qf, size_t nq, float max_d,
+                                         int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads) {
+  if (nd == 0) return 0;
+  AdaptorN<D> ad{dstf, nd};
+  TreeN<D> tree(D, ad, nanoflann::KDTreeSingleIndexAdaptorParams(10, nanoflann::KDTreeSingleIndexAdaptorFlags::None, 1));
+  nanoflann::SearchParameters params(0.0f, true);
+  std::vector<int64_t> tmp_idx(nq);
+  std::vector<float> tmp_d2(nq);
+  std::vector<char> keep(nq);
+  std::vector<Neighbor> nn;
+#pragma omp parallel for private(nn) schedule(dynamic, 256) num_threads(num_threads)
+  for (size_t i = 0; i < nq; i++) {
+    KNNResult sra(nn, 1, max_d);
+    tree.findNeighbors(sra, qf + (size_t)D * i, params);
+    nn.resize(sra.size());
+    float dist = 0.f;
+    keep[i] = !nn.empty() && (dist = nn[0].value) < max_d;
+    if (keep[i]) { tmp_idx[i] = (int64_t)nn[0].index; tmp_d2[i] = dist; }
+  }
+  size_t count = 0;
+  for (size_t i = 0; i < nq; i++)
+    if (keep[i]) { dst_idx[count] = tmp_idx[i]; src_idx[count] = (int64_t)i; d2[count] = tmp_d2[i]; ++count; }
+  return count;
+}
 
 }  // namespace
 
@@ -150,31 +180,13 @@ size_t ref_kdtree_radius_search(const void* tp, const float q[3], float radius_s
   return nn.size();
 }
 
-// The same loop over 6-D point+normal features (PointNormalFeaturesAdaptor, common_transformable_feature_adaptors.hpp:60-161):
-// the reference's kd-tree instantiated for DIM = 6 on row-major n x 6 feature arrays (tree built here, one call).
 size_t ref_find_correspondences6(const float* dst6, size_t nd, const float* q6, size_t nq, float max_d,
                                  int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads) {
-  if (nd == 0) return 0;
-  Adaptor6 ad{dst6, nd};
-  Tree6 tree(6, ad, nanoflann::KDTreeSingleIndexAdaptorParams(10, nanoflann::KDTreeSingleIndexAdaptorFlags::None, 1));
-  nanoflann::SearchParameters params(0.0f, true);
-  std::vector<int64_t> tmp_idx(nq);
-  std::vector<float> tmp_d2(nq);
-  std::vector<char> keep(nq);
-  std::vector<Neighbor> nn;
-#pragma omp parallel for private(nn) schedule(dynamic, 256) num_threads(num_threads)
-  for (size_t i = 0; i < nq; i++) {
-    KNNResult sra(nn, 1, max_d);
-    tree.findNeighbors(sra, q6 + 6 * i, params);
-    nn.resize(sra.size());
-    float dist = 0.f;
-    keep[i] = !nn.empty() && (dist = nn[0].value) < max_d;
-    if (keep[i]) { tmp_idx[i] = (int64_t)nn[0].index; tmp_d2[i] = dist; }
-  }
-  size_t count = 0;
-  for (size_t i = 0; i < nq; i++)
-    if (keep[i]) { dst_idx[count] = tmp_idx[i]; src_idx[count] = (int64_t)i; d2[count] = tmp_d2[i]; ++count; }
-  return count;
+  return ref_find_correspondences_n<6>(dst6, nd, q6, nq, max_d, dst_idx, src_idx, d2, num_threads);
+}
+size_t ref_find_correspondences9(const float* dst9, size_t nd, const float* q9, size_t nq, float max_d,
+                                 int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads) {
+  return ref_find_correspondences_n<9>(dst9, nd, q9, nq, max_d, dst_idx, src_idx, d2, num_threads);
 }
 
 }  // extern "C"

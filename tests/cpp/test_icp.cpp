@@ -138,6 +138,63 @@ int main(int argc, char** argv) {
     std::printf("weight evaluators: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp6.getNumberOfPerformedIterations(), r.iterations, e6);
     if (!(e6 <= 1e-5)) ++failures;
 
+    // feature adaptors of the engine (common_transformable_feature_adaptors.hpp: point+normal :60-161, point+colour :164-252,
+    // point+normal+colour :255-343) through the mirror: correspondence lists under tf against the oracle's exhaustive searches
+    {
+      const size_t m = 8000;
+      const double hm = std::pow((double)m, -1.0 / 3.0);
+      std::vector<float> d2p(dst.begin(), dst.begin() + 3 * m), d2n(nrm.begin(), nrm.begin() + 3 * m), s2p(3 * m), s2n(3 * m), dcol(3 * m), scol(3 * m);
+      float Ti[16], Tf[16];
+      std::memcpy(Tf, tf.m, sizeof(Tf));
+      // inverse of the rigid tf (col-major): R^T, -R^T t
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Ti[c * 4 + r] = Tf[r * 4 + c];
+      for (int r = 0; r < 3; ++r) Ti[12 + r] = -(Ti[r] * Tf[12] + Ti[4 + r] * Tf[13] + Ti[8 + r] * Tf[14]);
+      Ti[3] = Ti[7] = Ti[11] = 0.f; Ti[15] = 1.f;
+      std::vector<float> jp(3 * m);
+      for (size_t i = 0; i < 3 * m; ++i) {
+        jp[i] = d2p[i] + (2 * u01(51, i) - 1) * (float)(0.05 * hm);
+        dcol[i] = u01(52, i);
+        scol[i] = std::fmin(1.0f, std::fmax(0.0f, dcol[i] + (2 * u01(53, i) - 1) * 0.1f));
+      }
+      orc_transform_points(Ti, jp.data(), m, s2p.data());      // (ONE call: the oracle opens an OpenMP region per call)
+      orc_transform_normals(Ti, d2n.data(), m, s2n.data());
+      const ConstPointsView d2v(d2p), d2nv(d2n), s2v(s2p), s2nv(s2n), dcv(dcol), scv(scol);
+      const float wn = (float)(0.6 * hm), wc = (float)(0.8 * hm), r2 = (float)((2.5 * hm) * (2.5 * hm));
+      std::vector<float> dst6(6 * m), src6(6 * m), q6(6 * m), dst9(9 * m), src9(9 * m), q9(9 * m);
+      std::vector<int64_t> di(2 * m + 1), si(2 * m + 1); std::vector<float> dv(2 * m + 1);
+      auto compare = [&](const CorrespondenceSearchHIP::SearchResult& got, size_t nc, const char* what) {
+        size_t bad = (nc != got.size()) || nc < m / 2;
+        for (size_t k = 0; k < nc && k < got.size(); ++k)
+          bad += (got[k].indexInFirst != (size_t)di[k]) || (got[k].indexInSecond != (size_t)si[k]) || (got[k].value != dv[k]);
+        std::printf("feature adaptor %s: %zu correspondences, %zu mismatches vs oracle\n", what, got.size(), bad);
+        if (bad) ++failures;
+      };
+      SimpleCombinedMetricRigidICP3f fi(d2v, d2nv, s2v);
+      auto& eng = fi.correspondenceSearchEngine();
+      eng.setMaxDistance(r2);
+      // point + normal, BOTH directions
+      eng.setSearchDirection(CorrespondenceSearchDirection::BOTH).setPointNormalFeatureAdaptors(s2nv, wn);
+      orc_point_normal_features(d2p.data(), d2n.data(), m, wn, dst6.data());
+      orc_point_normal_features(s2p.data(), s2n.data(), m, wn, src6.data());
+      orc_transform_features6_mode(Tf, src6.data(), m, 0, q6.data());
+      compare(eng.findCorrespondences(tf).getCorrespondences(),
+              orc_find_correspondences_feat6_dir(dst6.data(), m, q6.data(), m, r2, 2, 0, di.data(), si.data(), dv.data(), 0), "point+normal (BOTH)");
+      // point + colour
+      eng.setSearchDirection(CorrespondenceSearchDirection::SECOND_TO_FIRST).setPointColorFeatureAdaptors(dcv, scv, wc);
+      orc_point_normal_features(d2p.data(), dcol.data(), m, wc, dst6.data());
+      orc_point_normal_features(s2p.data(), scol.data(), m, wc, src6.data());
+      orc_transform_features6_mode(Tf, src6.data(), m, 2, q6.data());
+      compare(eng.findCorrespondences(tf).getCorrespondences(),
+              orc_find_correspondences_feat6_dir(dst6.data(), m, q6.data(), m, r2, 0, 0, di.data(), si.data(), dv.data(), 0), "point+colour");
+      // point + normal + colour (9-D), FIRST_TO_SECOND
+      eng.setSearchDirection(CorrespondenceSearchDirection::FIRST_TO_SECOND).setPointNormalColorFeatureAdaptors(s2nv, dcv, scv, wn, wc);
+      orc_point_normal_color_features(d2p.data(), d2n.data(), dcol.data(), m, wn, wc, dst9.data());
+      orc_point_normal_color_features(s2p.data(), s2n.data(), scol.data(), m, wn, wc, src9.data());
+      orc_transform_features9_mode(Tf, src9.data(), m, 0, q9.data());
+      compare(eng.findCorrespondences(tf).getCorrespondences(),
+              orc_find_correspondences_feat9_dir(dst9.data(), m, q9.data(), m, r2, 1, 0, di.data(), si.data(), dv.data(), 0), "point+normal+colour (FIRST_TO_SECOND)");
+    }
+
     // affine instances (icp_common_instances.hpp:255, :266) through the mirrors
     SimpleCombinedMetricAffineICP3f icp4(dst_v, nrm_v, src_v);
     icp4.setPointToPointMetricWeight(0.1f).setPointToPlaneMetricWeight(1.0f);

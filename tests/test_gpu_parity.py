@@ -1787,3 +1787,68 @@ def test_feature_adaptors_directions_affine_colour_vs_oracle(Context, orc, hip_l
         ro = orc.icp_run(dst, dst_n, src, p, src_n=src_n)
         err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
         assert err <= 1e-4 and icp.last_ncorr_ == ro["last_ncorr"], (direction, err, icp.last_ncorr_, ro["last_ncorr"])
+
+
+@pytest.mark.gpu
+def test_point_normal_color_features_9d_vs_oracle(Context, orc, hip_lib):
+    """PointNormalColorFeaturesAdaptor3f (common_transformable_feature_adaptors.hpp:255-343): 9-D features (p, wn n, wc c), the normal
+    part following the transform (rigid: L; affine: L^-T renormalised), the colour part not.  Correspondence lists in every search
+    direction, rigid and affine transforms, both search kernels, element for element against the oracle's exhaustive 9-D search (pinned
+    on the reference's nanoflann for DIM = 9); a rigid loop against the oracle's pieces driven from here."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D
+    from cilantro_amd.icp import SimpleCombinedMetricAffineICP3f, SimpleCombinedMetricRigidICP3f
+
+    n = 12000
+    d = syn.make_pair(n, perturb=0.5)
+    h = d["h"]
+    dst, dst_n, src = d["dst"], d["dst_n"], d["src"]
+    Ti = np.linalg.inv(d["T_true"].astype(np.float64)).astype(np.float32)
+    src_n = orc.transform_normals(Ti, dst_n)
+    rng = np.random.default_rng(19)
+    dst_c = rng.random((n, 3)).astype(np.float32)
+    src_c = np.clip(dst_c + rng.normal(0, 0.05, (n, 3)), 0, 1).astype(np.float32)
+    wn, wc = 0.6 * h, 0.8 * h
+    r2 = float((2.5 * h) ** 2)
+    dst9 = orc.point_normal_color_features(dst, dst_n, dst_c, wn, wc)
+    src9 = orc.point_normal_color_features(src, src_n, src_c, wn, wc)
+    T_rigid = d["T_true"].astype(np.float32).copy(); T_rigid[:3, 3] += np.float32(0.2 * h)
+    T_aff = T_rigid.copy(); T_aff[:3, :3] = (T_aff[:3, :3].astype(np.float64) @ (np.eye(3) + np.array([[0.02, 0.01, 0], [0, -0.03, 0.015], [0.01, 0, 0.025]]))).astype(np.float32)
+
+    def lists_equal(g, o):
+        return len(g[0]) == len(o[0]) and np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]) and np.array_equal(g[2].view(np.uint32), o[2].view(np.uint32))
+
+    for tiled in (0, 2):
+        for T, mode, cls in ((T_rigid, 0, SimpleCombinedMetricRigidICP3f), (T_aff, 1, SimpleCombinedMetricAffineICP3f)):
+            q9 = orc.transform_features9(T, src9, mode)
+            for direction, recip, code in ((D.SECOND_TO_FIRST, False, 0), (D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 2), (D.BOTH, True, 2)):
+                icp = cls(dst, dst_n, src)
+                icp._ctx.set_option("tiled", tiled)
+                eng = icp.correspondenceSearchEngine()
+                eng.setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
+                eng.setPointNormalColorFeatureAdaptors(src_n, dst_c, src_c, wn, wc)
+                eng.findCorrespondences(T)
+                got = eng.getCorrespondences()
+                want = orc.find_correspondences_feat9_dir(dst9, q9, r2, code, recip)
+                assert len(want[0]) > 0.5 * n and lists_equal(got, want), (tiled, mode, direction, recip, len(got[0]), len(want[0]))
+    # the matches differ from the 6-D point+normal adaptor's on a good share of the queries (a dropped part would go unnoticed otherwise)
+    w9 = orc.find_correspondences_feat9_dir(dst9, orc.transform_features9(T_rigid, src9, 0), float("inf"), 0)
+    w6 = orc.find_correspondences_feat6_dir(dst9[:, :6].copy(), orc.transform_features6(T_rigid, src9[:, :6].copy(), 0), float("inf"), 0)
+    assert np.mean(w9[0] != w6[0]) > 0.002
+    # a rigid loop: transformFeatures -> findCorrespondences -> updateEstimate, five times
+    icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+    icp.correspondenceSearchEngine().setMaxDistance(r2).setPointNormalColorFeatureAdaptors(src_n, dst_c, src_c, wn, wc)
+    Tg = icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0).estimate().getTransform()
+    p = orc.make_params(metric=1, max_iter=1, conv_tol=0.0, max_sq_dist=r2, mode=orc.MODE_MIXED)
+    To = np.eye(4, dtype=np.float32)
+    for _ in range(5):
+        di, si, dv = orc.find_correspondences_feat9_dir(dst9, orc.transform_features9(To, src9, 0), r2, 0)
+        To, _ = orc.icp_update(dst, dst_n, src, To, di, si, p)
+    assert np.linalg.norm(Tg.astype(np.float64) - To.astype(np.float64)) <= TOL_T and icp.last_ncorr_ == len(di)
+    # switching the kind back on the same engine rebuilds what depends on it (the source's grid carries the reverse search's features)
+    eng = icp.correspondenceSearchEngine()
+    eng.setSearchDirection(D.FIRST_TO_SECOND).setPointNormalFeatureAdaptors(src_n, wn)
+    eng.findCorrespondences(T_rigid)
+    got = eng.getCorrespondences()
+    dst6 = orc.point_normal_features(dst, dst_n, wn)
+    want = orc.find_correspondences_feat6_dir(dst6, orc.transform_features6(T_rigid, orc.point_normal_features(src, src_n, wn), 0), r2, 1)
+    assert lists_equal(got, want)

@@ -322,6 +322,41 @@ def test_point_normal_feature_search_vs_reference_nanoflann(orc):
     assert np.mean(p1 != a1) > 0.2
 
 
+def test_feat9_oracle_vs_reference_nanoflann_dim9(orc):
+    """PointNormalColorFeaturesAdaptor (common_transformable_feature_adaptors.hpp:255-343): the oracle's exhaustive 9-D search with
+    nanoflann's DIM = 9 summation order (two groups of four, one tail term) against the reference's own nanoflann instantiated for
+    DIM = 9 -- indices and squared distances bit for bit; the transform moves points and normals, not colours."""
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(23)
+    n = 5000
+    dst = rng.random((n, 3)).astype(np.float32)
+    dn = rng.normal(size=(n, 3)); dn /= np.linalg.norm(dn, axis=1, keepdims=True); dn = dn.astype(np.float32)
+    dc = rng.random((n, 3)).astype(np.float32)
+    sel = rng.permutation(n)[:3000]
+    src = (dst + rng.normal(size=(n, 3)).astype(np.float32) * np.float32(0.01))[sel]
+    sn = dn[sel]
+    sc = np.clip(dc[sel] + rng.normal(0, 0.05, (len(sel), 3)), 0, 1).astype(np.float32)
+    ang = 0.05
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    T[:3, 3] = [0.01, -0.005, 0.002]
+    for wn, wc in ((0.02, 0.03), (0.3, 0.1), (0.0, 0.2)):
+        d9 = orc.point_normal_color_features(dst, dn, dc, wn, wc)
+        assert np.array_equal(d9[:, :3], dst) and np.array_equal(d9[:, 3:6], np.float32(wn) * dn) and np.array_equal(d9[:, 6:], np.float32(wc) * dc)
+        s9 = orc.point_normal_color_features(src, sn, sc, wn, wc)
+        q9 = orc.transform_features9(T, s9)
+        assert np.array_equal(q9[:, :3], orc.transform_points(T, src)) and np.array_equal(q9[:, 6:], s9[:, 6:])
+        assert np.array_equal(q9[:, :6], orc.transform_features6(T, s9[:, :6].copy()))
+        for max_sq in (0.05 ** 2, float("inf")):
+            a = orc.find_correspondences_feat9(d9, q9, max_sq)
+            b = orc.find_correspondences_feat9(d9, q9, max_sq, use_ref=True)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(a[0]) > 0
+    # the 9-D distance is not the 6-D one plus a colour term in a different order: DIM = 9 groups (d4, d5) with the colour's first two
+    a6 = orc.find_correspondences_feat6(d9[:, :6].copy(), q9[:, :6].copy(), float("inf"))
+    assert len(a6[0]) == len(a[0])
+
+
 def test_radius_search_oracle_vs_reference_nanoflann(orc):
     """KDTree::radiusSearch (core/kd_tree.hpp:251-282): the exhaustive oracle against the reference's own nanoflann with
     cilantro's RadiusSearchResultAdaptor -- same neighbour sets, bit-identical sorted distances, strict radius."""
