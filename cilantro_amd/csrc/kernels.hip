@@ -2485,10 +2485,13 @@ int warm_num_blocks(uint32_t ns) {
   // with more, shorter blocks those latency-bound tails take wave slots from the streaming ones (measured: 2048 / 4096 / 8192
   // blocks 0.106 / 0.124 / 0.142 ms at 10M)
   static const long exp_nb = [] { const char* e = getenv("CILHIP_EXP_WARM_BLOCKS"); return e ? atol(e) : 0L; }();
-  const long cap = exp_nb > 0 ? exp_nb : 1024;
-  long nb = ((long)ns + WARM_THREADS - 1) / WARM_THREADS;
-  if (nb > cap) nb = cap;
-  if (nb < 8) nb = 8;
+  // Small clouds: at least eight rounds per wave (a block's fixed costs -- pipeline fill, list search, row -- against its share
+  // of the stream), and 64 blocks are few enough for the epilogue to fold their rows itself, without the stage-1 kernel
+  // (measured per step: 100k points 64 blocks 0.0317 ms, 392 blocks 0.0350; 1M points 512 blocks 0.0511, 1024 blocks 0.0530).
+  if (exp_nb > 0) return (int)((exp_nb + 7) & ~7L);
+  long nb = (long)ns / (8 * WARM_THREADS);
+  if (nb > 1024) nb = 1024;
+  if (nb < 64) nb = 64;
   return (int)((nb + 7) & ~7L);
 }
 // (squared distances are NOT written by this form -- a store inside the streaming loop shares the in-order vmcnt counter with
