@@ -291,7 +291,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
-  if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return CILHIP_OK; }
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "point_weight_evaluator") || !strcmp(key, "plane_weight_evaluator")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "weight evaluator: 0 = Unity, 1 = Identity, 2 = RBF kernel");

@@ -1828,7 +1828,8 @@ int tiled_partial_rows(uint32_t ntiles) { return (int)(ntiles + deferred_blocks(
 template <int ACC>
 static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const int* tile_box, uint32_t ntiles, hipStream_t s) {
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
-  if (ACC != IM_NONE && a.tile_pipeline) hipLaunchKernelGGL((k_tile_pipe<ACC>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
+  if (ACC != IM_NONE && a.tile_pipeline == 2) hipLaunchKernelGGL((k_tile_pipe<ACC, true>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
+  else if (ACC != IM_NONE && a.tile_pipeline) hipLaunchKernelGGL((k_tile_pipe<ACC, false>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   else hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   hipLaunchKernelGGL((k_search_deferred<ACC>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
 }

@@ -387,7 +387,8 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        iteration) unless the device reports the source far from alignment, 2 = always inside the tiles.
  *   "tile_pipeline" (default 0): 1 = the one-pass tile iteration runs as ONE persistent, software-pipelined workgroup per CU
  *                        (k_tile_pipe: the next tile's points / cell table / row layout are in flight while the current tile is
- *                        searched) instead of one workgroup per tile.  Same results bit for bit; kept for A/B (measured slower).
+ *                        searched) instead of one workgroup per tile; 2 = the same with the next tile's points staged by LDS-DMA
+ *                        (no register holds them).  Same results bit for bit; kept for A/B (both measured slower: NOTEBOOK.md).
  *   "warm_start" (default 1): the warm-started iteration kernel (cilhip_get_last_warm_iterations): 0 = never, 1 = when the loop
  *                        has nearly stopped moving and the form pays on this cloud pair, 2 = from the second iteration on.
  *                        Neither option changes a result beyond the order of f64 additions.

@@ -305,7 +305,7 @@ def test_warm_kernel_matches_index_for_index_10m(Context, orc):
 
 
 def test_pipelined_tile_kernel_is_bitwise_the_tile_kernel(Context, orc):
-    """option tile_pipeline = 1 (k_tile_pipe: one persistent, software-pipelined workgroup per CU) against the default one
+    """option tile_pipeline = 1 / 2 (k_tile_pipe: one persistent, software-pipelined workgroup per CU; 2: LDS-DMA staging) against the default one
     workgroup per tile: the same partial-sum row per tile, hence the same transform BIT FOR BIT, the same matches; all
     accumulation variants; a start far enough for deferred queries and a region that exceeds its LDS buffer (duplicated points)."""
     rng = np.random.default_rng(15)
@@ -315,7 +315,7 @@ def test_pipelined_tile_kernel_is_bitwise_the_tile_kernel(Context, orc):
     for D, N in ((d["dst"], d["dst_n"]), (dense, dense_n)):
         for metric, w_p2p, w_p2pl in ((capi.METRIC_COMBINED, 0.0, 1.0), (capi.METRIC_COMBINED, 0.1, 1.0), (capi.METRIC_COMBINED, 1.0, 0.0), (capi.METRIC_POINT_TO_POINT, 0.0, 1.0)):
             out = {}
-            for pipe in (0, 1):
+            for pipe in (0, 1, 2):
                 ctx = Context()
                 for k, v in (("warm_start", 1), ("tiled", 2), ("tile_accumulation", 2), ("tile_pipeline", pipe)):
                     ctx.set_option(k, v)
@@ -328,7 +328,8 @@ def test_pipelined_tile_kernel_is_bitwise_the_tile_kernel(Context, orc):
                 idx, d2 = ctx.get_nn()
                 out[pipe] = (np.array(res.T[:], np.float32), int(res.last_ncorr), idx.copy(), d2.copy())
                 ctx.close()
-            assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), (metric, w_p2p, np.abs(out[0][0] - out[1][0]).max())
-            assert out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
-            m = out[0][2] != capi.NONE_IDX
-            assert np.array_equal(out[0][3][m].view(np.uint32), out[1][3][m].view(np.uint32))
+            for pipe in (1, 2):      # (2: the next tile's points staged by LDS-DMA)
+                assert np.array_equal(out[0][0].view(np.uint32), out[pipe][0].view(np.uint32)), (pipe, metric, w_p2p, np.abs(out[0][0] - out[pipe][0]).max())
+                assert out[0][1] == out[pipe][1] and np.array_equal(out[0][2], out[pipe][2]), pipe
+                m = out[0][2] != capi.NONE_IDX
+                assert np.array_equal(out[0][3][m].view(np.uint32), out[pipe][3][m].view(np.uint32)), pipe
