@@ -23,3 +23,6 @@ timeout 300 python bench.py --config kmeans > $O/bench_kmeans.json 2> $O/bench_k
 timeout 300 python bench.py --config ransac > $O/bench_ransac.json 2> $O/bench_ransac.err; cut -c1-300 $O/bench_ransac.json
 timeout 300 python bench.py --config c4_1gpu --steps 20 --warmup 3 --no-extras > $O/bench_c4_1gpu.json 2> $O/bench_c4.err; cut -c1-300 $O/bench_c4_1gpu.json
 timeout 200 tools/bin/read_bw_probe > $O/read_bw_probe.txt 2>&1; tail -3 $O/read_bw_probe.txt
+timeout 150 python tools/variants_bench.py 10000000 > $O/variants.txt 2>&1; grep "n=" $O/variants.txt | cut -c1-200
+timeout 150 python tools/directions_bench.py 10000000 > $O/directions.txt 2>&1; tail -6 $O/directions.txt | cut -c1-200
+timeout 100 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; tail -8 $O/size_sweep.txt | cut -c1-200
