@@ -60,11 +60,14 @@ struct cilhip_ctx {
   int last_fused_iters = 0, last_two_pass_iters = 0, last_warm_iters = 0;
   int run_calls = 0;              // cilhip_icp_partial_sums calls since cilhip_icp_begin
   bool run_warm_on = false;       // sharded runs: the loop has been seen to (nearly) stand still
+  unsigned int run_judged = 0;    // ... and the last published iteration whose count of searched queries has been judged
   std::vector<unsigned char> iter_form;   // form of every timed search / one-pass launch of the last run (FORM_*), in launch order
+  std::vector<unsigned char> trace_form;  // form of every iteration enqueued by the last run, timed or not (cilhip_get_last_run_trace)
   double form_ms[5] = {0, 0, 0, 0, 0};    // ... and the kernel time summed per form
   int form_n[5] = {0, 0, 0, 0, 0};
   int warm_start = 1;             // option "warm_start": 0 = never, 1 = when the device reports the source near alignment, 2 = from the second iteration on
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
+  uint4* d_trace = nullptr;                    // [RUN_TRACE_CAP] per-iteration loop state of the last run, written by the epilogue (cilhip_get_last_run_trace)
   uint32_t ntiles = 0;
   int tile_pipeline = 0;          // option "tile_pipeline": 1 = the in-tile accumulation runs as the persistent, software-pipelined kernel k_tile_pipe
                                   // (round 3 experiment, exact, measured 17 % slower than two workgroups per CU: off)
@@ -76,8 +79,16 @@ struct cilhip_ctx {
   float4* d_src_nrm_sorted = nullptr;
   uint32_t* d_nn_pos = nullptr;
   float* d_nn_d2 = nullptr;
-  float4* d_warm_rec = nullptr;   // [ns] float4 + 2 x [ns] F3: match records and the 12-byte source copy of the warm-started iterations (valid inside a run, after the first of them)
-  bool rec_valid = false;
+  float4* d_warm_rec = nullptr;   // [ns] float4 + 2 x [ns] F3: match records {matched point, margin key} {normal} and the 12-byte source copy of the warm-started iterations
+  bool rec_valid = false;         // the records describe the last executed iteration's matches (inside a run)
+  bool src3_valid = false;        // the 12-byte source copy matches d_src_sorted (rewritten after a re-sort)
+  float* d_nn_lb = nullptr;       // [ns] margin keys the search-only tile kernel leaves next to nn_pos (IterArgs::nn_lb)
+  bool lb_fresh = false;          // ... and they belong to the search that left nn_pos (inside a run)
+  bool tile_records = true;       // option "tile_records": the accumulating tile kernel writes the warm-started form's match records itself
+  float warm_enter = 0.15f;       // option "warm_enter_fraction": the bar a run starts with, as a fraction of a grid cell
+  float warm_thresh = 0.0f;       // a run's bar for (re-)entering the warm-started form: the last update moved no source point by more than this
+  int warm_strikes = 0;           // warm iterations of the run that had to search a quarter of their queries
+  float src_center[3] = {0, 0, 0}, src_half[3] = {0, 0, 0};   // bounding box of the source (source coordinates): the epilogue's bound on how far a query moves per update
   float* d_safe2 = nullptr;       // [grid.n] k_self_nn's table for the warm-started iteration; built with the target
   int cw_point_kind = 0, cw_plane_kind = 0;     // correspondence weight evaluators (CW_*), combined metric
   float cw_point_sigma = 1.0f, cw_plane_sigma = 1.0f;
@@ -194,6 +205,7 @@ int cilhip_create(cilhip_ctx** out, int device) {
       hipMalloc(&c->d_unproven, 128 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_unproven, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(&c->h_feedback, sizeof(Feedback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_feedback), c->h_feedback, 0) != hipSuccess ||
+      hipMalloc(&c->d_trace, RUN_TRACE_CAP * sizeof(uint4)) != hipSuccess || hipMemset(c->d_trace, 0, RUN_TRACE_CAP * sizeof(uint4)) != hipSuccess ||
       hipMalloc(&c->d_stage, REDUCE_STAGE_DOUBLES * sizeof(double)) != hipSuccess || hipMalloc(&c->d_sums, 3 * SUMS_MAX * sizeof(double)) != hipSuccess) {
     delete c;
     return CILHIP_ERR_HIP;
@@ -210,6 +222,8 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_nn_pos) (void)hipFree(c->d_nn_pos);
   if (c->d_nn_d2) (void)hipFree(c->d_nn_d2);
   if (c->d_warm_rec) { (void)hipFree(c->d_warm_rec); c->d_warm_rec = nullptr; }
+  if (c->d_nn_lb) { (void)hipFree(c->d_nn_lb); c->d_nn_lb = nullptr; }
+  c->src3_valid = false; c->lb_fresh = false;
   c->rec_valid = false;
   if (c->d_out_idx) (void)hipFree(c->d_out_idx);
   if (c->d_out_d2) (void)hipFree(c->d_out_d2);
@@ -254,6 +268,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_winner) (void)hipFree(c->d_winner);
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->d_dbg) (void)hipFree(c->d_dbg);
+  if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->d_defer_flag) (void)hipFree(c->d_defer_flag);
   if (c->d_unproven) (void)hipFree(c->d_unproven);
   if (c->d_rev_pos) (void)hipFree(c->d_rev_pos);
@@ -293,6 +308,12 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return CILHIP_OK; }
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
+  if (!strcmp(key, "tile_records")) { c->tile_records = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "warm_enter_fraction")) {
+    if (!(value > 0.0)) return fail(c, CILHIP_ERR_INVALID, "warm_enter_fraction: > 0 (fraction of a grid cell)");
+    c->warm_enter = (float)value;
+    return CILHIP_OK;
+  }
   if (!strcmp(key, "point_weight_evaluator") || !strcmp(key, "plane_weight_evaluator")) {
     if (value != 0.0 && value != 1.0 && value != 2.0) return fail(c, CILHIP_ERR_INVALID, "weight evaluator: 0 = Unity, 1 = Identity, 2 = RBF kernel");
     (key[1] == 'o' ? c->cw_point_kind : c->cw_plane_kind) = (int)value;
@@ -364,6 +385,26 @@ int cilhip_get_last_form_timing(cilhip_ctx* c, int form, double* kernel_ms, int*
   if (!c || form < 0 || form > 4) return CILHIP_ERR_INVALID;
   if (kernel_ms) *kernel_ms = c->form_ms[form];
   if (launches) *launches = c->form_n[form];
+  return CILHIP_OK;
+}
+
+int cilhip_get_last_run_trace(cilhip_ctx* c, int cap, int* n_out, unsigned int* unproven, unsigned int* listed, float* step, float* delta, int* form) {
+  if (!c || !n_out || cap < 0) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  IcpState hs;
+  CK(c, hipMemcpyAsync(&hs, c->d_state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  uint4 tr[RUN_TRACE_CAP];
+  CK(c, hipMemcpyAsync(tr, c->d_trace, sizeof(tr), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  const int n = std::min(std::min(hs.iterations, (int)RUN_TRACE_CAP), cap);
+  for (int i = 0; i < n; ++i) {
+    if (unproven) unproven[i] = tr[i].x;
+    if (listed) listed[i] = tr[i].y;
+    if (step) memcpy(&step[i], &tr[i].z, 4);
+    if (delta) memcpy(&delta[i], &tr[i].w, 4);
+    if (form) form[i] = (size_t)i < c->trace_form.size() ? (int)c->trace_form[i] : -1;
+  }
+  *n_out = n;
   return CILHIP_OK;
 }
 
@@ -444,9 +485,16 @@ int cilhip_set_source(cilhip_ctx* c, const float* xyz, size_t n, int mem) {
   CK(c, hipMalloc(&c->d_nn_d2, cap * sizeof(float)));
   c->ns = (uint32_t)n;
   double mean[3];
-  hipError_t e = mean3_device(c->d_src_xyz, c->ns, c->stream, mean);
+  float lo[3], hi[3];
+  hipError_t e = mean3_device(c->d_src_xyz, c->ns, c->stream, mean, lo, hi);
   if (e != hipSuccess) { c->err = std::string("mean3: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
-  for (int i = 0; i < 3; ++i) c->src_mean[i] = (float)mean[i];
+  for (int i = 0; i < 3; ++i) {
+    c->src_mean[i] = (float)mean[i];
+    // (centre and half extent rounded so that the box holds every point: the half extent is taken from the rounded centre)
+    c->src_center[i] = 0.5f * (lo[i] + hi[i]);
+    c->src_half[i] = c->ns ? std::max(hi[i] - c->src_center[i], c->src_center[i] - lo[i]) * 1.000001f : 0.0f;
+    if (!(c->src_half[i] >= 0.0f) || !std::isfinite(c->src_center[i])) { c->src_center[i] = 0.0f; c->src_half[i] = 1.0e30f; }   // (non-finite coordinates: no bound)
+  }
   const int nb = std::max(iter_num_blocks(c->ns), warm_num_blocks(c->ns));      // rows of partial sums: the streaming and the warm-started kernels
   if (nb > c->partial_blocks) {
     if (c->d_partials) (void)hipFree(c->d_partials);
@@ -553,6 +601,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
+    c->src3_valid = false; c->rec_valid = false; c->lb_fresh = false;     // (per sorted order)
     drop_matches(c);
   }
   return CILHIP_OK;
@@ -598,21 +647,38 @@ static bool filters_active(const cilhip_ctx* c) {
 // the A/B option "fused" (per-lane kernel) or "tile_accumulation" = 0.
 // kernel forms of an iteration's search (+ accumulation): cilhip_get_last_form_timing
 enum { FORM_SEARCH = 0, FORM_TILE_ONE_PASS = 1, FORM_WARM_FIRST = 2, FORM_WARM = 3, FORM_LANE_FUSED = 4 };
-// 1 + the largest distance of a corner of the target's grid from the origin: a point of a (roughly aligned) source moves by
-// at most delta * this per iteration, delta = the iteration's update norm
-static float warm_scale(const cilhip_ctx* c) {
-  const GridDev& g = c->grid;
-  const float hx = std::max(std::fabs(g.ox), std::fabs(g.ox + (float)g.nx * g.cell)), hy = std::max(std::fabs(g.oy), std::fabs(g.oy + (float)g.ny * g.cell)),
-              hz = std::max(std::fabs(g.oz), std::fabs(g.oz + (float)g.nz * g.cell));
-  return 1.0f + std::sqrt(hx * hx + hy * hy + hz * hz);
+// The warm-started form (k_warm) pays while the queries move little between iterations: a query is settled without any search as
+// long as it has moved less than the MARGIN its last search left it (distance to the second nearest target point minus distance
+// to the nearest, capped by the searched block's faces -- a good fraction of the target's point spacing, whatever the source is).
+// The epilogue publishes how far any source point can have moved in the last update (IcpState::motion_step); a run enters the
+// form when that falls below warm_thresh (a fraction of a cell), and the kernel's own count of the queries it had to search
+// corrects the guess: a quarter of them searched = one iteration through the cold form (whose searches leave fresh margins)
+// and half the bar; three such falls and the run stays cold.
+static void warm_run_reset(cilhip_ctx* c) { c->warm_thresh = c->warm_enter * c->grid.cell; c->warm_strikes = 0; }
+// a warm iteration was seen to search `listed` of its queries: keep going?
+static bool warm_keeps_paying(cilhip_ctx* c, unsigned int listed) {
+  if ((unsigned long long)listed * 4ull <= (unsigned long long)c->ns) return true;
+  c->warm_thresh *= 0.5f;
+  if (++c->warm_strikes >= 3) c->warm_banned = true;
+  return false;
 }
-// Will the NEXT step be small against a cell?  Extrapolated from the last two update norms (the loop contracts at least as fast
-// as it just did: quadratically for the point-to-plane metric, linearly for point-to-point): next <= delta * min(1, delta / prev).
-// Measured on the benchmark recipe (update norm x scale / cell per iteration): 1.97, 0.29, 7.5e-4, 3e-6 ...; from 0.8 cell away:
-// 1.3, 1.9, 2.2, 0.65, 4.7e-3, 5e-6.
-static bool warm_worthwhile(const cilhip_ctx* c, float delta, float prev_delta) {
-  const float ratio = (prev_delta > 0.0f && std::isfinite(prev_delta)) ? std::min(1.0f, delta / prev_delta) : 1.0f;
-  return delta * ratio * warm_scale(c) < 0.1f * c->grid.cell;
+static bool warm_worthwhile(const cilhip_ctx* c, float step) { return step < c->warm_thresh; }
+// the matches records / margin keys / 12-byte source copy of the warm-started iterations: allocated by the first run that can use them
+static int ensure_warm_buffers(cilhip_ctx* c) {
+  const size_t cap = c->ns ? c->ns : 1;
+  if (!c->d_warm_rec) { CK(c, hipMalloc(&c->d_warm_rec, cap * (sizeof(float4) + 2 * sizeof(F3)))); c->src3_valid = false; }
+  if (!c->d_nn_lb) CK(c, hipMalloc(&c->d_nn_lb, cap * sizeof(float)));
+  if (!c->src3_valid) {
+    launch_copy_src3(c->d_src_sorted, c->ns, reinterpret_cast<F3*>(c->d_warm_rec + cap) + cap, c->stream);
+    c->src3_valid = true;
+  }
+  return CILHIP_OK;
+}
+static void set_warm_args(const cilhip_ctx* c, IterArgs& wa) {
+  const size_t cap = c->ns ? c->ns : 1;
+  wa.warm_rec = c->d_warm_rec;
+  wa.warm_rec_n = reinterpret_cast<F3*>(c->d_warm_rec + cap);
+  wa.warm_src3 = wa.warm_rec_n + cap;
 }
 static bool weighted(const cilhip_ctx* c) { return c->cw_point_kind != CW_UNITY || c->cw_plane_kind != CW_UNITY; }
 // The per-pair weights of the combined-metric classes (PointToPoint/PointToPlaneCorrWeightEvaluatorT of
@@ -1215,6 +1281,8 @@ static SolveArgs make_solve_args(cilhip_ctx* c, const cilhip_icp_params* p, int 
   sa.guard_axis = c->guard_axis; sa.guard_slack = c->guard_slack;
   for (int i = 0; i < 3; ++i) { sa.guard_center[i] = c->guard_center[i]; sa.guard_half[i] = c->guard_half[i]; }
   for (int i = 0; i < 16; ++i) sa.guard_T[i] = c->guard_T[i];
+  for (int i = 0; i < 3; ++i) { sa.src_center[i] = c->src_center[i]; sa.src_half[i] = c->src_half[i]; }
+  sa.trace = c->d_trace;
   return sa;
 }
 
@@ -1229,7 +1297,7 @@ static hipEvent_t get_event(cilhip_ctx* c, size_t i) {
 }
 
 // What the run's epilogues have published (Feedback): a consistent snapshot of the LATEST published iteration.
-struct FbView { bool done; unsigned int iterations, unproven, listed; float delta, prev_delta; };
+struct FbView { bool done; unsigned int iterations, unproven, listed; float delta, prev_delta, step; };
 static inline void cpu_relax(unsigned spins) {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_pause();
@@ -1251,7 +1319,7 @@ static int wait_published(cilhip_ctx* c, unsigned int need, double patience_s, F
         // iterations ahead), so this read cannot be torn; its commit word is checked all the same
         const volatile FeedbackSlot* sl = &fb->slot[iters & 3u];
         v->done = done; v->iterations = iters;
-        v->unproven = sl->unproven; v->listed = sl->listed; v->delta = sl->delta; v->prev_delta = sl->prev_delta;
+        v->unproven = sl->unproven; v->listed = sl->listed; v->delta = sl->delta; v->prev_delta = sl->prev_delta; v->step = iters ? sl->step : INFINITY;
         if (iters == 0u || sl->commit == (((unsigned long long)c->run_tag << 32) | iters)) return 0;
       }
     }
@@ -1316,7 +1384,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   const bool zero_steps = gn && p->max_opt_iter == 0;
   const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 1) : 1;
   ++c->run_tag;
-  launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag);
+  launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half);
   IterArgs a = make_iter_args(c, p->max_sq_dist);
   a.cw = corr_weights_of(c, p);
   SolveArgs sa = make_solve_args(c, p, im, c->src_mean);
@@ -1463,14 +1531,16 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   // alignment: first iterations of a registration) the search runs with its in-LDS 3x3x3 second pass and a separate
   // streaming accumulation; once nearly all are proven, search + accumulation run as one pass inside the tiles.
   const bool wcap = warm_capable(c);
-  if (wcap) { rc = ensure_safe2(c); if (rc) return rc; }
+  if (wcap) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
   const bool paced = (tile_acc || wcap) && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
   if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
-  c->rec_valid = false;
-  c->iter_form.clear();
+  c->rec_valid = false; c->lb_fresh = false;
+  warm_run_reset(c);
+  c->iter_form.clear(); c->trace_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
-  bool warm_on = false;       // the loop has been seen to (nearly) stand still: iterations run warm-started until it is seen far again
+  bool warm_on = false;       // the loop has been seen to move little: iterations run warm-started until one of them has to search too many of its queries
+  unsigned int judged = 0;    // the last published iteration whose listed count has been judged
   bool all_stored = true;     // every iteration enqueued left its matches in nn_pos (finish_run_matches)
   for (size_t it = 0; it < p->max_iter; ++it) {
     if (paced && it >= 2) {
@@ -1479,30 +1549,32 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       rc = wait_published_or_sync(c, (unsigned int)(it - 1), &fv);
       if (rc) return rc;
       if (fv.done) break;
-      c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
-      if (c->far_mode) warm_on = false;
-      // the warm-started form pays while the nearest-other-point table settles nearly every query; when an eighth of them had
-      // to be searched from the lists (a source that is not the target's points plus small noise: matches at a good fraction
-      // of the point spacing) the tiles are faster: no more warm-started iterations on this cloud pair
-      if (c->warm_start == 1 && (unsigned long long)fv.listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; warm_on = false; }
-      if (!c->far_mode && c->warm_start == 1 && !warm_on && !c->warm_banned) {
-        // Candidate for the warm-started form (below): it pays once the source has (nearly) stopped moving -- the bounds it
-        // searches with are the distances to the PREVIOUS matches.  Decided on the step the loop made last, so wait for
-        // iteration it - 1 itself (a bubble of some tens of microseconds, only while this decision is pending): a point moves
-        // by at most delta * (1 + |x|) per iteration.
+      // the form of the COLD iterations (one pass / two passes), from the last cold iteration's count of queries its octant stage
+      // left open (a warm-started iteration counts something else there: the queries its own search took to the shells)
+      if (fv.iterations >= 1 && fv.iterations <= c->trace_form.size() && c->trace_form[fv.iterations - 1] <= FORM_TILE_ONE_PASS)
+        c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
+      // (a published iteration is judged once: the same one can be the latest at two consecutive looks)
+      bool fell = false;
+      if (warm_on && c->warm_start == 1 && fv.iterations > judged) {
+        judged = fv.iterations;
+        if (!warm_keeps_paying(c, fv.listed)) { warm_on = false; fell = true; }
+      }
+      if (c->warm_start == 1 && !warm_on && !fell && !c->warm_banned && fv.step < 8.0f * c->warm_thresh) {
+        // Candidate for the warm-started form (below).  Decided on the step the loop made LAST -- it is the distance between
+        // the queries the margins were left for and the queries about to be searched -- so wait for iteration it - 1 itself
+        // (a bubble of some tens of microseconds, only while this decision is pending and the loop is within reach of it).
         rc = wait_published_or_sync(c, (unsigned int)it, &fv);
         if (rc) return rc;
         if (fv.done) break;
-        warm_on = warm_worthwhile(c, fv.delta, fv.prev_delta);
+        if (fv.iterations > judged && fv.listed != 0u) { judged = fv.iterations; fell = !warm_keeps_paying(c, fv.listed); }
+        if (!fell && !c->warm_banned) warm_on = warm_worthwhile(c, fv.step);
       }
     }
     const bool one_pass = tile_acc && !c->far_mode;
-    // Third form, near alignment and from the second iteration on: the per-lane search + accumulation kernel WARM-STARTED
-    // from the previous iteration's matches (kept by the forms above) -- no tile to stage at all.  Same matches, same sums
-    // up to the order of the f64 additions.
-    // (not at it = 1 unless forced: the first step of a registration is its largest, the bounds from the matches of it = 0 are
-    //  loose -- measured at 10M: 0.43 ms against 0.30 ms for the tiles)
-    const bool warm = wcap && it >= 1 && (c->warm_start == 2 || ((one_pass || !tile_acc) && paced && it >= 2 && warm_on));
+    // Third form, from the second iteration on: search + accumulation WARM-STARTED from the previous iteration's matches and
+    // the margins their searches left (kept by the forms above) -- no tile to stage at all.  Same matches, same sums up to
+    // the order of the f64 additions.
+    const bool warm = wcap && it >= 1 && (c->warm_start == 2 || (paced && it >= 2 && warm_on));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     bool warm_first = false;
     for (size_t st = 0; st < opt_steps; ++st) {
@@ -1516,28 +1588,36 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           IterArgs wa = a;
           wa.warm_pos = c->d_nn_pos;
           wa.safe2 = c->d_safe2;
-          wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;      // bound beyond half a cell: what the tiles' octant stage calls unproven
-          // the first warm iteration of a stretch gathers through the stored positions and leaves a 32-byte match record per
-          // query; the following ones read the records (two coalesced loads) instead of gathering
-          if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * (sizeof(float4) + 2 * sizeof(F3))));
-          wa.warm_rec = c->d_warm_rec;
-          wa.warm_rec_n = reinterpret_cast<F3*>(c->d_warm_rec + c->ns);
-          wa.warm_src3 = wa.warm_rec_n + c->ns;
+          wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;
+          // the first warm iteration after the search-only forms gathers through the stored positions, takes the margin keys
+          // those searches left (nn_lb) and writes a match record per query; after a tile iteration with the accumulation
+          // inside -- which writes the records itself -- and from then on, the records are streamed instead
+          set_warm_args(c, wa);
+          wa.nn_lb = c->d_nn_lb; wa.lb_valid = c->lb_fresh ? 1 : 0;
           warm_first = !c->rec_valid;
           launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
-          c->rec_valid = true;
+          c->rec_valid = true; c->lb_fresh = false;
         } else if (st == 0 && one_pass) {
-          c->rec_valid = false;
           // search + accumulation of the first Gauss-Newton step inside the LDS tiles (one pass; the matches are only
           // stored when further Gauss-Newton steps will stream over them or the next iteration may start from them)
           IterArgs fa = a;
           fa.store_matches = (opt_steps > 1 || c->warm_start) ? 1 : 0;
           fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
+          // ... and from the second iteration on the tile leaves the match records of the warm-started form (not the first: a
+          // registration's first step is its largest, its margins would be spent at once)
+          const bool recs = wcap && it >= 1 && !c->tile_pipeline && c->tile_records && fa.store_matches;
+          if (recs) set_warm_args(c, fa);
           launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+          c->rec_valid = recs; c->lb_fresh = false;
           all_stored = all_stored && fa.store_matches != 0;
         } else if (st == 0) {
           c->rec_valid = false;
-          { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
+          // (search-only form of the tiles: the margin keys of its searches next to the matches)
+          IterArgs sa2 = a;
+          const bool keys = wcap && use_tiled(c) && !feat6(c);
+          if (keys) sa2.nn_lb = c->d_nn_lb;
+          c->lb_fresh = keys;
+          { const int src_rc = launch_search(c, sa2); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
@@ -1553,9 +1633,12 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         ++launches;
       }
       if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
-      if (timing && st == 0)
-        c->iter_form.push_back((unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
-                                               : (c->fused && !filters_active(c) && !feat6(c)) ? FORM_LANE_FUSED : FORM_SEARCH));
+      if (st == 0) {
+        const unsigned char form = (unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
+                                                   : (c->fused && !filters_active(c) && !feat6(c)) ? FORM_LANE_FUSED : FORM_SEARCH);
+        if (timing) c->iter_form.push_back(form);
+        c->trace_form.push_back(form);
+      }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
         const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : nb;
@@ -1621,14 +1704,15 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   c->run_prm = *p;
   for (int i = 0; i < 3; ++i) c->run_src_mean[i] = gmean ? gmean[i] : c->src_mean[i];
   ++c->run_tag;
-  launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream, c->d_feedback, c->run_tag);     // (the epilogue publishes the loop state: see cilhip_icp_partial_sums)
+  launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half);     // (the epilogue publishes the loop state: see cilhip_icp_partial_sums)
   CK(c, hipGetLastError());
   c->run_active = true;
   c->run_nev = 0;
   c->run_calls = 0;
-  c->run_warm_on = false;
-  c->rec_valid = false;
-  if (warm_capable(c)) { rc = ensure_safe2(c); if (rc) return rc; }
+  c->run_warm_on = false; c->run_judged = 0;
+  c->rec_valid = false; c->lb_fresh = false;
+  warm_run_reset(c);
+  if (warm_capable(c)) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
   c->iter_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
@@ -1656,20 +1740,25 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
       // published (a bounded wait for iteration run_calls - 2) says the source is near alignment.  Ranks may differ in their choice: the sums are
       // the same up to the order of the f64 additions.
       bool warm = false;
-      if (warm_capable(c) && c->run_calls >= 1) {
+      const bool wcap = warm_capable(c);
+      if (wcap && c->run_calls >= 1) {
         warm = c->warm_start == 2;
         if (!warm && c->run_calls >= 2) {
           // paced like cilhip_icp_run: at most two iterations ahead of the device (which never waits: an iteration takes
           // hundreds of microseconds), so that the loop state looked at is at least that of iteration run_calls - 2; a brief
-          // wait at most (5 s without news: the tiled form)
+          // wait at most (5 s without news: the cold form)
           FbView fv;
           if (wait_published(c, (unsigned int)(c->run_calls - 1), 5.0, &fv) == 0) {
             c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
-            if (c->far_mode) c->run_warm_on = false;
-            if ((unsigned long long)fv.listed * 8ull > (unsigned long long)c->ns) { c->warm_banned = true; c->run_warm_on = false; }
-            // (the step is the one of iteration run_calls - 2 here -- no second wait in the caller-driven protocol)
-            if (!c->far_mode && !c->run_warm_on && !c->warm_banned) c->run_warm_on = warm_worthwhile(c, fv.delta, fv.prev_delta);
-            warm = !c->far_mode && c->run_warm_on;
+            bool fell = false;
+            if (c->run_warm_on && fv.iterations > c->run_judged) {
+              c->run_judged = fv.iterations;
+              if (!warm_keeps_paying(c, fv.listed)) { c->run_warm_on = false; fell = true; }
+            }
+            // (the step is the one of iteration run_calls - 2 here -- no second wait in the caller-driven protocol: the margins
+            //  then have to cover two updates, which the kernel's own count of searched queries reports back)
+            if (!c->run_warm_on && !fell && !c->warm_banned) c->run_warm_on = warm_worthwhile(c, fv.step);
+            warm = c->run_warm_on;
           }
         }
       }
@@ -1679,23 +1768,23 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         wa.warm_pos = c->d_nn_pos;
         wa.safe2 = c->d_safe2;
         wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;
-        if (!c->d_warm_rec) CK(c, hipMalloc(&c->d_warm_rec, (size_t)c->ns * (sizeof(float4) + 2 * sizeof(F3))));
-        wa.warm_rec = c->d_warm_rec;
-          wa.warm_rec_n = reinterpret_cast<F3*>(c->d_warm_rec + c->ns);
-          wa.warm_src3 = wa.warm_rec_n + c->ns;
+        set_warm_args(c, wa);
+        wa.nn_lb = c->d_nn_lb; wa.lb_valid = c->lb_fresh ? 1 : 0;
         if (timing) c->iter_form.push_back((unsigned char)(c->rec_valid ? FORM_WARM : FORM_WARM_FIRST));
         launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
         prows = warm_num_blocks(c->ns);
-        c->rec_valid = true;
+        c->rec_valid = true; c->lb_fresh = false;
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
         ++c->last_fused_iters; ++c->last_warm_iters;
       } else if (tile_accumulation(c)) {
-        c->rec_valid = false;
         if (timing) c->iter_form.push_back((unsigned char)FORM_TILE_ONE_PASS);
         IterArgs fa = a;
         fa.store_matches = c->warm_start ? 1 : 0;
         fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
+        const bool recs = wcap && c->run_calls >= 1 && !c->tile_pipeline && c->tile_records && fa.store_matches;
+        if (recs) set_warm_args(c, fa);
         launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+        c->rec_valid = recs; c->lb_fresh = false;
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
         prows = tiled_partial_rows(c->ntiles);
         ++c->last_fused_iters;
@@ -1703,7 +1792,11 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         c->rec_valid = false;
         if (timing) c->iter_form.push_back((unsigned char)FORM_SEARCH);
         ++c->last_two_pass_iters;
-        if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+        IterArgs sa2 = a;
+        const bool keys = wcap && use_tiled(c);
+        if (keys) sa2.nn_lb = c->d_nn_lb;
+        c->lb_fresh = keys;
+        if (use_tiled(c)) launch_search_tiled(sa2, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         else launch_iter(a, IM_NONE, true, true, nb, c->stream);
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
         launch_iter(a, im, false, false, nb, c->stream);

@@ -83,10 +83,13 @@ static hipError_t bbox_mean(const float* d_xyz, uint32_t n, hipStream_t s, float
   return hipSuccess;
 }
 
-hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3]) {
-  float lo[3], hi[3];
-  if (n == 0) { mean_out[0] = mean_out[1] = mean_out[2] = 0.0; return hipSuccess; }
-  return bbox_mean(d_xyz, n, s, lo, hi, mean_out);
+hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3], float* lo_out, float* hi_out) {
+  float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+  hipError_t e = hipSuccess;
+  if (n == 0) mean_out[0] = mean_out[1] = mean_out[2] = 0.0;
+  else e = bbox_mean(d_xyz, n, s, lo, hi, mean_out);
+  for (int c = 0; c < 3; ++c) { if (lo_out) lo_out[c] = lo[c]; if (hi_out) hi_out[c] = hi[c]; }
+  return e;
 }
 
 __device__ __forceinline__ uint32_t cell_of(const GridDev& g, float x, float y, float z) {

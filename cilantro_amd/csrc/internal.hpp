@@ -77,6 +77,11 @@ struct IcpState {
   float violation_T[16];
   float Tprev[16];        // transform_ BEFORE the last update = the transform the last executed iteration searched under: what the
                           // engine's correspondence set refers to after estimate() (correspondence_search_kd_tree.hpp:231)
+  // Query motion since the run began (the warm-started iteration's margin test): motion_acc >= the PATH LENGTH every
+  // query q = T s has travelled over the run's updates (sum over updates of max over the source's bounding box of |T' s - T s|;
+  // rounded up), so the distance any query moved between two iterations is at most the difference of the two values;
+  // motion_eps >= the rounding error of one computed query under the current transform; motion_step = the last update's share.
+  float motion_acc, motion_eps, motion_step;
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -147,6 +152,14 @@ struct IterArgs {
   F3* warm_rec_n;              // [ns]: the matched point's normal
   F3* warm_src3;               // [ns]: the sorted source points without their index (12 B instead of 16)
   const float* safe2;          // [grid.n] per sorted target point: lower bound on the squared distance to its nearest other target point (k_self_nn)
+  // Margin keys (warm-started iterations).  A search that PROVES its result also knows a lower bound Lb on the
+  // distance from the query to every OTHER target point (second smallest distance inside the searched block, capped by the gap to
+  // the block's faces).  Stored per query as  B = +-(Lb - motion_eps + motion_acc)  (rounded down; sign: + match, - no match, then
+  // Lb bounds the distance to EVERY target point; +0 / -FLT_MIN: no bound known): under a later transform the same bound reads
+  // B - motion_acc' - motion_eps'.  nn_lb: written next to nn_pos by the search-only forms (null: not wanted); the accumulating
+  // tile kernel writes it straight into its match records (warm_rec[i].w) when warm_rec is set.
+  float* nn_lb;
+  int lb_valid;                // (record-writing warm kernel) nn_lb holds the keys of the search that left warm_pos
 };
 
 // What k_tile_boxes needs to compute the tiles' regions for the state's transform.
@@ -170,6 +183,8 @@ struct FeedbackSlot {
   unsigned int listed;          // IcpState::listed of that iteration
   float delta;                  // IcpState::delta (last_delta_norm_) of that iteration
   float prev_delta;             // ... and of the one before it
+  float step;                   // IcpState::motion_step: how far a source point can have moved in that iteration's update
+  float pad;
   unsigned long long commit;    // (run tag << 32) | iterations performed: sanity check of the slot
 };
 struct Feedback {
@@ -201,7 +216,11 @@ struct SolveArgs {
   float guard_slack;
   float guard_center[3], guard_half[3];
   float guard_T[16];       // transform the partition was made under
+  // bounding box of the source in SOURCE coordinates (centre, half extents): the epilogue bounds how far a query can move per update
+  float src_center[3], src_half[3];
+  uint4* trace;            // [RUN_TRACE_CAP] or null: per iteration {unproven, listed, bits(motion_step), bits(delta)} (cilhip_get_last_run_trace)
 };
+constexpr int RUN_TRACE_CAP = 256;
 
 #if defined(__HIPCC__)
 // The transformed feature part of a source point (the three adaptor behaviours of FeatSpec::mode).  f32, the engine's pinned
@@ -252,8 +271,9 @@ __device__ __forceinline__ float d9_features(float ax, float ay, float az, float
 void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nblocks, hipStream_t s);
 // warm-started search + accumulation (a.warm_pos / a.nn_pos: previous / new matches, may alias); nblocks: a multiple of 8
 void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s);
-// rec: 0 = gather through warm_pos, 1 = the same and write the match records, 2 = read the match records (a.warm_rec)
+// rec: 1 = gather through warm_pos (+ the searches' margin keys in nn_lb) and write the match records, 2 = read the match records (a.warm_rec)
 void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_t s);
+void launch_copy_src3(const float4* src_sorted, uint32_t ns, F3* out, hipStream_t s);   // a.warm_src3 of the record-reading form
 int warm_num_blocks(uint32_t ns);      // blocks (= partial-sum rows) of launch_warm
 void launch_solve(const SolveArgs& a, hipStream_t s);
 // acc_metric IM_NONE: search only; IM_KABSCH / IM_PLANE / IM_POINT / IM_BOTH: search + accumulation inside the tile
@@ -270,7 +290,8 @@ void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_s
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 128 * SUMS_MAX;
-void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb = nullptr, unsigned int run_tag = 0);
+void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb = nullptr, unsigned int run_tag = 0,
+                       const float* src_center = nullptr, const float* src_half = nullptr);
 void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
                        const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,
                        hipStream_t s);
@@ -347,6 +368,6 @@ hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const f
                        hipStream_t s, uint2** d_tiles_out, float4** d_tile_center_out, float tile_axes_out[9], uint32_t* ntiles_out,
                        SortWorkspace* ws = nullptr);
 void free_sort_workspace(SortWorkspace& ws);
-hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3]);
+hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3], float* lo_out = nullptr, float* hi_out = nullptr);
 
 }  // namespace cilhip

@@ -57,6 +57,35 @@ __device__ __forceinline__ float d2_pinned(float qx, float qy, float qz, float p
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// ---- margin keys (IterArgs::nn_lb, the match records' fourth component) ------------------------------------
+// A search that has PROVEN its result for a query q also knows a lower bound on the distance from q to every target point but
+// the match: the second smallest squared distance it evaluated (every point of the searched block was evaluated) and the gap
+// from q to the block's faces (everything else lies beyond), whichever is smaller.  Without a match the same bound holds for
+// every target point.  The key stores it relative to the run's motion clock: B = +-((lb - eps) + acc), rounded DOWN, so that
+// under a later transform of the same run  B - (acc' + eps')  is still such a bound (a query moves by at most acc' - acc
+// between the two searches; eps, eps': the rounding of the two computed queries).
+struct MotionRef { float acc, eps; };      // IcpState::motion_acc / ::motion_eps under the transform being searched
+#define MARGIN_NONE_NO_MATCH (-1.17549435e-38f) /* -FLT_MIN: no match, no bound known (+0: a match, no bound known) */
+__device__ __forceinline__ float margin_key(bool found, float second_sq, float gap, const MotionRef& m) {
+  // sqrt of a pinned squared distance: the true distance is at least that times (1 - 2^-22), the device's square root is within 1 ulp
+  const float lb = fminf(__fsqrt_rn(second_sq) * 0.999999f, gap);
+  const float b = __fmul_rn(__fadd_rn(__fsub_rn(lb, m.eps), m.acc), 0.9999995f);
+  return found ? fmaxf(b, 0.0f) : -fmaxf(b, 1.17549435e-38f);
+}
+
+// The accumulating tile kernel carries its two queries' keys through the second search and the barrier packed into ONE register:
+// 16 bits each -- sign = no match, 15 bits = (lb - eps) in units of cell / 8192, rounded DOWN (values beyond 4 cells: clamped; a
+// bound may always be smaller) -- and forms the key proper where it writes the record.
+__device__ __forceinline__ uint32_t margin_q15(bool found, float second_sq, float gap, const MotionRef& m, float inv_cell) {
+  const float lb = __fsub_rn(fminf(__fsqrt_rn(second_sq) * 0.999999f, gap), m.eps);
+  const float u = fminf(fmaxf(lb * inv_cell * 8192.0f, 0.0f), 32767.0f);
+  return (uint32_t)floorf(u) | (found ? 0u : 0x8000u);
+}
+__device__ __forceinline__ float margin_from_q15(uint32_t q, float cell, const MotionRef& m) {
+  const float b = __fmul_rn(__fadd_rn((float)(q & 0x7FFFu) * (cell * (1.0f / 8192.0f)), m.acc), 0.9999995f);
+  return (q & 0x8000u) ? -fmaxf(b, 1.17549435e-38f) : b;
+}
+
 struct NN {
   unsigned long long key;  // (bits(d2) << 32) | original target index : strict '<' + lowest-index tie-break
   uint32_t pos;            // position in the sorted target array, NONE_U32 if nothing within the radius
@@ -206,6 +235,90 @@ __device__ __forceinline__ void nn_search_shells(const GridDev& g, float qx, flo
     if (b == INFINITY) break;  // block covers the grid: everything scanned
     b -= g.margin;
     if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) break;
+  }
+}
+
+// The shell search once more, for a caller that wants a MARGIN with its result (the warm-started kernel's listed queries, DESIGN.md
+// 6.2): it looks `extra` further than the best found so far requires -- a cell or row is skipped only when its gap exceeds
+// sqrt(best) + extra, the shells end when the next one lies beyond that -- evaluates every point of the cells it does look at and
+// keeps the two smallest squared distances a1 <= b2 met (carried in from the blocks the caller has already scanned completely).
+// On return every target point that was not evaluated is at least sqrt(best d2, or the radius without a match) + extra away.
+__device__ __forceinline__ void scan_range4_track2(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, NN& best,
+                                                   float& a1, float& b2, float4& bp) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 4) {
+    uint32_t jj[4];
+    float4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { jj[k] = min(j + (uint32_t)k, last); p[k] = pts[jj[k]]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float e = d2_pinned(qx, qy, qz, p[k].x, p[k].y, p[k].z);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p[k].w);
+      if (key < best.key) { best.key = key; best.pos = jj[k]; bp = p[k]; }
+      if (j + (uint32_t)k <= last) { b2 = __builtin_amdgcn_fmed3f(a1, b2, e); a1 = fminf(a1, e); }
+    }
+  }
+}
+__device__ __forceinline__ void nn_search_shells_margin(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz, int s_start, NN& best,
+                                                        float& a1, float& b2, float4& bp, float extra) {
+  for (int s = s_start;; ++s) {
+    const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1);
+    const int y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+    const int xlo = cx - s, xhi = cx + s;
+    for (int z = z0; z <= z1; ++z) {
+      const bool zface = (z == cz - s) || (z == cz + s);
+      const float zl = g.oz + (float)z * g.cell;
+      const float gz = axis_gap(qz, zl, zl + g.cell, g.margin);
+      const float gz2 = gz * gz;
+      for (int y = y0; y <= y1; ++y) {
+        const bool face = zface || (y == cy - s) || (y == cy + s);
+        const float yl = g.oy + (float)y * g.cell;
+        const float gy = axis_gap(qy, yl, yl + g.cell, g.margin);
+        const float gyz2 = gz2 + gy * gy;
+        // (the limit follows the best found so far: rounded UP, so that what is skipped really lies beyond sqrt(best) + extra)
+        float lim = (__fsqrt_rn(__uint_as_float((uint32_t)(best.key >> 32))) + extra) * 1.000001f;
+        float lim2 = lim * lim * 1.000001f;
+        if (gyz2 * KSHRINK > lim2) continue;
+        const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+        if (face) {
+          const int xa = max(xlo, 0), xb = min(xhi, g.nx - 1);
+          if (xa <= xb) {
+            const float gx = axis_gap(qx, g.ox + (float)xa * g.cell, g.ox + (float)(xb + 1) * g.cell, g.margin);
+            if ((gyz2 + gx * gx) * KSHRINK <= lim2)
+              scan_range4_track2(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best, a1, b2, bp);
+          }
+        } else {
+          if (xlo >= 0 && xlo < g.nx) {
+            const float xl = g.ox + (float)xlo * g.cell;
+            const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
+            if ((gyz2 + gx * gx) * KSHRINK <= lim2)
+              scan_range4_track2(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, best, a1, b2, bp);
+          }
+          if (xhi >= 0 && xhi < g.nx) {
+            lim = (__fsqrt_rn(__uint_as_float((uint32_t)(best.key >> 32))) + extra) * 1.000001f;
+            lim2 = lim * lim * 1.000001f;
+            const float xl = g.ox + (float)xhi * g.cell;
+            const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
+            if ((gyz2 + gx * gx) * KSHRINK <= lim2)
+              scan_range4_track2(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, best, a1, b2, bp);
+          }
+        }
+      }
+    }
+    // lower bound on the distance to anything not yet scanned (outside the (2s+1)^3 block, inside the grid)
+    float b = INFINITY;
+    if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+    if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+    if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+    if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+    if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+    if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+    if (b == INFINITY) break;  // block covers the grid: everything scanned
+    b -= g.margin;
+    const float lim = (__fsqrt_rn(__uint_as_float((uint32_t)(best.key >> 32))) + extra) * 1.000001f;
+    if (b > 0.0f && lim * lim * 1.000001f < b * b * KSHRINK) break;
   }
 }
 
@@ -843,7 +956,7 @@ __device__ __forceinline__ float octant_bound(const GridDev& g, float qx, float 
 // radius while there is none): the 6-D feature distance of any candidate but the winner is at least that.
 template <bool TRACK2 = false>
 __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best, uint32_t& bl_out,
-                                              float* second_out = nullptr) {
+                                              float* second_out = nullptr, float* bound_out = nullptr) {
   float m12[2] = {INFINITY, INFINITY};
   const f32x2 qxy = {o.qx, o.qy};
   const float qz = o.qz;
@@ -926,6 +1039,7 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   if (TRACK2) *second_out = m12[1];
   bl_out = bl;      // LDS index of the winner (NONE_U32: nothing within the radius): the in-tile accumulation reads the point from there
   const float b = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
+  if (TRACK2 && bound_out) *bound_out = b;      // (shrunk) distance from q to the nearest face of the block: every point outside it is at least that far
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
 
@@ -939,27 +1053,36 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
 #define CILHIP_B27_CAND 6
 #endif
 constexpr int B27_CAND = CILHIP_B27_CAND;
+template <bool TRACK2 = false>
 __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
-                                               int cx, int cy, int cz, float max_sq, NN& best) {
+                                               int cx, int cy, int cz, float max_sq, NN& best, float* second_out = nullptr, float* bound_out = nullptr) {
+  float m12[2] = {INFINITY, INFINITY};      // (TRACK2: [1] = the second smallest squared distance evaluated, as in octant_search)
   const f32x2 qxy = {qx, qy};
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
   const int row0 = (cz - t.loz) * t.RY + (cy - t.loy);       // region row of the own cell
   const int e0 = row0 * t.W1 + (cx - t.lox) - 1;             // table entry of the x-1 cell of that row
   uint32_t sel = 0xFFFFu;
   uint32_t over = 0;            // bit r: run r is longer than B27_CAND
+  int e0v = e0;                 // (TRACK2: re-tied to each run's result below)
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const int off = (r / 3 - 1) * t.RY + (r % 3 - 1);
     const uint32_t dl = t.rowdelta[row0 + off];
-    const uint32_t rj = t.lcs[e0 + off * t.W1] - dl, re = t.lcs[e0 + off * t.W1 + 3] - dl;
+    const uint32_t rj = t.lcs[e0v + off * t.W1] - dl, re = t.lcs[e0v + off * t.W1 + 3] - dl;
     over |= (re > rj + (uint32_t)B27_CAND) ? (1u << r) : 0u;
+    constexpr int INFL = TRACK2 ? 2 : 3;        // loads in flight at a time: the block shares the kernel's 64 registers (TRACK2 keeps one more value)
 #pragma unroll
-    for (int h = 0; h < B27_CAND; h += 3) {     // three loads in flight at a time: the block shares the kernel's 64 registers
-      float4 p[3];
+    for (int h = 0; h < B27_CAND; h += INFL) {
+      float4 p[INFL];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) p[c] = t.lpts[rj + h + c];
+      for (int c = 0; c < INFL; ++c) p[c] = t.lpts[rj + h + c];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) eval_candidate_sel(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel);
+      for (int c = 0; c < INFL; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel, m12);
+    }
+    if (TRACK2 && r < 8) {   // ties the next run's addresses to this run's result: keeps the scheduler from issuing all 54 reads first (see octant_search)
+      uint32_t hi = (uint32_t)(bk >> 32);
+      asm volatile("" : "+v"(e0v), "+v"(hi), "+v"(m12[1]));
+      bk = ((unsigned long long)hi << 32) | (uint32_t)bk;
     }
   }
   uint32_t bl = NONE_U32;
@@ -969,7 +1092,7 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
     const int dz = (r * 11) >> 5, dy = r - 3 * dz;            // r/3, r%3 for r in 0..8
     const int off = (dz - 1) * t.RY + (dy - 1);
     brow = row0 + off;
-    bl = t.lcs[e0 + off * t.W1] - t.rowdelta[brow] + (sel & 7u);
+    bl = t.lcs[e0v + off * t.W1] - t.rowdelta[brow] + (sel & 7u);
   }
   // the rest of the long runs: each lane walks its own list of them (most lanes: none or one), so the wave pays
   // the longest list, not one pass per run of the block
@@ -979,14 +1102,14 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
     const int dz = (r * 11) >> 5, dy = r - 3 * dz;
     const int off = (dz - 1) * t.RY + (dy - 1);
     const uint32_t dl = t.rowdelta[row0 + off];
-    const uint32_t re = t.lcs[e0 + off * t.W1 + 3] - dl;
+    const uint32_t re = t.lcs[e0v + off * t.W1 + 3] - dl;
     const uint32_t before = bl;
-    for (uint32_t j = t.lcs[e0 + off * t.W1] - dl + (uint32_t)B27_CAND; j < re; j += 4) {
+    for (uint32_t j = t.lcs[e0v + off * t.W1] - dl + (uint32_t)B27_CAND; j < re; j += 4) {
       const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
-      eval_candidate(p0, qxy, qz, j, bk, bl);
-      eval_candidate(p1, qxy, qz, j + 1, bk, bl);
-      eval_candidate(p2, qxy, qz, j + 2, bk, bl);
-      eval_candidate(p3, qxy, qz, j + 3, bk, bl);
+      eval_candidate<TRACK2>(p0, qxy, qz, j, bk, bl, m12);
+      eval_candidate<TRACK2>(p1, qxy, qz, j + 1, bk, bl, m12);
+      eval_candidate<TRACK2>(p2, qxy, qz, j + 2, bk, bl, m12);
+      eval_candidate<TRACK2>(p3, qxy, qz, j + 3, bk, bl, m12);
     }
     if (bl != before) brow = row0 + off;
   }
@@ -1006,8 +1129,10 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
   if (cy + 2 < g.ny) b = fminf(b, g.cell - uy);
   if (cz - 1 > 0) b = fminf(b, uz);
   if (cz + 2 < g.nz) b = fminf(b, g.cell - uz);
-  if (b == INFINITY) return true;
+  if (TRACK2) *second_out = m12[1];
+  if (b == INFINITY) { if (TRACK2) *bound_out = INFINITY; return true; }
   b = fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin;
+  if (TRACK2) *bound_out = b;
   return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
 }
 
@@ -1015,14 +1140,15 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
 __device__ unsigned long long g_phase_clk[8];
 #define PHASE_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_clk[k], now_ - tprev_); tprev_ = now_; } } while (0)
 void debug_dump_pipe_clocks();
-__device__ unsigned long long g_warm_clk[8];
-#define WARM_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_warm_clk[k], now_ - tprev_); atomicAdd(&g_warm_clk[4 + (k)], 1ull); tprev_ = now_; } } while (0)
+__device__ unsigned long long g_warm_clk[16];
+#define WARM_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_warm_clk[k], now_ - tprev_); atomicAdd(&g_warm_clk[8 + (k)], 1ull); tprev_ = now_; } } while (0)
 static void debug_dump_warm_clocks() {
-  unsigned long long h[8];
+  unsigned long long h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_warm_clk), sizeof h) != hipSuccess) return;
-  if (h[4] == 0) return;
-  fprintf(stderr, "[warm clocks, 100 MHz ticks per block (thread 0), %llu blocks] prologue=%.1f stream=%.1f list=%.1f end=%.1f\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4],
-          (double)h[2] / h[4], (double)h[3] / h[4]);
+  if (h[8] == 0) return;
+  fprintf(stderr, "[warm clocks, 100 MHz ticks per block (thread 0: wave 0), %llu blocks] prologue=%.1f stream=%.1f levelA=%.1f (%.2f rounds) levelB=%.1f (%.2f) -=%.1f (%.2f) end=%.1f\n",
+          h[8], (double)h[0] / h[8], (double)h[1] / h[8], (double)h[2] / h[8], (double)h[10] / h[8], (double)h[3] / h[8], (double)h[11] / h[8], (double)h[4] / h[8],
+          (double)h[12] / h[8], (double)h[5] / h[8]);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warm_clk), h, sizeof h);
 }
@@ -1140,9 +1266,15 @@ __device__ __forceinline__ void defer_whole_tile(const IterArgs& a, uint32_t vb)
 // second smallest d3, no other candidate can win (their d6 >= their d3), and the usual geometric proof -- now with d6 --
 // settles the query.  Otherwise (normals that disagree by more than the spacing of the candidates) the query goes to the
 // clean-up pass, which searches by d6 outright.  Normals are not staged: the LDS budget holds the points.
-template <int ACC, bool FEAT6 = false>
+// LB: the tile also leaves what the warm-started iterations start from -- per settled query the margin key of
+// its search (second smallest distance in the block it searched, capped by the gap to the block's faces): the search-only form
+// into a.nn_lb next to a.nn_pos; the accumulating form straight into the MATCH RECORDS {matched point, key} {normal} the
+// record-reading warm kernel streams (a.warm_rec / a.warm_rec_n), so that the iteration after a tile iteration can already run
+// warm-started without a record-writing pass in between.
+template <int ACC, bool FEAT6 = false, bool LB = false>
 __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_search_tiled(IterArgs a, const uint2* __restrict__ tiles,
                                                                   const int* __restrict__ tile_box, uint32_t ntiles) {
+  static_assert(!(LB && FEAT6), "margin keys are a property of the 3-D point search");
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
   // XCD-aware tile order: block b runs on XCD b%8 -> each XCD gets one contiguous eighth of the tiles
@@ -1155,11 +1287,12 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   __shared__ uint32_t rowbase[TILE_MAXROWS + 1];
   __shared__ uint32_t rowdelta[TILE_MAXROWS];
   __shared__ uint32_t queue_count;            // queries queued for the 3x3x3 pass (phase 3)
-  __shared__ float tform_lds[16];             // the transform, for phase 3b
+  __shared__ float tform_lds[18];             // the transform (and the motion clock), for phase 3b
   __shared__ int geom_lds[8];                 // the region's geometry, for phase 3b (so that nothing it derives is kept live from here)
   float4* lpts = reinterpret_cast<float4*>(raw);
   if (threadIdx.x == 0) queue_count = 0;      // (several barriers before its first use)
   if (threadIdx.x < 16) tform_lds[threadIdx.x] = st->T[threadIdx.x];
+  if (LB && threadIdx.x == 16) { tform_lds[16] = st->motion_acc; tform_lds[17] = st->motion_eps; }
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   unsigned long long tprev_ = wall_clock64();
 #endif
@@ -1170,6 +1303,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
   const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};     // (scalar loads here: read in the tail they are vector loads with a round trip each)
+  const MotionRef mref = {LB ? st->motion_acc : 0.0f, LB ? st->motion_eps : 0.0f};
 
   // the lane's queries: issue the loads first, they fly while the region's cell table is fetched
   float4 s4[TILE_QPT];
@@ -1355,6 +1489,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   //  the search: P = rowbase[rows], block-uniform)
   uint32_t mpos[TILE_QPT];   // per query: sorted-target position of the match (NONE: none / not settled here)
   uint32_t mbl = 0;          // (accumulating form, feature search) the matches' LDS indices, 16 bits each: the matched points are read from the staged tile
+  uint32_t mkeys = 0;        // (accumulating form, LB) the settled queries' margin keys, 16 bits each
   uint32_t f6_pos[TILE_QPT];  // (feature search) the 3-D winners and the second smallest 3-D distances, until the lane's searches are done
   float f6_second[TILE_QPT];
 #pragma unroll
@@ -1366,6 +1501,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     best.pos = NONE_U32;
     uint32_t bl = NONE_U32;
     bool defer = false, unproven = false, pending = false;
+    float mkey = 0.0f;      // (LB, search-only form) the margin key of what this search settles
+    uint32_t mq = 0;        // (LB, accumulating form) ... packed (margin_q15)
     if (active) {
       if (fast && FEAT6) {
         // searched by the 3-D distance now; settled after BOTH of the lane's searches, with the winners' normals gathered
@@ -1375,7 +1512,10 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         mbl |= (bl & 0xFFFFu) << (16 * u);
         pending = true;
       } else if (fast) {
-        unproven = !octant_search(g, tl, oq[u], a.max_sq, best, bl);
+        float second = INFINITY, gapb = 0.0f;
+        unproven = !octant_search<LB>(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb);
+        if (LB && ACC == IM_NONE) mkey = margin_key(best.pos != NONE_U32, second, gapb, mref);
+        if (LB && ACC != IM_NONE) mq = margin_q15(best.pos != NONE_U32, second, gapb, mref, g.inv_cell);
       } else {
         // outside the tile's box or in the grid's outer layer (or beyond): nothing to find if the query is farther
         // from the grid than the radius, else the clean-up pass (generic search) takes it
@@ -1383,6 +1523,9 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         const float gy = axis_gap(oq[u].qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
         const float gz = axis_gap(oq[u].qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
         defer = (gx * gx + gy * gy + gz * gz) * KSHRINK < a.max_sq;
+        const float ggap = __fsqrt_rn((gx * gx + gy * gy + gz * gz) * KSHRINK) * 0.999999f;      // every target point lies inside the grid
+        if (LB && ACC == IM_NONE) mkey = margin_key(false, INFINITY, ggap, mref);
+        if (LB && ACC != IM_NONE) mq = margin_q15(false, INFINITY, ggap, mref, g.inv_cell);
       }
     }
     if (ACC != IM_NONE || FEAT6) {   // (accumulating form / feature search: no second pass in the tile, see 3b; the unproven ones are only counted)
@@ -1410,6 +1553,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       a.nn_pos[i] = best.pos;
       if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     }
+    if (LB && ACC == IM_NONE && active && !unproven && !defer) a.nn_lb[i] = mkey;
+    if (LB && ACC != IM_NONE) mkeys |= ((active && !defer) ? mq : 0u) << (16 * u);      // (the record is written in the tail)
     mpos[u] = (unproven | defer) ? NONE_U32 : best.pos;
     if (ACC != IM_NONE) mbl |= (bl & 0xFFFFu) << (16 * u);      // (bl < TILE_CAP + 8 < 2^16; NONE's low bits are never used: mpos says so)
     flags |= (unproven ? (1u << (16 + u)) : 0u) | (defer ? (1u << (24 + u)) : 0u) | (pending ? (1u << (20 + u)) : 0u);
@@ -1523,9 +1668,11 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         NN best;
         // (the region holds the octant blocks of the tile's queries, not necessarily all of this query's 3x3x3 block)
         const bool in27 = (cx - 1 >= tq.lox) & (cx + 1 <= hx27) & (cy - 1 >= tq.loy) & (cy + 1 <= hy27) & (cz - 1 >= tq.loz) & (cz + 1 <= hz27);
-        const bool proven = in27 && block27_search(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best);
+        float second = INFINITY, gapb = 0.0f;
+        const bool proven = in27 && block27_search<LB>(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best, &second, &gapb);
         a.nn_pos[i] = proven ? best.pos : DEFER_MARK;
         if (proven && a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+        if (LB && proven) a.nn_lb[i] = margin_key(best.pos != NONE_U32, second, gapb, MotionRef{tform_lds[16], tform_lds[17]});
       }
     }
     __syncthreads();
@@ -1571,6 +1718,16 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     }
 #pragma unroll
     for (int u = 0; u < TILE_QPT; ++u) fused_z<ACC>(mpos[u] != NONE_U32, qt[u][0], qt[u][1], qt[u][2], p4t[u], n4t[u], a.dst_mean, smt, z[u]);
+    if (LB) {
+      // the match records of the queries this tile settled (the deferred ones: the clean-up pass)
+#pragma unroll
+      for (int u = 0; u < TILE_QPT; ++u)
+        if (((flags >> u) & 1u) && !((flags >> (24 + u)) & 1u)) {
+          const uint32_t i = tile.x + u * TILE_THREADS + threadIdx.x;
+          a.warm_rec[i] = make_float4(p4t[u].x, p4t[u].y, p4t[u].z, margin_from_q15((mkeys >> (16 * u)) & 0xFFFFu, g.cell, mref));
+          if (FusedZ<ACC>::needs_normal && mpos[u] != NONE_U32) a.warm_rec_n[i] = F3{n4t[u].x, n4t[u].y, n4t[u].z};
+        }
+    }
     PHASE_CLK(4);
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
@@ -1671,14 +1828,22 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
 
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   const uint32_t W = ntiles * (2 * TILE_WAVES), nchunks = (W + 63u) >> 6;
+  // (margin keys / match records of the warm-started iterations: the generic search proves its result but keeps no bound on
+  //  the other points -- "no bound known"; the warm kernel searches such a query itself and then has one)
+  const float key_unknown_has = 0.0f, key_unknown_none = MARGIN_NONE_NO_MATCH;
   auto finish = [&](uint32_t i, float qx, float qy, float qz, const NN& best) {
     a.nn_pos[i] = best.pos;
     if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    if (ACC == IM_NONE && a.nn_lb) a.nn_lb[i] = best.pos != NONE_U32 ? key_unknown_has : key_unknown_none;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nv = p;
     if (ACC != IM_NONE && best.pos != NONE_U32) {
-      const float4 p = a.grid.pts[best.pos];
-      float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+      p = a.grid.pts[best.pos];
       if (TR::plane) nv = a.grid.nrm[best.pos];
       accumulate_pair<ACC>(accA, accB, T, iL, it, smt, dmean, false, true, qx, qy, qz, best.pos, p, nv, nv);
+    }
+    if (ACC != IM_NONE && a.warm_rec) {
+      a.warm_rec[i] = make_float4(p.x, p.y, p.z, best.pos != NONE_U32 ? key_unknown_has : key_unknown_none);
+      if (TR::plane) a.warm_rec_n[i] = F3{nv.x, nv.y, nv.z};
     }
   };
   // One chunk = 64 mask words, STRIDED through the mask array (slot j of chunk c = word j * nchunks + c): the 32 words of a
@@ -1830,6 +1995,10 @@ static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const i
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
   if (ACC != IM_NONE && a.tile_pipeline == 2) hipLaunchKernelGGL((k_tile_pipe<ACC, true>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   else if (ACC != IM_NONE && a.tile_pipeline) hipLaunchKernelGGL((k_tile_pipe<ACC, false>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
+  // (margin keys / match records for the warm-started iterations: the LB variants -- the search-only form when a.nn_lb is set, the
+  //  accumulating form when a.warm_rec is; the pipelined experiment kernels have no such variant)
+  else if (ACC == IM_NONE ? a.nn_lb != nullptr : a.warm_rec != nullptr)
+    hipLaunchKernelGGL((k_search_tiled<ACC, false, true>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   else hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   hipLaunchKernelGGL((k_search_deferred<ACC>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
 }
@@ -2113,6 +2282,40 @@ void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s) {
 // 16x16 f64 tile kept in registers across the whole chunk, fixed order => bitwise reproducible run to run).
 constexpr int WARM_THREADS = 256;
 constexpr int WARM_WAVES = WARM_THREADS / 64;
+
+// NR runs of the sorted target array, EVERY point evaluated (nothing culled: the caller wants a bound on all the points it did
+// not choose), eight independent loads in flight per trip over the flattened index space of the runs; keeps the best key and the
+// two smallest squared distances a1 <= b2 over the DISTINCT points met (the clamped re-reads past the end are not counted), and the
+// best point's record (bp) so that the caller need not fetch it again.
+template <int NR>
+__device__ __forceinline__ void scan_runs_track2(const float4* __restrict__ pts, const uint32_t (&rb)[NR], const uint32_t (&re)[NR], float qx, float qy, float qz,
+                                                 NN& best, float& a1, float& b2, float4& bp) {
+  uint32_t pre[NR];      // inclusive prefix sums of the run lengths
+  uint32_t total = 0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { total += re[r] - rb[r]; pre[r] = total; }
+  for (uint32_t t = 0; t < total; t += 8) {
+    uint32_t j[8];
+    float4 pc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t tt = min(t + (uint32_t)k, total - 1u);
+      uint32_t jj = rb[0] + tt;
+#pragma unroll
+      for (int r = 1; r < NR; ++r) jj = tt >= pre[r - 1] ? rb[r] + (tt - pre[r - 1]) : jj;
+      j[k] = jj;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pc[k] = pts[j[k]];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float e = d2_pinned(qx, qy, qz, pc[k].x, pc[k].y, pc[k].z);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(pc[k].w);
+      if (key < best.key) { best.key = key; best.pos = j[k]; bp = pc[k]; }
+      if (t + (uint32_t)k < total) { b2 = __builtin_amdgcn_fmed3f(a1, b2, e); a1 = fminf(a1, e); }
+    }
+  }
+}
 // REC: 0 = the old match, its normal and its table entry are gathered through warm_pos; 1 = the same, and every query's
 // match record {point, table entry} {normal} (16 + 12 B, two arrays in query order) and a 12-byte copy of its source point
 // are written; 2 = those are READ instead -- 40 B per query in three coalesced loads, no gather at all for the queries the
@@ -2133,12 +2336,16 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   // (loop state read HERE, into scalar registers: a load of it inside the streaming loop is a vector-memory load whose wait
   //  -- vmcnt counts in order -- also waits for the next round's prefetch, i.e. serialises memory latency and arithmetic)
   const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};
+  const MotionRef mref = {st->motion_acc, st->motion_eps};
+  const float Dk = __fadd_rn(mref.acc, mref.eps) * 1.000001f;      // the motion clock now (rounded up): what a key is compared against
   const GridDev& g = a.grid;
   __shared__ __attribute__((aligned(16))) unsigned char raw[WARM_WAVES * FUSED_WAVE_BYTES];
   __shared__ float4 dq[WARM_WAVES][WARM_QCAP];             // listed queries: {q = T s, index}
+  __shared__ float dr[WARM_WAVES][WARM_QCAP];              // ... and their bounds (squared)
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   float* const zb = reinterpret_cast<float*>(raw) + wave * (FUSED_WAVE_BYTES / 4);
   float4* const wq = dq[wave];
+  float* const wr = dr[wave];
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   unsigned long long tprev_ = wall_clock64();
 #endif
@@ -2154,7 +2361,6 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   const uint64_t beg64 = (uint64_t)vb * chunk;
   const uint32_t beg = beg64 < a.ns ? (uint32_t)beg64 : a.ns;
   const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
-  const float half = 0.5f * g.cell;
   const int sy = g.nx, sz = g.nx * g.ny;
   uint32_t nfar = 0;
 
@@ -2206,157 +2412,207 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     lds_to_mfma();
   };
 
-  // The search of the queries the table did not settle, one list round (64 entries) at a time.  An entry carries the query
-  // (index and transformed point), so everything that depends on them alone is requested TOGETHER: the stored position and
-  // the match record, and the run boundaries of the four rows of the octant block (three cell-table entries per row cover
-  // both "own cell" and "own cell + the neighbour q leans to").  Then one trip for up to eight candidates, one more for the
-  // new match's data if the match changed: three to four memory round trips instead of eight -- the tail every wave runs
-  // through at the end of its chunk is latency, not bandwidth.  From the old match (a real target point: its distance
-  // bounds the search) inside the octant block when the bound allows, else the generic shell search.  Stores what changed.
-  auto slow_round = [&](bool v, uint32_t i, float qx, float qy, float qz, float4& pm, float4& nm) -> bool {
+  // The search of the queries their margin did not settle.  A listed query comes with a BOUND: the squared distance R2 from its
+  // new position to its old match (a real target point: the nearest one is no farther), or the radius without one.  Every target
+  // point inside the ball of radius sqrt(R2) + extra around the query is evaluated (extra = a quarter of a cell) -- the cells the
+  // ball does not reach are skipped -- keeping the best key, the best point and the two smallest squared distances: the best is
+  // the exact match (it lies inside the ball), and every other target point is at least min(second smallest, sqrt(R2) + extra)
+  // away: the query leaves with a fresh margin key of up to a quarter of a cell.  Two LEVELS, each run over the wave's list 64
+  // entries at a time, what level A cannot take packed to the front of the list for level B:
+  //   A: the ball lies inside the 3x3x3 block around the query's cell: nine rows, each clipped to the cells the ball reaches -- the
+  //      18 run boundaries leave together, then one trip per eight candidates, one for the match's normal;
+  //   B: the 5x5x5 block slab by slab, rows beyond sqrt(best so far) + extra skipped, then (rarely) the shell search with the
+  //      same margin.
+  // Stores the match, its record and the key.
+  const float extra = 0.25f * g.cell;
+  auto slow_finish = [&](bool v, uint32_t i, const NN& best, const float4 bp, float key, float4& pm, float4& nm) -> bool {
+    const bool has = v && best.pos != NONE_U32;
+    nm = Z4;
+    if (NRM) nm = g.nrm[has ? best.pos : 0u];      // (unconditional: one trip for the whole wave)
+    pm = has ? make_float4(bp.x, bp.y, bp.z, 0.f) : Z4;
+    if (!has) nm = Z4;
+    if (v) {
+      a.nn_pos[i] = best.pos;
+      a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, key);
+      if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z};
+    }
+    return has;
+  };
+  struct SlowGeom { int cx, cy, cz; float ux, uy, uz; bool inner; uint32_t cid; };
+  auto slow_geom = [&](bool v, float qx, float qy, float qz) -> SlowGeom {
+    SlowGeom s;
     const float BIG = 1.0e9f;
     const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG), fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG),
                 fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
-    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-    const bool inner = v & (cx >= 1) & (cx <= g.nx - 2) & (cy >= 1) & (cy <= g.ny - 2) & (cz >= 1) & (cz <= g.nz - 2);
-    // offsets inside the cell; per axis: which neighbour q leans to, the gap to the face shared with it, the gap to the far
-    // face of the own cell (beyond which the octant block ends)
-    const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
-    const bool lx = ux < half, ly = uy < half, lz = uz < half;
-    const float nx_ = fmaxf((lx ? ux : g.cell - ux) - g.margin, 0.0f), ny_ = fmaxf((ly ? uy : g.cell - uy) - g.margin, 0.0f),
-                nz_ = fmaxf((lz ? uz : g.cell - uz) - g.margin, 0.0f);
-    const float ob = fminf(fminf(lx ? g.cell - ux : ux, ly ? g.cell - uy : uy), lz ? g.cell - uz : uz) - g.margin;   // nearest face of the octant block
-    const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
-    const int dy = ly ? -sy : sy, dz = lz ? -sz : sz;
-    // trip 1: all that depends on (i, q) alone -- straight-line, from addresses that are valid for every lane (a lane without
-    // an entry reads entry 0's data, a query outside the inner cells the rows of cell (1,1,1); both are masked afterwards),
-    // so that the loads leave together instead of one exec-masked group after the other
-    const uint32_t ii = v ? i : 0u;
-    uint32_t w = a.warm_pos[ii];
-    float4 r0 = Z4, s4 = Z4;
-    F3 r1 = {0.f, 0.f, 0.f};
-    if (REC == 2) { r0 = a.warm_rec[ii]; if (NRM) r1 = a.warm_rec_n[ii]; }
-    if (REC == 1) s4 = a.src[ii];
-    uint32_t cs[12];
-    {
-      const int xo = lx ? -1 : 0;
-      const int r00 = inner ? (int)cid : sz + sy + 1;
-      const int rows[4] = {r00, r00 + dy, r00 + dz, r00 + dy + dz};
+    s.cx = (int)floorf(fx); s.cy = (int)floorf(fy); s.cz = (int)floorf(fz);
+    s.inner = v & (s.cx >= 1) & (s.cx <= g.nx - 2) & (s.cy >= 1) & (s.cy <= g.ny - 2) & (s.cz >= 1) & (s.cz <= g.nz - 2);
+    s.ux = qx - (g.ox + (float)s.cx * g.cell); s.uy = qy - (g.oy + (float)s.cy * g.cell); s.uz = qz - (g.oz + (float)s.cz * g.cell);
+    s.cid = ((uint32_t)s.cz * (uint32_t)g.ny + (uint32_t)s.cy) * (uint32_t)g.nx + (uint32_t)s.cx;
+    return s;
+  };
+  // level A: returns whether it took the query (the ball fits the 3x3x3 block)
+  auto slow_levelA = [&](bool v, float qx, float qy, float qz, float R2, NN& best, float4& bp, float& key) -> bool {
+    const SlowGeom s = slow_geom(v, qx, qy, qz);
+    const float Rr = __fsqrt_rn(R2) * 1.000001f + extra;       // the ball's radius, rounded up
+    const float R2c = Rr * Rr * 1.000001f;
+    float b = INFINITY;      // faces of the 3x3x3 block that still have cells beyond them
+    if (s.cx - 1 > 0) b = fminf(b, s.ux);
+    if (s.cx + 2 < g.nx) b = fminf(b, g.cell - s.ux);
+    if (s.cy - 1 > 0) b = fminf(b, s.uy);
+    if (s.cy + 2 < g.ny) b = fminf(b, g.cell - s.uy);
+    if (s.cz - 1 > 0) b = fminf(b, s.uz);
+    if (s.cz + 2 < g.nz) b = fminf(b, g.cell - s.uz);
+    const bool fits = s.inner && (b == INFINITY || Rr < (fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin) * 0.999999f);
+    // (addresses valid for every lane: a lane that is not taken reads the rows of cell (1,1,1) and is masked afterwards, so that
+    //  the loads leave together instead of one exec-masked group after the other)
+    const int c0 = fits ? (int)s.cid : sz + sy + 1;
+    const float gm[3] = {fmaxf(s.uz - g.margin, 0.0f), 0.0f, fmaxf(g.cell - s.uz - g.margin, 0.0f)};
+    const float gn[3] = {fmaxf(s.uy - g.margin, 0.0f), 0.0f, fmaxf(g.cell - s.uy - g.margin, 0.0f)};
+    const float gxl = fmaxf(s.ux - g.margin, 0.0f), gxr = fmaxf(g.cell - s.ux - g.margin, 0.0f);
+    uint32_t rb9[9], re9[9];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cs[3 * r] = g.cell_start[rows[r] + xo]; cs[3 * r + 1] = g.cell_start[rows[r] + xo + 1]; cs[3 * r + 2] = g.cell_start[rows[r] + xo + 2];
-      }
+    for (int r = 0; r < 9; ++r) {
+      const float gyz2 = gm[r / 3] * gm[r / 3] + gn[r % 3] * gn[r % 3];
+      const bool take = fits && gyz2 * KSHRINK <= R2c;
+      const bool left = take && (gyz2 + gxl * gxl) * KSHRINK <= R2c, right = take && (gyz2 + gxr * gxr) * KSHRINK <= R2c;
+      const int row = c0 + (r / 3 - 1) * sz + (r % 3 - 1) * sy;
+      const uint32_t va = g.cell_start[row - (left ? 1 : 0)], vb2 = g.cell_start[row + 1 + (right ? 1 : 0)];
+      rb9[r] = take ? va : 0u; re9[r] = take ? vb2 : 0u;
     }
-    if (!v) w = NONE_U32;
-    // the old match: from its record, else (trip 1b) through the stored position
-    float4 pw = Z4, nw = Z4;
-    float s2 = -1.0f;
-    if (REC == 2) { pw = make_float4(r0.x, r0.y, r0.z, __uint_as_float(0xFFFFFFFFu)); nw = make_float4(r1.x, r1.y, r1.z, 0.f); s2 = r0.w; if (s2 < 0.0f) w = NONE_U32; }
-    else if (w != NONE_U32) { pw = g.pts[w]; s2 = a.safe2[w]; if (NRM) nw = g.nrm[w]; }
-    NN best;
     best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
     best.pos = NONE_U32;
-    float e_old = INFINITY;
-    if (w != NONE_U32) {
-      e_old = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
-      // (REC 2: the record does not hold the old match's original index; the placeholder loses every tie, and the old
-      //  match itself -- inside the ball it defines, hence inside the cells searched below -- is met again with its own)
-      if (e_old < a.max_sq) { best.key = ((unsigned long long)__float_as_uint(e_old) << 32) | __float_as_uint(pw.w); best.pos = w; }
+    if (fits) {
+      float a1 = INFINITY, b2 = INFINITY;
+      scan_runs_track2<9>(g.pts, rb9, re9, qx, qy, qz, best, a1, b2, bp);
+      // every point that was not evaluated lies beyond the ball
+      key = margin_key(best.pos != NONE_U32, best.pos != NONE_U32 ? b2 : a1, (__fsqrt_rn(R2) + extra) * 0.999999f, mref);
     }
-    const bool bounded = best.pos != NONE_U32 && inner && ob > 0.0f && e_old < ob * ob * KSHRINK;
-    if (bounded) {
-      const float bd = e_old;
-      const bool kx = nx_ * nx_ * KSHRINK <= bd, ky = ny_ * ny_ * KSHRINK <= bd, kz = nz_ * nz_ * KSHRINK <= bd;   // the ball reaches that neighbour
-      // up to four runs (rows y / y', z / z'), each one or two x-adjacent cells
-      uint32_t rb[4], re[4];
+    return fits;
+  };
+  // level B: settles every query it is given
+  auto slow_levelB = [&](bool v, float qx, float qy, float qz, float R2, NN& best, float4& bp, float& key) {
+    const SlowGeom s = slow_geom(v, qx, qy, qz);
+    // (the bound enters as a key with a placeholder index that loses every tie: the old match itself lies inside what is scanned
+    //  and is met again with its own)
+    best.key = ((unsigned long long)__float_as_uint(fminf(R2, a.max_sq)) << 32) | 0xFFFFFFFFull;
+    best.pos = NONE_U32;
+    float a1 = INFINITY, b2 = INFINITY;
+    bool proven = false;
+    if (s.inner) {
+      // the 5x5x5 block, one z-slab at a time from the middle outwards: five rows (runs of five x-adjacent cells, clipped to the
+      // grid), a row skipped when its gap exceeds sqrt(best so far) + extra
+      const int xa = max(s.cx - 2, 0), xb = min(s.cx + 2, g.nx - 1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool on = r == 0 || (r == 1 && ky) || (r == 2 && kz) || (r == 3 && ky && kz);
-        const uint32_t A = cs[3 * r], B = cs[3 * r + 1], C = cs[3 * r + 2];
-        rb[r] = on ? ((lx && !kx) ? B : A) : 0u;
-        re[r] = on ? ((!lx && !kx) ? B : C) : 0u;
-      }
-      const uint32_t c0 = re[0] - rb[0], c1 = c0 + (re[1] - rb[1]), c2 = c1 + (re[2] - rb[2]), total = c2 + (re[3] - rb[3]);
-      for (uint32_t t = 0; t < total; t += 8) {
-        uint32_t j[8];
-        float4 pc[8];
+      for (int k = 0; k < 5; ++k) {
+        const int dzz = (k == 0) ? 0 : (k & 1) ? (k + 1) / 2 : -(k / 2);      // 0, +1, -1, +2, -2
+        const int z = s.cz + dzz;
+        const bool zin = z >= 0 && z < g.nz;
+        const float zl = g.oz + (float)z * g.cell;
+        const float gz = axis_gap(qz, zl, zl + g.cell, g.margin);
+        const float lim = (__fsqrt_rn(__uint_as_float((uint32_t)(best.key >> 32))) + extra) * 1.000001f;
+        const float lim2 = lim * lim * 1.000001f;
+        uint32_t rb5[5], re5[5];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t tt = min(t + (uint32_t)k, total - 1u);      // (re-evaluating a candidate never changes the result)
-          j[k] = tt < c0 ? rb[0] + tt : tt < c1 ? rb[1] + (tt - c0) : tt < c2 ? rb[2] + (tt - c1) : rb[3] + (tt - c2);
+        for (int r = 0; r < 5; ++r) {
+          const int y = s.cy + r - 2;
+          const bool on = zin && y >= 0 && y < g.ny;
+          const float yl = g.oy + (float)y * g.cell;
+          const float gy = axis_gap(qy, yl, yl + g.cell, g.margin);
+          const bool take = on && (gz * gz + gy * gy) * KSHRINK <= lim2;
+          const uint32_t row = take ? ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx : 0u;
+          const uint32_t va = g.cell_start[row + (uint32_t)xa], vb2 = g.cell_start[row + (uint32_t)xb + 1u];
+          rb5[r] = take ? va : 0u; re5[r] = take ? vb2 : 0u;
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pc[k] = g.pts[j[k]];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float e = d2_pinned(qx, qy, qz, pc[k].x, pc[k].y, pc[k].z);
-          const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(pc[k].w);
-          if (key < best.key) { best.key = key; best.pos = j[k]; }
-        }
+        scan_runs_track2<5>(g.pts, rb5, re5, qx, qy, qz, best, a1, b2, bp);
       }
-    } else if (v) {
-      // no usable bound: the generic exact search (shells around the query's cell, pruned by whatever `best` holds)
+      float b = INFINITY;      // faces of the 5x5x5 block that still have cells beyond them
+      if (s.cx - 2 > 0) b = fminf(b, s.ux);
+      if (s.cx + 3 < g.nx) b = fminf(b, g.cell - s.ux);
+      if (s.cy - 2 > 0) b = fminf(b, s.uy);
+      if (s.cy + 3 < g.ny) b = fminf(b, g.cell - s.uy);
+      if (s.cz - 2 > 0) b = fminf(b, s.uz);
+      if (s.cz + 3 < g.nz) b = fminf(b, g.cell - s.uz);
+      if (b != INFINITY) b = fmaxf(b, 0.0f) + 2.0f * g.cell - 2.0f * g.margin;
+      const float lim = (__fsqrt_rn(__uint_as_float((uint32_t)(best.key >> 32))) + extra) * 1.000001f;
+      proven = b > 0.0f && lim * lim * 1.000001f < b * b * KSHRINK;      // everything outside the block lies beyond sqrt(best) + extra as well
+    }
+    bool skip = false;
+    if (v && !proven) {
+      // the shell search with the same margin (from the 5x5x5 block's result for an inner cell).  Counted: the host goes back to
+      // the tiled kernels when these are many.
       ++nfar;
-      if (REC == 2 && best.pos != NONE_U32) best.key = ((unsigned long long)__float_as_uint(e_old) << 32) | __float_as_uint(g.pts[w].w);
-      const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
-      bool skip = false;
-      int s0 = 0;
+      const bool inside = (s.cx >= 0) & (s.cx < g.nx) & (s.cy >= 0) & (s.cy < g.ny) & (s.cz >= 0) & (s.cz < g.nz);
+      int s0 = s.inner ? 3 : 0;
       if (!inside) {
         const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin), gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin),
                     gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
         skip = (gx * gx + gy * gy + gz * gz) * KSHRINK >= a.max_sq;      // farther than the radius from the whole grid
-        s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+        s0 = max(0, max(max(-s.cx, s.cx - (g.nx - 1)), max(max(-s.cy, s.cy - (g.ny - 1)), max(-s.cz, s.cz - (g.nz - 1)))));
+        if (skip) { best.pos = NONE_U32; key = margin_key(false, INFINITY, __fsqrt_rn((gx * gx + gy * gy + gz * gz) * KSHRINK) * 0.999999f, mref); }   // every target point lies inside the grid
       }
-      if (!skip) nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
+      if (!skip) nn_search_shells_margin(g, qx, qy, qz, s.cx, s.cy, s.cz, s0, best, a1, b2, bp, extra);
     }
-    const bool same = best.pos == w, has = best.pos != NONE_U32;
-    pm = nm = Z4;
-    if (has) {
-      if (same) { pm = pw; nm = nw; }
-      else { pm = g.pts[best.pos]; s2 = a.safe2[best.pos]; if (NRM) nm = g.nrm[best.pos]; }
+    if (!skip) {
+      // every point that was not evaluated lies beyond sqrt(best) + extra (the radius + extra without a match)
+      const float reach = (__fsqrt_rn(__uint_as_float((uint32_t)(best.key >> 32))) * 0.999999f + extra) * 0.999999f;
+      key = margin_key(best.pos != NONE_U32, best.pos != NONE_U32 ? b2 : a1, reach, mref);
     }
-    if (v) {
-      if (!same || a.nn_pos != a.warm_pos) a.nn_pos[i] = best.pos;      // (in place: unchanged matches are not rewritten)
-      if (REC == 1) a.warm_src3[i] = F3{s4.x, s4.y, s4.z};
-      if (REC == 1 || (REC == 2 && !same)) {
-        a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, has ? s2 : -1.0f);
-        if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z};
-      }
-    }
-    return has;
   };
 
   uint32_t qcount = 0;      // (wave-uniform)
-  // One round of the streaming loop for the query whose data has arrived: transform, the table's test, what a settled
+  // One round of the streaming loop for the query whose data has arrived: transform, the margin test, what a settled
   // query stores, the list entry of an unsettled one, the rank update.
-  auto round = [&](uint32_t i, bool valid, const F3 s3c, uint32_t w, float4 pm, float4 nm, float s2) {
+  // The margin test: the record's key says that when the match p was established every OTHER target point was at
+  // least |key| - (motion clock then) away from the query; the query has moved by at most (motion clock now) - (then) since, so
+  // every other point is still at least mrg = |key| - Dk away -- if p is strictly nearer than that it is THE nearest target
+  // point (ties excluded by the strictness), and nothing is looked at: not even the query's cell.  A negative key is the same
+  // bound for a query WITHOUT a match, over all target points: if mrg still exceeds the radius there is still none.
+  // lbv / s2 (REC 1): the key the search left in nn_lb (a.lb_valid) and the old match's nearest-other-point table entry -- any other
+  // target point p' has |q - p'| >= nnd(p) - |q - p|: a second lower bound, the larger key wins.
+  auto round = [&](uint32_t i, bool valid, const F3 s3c, uint32_t w, float4 pm, float4 nm, float keyv, float s2) {
     float qx, qy, qz;
     transform(make_float4(s3c.x, s3c.y, s3c.z, 0.f), qx, qy, qz);
-    // Nearer to the old match than half the distance from it to any other target point: it is THE nearest, nothing to look
-    // at -- not even the query's cell (the factor covers the 2^-22 relative rounding of the three f32 squared distances).
     const float e_old = d2_pinned(qx, qy, qz, pm.x, pm.y, pm.z);
-    const bool settled = valid && s2 >= 0.0f && e_old < a.max_sq && 4.0f * e_old < s2 * 0.99998f;
+    if (REC != 2) {
+      if (w != NONE_U32) {
+        const float alt = margin_key(true, INFINITY, __fsub_rn(__fsqrt_rn(fmaxf(s2, 0.0f)) * 0.999999f, __fsqrt_rn(e_old) * 1.000001f), mref);
+        keyv = fmaxf(a.lb_valid ? fmaxf(keyv, 0.0f) : 0.0f, alt);
+      } else {
+        keyv = a.lb_valid ? fminf(keyv, MARGIN_NONE_NO_MATCH) : MARGIN_NONE_NO_MATCH;
+      }
+    }
+    const float mrg = __fsub_rn(fabsf(keyv), Dk);
+    const float m2 = mrg * mrg * KSHRINK;
+    const bool ok = valid && mrg > 0.0f;
+    const bool shas = ok && keyv > 0.0f && e_old < m2 && e_old < a.max_sq;
+    const bool settled = shas || (ok && keyv < 0.0f && m2 >= a.max_sq);
     if (settled) {
       if (REC != 2 && a.nn_pos != a.warm_pos) a.nn_pos[i] = w;
-      if (REC == 1) { a.warm_src3[i] = s3c; a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, s2); if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z}; }
+      if (REC == 1) { a.warm_rec[i] = make_float4(pm.x, pm.y, pm.z, keyv); if (NRM) a.warm_rec_n[i] = F3{nm.x, nm.y, nm.z}; }
     }
     const bool todo = valid && !settled;
     const unsigned long long um = __ballot(todo);
-    if (todo) wq[qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = make_float4(qx, qy, qz, __uint_as_float(i));
+    if (todo) {
+      // the list entry and its bound: the squared distance to the old match if it has one inside the radius, else the radius
+      const uint32_t o = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u));
+      wq[o] = make_float4(qx, qy, qz, __uint_as_float(i));
+      wr[o] = ((REC == 2 ? !(keyv < 0.0f) : w != NONE_U32) && e_old < a.max_sq) ? e_old : a.max_sq;
+    }
     qcount += (uint32_t)__popcll(um);
-    z_to_lds(settled, qx, qy, qz, pm, nm);
+    z_to_lds(shas, qx, qy, qz, pm, nm);
   };
-  // What a round streams in.  REC 2: the 12-byte copy of the source point and the match record {point, table entry} {normal}
+  // What a round streams in.  REC 2: the 12-byte copy of the source point and the match record {point, margin key} {normal}
   // -- 40 B per query (28 without normals), all of it coalesced, TWO rounds in flight per wave (sets A and B; vmcnt retires in
-  // order, so the wait for A leaves B's loads flying).  REC 0 / 1: the sorted source record and the stored position one
-  // round, the gathers through that position (old match, its normal, its table entry) the next: a three-stage pipeline
-  // with one wait per round for loads that were issued a whole round earlier.
+  // order, so the wait for A leaves B's loads flying).  REC 1: the sorted source record, the stored position and the search's
+  // margin key one round, the gathers through that position (old match, its normal, its table entry) the next: a three-stage
+  // pipeline with one wait per round for loads that were issued a whole round earlier.
   uint32_t base = beg, qlisted = 0;
   F3 sA = F3{0.f, 0.f, 0.f}, nA = F3{0.f, 0.f, 0.f}, sB = F3{0.f, 0.f, 0.f}, nB = F3{0.f, 0.f, 0.f};
   float4 rA = Z4, rB = Z4;
   uint32_t iA = beg + threadIdx.x, iB = iA + WARM_THREADS;
   // (REC 0 / 1) stage 1 -> 2: source record + position of the round after next; stage 2 -> 3: what was gathered for the next round
   uint32_t w1 = NONE_U32, w2 = NONE_U32;
+  float l1 = 0.0f, l2 = 0.0f;
   F3 s1 = F3{0.f, 0.f, 0.f}, s2_ = F3{0.f, 0.f, 0.f};
   float4 gp = Z4, gn = Z4;
   float gs = -1.0f;
@@ -2371,7 +2627,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     if (NRM) nv = a.warm_rec_n[k];
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto load1 = [&](uint32_t k, F3& sv, uint32_t& wv) { const float4 t4 = a.src[k]; sv = F3{t4.x, t4.y, t4.z}; wv = a.warm_pos[k]; };
+  auto load1 = [&](uint32_t k, F3& sv, uint32_t& wv, float& lv) { const float4 t4 = a.src[k]; sv = F3{t4.x, t4.y, t4.z}; wv = a.warm_pos[k]; lv = a.nn_lb[k]; };
   // (every load of the streaming loop is UNCONDITIONAL, from an index clamped into the chunk / a position clamped into the
   //  target: a load under a divergent branch may or may not have been issued as far as the compiler's vmcnt bookkeeping
   //  is concerned, and the waits it then inserts drain the younger prefetches as well)
@@ -2390,9 +2646,9 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     load2(min(iA, last), sA, rA, nA);
     load2(min(iB, last), sB, rB, nB);
   } else {
-    load1(min(iA, last), s2_, w2);         // next round: record, then (dependent) its gathers
+    load1(min(iA, last), s2_, w2, l2);         // next round: record, then (dependent) its gathers
     gather(w2);
-    load1(min(iA + WARM_THREADS, last), s1, w1);      // the round after: record
+    load1(min(iA + WARM_THREADS, last), s1, w1, l1);      // the round after: record
   }
   // stream rounds until the chunk is done -- or the wave's list could not take two more rounds' queries (a source far from
   // alignment lists most of them): then the list is searched first
@@ -2400,13 +2656,13 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     for (; base < end && qcount <= (uint32_t)(WARM_QCAP - 128); base += 2 * WARM_THREADS) {
       // (a set's registers are consumed -- down to the terms in LDS -- BEFORE the set is requested again, so that the new
       //  loads can land in the same registers: no copy at the loop's end that would have to wait for them)
-      round(iA, iA < end, sA, NONE_U32, make_float4(rA.x, rA.y, rA.z, 0.f), make_float4(nA.x, nA.y, nA.z, 0.f), rA.w);
+      round(iA, iA < end, sA, NONE_U32, make_float4(rA.x, rA.y, rA.z, 0.f), make_float4(nA.x, nA.y, nA.z, 0.f), rA.w, 0.0f);
       __builtin_amdgcn_sched_barrier(0);
       iA += 2 * WARM_THREADS;
       load2(min(iA, last), sA, rA, nA);
       __builtin_amdgcn_sched_barrier(0);
       lds_to_mfma();
-      round(iB, iB < end, sB, NONE_U32, make_float4(rB.x, rB.y, rB.z, 0.f), make_float4(nB.x, nB.y, nB.z, 0.f), rB.w);
+      round(iB, iB < end, sB, NONE_U32, make_float4(rB.x, rB.y, rB.z, 0.f), make_float4(nB.x, nB.y, nB.z, 0.f), rB.w, 0.0f);
       __builtin_amdgcn_sched_barrier(0);
       iB += 2 * WARM_THREADS;
       load2(min(iB, last), sB, rB, nB);
@@ -2419,30 +2675,51 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
       const F3 sc = s2_;
       const uint32_t wc = w2;
       const float4 pc = gp, nc = gn;
-      const float gc = gs;
+      const float gc = gs, lc = l2;
       // next round: its record has arrived, its gathers leave now; the round after: its record leaves now
       iA += WARM_THREADS;
-      s2_ = s1; w2 = w1;
+      s2_ = s1; w2 = w1; l2 = l1;
       gather(w2);
-      load1(min(iA + WARM_THREADS, last), s1, w1);
-      round(i, i < end, sc, wc, pc, nc, gc);
+      load1(min(iA + WARM_THREADS, last), s1, w1, l1);
+      round(i, i < end, sc, wc, pc, nc, lc, gc);
       lds_to_mfma();
     }
   }
-  // the listed queries, 64 per round
+  // the listed queries: two levels, 64 entries per round, what level A cannot take packed to the front of the list for level B
   __builtin_amdgcn_wave_barrier();
   WARM_CLK(1);
-  for (uint32_t b0 = 0; b0 < qcount; b0 += 64u) {
-    const bool v = b0 + (uint32_t)lane < qcount;
-    const float4 ent = wq[min(b0 + (uint32_t)lane, (uint32_t)(WARM_QCAP - 1))];      // (lanes beyond the list: masked by v)
-    float4 pm = Z4, nm = Z4;
-    const bool has = slow_round(v, __float_as_uint(ent.w), ent.x, ent.y, ent.z, pm, nm);
-    rank_update(has, ent.x, ent.y, ent.z, pm, nm);
-  }
   qlisted += qcount;
+  for (int level = 0; level < 2 && qcount != 0u; ++level) {
+    uint32_t nopen = 0;
+    for (uint32_t b0 = 0; b0 < qcount; b0 += 64u) {
+      const bool v = b0 + (uint32_t)lane < qcount;
+      const uint32_t e = min(b0 + (uint32_t)lane, (uint32_t)(WARM_QCAP - 1));      // (lanes beyond the list: masked by v)
+      const float4 ent = wq[e];
+      const float R2 = wr[e];
+      NN best;
+      float4 bp = Z4;
+      float key = 0.0f;
+      bool taken = true;
+      if (level == 0) taken = slow_levelA(v, ent.x, ent.y, ent.z, R2, best, bp, key);
+      else slow_levelB(v, ent.x, ent.y, ent.z, R2, best, bp, key);
+      const bool open = v && !taken;
+      const unsigned long long om = __ballot(open);
+      // (this round's entries are in registers: the front of the list up to b0 + 64 is free)
+      if (open) {
+        const uint32_t o = nopen + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+        wq[o] = ent; wr[o] = R2;
+      }
+      nopen += (uint32_t)__popcll(om);
+      float4 pm = Z4, nm = Z4;
+      const bool has = slow_finish(v && taken, __float_as_uint(ent.w), best, bp, key, pm, nm);
+      rank_update(has, ent.x, ent.y, ent.z, pm, nm);
+      WARM_CLK(2 + level);
+    }
+    qcount = nopen;
+    __builtin_amdgcn_wave_barrier();
+  }
   qcount = 0;
   __builtin_amdgcn_wave_barrier();
-  WARM_CLK(2);
   if (base >= end) break;
   }
   if (a.unproven_cnt) {
@@ -2470,7 +2747,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     }
     a.partials[(size_t)vb * SUMS_MAX + threadIdx.x] = v1 - v2;
   }
-  WARM_CLK(3);
+  WARM_CLK(5);
 }
 
 #undef Z4
@@ -2478,8 +2755,7 @@ template <int ACC>
 static void launch_warm_m(const IterArgs& a, int rec, int nblocks, hipStream_t s) {
   const dim3 g(nblocks), b(WARM_THREADS);
   if (rec == 2) hipLaunchKernelGGL((k_warm<ACC, 2>), g, b, 0, s, a);
-  else if (rec == 1) hipLaunchKernelGGL((k_warm<ACC, 1>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((k_warm<ACC, 0>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_warm<ACC, 1>), g, b, 0, s, a);
 }
 int warm_num_blocks(uint32_t ns) {
   // ONE generation of blocks (4 resident per CU: registers, LDS): every wave searches its list once, at the end of its chunk --
@@ -2505,6 +2781,14 @@ void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_
     case IM_POINT: launch_warm_m<IM_POINT>(a, rec, nblocks, s); break;
     default: launch_warm_m<IM_BOTH>(a, rec, nblocks, s); break;
   }
+}
+
+// the 12-byte copy of the sorted source the record-reading warm kernel streams (once per sort of a source)
+__global__ void k_copy_src3(const float4* __restrict__ src, uint32_t ns, F3* __restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) { const float4 v = src[i]; out[i] = F3{v.x, v.y, v.z}; }
+}
+void launch_copy_src3(const float4* src_sorted, uint32_t ns, F3* out, hipStream_t s) {
+  if (ns) hipLaunchKernelGGL(k_copy_src3, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, src_sorted, ns, out);
 }
 
 // ---- accumulation over REVERSE matches (search directions FIRST_TO_SECOND / BOTH without post-filters) ----------------
@@ -2690,6 +2974,36 @@ int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hip
   return G;
 }
 
+// The warm-started iteration's margin test needs two numbers about the queries q = T s (s in the source's bounding box: centre c,
+// half extents h, source coordinates):
+//   * how far any query moves when T becomes T' :  |(T' - T)(s, 1)| = |A s + b| <= |A c + b| + sum_j |A e_j| h_j   (A = L' - L, b = t' - t;
+//     an affine function of s, the norm of its linear part bounded column by column) -- f64 of f32 entries, then rounded UP;
+//   * the rounding error of a computed query: three products and three sums per component, each within 2^-24 relative of
+//     |L_r0 x| + |L_r1 y| + |L_r2 z| + |t_r|: at most 2^-22 of that sum per component, sqrt(3) 2^-22 < 2^-21 for the norm of the three.
+__device__ __forceinline__ float motion_eps_of(const float* T, const float* c, const float* h) {
+  float m = 0.0f;
+  for (int r = 0; r < 3; ++r) {
+    float v = fabsf(T[12 + r]);
+    for (int j = 0; j < 3; ++j) v += fabsf(T[j * 4 + r]) * (fabsf(c[j]) + h[j]);
+    m = fmaxf(m, v);
+  }
+  return m * 6.0e-7f;      // > 2^-21
+}
+__device__ __forceinline__ float motion_step_of(const float* Told, const float* Tnew, const float* c, const float* h) {
+  double v2 = 0.0, spread = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    double v = (double)Tnew[12 + r] - (double)Told[12 + r];
+    for (int j = 0; j < 3; ++j) v += ((double)Tnew[j * 4 + r] - (double)Told[j * 4 + r]) * (double)c[j];
+    v2 += v * v;
+  }
+  for (int j = 0; j < 3; ++j) {
+    double col = 0.0;
+    for (int r = 0; r < 3; ++r) { const double d = (double)Tnew[j * 4 + r] - (double)Told[j * 4 + r]; col += d * d; }
+    spread += sqrt(col) * (double)h[j];
+  }
+  return (float)((sqrt(v2) + spread) * 1.000001);      // (the conversion rounds to nearest: 2^-24 relative, covered)
+}
+
 __device__ void reset_inner(IcpState* st) {
   for (int i = 0; i < 9; ++i) { st->dLd[i] = (i % 4 == 0) ? 1.0 : 0.0; st->innerL[i] = (i % 4 == 0) ? 1.0f : 0.0f; }
   for (int i = 0; i < 3; ++i) { st->dtd[i] = 0.0; st->innert[i] = 0.0f; }
@@ -2774,6 +3088,12 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   if (finalize) {
     float Tn[16];
     const float delta = compose_update(L, t, st->T, Tn);
+    {
+      const float step = motion_step_of(st->T, Tn, a.src_center, a.src_half);
+      st->motion_step = step;
+      st->motion_acc = (float)(((double)st->motion_acc + (double)step) * 1.000001);
+      st->motion_eps = motion_eps_of(Tn, a.src_center, a.src_half);
+    }
     for (int i = 0; i < 16; ++i) { st->Tprev[i] = st->T[i]; st->T[i] = Tn[i]; }
     float mx, my, mz;
     transform_point(Tn, a.src_mean[0], a.src_mean[1], a.src_mean[2], mx, my, mz);
@@ -2803,12 +3123,15 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   }
   __syncthreads();
   for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(a.state)[k] = reinterpret_cast<const uint32_t*>(&lst)[k];
+  if (a.trace != nullptr && a.gn_last_step && threadIdx.x == 0 && lst.iterations >= 1 && lst.iterations <= RUN_TRACE_CAP)
+    a.trace[lst.iterations - 1] = make_uint4(lst.unproven, lst.listed, __float_as_uint(lst.motion_step), __float_as_uint(lst.delta));
   if (a.feedback != nullptr && a.gn_last_step && threadIdx.x == 0) {
     FeedbackSlot* sl = &a.feedback->slot[(unsigned int)lst.iterations & 3u];
     sl->unproven = lst.unproven;
     sl->listed = lst.listed;
     sl->delta = lst.delta;
     sl->prev_delta = lst.prev_delta;
+    sl->step = lst.motion_step;
     sl->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
     __threadfence_system();
     a.feedback->latest = ((unsigned long long)a.run_tag << 32) | (lst.done ? 0x80000000ull : 0ull) | (unsigned long long)((unsigned int)lst.iterations & 0x7fffffffu);
@@ -2819,12 +3142,12 @@ void launch_solve(const SolveArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, a);
 }
 
-struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; };
+struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; float src_center[3], src_half[3]; };
 
 __global__ void k_init_state(IcpState* st, InitArgs ia) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (ia.fb != nullptr) {
-    for (int k = 0; k < 4; ++k) { ia.fb->slot[k].unproven = 0u; ia.fb->slot[k].listed = 0u; ia.fb->slot[k].delta = 0.0f; ia.fb->slot[k].prev_delta = 0.0f; ia.fb->slot[k].commit = 0ull; }
+    for (int k = 0; k < 4; ++k) { ia.fb->slot[k].unproven = 0u; ia.fb->slot[k].listed = 0u; ia.fb->slot[k].delta = 0.0f; ia.fb->slot[k].prev_delta = 0.0f; ia.fb->slot[k].step = 0.0f; ia.fb->slot[k].pad = 0.0f; ia.fb->slot[k].commit = 0ull; }
     __threadfence_system();
     ia.fb->latest = (unsigned long long)ia.run_tag << 32;
   }
@@ -2841,12 +3164,17 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
   st->slab_violation = 0; st->unproven = 0; st->listed = 0;
   st->violation_iter = 0; st->violation_delta = 0.0f; st->violation_ncorr = 0ull;
   for (int i = 0; i < 16; ++i) st->violation_T[i] = ia.T[i];
+  st->motion_acc = 0.0f; st->motion_step = INFINITY;
+  st->motion_eps = motion_eps_of(ia.T, ia.src_center, ia.src_half);
   reset_inner(st);
 }
 
-void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb, unsigned int run_tag) {
+void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb, unsigned int run_tag,
+                       const float* src_center, const float* src_half) {
   InitArgs ia;
   ia.fb = fb; ia.run_tag = run_tag;
+  // (no bounding box given: a huge one -- the margin test then settles nothing)
+  for (int i = 0; i < 3; ++i) { ia.src_center[i] = src_center ? src_center[i] : 0.0f; ia.src_half[i] = src_half ? src_half[i] : 1.0e30f; }
   for (int i = 0; i < 16; ++i) ia.T[i] = T0[i];
   for (int i = 0; i < 3; ++i) ia.src_mean[i] = src_mean[i];
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, st, ia);

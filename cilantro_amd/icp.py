@@ -286,6 +286,13 @@ class Context:
             out[f] = (ms.value, n.value)
         return out
 
+    def last_run_trace(self, cap=256):
+        """the last icp_run iteration by iteration: list of dicts {form, unproven, listed, step, delta} (cilhip_get_last_run_trace)"""
+        n = C.c_int(0)
+        un = (C.c_uint * cap)(); li = (C.c_uint * cap)(); st = (C.c_float * cap)(); de = (C.c_float * cap)(); fo = (C.c_int * cap)()
+        self._ck(self._L.cilhip_get_last_run_trace(self._h, cap, C.byref(n), un, li, st, de, fo))
+        return [{"form": fo[i], "unproven": un[i], "listed": li[i], "step": st[i], "delta": de[i]} for i in range(n.value)]
+
     def last_warm_iterations(self):
         """how many of the one-pass iterations of the last icp_run ran as the warm-started per-lane kernel"""
         a = C.c_int(0)

@@ -361,6 +361,12 @@ int cilhip_get_last_run_forms(cilhip_ctx* ctx, int* one_pass_iterations, int* tw
  * iteration on, near alignment, the search starts from the previous iteration's match -- a real target point, so its
  * distance from the new query bounds the search -- and usually ends inside the query's own cell; same matches. */
 int cilhip_get_last_warm_iterations(cilhip_ctx* ctx, int* warm_iterations);
+/* The last cilhip_icp_run iteration by iteration (at most the first 256, at most `cap`; written by the device's epilogue, read
+ * back here): queries the search's first stage left unproven, queries a warm-started iteration had to search, the bound on
+ * how far any source point moved in the iteration's update (what the warm-started form's margins are spent on), the update
+ * norm (last_delta_norm_ of icp_base.hpp:83) and the kernel form (the codes of cilhip_get_last_form_timing).  Any output
+ * array may be null.  Diagnostics: nothing in the loop depends on it. */
+int cilhip_get_last_run_trace(cilhip_ctx* ctx, int cap, int* n, unsigned int* unproven, unsigned int* listed, float* step, float* delta, int* form);
 /* With kernel timing on: kernel time (hipEvents on the ctx stream) and launch count of the last run's iterations per FORM of
  * their search kernel -- 0: search alone (a streaming accumulation follows: cilhip_get_last_timing2), 1: LDS-tiled search with
  * the accumulation inside the tile, 2: the first warm-started iteration of a stretch (gathers through the stored matches and
@@ -389,8 +395,15 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        (k_tile_pipe: the next tile's points / cell table / row layout are in flight while the current tile is
  *                        searched) instead of one workgroup per tile; 2 = the same with the next tile's points staged by LDS-DMA
  *                        (no register holds them).  Same results bit for bit; kept for A/B (both measured slower: NOTEBOOK.md).
- *   "warm_start" (default 1): the warm-started iteration kernel (cilhip_get_last_warm_iterations): 0 = never, 1 = when the loop
- *                        has nearly stopped moving and the form pays on this cloud pair, 2 = from the second iteration on.
+ *   "warm_start" (default 1): the warm-started iteration kernel (cilhip_get_last_warm_iterations): 0 = never, 1 = once the last
+ *                        update moved no source point by more than "warm_enter_fraction" of a grid cell (and for as long as the
+ *                        kernel settles most queries from their margins: it reports how many it had to search), 2 = from the
+ *                        second iteration on.
+ *   "tile_records" (default 1): the accumulating tile kernel writes the match records of the warm-started form itself (from a
+ *                        run's second iteration on), so that the next iteration can read them; 0 = the first warm-started
+ *                        iteration of a stretch gathers through the stored matches and writes them (A/B).
+ *   "warm_enter_fraction" (default 0.15): that bar, as a fraction of a grid cell (halved each time a warm-started iteration of
+ *                        the run had to search more than a quarter of its queries).
  *                        Neither option changes a result beyond the order of f64 additions.
  *   "cell_occupancy" (default 1): target points per grid cell, used by the next cilhip_set_target.
  *   "kernel_timing": same as cilhip_enable_kernel_timing.

@@ -170,6 +170,55 @@ def test_warm_kernel_matches_index_for_index(Context, orc):
     _report("warm_matches_1m.json", report)
 
 
+def _independent_source(base, n, seed):
+    """an independent uniform sample of the target's volume, moved by the inverse of the recipe's motion: its matches sit at about
+    half the target's point spacing (the regime of any two separately sampled clouds)"""
+    rng = np.random.default_rng(seed)
+    Ti = np.linalg.inv(base["T_true"].astype(np.float64))
+    return (rng.random((n, 3), dtype=np.float32).astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+
+
+def test_margin_records_every_route(Context, orc):
+    """The warm-started form's MARGIN proof on every route into it, index for index: the match records written by
+    the accumulating tile kernel itself (tile one pass -> record-reading warm kernel), the margin keys the search-only tile
+    kernel leaves next to its matches (two passes -> record-writing warm kernel), and the per-lane start (no keys: the
+    nearest-other-point table and the warm kernel's own full search).  Clouds: the recipe, an INDEPENDENTLY sampled source
+    (matches at half the point spacing: nothing the old half-the-target's-spacing rule could settle), a target with holes
+    and exact duplicates (margin 0: never settled without a search), and a source whose first warm iteration comes after
+    a large step (margins spent: the listed queries' own search)."""
+    rng = np.random.default_rng(21)
+    base, Dh, Nh = _holes_and_duplicates(rng)
+    n = len(base["src"])
+    far = syn.make_pair(n, perturb=0.9)
+    clouds = (("uniform", base["dst"], base["dst_n"], base["src"], False),
+              ("independent", base["dst"], base["dst_n"], _independent_source(base, n, 5), False),
+              ("holes+duplicates", Dh, Nh, base["src"], True),
+              ("far start", far["dst"], far["dst_n"], far["src"], False))
+    routes = (("tile records", (("tiled", 2), ("warm_enter_fraction", 1.0e9))),
+              ("search keys", (("tiled", 2), ("tile_accumulation", 0), ("warm_enter_fraction", 1.0e9))),
+              ("per lane", (("tiled", 0), ("warm_enter_fraction", 1.0e9))),
+              ("adaptive", ()))
+    r2 = base["max_sq_dist"]
+    report = {}
+    for cname, D, N, S, allow_ties in clouds:
+        for rname, opts in routes:
+            for metric, w_p2p, mname in ((capi.METRIC_COMBINED, 0.0, "plane"), (capi.METRIC_POINT_TO_POINT, 0.0, "kabsch")):
+                if mname == "kabsch" and rname in ("per lane", "adaptive"):
+                    continue
+                gi, gd, T, ctx, nc = _loop_matches(Context, D, N, S, r2, 7, metric, w_p2p, opts)
+                warm = ctx.last_warm_iterations()
+                trace = ctx.last_run_trace()
+                ctx.close()
+                if rname != "adaptive":
+                    # (bar out of the way: every iteration from the third on is warm-started unless one of them had to search a
+                    #  quarter of its queries -- then one cold iteration follows)
+                    assert warm >= 3, (cname, rname, mname, warm, trace)
+                chk = _check_against_fresh_search_and_reference(Context, orc, (cname, rname, mname), D, N, S, r2, gi, gd, T, nc, 100_000, rng, allow_ties)
+                report[f"{cname}/{rname}/{mname}"] = {"warm_iterations": warm, "forms": [t["form"] for t in trace], "listed": [t["listed"] for t in trace],
+                                                      "step_over_cell": None, **chk}
+    _report("margin_routes.json", report)
+
+
 def test_tile_and_lane_loop_kernels_matches_index_for_index(Context, orc):
     """The other forms an iteration can take, same check: the LDS tiles with the accumulation inside (one pass), the two-pass
     form (tiled search with its 3x3x3 pass + streaming accumulation), the per-lane search; and loops whose kernels keep no
