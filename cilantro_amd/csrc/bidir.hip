@@ -419,10 +419,10 @@ hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgr
   do {
     const float4* cand_pts = sgrid.pts;
     if (through_inverse) {
-      if (feat.w > 0.0f) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat);
+      if (feat.enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat);
       else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat);
     } else {
-      if (feat.w > 0.0f) { e = hipErrorNotSupported; break; }      // (a feature search under a (nearly) singular transform: not implemented)
+      if (feat.enabled) { e = hipErrorNotSupported; break; }      // (a feature search under a (nearly) singular transform: not implemented)
       if ((e = hipMalloc(&d_q, 3 * (size_t)ns * sizeof(float))) != hipSuccess) break;
       hipLaunchKernelGGL(k_transform_original, dim3(nblk(ns)), dim3(256), 0, s, d_src_xyz, ns, state, d_q);
       double mean[3];
@@ -492,7 +492,7 @@ void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const I
   const double ext_s = std::max({std::fabs((double)sgrid.ox), std::fabs((double)sgrid.oy), std::fabs((double)sgrid.oz)}) + (double)std::max(sgrid.nx, std::max(sgrid.ny, sgrid.nz)) * sgrid.cell;
   iv.eps = (float)(8e-6 * (ext_t + ext_s) + 1e-4 * ext_s);   // rounding of p' and of T s, and |T p' - p| for a linear part up to 1e-4 off orthonormal
   FeatSpec none{};
-  if (feat && feat->w > 0.0f) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, *feat);
+  if (feat && feat->enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, *feat);
   else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, none);
 }
 

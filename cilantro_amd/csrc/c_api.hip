@@ -84,6 +84,7 @@ struct cilhip_ctx {
   bool src3_valid = false;        // the 12-byte source copy matches d_src_sorted (rewritten after a re-sort)
   float* d_nn_lb = nullptr;       // [ns] margin keys the search-only tile kernel leaves next to nn_pos (IterArgs::nn_lb)
   bool lb_fresh = false;          // ... and they belong to the search that left nn_pos (inside a run)
+  bool warm_forecast = true;      // option "warm_forecast": the cold kernels' count of the queries a warm-started iteration would have to search gates the form
   bool tile_records = true;       // option "tile_records": the accumulating tile kernel writes the warm-started form's match records itself
   float warm_enter = 0.15f;       // option "warm_enter_fraction": the bar a run starts with, as a fraction of a grid cell
   float warm_thresh = 0.0f;       // a run's bar for (re-)entering the warm-started form: the last update moved no source point by more than this
@@ -303,11 +304,14 @@ int cilhip_synchronize(cilhip_ctx* c) {
 int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!c || !key) return CILHIP_ERR_INVALID;
   if (!strcmp(key, "fused")) { c->fused = value != 0.0; return CILHIP_OK; }
-  if (!strcmp(key, "inlier_fraction")) { c->inlier_fraction = value; return CILHIP_OK; }
-  if (!strcmp(key, "one_to_one")) { c->one_to_one = value != 0.0; return CILHIP_OK; }
+  // (a finished run's set that has not been searched again yet -- cilhip_get_last_matches_origin 2 -- would be filtered with the
+  //  NEW values: a changed post-filter drops it; a set already in memory is what its search left, whatever is set afterwards)
+  if (!strcmp(key, "inlier_fraction")) { if (c->inlier_fraction != value && c->pending_matches) drop_matches(c); c->inlier_fraction = value; return CILHIP_OK; }
+  if (!strcmp(key, "one_to_one")) { if (c->one_to_one != (value != 0.0) && c->pending_matches) drop_matches(c); c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return CILHIP_OK; }
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
+  if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tile_records")) { c->tile_records = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "warm_enter_fraction")) {
     if (!(value > 0.0)) return fail(c, CILHIP_ERR_INVALID, "warm_enter_fraction: > 0 (fraction of a grid cell)");
@@ -402,7 +406,7 @@ int cilhip_get_last_run_trace(cilhip_ctx* c, int cap, int* n_out, unsigned int* 
     if (listed) listed[i] = tr[i].y;
     if (step) memcpy(&step[i], &tr[i].z, 4);
     if (delta) memcpy(&delta[i], &tr[i].w, 4);
-    if (form) form[i] = (size_t)i < c->trace_form.size() ? (int)c->trace_form[i] : -1;
+    if (form) form[i] = (size_t)i < c->trace_form.size() ? (int)(c->trace_form[i] & 0x7f) : -1;
   }
   *n_out = n;
   return CILHIP_OK;
@@ -737,6 +741,7 @@ static int apply_filters(cilhip_ctx* c) {
 static FeatSpec feat_spec_of(const cilhip_ctx* c) {
   FeatSpec f{};
   f.w = c->normal_weight;
+  f.enabled = feat6(c) ? 1 : 0;
   if (c->feature_kind == 1) { f.src = c->d_src_rgb_sorted; f.dst = c->d_dst_rgb_sorted; f.mode = 2; }
   else { f.src = c->d_src_nrm ? c->d_src_nrm_sorted : nullptr; f.dst = c->grid.nrm; f.mode = c->transform_mode == 1 ? 1 : 0; }
   if (c->feature_kind == 2) { f.src2 = c->d_src_rgb_sorted; f.dst2 = c->d_dst_rgb_sorted; f.w2 = c->color_weight; }
@@ -849,7 +854,7 @@ static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq, const
   rf.src = c->has_src_grid ? c->src_grid.nrm : nullptr;
   if (rf.dst2) rf.src2 = c->d_src_rgb_grid;
   if (feat6(c) && (!rf.src || !rf.dst || (rf.dst2 && !rf.src2))) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
-  if (!feat6(c)) rf.w = 0.0f;
+  if (!feat6(c)) { rf.w = 0.0f; rf.enabled = 0; }
   const hipError_t e = find_pairs(rf, c->grid, c->src_grid, c->d_src_xyz, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm : nullptr, c->d_src_sorted, c->ns, c->d_state,
                                   c->d_state_id, T_host, max_sq, c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2,
                                   c->pairs, c->stream);
@@ -920,7 +925,16 @@ static int materialize_pending(cilhip_ctx* c) {
   memcpy(T, c->nn_T, sizeof(T));
   const float r = c->pending_max_sq;
   c->pending_matches = false;
-  const int rc = cilhip_find_correspondences(c, T, r, nullptr);
+  // (the search runs through the context's loop state: the finished run's state -- what cilhip_icp_state and
+  //  cilhip_get_slab_violation_state report -- is put back afterwards)
+  IcpState* keep = nullptr;
+  CK(c, hipMalloc(&keep, sizeof(IcpState)));
+  hipError_t e = hipMemcpyAsync(keep, c->d_state, sizeof(IcpState), hipMemcpyDeviceToDevice, c->stream);
+  int rc = e == hipSuccess ? cilhip_find_correspondences(c, T, r, nullptr) : CILHIP_ERR_HIP;
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_state, keep, sizeof(IcpState), hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(keep);
+  if (e != hipSuccess && rc == CILHIP_OK) { c->err = std::string("materialize_pending: ") + hipGetErrorString(e); rc = CILHIP_ERR_HIP; }
   if (rc == CILHIP_OK) c->matches_origin = 2;
   return rc;
 }
@@ -1551,11 +1565,15 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (fv.done) break;
       // the form of the COLD iterations (one pass / two passes), from the last cold iteration's count of queries its octant stage
       // left open (a warm-started iteration counts something else there: the queries its own search took to the shells)
-      if (fv.iterations >= 1 && fv.iterations <= c->trace_form.size() && c->trace_form[fv.iterations - 1] <= FORM_TILE_ONE_PASS)
+      if (fv.iterations >= 1 && fv.iterations <= c->trace_form.size() && (c->trace_form[fv.iterations - 1] & 0x7f) <= FORM_TILE_ONE_PASS)
         c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
+      // what the published iteration's `listed` count means: a warm-started iteration reports the queries it had to search, a
+      // cold iteration whose kernels leave margins (bit 7 of its form) the queries a warm-started iteration after it would have to
+      auto form_of = [&](const FbView& f) -> int { return (f.iterations >= 1 && f.iterations <= c->trace_form.size()) ? (int)c->trace_form[f.iterations - 1] : -1; };
+      auto is_warm = [&](const FbView& f) { const int fo = form_of(f); return fo >= 0 && ((fo & 0x7f) == FORM_WARM || (fo & 0x7f) == FORM_WARM_FIRST); };
       // (a published iteration is judged once: the same one can be the latest at two consecutive looks)
       bool fell = false;
-      if (warm_on && c->warm_start == 1 && fv.iterations > judged) {
+      if (warm_on && c->warm_start == 1 && fv.iterations > judged && is_warm(fv)) {
         judged = fv.iterations;
         if (!warm_keeps_paying(c, fv.listed)) { warm_on = false; fell = true; }
       }
@@ -1566,8 +1584,15 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         rc = wait_published_or_sync(c, (unsigned int)it, &fv);
         if (rc) return rc;
         if (fv.done) break;
-        if (fv.iterations > judged && fv.listed != 0u) { judged = fv.iterations; fell = !warm_keeps_paying(c, fv.listed); }
-        if (!fell && !c->warm_banned) warm_on = warm_worthwhile(c, fv.step);
+        if (is_warm(fv)) {
+          if (fv.iterations > judged && fv.listed != 0u) { judged = fv.iterations; fell = !warm_keeps_paying(c, fv.listed); }
+          if (!fell && !c->warm_banned) warm_on = warm_worthwhile(c, fv.step);
+        } else {
+          // the cold iteration's own forecast: enter only if at most an eighth of the queries would have to be searched
+          const int fo = form_of(fv);
+          const bool forecast_ok = !c->warm_forecast || !(fo >= 0 && (fo & 0x80)) || (unsigned long long)fv.listed * 8ull <= (unsigned long long)c->ns;
+          warm_on = forecast_ok && warm_worthwhile(c, fv.step);
+        }
       }
     }
     const bool one_pass = tile_acc && !c->far_mode;
@@ -1577,6 +1602,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     const bool warm = wcap && it >= 1 && (c->warm_start == 2 || (paced && it >= 2 && warm_on));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     bool warm_first = false;
+    bool counted = false;      // a cold iteration whose kernels count the queries a warm-started iteration after it would have to search
     for (size_t st = 0; st < opt_steps; ++st) {
       a.skip_if_inner_done = (st > 0);
       if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
@@ -1609,14 +1635,16 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           if (recs) set_warm_args(c, fa);
           launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
           c->rec_valid = recs; c->lb_fresh = false;
+          counted = recs;
           all_stored = all_stored && fa.store_matches != 0;
         } else if (st == 0) {
           c->rec_valid = false;
           // (search-only form of the tiles: the margin keys of its searches next to the matches)
           IterArgs sa2 = a;
-          const bool keys = wcap && use_tiled(c) && !feat6(c);
+          const bool keys = wcap && !feat6(c);
           if (keys) sa2.nn_lb = c->d_nn_lb;
           c->lb_fresh = keys;
+          counted = keys;
           { const int src_rc = launch_search(c, sa2); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
@@ -1637,7 +1665,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         const unsigned char form = (unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
                                                    : (c->fused && !filters_active(c) && !feat6(c)) ? FORM_LANE_FUSED : FORM_SEARCH);
         if (timing) c->iter_form.push_back(form);
-        c->trace_form.push_back(form);
+        c->trace_form.push_back((unsigned char)(form | (counted ? 0x80 : 0)));
       }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
@@ -1793,11 +1821,11 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         if (timing) c->iter_form.push_back((unsigned char)FORM_SEARCH);
         ++c->last_two_pass_iters;
         IterArgs sa2 = a;
-        const bool keys = wcap && use_tiled(c);
+        const bool keys = wcap;
         if (keys) sa2.nn_lb = c->d_nn_lb;
         c->lb_fresh = keys;
         if (use_tiled(c)) launch_search_tiled(sa2, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
-        else launch_iter(a, IM_NONE, true, true, nb, c->stream);
+        else launch_iter(sa2, IM_NONE, true, true, nb, c->stream);
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
         launch_iter(a, im, false, false, nb, c->stream);
       }

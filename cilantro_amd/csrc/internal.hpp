@@ -82,6 +82,9 @@ struct IcpState {
   // rounded up), so the distance any query moved between two iterations is at most the difference of the two values;
   // motion_eps >= the rounding error of one computed query under the current transform; motion_step = the last update's share.
   float motion_acc, motion_eps, motion_step;
+  // the step the NEXT update is expected to make at most: the last one times the contraction it showed (0 before there are two) --
+  // what the cold kernels' forecast of a warm-started iteration's searches is counted against
+  float motion_pred;
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -112,7 +115,8 @@ struct F3 { float x, y, z; };      // 12-byte record (one global_load_dwordx3 pe
 struct FeatSpec {
   const float4* src;     // the source's feature vectors in the order of the searched source array
   const float4* dst;     // the target's, in sorted-target order
-  float w;               // feature weight (0 = plain point features)
+  float w;               // weight of the first attribute (may be 0 under the 9-D adaptor: then only the second one counts)
+  int enabled;           // a feature adaptor is in force: candidates are compared by feature distance (0 = plain point features)
   int mode;
   float M[9];            // row-major L^-T (mode 1)
   float nw;
@@ -235,6 +239,8 @@ __device__ __forceinline__ void source_feature(const FeatSpec& a, const float* T
     const float v1 = __fadd_rn(__fmul_rn(M[3], wx), __fadd_rn(__fmul_rn(M[4], wy), __fmul_rn(M[5], wz)));
     const float v2 = __fadd_rn(__fmul_rn(M[6], wx), __fadd_rn(__fmul_rn(M[7], wy), __fmul_rn(M[8], wz)));
     const float nrm = (float)sqrt((double)__fadd_rn(__fmul_rn(v0, v0), __fadd_rn(__fmul_rn(v1, v1), __fmul_rn(v2, v2))));
+    // (Eigen's normalized() leaves a vector of norm 0 as it is: a zero normal, or a zero normal weight under the 9-D adaptor)
+    if (!(nrm > 0.0f)) { fx = __fmul_rn(a.nw, v0); fy = __fmul_rn(a.nw, v1); fz = __fmul_rn(a.nw, v2); return; }
     fx = __fmul_rn(a.nw, (float)((double)v0 / (double)nrm));
     fy = __fmul_rn(a.nw, (float)((double)v1 / (double)nrm));
     fz = __fmul_rn(a.nw, (float)((double)v2 / (double)nrm));

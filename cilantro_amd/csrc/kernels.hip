@@ -65,6 +65,14 @@ __device__ __forceinline__ float d2_pinned(float qx, float qy, float qz, float p
 // under a later transform of the same run  B - (acc' + eps')  is still such a bound (a query moves by at most acc' - acc
 // between the two searches; eps, eps': the rounding of the two computed queries).
 struct MotionRef { float acc, eps; };      // IcpState::motion_acc / ::motion_eps under the transform being searched
+// Would a query with this bound (lb on the other points, d2 to its match) have to be searched again by a warm-started iteration
+// if the next update moves the source as far as the last one did?  The LB forms of the cold kernels count these (and the queries
+// that leave without a bound) into the `listed` counters: the host enters the warm-started form only where it will pay.
+__device__ __forceinline__ bool margin_is_small(bool found, float second_sq, float gap, float best_sq, float max_sq, float step) {
+  const float lb = fminf(__fsqrt_rn(second_sq), gap);
+  const float need = found ? __fsqrt_rn(best_sq) : __fsqrt_rn(max_sq);      // (no match: the bound has to stay beyond the radius)
+  return !(lb - need > 2.0f * step);
+}
 #define MARGIN_NONE_NO_MATCH (-1.17549435e-38f) /* -FLT_MIN: no match, no bound known (+0: a match, no bound known) */
 __device__ __forceinline__ float margin_key(bool found, float second_sq, float gap, const MotionRef& m) {
   // sqrt of a pinned squared distance: the true distance is at least that times (1 - 2^-22), the device's square root is within 1 ulp
@@ -457,6 +465,126 @@ __device__ __forceinline__ void nn_search_from(const GridDev& g, float qx, float
     if (b == INFINITY) return;
     b -= g.margin;
     if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) return;
+  }
+  nn_search_shells(g, qx, qy, qz, cx, cy, cz, 2, best);
+}
+// The same search for a caller that wants the MARGIN with the result (the cold per-lane iterations of a run whose later
+// iterations may be warm-started): besides the best key it keeps the second smallest squared distance it evaluated
+// (m2: a median-of-three beside every compare; the radius stands in for "best" while nothing has been found, as in the tiles'
+// octant search) and the smallest squared gap of anything it SKIPPED (cull2: rows and side cells of the 3x3x3 block culled against
+// the best so far).  *lb_out = a lower bound on the distance from q to every target point but the match (to every target point
+// without one): min(sqrt(m2), sqrt(cull2), gap to the faces of the block that proved the result); 0 when the result came from the
+// shell search (no bound kept).
+__device__ __forceinline__ void scan_range4_m2(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, NN& best, float& m2) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 4) {
+    uint32_t jj[4];
+    float4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { jj[k] = min(j + (uint32_t)k, last); p[k] = pts[jj[k]]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float e = d2_pinned(qx, qy, qz, p[k].x, p[k].y, p[k].z);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p[k].w);
+      if (j + (uint32_t)k <= last) m2 = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(best.key >> 32)), m2, e);
+      if (key < best.key) { best.key = key; best.pos = jj[k]; }
+    }
+  }
+}
+__device__ __forceinline__ void nn_search_lb(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best, uint2* lst, float* lb_out) {
+  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  best.pos = NONE_U32;
+  *lb_out = 0.0f;
+  const float BIG = 1.0e9f;
+  const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
+  const float fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG);
+  const float fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
+  if (!inside) {
+    const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
+    const float gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
+    const float gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+    const float gg = (gx * gx + gy * gy + gz * gz) * KSHRINK;
+    if (gg >= max_sq) { *lb_out = __fsqrt_rn(gg) * 0.999999f; return; }      // every target point lies inside the grid
+    const int s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+    nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
+    return;
+  }
+  float m2 = INFINITY;
+  const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
+  const uint32_t b0 = g.cell_start[cid], e0 = g.cell_start[cid + 1];
+  scan_range4_m2(g.pts, b0, e0, qx, qy, qz, best, m2);
+  const float bd = __uint_as_float((uint32_t)(best.key >> 32));
+  const float xl = g.ox + (float)cx * g.cell, yl = g.oy + (float)cy * g.cell, zl = g.oz + (float)cz * g.cell;
+  const float gmx = fmaxf(qx - xl - g.margin, 0.0f), gpx = fmaxf(xl + g.cell - qx - g.margin, 0.0f);
+  const float gmy = fmaxf(qy - yl - g.margin, 0.0f), gpy = fmaxf(yl + g.cell - qy - g.margin, 0.0f);
+  const float gmz = fmaxf(qz - zl - g.margin, 0.0f), gpz = fmaxf(zl + g.cell - qz - g.margin, 0.0f);
+  const bool hmx = cx > 0, hpx = cx + 1 < g.nx, hmy = cy > 0, hpy = cy + 1 < g.ny, hmz = cz > 0, hpz = cz + 1 < g.nz;
+  {  // nothing outside the own cell can beat or tie the best: done
+    float b = INFINITY;
+    if (hmx) b = fminf(b, gmx);
+    if (hpx) b = fminf(b, gpx);
+    if (hmy) b = fminf(b, gmy);
+    if (hpy) b = fminf(b, gpy);
+    if (hmz) b = fminf(b, gmz);
+    if (hpz) b = fminf(b, gpz);
+    if (b == INFINITY || bd < b * b * KSHRINK) { *lb_out = fminf(__fsqrt_rn(m2) * 0.999999f, b); return; }
+  }
+  const float ax2[3] = {gmx * gmx, 0.0f, gpx * gpx};
+  const float ay2[3] = {gmy * gmy, 0.0f, gpy * gpy};
+  const float az2[3] = {gmz * gmz, 0.0f, gpz * gpz};
+  const bool okx[3] = {hmx, true, hpx}, oky[3] = {hmy, true, hpy}, okz[3] = {hmz, true, hpz};
+  float cull2 = INFINITY;      // smallest squared gap of a row / side cell that exists and was skipped
+  uint32_t ia[9], ib[9];
+  bool pass[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int dz = r / 3, dy = r % 3;
+    const float gyz2 = az2[dz] + ay2[dy];
+    const bool ex = okz[dz] && oky[dy];
+    const bool p = ex && (gyz2 * KSHRINK <= bd);
+    const bool left = p && okx[0] && ((gyz2 + ax2[0]) * KSHRINK <= bd);
+    const bool right = p && okx[2] && ((gyz2 + ax2[2]) * KSHRINK <= bd);
+    if (ex && !p) cull2 = fminf(cull2, gyz2);
+    if (p && okx[0] && !left) cull2 = fminf(cull2, gyz2 + ax2[0]);
+    if (p && okx[2] && !right) cull2 = fminf(cull2, gyz2 + ax2[2]);
+    const uint32_t row = cid + (uint32_t)((dz - 1) * g.ny * g.nx + (dy - 1) * g.nx);
+    pass[r] = (r == 4) ? (left || right) : p;
+    ia[r] = pass[r] ? (row - (left ? 1u : 0u)) : 0u;
+    ib[r] = pass[r] ? (row + 1u + (right ? 1u : 0u)) : 0u;
+  }
+  uint32_t va[9], vb[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { va[r] = g.cell_start[ia[r]]; vb[r] = g.cell_start[ib[r]]; }
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    if (r == 4) {
+      if (pass[r] && b0 > va[r]) { lst[cnt * ITER_THREADS] = make_uint2(va[r], b0); ++cnt; }
+      if (pass[r] && vb[r] > e0) { lst[cnt * ITER_THREADS] = make_uint2(e0, vb[r]); ++cnt; }
+    } else {
+      if (pass[r] && vb[r] > va[r]) { lst[cnt * ITER_THREADS] = make_uint2(va[r], vb[r]); ++cnt; }
+    }
+  }
+  for (int k = 0; k < cnt; ++k) {
+    const uint2 r = lst[k * ITER_THREADS];
+    scan_range4_m2(g.pts, r.x, r.y, qx, qy, qz, best, m2);
+  }
+  {  // does the 3x3x3 block prove exactness?
+    float b = INFINITY;
+    if (cx - 1 > 0) b = fminf(b, gmx + g.cell);
+    if (cx + 2 < g.nx) b = fminf(b, gpx + g.cell);
+    if (cy - 1 > 0) b = fminf(b, gmy + g.cell);
+    if (cy + 2 < g.ny) b = fminf(b, gpy + g.cell);
+    if (cz - 1 > 0) b = fminf(b, gmz + g.cell);
+    if (cz + 2 < g.nz) b = fminf(b, gpz + g.cell);
+    if (b != INFINITY) b -= g.margin;
+    if (b == INFINITY || (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK)) {
+      *lb_out = fminf(fminf(__fsqrt_rn(m2) * 0.999999f, __fsqrt_rn(cull2)), b);
+      return;
+    }
   }
   nn_search_shells(g, qx, qy, qz, cx, cy, cz, 2, best);
 }
@@ -1254,7 +1382,7 @@ __device__ __forceinline__ void defer_whole_tile(const IterArgs& a, uint32_t vb)
   if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
     for (int u = 0; u < TILE_QPT; ++u) a.defer_mask[(size_t)vb * (2 * TILE_WAVES) + u * TILE_WAVES + (threadIdx.x >> 6)] = ~0ull;
-    if (threadIdx.x == 0) { if (__hip_atomic_load(a.defer_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __hip_atomic_store(a.defer_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)TILE_QUERIES); }
+    if (threadIdx.x == 0) { if (__hip_atomic_load(a.defer_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __hip_atomic_store(a.defer_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)TILE_QUERIES); atomicAdd(a.unproven_cnt + 64u + (vb & 63u), (uint32_t)TILE_QUERIES); }
   }
   if (ACC != IM_NONE && threadIdx.x < SUMS_MAX) a.tile_partials[(size_t)vb * SUMS_MAX + threadIdx.x] = 0.0;
 }
@@ -1287,12 +1415,13 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   __shared__ uint32_t rowbase[TILE_MAXROWS + 1];
   __shared__ uint32_t rowdelta[TILE_MAXROWS];
   __shared__ uint32_t queue_count;            // queries queued for the 3x3x3 pass (phase 3)
-  __shared__ float tform_lds[18];             // the transform (and the motion clock), for phase 3b
+  __shared__ float tform_lds[19];             // the transform (and the motion clock), for phase 3b
+  __shared__ uint32_t small_count;            // (LB) queries that leave this tile with a margin a warm-started iteration could not use, or with none
   __shared__ int geom_lds[8];                 // the region's geometry, for phase 3b (so that nothing it derives is kept live from here)
   float4* lpts = reinterpret_cast<float4*>(raw);
-  if (threadIdx.x == 0) queue_count = 0;      // (several barriers before its first use)
+  if (threadIdx.x == 0) { queue_count = 0; small_count = 0; }      // (several barriers before their first use)
   if (threadIdx.x < 16) tform_lds[threadIdx.x] = st->T[threadIdx.x];
-  if (LB && threadIdx.x == 16) { tform_lds[16] = st->motion_acc; tform_lds[17] = st->motion_eps; }
+  if (LB && threadIdx.x == 16) { tform_lds[16] = st->motion_acc; tform_lds[17] = st->motion_eps; tform_lds[18] = st->motion_pred; }
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   unsigned long long tprev_ = wall_clock64();
 #endif
@@ -1304,6 +1433,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
   const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};     // (scalar loads here: read in the tail they are vector loads with a round trip each)
   const MotionRef mref = {LB ? st->motion_acc : 0.0f, LB ? st->motion_eps : 0.0f};
+  const float mstep = LB ? st->motion_pred : 0.0f;
 
   // the lane's queries: issue the loads first, they fly while the region's cell table is fetched
   float4 s4[TILE_QPT];
@@ -1516,6 +1646,13 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         unproven = !octant_search<LB>(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb);
         if (LB && ACC == IM_NONE) mkey = margin_key(best.pos != NONE_U32, second, gapb, mref);
         if (LB && ACC != IM_NONE) mq = margin_q15(best.pos != NONE_U32, second, gapb, mref, g.inv_cell);
+        if (LB) {
+          // (the accumulating form hands its unproven queries to the clean-up pass, which keeps no bound; the search-only form
+          //  counts them where its 3x3x3 pass settles them)
+          const bool small = unproven ? (ACC != IM_NONE) : margin_is_small(best.pos != NONE_U32, second, gapb, __uint_as_float((uint32_t)(best.key >> 32)), a.max_sq, mstep);
+          const unsigned long long ms = __ballot(small);
+          if (ms != 0ull && (threadIdx.x & 63u) == 0) atomicAdd(&small_count, (uint32_t)__popcll(ms));
+        }
       } else {
         // outside the tile's box or in the grid's outer layer (or beyond): nothing to find if the query is farther
         // from the grid than the radius, else the clean-up pass (generic search) takes it
@@ -1634,6 +1771,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   if (threadIdx.x == 0) {   // what the octant block did not prove, for the host's choice of the next iteration's form
     const uint32_t cu = queue_count;
     if (cu != 0u) atomicAdd(a.unproven_cnt + (vb & 63u), cu);
+    if (LB && ACC != IM_NONE) { const uint32_t cs = small_count; if (cs != 0u) atomicAdd(a.unproven_cnt + 64u + (vb & 63u), cs); }
   }
   uint32_t nqueued = (ACC == IM_NONE && !FEAT6) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)queue_count) : 0u;   // block-uniform
   if (ACC == IM_NONE && !FEAT6) {
@@ -1673,9 +1811,15 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         a.nn_pos[i] = proven ? best.pos : DEFER_MARK;
         if (proven && a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
         if (LB && proven) a.nn_lb[i] = margin_key(best.pos != NONE_U32, second, gapb, MotionRef{tform_lds[16], tform_lds[17]});
+        if (LB && (!proven || margin_is_small(best.pos != NONE_U32, second, gapb, __uint_as_float((uint32_t)(best.key >> 32)), a.max_sq, tform_lds[18])))
+          atomicAdd(&small_count, 1u);
       }
     }
     __syncthreads();
+  }
+  if (LB && ACC == IM_NONE && threadIdx.x == 0) {      // (after the barriers that order every wave's counts)
+    const uint32_t cs = small_count;
+    if (cs != 0u) atomicAdd(a.unproven_cnt + 64u + (vb & 63u), cs);
   }
   // ---- 4. home lanes: results of their queued queries; the deferred ones are published as one mask word per wave and
   //         query slot (bit = lane): the clean-up pass walks the masks in a fixed order ----
@@ -2162,7 +2306,9 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
   uint32_t inext = beg + threadIdx.x;
   float4 s4n = inext < end ? a.src[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t wn = (a.warm_pos && inext < end) ? a.warm_pos[inext] : NONE_U32;
-  uint32_t nfar = 0;
+  uint32_t nfar = 0, nsmall = 0;
+  const MotionRef mref = {st->motion_acc, st->motion_eps};
+  const float mstep = st->motion_pred;
   while (inext < end) {
     const uint32_t i = inext;
     const float4 s4 = s4n;
@@ -2187,7 +2333,17 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
         }
         nfar += far ? 1u : 0u;
       }
-      nn_search_from(a.grid, qx, qy, qz, a.max_sq, best, lst);
+      if (STORE && a.nn_lb != nullptr) {
+        // (a run whose later iterations may be warm-started: the margin key of this search next to the match, and the count of
+        //  the queries whose margin the next update would already have spent)
+        float lb = 0.0f;
+        nn_search_lb(a.grid, qx, qy, qz, a.max_sq, best, lst, &lb);
+        const bool found = best.pos != NONE_U32;
+        a.nn_lb[i] = lb > 0.0f ? margin_key(found, INFINITY, lb, mref) : (found ? 0.0f : MARGIN_NONE_NO_MATCH);
+        nsmall += (lb > 0.0f && !margin_is_small(found, INFINITY, lb, __uint_as_float((uint32_t)(best.key >> 32)), a.max_sq, mstep)) ? 0u : 1u;
+      } else {
+        nn_search_from(a.grid, qx, qy, qz, a.max_sq, best, lst);
+      }
       pos = best.pos;
       value = __uint_as_float((uint32_t)(best.key >> 32));
       if (STORE) { a.nn_pos[i] = pos; if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
@@ -2201,6 +2357,10 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
   if (a.warm_pos && a.unproven_cnt) {
     const double tot = wave_sum((double)nfar);
     if ((threadIdx.x & 63) == 0 && tot > 0.0) atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)tot);
+  }
+  if (STORE && a.nn_lb != nullptr && a.unproven_cnt) {
+    const double tot = wave_sum((double)nsmall);
+    if ((threadIdx.x & 63) == 0 && tot > 0.0) atomicAdd(a.unproven_cnt + 64u + (vb & 63u), (uint32_t)tot);
   }
   }
 
@@ -3090,6 +3250,8 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
     const float delta = compose_update(L, t, st->T, Tn);
     {
       const float step = motion_step_of(st->T, Tn, a.src_center, a.src_half);
+      const float prev = st->motion_step;
+      st->motion_pred = (prev < INFINITY && prev > 0.0f) ? step * fminf(1.0f, step / prev) : 0.0f;
       st->motion_step = step;
       st->motion_acc = (float)(((double)st->motion_acc + (double)step) * 1.000001);
       st->motion_eps = motion_eps_of(Tn, a.src_center, a.src_half);
@@ -3164,7 +3326,7 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
   st->slab_violation = 0; st->unproven = 0; st->listed = 0;
   st->violation_iter = 0; st->violation_delta = 0.0f; st->violation_ncorr = 0ull;
   for (int i = 0; i < 16; ++i) st->violation_T[i] = ia.T[i];
-  st->motion_acc = 0.0f; st->motion_step = INFINITY;
+  st->motion_acc = 0.0f; st->motion_step = INFINITY; st->motion_pred = 0.0f;
   st->motion_eps = motion_eps_of(ia.T, ia.src_center, ia.src_half);
   reset_inner(st);
 }

@@ -386,7 +386,7 @@ int cilhip_transform_ransac3f(int device, const float* dst_xyz, const float* src
       TR_CK(hipMalloc(&b.partial, (size_t)nb * TR_ROUND * sizeof(uint32_t)));
       TR_CK(hipMalloc(&b.dpartial, (size_t)TR_MAX_BLOCKS * 16 * sizeof(double)));
       TR_CK(hipMalloc(&b.chunk_counts, TR_MAX_BLOCKS * sizeof(uint32_t)));
-      if (max_iter) TR_CK(hipMemcpyAsync(b.samples, samples, 3 * max_iter * sizeof(uint32_t), hipMemcpyHostToDevice, b.s));
+      if (max_iter) TR_CK(hipMemcpy(b.samples, samples, 3 * max_iter * sizeof(uint32_t), hipMemcpyHostToDevice));      // (blocking: `samples` may be a local vector)
       TR_CK(hipEventRecord(b.e0, b.s));
       if (max_iter)
         hipLaunchKernelGGL(k_tmodels, dim3((unsigned)((mpad + 127) / 128)), dim3(128), 0, b.s, b.dst, b.src, b.samples, sample_size, (uint32_t)max_iter,

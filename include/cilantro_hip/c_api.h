@@ -399,6 +399,10 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        update moved no source point by more than "warm_enter_fraction" of a grid cell (and for as long as the
  *                        kernel settles most queries from their margins: it reports how many it had to search), 2 = from the
  *                        second iteration on.
+ *   "warm_forecast" (default 1): the cold iterations of a run count the queries whose margin the next update is expected to spend
+ *                        (or that leave without one); the warm-started form is entered only when that is at most an eighth of the
+ *                        queries -- a pair whose matches lie far beyond the target's point spacing never pays for a try.  0 = enter
+ *                        on the step alone (tests).
  *   "tile_records" (default 1): the accumulating tile kernel writes the match records of the warm-started form itself (from a
  *                        run's second iteration on), so that the next iteration can read them; 0 = the first warm-started
  *                        iteration of a stretch gathers through the stored matches and writes them (A/B).

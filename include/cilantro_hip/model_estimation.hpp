@@ -148,6 +148,7 @@ public:
   RigidTransformRANSACEstimator3f(const ConstPointsView& dst_points, const ConstPointsView& src_points, const std::vector<IdxT>& dst_ind,
                                   const std::vector<IdxT>& src_ind, int device = 0)
       : device_(device) {
+    if (dst_ind.size() != src_ind.size()) throw std::invalid_argument("dst / src pairs must have the same length");
     dst_.resize(3 * dst_ind.size()); src_.resize(3 * src_ind.size());
     for (size_t i = 0; i < dst_ind.size(); ++i)
       for (int d = 0; d < 3; ++d) { dst_[3 * i + d] = dst_points.data()[3 * dst_ind[i] + d]; src_[3 * i + d] = src_points.data()[3 * src_ind[i] + d]; }

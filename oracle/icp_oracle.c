@@ -335,6 +335,8 @@ void orc_transform_features6_mode(const float T[16], const float* in6, size_t n,
     if (mode == 2) { o[3] = a[3]; o[4] = a[4]; o[5] = a[5]; continue; }
     const float v0 = M[0] * a[3] + (M[1] * a[4] + M[2] * a[5]), v1 = M[3] * a[3] + (M[4] * a[4] + M[5] * a[5]), v2 = M[6] * a[3] + (M[7] * a[4] + M[8] * a[5]);
     const float nrm = sqrtf(v0 * v0 + (v1 * v1 + v2 * v2));
+    /* Eigen's normalized() returns a vector of norm 0 unchanged (a zero normal; a zero normal weight under the 9-D adaptor) */
+    if (!(nrm > 0.0f)) { o[3] = nw * v0; o[4] = nw * v1; o[5] = nw * v2; continue; }
     o[3] = nw * (v0 / nrm); o[4] = nw * (v1 / nrm); o[5] = nw * (v2 / nrm);
   }
   free(p); free(q);

@@ -194,9 +194,9 @@ def test_margin_records_every_route(Context, orc):
               ("independent", base["dst"], base["dst_n"], _independent_source(base, n, 5), False),
               ("holes+duplicates", Dh, Nh, base["src"], True),
               ("far start", far["dst"], far["dst_n"], far["src"], False))
-    routes = (("tile records", (("tiled", 2), ("warm_enter_fraction", 1.0e9))),
-              ("search keys", (("tiled", 2), ("tile_accumulation", 0), ("warm_enter_fraction", 1.0e9))),
-              ("per lane", (("tiled", 0), ("warm_enter_fraction", 1.0e9))),
+    routes = (("tile records", (("tiled", 2), ("warm_enter_fraction", 1.0e9), ("warm_forecast", 0))),
+              ("search keys", (("tiled", 2), ("tile_accumulation", 0), ("warm_enter_fraction", 1.0e9), ("warm_forecast", 0))),
+              ("per lane", (("tiled", 0), ("warm_enter_fraction", 1.0e9), ("warm_forecast", 0))),
               ("adaptive", ()))
     r2 = base["max_sq_dist"]
     report = {}

@@ -1830,6 +1830,23 @@ def test_point_normal_color_features_9d_vs_oracle(Context, orc, hip_lib):
                 got = eng.getCorrespondences()
                 want = orc.find_correspondences_feat9_dir(dst9, q9, r2, code, recip)
                 assert len(want[0]) > 0.5 * n and lists_equal(got, want), (tiled, mode, direction, recip, len(got[0]), len(want[0]))
+    # normal weight 0, colour weight > 0: still a 9-D search in BOTH halves of the other directions (the reverse half used to take the
+    # normal weight for "no features" and ran on the points alone), rigid and affine (Eigen's normalized() leaves the zero vector as it is)
+    dst9c = orc.point_normal_color_features(dst, dst_n, dst_c, 0.0, wc)
+    src9c = orc.point_normal_color_features(src, src_n, src_c, 0.0, wc)
+    for T, mode, cls in ((T_rigid, 0, SimpleCombinedMetricRigidICP3f), (T_aff, 1, SimpleCombinedMetricAffineICP3f)):
+        q9c = orc.transform_features9(T, src9c, mode)
+        for direction, recip, code in ((D.SECOND_TO_FIRST, False, 0), (D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 2), (D.BOTH, True, 2)):
+            icp = cls(dst, dst_n, src)
+            eng = icp.correspondenceSearchEngine()
+            eng.setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
+            eng.setPointNormalColorFeatureAdaptors(src_n, dst_c, src_c, 0.0, wc)
+            eng.findCorrespondences(T)
+            got = eng.getCorrespondences()
+            want = orc.find_correspondences_feat9_dir(dst9c, q9c, r2, code, recip)
+            plain = orc.find_correspondences_feat9_dir(orc.point_normal_color_features(dst, dst_n, dst_c, 0.0, 0.0), orc.transform_features9(T, orc.point_normal_color_features(src, src_n, src_c, 0.0, 0.0), mode), r2, code, recip)
+            assert lists_equal(got, want), ("wn = 0", mode, direction, recip, len(got[0]), len(want[0]))
+            assert not lists_equal(want, plain)      # (the colours do decide matches here: a search on the points alone is told apart)
     # the matches differ from the 6-D point+normal adaptor's on a good share of the queries (a dropped part would go unnoticed otherwise)
     w9 = orc.find_correspondences_feat9_dir(dst9, orc.transform_features9(T_rigid, src9, 0), float("inf"), 0)
     w6 = orc.find_correspondences_feat6_dir(dst9[:, :6].copy(), orc.transform_features6(T_rigid, src9[:, :6].copy(), 0), float("inf"), 0)
