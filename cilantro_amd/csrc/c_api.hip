@@ -1129,6 +1129,116 @@ int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t ma
   return CILHIP_OK;
 }
 
+// ---- two correspondence sets in one combined-metric estimate: CorrespondenceSearchCombinedMetricCombiner -------------
+// (registration/correspondence_search_combined_metric_combiner.hpp:8-81: the point-to-point terms read one engine's
+//  correspondences, the point-to-plane terms another's -- other radius, features, filters -- over the same two clouds.)
+// Each context accumulates its own block of the sums over its own stored matches (the point block, slots [28, 44), on
+// c_point; the plane block, slots [0, 28), on c_plane); the normal equations are assembled from the two.
+static int combined_two_sets_step(cilhip_ctx* cp, cilhip_ctx* cl, bool wp, bool wl, float w_p2p, float w_p2pl, const double L[9], const double t[3],
+                                  double sums[SUMS_MAX], bool* weighted_out) {
+  CorrWeights cwp = corr_weights_of(cp, true, w_p2p, w_p2pl), cwl = corr_weights_of(cl, true, w_p2p, w_p2pl);
+  const bool any = cwp.enabled || cwl.enabled;      // (some evaluator is not Unity: both blocks then carry their metric weight per pair)
+  cwp.enabled = cwl.enabled = any ? 1 : 0;
+  *weighted_out = any;
+  for (int i = 0; i < SUMS_MAX; ++i) sums[i] = 0.0;
+  double s1[SUMS_MAX], s2[SUMS_MAX];
+  if (wp) {
+    CK(cp, hipSetDevice(cp->device));
+    const int rc = accumulate_stored(cp, IM_POINT, L, t, s1, &cwp);
+    if (rc) return rc;
+    for (int i = 28; i < 44; ++i) sums[i] = s1[i];
+    if (!(s1[0] > 0.0)) sums[43] = 0.0;
+  }
+  if (wl) {
+    CK(cl, hipSetDevice(cl->device));
+    const int rc = accumulate_stored(cl, IM_PLANE, L, t, s2, &cwl);
+    if (rc) { if (cl != cp) cp->err = cl->err; return rc; }
+    for (int i = 0; i < 28; ++i) sums[i] = s2[i];
+  }
+  // slot 0 = the plane set's count; the point set's count travels in slot 43 (sum of the unit weights) -- keep a copy where
+  // the caller can tell "no point correspondences" from "no plane correspondences"
+  sums[44] = wp ? s1[0] : 0.0;
+  return CILHIP_OK;
+}
+
+int cilhip_estimate_combined_two_sets(cilhip_ctx* cp, cilhip_ctx* cl, float w_p2p, float w_p2pl, size_t max_iter, float conv_tol, float dT[16],
+                                      int* converged) {
+  if (!cp || !cl || !dT) return CILHIP_ERR_INVALID;
+  static_assert(SUMS_MAX >= 45, "slot 44 carries the point set's count");
+  { int prc = materialize_pending(cp); if (prc) return prc; prc = materialize_pending(cl); if (prc) { cp->err = cl->err; return prc; } }
+  if (!cp->have_nn || !cl->have_nn)
+    return fail(cp, CILHIP_ERR_INVALID, "estimate (two sets): both engines need stored SECOND_TO_FIRST correspondences (find_correspondences first)");
+  if (memcmp(cp->nn_T, cl->nn_T, sizeof(cp->nn_T)) != 0) return fail(cp, CILHIP_ERR_INVALID, "estimate (two sets): the two engines searched under different transforms");
+  if (cp->ns != cl->ns || cp->grid.n != cl->grid.n) return fail(cp, CILHIP_ERR_INVALID, "estimate (two sets): the two engines hold different clouds");
+  double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+  memcpy(dT, kIdentity, sizeof(kIdentity));
+  if (converged) *converged = 0;
+  bool wp = w_p2p > 0.0f, wl = w_p2pl > 0.0f;
+  if (!wp && !wl) return CILHIP_OK;                      // transform_estimation.hpp:264-272
+  float smt[3];
+  transform_point(cp->nn_T, cp->src_mean[0], cp->src_mean[1], cp->src_mean[2], smt[0], smt[1], smt[2]);
+  int conv = 0;
+  const size_t steps = max_iter ? max_iter : 1;          // (max_iter 0: one pass for the "no usable terms" test only)
+  for (size_t it = 0; it < steps; ++it) {
+    double sums[SUMS_MAX];
+    bool weighted_sums = false;
+    const int rc = combined_two_sets_step(cp, cl, wp, wl, w_p2p, w_p2pl, L, t, sums, &weighted_sums);
+    if (rc) return rc;
+    const bool has_p2p = wp && sums[44] > 0.0, has_p2pl = wl && sums[0] > 0.0;     // :264-267
+    if ((!has_p2p && !has_p2pl) || (has_p2pl && !cl->has_normals)) return CILHIP_OK;   // :269-272: identity, false
+    if (max_iter == 0) break;
+    double AtA[36], Atb[6], dth[6];
+    if (weighted_sums) gn_normal_equations(sums, has_p2p ? 1.0 : 0.0, has_p2pl ? 1.0 : 0.0, AtA, Atb, true);
+    else gn_normal_equations(sums, has_p2p ? (double)w_p2p : 0.0, has_p2pl ? (double)w_p2pl : 0.0, AtA, Atb, true);
+    ldlt6_solve(AtA, Atb, dth);
+    rigid_gn_update(dth, L, t);
+    double nrm = 0.0;
+    for (int i = 0; i < 6; ++i) nrm += dth[i] * dth[i];
+    if (std::sqrt(nrm) < (double)conv_tol) { conv = 1; break; }
+  }
+  double tt[3];
+  for (int r = 0; r < 3; ++r)
+    tt[r] = t[r] - (L[r * 3] * (double)smt[0] + L[r * 3 + 1] * (double)smt[1] + L[r * 3 + 2] * (double)smt[2]) + (double)cp->dst_mean[r];
+  pack_T(L, tt, dT);
+  if (converged) *converged = conv;
+  return CILHIP_OK;
+}
+
+// CombinedMetricSingleTransformICP over a Combiner (icp_single_transform_combined_metric.hpp:169-217 with the engine of
+// correspondence_search_combined_metric_combiner.hpp): per iteration both engines search under the current transform (each with
+// its own radius and options), the estimator reads the two sets, the instance class composes and tests the update norm.
+// Host-driven: a few synchronisations per iteration -- this is the reference's thin combination class, not the hot path.
+int cilhip_icp_run_two_sets(cilhip_ctx* cp, float max_sq_point, cilhip_ctx* cl, float max_sq_plane, const cilhip_icp_params* p, const float* T0,
+                            cilhip_icp_result* out) {
+  if (!cp || !cl || !p || !out) return CILHIP_ERR_INVALID;
+  if (p->metric != CILHIP_METRIC_COMBINED) return fail(cp, CILHIP_ERR_INVALID, "icp_run (two sets): the combined metric is what takes two correspondence sets");
+  if (cp->transform_mode != 0 || cl->transform_mode != 0) return fail(cp, CILHIP_ERR_UNSUPPORTED, "icp_run (two sets): rigid transforms");
+  if (cp->search_dir != 0 || cl->search_dir != 0) return fail(cp, CILHIP_ERR_UNSUPPORTED, "icp_run (two sets): SECOND_TO_FIRST engines");
+  float T[16];
+  memcpy(T, T0 ? T0 : kIdentity, sizeof(T));
+  memcpy(out->T, T, sizeof(T));
+  out->iterations = 0; out->last_delta_norm = INFINITY; out->last_ncorr = 0;
+  for (size_t it = 0; it < p->max_iter; ++it) {
+    size_t n1 = 0, n2 = 0;
+    int rc = cilhip_find_correspondences(cp, T, max_sq_point, &n1);
+    if (rc) return rc;
+    if (cl != cp) { rc = cilhip_find_correspondences(cl, T, max_sq_plane, &n2); if (rc) { cp->err = cl->err; return rc; } } else n2 = n1;
+    float dT[16];
+    int conv = 0;
+    rc = cilhip_estimate_combined_two_sets(cp, cl, p->w_p2p, p->w_p2pl, p->max_opt_iter, p->opt_conv_tol, dT, &conv);
+    if (rc) return rc;
+    double L[9], t[3];
+    for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) L[r * 3 + k] = (double)dT[k * 4 + r]; t[r] = (double)dT[12 + r]; }
+    float Tn[16];
+    const float delta = compose_update(L, t, T, Tn);      // rotation() polish, transform_ = tform_iter * transform_, update norm (:207-216)
+    memcpy(T, Tn, sizeof(T));
+    out->iterations = it + 1; out->last_delta_norm = delta; out->last_ncorr = n1 > n2 ? n1 : n2;
+    if (delta < p->conv_tol) break;                       // icp_base.hpp:83
+  }
+  memcpy(out->T, T, sizeof(T));
+  return CILHIP_OK;
+}
+
 static hipEvent_t get_event(cilhip_ctx* c, size_t i);
 static hipEvent_t get_acc_event(cilhip_ctx* c, size_t i);
 

@@ -653,6 +653,105 @@ class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
                                            self.transform_)
 
 
+class CorrespondenceSearchCombinedMetricCombiner:
+    """registration/correspondence_search_combined_metric_combiner.hpp:8-81: one engine finds the correspondences of the
+    combined metric's point-to-point terms, another those of its point-to-plane terms (own radius, post-filters, feature
+    adaptors).  Both engines hold the same two clouds (make_engine builds one more over them); the same object twice is the
+    single-engine case (:33-43)."""
+
+    def __init__(self, point_to_point_corr_search, point_to_plane_corr_search):
+        self.point_to_point_corr_search_ = point_to_point_corr_search
+        self.point_to_plane_corr_search_ = point_to_plane_corr_search
+
+    @staticmethod
+    def make_engine(dst_points, dst_normals, src_points, device=0, stream=None):
+        """a CorrespondenceSearchHIP over its own context holding the two clouds"""
+        ctx = Context(device, stream)
+        ctx.set_target(dst_points, dst_normals)
+        ctx.set_source(src_points)
+        return CorrespondenceSearchHIP(ctx)
+
+    def findCorrespondences(self, tform=None):
+        self.point_to_point_corr_search_.findCorrespondences(tform)
+        if self.point_to_plane_corr_search_ is not self.point_to_point_corr_search_:
+            self.point_to_plane_corr_search_.findCorrespondences(tform)
+        return self
+
+    def getPointToPointCorrespondences(self):
+        return self.point_to_point_corr_search_.getCorrespondences()
+
+    def getPointToPlaneCorrespondences(self):
+        return self.point_to_plane_corr_search_.getCorrespondences()
+
+    def pointToPointCorrespondenceSearchEngine(self):
+        return self.point_to_point_corr_search_
+
+    def pointToPlaneCorrespondenceSearchEngine(self):
+        return self.point_to_plane_corr_search_
+
+
+class CombinedMetricRigidICP3f(_IterativeClosestPointBase):
+    """CombinedMetricSingleTransformICP (registration/icp_single_transform_combined_metric.hpp:8-243) handed its correspondence
+    search engine instead of owning one -- here a CorrespondenceSearchCombinedMetricCombiner over two engines.  Defaults :44-47."""
+
+    def __init__(self, combiner):
+        # (no context of its own: the two engines' contexts hold the clouds)
+        self._combiner = combiner
+        self._engine = combiner
+        self._ctx = combiner.point_to_point_corr_search_._ctx
+        self.max_iterations_ = 15
+        self.convergence_tol_ = np.float32(1e-5)
+        self.iterations_ = 0
+        self.last_delta_norm_ = np.float32(np.inf)
+        self.transform_init_ = np.eye(4, dtype=np.float32)
+        self.transform_ = np.eye(4, dtype=np.float32)
+        self.last_ncorr_ = 0
+        self.max_optimization_iterations_ = 1
+        self.optimization_convergence_tol_ = np.float32(1e-5)
+        self.point_to_point_weight_ = np.float32(0.0)
+        self.point_to_plane_weight_ = np.float32(1.0)
+
+    def setPointToPointMetricWeight(self, w):
+        self.point_to_point_weight_ = np.float32(w)
+        return self
+
+    def setPointToPlaneMetricWeight(self, w):
+        self.point_to_plane_weight_ = np.float32(w)
+        return self
+
+    def setMaxNumberOfOptimizationStepIterations(self, n):
+        self.max_optimization_iterations_ = int(n)
+        return self
+
+    def setOptimizationStepConvergenceTolerance(self, tol):
+        self.optimization_convergence_tol_ = np.float32(tol)
+        return self
+
+    def estimate(self, max_iter=None, conv_tol=None):
+        if max_iter is not None:
+            self.max_iterations_ = int(max_iter)
+        if conv_tol is not None:
+            self.convergence_tol_ = np.float32(conv_tol)
+        e1, e2 = self._combiner.point_to_point_corr_search_, self._combiner.point_to_plane_corr_search_
+        p = capi.IcpParams()
+        self._ctx._L.cilhip_icp_default_params(C.byref(p))
+        p.metric = capi.METRIC_COMBINED
+        p.w_p2p, p.w_p2pl = float(self.point_to_point_weight_), float(self.point_to_plane_weight_)
+        p.max_iter, p.conv_tol = self.max_iterations_, float(self.convergence_tol_)
+        p.max_opt_iter, p.opt_conv_tol = self.max_optimization_iterations_, float(self.optimization_convergence_tol_)
+        res = capi.IcpResult()
+        T0 = _T_to_abi(self.transform_init_)
+        self._ctx._ck(self._ctx._L.cilhip_icp_run_two_sets(e1._ctx._h, float(e1.max_distance_), e2._ctx._h, float(e2.max_distance_), C.byref(p),
+                                                          T0.ctypes.data_as(C.c_void_p), C.byref(res)))
+        e1._corr = None
+        e2._corr = None
+        self.transform_ = _T_from_abi(res.T[:])
+        self.iterations_ = int(res.iterations)
+        self.last_delta_norm_ = np.float32(res.last_delta_norm)
+        self.last_ncorr_ = int(res.last_ncorr)
+        return self
+
+
 class SimplePointToPointMetricAffineICP3f(SimplePointToPointMetricRigidICP3f):
     """registration/icp_common_instances.hpp:255: the same loop and correspondence engine with an AffineTransform --
     the step is the affine closed form on the raw coordinates (transform_estimation.hpp:50-102), no rotation() polish."""

@@ -352,6 +352,18 @@ typedef struct {
   double build_ms;       /* last set_target wall time (upload + grid build) */
 } cilhip_grid_info;
 int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
+/* CorrespondenceSearchCombinedMetricCombiner (registration/correspondence_search_combined_metric_combiner.hpp:8-81): the combined
+ * metric's point-to-point terms read ONE engine's correspondence set, its point-to-plane terms ANOTHER's (own radius, feature
+ * adaptors, post-filters) over the same two clouds.  Both contexts hold the same target / source and SECOND_TO_FIRST matches
+ * found under the same transform (cilhip_find_correspondences on each); ctx_point == ctx_plane is the single-engine case.
+ * cilhip_estimate_combined_two_sets = estimateTransformCombinedMetric with its two set arguments
+ * (registration/transform_estimation.hpp:237-367); cilhip_icp_run_two_sets = the ICP loop of
+ * icp_single_transform_combined_metric.hpp:169-217 with that engine (host-driven: both searches, the estimate, compose, test). */
+int cilhip_estimate_combined_two_sets(cilhip_ctx* ctx_point, cilhip_ctx* ctx_plane, float w_p2p, float w_p2pl, size_t max_iter, float conv_tol,
+                                      float dT[16], int* converged);
+int cilhip_icp_run_two_sets(cilhip_ctx* ctx_point, float max_sq_point, cilhip_ctx* ctx_plane, float max_sq_plane, const cilhip_icp_params* p,
+                            const float* T0, cilhip_icp_result* out);
+
 /* How the iterations of the last cilhip_icp_run were executed: as ONE pass (search with the accumulation inside the LDS
  * tiles) or as TWO (search with its in-tile 3x3x3 second pass, then the streaming accumulation).  Large clouds choose per
  * iteration from the device's count of queries the first search stage left unproven (source far from alignment: two passes).

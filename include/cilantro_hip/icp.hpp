@@ -244,6 +244,7 @@ public:
   }
 
   void setSourceCount_(size_t n) { capacity_ += n; }  // internal: result capacity (called with both cloud sizes)
+  cilhip_ctx* context() const { return ctx_; }        // (extension)
 
 private:
   cilhip_ctx* ctx_;
@@ -452,6 +453,99 @@ private:
 // AffineTransform -- the step is the 12-unknown closed form (transform_estimation.hpp:50-102 on the raw coordinates for
 // the point-to-point class, :369-476 with the means for the combined class) and there is no rotation() polish.  The 4x4
 // holder type is shared with the rigid instances (AffineTransform3f below): its linear part is then a general 3x3 matrix.
+// A correspondence search engine that OWNS its context and clouds: what a user builds beside an ICP object's own engine, e.g. the
+// two engines of a CorrespondenceSearchCombinedMetricCombiner (the reference constructs CorrespondenceSearchKDTree objects over
+// feature adaptors of the same clouds, correspondence_search_kd_tree.hpp:25-45).
+class CorrespondenceSearchHIPOwned : private internal::CtxPtr, public CorrespondenceSearchHIP {
+public:
+  CorrespondenceSearchHIPOwned(const ConstPointsView& dst_p, const ConstPointsView& dst_n, const ConstPointsView& src_p, int device = 0)
+      : internal::CtxPtr(internal::make_ctx(device)), CorrespondenceSearchHIP(internal::CtxPtr::get()) {
+    if (dst_n.cols() && dst_n.cols() != dst_p.cols()) throw std::invalid_argument("dst normals must match dst points");
+    internal::check(context(), cilhip_set_target(context(), dst_p.data(), dst_n.cols() ? dst_n.data() : nullptr, dst_p.cols(), CILHIP_MEM_HOST), "set_target");
+    internal::check(context(), cilhip_set_source(context(), src_p.data(), src_p.cols(), CILHIP_MEM_HOST), "set_source");
+    setSourceCount_(src_p.cols());
+    setSourceCount_(dst_p.cols());
+  }
+};
+
+// registration/correspondence_search_combined_metric_combiner.hpp:8-81: the point-to-point terms of the combined metric read one
+// engine's correspondences, the point-to-plane terms another's.  Both engines hold the same two clouds.
+template <class PointToPointCorrespondenceSearchT, class PointToPlaneCorrespondenceSearchT>
+class CorrespondenceSearchCombinedMetricCombiner {
+public:
+  using PointToPointCorrespondenceSearch = PointToPointCorrespondenceSearchT;
+  using PointToPlaneCorrespondenceSearch = PointToPlaneCorrespondenceSearchT;
+  using PointToPointCorrespondenceSearchResult = typename PointToPointCorrespondenceSearchT::SearchResult;
+  using PointToPlaneCorrespondenceSearchResult = typename PointToPlaneCorrespondenceSearchT::SearchResult;
+
+  CorrespondenceSearchCombinedMetricCombiner(PointToPointCorrespondenceSearch& point_to_point_corr_search,
+                                             PointToPlaneCorrespondenceSearch& point_to_plane_corr_search)
+      : point_to_point_corr_search_(point_to_point_corr_search), point_to_plane_corr_search_(point_to_plane_corr_search) {}
+
+  bool sameEngine() const { return (const void*)&point_to_point_corr_search_ == (const void*)&point_to_plane_corr_search_; }
+  CorrespondenceSearchCombinedMetricCombiner& findCorrespondences() { return findCorrespondences(RigidTransform3f::Identity()); }
+  template <class TransformT>
+  CorrespondenceSearchCombinedMetricCombiner& findCorrespondences(const TransformT& tform) {      // :46-58
+    point_to_point_corr_search_.findCorrespondences(tform);
+    if (!sameEngine()) point_to_plane_corr_search_.findCorrespondences(tform);
+    return *this;
+  }
+  const PointToPointCorrespondenceSearchResult& getPointToPointCorrespondences() const { return point_to_point_corr_search_.getCorrespondences(); }
+  const PointToPlaneCorrespondenceSearchResult& getPointToPlaneCorrespondences() const { return point_to_plane_corr_search_.getCorrespondences(); }
+  PointToPointCorrespondenceSearch& pointToPointCorrespondenceSearchEngine() { return point_to_point_corr_search_; }
+  PointToPlaneCorrespondenceSearch& pointToPlaneCorrespondenceSearchEngine() { return point_to_plane_corr_search_; }
+
+private:
+  PointToPointCorrespondenceSearch& point_to_point_corr_search_;
+  PointToPlaneCorrespondenceSearch& point_to_plane_corr_search_;
+};
+
+// CombinedMetricSingleTransformICP handed its engine (icp_single_transform_combined_metric.hpp:8-243, rigid 3-D instance) -- here
+// a Combiner over two CorrespondenceSearchHIP engines: cilhip_icp_run_two_sets runs the loop (both searches, the estimator over
+// the two sets, compose, convergence test per iteration).  Defaults :44-47, icp_base.hpp:24-25.
+template <class CombinerT>
+class CombinedMetricRigidICP3f {
+public:
+  explicit CombinedMetricRigidICP3f(CombinerT& combiner) : combiner_(combiner) {}
+  CombinerT& correspondenceSearchEngine() { return combiner_; }
+  CombinedMetricRigidICP3f& setMaxNumberOfIterations(size_t n) { max_iterations_ = n; return *this; }
+  CombinedMetricRigidICP3f& setConvergenceTolerance(float t) { convergence_tol_ = t; return *this; }
+  CombinedMetricRigidICP3f& setPointToPointMetricWeight(float w) { point_to_point_weight_ = w; return *this; }
+  CombinedMetricRigidICP3f& setPointToPlaneMetricWeight(float w) { point_to_plane_weight_ = w; return *this; }
+  CombinedMetricRigidICP3f& setMaxNumberOfOptimizationStepIterations(size_t n) { max_optimization_iterations_ = n; return *this; }
+  CombinedMetricRigidICP3f& setOptimizationStepConvergenceTolerance(float t) { optimization_convergence_tol_ = t; return *this; }
+  template <class TransformT>
+  CombinedMetricRigidICP3f& setInitialTransform(const TransformT& t) { internal::to_abi(t, transform_init_.m); return *this; }
+  CombinedMetricRigidICP3f& estimate() {
+    cilhip_icp_params p;
+    cilhip_icp_default_params(&p);
+    p.metric = CILHIP_METRIC_COMBINED;
+    p.w_p2p = point_to_point_weight_; p.w_p2pl = point_to_plane_weight_;
+    p.max_iter = max_iterations_; p.conv_tol = convergence_tol_;
+    p.max_opt_iter = max_optimization_iterations_; p.opt_conv_tol = optimization_convergence_tol_;
+    auto& e1 = combiner_.pointToPointCorrespondenceSearchEngine();
+    auto& e2 = combiner_.pointToPlaneCorrespondenceSearchEngine();
+    cilhip_icp_result r;
+    internal::check(e1.context(), cilhip_icp_run_two_sets(e1.context(), e1.getMaxDistance(), e2.context(), e2.getMaxDistance(), &p, transform_init_.m, &r),
+                    "estimate (two correspondence sets)");
+    e1.invalidateFetched(); e2.invalidateFetched();
+    std::memcpy(transform_.m, r.T, sizeof(r.T));
+    iterations_ = r.iterations; last_delta_norm_ = r.last_delta_norm;
+    return *this;
+  }
+  const RigidTransform3f& getTransform() const { return transform_; }
+  size_t getNumberOfPerformedIterations() const { return iterations_; }
+  float getLastUpdateNorm() const { return last_delta_norm_; }
+  bool hasConverged() const { return last_delta_norm_ < convergence_tol_; }
+
+private:
+  CombinerT& combiner_;
+  size_t max_iterations_ = 15, iterations_ = 0, max_optimization_iterations_ = 1;
+  float convergence_tol_ = 1e-5f, optimization_convergence_tol_ = 1e-5f, point_to_point_weight_ = 0.0f, point_to_plane_weight_ = 1.0f;
+  float last_delta_norm_ = std::numeric_limits<float>::infinity();
+  RigidTransform3f transform_init_, transform_;
+};
+
 typedef RigidTransform3f AffineTransform3f;
 
 class SimplePointToPointMetricAffineICP3f : public SimplePointToPointMetricRigidICP3f {

@@ -797,6 +797,54 @@ int orc_estimate_combined_w(const float* dst_p, const float* dst_n, const float*
   return ok;
 }
 
+/* two correspondence sets: the point terms from (di, si, n), the plane terms from (dil, sil, nl) -- see estimate_combined2 */
+int orc_estimate_combined_two_sets(const float* dst_p, const float* dst_n, const float* src_p, const int64_t* di, const int64_t* si, size_t n,
+                                   const int64_t* dil, const int64_t* sil, size_t nl, float w_p2p, float w_p2pl, size_t max_iter, float conv_tol,
+                                   const float dst_mean[3], const float src_mean[3], int mode, float T_out[16]) {
+  int ok;
+  if (mode == ORC_MODE_F32) {
+    float L[9], t[3];
+    ok = estimate_combined2_m0(dst_p, dst_n, src_p, NULL, di, si, n, dil, sil, nl, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, NULL, NULL, NULL, NULL, NULL);
+    pack_T_f32(L, t, T_out);
+  } else if (mode == ORC_MODE_MIXED) {
+    double L[9], t[3];
+    ok = estimate_combined2_m1(dst_p, dst_n, src_p, NULL, di, si, n, dil, sil, nl, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, NULL, NULL, NULL, NULL, NULL);
+    pack_T_f64(L, t, T_out);
+  } else {
+    double L[9], t[3];
+    ok = estimate_combined2_m2(dst_p, dst_n, src_p, NULL, di, si, n, dil, sil, nl, w_p2p, w_p2pl, max_iter, conv_tol, dst_mean, src_mean, L, t, NULL, NULL, NULL, NULL, NULL);
+    pack_T_f64(L, t, T_out);
+  }
+  return ok;
+}
+/* one iteration of CombinedMetricSingleTransformICP over a Combiner's two sets (icp_single_transform_combined_metric.hpp:191-216) */
+float orc_icp_update_two_sets(const float* dst_p, const float* dst_n, size_t nd, const float* src_p, size_t ns, const float T_cur[16],
+                              const int64_t* di, const int64_t* si, size_t n, const int64_t* dil, const int64_t* sil, size_t nl,
+                              const orc_icp_params* prm, float T_new[16]) {
+  float dst_mean[3], src_mean[3], smt[3];
+  orc_mean3(dst_p, nd, prm->mode, dst_mean);
+  orc_mean3(src_p, ns, prm->mode, src_mean);
+  float* src_trans = (float*)malloc(3 * (ns ? ns : 1) * sizeof(float));
+  orc_transform_points(T_cur, src_p, ns, src_trans);
+  orc_transform_points(T_cur, src_mean, 1, smt);
+  float d;
+  if (prm->mode == ORC_MODE_F32) {
+    float L[9], t[3];
+    estimate_combined2_m0(dst_p, dst_n, src_trans, NULL, di, si, n, dil, sil, nl, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL, NULL, NULL, NULL);
+    d = compose_m0(L, t, T_cur, T_new);
+  } else if (prm->mode == ORC_MODE_MIXED) {
+    double L[9], t[3];
+    estimate_combined2_m1(dst_p, dst_n, src_trans, NULL, di, si, n, dil, sil, nl, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL, NULL, NULL, NULL);
+    d = compose_m1(L, t, T_cur, T_new);
+  } else {
+    double L[9], t[3];
+    estimate_combined2_m2(dst_p, dst_n, src_trans, NULL, di, si, n, dil, sil, nl, prm->w_p2p, prm->w_p2pl, prm->max_opt_iter, prm->opt_conv_tol, dst_mean, smt, L, t, NULL, NULL, NULL, NULL, NULL);
+    d = compose_m2(L, t, T_cur, T_new);
+  }
+  free(src_trans);
+  return d;
+}
+
 int orc_estimate_combined(const float* dst_p, const float* dst_n, const float* src_p, const float* src_n,
                           const int64_t* di, const int64_t* si, size_t n, float w_p2p, float w_p2pl,
                           size_t max_iter, float conv_tol, const float dst_mean[3],

@@ -117,6 +117,14 @@ int orc_estimate_combined(const float* dst_xyz, const float* dst_nrm, const floa
                           const float dst_mean[3], const float src_mean[3], int mode,
                           float T_out[16], double* AtA_out, double* Atb_out);
 
+/* Two correspondence sets, as a CorrespondenceSearchCombinedMetricCombiner hands them over
+ * (registration/correspondence_search_combined_metric_combiner.hpp:8-81): point terms from (dst_idx, src_idx, ncorr), plane terms
+ * from (dst_idx_pl, src_idx_pl, ncorr_pl); unity evaluators. */
+int orc_estimate_combined_two_sets(const float* dst_xyz, const float* dst_nrm, const float* src_trans_xyz, const int64_t* dst_idx,
+                                   const int64_t* src_idx, size_t ncorr, const int64_t* dst_idx_pl, const int64_t* src_idx_pl, size_t ncorr_pl,
+                                   float w_p2p, float w_p2pl, size_t max_iter, float conv_tol, const float dst_mean[3], const float src_mean[3],
+                                   int mode, float T_out[16]);
+
 /* The same with weight evaluators: val[k] = value of correspondence k (its search distance), wt = the evaluators. */
 int orc_estimate_combined_w(const float* dst_xyz, const float* dst_nrm, const float* src_trans_xyz,
                             const float* src_nrm_trans, const int64_t* dst_idx, const int64_t* src_idx, size_t ncorr,
@@ -200,6 +208,10 @@ float orc_icp_update(const float* dst_xyz, const float* dst_nrm, size_t nd, cons
                      const int64_t* src_idx, size_t ncorr, const orc_icp_params* prm,
                      float T_new[16]);
 
+/* ... over a Combiner's two sets (point terms / plane terms) */
+float orc_icp_update_two_sets(const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz, size_t ns, const float T_cur[16],
+                              const int64_t* dst_idx, const int64_t* src_idx, size_t ncorr, const int64_t* dst_idx_pl, const int64_t* src_idx_pl,
+                              size_t ncorr_pl, const orc_icp_params* prm, float T_new[16]);
 /* orc_icp_update with the correspondences' values (read by prm's weight evaluators; NULL = unity). */
 float orc_icp_update_w(const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz,
                        const float* src_nrm_or_null, size_t ns, const float T_cur[16], const int64_t* dst_idx,

@@ -120,6 +120,9 @@ def lib():
         L.orc_icp_update_w.restype = C.c_float
         L.orc_icp_update_w.argtypes = [_f32p, C.c_void_p, C.c_size_t, _f32p, C.c_void_p, C.c_size_t, _f32p, _i64p,
                                        _i64p, C.c_void_p, C.c_size_t, C.POINTER(IcpParams), _f32p]
+        L.orc_icp_update_two_sets.restype = C.c_float
+        L.orc_icp_update_two_sets.argtypes = [_f32p, _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p, _i64p, _i64p, C.c_size_t, _i64p, _i64p, C.c_size_t,
+                                              C.POINTER(IcpParams), _f32p]
         L.orc_pinned_expf.restype = C.c_float
         L.orc_pinned_expf.argtypes = [C.c_float]
         L.orc_icp_run.restype = C.c_int
@@ -506,6 +509,15 @@ def icp_update(dst, dst_n, src, T_cur, dst_idx, src_idx, params, src_n=None, val
     d = lib().orc_icp_update_w(dst, dn.ctypes.data if dn is not None else None, len(dst), src,
                                sn.ctypes.data if sn is not None else None, len(src),
                                T_to_colmajor(T_cur), di, si, val.ctypes.data if val is not None else None, len(di), C.byref(params), Tn)
+    return T_from_colmajor(Tn), float(d)
+
+
+def icp_update_two_sets(dst, dst_n, src, T_cur, dst_idx_pt, src_idx_pt, dst_idx_pl, src_idx_pl, params):
+    """one ICP iteration over a Combiner's two correspondence sets (point terms from the first, plane terms from the second)"""
+    dst = _c(dst).reshape(-1, 3); src = _c(src).reshape(-1, 3); dn = _c(dst_n).reshape(-1, 3)
+    d1 = _c(dst_idx_pt, np.int64); s1 = _c(src_idx_pt, np.int64); d2 = _c(dst_idx_pl, np.int64); s2 = _c(src_idx_pl, np.int64)
+    Tn = np.zeros(16, np.float32)
+    d = lib().orc_icp_update_two_sets(dst, dn, len(dst), src, len(src), T_to_colmajor(T_cur), d1, s1, len(d1), d2, s2, len(d2), C.byref(params), Tn)
     return T_from_colmajor(Tn), float(d)
 
 

@@ -215,6 +215,29 @@ int main(int argc, char** argv) {
     const double e5 = frob(icp5.getTransform().m, r.T);
     std::printf("affine point-to-point: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp5.getNumberOfPerformedIterations(), r.iterations, e5);
     if (!(e5 <= 1e-4) || icp5.getNumberOfPerformedIterations() != r.iterations) ++failures;
+    {
+      // CorrespondenceSearchCombinedMetricCombiner over two engines that own their contexts (correspondence_search_combined_metric_combiner.hpp):
+      // the same options on both = the single-engine class; a tighter point engine changes the estimate
+      CorrespondenceSearchHIPOwned e_pt(dst_v, nrm_v, src_v), e_pl(dst_v, nrm_v, src_v);
+      e_pt.setMaxDistance(max_sq); e_pl.setMaxDistance(max_sq);
+      CorrespondenceSearchCombinedMetricCombiner<CorrespondenceSearchHIPOwned, CorrespondenceSearchHIPOwned> comb(e_pt, e_pl);
+      CombinedMetricRigidICP3f<decltype(comb)> icp7(comb);
+      icp7.setPointToPointMetricWeight(0.2f).setPointToPlaneMetricWeight(1.0f).setMaxNumberOfIterations(5).setConvergenceTolerance(0.0f).estimate();
+      SimpleCombinedMetricRigidICP3f icp8(dst_v, nrm_v, src_v);
+      icp8.setPointToPointMetricWeight(0.2f).setPointToPlaneMetricWeight(1.0f);
+      icp8.correspondenceSearchEngine().setMaxDistance(max_sq);
+      icp8.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0f).estimate();
+      const double e7 = frob(icp7.getTransform().m, icp8.getTransform().m);
+      comb.findCorrespondences(icp7.getTransform());
+      const size_t n_pt = comb.getPointToPointCorrespondences().size(), n_pl = comb.getPointToPlaneCorrespondences().size();
+      e_pt.setMaxDistance(max_sq * 0.0004f);      // (0.04 h: inside the +-0.05 h noise of the recipe)
+      icp7.estimate();
+      comb.findCorrespondences(icp7.getTransform());
+      const size_t n_pt2 = comb.getPointToPointCorrespondences().size();
+      std::printf("combiner: same engines vs single-engine class |dT|_F=%.3e, sets %zu / %zu, tighter point engine %zu, iterations %zu\n", e7, n_pt, n_pl, n_pt2,
+                  icp7.getNumberOfPerformedIterations());
+      if (!(e7 <= 2e-6) || n_pt != n_pl || !(n_pt2 < n_pt) || icp7.getNumberOfPerformedIterations() != 5) ++failures;
+    }
   } catch (const std::runtime_error& e) {
     if (expect_no_device) { std::printf("OK (failed loudly): %s\n", e.what()); return 0; }
     std::printf("FAIL: %s\n", e.what());

@@ -1869,3 +1869,79 @@ def test_point_normal_color_features_9d_vs_oracle(Context, orc, hip_lib):
     dst6 = orc.point_normal_features(dst, dst_n, wn)
     want = orc.find_correspondences_feat6_dir(dst6, orc.transform_features6(T_rigid, orc.point_normal_features(src, src_n, wn), 0), r2, 1)
     assert lists_equal(got, want)
+
+
+def test_combined_metric_combiner_two_correspondence_sets_vs_oracle(Context, orc, hip_lib):
+    """CorrespondenceSearchCombinedMetricCombiner (registration/correspondence_search_combined_metric_combiner.hpp:8-81): the
+    combined metric's point-to-point terms from ONE engine's correspondences, its point-to-plane terms from ANOTHER's -- here a
+    tighter radius and the inlier-fraction + one-to-one post-filters on the point engine, the plain search on the plane engine.
+    One estimate (cilhip_estimate_combined_two_sets, several Gauss-Newton steps) and the whole loop (cilhip_icp_run_two_sets)
+    against the oracle's two-set restatement of transform_estimation.hpp:237-367 driven with the oracle's own searches; the
+    same engine twice equals the single-engine class."""
+    from cilantro_amd.icp import CombinedMetricRigidICP3f, CorrespondenceSearchCombinedMetricCombiner, SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(60000, perturb=0.6)
+    dst, dst_n, src, h = d["dst"], d["dst_n"], d["src"], d["h"]
+    r_pt, r_pl = np.float32((1.1 * h) ** 2), np.float32((2.0 * h) ** 2)
+    w_pt, w_pl = 0.35, 1.0
+    make = CorrespondenceSearchCombinedMetricCombiner.make_engine
+    e_pt = make(dst, dst_n, src); e_pt.setMaxDistance(r_pt).setInlierFraction(0.8).setOneToOne(True)
+    e_pl = make(dst, dst_n, src); e_pl.setMaxDistance(r_pl)
+    comb = CorrespondenceSearchCombinedMetricCombiner(e_pt, e_pl)
+    tree = orc.KDTree(dst, use_ref=orc.ref_available())
+
+    def oracle_sets(T):
+        q = orc.transform_points(T, src)
+        a1, a2, av = tree.find_correspondences(q, float(r_pt))
+        a1, a2, av = orc.filter_fraction(a1, a2, av, 0.8)
+        a1, a2, av = orc.filter_one_to_one(a1, a2, av)
+        b1, b2, bv = tree.find_correspondences(q, float(r_pl))
+        return (a1, a2), (b1, b2)
+
+    # (1) the two lists, then one estimate with three Gauss-Newton steps
+    T0 = np.eye(4, dtype=np.float32)
+    comb.findCorrespondences(T0)
+    (a1, a2), (b1, b2) = oracle_sets(T0)
+    g1 = comb.getPointToPointCorrespondences(); g2 = comb.getPointToPlaneCorrespondences()
+    assert np.array_equal(g1[0], a1) and np.array_equal(g1[1], a2) and np.array_equal(g2[0], b1) and np.array_equal(g2[1], b2)
+    assert 0 < len(a1) < len(b1)
+    T = np.zeros(16, np.float32); cv = C.c_int(0)
+    L = e_pt._ctx._L
+    e_pt._ctx._ck(L.cilhip_estimate_combined_two_sets(e_pt._ctx._h, e_pl._ctx._h, w_pt, w_pl, 3, 0.0, T.ctypes.data_as(C.c_void_p), C.byref(cv)))
+    po = orc.make_params(metric=1, w_p2p=w_pt, w_p2pl=w_pl, max_iter=1, conv_tol=0.0, max_sq_dist=float(r_pl), mode=orc.MODE_MIXED)
+    po.max_opt_iter, po.opt_conv_tol = 3, 0.0
+    To, _ = orc.icp_update_two_sets(dst, dst_n, src, T0, a1, a2, b1, b2, po)
+    # (the estimate is the un-composed step: compare it through the composed update of the oracle with an identity start, whose
+    #  polish only removes round-off)
+    assert np.linalg.norm(T.reshape(4, 4).T.astype(np.float64) - To.astype(np.float64)) <= 2e-6
+
+    # (2) the loop
+    icp = CombinedMetricRigidICP3f(comb)
+    icp.setPointToPointMetricWeight(w_pt).setPointToPlaneMetricWeight(w_pl).setMaxNumberOfIterations(6).setConvergenceTolerance(0.0)
+    Tg = icp.estimate().getTransform()
+    po.max_opt_iter, po.opt_conv_tol = 1, 1e-5
+    To = np.eye(4, dtype=np.float32)
+    for _ in range(6):
+        (a1, a2), (b1, b2) = oracle_sets(To)
+        To, dn = orc.icp_update_two_sets(dst, dst_n, src, To, a1, a2, b1, b2, po)
+    err = float(np.linalg.norm(Tg.astype(np.float64) - To.astype(np.float64)))
+    assert err <= TOL_T and icp.getNumberOfPerformedIterations() == 6, err
+    assert abs(float(icp.getLastUpdateNorm()) - dn) <= 1e-6
+    # a weight of zero on one side takes that engine's set out of the estimate altogether
+    icp0 = CombinedMetricRigidICP3f(comb).setPointToPointMetricWeight(0.0).setPointToPlaneMetricWeight(1.0).setMaxNumberOfIterations(3).setConvergenceTolerance(0.0)
+    ref = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+    ref.correspondenceSearchEngine().setMaxDistance(r_pl)
+    ref.setPointToPointMetricWeight(0.0).setMaxNumberOfIterations(3).setConvergenceTolerance(0.0)
+    assert np.linalg.norm(icp0.estimate().getTransform().astype(np.float64) - ref.estimate().getTransform().astype(np.float64)) <= 2e-6
+
+    # (3) the same engine twice = the single-engine class (:33-43)
+    same = CorrespondenceSearchCombinedMetricCombiner(e_pl, e_pl)
+    icp2 = CombinedMetricRigidICP3f(same).setPointToPointMetricWeight(w_pt).setPointToPlaneMetricWeight(w_pl).setMaxNumberOfIterations(5).setConvergenceTolerance(0.0)
+    ref2 = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+    ref2.correspondenceSearchEngine().setMaxDistance(r_pl)
+    ref2.setPointToPointMetricWeight(w_pt).setPointToPlaneMetricWeight(w_pl).setMaxNumberOfIterations(5).setConvergenceTolerance(0.0)
+    assert np.linalg.norm(icp2.estimate().getTransform().astype(np.float64) - ref2.estimate().getTransform().astype(np.float64)) <= 2e-6
+    # engines that searched under different transforms are refused
+    e_pt.findCorrespondences(T0); e_pl.findCorrespondences(To)
+    with pytest.raises(Exception):
+        e_pt._ctx._ck(L.cilhip_estimate_combined_two_sets(e_pt._ctx._h, e_pl._ctx._h, w_pt, w_pl, 1, 0.0, T.ctypes.data_as(C.c_void_p), C.byref(cv)))
