@@ -407,6 +407,28 @@ def bench_icp(a, torch, rank, world, local_rank):
                              "achieved": bytes_i / (ms_i * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         except Exception as e:
             extras["independent_source"] = {"error": repr(e)}
+        # the sharded loop driven from C (cilhip_multi_icp_run: what a C / C++ caller with several devices uses) on ONE shard: the cost of
+        # the protocol itself -- three calls per iteration instead of one enqueue-ahead loop -- against `ms_per_step` above
+        try:
+            from cilantro_amd.multi import PARTITION_SLABS, MultiDeviceRigidICP
+            ctx.close()
+            mm = MultiDeviceRigidICP([local_rank])
+            mm.set_clouds(d["dst"], d["dst_n"] if with_normals else None, d["src"], float(d["max_sq_dist"]), PARTITION_SLABS)
+            p.conv_tol = 0.0
+            p.max_iter = a.warmup; mm.icp_run(p, T0, check_every=1 << 20)
+            p.max_iter = a.steps; mm.icp_run(p, T0, check_every=1 << 20)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            rm = mm.icp_run(p, T0, check_every=1 << 20)
+            torch.cuda.synchronize(); dtm = time.perf_counter() - t0
+            Tm = np.array(rm.T[:], np.float32).reshape(4, 4).T
+            extras["multi_device_c_loop_one_shard"] = {
+                "entry": "cilhip_multi_icp_run, devices = [0], spatial slabs (one slab), state read once at the end",
+                "ms_per_step": dtm * 1e3 / a.steps, "icp_iterations_per_sec": a.steps / dtm,
+                "relative_to_cilhip_icp_run": (a.steps / dtm) / (a.steps / dt),
+                "max_abs_T_difference_to_the_timed_run": float(np.abs(Tm - np.array(res.T[:], np.float32).reshape(4, 4).T).max())}
+            mm.close()
+        except Exception as e:
+            extras["multi_device_c_loop_one_shard"] = {"error": repr(e)}
         out.update(extras)
     if rank == 0 and not sharded and not a.no_cpu_baseline:
         try:

@@ -2111,3 +2111,314 @@ int cilhip_get_last_timing(cilhip_ctx* c, double* loop_ms, double* search_ms, in
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// One process, several devices: the sharded protocols of DESIGN.md section 8 driven from C ("devices[]").
+// One context + stream per device; per iteration every context enqueues its partial sums (cilhip_icp_partial_sums), the 48
+// f64 are all-reduced ON THE DEVICES' STREAMS -- RCCL's ncclAllReduce (xGMI between the GPUs of a node), the library opened at
+// run time so that libcilantro_hip.so itself does not depend on it -- and every context applies the same sums
+// (cilhip_icp_apply_sums): identical transforms and convergence decisions everywhere, no host arithmetic in the loop.
+// Partitions: 0 = the source in contiguous shards, the target on every device; 1 = spatial slabs of target (+ halo) and source
+// with the device-side guard and re-partitioning.  Several shards on ONE device (devices[] repeating an
+// ordinal: tests on a single GPU) reduce through a kernel instead of RCCL.
+#include <dlfcn.h>
+
+namespace {
+typedef void* rccl_comm_t;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*CommInitAll)(rccl_comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  bool load() {
+    if (lib) return true;
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return false;
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd;
+  }
+};
+constexpr int RCCL_DOUBLE = 8, RCCL_SUM = 0;      // ncclDouble / ncclSum of rccl.h (ncclDataType_t / ncclRedOp_t)
+
+// out[r][k] = sum over shards of in[s][k], the same order on every shard (all buffers on one device)
+__global__ void k_sum_shards(double* const* bufs, int n) {
+  const int k = threadIdx.x;
+  if (k >= SUMS_MAX) return;
+  double v = 0.0;
+  for (int s = 0; s < n; ++s) v += bufs[s][k];
+  __syncthreads();
+  for (int s = 0; s < n; ++s) bufs[s][k] = v;
+}
+}  // namespace
+
+struct cilhip_multi {
+  int n = 0;
+  std::vector<int> dev;
+  std::vector<cilhip_ctx*> ctx;
+  std::vector<double*> d_sums;
+  bool distinct = true;            // all ordinals different: RCCL; otherwise the same-device reduction
+  RcclApi rccl;
+  std::vector<rccl_comm_t> comms;
+  double** d_bufs = nullptr;       // (same-device reduction) the shards' sum buffers
+  std::vector<hipEvent_t> ev;
+  std::string err;
+  // the clouds (host copies: slabs are cut again when the guard fires)
+  std::vector<float> dst, dstn, src;
+  size_t nd = 0, ns = 0;
+  float max_sq = 0.0f;
+  int partition = 0;
+  // slab partition
+  int axis = 0;
+  double halo = 0.0, slack = 0.0;
+  std::vector<double> bounds;
+  float T_part[16];
+  float src_center[3] = {0, 0, 0}, src_half[3] = {0, 0, 0}, gdm[3] = {0, 0, 0}, gsm[3] = {0, 0, 0};
+  int repartitions = 0;
+  double slack_opt = -1.0;         // cilhip_multi_set_slab_slack (< 0: twice the search radius)
+  std::vector<size_t> n_dst_local, n_src_local;
+};
+
+static int mfail(cilhip_multi* m, int code, const std::string& msg) { if (m) m->err = msg; return code; }
+#define MCK(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mfail((m), CILHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define MCTX(m, r, call) do { const int rc_ = (call); if (rc_ != CILHIP_OK) return mfail((m), rc_, std::string(#call) + ": " + cilhip_last_error((m)->ctx[r])); } while (0)
+
+extern "C" {
+
+int cilhip_multi_create(cilhip_multi** out, const int* devices, int ndev) {
+  if (!out || !devices || ndev <= 0 || ndev > 64) return CILHIP_ERR_INVALID;
+  *out = nullptr;
+  cilhip_multi* m = new (std::nothrow) cilhip_multi();
+  if (!m) return CILHIP_ERR_HIP;
+  m->n = ndev;
+  m->dev.assign(devices, devices + ndev);
+  for (int i = 0; i < ndev; ++i)
+    for (int j = 0; j < i; ++j) if (devices[i] == devices[j]) m->distinct = false;
+  m->ctx.assign(ndev, nullptr); m->d_sums.assign(ndev, nullptr);
+  m->n_dst_local.assign(ndev, 0); m->n_src_local.assign(ndev, 0);
+  int rc = CILHIP_OK;
+  for (int r = 0; r < ndev && rc == CILHIP_OK; ++r) {
+    rc = cilhip_create(&m->ctx[r], devices[r]);
+    if (rc == CILHIP_OK && (hipSetDevice(devices[r]) != hipSuccess || hipMalloc(&m->d_sums[r], SUMS_MAX * sizeof(double)) != hipSuccess)) rc = CILHIP_ERR_HIP;
+  }
+  // (CILHIP_MULTI_FORCE_RCCL=1: a single shard goes through RCCL too -- a communicator of one rank: what a one-GPU box can check of that path)
+  const bool force_rccl = ndev == 1 && getenv("CILHIP_MULTI_FORCE_RCCL") != nullptr && atoi(getenv("CILHIP_MULTI_FORCE_RCCL")) != 0;
+  if (rc == CILHIP_OK && (ndev > 1 || force_rccl)) {
+    if (m->distinct) {
+      if (!m->rccl.load()) rc = CILHIP_ERR_UNSUPPORTED;      // several devices need RCCL (librccl.so.1)
+      else {
+        m->comms.assign(ndev, nullptr);
+        if (m->rccl.CommInitAll(m->comms.data(), ndev, devices) != 0) rc = CILHIP_ERR_HIP;
+      }
+    } else {
+      for (int r = 1; r < ndev; ++r) if (devices[r] != devices[0]) rc = CILHIP_ERR_UNSUPPORTED;   // (repeated ordinals: all shards on one device)
+      if (rc == CILHIP_OK && (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&m->d_bufs, ndev * sizeof(double*)) != hipSuccess ||
+                              hipMemcpy(m->d_bufs, m->d_sums.data(), ndev * sizeof(double*), hipMemcpyHostToDevice) != hipSuccess))
+        rc = CILHIP_ERR_HIP;
+      for (int r = 0; r < ndev && rc == CILHIP_OK; ++r) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = CILHIP_ERR_HIP; else m->ev.push_back(e); }
+    }
+  }
+  if (rc != CILHIP_OK) { cilhip_multi_destroy(m); return rc; }
+  *out = m;
+  return CILHIP_OK;
+}
+
+void cilhip_multi_destroy(cilhip_multi* m) {
+  if (!m) return;
+  for (size_t r = 0; r < m->comms.size(); ++r) if (m->comms[r] && m->rccl.CommDestroy) (void)m->rccl.CommDestroy(m->comms[r]);
+  for (int r = 0; r < m->n; ++r) {
+    if (m->d_sums[r]) { (void)hipSetDevice(m->dev[r]); (void)hipFree(m->d_sums[r]); }
+    if (m->ctx[r]) cilhip_destroy(m->ctx[r]);
+  }
+  if (m->d_bufs) (void)hipFree(m->d_bufs);
+  for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+  delete m;
+}
+
+const char* cilhip_multi_last_error(const cilhip_multi* m) { return m ? m->err.c_str() : "null handle"; }
+cilhip_ctx* cilhip_multi_context(cilhip_multi* m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[rank] : nullptr; }
+int cilhip_multi_repartitions(const cilhip_multi* m) { return m ? m->repartitions : 0; }
+int cilhip_multi_set_slab_slack(cilhip_multi* m, float slack) { if (!m) return CILHIP_ERR_INVALID; m->slack_opt = slack; return CILHIP_OK; }
+int cilhip_multi_shard_sizes(const cilhip_multi* m, int rank, size_t* n_target, size_t* n_source) {
+  if (!m || rank < 0 || rank >= m->n) return CILHIP_ERR_INVALID;
+  if (n_target) *n_target = m->n_dst_local[rank];
+  if (n_source) *n_source = m->n_src_local[rank];
+  return CILHIP_OK;
+}
+
+}  // extern "C"
+
+// f64 mean rounded to f32: what the ICP classes hold as dst_mean_ / src_mean_ of the WHOLE clouds
+static void global_mean(const std::vector<float>& xyz, size_t n, float out[3]) {
+  double s[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) s[c] += (double)xyz[3 * i + c];
+  for (int c = 0; c < 3; ++c) out[c] = n ? (float)(s[c] / (double)n) : 0.0f;
+}
+
+// uploads every shard's clouds under the current partition (slabs: cut under T_part)
+static int multi_upload(cilhip_multi* m) {
+  const int n = m->n;
+  if (m->partition == 0) {
+    for (int r = 0; r < n; ++r) {
+      const size_t base = m->ns / n, rem = m->ns % n;
+      const size_t lo = r * base + std::min<size_t>(r, rem), hi = lo + base + ((size_t)r < rem ? 1 : 0);
+      MCTX(m, r, cilhip_set_target(m->ctx[r], m->dst.data(), m->dstn.empty() ? nullptr : m->dstn.data(), m->nd, CILHIP_MEM_HOST));
+      MCTX(m, r, cilhip_set_source(m->ctx[r], m->src.data() + 3 * lo, hi - lo, CILHIP_MEM_HOST));
+      MCTX(m, r, cilhip_set_slab_guard(m->ctx[r], -1, 0.0f, nullptr, nullptr, nullptr));
+      m->n_dst_local[r] = m->nd; m->n_src_local[r] = hi - lo;
+    }
+    return CILHIP_OK;
+  }
+  // slabs along m->axis: rank r owns the source points whose image under T_part lies in [b_r, b_r+1) and holds the target points in
+  // [b_r - halo, b_r+1 + halo)   (distributed.py SlabPartition: the same cut)
+  const int ax = m->axis;
+  std::vector<double> q(m->ns);
+  for (size_t i = 0; i < m->ns; ++i)
+    q[i] = (double)m->src[3 * i] * (double)m->T_part[0 * 4 + ax] + (double)m->src[3 * i + 1] * (double)m->T_part[1 * 4 + ax] +
+           (double)m->src[3 * i + 2] * (double)m->T_part[2 * 4 + ax] + (double)m->T_part[12 + ax];
+  m->bounds.assign(n + 1, 0.0);
+  m->bounds[0] = -INFINITY; m->bounds[n] = INFINITY;
+  if (n > 1 && m->ns) {      // boundaries at the source's quantiles: the queries are the work
+    std::vector<double> qs(q);
+    for (int r = 1; r < n; ++r) {
+      const size_t k = std::min(m->ns - 1, (size_t)((double)m->ns * r / n));
+      std::nth_element(qs.begin(), qs.begin() + k, qs.end());
+      m->bounds[r] = qs[k];
+    }
+  }
+  std::vector<float> d, dn, s;
+  for (int r = 0; r < n; ++r) {
+    const double b0 = m->bounds[r], b1 = m->bounds[r + 1];
+    d.clear(); dn.clear(); s.clear();
+    for (size_t i = 0; i < m->nd; ++i) {
+      const double x = (double)m->dst[3 * i + ax];
+      if (x >= b0 - m->halo && x < b1 + m->halo) {
+        d.insert(d.end(), m->dst.begin() + 3 * i, m->dst.begin() + 3 * i + 3);
+        if (!m->dstn.empty()) dn.insert(dn.end(), m->dstn.begin() + 3 * i, m->dstn.begin() + 3 * i + 3);
+      }
+    }
+    for (size_t i = 0; i < m->ns; ++i)
+      if (q[i] >= b0 && q[i] < b1) s.insert(s.end(), m->src.begin() + 3 * i, m->src.begin() + 3 * i + 3);
+    MCTX(m, r, cilhip_set_target(m->ctx[r], d.data(), m->dstn.empty() ? nullptr : dn.data(), d.size() / 3, CILHIP_MEM_HOST));
+    MCTX(m, r, cilhip_set_source(m->ctx[r], s.data(), s.size() / 3, CILHIP_MEM_HOST));
+    MCTX(m, r, cilhip_set_shard_info(m->ctx[r], 0, m->gdm, nullptr));
+    MCTX(m, r, cilhip_set_slab_guard(m->ctx[r], ax, (float)m->slack, m->src_center, m->src_half, m->T_part));
+    m->n_dst_local[r] = d.size() / 3; m->n_src_local[r] = s.size() / 3;
+  }
+  return CILHIP_OK;
+}
+
+extern "C" {
+
+int cilhip_multi_set_clouds(cilhip_multi* m, const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz, size_t ns, float max_sq_dist,
+                            int partition, const float* T_part) {
+  if (!m || (nd && !dst_xyz) || (ns && !src_xyz) || (partition != 0 && partition != 1)) return CILHIP_ERR_INVALID;
+  m->dst.assign(dst_xyz, dst_xyz + 3 * nd);
+  if (dst_nrm) m->dstn.assign(dst_nrm, dst_nrm + 3 * nd); else m->dstn.clear();
+  m->src.assign(src_xyz, src_xyz + 3 * ns);
+  m->nd = nd; m->ns = ns; m->max_sq = max_sq_dist; m->partition = partition;
+  memcpy(m->T_part, T_part ? T_part : kIdentity, sizeof(m->T_part));
+  global_mean(m->dst, nd, m->gdm);
+  global_mean(m->src, ns, m->gsm);
+  if (partition == 1) {
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (size_t i = 0; i < nd; ++i)
+      for (int c = 0; c < 3; ++c) { const double v = m->dst[3 * i + c]; if (i == 0 || v < lo[c]) lo[c] = v; if (i == 0 || v > hi[c]) hi[c] = v; }
+    m->axis = 0;
+    for (int c = 1; c < 3; ++c) if (hi[c] - lo[c] > hi[m->axis] - lo[m->axis]) m->axis = c;
+    const double r = std::isfinite(max_sq_dist) ? std::sqrt((double)max_sq_dist) : hi[m->axis] - lo[m->axis];
+    m->slack = m->slack_opt >= 0.0 ? m->slack_opt : 2.0 * r; m->halo = r + m->slack;
+    float slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+    for (size_t i = 0; i < ns; ++i)
+      for (int c = 0; c < 3; ++c) { const float v = m->src[3 * i + c]; if (i == 0 || v < slo[c]) slo[c] = v; if (i == 0 || v > shi[c]) shi[c] = v; }
+    for (int c = 0; c < 3; ++c) { m->src_center[c] = 0.5f * (slo[c] + shi[c]); m->src_half[c] = std::max(shi[c] - m->src_center[c], m->src_center[c] - slo[c]) * 1.000001f; }
+  }
+  m->repartitions = 0;
+  return multi_upload(m);
+}
+
+}  // extern "C"
+
+// the all-reduce of the shards' 48 partial sums, on the shards' streams
+static int multi_allreduce(cilhip_multi* m) {
+  if (m->n == 1 && m->comms.empty()) return CILHIP_OK;
+  if (m->distinct) {
+    if (m->rccl.GroupStart() != 0) return mfail(m, CILHIP_ERR_HIP, "ncclGroupStart");
+    for (int r = 0; r < m->n; ++r)
+      if (m->rccl.AllReduce(m->d_sums[r], m->d_sums[r], SUMS_MAX, RCCL_DOUBLE, RCCL_SUM, m->comms[r], m->ctx[r]->stream) != 0) return mfail(m, CILHIP_ERR_HIP, "ncclAllReduce");
+    if (m->rccl.GroupEnd() != 0) return mfail(m, CILHIP_ERR_HIP, "ncclGroupEnd");
+    return CILHIP_OK;
+  }
+  // one device: shard 0's stream waits for the others' partial sums, sums all buffers in shard order, the others wait for it
+  MCK(m, hipSetDevice(m->dev[0]));
+  for (int r = 1; r < m->n; ++r) { MCK(m, hipEventRecord(m->ev[r], m->ctx[r]->stream)); MCK(m, hipStreamWaitEvent(m->ctx[0]->stream, m->ev[r], 0)); }
+  hipLaunchKernelGGL(k_sum_shards, dim3(1), dim3(64), 0, m->ctx[0]->stream, m->d_bufs, m->n);
+  MCK(m, hipEventRecord(m->ev[0], m->ctx[0]->stream));
+  for (int r = 1; r < m->n; ++r) MCK(m, hipStreamWaitEvent(m->ctx[r]->stream, m->ev[0], 0));
+  return CILHIP_OK;
+}
+
+extern "C" {
+
+// IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) across the handle's devices.  check_every: how often the
+// loop state is read back (convergence; the slab guard) -- 0: the default 5.
+int cilhip_multi_icp_run(cilhip_multi* m, const cilhip_icp_params* p, const float* T0, int check_every, cilhip_icp_result* out) {
+  if (!m || !p || !out) return CILHIP_ERR_INVALID;
+  const int every0 = check_every > 0 ? check_every : 5;
+  float T_ck[16];
+  memcpy(T_ck, T0 ? T0 : kIdentity, sizeof(T_ck));
+  const size_t total = p->max_iter;
+  size_t base = 0, since = 0, begin_base = 0;      // base: iterations up to the last checked state; begin_base: up to the last begin
+  const float* gsm = m->n > 1 ? m->gsm : nullptr;  // (one shard: the context's own mean, as cilhip_icp_run)
+  if (m->partition == 1) {
+    gsm = m->gsm;
+    // the slabs are exact for searches under the transform they were cut under (+- the slack the guard watches): start from T0's own cut
+    if (memcmp(m->T_part, T_ck, sizeof(T_ck)) != 0) { memcpy(m->T_part, T_ck, sizeof(T_ck)); const int rc = multi_upload(m); if (rc) return rc; }
+  }
+  for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_begin(m->ctx[r], p, T_ck, gsm));
+  bool fresh = true;                               // the partition was made under exactly T_ck
+  int every = every0;
+  cilhip_icp_result st{};
+  memcpy(st.T, T_ck, sizeof(T_ck));
+  while (base + since < total) {
+    for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_partial_sums(m->ctx[r], m->d_sums[r]));
+    { const int rc = multi_allreduce(m); if (rc) return rc; }
+    for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_apply_sums(m->ctx[r], m->d_sums[r]));
+    ++since;
+    if (since % (size_t)every == 0 || base + since == total) {
+      MCTX(m, 0, cilhip_icp_state(m->ctx[0], &st));          // (the same state on every shard: same sums, same epilogue)
+      int bad = 0;
+      cilhip_icp_result vs{};
+      if (m->partition == 1) MCTX(m, 0, cilhip_get_slab_violation_state(m->ctx[0], &bad, &vs));
+      // The flag is about the NEXT search: the update that raised it is still exact (its search ran inside the halos), so every
+      // iteration up to and including it is kept (distributed.py SlabShardedRigidICP.estimate: the same bookkeeping).
+      if (bad && vs.iterations > 0) {
+        memcpy(T_ck, vs.T, sizeof(T_ck)); base = begin_base + vs.iterations; since = 0; fresh = false;
+        if (vs.last_delta_norm < p->conv_tol || base >= total) { *out = vs; out->iterations = base; return CILHIP_OK; }
+      } else if (!bad || (fresh && since == 1)) {
+        memcpy(T_ck, st.T, sizeof(T_ck)); base += since; since = 0; fresh = false;
+        if (st.last_delta_norm < p->conv_tol || base >= total) { *out = st; out->iterations = begin_base + st.iterations; return CILHIP_OK; }
+        every = bad ? 1 : every0;
+      }
+      if (bad) {
+        memcpy(m->T_part, T_ck, sizeof(T_ck));
+        { const int rc = multi_upload(m); if (rc) return rc; }
+        ++m->repartitions;
+        for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_begin(m->ctx[r], p, T_ck, m->gsm));
+        since = 0; begin_base = base; fresh = true; every = 1;
+      }
+    }
+  }
+  MCTX(m, 0, cilhip_icp_state(m->ctx[0], &st));
+  *out = st;
+  out->iterations = begin_base + st.iterations;
+  return CILHIP_OK;
+}
+
+}  // extern "C"

@@ -364,6 +364,32 @@ int cilhip_estimate_combined_two_sets(cilhip_ctx* ctx_point, cilhip_ctx* ctx_pla
 int cilhip_icp_run_two_sets(cilhip_ctx* ctx_point, float max_sq_point, cilhip_ctx* ctx_plane, float max_sq_plane, const cilhip_icp_params* p,
                             const float* T0, cilhip_icp_result* out);
 
+/* ---- one process, several devices (devices[], one stream per device) ---------------------------------------
+ * The sharded ICP loop driven from C: one context per entry of devices[], per iteration every context enqueues its partial
+ * sums, the 48 f64 are all-reduced on the devices' streams by RCCL (ncclAllReduce; librccl is opened at run time, only when
+ * ndev > 1) and every context applies them -- the reference has no counterpart; the loop is
+ * IterativeClosestPointBase::estimate (registration/icp_base.hpp:68-87).  devices[] may repeat ONE ordinal (several shards on one
+ * GPU, reduced by a kernel: what a single-GPU box can test).
+ * cilhip_multi_set_clouds copies the host clouds (they are cut again when a slab guard fires) and uploads every shard:
+ * partition 0 = the source in contiguous shards, the whole target on every device; 1 = spatial slabs along the longest axis of the
+ * target's bounding box, target slabs with a halo of sqrt(max_sq_dist) + slack (slack = 2 sqrt(max_sq_dist)), source points by the
+ * slab their image under T_part (null: identity; cilhip_multi_icp_run re-cuts under its T0) falls into, the device-side guard
+ * armed (cilhip_set_slab_guard) and handled inside cilhip_multi_icp_run: all shards re-partitioned under the last exact
+ * transform, no exact iteration discarded.  Engine options are set per shard through cilhip_multi_context(rank). */
+typedef struct cilhip_multi cilhip_multi;
+int cilhip_multi_create(cilhip_multi** out, const int* devices, int ndev);
+void cilhip_multi_destroy(cilhip_multi* m);
+const char* cilhip_multi_last_error(const cilhip_multi* m);
+cilhip_ctx* cilhip_multi_context(cilhip_multi* m, int rank);
+int cilhip_multi_set_clouds(cilhip_multi* m, const float* dst_xyz, const float* dst_nrm_or_null, size_t n_dst, const float* src_xyz, size_t n_src,
+                            float max_sq_dist, int partition, const float* T_part_or_null);
+int cilhip_multi_icp_run(cilhip_multi* m, const cilhip_icp_params* p, const float* T0, int check_every, cilhip_icp_result* out);
+int cilhip_multi_repartitions(const cilhip_multi* m);
+/* how far a source point may move along the slab axis before the slabs are cut again (the halos are the search radius + this);
+ * < 0: the default, twice the search radius.  Takes effect at the next cilhip_multi_set_clouds. */
+int cilhip_multi_set_slab_slack(cilhip_multi* m, float slack);
+int cilhip_multi_shard_sizes(const cilhip_multi* m, int rank, size_t* n_target, size_t* n_source);
+
 /* How the iterations of the last cilhip_icp_run were executed: as ONE pass (search with the accumulation inside the LDS
  * tiles) or as TWO (search with its in-tile 3x3x3 second pass, then the streaming accumulation).  Large clouds choose per
  * iteration from the device's count of queries the first search stage left unproven (source far from alignment: two passes).

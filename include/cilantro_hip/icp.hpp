@@ -546,6 +546,66 @@ private:
   RigidTransform3f transform_init_, transform_;
 };
 
+// The sharded ICP loop over several devices of one process (c_api.h: cilhip_multi_*): per iteration every device's context searches
+// and accumulates over its shard, RCCL all-reduces the 48 partial sums on the devices' streams, every context applies them.
+// SlabSharded (default): spatial slabs of target (+ halo) and source, exact nearest neighbours without any key exchange, the
+// device-side guard and re-partitioning inside; SourceSharded: the source in contiguous shards, the target on every device.  The
+// reference has no counterpart (single-process CPU); the loop is IterativeClosestPointBase::estimate (icp_base.hpp:68-87) for the
+// rigid combined / point-to-point metrics with their defaults (icp_single_transform_combined_metric.hpp:44-47).
+class MultiDeviceRigidICP {
+public:
+  enum struct Partition { SourceShards = 0, Slabs = 1 };
+  explicit MultiDeviceRigidICP(const std::vector<int>& devices) {
+    if (cilhip_multi_create(&m_, devices.data(), (int)devices.size()) != CILHIP_OK)
+      throw std::runtime_error("cilhip_multi_create failed (no usable HIP devices / RCCL for these ordinals; there is no CPU fallback)");
+  }
+  ~MultiDeviceRigidICP() { cilhip_multi_destroy(m_); }
+  MultiDeviceRigidICP(const MultiDeviceRigidICP&) = delete;
+  MultiDeviceRigidICP& operator=(const MultiDeviceRigidICP&) = delete;
+
+  // dst_n may be empty (point-to-point metric).  max_sq_dist: the engines' squared search radius (it sizes the slabs' halos).
+  MultiDeviceRigidICP& setClouds(const ConstPointsView& dst_p, const ConstPointsView& dst_n, const ConstPointsView& src_p, float max_sq_dist,
+                                 Partition part = Partition::Slabs) {
+    if (dst_n.cols() && dst_n.cols() != dst_p.cols()) throw std::invalid_argument("dst normals must match dst points");
+    ck(cilhip_multi_set_clouds(m_, dst_p.data(), dst_n.cols() ? dst_n.data() : nullptr, dst_p.cols(), src_p.data(), src_p.cols(), max_sq_dist, (int)part, nullptr));
+    max_sq_ = max_sq_dist;
+    return *this;
+  }
+  MultiDeviceRigidICP& setMaxNumberOfIterations(size_t n) { max_iterations_ = n; return *this; }
+  MultiDeviceRigidICP& setConvergenceTolerance(float t) { convergence_tol_ = t; return *this; }
+  MultiDeviceRigidICP& setPointToPointMetricWeight(float w) { w_p2p_ = w; return *this; }
+  MultiDeviceRigidICP& setPointToPlaneMetricWeight(float w) { w_p2pl_ = w; return *this; }
+  MultiDeviceRigidICP& usePointToPointMetric(bool b) { p2p_ = b; return *this; }      // SimplePointToPointMetricRigidICP3f instead of the combined metric
+  template <class TransformT>
+  MultiDeviceRigidICP& setInitialTransform(const TransformT& t) { internal::to_abi(t, transform_init_.m); return *this; }
+  MultiDeviceRigidICP& estimate() {
+    cilhip_icp_params p;
+    cilhip_icp_default_params(&p);
+    p.metric = p2p_ ? CILHIP_METRIC_POINT_TO_POINT : CILHIP_METRIC_COMBINED;
+    p.w_p2p = w_p2p_; p.w_p2pl = w_p2pl_; p.max_iter = max_iterations_; p.conv_tol = convergence_tol_; p.max_sq_dist = max_sq_;
+    cilhip_icp_result r;
+    ck(cilhip_multi_icp_run(m_, &p, transform_init_.m, 0, &r));
+    std::memcpy(transform_.m, r.T, sizeof(r.T));
+    iterations_ = r.iterations; last_delta_norm_ = r.last_delta_norm; last_ncorr_ = r.last_ncorr;
+    return *this;
+  }
+  const RigidTransform3f& getTransform() const { return transform_; }
+  size_t getNumberOfPerformedIterations() const { return iterations_; }
+  float getLastUpdateNorm() const { return last_delta_norm_; }
+  bool hasConverged() const { return last_delta_norm_ < convergence_tol_; }
+  size_t getNumberOfLastCorrespondences() const { return last_ncorr_; }
+  int getNumberOfRepartitions() const { return cilhip_multi_repartitions(m_); }
+  cilhip_ctx* context(int rank) { return cilhip_multi_context(m_, rank); }
+
+private:
+  void ck(int rc) const { if (rc != CILHIP_OK) throw std::runtime_error(std::string("MultiDeviceRigidICP: ") + cilhip_multi_last_error(m_)); }
+  cilhip_multi* m_ = nullptr;
+  size_t max_iterations_ = 15, iterations_ = 0, last_ncorr_ = 0;
+  float convergence_tol_ = 1e-5f, w_p2p_ = 0.0f, w_p2pl_ = 1.0f, max_sq_ = 0.01f * 0.01f, last_delta_norm_ = std::numeric_limits<float>::infinity();
+  bool p2p_ = false;
+  RigidTransform3f transform_init_, transform_;
+};
+
 typedef RigidTransform3f AffineTransform3f;
 
 class SimplePointToPointMetricAffineICP3f : public SimplePointToPointMetricRigidICP3f {

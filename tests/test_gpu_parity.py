@@ -2,6 +2,7 @@
 seeded inputs.  Integer / index work must be bit-exact; transforms within 1e-5 Frobenius
 (BASELINE.json north_star)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1945,3 +1946,58 @@ def test_combined_metric_combiner_two_correspondence_sets_vs_oracle(Context, orc
     e_pt.findCorrespondences(T0); e_pl.findCorrespondences(To)
     with pytest.raises(Exception):
         e_pt._ctx._ck(L.cilhip_estimate_combined_two_sets(e_pt._ctx._h, e_pl._ctx._h, w_pt, w_pl, 1, 0.0, T.ctypes.data_as(C.c_void_p), C.byref(cv)))
+
+
+def test_multi_device_c_entry_one_gpu(Context, orc, hip_lib):
+    """cilhip_multi_*: the sharded loop driven from C in ONE process (SURVEY.md 8(b) devices[]).  What a single-GPU box can check:
+    one shard == cilhip_icp_run bit for bit; several shards on the same device (devices = [0, 0, 0]: the all-reduce runs as the
+    same-device kernel instead of RCCL) -- source shards and spatial slabs -- give the single-context loop's transform to the
+    order of the f64 additions, iteration for iteration, also when the slab guard fires and all shards are cut again; the loop
+    against the oracle's."""
+    from cilantro_amd.multi import PARTITION_SLABS, PARTITION_SOURCE_SHARDS, MultiDeviceRigidICP
+
+    d = syn.make_pair(400_000, perturb=0.6)
+    dst, dst_n, src, r2 = d["dst"], d["dst_n"], d["src"], d["max_sq_dist"]
+
+    def params(iters, tol=0.0, r=r2):
+        ctx = Context()
+        p = capi.IcpParams(); ctx._L.cilhip_icp_default_params(C.byref(p)); ctx.close()
+        p.metric, p.w_p2p, p.w_p2pl, p.max_sq_dist, p.max_iter, p.conv_tol = capi.METRIC_COMBINED, 0.1, 1.0, float(r), iters, tol
+        return p
+
+    ctx = Context(); ctx.set_target(dst, dst_n); ctx.set_source(src)
+    ref = ctx.icp_run(params(8)); T_ref = np.array(ref.T[:], np.float32)
+    ctx.close()
+    # one shard: the same kernels in the same order
+    m = MultiDeviceRigidICP([0]); m.set_clouds(dst, dst_n, src, r2, PARTITION_SOURCE_SHARDS)
+    r1 = m.icp_run(params(8)); m.close()
+    assert np.array_equal(np.array(r1.T[:], np.float32).view(np.uint32), T_ref.view(np.uint32)) and int(r1.iterations) == 8 and int(r1.last_ncorr) == int(ref.last_ncorr)
+    # ... and through RCCL (a communicator of one rank: librccl opened at run time, ncclAllReduce of the 48 f64 on the context's stream)
+    os.environ["CILHIP_MULTI_FORCE_RCCL"] = "1"
+    try:
+        m = MultiDeviceRigidICP([0]); m.set_clouds(dst, dst_n, src, r2, PARTITION_SLABS)
+        r1 = m.icp_run(params(8)); m.close()
+    finally:
+        del os.environ["CILHIP_MULTI_FORCE_RCCL"]
+    assert np.array_equal(np.array(r1.T[:], np.float32).view(np.uint32), T_ref.view(np.uint32)) and int(r1.iterations) == 8
+    for part in (PARTITION_SOURCE_SHARDS, PARTITION_SLABS):
+        m = MultiDeviceRigidICP([0, 0, 0]); m.set_clouds(dst, dst_n, src, r2, part)
+        sizes = [m.shard_sizes(k) for k in range(3)]
+        assert sum(s[1] for s in sizes) == len(src)
+        if part == PARTITION_SLABS:
+            assert all(0 < s[0] < len(dst) for s in sizes)      # every device holds its slab + halo only
+        rr = m.icp_run(params(8)); T = np.array(rr.T[:], np.float32)
+        assert int(rr.iterations) == 8 and int(rr.last_ncorr) == int(ref.last_ncorr), (part, int(rr.iterations), int(rr.last_ncorr))
+        assert np.abs(T.astype(np.float64) - T_ref.astype(np.float64)).max() <= 2e-6, part
+        # convergence-gated: the same iteration count as the oracle's loop
+        rc = m.icp_run(params(30, 1e-5)); m.close()
+        po = orc.make_params(metric=1, w_p2p=0.1, w_p2pl=1.0, max_iter=30, conv_tol=1e-5, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
+        ro = orc.icp_run(dst, dst_n, src, po)
+        Tc = np.array(rc.T[:], np.float32).reshape(4, 4).T
+        assert int(rc.iterations) == ro["iterations"] and np.linalg.norm(Tc.astype(np.float64) - ro["T"].astype(np.float64)) <= TOL_T, part
+    # a slack of a hundredth of a cell: the guard fires with the first updates, all shards are cut again under the last exact transform
+    m = MultiDeviceRigidICP([0, 0]); m.set_slab_slack(0.01 * d["h"]); m.set_clouds(dst, dst_n, src, r2, PARTITION_SLABS)
+    rr = m.icp_run(params(8), check_every=2)
+    assert m.repartitions() >= 1 and int(rr.iterations) == 8 and int(rr.last_ncorr) == int(ref.last_ncorr), (m.repartitions(), int(rr.iterations))
+    assert np.abs(np.array(rr.T[:], np.float32).astype(np.float64) - T_ref.astype(np.float64)).max() <= 2e-6
+    m.close()
