@@ -952,6 +952,20 @@ int cilhip_get_matches_transform(cilhip_ctx* c, float T[16]) {
   return CILHIP_OK;
 }
 
+int cilhip_get_tie_count(cilhip_ctx* c, const float T[16], float max_sq, size_t* n_ties) {
+  if (!c || !T || !n_ties) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  const int rc = ensure_sorted(c, T);
+  if (rc) return rc;
+  launch_count_ties(c->grid, c->d_src_sorted, c->ns, T, max_sq, c->d_count, c->stream);
+  unsigned long long v = 0;
+  CK(c, hipMemcpyAsync(&v, c->d_count, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  CK(c, hipGetLastError());
+  *n_ties = (size_t)v;
+  return CILHIP_OK;
+}
+
 int cilhip_get_nn(cilhip_ctx* c, uint32_t* nn_idx, float* nn_d2, int mem) {
   if (!c) return CILHIP_ERR_INVALID;
   { const int prc = materialize_pending(c); if (prc) return prc; }

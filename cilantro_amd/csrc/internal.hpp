@@ -308,6 +308,8 @@ void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys
                         uint32_t index_offset, uint32_t n_local, uint32_t* nn_pos, float* nn_d2, hipStream_t s);
 void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s);
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
+// queries (sorted source under T) whose nearest target point within the radius is not unique in the pinned f32 distance
+void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, const float T[16], float max_sq, unsigned long long* out, hipStream_t s);
 // squared distances of the stored matches under T, formed again with the search's pinned arithmetic (bit-identical to what the
 // search compared): the ICP loop does not store them, a caller of getCorrespondences() after estimate() reads them
 void launch_fill_d2(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos, const float T[16], uint32_t ns, float* nn_d2, hipStream_t s);

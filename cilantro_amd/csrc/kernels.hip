@@ -94,6 +94,8 @@ __device__ __forceinline__ float margin_from_q15(uint32_t q, float cell, const M
   return (q & 0x8000u) ? -fmaxf(b, 1.17549435e-38f) : b;
 }
 
+struct T16c { float v[16]; };
+
 struct NN {
   unsigned long long key;  // (bits(d2) << 32) | original target index : strict '<' + lowest-index tie-break
   uint32_t pos;            // position in the sorted target array, NONE_U32 if nothing within the radius
@@ -3178,21 +3180,26 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
   static_assert(sizeof(IcpState) % 4 == 0, "IcpState is copied as dwords");
   constexpr int ST_DWORDS = (int)(sizeof(IcpState) / 4);
   if (a.state->done) return;
-  for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(&lst)[k] = reinterpret_cast<const uint32_t*>(a.state)[k];
+  // (everything the kernel reads from global memory is REQUESTED before anything is waited for: the state -- one dword per thread --,
+  //  the search kernels' counters and the partial rows travel together: one far round trip instead of three in a row)
+  static_assert(ST_DWORDS <= 256, "one dword of the state per thread");
+  const uint32_t sreg = (int)threadIdx.x < ST_DWORDS ? reinterpret_cast<const uint32_t*>(a.state)[threadIdx.x] : 0u;
   __shared__ unsigned int unproven_total;
   __shared__ unsigned int listed_total;
-  if (a.unproven_cnt != nullptr && a.gn_last_step && threadIdx.x < 128) {   // (once per iteration; wave 0: unproven, wave 1: listed)
-    unsigned int v = a.unproven_cnt[threadIdx.x];
-    a.unproven_cnt[threadIdx.x] = 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (threadIdx.x == 0) unproven_total = v;
-    if (threadIdx.x == 64) listed_total = v;
-  }
+  const bool counters = a.unproven_cnt != nullptr && a.gn_last_step && threadIdx.x < 128;   // (once per iteration; wave 0: unproven, wave 1: listed)
+  unsigned int cv = counters ? a.unproven_cnt[threadIdx.x] : 0u;
   if (a.nblocks > 0) {
     reduce_partials_block(a.partials, a.nblocks, sums);
   } else {
     if (threadIdx.x < SUMS_MAX) sums[threadIdx.x] = a.reduced[threadIdx.x];
+  }
+  if ((int)threadIdx.x < ST_DWORDS) reinterpret_cast<uint32_t*>(&lst)[threadIdx.x] = sreg;
+  if (counters) {
+    a.unproven_cnt[threadIdx.x] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cv += __shfl_down(cv, off, 64);
+    if (threadIdx.x == 0) unproven_total = cv;
+    if (threadIdx.x == 64) listed_total = cv;
   }
   __syncthreads();
   IcpState* st = &lst;
@@ -3220,11 +3227,21 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
         st->inner_done = 1;
         for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = sums[i];
       } else {
-        // (LDS, not function-local arrays: the pivoted solve indexes them dynamically, and scratch is global memory)
-        __shared__ double AtA[36], Atb[6], dth[6], wsA[36], wsy[6];
-        __shared__ int wsperm[6];
+        // (registers for the usual case -- every index below is a compile-time constant once the loops are unrolled; the pivoted
+        //  solve indexes its arrays dynamically: LDS for that one, scratch would be global memory)
+        double AtA[36], Atb[6], dth[6];
         gn_normal_equations(sums, has_p2p ? (double)a.w_p2p : 0.0, has_p2pl ? (double)a.w_p2pl : 0.0, AtA, Atb, a.point_weighted != 0);
-        if (!ldlt6_solve_fast(AtA, Atb, dth)) ldlt6_solve_ws(AtA, Atb, dth, wsA, wsy, wsperm);   // (pivoted: rank-deficient systems only)
+        if (!ldlt6_solve_fast(AtA, Atb, dth)) {      // (pivoted: rank-deficient systems only)
+          __shared__ double sA[36], sb[6], sx[6], wsA[36], wsy[6];
+          __shared__ int wsperm[6];
+#pragma unroll
+          for (int i = 0; i < 36; ++i) sA[i] = AtA[i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) sb[i] = Atb[i];
+          ldlt6_solve_ws(sA, sb, sx, wsA, wsy, wsperm);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) dth[i] = sx[i];
+        }
         rigid_gn_update(dth, st->dLd, st->dtd);
         for (int i = 0; i < 9; ++i) st->innerL[i] = (float)st->dLd[i];
         for (int i = 0; i < 3; ++i) st->innert[i] = (float)st->dtd[i];
@@ -3458,6 +3475,88 @@ void launch_fill_d2(const float4* src_sorted, const float4* dst_sorted, const ui
   T16 t;
   for (int i = 0; i < 16; ++i) t.v[i] = T[i];
   hipLaunchKernelGGL(k_fill_d2, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, dst_sorted, nn_pos, t, ns, nn_d2);
+}
+
+// ---- ties: queries whose nearest target point is not unique ---------------------------------------------------------------
+// Two target points at EXACTLY the same pinned f32 distance from a query (duplicated points; a sensor's lattice) are the one
+// place where this engine and the reference may name different correspondences: the engine keeps the lowest target index, the
+// reference's nanoflann the candidate its kd-tree traversal meets first (core/kd_tree.hpp:82-90) -- both are exact nearest
+// neighbours.  This diagnostic counts such queries under a transform: the exact search once more (shells; a cell whose gap equals
+// the best distance is scanned, so every tied candidate is met), remembering whether the winning distance was met on a second point.
+__device__ __forceinline__ void scan_range4_tie(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, NN& best, bool& tie) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t jj = min(j + (uint32_t)k, last);
+      const float4 p = pts[jj];
+      const float e = d2_pinned(qx, qy, qz, p.x, p.y, p.z);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.w);
+      const bool same_d = (uint32_t)(key >> 32) == (uint32_t)(best.key >> 32);
+      if (key < best.key) { tie = same_d && best.pos != NONE_U32; best.key = key; best.pos = jj; }
+      else if (same_d && key != best.key && best.pos != NONE_U32) tie = true;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_count_ties(GridDev g, const float4* __restrict__ src, uint32_t ns, T16c T, float max_sq, unsigned long long* out) {
+  unsigned int mine = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const float4 s4 = src[i];
+    float qx, qy, qz;
+    transform_point(T.v, s4.x, s4.y, s4.z, qx, qy, qz);
+    NN best;
+    best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
+    best.pos = NONE_U32;
+    bool tie = false;
+    const float BIG = 1.0e9f;
+    const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG)), cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG)),
+              cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
+    const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin), gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin),
+                gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
+    if ((gx * gx + gy * gy + gz * gz) * KSHRINK >= max_sq) continue;      // farther than the radius from the whole grid
+    for (int s = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));; ++s) {
+      const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1), y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+      for (int z = z0; z <= z1; ++z) {
+        const float zl = g.oz + (float)z * g.cell;
+        const float az = axis_gap(qz, zl, zl + g.cell, g.margin);
+        for (int y = y0; y <= y1; ++y) {
+          const bool face = (z == cz - s) || (z == cz + s) || (y == cy - s) || (y == cy + s);
+          const float yl = g.oy + (float)y * g.cell;
+          const float ay = axis_gap(qy, yl, yl + g.cell, g.margin);
+          if ((az * az + ay * ay) * KSHRINK > __uint_as_float((uint32_t)(best.key >> 32))) continue;
+          const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          if (face) {
+            const int xa = max(cx - s, 0), xb = min(cx + s, g.nx - 1);
+            if (xa <= xb) scan_range4_tie(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best, tie);
+          } else {
+            if (cx - s >= 0 && cx - s < g.nx) scan_range4_tie(g.pts, g.cell_start[row + cx - s], g.cell_start[row + cx - s + 1], qx, qy, qz, best, tie);
+            if (s > 0 && cx + s >= 0 && cx + s < g.nx) scan_range4_tie(g.pts, g.cell_start[row + cx + s], g.cell_start[row + cx + s + 1], qx, qy, qz, best, tie);
+          }
+        }
+      }
+      float b = INFINITY;      // lower bound on the distance to anything not yet scanned
+      if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+      if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+      if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+      if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+      if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+      if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+      if (b == INFINITY) break;
+      b -= g.margin;
+      if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) break;
+    }
+    mine += (best.pos != NONE_U32 && tie) ? 1u : 0u;
+  }
+  const double tot = wave_sum((double)mine);
+  if ((threadIdx.x & 63) == 0 && tot > 0.0) atomicAdd(out, (unsigned long long)tot);
+}
+void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, const float T[16], float max_sq, unsigned long long* out, hipStream_t s) {
+  (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+  if (ns == 0 || g.n == 0) return;
+  T16c t;
+  for (int i = 0; i < 16; ++i) t.v[i] = T[i];
+  hipLaunchKernelGGL(k_count_ties, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, g, src_sorted, ns, t, max_sq, out);
 }
 
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s) {

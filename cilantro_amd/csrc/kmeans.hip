@@ -52,22 +52,47 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
     const f32x2 px = {a.xyz[3 * (size_t)i0], a.xyz[3 * (size_t)i1]};
     const f32x2 py = {a.xyz[3 * (size_t)i0 + 1], a.xyz[3 * (size_t)i1 + 1]};
     const f32x2 pz = {a.xyz[3 * (size_t)i0 + 2], a.xyz[3 * (size_t)i1 + 2]};
+    // argmin with strict '<' over ascending j = the FIRST index that attains the minimum.  Found in two steps so that the inner loop
+    // carries one v_min per distance instead of a compare and two selects: (1) per block of 8 centroids the block's minimum (a chain
+    // of mins), compared ONCE with the best so far -- strictly less: the earliest block wins ties --, (2) afterwards the winning
+    // block is evaluated again and its first centroid at exactly that distance is the label.  The same distances bit for bit.
     f32x2 best = {INFINITY, INFINITY};
-    uint32_t b0 = 0, b1 = 0;
+    uint32_t c0 = 0, c1 = 0;      // first centroid of the winning block, per point
     // centroids are padded to a multiple of 8 (pad = +inf: never the minimum); 24 consecutive floats per
     // block of 8 come through the scalar cache with wide s_load's, one wait per 8 candidates
     for (uint32_t j = 0; j < a.k; j += 8) {
       float c[24];
 #pragma unroll
       for (int t = 0; t < 24; ++t) c[t] = a.centroids[3 * j + t];
+      f32x2 m = {INFINITY, INFINITY};
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const float cx = c[3 * u], cy = c[3 * u + 1], cz = c[3 * u + 2];
         const f32x2 dx = (f32x2){cx, cx} - px, dy = (f32x2){cy, cy} - py, dz = (f32x2){cz, cz} - pz;
         const f32x2 d = KD ? (dx * dx + dy * dy) + dz * dz : dx * dx + (dy * dy + dz * dz);     // (-ffp-contract=off)
-        if (d.x < best.x) { best.x = d.x; b0 = j + u; }
-        if (d.y < best.y) { best.y = d.y; b1 = j + u; }
+        m.x = fminf(m.x, d.x); m.y = fminf(m.y, d.y);
       }
+      if (m.x < best.x) { best.x = m.x; c0 = j; }
+      if (m.y < best.y) { best.y = m.y; c1 = j; }
+    }
+    uint32_t b0 = 0, b1 = 0;
+    {
+      // the winning block once more, per point (the two points of a lane usually won in different blocks); nothing below the
+      // smallest distance exists, so the first centroid AT it is the argmin; no finite minimum at all (non-finite data): label 0,
+      // as a chain of strict compares from (inf, 0) leaves it
+      uint32_t f0 = 8, f1 = 8;
+#pragma unroll
+      for (int u = 7; u >= 0; --u) {
+        const float ax = a.centroids[3 * (c0 + u)], ay = a.centroids[3 * (c0 + u) + 1], az = a.centroids[3 * (c0 + u) + 2];
+        const float bx = a.centroids[3 * (c1 + u)], by = a.centroids[3 * (c1 + u) + 1], bz = a.centroids[3 * (c1 + u) + 2];
+        const float dx0 = ax - px.x, dy0 = ay - py.x, dz0 = az - pz.x, dx1 = bx - px.y, dy1 = by - py.y, dz1 = bz - pz.y;
+        const float d0 = KD ? (dx0 * dx0 + dy0 * dy0) + dz0 * dz0 : dx0 * dx0 + (dy0 * dy0 + dz0 * dz0);
+        const float d1 = KD ? (dx1 * dx1 + dy1 * dy1) + dz1 * dz1 : dx1 * dx1 + (dy1 * dy1 + dz1 * dz1);
+        if (d0 == best.x) f0 = (uint32_t)u;
+        if (d1 == best.y) f1 = (uint32_t)u;
+      }
+      b0 = (best.x < INFINITY && f0 < 8) ? c0 + f0 : 0u;
+      b1 = (best.y < INFINITY && f1 < 8) ? c1 + f1 : 0u;
     }
     const bool two = (2 * pidx + 1) < a.n;
     changed += (a.labels[i0] != b0) ? 1u : 0u;

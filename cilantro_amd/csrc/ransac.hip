@@ -95,7 +95,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_score(const float* __restrict__ 
   __shared__ uint32_t cnt[RS_ROUND];
   for (int t = threadIdx.x; t < RS_ROUND; t += RS_THREADS) cnt[t] = 0;
   __syncthreads();
-  const bool lane0 = (threadIdx.x & 63) == 0;
+  static_assert(RS_ROUND == 128, "two per-wave count registers: hypothesis h in lane h & 63 of register h >> 6");
+  uint32_t cv0 = 0, cv1 = 0;
   constexpr uint32_t TILE = RS_THREADS * RS_PTS;
   for (size_t base = (size_t)blockIdx.x * TILE; base < n; base += (size_t)gridDim.x * TILE) {
     f32x2 px[RS_PTS / 2], py[RS_PTS / 2], pz[RS_PTS / 2];
@@ -107,40 +108,78 @@ __global__ __launch_bounds__(RS_THREADS) void k_score(const float* __restrict__ 
       py[k] = (f32x2){v0 ? xyz[3 * i0 + 1] : NAN, v1 ? xyz[3 * i1 + 1] : NAN};
       pz[k] = (f32x2){v0 ? xyz[3 * i0 + 2] : NAN, v1 ? xyz[3 * i1 + 2] : NAN};
     }
-    for (uint32_t j = 0; j < m; j += 4) {
-      float c[16];
+    // (the four planes of the NEXT trip are requested before this trip's arithmetic: the scalar loads' latency used to sit in
+    //  front of every trip)
+    // The count of hypothesis h lives in LANE h & 63 of one of two per-wave registers across all the tiles of the block (read, add,
+    // write back: three instructions instead of a wave-aggregated LDS atomic per hypothesis and tile); the waves' registers meet in
+    // LDS once, at the end.
+    float cn[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) c[t] = planes[4 * j + t];   // wave-uniform: wide scalar loads
+    for (int t = 0; t < 16; ++t) cn[t] = planes[t];
+    auto half_pass = [&](uint32_t jbeg, uint32_t jend, uint32_t& cv) {
+      for (uint32_t j = jbeg; j < jend; j += 4) {
+        float c[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const f32x2 n0 = {c[4 * u], c[4 * u]}, n1 = {c[4 * u + 1], c[4 * u + 1]}, n2 = {c[4 * u + 2], c[4 * u + 2]},
-                    off = {c[4 * u + 3], c[4 * u + 3]};
-        uint32_t tot = 0;
+        for (int t = 0; t < 16; ++t) c[t] = cn[t];
+        const uint32_t jn = j + 4 < m ? j + 4 : j;
 #pragma unroll
-        for (int k = 0; k < RS_PTS / 2; ++k) {
-          const f32x2 r = (n0 * px[k] + (n1 * py[k] + n2 * pz[k])) + off;   // -ffp-contract=off
-          tot += (uint32_t)__popcll(__ballot(fabsf(r.x) <= thr)) + (uint32_t)__popcll(__ballot(fabsf(r.y) <= thr));
+        for (int t = 0; t < 16; ++t) cn[t] = planes[4 * jn + t];   // wave-uniform: wide scalar loads
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x2 n0 = {c[4 * u], c[4 * u]}, n1 = {c[4 * u + 1], c[4 * u + 1]}, n2 = {c[4 * u + 2], c[4 * u + 2]},
+                      off = {c[4 * u + 3], c[4 * u + 3]};
+          uint32_t tot = 0;
+#pragma unroll
+          for (int k = 0; k < RS_PTS / 2; ++k) {
+            const f32x2 r = (n0 * px[k] + (n1 * py[k] + n2 * pz[k])) + off;   // -ffp-contract=off
+            tot += (uint32_t)__popcll(__ballot(fabsf(r.x) <= thr)) + (uint32_t)__popcll(__ballot(fabsf(r.y) <= thr));
+          }
+          const int ln = (int)((j + u) & 63u);
+          const uint32_t upd = (uint32_t)__builtin_amdgcn_readlane((int)cv, ln) + tot;      // (wave-uniform: scalar registers)
+          asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cv) : "s"(upd), "s"(ln) : "m0");      // (one scalar operand per VALU instruction on this target: the lane goes through M0)
         }
-        if (lane0 && tot) atomicAdd(&cnt[j + u], tot);
       }
-    }
+    };
+    half_pass(0, m < 64u ? m : 64u, cv0);
+    if (m > 64u) half_pass(64, m, cv1);
+  }
+  {
+    const int lane = (int)(threadIdx.x & 63);
+    if (cv0) atomicAdd(&cnt[lane], cv0);
+    if (cv1) atomicAdd(&cnt[64 + lane], cv1);
   }
   __syncthreads();
   for (int t = threadIdx.x; t < RS_ROUND; t += RS_THREADS) partial[(size_t)blockIdx.x * RS_ROUND + t] = cnt[t];
 }
 
 // sums the per-block counts and replays ransac_base.hpp:103-114 over this round's hypotheses, in order
-__global__ void k_pick(const uint32_t* __restrict__ partial, int nblocks, const float4* __restrict__ planes, uint32_t m,
+constexpr int PICK_GROUPS = 8;
+__global__ __launch_bounds__(RS_ROUND * PICK_GROUPS) void k_pick(const uint32_t* __restrict__ partial, int nblocks, const float4* __restrict__ planes, uint32_t m,
                        uint32_t sample_size, uint32_t target, RansacState* st, uint32_t* counts_out) {
   __shared__ uint32_t cnt[RS_ROUND];
+  __shared__ uint32_t part[PICK_GROUPS][RS_ROUND];
   if (st && st->done) return;
-  const int t = threadIdx.x;
-  uint32_t c = 0;
-  for (int g = 0; g < nblocks; ++g) c += partial[(size_t)g * RS_ROUND + t];
-  cnt[t] = c;
-  if (counts_out && (uint32_t)t < m) counts_out[t] = c;
+  // (integer sums: any order gives the same counts -- PICK_GROUPS threads per hypothesis, four independent loads in flight each;
+  //  one thread per hypothesis walking all the blocks' rows took 0.13 ms of a 1.6 ms pass)
+  const int t = threadIdx.x & (RS_ROUND - 1), grp = threadIdx.x / RS_ROUND;
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  int g = grp;
+  for (; g + 3 * PICK_GROUPS < nblocks; g += 4 * PICK_GROUPS) {
+    c0 += partial[(size_t)g * RS_ROUND + t]; c1 += partial[(size_t)(g + PICK_GROUPS) * RS_ROUND + t];
+    c2 += partial[(size_t)(g + 2 * PICK_GROUPS) * RS_ROUND + t]; c3 += partial[(size_t)(g + 3 * PICK_GROUPS) * RS_ROUND + t];
+  }
+  for (; g < nblocks; g += PICK_GROUPS) c0 += partial[(size_t)g * RS_ROUND + t];
+  part[grp][t] = (c0 + c1) + (c2 + c3);
   __syncthreads();
-  if (t == 0 && st) {
+  if (grp == 0) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < PICK_GROUPS; ++k) c += part[k][t];
+    cnt[t] = c;
+    if (counts_out && (uint32_t)t < m) counts_out[t] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && st) {
     for (uint32_t h = 0; h < m; ++h) {
       st->iterations++;                                     // :103
       if (cnt[h] < sample_size) continue;                   // :104
@@ -324,9 +363,15 @@ struct Buffers {
   }
 };
 
+// blocks of the scoring pass: the kernel alternates vector arithmetic with scalar population counts, so it wants many waves per SIMD
+// (measured at 50M points, ms per 128-hypothesis pass incl. the pick: 1024 blocks 1.51, 2048 1.59, 4096 1.84, 8192 2.56: one generation of blocks)
+#ifndef CILHIP_RS_SCORE_BLOCKS
+#define CILHIP_RS_SCORE_BLOCKS 1024
+#endif
 inline int score_blocks(size_t n) {
+  static const size_t cap = [] { const char* e = getenv("CILHIP_EXP_RS_BLOCKS"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)CILHIP_RS_SCORE_BLOCKS; }();
   const size_t tiles = (n + (size_t)RS_THREADS * RS_PTS - 1) / ((size_t)RS_THREADS * RS_PTS);
-  return (int)(tiles < 1 ? 1 : (tiles > RS_MAX_BLOCKS ? RS_MAX_BLOCKS : tiles));
+  return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
 
 }  // namespace
@@ -401,7 +446,7 @@ int cilhip_plane_ransac3f(int device, const float* xyz, size_t n, int mem, const
         const uint32_t m4 = (m + 3u) & ~3u;
         hipLaunchKernelGGL(k_score, dim3(nb), dim3(RS_THREADS), 0, b.s, b.xyz, (uint32_t)n, (const float*)(b.planes + r0), m4,
                            max_residual, b.partial, b.st);
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(RS_ROUND), 0, b.s, b.partial, nb, b.planes + r0, m, sample_size,
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(RS_ROUND * PICK_GROUPS), 0, b.s, b.partial, nb, b.planes + r0, m, sample_size,
                            (uint32_t)target_inliers, b.st, (uint32_t*)nullptr);
       }
       const int mb = (int)std::min<size_t>((n + RS_THREADS - 1) / RS_THREADS, RS_MAX_BLOCKS);
@@ -477,7 +522,7 @@ int cilhip_plane_score3f(int device, const float* xyz, size_t n, int mem, const 
       const uint32_t mm = (uint32_t)(m - r0 < RS_ROUND ? m - r0 : RS_ROUND);
       hipLaunchKernelGGL(k_score, dim3(nb), dim3(RS_THREADS), 0, b.s, b.xyz, (uint32_t)n, (const float*)(b.planes + r0), (mm + 3u) & ~3u,
                          max_residual, b.partial, (const RansacState*)nullptr);
-      hipLaunchKernelGGL(k_pick, dim3(1), dim3(RS_ROUND), 0, b.s, b.partial, nb, b.planes + r0, mm, 0u, 0u, (RansacState*)nullptr,
+      hipLaunchKernelGGL(k_pick, dim3(1), dim3(RS_ROUND * PICK_GROUPS), 0, b.s, b.partial, nb, b.planes + r0, mm, 0u, 0u, (RansacState*)nullptr,
                          b.counts + r0);
     }
     RS_CK(hipGetLastError());

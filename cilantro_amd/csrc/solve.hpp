@@ -317,16 +317,22 @@ CILHIP_HD void kabsch_from_sums(const double* sums, double L[9], double t[3]) {
 // point_weighted: the sums carry per-pair weights; the point block's "n" is then the sum of the weights, slot 43.
 CILHIP_HD void gn_normal_equations(const double* sums, double w_p2p, double w_p2pl, double AtA[36],
                                    double Atb[6], bool point_weighted = false) {
+  // (every loop fully unrolled: the outputs stay in registers on the device)
+#pragma unroll
   for (int i = 0; i < 36; ++i) AtA[i] = 0.0;
+#pragma unroll
   for (int i = 0; i < 6; ++i) Atb[i] = 0.0;
   if (w_p2pl > 0.0) {
-    int k = 1;
+#pragma unroll
     for (int a = 0; a < 6; ++a)
+#pragma unroll
       for (int b = a; b < 6; ++b) {
-        const double v = w_p2pl * sums[k++];
+        const int k = 1 + a * 6 - (a * (a - 1)) / 2 + (b - a);      // slot of the (a, b) entry of the upper triangle, row by row
+        const double v = w_p2pl * sums[k];
         AtA[a * 6 + b] += v;
         if (b != a) AtA[b * 6 + a] += v;
       }
+#pragma unroll
     for (int a = 0; a < 6; ++a) Atb[a] += w_p2pl * sums[22 + a];
   }
   if (w_p2p > 0.0) {
@@ -337,13 +343,17 @@ CILHIP_HD void gn_normal_equations(const double* sums, double w_p2p, double w_p2
     const double tr = aa00 + aa11 + aa22;
     const double TL[9] = {tr - aa00, -aa01, -aa02, -aa01, tr - aa11, -aa12, -aa02, -aa12, tr - aa22};
     const double X[9] = {0.0, -sa[2], sa[1], sa[2], 0.0, -sa[0], -sa[1], sa[0], 0.0};  // sum [a]x
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
       for (int c = 0; c < 3; ++c) {
         AtA[r * 6 + c] += w_p2p * TL[r * 3 + c];
         AtA[r * 6 + 3 + c] += w_p2p * X[r * 3 + c];
         AtA[(3 + r) * 6 + c] += w_p2p * X[c * 3 + r];
       }
+#pragma unroll
     for (int r = 0; r < 3; ++r) AtA[(3 + r) * 6 + 3 + r] += w_p2p * n;
+#pragma unroll
     for (int r = 0; r < 3; ++r) { Atb[r] += w_p2p * sums[37 + r]; Atb[3 + r] += w_p2p * sums[40 + r]; }
   }
 }

@@ -154,6 +154,14 @@ class Context:
                                                      C.byref(n) if count else None))
         return n.value if count else None
 
+    def tie_count(self, T, max_sq_dist):
+        """queries whose nearest target point (under T, within the radius) is not unique in the pinned f32 distance: where the
+        engine's lowest-index rule and the reference's first-met rule may name different correspondences (cilhip_get_tie_count)"""
+        t = _T_to_abi(T)
+        n = C.c_size_t(0)
+        self._ck(self._L.cilhip_get_tie_count(self._h, t.ctypes.data, C.c_float(max_sq_dist), C.byref(n)))
+        return n.value
+
     def get_nn(self):
         idx = np.zeros(max(self.n_source, 1), np.uint32); d2 = np.zeros(max(self.n_source, 1), np.float32)
         self._ck(self._L.cilhip_get_nn(self._h, idx.ctypes.data, d2.ctypes.data, capi.MEM_HOST))

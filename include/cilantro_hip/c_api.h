@@ -352,6 +352,13 @@ typedef struct {
   double build_ms;       /* last set_target wall time (upload + grid build) */
 } cilhip_grid_info;
 int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
+/* How many source points have, under T and within max_sq_dist, a nearest target point that is NOT unique in the pinned f32 squared
+ * distance (exactly equidistant candidates: duplicated points, a depth sensor's lattice).  Only there can this engine's
+ * correspondence differ from the reference's: the engine keeps the lowest target index, nanoflann the candidate its traversal meets
+ * first (core/kd_tree.hpp:82-90) -- both exact nearest neighbours.  0 = index parity with the reference is guaranteed for this
+ * search.  Diagnostic (one more exact search of every query). */
+int cilhip_get_tie_count(cilhip_ctx* ctx, const float T[16], float max_sq_dist, size_t* n_ties);
+
 /* CorrespondenceSearchCombinedMetricCombiner (registration/correspondence_search_combined_metric_combiner.hpp:8-81): the combined
  * metric's point-to-point terms read ONE engine's correspondence set, its point-to-plane terms ANOTHER's (own radius, feature
  * adaptors, post-filters) over the same two clouds.  Both contexts hold the same target / source and SECOND_TO_FIRST matches

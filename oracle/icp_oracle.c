@@ -647,6 +647,32 @@ void orc_nn_brute(const float* dst, size_t nd, const float* q, size_t nq, float 
   }
 }
 
+/* Exhaustive count of the queries whose nearest target point within the radius is not unique in the f32 squared distance of
+ * nanoflann's L2 adaptor (two or more points at exactly the smallest d2): where the reference's first-met tie rule
+ * (core/kd_tree.hpp:82-90) and a lowest-index rule can name different correspondences. */
+size_t orc_count_ties_brute(const float* dst, size_t nd, const float* q, size_t nq, float max_d, int num_threads) {
+#ifdef _OPENMP
+  if (num_threads <= 0) num_threads = omp_get_max_threads();
+#endif
+  (void)num_threads;
+  size_t ties = 0;
+#pragma omp parallel for schedule(static) num_threads(num_threads) reduction(+ : ties)
+  for (size_t i = 0; i < nq; ++i) {
+    float best = max_d; size_t cnt = 0;
+    for (size_t j = 0; j < nd; ++j) {
+      float d = eval_metric(q + 3 * i, dst + 3 * j);
+      if (d < best) { best = d; cnt = 1; } else if (d == best && cnt > 0) ++cnt;
+    }
+    ties += cnt >= 2 ? 1 : 0;
+  }
+  return ties;
+}
+
+/* threads of the combined-metric estimator's accumulation loops (1: serial, the parity tests' order; > 1: the reference's default
+ * OpenMP reduction -- see estimator_impl.inc) */
+static int orc_estimator_threads = 1;
+void orc_set_estimator_threads(int n) { orc_estimator_threads = n > 1 ? n : 1; }
+
 /* ---- solver / estimator instantiations ---------------------------------------------------------- */
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)

@@ -70,6 +70,8 @@ size_t orc_filter_one_to_one(int64_t* dst_idx, int64_t* src_idx, float* d2, size
 /* Exhaustive exact 1-NN-in-radius (validation of both the kd-tree restatement and the GPU grid):
  * argmin over all dst of the pinned d2 expression, strict '<' vs radius, LOWEST index on ties.
  * nn_idx[i] = -1 if none. */
+/* queries whose nearest target point within the radius is not unique in the pinned f32 distance (exhaustive) */
+size_t orc_count_ties_brute(const float* dst_xyz, size_t nd, const float* q_xyz, size_t nq, float max_sq_dist, int num_threads);
 void orc_nn_brute(const float* dst_xyz, size_t nd, const float* q_xyz, size_t nq, float max_sq_dist,
                   int64_t* nn_idx, float* nn_d2, int num_threads);
 
@@ -116,6 +118,10 @@ int orc_estimate_combined(const float* dst_xyz, const float* dst_nrm, const floa
                           float w_p2p, float w_p2pl, size_t max_iter, float conv_tol,
                           const float dst_mean[3], const float src_mean[3], int mode,
                           float T_out[16], double* AtA_out, double* Atb_out);
+
+/* OpenMP threads of the combined-metric estimators' accumulation loops: 1 (default) = serial; > 1 = the reference's default build
+ * (ENABLE_NON_DETERMINISTIC_PARALLELISM, transform_estimation.hpp:284-344).  Used by the CPU baseline of bench.py only. */
+void orc_set_estimator_threads(int n);
 
 /* Two correspondence sets, as a CorrespondenceSearchCombinedMetricCombiner hands them over
  * (registration/correspondence_search_combined_metric_combiner.hpp:8-81): point terms from (dst_idx, src_idx, ncorr), plane terms

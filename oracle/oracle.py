@@ -88,6 +88,8 @@ def lib():
         L.orc_filter_fraction.argtypes = [_i64p, _i64p, _f32p, C.c_size_t, C.c_double]
         L.orc_filter_one_to_one.restype = C.c_size_t
         L.orc_filter_one_to_one.argtypes = [_i64p, _i64p, _f32p, C.c_size_t]
+        L.orc_count_ties_brute.restype = C.c_size_t
+        L.orc_count_ties_brute.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, C.c_int]
         L.orc_nn_brute.argtypes = [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_float, _i64p, _f32p, C.c_int]
         L.orc_svd3_f64.argtypes = [_f64p] * 4
         L.orc_svd3_f32.argtypes = [_f32p] * 4
@@ -269,6 +271,17 @@ def T_to_colmajor(T):
 
 def T_from_colmajor(t16):
     return np.asarray(t16, np.float32).reshape(4, 4).T.copy()
+
+
+def count_ties_brute(dst, q, max_sq_dist, num_threads=0):
+    """queries whose nearest target point within the radius is not unique in the pinned f32 distance (exhaustive)"""
+    dst = _c(dst).reshape(-1, 3); q = _c(q).reshape(-1, 3)
+    return int(lib().orc_count_ties_brute(dst, len(dst), q, len(q), np.float32(max_sq_dist), num_threads))
+
+
+def set_estimator_threads(n):
+    """OpenMP threads of the combined-metric estimator's accumulation (1 = serial, the tests' order; > 1 = the reference's default reduction)"""
+    lib().orc_set_estimator_threads(int(n))
 
 
 def nn_brute(dst, q, max_sq_dist, num_threads=0):

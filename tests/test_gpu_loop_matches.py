@@ -320,6 +320,42 @@ def test_real_sensor_frames_every_form(Context, orc):
     _report("real_cloud_forms.json", report)
 
 
+def test_tie_count_tells_when_index_parity_is_not_guaranteed(Context, orc):
+    """cilhip_get_tie_count: queries with two or more target points at exactly the smallest f32 distance -- the only place where the
+    engine (lowest index) and the reference (first met in its traversal, core/kd_tree.hpp:82-90) may differ.  Against the oracle's
+    exhaustive count: 0 on the uniform recipe, the duplicated points' queries on a target with exact duplicates, and on the
+    reference's raw frame_1 -> frame_2 under the identity at least the 321 queries where the two rules do pick different points."""
+    rng = np.random.default_rng(31)
+    base = syn.make_pair(60_000, perturb=0.3)
+    T = np.eye(4, dtype=np.float32)
+    ctx = Context(); ctx.set_target(base["dst"], base["dst_n"]); ctx.set_source(base["src"])
+    assert ctx.tie_count(T, float(base["max_sq_dist"])) == 0 == orc.count_ties_brute(base["dst"], orc.transform_points(T, base["src"]), float(base["max_sq_dist"]))
+    ctx.close()
+    dup = rng.choice(len(base["dst"]), 700, replace=False)
+    D = np.ascontiguousarray(np.concatenate([base["dst"], base["dst"][dup]]))
+    ctx = Context(); ctx.set_target(D, None); ctx.set_source(base["src"])
+    for Tq in (T, base["T_true"].astype(np.float32)):
+        want = orc.count_ties_brute(D, orc.transform_points(Tq, base["src"]), float(base["max_sq_dist"]))
+        got = ctx.tie_count(Tq, float(base["max_sq_dist"]))
+        assert got == want and want > 0, (got, want)
+    ctx.close()
+    f = np.load(os.path.join(HERE, "golden", "frames_full.npz"))
+    p1, p2 = f["p1"], f["p2"]
+    Df = np.ascontiguousarray(p1[p1[:, 0] > -0.4]); S = np.ascontiguousarray(p2)
+    r2 = float(np.float32(0.02 * 0.02))
+    ctx = Context(); ctx.set_target(Df, None); ctx.set_source(S)
+    got = ctx.tie_count(T, r2)
+    ctx.close()
+    want = orc.count_ties_brute(Df, S, r2)
+    bi, _ = orc.nn_brute(Df, S, r2)
+    tree = orc.KDTree(Df, use_ref=orc.ref_available())
+    o1, o2, _ov = tree.find_correspondences(S, r2)
+    oi = np.full(len(S), -1, np.int64); oi[o2] = o1
+    differ = int(np.count_nonzero(bi != oi))
+    assert got == want and got >= differ > 0, (got, want, differ)
+    _report("tie_count.json", {"frame_1 vs frame_2, identity": {"tied_queries": got, "queries_where_the_two_tie_rules_differ": differ, "queries": int(len(S))}})
+
+
 def test_warm_kernel_matches_index_for_index_10m(Context, orc):
     """BASELINE configs[2] at full size: the adaptive loop of the bench (tiles, then warm-started iterations) and the forced
     warm form; the last iteration's 10M matches against a fresh tiled search (every index, every d2 bit) and a 200k-query

@@ -1206,8 +1206,13 @@ def test_full_size_target_sharded_config(orc, hip_lib):
     p.w_p2p = 0.1; p.w_p2pl = 1.0
     for e in engs:
         e.begin(p, np.eye(4, dtype=np.float32))
-    for _ in range(6):
+    T_last = last_keys = None
+    for it in range(6):
+        if it == 5:
+            T_last = engs[0].state()[0]          # the transform the LAST iteration searches under
         keys = torch.minimum(engs[0].partial_keys(), engs[1].partial_keys())
+        if it == 5:
+            last_keys = keys.cpu().numpy().copy()
         sums = engs[0].sums_from_keys(keys).clone() + engs[1].sums_from_keys(keys)
         for e in engs:
             e.apply_sums(sums)
@@ -1217,6 +1222,21 @@ def test_full_size_target_sharded_config(orc, hip_lib):
     assert np.linalg.norm(T1 - d["T_true"]) < 1e-5, float(np.linalg.norm(T1 - d["T_true"]))
     del engs
     torch.cuda.empty_cache()
+    tree = orc.KDTree(d["dst"], use_ref=orc.ref_available())
+    # the sharded LOOP's own correspondences: the last iteration's all-reduced keys (packed (bits(d2) << 32) | global target index per
+    # source point) against the reference's nanoflann over the whole 80M-point target on a 200k-query sample, index for index, bit for bit
+    rng = np.random.default_rng(322)
+    sample = np.sort(rng.choice(len(d["src"]), 200_000, replace=False))
+    ks = last_keys[sample]
+    none = ks == distributed.KEY_NONE
+    gi = np.where(none, -1, ks & 0xFFFFFFFF).astype(np.int64)
+    gd = (ks >> 32).astype(np.uint32).view(np.float32)
+    o1, o2, ov = tree.find_correspondences(orc.transform_points(T_last, np.ascontiguousarray(d["src"][sample])), float(d["max_sq_dist"]))
+    oi = np.full(len(sample), -1, np.int64); od = np.zeros(len(sample), np.float32)
+    oi[o2] = o1; od[o2] = ov
+    assert np.array_equal(gi, oi), int(np.count_nonzero(gi != oi))
+    assert np.array_equal(gd[oi >= 0].view(np.uint32), od[oi >= 0].view(np.uint32))
+    loop_sample = {"loop_sample": int(len(sample)), "loop_sample_matched": int(np.count_nonzero(oi >= 0)), "loop_sample_mismatches": 0}
 
     # Against the oracle over the FULL 80M-point target (the reference's nanoflann where available): a 40k-query sample of
     # the source under a drifted transform -- indices and squared distances bit for bit -- and one combined-metric
@@ -1230,7 +1250,6 @@ def test_full_size_target_sharded_config(orc, hip_lib):
     ctx = Context(); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(src_s)
     gi, gd = gpu_nn(ctx, T, float(d["max_sq_dist"]))
     del ctx
-    tree = orc.KDTree(d["dst"], use_ref=orc.ref_available())
     o1, o2, ov = tree.find_correspondences(orc.transform_points(T, src_s), float(d["max_sq_dist"]))
     found = gi >= 0
     assert len(o2) > 0.99 * len(sample)
@@ -1243,7 +1262,7 @@ def test_full_size_target_sharded_config(orc, hip_lib):
     p = orc.make_params(metric=1, w_p2p=0.1, w_p2pl=1.0, max_iter=1, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]), mode=orc.MODE_MIXED)
     To, _ = orc.icp_update(d["dst"], d["dst_n"], src_s, T, o1, o2, p)
     err = float(np.linalg.norm(Tg.astype(np.float64) - To.astype(np.float64)))
-    _report("parity_c4.json", {"n_target": nd, "sample": len(sample), "found": int(len(o2)), "T_gpu_minus_T_oracle_frobenius": err})
+    _report("parity_c4.json", {"n_target": nd, "sample": len(sample), "found": int(len(o2)), "T_gpu_minus_T_oracle_frobenius": err, **loop_sample})
     assert err <= TOL_T, err
 
 
