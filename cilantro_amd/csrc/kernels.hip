@@ -2274,22 +2274,36 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
     // Streaming pass over the stored matches, TWO elements per lane per trip and the next trip's source points /
     // match indices requested before the current gathers (matched point, normal) are consumed: every lane keeps
     // 4 coalesced loads + 4 gathers in flight.  Per-lane accumulation order is unchanged (i, i+T, i+2T, ...).
+    // (k_warm's three rules, DESIGN.md section 5: every load UNCONDITIONAL -- indices clamped into the chunk, positions clamped into
+    //  the target, the results masked afterwards: a load under a divergent branch "may not have been issued" for the compiler's
+    //  in-order vmcnt bookkeeping and its wait then drains the younger prefetch too --; the gathers of a trip leave before the next
+    //  trip's prefetch, so the wait for them leaves the prefetch in flight)
     uint32_t i0 = beg + threadIdx.x;
-    float4 sa = i0 < end ? a.src[i0] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 sb = i0 + ITER_THREADS < end ? a.src[i0 + ITER_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t pa = i0 < end ? a.nn_pos[i0] : NONE_U32, pb = i0 + ITER_THREADS < end ? a.nn_pos[i0 + ITER_THREADS] : NONE_U32;
+    const uint32_t last = end > beg ? end - 1u : 0u;
+    const bool nrm_a = TR::plane || (TR::affine && a.grid.nrm != nullptr);      // (uniform)
+    float4 sa = a.src[min(i0, last)], sb = a.src[min(i0 + ITER_THREADS, last)];
+    uint32_t pa = a.nn_pos[min(i0, last)], pb = a.nn_pos[min(i0 + ITER_THREADS, last)];
+    if (!(i0 < end)) pa = NONE_U32;
+    if (!(i0 + ITER_THREADS < end)) pb = NONE_U32;
     while (i0 < end) {
       const float4 s4a = sa, s4b = sb;
       const uint32_t posa = pa, posb = pb;
       const uint32_t ia = i0, ib = i0 + ITER_THREADS;
       float4 p_a = make_float4(0.f, 0.f, 0.f, 0.f), nv_a = p_a, sn_a = p_a, p_b = p_a, nv_b = p_a, sn_b = p_a;
       if (METRIC != IM_NONE) {
-        if (posa != NONE_U32) { p_a = a.grid.pts[posa]; if (TR::plane) { nv_a = a.grid.nrm[posa]; if (a.src_nrm) sn_a = a.src_nrm[ia]; } else if (TR::affine && a.grid.nrm) nv_a = a.grid.nrm[posa]; }
-        if (posb != NONE_U32) { p_b = a.grid.pts[posb]; if (TR::plane) { nv_b = a.grid.nrm[posb]; if (a.src_nrm) sn_b = a.src_nrm[ib]; } else if (TR::affine && a.grid.nrm) nv_b = a.grid.nrm[posb]; }
+        const uint32_t ga = posa != NONE_U32 ? posa : 0u, gb = posb != NONE_U32 ? posb : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        p_a = a.grid.pts[ga]; p_b = a.grid.pts[gb];
+        if (nrm_a) { nv_a = a.grid.nrm[ga]; nv_b = a.grid.nrm[gb]; }
+        if (TR::plane && a.src_nrm) { sn_a = a.src_nrm[min(ia, last)]; sn_b = a.src_nrm[min(ib, last)]; }
+        __builtin_amdgcn_sched_barrier(0);
       }
       i0 += 2 * ITER_THREADS;
-      if (i0 < end) { sa = a.src[i0]; pa = a.nn_pos[i0]; } else pa = NONE_U32;
-      if (i0 + ITER_THREADS < end) { sb = a.src[i0 + ITER_THREADS]; pb = a.nn_pos[i0 + ITER_THREADS]; } else pb = NONE_U32;
+      sa = a.src[min(i0, last)]; pa = a.nn_pos[min(i0, last)];
+      sb = a.src[min(i0 + ITER_THREADS, last)]; pb = a.nn_pos[min(i0 + ITER_THREADS, last)];
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(i0 < end)) pa = NONE_U32;
+      if (!(i0 + ITER_THREADS < end)) pb = NONE_U32;
       float qx, qy, qz;
       transform_point(T, s4a.x, s4a.y, s4a.z, qx, qy, qz);
       // stored matches: the stored distance (the feature search's is the 6-D one) or, where none is kept, formed again
