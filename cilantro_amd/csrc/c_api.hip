@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "internal.hpp"
+#include "tie_order.hpp"
 
 using namespace cilhip;
 
@@ -85,6 +86,11 @@ struct cilhip_ctx {
   float* d_nn_lb = nullptr;       // [ns] margin keys the search-only tile kernel leaves next to nn_pos (IterArgs::nn_lb)
   bool lb_fresh = false;          // ... and they belong to the search that left nn_pos (inside a run)
   bool warm_forecast = true;      // option "warm_forecast": the cold kernels' count of the queries a warm-started iteration would have to search gates the form
+  int tie_rule = 0;               // option "tie_rule": 0 = lowest target index among exactly equidistant points, 1 = the one the reference's kd-tree meets first
+  cilhip::TieOrderTree* tie_tree = nullptr;      // (tie_rule 1: built from the target on first use, tie_order.hpp)
+  std::vector<float> tie_xyz;                    // the target in its original order (the tree's view of it)
+  TieEntry* d_tie_entries = nullptr; uint32_t tie_cap = 0; unsigned int* d_tie_count = nullptr; uint2* d_tie_patch = nullptr; uint32_t tie_patch_cap = 0;
+  unsigned long long tie_resolved = 0, tie_changed = 0;      // of the last search / run under tie_rule 1: tied queries seen, matches that were re-pointed
   bool tile_records = true;       // option "tile_records": the accumulating tile kernel writes the warm-started form's match records itself
   float warm_enter = 0.15f;       // option "warm_enter_fraction": the bar a run starts with, as a fraction of a grid cell
   float warm_thresh = 0.0f;       // a run's bar for (re-)entering the warm-started form: the last update moved no source point by more than this
@@ -258,6 +264,10 @@ void cilhip_destroy(cilhip_ctx* c) {
   free_source(c);
   if (c->has_target) free_grid(c->grid);
   if (c->d_safe2) (void)hipFree(c->d_safe2);
+  if (c->d_tie_entries) (void)hipFree(c->d_tie_entries);
+  if (c->d_tie_count) (void)hipFree(c->d_tie_count);
+  if (c->d_tie_patch) (void)hipFree(c->d_tie_patch);
+  delete c->tie_tree;
   if (c->d_dst_rgb) (void)hipFree(c->d_dst_rgb);
   if (c->d_dst_rgb_sorted) (void)hipFree(c->d_dst_rgb_sorted);
   if (c->d_state) (void)hipFree(c->d_state);
@@ -312,6 +322,12 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return CILHIP_OK; }
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "tie_rule")) {
+    if (value != 0.0 && value != 1.0) return fail(c, CILHIP_ERR_INVALID, "tie_rule: 0 (lowest index) or 1 (the reference's kd-tree order)");
+    if ((int)value != c->tie_rule) drop_matches(c);
+    c->tie_rule = (int)value;
+    return CILHIP_OK;
+  }
   if (!strcmp(key, "tile_records")) { c->tile_records = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "warm_enter_fraction")) {
     if (!(value > 0.0)) return fail(c, CILHIP_ERR_INVALID, "warm_enter_fraction: > 0 (fraction of a grid cell)");
@@ -461,6 +477,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
   c->warm_banned = false;
+  delete c->tie_tree; c->tie_tree = nullptr; c->tie_xyz.clear();
   c->dst_rgb_sorted_ok = false;
   if (c->d_dst_rgb) { (void)hipFree(c->d_dst_rgb); c->d_dst_rgb = nullptr; }      // (colours belong to the target they were set for)
   if (c->d_dst_rgb_sorted) { (void)hipFree(c->d_dst_rgb_sorted); c->d_dst_rgb_sorted = nullptr; }
@@ -706,7 +723,7 @@ static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params*
 // a feature adaptor is in force (6-D point+normal or point+colour, 9-D point+normal+colour): correspondences are compared by feature distance
 static bool feat6(const cilhip_ctx* c) { return c->normal_weight > 0.0f || (c->feature_kind == 2 && c->color_weight > 0.0f); }
 static bool warm_capable(const cilhip_ctx* c) {
-  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused && !c->tie_rule;
 }
 // k_self_nn's nearest-other-point table (4 B per target point, 0.5 ms at 10M): built by the first warm-capable run on a target
 static int ensure_safe2(cilhip_ctx* c) {
@@ -716,7 +733,71 @@ static int ensure_safe2(cilhip_ctx* c) {
   return CILHIP_OK;
 }
 static bool tile_accumulation(const cilhip_ctx* c) {
-  return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+  return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused && !c->tie_rule;
+}
+
+// Option "tie_rule" = 1: re-point the stored matches (nn_pos, found under the transform in d_state) of the queries that have
+// several target points at exactly the smallest distance to the one the reference's kd-tree traversal meets first
+// (tie_order.hpp).  The device lists those queries with their candidates, the host walks the tree for each, a small kernel
+// patches the matches: one host round trip per search -- the price of the option, paid only by callers that ask for it.
+static int resolve_ties(cilhip_ctx* c) {
+  c->tie_resolved = c->tie_changed = 0;
+  if (!c->ns || !c->grid.n) return CILHIP_OK;
+  if (!c->tie_tree) {
+    std::vector<float4> sorted(c->grid.n);
+    CK(c, hipMemcpyAsync(sorted.data(), c->grid.pts, (size_t)c->grid.n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    c->tie_xyz.assign((size_t)c->grid.n * 3, 0.0f);
+    for (uint32_t j = 0; j < c->grid.n; ++j) {
+      uint32_t o; memcpy(&o, &sorted[j].w, 4);
+      if (o >= c->grid.n) return fail(c, CILHIP_ERR_INVALID, "tie_rule: target index out of range");
+      c->tie_xyz[3 * (size_t)o] = sorted[j].x; c->tie_xyz[3 * (size_t)o + 1] = sorted[j].y; c->tie_xyz[3 * (size_t)o + 2] = sorted[j].z;
+    }
+    c->tie_tree = new (std::nothrow) cilhip::TieOrderTree();
+    if (!c->tie_tree) return fail(c, CILHIP_ERR_HIP, "tie_rule: out of host memory");
+    c->tie_tree->build(c->tie_xyz.data(), c->grid.n);
+  }
+  if (!c->d_tie_count) CK(c, hipMalloc(&c->d_tie_count, sizeof(unsigned int)));
+  if (!c->tie_cap) {
+    c->tie_cap = c->ns / 16u > 65536u ? c->ns / 16u : 65536u;
+    CK(c, hipMalloc(&c->d_tie_entries, (size_t)c->tie_cap * sizeof(TieEntry)));
+  }
+  unsigned int cnt = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    launch_tie_candidates(c->grid, c->d_src_sorted, c->ns, c->d_state, c->d_nn_pos, c->d_tie_entries, c->tie_cap, c->d_tie_count, c->stream);
+    CK(c, hipMemcpyAsync(&cnt, c->d_tie_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    if (cnt <= c->tie_cap) break;
+    (void)hipFree(c->d_tie_entries); c->d_tie_entries = nullptr; c->tie_cap = 0;      // (more tied queries than the list holds: once more with room for all)
+    CK(c, hipMalloc(&c->d_tie_entries, (size_t)cnt * sizeof(TieEntry)));
+    c->tie_cap = cnt;
+  }
+  c->tie_resolved = cnt;
+  if (!cnt) return CILHIP_OK;
+  std::vector<TieEntry> ent(cnt);
+  CK(c, hipMemcpy(ent.data(), c->d_tie_entries, (size_t)cnt * sizeof(TieEntry), hipMemcpyDeviceToHost));
+  std::vector<uint2> patch;
+  for (const TieEntry& e : ent) {
+    if (e.n > (uint32_t)TIE_MAXC) return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule: a query has more than 8 target points at exactly its nearest distance");
+    const float q[3] = {e.qx, e.qy, e.qz};
+    uint32_t lowest = 0;
+    for (uint32_t k = 1; k < e.n; ++k) if (e.orig[k] < e.orig[lowest]) lowest = k;     // what the search stored
+    const uint32_t w = c->tie_tree->first_met(q, e.orig, (int)e.n);
+    if (w != e.orig[lowest])
+      for (uint32_t k = 0; k < e.n; ++k) if (e.orig[k] == w) { patch.push_back(make_uint2(e.i, e.pos[k])); break; }
+  }
+  c->tie_changed = patch.size();
+  if (patch.empty()) return CILHIP_OK;
+  if (patch.size() > c->tie_patch_cap) {
+    if (c->d_tie_patch) (void)hipFree(c->d_tie_patch);
+    c->d_tie_patch = nullptr; c->tie_patch_cap = 0;
+    CK(c, hipMalloc(&c->d_tie_patch, patch.size() * sizeof(uint2)));
+    c->tie_patch_cap = (uint32_t)patch.size();
+  }
+  CK(c, hipMemcpyAsync(c->d_tie_patch, patch.data(), patch.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+  launch_patch_matches(c->d_tie_patch, (uint32_t)patch.size(), c->d_nn_pos, c->stream);
+  CK(c, hipStreamSynchronize(c->stream));      // (patch lives on this frame)
+  return CILHIP_OK;
 }
 
 // filterCorrespondencesFraction then filterCorrespondencesOneToOne on the stored matches
@@ -874,6 +955,8 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
     linear_inverse_transpose_f32(T, c->feat_M);
   }
   IterArgs a = make_iter_args(c, max_sq);
+  if (c->tie_rule && (c->search_dir != 0 || feat6(c) || c->index_offset))
+    return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule = 1 covers SECOND_TO_FIRST searches over points on one whole target");
   if (c->search_dir != 0) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
     rc = run_pair_search(c, a, max_sq, T);
@@ -889,6 +972,7 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   if (c->ns) {
     rc = launch_search(c, a);
     if (rc) return rc;
+    if (c->tie_rule) { rc = resolve_ties(c); if (rc) return rc; }
   }
   CK(c, hipGetLastError());
   rc = apply_filters(c);
@@ -963,6 +1047,13 @@ int cilhip_get_tie_count(cilhip_ctx* c, const float T[16], float max_sq, size_t*
   CK(c, hipStreamSynchronize(c->stream));
   CK(c, hipGetLastError());
   *n_ties = (size_t)v;
+  return CILHIP_OK;
+}
+
+int cilhip_get_tie_rule_stats(cilhip_ctx* c, size_t* tied_queries, size_t* repointed) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (tied_queries) *tied_queries = (size_t)c->tie_resolved;
+  if (repointed) *repointed = (size_t)c->tie_changed;
   return CILHIP_OK;
 }
 
@@ -1508,6 +1599,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   if (!c || !p || !out) return CILHIP_ERR_INVALID;
   if (p->metric != CILHIP_METRIC_POINT_TO_POINT && p->metric != CILHIP_METRIC_COMBINED) return fail(c, CILHIP_ERR_INVALID, "icp_run: bad metric");
   CK(c, hipSetDevice(c->device));
+  if (c->tie_rule && (c->search_dir != 0 || feat6(c) || c->index_offset || c->transform_mode == 1))
+    return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule = 1 covers the rigid SECOND_TO_FIRST loop over points on one whole target");
   if (c->transform_mode == 1) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "the affine variants are not available on target shards");
     return icp_run_affine(c, p, T0, out);
@@ -1680,7 +1773,14 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   bool warm_on = false;       // the loop has been seen to move little: iterations run warm-started until one of them has to search too many of its queries
   unsigned int judged = 0;    // the last published iteration whose listed count has been judged
   bool all_stored = true;     // every iteration enqueued left its matches in nn_pos (finish_run_matches)
+  unsigned long long tie_seen = 0, tie_moved = 0;
   for (size_t it = 0; it < p->max_iter; ++it) {
+    if (c->tie_rule && it >= 1) {      // (the device is idle after each iteration's tie resolution anyway: stop at convergence)
+      int done = 0;
+      CK(c, hipMemcpyAsync(&done, reinterpret_cast<const char*>(c->d_state) + offsetof(IcpState, done), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      CK(c, hipStreamSynchronize(c->stream));
+      if (done) break;
+    }
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
       FbView fv;
@@ -1731,7 +1831,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       a.skip_if_inner_done = (st > 0);
       if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
       if (c->ns) {
-        if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
+        if (st == 0 && c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
           all_stored = all_stored && gn && opt_steps > 1;
         } else if (st == 0 && warm) {
@@ -1770,6 +1870,11 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           c->lb_fresh = keys;
           counted = keys;
           { const int src_rc = launch_search(c, sa2); if (src_rc) return src_rc; }
+          if (c->tie_rule) {      // (a host round trip per iteration: the option's price)
+            const int trc = resolve_ties(c);
+            if (trc) return trc;
+            tie_seen += c->tie_resolved; tie_moved += c->tie_changed;
+          }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
@@ -1780,14 +1885,14 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       if (timing && st == 0) {
         // (two events per iteration around the search / one-pass kernels; a two-pass iteration adds a pair around its
         //  streaming accumulation, kept in a list of its own)
-        if (single || (c->fused && !filters_active(c) && !feat6(c)) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+        if (single || (c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
         else CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream));
         ++launches;
       }
       if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
       if (st == 0) {
         const unsigned char form = (unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
-                                                   : (c->fused && !filters_active(c) && !feat6(c)) ? FORM_LANE_FUSED : FORM_SEARCH);
+                                                   : (c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) ? FORM_LANE_FUSED : FORM_SEARCH);
         if (timing) c->iter_form.push_back(form);
         c->trace_form.push_back((unsigned char)(form | (counted ? 0x80 : 0)));
       }
@@ -1812,6 +1917,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   }
   CK(c, hipEventRecord(e_end, c->stream));
   CK(c, hipGetLastError());
+  if (c->tie_rule) { c->tie_resolved = tie_seen; c->tie_changed = tie_moved; }
   float Tprev[16];
   rc = read_state(c, out, Tprev);
   if (rc) return rc;
@@ -1848,6 +1954,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   CK(c, hipSetDevice(c->device));
   if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
   if (filters_active(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "inlier_fraction / one_to_one are global filters: not available in sharded runs");
+  if (c->tie_rule) return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule = 1 is not available in sharded runs");
   if (c->search_dir != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available in sharded runs");
   if (feat6(c) || c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features and the affine variants are not available in sharded runs");
   const float* Ti = T0 ? T0 : kIdentity;

@@ -309,6 +309,12 @@ void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys
 void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s);
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
 // queries (sorted source under T) whose nearest target point within the radius is not unique in the pinned f32 distance
+// option "tie_rule" = 1: the tied queries of the stored matches with their equidistant candidates (sorted positions and original indices)
+constexpr int TIE_MAXC = 8;
+struct TieEntry { uint32_t i; float qx, qy, qz; uint32_t n; uint32_t pos[TIE_MAXC]; uint32_t orig[TIE_MAXC]; };
+void launch_tie_candidates(const GridDev& g, const float4* src_sorted, uint32_t ns, const IcpState* st, const uint32_t* nn_pos, TieEntry* out, uint32_t cap,
+                           unsigned int* counter, hipStream_t s);
+void launch_patch_matches(const uint2* patches, uint32_t n, uint32_t* nn_pos, hipStream_t s);
 void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, const float T[16], float max_sq, unsigned long long* out, hipStream_t s);
 // squared distances of the stored matches under T, formed again with the search's pinned arithmetic (bit-identical to what the
 // search compared): the ICP loop does not store them, a caller of getCorrespondences() after estimate() reads them

@@ -3573,6 +3573,93 @@ void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, 
   hipLaunchKernelGGL(k_count_ties, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, g, src_sorted, ns, t, max_sq, out);
 }
 
+// ... and, for option "tie_rule" = 1 (the reference's order of ties, tie_order.hpp): the tied queries of the STORED matches with all
+// their equidistant candidates.  The stored match gives the distance outright, so only the closed ball of that radius is looked
+// at (shells, cells beyond the distance skipped); every point at exactly that distance is a candidate.  Entries are appended
+// through an atomic counter (their order does not matter: the host resolves each on its own).
+__global__ __launch_bounds__(256) void k_tie_candidates(GridDev g, const float4* __restrict__ src, uint32_t ns, const IcpState* __restrict__ st,
+                                                        const uint32_t* __restrict__ nn_pos, TieEntry* __restrict__ out, uint32_t cap, unsigned int* counter) {
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t mp = nn_pos[i];
+    if (mp == NONE_U32) continue;
+    const float4 s4 = src[i];
+    float qx, qy, qz;
+    transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+    const float4 pm = g.pts[mp];
+    const float bd = d2_pinned(qx, qy, qz, pm.x, pm.y, pm.z);
+    const float BIG = 1.0e9f;
+    const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG)), cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG)),
+              cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
+    uint32_t cpos[TIE_MAXC];
+    uint32_t nc = 0;
+    for (int s = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));; ++s) {
+      const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1), y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+      for (int z = z0; z <= z1; ++z) {
+        const float zl = g.oz + (float)z * g.cell;
+        const float az = axis_gap(qz, zl, zl + g.cell, g.margin);
+        for (int y = y0; y <= y1; ++y) {
+          const bool face = (z == cz - s) || (z == cz + s) || (y == cy - s) || (y == cy + s);
+          const float yl = g.oy + (float)y * g.cell;
+          const float ay = axis_gap(qy, yl, yl + g.cell, g.margin);
+          if ((az * az + ay * ay) * KSHRINK > bd) continue;
+          const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+          uint32_t rb[2] = {0, 0}, re[2] = {0, 0};
+          if (face) {
+            const int xa = max(cx - s, 0), xb = min(cx + s, g.nx - 1);
+            if (xa <= xb) { rb[0] = g.cell_start[row + xa]; re[0] = g.cell_start[row + xb + 1]; }
+          } else {
+            if (cx - s >= 0 && cx - s < g.nx) { rb[0] = g.cell_start[row + cx - s]; re[0] = g.cell_start[row + cx - s + 1]; }
+            if (s > 0 && cx + s >= 0 && cx + s < g.nx) { rb[1] = g.cell_start[row + cx + s]; re[1] = g.cell_start[row + cx + s + 1]; }
+          }
+          for (int r = 0; r < 2; ++r)
+            for (uint32_t j = rb[r]; j < re[r]; ++j) {
+              const float4 p = g.pts[j];
+              if (d2_pinned(qx, qy, qz, p.x, p.y, p.z) == bd) { if (nc < (uint32_t)TIE_MAXC) cpos[nc] = j; ++nc; }
+            }
+        }
+      }
+      float b = INFINITY;      // lower bound on the distance to anything not yet scanned
+      if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+      if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+      if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+      if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+      if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+      if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+      if (b == INFINITY) break;
+      b -= g.margin;
+      if (b > 0.0f && bd < b * b * KSHRINK) break;
+    }
+    if (nc >= 2) {      // (the match itself is one of them)
+      const unsigned int slot = atomicAdd(counter, 1u);
+      if (slot < cap) {
+        TieEntry e;
+        e.i = i; e.qx = qx; e.qy = qy; e.qz = qz; e.n = nc;
+        for (uint32_t k = 0; k < (uint32_t)TIE_MAXC; ++k) {
+          e.pos[k] = k < nc ? cpos[k] : NONE_U32;
+          e.orig[k] = k < nc ? __float_as_uint(g.pts[cpos[k < nc ? k : 0]].w) : NONE_U32;
+        }
+        out[slot] = e;
+      }
+    }
+  }
+}
+__global__ void k_patch_matches(const uint2* __restrict__ patches, uint32_t n, uint32_t* __restrict__ nn_pos) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) nn_pos[patches[k].x] = patches[k].y;
+}
+void launch_tie_candidates(const GridDev& g, const float4* src_sorted, uint32_t ns, const IcpState* st, const uint32_t* nn_pos, TieEntry* out, uint32_t cap,
+                           unsigned int* counter, hipStream_t s) {
+  (void)hipMemsetAsync(counter, 0, sizeof(unsigned int), s);
+  if (ns == 0 || g.n == 0) return;
+  hipLaunchKernelGGL(k_tie_candidates, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, g, src_sorted, ns, st, nn_pos, out, cap, counter);
+}
+void launch_patch_matches(const uint2* patches, uint32_t n, uint32_t* nn_pos, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_patch_matches, dim3((n + 255u) / 256u), dim3(256), 0, s, patches, n, nn_pos);
+}
+
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s) {
   (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
   if (ns == 0) return;

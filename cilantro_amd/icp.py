@@ -162,6 +162,12 @@ class Context:
         self._ck(self._L.cilhip_get_tie_count(self._h, t.ctypes.data, C.c_float(max_sq_dist), C.byref(n)))
         return n.value
 
+    def tie_rule_stats(self):
+        """under option tie_rule = 1: (tied queries, matches re-pointed to the reference's choice) of the last search / run"""
+        a = C.c_size_t(0); b = C.c_size_t(0)
+        self._ck(self._L.cilhip_get_tie_rule_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def get_nn(self):
         idx = np.zeros(max(self.n_source, 1), np.uint32); d2 = np.zeros(max(self.n_source, 1), np.float32)
         self._ck(self._L.cilhip_get_nn(self._h, idx.ctypes.data, d2.ctypes.data, capi.MEM_HOST))

@@ -358,6 +358,10 @@ int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
  * first (core/kd_tree.hpp:82-90) -- both exact nearest neighbours.  0 = index parity with the reference is guaranteed for this
  * search.  Diagnostic (one more exact search of every query). */
 int cilhip_get_tie_count(cilhip_ctx* ctx, const float T[16], float max_sq_dist, size_t* n_ties);
+/* Under option "tie_rule" = 1: of the last cilhip_find_correspondences (or summed over the iterations of the last cilhip_icp_run),
+ * the queries that had several exactly equidistant nearest target points, and how many of their matches were re-pointed from
+ * the lowest index to the reference's choice. */
+int cilhip_get_tie_rule_stats(cilhip_ctx* ctx, size_t* tied_queries, size_t* repointed);
 
 /* CorrespondenceSearchCombinedMetricCombiner (registration/correspondence_search_combined_metric_combiner.hpp:8-81): the combined
  * metric's point-to-point terms read ONE engine's correspondence set, its point-to-plane terms ANOTHER's (own radius, feature
@@ -448,6 +452,17 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        (or that leave without one); the warm-started form is entered only when that is at most an eighth of the
  *                        queries -- a pair whose matches lie far beyond the target's point spacing never pays for a try.  0 = enter
  *                        on the step alone (tests).
+ *   "tie_rule" (default 0): which of several EXACTLY equidistant nearest target points a correspondence names.  0 = the lowest
+ *                        target index (what a brute-force argmin gives; every kernel form).  1 = the point the reference's kd-tree
+ *                        search returns: nanoflann keeps the candidate its traversal meets first (core/kd_tree.hpp:82-90 over
+ *                        nanoflann 1.7.1 searchLevel), which depends on the tree it built (leaf size 10, core/kd_tree.hpp:162-170).
+ *                        The engine then lists, after each search, the queries with tied candidates (device), walks a host
+ *                        restatement of that tree's build for them (csrc/tie_order.hpp) and re-points those matches: indices and
+ *                        loop results equal the reference's on clouds with duplicated points or lattice ties too
+ *                        (tests/test_gpu_tie_rule.py).  Costs one host round trip per search and runs the loop in its
+ *                        search + streaming-accumulation form; covers the rigid SECOND_TO_FIRST path over points on one whole
+ *                        target (CILHIP_ERR_UNSUPPORTED otherwise; more than 8 candidates at one distance: same).
+ *                        cilhip_get_tie_count tells beforehand whether a pair of clouds has any tie at all.
  *   "tile_records" (default 1): the accumulating tile kernel writes the match records of the warm-started form itself (from a
  *                        run's second iteration on), so that the next iteration can read them; 0 = the first warm-started
  *                        iteration of a stretch gathers through the stored matches and writes them (A/B).

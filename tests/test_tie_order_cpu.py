@@ -1,0 +1,83 @@
+"""csrc/tie_order.hpp (option "tie_rule" = 1) on the host: the tree restatement names, for every query with several exactly
+equidistant nearest target points, the point the reference's nanoflann returns (core/kd_tree.hpp:82-90; oracle/_ref when built,
+the oracle's kd-tree restatement otherwise).  No GPU: the header is host-only, compiled by tests/cpp/build.sh into a shim."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from cilantro_amd import synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "cpp", "bin", "libtie_order_shim.so")
+K = 12
+
+
+@pytest.fixture(scope="module")
+def shim():
+    if not os.path.exists(SHIM):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", os.path.join(ROOT, "tests", "cpp", "tie_order_shim.cpp"), "-o", SHIM])
+    L = C.CDLL(SHIM)
+    L.tie_shim_build.restype = C.c_void_p
+    L.tie_shim_build.argtypes = [C.c_void_p, C.c_uint32]
+    L.tie_shim_free.argtypes = [C.c_void_p]
+    L.tie_shim_first_met.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p]
+    return L
+
+
+def _pinned_d2(q, p):      # (dx*dx + dy*dy) + dz*dz in f32, no contraction: the engine's and nanoflann's 3-D distance
+    d = (q - p).astype(np.float32)
+    return ((d[..., 0] * d[..., 0]) + (d[..., 1] * d[..., 1])).astype(np.float32) + (d[..., 2] * d[..., 2]).astype(np.float32)
+
+
+def tied_queries(D, Q, r2):
+    """-> (query indices, candidates [n, K] ascending original index, counts)"""
+    _, nb = cKDTree(D.astype(np.float64)).query(Q.astype(np.float64), k=K)
+    d2 = _pinned_d2(Q[:, None, :], D[nb])
+    m = d2.min(axis=1)
+    tied = d2 == m[:, None]
+    cnt = tied.sum(axis=1)
+    assert cnt.max() < K
+    sel = np.nonzero((cnt >= 2) & (m <= r2))[0]
+    cand = np.zeros((len(sel), K), np.uint32)
+    for k, i in enumerate(sel):
+        c = np.sort(nb[i][tied[i]])
+        cand[k, : len(c)] = c
+    return sel, cand, cnt[sel].astype(np.int32)
+
+
+def _first_met(L, D, Q, cand, counts):
+    h = L.tie_shim_build(np.ascontiguousarray(D, np.float32).ctypes.data, len(D))
+    q = np.ascontiguousarray(Q, np.float32)
+    out = np.zeros(max(len(q), 1), np.uint32)
+    L.tie_shim_first_met(h, q.ctypes.data, cand.ctypes.data, counts.ctypes.data, K, len(q), out.ctypes.data)
+    L.tie_shim_free(h)
+    return out[: len(q)].astype(np.int64)
+
+
+def _clouds():
+    f = np.load(os.path.join(ROOT, "tests", "golden", "frames_full.npz"))
+    p1, p2 = f["p1"], f["p2"]
+    yield "frame_1 -> frame_2 (sensor lattice)", np.ascontiguousarray(p1[p1[:, 0] > -0.4]), np.ascontiguousarray(p2), float(np.float32(0.02 * 0.02))
+    rng = np.random.default_rng(3)
+    b = syn.make_pair(60_000, perturb=0.3)
+    dup = rng.choice(len(b["dst"]), 3000, replace=False)
+    D = np.ascontiguousarray(np.concatenate([b["dst"], b["dst"][dup], b["dst"][dup[:500]]]))      # doubled and tripled points
+    yield "duplicated target points", D, b["src"], float(b["max_sq_dist"])
+
+
+def test_first_met_is_the_reference_pick(shim, orc):
+    for name, D, S, r2 in _clouds():
+        sel, cand, counts = tied_queries(D, S, r2)
+        assert len(sel) > 500, name
+        got = _first_met(shim, D, S[sel], cand, counts)
+        tree = orc.KDTree(D, use_ref=orc.ref_available())
+        o1, o2, _ = tree.find_correspondences(S, r2)
+        oi = np.full(len(S), -1, np.int64)
+        oi[o2] = o1
+        assert np.array_equal(got, oi[sel]), (name, int(np.count_nonzero(got != oi[sel])))
+        # (and the rule matters: the lowest index is a different point for a good part of them)
+        assert np.count_nonzero(cand[:, 0].astype(np.int64) != oi[sel]) > len(sel) // 4, name
