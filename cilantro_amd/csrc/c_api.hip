@@ -91,6 +91,7 @@ struct cilhip_ctx {
   std::vector<float> tie_xyz;                    // the target in its original order (the tree's view of it)
   TieEntry* d_tie_entries = nullptr; uint32_t tie_cap = 0; unsigned int* d_tie_count = nullptr; uint2* d_tie_patch = nullptr; uint32_t tie_patch_cap = 0;
   unsigned long long tie_resolved = 0, tie_changed = 0;      // of the last search / run under tie_rule 1: tied queries seen, matches that were re-pointed
+  float warm_extra = 0.0625f;     // option "warm_extra_fraction"
   bool tile_records = true;       // option "tile_records": the accumulating tile kernel writes the warm-started form's match records itself
   float warm_enter = 0.15f;       // option "warm_enter_fraction": the bar a run starts with, as a fraction of a grid cell
   float warm_thresh = 0.0f;       // a run's bar for (re-)entering the warm-started form: the last update moved no source point by more than this
@@ -326,6 +327,11 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
     if (value != 0.0 && value != 1.0) return fail(c, CILHIP_ERR_INVALID, "tie_rule: 0 (lowest index) or 1 (the reference's kd-tree order)");
     if ((int)value != c->tie_rule) drop_matches(c);
     c->tie_rule = (int)value;
+    return CILHIP_OK;
+  }
+  if (!strcmp(key, "warm_extra_fraction")) {
+    if (!(value > 0.0 && value <= 1.0)) return fail(c, CILHIP_ERR_INVALID, "warm_extra_fraction: in (0, 1]");
+    c->warm_extra = (float)value;
     return CILHIP_OK;
   }
   if (!strcmp(key, "tile_records")) { c->tile_records = value != 0.0; return CILHIP_OK; }
@@ -697,6 +703,7 @@ static int ensure_warm_buffers(cilhip_ctx* c) {
 }
 static void set_warm_args(const cilhip_ctx* c, IterArgs& wa) {
   const size_t cap = c->ns ? c->ns : 1;
+  wa.warm_extra = c->warm_extra;
   wa.warm_rec = c->d_warm_rec;
   wa.warm_rec_n = reinterpret_cast<F3*>(c->d_warm_rec + cap);
   wa.warm_src3 = wa.warm_rec_n + cap;
@@ -1781,6 +1788,19 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
       CK(c, hipStreamSynchronize(c->stream));
       if (done) break;
     }
+    if (paced && it == 1 && wcap && c->warm_start == 1 && !c->warm_banned && !c->trace_form.empty() && (c->trace_form[0] & 0x80)) {
+      // The SECOND iteration can already run warm-started when the first one moved the source by a small fraction of a cell (a
+      // source that starts aligned: tracking, a refinement pass) and its kernels' own forecast agrees: worth one look at the
+      // first iteration's result before the second is enqueued (the device idles for the host's reaction once per run; a cold
+      // iteration costs three times a warm one).
+      FbView fv;
+      rc = wait_published_or_sync(c, 1u, &fv);
+      if (rc) return rc;
+      if (fv.done) break;
+      if ((c->trace_form[0] & 0x7f) <= FORM_TILE_ONE_PASS) c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
+      const bool forecast_ok = !c->warm_forecast || (unsigned long long)fv.listed * 8ull <= (unsigned long long)c->ns;
+      warm_on = fv.iterations == 1u && forecast_ok && warm_worthwhile(c, fv.step);
+    }
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
       FbView fv;
@@ -1823,7 +1843,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     // Third form, from the second iteration on: search + accumulation WARM-STARTED from the previous iteration's matches and
     // the margins their searches left (kept by the forms above) -- no tile to stage at all.  Same matches, same sums up to
     // the order of the f64 additions.
-    const bool warm = wcap && it >= 1 && (c->warm_start == 2 || (paced && it >= 2 && warm_on));
+    const bool warm = wcap && it >= 1 && (c->warm_start == 2 || (paced && warm_on));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     bool warm_first = false;
     bool counted = false;      // a cold iteration whose kernels count the queries a warm-started iteration after it would have to search

@@ -152,6 +152,7 @@ struct IterArgs {
   CorrWeights cw;              // per-correspondence weights (enabled = 0: unity)
   const uint32_t* warm_pos;    // [ns] or null: matches of the previous iteration, the per-lane search's warm start (may alias nn_pos)
   float warm_far_sq;           // warm bounds at or above this (squared) are counted in unproven_cnt
+  float warm_extra;            // (k_warm) a listed query's search reaches this fraction of a cell beyond its bound: the room of its fresh margin
   float4* warm_rec;            // [ns] or null: per query {matched point, its safe2 entry (< 0: no match)}
   F3* warm_rec_n;              // [ns]: the matched point's normal
   F3* warm_src3;               // [ns]: the sorted source points without their index (12 B instead of 16)

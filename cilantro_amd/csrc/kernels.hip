@@ -2600,7 +2600,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   //   B: the 5x5x5 block slab by slab, rows beyond sqrt(best so far) + extra skipped, then (rarely) the shell search with the
   //      same margin.
   // Stores the match, its record and the key.
-  const float extra = 0.25f * g.cell;
+  const float extra = a.warm_extra * g.cell;
   auto slow_finish = [&](bool v, uint32_t i, const NN& best, const float4 bp, float key, float4& pm, float4& nm) -> bool {
     const bool has = v && best.pos != NONE_U32;
     nm = Z4;

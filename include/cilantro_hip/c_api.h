@@ -463,6 +463,10 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        search + streaming-accumulation form; covers the rigid SECOND_TO_FIRST path over points on one whole
  *                        target (CILHIP_ERR_UNSUPPORTED otherwise; more than 8 candidates at one distance: same).
  *                        cilhip_get_tie_count tells beforehand whether a pair of clouds has any tie at all.
+ *   "warm_extra_fraction" (default 0.0625): a query the warm-started form has to search is searched inside the ball of its bound
+ *                        plus this fraction of a grid cell -- the room its fresh margin can have.  Larger: more cells per
+ *                        search, margins that last longer; measured best at 10M (independent source: 0.25 -> 0.216 ms per
+ *                        warm-started iteration, 0.0625 -> 0.197, 0.03 -> 0.199).  Never changes a result.
  *   "tile_records" (default 1): the accumulating tile kernel writes the match records of the warm-started form itself (from a
  *                        run's second iteration on), so that the next iteration can read them; 0 = the first warm-started
  *                        iteration of a stretch gathers through the stored matches and writes them (A/B).
