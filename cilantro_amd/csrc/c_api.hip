@@ -92,6 +92,7 @@ struct cilhip_ctx {
   TieEntry* d_tie_entries = nullptr; uint32_t tie_cap = 0; unsigned int* d_tie_count = nullptr; uint2* d_tie_patch = nullptr; uint32_t tie_patch_cap = 0;
   unsigned long long tie_resolved = 0, tie_changed = 0;      // of the last search / run under tie_rule 1: tied queries seen, matches that were re-pointed
   float warm_extra = 0.0625f;     // option "warm_extra_fraction"
+  bool pair_records = true;       // option "pair_records": the streaming accumulation gathers a match's point and normal from one 32-byte record (GridDev::pn)
   bool tile_records = true;       // option "tile_records": the accumulating tile kernel writes the warm-started form's match records itself
   float warm_enter = 0.15f;       // option "warm_enter_fraction": the bar a run starts with, as a fraction of a grid cell
   float warm_thresh = 0.0f;       // a run's bar for (re-)entering the warm-started form: the last update moved no source point by more than this
@@ -334,6 +335,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
     c->warm_extra = (float)value;
     return CILHIP_OK;
   }
+  if (!strcmp(key, "pair_records")) { c->pair_records = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tile_records")) { c->tile_records = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "warm_enter_fraction")) {
     if (!(value > 0.0)) return fail(c, CILHIP_ERR_INVALID, "warm_enter_fraction: > 0 (fraction of a grid cell)");
@@ -700,6 +702,15 @@ static int ensure_warm_buffers(cilhip_ctx* c) {
     c->src3_valid = true;
   }
   return CILHIP_OK;
+}
+// {point, normal} of every target position side by side (GridDev::pn), for the streaming accumulation's gathers: built by the first run
+// that streams over stored matches with a metric that reads normals (32 B per target point; without room for it the two arrays serve)
+static void ensure_pair_records(cilhip_ctx* c) {
+  if (c->grid.pn || !c->pair_records || !c->grid.nrm || !c->grid.n) return;
+  float4* pn = nullptr;
+  if (hipMalloc(&pn, (size_t)c->grid.n * 2 * sizeof(float4)) != hipSuccess) { (void)hipGetLastError(); return; }
+  launch_interleave_pn(c->grid.pts, c->grid.nrm, c->grid.n, pn, c->stream);
+  c->grid.pn = pn;
 }
 static void set_warm_args(const cilhip_ctx* c, IterArgs& wa) {
   const size_t cap = c->ns ? c->ns : 1;
@@ -1623,7 +1634,9 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 1) : 1;
   ++c->run_tag;
   launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half);
+  if (gn && c->ns >= 65536) ensure_pair_records(c);
   IterArgs a = make_iter_args(c, p->max_sq_dist);
+  if (!c->pair_records) a.grid.pn = nullptr;
   a.cw = corr_weights_of(c, p);
   SolveArgs sa = make_solve_args(c, p, im, c->src_mean);
   sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;

@@ -220,7 +220,7 @@ static void set_dims(GridDev& g, const float lo[3], const float hi[3], double ce
 hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStream_t s, GridBuildResult* out, double mean_out[3],
                       double target_occupancy) {
   GridDev g{};
-  g.n = n; g.pts = nullptr; g.nrm = nullptr; g.cell_start = nullptr;
+  g.n = n; g.pts = nullptr; g.nrm = nullptr; g.pn = nullptr; g.cell_start = nullptr;
   out->avg_occupancy = 0.0;
   if (n == 0) {
     // empty target: a minimal grid of empty cells; every search returns "none" (kd_tree_utilities.hpp:16-19)
@@ -290,8 +290,9 @@ hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStr
 void free_grid(GridDev& g) {
   if (g.pts) (void)hipFree((void*)g.pts);
   if (g.nrm) (void)hipFree((void*)g.nrm);
+  if (g.pn) (void)hipFree((void*)g.pn);
   if (g.cell_start) (void)hipFree((void*)g.cell_start);
-  g.pts = nullptr; g.nrm = nullptr; g.cell_start = nullptr;
+  g.pts = nullptr; g.nrm = nullptr; g.pn = nullptr; g.cell_start = nullptr;
 }
 
 // ---- source ordering + tiles ------------------------------------------------------------------------

@@ -47,6 +47,8 @@ struct GridDev {
   uint32_t n;                  // number of target points
   const float4* pts;           // [n]  sorted {x,y,z,orig_idx}
   const float4* nrm;           // [n]  sorted {nx,ny,nz,0} or nullptr
+  const float4* pn;            // [2n] or nullptr: point and normal of position j side by side ({pts[j], nrm[j]}, 32 B): what the streaming
+                               //      accumulation gathers through the stored matches -- one line per match instead of two (built on first use)
   const uint32_t* cell_start;  // [nx*ny*nz + 1]
 };
 
@@ -280,6 +282,7 @@ void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nbl
 void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s);
 // rec: 1 = gather through warm_pos (+ the searches' margin keys in nn_lb) and write the match records, 2 = read the match records (a.warm_rec)
 void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_t s);
+void launch_interleave_pn(const float4* pts, const float4* nrm, uint32_t n, float4* pn, hipStream_t s);
 void launch_copy_src3(const float4* src_sorted, uint32_t ns, F3* out, hipStream_t s);   // a.warm_src3 of the record-reading form
 int warm_num_blocks(uint32_t ns);      // blocks (= partial-sum rows) of launch_warm
 void launch_solve(const SolveArgs& a, hipStream_t s);

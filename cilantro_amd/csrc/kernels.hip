@@ -1271,6 +1271,7 @@ __device__ unsigned long long g_phase_clk[8];
 #define PHASE_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_clk[k], now_ - tprev_); tprev_ = now_; } } while (0)
 void debug_dump_pipe_clocks();
 __device__ unsigned long long g_warm_clk[16];
+__device__ unsigned long long g_warm_stamp[4096][2];      // per block of the LAST k_warm launch: start / end (100 MHz wall clock)
 #define WARM_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_warm_clk[k], now_ - tprev_); atomicAdd(&g_warm_clk[8 + (k)], 1ull); tprev_ = now_; } } while (0)
 static void debug_dump_warm_clocks() {
   unsigned long long h[16];
@@ -1281,6 +1282,24 @@ static void debug_dump_warm_clocks() {
           (double)h[12] / h[8], (double)h[5] / h[8]);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warm_clk), h, sizeof h);
+  // the last launch, block by block: when it started / ended relative to the first start; by XCD (blockIdx & 7)
+  static unsigned long long st[4096][2];
+  if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_warm_stamp), sizeof st) != hipSuccess) return;
+  unsigned long long t0 = ~0ull; int nb = 0;
+  for (int b = 0; b < 4096; ++b) if (st[b][1]) { nb = b + 1; if (st[b][0] < t0) t0 = st[b][0]; }
+  if (!nb) return;
+  double smax = 0, emax = 0, emin = 1e30, dsum = 0, dmin = 1e30, dmax = 0;
+  double xe[8] = {0}, xd[8] = {0}; int xn[8] = {0};
+  for (int b = 0; b < nb; ++b) {
+    const double s0 = (double)(st[b][0] - t0) / 100.0, e0 = (double)(st[b][1] - t0) / 100.0, d = e0 - s0;
+    if (s0 > smax) smax = s0; if (e0 > emax) emax = e0; if (e0 < emin) emin = e0; dsum += d; if (d < dmin) dmin = d; if (d > dmax) dmax = d;
+    if (e0 > xe[b & 7]) xe[b & 7] = e0; xd[b & 7] += d; ++xn[b & 7];
+  }
+  fprintf(stderr, "[warm stamps, last launch, %d blocks, us] last start=%.1f  first end=%.1f  last end=%.1f  block lifetime min/avg/max=%.1f/%.1f/%.1f  per XCD (avg life, last end):", nb, smax, emin, emax, dmin, dsum / nb, dmax);
+  for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f,%.1f", xn[x] ? xd[x] / xn[x] : 0.0, xe[x]);
+  fprintf(stderr, "\n");
+  memset(st, 0, sizeof st);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warm_stamp), st, sizeof st);
 }
 void debug_dump_phase_clocks() {
   debug_dump_pipe_clocks();
@@ -2293,8 +2312,13 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       if (METRIC != IM_NONE) {
         const uint32_t ga = posa != NONE_U32 ? posa : 0u, gb = posb != NONE_U32 ? posb : 0u;
         __builtin_amdgcn_sched_barrier(0);
-        p_a = a.grid.pts[ga]; p_b = a.grid.pts[gb];
-        if (nrm_a) { nv_a = a.grid.nrm[ga]; nv_b = a.grid.nrm[gb]; }
+        if (nrm_a && a.grid.pn != nullptr) {      // (uniform) point and normal of a match from ONE 32-byte record
+          p_a = a.grid.pn[2 * (size_t)ga]; nv_a = a.grid.pn[2 * (size_t)ga + 1];
+          p_b = a.grid.pn[2 * (size_t)gb]; nv_b = a.grid.pn[2 * (size_t)gb + 1];
+        } else {
+          p_a = a.grid.pts[ga]; p_b = a.grid.pts[gb];
+          if (nrm_a) { nv_a = a.grid.nrm[ga]; nv_b = a.grid.nrm[gb]; }
+        }
         if (TR::plane && a.src_nrm) { sn_a = a.src_nrm[min(ia, last)]; sn_b = a.src_nrm[min(ib, last)]; }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -2524,6 +2548,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   float* const wr = dr[wave];
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   unsigned long long tprev_ = wall_clock64();
+  if (threadIdx.x == 0 && blockIdx.x < 4096u) g_warm_stamp[blockIdx.x][0] = tprev_;
 #endif
   typedef double double4_t __attribute__((ext_vector_type(4)));
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -2924,6 +2949,9 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     a.partials[(size_t)vb * SUMS_MAX + threadIdx.x] = v1 - v2;
   }
   WARM_CLK(5);
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x < 4096u) g_warm_stamp[blockIdx.x][1] = wall_clock64();
+#endif
 }
 
 #undef Z4
@@ -2962,6 +2990,12 @@ void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_
 // the 12-byte copy of the sorted source the record-reading warm kernel streams (once per sort of a source)
 __global__ void k_copy_src3(const float4* __restrict__ src, uint32_t ns, F3* __restrict__ out) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) { const float4 v = src[i]; out[i] = F3{v.x, v.y, v.z}; }
+}
+__global__ void k_interleave_pn(const float4* __restrict__ pts, const float4* __restrict__ nrm, uint32_t n, float4* __restrict__ pn) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { pn[2 * (size_t)i] = pts[i]; pn[2 * (size_t)i + 1] = nrm[i]; }
+}
+void launch_interleave_pn(const float4* pts, const float4* nrm, uint32_t n, float4* pn, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_interleave_pn, dim3((n + 255u) / 256u < 8192u ? (n + 255u) / 256u : 8192u), dim3(256), 0, s, pts, nrm, n, pn);
 }
 void launch_copy_src3(const float4* src_sorted, uint32_t ns, F3* out, hipStream_t s) {
   if (ns) hipLaunchKernelGGL(k_copy_src3, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, src_sorted, ns, out);

@@ -39,7 +39,7 @@ def run(name, D, N, S, r2, metric=capi.METRIC_COMBINED):
 
 which = os.environ.get("WT_CASES", "recipe,indep,frames").split(",")
 if "recipe" in which or "indep" in which:
-    d = syn.make_pair(n, n, with_normals=True)
+    d = syn.make_pair(n, n, with_normals=True, noise=float(os.environ.get("WT_NOISE", "0.05")))
     if "recipe" in which:
         run("recipe", d["dst"], d["dst_n"], d["src"], d["max_sq_dist"])
         run("recipe p2p", d["dst"], None, d["src"], d["max_sq_dist"], capi.METRIC_POINT_TO_POINT)
