@@ -1271,7 +1271,7 @@ __device__ unsigned long long g_phase_clk[8];
 #define PHASE_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_clk[k], now_ - tprev_); tprev_ = now_; } } while (0)
 void debug_dump_pipe_clocks();
 __device__ unsigned long long g_warm_clk[16];
-__device__ unsigned long long g_warm_stamp[4096][2];      // per block of the LAST k_warm launch: start / end (100 MHz wall clock)
+__device__ unsigned long long g_warm_stamp[4096][3];      // per block of the LAST k_warm launch: start / end (100 MHz wall clock)
 #define WARM_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_warm_clk[k], now_ - tprev_); atomicAdd(&g_warm_clk[8 + (k)], 1ull); tprev_ = now_; } } while (0)
 static void debug_dump_warm_clocks() {
   unsigned long long h[16];
@@ -1283,7 +1283,7 @@ static void debug_dump_warm_clocks() {
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warm_clk), h, sizeof h);
   // the last launch, block by block: when it started / ended relative to the first start; by XCD (blockIdx & 7)
-  static unsigned long long st[4096][2];
+  static unsigned long long st[4096][3];
   if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_warm_stamp), sizeof st) != hipSuccess) return;
   unsigned long long t0 = ~0ull; int nb = 0;
   for (int b = 0; b < 4096; ++b) if (st[b][1]) { nb = b + 1; if (st[b][0] < t0) t0 = st[b][0]; }
@@ -1294,6 +1294,20 @@ static void debug_dump_warm_clocks() {
     const double s0 = (double)(st[b][0] - t0) / 100.0, e0 = (double)(st[b][1] - t0) / 100.0, d = e0 - s0;
     if (s0 > smax) smax = s0; if (e0 > emax) emax = e0; if (e0 < emin) emin = e0; dsum += d; if (d < dmin) dmin = d; if (d > dmax) dmax = d;
     if (e0 > xe[b & 7]) xe[b & 7] = e0; xd[b & 7] += d; ++xn[b & 7];
+  }
+  {
+    int hist[24] = {0}; double lw = 0, lwo = 0; int nw = 0, nwo = 0; double pos[8] = {0}; int posn[8] = {0};
+    for (int b = 0; b < nb; ++b) {
+      const double d = (double)(st[b][1] - st[b][0]) / 100.0;
+      int k = (int)(d / 5.0); if (k > 23) k = 23; ++hist[k];
+      if (st[b][2]) { lw += d; ++nw; } else { lwo += d; ++nwo; }
+      const int oct = ((b >> 3) * 8) / ((nb + 7) / 8); pos[oct < 8 ? oct : 7] += d; ++posn[oct < 8 ? oct : 7];
+    }
+    fprintf(stderr, "[warm stamps] lifetime histogram (5 us bins):");
+    for (int k = 0; k < 24; ++k) fprintf(stderr, " %d", hist[k]);
+    fprintf(stderr, "\n[warm stamps] blocks with listed queries: %d, avg life %.1f; without: %d, avg life %.1f; avg life by position of the chunk inside its XCD's share (eighths):", nw, nw ? lw / nw : 0.0, nwo, nwo ? lwo / nwo : 0.0);
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " %.1f", posn[k] ? pos[k] / posn[k] : 0.0);
+    fprintf(stderr, "\n");
   }
   fprintf(stderr, "[warm stamps, last launch, %d blocks, us] last start=%.1f  first end=%.1f  last end=%.1f  block lifetime min/avg/max=%.1f/%.1f/%.1f  per XCD (avg life, last end):", nb, smax, emin, emax, dmin, dsum / nb, dmax);
   for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f,%.1f", xn[x] ? xd[x] / xn[x] : 0.0, xe[x]);
@@ -2558,10 +2572,18 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
 
   const uint32_t nb = gridDim.x;
   const uint32_t vb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);      // XCD-aware (gridDim.x is a multiple of 8)
-  const uint32_t chunk = (((a.ns + nb - 1) / nb) + (WARM_THREADS - 1)) & ~(uint32_t)(WARM_THREADS - 1);
-  const uint64_t beg64 = (uint64_t)vb * chunk;
+  // The source in ROUNDS of 256 queries, dealt out evenly: every block gets floor(R / nb) rounds, the first R mod nb blocks IN DISPATCH
+  // ORDER (blockIdx: round-robin over the XCDs) one more -- no block without work (a chunk rounded up to whole rounds left the last
+  // 2 % of the blocks idle at 10M), the heavier blocks spread over the XCDs.  vb's range starts after the rounds of the chunks before it.
+  const uint32_t rounds_total = (a.ns + WARM_THREADS - 1) / WARM_THREADS, rbase = rounds_total / nb, rrem = rounds_total % nb;
+  const uint32_t per_x = nb >> 3, xme = blockIdx.x & 7u, jme = blockIdx.x >> 3;
+  uint32_t heavy_before = 0;      // heavier chunks among vb' < vb: chunk (x, j) is heavier iff its block index j * 8 + x < rrem
+  for (uint32_t x = 0; x < xme; ++x) heavy_before += rrem > x ? min((rrem - x + 7u) >> 3, per_x) : 0u;
+  heavy_before += rrem > xme ? min((rrem - xme + 7u) >> 3, jme) : 0u;
+  const uint64_t beg64 = ((uint64_t)vb * rbase + heavy_before) * WARM_THREADS;
+  const uint32_t my_rounds = rbase + (blockIdx.x < rrem ? 1u : 0u);
   const uint32_t beg = beg64 < a.ns ? (uint32_t)beg64 : a.ns;
-  const uint32_t end = (beg64 + chunk < a.ns) ? (uint32_t)(beg64 + chunk) : a.ns;
+  const uint32_t end = (beg64 + (uint64_t)my_rounds * WARM_THREADS < a.ns) ? (uint32_t)(beg64 + (uint64_t)my_rounds * WARM_THREADS) : a.ns;
   const int sy = g.nx, sz = g.nx * g.ny;
   uint32_t nfar = 0;
 
@@ -2951,6 +2973,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   WARM_CLK(5);
 #ifdef CILHIP_EXP_PHASE_CLOCKS
   if (threadIdx.x == 0 && blockIdx.x < 4096u) g_warm_stamp[blockIdx.x][1] = wall_clock64();
+  if (lane == 0 && blockIdx.x < 4096u && qlisted) atomicAdd(&g_warm_stamp[blockIdx.x][2], (unsigned long long)qlisted);
 #endif
 }
 
