@@ -120,6 +120,7 @@ struct cilhip_ctx {
   bool tile_acc = true;           // accumulate inside the LDS tiles of the search when the engine allows it (option "tile_accumulation", A/B)
   bool fused = false;             // true: search+accumulate in one kernel; false: search kernel + streaming accumulate kernel (faster: the search runs at 2x the occupancy)
   double cell_occupancy = 1.0;    // target points per grid cell (takes effect at the next set_target)
+  double refined_occupancy = 3.0; // option "refined_occupancy_factor": how much denser than that a REFINED grid (surface-like / clustered target) may stay
   unsigned long long* d_count = nullptr;
   uint32_t* d_out_idx = nullptr;  // [ns] original-order results
   float* d_out_d2 = nullptr;
@@ -383,6 +384,11 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   }
   if (!strcmp(key, "require_reciprocality")) { c->reciprocal = value != 0.0; drop_matches(c); c->have_pairs = false; return CILHIP_OK; }
   if (!strcmp(key, "cell_occupancy")) { c->cell_occupancy = value; return CILHIP_OK; }
+  if (!strcmp(key, "refined_occupancy_factor")) {
+    if (!(value >= 1.0 && value <= 64.0)) return fail(c, CILHIP_ERR_INVALID, "refined_occupancy_factor: in [1, 64]");
+    c->refined_occupancy = value;
+    return CILHIP_OK;
+  }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
 }
@@ -479,7 +485,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (nrm) { rc = upload(c, nrm, 3 * n, mem, &d_nrm); if (rc) { (void)hipFree(d_xyz); return rc; } }
   GridBuildResult r{};
   double mean[3];
-  hipError_t e = build_grid(d_xyz, d_nrm, (uint32_t)n, c->stream, &r, mean, c->cell_occupancy);
+  hipError_t e = build_grid(d_xyz, d_nrm, (uint32_t)n, c->stream, &r, mean, c->cell_occupancy, c->refined_occupancy);
   (void)hipFree(d_xyz);
   if (d_nrm) (void)hipFree(d_nrm);
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }

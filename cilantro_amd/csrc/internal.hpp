@@ -372,8 +372,10 @@ struct GridBuildResult {
 };
 // Builds the grid for n points (device xyz, optional device normals).  Allocates the sorted
 // arrays and the cell table (freed by free_grid).  Returns hipSuccess or an error.
+// refined_factor: a cloud whose density-based first guess leaves far too many points per cell (a surface, clusters) is refined until
+// the expected own-cell population is at most 3 x target x refined_factor (1: as dense a grid as for a volumetric cloud).
 hipError_t build_grid(const float* d_xyz, const float* d_nrm, uint32_t n, hipStream_t s,
-                      GridBuildResult* out, double mean_out[3], double target_occupancy);
+                      GridBuildResult* out, double mean_out[3], double target_occupancy, double refined_factor = 1.0);
 void free_grid(GridDev& g);
 // Sorts the source by the target-grid cell of T*s; writes {x,y,z,orig} records.  d_out preallocated [n].
 // Also emits the tile table of the LDS-tiled search kernel: tiles[t] = [begin,end) of <= TILE_QUERIES sorted

@@ -467,12 +467,23 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        plus this fraction of a grid cell -- the room its fresh margin can have.  Larger: more cells per
  *                        search, margins that last longer; measured best at 10M (independent source: 0.25 -> 0.216 ms per
  *                        warm-started iteration, 0.0625 -> 0.197, 0.03 -> 0.199).  Never changes a result.
+ *   "pair_records" (default 1): the streaming accumulation (second pass of a two-pass iteration, later Gauss-Newton steps) gathers a
+ *                        match's point and normal from ONE 32-byte record instead of two arrays (a copy of the target in that layout,
+ *                        32 B per point, built by the first run that needs it; without room for it the two arrays serve): 123.5 ->
+ *                        113.5 us at 10M.  0 = the two arrays (A/B).  Same values, same sums.
  *   "tile_records" (default 1): the accumulating tile kernel writes the match records of the warm-started form itself (from a
  *                        run's second iteration on), so that the next iteration can read them; 0 = the first warm-started
  *                        iteration of a stretch gathers through the stored matches and writes them (A/B).
  *   "warm_enter_fraction" (default 0.15): that bar, as a fraction of a grid cell (halved each time a warm-started iteration of
  *                        the run had to search more than a quarter of its queries).
  *                        Neither option changes a result beyond the order of f64 additions.
+ *   "refined_occupancy_factor" (default 3): a target whose density-based first guess of the cell size leaves far too many points per
+ *                        cell (a surface, clusters: most cells of its bounding box are empty) has its grid refined until the expected
+ *                        own-cell population is at most 3 x cell_occupancy x this factor.  1 = as fine a grid as a volumetric cloud
+ *                        gets.  A search that has to leave the first block of cells walks shells of mostly empty cells on such a cloud,
+ *                        and pays per cell: measured on the reference's sensor frames (120k points), frame_1 vs frame_2 (residuals of
+ *                        several cells) 0.67 ms per iteration at factor 1, 0.30 at 3, 0.25 at 5; the near-aligned pair 0.033 / 0.036 /
+ *                        0.045.  Used by the next cilhip_set_target; never changes a result.
  *   "cell_occupancy" (default 1): target points per grid cell, used by the next cilhip_set_target.
  *   "kernel_timing": same as cilhip_enable_kernel_timing.
  * Engine post-filters (correspondence_search_kd_tree.hpp:224-225, setInlierFraction / setOneToOne :253-271):
