@@ -215,12 +215,19 @@ def bench_icp(a, torch, rank, world, local_rank):
             dist.all_reduce(m)
             gmean = (m.cpu().numpy() / (n_src_rank * world)).astype(np.float32)
 
+    # the per-rank loop inside the library with its own RCCL communicator (cilhip_icp_iterate_ranked); CILHIP_BENCH_TORCH_ALLREDUCE=1 or a
+    # rank without a loadable librccl: three calls + torch's all-reduce per iteration (same sums either way)
+    native = sharded and os.environ.get("CILHIP_BENCH_TORCH_ALLREDUCE") != "1" and distributed.init_rank_comm(ctx, dist, None, "cuda")
+
     def run(iters, timing):
         p.max_iter = iters
         ctx.enable_kernel_timing(timing)
         if not sharded:
             return ctx.icp_run(p, T0)
         ctx.icp_begin(p, T0, gmean)
+        if native:
+            ctx.icp_iterate_ranked(iters)
+            return ctx.icp_state()
         for _ in range(iters):
             ctx.icp_partial_sums(sums.data_ptr())
             dist.all_reduce(sums)
@@ -335,6 +342,7 @@ def bench_icp(a, torch, rank, world, local_rank):
             "config": {"workload": f"{a.config}: {ns/1e6:g}M<->{nd/1e6:g}M synthetic float3 clouds " + label,
                        "n_target": nd, "n_source_per_gpu": ns_l, "n_source_total": n_src_total, "max_sq_dist": float(d["max_sq_dist"]),
                        "iterations": a.steps, "conv_tol": 0.0, "sharding": sharding, "slab": slab_info,
+                       "allreduce": ("library loop, ncclAllReduce on the context's stream (cilhip_icp_iterate_ranked)" if native else "torch.distributed.all_reduce per iteration") if sharded else None,
                        "grid": [gi.nx, gi.ny, gi.nz], "grid_cell": gi.cell, "grid_avg_occupancy": gi.avg_occupancy},
             "setup_ms": t_setup * 1e3, "source_sort_ms": sort_ms, "loop_ms_hip_events": loop_ms,
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,

@@ -93,6 +93,7 @@ struct cilhip_ctx {
   unsigned long long tie_resolved = 0, tie_changed = 0;      // of the last search / run under tie_rule 1: tied queries seen, matches that were re-pointed
   float warm_extra = 0.0625f;     // option "warm_extra_fraction"
   bool pair_records = true;       // option "pair_records": the streaming accumulation gathers a match's point and normal from one 32-byte record (GridDev::pn)
+  void* rank_comm = nullptr; int rank_comm_size = 0; double* d_rank_sums = nullptr;      // cilhip_rank_comm_*: this process' rank in an RCCL communicator
   bool tile_records = true;       // option "tile_records": the accumulating tile kernel writes the warm-started form's match records itself
   float warm_enter = 0.15f;       // option "warm_enter_fraction": the bar a run starts with, as a fraction of a grid cell
   float warm_thresh = 0.0f;       // a run's bar for (re-)entering the warm-started form: the last update moved no source point by more than this
@@ -264,6 +265,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)cilhip_rank_comm_destroy(c);
   free_source(c);
   if (c->has_target) free_grid(c->grid);
   if (c->d_safe2) (void)hipFree(c->d_safe2);
@@ -2011,14 +2013,18 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   c->rec_valid = false; c->lb_fresh = false;
   warm_run_reset(c);
   if (warm_capable(c)) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
-  c->iter_form.clear();
+  c->iter_form.clear(); c->trace_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
   return CILHIP_OK;
 }
 
-int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
-  if (!c || !sums_dev) return CILHIP_ERR_INVALID;
+// sums_dev != null: the 48 sums of this iteration's search + accumulation (cilhip_icp_partial_sums).  rows_dev != null instead: RANK_ROWS
+// rows that still have to be folded -- the stage-1 reduction with a FIXED number of groups, whatever form the iteration took and
+// however many blocks this rank has -- for the ranked loop, which all-reduces those (12 KB instead of 384 B: both latency-bound) and
+// lets the epilogue fold them as it does in cilhip_icp_run: one kernel and one gap less per iteration.
+constexpr int RANK_ROWS = 32;
+static int partial_sums_core(cilhip_ctx* c, double* sums_dev, double* rows_dev) {
   if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
   CK(c, hipSetDevice(c->device));
   const int im = iter_metric_of(c, &c->run_prm);
@@ -2026,6 +2032,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
   a.cw = corr_weights_of(c, &c->run_prm);
   const int nb = iter_num_blocks(c->ns);
   int prows = nb;
+  unsigned char form_now = FORM_LANE_FUSED;      // (the form this iteration takes: what its published counts will mean)
   if (c->ns) {
     if (c->fused) {
       launch_iter(a, im, true, false, nb, c->stream);
@@ -2047,15 +2054,32 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
           // wait at most (5 s without news: the cold form)
           FbView fv;
           if (wait_published(c, (unsigned int)(c->run_calls - 1), 5.0, &fv) == 0) {
-            c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
+            // (what a published iteration's counts mean depends on the form it ran in: as in cilhip_icp_run)
+            auto form_of = [&](const FbView& f) -> int { return (f.iterations >= 1 && f.iterations <= c->trace_form.size()) ? (int)c->trace_form[f.iterations - 1] : -1; };
+            auto is_warm = [&](const FbView& f) { const int fo = form_of(f); return fo >= 0 && ((fo & 0x7f) == FORM_WARM || (fo & 0x7f) == FORM_WARM_FIRST); };
+            if (form_of(fv) >= 0 && (form_of(fv) & 0x7f) <= FORM_TILE_ONE_PASS) c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
             bool fell = false;
-            if (c->run_warm_on && fv.iterations > c->run_judged) {
+            if (c->run_warm_on && fv.iterations > c->run_judged && is_warm(fv)) {
               c->run_judged = fv.iterations;
               if (!warm_keeps_paying(c, fv.listed)) { c->run_warm_on = false; fell = true; }
             }
-            // (the step is the one of iteration run_calls - 2 here -- no second wait in the caller-driven protocol: the margins
-            //  then have to cover two updates, which the kernel's own count of searched queries reports back)
-            if (!c->run_warm_on && !fell && !c->warm_banned) c->run_warm_on = warm_worthwhile(c, fv.step);
+            if (!c->run_warm_on && !fell && !c->warm_banned && fv.step < 8.0f * c->warm_thresh) {
+              // candidate for the warm-started form: decided on the step the loop made LAST -- wait for iteration run_calls - 1
+              // itself (its epilogue has been enqueued by the caller's previous apply; a bubble of some tens of microseconds, only
+              // while this decision is pending and the loop is within reach of it), then as cilhip_icp_run decides
+              FbView f2;
+              if (wait_published(c, (unsigned int)c->run_calls, 5.0, &f2) == 0) {
+                fv = f2;
+                if (is_warm(fv)) {
+                  if (fv.iterations > c->run_judged && fv.listed != 0u) { c->run_judged = fv.iterations; fell = !warm_keeps_paying(c, fv.listed); }
+                  if (!fell && !c->warm_banned) c->run_warm_on = warm_worthwhile(c, fv.step);
+                } else {
+                  const int fo = form_of(fv);
+                  const bool forecast_ok = !c->warm_forecast || !(fo >= 0 && (fo & 0x80)) || (unsigned long long)fv.listed * 8ull <= (unsigned long long)c->ns;
+                  c->run_warm_on = forecast_ok && warm_worthwhile(c, fv.step);
+                }
+              }
+            }
             warm = c->run_warm_on;
           }
         }
@@ -2069,6 +2093,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         set_warm_args(c, wa);
         wa.nn_lb = c->d_nn_lb; wa.lb_valid = c->lb_fresh ? 1 : 0;
         if (timing) c->iter_form.push_back((unsigned char)(c->rec_valid ? FORM_WARM : FORM_WARM_FIRST));
+        form_now = (unsigned char)(c->rec_valid ? FORM_WARM : FORM_WARM_FIRST);
         launch_warm(wa, im, c->rec_valid ? 2 : 1, warm_num_blocks(c->ns), c->stream);
         prows = warm_num_blocks(c->ns);
         c->rec_valid = true; c->lb_fresh = false;
@@ -2083,6 +2108,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         if (recs) set_warm_args(c, fa);
         launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         c->rec_valid = recs; c->lb_fresh = false;
+        form_now = (unsigned char)(FORM_TILE_ONE_PASS | (recs ? 0x80 : 0));
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
         prows = tiled_partial_rows(c->ntiles);
         ++c->last_fused_iters;
@@ -2094,6 +2120,7 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
         const bool keys = wcap;
         if (keys) sa2.nn_lb = c->d_nn_lb;
         c->lb_fresh = keys;
+        form_now = (unsigned char)(FORM_SEARCH | (keys ? 0x80 : 0));
         if (use_tiled(c)) launch_search_tiled(sa2, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         else launch_iter(sa2, IM_NONE, true, true, nb, c->stream);
         if (timing) CK(c, hipEventRecord(get_event(c, e + 1), c->stream));
@@ -2101,13 +2128,22 @@ int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
       }
       if (timing) { CK(c, hipEventRecord(get_event(c, e + 2), c->stream)); c->run_nev += 3; }
     }
-    launch_reduce_partials(c->d_partials, prows, c->d_stage, sums_dev, c->stream);
-  } else {
+    if (sums_dev) launch_reduce_partials(c->d_partials, prows, c->d_stage, sums_dev, c->stream);
+    else launch_reduce_stage1_groups(c->d_partials, prows, rows_dev, RANK_ROWS, c->stream);
+  } else if (sums_dev) {
     CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));
+  } else {
+    CK(c, hipMemsetAsync(rows_dev, 0, (size_t)RANK_ROWS * SUMS_MAX * sizeof(double), c->stream));
   }
+  c->trace_form.push_back(form_now);
   ++c->run_calls;
   CK(c, hipGetLastError());
   return CILHIP_OK;
+}
+
+int cilhip_icp_partial_sums(cilhip_ctx* c, double* sums_dev) {
+  if (!c || !sums_dev) return CILHIP_ERR_INVALID;
+  return partial_sums_core(c, sums_dev, nullptr);
 }
 
 int cilhip_icp_apply_sums(cilhip_ctx* c, const double* sums_dev) {
@@ -2292,6 +2328,9 @@ struct RcclApi {
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  struct UniqueId { char internal[128]; };      // ncclUniqueId of rccl.h (NCCL_UNIQUE_ID_BYTES = 128), passed by value
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(rccl_comm_t*, int, UniqueId, int) = nullptr;
   bool load() {
     if (lib) return true;
     lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -2302,7 +2341,9 @@ struct RcclApi {
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
     GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
-    return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd;
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetUniqueId && CommInitRank;
   }
 };
 constexpr int RCCL_DOUBLE = 8, RCCL_SUM = 0;      // ncclDouble / ncclSum of rccl.h (ncclDataType_t / ncclRedOp_t)
@@ -2578,6 +2619,73 @@ int cilhip_multi_icp_run(cilhip_multi* m, const cilhip_icp_params* p, const floa
   MCTX(m, 0, cilhip_icp_state(m->ctx[0], &st));
   *out = st;
   out->iterations = begin_base + st.iterations;
+  return CILHIP_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// One process PER device (torchrun, MPI): this process' context as one rank of an RCCL communicator, and the sharded loop's
+// inner triple -- partial sums, all-reduce of the 48 f64, epilogue -- run for a number of iterations inside ONE call: per
+// iteration the host enqueues a handful of launches and one ncclAllReduce on the context's stream instead of going through three
+// foreign-function calls and a framework collective (measured with one rank: 0.169 -> see DESIGN.md section 8).  The id travels
+// by whatever the launcher already has (torch.distributed broadcast, MPI_Bcast, a file).
+namespace { RcclApi g_rank_rccl; }
+
+extern "C" {
+
+int cilhip_rank_comm_unique_id(unsigned char id_out[128]) {
+  if (!id_out) return CILHIP_ERR_INVALID;
+  if (!g_rank_rccl.load()) return CILHIP_ERR_UNSUPPORTED;
+  RcclApi::UniqueId u;
+  if (g_rank_rccl.GetUniqueId(&u) != 0) return CILHIP_ERR_HIP;
+  memcpy(id_out, u.internal, sizeof(u.internal));
+  return CILHIP_OK;
+}
+
+int cilhip_rank_comm_init(cilhip_ctx* c, const unsigned char id[128], int nranks, int rank) {
+  if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return CILHIP_ERR_INVALID;
+  if (c->rank_comm) return fail(c, CILHIP_ERR_INVALID, "rank_comm_init: the context already holds a communicator");
+  if (!g_rank_rccl.load()) return fail(c, CILHIP_ERR_UNSUPPORTED, "rank_comm_init: librccl.so.1 could not be opened");
+  CK(c, hipSetDevice(c->device));
+  RcclApi::UniqueId u;
+  memcpy(u.internal, id, sizeof(u.internal));
+  rccl_comm_t comm = nullptr;
+  if (g_rank_rccl.CommInitRank(&comm, nranks, u, rank) != 0 || !comm) return fail(c, CILHIP_ERR_HIP, "ncclCommInitRank failed");
+  if (!c->d_rank_sums && hipMalloc(&c->d_rank_sums, (size_t)RANK_ROWS * SUMS_MAX * sizeof(double)) != hipSuccess) {
+    (void)g_rank_rccl.CommDestroy(comm);
+    return fail(c, CILHIP_ERR_HIP, "rank_comm_init: out of device memory");
+  }
+  c->rank_comm = comm; c->rank_comm_size = nranks;
+  return CILHIP_OK;
+}
+
+int cilhip_rank_comm_destroy(cilhip_ctx* c) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (c->rank_comm) { (void)hipStreamSynchronize(c->stream); (void)g_rank_rccl.CommDestroy(c->rank_comm); c->rank_comm = nullptr; c->rank_comm_size = 0; }
+  if (c->d_rank_sums) { (void)hipFree(c->d_rank_sums); c->d_rank_sums = nullptr; }
+  return CILHIP_OK;
+}
+
+int cilhip_icp_iterate_ranked(cilhip_ctx* c, int iterations) {
+  if (!c || iterations < 0) return CILHIP_ERR_INVALID;
+  if (!c->rank_comm) return fail(c, CILHIP_ERR_INVALID, "icp_iterate_ranked: cilhip_rank_comm_init first");
+  if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
+  CK(c, hipSetDevice(c->device));
+  const int im = iter_metric_of(c, &c->run_prm);
+  for (int k = 0; k < iterations; ++k) {
+    // this rank's RANK_ROWS rows of partial sums -> summed over the ranks, row by row -> folded by the epilogue (the same values on
+    // every rank: identical transforms and decisions everywhere)
+    const int rc = partial_sums_core(c, nullptr, c->d_rank_sums);
+    if (rc) return rc;
+    if (g_rank_rccl.AllReduce(c->d_rank_sums, c->d_rank_sums, (size_t)RANK_ROWS * SUMS_MAX, RCCL_DOUBLE, RCCL_SUM, c->rank_comm, c->stream) != 0)
+      return fail(c, CILHIP_ERR_HIP, "ncclAllReduce failed");
+    SolveArgs sa = make_solve_args(c, &c->run_prm, im, c->run_src_mean);
+    sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;
+    sa.partials = c->d_rank_sums; sa.nblocks = RANK_ROWS; sa.reduced = nullptr;
+    launch_solve(sa, c->stream);
+    CK(c, hipGetLastError());
+  }
   return CILHIP_OK;
 }
 

@@ -298,6 +298,7 @@ void launch_search_tiled_feat6(const IterArgs& a, const uint2* tiles, const floa
 void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_search_tiled -> stderr
 #endif
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
+void launch_reduce_stage1_groups(const double* partials, int nblocks, double* stage, int groups, hipStream_t s);
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 128 * SUMS_MAX;
 void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb = nullptr, unsigned int run_tag = 0,

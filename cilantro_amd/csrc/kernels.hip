@@ -3198,6 +3198,11 @@ void launch_reduce_partials(const double* partials, int nblocks, double* stage, 
   }
 }
 
+// Stage 1 with a number of groups the CALLER fixes (every group's row is written, empty groups as zeros)
+void launch_reduce_stage1_groups(const double* partials, int nblocks, double* stage, int groups, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_stage1, dim3(groups), dim3(256), 0, s, partials, nblocks, stage);
+}
+
 // Stage 1 only (the epilogue kernel k_solve folds the REDUCE_GROUPS rows itself).  Returns the number
 // of rows k_solve has to read from `stage`, or 0 if it should read `partials` directly.
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s) {

@@ -33,6 +33,42 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def init_rank_comm(ctx, dist, group=None, device="cuda"):
+    """This rank's context as a rank of a dedicated RCCL communicator (cilhip_rank_comm_init): rank 0 creates the id, ``dist``
+    (torch.distributed, initialised) carries its 128 bytes to every rank.  After it, ``ctx.icp_iterate_ranked(k)`` runs k
+    iterations of {partial sums, ncclAllReduce on the context's stream, epilogue} inside the library -- per iteration a handful of
+    launches instead of three calls and a framework collective.  Collective; returns whether it worked on EVERY rank (a rank whose
+    librccl cannot be opened makes all ranks keep the framework's all-reduce: both protocols give the same sums)."""
+    import torch
+
+    from .icp import Context
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok = torch.ones(1, dtype=torch.int32, device=device)
+    uid = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        try:
+            uid.copy_(torch.from_numpy(Context.rank_comm_unique_id()).to(device))
+        except Exception:
+            ok.zero_()
+    if world > 1:
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(uid, src=src, group=group)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        return False
+    try:
+        ctx.rank_comm_init(uid.cpu().numpy(), world, rank)
+    except Exception:
+        ok.zero_()
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        ctx.rank_comm_destroy()
+        return False
+    return True
+
+
 class HipShardEngine:
     """Per-rank engine backed by libcilantro_hip.so.  All work is enqueued on torch's current stream
     so the RCCL all-reduce is ordered after the partial-sum kernels without host synchronisation."""
@@ -64,6 +100,16 @@ class HipShardEngine:
 
     def apply_sums(self, sums):
         self.ctx.icp_apply_sums(sums.data_ptr())
+
+    def enable_native_allreduce(self, dist, group=None):
+        """Make this rank's context a rank of its own RCCL communicator (init_rank_comm below), so that the loops can run a block
+        of iterations inside ONE library call.  Collective.  Returns whether it worked on EVERY rank."""
+        self.native = init_rank_comm(self.ctx, dist, group, self.sums.device)
+        return self.native
+
+    def iterate(self, k):
+        """k iterations of the inner triple inside the library (needs enable_native_allreduce)"""
+        self.ctx.icp_iterate_ranked(k)
 
     def state(self):
         r = self.ctx.icp_state()
@@ -104,6 +150,18 @@ class ShardedRigidICP:
         T0 = np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32)
         gmean = self.global_source_mean()
         self.engine.begin(params, T0, gmean)
+        if getattr(self.engine, "native", False):
+            # blocks of iterations inside the library, its own all-reduce on the engine's stream
+            done, total = 0, int(params.max_iter)
+            while done < total:
+                k = min(check_every, total - done) if check_every else total
+                self.engine.iterate(k)
+                done += k
+                if check_every and done < total:
+                    T, iters, delta, nc = self.engine.state()
+                    if delta < params.conv_tol:
+                        break
+            return self.engine.state()
         for it in range(int(params.max_iter)):
             sums = self.engine.partial_sums()
             self._allreduce(sums)
@@ -301,10 +359,16 @@ class SlabShardedRigidICP:
         fresh = True                      # the engine's partition was made under exactly T_ck
         every = max(check_every, 1)
         while base + since < total:
-            sums = self.engine.partial_sums()
-            inner._allreduce(sums)
-            self.engine.apply_sums(sums)
-            since += 1
+            if getattr(self.engine, "native", False):
+                # up to the next check inside the library (its own all-reduce on the engine's stream)
+                k = min(every - since % every, total - base - since)
+                self.engine.iterate(k)
+                since += k
+            else:
+                sums = self.engine.partial_sums()
+                inner._allreduce(sums)
+                self.engine.apply_sums(sums)
+                since += 1
             if since % every == 0 or base + since == total:
                 T, iters, delta, nc = self.engine.state()
                 # (the same answers on every rank: same transform, same global box)
@@ -329,7 +393,10 @@ class SlabShardedRigidICP:
                 if bad:
                     if self.repartition is None:
                         raise RuntimeError("a source point may have left its slab's halo and no repartition function was given")
+                    was_native = getattr(self.engine, "native", False)
                     self.engine = self.repartition(T_ck)
+                    if was_native and self.dist is not None and hasattr(self.engine, "enable_native_allreduce"):
+                        self.engine.enable_native_allreduce(self.dist, self.group)      # (a new context: a new communicator; collective like the re-partition itself)
                     inner = ShardedRigidICP(self.engine, self.dist, self.group)
                     self.repartitions += 1
                     self.engine.begin(params, T_ck, None)

@@ -219,6 +219,28 @@ class Context:
     def icp_apply_sums(self, sums_dev_ptr):
         self._ck(self._L.cilhip_icp_apply_sums(self._h, C.c_void_p(sums_dev_ptr)))
 
+    @staticmethod
+    def rank_comm_unique_id():
+        """128 bytes that make the ranks of one RCCL communicator find each other: created on ONE rank, carried to all (cilhip_rank_comm_unique_id)"""
+        buf = np.zeros(128, np.uint8)
+        rc = capi.load().cilhip_rank_comm_unique_id(buf.ctypes.data)
+        if rc != capi.OK:
+            raise capi.CilhipError(rc, "cilhip_rank_comm_unique_id failed (librccl not loadable?)")
+        return buf
+
+    def rank_comm_init(self, unique_id, nranks, rank):
+        """this context as rank `rank` of `nranks` (collective: every rank calls it with the same id)"""
+        uid = np.ascontiguousarray(unique_id, np.uint8)
+        assert uid.size == 128
+        self._ck(self._L.cilhip_rank_comm_init(self._h, uid.ctypes.data, int(nranks), int(rank)))
+
+    def rank_comm_destroy(self):
+        self._ck(self._L.cilhip_rank_comm_destroy(self._h))
+
+    def icp_iterate_ranked(self, iterations):
+        """`iterations` x {partial sums -> ncclAllReduce of the 48 f64 on the context's stream -> epilogue}, between icp_begin and icp_state"""
+        self._ck(self._L.cilhip_icp_iterate_ranked(self._h, int(iterations)))
+
     def set_shard_info(self, target_index_offset, dst_mean=None, src_mean=None):
         dm = np.ascontiguousarray(dst_mean, np.float32) if dst_mean is not None else None
         sm = np.ascontiguousarray(src_mean, np.float32) if src_mean is not None else None

@@ -401,6 +401,20 @@ int cilhip_multi_repartitions(const cilhip_multi* m);
 int cilhip_multi_set_slab_slack(cilhip_multi* m, float slack);
 int cilhip_multi_shard_sizes(const cilhip_multi* m, int rank, size_t* n_target, size_t* n_source);
 
+/* ---- one process PER device (torchrun, MPI): this context as one rank of an RCCL communicator -------------------------------
+ * The sharded loop's inner triple (cilhip_icp_partial_sums, all-reduce of the 48 f64, cilhip_icp_apply_sums) for `iterations`
+ * iterations inside one call, the all-reduce = ncclAllReduce on the context's stream (librccl opened at run time): per iteration
+ * the host enqueues a handful of launches instead of three foreign-function calls and a framework collective.  Rank 0 creates
+ * the id (cilhip_rank_comm_unique_id), the launcher carries its 128 bytes to every rank (torch.distributed.broadcast, MPI_Bcast,
+ * a file), every rank calls cilhip_rank_comm_init(ctx, id, nranks, rank) -- collective, as ncclCommInitRank is.  Between
+ * cilhip_icp_begin and cilhip_icp_state the caller alternates cilhip_icp_iterate_ranked(k) with whatever it checks every k
+ * iterations (convergence, cilhip_get_slab_violation_state).  Every rank must ask for the same number of iterations.  The
+ * reference has no counterpart; the loop is IterativeClosestPointBase::estimate (registration/icp_base.hpp:68-87). */
+int cilhip_rank_comm_unique_id(unsigned char id_out[128]);
+int cilhip_rank_comm_init(cilhip_ctx* ctx, const unsigned char id[128], int nranks, int rank);
+int cilhip_rank_comm_destroy(cilhip_ctx* ctx);
+int cilhip_icp_iterate_ranked(cilhip_ctx* ctx, int iterations);
+
 /* How the iterations of the last cilhip_icp_run were executed: as ONE pass (search with the accumulation inside the LDS
  * tiles) or as TWO (search with its in-tile 3x3x3 second pass, then the streaming accumulation).  Large clouds choose per
  * iteration from the device's count of queries the first search stage left unproven (source far from alignment: two passes).

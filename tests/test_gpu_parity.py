@@ -1967,6 +1967,54 @@ def test_combined_metric_combiner_two_correspondence_sets_vs_oracle(Context, orc
         e_pt._ctx._ck(L.cilhip_estimate_combined_two_sets(e_pt._ctx._h, e_pl._ctx._h, w_pt, w_pl, 1, 0.0, T.ctypes.data_as(C.c_void_p), C.byref(cv)))
 
 
+def test_ranked_library_loop_one_rank_is_bitwise_the_python_protocol(hip_lib):
+    """cilhip_rank_comm_* + cilhip_icp_iterate_ranked: the sharded loop's inner triple inside the library with its own RCCL
+    communicator (one process per device).  With ONE rank (all a single-GPU box can run): the communicator comes up from the id,
+    and the loop -- blocks of iterations, state read between them -- gives bitwise the transform of the three-call protocol with
+    the sums passed through unchanged, and of cilhip_icp_run."""
+    import torch
+
+    from cilantro_amd import distributed
+    from cilantro_amd.icp import Context
+
+    d = syn.make_pair(400_000, perturb=0.3)
+    p = distributed.default_params(max_iter=9, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+    T0 = np.eye(4, dtype=np.float32)
+
+    ref = Context(); ref.set_target(d["dst"], d["dst_n"]); ref.set_source(d["src"])
+    r0 = ref.icp_run(p)
+    _, sm = ref.means()
+    ref.close()
+
+    def three_calls():
+        ctx = Context(0, torch.cuda.current_stream().cuda_stream); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+        sums = torch.zeros(capi.SUMS_LEN, dtype=torch.float64, device="cuda")
+        ctx.icp_begin(p, T0, sm)
+        for _ in range(9):
+            ctx.icp_partial_sums(sums.data_ptr()); ctx.icp_apply_sums(sums.data_ptr())
+        r = ctx.icp_state(); ctx.close()
+        return r
+
+    def ranked():
+        ctx = Context(0, torch.cuda.current_stream().cuda_stream); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+        ctx.rank_comm_init(Context.rank_comm_unique_id(), 1, 0)
+        with pytest.raises(RuntimeError):
+            ctx.rank_comm_init(Context.rank_comm_unique_id(), 1, 0)       # one communicator per context
+        ctx.icp_begin(p, T0, sm)
+        for k in (4, 3, 2):
+            ctx.icp_iterate_ranked(k)
+            assert int(ctx.icp_state().iterations) in (4, 7, 9)
+        r = ctx.icp_state()
+        ctx.rank_comm_destroy(); ctx.close()
+        return r
+
+    ra, rb = three_calls(), ranked()
+    for r in (ra, rb):
+        assert int(r.iterations) == 9 and int(r.last_ncorr) == int(r0.last_ncorr)
+    assert bytes(np.array(ra.T[:], np.float32)) == bytes(np.array(rb.T[:], np.float32))
+    assert float(np.abs(np.array(rb.T[:], np.float32) - np.array(r0.T[:], np.float32)).max()) <= 2e-7       # (forms may differ in the order of f64 additions)
+
+
 def test_multi_device_c_entry_one_gpu(Context, orc, hip_lib):
     """cilhip_multi_*: the sharded loop driven from C in ONE process (SURVEY.md 8(b) devices[]).  What a single-GPU box can check:
     one shard == cilhip_icp_run bit for bit; several shards on the same device (devices = [0, 0, 0]: the all-reduce runs as the
