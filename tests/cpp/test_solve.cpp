@@ -1,5 +1,6 @@
 // Host-side check of the fast paths in cilantro_amd/csrc/solve.hpp (compiled with hipcc, runs without a GPU):
 //   nearest_rotation_polar  vs the SVD-based nearest_rotation (U V^T, the reference's rotation() polish)
+//   kabsch_rotation_polar   vs the SVD-based Kabsch rotation (U V^T with the reflection fix)
 //   ldlt6_solve_fast        vs the pivoted LDL^T with pseudo-inverse semantics
 #include "../../cilantro_amd/csrc/solve.hpp"
 
@@ -45,6 +46,45 @@ int main() {
     double R[9];
     if (nearest_rotation_polar(refl, R) || nearest_rotation_polar(far, R) || nearest_rotation_polar(sing, R) || nearest_rotation_polar(nanm, R)) {
       std::printf("polar fast path accepted a matrix it must refuse\n"); ++failures;
+    }
+  }
+  // Kabsch rotation of a cross-covariance: scaled polar iteration vs the SVD (U V^T with the reference's reflection fix).  Covariances
+  // of random clouds under random rotations, anisotropic up to 1 : 1e-3 per axis (condition numbers up to ~1e6), plus noise.
+  {
+    double worst_k = 0.0;
+    int taken = 0, trials = 0;
+    for (int trial = 0; trial < 20000; ++trial) {
+      double ax[3] = {urand() - 0.5, urand() - 0.5, urand() - 0.5};
+      const double nrm = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]) + 1e-30;
+      for (double& v : ax) v /= nrm;
+      const double ang = 3.1 * urand(), c = std::cos(ang), s = std::sin(ang);
+      const double Rm[9] = {c + ax[0] * ax[0] * (1 - c), ax[0] * ax[1] * (1 - c) - ax[2] * s, ax[0] * ax[2] * (1 - c) + ax[1] * s,
+                            ax[1] * ax[0] * (1 - c) + ax[2] * s, c + ax[1] * ax[1] * (1 - c), ax[1] * ax[2] * (1 - c) - ax[0] * s,
+                            ax[2] * ax[0] * (1 - c) - ax[1] * s, ax[2] * ax[1] * (1 - c) + ax[0] * s, c + ax[2] * ax[2] * (1 - c)};
+      const double sc[3] = {1.0, std::pow(10.0, -3.0 * urand()), std::pow(10.0, -3.0 * urand())};
+      double sig[9] = {0};      // sum over points of (R p)(p)^T, p anisotropic
+      for (int k = 0; k < 30; ++k) {
+        double pt[3] = {sc[0] * (urand() - 0.5), sc[1] * (urand() - 0.5), sc[2] * (urand() - 0.5)}, q[3];
+        for (int r = 0; r < 3; ++r) q[r] = Rm[r * 3] * pt[0] + Rm[r * 3 + 1] * pt[1] + Rm[r * 3 + 2] * pt[2] + 1e-4 * sc[2] * (urand() - 0.5);
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) sig[r * 3 + cc] += q[r] * pt[cc];
+      }
+      double U[9], S[3], V[9], A[9], B[9];
+      svd3(sig, U, S, V);
+      uvt_fix(U, V, 2, A);
+      ++trials;
+      if (kabsch_rotation_polar(sig, B)) {
+        ++taken;
+        for (int i = 0; i < 9; ++i) worst_k = std::fmax(worst_k, std::fabs(A[i] - B[i]));
+      }
+    }
+    std::printf("Kabsch polar vs SVD: fast path taken %d / %d, max |dR| = %.3e\n", taken, trials, worst_k);
+    if (!(worst_k <= 1e-9) || taken < trials * 9 / 10) ++failures;
+    // must refuse: reflection (det < 0), singular (planar cloud), zero, NaN
+    const double refl[9] = {1, 0, 0, 0, 1, 0, 0, 0, -1}, sing[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0}, zero[9] = {0};
+    double nanm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; nanm[2] = NAN;
+    double R[9];
+    if (kabsch_rotation_polar(refl, R) || kabsch_rotation_polar(sing, R) || kabsch_rotation_polar(zero, R) || kabsch_rotation_polar(nanm, R)) {
+      std::printf("Kabsch polar fast path accepted a matrix it must refuse\n"); ++failures;
     }
   }
   // LDL^T: random SPD normal equations (J^T J of 40 random rows + ridge), against the pivoted solve
