@@ -2857,7 +2857,9 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   const uint32_t last = end > beg ? end - 1u : 0u;
   auto gather = [&](uint32_t wv) {
     const uint32_t wc = wv != NONE_U32 ? wv : 0u;
-    gp = g.pts[wc]; gs = a.safe2[wc]; if (NRM) gn = g.nrm[wc];
+    if (NRM && g.pn != nullptr) { gp = g.pn[2 * (size_t)wc]; gn = g.pn[2 * (size_t)wc + 1]; }      // (uniform) point and normal from one 32-byte record
+    else { gp = g.pts[wc]; if (NRM) gn = g.nrm[wc]; }
+    gs = a.safe2[wc];
     if (wv == NONE_U32) { gp = gn = Z4; gs = -1.0f; }
   };
   WARM_CLK(0);
