@@ -1967,6 +1967,54 @@ def test_combined_metric_combiner_two_correspondence_sets_vs_oracle(Context, orc
         e_pt._ctx._ck(L.cilhip_estimate_combined_two_sets(e_pt._ctx._h, e_pl._ctx._h, w_pt, w_pl, 1, 0.0, T.ctypes.data_as(C.c_void_p), C.byref(cv)))
 
 
+def test_grid_parameters_never_change_a_result(hip_lib, orc):
+    """The grid is a search structure, not part of the answer: whatever cell size the build picks (options cell_occupancy,
+    refined_occupancy_factor; the refined grids of surface-like targets) the correspondences equal the reference's nanoflann index for
+    index (up to exactly equidistant candidates: then an equally near point) and the loop ends on the same transform.  Clouds: the
+    reference's sensor frames (a surface: the grid IS refined) under the identity, and a volumetric cloud with doubled points."""
+    from cilantro_amd.icp import Context
+
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames_full.npz"))
+    p1, n1, p2 = f["p1"], f["n1"], f["p2"]
+    keep = p1[:, 0] > -0.4
+    rng = np.random.default_rng(8)
+    b = syn.make_pair(150_000, perturb=0.4)
+    dup = rng.choice(len(b["dst"]), 2000, replace=False)
+    clouds = (("frames", np.ascontiguousarray(p1[keep]), np.ascontiguousarray(n1[keep]), np.ascontiguousarray(p2), np.float32(0.02 ** 2)),
+              ("volumetric + duplicates", np.ascontiguousarray(np.concatenate([b["dst"], b["dst"][dup]])),
+               np.ascontiguousarray(np.concatenate([b["dst_n"], b["dst_n"][dup]])), b["src"], np.float32(b["max_sq_dist"])))
+    I = np.eye(4, dtype=np.float32)
+    for name, D, N, S, r2 in clouds:
+        tree = orc.KDTree(D, use_ref=orc.ref_available())
+        o1, o2, ov = tree.find_correspondences(S, float(r2))
+        oi = np.full(len(S), -1, np.int64); oi[o2] = o1
+        od = np.full(len(S), np.inf, np.float32); od[o2] = ov
+        Ts, cells = [], []
+        for opts in ((), (("refined_occupancy_factor", 1),), (("refined_occupancy_factor", 8),), (("cell_occupancy", 0.5),), (("cell_occupancy", 6),),
+                     (("cell_occupancy", 40), ("refined_occupancy_factor", 2))):
+            ctx = Context()
+            for k, v in opts:
+                ctx.set_option(k, v)
+            ctx.set_target(D, N); ctx.set_source(S)
+            cells.append(float(ctx.grid_info().cell))
+            ctx.find_correspondences(I, float(r2), count=False)
+            gi, gd = ctx.get_nn()
+            gi = gi.astype(np.int64); gi[gi == capi.NONE_IDX] = -1
+            assert np.array_equal(gi >= 0, oi >= 0), (name, opts)
+            m = gi >= 0
+            assert np.array_equal(gd[m].view(np.uint32), od[m].view(np.uint32)), (name, opts)        # the same distances, bit for bit
+            diff = np.nonzero(gi != oi)[0]                                                             # different index: only an exact tie
+            assert all(np.array_equal(D[gi[i]], D[oi[i]]) or gd[i] == od[i] for i in diff[:200]), (name, opts)
+            p = capi.IcpParams(); ctx._L.cilhip_icp_default_params(C.byref(p))
+            p.metric, p.w_p2p, p.max_sq_dist, p.max_iter, p.conv_tol = capi.METRIC_COMBINED, 0.0, float(r2), 8, 0.0
+            r = ctx.icp_run(p)
+            Ts.append(np.array(r.T[:], np.float64))
+            ctx.close()
+        assert len(set(round(c, 7) for c in cells)) >= 4, cells          # (the options did change the grid)
+        for T in Ts[1:]:
+            assert float(np.abs(T - Ts[0]).max()) <= 2e-6, (name, float(np.abs(T - Ts[0]).max()))
+
+
 def test_ranked_library_loop_one_rank_is_bitwise_the_python_protocol(hip_lib):
     """cilhip_rank_comm_* + cilhip_icp_iterate_ranked: the sharded loop's inner triple inside the library with its own RCCL
     communicator (one process per device).  With ONE rank (all a single-GPU box can run): the communicator comes up from the id,
