@@ -87,6 +87,22 @@ class OracleShardEngine:
         return self.T, self.iters, self.delta, self.nc
 
 
+class NativeLoopMixin:
+    """What cilantro_amd.distributed.HipShardEngine.enable_native_allreduce / iterate give the loops: blocks of iterations run by the
+    engine itself with its own all-reduce (here: gloo) -- the control flow of ShardedRigidICP / SlabShardedRigidICP around such an engine."""
+    native = False
+
+    def enable_native_allreduce(self, dist_, group=None):
+        self._dist, self._group, self.native = dist_, group, True
+        return True
+
+    def iterate(self, k):
+        for _ in range(int(k)):
+            sums = self.partial_sums()
+            self._dist.all_reduce(sums, group=self._group)
+            self.apply_sums(sums)
+
+
 class OracleTargetShardEngine(OracleShardEngine):
     """Test-only counterpart of HipTargetShardEngine: kd-tree over dst[lo:hi), keys with global indices."""
 
@@ -178,7 +194,7 @@ class OracleSlabEngine(OracleShardEngine):
         return self.viol, (self.viol_state if self.viol else self.state())
 
 
-def main_slab(metric, n, slack_cells):
+def main_slab(metric, n, slack_cells, native=False):
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     d = syn.make_pair(n, perturb=0.5)
@@ -187,9 +203,12 @@ def main_slab(metric, n, slack_cells):
 
     def engine_for(T):
         plans.append(distributed.SlabPartition.plan(d["dst"], d["src"], T, float(d["max_sq_dist"]), world, slack=slack))
-        return OracleSlabEngine(plans[-1], rank, d)
+        return (type("NativeSlabEngine", (NativeLoopMixin, OracleSlabEngine), {}) if native else OracleSlabEngine)(plans[-1], rank, d)
 
-    icp = distributed.SlabShardedRigidICP(engine_for(np.eye(4, dtype=np.float32)), dist, repartition=engine_for)
+    first = engine_for(np.eye(4, dtype=np.float32))
+    if native:
+        first.enable_native_allreduce(dist)
+    icp = distributed.SlabShardedRigidICP(first, dist, repartition=engine_for)
     p = distributed.default_params(metric=metric, max_iter=12, conv_tol=1e-6, max_sq_dist=float(d["max_sq_dist"]))
     T, iters, delta, nc = icp.estimate(p, check_every=2)
     counts = [None] * world
@@ -209,15 +228,20 @@ def main():
     metric = int(sys.argv[1]); n = int(sys.argv[2])
     if len(sys.argv) > 3 and sys.argv[3] == "tshard":
         return main_target_sharded(metric, n)
+    if len(sys.argv) > 3 and sys.argv[3].startswith("nslab"):
+        return main_slab(metric, n, float(sys.argv[3][5:] or -1), native=True)
     if len(sys.argv) > 3 and sys.argv[3].startswith("slab"):
         return main_slab(metric, n, float(sys.argv[3][4:] or -1))
+    native = len(sys.argv) > 3 and sys.argv[3] == "native"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     d = syn.make_pair(n, perturb=0.5)
     lo, hi = distributed.shard_bounds(n, rank, world)
-    eng = OracleShardEngine(d["dst"], d["dst_n"], d["src"][lo:hi])
+    eng = (type("NativeShardEngine", (NativeLoopMixin, OracleShardEngine), {}) if native else OracleShardEngine)(d["dst"], d["dst_n"], d["src"][lo:hi])
+    if native:
+        eng.enable_native_allreduce(dist)
     p = distributed.default_params(metric=metric, max_iter=12, conv_tol=1e-6, max_sq_dist=float(d["max_sq_dist"]))
-    T, iters, delta, nc = distributed.ShardedRigidICP(eng, dist).estimate(p, check_every=1)
+    T, iters, delta, nc = distributed.ShardedRigidICP(eng, dist).estimate(p, check_every=3 if native else 1)
     allT = [None] * world
     dist.all_gather_object(allT, T.tolist())
     if rank == 0:

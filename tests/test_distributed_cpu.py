@@ -88,6 +88,30 @@ def test_slab_sharded_icp_world2_matches_single_process(orc, metric):
         assert abs(r2["iters"] - ref["iterations"]) <= 1 and r2["ncorr"] == ref["last_ncorr"]
 
 
+def test_loops_around_an_engine_that_runs_blocks_of_iterations_itself(orc):
+    """cilhip_icp_iterate_ranked (one process per device: blocks of iterations inside the library, its own all-reduce) changes the
+    CONTROL FLOW of ShardedRigidICP / SlabShardedRigidICP: blocks up to the next check, early stop on convergence, a new
+    communicator for the engine a re-partition creates.  Played on the CPU by the test-only engine with the same interface
+    (`native`, `enable_native_allreduce`, `iterate`) over gloo, world size 2: same results as the per-iteration protocol and as the
+    single-process oracle run, with and without a guard that fires."""
+    n = 6000
+    d = syn.make_pair(n, perturb=0.5)
+    p = orc.make_params(metric=1, max_iter=12, conv_tol=1e-6, max_sq_dist=d["max_sq_dist"], mode=orc.MODE_MIXED)
+    ref = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+    plain = _run(2, 1, n)
+    r = _run(2, 1, n, "native")
+    assert r["world"] == 2 and r["identical"]
+    assert np.linalg.norm(np.array(r["T"], np.float64) - ref["T"]) <= 1e-5 and r["ncorr"] == ref["last_ncorr"]
+    # (checked every 3 iterations instead of every one: the loop may run up to 2 iterations past the tolerance; converged either way)
+    assert plain["iters"] <= r["iters"] <= plain["iters"] + 2
+    for mode, want_repart in (("nslab", False), ("nslab0.01", True)):
+        r2 = _run(2, 1, n, mode)
+        base = _run(2, 1, n, mode[1:])
+        assert r2["world"] == 2 and r2["identical"] and (r2["repartitions"] > 0) == want_repart
+        assert r2["T"] == base["T"] and r2["iters"] == base["iters"] and r2["ncorr"] == base["ncorr"] and r2["repartitions"] == base["repartitions"]
+        assert np.linalg.norm(np.array(r2["T"], np.float64) - ref["T"]) <= 1e-5
+
+
 def test_slab_partition_is_exact(orc):
     """Every owned query finds, inside its own slab + halo, exactly the neighbour the whole target gives it -- under the
     partition transform and under any transform that moves no point by more than the slack along the axis."""
