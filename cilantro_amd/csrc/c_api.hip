@@ -103,6 +103,7 @@ struct cilhip_ctx {
   int cw_point_kind = 0, cw_plane_kind = 0;     // correspondence weight evaluators (CW_*), combined metric
   float cw_point_sigma = 1.0f, cw_plane_sigma = 1.0f;
   bool have_nn = false;           // nn_pos/nn_d2 hold the result of a search
+  bool d2_stale = false;          // ... but nn_d2 has not been formed yet (matches left by a loop whose kernels keep no distances: ensure_d2)
   float nn_T[16];                 // transform used by that search
   // after cilhip_icp_run the engine's correspondence set is the last executed iteration's (correspondence_search_kd_tree.hpp:231 through
   // icp_base.hpp:32-38): either the loop's kernels left it in nn_pos (have_nn, origin 1) or it is searched again on demand under
@@ -193,7 +194,7 @@ static void drop_src_grid(cilhip_ctx* c) {
   if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }
   if (c->d_src_rgb_grid) { (void)hipFree(c->d_src_rgb_grid); c->d_src_rgb_grid = nullptr; }
 }
-static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->pending_matches = false; c->matches_origin = 0; }
+static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->d2_stale = false; c->pending_matches = false; c->matches_origin = 0; }
 
 extern "C" {
 
@@ -1005,7 +1006,7 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   if (rc) return rc;
   memcpy(c->nn_T, T, sizeof(c->nn_T));
   c->pending_matches = false;
-  c->have_nn = true;
+  c->have_nn = true; c->d2_stale = false;
   c->matches_origin = 3;
   if (n_found) {
     unsigned long long cnt = 0;
@@ -1017,7 +1018,18 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   return CILHIP_OK;
 }
 
+// nn_d2 of the matches a loop left behind (finish_run_matches), with the search's pinned arithmetic under the transform they were found under
+static int ensure_d2(cilhip_ctx* c) {
+  if (!c->d2_stale || !c->have_nn) return CILHIP_OK;
+  CK(c, hipSetDevice(c->device));
+  if (c->ns) launch_fill_d2(c->d_src_sorted, c->grid.pts, c->d_nn_pos, c->nn_T, c->ns, c->d_nn_d2, c->stream);
+  c->d2_stale = false;
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
 static int scatter_to_original(cilhip_ctx* c) {
+  { const int drc = ensure_d2(c); if (drc) return drc; }
   const size_t cap = c->ns ? c->ns : 1;
   if (!c->d_out_idx) CK(c, hipMalloc(&c->d_out_idx, cap * sizeof(uint32_t)));
   if (!c->d_out_d2) CK(c, hipMalloc(&c->d_out_d2, cap * sizeof(float)));
@@ -1029,8 +1041,9 @@ static int scatter_to_original(cilhip_ctx* c) {
 // The correspondence set of the last executed iteration of cilhip_icp_run, when the loop's kernels did not leave it in memory
 // (post-filters, pair-list directions, feature search, forms that store no matches): searched again under the transform that
 // iteration searched under.  The search is exact and deterministic: the same set.
+static int ensure_d2(cilhip_ctx* c);
 static int materialize_pending(cilhip_ctx* c) {
-  if (!c->pending_matches) return CILHIP_OK;
+  if (!c->pending_matches) return ensure_d2(c);      // (matches a loop left in place: their distances are formed now, if not yet)
   float T[16];
   memcpy(T, c->nn_T, sizeof(T));
   const float r = c->pending_max_sq;
@@ -1614,8 +1627,9 @@ static void finish_run_matches(cilhip_ctx* c, const cilhip_icp_params* p, size_t
   memcpy(c->nn_T, Tprev, sizeof(c->nn_T));
   if (pairs) { c->have_pairs = true; c->matches_origin = 1; return; }
   if (stored && c->ns) {
-    launch_fill_d2(c->d_src_sorted, c->grid.pts, c->d_nn_pos, Tprev, c->ns, c->d_nn_d2, c->stream);
-    c->have_nn = true; c->matches_origin = 1;
+    // (the squared distances of the stored matches are formed when somebody asks for them -- ensure_d2: a pass over the source that
+    //  a caller who only wants the transform does not pay, 80 us at 10M)
+    c->have_nn = true; c->d2_stale = true; c->matches_origin = 1;
   } else {
     c->pending_matches = true; c->pending_max_sq = p->max_sq_dist; c->matches_origin = 2;
   }
