@@ -70,6 +70,9 @@ def parse():
     return ap.parse_args()
 
 
+TIMING_STRIDE = 4      # kernel timing inside the timed region: iterations 0-2 and every 4th one carry events
+
+
 def source_hash():
     """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
     h = hashlib.sha256()
@@ -219,6 +222,8 @@ def bench_icp(a, torch, rank, world, local_rank):
     # rank without a loadable librccl: three calls + torch's all-reduce per iteration (same sums either way)
     native = sharded and os.environ.get("CILHIP_BENCH_TORCH_ALLREDUCE") != "1" and distributed.init_rank_comm(ctx, dist, None, "cuda")
 
+    ctx.set_option("kernel_timing_stride", TIMING_STRIDE)
+
     def run(iters, timing):
         p.max_iter = iters
         ctx.enable_kernel_timing(timing)
@@ -286,8 +291,12 @@ def bench_icp(a, torch, rank, world, local_rank):
             4: ("k_iter<metric, search> (per-lane fused search + accumulation)", one_pass_bytes),
         }
         ft = ctx.last_form_timing()
-        forms = {str(f): {"launches": n, "avg_kernel_ms": ms / n} for f, (ms, n) in ft.items() if n > 0}
-        dom = max(ft, key=lambda f: ft[f][0]) if launches > 0 else None      # the form the timed region spent most kernel time in
+        # launches of each form in the timed region (the run's trace), and how many of them carried events (kernel_timing_stride)
+        tr_forms = [int(t["form"]) & 0x7f for t in (ctx.last_run_trace() if not sharded else [])]
+        n_form = {f: (tr_forms.count(f) if tr_forms else ft[f][1]) for f in ft}
+        forms = {str(f): {"launches": n_form[f], "timed_launches": n, "avg_kernel_ms": ms / n} for f, (ms, n) in ft.items() if n > 0}
+        # the form the timed region spent most kernel time in (average of the timed launches x all launches of the form)
+        dom = max((f for f in ft if ft[f][1] > 0), key=lambda f: ft[f][0] / ft[f][1] * n_form[f], default=None) if launches > 0 else None
         fused = dom is not None and dom != 0
         traffic, traffic_note = None, "no PMC measurement of this build / workload committed"
         import glob
@@ -309,9 +318,11 @@ def bench_icp(a, torch, rank, world, local_rank):
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "measured_copy_bandwidth_GBps": copy_bandwidth(torch), "traffic": traffic, "traffic_note": traffic_note,
-                    "kernel": kern, "form": dom, "avg_kernel_ms": avg_ms, "launches": ft[dom][1], "algorithmic_bytes_per_launch": alg_bytes,
-                    "timing": "hipEvents around the kernel(s) on the context's stream, every launch of the timed region; the dominant "
-                              "kernel is the form with the largest share of the timed region's kernel time",
+                    "kernel": kern, "form": dom, "avg_kernel_ms": avg_ms, "launches": n_form[dom], "timed_launches": ft[dom][1], "algorithmic_bytes_per_launch": alg_bytes,
+                    "timing": "hipEvents attached to the kernels' own dispatch packets on the context's stream, inside the timed region: iterations 0-2 and "
+                              f"every {TIMING_STRIDE}th one (an event between two dependent kernels idles the device for ~6 us, two per iteration are a tenth of a "
+                              "warm-started iteration: all of them timed costs the run 9 %); the dominant kernel is the form with the largest share of the "
+                              "timed region's kernel time (average of its timed launches x its launches)",
                     "forms_in_timed_region": forms,
                     "all_forms_avg_kernel_ms": search_ms / launches}
             if 1 in ft and ft[1][1] > 0 and dom != 1:
@@ -319,7 +330,7 @@ def bench_icp(a, torch, rank, world, local_rank):
                 # iterations of every registration, and every iteration of a source that is not the target's points plus small
                 # noise (`independent_source` below), run in
                 cold_ms = ft[1][0] / ft[1][1]
-                out_cold = {"bound": "hbm", "kernel": FORMS[1][0], "form": 1, "avg_kernel_ms": cold_ms, "launches": ft[1][1],
+                out_cold = {"bound": "hbm", "kernel": FORMS[1][0], "form": 1, "avg_kernel_ms": cold_ms, "launches": n_form[1],
                             "algorithmic_bytes_per_launch": one_pass_bytes, "achieved": one_pass_bytes / (cold_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": one_pass_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             else:
@@ -394,8 +405,9 @@ def bench_icp(a, torch, rank, world, local_rank):
         except Exception as e:
             extras["converging_run"] = {"error": repr(e)}
         # A source that is NOT the target's points plus small noise: an independent uniform sample of the same volume (matches at
-        # about half the point spacing).  The nearest-other-point table settles few of its queries, so the adaptive loop stays
-        # with the LDS-tiled kernels: the regime every registration of two separately sampled clouds lives in.
+        # about half the point spacing): the regime every registration of two separately sampled clouds lives in.  The margin
+        # proof settles 96 % of its queries per iteration; the rest -- nearly equidistant first and second
+        # neighbours -- is searched again in every iteration.
         try:
             rng = np.random.default_rng(3)
             si = rng.random((ns, 3), dtype=np.float32)
@@ -410,14 +422,15 @@ def bench_icp(a, torch, rank, world, local_rank):
             ctx.synchronize(); dti = time.perf_counter() - t0
             fti = ctx.last_form_timing()
             nci = int(ri.last_ncorr)
-            domi = max(fti, key=lambda f: fti[f][0])
+            tri = [int(t["form"]) & 0x7f for t in ctx.last_run_trace()]
+            domi = max((f for f in fti if fti[f][1] > 0), key=lambda f: fti[f][0] / fti[f][1] * max(tri.count(f), 1))
             bytes_i = {0: 16.0 * ns + 12.0 * nd, 1: 12.0 * ns + 12.0 * nd + (12.0 * nci if with_normals else 0.0)}.get(domi, 12.0 * ns + (24.0 if with_normals else 12.0) * nci)
             ms_i = fti[domi][0] / max(fti[domi][1], 1)
             extras["independent_source"] = {
                 "workload": f"{ns/1e6:g}M independent uniform source points against the same {nd/1e6:g}M-point target, {a.steps} iterations, tolerance 0",
                 "ms_per_step": dti * 1e3 / a.steps, "icp_iterations_per_sec": a.steps / dti, "last_ncorr": nci,
                 "iterations_one_pass_two_pass": list(ctx.last_run_forms()), "iterations_warm_started": ctx.last_warm_iterations(),
-                "forms": {str(f): {"launches": n, "avg_kernel_ms": ms / n} for f, (ms, n) in fti.items() if n > 0},
+                "forms": {str(f): {"launches": tri.count(f), "timed_launches": n, "avg_kernel_ms": ms / n} for f, (ms, n) in fti.items() if n > 0},
                 "roofline": {"bound": "hbm", "form": domi, "avg_kernel_ms": ms_i, "algorithmic_bytes_per_launch": bytes_i,
                              "achieved": bytes_i / (ms_i * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         except Exception as e:

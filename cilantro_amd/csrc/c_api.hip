@@ -166,6 +166,8 @@ struct cilhip_ctx {
 
   // timing
   bool kernel_timing = false;
+  int timing_stride = 1;          // option "kernel_timing_stride": with kernel timing on, iterations 0..2 and every stride-th one carry events
+  std::vector<unsigned int> timed_iter;      // the iterations of the last run that did
   double last_loop_ms = 0.0, last_search_ms = 0.0, last_acc_ms = 0.0;
   int last_search_launches = 0;
   size_t run_nev = 0;             // sharded runs: hipEvents recorded by cilhip_icp_partial_sums since cilhip_icp_begin (3 per call)
@@ -393,6 +395,11 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
     return CILHIP_OK;
   }
   if (!strcmp(key, "kernel_timing")) { c->kernel_timing = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "kernel_timing_stride")) {
+    if (!(value >= 1.0 && value <= 4096.0)) return fail(c, CILHIP_ERR_INVALID, "kernel_timing_stride: 1 .. 4096");
+    c->timing_stride = (int)value;
+    return CILHIP_OK;
+  }
   return fail(c, CILHIP_ERR_INVALID, "set_option: unknown key");
 }
 
@@ -1810,7 +1817,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
   c->rec_valid = false; c->lb_fresh = false;
   warm_run_reset(c);
-  c->iter_form.clear(); c->trace_form.clear();
+  c->iter_form.clear(); c->trace_form.clear(); c->timed_iter.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   bool warm_on = false;       // the loop has been seen to move little: iterations run warm-started until one of them has to search too many of its queries
   unsigned int judged = 0;    // the last published iteration whose listed count has been judged
@@ -1882,9 +1889,16 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     bool warm_first = false;
     bool counted = false;      // a cold iteration whose kernels count the queries a warm-started iteration after it would have to search
+    // (kernel timing on: does THIS iteration carry events?  Every event between dependent kernels idles the device for ~6 us --
+    //  two per iteration are a tenth of a warm-started iteration at 10M -- so a caller may ask for a sample: option kernel_timing_stride)
+    const bool timing_it = timing && (c->timing_stride <= 1 || it < 3 || it % (size_t)c->timing_stride == 0);
     for (size_t st = 0; st < opt_steps; ++st) {
       a.skip_if_inner_done = (st > 0);
-      if (timing && st == 0) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+      // (the one-kernel forms are timed through their own dispatch packets: no event packets between dependent kernels)
+      const bool lane_fused = c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule;
+      const bool ext_ev = timing_it && st == 0 && c->ns && !lane_fused && (warm || one_pass);
+      if (timing_it && st == 0 && !ext_ev) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+      if (ext_ev) { hipEvent_t e0 = get_event(c, nev), e1 = get_event(c, nev + 1); set_launch_events(e0, e1); nev += 2; }
       if (c->ns) {
         if (st == 0 && c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
@@ -1931,24 +1945,25 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
             tie_seen += c->tie_resolved; tie_moved += c->tie_changed;
           }
           { const int frc = apply_filters(c); if (frc) return frc; }
-          if (timing) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
+          if (timing_it) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
         } else {
           launch_iter(a, im, false, false, nb, c->stream);
         }
       }
-      if (timing && st == 0) {
+      if (timing_it && st == 0) {
         // (two events per iteration around the search / one-pass kernels; a two-pass iteration adds a pair around its
         //  streaming accumulation, kept in a list of its own)
-        if (single || (c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+        if (ext_ev) {}
+        else if (single || (c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
         else CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream));
-        ++launches;
+        ++launches; c->timed_iter.push_back((unsigned int)it);
       }
       if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
       if (st == 0) {
         const unsigned char form = (unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
                                                    : (c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) ? FORM_LANE_FUSED : FORM_SEARCH);
-        if (timing) c->iter_form.push_back(form);
+        if (timing_it) c->iter_form.push_back(form);
         c->trace_form.push_back((unsigned char)(form | (counted ? 0x80 : 0)));
       }
       sa.gn_last_step = (st + 1 == opt_steps);
@@ -1986,7 +2001,8 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   c->last_search_ms = 0.0; c->last_search_launches = 0;
   if (timing) {
     // only iterations that actually executed (not the early-exit launches after convergence)
-    const size_t executed = out->iterations < (size_t)launches ? out->iterations : (size_t)launches;
+    size_t executed = 0;
+    while (executed < c->timed_iter.size() && executed < (size_t)launches && (size_t)c->timed_iter[executed] < out->iterations) ++executed;
     c->last_acc_ms = 0.0;
     for (size_t k = 0; k < executed; ++k) {
       float m = 0.f;

@@ -282,6 +282,9 @@ void launch_iter(const IterArgs& a, int metric, bool search, bool store, int nbl
 void launch_self_nn(const GridDev& g, float* safe2, hipStream_t s);
 // rec: 1 = gather through warm_pos (+ the searches' margin keys in nn_lb) and write the match records, 2 = read the match records (a.warm_rec)
 void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_t s);
+// kernel timing without extra packets: the NEXT launch_warm / launch_search_tiled of this thread attaches these events to its own
+// kernels' dispatch packets (start of its first kernel, stop of its last)
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
 void launch_interleave_pn(const float4* pts, const float4* nrm, uint32_t n, float4* pn, hipStream_t s);
 void launch_copy_src3(const float4* src_sorted, uint32_t ns, F3* out, hipStream_t s);   // a.warm_src3 of the record-reading form
 int warm_num_blocks(uint32_t ns);      // blocks (= partial-sum rows) of launch_warm

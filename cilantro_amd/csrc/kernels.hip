@@ -35,10 +35,23 @@
 //     kernel keeps per-lane f64 accumulators instead.  Fixed orders everywhere (per wave, per block, across blocks)
 //     => bitwise run-to-run reproducible (the reference's OpenMP reduction is not).
 #include "internal.hpp"
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstring>
 
 namespace cilhip {
+
+// Kernel timing without extra packets in the queue: a launcher that supports it attaches the caller's events to its kernels' OWN
+// dispatch packets (hipExtLaunchKernelGGL: start of the first kernel, stop of the last) instead of the caller recording events
+// around it -- an event recorded between two dependent kernels costs the device ~6 us of idle time each (measured: 11.5 us per
+// warm-started iteration of 110).  set_launch_events() arms the NEXT such launcher call of this thread.
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+template <typename... Args, typename F = void (*)(Args...)>
+static inline void launch_ev(F kernel, dim3 grid, dim3 block, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, Args... args) {
+  if (ev_start != nullptr || ev_stop != nullptr) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, ev_start, ev_stop, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+}
 
 // LDS-tiled search geometry: cube of 2^L cells per axis, <= TILE_QUERIES queries per tile,
 // TILE_THREADS threads per workgroup.  (4^3 cells / 256 queries / 256 threads, or 8^3 / 2048 / 1024.)
@@ -2170,7 +2183,7 @@ int tiled_partial_rows(uint32_t ntiles) { return (int)(ntiles + deferred_blocks(
 #include "tile_pipe.inc"
 
 template <int ACC>
-static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const int* tile_box, uint32_t ntiles, hipStream_t s) {
+static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const int* tile_box, uint32_t ntiles, hipStream_t s, hipEvent_t ev_stop) {
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
   if (ACC != IM_NONE && a.tile_pipeline == 2) hipLaunchKernelGGL((k_tile_pipe<ACC, true>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   else if (ACC != IM_NONE && a.tile_pipeline) hipLaunchKernelGGL((k_tile_pipe<ACC, false>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
@@ -2179,20 +2192,22 @@ static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const i
   else if (ACC == IM_NONE ? a.nn_lb != nullptr : a.warm_rec != nullptr)
     hipLaunchKernelGGL((k_search_tiled<ACC, false, true>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   else hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
-  hipLaunchKernelGGL((k_search_deferred<ACC>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), 0, s, a, tiles, ntiles);
+  launch_ev((k_search_deferred<ACC>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), s, (hipEvent_t) nullptr, ev_stop, a, tiles, ntiles);
 }
 
 // acc_metric: IM_NONE = search only (matches stored); IM_KABSCH / IM_PLANE / IM_POINT / IM_BOTH = search + accumulation of
 // the first Gauss-Newton step's sums in one pass (a.partials[0 .. tiled_partial_rows) rows afterwards).
 void launch_search_tiled(const IterArgs& a, int acc_metric, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s) {
-  if (ntiles == 0) return;
-  hipLaunchKernelGGL(k_tile_boxes, dim3((ntiles + 255) / 256), dim3(256), 0, s, make_box_args(a, tile_center, tile_box, ntiles, acc_metric != IM_NONE), a.state);
+  const hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;      // (armed by set_launch_events: consumed here)
+  g_ev_start = g_ev_stop = nullptr;
+  if (ntiles == 0) { if (ev_start) (void)hipEventRecord(ev_start, s); if (ev_stop) (void)hipEventRecord(ev_stop, s); return; }
+  launch_ev(k_tile_boxes, dim3((ntiles + 255) / 256), dim3(256), s, ev_start, (hipEvent_t) nullptr, make_box_args(a, tile_center, tile_box, ntiles, acc_metric != IM_NONE), a.state);
   switch (acc_metric) {
-    case IM_KABSCH: launch_search_tiled_m<IM_KABSCH>(a, tiles, tile_box, ntiles, s); break;
-    case IM_PLANE: launch_search_tiled_m<IM_PLANE>(a, tiles, tile_box, ntiles, s); break;
-    case IM_POINT: launch_search_tiled_m<IM_POINT>(a, tiles, tile_box, ntiles, s); break;
-    case IM_BOTH: launch_search_tiled_m<IM_BOTH>(a, tiles, tile_box, ntiles, s); break;
-    default: launch_search_tiled_m<IM_NONE>(a, tiles, tile_box, ntiles, s); break;
+    case IM_KABSCH: launch_search_tiled_m<IM_KABSCH>(a, tiles, tile_box, ntiles, s, ev_stop); break;
+    case IM_PLANE: launch_search_tiled_m<IM_PLANE>(a, tiles, tile_box, ntiles, s, ev_stop); break;
+    case IM_POINT: launch_search_tiled_m<IM_POINT>(a, tiles, tile_box, ntiles, s, ev_stop); break;
+    case IM_BOTH: launch_search_tiled_m<IM_BOTH>(a, tiles, tile_box, ntiles, s, ev_stop); break;
+    default: launch_search_tiled_m<IM_NONE>(a, tiles, tile_box, ntiles, s, ev_stop); break;
   }
 }
 
@@ -2983,8 +2998,10 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
 template <int ACC>
 static void launch_warm_m(const IterArgs& a, int rec, int nblocks, hipStream_t s) {
   const dim3 g(nblocks), b(WARM_THREADS);
-  if (rec == 2) hipLaunchKernelGGL((k_warm<ACC, 2>), g, b, 0, s, a);
-  else hipLaunchKernelGGL((k_warm<ACC, 1>), g, b, 0, s, a);
+  const hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;      // (armed by set_launch_events: consumed here)
+  g_ev_start = g_ev_stop = nullptr;
+  if (rec == 2) launch_ev((k_warm<ACC, 2>), g, b, s, ev_start, ev_stop, a);
+  else launch_ev((k_warm<ACC, 1>), g, b, s, ev_start, ev_stop, a);
 }
 int warm_num_blocks(uint32_t ns) {
   // ONE generation of blocks (4 resident per CU: registers, LDS): every wave searches its list once, at the end of its chunk --

@@ -481,6 +481,10 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        plus this fraction of a grid cell -- the room its fresh margin can have.  Larger: more cells per
  *                        search, margins that last longer; measured best at 10M (independent source: 0.25 -> 0.216 ms per
  *                        warm-started iteration, 0.0625 -> 0.197, 0.03 -> 0.199).  Never changes a result.
+ *   "kernel_timing_stride" (default 1): with kernel timing on (cilhip_enable_kernel_timing), iterations 0, 1, 2 and every stride-th one
+ *                        carry events; the others run as they do without timing.  An event between two dependent kernels idles the
+ *                        device for ~6 us: two per iteration are a tenth of a warm-started iteration at 10M.  The per-form averages
+ *                        of cilhip_get_last_form_timing are then over the timed launches (its `launches` = how many).
  *   "pair_records" (default 1): the streaming accumulation (second pass of a two-pass iteration, later Gauss-Newton steps) gathers a
  *                        match's point and normal from ONE 32-byte record instead of two arrays (a copy of the target in that layout,
  *                        32 B per point, built by the first run that needs it; without room for it the two arrays serve): 123.5 ->
