@@ -2068,7 +2068,8 @@ static int partial_sums_core(cilhip_ctx* c, double* sums_dev, double* rows_dev) 
       launch_iter(a, im, true, false, nb, c->stream);
     } else {
       a.nn_d2 = nullptr;   // no post-filters in sharded runs: nobody reads the squared distances (as in cilhip_icp_run)
-      const bool timing = c->kernel_timing && c->run_nev + 3 <= 3 * 4096;
+      const bool timing = c->kernel_timing && c->run_nev + 3 <= 3 * 4096 &&
+                          (c->timing_stride <= 1 || c->run_calls < 3 || c->run_calls % c->timing_stride == 0);      // (a sample of the iterations: option kernel_timing_stride)
       const size_t e = 2 + c->run_nev;
       if (timing) CK(c, hipEventRecord(get_event(c, e), c->stream));
       // Warm-started form (see cilhip_icp_run): from the second call on, when the latest loop state this run's epilogues have
