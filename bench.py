@@ -73,6 +73,38 @@ def parse():
 TIMING_STRIDE = 4      # kernel timing inside the timed region: iterations 0-2 and every 4th one carry events
 
 
+def stratified_form_timing(ft, forms, timed):
+    """Per-form kernel time of a run whose iterations were timed by SAMPLE (option kernel_timing_stride), as {form: (ms, n)} with
+    ms / n the estimate of the form's mean launch.  The first iteration of a stretch of one form is not like the others (the first
+    warm-started iteration after a cold one searches a hundred times more queries than the ones after it) and the sample always
+    holds it: the mean is formed per stratum -- first of a stretch / the rest -- and weighted by how many iterations of the run
+    each stratum has, not by how many of them happened to be timed.  forms: the run's form per iteration (its trace); timed:
+    [(iteration, ms)].  Without a trace (sharded runs) the plain sums of `ft` are returned."""
+    if not forms or not timed:
+        return ft
+    strat = lambda i: (forms[i], i == 0 or forms[i - 1] != forms[i])
+    count, tsum, tn = {}, {}, {}
+    for i in range(len(forms)):
+        count[strat(i)] = count.get(strat(i), 0) + 1
+    for i, ms in timed:
+        if i < len(forms):
+            tsum[strat(i)] = tsum.get(strat(i), 0.0) + ms
+            tn[strat(i)] = tn.get(strat(i), 0) + 1
+    out = {}
+    for f in set(forms):
+        num = den = 0.0
+        n_timed = 0
+        for first in (True, False):
+            k = (f, first)
+            if count.get(k, 0) and tn.get(k, 0):
+                num += tsum[k] / tn[k] * count[k]
+                den += count[k]
+                n_timed += tn[k]
+        if den > 0:
+            out[f] = (num / den * n_timed, n_timed)      # (ms, n) with ms / n = the weighted mean
+    return {f: out.get(f, ft.get(f, (0.0, 0))) for f in set(ft) | set(out)}
+
+
 def source_hash():
     """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
     h = hashlib.sha256()
@@ -294,6 +326,7 @@ def bench_icp(a, torch, rank, world, local_rank):
         # launches of each form in the timed region (the run's trace), and how many of them carried events (kernel_timing_stride)
         tr_forms = [int(t["form"]) & 0x7f for t in (ctx.last_run_trace() if not sharded else [])]
         n_form = {f: (tr_forms.count(f) if tr_forms else ft[f][1]) for f in ft}
+        ft = stratified_form_timing(ft, tr_forms, ctx.last_iteration_timing() if not sharded else [])
         forms = {str(f): {"launches": n_form[f], "timed_launches": n, "avg_kernel_ms": ms / n} for f, (ms, n) in ft.items() if n > 0}
         # the form the timed region spent most kernel time in (average of the timed launches x all launches of the form)
         dom = max((f for f in ft if ft[f][1] > 0), key=lambda f: ft[f][0] / ft[f][1] * n_form[f], default=None) if launches > 0 else None
@@ -322,7 +355,8 @@ def bench_icp(a, torch, rank, world, local_rank):
                     "timing": "hipEvents attached to the kernels' own dispatch packets on the context's stream, inside the timed region: iterations 0-2 and "
                               f"every {TIMING_STRIDE}th one (an event between two dependent kernels idles the device for ~6 us, two per iteration are a tenth of a "
                               "warm-started iteration: all of them timed costs the run 9 %); the dominant kernel is the form with the largest share of the "
-                              "timed region's kernel time (average of its timed launches x its launches)",
+                              "timed region's kernel time; a form's average = per stratum (first iteration of a stretch of the form / the rest) the mean of the timed "
+                              "launches, weighted by the stratum's share of the run's iterations",
                     "forms_in_timed_region": forms,
                     "all_forms_avg_kernel_ms": search_ms / launches}
             if 1 in ft and ft[1][1] > 0 and dom != 1:
@@ -420,9 +454,9 @@ def bench_icp(a, torch, rank, world, local_rank):
             ctx.synchronize(); t0 = time.perf_counter()
             ri = ctx.icp_run(p, T0)
             ctx.synchronize(); dti = time.perf_counter() - t0
-            fti = ctx.last_form_timing()
-            nci = int(ri.last_ncorr)
             tri = [int(t["form"]) & 0x7f for t in ctx.last_run_trace()]
+            fti = stratified_form_timing(ctx.last_form_timing(), tri, ctx.last_iteration_timing())
+            nci = int(ri.last_ncorr)
             domi = max((f for f in fti if fti[f][1] > 0), key=lambda f: fti[f][0] / fti[f][1] * max(tri.count(f), 1))
             bytes_i = {0: 16.0 * ns + 12.0 * nd, 1: 12.0 * ns + 12.0 * nd + (12.0 * nci if with_normals else 0.0)}.get(domi, 12.0 * ns + (24.0 if with_normals else 12.0) * nci)
             ms_i = fti[domi][0] / max(fti[domi][1], 1)

@@ -168,6 +168,7 @@ struct cilhip_ctx {
   bool kernel_timing = false;
   int timing_stride = 1;          // option "kernel_timing_stride": with kernel timing on, iterations 0..2 and every stride-th one carry events
   std::vector<unsigned int> timed_iter;      // the iterations of the last run that did
+  std::vector<float> timed_ms;               // ... and the kernel time of each (cilhip_get_last_iteration_timing)
   double last_loop_ms = 0.0, last_search_ms = 0.0, last_acc_ms = 0.0;
   int last_search_launches = 0;
   size_t run_nev = 0;             // sharded runs: hipEvents recorded by cilhip_icp_partial_sums since cilhip_icp_begin (3 per call)
@@ -422,6 +423,14 @@ int cilhip_get_last_timing2(cilhip_ctx* c, double* search_ms, double* accumulate
   if (!c) return CILHIP_ERR_INVALID;
   if (search_ms) *search_ms = c->last_search_ms;
   if (accumulate_ms) *accumulate_ms = c->last_acc_ms;
+  return CILHIP_OK;
+}
+
+int cilhip_get_last_iteration_timing(cilhip_ctx* c, int cap, int* n, unsigned int* iteration, float* kernel_ms) {
+  if (!c || !n || cap < 0) return CILHIP_ERR_INVALID;
+  const size_t m = c->timed_ms.size() < c->timed_iter.size() ? c->timed_ms.size() : c->timed_iter.size();
+  *n = (int)m;
+  for (size_t k = 0; k < m && k < (size_t)cap; ++k) { if (iteration) iteration[k] = c->timed_iter[k]; if (kernel_ms) kernel_ms[k] = c->timed_ms[k]; }
   return CILHIP_OK;
 }
 
@@ -2004,9 +2013,11 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     size_t executed = 0;
     while (executed < c->timed_iter.size() && executed < (size_t)launches && (size_t)c->timed_iter[executed] < out->iterations) ++executed;
     c->last_acc_ms = 0.0;
+    c->timed_ms.assign(executed, 0.0f);
     for (size_t k = 0; k < executed; ++k) {
       float m = 0.f;
       CK(c, hipEventElapsedTime(&m, c->ev[2 + 2 * k], c->ev[3 + 2 * k]));
+      c->timed_ms[k] = m;
       c->last_search_ms += m;
       if (k < c->iter_form.size()) { c->form_ms[c->iter_form[k]] += m; ++c->form_n[c->iter_form[k]]; }
     }

@@ -329,6 +329,14 @@ class Context:
         self._ck(self._L.cilhip_get_last_run_trace(self._h, cap, C.byref(n), un, li, st, de, fo))
         return [{"form": fo[i], "unproven": un[i], "listed": li[i], "step": st[i], "delta": de[i]} for i in range(n.value)]
 
+    def last_iteration_timing(self, cap=4096):
+        """[(iteration, kernel ms)] of the iterations of the last icp_run that carried events (kernel timing on; option kernel_timing_stride)"""
+        n = C.c_int(0)
+        it = np.zeros(cap, np.uint32); ms = np.zeros(cap, np.float32)
+        self._ck(self._L.cilhip_get_last_iteration_timing(self._h, cap, C.byref(n), it.ctypes.data, ms.ctypes.data))
+        k = min(n.value, cap)
+        return [(int(it[i]), float(ms[i])) for i in range(k)]
+
     def last_warm_iterations(self):
         """how many of the one-pass iterations of the last icp_run ran as the warm-started per-lane kernel"""
         a = C.c_int(0)

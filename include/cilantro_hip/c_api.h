@@ -435,6 +435,9 @@ int cilhip_get_last_run_trace(cilhip_ctx* ctx, int cap, int* n, unsigned int* un
  * the accumulation inside the tile, 2: the first warm-started iteration of a stretch (gathers through the stored matches and
  * writes the match records), 3: warm-started iterations reading the records, 4: the per-lane fused kernel (option "fused"). */
 int cilhip_get_last_form_timing(cilhip_ctx* ctx, int form, double* kernel_ms, int* launches);
+/* ... and iteration by iteration: which iterations of the last cilhip_icp_run carried events (option "kernel_timing_stride") and the time
+ * of the search (+ accumulation) kernel(s) of each.  *n = how many (may exceed cap: the first cap are written). */
+int cilhip_get_last_iteration_timing(cilhip_ctx* ctx, int cap, int* n, unsigned int* iteration, float* kernel_ms);
 
 /* ms of the kernels of the last cilhip_icp_run, measured with hipEvents on the ctx stream:
  * total loop, and the fused search+accumulate kernel alone (sum over executed iterations). */

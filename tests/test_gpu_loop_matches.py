@@ -219,6 +219,32 @@ def test_margin_records_every_route(Context, orc):
     _report("margin_routes.json", report)
 
 
+def test_kernel_timing_by_sample_changes_nothing_but_the_events(Context):
+    """Option kernel_timing_stride: with kernel timing on, iterations 0-2 and every stride-th one carry events (attached to the kernels' own
+    dispatch packets); the run's result is bitwise the untimed run's, the timed iterations are the announced ones, every one of them
+    reports a positive kernel time, and the per-form sums are over exactly those."""
+    d = syn.make_pair(700_000, perturb=0.3)
+    res = {}
+    for timing, stride in ((0, 1), (1, 1), (1, 4)):
+        ctx = Context()
+        ctx.set_option("kernel_timing_stride", stride)
+        ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+        ctx.enable_kernel_timing(bool(timing))
+        r = ctx.icp_run(_params(ctx, capi.METRIC_COMBINED, 0.0, d["max_sq_dist"], 20))
+        its = ctx.last_iteration_timing()
+        ft = ctx.last_form_timing()
+        ctx.close()
+        res[(timing, stride)] = bytes(np.array(r.T[:], np.float32))
+        if not timing:
+            assert its == []
+        else:
+            want = list(range(20)) if stride == 1 else [0, 1, 2, 4, 8, 12, 16]
+            assert [i for i, _ in its] == want and all(ms > 0.0 for _, ms in its), its
+            assert sum(n for _, n in ft.values()) == len(want)
+            assert abs(sum(ms for ms, _ in ft.values()) - sum(ms for _, ms in its)) <= 1e-3
+    assert res[(0, 1)] == res[(1, 1)] == res[(1, 4)]
+
+
 def test_tile_and_lane_loop_kernels_matches_index_for_index(Context, orc):
     """The other forms an iteration can take, same check: the LDS tiles with the accumulation inside (one pass), the two-pass
     form (tiled search with its 3x3x3 pass + streaming accumulation), the per-lane search; and loops whose kernels keep no
