@@ -71,3 +71,31 @@ def test_torch_default_stream_handle_maps_to_hip_stream_legacy():
     c.set_stream(None)
     assert (seen[-1] or 0) == 0 and not c._on_caller_stream
     c._h = None   # nothing to destroy
+
+
+def test_bench_forms_average_from_a_stratified_sample():
+    """bench.py times a SAMPLE of the iterations (an event between dependent kernels idles the device).  The first iteration of a
+    stretch of one form is not like the others and is always in the sample: a form's mean is formed per stratum (first of a
+    stretch / the rest) and weighted by the strata's share of the RUN, so that the estimate equals the all-launch mean when the
+    strata are homogeneous -- and is not pulled towards the first iteration by the sampling rate."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    forms = [1, 1] + [3] * 18
+    per_it = [0.29, 0.35, 0.122] + [0.084] * 17
+    timed = [(i, per_it[i]) for i in (0, 1, 2, 4, 8, 12, 16)]
+    plain = {1: (0.64, 2), 3: (sum(per_it[i] for i in (2, 4, 8, 12, 16)), 5)}
+    est = bench.stratified_form_timing(plain, forms, timed)
+    assert abs(est[3][0] / est[3][1] - sum(per_it[2:]) / 18) < 1e-12            # = the mean over all 18 launches
+    assert abs(plain[3][0] / plain[3][1] - 0.0916) < 1e-4                           # (the plain sample mean is 6 % off)
+    assert abs(est[1][0] / est[1][1] - 0.32) < 1e-12 and est[3][1] == 5 and est[1][1] == 2
+    # a second stretch of the same form after a fall back to the cold form: its first iteration is a stratum member too
+    forms2 = [0, 3, 3, 3, 0, 3, 3, 3]
+    timed2 = [(0, 0.5), (1, 0.3), (2, 0.1), (4, 0.5), (5, 0.3), (6, 0.1)]
+    e2 = bench.stratified_form_timing({0: (1.0, 2), 3: (0.8, 4)}, forms2, timed2)
+    assert abs(e2[3][0] / e2[3][1] - (0.3 * 2 + 0.1 * 4) / 6) < 1e-12
+    # no trace (sharded runs) or nothing timed: the plain sums
+    assert bench.stratified_form_timing(plain, [], timed) == plain and bench.stratified_form_timing(plain, forms, []) == plain
