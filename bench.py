@@ -258,7 +258,7 @@ def bench_icp(a, torch, rank, world, local_rank):
 
     def run(iters, timing):
         p.max_iter = iters
-        ctx.enable_kernel_timing(timing)
+        ctx.enable_kernel_timing(timing and os.environ.get("CILHIP_BENCH_NO_KERNEL_TIMING") != "1")      # (dev: what the events themselves cost)
         if not sharded:
             return ctx.icp_run(p, T0)
         ctx.icp_begin(p, T0, gmean)
