@@ -222,10 +222,53 @@ def main_slab(metric, n, slack_cells, native=False):
     dist.destroy_process_group()
 
 
+def main_rank_comm():
+    """distributed.init_rank_comm's collective logic over gloo with a stand-in context: the id created on rank 0 reaches every rank,
+    every rank joins with its own rank / the world size, and a rank that cannot join makes ALL ranks give up (and leave)."""
+    from cilantro_amd import icp
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    class FakeCtx:
+        def __init__(self, fail):
+            self.fail, self.got, self.destroyed = fail, None, 0
+
+        def rank_comm_init(self, uid, nranks, r):
+            if self.fail:
+                raise RuntimeError("no librccl here")
+            self.got = (bytes(np.asarray(uid, np.uint8)), int(nranks), int(r))
+
+        def rank_comm_destroy(self):
+            self.destroyed += 1
+
+    made = []
+    real = icp.Context.rank_comm_unique_id
+    icp.Context.rank_comm_unique_id = staticmethod(lambda: (made.append(1), (np.arange(128) * 7 % 251).astype(np.uint8))[1])
+    try:
+        ok_ctx = FakeCtx(False)
+        r1 = distributed.init_rank_comm(ok_ctx, dist, None, "cpu")
+        bad_ctx = FakeCtx(rank == world - 1)
+        r2 = distributed.init_rank_comm(bad_ctx, dist, None, "cpu")
+        icp.Context.rank_comm_unique_id = staticmethod(lambda: (_ for _ in ()).throw(RuntimeError("rank 0 has no librccl")))
+        none_ctx = FakeCtx(False)
+        r3 = distributed.init_rank_comm(none_ctx, dist, None, "cpu")
+    finally:
+        icp.Context.rank_comm_unique_id = real
+    rows = [None] * world
+    dist.all_gather_object(rows, {"rank": rank, "r1": r1, "got": [ok_ctx.got[0].hex(), ok_ctx.got[1], ok_ctx.got[2]] if ok_ctx.got else None, "made": len(made),
+                                  "r2": r2, "bad_destroyed": bad_ctx.destroyed, "r3": r3, "none_got": none_ctx.got})
+    if rank == 0:
+        print("RESULT " + json.dumps({"world": world, "rows": rows}))
+    dist.destroy_process_group()
+
+
 def main():
     import signal
     signal.alarm(300)      # a worker never outlives its test (SIGALRM's default action terminates the process)
     metric = int(sys.argv[1]); n = int(sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "rankcomm":
+        return main_rank_comm()
     if len(sys.argv) > 3 and sys.argv[3] == "tshard":
         return main_target_sharded(metric, n)
     if len(sys.argv) > 3 and sys.argv[3].startswith("nslab"):

@@ -112,6 +112,21 @@ def test_loops_around_an_engine_that_runs_blocks_of_iterations_itself(orc):
         assert np.linalg.norm(np.array(r2["T"], np.float64) - ref["T"]) <= 1e-5
 
 
+def test_rank_communicator_handshake_over_gloo():
+    """distributed.init_rank_comm (what bench.py --gpus N and the engines call before cilhip_icp_iterate_ranked) with a stand-in
+    context, world size 3 over gloo: the id is created once, on rank 0; every rank receives the same 128 bytes and joins with its own
+    rank; a rank that cannot join -- or a rank 0 that cannot create the id -- makes every rank fall back, and leave what it joined."""
+    r = _run(3, 0, 0, "rankcomm")
+    assert r["world"] == 3
+    rows = sorted(r["rows"], key=lambda x: x["rank"])
+    want = bytes((np.arange(128) * 7 % 251).astype(np.uint8)).hex()
+    for k, row in enumerate(rows):
+        assert row["r1"] is True and row["got"] == [want, 3, k]
+        assert row["made"] == (2 if k == 0 else 0)                       # (two successful creations, both on rank 0)
+        assert row["r2"] is False and row["bad_destroyed"] == 1          # one rank failed: all leave
+        assert row["r3"] is False and row["none_got"] is None            # no id: nobody tries to join
+
+
 def test_slab_partition_is_exact(orc):
     """Every owned query finds, inside its own slab + halo, exactly the neighbour the whole target gives it -- under the
     partition transform and under any transform that moves no point by more than the slack along the axis."""
