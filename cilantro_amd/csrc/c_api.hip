@@ -86,11 +86,16 @@ struct cilhip_ctx {
   float* d_nn_lb = nullptr;       // [ns] margin keys the search-only tile kernel leaves next to nn_pos (IterArgs::nn_lb)
   bool lb_fresh = false;          // ... and they belong to the search that left nn_pos (inside a run)
   bool warm_forecast = true;      // option "warm_forecast": the cold kernels' count of the queries a warm-started iteration would have to search gates the form
-  int tie_rule = 0;               // option "tie_rule": 0 = lowest target index among exactly equidistant points, 1 = the one the reference's kd-tree meets first
-  cilhip::TieOrderTree* tie_tree = nullptr;      // (tie_rule 1: built from the target on first use, tie_order.hpp)
-  std::vector<float> tie_xyz;                    // the target in its original order (the tree's view of it)
-  TieEntry* d_tie_entries = nullptr; uint32_t tie_cap = 0; unsigned int* d_tie_count = nullptr; uint2* d_tie_patch = nullptr; uint32_t tie_patch_cap = 0;
-  unsigned long long tie_resolved = 0, tie_changed = 0;      // of the last search / run under tie_rule 1: tied queries seen, matches that were re-pointed
+  // option "tie_rule": which of several EXACTLY equidistant nearest target points a correspondence names.  0 = the lowest target index;
+  // 1 = the one the reference's kd-tree traversal meets first, order tables built before the first search; 2 (default) = the same
+  // choice, the tables built when a search first MEETS a tie (that search / run is then executed again): a target that never ties never
+  // pays for a tree.  The device resolves ties inside its search kernels (TieDev, kernels.hip: tie_settle).
+  int tie_rule = 2;
+  uint2* d_tie_leaf_slot = nullptr;              // [grid.n] the order tables by sorted target position (null: not loaded)
+  uint4* d_tie_nodes = nullptr;
+  unsigned int* d_tie_counters = nullptr;        // [4] TieDev::counters
+  double tie_build_ms = 0.0;                     // host time of the last table build (tree + upload)
+  int tie_builds = 0;                            // table builds on this context (diagnostics)
   float warm_extra = 0.0625f;     // option "warm_extra_fraction"
   bool pair_records = true;       // option "pair_records": the streaming accumulation gathers a match's point and normal from one 32-byte record (GridDev::pn)
   void* rank_comm = nullptr; int rank_comm_size = 0; double* d_rank_sums = nullptr;      // cilhip_rank_comm_*: this process' rank in an RCCL communicator
@@ -198,6 +203,10 @@ static void drop_src_grid(cilhip_ctx* c) {
   if (c->d_src_rgb_grid) { (void)hipFree(c->d_src_rgb_grid); c->d_src_rgb_grid = nullptr; }
 }
 static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->d2_stale = false; c->pending_matches = false; c->matches_origin = 0; }
+static void drop_tie_tables(cilhip_ctx* c) {      // (they describe ONE target)
+  if (c->d_tie_leaf_slot) { (void)hipFree(c->d_tie_leaf_slot); c->d_tie_leaf_slot = nullptr; }
+  if (c->d_tie_nodes) { (void)hipFree(c->d_tie_nodes); c->d_tie_nodes = nullptr; }
+}
 
 extern "C" {
 
@@ -218,6 +227,7 @@ int cilhip_create(cilhip_ctx** out, int device) {
   if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&c->d_defer_flag, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_defer_flag, 0, sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&c->d_unproven, 128 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_unproven, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&c->d_tie_counters, 4 * sizeof(unsigned int)) != hipSuccess || hipMemset(c->d_tie_counters, 0, 4 * sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc(&c->h_feedback, sizeof(Feedback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_feedback), c->h_feedback, 0) != hipSuccess ||
       hipMalloc(&c->d_trace, RUN_TRACE_CAP * sizeof(uint4)) != hipSuccess || hipMemset(c->d_trace, 0, RUN_TRACE_CAP * sizeof(uint4)) != hipSuccess ||
@@ -273,10 +283,9 @@ void cilhip_destroy(cilhip_ctx* c) {
   free_source(c);
   if (c->has_target) free_grid(c->grid);
   if (c->d_safe2) (void)hipFree(c->d_safe2);
-  if (c->d_tie_entries) (void)hipFree(c->d_tie_entries);
-  if (c->d_tie_count) (void)hipFree(c->d_tie_count);
-  if (c->d_tie_patch) (void)hipFree(c->d_tie_patch);
-  delete c->tie_tree;
+  if (c->d_tie_leaf_slot) (void)hipFree(c->d_tie_leaf_slot);
+  if (c->d_tie_nodes) (void)hipFree(c->d_tie_nodes);
+  if (c->d_tie_counters) (void)hipFree(c->d_tie_counters);
   if (c->d_dst_rgb) (void)hipFree(c->d_dst_rgb);
   if (c->d_dst_rgb_sorted) (void)hipFree(c->d_dst_rgb_sorted);
   if (c->d_state) (void)hipFree(c->d_state);
@@ -332,8 +341,9 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tie_rule")) {
-    if (value != 0.0 && value != 1.0) return fail(c, CILHIP_ERR_INVALID, "tie_rule: 0 (lowest index) or 1 (the reference's kd-tree order)");
-    if ((int)value != c->tie_rule) drop_matches(c);
+    if (value != 0.0 && value != 1.0 && value != 2.0)
+      return fail(c, CILHIP_ERR_INVALID, "tie_rule: 0 (lowest index), 1 (the reference's kd-tree order, tables built up front) or 2 (the same, tables built when a tie is first met)");
+    if (((int)value != 0) != (c->tie_rule != 0)) drop_matches(c);
     c->tie_rule = (int)value;
     return CILHIP_OK;
   }
@@ -510,7 +520,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
   c->warm_banned = false;
-  delete c->tie_tree; c->tie_tree = nullptr; c->tie_xyz.clear();
+  drop_tie_tables(c);
   c->dst_rgb_sorted_ok = false;
   if (c->d_dst_rgb) { (void)hipFree(c->d_dst_rgb); c->d_dst_rgb = nullptr; }      // (colours belong to the target they were set for)
   if (c->d_dst_rgb_sorted) { (void)hipFree(c->d_dst_rgb_sorted); c->d_dst_rgb_sorted = nullptr; }
@@ -766,7 +776,7 @@ static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params*
 // a feature adaptor is in force (6-D point+normal or point+colour, 9-D point+normal+colour): correspondences are compared by feature distance
 static bool feat6(const cilhip_ctx* c) { return c->normal_weight > 0.0f || (c->feature_kind == 2 && c->color_weight > 0.0f); }
 static bool warm_capable(const cilhip_ctx* c) {
-  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused && !c->tie_rule;
+  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused;
 }
 // k_self_nn's nearest-other-point table (4 B per target point, 0.5 ms at 10M): built by the first warm-capable run on a target
 static int ensure_safe2(cilhip_ctx* c) {
@@ -776,71 +786,97 @@ static int ensure_safe2(cilhip_ctx* c) {
   return CILHIP_OK;
 }
 static bool tile_accumulation(const cilhip_ctx* c) {
-  return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused && !c->tie_rule;
+  return c->tile_acc && use_tiled(c) && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused;
 }
 
-// Option "tie_rule" = 1: re-point the stored matches (nn_pos, found under the transform in d_state) of the queries that have
-// several target points at exactly the smallest distance to the one the reference's kd-tree traversal meets first
-// (tie_order.hpp).  The device lists those queries with their candidates, the host walks the tree for each, a small kernel
-// patches the matches: one host round trip per search -- the price of the option, paid only by callers that ask for it.
-static int resolve_ties(cilhip_ctx* c) {
-  c->tie_resolved = c->tie_changed = 0;
-  if (!c->ns || !c->grid.n) return CILHIP_OK;
-  if (!c->tie_tree) {
-    std::vector<float4> sorted(c->grid.n);
-    CK(c, hipMemcpyAsync(sorted.data(), c->grid.pts, (size_t)c->grid.n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    CK(c, hipStreamSynchronize(c->stream));
-    c->tie_xyz.assign((size_t)c->grid.n * 3, 0.0f);
-    for (uint32_t j = 0; j < c->grid.n; ++j) {
-      uint32_t o; memcpy(&o, &sorted[j].w, 4);
-      if (o >= c->grid.n) return fail(c, CILHIP_ERR_INVALID, "tie_rule: target index out of range");
-      c->tie_xyz[3 * (size_t)o] = sorted[j].x; c->tie_xyz[3 * (size_t)o + 1] = sorted[j].y; c->tie_xyz[3 * (size_t)o + 2] = sorted[j].z;
-    }
-    c->tie_tree = new (std::nothrow) cilhip::TieOrderTree();
-    if (!c->tie_tree) return fail(c, CILHIP_ERR_HIP, "tie_rule: out of host memory");
-    c->tie_tree->build(c->tie_xyz.data(), c->grid.n);
+// ---- option "tie_rule": the reference's order among exactly equidistant nearest points ------------------------------------------
+// Is the option in force for this context's searches?  The order is the reference's kd-tree over the TARGET POINTS: it covers the
+// SECOND_TO_FIRST matches (also the forward half of BOTH) under rigid and affine transforms.  Feature adaptors search another
+// space (nanoflann's DIM = 6 / 9 tree), the reverse matches of FIRST_TO_SECOND / BOTH a tree over the transformed SOURCE that the
+// reference rebuilds every iteration, and an index shard of a target knows only its own points: those keep the lowest index
+// (tie_rule 2) or are refused (tie_rule 1, the explicit request).
+static bool tie_mode_on(const cilhip_ctx* c) { return c->tie_rule != 0 && !feat6(c) && c->index_offset == 0; }
+static TieDev tie_dev_of(const cilhip_ctx* c) {
+  TieDev t{};
+  t.mode = tie_mode_on(c) ? 1 : 0;
+  t.leaf_slot = t.mode ? c->d_tie_leaf_slot : nullptr;
+  t.nodes = c->d_tie_nodes;
+  t.counters = c->d_tie_counters;
+  return t;
+}
+// Order tables by this target's ORIGINAL (local) index -> device, by sorted position.
+static int load_tie_tables(cilhip_ctx* c, const uint32_t* leaf_by_index, const uint32_t* slot_by_index, const cilhip::TieNode* nodes, size_t n_nodes) {
+  static_assert(sizeof(cilhip::TieNode) == sizeof(uint4), "TieNode is read as one 16-byte record");
+  CK(c, hipSetDevice(c->device));
+  drop_tie_tables(c);
+  const size_t n = c->grid.n;
+  uint32_t *d_leaf = nullptr, *d_slot = nullptr;
+  CK(c, hipMalloc(&c->d_tie_leaf_slot, (n ? n : 1) * sizeof(uint2)));
+  CK(c, hipMalloc(&c->d_tie_nodes, (n_nodes ? n_nodes : 1) * sizeof(uint4)));
+  CK(c, hipMalloc(&d_leaf, (n ? n : 1) * sizeof(uint32_t)));
+  CK(c, hipMalloc(&d_slot, (n ? n : 1) * sizeof(uint32_t)));
+  hipError_t e = hipSuccess;
+  if (n) {
+    e = hipMemcpyAsync(d_leaf, leaf_by_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_slot, slot_by_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n_nodes) e = hipMemcpyAsync(c->d_tie_nodes, nodes, n_nodes * sizeof(uint4), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { launch_tie_tables_by_position(c->grid.pts, c->grid.n, d_leaf, d_slot, c->d_tie_leaf_slot, c->stream); e = hipGetLastError(); }
   }
-  if (!c->d_tie_count) CK(c, hipMalloc(&c->d_tie_count, sizeof(unsigned int)));
-  if (!c->tie_cap) {
-    c->tie_cap = c->ns / 16u > 65536u ? c->ns / 16u : 65536u;
-    CK(c, hipMalloc(&c->d_tie_entries, (size_t)c->tie_cap * sizeof(TieEntry)));
-  }
-  unsigned int cnt = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    launch_tie_candidates(c->grid, c->d_src_sorted, c->ns, c->d_state, c->d_nn_pos, c->d_tie_entries, c->tie_cap, c->d_tie_count, c->stream);
-    CK(c, hipMemcpyAsync(&cnt, c->d_tie_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
-    CK(c, hipStreamSynchronize(c->stream));
-    if (cnt <= c->tie_cap) break;
-    (void)hipFree(c->d_tie_entries); c->d_tie_entries = nullptr; c->tie_cap = 0;      // (more tied queries than the list holds: once more with room for all)
-    CK(c, hipMalloc(&c->d_tie_entries, (size_t)cnt * sizeof(TieEntry)));
-    c->tie_cap = cnt;
-  }
-  c->tie_resolved = cnt;
-  if (!cnt) return CILHIP_OK;
-  std::vector<TieEntry> ent(cnt);
-  CK(c, hipMemcpy(ent.data(), c->d_tie_entries, (size_t)cnt * sizeof(TieEntry), hipMemcpyDeviceToHost));
-  std::vector<uint2> patch;
-  for (const TieEntry& e : ent) {
-    if (e.n > (uint32_t)TIE_MAXC) return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule: a query has more than 8 target points at exactly its nearest distance");
-    const float q[3] = {e.qx, e.qy, e.qz};
-    uint32_t lowest = 0;
-    for (uint32_t k = 1; k < e.n; ++k) if (e.orig[k] < e.orig[lowest]) lowest = k;     // what the search stored
-    const uint32_t w = c->tie_tree->first_met(q, e.orig, (int)e.n);
-    if (w != e.orig[lowest])
-      for (uint32_t k = 0; k < e.n; ++k) if (e.orig[k] == w) { patch.push_back(make_uint2(e.i, e.pos[k])); break; }
-  }
-  c->tie_changed = patch.size();
-  if (patch.empty()) return CILHIP_OK;
-  if (patch.size() > c->tie_patch_cap) {
-    if (c->d_tie_patch) (void)hipFree(c->d_tie_patch);
-    c->d_tie_patch = nullptr; c->tie_patch_cap = 0;
-    CK(c, hipMalloc(&c->d_tie_patch, patch.size() * sizeof(uint2)));
-    c->tie_patch_cap = (uint32_t)patch.size();
-  }
-  CK(c, hipMemcpyAsync(c->d_tie_patch, patch.data(), patch.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-  launch_patch_matches(c->d_tie_patch, (uint32_t)patch.size(), c->d_nn_pos, c->stream);
-  CK(c, hipStreamSynchronize(c->stream));      // (patch lives on this frame)
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (the host arrays and the two staging buffers live on this frame)
+  (void)hipFree(d_leaf); (void)hipFree(d_slot);
+  if (e != hipSuccess) { drop_tie_tables(c); c->err = std::string("tie_rule: loading the order tables: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   return CILHIP_OK;
+}
+// The tables of THIS context's target, built from the device's copy of it (the context keeps no host copy of a cloud).
+static int build_tie_tables(cilhip_ctx* c) {
+  if (c->d_tie_leaf_slot || !c->has_target) return CILHIP_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  CK(c, hipSetDevice(c->device));
+  const uint32_t n = c->grid.n;
+  std::vector<float4> sorted(n ? n : 1);
+  if (n) CK(c, hipMemcpyAsync(sorted.data(), c->grid.pts, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  std::vector<float> xyz((size_t)n * 3, 0.0f);
+  for (uint32_t j = 0; j < n; ++j) {
+    uint32_t o; memcpy(&o, &sorted[j].w, 4);
+    if (o >= n) return fail(c, CILHIP_ERR_INVALID, "tie_rule: target index out of range");
+    xyz[3 * (size_t)o] = sorted[j].x; xyz[3 * (size_t)o + 1] = sorted[j].y; xyz[3 * (size_t)o + 2] = sorted[j].z;
+  }
+  { std::vector<float4>().swap(sorted); }
+  cilhip::TieOrderTree tree;
+  tree.build(xyz.data(), n);
+  const int rc = load_tie_tables(c, tree.leaf_of().data(), tree.slot_of().data(), tree.nodes().data(), tree.nodes().size());
+  if (rc) return rc;
+  c->tie_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ++c->tie_builds;
+  return CILHIP_OK;
+}
+// the counters of the searches since the last launch_init_state (a host round trip)
+static int read_tie_counters(cilhip_ctx* c, unsigned int out[4]) {
+  CK(c, hipMemcpyAsync(out, c->d_tie_counters, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+  CK(c, hipStreamSynchronize(c->stream));
+  return CILHIP_OK;
+}
+// tie_rule 1: the tables before the first search; refusals of the explicit request (see tie_mode_on)
+static int tie_prepare(cilhip_ctx* c, const char* what) {
+  if (c->tie_rule == 1 && (c->search_dir != 0 || feat6(c) || c->index_offset)) {
+    c->err = std::string(what) + ": tie_rule = 1 covers SECOND_TO_FIRST searches over point features on one whole target (tie_rule = 2 applies the reference's order where it is defined)";
+    return CILHIP_ERR_UNSUPPORTED;
+  }
+  if (c->tie_rule == 1 && tie_mode_on(c) && c->ns && c->grid.n) return build_tie_tables(c);
+  return CILHIP_OK;
+}
+// After a search / run: did it meet ties without tables (tie_rule 2)?  Then the tables are built and *again says: run it once more.
+static int tie_check_pending(cilhip_ctx* c, bool* again) {
+  *again = false;
+  if (!tie_mode_on(c) || c->d_tie_leaf_slot || !c->ns || !c->grid.n) return CILHIP_OK;
+  unsigned int cnt[4];
+  const int rc = read_tie_counters(c, cnt);
+  if (rc) return rc;
+  if (cnt[0] == 0u) return CILHIP_OK;
+  *again = true;
+  CK(c, hipMemsetAsync(c->d_tie_counters, 0, 4 * sizeof(unsigned int), c->stream));      // (the repeated search counts afresh)
+  return build_tie_tables(c);
 }
 
 // filterCorrespondencesFraction then filterCorrespondencesOneToOne on the stored matches
@@ -908,6 +944,8 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.store_matches = 1;
   a.tile_pipeline = c->tile_pipeline;
   a.skip_if_inner_done = 0;
+  a.tie = tie_dev_of(c);
+  if (a.tie.mode) a.tile_pipeline = 0;      // (the pipelined experiment kernels do not look at ties)
   return a;
 }
 
@@ -991,19 +1029,25 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   CK(c, hipSetDevice(c->device));
   int rc = ensure_sorted(c, T);
   if (rc) return rc;
-  launch_init_state(c->d_state, T, c->src_mean, c->stream);
+  rc = tie_prepare(c, "find_correspondences");
+  if (rc) return rc;
+  launch_init_state(c->d_state, T, c->src_mean, c->stream, nullptr, 0, nullptr, nullptr, c->d_tie_counters);
   if (feat6(c)) {
     rc = ensure_feature_arrays(c);
     if (rc) return rc;
     linear_inverse_transpose_f32(T, c->feat_M);
   }
   IterArgs a = make_iter_args(c, max_sq);
-  if (c->tie_rule && (c->search_dir != 0 || feat6(c) || c->index_offset))
-    return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule = 1 covers SECOND_TO_FIRST searches over points on one whole target");
   if (c->search_dir != 0) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
     rc = run_pair_search(c, a, max_sq, T);
     if (rc) return rc;
+    if (c->search_dir == 2) {      // (the forward half of BOTH met ties without tables: once more with them)
+      bool again = false;
+      rc = tie_check_pending(c, &again);
+      if (rc) return rc;
+      if (again) { a = make_iter_args(c, max_sq); rc = run_pair_search(c, a, max_sq, T); if (rc) return rc; }
+    }
     memcpy(c->nn_T, T, sizeof(c->nn_T));
     drop_matches(c);
     c->have_pairs = true;
@@ -1015,7 +1059,10 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
   if (c->ns) {
     rc = launch_search(c, a);
     if (rc) return rc;
-    if (c->tie_rule) { rc = resolve_ties(c); if (rc) return rc; }
+    bool again = false;      // (tie_rule 2: the search met ties and there were no order tables yet -- they exist now: once more)
+    rc = tie_check_pending(c, &again);
+    if (rc) return rc;
+    if (again) { a = make_iter_args(c, max_sq); rc = launch_search(c, a); if (rc) return rc; }
   }
   CK(c, hipGetLastError());
   rc = apply_filters(c);
@@ -1105,10 +1152,53 @@ int cilhip_get_tie_count(cilhip_ctx* c, const float T[16], float max_sq, size_t*
   return CILHIP_OK;
 }
 
+struct cilhip_tie_order { cilhip::TieOrderTree tree; };
+int cilhip_tie_order_create(const float* xyz, size_t n, cilhip_tie_order** out) {
+  if (!out || (n && !xyz) || n >= 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
+  cilhip_tie_order* o = new (std::nothrow) cilhip_tie_order();
+  if (!o) return CILHIP_ERR_HIP;
+  o->tree.build(xyz, (uint32_t)n);
+  *out = o;
+  return CILHIP_OK;
+}
+void cilhip_tie_order_destroy(cilhip_tie_order* order) { delete order; }
+int cilhip_load_tie_order(cilhip_ctx* c, const cilhip_tie_order* order, const uint32_t* global_index) {
+  if (!c || !order) return CILHIP_ERR_INVALID;
+  if (!c->has_target) return fail(c, CILHIP_ERR_INVALID, "load_tie_order: set_target first");
+  const uint32_t n = c->grid.n, N = order->tree.size();
+  if (n == 0) return load_tie_tables(c, nullptr, nullptr, order->tree.nodes().data(), order->tree.nodes().size());      // (a shard without target points)
+  if (!global_index) {
+    if (n != N) return fail(c, CILHIP_ERR_INVALID, "load_tie_order: the order was built for a cloud of another size (pass global_index for a part of it)");
+    return load_tie_tables(c, order->tree.leaf_of().data(), order->tree.slot_of().data(), order->tree.nodes().data(), order->tree.nodes().size());
+  }
+  std::vector<uint32_t> leaf(n ? n : 1), slot(n ? n : 1);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (global_index[i] >= N) return fail(c, CILHIP_ERR_INVALID, "load_tie_order: global index out of range");
+    leaf[i] = order->tree.leaf_of()[global_index[i]]; slot[i] = order->tree.slot_of()[global_index[i]];
+  }
+  return load_tie_tables(c, leaf.data(), slot.data(), order->tree.nodes().data(), order->tree.nodes().size());
+}
+int cilhip_build_tie_order(cilhip_ctx* c) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (!c->has_target) return fail(c, CILHIP_ERR_INVALID, "build_tie_order: set_target first");
+  return build_tie_tables(c);
+}
+int cilhip_get_tie_order_info(cilhip_ctx* c, cilhip_tie_order_info* out) {
+  if (!c || !out) return CILHIP_ERR_INVALID;
+  CK(c, hipSetDevice(c->device));
+  unsigned int cnt[4];
+  { const int rc = read_tie_counters(c, cnt); if (rc) return rc; }
+  out->loaded = c->d_tie_leaf_slot ? 1 : 0; out->builds = c->tie_builds; out->build_ms = c->tie_build_ms; out->pending = cnt[0];
+  return CILHIP_OK;
+}
+
 int cilhip_get_tie_rule_stats(cilhip_ctx* c, size_t* tied_queries, size_t* repointed) {
   if (!c) return CILHIP_ERR_INVALID;
-  if (tied_queries) *tied_queries = (size_t)c->tie_resolved;
-  if (repointed) *repointed = (size_t)c->tie_changed;
+  CK(c, hipSetDevice(c->device));
+  unsigned int cnt[4];
+  { const int rc = read_tie_counters(c, cnt); if (rc) return rc; }
+  if (tied_queries) *tied_queries = (size_t)cnt[1] + (size_t)cnt[0];
+  if (repointed) *repointed = (size_t)cnt[2];
   return CILHIP_OK;
 }
 
@@ -1651,12 +1741,23 @@ static void finish_run_matches(cilhip_ctx* c, const cilhip_icp_params* p, size_t
   }
 }
 
+static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, cilhip_icp_result* out);
 int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, cilhip_icp_result* out) {
   if (!c || !p || !out) return CILHIP_ERR_INVALID;
   if (p->metric != CILHIP_METRIC_POINT_TO_POINT && p->metric != CILHIP_METRIC_COMBINED) return fail(c, CILHIP_ERR_INVALID, "icp_run: bad metric");
   CK(c, hipSetDevice(c->device));
-  if (c->tie_rule && (c->search_dir != 0 || feat6(c) || c->index_offset || c->transform_mode == 1))
-    return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule = 1 covers the rigid SECOND_TO_FIRST loop over points on one whole target");
+  int rc = tie_prepare(c, "icp_run");
+  if (rc) return rc;
+  rc = icp_run_once(c, p, T0, out);
+  if (rc) return rc;
+  // tie_rule 2: some search of the run met exactly equidistant nearest points and the reference's order tables were not there: they
+  // are now (built once per target) -- the run is executed again, from T0, with the ties resolved inside its kernels
+  bool again = false;
+  rc = tie_check_pending(c, &again);
+  if (rc) return rc;
+  return again ? icp_run_once(c, p, T0, out) : CILHIP_OK;
+}
+static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, cilhip_icp_result* out) {
   if (c->transform_mode == 1) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "the affine variants are not available on target shards");
     return icp_run_affine(c, p, T0, out);
@@ -1671,7 +1772,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   const bool zero_steps = gn && p->max_opt_iter == 0;
   const size_t opt_steps = gn ? (p->max_opt_iter ? p->max_opt_iter : 1) : 1;
   ++c->run_tag;
-  launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half);
+  launch_init_state(c->d_state, Ti, c->src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half, c->d_tie_counters);
   if (gn && c->ns >= 65536) ensure_pair_records(c);
   IterArgs a = make_iter_args(c, p->max_sq_dist);
   if (!c->pair_records) a.grid.pn = nullptr;
@@ -1831,14 +1932,7 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   bool warm_on = false;       // the loop has been seen to move little: iterations run warm-started until one of them has to search too many of its queries
   unsigned int judged = 0;    // the last published iteration whose listed count has been judged
   bool all_stored = true;     // every iteration enqueued left its matches in nn_pos (finish_run_matches)
-  unsigned long long tie_seen = 0, tie_moved = 0;
   for (size_t it = 0; it < p->max_iter; ++it) {
-    if (c->tie_rule && it >= 1) {      // (the device is idle after each iteration's tie resolution anyway: stop at convergence)
-      int done = 0;
-      CK(c, hipMemcpyAsync(&done, reinterpret_cast<const char*>(c->d_state) + offsetof(IcpState, done), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      CK(c, hipStreamSynchronize(c->stream));
-      if (done) break;
-    }
     if (paced && it == 1 && wcap && c->warm_start == 1 && !c->warm_banned && !c->trace_form.empty() && (c->trace_form[0] & 0x80)) {
       // The SECOND iteration can already run warm-started when the first one moved the source by a small fraction of a cell (a
       // source that starts aligned: tracking, a refinement pass) and its kernels' own forecast agrees: worth one look at the
@@ -1904,12 +1998,12 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
     for (size_t st = 0; st < opt_steps; ++st) {
       a.skip_if_inner_done = (st > 0);
       // (the one-kernel forms are timed through their own dispatch packets: no event packets between dependent kernels)
-      const bool lane_fused = c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule;
+      const bool lane_fused = c->fused && !filters_active(c) && !feat6(c);
       const bool ext_ev = timing_it && st == 0 && c->ns && !lane_fused && (warm || one_pass);
       if (timing_it && st == 0 && !ext_ev) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
       if (ext_ev) { hipEvent_t e0 = get_event(c, nev), e1 = get_event(c, nev + 1); set_launch_events(e0, e1); nev += 2; }
       if (c->ns) {
-        if (st == 0 && c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) {
+        if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
           all_stored = all_stored && gn && opt_steps > 1;
         } else if (st == 0 && warm) {
@@ -1948,11 +2042,6 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
           c->lb_fresh = keys;
           counted = keys;
           { const int src_rc = launch_search(c, sa2); if (src_rc) return src_rc; }
-          if (c->tie_rule) {      // (a host round trip per iteration: the option's price)
-            const int trc = resolve_ties(c);
-            if (trc) return trc;
-            tie_seen += c->tie_resolved; tie_moved += c->tie_changed;
-          }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing_it) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
@@ -1964,14 +2053,14 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
         // (two events per iteration around the search / one-pass kernels; a two-pass iteration adds a pair around its
         //  streaming accumulation, kept in a list of its own)
         if (ext_ev) {}
-        else if (single || (c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
+        else if (single || (c->fused && !filters_active(c) && !feat6(c)) || !c->ns) CK(c, hipEventRecord(get_event(c, nev++), c->stream));
         else CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream));
         ++launches; c->timed_iter.push_back((unsigned int)it);
       }
       if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
       if (st == 0) {
         const unsigned char form = (unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
-                                                   : (c->fused && !filters_active(c) && !feat6(c) && !c->tie_rule) ? FORM_LANE_FUSED : FORM_SEARCH);
+                                                   : (c->fused && !filters_active(c) && !feat6(c)) ? FORM_LANE_FUSED : FORM_SEARCH);
         if (timing_it) c->iter_form.push_back(form);
         c->trace_form.push_back((unsigned char)(form | (counted ? 0x80 : 0)));
       }
@@ -1996,7 +2085,6 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   }
   CK(c, hipEventRecord(e_end, c->stream));
   CK(c, hipGetLastError());
-  if (c->tie_rule) { c->tie_resolved = tie_seen; c->tie_changed = tie_moved; }
   float Tprev[16];
   rc = read_state(c, out, Tprev);
   if (rc) return rc;
@@ -2036,7 +2124,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   CK(c, hipSetDevice(c->device));
   if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
   if (filters_active(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "inlier_fraction / one_to_one are global filters: not available in sharded runs");
-  if (c->tie_rule) return fail(c, CILHIP_ERR_UNSUPPORTED, "tie_rule = 1 is not available in sharded runs");
+  { const int trc = tie_prepare(c, "icp_begin"); if (trc) return trc; }
   if (c->search_dir != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available in sharded runs");
   if (feat6(c) || c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features and the affine variants are not available in sharded runs");
   const float* Ti = T0 ? T0 : kIdentity;
@@ -2045,7 +2133,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   c->run_prm = *p;
   for (int i = 0; i < 3; ++i) c->run_src_mean[i] = gmean ? gmean[i] : c->src_mean[i];
   ++c->run_tag;
-  launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half);     // (the epilogue publishes the loop state: see cilhip_icp_partial_sums)
+  launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half, c->d_tie_counters);     // (the epilogue publishes the loop state: see cilhip_icp_partial_sums)
   CK(c, hipGetLastError());
   c->run_active = true;
   c->run_nev = 0;
@@ -2314,12 +2402,20 @@ int cilhip_compute_residuals(cilhip_ctx* c, int metric, float w_p2p, float w_p2p
   if (metric != 0 && !c->has_normals) return fail(c, CILHIP_ERR_INVALID, "compute_residuals: combined metric needs target normals");
   int rc = ensure_sorted(c, T);
   if (rc) return rc;
-  launch_init_state(c->d_state, T, c->src_mean, c->stream);
+  rc = (c->tie_rule == 1 && tie_mode_on(c) && c->ns && c->grid.n) ? build_tie_tables(c) : CILHIP_OK;
+  if (rc) return rc;
+  launch_init_state(c->d_state, T, c->src_mean, c->stream, nullptr, 0, nullptr, nullptr, c->d_tie_counters);
   IterArgs a = make_iter_args(c, 3.402823466e+38f);
   float* d_out = out;
   if (mem != CILHIP_MEM_DEVICE) CK(c, hipMalloc(&d_out, (c->ns ? c->ns : 1) * sizeof(float)));
   launch_residuals(a, metric, w_p2p, w_p2pl, d_out, c->stream);
   CK(c, hipGetLastError());
+  if (metric != 0) {      // (the point-to-plane term reads the matched point's normal: which of two equidistant points matters)
+    bool again = false;
+    rc = tie_check_pending(c, &again);
+    if (rc) { if (mem != CILHIP_MEM_DEVICE) (void)hipFree(d_out); return rc; }
+    if (again) { a = make_iter_args(c, 3.402823466e+38f); launch_residuals(a, metric, w_p2p, w_p2pl, d_out, c->stream); CK(c, hipGetLastError()); }
+  }
   if (mem != CILHIP_MEM_DEVICE) {
     if (c->ns) CK(c, hipMemcpyAsync(out, d_out, (size_t)c->ns * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));
@@ -2393,10 +2489,9 @@ constexpr int RCCL_DOUBLE = 8, RCCL_SUM = 0;      // ncclDouble / ncclSum of rcc
 // out[r][k] = sum over shards of in[s][k], the same order on every shard (all buffers on one device)
 __global__ void k_sum_shards(double* const* bufs, int n) {
   const int k = threadIdx.x;
-  if (k >= SUMS_MAX) return;
+  if (k >= SUMS_MAX) return;      // (every k is independent: no barrier)
   double v = 0.0;
   for (int s = 0; s < n; ++s) v += bufs[s][k];
-  __syncthreads();
   for (int s = 0; s < n; ++s) bufs[s][k] = v;
 }
 }  // namespace
@@ -2426,9 +2521,16 @@ struct cilhip_multi {
   int repartitions = 0;
   double slack_opt = -1.0;         // cilhip_multi_set_slab_slack (< 0: twice the search radius)
   std::vector<size_t> n_dst_local, n_src_local;
+  // option "tie_rule" of the shards: the order among exactly equidistant nearest points is a property of the WHOLE target (the tree
+  // the reference builds over it): built once from the host copy when some shard's search first meets a tie, every shard is handed
+  // the entries of its own points (slabs: through the global index of each local point)
+  cilhip_tie_order* order = nullptr;
+  std::vector<std::vector<uint32_t>> gidx;      // slabs: per shard, global index of its target point i
+  bool tie_pending = false;                     // some shard's counters showed ties met without tables before they were reset (a re-partition inside a run)
 };
 
 static int mfail(cilhip_multi* m, int code, const std::string& msg) { if (m) m->err = msg; return code; }
+static int multi_upload_fwd(cilhip_multi* m);
 #define MCK(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mfail((m), CILHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 #define MCTX(m, r, call) do { const int rc_ = (call); if (rc_ != CILHIP_OK) return mfail((m), rc_, std::string(#call) + ": " + cilhip_last_error((m)->ctx[r])); } while (0)
 
@@ -2481,13 +2583,23 @@ void cilhip_multi_destroy(cilhip_multi* m) {
   }
   if (m->d_bufs) (void)hipFree(m->d_bufs);
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+  cilhip_tie_order_destroy(m->order);
   delete m;
 }
 
 const char* cilhip_multi_last_error(const cilhip_multi* m) { return m ? m->err.c_str() : "null handle"; }
 cilhip_ctx* cilhip_multi_context(cilhip_multi* m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[rank] : nullptr; }
 int cilhip_multi_repartitions(const cilhip_multi* m) { return m ? m->repartitions : 0; }
-int cilhip_multi_set_slab_slack(cilhip_multi* m, float slack) { if (!m) return CILHIP_ERR_INVALID; m->slack_opt = slack; return CILHIP_OK; }
+int cilhip_multi_set_slab_slack(cilhip_multi* m, float slack) {
+  if (!m) return CILHIP_ERR_INVALID;
+  m->slack_opt = slack;
+  // (halos are sized when the clouds are cut: with clouds already set the slabs are cut again now)
+  if (m->partition == 1 && (m->nd || m->ns)) {
+    const double r = std::isfinite(m->max_sq) ? std::sqrt((double)m->max_sq) : 0.0;
+    if (slack >= 0.0f && std::isfinite(m->max_sq)) { m->slack = slack; m->halo = r + m->slack; return multi_upload_fwd(m); }
+  }
+  return CILHIP_OK;
+}
 int cilhip_multi_shard_sizes(const cilhip_multi* m, int rank, size_t* n_target, size_t* n_source) {
   if (!m || rank < 0 || rank >= m->n) return CILHIP_ERR_INVALID;
   if (n_target) *n_target = m->n_dst_local[rank];
@@ -2505,6 +2617,8 @@ static void global_mean(const std::vector<float>& xyz, size_t n, float out[3]) {
 }
 
 // uploads every shard's clouds under the current partition (slabs: cut under T_part)
+static int multi_upload(cilhip_multi* m);
+static int multi_upload_fwd(cilhip_multi* m) { return multi_upload(m); }
 static int multi_upload(cilhip_multi* m) {
   const int n = m->n;
   if (m->partition == 0) {
@@ -2512,6 +2626,7 @@ static int multi_upload(cilhip_multi* m) {
       const size_t base = m->ns / n, rem = m->ns % n;
       const size_t lo = r * base + std::min<size_t>(r, rem), hi = lo + base + ((size_t)r < rem ? 1 : 0);
       MCTX(m, r, cilhip_set_target(m->ctx[r], m->dst.data(), m->dstn.empty() ? nullptr : m->dstn.data(), m->nd, CILHIP_MEM_HOST));
+      if (m->order) MCTX(m, r, cilhip_load_tie_order(m->ctx[r], m->order, nullptr));
       MCTX(m, r, cilhip_set_source(m->ctx[r], m->src.data() + 3 * lo, hi - lo, CILHIP_MEM_HOST));
       MCTX(m, r, cilhip_set_slab_guard(m->ctx[r], -1, 0.0f, nullptr, nullptr, nullptr));
       m->n_dst_local[r] = m->nd; m->n_src_local[r] = hi - lo;
@@ -2536,19 +2651,26 @@ static int multi_upload(cilhip_multi* m) {
     }
   }
   std::vector<float> d, dn, s;
+  m->gidx.assign(n, std::vector<uint32_t>());
+  // (whether the cloud HAS normals is a property of the whole cloud: a shard whose slab + halo holds no target point must still
+  //  take the point-to-plane branch of the epilogue like every other shard -- the all-reduced sums are the same everywhere)
+  static const float no_points[3] = {0.0f, 0.0f, 0.0f};
   for (int r = 0; r < n; ++r) {
     const double b0 = m->bounds[r], b1 = m->bounds[r + 1];
     d.clear(); dn.clear(); s.clear();
+    std::vector<uint32_t>& gi = m->gidx[r];
     for (size_t i = 0; i < m->nd; ++i) {
       const double x = (double)m->dst[3 * i + ax];
       if (x >= b0 - m->halo && x < b1 + m->halo) {
         d.insert(d.end(), m->dst.begin() + 3 * i, m->dst.begin() + 3 * i + 3);
         if (!m->dstn.empty()) dn.insert(dn.end(), m->dstn.begin() + 3 * i, m->dstn.begin() + 3 * i + 3);
+        gi.push_back((uint32_t)i);
       }
     }
     for (size_t i = 0; i < m->ns; ++i)
       if (q[i] >= b0 && q[i] < b1) s.insert(s.end(), m->src.begin() + 3 * i, m->src.begin() + 3 * i + 3);
-    MCTX(m, r, cilhip_set_target(m->ctx[r], d.data(), m->dstn.empty() ? nullptr : dn.data(), d.size() / 3, CILHIP_MEM_HOST));
+    MCTX(m, r, cilhip_set_target(m->ctx[r], d.empty() ? no_points : d.data(), m->dstn.empty() ? nullptr : (dn.empty() ? no_points : dn.data()), d.size() / 3, CILHIP_MEM_HOST));
+    if (m->order) MCTX(m, r, cilhip_load_tie_order(m->ctx[r], m->order, gi.empty() ? nullptr : gi.data()));
     MCTX(m, r, cilhip_set_source(m->ctx[r], s.data(), s.size() / 3, CILHIP_MEM_HOST));
     MCTX(m, r, cilhip_set_shard_info(m->ctx[r], 0, m->gdm, nullptr));
     MCTX(m, r, cilhip_set_slab_guard(m->ctx[r], ax, (float)m->slack, m->src_center, m->src_half, m->T_part));
@@ -2583,6 +2705,7 @@ int cilhip_multi_set_clouds(cilhip_multi* m, const float* dst_xyz, const float* 
     for (int c = 0; c < 3; ++c) { m->src_center[c] = 0.5f * (slo[c] + shi[c]); m->src_half[c] = std::max(shi[c] - m->src_center[c], m->src_center[c] - slo[c]) * 1.000001f; }
   }
   m->repartitions = 0;
+  cilhip_tie_order_destroy(m->order); m->order = nullptr; m->tie_pending = false;      // (belongs to the previous target)
   return multi_upload(m);
 }
 
@@ -2611,8 +2734,34 @@ extern "C" {
 
 // IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) across the handle's devices.  check_every: how often the
 // loop state is read back (convergence; the slab guard) -- 0: the default 5.
+static int multi_icp_run_once(cilhip_multi* m, const cilhip_icp_params* p, const float* T0, int check_every, cilhip_icp_result* out);
+// ties met by some shard's searches while no order tables were loaded (option "tie_rule" 2)?
+static int multi_ties_pending(cilhip_multi* m, bool* pending) {
+  *pending = m->tie_pending;
+  for (int r = 0; r < m->n && !*pending; ++r) {
+    cilhip_tie_order_info ti{};
+    MCTX(m, r, cilhip_get_tie_order_info(m->ctx[r], &ti));
+    if (!ti.loaded && ti.pending != 0) *pending = true;
+  }
+  return CILHIP_OK;
+}
 int cilhip_multi_icp_run(cilhip_multi* m, const cilhip_icp_params* p, const float* T0, int check_every, cilhip_icp_result* out) {
   if (!m || !p || !out) return CILHIP_ERR_INVALID;
+  m->tie_pending = false;
+  int rc = multi_icp_run_once(m, p, T0, check_every, out);
+  if (rc || m->order) return rc;
+  bool pending = false;
+  rc = multi_ties_pending(m, &pending);
+  if (rc || !pending) return rc;
+  // the reference's order over the WHOLE target, once; every shard gets the entries of its points; the run is executed again from T0
+  rc = cilhip_tie_order_create(m->dst.data(), m->nd, &m->order);
+  if (rc) return mfail(m, rc, "tie_rule: building the order tables of the whole target failed");
+  for (int r = 0; r < m->n; ++r)
+    MCTX(m, r, cilhip_load_tie_order(m->ctx[r], m->order, (m->partition == 1 && !m->gidx[r].empty()) ? m->gidx[r].data() : nullptr));
+  m->tie_pending = false;
+  return multi_icp_run_once(m, p, T0, check_every, out);
+}
+static int multi_icp_run_once(cilhip_multi* m, const cilhip_icp_params* p, const float* T0, int check_every, cilhip_icp_result* out) {
   const int every0 = check_every > 0 ? check_every : 5;
   float T_ck[16];
   memcpy(T_ck, T0 ? T0 : kIdentity, sizeof(T_ck));
@@ -2650,6 +2799,7 @@ int cilhip_multi_icp_run(cilhip_multi* m, const cilhip_icp_params* p, const floa
         every = bad ? 1 : every0;
       }
       if (bad) {
+        if (!m->order) { bool pend = false; const int prc = multi_ties_pending(m, &pend); if (prc) return prc; m->tie_pending = pend; }      // (the next begin resets the counters)
         memcpy(m->T_part, T_ck, sizeof(T_ck));
         { const int rc = multi_upload(m); if (rc) return rc; }
         ++m->repartitions;

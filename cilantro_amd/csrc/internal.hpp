@@ -109,6 +109,20 @@ struct CorrWeights {
 
 struct F3 { float x, y, z; };      // 12-byte record (one global_load_dwordx3 per lane)
 
+// Which of several EXACTLY equidistant nearest target points a correspondence names (option "tie_rule"; tie_order.hpp has the
+// why and the host side).  mode 0: the lowest target index -- what the packed keys give by themselves, nothing below is read.
+// mode 1: the point the reference's kd-tree traversal meets first.  Every search notices when the smallest distance was met on a
+// second point (an equality test beside the key compare); such a query is then looked at once more by tie_settle(): with the
+// order tables of the reference's tree loaded, all points at exactly that distance are enumerated (the closed ball of that
+// radius) and the first-met one is taken; without them the query is COUNTED (counters[0]) and keeps the lowest index -- the host
+// builds the tables and runs the search / loop again (tie_rule "auto": a target whose searches never tie never pays for a tree).
+struct TieDev {
+  const uint2* leaf_slot;   // [grid.n] by sorted target position: {leaf node, slot in the reference's permutation}; null: no tables loaded
+  const uint4* nodes;       // TieNode records: {parent, (depth << 3) | (split dimension << 1) | is-second-child, bits(divlow), bits(divhigh)}
+  unsigned int* counters;   // [4]  0: tied queries met without tables, 1: tied queries resolved with them, 2: of those, matches that are not the lowest index
+  int mode;
+};
+
 // Six-dimensional feature search (correspondence_search/common_transformable_feature_adaptors.hpp): features = (point, w * v), v a
 // per-point 3-vector (normal or colour).  mode: how the SOURCE's feature part follows the transform --
 //   0: rigid -- L * (w v)                                                         PointNormalFeaturesAdaptor, Isometry   :104-111
@@ -167,6 +181,7 @@ struct IterArgs {
   // tile kernel writes it straight into its match records (warm_rec[i].w) when warm_rec is set.
   float* nn_lb;
   int lb_valid;                // (record-writing warm kernel) nn_lb holds the keys of the search that left warm_pos
+  TieDev tie;                  // option "tie_rule"
 };
 
 // What k_tile_boxes needs to compute the tiles' regions for the state's transform.
@@ -305,7 +320,7 @@ void launch_reduce_stage1_groups(const double* partials, int nblocks, double* st
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 128 * SUMS_MAX;
 void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb = nullptr, unsigned int run_tag = 0,
-                       const float* src_center = nullptr, const float* src_half = nullptr);
+                       const float* src_center = nullptr, const float* src_half = nullptr, unsigned int* tie_counters = nullptr /*[4], zeroed*/);
 void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,
                        const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,
                        hipStream_t s);
@@ -317,12 +332,8 @@ void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys
 void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s);
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
 // queries (sorted source under T) whose nearest target point within the radius is not unique in the pinned f32 distance
-// option "tie_rule" = 1: the tied queries of the stored matches with their equidistant candidates (sorted positions and original indices)
-constexpr int TIE_MAXC = 8;
-struct TieEntry { uint32_t i; float qx, qy, qz; uint32_t n; uint32_t pos[TIE_MAXC]; uint32_t orig[TIE_MAXC]; };
-void launch_tie_candidates(const GridDev& g, const float4* src_sorted, uint32_t ns, const IcpState* st, const uint32_t* nn_pos, TieEntry* out, uint32_t cap,
-                           unsigned int* counter, hipStream_t s);
-void launch_patch_matches(const uint2* patches, uint32_t n, uint32_t* nn_pos, hipStream_t s);
+// the order tables by ORIGINAL target index -> by sorted position (TieDev::leaf_slot)
+void launch_tie_tables_by_position(const float4* dst_sorted, uint32_t n, const uint32_t* leaf_by_index, const uint32_t* slot_by_index, uint2* leaf_slot, hipStream_t s);
 void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, const float T[16], float max_sq, unsigned long long* out, hipStream_t s);
 // squared distances of the stored matches under T, formed again with the search's pinned arithmetic (bit-identical to what the
 // search compared): the ICP loop does not store them, a caller of getCorrespondences() after estimate() reads them

@@ -112,7 +112,14 @@ struct T16c { float v[16]; };
 struct NN {
   unsigned long long key;  // (bits(d2) << 32) | original target index : strict '<' + lowest-index tie-break
   uint32_t pos;            // position in the sorted target array, NONE_U32 if nothing within the radius
+  uint32_t tie = 0;        // some squared distance that was the smallest so far has been met on a second target point (sticky: may be set
+                           // for a distance that was beaten later -- tie_settle() looks again, exactly --, never missing for the final one)
 };
+// one candidate against the running best (the per-lane searches out of global memory: latency-bound, the two compares are free)
+__device__ __forceinline__ void nn_take(NN& best, unsigned long long k, uint32_t pos) {
+  best.tie |= (uint32_t)(((uint32_t)(k >> 32) == (uint32_t)(best.key >> 32)) & (k != best.key));      // same distance, another point (a clamped re-read has the same key)
+  if (k < best.key) { best.key = k; best.pos = pos; }
+}
 
 // distance from q to the interval [lo,hi], shrunk by the grid margin (never over-estimates)
 __device__ __forceinline__ float axis_gap(float q, float lo, float hi, float margin) {
@@ -135,10 +142,10 @@ __device__ __forceinline__ void scan_range4(const float4* __restrict__ pts, uint
     const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
     const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
     const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
-    if (k0 < best.key) { best.key = k0; best.pos = j; }
-    if (k1 < best.key) { best.key = k1; best.pos = j1; }
-    if (k2 < best.key) { best.key = k2; best.pos = j2; }
-    if (k3 < best.key) { best.key = k3; best.pos = j3; }
+    nn_take(best, k0, j);
+    nn_take(best, k1, j1);
+    nn_take(best, k2, j2);
+    nn_take(best, k3, j3);
   }
 }
 
@@ -457,14 +464,14 @@ __device__ __forceinline__ void nn_search_from(const GridDev& g, float qx, float
       const float e0 = d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z), e1 = d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z);
       const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
       const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
-      if (k0 < best.key) { best.key = k0; best.pos = j; }
-      if (k1 < best.key) { best.key = k1; best.pos = j1; }
+      nn_take(best, k0, j);
+      nn_take(best, k1, j1);
 #if CILHIP_CAND == 4
       const float e2 = d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z), e3 = d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z);
       const unsigned long long k2 = ((unsigned long long)__float_as_uint(e2) << 32) | __float_as_uint(p2.w);
       const unsigned long long k3 = ((unsigned long long)__float_as_uint(e3) << 32) | __float_as_uint(p3.w);
-      if (k2 < best.key) { best.key = k2; best.pos = j2; }
-      if (k3 < best.key) { best.key = k3; best.pos = j3; }
+      nn_take(best, k2, j2);
+      nn_take(best, k3, j3);
 #endif
       j += CILHIP_CAND;
     }
@@ -503,13 +510,14 @@ __device__ __forceinline__ void scan_range4_m2(const float4* __restrict__ pts, u
       const float e = d2_pinned(qx, qy, qz, p[k].x, p[k].y, p[k].z);
       const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p[k].w);
       if (j + (uint32_t)k <= last) m2 = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(best.key >> 32)), m2, e);
-      if (key < best.key) { best.key = key; best.pos = jj[k]; }
+      nn_take(best, key, jj[k]);
     }
   }
 }
 __device__ __forceinline__ void nn_search_lb(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best, uint2* lst, float* lb_out) {
   best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
   best.pos = NONE_U32;
+  best.tie = 0;
   *lb_out = 0.0f;
   const float BIG = 1.0e9f;
   const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
@@ -607,6 +615,7 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
                                           uint2* lst) {
   best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
   best.pos = NONE_U32;
+  best.tie = 0;
   nn_search_from(g, qx, qy, qz, max_sq, best, lst);
 }
 
@@ -622,6 +631,7 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
                                                 const Feat6* f6 = nullptr) {
   best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
   best.pos = NONE_U32;
+  best.tie = 0;
   const float BIG = 1.0e9f;
   const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
   const float fy = fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG);
@@ -661,7 +671,8 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
     for (int off = 1; off < G; off <<= 1) {
       const unsigned long long ok = __shfl_xor(best.key, off, 64);
       const uint32_t op = __shfl_xor(best.pos, off, 64);
-      if (ok < best.key) { best.key = ok; best.pos = op; }
+      best.tie |= __shfl_xor(best.tie, off, 64);      // (what a lane noticed in its rows; and the same distance on two lanes' points:)
+      nn_take(best, ok, op);
     }
     // lower bound on the distance to anything outside the block (and inside the grid)
     float b = INFINITY;
@@ -680,6 +691,83 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
     const float need = sqrtf(bd) * g.inv_cell + 1.0f;
     s = (best.pos == NONE_U32) ? s + max(1, s >> 1) : max(s + 1, (int)fminf(need, (float)(g.nx + g.ny + g.nz)));
   }
+}
+
+// ---- option "tie_rule": the reference's choice among exactly equidistant nearest points (TieDev, internal.hpp) --------------
+// Does the reference's traversal for query q reach the target point at sorted position pa before the one at pb?  Same leaf: the lower
+// slot of the reference's permutation.  Otherwise walk both leaves up to their lowest common ancestor (parents + depths); there
+// nanoflann's searchLevel (nanoflann.hpp:1931-1947) descends first into the child on the query's side of the split:
+// (val - divlow) + (val - divhigh) < 0 -> the first child.  (csrc/tie_order.hpp: before(); pinned against the reference's own
+// nanoflann by tests/test_tie_order_cpu.py.)
+__device__ __forceinline__ bool tie_before(const TieDev& tt, float qx, float qy, float qz, uint32_t pa, uint32_t pb) {
+  const uint2 la = tt.leaf_slot[pa], lb = tt.leaf_slot[pb];
+  if (la.x == lb.x) return la.y < lb.y;
+  uint32_t na = la.x, nb = lb.x;
+  uint4 A = tt.nodes[na], B = tt.nodes[nb];
+  uint32_t a_second = 0;      // is the node on a's path just below the common ancestor a SECOND child
+  while ((A.y >> 3) > (B.y >> 3)) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; }
+  while ((B.y >> 3) > (A.y >> 3)) { nb = B.x; B = tt.nodes[nb]; }
+  while (na != nb) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; nb = B.x; B = tt.nodes[nb]; }
+  const uint32_t feat = (A.y >> 1) & 3u;
+  const float val = feat == 0u ? qx : (feat == 1u ? qy : qz);
+  const float diff1 = __fsub_rn(val, __uint_as_float(A.z)), diff2 = __fsub_rn(val, __uint_as_float(A.w));
+  const uint32_t first_is_second = __fadd_rn(diff1, diff2) < 0.0f ? 0u : 1u;
+  return a_second == first_is_second;
+}
+// A query whose search noticed a tie (NN::tie, or second smallest distance == smallest): pos / bd = its match by the lowest-index rule
+// and that match's squared distance.  Returns the sorted position of the match the option asks for: every target point at EXACTLY
+// bd is enumerated -- the closed ball of that radius, shells of cells around the query's, rows beyond the distance skipped, ends when
+// the next shell lies strictly beyond it (a cell at exactly the distance is looked at) -- and the first-met one kept as they stream by
+// (the traversal order of one query is a total order: pairwise comparisons suffice, any number of candidates).  Without tables the
+// query is counted for the host and keeps its match.
+__device__ __forceinline__ uint32_t tie_settle(const GridDev& g, const TieDev& tt, float qx, float qy, float qz, uint32_t pos, float bd) {
+  if (tt.leaf_slot == nullptr) { atomicAdd(tt.counters, 1u); return pos; }
+  const float BIG = 1.0e9f;
+  const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG)), cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG)),
+            cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
+  uint32_t cur = pos, ncand = 0;
+  for (int s = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));; ++s) {
+    const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1), y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+    for (int z = z0; z <= z1; ++z) {
+      const float zl = g.oz + (float)z * g.cell;
+      const float az = axis_gap(qz, zl, zl + g.cell, g.margin);
+      for (int y = y0; y <= y1; ++y) {
+        const bool face = (z == cz - s) || (z == cz + s) || (y == cy - s) || (y == cy + s);
+        const float yl = g.oy + (float)y * g.cell;
+        const float ay = axis_gap(qy, yl, yl + g.cell, g.margin);
+        if ((az * az + ay * ay) * KSHRINK > bd) continue;
+        const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+        uint32_t rb[2] = {0, 0}, re[2] = {0, 0};
+        if (face) {
+          const int xa = max(cx - s, 0), xb = min(cx + s, g.nx - 1);
+          if (xa <= xb) { rb[0] = g.cell_start[row + xa]; re[0] = g.cell_start[row + xb + 1]; }
+        } else {
+          if (cx - s >= 0 && cx - s < g.nx) { rb[0] = g.cell_start[row + cx - s]; re[0] = g.cell_start[row + cx - s + 1]; }
+          if (s > 0 && cx + s >= 0 && cx + s < g.nx) { rb[1] = g.cell_start[row + cx + s]; re[1] = g.cell_start[row + cx + s + 1]; }
+        }
+        for (int r = 0; r < 2; ++r)
+          for (uint32_t j = rb[r]; j < re[r]; ++j) {
+            const float4 p = g.pts[j];
+            if (d2_pinned(qx, qy, qz, p.x, p.y, p.z) == bd) {
+              ++ncand;
+              if (j != cur && tie_before(tt, qx, qy, qz, j, cur)) cur = j;
+            }
+          }
+      }
+    }
+    float b = INFINITY;      // lower bound on the distance to anything not yet scanned
+    if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+    if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+    if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+    if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+    if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+    if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+    if (b == INFINITY) break;
+    b -= g.margin;
+    if (b > 0.0f && bd < b * b * KSHRINK) break;
+  }
+  if (ncand >= 2u) { atomicAdd(tt.counters + 1, 1u); if (cur != pos) atomicAdd(tt.counters + 2, 1u); }      // (a flag raised for a distance that was beaten later: one candidate)
+  return cur;
 }
 
 // ---- accumulation helpers ------------------------------------------------------------------------
@@ -994,9 +1082,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // IEEE operations per component, so d2 still rounds exactly as ((dx*dx)+(dy*dy))+(dz*dz)).
 // TRACK2 (feature search): also keep the two smallest squared distances met (m12[0] <= m12[1]) -- plain f32 min / median
 // beside the key compare; `counted` = false keeps a re-read candidate out of them.
+// Ties (option "tie_rule"): the tile only has to NOTICE that the smallest distance was met twice -- such a query is not proven here
+// and goes to the clean-up pass, which settles it with the reference's order.  TRACK2 knows from its second smallest distance;
+// otherwise `tie` collects "this candidate's distance equals the smallest so far" (one compare; the mask is scalar).  Sticky, and a
+// point read twice (over-reads past a short run) raises it too: a flag too many costs a deferral, never a result.
 template <bool TRACK2 = false>
 __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, float qz, uint32_t pos,
-                                               unsigned long long& bk, uint32_t& bp, float* m12 = nullptr, bool counted = true) {
+                                               unsigned long long& bk, uint32_t& bp, float* m12, bool counted, unsigned long long& tie) {
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
@@ -1004,6 +1096,7 @@ __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, 
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
   const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
+  if (!TRACK2) tie |= __ballot(counted & (__float_as_uint(e) == (uint32_t)(bk >> 32)));      // (a lane mask in scalar registers)
   if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], counted ? e : INFINITY);   // hi(bk) is the smallest so far
   bk = lt ? k : bk;
   bp = lt ? pos : bp;
@@ -1039,7 +1132,7 @@ constexpr int OCT_EXTRA = CILHIP_OCT_EXTRA;
 
 template <bool TRACK2 = false>
 __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 qxy, float qz, uint32_t code,
-                                                   unsigned long long& bk, uint32_t& sel, float* m12 = nullptr) {
+                                                   unsigned long long& bk, uint32_t& sel, float* m12, unsigned long long& tie) {
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
@@ -1047,6 +1140,7 @@ __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 q
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
   const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
+  if (!TRACK2) tie |= __ballot(__float_as_uint(e) == (uint32_t)(bk >> 32));
   if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], e);
   bk = lt ? k : bk;
   sel = lt ? code : sel;      // code is a compile-time constant: no address arithmetic per candidate
@@ -1099,8 +1193,9 @@ __device__ __forceinline__ float octant_bound(const GridDev& g, float qx, float 
 // radius while there is none): the 6-D feature distance of any candidate but the winner is at least that.
 template <bool TRACK2 = false>
 __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best, uint32_t& bl_out,
-                                              float* second_out = nullptr, float* bound_out = nullptr) {
+                                              float* second_out = nullptr, float* bound_out = nullptr, bool tie_defer = false) {
   float m12[2] = {INFINITY, INFINITY};
+  unsigned long long tie_m = 0ull;
   const f32x2 qxy = {o.qx, o.qy};
   const float qz = o.qz;
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
@@ -1121,7 +1216,7 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
 #pragma unroll
     for (int c = 0; c < OCT_CAND; ++c) p[c] = t.lpts[rj[k] + c];
 #pragma unroll
-    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel, m12);
+    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel, m12, tie_m);
     if (TRACK2 && k < 3) {   // ties the next run's address to this run's result: keeps the scheduler from issuing all 16 reads first (64 live registers)
       uint32_t hi = (uint32_t)(bk >> 32);
       asm volatile("" : "+v"(rj[k + 1]), "+v"(hi), "+v"(m12[1]));
@@ -1149,10 +1244,10 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
     const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, c0 | c1 | c2 | c3);
-    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, c0 | c1 | c2 | c3);
-    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, c0 | c1 | c2 | c3);
-    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, c0 | c1 | c2 | c3);
+    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
+    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
+    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
+    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
   }
   for (;;) {
     const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
@@ -1163,10 +1258,10 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
     const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12);
-    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12);
-    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12);
-    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12);
+    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, true, tie_m);
+    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, true, tie_m);
+    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, true, tie_m);
+    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, true, tie_m);
   }
   best.key = bk;
   // LDS index -> global position: the winner normally lies in the row of its run (one table read); an
@@ -1183,7 +1278,8 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   bl_out = bl;      // LDS index of the winner (NONE_U32: nothing within the radius): the in-tile accumulation reads the point from there
   const float b = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
   if (TRACK2 && bound_out) *bound_out = b;      // (shrunk) distance from q to the nearest face of the block: every point outside it is at least that far
-  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
+  const bool tie = TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : ((tie_m >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK && !(tie_defer && tie && bl != NONE_U32);
 }
 
 // The full 3x3x3 block of cells around the query's cell, for the queries the octant block did not prove, in
@@ -1198,8 +1294,10 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
 constexpr int B27_CAND = CILHIP_B27_CAND;
 template <bool TRACK2 = false>
 __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
-                                               int cx, int cy, int cz, float max_sq, NN& best, float* second_out = nullptr, float* bound_out = nullptr) {
+                                               int cx, int cy, int cz, float max_sq, NN& best, float* second_out = nullptr, float* bound_out = nullptr,
+                                               bool tie_defer = false) {
   float m12[2] = {INFINITY, INFINITY};      // (TRACK2: [1] = the second smallest squared distance evaluated, as in octant_search)
+  unsigned long long tie_m = 0ull;
   const f32x2 qxy = {qx, qy};
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
   const int row0 = (cz - t.loz) * t.RY + (cy - t.loy);       // region row of the own cell
@@ -1220,7 +1318,7 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
 #pragma unroll
       for (int c = 0; c < INFL; ++c) p[c] = t.lpts[rj + h + c];
 #pragma unroll
-      for (int c = 0; c < INFL; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel, m12);
+      for (int c = 0; c < INFL; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel, m12, tie_m);
     }
     if (TRACK2 && r < 8) {   // ties the next run's addresses to this run's result: keeps the scheduler from issuing all 54 reads first (see octant_search)
       uint32_t hi = (uint32_t)(bk >> 32);
@@ -1249,10 +1347,10 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
     const uint32_t before = bl;
     for (uint32_t j = t.lcs[e0v + off * t.W1] - dl + (uint32_t)B27_CAND; j < re; j += 4) {
       const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
-      eval_candidate<TRACK2>(p0, qxy, qz, j, bk, bl, m12);
-      eval_candidate<TRACK2>(p1, qxy, qz, j + 1, bk, bl, m12);
-      eval_candidate<TRACK2>(p2, qxy, qz, j + 2, bk, bl, m12);
-      eval_candidate<TRACK2>(p3, qxy, qz, j + 3, bk, bl, m12);
+      eval_candidate<TRACK2>(p0, qxy, qz, j, bk, bl, m12, true, tie_m);
+      eval_candidate<TRACK2>(p1, qxy, qz, j + 1, bk, bl, m12, true, tie_m);
+      eval_candidate<TRACK2>(p2, qxy, qz, j + 2, bk, bl, m12, true, tie_m);
+      eval_candidate<TRACK2>(p3, qxy, qz, j + 3, bk, bl, m12, true, tie_m);
     }
     if (bl != before) brow = row0 + off;
   }
@@ -1273,6 +1371,8 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
   if (cz - 1 > 0) b = fminf(b, uz);
   if (cz + 2 < g.nz) b = fminf(b, g.cell - uz);
   if (TRACK2) *second_out = m12[1];
+  const bool tie = TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : ((tie_m >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+  if (tie_defer && tie && bl != NONE_U32) { if (TRACK2) *bound_out = 0.0f; return false; }      // (a tie: the clean-up pass settles it with the reference's order)
   if (b == INFINITY) { if (TRACK2) *bound_out = INFINITY; return true; }
   b = fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin;
   if (TRACK2) *bound_out = b;
@@ -1691,7 +1791,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         pending = true;
       } else if (fast) {
         float second = INFINITY, gapb = 0.0f;
-        unproven = !octant_search<LB>(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb);
+        unproven = !octant_search<LB>(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb, a.tie.mode != 0);
         if (LB && ACC == IM_NONE) mkey = margin_key(best.pos != NONE_U32, second, gapb, mref);
         if (LB && ACC != IM_NONE) mq = margin_q15(best.pos != NONE_U32, second, gapb, mref, g.inv_cell);
         if (LB) {
@@ -1855,7 +1955,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         // (the region holds the octant blocks of the tile's queries, not necessarily all of this query's 3x3x3 block)
         const bool in27 = (cx - 1 >= tq.lox) & (cx + 1 <= hx27) & (cy - 1 >= tq.loy) & (cy + 1 <= hy27) & (cz - 1 >= tq.loz) & (cz + 1 <= hz27);
         float second = INFINITY, gapb = 0.0f;
-        const bool proven = in27 && block27_search<LB>(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best, &second, &gapb);
+        const bool proven = in27 && block27_search<LB>(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best, &second, &gapb, a.tie.mode != 0);
         a.nn_pos[i] = proven ? best.pos : DEFER_MARK;
         if (proven && a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
         if (LB && proven) a.nn_lb[i] = margin_key(best.pos != NONE_U32, second, gapb, MotionRef{tform_lds[16], tform_lds[17]});
@@ -2023,7 +2123,10 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
   // (margin keys / match records of the warm-started iterations: the generic search proves its result but keeps no bound on
   //  the other points -- "no bound known"; the warm kernel searches such a query itself and then has one)
   const float key_unknown_has = 0.0f, key_unknown_none = MARGIN_NONE_NO_MATCH;
-  auto finish = [&](uint32_t i, float qx, float qy, float qz, const NN& best) {
+  auto finish = [&](uint32_t i, float qx, float qy, float qz, NN& best) {
+    // (option "tie_rule": a query whose nearest distance was met on two points -- the tiles send theirs here -- takes the reference's pick)
+    if (!FEAT6 && a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)
+      best.pos = tie_settle(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)));
     a.nn_pos[i] = best.pos;
     if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     if (ACC == IM_NONE && a.nn_lb) a.nn_lb[i] = best.pos != NONE_U32 ? key_unknown_has : key_unknown_none;
@@ -2413,6 +2516,8 @@ __global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
       } else {
         nn_search_from(a.grid, qx, qy, qz, a.max_sq, best, lst);
       }
+      if (a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)      // (option "tie_rule")
+        best.pos = tie_settle(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)));
       pos = best.pos;
       value = __uint_as_float((uint32_t)(best.key >> 32));
       if (STORE) { a.nn_pos[i] = pos; if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32)); }
@@ -2663,8 +2768,14 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   //      same margin.
   // Stores the match, its record and the key.
   const float extra = a.warm_extra * g.cell;
-  auto slow_finish = [&](bool v, uint32_t i, const NN& best, const float4 bp, float key, float4& pm, float4& nm) -> bool {
+  auto slow_finish = [&](bool v, uint32_t i, float qx, float qy, float qz, NN& best, float4& bp, float key, float4& pm, float4& nm) -> bool {
     const bool has = v && best.pos != NONE_U32;
+    // (option "tie_rule": the two smallest distances of the search were equal -- the reference's pick among the points at that distance.
+    //  The key stays: every point but the match is at least the match's own distance away, whichever of them the match is.)
+    if (a.tie.mode != 0 && has && best.tie != 0u) {
+      const uint32_t w = tie_settle(g, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)));
+      if (w != best.pos) { best.pos = w; bp = g.pts[w]; }
+    }
     nm = Z4;
     if (NRM) nm = g.nrm[has ? best.pos : 0u];      // (unconditional: one trip for the whole wave)
     pm = has ? make_float4(bp.x, bp.y, bp.z, 0.f) : Z4;
@@ -2722,6 +2833,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     if (fits) {
       float a1 = INFINITY, b2 = INFINITY;
       scan_runs_track2<9>(g.pts, rb9, re9, qx, qy, qz, best, a1, b2, bp);
+      best.tie = (best.pos != NONE_U32 && b2 == __uint_as_float((uint32_t)(best.key >> 32))) ? 1u : 0u;
       // every point that was not evaluated lies beyond the ball
       key = margin_key(best.pos != NONE_U32, best.pos != NONE_U32 ? b2 : a1, (__fsqrt_rn(R2) + extra) * 0.999999f, mref);
     }
@@ -2790,6 +2902,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
       }
       if (!skip) nn_search_shells_margin(g, qx, qy, qz, s.cx, s.cy, s.cz, s0, best, a1, b2, bp, extra);
     }
+    best.tie = (best.pos != NONE_U32 && b2 == __uint_as_float((uint32_t)(best.key >> 32))) ? 1u : 0u;
     if (!skip) {
       // every point that was not evaluated lies beyond sqrt(best) + extra (the radius + extra without a match)
       const float reach = (__fsqrt_rn(__uint_as_float((uint32_t)(best.key >> 32))) * 0.999999f + extra) * 0.999999f;
@@ -2951,7 +3064,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
       }
       nopen += (uint32_t)__popcll(om);
       float4 pm = Z4, nm = Z4;
-      const bool has = slow_finish(v && taken, __float_as_uint(ent.w), best, bp, key, pm, nm);
+      const bool has = slow_finish(v && taken, __float_as_uint(ent.w), ent.x, ent.y, ent.z, best, bp, key, pm, nm);
       rank_update(has, ent.x, ent.y, ent.z, pm, nm);
       WARM_CLK(2 + level);
     }
@@ -3416,10 +3529,11 @@ void launch_solve(const SolveArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, a);
 }
 
-struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; float src_center[3], src_half[3]; };
+struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; float src_center[3], src_half[3]; unsigned int* tie_counters; };
 
 __global__ void k_init_state(IcpState* st, InitArgs ia) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (ia.tie_counters != nullptr) { for (int k = 0; k < 4; ++k) ia.tie_counters[k] = 0u; }
   if (ia.fb != nullptr) {
     for (int k = 0; k < 4; ++k) { ia.fb->slot[k].unproven = 0u; ia.fb->slot[k].listed = 0u; ia.fb->slot[k].delta = 0.0f; ia.fb->slot[k].prev_delta = 0.0f; ia.fb->slot[k].step = 0.0f; ia.fb->slot[k].pad = 0.0f; ia.fb->slot[k].commit = 0ull; }
     __threadfence_system();
@@ -3444,9 +3558,9 @@ __global__ void k_init_state(IcpState* st, InitArgs ia) {
 }
 
 void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb, unsigned int run_tag,
-                       const float* src_center, const float* src_half) {
+                       const float* src_center, const float* src_half, unsigned int* tie_counters) {
   InitArgs ia;
-  ia.fb = fb; ia.run_tag = run_tag;
+  ia.fb = fb; ia.run_tag = run_tag; ia.tie_counters = tie_counters;
   // (no bounding box given: a huge one -- the margin test then settles nothing)
   for (int i = 0; i < 3; ++i) { ia.src_center[i] = src_center ? src_center[i] : 0.0f; ia.src_half[i] = src_half ? src_half[i] : 1.0e30f; }
   for (int i = 0; i < 16; ++i) ia.T[i] = T0[i];
@@ -3654,91 +3768,16 @@ void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, 
   hipLaunchKernelGGL(k_count_ties, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, g, src_sorted, ns, t, max_sq, out);
 }
 
-// ... and, for option "tie_rule" = 1 (the reference's order of ties, tie_order.hpp): the tied queries of the STORED matches with all
-// their equidistant candidates.  The stored match gives the distance outright, so only the closed ball of that radius is looked
-// at (shells, cells beyond the distance skipped); every point at exactly that distance is a candidate.  Entries are appended
-// through an atomic counter (their order does not matter: the host resolves each on its own).
-__global__ __launch_bounds__(256) void k_tie_candidates(GridDev g, const float4* __restrict__ src, uint32_t ns, const IcpState* __restrict__ st,
-                                                        const uint32_t* __restrict__ nn_pos, TieEntry* __restrict__ out, uint32_t cap, unsigned int* counter) {
-  float T[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
-    const uint32_t mp = nn_pos[i];
-    if (mp == NONE_U32) continue;
-    const float4 s4 = src[i];
-    float qx, qy, qz;
-    transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
-    const float4 pm = g.pts[mp];
-    const float bd = d2_pinned(qx, qy, qz, pm.x, pm.y, pm.z);
-    const float BIG = 1.0e9f;
-    const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG)), cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG)),
-              cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
-    uint32_t cpos[TIE_MAXC];
-    uint32_t nc = 0;
-    for (int s = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));; ++s) {
-      const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1), y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
-      for (int z = z0; z <= z1; ++z) {
-        const float zl = g.oz + (float)z * g.cell;
-        const float az = axis_gap(qz, zl, zl + g.cell, g.margin);
-        for (int y = y0; y <= y1; ++y) {
-          const bool face = (z == cz - s) || (z == cz + s) || (y == cy - s) || (y == cy + s);
-          const float yl = g.oy + (float)y * g.cell;
-          const float ay = axis_gap(qy, yl, yl + g.cell, g.margin);
-          if ((az * az + ay * ay) * KSHRINK > bd) continue;
-          const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-          uint32_t rb[2] = {0, 0}, re[2] = {0, 0};
-          if (face) {
-            const int xa = max(cx - s, 0), xb = min(cx + s, g.nx - 1);
-            if (xa <= xb) { rb[0] = g.cell_start[row + xa]; re[0] = g.cell_start[row + xb + 1]; }
-          } else {
-            if (cx - s >= 0 && cx - s < g.nx) { rb[0] = g.cell_start[row + cx - s]; re[0] = g.cell_start[row + cx - s + 1]; }
-            if (s > 0 && cx + s >= 0 && cx + s < g.nx) { rb[1] = g.cell_start[row + cx + s]; re[1] = g.cell_start[row + cx + s + 1]; }
-          }
-          for (int r = 0; r < 2; ++r)
-            for (uint32_t j = rb[r]; j < re[r]; ++j) {
-              const float4 p = g.pts[j];
-              if (d2_pinned(qx, qy, qz, p.x, p.y, p.z) == bd) { if (nc < (uint32_t)TIE_MAXC) cpos[nc] = j; ++nc; }
-            }
-        }
-      }
-      float b = INFINITY;      // lower bound on the distance to anything not yet scanned
-      if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
-      if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
-      if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
-      if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
-      if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
-      if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
-      if (b == INFINITY) break;
-      b -= g.margin;
-      if (b > 0.0f && bd < b * b * KSHRINK) break;
-    }
-    if (nc >= 2) {      // (the match itself is one of them)
-      const unsigned int slot = atomicAdd(counter, 1u);
-      if (slot < cap) {
-        TieEntry e;
-        e.i = i; e.qx = qx; e.qy = qy; e.qz = qz; e.n = nc;
-        for (uint32_t k = 0; k < (uint32_t)TIE_MAXC; ++k) {
-          e.pos[k] = k < nc ? cpos[k] : NONE_U32;
-          e.orig[k] = k < nc ? __float_as_uint(g.pts[cpos[k < nc ? k : 0]].w) : NONE_U32;
-        }
-        out[slot] = e;
-      }
-    }
-  }
+// the order tables of option "tie_rule" (tie_order.hpp) arrive by ORIGINAL target index; the searches know sorted positions
+__global__ void k_tie_tables_by_position(const float4* __restrict__ dst_sorted, uint32_t n, const uint32_t* __restrict__ leaf_by_index,
+                                         const uint32_t* __restrict__ slot_by_index, uint2* __restrict__ leaf_slot) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t o = __float_as_uint(dst_sorted[j].w);
+  leaf_slot[j] = make_uint2(leaf_by_index[o], slot_by_index[o]);
 }
-__global__ void k_patch_matches(const uint2* __restrict__ patches, uint32_t n, uint32_t* __restrict__ nn_pos) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) nn_pos[patches[k].x] = patches[k].y;
-}
-void launch_tie_candidates(const GridDev& g, const float4* src_sorted, uint32_t ns, const IcpState* st, const uint32_t* nn_pos, TieEntry* out, uint32_t cap,
-                           unsigned int* counter, hipStream_t s) {
-  (void)hipMemsetAsync(counter, 0, sizeof(unsigned int), s);
-  if (ns == 0 || g.n == 0) return;
-  hipLaunchKernelGGL(k_tie_candidates, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, g, src_sorted, ns, st, nn_pos, out, cap, counter);
-}
-void launch_patch_matches(const uint2* patches, uint32_t n, uint32_t* nn_pos, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(k_patch_matches, dim3((n + 255u) / 256u), dim3(256), 0, s, patches, n, nn_pos);
+void launch_tie_tables_by_position(const float4* dst_sorted, uint32_t n, const uint32_t* leaf_by_index, const uint32_t* slot_by_index, uint2* leaf_slot, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_tie_tables_by_position, dim3((n + 255u) / 256u), dim3(256), 0, s, dst_sorted, n, leaf_by_index, slot_by_index, leaf_slot);
 }
 
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s) {
@@ -3762,6 +3801,8 @@ __global__ __launch_bounds__(256) void k_residuals(IterArgs a, int metric, float
     transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
     NN best;
     nn_search(a.grid, qx, qy, qz, a.max_sq, best, lst);
+    if (a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)
+      best.pos = tie_settle(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)));
     float v = __uint_as_float(0x7fc00000u);  // NaN when the target is empty (:221-224)
     if (best.pos != NONE_U32) {
       const float4 p = a.grid.pts[best.pos];

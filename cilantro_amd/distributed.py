@@ -69,6 +69,44 @@ def init_rank_comm(ctx, dist, group=None, device="cuda"):
     return True
 
 
+# Option "tie_rule" in sharded runs.  Which of several exactly equidistant nearest points the reference names is a property of the
+# tree it builds over the WHOLE target (csrc/tie_order.hpp).  The engines' kernels resolve ties from that tree's order tables when
+# they are loaded and COUNT the tied queries when they are not (tie_rule 2); the loops below look at the count after a run --
+# one MAX over the ranks, so that all take the same decision --, have every engine load the tables (built once per target and
+# process: _TIE_ORDERS) and run again.  Engines that know nothing of this (the CPU test engine) are never asked.
+_TIE_ORDERS = {}
+
+
+def _tie_order_of(dst):
+    """handle of the order tables of the whole target cloud `dst` (host array), built on first use"""
+    import ctypes as C
+
+    dst = np.ascontiguousarray(np.asarray(dst, np.float32).reshape(-1, 3))
+    key = (dst.ctypes.data, len(dst))
+    if key not in _TIE_ORDERS:
+        h = C.c_void_p()
+        rc = capi.load().cilhip_tie_order_create(dst.ctypes.data, len(dst), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("cilhip_tie_order_create failed")
+        _TIE_ORDERS[key] = (h, dst)      # (the array stays alive with its key)
+    return _TIE_ORDERS[key][0]
+
+
+def _ties_pending_anywhere(engine, dist, group, seen_before=False):
+    fn = getattr(engine, "ties_pending", None)
+    if fn is None:
+        return False
+    mine = 1 if (seen_before or fn()) else 0
+    if dist is not None and dist.get_world_size(group) > 1:
+        import torch
+
+        dev = engine.sums.device if hasattr(engine, "sums") else "cpu"
+        t = torch.tensor([mine], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        mine = int(t.item())
+    return mine != 0
+
+
 class HipShardEngine:
     """Per-rank engine backed by libcilantro_hip.so.  All work is enqueued on torch's current stream
     so the RCCL all-reduce is ordered after the partial-sum kernels without host synchronisation."""
@@ -116,6 +154,14 @@ class HipShardEngine:
         T = np.array(r.T[:], np.float32).reshape(4, 4).T.copy()
         return T, int(r.iterations), float(r.last_delta_norm), int(r.last_ncorr)
 
+    def ties_pending(self):
+        """this rank's searches since begin() met exactly equidistant nearest points and had no order tables (option tie_rule 2)"""
+        info = self.ctx.tie_order_info()
+        return (not info["loaded"]) and info["pending"] != 0
+
+    def load_tie_order(self):
+        self.ctx.build_tie_order()      # (this rank holds the whole target)
+
 
 class ShardedRigidICP:
     """IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) across ranks.
@@ -144,6 +190,13 @@ class ShardedRigidICP:
         return (t[:3] / max(t[3], 1.0)).astype(np.float32)
 
     def estimate(self, params, T0=None, check_every=0):
+        out = self._estimate_once(params, T0, check_every)
+        if _ties_pending_anywhere(self.engine, self.dist, self.group):      # (collective: every rank runs again or none)
+            self.engine.load_tie_order()
+            out = self._estimate_once(params, T0, check_every)
+        return out
+
+    def _estimate_once(self, params, T0=None, check_every=0):
         """Runs up to params.max_iter iterations.  check_every=0: enqueue everything and read the
         state once at the end (the device-side `done` flag turns the remaining launches into
         no-ops once converged); check_every=k: poll the state every k iterations and stop early."""
@@ -328,6 +381,16 @@ class HipSlabEngine(HipShardEngine):
         self.gdm, self.gsm = part.global_means(dst, src)
         self.ctx.set_shard_info(0, dst_mean=self.gdm)
         part.arm_guard(self.ctx)
+        self._dst_all = np.ascontiguousarray(np.asarray(dst, np.float32).reshape(-1, 3))
+        self._dst_index = np.ascontiguousarray(part.dst_index, np.uint32)
+        key = (self._dst_all.ctypes.data, len(self._dst_all))
+        if key in _TIE_ORDERS:      # (a re-partitioned engine of a target whose order is known: loaded at once)
+            self.load_tie_order()
+
+    def load_tie_order(self):
+        # the order of the WHOLE target; this rank's slab takes the entries of its own points
+        if len(self._dst_index):
+            self.ctx.load_tie_order(_tie_order_of(self._dst_all), self._dst_index)
 
     def begin(self, params, T0, global_src_mean):
         self.ctx.icp_begin(params, T0, self.gsm)
@@ -352,6 +415,14 @@ class SlabShardedRigidICP:
         self.repartitions = 0
 
     def estimate(self, params, T0=None, check_every=5):
+        self._ties_seen = False      # (an engine replaced by a re-partition takes its counters with it: looked at before it goes)
+        out = self._estimate_once(params, T0, check_every)
+        if _ties_pending_anywhere(self.engine, self.dist, self.group, self._ties_seen):      # (collective; engines made by later re-partitions load the tables themselves)
+            self.engine.load_tie_order()
+            out = self._estimate_once(params, T0, check_every)
+        return out
+
+    def _estimate_once(self, params, T0=None, check_every=5):
         T_ck = np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32).copy()
         total, base, since, begin_base = int(params.max_iter), 0, 0, 0   # base: iterations up to the last checked state; begin_base: up to the last begin()
         inner = ShardedRigidICP(self.engine, self.dist, self.group)
@@ -394,6 +465,8 @@ class SlabShardedRigidICP:
                     if self.repartition is None:
                         raise RuntimeError("a source point may have left its slab's halo and no repartition function was given")
                     was_native = getattr(self.engine, "native", False)
+                    tp = getattr(self.engine, "ties_pending", None)
+                    self._ties_seen = getattr(self, "_ties_seen", False) or (tp is not None and tp())
                     self.engine = self.repartition(T_ck)
                     if was_native and self.dist is not None and hasattr(self.engine, "enable_native_allreduce"):
                         self.engine.enable_native_allreduce(self.dist, self.group)      # (a new context: a new communicator; collective like the re-partition itself)

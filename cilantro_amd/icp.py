@@ -163,10 +163,26 @@ class Context:
         return n.value
 
     def tie_rule_stats(self):
-        """under option tie_rule = 1: (tied queries, matches re-pointed to the reference's choice) of the last search / run"""
+        """option tie_rule != 0: (tied queries, matches that are not the lowest index: the reference's traversal met another point first)
+        of the last search / run"""
         a = C.c_size_t(0); b = C.c_size_t(0)
         self._ck(self._L.cilhip_get_tie_rule_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def tie_order_info(self):
+        """the order tables behind option tie_rule (cilhip_get_tie_order_info): dict(loaded, builds, build_ms, pending)"""
+        o = capi.TieOrderInfo()
+        self._ck(self._L.cilhip_get_tie_order_info(self._h, C.byref(o)))
+        return {"loaded": bool(o.loaded), "builds": int(o.builds), "build_ms": float(o.build_ms), "pending": int(o.pending)}
+
+    def build_tie_order(self):
+        self._ck(self._L.cilhip_build_tie_order(self._h))
+
+    def load_tie_order(self, order_handle, global_index=None):
+        """order_handle: from capi cilhip_tie_order_create over the WHOLE target cloud; global_index: uint32 index in that cloud of each
+        of this context's target points (None: the context holds the whole cloud)"""
+        gi = None if global_index is None else np.ascontiguousarray(global_index, np.uint32)
+        self._ck(self._L.cilhip_load_tie_order(self._h, order_handle, None if gi is None else gi.ctypes.data))
 
     def get_nn(self):
         idx = np.zeros(max(self.n_source, 1), np.uint32); d2 = np.zeros(max(self.n_source, 1), np.float32)

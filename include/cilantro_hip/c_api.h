@@ -353,15 +353,33 @@ typedef struct {
 } cilhip_grid_info;
 int cilhip_get_grid_info(cilhip_ctx* ctx, cilhip_grid_info* out);
 /* How many source points have, under T and within max_sq_dist, a nearest target point that is NOT unique in the pinned f32 squared
- * distance (exactly equidistant candidates: duplicated points, a depth sensor's lattice).  Only there can this engine's
- * correspondence differ from the reference's: the engine keeps the lowest target index, nanoflann the candidate its traversal meets
- * first (core/kd_tree.hpp:82-90) -- both exact nearest neighbours.  0 = index parity with the reference is guaranteed for this
- * search.  Diagnostic (one more exact search of every query). */
+ * distance (exactly equidistant candidates: duplicated points, a depth sensor's lattice).  Only there do a brute-force argmin
+ * (lowest target index) and the reference differ: nanoflann keeps the candidate its traversal meets first (core/kd_tree.hpp:82-90) --
+ * both exact nearest neighbours; option "tie_rule" says which one the engine names.  Diagnostic (one more exact search of every query). */
 int cilhip_get_tie_count(cilhip_ctx* ctx, const float T[16], float max_sq_dist, size_t* n_ties);
-/* Under option "tie_rule" = 1: of the last cilhip_find_correspondences (or summed over the iterations of the last cilhip_icp_run),
- * the queries that had several exactly equidistant nearest target points, and how many of their matches were re-pointed from
- * the lowest index to the reference's choice. */
+/* Option "tie_rule" != 0: of the last cilhip_find_correspondences (or summed over the searches of the last cilhip_icp_run / since
+ * the last cilhip_icp_begin), the queries that had several exactly equidistant nearest target points, and how many of their
+ * matches are NOT the lowest index (the reference's traversal met another one first). */
 int cilhip_get_tie_rule_stats(cilhip_ctx* ctx, size_t* tied_queries, size_t* repointed);
+/* The order tables behind "tie_rule" (kd_tree.hpp:162-170 -> nanoflann.hpp:1150-1212, :1321-1428: the permutation and the splits of
+ * the index the reference builds over the target; csrc/tie_order.hpp).  loaded: this context's target has them on the device;
+ * builds: how often this context built them (tie_rule 2 builds when a search first meets a tie; never, on clouds that do not tie);
+ * build_ms: host time of the last build (tree on the host's cores + upload); pending: tied queries the searches since the last
+ * cilhip_icp_begin / find_correspondences met WITHOUT tables (cilhip_icp_run and cilhip_find_correspondences deal with those
+ * themselves; a caller driving cilhip_icp_begin / _partial_sums / _apply_sums reads it after its loop, calls
+ * cilhip_build_tie_order and runs the loop again -- cilantro_amd/distributed.py does). */
+typedef struct cilhip_tie_order_info { int loaded; int builds; double build_ms; size_t pending; } cilhip_tie_order_info;
+int cilhip_get_tie_order_info(cilhip_ctx* ctx, cilhip_tie_order_info* out);
+/* Builds and loads the tables for this context's own target now (no-op when loaded). */
+int cilhip_build_tie_order(cilhip_ctx* ctx);
+/* The same tables for a target that is only PART of the cloud the reference would index (a spatial slab of a sharded run): the
+ * order is a property of the WHOLE cloud.  cilhip_tie_order_create builds it once from the whole cloud (host memory, original
+ * order); cilhip_load_tie_order hands a context the entries of its own points: global_index[i] = index in the whole cloud of the
+ * context's target point i (null: the context holds the whole cloud). */
+typedef struct cilhip_tie_order cilhip_tie_order;
+int cilhip_tie_order_create(const float* xyz, size_t n, cilhip_tie_order** out);
+void cilhip_tie_order_destroy(cilhip_tie_order* order);
+int cilhip_load_tie_order(cilhip_ctx* ctx, const cilhip_tie_order* order, const uint32_t* global_index);
 
 /* CorrespondenceSearchCombinedMetricCombiner (registration/correspondence_search_combined_metric_combiner.hpp:8-81): the combined
  * metric's point-to-point terms read ONE engine's correspondence set, its point-to-plane terms ANOTHER's (own radius, feature
@@ -469,17 +487,20 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        (or that leave without one); the warm-started form is entered only when that is at most an eighth of the
  *                        queries -- a pair whose matches lie far beyond the target's point spacing never pays for a try.  0 = enter
  *                        on the step alone (tests).
- *   "tie_rule" (default 0): which of several EXACTLY equidistant nearest target points a correspondence names.  0 = the lowest
- *                        target index (what a brute-force argmin gives; every kernel form).  1 = the point the reference's kd-tree
- *                        search returns: nanoflann keeps the candidate its traversal meets first (core/kd_tree.hpp:82-90 over
- *                        nanoflann 1.7.1 searchLevel), which depends on the tree it built (leaf size 10, core/kd_tree.hpp:162-170).
- *                        The engine then lists, after each search, the queries with tied candidates (device), walks a host
- *                        restatement of that tree's build for them (csrc/tie_order.hpp) and re-points those matches: indices and
- *                        loop results equal the reference's on clouds with duplicated points or lattice ties too
- *                        (tests/test_gpu_tie_rule.py).  Costs one host round trip per search and runs the loop in its
- *                        search + streaming-accumulation form; covers the rigid SECOND_TO_FIRST path over points on one whole
- *                        target (CILHIP_ERR_UNSUPPORTED otherwise; more than 8 candidates at one distance: same).
- *                        cilhip_get_tie_count tells beforehand whether a pair of clouds has any tie at all.
+ *   "tie_rule" (default 2): which of several EXACTLY equidistant nearest target points a correspondence names.  The reference's
+ *                        kd-tree search returns the candidate its traversal meets FIRST (core/kd_tree.hpp:82-90 over nanoflann
+ *                        1.7.1 searchLevel), which depends on the tree it built (leaf size 10, core/kd_tree.hpp:162-170).
+ *                        2 = that point, on the device, in every kernel form: each search notices when its smallest distance was
+ *                        met on a second point and settles such a query from the order tables of the reference's tree (per point:
+ *                        leaf + slot of the reference's permutation; per node: parent, depth, split -- csrc/tie_order.hpp builds
+ *                        them on the host's cores, kernels.hip tie_settle reads them).  The tables are built when a search first
+ *                        MEETS a tie (that search / run is then executed once more): a target whose searches never tie never pays
+ *                        for a tree, one that does pays once.  1 = the same choice, tables built before the first search.
+ *                        0 = the lowest target index (what a brute-force argmin gives).  Covers the SECOND_TO_FIRST matches
+ *                        (also the forward half of BOTH) over point features, rigid and affine, sharded runs included
+ *                        (cilhip_load_tie_order); feature adaptors, reverse matches and index shards of a target keep the lowest
+ *                        index under 2 and are refused (CILHIP_ERR_UNSUPPORTED) under 1.  tests/test_gpu_tie_rule.py: every index
+ *                        of the reference's sensor frames and of a cloud with doubled and tripled points equals nanoflann's.
  *   "warm_extra_fraction" (default 0.0625): a query the warm-started form has to search is searched inside the ball of its bound
  *                        plus this fraction of a grid cell -- the room its fresh margin can have.  Larger: more cells per
  *                        search, margins that last longer; measured best at 10M (independent source: 0.25 -> 0.216 ms per

@@ -1,20 +1,44 @@
-// Test shim: csrc/tie_order.hpp (host-only) behind three C functions, so that the CPU suite can check the tree restatement
-// against the reference's nanoflann (oracle/_ref) without a GPU.  Built by tests/cpp/build.sh into tests/cpp/bin/libtie_order_shim.so.
+// Test shim: csrc/tie_order.hpp (host-only) behind a few C functions, so that the CPU suite can check the order tables against the
+// reference's nanoflann (oracle/_ref) without a GPU.  Built by tests/cpp/build.sh into tests/cpp/bin/libtie_order_shim.so.
 #include "../../cilantro_amd/csrc/tie_order.hpp"
+
+#include <cstring>
 
 struct Shim { std::vector<float> xyz; cilhip::TieOrderTree tree; };
 
 extern "C" {
-void* tie_shim_build(const float* xyz, uint32_t n) {
+void* tie_shim_build_mt(const float* xyz, uint32_t n, unsigned threads) {
   Shim* s = new Shim();
   s->xyz.assign(xyz, xyz + 3 * (size_t)n);
-  s->tree.build(s->xyz.data(), n);
+  s->tree.build(s->xyz.data(), n, 10, threads);
   return s;
 }
+void* tie_shim_build(const float* xyz, uint32_t n) { return tie_shim_build_mt(xyz, n, 1); }
 void tie_shim_free(void* h) { delete static_cast<Shim*>(h); }
 // per query k: cand[k*stride .. +count[k]) -> out[k]
 void tie_shim_first_met(void* h, const float* q, const uint32_t* cand, const int* count, int stride, uint32_t nq, uint32_t* out) {
   const Shim* s = static_cast<const Shim*>(h);
   for (uint32_t k = 0; k < nq; ++k) out[k] = s->tree.first_met(q + 3 * (size_t)k, cand + (size_t)k * stride, count[k]);
+}
+// the reference's permutation (slot of every point), leaf populations and depths: what must not depend on how many threads built the tree
+// (node ids do: they are list positions)
+int tie_shim_same_order(void* ha, void* hb) {
+  const Shim *a = static_cast<const Shim*>(ha), *b = static_cast<const Shim*>(hb);
+  if (a->tree.size() != b->tree.size() || a->tree.nodes().size() != b->tree.nodes().size()) return 0;
+  if (a->tree.slot_of() != b->tree.slot_of()) return 0;
+  for (uint32_t i = 0; i < a->tree.size(); ++i) {
+    // walk both leaf-to-root paths: same depths, same splits, same child sides
+    uint32_t na = a->tree.leaf_of()[i], nb = b->tree.leaf_of()[i];
+    for (;;) {
+      const cilhip::TieNode &x = a->tree.nodes()[na], &y = b->tree.nodes()[nb];
+      if (x.info != y.info) return 0;
+      if ((x.parent < 0) != (y.parent < 0)) return 0;
+      if (x.parent < 0) break;
+      na = (uint32_t)x.parent; nb = (uint32_t)y.parent;
+      const cilhip::TieNode &px = a->tree.nodes()[na], &py = b->tree.nodes()[nb];
+      if (std::memcmp(&px.divlow, &py.divlow, 4) || std::memcmp(&px.divhigh, &py.divhigh, 4)) return 0;
+    }
+  }
+  return 1;
 }
 }

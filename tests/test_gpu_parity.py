@@ -89,19 +89,33 @@ def test_nn_vs_bruteforce_exact(Context, orc, n):
     rng = np.random.default_rng(n)
     dst = rng.random((n, 3), dtype=np.float32)
     if n >= 1000:
-        dst[n // 2: n // 2 + 50] = dst[:50]          # exact duplicates -> ties resolved to lowest index
+        dst[n // 2: n // 2 + 50] = dst[:50]          # exact duplicates -> ties: lowest index under tie_rule 0, the reference's first-met point by default
     q = rng.random((max(n, 500), 3), dtype=np.float32) * 1.2 - 0.1   # some queries outside the bbox
     q[:20] = dst[:20] if n >= 20 else q[:20]          # zero-distance matches
     h = n ** (-1.0 / 3.0)
+    tree = orc.KDTree(dst, use_ref=orc.ref_available())
     for max_sq in (np.float32((0.7 * h) ** 2), np.float32(0.05), np.float32(3.4e38)):
+        # tie_rule 0: the brute-force argmin with the lowest index on ties
         ctx = Context()
+        ctx.set_option("tie_rule", 0)
         ctx.set_target(dst)
         ctx.set_source(q)
         gi, gd = gpu_nn(ctx, np.eye(4), max_sq)
+        ctx.close()
         bi, bd = orc.nn_brute(dst, q, max_sq)
         assert np.array_equal(gi, bi), (n, max_sq, np.nonzero(gi != bi)[0][:10])
         m = bi >= 0
         assert np.array_equal(gd[m], bd[m])
+        # default options: the reference's kd-tree search, index for index (ties included)
+        ctx = Context()
+        ctx.set_target(dst)
+        ctx.set_source(q)
+        gi, gd = gpu_nn(ctx, np.eye(4), max_sq)
+        ctx.close()
+        o1, o2, ov = tree.find_correspondences(q, float(max_sq))
+        oi = np.full(len(q), -1, np.int64); oi[o2] = o1
+        assert np.array_equal(gi, oi), (n, max_sq, np.nonzero(gi != oi)[0][:10])
+        assert np.array_equal(gd[oi >= 0].view(np.uint32), ov.view(np.uint32))
 
 
 def test_radius_edge_is_strict(Context, orc):

@@ -1,11 +1,11 @@
-"""Option "tie_rule" = 1: correspondences equal the reference's where several target points are EXACTLY equidistant too.
+"""Option "tie_rule" (default 2): correspondences equal the reference's where several target points are EXACTLY equidistant too.
 
-The engine's default names the lowest target index among tied candidates, nanoflann the one its traversal meets first
+A brute-force argmin names the lowest target index among tied candidates, nanoflann the one its traversal meets first
 (core/kd_tree.hpp:82-90) -- on the reference's raw sensor frames 660 of 120k queries are tied under the identity and 321 of them
-get a different (equally near) point.  With the option the device lists the tied queries, the host walks a restatement of the
-reference's tree for them (csrc/tie_order.hpp, pinned on the CPU by tests/test_tie_order_cpu.py) and the matches are re-pointed:
-every index equals nanoflann's, and the loop equals the oracle's loop over the reference's searches to the same 1e-5 as clouds
-without ties.
+get a different (equally near) point.  The engine resolves ties on the device, in every kernel form, from the order tables of the
+reference's tree (csrc/tie_order.hpp, pinned on the CPU by tests/test_tie_order_cpu.py; kernels.hip tie_settle): with DEFAULT
+options every index equals nanoflann's and the loop equals the oracle's loop over the reference's searches.  The tables are built
+when a search first meets a tie (tie_rule 2) or up front (1); 0 = the lowest index.
 """
 import ctypes as C
 import os
@@ -67,65 +67,176 @@ def _clouds():
     yield "duplicated target points", D, N, b["src"], np.float32(b["max_sq_dist"])
 
 
-def test_tie_rule_reference_names_nanoflann_s_points(Context, orc):
+def _icp_params(ctx, r2, iters=6):
+    p = capi.IcpParams()
+    ctx._L.cilhip_icp_default_params(C.byref(p))
+    p.metric, p.w_p2p, p.max_sq_dist, p.max_iter, p.conv_tol = capi.METRIC_COMBINED, 0.0, float(r2), iters, 0.0
+    return p
+
+
+def test_default_options_name_nanoflann_s_points(Context, orc):
     report = {}
     I = np.eye(4, dtype=np.float32)
     for name, D, N, S, r2 in _clouds():
         tree = orc.KDTree(D, use_ref=orc.ref_available())
         oi, _, ov = _ref_matches(tree, S, r2, len(S))
-        # (1) a single search: default rule differs on ties, tie_rule = 1 equals the reference everywhere
+        # (0) the lowest-index rule, for the record: differs from the reference on part of the tied queries
+        c0 = Context(); c0.set_option("tie_rule", 0); c0.set_target(D, N); c0.set_source(S)
+        c0.find_correspondences(I, float(r2), count=False)
+        lo, _ = c0.get_nn()
+        differ_lowest = int(np.count_nonzero(_signed(lo) != oi))
+        tied = c0.tie_count(I, float(r2))
+        res0 = c0.icp_run(_icp_params(c0, r2))
+        T0 = np.array(res0.T[:], np.float32).reshape(4, 4).T
+        assert c0.tie_order_info()["builds"] == 0
+        c0.close()
+        assert differ_lowest > 0 and tied >= differ_lowest, name
+        # (1) DEFAULT options, a single search: the first one meets ties, the tables are built, the search runs again
         ctx = Context(); ctx.set_target(D, N); ctx.set_source(S)
-        ctx.find_correspondences(I, float(r2), count=False)
-        lo, _ = ctx.get_nn()
-        differ_default = int(np.count_nonzero(_signed(lo) != oi))
-        tied = ctx.tie_count(I, float(r2))
-        ctx.set_option("tie_rule", 1)
+        assert not ctx.tie_order_info()["loaded"]
         nfound = ctx.find_correspondences(I, float(r2))
+        info = ctx.tie_order_info()
+        assert info["loaded"] and info["builds"] == 1 and info["pending"] == 0, info
         gi, gd = ctx.get_nn()
         gi = _signed(gi)
         seen, moved = ctx.tie_rule_stats()
         assert np.array_equal(gi, oi), (name, int(np.count_nonzero(gi != oi)))
         assert nfound == int(np.count_nonzero(oi >= 0))
         assert np.array_equal(gd[gi >= 0].view(np.uint32), ov.view(np.uint32)), name      # (ascending source order on both sides)
-        assert seen == tied and moved == differ_default and moved > 0, (name, seen, tied, moved, differ_default)
+        assert seen == tied and moved == differ_lowest, (name, seen, tied, moved, differ_lowest)
         # the engine-level list too (ascending source index, correspondence_search_kd_tree.hpp:231)
         i1, i2, v = ctx.get_correspondences()
         assert np.array_equal(i1.astype(np.int64), oi[oi >= 0]) and np.array_equal(i2.astype(np.int64), np.nonzero(oi >= 0)[0])
-        # (2) the loop: six iterations against the oracle's loop over the reference's searches
+        # (2) the loop, default options (adaptive forms): six iterations against the oracle's loop over the reference's searches
         po = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
         ro = orc.icp_run(D, N, S, po)
-        p = capi.IcpParams()
-        ctx._L.cilhip_icp_default_params(C.byref(p))
-        p.metric, p.w_p2p, p.max_sq_dist, p.max_iter, p.conv_tol = capi.METRIC_COMBINED, 0.0, float(r2), 6, 0.0
+        p = _icp_params(ctx, r2)
         res = ctx.icp_run(p)
         Tg = np.array(res.T[:], np.float32).reshape(4, 4).T
         err = float(np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64)))
         seen_l, moved_l = ctx.tie_rule_stats()
         assert err <= 1e-5 and int(res.iterations) == 6, (name, err)
-        assert ctx.last_warm_iterations() == 0
+        assert ctx.tie_order_info()["builds"] == 1      # (once per target)
+        one, two = ctx.last_run_forms()
         # the set the loop leaves behind: the reference's at the last iteration's transform, index for index
         T = ctx.matches_transform()
         li, _ = ctx.get_nn()
         oi_l, _, _ = _ref_matches(tree, orc.transform_points(T, S), r2, len(S))
         assert np.array_equal(_signed(li), oi_l), (name, int(np.count_nonzero(_signed(li) != oi_l)))
         assert int(res.last_ncorr) == int(np.count_nonzero(oi_l >= 0))
-        # (3) the default rule on the same pair, for the record: how far the ties move the loop
-        ctx.set_option("tie_rule", 0)
-        res0 = ctx.icp_run(p)
-        T0 = np.array(res0.T[:], np.float32).reshape(4, 4).T
         ctx.close()
-        report[name] = {"queries": int(len(S)), "tied_queries_identity": int(seen), "repointed_identity": int(moved),
-                        "tied_queries_over_6_iterations": int(seen_l), "repointed_over_6_iterations": int(moved_l),
-                        "T_minus_oracle_nanoflann_order_tie_rule_1": err,
+        # (3) a fresh context whose FIRST call is the loop: the run that meets the ties is executed again, same result bit for bit
+        c2 = Context(); c2.set_target(D, N); c2.set_source(S)
+        res2 = c2.icp_run(p)
+        assert c2.tie_order_info()["builds"] == 1
+        assert np.array_equal(np.array(res2.T[:], np.float32), np.array(res.T[:], np.float32)), name
+        c2.close()
+        # (4) tie_rule 1: tables up front, same result
+        c1 = Context(); c1.set_option("tie_rule", 1); c1.set_target(D, N); c1.set_source(S)
+        res1 = c1.icp_run(p)
+        assert np.array_equal(np.array(res1.T[:], np.float32), np.array(res.T[:], np.float32)), name
+        info1 = c1.tie_order_info()
+        c1.close()
+        report[name] = {"queries": int(len(S)), "tied_queries_identity": int(seen), "not_the_lowest_index_identity": int(moved),
+                        "tied_queries_over_6_iterations": int(seen_l), "not_the_lowest_index_over_6_iterations": int(moved_l),
+                        "forms_one_pass_two_pass": [int(one), int(two)],
+                        "order_tables_build_ms": info["build_ms"], "order_tables_build_ms_up_front": info1["build_ms"],
+                        "T_minus_oracle_nanoflann_order_default_options": err,
                         "T_minus_oracle_nanoflann_order_tie_rule_0": float(np.linalg.norm(T0.astype(np.float64) - ro["T"].astype(np.float64)))}
     _report("tie_rule.json", report)
 
 
-def test_tie_rule_refuses_what_it_does_not_cover(Context):
+def test_every_kernel_form_resolves_ties(Context, orc):
+    """the duplicated-points cloud through each form the loop can take (tiles one pass / two passes, per lane, warm-started from either
+    start): the last iteration's matches equal nanoflann's index for index, the loops agree with the oracle's"""
+    name, D, N, S, r2 = list(_clouds())[1]
+    tree = orc.KDTree(D, use_ref=orc.ref_available())
+    po = orc.make_params(metric=1, max_iter=8, conv_tol=0.0, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
+    ro = orc.icp_run(D, N, S, po)
+    forms = {"adaptive": {}, "tiles one pass": {"tiled": 2, "tile_accumulation": 2, "warm_start": 0},
+             "tiles two passes": {"tiled": 2, "tile_accumulation": 0, "warm_start": 0}, "per lane": {"tiled": 0, "warm_start": 0},
+             "per lane fused": {"tiled": 0, "warm_start": 0, "fused": 1},
+             "warm forced, tiled start": {"tiled": 2, "warm_start": 2}, "warm forced, per-lane start": {"tiled": 0, "warm_start": 2}}
+    out = {}
+    for fname, opts in forms.items():
+        ctx = Context()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_target(D, N); ctx.set_source(S)
+        res = ctx.icp_run(_icp_params(ctx, r2, 8))
+        Tg = np.array(res.T[:], np.float32).reshape(4, 4).T
+        err = float(np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64)))
+        T = ctx.matches_transform()
+        li, _ = ctx.get_nn()
+        oi_l, _, _ = _ref_matches(tree, orc.transform_points(T, S), r2, len(S))
+        bad = int(np.count_nonzero(_signed(li) != oi_l))
+        seen, moved = ctx.tie_rule_stats()
+        out[fname] = {"T_minus_oracle": err, "index_mismatches": bad, "warm_iterations": ctx.last_warm_iterations(), "tied": int(seen), "moved": int(moved)}
+        ctx.close()
+        assert bad == 0 and err <= 1e-5, (fname, out[fname])
+        assert seen > 0 and moved > 0, (fname, out[fname])
+    _report("tie_rule_forms.json", out)
+
+
+def test_tie_rule_1_refuses_what_the_order_does_not_cover(Context):
     d = syn.make_pair(20_000, perturb=0.3)
     ctx = Context(); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
     ctx.set_option("tie_rule", 1)
     ctx.set_option("search_direction", 2)
     with pytest.raises(RuntimeError):
         ctx.find_correspondences(np.eye(4, dtype=np.float32), float(d["max_sq_dist"]))
+    # the default applies the order where it is defined (the forward matches) and runs
+    ctx.set_option("tie_rule", 2)
+    ctx.find_correspondences(np.eye(4, dtype=np.float32), float(d["max_sq_dist"]))
     ctx.close()
+
+
+def test_sharded_runs_resolve_ties_from_the_whole_target_s_order(Context, orc):
+    """cilhip_multi_icp_run, three shards on one GPU, source shards and spatial slabs (a slab holds only PART of the target: the order
+    tables are the WHOLE cloud's, handed to each shard through the global indices of its points) on the duplicated-points cloud,
+    default options: the loop equals the oracle's over the reference's searches; also when the slab guard fires and the shards are
+    cut again (the tables are loaded again with the new cut)."""
+    from cilantro_amd.multi import PARTITION_SLABS, PARTITION_SOURCE_SHARDS, MultiDeviceRigidICP
+
+    name, D, N, S, r2 = list(_clouds())[1]
+    po = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
+    ro = orc.icp_run(D, N, S, po)
+    c = Context(); p = _icp_params(c, r2); c.close()
+    out = {}
+    for label, part, slack in (("source shards", PARTITION_SOURCE_SHARDS, None), ("slabs", PARTITION_SLABS, None), ("slabs, guard fires", PARTITION_SLABS, 0.002)):
+        m = MultiDeviceRigidICP([0, 0, 0])
+        if slack is not None:
+            m.set_slab_slack(slack)
+        m.set_clouds(D, N, S, r2, part)
+        rr = m.icp_run(p, check_every=2 if slack is not None else 0)
+        T = np.array(rr.T[:], np.float32).reshape(4, 4).T
+        err = float(np.linalg.norm(T.astype(np.float64) - ro["T"].astype(np.float64)))
+        out[label] = {"T_minus_oracle": err, "repartitions": m.repartitions(), "iterations": int(rr.iterations)}
+        # lowest index on the same shards, for the record (this cloud: the duplicates are the same POINT, the sums do not move)
+        m.close()
+        assert int(rr.iterations) == 6 and err <= 2e-6, (label, out[label])
+        if slack is not None:
+            assert out[label]["repartitions"] >= 1
+    _report("tie_rule_sharded.json", out)
+
+
+def test_empty_target_shard_keeps_the_point_to_plane_branch(Context, orc):
+    """a slab whose halo holds no target point at all (source reaching far beyond the target along the cut axis) must run the same
+    epilogue branch as the other shards: 'the target has normals' is a property of the whole cloud"""
+    from cilantro_amd.multi import PARTITION_SLABS, MultiDeviceRigidICP
+
+    d = syn.make_pair(120_000, perturb=0.3)
+    dst, dst_n, src, r2 = d["dst"], d["dst_n"], d["src"], d["max_sq_dist"]
+    far = src[: len(src) // 2].copy()
+    ax = int(np.argmax(dst.max(axis=0) - dst.min(axis=0)))
+    far[:, ax] -= 50.0      # half of the source far below the target along the cut axis: the first slab(s) see no target point
+    src2 = np.ascontiguousarray(np.concatenate([far, src]))
+    c = Context(); p = _icp_params(c, r2, 5); c.set_target(dst, dst_n); c.set_source(src2)
+    ref = c.icp_run(p); c.close()
+    m = MultiDeviceRigidICP([0, 0, 0]); m.set_slab_slack(0.5 * float(np.sqrt(r2))); m.set_clouds(dst, dst_n, src2, r2, PARTITION_SLABS)
+    sizes = [m.shard_sizes(k) for k in range(3)]
+    assert any(s[0] == 0 for s in sizes), sizes
+    rr = m.icp_run(p); m.close()
+    assert int(rr.iterations) == 5 and int(rr.last_ncorr) == int(ref.last_ncorr)
+    assert float(rr.last_delta_norm) > 0.0
+    assert np.abs(np.array(rr.T[:], np.float32).astype(np.float64) - np.array(ref.T[:], np.float32).astype(np.float64)).max() <= 2e-6

@@ -19,10 +19,13 @@ K = 12
 @pytest.fixture(scope="module")
 def shim():
     if not os.path.exists(SHIM):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", os.path.join(ROOT, "tests", "cpp", "tie_order_shim.cpp"), "-o", SHIM])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", os.path.join(ROOT, "tests", "cpp", "tie_order_shim.cpp"), "-o", SHIM])
     L = C.CDLL(SHIM)
     L.tie_shim_build.restype = C.c_void_p
     L.tie_shim_build.argtypes = [C.c_void_p, C.c_uint32]
+    L.tie_shim_build_mt.restype = C.c_void_p
+    L.tie_shim_build_mt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint]
+    L.tie_shim_same_order.argtypes = [C.c_void_p, C.c_void_p]
     L.tie_shim_free.argtypes = [C.c_void_p]
     L.tie_shim_first_met.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p]
     return L
@@ -81,3 +84,21 @@ def test_first_met_is_the_reference_pick(shim, orc):
         assert np.array_equal(got, oi[sel]), (name, int(np.count_nonzero(got != oi[sel])))
         # (and the rule matters: the lowest index is a different point for a good part of them)
         assert np.count_nonzero(cand[:, 0].astype(np.int64) != oi[sel]) > len(sel) // 4, name
+
+
+def test_threads_do_not_change_the_order(shim):
+    """sub-trees are independent: the tables a pool of threads leaves are the serial build's (permutation, depths, splits, child sides)"""
+    rng = np.random.default_rng(11)
+    D = rng.random((400_000, 3), dtype=np.float32)
+    D[rng.choice(len(D), 20_000, replace=False)] = D[rng.choice(len(D), 20_000, replace=False)]      # duplicated points
+    D[:30_000, 2] = np.float32(0.25)                                                                 # a flat sheet: many equal coordinates on a split plane
+    D = np.ascontiguousarray(D)
+    a = shim.tie_shim_build_mt(D.ctypes.data, len(D), 1)
+    b = shim.tie_shim_build_mt(D.ctypes.data, len(D), 8)
+    c = shim.tie_shim_build_mt(D.ctypes.data, len(D), 3)
+    try:
+        assert shim.tie_shim_same_order(a, b) == 1
+        assert shim.tie_shim_same_order(a, c) == 1
+    finally:
+        for h in (a, b, c):
+            shim.tie_shim_free(h)
