@@ -94,6 +94,10 @@ struct cilhip_ctx {
   uint2* d_tie_leaf_slot = nullptr;              // [grid.n] the order tables by sorted target position (null: not loaded)
   uint4* d_tie_nodes = nullptr;
   unsigned int* d_tie_counters = nullptr;        // [4] TieDev::counters
+  unsigned int* d_ticket = nullptr;              // [1] k_reduce_solve's ticket (zero between launches)
+  bool fused_epilogue = false;                   // option "fused_epilogue": stage-1 reduction + epilogue in ONE launch (the last of the 32 stage-1 blocks runs the
+                                                 // epilogue).  Bitwise the same results, measured SLOWER: 0.129 -> 0.136 ms per iteration at 10M, 0.037 -> 0.044 at 1M --
+                                                 // a device-scope fence costs more on this eight-L2 part than the kernel boundary it removes (NOTEBOOK.md): off
   double tie_build_ms = 0.0;                     // host time of the last table build (tree + upload)
   int tie_builds = 0;                            // table builds on this context (diagnostics)
   float warm_extra = 0.0625f;     // option "warm_extra_fraction"
@@ -228,6 +232,7 @@ int cilhip_create(cilhip_ctx** out, int device) {
       hipMalloc(&c->d_defer_flag, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_defer_flag, 0, sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&c->d_unproven, 128 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_unproven, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&c->d_tie_counters, 4 * sizeof(unsigned int)) != hipSuccess || hipMemset(c->d_tie_counters, 0, 4 * sizeof(unsigned int)) != hipSuccess ||
+      hipMalloc(&c->d_ticket, sizeof(unsigned int)) != hipSuccess || hipMemset(c->d_ticket, 0, sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc(&c->h_feedback, sizeof(Feedback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_feedback), c->h_feedback, 0) != hipSuccess ||
       hipMalloc(&c->d_trace, RUN_TRACE_CAP * sizeof(uint4)) != hipSuccess || hipMemset(c->d_trace, 0, RUN_TRACE_CAP * sizeof(uint4)) != hipSuccess ||
@@ -286,6 +291,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_tie_leaf_slot) (void)hipFree(c->d_tie_leaf_slot);
   if (c->d_tie_nodes) (void)hipFree(c->d_tie_nodes);
   if (c->d_tie_counters) (void)hipFree(c->d_tie_counters);
+  if (c->d_ticket) (void)hipFree(c->d_ticket);
   if (c->d_dst_rgb) (void)hipFree(c->d_dst_rgb);
   if (c->d_dst_rgb_sorted) (void)hipFree(c->d_dst_rgb_sorted);
   if (c->d_state) (void)hipFree(c->d_state);
@@ -340,6 +346,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return CILHIP_OK; }
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "fused_epilogue")) { c->fused_epilogue = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tie_rule")) {
     if (value != 0.0 && value != 1.0 && value != 2.0)
       return fail(c, CILHIP_ERR_INVALID, "tie_rule: 0 (lowest index), 1 (the reference's kd-tree order, tables built up front) or 2 (the same, tables built when a tie is first met)");
@@ -2067,11 +2074,10 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
         const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : nb;
-        const int rows = launch_reduce_stage1(c->d_partials, prows, c->d_stage, c->stream);
-        sa.partials = rows ? c->d_stage : c->d_partials;
-        sa.nblocks = rows ? rows : prows;
+        launch_reduce_and_solve(c->d_partials, prows, c->d_stage, c->fused_epilogue ? c->d_ticket : nullptr, sa, c->stream);
+      } else {
+        launch_solve(sa, c->stream);
       }
-      launch_solve(sa, c->stream);
     }
     // Long runs ("iterate until converged" with a large max_iter): the kernels of a converged run return at once, but
     // the post-filter / reduction launches do not look at the flag, so look at it from the host now and then and stop
@@ -2162,7 +2168,7 @@ static int partial_sums_core(cilhip_ctx* c, double* sums_dev, double* rows_dev) 
   const int nb = iter_num_blocks(c->ns);
   int prows = nb;
   unsigned char form_now = FORM_LANE_FUSED;      // (the form this iteration takes: what its published counts will mean)
-  if (c->ns) {
+  if (c->ns && c->grid.n) {      // (a shard without target points -- a slab beyond the target's extent -- has nothing to match: zero sums)
     if (c->fused) {
       launch_iter(a, im, true, false, nb, c->stream);
     } else {

@@ -318,6 +318,8 @@ void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_s
 void launch_reduce_partials(const double* partials, int nblocks, double* stage, double* out, hipStream_t s);
 void launch_reduce_stage1_groups(const double* partials, int nblocks, double* stage, int groups, hipStream_t s);
 int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hipStream_t s);
+// both stages of the reduction and the epilogue: one launch when there are more than 64 rows (ticket: one zeroed word per context; null: the two-kernel path)
+void launch_reduce_and_solve(const double* partials, int nblocks, double* stage, unsigned int* ticket, SolveArgs a, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 128 * SUMS_MAX;
 void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb = nullptr, unsigned int run_tag = 0,
                        const float* src_center = nullptr, const float* src_half = nullptr, unsigned int* tie_counters = nullptr /*[4], zeroed*/);

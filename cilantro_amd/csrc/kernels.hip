@@ -3381,7 +3381,8 @@ __device__ void reset_inner(IcpState* st) {
   st->pad0 = 0;
 }
 
-__global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
+// The epilogue proper (one block of 256 threads): k_solve's body, also the tail of k_reduce_solve's last block.
+__device__ __forceinline__ void solve_body(const SolveArgs& a) {
   __shared__ double sums[SUMS_MAX];
   __shared__ IcpState lst;   // the state is pulled into LDS in one coalesced pass, updated by one lane, written back in one pass:
                              // the serial epilogue then pays one global round trip instead of one per field it touches
@@ -3524,9 +3525,54 @@ __global__ __launch_bounds__(256) void k_solve(SolveArgs a) {
     a.feedback->latest = ((unsigned long long)a.run_tag << 32) | (lst.done ? 0x80000000ull : 0ull) | (unsigned long long)((unsigned int)lst.iterations & 0x7fffffffu);
   }
 }
+__global__ __launch_bounds__(256) void k_solve(SolveArgs a) { solve_body(a); }
 
 void launch_solve(const SolveArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, a);
+}
+
+// Stage 1 of the cross-block reduction AND the epilogue in one launch: the G blocks fold their slices as k_reduce_stage1 does (same
+// rows, same order: the sums are bitwise the two-kernel path's), publish their row -- a device-scope release: the row leaves this
+// XCD's L2 before the ticket is taken -- and the block that takes the LAST ticket (device-scope acquire: its caches are invalidated,
+// the other XCDs' rows are read from memory) runs the epilogue over the G rows.  One launch and one kernel boundary less per
+// iteration.  The same hand-over inside the 1024-block accumulation kernels was measured three times slower than they are
+// (NOTEBOOK.md: every one of their blocks pays the write-back while the others are still streaming); here it is paid by 32 blocks
+// whose only stores are their rows.
+__global__ __launch_bounds__(256) void k_reduce_solve(const double* __restrict__ partials, int nblocks, double* __restrict__ stage, unsigned int* ticket, SolveArgs a) {
+  if (a.state->done) return;      // (read by every block before any block can change it: the epilogue runs after the last ticket)
+  {
+    __shared__ double rsums[SUMS_MAX];
+    const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = blockIdx.x * per;
+    const int b1 = min(b0 + per, nblocks);
+    reduce_partials_block(partials + (size_t)b0 * SUMS_MAX, max(b1 - b0, 0), rsums);
+    if (threadIdx.x < SUMS_MAX) stage[blockIdx.x * SUMS_MAX + threadIdx.x] = rsums[threadIdx.x];
+  }
+  __shared__ unsigned int last_block;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, 1u);
+    last_block = (t == gridDim.x - 1u) ? 1u : 0u;
+    if (t == gridDim.x - 1u) *ticket = 0u;      // (for the next launch: nobody else touches it any more)
+  }
+  __syncthreads();
+  if (last_block == 0u) return;
+  __threadfence();
+  a.partials = stage;
+  a.nblocks = (int)gridDim.x;
+  a.reduced = nullptr;
+  solve_body(a);
+}
+// partials[nblocks] -> epilogue.  Few rows: the epilogue folds them itself; many: one launch does both stages (above).
+void launch_reduce_and_solve(const double* partials, int nblocks, double* stage, unsigned int* ticket, SolveArgs a, hipStream_t s) {
+  if (nblocks <= 64 || ticket == nullptr) {
+    const int rows = ticket == nullptr ? launch_reduce_stage1(partials, nblocks, stage, s) : 0;
+    a.partials = rows ? stage : partials; a.nblocks = rows ? rows : nblocks; a.reduced = nullptr;
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, a);
+    return;
+  }
+  hipLaunchKernelGGL(k_reduce_solve, dim3(reduce_groups(nblocks)), dim3(256), 0, s, partials, nblocks, stage, ticket, a);
 }
 
 struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; float src_center[3], src_half[3]; unsigned int* tie_counters; };

@@ -227,10 +227,10 @@ def test_empty_target_shard_keeps_the_point_to_plane_branch(Context, orc):
 
     d = syn.make_pair(120_000, perturb=0.3)
     dst, dst_n, src, r2 = d["dst"], d["dst_n"], d["src"], d["max_sq_dist"]
-    far = src[: len(src) // 2].copy()
+    far = src.copy()
     ax = int(np.argmax(dst.max(axis=0) - dst.min(axis=0)))
-    far[:, ax] -= 50.0      # half of the source far below the target along the cut axis: the first slab(s) see no target point
-    src2 = np.ascontiguousarray(np.concatenate([far, src]))
+    far[:, ax] -= 50.0      # two thirds of the source far below the target along the cut axis: the first of three slabs sees no target point
+    src2 = np.ascontiguousarray(np.concatenate([far, src[: len(src) // 2]]))
     c = Context(); p = _icp_params(c, r2, 5); c.set_target(dst, dst_n); c.set_source(src2)
     ref = c.icp_run(p); c.close()
     m = MultiDeviceRigidICP([0, 0, 0]); m.set_slab_slack(0.5 * float(np.sqrt(r2))); m.set_clouds(dst, dst_n, src2, r2, PARTITION_SLABS)
