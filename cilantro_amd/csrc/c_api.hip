@@ -95,9 +95,12 @@ struct cilhip_ctx {
   uint4* d_tie_nodes = nullptr;
   unsigned int* d_tie_counters = nullptr;        // [4] TieDev::counters
   unsigned int* d_ticket = nullptr;              // [1] k_reduce_solve's ticket (zero between launches)
+  int group_lanes = 0;                           // option "group_search": lanes per query of the per-lane search's cooperative form (0 = one lane per query; dev A/B)
   bool fused_epilogue = false;                   // option "fused_epilogue": stage-1 reduction + epilogue in ONE launch (the last of the 32 stage-1 blocks runs the
                                                  // epilogue).  Bitwise the same results, measured SLOWER: 0.129 -> 0.136 ms per iteration at 10M, 0.037 -> 0.044 at 1M --
                                                  // a device-scope fence costs more on this eight-L2 part than the kernel boundary it removes (NOTEBOOK.md): off
+  unsigned int tie_counters_host[4] = {0, 0, 0, 0};      // ... as read together with the loop state at the end of a run (read_state: one synchronisation for both)
+  bool tie_counters_fresh = false;
   double tie_build_ms = 0.0;                     // host time of the last table build (tree + upload)
   int tie_builds = 0;                            // table builds on this context (diagnostics)
   float warm_extra = 0.0625f;     // option "warm_extra_fraction"
@@ -231,7 +234,6 @@ int cilhip_create(cilhip_ctx** out, int device) {
   if (hipMalloc(&c->d_state, sizeof(IcpState)) != hipSuccess || hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&c->d_defer_flag, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_defer_flag, 0, sizeof(uint32_t)) != hipSuccess ||
       hipMalloc(&c->d_unproven, 128 * sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_unproven, 0, 128 * sizeof(uint32_t)) != hipSuccess ||
-      hipMalloc(&c->d_tie_counters, 4 * sizeof(unsigned int)) != hipSuccess || hipMemset(c->d_tie_counters, 0, 4 * sizeof(unsigned int)) != hipSuccess ||
       hipMalloc(&c->d_ticket, sizeof(unsigned int)) != hipSuccess || hipMemset(c->d_ticket, 0, sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc(&c->h_feedback, sizeof(Feedback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_feedback), c->h_feedback, 0) != hipSuccess ||
@@ -240,6 +242,8 @@ int cilhip_create(cilhip_ctx** out, int device) {
     delete c;
     return CILHIP_ERR_HIP;
   }
+  if (hipMemset(c->d_state, 0, sizeof(IcpState)) != hipSuccess) { delete c; return CILHIP_ERR_HIP; }
+  c->d_tie_counters = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(c->d_state) + offsetof(IcpState, tie_counters));      // (read with the state: read_state)
   memcpy(c->sort_T, kIdentity, sizeof(kIdentity));
   memcpy(c->nn_T, kIdentity, sizeof(kIdentity));
   *out = c;
@@ -290,7 +294,6 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_safe2) (void)hipFree(c->d_safe2);
   if (c->d_tie_leaf_slot) (void)hipFree(c->d_tie_leaf_slot);
   if (c->d_tie_nodes) (void)hipFree(c->d_tie_nodes);
-  if (c->d_tie_counters) (void)hipFree(c->d_tie_counters);
   if (c->d_ticket) (void)hipFree(c->d_ticket);
   if (c->d_dst_rgb) (void)hipFree(c->d_dst_rgb);
   if (c->d_dst_rgb_sorted) (void)hipFree(c->d_dst_rgb_sorted);
@@ -347,6 +350,11 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "fused_epilogue")) { c->fused_epilogue = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "group_search")) {
+    if (value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0) return fail(c, CILHIP_ERR_INVALID, "group_search: 0, 4, 8 or 16 lanes per query");
+    c->group_lanes = (int)value;
+    return CILHIP_OK;
+  }
   if (!strcmp(key, "tie_rule")) {
     if (value != 0.0 && value != 1.0 && value != 2.0)
       return fail(c, CILHIP_ERR_INVALID, "tie_rule: 0 (lowest index), 1 (the reference's kd-tree order, tables built up front) or 2 (the same, tables built when a tie is first met)");
@@ -866,6 +874,7 @@ static int read_tie_counters(cilhip_ctx* c, unsigned int out[4]) {
 }
 // tie_rule 1: the tables before the first search; refusals of the explicit request (see tie_mode_on)
 static int tie_prepare(cilhip_ctx* c, const char* what) {
+  c->tie_counters_fresh = false;      // (a new search / run: whatever the host holds of the counters is history)
   if (c->tie_rule == 1 && (c->search_dir != 0 || feat6(c) || c->index_offset)) {
     c->err = std::string(what) + ": tie_rule = 1 covers SECOND_TO_FIRST searches over point features on one whole target (tie_rule = 2 applies the reference's order where it is defined)";
     return CILHIP_ERR_UNSUPPORTED;
@@ -878,8 +887,13 @@ static int tie_check_pending(cilhip_ctx* c, bool* again) {
   *again = false;
   if (!tie_mode_on(c) || c->d_tie_leaf_slot || !c->ns || !c->grid.n) return CILHIP_OK;
   unsigned int cnt[4];
-  const int rc = read_tie_counters(c, cnt);
-  if (rc) return rc;
+  if (c->tie_counters_fresh) {      // (a run's read_state has just brought them over with the loop state: no second round trip)
+    memcpy(cnt, c->tie_counters_host, sizeof(cnt));
+  } else {
+    const int rc = read_tie_counters(c, cnt);
+    if (rc) return rc;
+  }
+  c->tie_counters_fresh = false;
   if (cnt[0] == 0u) return CILHIP_OK;
   *again = true;
   CK(c, hipMemsetAsync(c->d_tie_counters, 0, 4 * sizeof(unsigned int), c->stream));      // (the repeated search counts afresh)
@@ -969,6 +983,7 @@ static int launch_search(cilhip_ctx* c, const IterArgs& a) {
     return CILHIP_OK;
   }
   if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel
+  else if (c->group_lanes) launch_search_group(a, c->group_lanes, c->stream);                                  // several lanes per query
   else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);                                 // per-lane global-memory search
   return CILHIP_OK;
 }
@@ -1722,6 +1737,8 @@ static int read_state(cilhip_ctx* c, cilhip_icp_result* out, float* Tprev = null
   IcpState hs;
   CK(c, hipMemcpyAsync(&hs, c->d_state, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
   CK(c, hipStreamSynchronize(c->stream));
+  memcpy(c->tie_counters_host, hs.tie_counters, sizeof(c->tie_counters_host));
+  c->tie_counters_fresh = true;
   memcpy(out->T, hs.T, sizeof(hs.T));
   if (Tprev) memcpy(Tprev, hs.Tprev, sizeof(hs.Tprev));
   out->iterations = (size_t)hs.iterations;
@@ -2408,6 +2425,7 @@ int cilhip_compute_residuals(cilhip_ctx* c, int metric, float w_p2p, float w_p2p
   if (metric != 0 && !c->has_normals) return fail(c, CILHIP_ERR_INVALID, "compute_residuals: combined metric needs target normals");
   int rc = ensure_sorted(c, T);
   if (rc) return rc;
+  c->tie_counters_fresh = false;
   rc = (c->tie_rule == 1 && tie_mode_on(c) && c->ns && c->grid.n) ? build_tie_tables(c) : CILHIP_OK;
   if (rc) return rc;
   launch_init_state(c->d_state, T, c->src_mean, c->stream, nullptr, 0, nullptr, nullptr, c->d_tie_counters);

@@ -87,6 +87,8 @@ struct IcpState {
   // the step the NEXT update is expected to make at most: the last one times the contraction it showed (0 before there are two) --
   // what the cold kernels' forecast of a warm-started iteration's searches is counted against
   float motion_pred;
+  // TieDev::counters of the context's searches live HERE (the context's state only): the host reads them with the loop state, one copy
+  unsigned int tie_counters[4];
 };
 
 enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOTH = 4,
@@ -310,6 +312,7 @@ void launch_search_tiled(const IterArgs& a, int acc_metric, const uint2* tiles, 
                          uint32_t ntiles, hipStream_t s);
 int tiled_partial_rows(uint32_t ntiles);
 void launch_count_deferred(const unsigned long long* mask, uint32_t ntiles, uint32_t* out2, hipStream_t s);
+void launch_search_group(const IterArgs& a, int lanes /*4, 8, 16*/, hipStream_t s);   // exact search, several lanes per query (small / far-from-alignment clouds)
 void launch_search_feat6(const IterArgs& a, hipStream_t s);   // correspondence search over 6-D point+normal features (one lane per query, global memory: small clouds)
 void launch_search_tiled_feat6(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s);   // its LDS-tiled form
 #ifdef CILHIP_EXP_PHASE_CLOCKS

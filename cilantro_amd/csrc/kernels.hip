@@ -207,12 +207,34 @@ __device__ __forceinline__ void scan_range_f6(const float4* __restrict__ pts, ui
   }
 }
 
+// scan_range4 for a caller that keeps the second smallest squared distance it evaluated beside the best key (m2: a median-of-three
+// beside every compare; the clamped re-reads past the end of a range are not counted): the margin keys' bound on every other point,
+// and the tie test of option "tie_rule" for free (m2 == the best distance).
+__device__ __forceinline__ void scan_range4_m2(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, NN& best, float& m2) {
+  if (beg >= end) return;
+  const uint32_t last = end - 1;
+  for (uint32_t j = beg; j < end; j += 4) {
+    uint32_t jj[4];
+    float4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { jj[k] = min(j + (uint32_t)k, last); p[k] = pts[jj[k]]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float e = d2_pinned(qx, qy, qz, p[k].x, p[k].y, p[k].z);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p[k].w);
+      if (j + (uint32_t)k <= last) m2 = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(best.key >> 32)), m2, e);
+      if (key < best.key) { best.key = key; best.pos = jj[k]; }      // (ties: m2 == the best distance at the end -- the caller looks)
+    }
+  }
+}
 // Generic exact search: expanding Chebyshev shells s = s_start, s_start+1, ... around cell (cx,cy,cz)
 // (which may lie outside the grid), each shell scanned as runs of cells along x (contiguous in
 // memory), with conservative box-distance pruning.  `best` carries what inner shells already found.
 // Terminates when the pruning bound proves that no unscanned point can beat or tie the best.
+template <bool M2 = false>
 __device__ __forceinline__ void nn_search_shells(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                              int s_start, NN& best) {
+                                              int s_start, NN& best, float* m2p = nullptr) {
+  float m2 = M2 ? *m2p : 0.0f;
   for (int s = s_start;; ++s) {
     const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1);
     const int y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
@@ -236,20 +258,20 @@ __device__ __forceinline__ void nn_search_shells(const GridDev& g, float qx, flo
           if (xa <= xb) {
             const float gx = axis_gap(qx, g.ox + (float)xa * g.cell, g.ox + (float)(xb + 1) * g.cell, g.margin);
             if ((gyz2 + gx * gx) * KSHRINK <= bd)
-              scan_range4(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
+              { if (M2) scan_range4_m2(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best, m2); else scan_range4(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best); }
           }
         } else {
           if (xlo >= 0 && xlo < g.nx) {
             const float xl = g.ox + (float)xlo * g.cell;
             const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
             if ((gyz2 + gx * gx) * KSHRINK <= bd)
-              scan_range4(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, best);
+              { if (M2) scan_range4_m2(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, best, m2); else scan_range4(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, best); }
           }
           if (xhi >= 0 && xhi < g.nx) {
             const float xl = g.ox + (float)xhi * g.cell;
             const float gx = axis_gap(qx, xl, xl + g.cell, g.margin);
             if ((gyz2 + gx * gx) * KSHRINK <= __uint_as_float((uint32_t)(best.key >> 32)))
-              scan_range4(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, best);
+              { if (M2) scan_range4_m2(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, best, m2); else scan_range4(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, best); }
           }
         }
       }
@@ -266,6 +288,7 @@ __device__ __forceinline__ void nn_search_shells(const GridDev& g, float qx, flo
     b -= g.margin;
     if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) break;
   }
+  if (M2) *m2p = m2;
 }
 
 // The shell search once more, for a caller that wants a MARGIN with its result (the warm-started kernel's listed queries, DESIGN.md
@@ -376,16 +399,15 @@ __device__ __forceinline__ void nn_search_from(const GridDev& g, float qx, float
   const float fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
   const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
   const bool inside = (cx >= 0) & (cx < g.nx) & (cy >= 0) & (cy < g.ny) & (cz >= 0) & (cz < g.nz);
+  int s_shells = 2;      // (ONE call site of the shell search for both ways into it: it is inlined, and the kernels that hold this search live on their registers)
   if (!inside) {
     // query farther than the radius from the whole grid: nothing to find
     const float gx = axis_gap(qx, g.ox, g.ox + (float)g.nx * g.cell, g.margin);
     const float gy = axis_gap(qy, g.oy, g.oy + (float)g.ny * g.cell, g.margin);
     const float gz = axis_gap(qz, g.oz, g.oz + (float)g.nz * g.cell, g.margin);
     if ((gx * gx + gy * gy + gz * gz) * KSHRINK >= max_sq) return;
-    const int s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
-    nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
-    return;
-  }
+    s_shells = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+  } else {
   const uint32_t cid = ((uint32_t)cz * (uint32_t)g.ny + (uint32_t)cy) * (uint32_t)g.nx + (uint32_t)cx;
   const uint32_t b0 = g.cell_start[cid], e0 = g.cell_start[cid + 1];
   scan_range4(g.pts, b0, e0, qx, qy, qz, best);
@@ -488,7 +510,8 @@ __device__ __forceinline__ void nn_search_from(const GridDev& g, float qx, float
     b -= g.margin;
     if (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK) return;
   }
-  nn_search_shells(g, qx, qy, qz, cx, cy, cz, 2, best);
+  }
+  nn_search_shells(g, qx, qy, qz, cx, cy, cz, s_shells, best);
 }
 // The same search for a caller that wants the MARGIN with the result (the cold per-lane iterations of a run whose later
 // iterations may be warm-started): besides the best key it keeps the second smallest squared distance it evaluated
@@ -497,23 +520,6 @@ __device__ __forceinline__ void nn_search_from(const GridDev& g, float qx, float
 // the best so far).  *lb_out = a lower bound on the distance from q to every target point but the match (to every target point
 // without one): min(sqrt(m2), sqrt(cull2), gap to the faces of the block that proved the result); 0 when the result came from the
 // shell search (no bound kept).
-__device__ __forceinline__ void scan_range4_m2(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, NN& best, float& m2) {
-  if (beg >= end) return;
-  const uint32_t last = end - 1;
-  for (uint32_t j = beg; j < end; j += 4) {
-    uint32_t jj[4];
-    float4 p[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { jj[k] = min(j + (uint32_t)k, last); p[k] = pts[jj[k]]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float e = d2_pinned(qx, qy, qz, p[k].x, p[k].y, p[k].z);
-      const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p[k].w);
-      if (j + (uint32_t)k <= last) m2 = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(best.key >> 32)), m2, e);
-      nn_take(best, key, jj[k]);
-    }
-  }
-}
 __device__ __forceinline__ void nn_search_lb(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best, uint2* lst, float* lb_out) {
   best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
   best.pos = NONE_U32;
@@ -532,6 +538,7 @@ __device__ __forceinline__ void nn_search_lb(const GridDev& g, float qx, float q
     const float gg = (gx * gx + gy * gy + gz * gz) * KSHRINK;
     if (gg >= max_sq) { *lb_out = __fsqrt_rn(gg) * 0.999999f; return; }      // every target point lies inside the grid
     const int s0 = max(0, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+    // (queries outside the grid: the plain shell search -- no second-smallest tracking here; a tie among them is noticed by the keys)
     nn_search_shells(g, qx, qy, qz, cx, cy, cz, s0, best);
     return;
   }
@@ -553,7 +560,7 @@ __device__ __forceinline__ void nn_search_lb(const GridDev& g, float qx, float q
     if (hpy) b = fminf(b, gpy);
     if (hmz) b = fminf(b, gmz);
     if (hpz) b = fminf(b, gpz);
-    if (b == INFINITY || bd < b * b * KSHRINK) { *lb_out = fminf(__fsqrt_rn(m2) * 0.999999f, b); return; }
+    if (b == INFINITY || bd < b * b * KSHRINK) { *lb_out = fminf(__fsqrt_rn(m2) * 0.999999f, b); best.tie = (best.pos != NONE_U32 && m2 == bd) ? 1u : 0u; return; }
   }
   const float ax2[3] = {gmx * gmx, 0.0f, gpx * gpx};
   const float ay2[3] = {gmy * gmy, 0.0f, gpy * gpy};
@@ -606,10 +613,12 @@ __device__ __forceinline__ void nn_search_lb(const GridDev& g, float qx, float q
     if (b != INFINITY) b -= g.margin;
     if (b == INFINITY || (b > 0.0f && __uint_as_float((uint32_t)(best.key >> 32)) < b * b * KSHRINK)) {
       *lb_out = fminf(fminf(__fsqrt_rn(m2) * 0.999999f, __fsqrt_rn(cull2)), b);
+      best.tie = (best.pos != NONE_U32 && m2 == __uint_as_float((uint32_t)(best.key >> 32))) ? 1u : 0u;
       return;
     }
   }
-  nn_search_shells(g, qx, qy, qz, cx, cy, cz, 2, best);
+  nn_search_shells<true>(g, qx, qy, qz, cx, cy, cz, 2, best, &m2);
+  best.tie = (best.pos != NONE_U32 && m2 == __uint_as_float((uint32_t)(best.key >> 32))) ? 1u : 0u;
 }
 __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, float qz, float max_sq, NN& best,
                                           uint2* lst) {
@@ -1078,17 +1087,30 @@ static_assert(TILE_MAXROWS <= 64 * 8, "the row scan holds at most 8 rows per lan
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CILHIP_TIE_TRACK
+#define CILHIP_TIE_TRACK 1   /* dev: 1 = every tile variant tracks the second smallest distance (TRACK2), 0 = only the LB / feature variants (round 4) */
+#endif
+#ifndef CILHIP_TIE_MODE
+#define CILHIP_TIE_MODE 2    /* dev: 0 = the tiles do not look at ties, 1 = a suspected tie is unproven, 2 = suspected, then confirmed over the block's runs */
+#endif
+
 // One candidate against the running best.  (x,y) go through packed f32 math (v_pk_add/v_pk_mul: the same
 // IEEE operations per component, so d2 still rounds exactly as ((dx*dx)+(dy*dy))+(dz*dz)).
 // TRACK2 (feature search): also keep the two smallest squared distances met (m12[0] <= m12[1]) -- plain f32 min / median
 // beside the key compare; `counted` = false keeps a re-read candidate out of them.
-// Ties (option "tie_rule"): the tile only has to NOTICE that the smallest distance was met twice -- such a query is not proven here
-// and goes to the clean-up pass, which settles it with the reference's order.  TRACK2 knows from its second smallest distance;
-// otherwise `tie` collects "this candidate's distance equals the smallest so far" (one compare; the mask is scalar).  Sticky, and a
-// point read twice (over-reads past a short run) raises it too: a flag too many costs a deferral, never a result.
+// One candidate against the running best.  (x,y) go through packed f32 math (v_pk_add/v_pk_mul: the same
+// IEEE operations per component, so d2 still rounds exactly as ((dx*dx)+(dy*dy))+(dz*dz)).
+// TRACK2 (feature search): also keep the two smallest squared distances met (m12[0] <= m12[1]) -- plain f32 min / median
+// beside the key compare; `counted` = false keeps a re-read candidate out of them.
+// Ties (option "tie_rule"; and the lowest-index rule itself when the winner was first met through an over-read): the tiles only
+// NOTICE that the smallest distance may have been met twice -- cheaply and conservatively -- and then CONFIRM it exactly over the
+// block's own runs (tile_tie_confirm below); a confirmed tie is not settled in the tile: the clean-up pass applies the tie rule with
+// full keys.  Noticing: TRACK2 variants know from their second smallest distance; the others keep tacc = min over the candidates of
+// (bits(d2) XOR bits(smallest so far)) -- two integer operations in a vector register, 0 once any candidate repeats the smallest
+// distance of its moment (sticky; a point read twice does it too: the confirmation sorts that out).
 template <bool TRACK2 = false>
 __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, float qz, uint32_t pos,
-                                               unsigned long long& bk, uint32_t& bp, float* m12, bool counted, unsigned long long& tie) {
+                                               unsigned long long& bk, uint32_t& bp, float* m12, bool counted, uint32_t& tacc) {
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
@@ -1096,8 +1118,8 @@ __device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, 
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
   const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
-  if (!TRACK2) tie |= __ballot(counted & (__float_as_uint(e) == (uint32_t)(bk >> 32)));      // (a lane mask in scalar registers)
   if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], counted ? e : INFINITY);   // hi(bk) is the smallest so far
+  if (!TRACK2 && CILHIP_TIE_MODE != 0) tacc = min(tacc, (__float_as_uint(e) ^ (uint32_t)(bk >> 32)) | (counted ? 0u : 1u));
   bk = lt ? k : bk;
   bp = lt ? pos : bp;
 }
@@ -1132,7 +1154,7 @@ constexpr int OCT_EXTRA = CILHIP_OCT_EXTRA;
 
 template <bool TRACK2 = false>
 __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 qxy, float qz, uint32_t code,
-                                                   unsigned long long& bk, uint32_t& sel, float* m12, unsigned long long& tie) {
+                                                   unsigned long long& bk, uint32_t& sel, float* m12, uint32_t& tacc) {
   const f32x2 pxy = {p.x, p.y};
   const f32x2 d = qxy - pxy;
   const f32x2 m = d * d;
@@ -1140,8 +1162,8 @@ __device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 q
   const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
   const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
   const bool lt = k < bk;
-  if (!TRACK2) tie |= __ballot(__float_as_uint(e) == (uint32_t)(bk >> 32));
   if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], e);
+  if (!TRACK2 && CILHIP_TIE_MODE != 0) tacc = min(tacc, __float_as_uint(e) ^ (uint32_t)(bk >> 32));
   bk = lt ? k : bk;
   sel = lt ? code : sel;      // code is a compile-time constant: no address arithmetic per candidate
 }
@@ -1193,9 +1215,9 @@ __device__ __forceinline__ float octant_bound(const GridDev& g, float qx, float 
 // radius while there is none): the 6-D feature distance of any candidate but the winner is at least that.
 template <bool TRACK2 = false>
 __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best, uint32_t& bl_out,
-                                              float* second_out = nullptr, float* bound_out = nullptr, bool tie_defer = false) {
+                                              float* second_out = nullptr, float* bound_out = nullptr) {
   float m12[2] = {INFINITY, INFINITY};
-  unsigned long long tie_m = 0ull;
+  uint32_t tacc = 0xFFFFFFFFu;
   const f32x2 qxy = {o.qx, o.qy};
   const float qz = o.qz;
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
@@ -1216,7 +1238,7 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
 #pragma unroll
     for (int c = 0; c < OCT_CAND; ++c) p[c] = t.lpts[rj[k] + c];
 #pragma unroll
-    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel, m12, tie_m);
+    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel, m12, tacc);
     if (TRACK2 && k < 3) {   // ties the next run's address to this run's result: keeps the scheduler from issuing all 16 reads first (64 live registers)
       uint32_t hi = (uint32_t)(bk >> 32);
       asm volatile("" : "+v"(rj[k + 1]), "+v"(hi), "+v"(m12[1]));
@@ -1244,10 +1266,10 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
     const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
-    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
-    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
-    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, c0 | c1 | c2 | c3, tie_m);
+    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
+    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
+    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
+    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
   }
   for (;;) {
     const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
@@ -1258,10 +1280,10 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
     const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, true, tie_m);
-    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, true, tie_m);
-    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, true, tie_m);
-    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, true, tie_m);
+    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, true, tacc);
+    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, true, tacc);
+    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, true, tacc);
+    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, true, tacc);
   }
   best.key = bk;
   // LDS index -> global position: the winner normally lies in the row of its run (one table read); an
@@ -1278,8 +1300,33 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
   bl_out = bl;      // LDS index of the winner (NONE_U32: nothing within the radius): the in-tile accumulation reads the point from there
   const float b = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
   if (TRACK2 && bound_out) *bound_out = b;      // (shrunk) distance from q to the nearest face of the block: every point outside it is at least that far
-  const bool tie = TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : ((tie_m >> (threadIdx.x & 63u)) & 1ull) != 0ull;
-  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK && !(tie_defer && tie && bl != NONE_U32);
+  bool tie = CILHIP_TIE_MODE != 0 && bl != NONE_U32 && (TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : tacc == 0u);
+  if (CILHIP_TIE_MODE == 2 && tie) {
+    // CONFIRMED over the block's own four runs, clamped: another record at exactly the winner's distance.  (What raised the suspicion may
+    // have been the winner read twice -- the unclamped reads of an EMPTY run land on the next row's points, which another run of the
+    // block reads as its own: rows of the grid's pad layers, sparse data -- or a tie at a distance that was beaten later.  A tie
+    // partner OUTSIDE the block cannot coexist with the proof below: it would lie beyond the block's faces.)  A few lanes of some waves.
+    tie = false;
+    const float be = __uint_as_float((uint32_t)(bk >> 32));
+    int ebr = o.ebrow;
+    asm volatile("" : "+v"(ebr));      // (the runs are looked up again HERE: nothing of them stays live across the search for this rare branch)
+    const int crow = ebr >> 16, ceb = ebr & 0xFFFF;
+    for (int k = 0; k < 4; ++k) {
+      const int krow = crow + (k >> 1) * t.RY + (k & 1);
+      const int keb = ceb + ((k >> 1) * t.RY + (k & 1)) * t.W1;
+      const uint32_t kdl = t.rowdelta[krow];
+      const uint32_t j1 = t.lcs[keb + 2] - kdl;
+      for (uint32_t j = t.lcs[keb] - kdl; j < j1; ++j) {
+        const float4 p = t.lpts[j];
+        const f32x2 pxy = {p.x, p.y};
+        const f32x2 d = qxy - pxy;
+        const f32x2 m = d * d;
+        const float dz = __fsub_rn(qz, p.w);
+        tie |= (__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz)) == be) & (j != bl);
+      }
+    }
+  }
+  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK && !tie;
 }
 
 // The full 3x3x3 block of cells around the query's cell, for the queries the octant block did not prove, in
@@ -1294,10 +1341,9 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
 constexpr int B27_CAND = CILHIP_B27_CAND;
 template <bool TRACK2 = false>
 __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
-                                               int cx, int cy, int cz, float max_sq, NN& best, float* second_out = nullptr, float* bound_out = nullptr,
-                                               bool tie_defer = false) {
+                                               int cx, int cy, int cz, float max_sq, NN& best, float* second_out = nullptr, float* bound_out = nullptr) {
   float m12[2] = {INFINITY, INFINITY};      // (TRACK2: [1] = the second smallest squared distance evaluated, as in octant_search)
-  unsigned long long tie_m = 0ull;
+  uint32_t tacc = 0xFFFFFFFFu;
   const f32x2 qxy = {qx, qy};
   unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
   const int row0 = (cz - t.loz) * t.RY + (cy - t.loy);       // region row of the own cell
@@ -1318,7 +1364,7 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
 #pragma unroll
       for (int c = 0; c < INFL; ++c) p[c] = t.lpts[rj + h + c];
 #pragma unroll
-      for (int c = 0; c < INFL; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel, m12, tie_m);
+      for (int c = 0; c < INFL; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel, m12, tacc);
     }
     if (TRACK2 && r < 8) {   // ties the next run's addresses to this run's result: keeps the scheduler from issuing all 54 reads first (see octant_search)
       uint32_t hi = (uint32_t)(bk >> 32);
@@ -1347,10 +1393,10 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
     const uint32_t before = bl;
     for (uint32_t j = t.lcs[e0v + off * t.W1] - dl + (uint32_t)B27_CAND; j < re; j += 4) {
       const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
-      eval_candidate<TRACK2>(p0, qxy, qz, j, bk, bl, m12, true, tie_m);
-      eval_candidate<TRACK2>(p1, qxy, qz, j + 1, bk, bl, m12, true, tie_m);
-      eval_candidate<TRACK2>(p2, qxy, qz, j + 2, bk, bl, m12, true, tie_m);
-      eval_candidate<TRACK2>(p3, qxy, qz, j + 3, bk, bl, m12, true, tie_m);
+      eval_candidate<TRACK2>(p0, qxy, qz, j, bk, bl, m12, true, tacc);
+      eval_candidate<TRACK2>(p1, qxy, qz, j + 1, bk, bl, m12, true, tacc);
+      eval_candidate<TRACK2>(p2, qxy, qz, j + 2, bk, bl, m12, true, tacc);
+      eval_candidate<TRACK2>(p3, qxy, qz, j + 3, bk, bl, m12, true, tacc);
     }
     if (bl != before) brow = row0 + off;
   }
@@ -1371,8 +1417,28 @@ __device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& 
   if (cz - 1 > 0) b = fminf(b, uz);
   if (cz + 2 < g.nz) b = fminf(b, g.cell - uz);
   if (TRACK2) *second_out = m12[1];
-  const bool tie = TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : ((tie_m >> (threadIdx.x & 63u)) & 1ull) != 0ull;
-  if (tie_defer && tie && bl != NONE_U32) { if (TRACK2) *bound_out = 0.0f; return false; }      // (a tie: the clean-up pass settles it with the reference's order)
+  if (CILHIP_TIE_MODE != 0 && bl != NONE_U32 && (TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : tacc == 0u)) {
+    // a tie, or the winner read twice: confirmed over the block's own nine runs (see octant_search); a confirmed tie goes to the clean-up pass
+    bool tie = CILHIP_TIE_MODE == 1;
+    const float be = __uint_as_float((uint32_t)(bk >> 32));
+    int crow = (cz - t.loz) * t.RY + (cy - t.loy), ce0;
+    asm volatile("" : "+v"(crow));
+    ce0 = crow * t.W1 + (cx - t.lox) - 1;
+    for (int r = 0; CILHIP_TIE_MODE == 2 && r < 9; ++r) {
+      const int off = (r / 3 - 1) * t.RY + (r % 3 - 1);
+      const uint32_t dl = t.rowdelta[crow + off];
+      const uint32_t rj = t.lcs[ce0 + off * t.W1] - dl, re = t.lcs[ce0 + off * t.W1 + 3] - dl;
+      for (uint32_t j = rj; j < re; ++j) {
+        const float4 p = t.lpts[j];
+        const f32x2 pxy = {p.x, p.y};
+        const f32x2 d = qxy - pxy;
+        const f32x2 m = d * d;
+        const float dz = __fsub_rn(qz, p.w);
+        tie |= (__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz)) == be) & (j != bl);
+      }
+    }
+    if (tie) { if (TRACK2) *bound_out = 0.0f; return false; }
+  }
   if (b == INFINITY) { if (TRACK2) *bound_out = INFINITY; return true; }
   b = fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin;
   if (TRACK2) *bound_out = b;
@@ -1791,7 +1857,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         pending = true;
       } else if (fast) {
         float second = INFINITY, gapb = 0.0f;
-        unproven = !octant_search<LB>(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb, a.tie.mode != 0);
+        unproven = !octant_search<LB || CILHIP_TIE_TRACK>(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb);
         if (LB && ACC == IM_NONE) mkey = margin_key(best.pos != NONE_U32, second, gapb, mref);
         if (LB && ACC != IM_NONE) mq = margin_q15(best.pos != NONE_U32, second, gapb, mref, g.inv_cell);
         if (LB) {
@@ -1955,7 +2021,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         // (the region holds the octant blocks of the tile's queries, not necessarily all of this query's 3x3x3 block)
         const bool in27 = (cx - 1 >= tq.lox) & (cx + 1 <= hx27) & (cy - 1 >= tq.loy) & (cy + 1 <= hy27) & (cz - 1 >= tq.loz) & (cz + 1 <= hz27);
         float second = INFINITY, gapb = 0.0f;
-        const bool proven = in27 && block27_search<LB>(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best, &second, &gapb, a.tie.mode != 0);
+        const bool proven = in27 && block27_search<LB || CILHIP_TIE_TRACK>(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best, &second, &gapb);
         a.nn_pos[i] = proven ? best.pos : DEFER_MARK;
         if (proven && a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
         if (LB && proven) a.nn_lb[i] = margin_key(best.pos != NONE_U32, second, gapb, MotionRef{tform_lds[16], tform_lds[17]});
@@ -2362,6 +2428,44 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
   }
 }
 
+// The exact search with SEVERAL lanes per query (small clouds, sources far from alignment: one lane per query leaves the chip idle
+// behind chains of dependent trips -- the reference's 120k-point sensor frames are 1 900 waves for 1 024 SIMDs, a tenth of the lanes
+// walking every shell inside the radius): G adjacent lanes share a query, the rows of the block around its cell are dealt to them,
+// the minimum key goes round the group (nn_search_group: the clean-up pass's search), the block grows straight to the size the
+// best found so far needs.  Same keys, same tie rule; no margin key (the generic search keeps no bound on the other points).
+template <int G>
+__global__ __launch_bounds__(ITER_THREADS) void k_search_group(IterArgs a) {
+  const IcpState* __restrict__ st = a.state;
+  if (st->done) return;
+  float T[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  const int sub = threadIdx.x & (G - 1);
+  const uint64_t gid = ((uint64_t)blockIdx.x * ITER_THREADS + threadIdx.x) / G;
+  if (gid >= a.ns) return;      // (whole groups leave together)
+  const uint32_t i = (uint32_t)gid;
+  const float4 s4 = a.src[i];
+  float qx, qy, qz;
+  transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+  NN best;
+  nn_search_group<G>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
+  if (sub == 0) {
+    if (a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)
+      best.pos = tie_settle(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)));
+    a.nn_pos[i] = best.pos;
+    if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+    if (a.nn_lb) a.nn_lb[i] = best.pos != NONE_U32 ? 0.0f : MARGIN_NONE_NO_MATCH;      // (no bound known)
+  }
+}
+void launch_search_group(const IterArgs& a, int lanes, hipStream_t s) {
+  if (a.ns == 0) return;
+  const uint64_t threads = (uint64_t)a.ns * (uint64_t)lanes;
+  const dim3 grid((unsigned)((threads + ITER_THREADS - 1) / ITER_THREADS)), block(ITER_THREADS);
+  if (lanes == 16) hipLaunchKernelGGL((k_search_group<16>), grid, block, 0, s, a);
+  else if (lanes == 4) hipLaunchKernelGGL((k_search_group<4>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_search_group<8>), grid, block, 0, s, a);
+}
+
 void launch_search_feat6(const IterArgs& a, hipStream_t s) {
   if (a.ns == 0) return;
   const uint64_t lanes = (uint64_t)a.ns * FEAT6_GROUP;
@@ -2370,8 +2474,9 @@ void launch_search_feat6(const IterArgs& a, hipStream_t s) {
 
 // The fused iteration kernel.  METRIC: what to accumulate; SEARCH: run the grid search (else reuse the
 // stored matches: Gauss-Newton steps >= 1); STORE: keep (pos,d2) per query for later steps / the host.
+// (the search-only instantiation lives on its four waves per SIMD -- measured: three cost the far-from-alignment regimes a fifth --: held to 128 registers)
 template <int METRIC, bool SEARCH, bool STORE>
-__global__ __launch_bounds__(ITER_THREADS) void k_iter(IterArgs a) {
+__global__ __launch_bounds__(ITER_THREADS, (METRIC == IM_NONE && SEARCH) ? 4 : 1) void k_iter(IterArgs a) {
   using TR = AccTraits<METRIC>;
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;

@@ -501,6 +501,11 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        (cilhip_load_tie_order); feature adaptors, reverse matches and index shards of a target keep the lowest
  *                        index under 2 and are refused (CILHIP_ERR_UNSUPPORTED) under 1.  tests/test_gpu_tie_rule.py: every index
  *                        of the reference's sensor frames and of a cloud with doubled and tripled points equals nanoflann's.
+ *   "group_search" (default 0): lanes per query (4, 8, 16) of the global-memory search's cooperative form, 0 = one lane per query.
+ *   "fused_epilogue" (default 0): 1 = the stage-1 reduction of the partial sums and the epilogue run as ONE launch (the block that takes
+ *                        the last ticket of the 32 stage-1 blocks runs the epilogue behind a device-scope fence).  Bitwise the same
+ *                        results; measured slower than the two launches on this eight-L2 part (0.129 -> 0.136 ms per iteration at
+ *                        10M, 0.037 -> 0.044 at 1M: NOTEBOOK.md) -- kept for A/B runs.
  *   "warm_extra_fraction" (default 0.0625): a query the warm-started form has to search is searched inside the ball of its bound
  *                        plus this fraction of a grid cell -- the room its fresh margin can have.  Larger: more cells per
  *                        search, margins that last longer; measured best at 10M (independent source: 0.25 -> 0.216 ms per
