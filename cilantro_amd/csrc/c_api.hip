@@ -95,7 +95,11 @@ struct cilhip_ctx {
   uint4* d_tie_nodes = nullptr;
   unsigned int* d_tie_counters = nullptr;        // [4] TieDev::counters
   unsigned int* d_ticket = nullptr;              // [1] k_reduce_solve's ticket (zero between launches)
-  int group_lanes = 0;                           // option "group_search": lanes per query of the per-lane search's cooperative form (0 = one lane per query; dev A/B)
+  // option "group_search": the global-memory search with SEVERAL lanes per query (k_search_group: small clouds and sources far from
+  // alignment, where one lane per query leaves the chip idle behind chains of dependent trips).  -1 (default) = the ICP loop decides per
+  // iteration (cold iterations of clouds the tiles do not take: always for clouds below the warm-started form's floor, from the
+  // kernels' own forecast above it); 0 = never; 4 .. 64 = that many lanes in every global-memory search.
+  int group_lanes = -1;
   bool fused_epilogue = false;                   // option "fused_epilogue": stage-1 reduction + epilogue in ONE launch (the last of the 32 stage-1 blocks runs the
                                                  // epilogue).  Bitwise the same results, measured SLOWER: 0.129 -> 0.136 ms per iteration at 10M, 0.037 -> 0.044 at 1M --
                                                  // a device-scope fence costs more on this eight-L2 part than the kernel boundary it removes (NOTEBOOK.md): off
@@ -351,7 +355,8 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "fused_epilogue")) { c->fused_epilogue = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "group_search")) {
-    if (value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0) return fail(c, CILHIP_ERR_INVALID, "group_search: 0, 4, 8 or 16 lanes per query");
+    if (value != -1.0 && value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0 && value != 32.0 && value != 64.0)
+      return fail(c, CILHIP_ERR_INVALID, "group_search: -1 (the loop decides), 0 (never), or 4, 8, 16, 32, 64 lanes per query");
     c->group_lanes = (int)value;
     return CILHIP_OK;
   }
@@ -972,7 +977,8 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
 
 // The SECOND_TO_FIRST search under the transform held by c->d_state: LDS-tiled or per-lane kernel for point features, the
 // 6-D feature search when a normal weight is set.
-static int launch_search(cilhip_ctx* c, const IterArgs& a) {
+static int launch_search(cilhip_ctx* c, const IterArgs& a, int lanes = -1 /* -1: the option's own value when it names a lane count */) {
+  if (lanes < 0) lanes = c->group_lanes > 0 ? c->group_lanes : 0;
   if (feat6(c)) {
     if (c->feature_kind != 1 && (!c->has_normals || !c->d_src_nrm)) return fail(c, CILHIP_ERR_INVALID, "point+normal features need target and source normals");
     if (c->feature_kind == 1 && (!a.feat.src || !a.feat.dst)) return fail(c, CILHIP_ERR_INVALID, "colour features: cilhip_set_color_features first");
@@ -983,7 +989,7 @@ static int launch_search(cilhip_ctx* c, const IterArgs& a) {
     return CILHIP_OK;
   }
   if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);   // LDS-tiled search kernel
-  else if (c->group_lanes) launch_search_group(a, c->group_lanes, c->stream);                                  // several lanes per query
+  else if (lanes) launch_search_group(a, lanes, c->stream);                                                    // several lanes per query (a.warm_pos: the previous matches bound the search)
   else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);                                 // per-lane global-memory search
   return CILHIP_OK;
 }
@@ -1953,9 +1959,18 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
   warm_run_reset(c);
   c->iter_form.clear(); c->trace_form.clear(); c->timed_iter.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
+  // The cooperative search (several lanes per query) for the cold iterations of clouds the tiles do not take: lanes so that the
+  // queries fill the machine; below the warm-started form's floor always (nothing is lost: no margin keys are wanted there), above it
+  // while the cold kernels' forecast says that most queries are far from settled (their margins would not survive the next step) and
+  // the loop is not yet within reach of the warm-started form -- whose entry needs the keys only the one-lane search leaves.
+  const int glanes = c->group_lanes > 0 ? c->group_lanes
+                     : (c->group_lanes < 0 && !use_tiled(c) && !feat6(c) && !c->fused) ? (c->ns <= 400000u ? 16 : c->ns <= 1500000u ? 8 : 0) : 0;
+  bool group_now = glanes != 0 && (c->group_lanes > 0 || !wcap);
+  size_t next_probe = 0, probe_gap = 8;
   bool warm_on = false;       // the loop has been seen to move little: iterations run warm-started until one of them has to search too many of its queries
   unsigned int judged = 0;    // the last published iteration whose listed count has been judged
   bool all_stored = true;     // every iteration enqueued left its matches in nn_pos (finish_run_matches)
+  bool prev_stored = false;   // ... the previous one did
   for (size_t it = 0; it < p->max_iter; ++it) {
     if (paced && it == 1 && wcap && c->warm_start == 1 && !c->warm_banned && !c->trace_form.empty() && (c->trace_form[0] & 0x80)) {
       // The SECOND iteration can already run warm-started when the first one moved the source by a small fraction of a cell (a
@@ -1968,7 +1983,8 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       if (fv.done) break;
       if ((c->trace_form[0] & 0x7f) <= FORM_TILE_ONE_PASS) c->far_mode = (unsigned long long)fv.unproven * 16ull > (unsigned long long)c->ns;
       const bool forecast_ok = !c->warm_forecast || (unsigned long long)fv.listed * 8ull <= (unsigned long long)c->ns;
-      warm_on = fv.iterations == 1u && forecast_ok && warm_worthwhile(c, fv.step);
+      if (glanes && c->group_lanes < 0 && fv.iterations == 1u) group_now = (unsigned long long)fv.listed * 2ull > (unsigned long long)c->ns;
+      warm_on = fv.iterations == 1u && forecast_ok && !group_now && warm_worthwhile(c, fv.step);
     }
     if (paced && it >= 2) {
       // wait (briefly, if at all) until iteration it - 2 has been published
@@ -1984,6 +2000,12 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       // cold iteration whose kernels leave margins (bit 7 of its form) the queries a warm-started iteration after it would have to
       auto form_of = [&](const FbView& f) -> int { return (f.iterations >= 1 && f.iterations <= c->trace_form.size()) ? (int)c->trace_form[f.iterations - 1] : -1; };
       auto is_warm = [&](const FbView& f) { const int fo = form_of(f); return fo >= 0 && ((fo & 0x7f) == FORM_WARM || (fo & 0x7f) == FORM_WARM_FIRST); };
+      if (glanes && c->group_lanes < 0 && wcap) {
+        // a cold iteration that counted (bit 7 of its form): its forecast decides (every eighth iteration of a stretch of cooperative
+        // searches is such a one: below)
+        const int fo = form_of(fv);
+        if (fo >= 0 && (fo & 0x80)) group_now = (unsigned long long)fv.listed * 2ull > (unsigned long long)c->ns;
+      }
       // (a published iteration is judged once: the same one can be the latest at two consecutive looks)
       bool fell = false;
       if (warm_on && c->warm_start == 1 && fv.iterations > judged && is_warm(fv)) {
@@ -2002,9 +2024,10 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
           if (!fell && !c->warm_banned) warm_on = warm_worthwhile(c, fv.step);
         } else {
           // the cold iteration's own forecast: enter only if at most an eighth of the queries would have to be searched
+          // (never out of a stretch of cooperative searches: they leave no keys; its next one-lane iteration's forecast ends the stretch first)
           const int fo = form_of(fv);
           const bool forecast_ok = !c->warm_forecast || !(fo >= 0 && (fo & 0x80)) || (unsigned long long)fv.listed * 8ull <= (unsigned long long)c->ns;
-          warm_on = forecast_ok && warm_worthwhile(c, fv.step);
+          warm_on = forecast_ok && !(glanes && c->group_lanes < 0 && group_now) && warm_worthwhile(c, fv.step);
         }
       }
     }
@@ -2015,6 +2038,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
     const bool warm = wcap && it >= 1 && (c->warm_start == 2 || (paced && warm_on));
     const bool single = one_pass || warm;        // search + accumulation in one kernel
     bool warm_first = false;
+    bool stored_now = true;    // this iteration leaves its matches in nn_pos
     bool counted = false;      // a cold iteration whose kernels count the queries a warm-started iteration after it would have to search
     // (kernel timing on: does THIS iteration carry events?  Every event between dependent kernels idles the device for ~6 us --
     //  two per iteration are a tenth of a warm-started iteration at 10M -- so a caller may ask for a sample: option kernel_timing_stride)
@@ -2030,6 +2054,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
         if (st == 0 && c->fused && !filters_active(c) && !feat6(c)) {
           launch_iter(a, im, true, gn && opt_steps > 1, nb, c->stream);
           all_stored = all_stored && gn && opt_steps > 1;
+          stored_now = gn && opt_steps > 1;
         } else if (st == 0 && warm) {
           IterArgs wa = a;
           wa.warm_pos = c->d_nn_pos;
@@ -2057,15 +2082,24 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
           c->rec_valid = recs; c->lb_fresh = false;
           counted = recs;
           all_stored = all_stored && fa.store_matches != 0;
+          stored_now = fa.store_matches != 0;
         } else if (st == 0) {
           c->rec_valid = false;
           // (search-only form of the tiles: the margin keys of its searches next to the matches)
           IterArgs sa2 = a;
-          const bool keys = wcap && !feat6(c);
+          // (above the warm-started form's floor a stretch of cooperative searches is interrupted by a one-lane search now and then -- after
+          //  8 iterations, then 16, 32 ...: it leaves the margin keys and the forecast the loop's decisions, this form or that, the
+          //  warm-started one, are taken from)
+          const bool probe = c->group_lanes < 0 && wcap && it >= next_probe;
+          if (probe) { next_probe = it + probe_gap; probe_gap *= 2; }
+          const int lanes_it = (group_now && !probe && !use_tiled(c) && !feat6(c)) ? glanes : 0;
+          const bool keys = wcap && !feat6(c) && !lanes_it;
           if (keys) sa2.nn_lb = c->d_nn_lb;
           c->lb_fresh = keys;
           counted = keys;
-          { const int src_rc = launch_search(c, sa2); if (src_rc) return src_rc; }
+          // (the cooperative form: the previous iteration's matches, when it left them in nn_pos, bound every query's search)
+          if (lanes_it && it >= 1 && prev_stored) sa2.warm_pos = c->d_nn_pos;
+          { const int src_rc = launch_search(c, sa2, lanes_it); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing_it) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
@@ -2096,6 +2130,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
         launch_solve(sa, c->stream);
       }
     }
+    prev_stored = stored_now && c->ns != 0;
     // Long runs ("iterate until converged" with a large max_iter): the kernels of a converged run return at once, but
     // the post-filter / reduction launches do not look at the flag, so look at it from the host now and then and stop
     // enqueueing.  Short runs (the reference's default is 15) stay free of host round trips.

@@ -635,11 +635,16 @@ __device__ __forceinline__ void nn_search(const GridDev& g, float qx, float qy, 
 // block does not prove the result, s grows straight to the size the best found so far needs.  All control flow is
 // uniform within a group.  `sub` = lane index inside the group; every lane of the group returns the same result.
 // FEAT6: candidates are compared by the 6-D feature distance (the proof still uses the 3-D geometry: d6 >= d3).
-template <int G, bool FEAT6 = false>
+// INIT: `best` comes in holding a target point KNOWN to lie within the radius (the previous iteration's match under the current
+// transform, the same on every lane of the group): the first block is the one that point's distance needs, and rows beyond that
+// distance are never opened -- the search looks only where something nearer, or as near, can be; the result is the same.
+template <int G, bool FEAT6 = false, bool INIT = false>
 __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, float qy, float qz, float max_sq, int sub, int s_start, NN& best,
                                                 const Feat6* f6 = nullptr) {
-  best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
-  best.pos = NONE_U32;
+  if (!INIT) {
+    best.key = ((unsigned long long)__float_as_uint(max_sq) << 32);
+    best.pos = NONE_U32;
+  }
   best.tie = 0;
   const float BIG = 1.0e9f;
   const float fx = fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG);
@@ -654,6 +659,8 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
   }
   // first block size that reaches the grid at all
   int s = max(s_start, max(max(-cx, cx - (g.nx - 1)), max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1)))));
+  if (INIT && best.pos != NONE_U32)      // ... and that holds the ball of the known point's distance whatever the offset of q in its cell
+    s = max(s, (int)fminf(sqrtf(__uint_as_float((uint32_t)(best.key >> 32))) * g.inv_cell + 1.0f, (float)(g.nx + g.ny + g.nz)));
   for (;;) {
     const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1);
     const int y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
@@ -667,10 +674,23 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
       for (int k = sub; k < nrows; k += G) {
         const float zl = g.oz + (float)z * g.cell, yl = g.oy + (float)y * g.cell;
         const float gz = axis_gap(qz, zl, zl + g.cell, g.margin), gy = axis_gap(qy, yl, yl + g.cell, g.margin);
-        if ((gz * gz + gy * gy + gx2) * KSHRINK <= __uint_as_float((uint32_t)(best.key >> 32))) {
+        const float gyz2 = gz * gz + gy * gy, bd0 = __uint_as_float((uint32_t)(best.key >> 32));
+        if ((gyz2 + gx2) * KSHRINK <= bd0) {
           const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-          if (FEAT6) scan_range_f6(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, *f6, best);
-          else scan_range4(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, best);
+          // the row clipped to the cells the ball of the best distance so far can reach along x (a surface's rows hold many points the
+          // ball does not come near): reach = sqrt(bd / KSHRINK - gyz2), rounded UP, plus the grid margin -- a superset of the cells
+          // whose gap admits a candidate, so nothing that could win or tie is skipped
+          int xa_r = xa, xb_r = xb;
+          const float w2 = bd0 * (1.0f / KSHRINK) * 1.000001f - gyz2;
+          if (w2 < 1.0e30f) {
+            const float w = sqrtf(fmaxf(w2, 0.0f)) * 1.000001f + 2.0f * g.margin;
+            xa_r = max(xa, (int)floorf(fminf(fmaxf((qx - w - g.ox) * g.inv_cell, -BIG), BIG)) - 0);
+            xb_r = min(xb, (int)floorf(fminf(fmaxf((qx + w - g.ox) * g.inv_cell, -BIG), BIG)) + 0);
+          }
+          if (xa_r <= xb_r) {
+            if (FEAT6) scan_range_f6(g.pts, g.cell_start[row + xa_r], g.cell_start[row + xb_r + 1], qx, qy, qz, *f6, best);
+            else scan_range4(g.pts, g.cell_start[row + xa_r], g.cell_start[row + xb_r + 1], qx, qy, qz, best);
+          }
         }
         y += G;
         while (y > y1) { y -= wy; ++z; }
@@ -2448,7 +2468,17 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_group(IterArgs a) {
   float qx, qy, qz;
   transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
   NN best;
-  nn_search_group<G>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
+  best.key = ((unsigned long long)__float_as_uint(a.max_sq) << 32);
+  best.pos = NONE_U32;
+  if (a.warm_pos != nullptr) {      // the previous iteration's match bounds the search (every lane of the group reads the same record)
+    const uint32_t w = a.warm_pos[i];
+    if (w != NONE_U32) {
+      const float4 pw = a.grid.pts[w];
+      const float e = d2_pinned(qx, qy, qz, pw.x, pw.y, pw.z);
+      if (e < a.max_sq) { best.key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(pw.w); best.pos = w; }
+    }
+  }
+  nn_search_group<G, false, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
   if (sub == 0) {
     if (a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)
       best.pos = tie_settle(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)));
@@ -2461,7 +2491,9 @@ void launch_search_group(const IterArgs& a, int lanes, hipStream_t s) {
   if (a.ns == 0) return;
   const uint64_t threads = (uint64_t)a.ns * (uint64_t)lanes;
   const dim3 grid((unsigned)((threads + ITER_THREADS - 1) / ITER_THREADS)), block(ITER_THREADS);
-  if (lanes == 16) hipLaunchKernelGGL((k_search_group<16>), grid, block, 0, s, a);
+  if (lanes == 64) hipLaunchKernelGGL((k_search_group<64>), grid, block, 0, s, a);
+  else if (lanes == 32) hipLaunchKernelGGL((k_search_group<32>), grid, block, 0, s, a);
+  else if (lanes == 16) hipLaunchKernelGGL((k_search_group<16>), grid, block, 0, s, a);
   else if (lanes == 4) hipLaunchKernelGGL((k_search_group<4>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((k_search_group<8>), grid, block, 0, s, a);
 }

@@ -501,7 +501,14 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        (cilhip_load_tie_order); feature adaptors, reverse matches and index shards of a target keep the lowest
  *                        index under 2 and are refused (CILHIP_ERR_UNSUPPORTED) under 1.  tests/test_gpu_tie_rule.py: every index
  *                        of the reference's sensor frames and of a cloud with doubled and tripled points equals nanoflann's.
- *   "group_search" (default 0): lanes per query (4, 8, 16) of the global-memory search's cooperative form, 0 = one lane per query.
+ *   "group_search" (default -1): the global-memory search with SEVERAL lanes per query (small clouds, sources far from alignment: one
+ *                        lane per query leaves the chip idle behind chains of dependent trips -- the reference's 120k-point sensor
+ *                        frames: 0.34 -> 0.12 ms per iteration).  G adjacent lanes share a query: the rows of the block around its
+ *                        cell are dealt to them, each row clipped to the cells the ball of the best distance so far reaches, the
+ *                        minimum key goes round the group, the previous iteration's match bounds the search.  Same keys, same tie
+ *                        rule, same results.  -1 = the ICP loop decides per iteration (clouds the tiles do not take: always below
+ *                        the warm-started form's floor of 65 536 points; above it while the cold kernels' forecast says most
+ *                        queries are far from settled); 0 = never; 4, 8, 16, 32, 64 = that many lanes in every such search.
  *   "fused_epilogue" (default 0): 1 = the stage-1 reduction of the partial sums and the epilogue run as ONE launch (the block that takes
  *                        the last ticket of the 32 stage-1 blocks runs the epilogue behind a device-scope fence).  Bitwise the same
  *                        results; measured slower than the two launches on this eight-L2 part (0.129 -> 0.136 ms per iteration at

@@ -297,9 +297,10 @@ def test_real_sensor_frames_every_form(Context, orc):
     report = {}
     tree_ref = orc.KDTree(D, use_ref=orc.ref_available())
     cases = (("frame_1 vs moved+jittered frame_1", src_self, np.float32(0.01 * 0.01)), ("frame_1 vs frame_2", np.ascontiguousarray(p2), np.float32(0.02 * 0.02)))
-    forms = (("adaptive", (), None), ("warm forced, per-lane start", (("warm_start", 2), ("tiled", 0)), 1), ("warm forced, tiled start", (("warm_start", 2), ("tiled", 2)), 1),
+    forms = (("adaptive", (), None), ("warm forced, per-lane start", (("warm_start", 2), ("tiled", 0), ("group_search", 0)), 1), ("warm forced, tiled start", (("warm_start", 2), ("tiled", 2)), 1),
              ("tiles one pass", (("warm_start", 1), ("tiled", 2), ("tile_accumulation", 2)), 1), ("tiles two passes", (("warm_start", 0), ("tiled", 2), ("tile_accumulation", 0)), 1),
-             ("per lane", (("warm_start", 0), ("tiled", 0)), 1))
+             ("per lane", (("warm_start", 0), ("tiled", 0), ("group_search", 0)), 1), ("16 lanes per query", (("warm_start", 0), ("tiled", 0), ("group_search", 16)), 1),
+             ("8 lanes per query, warm forced", (("warm_start", 2), ("tiled", 0), ("group_search", 8)), 1))
     for cname, S, r2 in cases:
         po = orc.make_params(metric=1, max_iter=6, conv_tol=0.0, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
         # Two oracle loops.  (1) the reference's order of ties: nanoflann keeps the first candidate met in ITS tree traversal

@@ -154,7 +154,8 @@ def test_every_kernel_form_resolves_ties(Context, orc):
     po = orc.make_params(metric=1, max_iter=8, conv_tol=0.0, max_sq_dist=float(r2), mode=orc.MODE_MIXED)
     ro = orc.icp_run(D, N, S, po)
     forms = {"adaptive": {}, "tiles one pass": {"tiled": 2, "tile_accumulation": 2, "warm_start": 0},
-             "tiles two passes": {"tiled": 2, "tile_accumulation": 0, "warm_start": 0}, "per lane": {"tiled": 0, "warm_start": 0},
+             "tiles two passes": {"tiled": 2, "tile_accumulation": 0, "warm_start": 0}, "per lane": {"tiled": 0, "warm_start": 0, "group_search": 0}, "16 lanes per query": {"tiled": 0, "warm_start": 0, "group_search": 16},
+             "lanes chosen by the loop": {"tiled": 0, "warm_start": 0},
              "per lane fused": {"tiled": 0, "warm_start": 0, "fused": 1},
              "warm forced, tiled start": {"tiled": 2, "warm_start": 2}, "warm forced, per-lane start": {"tiled": 0, "warm_start": 2}}
     out = {}

@@ -23,11 +23,12 @@ src_self = ((p1 + jit).astype(np.float64) @ Tm[:3, :3].T + Tm[:3, 3]).astype(np.
 keep = p1[:, 0] > -0.4
 D, N = np.ascontiguousarray(p1[keep]), np.ascontiguousarray(n1[keep])
 cases = (("frame_1 vs moved+jittered frame_1", src_self, np.float32(0.01 * 0.01)), ("frame_1 vs frame_2", np.ascontiguousarray(p2), np.float32(0.02 * 0.02)))
-forms = (("adaptive", ()), ("warm forced, per-lane start", (("warm_start", 2), ("tiled", 0))), ("warm forced, tiled start", (("warm_start", 2), ("tiled", 2))),
+forms = (("adaptive", ()), ("warm forced, per-lane start", (("warm_start", 2), ("tiled", 0), ("group_search", 0))), ("warm forced, tiled start", (("warm_start", 2), ("tiled", 2))),
          ("tiles one pass", (("warm_start", 1), ("tiled", 2), ("tile_accumulation", 2))), ("tiles two passes", (("warm_start", 0), ("tiled", 2), ("tile_accumulation", 0))),
-         ("per lane", (("warm_start", 0), ("tiled", 0))), ("adaptive, tie_rule = 0 (lowest index)", (("tie_rule", 0),)),
-         ("4 lanes per query", (("warm_start", 0), ("tiled", 0), ("group_search", 4))), ("8 lanes per query", (("warm_start", 0), ("tiled", 0), ("group_search", 8))),
-         ("16 lanes per query", (("warm_start", 0), ("tiled", 0), ("group_search", 16))))
+         ("per lane", (("warm_start", 0), ("tiled", 0), ("group_search", 0))), ("adaptive, tie_rule = 0 (lowest index)", (("tie_rule", 0),)),
+         ("adaptive, one lane per query only (group_search 0)", (("group_search", 0),)),
+         ("8 lanes per query", (("warm_start", 0), ("tiled", 0), ("group_search", 8))),
+         ("16 lanes per query", (("warm_start", 0), ("tiled", 0), ("group_search", 16))), ("32 lanes per query", (("warm_start", 0), ("tiled", 0), ("group_search", 32))))
 print(f"{'registration / form':72s} {'ms/iter':>8s} {'one-pass':>8s} {'two-pass':>8s} {'warm':>5s} {'ncorr':>8s} {'step/cell (last)':>16s} {'ties resolved':>13s} {'tables ms':>9s}")
 for cname, S, r2 in cases:
     for fname, opts in forms:

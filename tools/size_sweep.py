@@ -10,7 +10,10 @@ sizes = [int(float(x)) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 els
 for n in sizes:
     d = syn.make_pair(n, n, with_normals=True)
     for metric in (capi.METRIC_COMBINED, capi.METRIC_POINT_TO_POINT):
-        ctx = Context(); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+        ctx = Context()
+        for kv in filter(None, os.environ.get("CILHIP_OPTS", "").split(",")):      # dev: CILHIP_OPTS="group_search=0,tie_rule=0"
+            ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+        ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
         p = capi.IcpParams(); ctx._L.cilhip_icp_default_params(C.byref(p))
         p.metric, p.max_sq_dist, p.max_iter, p.conv_tol = metric, float(d["max_sq_dist"]), 20, 0.0
         ctx.icp_run(p); ctx.icp_run(p)
