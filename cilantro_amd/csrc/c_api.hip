@@ -2894,6 +2894,18 @@ int cilhip_rank_comm_unique_id(unsigned char id_out[128]) {
   return CILHIP_OK;
 }
 
+// Everything of cilhip_rank_comm_init that can fail on ONE rank alone -- opening librccl, the buffer of the rows -- done beforehand, so
+// that the ranks can agree (one MIN over whatever channel the launcher has) to enter the collective ncclCommInitRank only when every
+// one of them will get through: a rank that bailed out before the collective would leave its peers waiting inside it.
+int cilhip_rank_comm_prepare(cilhip_ctx* c) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (!g_rank_rccl.load()) return fail(c, CILHIP_ERR_UNSUPPORTED, "rank_comm_prepare: librccl.so.1 could not be opened");
+  CK(c, hipSetDevice(c->device));
+  if (!c->d_rank_sums && hipMalloc(&c->d_rank_sums, (size_t)RANK_ROWS * SUMS_MAX * sizeof(double)) != hipSuccess)
+    return fail(c, CILHIP_ERR_HIP, "rank_comm_prepare: out of device memory");
+  return CILHIP_OK;
+}
+
 int cilhip_rank_comm_init(cilhip_ctx* c, const unsigned char id[128], int nranks, int rank) {
   if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return CILHIP_ERR_INVALID;
   if (c->rank_comm) return fail(c, CILHIP_ERR_INVALID, "rank_comm_init: the context already holds a communicator");

@@ -46,17 +46,25 @@ def init_rank_comm(ctx, dist, group=None, device="cuda"):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ok = torch.ones(1, dtype=torch.int32, device=device)
     uid = torch.zeros(128, dtype=torch.uint8, device=device)
-    if rank == 0:
-        try:
+    # (1) what can fail on ONE rank alone -- opening librccl, this rank's buffer; rank 0: creating the id -- happens BEFORE the
+    #     collective init, and the ranks agree on the outcome: a rank that bailed out early would leave its peers waiting inside
+    #     ncclCommInitRank (a deadlock, not a fallback)
+    try:
+        prep = getattr(ctx, "rank_comm_prepare", None)
+        if prep is not None:
+            prep()
+        if rank == 0:
             uid.copy_(torch.from_numpy(Context.rank_comm_unique_id()).to(device))
-        except Exception:
-            ok.zero_()
+    except Exception:
+        ok.zero_()
     if world > 1:
-        src = dist.get_global_rank(group, 0) if group is not None else 0
-        dist.broadcast(uid, src=src, group=group)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
     if int(ok.item()) == 0:
         return False
+    if world > 1:
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(uid, src=src, group=group)
+    # (2) the collective init: every rank enters it
     try:
         ctx.rank_comm_init(uid.cpu().numpy(), world, rank)
     except Exception:

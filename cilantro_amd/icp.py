@@ -244,6 +244,10 @@ class Context:
             raise capi.CilhipError(rc, "cilhip_rank_comm_unique_id failed (librccl not loadable?)")
         return buf
 
+    def rank_comm_prepare(self):
+        """what rank_comm_init can fail at on this rank alone (librccl, its buffer), done beforehand (cilhip_rank_comm_prepare)"""
+        self._ck(self._L.cilhip_rank_comm_prepare(self._h))
+
     def rank_comm_init(self, unique_id, nranks, rank):
         """this context as rank `rank` of `nranks` (collective: every rank calls it with the same id)"""
         uid = np.ascontiguousarray(unique_id, np.uint8)

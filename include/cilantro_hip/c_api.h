@@ -429,6 +429,9 @@ int cilhip_multi_shard_sizes(const cilhip_multi* m, int rank, size_t* n_target, 
  * iterations (convergence, cilhip_get_slab_violation_state).  Every rank must ask for the same number of iterations.  The
  * reference has no counterpart; the loop is IterativeClosestPointBase::estimate (registration/icp_base.hpp:68-87). */
 int cilhip_rank_comm_unique_id(unsigned char id_out[128]);
+/* What cilhip_rank_comm_init can fail at on one rank alone (opening librccl, its buffer), beforehand: the ranks agree -- one MIN over the
+ * launcher's channel -- before any of them enters the collective init (cilantro_amd/distributed.py init_rank_comm). */
+int cilhip_rank_comm_prepare(cilhip_ctx* ctx);
 int cilhip_rank_comm_init(cilhip_ctx* ctx, const unsigned char id[128], int nranks, int rank);
 int cilhip_rank_comm_destroy(cilhip_ctx* ctx);
 int cilhip_icp_iterate_ranked(cilhip_ctx* ctx, int iterations);

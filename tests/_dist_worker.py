@@ -253,11 +253,32 @@ def main_rank_comm():
         icp.Context.rank_comm_unique_id = staticmethod(lambda: (_ for _ in ()).throw(RuntimeError("rank 0 has no librccl")))
         none_ctx = FakeCtx(False)
         r3 = distributed.init_rank_comm(none_ctx, dist, None, "cpu")
+        icp.Context.rank_comm_unique_id = staticmethod(lambda: (np.arange(128) * 7 % 251).astype(np.uint8))
+
+        class PrepCtx(FakeCtx):      # an init that IS a collective (as ncclCommInitRank): a rank entering it alone would hang
+            def __init__(self, prep_fail):
+                super().__init__(False)
+                self.prep_fail, self.entered = prep_fail, 0
+
+            def rank_comm_prepare(self):
+                if self.prep_fail:
+                    raise RuntimeError("librccl cannot be opened on this rank")
+
+            def rank_comm_init(self, uid, nranks, r):
+                self.entered += 1
+                dist.barrier()
+                super().rank_comm_init(uid, nranks, r)
+
+        prep_bad = PrepCtx(rank == world - 1)
+        r4 = distributed.init_rank_comm(prep_bad, dist, None, "cpu")
+        prep_ok = PrepCtx(False)
+        r5 = distributed.init_rank_comm(prep_ok, dist, None, "cpu")
     finally:
         icp.Context.rank_comm_unique_id = real
     rows = [None] * world
     dist.all_gather_object(rows, {"rank": rank, "r1": r1, "got": [ok_ctx.got[0].hex(), ok_ctx.got[1], ok_ctx.got[2]] if ok_ctx.got else None, "made": len(made),
-                                  "r2": r2, "bad_destroyed": bad_ctx.destroyed, "r3": r3, "none_got": none_ctx.got})
+                                  "r2": r2, "bad_destroyed": bad_ctx.destroyed, "r3": r3, "none_got": none_ctx.got,
+                                  "r4": r4, "r4_entered": prep_bad.entered, "r5": r5, "r5_entered": prep_ok.entered})
     if rank == 0:
         print("RESULT " + json.dumps({"world": world, "rows": rows}))
     dist.destroy_process_group()

@@ -125,6 +125,9 @@ def test_rank_communicator_handshake_over_gloo():
         assert row["made"] == (2 if k == 0 else 0)                       # (two successful creations, both on rank 0)
         assert row["r2"] is False and row["bad_destroyed"] == 1          # one rank failed: all leave
         assert row["r3"] is False and row["none_got"] is None            # no id: nobody tries to join
+        # a rank that cannot even open librccl says so BEFORE the collective init: nobody enters it (entering it alone would hang)
+        assert row["r4"] is False and row["r4_entered"] == 0
+        assert row["r5"] is True and row["r5_entered"] == 1
 
 
 def test_slab_partition_is_exact(orc):
