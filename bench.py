@@ -331,7 +331,7 @@ def bench_icp(a, torch, rank, world, local_rank):
         # the form the timed region spent most kernel time in (average of the timed launches x all launches of the form)
         dom = max((f for f in ft if ft[f][1] > 0), key=lambda f: ft[f][0] / ft[f][1] * n_form[f], default=None) if launches > 0 else None
         fused = dom is not None and dom != 0
-        traffic, traffic_note = None, "no PMC measurement of this build / workload committed"
+        traffic, traffic_note, traffic_cold = None, "no PMC measurement of this build / workload committed", None
         import glob
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):      # newest round first
             try:
@@ -339,6 +339,7 @@ def bench_icp(a, torch, rank, world, local_rank):
                 w = tj["workload"]
                 if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and tj.get("form") == dom:
                     traffic, traffic_note = float(tj["traffic_bytes_per_launch"]), os.path.basename(tf) + ": " + tj.get("method", "")
+                    traffic_cold = tj.get("cold_forms")      # {"plain_tile": bytes per launch, "record_writing_tile": ...} of the same passes
                     break
                 if traffic_note.startswith("no PMC"):      # (name the newest file only)
                     traffic_note = "profiles/" + os.path.basename(tf) + " was measured on another build, workload or kernel form: not quoted"
@@ -358,7 +359,12 @@ def bench_icp(a, torch, rank, world, local_rank):
                               "timed region's kernel time; a form's average = per stratum (first iteration of a stretch of the form / the rest) the mean of the timed "
                               "launches, weighted by the stratum's share of the run's iterations",
                     "forms_in_timed_region": forms,
-                    "all_forms_avg_kernel_ms": search_ms / launches}
+                    # HBM bytes actually moved / time / peak (the counter traffic of the same build: wasted re-reads count as work here)
+                    "frac_moved_bytes": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    # every search / one-pass kernel of the timed region, launch-weighted: sum over the forms of (average launch x launches) / steps
+                    # (not in it: the reduction and epilogue kernels of an iteration, ~15 us, and the gaps between dependent launches)
+                    "kernel_ms_per_step": sum(ms / n * n_form[f] for f, (ms, n) in ft.items() if n > 0) / max(a.steps, 1),
+                    "timed_launches_unweighted_avg_kernel_ms": search_ms / launches}
             if 1 in ft and ft[1][1] > 0 and dom != 1:
                 # the COLD form beside the headline: the LDS-tiled search with the accumulation inside the tile -- what the first
                 # iterations of every registration, and every iteration of a source that is not the target's points plus small
@@ -367,6 +373,16 @@ def bench_icp(a, torch, rank, world, local_rank):
                 out_cold = {"bound": "hbm", "kernel": FORMS[1][0], "form": 1, "avg_kernel_ms": cold_ms, "launches": n_form[1],
                             "algorithmic_bytes_per_launch": one_pass_bytes, "achieved": one_pass_bytes / (cold_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": one_pass_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                # the two tile kernels behind that average, by the iteration they ran in: iteration 0 is the plain tile, the later ones also
+                # write the warm-started form's match records (k_search_tiled<metric, false, true>)
+                it_ms = dict(ctx.last_iteration_timing()) if not sharded else {}
+                for name, its in (("plain_tile", [0]), ("record_writing_tile", [i for i in range(1, len(tr_forms)) if tr_forms[i] == 1])):
+                    ms_l = [it_ms[i] for i in its if i in it_ms and i < len(tr_forms) and tr_forms[i] == 1]
+                    if ms_l:
+                        m = sum(ms_l) / len(ms_l)
+                        tb = (traffic_cold or {}).get(name)
+                        out_cold[name] = {"avg_kernel_ms": m, "timed_launches": len(ms_l), "frac": one_pass_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "traffic": tb, "frac_moved_bytes": (tb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None}
             else:
                 out_cold = None
             if dom == 0:
@@ -392,6 +408,9 @@ def bench_icp(a, torch, rank, world, local_rank):
             "setup_ms": t_setup * 1e3, "source_sort_ms": sort_ms, "loop_ms_hip_events": loop_ms,
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,
             "iterations_one_pass": one_pass_iters, "iterations_two_pass": two_pass_iters, "iterations_warm_started": ctx.last_warm_iterations(),
+            # option "tie_rule" (default 2): exactly equidistant nearest points take the reference's kd-tree order, resolved on the device; the order
+            # tables are built on the host's cores the first time a search of this target meets a tie (here: in the warm-up run, if at all)
+            "tie_order": dict(ctx.tie_order_info(), tied_queries_resolved_in_timed_run=ctx.tie_rule_stats()[0], not_the_lowest_index=ctx.tie_rule_stats()[1]),
             "roofline": roof, "roofline_cold": out_cold if dom is not None else None,
         }
     if not sharded and not a.no_extras:

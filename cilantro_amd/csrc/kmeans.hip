@@ -119,6 +119,126 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
   }
 }
 
+// ---- the same assignment, PRUNED exactly -------------------------------------------------------------------------------------
+// The brute-force pass evaluates n*k distances (5e10 at 50M x 1024: 8 ms, within 15 % of the instruction floor of doing that).  The
+// argmin itself only needs the centroids NEAR a point: the k centroids are binned into a uniform grid (about one per cell, built on the
+// host every Lloyd iteration -- k is a thousand --, sorted by cell, x fastest), the grid lives in LDS, and a point looks at the 3x3x3
+// block of cells around its own: nine runs of the sorted list.  The distance is the brute-force branch's, operation for operation
+// (dx*dx + (dy*dy + dz*dz), d = c - x, no contraction), the winner the lexicographic minimum of (distance, index) -- what a chain of
+// strict '<' over ascending j leaves.  PROOF of a result: every centroid outside the block lies beyond the block's faces (on the sides
+// where the grid goes on), so if the best distance is strictly below (gap - margin)^2 (1 - 2^-20) -- margin = cell / 1024 for the
+// rounding of the binning, the factor for the <= 2^-22 relative rounding of a computed distance -- nothing outside can win or tie.
+// A point whose block does not prove its result (a centroid-free neighbourhood: clustered centroids, outliers), and every point with a
+// non-finite coordinate, takes the exhaustive loop over all k centroids, out of LDS, with the same compare: exactness never depends on
+// the grid, only speed does.  Labels are bit-identical to the brute-force kernel's (tests/test_gpu_parity.py: both run, compared).
+struct KmGrid { float ox, oy, oz, cell, inv_cell, margin; int g; uint32_t kreal; };
+
+__global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr, const float4* __restrict__ cs_g, const uint32_t* __restrict__ cstart_g) {
+  extern __shared__ long long lsum[];                                     // [kpad*4] sums, then the grid
+  float4* const cs = reinterpret_cast<float4*>(lsum + (size_t)a.k * 4);   // [kpad] sorted centroids {x, y, z, bits(j)}
+  uint32_t* const cstart = reinterpret_cast<uint32_t*>(cs + a.k);         // [g^3 + 1]
+  const int g = gr.g, ncell = g * g * g;
+  for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS) lsum[t] = 0;
+  for (uint32_t t = threadIdx.x; t < a.k; t += KM_THREADS) cs[t] = cs_g[t];
+  for (int t = threadIdx.x; t <= ncell; t += KM_THREADS) cstart[t] = cstart_g[t];
+  __syncthreads();
+  unsigned int changed = 0;
+  for (uint32_t i = blockIdx.x * KM_THREADS + threadIdx.x; i < a.n; i += gridDim.x * KM_THREADS) {
+    const float px = a.xyz[3 * (size_t)i], py = a.xyz[3 * (size_t)i + 1], pz = a.xyz[3 * (size_t)i + 2];
+    float bd = INFINITY;
+    uint32_t bj = 0xFFFFFFFFu;
+    auto take = [&](const float4 c) {
+      const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
+      const float d = dx * dx + (dy * dy + dz * dz);      // (-ffp-contract=off: the brute-force branch's value, bit for bit)
+      const uint32_t j = __float_as_uint(c.w);
+      const bool better = (d < bd) | ((d == bd) & (j < bj));
+      bd = better ? d : bd;
+      bj = better ? j : bj;
+    };
+    bool proven = false;
+    const bool finite = (fabsf(px) < INFINITY) & (fabsf(py) < INFINITY) & (fabsf(pz) < INFINITY);
+    if (finite) {
+      const int cx = min(max((int)floorf((px - gr.ox) * gr.inv_cell), 0), g - 1), cy = min(max((int)floorf((py - gr.oy) * gr.inv_cell), 0), g - 1),
+                cz = min(max((int)floorf((pz - gr.oz) * gr.inv_cell), 0), g - 1);
+      const int xa = max(cx - 1, 0), xb = min(cx + 1, g - 1);
+      for (int zc = max(cz - 1, 0); zc <= min(cz + 1, g - 1); ++zc)
+        for (int yc = max(cy - 1, 0); yc <= min(cy + 1, g - 1); ++yc) {
+          const int row = (zc * g + yc) * g;
+          const uint32_t t1 = cstart[row + xb + 1];
+          for (uint32_t t = cstart[row + xa]; t < t1; ++t) take(cs[t]);
+        }
+      // distance from the point to the faces of the block beyond which the grid goes on
+      float gap = INFINITY;
+      if (cx - 1 > 0) gap = fminf(gap, px - (gr.ox + (float)(cx - 1) * gr.cell));
+      if (cx + 1 < g - 1) gap = fminf(gap, (gr.ox + (float)(cx + 2) * gr.cell) - px);
+      if (cy - 1 > 0) gap = fminf(gap, py - (gr.oy + (float)(cy - 1) * gr.cell));
+      if (cy + 1 < g - 1) gap = fminf(gap, (gr.oy + (float)(cy + 2) * gr.cell) - py);
+      if (cz - 1 > 0) gap = fminf(gap, pz - (gr.oz + (float)(cz - 1) * gr.cell));
+      if (cz + 1 < g - 1) gap = fminf(gap, (gr.oz + (float)(cz + 2) * gr.cell) - pz);
+      const float gb = gap - gr.margin;
+      proven = gap == INFINITY || (gb > 0.0f && bd < gb * gb * 0.99999905f);
+    }
+    if (!proven) {      // every centroid: the definition
+      bd = INFINITY; bj = 0xFFFFFFFFu;
+      for (uint32_t t = 0; t < gr.kreal; ++t) take(cs[t]);
+    }
+    const uint32_t b = (bd < INFINITY && bj != 0xFFFFFFFFu) ? bj : 0u;      // (no finite minimum at all: label 0, as a chain of strict compares from (inf, 0) leaves it)
+    changed += (a.labels[i] != b) ? 1u : 0u;
+    a.labels[i] = b;
+    if (a.accumulate) {
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 0], (unsigned long long)llrint((double)px * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 1], (unsigned long long)llrint((double)py * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 2], (unsigned long long)llrint((double)pz * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 3], 1ull);
+    }
+  }
+  if (changed) atomicAdd(a.changed, changed);
+  if (a.accumulate) {
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS)
+      if (lsum[t] != 0) atomicAdd((unsigned long long*)&a.sums[t], (unsigned long long)lsum[t]);
+  }
+}
+
+// The centroids' grid (host; k <= 2048): about one centroid per cell.  false: no usable grid (a non-finite centroid, fewer than 64
+// centroids, all of them in one spot) -- the brute-force pass takes the iteration.
+static bool build_centroid_grid(const float* c, size_t k, KmGrid& gr, std::vector<float4>& cs, std::vector<uint32_t>& cstart) {
+  if (k < 64) return false;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t j = 0; j < k; ++j)
+    for (int d = 0; d < 3; ++d) {
+      const double v = c[3 * j + d];
+      if (!std::isfinite(v)) return false;
+      lo[d] = std::min(lo[d], v); hi[d] = std::max(hi[d], v);
+    }
+  const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+  if (!(ext > 0.0) || !std::isfinite(ext)) return false;
+  int g = (int)std::lround(std::cbrt((double)k));
+  g = std::min(std::max(g, 2), 16);
+  const double cell = ext / g * 1.0001;      // (the largest coordinate falls inside the last cell)
+  gr.ox = (float)lo[0]; gr.oy = (float)lo[1]; gr.oz = (float)lo[2];
+  gr.cell = (float)cell; gr.inv_cell = (float)(1.0 / cell); gr.margin = (float)(cell / 1024.0); gr.g = g; gr.kreal = (uint32_t)k;
+  // (binned with the grid's own f32 numbers, in double: a centroid lies inside the box of its cell up to the rounding the margin covers)
+  const int ncell = g * g * g;
+  std::vector<uint32_t> cnt(ncell + 1, 0), cellof(k);
+  for (size_t j = 0; j < k; ++j) {
+    int ci[3];
+    const float o[3] = {gr.ox, gr.oy, gr.oz};
+    for (int d = 0; d < 3; ++d) ci[d] = std::min(std::max((int)std::floor(((double)c[3 * j + d] - (double)o[d]) / (double)gr.cell), 0), g - 1);
+    cellof[j] = (uint32_t)((ci[2] * g + ci[1]) * g + ci[0]);
+    ++cnt[cellof[j] + 1];
+  }
+  for (int t = 0; t < ncell; ++t) cnt[t + 1] += cnt[t];
+  cstart.assign(cnt.begin(), cnt.end());
+  std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+  for (size_t j = 0; j < k; ++j) {      // ascending j inside a cell
+    float4 v; v.x = c[3 * j]; v.y = c[3 * j + 1]; v.z = c[3 * j + 2];
+    const uint32_t jj = (uint32_t)j; std::memcpy(&v.w, &jj, 4);
+    cs[fill[cellof[j]]++] = v;
+  }
+  return true;
+}
+
 // farthest member of one cluster from a given point (empty-cluster repair, kmeans.hpp:145-168);
 // ties -> lowest point index (the reference's omp-critical order is unspecified)
 __global__ void k_farthest_member(const float* __restrict__ xyz, const uint32_t* __restrict__ labels, uint32_t n, uint32_t cluster,
@@ -145,6 +265,9 @@ __global__ void k_maxabs_bits(const float* __restrict__ v, size_t count, unsigne
 
 __global__ void k_set_label(uint32_t* labels, uint32_t i, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) labels[i] = v; }
 
+// (dev / tests: CILHIP_KMEANS_PRUNE=0 in the environment keeps the brute-force pass; the pruned pass is the default)
+static const bool g_kmeans_prune = [] { const char* e = getenv("CILHIP_KMEANS_PRUNE"); return !(e && e[0] == '0'); }();
+
 #define KM_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = CILHIP_ERR_HIP; goto done; } } while (0)
 
 int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
@@ -163,6 +286,12 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
   hipStream_t s = nullptr;
   std::vector<long long> hs(k * 4);
   std::vector<float> c_old(3 * k);
+  const size_t kpad8 = (k + 7) & ~(size_t)7;
+  float4 pad4; pad4.x = pad4.y = pad4.z = INFINITY; { const uint32_t none = 0xFFFFFFFFu; std::memcpy(&pad4.w, &none, 4); }
+  std::vector<float4> cs_host(kpad8, pad4);
+  std::vector<uint32_t> cstart_host;
+  float4* d_cs = nullptr;
+  uint32_t* d_cstart = nullptr;
   size_t iter = 0;
   {
     KM_CK(hipSetDevice(device));
@@ -208,7 +337,19 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
       KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
       KM_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
       KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1};
-      if (kd_order) hipLaunchKernelGGL(k_assign_accumulate<true>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
+      KmGrid gr{};
+      const bool pruned = !kd_order && g_kmeans_prune && build_centroid_grid(centroids, k, gr, cs_host, cstart_host);
+      if (pruned) {
+        // the grid of THIS iteration's centroids: sorted list + cell table, 20 KB
+        const size_t ncell1 = (size_t)gr.g * gr.g * gr.g + 1;
+        if (!d_cs) { KM_CK(hipMalloc(&d_cs, kpad * sizeof(float4))); KM_CK(hipMalloc(&d_cstart, (16 * 16 * 16 + 1) * sizeof(uint32_t))); }
+        KM_CK(hipMemcpyAsync(d_cs, cs_host.data(), kpad * sizeof(float4), hipMemcpyHostToDevice, s));
+        KM_CK(hipMemcpyAsync(d_cstart, cstart_host.data(), ncell1 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        const size_t lds = kpad * 4 * sizeof(long long) + kpad * sizeof(float4) + ncell1 * sizeof(uint32_t);
+        const int nb_g = (int)std::min<size_t>((n + KM_THREADS - 1) / KM_THREADS, 2048);
+        hipLaunchKernelGGL(k_assign_grid, dim3(nb_g), dim3(KM_THREADS), lds, s, a, gr, (const float4*)d_cs, (const uint32_t*)d_cstart);
+      }
+      else if (kd_order) hipLaunchKernelGGL(k_assign_accumulate<true>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
       else hipLaunchKernelGGL(k_assign_accumulate<false>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
       KM_CK(hipGetLastError());
       if (assign_only) break;
@@ -264,6 +405,8 @@ done:
   if (d_sums) (void)hipFree(d_sums);
   if (d_changed) (void)hipFree(d_changed);
   if (d_best) (void)hipFree(d_best);
+  if (d_cs) (void)hipFree(d_cs);
+  if (d_cstart) (void)hipFree(d_cstart);
   if (s) (void)hipStreamDestroy(s);
   return rc;
 }

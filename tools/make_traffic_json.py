@@ -27,8 +27,17 @@ for k, c in vals.items():
     w = sum(c["WRITE_SIZE"][3:]) / max(len(c["WRITE_SIZE"][3:]), 1) * 1024.0
     per[k] = {"FETCH_SIZE_bytes_reported": f, "WRITE_SIZE_bytes": w, "hbm_bytes": 2.0 * f + w, "launches": len(c["FETCH_SIZE"])}
     tot += 2.0 * f + w
+# the cold tile kernels of the same passes (bench.py: roofline_cold.plain_tile / .record_writing_tile): launch 0 of a pass is the warm-up
+# run's, every launch moves the same bytes
+cold = {}
+for f in glob.glob(f"{d}/*/**/*_counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"k_search_tiled<([1-4]), false, (true|false)>", r["Kernel_Name"])
+        if m and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            cold.setdefault("record_writing_tile" if m.group(2) == "true" else "plain_tile", collections.defaultdict(list))[r["Counter_Name"]].append(float(r["Counter_Value"]))
+cold_forms = {k: 2.0 * (sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)) * 1024.0 + (sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)) * 1024.0 for k, c in cold.items()}
 cfg = line.get("config", {})
-print(json.dumps({"traffic_bytes_per_launch": tot, "kernels": per, "source_hash": bench.source_hash(),
+print(json.dumps({"traffic_bytes_per_launch": tot, "kernels": per, "cold_forms": cold_forms, "source_hash": bench.source_hash(),
                   "form": form, "kernel_patterns": list(subs),
                   "workload": {"n_target": cfg.get("n_target"), "n_source_per_gpu": cfg.get("n_source_per_gpu"),
                                "metric": "p2plane" if "point-to-plane" in cfg.get("workload", "") else ("p2p" if "point-to-point" in cfg.get("workload", "") else "combined")},
