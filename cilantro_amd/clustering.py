@@ -66,6 +66,11 @@ class KMeans3f:
         return np.split(order, np.cumsum(counts)[:-1])
 
 
+def set_pruning(on=True):
+    """the brute-force branch's assignment computed exactly with pruning (default) or exhaustively (cilhip_kmeans_set_pruning; process-wide)"""
+    capi.load().cilhip_kmeans_set_pruning(1 if on else 0)
+
+
 def kmeans_assign(data, centroids, device=0, use_kd_tree=False):
     L = capi.load()
     p, n, mem, keep = _as_cloud(data)

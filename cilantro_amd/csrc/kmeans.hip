@@ -135,14 +135,68 @@ struct KmGrid { float ox, oy, oz, cell, inv_cell, margin; int g; uint32_t kreal;
 
 __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr, const float4* __restrict__ cs_g, const uint32_t* __restrict__ cstart_g) {
   extern __shared__ long long lsum[];                                     // [kpad*4] sums, then the grid
-  float4* const cs = reinterpret_cast<float4*>(lsum + (size_t)a.k * 4);   // [kpad] sorted centroids {x, y, z, bits(j)}
-  uint32_t* const cstart = reinterpret_cast<uint32_t*>(cs + a.k);         // [g^3 + 1]
+  float4* const cs = reinterpret_cast<float4*>(lsum + (size_t)a.k * 4);   // [kpad + 8] sorted centroids {x, y, z, bits(j)}, +inf pad behind them
+  uint32_t* const cstart = reinterpret_cast<uint32_t*>(cs + a.k + 8);     // [g^3 + 1]
   const int g = gr.g, ncell = g * g * g;
   for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS) lsum[t] = 0;
-  for (uint32_t t = threadIdx.x; t < a.k; t += KM_THREADS) cs[t] = cs_g[t];
+  for (uint32_t t = threadIdx.x; t < a.k + 8; t += KM_THREADS) cs[t] = cs_g[t];
   for (int t = threadIdx.x; t <= ncell; t += KM_THREADS) cstart[t] = cstart_g[t];
   __syncthreads();
   unsigned int changed = 0;
+
+  auto finish = [&](uint32_t i, float px, float py, float pz, float bd, uint32_t bj) {
+    const uint32_t b = (bd < INFINITY && bj != 0xFFFFFFFFu) ? bj : 0u;      // (no finite minimum at all: label 0, as a chain of strict compares from (inf, 0) leaves it)
+    changed += (a.labels[i] != b) ? 1u : 0u;
+    a.labels[i] = b;
+    if (a.accumulate) {
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 0], (unsigned long long)llrint((double)px * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 1], (unsigned long long)llrint((double)py * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 2], (unsigned long long)llrint((double)pz * a.scale));
+      atomicAdd((unsigned long long*)&lsum[b * 4 + 3], 1ull);
+    }
+  };
+  // a point its 3x3x3 block did not prove (one in seventy): the 5x5x5 block, then -- whatever that does not prove, and every point with a
+  // non-finite coordinate -- all k centroids: the definition.  (Queueing these per wave and searching them 64 at a time was measured
+  // slower, 1.80 against 1.42 ms: the wide search is not what the pass spends its time on.)
+  auto slow = [&](uint32_t i, float px, float py, float pz) {
+    float bd = INFINITY;
+    uint32_t bj = 0xFFFFFFFFu;
+    auto take = [&](const float4 c) {
+      const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
+      const float d = dx * dx + (dy * dy + dz * dz);
+      const uint32_t j = __float_as_uint(c.w);
+      const bool better = (d < bd) | ((d == bd) & (j < bj));
+      bd = better ? d : bd;
+      bj = better ? j : bj;
+    };
+    bool proven = false;
+    if ((fabsf(px) < INFINITY) & (fabsf(py) < INFINITY) & (fabsf(pz) < INFINITY)) {
+      const int cx = min(max((int)floorf((px - gr.ox) * gr.inv_cell), 0), g - 1), cy = min(max((int)floorf((py - gr.oy) * gr.inv_cell), 0), g - 1),
+                cz = min(max((int)floorf((pz - gr.oz) * gr.inv_cell), 0), g - 1);
+      const int xa = max(cx - 2, 0), xb = min(cx + 2, g - 1);
+      for (int zc = max(cz - 2, 0); zc <= min(cz + 2, g - 1); ++zc)
+        for (int yc = max(cy - 2, 0); yc <= min(cy + 2, g - 1); ++yc) {
+          const int row = (zc * g + yc) * g;
+          const uint32_t t1 = cstart[row + xb + 1];
+          for (uint32_t t = cstart[row + xa]; t < t1; ++t) take(cs[t]);
+        }
+      float gap = INFINITY;
+      if (cx - 2 > 0) gap = fminf(gap, px - (gr.ox + (float)(cx - 2) * gr.cell));
+      if (cx + 2 < g - 1) gap = fminf(gap, (gr.ox + (float)(cx + 3) * gr.cell) - px);
+      if (cy - 2 > 0) gap = fminf(gap, py - (gr.oy + (float)(cy - 2) * gr.cell));
+      if (cy + 2 < g - 1) gap = fminf(gap, (gr.oy + (float)(cy + 3) * gr.cell) - py);
+      if (cz - 2 > 0) gap = fminf(gap, pz - (gr.oz + (float)(cz - 2) * gr.cell));
+      if (cz + 2 < g - 1) gap = fminf(gap, (gr.oz + (float)(cz + 3) * gr.cell) - pz);
+      const float gb = gap - gr.margin;
+      proven = gap == INFINITY || (gb > 0.0f && bd < gb * gb * 0.99999905f);
+    }
+    if (!proven) {
+      bd = INFINITY; bj = 0xFFFFFFFFu;
+      for (uint32_t t = 0; t < gr.kreal; ++t) take(cs[t]);
+    }
+    finish(i, px, py, pz, bd, bj);
+  };
+
   for (uint32_t i = blockIdx.x * KM_THREADS + threadIdx.x; i < a.n; i += gridDim.x * KM_THREADS) {
     const float px = a.xyz[3 * (size_t)i], py = a.xyz[3 * (size_t)i + 1], pz = a.xyz[3 * (size_t)i + 2];
     float bd = INFINITY;
@@ -160,13 +214,26 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr,
     if (finite) {
       const int cx = min(max((int)floorf((px - gr.ox) * gr.inv_cell), 0), g - 1), cy = min(max((int)floorf((py - gr.oy) * gr.inv_cell), 0), g - 1),
                 cz = min(max((int)floorf((pz - gr.oz) * gr.inv_cell), 0), g - 1);
+      // Nine runs of the sorted list, in STRAIGHT-LINE code: four records of every run unconditionally -- reading past a short run only
+      // evaluates further real centroids (any centroid is a legitimate candidate of the argmin) or the +inf pad behind the list, a row
+      // clamped at the grid's edge is read twice (the compare is idempotent) -- so that the 36 reads of a point are independent and the
+      // wave executes each instruction once; only runs longer than four go through a loop afterwards.
       const int xa = max(cx - 1, 0), xb = min(cx + 1, g - 1);
-      for (int zc = max(cz - 1, 0); zc <= min(cz + 1, g - 1); ++zc)
-        for (int yc = max(cy - 1, 0); yc <= min(cy + 1, g - 1); ++yc) {
-          const int row = (zc * g + yc) * g;
-          const uint32_t t1 = cstart[row + xb + 1];
-          for (uint32_t t = cstart[row + xa]; t < t1; ++t) take(cs[t]);
-        }
+      uint32_t r0[9], r1[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int zc = min(max(cz + r / 3 - 1, 0), g - 1), yc = min(max(cy + r % 3 - 1, 0), g - 1);
+        const int row = (zc * g + yc) * g;
+        r0[r] = cstart[row + xa]; r1[r] = cstart[row + xb + 1];
+      }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const float4 c0 = cs[r0[r]], c1 = cs[r0[r] + 1], c2 = cs[r0[r] + 2], c3 = cs[r0[r] + 3];
+        take(c0); take(c1); take(c2); take(c3);
+      }
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+        for (uint32_t t = r0[r] + 4; t < r1[r]; ++t) take(cs[t]);
       // distance from the point to the faces of the block beyond which the grid goes on
       float gap = INFINITY;
       if (cx - 1 > 0) gap = fminf(gap, px - (gr.ox + (float)(cx - 1) * gr.cell));
@@ -178,19 +245,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr,
       const float gb = gap - gr.margin;
       proven = gap == INFINITY || (gb > 0.0f && bd < gb * gb * 0.99999905f);
     }
-    if (!proven) {      // every centroid: the definition
-      bd = INFINITY; bj = 0xFFFFFFFFu;
-      for (uint32_t t = 0; t < gr.kreal; ++t) take(cs[t]);
-    }
-    const uint32_t b = (bd < INFINITY && bj != 0xFFFFFFFFu) ? bj : 0u;      // (no finite minimum at all: label 0, as a chain of strict compares from (inf, 0) leaves it)
-    changed += (a.labels[i] != b) ? 1u : 0u;
-    a.labels[i] = b;
-    if (a.accumulate) {
-      atomicAdd((unsigned long long*)&lsum[b * 4 + 0], (unsigned long long)llrint((double)px * a.scale));
-      atomicAdd((unsigned long long*)&lsum[b * 4 + 1], (unsigned long long)llrint((double)py * a.scale));
-      atomicAdd((unsigned long long*)&lsum[b * 4 + 2], (unsigned long long)llrint((double)pz * a.scale));
-      atomicAdd((unsigned long long*)&lsum[b * 4 + 3], 1ull);
-    }
+    if (proven) finish(i, px, py, pz, bd, bj);
+    else slow(i, px, py, pz);
   }
   if (changed) atomicAdd(a.changed, changed);
   if (a.accumulate) {
@@ -213,7 +269,9 @@ static bool build_centroid_grid(const float* c, size_t k, KmGrid& gr, std::vecto
     }
   const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
   if (!(ext > 0.0) || !std::isfinite(ext)) return false;
-  int g = (int)std::lround(std::cbrt((double)k));
+  // about ONE centroid per cell (measured best: the pass pays per candidate read)
+  static const double per_cell = [] { const char* e = getenv("CILHIP_KMEANS_PER_CELL"); return e ? atof(e) : 1.0; }();      // (dev sweep at 50M x 1024: 0.5: 2.33 ms, 0.7: 1.58, 1: 1.47, 1.5: 1.72, 2: 2.34, 4: 4.14)
+  int g = (int)std::lround(std::cbrt((double)k / per_cell));
   g = std::min(std::max(g, 2), 16);
   const double cell = ext / g * 1.0001;      // (the largest coordinate falls inside the last cell)
   gr.ox = (float)lo[0]; gr.oy = (float)lo[1]; gr.oz = (float)lo[2];
@@ -265,8 +323,8 @@ __global__ void k_maxabs_bits(const float* __restrict__ v, size_t count, unsigne
 
 __global__ void k_set_label(uint32_t* labels, uint32_t i, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) labels[i] = v; }
 
-// (dev / tests: CILHIP_KMEANS_PRUNE=0 in the environment keeps the brute-force pass; the pruned pass is the default)
-static const bool g_kmeans_prune = [] { const char* e = getenv("CILHIP_KMEANS_PRUNE"); return !(e && e[0] == '0'); }();
+// the pruned pass is the default; cilhip_kmeans_set_pruning(0) (or CILHIP_KMEANS_PRUNE=0 in the environment) keeps the brute-force pass
+static bool g_kmeans_prune = [] { const char* e = getenv("CILHIP_KMEANS_PRUNE"); return !(e && e[0] == '0'); }();
 
 #define KM_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = CILHIP_ERR_HIP; goto done; } } while (0)
 
@@ -288,7 +346,7 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
   std::vector<float> c_old(3 * k);
   const size_t kpad8 = (k + 7) & ~(size_t)7;
   float4 pad4; pad4.x = pad4.y = pad4.z = INFINITY; { const uint32_t none = 0xFFFFFFFFu; std::memcpy(&pad4.w, &none, 4); }
-  std::vector<float4> cs_host(kpad8, pad4);
+  std::vector<float4> cs_host(kpad8 + 8, pad4);
   std::vector<uint32_t> cstart_host;
   float4* d_cs = nullptr;
   uint32_t* d_cstart = nullptr;
@@ -342,10 +400,10 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
       if (pruned) {
         // the grid of THIS iteration's centroids: sorted list + cell table, 20 KB
         const size_t ncell1 = (size_t)gr.g * gr.g * gr.g + 1;
-        if (!d_cs) { KM_CK(hipMalloc(&d_cs, kpad * sizeof(float4))); KM_CK(hipMalloc(&d_cstart, (16 * 16 * 16 + 1) * sizeof(uint32_t))); }
-        KM_CK(hipMemcpyAsync(d_cs, cs_host.data(), kpad * sizeof(float4), hipMemcpyHostToDevice, s));
+        if (!d_cs) { KM_CK(hipMalloc(&d_cs, (kpad + 8) * sizeof(float4))); KM_CK(hipMalloc(&d_cstart, (16 * 16 * 16 + 1) * sizeof(uint32_t))); }
+        KM_CK(hipMemcpyAsync(d_cs, cs_host.data(), (kpad + 8) * sizeof(float4), hipMemcpyHostToDevice, s));
         KM_CK(hipMemcpyAsync(d_cstart, cstart_host.data(), ncell1 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        const size_t lds = kpad * 4 * sizeof(long long) + kpad * sizeof(float4) + ncell1 * sizeof(uint32_t);
+        const size_t lds = kpad * 4 * sizeof(long long) + (kpad + 8) * sizeof(float4) + ncell1 * sizeof(uint32_t);
         const int nb_g = (int)std::min<size_t>((n + KM_THREADS - 1) / KM_THREADS, 2048);
         hipLaunchKernelGGL(k_assign_grid, dim3(nb_g), dim3(KM_THREADS), lds, s, a, gr, (const float4*)d_cs, (const uint32_t*)d_cstart);
       }
@@ -414,6 +472,8 @@ done:
 }  // namespace
 
 extern "C" {
+
+int cilhip_kmeans_set_pruning(int on) { g_kmeans_prune = on != 0; return CILHIP_OK; }
 
 int cilhip_kmeans3f(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
                     uint32_t* labels_out, size_t* iterations_out) {

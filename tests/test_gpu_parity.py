@@ -602,6 +602,54 @@ def test_kmeans3f_vs_oracle(orc, hip_lib):
         _kmeans_label_mismatches_are_near_ties(x, km.getPointToClusterIndexMap(), lo, co, k)
 
 
+def test_kmeans_pruned_assignment_is_the_exhaustive_one(orc, hip_lib):
+    """The pruned assignment pass (centroid grid in LDS, 3x3x3 / 5x5x5 block with a proof, all k centroids otherwise) against the
+    exhaustive pass of the same library and against the oracle: labels identical, element for element -- uniform and clustered
+    centroids (the grid's cells mostly empty: the fallbacks), duplicated centroids (equal distances: the lowest index wins), points far
+    outside the centroids' box, non-finite points, k from 64 (the grid's floor) to 2048; whole Lloyd runs bit for bit."""
+    from cilantro_amd import clustering
+    from cilantro_amd.clustering import KMeans3f, kmeans_assign
+
+    rng = np.random.default_rng(17)
+    n = 400_000
+    uni = rng.random((n, 3), dtype=np.float32)
+    centres = rng.random((25, 3)).astype(np.float32)
+    clu = (centres[rng.integers(0, 25, n)] + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+    far = uni.copy(); far[: n // 10] = (far[: n // 10] - 0.5) * 40.0      # a tenth of the points far outside
+    bad = uni.copy(); bad[5] = [np.nan, 0.1, 0.2]; bad[77] = [np.inf, 0.5, 0.5]; bad[1234] = [0.3, -np.inf, 0.9]
+    cases = []
+    for k in (64, 257, 1024, 2048):
+        cases.append((f"uniform k={k}", uni, uni[:k].copy()))
+    cases.append(("clustered data, centroids from it", clu, clu[:1024].copy()))
+    cases.append(("uniform data, clustered centroids", uni, clu[:1024].copy()))
+    dupc = uni[:512].copy(); dupc[256:] = dupc[:256]      # every centroid twice: exact ties between an index and index + 256
+    cases.append(("duplicated centroids", uni, dupc))
+    cases.append(("points far outside the centroids' box", far, uni[:1024].copy()))
+    cases.append(("non-finite points", bad, uni[:300].copy()))
+    flat = uni[:700].copy(); flat[:, 2] = 0.25      # centroids on a plane: a degenerate extent along z
+    cases.append(("coplanar centroids", uni, flat))
+    try:
+        for name, x, c0 in cases:
+            clustering.set_pruning(True)
+            lp = kmeans_assign(x, c0)
+            clustering.set_pruning(False)
+            le = kmeans_assign(x, c0)
+            assert np.array_equal(lp, le), (name, int(np.count_nonzero(lp != le)))
+            if "non-finite" not in name:
+                lo, _ = orc.kmeans_assign(x, c0)
+                assert np.array_equal(lp, lo), (name, int(np.count_nonzero(lp != lo)))
+        for name, x, c0 in (cases[2], cases[4], cases[7]):
+            clustering.set_pruning(True)
+            kp = KMeans3f(x).cluster(c0.copy(), max_iter=8, tol=0.0)
+            clustering.set_pruning(False)
+            ke = KMeans3f(x).cluster(c0.copy(), max_iter=8, tol=0.0)
+            assert kp.getNumberOfPerformedIterations() == ke.getNumberOfPerformedIterations(), name
+            assert np.array_equal(kp.getClusterCentroids().view(np.uint32), ke.getClusterCentroids().view(np.uint32)), name
+            assert np.array_equal(kp.getPointToClusterIndexMap(), ke.getPointToClusterIndexMap()), name
+    finally:
+        clustering.set_pruning(True)
+
+
 def _plane_cloud(n, seed, inlier_frac=0.6, noise=0.004):
     rng = np.random.default_rng(seed)
     x = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
