@@ -508,6 +508,25 @@ def bench_icp(a, torch, rank, world, local_rank):
                 "relative_to_cilhip_icp_run": (a.steps / dtm) / (a.steps / dt),
                 "max_abs_T_difference_to_the_timed_run": float(np.abs(Tm - np.array(res.T[:], np.float32).reshape(4, 4).T).max())}
             mm.close()
+            # ... and EIGHT shards on this one GPU (repeated ordinal: the all-reduce runs as the same-device kernel): what one GPU can show
+            # of an 8-device run's HOST side -- the enqueue calls of an iteration per shard, with one host thread per shard (the default)
+            # and with one thread walking the shards (CILHIP_MULTI_THREADS=0, round 4); the shards' kernels share the one device, so
+            # ms_per_step here is not a scaling figure
+            leg = {}
+            for label, thr in (("one_host_thread_per_shard", "1"), ("one_host_thread", "0")):
+                os.environ["CILHIP_MULTI_THREADS"] = thr
+                m8 = MultiDeviceRigidICP([local_rank] * 8)
+                m8.set_clouds(d["dst"], d["dst_n"] if with_normals else None, d["src"], float(d["max_sq_dist"]), PARTITION_SLABS)
+                p.max_iter = a.warmup; m8.icp_run(p, T0, check_every=1 << 20)
+                p.max_iter = a.steps; m8.icp_run(p, T0, check_every=1 << 20)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                r8 = m8.icp_run(p, T0, check_every=1 << 20)
+                torch.cuda.synchronize(); dt8 = time.perf_counter() - t0
+                leg[label] = {"ms_per_step": dt8 * 1e3 / a.steps, "host_enqueue_us_per_iteration_per_shard": m8.last_host_time(),
+                              "max_abs_T_difference_to_the_timed_run": float(np.abs(np.array(r8.T[:], np.float32).reshape(4, 4).T - np.array(res.T[:], np.float32).reshape(4, 4).T).max())}
+                m8.close()
+            os.environ.pop("CILHIP_MULTI_THREADS", None)
+            extras["multi_device_c_loop_8_shards_one_gpu"] = dict(leg, entry="cilhip_multi_icp_run, devices = [0] x 8, spatial slabs, state read once at the end")
         except Exception as e:
             extras["multi_device_c_loop_one_shard"] = {"error": repr(e)}
         out.update(extras)

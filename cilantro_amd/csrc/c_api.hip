@@ -100,6 +100,7 @@ struct cilhip_ctx {
   // iteration (cold iterations of clouds the tiles do not take: always for clouds below the warm-started form's floor, from the
   // kernels' own forecast above it); 0 = never; 4 .. 64 = that many lanes in every global-memory search.
   int group_lanes = -1;
+  double wait_us = 0.0;                          // time spent waiting for the device to publish loop state (wait_published), accumulated: not enqueue work
   bool fused_epilogue = false;                   // option "fused_epilogue": stage-1 reduction + epilogue in ONE launch (the last of the 32 stage-1 blocks runs the
                                                  // epilogue).  Bitwise the same results, measured SLOWER: 0.129 -> 0.136 ms per iteration at 10M, 0.037 -> 0.044 at 1M --
                                                  // a device-scope fence costs more on this eight-L2 part than the kernel boundary it removes (NOTEBOOK.md): off
@@ -1711,6 +1712,7 @@ static inline void cpu_relax(unsigned spins) {
 static int wait_published(cilhip_ctx* c, unsigned int need, double patience_s, FbView* v) {
   const volatile Feedback* fb = c->h_feedback;
   const auto t0 = std::chrono::steady_clock::now();
+  struct Acc { cilhip_ctx* c; std::chrono::steady_clock::time_point t; ~Acc() { c->wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); } } acc{c, t0};
   for (unsigned spins = 0;; ++spins) {
     const unsigned long long lt = fb->latest;
     if ((unsigned int)(lt >> 32) == c->run_tag) {
@@ -2586,6 +2588,10 @@ struct cilhip_multi {
   cilhip_tie_order* order = nullptr;
   std::vector<std::vector<uint32_t>> gidx;      // slabs: per shard, global index of its target point i
   bool tie_pending = false;                     // some shard's counters showed ties met without tables before they were reset (a re-partition inside a run)
+  // host time the shards' enqueue calls took in the last run (per iteration and shard, microseconds): with one host thread per shard
+  // (multi_iterate) it is what bounds an iteration whose kernels take tens of microseconds, not its sum over the shards
+  double host_us_per_iter_shard = 0.0;
+  bool threads = true;                          // CILHIP_MULTI_THREADS=0: one host thread walks the shards (round 4)
 };
 
 static int mfail(cilhip_multi* m, int code, const std::string& msg) { if (m) m->err = msg; return code; }
@@ -2604,6 +2610,7 @@ int cilhip_multi_create(cilhip_multi** out, const int* devices, int ndev) {
   m->dev.assign(devices, devices + ndev);
   for (int i = 0; i < ndev; ++i)
     for (int j = 0; j < i; ++j) if (devices[i] == devices[j]) m->distinct = false;
+  { const char* e = getenv("CILHIP_MULTI_THREADS"); m->threads = !(e && e[0] == '0'); }
   m->ctx.assign(ndev, nullptr); m->d_sums.assign(ndev, nullptr);
   m->n_dst_local.assign(ndev, 0); m->n_src_local.assign(ndev, 0);
   int rc = CILHIP_OK;
@@ -2789,7 +2796,83 @@ static int multi_allreduce(cilhip_multi* m) {
   return CILHIP_OK;
 }
 
+// `iters` iterations of {every shard's partial sums, the all-reduce of the 48 f64, every shard's epilogue}.  One host thread PER SHARD
+// (each enqueues on its own device's stream: at 8 devices x ~4 launches x ~5 us one thread walking the shards would bound an
+// iteration whose kernels take ~15 us), two rendezvous per iteration around the all-reduce, which one thread issues for all (RCCL
+// group call over the distinct devices / the same-device kernel).  An error on any shard is carried to the end: nobody leaves a
+// rendezvous early.
+static int multi_iterate(cilhip_multi* m, int iters) {
+  if (iters <= 0) return CILHIP_OK;
+  const auto t_begin = std::chrono::steady_clock::now();
+  if (m->n == 1 || !m->threads) {
+    double host = 0.0;
+    for (int k = 0; k < iters; ++k) {
+      const auto t0 = std::chrono::steady_clock::now();
+      double w0 = 0.0, w1 = 0.0;
+      for (int r = 0; r < m->n; ++r) w0 += m->ctx[r]->wait_us;
+      for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_partial_sums(m->ctx[r], m->d_sums[r]));
+      for (int r = 0; r < m->n; ++r) w1 += m->ctx[r]->wait_us;
+      host += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() - (w1 - w0);
+      { const int rc = multi_allreduce(m); if (rc) return rc; }
+      const auto t1 = std::chrono::steady_clock::now();
+      for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_apply_sums(m->ctx[r], m->d_sums[r]));
+      host += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    }
+    m->host_us_per_iter_shard = host / iters / m->n;
+    return CILHIP_OK;
+  }
+  const int n = m->n;
+  std::atomic<int> arrived{0}, generation{0}, failed{0};
+  std::vector<int> rcs(n, CILHIP_OK);
+  std::vector<double> host(n, 0.0);
+  int reduce_rc = CILHIP_OK;
+  auto rendezvous = [&]() {
+    const int gen = generation.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { arrived.store(0, std::memory_order_relaxed); generation.fetch_add(1, std::memory_order_release); }
+    else for (unsigned spins = 0; generation.load(std::memory_order_acquire) == gen; ++spins) cpu_relax(spins);
+  };
+  auto worker = [&](int r) {
+    (void)hipSetDevice(m->dev[r]);
+    for (int k = 0; k < iters; ++k) {
+      if (!failed.load(std::memory_order_relaxed)) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const double w0 = m->ctx[r]->wait_us;
+        const int rc = cilhip_icp_partial_sums(m->ctx[r], m->d_sums[r]);
+        host[r] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() - (m->ctx[r]->wait_us - w0);      // (waiting for the device's published state is not enqueue work)
+        if (rc) { rcs[r] = rc; failed.store(1); }
+      }
+      rendezvous();
+      if (r == 0 && !failed.load()) { reduce_rc = multi_allreduce(m); if (reduce_rc) failed.store(1); }
+      rendezvous();
+      if (!failed.load(std::memory_order_relaxed)) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = cilhip_icp_apply_sums(m->ctx[r], m->d_sums[r]);
+        host[r] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) { rcs[r] = rc; failed.store(1); }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int r = 1; r < n; ++r) th.emplace_back(worker, r);
+  worker(0);
+  for (auto& x : th) x.join();
+  (void)hipSetDevice(m->dev[0]);
+  for (int r = 0; r < n; ++r) if (rcs[r]) return mfail(m, rcs[r], std::string("shard ") + std::to_string(r) + ": " + cilhip_last_error(m->ctx[r]));
+  if (reduce_rc) return reduce_rc;
+  double mx = 0.0;
+  for (int r = 0; r < n; ++r) mx = std::max(mx, host[r]);
+  m->host_us_per_iter_shard = mx / iters;      // (the slowest shard's thread: what an iteration waits for on the host side)
+  (void)t_begin;
+  return CILHIP_OK;
+}
+
 extern "C" {
+
+int cilhip_multi_last_host_time(const cilhip_multi* m, double* us_per_iteration_per_shard) {
+  if (!m || !us_per_iteration_per_shard) return CILHIP_ERR_INVALID;
+  *us_per_iteration_per_shard = m->host_us_per_iter_shard;
+  return CILHIP_OK;
+}
 
 // IterativeClosestPointBase::estimate() (registration/icp_base.hpp:68-87) across the handle's devices.  check_every: how often the
 // loop state is read back (convergence; the slab guard) -- 0: the default 5.
@@ -2838,10 +2921,13 @@ static int multi_icp_run_once(cilhip_multi* m, const cilhip_icp_params* p, const
   cilhip_icp_result st{};
   memcpy(st.T, T_ck, sizeof(T_ck));
   while (base + since < total) {
-    for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_partial_sums(m->ctx[r], m->d_sums[r]));
-    { const int rc = multi_allreduce(m); if (rc) return rc; }
-    for (int r = 0; r < m->n; ++r) MCTX(m, r, cilhip_icp_apply_sums(m->ctx[r], m->d_sums[r]));
-    ++since;
+    {      // up to the next look at the loop state, in one block (one host thread per shard inside it)
+      const size_t to_check = (size_t)every - since % (size_t)every, left = total - base - since;
+      const int blk = (int)std::min<size_t>(std::min(to_check, left), 1u << 20);
+      const int rc = multi_iterate(m, blk);
+      if (rc) return rc;
+      since += (size_t)blk;
+    }
     if (since % (size_t)every == 0 || base + since == total) {
       MCTX(m, 0, cilhip_icp_state(m->ctx[0], &st));          // (the same state on every shard: same sums, same epilogue)
       int bad = 0;

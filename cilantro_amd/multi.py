@@ -62,6 +62,13 @@ class MultiDeviceRigidICP:
         """how far a source point may move along the slab axis before the slabs are cut again (< 0: twice the search radius)"""
         self._ck(self._L.cilhip_multi_set_slab_slack(self._h, float(slack)))
 
+    def last_host_time(self):
+        """host microseconds per iteration the (slowest) shard's enqueue calls took in the last icp_run"""
+        v = C.c_double(0.0)
+        self._L.cilhip_multi_last_host_time.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._ck(self._L.cilhip_multi_last_host_time(self._h, C.byref(v)))
+        return v.value
+
     def repartitions(self):
         return int(self._L.cilhip_multi_repartitions(self._h))
 

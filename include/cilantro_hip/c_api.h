@@ -419,6 +419,9 @@ cilhip_ctx* cilhip_multi_context(cilhip_multi* m, int rank);
 int cilhip_multi_set_clouds(cilhip_multi* m, const float* dst_xyz, const float* dst_nrm_or_null, size_t n_dst, const float* src_xyz, size_t n_src,
                             float max_sq_dist, int partition, const float* T_part_or_null);
 int cilhip_multi_icp_run(cilhip_multi* m, const cilhip_icp_params* p, const float* T0, int check_every, cilhip_icp_result* out);
+/* Host time the shards' enqueue calls took per iteration of the last cilhip_multi_icp_run (the slowest shard's thread: the run has one
+ * host thread per shard; CILHIP_MULTI_THREADS=0 in the environment: one thread walks the shards, and the figure is the mean per shard). */
+int cilhip_multi_last_host_time(const cilhip_multi* m, double* us_per_iteration_per_shard);
 int cilhip_multi_repartitions(const cilhip_multi* m);
 /* how far a source point may move along the slab axis before the slabs are cut again (the halos are the search radius + this);
  * < 0: the default, twice the search radius.  Takes effect at the next cilhip_multi_set_clouds. */
