@@ -241,3 +241,55 @@ def test_empty_target_shard_keeps_the_point_to_plane_branch(Context, orc):
     assert int(rr.iterations) == 5 and int(rr.last_ncorr) == int(ref.last_ncorr)
     assert float(rr.last_delta_norm) > 0.0
     assert np.abs(np.array(rr.T[:], np.float32).astype(np.float64) - np.array(ref.T[:], np.float32).astype(np.float64)).max() <= 2e-6
+
+
+def test_lattice_clouds_every_query_tied_eight_ways(Context, orc):
+    """A target on a regular lattice and queries at the centres of its cubes: EVERY query has eight exactly equidistant nearest target
+    points (any number of candidates: the old host path gave up beyond eight); queries on face and edge centres: four and two.  The
+    engine names nanoflann's choice for each, in a single search (tiled and global-memory kernels, one lane and sixteen lanes per query)
+    and through the loop's forms."""
+    m = 40
+    ax = (np.arange(m, dtype=np.float32) * np.float32(0.125)).astype(np.float32)
+    D = np.ascontiguousarray(np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3))
+    rng = np.random.default_rng(5)
+    D = np.ascontiguousarray(D[rng.permutation(len(D))])      # (the reference's tree depends on the order of the points)
+    N = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (len(D), 1))
+    c = (np.arange(m - 1, dtype=np.float32) * np.float32(0.125) + np.float32(0.0625)).astype(np.float32)
+    cube = np.stack(np.meshgrid(c, c, c, indexing="ij"), -1).reshape(-1, 3)                       # 8 corners each
+    face = np.stack(np.meshgrid(c, c, ax[:-1], indexing="ij"), -1).reshape(-1, 3)[::3]           # 4
+    edge = np.stack(np.meshgrid(c, ax[:-1], ax[:-1], indexing="ij"), -1).reshape(-1, 3)[::5]     # 2
+    S = np.ascontiguousarray(np.concatenate([cube, face, edge, D[:5000] + np.float32(0.01)]).astype(np.float32))
+    r2 = np.float32(0.2 * 0.2)
+    tree = orc.KDTree(D, use_ref=orc.ref_available())
+    oi, _, ov = _ref_matches(tree, S, r2, len(S))
+    I = np.eye(4, dtype=np.float32)
+    out = {}
+    for name, opts in (("tiled", {"tiled": 2}), ("one lane per query", {"tiled": 0, "group_search": 0}), ("16 lanes per query", {"tiled": 0, "group_search": 16})):
+        ctx = Context()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_target(D, N); ctx.set_source(S)
+        ctx.find_correspondences(I, float(r2), count=False)
+        gi, gd = ctx.get_nn()
+        seen, moved = ctx.tie_rule_stats()
+        ctx.close()
+        bad = int(np.count_nonzero(_signed(gi) != oi))
+        out[name] = {"queries": int(len(S)), "tied": int(seen), "not_the_lowest_index": int(moved), "index_mismatches": bad}
+        assert bad == 0, (name, out[name])
+        assert seen >= len(cube) + len(face) + len(edge), (name, out[name])
+        assert np.array_equal(gd[oi >= 0].view(np.uint32), ov.view(np.uint32)), name
+    # the loop (rigid motion of the lattice source: ties in every iteration), two forms
+    for name, opts in (("adaptive", {}), ("warm forced", {"warm_start": 2})):
+        ctx = Context()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_target(D, N); ctx.set_source(S)
+        res = ctx.icp_run(_icp_params(ctx, r2, 4))
+        T = ctx.matches_transform()
+        li, _ = ctx.get_nn()
+        oi_l, _, _ = _ref_matches(tree, orc.transform_points(T, S), r2, len(S))
+        bad = int(np.count_nonzero(_signed(li) != oi_l))
+        out["loop, " + name] = {"index_mismatches_last_iteration": bad, "warm_iterations": ctx.last_warm_iterations()}
+        ctx.close()
+        assert bad == 0 and int(res.iterations) == 4, (name, out)
+    _report("tie_rule_lattice.json", out)
