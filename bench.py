@@ -278,6 +278,21 @@ def bench_icp(a, torch, rank, world, local_rank):
 
     sort_ms = ctx.prepare_source(T0, force=True) if not a.no_extras else None   # (the first run below would do it lazily)
     run(a.warmup, False)
+    if sharded:
+        # option tie_rule in the sharded protocol driven by hand here: did some rank's warm-up searches meet exactly equidistant nearest points
+        # without order tables?  (cilhip_icp_run does this by itself; the sharded loops of distributed.py too.)  One MAX over the ranks -- all take
+        # the same decision --, then every rank loads the order of the WHOLE target (a slab: the entries of its points) before the timed region.
+        try:
+            pend = torch.tensor([1.0 if (ctx.tie_order_info()["pending"] and not ctx.tie_order_info()["loaded"]) else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(pend, op=dist.ReduceOp.MAX)
+            if pend.item() > 0:
+                if strong:
+                    ctx.load_tie_order(distributed._tie_order_of(d["dst"]), np.ascontiguousarray(part.dst_index, np.uint32))
+                else:
+                    ctx.build_tie_order()
+                run(a.warmup, False)
+        except Exception as e:      # (a report's refinement, never a reason to lose the run)
+            print(f"[bench] tie order in the sharded run skipped: {e!r}", file=sys.stderr)
     barrier()
     t0 = time.perf_counter()
     res = run(a.steps, True)

@@ -293,3 +293,25 @@ def test_lattice_clouds_every_query_tied_eight_ways(Context, orc):
         ctx.close()
         assert bad == 0 and int(res.iterations) == 4, (name, out)
     _report("tie_rule_lattice.json", out)
+
+
+def test_affine_loop_names_the_reference_s_points_too(Context, orc):
+    """the Affine ICP instances search like the rigid ones (the reference's kd-tree over the TARGET does not know the transform family):
+    with default options the set an affine loop leaves on the cloud with doubled and tripled target points equals nanoflann's under the loop's last transform, index
+    for index (the tied queries stay tied under every transform: the candidates are the same point); under tie_rule 0 it does not."""
+    name, D, N, S, r2 = list(_clouds())[1]
+    tree = orc.KDTree(D, use_ref=orc.ref_available())
+    bad = {}
+    for rule in (2, 0):
+        ctx = Context(); ctx.set_option("tie_rule", rule); ctx.set_option("transform_mode", 1)
+        ctx.set_target(D, N); ctx.set_source(S)
+        p = _icp_params(ctx, r2, 4)
+        p.w_p2p = 0.1
+        res = ctx.icp_run(p)
+        assert int(res.iterations) == 4
+        T = ctx.matches_transform()
+        li, _ = ctx.get_nn()
+        oi, _, _ = _ref_matches(tree, orc.transform_points(T, S), r2, len(S))
+        bad[rule] = int(np.count_nonzero(_signed(li) != oi))
+        ctx.close()
+    assert bad[2] == 0 and bad[0] > 100, bad
