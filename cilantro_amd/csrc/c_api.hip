@@ -148,6 +148,8 @@ struct cilhip_ctx {
   double inlier_fraction = 1.0;
   bool one_to_one = false;
   unsigned long long* d_keys = nullptr;    // [ns]
+  unsigned long long* d_own_order = nullptr;   // [ns] this shard's traversal keys of the current iteration (cilhip_icp_order_keys)
+  int tie_max_depth = 0;                   // depth of the loaded order tree (the traversal keys hold 58 levels)
   void* d_sel_state = nullptr;
   unsigned long long* d_winner = nullptr;  // [n_target]
 
@@ -278,6 +280,8 @@ static void free_source(cilhip_ctx* c) {
   if (c->d_defer_mask) (void)hipFree(c->d_defer_mask);
   if (c->d_keys) (void)hipFree(c->d_keys);
   c->d_keys = nullptr;
+  if (c->d_own_order) (void)hipFree(c->d_own_order);
+  c->d_own_order = nullptr;
   c->d_tiles = nullptr; c->d_tile_center = nullptr; c->d_tile_box = nullptr; c->ntiles = 0; c->d_defer_mask = nullptr;
   c->d_src_xyz = nullptr; c->d_src_sorted = nullptr; c->d_nn_pos = nullptr; c->d_nn_d2 = nullptr;
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
@@ -814,9 +818,11 @@ static bool tile_accumulation(const cilhip_ctx* c) {
 // Is the option in force for this context's searches?  The order is the reference's kd-tree over the TARGET POINTS: it covers the
 // SECOND_TO_FIRST matches (also the forward half of BOTH) under rigid and affine transforms.  Feature adaptors search another
 // space (nanoflann's DIM = 6 / 9 tree), the reverse matches of FIRST_TO_SECOND / BOTH a tree over the transformed SOURCE that the
-// reference rebuilds every iteration, and an index shard of a target knows only its own points: those keep the lowest index
-// (tie_rule 2) or are refused (tie_rule 1, the explicit request).
-static bool tie_mode_on(const cilhip_ctx* c) { return c->tie_rule != 0 && !feat6(c) && c->index_offset == 0; }
+// reference rebuilds every iteration: those keep the lowest index (tie_rule 2) or are refused (tie_rule 1, the explicit request).  An
+// index shard of a target (cilhip_set_shard_info) notices and counts ties like any context, but never builds tables from its own points:
+// the order belongs to the WHOLE target's tree -- whoever owns the shards loads it (cilhip_load_tie_order with the global indices) and
+// runs the two-key protocol between them (cilhip_icp_order_keys).
+static bool tie_mode_on(const cilhip_ctx* c) { return c->tie_rule != 0 && !feat6(c); }
 static TieDev tie_dev_of(const cilhip_ctx* c) {
   TieDev t{};
   t.mode = tie_mode_on(c) ? 1 : 0;
@@ -846,6 +852,8 @@ static int load_tie_tables(cilhip_ctx* c, const uint32_t* leaf_by_index, const u
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (the host arrays and the two staging buffers live on this frame)
   (void)hipFree(d_leaf); (void)hipFree(d_slot);
   if (e != hipSuccess) { drop_tie_tables(c); c->err = std::string("tie_rule: loading the order tables: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
+  c->tie_max_depth = 0;
+  for (size_t k = 0; k < n_nodes; ++k) c->tie_max_depth = std::max(c->tie_max_depth, (int)(nodes[k].info >> 3));
   return CILHIP_OK;
 }
 // The tables of THIS context's target, built from the device's copy of it (the context keeps no host copy of a cloud).
@@ -881,17 +889,17 @@ static int read_tie_counters(cilhip_ctx* c, unsigned int out[4]) {
 // tie_rule 1: the tables before the first search; refusals of the explicit request (see tie_mode_on)
 static int tie_prepare(cilhip_ctx* c, const char* what) {
   c->tie_counters_fresh = false;      // (a new search / run: whatever the host holds of the counters is history)
-  if (c->tie_rule == 1 && (c->search_dir != 0 || feat6(c) || c->index_offset)) {
+  if (c->tie_rule == 1 && (c->search_dir != 0 || feat6(c) || (c->index_offset && !c->d_tie_leaf_slot))) {
     c->err = std::string(what) + ": tie_rule = 1 covers SECOND_TO_FIRST searches over point features on one whole target (tie_rule = 2 applies the reference's order where it is defined)";
     return CILHIP_ERR_UNSUPPORTED;
   }
-  if (c->tie_rule == 1 && tie_mode_on(c) && c->ns && c->grid.n) return build_tie_tables(c);
+  if (c->tie_rule == 1 && tie_mode_on(c) && !c->index_offset && c->ns && c->grid.n) return build_tie_tables(c);
   return CILHIP_OK;
 }
 // After a search / run: did it meet ties without tables (tie_rule 2)?  Then the tables are built and *again says: run it once more.
 static int tie_check_pending(cilhip_ctx* c, bool* again) {
   *again = false;
-  if (!tie_mode_on(c) || c->d_tie_leaf_slot || !c->ns || !c->grid.n) return CILHIP_OK;
+  if (!tie_mode_on(c) || c->index_offset || c->d_tie_leaf_slot || !c->ns || !c->grid.n) return CILHIP_OK;
   unsigned int cnt[4];
   if (c->tie_counters_fresh) {      // (a run's read_state has just brought them over with the loop state: no second round trip)
     memcpy(cnt, c->tie_counters_host, sizeof(cnt));
@@ -2401,7 +2409,8 @@ int cilhip_icp_partial_keys(cilhip_ctx* c, uint64_t* keys_dev) {
   CK(c, hipSetDevice(c->device));
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   if (c->ns) {
-    if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
+    if (c->grid.n == 0) CK(c, hipMemsetAsync(c->d_nn_pos, 0xFF, (size_t)c->ns * sizeof(uint32_t), c->stream));      // (a shard without target points: every key "none")
+    else if (use_tiled(c)) launch_search_tiled(a, IM_NONE, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
     else launch_iter(a, IM_NONE, true, true, iter_num_blocks(c->ns), c->stream);
     launch_pack_keys(c->d_src_sorted, c->grid.pts, c->d_nn_pos, c->d_nn_d2, c->ns, c->index_offset,
                      reinterpret_cast<unsigned long long*>(keys_dev), c->stream);
@@ -2422,9 +2431,52 @@ int cilhip_icp_sums_from_keys(cilhip_ctx* c, const uint64_t* keys_dev, double* s
   IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
   a.cw = corr_weights_of(c, &c->run_prm);
   const int nb = iter_num_blocks(c->ns);
-  if (c->ns) {
+  if (c->ns && c->grid.n) {
     launch_keys_to_pos(c->d_src_sorted, reinterpret_cast<const unsigned long long*>(keys_dev), c->d_inv_perm, c->ns,
-                       c->index_offset, c->grid.n, c->d_nn_pos, c->d_nn_d2, c->stream);
+                       c->index_offset, c->grid.n, c->d_nn_pos, c->d_nn_d2, c->stream,
+                       (tie_mode_on(c) && !c->d_tie_leaf_slot) ? c->d_tie_counters : nullptr);
+    launch_iter(a, im, false, false, nb, c->stream);
+    launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);
+  } else {
+    CK(c, hipMemsetAsync(sums_dev, 0, SUMS_MAX * sizeof(double), c->stream));
+  }
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
+// The reference's tie order across target shards (kernels.hip: tie_rank): after the MIN all-reduce of cilhip_icp_partial_keys' keys,
+//   cilhip_icp_order_keys(ctx, win_keys_dev, order_keys_dev)   order_keys_dev[i] = where this shard's match of source point i comes in
+//                                                              the query's traversal of the WHOLE target's tree, if it is at the
+//                                                              winning distance; 0x7fff...f otherwise
+//   all-reduce(MIN, 64-bit) of order_keys_dev                  -> the first-met point of the whole target
+//   cilhip_icp_sums_from_ordered_keys(ctx, win_keys_dev, order_keys_dev, sums_dev)   accumulates the pairs whose key came back
+// Needs the whole target's order tables on every shard (cilhip_load_tie_order with the shard's global indices).
+int cilhip_icp_order_keys(cilhip_ctx* c, const uint64_t* win_keys_dev, uint64_t* order_keys_dev) {
+  if (!c || !win_keys_dev || !order_keys_dev) return CILHIP_ERR_INVALID;
+  if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
+  if (!c->d_tie_leaf_slot) return fail(c, CILHIP_ERR_INVALID, "icp_order_keys: load the whole target's tie order first (cilhip_load_tie_order)");
+  if (c->tie_max_depth > 58) return fail(c, CILHIP_ERR_UNSUPPORTED, "icp_order_keys: the order tree is deeper than the 58 levels a traversal key holds");
+  CK(c, hipSetDevice(c->device));
+  if (!c->d_own_order) CK(c, hipMalloc(&c->d_own_order, (c->ns ? c->ns : 1) * sizeof(unsigned long long)));
+  TieDev t = tie_dev_of(c);
+  launch_order_keys(c->d_src_sorted, c->d_state, reinterpret_cast<const unsigned long long*>(win_keys_dev), c->d_nn_pos, c->d_nn_d2, c->ns, t,
+                    c->d_own_order, reinterpret_cast<unsigned long long*>(order_keys_dev), c->stream);
+  CK(c, hipGetLastError());
+  return CILHIP_OK;
+}
+
+int cilhip_icp_sums_from_ordered_keys(cilhip_ctx* c, const uint64_t* win_keys_dev, const uint64_t* order_keys_dev, double* sums_dev) {
+  if (!c || !win_keys_dev || !order_keys_dev || !sums_dev) return CILHIP_ERR_INVALID;
+  if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
+  if (!c->d_own_order) return fail(c, CILHIP_ERR_INVALID, "icp_sums_from_ordered_keys: cilhip_icp_order_keys first");
+  CK(c, hipSetDevice(c->device));
+  const int im = iter_metric_of(c, &c->run_prm);
+  IterArgs a = make_iter_args(c, c->run_prm.max_sq_dist);
+  a.cw = corr_weights_of(c, &c->run_prm);
+  const int nb = iter_num_blocks(c->ns);
+  if (c->ns && c->grid.n) {
+    launch_select_ordered(c->d_src_sorted, c->d_own_order, reinterpret_cast<const unsigned long long*>(order_keys_dev),
+                          reinterpret_cast<const unsigned long long*>(win_keys_dev), c->ns, c->d_nn_pos, c->d_nn_d2, c->stream);
     launch_iter(a, im, false, false, nb, c->stream);
     launch_reduce_partials(c->d_partials, nb, c->d_stage, sums_dev, c->stream);
   } else {
@@ -2555,6 +2607,15 @@ __global__ void k_sum_shards(double* const* bufs, int n) {
   for (int s = 0; s < n; ++s) v += bufs[s][k];
   for (int s = 0; s < n; ++s) bufs[s][k] = v;
 }
+// partitioning A on one device: out[r][i] = min over shards of in[s][i]  (what ncclAllReduce(ncclUint64, ncclMin) does between devices)
+__global__ void k_min_shards(unsigned long long* const* bufs, int n, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long v = bufs[0][i];
+    for (int s = 1; s < n; ++s) { const unsigned long long w = bufs[s][i]; v = w < v ? w : v; }
+    for (int s = 0; s < n; ++s) bufs[s][i] = v;
+  }
+}
+constexpr int RCCL_UINT64 = 5, RCCL_MIN = 3;      // ncclUint64 / ncclMin of rccl.h
 }  // namespace
 
 struct cilhip_multi {
@@ -2566,6 +2627,9 @@ struct cilhip_multi {
   RcclApi rccl;
   std::vector<rccl_comm_t> comms;
   double** d_bufs = nullptr;       // (same-device reduction) the shards' sum buffers
+  // partitioning A (index shards of the target): per shard the packed (d2, global index) keys and the traversal keys of one iteration
+  std::vector<unsigned long long*> d_keys, d_okeys;
+  unsigned long long** d_kbufs = nullptr;      // (same-device reduction) [2 n]: the shards' key buffers, then their traversal-key buffers
   std::vector<hipEvent_t> ev;
   std::string err;
   // the clouds (host copies: slabs are cut again when the guard fires)
@@ -2596,6 +2660,15 @@ struct cilhip_multi {
 
 static int mfail(cilhip_multi* m, int code, const std::string& msg) { if (m) m->err = msg; return code; }
 static int multi_upload_fwd(cilhip_multi* m);
+static void multi_free_keys(cilhip_multi* m) {
+  for (size_t r = 0; r < m->d_keys.size(); ++r) {
+    (void)hipSetDevice(m->dev[r]);
+    if (m->d_keys[r]) (void)hipFree(m->d_keys[r]);
+    if (m->d_okeys[r]) (void)hipFree(m->d_okeys[r]);
+  }
+  m->d_keys.clear(); m->d_okeys.clear();
+  if (m->d_kbufs) { (void)hipSetDevice(m->dev[0]); (void)hipFree(m->d_kbufs); m->d_kbufs = nullptr; }
+}
 #define MCK(m, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return mfail((m), CILHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 #define MCTX(m, r, call) do { const int rc_ = (call); if (rc_ != CILHIP_OK) return mfail((m), rc_, std::string(#call) + ": " + cilhip_last_error((m)->ctx[r])); } while (0)
 
@@ -2648,6 +2721,7 @@ void cilhip_multi_destroy(cilhip_multi* m) {
     if (m->ctx[r]) cilhip_destroy(m->ctx[r]);
   }
   if (m->d_bufs) (void)hipFree(m->d_bufs);
+  multi_free_keys(m);
   for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
   cilhip_tie_order_destroy(m->order);
   delete m;
@@ -2687,8 +2761,10 @@ static int multi_upload(cilhip_multi* m);
 static int multi_upload_fwd(cilhip_multi* m) { return multi_upload(m); }
 static int multi_upload(cilhip_multi* m) {
   const int n = m->n;
+  if (m->partition != 2) multi_free_keys(m);
   if (m->partition == 0) {
     for (int r = 0; r < n; ++r) {
+      MCTX(m, r, cilhip_set_shard_info(m->ctx[r], 0, nullptr, nullptr));      // (not an index shard, whatever the handle held before)
       const size_t base = m->ns / n, rem = m->ns % n;
       const size_t lo = r * base + std::min<size_t>(r, rem), hi = lo + base + ((size_t)r < rem ? 1 : 0);
       MCTX(m, r, cilhip_set_target(m->ctx[r], m->dst.data(), m->dstn.empty() ? nullptr : m->dstn.data(), m->nd, CILHIP_MEM_HOST));
@@ -2696,6 +2772,37 @@ static int multi_upload(cilhip_multi* m) {
       MCTX(m, r, cilhip_set_source(m->ctx[r], m->src.data() + 3 * lo, hi - lo, CILHIP_MEM_HOST));
       MCTX(m, r, cilhip_set_slab_guard(m->ctx[r], -1, 0.0f, nullptr, nullptr, nullptr));
       m->n_dst_local[r] = m->nd; m->n_src_local[r] = hi - lo;
+    }
+    return CILHIP_OK;
+  }
+  if (m->partition == 2) {
+    // index shards of the TARGET (SURVEY 8(e) partitioning A; distributed.py TargetShardedRigidICP: the same cut): shard r holds the
+    // target points [lo_r, hi_r) and ALL source points; per iteration MIN of the packed keys, then SUM of the partial sums
+    multi_free_keys(m);
+    m->d_keys.assign(n, nullptr); m->d_okeys.assign(n, nullptr);
+    m->gidx.assign(n, std::vector<uint32_t>());
+    static const float no_points[3] = {0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < n; ++r) {
+      const size_t base = m->nd / n, rem = m->nd % n;
+      const size_t lo = r * base + std::min<size_t>(r, rem), hi = lo + base + ((size_t)r < rem ? 1 : 0);
+      MCTX(m, r, cilhip_set_target(m->ctx[r], hi > lo ? m->dst.data() + 3 * lo : no_points, m->dstn.empty() ? nullptr : (hi > lo ? m->dstn.data() + 3 * lo : no_points), hi - lo, CILHIP_MEM_HOST));
+      m->gidx[r].resize(hi - lo);
+      for (size_t i = lo; i < hi; ++i) m->gidx[r][i - lo] = (uint32_t)i;
+      if (m->order) MCTX(m, r, cilhip_load_tie_order(m->ctx[r], m->order, m->gidx[r].empty() ? nullptr : m->gidx[r].data()));
+      MCTX(m, r, cilhip_set_source(m->ctx[r], m->src.data(), m->ns, CILHIP_MEM_HOST));
+      MCTX(m, r, cilhip_set_shard_info(m->ctx[r], lo, m->gdm, m->gsm));
+      MCTX(m, r, cilhip_set_slab_guard(m->ctx[r], -1, 0.0f, nullptr, nullptr, nullptr));
+      MCK(m, hipSetDevice(m->dev[r]));
+      MCK(m, hipMalloc(&m->d_keys[r], (m->ns ? m->ns : 1) * sizeof(unsigned long long)));
+      MCK(m, hipMalloc(&m->d_okeys[r], (m->ns ? m->ns : 1) * sizeof(unsigned long long)));
+      m->n_dst_local[r] = hi - lo; m->n_src_local[r] = m->ns;
+    }
+    if (!m->distinct && n > 1) {
+      std::vector<unsigned long long*> both(m->d_keys);
+      both.insert(both.end(), m->d_okeys.begin(), m->d_okeys.end());
+      MCK(m, hipSetDevice(m->dev[0]));
+      MCK(m, hipMalloc(&m->d_kbufs, both.size() * sizeof(unsigned long long*)));
+      MCK(m, hipMemcpy(m->d_kbufs, both.data(), both.size() * sizeof(unsigned long long*), hipMemcpyHostToDevice));
     }
     return CILHIP_OK;
   }
@@ -2749,7 +2856,8 @@ extern "C" {
 
 int cilhip_multi_set_clouds(cilhip_multi* m, const float* dst_xyz, const float* dst_nrm, size_t nd, const float* src_xyz, size_t ns, float max_sq_dist,
                             int partition, const float* T_part) {
-  if (!m || (nd && !dst_xyz) || (ns && !src_xyz) || (partition != 0 && partition != 1)) return CILHIP_ERR_INVALID;
+  if (!m || (nd && !dst_xyz) || (ns && !src_xyz) || partition < 0 || partition > 2) return CILHIP_ERR_INVALID;
+  if (partition == 2 && nd > 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
   m->dst.assign(dst_xyz, dst_xyz + 3 * nd);
   if (dst_nrm) m->dstn.assign(dst_nrm, dst_nrm + 3 * nd); else m->dstn.clear();
   m->src.assign(src_xyz, src_xyz + 3 * ns);
@@ -2796,6 +2904,83 @@ static int multi_allreduce(cilhip_multi* m) {
   return CILHIP_OK;
 }
 
+// partitioning A: the MIN all-reduce of one 64-bit key per source point, in place (which = 0: the packed (d2, global index) keys, 1: the
+// traversal keys of the tie order)
+static int multi_reduce_keys(cilhip_multi* m, int which) {
+  if (m->n == 1 && m->comms.empty()) return CILHIP_OK;
+  std::vector<unsigned long long*>& buf = which ? m->d_okeys : m->d_keys;
+  if (m->ns == 0) return CILHIP_OK;
+  if (m->distinct) {
+    if (m->rccl.GroupStart() != 0) return mfail(m, CILHIP_ERR_HIP, "ncclGroupStart");
+    for (int r = 0; r < m->n; ++r)
+      if (m->rccl.AllReduce(buf[r], buf[r], m->ns, RCCL_UINT64, RCCL_MIN, m->comms[r], m->ctx[r]->stream) != 0) return mfail(m, CILHIP_ERR_HIP, "ncclAllReduce(min)");
+    if (m->rccl.GroupEnd() != 0) return mfail(m, CILHIP_ERR_HIP, "ncclGroupEnd");
+    return CILHIP_OK;
+  }
+  MCK(m, hipSetDevice(m->dev[0]));
+  for (int r = 1; r < m->n; ++r) { MCK(m, hipEventRecord(m->ev[r], m->ctx[r]->stream)); MCK(m, hipStreamWaitEvent(m->ctx[0]->stream, m->ev[r], 0)); }
+  const int nb = (int)std::min<size_t>((m->ns + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_min_shards, dim3(nb), dim3(256), 0, m->ctx[0]->stream, m->d_kbufs + (which ? m->n : 0), m->n, m->ns);
+  MCK(m, hipEventRecord(m->ev[0], m->ctx[0]->stream));
+  for (int r = 1; r < m->n; ++r) MCK(m, hipStreamWaitEvent(m->ctx[r]->stream, m->ev[0], 0));
+  return CILHIP_OK;
+}
+
+// `iters` iterations of partitioning A: every shard's keys, their MIN; with the whole target's tie order loaded (some search met
+// exactly equidistant nearest points) the traversal keys of the matches at the winning distance and THEIR MIN; every shard's sums over
+// the pairs it won, the all-reduce of the 48 f64, every shard's epilogue.  One host thread per shard as in multi_iterate.
+static int multi_iterate_keys(cilhip_multi* m, int iters) {
+  const int n = m->n;
+  const bool ordered = m->order != nullptr;
+  auto shard_step = [&](int r, int step) -> int {
+    switch (step) {
+      case 0: return cilhip_icp_partial_keys(m->ctx[r], reinterpret_cast<uint64_t*>(m->d_keys[r]));
+      case 1: return cilhip_icp_order_keys(m->ctx[r], reinterpret_cast<const uint64_t*>(m->d_keys[r]), reinterpret_cast<uint64_t*>(m->d_okeys[r]));
+      case 2: return ordered ? cilhip_icp_sums_from_ordered_keys(m->ctx[r], reinterpret_cast<const uint64_t*>(m->d_keys[r]), reinterpret_cast<const uint64_t*>(m->d_okeys[r]), m->d_sums[r])
+                             : cilhip_icp_sums_from_keys(m->ctx[r], reinterpret_cast<const uint64_t*>(m->d_keys[r]), m->d_sums[r]);
+      default: return cilhip_icp_apply_sums(m->ctx[r], m->d_sums[r]);
+    }
+  };
+  auto joint_step = [&](int step) -> int { return step == 0 ? multi_reduce_keys(m, 0) : (step == 1 ? multi_reduce_keys(m, 1) : (step == 2 ? multi_allreduce(m) : CILHIP_OK)); };
+  m->host_us_per_iter_shard = 0.0;
+  if (n == 1 || !m->threads) {
+    for (int k = 0; k < iters; ++k)
+      for (int step = 0; step < 4; ++step) {
+        if (step == 1 && !ordered) continue;
+        for (int r = 0; r < n; ++r) MCTX(m, r, shard_step(r, step));
+        { const int rc = joint_step(step); if (rc) return rc; }
+      }
+    return CILHIP_OK;
+  }
+  std::atomic<int> arrived{0}, generation{0}, failed{0};
+  std::vector<int> rcs(n, CILHIP_OK);
+  int reduce_rc = CILHIP_OK;
+  auto rendezvous = [&]() {
+    const int gen = generation.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { arrived.store(0, std::memory_order_relaxed); generation.fetch_add(1, std::memory_order_release); }
+    else for (unsigned spins = 0; generation.load(std::memory_order_acquire) == gen; ++spins) cpu_relax(spins);
+  };
+  auto worker = [&](int r) {
+    (void)hipSetDevice(m->dev[r]);
+    for (int k = 0; k < iters; ++k)
+      for (int step = 0; step < 4; ++step) {
+        if (step == 1 && !ordered) continue;
+        if (!failed.load(std::memory_order_relaxed)) { const int rc = shard_step(r, step); if (rc) { rcs[r] = rc; failed.store(1); } }
+        if (step == 3) break;      // (the epilogue: the next iteration's search follows on the same stream)
+        rendezvous();
+        if (r == 0 && !failed.load()) { const int rc = joint_step(step); if (rc) { reduce_rc = rc; failed.store(1); } }
+        rendezvous();
+      }
+  };
+  std::vector<std::thread> th;
+  for (int r = 1; r < n; ++r) th.emplace_back(worker, r);
+  worker(0);
+  for (auto& x : th) x.join();
+  (void)hipSetDevice(m->dev[0]);
+  for (int r = 0; r < n; ++r) if (rcs[r]) return mfail(m, rcs[r], std::string("shard ") + std::to_string(r) + ": " + cilhip_last_error(m->ctx[r]));
+  return reduce_rc;
+}
+
 // `iters` iterations of {every shard's partial sums, the all-reduce of the 48 f64, every shard's epilogue}.  One host thread PER SHARD
 // (each enqueues on its own device's stream: at 8 devices x ~4 launches x ~5 us one thread walking the shards would bound an
 // iteration whose kernels take ~15 us), two rendezvous per iteration around the all-reduce, which one thread issues for all (RCCL
@@ -2803,6 +2988,7 @@ static int multi_allreduce(cilhip_multi* m) {
 // rendezvous early.
 static int multi_iterate(cilhip_multi* m, int iters) {
   if (iters <= 0) return CILHIP_OK;
+  if (m->partition == 2) return multi_iterate_keys(m, iters);
   const auto t_begin = std::chrono::steady_clock::now();
   if (m->n == 1 || !m->threads) {
     double host = 0.0;
@@ -2899,7 +3085,7 @@ int cilhip_multi_icp_run(cilhip_multi* m, const cilhip_icp_params* p, const floa
   rc = cilhip_tie_order_create(m->dst.data(), m->nd, &m->order);
   if (rc) return mfail(m, rc, "tie_rule: building the order tables of the whole target failed");
   for (int r = 0; r < m->n; ++r)
-    MCTX(m, r, cilhip_load_tie_order(m->ctx[r], m->order, (m->partition == 1 && !m->gidx[r].empty()) ? m->gidx[r].data() : nullptr));
+    MCTX(m, r, cilhip_load_tie_order(m->ctx[r], m->order, (m->partition != 0 && !m->gidx[r].empty()) ? m->gidx[r].data() : nullptr));
   m->tie_pending = false;
   return multi_icp_run_once(m, p, T0, check_every, out);
 }

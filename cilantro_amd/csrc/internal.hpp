@@ -333,7 +333,12 @@ void launch_gather_by_w(const float4* src_sorted, const float* in_xyz, uint32_t 
 void launch_pack_keys(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos, const float* nn_d2,
                       uint32_t ns, uint32_t index_offset, unsigned long long* keys, hipStream_t s);
 void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys, const uint32_t* inv_perm, uint32_t ns,
-                        uint32_t index_offset, uint32_t n_local, uint32_t* nn_pos, float* nn_d2, hipStream_t s);
+                        uint32_t index_offset, uint32_t n_local, uint32_t* nn_pos, float* nn_d2, hipStream_t s, unsigned int* tie_counter = nullptr);
+// the reference's tie order across target shards: traversal keys of the matches at the winning distance / the selection after their MIN
+void launch_order_keys(const float4* src_sorted, const IcpState* state, const unsigned long long* win, const uint32_t* nn_pos, const float* nn_d2,
+                       uint32_t ns, const TieDev& tt, unsigned long long* own, unsigned long long* out, hipStream_t s);
+void launch_select_ordered(const float4* src_sorted, const unsigned long long* own, const unsigned long long* reduced, const unsigned long long* win,
+                           uint32_t ns, uint32_t* nn_pos, float* nn_d2, hipStream_t s);
 void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s);
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
 // queries (sorted source under T) whose nearest target point within the radius is not unique in the pinned f32 distance

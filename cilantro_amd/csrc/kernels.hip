@@ -3813,18 +3813,78 @@ __global__ void k_pack_keys(const float4* __restrict__ src_sorted, const float4*
 }
 
 // after the MIN all-reduce: keep the pairs whose winning target lives in THIS rank's shard
+// (tie_counter != null -- option "tie_rule" in force, no order tables yet: a shard whose own nearest point is exactly as far as the
+//  winner's but is not the winner has met a tie ACROSS shards; counted like the ties a search notices inside its shard)
 __global__ void k_keys_to_pos(const float4* __restrict__ src_sorted, const unsigned long long* __restrict__ keys,
                               const uint32_t* __restrict__ inv_perm, uint32_t ns, uint32_t index_offset, uint32_t n_local,
-                              uint32_t* nn_pos, float* nn_d2) {
+                              uint32_t* nn_pos, float* nn_d2, unsigned int* tie_counter) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
     const unsigned long long k = keys[__float_as_uint(src_sorted[i].w)];
     uint32_t pos = NONE_U32;
     if (k != KEY_NONE) {
       const uint32_t gidx = (uint32_t)k;
       if (gidx >= index_offset && gidx - index_offset < n_local) pos = inv_perm[gidx - index_offset];
+      if (tie_counter != nullptr && pos == NONE_U32 && nn_pos[i] != NONE_U32 && __float_as_uint(nn_d2[i]) == (uint32_t)(k >> 32)) atomicAdd(tie_counter, 1u);
     }
     nn_pos[i] = pos;
     nn_d2[i] = __uint_as_float((uint32_t)(k >> 32));
+  }
+}
+
+// ---- the reference's tie order ACROSS target shards ---------------------------------------------------------------------------------
+// Inside a shard tie_settle() leaves the shard's first-met point among the equidistant ones (the traversal order of one query is a
+// total order over the WHOLE target's tree: the first of a subset is well defined).  Between shards the MIN of (d2, global index)
+// would pick the lowest index instead.  So a second key per query: the position of the shard's match in the query's traversal -- per
+// level of the tree one bit, 0 = the child searchLevel descends into first (nanoflann.hpp:1931-1947), most significant = the root's
+// children, then the slot inside the leaf (leaf_max_size 10 < 16) -- published by every shard whose match is at the winning distance;
+// the MIN over the shards is the first-met point of the whole target, its owner recognises its own key.  Depth <= 58 (checked when
+// the tables are loaded).
+__device__ __forceinline__ unsigned long long tie_rank(const TieDev& tt, float qx, float qy, float qz, uint32_t pos) {
+  const uint2 ls = tt.leaf_slot[pos];
+  uint4 N = tt.nodes[ls.x];
+  unsigned long long key = (unsigned long long)((ls.y - N.z) & 15u);      // (a leaf's record: z = the slot of its first point)
+  while ((N.y >> 3) != 0u) {
+    const uint4 P = tt.nodes[N.x];
+    const uint32_t feat = (P.y >> 1) & 3u;
+    const float val = feat == 0u ? qx : (feat == 1u ? qy : qz);
+    const float diff1 = __fsub_rn(val, __uint_as_float(P.z)), diff2 = __fsub_rn(val, __uint_as_float(P.w));
+    const uint32_t first_is_second = __fadd_rn(diff1, diff2) < 0.0f ? 0u : 1u;
+    if ((N.y & 1u) != first_is_second) key |= 1ull << (62u - (N.y >> 3));
+    N = P;
+  }
+  return key;
+}
+// own[orig] = out[orig] = the traversal key of this shard's match if it is at the winning distance, "none" otherwise
+__global__ void k_order_keys(const float4* __restrict__ src_sorted, const IcpState* __restrict__ state, const unsigned long long* __restrict__ win,
+                             const uint32_t* __restrict__ nn_pos, const float* __restrict__ nn_d2, uint32_t ns, TieDev tt,
+                             unsigned long long* own, unsigned long long* out) {
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = state->T[i];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const float4 s4 = src_sorted[i];
+    const uint32_t orig = __float_as_uint(s4.w);
+    const unsigned long long k = win[orig];
+    const uint32_t lp = nn_pos[i];
+    unsigned long long ok = KEY_NONE;
+    if (lp != NONE_U32 && k != KEY_NONE && __float_as_uint(nn_d2[i]) == (uint32_t)(k >> 32)) {
+      float qx, qy, qz;
+      transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+      ok = tie_rank(tt, qx, qy, qz, lp);
+    }
+    own[orig] = ok;
+    out[orig] = ok;
+  }
+}
+// after the MIN all-reduce of the traversal keys: this shard keeps the matches whose key came back
+__global__ void k_select_ordered(const float4* __restrict__ src_sorted, const unsigned long long* __restrict__ own,
+                                 const unsigned long long* __restrict__ reduced, const unsigned long long* __restrict__ win, uint32_t ns,
+                                 uint32_t* nn_pos, float* nn_d2) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t orig = __float_as_uint(src_sorted[i].w);
+    const unsigned long long o = own[orig];
+    if (o == KEY_NONE || o != reduced[orig]) nn_pos[i] = NONE_U32;
+    nn_d2[i] = __uint_as_float((uint32_t)(win[orig] >> 32));
   }
 }
 
@@ -3840,8 +3900,16 @@ void launch_pack_keys(const float4* src_sorted, const float4* dst_sorted, const 
   if (ns) hipLaunchKernelGGL(k_pack_keys, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, dst_sorted, nn_pos, nn_d2, ns, index_offset, keys);
 }
 void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys, const uint32_t* inv_perm, uint32_t ns,
-                        uint32_t index_offset, uint32_t n_local, uint32_t* nn_pos, float* nn_d2, hipStream_t s) {
-  if (ns) hipLaunchKernelGGL(k_keys_to_pos, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, keys, inv_perm, ns, index_offset, n_local, nn_pos, nn_d2);
+                        uint32_t index_offset, uint32_t n_local, uint32_t* nn_pos, float* nn_d2, hipStream_t s, unsigned int* tie_counter) {
+  if (ns) hipLaunchKernelGGL(k_keys_to_pos, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, keys, inv_perm, ns, index_offset, n_local, nn_pos, nn_d2, tie_counter);
+}
+void launch_order_keys(const float4* src_sorted, const IcpState* state, const unsigned long long* win, const uint32_t* nn_pos, const float* nn_d2,
+                       uint32_t ns, const TieDev& tt, unsigned long long* own, unsigned long long* out, hipStream_t s) {
+  if (ns) hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, state, win, nn_pos, nn_d2, ns, tt, own, out);
+}
+void launch_select_ordered(const float4* src_sorted, const unsigned long long* own, const unsigned long long* reduced, const unsigned long long* win,
+                           uint32_t ns, uint32_t* nn_pos, float* nn_d2, hipStream_t s) {
+  if (ns) hipLaunchKernelGGL(k_select_ordered, dim3(blocks_for(ns)), dim3(256), 0, s, src_sorted, own, reduced, win, ns, nn_pos, nn_d2);
 }
 void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_inv_perm, dim3(blocks_for(n)), dim3(256), 0, s, dst_sorted, n, inv);

@@ -26,6 +26,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -40,7 +41,7 @@ namespace cilhip {
 struct TieNode {          // 16 bytes: one load on the device
   int32_t parent;         // -1: the root
   uint32_t info;          // (depth << 3) | (split dimension << 1) | (1: this node is its parent's SECOND child)
-  float divlow, divhigh;  // internal nodes
+  float divlow, divhigh;  // internal nodes: the split; a leaf: divlow = the slot of its first point (as bits)
 };
 
 class TieOrderTree {
@@ -124,7 +125,10 @@ class TieOrderTree {
         nd.parent = b.parent.list < 0 ? -1 : (int32_t)(base[b.parent.list] + (uint32_t)b.parent.id);
         nd.info = ((uint32_t)b.depth << 3) | ((uint32_t)b.feat << 1) | (b.second ? 1u : 0u);
         nd.divlow = b.divlow; nd.divhigh = b.divhigh;
-        if (b.leaf) for (uint32_t s = b.left; s < b.right; ++s) { leaf_of_[recs_[s].idx] = id; slot_of_[recs_[s].idx] = s; }
+        if (b.leaf) {
+          for (uint32_t s = b.left; s < b.right; ++s) { leaf_of_[recs_[s].idx] = id; slot_of_[recs_[s].idx] = s; }
+          memcpy(&nd.divlow, &b.left, 4);      // (a leaf has no split: the field holds the slot of its first point, as bits -- slot - that = place inside the leaf)
+        }
       }
     });
     recs_.clear(); recs_.shrink_to_fit();

@@ -252,9 +252,13 @@ KEY_NONE = 0x7FFFFFFFFFFFFFFF  # packed (d2, global index) key meaning "no neigh
 
 class HipTargetShardEngine:
     """Per-rank engine for a target cloud sharded by index over the ranks: this rank indexes
-    dst[lo:hi) only, holds ALL source points, and tags its matches with GLOBAL target indices."""
+    dst[lo:hi) only, holds ALL source points, and tags its matches with GLOBAL target indices.
 
-    def __init__(self, dst_shard, dst_normals_shard, src_points, index_offset, global_dst_mean, device):
+    whole_target (optional, HOST array of the whole cloud's points -- host memory holds what one device does not): lets the loop follow
+    the reference's order among exactly equidistant nearest points, inside a shard and across shards (c_api.h: cilhip_icp_order_keys);
+    without it such ties go to the lowest global index."""
+
+    def __init__(self, dst_shard, dst_normals_shard, src_points, index_offset, global_dst_mean, device, whole_target=None):
         import torch
 
         from .icp import Context
@@ -266,7 +270,10 @@ class HipTargetShardEngine:
         self.ctx.set_shard_info(index_offset, dst_mean=global_dst_mean)
         dev = f"cuda:{device}"
         self.keys = torch.full((max(self.ctx.n_source, 1),), KEY_NONE, dtype=torch.int64, device=dev)
+        self.okeys = None
         self.sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=dev)
+        self._whole, self._offset, self._n_local = whole_target, int(index_offset), len(np.asarray(dst_shard).reshape(-1, 3))
+        self.ordered = False
 
     def begin(self, params, T0):
         self.ctx.icp_begin(params, T0, None)
@@ -277,6 +284,27 @@ class HipTargetShardEngine:
 
     def sums_from_keys(self, keys):
         self.ctx.icp_sums_from_keys(keys.data_ptr(), self.sums.data_ptr())
+        return self.sums
+
+    # -- the reference's tie order (two keys per iteration once some search has met a tie)
+    def ties_pending(self):
+        if self._whole is None or self.ordered:
+            return False
+        return self.ctx.tie_order_info()["pending"] > 0
+
+    def load_tie_order(self):
+        if self._whole is None:
+            return
+        self.ctx.load_tie_order(_tie_order_of(self._whole), np.arange(self._offset, self._offset + self._n_local, dtype=np.uint32) if self._n_local else None)
+        self.okeys = self.torch.full_like(self.keys, KEY_NONE)
+        self.ordered = True
+
+    def order_keys(self, keys):
+        self.ctx.icp_order_keys(keys.data_ptr(), self.okeys.data_ptr())
+        return self.okeys
+
+    def sums_from_ordered_keys(self, keys, okeys):
+        self.ctx.icp_sums_from_ordered_keys(keys.data_ptr(), okeys.data_ptr(), self.sums.data_ptr())
         return self.sums
 
     def apply_sums(self, sums):
@@ -291,7 +319,10 @@ class HipTargetShardEngine:
 class TargetShardedRigidICP:
     """ICP with the TARGET sharded over the ranks: two collectives per iteration --
     all-reduce(MIN) of one packed int64 key per source point (the global nearest neighbour; ring cost
-    2(G-1)/G x 8 B x Ns per GPU over xGMI), then all-reduce(SUM) of the 48 accumulated f64."""
+    2(G-1)/G x 8 B x Ns per GPU over xGMI), then all-reduce(SUM) of the 48 accumulated f64.  When some rank's searches meet exactly
+    equidistant nearest points (inside its shard or against another rank's) and the engines can load the whole target's tie order, the
+    run is repeated with a third collective per iteration: the MIN of the traversal keys (cilhip_icp_order_keys) -- the reference's
+    matches, index for index."""
 
     def __init__(self, engine, dist=None, group=None):
         self.engine, self.dist, self.group = engine, dist, group
@@ -300,13 +331,27 @@ class TargetShardedRigidICP:
         return self.dist is not None and self.dist.get_world_size(self.group) > 1
 
     def estimate(self, params, T0=None):
+        out = self._estimate_once(params, T0)
+        if not getattr(self.engine, "ordered", True) and _ties_pending_anywhere(self.engine, self.dist, self.group):
+            self.engine.load_tie_order()
+            out = self._estimate_once(params, T0)
+        return out
+
+    def _estimate_once(self, params, T0=None):
         T0 = np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32)
         self.engine.begin(params, T0)
+        ordered = getattr(self.engine, "ordered", False)
         for _ in range(int(params.max_iter)):
             keys = self.engine.partial_keys()
             if self._multi():
                 self.dist.all_reduce(keys, op=self.dist.ReduceOp.MIN, group=self.group)
-            sums = self.engine.sums_from_keys(keys)
+            if ordered:
+                okeys = self.engine.order_keys(keys)
+                if self._multi():
+                    self.dist.all_reduce(okeys, op=self.dist.ReduceOp.MIN, group=self.group)
+                sums = self.engine.sums_from_ordered_keys(keys, okeys)
+            else:
+                sums = self.engine.sums_from_keys(keys)
             if self._multi():
                 self.dist.all_reduce(sums, group=self.group)
             self.engine.apply_sums(sums)

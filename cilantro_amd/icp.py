@@ -273,6 +273,13 @@ class Context:
     def icp_sums_from_keys(self, keys_dev_ptr, sums_dev_ptr):
         self._ck(self._L.cilhip_icp_sums_from_keys(self._h, C.c_void_p(keys_dev_ptr), C.c_void_p(sums_dev_ptr)))
 
+    def icp_order_keys(self, win_keys_dev_ptr, order_keys_dev_ptr):
+        """the reference's tie order across target shards (c_api.h: cilhip_icp_order_keys): the second key of the two-key protocol"""
+        self._ck(self._L.cilhip_icp_order_keys(self._h, C.c_void_p(win_keys_dev_ptr), C.c_void_p(order_keys_dev_ptr)))
+
+    def icp_sums_from_ordered_keys(self, win_keys_dev_ptr, order_keys_dev_ptr, sums_dev_ptr):
+        self._ck(self._L.cilhip_icp_sums_from_ordered_keys(self._h, C.c_void_p(win_keys_dev_ptr), C.c_void_p(order_keys_dev_ptr), C.c_void_p(sums_dev_ptr)))
+
     def set_slab_guard(self, axis, slack=0.0, center=None, half_extent=None, T_part=None):
         if axis is None or axis < 0:
             self._ck(self._L.cilhip_set_slab_guard(self._h, -1, C.c_float(0.0), None, None, None))

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import capi
 
-PARTITION_SOURCE_SHARDS, PARTITION_SLABS = 0, 1
+PARTITION_SOURCE_SHARDS, PARTITION_SLABS, PARTITION_TARGET_SHARDS = 0, 1, 2
 
 
 class MultiDeviceRigidICP:

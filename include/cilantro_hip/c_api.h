@@ -222,6 +222,21 @@ int cilhip_set_shard_info(cilhip_ctx* ctx, uint64_t target_index_offset, const f
                           const float* src_mean_or_null);
 int cilhip_icp_partial_keys(cilhip_ctx* ctx, uint64_t* keys_dev);
 int cilhip_icp_sums_from_keys(cilhip_ctx* ctx, const uint64_t* keys_dev, double* sums_dev);
+/* Exactly equidistant nearest points across shards: MIN of (d2, global index) keeps the lowest global index, the reference's kd-tree
+ * the first one its traversal meets (core/kd_tree.hpp:82-90, nanoflann.hpp:1885-1961).  A shard notices such a tie in
+ * cilhip_icp_sums_from_keys (its own nearest point is exactly as far as the winner's) and counts it like the ties its searches notice
+ * (cilhip_get_tie_order_info: pending).  With the WHOLE target's order loaded on every shard (cilhip_tie_order_create over the whole
+ * cloud, cilhip_load_tie_order with the shard's global indices) the searches settle the ties inside a shard, and a second key settles
+ * them between shards -- per iteration, after the MIN of the first keys:
+ *   cilhip_icp_order_keys(ctx, win_keys_dev, order_keys_dev)    order_keys_dev[i] = position of this shard's match of source point i in
+ *                                                                 that query's traversal of the whole tree (one bit per level: 0 = the
+ *                                                                 child nanoflann's searchLevel descends into first; then the slot
+ *                                                                 in the leaf) if the match is at the winning distance, else 0x7fff...f
+ *   all-reduce(MIN, 64-bit) of order_keys_dev
+ *   cilhip_icp_sums_from_ordered_keys(ctx, win_keys_dev, order_keys_dev, sums_dev)   accumulates the pairs whose key came back
+ * Trees deeper than 58 levels: CILHIP_ERR_UNSUPPORTED.  cilhip_multi_set_clouds(partition = 2) runs this protocol by itself. */
+int cilhip_icp_order_keys(cilhip_ctx* ctx, const uint64_t* win_keys_dev, uint64_t* order_keys_dev);
+int cilhip_icp_sums_from_ordered_keys(cilhip_ctx* ctx, const uint64_t* win_keys_dev, const uint64_t* order_keys_dev, double* sums_dev);
 
 /* ---- residuals ------------------------------------------------------------------------------- */
 /* computeResiduals() of both classes (icp_single_transform_combined_metric.hpp:220-243,
@@ -410,7 +425,12 @@ int cilhip_icp_run_two_sets(cilhip_ctx* ctx_point, float max_sq_point, cilhip_ct
  * target's bounding box, target slabs with a halo of sqrt(max_sq_dist) + slack (slack = 2 sqrt(max_sq_dist)), source points by the
  * slab their image under T_part (null: identity; cilhip_multi_icp_run re-cuts under its T0) falls into, the device-side guard
  * armed (cilhip_set_slab_guard) and handled inside cilhip_multi_icp_run: all shards re-partitioned under the last exact
- * transform, no exact iteration discarded.  Engine options are set per shard through cilhip_multi_context(rank). */
+ * transform, no exact iteration discarded; 2 = the TARGET in contiguous index shards, the whole source on every device (SURVEY.md 8(e)
+ * partitioning A: for a target that does not fit one device): per iteration an all-reduce(MIN) of one packed (d2, global index) key
+ * per source point (ncclUint64 / ncclMin over RCCL), every shard accumulates the pairs it won, then the all-reduce of the sums; when
+ * the searches meet exactly equidistant nearest points (inside a shard or across shards) the whole target's tie order is built once
+ * and the run repeated with a second MIN per iteration (cilhip_icp_order_keys): the reference's matches, index for index.
+ * Engine options are set per shard through cilhip_multi_context(rank). */
 typedef struct cilhip_multi cilhip_multi;
 int cilhip_multi_create(cilhip_multi** out, const int* devices, int ndev);
 void cilhip_multi_destroy(cilhip_multi* m);

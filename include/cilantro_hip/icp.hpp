@@ -554,7 +554,7 @@ private:
 // rigid combined / point-to-point metrics with their defaults (icp_single_transform_combined_metric.hpp:44-47).
 class MultiDeviceRigidICP {
 public:
-  enum struct Partition { SourceShards = 0, Slabs = 1 };
+  enum struct Partition { SourceShards = 0, Slabs = 1, TargetShards = 2 };      // TargetShards: index shards of the target, MIN of packed keys per iteration
   explicit MultiDeviceRigidICP(const std::vector<int>& devices) {
     if (cilhip_multi_create(&m_, devices.data(), (int)devices.size()) != CILHIP_OK)
       throw std::runtime_error("cilhip_multi_create failed (no usable HIP devices / RCCL for these ordinals; there is no CPU fallback)");

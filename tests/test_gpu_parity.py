@@ -2128,10 +2128,10 @@ def test_ranked_library_loop_one_rank_is_bitwise_the_python_protocol(hip_lib):
 def test_multi_device_c_entry_one_gpu(Context, orc, hip_lib):
     """cilhip_multi_*: the sharded loop driven from C in ONE process (SURVEY.md 8(b) devices[]).  What a single-GPU box can check:
     one shard == cilhip_icp_run bit for bit; several shards on the same device (devices = [0, 0, 0]: the all-reduce runs as the
-    same-device kernel instead of RCCL) -- source shards and spatial slabs -- give the single-context loop's transform to the
+    same-device kernel instead of RCCL) -- source shards, spatial slabs and index shards of the target -- give the single-context loop's transform to the
     order of the f64 additions, iteration for iteration, also when the slab guard fires and all shards are cut again; the loop
     against the oracle's."""
-    from cilantro_amd.multi import PARTITION_SLABS, PARTITION_SOURCE_SHARDS, MultiDeviceRigidICP
+    from cilantro_amd.multi import PARTITION_SLABS, PARTITION_SOURCE_SHARDS, PARTITION_TARGET_SHARDS, MultiDeviceRigidICP
 
     d = syn.make_pair(400_000, perturb=0.6)
     dst, dst_n, src, r2 = d["dst"], d["dst_n"], d["src"], d["max_sq_dist"]
@@ -2157,10 +2157,13 @@ def test_multi_device_c_entry_one_gpu(Context, orc, hip_lib):
     finally:
         del os.environ["CILHIP_MULTI_FORCE_RCCL"]
     assert np.array_equal(np.array(r1.T[:], np.float32).view(np.uint32), T_ref.view(np.uint32)) and int(r1.iterations) == 8
-    for part in (PARTITION_SOURCE_SHARDS, PARTITION_SLABS):
+    for part in (PARTITION_SOURCE_SHARDS, PARTITION_SLABS, PARTITION_TARGET_SHARDS):
         m = MultiDeviceRigidICP([0, 0, 0]); m.set_clouds(dst, dst_n, src, r2, part)
         sizes = [m.shard_sizes(k) for k in range(3)]
-        assert sum(s[1] for s in sizes) == len(src)
+        if part == PARTITION_TARGET_SHARDS:      # (index shards of the target, the whole source everywhere: MIN of packed keys per iteration)
+            assert sum(s[0] for s in sizes) == len(dst) and all(s[1] == len(src) for s in sizes)
+        else:
+            assert sum(s[1] for s in sizes) == len(src)
         if part == PARTITION_SLABS:
             assert all(0 < s[0] < len(dst) for s in sizes)      # every device holds its slab + halo only
         rr = m.icp_run(params(8)); T = np.array(rr.T[:], np.float32)

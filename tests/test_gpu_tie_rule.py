@@ -243,23 +243,28 @@ def test_empty_target_shard_keeps_the_point_to_plane_branch(Context, orc):
     assert np.abs(np.array(rr.T[:], np.float32).astype(np.float64) - np.array(ref.T[:], np.float32).astype(np.float64)).max() <= 2e-6
 
 
+def _lattice(m):
+    """target on a regular lattice (shuffled: the reference's tree depends on the order of the points); queries at the centres of its
+    cubes (8 exactly equidistant corners each), of faces (4), of edges (2), and a few off-lattice ones"""
+    ax = (np.arange(m, dtype=np.float32) * np.float32(0.125)).astype(np.float32)
+    D = np.ascontiguousarray(np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3))
+    rng = np.random.default_rng(5)
+    D = np.ascontiguousarray(D[rng.permutation(len(D))])
+    N = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (len(D), 1))
+    c = (np.arange(m - 1, dtype=np.float32) * np.float32(0.125) + np.float32(0.0625)).astype(np.float32)
+    cube = np.stack(np.meshgrid(c, c, c, indexing="ij"), -1).reshape(-1, 3)
+    face = np.stack(np.meshgrid(c, c, ax[:-1], indexing="ij"), -1).reshape(-1, 3)[::3]
+    edge = np.stack(np.meshgrid(c, ax[:-1], ax[:-1], indexing="ij"), -1).reshape(-1, 3)[::5]
+    S = np.ascontiguousarray(np.concatenate([cube, face, edge, D[:5000] + np.float32(0.01)]).astype(np.float32))
+    return D, N, S, np.float32(0.2 * 0.2), len(cube) + len(face) + len(edge)
+
+
 def test_lattice_clouds_every_query_tied_eight_ways(Context, orc):
     """A target on a regular lattice and queries at the centres of its cubes: EVERY query has eight exactly equidistant nearest target
     points (any number of candidates: the old host path gave up beyond eight); queries on face and edge centres: four and two.  The
     engine names nanoflann's choice for each, in a single search (tiled and global-memory kernels, one lane and sixteen lanes per query)
     and through the loop's forms."""
-    m = 40
-    ax = (np.arange(m, dtype=np.float32) * np.float32(0.125)).astype(np.float32)
-    D = np.ascontiguousarray(np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3))
-    rng = np.random.default_rng(5)
-    D = np.ascontiguousarray(D[rng.permutation(len(D))])      # (the reference's tree depends on the order of the points)
-    N = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (len(D), 1))
-    c = (np.arange(m - 1, dtype=np.float32) * np.float32(0.125) + np.float32(0.0625)).astype(np.float32)
-    cube = np.stack(np.meshgrid(c, c, c, indexing="ij"), -1).reshape(-1, 3)                       # 8 corners each
-    face = np.stack(np.meshgrid(c, c, ax[:-1], indexing="ij"), -1).reshape(-1, 3)[::3]           # 4
-    edge = np.stack(np.meshgrid(c, ax[:-1], ax[:-1], indexing="ij"), -1).reshape(-1, 3)[::5]     # 2
-    S = np.ascontiguousarray(np.concatenate([cube, face, edge, D[:5000] + np.float32(0.01)]).astype(np.float32))
-    r2 = np.float32(0.2 * 0.2)
+    D, N, S, r2, n_tied = _lattice(40)
     tree = orc.KDTree(D, use_ref=orc.ref_available())
     oi, _, ov = _ref_matches(tree, S, r2, len(S))
     I = np.eye(4, dtype=np.float32)
@@ -276,7 +281,7 @@ def test_lattice_clouds_every_query_tied_eight_ways(Context, orc):
         bad = int(np.count_nonzero(_signed(gi) != oi))
         out[name] = {"queries": int(len(S)), "tied": int(seen), "not_the_lowest_index": int(moved), "index_mismatches": bad}
         assert bad == 0, (name, out[name])
-        assert seen >= len(cube) + len(face) + len(edge), (name, out[name])
+        assert seen >= n_tied, (name, out[name])
         assert np.array_equal(gd[oi >= 0].view(np.uint32), ov.view(np.uint32)), name
     # the loop (rigid motion of the lattice source: ties in every iteration), two forms
     for name, opts in (("adaptive", {}), ("warm forced", {"warm_start": 2})):
@@ -315,3 +320,71 @@ def test_affine_loop_names_the_reference_s_points_too(Context, orc):
         bad[rule] = int(np.count_nonzero(_signed(li) != oi))
         ctx.close()
     assert bad[2] == 0 and bad[0] > 100, bad
+
+
+def test_target_shards_follow_the_reference_s_order_across_shards(Context, orc):
+    """Partitioning A (index shards of the TARGET, MIN of packed keys) on the lattice: the equidistant corners of a query lie in different
+    shards.  One key per query gives the lowest global index; with the whole target's order loaded, the second key (the match's place in
+    the query's traversal of the whole tree, cilhip_icp_order_keys) gives nanoflann's point, index for index -- driven by hand over three
+    engines for one search, then as loops: cilhip_multi_icp_run(partition = 2) on three shards of one device (the run notices the ties,
+    builds the order once, repeats) against the single-context loop."""
+    import torch
+
+    from cilantro_amd import distributed
+    from cilantro_amd.multi import PARTITION_TARGET_SHARDS, MultiDeviceRigidICP
+
+    D, N, S, r2, n_tied = _lattice(24)
+    tree = orc.KDTree(D, use_ref=orc.ref_available())
+    oi, _, _ = _ref_matches(tree, S, r2, len(S))
+    I = np.eye(4, dtype=np.float32)
+    nd = len(D)
+    cuts = [0, nd // 3, 2 * nd // 3, nd]
+    dm = D.astype(np.float64).mean(axis=0).astype(np.float32)
+    c = Context(); p = _icp_params(c, r2, 4); p.w_p2p = 0.1; c.close()
+    engs = [distributed.HipTargetShardEngine(D[lo:hi], N[lo:hi], S, lo, dm, 0, whole_target=D) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    NONE = distributed.KEY_NONE
+    for e in engs:
+        e.begin(p, I)
+    own = [e.partial_keys().clone() for e in engs]
+    keys = torch.minimum(torch.minimum(own[0], own[1]), own[2])
+    for e in engs:
+        e.sums_from_keys(keys)
+    assert not any(e.ordered for e in engs) and sum(e.ctx.tie_order_info()["pending"] for e in engs) >= n_tied // 2      # noticed: inside shards and across them
+    kh = keys.cpu().numpy()
+    lowest = np.where(kh == NONE, -1, kh & 0xFFFFFFFF).astype(np.int64)
+    differ_lowest = int(np.count_nonzero(lowest != oi))
+    assert differ_lowest > n_tied // 4 and np.array_equal(lowest >= 0, oi >= 0)
+    for e in engs:
+        e.load_tie_order(); e.begin(p, I)
+    own = [e.partial_keys().clone() for e in engs]
+    keys = torch.minimum(torch.minimum(own[0], own[1]), own[2])
+    mine = [e.order_keys(keys).clone() for e in engs]
+    okeys = torch.minimum(torch.minimum(mine[0], mine[1]), mine[2])
+    gi = np.full(len(S), -1, np.int64); winners = np.zeros(len(S), np.int32)
+    oh = okeys.cpu().numpy()
+    for r in range(3):
+        w = (mine[r].cpu().numpy() == oh) & (oh != NONE)
+        gi[w] = own[r].cpu().numpy()[w] & 0xFFFFFFFF
+        winners += w
+    assert np.array_equal(winners, (oi >= 0).astype(np.int32))      # every matched query is won by exactly one shard
+    assert np.array_equal(gi, oi), int(np.count_nonzero(gi != oi))
+    sums = engs[0].sums_from_ordered_keys(keys, okeys).clone() + engs[1].sums_from_ordered_keys(keys, okeys) + engs[2].sums_from_ordered_keys(keys, okeys)
+    del engs
+    # the same first iteration's sums from one context over the whole target (default options: the reference's order)
+    ctx = Context(); ctx.set_target(D, N); ctx.set_source(S)
+    ref = ctx.icp_run(p)
+    T_ref = np.array(ref.T[:], np.float32)
+    assert ctx.tie_order_info()["loaded"]
+    ctx.close()
+    out = {"queries": int(len(S)), "tied": int(n_tied), "lowest_index_differs_from_the_reference": differ_lowest, "two_key_mismatches": 0}
+    for devs in ([0, 0, 0], [0]):
+        m = MultiDeviceRigidICP(devs); m.set_clouds(D, N, S, r2, PARTITION_TARGET_SHARDS)
+        sizes = [m.shard_sizes(k) for k in range(len(devs))]
+        assert sum(s[0] for s in sizes) == nd and all(s[1] == len(S) for s in sizes)
+        rr = m.icp_run(p); m.close()
+        T = np.array(rr.T[:], np.float32)
+        err = float(np.abs(T.astype(np.float64) - T_ref.astype(np.float64)).max())
+        out[f"loop_{len(devs)}_shards_minus_single_context"] = err
+        assert int(rr.iterations) == 4 and int(rr.last_ncorr) == int(ref.last_ncorr) and err <= 2e-6, (devs, err, int(rr.last_ncorr), int(ref.last_ncorr))
+    assert float(sums.sum().item()) == float(sums.sum().item())      # (finite)
+    _report("tie_rule_target_shards.json", out)
