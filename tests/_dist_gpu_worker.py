@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_distributed.py: the product's sharded loops (cilantro_amd/distributed.py) with the PRODUCT's per-rank
-engines (HipShardEngine / HipSlabEngine over libcilantro_hip.so), one process per rank, all ranks on cuda:0 (one GPU per box), the
+engines (HipShardEngine / HipSlabEngine / HipTargetShardEngine over libcilantro_hip.so), one process per rank, all ranks on cuda:0 (one GPU per box), the
 48-double exchange over gloo.  Prints rank 0's result as JSON."""
 import json
 import os
@@ -39,6 +39,12 @@ def main():
         lo, hi = distributed.shard_bounds(len(d["src"]), rank, world)
         eng = distributed.HipShardEngine(d["dst"], d["dst_n"], d["src"][lo:hi], 0)
         T, it, delta, nc = distributed.ShardedRigidICP(eng, dist).estimate(p, T0, check_every=0)
+        extra["tables_loaded"] = eng.ctx.tie_order_info()["loaded"]
+    elif mode == "tshard":      # partitioning A: index shards of the target, MIN of packed keys (+ the traversal keys once ties were met)
+        lo, hi = distributed.shard_bounds(len(d["dst"]), rank, world)
+        dm = d["dst"].astype(np.float64).mean(axis=0).astype(np.float32)
+        eng = distributed.HipTargetShardEngine(d["dst"][lo:hi], d["dst_n"][lo:hi], d["src"], lo, dm, 0, whole_target=d["dst"])
+        T, it, delta, nc = distributed.TargetShardedRigidICP(eng, dist).estimate(p, T0)
         extra["tables_loaded"] = eng.ctx.tie_order_info()["loaded"]
     else:
         slack = None if mode == "slab" else float(mode[4:]) * d["h"]

@@ -41,7 +41,7 @@ def _run(world, mode, kind, n, iters):
     return json.loads(line[7:])
 
 
-@pytest.mark.parametrize("mode,kind", [("source", "plain"), ("slab", "plain"), ("slab0.01", "plain"), ("source", "dup"), ("slab", "dup")])
+@pytest.mark.parametrize("mode,kind", [("source", "plain"), ("slab", "plain"), ("slab0.01", "plain"), ("source", "dup"), ("slab", "dup"), ("tshard", "plain"), ("tshard", "dup")])
 def test_hip_engines_across_two_processes(orc, hip_lib, mode, kind):
     import _dist_gpu_worker as w
 
