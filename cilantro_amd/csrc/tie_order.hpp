@@ -265,6 +265,29 @@ class TieOrderTree {
     return a_second == first_is_second;
   }
 
+  // Where point `a` comes in query q's traversal, as ONE number (smaller = met earlier): per level from the root one bit -- 0 = the node on
+  // a's path is the child searchLevel descends into first -- most significant first, then a's place inside its leaf.  Comparing two
+  // points' keys is before(): the paths share their bits down to the lowest common ancestor and differ right below it.  What the device
+  // publishes per query when a target is held in index shards (kernels.hip: tie_rank): the MIN over the shards is the first-met point of
+  // the whole target.  Holds max_depth() <= 58 levels and leaves of up to 16 points.
+ public:
+  uint64_t traversal_key(const float q[3], uint32_t a) const {
+    uint32_t n = leaf_of_[a];
+    uint32_t left; memcpy(&left, &nodes_[n].divlow, 4);
+    uint64_t key = (uint64_t)((slot_of_[a] - left) & 15u);
+    while ((nodes_[n].info >> 3) != 0u) {
+      const TieNode& p = nodes_[(uint32_t)nodes_[n].parent];
+      const float val = q[(p.info >> 1) & 3u];
+      const float diff1 = val - p.divlow, diff2 = val - p.divhigh;
+      const uint32_t first_is_second = (diff1 + diff2) < 0 ? 0u : 1u;
+      if ((nodes_[n].info & 1u) != first_is_second) key |= 1ull << (62u - (nodes_[n].info >> 3));
+      n = (uint32_t)nodes_[n].parent;
+    }
+    return key;
+  }
+  uint32_t max_depth() const { uint32_t d = 0; for (const TieNode& t : nodes_) d = std::max(d, t.info >> 3); return d; }
+ private:
+
   uint32_t n_ = 0, leaf_max_ = 10;
   unsigned threads_ = 1;
   bool built_ = false;

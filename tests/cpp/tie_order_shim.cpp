@@ -20,6 +20,18 @@ void tie_shim_first_met(void* h, const float* q, const uint32_t* cand, const int
   const Shim* s = static_cast<const Shim*>(h);
   for (uint32_t k = 0; k < nq; ++k) out[k] = s->tree.first_met(q + 3 * (size_t)k, cand + (size_t)k * stride, count[k]);
 }
+// per query k: out[k] = the candidate with the smallest traversal key (what the MIN over index shards of a target leaves); *depth = the tree's
+void tie_shim_min_key(void* h, const float* q, const uint32_t* cand, const int* count, int stride, uint32_t nq, uint32_t* out, uint32_t* depth) {
+  const Shim* s = static_cast<const Shim*>(h);
+  for (uint32_t k = 0; k < nq; ++k) {
+    uint64_t best = ~0ull;
+    for (int j = 0; j < count[k]; ++j) {
+      const uint64_t key = s->tree.traversal_key(q + 3 * (size_t)k, cand[(size_t)k * stride + j]);
+      if (key < best) { best = key; out[k] = cand[(size_t)k * stride + j]; }
+    }
+  }
+  *depth = s->tree.max_depth();
+}
 // the reference's permutation (slot of every point), leaf populations and depths: what must not depend on how many threads built the tree
 // (node ids do: they are list positions)
 int tie_shim_same_order(void* ha, void* hb) {

@@ -28,6 +28,7 @@ def shim():
     L.tie_shim_same_order.argtypes = [C.c_void_p, C.c_void_p]
     L.tie_shim_free.argtypes = [C.c_void_p]
     L.tie_shim_first_met.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p]
+    L.tie_shim_min_key.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -84,6 +85,25 @@ def test_first_met_is_the_reference_pick(shim, orc):
         assert np.array_equal(got, oi[sel]), (name, int(np.count_nonzero(got != oi[sel])))
         # (and the rule matters: the lowest index is a different point for a good part of them)
         assert np.count_nonzero(cand[:, 0].astype(np.int64) != oi[sel]) > len(sel) // 4, name
+
+
+def test_smallest_traversal_key_is_the_reference_pick(shim, orc):
+    """index shards of a target settle ties between shards by ONE number per candidate (TieOrderTree::traversal_key; on the device
+    kernels.hip tie_rank): the candidate with the smallest key is the one the reference's nanoflann returns, whatever the number of
+    candidates; the keys' 58 levels are far from exhausted on these clouds"""
+    for name, D, S, r2 in _clouds():
+        sel, cand, counts = tied_queries(D, S, r2)
+        h = shim.tie_shim_build(np.ascontiguousarray(D, np.float32).ctypes.data, len(D))
+        q = np.ascontiguousarray(S[sel], np.float32)
+        out = np.zeros(len(q), np.uint32); depth = np.zeros(1, np.uint32)
+        shim.tie_shim_min_key(h, q.ctypes.data, cand.ctypes.data, counts.ctypes.data, K, len(q), out.ctypes.data, depth.ctypes.data)
+        shim.tie_shim_free(h)
+        tree = orc.KDTree(D, use_ref=orc.ref_available())
+        o1, o2, _ = tree.find_correspondences(S, r2)
+        oi = np.full(len(S), -1, np.int64)
+        oi[o2] = o1
+        assert np.array_equal(out.astype(np.int64), oi[sel]), (name, int(np.count_nonzero(out.astype(np.int64) != oi[sel])))
+        assert 8 <= int(depth[0]) <= 40, (name, int(depth[0]))
 
 
 def test_threads_do_not_change_the_order(shim):
