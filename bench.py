@@ -542,6 +542,21 @@ def bench_icp(a, torch, rank, world, local_rank):
                 m8.close()
             os.environ.pop("CILHIP_MULTI_THREADS", None)
             extras["multi_device_c_loop_8_shards_one_gpu"] = dict(leg, entry="cilhip_multi_icp_run, devices = [0] x 8, spatial slabs, state read once at the end")
+            # partitioning A from C: the TARGET in two index shards on this one GPU, the whole source on both (every query is searched twice,
+            # a MIN of one 64-bit key per query between the shards, each shard accumulates what it won): the protocol's cost, not a scaling figure
+            from cilantro_amd.multi import PARTITION_TARGET_SHARDS
+            m2 = MultiDeviceRigidICP([local_rank] * 2)
+            m2.set_clouds(d["dst"], d["dst_n"] if with_normals else None, d["src"], float(d["max_sq_dist"]), PARTITION_TARGET_SHARDS)
+            p.max_iter = a.warmup; m2.icp_run(p, T0, check_every=1 << 20)
+            p.max_iter = a.steps; m2.icp_run(p, T0, check_every=1 << 20)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r2 = m2.icp_run(p, T0, check_every=1 << 20)
+            torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+            extras["multi_device_c_loop_2_target_shards_one_gpu"] = {
+                "entry": "cilhip_multi_icp_run, devices = [0] x 2, partition 2 (index shards of the target, MIN of packed keys per iteration), state read once at the end",
+                "ms_per_step": dt2 * 1e3 / a.steps,
+                "max_abs_T_difference_to_the_timed_run": float(np.abs(np.array(r2.T[:], np.float32).reshape(4, 4).T - np.array(res.T[:], np.float32).reshape(4, 4).T).max())}
+            m2.close()
         except Exception as e:
             extras["multi_device_c_loop_one_shard"] = {"error": repr(e)}
         out.update(extras)

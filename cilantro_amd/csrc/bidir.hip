@@ -68,7 +68,7 @@ __device__ __forceinline__ float mapped_bound(float gap, const InvArgs& iv) { re
 // scan stays 3-D: d6 >= d3.
 template <bool FEAT6>
 __device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, uint32_t beg, uint32_t end, const float* T, float px, float py, float pz,
-                                               unsigned long long& bkey, uint32_t& bpos, const FeatSpec* fs = nullptr, float pfx = 0.f, float pfy = 0.f,
+                                               unsigned long long& bkey, uint32_t& bpos, uint32_t& tie, const FeatSpec* fs = nullptr, float pfx = 0.f, float pfy = 0.f,
                                                float pfz = 0.f, float pgx = 0.f, float pgy = 0.f, float pgz = 0.f) {
   if (beg >= end) return;
   const uint32_t last = end - 1;
@@ -97,7 +97,27 @@ __device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, u
         e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       }
       const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(c[k].w);
+      // (another source point at exactly the best distance so far -- not the clamped re-read of the same record: settled after the search,
+      //  where the candidates at the FINAL distance are enumerated again; a flag raised for a distance that is beaten later costs that look)
+      tie |= ((uint32_t)(key >> 32) == (uint32_t)(bkey >> 32) && key != bkey) ? 1u : 0u;
       if (key < bkey) { bkey = key; bpos = jj[k]; }
+    }
+  }
+}
+
+// settling a tie of the reverse search: every source point of [beg, end) whose transformed image is at EXACTLY bd from the target point
+// p is a candidate; the first one the reference's traversal of its tree over the transformed source meets (query = p) is kept
+__device__ __forceinline__ void scan_range_inv_ties(const float4* __restrict__ pts, uint32_t beg, uint32_t end, const float* T, float px, float py, float pz,
+                                                    float bd, const TieDev& tt, uint32_t& cur, uint32_t& ncand) {
+  for (uint32_t j = beg; j < end; ++j) {
+    const float4 c = pts[j];
+    float qx, qy, qz;
+    transform_point(T, c.x, c.y, c.z, qx, qy, qz);
+    const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
+    const float e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    if (__float_as_uint(e) == __float_as_uint(bd)) {
+      ++ncand;
+      if (j != cur && tie_before(tt, px, py, pz, j, cur)) cur = j;
     }
   }
 }
@@ -105,7 +125,7 @@ __device__ __forceinline__ void scan_range_inv(const float4* __restrict__ pts, u
 template <bool FEAT6>
 __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over the source, source space*/, const float4* __restrict__ dst_sorted, uint32_t nd,
                                                         const IcpState* __restrict__ st, InvArgs iv, float max_sq, uint32_t* __restrict__ rev_pos,
-                                                        float* __restrict__ rev_d2, FeatSpec fs) {
+                                                        float* __restrict__ rev_d2, FeatSpec fs, TieDev tt) {
   if (st->done) return;
   float T[16];
 #pragma unroll
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
     float sx, sy, sz;
     transform_point(iv.Ti, p.x, p.y, p.z, sx, sy, sz);
     unsigned long long bkey = (unsigned long long)__float_as_uint(max_sq) << 32;
-    uint32_t bpos = NONE_U32;
+    uint32_t bpos = NONE_U32, tie = 0u;
     const float BIG = 1.0e9f;
     const int cx = (int)floorf(fminf(fmaxf((sx - sg.ox) * sg.inv_cell, -BIG), BIG));
     const int cy = (int)floorf(fminf(fmaxf((sy - sg.oy) * sg.inv_cell, -BIG), BIG));
@@ -162,12 +182,12 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
           const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
           if (face) {
             const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
-            if (xa <= xb) scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
+            if (xa <= xb) scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
           } else {
             if (xlo >= 0 && xlo < sg.nx)
-              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
+              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
             if (xhi >= 0 && xhi < sg.nx)
-              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
+              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
           }
         }
       }
@@ -182,6 +202,52 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
       if (b == INFINITY) break;  // the block covers the grid: everything scanned
       const float lb = mapped_bound(b - sg.margin, iv);
       if (lb > 0.0f && __uint_as_float((uint32_t)(bkey >> 32)) < lb * lb * KS) break;
+    }
+    if (!FEAT6 && tt.mode != 0 && tie != 0u && bpos != NONE_U32) {
+      // option "tie_rule": the same shells again with the distance fixed (a row or a shell AT the distance is looked at: the bounds are strict)
+      if (tt.leaf_slot == nullptr) {
+        atomicAdd(tt.counters + 3, 1u);
+      } else {
+        const float bd = __uint_as_float((uint32_t)(bkey >> 32));
+        uint32_t cur = bpos, ncand = 0u;
+        for (int s2 = max(0, max(max(-cx, cx - (sg.nx - 1)), max(max(-cy, cy - (sg.ny - 1)), max(-cz, cz - (sg.nz - 1)))));; ++s2) {
+          const int z0 = max(cz - s2, 0), z1 = min(cz + s2, sg.nz - 1);
+          const int y0 = max(cy - s2, 0), y1 = min(cy + s2, sg.ny - 1);
+          const int xlo = cx - s2, xhi = cx + s2;
+          for (int z = z0; z <= z1; ++z) {
+            const bool zface = (z == cz - s2) || (z == cz + s2);
+            const float zl = sg.oz + (float)z * sg.cell;
+            const float gz = fmaxf(fmaxf(zl - sz, sz - (zl + sg.cell)) - sg.margin, 0.0f);
+            for (int y = y0; y <= y1; ++y) {
+              const bool face = zface || (y == cy - s2) || (y == cy + s2);
+              const float yl = sg.oy + (float)y * sg.cell;
+              const float gy = fmaxf(fmaxf(yl - sy, sy - (yl + sg.cell)) - sg.margin, 0.0f);
+              const float lbr = mapped_bound(sqrtf(gz * gz + gy * gy), iv);
+              if (lbr * lbr * KS > bd) continue;
+              const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
+              if (face) {
+                const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
+                if (xa <= xb) scan_range_inv_ties(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
+              } else {
+                if (xlo >= 0 && xlo < sg.nx) scan_range_inv_ties(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
+                if (s2 > 0 && xhi >= 0 && xhi < sg.nx) scan_range_inv_ties(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
+              }
+            }
+          }
+          float b2 = INFINITY;
+          if (cx - s2 > 0) b2 = fminf(b2, sx - (sg.ox + (float)(cx - s2) * sg.cell));
+          if (cx + s2 + 1 < sg.nx) b2 = fminf(b2, (sg.ox + (float)(cx + s2 + 1) * sg.cell) - sx);
+          if (cy - s2 > 0) b2 = fminf(b2, sy - (sg.oy + (float)(cy - s2) * sg.cell));
+          if (cy + s2 + 1 < sg.ny) b2 = fminf(b2, (sg.oy + (float)(cy + s2 + 1) * sg.cell) - sy);
+          if (cz - s2 > 0) b2 = fminf(b2, sz - (sg.oz + (float)(cz - s2) * sg.cell));
+          if (cz + s2 + 1 < sg.nz) b2 = fminf(b2, (sg.oz + (float)(cz + s2 + 1) * sg.cell) - sz);
+          if (b2 == INFINITY) break;
+          const float lb2 = mapped_bound(b2 - sg.margin, iv);
+          if (lb2 > 0.0f && bd < lb2 * lb2 * KS) break;
+        }
+        if (ncand >= 2u) { atomicAdd(tt.counters + 1, 1u); if (cur != bpos) atomicAdd(tt.counters + 2, 1u); }
+        bpos = cur;
+      }
     }
     rev_pos[jd] = bpos;
     rev_d2[jd] = __uint_as_float((uint32_t)(bkey >> 32));
@@ -365,7 +431,7 @@ static unsigned bits_for_u32(uint32_t n) {
 // one search, as the reference builds its kd-tree.
 hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgrid, const float* d_src_xyz, const float* d_src_nrm, const float4* src_sorted, uint32_t ns,
                       const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq, int direction, bool reciprocal,
-                      double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2, PairSet& out, hipStream_t s) {
+                      double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2, PairSet& out, hipStream_t s, const TieDev* rev_tie) {
   enum { REV_POS, REV_D2, KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, WINNER, SEL_KEYS, SEL_STATE, TMP };
   const uint32_t nd = g.n;
   out.count = 0;
@@ -419,8 +485,8 @@ hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgr
   do {
     const float4* cand_pts = sgrid.pts;
     if (through_inverse) {
-      if (feat.enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat);
-      else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat);
+      if (feat.enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat, TieDev{});
+      else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(nd)), dim3(256), 0, s, sgrid, g.pts, nd, state, iv, max_sq, rev_pos, rev_d2, feat, rev_tie ? *rev_tie : TieDev{});
     } else {
       if (feat.enabled) { e = hipErrorNotSupported; break; }      // (a feature search under a (nearly) singular transform: not implemented)
       if ((e = hipMalloc(&d_q, 3 * (size_t)ns * sizeof(float))) != hipSuccess) break;
@@ -483,7 +549,7 @@ hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgr
 }
 
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
-                                 const FeatSpec* feat) {
+                                 const FeatSpec* feat, const TieDev* rev_tie) {
   if (g.n == 0) return;
   InvArgs iv{};
   iv.rigid_on_device = 1;
@@ -492,8 +558,8 @@ void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const I
   const double ext_s = std::max({std::fabs((double)sgrid.ox), std::fabs((double)sgrid.oy), std::fabs((double)sgrid.oz)}) + (double)std::max(sgrid.nx, std::max(sgrid.ny, sgrid.nz)) * sgrid.cell;
   iv.eps = (float)(8e-6 * (ext_t + ext_s) + 1e-4 * ext_s);   // rounding of p' and of T s, and |T p' - p| for a linear part up to 1e-4 off orthonormal
   FeatSpec none{};
-  if (feat && feat->enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, *feat);
-  else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, none);
+  if (feat && feat->enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, *feat, TieDev{});
+  else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, none, rev_tie ? *rev_tie : TieDev{});
 }
 
 }  // namespace cilhip

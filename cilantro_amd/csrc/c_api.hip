@@ -108,6 +108,17 @@ struct cilhip_ctx {
   bool tie_counters_fresh = false;
   double tie_build_ms = 0.0;                     // host time of the last table build (tree + upload)
   int tie_builds = 0;                            // table builds on this context (diagnostics)
+  // the reverse matches of FIRST_TO_SECOND / BOTH: the reference's tree is over the TRANSFORMED source, a new one per search -- once a
+  // reverse search has met exactly equidistant source points (or under tie_rule 1) the host builds that tree's order tables before
+  // every reverse search (the loops then run host-driven, one search at a time)
+  bool rev_tie_aware = false;
+  uint2* d_rev_tie_leaf_slot = nullptr;          // [ns] by position in the source grid; valid for rev_tie_T only
+  uint4* d_rev_tie_nodes = nullptr;
+  size_t rev_tie_nodes_cap = 0;
+  bool rev_tie_valid = false;
+  float rev_tie_T[16];
+  std::vector<float> h_src;                      // host copy of the source (original order), fetched once for those builds
+  int rev_tie_builds = 0;
   float warm_extra = 0.0625f;     // option "warm_extra_fraction"
   bool pair_records = true;       // option "pair_records": the streaming accumulation gathers a match's point and normal from one 32-byte record (GridDev::pn)
   void* rank_comm = nullptr; int rank_comm_size = 0; double* d_rank_sums = nullptr;      // cilhip_rank_comm_*: this process' rank in an RCCL communicator
@@ -217,6 +228,12 @@ static void drop_src_grid(cilhip_ctx* c) {
   if (c->d_src_rgb_grid) { (void)hipFree(c->d_src_rgb_grid); c->d_src_rgb_grid = nullptr; }
 }
 static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->d2_stale = false; c->pending_matches = false; c->matches_origin = 0; }
+static void drop_rev_tie_tables(cilhip_ctx* c) {  // (they describe ONE source under ONE transform)
+  if (c->d_rev_tie_leaf_slot) { (void)hipFree(c->d_rev_tie_leaf_slot); c->d_rev_tie_leaf_slot = nullptr; }
+  if (c->d_rev_tie_nodes) { (void)hipFree(c->d_rev_tie_nodes); c->d_rev_tie_nodes = nullptr; }
+  c->rev_tie_nodes_cap = 0; c->rev_tie_valid = false; c->rev_tie_aware = false;
+  std::vector<float>().swap(c->h_src);
+}
 static void drop_tie_tables(cilhip_ctx* c) {      // (they describe ONE target)
   if (c->d_tie_leaf_slot) { (void)hipFree(c->d_tie_leaf_slot); c->d_tie_leaf_slot = nullptr; }
   if (c->d_tie_nodes) { (void)hipFree(c->d_tie_nodes); c->d_tie_nodes = nullptr; }
@@ -258,6 +275,7 @@ int cilhip_create(cilhip_ctx** out, int device) {
 }
 
 static void free_source(cilhip_ctx* c) {
+  drop_rev_tie_tables(c);
   if (c->d_src_xyz) (void)hipFree(c->d_src_xyz);
   if (c->d_src_sorted) (void)hipFree(c->d_src_sorted);
   if (c->d_nn_pos) (void)hipFree(c->d_nn_pos);
@@ -886,20 +904,86 @@ static int read_tie_counters(cilhip_ctx* c, unsigned int out[4]) {
   CK(c, hipStreamSynchronize(c->stream));
   return CILHIP_OK;
 }
+// The reverse matches' order (FIRST_TO_SECOND / BOTH): what k_reverse_search is handed.  Without valid tables it counts the tied target
+// points (counters[3]) and keeps the lowest source index.
+static TieDev tie_dev_rev(const cilhip_ctx* c) {
+  TieDev t{};
+  t.mode = tie_mode_on(c) ? 1 : 0;
+  t.leaf_slot = (t.mode && c->rev_tie_valid) ? c->d_rev_tie_leaf_slot : nullptr;
+  t.nodes = c->d_rev_tie_nodes;
+  t.counters = c->d_tie_counters;
+  return t;
+}
+// The order tables of the tree the reference builds over the source transformed by T (src_points_trans = transform_ * src, the engine's
+// pinned f32 expression; correspondence_search_kd_tree.hpp:185-222), by position in the source grid.  Host work per search: a copy of the
+// source comes over once, the transform and the tree build run on the host's cores (8 ms for a 110k-point frame, 0.25 s at 10M).
+static int build_rev_tie_tables(cilhip_ctx* c, const float T[16]) {
+  if (c->rev_tie_valid && memcmp(c->rev_tie_T, T, sizeof(c->rev_tie_T)) == 0) return CILHIP_OK;
+  c->rev_tie_valid = false;
+  const uint32_t n = c->ns;
+  if (!c->has_src_grid || n == 0) return CILHIP_OK;
+  CK(c, hipSetDevice(c->device));
+  if (c->h_src.size() != (size_t)n * 3) {
+    c->h_src.resize((size_t)n * 3);
+    CK(c, hipMemcpyAsync(c->h_src.data(), c->d_src_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+  }
+  std::vector<float> q((size_t)n * 3);
+  {
+    const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const unsigned parts = n >= 200000u ? nt : 1u;
+    std::vector<std::thread> th;
+    auto work = [&](uint32_t lo, uint32_t hi) {
+      for (uint32_t i = lo; i < hi; ++i) transform_point(T, c->h_src[3 * (size_t)i], c->h_src[3 * (size_t)i + 1], c->h_src[3 * (size_t)i + 2], q[3 * (size_t)i], q[3 * (size_t)i + 1], q[3 * (size_t)i + 2]);
+    };
+    for (unsigned k = 1; k < parts; ++k) th.emplace_back(work, (uint32_t)((uint64_t)n * k / parts), (uint32_t)((uint64_t)n * (k + 1) / parts));
+    work(0, (uint32_t)((uint64_t)n / parts));
+    for (auto& x : th) x.join();
+  }
+  cilhip::TieOrderTree tree;
+  tree.build(q.data(), n);
+  { std::vector<float>().swap(q); }
+  const size_t n_nodes = tree.nodes().size();
+  if (!c->d_rev_tie_leaf_slot) CK(c, hipMalloc(&c->d_rev_tie_leaf_slot, (size_t)n * sizeof(uint2)));
+  if (n_nodes > c->rev_tie_nodes_cap) {
+    if (c->d_rev_tie_nodes) { (void)hipFree(c->d_rev_tie_nodes); c->d_rev_tie_nodes = nullptr; c->rev_tie_nodes_cap = 0; }
+    CK(c, hipMalloc(&c->d_rev_tie_nodes, (n_nodes + n_nodes / 8 + 16) * sizeof(uint4)));
+    c->rev_tie_nodes_cap = n_nodes + n_nodes / 8 + 16;
+  }
+  uint32_t *d_leaf = nullptr, *d_slot = nullptr;
+  CK(c, hipMalloc(&d_leaf, (size_t)n * sizeof(uint32_t)));
+  hipError_t e = hipMalloc(&d_slot, (size_t)n * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_leaf, tree.leaf_of().data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_slot, tree.slot_of().data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_rev_tie_nodes, tree.nodes().data(), n_nodes * sizeof(uint4), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { launch_tie_tables_by_position(c->src_grid.pts, n, d_leaf, d_slot, c->d_rev_tie_leaf_slot, c->stream); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_leaf); if (d_slot) (void)hipFree(d_slot);
+  if (e != hipSuccess) { c->err = std::string("tie_rule: the transformed source's order tables: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
+  memcpy(c->rev_tie_T, T, sizeof(c->rev_tie_T));
+  c->rev_tie_valid = true;
+  ++c->rev_tie_builds;
+  return CILHIP_OK;
+}
 // tie_rule 1: the tables before the first search; refusals of the explicit request (see tie_mode_on)
 static int tie_prepare(cilhip_ctx* c, const char* what) {
   c->tie_counters_fresh = false;      // (a new search / run: whatever the host holds of the counters is history)
-  if (c->tie_rule == 1 && (c->search_dir != 0 || feat6(c) || (c->index_offset && !c->d_tie_leaf_slot))) {
-    c->err = std::string(what) + ": tie_rule = 1 covers SECOND_TO_FIRST searches over point features on one whole target (tie_rule = 2 applies the reference's order where it is defined)";
+  if (c->tie_rule == 1 && (feat6(c) || (c->index_offset && !c->d_tie_leaf_slot))) {
+    c->err = std::string(what) + ": tie_rule = 1 covers searches over point features (the 6-D / 9-D adaptors' trees are not restated) on a whole target or on shards with the whole target's order loaded (tie_rule = 2 applies the reference's order where it is defined)";
     return CILHIP_ERR_UNSUPPORTED;
   }
-  if (c->tie_rule == 1 && tie_mode_on(c) && !c->index_offset && c->ns && c->grid.n) return build_tie_tables(c);
+  if (c->tie_rule == 1 && c->search_dir != 0) c->rev_tie_aware = true;
+  if (c->tie_rule == 0) c->rev_tie_aware = false;
+  if (c->tie_rule == 1 && tie_mode_on(c) && !c->index_offset && c->search_dir != 1 && c->ns && c->grid.n) return build_tie_tables(c);
   return CILHIP_OK;
 }
 // After a search / run: did it meet ties without tables (tie_rule 2)?  Then the tables are built and *again says: run it once more.
 static int tie_check_pending(cilhip_ctx* c, bool* again) {
   *again = false;
-  if (!tie_mode_on(c) || c->index_offset || c->d_tie_leaf_slot || !c->ns || !c->grid.n) return CILHIP_OK;
+  if (!tie_mode_on(c) || c->index_offset || !c->ns || !c->grid.n) return CILHIP_OK;
+  const bool fwd_open = !c->d_tie_leaf_slot && c->search_dir != 1;      // (forward matches: SECOND_TO_FIRST, the forward half of BOTH)
+  const bool rev_open = !c->rev_tie_aware && c->search_dir != 0;
+  if (!fwd_open && !rev_open) return CILHIP_OK;
   unsigned int cnt[4];
   if (c->tie_counters_fresh) {      // (a run's read_state has just brought them over with the loop state: no second round trip)
     memcpy(cnt, c->tie_counters_host, sizeof(cnt));
@@ -908,10 +992,12 @@ static int tie_check_pending(cilhip_ctx* c, bool* again) {
     if (rc) return rc;
   }
   c->tie_counters_fresh = false;
-  if (cnt[0] == 0u) return CILHIP_OK;
+  const bool fwd = fwd_open && cnt[0] != 0u, rev = rev_open && cnt[3] != 0u;
+  if (!fwd && !rev) return CILHIP_OK;
   *again = true;
   CK(c, hipMemsetAsync(c->d_tie_counters, 0, 4 * sizeof(unsigned int), c->stream));      // (the repeated search counts afresh)
-  return build_tie_tables(c);
+  if (rev) c->rev_tie_aware = true;      // (the tables themselves: per search, under its transform -- run_pair_search)
+  return fwd ? build_tie_tables(c) : CILHIP_OK;
 }
 
 // filterCorrespondencesFraction then filterCorrespondencesOneToOne on the stored matches
@@ -1054,9 +1140,11 @@ static int run_pair_search(cilhip_ctx* c, const IterArgs& a, float max_sq, const
   if (rf.dst2) rf.src2 = c->d_src_rgb_grid;
   if (feat6(c) && (!rf.src || !rf.dst || (rf.dst2 && !rf.src2))) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
   if (!feat6(c)) { rf.w = 0.0f; rf.enabled = 0; }
+  if (c->rev_tie_aware && tie_mode_on(c)) { const int trc = build_rev_tie_tables(c, T_host); if (trc) return trc; }
+  const TieDev rt = tie_dev_rev(c);
   const hipError_t e = find_pairs(rf, c->grid, c->src_grid, c->d_src_xyz, (c->d_src_nrm && c->symmetric) ? c->d_src_nrm : nullptr, c->d_src_sorted, c->ns, c->d_state,
                                   c->d_state_id, T_host, max_sq, c->search_dir, c->reciprocal, c->inlier_fraction, c->one_to_one, c->d_nn_pos, c->d_nn_d2,
-                                  c->pairs, c->stream);
+                                  c->pairs, c->stream, &rt);
   if (e != hipSuccess) { c->err = std::string("find_pairs: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   return CILHIP_OK;
 }
@@ -1079,7 +1167,7 @@ int cilhip_find_correspondences(cilhip_ctx* c, const float T[16], float max_sq, 
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available on target shards");
     rc = run_pair_search(c, a, max_sq, T);
     if (rc) return rc;
-    if (c->search_dir == 2) {      // (the forward half of BOTH met ties without tables: once more with them)
+    {      // (ties met without tables -- the forward half of BOTH: the target's; the reverse matches: the transformed source's --: once more with them)
       bool again = false;
       rc = tie_check_pending(c, &again);
       if (rc) return rc;
@@ -1845,7 +1933,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
         const double dot = (double)Ti[i * 4] * Ti[j * 4] + (double)Ti[i * 4 + 1] * Ti[j * 4 + 1] + (double)Ti[i * 4 + 2] * Ti[j * 4 + 2];
         if (std::fabs(dot - (i == j ? 1.0 : 0.0)) > 1e-5) t0_rigid = false;
       }
-    if (!filters_active(c) && !(c->d_src_nrm && c->symmetric) && t0_rigid && c->ns && c->grid.n && !feat_weights) {
+    if (!filters_active(c) && !(c->d_src_nrm && c->symmetric) && t0_rigid && c->ns && c->grid.n && !feat_weights && !(c->rev_tie_aware && tie_mode_on(c))) {
       rc = ensure_reverse_buffers(c);
       if (rc) return rc;
       FeatSpec rf = a.feat;
@@ -1871,7 +1959,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
           a.skip_if_inner_done = ar.skip_if_inner_done = (st > 0);
           if (st == 0) {
             if (c->search_dir == 2) { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
-            launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr);
+            { const TieDev rt = tie_dev_rev(c); launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr, &rt); }
           }
           if (both_union) launch_iter(a, im, false, false, nb_f, c->stream);
           launch_acc_reverse(ar, im, c->src_grid.pts, c->d_rev_pos, c->grid.n, rmode, c->d_nn_pos, c->d_src_inv, nb_r, c->stream);

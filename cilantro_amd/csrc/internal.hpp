@@ -121,7 +121,8 @@ struct F3 { float x, y, z; };      // 12-byte record (one global_load_dwordx3 pe
 struct TieDev {
   const uint2* leaf_slot;   // [grid.n] by sorted target position: {leaf node, slot in the reference's permutation}; null: no tables loaded
   const uint4* nodes;       // TieNode records: {parent, (depth << 3) | (split dimension << 1) | is-second-child, bits(divlow), bits(divhigh)}
-  unsigned int* counters;   // [4]  0: tied queries met without tables, 1: tied queries resolved with them, 2: of those, matches that are not the lowest index
+  unsigned int* counters;   // [4]  0: tied queries met without tables, 1: tied queries resolved with them, 2: of those, matches that are not the lowest index,
+                            //      3: (reverse searches of FIRST_TO_SECOND / BOTH) tied target points met without the transformed source's tables
   int mode;
 };
 
@@ -247,6 +248,27 @@ struct SolveArgs {
 constexpr int RUN_TRACE_CAP = 256;
 
 #if defined(__HIPCC__)
+// ---- option "tie_rule": the reference's choice among exactly equidistant nearest points (TieDev above) --------------
+// Does the reference's traversal for query q reach the target point at sorted position pa before the one at pb?  Same leaf: the lower
+// slot of the reference's permutation.  Otherwise walk both leaves up to their lowest common ancestor (parents + depths); there
+// nanoflann's searchLevel (nanoflann.hpp:1931-1947) descends first into the child on the query's side of the split:
+// (val - divlow) + (val - divhigh) < 0 -> the first child.  (csrc/tie_order.hpp: before(); pinned against the reference's own
+// nanoflann by tests/test_tie_order_cpu.py.)
+__device__ __forceinline__ bool tie_before(const TieDev& tt, float qx, float qy, float qz, uint32_t pa, uint32_t pb) {
+  const uint2 la = tt.leaf_slot[pa], lb = tt.leaf_slot[pb];
+  if (la.x == lb.x) return la.y < lb.y;
+  uint32_t na = la.x, nb = lb.x;
+  uint4 A = tt.nodes[na], B = tt.nodes[nb];
+  uint32_t a_second = 0;      // is the node on a's path just below the common ancestor a SECOND child
+  while ((A.y >> 3) > (B.y >> 3)) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; }
+  while ((B.y >> 3) > (A.y >> 3)) { nb = B.x; B = tt.nodes[nb]; }
+  while (na != nb) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; nb = B.x; B = tt.nodes[nb]; }
+  const uint32_t feat = (A.y >> 1) & 3u;
+  const float val = feat == 0u ? qx : (feat == 1u ? qy : qz);
+  const float diff1 = __fsub_rn(val, __uint_as_float(A.z)), diff2 = __fsub_rn(val, __uint_as_float(A.w));
+  const uint32_t first_is_second = __fadd_rn(diff1, diff2) < 0.0f ? 0u : 1u;
+  return a_second == first_is_second;
+}
 // The transformed feature part of a source point (the three adaptor behaviours of FeatSpec::mode).  f32, the engine's pinned
 // 3-term pairing r0*x + (r1*y + r2*z) for every matrix-vector product (Eigen's unrolled redux); the affine case's norm and
 // divisions are the correctly rounded f32 ones (formed in f64: the device's f32 sqrt / divide instructions are not).
@@ -382,12 +404,15 @@ void free_pairs(PairSet& p);
 // the reverse search of those directions alone (every target point against the source, through the inverse of the state's
 // rigid transform computed on the device): rev_pos / rev_d2 [nd] by target sorted position
 // feat (optional, w > 0): the reverse matches are the nearest 6-D FEATURES (feat->src in the source grid's order, feat->dst by target position)
+// rev_tie (option "tie_rule" for these matches): the reference searches a kd-tree over the TRANSFORMED SOURCE, rebuilt every iteration
+// (correspondence_search_kd_tree.hpp:185-222): leaf_slot = that tree's order tables by position in the source grid, valid for the state's
+// transform only (the host builds them per search); null = count the tied target points (counters[3]) and keep the lowest source index
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
-                                 const FeatSpec* feat = nullptr);
+                                 const FeatSpec* feat = nullptr, const TieDev* rev_tie = nullptr);
 hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& src_grid /*over the source, SOURCE coordinates*/, const float* d_src_xyz, const float* d_src_nrm,
                       const float4* src_sorted, uint32_t ns, const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq,
                       int direction, bool reciprocal, double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2,
-                      PairSet& out, hipStream_t s);
+                      PairSet& out, hipStream_t s, const TieDev* rev_tie = nullptr);
 
 // grid_build.hip
 struct GridBuildResult {

@@ -722,27 +722,7 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
   }
 }
 
-// ---- option "tie_rule": the reference's choice among exactly equidistant nearest points (TieDev, internal.hpp) --------------
-// Does the reference's traversal for query q reach the target point at sorted position pa before the one at pb?  Same leaf: the lower
-// slot of the reference's permutation.  Otherwise walk both leaves up to their lowest common ancestor (parents + depths); there
-// nanoflann's searchLevel (nanoflann.hpp:1931-1947) descends first into the child on the query's side of the split:
-// (val - divlow) + (val - divhigh) < 0 -> the first child.  (csrc/tie_order.hpp: before(); pinned against the reference's own
-// nanoflann by tests/test_tie_order_cpu.py.)
-__device__ __forceinline__ bool tie_before(const TieDev& tt, float qx, float qy, float qz, uint32_t pa, uint32_t pb) {
-  const uint2 la = tt.leaf_slot[pa], lb = tt.leaf_slot[pb];
-  if (la.x == lb.x) return la.y < lb.y;
-  uint32_t na = la.x, nb = lb.x;
-  uint4 A = tt.nodes[na], B = tt.nodes[nb];
-  uint32_t a_second = 0;      // is the node on a's path just below the common ancestor a SECOND child
-  while ((A.y >> 3) > (B.y >> 3)) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; }
-  while ((B.y >> 3) > (A.y >> 3)) { nb = B.x; B = tt.nodes[nb]; }
-  while (na != nb) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; nb = B.x; B = tt.nodes[nb]; }
-  const uint32_t feat = (A.y >> 1) & 3u;
-  const float val = feat == 0u ? qx : (feat == 1u ? qy : qz);
-  const float diff1 = __fsub_rn(val, __uint_as_float(A.z)), diff2 = __fsub_rn(val, __uint_as_float(A.w));
-  const uint32_t first_is_second = __fadd_rn(diff1, diff2) < 0.0f ? 0u : 1u;
-  return a_second == first_is_second;
-}
+// (tie_before(): internal.hpp -- shared with the reverse searches of bidir.hip)
 // A query whose search noticed a tie (NN::tie, or second smallest distance == smallest): pos / bd = its match by the lowest-index rule
 // and that match's squared distance.  Returns the sorted position of the match the option asks for: every target point at EXACTLY
 // bd is enumerated -- the closed ball of that radius, shells of cells around the query's, rows beyond the distance skipped, ends when

@@ -388,3 +388,60 @@ def test_target_shards_follow_the_reference_s_order_across_shards(Context, orc):
         assert int(rr.iterations) == 4 and int(rr.last_ncorr) == int(ref.last_ncorr) and err <= 2e-6, (devs, err, int(rr.last_ncorr), int(ref.last_ncorr))
     assert float(sums.sum().item()) == float(sums.sum().item())      # (finite)
     _report("tie_rule_target_shards.json", out)
+
+
+def test_other_search_directions_follow_the_tree_over_the_transformed_source(Context, orc):
+    """FIRST_TO_SECOND / BOTH: the reference searches a kd-tree built over the TRANSFORMED source, a new one per iteration
+    (correspondence_search_kd_tree.hpp:185-222): among source points exactly equidistant from a target point it returns the one THAT tree's
+    traversal meets first.  A source with doubled and tripled points (tied under every transform) and the lattice (every target point of
+    the test tied 8 / 4 / 2 ways under the identity): with default options the pair lists equal the oracle's, pair for pair -- the first
+    search notices the ties, the tables of the transformed source's tree are built on the host, the search is repeated --, through the
+    filters and reciprocity, and as whole loops (a tree per iteration).  With tie_rule 0 a good part of the pairs name another point."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D, CorrespondenceSearchHIP, SimpleCombinedMetricRigidICP3f
+
+    code = {D.SECOND_TO_FIRST: 0, D.FIRST_TO_SECOND: 1, D.BOTH: 2}
+    rng = np.random.default_rng(11)
+    b = syn.make_pair(60_000, 45_000, with_normals=True)
+    dup = rng.choice(len(b["src"]), 4000, replace=False)
+    S = np.ascontiguousarray(np.concatenate([b["src"], b["src"][dup], b["src"][dup[:700]]]))
+    S = np.ascontiguousarray(S[rng.permutation(len(S))])
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = [0.004, -0.003, 0.002]
+    c, s_ = np.cos(0.01), np.sin(0.01)
+    T[:3, :3] = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+    LD, LN, LS, lr2, n_tied = _lattice(20)
+    out = {}
+    for name, dst, dst_n, src, r2, Tq in (("duplicated source points", b["dst"], b["dst_n"], S, float(b["max_sq_dist"]), T),
+                                          ("lattice source, cube centres as the target", LS, np.tile(np.array([[0, 0, 1.0]], np.float32), (len(LS), 1)), LD, float(lr2), np.eye(4, dtype=np.float32))):
+        q = orc.transform_points(Tq, src)
+        for rule in (2, 0):
+            ctx = Context(); ctx.set_option("tie_rule", rule)
+            ctx.set_target(dst, dst_n); ctx.set_source(src)
+            eng = CorrespondenceSearchHIP(ctx=ctx).setMaxDistance(r2)
+            for direction, recip, frac, o2o in ((D.FIRST_TO_SECOND, False, 1.0, False), (D.BOTH, False, 1.0, False), (D.BOTH, True, 1.0, False),
+                                                (D.FIRST_TO_SECOND, False, 0.7, True)):
+                eng.setSearchDirection(direction).setRequireReciprocality(recip).setInlierFraction(frac).setOneToOne(o2o)
+                eng.findCorrespondences(Tq)
+                g1, g2, gv = eng.getCorrespondences()
+                o1, o2, ov = orc.find_correspondences_dir(dst, q, r2, code[direction], recip, frac, o2o)
+                same = len(g1) == len(o1) and np.array_equal(g1, o1) and np.array_equal(g2, o2) and np.array_equal(gv, ov)
+                key = f"{name}: {direction.name}{' reciprocal' if recip else ''}{' filtered' if o2o else ''}, tie_rule {rule}"
+                out[key] = {"pairs": int(len(o1)), "identical": bool(same),
+                            "pairs_naming_another_point": int(np.count_nonzero(g2 != o2)) if len(g1) == len(o1) else -1}
+                if rule == 2:
+                    assert same, (key, out[key])
+            if rule == 0:
+                assert any(v["pairs_naming_another_point"] > 50 for k, v in out.items() if k.startswith(name) and k.endswith("rule 0")), out
+            ctx.close()
+    # whole loops on the duplicated source: a tree over the transformed source per iteration
+    for direction, recip in ((D.FIRST_TO_SECOND, False), (D.BOTH, False), (D.BOTH, True)):
+        icp = SimpleCombinedMetricRigidICP3f(b["dst"], b["dst_n"], S)
+        icp.correspondenceSearchEngine().setMaxDistance(float(b["max_sq_dist"])).setSearchDirection(direction).setRequireReciprocality(recip)
+        icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, max_sq_dist=float(b["max_sq_dist"]), max_iter=5, conv_tol=0.0, direction=code[direction], reciprocal=recip)
+        ro = orc.icp_run(b["dst"], b["dst_n"], S, p)
+        err = float(np.linalg.norm(Tg.astype(np.float64) - ro["T"]))
+        g1, g2, gv = icp.correspondenceSearchEngine().getCorrespondences()
+        out[f"loop {direction.name}{' reciprocal' if recip else ''}"] = {"T_minus_oracle": err, "ncorr": int(icp.last_ncorr_), "oracle_ncorr": int(ro["last_ncorr"])}
+        assert icp.getNumberOfPerformedIterations() == 5 and icp.last_ncorr_ == ro["last_ncorr"] and err <= 2e-6, (direction, recip, err)
+    _report("tie_rule_directions.json", out)
