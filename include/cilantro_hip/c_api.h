@@ -528,11 +528,16 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        them on the host's cores, kernels.hip tie_settle reads them).  The tables are built when a search first
  *                        MEETS a tie (that search / run is then executed once more): a target whose searches never tie never pays
  *                        for a tree, one that does pays once.  1 = the same choice, tables built before the first search.
- *                        0 = the lowest target index (what a brute-force argmin gives).  Covers the SECOND_TO_FIRST matches
- *                        (also the forward half of BOTH) over point features, rigid and affine, sharded runs included
- *                        (cilhip_load_tie_order); feature adaptors, reverse matches and index shards of a target keep the lowest
- *                        index under 2 and are refused (CILHIP_ERR_UNSUPPORTED) under 1.  tests/test_gpu_tie_rule.py: every index
- *                        of the reference's sensor frames and of a cloud with doubled and tripled points equals nanoflann's.
+ *                        0 = the lowest index (what a brute-force argmin gives).  Covers every search over point features:
+ *                        SECOND_TO_FIRST, rigid and affine, sharded runs included (cilhip_load_tie_order; index shards of a target:
+ *                        cilhip_icp_order_keys), and the reverse matches of FIRST_TO_SECOND / BOTH -- there the reference's tree is
+ *                        over the TRANSFORMED SOURCE, a new one per search (correspondence_search_kd_tree.hpp:185-222): a reverse
+ *                        search notices target points with several exactly equidistant source points; from then on (under 1: from
+ *                        the start) the host builds that tree's tables before every reverse search (8 ms for a 110k-point cloud,
+ *                        0.25 s at 10M points) and the loops run one search at a time.  The 6-D / 9-D feature adaptors keep the
+ *                        lowest index under 2 and are refused (CILHIP_ERR_UNSUPPORTED) under 1.  tests/test_gpu_tie_rule.py: every
+ *                        index of the reference's sensor frames, of clouds with doubled and tripled points and of lattices with
+ *                        8-way ties equals nanoflann's, in every direction.
  *   "group_search" (default -1): the global-memory search with SEVERAL lanes per query (small clouds, sources far from alignment: one
  *                        lane per query leaves the chip idle behind chains of dependent trips -- the reference's 120k-point sensor
  *                        frames: 0.34 -> 0.12 ms per iteration).  G adjacent lanes share a query: the rows of the block around its
