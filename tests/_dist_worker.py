@@ -145,6 +145,164 @@ class OracleTargetShardEngine(OracleShardEngine):
         return self.sums
 
 
+class OrderedTargetShardEngine(OracleTargetShardEngine):
+    """Test-only counterpart of HipTargetShardEngine WITH the whole target at hand (whole_target=...): the shard's exact nearest
+    points per query, all of them when several are equidistant (scipy neighbours + the pinned distance expression); without the order
+    the lowest index of the shard and a count of what was tied (inside the shard, and against the winner of the MIN), with it the
+    first-met one of the reference's tree over the WHOLE target and the traversal key of that match -- the host restatement
+    (csrc/tie_order.hpp behind tests/cpp/tie_order_shim.cpp), which tests/test_tie_order_cpu.py pins against the reference's nanoflann."""
+    K = 12
+
+    def __init__(self, dst_full, dst_n_full, src, lo, hi):
+        import ctypes as C
+
+        from scipy.spatial import cKDTree
+
+        super().__init__(dst_full, dst_n_full, src, lo, hi)
+        self.dst_full = np.ascontiguousarray(dst_full, np.float32)
+        self.ck = cKDTree(self.dst.astype(np.float64))
+        self.L = C.CDLL(os.path.join(ROOT, "tests", "cpp", "bin", "libtie_order_shim.so"))
+        self.L.tie_shim_build.restype = C.c_void_p
+        self.L.tie_shim_build.argtypes = [C.c_void_p, C.c_uint32]
+        self.L.tie_shim_first_met.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p]
+        self.L.tie_shim_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        self.h, self.ordered, self.pending = None, False, 0
+        self.okeys = torch.full((len(src),), distributed.KEY_NONE, dtype=torch.int64)
+
+    @staticmethod
+    def _pinned_d2(a, b):
+        d = (a - b).astype(np.float32)
+        return ((d[..., 0] * d[..., 0]) + (d[..., 1] * d[..., 1])).astype(np.float32) + (d[..., 2] * d[..., 2]).astype(np.float32)
+
+    def begin(self, params, T0):
+        super().begin(params, T0)
+        self.pending = 0
+
+    def partial_keys(self):
+        self.keys.fill_(distributed.KEY_NONE)
+        self.m_si = np.zeros(0, np.int64)
+        if self.done:
+            return self.keys
+        self.q = orc.transform_points(self.T, self.src)
+        _, si, d2 = self.tree.find_correspondences(self.q, self.p.max_sq_dist, num_threads=1)      # which queries match inside the radius, at what distance
+        qm = np.ascontiguousarray(self.q[si])
+        _, nb = self.ck.query(qm.astype(np.float64), k=self.K)
+        dd = self._pinned_d2(qm[:, None, :], self.dst[nb])
+        tied = dd == d2[:, None]
+        cnt = tied.sum(axis=1)
+        assert cnt.min() >= 1 and cnt.max() < self.K
+        cand = np.zeros((len(si), self.K), np.uint32)
+        order = np.argsort(np.where(tied, nb, np.iinfo(np.int64).max), axis=1)      # tied ones first, ascending index
+        cand[:] = (np.take_along_axis(nb, order, axis=1) + self.lo).astype(np.uint32)
+        if self.ordered:
+            pick = np.zeros(len(si), np.uint32)
+            cnt32 = np.ascontiguousarray(cnt, np.int32)      # (kept alive across the call)
+            self.L.tie_shim_first_met(self.h, qm.ctypes.data, cand.ctypes.data, cnt32.ctypes.data, self.K, len(si), pick.ctypes.data)
+        else:
+            pick = cand[:, 0].copy()                      # the lowest index
+            self.pending += int(np.count_nonzero(cnt >= 2))
+        self.m_si, self.m_gi, self.m_d2 = si.astype(np.int64), pick.astype(np.int64), d2
+        k = (d2.view(np.uint32).astype(np.int64) << 32) | self.m_gi
+        self.keys[torch.from_numpy(self.m_si)] = torch.from_numpy(k)
+        return self.keys
+
+    def _accumulate(self, si, gi):
+        self.sums.zero_()
+        self.last_won = (si, gi)
+        di = gi - self.lo
+        s = np.zeros(distributed.SUMS_LEN)
+        if self.p.metric == capi.METRIC_POINT_TO_POINT:
+            _, s16, _ = orc.estimate_p2p(self.dst, self.q, di, si, orc.MODE_MIXED)
+            s[:16] = s16
+        else:
+            smt = orc.transform_points(self.T, self.gmean.reshape(1, 3))[0]
+            _, AtA, Atb, _ = orc.estimate_combined(self.dst, self.dst_n, self.q, di, si, 0.0, 1.0, self.dst_mean, smt, 1, 1e-5, orc.MODE_MIXED)
+            s[0] = len(di); s[1:22] = AtA[np.triu_indices(6)]; s[22:28] = Atb
+        self.sums.copy_(torch.from_numpy(s))
+        return self.sums
+
+    def sums_from_keys(self, keys):
+        if self.done:
+            self.sums.zero_()
+            return self.sums
+        k = keys.numpy()[self.m_si]
+        won = (k & 0xFFFFFFFF) == self.m_gi
+        self.pending += int(np.count_nonzero(~won & ((k >> 32) == (self.m_d2.view(np.uint32).astype(np.int64)))))      # as far as the winner, not the winner
+        return self._accumulate(self.m_si[won], self.m_gi[won])
+
+    def ties_pending(self):
+        return (not self.ordered) and self.pending > 0
+
+    def load_tie_order(self):
+        self.h = self.L.tie_shim_build(self.dst_full.ctypes.data, len(self.dst_full))
+        self.ordered = True
+
+    def order_keys(self, keys):
+        self.okeys.fill_(distributed.KEY_NONE)
+        if self.done or len(self.m_si) == 0:
+            return self.okeys
+        k = keys.numpy()[self.m_si]
+        at = (k >> 32) == self.m_d2.view(np.uint32).astype(np.int64)
+        qa = np.ascontiguousarray(self.q[self.m_si[at]]); ia = np.ascontiguousarray(self.m_gi[at].astype(np.uint32))
+        out = np.zeros(len(ia), np.uint64)
+        self.L.tie_shim_keys(self.h, qa.ctypes.data, ia.ctypes.data, len(ia), out.ctypes.data)
+        self.own = np.full(len(self.src), distributed.KEY_NONE, np.int64)
+        self.own[self.m_si[at]] = out.astype(np.int64)
+        self.okeys.copy_(torch.from_numpy(self.own))
+        return self.okeys
+
+    def sums_from_ordered_keys(self, keys, okeys):
+        if self.done:
+            self.sums.zero_()
+            return self.sums
+        o = okeys.numpy()[self.m_si]
+        won = (self.own[self.m_si] != distributed.KEY_NONE) & (self.own[self.m_si] == o)
+        return self._accumulate(self.m_si[won], self.m_gi[won])
+
+
+def main_target_sharded_ties(metric, n):
+    """index shards of a target with doubled and tripled points, shuffled (ties inside the shards and across them): the protocol of
+    TargetShardedRigidICP -- a first run that notices, the order, a second run with the third collective -- over gloo; the last
+    iteration's pairs, gathered from the ranks that won them, against the reference's nanoflann over the whole target"""
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    d = syn.make_pair(n, perturb=0.5)
+    rng = np.random.default_rng(17)
+    dup = rng.choice(n, n // 10, replace=False)
+    dst = np.concatenate([d["dst"], d["dst"][dup], d["dst"][dup[: n // 40]]]); dst_n = np.concatenate([d["dst_n"], d["dst_n"][dup], d["dst_n"][dup[: n // 40]]])
+    perm = rng.permutation(len(dst))
+    dst, dst_n = np.ascontiguousarray(dst[perm]), np.ascontiguousarray(dst_n[perm])
+    lo, hi = distributed.shard_bounds(len(dst), rank, world)
+    eng = OrderedTargetShardEngine(dst, dst_n, d["src"], lo, hi)
+    p = distributed.default_params(metric=metric, max_iter=6, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]))
+    T, iters, delta, nc = distributed.TargetShardedRigidICP(eng, dist).estimate(p)
+    rows = [None] * world
+    dist.all_gather_object(rows, {"T": T.tolist(), "ordered": bool(eng.ordered), "si": eng.last_won[0].tolist(), "gi": eng.last_won[1].tolist()})
+    if rank == 0:
+        got = np.full(len(d["src"]), -1, np.int64); times = np.zeros(len(d["src"]), np.int64)
+        for r in rows:
+            got[np.array(r["si"], np.int64)] = np.array(r["gi"], np.int64); times[np.array(r["si"], np.int64)] += 1
+        tree = orc.KDTree(dst, use_ref=orc.ref_available())
+        o1, o2, _ = tree.find_correspondences(eng.q, float(d["max_sq_dist"]))
+        want = np.full(len(d["src"]), -1, np.int64); want[o2] = o1
+        low = np.full(len(d["src"]), -1, np.int64)      # what one key alone would have named: the lowest index among the equidistant ones
+        from scipy.spatial import cKDTree
+        _, nb = cKDTree(dst.astype(np.float64)).query(eng.q[o2].astype(np.float64), k=6)
+        dd = OrderedTargetShardEngine._pinned_d2(eng.q[o2][:, None, :], dst[nb])
+        low[o2] = np.where(dd == dd.min(axis=1, keepdims=True), nb, np.iinfo(np.int64).max).min(axis=1)
+        if os.environ.get("DIST_DEBUG"):
+            for i in np.nonzero(got != want)[0][:5]:
+                dq = OrderedTargetShardEngine._pinned_d2(eng.q[i][None, :], dst[[got[i], want[i]]]) if got[i] >= 0 and want[i] >= 0 else None
+                print("DEBUG", int(i), int(got[i]), int(want[i]), None if dq is None else dq.view(np.uint32).tolist(), dst[got[i]].tolist() if got[i] >= 0 else None, dst[want[i]].tolist() if want[i] >= 0 else None, eng.q[i].tolist(), file=sys.stderr)
+        po = orc.make_params(metric=metric, max_iter=6, conv_tol=0.0, max_sq_dist=float(d["max_sq_dist"]), mode=orc.MODE_MIXED)
+        ro = orc.icp_run(dst, dst_n, d["src"], po)
+        print("RESULT " + json.dumps({"world": world, "identical": all(r["T"] == rows[0]["T"] for r in rows), "ordered": [r["ordered"] for r in rows],
+                                       "iters": iters, "ncorr": nc, "oracle_ncorr": int(ro["last_ncorr"]), "T_err": float(np.linalg.norm(np.array(T, np.float64) - ro["T"])),
+                                       "mismatches": int(np.count_nonzero(got != want)), "won_once": bool(np.array_equal(times, (want >= 0).astype(np.int64))),
+                                       "lowest_index_would_differ": int(np.count_nonzero(low != want))}))
+    dist.destroy_process_group()
+
+
 def main_target_sharded(metric, n):
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -292,6 +450,8 @@ def main():
         return main_rank_comm()
     if len(sys.argv) > 3 and sys.argv[3] == "tshard":
         return main_target_sharded(metric, n)
+    if len(sys.argv) > 3 and sys.argv[3] == "tshardties":
+        return main_target_sharded_ties(metric, n)
     if len(sys.argv) > 3 and sys.argv[3].startswith("nslab"):
         return main_slab(metric, n, float(sys.argv[3][5:] or -1), native=True)
     if len(sys.argv) > 3 and sys.argv[3].startswith("slab"):

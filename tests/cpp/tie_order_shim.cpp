@@ -32,6 +32,11 @@ void tie_shim_min_key(void* h, const float* q, const uint32_t* cand, const int* 
   }
   *depth = s->tree.max_depth();
 }
+// out[k] = traversal key of target point idx[k] for query k
+void tie_shim_keys(void* h, const float* q, const uint32_t* idx, uint32_t nq, uint64_t* out) {
+  const Shim* s = static_cast<const Shim*>(h);
+  for (uint32_t k = 0; k < nq; ++k) out[k] = s->tree.traversal_key(q + 3 * (size_t)k, idx[k]);
+}
 // the reference's permutation (slot of every point), leaf populations and depths: what must not depend on how many threads built the tree
 // (node ids do: they are list positions)
 int tie_shim_same_order(void* ha, void* hb) {

@@ -67,6 +67,19 @@ def test_target_sharded_icp_world2_matches_single_process(orc, metric):
     assert r2["ncorr"] == ref["last_ncorr"]
 
 
+def test_target_sharded_ties_follow_the_reference_s_order_world2(orc):
+    """Exactly equidistant nearest points inside the index shards of a target and ACROSS them (doubled and tripled points, shuffled):
+    TargetShardedRigidICP runs once with one key per query, every rank notices (its own ties; a nearest point as far as the winner's
+    that is not the winner), all agree (all-reduce MAX), load the whole target's order and run again with the third collective -- the
+    MIN of the traversal keys.  The last iteration's pairs, gathered from the ranks that won them: every matched query won by exactly
+    one rank, index for index the reference's nanoflann over the whole target (one key alone names another point for hundreds)."""
+    r = _run(2, 1, 12000, "tshardties")
+    assert r["world"] == 2 and r["identical"] and r["ordered"] == [True, True] and r["iters"] == 6
+    assert r["won_once"] and r["mismatches"] == 0, r
+    assert r["lowest_index_would_differ"] > 100, r
+    assert r["ncorr"] == r["oracle_ncorr"] and r["T_err"] <= 1e-5, r
+
+
 @pytest.mark.parametrize("metric", [0, 1])
 def test_slab_sharded_icp_world2_matches_single_process(orc, metric):
     """SURVEY 8(e) partitioning B: target and source cut into spatial slabs (halo = radius + slack), one all-reduce(sum) of
