@@ -42,6 +42,22 @@ __global__ __launch_bounds__(256) void k_read1(const float4* __restrict__ a, siz
   }
   if (s == 12345.678f) out[0] = s;
 }
+// the same sweep from the END of the buffer (rev): what a pass that follows a forward pass finds in the memory-side cache (256 MB
+// "infinity cache"): a forward pass over more than the cache leaves its TAIL there, a pass in the same direction starts at the head
+// (every line evicted before it is reached again), a pass in the opposite direction starts where the last one ended
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_read1_dir(const float4* __restrict__ a, size_t n4, int rev, float* out) {
+  float s = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256u;
+  for (size_t i0 = (size_t)blockIdx.x * 256u + threadIdx.x; i0 < n4; i0 += stride * DEPTH) {
+    float4 r[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { const size_t i = i0 + stride * d; r[d] = i < n4 ? a[rev ? n4 - 1 - i : i] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) s += r[d].x + r[d].y + r[d].z + r[d].w;
+  }
+  if (s == 12345.678f) out[0] = s;
+}
 template <class F>
 static double time_ms(F f, int reps = 20) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -75,6 +91,15 @@ int main(int argc, char** argv) {
       double t4 = time_ms([&] { hipLaunchKernelGGL((k_read1<4>), dim3(nb), dim3(256), 0, 0, (const float4*)x, n4, out); });
       printf("read1 %4zu MiB grid-stride blocks=%5d: depth2 %.4f ms %.2f TB/s | depth4 %.4f ms %.2f TB/s\n", mb, nb, t2, n4 * 16.0 / t2 / 1e9, t4, n4 * 16.0 / t4 / 1e9);
     }
+  }
+  // the memory-side cache: repeated passes over buffers below and above its size, and passes that alternate direction
+  for (size_t mb : {64ull, 128ull, 192ull, 256ull, 320ull, 400ull, 800ull}) {
+    const size_t n4 = mb * (1ull << 20) / 16;
+    const int nb = 8192;
+    double tf = time_ms([&] { hipLaunchKernelGGL((k_read1_dir<4>), dim3(nb), dim3(256), 0, 0, (const float4*)x, n4, 0, out); });
+    int flip = 0;
+    double ta = time_ms([&] { hipLaunchKernelGGL((k_read1_dir<4>), dim3(nb), dim3(256), 0, 0, (const float4*)x, n4, flip, out); flip ^= 1; });
+    printf("read1 %4zu MiB repeated: same direction %.4f ms %.2f TB/s | alternating direction %.4f ms %.2f TB/s\n", mb, tf, n4 * 16.0 / tf / 1e9, ta, n4 * 16.0 / ta / 1e9);
   }
   double tc = time_ms([&] { CK(hipMemcpyAsync(y, x, G, hipMemcpyDeviceToDevice, 0)); }, 10);
   printf("device copy 1 GiB: %.4f ms = %.2f TB/s (read + write)\n", tc, 2.0 * G / tc / 1e9);
