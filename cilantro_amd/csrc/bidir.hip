@@ -117,7 +117,7 @@ __device__ __forceinline__ void scan_range_inv_ties(const float4* __restrict__ p
     const float e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
     if (__float_as_uint(e) == __float_as_uint(bd)) {
       ++ncand;
-      if (j != cur && tie_before(tt, px, py, pz, j, cur)) cur = j;
+      if (tt.leaf_slot != nullptr && j != cur && tie_before(tt, px, py, pz, j, cur)) cur = j;
     }
   }
 }
@@ -204,10 +204,10 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
       if (lb > 0.0f && __uint_as_float((uint32_t)(bkey >> 32)) < lb * lb * KS) break;
     }
     if (!FEAT6 && tt.mode != 0 && tie != 0u && bpos != NONE_U32) {
-      // option "tie_rule": the same shells again with the distance fixed (a row or a shell AT the distance is looked at: the bounds are strict)
-      if (tt.leaf_slot == nullptr) {
-        atomicAdd(tt.counters + 3, 1u);
-      } else {
+      // option "tie_rule": the same shells again with the distance fixed (a row or a shell AT the distance is looked at: the bounds are strict).
+      // The flag may be stale (raised for a distance that was beaten later): the candidates at the FINAL distance are counted either way --
+      // without the tables a target point with two or more of them is reported (counters[3]) and keeps the lowest source index.
+      {
         const float bd = __uint_as_float((uint32_t)(bkey >> 32));
         uint32_t cur = bpos, ncand = 0u;
         for (int s2 = max(0, max(max(-cx, cx - (sg.nx - 1)), max(max(-cy, cy - (sg.ny - 1)), max(-cz, cz - (sg.nz - 1)))));; ++s2) {
@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
           const float lb2 = mapped_bound(b2 - sg.margin, iv);
           if (lb2 > 0.0f && bd < lb2 * lb2 * KS) break;
         }
-        if (ncand >= 2u) { atomicAdd(tt.counters + 1, 1u); if (cur != bpos) atomicAdd(tt.counters + 2, 1u); }
+        if (ncand >= 2u) {
+          if (tt.leaf_slot == nullptr) atomicAdd(tt.counters + 3, 1u);
+          else { atomicAdd(tt.counters + 1, 1u); if (cur != bpos) atomicAdd(tt.counters + 2, 1u); }
+        }
         bpos = cur;
       }
     }

@@ -992,7 +992,12 @@ static int tie_check_pending(cilhip_ctx* c, bool* again) {
     if (rc) return rc;
   }
   c->tie_counters_fresh = false;
-  const bool fwd = fwd_open && cnt[0] != 0u, rev = rev_open && cnt[3] != 0u;
+  // Forward matches: any tie, the tables are built once per target.  Reverse matches: the tables cost a host tree build PER SEARCH (0.25 s
+  // at 10M points against an iteration of a millisecond), so the automatic rule pays it for clouds that tie systematically -- duplicated
+  // points, lattices: at least 16 tied target points and one in 100 000 -- and not for the isolated coincidence of two f32 distances in a
+  // large random cloud (about one target point in ten million): those keep the lowest source index and stay counted
+  // (cilhip_get_tie_rule_stats); tie_rule 1 follows the reference for every one of them.
+  const bool fwd = fwd_open && cnt[0] != 0u, rev = rev_open && cnt[3] >= 16u && (unsigned long long)cnt[3] * 100000ull >= (unsigned long long)c->grid.n;
   if (!fwd && !rev) return CILHIP_OK;
   *again = true;
   CK(c, hipMemsetAsync(c->d_tie_counters, 0, 4 * sizeof(unsigned int), c->stream));      // (the repeated search counts afresh)
@@ -1322,7 +1327,7 @@ int cilhip_get_tie_rule_stats(cilhip_ctx* c, size_t* tied_queries, size_t* repoi
   CK(c, hipSetDevice(c->device));
   unsigned int cnt[4];
   { const int rc = read_tie_counters(c, cnt); if (rc) return rc; }
-  if (tied_queries) *tied_queries = (size_t)cnt[1] + (size_t)cnt[0];
+  if (tied_queries) *tied_queries = (size_t)cnt[1] + (size_t)cnt[0] + (size_t)cnt[3];      // (settled from tables + met without them, forward and reverse)
   if (repointed) *repointed = (size_t)cnt[2];
   return CILHIP_OK;
 }
