@@ -180,15 +180,22 @@ def test_every_kernel_form_resolves_ties(Context, orc):
 
 
 def test_tie_rule_1_refuses_what_the_order_does_not_cover(Context):
+    """the explicit request covers every search over POINTS (all directions: the reverse matches' tables are built from the first
+    search on); the 6-D feature adaptors search another tree (nanoflann DIM = 6), which is not restated: refused, not silently approximated"""
     d = syn.make_pair(20_000, perturb=0.3)
-    ctx = Context(); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+    I = np.eye(4, dtype=np.float32)
+    ctx = Context(); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"], np.ascontiguousarray(d["dst_n"][: len(d["src"])]))
     ctx.set_option("tie_rule", 1)
-    ctx.set_option("search_direction", 2)
+    for direction in (1, 2):
+        ctx.set_option("search_direction", direction)
+        ctx.find_correspondences(I, float(d["max_sq_dist"]))
+    ctx.set_option("search_direction", 0)
+    ctx.set_option("feature_normal_weight", 0.1)
     with pytest.raises(RuntimeError):
-        ctx.find_correspondences(np.eye(4, dtype=np.float32), float(d["max_sq_dist"]))
-    # the default applies the order where it is defined (the forward matches) and runs
+        ctx.find_correspondences(I, float(d["max_sq_dist"]))
+    # the default applies the order where it is defined and runs
     ctx.set_option("tie_rule", 2)
-    ctx.find_correspondences(np.eye(4, dtype=np.float32), float(d["max_sq_dist"]))
+    ctx.find_correspondences(I, float(d["max_sq_dist"]))
     ctx.close()
 
 
