@@ -211,7 +211,8 @@ def test_sharded_runs_resolve_ties_from_the_whole_target_s_order(Context, orc):
     ro = orc.icp_run(D, N, S, po)
     c = Context(); p = _icp_params(c, r2); c.close()
     out = {}
-    for label, part, slack in (("source shards", PARTITION_SOURCE_SHARDS, None), ("slabs", PARTITION_SLABS, None), ("slabs, guard fires", PARTITION_SLABS, 0.002)):
+    for label, part, slack in (("source shards", PARTITION_SOURCE_SHARDS, None), ("slabs", PARTITION_SLABS, None), ("slabs, guard fires", PARTITION_SLABS, 0.002),
+                               ("index shards of the target", 2, None)):
         m = MultiDeviceRigidICP([0, 0, 0])
         if slack is not None:
             m.set_slab_slack(slack)
