@@ -535,7 +535,8 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        search counts the target points with several exactly equidistant source points; when they are
  *                        systematic (at least 16 and one target point in 100 000: duplicated points, lattices; under 1: always,
  *                        from the start) the host builds that tree's tables before every reverse search (8 ms for a 110k-point
- *                        cloud, 0.25 s at 10M points) and the loops run one search at a time.  Below that (the coincidence of
+ *                        cloud, 0.25 s at 10M points) and the loops run one search at a time -- for this source, until it is set
+ *                        again (duplicated points and lattices tie under every transform / systematically).  Below that (the coincidence of
  *                        two f32 distances in a large random cloud: about one target point in ten million) rule 2 keeps the
  *                        lowest source index for those and reports them (cilhip_get_tie_rule_stats).  The 6-D / 9-D feature adaptors keep the
  *                        lowest index under 2 and are refused (CILHIP_ERR_UNSUPPORTED) under 1.  tests/test_gpu_tie_rule.py: every
