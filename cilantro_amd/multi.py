@@ -2,7 +2,9 @@
 
 The sharded protocols of cilantro_amd/distributed.py (one process per GPU over torch.distributed) exist a second time below the
 C ABI, for callers without Python / torch: one context per device, RCCL's all-reduce of the 48 partial sums on the devices'
-streams, the slab guard and the re-partitioning handled inside the library.  This module is the thin ctypes mirror of
+streams, the slab guard and the re-partitioning handled inside the library; PARTITION_TARGET_SHARDS: the target in index shards, a MIN
+all-reduce of one packed (d2, global index) key per source point and iteration, the reference's tie order across shards through a
+second key (c_api.h: cilhip_icp_order_keys).  This module is the thin ctypes mirror of
 ``cilantro_hip::MultiDeviceRigidICP`` (include/cilantro_hip/icp.hpp).
 """
 import ctypes as C

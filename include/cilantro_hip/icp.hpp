@@ -549,7 +549,8 @@ private:
 // The sharded ICP loop over several devices of one process (c_api.h: cilhip_multi_*): per iteration every device's context searches
 // and accumulates over its shard, RCCL all-reduces the 48 partial sums on the devices' streams, every context applies them.
 // SlabSharded (default): spatial slabs of target (+ halo) and source, exact nearest neighbours without any key exchange, the
-// device-side guard and re-partitioning inside; SourceSharded: the source in contiguous shards, the target on every device.  The
+// device-side guard and re-partitioning inside; SourceShards: the source in contiguous shards, the target on every device; TargetShards: the
+// target in index shards (a target that does not fit one device), the whole source everywhere, a MIN all-reduce of packed keys per iteration.  The
 // reference has no counterpart (single-process CPU); the loop is IterativeClosestPointBase::estimate (icp_base.hpp:68-87) for the
 // rigid combined / point-to-point metrics with their defaults (icp_single_transform_combined_metric.hpp:44-47).
 class MultiDeviceRigidICP {
