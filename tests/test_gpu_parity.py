@@ -1284,6 +1284,19 @@ def test_full_size_target_sharded_config(orc, hip_lib):
     assert np.linalg.norm(T1 - d["T_true"]) < 1e-5, float(np.linalg.norm(T1 - d["T_true"]))
     del engs
     torch.cuda.empty_cache()
+    # the same protocol through the C entry (cilhip_multi_set_clouds, partition 2: two index shards of the 80M-point target on this one device,
+    # the MIN of the packed keys as a kernel between them): the transform of the unsharded run again
+    from cilantro_amd import capi as _capi
+    from cilantro_amd.multi import PARTITION_TARGET_SHARDS, MultiDeviceRigidICP
+    m = MultiDeviceRigidICP([0, 0]); m.set_clouds(d["dst"], d["dst_n"], d["src"], float(d["max_sq_dist"]), PARTITION_TARGET_SHARDS)
+    assert [m.shard_sizes(k) for k in range(2)] == [(half, len(d["src"])), (nd - half, len(d["src"]))]
+    pc = _capi.IcpParams(); _capi.load().cilhip_icp_default_params(C.byref(pc))
+    pc.metric, pc.w_p2p, pc.w_p2pl, pc.max_sq_dist, pc.max_iter, pc.conv_tol = _capi.METRIC_COMBINED, 0.1, 1.0, float(d["max_sq_dist"]), 6, 0.0
+    rm = m.icp_run(pc); m.close()
+    Tm = np.array(rm.T[:], np.float32).reshape(4, 4).T
+    assert int(rm.iterations) == 6 and int(rm.last_ncorr) == nc1 and np.abs(Tm.astype(np.float64) - T1.astype(np.float64)).max() <= 1e-6
+    del m
+    torch.cuda.empty_cache()
     tree = orc.KDTree(d["dst"], use_ref=orc.ref_available())
     # the sharded LOOP's own correspondences: the last iteration's all-reduced keys (packed (bits(d2) << 32) | global target index per
     # source point) against the reference's nanoflann over the whole 80M-point target on a 200k-query sample, index for index, bit for bit
