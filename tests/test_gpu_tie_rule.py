@@ -453,3 +453,35 @@ def test_other_search_directions_follow_the_tree_over_the_transformed_source(Con
         out[f"loop {direction.name}{' reciprocal' if recip else ''}"] = {"T_minus_oracle": err, "ncorr": int(icp.last_ncorr_), "oracle_ncorr": int(ro["last_ncorr"])}
         assert icp.getNumberOfPerformedIterations() == 5 and icp.last_ncorr_ == ro["last_ncorr"] and err <= 2e-6, (direction, recip, err)
     _report("tie_rule_directions.json", out)
+
+
+def test_hundreds_of_copies_of_one_point(Context, orc):
+    """300 copies of each of two points among 50 others, 500 queries: every query has hundreds of exactly equidistant nearest points (no
+    cap on the candidates: they stream through the comparison), the reference's tree over such a cloud is all zero-extent splits -- the
+    engine names nanoflann's pick for every query, one lane and several lanes per query, and as a loop."""
+    rng = np.random.default_rng(23)
+    A = np.array([0.25, 0.5, 0.75], np.float32); B = np.array([0.75, 0.25, 0.5], np.float32)
+    D = np.concatenate([np.tile(A, (300, 1)), np.tile(B, (300, 1)), rng.random((50, 3), dtype=np.float32)])
+    D = np.ascontiguousarray(D[rng.permutation(len(D))].astype(np.float32))
+    N = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (len(D), 1))
+    S = np.ascontiguousarray(np.concatenate([rng.random((400, 3), dtype=np.float32), D[rng.integers(0, len(D), 100)] + np.float32(1e-3)]).astype(np.float32))
+    r2 = np.float32(4.0)
+    tree = orc.KDTree(D, use_ref=orc.ref_available())
+    oi, _, ov = _ref_matches(tree, S, r2, len(S))
+    I = np.eye(4, dtype=np.float32)
+    for name, opts in (("default", {}), ("one lane per query", {"tiled": 0, "group_search": 0}), ("16 lanes per query", {"tiled": 0, "group_search": 16}), ("tiles", {"tiled": 2})):
+        ctx = Context()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_target(D, N); ctx.set_source(S)
+        ctx.find_correspondences(I, float(r2), count=False)
+        gi, gd = ctx.get_nn()
+        seen, moved = ctx.tie_rule_stats()
+        assert np.array_equal(_signed(gi), oi), (name, int(np.count_nonzero(_signed(gi) != oi)))
+        assert seen > 50 and moved > 50, (name, seen, moved)      # (the queries whose nearest point is one of the two copied ones)
+        res = ctx.icp_run(_icp_params(ctx, r2, 3))
+        T = ctx.matches_transform()
+        li, _ = ctx.get_nn()
+        oi_l, _, _ = _ref_matches(tree, orc.transform_points(T, S), r2, len(S))
+        assert np.array_equal(_signed(li), oi_l) and int(res.iterations) == 3, name
+        ctx.close()

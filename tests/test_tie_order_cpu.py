@@ -122,3 +122,40 @@ def test_threads_do_not_change_the_order(shim):
     finally:
         for h in (a, b, c):
             shim.tie_shim_free(h)
+
+
+def test_degenerate_clouds_massive_duplicates_lines_tiny(shim, orc):
+    """what the restated build must get right where nanoflann's splits degenerate: hundreds of copies of one point (zero-extent boxes: the
+    plane split balances the copies by position), points on a line (two dimensions without extent), clouds smaller than a leaf.  Every
+    query below has ALL copies of its nearest point as candidates; the pick (first met, and smallest traversal key) is the reference's."""
+    rng = np.random.default_rng(23)
+    A = np.array([0.25, 0.5, 0.75], np.float32); B = np.array([0.75, 0.25, 0.5], np.float32)
+    clouds = {
+        "300 + 300 copies of two points and 50 others": np.concatenate([np.tile(A, (300, 1)), np.tile(B, (300, 1)), rng.random((50, 3), dtype=np.float32)]),
+        "a line with doubled points": np.concatenate([np.stack([np.linspace(0, 1, 400, dtype=np.float32), np.full(400, 0.5, np.float32), np.full(400, 0.5, np.float32)], 1)] * 2),
+        "seven points, three of them the same": np.concatenate([rng.random((4, 3), dtype=np.float32), np.tile(A, (3, 1))]),
+        "one point five times": np.tile(B, (5, 1)),
+    }
+    for name, D in clouds.items():
+        D = np.ascontiguousarray(D[rng.permutation(len(D))].astype(np.float32))
+        Q = np.ascontiguousarray(np.concatenate([rng.random((400, 3), dtype=np.float32), D[rng.integers(0, len(D), 100)] + np.float32(1e-3)]).astype(np.float32))
+        tree = orc.KDTree(D, use_ref=orc.ref_available())
+        o1, o2, ov = tree.find_correspondences(Q, 1.0e9)
+        assert len(o2) == len(Q)
+        # all target points at exactly the nearest distance (the pinned expression), per query
+        d2 = _pinned_d2(Q[:, None, :], D[None, :, :])
+        tied = d2 == d2.min(axis=1, keepdims=True)
+        cnt = tied.sum(axis=1).astype(np.int32)
+        stride = int(cnt.max())
+        cand = np.zeros((len(Q), stride), np.uint32)
+        for k in range(len(Q)):
+            cand[k, : cnt[k]] = np.nonzero(tied[k])[0]
+        h = shim.tie_shim_build(D.ctypes.data, len(D))
+        got = np.zeros(len(Q), np.uint32); got2 = np.zeros(len(Q), np.uint32); depth = np.zeros(1, np.uint32)
+        shim.tie_shim_first_met(h, Q.ctypes.data, cand.ctypes.data, cnt.ctypes.data, stride, len(Q), got.ctypes.data)
+        shim.tie_shim_min_key(h, Q.ctypes.data, cand.ctypes.data, cnt.ctypes.data, stride, len(Q), got2.ctypes.data, depth.ctypes.data)
+        shim.tie_shim_free(h)
+        want = np.zeros(len(Q), np.int64); want[o2] = o1
+        assert np.array_equal(got.astype(np.int64), want), (name, int(np.count_nonzero(got.astype(np.int64) != want)))
+        assert np.array_equal(got2.astype(np.int64), want), (name, "keys", int(np.count_nonzero(got2.astype(np.int64) != want)))
+        assert int(depth[0]) <= 58, (name, int(depth[0]))
