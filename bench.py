@@ -108,7 +108,7 @@ def stratified_form_timing(ft, forms, timed):
 def source_hash():
     """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "tile_pipe.inc", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp"):
+    for f in ("kernels.hip", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp"):
         with open(os.path.join(ROOT, "cilantro_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

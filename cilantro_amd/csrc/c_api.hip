@@ -70,7 +70,6 @@ struct cilhip_ctx {
   uint32_t* d_dbg = nullptr;                   // [2] cilhip_debug_counters scratch
   uint4* d_trace = nullptr;                    // [RUN_TRACE_CAP] per-iteration loop state of the last run, written by the epilogue (cilhip_get_last_run_trace)
   uint32_t ntiles = 0;
-  int tile_pipeline = 0;          // option "tile_pipeline": 1 = the in-tile accumulation runs as the persistent, software-pipelined kernel k_tile_pipe
                                   // (round 3 experiment, exact, measured 17 % slower than two workgroups per CU: off)
   int tiled = 1;                  // 0: per-lane global-memory search; 1: LDS-tiled search when the cloud is large enough; 2: always tiled
   bool src_sorted = false;
@@ -373,7 +372,6 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "inlier_fraction")) { if (c->inlier_fraction != value && c->pending_matches) drop_matches(c); c->inlier_fraction = value; return CILHIP_OK; }
   if (!strcmp(key, "one_to_one")) { if (c->one_to_one != (value != 0.0) && c->pending_matches) drop_matches(c); c->one_to_one = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "tiled")) { c->tiled = (int)value; return CILHIP_OK; }
-  if (!strcmp(key, "tile_pipeline")) { c->tile_pipeline = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return CILHIP_OK; }
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "fused_epilogue")) { c->fused_epilogue = value != 0.0; return CILHIP_OK; }
@@ -741,7 +739,7 @@ static bool use_tiled(const cilhip_ctx* c) {
   const double fill = (double)c->ns / ((double)c->ntiles * (double)TILE_QUERIES);
   const double region_cells = (double)(CUBE_EDGE + 3) * (CUBE_EDGE + 3) * (CUBE_EDGE + 3);
   const double density = c->grid_occ > 1.0 ? c->grid_occ - 1.0 : c->grid_occ;   // sum(count^2)/n = lambda + 1 for a Poisson cloud
-  return fill >= 0.45 && density * region_cells <= 0.92 * (double)CILHIP_TILE_CAP;
+  return fill >= 0.45 && density * region_cells <= 0.92 * (double)TILE_CAP;
 }
 
 static bool filters_active(const cilhip_ctx* c) {
@@ -1068,10 +1066,8 @@ static IterArgs make_iter_args(cilhip_ctx* c, float max_sq) {
   a.defer_flag = c->d_defer_flag;
   a.unproven_cnt = c->d_unproven;
   a.store_matches = 1;
-  a.tile_pipeline = c->tile_pipeline;
   a.skip_if_inner_done = 0;
   a.tie = tie_dev_of(c);
-  if (a.tie.mode) a.tile_pipeline = 0;      // (the pipelined experiment kernels do not look at ties)
   return a;
 }
 
@@ -2179,7 +2175,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
           fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
           // ... and from the second iteration on the tile leaves the match records of the warm-started form (not the first: a
           // registration's first step is its largest, its margins would be spent at once)
-          const bool recs = wcap && it >= 1 && !c->tile_pipeline && c->tile_records && fa.store_matches;
+          const bool recs = wcap && it >= 1 && c->tile_records && fa.store_matches;
           if (recs) set_warm_args(c, fa);
           launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
           c->rec_valid = recs; c->lb_fresh = false;
@@ -2395,7 +2391,7 @@ static int partial_sums_core(cilhip_ctx* c, double* sums_dev, double* rows_dev) 
         IterArgs fa = a;
         fa.store_matches = c->warm_start ? 1 : 0;
         fa.partials = c->d_partials + (size_t)c->ntiles * SUMS_MAX;
-        const bool recs = wcap && c->run_calls >= 1 && !c->tile_pipeline && c->tile_records && fa.store_matches;
+        const bool recs = wcap && c->run_calls >= 1 && c->tile_records && fa.store_matches;
         if (recs) set_warm_args(c, fa);
         launch_search_tiled(fa, im, c->d_tiles, c->d_tile_center, c->d_tile_box, c->ntiles, c->stream);
         c->rec_valid = recs; c->lb_fresh = false;

@@ -26,14 +26,18 @@ constexpr int GRID_PAD = 2;
 #ifndef CILHIP_TILE_WAVES_PER_SIMD
 #define CILHIP_TILE_WAVES_PER_SIMD 8   /* resident waves per SIMD the tiled kernel is compiled for (register budget) */
 #endif
-#ifndef CILHIP_TILE_CAP
-#define CILHIP_TILE_CAP 3840   /* target points one tile can stage in LDS (16 B each) */
+#ifndef CILHIP_TILE_BYTES
+#define CILHIP_TILE_BYTES 61568   /* LDS bytes of a tile's staged target points (pairs of records {x0, x1, y0, y1, z0, z1}: 12 B per point, + pad records); >= 3584 B per wave (accumulation scratch) */
 #endif
 #ifndef CILHIP_TILE_MAXE
 #define CILHIP_TILE_MAXE 4352  /* entries of the staged cell table: region rows x (region width + 1) */
 #endif
 constexpr int TILE_THREADS = CILHIP_TILE_THREADS;  // workgroup size of the tiled search kernel
 constexpr int TILE_QUERIES = 2 * TILE_THREADS;     // max queries per tile (two per lane)
+constexpr int TILE_BYTES = CILHIP_TILE_BYTES;
+constexpr int TILE_MAXSPAN = CUBE_EDGE + 6;                  // region rows per axis (y, z) the row tables hold
+constexpr int TILE_MAXROWS = TILE_MAXSPAN * TILE_MAXSPAN;    // RY*RZ
+constexpr int TILE_CAP = TILE_BYTES / 12 - 12;     // target points one tile can stage in LDS (behind them: 10 pad records, the 3x3x3 pass's queue)
 
 // Uniform grid over the target cloud (the structure that replaces the nanoflann kd-tree).
 // Target points are stored sorted by linear cell id (x fastest) as 16-byte records
@@ -163,7 +167,6 @@ struct IterArgs {
   uint32_t* defer_flag;    // [1] set by a tile that defers a query: the clean-up pass has work
   uint32_t* unproven_cnt;  // [128] (spread by tile / block index) [0, 64): queries the octant block did not prove (how far the source is from
                            // alignment; the warm-started kernel: queries without a usable bound), [64, 128): queries the warm-started kernel listed
-  int tile_pipeline;       // tiled search with in-tile accumulation: the persistent, software-pipelined kernel (k_tile_pipe) instead of one workgroup per tile
   int store_matches;       // tiled search: also write nn_pos / nn_d2 for the queries settled inside the tile (the pure ICP loop needs neither)
   int skip_if_inner_done;
   int no_centering;        // affine point-to-point class: moments of the raw coordinates (no means subtracted)

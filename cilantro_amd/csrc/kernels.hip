@@ -1072,56 +1072,86 @@ __device__ __forceinline__ void fused_z(bool has, float qx, float qy, float qz, 
 // radius), queries outside the grid or outside the tile's box, the slabs of a region that exceed the LDS
 // budget (and whole tiles whose region cannot be staged at all: queries that drifted far from their
 // sort-time cells) fall back to the global-memory search of the clean-up pass, k_search_todo.
-constexpr int TILE_CAP = CILHIP_TILE_CAP;                    // staged target points per tile (16 B each)
-constexpr int TILE_MAXSPAN = CUBE_EDGE + 6;                  // region rows per axis (y, z) the row tables hold
-constexpr int TILE_MAXROWS = TILE_MAXSPAN * TILE_MAXSPAN;    // RY*RZ
 constexpr int TILE_MAXE = CILHIP_TILE_MAXE;                  // entries of the staged cell table: rows * (RX + 1)
 constexpr int TILE_QPT = TILE_QUERIES / TILE_THREADS;        // queries per thread
 constexpr int TILE_WAVES = TILE_THREADS / 64;
 constexpr uint32_t DEFER_MARK = 0xFFFFFFFEu;                 // nn_pos value: "the LDS tile could not settle this query" (between a tile's 3x3x3 pass and its home lanes)
 constexpr int FUSED_WAVE_BYTES = 3584;                       // per-wave scratch of the in-tile accumulation (64 correspondences x 14 floats) carved from the point buffer
-static_assert(FUSED_WAVE_BYTES * TILE_WAVES <= (TILE_CAP + 8) * 16, "the accumulation scratch reuses the tile's point buffer");
+static_assert(FUSED_WAVE_BYTES * TILE_WAVES <= TILE_BYTES, "the accumulation scratch reuses the tile's point buffer");
 static_assert(FUSED_WAVE_BYTES >= 64 * 8 * 4 + 64 && FUSED_WAVE_BYTES >= 4 * 64 * 8, "scratch holds the padded 8-float layout and the wave's 16x16 f64 tile");
+static_assert(TILE_CAP + 8 < 65536, "LDS slots are packed into 16 bits");
 static_assert(TILE_MAXE <= 65536 && TILE_MAXROWS <= 32767, "OctQuery packs a table index and a row into 16 bits each");
 static_assert(TILE_MAXROWS <= 64 * 8, "the row scan holds at most 8 rows per lane of one wave");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef CILHIP_TIE_TRACK
-#define CILHIP_TIE_TRACK 1   /* dev: 1 = every tile variant tracks the second smallest distance (TRACK2), 0 = only the LB / feature variants (round 4) */
-#endif
-#ifndef CILHIP_TIE_MODE
-#define CILHIP_TIE_MODE 2    /* dev: 0 = the tiles do not look at ties, 1 = a suspected tie is unproven, 2 = suspected, then confirmed over the block's runs */
-#endif
+// ---- The staged tile in LDS: PAIRS of records {x0, x1, y0, y1, z0, z1}, 24 bytes, slots in the order of the sorted target array
+// row by row (slot j = half j & 1 of pair j >> 1). ----
+// (No index: a match is named by its LDS slot -> sorted position; which of several EXACTLY equidistant points wins is never
+//  decided in the tile -- a tie is noticed, confirmed and handed to the clean-up pass, which applies the tie rule with full keys.)
+// One ds_read_b64 delivers the SAME coordinate of the two records of a pair as an aligned register pair -- the operands of the packed
+// f32 instructions (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations per component, so d2 still rounds exactly as
+// ((dx*dx)+(dy*dy))+(dz*dz)) -- at the LDS's full rate (256 B/clk; ds_read2_b32 over 12-byte records measured half of it, and the
+// LDS busy for half of the kernel's time).  A run that starts on an odd slot is read from the even slot before it: one more real
+// target point among the candidates -- a superset of the block never hurts the minimum or the proof.
+//
+// Candidates are ranked by a 32-bit key: the bits of d2 with the low KB bits replaced by the candidate's SLOT CODE (a compile-time
+// constant per straight-line slot).  The running smallest and second smallest keys cost one v_min_u32 and one v_med3_u32 per
+// candidate, nothing is selected or compared in 64 bits, and the winner's slot comes out of the key.  The truncation is monotone, so
+// the smallest key belongs to a candidate whose d2 is within 2^(KB-23) of the smallest; whenever the two smallest keys agree in
+// their distance bits (two candidates nearer to each other than the truncation, a genuine tie, a record read through two runs),
+// or the smallest lies within the truncation of the search radius, the block is scanned again EXACTLY (clamped runs, full f32
+// compares: a few lanes of some waves).  The truncated second smallest key is a valid LOWER bound of every other candidate's d2,
+// which is all the margin keys and the feature search need of it.
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
-// One candidate against the running best.  (x,y) go through packed f32 math (v_pk_add/v_pk_mul: the same
-// IEEE operations per component, so d2 still rounds exactly as ((dx*dx)+(dy*dy))+(dz*dz)).
-// TRACK2 (feature search): also keep the two smallest squared distances met (m12[0] <= m12[1]) -- plain f32 min / median
-// beside the key compare; `counted` = false keeps a re-read candidate out of them.
-// One candidate against the running best.  (x,y) go through packed f32 math (v_pk_add/v_pk_mul: the same
-// IEEE operations per component, so d2 still rounds exactly as ((dx*dx)+(dy*dy))+(dz*dz)).
-// TRACK2 (feature search): also keep the two smallest squared distances met (m12[0] <= m12[1]) -- plain f32 min / median
-// beside the key compare; `counted` = false keeps a re-read candidate out of them.
-// Ties (option "tie_rule"; and the lowest-index rule itself when the winner was first met through an over-read): the tiles only
-// NOTICE that the smallest distance may have been met twice -- cheaply and conservatively -- and then CONFIRM it exactly over the
-// block's own runs (tile_tie_confirm below); a confirmed tie is not settled in the tile: the clean-up pass applies the tie rule with
-// full keys.  Noticing: TRACK2 variants know from their second smallest distance; the others keep tacc = min over the candidates of
-// (bits(d2) XOR bits(smallest so far)) -- two integer operations in a vector register, 0 once any candidate repeats the smallest
-// distance of its moment (sticky; a point read twice does it too: the confirmation sorts that out).
-template <bool TRACK2 = false>
-__device__ __forceinline__ void eval_candidate(const float4 p, const f32x2 qxy, float qz, uint32_t pos,
-                                               unsigned long long& bk, uint32_t& bp, float* m12, bool counted, uint32_t& tacc) {
-  const f32x2 pxy = {p.x, p.y};
-  const f32x2 d = qxy - pxy;
-  const f32x2 m = d * d;
-  const float dz = __fsub_rn(qz, p.w);      // LDS record layout {x, y, bits(index), z}: see k_search_tiled, staging
-  const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
-  const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
-  const bool lt = k < bk;
-  if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], counted ? e : INFINITY);   // hi(bk) is the smallest so far
-  if (!TRACK2 && CILHIP_TIE_MODE != 0) tacc = min(tacc, (__float_as_uint(e) ^ (uint32_t)(bk >> 32)) | (counted ? 0u : 1u));
-  bk = lt ? k : bk;
-  bp = lt ? pos : bp;
+struct Run4 { f32x2 x0, y0, z0, x1, y1, z1; };   // four consecutive records as coordinate pairs (slots 0,1 and 2,3)
+
+// request two consecutive pairs (four slots) starting at the pair at LDS byte address `addr` (six ds_read_b64; nothing waits here)
+__device__ __forceinline__ void lds_issue_run4(uint32_t addr, Run4& r) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(r.x0) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(r.y0) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(r.z0) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(r.x1) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(r.y1) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:40" : "=v"(r.z1) : "v"(addr));
+}
+// one pair
+__device__ __forceinline__ void lds_issue_pair(uint32_t addr, f32x2& x, f32x2& y, f32x2& z) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(x) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(y) : "v"(addr));
+  asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(z) : "v"(addr));
+}
+// slot -> LDS byte address of its pair / dword index of its x inside the float array
+__device__ __forceinline__ uint32_t lds_pair_addr(uint32_t base, uint32_t slot) { return base + __umul24(slot >> 1, 24u); }
+__device__ __forceinline__ uint32_t lds_slot_x(uint32_t slot) { return __umul24(slot >> 1, 6u) + (slot & 1u); }
+// wait until at most N of the LDS operations issued so far are outstanding (they return in order, so everything requested
+// before the youngest N has arrived); the registers go through the statement so that no use is scheduled ahead of it
+template <int N>
+__device__ __forceinline__ void lds_wait_run4(Run4& r) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(r.x0), "+v"(r.y0), "+v"(r.z0), "+v"(r.x1), "+v"(r.y1), "+v"(r.z1) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_pair(f32x2& x, f32x2& y, f32x2& z) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(x), "+v"(y), "+v"(z) : "n"(N));
+}
+
+// two candidates against the two smallest keys (b <= s); `code` is a compile-time constant at every call site (an inline operand)
+__device__ __forceinline__ void eval_pair(uint32_t code, const f32x2 X, const f32x2 Y, const f32x2 Z, const f32x2 qx, const f32x2 qy, const f32x2 qz, uint32_t kmask,
+                                          uint32_t& b, uint32_t& s) {
+  const f32x2 dx = qx - X, dy = qy - Y, dz = qz - Z;
+  const f32x2 e = (dx * dx + dy * dy) + dz * dz;
+  const uint32_t k0 = (__float_as_uint(e.x) & kmask) | code, k1 = (__float_as_uint(e.y) & kmask) | (code + 1u);
+  s = umed3(b, s, k0); b = min(b, k0);
+  s = umed3(b, s, k1); b = min(b, k1);
+}
+__device__ __forceinline__ void eval_run4(uint32_t code, const Run4& r, const f32x2 qx, const f32x2 qy, const f32x2 qz, uint32_t kmask, uint32_t& b, uint32_t& s) {
+  eval_pair(code, r.x0, r.y0, r.z0, qx, qy, qz, kmask, b, s);
+  eval_pair(code + 2u, r.x1, r.y1, r.z1, qx, qy, qz, kmask, b, s);
 }
 
 // LDS tile index -> position in the global sorted target array (row found by binary search over rowbase)
@@ -1136,37 +1166,37 @@ __device__ __forceinline__ uint32_t lds_to_global(uint32_t l, const uint32_t* ro
 }
 
 struct TileLds {
-  const float4* lpts;
+  const float* lp;            // the staged pairs {x0, x1, y0, y1, z0, z1}
+  uint32_t lp_addr;           // the same, as an LDS byte address
+  uint32_t pad;               // slot of the first of the 8 pad records (d2 = inf) behind the staged points
   const uint32_t* lcs;        // [rows][W1] cell_start values (GLOBAL sorted positions) of the region's cells, +1 end column
   const uint32_t* rowbase;    // [rows+1] LDS index of the first staged point of each region row
   const uint32_t* rowdelta;   // [rows]   global sorted position - LDS index, per row (mod 2^32)
   int lox, loy, loz, RY, W1, rows;
 };
 
-#ifndef CILHIP_OCT_CAND
-#define CILHIP_OCT_CAND 4   /* candidates per run evaluated unconditionally (a run = 2 cells, ~2 points at the default occupancy) */
-#endif
+__device__ __forceinline__ float lds_d2(const float* lp, uint32_t j, float qx, float qy, float qz) {
+  const float* const w = lp + lds_slot_x(j);
+  return d2_pinned(qx, qy, qz, w[0], w[2], w[4]);
+}
+
+// the exact scan of a block's runs (clamped): smallest d2 (lowest slot among equals), the second smallest over the OTHER slots,
+// whether another slot repeats the smallest exactly
+struct ExactScan { float e1, e2; uint32_t bl; bool tie; };
+__device__ __forceinline__ void exact_take(ExactScan& x, float e, uint32_t j) {
+  if (e < x.e1) { x.e2 = x.e1; x.e1 = e; x.bl = j; x.tie = false; }
+  else { x.tie |= e == x.e1; x.e2 = fminf(x.e2, e); }
+}
+
 #ifndef CILHIP_OCT_EXTRA
 #define CILHIP_OCT_EXTRA 1  /* further quads taken in straight-line code before the overflow loop */
 #endif
-constexpr int OCT_CAND = CILHIP_OCT_CAND;
+#ifndef CILHIP_EXP_HACK
+#define CILHIP_EXP_HACK 0   /* dev: timing-only experiments (WRONG results): 1 = one run per octant search, 2 = no staging loads, 3 = no cell-table loads, 4 = no normal gather */
+#endif
+constexpr int OCT_CAND = 4;   // candidates per run evaluated unconditionally (a run = 2 cells, ~2 points at the default occupancy)
 constexpr int OCT_EXTRA = CILHIP_OCT_EXTRA;
-
-template <bool TRACK2 = false>
-__device__ __forceinline__ void eval_candidate_sel(const float4 p, const f32x2 qxy, float qz, uint32_t code,
-                                                   unsigned long long& bk, uint32_t& sel, float* m12, uint32_t& tacc) {
-  const f32x2 pxy = {p.x, p.y};
-  const f32x2 d = qxy - pxy;
-  const f32x2 m = d * d;
-  const float dz = __fsub_rn(qz, p.w);      // LDS record layout {x, y, bits(index), z}: see k_search_tiled, staging
-  const float e = __fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz));
-  const unsigned long long k = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(p.z);
-  const bool lt = k < bk;
-  if (TRACK2) m12[1] = __builtin_amdgcn_fmed3f(__uint_as_float((uint32_t)(bk >> 32)), m12[1], e);
-  if (!TRACK2 && CILHIP_TIE_MODE != 0) tacc = min(tacc, __float_as_uint(e) ^ (uint32_t)(bk >> 32));
-  bk = lt ? k : bk;
-  sel = lt ? code : sel;      // code is a compile-time constant: no address arithmetic per candidate
-}
+constexpr uint32_t OCT_KMASK = 0xFFFFFFE0u, OCT_NOCODE = 31u, OCT_OVER = 16u;   // 5 code bits: 16 straight-line slots, 4 of the current overflow quad
 
 // What a lane keeps of one query between its preparation (while the target points are still in flight) and the search.
 struct OctQuery {
@@ -1183,8 +1213,7 @@ struct OctQuery {
 // octant_prepare() only needs the query; octant_search() runs out of LDS in STRAIGHT-LINE code: every lane
 // evaluates exactly OCT_CAND unclamped candidates per run (reading past a short run only evaluates further
 // real target points or the far-away pad records -- never wrong), no per-lane loop or branch, so the wave
-// executes each instruction once with all lanes busy.  The winner is tracked as a small constant (run, slot)
-// code and turned into an LDS index once.
+// executes each instruction once with all lanes busy.
 // Returns whether the block lies inside the staged region [lo, hi] (cells, inclusive) -- all the fast path needs.  The
 // block of the other queries is clamped into the region so that the code below stays branch-free; their result is dropped.
 __device__ __forceinline__ bool octant_prepare(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
@@ -1210,17 +1239,15 @@ __device__ __forceinline__ float octant_bound(const GridDev& g, float qx, float 
   return fminf(fminf(fmaxf(ux, g.cell - ux), fmaxf(uy, g.cell - uy)), fmaxf(uz, g.cell - uz));
 }
 
-// Returns true (result proven exact) iff the best found is strictly nearer than any point outside the block can be.
-// TRACK2 (feature search): *second_out = the second smallest 3-D squared distance among the candidates evaluated (the
-// radius while there is none): the 6-D feature distance of any candidate but the winner is at least that.
-template <bool TRACK2 = false>
+// Returns true (result proven exact) iff the best found is strictly nearer than any point outside the block can be and no other
+// record lies at exactly its distance.  best.key = bits(d2) << 32 (exact d2 of the winner; the radius when there is none), best.pos its
+// sorted position, bl_out its LDS slot; *second_out = a lower bound of the squared distance of every OTHER record evaluated (at most the
+// radius); *bound_out = the (shrunk) distance from q to the nearest face of the block.
 __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t, const OctQuery& o, float max_sq, NN& best, uint32_t& bl_out,
                                               float* second_out = nullptr, float* bound_out = nullptr) {
-  float m12[2] = {INFINITY, INFINITY};
-  uint32_t tacc = 0xFFFFFFFFu;
-  const f32x2 qxy = {o.qx, o.qy};
-  const float qz = o.qz;
-  unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  const f32x2 qx = {o.qx, o.qx}, qy = {o.qy, o.qy}, qz = {o.qz, o.qz};
+  const uint32_t init = (__float_as_uint(max_sq) & OCT_KMASK) | OCT_NOCODE;
+  uint32_t b = init, s = init;
   uint32_t rj[4], re[4];
   const int row00 = o.ebrow >> 16, eb00 = o.ebrow & 0xFFFF;
 #pragma unroll
@@ -1228,48 +1255,49 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     const int row = row00 + (k >> 1) * t.RY + (k & 1);
     const int eb = eb00 + ((k >> 1) * t.RY + (k & 1)) * t.W1;
     const uint32_t dl = t.rowdelta[row];
-    rj[k] = t.lcs[eb] - dl;
+    rj[k] = (t.lcs[eb] - dl) & ~1u;      // (the even slot at or before the run's first)
     re[k] = t.lcs[eb + 2] - dl;
   }
-  uint32_t sel = 0xFFu;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float4 p[OCT_CAND];
-#pragma unroll
-    for (int c = 0; c < OCT_CAND; ++c) p[c] = t.lpts[rj[k] + c];
-#pragma unroll
-    for (int c = 0; c < OCT_CAND; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(k * OCT_CAND + c), bk, sel, m12, tacc);
-    if (TRACK2 && k < 3) {   // ties the next run's address to this run's result: keeps the scheduler from issuing all 16 reads first (64 live registers)
-      uint32_t hi = (uint32_t)(bk >> 32);
-      asm volatile("" : "+v"(rj[k + 1]), "+v"(hi), "+v"(m12[1]));
-      bk = ((unsigned long long)hi << 32) | (uint32_t)bk;
-    }
+  {
+    Run4 r0, r1;
+    lds_issue_run4(lds_pair_addr(t.lp_addr, rj[0]), r0);
+    lds_issue_run4(lds_pair_addr(t.lp_addr, rj[1]), r1);
+    lds_wait_run4<6>(r0);
+    eval_run4(0u, r0, qx, qy, qz, OCT_KMASK, b, s);
+#if CILHIP_EXP_HACK != 1
+    lds_issue_run4(lds_pair_addr(t.lp_addr, rj[2]), r0);
+    lds_wait_run4<6>(r1);
+    eval_run4(4u, r1, qx, qy, qz, OCT_KMASK, b, s);
+    lds_issue_run4(lds_pair_addr(t.lp_addr, rj[3]), r1);
+    lds_wait_run4<6>(r0);
+    eval_run4(8u, r0, qx, qy, qz, OCT_KMASK, b, s);
+    lds_wait_run4<0>(r1);
+    eval_run4(12u, r1, qx, qy, qz, OCT_KMASK, b, s);
+#else
+    lds_wait_run4<0>(r1);
+#endif
   }
-  uint32_t bl = NONE_U32;
-  if (sel != 0xFFu) {
-    const uint32_t k = sel / OCT_CAND;
-    bl = (k == 0 ? rj[0] : k == 1 ? rj[1] : k == 2 ? rj[2] : rj[3]) + (sel - k * OCT_CAND);
-  }
-  // Runs longer than OCT_CAND.  A flattened per-lane loop costs the whole wave its longest lane (and every
-  // transition between runs is a wave-wide iteration), and some lane of almost every wave has one long run.
-  // So: OCT_EXTRA more quads in straight-line code -- every lane takes the first run it has not finished
-  // (or harmlessly re-reads its first candidates) -- and only then the loop, which few waves enter.
-  uint32_t nj[4];
+  // Runs longer than OCT_CAND.  A flattened per-lane loop costs the whole wave its longest lane, and some lane of almost every
+  // wave has one long run.  So: OCT_EXTRA more quads in straight-line code -- every lane takes the first run it has not finished
+  // (the others read the pad records: d2 = inf) -- and only then the loop, which few waves enter.  The overflow quad's slots carry
+  // the codes 16..19; `bov` remembers the quad that last improved the minimum.
+  uint32_t nj[4], bov = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) nj[k] = rj[k] + OCT_CAND;
 #pragma unroll
   for (int x = 0; x < OCT_EXTRA; ++x) {
     const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
-    const uint32_t jx = c0 ? nj[0] : c1 ? nj[1] : c2 ? nj[2] : c3 ? nj[3] : rj[0];
+    const uint32_t jx = c0 ? nj[0] : c1 ? nj[1] : c2 ? nj[2] : c3 ? nj[3] : t.pad;      // (t.pad: even)
     nj[0] += c0 ? 4u : 0u;
     nj[1] += (!c0 & c1) ? 4u : 0u;
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
-    const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
-    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
-    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
-    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, c0 | c1 | c2 | c3, tacc);
+    Run4 r;
+    lds_issue_run4(lds_pair_addr(t.lp_addr, jx), r);
+    const uint32_t bprev = b;
+    lds_wait_run4<0>(r);
+    eval_run4(OCT_OVER, r, qx, qy, qz, OCT_KMASK, b, s);
+    bov = b != bprev ? jx : bov;
   }
   for (;;) {
     const bool c0 = nj[0] < re[0], c1 = nj[1] < re[1], c2 = nj[2] < re[2], c3 = nj[3] < re[3];
@@ -1279,54 +1307,57 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     nj[1] += (!c0 & c1) ? 4u : 0u;
     nj[2] += (!c0 & !c1 & c2) ? 4u : 0u;
     nj[3] += (!c0 & !c1 & !c2 & c3) ? 4u : 0u;
-    const float4 p0 = t.lpts[jx], p1 = t.lpts[jx + 1], p2 = t.lpts[jx + 2], p3 = t.lpts[jx + 3];
-    eval_candidate<TRACK2>(p0, qxy, qz, jx, bk, bl, m12, true, tacc);
-    eval_candidate<TRACK2>(p1, qxy, qz, jx + 1, bk, bl, m12, true, tacc);
-    eval_candidate<TRACK2>(p2, qxy, qz, jx + 2, bk, bl, m12, true, tacc);
-    eval_candidate<TRACK2>(p3, qxy, qz, jx + 3, bk, bl, m12, true, tacc);
+    Run4 r;
+    lds_issue_run4(lds_pair_addr(t.lp_addr, jx), r);
+    const uint32_t bprev = b;
+    lds_wait_run4<0>(r);
+    eval_run4(OCT_OVER, r, qx, qy, qz, OCT_KMASK, b, s);
+    bov = b != bprev ? jx : bov;
   }
-  best.key = bk;
+  // the winner's slot out of its code
+  const uint32_t code = b & ~OCT_KMASK;
+  uint32_t bl = NONE_U32;
+  float e1 = max_sq, second = __uint_as_float(s & OCT_KMASK);
+  bool tie = false;
+  if (code != OCT_NOCODE) {
+    const uint32_t k = code >> 2;
+    bl = (code >= OCT_OVER ? bov : (k == 0 ? rj[0] : k == 1 ? rj[1] : k == 2 ? rj[2] : rj[3])) + (code & 3u);
+    e1 = lds_d2(t.lp, bl, o.qx, o.qy, o.qz);
+    if ((((b ^ s) & OCT_KMASK) == 0u) | (((b ^ init) & OCT_KMASK) == 0u)) {
+      // the two smallest keys agree in their distance bits, or the smallest lies within the truncation of the radius: decided exactly,
+      // over the block's own four runs, clamped (the runs are looked up again HERE: nothing of them stays live for this rare branch)
+      ExactScan x{INFINITY, INFINITY, NONE_U32, false};
+      int ebr = o.ebrow;
+      asm volatile("" : "+v"(ebr));
+      const int crow = ebr >> 16, ceb = ebr & 0xFFFF;
+      for (int k2 = 0; k2 < 4; ++k2) {
+        const int krow = crow + (k2 >> 1) * t.RY + (k2 & 1);
+        const int keb = ceb + ((k2 >> 1) * t.RY + (k2 & 1)) * t.W1;
+        const uint32_t kdl = t.rowdelta[krow];
+        const uint32_t j1 = t.lcs[keb + 2] - kdl;
+        for (uint32_t j = t.lcs[keb] - kdl; j < j1; ++j) exact_take(x, lds_d2(t.lp, j, o.qx, o.qy, o.qz), j);
+      }
+      bl = x.bl; e1 = x.e1; second = x.e2; tie = x.tie;      // (x.bl == NONE: the key's winner was an over-read record outside the block)
+    }
+    if (!(e1 < max_sq)) { second = fminf(second, e1); bl = NONE_U32; e1 = max_sq; tie = false; }
+  }
+  second = fminf(second, max_sq);
+  best.key = ((unsigned long long)__float_as_uint(e1) << 32);
   // LDS index -> global position: the winner normally lies in the row of its run (one table read); an
   // over-read winner past the end of that row (or one picked up through a clipped run) takes the binary search
   uint32_t pos = NONE_U32;
   if (bl != NONE_U32) {
     const int k = (int)(bl >= rj[1]) + (int)(bl >= rj[2]) + (int)(bl >= rj[3]);   // the runs ascend in LDS
     const int row = row00 + (k >> 1) * t.RY + (k & 1);
-    if (bl < t.rowbase[row + 1]) pos = bl + t.rowdelta[row];
-    else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
+    if (bl >= t.rowbase[row] && bl < t.rowbase[row + 1]) pos = bl + t.rowdelta[row];
+    else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);      // (the even slot before an odd run start belongs to the row before)
   }
   best.pos = pos;
-  if (TRACK2) *second_out = m12[1];
+  if (second_out) *second_out = second;
   bl_out = bl;      // LDS index of the winner (NONE_U32: nothing within the radius): the in-tile accumulation reads the point from there
-  const float b = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
-  if (TRACK2 && bound_out) *bound_out = b;      // (shrunk) distance from q to the nearest face of the block: every point outside it is at least that far
-  bool tie = CILHIP_TIE_MODE != 0 && bl != NONE_U32 && (TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : tacc == 0u);
-  if (CILHIP_TIE_MODE == 2 && tie) {
-    // CONFIRMED over the block's own four runs, clamped: another record at exactly the winner's distance.  (What raised the suspicion may
-    // have been the winner read twice -- the unclamped reads of an EMPTY run land on the next row's points, which another run of the
-    // block reads as its own: rows of the grid's pad layers, sparse data -- or a tie at a distance that was beaten later.  A tie
-    // partner OUTSIDE the block cannot coexist with the proof below: it would lie beyond the block's faces.)  A few lanes of some waves.
-    tie = false;
-    const float be = __uint_as_float((uint32_t)(bk >> 32));
-    int ebr = o.ebrow;
-    asm volatile("" : "+v"(ebr));      // (the runs are looked up again HERE: nothing of them stays live across the search for this rare branch)
-    const int crow = ebr >> 16, ceb = ebr & 0xFFFF;
-    for (int k = 0; k < 4; ++k) {
-      const int krow = crow + (k >> 1) * t.RY + (k & 1);
-      const int keb = ceb + ((k >> 1) * t.RY + (k & 1)) * t.W1;
-      const uint32_t kdl = t.rowdelta[krow];
-      const uint32_t j1 = t.lcs[keb + 2] - kdl;
-      for (uint32_t j = t.lcs[keb] - kdl; j < j1; ++j) {
-        const float4 p = t.lpts[j];
-        const f32x2 pxy = {p.x, p.y};
-        const f32x2 d = qxy - pxy;
-        const f32x2 m = d * d;
-        const float dz = __fsub_rn(qz, p.w);
-        tie |= (__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz)) == be) & (j != bl);
-      }
-    }
-  }
-  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK && !tie;
+  const float bd = octant_bound(g, o.qx, o.qy, o.qz) - g.margin;
+  if (bound_out) *bound_out = bd;      // (shrunk) distance from q to the nearest face of the block: every point outside it is at least that far
+  return bd > 0.0f && e1 < bd * bd * KSHRINK && !tie;
 }
 
 // The full 3x3x3 block of cells around the query's cell, for the queries the octant block did not prove, in
@@ -1334,121 +1365,129 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
 // the wave executes each instruction once with all its lanes busy (the queued queries are packed densely over the
 // lanes, see phase 3b of the kernel).  Longer runs go through a per-lane list afterwards (most lanes: none or one).
 // Needs cx, cy, cz one cell inside the region on every side (the fast range).  Returns false if the block does not
-// prove the result (the query then goes to the clean-up pass).
-#ifndef CILHIP_B27_CAND
-#define CILHIP_B27_CAND 6
-#endif
-constexpr int B27_CAND = CILHIP_B27_CAND;
-template <bool TRACK2 = false>
-__device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& t, float qx, float qy, float qz,
+// prove the result (the query then goes to the clean-up pass).  Keys as in octant_search, six code bits.
+constexpr int B27_CAND = 6;
+constexpr uint32_t B27_KMASK = 0xFFFFFFC0u, B27_NOCODE = 63u, B27_OVER = 56u;   // 54 straight-line slots (run * 6 + slot), 56 / 57: the current overflow pair
+__device__ __forceinline__ bool block27_search(const GridDev& g, const TileLds& t, float qx_, float qy_, float qz_,
                                                int cx, int cy, int cz, float max_sq, NN& best, float* second_out = nullptr, float* bound_out = nullptr) {
-  float m12[2] = {INFINITY, INFINITY};      // (TRACK2: [1] = the second smallest squared distance evaluated, as in octant_search)
-  uint32_t tacc = 0xFFFFFFFFu;
-  const f32x2 qxy = {qx, qy};
-  unsigned long long bk = ((unsigned long long)__float_as_uint(max_sq) << 32);
+  const f32x2 qx = {qx_, qx_}, qy = {qy_, qy_}, qz = {qz_, qz_};
+  const uint32_t init = (__float_as_uint(max_sq) & B27_KMASK) | B27_NOCODE;
+  uint32_t b = init, s = init;
   const int row0 = (cz - t.loz) * t.RY + (cy - t.loy);       // region row of the own cell
   const int e0 = row0 * t.W1 + (cx - t.lox) - 1;             // table entry of the x-1 cell of that row
-  uint32_t sel = 0xFFFFu;
   uint32_t over = 0;            // bit r: run r is longer than B27_CAND
-  int e0v = e0;                 // (TRACK2: re-tied to each run's result below)
+  {
+    // two register sets: the records of run r + 1 fly while run r is evaluated and the table entries of run r + 2 are read
+    struct Run6 { f32x2 x0, y0, z0, x1, y1, z1, x2, y2, z2; } A, B;
+    auto issue6 = [&](uint32_t rj, Run6& q) {
+      const uint32_t addr = lds_pair_addr(t.lp_addr, rj);
+      lds_issue_pair(addr, q.x0, q.y0, q.z0);
+      lds_issue_pair(addr + 24u, q.x1, q.y1, q.z1);
+      lds_issue_pair(addr + 48u, q.x2, q.y2, q.z2);
+    };
+    auto eval6 = [&](uint32_t code, const Run6& q) {
+      eval_pair(code, q.x0, q.y0, q.z0, qx, qy, qz, B27_KMASK, b, s);
+      eval_pair(code + 2u, q.x1, q.y1, q.z1, qx, qy, qz, B27_KMASK, b, s);
+      eval_pair(code + 4u, q.x2, q.y2, q.z2, qx, qy, qz, B27_KMASK, b, s);
+    };
+    auto table = [&](int r) -> uint32_t {
+      const int off = (r / 3 - 1) * t.RY + (r % 3 - 1);
+      const uint32_t dl = t.rowdelta[row0 + off];
+      const uint32_t rj = (t.lcs[e0 + off * t.W1] - dl) & ~1u;      // (the even slot at or before the run's first)
+      over |= (t.lcs[e0 + off * t.W1 + 3] - dl > rj + (uint32_t)B27_CAND) ? (1u << r) : 0u;
+      return rj;
+    };
+    uint32_t rj0 = table(0), rj1 = table(1);
+    issue6(rj0, A);
 #pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const int off = (r / 3 - 1) * t.RY + (r % 3 - 1);
-    const uint32_t dl = t.rowdelta[row0 + off];
-    const uint32_t rj = t.lcs[e0v + off * t.W1] - dl, re = t.lcs[e0v + off * t.W1 + 3] - dl;
-    over |= (re > rj + (uint32_t)B27_CAND) ? (1u << r) : 0u;
-    constexpr int INFL = TRACK2 ? 2 : 3;        // loads in flight at a time: the block shares the kernel's 64 registers (TRACK2 keeps one more value)
-#pragma unroll
-    for (int h = 0; h < B27_CAND; h += INFL) {
-      float4 p[INFL];
-#pragma unroll
-      for (int c = 0; c < INFL; ++c) p[c] = t.lpts[rj + h + c];
-#pragma unroll
-      for (int c = 0; c < INFL; ++c) eval_candidate_sel<TRACK2>(p[c], qxy, qz, (uint32_t)(r * 8 + h + c), bk, sel, m12, tacc);
+    for (int r = 0; r < 9; ++r) {
+      Run6& cur = (r & 1) ? B : A;
+      Run6& nxt = (r & 1) ? A : B;
+      if (r < 8) issue6((r & 1) ? rj0 : rj1, nxt);
+      if (r < 8) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(cur.x0), "+v"(cur.y0), "+v"(cur.z0), "+v"(cur.x1), "+v"(cur.y1), "+v"(cur.z1), "+v"(cur.x2), "+v"(cur.y2), "+v"(cur.z2));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur.x0), "+v"(cur.y0), "+v"(cur.z0), "+v"(cur.x1), "+v"(cur.y1), "+v"(cur.z1), "+v"(cur.x2), "+v"(cur.y2), "+v"(cur.z2));
+      eval6((uint32_t)(r * 6), cur);
+      if (r < 7) { if (r & 1) rj1 = table(r + 2); else rj0 = table(r + 2); }
     }
-    if (TRACK2 && r < 8) {   // ties the next run's addresses to this run's result: keeps the scheduler from issuing all 54 reads first (see octant_search)
-      uint32_t hi = (uint32_t)(bk >> 32);
-      asm volatile("" : "+v"(e0v), "+v"(hi), "+v"(m12[1]));
-      bk = ((unsigned long long)hi << 32) | (uint32_t)bk;
-    }
-  }
-  uint32_t bl = NONE_U32;
-  int brow = row0;
-  if (sel != 0xFFFFu) {
-    const int r = (int)(sel >> 3);
-    const int dz = (r * 11) >> 5, dy = r - 3 * dz;            // r/3, r%3 for r in 0..8
-    const int off = (dz - 1) * t.RY + (dy - 1);
-    brow = row0 + off;
-    bl = t.lcs[e0v + off * t.W1] - t.rowdelta[brow] + (sel & 7u);
   }
   // the rest of the long runs: each lane walks its own list of them (most lanes: none or one), so the wave pays
   // the longest list, not one pass per run of the block
+  uint32_t bov = 0;
   while (over) {
     const int r = __ffs(over) - 1;
     over &= over - 1;
     const int dz = (r * 11) >> 5, dy = r - 3 * dz;
     const int off = (dz - 1) * t.RY + (dy - 1);
     const uint32_t dl = t.rowdelta[row0 + off];
-    const uint32_t re = t.lcs[e0v + off * t.W1 + 3] - dl;
-    const uint32_t before = bl;
-    for (uint32_t j = t.lcs[e0v + off * t.W1] - dl + (uint32_t)B27_CAND; j < re; j += 4) {
-      const float4 p0 = t.lpts[j], p1 = t.lpts[j + 1], p2 = t.lpts[j + 2], p3 = t.lpts[j + 3];
-      eval_candidate<TRACK2>(p0, qxy, qz, j, bk, bl, m12, true, tacc);
-      eval_candidate<TRACK2>(p1, qxy, qz, j + 1, bk, bl, m12, true, tacc);
-      eval_candidate<TRACK2>(p2, qxy, qz, j + 2, bk, bl, m12, true, tacc);
-      eval_candidate<TRACK2>(p3, qxy, qz, j + 3, bk, bl, m12, true, tacc);
+    const uint32_t re = t.lcs[e0 + off * t.W1 + 3] - dl;
+    for (uint32_t j = ((t.lcs[e0 + off * t.W1] - dl) & ~1u) + (uint32_t)B27_CAND; j < re; j += 2) {
+      f32x2 ax, ay, az;
+      lds_issue_pair(lds_pair_addr(t.lp_addr, j), ax, ay, az);
+      const uint32_t bprev = b;
+      lds_wait_pair<0>(ax, ay, az);
+      eval_pair(B27_OVER, ax, ay, az, qx, qy, qz, B27_KMASK, b, s);
+      bov = b != bprev ? j : bov;
     }
-    if (bl != before) brow = row0 + off;
   }
-  best.key = bk;
+  const uint32_t code = b & ~B27_KMASK;
+  uint32_t bl = NONE_U32;
+  int brow = row0;
+  float e1 = max_sq, second = __uint_as_float(s & B27_KMASK);
+  bool tie = false;
+  if (code != B27_NOCODE) {
+    if (code >= B27_OVER) bl = bov + (code - B27_OVER);
+    else {
+      const int r = (int)((code * 43u) >> 8);                   // code / 6 for code < 54
+      const int dz = (r * 11) >> 5, dy = r - 3 * dz;            // r/3, r%3 for r in 0..8
+      const int off = (dz - 1) * t.RY + (dy - 1);
+      brow = row0 + off;
+      bl = ((t.lcs[e0 + off * t.W1] - t.rowdelta[brow]) & ~1u) + (code - (uint32_t)r * 6u);
+    }
+    e1 = lds_d2(t.lp, bl, qx_, qy_, qz_);
+    if ((((b ^ s) & B27_KMASK) == 0u) | (((b ^ init) & B27_KMASK) == 0u)) {
+      // decided exactly over the block's own nine runs, clamped (see octant_search)
+      ExactScan x{INFINITY, INFINITY, NONE_U32, false};
+      int crow = (cz - t.loz) * t.RY + (cy - t.loy), ce0;
+      asm volatile("" : "+v"(crow));
+      ce0 = crow * t.W1 + (cx - t.lox) - 1;
+      for (int r = 0; r < 9; ++r) {
+        const int off = (r / 3 - 1) * t.RY + (r % 3 - 1);
+        const uint32_t dl = t.rowdelta[crow + off];
+        const uint32_t rj = t.lcs[ce0 + off * t.W1] - dl, re = t.lcs[ce0 + off * t.W1 + 3] - dl;
+        for (uint32_t j = rj; j < re; ++j) exact_take(x, lds_d2(t.lp, j, qx_, qy_, qz_), j);
+      }
+      bl = x.bl; e1 = x.e1; second = x.e2; tie = x.tie;
+    }
+    if (!(e1 < max_sq)) { second = fminf(second, e1); bl = NONE_U32; e1 = max_sq; tie = false; }
+  }
+  second = fminf(second, max_sq);
+  best.key = ((unsigned long long)__float_as_uint(e1) << 32);
   uint32_t pos = NONE_U32;
   if (bl != NONE_U32) {
-    if (bl < t.rowbase[brow + 1]) pos = bl + t.rowdelta[brow];   // an over-read winner may lie past the end of its run's row
+    if (bl >= t.rowbase[brow] && bl < t.rowbase[brow + 1]) pos = bl + t.rowdelta[brow];   // (an over-read / overflow / re-scanned winner: the binary search)
     else pos = lds_to_global(bl, t.rowbase, t.rowdelta, t.rows);
   }
   best.pos = pos;
   // does the 3x3x3 block prove exactness?  (no bound from a side where the block reaches the edge of the grid)
-  const float ux = qx - (g.ox + (float)cx * g.cell), uy = qy - (g.oy + (float)cy * g.cell), uz = qz - (g.oz + (float)cz * g.cell);
-  float b = INFINITY;
-  if (cx - 1 > 0) b = fminf(b, ux);
-  if (cx + 2 < g.nx) b = fminf(b, g.cell - ux);
-  if (cy - 1 > 0) b = fminf(b, uy);
-  if (cy + 2 < g.ny) b = fminf(b, g.cell - uy);
-  if (cz - 1 > 0) b = fminf(b, uz);
-  if (cz + 2 < g.nz) b = fminf(b, g.cell - uz);
-  if (TRACK2) *second_out = m12[1];
-  if (CILHIP_TIE_MODE != 0 && bl != NONE_U32 && (TRACK2 ? m12[1] == __uint_as_float((uint32_t)(bk >> 32)) : tacc == 0u)) {
-    // a tie, or the winner read twice: confirmed over the block's own nine runs (see octant_search); a confirmed tie goes to the clean-up pass
-    bool tie = CILHIP_TIE_MODE == 1;
-    const float be = __uint_as_float((uint32_t)(bk >> 32));
-    int crow = (cz - t.loz) * t.RY + (cy - t.loy), ce0;
-    asm volatile("" : "+v"(crow));
-    ce0 = crow * t.W1 + (cx - t.lox) - 1;
-    for (int r = 0; CILHIP_TIE_MODE == 2 && r < 9; ++r) {
-      const int off = (r / 3 - 1) * t.RY + (r % 3 - 1);
-      const uint32_t dl = t.rowdelta[crow + off];
-      const uint32_t rj = t.lcs[ce0 + off * t.W1] - dl, re = t.lcs[ce0 + off * t.W1 + 3] - dl;
-      for (uint32_t j = rj; j < re; ++j) {
-        const float4 p = t.lpts[j];
-        const f32x2 pxy = {p.x, p.y};
-        const f32x2 d = qxy - pxy;
-        const f32x2 m = d * d;
-        const float dz = __fsub_rn(qz, p.w);
-        tie |= (__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(dz, dz)) == be) & (j != bl);
-      }
-    }
-    if (tie) { if (TRACK2) *bound_out = 0.0f; return false; }
-  }
-  if (b == INFINITY) { if (TRACK2) *bound_out = INFINITY; return true; }
-  b = fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin;
-  if (TRACK2) *bound_out = b;
-  return b > 0.0f && __uint_as_float((uint32_t)(bk >> 32)) < b * b * KSHRINK;
+  const float ux = qx_ - (g.ox + (float)cx * g.cell), uy = qy_ - (g.oy + (float)cy * g.cell), uz = qz_ - (g.oz + (float)cz * g.cell);
+  float bd = INFINITY;
+  if (cx - 1 > 0) bd = fminf(bd, ux);
+  if (cx + 2 < g.nx) bd = fminf(bd, g.cell - ux);
+  if (cy - 1 > 0) bd = fminf(bd, uy);
+  if (cy + 2 < g.ny) bd = fminf(bd, g.cell - uy);
+  if (cz - 1 > 0) bd = fminf(bd, uz);
+  if (cz + 2 < g.nz) bd = fminf(bd, g.cell - uz);
+  if (second_out) *second_out = second;
+  if (tie) { if (bound_out) *bound_out = 0.0f; return false; }      // a confirmed tie goes to the clean-up pass
+  if (bd == INFINITY) { if (bound_out) *bound_out = INFINITY; return true; }
+  bd = fmaxf(bd, 0.0f) + g.cell - 2.0f * g.margin;
+  if (bound_out) *bound_out = bd;
+  return bd > 0.0f && e1 < bd * bd * KSHRINK;
 }
 
 #ifdef CILHIP_EXP_PHASE_CLOCKS
 __device__ unsigned long long g_phase_clk[8];
 #define PHASE_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_clk[k], now_ - tprev_); tprev_ = now_; } } while (0)
-void debug_dump_pipe_clocks();
 __device__ unsigned long long g_warm_clk[16];
 __device__ unsigned long long g_warm_stamp[4096][3];      // per block of the LAST k_warm launch: start / end (100 MHz wall clock)
 #define WARM_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_warm_clk[k], now_ - tprev_); atomicAdd(&g_warm_clk[8 + (k)], 1ull); tprev_ = now_; } } while (0)
@@ -1495,7 +1534,6 @@ static void debug_dump_warm_clocks() {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warm_stamp), st, sizeof st);
 }
 void debug_dump_phase_clocks() {
-  debug_dump_pipe_clocks();
   debug_dump_warm_clocks();
   unsigned long long h[8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof h) != hipSuccess) return;
@@ -1624,7 +1662,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   const uint32_t vb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per || vb >= ntiles) return;
 
-  __shared__ __attribute__((aligned(16))) unsigned char raw[(TILE_CAP + 8) * sizeof(float4)];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[TILE_BYTES];
   __shared__ uint32_t lcs[TILE_MAXE];
   __shared__ uint32_t rowbase[TILE_MAXROWS + 1];
   __shared__ uint32_t rowdelta[TILE_MAXROWS];
@@ -1632,7 +1670,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   __shared__ float tform_lds[19];             // the transform (and the motion clock), for phase 3b
   __shared__ uint32_t small_count;            // (LB) queries that leave this tile with a margin a warm-started iteration could not use, or with none
   __shared__ int geom_lds[8];                 // the region's geometry, for phase 3b (so that nothing it derives is kept live from here)
-  float4* lpts = reinterpret_cast<float4*>(raw);
+  float* const lp = reinterpret_cast<float*>(raw);      // staged pairs {x0, x1, y0, y1, z0, z1}
   if (threadIdx.x == 0) { queue_count = 0; small_count = 0; }      // (several barriers before their first use)
   if (threadIdx.x < 16) tform_lds[threadIdx.x] = st->T[threadIdx.x];
   if (LB && threadIdx.x == 16) { tform_lds[16] = st->motion_acc; tform_lds[17] = st->motion_eps; tform_lds[18] = st->motion_pred; }
@@ -1697,6 +1735,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         const uint32_t x = e - __umul24(r, (uint32_t)W1);
         const uint32_t zr = __umul24(r, inv_ry) >> 16;
         const uint32_t gi = gbase + __umul24(zr, slab) + __umul24(r - __umul24(zr, (uint32_t)RY), rowstride) + x;
+        if (CILHIP_EXP_HACK == 3) v[k] = gi; else
         v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_cs, e < (uint32_t)E ? gi * 4u : 0xFFFFFFFFu, 0, 0);
       }
     }
@@ -1807,20 +1846,23 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
           const uint32_t o = o0 + 16u * (uint32_t)half;
           const bool has = o < l;
           dst[m] = has ? f + o : NONE_U32;
+          if (CILHIP_EXP_HACK == 2) v[m] = u32x4{f, o, d, 0u}; else
           v[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_pts, has ? (f + o + d) * 16u : 0xFFFFFFFFu, 0, 0);
         }
 #pragma unroll
         for (int m = 0; m < STAGE_ROWS; ++m)
-          if (dst[m] != NONE_U32)   // LDS record = {x, y, bits(index), z}: index and (later) d2 then sit in one aligned register pair, the 64-bit key
-            lpts[dst[m]] = make_float4(__uint_as_float(v[m].x), __uint_as_float(v[m].y), __uint_as_float(v[m].w), __uint_as_float(v[m].z));
+          if (dst[m] != NONE_U32) {
+            float* const w = lp + lds_slot_x(dst[m]);
+            w[0] = __uint_as_float(v[m].x); w[2] = __uint_as_float(v[m].y); w[4] = __uint_as_float(v[m].z);
+          }
       }
     }
     // rare leftovers: rows longer than 32 points
     for (int r = grp; r < rows; r += GR) {
       const uint32_t f = rowbase[r], l = rowbase[r + 1] - f, d = rowdelta[r];
-      for (uint32_t o = o0 + 32u; o < l; o += 16) { const float4 q = g.pts[f + o + d]; lpts[f + o] = make_float4(q.x, q.y, q.w, q.z); }
+      for (uint32_t o = o0 + 32u; o < l; o += 16) { const float4 q = g.pts[f + o + d]; float* const w = lp + lds_slot_x(f + o); w[0] = q.x; w[2] = q.y; w[4] = q.z; }
     }
-    if (threadIdx.x < 8) lpts[P + threadIdx.x] = make_float4(1.0e30f, 1.0e30f, __uint_as_float(NONE_U32), 1.0e30f);  // pad: d2 = inf
+    if (threadIdx.x < 30) lp[lds_slot_x(P + threadIdx.x / 3u) + 2u * (threadIdx.x % 3u)] = 1.0e30f;  // 10 pad records (d2 = inf): the unclamped reads end at most 4 slots behind the even slot at or after P
   }
   __syncthreads();
   PHASE_CLK(2);
@@ -1828,7 +1870,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
   // 3a: the octant block, every lane, straight-line.  Queries it does not prove are QUEUED in LDS (16-bit slot ids in
   // the unused tail of the point buffer) instead of being finished in place: finishing them in place costs a wave the
   // whole 3x3x3 search even when one of its lanes needs it.
-  TileLds tl{lpts, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};
+  TileLds tl{lp, (uint32_t)reinterpret_cast<uintptr_t>(raw), (P + 1u) & ~1u, lcs, rowbase, rowdelta, lox, loy, loz, RY, W1, rows};      // (low 32 bits of a generic pointer into LDS = the LDS byte address)
   // (queue base and capacity are re-derived from the LDS row table where needed rather than kept in registers across
   //  the search: P = rowbase[rows], block-uniform)
   uint32_t mpos[TILE_QPT];   // per query: sorted-target position of the match (NONE: none / not settled here)
@@ -1851,13 +1893,13 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       if (fast && FEAT6) {
         // searched by the 3-D distance now; settled after BOTH of the lane's searches, with the winners' normals gathered
         // in one round trip (below)
-        (void)octant_search<true>(g, tl, oq[u], a.max_sq, best, bl, &f6_second[u]);
+        (void)octant_search(g, tl, oq[u], a.max_sq, best, bl, &f6_second[u]);
         f6_pos[u] = best.pos;
         mbl |= (bl & 0xFFFFu) << (16 * u);
         pending = true;
       } else if (fast) {
         float second = INFINITY, gapb = 0.0f;
-        unproven = !octant_search<LB || CILHIP_TIE_TRACK>(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb);
+        unproven = !octant_search(g, tl, oq[u], a.max_sq, best, bl, &second, &gapb);
         if (LB && ACC == IM_NONE) mkey = margin_key(best.pos != NONE_U32, second, gapb, mref);
         if (LB && ACC != IM_NONE) mq = margin_q15(best.pos != NONE_U32, second, gapb, mref, g.inv_cell);
         if (LB) {
@@ -1892,8 +1934,8 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       base = __shfl(base, leader, 64);
       const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[rows]);
-      uint16_t* const queue = reinterpret_cast<uint16_t*>(lpts + Pq + 8);
-      const uint32_t queue_cap = min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 8u);
+      uint16_t* const queue = reinterpret_cast<uint16_t*>(raw + ((Pq + 12u) >> 1) * 24u);
+      const uint32_t queue_cap = min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 6u);
       if (unproven) {
         if (slot < queue_cap) {
           queue[slot] = (uint16_t)(u * TILE_THREADS + threadIdx.x);
@@ -1919,7 +1961,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       if (((flags >> (20 + u)) & 1u) && f6_pos[u] != NONE_U32) {
         np[u] = target_features(a)[f6_pos[u]];
         if (a.feat.dst2 != nullptr) cp[u] = a.feat.dst2[f6_pos[u]];
-        rr[u] = lpts[(mbl >> (16 * u)) & 0xFFFFu];
+        { const float* const w = lp + lds_slot_x((mbl >> (16 * u)) & 0xFFFFu); rr[u] = make_float4(w[0], w[2], w[4], 0.f); }
       }
     }
 #pragma unroll
@@ -1932,7 +1974,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       if (pend && f6_pos[u] != NONE_U32) {
         Feat6 f;
         query_features(a, T, i, false, f);
-        const float d6 = d6_pinned(oq[u].qx, oq[u].qy, oq[u].qz, f, make_float4(rr[u].x, rr[u].y, rr[u].w, 0.f), np[u], cp[u]);
+        const float d6 = d6_pinned(oq[u].qx, oq[u].qy, oq[u].qz, f, make_float4(rr[u].x, rr[u].y, rr[u].z, 0.f), np[u], cp[u]);
         ambiguous = !(f6_second[u] > d6);           // another candidate's d6 (>= its d3 >= second) could be <= d6: not settled here
         if (d6 < a.max_sq) { dbest = d6; pos = f6_pos[u]; }
       }
@@ -1961,9 +2003,9 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       p4t[u] = n4t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       qt[u][0] = qt[u][1] = qt[u][2] = 0.0f;
       if (mpos[u] != NONE_U32) {
-        if (FusedZ<ACC>::needs_normal) n4t[u] = g.nrm[mpos[u]];                 // the one gather from HBM
-        const float4 r = lpts[(mbl >> (16 * u)) & 0xFFFFu];                     // LDS record {x, y, index, z}
-        p4t[u] = make_float4(r.x, r.y, r.w, 0.f);
+        if (FusedZ<ACC>::needs_normal) n4t[u] = CILHIP_EXP_HACK == 4 ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[mpos[u]];                 // the one gather from HBM
+        const float* const w = lp + lds_slot_x((mbl >> (16 * u)) & 0xFFFFu);    // the matched point out of the staged tile
+        p4t[u] = make_float4(w[0], w[2], w[4], 0.f);
         if (u == TILE_QPT - 1) {
           qt[u][0] = oq[u].qx; qt[u][1] = oq[u].qy; qt[u][2] = oq[u].qz;        // searched last: still in registers
         } else {
@@ -1993,19 +2035,19 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
     // sort-time cells): WHICH queries found room depends on the order the waves arrived in, so none of them is taken --
     // all unproven queries of the tile go to the clean-up pass (the set is then the same in every run).
     const uint32_t Pq0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[rows]);
-    if (nqueued > min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq0) * 8u)) {
+    if (nqueued > min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq0) * 6u)) {
 #pragma unroll
       for (int u = 0; u < TILE_QPT; ++u) if ((flags >> (16 + u)) & 1u) flags = (flags & ~(1u << (16 + u))) | (1u << (24 + u));
       nqueued = 0;
     }
   }
   if (ACC == IM_NONE && !FEAT6 && nqueued != 0) {
-    TileLds tq{lpts, lcs, rowbase, rowdelta, __builtin_amdgcn_readfirstlane(geom_lds[0]), __builtin_amdgcn_readfirstlane(geom_lds[1]),
+    const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[__builtin_amdgcn_readfirstlane(geom_lds[5])]);
+    TileLds tq{lp, (uint32_t)reinterpret_cast<uintptr_t>(raw), (Pq + 1u) & ~1u, lcs, rowbase, rowdelta, __builtin_amdgcn_readfirstlane(geom_lds[0]), __builtin_amdgcn_readfirstlane(geom_lds[1]),
                __builtin_amdgcn_readfirstlane(geom_lds[2]), __builtin_amdgcn_readfirstlane(geom_lds[3]),
                __builtin_amdgcn_readfirstlane(geom_lds[4]), __builtin_amdgcn_readfirstlane(geom_lds[5])};
-    const uint32_t Pq = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowbase[tq.rows]);
-    const uint16_t* const queue = reinterpret_cast<const uint16_t*>(lpts + Pq + 8);
-    const uint32_t nq = min(nqueued, min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 8u));
+    const uint16_t* const queue = reinterpret_cast<const uint16_t*>(raw + ((Pq + 12u) >> 1) * 24u);
+    const uint32_t nq = min(nqueued, min((uint32_t)TILE_QUERIES, ((uint32_t)TILE_CAP - Pq) * 6u));
     const int hx27 = tq.lox + tq.W1 - 2, hy27 = tq.loy + tq.RY - 1, hz27 = tq.loz + tq.rows / tq.RY - 1;   // last staged cell per axis
     if (threadIdx.x < nq) {   // wave-uniform except in the last wave
       float Tq[16];        // from LDS rather than kept live across the kernel
@@ -2021,7 +2063,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         // (the region holds the octant blocks of the tile's queries, not necessarily all of this query's 3x3x3 block)
         const bool in27 = (cx - 1 >= tq.lox) & (cx + 1 <= hx27) & (cy - 1 >= tq.loy) & (cy + 1 <= hy27) & (cz - 1 >= tq.loz) & (cz + 1 <= hz27);
         float second = INFINITY, gapb = 0.0f;
-        const bool proven = in27 && block27_search<LB || CILHIP_TIE_TRACK>(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best, &second, &gapb);
+        const bool proven = in27 && block27_search(g, tq, qx, qy, qz, cx, cy, cz, a.max_sq, best, &second, &gapb);
         a.nn_pos[i] = proven ? best.pos : DEFER_MARK;
         if (proven && a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
         if (LB && proven) a.nn_lb[i] = margin_key(best.pos != NONE_U32, second, gapb, MotionRef{tform_lds[16], tform_lds[17]});
@@ -2349,16 +2391,12 @@ static uint32_t deferred_blocks(uint32_t ntiles) {
 // block of the clean-up pass (a.partials = a.tile_partials + ntiles rows)
 int tiled_partial_rows(uint32_t ntiles) { return (int)(ntiles + deferred_blocks(ntiles)); }
 
-#include "tile_pipe.inc"
-
 template <int ACC>
 static void launch_search_tiled_m(const IterArgs& a, const uint2* tiles, const int* tile_box, uint32_t ntiles, hipStream_t s, hipEvent_t ev_stop) {
   const uint32_t nb = ((ntiles + 7u) >> 3) << 3;
-  if (ACC != IM_NONE && a.tile_pipeline == 2) hipLaunchKernelGGL((k_tile_pipe<ACC, true>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
-  else if (ACC != IM_NONE && a.tile_pipeline) hipLaunchKernelGGL((k_tile_pipe<ACC, false>), dim3(pipe_blocks(ntiles)), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   // (margin keys / match records for the warm-started iterations: the LB variants -- the search-only form when a.nn_lb is set, the
-  //  accumulating form when a.warm_rec is; the pipelined experiment kernels have no such variant)
-  else if (ACC == IM_NONE ? a.nn_lb != nullptr : a.warm_rec != nullptr)
+  //  accumulating form when a.warm_rec is)
+  if (ACC == IM_NONE ? a.nn_lb != nullptr : a.warm_rec != nullptr)
     hipLaunchKernelGGL((k_search_tiled<ACC, false, true>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   else hipLaunchKernelGGL((k_search_tiled<ACC>), dim3(nb), dim3(TILE_THREADS), 0, s, a, tiles, tile_box, ntiles);
   launch_ev((k_search_deferred<ACC>), dim3(deferred_blocks(ntiles)), dim3(ITER_THREADS), s, (hipEvent_t) nullptr, ev_stop, a, tiles, ntiles);

@@ -507,10 +507,6 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   "tile_accumulation" (default 1): where the first Gauss-Newton step of an iteration is accumulated when the tiled search runs
  *                        without post-filters: 0 = always in a separate streaming pass, 1 = inside the LDS tiles (one pass per
  *                        iteration) unless the device reports the source far from alignment, 2 = always inside the tiles.
- *   "tile_pipeline" (default 0): 1 = the one-pass tile iteration runs as ONE persistent, software-pipelined workgroup per CU
- *                        (k_tile_pipe: the next tile's points / cell table / row layout are in flight while the current tile is
- *                        searched) instead of one workgroup per tile; 2 = the same with the next tile's points staged by LDS-DMA
- *                        (no register holds them).  Same results bit for bit; kept for A/B (both measured slower: NOTEBOOK.md).
  *   "warm_start" (default 1): the warm-started iteration kernel (cilhip_get_last_warm_iterations): 0 = never, 1 = once the last
  *                        update moved no source point by more than "warm_enter_fraction" of a grid cell (and for as long as the
  *                        kernel settles most queries from their margins: it reports how many it had to search), 2 = from the

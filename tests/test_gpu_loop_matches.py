@@ -426,32 +426,3 @@ def test_warm_kernel_matches_index_for_index_10m(Context, orc):
     _report("warm_matches_10m.json", report)
 
 
-def test_pipelined_tile_kernel_is_bitwise_the_tile_kernel(Context, orc):
-    """option tile_pipeline = 1 / 2 (k_tile_pipe: one persistent, software-pipelined workgroup per CU; 2: LDS-DMA staging) against the default one
-    workgroup per tile: the same partial-sum row per tile, hence the same transform BIT FOR BIT, the same matches; all
-    accumulation variants; a start far enough for deferred queries and a region that exceeds its LDS buffer (duplicated points)."""
-    rng = np.random.default_rng(15)
-    d = syn.make_pair(1_500_000, perturb=0.6)
-    dense = np.ascontiguousarray(np.concatenate([d["dst"], d["dst"][:200_000] + np.float32(1e-4)]))       # a region of twice the density
-    dense_n = np.ascontiguousarray(np.concatenate([d["dst_n"], d["dst_n"][:200_000]]))
-    for D, N in ((d["dst"], d["dst_n"]), (dense, dense_n)):
-        for metric, w_p2p, w_p2pl in ((capi.METRIC_COMBINED, 0.0, 1.0), (capi.METRIC_COMBINED, 0.1, 1.0), (capi.METRIC_COMBINED, 1.0, 0.0), (capi.METRIC_POINT_TO_POINT, 0.0, 1.0)):
-            out = {}
-            for pipe in (0, 1, 2):
-                ctx = Context()
-                for k, v in (("warm_start", 1), ("tiled", 2), ("tile_accumulation", 2), ("tile_pipeline", pipe)):
-                    ctx.set_option(k, v)
-                ctx.set_target(D, N)
-                ctx.set_source(d["src"])
-                p = _params(ctx, metric, w_p2p, d["max_sq_dist"], 4)
-                p.w_p2pl = w_p2pl
-                res = ctx.icp_run(p)
-                assert ctx.last_matches_origin() == 1
-                idx, d2 = ctx.get_nn()
-                out[pipe] = (np.array(res.T[:], np.float32), int(res.last_ncorr), idx.copy(), d2.copy())
-                ctx.close()
-            for pipe in (1, 2):      # (2: the next tile's points staged by LDS-DMA)
-                assert np.array_equal(out[0][0].view(np.uint32), out[pipe][0].view(np.uint32)), (pipe, metric, w_p2p, np.abs(out[0][0] - out[pipe][0]).max())
-                assert out[0][1] == out[pipe][1] and np.array_equal(out[0][2], out[pipe][2]), pipe
-                m = out[0][2] != capi.NONE_IDX
-                assert np.array_equal(out[0][3][m].view(np.uint32), out[pipe][3][m].view(np.uint32)), pipe
