@@ -475,12 +475,31 @@ class SlabShardedRigidICP:
             out = self._estimate_once(params, T0, check_every)
         return out
 
+    def _swap_engine(self, T):
+        """replace the engine by one partitioned under ``T`` (collective: every rank calls it at the same iteration)"""
+        was_native = getattr(self.engine, "native", False)
+        tp = getattr(self.engine, "ties_pending", None)
+        self._ties_seen = getattr(self, "_ties_seen", False) or (tp is not None and tp())
+        self.engine = self.repartition(T)
+        if was_native and self.dist is not None and hasattr(self.engine, "enable_native_allreduce"):
+            self.engine.enable_native_allreduce(self.dist, self.group)      # (a new context: a new communicator; collective like the re-partition itself)
+        self.repartitions += 1
+
     def _estimate_once(self, params, T0=None, check_every=5):
         T_ck = np.eye(4, dtype=np.float32) if T0 is None else np.asarray(T0, np.float32).copy()
         total, base, since, begin_base = int(params.max_iter), 0, 0, 0   # base: iterations up to the last checked state; begin_base: up to the last begin()
+        # The slabs (and the guard's reference transform) of the engine at hand may have been cut under ANOTHER transform: an engine
+        # left by a re-partition of an earlier run -- the re-run after the tie order was loaded starts from T0 again.  The guard only
+        # looks at transforms AFTER an update, so a first search under T_ck against slabs cut under something else would be accepted
+        # unchecked: cut again under T_ck first (the C loop does the same: cilhip_multi_icp_run re-uploads when T_part != T0).
+        part = getattr(self.engine, "part", None)
+        Tp = None if part is None else np.asarray(part.T_part, np.float32).reshape(4, 4)
+        if Tp is not None and not np.array_equal(Tp, T_ck.reshape(4, 4)) and self.repartition is not None:
+            self._swap_engine(T_ck)
+            Tp = T_ck.reshape(4, 4)
         inner = ShardedRigidICP(self.engine, self.dist, self.group)
         self.engine.begin(params, T_ck, None)
-        fresh = True                      # the engine's partition was made under exactly T_ck
+        fresh = Tp is None or np.array_equal(Tp, T_ck.reshape(4, 4))      # the engine's partition was made under exactly T_ck
         every = max(check_every, 1)
         while base + since < total:
             if getattr(self.engine, "native", False):
@@ -517,14 +536,8 @@ class SlabShardedRigidICP:
                 if bad:
                     if self.repartition is None:
                         raise RuntimeError("a source point may have left its slab's halo and no repartition function was given")
-                    was_native = getattr(self.engine, "native", False)
-                    tp = getattr(self.engine, "ties_pending", None)
-                    self._ties_seen = getattr(self, "_ties_seen", False) or (tp is not None and tp())
-                    self.engine = self.repartition(T_ck)
-                    if was_native and self.dist is not None and hasattr(self.engine, "enable_native_allreduce"):
-                        self.engine.enable_native_allreduce(self.dist, self.group)      # (a new context: a new communicator; collective like the re-partition itself)
+                    self._swap_engine(T_ck)
                     inner = ShardedRigidICP(self.engine, self.dist, self.group)
-                    self.repartitions += 1
                     self.engine.begin(params, T_ck, None)
                     since, begin_base, fresh, every = 0, base, True, 1
         T, iters, delta, nc = self.engine.state()

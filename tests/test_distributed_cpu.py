@@ -99,6 +99,11 @@ def test_slab_sharded_icp_world2_matches_single_process(orc, metric):
         T2 = np.array(r2["T"], np.float64)
         assert np.linalg.norm(T2 - ref["T"]) <= 1e-5, np.linalg.norm(T2 - ref["T"])
         assert abs(r2["iters"] - ref["iterations"]) <= 1 and r2["ncorr"] == ref["last_ncorr"]
+        # estimate() once more from the identity on the same object: an engine left by a re-partition is cut again under the start
+        # (at least the one re-cut + the run's own), the result is the first run's
+        assert r2["rerun"]["same"], r2["rerun"]
+        if want_repart:
+            assert r2["rerun"]["recut"] >= 1 + r2["repartitions"], r2["rerun"]
 
 
 def test_loops_around_an_engine_that_runs_blocks_of_iterations_itself(orc):
