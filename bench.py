@@ -296,6 +296,7 @@ def bench_icp(a, torch, rank, world, local_rank):
     barrier()
     t0 = time.perf_counter()
     res = run(a.steps, True)
+    t_enqueue = time.perf_counter() - t0      # (host time of the calls that enqueue the timed region, incl. the final state read-back)
     barrier()
     dt = time.perf_counter() - t0
     n_src_total = n_src_rank
@@ -309,6 +310,13 @@ def bench_icp(a, torch, rank, world, local_rank):
         if strong:
             assert not ctx.slab_violation(), "a source point left its slab's halo: the partition had to be redone (not expected in the bench)"
     assert int(res.iterations) == a.steps, (res.iterations, a.steps)
+    sf = None
+    if sharded:
+        # every rank's own figures of the timed region (sampled iterations: kernel_timing_stride), gathered for the line
+        ftr = ctx.last_form_timing()
+        k_ms = sum(ms for ms, n in ftr.values()) / max(sum(n for ms, n in ftr.values()), 1)
+        ar_ms, ar_n = ctx.last_allreduce_timing() if native else (0.0, 0)
+        sf = scaling_fields(torch, dist, world, "cuda", k_ms, (ar_ms * 1e3 / ar_n) if ar_n else None, t_enqueue * 1e6 / max(a.steps, 1))
 
     out = None
     if rank == 0:
@@ -428,6 +436,8 @@ def bench_icp(a, torch, rank, world, local_rank):
             "tie_order": dict(ctx.tie_order_info(), tied_queries_resolved_in_timed_run=ctx.tie_rule_stats()[0], not_the_lowest_index=ctx.tie_rule_stats()[1]),
             "roofline": roof, "roofline_cold": out_cold if dom is not None else None,
         }
+        if sf is not None:
+            out.update(sf)
     if not sharded and not a.no_extras:
         extras = {}
         # cost of a whole estimate() the way the reference's example calls it (15 iterations), sort included: what a caller sees
@@ -709,6 +719,22 @@ def bench_ransac(a, torch):
     print(json.dumps(out))
 
 
+def scaling_fields(torch, dist, world, device, kernel_ms_per_step, allreduce_us, enqueue_us=None):
+    """What a scaling curve is read against, on the line of an N-rank run: how many ranks the collective spans, every rank's own kernel
+    time per iteration and the time its all-reduce takes on the stream (hipEvents around the collective).  One all-gather over the
+    launcher's process group (RCCL on the GPUs; the CPU test of the launch path plays it over gloo)."""
+    mine = torch.tensor([float(kernel_ms_per_step), float(allreduce_us) if allreduce_us is not None else -1.0,
+                         float(enqueue_us) if enqueue_us is not None else -1.0], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    rows = [p.cpu().tolist() for p in parts]
+    ar = [r[1] for r in rows if r[1] >= 0.0]
+    enq = [r[2] for r in rows if r[2] >= 0.0]
+    return {"rccl_ranks": world, "kernel_ms_per_step_per_rank": [r[0] for r in rows],
+            "allreduce_us_per_iteration": (max(ar) if ar else None), "allreduce_us_per_iteration_per_rank": ar or None,
+            "host_enqueue_us_per_iteration_per_rank": enq or None}
+
+
 def relaunch_under_torchrun(a):
     """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
     127.0.0.1).  Never prints a 1-GPU line for an N-GPU request: fewer visible devices than ranks is an error."""
@@ -739,8 +765,10 @@ def selftest_spawn(a, rank, world):
     dist.init_process_group("gloo")
     ones = torch.ones(1, dtype=torch.float64)
     dist.all_reduce(ones)
+    # the per-rank fields of an N-rank line, gathered exactly as bench_icp gathers them (stand-in figures: rank r reports r + 1)
+    sf = scaling_fields(torch, dist, world, "cpu", 0.1 * (rank + 1), 10.0 * (rank + 1), 1.0 * (rank + 1))
     if rank == 0:
-        print(json.dumps({"selftest_spawn": True, "n_gpus": world, "ranks_in_all_reduce": int(ones.item()), "requested": a.gpus}))
+        print(json.dumps(dict({"selftest_spawn": True, "n_gpus": world, "ranks_in_all_reduce": int(ones.item()), "requested": a.gpus}, **sf)))
     dist.destroy_process_group()
 
 

@@ -202,6 +202,9 @@ struct cilhip_ctx {
   int last_search_launches = 0;
   size_t run_nev = 0;             // sharded runs: hipEvents recorded by cilhip_icp_partial_sums since cilhip_icp_begin (3 per call)
   std::vector<hipEvent_t> ev, ev_acc;
+  std::vector<hipEvent_t> ev_ar;  // ranked loop: event pairs around the sampled all-reduces since cilhip_icp_begin (cilhip_get_last_allreduce_timing)
+  size_t run_nar = 0;             // ... how many of them are recorded
+  double last_allreduce_ms = 0.0; int last_allreduce_n = 0;
 
 };
 
@@ -342,6 +345,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_sums) (void)hipFree(c->d_sums);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   for (auto e : c->ev_acc) (void)hipEventDestroy(e);
+  for (auto e : c->ev_ar) (void)hipEventDestroy(e);
 
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -2293,7 +2297,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   launch_init_state(c->d_state, Ti, c->run_src_mean, c->stream, c->d_feedback, c->run_tag, c->src_center, c->src_half, c->d_tie_counters);     // (the epilogue publishes the loop state: see cilhip_icp_partial_sums)
   CK(c, hipGetLastError());
   c->run_active = true;
-  c->run_nev = 0;
+  c->run_nev = 0; c->run_nar = 0; c->last_allreduce_ms = 0.0; c->last_allreduce_n = 0;
   c->run_calls = 0;
   c->run_warm_on = false; c->run_judged = 0;
   c->rec_valid = false; c->lb_fresh = false;
@@ -2579,6 +2583,12 @@ int cilhip_icp_state(cilhip_ctx* c, cilhip_icp_result* out) {
   if (!c || !out) return CILHIP_ERR_INVALID;
   CK(c, hipSetDevice(c->device));
   const int rc = read_state(c, out);   // (synchronises the stream)
+  if (rc == CILHIP_OK && c->run_nar) {
+    double ms = 0.0;
+    for (size_t k = 0; k + 2 <= c->run_nar; k += 2) { float a = 0.f; CK(c, hipEventElapsedTime(&a, c->ev_ar[k], c->ev_ar[k + 1])); ms += a; }
+    c->last_allreduce_ms = ms; c->last_allreduce_n = (int)(c->run_nar / 2);
+    c->run_nar = 0;
+  }
   if (rc == CILHIP_OK && c->run_nev) {
     // kernel timing of a sharded run: search / accumulation time summed over the cilhip_icp_partial_sums calls since
     // cilhip_icp_begin (read with cilhip_get_last_timing / cilhip_get_last_timing2)
@@ -3291,6 +3301,13 @@ int cilhip_rank_comm_destroy(cilhip_ctx* c) {
   return CILHIP_OK;
 }
 
+int cilhip_get_last_allreduce_timing(cilhip_ctx* c, double* total_ms, int* timed) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if (total_ms) *total_ms = c->last_allreduce_ms;
+  if (timed) *timed = c->last_allreduce_n;
+  return CILHIP_OK;
+}
+
 int cilhip_icp_iterate_ranked(cilhip_ctx* c, int iterations) {
   if (!c || iterations < 0) return CILHIP_ERR_INVALID;
   if (!c->rank_comm) return fail(c, CILHIP_ERR_INVALID, "icp_iterate_ranked: cilhip_rank_comm_init first");
@@ -3300,10 +3317,20 @@ int cilhip_icp_iterate_ranked(cilhip_ctx* c, int iterations) {
   for (int k = 0; k < iterations; ++k) {
     // this rank's RANK_ROWS rows of partial sums -> summed over the ranks, row by row -> folded by the epilogue (the same values on
     // every rank: identical transforms and decisions everywhere)
+    // (with kernel timing on, the iterations that carry kernel events also time their collective: what the all-reduce costs per
+    //  iteration ON THE STREAM -- launch of RCCL's kernel, the exchange over xGMI, the wait for the slowest rank -- is the figure a
+    //  scaling curve has to be read against; cilhip_get_last_allreduce_timing)
+    const bool time_ar = c->kernel_timing && c->run_nar + 2 <= 2 * 4096 &&
+                         (c->timing_stride <= 1 || c->run_calls < 3 || c->run_calls % c->timing_stride == 0);
     const int rc = partial_sums_core(c, nullptr, c->d_rank_sums);
     if (rc) return rc;
+    if (time_ar) {
+      while (c->ev_ar.size() < c->run_nar + 2) { hipEvent_t e; CK(c, hipEventCreate(&e)); c->ev_ar.push_back(e); }
+      CK(c, hipEventRecord(c->ev_ar[c->run_nar], c->stream));
+    }
     if (g_rank_rccl.AllReduce(c->d_rank_sums, c->d_rank_sums, (size_t)RANK_ROWS * SUMS_MAX, RCCL_DOUBLE, RCCL_SUM, c->rank_comm, c->stream) != 0)
       return fail(c, CILHIP_ERR_HIP, "ncclAllReduce failed");
+    if (time_ar) { CK(c, hipEventRecord(c->ev_ar[c->run_nar + 1], c->stream)); c->run_nar += 2; }
     SolveArgs sa = make_solve_args(c, &c->run_prm, im, c->run_src_mean);
     sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;
     sa.partials = c->d_rank_sums; sa.nblocks = RANK_ROWS; sa.reduced = nullptr;

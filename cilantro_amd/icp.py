@@ -261,6 +261,12 @@ class Context:
         """`iterations` x {partial sums -> ncclAllReduce of the 48 f64 on the context's stream -> epilogue}, between icp_begin and icp_state"""
         self._ck(self._L.cilhip_icp_iterate_ranked(self._h, int(iterations)))
 
+    def last_allreduce_timing(self):
+        """-> (ms summed over the timed iterations, how many were timed) of the ranked loop's ncclAllReduce since icp_begin (after icp_state)"""
+        a = C.c_double(0); n = C.c_int(0)
+        self._ck(self._L.cilhip_get_last_allreduce_timing(self._h, C.byref(a), C.byref(n)))
+        return a.value, n.value
+
     def set_shard_info(self, target_index_offset, dst_mean=None, src_mean=None):
         dm = np.ascontiguousarray(dst_mean, np.float32) if dst_mean is not None else None
         sm = np.ascontiguousarray(src_mean, np.float32) if src_mean is not None else None

@@ -464,6 +464,11 @@ int cilhip_rank_comm_prepare(cilhip_ctx* ctx);
 int cilhip_rank_comm_init(cilhip_ctx* ctx, const unsigned char id[128], int nranks, int rank);
 int cilhip_rank_comm_destroy(cilhip_ctx* ctx);
 int cilhip_icp_iterate_ranked(cilhip_ctx* ctx, int iterations);
+/* With kernel timing on (cilhip_enable_kernel_timing; sampled by option "kernel_timing_stride"): the time of the ranked loop's
+ * ncclAllReduce ON THE STREAM -- hipEvents around the collective: launch of RCCL's kernel, the exchange over xGMI, the wait for the
+ * slowest rank -- summed over the `timed` iterations since cilhip_icp_begin; valid after cilhip_icp_state.  (No reference
+ * counterpart: what bench.py --gpus N reports as allreduce_us_per_iteration.) */
+int cilhip_get_last_allreduce_timing(cilhip_ctx* ctx, double* total_ms, int* timed);
 
 /* How the iterations of the last cilhip_icp_run were executed: as ONE pass (search with the accumulation inside the LDS
  * tiles) or as TWO (search with its in-tile 3x3x3 second pass, then the streaming accumulation).  Large clouds choose per

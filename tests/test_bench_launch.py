@@ -40,3 +40,8 @@ def test_self_launch_spawns_one_rank_per_requested_gpu():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     r = json.loads(line)
     assert r["selftest_spawn"] and r["n_gpus"] == 2 and r["ranks_in_all_reduce"] == 2
+    # the per-rank fields an N-rank line carries, gathered over the group by the function bench_icp uses
+    assert r["rccl_ranks"] == 2
+    assert r["kernel_ms_per_step_per_rank"] == pytest.approx([0.1, 0.2])
+    assert r["allreduce_us_per_iteration"] == pytest.approx(20.0) and r["allreduce_us_per_iteration_per_rank"] == pytest.approx([10.0, 20.0])
+    assert r["host_enqueue_us_per_iteration_per_rank"] == pytest.approx([1.0, 2.0])
