@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--metric", choices=["p2plane", "p2p"], default=None, help="(compatibility) c3 sizes with another metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-start / converging-trajectory measurements")
+    ap.add_argument("--no-other-configs", action="store_true", help="default line only: skip the c2 / kmeans / ransac / c4_1gpu figures it carries as `other_configs`")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="source points of the CPU baseline sample")
     return ap.parse_args()
 
@@ -175,7 +176,7 @@ def copy_bandwidth(torch):
         return None
 
 
-def bench_icp(a, torch, rank, world, local_rank):
+def bench_icp(a, torch, rank, world, local_rank, emit=True):
     from cilantro_amd import capi, distributed
     from cilantro_amd import synthetic as syn
     from cilantro_amd.icp import Context
@@ -296,7 +297,6 @@ def bench_icp(a, torch, rank, world, local_rank):
     barrier()
     t0 = time.perf_counter()
     res = run(a.steps, True)
-    t_enqueue = time.perf_counter() - t0      # (host time of the calls that enqueue the timed region, incl. the final state read-back)
     barrier()
     dt = time.perf_counter() - t0
     n_src_total = n_src_rank
@@ -316,7 +316,7 @@ def bench_icp(a, torch, rank, world, local_rank):
         ftr = ctx.last_form_timing()
         k_ms = sum(ms for ms, n in ftr.values()) / max(sum(n for ms, n in ftr.values()), 1)
         ar_ms, ar_n = ctx.last_allreduce_timing() if native else (0.0, 0)
-        sf = scaling_fields(torch, dist, world, "cuda", k_ms, (ar_ms * 1e3 / ar_n) if ar_n else None, t_enqueue * 1e6 / max(a.steps, 1))
+        sf = scaling_fields(torch, dist, world, "cuda", k_ms, (ar_ms * 1e3 / ar_n) if ar_n else None, ctx.last_host_enqueue_time() if native else None)
 
     out = None
     if rank == 0:
@@ -575,13 +575,51 @@ def bench_icp(a, torch, rank, world, local_rank):
             out["cpu_baseline"] = cpu_baseline_icp(d, metric, w_p2p, w_p2pl, min(a.cpu_sample, ns), T0)
         except Exception as e:  # the baseline is a report, never the product path
             out["cpu_baseline"] = {"error": repr(e)}
-    if rank == 0:
+    if rank == 0 and emit and not sharded and a.config == "c3" and not a.no_extras and not a.no_other_configs and a.n is None:
+        out["other_configs"] = other_configs(a, torch, local_rank)
+    if rank == 0 and emit:
         print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
+    if not emit:
+        ctx.close()      # (a figure for another line: its context and clouds go before the next configuration is set up)
+    return out
 
 
-def bench_kmeans(a, torch):
+def other_configs(a, torch, local_rank, budget_s=150.0):
+    """The default line is the one the driver times; the other BASELINE configurations ride on it as `other_configs` -- ms_per_step and
+    roofline.frac each, measured by the very functions their own `--config` lines come from (`value`, `config`, `roofline` of the line
+    itself stay C3's).  A wall-clock budget keeps the default run inside a few minutes: what does not fit is named, not dropped silently."""
+    import copy
+    import gc
+
+    res, t_begin = {}, time.perf_counter()
+    for cfg in ("c2", "kmeans", "ransac", "c4_1gpu"):
+        spent = time.perf_counter() - t_begin
+        if spent > budget_s:
+            res[cfg] = {"skipped": f"wall-clock budget of {budget_s:.0f} s spent ({spent:.0f} s)"}
+            continue
+        b = copy.copy(a)
+        b.config, b.no_extras, b.no_cpu_baseline, b.n, b.metric = cfg, True, True, None, None
+        t0 = time.perf_counter()
+        try:
+            if cfg == "kmeans":
+                o = bench_kmeans(b, torch, emit=False)
+            elif cfg == "ransac":
+                o = bench_ransac(b, torch, emit=False)
+            else:
+                o = bench_icp(b, torch, 0, 1, local_rank, emit=False)
+            res[cfg] = {"workload": o["config"]["workload"], "metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_kernel_ms")},
+                        "wall_s": time.perf_counter() - t0}
+        except Exception as e:      # (a report's refinement, never a reason to lose the line)
+            res[cfg] = {"error": repr(e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
+
+
+def bench_kmeans(a, torch, emit=True):
     """BASELINE configs[4], first half: KMeans3f k = 1024 on 50M points, explicit initial centroids (the first k points).
     Step = one Lloyd iteration (brute-force assignment + centroid update, one pass over the points)."""
     from cilantro_amd import synthetic as syn
@@ -647,10 +685,12 @@ def bench_kmeans(a, torch):
                                              f"OpenMP parallel for over the points as the reference's :100, {cores} threads), median of 3 after a warm-up"}
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
-def bench_ransac(a, torch):
+def bench_ransac(a, torch, emit=True):
     """BASELINE configs[4], second half: plane RANSAC inlier counting on 50M points.  Step = one scoring pass of 128
     hypotheses over all points (the estimator scores its hypotheses 128 at a time)."""
     from cilantro_amd.model_estimation import PlaneRANSACEstimator3f
@@ -716,7 +756,9 @@ def bench_ransac(a, torch):
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     assert int(cnt[0]) == int(cnt1[0])
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 def scaling_fields(torch, dist, world, device, kernel_ms_per_step, allreduce_us, enqueue_us=None):

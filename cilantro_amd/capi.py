@@ -19,14 +19,14 @@ NONE_IDX = 0xFFFFFFFF
 # every symbol include/cilantro_hip/c_api.h declares (tests/test_capi_symbols.py checks the header against this)
 SYMBOLS = [
     "cilhip_create", "cilhip_destroy", "cilhip_last_error", "cilhip_set_stream", "cilhip_synchronize",
-    "cilhip_set_target", "cilhip_set_source", "cilhip_set_source_normals", "cilhip_get_means", "cilhip_set_color_features", "cilhip_find_correspondences",
+    "cilhip_set_target", "cilhip_set_source", "cilhip_set_source_normals", "cilhip_get_means", "cilhip_set_color_features", "cilhip_share_target", "cilhip_find_correspondences",
     "cilhip_get_nn", "cilhip_get_correspondences", "cilhip_estimate_point_to_point",
     "cilhip_estimate_combined", "cilhip_estimate_affine", "cilhip_icp_default_params", "cilhip_icp_run", "cilhip_icp_begin",
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
-    "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing", "cilhip_prepare_source", "cilhip_get_last_run_forms", "cilhip_get_last_warm_iterations", "cilhip_get_last_matches_origin", "cilhip_get_matches_transform", "cilhip_get_last_form_timing", "cilhip_get_last_iteration_timing", "cilhip_get_last_run_trace", "cilhip_estimate_combined_two_sets", "cilhip_icp_run_two_sets", "cilhip_kmeans_set_pruning", "cilhip_get_tie_count", "cilhip_get_tie_rule_stats", "cilhip_get_tie_order_info", "cilhip_build_tie_order", "cilhip_tie_order_create", "cilhip_tie_order_destroy", "cilhip_load_tie_order", "cilhip_multi_create", "cilhip_multi_destroy", "cilhip_multi_last_error", "cilhip_multi_context", "cilhip_multi_set_clouds", "cilhip_multi_icp_run", "cilhip_multi_repartitions", "cilhip_multi_last_host_time", "cilhip_multi_set_slab_slack", "cilhip_multi_shard_sizes", "cilhip_rank_comm_unique_id", "cilhip_rank_comm_prepare", "cilhip_rank_comm_init", "cilhip_rank_comm_destroy", "cilhip_icp_iterate_ranked", "cilhip_get_last_allreduce_timing", "cilhip_set_slab_guard", "cilhip_get_slab_violation", "cilhip_get_slab_violation_state",
-    "cilhip_set_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
+    "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing", "cilhip_prepare_source", "cilhip_get_last_run_forms", "cilhip_get_last_warm_iterations", "cilhip_get_last_matches_origin", "cilhip_get_matches_transform", "cilhip_get_last_form_timing", "cilhip_get_last_iteration_timing", "cilhip_get_last_run_trace", "cilhip_estimate_combined_two_sets", "cilhip_icp_run_two_sets", "cilhip_kmeans_set_pruning", "cilhip_get_tie_count", "cilhip_get_tie_rule_stats", "cilhip_get_tie_order_info", "cilhip_build_tie_order", "cilhip_tie_order_create", "cilhip_tie_order_destroy", "cilhip_load_tie_order", "cilhip_multi_create", "cilhip_multi_destroy", "cilhip_multi_last_error", "cilhip_multi_context", "cilhip_multi_set_clouds", "cilhip_multi_icp_run", "cilhip_multi_repartitions", "cilhip_multi_last_host_time", "cilhip_multi_set_slab_slack", "cilhip_multi_shard_sizes", "cilhip_rank_comm_unique_id", "cilhip_rank_comm_prepare", "cilhip_rank_comm_init", "cilhip_rank_comm_destroy", "cilhip_icp_iterate_ranked", "cilhip_get_last_allreduce_timing", "cilhip_get_last_host_enqueue_time", "cilhip_set_slab_guard", "cilhip_get_slab_violation", "cilhip_get_slab_violation_state",
+    "cilhip_set_option", "cilhip_option_count", "cilhip_option_info", "cilhip_set_option_id", "cilhip_get_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
     "cilhip_icp_sums_from_keys", "cilhip_icp_order_keys", "cilhip_icp_sums_from_ordered_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign", "cilhip_kmeans3f_ex", "cilhip_kmeans3f_assign_ex",
-    "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f", "cilhip_transform_ransac3f", "cilhip_transform_score3f", "cilhip_transform_fit3f", "cilhip_knn3f", "cilhip_normals_knn3f", "cilhip_normals_radius3f", "cilhip_radius_search3f",
+    "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f", "cilhip_transform_ransac3f", "cilhip_transform_score3f", "cilhip_transform_fit3f", "cilhip_knn3f", "cilhip_knn_set_tie_rule", "cilhip_normals_knn3f", "cilhip_normals_radius3f", "cilhip_radius_search3f",
 ]
 
 
@@ -51,6 +51,11 @@ class GridInfo(C.Structure):
         ("origin", C.c_float * 3), ("n_cells", C.c_size_t), ("avg_occupancy", C.c_double),
         ("build_ms", C.c_double),
     ]
+
+
+class OptionInfo(C.Structure):
+    _fields_ = [("id", C.c_int), ("key", C.c_char_p), ("default_value", C.c_double), ("min_value", C.c_double), ("max_value", C.c_double),
+                ("doc", C.c_char_p)]
 
 
 class TieOrderInfo(C.Structure):
@@ -124,6 +129,12 @@ def load():
     L.cilhip_get_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.cilhip_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.cilhip_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.cilhip_share_target.argtypes = [vp, vp]
+    L.cilhip_option_count.argtypes = []
+    L.cilhip_option_info.argtypes = [C.c_int]
+    L.cilhip_option_info.restype = C.POINTER(OptionInfo)
+    L.cilhip_set_option_id.argtypes = [vp, C.c_int, C.c_double]
+    L.cilhip_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     L.cilhip_set_shard_info.argtypes = [vp, C.c_uint64, f32p, f32p]
     L.cilhip_icp_partial_keys.argtypes = [vp, vp]
     L.cilhip_debug_counters.argtypes = [vp, vp]
@@ -181,13 +192,14 @@ def load():
     L.cilhip_rank_comm_destroy.argtypes = [vp]
     L.cilhip_icp_iterate_ranked.argtypes = [vp, C.c_int]
     L.cilhip_get_last_allreduce_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.cilhip_get_last_host_enqueue_time.argtypes = [vp, C.POINTER(C.c_double)]
     L.cilhip_get_last_run_trace.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.cilhip_set_slab_guard.argtypes = [vp, C.c_int, C.c_float, f32p, f32p, f32p]
     L.cilhip_get_slab_violation.argtypes = [vp, C.POINTER(C.c_int)]
     L.cilhip_get_slab_violation_state.argtypes = [vp, C.POINTER(C.c_int), vp]
     for name in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if the library does not export it
-        if name not in ("cilhip_destroy", "cilhip_last_error", "cilhip_icp_default_params"):
+        if name not in ("cilhip_destroy", "cilhip_last_error", "cilhip_icp_default_params", "cilhip_option_info"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -197,3 +209,13 @@ class CilhipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"cilhip error {code}: {msg}")
         self.code = code
+
+
+def options():
+    """the option table of the library (cilhip_option_info): [{id, key, default, min, max, doc}]; needs no device"""
+    L = load()
+    out = []
+    for i in range(L.cilhip_option_count()):
+        o = L.cilhip_option_info(i).contents
+        out.append({"id": o.id, "key": o.key.decode(), "default": o.default_value, "min": o.min_value, "max": o.max_value, "doc": o.doc.decode()})
+    return out

@@ -21,8 +21,12 @@
 
 using namespace cilhip;
 
+// Device allocations of a target that SEVERAL contexts use (cilhip_share_target): freed when the last of them lets go.
+struct TargetShare { int refs = 0; std::vector<void*> allocs; };
+
 struct cilhip_ctx {
   int device = 0;
+  TargetShare* tshare = nullptr;  // non-null: some of this context's target pointers belong to a share (target_ptr_free / release_target_share)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
@@ -205,6 +209,7 @@ struct cilhip_ctx {
   std::vector<hipEvent_t> ev_ar;  // ranked loop: event pairs around the sampled all-reduces since cilhip_icp_begin (cilhip_get_last_allreduce_timing)
   size_t run_nar = 0;             // ... how many of them are recorded
   double last_allreduce_ms = 0.0; int last_allreduce_n = 0;
+  double run_enqueue_us = 0.0; int run_enqueue_iters = 0;      // ranked loop: host time of its enqueue calls (the paced waits for the device's feedback word excluded)
 
 };
 
@@ -236,9 +241,35 @@ static void drop_rev_tie_tables(cilhip_ctx* c) {  // (they describe ONE source u
   c->rev_tie_nodes_cap = 0; c->rev_tie_valid = false; c->rev_tie_aware = false;
   std::vector<float>().swap(c->h_src);
 }
+// a target-side allocation of this context: freed here unless it belongs to a share (then by whoever lets go of the share last)
+static void target_ptr_free(cilhip_ctx* c, const void* p) {
+  if (!p) return;
+  if (c->tshare && std::find(c->tshare->allocs.begin(), c->tshare->allocs.end(), p) != c->tshare->allocs.end()) return;
+  (void)hipFree(const_cast<void*>(p));
+}
+static void release_target_share(cilhip_ctx* c) {
+  if (!c->tshare) return;
+  if (--c->tshare->refs == 0) {
+    for (void* p : c->tshare->allocs) (void)hipFree(p);
+    delete c->tshare;
+  }
+  c->tshare = nullptr;
+}
 static void drop_tie_tables(cilhip_ctx* c) {      // (they describe ONE target)
-  if (c->d_tie_leaf_slot) { (void)hipFree(c->d_tie_leaf_slot); c->d_tie_leaf_slot = nullptr; }
-  if (c->d_tie_nodes) { (void)hipFree(c->d_tie_nodes); c->d_tie_nodes = nullptr; }
+  target_ptr_free(c, c->d_tie_leaf_slot); c->d_tie_leaf_slot = nullptr;
+  target_ptr_free(c, c->d_tie_nodes); c->d_tie_nodes = nullptr;
+}
+// everything a context holds of its target (its own allocations are freed, shared ones only let go of)
+static void release_target(cilhip_ctx* c) {
+  if (c->has_target) {
+    target_ptr_free(c, c->grid.pts); target_ptr_free(c, c->grid.nrm); target_ptr_free(c, c->grid.pn); target_ptr_free(c, c->grid.cell_start);
+    c->grid.pts = nullptr; c->grid.nrm = nullptr; c->grid.pn = nullptr; c->grid.cell_start = nullptr;
+    c->has_target = false;
+  }
+  target_ptr_free(c, c->d_inv_perm); c->d_inv_perm = nullptr;
+  target_ptr_free(c, c->d_safe2); c->d_safe2 = nullptr;
+  drop_tie_tables(c);
+  release_target_share(c);
 }
 
 extern "C" {
@@ -319,10 +350,7 @@ void cilhip_destroy(cilhip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)cilhip_rank_comm_destroy(c);
   free_source(c);
-  if (c->has_target) free_grid(c->grid);
-  if (c->d_safe2) (void)hipFree(c->d_safe2);
-  if (c->d_tie_leaf_slot) (void)hipFree(c->d_tie_leaf_slot);
-  if (c->d_tie_nodes) (void)hipFree(c->d_tie_nodes);
+  release_target(c);
   if (c->d_ticket) (void)hipFree(c->d_ticket);
   if (c->d_dst_rgb) (void)hipFree(c->d_dst_rgb);
   if (c->d_dst_rgb_sorted) (void)hipFree(c->d_dst_rgb_sorted);
@@ -330,7 +358,6 @@ void cilhip_destroy(cilhip_ctx* c) {
   if (c->d_state_id) (void)hipFree(c->d_state_id);
   free_pairs(c->pairs);
   if (c->d_partials) (void)hipFree(c->d_partials);
-  if (c->d_inv_perm) (void)hipFree(c->d_inv_perm);
   if (c->d_sel_state) (void)hipFree(c->d_sel_state);
   if (c->d_winner) (void)hipFree(c->d_winner);
   if (c->d_count) (void)hipFree(c->d_count);
@@ -368,8 +395,66 @@ int cilhip_synchronize(cilhip_ctx* c) {
   return CILHIP_OK;
 }
 
+// ---- the options of a context, as a table a C caller can enumerate and check at compile time (enum cilhip_option in c_api.h):
+// id, key, default, admissible range, one line of documentation, how to read the current value back.  cilhip_set_option() below
+// validates and applies; the table is what tests/test_capi_symbols.py walks (every option documented, accepted with its default,
+// readable, exercised by a test).  Long-form documentation: c_api.h above cilhip_set_option.
+namespace {
+struct OptionRow { cilhip_option_info_t info; double (*get)(const cilhip_ctx*); };
+#define OPT(ID, KEY, DEF, LO, HI, DOC, EXPR) {{ID, KEY, DEF, LO, HI, DOC}, [](const cilhip_ctx* c) -> double { return (double)(EXPR); }}
+const OptionRow g_options[] = {
+  OPT(CILHIP_OPT_FUSED, "fused", 0, 0, 1, "1 = one per-lane search+accumulate kernel per iteration; 0 = search kernel + streaming accumulation (or the LDS tiles)", c->fused),
+  OPT(CILHIP_OPT_INLIER_FRACTION, "inlier_fraction", 1, 0, 1, "CorrespondenceSearchKDTree::setInlierFraction: keep that fraction of the correspondences, nearest first", c->inlier_fraction),
+  OPT(CILHIP_OPT_ONE_TO_ONE, "one_to_one", 0, 0, 1, "setOneToOne: a target point keeps only its nearest source point", c->one_to_one),
+  OPT(CILHIP_OPT_TILED, "tiled", 1, 0, 2, "LDS-tiled search: 0 = never, 1 = when the cloud fills the chip with full tiles, 2 = always", c->tiled),
+  OPT(CILHIP_OPT_WARM_START, "warm_start", 1, 0, 2, "warm-started iterations (margin proof): 0 = never, 1 = when the loop is near alignment, 2 = from the second iteration on", c->warm_start),
+  OPT(CILHIP_OPT_WARM_FORECAST, "warm_forecast", 1, 0, 1, "the cold kernels' forecast gates the warm-started form (0: the step alone; tests)", c->warm_forecast),
+  OPT(CILHIP_OPT_FUSED_EPILOGUE, "fused_epilogue", 0, 0, 1, "stage-1 reduction + epilogue as one launch behind a device-scope fence (bitwise equal, measured slower; A/B)", c->fused_epilogue),
+  OPT(CILHIP_OPT_GROUP_SEARCH, "group_search", -1, -1, 64, "lanes per query of the cooperative global-memory search: -1 = the loop decides, 0 = never, 4 / 8 / 16 / 32 / 64", c->group_lanes),
+  OPT(CILHIP_OPT_TIE_RULE, "tie_rule", 2, 0, 2, "exactly equidistant nearest points: 0 = lowest index, 1 = the reference's kd-tree order (tables up front), 2 = the same, tables when a tie is first met", c->tie_rule),
+  OPT(CILHIP_OPT_WARM_EXTRA_FRACTION, "warm_extra_fraction", 0.0625, 1e-9, 1, "room (fraction of a cell) of the ball a warm-started iteration searches a listed query in", c->warm_extra),
+  OPT(CILHIP_OPT_PAIR_RECORDS, "pair_records", 1, 0, 1, "streaming accumulation gathers a match's point and normal from one 32-byte record (A/B)", c->pair_records),
+  OPT(CILHIP_OPT_TILE_RECORDS, "tile_records", 1, 0, 1, "the accumulating tile kernel writes the warm-started form's match records itself (A/B)", c->tile_records),
+  OPT(CILHIP_OPT_WARM_ENTER_FRACTION, "warm_enter_fraction", 0.15, 1e-9, 1e9, "the warm-started form is entered once an update moves no source point by more than this fraction of a cell", c->warm_enter),
+  OPT(CILHIP_OPT_POINT_WEIGHT_EVALUATOR, "point_weight_evaluator", 0, 0, 2, "combined metric, point-to-point terms: 0 = UnityWeightEvaluator, 1 = DistanceEvaluator, 2 = RBFKernelWeightEvaluator", c->cw_point_kind),
+  OPT(CILHIP_OPT_PLANE_WEIGHT_EVALUATOR, "plane_weight_evaluator", 0, 0, 2, "combined metric, point-to-plane terms: 0 = Unity, 1 = Identity (distance), 2 = RBF kernel", c->cw_plane_kind),
+  OPT(CILHIP_OPT_POINT_WEIGHT_SIGMA, "point_weight_sigma", 1, 1e-30, 1e30, "sigma of the RBF evaluator of the point-to-point terms", c->cw_point_sigma),
+  OPT(CILHIP_OPT_PLANE_WEIGHT_SIGMA, "plane_weight_sigma", 1, 1e-30, 1e30, "sigma of the RBF evaluator of the point-to-plane terms", c->cw_plane_sigma),
+  OPT(CILHIP_OPT_TILE_ACCUMULATION, "tile_accumulation", 1, 0, 2, "first Gauss-Newton step accumulated inside the LDS tiles: 0 = never, 1 = unless the source is far from alignment, 2 = always", (c->tile_acc ? (c->tile_acc_adaptive ? 1 : 2) : 0)),
+  OPT(CILHIP_OPT_SEARCH_DIRECTION, "search_direction", 0, 0, 2, "CorrespondenceSearchDirection: 0 = SECOND_TO_FIRST, 1 = FIRST_TO_SECOND, 2 = BOTH", c->search_dir),
+  OPT(CILHIP_OPT_FEATURE_NORMAL_WEIGHT, "feature_normal_weight", 0, 0, 1e30, "PointNormalFeaturesAdaptor's normal weight (> 0: the search runs on 6-D features)", c->normal_weight),
+  OPT(CILHIP_OPT_FEATURE_KIND, "feature_kind", 0, 0, 2, "second feature block: 0 = normals (follow the transform), 1 = colours (do not), 2 = normals + colours (9-D)", c->feature_kind),
+  OPT(CILHIP_OPT_FEATURE_COLOR_WEIGHT, "feature_color_weight", 0, 0, 1e30, "PointNormalColorFeaturesAdaptor's colour weight (feature_kind 2)", c->color_weight),
+  OPT(CILHIP_OPT_SYMMETRIC_METRIC, "symmetric_metric", 1, 0, 1, "source normals, when set, switch the combined metric to the symmetric objective", c->symmetric),
+  OPT(CILHIP_OPT_TRANSFORM_MODE, "transform_mode", 0, 0, 1, "ICP instance family: 0 = rigid, 1 = affine", c->transform_mode),
+  OPT(CILHIP_OPT_REQUIRE_RECIPROCALITY, "require_reciprocality", 0, 0, 1, "setRequireReciprocality (search_direction BOTH)", c->reciprocal),
+  OPT(CILHIP_OPT_CELL_OCCUPANCY, "cell_occupancy", 1, 1e-3, 1e6, "target points per grid cell the next cilhip_set_target aims at", c->cell_occupancy),
+  OPT(CILHIP_OPT_REFINED_OCCUPANCY_FACTOR, "refined_occupancy_factor", 3, 1, 64, "how much denser than that a grid that had to be refined (surface, clusters) may stay", c->refined_occupancy),
+  OPT(CILHIP_OPT_KERNEL_TIMING, "kernel_timing", 0, 0, 1, "hipEvents around the search / accumulation kernels (cilhip_enable_kernel_timing)", c->kernel_timing),
+  OPT(CILHIP_OPT_KERNEL_TIMING_STRIDE, "kernel_timing_stride", 1, 1, 4096, "with kernel timing on: iterations 0..2 and every stride-th one carry events", c->timing_stride),
+};
+#undef OPT
+constexpr int N_OPTIONS = (int)(sizeof(g_options) / sizeof(g_options[0]));
+static_assert(N_OPTIONS == CILHIP_OPT_COUNT, "one table row per enum cilhip_option value, in the enum's order");
+}  // namespace
+
+int cilhip_option_count(void) { return N_OPTIONS; }
+const cilhip_option_info_t* cilhip_option_info(int id) { return (id >= 0 && id < N_OPTIONS) ? &g_options[id].info : nullptr; }
+int cilhip_set_option_id(cilhip_ctx* c, cilhip_option id, double value) {
+  if (!c) return CILHIP_ERR_INVALID;
+  if ((int)id < 0 || (int)id >= N_OPTIONS) return fail(c, CILHIP_ERR_INVALID, "set_option_id: unknown option");
+  return cilhip_set_option(c, g_options[(int)id].info.key, value);
+}
+int cilhip_get_option(cilhip_ctx* c, const char* key, double* value) {
+  if (!c || !key || !value) return CILHIP_ERR_INVALID;
+  for (int i = 0; i < N_OPTIONS; ++i)
+    if (!strcmp(key, g_options[i].info.key)) { *value = g_options[i].get(c); return CILHIP_OK; }
+  return fail(c, CILHIP_ERR_INVALID, "get_option: unknown key");
+}
+
 int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!c || !key) return CILHIP_ERR_INVALID;
+  if (value != value) return fail(c, CILHIP_ERR_INVALID, "set_option: the value is not a number");
   if (!strcmp(key, "fused")) { c->fused = value != 0.0; return CILHIP_OK; }
   // (a finished run's set that has not been searched again yet -- cilhip_get_last_matches_origin 2 -- would be filtered with the
   //  NEW values: a changed post-filter drops it; a set already in memory is what its search left, whatever is set afterwards)
@@ -548,8 +633,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if ((n && !xyz) || n >= 0xFFFFFFF0ull) return fail(c, CILHIP_ERR_INVALID, "set_target: bad cloud (null or >= 2^32-16 points)");
   CK(c, hipSetDevice(c->device));
   auto t0 = std::chrono::steady_clock::now();
-  if (c->has_target) { free_grid(c->grid); c->has_target = false; }
-  if (c->d_inv_perm) { (void)hipFree(c->d_inv_perm); c->d_inv_perm = nullptr; }
+  release_target(c);      // (incl. the order tables, the nearest-other-point table: they describe ONE target; a shared target is only let go of)
   if (c->d_winner) { (void)hipFree(c->d_winner); c->d_winner = nullptr; }
   if (c->d_rev_pos) { (void)hipFree(c->d_rev_pos); c->d_rev_pos = nullptr; }
   if (c->d_rev_d2) { (void)hipFree(c->d_rev_d2); c->d_rev_d2 = nullptr; }
@@ -565,11 +649,9 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (e != hipSuccess) { c->err = std::string("build_grid: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->grid = r.grid; c->grid_occ = r.avg_occupancy; c->grid_cells = r.n_cells;
   c->warm_banned = false;
-  drop_tie_tables(c);
   c->dst_rgb_sorted_ok = false;
   if (c->d_dst_rgb) { (void)hipFree(c->d_dst_rgb); c->d_dst_rgb = nullptr; }      // (colours belong to the target they were set for)
   if (c->d_dst_rgb_sorted) { (void)hipFree(c->d_dst_rgb_sorted); c->d_dst_rgb_sorted = nullptr; }
-  if (c->d_safe2) { (void)hipFree(c->d_safe2); c->d_safe2 = nullptr; }      // (rebuilt by the first run that can use it: ensure_safe2)
   c->has_normals = (nrm != nullptr);
   for (int i = 0; i < 3; ++i) c->dst_mean[i] = (float)mean[i];
   c->has_target = true;
@@ -578,6 +660,48 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   c->have_pairs = false; c->pairs.count = 0;
   c->far_mode = true;
   c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return CILHIP_OK;
+}
+
+// CorrespondenceSearchKDTree::getFirstSearchTree / setFirstSearchTree (correspondence_search_kd_tree.hpp:273-296): a second engine
+// takes the index another one built instead of building its own.  Here: `c` takes `from`'s target as it stands -- the sorted
+// points and normals, the cell table, and whatever has been built on top of them by now (the paired point+normal records, the
+// nearest-other-point table, the order tables of the reference's tree, the index -> position map) -- without copying a byte.  The
+// allocations move into a reference-counted share: either context may be destroyed or given another target first, the memory goes
+// when the last user lets go.  What one of them builds LATER (tables a run finds it needs) is its own.
+int cilhip_share_target(cilhip_ctx* c, cilhip_ctx* from) {
+  if (!c || !from || c == from) return CILHIP_ERR_INVALID;
+  if (!from->has_target) return fail(c, CILHIP_ERR_INVALID, "share_target: the other context has no target");
+  if (c->device != from->device) return fail(c, CILHIP_ERR_INVALID, "share_target: the two contexts live on different devices");
+  CK(c, hipSetDevice(c->device));
+  CK(c, hipStreamSynchronize(from->stream));      // (whatever is still building the lender's tables)
+  CK(c, hipStreamSynchronize(c->stream));
+  release_target(c);
+  if (c->d_winner) { (void)hipFree(c->d_winner); c->d_winner = nullptr; }
+  if (c->d_rev_pos) { (void)hipFree(c->d_rev_pos); c->d_rev_pos = nullptr; }
+  if (c->d_rev_d2) { (void)hipFree(c->d_rev_d2); c->d_rev_d2 = nullptr; }
+  if (c->d_dst_rgb) { (void)hipFree(c->d_dst_rgb); c->d_dst_rgb = nullptr; }
+  if (c->d_dst_rgb_sorted) { (void)hipFree(c->d_dst_rgb_sorted); c->d_dst_rgb_sorted = nullptr; }
+  c->dst_rgb_sorted_ok = false;
+  // the lender's own allocations become the share's (its earlier share, if it has one, already holds the rest)
+  if (!from->tshare) { from->tshare = new (std::nothrow) TargetShare(); if (!from->tshare) return fail(c, CILHIP_ERR_HIP, "share_target: out of memory"); from->tshare->refs = 1; }
+  TargetShare* sh = from->tshare;
+  const void* ptrs[] = {from->grid.pts, from->grid.nrm, from->grid.pn, from->grid.cell_start, from->d_inv_perm, from->d_safe2, from->d_tie_leaf_slot, from->d_tie_nodes};
+  for (const void* p : ptrs)
+    if (p && std::find(sh->allocs.begin(), sh->allocs.end(), p) == sh->allocs.end()) sh->allocs.push_back(const_cast<void*>(p));
+  ++sh->refs;
+  c->tshare = sh;
+  c->grid = from->grid; c->has_target = true; c->has_normals = from->has_normals;
+  c->grid_occ = from->grid_occ; c->grid_cells = from->grid_cells; c->build_ms = 0.0;
+  for (int i = 0; i < 3; ++i) c->dst_mean[i] = from->dst_mean[i];
+  c->index_offset = from->index_offset;
+  c->d_inv_perm = from->d_inv_perm; c->d_safe2 = from->d_safe2;
+  c->d_tie_leaf_slot = from->d_tie_leaf_slot; c->d_tie_nodes = from->d_tie_nodes;
+  c->warm_banned = false;
+  c->src_sorted = false;  // source order is tied to the target grid
+  drop_matches(c);
+  c->have_pairs = false; c->pairs.count = 0;
+  c->far_mode = true;
   return CILHIP_OK;
 }
 
@@ -2298,6 +2422,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   CK(c, hipGetLastError());
   c->run_active = true;
   c->run_nev = 0; c->run_nar = 0; c->last_allreduce_ms = 0.0; c->last_allreduce_n = 0;
+  c->run_enqueue_us = 0.0; c->run_enqueue_iters = 0;
   c->run_calls = 0;
   c->run_warm_on = false; c->run_judged = 0;
   c->rec_valid = false; c->lb_fresh = false;
@@ -3308,12 +3433,22 @@ int cilhip_get_last_allreduce_timing(cilhip_ctx* c, double* total_ms, int* timed
   return CILHIP_OK;
 }
 
+int cilhip_get_last_host_enqueue_time(cilhip_ctx* c, double* us_per_iteration) {
+  if (!c || !us_per_iteration) return CILHIP_ERR_INVALID;
+  *us_per_iteration = c->run_enqueue_iters ? c->run_enqueue_us / c->run_enqueue_iters : 0.0;
+  return CILHIP_OK;
+}
+
 int cilhip_icp_iterate_ranked(cilhip_ctx* c, int iterations) {
   if (!c || iterations < 0) return CILHIP_ERR_INVALID;
   if (!c->rank_comm) return fail(c, CILHIP_ERR_INVALID, "icp_iterate_ranked: cilhip_rank_comm_init first");
   if (!c->run_active) return fail(c, CILHIP_ERR_INVALID, "icp_begin first");
   CK(c, hipSetDevice(c->device));
   const int im = iter_metric_of(c, &c->run_prm);
+  const auto t_call = std::chrono::steady_clock::now();
+  const double wait0 = c->wait_us;
+  struct Acc { cilhip_ctx* c; std::chrono::steady_clock::time_point t; double w0; int n;
+               ~Acc() { c->run_enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count() - (c->wait_us - w0); c->run_enqueue_iters += n; } } acc{c, t_call, wait0, iterations};
   for (int k = 0; k < iterations; ++k) {
     // this rank's RANK_ROWS rows of partial sums -> summed over the ranks, row by row -> folded by the epilogue (the same values on
     // every rank: identical transforms and decisions everywhere)

@@ -1191,9 +1191,6 @@ __device__ __forceinline__ void exact_take(ExactScan& x, float e, uint32_t j) {
 #ifndef CILHIP_OCT_EXTRA
 #define CILHIP_OCT_EXTRA 1  /* further quads taken in straight-line code before the overflow loop */
 #endif
-#ifndef CILHIP_EXP_HACK
-#define CILHIP_EXP_HACK 0   /* dev: timing-only experiments (WRONG results): 1 = one run per octant search, 2 = no staging loads, 3 = no cell-table loads, 4 = no normal gather */
-#endif
 constexpr int OCT_CAND = 4;   // candidates per run evaluated unconditionally (a run = 2 cells, ~2 points at the default occupancy)
 constexpr int OCT_EXTRA = CILHIP_OCT_EXTRA;
 constexpr uint32_t OCT_KMASK = 0xFFFFFFE0u, OCT_NOCODE = 31u, OCT_OVER = 16u;   // 5 code bits: 16 straight-line slots, 4 of the current overflow quad
@@ -1264,7 +1261,6 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     lds_issue_run4(lds_pair_addr(t.lp_addr, rj[1]), r1);
     lds_wait_run4<6>(r0);
     eval_run4(0u, r0, qx, qy, qz, OCT_KMASK, b, s);
-#if CILHIP_EXP_HACK != 1
     lds_issue_run4(lds_pair_addr(t.lp_addr, rj[2]), r0);
     lds_wait_run4<6>(r1);
     eval_run4(4u, r1, qx, qy, qz, OCT_KMASK, b, s);
@@ -1273,9 +1269,6 @@ __device__ __forceinline__ bool octant_search(const GridDev& g, const TileLds& t
     eval_run4(8u, r0, qx, qy, qz, OCT_KMASK, b, s);
     lds_wait_run4<0>(r1);
     eval_run4(12u, r1, qx, qy, qz, OCT_KMASK, b, s);
-#else
-    lds_wait_run4<0>(r1);
-#endif
   }
   // Runs longer than OCT_CAND.  A flattened per-lane loop costs the whole wave its longest lane, and some lane of almost every
   // wave has one long run.  So: OCT_EXTRA more quads in straight-line code -- every lane takes the first run it has not finished
@@ -1735,7 +1728,6 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
         const uint32_t x = e - __umul24(r, (uint32_t)W1);
         const uint32_t zr = __umul24(r, inv_ry) >> 16;
         const uint32_t gi = gbase + __umul24(zr, slab) + __umul24(r - __umul24(zr, (uint32_t)RY), rowstride) + x;
-        if (CILHIP_EXP_HACK == 3) v[k] = gi; else
         v[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_cs, e < (uint32_t)E ? gi * 4u : 0xFFFFFFFFu, 0, 0);
       }
     }
@@ -1846,7 +1838,6 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
           const uint32_t o = o0 + 16u * (uint32_t)half;
           const bool has = o < l;
           dst[m] = has ? f + o : NONE_U32;
-          if (CILHIP_EXP_HACK == 2) v[m] = u32x4{f, o, d, 0u}; else
           v[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_pts, has ? (f + o + d) * 16u : 0xFFFFFFFFu, 0, 0);
         }
 #pragma unroll
@@ -2003,7 +1994,7 @@ __global__ __launch_bounds__(TILE_THREADS, CILHIP_TILE_WAVES_PER_SIMD) void k_se
       p4t[u] = n4t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       qt[u][0] = qt[u][1] = qt[u][2] = 0.0f;
       if (mpos[u] != NONE_U32) {
-        if (FusedZ<ACC>::needs_normal) n4t[u] = CILHIP_EXP_HACK == 4 ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[mpos[u]];                 // the one gather from HBM
+        if (FusedZ<ACC>::needs_normal) n4t[u] = g.nrm[mpos[u]];                 // the one gather from HBM
         const float* const w = lp + lds_slot_x((mbl >> (16 * u)) & 0xFFFFu);    // the matched point out of the staged tile
         p4t[u] = make_float4(w[0], w[2], w[4], 0.f);
         if (u == TILE_QPT - 1) {

@@ -7,14 +7,21 @@
 //                                           optional flip towards the view point, curvature = l0 / (l0+l1+l2)
 //
 // One lane per query.  The k best candidates live in LDS as a per-lane sorted column of 64-bit keys
-// (bits(d2) << 32 | original index: strict '<' plus lowest-index tie-break, the rule of the 1-NN path).  The
-// grid is searched in expanding Chebyshev shells; a row / cell is skipped when its box distance already
-// exceeds the current k-th best, and the search stops when every unscanned point is provably farther than
-// the k-th best.  d2 is the pinned ((dx*dx)+(dy*dy))+(dz*dz), so neighbour sets and distances are
-// bit-identical to the reference except on exactly tied distances at the k-th place.
+// (bits(d2) << 32 | original index).  The grid is searched in expanding Chebyshev shells; a row / cell is skipped when
+// its box distance already exceeds the current k-th best, and the search stops when every unscanned point is provably
+// farther than the k-th best.  d2 is the pinned ((dx*dx)+(dy*dy))+(dz*dz): neighbour sets and distances are those of the
+// reference bit for bit.
+// Exactly equal distances.  The reference's result set (core/kd_tree.hpp:80-99: insertion with a strict '>' shift, candidates
+// admitted by nanoflann only while dist < worstDist) keeps, among equal distances, the candidates its kd-tree traversal meets
+// FIRST, in that order -- inside the list and at the k-th place.  Here (cilhip_knn_set_tie_rule, default 2): the search notices a
+// query whose list holds equal distances or whose k-th distance was met on a further point; the order tables of the reference's
+// tree over the searched cloud are then built once (csrc/tie_order.hpp, as for the 1-NN path), the search runs again with sorted
+// POSITIONS in the keys, every group of equal distances inside a list is ordered by tie_before(), and a tied k-th place is refilled
+// from ALL points at exactly that distance, first met first.  Rule 0: lowest index (the keys' own order).
 // Queries are processed in target-grid cell order (neighbouring lanes scan the same cells).
 #include "../../include/cilantro_hip/c_api.h"
 #include "internal.hpp"
+#include "tie_order.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
@@ -47,6 +54,11 @@ struct KnnArgs {
   float* curvature;        // [nq] or null
   float vp[3];
   int use_vp;
+  // equal distances (see the header comment): tie.mode != 0 -- the reference's order; tie.leaf_slot == null -- only count the queries
+  // that would need it (tie_count); by_pos -- the keys carry sorted positions instead of original indices (set with the tables)
+  TieDev tie;
+  unsigned int* tie_count;
+  int by_pos;
 };
 
 __device__ __forceinline__ float d2_pinned(float qx, float qy, float qz, float px, float py, float pz) {
@@ -61,26 +73,31 @@ struct KList {
   uint32_t k, cnt;
   unsigned long long worst;  // a candidate enters iff key < worst
   unsigned long long none_key;
+  uint32_t tie_bits;         // bits of the distance at which a candidate last fell off (or stayed out of) a FULL list while an entry at exactly that
+                             // distance stayed in: the k-th place is tied iff this is the final k-th distance (the k-th distance only shrinks)
   __device__ __forceinline__ float worst_d2() const { return __uint_as_float((uint32_t)(worst >> 32)); }
   __device__ __forceinline__ void insert(unsigned long long key) {
-    if (key >= worst) return;
+    if (key >= worst) { if (cnt == k && (uint32_t)(key >> 32) == (uint32_t)(worst >> 32)) tie_bits = (uint32_t)(key >> 32); return; }
+    const bool full = cnt == k;
+    const unsigned long long out = full ? col[(size_t)(k - 1) * KNN_THREADS] : 0ull;
     uint32_t j = cnt < k ? cnt : k - 1;
     while (j > 0 && col[(size_t)(j - 1) * KNN_THREADS] > key) { col[(size_t)j * KNN_THREADS] = col[(size_t)(j - 1) * KNN_THREADS]; --j; }
     col[(size_t)j * KNN_THREADS] = key;
     if (cnt < k) ++cnt;
     worst = cnt < k ? none_key : col[(size_t)(k - 1) * KNN_THREADS];
+    if (full && (uint32_t)(out >> 32) == (uint32_t)(worst >> 32)) tie_bits = (uint32_t)(out >> 32);
   }
 };
 
-__device__ __forceinline__ void scan_run(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, KList& L) {
+__device__ __forceinline__ void scan_run(const float4* __restrict__ pts, uint32_t beg, uint32_t end, float qx, float qy, float qz, KList& L, bool by_pos) {
   if (beg >= end) return;
   const uint32_t last = end - 1;
   for (uint32_t j = beg; j < end; j += 4) {
     const float4 p0 = pts[j], p1 = pts[min(j + 1, last)], p2 = pts[min(j + 2, last)], p3 = pts[min(j + 3, last)];
-    const unsigned long long k0 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z)) << 32) | __float_as_uint(p0.w);
-    const unsigned long long k1 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z)) << 32) | __float_as_uint(p1.w);
-    const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z)) << 32) | __float_as_uint(p2.w);
-    const unsigned long long k3 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z)) << 32) | __float_as_uint(p3.w);
+    const unsigned long long k0 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p0.x, p0.y, p0.z)) << 32) | (by_pos ? j : __float_as_uint(p0.w));
+    const unsigned long long k1 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p1.x, p1.y, p1.z)) << 32) | (by_pos ? j + 1 : __float_as_uint(p1.w));
+    const unsigned long long k2 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p2.x, p2.y, p2.z)) << 32) | (by_pos ? j + 2 : __float_as_uint(p2.w));
+    const unsigned long long k3 = ((unsigned long long)__float_as_uint(d2_pinned(qx, qy, qz, p3.x, p3.y, p3.z)) << 32) | (by_pos ? j + 3 : __float_as_uint(p3.w));
     L.insert(k0);
     if (j + 1 <= last) L.insert(k1);   // (a clamped duplicate must not enter twice)
     if (j + 2 <= last) L.insert(k2);
@@ -101,6 +118,8 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(KnnArgs a) {
   L.k = a.k; L.cnt = 0;
   L.none_key = ((unsigned long long)__float_as_uint(a.radius_sq) << 32);
   L.worst = L.none_key;
+  L.tie_bits = 0xFFFFFFFFu;
+  const bool by_pos = a.by_pos != 0;
   const float BIG = 1.0e9f;
   const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG));
   const int cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG));
@@ -133,18 +152,18 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(KnnArgs a) {
             const int xa = max(xlo, 0), xb = min(xhi, g.nx - 1);
             if (xa <= xb) {
               const float gx = gap(qx, g.ox + (float)xa * g.cell, g.ox + (float)(xb + 1) * g.cell, g.margin);
-              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, L);
+              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, L, by_pos);
             }
           } else {
             if (xlo >= 0 && xlo < g.nx) {
               const float xl = g.ox + (float)xlo * g.cell;
               const float gx = gap(qx, xl, xl + g.cell, g.margin);
-              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, L);
+              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xlo], g.cell_start[row + xlo + 1], qx, qy, qz, L, by_pos);
             }
             if (xhi >= 0 && xhi < g.nx && xhi != xlo) {
               const float xl = g.ox + (float)xhi * g.cell;
               const float gx = gap(qx, xl, xl + g.cell, g.margin);
-              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, L);
+              if ((gyz2 + gx * gx) * KNN_SHRINK <= L.worst_d2()) scan_run(g.pts, g.cell_start[row + xhi], g.cell_start[row + xhi + 1], qx, qy, qz, L, by_pos);
             }
           }
         }
@@ -163,6 +182,90 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(KnnArgs a) {
     }
   }
   const uint32_t m = L.cnt;
+  if (a.tie.mode != 0 && m > 0) {
+    // equal distances inside the list, or at its k-th place (header comment)
+    const uint32_t wbits = (uint32_t)(L.col[(size_t)(m - 1) * KNN_THREADS] >> 32);
+    const bool boundary = m == a.k && L.tie_bits == wbits;
+    bool interior = false;
+    for (uint32_t j = 1; j < m; ++j) interior |= (uint32_t)(L.col[(size_t)j * KNN_THREADS] >> 32) == (uint32_t)(L.col[(size_t)(j - 1) * KNN_THREADS] >> 32);
+    if (boundary || interior) {
+      if (a.tie.leaf_slot == nullptr) atomicAdd(a.tie_count, 1u);
+      else {      // (by_pos: the keys' low words are sorted positions)
+        uint32_t end = m;
+        if (boundary) {
+          // the k-th place: every point at exactly the k-th distance competes for the slots [first, k), first met first
+          uint32_t first = m - 1;
+          while (first > 0 && (uint32_t)(L.col[(size_t)(first - 1) * KNN_THREADS] >> 32) == wbits) --first;
+          const uint32_t cap = a.k - first;
+          uint32_t filled = 0;
+          const float bd = __uint_as_float(wbits);
+          const unsigned long long hi = (unsigned long long)wbits << 32;
+          for (int s = s0;; ++s) {
+            const int z0 = max(cz - s, 0), z1 = min(cz + s, g.nz - 1), y0 = max(cy - s, 0), y1 = min(cy + s, g.ny - 1);
+            for (int z = z0; z <= z1; ++z) {
+              const float zl = g.oz + (float)z * g.cell;
+              const float az = gap(qz, zl, zl + g.cell, g.margin);
+              for (int y = y0; y <= y1; ++y) {
+                const bool face = (z == cz - s) || (z == cz + s) || (y == cy - s) || (y == cy + s);
+                const float yl = g.oy + (float)y * g.cell;
+                const float ay = gap(qy, yl, yl + g.cell, g.margin);
+                if ((az * az + ay * ay) * KNN_SHRINK > bd) continue;
+                const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+                uint32_t rb[2] = {0, 0}, re[2] = {0, 0};
+                if (face) {
+                  const int xa = max(cx - s, 0), xb = min(cx + s, g.nx - 1);
+                  if (xa <= xb) { rb[0] = g.cell_start[row + xa]; re[0] = g.cell_start[row + xb + 1]; }
+                } else {
+                  if (cx - s >= 0 && cx - s < g.nx) { rb[0] = g.cell_start[row + cx - s]; re[0] = g.cell_start[row + cx - s + 1]; }
+                  if (s > 0 && cx + s >= 0 && cx + s < g.nx) { rb[1] = g.cell_start[row + cx + s]; re[1] = g.cell_start[row + cx + s + 1]; }
+                }
+                for (int r = 0; r < 2; ++r)
+                  for (uint32_t j = rb[r]; j < re[r]; ++j) {
+                    const float4 p = g.pts[j];
+                    if (d2_pinned(qx, qy, qz, p.x, p.y, p.z) != bd) continue;
+                    // the adaptor's insertion among equal distances: behind everything met earlier (core/kd_tree.hpp:82-96)
+                    uint32_t i = filled;
+                    while (i > 0 && tie_before(a.tie, qx, qy, qz, j, (uint32_t)L.col[(size_t)(first + i - 1) * KNN_THREADS])) {
+                      if (i < cap) L.col[(size_t)(first + i) * KNN_THREADS] = L.col[(size_t)(first + i - 1) * KNN_THREADS];
+                      --i;
+                    }
+                    if (i < cap) L.col[(size_t)(first + i) * KNN_THREADS] = hi | j;
+                    if (filled < cap) ++filled;
+                  }
+              }
+            }
+            float b = INFINITY;      // lower bound on the distance to anything not yet scanned
+            if (cx - s > 0) b = fminf(b, qx - (g.ox + (float)(cx - s) * g.cell));
+            if (cx + s + 1 < g.nx) b = fminf(b, (g.ox + (float)(cx + s + 1) * g.cell) - qx);
+            if (cy - s > 0) b = fminf(b, qy - (g.oy + (float)(cy - s) * g.cell));
+            if (cy + s + 1 < g.ny) b = fminf(b, (g.oy + (float)(cy + s + 1) * g.cell) - qy);
+            if (cz - s > 0) b = fminf(b, qz - (g.oz + (float)(cz - s) * g.cell));
+            if (cz + s + 1 < g.nz) b = fminf(b, (g.oz + (float)(cz + s + 1) * g.cell) - qz);
+            if (b == INFINITY) break;
+            b -= g.margin;
+            if (b > 0.0f && bd < b * b * KNN_SHRINK) break;
+          }
+          end = first;
+        }
+        // groups of equal distances inside the list: all their points are in it, ordered as the traversal meets them
+        for (uint32_t j = 1; j < end; ++j) {
+          const unsigned long long key = L.col[(size_t)j * KNN_THREADS];
+          uint32_t i = j;
+          while (i > 0 && (uint32_t)(L.col[(size_t)(i - 1) * KNN_THREADS] >> 32) == (uint32_t)(key >> 32) &&
+                 tie_before(a.tie, qx, qy, qz, (uint32_t)key, (uint32_t)L.col[(size_t)(i - 1) * KNN_THREADS])) {
+            L.col[(size_t)i * KNN_THREADS] = L.col[(size_t)(i - 1) * KNN_THREADS];
+            --i;
+          }
+          L.col[(size_t)i * KNN_THREADS] = key;
+        }
+      }
+    }
+  }
+  if (by_pos)      // positions -> original indices, for everything that follows
+    for (uint32_t j = 0; j < m; ++j) {
+      const unsigned long long key = L.col[(size_t)j * KNN_THREADS];
+      L.col[(size_t)j * KNN_THREADS] = (key & 0xFFFFFFFF00000000ull) | (unsigned long long)__float_as_uint(g.pts[(uint32_t)key].w);
+    }
   if (a.out_cnt) a.out_cnt[orig] = m;
   if (a.out_idx) {
     for (uint32_t j = 0; j < a.k; ++j) {
@@ -267,6 +370,8 @@ __global__ __launch_bounds__(KNN_THREADS) void k_radius_pca(KnnArgs a) {
   if (a.curvature) a.curvature[orig] = curv;
 }
 
+int g_knn_tie_rule = 2;      // cilhip_knn_set_tie_rule
+
 #define KN_CK(x)               \
   do {                         \
     if ((x) != hipSuccess) {   \
@@ -292,6 +397,10 @@ int knn_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_
   uint2* d_tiles = nullptr;
   float4* d_tc = nullptr;
   uint32_t *d_idx = nullptr, *d_cnt = nullptr;
+  unsigned int* d_tiecnt = nullptr;
+  uint2* d_tie_ls = nullptr;
+  uint4* d_tie_nodes = nullptr;
+  uint32_t *d_tie_leaf = nullptr, *d_tie_slot = nullptr;
   GridBuildResult gr{};
   bool have_grid = false;
   {
@@ -346,8 +455,51 @@ int knn_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_
     }
     if (radius_only)
       hipLaunchKernelGGL(k_radius_pca, dim3((unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), 0, s, a);
-    else
-      hipLaunchKernelGGL(k_knn, dim3((unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), k * KNN_THREADS * sizeof(unsigned long long), s, a);
+    else {
+      // equal distances (header comment): rule 2 -- search, and only if some list needs the reference's order build its tables and search
+      // again; rule 1 -- tables first; rule 0 -- the keys' own order (lowest index)
+      const int rule = g_knn_tie_rule;
+      a.tie = TieDev{}; a.tie.mode = rule != 0 ? 1 : 0; a.by_pos = 0;
+      if (rule != 0) { KN_CK(hipMalloc(&d_tiecnt, sizeof(unsigned int))); KN_CK(hipMemsetAsync(d_tiecnt, 0, sizeof(unsigned int), s)); a.tie_count = d_tiecnt; }
+      for (int pass = 0; pass < 2; ++pass) {
+        bool need_tables = rule == 1 && pass == 0;
+        if (!need_tables) {
+          hipLaunchKernelGGL(k_knn, dim3((unsigned)((n_query + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), k * KNN_THREADS * sizeof(unsigned long long), s, a);
+          KN_CK(hipGetLastError());
+          if (rule != 2 || pass == 1 || a.tie.leaf_slot != nullptr) break;
+          unsigned int tied = 0;
+          KN_CK(hipMemcpyAsync(&tied, d_tiecnt, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+          KN_CK(hipStreamSynchronize(s));
+          if (tied == 0) break;
+          need_tables = true;
+        }
+        if (need_tables && n_ref) {
+          // the order tables of the tree the reference builds over the searched cloud (nanoflann 1.7.1, leaf size 10: core/kd_tree.hpp:162-170)
+          std::vector<float> h_ref;
+          const float* hx = ref_xyz;
+          if (mem == CILHIP_MEM_DEVICE) {
+            h_ref.resize(3 * n_ref);
+            KN_CK(hipMemcpyAsync(h_ref.data(), d_ref, 3 * n_ref * sizeof(float), hipMemcpyDeviceToHost, s));
+            KN_CK(hipStreamSynchronize(s));
+            hx = h_ref.data();
+          }
+          TieOrderTree tree;
+          tree.build(hx, (uint32_t)n_ref);
+          const size_t nn = tree.nodes().size();
+          KN_CK(hipMalloc(&d_tie_ls, n_ref * sizeof(uint2)));
+          KN_CK(hipMalloc(&d_tie_nodes, (nn ? nn : 1) * sizeof(uint4)));
+          KN_CK(hipMalloc(&d_tie_leaf, n_ref * sizeof(uint32_t)));
+          KN_CK(hipMalloc(&d_tie_slot, n_ref * sizeof(uint32_t)));
+          KN_CK(hipMemcpyAsync(d_tie_leaf, tree.leaf_of().data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+          KN_CK(hipMemcpyAsync(d_tie_slot, tree.slot_of().data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+          if (nn) KN_CK(hipMemcpyAsync(d_tie_nodes, tree.nodes().data(), nn * sizeof(uint4), hipMemcpyHostToDevice, s));
+          launch_tie_tables_by_position(gr.grid.pts, gr.grid.n, d_tie_leaf, d_tie_slot, d_tie_ls, s);
+          KN_CK(hipGetLastError());
+          KN_CK(hipStreamSynchronize(s));      // (the tree's arrays live on this frame)
+          a.tie.leaf_slot = d_tie_ls; a.tie.nodes = d_tie_nodes; a.by_pos = 1;
+        }
+      }
+    }
     KN_CK(hipGetLastError());
     if (idx_out) KN_CK(hipMemcpyAsync(idx_out, d_idx, n_query * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (idx_out && d2_out) KN_CK(hipMemcpyAsync(d2_out, d_d2, n_query * k * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -368,6 +520,11 @@ done:
   if (d_cnt) (void)hipFree(d_cnt);
   if (d_nrm) (void)hipFree(d_nrm);
   if (d_curv) (void)hipFree(d_curv);
+  if (d_tiecnt) (void)hipFree(d_tiecnt);
+  if (d_tie_ls) (void)hipFree(d_tie_ls);
+  if (d_tie_nodes) (void)hipFree(d_tie_nodes);
+  if (d_tie_leaf) (void)hipFree(d_tie_leaf);
+  if (d_tie_slot) (void)hipFree(d_tie_slot);
   if (s) (void)hipStreamDestroy(s);
   return rc;
 }
@@ -546,6 +703,12 @@ extern "C" {
 int cilhip_radius_search3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, float radius_sq,
                            uint64_t* offsets_out, uint32_t* idx_out, float* d2_out, size_t capacity, size_t* total_out) {
   return cilhip::radius_impl(device, ref_xyz, n_ref, query_xyz, n_query, mem, radius_sq, offsets_out, idx_out, d2_out, capacity, total_out);
+}
+
+int cilhip_knn_set_tie_rule(int rule) {
+  if (rule < 0 || rule > 2) return CILHIP_ERR_INVALID;
+  cilhip::g_knn_tie_rule = rule;
+  return CILHIP_OK;
 }
 
 int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k,

@@ -131,6 +131,12 @@ class Context:
         self._ck(self._L.cilhip_set_target(self._h, p, q, n, mem))
         self.n_target = n
 
+    def share_target(self, other):
+        """CorrespondenceSearchKDTree::setFirstSearchTree(other.getFirstSearchTree()) (correspondence_search_kd_tree.hpp:273-296): search the
+        index `other` built -- and everything built on top of it so far -- instead of building one; nothing is copied, either context may go first"""
+        self._ck(self._L.cilhip_share_target(self._h, other._h))
+        self.n_target = other.n_target
+
     def set_source(self, points, normals=None):
         p, n, mem, k = _as_cloud(points)
         self._settle_device_inputs(mem)
@@ -260,6 +266,17 @@ class Context:
     def icp_iterate_ranked(self, iterations):
         """`iterations` x {partial sums -> ncclAllReduce of the 48 f64 on the context's stream -> epilogue}, between icp_begin and icp_state"""
         self._ck(self._L.cilhip_icp_iterate_ranked(self._h, int(iterations)))
+
+    def last_host_enqueue_time(self):
+        """us of host time per iteration the ranked loop's enqueue calls took since icp_begin (paced waits excluded)"""
+        v = C.c_double(0)
+        self._ck(self._L.cilhip_get_last_host_enqueue_time(self._h, C.byref(v)))
+        return v.value
+
+    def get_option(self, key):
+        v = C.c_double(0)
+        self._ck(self._L.cilhip_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def last_allreduce_timing(self):
         """-> (ms summed over the timed iterations, how many were timed) of the ranked loop's ncclAllReduce since icp_begin (after icp_state)"""

@@ -19,6 +19,15 @@ from . import capi
 from .icp import _as_cloud
 
 
+def set_knn_tie_rule(rule):
+    """which of several EXACTLY equidistant points a k-NN list names, and in which order (cilhip_knn_set_tie_rule; process-wide):
+    2 (default) = the reference's -- the ones its kd-tree traversal meets first, in that order (core/kd_tree.hpp:80-99) --, its order
+    tables built the first time a call meets equal distances; 1 = the same, tables built up front; 0 = lowest index"""
+    rc = capi.load().cilhip_knn_set_tie_rule(int(rule))
+    if rc != capi.OK:
+        raise capi.CilhipError(rc, "cilhip_knn_set_tie_rule: 0, 1 or 2")
+
+
 class KDTree3f:
     def __init__(self, points, device=0):
         self._L = capi.load()

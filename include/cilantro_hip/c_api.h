@@ -94,6 +94,15 @@ int cilhip_get_means(cilhip_ctx* ctx, float dst_mean[3], float src_mean[3]);
  * "feature_kind" = 1, "feature_normal_weight" = the colour weight) and for the 9-D point + normal + colour adaptor (:255-343;
  * "feature_kind" = 2, "feature_color_weight").  After cilhip_set_target and cilhip_set_source. */
 int cilhip_set_color_features(cilhip_ctx* ctx, const float* dst_rgb, const float* src_rgb, int mem);
+/* CorrespondenceSearchKDTree::getFirstSearchTree() / setFirstSearchTree(tree) (correspondence_search/correspondence_search_kd_tree.hpp:273-296;
+ * the shared_ptr<SearchTree> of :299-300): a second engine searches the index another engine built instead of building its own --
+ * many sources registered against one model (examples/fusion.cpp style) pay for the index once.  `ctx` takes `from`'s target as it
+ * stands: the cell-sorted points and normals, the cell table, and everything built on top of them by now (point+normal records,
+ * the nearest-other-point table of the warm-started iterations, the order tables of the reference's tree, the index -> position
+ * map), without copying: the allocations become a reference-counted share, so either context may be destroyed or given another
+ * target first.  What a context builds later is its own.  Same device; neither context may have work in flight on another host
+ * thread during the call.  Colour features are per context (cilhip_set_color_features again). */
+int cilhip_share_target(cilhip_ctx* ctx, cilhip_ctx* from);
 
 /* ---- correspondence search (engine concept) -------------------------------------------------- */
 /* CorrespondenceSearchKDTree::findCorrespondences(tform), SECOND_TO_FIRST, L2, identity
@@ -101,7 +110,8 @@ int cilhip_set_color_features(cilhip_ctx* ctx, const float* dst_rgb, const float
  * (correspondence_search/correspondence_search_kd_tree.hpp:107-229 live code :185-228):
  *   q_i = T*s_i (common_transformable_feature_adaptors.hpp:28-33), exact 1-NN of q_i among dst with
  *   d2 < max_sq_dist, strict (correspondence_search_kd_tree_utilities.hpp:26-33; nanoflann.hpp:1901).
- * Ties on d2 resolve to the LOWEST dst index (the reference keeps the first met in kd-tree order).
+ * Ties on d2 (several target points at EXACTLY the smallest distance) name the point the reference's kd-tree traversal meets first
+ * (option "tie_rule" = 2, the default; 0: the lowest dst index).
  * Results stay on the device; n_found (optional) forces a sync and returns the count. */
 int cilhip_find_correspondences(cilhip_ctx* ctx, const float T[16], float max_sq_dist,
                                 size_t* n_found_or_null);
@@ -336,8 +346,15 @@ int cilhip_transform_fit3f(int device, const float* dst_xyz, const float* src_xy
  * INFINITY for a plain k-NN), ascending by (d2, index).  query_xyz == NULL: the reference points are the queries
  * (every point then finds itself first).  1 <= k <= 32.  All outputs are HOST arrays:
  * idx_out [n_query*k] (row per query, padded with 0xFFFFFFFF), d2_out [n_query*k] or NULL (padded with +inf),
- * counts_out [n_query] or NULL (neighbours found).  Neighbour sets and distances are bit-identical to the
- * reference except on exactly tied distances at the k-th place (there: lowest index here, first met there). */
+ * counts_out [n_query] or NULL (neighbours found).  Neighbour sets, their order and the distances are the reference's bit for
+ * bit -- among EXACTLY equal distances (inside a list and at its k-th place) the candidates the reference's kd-tree traversal meets
+ * first, in that order (core/kd_tree.hpp:80-99 over nanoflann searchLevel): the search notices lists that hold equal distances or
+ * whose k-th distance was met on a further point, builds the order tables of the reference's tree over the searched cloud
+ * (csrc/tie_order.hpp) the first time a call needs them, and searches again with them -- a cloud without exact ties never pays.
+ * cilhip_knn_set_tie_rule (process-wide; also cilhip_normals_knn3f): 2 = that (default), 1 = tables built up front, 0 = lowest
+ * index among equal distances (a brute-force argsort's order).  tests/test_gpu_parity.py: the reference's sensor frames and
+ * lattices, index for index against the reference's own nanoflann knnSearch. */
+int cilhip_knn_set_tie_rule(int rule);
 int cilhip_knn3f(int device, const float* ref_xyz, size_t n_ref, const float* query_xyz, size_t n_query, int mem, size_t k,
                  float max_sq_dist, uint32_t* idx_out, float* d2_out, uint32_t* counts_out);
 /* KDTree<float,3>::radiusSearch (core/kd_tree.hpp:251-282; RadiusSearchResultAdaptor :111-142): per query, EVERY target
@@ -469,6 +486,10 @@ int cilhip_icp_iterate_ranked(cilhip_ctx* ctx, int iterations);
  * slowest rank -- summed over the `timed` iterations since cilhip_icp_begin; valid after cilhip_icp_state.  (No reference
  * counterpart: what bench.py --gpus N reports as allreduce_us_per_iteration.) */
 int cilhip_get_last_allreduce_timing(cilhip_ctx* ctx, double* total_ms, int* timed);
+/* Host time the ranked loop's enqueue calls took per iteration since cilhip_icp_begin -- launches and the collective's enqueue, the
+ * paced waits for the device's feedback word (the host stays at most two iterations ahead) excluded: what must stay below a rank's
+ * iteration time for the host to be off the critical path (bench.py: host_enqueue_us_per_iteration_per_rank). */
+int cilhip_get_last_host_enqueue_time(cilhip_ctx* ctx, double* us_per_iteration);
 
 /* How the iterations of the last cilhip_icp_run were executed: as ONE pass (search with the accumulation inside the LDS
  * tiles) or as TWO (search with its in-tile 3x3x3 second pass, then the streaming accumulation).  Large clouds choose per
@@ -635,6 +656,31 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        building blocks, cilhip_estimate_combined); the accumulation then always runs as its own
  *                        streaming pass. */
 int cilhip_set_option(cilhip_ctx* ctx, const char* key, double value);
+/* The same options as a typed table: an enum a C caller can check at compile time, and per option its key, default, admissible
+ * range and one line of documentation (the long form is the comment above).  cilhip_option_info(id) is valid for
+ * 0 <= id < cilhip_option_count() == CILHIP_OPT_COUNT, in the enum's order (NULL otherwise); cilhip_set_option_id is
+ * cilhip_set_option by id; cilhip_get_option reads the current value back.  tests/test_capi_symbols.py walks the table: every
+ * option is documented, accepted with its default, readable, and named by at least one test. */
+typedef enum cilhip_option {
+  CILHIP_OPT_FUSED = 0, CILHIP_OPT_INLIER_FRACTION, CILHIP_OPT_ONE_TO_ONE, CILHIP_OPT_TILED, CILHIP_OPT_WARM_START, CILHIP_OPT_WARM_FORECAST,
+  CILHIP_OPT_FUSED_EPILOGUE, CILHIP_OPT_GROUP_SEARCH, CILHIP_OPT_TIE_RULE, CILHIP_OPT_WARM_EXTRA_FRACTION, CILHIP_OPT_PAIR_RECORDS,
+  CILHIP_OPT_TILE_RECORDS, CILHIP_OPT_WARM_ENTER_FRACTION, CILHIP_OPT_POINT_WEIGHT_EVALUATOR, CILHIP_OPT_PLANE_WEIGHT_EVALUATOR,
+  CILHIP_OPT_POINT_WEIGHT_SIGMA, CILHIP_OPT_PLANE_WEIGHT_SIGMA, CILHIP_OPT_TILE_ACCUMULATION, CILHIP_OPT_SEARCH_DIRECTION,
+  CILHIP_OPT_FEATURE_NORMAL_WEIGHT, CILHIP_OPT_FEATURE_KIND, CILHIP_OPT_FEATURE_COLOR_WEIGHT, CILHIP_OPT_SYMMETRIC_METRIC,
+  CILHIP_OPT_TRANSFORM_MODE, CILHIP_OPT_REQUIRE_RECIPROCALITY, CILHIP_OPT_CELL_OCCUPANCY, CILHIP_OPT_REFINED_OCCUPANCY_FACTOR,
+  CILHIP_OPT_KERNEL_TIMING, CILHIP_OPT_KERNEL_TIMING_STRIDE,
+  CILHIP_OPT_COUNT
+} cilhip_option;
+typedef struct cilhip_option_info_t {
+  int id;                 /* enum cilhip_option */
+  const char* key;        /* the name cilhip_set_option takes */
+  double default_value, min_value, max_value;
+  const char* doc;
+} cilhip_option_info_t;
+int cilhip_option_count(void);
+const cilhip_option_info_t* cilhip_option_info(int id);
+int cilhip_set_option_id(cilhip_ctx* ctx, cilhip_option id, double value);
+int cilhip_get_option(cilhip_ctx* ctx, const char* key, double* value);
 /* With "fused"=0 and kernel timing on: ms spent in the search kernels and in the accumulation
  * kernels of the last cilhip_icp_run (sum over executed iterations).  Sharded runs: the same two sums over the
  * cilhip_icp_partial_sums calls since cilhip_icp_begin, available after cilhip_icp_state (which synchronises);

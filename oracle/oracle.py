@@ -200,6 +200,8 @@ def ref():
         R.ref_kdtree_free.argtypes = [C.c_void_p]
         R.ref_kdtree_knn_in_radius.restype = C.c_size_t
         R.ref_kdtree_knn_in_radius.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_float, _u64p, _f32p]
+        R.ref_kdtree_knn_batch.restype = None
+        R.ref_kdtree_knn_batch.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, C.c_float, _i64p, _f32p, _u32p, C.c_int]
         R.ref_kdtree_radius_search.restype = C.c_size_t
         R.ref_kdtree_radius_search.argtypes = [C.c_void_p, _f32p, C.c_float, _u64p, _f32p, C.c_size_t]
         R.ref_find_correspondences6.restype = C.c_size_t
@@ -640,6 +642,16 @@ def knn_batch(tree, queries, k, radius_sq=np.inf):
     q = _c(queries).reshape(-1, 3)
     idx = np.zeros((len(q), k), np.int64); d2 = np.zeros((len(q), k), np.float32); cnt = np.zeros(len(q), np.uint32)
     lib().orc_knn_batch(tree.h, q, len(q), k, np.float32(radius_sq), idx.reshape(-1), d2.reshape(-1), cnt)
+    return idx, d2, cnt
+
+
+def ref_knn_batch(tree, queries, k, radius_sq=np.float32(np.finfo(np.float32).max), num_threads=0):
+    """tree: oracle.KDTree(use_ref=True) -- the REFERENCE's own nanoflann knnSearch through cilantro's result adaptor
+    -> (idx int64 [nq,k] -1 padded, d2 [nq,k], counts)"""
+    assert tree.use_ref
+    q = _c(queries).reshape(-1, 3)
+    idx = np.zeros((len(q), k), np.int64); d2 = np.zeros((len(q), k), np.float32); cnt = np.zeros(len(q), np.uint32)
+    ref().ref_kdtree_knn_batch(tree.h, q, len(q), k, np.float32(radius_sq), idx.reshape(-1), d2.reshape(-1), cnt, int(num_threads) if num_threads > 0 else (os.cpu_count() or 1))
     return idx, d2, cnt
 
 

@@ -133,6 +133,29 @@ size_t ref_kdtree_knn_in_radius(const void* tp, const float q[3], size_t k, floa
   return sra.size();
 }
 
+// KDTree::kNNInRadiusSearch for many queries (core/kd_tree.hpp:283-291 in the loop of e.g. core/normal_estimation.hpp:294-420): the
+// reference's own knnSearch through cilantro's result adaptor -- its order among EXACTLY equal distances (first met stays ahead,
+// at every slot and at the k-th place) is what the engine's k-NN is held to.  idx / d2: nq x k, -1 / +inf padded; cnt: nq or null.
+void ref_kdtree_knn_batch(const void* tp, const float* q, size_t nq, size_t k, float radius_sq, int64_t* idx, float* d2, uint32_t* cnt,
+                          int num_threads) {
+  const RefTree* t = static_cast<const RefTree*>(tp);
+  std::vector<Neighbor> nn;
+#pragma omp parallel for private(nn) schedule(dynamic, 256) num_threads(num_threads)
+  for (size_t i = 0; i < nq; i++) {
+    size_t m = 0;
+    if (t->adaptor.n != 0 && k != 0) {
+      KNNResult sra(nn, k, radius_sq);
+      t->tree.findNeighbors(sra, q + 3 * i, t->params);
+      m = sra.size();
+    }
+    for (size_t j = 0; j < k; ++j) {
+      idx[i * k + j] = j < m ? (int64_t)nn[j].index : -1;
+      d2[i * k + j] = j < m ? nn[j].value : std::numeric_limits<float>::infinity();
+    }
+    if (cnt) cnt[i] = (uint32_t)m;
+  }
+}
+
 // correspondence_search_kd_tree_utilities.hpp:7-51, ref_is_first, identity evaluator
 size_t ref_find_correspondences(const void* tp, const float* q, size_t nq, float max_d,
                                 int64_t* dst_idx, int64_t* src_idx, float* d2, int num_threads) {

@@ -78,3 +78,49 @@ def test_every_option_key_is_documented_in_the_header():
     assert len(keys) >= 15
     missing = [k for k in keys if '"%s"' % k not in hdr]
     assert not missing, missing
+
+
+def test_option_table_documents_every_option(hip_lib):
+    """the typed option table (enum cilhip_option / cilhip_option_info): one row per key cilhip_set_option accepts, in the enum's order, each
+    with a default inside its range and a line of documentation; every key is also named, quoted, by at least one test or dev tool."""
+    import re
+
+    opts = capi.options()
+    hdr = open(HEADER).read()
+    enum = re.search(r"typedef enum cilhip_option \{(.*?)\} cilhip_option;", hdr, re.S).group(1)
+    names = [n.strip().split("=")[0].strip() for n in enum.replace("\n", " ").split(",") if n.strip()]
+    assert names[-1] == "CILHIP_OPT_COUNT" and len(names) - 1 == len(opts)
+    for i, (o, n) in enumerate(zip(opts, names)):
+        assert o["id"] == i and n == "CILHIP_OPT_" + o["key"].upper(), (i, o["key"], n)
+        assert len(o["doc"]) >= 20 and o["min"] <= o["default"] <= o["max"], o
+    src = open(os.path.join(ROOT, "cilantro_amd", "csrc", "c_api.hip")).read()
+    keys = sorted(set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', src)))
+    assert sorted(o["key"] for o in opts) == keys
+    assert hip_lib.cilhip_option_info(-1) is None or not hip_lib.cilhip_option_info(-1)
+    assert not hip_lib.cilhip_option_info(len(opts))
+    # named by a test (or, for the dev-only A/B switches, by a dev tool)
+    corpus = ""
+    for d in ("tests", "tools"):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith(".py") and f != os.path.basename(__file__):
+                corpus += open(os.path.join(ROOT, d, f), errors="ignore").read()
+    corpus += open(os.path.join(ROOT, "bench.py")).read() + open(os.path.join(ROOT, "cilantro_amd", "icp.py")).read()
+    unnamed = [o["key"] for o in opts if '"%s"' % o["key"] not in corpus]
+    assert not unnamed, unnamed
+
+
+@pytest.mark.gpu
+def test_every_option_takes_its_default_and_reads_back():
+    from cilantro_amd.icp import Context
+
+    ctx = Context(0)
+    for o in capi.options():
+        ctx.set_option(o["key"], o["default"])
+        assert ctx.get_option(o["key"]) == pytest.approx(o["default"]), o["key"]
+        ctx._ck(ctx._L.cilhip_set_option_id(ctx._h, o["id"], o["default"]))
+    for key, bad in (("tie_rule", 3), ("group_search", 5), ("search_direction", 7), ("kernel_timing_stride", 0), ("refined_occupancy_factor", 0.5), ("tiled", float("nan"))):
+        with pytest.raises(capi.CilhipError):
+            ctx.set_option(key, bad)
+    with pytest.raises(capi.CilhipError):
+        ctx.get_option("no_such_option")
+    ctx.close()

@@ -245,6 +245,31 @@ def test_kernel_timing_by_sample_changes_nothing_but_the_events(Context):
     assert res[(0, 1)] == res[(1, 1)] == res[(1, 4)]
 
 
+def test_ab_switches_never_change_a_result(Context):
+    """The options that exist for A/B runs -- "pair_records", "tile_records", "warm_extra_fraction" and the "kernel_timing" switch --
+    choose HOW a loop gets to its matches and sums, never which: the last iteration's matches index for index, the distances bit for bit,
+    the transform to the order of the f64 additions (<= 1e-6), on the recipe and on an independent source (the regime where a
+    warm-started iteration searches queries again)."""
+    rng = np.random.default_rng(21)
+    d = syn.make_pair(1_200_000, perturb=0.3)
+    cases = {"recipe": d["src"], "independent": _independent_source(d, 1_200_000, 5)}
+    for name, S in cases.items():
+        base = None
+        for opts in ((), (("pair_records", 0),), (("tile_records", 0),), (("warm_extra_fraction", 0.25),), (("warm_extra_fraction", 0.01),), (("kernel_timing", 1),),
+                     (("pair_records", 0), ("tile_records", 0), ("kernel_timing", 1))):
+            gi, gd, T, ctx, nc = _loop_matches(Context, d["dst"], d["dst_n"], S, d["max_sq_dist"], 8, options=opts)
+            for k, v in opts:
+                assert ctx.get_option(k) == pytest.approx(v)
+            ctx.close()
+            if base is None:
+                base = (gi, gd, T, nc)
+                continue
+            assert nc == base[3] and np.array_equal(gi, base[0]), (name, opts)
+            m = gi >= 0
+            assert np.array_equal(gd[m].view(np.uint32), base[1][m].view(np.uint32)), (name, opts)
+            assert np.abs(T - base[2]).max() <= 1e-6, (name, opts, np.abs(T - base[2]).max())
+
+
 def test_tile_and_lane_loop_kernels_matches_index_for_index(Context, orc):
     """The other forms an iteration can take, same check: the LDS tiles with the accumulation inside (one pass), the two-pass
     form (tiled search with its 3x3x3 pass + streaming accumulation), the per-lane search; and loops whose kernels keep no

@@ -1,9 +1,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import sys
+"""dev: variant builds of the library for same-box A/B runs (tools/ab_variants.sh, tools/ab_kstats.sh): tile geometries"""
 from cilantro_amd import build
 variants = {
- "_h1": ["CILHIP_EXP_HACK=1"], "_h2": ["CILHIP_EXP_HACK=2"], "_h3": ["CILHIP_EXP_HACK=3"], "_h4": ["CILHIP_EXP_HACK=4"],
  "_v1": ["CILHIP_CUBE_EDGE=9","CILHIP_TILE_THREADS=448","CILHIP_TILE_BYTES=25088","CILHIP_TILE_MAXE=2112"],
  "_v2": ["CILHIP_CUBE_EDGE=8","CILHIP_TILE_THREADS=320","CILHIP_TILE_BYTES=17920","CILHIP_TILE_MAXE=1600"],
  "_v3": ["CILHIP_CUBE_EDGE=10","CILHIP_TILE_THREADS=576","CILHIP_TILE_BYTES=32256","CILHIP_TILE_MAXE=2720"],
