@@ -46,6 +46,14 @@ __global__ void k_transform_original(const float* __restrict__ src_xyz, uint32_t
   }
 }
 
+// the same under a transform the HOST holds (the order tables of the tree the reference builds over the transformed source: c_api.hip)
+__global__ void k_transform_original_T(const float* __restrict__ src_xyz, uint32_t ns, TfDev Tf, float* __restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    float qx, qy, qz;
+    transform_point(Tf.m, src_xyz[3 * (size_t)i], src_xyz[3 * (size_t)i + 1], src_xyz[3 * (size_t)i + 2], qx, qy, qz);
+    out[3 * (size_t)i] = qx; out[3 * (size_t)i + 1] = qy; out[3 * (size_t)i + 2] = qz;
+  }
+}
 // ---- reverse search without a per-search index -------------------------------------------------------------------
 // The reference rebuilds a kd-tree over the transformed source q = T s for every FIRST_TO_SECOND / BOTH search
 // (correspondence_search_kd_tree.hpp:188-190, :209-211).  Here the source is indexed ONCE, in its own coordinates
@@ -346,6 +354,13 @@ __global__ void k_gather_pair_view(const float* __restrict__ src_xyz, const floa
 }
 
 }  // namespace
+
+void launch_transform_original_host_T(const float* d_src_xyz, uint32_t ns, const float T[16], float* d_out, hipStream_t s) {
+  TfDev tf;
+  for (int k = 0; k < 16; ++k) tf.m[k] = T[k];
+  hipLaunchKernelGGL(k_transform_original_T, dim3(nblk(ns)), dim3(256), 0, s, d_src_xyz, ns, tf, d_out);
+}
+
 
 void free_pairs(PairSet& p) {
   uint32_t** u[] = {&p.first, &p.second, &p.posd, &p.poss, &p.first2, &p.second2, &p.posd2, &p.poss2};

@@ -6,7 +6,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -17,7 +20,6 @@
 #include <vector>
 
 #include "internal.hpp"
-#include "tie_order.hpp"
 
 using namespace cilhip;
 
@@ -120,7 +122,6 @@ struct cilhip_ctx {
   size_t rev_tie_nodes_cap = 0;
   bool rev_tie_valid = false;
   float rev_tie_T[16];
-  std::vector<float> h_src;                      // host copy of the source (original order), fetched once for those builds
   int rev_tie_builds = 0;
   float warm_extra = 0.0625f;     // option "warm_extra_fraction"
   bool pair_records = true;       // option "pair_records": the streaming accumulation gathers a match's point and normal from one 32-byte record (GridDev::pn)
@@ -239,7 +240,6 @@ static void drop_rev_tie_tables(cilhip_ctx* c) {  // (they describe ONE source u
   if (c->d_rev_tie_leaf_slot) { (void)hipFree(c->d_rev_tie_leaf_slot); c->d_rev_tie_leaf_slot = nullptr; }
   if (c->d_rev_tie_nodes) { (void)hipFree(c->d_rev_tie_nodes); c->d_rev_tie_nodes = nullptr; }
   c->rev_tie_nodes_cap = 0; c->rev_tie_valid = false; c->rev_tie_aware = false;
-  std::vector<float>().swap(c->h_src);
 }
 // a target-side allocation of this context: freed here unless it belongs to a share (then by whoever lets go of the share last)
 static void target_ptr_free(cilhip_ctx* c, const void* p) {
@@ -982,44 +982,53 @@ static int load_tie_tables(cilhip_ctx* c, const uint32_t* leaf_by_index, const u
   drop_tie_tables(c);
   const size_t n = c->grid.n;
   uint32_t *d_leaf = nullptr, *d_slot = nullptr;
-  CK(c, hipMalloc(&c->d_tie_leaf_slot, (n ? n : 1) * sizeof(uint2)));
-  CK(c, hipMalloc(&c->d_tie_nodes, (n_nodes ? n_nodes : 1) * sizeof(uint4)));
-  CK(c, hipMalloc(&d_leaf, (n ? n : 1) * sizeof(uint32_t)));
-  CK(c, hipMalloc(&d_slot, (n ? n : 1) * sizeof(uint32_t)));
-  hipError_t e = hipSuccess;
-  if (n) {
+  // (d_tie_leaf_slot != null is the "tables loaded" flag: nothing may be left half set when an allocation fails)
+  hipError_t e = hipMalloc(&c->d_tie_leaf_slot, (n ? n : 1) * sizeof(uint2));
+  if (e == hipSuccess) e = hipMalloc(&c->d_tie_nodes, (n_nodes ? n_nodes : 1) * sizeof(uint4));
+  if (e == hipSuccess) e = hipMalloc(&d_leaf, (n ? n : 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&d_slot, (n ? n : 1) * sizeof(uint32_t));
+  if (e == hipSuccess && n) {
     e = hipMemcpyAsync(d_leaf, leaf_by_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_slot, slot_by_index, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && n_nodes) e = hipMemcpyAsync(c->d_tie_nodes, nodes, n_nodes * sizeof(uint4), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) { launch_tie_tables_by_position(c->grid.pts, c->grid.n, d_leaf, d_slot, c->d_tie_leaf_slot, c->stream); e = hipGetLastError(); }
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (the host arrays and the two staging buffers live on this frame)
-  (void)hipFree(d_leaf); (void)hipFree(d_slot);
+  if (d_leaf) (void)hipFree(d_leaf);
+  if (d_slot) (void)hipFree(d_slot);
   if (e != hipSuccess) { drop_tie_tables(c); c->err = std::string("tie_rule: loading the order tables: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   c->tie_max_depth = 0;
   for (size_t k = 0; k < n_nodes; ++k) c->tie_max_depth = std::max(c->tie_max_depth, (int)(nodes[k].info >> 3));
   return CILHIP_OK;
 }
-// The tables of THIS context's target, built from the device's copy of it (the context keeps no host copy of a cloud).
+// The tables of THIS context's target, built on the device from the grid's own records (tie_build.hip).
 static int build_tie_tables(cilhip_ctx* c) {
   if (c->d_tie_leaf_slot || !c->has_target) return CILHIP_OK;
   const auto t0 = std::chrono::steady_clock::now();
   CK(c, hipSetDevice(c->device));
   const uint32_t n = c->grid.n;
-  std::vector<float4> sorted(n ? n : 1);
-  if (n) CK(c, hipMemcpyAsync(sorted.data(), c->grid.pts, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-  CK(c, hipStreamSynchronize(c->stream));
-  std::vector<float> xyz((size_t)n * 3, 0.0f);
-  for (uint32_t j = 0; j < n; ++j) {
-    uint32_t o; memcpy(&o, &sorted[j].w, 4);
-    if (o >= n) return fail(c, CILHIP_ERR_INVALID, "tie_rule: target index out of range");
-    xyz[3 * (size_t)o] = sorted[j].x; xyz[3 * (size_t)o + 1] = sorted[j].y; xyz[3 * (size_t)o + 2] = sorted[j].z;
+  drop_tie_tables(c);
+  uint32_t *d_leaf = nullptr, *d_slot = nullptr;
+  uint4* d_nodes = nullptr;
+  size_t n_nodes = 0;
+  int depth = 0;
+  hipError_t e = hipMalloc(&d_leaf, (n ? n : 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&d_slot, (n ? n : 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&c->d_tie_leaf_slot, (n ? n : 1) * sizeof(uint2));
+  if (e == hipSuccess) e = tie_order_build_device(nullptr, c->grid.pts, n, c->stream, d_leaf, d_slot, &d_nodes, &n_nodes, &depth);
+  if (e == hipSuccess && !d_nodes) e = hipMalloc(&d_nodes, sizeof(uint4));      // (an empty target)
+  if (e == hipSuccess && n) { launch_tie_tables_by_position(c->grid.pts, n, d_leaf, d_slot, c->d_tie_leaf_slot, c->stream); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (d_leaf) (void)hipFree(d_leaf);
+  if (d_slot) (void)hipFree(d_slot);
+  if (e != hipSuccess) {
+    if (d_nodes) (void)hipFree(d_nodes);
+    drop_tie_tables(c);
+    c->err = std::string("tie_rule: building the order tables: ") + hipGetErrorString(e);
+    return CILHIP_ERR_HIP;
   }
-  { std::vector<float4>().swap(sorted); }
-  cilhip::TieOrderTree tree;
-  tree.build(xyz.data(), n);
-  const int rc = load_tie_tables(c, tree.leaf_of().data(), tree.slot_of().data(), tree.nodes().data(), tree.nodes().size());
-  if (rc) return rc;
+  c->d_tie_nodes = d_nodes;
+  c->tie_max_depth = depth;
   c->tie_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ++c->tie_builds;
   return CILHIP_OK;
@@ -1049,42 +1058,27 @@ static int build_rev_tie_tables(cilhip_ctx* c, const float T[16]) {
   const uint32_t n = c->ns;
   if (!c->has_src_grid || n == 0) return CILHIP_OK;
   CK(c, hipSetDevice(c->device));
-  if (c->h_src.size() != (size_t)n * 3) {
-    c->h_src.resize((size_t)n * 3);
-    CK(c, hipMemcpyAsync(c->h_src.data(), c->d_src_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    CK(c, hipStreamSynchronize(c->stream));
-  }
-  std::vector<float> q((size_t)n * 3);
-  {
-    const unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const unsigned parts = n >= 200000u ? nt : 1u;
-    std::vector<std::thread> th;
-    auto work = [&](uint32_t lo, uint32_t hi) {
-      for (uint32_t i = lo; i < hi; ++i) transform_point(T, c->h_src[3 * (size_t)i], c->h_src[3 * (size_t)i + 1], c->h_src[3 * (size_t)i + 2], q[3 * (size_t)i], q[3 * (size_t)i + 1], q[3 * (size_t)i + 2]);
-    };
-    for (unsigned k = 1; k < parts; ++k) th.emplace_back(work, (uint32_t)((uint64_t)n * k / parts), (uint32_t)((uint64_t)n * (k + 1) / parts));
-    work(0, (uint32_t)((uint64_t)n / parts));
-    for (auto& x : th) x.join();
-  }
-  cilhip::TieOrderTree tree;
-  tree.build(q.data(), n);
-  { std::vector<float>().swap(q); }
-  const size_t n_nodes = tree.nodes().size();
-  if (!c->d_rev_tie_leaf_slot) CK(c, hipMalloc(&c->d_rev_tie_leaf_slot, (size_t)n * sizeof(uint2)));
-  if (n_nodes > c->rev_tie_nodes_cap) {
-    if (c->d_rev_tie_nodes) { (void)hipFree(c->d_rev_tie_nodes); c->d_rev_tie_nodes = nullptr; c->rev_tie_nodes_cap = 0; }
-    CK(c, hipMalloc(&c->d_rev_tie_nodes, (n_nodes + n_nodes / 8 + 16) * sizeof(uint4)));
-    c->rev_tie_nodes_cap = n_nodes + n_nodes / 8 + 16;
-  }
+  float* d_q = nullptr;
   uint32_t *d_leaf = nullptr, *d_slot = nullptr;
-  CK(c, hipMalloc(&d_leaf, (size_t)n * sizeof(uint32_t)));
-  hipError_t e = hipMalloc(&d_slot, (size_t)n * sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMemcpyAsync(d_leaf, tree.leaf_of().data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_slot, tree.slot_of().data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(c->d_rev_tie_nodes, tree.nodes().data(), n_nodes * sizeof(uint4), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) { launch_tie_tables_by_position(c->src_grid.pts, n, d_leaf, d_slot, c->d_rev_tie_leaf_slot, c->stream); e = hipGetLastError(); }
+  uint4* d_nodes = nullptr;
+  size_t n_nodes = 0;
+  hipError_t e = hipMalloc(&d_q, (size_t)n * 3 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_leaf, (size_t)n * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&d_slot, (size_t)n * sizeof(uint32_t));
+  if (e == hipSuccess && !c->d_rev_tie_leaf_slot) e = hipMalloc(&c->d_rev_tie_leaf_slot, (size_t)n * sizeof(uint2));
+  if (e == hipSuccess) { launch_transform_original_host_T(c->d_src_xyz, n, T, d_q, c->stream); e = hipGetLastError(); }      // q = fl(T s), the engine's pinned expression
+  if (e == hipSuccess) e = tie_order_build_device(d_q, nullptr, n, c->stream, d_leaf, d_slot, &d_nodes, &n_nodes, nullptr);
+  if (e == hipSuccess) {
+    if (c->d_rev_tie_nodes) (void)hipFree(c->d_rev_tie_nodes);
+    c->d_rev_tie_nodes = d_nodes; c->rev_tie_nodes_cap = n_nodes; d_nodes = nullptr;
+    launch_tie_tables_by_position(c->src_grid.pts, n, d_leaf, d_slot, c->d_rev_tie_leaf_slot, c->stream);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_leaf); if (d_slot) (void)hipFree(d_slot);
+  if (d_q) (void)hipFree(d_q);
+  if (d_leaf) (void)hipFree(d_leaf);
+  if (d_slot) (void)hipFree(d_slot);
+  if (d_nodes) (void)hipFree(d_nodes);
   if (e != hipSuccess) { c->err = std::string("tie_rule: the transformed source's order tables: ") + hipGetErrorString(e); return CILHIP_ERR_HIP; }
   memcpy(c->rev_tie_T, T, sizeof(c->rev_tie_T));
   c->rev_tie_valid = true;
@@ -1406,31 +1400,74 @@ int cilhip_get_tie_count(cilhip_ctx* c, const float T[16], float max_sq, size_t*
   return CILHIP_OK;
 }
 
-struct cilhip_tie_order { cilhip::TieOrderTree tree; };
+struct cilhip_tie_order { std::vector<uint32_t> leaf, slot; std::vector<cilhip::TieNode> nodes; uint32_t n = 0; int max_depth = 0; };
 int cilhip_tie_order_create(const float* xyz, size_t n, cilhip_tie_order** out) {
   if (!out || (n && !xyz) || n >= 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
-  cilhip_tie_order* o = new (std::nothrow) cilhip_tie_order();
-  if (!o) return CILHIP_ERR_HIP;
-  o->tree.build(xyz, (uint32_t)n);
+  *out = nullptr;
+  int ndev = 0, dev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipGetDevice(&dev) != hipSuccess) return CILHIP_ERR_NO_DEVICE;      // (built on the device: no CPU fallback)
+  cilhip_tie_order* o = nullptr;
+  float* d_xyz = nullptr;
+  uint32_t *d_leaf = nullptr, *d_slot = nullptr;
+  uint4* d_nodes = nullptr;
+  size_t n_nodes = 0;
+  hipStream_t s = nullptr;
+  hipError_t e = hipSuccess;
+  int rc = CILHIP_OK;
+  try {
+    o = new cilhip_tie_order();
+    o->n = (uint32_t)n;
+    o->leaf.assign(n, 0u); o->slot.assign(n, 0u);
+    if (n) {
+      e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipMalloc(&d_xyz, n * 3 * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc(&d_leaf, n * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMalloc(&d_slot, n * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = tie_order_build_device(d_xyz, nullptr, (uint32_t)n, s, d_leaf, d_slot, &d_nodes, &n_nodes, &o->max_depth);
+      if (e == hipSuccess) { o->nodes.resize(n_nodes); e = hipMemcpyAsync(o->nodes.data(), d_nodes, n_nodes * sizeof(uint4), hipMemcpyDeviceToHost, s); }
+      if (e == hipSuccess) e = hipMemcpyAsync(o->leaf.data(), d_leaf, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(o->slot.data(), d_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+  } catch (...) { rc = CILHIP_ERR_HIP; }      // (out of host memory: never across the C boundary)
+  if (d_xyz) (void)hipFree(d_xyz);
+  if (d_leaf) (void)hipFree(d_leaf);
+  if (d_slot) (void)hipFree(d_slot);
+  if (d_nodes) (void)hipFree(d_nodes);
+  if (s) (void)hipStreamDestroy(s);
+  if (e != hipSuccess) rc = CILHIP_ERR_HIP;
+  if (rc != CILHIP_OK) { delete o; return rc; }
   *out = o;
   return CILHIP_OK;
 }
 void cilhip_tie_order_destroy(cilhip_tie_order* order) { delete order; }
+int cilhip_tie_order_tables(const cilhip_tie_order* o, uint32_t* leaf_by_index, uint32_t* slot_by_index, void* nodes_out, size_t nodes_cap, size_t* n_nodes, int* max_depth) {
+  if (!o) return CILHIP_ERR_INVALID;
+  if (leaf_by_index && o->n) memcpy(leaf_by_index, o->leaf.data(), (size_t)o->n * sizeof(uint32_t));
+  if (slot_by_index && o->n) memcpy(slot_by_index, o->slot.data(), (size_t)o->n * sizeof(uint32_t));
+  if (nodes_out && nodes_cap) memcpy(nodes_out, o->nodes.data(), std::min(nodes_cap, o->nodes.size()) * sizeof(cilhip::TieNode));
+  if (n_nodes) *n_nodes = o->nodes.size();
+  if (max_depth) *max_depth = o->max_depth;
+  return CILHIP_OK;
+}
 int cilhip_load_tie_order(cilhip_ctx* c, const cilhip_tie_order* order, const uint32_t* global_index) {
   if (!c || !order) return CILHIP_ERR_INVALID;
   if (!c->has_target) return fail(c, CILHIP_ERR_INVALID, "load_tie_order: set_target first");
-  const uint32_t n = c->grid.n, N = order->tree.size();
-  if (n == 0) return load_tie_tables(c, nullptr, nullptr, order->tree.nodes().data(), order->tree.nodes().size());      // (a shard without target points)
+  const uint32_t n = c->grid.n, N = order->n;
+  if (n == 0) return load_tie_tables(c, nullptr, nullptr, order->nodes.data(), order->nodes.size());      // (a shard without target points)
   if (!global_index) {
     if (n != N) return fail(c, CILHIP_ERR_INVALID, "load_tie_order: the order was built for a cloud of another size (pass global_index for a part of it)");
-    return load_tie_tables(c, order->tree.leaf_of().data(), order->tree.slot_of().data(), order->tree.nodes().data(), order->tree.nodes().size());
+    return load_tie_tables(c, order->leaf.data(), order->slot.data(), order->nodes.data(), order->nodes.size());
   }
-  std::vector<uint32_t> leaf(n ? n : 1), slot(n ? n : 1);
-  for (uint32_t i = 0; i < n; ++i) {
-    if (global_index[i] >= N) return fail(c, CILHIP_ERR_INVALID, "load_tie_order: global index out of range");
-    leaf[i] = order->tree.leaf_of()[global_index[i]]; slot[i] = order->tree.slot_of()[global_index[i]];
-  }
-  return load_tie_tables(c, leaf.data(), slot.data(), order->tree.nodes().data(), order->tree.nodes().size());
+  try {
+    std::vector<uint32_t> leaf(n ? n : 1), slot(n ? n : 1);
+    for (uint32_t i = 0; i < n; ++i) {
+      if (global_index[i] >= N) return fail(c, CILHIP_ERR_INVALID, "load_tie_order: global index out of range");
+      leaf[i] = order->leaf[global_index[i]]; slot[i] = order->slot[global_index[i]];
+    }
+    return load_tie_tables(c, leaf.data(), slot.data(), order->nodes.data(), order->nodes.size());
+  } catch (...) { return fail(c, CILHIP_ERR_HIP, "load_tie_order: out of host memory"); }
 }
 int cilhip_build_tie_order(cilhip_ctx* c) {
   if (!c) return CILHIP_ERR_INVALID;

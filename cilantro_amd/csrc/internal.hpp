@@ -368,6 +368,21 @@ void launch_inv_perm(const float4* dst_sorted, uint32_t n, uint32_t* inv, hipStr
 void launch_count_found(const uint32_t* nn_pos, uint32_t ns, unsigned long long* out, hipStream_t s);
 // queries (sorted source under T) whose nearest target point within the radius is not unique in the pinned f32 distance
 // the order tables by ORIGINAL target index -> by sorted position (TieDev::leaf_slot)
+// q = fl(T s) for every source point (original order), the search kernels' pinned expression, T held by the host (bidir.hip)
+void launch_transform_original_host_T(const float* d_src_xyz, uint32_t ns, const float T[16], float* d_out, hipStream_t s);
+// One node of the order tables (TieDev::nodes reads it as a uint4).
+struct TieNode {          // 16 bytes: one load on the device
+  int32_t parent;         // -1: the root
+  uint32_t info;          // (depth << 3) | (split dimension << 1) | (1: this node is its parent's SECOND child)
+  float divlow, divhigh;  // internal nodes: the split; a leaf: divlow = the slot of its first point (as bits)
+};
+// tie_build.hip: the order tables of the index the reference builds over a cloud (nanoflann 1.7.1 divideTree / middleSplit_ /
+// planeSplit, leaf size 10), level by level on the device.  Input: d_xyz -- the cloud in its ORIGINAL order, 3 floats per point -- or
+// d_sorted -- {x, y, z, bits(original index)} records in any order (exactly one non-null).  Output by ORIGINAL index: the leaf node of
+// every point and its slot in the reference's permutation (device arrays [n] the caller provides); *d_nodes_out: the TieNode
+// records (hipMalloc'ed: the caller frees), breadth-first ids.
+hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, uint32_t n, hipStream_t s, uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index,
+                                  uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out);
 void launch_tie_tables_by_position(const float4* dst_sorted, uint32_t n, const uint32_t* leaf_by_index, const uint32_t* slot_by_index, uint2* leaf_slot, hipStream_t s);
 void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, const float T[16], float max_sq, unsigned long long* out, hipStream_t s);
 // squared distances of the stored matches under T, formed again with the search's pinned arithmetic (bit-identical to what the

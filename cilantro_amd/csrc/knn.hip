@@ -15,13 +15,12 @@
 // admitted by nanoflann only while dist < worstDist) keeps, among equal distances, the candidates its kd-tree traversal meets
 // FIRST, in that order -- inside the list and at the k-th place.  Here (cilhip_knn_set_tie_rule, default 2): the search notices a
 // query whose list holds equal distances or whose k-th distance was met on a further point; the order tables of the reference's
-// tree over the searched cloud are then built once (csrc/tie_order.hpp, as for the 1-NN path), the search runs again with sorted
+// tree over the searched cloud are then built once (csrc/tie_build.hip, as for the 1-NN path), the search runs again with sorted
 // POSITIONS in the keys, every group of equal distances inside a list is ordered by tie_before(), and a tied k-th place is refilled
 // from ALL points at exactly that distance, first met first.  Rule 0: lowest index (the keys' own order).
 // Queries are processed in target-grid cell order (neighbouring lanes scan the same cells).
 #include "../../include/cilantro_hip/c_api.h"
 #include "internal.hpp"
-#include "tie_order.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
@@ -474,28 +473,15 @@ int knn_impl(int device, const float* ref_xyz, size_t n_ref, const float* query_
           need_tables = true;
         }
         if (need_tables && n_ref) {
-          // the order tables of the tree the reference builds over the searched cloud (nanoflann 1.7.1, leaf size 10: core/kd_tree.hpp:162-170)
-          std::vector<float> h_ref;
-          const float* hx = ref_xyz;
-          if (mem == CILHIP_MEM_DEVICE) {
-            h_ref.resize(3 * n_ref);
-            KN_CK(hipMemcpyAsync(h_ref.data(), d_ref, 3 * n_ref * sizeof(float), hipMemcpyDeviceToHost, s));
-            KN_CK(hipStreamSynchronize(s));
-            hx = h_ref.data();
-          }
-          TieOrderTree tree;
-          tree.build(hx, (uint32_t)n_ref);
-          const size_t nn = tree.nodes().size();
+          // the order tables of the tree the reference builds over the searched cloud (nanoflann 1.7.1, leaf size 10: core/kd_tree.hpp:162-170),
+          // built on the device (tie_build.hip)
+          size_t nn = 0;
           KN_CK(hipMalloc(&d_tie_ls, n_ref * sizeof(uint2)));
-          KN_CK(hipMalloc(&d_tie_nodes, (nn ? nn : 1) * sizeof(uint4)));
           KN_CK(hipMalloc(&d_tie_leaf, n_ref * sizeof(uint32_t)));
           KN_CK(hipMalloc(&d_tie_slot, n_ref * sizeof(uint32_t)));
-          KN_CK(hipMemcpyAsync(d_tie_leaf, tree.leaf_of().data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-          KN_CK(hipMemcpyAsync(d_tie_slot, tree.slot_of().data(), n_ref * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-          if (nn) KN_CK(hipMemcpyAsync(d_tie_nodes, tree.nodes().data(), nn * sizeof(uint4), hipMemcpyHostToDevice, s));
+          KN_CK(tie_order_build_device(d_ref, nullptr, (uint32_t)n_ref, s, d_tie_leaf, d_tie_slot, &d_tie_nodes, &nn, nullptr));
           launch_tie_tables_by_position(gr.grid.pts, gr.grid.n, d_tie_leaf, d_tie_slot, d_tie_ls, s);
           KN_CK(hipGetLastError());
-          KN_CK(hipStreamSynchronize(s));      // (the tree's arrays live on this frame)
           a.tie.leaf_slot = d_tie_ls; a.tie.nodes = d_tie_nodes; a.by_pos = 1;
         }
       }

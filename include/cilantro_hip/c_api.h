@@ -400,9 +400,10 @@ int cilhip_get_tie_count(cilhip_ctx* ctx, const float T[16], float max_sq_dist, 
  * matches are NOT the lowest index (the reference's traversal met another one first). */
 int cilhip_get_tie_rule_stats(cilhip_ctx* ctx, size_t* tied_queries, size_t* repointed);
 /* The order tables behind "tie_rule" (kd_tree.hpp:162-170 -> nanoflann.hpp:1150-1212, :1321-1428: the permutation and the splits of
- * the index the reference builds over the target; csrc/tie_order.hpp).  loaded: this context's target has them on the device;
- * builds: how often this context built them (tie_rule 2 builds when a search first meets a tie; never, on clouds that do not tie);
- * build_ms: host time of the last build (tree on the host's cores + upload); pending: tied queries the searches since the last
+ * the index the reference builds over the target), built ON THE DEVICE (csrc/tie_build.hip: all nodes of a level are independent
+ * segments -- a segmented min / max, two flagged prefix sums and two scatters per level reproduce planeSplit's two-pointer sweeps slot
+ * for slot).  loaded: this context's target has them on the device; builds: how often this context built them (tie_rule 2 builds
+ * when a search first meets a tie; never, on clouds that do not tie); build_ms: wall time of the last build; pending: tied queries the searches since the last
  * cilhip_icp_begin / find_correspondences met WITHOUT tables (cilhip_icp_run and cilhip_find_correspondences deal with those
  * themselves; a caller driving cilhip_icp_begin / _partial_sums / _apply_sums reads it after its loop, calls
  * cilhip_build_tie_order and runs the loop again -- cilantro_amd/distributed.py does). */
@@ -412,11 +413,16 @@ int cilhip_get_tie_order_info(cilhip_ctx* ctx, cilhip_tie_order_info* out);
 int cilhip_build_tie_order(cilhip_ctx* ctx);
 /* The same tables for a target that is only PART of the cloud the reference would index (a spatial slab of a sharded run): the
  * order is a property of the WHOLE cloud.  cilhip_tie_order_create builds it once from the whole cloud (host memory, original
- * order); cilhip_load_tie_order hands a context the entries of its own points: global_index[i] = index in the whole cloud of the
- * context's target point i (null: the context holds the whole cloud). */
+ * order; built on the calling thread's current HIP device -- CILHIP_ERR_NO_DEVICE without one -- and kept on the host);
+ * cilhip_load_tie_order hands a context the entries of its own points: global_index[i] = index in the whole cloud of the
+ * context's target point i (null: the context holds the whole cloud).  cilhip_tie_order_tables copies the tables out (tests,
+ * tools: leaf and slot by original index, 16-byte node records {parent, (depth << 3) | (dimension << 1) | second child, divlow,
+ * divhigh}; any pointer may be null). */
 typedef struct cilhip_tie_order cilhip_tie_order;
 int cilhip_tie_order_create(const float* xyz, size_t n, cilhip_tie_order** out);
 void cilhip_tie_order_destroy(cilhip_tie_order* order);
+int cilhip_tie_order_tables(const cilhip_tie_order* order, uint32_t* leaf_by_index, uint32_t* slot_by_index, void* nodes_out, size_t nodes_cap,
+                            size_t* n_nodes, int* max_depth);
 int cilhip_load_tie_order(cilhip_ctx* ctx, const cilhip_tie_order* order, const uint32_t* global_index);
 
 /* CorrespondenceSearchCombinedMetricCombiner (registration/correspondence_search_combined_metric_combiner.hpp:8-81): the combined

@@ -10,7 +10,7 @@ g++ -O2 -std=c++17 -ffp-contract=off -I"$ROOT/include" "$HERE/$t.cpp" -o "$HERE/
 done
 # host-side check of the fast paths in csrc/solve.hpp (hipcc: the header pulls in the HIP runtime API; runs without a GPU)
 /opt/rocm/bin/hipcc -O2 -std=c++17 -ffp-contract=off --offload-arch=gfx950 "$HERE/test_solve.cpp" -o "$HERE/bin/test_solve"
-# csrc/tie_order.hpp (option "tie_rule" = 1) as a host library for the CPU suite
+# tests/cpp/tie_order_host.hpp (the host restatement of the reference's index build: the cross-check of csrc/tie_build.hip) as a host library
 g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC -pthread "$HERE/tie_order_shim.cpp" -o "$HERE/bin/libtie_order_shim.so"
 # host-only PLY round-trip helper (no GPU library needed)
 g++ -O2 -std=c++17 -I"$ROOT/include" "$HERE/test_ply.cpp" -o "$HERE/bin/test_ply"

@@ -1,4 +1,5 @@
-// tie_order.hpp -- which of several EXACTLY equidistant target points the reference would return (option "tie_rule", host side).
+// tie_order_host.hpp -- TEST INFRASTRUCTURE (the CPU cross-check of cilantro_amd/csrc/tie_build.hip; the product builds these tables on the
+// device and never includes this file) -- which of several EXACTLY equidistant target points the reference would return (option "tie_rule").
 //
 // The engine's nearest neighbour is the brute-force argmin of the pinned f32 squared distance.  The reference keeps the candidate
 // its kd-tree traversal meets FIRST (core/kd_tree.hpp:82-90: a strict '<' insert into the k = 1 result set; nanoflann's

@@ -1,6 +1,7 @@
-// Test shim: csrc/tie_order.hpp (host-only) behind a few C functions, so that the CPU suite can check the order tables against the
-// reference's nanoflann (oracle/_ref) without a GPU.  Built by tests/cpp/build.sh into tests/cpp/bin/libtie_order_shim.so.
-#include "../../cilantro_amd/csrc/tie_order.hpp"
+// Test shim: tests/cpp/tie_order_host.hpp (the host restatement of the reference's build: the CPU cross-check of the device build in
+// csrc/tie_build.hip) behind a few C functions, so that the CPU suite can check the order tables against the reference's nanoflann
+// (oracle/_ref) without a GPU, and the GPU suite the device's tables against these.  Built by tests/cpp/build.sh into tests/cpp/bin/libtie_order_shim.so.
+#include "tie_order_host.hpp"
 
 #include <cstring>
 
@@ -55,6 +56,31 @@ int tie_shim_same_order(void* ha, void* hb) {
       const cilhip::TieNode &px = a->tree.nodes()[na], &py = b->tree.nodes()[nb];
       if (std::memcmp(&px.divlow, &py.divlow, 4) || std::memcmp(&px.divhigh, &py.divhigh, 4)) return 0;
     }
+  }
+  return 1;
+}
+// the same comparison against RAW tables (the device build's, copied out by cilhip_tie_order_tables): 1 = the same permutation and
+// the same leaf-to-root path for every point; otherwise 0 and *first_bad = a point that differs
+int tie_shim_same_as_tables(void* ha, uint32_t n, const uint32_t* leaf, const uint32_t* slot, const cilhip::TieNode* nodes, size_t n_nodes, uint32_t* first_bad) {
+  const Shim* a = static_cast<const Shim*>(ha);
+  *first_bad = 0xFFFFFFFFu;
+  if (a->tree.size() != n || a->tree.nodes().size() != n_nodes) return 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    bool ok = a->tree.slot_of()[i] == slot[i];
+    uint32_t na = a->tree.leaf_of()[i], nb = leaf[i];
+    if (ok && nb >= n_nodes) ok = false;
+    // a leaf's record holds the slot of its first point
+    if (ok && std::memcmp(&a->tree.nodes()[na].divlow, &nodes[nb].divlow, 4)) ok = false;
+    while (ok) {
+      const cilhip::TieNode &x = a->tree.nodes()[na], &y = nodes[nb];
+      if (x.info != y.info || (x.parent < 0) != (y.parent < 0)) { ok = false; break; }
+      if (x.parent < 0) break;
+      na = (uint32_t)x.parent; nb = (uint32_t)y.parent;
+      if (nb >= n_nodes) { ok = false; break; }
+      const cilhip::TieNode &px = a->tree.nodes()[na], &py = nodes[nb];
+      if (std::memcmp(&px.divlow, &py.divlow, 4) || std::memcmp(&px.divhigh, &py.divhigh, 4)) ok = false;
+    }
+    if (!ok) { *first_bad = i; return 0; }
   }
   return 1;
 }

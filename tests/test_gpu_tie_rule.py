@@ -485,3 +485,84 @@ def test_hundreds_of_copies_of_one_point(Context, orc):
         oi_l, _, _ = _ref_matches(tree, orc.transform_points(T, S), r2, len(S))
         assert np.array_equal(_signed(li), oi_l) and int(res.iterations) == 3, name
         ctx.close()
+
+
+def _shim():
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    so = os.path.join(root, "tests", "cpp", "bin", "libtie_order_shim.so")
+    if not os.path.exists(so):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", os.path.join(root, "tests", "cpp", "tie_order_shim.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.tie_shim_build_mt.restype = C.c_void_p
+    L.tie_shim_build_mt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint]
+    L.tie_shim_free.argtypes = [C.c_void_p]
+    L.tie_shim_same_as_tables.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    return L
+
+
+def _device_tables(L, D):
+    import time
+
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    rc = L.cilhip_tie_order_create(D.ctypes.data, len(D), C.byref(h))
+    dt = time.perf_counter() - t0
+    assert rc == capi.OK, rc
+    nn = C.c_size_t(0); depth = C.c_int(0)
+    L.cilhip_tie_order_tables(h, None, None, None, 0, C.byref(nn), C.byref(depth))
+    leaf = np.zeros(max(len(D), 1), np.uint32); slot = np.zeros(max(len(D), 1), np.uint32); nodes = np.zeros((max(nn.value, 1), 4), np.uint32)
+    L.cilhip_tie_order_tables(h, leaf.ctypes.data, slot.ctypes.data, nodes.ctypes.data, nn.value, None, None)
+    L.cilhip_tie_order_destroy(h)
+    return leaf, slot, nodes, nn.value, depth.value, dt
+
+
+def test_device_built_order_tables_are_the_host_restatement_s(hip_lib, Context):
+    """csrc/tie_build.hip against tests/cpp/tie_order_host.hpp (which tests/test_tie_order_cpu.py pins against the reference's own
+    nanoflann): the SAME permutation slot for slot and the same leaf-to-root path (depths, split dimensions, divlow / divhigh bit for
+    bit, child sides) for every point -- node ids are labels (breadth-first here, depth-first per worker there).  Random clouds with
+    duplicated points and a flat sheet (many coordinates ON a split plane), the reference's sensor frame (a lattice), an integer lattice,
+    the degenerate clouds of the CPU suite (hundreds of copies of one point, lines, clouds below a leaf) and sizes around the leaf size."""
+    sh = _shim()
+    rng = np.random.default_rng(11)
+    big = rng.random((400_000, 3), dtype=np.float32)
+    big[rng.choice(len(big), 20_000, replace=False)] = big[rng.choice(len(big), 20_000, replace=False)]
+    big[:30_000, 2] = np.float32(0.25)
+    f = np.load(os.path.join(HERE, "golden", "frames_full.npz"))
+    A = np.array([0.25, 0.5, 0.75], np.float32); B = np.array([0.75, 0.25, 0.5], np.float32)
+    clouds = {
+        "400k random, duplicates, a flat sheet": big,
+        "sensor frame_1": f["p1"],
+        "integer lattice 30^3": np.stack(np.meshgrid(*[np.arange(30, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3),
+        "300 + 300 copies of two points and 50 others": np.concatenate([np.tile(A, (300, 1)), np.tile(B, (300, 1)), rng.random((50, 3), dtype=np.float32)]),
+        "a line with doubled points": np.concatenate([np.stack([np.linspace(0, 1, 400, dtype=np.float32), np.full(400, 0.5, np.float32), np.full(400, 0.5, np.float32)], 1)] * 2),
+        "seven points, three of them the same": np.concatenate([rng.random((4, 3), dtype=np.float32), np.tile(A, (3, 1))]),
+        "one point five times": np.tile(B, (5, 1)),
+        "20000 copies of one point": np.tile(A, (20_000, 1)),
+    }
+    for n in (1, 2, 10, 11, 12, 21, 22, 23, 100, 1000):
+        clouds[f"{n} random points"] = rng.random((n, 3), dtype=np.float32)
+    report = {}
+    for name, D in clouds.items():
+        D = np.ascontiguousarray(D[rng.permutation(len(D))].astype(np.float32)) if len(D) > 1 else np.ascontiguousarray(D, np.float32)
+        leaf, slot, nodes, nn, depth, dt = _device_tables(hip_lib, D)
+        h = sh.tie_shim_build_mt(D.ctypes.data, len(D), 1)
+        bad = np.zeros(1, np.uint32)
+        same = sh.tie_shim_same_as_tables(h, len(D), leaf.ctypes.data, slot.ctypes.data, nodes.ctypes.data, nn, bad.ctypes.data)
+        sh.tie_shim_free(h)
+        assert same == 1, (name, "first differing point", int(bad[0]), "nodes", nn, "depth", depth)
+        assert sorted(slot[: len(D)].tolist()) == list(range(len(D))), name          # a permutation
+        report[name] = {"points": len(D), "nodes": nn, "depth": depth, "create_ms_incl_transfers": dt * 1e3}
+    # ... and the build a context does for its own target when its searches tie, timed (no host copy of the cloud involved)
+    for name, D in (("sensor frame_1", np.ascontiguousarray(f["p1"], np.float32)), ("400k", np.ascontiguousarray(big)), ("10M uniform", syn.make_dst(10_000_000))):
+        ctx = Context(0)
+        ctx.set_target(D, None)
+        ctx.build_tie_order()
+        ctx._ck(ctx._L.cilhip_synchronize(ctx._h))
+        info = ctx.tie_order_info()
+        assert info["loaded"] and info["builds"] == 1
+        report["context build, " + name] = {"points": len(D), "build_ms": info["build_ms"]}
+        ctx.close()
+    _report("tie_order_device_build.json", report)

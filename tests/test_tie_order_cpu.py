@@ -1,4 +1,5 @@
-"""csrc/tie_order.hpp (option "tie_rule" = 1) on the host: the tree restatement names, for every query with several exactly
+"""tests/cpp/tie_order_host.hpp (the host restatement of the index build behind option "tie_rule"; the product builds the same tables on the
+device: csrc/tie_build.hip, checked against this one in tests/test_gpu_tie_rule.py): the tree restatement names, for every query with several exactly
 equidistant nearest target points, the point the reference's nanoflann returns (core/kd_tree.hpp:82-90; oracle/_ref when built,
 the oracle's kd-tree restatement otherwise).  No GPU: the header is host-only, compiled by tests/cpp/build.sh into a shim."""
 import ctypes as C
