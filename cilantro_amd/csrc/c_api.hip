@@ -42,6 +42,8 @@ struct cilhip_ctx {
   double build_ms = 0.0;
   float dst_mean[3] = {0, 0, 0};
   uint32_t index_offset = 0;      // global index of this shard's first target point (target-sharded runs)
+  bool partial_target = false;    // this context holds only PART of the cloud the reference would index (an index shard, a spatial slab: cilhip_set_shard_info
+                                  // with an offset or the whole cloud's mean): the order tables are the WHOLE cloud's -- loaded (cilhip_load_tie_order), never built here
   uint32_t* d_inv_perm = nullptr; // [n_target] original local index -> sorted position (built on first use)
 
   // source
@@ -654,6 +656,7 @@ int cilhip_set_target(cilhip_ctx* c, const float* xyz, const float* nrm, size_t 
   if (c->d_dst_rgb_sorted) { (void)hipFree(c->d_dst_rgb_sorted); c->d_dst_rgb_sorted = nullptr; }
   c->has_normals = (nrm != nullptr);
   for (int i = 0; i < 3; ++i) c->dst_mean[i] = (float)mean[i];
+  c->partial_target = false;      // (a new target stands for itself until cilhip_set_shard_info says otherwise)
   c->has_target = true;
   c->src_sorted = false;  // source order is tied to the target grid
   drop_matches(c);
@@ -694,7 +697,7 @@ int cilhip_share_target(cilhip_ctx* c, cilhip_ctx* from) {
   c->grid = from->grid; c->has_target = true; c->has_normals = from->has_normals;
   c->grid_occ = from->grid_occ; c->grid_cells = from->grid_cells; c->build_ms = 0.0;
   for (int i = 0; i < 3; ++i) c->dst_mean[i] = from->dst_mean[i];
-  c->index_offset = from->index_offset;
+  c->index_offset = from->index_offset; c->partial_target = from->partial_target;
   c->d_inv_perm = from->d_inv_perm; c->d_safe2 = from->d_safe2;
   c->d_tie_leaf_slot = from->d_tie_leaf_slot; c->d_tie_nodes = from->d_tie_nodes;
   c->warm_banned = false;
@@ -1088,19 +1091,19 @@ static int build_rev_tie_tables(cilhip_ctx* c, const float T[16]) {
 // tie_rule 1: the tables before the first search; refusals of the explicit request (see tie_mode_on)
 static int tie_prepare(cilhip_ctx* c, const char* what) {
   c->tie_counters_fresh = false;      // (a new search / run: whatever the host holds of the counters is history)
-  if (c->tie_rule == 1 && (feat6(c) || (c->index_offset && !c->d_tie_leaf_slot))) {
+  if (c->tie_rule == 1 && (feat6(c) || (c->partial_target && !c->d_tie_leaf_slot))) {
     c->err = std::string(what) + ": tie_rule = 1 covers searches over point features (the 6-D / 9-D adaptors' trees are not restated) on a whole target or on shards with the whole target's order loaded (tie_rule = 2 applies the reference's order where it is defined)";
     return CILHIP_ERR_UNSUPPORTED;
   }
   if (c->tie_rule == 1 && c->search_dir != 0) c->rev_tie_aware = true;
   if (c->tie_rule == 0) c->rev_tie_aware = false;
-  if (c->tie_rule == 1 && tie_mode_on(c) && !c->index_offset && c->search_dir != 1 && c->ns && c->grid.n) return build_tie_tables(c);
+  if (c->tie_rule == 1 && tie_mode_on(c) && !c->partial_target && c->search_dir != 1 && c->ns && c->grid.n) return build_tie_tables(c);
   return CILHIP_OK;
 }
 // After a search / run: did it meet ties without tables (tie_rule 2)?  Then the tables are built and *again says: run it once more.
 static int tie_check_pending(cilhip_ctx* c, bool* again) {
   *again = false;
-  if (!tie_mode_on(c) || c->index_offset || !c->ns || !c->grid.n) return CILHIP_OK;
+  if (!tie_mode_on(c) || c->partial_target || !c->ns || !c->grid.n) return CILHIP_OK;      // (a part of a target: its caller loads the whole cloud's order)
   const bool fwd_open = !c->d_tie_leaf_slot && c->search_dir != 1;      // (forward matches: SECOND_TO_FIRST, the forward half of BOTH)
   const bool rev_open = !c->rev_tie_aware && c->search_dir != 0;
   if (!fwd_open && !rev_open) return CILHIP_OK;
@@ -1472,6 +1475,7 @@ int cilhip_load_tie_order(cilhip_ctx* c, const cilhip_tie_order* order, const ui
 int cilhip_build_tie_order(cilhip_ctx* c) {
   if (!c) return CILHIP_ERR_INVALID;
   if (!c->has_target) return fail(c, CILHIP_ERR_INVALID, "build_tie_order: set_target first");
+  if (c->partial_target) return fail(c, CILHIP_ERR_INVALID, "build_tie_order: this context holds a PART of a target (cilhip_set_shard_info): the order is the whole cloud's -- cilhip_tie_order_create + cilhip_load_tie_order");
   return build_tie_tables(c);
 }
 int cilhip_get_tie_order_info(cilhip_ctx* c, cilhip_tie_order_info* out) {
@@ -2617,6 +2621,7 @@ int cilhip_set_shard_info(cilhip_ctx* c, uint64_t target_index_offset, const flo
   if (!c) return CILHIP_ERR_INVALID;
   if (target_index_offset + (c->has_target ? c->grid.n : 0) > 0xFFFFFFFFull) return fail(c, CILHIP_ERR_INVALID, "global target indices must fit 32 bits");
   c->index_offset = (uint32_t)target_index_offset;
+  c->partial_target = target_index_offset != 0 || dst_mean != nullptr;      // (the whole cloud's mean handed in: this target is a part of it)
   if (dst_mean) memcpy(c->dst_mean, dst_mean, sizeof(c->dst_mean));
   if (src_mean) memcpy(c->src_mean, src_mean, sizeof(c->src_mean));
   return CILHIP_OK;

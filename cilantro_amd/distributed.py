@@ -78,26 +78,56 @@ def init_rank_comm(ctx, dist, group=None, device="cuda"):
 
 
 # Option "tie_rule" in sharded runs.  Which of several exactly equidistant nearest points the reference names is a property of the
-# tree it builds over the WHOLE target (csrc/tie_order.hpp).  The engines' kernels resolve ties from that tree's order tables when
+# tree it builds over the WHOLE target (csrc/tie_build.hip builds its order tables on the device).  The engines' kernels resolve ties from that tree's order tables when
 # they are loaded and COUNT the tied queries when they are not (tie_rule 2); the loops below look at the count after a run --
 # one MAX over the ranks, so that all take the same decision --, have every engine load the tables (built once per target and
 # process: _TIE_ORDERS) and run again.  Engines that know nothing of this (the CPU test engine) are never asked.
-_TIE_ORDERS = {}
+_TIE_ORDERS = {}      # content key of a target cloud -> order handle; at most _TIE_ORDERS_MAX of them (least recently used goes, with its handle)
+_TIE_ORDERS_MAX = 2
+
+
+def _tie_order_key(dst):
+    """a key of the cloud's CONTENT (a buffer reused in place for another cloud of the same size must not find the old tables)"""
+    try:
+        import xxhash
+
+        return (len(dst), xxhash.xxh64(memoryview(dst).cast("B")).intdigest())
+    except ImportError:
+        import zlib
+
+        return (len(dst), zlib.crc32(memoryview(dst).cast("B")))
+
+
+def _tie_order_known(dst):
+    dst = np.ascontiguousarray(np.asarray(dst, np.float32).reshape(-1, 3))
+    return _tie_order_key(dst) in _TIE_ORDERS
+
+
+def release_tie_orders():
+    """free every cached order handle (cilhip_tie_order_destroy)"""
+    L = capi.load()
+    for h in _TIE_ORDERS.values():
+        L.cilhip_tie_order_destroy(h)
+    _TIE_ORDERS.clear()
 
 
 def _tie_order_of(dst):
-    """handle of the order tables of the whole target cloud `dst` (host array), built on first use"""
+    """handle of the order tables of the whole target cloud `dst` (host array), built on first use (on the current HIP device)"""
     import ctypes as C
 
     dst = np.ascontiguousarray(np.asarray(dst, np.float32).reshape(-1, 3))
-    key = (dst.ctypes.data, len(dst))
-    if key not in _TIE_ORDERS:
-        h = C.c_void_p()
-        rc = capi.load().cilhip_tie_order_create(dst.ctypes.data, len(dst), C.byref(h))
-        if rc != 0:
-            raise RuntimeError("cilhip_tie_order_create failed")
-        _TIE_ORDERS[key] = (h, dst)      # (the array stays alive with its key)
-    return _TIE_ORDERS[key][0]
+    key = _tie_order_key(dst)
+    if key in _TIE_ORDERS:
+        _TIE_ORDERS[key] = _TIE_ORDERS.pop(key)      # (most recently used last)
+        return _TIE_ORDERS[key]
+    h = C.c_void_p()
+    rc = capi.load().cilhip_tie_order_create(dst.ctypes.data, len(dst), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"cilhip_tie_order_create failed ({rc})")
+    while len(_TIE_ORDERS) >= _TIE_ORDERS_MAX:      # (the handle keeps its own copy of the tables: nothing refers to the evicted cloud)
+        capi.load().cilhip_tie_order_destroy(_TIE_ORDERS.pop(next(iter(_TIE_ORDERS))))
+    _TIE_ORDERS[key] = h
+    return h
 
 
 def _ties_pending_anywhere(engine, dist, group, seen_before=False):
@@ -436,8 +466,7 @@ class HipSlabEngine(HipShardEngine):
         part.arm_guard(self.ctx)
         self._dst_all = np.ascontiguousarray(np.asarray(dst, np.float32).reshape(-1, 3))
         self._dst_index = np.ascontiguousarray(part.dst_index, np.uint32)
-        key = (self._dst_all.ctypes.data, len(self._dst_all))
-        if key in _TIE_ORDERS:      # (a re-partitioned engine of a target whose order is known: loaded at once)
+        if _tie_order_known(self._dst_all):      # (a re-partitioned engine of a target whose order is known: loaded at once)
             self.load_tie_order()
 
     def load_tie_order(self):
