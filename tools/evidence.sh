@@ -6,6 +6,7 @@
 #            groups), their summary, the traffic JSON (tools/make_traffic_json.py)
 #   search   the SQ / LDS counter passes of the tile kernel alone (tools/pmc_search.sh on the loop without warm start)
 #   configs  bench lines + kernel statistics of the other configurations (c2, c4_1gpu, kmeans, ransac)
+#   c5pmc    KMeans' pruned assignment under the SQ / LDS counter passes + every launch's duration
 #   regimes  the loop iteration by iteration (recipe / independent source / sensor frames / configs[3]'s shape), the real-cloud report,
 #            variants, search directions, the size sweep, the read-bandwidth probe, the tie-order build times
 #   full     the default line in full (extras + CPU baseline): the long one, last
@@ -47,6 +48,23 @@ if has configs; then
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$cfg -- $C2 > $O/bench_${cfg}_profiled.json 2> $O/trace_$cfg.log
     cp $O/trace_$cfg/*/*_kernel_stats.csv $O/config_${cfg}_kernel_stats.csv 2>/dev/null
   done
+  prune
+fi
+if has c5pmc; then
+  # KMeans' pruned assignment: the SQ / LDS counter passes that name its limiter, and every launch's duration (the 1.3 - 3.4 ms spread)
+  KM="python bench.py --config kmeans --no-cpu-baseline"
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/c5/sq -- $KM > $O/c5_sq.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VMEM_RD --output-format csv -d $O/c5/sq2 -- $KM > $O/c5_sq2.log 2>&1
+  python tools/pmc_summary.py $O/c5 k_assign > $O/config_c5_pmc_summary.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/c5/trace -- $KM > $O/c5_trace.log 2>&1
+  python - $O <<'PY' > $O/config_c5_launches.txt 2>&1
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/c5/trace/*/*_kernel_trace.csv"):
+    rows = [r for r in csv.DictReader(open(f)) if "k_assign_grid" in r["Kernel_Name"] or "k_centroid_grid" in r["Kernel_Name"] or "k_assign_accumulate" in r["Kernel_Name"]]
+    t0 = min(int(r["Start_Timestamp"]) for r in rows) if rows else 0
+    for i, r in enumerate(rows):
+        print(f"{i:3d} {r['Kernel_Name'][:48]:48s} start_ms={(int(r['Start_Timestamp']) - t0) / 1e6:9.3f} dur_us={(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:9.1f}")
+PY
   prune
 fi
 if has regimes; then
