@@ -15,7 +15,7 @@
 //                               misplaced L (position >= lim1, descending); everything else stays.  One exclusive scan of the flags gives
 //                               every element its rank, a scatter through two rank -> position tables moves the records.  Second pass: the
 //                               same over [lim1, count) with "value <= cut".  (The sweep's `right != 0` guards only end it; they never
-//                               leave an element on the wrong side: checked case by case in DESIGN 6.7.)
+//                               leave an element on the wrong side: checked case by case in DESIGN 6.10.)
 //
 // Node ids are breadth-first here (the host build numbers depth-first per worker): ids are labels -- tie_before() follows parent links
 // -- so the tables agree with the host's up to that relabelling; tests/test_gpu_tie_rule.py compares slot for slot and path for path.
