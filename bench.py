@@ -660,12 +660,19 @@ def bench_kmeans(a, torch, emit=True):
            "scaling": "weak", "vs_baseline": None, "dtype": "f32 distances / exact fixed-point sums", "data": "synthetic",
            "config": {"workload": f"kmeans: KMeans3f k = {k} on {n/1e6:g}M uniform points, initial centroids = the first k points, tol = 0", "n_points": n, "k": k,
                       "assignment": "pruned exactly: labels bit-identical to the exhaustive argmin (tests/test_gpu_parity.py::test_kmeans_pruned_assignment_is_the_exhaustive_one)"},
-           # the pruned pass is bound by neither ceiling: it gathers ~40 records per point out of LDS, lanes of a wave in different cells
+           # HBM and the arithmetic ceiling are both far away (fractions below); what binds the pruned pass is VALU ISSUE: roofline.limiter
            "roofline": {"bound": "hbm", "achieved": bytes_step * a.steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_step * a.steps / dt / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel": "k_assign_grid", "algorithmic_bytes_per_launch": bytes_step,
                         "valu_frac_of_evaluated_distances": 8.0 * read_evals / dt / 1e12 / VALU_NOFMA_PEAK_TFLOPS,
                         "note": "12 B point + label read + label written per point against 8 TB/s; the distances it does evaluate (>= 36 per point, 8 individually rounded f32 ops each) "
-                                "against the 78.6 TFLOP/s non-FMA vector ceiling: valu_frac_of_evaluated_distances -- the pass is a gather out of LDS with the lanes of a wave in different cells, bound by neither"},
+                                "against the 78.6 TFLOP/s non-FMA vector ceiling: valu_frac_of_evaluated_distances -- neither binds; `limiter` does",
+                        # counters of this kernel on this workload (profiles/r06_config_c5_pmc_summary.txt: SQ_INSTS_VALU of a steady-state launch) against the measured
+                        # issue rate of the instructions it is made of (profiles/r06_valu_rate_probe.txt: 2.0 ns per wave-instruction and SIMD, 1024 SIMDs)
+                        "limiter": ({"bound": "valu issue", "wave_instructions_per_launch": 6.15e8, "ns_per_wave_instruction_per_simd": 2.0, "simds": 1024,
+                                     "frac": 6.15e8 * 2.0e-9 / 1024.0 / (dt / a.steps),
+                                     "lds_array_busy": "about 0.7 (SQ_LDS_IDX_ACTIVE 5.5e8 cycles per launch over 256 CUs; 62 % of them bank conflicts: the lanes of a wave sit in different centroid cells)",
+                                     "source": "profiles/r06_config_c5_pmc_summary.txt, profiles/r06_valu_rate_probe.txt (counted on n = 50M, k = 1024)"}
+                                    if (n == 50_000_000 and k == 1024) else None)},
            "exhaustive_pass": {"ms_per_step": dt_ex * 1e3 / a.steps, "distances_per_sec": evals / dt_ex, "kernel": "k_assign_accumulate",
                                "roofline": {"bound": "valu", "achieved": flops_ex / dt_ex / 1e12, "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_ex / dt_ex / 1e12 / VALU_NOFMA_PEAK_TFLOPS,
                                             "note": "8 individually rounded f32 ops per distance (no FMA contraction: labels must match the reference bit for bit); peak = half of the 157.3 TFLOP/s FMA figure"}}}
