@@ -98,6 +98,9 @@ struct cilhip_ctx {
   // choice, the tables built when a search first MEETS a tie (that search / run is then executed again): a target that never ties never
   // pays for a tree.  The device resolves ties inside its search kernels (TieDev, kernels.hip: tie_settle).
   int tie_rule = 2;
+  uint2* d_tief_leaf_slot = nullptr;             // [grid.n] the order tables of the FEATURE tree (6-D / 9-D adaptors: points + weighted normals / colours), for the
+  uint4* d_tief_nodes = nullptr;                 // feature options they were built under (dropped with any of them); TieNode::info with four dimension bits
+  int tief_builds = 0;
   uint2* d_tie_leaf_slot = nullptr;              // [grid.n] the order tables by sorted target position (null: not loaded)
   uint4* d_tie_nodes = nullptr;
   unsigned int* d_tie_counters = nullptr;        // [4] TieDev::counters
@@ -257,6 +260,10 @@ static void release_target_share(cilhip_ctx* c) {
   }
   c->tshare = nullptr;
 }
+static void drop_feat_tie_tables(cilhip_ctx* c) {      // (one target under one set of feature options; never shared)
+  if (c->d_tief_leaf_slot) { (void)hipFree(c->d_tief_leaf_slot); c->d_tief_leaf_slot = nullptr; }
+  if (c->d_tief_nodes) { (void)hipFree(c->d_tief_nodes); c->d_tief_nodes = nullptr; }
+}
 static void drop_tie_tables(cilhip_ctx* c) {      // (they describe ONE target)
   target_ptr_free(c, c->d_tie_leaf_slot); c->d_tie_leaf_slot = nullptr;
   target_ptr_free(c, c->d_tie_nodes); c->d_tie_nodes = nullptr;
@@ -271,6 +278,7 @@ static void release_target(cilhip_ctx* c) {
   target_ptr_free(c, c->d_inv_perm); c->d_inv_perm = nullptr;
   target_ptr_free(c, c->d_safe2); c->d_safe2 = nullptr;
   drop_tie_tables(c);
+  drop_feat_tie_tables(c);
   release_target_share(c);
 }
 
@@ -509,18 +517,20 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   }
   if (!strcmp(key, "feature_normal_weight")) {
     if (!(value >= 0.0)) return fail(c, CILHIP_ERR_INVALID, "feature_normal_weight: >= 0 (0 = plain point features)");
+    if (c->normal_weight != (float)value) drop_feat_tie_tables(c);
     c->normal_weight = (float)value; drop_matches(c); c->have_pairs = false;
     return CILHIP_OK;
   }
   if (!strcmp(key, "feature_kind")) {
     if (value != 0.0 && value != 1.0 && value != 2.0)
       return fail(c, CILHIP_ERR_INVALID, "feature_kind: 0 = normals (follow the transform), 1 = colours (do not), 2 = normals + colours (9-D)");
-    if ((int)value != c->feature_kind) drop_src_grid(c);      // (the source's grid carries the feature vectors of the reverse searches)
+    if ((int)value != c->feature_kind) { drop_src_grid(c); drop_feat_tie_tables(c); }      // (the source's grid carries the feature vectors of the reverse searches)
     c->feature_kind = (int)value; drop_matches(c); c->have_pairs = false;
     return CILHIP_OK;
   }
   if (!strcmp(key, "feature_color_weight")) {
     if (!(value >= 0.0)) return fail(c, CILHIP_ERR_INVALID, "feature_color_weight: >= 0");
+    if (c->color_weight != (float)value) drop_feat_tie_tables(c);
     c->color_weight = (float)value; drop_matches(c); c->have_pairs = false;
     return CILHIP_OK;
   }
@@ -780,6 +790,7 @@ int cilhip_set_color_features(cilhip_ctx* c, const float* dst_rgb, const float* 
   c->dst_rgb_sorted_ok = false;
   c->src_sorted = false;                                   // the source's sorted copy is (re)built with the next sort
   drop_src_grid(c);      // (it carries the features of the reverse searches)
+  drop_feat_tie_tables(c);      // (the colours are coordinates of the feature tree)
   drop_matches(c);
   c->have_pairs = false; c->pairs.count = 0;
   return CILHIP_OK;
@@ -970,8 +981,18 @@ static bool tile_accumulation(const cilhip_ctx* c) {
 // the order belongs to the WHOLE target's tree -- whoever owns the shards loads it (cilhip_load_tie_order with the global indices) and
 // runs the two-key protocol between them (cilhip_icp_order_keys).
 static bool tie_mode_on(const cilhip_ctx* c) { return c->tie_rule != 0 && !feat6(c); }
+// ... and over 6-D / 9-D features: the forward (SECOND_TO_FIRST) search of a whole target follows the reference's DIM = 6 / 9 tree
+// (its order tables: tie_order_build_device_features; tie_settle<true> / tie_before_nd on the device)
+static bool tie_feat_on(const cilhip_ctx* c) { return c->tie_rule != 0 && feat6(c) && c->search_dir == 0 && !c->partial_target && !c->index_offset; }
 static TieDev tie_dev_of(const cilhip_ctx* c) {
   TieDev t{};
+  if (feat6(c)) {
+    t.mode = tie_feat_on(c) ? 1 : 0;
+    t.leaf_slot = t.mode ? c->d_tief_leaf_slot : nullptr;
+    t.nodes = c->d_tief_nodes;
+    t.counters = c->d_tie_counters;
+    return t;
+  }
   t.mode = tie_mode_on(c) ? 1 : 0;
   t.leaf_slot = t.mode ? c->d_tie_leaf_slot : nullptr;
   t.nodes = c->d_tie_nodes;
@@ -1089,12 +1110,47 @@ static int build_rev_tie_tables(cilhip_ctx* c, const float T[16]) {
   return CILHIP_OK;
 }
 // tie_rule 1: the tables before the first search; refusals of the explicit request (see tie_mode_on)
+static int ensure_feature_arrays(cilhip_ctx* c);
+static FeatSpec feat_spec_of(const cilhip_ctx* c);
+// The order tables of the tree the reference's feature adaptor searches (DIM = 6: points + weighted normals or colours; 9: + colours), for
+// this target under the CURRENT feature options, built on the device (tie_build.hip).
+static int build_feat_tie_tables(cilhip_ctx* c) {
+  if (c->d_tief_leaf_slot || !c->has_target) return CILHIP_OK;
+  CK(c, hipSetDevice(c->device));
+  { const int rc = ensure_feature_arrays(c); if (rc) return rc; }
+  const FeatSpec f = feat_spec_of(c);
+  const int dim = c->feature_kind == 2 ? 9 : 6;
+  if (!f.dst || (dim == 9 && !f.dst2)) return fail(c, CILHIP_ERR_INVALID, "tie_rule: the target's feature attributes (normals / colours) are not set");
+  const uint32_t n = c->grid.n;
+  uint32_t *d_leaf = nullptr, *d_slot = nullptr;
+  uint4* d_nodes = nullptr;
+  size_t n_nodes = 0;
+  hipError_t e = hipMalloc(&d_leaf, (n ? n : 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&d_slot, (n ? n : 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&c->d_tief_leaf_slot, (n ? n : 1) * sizeof(uint2));
+  if (e == hipSuccess) e = tie_order_build_device_features(dim, c->grid.pts, f.dst, f.w, f.dst2, f.w2, n, c->stream, d_leaf, d_slot, &d_nodes, &n_nodes, nullptr);
+  if (e == hipSuccess && !d_nodes) e = hipMalloc(&d_nodes, sizeof(uint4));
+  if (e == hipSuccess && n) { launch_tie_tables_by_position(c->grid.pts, n, d_leaf, d_slot, c->d_tief_leaf_slot, c->stream); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (d_leaf) (void)hipFree(d_leaf);
+  if (d_slot) (void)hipFree(d_slot);
+  if (e != hipSuccess) {
+    if (d_nodes) (void)hipFree(d_nodes);
+    drop_feat_tie_tables(c);
+    c->err = std::string("tie_rule: building the feature tree's order tables: ") + hipGetErrorString(e);
+    return CILHIP_ERR_HIP;
+  }
+  c->d_tief_nodes = d_nodes;
+  ++c->tief_builds;
+  return CILHIP_OK;
+}
 static int tie_prepare(cilhip_ctx* c, const char* what) {
   c->tie_counters_fresh = false;      // (a new search / run: whatever the host holds of the counters is history)
-  if (c->tie_rule == 1 && (feat6(c) || (c->partial_target && !c->d_tie_leaf_slot))) {
-    c->err = std::string(what) + ": tie_rule = 1 covers searches over point features (the 6-D / 9-D adaptors' trees are not restated) on a whole target or on shards with the whole target's order loaded (tie_rule = 2 applies the reference's order where it is defined)";
+  if (c->tie_rule == 1 && ((feat6(c) && !tie_feat_on(c)) || (!feat6(c) && c->partial_target && !c->d_tie_leaf_slot))) {
+    c->err = std::string(what) + ": tie_rule = 1 covers the SECOND_TO_FIRST search (point features: every direction) on a whole target, or on shards of a point-feature target with the whole target's order loaded (tie_rule = 2 applies the reference's order where it is defined)";
     return CILHIP_ERR_UNSUPPORTED;
   }
+  if (c->tie_rule == 1 && tie_feat_on(c) && c->ns && c->grid.n) return build_feat_tie_tables(c);
   if (c->tie_rule == 1 && c->search_dir != 0) c->rev_tie_aware = true;
   if (c->tie_rule == 0) c->rev_tie_aware = false;
   if (c->tie_rule == 1 && tie_mode_on(c) && !c->partial_target && c->search_dir != 1 && c->ns && c->grid.n) return build_tie_tables(c);
@@ -1103,6 +1159,17 @@ static int tie_prepare(cilhip_ctx* c, const char* what) {
 // After a search / run: did it meet ties without tables (tie_rule 2)?  Then the tables are built and *again says: run it once more.
 static int tie_check_pending(cilhip_ctx* c, bool* again) {
   *again = false;
+  if (tie_feat_on(c)) {      // a feature search: its forward matches counted tied queries while the feature tree's tables were not there
+    if (c->d_tief_leaf_slot || !c->ns || !c->grid.n) return CILHIP_OK;
+    unsigned int cnt[4];
+    if (c->tie_counters_fresh) memcpy(cnt, c->tie_counters_host, sizeof(cnt));
+    else { const int rc = read_tie_counters(c, cnt); if (rc) return rc; }
+    c->tie_counters_fresh = false;
+    if (cnt[0] == 0u) return CILHIP_OK;
+    *again = true;
+    CK(c, hipMemsetAsync(c->d_tie_counters, 0, 4 * sizeof(unsigned int), c->stream));
+    return build_feat_tie_tables(c);
+  }
   if (!tie_mode_on(c) || c->partial_target || !c->ns || !c->grid.n) return CILHIP_OK;      // (a part of a target: its caller loads the whole cloud's order)
   const bool fwd_open = !c->d_tie_leaf_slot && c->search_dir != 1;      // (forward matches: SECOND_TO_FIRST, the forward half of BOTH)
   const bool rev_open = !c->rev_tie_aware && c->search_dir != 0;
@@ -1483,7 +1550,7 @@ int cilhip_get_tie_order_info(cilhip_ctx* c, cilhip_tie_order_info* out) {
   CK(c, hipSetDevice(c->device));
   unsigned int cnt[4];
   { const int rc = read_tie_counters(c, cnt); if (rc) return rc; }
-  out->loaded = c->d_tie_leaf_slot ? 1 : 0; out->builds = c->tie_builds; out->build_ms = c->tie_build_ms; out->pending = cnt[0];
+  out->loaded = (feat6(c) ? c->d_tief_leaf_slot != nullptr : c->d_tie_leaf_slot != nullptr) ? 1 : 0; out->builds = c->tie_builds + c->tief_builds; out->build_ms = c->tie_build_ms; out->pending = cnt[0];
   return CILHIP_OK;
 }
 

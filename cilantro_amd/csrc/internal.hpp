@@ -383,6 +383,10 @@ struct TieNode {          // 16 bytes: one load on the device
 // records (hipMalloc'ed: the caller frees), breadth-first ids.
 hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, uint32_t n, hipStream_t s, uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index,
                                   uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out);
+// ... and of the tree a feature adaptor's search walks (DIM = 6 / 9: points + w1 * att1 [+ w2 * att2], attributes by sorted position);
+// TieNode::info there = (depth << 5) | (split dimension << 1) | second child (tie_before_nd)
+hipError_t tie_order_build_device_features(int dim, const float4* d_sorted, const float4* att1, float w1, const float4* att2, float w2, uint32_t n, hipStream_t s,
+                                           uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index, uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out);
 void launch_tie_tables_by_position(const float4* dst_sorted, uint32_t n, const uint32_t* leaf_by_index, const uint32_t* slot_by_index, uint2* leaf_slot, hipStream_t s);
 void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, const float T[16], float max_sq, unsigned long long* out, hipStream_t s);
 // squared distances of the stored matches under T, formed again with the search's pinned arithmetic (bit-identical to what the

@@ -202,8 +202,8 @@ __device__ __forceinline__ void scan_range_f6(const float4* __restrict__ pts, ui
     const float e0 = d6_pinned(qx, qy, qz, f, p0, n0, c0), e1 = d6_pinned(qx, qy, qz, f, p1, n1, c1);
     const unsigned long long k0 = ((unsigned long long)__float_as_uint(e0) << 32) | __float_as_uint(p0.w);
     const unsigned long long k1 = ((unsigned long long)__float_as_uint(e1) << 32) | __float_as_uint(p1.w);
-    if (k0 < best.key) { best.key = k0; best.pos = j; }
-    if (k1 < best.key) { best.key = k1; best.pos = j1; }
+    nn_take(best, k0, j);      // (the tie flag of option "tie_rule": the same 6-D / 9-D distance met on another point)
+    nn_take(best, k1, j1);
   }
 }
 
@@ -729,8 +729,30 @@ __device__ __forceinline__ void nn_search_group(const GridDev& g, float qx, floa
 // the next shell lies strictly beyond it (a cell at exactly the distance is looked at) -- and the first-met one kept as they stream by
 // (the traversal order of one query is a total order: pairwise comparisons suffice, any number of candidates).  Without tables the
 // query is counted for the host and keeps its match.
-__device__ __forceinline__ uint32_t tie_settle(const GridDev& g, const TieDev& tt, float qx, float qy, float qz, uint32_t pos, float bd) {
+// FEAT6: the same over 6-D / 9-D feature distances (every point at feature distance bd lies inside the 3-D ball of that radius: d6 >= d3), ordered by
+// the feature tree's tables (tie_before_nd; the query's feature vector = its point and transformed feature parts).
+__device__ __forceinline__ bool tie_before_nd(const TieDev& tt, const float* qf, uint32_t pa, uint32_t pb) {
+  const uint2 la = tt.leaf_slot[pa], lb = tt.leaf_slot[pb];
+  if (la.x == lb.x) return la.y < lb.y;
+  uint32_t na = la.x, nb = lb.x;
+  uint4 A = tt.nodes[na], B = tt.nodes[nb];
+  uint32_t a_second = 0;      // (TieNode::info of a feature tree: (depth << 5) | (split dimension << 1) | second child)
+  while ((A.y >> 5) > (B.y >> 5)) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; }
+  while ((B.y >> 5) > (A.y >> 5)) { nb = B.x; B = tt.nodes[nb]; }
+  while (na != nb) { a_second = A.y & 1u; na = A.x; A = tt.nodes[na]; nb = B.x; B = tt.nodes[nb]; }
+  const uint32_t feat = (A.y >> 1) & 15u;
+  float val = qf[0];
+#pragma unroll
+  for (uint32_t d = 1; d < 9; ++d) val = feat == d ? qf[d] : val;
+  const float diff1 = __fsub_rn(val, __uint_as_float(A.z)), diff2 = __fsub_rn(val, __uint_as_float(A.w));
+  const uint32_t first_is_second = __fadd_rn(diff1, diff2) < 0.0f ? 0u : 1u;
+  return a_second == first_is_second;
+}
+template <bool FEAT6 = false>
+__device__ __forceinline__ uint32_t tie_settle(const GridDev& g, const TieDev& tt, float qx, float qy, float qz, uint32_t pos, float bd, const Feat6* f6 = nullptr) {
   if (tt.leaf_slot == nullptr) { atomicAdd(tt.counters, 1u); return pos; }
+  float qf[9] = {qx, qy, qz, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (FEAT6) { qf[3] = f6->fx; qf[4] = f6->fy; qf[5] = f6->fz; qf[6] = f6->gx; qf[7] = f6->gy; qf[8] = f6->gz; }
   const float BIG = 1.0e9f;
   const int cx = (int)floorf(fminf(fmaxf((qx - g.ox) * g.inv_cell, -BIG), BIG)), cy = (int)floorf(fminf(fmaxf((qy - g.oy) * g.inv_cell, -BIG), BIG)),
             cz = (int)floorf(fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG));
@@ -757,9 +779,12 @@ __device__ __forceinline__ uint32_t tie_settle(const GridDev& g, const TieDev& t
         for (int r = 0; r < 2; ++r)
           for (uint32_t j = rb[r]; j < re[r]; ++j) {
             const float4 p = g.pts[j];
-            if (d2_pinned(qx, qy, qz, p.x, p.y, p.z) == bd) {
+            float e;
+            if (FEAT6) e = d6_pinned(qx, qy, qz, *f6, p, f6->nrm[j], f6->att2 != nullptr ? f6->att2[j] : make_float4(0.f, 0.f, 0.f, 0.f));
+            else e = d2_pinned(qx, qy, qz, p.x, p.y, p.z);
+            if (e == bd) {
               ++ncand;
-              if (j != cur && tie_before(tt, qx, qy, qz, j, cur)) cur = j;
+              if (j != cur && (FEAT6 ? tie_before_nd(tt, qf, j, cur) : tie_before(tt, qx, qy, qz, j, cur))) cur = j;
             }
           }
       }
@@ -2222,10 +2247,10 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
   // (margin keys / match records of the warm-started iterations: the generic search proves its result but keeps no bound on
   //  the other points -- "no bound known"; the warm kernel searches such a query itself and then has one)
   const float key_unknown_has = 0.0f, key_unknown_none = MARGIN_NONE_NO_MATCH;
-  auto finish = [&](uint32_t i, float qx, float qy, float qz, NN& best) {
+  auto finish = [&](uint32_t i, float qx, float qy, float qz, NN& best, const Feat6* f6 = nullptr) {
     // (option "tie_rule": a query whose nearest distance was met on two points -- the tiles send theirs here -- takes the reference's pick)
-    if (!FEAT6 && a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)
-      best.pos = tie_settle(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)));
+    if (a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)
+      best.pos = tie_settle<FEAT6>(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)), f6);
     a.nn_pos[i] = best.pos;
     if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
     if (ACC == IM_NONE && a.nn_lb) a.nn_lb[i] = best.pos != NONE_U32 ? key_unknown_has : key_unknown_none;
@@ -2334,10 +2359,11 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_deferred(IterArgs a, co
               Feat6 f;
               query_features(a, T, i, true, f);
               nn_search_group<TODO_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
+              if (sub == 0) finish(i, qx, qy, qz, best, &f);
             } else {
               nn_search_group<TODO_GROUP>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best);
+              if (sub == 0) finish(i, qx, qy, qz, best);
             }
-            if (sub == 0) finish(i, qx, qy, qz, best);
           }
         }
       }
@@ -2452,6 +2478,9 @@ __global__ __launch_bounds__(ITER_THREADS) void k_search_feat6(IterArgs a) {
   NN best;
   nn_search_group<FEAT6_GROUP, true>(a.grid, qx, qy, qz, a.max_sq, sub, 1, best, &f);
   if (sub == 0) {
+    // (option "tie_rule": exactly equal feature distances take the pick of the reference's DIM = 6 / 9 tree)
+    if (a.tie.mode != 0 && best.tie != 0u && best.pos != NONE_U32)
+      best.pos = tie_settle<true>(a.grid, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)), &f);
     a.nn_pos[i] = best.pos;
     if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
   }

@@ -37,52 +37,72 @@ constexpr uint32_t LEAF_MAX = 10;      // core/kd_tree.hpp:162-170
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int TB = 256;
 
-struct MM { float mn[3], mx[3]; };
-struct MMOp {
-  __host__ __device__ MM operator()(const MM& a, const MM& b) const {
-    MM r;
-    for (int d = 0; d < 3; ++d) { r.mn[d] = a.mn[d] < b.mn[d] ? a.mn[d] : b.mn[d]; r.mx[d] = a.mx[d] > b.mx[d] ? a.mx[d] : b.mx[d]; }
+// DIM = 3: the point tree of the ICP / k-NN searches; DIM = 6 / 9: the trees the reference's feature adaptors search (points + weighted
+// normals or colours; points + normals + colours: correspondence_search/common_transformable_feature_adaptors.hpp:60-343 through a
+// KDTree of that dimension).  The same build: nanoflann's code is generic in DIM.
+template <int DIM> struct Rec { float c[DIM]; uint32_t idx; };      // a record of the reference's vAcc_ with the coordinates alongside (DIM = 3: a float4)
+template <int DIM> struct MM { float mn[DIM], mx[DIM]; };
+template <int DIM> struct MMOp {
+  __host__ __device__ MM<DIM> operator()(const MM<DIM>& a, const MM<DIM>& b) const {
+    MM<DIM> r;
+    for (int d = 0; d < DIM; ++d) { r.mn[d] = a.mn[d] < b.mn[d] ? a.mn[d] : b.mn[d]; r.mx[d] = a.mx[d] > b.mx[d] ? a.mx[d] : b.mx[d]; }
     return r;
   }
 };
-struct ToMM {
-  __host__ __device__ MM operator()(const float4& p) const { return MM{{p.x, p.y, p.z}, {p.x, p.y, p.z}}; }
+template <int DIM> struct ToMM {
+  __host__ __device__ MM<DIM> operator()(const Rec<DIM>& p) const { MM<DIM> m; for (int d = 0; d < DIM; ++d) m.mn[d] = m.mx[d] = p.c[d]; return m; }
 };
+// TieNode::info: (depth << SHIFT) | (split dimension << 1) | second child -- two dimension bits for the point tree (the format of
+// tie_before / tie_rank), four for the feature trees (tie_before_nd)
+template <int DIM> struct InfoShift { static constexpr uint32_t value = DIM == 3 ? 3u : 5u; };
 
 // an internal node of the current level (more than LEAF_MAX points)
-struct Act {
-  uint32_t left, right;      // its slice of the record array
-  float blo[3], bhi[3];      // the box handed down to it (loose: the parent's box cut at the parent's cutval)
-  MM mm;                     // min / max of its points per dimension
-  uint32_t node, depth;      // its TieNode id
-  int feat; float cut;       // middleSplit_'s choice
-  uint32_t lim1, lim2, idx;  // planeSplit's limits, the split index
+template <int DIM> struct Act {
+  uint32_t left, right;        // its slice of the record array
+  float blo[DIM], bhi[DIM];    // the box handed down to it (loose: the parent's box cut at the parent's cutval)
+  MM<DIM> mm;                  // min / max of its points per dimension
+  uint32_t node, depth;        // its TieNode id
+  int feat; float cut;         // middleSplit_'s choice
+  uint32_t lim1, lim2, idx;    // planeSplit's limits, the split index
 };
 
-__device__ __forceinline__ float coord(const float4& p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
+template <int DIM> __device__ __forceinline__ float coord(const Rec<DIM>& p, int d) {
+  float v = p.c[0];
+#pragma unroll
+  for (int k = 1; k < DIM; ++k) v = d == k ? p.c[k] : v;
+  return v;
+}
 
-__global__ void k_init_recs(const float* __restrict__ xyz, uint32_t n, float4* __restrict__ recs, uint32_t* __restrict__ node_of) {
+__global__ void k_init_recs(const float* __restrict__ xyz, uint32_t n, Rec<3>* __restrict__ recs, uint32_t* __restrict__ node_of) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    recs[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __uint_as_float(i));
+    recs[i] = Rec<3>{{xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]}, i};
     node_of[i] = 0u;
   }
 }
-// records given as {x, y, z, bits(original index)} in ANY order (a grid's sorted points): back to the original order
-__global__ void k_init_recs_from_sorted(const float4* __restrict__ sorted, uint32_t n, float4* __restrict__ recs, uint32_t* __restrict__ node_of) {
+// records given as {x, y, z, bits(original index)} in ANY order (a grid's sorted points), with the feature parts the adaptors append
+// (w1 * att1[j], w2 * att2[j]: formed in f32 as the adaptors store them, :90 / :192 / :296): back to the original order
+template <int DIM>
+__global__ void k_init_recs_from_sorted(const float4* __restrict__ sorted, const float4* __restrict__ att1, float w1, const float4* __restrict__ att2, float w2,
+                                        uint32_t n, Rec<DIM>* __restrict__ recs, uint32_t* __restrict__ node_of) {
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const float4 p = sorted[j];
     const uint32_t i = __float_as_uint(p.w);
-    if (i < n) recs[i] = p;
+    Rec<DIM> r;
+    r.c[0] = p.x; r.c[1] = p.y; r.c[2] = p.z; r.idx = i;
+    if (DIM >= 6) { const float4 a = att1[j]; r.c[3] = __fmul_rn(w1, a.x); r.c[4] = __fmul_rn(w1, a.y); r.c[DIM >= 6 ? 5 : 0] = __fmul_rn(w1, a.z); }
+    if (DIM >= 9) { const float4 a = att2[j]; r.c[DIM >= 9 ? 6 : 0] = __fmul_rn(w2, a.x); r.c[DIM >= 9 ? 7 : 0] = __fmul_rn(w2, a.y); r.c[DIM >= 9 ? 8 : 0] = __fmul_rn(w2, a.z); }
+    if (i < n) recs[i] = r;
     node_of[j] = 0u;
   }
 }
 
 // the root: computeBoundingBox (:1846-1877) = min / max over all points (the one run of the first reduce_by_key)
-__global__ void k_root(const MM* __restrict__ agg, uint32_t n, Act* __restrict__ act, uint32_t* __restrict__ counts, uint4* __restrict__ nodes) {
+template <int DIM>
+__global__ void k_root(const MM<DIM>* __restrict__ agg, uint32_t n, Act<DIM>* __restrict__ act, uint32_t* __restrict__ counts, uint4* __restrict__ nodes) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  Act a{};
+  Act<DIM> a{};
   a.left = 0; a.right = n; a.mm = agg[0]; a.node = 0; a.depth = 0;
-  for (int d = 0; d < 3; ++d) { a.blo[d] = a.mm.mn[d]; a.bhi[d] = a.mm.mx[d]; }
+  for (int d = 0; d < DIM; ++d) { a.blo[d] = a.mm.mn[d]; a.bhi[d] = a.mm.mx[d]; }
   const bool leaf = n <= LEAF_MAX;
   counts[0] = leaf ? 0u : 1u;      // active nodes of level 0
   counts[1] = 1u;                  // nodes so far
@@ -91,38 +111,42 @@ __global__ void k_root(const MM* __restrict__ agg, uint32_t n, Act* __restrict__
 }
 
 // middleSplit_: the cut dimension and value of every active node
-__global__ void k_decide(Act* __restrict__ act, const uint32_t* __restrict__ counts) {
+template <int DIM>
+__global__ void k_decide(Act<DIM>* __restrict__ act, const uint32_t* __restrict__ counts) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= counts[0]) return;
-  Act& A = act[a];
+  Act<DIM>& A = act[a];
   const float EPS = 0.00001f;
   float max_span = __fsub_rn(A.bhi[0], A.blo[0]);
-  for (int d = 1; d < 3; ++d) { const float span = __fsub_rn(A.bhi[d], A.blo[d]); if (span > max_span) max_span = span; }
+  for (int d = 1; d < DIM; ++d) { const float span = __fsub_rn(A.bhi[d], A.blo[d]); if (span > max_span) max_span = span; }
   const float thr = __fmul_rn(__fsub_rn(1.0f, EPS), max_span);
   float max_spread = -1.0f, min_elem = 0.0f, max_elem = 0.0f;
   int feat = 0;
-  for (int d = 0; d < 3; ++d) {
+  for (int d = 0; d < DIM; ++d) {
     const float span = __fsub_rn(A.bhi[d], A.blo[d]);
     if (span >= thr) {
       const float spread = __fsub_rn(A.mm.mx[d], A.mm.mn[d]);
       if (spread > max_spread) { feat = d; max_spread = spread; min_elem = A.mm.mn[d]; max_elem = A.mm.mx[d]; }
     }
   }
-  const float split_val = __fadd_rn(A.blo[feat], A.bhi[feat]) / 2;
+  float lo_f = A.blo[0], hi_f = A.bhi[0];
+#pragma unroll
+  for (int d = 1; d < DIM; ++d) { lo_f = feat == d ? A.blo[d] : lo_f; hi_f = feat == d ? A.bhi[d] : hi_f; }
+  const float split_val = __fadd_rn(lo_f, hi_f) / 2;
   A.feat = feat;
   A.cut = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
 }
 
 // flags of a planeSplit pass: PASS 1 -- "not (value < cut)" over the node's slice; PASS 2 -- "value > cut" over [lim1, count)
-template <int PASS>
-__global__ void k_flags(const float4* __restrict__ recs, const uint32_t* __restrict__ node_of, const Act* __restrict__ act, uint32_t n, uint32_t* __restrict__ flags) {
+template <int DIM, int PASS>
+__global__ void k_flags(const Rec<DIM>* __restrict__ recs, const uint32_t* __restrict__ node_of, const Act<DIM>* __restrict__ act, uint32_t n, uint32_t* __restrict__ flags) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p <= n; p += gridDim.x * blockDim.x) {
     uint32_t f = 0;
     if (p < n) {
       const uint32_t a = node_of[p];
       if (a != NONE) {
-        const Act& A = act[a];
-        const float v = coord(recs[p], A.feat);
+        const Act<DIM>& A = act[a];
+        const float v = coord<DIM>(recs[p], A.feat);
         f = PASS == 1 ? (v < A.cut ? 0u : 1u) : ((p - A.left >= A.lim1 && v > A.cut) ? 1u : 0u);
       }
     }
@@ -133,13 +157,13 @@ __global__ void k_flags(const float4* __restrict__ recs, const uint32_t* __restr
 // ranks: S = exclusive scan of the flags.  Inside the pass's range [lo, hi) of a node: nF = flagged elements, nU = the others = the
 // limit; a flagged element at relative position < nU is misplaced (rank = flagged elements before it), an unflagged one at >= nU is
 // (rank from the right = unflagged elements behind it); rank -> position tables for the scatter.
-template <int PASS>
-__global__ void k_ranks(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ S, const uint32_t* __restrict__ node_of, Act* __restrict__ act, uint32_t n,
+template <int DIM, int PASS>
+__global__ void k_ranks(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ S, const uint32_t* __restrict__ node_of, Act<DIM>* __restrict__ act, uint32_t n,
                         uint32_t* __restrict__ posF, uint32_t* __restrict__ posU) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
     const uint32_t a = node_of[p];
     if (a == NONE) continue;
-    Act& A = act[a];
+    Act<DIM>& A = act[a];
     const uint32_t lo = PASS == 1 ? A.left : A.left + A.lim1, hi = A.right;
     if (p < lo) continue;
     const uint32_t nF = S[hi] - S[lo], nU = (hi - lo) - nF;
@@ -152,14 +176,14 @@ __global__ void k_ranks(const uint32_t* __restrict__ flags, const uint32_t* __re
 }
 // (a pass whose range is EMPTY -- lim1 == count cannot happen, see k_children -- never reaches p == lo: lim2 is preset there)
 
-template <int PASS>
-__global__ void k_scatter(const float4* __restrict__ in, float4* __restrict__ out, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ S,
-                          const uint32_t* __restrict__ node_of, const Act* __restrict__ act, uint32_t n, const uint32_t* __restrict__ posF, const uint32_t* __restrict__ posU) {
+template <int DIM, int PASS>
+__global__ void k_scatter(const Rec<DIM>* __restrict__ in, Rec<DIM>* __restrict__ out, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ S,
+                          const uint32_t* __restrict__ node_of, const Act<DIM>* __restrict__ act, uint32_t n, const uint32_t* __restrict__ posF, const uint32_t* __restrict__ posU) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
     uint32_t dest = p;
     const uint32_t a = node_of[p];
     if (a != NONE) {
-      const Act& A = act[a];
+      const Act<DIM>& A = act[a];
       const uint32_t lo = PASS == 1 ? A.left : A.left + A.lim1, hi = A.right;
       if (p >= lo) {
         const uint32_t nF = S[hi] - S[lo], nU = (hi - lo) - nF;
@@ -174,10 +198,11 @@ __global__ void k_scatter(const float4* __restrict__ in, float4* __restrict__ ou
 
 // the split index (:1169-1176 via middleSplit_ :1360-1371), the children's ids (breadth-first: 2 per active node, in the nodes' order)
 // and which of them go on (more than LEAF_MAX points): internal[2a + c]
-__global__ void k_children(Act* __restrict__ act, const uint32_t* __restrict__ counts, uint32_t* __restrict__ internal) {
+template <int DIM>
+__global__ void k_children(Act<DIM>* __restrict__ act, const uint32_t* __restrict__ counts, uint32_t* __restrict__ internal) {
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= counts[0]) { if (a == counts[0]) { internal[2 * a] = 0u; } return; }      // (one entry behind the last: the scan's total)
-  Act& A = act[a];
+  Act<DIM>& A = act[a];
   const uint32_t count = A.right - A.left;
   const uint32_t idx = A.lim1 > count / 2 ? A.lim1 : (A.lim2 < count / 2 ? A.lim2 : count / 2);
   A.idx = idx;
@@ -186,45 +211,53 @@ __global__ void k_children(Act* __restrict__ act, const uint32_t* __restrict__ c
 }
 
 // per record: the key of the child it now belongs to (2a + c), for the children's min / max
-__global__ void k_child_keys(const uint32_t* __restrict__ node_of, const Act* __restrict__ act, uint32_t n, uint32_t* __restrict__ keys) {
+template <int DIM>
+__global__ void k_child_keys(const uint32_t* __restrict__ node_of, const Act<DIM>* __restrict__ act, uint32_t n, uint32_t* __restrict__ keys) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
     const uint32_t a = node_of[p];
     keys[p] = a == NONE ? NONE : 2u * a + (p >= act[a].left + act[a].idx ? 1u : 0u);
   }
 }
-__global__ void k_store_mm(const uint32_t* __restrict__ uk, const MM* __restrict__ agg, const uint32_t* __restrict__ nruns, uint32_t cap, MM* __restrict__ child_mm) {
+template <int DIM>
+__global__ void k_store_mm(const uint32_t* __restrict__ uk, const MM<DIM>* __restrict__ agg, const uint32_t* __restrict__ nruns, uint32_t cap, MM<DIM>* __restrict__ child_mm) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= *nruns || r >= cap) return;
   if (uk[r] != NONE) child_mm[uk[r]] = agg[r];
 }
 
 // the node's record (split + the children's tight bounds along it, :1196-1205), the children's records, the next level's active nodes
-__global__ void k_finish(const Act* __restrict__ act, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ internal_scan, const MM* __restrict__ child_mm,
-                         uint4* __restrict__ nodes, uint32_t node_cap, Act* __restrict__ act_next, uint32_t* __restrict__ counts_next) {
+template <int DIM>
+__global__ void k_finish(const Act<DIM>* __restrict__ act, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ internal_scan, const MM<DIM>* __restrict__ child_mm,
+                         uint4* __restrict__ nodes, uint32_t node_cap, Act<DIM>* __restrict__ act_next, uint32_t* __restrict__ counts_next) {
+  constexpr uint32_t SH = InfoShift<DIM>::value;
   const uint32_t na = counts[0];
   const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a == 0) { counts_next[0] = internal_scan[2 * na]; counts_next[1] = counts[1] + 2u * na; }
   if (a >= na) return;
-  const Act& A = act[a];
+  const Act<DIM>& A = act[a];
   const uint32_t base = counts[1];      // ids of this level's children start here
-  const MM m1 = child_mm[2 * a], m2 = child_mm[2 * a + 1];
+  const MM<DIM> m1 = child_mm[2 * a], m2 = child_mm[2 * a + 1];
+  float dlow = m1.mx[0], dhigh = m2.mn[0];
+#pragma unroll
+  for (int d = 1; d < DIM; ++d) { dlow = A.feat == d ? m1.mx[d] : dlow; dhigh = A.feat == d ? m2.mn[d] : dhigh; }
   if (A.node < node_cap) {
     uint4 nd = nodes[A.node];
-    nd.y = (A.depth << 3) | ((uint32_t)A.feat << 1) | (nd.y & 1u);
-    nd.z = __float_as_uint(m1.mx[A.feat]);      // divlow
-    nd.w = __float_as_uint(m2.mn[A.feat]);      // divhigh
+    nd.y = (A.depth << SH) | ((uint32_t)A.feat << 1) | (nd.y & 1u);
+    nd.z = __float_as_uint(dlow);       // divlow
+    nd.w = __float_as_uint(dhigh);      // divhigh
     nodes[A.node] = nd;
   }
   for (uint32_t c = 0; c < 2; ++c) {
     const uint32_t id = base + 2u * a + c;
     const uint32_t left = c == 0 ? A.left : A.left + A.idx, right = c == 0 ? A.left + A.idx : A.right;
     const bool internal = (right - left) > LEAF_MAX;
-    if (id < node_cap) nodes[id] = make_uint4(A.node, ((A.depth + 1u) << 3) | c, internal ? 0u : left, 0u);      // (a leaf: z = the slot of its first point)
+    if (id < node_cap) nodes[id] = make_uint4(A.node, ((A.depth + 1u) << SH) | c, internal ? 0u : left, 0u);      // (a leaf: z = the slot of its first point)
     if (internal) {
-      Act B{};
+      Act<DIM> B{};
       B.left = left; B.right = right; B.node = id; B.depth = A.depth + 1u;
-      for (int d = 0; d < 3; ++d) { B.blo[d] = A.blo[d]; B.bhi[d] = A.bhi[d]; }
-      if (c == 0) B.bhi[A.feat] = A.cut; else B.blo[A.feat] = A.cut;
+      for (int d = 0; d < DIM; ++d) { B.blo[d] = A.blo[d]; B.bhi[d] = A.bhi[d]; }
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) if (A.feat == d) { if (c == 0) B.bhi[d] = A.cut; else B.blo[d] = A.cut; }
       B.mm = c == 0 ? m1 : m2;
       B.lim1 = B.lim2 = B.idx = 0;
       act_next[internal_scan[2 * a + c]] = B;
@@ -233,7 +266,8 @@ __global__ void k_finish(const Act* __restrict__ act, const uint32_t* __restrict
 }
 
 // every record of this level's nodes moves to its child: the next level's active index, or -- a leaf -- its final leaf and slot
-__global__ void k_descend(const float4* __restrict__ recs, uint32_t* __restrict__ node_of, const Act* __restrict__ act, const uint32_t* __restrict__ counts,
+template <int DIM>
+__global__ void k_descend(const Rec<DIM>* __restrict__ recs, uint32_t* __restrict__ node_of, const Act<DIM>* __restrict__ act, const uint32_t* __restrict__ counts,
                           const uint32_t* __restrict__ internal_scan, const uint32_t* __restrict__ internal, uint32_t n, uint32_t* __restrict__ leaf_by_index,
                           uint32_t* __restrict__ slot_by_index) {
   const uint32_t base = counts[1];
@@ -244,29 +278,31 @@ __global__ void k_descend(const float4* __restrict__ recs, uint32_t* __restrict_
     if (internal[2 * a + c]) node_of[p] = internal_scan[2 * a + c];
     else {
       node_of[p] = NONE;
-      const uint32_t i = __float_as_uint(recs[p].w);
+      const uint32_t i = recs[p].idx;
       leaf_by_index[i] = base + 2u * a + c;
       slot_by_index[i] = p;
     }
   }
 }
 // a cloud of at most LEAF_MAX points: the root is the only leaf
-__global__ void k_root_leaf(const float4* __restrict__ recs, uint32_t n, uint32_t* __restrict__ leaf_by_index, uint32_t* __restrict__ slot_by_index) {
+template <int DIM>
+__global__ void k_root_leaf(const Rec<DIM>* __restrict__ recs, uint32_t n, uint32_t* __restrict__ leaf_by_index, uint32_t* __restrict__ slot_by_index) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const uint32_t i = __float_as_uint(recs[p].w);
+  const uint32_t i = recs[p].idx;
   leaf_by_index[i] = 0u; slot_by_index[i] = p;
 }
 
 #define TB_TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
 
-}  // namespace
-
-// d_xyz: the cloud in its ORIGINAL order (3 floats per point), or d_sorted: {x, y, z, bits(original index)} records in any order (one
-// of the two).  d_leaf_by_index / d_slot_by_index: [n], by ORIGINAL index, as TieOrderTree::leaf_of() / slot_of().  *d_nodes_out: the
-// TieNode records (hipMalloc'ed here, the caller frees), *n_nodes_out how many; *max_depth_out the deepest node's depth.
-hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, uint32_t n, hipStream_t s, uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index,
-                                  uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out) {
+// The build.  Records come from d_xyz (DIM = 3: the cloud in its ORIGINAL order) or from d_sorted (+ the feature parts att1 / att2 by the
+// same positions, weighted): back to the original order first -- the reference's vAcc_ starts as 0 .. n-1.
+template <int DIM>
+hipError_t build_impl(const float* d_xyz, const float4* d_sorted, const float4* att1, float w1, const float4* att2, float w2, uint32_t n, hipStream_t s,
+                      uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index, uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out) {
+  typedef Rec<DIM> R;
+  typedef MM<DIM> M;
+  typedef Act<DIM> A;
   *d_nodes_out = nullptr; *n_nodes_out = 0; if (max_depth_out) *max_depth_out = 0;
   if (n == 0) return hipSuccess;
   hipError_t e = hipSuccess;
@@ -275,11 +311,11 @@ hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, ui
   // point), in practice ~0.3 n -- the node array grows by doubling when a level does not fit
   const uint32_t act_cap = n / (LEAF_MAX + 1) + 2;
   size_t node_cap = std::max<size_t>(1024, (size_t)n / 2 + 64);
-  float4 *recA = nullptr, *recB = nullptr;
+  R *recA = nullptr, *recB = nullptr;
   uint32_t *node_of = nullptr, *flags = nullptr, *S = nullptr, *posF = nullptr, *posU = nullptr, *keys = nullptr, *uk = nullptr, *internal = nullptr, *iscan = nullptr;
   uint32_t *counts = nullptr, *nruns = nullptr;
-  MM *agg = nullptr, *child_mm = nullptr;
-  Act *act0 = nullptr, *act1 = nullptr;
+  M *agg = nullptr, *child_mm = nullptr;
+  A *act0 = nullptr, *act1 = nullptr;
   uint4* nodes = nullptr;
   void *tmp = nullptr, *ws = nullptr;
   size_t tmp_bytes = 0;
@@ -291,41 +327,42 @@ hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, ui
       size_t b1 = 0, b2 = 0, b3 = 0;
       TB_TRY(rocprim::exclusive_scan(nullptr, b1, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s));
       TB_TRY(rocprim::exclusive_scan(nullptr, b2, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 2 * (size_t)act_cap + 1, rocprim::plus<uint32_t>(), s));
-      auto vals = rocprim::make_transform_iterator((const float4*)nullptr, ToMM());
-      TB_TRY(rocprim::reduce_by_key(nullptr, b3, (uint32_t*)nullptr, vals, (size_t)n, (uint32_t*)nullptr, (MM*)nullptr, (uint32_t*)nullptr, MMOp(), rocprim::equal_to<uint32_t>(), s));
+      auto vals = rocprim::make_transform_iterator((const R*)nullptr, ToMM<DIM>());
+      TB_TRY(rocprim::reduce_by_key(nullptr, b3, (uint32_t*)nullptr, vals, (size_t)n, (uint32_t*)nullptr, (M*)nullptr, (uint32_t*)nullptr, MMOp<DIM>(), rocprim::equal_to<uint32_t>(), s));
       tmp_bytes = std::max(b1, std::max(b2, b3));
     }
     // ONE allocation for the whole workspace (twenty hipMalloc / hipFree pairs were a third of a small cloud's build)
     {
       size_t off = 0;
       auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-      const size_t o_recA = take((size_t)n * sizeof(float4)), o_recB = take((size_t)n * sizeof(float4)), o_node = take((size_t)n * 4), o_flags = take(((size_t)n + 1) * 4),
+      const size_t o_recA = take((size_t)n * sizeof(R)), o_recB = take((size_t)n * sizeof(R)), o_node = take((size_t)n * 4), o_flags = take(((size_t)n + 1) * 4),
                    o_S = take(((size_t)n + 1) * 4), o_posF = take((size_t)n * 4), o_posU = take((size_t)n * 4), o_keys = take((size_t)n * 4), o_uk = take(run_cap * 4),
-                   o_agg = take(run_cap * sizeof(MM)), o_cmm = take((2 * (size_t)act_cap + 2) * sizeof(MM)), o_int = take((2 * (size_t)act_cap + 2) * 4),
-                   o_iscan = take((2 * (size_t)act_cap + 2) * 4), o_counts = take(16), o_nruns = take(4), o_act0 = take((size_t)act_cap * sizeof(Act)),
-                   o_act1 = take((size_t)act_cap * sizeof(Act)), o_tmp = take(tmp_bytes ? tmp_bytes : 16);
+                   o_agg = take(run_cap * sizeof(M)), o_cmm = take((2 * (size_t)act_cap + 2) * sizeof(M)), o_int = take((2 * (size_t)act_cap + 2) * 4),
+                   o_iscan = take((2 * (size_t)act_cap + 2) * 4), o_counts = take(16), o_nruns = take(4), o_act0 = take((size_t)act_cap * sizeof(A)),
+                   o_act1 = take((size_t)act_cap * sizeof(A)), o_tmp = take(tmp_bytes ? tmp_bytes : 16);
       TB_TRY(hipMalloc(&ws, off));
       unsigned char* b = static_cast<unsigned char*>(ws);
-      recA = (float4*)(b + o_recA); recB = (float4*)(b + o_recB); node_of = (uint32_t*)(b + o_node); flags = (uint32_t*)(b + o_flags); S = (uint32_t*)(b + o_S);
-      posF = (uint32_t*)(b + o_posF); posU = (uint32_t*)(b + o_posU); keys = (uint32_t*)(b + o_keys); uk = (uint32_t*)(b + o_uk); agg = (MM*)(b + o_agg);
-      child_mm = (MM*)(b + o_cmm); internal = (uint32_t*)(b + o_int); iscan = (uint32_t*)(b + o_iscan); counts = (uint32_t*)(b + o_counts); nruns = (uint32_t*)(b + o_nruns);
-      act0 = (Act*)(b + o_act0); act1 = (Act*)(b + o_act1); tmp = b + o_tmp;
+      recA = (R*)(b + o_recA); recB = (R*)(b + o_recB); node_of = (uint32_t*)(b + o_node); flags = (uint32_t*)(b + o_flags); S = (uint32_t*)(b + o_S);
+      posF = (uint32_t*)(b + o_posF); posU = (uint32_t*)(b + o_posU); keys = (uint32_t*)(b + o_keys); uk = (uint32_t*)(b + o_uk); agg = (M*)(b + o_agg);
+      child_mm = (M*)(b + o_cmm); internal = (uint32_t*)(b + o_int); iscan = (uint32_t*)(b + o_iscan); counts = (uint32_t*)(b + o_counts); nruns = (uint32_t*)(b + o_nruns);
+      act0 = (A*)(b + o_act0); act1 = (A*)(b + o_act1); tmp = b + o_tmp;
     }
     TB_TRY(hipMalloc(&nodes, node_cap * sizeof(uint4)));
-    if (d_sorted) hipLaunchKernelGGL(k_init_recs_from_sorted, dim3(gp), dim3(TB), 0, s, d_sorted, n, recA, node_of);
-    else hipLaunchKernelGGL(k_init_recs, dim3(gp), dim3(TB), 0, s, d_xyz, n, recA, node_of);
+    if (d_sorted) hipLaunchKernelGGL((k_init_recs_from_sorted<DIM>), dim3(gp), dim3(TB), 0, s, d_sorted, att1, w1, att2, w2, n, recA, node_of);
+    else if (DIM == 3) hipLaunchKernelGGL(k_init_recs, dim3(gp), dim3(TB), 0, s, d_xyz, n, reinterpret_cast<Rec<3>*>(recA), node_of);
+    else { e = hipErrorInvalidValue; goto done; }
     // the root's box: one run of key 0
     TB_TRY(hipMemsetAsync(keys, 0, (size_t)n * 4, s));
     {
-      auto vals = rocprim::make_transform_iterator(recA, ToMM());
+      auto vals = rocprim::make_transform_iterator((const R*)recA, ToMM<DIM>());
       size_t b = tmp_bytes;
-      TB_TRY(rocprim::reduce_by_key(tmp, b, keys, vals, (size_t)n, uk, agg, nruns, MMOp(), rocprim::equal_to<uint32_t>(), s));
+      TB_TRY(rocprim::reduce_by_key(tmp, b, keys, vals, (size_t)n, uk, agg, nruns, MMOp<DIM>(), rocprim::equal_to<uint32_t>(), s));
     }
-    hipLaunchKernelGGL(k_root, dim3(1), dim3(64), 0, s, agg, n, act0, counts, nodes);
+    hipLaunchKernelGGL((k_root<DIM>), dim3(1), dim3(64), 0, s, (const M*)agg, n, act0, counts, nodes);
     TB_TRY(hipMemcpyAsync(h_counts, counts, 8, hipMemcpyDeviceToHost, s));
     TB_TRY(hipStreamSynchronize(s));
-    if (h_counts[0] == 0) hipLaunchKernelGGL(k_root_leaf, dim3((n + TB - 1) / TB), dim3(TB), 0, s, recA, n, d_leaf_by_index, d_slot_by_index);
-    Act *cur = act0, *nxt = act1;
+    if (h_counts[0] == 0) hipLaunchKernelGGL((k_root_leaf<DIM>), dim3((n + TB - 1) / TB), dim3(TB), 0, s, (const R*)recA, n, d_leaf_by_index, d_slot_by_index);
+    A *cur = act0, *nxt = act1;
     uint32_t *cnt_cur = counts, *cnt_nxt = counts + 2;
     while (h_counts[0] != 0) {
       const uint32_t na = h_counts[0];
@@ -338,32 +375,36 @@ hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, ui
         (void)hipFree(nodes); nodes = nn; node_cap = ncap;
       }
       const unsigned ga = (na + TB) / TB + 1;
-      hipLaunchKernelGGL(k_decide, dim3(ga), dim3(TB), 0, s, cur, cnt_cur);
+      hipLaunchKernelGGL((k_decide<DIM>), dim3(ga), dim3(TB), 0, s, cur, (const uint32_t*)cnt_cur);
       // planeSplit, first pass: recA -> recB
-      hipLaunchKernelGGL(k_flags<1>, dim3(gp), dim3(TB), 0, s, recA, node_of, cur, n, flags);
+      hipLaunchKernelGGL((k_flags<DIM, 1>), dim3(gp), dim3(TB), 0, s, (const R*)recA, (const uint32_t*)node_of, (const A*)cur, n, flags);
       { size_t b = tmp_bytes; TB_TRY(rocprim::exclusive_scan(tmp, b, flags, S, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s)); }
-      hipLaunchKernelGGL(k_ranks<1>, dim3(gp), dim3(TB), 0, s, flags, S, node_of, cur, n, posF, posU);
-      hipLaunchKernelGGL(k_scatter<1>, dim3(gp), dim3(TB), 0, s, recA, recB, flags, S, node_of, cur, n, posF, posU);
+      hipLaunchKernelGGL((k_ranks<DIM, 1>), dim3(gp), dim3(TB), 0, s, (const uint32_t*)flags, (const uint32_t*)S, (const uint32_t*)node_of, cur, n, posF, posU);
+      hipLaunchKernelGGL((k_scatter<DIM, 1>), dim3(gp), dim3(TB), 0, s, (const R*)recA, recB, (const uint32_t*)flags, (const uint32_t*)S, (const uint32_t*)node_of, (const A*)cur, n,
+                         (const uint32_t*)posF, (const uint32_t*)posU);
       // second pass: recB -> recA
-      hipLaunchKernelGGL(k_flags<2>, dim3(gp), dim3(TB), 0, s, recB, node_of, cur, n, flags);
+      hipLaunchKernelGGL((k_flags<DIM, 2>), dim3(gp), dim3(TB), 0, s, (const R*)recB, (const uint32_t*)node_of, (const A*)cur, n, flags);
       { size_t b = tmp_bytes; TB_TRY(rocprim::exclusive_scan(tmp, b, flags, S, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s)); }
-      hipLaunchKernelGGL(k_ranks<2>, dim3(gp), dim3(TB), 0, s, flags, S, node_of, cur, n, posF, posU);
-      hipLaunchKernelGGL(k_scatter<2>, dim3(gp), dim3(TB), 0, s, recB, recA, flags, S, node_of, cur, n, posF, posU);
+      hipLaunchKernelGGL((k_ranks<DIM, 2>), dim3(gp), dim3(TB), 0, s, (const uint32_t*)flags, (const uint32_t*)S, (const uint32_t*)node_of, cur, n, posF, posU);
+      hipLaunchKernelGGL((k_scatter<DIM, 2>), dim3(gp), dim3(TB), 0, s, (const R*)recB, recA, (const uint32_t*)flags, (const uint32_t*)S, (const uint32_t*)node_of, (const A*)cur, n,
+                         (const uint32_t*)posF, (const uint32_t*)posU);
       // children
-      hipLaunchKernelGGL(k_children, dim3(ga), dim3(TB), 0, s, cur, cnt_cur, internal);
+      hipLaunchKernelGGL((k_children<DIM>), dim3(ga), dim3(TB), 0, s, cur, (const uint32_t*)cnt_cur, internal);
       { size_t b = tmp_bytes; TB_TRY(rocprim::exclusive_scan(tmp, b, internal, iscan, 0u, 2 * (size_t)na + 1, rocprim::plus<uint32_t>(), s)); }
-      hipLaunchKernelGGL(k_child_keys, dim3(gp), dim3(TB), 0, s, node_of, cur, n, keys);
+      hipLaunchKernelGGL((k_child_keys<DIM>), dim3(gp), dim3(TB), 0, s, (const uint32_t*)node_of, (const A*)cur, n, keys);
       {
-        auto vals = rocprim::make_transform_iterator(recA, ToMM());
+        auto vals = rocprim::make_transform_iterator((const R*)recA, ToMM<DIM>());
         size_t b = tmp_bytes;
-        TB_TRY(rocprim::reduce_by_key(tmp, b, keys, vals, (size_t)n, uk, agg, nruns, MMOp(), rocprim::equal_to<uint32_t>(), s));
+        TB_TRY(rocprim::reduce_by_key(tmp, b, keys, vals, (size_t)n, uk, agg, nruns, MMOp<DIM>(), rocprim::equal_to<uint32_t>(), s));
       }
       {
         const uint32_t rc = (uint32_t)std::min<size_t>(4 * (size_t)na + 4, 4 * (size_t)act_cap + 4);
-        hipLaunchKernelGGL(k_store_mm, dim3((rc + TB - 1) / TB), dim3(TB), 0, s, uk, agg, nruns, rc, child_mm);
+        hipLaunchKernelGGL((k_store_mm<DIM>), dim3((rc + TB - 1) / TB), dim3(TB), 0, s, (const uint32_t*)uk, (const M*)agg, (const uint32_t*)nruns, rc, child_mm);
       }
-      hipLaunchKernelGGL(k_finish, dim3(ga), dim3(TB), 0, s, cur, cnt_cur, iscan, child_mm, nodes, (uint32_t)std::min<size_t>(node_cap, 0xFFFFFFFFu), nxt, cnt_nxt);
-      hipLaunchKernelGGL(k_descend, dim3(gp), dim3(TB), 0, s, recA, node_of, cur, cnt_cur, iscan, internal, n, d_leaf_by_index, d_slot_by_index);
+      hipLaunchKernelGGL((k_finish<DIM>), dim3(ga), dim3(TB), 0, s, (const A*)cur, (const uint32_t*)cnt_cur, (const uint32_t*)iscan, (const M*)child_mm, nodes,
+                         (uint32_t)std::min<size_t>(node_cap, 0xFFFFFFFFu), nxt, cnt_nxt);
+      hipLaunchKernelGGL((k_descend<DIM>), dim3(gp), dim3(TB), 0, s, (const R*)recA, node_of, (const A*)cur, (const uint32_t*)cnt_cur, (const uint32_t*)iscan, (const uint32_t*)internal, n,
+                         d_leaf_by_index, d_slot_by_index);
       TB_TRY(hipGetLastError());
       TB_TRY(hipMemcpyAsync(h_counts, cnt_nxt, 8, hipMemcpyDeviceToHost, s));
       TB_TRY(hipStreamSynchronize(s));
@@ -381,6 +422,24 @@ done:
   if (ws) (void)hipFree(ws);
   if (nodes) (void)hipFree(nodes);
   return e;
+}
+
+}  // namespace
+
+// d_xyz: the cloud in its ORIGINAL order (3 floats per point), or d_sorted: {x, y, z, bits(original index)} records in any order (one
+// of the two).  d_leaf_by_index / d_slot_by_index: [n], by ORIGINAL index.  *d_nodes_out: the TieNode records (hipMalloc'ed here, the
+// caller frees), *n_nodes_out how many; *max_depth_out the deepest node's depth.
+hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, uint32_t n, hipStream_t s, uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index,
+                                  uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out) {
+  return build_impl<3>(d_xyz, d_sorted, nullptr, 0.0f, nullptr, 0.0f, n, s, d_leaf_by_index, d_slot_by_index, d_nodes_out, n_nodes_out, max_depth_out);
+}
+// The tree of a feature adaptor's search: records (p, w1 * att1[, w2 * att2]) from the grid's sorted points and the attributes at the same
+// positions; dim = 6 or 9.  Node records carry the split dimension in four bits: TieNode::info = (depth << 5) | (dimension << 1) | second child.
+hipError_t tie_order_build_device_features(int dim, const float4* d_sorted, const float4* att1, float w1, const float4* att2, float w2, uint32_t n, hipStream_t s,
+                                           uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index, uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out) {
+  if (dim == 6) return build_impl<6>(nullptr, d_sorted, att1, w1, nullptr, 0.0f, n, s, d_leaf_by_index, d_slot_by_index, d_nodes_out, n_nodes_out, max_depth_out);
+  if (dim == 9) return build_impl<9>(nullptr, d_sorted, att1, w1, att2, w2, n, s, d_leaf_by_index, d_slot_by_index, d_nodes_out, n_nodes_out, max_depth_out);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace cilhip

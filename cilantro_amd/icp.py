@@ -131,6 +131,15 @@ class Context:
         self._ck(self._L.cilhip_set_target(self._h, p, q, n, mem))
         self.n_target = n
 
+    def set_color_features(self, dst_colors, src_colors):
+        """per-point colours of both clouds (cilhip_set_color_features): the attribute of feature_kind 1 / the second attribute of feature_kind 2"""
+        d, nd, mem, _k1 = _as_cloud(dst_colors)
+        s, ns, mem2, _k2 = _as_cloud(src_colors)
+        if mem != mem2:
+            raise ValueError("colours of both clouds must live in the same memory space")
+        self._settle_device_inputs(mem)
+        self._ck(self._L.cilhip_set_color_features(self._h, d, s, mem))
+
     def share_target(self, other):
         """CorrespondenceSearchKDTree::setFirstSearchTree(other.getFirstSearchTree()) (correspondence_search_kd_tree.hpp:273-296): search the
         index `other` built -- and everything built on top of it so far -- instead of building one; nothing is copied, either context may go first"""

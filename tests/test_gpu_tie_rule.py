@@ -181,7 +181,8 @@ def test_every_kernel_form_resolves_ties(Context, orc):
 
 def test_tie_rule_1_refuses_what_the_order_does_not_cover(Context):
     """the explicit request covers every search over POINTS (all directions: the reverse matches' tables are built from the first
-    search on); the 6-D feature adaptors search another tree (nanoflann DIM = 6), which is not restated: refused, not silently approximated"""
+    search on) and the forward search of the 6-D / 9-D feature adaptors (the DIM = 6 / 9 tree over the target's features); the reverse
+    feature searches walk a tree over the transformed SOURCE features, which is not restated: refused, not silently approximated"""
     d = syn.make_pair(20_000, perturb=0.3)
     I = np.eye(4, dtype=np.float32)
     ctx = Context(); ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"], np.ascontiguousarray(d["dst_n"][: len(d["src"])]))
@@ -191,8 +192,12 @@ def test_tie_rule_1_refuses_what_the_order_does_not_cover(Context):
         ctx.find_correspondences(I, float(d["max_sq_dist"]))
     ctx.set_option("search_direction", 0)
     ctx.set_option("feature_normal_weight", 0.1)
-    with pytest.raises(RuntimeError):
-        ctx.find_correspondences(I, float(d["max_sq_dist"]))
+    ctx.find_correspondences(I, float(d["max_sq_dist"]))          # (round 6: the forward feature search follows the DIM = 6 tree; its tables are built up front)
+    assert ctx.tie_order_info()["loaded"]
+    for direction in (1, 2):                                        # the reverse feature searches walk a tree over the TRANSFORMED source features: not restated
+        ctx.set_option("search_direction", direction)
+        with pytest.raises(RuntimeError):
+            ctx.find_correspondences(I, float(d["max_sq_dist"]))
     # the default applies the order where it is defined and runs
     ctx.set_option("tie_rule", 2)
     ctx.find_correspondences(I, float(d["max_sq_dist"]))
@@ -566,3 +571,80 @@ def test_device_built_order_tables_are_the_host_restatement_s(hip_lib, Context):
         report["context build, " + name] = {"points": len(D), "build_ms": info["build_ms"]}
         ctx.close()
     _report("tie_order_device_build.json", report)
+
+
+def test_feature_searches_follow_the_reference_s_feature_tree_on_ties(Context, orc):
+    """PointNormalFeaturesAdaptor / PointColorFeaturesAdaptor / PointNormalColorFeaturesAdaptor (common_transformable_feature_adaptors.hpp:60-343):
+    the reference searches a KDTree of DIM = 6 / 9 over (p, w n [, wc c]); among EXACTLY equal feature distances it keeps the first point that
+    tree's traversal meets.  Targets whose feature vectors repeat -- doubled / tripled points with their normals and colours, a lattice with one
+    normal for all -- through both search kernels, with DEFAULT options: every index equals the reference's own nanoflann instantiated for that
+    DIM (oracle/_ref), where a lowest-index rule differs on thousands of queries; tie_rule 1 (tables up front) the same."""
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref is not built")
+    rng = np.random.default_rng(51)
+    base = syn.make_pair(30_000, perturb=0.4)
+    h = base["h"]
+    nd = len(base["dst"])
+    D = np.ascontiguousarray(np.concatenate([base["dst"], base["dst"][:9000], base["dst"][:3000]]))
+    N = np.ascontiguousarray(np.concatenate([base["dst_n"], base["dst_n"][:9000], base["dst_n"][:3000]]))
+    Cd = rng.random((nd, 3)).astype(np.float32)
+    Cd = np.ascontiguousarray(np.concatenate([Cd, Cd[:9000], Cd[:3000]]))
+    S = base["src"]
+    Ti = np.linalg.inv(base["T_true"].astype(np.float64)).astype(np.float32)
+    Sn = orc.transform_normals(Ti, base["dst_n"])
+    Cs = np.clip(Cd[:len(S)] + rng.normal(0, 0.05, (len(S), 3)), 0, 1).astype(np.float32)
+    lat = np.ascontiguousarray(np.stack(np.meshgrid(*[np.arange(22, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * np.float32(h))
+    latn = np.ascontiguousarray(np.tile(np.array([0.0, 0.6, 0.8], np.float32), (len(lat), 1)))
+    lats = np.ascontiguousarray(lat[:6000] + np.float32(0.5 * h))              # queries on cell centres: eight equidistant corners each
+    T = base["T_true"].astype(np.float32).copy(); T[:3, 3] += np.float32(0.15 * h)
+    I = np.eye(4, dtype=np.float32)
+    wn, wc = 0.6 * h, 0.8 * h
+    r2 = float((3.0 * h) ** 2)
+    report = {}
+    cases = [("doubled points, 6-D normals", D, N, None, S, Sn, None, T, 0), ("doubled points, 6-D colours", D, N, Cd, S, Sn, Cs, T, 1),
+             ("doubled points, 9-D", D, N, Cd, S, Sn, Cs, T, 2), ("lattice, one normal, 6-D", lat, latn, None, lats, latn[:len(lats)], None, I, 0)]
+    for name, dst, dn, dc, src, sn, sc, Tq, kind in cases:
+        if kind == 0:
+            dstf, srcf = orc.point_normal_features(dst, dn, wn), orc.point_normal_features(src, sn, wn)
+            qf = orc.transform_features6(Tq, srcf, 0)
+            oi, osrc, od = orc.find_correspondences_feat6(dstf, qf, r2, use_ref=True)
+        elif kind == 1:
+            dstf, srcf = orc.point_normal_features(dst, dc, wc), orc.point_normal_features(src, sc, wc)
+            qf = orc.transform_features6(Tq, srcf, 2)
+            oi, osrc, od = orc.find_correspondences_feat6(dstf, qf, r2, use_ref=True)
+        else:
+            dstf, srcf = orc.point_normal_color_features(dst, dn, dc, wn, wc), orc.point_normal_color_features(src, sn, sc, wn, wc)
+            qf = orc.transform_features9(Tq, srcf, 0)
+            oi, osrc, od = orc.find_correspondences_feat9(dstf, qf, r2, use_ref=True)
+        want = np.full(len(src), -1, np.int64); want[osrc] = oi
+        for tiled in (0, 2):
+            for rule in (2, 1, 0):
+                ctx = Context()
+                ctx.set_option("tiled", tiled); ctx.set_option("tie_rule", rule)
+                ctx.set_target(dst, dn); ctx.set_source(src, sn)
+                if kind >= 1:
+                    ctx.set_color_features(dc, sc)
+                ctx.set_option("feature_kind", kind)
+                if kind != 1:
+                    ctx.set_option("feature_normal_weight", wn)
+                else:
+                    ctx.set_option("feature_normal_weight", wc)
+                if kind == 2:
+                    ctx.set_option("feature_color_weight", wc)
+                ctx.find_correspondences(Tq, r2)
+                gi, gd = ctx.get_nn()
+                gi = _signed(gi)
+                info = ctx.tie_order_info()
+                ctx.close()
+                nbad = int(np.count_nonzero(gi != want))
+                if rule == 0:
+                    report.setdefault(name, {})["queries"] = len(src)
+                    report[name]["indices a lowest-index rule answers differently"] = nbad
+                else:
+                    assert nbad == 0, (name, tiled, rule, nbad)
+                    assert info["loaded"], (name, tiled, rule)
+                if rule != 0:      # ... and the distances bit for bit (osrc ascends: the reference's list is in source order)
+                    assert np.array_equal(gd[gi >= 0].view(np.uint32), od.view(np.uint32))
+    assert report["doubled points, 6-D normals"]["indices a lowest-index rule answers differently"] > 1000
+    assert report["lattice, one normal, 6-D"]["indices a lowest-index rule answers differently"] > 1000
+    _report("tie_rule_features.json", report)
