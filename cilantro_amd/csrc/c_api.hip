@@ -975,8 +975,9 @@ static bool tile_accumulation(const cilhip_ctx* c) {
 // ---- option "tie_rule": the reference's order among exactly equidistant nearest points ------------------------------------------
 // Is the option in force for this context's searches?  The order is the reference's kd-tree over the TARGET POINTS: it covers the
 // SECOND_TO_FIRST matches (also the forward half of BOTH) under rigid and affine transforms.  Feature adaptors search another
-// space (nanoflann's DIM = 6 / 9 tree), the reverse matches of FIRST_TO_SECOND / BOTH a tree over the transformed SOURCE that the
-// reference rebuilds every iteration: those keep the lowest index (tie_rule 2) or are refused (tie_rule 1, the explicit request).  An
+// space (nanoflann's DIM = 6 / 9 tree: tie_feat_on below), the reverse matches of FIRST_TO_SECOND / BOTH a tree over the transformed
+// SOURCE that the reference rebuilds every iteration (rev_tie_aware); the feature adaptors' reverse searches keep the lowest index
+// (tie_rule 2) or are refused (tie_rule 1, the explicit request).  An
 // index shard of a target (cilhip_set_shard_info) notices and counts ties like any context, but never builds tables from its own points:
 // the order belongs to the WHOLE target's tree -- whoever owns the shards loads it (cilhip_load_tie_order with the global indices) and
 // runs the two-key protocol between them (cilhip_icp_order_keys).

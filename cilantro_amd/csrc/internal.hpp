@@ -115,7 +115,7 @@ struct CorrWeights {
 
 struct F3 { float x, y, z; };      // 12-byte record (one global_load_dwordx3 per lane)
 
-// Which of several EXACTLY equidistant nearest target points a correspondence names (option "tie_rule"; tie_order.hpp has the
+// Which of several EXACTLY equidistant nearest target points a correspondence names (option "tie_rule"; tie_build.hip has the
 // why and the host side).  mode 0: the lowest target index -- what the packed keys give by themselves, nothing below is read.
 // mode 1: the point the reference's kd-tree traversal meets first.  Every search notices when the smallest distance was met on a
 // second point (an equality test beside the key compare); such a query is then looked at once more by tie_settle(): with the
@@ -255,7 +255,7 @@ constexpr int RUN_TRACE_CAP = 256;
 // Does the reference's traversal for query q reach the target point at sorted position pa before the one at pb?  Same leaf: the lower
 // slot of the reference's permutation.  Otherwise walk both leaves up to their lowest common ancestor (parents + depths); there
 // nanoflann's searchLevel (nanoflann.hpp:1931-1947) descends first into the child on the query's side of the split:
-// (val - divlow) + (val - divhigh) < 0 -> the first child.  (csrc/tie_order.hpp: before(); pinned against the reference's own
+// (val - divlow) + (val - divhigh) < 0 -> the first child.  (tests/cpp/tie_order_host.hpp: before(), the host restatement; pinned against the reference's own
 // nanoflann by tests/test_tie_order_cpu.py.)
 __device__ __forceinline__ bool tie_before(const TieDev& tt, float qx, float qy, float qz, uint32_t pa, uint32_t pb) {
   const uint2 la = tt.leaf_slot[pa], lb = tt.leaf_slot[pb];
@@ -381,6 +381,7 @@ struct TieNode {          // 16 bytes: one load on the device
 // d_sorted -- {x, y, z, bits(original index)} records in any order (exactly one non-null).  Output by ORIGINAL index: the leaf node of
 // every point and its slot in the reference's permutation (device arrays [n] the caller provides); *d_nodes_out: the TieNode
 // records (hipMalloc'ed: the caller frees), breadth-first ids.
+extern int g_knn_tie_rule;      // knn.hip: cilhip_knn_set_tie_rule (k-NN lists and the KMeans kd branch)
 hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, uint32_t n, hipStream_t s, uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index,
                                   uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out);
 // ... and of the tree a feature adaptor's search walks (DIM = 6 / 9: points + w1 * att1 [+ w2 * att2], attributes by sorted position);

@@ -4057,7 +4057,7 @@ void launch_count_ties(const GridDev& g, const float4* src_sorted, uint32_t ns, 
   hipLaunchKernelGGL(k_count_ties, dim3((int)((ns + 255u) / 256u < 4096u ? (ns + 255u) / 256u : 4096u)), dim3(256), 0, s, g, src_sorted, ns, t, max_sq, out);
 }
 
-// the order tables of option "tie_rule" (tie_order.hpp) arrive by ORIGINAL target index; the searches know sorted positions
+// the order tables of option "tie_rule" (tie_build.hip) arrive by ORIGINAL target index; the searches know sorted positions
 __global__ void k_tie_tables_by_position(const float4* __restrict__ dst_sorted, uint32_t n, const uint32_t* __restrict__ leaf_by_index,
                                          const uint32_t* __restrict__ slot_by_index, uint2* __restrict__ leaf_slot) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

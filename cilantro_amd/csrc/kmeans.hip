@@ -11,6 +11,7 @@
 // d2 is (c-x).squaredNorm() with Eigen's 3-term redux pairing d0*d0 + (d1*d1 + d2*d2), no FMA contraction,
 // so labels are bit-identical to the reference given identical centroids.
 #include "../../include/cilantro_hip/c_api.h"
+#include "internal.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -33,11 +34,16 @@ struct KmArgs {
   unsigned int* changed;   // [1]
   double scale;            // 2^S
   int accumulate;
+  cilhip::TieDev tie;      // KD only: order tables of the reference's tree over THIS iteration's centroids, by centroid index (leaf_slot null: none)
 };
 
 // KD: the distance the reference's kd-tree branch compares (use_kd_tree = true, kmeans.hpp:86-94: a KDTree over the centroids,
 // nanoflann's L2 metric) -- ((dx*dx) + (dy*dy)) + (dz*dz) -- instead of the brute-force branch's Eigen squaredNorm pairing
 // dx*dx + (dy*dy + dz*dz) (:107).  Same argmin except where two centroids are equidistant to within that rounding.
+// Among centroids at EXACTLY the same distance the tree returns the one its traversal meets first (nanoflann keeps a candidate on a
+// strict '<' only): the pass notices such points -- a later block's minimum equal to the best so far, or two hits inside the winning
+// block -- and settles them with tie_before() over the order tables of the tree the reference would have built on these centroids
+// (tie_build.hip, rebuilt every Lloyd iteration like the reference's KDTree, kmeans.hpp:87).  No tables: the lowest index.
 template <bool KD>
 __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
   extern __shared__ long long lsum[];  // [k*4]
@@ -58,6 +64,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
     // block is evaluated again and its first centroid at exactly that distance is the label.  The same distances bit for bit.
     f32x2 best = {INFINITY, INFINITY};
     uint32_t c0 = 0, c1 = 0;      // first centroid of the winning block, per point
+    bool t0 = false, t1 = false;  // (KD) the best distance was met more than once
     // centroids are padded to a multiple of 8 (pad = +inf: never the minimum); 24 consecutive floats per
     // block of 8 come through the scalar cache with wide s_load's, one wait per 8 candidates
     for (uint32_t j = 0; j < a.k; j += 8) {
@@ -72,15 +79,17 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
         const f32x2 d = KD ? (dx * dx + dy * dy) + dz * dz : dx * dx + (dy * dy + dz * dz);     // (-ffp-contract=off)
         m.x = fminf(m.x, d.x); m.y = fminf(m.y, d.y);
       }
-      if (m.x < best.x) { best.x = m.x; c0 = j; }
-      if (m.y < best.y) { best.y = m.y; c1 = j; }
+      if (m.x < best.x) { best.x = m.x; c0 = j; t0 = false; }
+      else if (KD && m.x == best.x && m.x < INFINITY) t0 = true;
+      if (m.y < best.y) { best.y = m.y; c1 = j; t1 = false; }
+      else if (KD && m.y == best.y && m.y < INFINITY) t1 = true;
     }
     uint32_t b0 = 0, b1 = 0;
     {
       // the winning block once more, per point (the two points of a lane usually won in different blocks); nothing below the
       // smallest distance exists, so the first centroid AT it is the argmin; no finite minimum at all (non-finite data): label 0,
       // as a chain of strict compares from (inf, 0) leaves it
-      uint32_t f0 = 8, f1 = 8;
+      uint32_t f0 = 8, f1 = 8, h0 = 0, h1 = 0;
 #pragma unroll
       for (int u = 7; u >= 0; --u) {
         const float ax = a.centroids[3 * (c0 + u)], ay = a.centroids[3 * (c0 + u) + 1], az = a.centroids[3 * (c0 + u) + 2];
@@ -88,11 +97,24 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
         const float dx0 = ax - px.x, dy0 = ay - py.x, dz0 = az - pz.x, dx1 = bx - px.y, dy1 = by - py.y, dz1 = bz - pz.y;
         const float d0 = KD ? (dx0 * dx0 + dy0 * dy0) + dz0 * dz0 : dx0 * dx0 + (dy0 * dy0 + dz0 * dz0);
         const float d1 = KD ? (dx1 * dx1 + dy1 * dy1) + dz1 * dz1 : dx1 * dx1 + (dy1 * dy1 + dz1 * dz1);
-        if (d0 == best.x) f0 = (uint32_t)u;
-        if (d1 == best.y) f1 = (uint32_t)u;
+        if (d0 == best.x) { f0 = (uint32_t)u; ++h0; }
+        if (d1 == best.y) { f1 = (uint32_t)u; ++h1; }
       }
       b0 = (best.x < INFINITY && f0 < 8) ? c0 + f0 : 0u;
       b1 = (best.y < INFINITY && f1 < 8) ? c1 + f1 : 0u;
+      if (KD && a.tie.leaf_slot != nullptr) {
+        // every centroid at the best distance, the one the reference's traversal reaches first (rare: the loop is scalar per point)
+        auto settle = [&](float qx, float qy, float qz, float bd, uint32_t cur) {
+          for (uint32_t j = 0; j < a.k; ++j) {
+            const float dx = a.centroids[3 * j] - qx, dy = a.centroids[3 * j + 1] - qy, dz = a.centroids[3 * j + 2] - qz;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if (d == bd && j != cur && cilhip::tie_before(a.tie, qx, qy, qz, j, cur)) cur = j;
+          }
+          return cur;
+        };
+        if ((t0 || h0 > 1) && best.x < INFINITY) b0 = settle(px.x, py.x, pz.x, best.x, b0);
+        if ((t1 || h1 > 1) && best.y < INFINITY) b1 = settle(px.y, py.y, pz.y, best.y, b1);
+      }
     }
     const bool two = (2 * pidx + 1) < a.n;
     changed += (a.labels[i0] != b0) ? 1u : 0u;
@@ -321,6 +343,11 @@ __global__ void k_maxabs_bits(const float* __restrict__ v, size_t count, unsigne
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+__global__ void k_zip_tables(const uint32_t* __restrict__ leaf, const uint32_t* __restrict__ slot, uint2* __restrict__ out, uint32_t k) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < k) out[j] = make_uint2(leaf[j], slot[j]);
+}
+
 __global__ void k_set_label(uint32_t* labels, uint32_t i, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) labels[i] = v; }
 
 // the pruned pass is the default; cilhip_kmeans_set_pruning(0) (or CILHIP_KMEANS_PRUNE=0 in the environment) keeps the brute-force pass
@@ -350,6 +377,9 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
   std::vector<uint32_t> cstart_host;
   float4* d_cs = nullptr;
   uint32_t* d_cstart = nullptr;
+  uint32_t* d_tleaf = nullptr;      // kd branch: order tables of the reference's tree over the centroids (leaf, slot by centroid index)
+  uint2* d_tls = nullptr;
+  uint4* d_tnodes = nullptr;
   size_t iter = 0;
   {
     KM_CK(hipSetDevice(device));
@@ -394,7 +424,20 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
       KM_CK(hipMemcpyAsync(d_c, cpad.data(), 3 * kpad * sizeof(float), hipMemcpyHostToDevice, s));
       KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
       KM_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
-      KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1};
+      KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1, {nullptr, nullptr, nullptr, 0}};
+      if (kd_order && cilhip::g_knn_tie_rule != 0 && k > 1) {
+        // the tree the reference builds over THIS iteration's centroids (kmeans.hpp:87), as order tables (about a millisecond)
+        bool finite = true;
+        for (size_t t = 0; t < 3 * k; ++t) finite = finite && std::isfinite(centroids[t]);
+        if (finite) {
+          if (!d_tleaf) { KM_CK(hipMalloc(&d_tleaf, 2 * kpad * sizeof(uint32_t))); KM_CK(hipMalloc(&d_tls, kpad * sizeof(uint2))); }
+          if (d_tnodes) { (void)hipFree(d_tnodes); d_tnodes = nullptr; }
+          size_t nn = 0; int depth = 0;
+          KM_CK(cilhip::tie_order_build_device(d_c, nullptr, (uint32_t)k, s, d_tleaf, d_tleaf + kpad, &d_tnodes, &nn, &depth));
+          hipLaunchKernelGGL(k_zip_tables, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_tleaf, (const uint32_t*)(d_tleaf + kpad), d_tls, (uint32_t)k);
+          a.tie.leaf_slot = d_tls; a.tie.nodes = d_tnodes; a.tie.mode = 1;
+        }
+      }
       KmGrid gr{};
       const bool pruned = !kd_order && g_kmeans_prune && build_centroid_grid(centroids, k, gr, cs_host, cstart_host);
       if (pruned) {
@@ -465,6 +508,9 @@ done:
   if (d_best) (void)hipFree(d_best);
   if (d_cs) (void)hipFree(d_cs);
   if (d_cstart) (void)hipFree(d_cstart);
+  if (d_tleaf) (void)hipFree(d_tleaf);
+  if (d_tls) (void)hipFree(d_tls);
+  if (d_tnodes) (void)hipFree(d_tnodes);
   if (s) (void)hipStreamDestroy(s);
   return rc;
 }

@@ -31,6 +31,7 @@
 #include <vector>
 
 namespace cilhip {
+int g_knn_tie_rule = 2;      // cilhip_knn_set_tie_rule (k-NN lists; kmeans.hip: the kd branch)
 
 namespace {
 
@@ -369,7 +370,6 @@ __global__ __launch_bounds__(KNN_THREADS) void k_radius_pca(KnnArgs a) {
   if (a.curvature) a.curvature[orig] = curv;
 }
 
-int g_knn_tie_rule = 2;      // cilhip_knn_set_tie_rule
 
 #define KN_CK(x)               \
   do {                         \

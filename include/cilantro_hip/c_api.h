@@ -278,7 +278,10 @@ int cilhip_kmeans3f_assign(int device, const float* xyz, size_t n, int mem, cons
  * uses): a kd-tree over the centroids is only a way of finding the same nearest centroid, so the device runs the same exhaustive
  * pass; what the flag changes is the ROUNDING of the compared distance -- nanoflann's L2 metric ((dx*dx)+(dy*dy))+(dz*dz)
  * instead of Eigen's squaredNorm pairing of the brute-force branch -- so that labels equal the reference's kd-tree branch
- * wherever its nearest centroid is unique (exactly equidistant centroids: lowest index here, first met in the tree there). */
+ * wherever its nearest centroid is unique; among EXACTLY equidistant centroids the one the reference's traversal meets first: the
+ * order tables of the tree over the iteration's centroids are built on the device every Lloyd iteration (about a millisecond, like
+ * the reference's KDTree at :87), the pass notices points whose best distance was met twice and settles them with tie_before
+ * (cilhip_knn_set_tie_rule(0): the lowest index instead).  tests/test_gpu_tie_rule.py: lattice centroids, label for label. */
 int cilhip_kmeans3f_ex(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol, int use_kd_tree,
                        uint32_t* labels_out, size_t* iterations_out);
 int cilhip_kmeans3f_assign_ex(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k, int use_kd_tree,
@@ -350,7 +353,7 @@ int cilhip_transform_fit3f(int device, const float* dst_xyz, const float* src_xy
  * bit -- among EXACTLY equal distances (inside a list and at its k-th place) the candidates the reference's kd-tree traversal meets
  * first, in that order (core/kd_tree.hpp:80-99 over nanoflann searchLevel): the search notices lists that hold equal distances or
  * whose k-th distance was met on a further point, builds the order tables of the reference's tree over the searched cloud
- * (csrc/tie_order.hpp) the first time a call needs them, and searches again with them -- a cloud without exact ties never pays.
+ * (csrc/tie_build.hip, on the device) the first time a call needs them, and searches again with them -- a cloud without exact ties never pays.
  * cilhip_knn_set_tie_rule (process-wide; also cilhip_normals_knn3f): 2 = that (default), 1 = tables built up front, 0 = lowest
  * index among equal distances (a brute-force argsort's order).  tests/test_gpu_parity.py: the reference's sensor frames and
  * lattices, index for index against the reference's own nanoflann knnSearch. */
@@ -552,8 +555,8 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        1.7.1 searchLevel), which depends on the tree it built (leaf size 10, core/kd_tree.hpp:162-170).
  *                        2 = that point, on the device, in every kernel form: each search notices when its smallest distance was
  *                        met on a second point and settles such a query from the order tables of the reference's tree (per point:
- *                        leaf + slot of the reference's permutation; per node: parent, depth, split -- csrc/tie_order.hpp builds
- *                        them on the host's cores, kernels.hip tie_settle reads them).  The tables are built when a search first
+ *                        leaf + slot of the reference's permutation; per node: parent, depth, split -- csrc/tie_build.hip builds
+ *                        them on the device, level by level, kernels.hip tie_settle reads them).  The tables are built when a search first
  *                        MEETS a tie (that search / run is then executed once more): a target whose searches never tie never pays
  *                        for a tree, one that does pays once.  1 = the same choice, tables built before the first search.
  *                        0 = the lowest index (what a brute-force argmin gives).  Covers every search over point features:
@@ -562,12 +565,14 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        over the TRANSFORMED SOURCE, a new one per search (correspondence_search_kd_tree.hpp:185-222): a reverse
  *                        search counts the target points with several exactly equidistant source points; when they are
  *                        systematic (at least 16 and one target point in 100 000: duplicated points, lattices; under 1: always,
- *                        from the start) the host builds that tree's tables before every reverse search (8 ms for a 110k-point
- *                        cloud, 0.25 s at 10M points) and the loops run one search at a time -- for this source, until it is set
+ *                        from the start) that tree's tables are built (on the device) before every reverse search (2 ms for a
+ *                        110k-point cloud, 25 ms at 10M points) and the loops run one search at a time -- for this source, until it is set
  *                        again (duplicated points and lattices tie under every transform / systematically).  Below that (the coincidence of
  *                        two f32 distances in a large random cloud: about one target point in ten million) rule 2 keeps the
- *                        lowest source index for those and reports them (cilhip_get_tie_rule_stats).  The 6-D / 9-D feature adaptors keep the
- *                        lowest index under 2 and are refused (CILHIP_ERR_UNSUPPORTED) under 1.  tests/test_gpu_tie_rule.py: every
+ *                        lowest source index for those and reports them (cilhip_get_tie_rule_stats).  The 6-D / 9-D feature adaptors
+ *                        (SECOND_TO_FIRST) follow the tree the reference builds over the target's FEATURES (DIM = 6 / 9: other
+ *                        splits, other leaves; tables per feature weights, rebuilt when those change; tie_before_nd); their
+ *                        reverse searches keep the lowest index (refused under 1).  tests/test_gpu_tie_rule.py: every
  *                        index of the reference's sensor frames, of clouds with doubled and tripled points and of lattices with
  *                        8-way ties equals nanoflann's, in every direction.
  *   "group_search" (default -1): the global-memory search with SEVERAL lanes per query (small clouds, sources far from alignment: one

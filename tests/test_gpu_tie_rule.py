@@ -648,3 +648,52 @@ def test_feature_searches_follow_the_reference_s_feature_tree_on_ties(Context, o
     assert report["doubled points, 6-D normals"]["indices a lowest-index rule answers differently"] > 1000
     assert report["lattice, one normal, 6-D"]["indices a lowest-index rule answers differently"] > 1000
     _report("tie_rule_features.json", report)
+
+
+def test_kmeans_kd_branch_names_the_centroid_the_reference_s_tree_meets_first(orc, hip_lib):
+    """KMeans use_kd_tree = true (clustering/kmeans.hpp:86-94): the reference builds a KDTree over the centroids every iteration and
+    keeps the first centroid its traversal meets among exactly equidistant ones.  Lattice centroids (and duplicated ones) with points on
+    the half-lattice: most points are tied 2, 4 or 8 ways.  One assignment pass against the reference's own nanoflann over the same
+    centroids, label for label; whole Lloyd runs against a loop of that same search + the reference's update; rule 0 = lowest index."""
+    if not orc.ref_available():
+        pytest.skip("oracle/_ref not built")
+    from cilantro_amd.clustering import KMeans3f, kmeans_assign
+    from cilantro_amd.normal_estimation import set_knn_tie_rule
+    rng = np.random.default_rng(5)
+    differ_total = 0
+    for g, dup in ((2, 0), (4, 0), (4, 9), (10, 0), (12, 40)):
+        lat = np.stack(np.meshgrid(np.arange(g), np.arange(g), np.arange(g), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        c0 = lat[rng.permutation(len(lat))]
+        if dup:
+            c0 = np.concatenate([c0, c0[rng.integers(0, len(c0), dup)]])[rng.permutation(len(c0) + dup)]
+        x = (rng.integers(-1, 2 * g + 1, size=(60000, 3)) * 0.5).astype(np.float32)
+        x[::7] += rng.normal(0, 0.05, size=x[::7].shape).astype(np.float32)      # (and some untied ones)
+        tree = orc.KDTree(c0, use_ref=True)
+        di, si, _ = tree.find_correspondences(x, 3.0e38)
+        assert len(si) == len(x)
+        lab_r = np.empty(len(x), np.int64); lab_r[si] = di
+        lab_g = kmeans_assign(x, c0, use_kd_tree=True)
+        assert np.array_equal(lab_g.astype(np.int64), lab_r), (g, dup, int((lab_g != lab_r).sum()))
+        # lowest index among equals: numpy's argmin over exact distances (half-lattice coordinates: every f32 operation is exact)
+        lab_o = np.concatenate([np.argmin(((x[a:a + 4096, None, :] - c0[None]) ** 2).sum(-1), axis=1) for a in range(0, len(x), 4096)])
+        tied = x[:, 0] * 2 == np.round(x[:, 0] * 2)      # (the jittered points are not compared under rule 0: their distances round)
+        differ_total += int((lab_o != lab_r)[tied].sum())
+        try:
+            set_knn_tie_rule(0)
+            assert np.array_equal(kmeans_assign(x, c0, use_kd_tree=True).astype(np.int64)[tied], lab_o[tied])
+        finally:
+            set_knn_tie_rule(2)
+    assert differ_total > 1000      # the data does tell the two rules apart
+    # whole runs: the reference's loop with its tree search as the assignment step (labels -> f32 serial sums like kmeans.hpp:126-131)
+    g = 4
+    lat = np.stack(np.meshgrid(np.arange(g), np.arange(g), np.arange(g), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    c0 = lat[rng.permutation(len(lat))][:24].copy()
+    x = (rng.integers(0, 2 * g - 1, size=(20000, 3)) * 0.5).astype(np.float32)
+    km = KMeans3f(x).cluster(c0, max_iter=1, tol=0.0, use_kd_tree=True)
+    tree = orc.KDTree(c0, use_ref=True)
+    di, si, _ = tree.find_correspondences(x, 3.0e38)
+    lab_r = np.empty(len(x), np.int64); lab_r[si] = di
+    assert np.array_equal(km.getPointToClusterIndexMap().astype(np.int64), lab_r)
+    cen = np.stack([x[lab_r == j].astype(np.float64).mean(0) if (lab_r == j).any() else c0[j] for j in range(len(c0))])
+    full = np.array([(lab_r == j).any() for j in range(len(c0))])
+    assert np.abs(km.getClusterCentroids()[full] - cen[full]).max() <= 1e-5
