@@ -139,6 +139,11 @@ struct cilhip_ctx {
   float* d_safe2 = nullptr;       // [grid.n] k_self_nn's table for the warm-started iteration; built with the target
   int cw_point_kind = 0, cw_plane_kind = 0;     // correspondence weight evaluators (CW_*), combined metric
   float cw_point_sigma = 1.0f, cw_plane_sigma = 1.0f;
+  cilhip_pair_weight_fn weight_fn = nullptr;    // a caller's own evaluators (cilhip_set_pair_weight_callback): the estimates call them on the host
+  void* weight_user = nullptr;
+  float* d_wtab = nullptr;        // [2 * wtab_cap] point / plane weights by stream position (CorrWeights::point_table / plane_table)
+  float* d_wtab_in = nullptr;     // [2 * wtab_cap] ... by original source index, as the host filled them
+  size_t wtab_cap = 0;
   bool have_nn = false;           // nn_pos/nn_d2 hold the result of a search
   bool d2_stale = false;          // ... but nn_d2 has not been formed yet (matches left by a loop whose kernels keep no distances: ensure_d2)
   float nn_T[16];                 // transform used by that search
@@ -362,6 +367,8 @@ void cilhip_destroy(cilhip_ctx* c) {
   free_source(c);
   release_target(c);
   if (c->d_ticket) (void)hipFree(c->d_ticket);
+  if (c->d_wtab) (void)hipFree(c->d_wtab);
+  if (c->d_wtab_in) (void)hipFree(c->d_wtab_in);
   if (c->d_dst_rgb) (void)hipFree(c->d_dst_rgb);
   if (c->d_dst_rgb_sorted) (void)hipFree(c->d_dst_rgb_sorted);
   if (c->d_state) (void)hipFree(c->d_state);
@@ -937,7 +944,7 @@ static void set_warm_args(const cilhip_ctx* c, IterArgs& wa) {
   wa.warm_rec_n = reinterpret_cast<F3*>(c->d_warm_rec + cap);
   wa.warm_src3 = wa.warm_rec_n + cap;
 }
-static bool weighted(const cilhip_ctx* c) { return c->cw_point_kind != CW_UNITY || c->cw_plane_kind != CW_UNITY; }
+static bool weighted(const cilhip_ctx* c) { return c->weight_fn != nullptr || c->cw_point_kind != CW_UNITY || c->cw_plane_kind != CW_UNITY; }
 // The per-pair weights of the combined-metric classes (PointToPoint/PointToPlaneCorrWeightEvaluatorT of
 // icp_single_transform_combined_metric.hpp:11-14; the point-to-point class has none): evaluator(corr.value) times the
 // metric weight, in f32.  RBF coefficient as common_pair_evaluators.hpp:53.
@@ -948,6 +955,8 @@ static CorrWeights corr_weights_of(const cilhip_ctx* c, bool combined_metric, fl
   w.point_coeff = -0.5f / (c->cw_point_sigma * c->cw_point_sigma);
   w.plane_coeff = -0.5f / (c->cw_plane_sigma * c->cw_plane_sigma);
   w.w_p2p = w_p2p; w.w_p2pl = w_p2pl;
+  // (a caller's own evaluators: prepare_pair_weights() has put the weights of the stored correspondences into the tables)
+  if (w.enabled && c->weight_fn) { w.point_table = c->d_wtab; w.plane_table = c->d_wtab + c->wtab_cap; }
   return w;
 }
 static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params* p) {
@@ -1650,6 +1659,63 @@ static void pack_T(const double L[9], const double t[3], float T[16]) {
   for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) T[cc * 4 + r] = (float)L[r * 3 + cc]; T[12 + r] = (float)t[r]; }
 }
 
+// ---- a caller's own weight evaluators -----------------------------------------------------------------------------------------
+// The reference's combined-metric classes take their evaluators as template arguments (icp_single_transform_combined_metric.hpp:10-14)
+// and the estimators call them per correspondence: evaluator(corr.indexInFirst, corr.indexInSecond, corr.value)
+// (transform_estimation.hpp:303, :332, :432, :453).  A functor cannot cross a C boundary onto the device; with a callback set, every
+// estimate brings the stored correspondence set to the host, lets the callback fill both weights of every pair, and the accumulation
+// pass reads them from tables (CorrWeights::point_table) instead of evaluating a kind.  Stored order: ascending source index
+// (SECOND_TO_FIRST), or the pair list's (first, second).
+static int prepare_pair_weights(cilhip_ctx* c) {
+  if (!c->weight_fn) return CILHIP_OK;
+  const bool pairs = c->have_pairs;
+  const size_t slots = pairs ? c->pairs.count : c->ns;      // stream positions
+  if (slots > c->wtab_cap || !c->d_wtab) {
+    if (c->d_wtab) (void)hipFree(c->d_wtab);
+    if (c->d_wtab_in) (void)hipFree(c->d_wtab_in);
+    c->d_wtab = c->d_wtab_in = nullptr; c->wtab_cap = 0;
+    const size_t cap = slots ? slots : 1;
+    CK(c, hipMalloc(&c->d_wtab, 2 * cap * sizeof(float)));
+    CK(c, hipMalloc(&c->d_wtab_in, 2 * cap * sizeof(float)));
+    c->wtab_cap = cap;
+  }
+  if (slots == 0) return CILHIP_OK;
+  std::vector<uint64_t> i1(slots), i2(slots);
+  std::vector<float> val(slots), wq(slots, 0.0f), wl(slots, 0.0f);
+  size_t cnt = 0;
+  if (pairs) {
+    std::vector<uint32_t> f(slots), sc(slots);
+    CK(c, hipMemcpyAsync(f.data(), c->pairs.first, slots * 4, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipMemcpyAsync(sc.data(), c->pairs.second, slots * 4, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipMemcpyAsync(val.data(), c->pairs.d2, slots * 4, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < slots; ++k) { i1[k] = f[k]; i2[k] = sc[k]; }
+    cnt = slots;
+  } else {
+    std::vector<uint32_t> idx(slots);
+    std::vector<float> d2(slots);
+    const int rc = cilhip_get_nn(c, idx.data(), d2.data(), CILHIP_MEM_HOST);
+    if (rc) return rc;
+    for (size_t i = 0; i < slots; ++i)
+      if (idx[i] != NONE_U32) { i1[cnt] = idx[i]; i2[cnt] = i; val[cnt] = d2[i]; ++cnt; }
+  }
+  if (cnt) c->weight_fn(c->weight_user, i1.data(), i2.data(), val.data(), cnt, wq.data(), wl.data());
+  if (pairs) {
+    CK(c, hipMemcpyAsync(c->d_wtab, wq.data(), slots * 4, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemcpyAsync(c->d_wtab + c->wtab_cap, wl.data(), slots * 4, hipMemcpyHostToDevice, c->stream));
+  } else {
+    // by original source index (unmatched: 0, never read), then into the sorted order the pass streams over
+    std::vector<float> oq(slots, 0.0f), ol(slots, 0.0f);
+    for (size_t k = 0; k < cnt; ++k) { oq[i2[k]] = wq[k]; ol[i2[k]] = wl[k]; }
+    CK(c, hipMemcpyAsync(c->d_wtab_in, oq.data(), slots * 4, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipMemcpyAsync(c->d_wtab_in + c->wtab_cap, ol.data(), slots * 4, hipMemcpyHostToDevice, c->stream));
+    launch_gather1_by_w(c->d_src_sorted, c->d_wtab_in, (uint32_t)slots, c->d_wtab, c->stream);
+    launch_gather1_by_w(c->d_src_sorted, c->d_wtab_in + c->wtab_cap, (uint32_t)slots, c->d_wtab + c->wtab_cap, c->stream);
+  }
+  CK(c, hipStreamSynchronize(c->stream));      // (the host vectors go out of scope)
+  return CILHIP_OK;
+}
+
 // Accumulate over the stored matches (transform = nn_T) and bring the reduced sums to the host.
 static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], const double innert[3], double sums[SUMS_MAX],
                              const CorrWeights* cw = nullptr) {
@@ -1664,9 +1730,21 @@ static int accumulate_stored(cilhip_ctx* c, int metric, const double innerL[9], 
   }
   IterArgs a = make_iter_args(c, 0.0f);
   if (cw) a.cw = *cw;
-  const int nb = iter_num_blocks(c->ns);
+  // (a pair list -- FIRST_TO_SECOND / BOTH -- carries its own view of the source, per pair)
+  if (c->have_pairs) {
+    a.src = c->pairs.src_view; a.ns = c->pairs.count; a.nn_pos = c->pairs.posd; a.nn_d2 = c->pairs.d2;
+    a.src_nrm = (c->d_src_nrm && c->symmetric) ? c->pairs.nrm_view : nullptr;
+  }
+  const int nb = iter_num_blocks(a.ns);
   for (int i = 0; i < SUMS_MAX; ++i) sums[i] = 0.0;
-  if (c->ns == 0) return CILHIP_OK;
+  if (a.ns == 0) return CILHIP_OK;
+  if (nb > c->partial_blocks) {
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    c->d_partials = nullptr; c->partial_blocks = 0;
+    CK(c, hipMalloc(&c->d_partials, (size_t)nb * SUMS_MAX * sizeof(double)));
+    c->partial_blocks = nb;
+  }
+  a.partials = c->d_partials;
   launch_iter(a, metric, false, false, nb, c->stream);
   launch_reduce_partials(c->d_partials, nb, c->d_stage, c->d_sums, c->stream);
   CK(c, hipGetLastError());
@@ -1695,8 +1773,9 @@ int cilhip_estimate_combined(cilhip_ctx* c, float w_p2p, float w_p2pl, size_t ma
                              double* AtA_out, double* Atb_out, int* converged) {
   if (!c || !dT) return CILHIP_ERR_INVALID;
   { const int prc = materialize_pending(c); if (prc) return prc; }
-  if (!c->have_nn) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
+  if (!c->have_nn && !c->have_pairs) return fail(c, CILHIP_ERR_INVALID, "estimate: run find_correspondences first");
   CK(c, hipSetDevice(c->device));
+  { const int wrc = prepare_pair_weights(c); if (wrc) return wrc; }
   double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
   memcpy(dT, kIdentity, sizeof(kIdentity));
   if (converged) *converged = 0;
@@ -1783,6 +1862,7 @@ int cilhip_estimate_combined_two_sets(cilhip_ctx* cp, cilhip_ctx* cl, float w_p2
     return fail(cp, CILHIP_ERR_INVALID, "estimate (two sets): both engines need stored SECOND_TO_FIRST correspondences (find_correspondences first)");
   if (memcmp(cp->nn_T, cl->nn_T, sizeof(cp->nn_T)) != 0) return fail(cp, CILHIP_ERR_INVALID, "estimate (two sets): the two engines searched under different transforms");
   if (cp->ns != cl->ns || cp->grid.n != cl->grid.n) return fail(cp, CILHIP_ERR_INVALID, "estimate (two sets): the two engines hold different clouds");
+  { int wrc = prepare_pair_weights(cp); if (wrc) return wrc; if (cl != cp) { wrc = prepare_pair_weights(cl); if (wrc) { cp->err = cl->err; return wrc; } } }
   double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
   memcpy(dT, kIdentity, sizeof(kIdentity));
   if (converged) *converged = 0;
@@ -1904,6 +1984,7 @@ int cilhip_estimate_affine(cilhip_ctx* c, float w_p2p, float w_p2pl, int centere
   if (wl && !c->has_normals) return CILHIP_OK;           // dst_p.cols() != dst_n.cols() -> identity, false
   double sums[3 * SUMS_MAX];
   // weight evaluators (the combined-metric class only: `centered` distinguishes it from the point-to-point class here)
+  if (centered) { const int wrc = prepare_pair_weights(c); if (wrc) return wrc; }
   const CorrWeights cw = corr_weights_of(c, centered != 0, w_p2p, w_p2pl);
   const int rc = affine_accumulate(c, centered != 0, wl, sums, &cw);
   if (rc) return rc;
@@ -1972,6 +2053,12 @@ static int icp_run_affine(cilhip_ctx* c, const cilhip_icp_params* p, const float
   float ms = 0.f;
   CK(c, hipEventElapsedTime(&ms, e_beg, e_end));
   c->last_loop_ms = ms; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
+  return CILHIP_OK;
+}
+
+int cilhip_set_pair_weight_callback(cilhip_ctx* c, cilhip_pair_weight_fn fn, void* user) {
+  if (!c) return CILHIP_ERR_INVALID;
+  c->weight_fn = fn; c->weight_user = fn ? user : nullptr;
   return CILHIP_OK;
 }
 
@@ -2124,6 +2211,13 @@ int cilhip_icp_run(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, c
   return again ? icp_run_once(c, p, T0, out) : CILHIP_OK;
 }
 static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0, cilhip_icp_result* out) {
+  if (c->weight_fn && p->metric == CILHIP_METRIC_COMBINED && c->transform_mode == 0) {
+    // a caller's own weight evaluators run on the host: the reference's loop step by step (search, estimate over the stored set with
+    // the callback's weights, rotation() polish + compose), the combiner's loop with one engine in both roles
+    if (c->search_dir != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "a pair-weight callback runs with SECOND_TO_FIRST searches (rigid loop); estimate from pair lists through cilhip_estimate_combined");
+    c->last_loop_ms = 0.0; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
+    return cilhip_icp_run_two_sets(c, p->max_sq_dist, c, p->max_sq_dist, p, T0, out);
+  }
   if (c->transform_mode == 1) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "the affine variants are not available on target shards");
     return icp_run_affine(c, p, T0, out);

@@ -111,6 +111,10 @@ struct CorrWeights {
   int point_kind, plane_kind;
   float point_coeff, plane_coeff;   // RBF: -0.5 / sigma^2 (common_pair_evaluators.hpp:53)
   float w_p2p, w_p2pl;              // the metric weights, folded into the per-pair weight
+  // a caller's own evaluators (cilhip_set_pair_weight_callback): the weights of every stored correspondence, evaluated on the host, by
+  // position in the stream the accumulation pass walks (sorted source position, or pair index of a pair list); null: the kinds above
+  const float* point_table;
+  const float* plane_table;
 };
 
 struct F3 { float x, y, z; };      // 12-byte record (one global_load_dwordx3 per lane)
@@ -355,6 +359,8 @@ void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const
                        const float* nn_d2, uint32_t ns, uint32_t* out_idx, float* out_d2,
                        hipStream_t s);
 void launch_gather_by_w(const float4* src_sorted, const float* in_xyz, uint32_t ns, float4* out, hipStream_t s);
+// out[i] = in[original index of the source point at sorted position i]  (one float per point)
+void launch_gather1_by_w(const float4* src_sorted, const float* in, uint32_t ns, float* out, hipStream_t s);
 void launch_pack_keys(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos, const float* nn_d2,
                       uint32_t ns, uint32_t index_offset, unsigned long long* keys, hipStream_t s);
 void launch_keys_to_pos(const float4* src_sorted, const unsigned long long* keys, const uint32_t* inv_perm, uint32_t ns,

@@ -2590,9 +2590,17 @@ __global__ __launch_bounds__(ITER_THREADS, (METRIC == IM_NONE && SEARCH) ? 4 : 1
 
   // the accumulation of one matched pair (q = T*s already formed); shared by the loops below
   // (value: the correspondence's search distance, read by the weight evaluators only)
-  auto accumulate = [&](float value, float qx, float qy, float qz, uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
+  // (idx: the correspondence's position in the stream -- what a caller's own evaluators' weight tables are indexed by)
+  auto accumulate = [&](float value, uint32_t idx, float qx, float qy, float qz, uint32_t pos, const float4 p, const float4 nvp, const float4 snp) {
     float wq = 1.0f, wp = 1.0f;
-    if (a.cw.enabled) pair_weights(a.cw, value, wq, wp);
+    if (a.cw.enabled) {
+      if (a.cw.point_table != nullptr) {
+        const uint32_t ii = pos != NONE_U32 ? idx : 0u;
+        wq = __fmul_rn(a.cw.w_p2p, a.cw.point_table[ii]); wp = __fmul_rn(a.cw.w_p2pl, a.cw.plane_table[ii]);
+      } else {
+        pair_weights(a.cw, value, wq, wp);
+      }
+    }
     accumulate_pair<METRIC>(accA, accB, T, iL, it, smt, dmean, a.src_nrm != nullptr, a.grid.nrm != nullptr, qx, qy, qz, pos, p, nvp, snp, wq, wp);
   };
 
@@ -2640,10 +2648,10 @@ __global__ __launch_bounds__(ITER_THREADS, (METRIC == IM_NONE && SEARCH) ? 4 : 1
       // stored matches: the stored distance (the feature search's is the 6-D one) or, where none is kept, formed again
       float va = 0.0f, vb2 = 0.0f;
       if (a.cw.enabled && posa != NONE_U32) va = a.nn_d2 ? a.nn_d2[ia] : d2_pinned(qx, qy, qz, p_a.x, p_a.y, p_a.z);
-      accumulate(va, qx, qy, qz, posa, p_a, nv_a, sn_a);
+      accumulate(va, ia, qx, qy, qz, posa, p_a, nv_a, sn_a);
       transform_point(T, s4b.x, s4b.y, s4b.z, qx, qy, qz);
       if (a.cw.enabled && posb != NONE_U32) vb2 = a.nn_d2 ? a.nn_d2[ib] : d2_pinned(qx, qy, qz, p_b.x, p_b.y, p_b.z);
-      accumulate(vb2, qx, qy, qz, posb, p_b, nv_b, sn_b);
+      accumulate(vb2, ib, qx, qy, qz, posb, p_b, nv_b, sn_b);
     }
   } else {
   // Warm start (a.warm_pos: the matches of the PREVIOUS iteration, may alias nn_pos): the old match is a real target point,
@@ -2701,7 +2709,7 @@ __global__ __launch_bounds__(ITER_THREADS, (METRIC == IM_NONE && SEARCH) ? 4 : 1
         if (TR::plane) { nvp = a.grid.nrm[pos]; if (a.src_nrm) snp = a.src_nrm[i]; } else if (TR::affine && a.grid.nrm) nvp = a.grid.nrm[pos];
       }
     }
-    accumulate(value, qx, qy, qz, pos, p, nvp, snp);
+    accumulate(value, i, qx, qy, qz, pos, p, nvp, snp);
   }
   if (a.warm_pos && a.unproven_cnt) {
     const double tot = wave_sum((double)nfar);
@@ -3825,6 +3833,13 @@ __global__ void k_gather_by_w(const float4* __restrict__ src_sorted, const float
   }
 }
 
+__global__ void k_gather1_by_w(const float4* __restrict__ src_sorted, const float* __restrict__ in, uint32_t ns, float* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ns) out[i] = in[__float_as_uint(src_sorted[i].w)];
+}
+void launch_gather1_by_w(const float4* src_sorted, const float* in, uint32_t ns, float* out, hipStream_t s) {
+  if (ns) hipLaunchKernelGGL(k_gather1_by_w, dim3((ns + 255u) / 256u), dim3(256), 0, s, src_sorted, in, ns, out);
+}
 void launch_gather_by_w(const float4* src_sorted, const float* in_xyz, uint32_t ns, float4* out, hipStream_t s) {
   if (ns == 0) return;
   const int nb = (int)((ns + 255) / 256 < 4096 ? (ns + 255) / 256 : 4096);

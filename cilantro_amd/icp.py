@@ -365,6 +365,25 @@ class Context:
     def set_option(self, key, value):
         self._ck(self._L.cilhip_set_option(self._h, key.encode(), float(value)))
 
+    def set_pair_weight_callback(self, fn):
+        """a caller's own correspondence weight evaluators (cilhip_set_pair_weight_callback): fn(index_in_first, index_in_second,
+        value) -> (point weights, plane weights), called once per estimate with the whole stored correspondence set as numpy arrays
+        (uint64, uint64, float32); None = back to the option-selected stock evaluators"""
+        if fn is None:
+            self._weight_cb = None
+            self._ck(self._L.cilhip_set_pair_weight_callback(self._h, capi.PAIR_WEIGHT_FN(), None))
+            return
+
+        def tramp(_user, i1, i2, val, n, wq, wl):
+            n = int(n)
+            a1 = np.ctypeslib.as_array(i1, shape=(n,)); a2 = np.ctypeslib.as_array(i2, shape=(n,)); v = np.ctypeslib.as_array(val, shape=(n,))
+            q, l = fn(a1, a2, v)
+            np.ctypeslib.as_array(wq, shape=(n,))[:] = np.asarray(q, np.float32)
+            np.ctypeslib.as_array(wl, shape=(n,))[:] = np.asarray(l, np.float32)
+
+        self._weight_cb = capi.PAIR_WEIGHT_FN(tramp)      # (kept alive with the context)
+        self._ck(self._L.cilhip_set_pair_weight_callback(self._h, self._weight_cb, None))
+
     def last_run_forms(self):
         """(iterations run as one pass, iterations run as search + streaming accumulation) of the last icp_run"""
         a = C.c_int(0); b = C.c_int(0)
@@ -670,6 +689,20 @@ class RBFKernelWeightEvaluator:
         return self
 
 
+def _as_host_evaluator(ev):
+    """a stock evaluator object as the host function the reference's class computes (core/common_pair_evaluators.hpp), any other
+    callable as it is"""
+    kind = getattr(ev, "kind", None)
+    if kind is None:
+        return ev
+    if kind == 0:
+        return lambda i1, i2, v: np.ones(len(v), np.float32)
+    if kind == 1:
+        return lambda i1, i2, v: np.asarray(v, np.float32)
+    coeff = np.float32(-0.5) / (np.float32(ev.sigma) * np.float32(ev.sigma))
+    return lambda i1, i2, v: np.exp(coeff * np.asarray(v, np.float32)).astype(np.float32)
+
+
 class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
     """registration/icp_common_instances.hpp:261 (wrapper :74-97) over
     CombinedMetricSingleTransformICP (icp_single_transform_combined_metric.hpp); defaults :44-47."""
@@ -705,9 +738,17 @@ class SimpleCombinedMetricRigidICP3f(_IterativeClosestPointBase):
         return self
 
     def _push_weight_evaluators(self):
-        for name, ev in (("point", self.point_corr_eval_), ("plane", self.plane_corr_eval_)):
-            self._ctx.set_option(name + "_weight_evaluator", ev.kind)
-            self._ctx.set_option(name + "_weight_sigma", ev.sigma)
+        evs = (("point", self.point_corr_eval_), ("plane", self.plane_corr_eval_))
+        if all(hasattr(ev, "kind") for _, ev in evs):      # the three stock classes: evaluated on the device
+            self._ctx.set_pair_weight_callback(None)
+            for name, ev in evs:
+                self._ctx.set_option(name + "_weight_evaluator", ev.kind)
+                self._ctx.set_option(name + "_weight_sigma", ev.sigma)
+            return
+        # any other callable evaluator(index_in_first, index_in_second, value) -> weights (arrays in, array out): the reference's
+        # template argument (icp_single_transform_combined_metric.hpp:10-14); evaluated on the host, per estimate
+        fns = [_as_host_evaluator(ev) for _, ev in evs]
+        self._ctx.set_pair_weight_callback(lambda i1, i2, v: (fns[0](i1, i2, v), fns[1](i1, i2, v)))
 
     def getPointToPointMetricWeight(self):
         return self.point_to_point_weight_

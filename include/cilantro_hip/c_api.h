@@ -189,6 +189,24 @@ void cilhip_icp_default_params(cilhip_icp_params* p);
 int cilhip_icp_run(cilhip_ctx* ctx, const cilhip_icp_params* prm, const float T0_or_null[16],
                    cilhip_icp_result* out);
 
+/* A caller's OWN correspondence weight evaluators.  The reference takes them as template arguments of the combined-metric classes
+ * (registration/icp_single_transform_combined_metric.hpp:10-14, icp_common_instances.hpp:74-97) and its estimators call them once per
+ * correspondence: point_corr_evaluator(corr.indexInFirst, corr.indexInSecond, corr.value) and the plane one alike
+ * (registration/transform_estimation.hpp:303, :332 rigid; :432, :453 affine; core/common_pair_evaluators.hpp:14-80 are the three stock
+ * classes, which the options "point_weight_evaluator" / "plane_weight_evaluator" evaluate on the device).  A functor cannot cross a C
+ * boundary onto the device: with a callback set, every combined-metric estimate brings the stored correspondence set to the host, calls
+ * fn ONCE with all n correspondences -- index_in_first (target), index_in_second (source), value (the search's squared distance; the
+ * feature distance under a feature adaptor), in stored order: ascending source index, or ascending (first, second) for the pair
+ * lists of FIRST_TO_SECOND / BOTH -- and fn writes both weights of every pair (the metric weights w_p2p / w_p2pl multiply them as in
+ * the reference).  The accumulation then reads the weights from tables; cilhip_icp_run becomes the reference's loop step by step on
+ * the host (search, estimate, rotation() polish, compose: cilhip_icp_run_two_sets with this engine in both roles; SECOND_TO_FIRST).
+ * Applies to cilhip_estimate_combined, _estimate_combined_two_sets (each context its own callback), _estimate_affine (combined class)
+ * and the loops over them; the point-to-point classes have no evaluators.  fn = NULL: back to the option-selected stock evaluators.
+ * fn runs on the calling thread, between device passes. */
+typedef void (*cilhip_pair_weight_fn)(void* user, const uint64_t* index_in_first, const uint64_t* index_in_second, const float* value,
+                                      size_t n, float* point_weight_out, float* plane_weight_out);
+int cilhip_set_pair_weight_callback(cilhip_ctx* ctx, cilhip_pair_weight_fn fn, void* user);
+
 /* ---- building blocks for source-sharded multi-GPU runs (one process per GPU) ----------------- */
 /* Each rank holds the full target and a shard of the source.  Per iteration:
  *   cilhip_icp_begin (once)  ->  { cilhip_icp_partial_sums -> all-reduce(sum) of

@@ -33,6 +33,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -368,19 +369,34 @@ private:
 
 // The correspondence weight evaluators of the combined-metric classes (core/common_pair_evaluators.hpp:14-27 Identity,
 // :30-43 Unity, :46-80 RBF kernel over squared distances).  The reference fixes their TYPES as template arguments
-// (icp_single_transform_combined_metric.hpp:11-14); here one runtime object covers the three.
+// (icp_single_transform_combined_metric.hpp:11-14); here one runtime object covers the three stock classes -- evaluated on the device --
+// and any functor of the reference's call shape, evaluator(indexInFirst, indexInSecond, value) (transform_estimation.hpp:303, :332):
+// such an object makes the estimates call back to the host once per estimate (cilhip_set_pair_weight_callback).
 class CorrespondenceWeightEvaluator {
 public:
-  enum Kind { Unity = 0, Identity = 1, RBFKernel = 2 };
+  enum Kind { Unity = 0, Identity = 1, RBFKernel = 2, Custom = 3 };
+  using Functor = std::function<float(size_t, size_t, float)>;
   CorrespondenceWeightEvaluator(Kind kind = Unity, float sigma = 1.0f) : kind_(kind), sigma_(sigma) {}
+  CorrespondenceWeightEvaluator(Functor f) : kind_(Custom), sigma_(1.0f), fn_(std::move(f)) {}
   inline CorrespondenceWeightEvaluator& setKind(Kind k) { kind_ = k; return *this; }
   inline CorrespondenceWeightEvaluator& setSigma(float sigma) { sigma_ = sigma; return *this; }   // :55-58
+  inline CorrespondenceWeightEvaluator& setFunctor(Functor f) { fn_ = std::move(f); kind_ = Custom; return *this; }
   inline Kind kind() const { return kind_; }
   inline float sigma() const { return sigma_; }
+  // the host evaluation (what the reference's class computes): used when EITHER evaluator of an instance is a functor
+  inline float operator()(size_t i, size_t j, float value) const {
+    switch (kind_) {
+      case Unity: return 1.0f;
+      case Identity: return value;
+      case RBFKernel: return std::exp((-0.5f / (sigma_ * sigma_)) * value);
+      default: return fn_(i, j, value);
+    }
+  }
 
 private:
   Kind kind_;
   float sigma_;
+  Functor fn_;
 };
 
 // icp_single_transform_combined_metric.hpp + icp_common_instances.hpp:74-97,261
@@ -424,11 +440,23 @@ public:
   inline CorrespondenceWeightEvaluator& pointToPlaneCorrespondenceWeightEvaluator() { return plane_corr_eval_; }
 
 private:
+  static void weightTrampoline_(void* user, const uint64_t* i1, const uint64_t* i2, const float* value, size_t n, float* wq, float* wl) {
+    const SimpleCombinedMetricRigidICP3f* self = static_cast<const SimpleCombinedMetricRigidICP3f*>(user);
+    for (size_t k = 0; k < n; ++k) {
+      wq[k] = self->point_corr_eval_((size_t)i1[k], (size_t)i2[k], value[k]);
+      wl[k] = self->plane_corr_eval_((size_t)i1[k], (size_t)i2[k], value[k]);
+    }
+  }
   void fillParams(cilhip_icp_params& p) const {
-    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "point_weight_evaluator", (double)point_corr_eval_.kind()), "point_weight_evaluator");
-    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "point_weight_sigma", (double)point_corr_eval_.sigma()), "point_weight_sigma");
-    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "plane_weight_evaluator", (double)plane_corr_eval_.kind()), "plane_weight_evaluator");
-    internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "plane_weight_sigma", (double)plane_corr_eval_.sigma()), "plane_weight_sigma");
+    const bool custom = point_corr_eval_.kind() == CorrespondenceWeightEvaluator::Custom || plane_corr_eval_.kind() == CorrespondenceWeightEvaluator::Custom;
+    internal::check(ctx_.get(), cilhip_set_pair_weight_callback(ctx_.get(), custom ? &weightTrampoline_ : nullptr, const_cast<SimpleCombinedMetricRigidICP3f*>(this)),
+                    "set_pair_weight_callback");
+    if (!custom) {
+      internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "point_weight_evaluator", (double)point_corr_eval_.kind()), "point_weight_evaluator");
+      internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "point_weight_sigma", (double)point_corr_eval_.sigma()), "point_weight_sigma");
+      internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "plane_weight_evaluator", (double)plane_corr_eval_.kind()), "plane_weight_evaluator");
+      internal::check(ctx_.get(), cilhip_set_option(ctx_.get(), "plane_weight_sigma", (double)plane_corr_eval_.sigma()), "plane_weight_sigma");
+    }
     p.metric = CILHIP_METRIC_COMBINED;
     p.w_p2p = point_to_point_weight_;
     p.w_p2pl = point_to_plane_weight_;

@@ -138,6 +138,22 @@ int main(int argc, char** argv) {
     std::printf("weight evaluators: iters gpu=%zu oracle=%zu |T_gpu-T_oracle|_F=%.3e\n", icp6.getNumberOfPerformedIterations(), r.iterations, e6);
     if (!(e6 <= 1e-5)) ++failures;
 
+    // ... and the same two evaluators as FUNCTORS of the reference's call shape, evaluator(indexInFirst, indexInSecond, value)
+    // (transform_estimation.hpp:303, :332): evaluated on the host through cilhip_set_pair_weight_callback, the loop step by step
+    {
+      SimpleCombinedMetricRigidICP3f icp7(dst_v, nrm_v, src_v);
+      icp7.setPointToPointMetricWeight(0.2f).setPointToPlaneMetricWeight(1.0f);
+      const float hf = (float)h;
+      size_t calls = 0;
+      icp7.pointToPlaneCorrespondenceWeightEvaluator().setFunctor([hf, &calls](size_t, size_t, float v) { ++calls; return std::exp((-0.5f / (hf * hf)) * v); });
+      icp7.pointToPointCorrespondenceWeightEvaluator().setFunctor([](size_t, size_t, float v) { return v; });
+      icp7.correspondenceSearchEngine().setMaxDistance(max_sq);
+      icp7.setConvergenceTolerance(0.0f).setMaxNumberOfIterations(8).estimate();
+      const double e7 = frob(icp7.getTransform().m, r.T), e76 = frob(icp7.getTransform().m, icp6.getTransform().m);
+      std::printf("functor evaluators: iters gpu=%zu calls=%zu |T_gpu-T_oracle|_F=%.3e |T_functor-T_enum|_F=%.3e\n", icp7.getNumberOfPerformedIterations(), calls, e7, e76);
+      if (!(e7 <= 1e-5) || !(e76 <= 1e-6) || calls == 0 || icp7.getNumberOfPerformedIterations() != icp6.getNumberOfPerformedIterations()) ++failures;
+    }
+
     // feature adaptors of the engine (common_transformable_feature_adaptors.hpp: point+normal :60-161, point+colour :164-252,
     // point+normal+colour :255-343) through the mirror: correspondence lists under tf against the oracle's exhaustive searches
     {

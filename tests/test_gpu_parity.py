@@ -1712,6 +1712,113 @@ def test_correspondence_weight_evaluators_vs_oracle(Context, orc, hip_lib):
 
 
 @pytest.mark.gpu
+def test_functor_weight_evaluators_through_the_callback(Context, orc, hip_lib):
+    """The reference's evaluators are template arguments: ANY functor evaluator(indexInFirst, indexInSecond, value)
+    (icp_single_transform_combined_metric.hpp:10-14; called at transform_estimation.hpp:303, :332).  Here such a functor runs on the
+    host through cilhip_set_pair_weight_callback.  (1) functors that restate the stock classes give the stock classes' normal
+    equations; (2) a functor that reads the INDICES (weight 0 for odd source indices, 1 + index/n for the others on the plane terms)
+    against the oracle's estimate over the surviving correspondences with those weights folded in by linearity; (3) whole loops:
+    functor = stock restated against the oracle's loop with the stock kind, and a robust (Cauchy) kernel the reference has no class
+    for against a numpy restatement of the loop built from the engine's own search + the oracle's weighted-by-kind estimator
+    (Identity kind over pre-weighted values)."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f, UnityWeightEvaluator
+
+    U, I, R = orc.W_UNITY, orc.W_IDENTITY, orc.W_RBF
+    d = syn.make_pair(150000, perturb=0.5)
+    r2 = float(d["max_sq_dist"]); sigma = 0.4 * np.sqrt(r2)
+    T = syn.true_transform(d["h"], 0.1).astype(np.float32)
+    ctx = Context()
+    ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+    ctx.find_correspondences(T, r2)
+    g1, g2, gv = ctx.get_correspondences()
+    q = orc.transform_points(T, d["src"])
+    dm, sm = ctx.means()
+    smt = orc.transform_points(T, sm.reshape(1, 3))[0]
+    coeff = np.float32(-0.5) / (np.float32(sigma) * np.float32(sigma))
+    seen = {}
+
+    def stock_as_functors(i1, i2, v):
+        seen["n"] = len(v); seen["i1"] = i1.copy(); seen["i2"] = i2.copy(); seen["v"] = v.copy()
+        return v.copy(), np.exp(coeff * v).astype(np.float32)          # Identity on the point terms, RBF on the plane terms
+
+    # (1) against the device-evaluated stock classes and the oracle
+    ctx.set_option("point_weight_evaluator", I); ctx.set_option("plane_weight_evaluator", R)
+    ctx.set_option("point_weight_sigma", 1.0); ctx.set_option("plane_weight_sigma", sigma)
+    Ts, AtAs, Atbs, _ = ctx.estimate_combined(0.3, 1.0, 1, 1e-5)
+    ctx.set_option("point_weight_evaluator", U); ctx.set_option("plane_weight_evaluator", U)
+    ctx.set_pair_weight_callback(stock_as_functors)
+    Tf, AtAf, Atbf, _ = ctx.estimate_combined(0.3, 1.0, 1, 1e-5)
+    # the callback saw the stored set in its stored order: the list get_correspondences returns
+    assert seen["n"] == len(g1) and np.array_equal(seen["i1"], g1) and np.array_equal(seen["i2"], g2) and np.array_equal(seen["v"], gv)
+    scale = np.abs(AtAs).max()
+    assert np.abs(AtAf - AtAs).max() <= 1e-6 * scale and np.abs(Atbf - Atbs).max() <= 1e-6 * np.abs(Atbs).max()   # (numpy's expf against the device's)
+    assert np.linalg.norm(Tf.astype(np.float64) - Ts.astype(np.float64)) < 1e-6
+    To = orc.estimate_combined(d["dst"], d["dst_n"], q, g1, g2, 0.3, 1.0, dm, smt, 1, 1e-5, orc.MODE_MIXED, values=gv, weights=(I, R, 1.0, sigma))[0]
+    assert np.linalg.norm(Tf.astype(np.float64) - To) < 1e-6
+
+    # (2) weights from the indices: plane terms only; the oracle's Identity kind over "values" that ARE the weights
+    n_src = len(d["src"])
+    def by_index(i1, i2, v):
+        w = np.where(i2 % 2 == 1, 0.0, 1.0 + i2.astype(np.float64) / n_src).astype(np.float32)
+        return np.ones(len(v), np.float32), w
+    ctx.set_pair_weight_callback(by_index)
+    Tg, AtA, Atb, _ = ctx.estimate_combined(0.0, 1.0, 1, 1e-5)
+    keep = g2 % 2 == 0
+    wv = (1.0 + g2[keep].astype(np.float64) / n_src).astype(np.float32)
+    To, AtAo, Atbo, _ = orc.estimate_combined(d["dst"], d["dst_n"], q, g1[keep], g2[keep], 0.0, 1.0, dm, smt, 1, 1e-5, orc.MODE_MIXED,
+                                              values=wv, weights=(U, I, 1.0, 1.0))
+    scale = np.abs(AtAo).max()
+    assert np.abs(AtA - AtAo).max() <= 1e-9 * scale, np.abs(AtA - AtAo).max() / scale
+    assert np.abs(Atb - Atbo).max() <= 1e-9 * np.abs(Atbo).max() + 1e-12 * scale
+    assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6
+    ctx.set_pair_weight_callback(None)
+    Tu = ctx.estimate_combined(0.0, 1.0, 1, 1e-5)[0]
+    assert np.linalg.norm(Tu - Tg) > 1e-7                                # (back to unit weights; the index weights did change the estimate)
+
+    # (3) whole loops through the mirror class
+    dl = syn.make_pair(60000, perturb=0.5)
+    r2 = float(dl["max_sq_dist"]); sigma = 0.4 * np.sqrt(r2)
+    coeff = np.float32(-0.5) / (np.float32(sigma) * np.float32(sigma))
+    rbf = lambda i1, i2, v: np.exp(coeff * v).astype(np.float32)
+    for frac, o2o in ((1.0, False), (0.8, True)):
+        icp = SimpleCombinedMetricRigidICP3f(dl["dst"], dl["dst_n"], dl["src"])
+        icp.setPointToPointMetricWeight(0.2).setPointToPlaneMetricWeight(1.0)
+        icp.setCorrespondenceWeightEvaluators(UnityWeightEvaluator(), rbf)          # a stock object and a plain callable side by side
+        icp.correspondenceSearchEngine().setMaxDistance(r2).setInlierFraction(frac).setOneToOne(o2o)
+        icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, w_p2p=0.2, w_p2pl=1.0, max_iter=8, conv_tol=0.0, max_opt_iter=1, opt_conv_tol=1e-5, max_sq_dist=r2,
+                            mode=orc.MODE_MIXED, inlier_fraction=frac, one_to_one=o2o, point_weight=U, plane_weight=R, point_sigma=1.0, plane_sigma=sigma)
+        ro = orc.icp_run(dl["dst"], dl["dst_n"], dl["src"], p)
+        err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
+        assert err <= TOL_T and icp.getNumberOfPerformedIterations() == ro["iterations"], (frac, o2o, err)
+    # a robust kernel the reference has no class for: w = 1 / (1 + value / c^2) on both terms; the loop restated with the engine's own
+    # search and the oracle's estimator fed the weights as Identity-kind values
+    c2 = np.float32(0.25 * r2)
+    cauchy = lambda i1, i2, v: (np.float32(1.0) / (np.float32(1.0) + v / c2)).astype(np.float32)
+    icp = SimpleCombinedMetricRigidICP3f(dl["dst"], dl["dst_n"], dl["src"])
+    icp.setPointToPointMetricWeight(0.1).setPointToPlaneMetricWeight(1.0).setCorrespondenceWeightEvaluators(cauchy, cauchy)
+    icp.correspondenceSearchEngine().setMaxDistance(r2)
+    icp.setMaxNumberOfIterations(5).setConvergenceTolerance(0.0)
+    Tg = icp.estimate().getTransform()
+    ref = Context()
+    ref.set_target(dl["dst"], dl["dst_n"]); ref.set_source(dl["src"])
+    dm, sm = ref.means()
+    Tc = np.eye(4, dtype=np.float32)
+    for _ in range(5):
+        ref.find_correspondences(Tc, r2)
+        g1, g2, gv = ref.get_correspondences()
+        qq = orc.transform_points(Tc, dl["src"])
+        smt = orc.transform_points(Tc, sm.reshape(1, 3))[0]
+        w = cauchy(g1, g2, gv)
+        dT = orc.estimate_combined(dl["dst"], dl["dst_n"], qq, g1, g2, 0.1, 1.0, dm, smt, 1, 1e-5, orc.MODE_MIXED, values=w, weights=(I, I, 1.0, 1.0))[0]
+        step = np.eye(4)                                                     # rotation() polish + transform_ = tform_iter * transform_ (:207-213)
+        step[:3, :3] = orc.nearest_rotation(np.asarray(dT[:3, :3], np.float64)); step[:3, 3] = dT[:3, 3]
+        Tc = (step @ Tc.astype(np.float64)).astype(np.float32)
+    err = np.linalg.norm(Tg.astype(np.float64) - Tc.astype(np.float64))
+    assert err <= TOL_T, err
+
+
 def test_warm_started_iterations_find_the_same_matches(Context, orc, hip_lib):
     """From the second iteration on (near alignment) the loop runs a per-lane kernel that starts every search from the
     previous iteration's match: a real target point bounds the search, and a query nearer to it than half its distance to
