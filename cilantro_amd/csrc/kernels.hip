@@ -1516,6 +1516,7 @@ static void debug_dump_warm_clocks() {
   fprintf(stderr, "[warm clocks, 100 MHz ticks per block (thread 0: wave 0), %llu blocks] prologue=%.1f stream=%.1f levelA=%.1f (%.2f rounds) levelB=%.1f (%.2f) -=%.1f (%.2f) end=%.1f\n",
           h[8], (double)h[0] / h[8], (double)h[1] / h[8], (double)h[2] / h[8], (double)h[10] / h[8], (double)h[3] / h[8], (double)h[11] / h[8], (double)h[4] / h[8],
           (double)h[12] / h[8], (double)h[5] / h[8]);
+  fprintf(stderr, "[warm list] entries at level A %llu, left open %llu (bound = radius: %llu, bound > cell: %llu)\n", h[6], h[7], h[14], h[15]);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_warm_clk), h, sizeof h);
   // the last launch, block by block: when it started / ended relative to the first start; by XCD (blockIdx & 7)
@@ -2970,7 +2971,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     }
     return has;
   };
-  struct SlowGeom { int cx, cy, cz; float ux, uy, uz; bool inner; uint32_t cid; };
+  struct SlowGeom { int cx, cy, cz; float ux, uy, uz; bool inner, inside; uint32_t cid; };
   auto slow_geom = [&](bool v, float qx, float qy, float qz) -> SlowGeom {
     SlowGeom s;
     const float BIG = 1.0e9f;
@@ -2978,6 +2979,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
                 fz = fminf(fmaxf((qz - g.oz) * g.inv_cell, -BIG), BIG);
     s.cx = (int)floorf(fx); s.cy = (int)floorf(fy); s.cz = (int)floorf(fz);
     s.inner = v & (s.cx >= 1) & (s.cx <= g.nx - 2) & (s.cy >= 1) & (s.cy <= g.ny - 2) & (s.cz >= 1) & (s.cz <= g.nz - 2);
+    s.inside = v & (s.cx >= 0) & (s.cx < g.nx) & (s.cy >= 0) & (s.cy < g.ny) & (s.cz >= 0) & (s.cz < g.nz);
     s.ux = qx - (g.ox + (float)s.cx * g.cell); s.uy = qy - (g.oy + (float)s.cy * g.cell); s.uz = qz - (g.oz + (float)s.cz * g.cell);
     s.cid = ((uint32_t)s.cz * (uint32_t)g.ny + (uint32_t)s.cy) * (uint32_t)g.nx + (uint32_t)s.cx;
     return s;
@@ -2994,7 +2996,9 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     if (s.cy + 2 < g.ny) b = fminf(b, g.cell - s.uy);
     if (s.cz - 1 > 0) b = fminf(b, s.uz);
     if (s.cz + 2 < g.nz) b = fminf(b, g.cell - s.uz);
-    const bool fits = s.inner && (b == INFINITY || Rr < (fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin) * 0.999999f);
+    // (a query in the grid's OUTER layer is taken too: the rows and cells of its block that lie outside the grid do not exist -- every
+    //  target point is inside the grid --, they are skipped; 2.7 % of the queries of a 220^3 grid, which used to go to the shells)
+    const bool fits = s.inside && (b == INFINITY || Rr < (fmaxf(b, 0.0f) + g.cell - 2.0f * g.margin) * 0.999999f);
     // (addresses valid for every lane: a lane that is not taken reads the rows of cell (1,1,1) and is masked afterwards, so that
     //  the loads leave together instead of one exec-masked group after the other)
     const int c0 = fits ? (int)s.cid : sz + sy + 1;
@@ -3005,9 +3009,10 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
       const float gyz2 = gm[r / 3] * gm[r / 3] + gn[r % 3] * gn[r % 3];
-      const bool take = fits && gyz2 * KSHRINK <= R2c;
-      const bool left = take && (gyz2 + gxl * gxl) * KSHRINK <= R2c, right = take && (gyz2 + gxr * gxr) * KSHRINK <= R2c;
-      const int row = c0 + (r / 3 - 1) * sz + (r % 3 - 1) * sy;
+      const bool exists = (unsigned)(s.cz + r / 3 - 1) < (unsigned)g.nz && (unsigned)(s.cy + r % 3 - 1) < (unsigned)g.ny;
+      const bool take = fits && exists && gyz2 * KSHRINK <= R2c;
+      const bool left = take && s.cx > 0 && (gyz2 + gxl * gxl) * KSHRINK <= R2c, right = take && s.cx + 1 < g.nx && (gyz2 + gxr * gxr) * KSHRINK <= R2c;
+      const int row = take ? c0 + (r / 3 - 1) * sz + (r % 3 - 1) * sy : sz + sy + 1;
       const uint32_t va = g.cell_start[row - (left ? 1 : 0)], vb2 = g.cell_start[row + 1 + (right ? 1 : 0)];
       rb9[r] = take ? va : 0u; re9[r] = take ? vb2 : 0u;
     }
@@ -3240,6 +3245,14 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
       else slow_levelB(v, ent.x, ent.y, ent.z, R2, best, bp, key);
       const bool open = v && !taken;
       const unsigned long long om = __ballot(open);
+#ifdef CILHIP_EXP_PHASE_CLOCKS
+      if (level == 0) {      // who is left open by level A: all / bound = the radius / bound beyond a cell
+        if (v) atomicAdd(&g_warm_clk[6], 1ull);
+        if (open) atomicAdd(&g_warm_clk[7], 1ull);
+        if (open && R2 >= a.max_sq) atomicAdd(&g_warm_clk[14], 1ull);
+        if (open && R2 < a.max_sq && R2 > g.cell * g.cell) atomicAdd(&g_warm_clk[15], 1ull);
+      }
+#endif
       // (this round's entries are in registers: the front of the list up to b0 + 64 is free)
       if (open) {
         const uint32_t o = nopen + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
