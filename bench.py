@@ -106,13 +106,33 @@ def stratified_form_timing(ft, forms, timed):
     return {f: out.get(f, ft.get(f, (0.0, 0))) for f in set(ft) | set(out)}
 
 
-def source_hash():
+def source_hash(files=("kernels.hip", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp")):
     """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp"):
+    for f in files:
         with open(os.path.join(ROOT, "cilantro_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+KERNEL_SOURCES = {"kmeans": ("kmeans.hip", "internal.hpp", "tie_build.hip"), "ransac": ("ransac.hip",)}
+
+
+def config_traffic(config, workload):
+    """(HBM bytes per launch of the configuration's dominant kernel, note) from profiles/r*_traffic_<config>.json (tools/make_traffic_json.py
+    --config), quoted only for the build (hash of the kernel's sources) and the workload it was counted on; (None, why) otherwise."""
+    import glob
+    note = "no PMC measurement of this build / workload committed"
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{config}.json")), reverse=True):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("source_hash") == source_hash(KERNEL_SOURCES[config]) and tj.get("workload") == workload:
+                return float(tj["traffic_bytes_per_launch"]), os.path.basename(tf) + ": " + tj.get("method", "")
+            if note.startswith("no PMC"):
+                note = "profiles/" + os.path.basename(tf) + " was measured on another build or workload: not quoted"
+        except Exception:
+            pass
+    return None, note
 
 
 def cpu_baseline_icp(d, metric, w_p2p, w_p2pl, n_sample, T):
@@ -356,7 +376,7 @@ def bench_icp(a, torch, rank, world, local_rank, emit=True):
         fused = dom is not None and dom != 0
         traffic, traffic_note, traffic_cold = None, "no PMC measurement of this build / workload committed", None
         import glob
-        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):      # newest round first
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) + glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_c*.json")), reverse=True):      # newest round first
             try:
                 tj = json.load(open(tf))
                 w = tj["workload"]
@@ -610,7 +630,7 @@ def other_configs(a, torch, local_rank, budget_s=150.0):
             else:
                 o = bench_icp(b, torch, 0, 1, local_rank, emit=False)
             res[cfg] = {"workload": o["config"]["workload"], "metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
-                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_kernel_ms")},
+                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_kernel_ms", "traffic")},
                         "wall_s": time.perf_counter() - t0}
         except Exception as e:      # (a report's refinement, never a reason to lose the line)
             res[cfg] = {"error": repr(e)}
@@ -655,6 +675,7 @@ def bench_kmeans(a, torch, emit=True):
     flops_ex = 8.0 * evals                    # 3 sub, 3 mul, 2 add per point-centroid distance, each individually rounded
     read_evals = 36.0 * float(n) * a.steps    # distances the pruned pass evaluates at least: four records of each of the nine runs of a point's block
     bytes_step = 20.0 * float(n)              # 12 B point + 4 B label read + 4 B label written
+    km_traffic, km_note = config_traffic("kmeans", {"n_points": n, "k": k})
     out = {"metric": "KMeans3f point-centroid distance evaluations/sec (k = 1024), brute-force equivalent", "value": evals / dt, "unit": "distances/s",
            "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32 distances / exact fixed-point sums", "data": "synthetic",
@@ -662,7 +683,7 @@ def bench_kmeans(a, torch, emit=True):
                       "assignment": "pruned exactly: labels bit-identical to the exhaustive argmin (tests/test_gpu_parity.py::test_kmeans_pruned_assignment_is_the_exhaustive_one)"},
            # HBM and the arithmetic ceiling are both far away (fractions below); what binds the pruned pass is VALU ISSUE: roofline.limiter
            "roofline": {"bound": "hbm", "achieved": bytes_step * a.steps / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_step * a.steps / dt / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "k_assign_grid", "algorithmic_bytes_per_launch": bytes_step,
+                        "traffic": km_traffic, "traffic_note": km_note, "kernel": "k_assign_grid", "algorithmic_bytes_per_launch": bytes_step,
                         "valu_frac_of_evaluated_distances": 8.0 * read_evals / dt / 1e12 / VALU_NOFMA_PEAK_TFLOPS,
                         "note": "12 B point + label read + label written per point against 8 TB/s; the distances it does evaluate (>= 36 per point, 8 individually rounded f32 ops each) "
                                 "against the 78.6 TFLOP/s non-FMA vector ceiling: valu_frac_of_evaluated_distances -- neither binds; `limiter` does",
@@ -728,11 +749,12 @@ def bench_ransac(a, torch, emit=True):
     dt = tk - t1                                  # a.steps passes of 128 hypotheses
     tests = float(n) * 128 * a.steps
     alg = 12.0 * n                                # one read of the points per 128-hypothesis pass
+    rs_traffic, rs_note = config_traffic("ransac", {"n_points": n})
     out = {"metric": "plane RANSAC point-plane tests/sec", "value": tests / dt, "unit": "tests/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"ransac: PlaneRANSACEstimator3f inlier counting, {n/1e6:g}M points, 128 hypotheses per pass", "n_points": n},
            "roofline": {"bound": "valu", "achieved": 6.0 * tests / dt / 1e12, "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": 6.0 * tests / dt / 1e12 / VALU_NOFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_score",
+                        "frac": 6.0 * tests / dt / 1e12 / VALU_NOFMA_PEAK_TFLOPS, "traffic": rs_traffic, "traffic_note": rs_note, "kernel": "k_score",
                         "note": "6 individually rounded f32 operations per point-plane test (3 multiplies + 3 additions of n.p + offset, hyperplane.hpp absDistance; the "
                                 "|.| <= threshold compare and the ballot/popcount are not counted), no FMA contraction: counts must match the reference bit for bit; "
                                 "peak = half of the 157.3 TFLOP/s FMA figure.  128 hypotheses share one read of the points, so HBM is not the bound:",

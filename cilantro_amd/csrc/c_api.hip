@@ -1666,8 +1666,20 @@ static void pack_T(const double L[9], const double t[3], float T[16]) {
 // estimate brings the stored correspondence set to the host, lets the callback fill both weights of every pair, and the accumulation
 // pass reads them from tables (CorrWeights::point_table) instead of evaluating a kind.  Stored order: ascending source index
 // (SECOND_TO_FIRST), or the pair list's (first, second).
+static int prepare_pair_weights_impl(cilhip_ctx* c);
 static int prepare_pair_weights(cilhip_ctx* c) {
   if (!c->weight_fn) return CILHIP_OK;
+  // (host vectors of the size of the correspondence set: an allocation failure must not cross the C boundary; neither may whatever a
+  //  C++ callback lets escape)
+  try {
+    return prepare_pair_weights_impl(c);
+  } catch (const std::bad_alloc&) {
+    return fail(c, CILHIP_ERR_HIP, "pair-weight callback: out of host memory for the correspondence set");
+  } catch (...) {
+    return fail(c, CILHIP_ERR_INVALID, "pair-weight callback: an exception escaped the callback");
+  }
+}
+static int prepare_pair_weights_impl(cilhip_ctx* c) {
   const bool pairs = c->have_pairs;
   const size_t slots = pairs ? c->pairs.count : c->ns;      // stream positions
   if (slots > c->wtab_cap || !c->d_wtab) {

@@ -95,6 +95,10 @@ class Context:
             pass
 
     def _ck(self, rc):
+        exc = getattr(self, "_weight_exc", None)
+        if exc is not None:      # (a pair-weight callback raised inside the library call: ctypes cannot carry it through the C frames)
+            self._weight_exc = None
+            raise exc
         if rc != capi.OK:
             raise capi.CilhipError(rc, self._L.cilhip_last_error(self._h).decode())
 
@@ -375,11 +379,16 @@ class Context:
             return
 
         def tramp(_user, i1, i2, val, n, wq, wl):
-            n = int(n)
-            a1 = np.ctypeslib.as_array(i1, shape=(n,)); a2 = np.ctypeslib.as_array(i2, shape=(n,)); v = np.ctypeslib.as_array(val, shape=(n,))
-            q, l = fn(a1, a2, v)
-            np.ctypeslib.as_array(wq, shape=(n,))[:] = np.asarray(q, np.float32)
-            np.ctypeslib.as_array(wl, shape=(n,))[:] = np.asarray(l, np.float32)
+            try:
+                if getattr(self, "_weight_exc", None) is not None:
+                    return      # (an earlier call raised: the weights stay 0, the exception surfaces when the library call returns)
+                n = int(n)
+                a1 = np.ctypeslib.as_array(i1, shape=(n,)); a2 = np.ctypeslib.as_array(i2, shape=(n,)); v = np.ctypeslib.as_array(val, shape=(n,))
+                q, l = fn(a1, a2, v)
+                np.ctypeslib.as_array(wq, shape=(n,))[:] = np.asarray(q, np.float32)
+                np.ctypeslib.as_array(wl, shape=(n,))[:] = np.asarray(l, np.float32)
+            except BaseException as e:      # noqa: BLE001  (kept for _ck)
+                self._weight_exc = e
 
         self._weight_cb = capi.PAIR_WEIGHT_FN(tramp)      # (kept alive with the context)
         self._ck(self._L.cilhip_set_pair_weight_callback(self._h, self._weight_cb, None))

@@ -31,6 +31,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <limits>
 #include <memory>
 #include <functional>
@@ -294,7 +295,11 @@ public:
     p.conv_tol = convergence_tol_;
     p.max_sq_dist = engine_.getMaxDistance();
     cilhip_icp_result r;
-    internal::check(ctx_.get(), cilhip_icp_run(ctx_.get(), &p, transform_init_.m, &r), "estimate");
+    pending_exception_ = nullptr;
+    const int run_rc = cilhip_icp_run(ctx_.get(), &p, transform_init_.m, &r);
+    // (a functor evaluator that threw inside the library's callback: caught at the C boundary, rethrown here)
+    if (pending_exception_) { std::exception_ptr e = pending_exception_; pending_exception_ = nullptr; std::rethrow_exception(e); }
+    internal::check(ctx_.get(), run_rc, "estimate");
     engine_.invalidateFetched();      // the engine now holds the last iteration's set (correspondence_search_kd_tree.hpp:231)
     std::memcpy(transform_.m, r.T, sizeof(r.T));
     iterations_ = r.iterations;
@@ -337,6 +342,7 @@ protected:
   float convergence_tol_;
   float last_delta_norm_;
   size_t last_ncorr_;
+  std::exception_ptr pending_exception_;      // thrown by a caller's functor inside a library callback: rethrown by estimate()
   Transform transform_init_;
   Transform transform_;
   size_t n_src_ = 0;
@@ -441,10 +447,16 @@ public:
 
 private:
   static void weightTrampoline_(void* user, const uint64_t* i1, const uint64_t* i2, const float* value, size_t n, float* wq, float* wl) {
-    const SimpleCombinedMetricRigidICP3f* self = static_cast<const SimpleCombinedMetricRigidICP3f*>(user);
-    for (size_t k = 0; k < n; ++k) {
-      wq[k] = self->point_corr_eval_((size_t)i1[k], (size_t)i2[k], value[k]);
-      wl[k] = self->plane_corr_eval_((size_t)i1[k], (size_t)i2[k], value[k]);
+    SimpleCombinedMetricRigidICP3f* self = static_cast<SimpleCombinedMetricRigidICP3f*>(user);
+    try {
+      if (self->pending_exception_) return;      // (an earlier call threw: the run is abandoned by estimate(); weights stay 0)
+      for (size_t k = 0; k < n; ++k) {
+        wq[k] = self->point_corr_eval_((size_t)i1[k], (size_t)i2[k], value[k]);
+        wl[k] = self->plane_corr_eval_((size_t)i1[k], (size_t)i2[k], value[k]);
+      }
+    } catch (...) {      // (no exception may cross the C frames of the library)
+      self->pending_exception_ = std::current_exception();
+      for (size_t k = 0; k < n; ++k) wq[k] = wl[k] = 0.0f;
     }
   }
   void fillParams(cilhip_icp_params& p) const {

@@ -152,6 +152,12 @@ int main(int argc, char** argv) {
       const double e7 = frob(icp7.getTransform().m, r.T), e76 = frob(icp7.getTransform().m, icp6.getTransform().m);
       std::printf("functor evaluators: iters gpu=%zu calls=%zu |T_gpu-T_oracle|_F=%.3e |T_functor-T_enum|_F=%.3e\n", icp7.getNumberOfPerformedIterations(), calls, e7, e76);
       if (!(e7 <= 1e-5) || !(e76 <= 1e-6) || calls == 0 || icp7.getNumberOfPerformedIterations() != icp6.getNumberOfPerformedIterations()) ++failures;
+      // a functor that throws: caught at the C boundary, rethrown by estimate()
+      icp7.pointToPointCorrespondenceWeightEvaluator().setFunctor([](size_t, size_t, float) -> float { throw std::runtime_error("evaluator failed"); });
+      bool rethrown = false;
+      try { icp7.estimate(); } catch (const std::runtime_error& ex) { rethrown = std::string(ex.what()) == "evaluator failed"; }
+      std::printf("throwing functor: rethrown by estimate() = %d\n", (int)rethrown);
+      if (!rethrown) ++failures;
     }
 
     // feature adaptors of the engine (common_transformable_feature_adaptors.hpp: point+normal :60-161, point+colour :164-252,

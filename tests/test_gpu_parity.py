@@ -1771,6 +1771,12 @@ def test_functor_weight_evaluators_through_the_callback(Context, orc, hip_lib):
     assert np.abs(AtA - AtAo).max() <= 1e-9 * scale, np.abs(AtA - AtAo).max() / scale
     assert np.abs(Atb - Atbo).max() <= 1e-9 * np.abs(Atbo).max() + 1e-12 * scale
     assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6
+    # a callback that raises: the exception surfaces from the library call it happened in
+    def broken(i1, i2, v):
+        raise ValueError("evaluator failed")
+    ctx.set_pair_weight_callback(broken)
+    with pytest.raises(ValueError, match="evaluator failed"):
+        ctx.estimate_combined(0.0, 1.0, 1, 1e-5)
     ctx.set_pair_weight_callback(None)
     Tu = ctx.estimate_combined(0.0, 1.0, 1, 1e-5)[0]
     assert np.linalg.norm(Tu - Tg) > 1e-7                                # (back to unit weights; the index weights did change the estimate)

@@ -48,6 +48,24 @@ if has configs; then
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$cfg -- $C2 > $O/bench_${cfg}_profiled.json 2> $O/trace_$cfg.log
     cp $O/trace_$cfg/*/*_kernel_stats.csv $O/config_${cfg}_kernel_stats.csv 2>/dev/null
   done
+  # HBM traffic of every configuration's dominant kernel (the counters of `core`, per configuration): profiles/<tag>_traffic_<cfg>.json
+  for cfg in c2 c4_1gpu; do
+    C2="python bench.py --config $cfg --steps 20 --warmup 3 --no-extras --no-cpu-baseline --no-other-configs"
+    mkdir -p $O/pmc_$cfg
+    timeout 300 $C2 > $O/pmc_$cfg/bench_line.json 2> $O/pmc_$cfg/bench.err
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_$cfg/fetch -- $C2 > $O/pmc_$cfg/fetch.log 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_$cfg/write -- $C2 > $O/pmc_$cfg/write.log 2>&1
+    python tools/make_traffic_json.py $O/pmc_$cfg > $O/traffic_$cfg.json 2> $O/traffic_$cfg.err
+  done
+  for cfg in kmeans ransac; do
+    C2="python bench.py --config $cfg --no-cpu-baseline"
+    mkdir -p $O/pmc_$cfg
+    timeout 300 $C2 > $O/pmc_$cfg/bench_line.json 2> $O/pmc_$cfg/bench.err
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_$cfg/fetch -- $C2 > $O/pmc_$cfg/fetch.log 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_$cfg/write -- $C2 > $O/pmc_$cfg/write.log 2>&1
+    python tools/make_traffic_json.py $O/pmc_$cfg --config $cfg $([ $cfg = kmeans ] && echo k_assign_grid || echo k_score) > $O/traffic_$cfg.json 2> $O/traffic_$cfg.err
+  done
+  head -5 $O/traffic_c2.json $O/traffic_c4_1gpu.json $O/traffic_kmeans.json $O/traffic_ransac.json
   prune
 fi
 if has c5pmc; then

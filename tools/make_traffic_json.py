@@ -10,6 +10,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (source_hash)
 
 d, subs = sys.argv[1], sys.argv[2:]
+if subs and subs[0] == "--config":
+    # the next-tier configurations: <pmc dir> --config kmeans|ransac <kernel regex>  ->  profiles/rNN_traffic_<config>.json
+    config, pat = subs[1], subs[2]
+    line = json.loads(open(f"{d}/bench_line.json").read())
+    c = collections.defaultdict(list)
+    for f in glob.glob(f"{d}/*/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if re.search(pat, r["Kernel_Name"]) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    skip = 3 if len(c["FETCH_SIZE"]) > 6 else 0      # (warm-up launches)
+    fb = sum(c["FETCH_SIZE"][skip:]) / max(len(c["FETCH_SIZE"][skip:]), 1) * 1024.0
+    wb = sum(c["WRITE_SIZE"][skip:]) / max(len(c["WRITE_SIZE"][skip:]), 1) * 1024.0
+    cfg = line.get("config", {})
+    print(json.dumps({"config": config, "kernel_pattern": pat, "traffic_bytes_per_launch": 2.0 * fb + wb, "FETCH_SIZE_bytes_reported": fb, "WRITE_SIZE_bytes": wb,
+                      "launches": len(c["FETCH_SIZE"]), "source_hash": bench.source_hash(bench.KERNEL_SOURCES[config]),
+                      "workload": {k: cfg.get(k) for k in (("n_points", "k") if config == "kmeans" else ("n_points",))},
+                      "algorithmic_bytes_per_launch": (line.get("roofline") or {}).get("algorithmic_bytes_per_launch"),
+                      "method": f"separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python bench.py --config {config} --no-cpu-baseline`; HBM bytes = "
+                                "2 x FETCH_SIZE + WRITE_SIZE (profiles/r02_calibration.txt)"}, indent=1))
+    sys.exit(0)
 line = json.loads(open(f"{d}/bench_line.json").read()) if os.path.exists(f"{d}/bench_line.json") else {}
 form = (line.get("roofline") or {}).get("form")
 if not subs:
