@@ -25,7 +25,7 @@ SYMBOLS = [
     "cilhip_icp_partial_sums", "cilhip_icp_apply_sums", "cilhip_icp_state", "cilhip_compute_residuals",
     "cilhip_get_grid_info", "cilhip_get_last_timing", "cilhip_enable_kernel_timing", "cilhip_prepare_source", "cilhip_get_last_run_forms", "cilhip_get_last_warm_iterations", "cilhip_get_last_matches_origin", "cilhip_get_matches_transform", "cilhip_get_last_form_timing", "cilhip_get_last_iteration_timing", "cilhip_get_last_run_trace", "cilhip_estimate_combined_two_sets", "cilhip_icp_run_two_sets", "cilhip_set_pair_weight_callback", "cilhip_kmeans_set_pruning", "cilhip_get_tie_count", "cilhip_get_tie_rule_stats", "cilhip_get_tie_order_info", "cilhip_build_tie_order", "cilhip_tie_order_create", "cilhip_tie_order_destroy", "cilhip_tie_order_tables", "cilhip_load_tie_order", "cilhip_multi_create", "cilhip_multi_destroy", "cilhip_multi_last_error", "cilhip_multi_context", "cilhip_multi_set_clouds", "cilhip_multi_icp_run", "cilhip_multi_repartitions", "cilhip_multi_last_host_time", "cilhip_multi_set_slab_slack", "cilhip_multi_shard_sizes", "cilhip_rank_comm_unique_id", "cilhip_rank_comm_prepare", "cilhip_rank_comm_init", "cilhip_rank_comm_destroy", "cilhip_icp_iterate_ranked", "cilhip_get_last_allreduce_timing", "cilhip_get_last_host_enqueue_time", "cilhip_set_slab_guard", "cilhip_get_slab_violation", "cilhip_get_slab_violation_state",
     "cilhip_set_option", "cilhip_option_count", "cilhip_option_info", "cilhip_set_option_id", "cilhip_get_option", "cilhip_get_last_timing2", "cilhip_set_shard_info", "cilhip_icp_partial_keys",
-    "cilhip_icp_sums_from_keys", "cilhip_icp_order_keys", "cilhip_icp_sums_from_ordered_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign", "cilhip_kmeans3f_ex", "cilhip_kmeans3f_assign_ex",
+    "cilhip_icp_sums_from_keys", "cilhip_icp_order_keys", "cilhip_icp_sums_from_ordered_keys", "cilhip_debug_counters", "cilhip_kmeans3f", "cilhip_kmeans3f_assign", "cilhip_kmeans3f_ex", "cilhip_kmeans3f_assign_ex", "cilhip_kmeans_shard_create", "cilhip_kmeans_shard_destroy", "cilhip_kmeans_shard_maxabs", "cilhip_kmeans_scale_exponent", "cilhip_kmeans_shard_assign", "cilhip_kmeans_shard_farthest", "cilhip_kmeans_shard_move_point", "cilhip_kmeans_shard_labels",
     "cilhip_plane_ransac3f", "cilhip_plane_score3f", "cilhip_plane_fit3f", "cilhip_transform_ransac3f", "cilhip_transform_score3f", "cilhip_transform_fit3f", "cilhip_knn3f", "cilhip_knn_set_tie_rule", "cilhip_normals_knn3f", "cilhip_normals_radius3f", "cilhip_radius_search3f",
 ]
 
@@ -147,6 +147,15 @@ def load():
     L.cilhip_kmeans3f_assign.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, vp]
     L.cilhip_kmeans3f_ex.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_size_t, C.c_float, C.c_int, vp, C.POINTER(C.c_size_t)]
     L.cilhip_kmeans3f_assign_ex.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_int, vp]
+    L.cilhip_kmeans_shard_create.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.cilhip_kmeans_shard_destroy.argtypes = [vp]
+    L.cilhip_kmeans_shard_destroy.restype = None
+    L.cilhip_kmeans_shard_maxabs.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cilhip_kmeans_scale_exponent.argtypes = [C.c_double, C.c_size_t]
+    L.cilhip_kmeans_shard_assign.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_uint64)]
+    L.cilhip_kmeans_shard_farthest.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint64)]
+    L.cilhip_kmeans_shard_move_point.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
+    L.cilhip_kmeans_shard_labels.argtypes = [vp, vp]
     L.cilhip_plane_ransac3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, vp, C.c_uint64, C.c_float, C.c_size_t, C.c_size_t,
                                         C.c_int, C.POINTER(PlaneModel), vp, vp]
     L.cilhip_plane_score3f.argtypes = [C.c_int, f32p, C.c_size_t, C.c_int, f32p, C.c_size_t, C.c_float, vp]

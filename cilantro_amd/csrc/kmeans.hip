@@ -15,8 +15,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <vector>
 
 namespace {
@@ -353,87 +355,88 @@ __global__ void k_set_label(uint32_t* labels, uint32_t i, uint32_t v) { if (thre
 // the pruned pass is the default; cilhip_kmeans_set_pruning(0) (or CILHIP_KMEANS_PRUNE=0 in the environment) keeps the brute-force pass
 static bool g_kmeans_prune = [] { const char* e = getenv("CILHIP_KMEANS_PRUNE"); return !(e && e[0] == '0'); }();
 
-#define KM_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = CILHIP_ERR_HIP; goto done; } } while (0)
+}  // namespace
 
-int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
-                uint32_t* labels_out, size_t* iterations_out, bool assign_only, bool kd_order = false) {
-  if (!xyz || !centroids || k == 0 || n == 0 || n >= 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
-  if (k > KM_MAX_K) return CILHIP_ERR_UNSUPPORTED;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CILHIP_ERR_NO_DEVICE;
-  if (device < 0 || device >= ndev) return CILHIP_ERR_INVALID;
-  int rc = CILHIP_OK;
-  float *d_xyz = nullptr, *d_c = nullptr;
+// ---- one shard of the points on one device: the state a Lloyd loop works on ---------------------------------------------------------
+// The single-device entry points (kmeans_impl below) drive ONE shard that holds all points; a multi-GPU run (points
+// sharded, centroids replicated, all-reduce of k x (3 sums + count)) drives one shard per rank through the same calls
+// (cilhip_kmeans_shard_*; cilantro_amd/distributed_models.py is the loop).  The cluster sums are exact fixed-point integers, so the
+// all-reduced sums -- and with them the centroids and every later assignment -- are the single-device run's bit for bit.
+struct cilhip_kmeans_shard {
+  int device = 0;
+  hipStream_t s = nullptr;
+  float* d_xyz = nullptr;
+  bool own_xyz = false;
+  size_t n = 0, k = 0, kpad = 0;
+  uint64_t index_offset = 0;        // global index of this shard's point 0 (the empty-cluster repair's tie rule: lowest GLOBAL index)
+  float* d_c = nullptr;
   uint32_t* d_lab = nullptr;
   long long* d_sums = nullptr;
   unsigned int* d_changed = nullptr;
   unsigned long long* d_best = nullptr;
-  hipStream_t s = nullptr;
-  std::vector<long long> hs(k * 4);
-  std::vector<float> c_old(3 * k);
-  const size_t kpad8 = (k + 7) & ~(size_t)7;
-  float4 pad4; pad4.x = pad4.y = pad4.z = INFINITY; { const uint32_t none = 0xFFFFFFFFu; std::memcpy(&pad4.w, &none, 4); }
-  std::vector<float4> cs_host(kpad8 + 8, pad4);
-  std::vector<uint32_t> cstart_host;
   float4* d_cs = nullptr;
   uint32_t* d_cstart = nullptr;
   uint32_t* d_tleaf = nullptr;      // kd branch: order tables of the reference's tree over the centroids (leaf, slot by centroid index)
   uint2* d_tls = nullptr;
   uint4* d_tnodes = nullptr;
-  size_t iter = 0;
-  {
-    KM_CK(hipSetDevice(device));
-    KM_CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  std::vector<float4> cs_host;
+  std::vector<uint32_t> cstart_host;
+  std::vector<float> cpad;
+
+  int init(int dev, const float* xyz, size_t n_, int mem, size_t k_, uint64_t offset) {
+    device = dev; n = n_; k = k_; kpad = (k + 7) & ~(size_t)7; index_offset = offset;
+    float4 pad4; pad4.x = pad4.y = pad4.z = INFINITY; { const uint32_t none = 0xFFFFFFFFu; std::memcpy(&pad4.w, &none, 4); }
+    cs_host.assign(kpad + 8, pad4);
+    cpad.assign(3 * kpad, INFINITY);                              // device copy padded with +inf centroids
+#define KS_CK(x) do { if ((x) != hipSuccess) return CILHIP_ERR_HIP; } while (0)
+    KS_CK(hipSetDevice(device));
+    KS_CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     if (mem == CILHIP_MEM_DEVICE) {
       d_xyz = const_cast<float*>(xyz);
     } else {
-      KM_CK(hipMalloc(&d_xyz, 3 * n * sizeof(float)));
-      KM_CK(hipMemcpyAsync(d_xyz, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
+      KS_CK(hipMalloc(&d_xyz, (n ? 3 * n : 1) * sizeof(float)));
+      own_xyz = true;
+      if (n) KS_CK(hipMemcpyAsync(d_xyz, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, s));
     }
-    const size_t kpad = (k + 7) & ~(size_t)7;                     // device copy padded with +inf centroids
-    std::vector<float> cpad(3 * kpad, INFINITY);
-    KM_CK(hipMalloc(&d_c, 3 * kpad * sizeof(float)));
-    KM_CK(hipMalloc(&d_lab, n * sizeof(uint32_t)));
-    KM_CK(hipMalloc(&d_sums, ((k + 7) & ~(size_t)7) * 4 * sizeof(long long)));
-    KM_CK(hipMalloc(&d_changed, sizeof(unsigned int)));
-    KM_CK(hipMalloc(&d_best, sizeof(unsigned long long)));
-    KM_CK(hipMemsetAsync(d_lab, 0, n * sizeof(uint32_t), s));   // point_to_cluster_index_map_.resize(n): zeros (:80)
-    // fixed-point scale: |x| * 2^S < 2^(62 - ceil(log2 n)) so that a whole cluster's sum cannot overflow int64
-    double maxabs = 0.0;
-    {
-      unsigned int hmax = 0;   // max |x| as f32 bits (non-negative floats order like unsigned ints)
-      KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
-      hipLaunchKernelGGL(k_maxabs_bits, dim3(1024), dim3(256), 0, s, d_xyz, 3 * n, d_changed);
-      KM_CK(hipMemcpyAsync(&hmax, d_changed, sizeof(hmax), hipMemcpyDeviceToHost, s));
-      KM_CK(hipStreamSynchronize(s));
-      float f;
-      std::memcpy(&f, &hmax, sizeof(f));
-      maxabs = (double)f;
-    }
-    int e = 0;
-    (void)std::frexp(maxabs > 0.0 ? maxabs : 1.0, &e);           // maxabs < 2^e
-    int nbits = 0;
-    while (((size_t)1 << nbits) < n) ++nbits;
-    const int S = 62 - nbits - e;
-    const double scale = std::ldexp(1.0, S);
-    const int nblocks = (int)std::min<size_t>((n / 2 + KM_THREADS - 1) / KM_THREADS + 1, 1024);
-    const float tol_sq = tol * tol;
-    const size_t rounds = assign_only ? 1 : max_iter;
-    while (iter < rounds) {
-      std::memcpy(cpad.data(), centroids, 3 * k * sizeof(float));
-      KM_CK(hipMemcpyAsync(d_c, cpad.data(), 3 * kpad * sizeof(float), hipMemcpyHostToDevice, s));
-      KM_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
-      KM_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
+    KS_CK(hipMalloc(&d_c, 3 * kpad * sizeof(float)));
+    KS_CK(hipMalloc(&d_lab, (n ? n : 1) * sizeof(uint32_t)));
+    KS_CK(hipMalloc(&d_sums, kpad * 4 * sizeof(long long)));
+    KS_CK(hipMalloc(&d_changed, sizeof(unsigned int)));
+    KS_CK(hipMalloc(&d_best, sizeof(unsigned long long)));
+    KS_CK(hipMemsetAsync(d_lab, 0, (n ? n : 1) * sizeof(uint32_t), s));   // point_to_cluster_index_map_.resize(n): zeros (:80)
+    return CILHIP_OK;
+  }
+  // max |coordinate| of the shard (f32; 0 for an empty one)
+  int maxabs(float* out) {
+    KS_CK(hipSetDevice(device));
+    unsigned int hmax = 0;   // max |x| as f32 bits (non-negative floats order like unsigned ints)
+    KS_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
+    if (n) hipLaunchKernelGGL(k_maxabs_bits, dim3(1024), dim3(256), 0, s, d_xyz, 3 * n, d_changed);
+    KS_CK(hipMemcpyAsync(&hmax, d_changed, sizeof(hmax), hipMemcpyDeviceToHost, s));
+    KS_CK(hipStreamSynchronize(s));
+    std::memcpy(out, &hmax, sizeof(float));
+    return CILHIP_OK;
+  }
+  // one assignment pass over the shard under `centroids` (kmeans.hpp:95-119 / :86-94): labels updated in place, the shard's exact
+  // fixed-point sums {x, y, z, count} per cluster (scale 2^S) and the number of labels that changed
+  int assign(const float* centroids, double scale, bool kd_order, bool assign_only, long long* sums_out, unsigned int* changed_out) {
+    KS_CK(hipSetDevice(device));
+    std::memcpy(cpad.data(), centroids, 3 * k * sizeof(float));
+    KS_CK(hipMemcpyAsync(d_c, cpad.data(), 3 * kpad * sizeof(float), hipMemcpyHostToDevice, s));
+    KS_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
+    KS_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
+    if (n) {
+      const int nblocks = (int)std::min<size_t>((n / 2 + KM_THREADS - 1) / KM_THREADS + 1, 1024);
       KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1, {nullptr, nullptr, nullptr, 0}};
       if (kd_order && cilhip::g_knn_tie_rule != 0 && k > 1) {
         // the tree the reference builds over THIS iteration's centroids (kmeans.hpp:87), as order tables (about a millisecond)
         bool finite = true;
         for (size_t t = 0; t < 3 * k; ++t) finite = finite && std::isfinite(centroids[t]);
         if (finite) {
-          if (!d_tleaf) { KM_CK(hipMalloc(&d_tleaf, 2 * kpad * sizeof(uint32_t))); KM_CK(hipMalloc(&d_tls, kpad * sizeof(uint2))); }
+          if (!d_tleaf) { KS_CK(hipMalloc(&d_tleaf, 2 * kpad * sizeof(uint32_t))); KS_CK(hipMalloc(&d_tls, kpad * sizeof(uint2))); }
           if (d_tnodes) { (void)hipFree(d_tnodes); d_tnodes = nullptr; }
           size_t nn = 0; int depth = 0;
-          KM_CK(cilhip::tie_order_build_device(d_c, nullptr, (uint32_t)k, s, d_tleaf, d_tleaf + kpad, &d_tnodes, &nn, &depth));
+          KS_CK(cilhip::tie_order_build_device(d_c, nullptr, (uint32_t)k, s, d_tleaf, d_tleaf + kpad, &d_tnodes, &nn, &depth));
           hipLaunchKernelGGL(k_zip_tables, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_tleaf, (const uint32_t*)(d_tleaf + kpad), d_tls, (uint32_t)k);
           a.tie.leaf_slot = d_tls; a.tie.nodes = d_tnodes; a.tie.mode = 1;
         }
@@ -443,21 +446,112 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
       if (pruned) {
         // the grid of THIS iteration's centroids: sorted list + cell table, 20 KB
         const size_t ncell1 = (size_t)gr.g * gr.g * gr.g + 1;
-        if (!d_cs) { KM_CK(hipMalloc(&d_cs, (kpad + 8) * sizeof(float4))); KM_CK(hipMalloc(&d_cstart, (16 * 16 * 16 + 1) * sizeof(uint32_t))); }
-        KM_CK(hipMemcpyAsync(d_cs, cs_host.data(), (kpad + 8) * sizeof(float4), hipMemcpyHostToDevice, s));
-        KM_CK(hipMemcpyAsync(d_cstart, cstart_host.data(), ncell1 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        if (!d_cs) { KS_CK(hipMalloc(&d_cs, (kpad + 8) * sizeof(float4))); KS_CK(hipMalloc(&d_cstart, (16 * 16 * 16 + 1) * sizeof(uint32_t))); }
+        KS_CK(hipMemcpyAsync(d_cs, cs_host.data(), (kpad + 8) * sizeof(float4), hipMemcpyHostToDevice, s));
+        KS_CK(hipMemcpyAsync(d_cstart, cstart_host.data(), ncell1 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         const size_t lds = kpad * 4 * sizeof(long long) + (kpad + 8) * sizeof(float4) + ncell1 * sizeof(uint32_t);
         const int nb_g = (int)std::min<size_t>((n + KM_THREADS - 1) / KM_THREADS, 2048);
         hipLaunchKernelGGL(k_assign_grid, dim3(nb_g), dim3(KM_THREADS), lds, s, a, gr, (const float4*)d_cs, (const uint32_t*)d_cstart);
       }
       else if (kd_order) hipLaunchKernelGGL(k_assign_accumulate<true>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
       else hipLaunchKernelGGL(k_assign_accumulate<false>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
-      KM_CK(hipGetLastError());
-      if (assign_only) break;
+      KS_CK(hipGetLastError());
+    }
+    if (assign_only) return CILHIP_OK;
+    unsigned int changed = 0;
+    KS_CK(hipMemcpyAsync(&changed, d_changed, sizeof(changed), hipMemcpyDeviceToHost, s));
+    KS_CK(hipMemcpyAsync(sums_out, d_sums, k * 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
+    KS_CK(hipStreamSynchronize(s));
+    *changed_out = changed;
+    return CILHIP_OK;
+  }
+  // farthest member of `cluster` from `center` among the shard's points: key = (bits(d) << 32) | (0xFFFFFFFF - GLOBAL index), 0 = no
+  // member; the maximum over shards names the point the reference's sweep keeps (ties: lowest index)
+  int farthest(uint32_t cluster, const float center[3], unsigned long long* key_out) {
+    KS_CK(hipSetDevice(device));
+    KS_CK(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), s));
+    if (n) hipLaunchKernelGGL(k_farthest_member, dim3(1024), dim3(256), 0, s, d_xyz, d_lab, (uint32_t)n, cluster, center[0], center[1], center[2], d_best);
+    unsigned long long best = 0;
+    KS_CK(hipMemcpyAsync(&best, d_best, sizeof(best), hipMemcpyDeviceToHost, s));
+    KS_CK(hipStreamSynchronize(s));
+    if (best) {      // local -> global index
+      const uint32_t li = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
+      best = (best & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(index_offset + li));
+    }
+    *key_out = best;
+    return CILHIP_OK;
+  }
+  // the point with LOCAL index li moves to `cluster`; its coordinates
+  int move_point(uint32_t li, uint32_t cluster, float p[3]) {
+    if (li >= n) return CILHIP_ERR_INVALID;
+    KS_CK(hipSetDevice(device));
+    hipLaunchKernelGGL(k_set_label, dim3(1), dim3(64), 0, s, d_lab, li, cluster);
+    KS_CK(hipMemcpyAsync(p, d_xyz + 3 * (size_t)li, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    KS_CK(hipStreamSynchronize(s));
+    return CILHIP_OK;
+  }
+  int labels(uint32_t* out) {
+    KS_CK(hipSetDevice(device));
+    if (n) KS_CK(hipMemcpyAsync(out, d_lab, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    KS_CK(hipStreamSynchronize(s));
+    return CILHIP_OK;
+  }
+#undef KS_CK
+  void release() {
+    (void)hipSetDevice(device);
+    if (s) (void)hipStreamSynchronize(s);
+    if (own_xyz && d_xyz) (void)hipFree(d_xyz);
+    if (d_c) (void)hipFree(d_c);
+    if (d_lab) (void)hipFree(d_lab);
+    if (d_sums) (void)hipFree(d_sums);
+    if (d_changed) (void)hipFree(d_changed);
+    if (d_best) (void)hipFree(d_best);
+    if (d_cs) (void)hipFree(d_cs);
+    if (d_cstart) (void)hipFree(d_cstart);
+    if (d_tleaf) (void)hipFree(d_tleaf);
+    if (d_tls) (void)hipFree(d_tls);
+    if (d_tnodes) (void)hipFree(d_tnodes);
+    if (s) (void)hipStreamDestroy(s);
+    d_xyz = nullptr; s = nullptr;
+  }
+};
+
+namespace {
+
+// the fixed-point scale of the cluster sums: |x| * 2^S < 2^(62 - ceil(log2 n)) so that a whole cluster's sum cannot overflow int64
+// (n = ALL points, maxabs = the largest |coordinate| of all of them: every shard of a run uses the same S)
+int kmeans_scale_exponent(double maxabs, size_t n) {
+  int e = 0;
+  (void)std::frexp(maxabs > 0.0 ? maxabs : 1.0, &e);           // maxabs < 2^e
+  int nbits = 0;
+  while (((size_t)1 << nbits) < n) ++nbits;
+  return 62 - nbits - e;
+}
+
+int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
+                uint32_t* labels_out, size_t* iterations_out, bool assign_only, bool kd_order = false) {
+  if (!xyz || !centroids || k == 0 || n == 0 || n >= 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
+  if (k > KM_MAX_K) return CILHIP_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CILHIP_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return CILHIP_ERR_INVALID;
+  int rc = CILHIP_OK;
+  std::vector<long long> hs(k * 4);
+  std::vector<float> c_old(3 * k);
+  size_t iter = 0;
+  cilhip_kmeans_shard sh;
+#define KM_RC(x) do { rc = (x); if (rc != CILHIP_OK) goto done; } while (0)
+  {
+    KM_RC(sh.init(device, xyz, n, mem, k, 0));
+    float fmax = 0.0f;
+    KM_RC(sh.maxabs(&fmax));
+    const double scale = std::ldexp(1.0, kmeans_scale_exponent((double)fmax, n));
+    const float tol_sq = tol * tol;
+    const size_t rounds = assign_only ? 1 : max_iter;
+    while (iter < rounds) {
       unsigned int changed = 0;
-      KM_CK(hipMemcpyAsync(&changed, d_changed, sizeof(changed), hipMemcpyDeviceToHost, s));
-      KM_CK(hipMemcpyAsync(hs.data(), d_sums, k * 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
-      KM_CK(hipStreamSynchronize(s));
+      KM_RC(sh.assign(centroids, scale, kd_order, assign_only, hs.data(), &changed));
+      if (assign_only) break;
       if (changed == 0 && iter > 0) break;                                            // kmeans.hpp:122
       if (tol > 0.0f) std::memcpy(c_old.data(), centroids, 3 * k * sizeof(float));   // :123
       // empty clusters (:134-176), processed in ascending cluster index like the reference
@@ -467,16 +561,11 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
         for (size_t j = 1; j < k; ++j) if (hs[j * 4 + 3] > hs[mx * 4 + 3]) mx = j;
         const double cm = (double)hs[mx * 4 + 3];
         const float oc[3] = {(float)((double)hs[mx * 4] / scale / cm), (float)((double)hs[mx * 4 + 1] / scale / cm), (float)((double)hs[mx * 4 + 2] / scale / cm)};
-        KM_CK(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(k_farthest_member, dim3(1024), dim3(256), 0, s, d_xyz, d_lab, (uint32_t)n, (uint32_t)mx, oc[0], oc[1], oc[2], d_best);
         unsigned long long best = 0;
-        KM_CK(hipMemcpyAsync(&best, d_best, sizeof(best), hipMemcpyDeviceToHost, s));
-        KM_CK(hipStreamSynchronize(s));
+        KM_RC(sh.farthest((uint32_t)mx, oc, &best));
         const uint32_t mi = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu);
-        hipLaunchKernelGGL(k_set_label, dim3(1), dim3(64), 0, s, d_lab, mi, (uint32_t)i);
         float p[3];
-        KM_CK(hipMemcpyAsync(p, d_xyz + 3 * (size_t)mi, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
-        KM_CK(hipStreamSynchronize(s));
+        KM_RC(sh.move_point(mi, (uint32_t)i, p));
         for (int d = 0; d < 3; ++d) hs[mx * 4 + d] -= (long long)std::llrint((double)p[d] * scale);
         hs[mx * 4 + 3]--; hs[i * 4 + 3]++;   // the reference does not add the point to cluster i's sum (:171-175)
       }
@@ -493,25 +582,12 @@ int kmeans_impl(int device, const float* xyz, size_t n, int mem, float* centroid
         if (mxs < tol_sq) break;
       }
     }
-    if (labels_out) {
-      KM_CK(hipMemcpyAsync(labels_out, d_lab, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    }
-    KM_CK(hipStreamSynchronize(s));
+    if (labels_out) KM_RC(sh.labels(labels_out));
   }
 done:
+#undef KM_RC
   if (iterations_out) *iterations_out = iter;
-  if (mem != CILHIP_MEM_DEVICE && d_xyz) (void)hipFree(d_xyz);
-  if (d_c) (void)hipFree(d_c);
-  if (d_lab) (void)hipFree(d_lab);
-  if (d_sums) (void)hipFree(d_sums);
-  if (d_changed) (void)hipFree(d_changed);
-  if (d_best) (void)hipFree(d_best);
-  if (d_cs) (void)hipFree(d_cs);
-  if (d_cstart) (void)hipFree(d_cstart);
-  if (d_tleaf) (void)hipFree(d_tleaf);
-  if (d_tls) (void)hipFree(d_tls);
-  if (d_tnodes) (void)hipFree(d_tnodes);
-  if (s) (void)hipStreamDestroy(s);
+  sh.release();
   return rc;
 }
 
@@ -520,6 +596,46 @@ done:
 extern "C" {
 
 int cilhip_kmeans_set_pruning(int on) { g_kmeans_prune = on != 0; return CILHIP_OK; }
+
+int cilhip_kmeans_shard_create(int device, const float* xyz, size_t n, int mem, size_t k, uint64_t index_offset, cilhip_kmeans_shard** out) {
+  if (!out || (!xyz && n) || k == 0 || n >= 0xFFFFFFF0ull) return CILHIP_ERR_INVALID;
+  *out = nullptr;
+  if (k > KM_MAX_K) return CILHIP_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CILHIP_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return CILHIP_ERR_INVALID;
+  cilhip_kmeans_shard* h = new (std::nothrow) cilhip_kmeans_shard();
+  if (!h) return CILHIP_ERR_HIP;
+  int rc = CILHIP_ERR_HIP;
+  try { rc = h->init(device, xyz, n, mem, k, index_offset); } catch (...) { rc = CILHIP_ERR_HIP; }
+  if (rc != CILHIP_OK) { h->release(); delete h; return rc; }
+  *out = h;
+  return CILHIP_OK;
+}
+void cilhip_kmeans_shard_destroy(cilhip_kmeans_shard* h) { if (h) { h->release(); delete h; } }
+int cilhip_kmeans_shard_maxabs(cilhip_kmeans_shard* h, float* maxabs_out) { return (h && maxabs_out) ? h->maxabs(maxabs_out) : CILHIP_ERR_INVALID; }
+int cilhip_kmeans_scale_exponent(double maxabs_all, size_t n_all) { return kmeans_scale_exponent(maxabs_all, n_all); }
+int cilhip_kmeans_shard_assign(cilhip_kmeans_shard* h, const float* centroids, int scale_exponent, int use_kd_tree, int64_t* sums_out, uint64_t* changed_out) {
+  if (!h || !centroids || !sums_out || !changed_out) return CILHIP_ERR_INVALID;
+  unsigned int ch = 0;
+  static_assert(sizeof(long long) == sizeof(int64_t), "the fixed-point sums are 64-bit");
+  int rc = CILHIP_ERR_HIP;
+  try { rc = h->assign(centroids, std::ldexp(1.0, scale_exponent), use_kd_tree != 0, false, reinterpret_cast<long long*>(sums_out), &ch); } catch (...) { rc = CILHIP_ERR_HIP; }
+  *changed_out = ch;
+  return rc;
+}
+int cilhip_kmeans_shard_farthest(cilhip_kmeans_shard* h, uint32_t cluster, const float center[3], uint64_t* key_out) {
+  if (!h || !center || !key_out) return CILHIP_ERR_INVALID;
+  unsigned long long key = 0;
+  const int rc = h->farthest(cluster, center, &key);
+  *key_out = key;
+  return rc;
+}
+int cilhip_kmeans_shard_move_point(cilhip_kmeans_shard* h, uint64_t global_index, uint32_t to_cluster, float xyz_out[3]) {
+  if (!h || !xyz_out || global_index < h->index_offset || global_index - h->index_offset >= h->n) return CILHIP_ERR_INVALID;
+  return h->move_point((uint32_t)(global_index - h->index_offset), to_cluster, xyz_out);
+}
+int cilhip_kmeans_shard_labels(cilhip_kmeans_shard* h, uint32_t* labels_out) { return (h && (labels_out || h->n == 0)) ? h->labels(labels_out) : CILHIP_ERR_INVALID; }
 
 int cilhip_kmeans3f(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol,
                     uint32_t* labels_out, size_t* iterations_out) {

@@ -305,6 +305,29 @@ int cilhip_kmeans3f_ex(int device, const float* xyz, size_t n, int mem, float* c
 int cilhip_kmeans3f_assign_ex(int device, const float* xyz, size_t n, int mem, const float* centroids, size_t k, int use_kd_tree,
                               uint32_t* labels_out);
 
+/* KMeans over SHARDS of the points (last row: "points sharded, centroids replicated; all-reduce of k x (3 sums +
+ * count)"): one shard object per device / rank holds its points and their labels; a Lloyd iteration is cilhip_kmeans_shard_assign on
+ * every shard under the same centroids, the SUM of the shards' fixed-point sums {x, y, z, count} per cluster (int64: exact, order-free --
+ * MPI / RCCL all-reduce of 4k integers), then clustering/kmeans.hpp:122-188 on the summed values, identically on every rank.  All shards
+ * of a run use ONE scale exponent: cilhip_kmeans_scale_exponent(largest |coordinate| over all shards, total point count).  The
+ * empty-cluster repair (:134-176) needs the farthest member of a cluster over all shards: cilhip_kmeans_shard_farthest returns this shard's
+ * candidate as a key (bits(distance^2) << 32 | 0xFFFFFFFF - GLOBAL index; 0 = no member) whose MAXIMUM over the shards names the
+ * reference's point (ties: lowest index); its owner moves it (cilhip_kmeans_shard_move_point: new label, coordinates out -- every rank
+ * subtracts them from the donor cluster's sums).  With one shard holding all points this is cilhip_kmeans3f_ex itself (it runs on these
+ * calls); with several the centroids, labels and iteration counts are the single-device run's bit for bit (the sums are integers).
+ * cilantro_amd/distributed_models.py: ShardedKMeans3f is the loop over torch.distributed; tests/test_distributed_cpu.py (gloo, world 2)
+ * and tests/test_gpu_distributed.py (two processes, HIP shards). */
+typedef struct cilhip_kmeans_shard cilhip_kmeans_shard;
+int cilhip_kmeans_shard_create(int device, const float* xyz, size_t n, int mem, size_t k, uint64_t index_offset, cilhip_kmeans_shard** out);
+void cilhip_kmeans_shard_destroy(cilhip_kmeans_shard* shard);
+int cilhip_kmeans_shard_maxabs(cilhip_kmeans_shard* shard, float* maxabs_out);
+int cilhip_kmeans_scale_exponent(double maxabs_all, size_t n_all);
+int cilhip_kmeans_shard_assign(cilhip_kmeans_shard* shard, const float* centroids, int scale_exponent, int use_kd_tree, int64_t* sums_out /* [4k] */,
+                               uint64_t* changed_out);
+int cilhip_kmeans_shard_farthest(cilhip_kmeans_shard* shard, uint32_t cluster, const float center[3], uint64_t* key_out);
+int cilhip_kmeans_shard_move_point(cilhip_kmeans_shard* shard, uint64_t global_index, uint32_t to_cluster, float xyz_out[3]);
+int cilhip_kmeans_shard_labels(cilhip_kmeans_shard* shard, uint32_t* labels_out);
+
 /* ---- next tier: PlaneRANSACEstimator3f ----------------------------------- */
 typedef struct {
   float normal[3];     /* Eigen::Hyperplane<float,3>::normal()  (unit; sign as PCA leaves it)               */

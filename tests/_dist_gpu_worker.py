@@ -24,6 +24,52 @@ def clouds(kind, n):
     return d
 
 
+def main_models(mode, kind, n, iters):
+    """SURVEY.md 8(e), last row: KMeans / RANSAC scoring with the points sharded over the ranks (cilantro_amd/distributed_models.py),
+    HIP shards on every rank, against the single-device entry points on rank 0"""
+    from cilantro_amd import distributed_models as dm
+    from cilantro_amd.clustering import KMeans3f
+    from cilantro_amd.model_estimation import PlaneRANSACEstimator3f
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(11)
+    x = rng.random((n, 3), dtype=np.float32)
+    out = {"rank": rank}
+    cut = [0, n // 3, n] if world == 2 else [round(i * n / world) for i in range(world + 1)]
+    lo, hi = cut[rank], cut[rank + 1]
+    if mode == "kmeans":
+        k, tol, kd = (1024 if kind == "big" else 64), (2e-2 if kind == "tol" else 0.0), kind == "kd"
+        c0 = x[:k].copy()
+        if kind == "empty":
+            c0[5] = [50.0, 50.0, 50.0]; c0[40] = [-40.0, 3.0, 2.0]
+        if kind == "kd":                # lattice centroids + half-lattice points: exact ties, the reference's tree order on every rank
+            g = 4
+            c0 = np.stack(np.meshgrid(np.arange(g), np.arange(g), np.arange(g), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)[rng.permutation(g ** 3)]
+            x = (rng.integers(-1, 2 * g + 1, size=(n, 3)) * 0.5).astype(np.float32)
+        eng = dm.HipKMeansShard(x[lo:hi], len(c0), lo, 0)
+        km = dm.ShardedKMeans3f(eng, dist).cluster(c0, max_iter=iters, tol=tol, use_kd_tree=kd)
+        out.update(cent=km.getClusterCentroids().astype(np.float64).tolist(), lab=km.getPointToClusterIndexMap().tolist(), it=km.getNumberOfPerformedIterations())
+        eng.close()
+        if rank == 0:
+            one = KMeans3f(x).cluster(c0, max_iter=iters, tol=tol, use_kd_tree=kd)
+            out.update(one_cent=one.getClusterCentroids().astype(np.float64).tolist(), one_lab=one.getPointToClusterIndexMap().tolist(), one_it=one.getNumberOfPerformedIterations())
+    else:
+        x = x * 2 - 1
+        x[: n // 2, 2] = 0.25 * x[: n // 2, 0] + 0.1
+        nrm = rng.normal(size=(256, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        planes = np.concatenate([nrm, rng.uniform(-0.5, 0.5, (256, 1))], axis=1).astype(np.float32)
+        pe = PlaneRANSACEstimator3f(x[lo:hi]).setMaxInlierResidual(0.02)
+        tot = dm.sharded_plane_inlier_counts(pe.countInliers, planes, dist)
+        out.update(counts=np.asarray(tot).tolist())
+        if rank == 0:
+            out.update(one_counts=np.asarray(PlaneRANSACEstimator3f(x).setMaxInlierResidual(0.02).countInliers(planes)).tolist())
+    rows = [None] * world
+    dist.all_gather_object(rows, out)
+    if rank == 0:
+        print("RESULT " + json.dumps({"world": world, "rows": rows}))
+    dist.destroy_process_group()
+
+
 def main():
     import signal
     signal.alarm(600)
@@ -31,6 +77,8 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
+    if mode in ("kmeans", "ransac"):
+        return main_models(mode, kind, n, iters)
     d = clouds(kind, n)
     p = distributed.default_params(capi.METRIC_COMBINED, max_sq_dist=float(d["max_sq_dist"]), max_iter=iters, conv_tol=0.0)
     T0 = np.eye(4, dtype=np.float32)

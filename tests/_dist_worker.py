@@ -449,10 +449,116 @@ def main_rank_comm():
     dist.destroy_process_group()
 
 
+class OracleKMeansShard:
+    """Same interface as cilantro_amd.distributed_models.HipKMeansShard, computed on the CPU by the checker: the oracle's assignment
+    (kmeans.hpp:95-119 / :86-94) and numpy for the fixed-point sums."""
+
+    def __init__(self, points, k, index_offset=0):
+        self.x = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        self.n, self.k, self.index_offset = len(self.x), int(k), int(index_offset)
+        self.lab = np.zeros(self.n, np.int64)
+
+    def maxabs(self):
+        return float(np.abs(self.x).max()) if self.n else 0.0
+
+    def assign(self, centroids, scale_exp, use_kd_tree=False):
+        sums = np.zeros((self.k, 4), np.int64)
+        if self.n == 0:
+            return sums, 0
+        new, _ = orc.kmeans_assign(self.x, centroids, use_kd_tree=use_kd_tree)
+        changed = int((new != self.lab).sum())
+        self.lab = new.astype(np.int64)
+        fx = np.rint(self.x.astype(np.float64) * np.ldexp(1.0, scale_exp)).astype(np.int64)
+        for d in range(3):
+            np.add.at(sums[:, d], self.lab, fx[:, d])
+        np.add.at(sums[:, 3], self.lab, 1)
+        return sums, changed
+
+    def farthest(self, cluster, center):
+        m = np.nonzero(self.lab == cluster)[0]
+        if len(m) == 0:
+            return 0
+        c = np.asarray(center, np.float32)
+        d = c[None, :] - self.x[m]
+        e = d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])
+        keys = (e.astype(np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - (m + self.index_offset).astype(np.uint64))
+        return int(keys.max())
+
+    def move_point(self, global_index, to_cluster):
+        li = int(global_index) - self.index_offset
+        self.lab[li] = to_cluster
+        return self.x[li].copy()
+
+    def labels(self):
+        return self.lab.copy()
+
+
+def main_kmeans(n, case):
+    """ShardedKMeans3f over gloo against the SAME loop over one shard that holds all points (bit for bit: the sums are integers) and
+    against the oracle's KMeans (the reference's loop: f32 serial sums)"""
+    from cilantro_amd import distributed_models as dm
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(7)
+    x = rng.random((n, 3), dtype=np.float32)
+    k, iters, tol, kd = 24, 12, 0.0, False
+    c0 = x[:k].copy()
+    if case == "empty":                 # a far-away initial centroid attracts nothing: the repair (kmeans.hpp:134-176) across ranks
+        c0[5] = [50.0, 50.0, 50.0]; c0[11] = [-40.0, 3.0, 2.0]; iters = 4
+    elif case == "tol":
+        iters, tol = 100, 1e-3
+    elif case == "kd":
+        kd = True
+    # uneven shards, one of them possibly holding the moved point
+    cut = [0, n // 3, n] if world == 2 else [round(i * n / world) for i in range(world + 1)]
+    lo, hi = cut[rank], cut[rank + 1]
+    km = dm.ShardedKMeans3f(OracleKMeansShard(x[lo:hi], k, lo), dist).cluster(c0, max_iter=iters, tol=tol, use_kd_tree=kd)
+    rows = [None] * world
+    dist.all_gather_object(rows, {"rank": rank, "cent": km.getClusterCentroids().tolist(), "lab": km.getPointToClusterIndexMap().tolist(), "it": km.getNumberOfPerformedIterations()})
+    if rank == 0:
+        one = dm.ShardedKMeans3f(OracleKMeansShard(x, k, 0), None).cluster(c0, max_iter=iters, tol=tol, use_kd_tree=kd)
+        lab = np.concatenate([np.array(r["lab"], np.int64) for r in sorted(rows, key=lambda r: r["rank"])])
+        co, lo_, ito = orc.kmeans(x, c0, max_iter=iters, tol=tol, mode=1, use_kd_tree=kd)
+        print("RESULT " + json.dumps({"world": world, "same_centroids_on_all_ranks": all(r["cent"] == rows[0]["cent"] for r in rows),
+                                       "equals_one_shard": bool(np.array_equal(np.array(rows[0]["cent"], np.float32), one.getClusterCentroids())
+                                                                and np.array_equal(lab, one.getPointToClusterIndexMap()) and rows[0]["it"] == one.getNumberOfPerformedIterations()),
+                                       "it": rows[0]["it"], "oracle_it": int(ito), "centroid_err_vs_oracle": float(np.abs(np.array(rows[0]["cent"]) - co).max()),
+                                       "label_mismatches_vs_oracle": int((lab != lo_).sum())}))
+    dist.destroy_process_group()
+
+
+def main_ransac_counts(n):
+    from cilantro_amd import distributed_models as dm
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(9)
+    x = (rng.random((n, 3), dtype=np.float32) * 2 - 1)
+    x[: n // 2, 2] = 0.25 * x[: n // 2, 0] + 0.1
+    nrm = rng.normal(size=(32, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    planes = np.concatenate([nrm, rng.uniform(-0.5, 0.5, (32, 1))], axis=1).astype(np.float32)
+    planes[0] = np.array([0.25, 0.0, -1.0, 0.1], np.float32) / np.float32(np.sqrt(1.0625))
+    thr = np.float32(0.02)
+
+    def count(shard):
+        return lambda pl: np.array([int((np.abs((shard * p[None, :3]).sum(1) + p[3]) <= thr).sum()) for p in pl], np.int64)
+
+    lo, hi = distributed.shard_bounds(n, rank, world)
+    tot = dm.sharded_plane_inlier_counts(count(x[lo:hi]), planes, dist)
+    if rank == 0:
+        print("RESULT " + json.dumps({"world": world, "equal": bool(np.array_equal(tot, count(x)(planes))), "best": int(np.argmax(tot))}))
+    dist.destroy_process_group()
+
+
 def main():
     import signal
     signal.alarm(300)      # a worker never outlives its test (SIGALRM's default action terminates the process)
     metric = int(sys.argv[1]); n = int(sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3].startswith("kmeans"):
+        return main_kmeans(n, sys.argv[3][6:])
+    if len(sys.argv) > 3 and sys.argv[3] == "ransac":
+        return main_ransac_counts(n)
     if len(sys.argv) > 3 and sys.argv[3] == "rankcomm":
         return main_rank_comm()
     if len(sys.argv) > 3 and sys.argv[3] == "tshard":

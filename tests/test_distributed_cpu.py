@@ -174,3 +174,20 @@ def test_slab_partition_is_exact(orc):
                 gi, gs, gv = full.find_correspondences(q, d["max_sq_dist"])
                 assert np.array_equal(ls, gs) and np.array_equal(part.dst_index[li], gi) and np.array_equal(lv, gv)
         assert (owned == 1).all()
+
+
+@pytest.mark.parametrize("case", ["", "empty", "tol", "kd"])
+def test_sharded_kmeans_world2_is_the_one_shard_run(orc, case):
+    """SURVEY.md 8(e), last row: KMeans with the points sharded, centroids replicated, all-reduce of k x (3 sums + count).  The sums
+    are exact integers: the sharded loop's centroids, labels and iteration count equal the same loop over ONE shard bit for bit
+    (also through the empty-cluster repair, whose farthest member lives on some rank, and the tolerance exit); against the oracle's
+    KMeans (the reference's f32 serial sums) the centroids agree to 1e-5."""
+    r = _run(2, 0, 20000, "kmeans" + case)
+    assert r["world"] == 2 and r["same_centroids_on_all_ranks"] and r["equals_one_shard"], r
+    assert r["centroid_err_vs_oracle"] <= 1e-5 and r["label_mismatches_vs_oracle"] <= 20 and abs(r["it"] - r["oracle_it"]) <= 1, r
+
+
+def test_sharded_ransac_counts_world2(orc):
+    """... and the RANSAC scoring pass: per-hypothesis inlier counts of the shards, summed"""
+    r = _run(2, 0, 30000, "ransac")
+    assert r["world"] == 2 and r["equal"] and r["best"] == 0, r

@@ -60,3 +60,27 @@ def test_hip_engines_across_two_processes(orc, hip_lib, mode, kind):
         assert all(row["tables_loaded"] for row in rows)       # ties were met: every rank loaded the order of the WHOLE target
     if mode == "slab0.01":
         assert all(row["repartitions"] >= 1 for row in rows)   # the guard fired: all ranks cut their slabs again
+
+
+@pytest.mark.parametrize("kind", ["plain", "empty", "tol", "kd", "big"])
+def test_sharded_kmeans_across_two_processes(hip_lib, kind):
+    """SURVEY.md 8(e), last row: KMeans with the points sharded (HIP shards: cilhip_kmeans_shard_*), centroids replicated, one all-reduce
+    of 4k + 1 integers per Lloyd iteration.  The sums are exact fixed-point integers: centroids, labels and the iteration count are the
+    single-device cilhip_kmeans3f_ex's BIT FOR BIT -- through the pruned assignment (k = 1024), the kd branch with exact ties, the
+    tolerance exit and the empty-cluster repair whose farthest member lives on one of the ranks."""
+    n, iters = (400_000, 6) if kind == "big" else (120_000, 100 if kind == "tol" else 8)
+    r = _run(2, "kmeans", kind, n, iters)
+    rows = sorted(r["rows"], key=lambda x: x["rank"])
+    assert r["world"] == 2 and rows[0]["cent"] == rows[1]["cent"] and rows[0]["it"] == rows[1]["it"]
+    one_c, one_l = np.array(rows[0]["one_cent"]), np.array(rows[0]["one_lab"])
+    lab = np.concatenate([np.array(row["lab"]) for row in rows])
+    assert np.array_equal(np.array(rows[0]["cent"]), one_c), (kind, np.abs(np.array(rows[0]["cent"]) - one_c).max())
+    assert np.array_equal(lab, one_l) and rows[0]["it"] == rows[0]["one_it"], (kind, int((lab != one_l).sum()), rows[0]["it"], rows[0]["one_it"])
+    if kind == "tol":
+        assert rows[0]["it"] < iters
+
+
+def test_sharded_ransac_counts_across_two_processes(hip_lib):
+    r = _run(2, "ransac", "plain", 300_000, 1)
+    rows = sorted(r["rows"], key=lambda x: x["rank"])
+    assert rows[0]["counts"] == rows[1]["counts"] == rows[0]["one_counts"] and max(rows[0]["counts"]) > 0
