@@ -10,7 +10,8 @@ reduction and the on-device 6x6 / 3x3 solve.
                          the configuration BASELINE's metric is quoted on.
            c2            configs[1]: 1M <-> 1M, point-to-point (SimplePointToPointMetricRigidICP3f)
            c4 / c4_1gpu  configs[3]: 10M source points against an 80M-point target, combined metric 0.1 / 1.0
-           kmeans        configs[4]: KMeans3f k = 1024 on 50M points (step = one Lloyd iteration)
+           kmeans        configs[4]: KMeans3f k = 1024 on 50M points (step = one Lloyd iteration); --gpus N: 50M points PER RANK, centroids
+                         replicated, one all-reduce of 4k + 1 int64 per iteration (last row; weak scaling)
            ransac        configs[4]: plane RANSAC scoring on 50M points (step = one pass of 128 hypotheses)
   --gpus N (one process per GPU; backend "nccl" = RCCL).  Started without a launcher (`python bench.py --gpus N`) the script
       re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; started
@@ -639,6 +640,49 @@ def other_configs(a, torch, local_rank, budget_s=150.0):
     return res
 
 
+def bench_kmeans_sharded(a, torch, rank, world, local_rank):
+    """--config kmeans --gpus N: the points sharded over the ranks (50M per rank: weak scaling), centroids replicated, ONE all-reduce of
+    4k + 1 int64 per Lloyd iteration over RCCL (cilantro_amd/distributed_models.py: ShardedKMeans3f; SURVEY.md 8(e), last row).
+    Results are the single-device run's bit for bit (exact integer sums); value = point-centroid distances per second over all ranks."""
+    import torch.distributed as dist
+
+    from cilantro_amd import distributed_models as dm, synthetic as syn
+
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n, k = (a.n or 50_000_000), 1024
+    x = syn.make_dst(n, offset=rank * n)       # (counter-based generator: the ranks' shards are consecutive pieces of ONE cloud of world * n points)
+    c0 = syn.make_dst(k).copy()                # ... whose first k points are the initial centroids, on every rank
+    xd = torch.from_numpy(x).cuda()
+    eng = dm.HipKMeansShard(xd, k, rank * n, local_rank)
+    km = dm.ShardedKMeans3f(eng, dist, device="cuda")
+    km.cluster(c0, max_iter=max(a.warmup, 1), tol=0.0, fetch_labels=False)
+
+    def timed(iters):
+        dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        km.cluster(c0, max_iter=iters, tol=0.0, fetch_labels=False)
+        torch.cuda.synchronize(); dist.barrier()
+        return time.perf_counter() - t0
+
+    t1 = timed(1)                              # fixed costs (scale, labels) cancel in the difference
+    tk = timed(a.steps + 1)
+    assert km.getNumberOfPerformedIterations() == a.steps + 1
+    t = torch.tensor([tk - t1], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        evals = float(n) * world * k * a.steps
+        print(json.dumps({"metric": "KMeans3f point-centroid distance evaluations/sec (k = 1024), brute-force equivalent", "value": evals / dt, "unit": "distances/s",
+                          "n_gpus": world, "rccl_ranks": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32 distances / exact fixed-point sums", "data": "synthetic",
+                          "config": {"workload": f"kmeans: KMeans3f k = {k}, {n/1e6:g}M uniform points PER RANK, initial centroids replicated, tol = 0", "n_points_per_gpu": n, "k": k,
+                                     "sharding": "points; centroids replicated", "allreduce": f"{4 * k + 1} int64 (sum) per Lloyd iteration over RCCL"},
+                          "roofline": {"bound": "hbm", "achieved": 20.0 * n * world * a.steps / dt / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                       "frac": 20.0 * n * a.steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_assign_grid",
+                                       "note": "per rank as on one device (see --gpus 1: the pruned pass is VALU-issue-bound); the exchange is 32 KB per iteration"}}))
+    eng.close()
+    dist.destroy_process_group()
+
+
 def bench_kmeans(a, torch, emit=True):
     """BASELINE configs[4], first half: KMeans3f k = 1024 on 50M points, explicit initial centroids (the first k points).
     Step = one Lloyd iteration (brute-force assignment + centroid update, one pass over the points)."""
@@ -846,12 +890,12 @@ def selftest_spawn(a, rank, world):
 def main():
     a = parse()
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
-    if a.gpus > 1 and not launched and a.config not in ("kmeans", "ransac"):
+    if a.gpus > 1 and not launched and a.config != "ransac":
         relaunch_under_torchrun(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and not (world == 1 and a.config in ("kmeans", "ransac")):
+    if world != a.gpus and not (world == 1 and a.config == "ransac"):
         raise SystemExit(f"bench.py --gpus {a.gpus} started with WORLD_SIZE = {world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus}) or let bench.py launch itself")
     if a.selftest_spawn:
@@ -864,7 +908,9 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     if a.config == "kmeans":
-        if rank == 0:
+        if world > 1:
+            bench_kmeans_sharded(a, torch, rank, world, local_rank)
+        else:
             bench_kmeans(a, torch)
     elif a.config == "ransac":
         if rank == 0:

@@ -117,7 +117,8 @@ class ShardedKMeans3f:
         self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op), group=self.group)
         return t.cpu().numpy()
 
-    def cluster(self, centroids, max_iter=100, tol=float(np.finfo(np.float32).eps), use_kd_tree=False):
+    def cluster(self, centroids, max_iter=100, tol=float(np.finfo(np.float32).eps), use_kd_tree=False, fetch_labels=True):
+        """fetch_labels=False leaves the labels on the device (getPointToClusterIndexMap() then fetches them on demand)"""
         eng = self.engine
         cent = np.ascontiguousarray(centroids, np.float32).reshape(-1, 3).copy()
         k = len(cent)
@@ -162,7 +163,7 @@ class ShardedKMeans3f:
                 if mxs < tol_sq:
                     break
         self.cluster_centroids_ = cent
-        self.point_to_cluster_index_map_ = eng.labels()
+        self.point_to_cluster_index_map_ = eng.labels() if fetch_labels else None
         self.iteration_count_ = it
         return self
 
@@ -170,6 +171,8 @@ class ShardedKMeans3f:
         return self.cluster_centroids_
 
     def getPointToClusterIndexMap(self):
+        if self.point_to_cluster_index_map_ is None and self.cluster_centroids_ is not None:
+            self.point_to_cluster_index_map_ = self.engine.labels()
         return self.point_to_cluster_index_map_
 
     def getNumberOfPerformedIterations(self):
