@@ -191,3 +191,16 @@ def test_sharded_ransac_counts_world2(orc):
     """... and the RANSAC scoring pass: per-hypothesis inlier counts of the shards, summed"""
     r = _run(2, 0, 30000, "ransac")
     assert r["world"] == 2 and r["equal"] and r["best"] == 0, r
+
+
+def test_kmeans_scale_exponent_python_and_library_agree():
+    """every shard of a sharded KMeans run must use ONE fixed-point scale: the Python loop's restatement against the library's (pure host
+    code: callable without a device)"""
+    import ctypes as C
+
+    from cilantro_amd import capi, distributed_models as dm
+
+    L = capi.load()
+    for maxabs in (0.0, 1e-30, 0.4999, 0.5, 1.0, 1.0000001, 3.99, 4.0, 1234.5, 3.0e38):
+        for n in (1, 2, 3, 1000, 1 << 20, (1 << 20) + 1, 50_000_000, 400_000_000, 0xFFFFFFEF):
+            assert dm.scale_exponent(maxabs, n) == L.cilhip_kmeans_scale_exponent(C.c_double(np.float32(maxabs)), C.c_size_t(n)), (maxabs, n)

@@ -10,6 +10,8 @@
 #   regimes  the loop iteration by iteration (recipe / independent source / sensor frames / configs[3]'s shape), the real-cloud report,
 #            variants, search directions, the size sweep, the read-bandwidth probe, the tie-order build times
 #   full     the default line in full (extras + CPU baseline): the long one, last
+#   lines    ONLY the bench lines again (default in full, c2, c4_1gpu, kmeans, ransac), no profiler: after `core` / `configs` of the same build
+#            were collected into profiles/ (tools/collect_profiles.sh), so that the lines quote the build's counter traffic
 cd /tmp && export TMPDIR=/tmp
 TAG=${1:-dev}; shift; SECTIONS=${*:-core configs regimes full}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}final; mkdir -p $O; cd $R
@@ -101,4 +103,12 @@ if has regimes; then
 fi
 if has full; then
   timeout 600 python bench.py > $O/bench_c3_full.json 2> $O/bench_c3_full.err; cut -c1-700 $O/bench_c3_full.json
+fi
+if has lines; then
+  timeout 200 python bench.py --config c2 > $O/bench_c2.json 2> $O/bench_c2.err
+  timeout 300 python bench.py --config c4_1gpu --steps 20 --warmup 3 --no-extras > $O/bench_c4_1gpu.json 2> $O/bench_c4.err
+  timeout 300 python bench.py --config kmeans > $O/bench_kmeans_profiled.json 2> $O/bench_kmeans.err
+  timeout 300 python bench.py --config ransac > $O/bench_ransac_profiled.json 2> $O/bench_ransac.err
+  timeout 900 python bench.py > $O/bench_c3_full.json 2> $O/bench_c3_full.err
+  cut -c1-200 $O/bench_c3_full.json
 fi
