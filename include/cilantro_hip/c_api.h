@@ -149,7 +149,9 @@ int cilhip_estimate_point_to_point(cilhip_ctx* ctx, float dT_out[16], double* su
 /* estimateTransformCombinedMetric (rigid 3D, unity weights), transform_estimation.hpp:237-367,
  * called as icp_single_transform_combined_metric.hpp:191-196 does (dst_mean, T*src_mean).
  * AtA_or_null (36, row-major) / Atb_or_null (6): first Gauss-Newton step's normal equations.
- * *converged_or_null: the reference's bool return (d_theta.norm() < conv_tol inside max_iter). */
+ * *converged_or_null: the reference's bool return (d_theta.norm() < conv_tol inside max_iter).
+ * Reads the stored set of the last search whatever its direction: the per-source matches of SECOND_TO_FIRST or the pair list of
+ * FIRST_TO_SECOND / BOTH (one term per pair); with the context's weight evaluators (options) or pair-weight callback. */
 int cilhip_estimate_combined(cilhip_ctx* ctx, float w_p2p, float w_p2pl, size_t max_iter,
                              float conv_tol, float dT_out[16], double* AtA_or_null,
                              double* Atb_or_null, int* converged_or_null);

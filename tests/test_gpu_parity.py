@@ -871,6 +871,55 @@ def test_search_directions_vs_oracle(Context, orc, hip_lib):
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (direction, recip, np.linalg.norm(Tg - ro["T"]))
 
 
+def test_estimate_over_a_pair_list_and_with_a_callback(Context, orc, hip_lib):
+    """cilhip_estimate_combined over the PAIR LIST of FIRST_TO_SECOND / BOTH searches (one correspondence per pair: a source point may
+    occur several times), against the oracle's estimator over the same list; and with a pair-weight callback, which then sees the
+    list in its stored order (ascending (first, second)) and whose weights are read by pair index."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D, CorrespondenceSearchHIP
+
+    d = syn.make_pair(60000, 45000, with_normals=True)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = [0.004, -0.003, 0.002]
+    q = orc.transform_points(T, d["src"])
+    r2 = float(d["max_sq_dist"])
+    ctx = Context()
+    ctx.set_target(d["dst"], d["dst_n"]); ctx.set_source(d["src"])
+    eng = CorrespondenceSearchHIP(ctx=ctx).setMaxDistance(r2)
+    dm, sm = ctx.means()
+    smt = orc.transform_points(T, sm.reshape(1, 3))[0]
+    for direction, recip in ((D.FIRST_TO_SECOND, False), (D.BOTH, False), (D.BOTH, True)):
+        eng.setSearchDirection(direction).setRequireReciprocality(recip)
+        eng.findCorrespondences(T)
+        g1, g2, gv = eng.getCorrespondences()
+        assert len(np.unique(g2)) < len(g2) or direction == D.BOTH and recip      # (a pair list proper: some source point occurs twice)
+        for w_p2p, w_p2pl in ((0.0, 1.0), (0.3, 1.0)):
+            Tg, AtA, Atb, _ = ctx.estimate_combined(w_p2p, w_p2pl, 1, 1e-5)
+            To, AtAo, Atbo, _ = orc.estimate_combined(d["dst"], d["dst_n"], q, g1, g2, w_p2p, w_p2pl, dm, smt, 1, 1e-5, orc.MODE_MIXED)
+            scale = np.abs(AtAo).max()
+            tol = 1e-9 if w_p2p == 0.0 else 2e-6
+            assert np.abs(AtA - AtAo).max() <= tol * scale and np.abs(Atb - Atbo).max() <= tol * np.abs(Atbo).max() + 1e-3 * tol * scale, (direction, recip, w_p2p)
+            assert np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6
+        # weights by pair: every second PAIR of the list dropped, the others weighted by their position
+        seen = {}
+
+        def by_pair(i1, i2, v):
+            seen["i1"], seen["i2"] = i1.copy(), i2.copy()
+            w = np.where(np.arange(len(v)) % 2 == 1, 0.0, 1.0 + np.arange(len(v)) / len(v)).astype(np.float32)
+            return np.ones(len(v), np.float32), w
+
+        ctx.set_pair_weight_callback(by_pair)
+        Tg, AtA, Atb, _ = ctx.estimate_combined(0.0, 1.0, 1, 1e-5)
+        ctx.set_pair_weight_callback(None)
+        assert np.array_equal(seen["i1"], g1) and np.array_equal(seen["i2"], g2)
+        keep = np.arange(len(g1)) % 2 == 0
+        wv = (1.0 + np.arange(len(g1))[keep] / len(g1)).astype(np.float32)
+        To, AtAo, Atbo, _ = orc.estimate_combined(d["dst"], d["dst_n"], q, g1[keep], g2[keep], 0.0, 1.0, dm, smt, 1, 1e-5, orc.MODE_MIXED,
+                                                  values=wv, weights=(orc.W_UNITY, orc.W_IDENTITY, 1.0, 1.0))
+        scale = np.abs(AtAo).max()
+        assert np.abs(AtA - AtAo).max() <= 1e-9 * scale and np.linalg.norm(Tg.astype(np.float64) - To) < 1e-6, (direction, recip)
+    eng.setSearchDirection(D.SECOND_TO_FIRST).setRequireReciprocality(False)
+
+
 def test_frame1_recipe_real_cloud(orc, hip_lib, Context):
     """BASELINE configs[0]: real sensor data -- the reference's examples/test_clouds/frame_1.ply
     through the recipe and parameters of examples/rigid_icp.cpp (fixture tests/golden/frame1_c1.npz)."""
