@@ -2624,6 +2624,8 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   CK(c, hipSetDevice(c->device));
   if (p->metric == CILHIP_METRIC_COMBINED && p->max_opt_iter != 1) return fail(c, CILHIP_ERR_UNSUPPORTED, "sharded runs support max_opt_iter == 1");
   if (filters_active(c)) return fail(c, CILHIP_ERR_UNSUPPORTED, "inlier_fraction / one_to_one are global filters: not available in sharded runs");
+  if (c->weight_fn && p->metric == CILHIP_METRIC_COMBINED)
+    return fail(c, CILHIP_ERR_UNSUPPORTED, "a pair-weight callback is evaluated on the host, per estimate: not available in sharded runs (the stock evaluators are)");
   { const int trc = tie_prepare(c, "icp_begin"); if (trc) return trc; }
   if (c->search_dir != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "search directions other than SECOND_TO_FIRST are not available in sharded runs");
   if (feat6(c) || c->transform_mode != 0) return fail(c, CILHIP_ERR_UNSUPPORTED, "point+normal features and the affine variants are not available in sharded runs");

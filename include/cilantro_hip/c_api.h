@@ -204,7 +204,8 @@ int cilhip_icp_run(cilhip_ctx* ctx, const cilhip_icp_params* prm, const float T0
  * the host (search, estimate, rotation() polish, compose: cilhip_icp_run_two_sets with this engine in both roles; SECOND_TO_FIRST).
  * Applies to cilhip_estimate_combined, _estimate_combined_two_sets (each context its own callback), _estimate_affine (combined class)
  * and the loops over them; the point-to-point classes have no evaluators.  fn = NULL: back to the option-selected stock evaluators.
- * fn runs on the calling thread, between device passes. */
+ * fn runs on the calling thread, between device passes.  The sharded building blocks (cilhip_icp_begin ...) refuse a context with a
+ * callback (CILHIP_ERR_UNSUPPORTED: no host in their loop); the stock evaluators work there. */
 typedef void (*cilhip_pair_weight_fn)(void* user, const uint64_t* index_in_first, const uint64_t* index_in_second, const float* value,
                                       size_t n, float* point_weight_out, float* plane_weight_out);
 int cilhip_set_pair_weight_callback(cilhip_ctx* ctx, cilhip_pair_weight_fn fn, void* user);

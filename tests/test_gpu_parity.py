@@ -1826,6 +1826,11 @@ def test_functor_weight_evaluators_through_the_callback(Context, orc, hip_lib):
     ctx.set_pair_weight_callback(broken)
     with pytest.raises(ValueError, match="evaluator failed"):
         ctx.estimate_combined(0.0, 1.0, 1, 1e-5)
+    # ... and a sharded run (partial sums of one shard: no host in the loop) refuses it instead of reading stale tables
+    ctx.set_pair_weight_callback(by_index)
+    from cilantro_amd import capi, distributed
+    with pytest.raises(capi.CilhipError):
+        ctx.icp_begin(distributed.default_params(capi.METRIC_COMBINED, max_sq_dist=r2, max_iter=2), np.eye(4, dtype=np.float32), sm)
     ctx.set_pair_weight_callback(None)
     Tu = ctx.estimate_combined(0.0, 1.0, 1, 1e-5)[0]
     assert np.linalg.norm(Tu - Tg) > 1e-7                                # (back to unit weights; the index weights did change the estimate)
