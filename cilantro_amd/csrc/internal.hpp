@@ -5,8 +5,11 @@
 #include <stdint.h>
 
 #include <string>
+#include <thread>
 
 #include "solve.hpp"
+
+struct cilhip_ctx;      // (c_api.h: the opaque context)
 
 namespace cilhip {
 
@@ -469,4 +472,15 @@ hipError_t sort_source(const float* d_xyz, uint32_t n, const GridDev& g, const f
 void free_sort_workspace(SortWorkspace& ws);
 hipError_t mean3_device(const float* d_xyz, uint32_t n, hipStream_t s, double mean_out[3], float* lo_out = nullptr, float* hi_out = nullptr);
 
+// c_api.hip <-> multi.hip
+hipStream_t ctx_stream(const ::cilhip_ctx* c);
+double ctx_wait_us(const ::cilhip_ctx* c);      // microseconds this context's host loop has spent waiting for published loop state
+constexpr float kIdentity16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+// spin-wait courtesy (host)
+inline void cpu_relax(unsigned spins) {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+  if ((spins & 255u) == 255u) std::this_thread::yield();      // (the device publishes within tens of microseconds: rarely reached)
+}
 }  // namespace cilhip
