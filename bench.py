@@ -107,7 +107,7 @@ def stratified_form_timing(ft, forms, timed):
     return {f: out.get(f, ft.get(f, (0.0, 0))) for f in set(ft) | set(out)}
 
 
-def source_hash(files=("kernels.hip", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp")):
+def source_hash(files=("kernels.hip", "warm.hip", "epilogue.hip", "search_device.hpp", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp")):
     """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
     h = hashlib.sha256()
     for f in files:

@@ -2886,7 +2886,7 @@ int cilhip_icp_sums_from_keys(cilhip_ctx* c, const uint64_t* keys_dev, double* s
   return CILHIP_OK;
 }
 
-// The reference's tie order across target shards (kernels.hip: tie_rank): after the MIN all-reduce of cilhip_icp_partial_keys' keys,
+// The reference's tie order across target shards (extract.hip: tie_rank): after the MIN all-reduce of cilhip_icp_partial_keys' keys,
 //   cilhip_icp_order_keys(ctx, win_keys_dev, order_keys_dev)   order_keys_dev[i] = where this shard's match of source point i comes in
 //                                                              the query's traversal of the WHOLE target's tree, if it is at the
 //                                                              winning distance; 0x7fff...f otherwise

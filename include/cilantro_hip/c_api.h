@@ -600,7 +600,7 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        2 = that point, on the device, in every kernel form: each search notices when its smallest distance was
  *                        met on a second point and settles such a query from the order tables of the reference's tree (per point:
  *                        leaf + slot of the reference's permutation; per node: parent, depth, split -- csrc/tie_build.hip builds
- *                        them on the device, level by level, kernels.hip tie_settle reads them).  The tables are built when a search first
+ *                        them on the device, level by level, csrc/search_device.hpp tie_settle reads them).  The tables are built when a search first
  *                        MEETS a tie (that search / run is then executed once more): a target whose searches never tie never pays
  *                        for a tree, one that does pays once.  1 = the same choice, tables built before the first search.
  *                        0 = the lowest index (what a brute-force argmin gives).  Covers every search over point features:

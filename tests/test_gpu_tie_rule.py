@@ -3,7 +3,7 @@
 A brute-force argmin names the lowest target index among tied candidates, nanoflann the one its traversal meets first
 (core/kd_tree.hpp:82-90) -- on the reference's raw sensor frames 660 of 120k queries are tied under the identity and 321 of them
 get a different (equally near) point.  The engine resolves ties on the device, in every kernel form, from the order tables of the
-reference's tree (csrc/tie_order.hpp, pinned on the CPU by tests/test_tie_order_cpu.py; kernels.hip tie_settle): with DEFAULT
+reference's tree (csrc/tie_build.hip; its host restatement tests/cpp/tie_order_host.hpp is pinned on the CPU by tests/test_tie_order_cpu.py; csrc/search_device.hpp tie_settle): with DEFAULT
 options every index equals nanoflann's and the loop equals the oracle's loop over the reference's searches.  The tables are built
 when a search first meets a tie (tie_rule 2) or up front (1); 0 = the lowest index.
 """

@@ -90,7 +90,7 @@ def test_first_met_is_the_reference_pick(shim, orc):
 
 def test_smallest_traversal_key_is_the_reference_pick(shim, orc):
     """index shards of a target settle ties between shards by ONE number per candidate (TieOrderTree::traversal_key; on the device
-    kernels.hip tie_rank): the candidate with the smallest key is the one the reference's nanoflann returns, whatever the number of
+    csrc/search_device.hpp tie_rank): the candidate with the smallest key is the one the reference's nanoflann returns, whatever the number of
     candidates; the keys' 58 levels are far from exhausted on these clouds"""
     for name, D, S, r2 in _clouds():
         sel, cand, counts = tied_queries(D, S, r2)
