@@ -119,7 +119,7 @@ struct cilhip_ctx {
   double tie_build_ms = 0.0;                     // host time of the last table build (tree + upload)
   int tie_builds = 0;                            // table builds on this context (diagnostics)
   // the reverse matches of FIRST_TO_SECOND / BOTH: the reference's tree is over the TRANSFORMED source, a new one per search -- once a
-  // reverse search has met exactly equidistant source points (or under tie_rule 1) the host builds that tree's order tables before
+  // reverse search has met exactly equidistant source points (or under tie_rule 1) that tree's order tables are built (on the device) before
   // every reverse search (the loops then run host-driven, one search at a time)
   bool rev_tie_aware = false;
   uint2* d_rev_tie_leaf_slot = nullptr;          // [ns] by position in the source grid; valid for rev_tie_T only
@@ -1089,8 +1089,8 @@ static TieDev tie_dev_rev(const cilhip_ctx* c) {
   return t;
 }
 // The order tables of the tree the reference builds over the source transformed by T (src_points_trans = transform_ * src, the engine's
-// pinned f32 expression; correspondence_search_kd_tree.hpp:185-222), by position in the source grid.  Host work per search: a copy of the
-// source comes over once, the transform and the tree build run on the host's cores (8 ms for a 110k-point frame, 0.25 s at 10M).
+// pinned f32 expression; correspondence_search_kd_tree.hpp:185-222), by position in the source grid.  Device work per search: the
+// transform of the source (its original order) and tie_order_build_device over it (2 ms for a 110k-point frame, 25 ms at 10M).
 static int build_rev_tie_tables(cilhip_ctx* c, const float T[16]) {
   if (c->rev_tie_valid && memcmp(c->rev_tie_T, T, sizeof(c->rev_tie_T)) == 0) return CILHIP_OK;
   c->rev_tie_valid = false;

@@ -438,7 +438,7 @@ void free_pairs(PairSet& p);
 // feat (optional, w > 0): the reverse matches are the nearest 6-D FEATURES (feat->src in the source grid's order, feat->dst by target position)
 // rev_tie (option "tie_rule" for these matches): the reference searches a kd-tree over the TRANSFORMED SOURCE, rebuilt every iteration
 // (correspondence_search_kd_tree.hpp:185-222): leaf_slot = that tree's order tables by position in the source grid, valid for the state's
-// transform only (the host builds them per search); null = count the tied target points (counters[3]) and keep the lowest source index
+// transform only (built per search: c_api.hip build_rev_tie_tables); null = count the tied target points (counters[3]) and keep the lowest source index
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
                                  const FeatSpec* feat = nullptr, const TieDev* rev_tie = nullptr);
 hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& src_grid /*over the source, SOURCE coordinates*/, const float* d_src_xyz, const float* d_src_nrm,
