@@ -25,6 +25,7 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int KM_THREADS = 256;
+constexpr int KM_TIE_LIST = 1 << 16;   // tied points a pruned kd pass lists for k_fix_ties (more: the pass runs again with the tables)
 constexpr int KM_MAX_K = 2048;   // LDS accumulators: k * 4 * 8 B <= 64 KiB of dynamic LDS
 
 struct KmArgs {
@@ -37,6 +38,10 @@ struct KmArgs {
   double scale;            // 2^S
   int accumulate;
   cilhip::TieDev tie;      // KD only: order tables of the reference's tree over THIS iteration's centroids, by centroid index (leaf_slot null: none)
+  unsigned int* tie_count; // KD only, no tables: points whose best distance was met on two centroids are COUNTED here (they keep the lowest index; the host
+                           // builds the tables and runs the pass again -- a cloud without exact ties never pays for a tree); null: not counted
+  uint2* tie_list;         // ... and (the pruned pass) LISTED: {point, its label before the pass}, so that only they are looked at again (k_fix_ties)
+  uint32_t tie_cap;        // entries the list holds (more tied points than that: the pass runs again instead)
 };
 
 // KD: the distance the reference's kd-tree branch compares (use_kd_tree = true, kmeans.hpp:86-94: a KDTree over the centroids,
@@ -116,6 +121,9 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
         };
         if ((t0 || h0 > 1) && best.x < INFINITY) b0 = settle(px.x, py.x, pz.x, best.x, b0);
         if ((t1 || h1 > 1) && best.y < INFINITY) b1 = settle(px.y, py.y, pz.y, best.y, b1);
+      } else if (KD && a.tie_count != nullptr) {
+        const bool two = (2 * pidx + 1) < a.n;
+        if (((t0 || h0 > 1) && best.x < INFINITY) || (two && (t1 || h1 > 1) && best.y < INFINITY)) atomicAdd(a.tie_count, 1u);
       }
     }
     const bool two = (2 * pidx + 1) < a.n;
@@ -157,6 +165,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_accumulate(KmArgs a) {
 // the grid, only speed does.  Labels are bit-identical to the brute-force kernel's (tests/test_gpu_parity.py: both run, compared).
 struct KmGrid { float ox, oy, oz, cell, inv_cell, margin; int g; uint32_t kreal; };
 
+// KD: the kd-tree branch's distance rounding ((dx*dx + dy*dy) + dz*dz, k_assign_accumulate<true>) and its choice among EXACTLY equidistant
+// centroids: a point whose best distance was met on a second centroid is settled from the order tables of the reference's tree over the
+// centroids (all centroids at exactly that distance, tie_before), or counted when there are none (the host builds them and runs again).
+template <bool KD>
 __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr, const float4* __restrict__ cs_g, const uint32_t* __restrict__ cstart_g) {
   extern __shared__ long long lsum[];                                     // [kpad*4] sums, then the grid
   float4* const cs = reinterpret_cast<float4*>(lsum + (size_t)a.k * 4);   // [kpad + 8] sorted centroids {x, y, z, bits(j)}, +inf pad behind them
@@ -168,8 +180,23 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr,
   __syncthreads();
   unsigned int changed = 0;
 
-  auto finish = [&](uint32_t i, float px, float py, float pz, float bd, uint32_t bj) {
-    const uint32_t b = (bd < INFINITY && bj != 0xFFFFFFFFu) ? bj : 0u;      // (no finite minimum at all: label 0, as a chain of strict compares from (inf, 0) leaves it)
+  auto finish = [&](uint32_t i, float px, float py, float pz, float bd, uint32_t bj, bool tied) {
+    uint32_t b = (bd < INFINITY && bj != 0xFFFFFFFFu) ? bj : 0u;      // (no finite minimum at all: label 0, as a chain of strict compares from (inf, 0) leaves it)
+    if (KD && tied && bd < INFINITY && bj != 0xFFFFFFFFu) {
+      if (a.tie.leaf_slot != nullptr) {
+        // every centroid at exactly the best distance (the flag may be a beaten distance's: then there is one), the first the reference's traversal meets
+        for (uint32_t t = 0; t < gr.kreal; ++t) {
+          const float4 c = cs[t];
+          const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          const uint32_t j = __float_as_uint(c.w);
+          if (d == bd && j != b && cilhip::tie_before(a.tie, px, py, pz, j, b)) b = j;
+        }
+      } else if (a.tie_count != nullptr) {
+        const uint32_t slot = atomicAdd(a.tie_count, 1u);
+        if (slot < a.tie_cap) a.tie_list[slot] = make_uint2(i, a.labels[i]);
+      }
+    }
     changed += (a.labels[i] != b) ? 1u : 0u;
     a.labels[i] = b;
     if (a.accumulate) {
@@ -185,10 +212,12 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr,
   auto slow = [&](uint32_t i, float px, float py, float pz) {
     float bd = INFINITY;
     uint32_t bj = 0xFFFFFFFFu;
+    bool tied = false;
     auto take = [&](const float4 c) {
       const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
-      const float d = dx * dx + (dy * dy + dz * dz);
+      const float d = KD ? (dx * dx + dy * dy) + dz * dz : dx * dx + (dy * dy + dz * dz);
       const uint32_t j = __float_as_uint(c.w);
+      if (KD) tied = tied | ((d == bd) & (j != bj) & (d < INFINITY));      // (sticky: finish() looks again, exactly; a row read twice at the grid's edge is the same j)
       const bool better = (d < bd) | ((d == bd) & (j < bj));
       bd = better ? d : bd;
       bj = better ? j : bj;
@@ -215,20 +244,22 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr,
       proven = gap == INFINITY || (gb > 0.0f && bd < gb * gb * 0.99999905f);
     }
     if (!proven) {
-      bd = INFINITY; bj = 0xFFFFFFFFu;
+      bd = INFINITY; bj = 0xFFFFFFFFu; tied = false;
       for (uint32_t t = 0; t < gr.kreal; ++t) take(cs[t]);
     }
-    finish(i, px, py, pz, bd, bj);
+    finish(i, px, py, pz, bd, bj, tied);
   };
 
   for (uint32_t i = blockIdx.x * KM_THREADS + threadIdx.x; i < a.n; i += gridDim.x * KM_THREADS) {
     const float px = a.xyz[3 * (size_t)i], py = a.xyz[3 * (size_t)i + 1], pz = a.xyz[3 * (size_t)i + 2];
     float bd = INFINITY;
     uint32_t bj = 0xFFFFFFFFu;
+    bool tied = false;
     auto take = [&](const float4 c) {
       const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
-      const float d = dx * dx + (dy * dy + dz * dz);      // (-ffp-contract=off: the brute-force branch's value, bit for bit)
+      const float d = KD ? (dx * dx + dy * dy) + dz * dz : dx * dx + (dy * dy + dz * dz);      // (-ffp-contract=off: the branch's own value, bit for bit)
       const uint32_t j = __float_as_uint(c.w);
+      if (KD) tied = tied | ((d == bd) & (j != bj) & (d < INFINITY));
       const bool better = (d < bd) | ((d == bd) & (j < bj));
       bd = better ? d : bd;
       bj = better ? j : bj;
@@ -269,7 +300,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr,
       const float gb = gap - gr.margin;
       proven = gap == INFINITY || (gb > 0.0f && bd < gb * gb * 0.99999905f);
     }
-    if (proven) finish(i, px, py, pz, bd, bj);
+    if (proven) finish(i, px, py, pz, bd, bj, tied);
     else slow(i, px, py, pz);
   }
   if (changed) atomicAdd(a.changed, changed);
@@ -278,6 +309,42 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign_grid(KmArgs a, KmGrid gr,
     for (uint32_t t = threadIdx.x; t < a.k * 4; t += KM_THREADS)
       if (lsum[t] != 0) atomicAdd((unsigned long long*)&a.sums[t], (unsigned long long)lsum[t]);
   }
+}
+
+// The tied points of a kd-branch pass, looked at again once the order tables of the reference's tree over the centroids exist: the point's
+// nearest centroids once more (all k: a handful of points), the first one the reference's traversal meets among those at exactly the
+// smallest distance; where that is not the lowest index the pass left, the label, the two clusters' exact sums and the count of changed
+// labels are corrected in place -- integers: the result is what a pass WITH the tables gives, bit for bit.
+__global__ void k_fix_ties(KmArgs a, const uint2* __restrict__ list, uint32_t count) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const uint32_t i = list[e].x, prev = list[e].y;
+  const float px = a.xyz[3 * (size_t)i], py = a.xyz[3 * (size_t)i + 1], pz = a.xyz[3 * (size_t)i + 2];
+  float bd = INFINITY;
+  uint32_t bj = 0;
+  for (uint32_t j = 0; j < a.k; ++j) {      // (a.k = padded count; the pads are +inf)
+    const float dx = a.centroids[3 * j] - px, dy = a.centroids[3 * j + 1] - py, dz = a.centroids[3 * j + 2] - pz;
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    if (d < bd) { bd = d; bj = j; }
+  }
+  if (!(bd < INFINITY)) return;
+  uint32_t cur = bj;
+  for (uint32_t j = 0; j < a.k; ++j) {
+    const float dx = a.centroids[3 * j] - px, dy = a.centroids[3 * j + 1] - py, dz = a.centroids[3 * j + 2] - pz;
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    if (d == bd && j != cur && cilhip::tie_before(a.tie, px, py, pz, j, cur)) cur = j;
+  }
+  if (cur == bj) return;
+  a.labels[i] = cur;
+  if (a.accumulate) {
+    const unsigned long long fx = (unsigned long long)llrint((double)px * a.scale), fy = (unsigned long long)llrint((double)py * a.scale),
+                             fz = (unsigned long long)llrint((double)pz * a.scale);
+    unsigned long long* const sm = reinterpret_cast<unsigned long long*>(a.sums);
+    atomicAdd(&sm[bj * 4 + 0], 0ull - fx); atomicAdd(&sm[bj * 4 + 1], 0ull - fy); atomicAdd(&sm[bj * 4 + 2], 0ull - fz); atomicAdd(&sm[bj * 4 + 3], 0ull - 1ull);
+    atomicAdd(&sm[cur * 4 + 0], fx); atomicAdd(&sm[cur * 4 + 1], fy); atomicAdd(&sm[cur * 4 + 2], fz); atomicAdd(&sm[cur * 4 + 3], 1ull);
+  }
+  const unsigned int was = prev != bj ? 1u : 0u, is = prev != cur ? 1u : 0u;
+  if (was != is) atomicAdd(a.changed, is - was);      // (unsigned wrap-around: -1)
 }
 
 // The centroids' grid (host; k <= 2048): about one centroid per cell.  false: no usable grid (a non-finite centroid, fewer than 64
@@ -379,6 +446,9 @@ struct cilhip_kmeans_shard {
   uint32_t* d_tleaf = nullptr;      // kd branch: order tables of the reference's tree over the centroids (leaf, slot by centroid index)
   uint2* d_tls = nullptr;
   uint4* d_tnodes = nullptr;
+  uint32_t* d_lab_prev = nullptr;   // kd branch: the labels before a pass (put back when the pass has to run again with the tables)
+  uint2* d_tie_list = nullptr;      // kd branch, pruned pass: the tied points {index, label before the pass}
+  int tie_table_builds = 0;         // passes that met exact ties (diagnostics)
   std::vector<float4> cs_host;
   std::vector<uint32_t> cstart_host;
   std::vector<float> cpad;
@@ -401,7 +471,7 @@ struct cilhip_kmeans_shard {
     KS_CK(hipMalloc(&d_c, 3 * kpad * sizeof(float)));
     KS_CK(hipMalloc(&d_lab, (n ? n : 1) * sizeof(uint32_t)));
     KS_CK(hipMalloc(&d_sums, kpad * 4 * sizeof(long long)));
-    KS_CK(hipMalloc(&d_changed, sizeof(unsigned int)));
+    KS_CK(hipMalloc(&d_changed, 2 * sizeof(unsigned int)));      // [0] labels changed, [1] (kd branch) tied points met without tables
     KS_CK(hipMalloc(&d_best, sizeof(unsigned long long)));
     KS_CK(hipMemsetAsync(d_lab, 0, (n ? n : 1) * sizeof(uint32_t), s));   // point_to_cluster_index_map_.resize(n): zeros (:80)
     return CILHIP_OK;
@@ -427,35 +497,67 @@ struct cilhip_kmeans_shard {
     KS_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
     if (n) {
       const int nblocks = (int)std::min<size_t>((n / 2 + KM_THREADS - 1) / KM_THREADS + 1, 1024);
-      KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1, {nullptr, nullptr, nullptr, 0}};
-      if (kd_order && cilhip::g_knn_tie_rule != 0 && k > 1) {
-        // the tree the reference builds over THIS iteration's centroids (kmeans.hpp:87), as order tables (about a millisecond)
-        bool finite = true;
-        for (size_t t = 0; t < 3 * k; ++t) finite = finite && std::isfinite(centroids[t]);
-        if (finite) {
+      KmArgs a{d_xyz, d_c, (uint32_t)n, (uint32_t)kpad, d_lab, d_sums, d_changed, scale, assign_only ? 0 : 1, {nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 0u};
+      // The kd branch's choice among exactly equidistant centroids needs the order tables of the tree the reference builds over THIS
+      // iteration's centroids (kmeans.hpp:87) -- about a millisecond, as much as the whole pruned pass.  So the pass first runs WITHOUT
+      // them and counts the points whose best distance was met on two centroids (none on data without exact ties); only then the
+      // tables are built, the labels put back (the count of changed labels is against the previous iteration's) and the pass runs again.
+      bool finite = true;
+      if (kd_order) for (size_t t = 0; t < 3 * k; ++t) finite = finite && std::isfinite(centroids[t]);
+      const bool ties_matter = kd_order && cilhip::g_knn_tie_rule != 0 && k > 1 && finite;
+      if (ties_matter) {
+        if (!d_lab_prev) KS_CK(hipMalloc(&d_lab_prev, n * sizeof(uint32_t)));
+        KS_CK(hipMemcpyAsync(d_lab_prev, d_lab, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        KS_CK(hipMemsetAsync(d_changed + 1, 0, sizeof(unsigned int), s));
+        a.tie_count = d_changed + 1;
+        if (!d_tie_list) KS_CK(hipMalloc(&d_tie_list, (size_t)KM_TIE_LIST * sizeof(uint2)));
+        a.tie_list = d_tie_list; a.tie_cap = KM_TIE_LIST;
+      }
+      KmGrid gr{};
+      const bool pruned = g_kmeans_prune && build_centroid_grid(centroids, k, gr, cs_host, cstart_host);
+      const size_t ncell1 = pruned ? (size_t)gr.g * gr.g * gr.g + 1 : 0;
+      if (pruned) {
+        // the grid of THIS iteration's centroids: sorted list + cell table, 20 KB
+        if (!d_cs) { KS_CK(hipMalloc(&d_cs, (kpad + 8) * sizeof(float4))); KS_CK(hipMalloc(&d_cstart, (16 * 16 * 16 + 1) * sizeof(uint32_t))); }
+        KS_CK(hipMemcpyAsync(d_cs, cs_host.data(), (kpad + 8) * sizeof(float4), hipMemcpyHostToDevice, s));
+        KS_CK(hipMemcpyAsync(d_cstart, cstart_host.data(), ncell1 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+      }
+      auto pass = [&]() {
+        if (pruned) {
+          const size_t lds = kpad * 4 * sizeof(long long) + (kpad + 8) * sizeof(float4) + ncell1 * sizeof(uint32_t);
+          const int nb_g = (int)std::min<size_t>((n + KM_THREADS - 1) / KM_THREADS, 2048);
+          if (kd_order) hipLaunchKernelGGL(k_assign_grid<true>, dim3(nb_g), dim3(KM_THREADS), lds, s, a, gr, (const float4*)d_cs, (const uint32_t*)d_cstart);
+          else hipLaunchKernelGGL(k_assign_grid<false>, dim3(nb_g), dim3(KM_THREADS), lds, s, a, gr, (const float4*)d_cs, (const uint32_t*)d_cstart);
+        }
+        else if (kd_order) hipLaunchKernelGGL(k_assign_accumulate<true>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
+        else hipLaunchKernelGGL(k_assign_accumulate<false>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
+      };
+      pass();
+      KS_CK(hipGetLastError());
+      if (ties_matter) {
+        unsigned int tied = 0;
+        KS_CK(hipMemcpyAsync(&tied, d_changed + 1, sizeof(tied), hipMemcpyDeviceToHost, s));
+        KS_CK(hipStreamSynchronize(s));
+        if (tied != 0) {
           if (!d_tleaf) { KS_CK(hipMalloc(&d_tleaf, 2 * kpad * sizeof(uint32_t))); KS_CK(hipMalloc(&d_tls, kpad * sizeof(uint2))); }
           if (d_tnodes) { (void)hipFree(d_tnodes); d_tnodes = nullptr; }
           size_t nn = 0; int depth = 0;
           KS_CK(cilhip::tie_order_build_device(d_c, nullptr, (uint32_t)k, s, d_tleaf, d_tleaf + kpad, &d_tnodes, &nn, &depth));
           hipLaunchKernelGGL(k_zip_tables, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_tleaf, (const uint32_t*)(d_tleaf + kpad), d_tls, (uint32_t)k);
-          a.tie.leaf_slot = d_tls; a.tie.nodes = d_tnodes; a.tie.mode = 1;
+          a.tie.leaf_slot = d_tls; a.tie.nodes = d_tnodes; a.tie.mode = 1; a.tie_count = nullptr;
+          ++tie_table_builds;
+          if (pruned && tied <= (unsigned int)KM_TIE_LIST) {
+            // the pruned pass listed its tied points: only they are looked at again
+            hipLaunchKernelGGL(k_fix_ties, dim3((tied + 255u) / 256u), dim3(256), 0, s, a, (const uint2*)d_tie_list, (uint32_t)tied);
+          } else {
+            KS_CK(hipMemcpyAsync(d_lab, d_lab_prev, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            KS_CK(hipMemsetAsync(d_changed, 0, sizeof(unsigned int), s));
+            KS_CK(hipMemsetAsync(d_sums, 0, kpad * 4 * sizeof(long long), s));
+            pass();
+          }
+          KS_CK(hipGetLastError());
         }
       }
-      KmGrid gr{};
-      const bool pruned = !kd_order && g_kmeans_prune && build_centroid_grid(centroids, k, gr, cs_host, cstart_host);
-      if (pruned) {
-        // the grid of THIS iteration's centroids: sorted list + cell table, 20 KB
-        const size_t ncell1 = (size_t)gr.g * gr.g * gr.g + 1;
-        if (!d_cs) { KS_CK(hipMalloc(&d_cs, (kpad + 8) * sizeof(float4))); KS_CK(hipMalloc(&d_cstart, (16 * 16 * 16 + 1) * sizeof(uint32_t))); }
-        KS_CK(hipMemcpyAsync(d_cs, cs_host.data(), (kpad + 8) * sizeof(float4), hipMemcpyHostToDevice, s));
-        KS_CK(hipMemcpyAsync(d_cstart, cstart_host.data(), ncell1 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        const size_t lds = kpad * 4 * sizeof(long long) + (kpad + 8) * sizeof(float4) + ncell1 * sizeof(uint32_t);
-        const int nb_g = (int)std::min<size_t>((n + KM_THREADS - 1) / KM_THREADS, 2048);
-        hipLaunchKernelGGL(k_assign_grid, dim3(nb_g), dim3(KM_THREADS), lds, s, a, gr, (const float4*)d_cs, (const uint32_t*)d_cstart);
-      }
-      else if (kd_order) hipLaunchKernelGGL(k_assign_accumulate<true>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
-      else hipLaunchKernelGGL(k_assign_accumulate<false>, dim3(nblocks), dim3(KM_THREADS), assign_only ? 0 : kpad * 4 * sizeof(long long), s, a);
-      KS_CK(hipGetLastError());
     }
     if (assign_only) return CILHIP_OK;
     unsigned int changed = 0;
@@ -511,6 +613,8 @@ struct cilhip_kmeans_shard {
     if (d_tleaf) (void)hipFree(d_tleaf);
     if (d_tls) (void)hipFree(d_tls);
     if (d_tnodes) (void)hipFree(d_tnodes);
+    if (d_lab_prev) (void)hipFree(d_lab_prev);
+    if (d_tie_list) (void)hipFree(d_tie_list);
     if (s) (void)hipStreamDestroy(s);
     d_xyz = nullptr; s = nullptr;
   }

@@ -638,6 +638,13 @@ def test_kmeans_pruned_assignment_is_the_exhaustive_one(orc, hip_lib):
             if "non-finite" not in name:
                 lo, _ = orc.kmeans_assign(x, c0)
                 assert np.array_equal(lp, lo), (name, int(np.count_nonzero(lp != lo)))
+            # the kd branch (use_kd_tree: nanoflann's rounding of the distance, the tree's choice among equal distances) through the
+            # same grid: pruned == exhaustive, label for label -- also with duplicated centroids (exact ties: tables on demand)
+            clustering.set_pruning(True)
+            kp = kmeans_assign(x, c0, use_kd_tree=True)
+            clustering.set_pruning(False)
+            ke = kmeans_assign(x, c0, use_kd_tree=True)
+            assert np.array_equal(kp, ke), (name, "kd", int(np.count_nonzero(kp != ke)))
         for name, x, c0 in (cases[2], cases[4], cases[7]):
             clustering.set_pruning(True)
             kp = KMeans3f(x).cluster(c0.copy(), max_iter=8, tol=0.0)
@@ -646,6 +653,13 @@ def test_kmeans_pruned_assignment_is_the_exhaustive_one(orc, hip_lib):
             assert kp.getNumberOfPerformedIterations() == ke.getNumberOfPerformedIterations(), name
             assert np.array_equal(kp.getClusterCentroids().view(np.uint32), ke.getClusterCentroids().view(np.uint32)), name
             assert np.array_equal(kp.getPointToClusterIndexMap(), ke.getPointToClusterIndexMap()), name
+            clustering.set_pruning(True)
+            kp = KMeans3f(x).cluster(c0.copy(), max_iter=8, tol=0.0, use_kd_tree=True)
+            clustering.set_pruning(False)
+            ke = KMeans3f(x).cluster(c0.copy(), max_iter=8, tol=0.0, use_kd_tree=True)
+            assert kp.getNumberOfPerformedIterations() == ke.getNumberOfPerformedIterations(), (name, "kd")
+            assert np.array_equal(kp.getClusterCentroids().view(np.uint32), ke.getClusterCentroids().view(np.uint32)), (name, "kd")
+            assert np.array_equal(kp.getPointToClusterIndexMap(), ke.getPointToClusterIndexMap()), (name, "kd")
     finally:
         clustering.set_pruning(True)
 

@@ -674,6 +674,13 @@ def test_kmeans_kd_branch_names_the_centroid_the_reference_s_tree_meets_first(or
         lab_r = np.empty(len(x), np.int64); lab_r[si] = di
         lab_g = kmeans_assign(x, c0, use_kd_tree=True)
         assert np.array_equal(lab_g.astype(np.int64), lab_r), (g, dup, int((lab_g != lab_r).sum()))
+        # (from 64 centroids on that was the PRUNED pass -- centroid grid, proof, tables built only because ties were met --: the exhaustive one agrees)
+        from cilantro_amd import clustering
+        clustering.set_pruning(False)
+        try:
+            assert np.array_equal(kmeans_assign(x, c0, use_kd_tree=True).astype(np.int64), lab_r), (g, dup)
+        finally:
+            clustering.set_pruning(True)
         # lowest index among equals: numpy's argmin over exact distances (half-lattice coordinates: every f32 operation is exact)
         lab_o = np.concatenate([np.argmin(((x[a:a + 4096, None, :] - c0[None]) ** 2).sum(-1), axis=1) for a in range(0, len(x), 4096)])
         tied = x[:, 0] * 2 == np.round(x[:, 0] * 2)      # (the jittered points are not compared under rule 0: their distances round)
