@@ -293,6 +293,281 @@ __global__ void k_root_leaf(const Rec<DIM>* __restrict__ recs, uint32_t n, uint3
   leaf_by_index[i] = 0u; slot_by_index[i] = p;
 }
 
+// ---- small clouds: the whole build in ONE workgroup -------------------------------------------------------------------------------------
+// A level of the general build is some twenty launches and a read-back of two counters: a cloud of a thousand points -- the centroids of
+// a KMeans iteration, whose kd branch wants these tables in every iteration that meets exact ties (kmeans.hip) -- spends a millisecond on
+// launch chains.  Up to SMALL_N points one workgroup runs the SAME passes (the same flags, ranks, scatters, the same node records) as
+// phases between barriers, with block-wide prefix sums and min / max through LDS atomics on order-preserving integer images of the floats.
+constexpr uint32_t SMALL_N = 2048;
+constexpr uint32_t SMALL_T = 1024;
+constexpr uint32_t SMALL_ACT = SMALL_N / (LEAF_MAX + 1) + 2;
+
+struct SmallWs {
+  Rec<3>*recA, *recB;
+  uint32_t *node_of, *flags, *S, *posF, *posU, *internal, *iscan;
+  MM<3>* child_mm;
+  Act<3>*act0, *act1;
+  uint32_t* out;      // [2]: nodes, depth
+};
+
+__device__ __forceinline__ uint32_t ord_of(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ord_inv(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); }
+
+// out[i] = in[0] + ... + in[i - 1], i < count (count <= a few thousand), by the whole block; tmp: SMALL_T words of LDS
+__device__ void block_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t count, uint32_t* tmp) {
+  const uint32_t T = blockDim.x, t = threadIdx.x;
+  const uint32_t per = (count + T - 1u) / T;
+  const uint32_t b = min(t * per, count), e = min(b + per, count);
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; ++i) sum += in[i];
+  tmp[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < T; off <<= 1) {
+    const uint32_t v = t >= off ? tmp[t - off] : 0u;
+    __syncthreads();
+    tmp[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = tmp[t] - sum;
+  for (uint32_t i = b; i < e; ++i) { const uint32_t f = in[i]; out[i] = run; run += f; }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(SMALL_T) void k_build_small(const float* __restrict__ xyz, const float4* __restrict__ sorted, uint32_t n, SmallWs w, uint4* __restrict__ nodes,
+                                                         uint32_t node_cap, uint32_t* __restrict__ leaf_by_index, uint32_t* __restrict__ slot_by_index) {
+  __shared__ uint32_t tmp[SMALL_T];
+  __shared__ uint32_t mmk[2 * SMALL_ACT + 2][6];      // min x, y, z, max x, y, z of a level's children (ordered integer images)
+  __shared__ uint32_t s_na, s_nodes;
+  const uint32_t T = blockDim.x, t = threadIdx.x;
+  constexpr uint32_t SH = InfoShift<3>::value;
+  Rec<3>*recA = w.recA, *recB = w.recB;
+  // records in the ORIGINAL order (the reference's vAcc_ starts as 0 .. n-1)
+  for (uint32_t p = t; p < n; p += T) {
+    if (sorted) { const float4 q = sorted[p]; const uint32_t i = __float_as_uint(q.w); if (i < n) recA[i] = Rec<3>{{q.x, q.y, q.z}, i}; }
+    else recA[p] = Rec<3>{{xyz[3 * (size_t)p], xyz[3 * (size_t)p + 1], xyz[3 * (size_t)p + 2]}, p};
+    w.node_of[p] = 0u;
+  }
+  if (t < 6) mmk[0][t] = t < 3 ? 0xFFFFFFFFu : 0u;
+  __syncthreads();
+  for (uint32_t p = t; p < n; p += T) {
+    const Rec<3> r = recA[p];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { atomicMin(&mmk[0][d], ord_of(r.c[d])); atomicMax(&mmk[0][3 + d], ord_of(r.c[d])); }
+  }
+  __syncthreads();
+  if (t == 0) {      // the root (k_root)
+    Act<3> a{};
+    a.left = 0; a.right = n; a.node = 0; a.depth = 0;
+    for (int d = 0; d < 3; ++d) { a.mm.mn[d] = ord_inv(mmk[0][d]); a.mm.mx[d] = ord_inv(mmk[0][3 + d]); a.blo[d] = a.mm.mn[d]; a.bhi[d] = a.mm.mx[d]; }
+    const bool leaf = n <= LEAF_MAX;
+    s_na = leaf ? 0u : 1u; s_nodes = 1u;
+    if (!leaf) w.act0[0] = a;
+    nodes[0] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  if (s_na == 0u) {      // at most LEAF_MAX points: the root is the only leaf (k_root_leaf)
+    for (uint32_t p = t; p < n; p += T) { const uint32_t i = recA[p].idx; leaf_by_index[i] = 0u; slot_by_index[i] = p; }
+    if (t == 0) { w.out[0] = 1u; w.out[1] = 0u; }
+    return;
+  }
+  Act<3>*cur = w.act0, *nxt = w.act1;
+  uint32_t depth = 0;
+  for (;;) {
+    const uint32_t na = s_na, base = s_nodes;      // (block-uniform: read after a barrier)
+    // middleSplit_ (k_decide)
+    if (t < na) {
+      Act<3>& A = cur[t];
+      const float EPS = 0.00001f;
+      float max_span = __fsub_rn(A.bhi[0], A.blo[0]);
+      for (int d = 1; d < 3; ++d) { const float span = __fsub_rn(A.bhi[d], A.blo[d]); if (span > max_span) max_span = span; }
+      const float thr = __fmul_rn(__fsub_rn(1.0f, EPS), max_span);
+      float max_spread = -1.0f, min_elem = 0.0f, max_elem = 0.0f;
+      int feat = 0;
+      for (int d = 0; d < 3; ++d) {
+        const float span = __fsub_rn(A.bhi[d], A.blo[d]);
+        if (span >= thr) {
+          const float spread = __fsub_rn(A.mm.mx[d], A.mm.mn[d]);
+          if (spread > max_spread) { feat = d; max_spread = spread; min_elem = A.mm.mn[d]; max_elem = A.mm.mx[d]; }
+        }
+      }
+      const float lo_f = feat == 0 ? A.blo[0] : feat == 1 ? A.blo[1] : A.blo[2], hi_f = feat == 0 ? A.bhi[0] : feat == 1 ? A.bhi[1] : A.bhi[2];
+      const float split_val = __fadd_rn(lo_f, hi_f) / 2;
+      A.feat = feat;
+      A.cut = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
+    }
+    __syncthreads();
+    // planeSplit: two passes of {flags, prefix sums, ranks, scatter} (k_flags / k_ranks / k_scatter)
+    for (int pass = 1; pass <= 2; ++pass) {
+      const Rec<3>* in = pass == 1 ? recA : recB;
+      Rec<3>* outp = pass == 1 ? recB : recA;
+      for (uint32_t p = t; p <= n; p += T) {
+        uint32_t f = 0;
+        if (p < n) {
+          const uint32_t a = w.node_of[p];
+          if (a != NONE) {
+            const Act<3>& A = cur[a];
+            const float v = coord<3>(in[p], A.feat);
+            f = pass == 1 ? (v < A.cut ? 0u : 1u) : ((p - A.left >= A.lim1 && v > A.cut) ? 1u : 0u);
+          }
+        }
+        w.flags[p] = f;
+      }
+      __syncthreads();
+      block_exclusive_scan(w.flags, w.S, n + 1u, tmp);
+      for (uint32_t p = t; p < n; p += T) {
+        const uint32_t a = w.node_of[p];
+        if (a == NONE) continue;
+        Act<3>& A = cur[a];
+        const uint32_t lo = pass == 1 ? A.left : A.left + A.lim1, hi = A.right;
+        if (p < lo) continue;
+        const uint32_t nF = w.S[hi] - w.S[lo], nU = (hi - lo) - nF;
+        const uint32_t rel = p - lo, Fb = w.S[p] - w.S[lo];
+        if (w.flags[p]) { if (rel < nU) w.posF[lo + Fb] = p; }
+        else if (rel >= nU) { const uint32_t Ub = rel - Fb; w.posU[lo + (nU - Ub - 1u)] = p; }
+      }
+      __syncthreads();
+      // (the limits are written AFTER every thread has read lim1 as this pass's range start)
+      for (uint32_t p = t; p < n; p += T) {
+        const uint32_t a = w.node_of[p];
+        if (a == NONE) continue;
+        Act<3>& A = cur[a];
+        const uint32_t lo = pass == 1 ? A.left : A.left + A.lim1;
+        if (p != lo) continue;
+        const uint32_t nF = w.S[A.right] - w.S[lo], nU = (A.right - lo) - nF;
+        if (pass == 1) A.lim1 = nU; else A.lim2 = A.lim1 + nU;
+      }
+      for (uint32_t p = t; p < n; p += T) {
+        uint32_t dest = p;
+        const uint32_t a = w.node_of[p];
+        if (a != NONE) {
+          const Act<3>& A = cur[a];
+          // (pass 1 scatters with the range [left, right); pass 2 with [left + lim1, right): lim1 is not touched by pass 2's limit write)
+          const uint32_t lo = pass == 1 ? A.left : A.left + A.lim1, hi = A.right;
+          if (p >= lo) {
+            const uint32_t nF = w.S[hi] - w.S[lo], nU = (hi - lo) - nF;
+            const uint32_t rel = p - lo, Fb = w.S[p] - w.S[lo];
+            if (w.flags[p]) { if (rel < nU) dest = w.posU[lo + Fb]; }
+            else if (rel >= nU) { const uint32_t Ub = rel - Fb; dest = w.posF[lo + (nU - Ub - 1u)]; }
+          }
+        }
+        outp[dest] = in[p];
+      }
+      __syncthreads();
+    }
+    // the split index, which children go on (k_children), their active indices
+    if (t < na) {
+      Act<3>& A = cur[t];
+      const uint32_t count = A.right - A.left;
+      const uint32_t idx = A.lim1 > count / 2 ? A.lim1 : (A.lim2 < count / 2 ? A.lim2 : count / 2);
+      A.idx = idx;
+      w.internal[2 * t] = idx > LEAF_MAX ? 1u : 0u;
+      w.internal[2 * t + 1] = (count - idx) > LEAF_MAX ? 1u : 0u;
+    }
+    if (t == na) w.internal[2 * na] = 0u;
+    for (uint32_t c = t; c < 2u * na; c += T) { mmk[c][0] = mmk[c][1] = mmk[c][2] = 0xFFFFFFFFu; mmk[c][3] = mmk[c][4] = mmk[c][5] = 0u; }
+    __syncthreads();
+    block_exclusive_scan(w.internal, w.iscan, 2u * na + 1u, tmp);
+    // the children's min / max (the general build: reduce_by_key over the child keys)
+    for (uint32_t p = t; p < n; p += T) {
+      const uint32_t a = w.node_of[p];
+      if (a == NONE) continue;
+      const uint32_t key = 2u * a + (p >= cur[a].left + cur[a].idx ? 1u : 0u);
+      const Rec<3> r = recA[p];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { atomicMin(&mmk[key][d], ord_of(r.c[d])); atomicMax(&mmk[key][3 + d], ord_of(r.c[d])); }
+    }
+    __syncthreads();
+    for (uint32_t c = t; c < 2u * na; c += T) {
+      MM<3> m;
+      for (int d = 0; d < 3; ++d) { m.mn[d] = ord_inv(mmk[c][d]); m.mx[d] = ord_inv(mmk[c][3 + d]); }
+      w.child_mm[c] = m;
+    }
+    __syncthreads();
+    // node records, the next level's active nodes (k_finish)
+    if (t < na) {
+      const Act<3>& A = cur[t];
+      const MM<3> m1 = w.child_mm[2 * t], m2 = w.child_mm[2 * t + 1];
+      const float dlow = A.feat == 0 ? m1.mx[0] : A.feat == 1 ? m1.mx[1] : m1.mx[2], dhigh = A.feat == 0 ? m2.mn[0] : A.feat == 1 ? m2.mn[1] : m2.mn[2];
+      if (A.node < node_cap) {
+        uint4 nd = nodes[A.node];
+        nd.y = (A.depth << SH) | ((uint32_t)A.feat << 1) | (nd.y & 1u);
+        nd.z = __float_as_uint(dlow);
+        nd.w = __float_as_uint(dhigh);
+        nodes[A.node] = nd;
+      }
+      for (uint32_t c = 0; c < 2; ++c) {
+        const uint32_t id = base + 2u * t + c;
+        const uint32_t left = c == 0 ? A.left : A.left + A.idx, right = c == 0 ? A.left + A.idx : A.right;
+        const bool internal = (right - left) > LEAF_MAX;
+        if (id < node_cap) nodes[id] = make_uint4(A.node, ((A.depth + 1u) << SH) | c, internal ? 0u : left, 0u);
+        if (internal) {
+          Act<3> B{};
+          B.left = left; B.right = right; B.node = id; B.depth = A.depth + 1u;
+          for (int d = 0; d < 3; ++d) { B.blo[d] = A.blo[d]; B.bhi[d] = A.bhi[d]; }
+          for (int d = 0; d < 3; ++d) if (A.feat == d) { if (c == 0) B.bhi[d] = A.cut; else B.blo[d] = A.cut; }
+          B.mm = c == 0 ? m1 : m2;
+          B.lim1 = B.lim2 = B.idx = 0;
+          nxt[w.iscan[2 * t + c]] = B;
+        }
+      }
+    }
+    // every record to its child: the next level's active index, or its final leaf and slot (k_descend)
+    for (uint32_t p = t; p < n; p += T) {
+      const uint32_t a = w.node_of[p];
+      if (a == NONE) continue;
+      const uint32_t c = p >= cur[a].left + cur[a].idx ? 1u : 0u;
+      if (w.internal[2 * a + c]) w.node_of[p] = w.iscan[2 * a + c];
+      else {
+        w.node_of[p] = NONE;
+        const uint32_t i = recA[p].idx;
+        leaf_by_index[i] = base + 2u * a + c;
+        slot_by_index[i] = p;
+      }
+    }
+    __syncthreads();
+    if (t == 0) { s_na = w.iscan[2 * na]; s_nodes = base + 2u * na; }
+    __syncthreads();
+    { Act<3>* x = cur; cur = nxt; nxt = x; }
+    ++depth;
+    if (s_na == 0u || depth > 200u) break;
+  }
+  if (t == 0) { w.out[0] = s_nodes; w.out[1] = depth; }
+}
+
+// the build of a cloud of at most SMALL_N points: one allocation, one launch, one read-back
+hipError_t build_small(const float* d_xyz, const float4* d_sorted, uint32_t n, hipStream_t s, uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index, uint4** d_nodes_out,
+                       size_t* n_nodes_out, int* max_depth_out) {
+  hipError_t e = hipSuccess;
+  void* ws = nullptr;
+  uint4* nodes = nullptr;
+  const size_t node_cap = 2 * (size_t)n + 2;      // (every split leaves both children non-empty: at most 2n - 1 nodes)
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_recA = take((size_t)n * sizeof(Rec<3>)), o_recB = take((size_t)n * sizeof(Rec<3>)), o_node = take((size_t)n * 4), o_flags = take(((size_t)n + 1) * 4),
+               o_S = take(((size_t)n + 1) * 4), o_posF = take((size_t)n * 4), o_posU = take((size_t)n * 4), o_int = take((2 * (size_t)SMALL_ACT + 2) * 4),
+               o_iscan = take((2 * (size_t)SMALL_ACT + 2) * 4), o_cmm = take((2 * (size_t)SMALL_ACT + 2) * sizeof(MM<3>)), o_act0 = take((size_t)SMALL_ACT * sizeof(Act<3>)),
+               o_act1 = take((size_t)SMALL_ACT * sizeof(Act<3>)), o_out = take(16);
+  uint32_t h_out[2] = {0, 0};
+  do {
+    if ((e = hipMalloc(&ws, off)) != hipSuccess) break;
+    if ((e = hipMalloc(&nodes, node_cap * sizeof(uint4))) != hipSuccess) break;
+    unsigned char* b = static_cast<unsigned char*>(ws);
+    SmallWs w{(Rec<3>*)(b + o_recA), (Rec<3>*)(b + o_recB), (uint32_t*)(b + o_node), (uint32_t*)(b + o_flags), (uint32_t*)(b + o_S), (uint32_t*)(b + o_posF), (uint32_t*)(b + o_posU),
+              (uint32_t*)(b + o_int), (uint32_t*)(b + o_iscan), (MM<3>*)(b + o_cmm), (Act<3>*)(b + o_act0), (Act<3>*)(b + o_act1), (uint32_t*)(b + o_out)};
+    hipLaunchKernelGGL(k_build_small, dim3(1), dim3(SMALL_T), 0, s, d_xyz, d_sorted, n, w, nodes, (uint32_t)node_cap, d_leaf_by_index, d_slot_by_index);
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(h_out, w.out, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+    if (h_out[1] > 200u) { e = hipErrorUnknown; break; }
+    *d_nodes_out = nodes; nodes = nullptr;
+    *n_nodes_out = h_out[0];
+    if (max_depth_out) *max_depth_out = (int)h_out[1];
+  } while (0);
+  if (ws) (void)hipFree(ws);
+  if (nodes) (void)hipFree(nodes);
+  return e;
+}
+
 #define TB_TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
 
 // The build.  Records come from d_xyz (DIM = 3: the cloud in its ORIGINAL order) or from d_sorted (+ the feature parts att1 / att2 by the
@@ -431,6 +706,10 @@ done:
 // caller frees), *n_nodes_out how many; *max_depth_out the deepest node's depth.
 hipError_t tie_order_build_device(const float* d_xyz, const float4* d_sorted, uint32_t n, hipStream_t s, uint32_t* d_leaf_by_index, uint32_t* d_slot_by_index,
                                   uint4** d_nodes_out, size_t* n_nodes_out, int* max_depth_out) {
+  if (n != 0 && n <= SMALL_N && (d_xyz != nullptr) != (d_sorted != nullptr)) {      // one workgroup: a launch instead of twenty per level
+    *d_nodes_out = nullptr; *n_nodes_out = 0; if (max_depth_out) *max_depth_out = 0;
+    return build_small(d_xyz, d_sorted, n, s, d_leaf_by_index, d_slot_by_index, d_nodes_out, n_nodes_out, max_depth_out);
+  }
   return build_impl<3>(d_xyz, d_sorted, nullptr, 0.0f, nullptr, 0.0f, n, s, d_leaf_by_index, d_slot_by_index, d_nodes_out, n_nodes_out, max_depth_out);
 }
 // The tree of a feature adaptor's search: records (p, w1 * att1[, w2 * att2]) from the grid's sorted points and the attributes at the same

@@ -297,12 +297,12 @@ int cilhip_kmeans3f_assign(int device, const float* xyz, size_t n, int mem, cons
                            uint32_t* labels_out);
 /* ... with the reference's `use_kd_tree` argument (clustering/kmeans.hpp:24-30, branch :86-94 -- the mode examples/kmeans.cpp
  * uses): a kd-tree over the centroids is only a way of finding the same nearest centroid, so the device runs the same pass (pruned
- * through the centroid grid like the brute-force branch's: 50M x 1024 in 1.9 ms per Lloyd iteration, 3.2 ms when exact ties are met);
+ * through the centroid grid like the brute-force branch's: 50M x 1024 in 1.9 ms per Lloyd iteration, 2.2 - 2.7 ms when exact ties are met);
  * what the flag changes is the ROUNDING of the compared distance -- nanoflann's L2 metric ((dx*dx)+(dy*dy))+(dz*dz)
  * instead of Eigen's squaredNorm pairing of the brute-force branch -- so that labels equal the reference's kd-tree branch
  * wherever its nearest centroid is unique; among EXACTLY equidistant centroids the one the reference's traversal meets first: the
- * order tables of the tree over the iteration's centroids are built on the device (about a millisecond, like the reference's KDTree
- * at :87) in the iterations whose pass met such points -- it lists them, k_fix_ties settles them with tie_before afterwards
+ * order tables of the tree over the iteration's centroids are built on the device (one workgroup for up to 2048 points: a fraction of a
+ * millisecond; the reference builds its KDTree at :87) in the iterations whose pass met such points -- it lists them, k_fix_ties settles them with tie_before afterwards
  * (cilhip_knn_set_tie_rule(0): the lowest index instead).  tests/test_gpu_tie_rule.py: lattice centroids, label for label. */
 int cilhip_kmeans3f_ex(int device, const float* xyz, size_t n, int mem, float* centroids, size_t k, size_t max_iter, float tol, int use_kd_tree,
                        uint32_t* labels_out, size_t* iterations_out);
