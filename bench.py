@@ -695,15 +695,15 @@ def bench_kmeans(a, torch, emit=True):
     c0 = x[:k].copy()
     KMeans3f(xd).cluster(c0, max_iter=max(a.warmup, 1), tol=0.0)
 
-    def timed(iters):
+    def timed(iters, kd=False):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        km = KMeans3f(xd).cluster(c0, max_iter=iters, tol=0.0)
+        km = KMeans3f(xd).cluster(c0, max_iter=iters, tol=0.0, use_kd_tree=kd)
         torch.cuda.synchronize()
         return time.perf_counter() - t0, km
 
-    def per_step():
-        t1, _ = timed(1)                      # fixed costs (centroid upload, label download) cancel in the difference
-        tk, km = timed(a.steps + 1)
+    def per_step(kd=False):
+        t1, _ = timed(1, kd)                  # fixed costs (centroid upload, label download) cancel in the difference
+        tk, km = timed(a.steps + 1, kd)
         assert km.getNumberOfPerformedIterations() == a.steps + 1
         return tk - t1
 
@@ -715,6 +715,15 @@ def bench_kmeans(a, torch, emit=True):
         dt_ex = per_step()                    # the exhaustive pass of the same library (n * k distances): what round 4's line measured
     finally:
         clustering.set_pruning(True)
+    # ... and the reference's use_kd_tree branch (the mode its examples/kmeans.cpp runs): the same pruned pass with nanoflann's rounding, the
+    # order tables of the tree over the centroids built in the iterations that meet exactly equidistant centroids
+    dt_kd = None
+    if emit:
+        try:
+            KMeans3f(xd).cluster(c0, max_iter=1, tol=0.0, use_kd_tree=True)
+            dt_kd = per_step(True)
+        except Exception:
+            dt_kd = None
     evals = float(n) * k * a.steps
     flops_ex = 8.0 * evals                    # 3 sub, 3 mul, 2 add per point-centroid distance, each individually rounded
     read_evals = 36.0 * float(n) * a.steps    # distances the pruned pass evaluates at least: four records of each of the nine runs of a point's block
@@ -738,6 +747,8 @@ def bench_kmeans(a, torch, emit=True):
                                      "lds_array_busy": "about 0.7 (SQ_LDS_IDX_ACTIVE 5.5e8 cycles per launch over 256 CUs; 62 % of them bank conflicts: the lanes of a wave sit in different centroid cells)",
                                      "source": "profiles/r06_config_c5_pmc_summary.txt, profiles/r06_valu_rate_probe.txt (counted on n = 50M, k = 1024)"}
                                     if (n == 50_000_000 and k == 1024) else None)},
+           "kd_branch": ({"ms_per_step": dt_kd * 1e3 / a.steps, "note": "use_kd_tree = true (clustering/kmeans.hpp:86-94): labels equal the reference's tree search, exact ties included"}
+                         if dt_kd is not None else None),
            "exhaustive_pass": {"ms_per_step": dt_ex * 1e3 / a.steps, "distances_per_sec": evals / dt_ex, "kernel": "k_assign_accumulate",
                                "roofline": {"bound": "valu", "achieved": flops_ex / dt_ex / 1e12, "peak": VALU_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_ex / dt_ex / 1e12 / VALU_NOFMA_PEAK_TFLOPS,
                                             "note": "8 individually rounded f32 ops per distance (no FMA contraction: labels must match the reference bit for bit); peak = half of the 157.3 TFLOP/s FMA figure"}}}
