@@ -14,8 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libcilantro_hip.so")
-SOURCES = ["kernels.hip", "warm.hip", "epilogue.hip", "extract.hip", "grid_build.hip", "filters.hip", "kmeans.hip", "ransac.hip", "ransac_transform.hip", "knn.hip", "bidir.hip", "tie_build.hip", "c_api.hip", "multi.hip"]
-HEADERS = ["internal.hpp", "solve.hpp", "rccl_api.hpp", "search_device.hpp", os.path.join("..", "..", "include", "cilantro_hip", "c_api.h")]
+SOURCES = ["kernels.hip", "warm.hip", "epilogue.hip", "affine.hip", "extract.hip", "grid_build.hip", "filters.hip", "kmeans.hip", "ransac.hip", "ransac_transform.hip", "knn.hip", "bidir.hip", "tie_build.hip", "c_api.hip", "multi.hip"]
+HEADERS = ["internal.hpp", "solve.hpp", "rccl_api.hpp", "search_device.hpp", "affine_device.hpp", os.path.join("..", "..", "include", "cilantro_hip", "c_api.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the pinned f32 expressions (d2, T*s, per-term residuals) must round exactly as
 # written on host and device; f64 accumulations use explicit fma().
@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # kernels.hip: the SLP vectoriser pairs scalar f32 operations of DIFFERENT candidates into v_pk_* instructions and pays
 # for it in v_mov's that gather the operands (measured: +7 % VALU in the search kernel's hot block); the packed math that
 # pays is written explicitly (f32x2).
-EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("kernels.hip", "warm.hip", "epilogue.hip", "extract.hip")}
+EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("kernels.hip", "warm.hip", "epilogue.hip", "affine.hip", "extract.hip")}
 
 
 def _stale(out, deps):

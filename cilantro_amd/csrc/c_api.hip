@@ -111,6 +111,8 @@ struct cilhip_ctx {
   // kernels' own forecast above it); 0 = never; 4 .. 64 = that many lanes in every global-memory search.
   int group_lanes = -1;
   double wait_us = 0.0;                          // time spent waiting for the device to publish loop state (wait_published), accumulated: not enqueue work
+  bool affine_device_loop = true;                // option "affine_device_loop": the affine classes' loop device-resident (one-pass moments on the matrix cores, 12-unknown
+                                                 // solve in the epilogue kernel) whenever nothing needs the stored set per iteration; 0 = the host-driven loop (A/B)
   bool fused_epilogue = false;                   // option "fused_epilogue": stage-1 reduction + epilogue in ONE launch (the last of the 32 stage-1 blocks runs the
                                                  // epilogue).  Bitwise the same results, measured SLOWER: 0.129 -> 0.136 ms per iteration at 10M, 0.037 -> 0.044 at 1M --
                                                  // a device-scope fence costs more on this eight-L2 part than the kernel boundary it removes (NOTEBOOK.md): off
@@ -454,6 +456,7 @@ const OptionRow g_options[] = {
   OPT(CILHIP_OPT_REFINED_OCCUPANCY_FACTOR, "refined_occupancy_factor", 3, 1, 64, "how much denser than that a grid that had to be refined (surface, clusters) may stay", c->refined_occupancy),
   OPT(CILHIP_OPT_KERNEL_TIMING, "kernel_timing", 0, 0, 1, "hipEvents around the search / accumulation kernels (cilhip_enable_kernel_timing)", c->kernel_timing),
   OPT(CILHIP_OPT_KERNEL_TIMING_STRIDE, "kernel_timing_stride", 1, 1, 4096, "with kernel timing on: iterations 0..2 and every stride-th one carry events", c->timing_stride),
+  OPT(CILHIP_OPT_AFFINE_DEVICE_LOOP, "affine_device_loop", 1, 0, 1, "affine classes: 1 = device-resident loop (one-pass moments, solve in the epilogue kernel), 0 = host-driven loop (three passes + host solve; A/B)", c->affine_device_loop),
 };
 #undef OPT
 constexpr int N_OPTIONS = (int)(sizeof(g_options) / sizeof(g_options[0]));
@@ -486,6 +489,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "fused_epilogue")) { c->fused_epilogue = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "affine_device_loop")) { c->affine_device_loop = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "group_search")) {
     if (value != -1.0 && value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0 && value != 32.0 && value != 64.0)
       return fail(c, CILHIP_ERR_INVALID, "group_search: -1 (the loop decides), 0 (never), or 4, 8, 16, 32, 64 lanes per query");
@@ -2236,15 +2240,23 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
     c->last_loop_ms = 0.0; c->last_search_ms = 0.0; c->last_acc_ms = 0.0; c->last_search_launches = 0;
     return cilhip_icp_run_two_sets(c, p->max_sq_dist, c, p->max_sq_dist, p, T0, out);
   }
-  if (c->transform_mode == 1) {
+  // The affine classes: their loop runs device-resident like the rigid one -- search-only kernels + one streaming pass of moments
+  // (k_acc_affine) while the source is far from alignment, search + moments in the warm-started kernel afterwards, the 12-unknown solve
+  // and the f32 compose in k_solve_affine -- unless something asks for the stored set per iteration (post-filters, per-pair weights,
+  // other directions, feature adaptors): those keep the host-driven loop (icp_run_affine: three passes + a host solve per iteration).
+  const bool affine = c->transform_mode == 1;
+  if (affine) {
     if (c->index_offset) return fail(c, CILHIP_ERR_UNSUPPORTED, "the affine variants are not available on target shards");
-    return icp_run_affine(c, p, T0, out);
+    const bool device_loop = c->affine_device_loop && c->ns != 0 && c->grid.n != 0 && c->search_dir == 0 && !filters_active(c) && !weighted(c) && !feat6(c) && !c->fused &&
+                             !(c->d_src_nrm && c->symmetric) && c->guard_axis < 0;
+    if (!device_loop) return icp_run_affine(c, p, T0, out);
   }
   const float* Ti = T0 ? T0 : kIdentity;
   int rc = ensure_sorted(c, Ti);
   if (rc) return rc;
-  const int im = iter_metric_of(c, p);
-  const bool gn = (im != IM_KABSCH);
+  const bool affine_combined = affine && p->metric == CILHIP_METRIC_COMBINED;
+  const int im = !affine ? iter_metric_of(c, p) : (affine_combined && p->w_p2pl > 0.0f && c->has_normals) ? IM_AFFC : IM_AFFP;
+  const bool gn = (im != IM_KABSCH) && !affine;
   // max_optimization_iterations == 0 (combined metric): the estimator's loop body never runs -- one accumulation pass still counts
   // the correspondences (the "no usable terms" test, transform_estimation.hpp:264-272), the epilogue skips the solve
   const bool zero_steps = gn && p->max_opt_iter == 0;
@@ -2259,6 +2271,23 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
   sa.feedback = c->d_feedback; sa.run_tag = c->run_tag;
   sa.gn_zero_steps = zero_steps ? 1 : 0;
   const int nb = sa.nblocks;
+  const int nb_aff = affine ? affine_acc_blocks(c->ns) : 0;
+  if (affine) {
+    a.no_centering = affine_combined ? 0 : 1;
+    sa.affine_centered = affine_combined ? 1 : 0;
+    if (!affine_combined) { sa.w_p2p = 1.0f; sa.w_p2pl = 0.0f; }      // the point-to-point class: unit point terms of the raw coordinates
+    // rows of AFF_ROW doubles: the streaming pass's or the warm-started kernel's
+    const size_t rows = (size_t)std::max(nb_aff, warm_num_blocks(c->ns));
+    const size_t need = (rows * AFF_ROW + SUMS_MAX - 1) / SUMS_MAX;
+    if (need > (size_t)c->partial_blocks) {
+      if (c->d_partials) (void)hipFree(c->d_partials);
+      c->d_partials = nullptr; c->partial_blocks = 0;
+      CK(c, hipMalloc(&c->d_partials, need * SUMS_MAX * sizeof(double)));
+      c->partial_blocks = (int)need;
+      a.partials = c->d_partials; a.tile_partials = c->d_partials;
+      sa.partials = c->d_partials;
+    }
+  }
   if (c->ns == 0) {  // no source points: the epilogue runs on all-zero sums (identity step)
     CK(c, hipMemsetAsync(c->d_sums, 0, SUMS_MAX * sizeof(double), c->stream));
     sa.nblocks = 0;
@@ -2386,7 +2415,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
   if (feat6(c)) { rc = ensure_feature_arrays(c); if (rc) return rc; a.feat = feat_spec_of(c); }
   if (!filters_active(c) && !(a.cw.enabled && feat6(c))) a.nn_d2 = nullptr;   // nobody reads the distances inside the loop: 4 B per query less to write
                                                                               // (a weight evaluator over the 6-D feature distance does)
-  const bool tile_acc = tile_accumulation(c);
+  const bool tile_acc = tile_accumulation(c) && !affine;      // (the tiles accumulate the rigid classes' terms only)
   const bool timing = c->kernel_timing && p->max_iter <= 4096;
   hipEvent_t e_beg = get_event(c, 0), e_end = get_event(c, 1);
   CK(c, hipEventRecord(e_beg, c->stream));
@@ -2550,7 +2579,8 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
           { const int src_rc = launch_search(c, sa2, lanes_it); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing_it) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
-          launch_iter(a, im, false, false, nb, c->stream);                    // streaming accumulation kernel
+          if (affine) launch_acc_affine(a, im, nb_aff, c->stream);            // streaming accumulation kernel
+          else launch_iter(a, im, false, false, nb, c->stream);
         } else {
           launch_iter(a, im, false, false, nb, c->stream);
         }
@@ -2572,8 +2602,9 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
-        const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : nb;
-        launch_reduce_and_solve(c->d_partials, prows, c->d_stage, c->fused_epilogue ? c->d_ticket : nullptr, sa, c->stream);
+        const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : affine ? nb_aff : nb;
+        if (affine) launch_reduce_and_solve_affine(c->d_partials, prows, c->d_stage, sa, c->stream);
+        else launch_reduce_and_solve(c->d_partials, prows, c->d_stage, c->fused_epilogue ? c->d_ticket : nullptr, sa, c->stream);
       } else {
         launch_solve(sa, c->stream);
       }

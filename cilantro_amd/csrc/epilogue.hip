@@ -1,5 +1,6 @@
 // epilogue.hip -- the epilogue of an iteration: fixed-order reduction of the block partials (k_reduce_stage1), the one-block solve + compose + loop state (k_solve, solve.hpp), k_init_state; split from kernels.hip.
 #include "search_device.hpp"
+#include "affine_device.hpp"
 
 namespace cilhip {
 
@@ -109,6 +110,61 @@ __device__ void reset_inner(IcpState* st) {
   st->pad0 = 0;
 }
 
+// The tail of an outer iteration once the new transform is known (icp_base.hpp:75-86): motion clock of the warm-started form, Tprev / T,
+// the transformed source mean, delta / iterations / ncorr / done, the slab guard.  Shared by the rigid and the affine epilogue.
+__device__ __forceinline__ void finalize_state(IcpState* st, const SolveArgs& a, const float* Tn, const float delta) {
+  {
+    const float step = motion_step_of(st->T, Tn, a.src_center, a.src_half);
+    const float prev = st->motion_step;
+    st->motion_pred = (prev < INFINITY && prev > 0.0f) ? step * fminf(1.0f, step / prev) : 0.0f;
+    st->motion_step = step;
+    st->motion_acc = (float)(((double)st->motion_acc + (double)step) * 1.000001);
+    st->motion_eps = motion_eps_of(Tn, a.src_center, a.src_half);
+  }
+  for (int i = 0; i < 16; ++i) { st->Tprev[i] = st->T[i]; st->T[i] = Tn[i]; }
+  float mx, my, mz;
+  transform_point(Tn, a.src_mean[0], a.src_mean[1], a.src_mean[2], mx, my, mz);
+  st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
+  st->prev_delta = st->delta;
+  st->delta = delta;
+  st->iterations += 1;
+  st->ncorr = (unsigned long long)(st->sums[0] + 0.5);   // (the sums of the last accumulation that ran: a converged inner loop skips the later ones)
+  st->done = (delta < a.conv_tol) ? 1 : 0;                            // icp_base.hpp:83
+  reset_inner(st);
+  if (a.guard_axis >= 0) {
+    // |((T - T_part) p)_axis| over the source's bounding box: an affine function of p, extreme at a corner
+    const int ax = a.guard_axis;
+    float d = Tn[12 + ax] - a.guard_T[12 + ax], spread = 0.0f;
+    for (int j = 0; j < 3; ++j) {
+      const float dl = Tn[j * 4 + ax] - a.guard_T[j * 4 + ax];
+      d += dl * a.guard_center[j];
+      spread += fabsf(dl) * a.guard_half[j];
+    }
+    if (!(fabsf(d) + spread <= a.guard_slack) && st->slab_violation == 0) {
+      st->slab_violation = 1;
+      st->violation_iter = st->iterations; st->violation_delta = delta; st->violation_ncorr = st->ncorr;
+      for (int i = 0; i < 16; ++i) st->violation_T[i] = Tn[i];
+    }
+  }
+}
+
+// what the host's paced loop and cilhip_get_last_run_trace read: the iteration's record, then -- after a system-scope fence -- `latest`
+__device__ __forceinline__ void publish_state(const SolveArgs& a, const IcpState& lst) {
+  if (a.trace != nullptr && a.gn_last_step && threadIdx.x == 0 && lst.iterations >= 1 && lst.iterations <= RUN_TRACE_CAP)
+    a.trace[lst.iterations - 1] = make_uint4(lst.unproven, lst.listed, __float_as_uint(lst.motion_step), __float_as_uint(lst.delta));
+  if (a.feedback != nullptr && a.gn_last_step && threadIdx.x == 0) {
+    FeedbackSlot* sl = &a.feedback->slot[(unsigned int)lst.iterations & 3u];
+    sl->unproven = lst.unproven;
+    sl->listed = lst.listed;
+    sl->delta = lst.delta;
+    sl->prev_delta = lst.prev_delta;
+    sl->step = lst.motion_step;
+    sl->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
+    __threadfence_system();
+    a.feedback->latest = ((unsigned long long)a.run_tag << 32) | (lst.done ? 0x80000000ull : 0ull) | (unsigned long long)((unsigned int)lst.iterations & 0x7fffffffu);
+  }
+}
+
 // The epilogue proper (one block of 256 threads): k_solve's body, also the tail of k_reduce_solve's last block.
 __device__ __forceinline__ void solve_body(const SolveArgs& a) {
   __shared__ double sums[SUMS_MAX];
@@ -202,56 +258,12 @@ __device__ __forceinline__ void solve_body(const SolveArgs& a) {
   if (finalize) {
     float Tn[16];
     const float delta = compose_update(L, t, st->T, Tn);
-    {
-      const float step = motion_step_of(st->T, Tn, a.src_center, a.src_half);
-      const float prev = st->motion_step;
-      st->motion_pred = (prev < INFINITY && prev > 0.0f) ? step * fminf(1.0f, step / prev) : 0.0f;
-      st->motion_step = step;
-      st->motion_acc = (float)(((double)st->motion_acc + (double)step) * 1.000001);
-      st->motion_eps = motion_eps_of(Tn, a.src_center, a.src_half);
-    }
-    for (int i = 0; i < 16; ++i) { st->Tprev[i] = st->T[i]; st->T[i] = Tn[i]; }
-    float mx, my, mz;
-    transform_point(Tn, a.src_mean[0], a.src_mean[1], a.src_mean[2], mx, my, mz);
-    st->smt[0] = mx; st->smt[1] = my; st->smt[2] = mz;
-    st->prev_delta = st->delta;
-    st->delta = delta;
-    st->iterations += 1;
-    st->ncorr = (unsigned long long)(st->sums[0] + 0.5);   // (the sums of the last accumulation that ran: a converged inner loop skips the later ones)
-    st->done = (delta < a.conv_tol) ? 1 : 0;                            // icp_base.hpp:83
-    reset_inner(st);
-    if (a.guard_axis >= 0) {
-      // |((T - T_part) p)_axis| over the source's bounding box: an affine function of p, extreme at a corner
-      const int ax = a.guard_axis;
-      float d = Tn[12 + ax] - a.guard_T[12 + ax], spread = 0.0f;
-      for (int j = 0; j < 3; ++j) {
-        const float dl = Tn[j * 4 + ax] - a.guard_T[j * 4 + ax];
-        d += dl * a.guard_center[j];
-        spread += fabsf(dl) * a.guard_half[j];
-      }
-      if (!(fabsf(d) + spread <= a.guard_slack) && st->slab_violation == 0) {
-        st->slab_violation = 1;
-        st->violation_iter = st->iterations; st->violation_delta = delta; st->violation_ncorr = st->ncorr;
-        for (int i = 0; i < 16; ++i) st->violation_T[i] = Tn[i];
-      }
-    }
+    finalize_state(st, a, Tn, delta);
   }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < ST_DWORDS; k += 256) reinterpret_cast<uint32_t*>(a.state)[k] = reinterpret_cast<const uint32_t*>(&lst)[k];
-  if (a.trace != nullptr && a.gn_last_step && threadIdx.x == 0 && lst.iterations >= 1 && lst.iterations <= RUN_TRACE_CAP)
-    a.trace[lst.iterations - 1] = make_uint4(lst.unproven, lst.listed, __float_as_uint(lst.motion_step), __float_as_uint(lst.delta));
-  if (a.feedback != nullptr && a.gn_last_step && threadIdx.x == 0) {
-    FeedbackSlot* sl = &a.feedback->slot[(unsigned int)lst.iterations & 3u];
-    sl->unproven = lst.unproven;
-    sl->listed = lst.listed;
-    sl->delta = lst.delta;
-    sl->prev_delta = lst.prev_delta;
-    sl->step = lst.motion_step;
-    sl->commit = ((unsigned long long)a.run_tag << 32) | (unsigned long long)(unsigned int)lst.iterations;
-    __threadfence_system();
-    a.feedback->latest = ((unsigned long long)a.run_tag << 32) | (lst.done ? 0x80000000ull : 0ull) | (unsigned long long)((unsigned int)lst.iterations & 0x7fffffffu);
-  }
+  publish_state(a, lst);
 }
 __global__ __launch_bounds__(256) void k_solve(SolveArgs a) { solve_body(a); }
 
@@ -301,6 +313,184 @@ void launch_reduce_and_solve(const double* partials, int nblocks, double* stage,
     return;
   }
   hipLaunchKernelGGL(k_reduce_solve, dim3(reduce_groups(nblocks)), dim3(256), 0, s, partials, nblocks, stage, ticket, a);
+}
+
+
+// ---- the affine classes' epilogue (SimpleCombinedMetricAffineICP3f / SimplePointToPointMetricAffineICP3f) ----------------------------------
+// Rows of AFF_ROW doubles (affine_device.hpp) -> fixed-order fold -> AtA (12x12), Atb -> AtA.ldlt().solve(Atb) (diagonal pivoting,
+// pseudo-inverse of D: solve.hpp ldlt_solve_n operation for operation, its elimination steps dealt out to the block's threads) ->
+// tform = t_dst * tform * t_src (transform_estimation.hpp:466-473) -> transform_ = tform_iter * transform_ in f32, delta = the
+// Frobenius norm of tform_iter - I (icp_single_transform_combined_metric.hpp:207-216 without the rotation() polish of the rigid
+// classes; icp_single_transform_point_to_point_metric.hpp:56-64) -> the loop state.  No host round trip per iteration.
+constexpr int AFF_GROUPS = 32;
+__device__ __forceinline__ double aff_fold_rows(const double* __restrict__ rows, int n, int slot) {
+  double v = 0.0;
+  int b = 0;
+  for (; b + 8 <= n; b += 8) {          // 8 independent loads in flight, added in ascending order
+    double r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = rows[(size_t)(b + k) * AFF_ROW + slot];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += r[k];
+  }
+  for (; b < n; ++b) v += rows[(size_t)b * AFF_ROW + slot];
+  return v;
+}
+__global__ __launch_bounds__(AFF_ROW) void k_reduce_affine(const double* __restrict__ partials, int nrows, double* __restrict__ stage, const IcpState* st) {
+  if (st->done) return;
+  const int per = (nrows + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int b0 = min((int)blockIdx.x * per, nrows), b1 = min(b0 + per, nrows);
+  stage[(size_t)blockIdx.x * AFF_ROW + threadIdx.x] = aff_fold_rows(partials + (size_t)b0 * AFF_ROW, b1 - b0, (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(AFF_ROW) void k_solve_affine(SolveArgs a) {
+  __shared__ double sums[AFF_ROW];
+  __shared__ IcpState lst;
+  __shared__ double A[144], rhs[12], y[12], x[12];
+  __shared__ int perm[12], s_piv;
+  __shared__ unsigned int unproven_total, listed_total;
+  constexpr int ST_DWORDS = (int)(sizeof(IcpState) / 4);
+  constexpr int NT = AFF_ROW, N = 12;
+  const int t = (int)threadIdx.x;
+  if (a.state->done) return;
+  uint32_t sreg[(ST_DWORDS + NT - 1) / NT];
+#pragma unroll
+  for (int k = 0; k < (ST_DWORDS + NT - 1) / NT; ++k) sreg[k] = t + k * NT < ST_DWORDS ? reinterpret_cast<const uint32_t*>(a.state)[t + k * NT] : 0u;
+  const bool counters = a.unproven_cnt != nullptr;
+  unsigned int cv = counters ? a.unproven_cnt[t] : 0u;      // (128 threads: wave 0 the unproven counts, wave 1 the listed ones)
+  sums[t] = aff_fold_rows(a.partials, a.nblocks, t);
+#pragma unroll
+  for (int k = 0; k < (ST_DWORDS + NT - 1) / NT; ++k) if (t + k * NT < ST_DWORDS) reinterpret_cast<uint32_t*>(&lst)[t + k * NT] = sreg[k];
+  if (counters) {
+    a.unproven_cnt[t] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cv += __shfl_down(cv, off, 64);
+    if (t == 0) unproven_total = cv;
+    if (t == 64) listed_total = cv;
+  }
+  __syncthreads();
+  IcpState* st = &lst;
+  const double n = sums[72 + aff_pair(3, 3)];
+  const bool wp = a.w_p2p > 0.0f, wl = a.w_p2pl > 0.0f;
+  // transform_estimation.hpp:400-409: no usable terms, or plane terms without normals -> identity (and n == 0: nothing to solve)
+  const bool identity = (!wp && !wl) || (wl && !a.has_normals) || !(n > 0.0);
+  if (!identity) {
+    const double w_pt = wp ? (double)a.w_p2p : 0.0, w_pl = wl ? (double)a.w_p2pl : 0.0;
+    // unknown (j, a): 3 j + a for the linear part's row j, 9 + j for the translation -- eq_vec's own order (:457-460)
+    auto ja = [](int r, int& j, int& aa) { if (r < 9) { j = r / 3; aa = r % 3; } else { j = r - 9; aa = 3; } };
+    for (int e = t; e < 144; e += NT) {
+      const int r = e / 12, c = e % 12;
+      int j, aa, k, bb;
+      ja(r, j, aa); ja(c, k, bb);
+      const int ab = aa < bb ? aff_pair(aa, bb) : aff_pair(bb, aa);
+      double v = 0.0;
+      if (w_pl > 0.0) v += w_pl * sums[(j < k ? aff_jk(j, k) : aff_jk(k, j)) * 10 + ab];      // sum n_j n_k s'_a s'_b
+      if (w_pt > 0.0 && j == k) v += w_pt * sums[72 + ab];                                    // sum s'_a s'_b
+      A[e] = v;
+    }
+    if (t < 12) {
+      int j, aa;
+      ja(t, j, aa);
+      double bv = 0.0;
+      if (w_pl > 0.0) bv += w_pl * sums[60 + 4 * j + aa];      // sum (n.d) n_j s'_a
+      if (w_pt > 0.0) bv += w_pt * sums[82 + 4 * j + aa];      // sum d_j s'_a
+      rhs[t] = bv;
+      perm[t] = t;
+    }
+    __syncthreads();
+    const double tiny = 2.2250738585072014e-308;
+    for (int k = 0; k < N; ++k) {
+      if (t == 0) {
+        int piv = k;
+        double best = fabs(A[k * N + k]);
+        for (int i = k + 1; i < N; ++i) if (fabs(A[i * N + i]) > best) { best = fabs(A[i * N + i]); piv = i; }
+        s_piv = piv;
+      }
+      __syncthreads();
+      const int piv = s_piv;
+      if (piv != k) {
+        if (t < N) { const double v = A[k * N + t]; A[k * N + t] = A[piv * N + t]; A[piv * N + t] = v; }
+        __syncthreads();
+        if (t < N) { const double v = A[t * N + k]; A[t * N + k] = A[t * N + piv]; A[t * N + piv] = v; }
+        if (t == 0) { const int v = perm[k]; perm[k] = perm[piv]; perm[piv] = v; }
+        __syncthreads();
+      }
+      const double dk = A[k * N + k];
+      if (fabs(dk) <= tiny) {
+        if (t > k && t < N) A[t * N + k] = 0.0;
+        __syncthreads();
+        continue;
+      }
+      if (t > k && t < N) A[t * N + k] = A[t * N + k] / dk;
+      __syncthreads();
+      for (int e = t; e < 144; e += NT) {
+        const int i = e / 12, j = e % 12;
+        if (j > k && j <= i) {
+          const double v = __dsub_rn(A[i * N + j], __dmul_rn(__dmul_rn(A[i * N + k], dk), A[j * N + k]));
+          A[i * N + j] = v;
+          A[j * N + i] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t == 0) {
+    if (counters) { st->unproven = unproven_total; st->listed = listed_total; }
+    double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tr[3] = {0, 0, 0};
+    if (!identity) {
+      for (int i = 0; i < N; ++i) y[i] = rhs[perm[i]];
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < i; ++j) y[i] = __dsub_rn(y[i], __dmul_rn(A[i * N + j], y[j]));
+      for (int i = 0; i < N; ++i) { const double d = A[i * N + i]; y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0; }
+      for (int i = N - 1; i >= 0; --i)
+        for (int j = i + 1; j < N; ++j) y[i] = __dsub_rn(y[i], __dmul_rn(A[j * N + i], y[j]));
+      for (int i = 0; i < N; ++i) x[perm[i]] = y[i];
+      for (int i = 0; i < 9; ++i) L[i] = x[i];              // :470-472 row-major linear part, then the translation
+      for (int i = 0; i < 3; ++i) tr[i] = x[9 + i];
+      if (a.affine_centered)                                // :473 tform = t_dst * tform * t_src
+        for (int r = 0; r < 3; ++r)
+          tr[r] = tr[r] - (L[r * 3] * (double)st->smt[0] + L[r * 3 + 1] * (double)st->smt[1] + L[r * 3 + 2] * (double)st->smt[2]) + (double)a.dst_mean[r];
+    }
+    float dT[16];
+    for (int i = 0; i < 16; ++i) dT[i] = 0.0f;
+    dT[15] = 1.0f;
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) dT[c * 4 + r] = (float)L[r * 3 + c]; dT[12 + r] = (float)tr[r]; }
+    // transform_ = tform_iter * transform_ (f32, Eigen's affine product) and |tform_iter - I|_F
+    const float* T = st->T;
+    float Tn[16];
+    for (int i = 0; i < 16; ++i) Tn[i] = 0.0f;
+    Tn[15] = 1.0f;
+    for (int r = 0; r < 3; ++r) {
+      for (int cc = 0; cc < 3; ++cc)
+        Tn[cc * 4 + r] = __fadd_rn(__fadd_rn(__fmul_rn(dT[0 * 4 + r], T[cc * 4 + 0]), __fmul_rn(dT[1 * 4 + r], T[cc * 4 + 1])), __fmul_rn(dT[2 * 4 + r], T[cc * 4 + 2]));
+      Tn[12 + r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(dT[0 * 4 + r], T[12]), __fmul_rn(dT[1 * 4 + r], T[13])), __fmul_rn(dT[2 * 4 + r], T[14])), dT[12 + r]);
+    }
+    float dn = 0.0f;
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) { const float v = __fsub_rn(dT[cc * 4 + r], r == cc ? 1.0f : 0.0f); dn = __fadd_rn(dn, __fmul_rn(v, v)); }
+    for (int r = 0; r < 3; ++r) dn = __fadd_rn(dn, __fmul_rn(dT[12 + r], dT[12 + r]));
+    const float delta = sqrtf(dn);
+    for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = 0.0;
+    st->sums[0] = n;
+    finalize_state(st, a, Tn, delta);
+  }
+  __syncthreads();
+  for (int k = t; k < ST_DWORDS; k += NT) reinterpret_cast<uint32_t*>(a.state)[k] = reinterpret_cast<const uint32_t*>(&lst)[k];
+  publish_state(a, lst);
+}
+
+// rows -> epilogue: more than 64 rows go through AFF_GROUPS partial folds first (same rows, same order every run)
+void launch_reduce_and_solve_affine(const double* partials, int nrows, double* stage, const SolveArgs& a0, hipStream_t s) {
+  SolveArgs a = a0;
+  a.gn_last_step = 1;
+  if (nrows > 64) {
+    hipLaunchKernelGGL(k_reduce_affine, dim3(AFF_GROUPS), dim3(AFF_ROW), 0, s, partials, nrows, stage, (const IcpState*)a.state);
+    a.partials = stage; a.nblocks = AFF_GROUPS;
+  } else {
+    a.partials = partials; a.nblocks = nrows;
+  }
+  a.reduced = nullptr;
+  hipLaunchKernelGGL(k_solve_affine, dim3(1), dim3(AFF_ROW), 0, s, a);
 }
 
 struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; float src_center[3], src_half[3]; unsigned int* tie_counters; };

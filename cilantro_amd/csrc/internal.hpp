@@ -102,7 +102,14 @@ enum IterMetric { IM_NONE = 0, IM_KABSCH = 1, IM_PLANE = 2, IM_POINT = 3, IM_BOT
                   // moments of the 12-unknown affine normal equations (transform_estimation.hpp:369-476), three streaming passes:
                   IM_AFF0 = 5,    // [0] n, [1..6] sum s s^T (upper), [7..9] sum s, [10..18] sum s_a d_r, [19..21] sum d, [22..33] sum (n.d) n_j (s,1)_a
                   IM_AFF1 = 6,    // sum n_j n_k (s,1)_a (s,1)_b, (j,k) = (0,0),(0,1),(0,2) x the 10 pairs a <= b
-                  IM_AFF2 = 7 };  // the same for (j,k) = (1,1),(1,2),(2,2)
+                  IM_AFF2 = 7,    // the same for (j,k) = (1,1),(1,2),(2,2)
+                  // ... and the same moments in ONE pass on the matrix cores (affine_device.hpp: rows of AFF_ROW doubles, layout AffSlot), the
+                  // loops of the affine classes without per-pair weights: IM_AFFC with the target's normals, IM_AFFP without (point terms only)
+                  IM_AFFC = 8, IM_AFFP = 9 };
+inline bool im_affine_fused(int m) { return m == IM_AFFC || m == IM_AFFP; }
+// One row of partial sums of the one-pass affine moments: 94 used of 128 (affine_device.hpp: what they are, where they sit).
+constexpr int AFF_ROW = 128;
+constexpr int AFF_SUMS = 94;
 
 // Correspondence weight evaluators of the combined-metric classes (core/common_pair_evaluators.hpp:14-27 Identity, :30-43
 // Unity, :46-80 RBF kernel over squared distances), selected per term type.  enabled: some evaluator is not Unity -- the
@@ -242,6 +249,7 @@ struct SolveArgs {
   int gn_last_step;        // finalize the outer iteration after this GN step
   int gn_zero_steps;       // max_optimization_iterations == 0: the estimator's loop does not run, tform = t_dst * I * t_src (transform_estimation.hpp:281, :365)
   int has_normals;
+  int affine_centered;     // (IM_AFFC / IM_AFFP) 1: the combined-metric class (means subtracted, tform = t_dst * tform * t_src), 0: the point-to-point class
   // spatially sharded runs (slab partition of target and source along one axis): after every update of the transform the
   // epilogue bounds how far ANY source point (global bounding box of the source, in source coordinates) can have moved
   // along the slab axis since the partition was made, and raises IcpState::slab_violation when that exceeds the slack the
@@ -356,6 +364,11 @@ int launch_reduce_stage1(const double* partials, int nblocks, double* stage, hip
 // both stages of the reduction and the epilogue: one launch when there are more than 64 rows (ticket: one zeroed word per context; null: the two-kernel path)
 void launch_reduce_and_solve(const double* partials, int nblocks, double* stage, unsigned int* ticket, SolveArgs a, hipStream_t s);
 constexpr int REDUCE_STAGE_DOUBLES = 128 * SUMS_MAX;
+// affine.hip -- the affine classes' loop on the device: one-pass moments over stored matches (IM_AFFC / IM_AFFP; a.partials: rows of
+// AFF_ROW doubles), their fixed-order reduction and the 12-unknown solve + compose + loop state in one epilogue
+int affine_acc_blocks(uint32_t ns);
+void launch_acc_affine(const IterArgs& a, int metric, int nblocks, hipStream_t s);
+void launch_reduce_and_solve_affine(const double* partials, int nrows, double* stage /*[32 * AFF_ROW]*/, const SolveArgs& a, hipStream_t s);
 void launch_init_state(IcpState* st, const float T0[16], const float src_mean[3], hipStream_t s, Feedback* fb = nullptr, unsigned int run_tag = 0,
                        const float* src_center = nullptr, const float* src_half = nullptr, unsigned int* tie_counters = nullptr /*[4], zeroed*/);
 void launch_scatter_nn(const float4* src_sorted, const float4* dst_sorted, const uint32_t* nn_pos,

@@ -972,7 +972,7 @@ template <int ACC>
 struct FusedZ {
   static constexpr bool plane = (ACC == IM_PLANE || ACC == IM_BOTH);
   static constexpr int NC = (ACC == IM_BOTH) ? 14 : 8;
-  static constexpr bool needs_normal = plane;
+  static constexpr bool needs_normal = plane || ACC == IM_AFFC;      // (IM_AFFC / IM_AFFP: affine_device.hpp forms the terms; only this flag is read)
   __device__ static bool slot_terms(int s, int& i1, int& j1, int& i2, int& j2) {
     i1 = j1 = 0; i2 = j2 = -1;
     if (ACC == IM_KABSCH) {

@@ -333,8 +333,8 @@ __device__ void block_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t
   __syncthreads();
 }
 
-__global__ __launch_bounds__(SMALL_T) void k_build_small(const float* __restrict__ xyz, const float4* __restrict__ sorted, uint32_t n, SmallWs w, uint4* __restrict__ nodes,
-                                                         uint32_t node_cap, uint32_t* __restrict__ leaf_by_index, uint32_t* __restrict__ slot_by_index) {
+__global__ __launch_bounds__(SMALL_T) void k_build_small(const float* xyz, const float4* sorted, uint32_t n, SmallWs w, uint4* nodes,
+                                                         uint32_t node_cap, uint32_t* leaf_by_index, uint32_t* slot_by_index) {      // (no __restrict__: the threads of the block hand data to each other through these arrays)
   __shared__ uint32_t tmp[SMALL_T];
   __shared__ uint32_t mmk[2 * SMALL_ACT + 2][6];      // min x, y, z, max x, y, z of a level's children (ordered integer images)
   __shared__ uint32_t s_na, s_nodes;
@@ -426,16 +426,6 @@ __global__ __launch_bounds__(SMALL_T) void k_build_small(const float* __restrict
         else if (rel >= nU) { const uint32_t Ub = rel - Fb; w.posU[lo + (nU - Ub - 1u)] = p; }
       }
       __syncthreads();
-      // (the limits are written AFTER every thread has read lim1 as this pass's range start)
-      for (uint32_t p = t; p < n; p += T) {
-        const uint32_t a = w.node_of[p];
-        if (a == NONE) continue;
-        Act<3>& A = cur[a];
-        const uint32_t lo = pass == 1 ? A.left : A.left + A.lim1;
-        if (p != lo) continue;
-        const uint32_t nF = w.S[A.right] - w.S[lo], nU = (A.right - lo) - nF;
-        if (pass == 1) A.lim1 = nU; else A.lim2 = A.lim1 + nU;
-      }
       for (uint32_t p = t; p < n; p += T) {
         uint32_t dest = p;
         const uint32_t a = w.node_of[p];
@@ -451,6 +441,17 @@ __global__ __launch_bounds__(SMALL_T) void k_build_small(const float* __restrict
           }
         }
         outp[dest] = in[p];
+      }
+      __syncthreads();
+      // (the limits are written in a phase of their own: no thread of the block reads a node's record while one writes it)
+      for (uint32_t p = t; p < n; p += T) {
+        const uint32_t a = w.node_of[p];
+        if (a == NONE) continue;
+        Act<3>& A = cur[a];
+        const uint32_t lo = pass == 1 ? A.left : A.left + A.lim1;
+        if (p != lo) continue;
+        const uint32_t nF = w.S[A.right] - w.S[lo], nU = (A.right - lo) - nF;
+        if (pass == 1) A.lim1 = nU; else A.lim2 = A.lim1 + nU;
       }
       __syncthreads();
     }
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(SMALL_T) void k_build_small(const float* __restrict
     ++depth;
     if (s_na == 0u || depth > 200u) break;
   }
+  __syncthreads();
   if (t == 0) { w.out[0] = s_nodes; w.out[1] = depth; }
 }
 

@@ -1,5 +1,6 @@
 // warm.hip -- the warm-started iteration (k_warm<metric, rec>: margin proof, list search, matrix-core accumulation) and k_self_nn's nearest-other-point table; split from kernels.hip (overview there, DESIGN.md sections 5 and 6.2).
 #include "search_device.hpp"
+#include "affine_device.hpp"
 
 namespace cilhip {
 
@@ -161,7 +162,10 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   for (int i = 0; i < 12; ++i) T[i] = st->T[(i / 3) * 4 + (i % 3)];     // columns 0..3, rows 0..2
   // (loop state read HERE, into scalar registers: a load of it inside the streaming loop is a vector-memory load whose wait
   //  -- vmcnt counts in order -- also waits for the next round's prefetch, i.e. serialises memory latency and arithmetic)
-  const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};
+  constexpr bool AFF = (ACC == IM_AFFC || ACC == IM_AFFP);      // the affine classes' moments (affine_device.hpp)
+  const bool raw_moments = AFF && a.no_centering;                // (point-to-point class: no means subtracted)
+  const float smt[3] = {raw_moments ? 0.0f : st->smt[0], raw_moments ? 0.0f : st->smt[1], raw_moments ? 0.0f : st->smt[2]};
+  const float dmn[3] = {raw_moments ? 0.0f : a.dst_mean[0], raw_moments ? 0.0f : a.dst_mean[1], raw_moments ? 0.0f : a.dst_mean[2]};
   const MotionRef mref = {st->motion_acc, st->motion_eps};
   const float Dk = __fadd_rn(mref.acc, mref.eps) * 1.000001f;      // the motion clock now (rounded up): what a key is compared against
   const GridDev& g = a.grid;
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
 #endif
   typedef double double4_t __attribute__((ext_vector_type(4)));
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const AffLane afl = aff_lane((int)(threadIdx.x & 63u));
   constexpr int NC = FusedZ<ACC>::NC;
   constexpr bool DUAL = NC <= 8;
   constexpr bool NRM = FusedZ<ACC>::needs_normal;
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   // (two halves: the terms z of the wave's correspondences -> LDS; then LDS -> f64 operands -> the matrix cores.  Between them
   //  a round's streamed registers are dead, which is where the streaming loop requests the data of the round after next.)
   auto z_to_lds = [&](bool has, float qx, float qy, float qz, const float4 pm, const float4 nm) {
+    if (AFF) { aff_record<NRM>(has, qx, qy, qz, pm, nm, dmn, smt, zb + lane * AFF_REC); return; }
     float z[16];
     fused_z<ACC>(has, qx, qy, qz, pm, nm, a.dst_mean, smt, z);
     if (DUAL) {
@@ -223,7 +229,9 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   };
   auto lds_to_mfma = [&]() {
     __builtin_amdgcn_wave_barrier();
-    if (DUAL) {
+    if (AFF) {
+      aff_mfma_round(zb, lane, afl, acc);
+    } else if (DUAL) {
       const int comp = lane & 7, hf = (lane >> 3) & 1, k4 = lane >> 4;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
@@ -584,6 +592,10 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     if (lane == 0 && tot > 0.0) atomicAdd(a.unproven_cnt + (vb & 63u), (uint32_t)tot);
     if (lane == 0 && qlisted != 0u) atomicAdd(a.unproven_cnt + 64u + ((vb * WARM_WAVES + (uint32_t)wave) & 63u), qlisted);   // listed queries: is the form paying?
   }
+  if (AFF) {
+    aff_write_row<WARM_WAVES>(raw, wave, lane, acc, a.partials + (size_t)vb * AFF_ROW);
+    return;
+  }
   double* const db = reinterpret_cast<double*>(raw + wave * FUSED_WAVE_BYTES);
 #pragma unroll
   for (int r = 0; r < 4; ++r) db[r * 64 + lane] = acc[r];
@@ -642,6 +654,8 @@ void launch_warm(const IterArgs& a, int metric, int rec, int nblocks, hipStream_
     case IM_KABSCH: launch_warm_m<IM_KABSCH>(a, rec, nblocks, s); break;
     case IM_PLANE: launch_warm_m<IM_PLANE>(a, rec, nblocks, s); break;
     case IM_POINT: launch_warm_m<IM_POINT>(a, rec, nblocks, s); break;
+    case IM_AFFC: launch_warm_m<IM_AFFC>(a, rec, nblocks, s); break;
+    case IM_AFFP: launch_warm_m<IM_AFFP>(a, rec, nblocks, s); break;
     default: launch_warm_m<IM_BOTH>(a, rec, nblocks, s); break;
   }
 }

@@ -697,8 +697,13 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        1 = affine -- Simple{PointToPoint,Combined}MetricAffineICP3f: same loop and correspondence engine,
  *                        the step is cilhip_estimate_affine's closed form and there is no rotation() polish
  *                        (icp_single_transform_combined_metric.hpp:207-216); max_opt_iter / opt_conv_tol are unused,
- *                        as in the reference's affine overload.  Host-driven loop (one 12x12 solve per iteration).
- *                        Not available in sharded runs.
+ *                        as in the reference's affine overload.  Not available in sharded runs.
+ *   "affine_device_loop" (default 1): the affine classes' loop runs device-resident like the rigid one whenever nothing needs the
+ *                        stored correspondence set per iteration (SECOND_TO_FIRST, no post-filters, unity evaluators, point features):
+ *                        search-only kernels + ONE streaming pass of the 112 moments on the matrix cores while the source is far from
+ *                        alignment, search + moments in the warm-started kernel afterwards, the pivoted 12x12 LDL^T, the un-centring and
+ *                        the f32 compose in the epilogue kernel -- no host round trip per iteration.  0 = the host-driven loop (three
+ *                        moment passes + a host solve per iteration: what the other configurations run), for A/B runs.
  * Correspondence weight evaluators of the combined-metric classes (the PointToPoint/PointToPlaneCorrWeightEvaluatorT
  * template arguments of registration/icp_single_transform_combined_metric.hpp:11-14, core/common_pair_evaluators.hpp):
  *   "point_weight_evaluator", "plane_weight_evaluator" (default 0): 0 = UnityWeightEvaluator (:30-43),
@@ -724,7 +729,7 @@ typedef enum cilhip_option {
   CILHIP_OPT_POINT_WEIGHT_SIGMA, CILHIP_OPT_PLANE_WEIGHT_SIGMA, CILHIP_OPT_TILE_ACCUMULATION, CILHIP_OPT_SEARCH_DIRECTION,
   CILHIP_OPT_FEATURE_NORMAL_WEIGHT, CILHIP_OPT_FEATURE_KIND, CILHIP_OPT_FEATURE_COLOR_WEIGHT, CILHIP_OPT_SYMMETRIC_METRIC,
   CILHIP_OPT_TRANSFORM_MODE, CILHIP_OPT_REQUIRE_RECIPROCALITY, CILHIP_OPT_CELL_OCCUPANCY, CILHIP_OPT_REFINED_OCCUPANCY_FACTOR,
-  CILHIP_OPT_KERNEL_TIMING, CILHIP_OPT_KERNEL_TIMING_STRIDE,
+  CILHIP_OPT_KERNEL_TIMING, CILHIP_OPT_KERNEL_TIMING_STRIDE, CILHIP_OPT_AFFINE_DEVICE_LOOP,
   CILHIP_OPT_COUNT
 } cilhip_option;
 typedef struct cilhip_option_info_t {

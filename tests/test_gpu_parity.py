@@ -1049,6 +1049,59 @@ def test_tiled_clean_up_pass_sparse_far_and_unbounded(Context, orc):
 
 
 @pytest.mark.gpu
+def test_affine_loop_on_the_device_vs_host_driven_loop_and_oracle(Context, orc, hip_lib):
+    """The affine classes' device-resident loop (option "affine_device_loop": search-only kernels + k_acc_affine while cold,
+    k_warm<IM_AFFC / IM_AFFP> afterwards, the 12-unknown solve in k_solve_affine) against the host-driven loop it replaces
+    (three moment passes + ldlt_solve_n on the host) and the oracle's affine ICP: same iteration counts, same correspondence
+    sets, transforms equal to the order of the f64 additions (transform_estimation.hpp:369-476, :50-102;
+    icp_single_transform_combined_metric.hpp:207-216)."""
+    from cilantro_amd.icp import SimpleCombinedMetricAffineICP3f, SimplePointToPointMetricAffineICP3f
+
+    n = 200_000
+    rng = np.random.default_rng(11)
+    for perturb in (0.15, 0.8):
+        d = syn.make_pair(n, perturb=perturb)
+        S = np.eye(3) + 0.003 * rng.normal(size=(3, 3))
+        c0 = np.array([0.5, 0.5, 0.5])
+        src = ((d["src"].astype(np.float64) - c0) @ S.T + c0).astype(np.float32)
+        dst, dst_n = d["dst"], d["dst_n"]
+        max_sq = float((3 * d["h"]) ** 2)
+        for metric, wts in ((1, (0.1, 1.0)), (1, (0.0, 1.0)), (1, (1.0, 0.0)), (0, (1.0, 0.0))):
+            for max_iter, tol in ((12, 0.0), (40, 1e-5)):
+                got = {}
+                for loop in (1, 0):
+                    if metric == 1:
+                        icp = SimpleCombinedMetricAffineICP3f(dst, dst_n, src)
+                        icp.setPointToPointMetricWeight(wts[0]).setPointToPlaneMetricWeight(wts[1])
+                    else:
+                        icp = SimplePointToPointMetricAffineICP3f(dst, src)
+                    icp._ctx.set_option("affine_device_loop", loop)
+                    icp.correspondenceSearchEngine().setMaxDistance(max_sq)
+                    icp.setMaxNumberOfIterations(max_iter).setConvergenceTolerance(tol)
+                    T = icp.estimate().getTransform().astype(np.float64)
+                    i1, i2, dv = icp._ctx.get_correspondences()
+                    got[loop] = (T, icp.getNumberOfPerformedIterations(), icp.last_ncorr_, i1.copy(), i2.copy(), dv.copy(), icp._ctx.last_warm_iterations())
+                (Td, itd, ncd, a1, a2, av, warm_d), (Th, ith, nch, b1, b2, bv, _) = got[1], got[0]
+                assert abs(itd - ith) <= (0 if tol == 0.0 else 1), (perturb, metric, wts, itd, ith)
+                assert np.linalg.norm(Td - Th) < 2e-6, (perturb, metric, wts, max_iter, np.linalg.norm(Td - Th))
+                if tol == 0.0:
+                    assert ncd == nch
+                    # the set the last iteration estimated from, element for element (its distances under transforms that differ in
+                    # their last bits: the two loops add the same terms in different orders)
+                    assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.allclose(av, bv, rtol=0.0, atol=5e-9)
+                    assert warm_d > 0, "the warm-started affine kernel never ran"
+                if metric == 1 and wts == (0.1, 1.0) or metric == 0:
+                    p = orc.make_params(metric=metric, w_p2p=wts[0], w_p2pl=wts[1], max_iter=max_iter, conv_tol=tol, max_sq_dist=max_sq,
+                                        mode=orc.MODE_MIXED, affine=True)
+                    r = orc.icp_run(dst, dst_n, src, p)
+                    err = np.linalg.norm(Td - r["T"].astype(np.float64))
+                    assert err <= 3e-5, (perturb, metric, max_iter, err)
+                    assert abs(itd - r["iterations"]) <= (0 if tol == 0.0 else 1)
+                    if tol == 0.0:
+                        assert ncd == r["last_ncorr"]
+
+
+@pytest.mark.gpu
 def test_affine_variants_vs_oracle(Context, orc, hip_lib):
     """SURVEY 8(f) rank 3, affine variants: the 12-unknown closed forms (transform_estimation.hpp:50-102, :369-476) and the
     Affine ICP instances (icp_common_instances.hpp:255, :266).  The device accumulates the moments of the normal equations
