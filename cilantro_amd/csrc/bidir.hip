@@ -130,12 +130,129 @@ __device__ __forceinline__ void scan_range_inv_ties(const float4* __restrict__ p
   }
 }
 
+// the reverse match of ONE target point (sorted position jd): shells of the source grid around p' = T^-1 p, candidates compared by the
+// pinned d2(p, T s); T / iv as set up by inverse_for_state()
 template <bool FEAT6>
-__global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over the source, source space*/, const float4* __restrict__ dst_sorted, uint32_t nd,
-                                                        const IcpState* __restrict__ st, InvArgs iv, float max_sq, uint32_t* __restrict__ rev_pos,
-                                                        float* __restrict__ rev_d2, FeatSpec fs, TieDev tt) {
-  if (st->done) return;
-  float T[16];
+__device__ __forceinline__ void reverse_search_point(const GridDev& sg, const float4* __restrict__ dst_sorted, uint32_t jd, const float* T, const InvArgs& iv, float max_sq,
+                                                     uint32_t* __restrict__ rev_pos, float* __restrict__ rev_d2, const FeatSpec& fs, const TieDev& tt) {
+  const float KS = 0.99999905f;
+  const float4 p = dst_sorted[jd];
+  float pfx = 0.f, pfy = 0.f, pfz = 0.f;
+  float pgx = 0.f, pgy = 0.f, pgz = 0.f;
+  if (FEAT6) { const float4 v = fs.dst[jd]; pfx = __fmul_rn(fs.w, v.x); pfy = __fmul_rn(fs.w, v.y); pfz = __fmul_rn(fs.w, v.z); }      // the adaptor stores w * v (:90)
+  if (FEAT6 && fs.dst2 != nullptr) { const float4 v = fs.dst2[jd]; pgx = __fmul_rn(fs.w2, v.x); pgy = __fmul_rn(fs.w2, v.y); pgz = __fmul_rn(fs.w2, v.z); }
+  float sx, sy, sz;
+  transform_point(iv.Ti, p.x, p.y, p.z, sx, sy, sz);
+  unsigned long long bkey = (unsigned long long)__float_as_uint(max_sq) << 32;
+  uint32_t bpos = NONE_U32, tie = 0u;
+  const float BIG = 1.0e9f;
+  const int cx = (int)floorf(fminf(fmaxf((sx - sg.ox) * sg.inv_cell, -BIG), BIG));
+  const int cy = (int)floorf(fminf(fmaxf((sy - sg.oy) * sg.inv_cell, -BIG), BIG));
+  const int cz = (int)floorf(fminf(fmaxf((sz - sg.oz) * sg.inv_cell, -BIG), BIG));
+  {  // farther than the radius from the whole source grid: nothing to find
+    const float gx = fmaxf(fmaxf(sg.ox - sx, sx - (sg.ox + (float)sg.nx * sg.cell)) - sg.margin, 0.0f);
+    const float gy = fmaxf(fmaxf(sg.oy - sy, sy - (sg.oy + (float)sg.ny * sg.cell)) - sg.margin, 0.0f);
+    const float gz = fmaxf(fmaxf(sg.oz - sz, sz - (sg.oz + (float)sg.nz * sg.cell)) - sg.margin, 0.0f);
+    const float lb = mapped_bound(sqrtf(gx * gx + gy * gy + gz * gz), iv);
+    if (lb * lb * KS >= max_sq) { rev_pos[jd] = NONE_U32; rev_d2[jd] = max_sq; return; }
+  }
+  int s = max(0, max(max(-cx, cx - (sg.nx - 1)), max(max(-cy, cy - (sg.ny - 1)), max(-cz, cz - (sg.nz - 1)))));   // first shell that reaches the grid
+  for (;; ++s) {
+    const int z0 = max(cz - s, 0), z1 = min(cz + s, sg.nz - 1);
+    const int y0 = max(cy - s, 0), y1 = min(cy + s, sg.ny - 1);
+    const int xlo = cx - s, xhi = cx + s;
+    for (int z = z0; z <= z1; ++z) {
+      const bool zface = (z == cz - s) || (z == cz + s);
+      const float zl = sg.oz + (float)z * sg.cell;
+      const float gz = fmaxf(fmaxf(zl - sz, sz - (zl + sg.cell)) - sg.margin, 0.0f);
+      for (int y = y0; y <= y1; ++y) {
+        const bool face = zface || (y == cy - s) || (y == cy + s);
+        const float yl = sg.oy + (float)y * sg.cell;
+        const float gy = fmaxf(fmaxf(yl - sy, sy - (yl + sg.cell)) - sg.margin, 0.0f);
+        const float bd = __uint_as_float((uint32_t)(bkey >> 32));
+        {
+          const float lb = mapped_bound(sqrtf(gz * gz + gy * gy), iv);
+          if (lb * lb * KS > bd) continue;
+        }
+        const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
+        if (face) {
+          const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
+          if (xa <= xb) scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
+        } else {
+          if (xlo >= 0 && xlo < sg.nx)
+            scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
+          if (xhi >= 0 && xhi < sg.nx)
+            scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
+        }
+      }
+    }
+    // lower bound (source space) on the distance to anything outside the (2s+1)^3 block and inside the grid
+    float b = INFINITY;
+    if (cx - s > 0) b = fminf(b, sx - (sg.ox + (float)(cx - s) * sg.cell));
+    if (cx + s + 1 < sg.nx) b = fminf(b, (sg.ox + (float)(cx + s + 1) * sg.cell) - sx);
+    if (cy - s > 0) b = fminf(b, sy - (sg.oy + (float)(cy - s) * sg.cell));
+    if (cy + s + 1 < sg.ny) b = fminf(b, (sg.oy + (float)(cy + s + 1) * sg.cell) - sy);
+    if (cz - s > 0) b = fminf(b, sz - (sg.oz + (float)(cz - s) * sg.cell));
+    if (cz + s + 1 < sg.nz) b = fminf(b, (sg.oz + (float)(cz + s + 1) * sg.cell) - sz);
+    if (b == INFINITY) break;  // the block covers the grid: everything scanned
+    const float lb = mapped_bound(b - sg.margin, iv);
+    if (lb > 0.0f && __uint_as_float((uint32_t)(bkey >> 32)) < lb * lb * KS) break;
+  }
+  if (!FEAT6 && tt.mode != 0 && tie != 0u && bpos != NONE_U32) {
+    // option "tie_rule": the same shells again with the distance fixed (a row or a shell AT the distance is looked at: the bounds are strict).
+    // The flag may be stale (raised for a distance that was beaten later): the candidates at the FINAL distance are counted either way --
+    // without the tables a target point with two or more of them is reported (counters[3]) and keeps the lowest source index.
+    {
+      const float bd = __uint_as_float((uint32_t)(bkey >> 32));
+      uint32_t cur = bpos, ncand = 0u;
+      for (int s2 = max(0, max(max(-cx, cx - (sg.nx - 1)), max(max(-cy, cy - (sg.ny - 1)), max(-cz, cz - (sg.nz - 1)))));; ++s2) {
+        const int z0 = max(cz - s2, 0), z1 = min(cz + s2, sg.nz - 1);
+        const int y0 = max(cy - s2, 0), y1 = min(cy + s2, sg.ny - 1);
+        const int xlo = cx - s2, xhi = cx + s2;
+        for (int z = z0; z <= z1; ++z) {
+          const bool zface = (z == cz - s2) || (z == cz + s2);
+          const float zl = sg.oz + (float)z * sg.cell;
+          const float gz = fmaxf(fmaxf(zl - sz, sz - (zl + sg.cell)) - sg.margin, 0.0f);
+          for (int y = y0; y <= y1; ++y) {
+            const bool face = zface || (y == cy - s2) || (y == cy + s2);
+            const float yl = sg.oy + (float)y * sg.cell;
+            const float gy = fmaxf(fmaxf(yl - sy, sy - (yl + sg.cell)) - sg.margin, 0.0f);
+            const float lbr = mapped_bound(sqrtf(gz * gz + gy * gy), iv);
+            if (lbr * lbr * KS > bd) continue;
+            const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
+            if (face) {
+              const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
+              if (xa <= xb) scan_range_inv_ties(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
+            } else {
+              if (xlo >= 0 && xlo < sg.nx) scan_range_inv_ties(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
+              if (s2 > 0 && xhi >= 0 && xhi < sg.nx) scan_range_inv_ties(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
+            }
+          }
+        }
+        float b2 = INFINITY;
+        if (cx - s2 > 0) b2 = fminf(b2, sx - (sg.ox + (float)(cx - s2) * sg.cell));
+        if (cx + s2 + 1 < sg.nx) b2 = fminf(b2, (sg.ox + (float)(cx + s2 + 1) * sg.cell) - sx);
+        if (cy - s2 > 0) b2 = fminf(b2, sy - (sg.oy + (float)(cy - s2) * sg.cell));
+        if (cy + s2 + 1 < sg.ny) b2 = fminf(b2, (sg.oy + (float)(cy + s2 + 1) * sg.cell) - sy);
+        if (cz - s2 > 0) b2 = fminf(b2, sz - (sg.oz + (float)(cz - s2) * sg.cell));
+        if (cz + s2 + 1 < sg.nz) b2 = fminf(b2, (sg.oz + (float)(cz + s2 + 1) * sg.cell) - sz);
+        if (b2 == INFINITY) break;
+        const float lb2 = mapped_bound(b2 - sg.margin, iv);
+        if (lb2 > 0.0f && bd < lb2 * lb2 * KS) break;
+      }
+      if (ncand >= 2u) {
+        if (tt.leaf_slot == nullptr) atomicAdd(tt.counters + 3, 1u);
+        else { atomicAdd(tt.counters + 1, 1u); if (cur != bpos) atomicAdd(tt.counters + 2, 1u); }
+      }
+      bpos = cur;
+    }
+  }
+  rev_pos[jd] = bpos;
+  rev_d2[jd] = __uint_as_float((uint32_t)(bkey >> 32));
+}
+
+// the state's transform and, for the device-resident (rigid) loops, its inverse [L^T | -L^T t]
+__device__ __forceinline__ void inverse_for_state(const IcpState* __restrict__ st, float* T, InvArgs& iv) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
   if (iv.rigid_on_device) {
@@ -147,122 +264,73 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
     }
     iv.Ti[3] = iv.Ti[7] = iv.Ti[11] = 0.0f; iv.Ti[15] = 1.0f;
   }
-  const float KS = 0.99999905f;
-  for (uint32_t jd = blockIdx.x * blockDim.x + threadIdx.x; jd < nd; jd += gridDim.x * blockDim.x) {
-    const float4 p = dst_sorted[jd];
-    float pfx = 0.f, pfy = 0.f, pfz = 0.f;
-    float pgx = 0.f, pgy = 0.f, pgz = 0.f;
-    if (FEAT6) { const float4 v = fs.dst[jd]; pfx = __fmul_rn(fs.w, v.x); pfy = __fmul_rn(fs.w, v.y); pfz = __fmul_rn(fs.w, v.z); }      // the adaptor stores w * v (:90)
-    if (FEAT6 && fs.dst2 != nullptr) { const float4 v = fs.dst2[jd]; pgx = __fmul_rn(fs.w2, v.x); pgy = __fmul_rn(fs.w2, v.y); pgz = __fmul_rn(fs.w2, v.z); }
-    float sx, sy, sz;
-    transform_point(iv.Ti, p.x, p.y, p.z, sx, sy, sz);
-    unsigned long long bkey = (unsigned long long)__float_as_uint(max_sq) << 32;
-    uint32_t bpos = NONE_U32, tie = 0u;
-    const float BIG = 1.0e9f;
-    const int cx = (int)floorf(fminf(fmaxf((sx - sg.ox) * sg.inv_cell, -BIG), BIG));
-    const int cy = (int)floorf(fminf(fmaxf((sy - sg.oy) * sg.inv_cell, -BIG), BIG));
-    const int cz = (int)floorf(fminf(fmaxf((sz - sg.oz) * sg.inv_cell, -BIG), BIG));
-    {  // farther than the radius from the whole source grid: nothing to find
-      const float gx = fmaxf(fmaxf(sg.ox - sx, sx - (sg.ox + (float)sg.nx * sg.cell)) - sg.margin, 0.0f);
-      const float gy = fmaxf(fmaxf(sg.oy - sy, sy - (sg.oy + (float)sg.ny * sg.cell)) - sg.margin, 0.0f);
-      const float gz = fmaxf(fmaxf(sg.oz - sz, sz - (sg.oz + (float)sg.nz * sg.cell)) - sg.margin, 0.0f);
-      const float lb = mapped_bound(sqrtf(gx * gx + gy * gy + gz * gz), iv);
-      if (lb * lb * KS >= max_sq) { rev_pos[jd] = NONE_U32; rev_d2[jd] = max_sq; continue; }
-    }
-    int s = max(0, max(max(-cx, cx - (sg.nx - 1)), max(max(-cy, cy - (sg.ny - 1)), max(-cz, cz - (sg.nz - 1)))));   // first shell that reaches the grid
-    for (;; ++s) {
-      const int z0 = max(cz - s, 0), z1 = min(cz + s, sg.nz - 1);
-      const int y0 = max(cy - s, 0), y1 = min(cy + s, sg.ny - 1);
-      const int xlo = cx - s, xhi = cx + s;
-      for (int z = z0; z <= z1; ++z) {
-        const bool zface = (z == cz - s) || (z == cz + s);
-        const float zl = sg.oz + (float)z * sg.cell;
-        const float gz = fmaxf(fmaxf(zl - sz, sz - (zl + sg.cell)) - sg.margin, 0.0f);
-        for (int y = y0; y <= y1; ++y) {
-          const bool face = zface || (y == cy - s) || (y == cy + s);
-          const float yl = sg.oy + (float)y * sg.cell;
-          const float gy = fmaxf(fmaxf(yl - sy, sy - (yl + sg.cell)) - sg.margin, 0.0f);
-          const float bd = __uint_as_float((uint32_t)(bkey >> 32));
-          {
-            const float lb = mapped_bound(sqrtf(gz * gz + gy * gy), iv);
-            if (lb * lb * KS > bd) continue;
-          }
-          const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
-          if (face) {
-            const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
-            if (xa <= xb) scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
-          } else {
-            if (xlo >= 0 && xlo < sg.nx)
-              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
-            if (xhi >= 0 && xhi < sg.nx)
-              scan_range_inv<FEAT6>(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bkey, bpos, tie, &fs, pfx, pfy, pfz, pgx, pgy, pgz);
-          }
-        }
-      }
-      // lower bound (source space) on the distance to anything outside the (2s+1)^3 block and inside the grid
-      float b = INFINITY;
-      if (cx - s > 0) b = fminf(b, sx - (sg.ox + (float)(cx - s) * sg.cell));
-      if (cx + s + 1 < sg.nx) b = fminf(b, (sg.ox + (float)(cx + s + 1) * sg.cell) - sx);
-      if (cy - s > 0) b = fminf(b, sy - (sg.oy + (float)(cy - s) * sg.cell));
-      if (cy + s + 1 < sg.ny) b = fminf(b, (sg.oy + (float)(cy + s + 1) * sg.cell) - sy);
-      if (cz - s > 0) b = fminf(b, sz - (sg.oz + (float)(cz - s) * sg.cell));
-      if (cz + s + 1 < sg.nz) b = fminf(b, (sg.oz + (float)(cz + s + 1) * sg.cell) - sz);
-      if (b == INFINITY) break;  // the block covers the grid: everything scanned
-      const float lb = mapped_bound(b - sg.margin, iv);
-      if (lb > 0.0f && __uint_as_float((uint32_t)(bkey >> 32)) < lb * lb * KS) break;
-    }
-    if (!FEAT6 && tt.mode != 0 && tie != 0u && bpos != NONE_U32) {
-      // option "tie_rule": the same shells again with the distance fixed (a row or a shell AT the distance is looked at: the bounds are strict).
-      // The flag may be stale (raised for a distance that was beaten later): the candidates at the FINAL distance are counted either way --
-      // without the tables a target point with two or more of them is reported (counters[3]) and keeps the lowest source index.
-      {
-        const float bd = __uint_as_float((uint32_t)(bkey >> 32));
-        uint32_t cur = bpos, ncand = 0u;
-        for (int s2 = max(0, max(max(-cx, cx - (sg.nx - 1)), max(max(-cy, cy - (sg.ny - 1)), max(-cz, cz - (sg.nz - 1)))));; ++s2) {
-          const int z0 = max(cz - s2, 0), z1 = min(cz + s2, sg.nz - 1);
-          const int y0 = max(cy - s2, 0), y1 = min(cy + s2, sg.ny - 1);
-          const int xlo = cx - s2, xhi = cx + s2;
-          for (int z = z0; z <= z1; ++z) {
-            const bool zface = (z == cz - s2) || (z == cz + s2);
-            const float zl = sg.oz + (float)z * sg.cell;
-            const float gz = fmaxf(fmaxf(zl - sz, sz - (zl + sg.cell)) - sg.margin, 0.0f);
-            for (int y = y0; y <= y1; ++y) {
-              const bool face = zface || (y == cy - s2) || (y == cy + s2);
-              const float yl = sg.oy + (float)y * sg.cell;
-              const float gy = fmaxf(fmaxf(yl - sy, sy - (yl + sg.cell)) - sg.margin, 0.0f);
-              const float lbr = mapped_bound(sqrtf(gz * gz + gy * gy), iv);
-              if (lbr * lbr * KS > bd) continue;
-              const uint32_t row = ((uint32_t)z * (uint32_t)sg.ny + (uint32_t)y) * (uint32_t)sg.nx;
-              if (face) {
-                const int xa = max(xlo, 0), xb = min(xhi, sg.nx - 1);
-                if (xa <= xb) scan_range_inv_ties(sg.pts, sg.cell_start[row + xa], sg.cell_start[row + xb + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
-              } else {
-                if (xlo >= 0 && xlo < sg.nx) scan_range_inv_ties(sg.pts, sg.cell_start[row + xlo], sg.cell_start[row + xlo + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
-                if (s2 > 0 && xhi >= 0 && xhi < sg.nx) scan_range_inv_ties(sg.pts, sg.cell_start[row + xhi], sg.cell_start[row + xhi + 1], T, p.x, p.y, p.z, bd, tt, cur, ncand);
-              }
-            }
-          }
-          float b2 = INFINITY;
-          if (cx - s2 > 0) b2 = fminf(b2, sx - (sg.ox + (float)(cx - s2) * sg.cell));
-          if (cx + s2 + 1 < sg.nx) b2 = fminf(b2, (sg.ox + (float)(cx + s2 + 1) * sg.cell) - sx);
-          if (cy - s2 > 0) b2 = fminf(b2, sy - (sg.oy + (float)(cy - s2) * sg.cell));
-          if (cy + s2 + 1 < sg.ny) b2 = fminf(b2, (sg.oy + (float)(cy + s2 + 1) * sg.cell) - sy);
-          if (cz - s2 > 0) b2 = fminf(b2, sz - (sg.oz + (float)(cz - s2) * sg.cell));
-          if (cz + s2 + 1 < sg.nz) b2 = fminf(b2, (sg.oz + (float)(cz + s2 + 1) * sg.cell) - sz);
-          if (b2 == INFINITY) break;
-          const float lb2 = mapped_bound(b2 - sg.margin, iv);
-          if (lb2 > 0.0f && bd < lb2 * lb2 * KS) break;
-        }
-        if (ncand >= 2u) {
-          if (tt.leaf_slot == nullptr) atomicAdd(tt.counters + 3, 1u);
-          else { atomicAdd(tt.counters + 1, 1u); if (cur != bpos) atomicAdd(tt.counters + 2, 1u); }
-        }
-        bpos = cur;
-      }
-    }
-    rev_pos[jd] = bpos;
-    rev_d2[jd] = __uint_as_float((uint32_t)(bkey >> 32));
+}
+
+template <bool FEAT6>
+__global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over the source, source space*/, const float4* __restrict__ dst_sorted, uint32_t nd,
+                                                        const IcpState* __restrict__ st, InvArgs iv, float max_sq, uint32_t* __restrict__ rev_pos,
+                                                        float* __restrict__ rev_d2, FeatSpec fs, TieDev tt) {
+  if (st->done) return;
+  float T[16];
+  inverse_for_state(st, T, iv);
+  for (uint32_t jd = blockIdx.x * blockDim.x + threadIdx.x; jd < nd; jd += gridDim.x * blockDim.x)
+    reverse_search_point<FEAT6>(sg, dst_sorted, jd, T, iv, max_sq, rev_pos, rev_d2, fs, tt);
+}
+
+// The reverse search WARM-STARTED from the previous iteration's reverse matches (the device-resident FIRST_TO_SECOND / BOTH loops, from
+// their second iteration on).  A target point p whose old match s_i still satisfies |p - T s_i| < half the distance from T s_i to its
+// nearest other transformed source point has s_i as its one nearest source point (any other T s_j is at least nnd - |p - T s_i| away):
+// no cell is looked at.  nnd in target space from a table over the SOURCE grid (k_self_nn: a lower bound on the squared distance to the
+// nearest other source point, 0 for a duplicate): |T s_i - T s_j| >= smin |s_i - s_j| - 2 eps_q for the computed images (eps_q =
+// IcpState::motion_eps: the rounding error of one computed T s).  In pinned arithmetic: m = smin sqrt(safe2) - 2 eps_q (rounded down),
+// settled iff m > 0 and 4 e (1 + 1e-5) < m^2 with e = the pinned d2(p, T s_i) -- the value the full search would return for that pair;
+// the strict inequality excludes ties.  Everything else (no old match, test failed) is LISTED in LDS and searched by the block's
+// lanes densely packed -- the full shell search above, so the result is the exact argmin either way.
+constexpr int RW_ROUNDS = 16;                  // rounds of 256 target points between two searches of the block's list
+constexpr int RW_CAP = RW_ROUNDS * 256;       // ... which therefore holds them all if need be
+__global__ __launch_bounds__(256) void k_reverse_warm(GridDev sg, const float4* __restrict__ dst_sorted, uint32_t nd, const IcpState* __restrict__ st, InvArgs iv, float max_sq,
+                                                      uint32_t* __restrict__ rev_pos, float* __restrict__ rev_d2, const float* __restrict__ src_safe2, TieDev tt) {
+  if (st->done) return;
+  float T[16];
+  inverse_for_state(st, T, iv);
+  const float eps2 = st->motion_eps * 2.0002f;
+  __shared__ uint32_t list[RW_CAP];
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0u;
+  __syncthreads();
+  const FeatSpec none{};
+  const uint32_t rounds = (nd + 255u) / 256u, last = nd - 1u;
+  auto flush = [&]() {
+    const uint32_t n = cnt;
+    for (uint32_t k = threadIdx.x; k < n; k += 256u) reverse_search_point<false>(sg, dst_sorted, list[k], T, iv, max_sq, rev_pos, rev_d2, none, tt);
+    __syncthreads();
+    if (threadIdx.x == 0) cnt = 0u;
+    __syncthreads();
+  };
+  uint32_t since = 0;
+  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+    if (since == (uint32_t)RW_ROUNDS) { __syncthreads(); flush(); since = 0; }
+    ++since;
+    const uint32_t jd = r * 256u + threadIdx.x;
+    const bool valid = jd < nd;
+    const uint32_t jc = min(jd, last);
+    const float4 p = dst_sorted[jc];
+    const uint32_t rp = rev_pos[jc];
+    const bool has = valid && rp != NONE_U32;
+    const uint32_t rc = has ? rp : 0u;
+    const float4 c = sg.pts[rc];
+    const float sf = src_safe2[rc];
+    float qx, qy, qz;
+    transform_point(T, c.x, c.y, c.z, qx, qy, qz);
+    const float dx = __fsub_rn(p.x, qx), dy = __fsub_rn(p.y, qy), dz = __fsub_rn(p.z, qz);
+    const float e = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    const float m = iv.smin * sqrtf(sf) * 0.99999f - eps2;
+    const bool settled = has && m > 0.0f && 4.0f * e * 1.00001f < m * m && e < max_sq;
+    if (settled) rev_d2[jd] = e;
+    else if (valid) list[atomicAdd(&cnt, 1u)] = jd;
   }
+  __syncthreads();
+  flush();
 }
 
 // candidate slots [0, nd): reverse matches (target point jd -> nearest transformed source point)
@@ -567,7 +635,7 @@ hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgr
 }
 
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
-                                 const FeatSpec* feat, const TieDev* rev_tie) {
+                                 const FeatSpec* feat, const TieDev* rev_tie, const float* warm_src_safe2) {
   if (g.n == 0) return;
   InvArgs iv{};
   iv.rigid_on_device = 1;
@@ -576,6 +644,11 @@ void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const I
   const double ext_s = std::max({std::fabs((double)sgrid.ox), std::fabs((double)sgrid.oy), std::fabs((double)sgrid.oz)}) + (double)std::max(sgrid.nx, std::max(sgrid.ny, sgrid.nz)) * sgrid.cell;
   iv.eps = (float)(8e-6 * (ext_t + ext_s) + 1e-4 * ext_s);   // rounding of p' and of T s, and |T p' - p| for a linear part up to 1e-4 off orthonormal
   FeatSpec none{};
+  if (warm_src_safe2 != nullptr && !(feat && feat->enabled)) {      // rev_pos holds the previous iteration's reverse matches
+    hipLaunchKernelGGL(k_reverse_warm, dim3(std::min<uint32_t>((g.n + 255u) / 256u, 4096u)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, warm_src_safe2,
+                       rev_tie ? *rev_tie : TieDev{});
+    return;
+  }
   if (feat && feat->enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, *feat, TieDev{});
   else hipLaunchKernelGGL(k_reverse_search<false>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, none, rev_tie ? *rev_tie : TieDev{});
 }

@@ -198,6 +198,8 @@ struct cilhip_ctx {
   PairSet pairs;
   GridDev src_grid{};             // grid over the source in SOURCE coordinates (built on the first FIRST_TO_SECOND / BOTH search of a source)
   bool has_src_grid = false;
+  float* d_src_safe2 = nullptr;   // [ns] k_self_nn's table over the SOURCE grid: the margin test of the warm-started reverse search (k_reverse_warm)
+  bool reverse_warm = true;       // option "reverse_warm_start": the device-resident FIRST_TO_SECOND / BOTH loops start every reverse search but the first from the previous matches
   uint32_t *d_rev_pos = nullptr, *d_src_inv = nullptr;   // list-free loops of those directions: reverse matches by target position; original -> sorted source position
   float* d_rev_d2 = nullptr;
   bool have_pairs = false;        // `pairs` holds the result of the last find_correspondences
@@ -250,6 +252,7 @@ double ctx_wait_us(const cilhip_ctx* c) { return c->wait_us; }
 // the stored correspondence set (matches or pair list) no longer describes anything a caller may read
 static void drop_src_grid(cilhip_ctx* c) {
   if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }
+  if (c->d_src_safe2) { (void)hipFree(c->d_src_safe2); c->d_src_safe2 = nullptr; }
   if (c->d_src_rgb_grid) { (void)hipFree(c->d_src_rgb_grid); c->d_src_rgb_grid = nullptr; }
 }
 static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->d2_stale = false; c->pending_matches = false; c->matches_origin = 0; }
@@ -456,6 +459,7 @@ const OptionRow g_options[] = {
   OPT(CILHIP_OPT_REFINED_OCCUPANCY_FACTOR, "refined_occupancy_factor", 3, 1, 64, "how much denser than that a grid that had to be refined (surface, clusters) may stay", c->refined_occupancy),
   OPT(CILHIP_OPT_KERNEL_TIMING, "kernel_timing", 0, 0, 1, "hipEvents around the search / accumulation kernels (cilhip_enable_kernel_timing)", c->kernel_timing),
   OPT(CILHIP_OPT_KERNEL_TIMING_STRIDE, "kernel_timing_stride", 1, 1, 4096, "with kernel timing on: iterations 0..2 and every stride-th one carry events", c->timing_stride),
+  OPT(CILHIP_OPT_REVERSE_WARM_START, "reverse_warm_start", 1, 0, 1, "device-resident FIRST_TO_SECOND / BOTH loops: reverse searches after the first start from the previous reverse matches (margin test over the source; A/B)", c->reverse_warm),
   OPT(CILHIP_OPT_AFFINE_DEVICE_LOOP, "affine_device_loop", 1, 0, 1, "affine classes: 1 = device-resident loop (one-pass moments, solve in the epilogue kernel), 0 = host-driven loop (three passes + host solve; A/B)", c->affine_device_loop),
 };
 #undef OPT
@@ -489,6 +493,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "warm_start")) { c->warm_start = (int)value; return CILHIP_OK; }
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "fused_epilogue")) { c->fused_epilogue = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "reverse_warm_start")) { c->reverse_warm = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "affine_device_loop")) { c->affine_device_loop = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "group_search")) {
     if (value != -1.0 && value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0 && value != 32.0 && value != 64.0)
@@ -1328,6 +1333,10 @@ static int ensure_reverse_buffers(cilhip_ctx* c) {
   if (!c->d_rev_pos) {
     CK(c, hipMalloc(&c->d_rev_pos, (c->grid.n ? c->grid.n : 1) * sizeof(uint32_t)));
     CK(c, hipMalloc(&c->d_rev_d2, (c->grid.n ? c->grid.n : 1) * sizeof(float)));
+  }
+  if (!c->d_src_safe2 && c->has_src_grid && c->reverse_warm) {      // (lives and dies with the source grid: drop_src_grid)
+    CK(c, hipMalloc(&c->d_src_safe2, (c->ns ? c->ns : 1) * sizeof(float)));
+    launch_self_nn(c->src_grid, c->d_src_safe2, c->stream);
   }
   if (!c->d_src_inv) {      // original source index -> position in the cube-sorted source (the forward matches are stored by that)
     CK(c, hipMalloc(&c->d_src_inv, (c->ns ? c->ns : 1) * sizeof(uint32_t)));
@@ -2320,29 +2329,60 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       if (rf.dst2) rf.src2 = c->d_src_rgb_grid;
       if (feat6(c) && (!rf.src || !rf.dst || (rf.dst2 && !rf.src2))) return fail(c, CILHIP_ERR_INVALID, "feature search: both clouds' feature vectors are needed");
       const int nb_f = iter_num_blocks(c->ns), nb_r = iter_num_blocks(c->grid.n);
-      if (nb_f + nb_r > c->partial_blocks) {
+      // BOTH: the forward half runs warm-started from its third iteration on (search + accumulation in k_warm, like the plain loop's
+      // steady state: exact whatever the source's distance, and these loops have no cheaper forward form to go back to)
+      const bool fwd_wcap = c->search_dir == 2 && warm_capable(c);
+      if (fwd_wcap) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
+      const int nb_w = fwd_wcap ? warm_num_blocks(c->ns) : 0;
+      const int nb_fmax = std::max(nb_f, nb_w);
+      if (nb_fmax + nb_r > c->partial_blocks) {
         if (c->d_partials) (void)hipFree(c->d_partials);
         c->d_partials = nullptr; c->partial_blocks = 0;
-        CK(c, hipMalloc(&c->d_partials, (size_t)(nb_f + nb_r) * SUMS_MAX * sizeof(double)));
-        c->partial_blocks = nb_f + nb_r;
-        a.partials = c->d_partials; a.tile_partials = c->d_partials;
+        CK(c, hipMalloc(&c->d_partials, (size_t)(nb_fmax + nb_r) * SUMS_MAX * sizeof(double)));
+        c->partial_blocks = nb_fmax + nb_r;
       }
       const bool both_union = c->search_dir == 2 && !c->reciprocal;
       const int rmode = c->search_dir == 1 ? 1 : (c->reciprocal ? 3 : 2);
+      // rows: the reverse matches' first, the forward half's (streaming pass or warm-started kernel) behind them
       IterArgs ar = a;
-      ar.partials = c->d_partials + (both_union ? (size_t)nb_f * SUMS_MAX : 0);
-      const int rows_total = both_union ? nb_f + nb_r : nb_r;
+      ar.partials = c->d_partials;
+      a.partials = c->d_partials + (size_t)nb_r * SUMS_MAX; a.tile_partials = a.partials;
       a.nn_d2 = nullptr;
+      c->rec_valid = false; c->lb_fresh = false;
+      warm_run_reset(c);
       for (size_t it = 0; it < p->max_iter; ++it) {
+        bool fwd_warm = false;
         for (size_t st = 0; st < opt_steps; ++st) {
           a.skip_if_inner_done = ar.skip_if_inner_done = (st > 0);
           if (st == 0) {
-            if (c->search_dir == 2) { const int src_rc = launch_search(c, a); if (src_rc) return src_rc; }
-            { const TieDev rt = tie_dev_rev(c); launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr, &rt); }
+            if (c->search_dir == 2) {
+              fwd_warm = fwd_wcap && it >= 2;
+              if (fwd_warm) {
+                IterArgs wa = a;
+                wa.warm_pos = c->d_nn_pos;
+                wa.safe2 = c->d_safe2;
+                wa.warm_far_sq = 0.25f * c->grid.cell * c->grid.cell;
+                set_warm_args(c, wa);
+                wa.nn_lb = c->d_nn_lb; wa.lb_valid = c->lb_fresh ? 1 : 0;
+                launch_warm(wa, im, c->rec_valid ? 2 : 1, nb_w, c->stream);
+                c->rec_valid = true; c->lb_fresh = false;
+              } else {
+                IterArgs sa2 = a;
+                if (fwd_wcap) { sa2.nn_lb = c->d_nn_lb; c->lb_fresh = true; }      // (the margin keys the first warm-started iteration starts from)
+                c->rec_valid = false;
+                const int src_rc = launch_search(c, sa2);
+                if (src_rc) return src_rc;
+              }
+            }
+            // (from the second iteration on d_rev_pos holds the previous reverse matches: the search starts from them)
+            const float* warm_tab = (it >= 1 && c->reverse_warm && !feat6(c)) ? c->d_src_safe2 : nullptr;
+            { const TieDev rt = tie_dev_rev(c); launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr, &rt, warm_tab); }
           }
-          if (both_union) launch_iter(a, im, false, false, nb_f, c->stream);
+          const bool fwd_in_kernel = fwd_warm && st == 0;      // (the warm-started kernel accumulated the first step's terms itself)
+          if (both_union && !fwd_in_kernel) launch_iter(a, im, false, false, nb_f, c->stream);
           launch_acc_reverse(ar, im, c->src_grid.pts, c->d_rev_pos, c->grid.n, rmode, c->d_nn_pos, c->d_src_inv, nb_r, c->stream);
           sa.gn_last_step = (st + 1 == opt_steps);
+          const int rows_total = nb_r + (both_union ? (fwd_in_kernel ? nb_w : nb_f) : 0);
           const int rows = launch_reduce_stage1(c->d_partials, rows_total, c->d_stage, c->stream);
           sa.partials = rows ? c->d_stage : c->d_partials;
           sa.nblocks = rows ? rows : rows_total;

@@ -452,8 +452,10 @@ void free_pairs(PairSet& p);
 // rev_tie (option "tie_rule" for these matches): the reference searches a kd-tree over the TRANSFORMED SOURCE, rebuilt every iteration
 // (correspondence_search_kd_tree.hpp:185-222): leaf_slot = that tree's order tables by position in the source grid, valid for the state's
 // transform only (built per search: c_api.hip build_rev_tie_tables); null = count the tied target points (counters[3]) and keep the lowest source index
+// warm_src_safe2 (plain point features only): rev_pos holds the PREVIOUS iteration's reverse matches, the table is k_self_nn's over the source grid -- k_reverse_warm
+// settles every target point whose old match passes the margin test without a search and searches the rest (the same exact result)
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
-                                 const FeatSpec* feat = nullptr, const TieDev* rev_tie = nullptr);
+                                 const FeatSpec* feat = nullptr, const TieDev* rev_tie = nullptr, const float* warm_src_safe2 = nullptr);
 hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& src_grid /*over the source, SOURCE coordinates*/, const float* d_src_xyz, const float* d_src_nrm,
                       const float4* src_sorted, uint32_t ns, const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq,
                       int direction, bool reciprocal, double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2,

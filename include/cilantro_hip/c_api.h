@@ -674,6 +674,12 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *   cilhip_get_correspondences (cilhip_get_nn does not apply); the post-filters follow the reference's branches for
  *   those directions (one-to-one: per source point for FIRST_TO_SECOND, a no-op for BOTH, correspondence.hpp:72-98);
  *   cilhip_icp_run accumulates over the pair list.  Not available in sharded runs.
+ *   "reverse_warm_start" (default 1): the device-resident loops of those directions (rigid start transform, no post-filters, plain
+ *                        point features) start every reverse search but the first from the previous iteration's reverse matches: a
+ *                        target point whose old match T s_i is nearer than half the distance from T s_i to its nearest other
+ *                        transformed source point (a table over the source, built once) keeps it without looking at a cell; the rest
+ *                        is searched as before -- the exact argmin either way (bidir.hip k_reverse_warm).  0 = every search from
+ *                        scratch, for A/B runs.
  * Feature adaptor of the engine (correspondence_search/common_transformable_feature_adaptors.hpp):
  *   "feature_normal_weight" (default 0 = PointFeaturesAdaptor3f, :8-57): w > 0 = PointNormalFeaturesAdaptor3f (:60-161)
  *                        on both clouds -- features (p, w n), transformed as (T p, L (w n)), matched by the 6-D squared
@@ -729,7 +735,7 @@ typedef enum cilhip_option {
   CILHIP_OPT_POINT_WEIGHT_SIGMA, CILHIP_OPT_PLANE_WEIGHT_SIGMA, CILHIP_OPT_TILE_ACCUMULATION, CILHIP_OPT_SEARCH_DIRECTION,
   CILHIP_OPT_FEATURE_NORMAL_WEIGHT, CILHIP_OPT_FEATURE_KIND, CILHIP_OPT_FEATURE_COLOR_WEIGHT, CILHIP_OPT_SYMMETRIC_METRIC,
   CILHIP_OPT_TRANSFORM_MODE, CILHIP_OPT_REQUIRE_RECIPROCALITY, CILHIP_OPT_CELL_OCCUPANCY, CILHIP_OPT_REFINED_OCCUPANCY_FACTOR,
-  CILHIP_OPT_KERNEL_TIMING, CILHIP_OPT_KERNEL_TIMING_STRIDE, CILHIP_OPT_AFFINE_DEVICE_LOOP,
+  CILHIP_OPT_KERNEL_TIMING, CILHIP_OPT_KERNEL_TIMING_STRIDE, CILHIP_OPT_REVERSE_WARM_START, CILHIP_OPT_AFFINE_DEVICE_LOOP,
   CILHIP_OPT_COUNT
 } cilhip_option;
 typedef struct cilhip_option_info_t {

@@ -885,6 +885,48 @@ def test_search_directions_vs_oracle(Context, orc, hip_lib):
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (direction, recip, np.linalg.norm(Tg - ro["T"]))
 
 
+def test_reverse_searches_started_from_the_previous_matches_change_nothing(Context, orc, hip_lib):
+    """FIRST_TO_SECOND / BOTH loops on the device (correspondence_search_kd_tree.hpp:185-222): from the second iteration on the reverse
+    search starts from the previous reverse matches (bidir.hip k_reverse_warm: margin test over the source, listed rest searched in
+    full).  Exact either way, and the accumulation streams by target position: with the option both ways the loop state after every run
+    is BITWISE the same -- transform, iteration count, correspondence count, the pair list left behind.  Clouds: the recipe, a far
+    start, a source with doubled points (margin 0: never settled without a look), a sparse source."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D, SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f
+
+    rng = np.random.default_rng(3)
+    cases = []
+    d = syn.make_pair(200_000, 200_000, with_normals=True); cases.append(("recipe", d["dst"], d["dst_n"], d["src"], float(d["max_sq_dist"])))
+    d = syn.make_pair(120_000, 90_000, with_normals=True, perturb=0.8); cases.append(("far", d["dst"], d["dst_n"], d["src"], float((3 * d["h"]) ** 2)))
+    d = syn.make_pair(100_000, 100_000, with_normals=True)
+    pick = rng.choice(100_000, 5_000, replace=False)
+    cases.append(("doubled", d["dst"], d["dst_n"], np.ascontiguousarray(np.concatenate([d["src"], d["src"][pick]])), float(d["max_sq_dist"])))
+    d = syn.make_pair(150_000, 20_000, with_normals=True, src_stride=7); cases.append(("sparse", d["dst"], d["dst_n"], d["src"], float(d["max_sq_dist"])))
+    for name, dst, dst_n, src, r2 in cases:
+        for direction, recip, metric in ((D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 1), (D.BOTH, True, 0), (D.FIRST_TO_SECOND, False, 0)):
+            got = []
+            for warm in (1, 0):
+                icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src) if metric == 1 else SimplePointToPointMetricRigidICP3f(dst, src)
+                icp._ctx.set_option("reverse_warm_start", warm)
+                icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
+                icp.setMaxNumberOfIterations(10).setConvergenceTolerance(0.0)
+                T = icp.estimate().getTransform()
+                g1, g2, gv = icp._ctx.get_correspondences()
+                got.append((T.copy(), icp.getNumberOfPerformedIterations(), icp.last_ncorr_, g1.copy(), g2.copy(), gv.copy()))
+            (Tw, iw, nw, a1, a2, av), (Tc, ic, nc, b1, b2, bv) = got
+            assert iw == ic and nw == nc, (name, direction, recip, metric)
+            assert np.array_equal(Tw.view(np.uint32), Tc.view(np.uint32)), (name, direction, recip, metric, np.abs(Tw - Tc).max())
+            assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(av.view(np.uint32), bv.view(np.uint32)), (name, direction, recip)
+        # ... and the loop is still the reference's: one case per cloud against the oracle
+        icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
+        icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(D.FIRST_TO_SECOND)
+        icp.setMaxNumberOfIterations(10).setConvergenceTolerance(0.0)
+        Tg = icp.estimate().getTransform()
+        p = orc.make_params(metric=1, max_sq_dist=r2, max_iter=10, conv_tol=0.0, direction=1, reciprocal=False)
+        ro = orc.icp_run(dst, dst_n, src, p)
+        assert icp.last_ncorr_ == ro["last_ncorr"], name
+        assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (name, np.linalg.norm(Tg - ro["T"]))
+
+
 def test_estimate_over_a_pair_list_and_with_a_callback(Context, orc, hip_lib):
     """cilhip_estimate_combined over the PAIR LIST of FIRST_TO_SECOND / BOTH searches (one correspondence per pair: a source point may
     occur several times), against the oracle's estimator over the same list; and with a pair-weight callback, which then sees the
