@@ -440,17 +440,17 @@ void free_pairs(PairSet& p) {
   p.d2 = p.d2b = nullptr; p.src_view = p.nrm_view = nullptr;
   p.cap = 0; p.count = 0;
   for (void*& w : p.ws) { if (w) (void)hipFree(w); w = nullptr; }
-  p.ws_cand = 0; p.ws_tmp_bytes = 0;
+  p.ws_cand = 0; p.ws_tmp_bytes = 0; p.ws_nd = 0; p.ws_ns = 0;
 }
 
 static hipError_t ensure_pairs(PairSet& p, size_t cap, bool with_normals) {
   if (cap <= p.cap && (!with_normals || p.nrm_view)) return hipSuccess;
   void* keep_ws[PairSet::WS_COUNT];
   for (int k = 0; k < PairSet::WS_COUNT; ++k) { keep_ws[k] = p.ws[k]; p.ws[k] = nullptr; }   // (free_pairs would drop the workspace too)
-  const size_t wc = p.ws_cand, wt = p.ws_tmp_bytes;
+  const size_t wc = p.ws_cand, wt = p.ws_tmp_bytes, wnd = p.ws_nd, wns = p.ws_ns;
   free_pairs(p);
   for (int k = 0; k < PairSet::WS_COUNT; ++k) p.ws[k] = keep_ws[k];
-  p.ws_cand = wc; p.ws_tmp_bytes = wt;
+  p.ws_cand = wc; p.ws_tmp_bytes = wt; p.ws_nd = wnd; p.ws_ns = wns;
   const size_t c = cap ? cap : 1;
   uint32_t** u[] = {&p.first, &p.second, &p.posd, &p.poss, &p.first2, &p.second2, &p.posd2, &p.poss2};
   for (auto q : u) HIP_TRY(hipMalloc(q, c * sizeof(uint32_t)));
@@ -467,17 +467,28 @@ static hipError_t ensure_pairs(PairSet& p, size_t cap, bool with_normals) {
 static hipError_t ensure_ws(PairSet& p, size_t ncand, size_t nd, size_t ns, size_t tmp_bytes) {
   enum { REV_POS, REV_D2, KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, WINNER, SEL_KEYS, SEL_STATE, TMP };
   if (ncand > p.ws_cand) {
-    const int cand_slots[] = {KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, SEL_KEYS, REV_POS, REV_D2, WINNER};
+    const int cand_slots[] = {KEYS_IN, KEYS_OUT, SLOTS_IN, SLOTS_OUT, C_POSD, C_POSS, C_D2, FLAGS, OFFS, SEL_KEYS};
     for (int k : cand_slots) { if (p.ws[k]) (void)hipFree(p.ws[k]); p.ws[k] = nullptr; }
     const size_t c = ncand;
     HIP_TRY(hipMalloc(&p.ws[KEYS_IN], c * 8)); HIP_TRY(hipMalloc(&p.ws[KEYS_OUT], c * 8)); HIP_TRY(hipMalloc(&p.ws[SEL_KEYS], c * 8));
     HIP_TRY(hipMalloc(&p.ws[SLOTS_IN], c * 4)); HIP_TRY(hipMalloc(&p.ws[SLOTS_OUT], c * 4));
     HIP_TRY(hipMalloc(&p.ws[C_POSD], c * 4)); HIP_TRY(hipMalloc(&p.ws[C_POSS], c * 4)); HIP_TRY(hipMalloc(&p.ws[C_D2], c * 4));
     HIP_TRY(hipMalloc(&p.ws[FLAGS], c * 4)); HIP_TRY(hipMalloc(&p.ws[OFFS], c * 4));
-    HIP_TRY(hipMalloc(&p.ws[REV_POS], (nd ? nd : 1) * 4)); HIP_TRY(hipMalloc(&p.ws[REV_D2], (nd ? nd : 1) * 4));
-    HIP_TRY(hipMalloc(&p.ws[WINNER], (ns ? ns : 1) * 8));
     if (!p.ws[SEL_STATE]) HIP_TRY(hipMalloc(&p.ws[SEL_STATE], filter_state_bytes()));
     p.ws_cand = ncand;
+  }
+  // (sized by the clouds, not by the candidates: a FIRST_TO_SECOND search -- nd candidates -- after a BOTH search of a smaller target
+  //  -- nd' + ns' >= nd candidates -- keeps the candidate arrays and still needs longer per-target arrays)
+  if (nd > p.ws_nd || !p.ws[REV_POS]) {
+    for (int k : {REV_POS, REV_D2}) { if (p.ws[k]) (void)hipFree(p.ws[k]); p.ws[k] = nullptr; }
+    HIP_TRY(hipMalloc(&p.ws[REV_POS], (nd ? nd : 1) * 4)); HIP_TRY(hipMalloc(&p.ws[REV_D2], (nd ? nd : 1) * 4));
+    p.ws_nd = nd;
+  }
+  if (ns > p.ws_ns || !p.ws[WINNER]) {
+    if (p.ws[WINNER]) (void)hipFree(p.ws[WINNER]);
+    p.ws[WINNER] = nullptr;
+    HIP_TRY(hipMalloc(&p.ws[WINNER], (ns ? ns : 1) * 8));
+    p.ws_ns = ns;
   }
   if (tmp_bytes > p.ws_tmp_bytes) {
     if (p.ws[TMP]) (void)hipFree(p.ws[TMP]);

@@ -443,7 +443,7 @@ struct PairSet {
   // workspace of find_pairs (reverse matches, sort keys / slots, flags, scan temporaries ...): allocated once per size
   static constexpr int WS_COUNT = 15;
   void* ws[WS_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t ws_cand = 0, ws_tmp_bytes = 0;
+  size_t ws_cand = 0, ws_tmp_bytes = 0, ws_nd = 0, ws_ns = 0;      // what the workspace was sized for: candidates, scan scratch, target / source points
 };
 void free_pairs(PairSet& p);
 // the reverse search of those directions alone (every target point against the source, through the inverse of the state's

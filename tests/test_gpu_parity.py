@@ -927,6 +927,35 @@ def test_reverse_searches_started_from_the_previous_matches_change_nothing(Conte
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (name, np.linalg.norm(Tg - ro["T"]))
 
 
+def test_pair_search_workspace_follows_the_clouds(Context, orc, hip_lib):
+    """One context, a BOTH search of a small pair and then a FIRST_TO_SECOND search against a LARGER target with fewer candidates than the
+    BOTH search had (n_target' <= n_target + n_source): the search's per-target arrays are sized by the target, not by the candidate
+    count (tools/api_fuzz.py seed 1 found them too short: a memory fault).  Lists equal a fresh context's."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D, CorrespondenceSearchHIP
+
+    small = syn.make_pair(30_000, 30_000, with_normals=True)
+    big = syn.make_pair(50_000, 20_000, with_normals=True, src_stride=2)
+    T = np.eye(4, dtype=np.float32)
+    live = Context()
+    live.set_target(small["dst"], small["dst_n"]); live.set_source(small["src"])
+    eng = CorrespondenceSearchHIP(ctx=live).setMaxDistance(float(small["max_sq_dist"])).setSearchDirection(D.BOTH)
+    eng.findCorrespondences(T)
+    assert len(eng.getCorrespondences()[0]) > 30_000
+    live.set_target(big["dst"], big["dst_n"]); live.set_source(big["src"])
+    eng.setMaxDistance(float(big["max_sq_dist"])).setSearchDirection(D.FIRST_TO_SECOND).setOneToOne(True)
+    eng.findCorrespondences(T)
+    a = eng.getCorrespondences()
+    fresh = Context()
+    fresh.set_target(big["dst"], big["dst_n"]); fresh.set_source(big["src"])
+    eng2 = CorrespondenceSearchHIP(ctx=fresh).setMaxDistance(float(big["max_sq_dist"])).setSearchDirection(D.FIRST_TO_SECOND).setOneToOne(True)
+    eng2.findCorrespondences(T)
+    b = eng2.getCorrespondences()
+    assert len(a[0]) == len(b[0]) and all(np.array_equal(x, y) for x, y in zip(a, b))
+    q = orc.transform_points(T, big["src"])
+    o1, o2, ov = orc.find_correspondences_dir(big["dst"], q, float(big["max_sq_dist"]), 1, False, 1.0, True)
+    assert np.array_equal(a[0], o1) and np.array_equal(a[1], o2) and np.array_equal(a[2], ov)
+
+
 def test_estimate_over_a_pair_list_and_with_a_callback(Context, orc, hip_lib):
     """cilhip_estimate_combined over the PAIR LIST of FIRST_TO_SECOND / BOTH searches (one correspondence per pair: a source point may
     occur several times), against the oracle's estimator over the same list; and with a pair-weight callback, which then sees the

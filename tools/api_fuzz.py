@@ -22,7 +22,7 @@ rng = np.random.default_rng(seed)
 
 OPTS = {"search_direction": (0, 1, 2), "require_reciprocality": (0, 1), "inlier_fraction": (1.0, 0.7), "one_to_one": (0, 1), "tie_rule": (2, 1, 0),
         "tiled": (1, 0, 2), "warm_start": (1, 0, 2), "tile_accumulation": (1, 0, 2), "point_weight_evaluator": (0, 1, 2), "plane_weight_evaluator": (0, 2),
-        "group_search": (-1, 0, 8), "symmetric_metric": (1, 0)}
+        "group_search": (-1, 0, 8), "symmetric_metric": (1, 0), "transform_mode": (0, 1), "affine_device_loop": (1, 0), "reverse_warm_start": (1, 0)}
 DEFAULTS = {k: v[0] for k, v in OPTS.items()}
 
 
@@ -75,7 +75,7 @@ def plan(steps):
     for _ in range(steps):
         op = str(rng.choice(["target", "source", "option", "search", "estimate", "loop", "loop"], p=[0.08, 0.12, 0.25, 0.2, 0.1, 0.15, 0.1]))
         if op == "target":
-            ops.append((op, int(rng.integers(500, 150000)), float(rng.uniform(0.1, 0.9)), bool(rng.random() < 0.3), int(rng.integers(1 << 30))))
+            ops.append((op, int(rng.integers(500, 150000)) if rng.random() < 0.7 else int(rng.integers(150000, 400000)), float(rng.uniform(0.1, 0.9)), bool(rng.random() < 0.3), int(rng.integers(1 << 30))))
         elif op == "source":
             ops.append((op, float(rng.random()), int(rng.integers(1 << 30))))
         elif op == "option":
