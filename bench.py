@@ -107,7 +107,7 @@ def stratified_form_timing(ft, forms, timed):
     return {f: out.get(f, ft.get(f, (0.0, 0))) for f in set(ft) | set(out)}
 
 
-def source_hash(files=("kernels.hip", "warm.hip", "epilogue.hip", "search_device.hpp", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp")):
+def source_hash(files=("kernels.hip", "warm.hip", "epilogue.hip", "search_device.hpp", "affine_device.hpp", "internal.hpp", "c_api.hip", "grid_build.hip", "solve.hpp")):
     """sha256 over the kernel sources: profile-derived numbers (roofline.traffic) are only quoted for the build they were measured on."""
     h = hashlib.sha256()
     for f in files:
@@ -453,7 +453,7 @@ def bench_icp(a, torch, rank, world, local_rank, emit=True):
             "last_ncorr": nc, "T_err_vs_truth_frobenius": err_true,
             "iterations_one_pass": one_pass_iters, "iterations_two_pass": two_pass_iters, "iterations_warm_started": ctx.last_warm_iterations(),
             # option "tie_rule" (default 2): exactly equidistant nearest points take the reference's kd-tree order, resolved on the device; the order
-            # tables are built on the host's cores the first time a search of this target meets a tie (here: in the warm-up run, if at all)
+            # tables are built on the device the first time a search of this target meets a tie (here: in the warm-up run, if at all)
             "tie_order": dict(ctx.tie_order_info(), tied_queries_resolved_in_timed_run=ctx.tie_rule_stats()[0], not_the_lowest_index=ctx.tie_rule_stats()[1]),
             "roofline": roof, "roofline_cold": out_cold if dom is not None else None,
         }
@@ -534,6 +534,40 @@ def bench_icp(a, torch, rank, world, local_rank, emit=True):
                              "achieved": bytes_i / (ms_i * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_i / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         except Exception as e:
             extras["independent_source"] = {"error": repr(e)}
+        # The other ICP instance families / engine directions on the SAME clouds (driver-timed companions of `ms_per_step`): the affine classes
+        # (device-resident loop: one-pass moments on the matrix cores, 12-unknown solve in the epilogue kernel) and the FIRST_TO_SECOND / BOTH
+        # search directions (reverse searches warm-started from the previous reverse matches), a.steps iterations each, tolerance 0.
+        try:
+            import copy
+            variants = {}
+            for vname, vopts, vmetric in (("affine_combined", {"transform_mode": 1}, capi.METRIC_COMBINED),
+                                          ("affine_point_to_point", {"transform_mode": 1}, capi.METRIC_POINT_TO_POINT),
+                                          ("first_to_second", {"search_direction": 1}, capi.METRIC_COMBINED),
+                                          ("both", {"search_direction": 2}, capi.METRIC_COMBINED),
+                                          ("both_reciprocal", {"search_direction": 2, "require_reciprocality": 1}, capi.METRIC_COMBINED)):
+                if not with_normals and vmetric == capi.METRIC_COMBINED:
+                    continue
+                cv = Context(local_rank, stream)
+                for k, v in vopts.items():
+                    cv.set_option(k, v)
+                cv.set_target(dst_t, nrm_t); cv.set_source(src_t)
+                pv = copy.copy(p)
+                pv.metric = vmetric
+                pv.w_p2p, pv.w_p2pl = (w_p2p, w_p2pl) if with_normals else (0.0, 1.0)
+                pv.conv_tol = 0.0; pv.max_iter = a.steps
+                cv.icp_run(pv, T0)                   # (sort, grids / tables of the variant, warm-up)
+                cv.synchronize(); t0 = time.perf_counter()
+                rv = cv.icp_run(pv, T0)
+                cv.synchronize(); dtv = time.perf_counter() - t0
+                lv = cv.last_timing()[0]
+                Tv = np.array(rv.T[:], dtype=np.float64).reshape(4, 4).T
+                variants[vname] = {"ms_per_step": dtv * 1e3 / a.steps, "loop_ms_per_step_hip_events": lv / a.steps, "iterations": int(rv.iterations),
+                                   "last_ncorr": int(rv.last_ncorr), "iterations_warm_started": cv.last_warm_iterations(),
+                                   "T_err_vs_truth_frobenius": float(np.linalg.norm(Tv - d["T_true"]))}
+                cv.close()
+            extras["variants"] = variants
+        except Exception as e:
+            extras["variants"] = {"error": repr(e)}
         # the sharded loop driven from C (cilhip_multi_icp_run: what a C / C++ caller with several devices uses) on ONE shard: the cost of
         # the protocol itself -- three calls per iteration instead of one enqueue-ahead loop -- against `ms_per_step` above
         try:

@@ -2350,6 +2350,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       a.nn_d2 = nullptr;
       c->rec_valid = false; c->lb_fresh = false;
       warm_run_reset(c);
+      c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
       for (size_t it = 0; it < p->max_iter; ++it) {
         bool fwd_warm = false;
         for (size_t st = 0; st < opt_steps; ++st) {
@@ -2366,6 +2367,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
                 wa.nn_lb = c->d_nn_lb; wa.lb_valid = c->lb_fresh ? 1 : 0;
                 launch_warm(wa, im, c->rec_valid ? 2 : 1, nb_w, c->stream);
                 c->rec_valid = true; c->lb_fresh = false;
+                ++c->last_warm_iters;
               } else {
                 IterArgs sa2 = a;
                 if (fwd_wcap) { sa2.nn_lb = c->d_nn_lb; c->lb_fresh = true; }      // (the margin keys the first warm-started iteration starts from)
