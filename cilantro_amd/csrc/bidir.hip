@@ -15,12 +15,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <utility>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "internal.hpp"
+#include "rank_update.hpp"
 
 namespace cilhip {
 
@@ -286,36 +288,80 @@ __global__ __launch_bounds__(256) void k_reverse_search(GridDev sg /*grid over t
 // settled iff m > 0 and 4 e (1 + 1e-5) < m^2 with e = the pinned d2(p, T s_i) -- the value the full search would return for that pair;
 // the strict inequality excludes ties.  Everything else (no old match, test failed) is LISTED in LDS and searched by the block's
 // lanes densely packed -- the full shell search above, so the result is the exact argmin either way.
-constexpr int RW_ROUNDS = 16;                  // rounds of 256 target points between two searches of the block's list
-constexpr int RW_CAP = RW_ROUNDS * 256;       // ... which therefore holds them all if need be
+// Wave-centric: every wave lists its own unsettled points (ballot order: the same list in every run) and searches its list after
+// RW_ROUNDS rounds -- no block-wide barrier in the loop.  ACC != IM_NONE: the first Gauss-Newton step's sums over the reverse matches
+// are accumulated HERE, on the matrix cores (rank_update.hpp: the terms of k_warm / the tiles), for the settled points as they stream by
+// and for the listed ones after their search -- one pass over the target instead of search + k_acc_reverse; mode (k_acc_reverse's): 1 = all
+// reverse matches, 2 = those that are not reciprocal duplicates of a forward match, 3 = only those; one row of SUMS_MAX sums per block.
+constexpr int RW_ROUNDS = 16;                  // rounds between two searches of a wave's list
+constexpr int RW_WCAP = RW_ROUNDS * 64;        // ... which therefore holds all of the wave's points if need be
+constexpr int RW_WAVES = 4;
+struct RevAcc {
+  float dst_mean[3];
+  const float4* dst_nrm;        // target normals by sorted position (plane terms)
+  int mode;
+  const uint32_t* fwd_pos;      // forward matches by sorted source position (modes 2 / 3)
+  const uint32_t* src_inv;      // original source index -> sorted source position
+  double* partials;             // [gridDim.x * SUMS_MAX]
+};
+template <int ACC>
 __global__ __launch_bounds__(256) void k_reverse_warm(GridDev sg, const float4* __restrict__ dst_sorted, uint32_t nd, const IcpState* __restrict__ st, InvArgs iv, float max_sq,
-                                                      uint32_t* __restrict__ rev_pos, float* __restrict__ rev_d2, const float* __restrict__ src_safe2, TieDev tt) {
+                                                      uint32_t* __restrict__ rev_pos, float* __restrict__ rev_d2, const float* __restrict__ src_safe2, TieDev tt, RevAcc ra) {
   if (st->done) return;
   float T[16];
   inverse_for_state(st, T, iv);
   const float eps2 = st->motion_eps * 2.0002f;
-  __shared__ uint32_t list[RW_CAP];
-  __shared__ uint32_t cnt;
-  if (threadIdx.x == 0) cnt = 0u;
-  __syncthreads();
+  const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};
+  __shared__ uint32_t list[RW_WAVES * RW_WCAP];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[ACC != IM_NONE ? RW_WAVES * FUSED_WAVE_BYTES : 16];
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  uint32_t* const wl = list + wave * RW_WCAP;
+  float* const zb = reinterpret_cast<float*>(raw) + (ACC != IM_NONE ? wave * (FUSED_WAVE_BYTES / 4) : 0);
+  WaveRank<ACC == IM_NONE ? IM_KABSCH : ACC> rank;
+  constexpr bool NRM = FusedZ<ACC>::needs_normal;
   const FeatSpec none{};
   const uint32_t rounds = (nd + 255u) / 256u, last = nd - 1u;
+  // a correspondence (target position jd, source-grid record c) counts under `mode`
+  // (evaluated by every lane, from a valid record: no divergent branch around the two dependent loads)
+  auto counts = [&](uint32_t jd, const float4 c) -> bool {
+    if (ra.mode < 2) return true;      // (uniform)
+    const bool dup = ra.fwd_pos[ra.src_inv[__float_as_uint(c.w)]] == jd;
+    return dup == (ra.mode == 3);
+  };
+  uint32_t wcnt = 0;      // (wave-uniform)
   auto flush = [&]() {
-    const uint32_t n = cnt;
-    for (uint32_t k = threadIdx.x; k < n; k += 256u) reverse_search_point<false>(sg, dst_sorted, list[k], T, iv, max_sq, rev_pos, rev_d2, none, tt);
-    __syncthreads();
-    if (threadIdx.x == 0) cnt = 0u;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k0 = 0; k0 < wcnt; k0 += 64u) {
+      const bool active = k0 + (uint32_t)lane < wcnt;
+      const uint32_t jd = wl[min(k0 + (uint32_t)lane, (uint32_t)(RW_WCAP - 1))];
+      if (active) reverse_search_point<false>(sg, dst_sorted, jd, T, iv, max_sq, rev_pos, rev_d2, none, tt);
+      if (ACC != IM_NONE) {
+        const uint32_t rp = active ? rev_pos[jd] : NONE_U32;      // (the lane's own store)
+        const bool has0 = rp != NONE_U32;
+        const float4 c = sg.pts[has0 ? rp : 0u];
+        const float4 p = dst_sorted[active ? jd : 0u];
+        float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (NRM) nv = ra.dst_nrm[active ? jd : 0u];
+        float qx, qy, qz;
+        transform_point(T, c.x, c.y, c.z, qx, qy, qz);
+        const bool cnt = counts(jd, c);
+        rank.update(zb, lane, has0 && cnt, qx, qy, qz, p, nv, ra.dst_mean, smt);
+      }
+    }
+    wcnt = 0;
+    __builtin_amdgcn_wave_barrier();
   };
   uint32_t since = 0;
   for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
-    if (since == (uint32_t)RW_ROUNDS) { __syncthreads(); flush(); since = 0; }
+    if (since == (uint32_t)RW_ROUNDS) { flush(); since = 0; }
     ++since;
     const uint32_t jd = r * 256u + threadIdx.x;
     const bool valid = jd < nd;
     const uint32_t jc = min(jd, last);
     const float4 p = dst_sorted[jc];
     const uint32_t rp = rev_pos[jc];
+    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC != IM_NONE && NRM) nv = ra.dst_nrm[jc];
     const bool has = valid && rp != NONE_U32;
     const uint32_t rc = has ? rp : 0u;
     const float4 c = sg.pts[rc];
@@ -327,10 +373,14 @@ __global__ __launch_bounds__(256) void k_reverse_warm(GridDev sg, const float4* 
     const float m = iv.smin * sqrtf(sf) * 0.99999f - eps2;
     const bool settled = has && m > 0.0f && 4.0f * e * 1.00001f < m * m && e < max_sq;
     if (settled) rev_d2[jd] = e;
-    else if (valid) list[atomicAdd(&cnt, 1u)] = jd;
+    const bool todo = valid && !settled;
+    const unsigned long long um = __ballot(todo);
+    if (todo) wl[wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = jd;
+    wcnt += (uint32_t)__popcll(um);
+    if (ACC != IM_NONE) { const bool cnt = counts(jd, c); rank.update(zb, lane, settled && cnt, qx, qy, qz, p, nv, ra.dst_mean, smt); }
   }
-  __syncthreads();
   flush();
+  if (ACC != IM_NONE) rank.template write_row<RW_WAVES>(raw, wave, lane, ra.partials + (size_t)blockIdx.x * SUMS_MAX);
 }
 
 // candidate slots [0, nd): reverse matches (target point jd -> nearest transformed source point)
@@ -645,8 +695,14 @@ hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgr
   return e;
 }
 
+int reverse_warm_blocks(uint32_t nd) {      // at least eight rounds of 256 target points per block
+  long nb = ((long)nd + 8 * 256 - 1) / (8 * 256);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
-                                 const FeatSpec* feat, const TieDev* rev_tie, const float* warm_src_safe2) {
+                                 const FeatSpec* feat, const TieDev* rev_tie, const float* warm_src_safe2, const RevFused* fused) {
   if (g.n == 0) return;
   InvArgs iv{};
   iv.rigid_on_device = 1;
@@ -656,8 +712,21 @@ void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const I
   iv.eps = (float)(8e-6 * (ext_t + ext_s) + 1e-4 * ext_s);   // rounding of p' and of T s, and |T p' - p| for a linear part up to 1e-4 off orthonormal
   FeatSpec none{};
   if (warm_src_safe2 != nullptr && !(feat && feat->enabled)) {      // rev_pos holds the previous iteration's reverse matches
-    hipLaunchKernelGGL(k_reverse_warm, dim3(std::min<uint32_t>((g.n + 255u) / 256u, 4096u)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, warm_src_safe2,
-                       rev_tie ? *rev_tie : TieDev{});
+    const dim3 gb(reverse_warm_blocks(g.n)), tb(256);
+    const TieDev tt = rev_tie ? *rev_tie : TieDev{};
+    RevAcc ra{};
+    int acc = IM_NONE;
+    if (fused) {
+      acc = fused->metric; ra.mode = fused->mode; ra.fwd_pos = fused->fwd_pos; ra.src_inv = fused->src_inv; ra.partials = fused->partials; ra.dst_nrm = g.nrm;
+      for (int k = 0; k < 3; ++k) ra.dst_mean[k] = fused->dst_mean[k];
+    }
+    switch (acc) {
+      case IM_KABSCH: hipLaunchKernelGGL((k_reverse_warm<IM_KABSCH>), gb, tb, 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, warm_src_safe2, tt, ra); break;
+      case IM_PLANE: hipLaunchKernelGGL((k_reverse_warm<IM_PLANE>), gb, tb, 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, warm_src_safe2, tt, ra); break;
+      case IM_POINT: hipLaunchKernelGGL((k_reverse_warm<IM_POINT>), gb, tb, 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, warm_src_safe2, tt, ra); break;
+      case IM_BOTH: hipLaunchKernelGGL((k_reverse_warm<IM_BOTH>), gb, tb, 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, warm_src_safe2, tt, ra); break;
+      default: hipLaunchKernelGGL((k_reverse_warm<IM_NONE>), gb, tb, 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, warm_src_safe2, tt, ra); break;
+    }
     return;
   }
   if (feat && feat->enabled) hipLaunchKernelGGL(k_reverse_search<true>, dim3(iter_num_blocks(g.n)), dim3(256), 0, s, sgrid, g.pts, g.n, state, iv, max_sq, rev_pos, rev_d2, *feat, TieDev{});

@@ -2335,26 +2335,32 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       if (fwd_wcap) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
       const int nb_w = fwd_wcap ? warm_num_blocks(c->ns) : 0;
       const int nb_fmax = std::max(nb_f, nb_w);
-      if (nb_fmax + nb_r > c->partial_blocks) {
+      // the warm-started reverse search accumulates the first step's sums itself (one pass over the target; per-pair weights keep the separate pass)
+      const bool rev_fusable = c->reverse_warm && !feat6(c) && !a.cw.enabled && c->d_src_safe2 != nullptr;
+      const int nb_rw = rev_fusable ? reverse_warm_blocks(c->grid.n) : 0;
+      const int nb_rmax = std::max(nb_r, nb_rw);
+      if (nb_fmax + nb_rmax > c->partial_blocks) {
         if (c->d_partials) (void)hipFree(c->d_partials);
         c->d_partials = nullptr; c->partial_blocks = 0;
-        CK(c, hipMalloc(&c->d_partials, (size_t)(nb_fmax + nb_r) * SUMS_MAX * sizeof(double)));
-        c->partial_blocks = nb_fmax + nb_r;
+        CK(c, hipMalloc(&c->d_partials, (size_t)(nb_fmax + nb_rmax) * SUMS_MAX * sizeof(double)));
+        c->partial_blocks = nb_fmax + nb_rmax;
       }
       const bool both_union = c->search_dir == 2 && !c->reciprocal;
       const int rmode = c->search_dir == 1 ? 1 : (c->reciprocal ? 3 : 2);
-      // rows: the reverse matches' first, the forward half's (streaming pass or warm-started kernel) behind them
+      // rows: the reverse matches' first, the forward half's (streaming pass or warm-started kernel) right behind them
       IterArgs ar = a;
       ar.partials = c->d_partials;
-      a.partials = c->d_partials + (size_t)nb_r * SUMS_MAX; a.tile_partials = a.partials;
       a.nn_d2 = nullptr;
       c->rec_valid = false; c->lb_fresh = false;
       warm_run_reset(c);
       c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
       for (size_t it = 0; it < p->max_iter; ++it) {
         bool fwd_warm = false;
+        const bool rev_fused = rev_fusable && it >= 1;      // (this iteration's reverse search starts from the previous matches and accumulates)
         for (size_t st = 0; st < opt_steps; ++st) {
           a.skip_if_inner_done = ar.skip_if_inner_done = (st > 0);
+          const int rev_rows = (rev_fused && st == 0) ? nb_rw : nb_r;
+          a.partials = c->d_partials + (size_t)rev_rows * SUMS_MAX; a.tile_partials = a.partials;
           if (st == 0) {
             if (c->search_dir == 2) {
               fwd_warm = fwd_wcap && it >= 2;
@@ -2378,13 +2384,16 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
             }
             // (from the second iteration on d_rev_pos holds the previous reverse matches: the search starts from them)
             const float* warm_tab = (it >= 1 && c->reverse_warm && !feat6(c)) ? c->d_src_safe2 : nullptr;
-            { const TieDev rt = tie_dev_rev(c); launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr, &rt, warm_tab); }
+            RevFused rfu{};
+            rfu.metric = im; rfu.mode = rmode; rfu.fwd_pos = c->d_nn_pos; rfu.src_inv = c->d_src_inv; rfu.partials = c->d_partials;
+            for (int k = 0; k < 3; ++k) rfu.dst_mean[k] = a.dst_mean[k];
+            { const TieDev rt = tie_dev_rev(c); launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr, &rt, warm_tab, rev_fused ? &rfu : nullptr); }
           }
           const bool fwd_in_kernel = fwd_warm && st == 0;      // (the warm-started kernel accumulated the first step's terms itself)
           if (both_union && !fwd_in_kernel) launch_iter(a, im, false, false, nb_f, c->stream);
-          launch_acc_reverse(ar, im, c->src_grid.pts, c->d_rev_pos, c->grid.n, rmode, c->d_nn_pos, c->d_src_inv, nb_r, c->stream);
+          if (!(rev_fused && st == 0)) launch_acc_reverse(ar, im, c->src_grid.pts, c->d_rev_pos, c->grid.n, rmode, c->d_nn_pos, c->d_src_inv, nb_r, c->stream);
           sa.gn_last_step = (st + 1 == opt_steps);
-          const int rows_total = nb_r + (both_union ? (fwd_in_kernel ? nb_w : nb_f) : 0);
+          const int rows_total = rev_rows + (both_union ? (fwd_in_kernel ? nb_w : nb_f) : 0);
           const int rows = launch_reduce_stage1(c->d_partials, rows_total, c->d_stage, c->stream);
           sa.partials = rows ? c->d_stage : c->d_partials;
           sa.nblocks = rows ? rows : rows_total;

@@ -454,8 +454,12 @@ void free_pairs(PairSet& p);
 // transform only (built per search: c_api.hip build_rev_tie_tables); null = count the tied target points (counters[3]) and keep the lowest source index
 // warm_src_safe2 (plain point features only): rev_pos holds the PREVIOUS iteration's reverse matches, the table is k_self_nn's over the source grid -- k_reverse_warm
 // settles every target point whose old match passes the margin test without a search and searches the rest (the same exact result)
+// fused (with warm_src_safe2): the first Gauss-Newton step's sums over the reverse matches accumulated in the same kernel (rows of SUMS_MAX doubles, one per block:
+// reverse_warm_blocks(nd) of them) instead of by launch_acc_reverse afterwards; mode as launch_acc_reverse's
+struct RevFused { int metric; int mode; const uint32_t* fwd_pos; const uint32_t* src_inv; double* partials; float dst_mean[3]; };
+int reverse_warm_blocks(uint32_t nd);
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
-                                 const FeatSpec* feat = nullptr, const TieDev* rev_tie = nullptr, const float* warm_src_safe2 = nullptr);
+                                 const FeatSpec* feat = nullptr, const TieDev* rev_tie = nullptr, const float* warm_src_safe2 = nullptr, const RevFused* fused = nullptr);
 hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& src_grid /*over the source, SOURCE coordinates*/, const float* d_src_xyz, const float* d_src_nrm,
                       const float4* src_sorted, uint32_t ns, const IcpState* state, const IcpState* id_state, const float T_host[16], float max_sq,
                       int direction, bool reciprocal, double inlier_fraction, bool one_to_one, const uint32_t* fwd_pos, const float* fwd_d2,

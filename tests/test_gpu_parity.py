@@ -887,10 +887,12 @@ def test_search_directions_vs_oracle(Context, orc, hip_lib):
 
 def test_reverse_searches_started_from_the_previous_matches_change_nothing(Context, orc, hip_lib):
     """FIRST_TO_SECOND / BOTH loops on the device (correspondence_search_kd_tree.hpp:185-222): from the second iteration on the reverse
-    search starts from the previous reverse matches (bidir.hip k_reverse_warm: margin test over the source, listed rest searched in
-    full).  Exact either way, and the accumulation streams by target position: with the option both ways the loop state after every run
-    is BITWISE the same -- transform, iteration count, correspondence count, the pair list left behind.  Clouds: the recipe, a far
-    start, a source with doubled points (margin 0: never settled without a look), a sparse source."""
+    search starts from the previous reverse matches (bidir.hip k_reverse_warm: margin test over the source, the listed rest searched in
+    full) and accumulates the first step's sums in the same pass (matrix cores).  The matches are exact either way: with the option both
+    ways the runs perform the same iterations over the same correspondence sets -- the pair list left behind is equal element for
+    element, its distances to the last bits of transforms that differ only by the order of the f64 additions -- and a run repeated is
+    BITWISE the same (fixed summation order, ballot-ordered lists).  Clouds: the recipe, a far start, a source with doubled points
+    (margin 0: never settled without a look), a sparse source."""
     from cilantro_amd.icp import CorrespondenceSearchDirection as D, SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f
 
     rng = np.random.default_rng(3)
@@ -902,20 +904,28 @@ def test_reverse_searches_started_from_the_previous_matches_change_nothing(Conte
     cases.append(("doubled", d["dst"], d["dst_n"], np.ascontiguousarray(np.concatenate([d["src"], d["src"][pick]])), float(d["max_sq_dist"])))
     d = syn.make_pair(150_000, 20_000, with_normals=True, src_stride=7); cases.append(("sparse", d["dst"], d["dst_n"], d["src"], float(d["max_sq_dist"])))
     for name, dst, dst_n, src, r2 in cases:
-        for direction, recip, metric in ((D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 1), (D.BOTH, True, 0), (D.FIRST_TO_SECOND, False, 0)):
+        # (every accumulation form of the fused pass: plane terms only, both, point terms only -- wts -- and the Kabsch moments, in every mode)
+        for direction, recip, metric, wts in ((D.FIRST_TO_SECOND, False, 1, (0.1, 1.0)), (D.BOTH, False, 1, (0.0, 1.0)), (D.BOTH, True, 0, None),
+                                              (D.FIRST_TO_SECOND, False, 0, None), (D.BOTH, True, 1, (0.0, 1.0)), (D.BOTH, False, 1, (1.0, 0.0)),
+                                              (D.BOTH, True, 1, (0.1, 1.0)), (D.FIRST_TO_SECOND, False, 1, (0.0, 1.0))):
             got = []
-            for warm in (1, 0):
+            for warm in (1, 0, 1):
                 icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src) if metric == 1 else SimplePointToPointMetricRigidICP3f(dst, src)
+                if wts is not None:
+                    icp.setPointToPointMetricWeight(wts[0]).setPointToPlaneMetricWeight(wts[1])
                 icp._ctx.set_option("reverse_warm_start", warm)
                 icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
                 icp.setMaxNumberOfIterations(10).setConvergenceTolerance(0.0)
                 T = icp.estimate().getTransform()
                 g1, g2, gv = icp._ctx.get_correspondences()
                 got.append((T.copy(), icp.getNumberOfPerformedIterations(), icp.last_ncorr_, g1.copy(), g2.copy(), gv.copy()))
-            (Tw, iw, nw, a1, a2, av), (Tc, ic, nc, b1, b2, bv) = got
+            (Tw, iw, nw, a1, a2, av), (Tc, ic, nc, b1, b2, bv), (Tr, ir, nr, c1, c2, cv) = got
             assert iw == ic and nw == nc, (name, direction, recip, metric)
-            assert np.array_equal(Tw.view(np.uint32), Tc.view(np.uint32)), (name, direction, recip, metric, np.abs(Tw - Tc).max())
-            assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(av.view(np.uint32), bv.view(np.uint32)), (name, direction, recip)
+            assert np.abs(Tw.astype(np.float64) - Tc).max() < 1e-6, (name, direction, recip, metric, np.abs(Tw - Tc).max())
+            assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.allclose(av, bv, rtol=0.0, atol=5e-9), (name, direction, recip)
+            # the same run again: bitwise
+            assert ir == iw and nr == nw and np.array_equal(Tw.view(np.uint32), Tr.view(np.uint32)), (name, direction, recip, metric)
+            assert np.array_equal(a1, c1) and np.array_equal(a2, c2) and np.array_equal(av.view(np.uint32), cv.view(np.uint32)), (name, direction, recip)
         # ... and the loop is still the reference's: one case per cloud against the oracle
         icp = SimpleCombinedMetricRigidICP3f(dst, dst_n, src)
         icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(D.FIRST_TO_SECOND)

@@ -97,6 +97,11 @@ if has regimes; then
   [ -x tools/bin/read_bw_probe ] && timeout 200 tools/bin/read_bw_probe > $O/read_bw_probe.txt 2>&1
   timeout 150 python tools/variants_bench.py 10000000 > $O/variants.txt 2>&1; grep "n=" $O/variants.txt | cut -c1-200
   timeout 150 python tools/directions_bench.py 10000000 > $O/directions.txt 2>&1; tail -6 $O/directions.txt | cut -c1-200
+  timeout 200 python tools/affine_forms.py 10000000 20 > $O/affine_forms.txt 2>&1; python tools/affine_forms.py 1000000 20 >> $O/affine_forms.txt 2>&1; grep "n=" $O/affine_forms.txt | cut -c1-160
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_affine -- python tools/affine_forms.py 10000000 20 > $O/trace_affine.log 2>&1
+  cp $O/trace_affine/*/*_kernel_stats.csv $O/affine_kernel_stats.csv 2>/dev/null
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_directions -- python tools/directions_bench.py 10000000 > $O/trace_directions.log 2>&1
+  cp $O/trace_directions/*/*_kernel_stats.csv $O/directions_kernel_stats.csv 2>/dev/null
   timeout 100 python tools/size_sweep.py > $O/size_sweep.txt 2>&1; tail -8 $O/size_sweep.txt | cut -c1-200
   timeout 300 python tools/tie_order_build_time.py > $O/tie_order_build.txt 2>&1; tail -4 $O/tie_order_build.txt
   prune
