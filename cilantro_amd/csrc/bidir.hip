@@ -302,6 +302,7 @@ struct RevAcc {
   int mode;
   const uint32_t* fwd_pos;      // forward matches by sorted source position (modes 2 / 3)
   const uint32_t* src_inv;      // original source index -> sorted source position
+  const uint32_t* grid_to_sorted;   // ... composed with the source grid's order: source-grid position -> sorted source position (gathered beside the record itself)
   double* partials;             // [gridDim.x * SUMS_MAX]
 };
 template <int ACC>
@@ -323,9 +324,9 @@ __global__ __launch_bounds__(256) void k_reverse_warm(GridDev sg, const float4* 
   const uint32_t rounds = (nd + 255u) / 256u, last = nd - 1u;
   // a correspondence (target position jd, source-grid record c) counts under `mode`
   // (evaluated by every lane, from a valid record: no divergent branch around the two dependent loads)
-  auto counts = [&](uint32_t jd, const float4 c) -> bool {
+  auto counts = [&](uint32_t jd, uint32_t sorted_pos) -> bool {
     if (ra.mode < 2) return true;      // (uniform)
-    const bool dup = ra.fwd_pos[ra.src_inv[__float_as_uint(c.w)]] == jd;
+    const bool dup = ra.fwd_pos[sorted_pos] == jd;
     return dup == (ra.mode == 3);
   };
   uint32_t wcnt = 0;      // (wave-uniform)
@@ -339,33 +340,47 @@ __global__ __launch_bounds__(256) void k_reverse_warm(GridDev sg, const float4* 
         const uint32_t rp = active ? rev_pos[jd] : NONE_U32;      // (the lane's own store)
         const bool has0 = rp != NONE_U32;
         const float4 c = sg.pts[has0 ? rp : 0u];
+        const uint32_t sp = ra.mode >= 2 ? ra.grid_to_sorted[has0 ? rp : 0u] : 0u;
         const float4 p = dst_sorted[active ? jd : 0u];
         float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (NRM) nv = ra.dst_nrm[active ? jd : 0u];
         float qx, qy, qz;
         transform_point(T, c.x, c.y, c.z, qx, qy, qz);
-        const bool cnt = counts(jd, c);
+        const bool cnt = counts(jd, sp);
         rank.update(zb, lane, has0 && cnt, qx, qy, qz, p, nv, ra.dst_mean, smt);
       }
     }
     wcnt = 0;
     __builtin_amdgcn_wave_barrier();
   };
+  // Software-pipelined by one round: the coalesced loads of the NEXT round (point, old match, normal) leave right behind the two gathers
+  // the current round depends on (the old match's source record and its table entry), so that a wave always has two rounds' trips in flight.
   uint32_t since = 0;
-  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+  uint32_t r = blockIdx.x;
+  float4 pN = make_float4(0.f, 0.f, 0.f, 0.f), nvN = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t rpN = NONE_U32;
+  if (r < rounds) {
+    const uint32_t jc = min(r * 256u + threadIdx.x, last);
+    pN = dst_sorted[jc]; rpN = rev_pos[jc];
+    if (ACC != IM_NONE && NRM) nvN = ra.dst_nrm[jc];
+  }
+  for (; r < rounds; r += gridDim.x) {
     if (since == (uint32_t)RW_ROUNDS) { flush(); since = 0; }
     ++since;
     const uint32_t jd = r * 256u + threadIdx.x;
     const bool valid = jd < nd;
-    const uint32_t jc = min(jd, last);
-    const float4 p = dst_sorted[jc];
-    const uint32_t rp = rev_pos[jc];
-    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACC != IM_NONE && NRM) nv = ra.dst_nrm[jc];
+    const float4 p = pN, nv = nvN;
+    const uint32_t rp = rpN;
     const bool has = valid && rp != NONE_U32;
     const uint32_t rc = has ? rp : 0u;
     const float4 c = sg.pts[rc];
     const float sf = src_safe2[rc];
+    const uint32_t sp = (ACC != IM_NONE && ra.mode >= 2) ? ra.grid_to_sorted[rc] : 0u;      // (uniform condition; the same trip as the record)
+    if (r + gridDim.x < rounds) {      // (uniform)
+      const uint32_t jn = min((r + gridDim.x) * 256u + threadIdx.x, last);
+      pN = dst_sorted[jn]; rpN = rev_pos[jn];
+      if (ACC != IM_NONE && NRM) nvN = ra.dst_nrm[jn];
+    }
     float qx, qy, qz;
     transform_point(T, c.x, c.y, c.z, qx, qy, qz);
     const float dx = __fsub_rn(p.x, qx), dy = __fsub_rn(p.y, qy), dz = __fsub_rn(p.z, qz);
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(256) void k_reverse_warm(GridDev sg, const float4* 
     const unsigned long long um = __ballot(todo);
     if (todo) wl[wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = jd;
     wcnt += (uint32_t)__popcll(um);
-    if (ACC != IM_NONE) { const bool cnt = counts(jd, c); rank.update(zb, lane, settled && cnt, qx, qy, qz, p, nv, ra.dst_mean, smt); }
+    if (ACC != IM_NONE) { const bool cnt = counts(jd, sp); rank.update(zb, lane, settled && cnt, qx, qy, qz, p, nv, ra.dst_mean, smt); }
   }
   flush();
   if (ACC != IM_NONE) rank.template write_row<RW_WAVES>(raw, wave, lane, ra.partials + (size_t)blockIdx.x * SUMS_MAX);
@@ -695,6 +710,12 @@ hipError_t find_pairs(const FeatSpec& feat, const GridDev& g, const GridDev& sgr
   return e;
 }
 
+__global__ void k_grid_to_sorted(const float4* __restrict__ sgrid_pts, uint32_t ns, const uint32_t* __restrict__ src_inv, uint32_t* __restrict__ out) {
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ns; g += gridDim.x * blockDim.x) out[g] = src_inv[__float_as_uint(sgrid_pts[g].w)];
+}
+void launch_grid_to_sorted(const float4* sgrid_pts, uint32_t ns, const uint32_t* src_inv, uint32_t* out, hipStream_t s) {
+  if (ns) hipLaunchKernelGGL(k_grid_to_sorted, dim3(std::min<uint32_t>((ns + 255u) / 256u, 4096u)), dim3(256), 0, s, sgrid_pts, ns, src_inv, out);
+}
 int reverse_warm_blocks(uint32_t nd) {      // at least eight rounds of 256 target points per block
   long nb = ((long)nd + 8 * 256 - 1) / (8 * 256);
   if (nb > 2048) nb = 2048;
@@ -717,7 +738,7 @@ void launch_reverse_search_rigid(const GridDev& g, const GridDev& sgrid, const I
     RevAcc ra{};
     int acc = IM_NONE;
     if (fused) {
-      acc = fused->metric; ra.mode = fused->mode; ra.fwd_pos = fused->fwd_pos; ra.src_inv = fused->src_inv; ra.partials = fused->partials; ra.dst_nrm = g.nrm;
+      acc = fused->metric; ra.mode = fused->mode; ra.fwd_pos = fused->fwd_pos; ra.src_inv = fused->src_inv; ra.grid_to_sorted = fused->grid_to_sorted; ra.partials = fused->partials; ra.dst_nrm = g.nrm;
       for (int k = 0; k < 3; ++k) ra.dst_mean[k] = fused->dst_mean[k];
     }
     switch (acc) {

@@ -200,6 +200,7 @@ struct cilhip_ctx {
   bool has_src_grid = false;
   float* d_src_safe2 = nullptr;   // [ns] k_self_nn's table over the SOURCE grid: the margin test of the warm-started reverse search (k_reverse_warm)
   bool reverse_warm = true;       // option "reverse_warm_start": the device-resident FIRST_TO_SECOND / BOTH loops start every reverse search but the first from the previous matches
+  uint32_t* d_grid_to_sorted = nullptr;   // [ns] source-grid position -> sorted source position (d_src_inv through the source grid's order): the fused reverse pass's duplicate test
   uint32_t *d_rev_pos = nullptr, *d_src_inv = nullptr;   // list-free loops of those directions: reverse matches by target position; original -> sorted source position
   float* d_rev_d2 = nullptr;
   bool have_pairs = false;        // `pairs` holds the result of the last find_correspondences
@@ -253,6 +254,7 @@ double ctx_wait_us(const cilhip_ctx* c) { return c->wait_us; }
 static void drop_src_grid(cilhip_ctx* c) {
   if (c->has_src_grid) { free_grid(c->src_grid); c->has_src_grid = false; }
   if (c->d_src_safe2) { (void)hipFree(c->d_src_safe2); c->d_src_safe2 = nullptr; }
+  if (c->d_grid_to_sorted) { (void)hipFree(c->d_grid_to_sorted); c->d_grid_to_sorted = nullptr; }
   if (c->d_src_rgb_grid) { (void)hipFree(c->d_src_rgb_grid); c->d_src_rgb_grid = nullptr; }
 }
 static void drop_matches(cilhip_ctx* c) { c->have_nn = false; c->d2_stale = false; c->pending_matches = false; c->matches_origin = 0; }
@@ -363,6 +365,7 @@ static void free_source(cilhip_ctx* c) {
   c->d_out_idx = nullptr; c->d_out_d2 = nullptr;
   drop_src_grid(c);
   if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
+  if (c->d_grid_to_sorted) { (void)hipFree(c->d_grid_to_sorted); c->d_grid_to_sorted = nullptr; }
   c->has_source = false; c->src_sorted = false; drop_matches(c); c->ns = 0;
   c->have_pairs = false; c->pairs.count = 0;   // a pair list refers to the source / target it was found on
   c->far_mode = true;
@@ -867,6 +870,7 @@ static int ensure_sorted(cilhip_ctx* c, const float T[16]) {
     if (c->d_src_nrm) launch_gather_by_w(c->d_src_sorted, c->d_src_nrm, c->ns, c->d_src_nrm_sorted, c->stream);
     if (c->d_src_rgb) launch_gather_by_w(c->d_src_sorted, c->d_src_rgb, c->ns, c->d_src_rgb_sorted, c->stream);
     if (c->d_src_inv) { (void)hipFree(c->d_src_inv); c->d_src_inv = nullptr; }
+    if (c->d_grid_to_sorted) { (void)hipFree(c->d_grid_to_sorted); c->d_grid_to_sorted = nullptr; }
     memcpy(c->sort_T, T, sizeof(c->sort_T));
     c->src_sorted = true;
     c->src3_valid = false; c->rec_valid = false; c->lb_fresh = false;     // (per sorted order)
@@ -1341,6 +1345,10 @@ static int ensure_reverse_buffers(cilhip_ctx* c) {
   if (!c->d_src_inv) {      // original source index -> position in the cube-sorted source (the forward matches are stored by that)
     CK(c, hipMalloc(&c->d_src_inv, (c->ns ? c->ns : 1) * sizeof(uint32_t)));
     launch_inv_perm(c->d_src_sorted, c->ns, c->d_src_inv, c->stream);
+  }
+  if (!c->d_grid_to_sorted && c->has_src_grid) {
+    CK(c, hipMalloc(&c->d_grid_to_sorted, (c->ns ? c->ns : 1) * sizeof(uint32_t)));
+    launch_grid_to_sorted(c->src_grid.pts, c->ns, c->d_src_inv, c->d_grid_to_sorted, c->stream);
   }
   return CILHIP_OK;
 }
@@ -2385,7 +2393,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
             // (from the second iteration on d_rev_pos holds the previous reverse matches: the search starts from them)
             const float* warm_tab = (it >= 1 && c->reverse_warm && !feat6(c)) ? c->d_src_safe2 : nullptr;
             RevFused rfu{};
-            rfu.metric = im; rfu.mode = rmode; rfu.fwd_pos = c->d_nn_pos; rfu.src_inv = c->d_src_inv; rfu.partials = c->d_partials;
+            rfu.metric = im; rfu.mode = rmode; rfu.fwd_pos = c->d_nn_pos; rfu.src_inv = c->d_src_inv; rfu.grid_to_sorted = c->d_grid_to_sorted; rfu.partials = c->d_partials;
             for (int k = 0; k < 3; ++k) rfu.dst_mean[k] = a.dst_mean[k];
             { const TieDev rt = tie_dev_rev(c); launch_reverse_search_rigid(c->grid, c->src_grid, c->d_state, p->max_sq_dist, c->d_rev_pos, c->d_rev_d2, c->stream, feat6(c) ? &rf : nullptr, &rt, warm_tab, rev_fused ? &rfu : nullptr); }
           }

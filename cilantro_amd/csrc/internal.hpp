@@ -456,7 +456,8 @@ void free_pairs(PairSet& p);
 // settles every target point whose old match passes the margin test without a search and searches the rest (the same exact result)
 // fused (with warm_src_safe2): the first Gauss-Newton step's sums over the reverse matches accumulated in the same kernel (rows of SUMS_MAX doubles, one per block:
 // reverse_warm_blocks(nd) of them) instead of by launch_acc_reverse afterwards; mode as launch_acc_reverse's
-struct RevFused { int metric; int mode; const uint32_t* fwd_pos; const uint32_t* src_inv; double* partials; float dst_mean[3]; };
+struct RevFused { int metric; int mode; const uint32_t* fwd_pos; const uint32_t* src_inv; const uint32_t* grid_to_sorted; double* partials; float dst_mean[3]; };
+void launch_grid_to_sorted(const float4* sgrid_pts, uint32_t ns, const uint32_t* src_inv, uint32_t* out /*[ns] by source-grid position*/, hipStream_t s);
 int reverse_warm_blocks(uint32_t nd);
 void launch_reverse_search_rigid(const GridDev& g, const GridDev& src_grid, const IcpState* state, float max_sq, uint32_t* rev_pos, float* rev_d2, hipStream_t s,
                                  const FeatSpec* feat = nullptr, const TieDev* rev_tie = nullptr, const float* warm_src_safe2 = nullptr, const RevFused* fused = nullptr);
