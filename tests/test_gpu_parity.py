@@ -230,6 +230,50 @@ def test_icp_end_to_end_vs_oracle(orc, hip_lib, metric, n):
             assert icp.hasConverged()
 
 
+def test_every_accumulating_form_with_half_of_the_matches_cut_by_the_radius(orc, hip_lib):
+    """Every kernel that forms the estimators' terms itself (k_warm, the accumulating tiles, the streaming passes, k_warm<IM_AFFC / IM_AFFP>,
+    k_acc_affine) with a radius that leaves about half of the queries WITHOUT a correspondence -- lanes that contribute zeros sit next to
+    lanes that contribute terms in every wave, in every accumulation form (Kabsch moments, plane terms, point terms, both; the affine
+    moments).  Transforms and correspondence counts against the oracle's loops.  (Round 6: a back-end miscompile dropped one component of
+    the plane-terms vector on a path with such lanes -- NOTEBOOK; this is the test that would have seen it in any of these kernels.)"""
+    from cilantro_amd.icp import (SimpleCombinedMetricRigidICP3f, SimplePointToPointMetricRigidICP3f, SimpleCombinedMetricAffineICP3f,
+                                  SimplePointToPointMetricAffineICP3f)
+
+    n = 200_000
+    d = syn.make_pair(n, perturb=0.1, noise=0.3)
+    # nearest distances of this pair are spread over (0, ~0.5 h): a radius at their median cuts half of them
+    ctx_probe = SimplePointToPointMetricRigidICP3f(d["dst"], d["src"])
+    ctx_probe.correspondenceSearchEngine().setMaxDistance(float(d["max_sq_dist"]))
+    ctx_probe._ctx.find_correspondences(d["T_true"].astype(np.float32), float(d["max_sq_dist"]), count=False)
+    dv = ctx_probe._ctx.get_correspondences()[2]
+    r2 = float(np.median(dv))
+    forms = (("adaptive", {}), ("warm from the second iteration", {"warm_start": 2}), ("tiles, accumulating", {"tiled": 2, "tile_accumulation": 2, "warm_start": 0}),
+             ("streaming passes", {"tiled": 0, "warm_start": 0, "tile_accumulation": 0}))
+    T0 = d["T_true"].astype(np.float32).copy()
+    T0[:3, 3] += np.float32(0.05 * d["h"])
+    for affine in (False, True):
+        for metric, wts in ((0, None), (1, (0.0, 1.0)), (1, (1.0, 0.0)), (1, (0.1, 1.0))):
+            p = orc.make_params(metric=metric, w_p2p=wts[0] if wts else 0.0, w_p2pl=wts[1] if wts else 1.0, max_iter=6, conv_tol=0.0, max_sq_dist=r2,
+                                mode=orc.MODE_MIXED, affine=affine)
+            ro = orc.icp_run(d["dst"], d["dst_n"], d["src"], p, T0=T0)
+            assert 0.25 * n < ro["last_ncorr"] < 0.75 * n, ro["last_ncorr"]
+            for name, opts in forms:
+                if metric == 1:
+                    icp = (SimpleCombinedMetricAffineICP3f if affine else SimpleCombinedMetricRigidICP3f)(d["dst"], d["dst_n"], d["src"])
+                    icp.setPointToPointMetricWeight(wts[0]).setPointToPlaneMetricWeight(wts[1])
+                else:
+                    icp = (SimplePointToPointMetricAffineICP3f if affine else SimplePointToPointMetricRigidICP3f)(d["dst"], d["src"])
+                for k, v in opts.items():
+                    icp._ctx.set_option(k, v)
+                icp.correspondenceSearchEngine().setMaxDistance(r2)
+                icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0).setInitialTransform(T0)
+                Tg = icp.estimate().getTransform()
+                err = np.linalg.norm(Tg.astype(np.float64) - ro["T"].astype(np.float64))
+                assert err <= (3e-5 if affine else TOL_T), (affine, metric, wts, name, err)
+                # (a query whose distance sits within rounding of the radius may fall on either side under transforms that differ in their last bits)
+                assert abs(icp.last_ncorr_ - ro["last_ncorr"]) <= 5, (affine, metric, wts, name, icp.last_ncorr_, ro["last_ncorr"])
+
+
 def test_icp_combined_weights_and_gn_steps(orc, hip_lib):
     from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
 
