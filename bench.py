@@ -847,7 +847,13 @@ def bench_ransac(a, torch, emit=True):
                         "note": "6 individually rounded f32 operations per point-plane test (3 multiplies + 3 additions of n.p + offset, hyperplane.hpp absDistance; the "
                                 "|.| <= threshold compare and the ballot/popcount are not counted), no FMA contraction: counts must match the reference bit for bit; "
                                 "peak = half of the 157.3 TFLOP/s FMA figure.  128 hypotheses share one read of the points, so HBM is not the bound:",
-                        "hbm_GBps": alg / (dt / a.steps) / 1e9, "hbm_frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg}}
+                        "hbm_GBps": alg / (dt / a.steps) / 1e9, "hbm_frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+                        # what the instruction stream itself allows: per PAIR of tests of a lane six packed f32 operations (v_pk_mul / v_pk_add: two tests
+                        # each) and two compares (|r| <= thr, one test each; the counts go through ballots on the scalar unit), at the issue rates
+                        # tools/valu_rate_probe measured on this part (profiles/r06_valu_rate_probe.txt: 2.0 ns per wave-instruction and SIMD for
+                        # v_pk_*, 1.45 ns for single-operation f32 instructions), 1024 SIMDs
+                        "issue_bound": {"ns_per_128_lane_tests": 6 * 2.0 + 2 * 1.45, "bound_ms_per_step": float(n) * 128 / 128.0 * (6 * 2.0 + 2 * 1.45) * 1e-6 / 1024.0,
+                                        "frac": float(n) * 128 / 128.0 * (6 * 2.0 + 2 * 1.45) * 1e-6 / 1024.0 / (dt * 1e3 / a.steps)}}}
     if not a.no_cpu_baseline:
         try:
             from oracle import oracle as orc
