@@ -343,32 +343,54 @@ __global__ __launch_bounds__(AFF_ROW) void k_reduce_affine(const double* __restr
   stage[(size_t)blockIdx.x * AFF_ROW + threadIdx.x] = aff_fold_rows(partials + (size_t)b0 * AFF_ROW, b1 - b0, (int)threadIdx.x);
 }
 
-__global__ __launch_bounds__(AFF_ROW) void k_solve_affine(SolveArgs a) {
+// (ONE wave: the barriers between the elimination's phases then cost nothing -- with two waves they were a third of the kernel)
+constexpr int AFF_SOLVE_THREADS = 64;
+__global__ __launch_bounds__(AFF_SOLVE_THREADS) void k_solve_affine(SolveArgs a) {
   __shared__ double sums[AFF_ROW];
   __shared__ IcpState lst;
-  __shared__ double A[144], rhs[12], y[12], x[12];
-  __shared__ int perm[12], s_piv;
+  __shared__ double A[144], rhs[12], x[12];
+  __shared__ int perm[12];
   __shared__ unsigned int unproven_total, listed_total;
   constexpr int ST_DWORDS = (int)(sizeof(IcpState) / 4);
-  constexpr int NT = AFF_ROW, N = 12;
+  constexpr int NT = AFF_SOLVE_THREADS, N = 12;
+  static_assert(AFF_ROW == 2 * NT, "two slots of a row per thread");
   const int t = (int)threadIdx.x;
   if (a.state->done) return;
+#ifdef CILHIP_EXP_AFF_CLOCKS
+  const unsigned long long c0_ = wall_clock64();
+  unsigned long long c1_ = 0, c2_ = 0, c3_ = 0;
+#define AFF_CLK(v) v = wall_clock64()
+#else
+#define AFF_CLK(v)
+#endif
   uint32_t sreg[(ST_DWORDS + NT - 1) / NT];
 #pragma unroll
   for (int k = 0; k < (ST_DWORDS + NT - 1) / NT; ++k) sreg[k] = t + k * NT < ST_DWORDS ? reinterpret_cast<const uint32_t*>(a.state)[t + k * NT] : 0u;
   const bool counters = a.unproven_cnt != nullptr;
-  unsigned int cv = counters ? a.unproven_cnt[t] : 0u;      // (128 threads: wave 0 the unproven counts, wave 1 the listed ones)
-  sums[t] = aff_fold_rows(a.partials, a.nblocks, t);
+  unsigned int cv = counters ? a.unproven_cnt[t] : 0u, cw = counters ? a.unproven_cnt[NT + t] : 0u;      // (the unproven counts / the listed ones)
+  {      // both slots of the thread in one sweep over the rows: sixteen independent loads in flight, each slot added in ascending row order
+    double v0 = 0.0, v1 = 0.0;
+    int b = 0;
+    for (; b + 8 <= a.nblocks; b += 8) {
+      double r0[8], r1[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { r0[k] = a.partials[(size_t)(b + k) * AFF_ROW + t]; r1[k] = a.partials[(size_t)(b + k) * AFF_ROW + NT + t]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { v0 += r0[k]; v1 += r1[k]; }
+    }
+    for (; b < a.nblocks; ++b) { v0 += a.partials[(size_t)b * AFF_ROW + t]; v1 += a.partials[(size_t)b * AFF_ROW + NT + t]; }
+    sums[t] = v0; sums[NT + t] = v1;
+  }
 #pragma unroll
   for (int k = 0; k < (ST_DWORDS + NT - 1) / NT; ++k) if (t + k * NT < ST_DWORDS) reinterpret_cast<uint32_t*>(&lst)[t + k * NT] = sreg[k];
   if (counters) {
-    a.unproven_cnt[t] = 0u;
+    a.unproven_cnt[t] = 0u; a.unproven_cnt[NT + t] = 0u;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cv += __shfl_down(cv, off, 64);
-    if (t == 0) unproven_total = cv;
-    if (t == 64) listed_total = cv;
+    for (int off = 32; off > 0; off >>= 1) { cv += __shfl_down(cv, off, 64); cw += __shfl_down(cw, off, 64); }
+    if (t == 0) { unproven_total = cv; listed_total = cw; }
   }
   __syncthreads();
+  AFF_CLK(c1_);
   IcpState* st = &lst;
   const double n = sums[72 + aff_pair(3, 3)];
   const bool wp = a.w_p2p > 0.0f, wl = a.w_p2pl > 0.0f;
@@ -398,16 +420,25 @@ __global__ __launch_bounds__(AFF_ROW) void k_solve_affine(SolveArgs a) {
       perm[t] = t;
     }
     __syncthreads();
+    AFF_CLK(c2_);
     const double tiny = 2.2250738585072014e-308;
+    // (what a lane updates in every elimination step: up to three entries (i, j) of the lower triangle, fixed)
+    int ui[3], uj[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const int e = t + q * NT; ui[q] = e < 144 ? e / 12 : 0; uj[q] = e < 144 ? e % 12 : 12; }
     for (int k = 0; k < N; ++k) {
-      if (t == 0) {
-        int piv = k;
-        double best = fabs(A[k * N + k]);
-        for (int i = k + 1; i < N; ++i) if (fabs(A[i * N + i]) > best) { best = fabs(A[i * N + i]); piv = i; }
-        s_piv = piv;
+      // the pivot: the largest remaining |diagonal|, the lowest index among equals (ldlt_solve_n's scan: a later entry replaces the best only
+      // if strictly larger) -- lanes 0 .. 11 hold one diagonal entry each, a butterfly over 16 lanes finds it
+      double pv = (t < N && t >= k) ? fabs(A[t * N + t]) : -1.0;
+      int piv = t < N ? t : N;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(pv, off, 64);
+        const int oi = __shfl_xor(piv, off, 64);
+        if (ov > pv || (ov == pv && oi < piv)) { pv = ov; piv = oi; }
       }
-      __syncthreads();
-      const int piv = s_piv;
+      piv = __shfl(piv, 0, 64);
+      if (!(piv >= k && piv < N)) piv = k;      // (nothing comparable on the diagonal: no swap)
       if (piv != k) {
         if (t < N) { const double v = A[k * N + t]; A[k * N + t] = A[piv * N + t]; A[piv * N + t] = v; }
         __syncthreads();
@@ -423,8 +454,9 @@ __global__ __launch_bounds__(AFF_ROW) void k_solve_affine(SolveArgs a) {
       }
       if (t > k && t < N) A[t * N + k] = A[t * N + k] / dk;
       __syncthreads();
-      for (int e = t; e < 144; e += NT) {
-        const int i = e / 12, j = e % 12;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int i = ui[q], j = uj[q];
         if (j > k && j <= i) {
           const double v = __dsub_rn(A[i * N + j], __dmul_rn(__dmul_rn(A[i * N + k], dk), A[j * N + k]));
           A[i * N + j] = v;
@@ -434,17 +466,30 @@ __global__ __launch_bounds__(AFF_ROW) void k_solve_affine(SolveArgs a) {
       __syncthreads();
     }
   }
+  AFF_CLK(c3_);
   if (t == 0) {
     if (counters) { st->unproven = unproven_total; st->listed = listed_total; }
     double L[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tr[3] = {0, 0, 0};
     if (!identity) {
-      for (int i = 0; i < N; ++i) y[i] = rhs[perm[i]];
-      for (int i = 0; i < N; ++i)
-        for (int j = 0; j < i; ++j) y[i] = __dsub_rn(y[i], __dmul_rn(A[i * N + j], y[j]));
-      for (int i = 0; i < N; ++i) { const double d = A[i * N + i]; y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0; }
-      for (int i = N - 1; i >= 0; --i)
-        for (int j = i + 1; j < N; ++j) y[i] = __dsub_rn(y[i], __dmul_rn(A[j * N + i], y[j]));
-      for (int i = 0; i < N; ++i) x[perm[i]] = y[i];
+      // (the two triangular solves with y in REGISTERS -- every index a compile-time constant once unrolled: through an LDS array each of
+      //  their 132 steps was a dependent LDS round trip, two thirds of the kernel)
+      double yr[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) yr[i] = rhs[perm[i]];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) yr[i] = __dsub_rn(yr[i], __dmul_rn(A[i * N + j], yr[j]));
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) { const double d = A[i * N + i]; yr[i] = (fabs(d) > 2.2250738585072014e-308) ? yr[i] / d : 0.0; }
+#pragma unroll
+      for (int i = N - 1; i >= 0; --i) {
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) yr[i] = __dsub_rn(yr[i], __dmul_rn(A[j * N + i], yr[j]));
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[perm[i]] = yr[i];
       for (int i = 0; i < 9; ++i) L[i] = x[i];              // :470-472 row-major linear part, then the translation
       for (int i = 0; i < 3; ++i) tr[i] = x[9 + i];
       if (a.affine_centered)                                // :473 tform = t_dst * tform * t_src
@@ -473,6 +518,13 @@ __global__ __launch_bounds__(AFF_ROW) void k_solve_affine(SolveArgs a) {
     for (int i = 0; i < SUMS_MAX; ++i) st->sums[i] = 0.0;
     st->sums[0] = n;
     finalize_state(st, a, Tn, delta);
+#ifdef CILHIP_EXP_AFF_CLOCKS
+    {      // (dev build: the trace's counters carry the phases in 10 ns ticks: fold | assembly, elimination | solves + compose + state)
+      const unsigned long long c4_ = wall_clock64();
+      st->unproven = (unsigned int)((c1_ - c0_) & 0xffffu) | (unsigned int)(((c2_ - c1_) & 0xffffu) << 16);
+      st->listed = (unsigned int)((c3_ - c2_) & 0xffffu) | (unsigned int)(((c4_ - c3_) & 0xffffu) << 16);
+    }
+#endif
   }
   __syncthreads();
   for (int k = t; k < ST_DWORDS; k += NT) reinterpret_cast<uint32_t*>(a.state)[k] = reinterpret_cast<const uint32_t*>(&lst)[k];
@@ -490,7 +542,7 @@ void launch_reduce_and_solve_affine(const double* partials, int nrows, double* s
     a.partials = partials; a.nblocks = nrows;
   }
   a.reduced = nullptr;
-  hipLaunchKernelGGL(k_solve_affine, dim3(1), dim3(AFF_ROW), 0, s, a);
+  hipLaunchKernelGGL(k_solve_affine, dim3(1), dim3(AFF_SOLVE_THREADS), 0, s, a);
 }
 
 struct InitArgs { float T[16]; float src_mean[3]; Feedback* fb; unsigned int run_tag; float src_center[3], src_half[3]; unsigned int* tie_counters; };
