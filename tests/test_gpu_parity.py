@@ -1386,6 +1386,50 @@ def test_point_normal_feature_search_vs_oracle(Context, orc, hip_lib):
 
 
 @pytest.mark.gpu
+def test_full_size_variants_10m(Context, orc, hip_lib):
+    """The round-6 loops at BASELINE configs[2]'s full size (10M <-> 10M), through properties that need no exhaustive oracle: the
+    affine classes' device-resident loop against the host-driven loop it replaces (option affine_device_loop), the FIRST_TO_SECOND /
+    BOTH loops with their reverse searches warm-started + accumulating in the same pass against searched from scratch + a separate
+    pass (option reverse_warm_start) -- same iterations, same correspondence counts, transforms equal to the order of the f64
+    additions, the known transform recovered.  Figures: gpurun_out/variants_parity_10m.json."""
+    from cilantro_amd.icp import (CorrespondenceSearchDirection as D, SimpleCombinedMetricAffineICP3f, SimplePointToPointMetricAffineICP3f,
+                                  SimpleCombinedMetricRigidICP3f)
+
+    n = 10_000_000
+    d = syn.make_pair(n, perturb=0.3)
+    r2 = float(d["max_sq_dist"])
+    report = {}
+    for name, mk, opt in (("affine_combined", lambda: SimpleCombinedMetricAffineICP3f(d["dst"], d["dst_n"], d["src"]), "affine_device_loop"),
+                          ("affine_point_to_point", lambda: SimplePointToPointMetricAffineICP3f(d["dst"], d["src"]), "affine_device_loop"),
+                          ("first_to_second", lambda: SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"]), "reverse_warm_start"),
+                          ("both", lambda: SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"]), "reverse_warm_start"),
+                          ("both_reciprocal", lambda: SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"]), "reverse_warm_start")):
+        got = []
+        for on in (1, 0):
+            icp = mk()
+            icp._ctx.set_option(opt, on)
+            eng = icp.correspondenceSearchEngine().setMaxDistance(r2)
+            if name == "first_to_second":
+                eng.setSearchDirection(D.FIRST_TO_SECOND)
+            elif name.startswith("both"):
+                eng.setSearchDirection(D.BOTH).setRequireReciprocality(name == "both_reciprocal")
+            icp.setMaxNumberOfIterations(8).setConvergenceTolerance(0.0)
+            icp.estimate()      # (the tables a first call builds -- source grid, nearest-other-point tables -- stay out of the figure below)
+            T = icp.estimate().getTransform().astype(np.float64)
+            got.append((T, icp.getNumberOfPerformedIterations(), icp.last_ncorr_, icp._ctx.last_timing()[0] / 8.0))
+            del icp
+        (T1, i1, n1, ms1), (T0, i0, n0, ms0) = got
+        dT = float(np.abs(T1 - T0).max())
+        err = float(np.linalg.norm(T1 - d["T_true"]))
+        report[name] = {"iterations": i1, "last_ncorr": int(n1), "max_abs_T_difference_fast_vs_plain_form": dT, "T_err_vs_truth_frobenius": err,
+                        "loop_ms_per_iteration_fast": ms1, "loop_ms_per_iteration_plain": ms0}
+        assert i1 == i0 and n1 == n0, (name, i1, i0, n1, n0)
+        assert dT < 2e-6, (name, dT)
+        assert err < 2e-5, (name, err)
+    _report("variants_parity_10m.json", report)
+
+
+@pytest.mark.gpu
 def test_full_size_properties_10m(Context, orc, hip_lib):
     """BASELINE configs[2] at its full size (10M <-> 10M, point-to-plane), through properties that do not need an
     exhaustive oracle:

@@ -21,6 +21,6 @@ cpf $O/affine_kernel_stats.csv $P/${TAG}_affine_kernel_stats.csv
 cpf $O/directions_kernel_stats.csv $P/${TAG}_directions_kernel_stats.csv
 for f in warm_trace_10m warm_trace_1m warm_trace_c4 real_cloud tie_order_build variants directions affine_forms size_sweep; do cpf $O/$f.txt $P/${TAG}_$f.txt; done
 # the parity / tie reports the GPU test suite writes into gpurun_out/
-for f in parity_10m parity_c4 margin_routes warm_matches_10m warm_matches_1m tie_rule tie_rule_forms tie_rule_lattice tie_rule_sharded tie_rule_directions tie_rule_target_shards tie_rule_features tie_count knn_tie_rule real_cloud_forms tie_order_device_build; do
+for f in parity_10m variants_parity_10m parity_c4 margin_routes warm_matches_10m warm_matches_1m tie_rule tie_rule_forms tie_rule_lattice tie_rule_sharded tie_rule_directions tie_rule_target_shards tie_rule_features tie_count knn_tie_rule real_cloud_forms tie_order_device_build; do
   cpf gpurun_out/$f.json $P/${TAG}_$f.json
 done
