@@ -981,6 +981,31 @@ def test_reverse_searches_started_from_the_previous_matches_change_nothing(Conte
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (name, np.linalg.norm(Tg - ro["T"]))
 
 
+def test_search_directions_with_several_gauss_newton_steps_vs_oracle(orc, hip_lib):
+    """FIRST_TO_SECOND / BOTH / reciprocal with max_optimization_iterations = 3 (transform_estimation.hpp:298-366 inside the loop of
+    icp_base.hpp:68-87): the first step's sums come from the fused reverse pass (and BOTH's forward half from the warm-started kernel), the
+    later steps stream over the stored matches under the inner transform -- both ways of the option, against the oracle's loop."""
+    from cilantro_amd.icp import CorrespondenceSearchDirection as D, SimpleCombinedMetricRigidICP3f
+
+    d = syn.make_pair(100_000, 80_000, with_normals=True, perturb=0.5)
+    r2 = float(d["max_sq_dist"])
+    for direction, recip, code in ((D.FIRST_TO_SECOND, False, 1), (D.BOTH, False, 2), (D.BOTH, True, 2)):
+        for wts in ((0.0, 1.0), (0.3, 1.0)):
+            p = orc.make_params(metric=1, w_p2p=wts[0], w_p2pl=wts[1], max_sq_dist=r2, max_iter=6, conv_tol=0.0, max_opt_iter=3, opt_conv_tol=1e-7,
+                                direction=code, reciprocal=recip, mode=orc.MODE_MIXED)
+            ro = orc.icp_run(d["dst"], d["dst_n"], d["src"], p)
+            for warm in (1, 0):
+                icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"])
+                icp.setPointToPointMetricWeight(wts[0]).setPointToPlaneMetricWeight(wts[1])
+                icp.setMaxNumberOfOptimizationStepIterations(3).setOptimizationStepConvergenceTolerance(1e-7)
+                icp._ctx.set_option("reverse_warm_start", warm)
+                icp.correspondenceSearchEngine().setMaxDistance(r2).setSearchDirection(direction).setRequireReciprocality(recip)
+                icp.setMaxNumberOfIterations(6).setConvergenceTolerance(0.0)
+                T = icp.estimate().getTransform()
+                assert icp.last_ncorr_ == ro["last_ncorr"], (direction, recip, wts, warm)
+                assert np.linalg.norm(T.astype(np.float64) - ro["T"]) <= TOL_T, (direction, recip, wts, warm)
+
+
 def test_pair_search_workspace_follows_the_clouds(Context, orc, hip_lib):
     """One context, a BOTH search of a small pair and then a FIRST_TO_SECOND search against a LARGER target with fewer candidates than the
     BOTH search had (n_target' <= n_target + n_source): the search's per-target arrays are sized by the target, not by the candidate
