@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libcilantro_hip.so")
-SOURCES = ["kernels.hip", "warm.hip", "epilogue.hip", "affine.hip", "extract.hip", "grid_build.hip", "filters.hip", "kmeans.hip", "ransac.hip", "ransac_transform.hip", "knn.hip", "bidir.hip", "tie_build.hip", "c_api.hip", "multi.hip"]
+SOURCES = ["kernels.hip", "warm.hip", "epilogue.hip", "affine.hip", "feat_warm.hip", "extract.hip", "grid_build.hip", "filters.hip", "kmeans.hip", "ransac.hip", "ransac_transform.hip", "knn.hip", "bidir.hip", "tie_build.hip", "c_api.hip", "multi.hip"]
 HEADERS = ["internal.hpp", "solve.hpp", "rccl_api.hpp", "search_device.hpp", "affine_device.hpp", os.path.join("..", "..", "include", "cilantro_hip", "c_api.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the pinned f32 expressions (d2, T*s, per-term residuals) must round exactly as

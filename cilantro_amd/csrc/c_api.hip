@@ -111,6 +111,7 @@ struct cilhip_ctx {
   // kernels' own forecast above it); 0 = never; 4 .. 64 = that many lanes in every global-memory search.
   int group_lanes = -1;
   double wait_us = 0.0;                          // time spent waiting for the device to publish loop state (wait_published), accumulated: not enqueue work
+  bool feat_warm = true;                         // option "feature_warm_start": the feature adaptors' forward search warm-started from the previous matches once the loop moves little (feat_warm.hip)
   bool affine_device_loop = true;                // option "affine_device_loop": the affine classes' loop device-resident (one-pass moments on the matrix cores, 12-unknown
                                                  // solve in the epilogue kernel) whenever nothing needs the stored set per iteration; 0 = the host-driven loop (A/B)
   bool fused_epilogue = false;                   // option "fused_epilogue": stage-1 reduction + epilogue in ONE launch (the last of the 32 stage-1 blocks runs the
@@ -463,6 +464,7 @@ const OptionRow g_options[] = {
   OPT(CILHIP_OPT_KERNEL_TIMING, "kernel_timing", 0, 0, 1, "hipEvents around the search / accumulation kernels (cilhip_enable_kernel_timing)", c->kernel_timing),
   OPT(CILHIP_OPT_KERNEL_TIMING_STRIDE, "kernel_timing_stride", 1, 1, 4096, "with kernel timing on: iterations 0..2 and every stride-th one carry events", c->timing_stride),
   OPT(CILHIP_OPT_REVERSE_WARM_START, "reverse_warm_start", 1, 0, 1, "device-resident FIRST_TO_SECOND / BOTH loops: reverse searches after the first start from the previous reverse matches (margin test over the source; A/B)", c->reverse_warm),
+  OPT(CILHIP_OPT_FEATURE_WARM_START, "feature_warm_start", 1, 0, 1, "feature adaptors (SECOND_TO_FIRST loops): searches warm-started from the previous matches once the loop moves little (margin test with the feature distance; A/B)", c->feat_warm),
   OPT(CILHIP_OPT_AFFINE_DEVICE_LOOP, "affine_device_loop", 1, 0, 1, "affine classes: 1 = device-resident loop (one-pass moments, solve in the epilogue kernel), 0 = host-driven loop (three passes + host solve; A/B)", c->affine_device_loop),
 };
 #undef OPT
@@ -497,6 +499,7 @@ int cilhip_set_option(cilhip_ctx* c, const char* key, double value) {
   if (!strcmp(key, "warm_forecast")) { c->warm_forecast = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "fused_epilogue")) { c->fused_epilogue = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "reverse_warm_start")) { c->reverse_warm = value != 0.0; return CILHIP_OK; }
+  if (!strcmp(key, "feature_warm_start")) { c->feat_warm = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "affine_device_loop")) { c->affine_device_loop = value != 0.0; return CILHIP_OK; }
   if (!strcmp(key, "group_search")) {
     if (value != -1.0 && value != 0.0 && value != 4.0 && value != 8.0 && value != 16.0 && value != 32.0 && value != 64.0)
@@ -2488,7 +2491,14 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
   // streaming accumulation; once nearly all are proven, search + accumulation run as one pass inside the tiles.
   const bool wcap = warm_capable(c);
   if (wcap) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
-  const bool paced = (tile_acc || wcap) && c->ns && p->max_iter > 2 && c->tile_acc_adaptive;
+  // the feature adaptors' searches warm-started from the previous matches (feat_warm.hip): once the published step is within reach,
+  // while the kernel's own count of the queries it had to search says that it pays
+  // (from 400 000 source points up: below, the look at the published state before every enqueue costs what the form saves -- measured 200k: +5 %, 1M: -23 %)
+  const bool fwcap = feat6(c) && c->feat_warm && c->warm_start != 0 && c->ns >= 400000 && !filters_active(c) && !c->fused && !affine;
+  if (fwcap) { rc = ensure_safe2(c); if (rc) return rc; }
+  bool feat_warm_now = false;
+  unsigned int feat_judged = 0;
+  const bool paced = ((tile_acc || wcap) && c->ns && p->max_iter > 2 && c->tile_acc_adaptive) || (fwcap && p->max_iter > 2);
   if (tile_acc && !c->tile_acc_adaptive) c->far_mode = false;
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;
   c->rec_valid = false; c->lb_fresh = false;
@@ -2528,6 +2538,12 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       rc = wait_published_or_sync(c, (unsigned int)(it - 1), &fv);
       if (rc) return rc;
       if (fv.done) break;
+      if (fwcap && !c->warm_banned) {
+        // (a warm-started feature search reports the queries it had to search in full: more than a quarter of them = a cold tile search's price)
+        const bool was_fw = fv.iterations >= 1 && fv.iterations <= c->trace_form.size() && (c->trace_form[fv.iterations - 1] & 0x7f) == FORM_WARM;
+        if (was_fw && fv.iterations > feat_judged) { feat_judged = fv.iterations; if (!warm_keeps_paying(c, fv.listed)) feat_warm_now = false; }
+        else if (!feat_warm_now) feat_warm_now = warm_worthwhile(c, fv.step);
+      }
       // the form of the COLD iterations (one pass / two passes), from the last cold iteration's count of queries its octant stage
       // left open (a warm-started iteration counts something else there: the queries its own search took to the shells)
       if (fv.iterations >= 1 && fv.iterations <= c->trace_form.size() && (c->trace_form[fv.iterations - 1] & 0x7f) <= FORM_TILE_ONE_PASS)
@@ -2544,11 +2560,11 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       }
       // (a published iteration is judged once: the same one can be the latest at two consecutive looks)
       bool fell = false;
-      if (warm_on && c->warm_start == 1 && fv.iterations > judged && is_warm(fv)) {
+      if (wcap && warm_on && c->warm_start == 1 && fv.iterations > judged && is_warm(fv)) {
         judged = fv.iterations;
         if (!warm_keeps_paying(c, fv.listed)) { warm_on = false; fell = true; }
       }
-      if (c->warm_start == 1 && !warm_on && !fell && !c->warm_banned && fv.step < 8.0f * c->warm_thresh) {
+      if (wcap && c->warm_start == 1 && !warm_on && !fell && !c->warm_banned && fv.step < 8.0f * c->warm_thresh) {
         // Candidate for the warm-started form (below).  Decided on the step the loop made LAST -- it is the distance between
         // the queries the margins were left for and the queries about to be searched -- so wait for iteration it - 1 itself
         // (a bubble of some tens of microseconds, only while this decision is pending and the loop is within reach of it).
@@ -2576,6 +2592,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
     bool warm_first = false;
     bool stored_now = true;    // this iteration leaves its matches in nn_pos
     bool counted = false;      // a cold iteration whose kernels count the queries a warm-started iteration after it would have to search
+    bool feat_warm_it = false; // this iteration's feature search ran warm-started
     // (kernel timing on: does THIS iteration carry events?  Every event between dependent kernels idles the device for ~6 us --
     //  two per iteration are a tenth of a warm-started iteration at 10M -- so a caller may ask for a sample: option kernel_timing_stride)
     const bool timing_it = timing && (c->timing_stride <= 1 || it < 3 || it % (size_t)c->timing_stride == 0);
@@ -2635,7 +2652,9 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
           counted = keys;
           // (the cooperative form: the previous iteration's matches, when it left them in nn_pos, bound every query's search)
           if (lanes_it && it >= 1 && prev_stored) sa2.warm_pos = c->d_nn_pos;
-          { const int src_rc = launch_search(c, sa2, lanes_it); if (src_rc) return src_rc; }
+          feat_warm_it = fwcap && feat_warm_now && it >= 1 && prev_stored && !c->warm_banned;
+          if (feat_warm_it) { sa2.safe2 = c->d_safe2; launch_feat_warm(sa2, c->stream); ++c->last_warm_iters; }
+          else { const int src_rc = launch_search(c, sa2, lanes_it); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing_it) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           if (affine) launch_acc_affine(a, im, nb_aff, c->stream);            // streaming accumulation kernel
@@ -2654,7 +2673,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       }
       if (st == 0) { if (single) ++c->last_fused_iters; else ++c->last_two_pass_iters; if (warm) ++c->last_warm_iters; }
       if (st == 0) {
-        const unsigned char form = (unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : one_pass ? FORM_TILE_ONE_PASS
+        const unsigned char form = (unsigned char)(warm ? (warm_first ? FORM_WARM_FIRST : FORM_WARM) : feat_warm_it ? FORM_WARM : one_pass ? FORM_TILE_ONE_PASS
                                                    : (c->fused && !filters_active(c) && !feat6(c)) ? FORM_LANE_FUSED : FORM_SEARCH);
         if (timing_it) c->iter_form.push_back(form);
         c->trace_form.push_back((unsigned char)(form | (counted ? 0x80 : 0)));

@@ -695,6 +695,12 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        the normal part follows the transform as for kind 0, the colour part does not move; wn through
  *                        "feature_normal_weight", wc through "feature_color_weight"; needs both clouds' normals and colours.
  *   "feature_color_weight" (default 0): the colour weight of feature_kind 2.
+ *   "feature_warm_start" (default 1): SECOND_TO_FIRST loops over features (rigid classes, no post-filters, >= 400 000 source points):
+ *                        once an update moves no source point by more than the warm-started form's entry fraction of a cell, the
+ *                        search starts from the previous matches -- a query whose old match p has 4 d_feat(q, p) < nnd(p)^2 (nnd: the
+ *                        distance from p to its nearest other target point; d_feat >= the squared point distance) keeps it without looking
+ *                        at a cell, the rest is searched in full (feat_warm.hip) -- and goes back to the tile search when more than a
+ *                        quarter of the queries had to be searched.  Same correspondences either way; 0 = every search from scratch (A/B).
  *   "symmetric_metric" (default 1): 0 = source normals feed the feature adaptor only and the combined metric stays the
  *                        three-cloud one (the reference decides this by the ICP constructor used,
  *                        icp_common_instances.hpp:74-97).
@@ -735,7 +741,7 @@ typedef enum cilhip_option {
   CILHIP_OPT_POINT_WEIGHT_SIGMA, CILHIP_OPT_PLANE_WEIGHT_SIGMA, CILHIP_OPT_TILE_ACCUMULATION, CILHIP_OPT_SEARCH_DIRECTION,
   CILHIP_OPT_FEATURE_NORMAL_WEIGHT, CILHIP_OPT_FEATURE_KIND, CILHIP_OPT_FEATURE_COLOR_WEIGHT, CILHIP_OPT_SYMMETRIC_METRIC,
   CILHIP_OPT_TRANSFORM_MODE, CILHIP_OPT_REQUIRE_RECIPROCALITY, CILHIP_OPT_CELL_OCCUPANCY, CILHIP_OPT_REFINED_OCCUPANCY_FACTOR,
-  CILHIP_OPT_KERNEL_TIMING, CILHIP_OPT_KERNEL_TIMING_STRIDE, CILHIP_OPT_REVERSE_WARM_START, CILHIP_OPT_AFFINE_DEVICE_LOOP,
+  CILHIP_OPT_KERNEL_TIMING, CILHIP_OPT_KERNEL_TIMING_STRIDE, CILHIP_OPT_REVERSE_WARM_START, CILHIP_OPT_FEATURE_WARM_START, CILHIP_OPT_AFFINE_DEVICE_LOOP,
   CILHIP_OPT_COUNT
 } cilhip_option;
 typedef struct cilhip_option_info_t {

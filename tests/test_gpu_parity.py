@@ -981,6 +981,47 @@ def test_reverse_searches_started_from_the_previous_matches_change_nothing(Conte
         assert np.linalg.norm(Tg.astype(np.float64) - ro["T"]) <= TOL_T, (name, np.linalg.norm(Tg - ro["T"]))
 
 
+def test_feature_searches_started_from_the_previous_matches_change_nothing(Context, orc, hip_lib):
+    """Feature-adaptor loops (common_transformable_feature_adaptors.hpp:60-343) with the search warm-started from the previous matches
+    (feat_warm.hip: the margin test with the feature distance, listed rest searched in full) against every search from scratch
+    (option feature_warm_start): the searches are exact either way and the sums are the same streaming pass's, so the loop state is
+    BITWISE the same -- transform, iterations, correspondence count, the correspondence set left behind -- for the 6-D point+normal,
+    point+colour and the 9-D adaptors, with the symmetric metric and without; and the warm-started form really ran."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    n = 400_000
+    d = syn.make_pair(n, n, with_normals=True)
+    rng = np.random.default_rng(5)
+    src_n = d["dst_n"] + 0.02 * rng.normal(size=d["dst_n"].shape).astype(np.float32)
+    src_n = np.ascontiguousarray((src_n / np.linalg.norm(src_n, axis=1, keepdims=True)).astype(np.float32))
+    col_d = rng.random((n, 3), dtype=np.float32)
+    col_s = np.ascontiguousarray(np.clip(col_d + 0.01 * rng.normal(size=(n, 3)).astype(np.float32), 0, 1).astype(np.float32))
+    h = d["h"]
+    for kind in ("normals", "colours", "both"):
+        for symmetric in (1, 0):
+            got = []
+            for warm in (1, 0):
+                icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"], src_n)
+                eng = icp.correspondenceSearchEngine().setMaxDistance(float(d["max_sq_dist"]))
+                if kind == "normals":
+                    eng.setPointNormalFeatureAdaptors(src_n, 0.5 * h)
+                elif kind == "colours":
+                    eng.setPointColorFeatureAdaptors(col_d, col_s, 0.3 * h)
+                else:
+                    eng.setPointNormalColorFeatureAdaptors(src_n, col_d, col_s, 0.5 * h, 0.3 * h)
+                icp._ctx.set_option("symmetric_metric", symmetric)
+                icp._ctx.set_option("feature_warm_start", warm)
+                icp.setMaxNumberOfIterations(12).setConvergenceTolerance(0.0)
+                T = icp.estimate().getTransform()
+                g1, g2, gv = icp._ctx.get_correspondences()
+                got.append((T.copy(), icp.getNumberOfPerformedIterations(), icp.last_ncorr_, g1.copy(), g2.copy(), gv.copy(), icp._ctx.last_warm_iterations()))
+            (Tw, iw, nw, a1, a2, av, ww), (Tc, ic, nc, b1, b2, bv, wc) = got
+            assert ww > 0 and wc == 0, (kind, symmetric, ww, wc)
+            assert iw == ic and nw == nc, (kind, symmetric)
+            assert np.array_equal(Tw.view(np.uint32), Tc.view(np.uint32)), (kind, symmetric, np.abs(Tw - Tc).max())
+            assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and np.array_equal(av.view(np.uint32), bv.view(np.uint32)), (kind, symmetric)
+
+
 def test_search_directions_with_several_gauss_newton_steps_vs_oracle(orc, hip_lib):
     """FIRST_TO_SECOND / BOTH / reciprocal with max_optimization_iterations = 3 (transform_estimation.hpp:298-366 inside the loop of
     icp_base.hpp:68-87): the first step's sums come from the fused reverse pass (and BOTH's forward half from the warm-started kernel), the
