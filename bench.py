@@ -544,13 +544,21 @@ def bench_icp(a, torch, rank, world, local_rank, emit=True):
                                           ("affine_point_to_point", {"transform_mode": 1}, capi.METRIC_POINT_TO_POINT),
                                           ("first_to_second", {"search_direction": 1}, capi.METRIC_COMBINED),
                                           ("both", {"search_direction": 2}, capi.METRIC_COMBINED),
-                                          ("both_reciprocal", {"search_direction": 2, "require_reciprocality": 1}, capi.METRIC_COMBINED)):
+                                          ("both_reciprocal", {"search_direction": 2, "require_reciprocality": 1}, capi.METRIC_COMBINED),
+                                          # PointNormalFeaturesAdaptor on both clouds (6-D search, normal weight h / 2, the source's normals = its twin's), three-cloud metric
+                                          ("features_point_normal", {"feature_kind": 0, "feature_normal_weight": 0.5 * float(d["h"]), "symmetric_metric": 0}, capi.METRIC_COMBINED)):
                 if not with_normals and vmetric == capi.METRIC_COMBINED:
                     continue
+                if vname == "features_point_normal" and ns != nd:
+                    continue
                 cv = Context(local_rank, stream)
+                cv.set_target(dst_t, nrm_t); cv.set_source(src_t)
+                if vname == "features_point_normal":
+                    from cilantro_amd.icp import _as_cloud
+                    qn, _, memn, _keep = _as_cloud(nrm_t)
+                    cv._ck(cv._L.cilhip_set_source_normals(cv._h, qn, memn))
                 for k, v in vopts.items():
                     cv.set_option(k, v)
-                cv.set_target(dst_t, nrm_t); cv.set_source(src_t)
                 pv = copy.copy(p)
                 pv.metric = vmetric
                 pv.w_p2p, pv.w_p2pl = (w_p2p, w_p2pl) if with_normals else (0.0, 1.0)
