@@ -2495,7 +2495,17 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
   // while the kernel's own count of the queries it had to search says that it pays
   // (from 400 000 source points up: below, the look at the published state before every enqueue costs what the form saves -- measured 200k: +5 %, 1M: -23 %)
   const bool fwcap = feat6(c) && c->feat_warm && c->warm_start != 0 && c->ns >= 400000 && !filters_active(c) && !c->fused && !affine;
-  if (fwcap) { rc = ensure_safe2(c); if (rc) return rc; }
+  if (fwcap) {
+    rc = ensure_safe2(c); if (rc) return rc;
+    const int rows = feat_warm_blocks(c->ns);
+    if (rows > c->partial_blocks) {
+      if (c->d_partials) (void)hipFree(c->d_partials);
+      c->d_partials = nullptr; c->partial_blocks = 0;
+      CK(c, hipMalloc(&c->d_partials, (size_t)rows * SUMS_MAX * sizeof(double)));
+      c->partial_blocks = rows;
+      a.partials = c->d_partials; a.tile_partials = c->d_partials; sa.partials = c->d_partials;
+    }
+  }
   bool feat_warm_now = false;
   unsigned int feat_judged = 0;
   const bool paced = ((tile_acc || wcap) && c->ns && p->max_iter > 2 && c->tile_acc_adaptive) || (fwcap && p->max_iter > 2);
@@ -2593,6 +2603,7 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
     bool stored_now = true;    // this iteration leaves its matches in nn_pos
     bool counted = false;      // a cold iteration whose kernels count the queries a warm-started iteration after it would have to search
     bool feat_warm_it = false; // this iteration's feature search ran warm-started
+    bool feat_fused_it = false; // ... and accumulated the first step's sums itself
     // (kernel timing on: does THIS iteration carry events?  Every event between dependent kernels idles the device for ~6 us --
     //  two per iteration are a tenth of a warm-started iteration at 10M -- so a caller may ask for a sample: option kernel_timing_stride)
     const bool timing_it = timing && (c->timing_stride <= 1 || it < 3 || it % (size_t)c->timing_stride == 0);
@@ -2653,12 +2664,14 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
           // (the cooperative form: the previous iteration's matches, when it left them in nn_pos, bound every query's search)
           if (lanes_it && it >= 1 && prev_stored) sa2.warm_pos = c->d_nn_pos;
           feat_warm_it = fwcap && feat_warm_now && it >= 1 && prev_stored && !c->warm_banned;
-          if (feat_warm_it) { sa2.safe2 = c->d_safe2; launch_feat_warm(sa2, c->stream); ++c->last_warm_iters; }
+          // (... with the sums in the same pass when the terms are the three-cloud metric's own: no source normals in the objective, no per-pair weights)
+          feat_fused_it = feat_warm_it && !(c->d_src_nrm && c->symmetric) && !a.cw.enabled;
+          if (feat_warm_it) { sa2.safe2 = c->d_safe2; sa2.partials = c->d_partials; launch_feat_warm(sa2, feat_fused_it ? im : (int)IM_NONE, c->stream); ++c->last_warm_iters; }
           else { const int src_rc = launch_search(c, sa2, lanes_it); if (src_rc) return src_rc; }
           { const int frc = apply_filters(c); if (frc) return frc; }
           if (timing_it) { CK(c, hipEventRecord(get_event(c, nev++), c->stream)); CK(c, hipEventRecord(get_acc_event(c, nacc++), c->stream)); }
           if (affine) launch_acc_affine(a, im, nb_aff, c->stream);            // streaming accumulation kernel
-          else launch_iter(a, im, false, false, nb, c->stream);
+          else if (!feat_fused_it) launch_iter(a, im, false, false, nb, c->stream);
         } else {
           launch_iter(a, im, false, false, nb, c->stream);
         }
@@ -2680,7 +2693,8 @@ static int icp_run_once(cilhip_ctx* c, const cilhip_icp_params* p, const float* 
       }
       sa.gn_last_step = (st + 1 == opt_steps);
       if (c->ns) {
-        const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : affine ? nb_aff : nb;
+        const int prows = (st == 0 && warm) ? warm_num_blocks(c->ns) : (st == 0 && one_pass) ? tiled_partial_rows(c->ntiles) : (st == 0 && feat_fused_it) ? feat_warm_blocks(c->ns)
+                          : affine ? nb_aff : nb;
         if (affine) launch_reduce_and_solve_affine(c->d_partials, prows, c->d_stage, sa, c->stream);
         else launch_reduce_and_solve(c->d_partials, prows, c->d_stage, c->fused_epilogue ? c->d_ticket : nullptr, sa, c->stream);
       } else {

@@ -8,9 +8,12 @@
 // squared distance, against the same table (k_self_nn's safe2: a lower bound on nnd^2).  In pinned arithmetic: settled iff
 // e = d6_pinned(q, p) < max_sq  and  4 e (1 + 2e-5) < safe2[p]  (strict: a second feature at the same distance fails it).  Every other query
 // is listed per wave (ballot order) and searched in full by the wave's lanes, densely packed: nn_search_group<1, true> + tie_settle<true>,
-// what k_search_feat6 runs -- the exact argmin with the reference's tie order either way.  Search only: nn_pos (and nn_d2 when somebody
-// reads it) in, nn_pos out; the sums are the streaming pass's (it also carries the symmetric metric these loops usually run with).
+// what k_search_feat6 runs -- the exact argmin with the reference's tie order either way.  nn_pos (and nn_d2 when somebody reads it) in,
+// nn_pos out.  ACC != IM_NONE: the first Gauss-Newton step's sums in the same pass, on the matrix cores (rank_update.hpp: the terms of
+// k_warm / the tiles; the three-cloud metric without per-pair weights) -- for the settled queries as they stream by, for the listed ones
+// after their search; ACC == IM_NONE: search only, the sums are the streaming pass's (the symmetric metric, weight evaluators).
 #include "search_device.hpp"
+#include "rank_update.hpp"
 
 namespace cilhip {
 
@@ -19,15 +22,21 @@ constexpr int FW_ROUNDS = 16;                  // rounds between two searches of
 constexpr int FW_WCAP = FW_ROUNDS * 64;
 constexpr int FW_WAVES = 4;
 
+template <int ACC>
 __global__ __launch_bounds__(256) void k_feat_warm(IterArgs a) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
   float T[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) T[k] = st->T[k];
+  const float smt[3] = {st->smt[0], st->smt[1], st->smt[2]};
   __shared__ uint32_t list[FW_WAVES * FW_WCAP];
+  __shared__ __attribute__((aligned(16))) unsigned char raw[ACC != IM_NONE ? FW_WAVES * FUSED_WAVE_BYTES : 16];
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   uint32_t* const wl = list + wave * FW_WCAP;
+  float* const zb = reinterpret_cast<float*>(raw) + (ACC != IM_NONE ? wave * (FUSED_WAVE_BYTES / 4) : 0);
+  WaveRank<ACC == IM_NONE ? IM_KABSCH : ACC> rank;
+  constexpr bool NRM = FusedZ<ACC>::needs_normal;
   const GridDev& g = a.grid;
   const uint32_t rounds = (a.ns + 255u) / 256u, last = a.ns - 1u;
   uint32_t wcnt = 0;      // (wave-uniform)
@@ -36,11 +45,12 @@ __global__ __launch_bounds__(256) void k_feat_warm(IterArgs a) {
     __builtin_amdgcn_wave_barrier();
     for (uint32_t k0 = 0; k0 < wcnt; k0 += 64u) {
       const bool active = k0 + (uint32_t)lane < wcnt;
-      const uint32_t i = wl[min(k0 + (uint32_t)lane, (uint32_t)(FW_WCAP - 1))];
+      const uint32_t i = active ? wl[min(k0 + (uint32_t)lane, (uint32_t)(FW_WCAP - 1))] : 0u;      // (a slot beyond the list holds nothing meaningful)
+      const float4 s4 = a.src[i];
+      float qx, qy, qz;
+      transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
+      uint32_t found = NONE_U32;
       if (active) {
-        const float4 s4 = a.src[i];
-        float qx, qy, qz;
-        transform_point(T, s4.x, s4.y, s4.z, qx, qy, qz);
         Feat6 f;
         query_features(a, T, i, true, f);
         NN best;
@@ -50,6 +60,14 @@ __global__ __launch_bounds__(256) void k_feat_warm(IterArgs a) {
           best.pos = tie_settle<true>(g, a.tie, qx, qy, qz, best.pos, __uint_as_float((uint32_t)(best.key >> 32)), &f);
         a.nn_pos[i] = best.pos;
         if (a.nn_d2) a.nn_d2[i] = __uint_as_float((uint32_t)(best.key >> 32));
+        found = best.pos;
+      }
+      if (ACC != IM_NONE) {      // (every lane of the wave: the rank update is a wave-wide operation)
+        const bool hasf = found != NONE_U32;
+        const float4 pf = g.pts[hasf ? found : 0u];
+        float4 nvf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (NRM) nvf = g.nrm[hasf ? found : 0u];
+        rank.update(zb, lane, hasf, qx, qy, qz, pf, nvf, a.dst_mean, smt);
       }
     }
     wcnt = 0;
@@ -82,17 +100,34 @@ __global__ __launch_bounds__(256) void k_feat_warm(IterArgs a) {
     if (todo) wl[wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = i;
     wcnt += (uint32_t)__popcll(um);
     nlisted += (uint32_t)__popcll(um);
+    if (ACC != IM_NONE) {
+      float4 nvt = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NRM) nvt = g.nrm[wc];      // (the target's NORMAL: the feature vector beside it may be a colour)
+      rank.update(zb, lane, settled, qx, qy, qz, p, nvt, a.dst_mean, smt);
+    }
   }
   flush();
+  if (ACC != IM_NONE) rank.template write_row<FW_WAVES>(raw, wave, lane, a.partials + (size_t)blockIdx.x * SUMS_MAX);
   if (a.unproven_cnt && lane == 0 && nlisted != 0u) atomicAdd(a.unproven_cnt + 64u + ((blockIdx.x * FW_WAVES + (uint32_t)wave) & 63u), nlisted);      // listed queries: is the form paying?
 }
 }  // namespace
 
-void launch_feat_warm(const IterArgs& a, hipStream_t s) {
-  if (a.ns == 0) return;
-  long nb = ((long)a.ns + 8 * 256 - 1) / (8 * 256);      // at least eight rounds per block
+int feat_warm_blocks(uint32_t ns) {      // at least eight rounds of 256 queries per block
+  long nb = ((long)ns + 8 * 256 - 1) / (8 * 256);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(k_feat_warm, dim3((unsigned)nb), dim3(256), 0, s, a);
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+void launch_feat_warm(const IterArgs& a, int acc_metric, hipStream_t s) {
+  if (a.ns == 0) return;
+  const dim3 gb(feat_warm_blocks(a.ns)), tb(256);
+  switch (acc_metric) {
+    case IM_KABSCH: hipLaunchKernelGGL((k_feat_warm<IM_KABSCH>), gb, tb, 0, s, a); break;
+    case IM_PLANE: hipLaunchKernelGGL((k_feat_warm<IM_PLANE>), gb, tb, 0, s, a); break;
+    case IM_POINT: hipLaunchKernelGGL((k_feat_warm<IM_POINT>), gb, tb, 0, s, a); break;
+    case IM_BOTH: hipLaunchKernelGGL((k_feat_warm<IM_BOTH>), gb, tb, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_feat_warm<IM_NONE>), gb, tb, 0, s, a); break;
+  }
 }
 
 }  // namespace cilhip

@@ -355,7 +355,9 @@ void launch_count_deferred(const unsigned long long* mask, uint32_t ntiles, uint
 void launch_search_group(const IterArgs& a, int lanes /*4, 8, 16*/, hipStream_t s);   // exact search, several lanes per query (small / far-from-alignment clouds)
 void launch_search_feat6(const IterArgs& a, hipStream_t s);   // correspondence search over 6-D point+normal features (one lane per query, global memory: small clouds)
 // feat_warm.hip: the same search warm-started from the matches in a.nn_pos (in / out), margin test against a.safe2 (k_self_nn's table); listed queries counted in a.unproven_cnt[64 ..)
-void launch_feat_warm(const IterArgs& a, hipStream_t s);
+// acc_metric != IM_NONE: the first Gauss-Newton step's sums in the same pass (feat_warm_blocks(ns) rows of SUMS_MAX doubles in a.partials)
+int feat_warm_blocks(uint32_t ns);
+void launch_feat_warm(const IterArgs& a, int acc_metric, hipStream_t s);
 void launch_search_tiled_feat6(const IterArgs& a, const uint2* tiles, const float4* tile_center, int* tile_box, uint32_t ntiles, hipStream_t s);   // its LDS-tiled form
 #ifdef CILHIP_EXP_PHASE_CLOCKS
 void debug_dump_phase_clocks();   // dev experiment: per-phase clock sums of k_search_tiled -> stderr

@@ -700,7 +700,8 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        search starts from the previous matches -- a query whose old match p has 4 d_feat(q, p) < nnd(p)^2 (nnd: the
  *                        distance from p to its nearest other target point; d_feat >= the squared point distance) keeps it without looking
  *                        at a cell, the rest is searched in full (feat_warm.hip) -- and goes back to the tile search when more than a
- *                        quarter of the queries had to be searched.  Same correspondences either way; 0 = every search from scratch (A/B).
+ *                        quarter of the queries had to be searched.  With the three-cloud metric and unity evaluators the same pass also
+ *                        accumulates the step's sums.  Same correspondences either way; 0 = every search from scratch (A/B).
  *   "symmetric_metric" (default 1): 0 = source normals feed the feature adaptor only and the combined metric stays the
  *                        three-cloud one (the reference decides this by the ICP constructor used,
  *                        icp_common_instances.hpp:74-97).

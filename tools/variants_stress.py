@@ -1,7 +1,7 @@
 """dev: randomised A/B of round 6's loops against the forms they replace -- the affine classes' device-resident loop (affine_device_loop), the fused
 warm-started reverse pass of FIRST_TO_SECOND / BOTH (reverse_warm_start), the warm-started feature search (feature_warm_start) -- over random
 sizes, start transforms, noise levels, radii, weights, Gauss-Newton steps, duplicated points.  Same iterations / correspondence counts, transforms
-equal to the order of the f64 additions (feature search: bitwise).  usage: variants_stress.py [cases] [seed]"""
+equal to the order of the f64 additions.  usage: variants_stress.py [cases] [seed]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -59,7 +59,7 @@ for case in range(cases):
         continue
     (T1, i1, n1, w1), (T0, i0, n0, w0) = got
     dT = float(np.abs(T1.astype(np.float64) - T0).max())
-    tol = 0.0 if kind == "feature" else 5e-6
+    tol = 5e-6
     ok = i1 == i0 and n1 == n0 and dT <= tol
     bad += 0 if ok else 1
     print(f"[{case}] {'ok ' if ok else 'DIFF'} {desc}: iterations {i1}/{i0} ncorr {n1}/{n0} max|dT| {dT:.3g} warm {w1}/{w0}", flush=True)
