@@ -546,14 +546,16 @@ def bench_icp(a, torch, rank, world, local_rank, emit=True):
                                           ("both", {"search_direction": 2}, capi.METRIC_COMBINED),
                                           ("both_reciprocal", {"search_direction": 2, "require_reciprocality": 1}, capi.METRIC_COMBINED),
                                           # PointNormalFeaturesAdaptor on both clouds (6-D search, normal weight h / 2, the source's normals = its twin's), three-cloud metric
+                                          # the four-cloud constructor: the symmetric point-to-plane objective (source normals = the twins')
+                                          ("symmetric_metric", {"symmetric_metric": 1}, capi.METRIC_COMBINED),
                                           ("features_point_normal", {"feature_kind": 0, "feature_normal_weight": 0.5 * float(d["h"]), "symmetric_metric": 0}, capi.METRIC_COMBINED)):
                 if not with_normals and vmetric == capi.METRIC_COMBINED:
                     continue
-                if vname == "features_point_normal" and ns != nd:
+                if vname in ("features_point_normal", "symmetric_metric") and ns != nd:
                     continue
                 cv = Context(local_rank, stream)
                 cv.set_target(dst_t, nrm_t); cv.set_source(src_t)
-                if vname == "features_point_normal":
+                if vname in ("features_point_normal", "symmetric_metric"):
                     from cilantro_amd.icp import _as_cloud
                     qn, _, memn, _keep = _as_cloud(nrm_t)
                     cv._ck(cv._L.cilhip_set_source_normals(cv._h, qn, memn))

@@ -989,7 +989,8 @@ static CorrWeights corr_weights_of(const cilhip_ctx* c, const cilhip_icp_params*
 // a feature adaptor is in force (6-D point+normal or point+colour, 9-D point+normal+colour): correspondences are compared by feature distance
 static bool feat6(const cilhip_ctx* c) { return c->normal_weight > 0.0f || (c->feature_kind == 2 && c->color_weight > 0.0f); }
 static bool warm_capable(const cilhip_ctx* c) {
-  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !feat6(c) && !(c->d_src_nrm && c->symmetric) && !c->fused;
+  // (the symmetric objective -- source normals set, option symmetric_metric on -- runs warm-started too: k_warm<., ., SYM> streams the source normals)
+  return c->warm_start && c->ns >= 65536 && !filters_active(c) && !weighted(c) && !feat6(c) && !c->fused;
 }
 // k_self_nn's nearest-other-point table (4 B per target point, 0.5 ms at 10M): built by the first warm-capable run on a target
 static int ensure_safe2(cilhip_ctx* c) {
@@ -2773,7 +2774,7 @@ int cilhip_icp_begin(cilhip_ctx* c, const cilhip_icp_params* p, const float* T0,
   c->run_warm_on = false; c->run_judged = 0;
   c->rec_valid = false; c->lb_fresh = false;
   warm_run_reset(c);
-  if (warm_capable(c)) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
+  if (warm_capable(c) && !(c->d_src_nrm && c->symmetric)) { rc = ensure_safe2(c); if (rc) return rc; rc = ensure_warm_buffers(c); if (rc) return rc; }
   c->iter_form.clear(); c->trace_form.clear();
   for (int k = 0; k < 5; ++k) { c->form_ms[k] = 0.0; c->form_n[k] = 0; }
   c->last_fused_iters = c->last_two_pass_iters = c->last_warm_iters = 0;    // counted per cilhip_icp_partial_sums call (cilhip_get_last_run_forms)
@@ -2807,7 +2808,7 @@ static int partial_sums_core(cilhip_ctx* c, double* sums_dev, double* rows_dev) 
       // published (a bounded wait for iteration run_calls - 2) says the source is near alignment.  Ranks may differ in their choice: the sums are
       // the same up to the order of the f64 additions.
       bool warm = false;
-      const bool wcap = warm_capable(c);
+      const bool wcap = warm_capable(c) && !(c->d_src_nrm && c->symmetric);      // (the sharded building blocks: the symmetric objective stays with the streaming pass)
       if (wcap && c->run_calls >= 1) {
         warm = c->warm_start == 2;
         if (!warm && c->run_calls >= 2) {

@@ -153,7 +153,7 @@ __device__ __forceinline__ void scan_runs_track2(const float4* __restrict__ pts,
 // need be: a source far from alignment).
 constexpr int WARM_QCAP = 256;                              // listed queries per wave (16 B each); a list that could not take another round is searched at once
 #define Z4 make_float4(0.f, 0.f, 0.f, 0.f)
-template <int ACC, int REC>
+template <int ACC, int REC, bool SYM = false>
 __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   const IcpState* __restrict__ st = a.state;
   if (st->done) return;
@@ -210,6 +210,15 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     qz = __fadd_rn(__fadd_rn(__fmul_rn(T[2], s4.x), __fadd_rn(__fmul_rn(T[5], s4.y), __fmul_rn(T[8], s4.z))), T[11]);
   };
 
+  // SYM -- the symmetric objective (transform_estimation.hpp:705-706; accumulate_pair's sym branch on the first Gauss-Newton step, where the inner
+  // transform is the identity): the plane terms' normal is n_dst + R n_src, the source normal streamed with the query, every operation rounded
+  // as the streaming pass rounds it.
+  auto sym_normal = [&](const float4 nd, const float4 sn) -> float4 {
+    const float t0 = __fadd_rn(__fmul_rn(T[0], sn.x), __fadd_rn(__fmul_rn(T[3], sn.y), __fmul_rn(T[6], sn.z)));
+    const float t1 = __fadd_rn(__fmul_rn(T[1], sn.x), __fadd_rn(__fmul_rn(T[4], sn.y), __fmul_rn(T[7], sn.z)));
+    const float t2 = __fadd_rn(__fmul_rn(T[2], sn.x), __fadd_rn(__fmul_rn(T[5], sn.y), __fmul_rn(T[8], sn.z)));
+    return make_float4(__fadd_rn(nd.x, t0), __fadd_rn(nd.y, t1), __fadd_rn(nd.z, t2), 0.f);
+  };
   // rank update of the wave's 16x16 tile with one round of (up to) 64 correspondences (k_search_tiled, step 5)
   // (two halves: the terms z of the wave's correspondences -> LDS; then LDS -> f64 operands -> the matrix cores.  Between them
   //  a round's streamed registers are dead, which is where the streaming loop requests the data of the round after next.)
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   // bound for a query WITHOUT a match, over all target points: if mrg still exceeds the radius there is still none.
   // lbv / s2 (REC 1): the key the search left in nn_lb (a.lb_valid) and the old match's nearest-other-point table entry -- any other
   // target point p' has |q - p'| >= nnd(p) - |q - p|: a second lower bound, the larger key wins.
-  auto round = [&](uint32_t i, bool valid, const F3 s3c, uint32_t w, float4 pm, float4 nm, float keyv, float s2) {
+  auto round = [&](uint32_t i, bool valid, const F3 s3c, uint32_t w, float4 pm, float4 nm, float keyv, float s2, const float4 sn = make_float4(0.f, 0.f, 0.f, 0.f)) {
     float qx, qy, qz;
     transform(make_float4(s3c.x, s3c.y, s3c.z, 0.f), qx, qy, qz);
     const float e_old = d2_pinned(qx, qy, qz, pm.x, pm.y, pm.z);
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
       wr[o] = ((REC == 2 ? !(keyv < 0.0f) : w != NONE_U32) && e_old < a.max_sq) ? e_old : a.max_sq;
     }
     qcount += (uint32_t)__popcll(um);
-    z_to_lds(shas, qx, qy, qz, pm, nm);
+    z_to_lds(shas, qx, qy, qz, pm, SYM ? sym_normal(nm, sn) : nm);
   };
   // What a round streams in.  REC 2: the 12-byte copy of the source point and the match record {point, margin key} {normal}
   // -- 40 B per query (28 without normals), all of it coalesced, TWO rounds in flight per wave (sets A and B; vmcnt retires in
@@ -464,6 +473,8 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   uint32_t base = beg, qlisted = 0;
   F3 sA = F3{0.f, 0.f, 0.f}, nA = F3{0.f, 0.f, 0.f}, sB = F3{0.f, 0.f, 0.f}, nB = F3{0.f, 0.f, 0.f};
   float4 rA = Z4, rB = Z4;
+  float4 snA = Z4, snB = Z4;      // (SYM) the queries' source normals
+  float4 sn1 = Z4, sn2 = Z4;
   uint32_t iA = beg + threadIdx.x, iB = iA + WARM_THREADS;
   // (REC 0 / 1) stage 1 -> 2: source record + position of the round after next; stage 2 -> 3: what was gathered for the next round
   uint32_t w1 = NONE_U32, w2 = NONE_U32;
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   float gs = -1.0f;
   // (the three loads leave in THIS order everywhere -- scheduling barriers -- : the wait for a set is computed from the
   //  position of its loads in the in-order vmcnt queue, merged over all paths into the loop)
-  auto load2 = [&](uint32_t k, F3& sv, float4& rv, F3& nv) {
+  auto load2 = [&](uint32_t k, F3& sv, float4& rv, F3& nv, float4& snv) {
     __builtin_amdgcn_sched_barrier(0);
     sv = a.warm_src3[k];
     __builtin_amdgcn_sched_barrier(0);
@@ -481,8 +492,9 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (NRM) nv = a.warm_rec_n[k];
     __builtin_amdgcn_sched_barrier(0);
+    if (SYM) { snv = a.src_nrm[k]; __builtin_amdgcn_sched_barrier(0); }
   };
-  auto load1 = [&](uint32_t k, F3& sv, uint32_t& wv, float& lv) { const float4 t4 = a.src[k]; sv = F3{t4.x, t4.y, t4.z}; wv = a.warm_pos[k]; lv = a.nn_lb[k]; };
+  auto load1 = [&](uint32_t k, F3& sv, uint32_t& wv, float& lv, float4& snv) { const float4 t4 = a.src[k]; sv = F3{t4.x, t4.y, t4.z}; wv = a.warm_pos[k]; lv = a.nn_lb[k]; if (SYM) snv = a.src_nrm[k]; };
   // (every load of the streaming loop is UNCONDITIONAL, from an index clamped into the chunk / a position clamped into the
   //  target: a load under a divergent branch may or may not have been issued as far as the compiler's vmcnt bookkeeping
   //  is concerned, and the waits it then inserts drain the younger prefetches as well)
@@ -500,12 +512,12 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
   //  registers with loads in flight must not live across that search, where they would be spilled and reloaded)
   // (unconditionally: an empty chunk reads element 0, which exists)
   if (REC == 2) {
-    load2(min(iA, last), sA, rA, nA);
-    load2(min(iB, last), sB, rB, nB);
+    load2(min(iA, last), sA, rA, nA, snA);
+    load2(min(iB, last), sB, rB, nB, snB);
   } else {
-    load1(min(iA, last), s2_, w2, l2);         // next round: record, then (dependent) its gathers
+    load1(min(iA, last), s2_, w2, l2, sn2);         // next round: record, then (dependent) its gathers
     gather(w2);
-    load1(min(iA + WARM_THREADS, last), s1, w1, l1);      // the round after: record
+    load1(min(iA + WARM_THREADS, last), s1, w1, l1, sn1);      // the round after: record
   }
   // stream rounds until the chunk is done -- or the wave's list could not take two more rounds' queries (a source far from
   // alignment lists most of them): then the list is searched first
@@ -513,16 +525,16 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
     for (; base < end && qcount <= (uint32_t)(WARM_QCAP - 128); base += 2 * WARM_THREADS) {
       // (a set's registers are consumed -- down to the terms in LDS -- BEFORE the set is requested again, so that the new
       //  loads can land in the same registers: no copy at the loop's end that would have to wait for them)
-      round(iA, iA < end, sA, NONE_U32, make_float4(rA.x, rA.y, rA.z, 0.f), make_float4(nA.x, nA.y, nA.z, 0.f), rA.w, 0.0f);
+      round(iA, iA < end, sA, NONE_U32, make_float4(rA.x, rA.y, rA.z, 0.f), make_float4(nA.x, nA.y, nA.z, 0.f), rA.w, 0.0f, snA);
       __builtin_amdgcn_sched_barrier(0);
       iA += 2 * WARM_THREADS;
-      load2(min(iA, last), sA, rA, nA);
+      load2(min(iA, last), sA, rA, nA, snA);
       __builtin_amdgcn_sched_barrier(0);
       lds_to_mfma();
-      round(iB, iB < end, sB, NONE_U32, make_float4(rB.x, rB.y, rB.z, 0.f), make_float4(nB.x, nB.y, nB.z, 0.f), rB.w, 0.0f);
+      round(iB, iB < end, sB, NONE_U32, make_float4(rB.x, rB.y, rB.z, 0.f), make_float4(nB.x, nB.y, nB.z, 0.f), rB.w, 0.0f, snB);
       __builtin_amdgcn_sched_barrier(0);
       iB += 2 * WARM_THREADS;
-      load2(min(iB, last), sB, rB, nB);
+      load2(min(iB, last), sB, rB, nB, snB);
       __builtin_amdgcn_sched_barrier(0);
       lds_to_mfma();
     }
@@ -533,12 +545,13 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
       const uint32_t wc = w2;
       const float4 pc = gp, nc = gn;
       const float gc = gs, lc = l2;
+      const float4 snc = sn2;
       // next round: its record has arrived, its gathers leave now; the round after: its record leaves now
       iA += WARM_THREADS;
-      s2_ = s1; w2 = w1; l2 = l1;
+      s2_ = s1; w2 = w1; l2 = l1; sn2 = sn1;
       gather(w2);
-      load1(min(iA + WARM_THREADS, last), s1, w1, l1);
-      round(i, i < end, sc, wc, pc, nc, lc, gc);
+      load1(min(iA + WARM_THREADS, last), s1, w1, l1, sn1);
+      round(i, i < end, sc, wc, pc, nc, lc, gc, snc);
       lds_to_mfma();
     }
   }
@@ -577,6 +590,7 @@ __global__ __launch_bounds__(WARM_THREADS, 4) void k_warm(IterArgs a) {
       nopen += (uint32_t)__popcll(om);
       float4 pm = Z4, nm = Z4;
       const bool has = slow_finish(v && taken, __float_as_uint(ent.w), ent.x, ent.y, ent.z, best, bp, key, pm, nm);
+      if (SYM) { const float4 snl = a.src_nrm[v ? __float_as_uint(ent.w) : 0u]; nm = sym_normal(nm, snl); }      // (after slow_finish stored the TARGET's normal in the record)
       rank_update(has, ent.x, ent.y, ent.z, pm, nm);
       WARM_CLK(2 + level);
     }
@@ -629,6 +643,12 @@ static void launch_warm_m(const IterArgs& a, int rec, int nblocks, hipStream_t s
   const dim3 g(nblocks), b(WARM_THREADS);
   const hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;      // (armed by set_launch_events: consumed here)
   g_ev_start = g_ev_stop = nullptr;
+  // (source normals in the arguments = the symmetric objective: the plane-term forms stream them with the queries)
+  if (FusedZ<ACC>::plane && ACC != IM_AFFC && a.src_nrm != nullptr) {
+    if (rec == 2) launch_ev((k_warm<(FusedZ<ACC>::plane ? ACC : IM_PLANE), 2, true>), g, b, s, ev_start, ev_stop, a);
+    else launch_ev((k_warm<(FusedZ<ACC>::plane ? ACC : IM_PLANE), 1, true>), g, b, s, ev_start, ev_stop, a);
+    return;
+  }
   if (rec == 2) launch_ev((k_warm<ACC, 2>), g, b, s, ev_start, ev_stop, a);
   else launch_ev((k_warm<ACC, 1>), g, b, s, ev_start, ev_stop, a);
 }

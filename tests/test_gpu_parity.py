@@ -274,6 +274,39 @@ def test_every_accumulating_form_with_half_of_the_matches_cut_by_the_radius(orc,
                 assert abs(icp.last_ncorr_ - ro["last_ncorr"]) <= 5, (affine, metric, wts, name, icp.last_ncorr_, ro["last_ncorr"])
 
 
+def test_symmetric_metric_warm_started_vs_streaming_pass_and_oracle(orc, hip_lib):
+    """The symmetric objective (four-cloud constructor; transform_estimation.hpp:479-744 through accumulate_pair's sym branch) in the
+    warm-started form (k_warm<., ., SYM>: the source normals streamed with the queries, n = n_dst + R n_src formed as the streaming pass
+    forms it) against the loop without warm start (search + streaming pass every iteration) and against the oracle's symmetric loop:
+    same iterations and counts, transforms to the order of the f64 additions; with both terms and plane terms only; a radius that cuts
+    matches; and the warm-started form really ran."""
+    from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
+
+    n = 200_000
+    d = syn.make_pair(n, n, with_normals=True, perturb=0.4)
+    rng = np.random.default_rng(9)
+    src_n = d["dst_n"] + 0.05 * rng.normal(size=d["dst_n"].shape).astype(np.float32)
+    src_n = np.ascontiguousarray((src_n / np.linalg.norm(src_n, axis=1, keepdims=True)).astype(np.float32))
+    for wts in ((0.0, 1.0), (0.2, 1.0)):
+        for r2 in (float(d["max_sq_dist"]), float((0.12 * d["h"]) ** 2)):
+            p = orc.make_params(metric=1, w_p2p=wts[0], w_p2pl=wts[1], max_iter=10, conv_tol=0.0, max_sq_dist=r2, mode=orc.MODE_MIXED)
+            ro = orc.icp_run(d["dst"], d["dst_n"], d["src"], p, src_n=src_n)
+            got = []
+            for warm in (1, 2, 0):
+                icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], d["src"], src_n)
+                icp.setPointToPointMetricWeight(wts[0]).setPointToPlaneMetricWeight(wts[1])
+                icp._ctx.set_option("warm_start", warm)
+                icp.correspondenceSearchEngine().setMaxDistance(r2)
+                icp.setMaxNumberOfIterations(10).setConvergenceTolerance(0.0)
+                T = icp.estimate().getTransform().astype(np.float64)
+                got.append((T, icp.getNumberOfPerformedIterations(), icp.last_ncorr_, icp._ctx.last_warm_iterations()))
+                assert np.linalg.norm(T - ro["T"].astype(np.float64)) <= TOL_T, (wts, r2, warm, np.linalg.norm(T - ro["T"]))
+                assert abs(icp.last_ncorr_ - ro["last_ncorr"]) <= 3, (wts, r2, warm, icp.last_ncorr_, ro["last_ncorr"])
+            assert got[1][3] >= 8 and got[2][3] == 0, [g[3] for g in got]      # warm_start 2: from the second iteration on; 0: never
+            for g in got[:2]:
+                assert g[1] == got[2][1] and abs(g[2] - got[2][2]) <= 3 and np.abs(g[0] - got[2][0]).max() < 2e-6, (wts, r2)
+
+
 def test_icp_combined_weights_and_gn_steps(orc, hip_lib):
     from cilantro_amd.icp import SimpleCombinedMetricRigidICP3f
 
