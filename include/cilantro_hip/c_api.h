@@ -704,7 +704,9 @@ int cilhip_enable_kernel_timing(cilhip_ctx* ctx, int on);
  *                        accumulates the step's sums.  Same correspondences either way; 0 = every search from scratch (A/B).
  *   "symmetric_metric" (default 1): 0 = source normals feed the feature adaptor only and the combined metric stays the
  *                        three-cloud one (the reference decides this by the ICP constructor used,
- *                        icp_common_instances.hpp:74-97).
+ *                        icp_common_instances.hpp:74-97).  The symmetric objective runs the plain loop's kernel forms, the
+ *                        warm-started one included (the queries' source normals streamed with them); the accumulating tiles and the
+ *                        sharded building blocks keep the streaming pass for it.
  * Transform family (registration/icp_common_instances.hpp:253-267):
  *   "transform_mode" (default 0): 0 = rigid -- cilhip_icp_run is Simple{PointToPoint,Combined}MetricRigidICP3f;
  *                        1 = affine -- Simple{PointToPoint,Combined}MetricAffineICP3f: same loop and correspondence engine,
