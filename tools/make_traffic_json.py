@@ -34,7 +34,7 @@ line = json.loads(open(f"{d}/bench_line.json").read()) if os.path.exists(f"{d}/b
 form = (line.get("roofline") or {}).get("form")
 if not subs:
     subs = {0: [r"k_search_tiled<0", r"k_search_deferred<0", r"k_iter<\d+, true"], 1: [r"k_search_tiled<[1-4]", r"k_search_deferred<[1-4]"],
-            2: [r"k_warm<\d+, 1>"], 3: [r"k_warm<\d+, 2>"], 4: [r"k_iter<\d+, true"]}[form]
+            2: [r"k_warm<\d+, 1(, \w+)?>"], 3: [r"k_warm<\d+, 2(, \w+)?>"], 4: [r"k_iter<\d+, true"]}[form]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{d}/*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
