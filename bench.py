@@ -127,7 +127,7 @@ def config_traffic(config, workload):
     for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{config}.json")), reverse=True):
         try:
             tj = json.load(open(tf))
-            if tj.get("source_hash") == source_hash(KERNEL_SOURCES[config]) and tj.get("workload") == workload:
+            if tj.get("source_hash") == source_hash(KERNEL_SOURCES[config]) and tj.get("workload") == workload and float(tj.get("traffic_bytes_per_launch") or 0.0) > 0.0:
                 return float(tj["traffic_bytes_per_launch"]), os.path.basename(tf) + ": " + tj.get("method", "")
             if note.startswith("no PMC"):
                 note = "profiles/" + os.path.basename(tf) + " was measured on another build or workload: not quoted"
@@ -381,7 +381,9 @@ def bench_icp(a, torch, rank, world, local_rank, emit=True):
             try:
                 tj = json.load(open(tf))
                 w = tj["workload"]
-                if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and tj.get("form") == dom:
+                # (a file without a positive figure -- its passes did not find the kernel -- is not a measurement)
+                if tj.get("source_hash") == source_hash() and (w["n_target"], w["n_source_per_gpu"], w["metric"]) == (nd_l, ns_l, metric) and tj.get("form") == dom \
+                        and float(tj.get("traffic_bytes_per_launch") or 0.0) > 0.0:
                     traffic, traffic_note = float(tj["traffic_bytes_per_launch"]), os.path.basename(tf) + ": " + tj.get("method", "")
                     traffic_cold = tj.get("cold_forms")      # {"plain_tile": bytes per launch, "record_writing_tile": ...} of the same passes
                     break
