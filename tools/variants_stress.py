@@ -13,7 +13,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(cases):
-    kind = str(rng.choice(["affine", "reverse", "feature"]))
+    kind = str(rng.choice(["affine", "reverse", "feature", "symmetric"]))
     n = int(rng.integers(70_000, 700_000)) if kind != "feature" else int(rng.integers(400_000, 900_000))
     ns = n if kind == "feature" else int(n * rng.uniform(0.3, 1.0))
     stride = 1 if ns == n else max(1, n // ns)
@@ -37,10 +37,14 @@ for case in range(cases):
             if kind == "affine":
                 icp = SimpleCombinedMetricAffineICP3f(d["dst"], d["dst_n"], src) if metric else SimplePointToPointMetricAffineICP3f(d["dst"], src)
                 icp._ctx.set_option("affine_device_loop", on)
+            elif kind == "symmetric":      # the four-cloud classes: warm-started (k_warm<., ., SYM>) against search + streaming pass every iteration
+                sn = d["dst_n"][(np.arange(len(src)) * stride) % n]
+                icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], src, np.ascontiguousarray(sn))
+                icp._ctx.set_option("warm_start", (1 + case % 2) if on else 0)
             else:
                 icp = SimpleCombinedMetricRigidICP3f(d["dst"], d["dst_n"], src) if metric else SimplePointToPointMetricRigidICP3f(d["dst"], src)
-            if metric:
-                icp.setPointToPointMetricWeight(wts[0]).setPointToPlaneMetricWeight(wts[1])
+            if metric or kind == "symmetric":
+                icp.setPointToPointMetricWeight(wts[0]).setPointToPlaneMetricWeight(wts[1] if kind != "symmetric" else 1.0)
                 if kind != "affine":
                     icp.setMaxNumberOfOptimizationStepIterations(steps).setOptimizationStepConvergenceTolerance(1e-7)
             eng = icp.correspondenceSearchEngine().setMaxDistance(r2)
